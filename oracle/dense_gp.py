@@ -1,0 +1,103 @@
+"""ORACLE (test infrastructure only). Dense (O(N^3)) Gaussian-process oracle, independent of any
+state-space code. It plays the role that the naive AbstractGPs GP plays in the reference's own tests
+(`fx_naive` in /root/reference/test/gp/lti_sde.jl:181-200 and test/gp/posterior_lti_sde.jl:62-89):
+the state-space result must equal the dense-GP result.
+
+Third-party arithmetic restated (not under /root/reference): KernelFunctions.jl closed forms
+(compat "0.9, 0.10.1", Project.toml) and AbstractGPs.jl FiniteGP logpdf / posterior (compat "0.5.17"):
+    Matern12:  exp(-|tau|)
+    Matern32:  (1 + sqrt3 |tau|) exp(-sqrt3 |tau|)
+    Matern52:  (1 + sqrt5 |tau| + 5 tau^2 / 3) exp(-sqrt5 |tau|)
+    Constant:  c
+    Periodic:  exp(-0.5 sin^2(pi tau) / r^2)      (the kernel ApproxPeriodicKernel approximates)
+    sigma2 * k, k o ScaleTransform(s) (tau -> s tau), sums and products.
+The reference's `cosine` SDE (lti_sde.jl:239-252) has stationary covariance cos(tau); that is what the
+oracle uses for ("cosine",) so that it matches the SDE the reference builds.
+"""
+import numpy as np
+from scipy.linalg import cho_factor, cho_solve
+
+LOG2PI = float(np.log(2.0 * np.pi))
+
+
+def kappa(k, tau):
+    name = k[0]
+    at = np.abs(tau)
+    if name == "matern12":
+        return np.exp(-at)
+    if name == "matern32":
+        return (1 + np.sqrt(3.0) * at) * np.exp(-np.sqrt(3.0) * at)
+    if name == "matern52":
+        return (1 + np.sqrt(5.0) * at + 5.0 * at ** 2 / 3.0) * np.exp(-np.sqrt(5.0) * at)
+    if name == "cosine":
+        return np.cos(at)
+    if name == "constant":
+        return np.full_like(at, float(k[1]))
+    if name == "approx_periodic":
+        return np.exp(-0.5 * np.sin(np.pi * at) ** 2 / k[2] ** 2)
+    if name == "scaled":
+        return k[1] * kappa(k[2], tau)
+    if name == "stretched":
+        return kappa(k[2], k[1] * tau)
+    if name == "sum":
+        return sum(kappa(kk, tau) for kk in k[1:])
+    if name == "product":
+        out = np.ones_like(at)
+        for kk in k[1:]:
+            out = out * kappa(kk, tau)
+        return out
+    raise ValueError(name)
+
+
+def kernelmatrix(k, x1, x2=None):
+    x2 = x1 if x2 is None else x2
+    return kappa(k, x1[:, None] - x2[None, :])
+
+
+def _mean(mean, x):
+    if mean is None or mean[0] == "zero":
+        return np.zeros(len(x))
+    if mean[0] == "const":
+        return np.full(len(x), float(mean[1]))
+    return np.array([mean[1](v) for v in x], dtype=np.float64)
+
+
+def _noise(sigma2, n):
+    s = np.atleast_1d(np.asarray(sigma2, dtype=np.float64))
+    return s if len(s) == n else np.full(n, s[0])
+
+
+def logpdf(k, x, sigma2, y, mean=None):
+    n = len(x)
+    K = kernelmatrix(k, x) + np.diag(_noise(sigma2, n))
+    c = cho_factor(K, lower=True)
+    r = np.asarray(y) - _mean(mean, x)
+    logdet = 2.0 * np.sum(np.log(np.diag(c[0])))
+    return float(-(n * LOG2PI + logdet + r @ cho_solve(c, r)) / 2.0)
+
+
+def marginals(k, x, sigma2, mean=None):
+    n = len(x)
+    return _mean(mean, x), np.diag(kernelmatrix(k, x)) + _noise(sigma2, n)
+
+
+def posterior_marginals(k, x_tr, sigma2_tr, y_tr, x_pr, sigma2_pr=0.0, mean=None):
+    ntr, npr = len(x_tr), len(x_pr)
+    K = kernelmatrix(k, x_tr) + np.diag(_noise(sigma2_tr, ntr))
+    c = cho_factor(K, lower=True)
+    Ks = kernelmatrix(k, x_pr, x_tr)
+    mu = _mean(mean, x_pr) + Ks @ cho_solve(c, np.asarray(y_tr) - _mean(mean, x_tr))
+    var = np.diag(kernelmatrix(k, x_pr)) - np.einsum("ij,ji->i", Ks, cho_solve(c, Ks.T))
+    return mu, var + _noise(sigma2_pr, npr)
+
+
+def posterior_logpdf(k, x_tr, sigma2_tr, y_tr, x_pr, sigma2_pr, y_pr, mean=None):
+    ntr, npr = len(x_tr), len(x_pr)
+    K = kernelmatrix(k, x_tr) + np.diag(_noise(sigma2_tr, ntr))
+    c = cho_factor(K, lower=True)
+    Ks = kernelmatrix(k, x_pr, x_tr)
+    mu = _mean(mean, x_pr) + Ks @ cho_solve(c, np.asarray(y_tr) - _mean(mean, x_tr))
+    C = kernelmatrix(k, x_pr) - Ks @ cho_solve(c, Ks.T) + np.diag(_noise(sigma2_pr, npr))
+    cc = cho_factor(C, lower=True)
+    r = np.asarray(y_pr) - mu
+    return float(-(npr * LOG2PI + 2 * np.sum(np.log(np.diag(cc[0]))) + r @ cho_solve(cc, r)) / 2.0)
