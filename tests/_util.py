@@ -1,0 +1,119 @@
+"""Shared helpers for the test tiers (test infrastructure)."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+from oracle import components as oc
+from oracle import lgssm_ref as ref
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+_dp = ctypes.POINTER(ctypes.c_double)
+_i64 = ctypes.c_int64
+
+
+def pack(model):
+    """dict model (oracle convention, kind 'scalar') -> flat column-major blocks + strides (0 == Fill)."""
+    d = len(model["x0m"])
+    A = np.ascontiguousarray(np.swapaxes(model["A"], -1, -2)).reshape(-1)
+    Q = np.ascontiguousarray(np.swapaxes(model["Q"], -1, -2)).reshape(-1)
+    a = np.ascontiguousarray(model["a"]).reshape(-1)
+    H = np.ascontiguousarray(model["H"]).reshape(-1)
+    h = np.ascontiguousarray(np.atleast_1d(model["h"]), dtype=np.float64).reshape(-1)
+    R = np.ascontiguousarray(np.atleast_1d(model["R"]), dtype=np.float64).reshape(-1)
+    st = lambda arr, n: n if arr.shape[0] > 1 else 0
+    return dict(d=d, T=model["T"], ordering=0 if model["ordering"] == "F" else 1,
+                A=A, sA=st(model["A"], d * d), a=a, sa=st(model["a"], d), Q=Q, sQ=st(model["Q"], d * d),
+                H=H, sH=st(model["H"], d), h=h, sh=st(np.atleast_1d(model["h"]), 1),
+                R=R, sR=st(np.atleast_1d(model["R"]), 1),
+                x0m=np.ascontiguousarray(model["x0m"], dtype=np.float64),
+                x0P=np.ascontiguousarray(model["x0P"].T, dtype=np.float64).reshape(-1))
+
+
+def is_lti(pk):
+    return pk["sA"] == 0 and pk["sa"] == 0 and pk["sQ"] == 0 and pk["sH"] == 0 and pk["sh"] == 0
+
+
+def gp_case(k, t, s2, seed, mean=None):
+    """Model from a kernel spec + a draw y from it (as the reference bench does, single_output_gps.jl:143-145)."""
+    rng = np.random.default_rng(seed)
+    model = oc.build_lgssm(k, t, s2, mean)
+    T, d = model["T"], len(model["x0m"])
+    eps = (rng.standard_normal((T, d)), rng.standard_normal(T), rng.standard_normal(d))
+    return model, ref.rand(model, *eps), eps
+
+
+def random_lgssm(rng, tv, d, T, ordering="F"):
+    """test/models/model_test_utils.jl:163-263 (scalar-output variants), stable transitions."""
+    def psd(n, lo, hi):
+        U = np.linalg.qr(rng.standard_normal((n, n)))[0]
+        return (U * (rng.random(n) * (hi - lo) + lo)) @ U.T
+    x0m, x0P = rng.standard_normal(d), psd(d, 0.9, 1.1)
+    n = T if tv else 1
+    A = np.stack([-psd(d, 0.1, 0.9) + 0.2 * rng.standard_normal((d, d)) for _ in range(n)])
+    A = np.stack([Ai / max(1.0, 1.1 * np.abs(np.linalg.eigvals(Ai)).max()) for Ai in A])
+    a = rng.standard_normal((n, d))
+    Q = np.stack([psd(d, 0.2, 1.5) for _ in range(n)])
+    H, h, R = rng.standard_normal((n, d)), rng.standard_normal(n), rng.random(n) + 0.1
+    return dict(ordering=ordering, kind="scalar", T=T, A=A, a=a, Q=Q, H=H, h=h, R=R, x0m=x0m, x0P=x0P)
+
+
+# --------------------------------------------------------------------------- hostsim (CPU emulation of the chunk algorithm)
+_HOSTSIM = None
+
+
+def hostsim():
+    global _HOSTSIM
+    if _HOSTSIM is None:
+        src = os.path.join(HERE, "hostsim", "hostsim.cpp")
+        so = os.path.join(HERE, "hostsim", "libhostsim.so")
+        deps = [src] + [os.path.join(ROOT, "temporalgps.jl_amd", "csrc", f) for f in ("tgp_math.hpp", "tgp_chunk.hpp")]
+        if not os.path.exists(so) or any(os.path.getmtime(p) > os.path.getmtime(so) for p in deps):
+            subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-o", so, src])
+        _HOSTSIM = ctypes.CDLL(so)
+    return _HOSTSIM
+
+
+def _p(x):
+    return None if x is None else x.ctypes.data_as(_dp)
+
+
+def hostsim_run(model, what, y=None, missing=None, L0=4, BS=3, Rnew=None, eps=None, want_ggl=False):
+    pk = pack(model)
+    d, T = pk["d"], pk["T"]
+    out = {}
+    lml = ctypes.c_double(0.0)
+    m_out = P_out = G = g = L = xfm = xfP = mean = var = None
+    if what == 1:
+        m_out, P_out = np.zeros((T, d)), np.zeros((T, d, d))
+    if what == 2:
+        xfm, xfP = np.zeros(d), np.zeros((d, d))
+        if want_ggl:
+            G, g, L = np.zeros((T, d, d)), np.zeros((T, d)), np.zeros((T, d, d))
+        if Rnew is not None:
+            mean, var = np.zeros(T), np.zeros(T)
+    if what in (3, 4):
+        mean, var = np.zeros(T), np.zeros(T)
+    Rn = None if Rnew is None else np.ascontiguousarray(np.atleast_1d(Rnew), dtype=np.float64)
+    miss = None if missing is None else np.ascontiguousarray(missing, dtype=np.uint8)
+    yv = np.zeros(T) if y is None else np.ascontiguousarray(y, dtype=np.float64)
+    et = ee = None
+    x0m = pk["x0m"]
+    x0P = pk["x0P"]
+    if what == 4:
+        et = np.ascontiguousarray(eps[0], dtype=np.float64)
+        ee = np.ascontiguousarray(eps[1], dtype=np.float64)
+        x0m = ref.rand_x0(eps[2], model["x0m"], model["x0P"])
+        x0P = np.zeros(d * d)
+    rc = hostsim().hostsim_run(
+        d, int(is_lti(pk)), what, L0, BS, _i64(T), pk["ordering"], _p(pk["A"]), _i64(pk["sA"]), _p(pk["a"]), _i64(pk["sa"]),
+        _p(pk["Q"]), _i64(pk["sQ"]), _p(pk["H"]), _i64(pk["sH"]), _p(pk["h"]), _i64(pk["sh"]), _p(pk["R"]), _i64(pk["sR"]),
+        _p(yv), None if miss is None else miss.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)),
+        _p(x0m), _p(x0P), ctypes.byref(lml), _p(m_out), _p(P_out), _p(G), _p(g), _p(L), _p(xfm), _p(xfP),
+        _p(Rn), _i64(0 if Rn is None or Rn.shape[0] == 1 else 1), _p(mean), _p(var), _p(et), _p(ee))
+    out.update(rc=rc, lml=lml.value, m=m_out, P=None if P_out is None else np.swapaxes(P_out, -1, -2),
+               G=None if G is None else np.swapaxes(G, -1, -2), g=g, L=None if L is None else np.swapaxes(L, -1, -2),
+               xfm=xfm, xfP=None if xfP is None else xfP.T, mean=mean, var=var)
+    return out

@@ -1,0 +1,202 @@
+// TEST INFRASTRUCTURE ONLY (never part of the product library, never a fallback).
+// Runs the engine's per-lane chunk functions and scan monoids (temporalgps.jl_amd/csrc/tgp_math.hpp,
+// tgp_chunk.hpp -- the very same headers the HIP kernels instantiate) sequentially on the host, with a
+// small block size so that multi-level scans are exercised at tiny T. This lets the CPU-only test tier
+// check the time-parallel algorithm (elements, combines, chunk hand-offs, scratch indexing) against the
+// oracle without a GPU; the GPU tier then only has to establish that the HIP launch / shuffle / LDS
+// mechanics reproduce it.
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../../temporalgps.jl_amd/csrc/tgp_chunk.hpp"
+
+using namespace tgp;
+
+namespace {
+
+struct SoA {  // [ncomp][n]
+    std::vector<double> v;
+    int64_t n = 0;
+    int nc = 0;
+    void init(int nc_, int64_t n_) { nc = nc_; n = n_; v.assign((size_t)nc * n, 0.0); }
+};
+
+template <int D> struct FM {
+    using E = FElem<D>;
+    static constexpr int NC = Dim<D>::NF;
+    static void load(E& e, const SoA& s, int64_t i) { load_felem<D>(e, [&](int k) { return s.v[(size_t)k * s.n + i]; }); }
+    static void combine(const E& a, const E& b, E& o) { f_combine<D>(a, b, o); }
+    static void apply(const E& e, const State<D>& in, State<D>& out) { f_apply<D>(e, in, out); }
+};
+template <int D, bool COV> struct AM {
+    using E = AElem<D>;
+    static constexpr int NC = Dim<D>::NA;
+    static void load(E& e, const SoA& s, int64_t i) { load_aelem<D>(e, [&](int k) { return s.v[(size_t)k * s.n + i]; }); }
+    static void combine(const E& a, const E& b, E& o) { a_combine<D, COV>(a, b, o); }
+    static void apply(const E& e, const State<D>& in, State<D>& out) { a_apply<D, COV>(e, in, out); }
+};
+
+template <int D> void store_elem(const FElem<D>& e, SoA& s, int64_t i) {
+    store_felem<D>(e, [&](int k, double v) { s.v[(size_t)k * s.n + i] = v; });
+}
+template <int D> void store_elem(const AElem<D>& e, SoA& s, int64_t i) {
+    store_aelem<D>(e, [&](int k, double v) { s.v[(size_t)k * s.n + i] = v; });
+}
+
+// hierarchical scan, mirrors the GPU structure: reduce blocks upward, scan the top block, apply downward.
+template <int D, class M> void hier_scan(const SoA& E0, const State<D>& x0, std::vector<State<D>>& S0, State<D>& fin, int BS) {
+    std::vector<SoA> E;
+    E.push_back(E0);
+    while (E.back().n > BS) {
+        const SoA& lo = E.back();
+        SoA hi;
+        hi.init(M::NC, (lo.n + BS - 1) / BS);
+        for (int64_t b = 0; b < hi.n; ++b) {
+            typename M::E acc, cur, tmp;
+            acc.identity();
+            for (int64_t i = b * BS; i < lo.n && i < (b + 1) * BS; ++i) {
+                M::load(cur, lo, i);
+                M::combine(acc, cur, tmp);
+                acc = tmp;
+            }
+            store_elem<D>(acc, hi, b);
+        }
+        E.push_back(hi);
+    }
+    std::vector<std::vector<State<D>>> S(E.size());
+    for (int l = (int)E.size() - 1; l >= 0; --l) {
+        S[l].resize(E[l].n);
+        int64_t nb = (l == (int)E.size() - 1) ? 1 : E[l + 1].n;
+        int64_t bs = (l == (int)E.size() - 1) ? E[l].n : BS;
+        for (int64_t b = 0; b < nb; ++b) {
+            State<D> carry = (l == (int)E.size() - 1) ? x0 : S[l + 1][b];
+            typename M::E acc, cur, tmp;
+            acc.identity();
+            for (int64_t i = b * bs; i < E[l].n && i < (b + 1) * bs; ++i) {
+                M::apply(acc, carry, S[l][i]);
+                M::load(cur, E[l], i);
+                M::combine(acc, cur, tmp);
+                acc = tmp;
+            }
+            if (l == (int)E.size() - 1) M::apply(acc, carry, fin);
+        }
+    }
+    S0 = S[0];
+}
+
+template <int D> State<D> make_state(const double* m, const double* P) {
+    State<D> s;
+    for (int i = 0; i < D; ++i) s.m[i] = m[i];
+    for (int i = 0; i < D * D; ++i) s.P[i] = P[i];
+    return s;
+}
+
+struct Args {
+    ModelView mv;
+    const double *x0m, *x0P;
+    int L0, BS;
+    // outputs / extra inputs
+    double* lml;
+    double *m_out, *P_out;
+    double *G_out, *g_out, *L_out, *xfm, *xfP;
+    const double* Rnew;
+    int64_t sRn;
+    double *mean_out, *var_out;
+    const double *eps_t, *eps_e;
+    int what;  // 0 logpdf, 1 filter, 2 posterior(+marginals if mean_out), 3 prior marginals, 4 rand
+};
+
+template <int D, bool LTI> int run(const Args& a) {
+    const ModelView& mv = a.mv;
+    int64_t n0 = (mv.T + a.L0 - 1) / a.L0;
+    State<D> x0 = make_state<D>(a.x0m, a.x0P);
+    int bad = 0;
+    if (a.what <= 2) {
+        SoA E0;
+        E0.init(Dim<D>::NF, n0);
+        for (int64_t c = 0; c < n0; ++c)
+            chunk_reduce_filter<D, LTI>(mv, c, a.L0, [&](int k, double v) { E0.v[(size_t)k * n0 + c] = v; });
+        std::vector<State<D>> S0;
+        State<D> fin;
+        hier_scan<D, FM<D>>(E0, x0, S0, fin, a.BS);
+        double lml = 0.0, nmiss = 0.0;
+        FilterOut fo{a.m_out, a.P_out, nullptr, a.G_out, a.g_out, a.L_out};
+        std::vector<double> fs;
+        SoA R0;
+        if (a.what == 2) {
+            fs.assign((size_t)((n0 + 63) / 64) * 64 * a.L0 * Dim<D>::NS, 0.0);
+            fo.fs = fs.data();
+            R0.init(Dim<D>::NA, n0);
+        }
+        for (int64_t c = 0; c < n0; ++c) {
+            State<D> x = S0[c];
+            ChunkStats cs;
+            auto nost = [](int, double) {};
+            if (a.what == 0) cs = chunk_apply_filter<D, LTI, 0>(mv, c, a.L0, x, fo, nost);
+            else if (a.what == 1) cs = chunk_apply_filter<D, LTI, 1>(mv, c, a.L0, x, fo, nost);
+            else cs = chunk_apply_filter<D, LTI, 2>(mv, c, a.L0, x, fo, [&](int k, double v) { R0.v[(size_t)k * n0 + (n0 - 1 - c)] = v; });
+            lml += cs.lml;
+            nmiss += cs.nmiss;
+            bad |= cs.bad;
+        }
+        if (a.lml) *a.lml = lml + nmiss * 0.5 * (kLog2Pi + log(kLargeVar));
+        if (a.xfm) {
+            for (int i = 0; i < D; ++i) a.xfm[i] = fin.m[i];
+            for (int i = 0; i < D * D; ++i) a.xfP[i] = fin.P[i];
+        }
+        if (a.what == 2 && a.mean_out) {
+            std::vector<State<D>> S0r;
+            State<D> fin_r;
+            hier_scan<D, AM<D, true>>(R0, fin, S0r, fin_r, a.BS);
+            for (int64_t c = 0; c < n0; ++c) {
+                State<D> xs = S0r[n0 - 1 - c];
+                bad |= chunk_smooth<D, LTI>(mv, c, a.L0, xs, S0[c], fs.data(), a.Rnew, a.sRn, a.mean_out, a.var_out);
+            }
+        }
+    } else {
+        SoA E0;
+        E0.init(Dim<D>::NA, n0);
+        for (int64_t c = 0; c < n0; ++c) {
+            auto st = [&](int k, double v) { E0.v[(size_t)k * n0 + c] = v; };
+            if (a.what == 3) bad |= chunk_reduce_affine<D, LTI, false>(mv, c, a.L0, nullptr, st);
+            else bad |= chunk_reduce_affine<D, LTI, true>(mv, c, a.L0, a.eps_t, st);
+        }
+        std::vector<State<D>> S0;
+        State<D> fin;
+        if (a.what == 3) hier_scan<D, AM<D, true>>(E0, x0, S0, fin, a.BS);
+        else hier_scan<D, AM<D, false>>(E0, x0, S0, fin, a.BS);
+        for (int64_t c = 0; c < n0; ++c) {
+            State<D> x = S0[c];
+            if (a.what == 3) bad |= chunk_apply_affine<D, LTI, false>(mv, c, a.L0, x, nullptr, nullptr, a.mean_out, a.var_out);
+            else bad |= chunk_apply_affine<D, LTI, true>(mv, c, a.L0, x, a.eps_t, a.eps_e, a.mean_out, nullptr);
+        }
+    }
+    return bad ? 2 : 0;
+}
+
+template <int D> int run_d(const Args& a, bool lti) { return lti ? run<D, true>(a) : run<D, false>(a); }
+
+}  // namespace
+
+extern "C" int hostsim_run(int d, int lti, int what, int L0, int BS, int64_t T, int ordering, const double* A, int64_t sA,
+                           const double* av, int64_t sa, const double* Q, int64_t sQ, const double* H, int64_t sH,
+                           const double* h, int64_t sh, const double* R, int64_t sR, const double* y, const uint8_t* missing,
+                           const double* x0m, const double* x0P, double* lml, double* m_out, double* P_out, double* G_out,
+                           double* g_out, double* L_out, double* xfm, double* xfP, const double* Rnew, int64_t sRn,
+                           double* mean_out, double* var_out, const double* eps_t, const double* eps_e) {
+    Args a;
+    a.mv = ModelView{T, ordering, 0, A, av, Q, H, h, R, sA, sa, sQ, sH, sh, sR, y, missing};
+    a.x0m = x0m; a.x0P = x0P; a.L0 = L0; a.BS = BS; a.lml = lml; a.m_out = m_out; a.P_out = P_out;
+    a.G_out = G_out; a.g_out = g_out; a.L_out = L_out; a.xfm = xfm; a.xfP = xfP; a.Rnew = Rnew; a.sRn = sRn;
+    a.mean_out = mean_out; a.var_out = var_out; a.eps_t = eps_t; a.eps_e = eps_e; a.what = what;
+    switch (d) {
+        case 1: return run_d<1>(a, lti);
+        case 2: return run_d<2>(a, lti);
+        case 3: return run_d<3>(a, lti);
+        case 4: return run_d<4>(a, lti);
+        case 5: return run_d<5>(a, lti);
+        case 6: return run_d<6>(a, lti);
+        default: return 4;
+    }
+}
