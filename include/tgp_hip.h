@@ -1,0 +1,139 @@
+/* libtgp_hip.so -- C ABI of the MI355X (gfx950) Kalman filter / RTS smoother engine.
+ *
+ * Drop-in boundary for the linear-Gaussian state-space hot path of TemporalGPs.jl. The reference has no
+ * FFI layer; its extension seam is Julia dispatch on the StorageType tag handed to `to_sde`
+ * (/root/reference/src/util/storage_types.jl:1, src/gp/lti_sde.jl:12-16) and on the AbstractLGSSM
+ * supertype (src/models/lgssm.jl:1). Each entry point below replaces one reference method on an LGSSM;
+ * the Julia-side binding a maintainer adds is shown in INTEGRATION.md (julia/TemporalGPsHIP.jl).
+ *
+ * Conventions
+ *   - all reals are fp64, all sizes int64_t, matrices are column-major d x d blocks (Julia layout);
+ *   - per-step arrays are [T][...] contiguous; an array flagged TGP_SHARED_* holds ONE block used by all
+ *     steps (FillArrays.Fill: what RegularSpacing inputs produce, lti_sde.jl:148-160);
+ *   - scalar observations only for now (p == 1, ScalarOutputLGC, linear_gaussian_conditionals.jl:225-257):
+ *     H is the d-vector with emission.A = H', h and R are scalars per step;
+ *   - ordering 0 = Forward, 1 = Reverse (gauss_markov_model.jl:1-9,38-40);
+ *   - return codes: 0 ok; 1 bad argument / dimension mismatch (lgssm.jl:202-208); 2 not positive
+ *     definite (Julia PosDefException / DomainError at lgc.jl:135,250, lgssm.jl:235); 3 HIP runtime error;
+ *     4 unsupported. No exception or abort crosses the ABI; tgp_last_error() gives the message.
+ *   - ownership: host pointers are read/written during the call only and never retained. Device pointers
+ *     (TGP_DEVICE_PTRS / TGP_IN_DEVICE / TGP_OUT_DEVICE) are BORROWED: model arrays must stay alive until
+ *     the next tgp_model_set / tgp_destroy, per-call arrays until the call returns.
+ *   - threading: calls on one handle are serialised by the caller; one HIP stream per handle; every call
+ *     returns with its results complete (blocking). Distinct handles are independent.
+ */
+#ifndef TGP_HIP_H
+#define TGP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tgp_handle tgp_handle;
+
+/* ---- flags ------------------------------------------------------------------------------------ */
+#define TGP_SHARED_A (1u << 0)
+#define TGP_SHARED_a (1u << 1)
+#define TGP_SHARED_Q (1u << 2)
+#define TGP_SHARED_H (1u << 3)
+#define TGP_SHARED_h (1u << 4)
+#define TGP_SHARED_R (1u << 5) /* also: Rnew is one scalar in tgp_posterior_marginals */
+#define TGP_SHARED_ALL 0x3fu
+#define TGP_DEVICE_PTRS (1u << 16) /* tgp_model_set: A..R are device pointers (borrowed) */
+#define TGP_IN_DEVICE (1u << 16)   /* per-call inputs (y, missing, Rnew, eps) are device pointers */
+#define TGP_OUT_DEVICE (1u << 17)  /* per-call array outputs are device pointers */
+#define TGP_REUSE_REDUCE (1u << 18) /* reuse pass 1 + upward scans of the previous call (same model & y) */
+
+/* ---- return codes ----------------------------------------------------------------------------- */
+#define TGP_OK 0
+#define TGP_EINVAL 1
+#define TGP_ENOTPD 2
+#define TGP_EHIP 3
+#define TGP_EUNSUPPORTED 4
+
+/* ---- options (tgp_set_option) ------------------------------------------------------------------ */
+#define TGP_OPT_CHUNK 1   /* steps per lane in the chunked scan (0 = auto) */
+#define TGP_OPT_PROFILE 2 /* 1: bracket every kernel with hipEvents (see tgp_profile_*) */
+
+/* ---- lifetime ---------------------------------------------------------------------------------- */
+int tgp_create(tgp_handle** h, int device);
+int tgp_destroy(tgp_handle* h);
+const char* tgp_last_error(const tgp_handle* h);
+int tgp_set_option(tgp_handle* h, int option, int64_t value);
+/* run on a caller-provided hipStream_t (e.g. torch's current stream); NULL restores the handle's own */
+int tgp_set_stream(tgp_handle* h, void* hip_stream);
+const char* tgp_version(void);
+
+/* ---- model: replaces the LGSSM / GaussMarkovModel containers -----------------------------------
+ * lgssm.jl:9-12, gauss_markov_model.jl:20-32 (As, as, Qs, x0) + emissions (A = H', a = h, Q = R).
+ * x0m (d) and x0P (d*d) are always host pointers. */
+int tgp_model_set(tgp_handle* h, int64_t T, int d, int p, int ordering, uint32_t flags, const double* A,
+                  const double* a, const double* Q, const double* H, const double* hh, const double* R,
+                  const double* x0m, const double* x0P);
+/* replace only x0 (used for the carry-in state of a time shard) */
+int tgp_model_set_x0(tgp_handle* h, const double* x0m, const double* x0P);
+
+/* ---- logpdf(model::LGSSM, y): lgssm.jl:147-165 (+ missings.jl:8-13 when `missing` != NULL) ------ */
+int tgp_logpdf(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t flags, double* out);
+
+/* ---- _filter(model, y): lgssm.jl:171-187. m_out [T][d], P_out [T][d*d] (either may be NULL);
+ *      lml_out (host, may be NULL) receives the log marginal likelihood as a by-product. */
+int tgp_filter(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t flags, double* m_out,
+               double* P_out, double* lml_out);
+
+/* ---- posterior(model, y): lgssm.jl:193-238. Materialises the time-reversed model:
+ *      G [T][d*d], g [T][d], L [T][d*d] (all three or none), xfm (d) / xfP (d*d): x0 of the posterior
+ *      (host pointers). Forward priors only. */
+int tgp_posterior(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t flags, double* G,
+                  double* g, double* L, double* xfm, double* xfP);
+
+/* ---- marginals(replace_observation_noise_cov(posterior(model, y), Rnew)): the benchmarked
+ *      `marginals(posterior(fx, y)(x))` path, posterior_lti_sde.jl:27-36 -> lgssm.jl:99-115,193-238,
+ *      missings.jl:35-41. Forward filter + RTS smoother + emission predict, nothing materialised.
+ *      Rnew [T] (or one scalar with TGP_SHARED_R); mean_out, var_out [T]; lml_out host, may be NULL. */
+int tgp_posterior_marginals(tgp_handle* h, const double* y, const uint8_t* missing, const double* Rnew,
+                            uint32_t flags, double* mean_out, double* var_out, double* lml_out);
+
+/* ---- marginals(model): lgssm.jl:99-115 for the model as given (prior marginals for a Forward prior,
+ *      smoothing marginals for a materialised Reverse posterior). */
+int tgp_marginals(tgp_handle* h, uint32_t flags, double* mean_out, double* var_out);
+
+/* ---- rand(rng, model) with the randomness supplied: lgssm.jl:65-91, lgc.jl:84-87,241-243,
+ *      gaussian.jl:35-43. eps_t [T][d], eps_e [T], eps_0 [d] (eps_0 always host). y_out [T]. */
+int tgp_rand(tgp_handle* h, const double* eps_t, const double* eps_e, const double* eps_0, uint32_t flags,
+             double* y_out);
+
+/* ---- time sharding across GPUs -------------------------------------------
+ * A shard reduces its whole segment to ONE scan element, the host exchanges the (tiny) elements
+ * (torch.distributed all_gather over RCCL), folds those of the shards to its left onto x0, sets the
+ * result with tgp_model_set_x0 and finishes with the normal entry points + TGP_REUSE_REDUCE.
+ *   kind 0: filter element  (d*d + d + d(d+1)/2 + d + d(d+1)/2 doubles, packed)
+ *   kind 1: smoother element (d*d + d + d(d+1)/2 doubles) -- valid after tgp_smoother_forward        */
+int tgp_elem_size(int kind, int d);
+int tgp_segment_reduce(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t flags, double* elem_out);
+/* host-side monoid operations on packed elements / states (m (d), P (d*d) column-major) */
+int tgp_elem_apply(int kind, int d, const double* elem, const double* m, const double* P, double* m_out, double* P_out);
+int tgp_elem_combine(int kind, int d, const double* earlier, const double* later, double* out);
+
+/* two-phase posterior marginals for shards: forward (filter + reverse chunk elements; returns the
+ * segment's smoother element and its final filtered state), then backward from the smoothed state at
+ * the segment end (xs_m/xs_P host; NULL => the segment's own final filtered state). */
+int tgp_smoother_forward(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t flags,
+                         double* rev_elem_out, double* xfm, double* xfP, double* lml_out);
+int tgp_smoother_backward(tgp_handle* h, const double* xs_m, const double* xs_P, const double* Rnew,
+                          uint32_t flags, double* mean_out, double* var_out);
+
+/* ---- timing ------------------------------------------------------------------------------------ */
+/* device time of the last call (hipEvent, kernels only) and its host<->device copy times, ms */
+int tgp_last_timing(const tgp_handle* h, double* kernel_ms, double* h2d_ms, double* d2h_ms);
+/* per-kernel hipEvent profile accumulated since tgp_profile_reset (TGP_OPT_PROFILE = 1) */
+int tgp_profile_reset(tgp_handle* h);
+int tgp_profile_count(tgp_handle* h);
+int tgp_profile_get(tgp_handle* h, int idx, char* name, int name_cap, double* total_ms, int64_t* calls);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TGP_HIP_H */

@@ -1,0 +1,11 @@
+"""MI355X-native Kalman filter / RTS smoother engine behind TemporalGPs.jl's LGSSM interface.
+
+Import as `import temporalgps_jl_amd as tgp` (the directory name contains a dot, so the repo root ships a
+one-file import shim `temporalgps_jl_amd.py`).
+"""
+from . import _lib
+from .lgssm import (LGSSM, Forward, Gaussian, GaussMarkovModel, Reverse, ScalarOutputLGC, _filter, logpdf, marginals,
+                    posterior, posterior_marginals, rand, replace_observation_noise_cov)
+
+__all__ = ["LGSSM", "Forward", "Reverse", "Gaussian", "GaussMarkovModel", "ScalarOutputLGC", "logpdf", "_filter",
+           "posterior", "marginals", "posterior_marginals", "rand", "replace_observation_noise_cov", "_lib"]

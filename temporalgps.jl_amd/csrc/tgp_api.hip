@@ -1,0 +1,929 @@
+// C ABI of libtgp_hip.so (see include/tgp_hip.h): handle, device buffers, launch orchestration.
+// Host orchestration of one call (single stream, kernel boundaries are the only synchronisation):
+//   forward:  k_reduce_filter -> k_scan_reduce^* -> k_scan_apply(top) -> k_scan_apply^* -> k_apply_filter -> k_finalize
+//   smoother: (forward with MODE 2) -> k_scan_reduce^* -> k_scan_apply(top) -> k_scan_apply^* -> k_smooth
+#include "../../include/tgp_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "tgp_kernels.hpp"
+
+namespace tgp {
+const KernelTable *kernel_table_d1(), *kernel_table_d2(), *kernel_table_d3(), *kernel_table_d4(), *kernel_table_d5(),
+    *kernel_table_d6(), *kernel_table_d7(), *kernel_table_d8();
+const KernelTable* kernel_table(int d) {
+    switch (d) {
+        case 1: return kernel_table_d1();
+        case 2: return kernel_table_d2();
+        case 3: return kernel_table_d3();
+        case 4: return kernel_table_d4();
+        case 5: return kernel_table_d5();
+        case 6: return kernel_table_d6();
+        case 7: return kernel_table_d7();
+        case 8: return kernel_table_d8();
+        default: return nullptr;
+    }
+}
+}  // namespace tgp
+
+using namespace tgp;
+
+// result[0] = sum lml + nmiss * log(2 pi 1e15)/2 (missings.jl:45-53); result[1] = nmiss; result[2] = bad.
+// Fixed-order summation: the result is bit-reproducible from run to run.
+__global__ __launch_bounds__(256) void k_finalize(const double* __restrict__ partial, int64_t nblocks, double* __restrict__ result) {
+    __shared__ double sh[12];
+    double a = 0.0, b = 0.0;
+    int c = 0;
+    for (int64_t i = threadIdx.x; i < nblocks; i += 256) {
+        a += partial[3 * i];
+        b += partial[3 * i + 1];
+        c |= partial[3 * i + 2] != 0.0;
+    }
+    block_sum3(a, b, c, sh);
+    if (threadIdx.x == 0) {
+        result[0] = a + b * 0.5 * (kLog2Pi + log(kLargeVar));
+        result[1] = b;
+        result[2] = (double)c;
+    }
+}
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e == hipSuccess) cap = bytes;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    double* d() const { return static_cast<double*>(p); }
+};
+
+struct ScanCtx {
+    int monoid = 0, NC = 0, NS = 0;
+    std::vector<int64_t> n;
+    std::vector<double*> E, S;
+    double* fin = nullptr;
+    DevBuf slab;
+};
+
+struct ProfEntry {
+    std::string name;
+    double ms = 0.0;
+    int64_t calls = 0;
+};
+struct PendingEvt {
+    int idx;
+    hipEvent_t a, b;
+};
+
+constexpr int kTopBS = 512;
+
+}  // namespace
+
+struct tgp_handle {
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    std::string err;
+    // model
+    bool have_model = false, lti = false;
+    int64_t T = 0;
+    int d = 0, p = 1, ordering = 0;
+    ModelView mv{};
+    const KernelTable* kt = nullptr;
+    DevBuf bA, ba, bQ, bH, bh, bR;
+    std::vector<double> x0m, x0P;
+    DevBuf bx0, bx0r;
+    // per-call staging
+    DevBuf by, bmiss, bRnew, beps_t, beps_e, bo1, bo2, bo3;
+    // scans and scratch
+    ScanCtx F, Rv;
+    DevBuf fs, partial, result, badflag, segtmp;
+    int64_t opt_chunk = 0;
+    int profile = 0;
+    int L0 = 0;
+    int64_t n0 = 0;
+    bool reduce_valid = false, smoother_valid = false;
+    // timing
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    double kernel_ms = 0.0, h2d_ms = 0.0, d2h_ms = 0.0;
+    std::vector<ProfEntry> prof;
+    std::vector<PendingEvt> pending;
+    std::vector<hipEvent_t> evpool;
+
+    int fail(int code, const std::string& msg) {
+        err = msg;
+        return code;
+    }
+};
+
+#define HIPCHK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) return h->fail(TGP_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+#define TRY(expr)             \
+    do {                      \
+        int rc_ = (expr);     \
+        if (rc_ != TGP_OK) return rc_; \
+    } while (0)
+
+namespace {
+
+// ------------------------------------------------------------------------------------------ profiling
+struct LaunchScope {
+    tgp_handle* h;
+    int idx = -1;
+    hipEvent_t a = nullptr, b = nullptr;
+    LaunchScope(tgp_handle* h_, const char* name) : h(h_) {
+        if (!h->profile) return;
+        for (size_t i = 0; i < h->prof.size(); ++i)
+            if (h->prof[i].name == name) idx = (int)i;
+        if (idx < 0) {
+            h->prof.push_back(ProfEntry{name, 0.0, 0});
+            idx = (int)h->prof.size() - 1;
+        }
+        auto get = [&]() {
+            hipEvent_t e = nullptr;
+            if (!h->evpool.empty()) {
+                e = h->evpool.back();
+                h->evpool.pop_back();
+            } else {
+                (void)hipEventCreate(&e);
+            }
+            return e;
+        };
+        a = get();
+        b = get();
+        (void)hipEventRecord(a, h->stream);
+    }
+    ~LaunchScope() {
+        if (idx < 0) return;
+        (void)hipEventRecord(b, h->stream);
+        h->pending.push_back(PendingEvt{idx, a, b});
+    }
+};
+
+void resolve_profile(tgp_handle* h) {
+    for (auto& pe : h->pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, pe.a, pe.b) == hipSuccess) {
+            h->prof[pe.idx].ms += ms;
+            h->prof[pe.idx].calls += 1;
+        }
+        h->evpool.push_back(pe.a);
+        h->evpool.push_back(pe.b);
+    }
+    h->pending.clear();
+}
+
+// ------------------------------------------------------------------------------------------ helpers
+int bind_device(tgp_handle* h) {
+    HIPCHK(hipSetDevice(h->device));
+    return TGP_OK;
+}
+
+int stage_in(tgp_handle* h, DevBuf& buf, const void* src, size_t bytes, bool is_dev, const void** out) {
+    if (src == nullptr) {
+        *out = nullptr;
+        return TGP_OK;
+    }
+    if (is_dev) {
+        *out = src;
+        return TGP_OK;
+    }
+    HIPCHK(buf.ensure(bytes));
+    HIPCHK(hipMemcpyAsync(buf.p, src, bytes, hipMemcpyHostToDevice, h->stream));
+    *out = buf.p;
+    return TGP_OK;
+}
+
+// device destination for an output array: the user's pointer if it is a device pointer, else staging
+int stage_out(tgp_handle* h, DevBuf& buf, double* user, size_t bytes, bool is_dev, double** out) {
+    if (user == nullptr) {
+        *out = nullptr;
+        return TGP_OK;
+    }
+    if (is_dev) {
+        *out = user;
+        return TGP_OK;
+    }
+    HIPCHK(buf.ensure(bytes));
+    *out = buf.d();
+    return TGP_OK;
+}
+
+int copy_back(tgp_handle* h, double* user, const double* dev, size_t bytes, bool is_dev) {
+    if (user == nullptr || is_dev) return TGP_OK;
+    HIPCHK(hipMemcpyAsync(user, dev, bytes, hipMemcpyDeviceToHost, h->stream));
+    return TGP_OK;
+}
+
+void pack_state(int d, const double* m, const double* P, std::vector<double>& out) {
+    out.clear();
+    for (int i = 0; i < d; ++i) out.push_back(m[i]);
+    for (int j = 0; j < d; ++j)
+        for (int i = 0; i <= j; ++i) out.push_back(P[i + j * d]);
+}
+void unpack_state(int d, const double* pk, double* m, double* P) {
+    for (int i = 0; i < d; ++i) m[i] = pk[i];
+    int n = d;
+    for (int j = 0; j < d; ++j)
+        for (int i = 0; i <= j; ++i) {
+            P[i + j * d] = pk[n];
+            P[j + i * d] = pk[n];
+            ++n;
+        }
+}
+
+int upload_x0(tgp_handle* h, DevBuf& buf, const double* m, const double* P) {
+    std::vector<double> pk;
+    pack_state(h->d, m, P, pk);
+    HIPCHK(buf.ensure(pk.size() * sizeof(double)));
+    HIPCHK(hipMemcpyAsync(buf.p, pk.data(), pk.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));  // pk is a temporary
+    return TGP_OK;
+}
+
+int state_size(int d) { return d + d * (d + 1) / 2; }
+int felem_size(int d) { return d * d + 2 * d + d * (d + 1); }
+int aelem_size(int d) { return d * d + d + d * (d + 1) / 2; }
+
+void choose_chunk(tgp_handle* h) {
+    int64_t L0 = h->opt_chunk;
+    if (L0 <= 0) {
+        // aim at ~4 waves per SIMD (256 CUs x 4 SIMDs x 64 lanes x 4) before growing the chunk
+        const int64_t lanes = 256LL * 4 * 64 * 4;
+        L0 = (h->T + lanes - 1) / lanes;
+        if (L0 < 8) L0 = 8;
+        if (L0 > 64) L0 = 64;
+    }
+    if (L0 > h->T) L0 = h->T > 0 ? h->T : 1;
+    h->L0 = (int)L0;
+    h->n0 = (h->T + L0 - 1) / L0;
+}
+
+int scan_prepare(tgp_handle* h, ScanCtx& c, int monoid, int64_t n0) {
+    c.monoid = monoid;
+    c.NC = (monoid == kFilter) ? felem_size(h->d) : aelem_size(h->d);
+    c.NS = state_size(h->d);
+    c.n.clear();
+    c.n.push_back(n0);
+    while (c.n.back() > kTopBS) c.n.push_back((c.n.back() + 255) / 256);
+    size_t total = (size_t)c.NS;
+    for (int64_t n : c.n) total += (size_t)(c.NC + c.NS) * (size_t)n;
+    HIPCHK(c.slab.ensure(total * sizeof(double)));
+    double* p = c.slab.d();
+    c.E.clear();
+    c.S.clear();
+    for (int64_t n : c.n) {
+        c.E.push_back(p);
+        p += (size_t)c.NC * n;
+        c.S.push_back(p);
+        p += (size_t)c.NS * n;
+    }
+    c.fin = p;
+    return TGP_OK;
+}
+
+void scan_up(tgp_handle* h, ScanCtx& c) {
+    for (size_t l = 0; l + 1 < c.n.size(); ++l) {
+        LaunchScope ls(h, c.monoid == kFilter ? "k_scan_reduce<filter>" : "k_scan_reduce<affine>");
+        h->kt->scan_reduce(c.monoid, c.E[l], c.n[l], c.E[l + 1], c.n[l + 1], h->stream);
+    }
+}
+
+void scan_down(tgp_handle* h, ScanCtx& c, const double* x0dev) {
+    const int top = (int)c.n.size() - 1;
+    {
+        LaunchScope ls(h, c.monoid == kFilter ? "k_scan_apply<filter,top>" : "k_scan_apply<affine,top>");
+        h->kt->scan_apply(c.monoid, c.n[top] <= 256 ? 256 : kTopBS, c.E[top], c.n[top], x0dev, 1, c.S[top], c.fin, h->stream);
+    }
+    for (int l = top - 1; l >= 0; --l) {
+        LaunchScope ls(h, c.monoid == kFilter ? "k_scan_apply<filter>" : "k_scan_apply<affine>");
+        h->kt->scan_apply(c.monoid, 256, c.E[l], c.n[l], c.S[l + 1], c.n[l + 1], c.S[l], nullptr, h->stream);
+    }
+}
+
+// reduce the top level of `c` to a single element and copy it to the host
+int scan_total_to_host(tgp_handle* h, ScanCtx& c, double* elem_out) {
+    const int top = (int)c.n.size() - 1;
+    const double* src = c.E[top];
+    int64_t n = c.n[top];
+    HIPCHK(h->segtmp.ensure((size_t)c.NC * 4 * sizeof(double)));
+    double* t0 = h->segtmp.d();
+    double* t1 = t0 + (size_t)c.NC * 2;
+    while (true) {
+        int64_t nhi = (n + 255) / 256;
+        {
+            LaunchScope ls(h, "k_scan_reduce<segment>");
+            h->kt->scan_reduce(c.monoid, src, n, t0, nhi, h->stream);
+        }
+        if (nhi == 1) break;
+        src = t0;
+        n = nhi;
+        std::swap(t0, t1);
+    }
+    HIPCHK(hipMemcpyAsync(elem_out, t0, (size_t)c.NC * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return TGP_OK;
+}
+
+struct CallTimer {
+    tgp_handle* h;
+    explicit CallTimer(tgp_handle* h_) : h(h_) { (void)hipEventRecord(h->ev[0], h->stream); }
+    void inputs_done() { (void)hipEventRecord(h->ev[1], h->stream); }
+    void kernels_done() { (void)hipEventRecord(h->ev[2], h->stream); }
+    int finish() {
+        (void)hipEventRecord(h->ev[3], h->stream);
+        HIPCHK(hipStreamSynchronize(h->stream));
+        float a = 0.f, b = 0.f, c = 0.f;
+        (void)hipEventElapsedTime(&a, h->ev[0], h->ev[1]);
+        (void)hipEventElapsedTime(&b, h->ev[1], h->ev[2]);
+        (void)hipEventElapsedTime(&c, h->ev[2], h->ev[3]);
+        h->h2d_ms = a;
+        h->kernel_ms = b;
+        h->d2h_ms = c;
+        resolve_profile(h);
+        return TGP_OK;
+    }
+};
+
+int check_ready(tgp_handle* h) {
+    if (!h) return TGP_EINVAL;
+    if (!h->have_model) return h->fail(TGP_EINVAL, "no model set (call tgp_model_set first)");
+    return bind_device(h);
+}
+
+// forward pass 1 + upward scans (skipped when the caller vouches for reuse)
+int forward_reduce(tgp_handle* h, uint32_t flags) {
+    if ((flags & TGP_REUSE_REDUCE) && h->reduce_valid) return TGP_OK;
+    choose_chunk(h);
+    TRY(scan_prepare(h, h->F, kFilter, h->n0));
+    {
+        LaunchScope ls(h, h->lti ? "k_reduce_filter<lti>" : "k_reduce_filter<per-step>");
+        h->kt->reduce_filter(h->lti, h->mv, h->L0, h->n0, h->F.E[0], h->stream);
+    }
+    scan_up(h, h->F);
+    h->reduce_valid = true;
+    h->smoother_valid = false;
+    return TGP_OK;
+}
+
+int set_obs(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t flags) {
+    if (y == nullptr) return h->fail(TGP_EINVAL, "y is NULL");
+    const bool dev = (flags & TGP_IN_DEVICE) != 0;
+    const void* p = nullptr;
+    if ((flags & TGP_REUSE_REDUCE) && h->reduce_valid) return TGP_OK;  // caller vouches: same y as the previous call
+    TRY(stage_in(h, h->by, y, (size_t)h->T * sizeof(double), dev, &p));
+    h->mv.y = static_cast<const double*>(p);
+    TRY(stage_in(h, h->bmiss, missing, (size_t)h->T, dev, &p));
+    h->mv.missing = static_cast<const uint8_t*>(p);
+    return TGP_OK;
+}
+
+// forward filter to the end. mode 0/1/2 as in chunk_apply_filter. Fills h->result (lml, nmiss, bad).
+int forward_apply(tgp_handle* h, int mode, const FilterOut& fo) {
+    scan_down(h, h->F, h->bx0.d());
+    const int64_t nblocks = (h->n0 + 255) / 256;
+    HIPCHK(h->partial.ensure((size_t)nblocks * 3 * sizeof(double)));
+    HIPCHK(h->result.ensure(4 * sizeof(double)));
+    double* R0 = nullptr;
+    if (mode == 2) {
+        TRY(scan_prepare(h, h->Rv, kAffineCov, h->n0));
+        R0 = h->Rv.E[0];
+    }
+    {
+        const char* nm = mode == 0 ? (h->lti ? "k_apply_filter<lti,logpdf>" : "k_apply_filter<per-step,logpdf>")
+                         : mode == 1 ? (h->lti ? "k_apply_filter<lti,filter>" : "k_apply_filter<per-step,filter>")
+                                     : (h->lti ? "k_apply_filter<lti,posterior>" : "k_apply_filter<per-step,posterior>");
+        LaunchScope ls(h, nm);
+        h->kt->apply_filter(h->lti, mode, h->mv, h->L0, h->n0, h->F.S[0], fo, R0, h->partial.d(), h->stream);
+    }
+    {
+        LaunchScope ls(h, "k_finalize");
+        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, h->stream, h->partial.d(), nblocks, h->result.d());
+    }
+    return TGP_OK;
+}
+
+int fetch_result(tgp_handle* h, double* lml_out) {
+    double res[3] = {0, 0, 0};
+    HIPCHK(hipMemcpyAsync(res, h->result.p, sizeof res, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (lml_out) *lml_out = res[0];
+    if (res[2] != 0.0) return h->fail(TGP_ENOTPD, "innovation variance / predicted covariance not positive definite");
+    return TGP_OK;
+}
+
+int check_badflag(tgp_handle* h) {
+    int bad = 0;
+    HIPCHK(hipMemcpyAsync(&bad, h->badflag.p, sizeof bad, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (bad) return h->fail(TGP_ENOTPD, "matrix not positive definite (Cholesky failed)");
+    return TGP_OK;
+}
+
+int zero_badflag(tgp_handle* h) {
+    HIPCHK(h->badflag.ensure(sizeof(int)));
+    HIPCHK(hipMemsetAsync(h->badflag.p, 0, sizeof(int), h->stream));
+    return TGP_OK;
+}
+
+template <int D> int host_apply(int kind, const double* elem, const double* m, const double* P, double* mo, double* Po) {
+    State<D> in, out;
+    for (int i = 0; i < D; ++i) in.m[i] = m[i];
+    for (int i = 0; i < D * D; ++i) in.P[i] = P[i];
+    if (kind == 0) {
+        FElem<D> e;
+        load_felem<D>(e, [&](int k) { return elem[k]; });
+        f_apply<D>(e, in, out);
+    } else {
+        AElem<D> e;
+        load_aelem<D>(e, [&](int k) { return elem[k]; });
+        a_apply<D, true>(e, in, out);
+    }
+    for (int i = 0; i < D; ++i) mo[i] = out.m[i];
+    for (int i = 0; i < D * D; ++i) Po[i] = out.P[i];
+    return TGP_OK;
+}
+template <int D> int host_combine(int kind, const double* ei, const double* ej, double* out) {
+    if (kind == 0) {
+        FElem<D> a, b, o;
+        load_felem<D>(a, [&](int k) { return ei[k]; });
+        load_felem<D>(b, [&](int k) { return ej[k]; });
+        f_combine<D>(a, b, o);
+        store_felem<D>(o, [&](int k, double v) { out[k] = v; });
+    } else {
+        AElem<D> a, b, o;
+        load_aelem<D>(a, [&](int k) { return ei[k]; });
+        load_aelem<D>(b, [&](int k) { return ej[k]; });
+        a_combine<D, true>(a, b, o);
+        store_aelem<D>(o, [&](int k, double v) { out[k] = v; });
+    }
+    return TGP_OK;
+}
+
+#define DISPATCH_D(d, fn, ...)              \
+    switch (d) {                            \
+        case 1: return fn<1>(__VA_ARGS__);  \
+        case 2: return fn<2>(__VA_ARGS__);  \
+        case 3: return fn<3>(__VA_ARGS__);  \
+        case 4: return fn<4>(__VA_ARGS__);  \
+        case 5: return fn<5>(__VA_ARGS__);  \
+        case 6: return fn<6>(__VA_ARGS__);  \
+        case 7: return fn<7>(__VA_ARGS__);  \
+        case 8: return fn<8>(__VA_ARGS__);  \
+        default: return TGP_EUNSUPPORTED;   \
+    }
+
+}  // namespace
+
+// =========================================================================================== C ABI
+extern "C" {
+
+const char* tgp_version(void) { return "tgp_hip 0.1 (gfx950)"; }
+
+int tgp_create(tgp_handle** out, int device) {
+    if (!out) return TGP_EINVAL;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return TGP_EHIP;
+    if (device < 0 || device >= ndev) return TGP_EINVAL;
+    tgp_handle* h = new tgp_handle();
+    h->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete h;
+        return TGP_EHIP;
+    }
+    h->stream = h->own_stream;
+    for (auto& e : h->ev)
+        if (hipEventCreate(&e) != hipSuccess) {
+            delete h;
+            return TGP_EHIP;
+        }
+    *out = h;
+    return TGP_OK;
+}
+
+int tgp_destroy(tgp_handle* h) {
+    if (!h) return TGP_OK;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    for (DevBuf* b : {&h->bA, &h->ba, &h->bQ, &h->bH, &h->bh, &h->bR, &h->bx0, &h->bx0r, &h->by, &h->bmiss, &h->bRnew, &h->beps_t,
+                      &h->beps_e, &h->bo1, &h->bo2, &h->bo3, &h->F.slab, &h->Rv.slab, &h->fs, &h->partial, &h->result, &h->badflag,
+                      &h->segtmp})
+        b->release();
+    for (auto& e : h->ev)
+        if (e) (void)hipEventDestroy(e);
+    for (auto& pe : h->pending) {
+        (void)hipEventDestroy(pe.a);
+        (void)hipEventDestroy(pe.b);
+    }
+    for (auto& e : h->evpool) (void)hipEventDestroy(e);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    delete h;
+    return TGP_OK;
+}
+
+const char* tgp_last_error(const tgp_handle* h) { return h ? h->err.c_str() : "null handle"; }
+
+int tgp_set_option(tgp_handle* h, int option, int64_t value) {
+    if (!h) return TGP_EINVAL;
+    if (option == TGP_OPT_CHUNK) {
+        if (value < 0 || value > 4096) return h->fail(TGP_EINVAL, "TGP_OPT_CHUNK out of range");
+        h->opt_chunk = value;
+        h->reduce_valid = false;
+        h->smoother_valid = false;
+        return TGP_OK;
+    }
+    if (option == TGP_OPT_PROFILE) {
+        h->profile = value != 0;
+        return TGP_OK;
+    }
+    return h->fail(TGP_EINVAL, "unknown option");
+}
+
+int tgp_set_stream(tgp_handle* h, void* hip_stream) {
+    if (!h) return TGP_EINVAL;
+    (void)hipStreamSynchronize(h->stream);
+    h->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->own_stream;
+    return TGP_OK;
+}
+
+int tgp_model_set(tgp_handle* h, int64_t T, int d, int p, int ordering, uint32_t flags, const double* A, const double* a,
+                  const double* Q, const double* H, const double* hh, const double* R, const double* x0m, const double* x0P) {
+    if (!h) return TGP_EINVAL;
+    TRY(bind_device(h));
+    h->have_model = false;
+    h->reduce_valid = false;
+    h->smoother_valid = false;
+    if (T <= 0) return h->fail(TGP_EINVAL, "T must be positive");
+    if (p != 1) return h->fail(TGP_EUNSUPPORTED, "only scalar observations (p == 1) are implemented");
+    if (ordering != 0 && ordering != 1) return h->fail(TGP_EINVAL, "ordering must be 0 (Forward) or 1 (Reverse)");
+    const KernelTable* kt = kernel_table(d);
+    if (!kt) return h->fail(TGP_EUNSUPPORTED, "state dimension d must be in 1..8 for the per-lane scan path");
+    if (!A || !a || !Q || !H || !hh || !R || !x0m || !x0P) return h->fail(TGP_EINVAL, "null model array");
+    h->kt = kt;
+    h->T = T;
+    h->d = d;
+    h->p = p;
+    h->ordering = ordering;
+    const bool dev = (flags & TGP_DEVICE_PTRS) != 0;
+    auto cnt = [&](uint32_t bit, int64_t per) { return (size_t)((flags & bit) ? per : per * T) * sizeof(double); };
+    const void *pA, *pa, *pQ, *pH, *ph, *pR;
+    TRY(stage_in(h, h->bA, A, cnt(TGP_SHARED_A, d * d), dev, &pA));
+    TRY(stage_in(h, h->ba, a, cnt(TGP_SHARED_a, d), dev, &pa));
+    TRY(stage_in(h, h->bQ, Q, cnt(TGP_SHARED_Q, d * d), dev, &pQ));
+    TRY(stage_in(h, h->bH, H, cnt(TGP_SHARED_H, d), dev, &pH));
+    TRY(stage_in(h, h->bh, hh, cnt(TGP_SHARED_h, 1), dev, &ph));
+    TRY(stage_in(h, h->bR, R, cnt(TGP_SHARED_R, 1), dev, &pR));
+    ModelView& mv = h->mv;
+    mv = ModelView{};
+    mv.T = T;
+    mv.ordering = ordering;
+    mv.A = (const double*)pA;
+    mv.a = (const double*)pa;
+    mv.Q = (const double*)pQ;
+    mv.H = (const double*)pH;
+    mv.h = (const double*)ph;
+    mv.R = (const double*)pR;
+    mv.sA = (flags & TGP_SHARED_A) ? 0 : d * d;
+    mv.sa = (flags & TGP_SHARED_a) ? 0 : d;
+    mv.sQ = (flags & TGP_SHARED_Q) ? 0 : d * d;
+    mv.sH = (flags & TGP_SHARED_H) ? 0 : d;
+    mv.sh = (flags & TGP_SHARED_h) ? 0 : 1;
+    mv.sR = (flags & TGP_SHARED_R) ? 0 : 1;
+    const uint32_t lti_bits = TGP_SHARED_A | TGP_SHARED_a | TGP_SHARED_Q | TGP_SHARED_H | TGP_SHARED_h;
+    h->lti = (flags & lti_bits) == lti_bits;
+    h->x0m.assign(x0m, x0m + d);
+    h->x0P.assign(x0P, x0P + d * d);
+    TRY(upload_x0(h, h->bx0, x0m, x0P));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->have_model = true;
+    return TGP_OK;
+}
+
+int tgp_model_set_x0(tgp_handle* h, const double* x0m, const double* x0P) {
+    TRY(check_ready(h));
+    if (!x0m || !x0P) return h->fail(TGP_EINVAL, "null x0");
+    h->x0m.assign(x0m, x0m + h->d);
+    h->x0P.assign(x0P, x0P + h->d * h->d);
+    h->smoother_valid = false;
+    return upload_x0(h, h->bx0, x0m, x0P);
+}
+
+int tgp_logpdf(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t flags, double* out) {
+    TRY(check_ready(h));
+    if (!out) return h->fail(TGP_EINVAL, "out is NULL");
+    CallTimer tm(h);
+    TRY(set_obs(h, y, missing, flags));
+    tm.inputs_done();
+    TRY(forward_reduce(h, flags));
+    FilterOut fo{};
+    TRY(forward_apply(h, 0, fo));
+    tm.kernels_done();
+    int rc = fetch_result(h, out);
+    TRY(tm.finish());
+    return rc;
+}
+
+int tgp_filter(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t flags, double* m_out, double* P_out, double* lml_out) {
+    TRY(check_ready(h));
+    const bool odev = (flags & TGP_OUT_DEVICE) != 0;
+    const size_t nm = (size_t)h->T * h->d * sizeof(double), nP = nm * h->d;
+    CallTimer tm(h);
+    TRY(set_obs(h, y, missing, flags));
+    tm.inputs_done();
+    TRY(forward_reduce(h, flags));
+    FilterOut fo{};
+    TRY(stage_out(h, h->bo1, m_out, nm, odev, &fo.m_out));
+    TRY(stage_out(h, h->bo2, P_out, nP, odev, &fo.P_out));
+    TRY(forward_apply(h, 1, fo));
+    tm.kernels_done();
+    TRY(copy_back(h, m_out, fo.m_out, nm, odev));
+    TRY(copy_back(h, P_out, fo.P_out, nP, odev));
+    int rc = fetch_result(h, lml_out);
+    TRY(tm.finish());
+    return rc;
+}
+
+int tgp_posterior(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t flags, double* G, double* g, double* L,
+                  double* xfm, double* xfP) {
+    TRY(check_ready(h));
+    if (h->ordering != 0) return h->fail(TGP_EUNSUPPORTED, "posterior of a Reverse-ordered model is not implemented on the device");
+    if ((G || g || L) && !(G && g && L)) return h->fail(TGP_EINVAL, "G, g, L must be given together");
+    const bool odev = (flags & TGP_OUT_DEVICE) != 0;
+    const size_t ng = (size_t)h->T * h->d * sizeof(double), nG = ng * h->d;
+    CallTimer tm(h);
+    TRY(set_obs(h, y, missing, flags));
+    tm.inputs_done();
+    TRY(forward_reduce(h, flags));
+    FilterOut fo{};
+    TRY(stage_out(h, h->bo1, G, nG, odev, &fo.G_out));
+    TRY(stage_out(h, h->bo2, g, ng, odev, &fo.g_out));
+    TRY(stage_out(h, h->bo3, L, nG, odev, &fo.L_out));
+    TRY(forward_apply(h, 2, fo));
+    tm.kernels_done();
+    TRY(copy_back(h, G, fo.G_out, nG, odev));
+    TRY(copy_back(h, g, fo.g_out, ng, odev));
+    TRY(copy_back(h, L, fo.L_out, nG, odev));
+    if (xfm && xfP) {
+        std::vector<double> pk(state_size(h->d));
+        HIPCHK(hipMemcpyAsync(pk.data(), h->F.fin, pk.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        unpack_state(h->d, pk.data(), xfm, xfP);
+    }
+    int rc = fetch_result(h, nullptr);
+    TRY(tm.finish());
+    return rc;
+}
+
+static int smoother_forward_impl(tgp_handle* h, uint32_t flags) {
+    TRY(forward_reduce(h, flags));
+    const size_t fsz = (size_t)((h->n0 + 63) / 64) * 64 * h->L0 * state_size(h->d) * sizeof(double);
+    HIPCHK(h->fs.ensure(fsz));
+    FilterOut fo{};
+    fo.fs = h->fs.d();
+    TRY(forward_apply(h, 2, fo));
+    scan_up(h, h->Rv);
+    h->smoother_valid = true;
+    return TGP_OK;
+}
+
+static int smoother_backward_impl(tgp_handle* h, const double* xs_dev, const double* Rnew_dev, int64_t sRn, double* mean_dev, double* var_dev) {
+    scan_down(h, h->Rv, xs_dev);
+    TRY(zero_badflag(h));
+    {
+        LaunchScope ls(h, h->lti ? "k_smooth<lti>" : "k_smooth<per-step>");
+        h->kt->smooth(h->lti, h->mv, h->L0, h->n0, h->F.S[0], h->Rv.S[0], h->fs.d(), Rnew_dev, sRn, mean_dev, var_dev,
+                      static_cast<int*>(h->badflag.p), h->stream);
+    }
+    return TGP_OK;
+}
+
+int tgp_posterior_marginals(tgp_handle* h, const double* y, const uint8_t* missing, const double* Rnew, uint32_t flags,
+                            double* mean_out, double* var_out, double* lml_out) {
+    TRY(check_ready(h));
+    if (!Rnew || !mean_out || !var_out) return h->fail(TGP_EINVAL, "null Rnew / output");
+    if (h->ordering != 0) return h->fail(TGP_EUNSUPPORTED, "posterior of a Reverse-ordered model is not implemented on the device");
+    const bool idev = (flags & TGP_IN_DEVICE) != 0, odev = (flags & TGP_OUT_DEVICE) != 0;
+    const bool rshared = (flags & TGP_SHARED_R) != 0;
+    const size_t nT = (size_t)h->T * sizeof(double);
+    CallTimer tm(h);
+    const void* pR = nullptr;
+    TRY(stage_in(h, h->bRnew, Rnew, rshared ? sizeof(double) : nT, idev, &pR));
+    TRY(set_obs(h, y, missing, flags));
+    tm.inputs_done();
+    TRY(smoother_forward_impl(h, flags));
+    double *dm = nullptr, *dv = nullptr;
+    TRY(stage_out(h, h->bo1, mean_out, nT, odev, &dm));
+    TRY(stage_out(h, h->bo2, var_out, nT, odev, &dv));
+    TRY(smoother_backward_impl(h, h->F.fin, (const double*)pR, rshared ? 0 : 1, dm, dv));
+    tm.kernels_done();
+    TRY(copy_back(h, mean_out, dm, nT, odev));
+    TRY(copy_back(h, var_out, dv, nT, odev));
+    int rc = fetch_result(h, lml_out);
+    if (rc == TGP_OK) rc = check_badflag(h);
+    TRY(tm.finish());
+    return rc;
+}
+
+int tgp_smoother_forward(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t flags, double* rev_elem_out, double* xfm,
+                         double* xfP, double* lml_out) {
+    TRY(check_ready(h));
+    if (h->ordering != 0) return h->fail(TGP_EUNSUPPORTED, "posterior of a Reverse-ordered model is not implemented on the device");
+    CallTimer tm(h);
+    TRY(set_obs(h, y, missing, flags));
+    tm.inputs_done();
+    TRY(smoother_forward_impl(h, flags));
+    if (rev_elem_out) TRY(scan_total_to_host(h, h->Rv, rev_elem_out));
+    tm.kernels_done();
+    if (xfm && xfP) {
+        std::vector<double> pk(state_size(h->d));
+        HIPCHK(hipMemcpyAsync(pk.data(), h->F.fin, pk.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        unpack_state(h->d, pk.data(), xfm, xfP);
+    }
+    int rc = fetch_result(h, lml_out);
+    TRY(tm.finish());
+    return rc;
+}
+
+int tgp_smoother_backward(tgp_handle* h, const double* xs_m, const double* xs_P, const double* Rnew, uint32_t flags, double* mean_out,
+                          double* var_out) {
+    TRY(check_ready(h));
+    if (!h->smoother_valid) return h->fail(TGP_EINVAL, "tgp_smoother_backward needs a preceding tgp_smoother_forward");
+    if (!Rnew || !mean_out || !var_out) return h->fail(TGP_EINVAL, "null Rnew / output");
+    const bool idev = (flags & TGP_IN_DEVICE) != 0, odev = (flags & TGP_OUT_DEVICE) != 0;
+    const bool rshared = (flags & TGP_SHARED_R) != 0;
+    const size_t nT = (size_t)h->T * sizeof(double);
+    CallTimer tm(h);
+    const void* pR = nullptr;
+    TRY(stage_in(h, h->bRnew, Rnew, rshared ? sizeof(double) : nT, idev, &pR));
+    const double* xs_dev = h->F.fin;
+    if (xs_m && xs_P) {
+        TRY(upload_x0(h, h->bx0r, xs_m, xs_P));
+        xs_dev = h->bx0r.d();
+    }
+    tm.inputs_done();
+    double *dm = nullptr, *dv = nullptr;
+    TRY(stage_out(h, h->bo1, mean_out, nT, odev, &dm));
+    TRY(stage_out(h, h->bo2, var_out, nT, odev, &dv));
+    TRY(smoother_backward_impl(h, xs_dev, (const double*)pR, rshared ? 0 : 1, dm, dv));
+    tm.kernels_done();
+    TRY(copy_back(h, mean_out, dm, nT, odev));
+    TRY(copy_back(h, var_out, dv, nT, odev));
+    int rc = check_badflag(h);
+    TRY(tm.finish());
+    return rc;
+}
+
+static int affine_impl(tgp_handle* h, bool rnd, const double* x0dev, const double* eps_t, const double* eps_e, double* mean_dev,
+                       double* var_dev) {
+    choose_chunk(h);
+    h->reduce_valid = false;
+    h->smoother_valid = false;
+    const int monoid = rnd ? kAffineMean : kAffineCov;
+    TRY(scan_prepare(h, h->Rv, monoid, h->n0));
+    TRY(zero_badflag(h));
+    int* bad = static_cast<int*>(h->badflag.p);
+    {
+        LaunchScope ls(h, rnd ? "k_reduce_affine<rand>" : "k_reduce_affine<marginals>");
+        h->kt->reduce_affine(h->lti, rnd, h->mv, h->L0, h->n0, eps_t, h->Rv.E[0], bad, h->stream);
+    }
+    scan_up(h, h->Rv);
+    scan_down(h, h->Rv, x0dev);
+    {
+        LaunchScope ls(h, rnd ? "k_apply_affine<rand>" : "k_apply_affine<marginals>");
+        h->kt->apply_affine(h->lti, rnd, h->mv, h->L0, h->n0, h->Rv.S[0], eps_t, eps_e, mean_dev, var_dev, bad, h->stream);
+    }
+    return TGP_OK;
+}
+
+int tgp_marginals(tgp_handle* h, uint32_t flags, double* mean_out, double* var_out) {
+    TRY(check_ready(h));
+    if (!mean_out || !var_out) return h->fail(TGP_EINVAL, "null output");
+    const bool odev = (flags & TGP_OUT_DEVICE) != 0;
+    const size_t nT = (size_t)h->T * sizeof(double);
+    CallTimer tm(h);
+    tm.inputs_done();
+    double *dm = nullptr, *dv = nullptr;
+    TRY(stage_out(h, h->bo1, mean_out, nT, odev, &dm));
+    TRY(stage_out(h, h->bo2, var_out, nT, odev, &dv));
+    TRY(affine_impl(h, false, h->bx0.d(), nullptr, nullptr, dm, dv));
+    tm.kernels_done();
+    TRY(copy_back(h, mean_out, dm, nT, odev));
+    TRY(copy_back(h, var_out, dv, nT, odev));
+    int rc = check_badflag(h);
+    TRY(tm.finish());
+    return rc;
+}
+
+int tgp_rand(tgp_handle* h, const double* eps_t, const double* eps_e, const double* eps_0, uint32_t flags, double* y_out) {
+    TRY(check_ready(h));
+    if (!eps_t || !eps_e || !eps_0 || !y_out) return h->fail(TGP_EINVAL, "null eps / output");
+    const bool idev = (flags & TGP_IN_DEVICE) != 0, odev = (flags & TGP_OUT_DEVICE) != 0;
+    const size_t nT = (size_t)h->T * sizeof(double);
+    const int d = h->d;
+    // x0 = m + cholesky(Symmetric(P + 1e-12 I)).U' eps_0   (gaussian.jl:35-43) -- d x d, on the host
+    std::vector<double> U((size_t)d * d, 0.0), x0(d), zeroP((size_t)d * d, 0.0);
+    for (int j = 0; j < d; ++j) {
+        for (int i = 0; i <= j; ++i) {
+            double acc = h->x0P[i + j * d] + (i == j ? 1e-12 : 0.0);
+            for (int k = 0; k < i; ++k) acc -= U[k + i * d] * U[k + j * d];
+            if (i == j) {
+                if (!(acc > 0.0)) return h->fail(TGP_ENOTPD, "x0.P + 1e-12 I is not positive definite");
+                U[j + j * d] = std::sqrt(acc);
+            } else {
+                U[i + j * d] = acc / U[i + i * d];
+            }
+        }
+    }
+    for (int i = 0; i < d; ++i) {
+        double acc = 0.0;
+        for (int k = 0; k <= i; ++k) acc += U[k + i * d] * eps_0[k];
+        x0[i] = h->x0m[i] + acc;
+    }
+    CallTimer tm(h);
+    TRY(upload_x0(h, h->bx0r, x0.data(), zeroP.data()));
+    const void *pet = nullptr, *pee = nullptr;
+    TRY(stage_in(h, h->beps_t, eps_t, nT * d, idev, &pet));
+    TRY(stage_in(h, h->beps_e, eps_e, nT, idev, &pee));
+    tm.inputs_done();
+    double* dy = nullptr;
+    TRY(stage_out(h, h->bo1, y_out, nT, odev, &dy));
+    TRY(affine_impl(h, true, h->bx0r.d(), (const double*)pet, (const double*)pee, dy, nullptr));
+    tm.kernels_done();
+    TRY(copy_back(h, y_out, dy, nT, odev));
+    int rc = check_badflag(h);
+    TRY(tm.finish());
+    return rc;
+}
+
+int tgp_elem_size(int kind, int d) { return kind == 0 ? felem_size(d) : aelem_size(d); }
+
+int tgp_segment_reduce(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t flags, double* elem_out) {
+    TRY(check_ready(h));
+    if (!elem_out) return h->fail(TGP_EINVAL, "elem_out is NULL");
+    CallTimer tm(h);
+    TRY(set_obs(h, y, missing, flags));
+    tm.inputs_done();
+    TRY(forward_reduce(h, flags));
+    TRY(scan_total_to_host(h, h->F, elem_out));
+    tm.kernels_done();
+    return tm.finish();
+}
+
+int tgp_elem_apply(int kind, int d, const double* elem, const double* m, const double* P, double* m_out, double* P_out) {
+    if (!elem || !m || !P || !m_out || !P_out) return TGP_EINVAL;
+    DISPATCH_D(d, host_apply, kind, elem, m, P, m_out, P_out)
+}
+
+int tgp_elem_combine(int kind, int d, const double* earlier, const double* later, double* out) {
+    if (!earlier || !later || !out) return TGP_EINVAL;
+    DISPATCH_D(d, host_combine, kind, earlier, later, out)
+}
+
+int tgp_last_timing(const tgp_handle* h, double* kernel_ms, double* h2d_ms, double* d2h_ms) {
+    if (!h) return TGP_EINVAL;
+    if (kernel_ms) *kernel_ms = h->kernel_ms;
+    if (h2d_ms) *h2d_ms = h->h2d_ms;
+    if (d2h_ms) *d2h_ms = h->d2h_ms;
+    return TGP_OK;
+}
+
+int tgp_profile_reset(tgp_handle* h) {
+    if (!h) return TGP_EINVAL;
+    resolve_profile(h);
+    h->prof.clear();
+    return TGP_OK;
+}
+int tgp_profile_count(tgp_handle* h) { return h ? (int)h->prof.size() : 0; }
+int tgp_profile_get(tgp_handle* h, int idx, char* name, int name_cap, double* total_ms, int64_t* calls) {
+    if (!h || idx < 0 || idx >= (int)h->prof.size()) return TGP_EINVAL;
+    if (name && name_cap > 0) {
+        std::strncpy(name, h->prof[idx].name.c_str(), (size_t)name_cap - 1);
+        name[name_cap - 1] = 0;
+    }
+    if (total_ms) *total_ms = h->prof[idx].ms;
+    if (calls) *calls = h->prof[idx].calls;
+    return TGP_OK;
+}
+
+}  // extern "C"

@@ -150,9 +150,11 @@ TGP_HD ChunkStats chunk_apply_filter(const ModelView& mv, int64_t c, int L0, Sta
         cs.nmiss += sl.is_missing ? 1.0 : 0.0;
         if (MODE >= 1 && out.m_out) {
             TGP_UNROLL for (int i = 0; i < D; ++i) out.m_out[sl.te * D + i] = x.m[i];
+        }
+        if (MODE >= 1 && out.P_out) {
             TGP_UNROLL for (int i = 0; i < D * D; ++i) out.P_out[sl.te * D * D + i] = x.P[i];
         }
-        if (MODE == 2) {
+        if (MODE == 2 && out.fs) {
             int i = (int)(r - r0);
             double* fs = out.fs;
             int L0_ = L0;

@@ -1,0 +1,241 @@
+// gfx950 kernels of the time-parallel Kalman engine (wave64, one chunk / one scan element per lane).
+//
+//   k_reduce_filter / k_reduce_affine   pass 1: chunk of L0 steps -> one element (SoA, coalesced store)
+//   k_scan<REDUCE>                      block of BS elements -> one element (shuffle tree + LDS across waves)
+//   k_scan<APPLY>                       block carry-in state + exclusive in-block prefix -> per-element carry-in state
+//   k_apply_filter / k_apply_affine     pass 2: the reference's sequential recursion inside every chunk
+//   k_smooth                            pass 3: RTS smoother inside every chunk
+//   k_finalize (tgp_api.hip)            deterministic fixed-order sum of the per-block log-likelihood partials
+//
+// Kernel boundaries provide all inter-workgroup ordering (no in-launch hand-offs, so none of the
+// cross-XCD visibility hazards of MI355X_MICROARCH.md apply); every launch covers >> 256 workgroups
+// at the benchmarked sizes.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "tgp_chunk.hpp"
+
+namespace tgp {
+
+// ---------------------------------------------------------------- monoid traits (device)
+template <int D> struct FilterMonoid {
+    using E = FElem<D>;
+    static constexpr int NC = Dim<D>::NF;
+    template <typename Ld> static __device__ __forceinline__ void load(E& e, Ld ld) { load_felem<D>(e, ld); }
+    template <typename St> static __device__ __forceinline__ void store(const E& e, St st) { store_felem<D>(e, st); }
+    static __device__ __forceinline__ void combine(const E& a, const E& b, E& o) { f_combine<D>(a, b, o); }
+    static __device__ __forceinline__ void apply(const E& e, const State<D>& in, State<D>& out) { f_apply<D>(e, in, out); }
+};
+template <int D, bool COV> struct AffineMonoid {
+    using E = AElem<D>;
+    static constexpr int NC = Dim<D>::NA;
+    template <typename Ld> static __device__ __forceinline__ void load(E& e, Ld ld) { load_aelem<D>(e, ld); }
+    template <typename St> static __device__ __forceinline__ void store(const E& e, St st) { store_aelem<D>(e, st); }
+    static __device__ __forceinline__ void combine(const E& a, const E& b, E& o) { a_combine<D, COV>(a, b, o); }
+    static __device__ __forceinline__ void apply(const E& e, const State<D>& in, State<D>& out) { a_apply<D, COV>(e, in, out); }
+};
+
+template <class E> __device__ __forceinline__ void shfl_up_elem(const E& in, E& out, int off) {
+    constexpr int N = sizeof(E) / sizeof(double);
+    const double* s = reinterpret_cast<const double*>(&in);
+    double* d = reinterpret_cast<double*>(&out);
+    TGP_UNROLL for (int i = 0; i < N; ++i) d[i] = __shfl_up(s[i], off, 64);
+}
+template <class E> __device__ __forceinline__ void shfl_down_elem(const E& in, E& out, int off) {
+    constexpr int N = sizeof(E) / sizeof(double);
+    const double* s = reinterpret_cast<const double*>(&in);
+    double* d = reinterpret_cast<double*>(&out);
+    TGP_UNROLL for (int i = 0; i < N; ++i) d[i] = __shfl_down(s[i], off, 64);
+}
+
+// ---------------------------------------------------------------- pass 1
+template <int D, bool LTI>
+__global__ __launch_bounds__(256) void k_reduce_filter(ModelView mv, int L0, int64_t n0, double* __restrict__ E0) {
+    int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= n0) return;
+    chunk_reduce_filter<D, LTI>(mv, c, L0, [=](int k, double v) { E0[(int64_t)k * n0 + c] = v; });
+}
+
+template <int D, bool LTI, bool RAND>
+__global__ __launch_bounds__(256) void k_reduce_affine(ModelView mv, int L0, int64_t n0, const double* __restrict__ eps_t,
+                                                       double* __restrict__ E0, int* __restrict__ bad) {
+    int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= n0) return;
+    int rc = chunk_reduce_affine<D, LTI, RAND>(mv, c, L0, eps_t, [=](int k, double v) { E0[(int64_t)k * n0 + c] = v; });
+    if (rc) atomicOr(bad, 1);
+}
+
+// ---------------------------------------------------------------- block scans over elements
+// REDUCE: Ehi[b] = E[b*BS] o ... o E[b*BS + BS - 1]   (identity-padded tail)
+template <class M, int BS>
+__global__ __launch_bounds__(BS) void k_scan_reduce(const double* __restrict__ Ein, int64_t n, double* __restrict__ Ehi, int64_t nhi) {
+    using E = typename M::E;
+    constexpr int NW = BS / 64;
+    __shared__ double wt[NW][M::NC];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int64_t idx = (int64_t)blockIdx.x * BS + tid;
+    E e, o, t;
+    if (idx < n) M::load(e, [=](int k) { return Ein[(int64_t)k * n + idx]; });
+    else e.identity();
+    // ordered tree reduction inside the wave: lane l absorbs lane l+off (later elements on the right)
+    TGP_UNROLL for (int off = 1; off < 64; off <<= 1) {
+        shfl_down_elem(e, o, off);
+        M::combine(e, o, t);
+        if ((lane & (2 * off - 1)) == 0) e = t;
+    }
+    if (lane == 0) M::store(e, [&](int k, double v) { wt[wid][k] = v; });
+    __syncthreads();
+    if (tid == 0) {
+        TGP_UNROLL for (int w = 1; w < NW; ++w) {
+            M::load(o, [&](int k) { return wt[w][k]; });
+            M::combine(e, o, t);
+            e = t;
+        }
+        const int64_t b = blockIdx.x;
+        M::store(e, [=](int k, double v) { Ehi[(int64_t)k * nhi + b] = v; });
+    }
+}
+
+// APPLY: S[i] = apply(E[b*BS] o ... o E[i-1], carry[b]) ; optionally fin = apply(all of block 0.., carry) (top level)
+template <int D, class M, int BS>
+__global__ __launch_bounds__(BS) void k_scan_apply(const double* __restrict__ Ein, int64_t n, const double* __restrict__ carry,
+                                                   int64_t ncarry, double* __restrict__ S, double* __restrict__ fin) {
+    using E = typename M::E;
+    constexpr int NW = BS / 64;
+    __shared__ double wt[NW][M::NC];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int64_t b = blockIdx.x;
+    const int64_t idx = b * BS + tid;
+    E e, o, t;
+    if (idx < n) M::load(e, [=](int k) { return Ein[(int64_t)k * n + idx]; });
+    else e.identity();
+    // inclusive Kogge-Stone scan inside the wave
+    TGP_UNROLL for (int off = 1; off < 64; off <<= 1) {
+        shfl_up_elem(e, o, off);
+        M::combine(o, e, t);
+        if (lane >= off) e = t;
+    }
+    if (lane == 63) M::store(e, [&](int k, double v) { wt[wid][k] = v; });
+    __syncthreads();
+    // exclusive prefix of this lane inside the block
+    E ex;
+    shfl_up_elem(e, ex, 1);
+    if (lane == 0) ex.identity();
+    if (NW > 1) {
+        E wp;
+        wp.identity();
+        for (int w = 0; w < wid; ++w) {
+            M::load(o, [&](int k) { return wt[w][k]; });
+            M::combine(wp, o, t);
+            wp = t;
+        }
+        M::combine(wp, ex, t);
+        ex = t;
+        if (fin != nullptr && tid == BS - 1) {
+            M::combine(wp, e, t);
+            e = t;
+        }
+    }
+    State<D> cs, st;
+    load_state<D>(cs, [=](int k) { return carry[(int64_t)k * ncarry + b]; });
+    if (idx < n) {
+        M::apply(ex, cs, st);
+        store_state<D>(st, [=](int k, double v) { S[(int64_t)k * n + idx] = v; });
+    }
+    if (fin != nullptr && tid == BS - 1) {
+        M::apply(e, cs, st);
+        store_state<D>(st, [=](int k, double v) { fin[k] = v; });
+    }
+}
+
+// ---------------------------------------------------------------- deterministic block reduction of (lml, nmiss, bad)
+__device__ __forceinline__ void block_sum3(double& a, double& b, int& c, double* sh /* [3*4] */) {
+    TGP_UNROLL for (int off = 32; off >= 1; off >>= 1) {
+        a += __shfl_down(a, off, 64);
+        b += __shfl_down(b, off, 64);
+        c |= __shfl_down(c, off, 64);
+    }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0) { sh[wid] = a; sh[4 + wid] = b; sh[8 + wid] = (double)c; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a = ((sh[0] + sh[1]) + (sh[2] + sh[3]));
+        b = ((sh[4] + sh[5]) + (sh[6] + sh[7]));
+        c = (sh[8] + sh[9] + sh[10] + sh[11]) != 0.0;
+    }
+}
+
+// ---------------------------------------------------------------- pass 2
+template <int D, bool LTI, int MODE>
+__global__ __launch_bounds__(256) void k_apply_filter(ModelView mv, int L0, int64_t n0, const double* __restrict__ S0, FilterOut out,
+                                                      double* __restrict__ R0, double* __restrict__ partial) {
+    __shared__ double sh[12];
+    int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    double lml = 0.0, nmiss = 0.0;
+    int bad = 0;
+    if (c < n0) {
+        State<D> x;
+        load_state<D>(x, [=](int k) { return S0[(int64_t)k * n0 + c]; });
+        ChunkStats cs = chunk_apply_filter<D, LTI, MODE>(mv, c, L0, x, out, [=](int k, double v) { R0[(int64_t)k * n0 + (n0 - 1 - c)] = v; });
+        lml = cs.lml;
+        nmiss = cs.nmiss;
+        bad = cs.bad;
+    }
+    block_sum3(lml, nmiss, bad, sh);
+    if (threadIdx.x == 0) {
+        partial[3 * (int64_t)blockIdx.x + 0] = lml;
+        partial[3 * (int64_t)blockIdx.x + 1] = nmiss;
+        partial[3 * (int64_t)blockIdx.x + 2] = (double)bad;
+    }
+}
+
+// ---------------------------------------------------------------- pass 3
+template <int D, bool LTI>
+__global__ __launch_bounds__(256) void k_smooth(ModelView mv, int L0, int64_t n0, const double* __restrict__ S0, const double* __restrict__ S0r,
+                                                const double* __restrict__ fs, const double* __restrict__ Rnew, int64_t sRn,
+                                                double* __restrict__ mean_out, double* __restrict__ var_out, int* __restrict__ bad) {
+    int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= n0) return;
+    State<D> xs, carry;
+    const int64_t q = n0 - 1 - c;
+    load_state<D>(xs, [=](int k) { return S0r[(int64_t)k * n0 + q]; });
+    load_state<D>(carry, [=](int k) { return S0[(int64_t)k * n0 + c]; });
+    int rc = chunk_smooth<D, LTI>(mv, c, L0, xs, carry, fs, Rnew, sRn, mean_out, var_out);
+    if (rc) atomicOr(bad, 1);
+}
+
+// ---------------------------------------------------------------- affine pass 2
+template <int D, bool LTI, bool RAND>
+__global__ __launch_bounds__(256) void k_apply_affine(ModelView mv, int L0, int64_t n0, const double* __restrict__ S0, const double* __restrict__ eps_t,
+                                                      const double* __restrict__ eps_e, double* __restrict__ mean_out, double* __restrict__ var_out,
+                                                      int* __restrict__ bad) {
+    int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= n0) return;
+    State<D> x;
+    load_state<D>(x, [=](int k) { return S0[(int64_t)k * n0 + c]; });
+    int rc = chunk_apply_affine<D, LTI, RAND>(mv, c, L0, x, eps_t, eps_e, mean_out, var_out);
+    if (rc) atomicOr(bad, 1);
+}
+
+// ---------------------------------------------------------------- per-D launch table (filled by tgp_inst_dN.hip)
+enum ScanMonoid { kFilter = 0, kAffineCov = 1, kAffineMean = 2 };
+
+struct KernelTable {
+    int d;
+    void (*reduce_filter)(bool lti, const ModelView&, int L0, int64_t n0, double* E0, hipStream_t);
+    void (*apply_filter)(bool lti, int mode, const ModelView&, int L0, int64_t n0, const double* S0, const FilterOut&, double* R0,
+                         double* partial, hipStream_t);
+    void (*smooth)(bool lti, const ModelView&, int L0, int64_t n0, const double* S0, const double* S0r, const double* fs,
+                   const double* Rnew, int64_t sRn, double* mean_out, double* var_out, int* bad, hipStream_t);
+    void (*reduce_affine)(bool lti, bool rnd, const ModelView&, int L0, int64_t n0, const double* eps_t, double* E0, int* bad, hipStream_t);
+    void (*apply_affine)(bool lti, bool rnd, const ModelView&, int L0, int64_t n0, const double* S0, const double* eps_t,
+                         const double* eps_e, double* mean_out, double* var_out, int* bad, hipStream_t);
+    // block scans: bs == 256 (intermediate levels) or 512 (single top block)
+    void (*scan_reduce)(int monoid, const double* Ein, int64_t n, double* Ehi, int64_t nhi, hipStream_t);
+    void (*scan_apply)(int monoid, int bs, const double* Ein, int64_t n, const double* carry, int64_t ncarry, double* S, double* fin,
+                       hipStream_t);
+};
+
+const KernelTable* kernel_table(int d);
+
+}  // namespace tgp

@@ -1,0 +1,302 @@
+"""Host-side mirror of the reference's LGSSM interface, dispatching every T-step algorithm to the HIP
+engine (libtgp_hip.so). Same names, argument meaning and error behaviour as
+
+    /root/reference/src/models/lgssm.jl                 LGSSM, rand, marginals, logpdf, _filter, posterior
+    /root/reference/src/models/gauss_markov_model.jl    Forward, Reverse, GaussMarkovModel
+    /root/reference/src/models/linear_gaussian_conditionals.jl:225-257   ScalarOutputLGC
+    /root/reference/src/models/missings.jl              missing handling, replace_observation_noise_cov
+    /root/reference/src/util/gaussian.jl                Gaussian
+
+Arrays follow NumPy conventions (A[t] is the d x d matrix, row-major); a leading dimension of 1 is a
+FillArrays.Fill (one block shared by all steps -- what RegularSpacing inputs produce). Arrays may be
+NumPy (host; copied to the device per call) or torch CUDA tensors (used in place, results stay on the
+device). Missing observations are NaN entries of y (Julia: `missing`).
+There is no CPU implementation here: without the built library and a GPU every call raises.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+__all__ = ["Forward", "Reverse", "Gaussian", "GaussMarkovModel", "ScalarOutputLGC", "LGSSM", "logpdf", "_filter",
+           "posterior", "marginals", "rand", "replace_observation_noise_cov", "posterior_marginals", "ε_randn"]
+
+
+class _Ordering:
+    def __init__(self, name, code):
+        self.name, self.code = name, code
+
+    def __repr__(self):
+        return self.name + "()"
+
+
+Forward = _Ordering("Forward", 0)
+Reverse = _Ordering("Reverse", 1)
+
+
+def reverse(ordering):
+    return Reverse if ordering is Forward else Forward
+
+
+class Gaussian:
+    """util/gaussian.jl:16-31."""
+
+    def __init__(self, m, P):
+        self.m, self.P = m, P
+
+    def __repr__(self):
+        return f"Gaussian(m={self.m}, P={self.P})"
+
+
+def _is_torch(x):
+    return hasattr(x, "data_ptr")
+
+
+def _lead(x):
+    return int(x.shape[0])
+
+
+class GaussMarkovModel:
+    """x[t] = A[t] x[t-1] + a[t] + eps[t], eps[t] ~ N(0, Q[t])  (gauss_markov_model.jl:20-32)."""
+
+    def __init__(self, ordering, As, as_, Qs, x0):
+        self.ordering, self.As, self.as_, self.Qs, self.x0 = ordering, As, as_, Qs, x0
+
+    def __len__(self):
+        return max(_lead(self.As), _lead(self.as_), _lead(self.Qs))
+
+    @property
+    def dim(self):
+        return int(self.As.shape[-1])
+
+
+class ScalarOutputLGC:
+    """StructArray of scalar-output emissions y | x ~ N(H'x + h, R) (lgc.jl:225-243): H (T|1, d), h (T|1,), R (T|1,)."""
+
+    def __init__(self, H, h, R):
+        self.H, self.h, self.R = H, h, R
+
+
+class LGSSM:
+    """lgssm.jl:9-12. `T` must be given when every array is a Fill."""
+
+    def __init__(self, transitions, emissions, T=None, device=0):
+        self.transitions, self.emissions = transitions, emissions
+        n = max(len(transitions), _lead(emissions.H), _lead(emissions.h), _lead(emissions.R))
+        self.T = int(T) if T is not None else n
+        if n > 1 and n != self.T:
+            raise ValueError(f"inconsistent lengths: arrays have {n} steps, T={self.T}")
+        self.device = device
+        self._handle = None
+        self._keep = None
+
+    def __len__(self):
+        return self.T
+
+    @property
+    def ordering(self):
+        return self.transitions.ordering
+
+    @property
+    def x0(self):
+        return self.transitions.x0
+
+    @property
+    def dim(self):
+        return self.transitions.dim
+
+    # ---------------------------------------------------------------- device binding
+    def _blocks(self, x, per, transpose=False):
+        """-> (contiguous fp64 array in ABI layout, is_shared)."""
+        shared = _lead(x) == 1
+        if not shared and _lead(x) != self.T:
+            raise ValueError(f"array has {_lead(x)} steps, expected 1 or {self.T}")
+        if _is_torch(x):
+            import torch
+            t = x.to(torch.float64)
+            if transpose:
+                t = t.transpose(-1, -2)
+            return t.contiguous(), shared
+        a = np.asarray(x, dtype=np.float64)
+        if transpose:
+            a = np.swapaxes(a, -1, -2)
+        return np.ascontiguousarray(a), shared
+
+    def handle(self):
+        """Create the device handle and upload / bind the model on first use."""
+        if self._handle is not None:
+            return self._handle
+        tr, em = self.transitions, self.emissions
+        d = self.dim
+        A, sA = self._blocks(tr.As, d * d, transpose=True)   # column-major blocks == row-major of A'
+        a, sa = self._blocks(tr.as_, d)
+        Q, sQ = self._blocks(tr.Qs, d * d, transpose=True)
+        H, sH = self._blocks(em.H, d)
+        h, sh = self._blocks(em.h, 1)
+        R, sR = self._blocks(em.R, 1)
+        arrs = (A, a, Q, H, h, R)
+        on_dev = [_lib.is_device(x) for x in arrs]
+        if any(on_dev) and not all(on_dev):
+            raise ValueError("model arrays must be all NumPy or all CUDA tensors")
+        flags = 0
+        for bit, s in zip((_lib.SHARED_A, _lib.SHARED_a, _lib.SHARED_Q, _lib.SHARED_H, _lib.SHARED_h, _lib.SHARED_R),
+                          (sA, sa, sQ, sH, sh, sR)):
+            flags |= bit if s else 0
+        if all(on_dev):
+            flags |= _lib.DEVICE_PTRS
+        hd = _lib.Handle(self.device)
+        x0m = np.ascontiguousarray(np.asarray(_to_numpy(self.x0.m), dtype=np.float64))
+        x0P = np.ascontiguousarray(np.asarray(_to_numpy(self.x0.P), dtype=np.float64).T)
+        hd.check(hd.lib.tgp_model_set(hd.h, self.T, d, 1, self.ordering.code, flags, _lib.ptr(A), _lib.ptr(a), _lib.ptr(Q),
+                                      _lib.ptr(H), _lib.ptr(h), _lib.ptr(R), _lib.ptr(x0m), _lib.ptr(x0P)))
+        self._keep = arrs            # borrowed device pointers must outlive the handle
+        self._handle = hd
+        self._on_device = all(on_dev)
+        return hd
+
+
+def _to_numpy(x):
+    if _is_torch(x):
+        return x.detach().cpu().numpy()
+    return np.asarray(x)
+
+
+def _check_inputs(model, y):
+    """lgssm.jl:202-208."""
+    if len(model) != len(y):
+        raise ValueError(f"Dimension mismatch. length(prior) is {len(model)}, but length(y) is {len(y)}")
+
+
+def _obs(y):
+    """-> (y contiguous fp64, missing mask or None, in_device). NaN == missing (host arrays only;
+    for CUDA tensors pass a (y, mask) tuple)."""
+    mask = None
+    if isinstance(y, tuple):
+        y, mask = y
+    if _is_torch(y) and y.is_cuda:
+        import torch
+        yy = y.to(torch.float64).contiguous()
+        mm = None if mask is None else mask.to(torch.uint8).contiguous()
+        return yy, mm, True
+    if isinstance(y, np.ma.MaskedArray):
+        mask = np.ma.getmaskarray(y) if mask is None else mask
+        y = y.filled(0.0)
+    yy = np.ascontiguousarray(_to_numpy(y), dtype=np.float64)
+    if mask is None and np.isnan(yy).any():
+        mask = np.isnan(yy)
+    mm = None if mask is None else np.ascontiguousarray(_to_numpy(mask).astype(np.uint8))
+    return yy, mm, False
+
+
+def _out(model, shape, like_device):
+    if like_device:
+        import torch
+        return torch.empty(shape, dtype=torch.float64, device=f"cuda:{model.device}")
+    return np.empty(shape, dtype=np.float64)
+
+
+def logpdf(model, y):
+    """lgssm.jl:147-151 (+ missings.jl:8-13)."""
+    _check_inputs(model, y[0] if isinstance(y, tuple) else y)
+    hd = model.handle()
+    yy, mm, dev = _obs(y)
+    out = ctypes.c_double()
+    hd.check(hd.lib.tgp_logpdf(hd.h, _lib.ptr(yy), _lib.ptr(mm), _lib.IN_DEVICE if dev else 0, ctypes.byref(out)))
+    return out.value
+
+
+def _filter(model, y):
+    """lgssm.jl:171-173: filtering distributions, returned as (means (T,d), covs (T,d,d))."""
+    _check_inputs(model, y[0] if isinstance(y, tuple) else y)
+    hd = model.handle()
+    yy, mm, dev = _obs(y)
+    T, d = model.T, model.dim
+    m, P = _out(model, (T, d), dev), _out(model, (T, d, d), dev)
+    flags = (_lib.IN_DEVICE | _lib.OUT_DEVICE) if dev else 0
+    hd.check(hd.lib.tgp_filter(hd.h, _lib.ptr(yy), _lib.ptr(mm), flags, _lib.ptr(m), _lib.ptr(P), None))
+    return m, P   # P blocks are symmetric, so the column-major blocks read correctly as row-major
+
+
+def posterior(model, y):
+    """lgssm.jl:193-200: the posterior LGSSM (opposite ordering, transitions (G, g, L), x0 = final filtering state)."""
+    _check_inputs(model, y[0] if isinstance(y, tuple) else y)
+    hd = model.handle()
+    yy, mm, dev = _obs(y)
+    T, d = model.T, model.dim
+    G, g, L = _out(model, (T, d, d), dev), _out(model, (T, d), dev), _out(model, (T, d, d), dev)
+    xfm, xfP = np.empty(d), np.empty((d, d))
+    flags = (_lib.IN_DEVICE | _lib.OUT_DEVICE) if dev else 0
+    hd.check(hd.lib.tgp_posterior(hd.h, _lib.ptr(yy), _lib.ptr(mm), flags, _lib.ptr(G), _lib.ptr(g), _lib.ptr(L),
+                                  _lib.ptr(xfm), _lib.ptr(xfP)))
+    Gm = G.transpose(-1, -2) if dev else np.swapaxes(G, -1, -2)     # column-major blocks -> G[t][i, j]
+    trans = GaussMarkovModel(reverse(model.ordering), Gm, g, L, Gaussian(xfm, xfP.T.copy()))
+    return LGSSM(trans, model.emissions, T=T, device=model.device)
+
+
+def replace_observation_noise_cov(model, R_new):
+    """missings.jl:35-41."""
+    em = model.emissions
+    R = R_new if _is_torch(R_new) else np.atleast_1d(np.asarray(R_new, dtype=np.float64))
+    return LGSSM(model.transitions, ScalarOutputLGC(em.H, em.h, R), T=model.T, device=model.device)
+
+
+def marginals(model):
+    """lgssm.jl:99-115: emission marginals of the model as given, returned as (mean (T,), var (T,))."""
+    hd = model.handle()
+    dev = model._on_device
+    mean, var = _out(model, (model.T,), dev), _out(model, (model.T,), dev)
+    hd.check(hd.lib.tgp_marginals(hd.h, _lib.OUT_DEVICE if dev else 0, _lib.ptr(mean), _lib.ptr(var)))
+    return mean, var
+
+
+def posterior_marginals(model, y, R_new):
+    """marginals(replace_observation_noise_cov(posterior(model, y), R_new)) without materialising the
+    posterior model -- the `marginals(posterior(fx, y)(x))` path (posterior_lti_sde.jl:27-36)."""
+    _check_inputs(model, y[0] if isinstance(y, tuple) else y)
+    hd = model.handle()
+    yy, mm, dev = _obs(y)
+    flags = (_lib.IN_DEVICE | _lib.OUT_DEVICE) if dev else 0
+    if dev and _is_torch(R_new):
+        Rn = R_new.contiguous()
+    elif dev:
+        import torch
+        Rn = torch.as_tensor(np.atleast_1d(np.asarray(R_new, dtype=np.float64)), device=yy.device)
+    else:
+        Rn = np.ascontiguousarray(np.atleast_1d(_to_numpy(R_new)), dtype=np.float64)
+    if Rn.shape[0] == 1:
+        flags |= _lib.SHARED_R
+    elif Rn.shape[0] != model.T:
+        raise ValueError("R_new must have length 1 or T")
+    mean, var = _out(model, (model.T,), dev), _out(model, (model.T,), dev)
+    hd.check(hd.lib.tgp_posterior_marginals(hd.h, _lib.ptr(yy), _lib.ptr(mm), _lib.ptr(Rn), flags, _lib.ptr(mean),
+                                            _lib.ptr(var), None))
+    return mean, var
+
+
+def ε_randn(rng, model):
+    """lgssm.jl:72-77: all the randomness one sample needs, drawn up front in the reference's order
+    (T transition vectors, then T emission scalars; x0's draw comes after, lgssm.jl:67)."""
+    T, d = model.T, model.dim
+    return rng.standard_normal((T, d)), rng.standard_normal(T)
+
+
+def rand(rng_or_eps, model):
+    """lgssm.jl:65-69. `rng_or_eps` is a numpy Generator, or the explicit (eps_t (T,d), eps_e (T,), eps_0 (d,))."""
+    if isinstance(rng_or_eps, tuple):
+        eps_t, eps_e, eps_0 = rng_or_eps
+    else:
+        eps_t, eps_e = ε_randn(rng_or_eps, model)
+        eps_0 = rng_or_eps.standard_normal(model.dim)
+    hd = model.handle()
+    dev = _lib.is_device(eps_t)
+    if dev:
+        et, ee = eps_t.contiguous(), eps_e.contiguous()
+    else:
+        et = np.ascontiguousarray(_to_numpy(eps_t), dtype=np.float64)
+        ee = np.ascontiguousarray(_to_numpy(eps_e), dtype=np.float64)
+    e0 = np.ascontiguousarray(_to_numpy(eps_0), dtype=np.float64)
+    y = _out(model, (model.T,), dev)
+    flags = (_lib.IN_DEVICE | _lib.OUT_DEVICE) if dev else 0
+    hd.check(hd.lib.tgp_rand(hd.h, _lib.ptr(et), _lib.ptr(ee), _lib.ptr(e0), flags, _lib.ptr(y)))
+    return y

@@ -1,0 +1,457 @@
+"""GP -> LTI SDE -> LGSSM: the host-side layer that feeds the device hot path, mirroring the API surface of
+
+    /root/reference/src/gp/lti_sde.jl            LTISDE, to_sde, FiniteLTISDE methods (marginals, mean_and_var, mean, var,
+                                                 rand, logpdf), build_lgssm, lgssm_components, kernel -> SDE tables
+    /root/reference/src/gp/posterior_lti_sde.jl  PosteriorLTISDE: marginals / mean_and_var / rand / logpdf of the posterior
+    /root/reference/src/util/regular_data.jl     RegularSpacing
+    /root/reference/src/util/storage_types.jl    StorageType tags -- HIPStorage is the new tag that selects this backend
+
+This layer is O(#distinct dt) host work for regular spacing (one matrix exponential) exactly as in the
+reference; every T-step recursion it triggers runs on the GPU through `lgssm.py` -> libtgp_hip.so.
+Kernels are small classes (KernelFunctions.jl names); `sigma2 * k`, `k1 + k2`, `k1 * k2` and
+`k.stretch(s)` (== k ∘ ScaleTransform(s)) build the algebra.
+"""
+import numpy as np
+from scipy.linalg import block_diag, expm
+from scipy.special import ive
+
+from . import lgssm as L
+
+
+# ------------------------------------------------------------------------------------------ storage tag / inputs
+class HIPStorage:
+    """StorageType tag selecting the MI355X backend (the seam of storage_types.jl:1-61)."""
+
+    def __init__(self, eltype=np.float64, device=0):
+        if np.dtype(eltype) != np.float64:
+            raise ValueError("the HIP backend computes in Float64")
+        self.eltype, self.device = np.float64, device
+
+
+class RegularSpacing:
+    """RegularSpacing(t0, dt, N) (regular_data.jl:8-22)."""
+
+    def __init__(self, t0, dt, N):
+        self.t0, self.dt, self.N = float(t0), float(dt), int(N)
+
+    def __len__(self):
+        return self.N
+
+    def __getitem__(self, n):
+        return self.t0 + n * self.dt
+
+    def step(self):
+        return self.dt
+
+    def collect(self):
+        return self.t0 + np.arange(self.N) * self.dt
+
+    def __eq__(self, other):
+        return isinstance(other, RegularSpacing) and (self.t0, self.dt, self.N) == (other.t0, other.dt, other.N)
+
+
+def _times(x):
+    return x.collect() if isinstance(x, RegularSpacing) else np.asarray(x, dtype=np.float64)
+
+
+def _same_inputs(x1, x2):
+    if isinstance(x1, RegularSpacing) and isinstance(x2, RegularSpacing):
+        return x1 == x2
+    a, b = _times(x1), _times(x2)
+    return a.shape == b.shape and np.array_equal(a, b)
+
+
+# ------------------------------------------------------------------------------------------ kernels
+class Kernel:
+    def __add__(self, other):
+        return KernelSum(*(self._terms(KernelSum) + other._terms(KernelSum)))
+
+    def __mul__(self, other):
+        if isinstance(other, Kernel):
+            return KernelProduct(*(self._terms(KernelProduct) + other._terms(KernelProduct)))
+        return ScaledKernel(float(other), self)
+
+    __rmul__ = __mul__
+
+    def _terms(self, cls):
+        return list(self.kernels) if isinstance(self, cls) else [self]
+
+    def stretch(self, s):
+        """k ∘ ScaleTransform(s)."""
+        return StretchedKernel(float(s), self)
+
+
+def _cm(n, vals):
+    return np.array(vals, dtype=np.float64).reshape(n, n, order="F")    # SMatrix{n,n}(column-major literals)
+
+
+class SimpleKernel(Kernel):
+    """to_sde -> (F, q, H); stationary_distribution -> (m, P)."""
+
+    def lgssm_components(self, t):
+        x0 = self.stationary_distribution()
+        A, a, Q, H, h = broadcast_components(self.to_sde(), x0, t)
+        return A, a, Q, H, h, x0
+
+
+class Matern12Kernel(SimpleKernel):      # lti_sde.jl:189-203
+    def to_sde(self):
+        return np.array([[-1.0]]), 2.0, np.array([1.0])
+
+    def stationary_distribution(self):
+        return np.zeros(1), np.array([[1.0]])
+
+
+class Matern32Kernel(SimpleKernel):      # lti_sde.jl:205-218
+    def to_sde(self):
+        lam = np.sqrt(3.0)
+        return _cm(2, [0, -3, 1, -2 * lam]), 4 * lam ** 3, np.array([1.0, 0.0])
+
+    def stationary_distribution(self):
+        return np.zeros(2), np.diag([1.0, 3.0])
+
+
+class Matern52Kernel(SimpleKernel):      # lti_sde.jl:222-235
+    def to_sde(self):
+        lam = np.sqrt(5.0)
+        return _cm(3, [0, 0, -lam ** 3, 1, 0, -3 * lam ** 2, 0, 1, -3 * lam]), 8 * lam ** 5 / 3, np.array([1.0, 0.0, 0.0])
+
+    def stationary_distribution(self):
+        kap = 5.0 / 3.0
+        return np.zeros(3), _cm(3, [1, 0, -kap, 0, kap, 0, -kap, 0, 25])
+
+
+class CosineKernel(SimpleKernel):        # lti_sde.jl:239-252
+    def to_sde(self):
+        return _cm(2, [0, 1, -1, 0]), 0.0, np.array([1.0, 0.0])
+
+    def stationary_distribution(self):
+        return np.zeros(2), np.eye(2)
+
+
+class ConstantKernel(SimpleKernel):      # lti_sde.jl:311-321
+    def __init__(self, c=1.0):
+        self.c = float(c)
+
+    def to_sde(self):
+        return np.array([[0.0]]), 0.0, np.array([1.0])
+
+    def stationary_distribution(self):
+        return np.zeros(1), np.array([[self.c]])
+
+
+class ApproxPeriodicKernel(SimpleKernel):  # lti_sde.jl:255-307 (sum of N cosine kernels; default N = 7)
+    def __init__(self, N=7, r=1.0):
+        self.N, self.r = int(N), float(r)
+
+    def to_sde(self):
+        F0, _, H0 = CosineKernel().to_sde()
+        return block_diag(*[2 * np.pi * i * F0 for i in range(self.N)]), 0.0, np.tile(H0, self.N)
+
+    def stationary_distribution(self):
+        l2 = 1.0 / (4.0 * self.r ** 2)
+        Ps = [(1 + (j != 1)) * ive(j - 1, l2) * np.eye(2) for j in range(1, self.N + 1)]   # besseli(j-1,l2)/exp(l2)
+        return np.zeros(2 * self.N), block_diag(*Ps)
+
+
+class ScaledKernel(Kernel):              # lti_sde.jl:324-346
+    def __init__(self, sigma2, kernel):
+        self.sigma2, self.kernel = sigma2, kernel
+
+    def to_sde(self):
+        F, q, H = self.kernel.to_sde()
+        return F, self.sigma2 * q, np.sqrt(self.sigma2) * H
+
+    def stationary_distribution(self):
+        return self.kernel.stationary_distribution()
+
+    def lgssm_components(self, t):
+        A, a, Q, H, h, x0 = self.kernel.lgssm_components(t)
+        sig = np.sqrt(self.sigma2)
+        return A, a, Q, sig * H, sig * h, x0
+
+
+class StretchedKernel(Kernel):           # lti_sde.jl:350-373
+    def __init__(self, s, kernel):
+        self.s, self.kernel = s, kernel
+
+    def to_sde(self):
+        F, q, H = self.kernel.to_sde()
+        return F * self.s, q, H
+
+    def stationary_distribution(self):
+        return self.kernel.stationary_distribution()
+
+    def lgssm_components(self, t):
+        if isinstance(t, RegularSpacing):
+            t2 = RegularSpacing(self.s * t.t0, self.s * t.dt, t.N)
+        else:
+            t2 = self.s * np.asarray(t, dtype=np.float64)
+        return self.kernel.lgssm_components(t2)
+
+
+class KernelProduct(Kernel):             # lti_sde.jl:377-400
+    def __init__(self, *kernels):
+        self.kernels = kernels
+
+    def lgssm_components(self, t):
+        sdes = [k.to_sde() for k in self.kernels]
+        x0s = [k.stationary_distribution() for k in self.kernels]
+        F, H, m0, P0 = sdes[0][0], sdes[0][2], x0s[0][0], x0s[0][1]
+        for (Fb, _, Hb), (mb, Pb) in zip(sdes[1:], x0s[1:]):
+            F = np.kron(F, np.eye(Fb.shape[0])) + np.kron(np.eye(F.shape[0]), Fb)
+            H, m0, P0 = np.kron(H, Hb), np.kron(m0, mb), np.kron(P0, Pb)
+        q = float(np.prod([s[1] for s in sdes]))
+        A, a, Q, Hs, hs = broadcast_components((F, q, H), (m0, P0), t)
+        return A, a, Q, Hs, hs, (m0, P0)
+
+
+class KernelSum(Kernel):                 # lti_sde.jl:404-445
+    def __init__(self, *kernels):
+        self.kernels = kernels
+
+    def lgssm_components(self, t):
+        parts = [k.lgssm_components(t) for k in self.kernels]
+        T = len(t)
+
+        def stack(idx, join):
+            n = max(p[idx].shape[0] for p in parts)
+            ex = [p[idx] if p[idx].shape[0] == n else np.repeat(p[idx], n, axis=0) for p in parts]
+            return np.stack([join([e[i] for e in ex]) for i in range(n)])
+        A = stack(0, lambda bs: block_diag(*bs))
+        Q = stack(2, lambda bs: block_diag(*bs))
+        a = stack(1, np.concatenate)
+        H = stack(3, np.concatenate)
+        h = stack(4, lambda bs: np.sum(bs))
+        m0 = np.concatenate([p[5][0] for p in parts])
+        P0 = block_diag(*[p[5][1] for p in parts])
+        assert A.shape[0] in (1, T)
+        return A, a, Q, H, h, (m0, P0)
+
+
+def broadcast_components(FqH, x0, t):
+    """lti_sde.jl:135-160: A = exp(F dt), Q = P - A P A'. Regular spacing -> one shared block (Fill);
+    irregular -> per-step blocks with dt_1 = 1 (t0 := t1 - 1, lti_sde.jl:139)."""
+    F, _, H = FqH
+    _, P0 = x0
+    P = np.triu(P0) + np.triu(P0, 1).T
+    d = F.shape[0]
+    if isinstance(t, RegularSpacing):
+        A = expm(F * t.dt)
+        return A[None], np.zeros((1, d)), (P - A @ P @ A.T)[None], np.array(H, dtype=np.float64)[None], np.zeros(1)
+    tt = np.asarray(t, dtype=np.float64)
+    dts = np.diff(np.concatenate([[tt[0] - 1.0], tt]))
+    uniq, inv = np.unique(dts, return_inverse=True)          # one exponential per distinct dt
+    Au = np.stack([expm(F * dt) for dt in uniq])
+    Qu = np.stack([P - Ai @ P @ Ai.T for Ai in Au])
+    return Au[inv], np.zeros((1, d)), Qu[inv], np.array(H, dtype=np.float64)[None], np.zeros(1)
+
+
+def to_kernel(spec):
+    """Nested-tuple spec (as used by the test-suite / bench) -> kernel object."""
+    if isinstance(spec, Kernel):
+        return spec
+    name = spec[0]
+    simple = {"matern12": Matern12Kernel, "matern32": Matern32Kernel, "matern52": Matern52Kernel, "cosine": CosineKernel}
+    if name in simple:
+        return simple[name]()
+    if name == "constant":
+        return ConstantKernel(spec[1])
+    if name == "approx_periodic":
+        return ApproxPeriodicKernel(spec[1], spec[2])
+    if name == "scaled":
+        return ScaledKernel(float(spec[1]), to_kernel(spec[2]))
+    if name == "stretched":
+        return StretchedKernel(float(spec[1]), to_kernel(spec[2]))
+    if name == "sum":
+        return KernelSum(*[to_kernel(s) for s in spec[1:]])
+    if name == "product":
+        return KernelProduct(*[to_kernel(s) for s in spec[1:]])
+    raise ValueError(name)
+
+
+# ------------------------------------------------------------------------------------------ mean functions / GP
+class ZeroMean:
+    def __call__(self, t):
+        return None
+
+
+class ConstMean:
+    def __init__(self, c):
+        self.c = float(c)
+
+    def __call__(self, t):
+        return np.full(len(t), self.c)
+
+
+class CustomMean:
+    def __init__(self, f):
+        self.f = f
+
+    def __call__(self, t):
+        return np.array([self.f(v) for v in _times(t)], dtype=np.float64)
+
+
+class GP:
+    def __init__(self, *args):
+        if len(args) == 1:
+            self.mean, self.kernel = ZeroMean(), args[0]
+        else:
+            m, self.kernel = args
+            self.mean = ConstMean(m) if np.isscalar(m) else m
+
+
+def build_lgssm(kernel, x, sigma2s, mean=None, device=0, force_per_step=False):
+    """lti_sde.jl:71-80 -> device LGSSM. `sigma2s`: scalar (Fill) or length-T array.
+    force_per_step replicates Fill blocks to per-step arrays (the general layout, for benchmarking it)."""
+    A, a, Q, H, h, (m0, P0) = kernel.lgssm_components(x)
+    T = len(x)
+    mv = None if mean is None else mean(x)
+    if mv is not None:
+        h = (h if h.shape[0] == T else np.repeat(h, T, axis=0)) + mv          # lti_sde.jl:118-131
+    R = np.atleast_1d(np.asarray(sigma2s, dtype=np.float64))
+    if force_per_step:
+        rep = lambda z: z if z.shape[0] == T else np.repeat(z, T, axis=0)
+        A, a, Q, H, h, R = rep(A), rep(a), rep(Q), rep(H), rep(h), rep(R)
+    trans = L.GaussMarkovModel(L.Forward, A, a, Q, L.Gaussian(np.asarray(m0, dtype=np.float64), np.asarray(P0, dtype=np.float64)))
+    return L.LGSSM(trans, L.ScalarOutputLGC(H, h, R), T=T, device=device)
+
+
+class LTISDE:
+    """lti_sde.jl:7-16."""
+
+    def __init__(self, f, storage):
+        self.f, self.storage = f, storage
+
+    def __call__(self, x, sigma2=1e-12):            # FiniteGP(f, x, 1e-12) default jitter: lti_sde.jl:27-29
+        return FiniteLTISDE(self, x, sigma2)
+
+
+def to_sde(f, storage=None):
+    return LTISDE(f, storage or HIPStorage())
+
+
+class FiniteLTISDE:
+    """FiniteGP{<:LTISDE}: the object logpdf / marginals / rand / posterior are called on."""
+
+    def __init__(self, f, x, sigma2):
+        self.f, self.x = f, x
+        s = np.atleast_1d(np.asarray(sigma2, dtype=np.float64))
+        if s.shape[0] not in (1, len(x)):
+            raise ValueError("noise variances must be a scalar or one per input")
+        self.sigma2 = s
+        self._model = None
+
+    def build_lgssm(self):
+        if self._model is None:
+            self._model = build_lgssm(self.f.f.kernel, self.x, self.sigma2, self.f.f.mean, self.f.storage.device)
+        return self._model
+
+
+def marginals(fx):
+    """-> (mean, std): the Normal marginals (lti_sde.jl:33-35 / posterior_lti_sde.jl:18-37, gaussian.jl:61-63)."""
+    m, v = mean_and_var(fx)
+    return m, np.sqrt(v)
+
+
+def mean_and_var(fx):
+    if isinstance(fx, FinitePosteriorLTISDE):
+        return fx._mean_and_var()
+    return L.marginals(fx.build_lgssm())
+
+
+def mean(fx):
+    return mean_and_var(fx)[0]
+
+
+def var(fx):
+    return mean_and_var(fx)[1]
+
+
+def logpdf(fx, y):
+    """lti_sde.jl:60-68 / posterior_lti_sde.jl:62-78. NaN entries of y are `missing`."""
+    if isinstance(fx, FinitePosteriorLTISDE):
+        return fx._logpdf(y)
+    return L.logpdf(fx.build_lgssm(), y)
+
+
+def rand(rng, fx, N=None):
+    """lti_sde.jl:48-58 / posterior_lti_sde.jl:48-58."""
+    if N is not None:
+        return np.stack([rand(rng, fx) for _ in range(N)], axis=1)
+    if isinstance(fx, FinitePosteriorLTISDE):
+        return fx._rand(rng)
+    return L.rand(rng, fx.build_lgssm())
+
+
+def posterior(fx, y):
+    """posterior_lti_sde.jl:7-10: lazy -- all the work happens in marginals / rand / logpdf of the result."""
+    return PosteriorLTISDE(fx.f, dict(y=np.asarray(y, dtype=np.float64), x=fx.x, sigma2=fx.sigma2))
+
+
+class PosteriorLTISDE:
+    def __init__(self, prior, data):
+        self.prior, self.data = prior, data
+
+    def __call__(self, x, sigma2=1e-18):            # AbstractGPs' FiniteGP default jitter for posterior queries
+        return FinitePosteriorLTISDE(self, x, sigma2)
+
+
+def _noise(s, n):
+    s = np.atleast_1d(np.asarray(s, dtype=np.float64))
+    return s if s.shape[0] == n else np.full(n, s[0])
+
+
+class FinitePosteriorLTISDE:
+    LARGE_VAR = 1e15                                 # missings.jl:43
+
+    def __init__(self, f, x, sigma2):
+        self.f, self.x = f, x
+        self.sigma2 = np.atleast_1d(np.asarray(sigma2, dtype=np.float64))
+
+    def _merge(self, sigma2_pr, y_pr_missing=True):
+        """merge_datasets (posterior_lti_sde.jl:97-123): join + sort training and prediction inputs."""
+        d = self.f.data
+        xt, xp = _times(d["x"]), _times(self.x)
+        ntr, npr = len(xt), len(xp)
+        x_raw = np.concatenate([xt, xp])
+        order = np.argsort(x_raw, kind="stable")
+        inv = np.argsort(order, kind="stable")
+        S = np.concatenate([_noise(d["sigma2"], ntr), sigma2_pr])[order]
+        y = np.concatenate([d["y"], np.full(npr, np.nan)])[order]
+        return x_raw[order], S, y, inv[:ntr], inv[ntr:]
+
+    def _posterior_model(self, x, S, y):
+        prior = self.f.prior
+        return build_lgssm(prior.f.kernel, x, S, prior.f.mean, prior.storage.device)
+
+    def _mean_and_var(self):
+        d = self.f.data
+        if _same_inputs(self.x, d["x"]):             # posterior_lti_sde.jl:27-36 -- the benchmarked path
+            model = self._posterior_model(d["x"], d["sigma2"], d["y"])
+            return L.posterior_marginals(model, d["y"], _noise(self.sigma2, len(self.x)) if len(self.sigma2) > 1 else self.sigma2)
+        npr = len(self.x)
+        x, S, y, _, pr = self._merge(np.full(npr, self.LARGE_VAR))
+        s_full = np.zeros(len(x))
+        s_full[pr] = _noise(self.sigma2, npr)        # build_prediction_obs_vars :136-144
+        m, v = L.posterior_marginals(self._posterior_model(x, S, y), y, s_full)
+        return m[pr], v[pr]
+
+    def _rand(self, rng):
+        npr = len(self.x)
+        x, S, y, _, pr = self._merge(np.full(npr, self.LARGE_VAR))
+        s_full = np.zeros(len(x))
+        s_full[pr] = _noise(self.sigma2, npr)
+        post = L.replace_observation_noise_cov(L.posterior(self._posterior_model(x, S, y), y), s_full)
+        return L.rand(rng, post)[pr]
+
+    def _logpdf(self, y_pr):
+        npr = len(self.x)
+        s_pr = _noise(self.sigma2, npr)
+        x, S, y, tr, pr = self._merge(s_pr)
+        s_full = np.zeros(len(x))
+        s_full[pr] = s_pr
+        post = L.replace_observation_noise_cov(L.posterior(self._posterior_model(x, S, y), y), s_full)
+        y_full = np.full(len(x), np.nan)             # build_prediction_obs :148-158: training points are missing
+        y_full[pr] = y_pr
+        return L.logpdf(post, y_full)

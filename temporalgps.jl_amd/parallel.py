@@ -1,0 +1,174 @@
+"""Time-sharding of one LGSSM across the GPUs of a node (not in the reference, whose
+scan is a single sequential loop, /root/reference/src/util/scan.jl:15-28).
+
+One process per GPU (torch.distributed; backend "nccl" == RCCL over xGMI, "gloo" in the CPU tests). Rank r
+owns the contiguous segment [r T/W, (r+1) T/W) of the series and an LGSSM over just that segment.
+
+  forward:   every rank reduces its segment to ONE filter element           (tgp_segment_reduce, local)
+             all_gather of the W elements (<= a few hundred bytes each)       -- the only forward exchange
+             rank r folds elements 0..r-1 onto the prior x0 -> its carry-in   (tgp_elem_apply, host, W-1 tiny ops)
+             local filter from the carry-in (reusing pass 1), all_reduce(sum) of one scalar for logpdf
+  backward:  every rank reduces its segment to ONE smoother element          (tgp_smoother_forward, local)
+             all_gather of the W elements + the last rank's final state       -- the only backward exchange
+             rank r folds elements W-1..r+1 onto x_T|T -> smoothed state at its segment end, then smooths locally
+
+No bulk data ever crosses xGMI: the exchange is latency-bound, outputs stay sharded.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from . import lgssm as L
+
+
+def segment_bounds(T, world, rank):
+    """Contiguous, balanced split of 0..T into `world` segments."""
+    base, rem = divmod(int(T), int(world))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class HIPEngine:
+    """The product engine: thin calls into libtgp_hip.so for one segment model."""
+
+    def __init__(self, model):
+        self.model, self.hd = model, model.handle()
+        self.d = model.dim
+
+    def _obs(self, y):
+        yy, mm, dev = L._obs(y)
+        return yy, mm, (_lib.IN_DEVICE if dev else 0), dev
+
+    def x0(self):
+        return np.asarray(L._to_numpy(self.model.x0.m), dtype=np.float64), np.asarray(L._to_numpy(self.model.x0.P), dtype=np.float64)
+
+    def elem_size(self, kind):
+        return self.hd.lib.tgp_elem_size(kind, self.d)
+
+    def segment_reduce(self, y):
+        yy, mm, fl, _ = self._obs(y)
+        out = np.empty(self.elem_size(0))
+        self.hd.check(self.hd.lib.tgp_segment_reduce(self.hd.h, _lib.ptr(yy), _lib.ptr(mm), fl, _lib.ptr(out)))
+        return out
+
+    def elem_apply(self, kind, elem, m, P):
+        mo, Po = np.empty(self.d), np.empty((self.d, self.d))
+        Pc = np.ascontiguousarray(np.asarray(P, dtype=np.float64).T)
+        e = np.ascontiguousarray(elem, dtype=np.float64)
+        mc = np.ascontiguousarray(m, dtype=np.float64)
+        rc = self.hd.lib.tgp_elem_apply(kind, self.d, _lib.ptr(e), _lib.ptr(mc), _lib.ptr(Pc), _lib.ptr(mo), _lib.ptr(Po))
+        if rc != 0:
+            raise _lib.TGPError(rc, "tgp_elem_apply")
+        return mo, Po.T.copy()
+
+    def set_x0(self, m, P):
+        mc = np.ascontiguousarray(m, dtype=np.float64)
+        Pc = np.ascontiguousarray(np.asarray(P, dtype=np.float64).T)
+        self.hd.check(self.hd.lib.tgp_model_set_x0(self.hd.h, _lib.ptr(mc), _lib.ptr(Pc)))
+
+    def logpdf(self, y, reuse):
+        yy, mm, fl, _ = self._obs(y)
+        out = ctypes.c_double()
+        self.hd.check(self.hd.lib.tgp_logpdf(self.hd.h, _lib.ptr(yy), _lib.ptr(mm), fl | (_lib.REUSE_REDUCE if reuse else 0),
+                                             ctypes.byref(out)))
+        return out.value
+
+    def smoother_forward(self, y, reuse):
+        yy, mm, fl, _ = self._obs(y)
+        rev = np.empty(self.elem_size(1))
+        xfm, xfP = np.empty(self.d), np.empty((self.d, self.d))
+        lml = ctypes.c_double()
+        self.hd.check(self.hd.lib.tgp_smoother_forward(self.hd.h, _lib.ptr(yy), _lib.ptr(mm), fl | (_lib.REUSE_REDUCE if reuse else 0),
+                                                       _lib.ptr(rev), _lib.ptr(xfm), _lib.ptr(xfP), ctypes.byref(lml)))
+        return rev, xfm, xfP.T.copy(), lml.value
+
+    def smoother_backward(self, xs, R_new, like):
+        dev = _lib.is_device(like)
+        T = self.model.T
+        mean, var = L._out(self.model, (T,), dev), L._out(self.model, (T,), dev)
+        if dev and not L._is_torch(R_new):
+            import torch
+            R_new = torch.as_tensor(np.atleast_1d(np.asarray(R_new, dtype=np.float64)), device=like.device)
+        Rn = R_new.contiguous() if L._is_torch(R_new) else np.ascontiguousarray(np.atleast_1d(R_new), dtype=np.float64)
+        flags = ((_lib.IN_DEVICE | _lib.OUT_DEVICE) if dev else 0) | (_lib.SHARED_R if Rn.shape[0] == 1 else 0)
+        if xs is None:
+            pm = pP = None
+        else:
+            pm = np.ascontiguousarray(xs[0], dtype=np.float64)
+            pP = np.ascontiguousarray(np.asarray(xs[1], dtype=np.float64).T)
+        self.hd.check(self.hd.lib.tgp_smoother_backward(self.hd.h, _lib.ptr(pm), _lib.ptr(pP), _lib.ptr(Rn), flags,
+                                                        _lib.ptr(mean), _lib.ptr(var)))
+        return mean, var
+
+
+class ShardedLGSSM:
+    """logpdf / posterior marginals of a series whose time axis is split across `world` ranks.
+    `model` is this rank's segment LGSSM (x0 = the GLOBAL prior on every rank). With world == 1 this is
+    exactly the single-GPU path. `engine` is injectable for the CPU (gloo) tests."""
+
+    def __init__(self, model, world=1, rank=0, engine=None, group=None):
+        self.model, self.world, self.rank, self.group = model, int(world), int(rank), group
+        self.engine = engine if engine is not None else (HIPEngine(model) if self.world > 1 else None)
+
+    # -- collectives on tiny host vectors (the payload is a few hundred bytes; latency-bound)
+    def _all_gather(self, vec):
+        import torch
+        import torch.distributed as dist
+        dev = "cuda" if dist.get_backend(self.group) == "nccl" else "cpu"
+        t = torch.as_tensor(np.ascontiguousarray(vec), dtype=torch.float64).to(dev)
+        out = [torch.empty_like(t) for _ in range(self.world)]
+        dist.all_gather(out, t, group=self.group)
+        return [o.cpu().numpy() for o in out]
+
+    def _all_reduce_sum(self, x):
+        import torch
+        import torch.distributed as dist
+        dev = "cuda" if dist.get_backend(self.group) == "nccl" else "cpu"
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return float(t.item())
+
+    def _forward_exchange(self, y):
+        """Pass 1 + exchange: sets this segment's carry-in state. Always recomputed (no caching across API
+        calls: each logpdf / posterior_marginals call does its full work, like the reference's); the True it
+        returns lets the SAME call reuse the pass-1 elements it has just produced."""
+        e = self.engine
+        elems = self._all_gather(e.segment_reduce(y))
+        m, P = self._x0
+        for r in range(self.rank):
+            m, P = e.elem_apply(0, elems[r], m, P)
+        e.set_x0(m, P)
+        return True
+
+    def logpdf(self, y):
+        if self.world == 1:
+            return L.logpdf(self.model, y)
+        if not hasattr(self, "_x0"):
+            self._x0 = self.engine.x0()
+        reuse = self._forward_exchange(y)
+        return self._all_reduce_sum(self.engine.logpdf(y, reuse))
+
+    def posterior_marginals(self, y, R_new):
+        """This rank's slice of marginals(posterior(fx, y)(x)); R_new is the slice's new noise (or a scalar)."""
+        if self.world == 1:
+            return L.posterior_marginals(self.model, y, R_new)
+        if not hasattr(self, "_x0"):
+            self._x0 = self.engine.x0()
+        e = self.engine
+        reuse = self._forward_exchange(y)
+        rev, xfm, xfP, _ = e.smoother_forward(y, reuse)
+        d = e.d
+        packed = np.concatenate([rev, xfm, np.asarray(xfP).reshape(-1)])
+        allp = self._all_gather(packed)
+        nrev = len(rev)
+        if self.rank == self.world - 1:
+            xs = None
+        else:
+            last = allp[self.world - 1]
+            m, P = last[nrev:nrev + d], last[nrev + d:].reshape(d, d)
+            for r in range(self.world - 1, self.rank, -1):
+                m, P = e.elem_apply(1, allp[r][:nrev], m, P)
+            xs = (m, P)
+        y_arr = y[0] if isinstance(y, tuple) else y
+        return e.smoother_backward(xs, R_new, y_arr)

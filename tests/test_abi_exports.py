@@ -1,0 +1,63 @@
+"""CPU tier: the C-ABI library loads and exports every symbol include/tgp_hip.h declares (no compute)."""
+import os
+import re
+
+import pytest
+
+from tests._util import ROOT
+
+
+def test_library_exports_every_declared_symbol():
+    so = os.path.join(ROOT, "temporalgps.jl_amd", "libtgp_hip.so")
+    if not os.path.exists(so):
+        import __graft_entry__ as g
+        g.build()
+    import temporalgps_jl_amd as tgp
+    lib = tgp._lib.load()
+    header = open(os.path.join(ROOT, "include", "tgp_hip.h")).read()
+    declared = set(re.findall(r"\b(tgp_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/tgp_hip.h but not exported"
+    assert declared == set(tgp._lib.EXPORTS), declared ^ set(tgp._lib.EXPORTS)
+
+
+def test_host_side_monoid_ops_match_definition():
+    """tgp_elem_apply / tgp_elem_combine are pure host functions of the ABI (no GPU needed)."""
+    import ctypes
+    import numpy as np
+    import temporalgps_jl_amd as tgp
+    lib = tgp._lib.load()
+    d = 3
+    n = lib.tgp_elem_size(1, d)
+    assert n == d * d + d + d * (d + 1) // 2 and lib.tgp_elem_size(0, d) == d * d + 2 * d + d * (d + 1)
+    rng = np.random.default_rng(0)
+
+    def pack_affine(E, g, L):
+        return np.concatenate([E.T.reshape(-1), g, np.array([L[i, j] for j in range(d) for i in range(j + 1)])])
+
+    def sym(n_):
+        X = rng.standard_normal((n_, n_))
+        return X @ X.T
+    E1, g1, L1, E2, g2, L2 = rng.standard_normal((d, d)), rng.standard_normal(d), sym(d), rng.standard_normal((d, d)), rng.standard_normal(d), sym(d)
+    out = np.zeros(n)
+    p = lambda a: a.ctypes.data
+    e1, e2 = pack_affine(E1, g1, L1), pack_affine(E2, g2, L2)
+    assert lib.tgp_elem_combine(1, d, p(e1), p(e2), p(out)) == 0
+    want = pack_affine(E2 @ E1, E2 @ g1 + g2, E2 @ L1 @ E2.T + L2)
+    np.testing.assert_allclose(out, want, rtol=1e-12, atol=1e-12)
+    m, P = rng.standard_normal(d), sym(d)
+    mo, Po = np.zeros(d), np.zeros((d, d))
+    Pc = np.ascontiguousarray(P.T)
+    assert lib.tgp_elem_apply(1, d, p(e1), p(m), p(Pc), p(mo), p(Po)) == 0
+    np.testing.assert_allclose(mo, E1 @ m + g1, rtol=1e-12)
+    np.testing.assert_allclose(Po.T, E1 @ P @ E1.T + L1, rtol=1e-12)
+
+
+def test_product_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import temporalgps_jl_amd as tgp
+    with pytest.raises(tgp._lib.TGPError):
+        tgp._lib.Handle(0)

@@ -1,0 +1,186 @@
+"""GPU tier (-m gpu): the HIP path, called through the C ABI (ctypes -> libtgp_hip.so), against the oracle
+on the same seeded inputs. Tolerances (fp64, north_star "stated fp64 tolerance"):
+   logpdf            rel 1e-10 vs the sequential restatement
+   filter / posterior states, marginals   abs/rel 1e-8 (the reference's 1e-10 jitter in invert_dynamics
+                                          is visible at ~1e-10)
+   rand              rel 1e-9 given identical noise
+"""
+import numpy as np
+import pytest
+
+from oracle import components as oc
+from oracle import lgssm_ref as ref
+from oracle import seq_kalman as sk
+from tests import _util as U
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tgp():
+    import temporalgps_jl_amd as t
+    t._lib.load()
+    return t
+
+
+def to_device_model(tgp, model):
+    assert model["kind"] == "scalar"
+    tr = tgp.GaussMarkovModel(tgp.Forward if model["ordering"] == "F" else tgp.Reverse, model["A"], model["a"], model["Q"],
+                              tgp.Gaussian(model["x0m"], model["x0P"]))
+    return tgp.LGSSM(tr, tgp.ScalarOutputLGC(model["H"], np.atleast_1d(model["h"]), np.atleast_1d(model["R"])), T=model["T"])
+
+
+def check_all(tgp, model, y, eps, chunk=None, missing=None):
+    dm = to_device_model(tgp, model)
+    if chunk is not None:
+        dm.handle().set_option(tgp._lib.OPT_CHUNK, chunk)
+    T = model["T"]
+    yin = y.copy()
+    if missing is not None:
+        yin[missing] = np.nan
+        lp = ref.logpdf_missing(model, y, missing)
+        fm, fP = ref.filter_missing(model, y, missing)
+        post = ref.posterior_missing(model, y, missing)
+    else:
+        lp = ref.logpdf(model, y)
+        fm, fP = ref.filter_(model, y)
+        post = ref.posterior(model, y) if model["ordering"] == "F" else None
+    got = tgp.logpdf(dm, yin)
+    assert abs(got - lp) <= 1e-10 * abs(lp), (got, lp)
+    m, P = tgp._filter(dm, yin)
+    np.testing.assert_allclose(m, fm, rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(P, fP, rtol=1e-8, atol=1e-9)
+    if post is not None:
+        dpost = tgp.posterior(dm, yin)
+        assert dpost.ordering is tgp.Reverse
+        np.testing.assert_allclose(dpost.transitions.As, post["A"], rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(dpost.transitions.as_, post["a"], rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(dpost.transitions.Qs, post["Q"], rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(dpost.x0.m, post["x0m"], rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(dpost.x0.P, post["x0P"], rtol=1e-8, atol=1e-9)
+        Rn = np.random.default_rng(5).random(T) * 0.1
+        pm, pv = ref.marginals(ref.replace_observation_noise_cov(post, Rn))
+        gm, gv = tgp.posterior_marginals(dm, yin, Rn)
+        np.testing.assert_allclose(gm, pm, rtol=1e-8, atol=1e-8)
+        np.testing.assert_allclose(gv, pv, rtol=1e-8, atol=1e-9)
+        # marginals of the MATERIALISED posterior model (Reverse ordering, per-step G, g, L)
+        gm2, gv2 = tgp.marginals(tgp.replace_observation_noise_cov(dpost, Rn))
+        np.testing.assert_allclose(gm2, pm, rtol=1e-8, atol=1e-8)
+        np.testing.assert_allclose(gv2, pv, rtol=1e-8, atol=1e-9)
+    mm, mv = ref.marginals(model)
+    gm, gv = tgp.marginals(dm)
+    np.testing.assert_allclose(gm, mm, rtol=1e-10, atol=1e-11)
+    np.testing.assert_allclose(gv, mv, rtol=1e-10, atol=1e-11)
+    if eps is not None:
+        ys = tgp.rand(eps, dm)
+        np.testing.assert_allclose(ys, ref.rand(model, *eps), rtol=1e-9, atol=1e-9)
+
+
+GP_CASES = [
+    (("matern12",), ("regular", 0.0, 0.1, 997), 0.1),
+    (("matern32",), ("regular", 0.0, 0.1, 1000), 0.1),               # cfg1-like (T reduced for the Python oracle)
+    (("matern52",), ("regular", 0.0, 0.1, 1333), 0.1),
+    (("sum", ("matern52",), ("matern32",)), ("regular", 0.0, 0.1, 500), 0.1),
+    (("sum", ("matern52",), ("matern52",)), ("regular", 0.0, 0.05, 400), 0.2),
+    (("sum", ("matern52",), ("matern12",)), ("regular", 0.0, 0.05, 400), 0.2),
+    (("scaled", 1.0, ("stretched", 1 / 2.3, ("matern52",))), ("regular", -5.0, 1e-2, 2000), 0.5),   # bench/single_output_gps.jl
+]
+
+
+@pytest.mark.parametrize("i", range(len(GP_CASES)))
+@pytest.mark.parametrize("chunk", [None, 1, 3])
+def test_gp_regular_spacing(tgp, i, chunk):
+    k, t, s2 = GP_CASES[i]
+    model, y, eps = U.gp_case(k, t, s2, seed=i)
+    check_all(tgp, model, y, eps, chunk=chunk)
+
+
+def test_gp_irregular_heteroscedastic(tgp):
+    rng = np.random.default_rng(42)
+    t = np.cumsum(rng.random(800) * 0.1 + 0.05)
+    model, y, eps = U.gp_case(("scaled", 1.5, ("stretched", 0.7, ("matern52",))), t, rng.random(800) * 0.2 + 0.05, seed=9,
+                              mean=("const", 3.0))
+    check_all(tgp, model, y, eps)
+
+
+@pytest.mark.parametrize("d", [1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("tv", [True, False])
+def test_random_lgssm(tgp, d, tv):
+    rng = np.random.default_rng(10 * d + tv)
+    T = 300
+    model = U.random_lgssm(rng, tv, d, T)
+    eps = (rng.standard_normal((T, d)), rng.standard_normal(T), rng.standard_normal(d))
+    check_all(tgp, model, ref.rand(model, *eps), eps, chunk=2)
+
+
+@pytest.mark.parametrize("tv", [True, False])
+def test_missing(tgp, tv):
+    rng = np.random.default_rng(3)
+    T, d = 700, 3
+    model = U.random_lgssm(rng, tv, d, T)
+    y = rng.standard_normal(T)
+    check_all(tgp, model, y, None, missing=rng.random(T) < 0.3)
+
+
+@pytest.mark.parametrize("tv", [True, False])
+def test_reverse_ordering(tgp, tv):
+    rng = np.random.default_rng(11)
+    T, d = 400, 3
+    model = U.random_lgssm(rng, tv, d, T, ordering="R")
+    eps = (rng.standard_normal((T, d)), rng.standard_normal(T), rng.standard_normal(d))
+    check_all(tgp, model, ref.rand(model, *eps), eps)
+
+
+def test_errors(tgp):
+    rng = np.random.default_rng(0)
+    model = U.random_lgssm(rng, False, 2, 10)
+    dm = to_device_model(tgp, model)
+    with pytest.raises(ValueError, match="Dimension mismatch"):       # lgssm.jl:202-208
+        tgp.logpdf(dm, np.zeros(11))
+    with pytest.raises(ValueError, match="Dimension mismatch"):
+        tgp.posterior(dm, np.zeros(9))
+    bad = dict(model, R=np.array([-10.0]))                            # S <= 0: Julia throws DomainError (sqrt)
+    with pytest.raises(tgp._lib.NotPositiveDefinite):
+        tgp.logpdf(to_device_model(tgp, bad), rng.standard_normal(10))
+    rev = dict(model, ordering="R")
+    with pytest.raises(tgp._lib.TGPError):                            # documented as unsupported
+        tgp.posterior(to_device_model(tgp, rev), np.zeros(10))
+
+
+@pytest.mark.parametrize("kname,T", [("matern32", 1_000_000), ("matern52", 1_000_000)])
+def test_large_T_vs_c_oracle(tgp, kname, T):
+    """Multi-level scans at scale, against the C restatement (same inputs)."""
+    model = oc.build_lgssm((kname,), ("regular", 0.0, 0.1, T), 0.1)
+    d = len(model["x0m"])
+    rng = np.random.default_rng(2)
+    eps = (rng.standard_normal((T, d)), rng.standard_normal(T), rng.standard_normal(d))
+    y = sk.rand(model, *eps)
+    dm = to_device_model(tgp, model)
+    lp_ref = sk.logpdf(model, y)
+    for chunk in (None, 2):
+        dm.handle().set_option(tgp._lib.OPT_CHUNK, chunk or 0)
+        lp = tgp.logpdf(dm, y)
+        assert abs(lp - lp_ref) <= 1e-10 * abs(lp_ref), (chunk, lp, lp_ref)
+        assert tgp.logpdf(dm, y) == lp       # fixed-order reductions: bit-reproducible
+    mean_ref, var_ref = sk.posterior_marginals(model, y, np.array([1e-18]))
+    mean, var = tgp.posterior_marginals(dm, y, np.array([1e-18]))
+    assert np.max(np.abs(mean - mean_ref)) <= 1e-8
+    assert np.max(np.abs(var - var_ref)) <= 1e-8
+    np.testing.assert_allclose(tgp.rand(eps, dm), y, rtol=1e-9, atol=1e-9)
+
+
+def test_device_resident_inputs(tgp):
+    """torch CUDA tensors are used in place (no host copies) and results stay on the device."""
+    import torch
+    T = 50_000
+    model = oc.build_lgssm(("matern52",), ("regular", 0.0, 0.1, T), 0.1)
+    rng = np.random.default_rng(4)
+    y = sk.rand(model, rng.standard_normal((T, 3)), rng.standard_normal(T), rng.standard_normal(3))
+    dm = to_device_model(tgp, model)
+    yd = torch.as_tensor(y, device="cuda:0")
+    lp = tgp.logpdf(dm, yd)
+    assert abs(lp - sk.logpdf(model, y)) <= 1e-10 * abs(lp)
+    mean, var = tgp.posterior_marginals(dm, yd, np.array([0.0]))
+    assert mean.is_cuda and var.is_cuda
+    mr, vr = sk.posterior_marginals(model, y, np.array([0.0]))
+    assert np.max(np.abs(mean.cpu().numpy() - mr)) <= 1e-8 and np.max(np.abs(var.cpu().numpy() - vr)) <= 1e-8
