@@ -74,6 +74,16 @@ def load():
             raise RuntimeError(
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(make -C temporalgps.jl_amd/csrc). There is no CPU fallback.")
+        # PyTorch ships its own copy of the HIP runtime (same soname). If libtgp_hip.so pulled in the system
+        # copy first, a later torch.cuda initialisation in the same process finds "No HIP GPUs"; so let
+        # torch's runtime load and initialise first whenever torch is present (torch is only plumbing here:
+        # device tensors, streams, torch.distributed).
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except ImportError:
+            pass
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in _SIGS.items():
             fn = getattr(lib, name)

@@ -80,7 +80,8 @@ def _p(x):
     return None if x is None else x.ctypes.data_as(_dp)
 
 
-def hostsim_run(model, what, y=None, missing=None, L0=4, BS=3, Rnew=None, eps=None, want_ggl=False):
+def hostsim_run(model, what, y=None, missing=None, L0=4, BS=3, Rnew=None, eps=None, want_ggl=False, want_elem=False,
+                want_rev=False, xs=None):
     pk = pack(model)
     d, T = pk["d"], pk["T"]
     out = {}
@@ -107,13 +108,19 @@ def hostsim_run(model, what, y=None, missing=None, L0=4, BS=3, Rnew=None, eps=No
         ee = np.ascontiguousarray(eps[1], dtype=np.float64)
         x0m = ref.rand_x0(eps[2], model["x0m"], model["x0P"])
         x0P = np.zeros(d * d)
+    d_ = pk["d"]
+    elem = np.zeros(d_ * d_ + 2 * d_ + d_ * (d_ + 1)) if want_elem else None
+    rev = np.zeros(d_ * d_ + d_ + d_ * (d_ + 1) // 2) if want_rev else None
+    xs_m = None if xs is None else np.ascontiguousarray(xs[0], dtype=np.float64)
+    xs_P = None if xs is None else np.ascontiguousarray(np.asarray(xs[1]).T, dtype=np.float64)
     rc = hostsim().hostsim_run(
         d, int(is_lti(pk)), what, L0, BS, _i64(T), pk["ordering"], _p(pk["A"]), _i64(pk["sA"]), _p(pk["a"]), _i64(pk["sa"]),
         _p(pk["Q"]), _i64(pk["sQ"]), _p(pk["H"]), _i64(pk["sH"]), _p(pk["h"]), _i64(pk["sh"]), _p(pk["R"]), _i64(pk["sR"]),
         _p(yv), None if miss is None else miss.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)),
         _p(x0m), _p(x0P), ctypes.byref(lml), _p(m_out), _p(P_out), _p(G), _p(g), _p(L), _p(xfm), _p(xfP),
-        _p(Rn), _i64(0 if Rn is None or Rn.shape[0] == 1 else 1), _p(mean), _p(var), _p(et), _p(ee))
+        _p(Rn), _i64(0 if Rn is None or Rn.shape[0] == 1 else 1), _p(mean), _p(var), _p(et), _p(ee),
+        _p(elem), _p(rev), _p(xs_m), _p(xs_P))
     out.update(rc=rc, lml=lml.value, m=m_out, P=None if P_out is None else np.swapaxes(P_out, -1, -2),
                G=None if G is None else np.swapaxes(G, -1, -2), g=g, L=None if L is None else np.swapaxes(L, -1, -2),
-               xfm=xfm, xfP=None if xfP is None else xfP.T, mean=mean, var=var)
+               xfm=xfm, xfP=None if xfP is None else xfP.T, mean=mean, var=var, elem=elem, rev=rev)
     return out

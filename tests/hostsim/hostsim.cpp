@@ -104,19 +104,37 @@ struct Args {
     int64_t sRn;
     double *mean_out, *var_out;
     const double *eps_t, *eps_e;
-    int what;  // 0 logpdf, 1 filter, 2 posterior(+marginals if mean_out), 3 prior marginals, 4 rand
+    int what;  // 0 logpdf, 1 filter, 2 posterior(+marginals if mean_out), 3 prior marginals, 4 rand, 5 segment reduce
+    double *elem_out, *rev_out;   // total filter element of the segment / total smoother element
+    const double *xs_m, *xs_P;    // smoothed state at the segment end (null: the final filtered state)
 };
+
+template <int D, class M> void total_elem(const SoA& E0, double* out) {
+    typename M::E acc, cur, tmp;
+    acc.identity();
+    for (int64_t i = 0; i < E0.n; ++i) {
+        M::load(cur, E0, i);
+        M::combine(acc, cur, tmp);
+        acc = tmp;
+    }
+    SoA one;
+    one.init(M::NC, 1);
+    store_elem<D>(acc, one, 0);
+    for (int k = 0; k < M::NC; ++k) out[k] = one.v[k];
+}
 
 template <int D, bool LTI> int run(const Args& a) {
     const ModelView& mv = a.mv;
     int64_t n0 = (mv.T + a.L0 - 1) / a.L0;
     State<D> x0 = make_state<D>(a.x0m, a.x0P);
     int bad = 0;
-    if (a.what <= 2) {
+    if (a.what <= 2 || a.what == 5) {
         SoA E0;
         E0.init(Dim<D>::NF, n0);
         for (int64_t c = 0; c < n0; ++c)
             chunk_reduce_filter<D, LTI>(mv, c, a.L0, [&](int k, double v) { E0.v[(size_t)k * n0 + c] = v; });
+        if (a.elem_out) total_elem<D, FM<D>>(E0, a.elem_out);
+        if (a.what == 5) return 0;
         std::vector<State<D>> S0;
         State<D> fin;
         hier_scan<D, FM<D>>(E0, x0, S0, fin, a.BS);
@@ -145,10 +163,12 @@ template <int D, bool LTI> int run(const Args& a) {
             for (int i = 0; i < D; ++i) a.xfm[i] = fin.m[i];
             for (int i = 0; i < D * D; ++i) a.xfP[i] = fin.P[i];
         }
+        if (a.what == 2 && a.rev_out) total_elem<D, AM<D, true>>(R0, a.rev_out);
         if (a.what == 2 && a.mean_out) {
             std::vector<State<D>> S0r;
             State<D> fin_r;
-            hier_scan<D, AM<D, true>>(R0, fin, S0r, fin_r, a.BS);
+            State<D> seed = a.xs_m ? make_state<D>(a.xs_m, a.xs_P) : fin;
+            hier_scan<D, AM<D, true>>(R0, seed, S0r, fin_r, a.BS);
             for (int64_t c = 0; c < n0; ++c) {
                 State<D> xs = S0r[n0 - 1 - c];
                 bad |= chunk_smooth<D, LTI>(mv, c, a.L0, xs, S0[c], fs.data(), a.Rnew, a.sRn, a.mean_out, a.var_out);
@@ -184,12 +204,14 @@ extern "C" int hostsim_run(int d, int lti, int what, int L0, int BS, int64_t T, 
                            const double* h, int64_t sh, const double* R, int64_t sR, const double* y, const uint8_t* missing,
                            const double* x0m, const double* x0P, double* lml, double* m_out, double* P_out, double* G_out,
                            double* g_out, double* L_out, double* xfm, double* xfP, const double* Rnew, int64_t sRn,
-                           double* mean_out, double* var_out, const double* eps_t, const double* eps_e) {
+                           double* mean_out, double* var_out, const double* eps_t, const double* eps_e, double* elem_out,
+                           double* rev_out, const double* xs_m, const double* xs_P) {
     Args a;
     a.mv = ModelView{T, ordering, 0, A, av, Q, H, h, R, sA, sa, sQ, sH, sh, sR, y, missing};
     a.x0m = x0m; a.x0P = x0P; a.L0 = L0; a.BS = BS; a.lml = lml; a.m_out = m_out; a.P_out = P_out;
     a.G_out = G_out; a.g_out = g_out; a.L_out = L_out; a.xfm = xfm; a.xfP = xfP; a.Rnew = Rnew; a.sRn = sRn;
     a.mean_out = mean_out; a.var_out = var_out; a.eps_t = eps_t; a.eps_e = eps_e; a.what = what;
+    a.elem_out = elem_out; a.rev_out = rev_out; a.xs_m = xs_m; a.xs_P = xs_P;
     switch (d) {
         case 1: return run_d<1>(a, lti);
         case 2: return run_d<2>(a, lti);
