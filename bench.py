@@ -114,8 +114,6 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    hd.set_option(tgp._lib.OPT_PROFILE, 1)
-    hd.profile_reset()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -126,6 +124,14 @@ def main():
     if world > 1:
         dist.barrier()
     dt_s = time.perf_counter() - t0
+    # per-kernel durations: the SAME K steps once more with every launch bracketed by hipEvents on the
+    # handle's stream (kept out of the timed region above: two event records per launch slow the host
+    # enqueue enough to open gaps between the ~20-300 us kernels).
+    hd.set_option(tgp._lib.OPT_PROFILE, 1)
+    hd.profile_reset()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
     hd.set_option(tgp._lib.OPT_PROFILE, 0)
     if world > 1:
         tmax = torch.tensor([dt_s], dtype=torch.float64, device=f"cuda:{local}")

@@ -113,7 +113,8 @@ struct tgp_handle {
     DevBuf by, bmiss, bRnew, beps_t, beps_e, bo1, bo2, bo3;
     // scans and scratch
     ScanCtx F, Rv;
-    DevBuf fs, partial, result, badflag, segtmp;
+    DevBuf fs, partial, result, segtmp;
+    double* host_result = nullptr;  // pinned, 8 doubles: [0] lml [1] nmiss [2] filter-bad ; int flags at [4]
     int64_t opt_chunk = 0;
     int profile = 0;
     int L0 = 0;
@@ -284,7 +285,7 @@ int scan_prepare(tgp_handle* h, ScanCtx& c, int monoid, int64_t n0) {
     c.NS = state_size(h->d);
     c.n.clear();
     c.n.push_back(n0);
-    while (c.n.back() > kTopBS) c.n.push_back((c.n.back() + 255) / 256);
+    while (c.n.back() > (int64_t)kTopBS * kScanE) c.n.push_back((c.n.back() + 256 * kScanE - 1) / (256 * kScanE));
     size_t total = (size_t)c.NS;
     for (int64_t n : c.n) total += (size_t)(c.NC + c.NS) * (size_t)n;
     HIPCHK(c.slab.ensure(total * sizeof(double)));
@@ -312,7 +313,7 @@ void scan_down(tgp_handle* h, ScanCtx& c, const double* x0dev) {
     const int top = (int)c.n.size() - 1;
     {
         LaunchScope ls(h, c.monoid == kFilter ? "k_scan_apply<filter,top>" : "k_scan_apply<affine,top>");
-        h->kt->scan_apply(c.monoid, c.n[top] <= 256 ? 256 : kTopBS, c.E[top], c.n[top], x0dev, 1, c.S[top], c.fin, h->stream);
+        h->kt->scan_apply(c.monoid, c.n[top] <= 256 * kScanE ? 256 : kTopBS, c.E[top], c.n[top], x0dev, 1, c.S[top], c.fin, h->stream);
     }
     for (int l = top - 1; l >= 0; --l) {
         LaunchScope ls(h, c.monoid == kFilter ? "k_scan_apply<filter>" : "k_scan_apply<affine>");
@@ -329,7 +330,7 @@ int scan_total_to_host(tgp_handle* h, ScanCtx& c, double* elem_out) {
     double* t0 = h->segtmp.d();
     double* t1 = t0 + (size_t)c.NC * 2;
     while (true) {
-        int64_t nhi = (n + 255) / 256;
+        int64_t nhi = (n + 256 * kScanE - 1) / (256 * kScanE);
         {
             LaunchScope ls(h, "k_scan_reduce<segment>");
             h->kt->scan_reduce(c.monoid, src, n, t0, nhi, h->stream);
@@ -346,10 +347,15 @@ int scan_total_to_host(tgp_handle* h, ScanCtx& c, double* elem_out) {
 
 struct CallTimer {
     tgp_handle* h;
-    explicit CallTimer(tgp_handle* h_) : h(h_) { (void)hipEventRecord(h->ev[0], h->stream); }
+    explicit CallTimer(tgp_handle* h_) : h(h_) {
+        (void)hipEventRecord(h->ev[0], h->stream);
+        (void)hipMemsetAsync(h->result.p, 0, 8 * sizeof(double), h->stream);   // lml / flags of this call
+    }
     void inputs_done() { (void)hipEventRecord(h->ev[1], h->stream); }
     void kernels_done() { (void)hipEventRecord(h->ev[2], h->stream); }
-    int finish() {
+    // one 64-byte D2H into pinned memory + ONE stream sync per call; then decode lml and the error flags
+    int finish(double* lml_out = nullptr) {
+        HIPCHK(hipMemcpyAsync(h->host_result, h->result.p, 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         (void)hipEventRecord(h->ev[3], h->stream);
         HIPCHK(hipStreamSynchronize(h->stream));
         float a = 0.f, b = 0.f, c = 0.f;
@@ -360,6 +366,11 @@ struct CallTimer {
         h->kernel_ms = b;
         h->d2h_ms = c;
         resolve_profile(h);
+        if (lml_out) *lml_out = h->host_result[0];
+        int flags = 0;
+        std::memcpy(&flags, &h->host_result[4], sizeof flags);
+        if (h->host_result[2] != 0.0) return h->fail(TGP_ENOTPD, "innovation variance / predicted covariance not positive definite");
+        if (flags) return h->fail(TGP_ENOTPD, "matrix not positive definite (Cholesky failed)");
         return TGP_OK;
     }
 };
@@ -402,7 +413,6 @@ int forward_apply(tgp_handle* h, int mode, const FilterOut& fo) {
     scan_down(h, h->F, h->bx0.d());
     const int64_t nblocks = (h->n0 + 255) / 256;
     HIPCHK(h->partial.ensure((size_t)nblocks * 3 * sizeof(double)));
-    HIPCHK(h->result.ensure(4 * sizeof(double)));
     double* R0 = nullptr;
     if (mode == 2) {
         TRY(scan_prepare(h, h->Rv, kAffineCov, h->n0));
@@ -422,28 +432,7 @@ int forward_apply(tgp_handle* h, int mode, const FilterOut& fo) {
     return TGP_OK;
 }
 
-int fetch_result(tgp_handle* h, double* lml_out) {
-    double res[3] = {0, 0, 0};
-    HIPCHK(hipMemcpyAsync(res, h->result.p, sizeof res, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    if (lml_out) *lml_out = res[0];
-    if (res[2] != 0.0) return h->fail(TGP_ENOTPD, "innovation variance / predicted covariance not positive definite");
-    return TGP_OK;
-}
-
-int check_badflag(tgp_handle* h) {
-    int bad = 0;
-    HIPCHK(hipMemcpyAsync(&bad, h->badflag.p, sizeof bad, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    if (bad) return h->fail(TGP_ENOTPD, "matrix not positive definite (Cholesky failed)");
-    return TGP_OK;
-}
-
-int zero_badflag(tgp_handle* h) {
-    HIPCHK(h->badflag.ensure(sizeof(int)));
-    HIPCHK(hipMemsetAsync(h->badflag.p, 0, sizeof(int), h->stream));
-    return TGP_OK;
-}
+int* flag_ptr(tgp_handle* h) { return reinterpret_cast<int*>(h->result.d() + 4); }
 
 template <int D> int host_apply(int kind, const double* elem, const double* m, const double* P, double* mo, double* Po) {
     State<D> in, out;
@@ -517,6 +506,11 @@ int tgp_create(tgp_handle** out, int device) {
             delete h;
             return TGP_EHIP;
         }
+    if (hipHostMalloc(reinterpret_cast<void**>(&h->host_result), 8 * sizeof(double), hipHostMallocDefault) != hipSuccess ||
+        h->result.ensure(8 * sizeof(double)) != hipSuccess) {
+        delete h;
+        return TGP_EHIP;
+    }
     *out = h;
     return TGP_OK;
 }
@@ -526,8 +520,7 @@ int tgp_destroy(tgp_handle* h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     for (DevBuf* b : {&h->bA, &h->ba, &h->bQ, &h->bH, &h->bh, &h->bR, &h->bx0, &h->bx0r, &h->by, &h->bmiss, &h->bRnew, &h->beps_t,
-                      &h->beps_e, &h->bo1, &h->bo2, &h->bo3, &h->F.slab, &h->Rv.slab, &h->fs, &h->partial, &h->result, &h->badflag,
-                      &h->segtmp})
+                      &h->beps_e, &h->bo1, &h->bo2, &h->bo3, &h->F.slab, &h->Rv.slab, &h->fs, &h->partial, &h->result, &h->segtmp})
         b->release();
     for (auto& e : h->ev)
         if (e) (void)hipEventDestroy(e);
@@ -536,6 +529,7 @@ int tgp_destroy(tgp_handle* h) {
         (void)hipEventDestroy(pe.b);
     }
     for (auto& e : h->evpool) (void)hipEventDestroy(e);
+    if (h->host_result) (void)hipHostFree(h->host_result);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
     return TGP_OK;
@@ -638,9 +632,7 @@ int tgp_logpdf(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t 
     FilterOut fo{};
     TRY(forward_apply(h, 0, fo));
     tm.kernels_done();
-    int rc = fetch_result(h, out);
-    TRY(tm.finish());
-    return rc;
+    return tm.finish(out);
 }
 
 int tgp_filter(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t flags, double* m_out, double* P_out, double* lml_out) {
@@ -658,9 +650,7 @@ int tgp_filter(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t 
     tm.kernels_done();
     TRY(copy_back(h, m_out, fo.m_out, nm, odev));
     TRY(copy_back(h, P_out, fo.P_out, nP, odev));
-    int rc = fetch_result(h, lml_out);
-    TRY(tm.finish());
-    return rc;
+    return tm.finish(lml_out);
 }
 
 int tgp_posterior(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t flags, double* G, double* g, double* L,
@@ -689,9 +679,7 @@ int tgp_posterior(tgp_handle* h, const double* y, const uint8_t* missing, uint32
         HIPCHK(hipStreamSynchronize(h->stream));
         unpack_state(h->d, pk.data(), xfm, xfP);
     }
-    int rc = fetch_result(h, nullptr);
-    TRY(tm.finish());
-    return rc;
+    return tm.finish();
 }
 
 static int smoother_forward_impl(tgp_handle* h, uint32_t flags) {
@@ -708,11 +696,10 @@ static int smoother_forward_impl(tgp_handle* h, uint32_t flags) {
 
 static int smoother_backward_impl(tgp_handle* h, const double* xs_dev, const double* Rnew_dev, int64_t sRn, double* mean_dev, double* var_dev) {
     scan_down(h, h->Rv, xs_dev);
-    TRY(zero_badflag(h));
     {
         LaunchScope ls(h, h->lti ? "k_smooth<lti>" : "k_smooth<per-step>");
         h->kt->smooth(h->lti, h->mv, h->L0, h->n0, h->F.S[0], h->Rv.S[0], h->fs.d(), Rnew_dev, sRn, mean_dev, var_dev,
-                      static_cast<int*>(h->badflag.p), h->stream);
+                      flag_ptr(h), h->stream);
     }
     return TGP_OK;
 }
@@ -738,10 +725,7 @@ int tgp_posterior_marginals(tgp_handle* h, const double* y, const uint8_t* missi
     tm.kernels_done();
     TRY(copy_back(h, mean_out, dm, nT, odev));
     TRY(copy_back(h, var_out, dv, nT, odev));
-    int rc = fetch_result(h, lml_out);
-    if (rc == TGP_OK) rc = check_badflag(h);
-    TRY(tm.finish());
-    return rc;
+    return tm.finish(lml_out);
 }
 
 int tgp_smoother_forward(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t flags, double* rev_elem_out, double* xfm,
@@ -760,9 +744,7 @@ int tgp_smoother_forward(tgp_handle* h, const double* y, const uint8_t* missing,
         HIPCHK(hipStreamSynchronize(h->stream));
         unpack_state(h->d, pk.data(), xfm, xfP);
     }
-    int rc = fetch_result(h, lml_out);
-    TRY(tm.finish());
-    return rc;
+    return tm.finish(lml_out);
 }
 
 int tgp_smoother_backward(tgp_handle* h, const double* xs_m, const double* xs_P, const double* Rnew, uint32_t flags, double* mean_out,
@@ -789,9 +771,7 @@ int tgp_smoother_backward(tgp_handle* h, const double* xs_m, const double* xs_P,
     tm.kernels_done();
     TRY(copy_back(h, mean_out, dm, nT, odev));
     TRY(copy_back(h, var_out, dv, nT, odev));
-    int rc = check_badflag(h);
-    TRY(tm.finish());
-    return rc;
+    return tm.finish();
 }
 
 static int affine_impl(tgp_handle* h, bool rnd, const double* x0dev, const double* eps_t, const double* eps_e, double* mean_dev,
@@ -801,8 +781,7 @@ static int affine_impl(tgp_handle* h, bool rnd, const double* x0dev, const doubl
     h->smoother_valid = false;
     const int monoid = rnd ? kAffineMean : kAffineCov;
     TRY(scan_prepare(h, h->Rv, monoid, h->n0));
-    TRY(zero_badflag(h));
-    int* bad = static_cast<int*>(h->badflag.p);
+    int* bad = flag_ptr(h);
     {
         LaunchScope ls(h, rnd ? "k_reduce_affine<rand>" : "k_reduce_affine<marginals>");
         h->kt->reduce_affine(h->lti, rnd, h->mv, h->L0, h->n0, eps_t, h->Rv.E[0], bad, h->stream);
@@ -830,9 +809,7 @@ int tgp_marginals(tgp_handle* h, uint32_t flags, double* mean_out, double* var_o
     tm.kernels_done();
     TRY(copy_back(h, mean_out, dm, nT, odev));
     TRY(copy_back(h, var_out, dv, nT, odev));
-    int rc = check_badflag(h);
-    TRY(tm.finish());
-    return rc;
+    return tm.finish();
 }
 
 int tgp_rand(tgp_handle* h, const double* eps_t, const double* eps_e, const double* eps_0, uint32_t flags, double* y_out) {
@@ -871,9 +848,7 @@ int tgp_rand(tgp_handle* h, const double* eps_t, const double* eps_e, const doub
     TRY(affine_impl(h, true, h->bx0r.d(), (const double*)pet, (const double*)pee, dy, nullptr));
     tm.kernels_done();
     TRY(copy_back(h, y_out, dy, nT, odev));
-    int rc = check_badflag(h);
-    TRY(tm.finish());
-    return rc;
+    return tm.finish();
 }
 
 int tgp_elem_size(int kind, int d) { return kind == 0 ? felem_size(d) : aelem_size(d); }

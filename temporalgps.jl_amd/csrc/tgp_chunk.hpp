@@ -38,6 +38,29 @@ TGP_HD int64_t fs_index(int64_t c, int i, int k, int L0, int NS) {
     return ((((c >> 6) * L0 + i) * NS + k) << 6) + (c & 63);
 }
 
+TGP_HD int64_t step_index(const ModelView& mv, int64_t r) { return mv.ordering == 0 ? r : mv.T - 1 - r; }
+
+// Per-step SCALAR streams (y, per-step R, R_new in; mean/var out) are accessed through an IO object in
+// groups of G consecutive steps. A lane's chunk is contiguous in time, so lane-wise access is strided by
+// L0*8 bytes across the wave; the device IO (WaveIO, tgp_kernels.hpp) instead lets 8 lanes fetch / write
+// one chunk's 64 contiguous bytes and transposes through wave-private LDS. DirectIO is the plain form
+// (host emulation, and the reference semantics the staged form must reproduce).
+struct DirectIO {
+    static constexpr int G = 8;
+    const double* a0;  // y
+    const double* a1;  // per-step R (or R_new); only read when its stride is non-zero
+    double* o0;
+    double* o1;
+    TGP_HD void begin(const ModelView&, int64_t, int, int) {}
+    TGP_HD double in0(int64_t te, int) const { return a0[te]; }
+    TGP_HD double in1(int64_t te, int) const { return a1[te]; }
+    TGP_HD void out(int64_t te, int, double x0, double x1) {
+        o0[te] = x0;
+        if (o1) o1[te] = x1;
+    }
+    TGP_HD void flush(const ModelView&, int64_t, int, int) {}
+};
+
 // Loads one processing step. LTI == true: A, a, Q, H, h are shared and loaded once (hoisted).
 template <int D, bool LTI> struct StepLoader {
     double A[D * D], a[D], Q[D * D], H[D], h, R, y;
@@ -64,41 +87,57 @@ template <int D, bool LTI> struct StepLoader {
             TGP_UNROLL for (int i = 0; i < D; ++i) a[i] = pa[i];
         }
     }
+    // emission H, h (R separately: it may come through the staged IO)
     TGP_HD void load_emission(const ModelView& mv) {
         if (!LTI) {
             const double* pH = mv.H + te * mv.sH;
             TGP_UNROLL for (int i = 0; i < D; ++i) H[i] = pH[i];
             h = mv.h[te * mv.sh];
         }
-        R = mv.R[te * mv.sR];
     }
-    TGP_HD void load_obs(const ModelView& mv) {
-        y = mv.y[te];
+    TGP_HD void load_R_direct(const ModelView& mv) { R = mv.R[te * mv.sR]; }
+    // y via io.in0, per-step R via io.in1 (io.a1 == mv.R); shared R read once per step from mv.R[0]
+    template <class IO> TGP_HD void load_obs(const ModelView& mv, const IO& io, int i) {
+        R = (mv.sR == 0) ? mv.R[0] : io.in1(te, i);
+        y = io.in0(te, i);
         is_missing = (mv.missing != nullptr) && (mv.missing[te] != 0);
         if (is_missing) { y = 0.0; R = kLargeVar; }
     }
-    TGP_HD void load(const ModelView& mv, int64_t r) {
+    template <class IO> TGP_HD void load(const ModelView& mv, int64_t r, const IO& io, int i) {
         index(mv, r);
         load_transition(mv);
         load_emission(mv);
-        load_obs(mv);
+        load_obs(mv, io, i);
     }
 };
 
 // ------------------------------------------------------------------------------------------ pass 1
-template <int D, bool LTI, typename Store>
-TGP_HD void chunk_reduce_filter(const ModelView& mv, int64_t c, int L0, Store st) {
-    int64_t r0 = c * (int64_t)L0;
-    int64_t r1 = r0 + L0 < mv.T ? r0 + L0 : mv.T;
+// Chunk bounds; lanes past the last chunk (c >= n0) get an empty range but still take part in the
+// wave-cooperative IO.
+TGP_HD void chunk_range(const ModelView& mv, int64_t c, int L0, int64_t& r0, int64_t& r1) {
+    r0 = c * (int64_t)L0;
+    if (r0 > mv.T) r0 = mv.T;
+    r1 = r0 + L0 < mv.T ? r0 + L0 : mv.T;
+}
+
+template <int D, bool LTI, class IO, typename Store>
+TGP_HD void chunk_reduce_filter(const ModelView& mv, int64_t c, int L0, IO& io, Store st) {
+    int64_t r0, r1;
+    chunk_range(mv, c, L0, r0, r1);
     FElem<D> e;
     e.identity();
     StepLoader<D, LTI> sl;
     sl.init(mv);
-    for (int64_t r = r0; r < r1; ++r) {
-        sl.load(mv, r);
-        f_extend<D>(e, sl.do_predict, sl.A, sl.a, sl.Q, sl.H, sl.h, sl.R, sl.y);
+    for (int g = 0; g < L0; g += IO::G) {
+        io.begin(mv, c, g, L0);
+        const int64_t rg = r0 + g;
+        const int gend = (int)((r1 - rg) < IO::G ? (r1 - rg) : IO::G);
+        for (int i = 0; i < gend; ++i) {
+            sl.load(mv, rg + i, io, i);
+            f_extend<D>(e, sl.do_predict, sl.A, sl.a, sl.Q, sl.H, sl.h, sl.R, sl.y);
+        }
     }
-    store_felem<D>(e, st);
+    if (r1 > r0) store_felem<D>(e, st);
 }
 
 // ------------------------------------------------------------------------------------------ pass 2
@@ -119,18 +158,23 @@ struct ChunkStats {
 
 // MODE 0: logpdf only. MODE 1: + filtering distributions. MODE 2: + filtered-state scratch, reverse
 // (smoother) chunk element, optional (G, g, L) output.  `rst` stores the reverse element (MODE 2).
-template <int D, bool LTI, int MODE, typename RStore>
-TGP_HD ChunkStats chunk_apply_filter(const ModelView& mv, int64_t c, int L0, State<D>& x, const FilterOut& out, RStore rst) {
-    int64_t r0 = c * (int64_t)L0;
-    int64_t r1 = r0 + L0 < mv.T ? r0 + L0 : mv.T;
+template <int D, bool LTI, int MODE, class IO, typename RStore>
+TGP_HD ChunkStats chunk_apply_filter(const ModelView& mv, int64_t c, int L0, State<D>& x, const FilterOut& out, IO& io, RStore rst) {
+    int64_t r0, r1;
+    chunk_range(mv, c, L0, r0, r1);
     ChunkStats cs{0.0, 0.0, 0};
     StepLoader<D, LTI> sl;
     sl.init(mv);
     AElem<D> rev;
     if (MODE == 2) rev.identity();
     bool ok = true;
-    for (int64_t r = r0; r < r1; ++r) {
-        sl.load(mv, r);
+    for (int g = 0; g < L0; g += IO::G) {
+      io.begin(mv, c, g, L0);
+      const int64_t rg = r0 + g;
+      const int gend = (int)((r1 - rg) < IO::G ? (r1 - rg) : IO::G);
+      for (int gi = 0; gi < gend; ++gi) {
+        const int64_t r = rg + gi;
+        sl.load(mv, r, io, gi);
         if (MODE == 2) {
             double mf[D], Pf[D * D];
             copy_n<D>(x.m, mf);
@@ -160,8 +204,9 @@ TGP_HD ChunkStats chunk_apply_filter(const ModelView& mv, int64_t c, int L0, Sta
             int L0_ = L0;
             store_state<D>(x, [=](int k, double v) { fs[fs_index(c, i, k, L0_, Dim<D>::NS)] = v; });
         }
+      }
     }
-    if (MODE == 2) store_aelem<D>(rev, rst);
+    if (MODE == 2 && r1 > r0) store_aelem<D>(rev, rst);
     cs.bad = ok ? 0 : 1;
     return cs;
 }
@@ -170,37 +215,44 @@ TGP_HD ChunkStats chunk_apply_filter(const ModelView& mv, int64_t c, int L0, Sta
 // RTS smoother on chunk c. `xs` = smoothed state at the chunk's LAST step; `carry` = filtered state
 // just before the chunk's first step. Emits N(H x + h, H P H' + Rnew) for every step (lgssm.jl:111-115
 // on the posterior model with replace_observation_noise_cov, missings.jl:35-41).
-template <int D, bool LTI>
+template <int D, bool LTI, class IO>
 TGP_HD int chunk_smooth(const ModelView& mv, int64_t c, int L0, State<D>& xs, const State<D>& carry, const double* fs,
-                        const double* Rnew, int64_t sRn, double* mean_out, double* var_out) {
-    int64_t r0 = c * (int64_t)L0;
-    int64_t r1 = r0 + L0 < mv.T ? r0 + L0 : mv.T;
+                        int64_t sRn, IO& io) {
+    int64_t r0, r1;
+    chunk_range(mv, c, L0, r0, r1);
     StepLoader<D, LTI> sl;
     sl.init(mv);
     bool ok = true;
-    for (int64_t r = r1 - 1; r >= r0; --r) {
-        sl.index(mv, r);
-        sl.load_transition(mv);
-        sl.load_emission(mv);
-        double mean, var;
-        emit_scalar<D>(sl.H, sl.h, Rnew[sl.te * sRn], xs.m, xs.P, mean, var);
-        mean_out[sl.te] = mean;
-        var_out[sl.te] = var;
-        State<D> xf;  // filtered state before this step
-        if (r == r0) {
-            xf = carry;
-        } else {
-            int i = (int)(r - r0) - 1;
-            int L0_ = L0;
-            load_state<D>(xf, [=](int k) { return fs[fs_index(c, i, k, L0_, Dim<D>::NS)]; });
+    const double Rn_shared = (sRn == 0) ? io.a1[0] : 0.0;
+    for (int g = ((L0 - 1) / IO::G) * IO::G; g >= 0; g -= IO::G) {
+        io.begin(mv, c, g, L0);   // stages R_new (io.a1) when it is per-step
+        const int64_t rg = r0 + g;
+        const int gend = (int)((r1 - rg) < IO::G ? (r1 - rg) : IO::G);
+        for (int gi = gend - 1; gi >= 0; --gi) {
+            const int64_t r = rg + gi;
+            sl.index(mv, r);
+            sl.load_transition(mv);
+            sl.load_emission(mv);
+            double mean, var;
+            emit_scalar<D>(sl.H, sl.h, (sRn == 0) ? Rn_shared : io.in1(sl.te, gi), xs.m, xs.P, mean, var);
+            io.out(sl.te, gi, mean, var);
+            State<D> xf;  // filtered state before this step
+            if (r == r0) {
+                xf = carry;
+            } else {
+                int i = (int)(r - r0) - 1;
+                int L0_ = L0;
+                load_state<D>(xf, [=](int k) { return fs[fs_index(c, i, k, L0_, Dim<D>::NS)]; });
+            }
+            double mp[D], Pp[D * D];
+            copy_n<D>(xf.m, mp);
+            copy_n<D * D>(xf.P, Pp);
+            predict<D>(sl.A, sl.a, sl.Q, mp, Pp);
+            double G[D * D], g_[D], L[D * D];
+            ok = invert_dynamics<D>(xf.m, xf.P, mp, Pp, sl.A, G, g_, L) && ok;
+            predict<D>(G, g_, L, xs.m, xs.P);
         }
-        double mp[D], Pp[D * D];
-        copy_n<D>(xf.m, mp);
-        copy_n<D * D>(xf.P, Pp);
-        predict<D>(sl.A, sl.a, sl.Q, mp, Pp);
-        double G[D * D], g[D], L[D * D];
-        ok = invert_dynamics<D>(xf.m, xf.P, mp, Pp, sl.A, G, g, L) && ok;
-        predict<D>(G, g, L, xs.m, xs.P);
+        io.flush(mv, c, g, L0);
     }
     return ok ? 0 : 1;
 }
@@ -219,8 +271,8 @@ template <int D> TGP_HD bool noise_factor(const double* Q, double* Lq) {  // low
 
 template <int D, bool LTI, bool RAND, typename Store>
 TGP_HD int chunk_reduce_affine(const ModelView& mv, int64_t c, int L0, const double* eps_t, Store st) {
-    int64_t r0 = c * (int64_t)L0;
-    int64_t r1 = r0 + L0 < mv.T ? r0 + L0 : mv.T;
+    int64_t r0, r1;
+    chunk_range(mv, c, L0, r0, r1);
     AElem<D> e;
     e.identity();
     StepLoader<D, LTI> sl;
@@ -250,20 +302,25 @@ TGP_HD int chunk_reduce_affine(const ModelView& mv, int64_t c, int L0, const dou
     return ok ? 0 : 1;
 }
 
-template <int D, bool LTI, bool RAND>
-TGP_HD int chunk_apply_affine(const ModelView& mv, int64_t c, int L0, State<D>& x, const double* eps_t, const double* eps_e,
-                              double* mean_out, double* var_out) {
-    int64_t r0 = c * (int64_t)L0;
-    int64_t r1 = r0 + L0 < mv.T ? r0 + L0 : mv.T;
+template <int D, bool LTI, bool RAND, class IO>
+TGP_HD int chunk_apply_affine(const ModelView& mv, int64_t c, int L0, State<D>& x, const double* eps_t, IO& io) {
+    int64_t r0, r1;
+    chunk_range(mv, c, L0, r0, r1);
     StepLoader<D, LTI> sl;
     sl.init(mv);
     double Lq[D * D];
     bool ok = true;
     if (RAND && LTI) ok = noise_factor<D>(sl.Q, Lq);
-    for (int64_t r = r0; r < r1; ++r) {
+    for (int g = 0; g < L0; g += IO::G) {
+      io.begin(mv, c, g, L0);   // RAND: stages eps_e (io.a0); per-step R (io.a1)
+      const int64_t rg = r0 + g;
+      const int gend = (int)((r1 - rg) < IO::G ? (r1 - rg) : IO::G);
+      for (int gi = 0; gi < gend; ++gi) {
+        const int64_t r = rg + gi;
         sl.index(mv, r);
         sl.load_transition(mv);
         sl.load_emission(mv);
+        const double R = (mv.sR == 0) ? mv.R[0] : io.in1(sl.te, gi);
         if (sl.do_predict) {
             if (RAND) {
                 if (!LTI) ok = noise_factor<D>(sl.Q, Lq) && ok;
@@ -282,13 +339,14 @@ TGP_HD int chunk_apply_affine(const ModelView& mv, int64_t c, int L0, State<D>& 
         if (RAND) {
             double yy = 0.0;
             TGP_UNROLL for (int i = 0; i < D; ++i) yy = fma(sl.H[i], x.m[i], yy);
-            mean_out[sl.te] = (yy + sl.h) + sqrt(sl.R) * eps_e[sl.te];   // lgc.jl:241-243
+            io.out(sl.te, gi, (yy + sl.h) + sqrt(R) * io.in0(sl.te, gi), 0.0);   // lgc.jl:241-243
         } else {
             double mean, var;
-            emit_scalar<D>(sl.H, sl.h, sl.R, x.m, x.P, mean, var);
-            mean_out[sl.te] = mean;
-            var_out[sl.te] = var;
+            emit_scalar<D>(sl.H, sl.h, R, x.m, x.P, mean, var);
+            io.out(sl.te, gi, mean, var);
         }
+      }
+      io.flush(mv, c, g, L0);
     }
     return ok ? 0 : 1;
 }

@@ -48,12 +48,87 @@ template <class E> __device__ __forceinline__ void shfl_down_elem(const E& in, E
     TGP_UNROLL for (int i = 0; i < N; ++i) d[i] = __shfl_down(s[i], off, 64);
 }
 
+// ---------------------------------------------------------------- wave-cooperative staged IO
+// 8 lanes move one chunk's 8 consecutive scalars (64 contiguous bytes) between HBM and wave-private LDS;
+// each lane then reads / writes its own chunk's values from LDS (row stride 9 doubles: conflict-free for
+// ds_read_b64 / ds_write_b64). No block barrier: a wave's LDS operations execute in issue order.
+constexpr int kIoLD = 9;
+constexpr int kIoSlot = 64 * kIoLD;  // doubles per slot per wave
+
+// Dynamic LDS of the chunk kernels, addressed by INDEX (never through a generic pointer: hipcc (ROCm 7.2)
+// mis-selects the generic->local null check in the large d >= 7 kernels when a flat pointer to LDS is
+// carried in a struct).
+extern __shared__ __attribute__((aligned(16))) double tgp_lds[];
+
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <bool IN0, bool IN1, bool OUT0, bool OUT1> struct WaveIO {
+    static constexpr int G = 8;
+    static constexpr int kOff0 = 0;
+    static constexpr int kOff1 = (IN0 ? 1 : 0) * kIoSlot;
+    static constexpr int kOffO0 = ((IN0 ? 1 : 0) + (IN1 ? 1 : 0)) * kIoSlot;
+    static constexpr int kOffO1 = ((IN0 ? 1 : 0) + (IN1 ? 1 : 0) + (OUT0 ? 1 : 0)) * kIoSlot;
+    static constexpr int kSlots = (IN0 ? 1 : 0) + (IN1 ? 1 : 0) + (OUT0 ? 1 : 0) + (OUT1 ? 1 : 0);
+    const double* a0;
+    const double* a1;
+    double* o0;
+    double* o1;
+    bool st1;    // a1 is per-step (stage it); otherwise the caller reads a1[0]
+    int wb;      // this wave's base index into tgp_lds
+    int lane;
+    static constexpr size_t lds_bytes() { return 4 * (size_t)kSlots * kIoSlot * sizeof(double); }
+    __device__ __forceinline__ static int wave_base() { return (int)(threadIdx.x >> 6) * kSlots * kIoSlot; }
+
+    __device__ __forceinline__ void begin(const ModelView& mv, int64_t c, int g, int L0) {
+        if (!IN0 && !(IN1 && st1)) return;
+        const int64_t c0 = c - lane;
+        wave_sync();
+        TGP_UNROLL for (int j = 0; j < 8; ++j) {
+            const int row = j * 8 + (lane >> 3);
+            const int64_t r = (c0 + row) * L0 + g + (lane & 7);
+            if (r < mv.T) {
+                const int64_t te = step_index(mv, r);
+                if (IN0) tgp_lds[wb + kOff0 + row * kIoLD + (lane & 7)] = a0[te];
+                if (IN1 && st1) tgp_lds[wb + kOff1 + row * kIoLD + (lane & 7)] = a1[te];
+            }
+        }
+        wave_sync();
+    }
+    __device__ __forceinline__ double in0(int64_t, int i) const { return tgp_lds[wb + kOff0 + lane * kIoLD + i]; }
+    __device__ __forceinline__ double in1(int64_t, int i) const { return tgp_lds[wb + kOff1 + lane * kIoLD + i]; }
+    __device__ __forceinline__ void out(int64_t, int i, double x0, double x1) {
+        if (OUT0) tgp_lds[wb + kOffO0 + lane * kIoLD + i] = x0;
+        if (OUT1) tgp_lds[wb + kOffO1 + lane * kIoLD + i] = x1;
+    }
+    __device__ __forceinline__ void flush(const ModelView& mv, int64_t c, int g, int L0) {
+        if (!OUT0) return;
+        const int64_t c0 = c - lane;
+        wave_sync();
+        TGP_UNROLL for (int j = 0; j < 8; ++j) {
+            const int row = j * 8 + (lane >> 3);
+            const int64_t cc = c0 + row;
+            const int64_t r = cc * L0 + g + (lane & 7);
+            const int64_t r1c = (cc + 1) * L0 < mv.T ? (cc + 1) * L0 : mv.T;
+            if (r < r1c) {
+                const int64_t te = step_index(mv, r);
+                o0[te] = tgp_lds[wb + kOffO0 + row * kIoLD + (lane & 7)];
+                if (OUT1 && o1 != nullptr) o1[te] = tgp_lds[wb + kOffO1 + row * kIoLD + (lane & 7)];
+            }
+        }
+        wave_sync();
+    }
+};
+
 // ---------------------------------------------------------------- pass 1
 template <int D, bool LTI>
 __global__ __launch_bounds__(256) void k_reduce_filter(ModelView mv, int L0, int64_t n0, double* __restrict__ E0) {
-    int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (c >= n0) return;
-    chunk_reduce_filter<D, LTI>(mv, c, L0, [=](int k, double v) { E0[(int64_t)k * n0 + c] = v; });
+    using IO = WaveIO<true, true, false, false>;
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    IO io{mv.y, mv.R, nullptr, nullptr, mv.sR != 0, IO::wave_base(), (int)(threadIdx.x & 63)};
+    chunk_reduce_filter<D, LTI>(mv, c, L0, io, [=](int k, double v) { E0[(int64_t)k * n0 + c] = v; });
 }
 
 template <int D, bool LTI, bool RAND>
@@ -66,6 +141,9 @@ __global__ __launch_bounds__(256) void k_reduce_affine(ModelView mv, int L0, int
 }
 
 // ---------------------------------------------------------------- block scans over elements
+// One element per lane, fully unrolled rounds. (Measured alternatives, both rejected: 8 elements per lane run
+// sequentially -- 1.7-2x slower, too few and too serial lanes; `#pragma unroll 1` round loops -- hipcc 7.2
+// miscompiles the predicated struct copies of the spilled d >= 6 elements.)
 // REDUCE: Ehi[b] = E[b*BS] o ... o E[b*BS + BS - 1]   (identity-padded tail)
 template <class M, int BS>
 __global__ __launch_bounds__(BS) void k_scan_reduce(const double* __restrict__ Ein, int64_t n, double* __restrict__ Ehi, int64_t nhi) {
@@ -169,18 +247,20 @@ __device__ __forceinline__ void block_sum3(double& a, double& b, int& c, double*
 template <int D, bool LTI, int MODE>
 __global__ __launch_bounds__(256) void k_apply_filter(ModelView mv, int L0, int64_t n0, const double* __restrict__ S0, FilterOut out,
                                                       double* __restrict__ R0, double* __restrict__ partial) {
+    using IO = WaveIO<true, true, false, false>;
     __shared__ double sh[12];
-    int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    double lml = 0.0, nmiss = 0.0;
-    int bad = 0;
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    IO io{mv.y, mv.R, nullptr, nullptr, mv.sR != 0, IO::wave_base(), (int)(threadIdx.x & 63)};
+    State<D> x;
     if (c < n0) {
-        State<D> x;
         load_state<D>(x, [=](int k) { return S0[(int64_t)k * n0 + c]; });
-        ChunkStats cs = chunk_apply_filter<D, LTI, MODE>(mv, c, L0, x, out, [=](int k, double v) { R0[(int64_t)k * n0 + (n0 - 1 - c)] = v; });
-        lml = cs.lml;
-        nmiss = cs.nmiss;
-        bad = cs.bad;
+    } else {
+        set_zero<D>(x.m);
+        set_identity<D>(x.P);
     }
+    ChunkStats cs = chunk_apply_filter<D, LTI, MODE>(mv, c, L0, x, out, io, [=](int k, double v) { R0[(int64_t)k * n0 + (n0 - 1 - c)] = v; });
+    double lml = cs.lml, nmiss = cs.nmiss;
+    int bad = cs.bad;
     block_sum3(lml, nmiss, bad, sh);
     if (threadIdx.x == 0) {
         partial[3 * (int64_t)blockIdx.x + 0] = lml;
@@ -194,14 +274,21 @@ template <int D, bool LTI>
 __global__ __launch_bounds__(256) void k_smooth(ModelView mv, int L0, int64_t n0, const double* __restrict__ S0, const double* __restrict__ S0r,
                                                 const double* __restrict__ fs, const double* __restrict__ Rnew, int64_t sRn,
                                                 double* __restrict__ mean_out, double* __restrict__ var_out, int* __restrict__ bad) {
-    int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (c >= n0) return;
+    using IO = WaveIO<false, true, true, true>;
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    IO io{nullptr, Rnew, mean_out, var_out, sRn != 0, IO::wave_base(), (int)(threadIdx.x & 63)};
     State<D> xs, carry;
-    const int64_t q = n0 - 1 - c;
-    load_state<D>(xs, [=](int k) { return S0r[(int64_t)k * n0 + q]; });
-    load_state<D>(carry, [=](int k) { return S0[(int64_t)k * n0 + c]; });
-    int rc = chunk_smooth<D, LTI>(mv, c, L0, xs, carry, fs, Rnew, sRn, mean_out, var_out);
-    if (rc) atomicOr(bad, 1);
+    if (c < n0) {
+        const int64_t q = n0 - 1 - c;
+        load_state<D>(xs, [=](int k) { return S0r[(int64_t)k * n0 + q]; });
+        load_state<D>(carry, [=](int k) { return S0[(int64_t)k * n0 + c]; });
+    } else {
+        set_zero<D>(xs.m);
+        set_identity<D>(xs.P);
+        carry = xs;
+    }
+    int rc = chunk_smooth<D, LTI>(mv, c, L0, xs, carry, fs, sRn, io);
+    if (rc && c < n0) atomicOr(bad, 1);
 }
 
 // ---------------------------------------------------------------- affine pass 2
@@ -209,16 +296,23 @@ template <int D, bool LTI, bool RAND>
 __global__ __launch_bounds__(256) void k_apply_affine(ModelView mv, int L0, int64_t n0, const double* __restrict__ S0, const double* __restrict__ eps_t,
                                                       const double* __restrict__ eps_e, double* __restrict__ mean_out, double* __restrict__ var_out,
                                                       int* __restrict__ bad) {
-    int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (c >= n0) return;
+    using IO = WaveIO<RAND, true, true, !RAND>;
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    IO io{eps_e, mv.R, mean_out, var_out, mv.sR != 0, IO::wave_base(), (int)(threadIdx.x & 63)};
     State<D> x;
-    load_state<D>(x, [=](int k) { return S0[(int64_t)k * n0 + c]; });
-    int rc = chunk_apply_affine<D, LTI, RAND>(mv, c, L0, x, eps_t, eps_e, mean_out, var_out);
-    if (rc) atomicOr(bad, 1);
+    if (c < n0) {
+        load_state<D>(x, [=](int k) { return S0[(int64_t)k * n0 + c]; });
+    } else {
+        set_zero<D>(x.m);
+        set_identity<D>(x.P);
+    }
+    int rc = chunk_apply_affine<D, LTI, RAND>(mv, c, L0, x, eps_t, io);
+    if (rc && c < n0) atomicOr(bad, 1);
 }
 
 // ---------------------------------------------------------------- per-D launch table (filled by tgp_inst_dN.hip)
 enum ScanMonoid { kFilter = 0, kAffineCov = 1, kAffineMean = 2 };
+constexpr int kScanE = 1;   // elements per lane in the block scans
 
 struct KernelTable {
     int d;
@@ -230,7 +324,7 @@ struct KernelTable {
     void (*reduce_affine)(bool lti, bool rnd, const ModelView&, int L0, int64_t n0, const double* eps_t, double* E0, int* bad, hipStream_t);
     void (*apply_affine)(bool lti, bool rnd, const ModelView&, int L0, int64_t n0, const double* S0, const double* eps_t,
                          const double* eps_e, double* mean_out, double* var_out, int* bad, hipStream_t);
-    // block scans: bs == 256 (intermediate levels) or 512 (single top block)
+    // block scans: bs == 256 (intermediate levels) or 512 (single top block); kScanE elements per lane
     void (*scan_reduce)(int monoid, const double* Ein, int64_t n, double* Ehi, int64_t nhi, hipStream_t);
     void (*scan_apply)(int monoid, int bs, const double* Ein, int64_t n, const double* carry, int64_t ncarry, double* S, double* fin,
                        hipStream_t);

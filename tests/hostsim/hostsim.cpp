@@ -132,7 +132,10 @@ template <int D, bool LTI> int run(const Args& a) {
         SoA E0;
         E0.init(Dim<D>::NF, n0);
         for (int64_t c = 0; c < n0; ++c)
-            chunk_reduce_filter<D, LTI>(mv, c, a.L0, [&](int k, double v) { E0.v[(size_t)k * n0 + c] = v; });
+        {
+            DirectIO io{mv.y, mv.R, nullptr, nullptr};
+            chunk_reduce_filter<D, LTI>(mv, c, a.L0, io, [&](int k, double v) { E0.v[(size_t)k * n0 + c] = v; });
+        }
         if (a.elem_out) total_elem<D, FM<D>>(E0, a.elem_out);
         if (a.what == 5) return 0;
         std::vector<State<D>> S0;
@@ -151,9 +154,10 @@ template <int D, bool LTI> int run(const Args& a) {
             State<D> x = S0[c];
             ChunkStats cs;
             auto nost = [](int, double) {};
-            if (a.what == 0) cs = chunk_apply_filter<D, LTI, 0>(mv, c, a.L0, x, fo, nost);
-            else if (a.what == 1) cs = chunk_apply_filter<D, LTI, 1>(mv, c, a.L0, x, fo, nost);
-            else cs = chunk_apply_filter<D, LTI, 2>(mv, c, a.L0, x, fo, [&](int k, double v) { R0.v[(size_t)k * n0 + (n0 - 1 - c)] = v; });
+            DirectIO io{mv.y, mv.R, nullptr, nullptr};
+            if (a.what == 0) cs = chunk_apply_filter<D, LTI, 0>(mv, c, a.L0, x, fo, io, nost);
+            else if (a.what == 1) cs = chunk_apply_filter<D, LTI, 1>(mv, c, a.L0, x, fo, io, nost);
+            else cs = chunk_apply_filter<D, LTI, 2>(mv, c, a.L0, x, fo, io, [&](int k, double v) { R0.v[(size_t)k * n0 + (n0 - 1 - c)] = v; });
             lml += cs.lml;
             nmiss += cs.nmiss;
             bad |= cs.bad;
@@ -171,7 +175,8 @@ template <int D, bool LTI> int run(const Args& a) {
             hier_scan<D, AM<D, true>>(R0, seed, S0r, fin_r, a.BS);
             for (int64_t c = 0; c < n0; ++c) {
                 State<D> xs = S0r[n0 - 1 - c];
-                bad |= chunk_smooth<D, LTI>(mv, c, a.L0, xs, S0[c], fs.data(), a.Rnew, a.sRn, a.mean_out, a.var_out);
+                DirectIO io{nullptr, a.Rnew, a.mean_out, a.var_out};
+                bad |= chunk_smooth<D, LTI>(mv, c, a.L0, xs, S0[c], fs.data(), a.sRn, io);
             }
         }
     } else {
@@ -188,8 +193,9 @@ template <int D, bool LTI> int run(const Args& a) {
         else hier_scan<D, AM<D, false>>(E0, x0, S0, fin, a.BS);
         for (int64_t c = 0; c < n0; ++c) {
             State<D> x = S0[c];
-            if (a.what == 3) bad |= chunk_apply_affine<D, LTI, false>(mv, c, a.L0, x, nullptr, nullptr, a.mean_out, a.var_out);
-            else bad |= chunk_apply_affine<D, LTI, true>(mv, c, a.L0, x, a.eps_t, a.eps_e, a.mean_out, nullptr);
+            DirectIO io{a.eps_e, mv.R, a.mean_out, a.what == 3 ? a.var_out : nullptr};
+            if (a.what == 3) bad |= chunk_apply_affine<D, LTI, false>(mv, c, a.L0, x, nullptr, io);
+            else bad |= chunk_apply_affine<D, LTI, true>(mv, c, a.L0, x, a.eps_t, io);
         }
     }
     return bad ? 2 : 0;

@@ -113,6 +113,31 @@ def test_random_lgssm(tgp, d, tv):
     check_all(tgp, model, ref.rand(model, *eps), eps, chunk=2)
 
 
+@pytest.mark.parametrize("d", [1, 2, 3, 4, 5, 6, 7, 8])
+def test_multilevel_scan_every_d(tgp, d):
+    """n0 = 3000 chunk elements -> two scan levels + top, for every compiled state dimension."""
+    rng = np.random.default_rng(70 + d)
+    T = 6000
+    model = U.random_lgssm(rng, False, d, T)
+    model["R"] = rng.random(T) + 0.1                      # per-step R through the staged IO
+    eps = (rng.standard_normal((T, d)), rng.standard_normal(T), rng.standard_normal(d))
+    y = sk.rand(model, *eps)
+    dm = to_device_model(tgp, model)
+    dm.handle().set_option(tgp._lib.OPT_CHUNK, 2)
+    lp = sk.logpdf(model, y)
+    assert abs(tgp.logpdf(dm, y) - lp) <= 1e-10 * abs(lp)
+    Rn = rng.random(T) * 0.1
+    pm, pv = sk.posterior_marginals(model, y, Rn)
+    gm, gv = tgp.posterior_marginals(dm, y, Rn)
+    np.testing.assert_allclose(gm, pm, rtol=1e-8, atol=1e-8)
+    np.testing.assert_allclose(gv, pv, rtol=1e-8, atol=1e-9)
+    mm, mv = sk.prior_marginals(model)
+    gm, gv = tgp.marginals(dm)
+    np.testing.assert_allclose(gm, mm, rtol=1e-10, atol=1e-11)
+    np.testing.assert_allclose(gv, mv, rtol=1e-10, atol=1e-11)
+    np.testing.assert_allclose(tgp.rand(eps, dm), y, rtol=1e-9, atol=1e-9)
+
+
 @pytest.mark.parametrize("tv", [True, False])
 def test_missing(tgp, tv):
     rng = np.random.default_rng(3)
