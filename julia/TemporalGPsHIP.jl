@@ -1,0 +1,176 @@
+# TemporalGPsHIP.jl -- Julia-side glue for the MI355X backend (libtgp_hip.so, include/tgp_hip.h).
+#
+# NOT EXECUTED IN THIS REPOSITORY'S CI: neither the build image nor the GPU box has Julia
+# (gpurun_out/julia.txt). It is the binding a TemporalGPs.jl maintainer adds; every ccall below has an
+# executed twin in temporalgps.jl_amd/_lib.py + lgssm.py (ctypes), which is what the test-suite drives.
+#
+# Seam (reference, v0.7.3):
+#   StorageType tag given to `to_sde`          src/util/storage_types.jl:1,  src/gp/lti_sde.jl:12-16
+#   AbstractLGSSM interface                    src/models/lgssm.jl:1, test/test_util.jl:71-155
+#   build_lgssm(f::LTISDE, x, Σys)             src/gp/lti_sde.jl:71-80
+# Callers that stay UNCHANGED: src/gp/lti_sde.jl:33-68, src/gp/posterior_lti_sde.jl:18-78.
+module TemporalGPsHIP
+
+using TemporalGPs, AbstractGPs, FillArrays, StaticArrays, LinearAlgebra, Random
+import TemporalGPs: StorageType, AbstractLGSSM, LTISDE, build_lgssm, lgssm_components, get_mean, get_kernel,
+    posterior, marginals_diag, replace_observation_noise_cov, _filter, x0, ordering, Forward, Reverse, Gaussian,
+    SArrayStorage
+
+const libtgp = get(ENV, "TGP_HIP_LIB", "libtgp_hip.so")
+
+# flags (include/tgp_hip.h)
+const SHARED_A, SHARED_a, SHARED_Q, SHARED_H, SHARED_h, SHARED_R = (UInt32(1) << i for i in 0:5)
+
+struct HIPStorage{T<:Real} <: StorageType{T}
+    device::Int
+end
+HIPStorage(::Type{Float64}=Float64; device::Int=0) = HIPStorage{Float64}(device)
+
+mutable struct Handle
+    ptr::Ptr{Cvoid}
+    function Handle(device::Integer)
+        r = Ref{Ptr{Cvoid}}(C_NULL)
+        rc = ccall((:tgp_create, libtgp), Cint, (Ref{Ptr{Cvoid}}, Cint), r, device)
+        rc == 0 || error("tgp_create failed with code $rc (is an MI355X visible?)")
+        h = new(r[])
+        finalizer(x -> ccall((:tgp_destroy, libtgp), Cint, (Ptr{Cvoid},), x.ptr), h)
+        return h
+    end
+end
+
+function check(h::Handle, rc::Cint)
+    rc == 0 && return nothing
+    msg = unsafe_string(ccall((:tgp_last_error, libtgp), Cstring, (Ptr{Cvoid},), h.ptr))
+    rc == 2 && throw(PosDefException(0))          # mirrors cholesky / sqrt failures on the CPU path
+    throw(error("libtgp_hip error $rc: $msg"))
+end
+
+"""Device-backed LGSSM: the flat column-major blocks live in `bufs` (host) and are uploaded once."""
+struct DeviceLGSSM{Tord} <: AbstractLGSSM
+    ordering::Tord
+    h::Handle
+    T::Int
+    d::Int
+    bufs::NamedTuple      # A, a, Q, H, hh, R :: Vector{Float64}; keeps the host copies alive
+    flags::UInt32
+    x0::Gaussian
+end
+
+Base.length(m::DeviceLGSSM) = m.T
+Base.eachindex(m::DeviceLGSSM{Forward}) = 1:m.T
+Base.eachindex(m::DeviceLGSSM{Reverse}) = reverse(1:m.T)
+TemporalGPs.ordering(m::DeviceLGSSM) = m.ordering
+TemporalGPs.x0(m::DeviceLGSSM) = m.x0
+TemporalGPs.storage_type(::DeviceLGSSM) = HIPStorage(Float64)
+
+# Fill => one shared block + TGP_SHARED_* bit; Vector => per-step blocks (lti_sde.jl:135-160)
+_flat(x::Fill) = (collect(Float64, vec(Array(first(x)))), true)
+_flat(x::AbstractVector) = (reduce(vcat, (collect(Float64, vec(Array(xi))) for xi in x)), false)
+_flat(x::Fill{<:Real}) = ([Float64(first(x))], true)
+_flat(x::AbstractVector{<:Real}) = (collect(Float64, x), false)
+
+function DeviceLGSSM(ord, As, as, Qs, Hs, hs, Σs, x0::Gaussian, device::Int)
+    T, d = length(As), length(first(as))
+    (A, sA), (a, sa), (Q, sQ) = _flat(As), _flat(as), _flat(Qs)
+    (H, sH), (hh, sh), (R, sR) = _flat(Hs), _flat(hs), _flat(Σs)
+    flags = UInt32(0)
+    for (bit, s) in zip((SHARED_A, SHARED_a, SHARED_Q, SHARED_H, SHARED_h, SHARED_R), (sA, sa, sQ, sH, sh, sR))
+        s && (flags |= bit)
+    end
+    h = Handle(device)
+    x0m, x0P = collect(Float64, x0.m), collect(Float64, vec(Array(x0.P)))
+    GC.@preserve A a Q H hh R x0m x0P begin
+        check(h, ccall((:tgp_model_set, libtgp), Cint,
+            (Ptr{Cvoid}, Int64, Cint, Cint, Cint, UInt32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+             Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+            h.ptr, T, d, 1, ord isa Forward ? 0 : 1, flags, A, a, Q, H, hh, R, x0m, x0P))
+    end
+    return DeviceLGSSM(ord, h, T, d, (; A, a, Q, H, hh, R), flags, x0)
+end
+
+# The one method that selects the backend: components are built by the reference's own host code
+# (SArrayStorage flavour), then packed (lti_sde.jl:71-80).
+function TemporalGPs.build_lgssm(f::LTISDE{<:GP,<:HIPStorage}, x::AbstractVector, Σys::AbstractVector)
+    As, as, Qs, (Hs, hs), x0 = lgssm_components(get_mean(f), get_kernel(f), x, SArrayStorage(Float64))
+    return DeviceLGSSM(Forward(), As, as, Qs, Hs, hs, Σys, x0, f.storage.device)
+end
+
+_split_missing(y::AbstractVector{<:Real}) = (collect(Float64, y), C_NULL, nothing)
+function _split_missing(y::AbstractVector{Union{Missing,T}}) where {T<:Real}
+    mask = UInt8.(ismissing.(y))
+    return (Float64[ismissing(v) ? 0.0 : v for v in y], pointer(mask), mask)
+end
+
+function AbstractGPs.logpdf(m::DeviceLGSSM, y::AbstractVector{<:Union{Missing,Real}})
+    length(m) == length(y) || throw(error("Dimension mismatch. length(prior) is $(length(m)), but length(y) is $(length(y))"))
+    yv, mp, mask = _split_missing(y)
+    out = Ref{Float64}(0.0)
+    GC.@preserve yv mask check(m.h, ccall((:tgp_logpdf, libtgp), Cint,
+        (Ptr{Cvoid}, Ptr{Float64}, Ptr{UInt8}, UInt32, Ref{Float64}), m.h.ptr, yv, mp, UInt32(0), out))
+    return out[]
+end
+
+function TemporalGPs._filter(m::DeviceLGSSM, y::AbstractVector)
+    yv, mp, mask = _split_missing(y)
+    ms, Ps = Matrix{Float64}(undef, m.d, m.T), Array{Float64,3}(undef, m.d, m.d, m.T)
+    GC.@preserve yv mask check(m.h, ccall((:tgp_filter, libtgp), Cint,
+        (Ptr{Cvoid}, Ptr{Float64}, Ptr{UInt8}, UInt32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+        m.h.ptr, yv, mp, UInt32(0), ms, Ps, C_NULL))
+    return [Gaussian(ms[:, t], Ps[:, :, t]) for t in 1:m.T]
+end
+
+function TemporalGPs.posterior(m::DeviceLGSSM{Forward}, y::AbstractVector)
+    length(m) == length(y) || throw(error("Dimension mismatch. length(prior) is $(length(m)), but length(y) is $(length(y))"))
+    yv, mp, mask = _split_missing(y)
+    G, g, L = Array{Float64,3}(undef, m.d, m.d, m.T), Matrix{Float64}(undef, m.d, m.T), Array{Float64,3}(undef, m.d, m.d, m.T)
+    xfm, xfP = Vector{Float64}(undef, m.d), Matrix{Float64}(undef, m.d, m.d)
+    GC.@preserve yv mask check(m.h, ccall((:tgp_posterior, libtgp), Cint,
+        (Ptr{Cvoid}, Ptr{Float64}, Ptr{UInt8}, UInt32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+        m.h.ptr, yv, mp, UInt32(0), G, g, L, xfm, xfP))
+    Gs, gs, Ls = [G[:, :, t] for t in 1:m.T], [g[:, t] for t in 1:m.T], [L[:, :, t] for t in 1:m.T]
+    Hs = m.flags & SHARED_H != 0 ? Fill(m.bufs.H, m.T) : [m.bufs.H[(t-1)*m.d+1:t*m.d] for t in 1:m.T]
+    hs = m.flags & SHARED_h != 0 ? Fill(m.bufs.hh[1], m.T) : m.bufs.hh
+    Rs = m.flags & SHARED_R != 0 ? Fill(m.bufs.R[1], m.T) : m.bufs.R
+    return DeviceLGSSM(Reverse(), Gs, gs, Ls, Hs, hs, Rs, Gaussian(xfm, xfP), 0)
+end
+
+function TemporalGPs.replace_observation_noise_cov(m::DeviceLGSSM, Σs_new::AbstractVector)
+    # re-bind the model with the new noise; the transition blocks are reused as they are
+    d, T = m.d, m.T
+    blk(v, n, shared) = shared ? Fill(v[1:n], T) : [v[(t-1)*n+1:t*n] for t in 1:T]
+    mat(v, shared) = shared ? Fill(reshape(v[1:d*d], d, d), T) : [reshape(v[(t-1)*d*d+1:t*d*d], d, d) for t in 1:T]
+    return DeviceLGSSM(m.ordering, mat(m.bufs.A, m.flags & SHARED_A != 0), blk(m.bufs.a, d, m.flags & SHARED_a != 0),
+        mat(m.bufs.Q, m.flags & SHARED_Q != 0), blk(m.bufs.H, d, m.flags & SHARED_H != 0),
+        m.flags & SHARED_h != 0 ? Fill(m.bufs.hh[1], T) : m.bufs.hh, Σs_new, m.x0, 0)
+end
+
+function AbstractGPs.marginals(m::DeviceLGSSM)
+    mean, var = Vector{Float64}(undef, m.T), Vector{Float64}(undef, m.T)
+    check(m.h, ccall((:tgp_marginals, libtgp), Cint, (Ptr{Cvoid}, UInt32, Ptr{Float64}, Ptr{Float64}),
+        m.h.ptr, UInt32(0), mean, var))
+    return [Gaussian(mean[t], var[t]) for t in 1:m.T]      # marginals(::Gaussian) -> Normal(mean, sqrt(var)), gaussian.jl:61-63
+end
+
+function AbstractGPs.rand(rng::AbstractRNG, m::DeviceLGSSM)
+    # randomness drawn in the reference's order (lgssm.jl:65-77): T transition vectors, T emission scalars, then x0
+    eps_t = randn(rng, m.d, m.T); eps_e = randn(rng, m.T); eps_0 = randn(rng, m.d)
+    y = Vector{Float64}(undef, m.T)
+    check(m.h, ccall((:tgp_rand, libtgp), Cint,
+        (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, UInt32, Ptr{Float64}),
+        m.h.ptr, eps_t, eps_e, eps_0, UInt32(0), y))
+    return y
+end
+
+"""Fused `marginals(replace_observation_noise_cov(posterior(model, y), Σs_new))` (posterior_lti_sde.jl:27-36):
+nothing is materialised on the host."""
+function posterior_marginals(m::DeviceLGSSM{Forward}, y::AbstractVector, Σs_new::AbstractVector{<:Real})
+    yv, mp, mask = _split_missing(y)
+    R, fl = Σs_new isa Fill ? ([Float64(first(Σs_new))], SHARED_R) : (collect(Float64, Σs_new), UInt32(0))
+    mean, var = Vector{Float64}(undef, m.T), Vector{Float64}(undef, m.T)
+    GC.@preserve yv mask R check(m.h, ccall((:tgp_posterior_marginals, libtgp), Cint,
+        (Ptr{Cvoid}, Ptr{Float64}, Ptr{UInt8}, Ptr{Float64}, UInt32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+        m.h.ptr, yv, mp, R, fl, mean, var, C_NULL))
+    return mean, var
+end
+
+end # module
