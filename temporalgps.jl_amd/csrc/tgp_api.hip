@@ -52,6 +52,15 @@ __global__ __launch_bounds__(256) void k_finalize(const double* __restrict__ par
     }
 }
 
+// model re-layout (once per model / chunk size)
+// Lane = chunk, so the (slow, strided) reads happen once here and every later pass reads coalesced rows.
+__global__ __launch_bounds__(256) void k_tile_model(ModelView raw, int d, uint32_t mask, int nc, int L0, int64_t n0, double* __restrict__ tile) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= n0) return;
+    for (int i = 0; i < L0; ++i) tile_one_step(raw, d, mask, nc, L0, c, i, tile);
+}
+
+
 namespace {
 
 struct DevBuf {
@@ -104,7 +113,10 @@ struct tgp_handle {
     bool have_model = false, lti = false;
     int64_t T = 0;
     int d = 0, p = 1, ordering = 0;
-    ModelView mv{};
+    ModelView mv{};       // what the kernels see (tile pointer valid after ensure_tiled)
+    ModelView raw{};      // the arrays as handed over (reference layout): source of the tiling
+    DevBuf tile;
+    int tile_L0 = 0;
     const KernelTable* kt = nullptr;
     DevBuf bA, ba, bQ, bH, bh, bR;
     std::vector<double> x0m, x0P;
@@ -381,10 +393,31 @@ int check_ready(tgp_handle* h) {
     return bind_device(h);
 }
 
+// General (per-step) layout: (re)build the time-tiled copy of the per-step arrays for the current chunk size.
+int ensure_tiled(tgp_handle* h) {
+    if (h->lti) return TGP_OK;
+    if (h->tile_L0 == h->L0 && h->mv.tile != nullptr) return TGP_OK;
+    const uint32_t mask = tile_mask_of(h->raw);
+    const int nc = tile_offset(mask, 0u, h->d);
+    const size_t n = (size_t)((h->n0 + 63) / 64) * 64 * (size_t)h->L0 * (size_t)nc;
+    HIPCHK(h->tile.ensure(n * sizeof(double)));
+    {
+        LaunchScope ls(h, "k_tile_model");
+        hipLaunchKernelGGL(k_tile_model, dim3((unsigned)((h->n0 + 255) / 256)), dim3(256), 0, h->stream, h->raw, h->d, mask, nc, h->L0,
+                           h->n0, h->tile.d());
+    }
+    h->mv.tile = h->tile.d();
+    h->mv.tile_nc = nc;
+    h->mv.tile_mask = mask;
+    h->tile_L0 = h->L0;
+    return TGP_OK;
+}
+
 // forward pass 1 + upward scans (skipped when the caller vouches for reuse)
 int forward_reduce(tgp_handle* h, uint32_t flags) {
     if ((flags & TGP_REUSE_REDUCE) && h->reduce_valid) return TGP_OK;
     choose_chunk(h);
+    TRY(ensure_tiled(h));
     TRY(scan_prepare(h, h->F, kFilter, h->n0));
     {
         LaunchScope ls(h, h->lti ? "k_reduce_filter<lti>" : "k_reduce_filter<per-step>");
@@ -520,7 +553,7 @@ int tgp_destroy(tgp_handle* h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     for (DevBuf* b : {&h->bA, &h->ba, &h->bQ, &h->bH, &h->bh, &h->bR, &h->bx0, &h->bx0r, &h->by, &h->bmiss, &h->bRnew, &h->beps_t,
-                      &h->beps_e, &h->bo1, &h->bo2, &h->bo3, &h->F.slab, &h->Rv.slab, &h->fs, &h->partial, &h->result, &h->segtmp})
+                      &h->beps_e, &h->bo1, &h->bo2, &h->bo3, &h->F.slab, &h->Rv.slab, &h->fs, &h->partial, &h->result, &h->segtmp, &h->tile})
         b->release();
     for (auto& e : h->ev)
         if (e) (void)hipEventDestroy(e);
@@ -605,6 +638,8 @@ int tgp_model_set(tgp_handle* h, int64_t T, int d, int p, int ordering, uint32_t
     mv.sR = (flags & TGP_SHARED_R) ? 0 : 1;
     const uint32_t lti_bits = TGP_SHARED_A | TGP_SHARED_a | TGP_SHARED_Q | TGP_SHARED_H | TGP_SHARED_h;
     h->lti = (flags & lti_bits) == lti_bits;
+    h->raw = mv;
+    h->tile_L0 = 0;
     h->x0m.assign(x0m, x0m + d);
     h->x0P.assign(x0P, x0P + d * d);
     TRY(upload_x0(h, h->bx0, x0m, x0P));
@@ -777,6 +812,7 @@ int tgp_smoother_backward(tgp_handle* h, const double* xs_m, const double* xs_P,
 static int affine_impl(tgp_handle* h, bool rnd, const double* x0dev, const double* eps_t, const double* eps_e, double* mean_dev,
                        double* var_dev) {
     choose_chunk(h);
+    TRY(ensure_tiled(h));
     h->reduce_valid = false;
     h->smoother_valid = false;
     const int monoid = rnd ? kAffineMean : kAffineCov;

@@ -32,13 +32,65 @@ struct ModelView {
     int64_t sA, sa, sQ, sH, sh, sR;  // stride in doubles per step; 0 == Fill (shared)
     const double* y;                 // [T]
     const uint8_t* missing;          // [T] or nullptr; 1 => y := 0, R := 1e15 (missings.jl:55-101)
+    // Time-tiled copy of the PER-STEP model arrays (general layout), in processing order:
+    //   tile[ ((chunk/64 * L0 + step_in_chunk) * tile_nc + component) * 64 + chunk%64 ]
+    // so that a wave (64 consecutive chunks) reads one component of one step as ONE coalesced 512-byte
+    // row. tile_mask says which arrays are in the record (order A, a, Q, H, h, R); the others are shared.
+    const double* tile;
+    int32_t tile_nc;
+    uint32_t tile_mask;
 };
+
+enum : uint32_t { kTileA = 1u, kTilea = 2u, kTileQ = 4u, kTileH = 8u, kTileh = 16u, kTileR = 32u };
+
+// offset (in doubles) of array `bit` inside one step record
+TGP_HD int tile_offset(uint32_t mask, uint32_t bit, int d) {
+    int off = 0;
+    if (bit == kTileA) return off;
+    if (mask & kTileA) off += d * d;
+    if (bit == kTilea) return off;
+    if (mask & kTilea) off += d;
+    if (bit == kTileQ) return off;
+    if (mask & kTileQ) off += d * d;
+    if (bit == kTileH) return off;
+    if (mask & kTileH) off += d;
+    if (bit == kTileh) return off;
+    if (mask & kTileh) off += 1;
+    if (bit == kTileR) return off;
+    if (mask & kTileR) off += 1;
+    return off;  // bit == 0: total record size
+}
 
 TGP_HD int64_t fs_index(int64_t c, int i, int k, int L0, int NS) {
     return ((((c >> 6) * L0 + i) * NS + k) << 6) + (c & 63);
 }
 
 TGP_HD int64_t step_index(const ModelView& mv, int64_t r) { return mv.ordering == 0 ? r : mv.T - 1 - r; }
+// storage index of the TRANSITION applied at processing step r (Reverse: the previous step's, r >= 1)
+TGP_HD int64_t trans_index(const ModelView& mv, int64_t r) { return mv.ordering == 0 ? r : mv.T - r; }
+
+// Writes processing step (c, i) of the per-step arrays of `raw` (reference layout: [T][...] blocks, strides
+// raw.s*) into the time-tiled record. Transitions are stored at the processing step that APPLIES them
+// (Reverse ordering: the previous storage index; the skipped predict at r = 0 is zero-filled).
+TGP_HD void tile_one_step(const ModelView& raw, int d, uint32_t mask, int nc, int L0, int64_t c, int i, double* tile) {
+    const int64_t r = c * (int64_t)L0 + i;
+    if (r >= raw.T) return;
+    const int64_t te = step_index(raw, r), tt = trans_index(raw, r);
+    const bool pred = !(raw.ordering != 0 && r == 0);
+    const int64_t base = fs_index(c, i, 0, L0, nc);
+    int off = 0;
+    if (mask & kTileA) { for (int k = 0; k < d * d; ++k) tile[base + (int64_t)(off + k) * 64] = pred ? raw.A[tt * raw.sA + k] : 0.0; off += d * d; }
+    if (mask & kTilea) { for (int k = 0; k < d; ++k) tile[base + (int64_t)(off + k) * 64] = pred ? raw.a[tt * raw.sa + k] : 0.0; off += d; }
+    if (mask & kTileQ) { for (int k = 0; k < d * d; ++k) tile[base + (int64_t)(off + k) * 64] = pred ? raw.Q[tt * raw.sQ + k] : 0.0; off += d * d; }
+    if (mask & kTileH) { for (int k = 0; k < d; ++k) tile[base + (int64_t)(off + k) * 64] = raw.H[te * raw.sH + k]; off += d; }
+    if (mask & kTileh) { tile[base + (int64_t)off * 64] = raw.h[te * raw.sh]; off += 1; }
+    if (mask & kTileR) { tile[base + (int64_t)off * 64] = raw.R[te * raw.sR]; off += 1; }
+}
+
+TGP_HD uint32_t tile_mask_of(const ModelView& raw) {
+    return (raw.sA ? kTileA : 0u) | (raw.sa ? kTilea : 0u) | (raw.sQ ? kTileQ : 0u) | (raw.sH ? kTileH : 0u) |
+           (raw.sh ? kTileh : 0u) | (raw.sR ? kTileR : 0u);
+}
 
 // Per-step SCALAR streams (y, per-step R, R_new in; mean/var out) are accessed through an IO object in
 // groups of G consecutive steps. A lane's chunk is contiguous in time, so lane-wise access is strided by
@@ -61,55 +113,69 @@ struct DirectIO {
     TGP_HD void flush(const ModelView&, int64_t, int, int) {}
 };
 
-// Loads one processing step. LTI == true: A, a, Q, H, h are shared and loaded once (hoisted).
+// Loads one processing step. LTI == true: A, a, Q, H, h are shared and loaded once (hoisted); only y and,
+// when per-step, R stream (through the IO). LTI == false: per-step arrays come from the time-tiled
+// record (coalesced rows), arrays not in the record are shared and hoisted.
 template <int D, bool LTI> struct StepLoader {
     double A[D * D], a[D], Q[D * D], H[D], h, R, y;
     bool do_predict, is_missing;
-    int64_t te, tt;
+    int64_t te;
+    int oA, oa, oQ, oH, oh, oR;
 
     TGP_HD void init(const ModelView& mv) {
-        if (LTI) {
-            TGP_UNROLL for (int i = 0; i < D * D; ++i) { A[i] = mv.A[i]; Q[i] = mv.Q[i]; }
-            TGP_UNROLL for (int i = 0; i < D; ++i) { a[i] = mv.a[i]; H[i] = mv.H[i]; }
-            h = mv.h[0];
+        const uint32_t m = LTI ? 0u : mv.tile_mask;
+        if (!(m & kTileA)) { TGP_UNROLL for (int i = 0; i < D * D; ++i) A[i] = mv.A[i]; }
+        if (!(m & kTileQ)) { TGP_UNROLL for (int i = 0; i < D * D; ++i) Q[i] = mv.Q[i]; }
+        if (!(m & kTilea)) { TGP_UNROLL for (int i = 0; i < D; ++i) a[i] = mv.a[i]; }
+        if (!(m & kTileH)) { TGP_UNROLL for (int i = 0; i < D; ++i) H[i] = mv.H[i]; }
+        if (!(m & kTileh)) h = mv.h[0];
+        if (!LTI) {
+            oA = tile_offset(m, kTileA, D); oa = tile_offset(m, kTilea, D); oQ = tile_offset(m, kTileQ, D);
+            oH = tile_offset(m, kTileH, D); oh = tile_offset(m, kTileh, D); oR = tile_offset(m, kTileR, D);
         }
     }
     TGP_HD void index(const ModelView& mv, int64_t r) {
-        if (mv.ordering == 0) { te = r; tt = r; do_predict = true; }
-        else { te = mv.T - 1 - r; tt = mv.T - r; do_predict = (r != 0); }
+        te = step_index(mv, r);
+        do_predict = !(mv.ordering != 0 && r == 0);
     }
-    TGP_HD void load_transition(const ModelView& mv) {
+    // c = chunk, i = step inside the chunk
+    TGP_HD void load_transition(const ModelView& mv, int64_t c, int i, int L0) {
         if (!LTI && do_predict) {
-            const double* pA = mv.A + tt * mv.sA;
-            const double* pQ = mv.Q + tt * mv.sQ;
-            const double* pa = mv.a + tt * mv.sa;
-            TGP_UNROLL for (int i = 0; i < D * D; ++i) { A[i] = pA[i]; Q[i] = pQ[i]; }
-            TGP_UNROLL for (int i = 0; i < D; ++i) a[i] = pa[i];
+            const double* p = mv.tile + fs_index(c, i, 0, L0, mv.tile_nc);
+            if (mv.tile_mask & kTileA) { TGP_UNROLL for (int k = 0; k < D * D; ++k) A[k] = p[(oA + k) * 64]; }
+            if (mv.tile_mask & kTileQ) { TGP_UNROLL for (int k = 0; k < D * D; ++k) Q[k] = p[(oQ + k) * 64]; }
+            if (mv.tile_mask & kTilea) { TGP_UNROLL for (int k = 0; k < D; ++k) a[k] = p[(oa + k) * 64]; }
         }
     }
-    // emission H, h (R separately: it may come through the staged IO)
-    TGP_HD void load_emission(const ModelView& mv) {
+    TGP_HD void load_emission(const ModelView& mv, int64_t c, int i, int L0) {
         if (!LTI) {
-            const double* pH = mv.H + te * mv.sH;
-            TGP_UNROLL for (int i = 0; i < D; ++i) H[i] = pH[i];
-            h = mv.h[te * mv.sh];
+            const double* p = mv.tile + fs_index(c, i, 0, L0, mv.tile_nc);
+            if (mv.tile_mask & kTileH) { TGP_UNROLL for (int k = 0; k < D; ++k) H[k] = p[(oH + k) * 64]; }
+            if (mv.tile_mask & kTileh) h = p[oh * 64];
         }
     }
-    TGP_HD void load_R_direct(const ModelView& mv) { R = mv.R[te * mv.sR]; }
-    // y via io.in0, per-step R via io.in1 (io.a1 == mv.R); shared R read once per step from mv.R[0]
-    template <class IO> TGP_HD void load_obs(const ModelView& mv, const IO& io, int i) {
-        R = (mv.sR == 0) ? mv.R[0] : io.in1(te, i);
-        y = io.in0(te, i);
+    // R of this step: tiled record (general layout) / shared scalar / staged stream (LTI with per-step R)
+    template <class IO> TGP_HD double load_R(const ModelView& mv, int64_t c, int i, int L0, const IO& io, int gi) const {
+        if (!LTI && (mv.tile_mask & kTileR)) return mv.tile[fs_index(c, i, oR, L0, mv.tile_nc)];
+        return (mv.sR == 0) ? mv.R[0] : io.in1(te, gi);
+    }
+    template <class IO> TGP_HD void load_obs(const ModelView& mv, int64_t c, int i, int L0, const IO& io, int gi) {
+        R = load_R(mv, c, i, L0, io, gi);
+        y = io.in0(te, gi);
         is_missing = (mv.missing != nullptr) && (mv.missing[te] != 0);
         if (is_missing) { y = 0.0; R = kLargeVar; }
     }
-    template <class IO> TGP_HD void load(const ModelView& mv, int64_t r, const IO& io, int i) {
+    // full step: i = step inside the chunk (r = c*L0 + i), gi = position inside the IO group
+    template <class IO> TGP_HD void load(const ModelView& mv, int64_t r, int64_t c, int i, int L0, const IO& io, int gi) {
         index(mv, r);
-        load_transition(mv);
-        load_emission(mv);
-        load_obs(mv, io, i);
+        load_transition(mv, c, i, L0);
+        load_emission(mv, c, i, L0);
+        load_obs(mv, c, i, L0, io, gi);
     }
 };
+
+// Whether the IO must stage mv.R: only the LTI family streams a per-step R through it.
+template <bool LTI> TGP_HD bool io_stages_R(const ModelView& mv) { return LTI && mv.sR != 0; }
 
 // ------------------------------------------------------------------------------------------ pass 1
 // Chunk bounds; lanes past the last chunk (c >= n0) get an empty range but still take part in the
@@ -133,7 +199,7 @@ TGP_HD void chunk_reduce_filter(const ModelView& mv, int64_t c, int L0, IO& io, 
         const int64_t rg = r0 + g;
         const int gend = (int)((r1 - rg) < IO::G ? (r1 - rg) : IO::G);
         for (int i = 0; i < gend; ++i) {
-            sl.load(mv, rg + i, io, i);
+            sl.load(mv, rg + i, c, g + i, L0, io, i);
             f_extend<D>(e, sl.do_predict, sl.A, sl.a, sl.Q, sl.H, sl.h, sl.R, sl.y);
         }
     }
@@ -172,9 +238,10 @@ TGP_HD ChunkStats chunk_apply_filter(const ModelView& mv, int64_t c, int L0, Sta
       io.begin(mv, c, g, L0);
       const int64_t rg = r0 + g;
       const int gend = (int)((r1 - rg) < IO::G ? (r1 - rg) : IO::G);
+      double sprod = 1.0, quad = 0.0;   // product of the group's innovation variances, sum of v^2 / S
       for (int gi = 0; gi < gend; ++gi) {
         const int64_t r = rg + gi;
-        sl.load(mv, r, io, gi);
+        sl.load(mv, r, c, g + gi, L0, io, gi);
         if (MODE == 2) {
             double mf[D], Pf[D * D];
             copy_n<D>(x.m, mf);
@@ -190,7 +257,13 @@ TGP_HD ChunkStats chunk_apply_filter(const ModelView& mv, int64_t c, int L0, Sta
         } else if (sl.do_predict) {
             predict<D>(sl.A, sl.a, sl.Q, x.m, x.P);
         }
-        cs.lml += update_scalar<D>(sl.H, sl.h, sl.R, sl.y, x.m, x.P, ok);
+        double S;
+        quad += update_scalar_nolog<D>(sl.H, sl.h, sl.R, sl.y, x.m, x.P, ok, S);
+        sprod *= S;
+        if (sprod > 1e100 || sprod < 1e-100) {   // keep the running product far from over/underflow
+            cs.lml -= 0.5 * log(sprod);
+            sprod = 1.0;
+        }
         cs.nmiss += sl.is_missing ? 1.0 : 0.0;
         if (MODE >= 1 && out.m_out) {
             TGP_UNROLL for (int i = 0; i < D; ++i) out.m_out[sl.te * D + i] = x.m[i];
@@ -205,6 +278,8 @@ TGP_HD ChunkStats chunk_apply_filter(const ModelView& mv, int64_t c, int L0, Sta
             store_state<D>(x, [=](int k, double v) { fs[fs_index(c, i, k, L0_, Dim<D>::NS)] = v; });
         }
       }
+      // lml of the group: -(n log 2pi + log prod S + sum v^2/S) / 2   (lgc.jl:254 summed over the group)
+      if (gend > 0) cs.lml -= 0.5 * (gend * kLog2Pi + log(sprod) + quad);
     }
     if (MODE == 2 && r1 > r0) store_aelem<D>(rev, rst);
     cs.bad = ok ? 0 : 1;
@@ -231,8 +306,8 @@ TGP_HD int chunk_smooth(const ModelView& mv, int64_t c, int L0, State<D>& xs, co
         for (int gi = gend - 1; gi >= 0; --gi) {
             const int64_t r = rg + gi;
             sl.index(mv, r);
-            sl.load_transition(mv);
-            sl.load_emission(mv);
+            sl.load_transition(mv, c, g + gi, L0);
+            sl.load_emission(mv, c, g + gi, L0);
             double mean, var;
             emit_scalar<D>(sl.H, sl.h, (sRn == 0) ? Rn_shared : io.in1(sl.te, gi), xs.m, xs.P, mean, var);
             io.out(sl.te, gi, mean, var);
@@ -282,12 +357,12 @@ TGP_HD int chunk_reduce_affine(const ModelView& mv, int64_t c, int L0, const dou
     if (RAND && LTI) ok = noise_factor<D>(sl.Q, Lq);
     for (int64_t r = r0; r < r1; ++r) {
         sl.index(mv, r);
-        sl.load_transition(mv);
+        sl.load_transition(mv, c, (int)(r - r0), L0);
         if (!sl.do_predict) continue;
         if (RAND) {
             if (!LTI) ok = noise_factor<D>(sl.Q, Lq) && ok;
             double cvec[D];
-            const double* ep = eps_t + sl.tt * D;
+            const double* ep = eps_t + trans_index(mv, r) * D;
             TGP_UNROLL for (int i = 0; i < D; ++i) {
                 double acc = sl.a[i];
                 TGP_UNROLL for (int k = 0; k <= i; ++k) acc = fma(Lq[i + k * D], ep[k], acc);
@@ -318,13 +393,13 @@ TGP_HD int chunk_apply_affine(const ModelView& mv, int64_t c, int L0, State<D>& 
       for (int gi = 0; gi < gend; ++gi) {
         const int64_t r = rg + gi;
         sl.index(mv, r);
-        sl.load_transition(mv);
-        sl.load_emission(mv);
-        const double R = (mv.sR == 0) ? mv.R[0] : io.in1(sl.te, gi);
+        sl.load_transition(mv, c, g + gi, L0);
+        sl.load_emission(mv, c, g + gi, L0);
+        const double R = sl.load_R(mv, c, g + gi, L0, io, gi);
         if (sl.do_predict) {
             if (RAND) {
                 if (!LTI) ok = noise_factor<D>(sl.Q, Lq) && ok;
-                const double* ep = eps_t + sl.tt * D;
+                const double* ep = eps_t + trans_index(mv, r) * D;
                 double xn[D];
                 mat_vec<D>(sl.A, x.m, xn);
                 TGP_UNROLL for (int i = 0; i < D; ++i) {

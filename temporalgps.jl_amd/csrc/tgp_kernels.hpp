@@ -127,7 +127,7 @@ template <int D, bool LTI>
 __global__ __launch_bounds__(256) void k_reduce_filter(ModelView mv, int L0, int64_t n0, double* __restrict__ E0) {
     using IO = WaveIO<true, true, false, false>;
     const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    IO io{mv.y, mv.R, nullptr, nullptr, mv.sR != 0, IO::wave_base(), (int)(threadIdx.x & 63)};
+    IO io{mv.y, mv.R, nullptr, nullptr, io_stages_R<LTI>(mv), IO::wave_base(), (int)(threadIdx.x & 63)};
     chunk_reduce_filter<D, LTI>(mv, c, L0, io, [=](int k, double v) { E0[(int64_t)k * n0 + c] = v; });
 }
 
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void k_apply_filter(ModelView mv, int L0, int6
     using IO = WaveIO<true, true, false, false>;
     __shared__ double sh[12];
     const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    IO io{mv.y, mv.R, nullptr, nullptr, mv.sR != 0, IO::wave_base(), (int)(threadIdx.x & 63)};
+    IO io{mv.y, mv.R, nullptr, nullptr, io_stages_R<LTI>(mv), IO::wave_base(), (int)(threadIdx.x & 63)};
     State<D> x;
     if (c < n0) {
         load_state<D>(x, [=](int k) { return S0[(int64_t)k * n0 + c]; });
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256) void k_apply_affine(ModelView mv, int L0, int6
                                                       int* __restrict__ bad) {
     using IO = WaveIO<RAND, true, true, !RAND>;
     const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    IO io{eps_e, mv.R, mean_out, var_out, mv.sR != 0, IO::wave_base(), (int)(threadIdx.x & 63)};
+    IO io{eps_e, mv.R, mean_out, var_out, io_stages_R<LTI>(mv), IO::wave_base(), (int)(threadIdx.x & 63)};
     State<D> x;
     if (c < n0) {
         load_state<D>(x, [=](int k) { return S0[(int64_t)k * n0 + c]; });

@@ -142,6 +142,32 @@ template <int D> TGP_HD double update_scalar(const double* H, double h, double R
     return -(kLog2Pi + 2.0 * log(sqrtS) + alpha * alpha) * 0.5;
 }
 
+// Same update with the transcendental work trimmed for the device hot loop: one reciprocal of S instead of
+// sqrt + reciprocal (B'B = V'V / S, B'alpha = V' v / S), and the log is left to the caller, who takes ONE log
+// of the product of up to 8 consecutive S (log prod = sum log up to rounding). Returns v^2 / S; S in S_out.
+template <int D> TGP_HD double update_scalar_nolog(const double* H, double h, double R, double y, double* m, double* P, bool& ok, double& S_out) {
+    double V[D];
+    TGP_UNROLL for (int j = 0; j < D; ++j) {
+        double acc = 0.0;
+        TGP_UNROLL for (int k = 0; k < D; ++k) acc = fma(H[k], P[k + j * D], acc);
+        V[j] = acc;
+    }
+    double s2 = 0.0, hm = 0.0;
+    TGP_UNROLL for (int k = 0; k < D; ++k) { s2 = fma(V[k], H[k], s2); hm = fma(H[k], m[k], hm); }
+    const double S = s2 + R;
+    ok = ok && (S > 0.0);
+    const double iS = 1.0 / S;
+    const double v = y - (hm + h);
+    const double viS = v * iS;
+    TGP_UNROLL for (int i = 0; i < D; ++i) m[i] = fma(V[i], viS, m[i]);
+    TGP_UNROLL for (int j = 0; j < D; ++j) {
+        const double w = V[j] * iS;
+        TGP_UNROLL for (int i = 0; i < D; ++i) P[i + j * D] = fma(-V[i], w, P[i + j * D]);
+    }
+    S_out = S;
+    return v * viS;
+}
+
 // emission predict for scalar outputs: mean = H'm + h ; var = (H' Symmetric(P)) H + R
 template <int D> TGP_HD void emit_scalar(const double* H, double h, double R, const double* m, const double* P, double& mean, double& var) {
     double mu = 0.0, v = 0.0;

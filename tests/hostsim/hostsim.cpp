@@ -124,8 +124,17 @@ template <int D, class M> void total_elem(const SoA& E0, double* out) {
 }
 
 template <int D, bool LTI> int run(const Args& a) {
-    const ModelView& mv = a.mv;
+    ModelView mv = a.mv;
     int64_t n0 = (mv.T + a.L0 - 1) / a.L0;
+    std::vector<double> tile;
+    if (!LTI) {   // general layout: time-tiled copy of the per-step arrays, as tgp_api.hip builds on the device
+        mv.tile_mask = tile_mask_of(mv);
+        mv.tile_nc = tile_offset(mv.tile_mask, 0u, D);
+        tile.assign((size_t)((n0 + 63) / 64) * 64 * a.L0 * (mv.tile_nc > 0 ? mv.tile_nc : 1), 0.0);
+        for (int64_t c = 0; c < n0; ++c)
+            for (int i = 0; i < a.L0; ++i) tile_one_step(a.mv, D, mv.tile_mask, mv.tile_nc, a.L0, c, i, tile.data());
+        mv.tile = tile.data();
+    }
     State<D> x0 = make_state<D>(a.x0m, a.x0P);
     int bad = 0;
     if (a.what <= 2 || a.what == 5) {
@@ -213,7 +222,7 @@ extern "C" int hostsim_run(int d, int lti, int what, int L0, int BS, int64_t T, 
                            double* mean_out, double* var_out, const double* eps_t, const double* eps_e, double* elem_out,
                            double* rev_out, const double* xs_m, const double* xs_P) {
     Args a;
-    a.mv = ModelView{T, ordering, 0, A, av, Q, H, h, R, sA, sa, sQ, sH, sh, sR, y, missing};
+    a.mv = ModelView{T, ordering, 0, A, av, Q, H, h, R, sA, sa, sQ, sH, sh, sR, y, missing, nullptr, 0, 0u};
     a.x0m = x0m; a.x0P = x0P; a.L0 = L0; a.BS = BS; a.lml = lml; a.m_out = m_out; a.P_out = P_out;
     a.G_out = G_out; a.g_out = g_out; a.L_out = L_out; a.xfm = xfm; a.xfP = xfP; a.Rnew = Rnew; a.sRn = sRn;
     a.mean_out = mean_out; a.var_out = var_out; a.eps_t = eps_t; a.eps_e = eps_e; a.what = what;
