@@ -280,11 +280,14 @@ int aelem_size(int d) { return d * d + d + d * (d + 1) / 2; }
 void choose_chunk(tgp_handle* h) {
     int64_t L0 = h->opt_chunk;
     if (L0 <= 0) {
-        // aim at ~4 waves per SIMD (256 CUs x 4 SIMDs x 64 lanes x 4) before growing the chunk
-        const int64_t lanes = 256LL * 4 * 64 * 4;
-        L0 = (h->T + lanes - 1) / lanes;
+        // One lane per chunk, 256-lane workgroups, 256 CUs: kernel time goes with ceil(workgroups / 256), so
+        // size the chunk to land just under k full rounds of 256 workgroups (measured at T = 1e7, d = 3:
+        // L0 = 80 (k = 2) 1.12 ms/step; 96: 1.14; 128: 1.38; 160 (k = 1): 1.19; 39 (k = 4): 1.24).
+        const int64_t round = 256LL * 256;
+        int64_t k = (h->T + round * 160 - 1) / (round * 160);
+        if (k < 2) k = 2;
+        L0 = (h->T + round * k - 1) / (round * k);
         if (L0 < 8) L0 = 8;
-        if (L0 > 64) L0 = 64;
     }
     if (L0 > h->T) L0 = h->T > 0 ? h->T : 1;
     h->L0 = (int)L0;
@@ -454,7 +457,8 @@ int forward_apply(tgp_handle* h, int mode, const FilterOut& fo) {
     {
         const char* nm = mode == 0 ? (h->lti ? "k_apply_filter<lti,logpdf>" : "k_apply_filter<per-step,logpdf>")
                          : mode == 1 ? (h->lti ? "k_apply_filter<lti,filter>" : "k_apply_filter<per-step,filter>")
-                                     : (h->lti ? "k_apply_filter<lti,posterior>" : "k_apply_filter<per-step,posterior>");
+                         : mode == 2 ? (h->lti ? "k_apply_filter<lti,posterior>" : "k_apply_filter<per-step,posterior>")
+                                     : (h->lti ? "k_apply_filter<lti,materialise>" : "k_apply_filter<per-step,materialise>");
         LaunchScope ls(h, nm);
         h->kt->apply_filter(h->lti, mode, h->mv, h->L0, h->n0, h->F.S[0], fo, R0, h->partial.d(), h->stream);
     }
@@ -703,7 +707,7 @@ int tgp_posterior(tgp_handle* h, const double* y, const uint8_t* missing, uint32
     TRY(stage_out(h, h->bo1, G, nG, odev, &fo.G_out));
     TRY(stage_out(h, h->bo2, g, ng, odev, &fo.g_out));
     TRY(stage_out(h, h->bo3, L, nG, odev, &fo.L_out));
-    TRY(forward_apply(h, 2, fo));
+    TRY(forward_apply(h, (G != nullptr) ? 3 : 0, fo));
     tm.kernels_done();
     TRY(copy_back(h, G, fo.G_out, nG, odev));
     TRY(copy_back(h, g, fo.g_out, ng, odev));

@@ -222,8 +222,13 @@ struct ChunkStats {
     int32_t bad;  // 1 => non-positive innovation variance / Cholesky failure inside this chunk
 };
 
-// MODE 0: logpdf only. MODE 1: + filtering distributions. MODE 2: + filtered-state scratch, reverse
-// (smoother) chunk element, optional (G, g, L) output.  `rst` stores the reverse element (MODE 2).
+// MODE 0: logpdf only. MODE 1: + filtering distributions. MODE 2: smoother forward pass -- filtering-state
+// scratch + the chunk's smoother element, composed step by step from the reference's own (jittered)
+// invert_dynamics and stored through `rst`. MODE 3: materialise the posterior model: per-step
+// invert_dynamics -> (G, g, L) outputs (lgssm.jl:215-221), no scratch, no element.
+// (A chunk-level closed form of the smoother element from the chunk's filter element -- chunk_smoother_element,
+// tgp_math.hpp -- needs no per-step work, but it is the EXACT smoother: it differs from the reference's
+// 1e-10-jittered recursion by up to 2.5e-8 on the bench parametrisation, so it is not used.)
 template <int D, bool LTI, int MODE, class IO, typename RStore>
 TGP_HD ChunkStats chunk_apply_filter(const ModelView& mv, int64_t c, int L0, State<D>& x, const FilterOut& out, IO& io, RStore rst) {
     int64_t r0, r1;
@@ -242,17 +247,17 @@ TGP_HD ChunkStats chunk_apply_filter(const ModelView& mv, int64_t c, int L0, Sta
       for (int gi = 0; gi < gend; ++gi) {
         const int64_t r = rg + gi;
         sl.load(mv, r, c, g + gi, L0, io, gi);
-        if (MODE == 2) {
+        if (MODE >= 2) {
             double mf[D], Pf[D * D];
             copy_n<D>(x.m, mf);
             copy_n<D * D>(x.P, Pf);
             predict<D>(sl.A, sl.a, sl.Q, x.m, x.P);
-            double G[D * D], g[D], L[D * D];
-            ok = invert_dynamics<D>(mf, Pf, x.m, x.P, sl.A, G, g, L) && ok;
-            a_extend_right<D>(rev, G, g, L);
-            if (out.G_out) {
+            double G[D * D], g_[D], L[D * D];
+            ok = invert_dynamics<D>(mf, Pf, x.m, x.P, sl.A, G, g_, L) && ok;
+            if (MODE == 2) a_extend_right<D>(rev, G, g_, L);
+            if (MODE == 3 && out.G_out) {
                 TGP_UNROLL for (int i = 0; i < D * D; ++i) { out.G_out[sl.te * D * D + i] = G[i]; out.L_out[sl.te * D * D + i] = L[i]; }
-                TGP_UNROLL for (int i = 0; i < D; ++i) out.g_out[sl.te * D + i] = g[i];
+                TGP_UNROLL for (int i = 0; i < D; ++i) out.g_out[sl.te * D + i] = g_[i];
             }
         } else if (sl.do_predict) {
             predict<D>(sl.A, sl.a, sl.Q, x.m, x.P);

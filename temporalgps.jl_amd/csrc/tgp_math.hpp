@@ -23,6 +23,18 @@
 
 #define TGP_UNROLL _Pragma("unroll")
 
+// State dimensions >= TGP_BIG_D do not fit one lane's register file (d = 6: ~800 VGPRs of live matrices
+// against 512): fully inlined, hipcc 7.2 spills hundreds of VGPRs and SGPRs and we measured silently wrong
+// results from that path. For those D the per-step / per-combine building blocks are real (noinline)
+// device functions: each has a small register footprint and the matrices live in the lane's private
+// (scratch) memory by construction. d <= 4 stays fully inlined in registers.
+#define TGP_BIG_D 5
+#if defined(__HIPCC__)
+#define TGP_NOINLINE __host__ __device__ __attribute__((noinline))
+#else
+#define TGP_NOINLINE __attribute__((noinline))
+#endif
+
 namespace tgp {
 
 constexpr double kLog2Pi = 1.8378770664093454835606594728112;
@@ -107,7 +119,7 @@ template <int D, typename Load> TGP_HD void load_sym(double* P, Load ld, int bas
 
 // ---------------------------------------------------------------- reference per-step maths
 // predict: m <- A m + a ; P <- (A Symmetric(P)) A' + Q
-template <int D> TGP_HD void predict(const double* A, const double* a, const double* Q, double* m, double* P) {
+template <int D> TGP_HD void predict_impl(const double* A, const double* a, const double* Q, double* m, double* P) {
     double mp[D], AS[D * D];
     sym_upper<D>(P);
     mat_vec<D>(A, m, mp);
@@ -121,7 +133,7 @@ template <int D> TGP_HD void predict(const double* A, const double* a, const dou
 }
 
 // ScalarOutputLGC update; returns lml. `ok` is cleared when S is not positive (Julia: DomainError).
-template <int D> TGP_HD double update_scalar(const double* H, double h, double R, double y, double* m, double* P, bool& ok) {
+template <int D> TGP_HD double update_scalar_impl(const double* H, double h, double R, double y, double* m, double* P, bool& ok) {
     double V[D];
     TGP_UNROLL for (int j = 0; j < D; ++j) {
         double acc = 0.0;
@@ -145,7 +157,7 @@ template <int D> TGP_HD double update_scalar(const double* H, double h, double R
 // Same update with the transcendental work trimmed for the device hot loop: one reciprocal of S instead of
 // sqrt + reciprocal (B'B = V'V / S, B'alpha = V' v / S), and the log is left to the caller, who takes ONE log
 // of the product of up to 8 consecutive S (log prod = sum log up to rounding). Returns v^2 / S; S in S_out.
-template <int D> TGP_HD double update_scalar_nolog(const double* H, double h, double R, double y, double* m, double* P, bool& ok, double& S_out) {
+template <int D> TGP_HD double update_scalar_nolog_impl(const double* H, double h, double R, double y, double* m, double* P, bool& ok, double& S_out) {
     double V[D];
     TGP_UNROLL for (int j = 0; j < D; ++j) {
         double acc = 0.0;
@@ -201,11 +213,11 @@ template <int D> TGP_HD bool chol_upper(const double* S, double* U) {
 }
 
 // invert_dynamics (lgssm.jl:231-238): filtered (mf,Pf), predicted (mp,Pp), transition A -> (G,g,L)
-template <int D> TGP_HD bool invert_dynamics(const double* mf, const double* Pf, const double* mp, const double* Pp,
-                                             const double* A, double* G, double* g, double* L) {
+template <int D> TGP_HD bool invert_dynamics_impl(const double* mf, const double* Pf, const double* mp, const double* Pp,
+                                             const double* A, double* G, double* g, double* L, double jitter) {
     double Pj[D * D], U[D * D], Gt[D * D], UG[D * D];
     copy_n<D * D>(Pp, Pj);
-    TGP_UNROLL for (int i = 0; i < D; ++i) Pj[i + i * D] += 1e-10;
+    TGP_UNROLL for (int i = 0; i < D; ++i) Pj[i + i * D] += jitter;
     bool ok = chol_upper<D>(Pj, U);
     double invd[D];
     TGP_UNROLL for (int i = 0; i < D; ++i) invd[i] = 1.0 / U[i + i * D];
@@ -302,7 +314,7 @@ template <int D> struct FElem {
 };
 
 // out = later(j) o earlier(i)
-template <int D> TGP_HD void f_combine(const FElem<D>& ei, const FElem<D>& ej, FElem<D>& out) {
+template <int D> TGP_HD void f_combine_impl(const FElem<D>& ei, const FElem<D>& ej, FElem<D>& out) {
     double M[D * D], Minv[D * D], T1[D * D], T2[D * D], u[D], w[D];
     mat_mul<D>(ei.C, ej.J, M);  // C_i J_j
     TGP_UNROLL for (int i = 0; i < D; ++i) M[i + i * D] += 1.0;
@@ -342,7 +354,7 @@ template <int D> TGP_HD void f_combine(const FElem<D>& ei, const FElem<D>& ej, F
 }
 
 // posterior state after the run, given the state before it
-template <int D> TGP_HD void f_apply(const FElem<D>& e, const State<D>& in, State<D>& out) {
+template <int D> TGP_HD void f_apply_impl(const FElem<D>& e, const State<D>& in, State<D>& out) {
     double M[D * D], Minv[D * D], T1[D * D], T2[D * D], u[D], w[D];
     mat_mul<D>(in.P, e.J, M);
     TGP_UNROLL for (int i = 0; i < D; ++i) M[i + i * D] += 1.0;
@@ -362,7 +374,7 @@ template <int D> TGP_HD void f_apply(const FElem<D>& e, const State<D>& in, Stat
 // Extend a running element by ONE scalar-output Kalman step (cheap: no solve, rank-one update).
 // do_predict == false skips the transition (first processed step of a Reverse-ordered model).
 template <int D>
-TGP_HD void f_extend(FElem<D>& e, bool do_predict, const double* A, const double* a, const double* Q, const double* H,
+TGP_HD void f_extend_impl(FElem<D>& e, bool do_predict, const double* A, const double* a, const double* Q, const double* H,
                      double h, double R, double y) {
     if (do_predict) {
         double T1[D * D], T2[D * D], bp[D];
@@ -405,7 +417,7 @@ template <int D> struct AElem {
 };
 
 // out = later(j) o earlier(i)  (processing order; for the smoother "earlier" means later in time)
-template <int D, bool COV> TGP_HD void a_combine(const AElem<D>& ei, const AElem<D>& ej, AElem<D>& out) {
+template <int D, bool COV> TGP_HD void a_combine_impl(const AElem<D>& ei, const AElem<D>& ej, AElem<D>& out) {
     double nE[D * D], ng[D];
     mat_mul<D>(ej.E, ei.E, nE);
     mat_vec<D>(ej.E, ei.g, ng);
@@ -422,7 +434,7 @@ template <int D, bool COV> TGP_HD void a_combine(const AElem<D>& ei, const AElem
     copy_n<D * D>(nE, out.E);
 }
 
-template <int D, bool COV> TGP_HD void a_apply(const AElem<D>& e, const State<D>& in, State<D>& out) {
+template <int D, bool COV> TGP_HD void a_apply_impl(const AElem<D>& e, const State<D>& in, State<D>& out) {
     double nm[D];
     mat_vec<D>(e.E, in.m, nm);
     TGP_UNROLL for (int i = 0; i < D; ++i) out.m[i] = nm[i] + e.g[i];
@@ -438,7 +450,7 @@ template <int D, bool COV> TGP_HD void a_apply(const AElem<D>& e, const State<D>
 }
 
 // running composition in processing order:  e <- step o e   with step = (A, c, Q)
-template <int D, bool COV> TGP_HD void a_extend(AElem<D>& e, const double* A, const double* c, const double* Q) {
+template <int D, bool COV> TGP_HD void a_extend_impl(AElem<D>& e, const double* A, const double* c, const double* Q) {
     double T1[D * D], gp[D];
     mat_mul<D>(A, e.E, T1);
     copy_n<D * D>(T1, e.E);
@@ -454,7 +466,7 @@ template <int D, bool COV> TGP_HD void a_extend(AElem<D>& e, const double* A, co
 
 // running composition for the time-REVERSED chain while sweeping forward in time:
 //   x_s = E x_{k-1} + ghat + N(0, Lhat),  x_{k-1} = G x_k + g + N(0, L)   =>   e <- e o (G, g, L)
-template <int D> TGP_HD void a_extend_right(AElem<D>& e, const double* G, const double* g, const double* L) {
+template <int D> TGP_HD void a_extend_right_impl(AElem<D>& e, const double* G, const double* g, const double* L) {
     double T1[D * D], T2[D * D], eg[D];
     mat_vec<D>(e.E, g, eg);
     TGP_UNROLL for (int i = 0; i < D; ++i) e.g[i] += eg[i];
@@ -463,6 +475,86 @@ template <int D> TGP_HD void a_extend_right(AElem<D>& e, const double* G, const 
     TGP_UNROLL for (int i = 0; i < D * D; ++i) e.L[i] += T2[i];
     mat_mul<D>(e.E, G, T1);
     copy_n<D * D>(T1, e.E);
+}
+
+// ---------------------------------------------------------------- inline (d <= 4) / out-of-line (d >= 5) dispatch
+
+template <int D> TGP_NOINLINE void predict_out(const double* A, const double* a, const double* Q, double* m, double* P) { predict_impl<D>(A, a, Q, m, P); }
+template <int D> TGP_HD void predict(const double* A, const double* a, const double* Q, double* m, double* P) {
+    if constexpr (D >= TGP_BIG_D) { predict_out<D>(A, a, Q, m, P); } else { predict_impl<D>(A, a, Q, m, P); }
+}
+
+template <int D> TGP_NOINLINE double update_scalar_out(const double* H, double h, double R, double y, double* m, double* P, bool& ok) { return update_scalar_impl<D>(H, h, R, y, m, P, ok); }
+template <int D> TGP_HD double update_scalar(const double* H, double h, double R, double y, double* m, double* P, bool& ok) {
+    if constexpr (D >= TGP_BIG_D) { return update_scalar_out<D>(H, h, R, y, m, P, ok); } else { return update_scalar_impl<D>(H, h, R, y, m, P, ok); }
+}
+
+template <int D> TGP_NOINLINE double update_scalar_nolog_out(const double* H, double h, double R, double y, double* m, double* P, bool& ok, double& S_out) { return update_scalar_nolog_impl<D>(H, h, R, y, m, P, ok, S_out); }
+template <int D> TGP_HD double update_scalar_nolog(const double* H, double h, double R, double y, double* m, double* P, bool& ok, double& S_out) {
+    if constexpr (D >= TGP_BIG_D) { return update_scalar_nolog_out<D>(H, h, R, y, m, P, ok, S_out); } else { return update_scalar_nolog_impl<D>(H, h, R, y, m, P, ok, S_out); }
+}
+
+template <int D> TGP_NOINLINE bool invert_dynamics_out(const double* mf, const double* Pf, const double* mp, const double* Pp, const double* A, double* G, double* g, double* L, double jitter) { return invert_dynamics_impl<D>(mf, Pf, mp, Pp, A, G, g, L, jitter); }
+template <int D> TGP_HD bool invert_dynamics(const double* mf, const double* Pf, const double* mp, const double* Pp, const double* A, double* G, double* g, double* L, double jitter = 1e-10) {
+    if constexpr (D >= TGP_BIG_D) { return invert_dynamics_out<D>(mf, Pf, mp, Pp, A, G, g, L, jitter); } else { return invert_dynamics_impl<D>(mf, Pf, mp, Pp, A, G, g, L, jitter); }
+}
+
+template <int D> TGP_NOINLINE void f_combine_out(const FElem<D>& ei, const FElem<D>& ej, FElem<D>& out) { f_combine_impl<D>(ei, ej, out); }
+template <int D> TGP_HD void f_combine(const FElem<D>& ei, const FElem<D>& ej, FElem<D>& out) {
+    if constexpr (D >= TGP_BIG_D) { f_combine_out<D>(ei, ej, out); } else { f_combine_impl<D>(ei, ej, out); }
+}
+
+template <int D> TGP_NOINLINE void f_apply_out(const FElem<D>& e, const State<D>& in, State<D>& out) { f_apply_impl<D>(e, in, out); }
+template <int D> TGP_HD void f_apply(const FElem<D>& e, const State<D>& in, State<D>& out) {
+    if constexpr (D >= TGP_BIG_D) { f_apply_out<D>(e, in, out); } else { f_apply_impl<D>(e, in, out); }
+}
+
+template <int D, bool COV> TGP_NOINLINE void a_combine_out(const AElem<D>& ei, const AElem<D>& ej, AElem<D>& out) { a_combine_impl<D, COV>(ei, ej, out); }
+template <int D, bool COV> TGP_HD void a_combine(const AElem<D>& ei, const AElem<D>& ej, AElem<D>& out) {
+    if constexpr (D >= TGP_BIG_D) { a_combine_out<D, COV>(ei, ej, out); } else { a_combine_impl<D, COV>(ei, ej, out); }
+}
+
+template <int D, bool COV> TGP_NOINLINE void a_apply_out(const AElem<D>& e, const State<D>& in, State<D>& out) { a_apply_impl<D, COV>(e, in, out); }
+template <int D, bool COV> TGP_HD void a_apply(const AElem<D>& e, const State<D>& in, State<D>& out) {
+    if constexpr (D >= TGP_BIG_D) { a_apply_out<D, COV>(e, in, out); } else { a_apply_impl<D, COV>(e, in, out); }
+}
+
+template <int D, bool COV> TGP_NOINLINE void a_extend_out(AElem<D>& e, const double* A, const double* c, const double* Q) { a_extend_impl<D, COV>(e, A, c, Q); }
+template <int D, bool COV> TGP_HD void a_extend(AElem<D>& e, const double* A, const double* c, const double* Q) {
+    if constexpr (D >= TGP_BIG_D) { a_extend_out<D, COV>(e, A, c, Q); } else { a_extend_impl<D, COV>(e, A, c, Q); }
+}
+
+template <int D> TGP_NOINLINE void a_extend_right_out(AElem<D>& e, const double* G, const double* g, const double* L) { a_extend_right_impl<D>(e, G, g, L); }
+template <int D> TGP_HD void a_extend_right(AElem<D>& e, const double* G, const double* g, const double* L) {
+    if constexpr (D >= TGP_BIG_D) { a_extend_right_out<D>(e, G, g, L); } else { a_extend_right_impl<D>(e, G, g, L); }
+}
+
+template <int D> TGP_NOINLINE void f_extend_out(FElem<D>& e, bool do_predict, const double* A, const double* a, const double* Q, const double* H, double h, double R, double y) {
+    f_extend_impl<D>(e, do_predict, A, a, Q, H, h, R, y);
+}
+template <int D> TGP_HD void f_extend(FElem<D>& e, bool do_predict, const double* A, const double* a, const double* Q, const double* H, double h, double R, double y) {
+    if constexpr (D >= TGP_BIG_D) { f_extend_out<D>(e, do_predict, A, a, Q, H, h, R, y); } else { f_extend_impl<D>(e, do_predict, A, a, Q, H, h, R, y); }
+}
+
+// Smoother element of a whole chunk (s, e] WITHOUT per-step work, from quantities the forward pass already
+// has: the chunk's filter element, the filtering state before the chunk (xs) and after it (xe).
+//   p(x_s | y_{1:e})      = N(mt, Pt),  Pt = (I + P_s J)^-1 P_s,  mt = (I + P_s J)^-1 (m_s + P_s eta)
+//   x_e | x_s, y_{s+1:e}  = N(Abar x_s + b, C)            =>  x_s | x_e, y_{1:e} = N(E x_e + g, L)
+// which is invert_dynamics applied to (mt, Pt) -> (m_e, P_e) through Abar (no jitter: this is our own
+// chunk-level construct; the per-step 1e-10 jitter of lgssm.jl:235 stays where the reference has it).
+template <int D> TGP_HD bool chunk_smoother_element(const FElem<D>& e, const State<D>& xs, const State<D>& xe, AElem<D>& r) {
+    double M[D * D], Minv[D * D], Pt[D * D], u[D], mt[D];
+    mat_mul<D>(xs.P, e.J, M);
+    TGP_UNROLL for (int i = 0; i < D; ++i) M[i + i * D] += 1.0;
+    mat_inverse<D>(M, Minv);
+    mat_mul<D>(Minv, xs.P, Pt);
+    symmetrize<D>(Pt);
+    mat_vec<D>(xs.P, e.eta, u);
+    TGP_UNROLL for (int i = 0; i < D; ++i) u[i] += xs.m[i];
+    mat_vec<D>(Minv, u, mt);
+    bool ok = invert_dynamics<D>(mt, Pt, xe.m, xe.P, e.A, r.E, r.g, r.L, 0.0);
+    symmetrize<D>(r.L);
+    return ok;
 }
 
 // ---------------------------------------------------------------- packed (SoA) element / state I/O

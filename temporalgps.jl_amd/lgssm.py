@@ -137,6 +137,8 @@ class LGSSM:
         R, sR = self._blocks(em.R, 1)
         arrs = (A, a, Q, H, h, R)
         on_dev = [_lib.is_device(x) for x in arrs]
+        if any(on_dev):
+            _sync_torch(next(x for x in arrs if _lib.is_device(x)))
         if any(on_dev) and not all(on_dev):
             raise ValueError("model arrays must be all NumPy or all CUDA tensors")
         flags = 0
@@ -154,6 +156,13 @@ class LGSSM:
         self._handle = hd
         self._on_device = all(on_dev)
         return hd
+
+
+def _sync_torch(t):
+    """The library runs on its own HIP stream: make sure whatever torch has queued to produce a CUDA tensor
+    we are about to read has finished (torch ops are asynchronous on torch's current stream)."""
+    import torch
+    torch.cuda.current_stream(t.device).synchronize()
 
 
 def _to_numpy(x):
@@ -178,6 +187,7 @@ def _obs(y):
         import torch
         yy = y.to(torch.float64).contiguous()
         mm = None if mask is None else mask.to(torch.uint8).contiguous()
+        _sync_torch(yy)
         return yy, mm, True
     if isinstance(y, np.ma.MaskedArray):
         mask = np.ma.getmaskarray(y) if mask is None else mask
@@ -292,6 +302,7 @@ def rand(rng_or_eps, model):
     dev = _lib.is_device(eps_t)
     if dev:
         et, ee = eps_t.contiguous(), eps_e.contiguous()
+        _sync_torch(et)
     else:
         et = np.ascontiguousarray(_to_numpy(eps_t), dtype=np.float64)
         ee = np.ascontiguousarray(_to_numpy(eps_e), dtype=np.float64)

@@ -166,7 +166,16 @@ template <int D, bool LTI> int run(const Args& a) {
             DirectIO io{mv.y, mv.R, nullptr, nullptr};
             if (a.what == 0) cs = chunk_apply_filter<D, LTI, 0>(mv, c, a.L0, x, fo, io, nost);
             else if (a.what == 1) cs = chunk_apply_filter<D, LTI, 1>(mv, c, a.L0, x, fo, io, nost);
-            else cs = chunk_apply_filter<D, LTI, 2>(mv, c, a.L0, x, fo, io, [&](int k, double v) { R0.v[(size_t)k * n0 + (n0 - 1 - c)] = v; });
+            else {
+                if (a.G_out) {   // materialised posterior model (MODE 3) ...
+                    State<D> x3 = x;
+                    FilterOut f3{nullptr, nullptr, nullptr, a.G_out, a.g_out, a.L_out};
+                    ChunkStats c3 = chunk_apply_filter<D, LTI, 3>(mv, c, a.L0, x3, f3, io, nost);
+                    bad |= c3.bad;
+                }
+                FilterOut f2{nullptr, nullptr, fo.fs, nullptr, nullptr, nullptr};   // ... and the smoother forward pass (MODE 2)
+                cs = chunk_apply_filter<D, LTI, 2>(mv, c, a.L0, x, f2, io, [&](int k, double v) { R0.v[(size_t)k * n0 + (n0 - 1 - c)] = v; });
+            }
             lml += cs.lml;
             nmiss += cs.nmiss;
             bad |= cs.bad;
