@@ -60,6 +60,27 @@ def cpu_baseline(name, T_sample):
                        f"({T_sample / (t1 - t0):.3e} steps/s) + posterior marginals {t2 - t1:.3f}s")
 
 
+def pmc_traffic(kname, d, layout):
+    """HBM bytes per launch of `kname` from the committed PMC summary (profiles/r01_pmc_traffic.json: separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command, FETCH doubled per
+    MI355X_MICROARCH.md). None when the summary has no entry (other d / workload)."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    table = json.load(open(path)).get(layout, {})
+    lti = "true" if layout == "lti" else "false"
+    base = kname.split("<")[0]
+    mode = {"logpdf": 0, "filter": 1, "posterior": 2, "materialise": 3}
+    if base in ("k_reduce_filter", "k_smooth"):
+        key = f"{base}<{d}, {lti}>"
+    elif base == "k_apply_filter":
+        key = f"{base}<{d}, {lti}, {mode[kname.split(',')[1].rstrip('>')]}>"
+    else:
+        return None
+    ent = table.get(key)
+    return None if ent is None else ent["hbm_bytes"]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -156,8 +177,10 @@ def main():
             if lti and ("posterior" in kname or "smooth" in kname):
                 per_unit = 24
             ach = per_unit * Tseg / (avg_ms * 1e-3) / 1e9
+            traffic = pmc_traffic(kname, d, args.layout) if (T == 10_000_000 and world == 1) else None
             roof = dict(bound="hbm", kernel=kname, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
-                        traffic=None, avg_kernel_ms=avg_ms, algorithmic_bytes_per_step=per_unit,
+                        traffic=traffic, traffic_unit="bytes per launch (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, profiles/)",
+                        algorithmic_bytes=per_unit * Tseg, avg_kernel_ms=avg_ms, algorithmic_bytes_per_step=per_unit,
                         note=("LTI (Fill) layout streams only y in / (mean,var) out: this kernel is fp64-VALU bound, the HBM "
                               "fraction is reported for completeness" if lti else "per-step layout: HBM bound"))
         out = dict(
