@@ -60,6 +60,43 @@ def cpu_baseline(name, T_sample):
                        f"({T_sample / (t1 - t0):.3e} steps/s) + posterior marginals {t2 - t1:.3f}s")
 
 
+def general_layout_leg(tgp, torch, name, T, d, device, steps):
+    """The same series with the model in the GENERAL (per-step) layout -- every step carries its own A, a, Q, H, h, R
+    (what irregular spacing / prediction at new inputs produce, lti_sde.jl:135-146): the HBM-bound regime the
+    scan kernel's roofline target is stated for. Returns the roofline of its dominant kernel."""
+    model = build_model(tgp, name, T, "per_step", device)
+    hd = model.handle()
+    gen = torch.Generator(device=f"cuda:{device}")
+    gen.manual_seed(99)
+    y = torch.randn((T,), dtype=torch.float64, device=f"cuda:{device}", generator=gen)
+    Rnew = torch.full((1,), 1e-18, dtype=torch.float64, device=f"cuda:{device}")
+    for _ in range(2):
+        tgp.logpdf(model, y)
+        tgp.posterior_marginals(model, y, Rnew)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tgp.logpdf(model, y)
+        tgp.posterior_marginals(model, y, Rnew)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    hd.set_option(tgp._lib.OPT_PROFILE, 1)
+    hd.profile_reset()
+    for _ in range(steps):
+        tgp.logpdf(model, y)
+        tgp.posterior_marginals(model, y, Rnew)
+    hd.set_option(tgp._lib.OPT_PROFILE, 0)
+    prof = {k: v for k, v in hd.profile().items() if k.startswith(("k_reduce_filter", "k_apply_filter", "k_smooth"))}
+    kname, st = max(prof.items(), key=lambda kv: kv[1]["total_ms"])
+    avg_ms = st["total_ms"] / st["calls"]
+    per_unit = 8 * (2 * d * d + 2 * d + 3) + (24 if ("posterior" in kname or "smooth" in kname) else 0)
+    ach = per_unit * T / (avg_ms * 1e-3) / 1e9
+    return dict(bound="hbm", kernel=kname, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
+                traffic=pmc_traffic(kname, d, "per_step") if T == 10_000_000 else None, algorithmic_bytes=per_unit * T,
+                avg_kernel_ms=avg_ms, algorithmic_bytes_per_step=per_unit, steps_per_s=T / dt, ms_per_step=dt * 1e3,
+                kernels={k: dict(avg_ms=v["total_ms"] / max(1, v["calls"]), calls=v["calls"]) for k, v in hd.profile().items()})
+
+
 def pmc_traffic(kname, d, layout):
     """HBM bytes per launch of `kname` from the committed PMC summary (profiles/r01_pmc_traffic.json: separate
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command, FETCH doubled per
@@ -91,6 +128,7 @@ def main():
     ap.add_argument("--layout", default="lti", choices=["lti", "per_step"])
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-general-leg", action="store_true", help="skip the per-step-layout roofline leg")
     ap.add_argument("--cpu-sample", type=int, default=2_000_000)
     args = ap.parse_args()
 
@@ -193,6 +231,8 @@ def main():
             roofline=roof,
             kernels={k: dict(avg_ms=v["total_ms"] / max(1, v["calls"]), calls=v["calls"]) for k, v in prof.items()},
         )
+        if args.layout == "lti" and world == 1 and not args.no_general_leg:
+            out["roofline_general_layout"] = general_layout_leg(tgp, torch, name, T, d, local, max(3, args.steps // 2))
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(name, args.cpu_sample)
         print(json.dumps(out))

@@ -10,8 +10,13 @@
  *   - all reals are fp64, all sizes int64_t, matrices are column-major d x d blocks (Julia layout);
  *   - per-step arrays are [T][...] contiguous; an array flagged TGP_SHARED_* holds ONE block used by all
  *     steps (FillArrays.Fill: what RegularSpacing inputs produce, lti_sde.jl:148-160);
- *   - scalar observations only for now (p == 1, ScalarOutputLGC, linear_gaussian_conditionals.jl:225-257):
- *     H is the d-vector with emission.A = H', h and R are scalars per step;
+ *   - observations: p == 1 is ScalarOutputLGC (linear_gaussian_conditionals.jl:225-257): H is the d-vector with
+ *     emission.A = H', h and R scalars per step. p > 1 is SmallOutputLGC (lgc.jl:113-141) with DIAGONAL noise:
+ *     H is [T][p][d] (row j = emission.A[j, :], i.e. Julia's A' column-major), h [T][p], R [T][p] the noise
+ *     diagonal, y / missing / mean / var / eps_e are [T][p]. The p observations of a time step are absorbed as
+ *     p consecutive scalar updates (algebraically the joint update). A dense R must be whitened by the caller
+ *     (H <- L^-1 H, h <- L^-1 h, y <- L^-1 y, R <- I, lml -= sum log diag L); the Python mirror does that.
+ *     `marginals` / `posterior_marginals` return the DIAGONAL of the p x p marginal covariance.
  *   - ordering 0 = Forward, 1 = Reverse (gauss_markov_model.jl:1-9,38-40);
  *   - return codes: 0 ok; 1 bad argument / dimension mismatch (lgssm.jl:202-208); 2 not positive
  *     definite (Julia PosDefException / DomainError at lgc.jl:135,250, lgssm.jl:235); 3 HIP runtime error;
@@ -41,6 +46,7 @@ typedef struct tgp_handle tgp_handle;
 #define TGP_SHARED_h (1u << 4)
 #define TGP_SHARED_R (1u << 5) /* also: Rnew is one scalar in tgp_posterior_marginals */
 #define TGP_SHARED_ALL 0x3fu
+#define TGP_SMALL_OUTPUT (1u << 8) /* tgp_model_set: emissions are SmallOutputLGC even though p == 1 (rand adds 1e-9 to R) */
 #define TGP_DEVICE_PTRS (1u << 16) /* tgp_model_set: A..R are device pointers (borrowed) */
 #define TGP_IN_DEVICE (1u << 16)   /* per-call inputs (y, missing, Rnew, eps) are device pointers */
 #define TGP_OUT_DEVICE (1u << 17)  /* per-call array outputs are device pointers */

@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libtgp_hip.so")
 # flags / codes / options (mirror include/tgp_hip.h)
 SHARED_A, SHARED_a, SHARED_Q, SHARED_H, SHARED_h, SHARED_R = (1 << i for i in range(6))
 SHARED_ALL = 0x3F
+SMALL_OUTPUT = 1 << 8
 DEVICE_PTRS = 1 << 16
 IN_DEVICE = 1 << 16
 OUT_DEVICE = 1 << 17

@@ -54,12 +54,14 @@ __global__ __launch_bounds__(256) void k_finalize(const double* __restrict__ par
 
 // model re-layout (once per model / chunk size)
 // Lane = chunk, so the (slow, strided) reads happen once here and every later pass reads coalesced rows.
-__global__ __launch_bounds__(256) void k_tile_model(ModelView raw, int d, uint32_t mask, int nc, int L0, int64_t n0, double* __restrict__ tile) {
+__global__ __launch_bounds__(256) void k_tile_model(ModelView raw, int d, uint32_t mask, int nc_t, int nc_e, int L0, int64_t n0,
+                                                    double* __restrict__ tile_t, double* __restrict__ tile_e) {
     const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (c >= n0) return;
-    for (int i = 0; i < L0; ++i) tile_one_step(raw, d, mask, nc, L0, c, i, tile);
+    const int Lt = L0 / raw.p;
+    for (int tl = 0; tl < Lt; ++tl) tile_transition(raw, d, mask, nc_t, Lt, c, tl, tile_t);
+    for (int i = 0; i < L0; ++i) tile_emission(raw, d, mask, nc_e, L0, c, i, tile_e);
 }
-
 
 namespace {
 
@@ -115,7 +117,7 @@ struct tgp_handle {
     int d = 0, p = 1, ordering = 0;
     ModelView mv{};       // what the kernels see (tile pointer valid after ensure_tiled)
     ModelView raw{};      // the arrays as handed over (reference layout): source of the tiling
-    DevBuf tile;
+    DevBuf tile_t, tile_e;
     int tile_L0 = 0;
     const KernelTable* kt = nullptr;
     DevBuf bA, ba, bQ, bH, bh, bR;
@@ -283,15 +285,17 @@ void choose_chunk(tgp_handle* h) {
         // One lane per chunk, 256-lane workgroups, 256 CUs: kernel time goes with ceil(workgroups / 256), so
         // size the chunk to land just under k full rounds of 256 workgroups (measured at T = 1e7, d = 3:
         // L0 = 80 (k = 2) 1.12 ms/step; 96: 1.14; 128: 1.38; 160 (k = 1): 1.19; 39 (k = 4): 1.24).
-        const int64_t round = 256LL * 256;
-        int64_t k = (h->T + round * 160 - 1) / (round * 160);
+        const int64_t round = 256LL * 256, Tm0 = h->T * h->p;
+        int64_t k = (Tm0 + round * 160 - 1) / (round * 160);
         if (k < 2) k = 2;
-        L0 = (h->T + round * k - 1) / (round * k);
+        L0 = (Tm0 + round * k - 1) / (round * k);
         if (L0 < 8) L0 = 8;
     }
-    if (L0 > h->T) L0 = h->T > 0 ? h->T : 1;
+    const int64_t Tm = h->T * h->p;                       // processing steps (one scalar observation each)
+    L0 = ((L0 + h->p - 1) / h->p) * h->p;                 // whole time steps per chunk
+    if (L0 > Tm) L0 = Tm;
     h->L0 = (int)L0;
-    h->n0 = (h->T + L0 - 1) / L0;
+    h->n0 = (Tm + L0 - 1) / L0;
 }
 
 int scan_prepare(tgp_handle* h, ScanCtx& c, int monoid, int64_t n0) {
@@ -399,18 +403,21 @@ int check_ready(tgp_handle* h) {
 // General (per-step) layout: (re)build the time-tiled copy of the per-step arrays for the current chunk size.
 int ensure_tiled(tgp_handle* h) {
     if (h->lti) return TGP_OK;
-    if (h->tile_L0 == h->L0 && h->mv.tile != nullptr) return TGP_OK;
+    if (h->tile_L0 == h->L0 && h->mv.tile_mask != 0u) return TGP_OK;
     const uint32_t mask = tile_mask_of(h->raw);
-    const int nc = tile_offset(mask, 0u, h->d);
-    const size_t n = (size_t)((h->n0 + 63) / 64) * 64 * (size_t)h->L0 * (size_t)nc;
-    HIPCHK(h->tile.ensure(n * sizeof(double)));
+    const int nc_t = tile_offset_t(mask, 0u, h->d), nc_e = tile_offset_e(mask, 0u, h->d);
+    const size_t nblk = (size_t)((h->n0 + 63) / 64) * 64;
+    HIPCHK(h->tile_t.ensure((nblk * (size_t)(h->L0 / h->p) * (size_t)nc_t + 1) * sizeof(double)));
+    HIPCHK(h->tile_e.ensure((nblk * (size_t)h->L0 * (size_t)nc_e + 1) * sizeof(double)));
     {
         LaunchScope ls(h, "k_tile_model");
-        hipLaunchKernelGGL(k_tile_model, dim3((unsigned)((h->n0 + 255) / 256)), dim3(256), 0, h->stream, h->raw, h->d, mask, nc, h->L0,
-                           h->n0, h->tile.d());
+        hipLaunchKernelGGL(k_tile_model, dim3((unsigned)((h->n0 + 255) / 256)), dim3(256), 0, h->stream, h->raw, h->d, mask, nc_t, nc_e,
+                           h->L0, h->n0, h->tile_t.d(), h->tile_e.d());
     }
-    h->mv.tile = h->tile.d();
-    h->mv.tile_nc = nc;
+    h->mv.tile_t = h->tile_t.d();
+    h->mv.tile_e = h->tile_e.d();
+    h->mv.nc_t = nc_t;
+    h->mv.nc_e = nc_e;
     h->mv.tile_mask = mask;
     h->tile_L0 = h->L0;
     return TGP_OK;
@@ -437,9 +444,9 @@ int set_obs(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t fla
     const bool dev = (flags & TGP_IN_DEVICE) != 0;
     const void* p = nullptr;
     if ((flags & TGP_REUSE_REDUCE) && h->reduce_valid) return TGP_OK;  // caller vouches: same y as the previous call
-    TRY(stage_in(h, h->by, y, (size_t)h->T * sizeof(double), dev, &p));
+    TRY(stage_in(h, h->by, y, (size_t)h->T * h->p * sizeof(double), dev, &p));
     h->mv.y = static_cast<const double*>(p);
-    TRY(stage_in(h, h->bmiss, missing, (size_t)h->T, dev, &p));
+    TRY(stage_in(h, h->bmiss, missing, (size_t)h->T * h->p, dev, &p));
     h->mv.missing = static_cast<const uint8_t*>(p);
     return TGP_OK;
 }
@@ -557,7 +564,7 @@ int tgp_destroy(tgp_handle* h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     for (DevBuf* b : {&h->bA, &h->ba, &h->bQ, &h->bH, &h->bh, &h->bR, &h->bx0, &h->bx0r, &h->by, &h->bmiss, &h->bRnew, &h->beps_t,
-                      &h->beps_e, &h->bo1, &h->bo2, &h->bo3, &h->F.slab, &h->Rv.slab, &h->fs, &h->partial, &h->result, &h->segtmp, &h->tile})
+                      &h->beps_e, &h->bo1, &h->bo2, &h->bo3, &h->F.slab, &h->Rv.slab, &h->fs, &h->partial, &h->result, &h->segtmp, &h->tile_t, &h->tile_e})
         b->release();
     for (auto& e : h->ev)
         if (e) (void)hipEventDestroy(e);
@@ -605,7 +612,7 @@ int tgp_model_set(tgp_handle* h, int64_t T, int d, int p, int ordering, uint32_t
     h->reduce_valid = false;
     h->smoother_valid = false;
     if (T <= 0) return h->fail(TGP_EINVAL, "T must be positive");
-    if (p != 1) return h->fail(TGP_EUNSUPPORTED, "only scalar observations (p == 1) are implemented");
+    if (p < 1 || p > 64) return h->fail(TGP_EUNSUPPORTED, "observation dimension p must be in 1..64 (diagonal noise)");
     if (ordering != 0 && ordering != 1) return h->fail(TGP_EINVAL, "ordering must be 0 (Forward) or 1 (Reverse)");
     const KernelTable* kt = kernel_table(d);
     if (!kt) return h->fail(TGP_EUNSUPPORTED, "state dimension d must be in 1..8 for the per-lane scan path");
@@ -621,12 +628,15 @@ int tgp_model_set(tgp_handle* h, int64_t T, int d, int p, int ordering, uint32_t
     TRY(stage_in(h, h->bA, A, cnt(TGP_SHARED_A, d * d), dev, &pA));
     TRY(stage_in(h, h->ba, a, cnt(TGP_SHARED_a, d), dev, &pa));
     TRY(stage_in(h, h->bQ, Q, cnt(TGP_SHARED_Q, d * d), dev, &pQ));
-    TRY(stage_in(h, h->bH, H, cnt(TGP_SHARED_H, d), dev, &pH));
-    TRY(stage_in(h, h->bh, hh, cnt(TGP_SHARED_h, 1), dev, &ph));
-    TRY(stage_in(h, h->bR, R, cnt(TGP_SHARED_R, 1), dev, &pR));
+    TRY(stage_in(h, h->bH, H, cnt(TGP_SHARED_H, (int64_t)p * d), dev, &pH));
+    TRY(stage_in(h, h->bh, hh, cnt(TGP_SHARED_h, p), dev, &ph));
+    TRY(stage_in(h, h->bR, R, cnt(TGP_SHARED_R, p), dev, &pR));
     ModelView& mv = h->mv;
     mv = ModelView{};
-    mv.T = T;
+    mv.T = T * p;       // processing steps
+    mv.Tt = T;
+    mv.p = p;
+    mv.small_out = (flags & TGP_SMALL_OUTPUT) != 0 || p > 1;
     mv.ordering = ordering;
     mv.A = (const double*)pA;
     mv.a = (const double*)pa;
@@ -637,9 +647,9 @@ int tgp_model_set(tgp_handle* h, int64_t T, int d, int p, int ordering, uint32_t
     mv.sA = (flags & TGP_SHARED_A) ? 0 : d * d;
     mv.sa = (flags & TGP_SHARED_a) ? 0 : d;
     mv.sQ = (flags & TGP_SHARED_Q) ? 0 : d * d;
-    mv.sH = (flags & TGP_SHARED_H) ? 0 : d;
-    mv.sh = (flags & TGP_SHARED_h) ? 0 : 1;
-    mv.sR = (flags & TGP_SHARED_R) ? 0 : 1;
+    mv.sH = (flags & TGP_SHARED_H) ? 0 : (int64_t)p * d;
+    mv.sh = (flags & TGP_SHARED_h) ? 0 : p;
+    mv.sR = (flags & TGP_SHARED_R) ? 0 : p;
     const uint32_t lti_bits = TGP_SHARED_A | TGP_SHARED_a | TGP_SHARED_Q | TGP_SHARED_H | TGP_SHARED_h;
     h->lti = (flags & lti_bits) == lti_bits;
     h->raw = mv;
@@ -750,10 +760,10 @@ int tgp_posterior_marginals(tgp_handle* h, const double* y, const uint8_t* missi
     if (h->ordering != 0) return h->fail(TGP_EUNSUPPORTED, "posterior of a Reverse-ordered model is not implemented on the device");
     const bool idev = (flags & TGP_IN_DEVICE) != 0, odev = (flags & TGP_OUT_DEVICE) != 0;
     const bool rshared = (flags & TGP_SHARED_R) != 0;
-    const size_t nT = (size_t)h->T * sizeof(double);
+    const size_t nT = (size_t)h->T * h->p * sizeof(double);   // one value per (time step, observation)
     CallTimer tm(h);
     const void* pR = nullptr;
-    TRY(stage_in(h, h->bRnew, Rnew, rshared ? sizeof(double) : nT, idev, &pR));
+    TRY(stage_in(h, h->bRnew, Rnew, rshared ? (size_t)h->p * sizeof(double) : nT, idev, &pR));
     TRY(set_obs(h, y, missing, flags));
     tm.inputs_done();
     TRY(smoother_forward_impl(h, flags));
@@ -793,10 +803,10 @@ int tgp_smoother_backward(tgp_handle* h, const double* xs_m, const double* xs_P,
     if (!Rnew || !mean_out || !var_out) return h->fail(TGP_EINVAL, "null Rnew / output");
     const bool idev = (flags & TGP_IN_DEVICE) != 0, odev = (flags & TGP_OUT_DEVICE) != 0;
     const bool rshared = (flags & TGP_SHARED_R) != 0;
-    const size_t nT = (size_t)h->T * sizeof(double);
+    const size_t nT = (size_t)h->T * h->p * sizeof(double);   // one value per (time step, observation)
     CallTimer tm(h);
     const void* pR = nullptr;
-    TRY(stage_in(h, h->bRnew, Rnew, rshared ? sizeof(double) : nT, idev, &pR));
+    TRY(stage_in(h, h->bRnew, Rnew, rshared ? (size_t)h->p * sizeof(double) : nT, idev, &pR));
     const double* xs_dev = h->F.fin;
     if (xs_m && xs_P) {
         TRY(upload_x0(h, h->bx0r, xs_m, xs_P));
@@ -839,7 +849,7 @@ int tgp_marginals(tgp_handle* h, uint32_t flags, double* mean_out, double* var_o
     TRY(check_ready(h));
     if (!mean_out || !var_out) return h->fail(TGP_EINVAL, "null output");
     const bool odev = (flags & TGP_OUT_DEVICE) != 0;
-    const size_t nT = (size_t)h->T * sizeof(double);
+    const size_t nT = (size_t)h->T * h->p * sizeof(double);   // one value per (time step, observation)
     CallTimer tm(h);
     tm.inputs_done();
     double *dm = nullptr, *dv = nullptr;
@@ -856,7 +866,7 @@ int tgp_rand(tgp_handle* h, const double* eps_t, const double* eps_e, const doub
     TRY(check_ready(h));
     if (!eps_t || !eps_e || !eps_0 || !y_out) return h->fail(TGP_EINVAL, "null eps / output");
     const bool idev = (flags & TGP_IN_DEVICE) != 0, odev = (flags & TGP_OUT_DEVICE) != 0;
-    const size_t nT = (size_t)h->T * sizeof(double);
+    const size_t nT = (size_t)h->T * h->p * sizeof(double);   // one value per (time step, observation)
     const int d = h->d;
     // x0 = m + cholesky(Symmetric(P + 1e-12 I)).U' eps_0   (gaussian.jl:35-43) -- d x d, on the host
     std::vector<double> U((size_t)d * d, 0.0), x0(d), zeroP((size_t)d * d, 0.0);
@@ -880,7 +890,7 @@ int tgp_rand(tgp_handle* h, const double* eps_t, const double* eps_e, const doub
     CallTimer tm(h);
     TRY(upload_x0(h, h->bx0r, x0.data(), zeroP.data()));
     const void *pet = nullptr, *pee = nullptr;
-    TRY(stage_in(h, h->beps_t, eps_t, nT * d, idev, &pet));
+    TRY(stage_in(h, h->beps_t, eps_t, (size_t)h->T * d * sizeof(double), idev, &pet));
     TRY(stage_in(h, h->beps_e, eps_e, nT, idev, &pee));
     tm.inputs_done();
     double* dy = nullptr;

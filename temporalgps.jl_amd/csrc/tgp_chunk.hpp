@@ -20,31 +20,36 @@
 namespace tgp {
 
 struct ModelView {
-    int64_t T;
+    int64_t T;         // number of PROCESSING steps = Tt * p (one scalar observation each)
     int32_t ordering;  // 0 = Forward, 1 = Reverse
-    int32_t pad_;
-    const double* A;   // [T|1][d*d] column-major
-    const double* a;   // [T|1][d]
-    const double* Q;   // [T|1][d*d]
-    const double* H;   // [T|1][d]     (ScalarOutputLGC: A = H')
-    const double* h;   // [T|1]
-    const double* R;   // [T|1]
-    int64_t sA, sa, sQ, sH, sh, sR;  // stride in doubles per step; 0 == Fill (shared)
-    const double* y;                 // [T]
-    const uint8_t* missing;          // [T] or nullptr; 1 => y := 0, R := 1e15 (missings.jl:55-101)
-    // Time-tiled copy of the PER-STEP model arrays (general layout), in processing order:
-    //   tile[ ((chunk/64 * L0 + step_in_chunk) * tile_nc + component) * 64 + chunk%64 ]
-    // so that a wave (64 consecutive chunks) reads one component of one step as ONE coalesced 512-byte
-    // row. tile_mask says which arrays are in the record (order A, a, Q, H, h, R); the others are shared.
-    const double* tile;
-    int32_t tile_nc;
+    int32_t p;         // observations per time step (1: ScalarOutputLGC; > 1: SmallOutputLGC with diagonal R, run as p
+                       // consecutive scalar updates -- algebraically the joint update of lgc.jl:129-141)
+    const double* A;   // [Tt|1][d*d] column-major
+    const double* a;   // [Tt|1][d]
+    const double* Q;   // [Tt|1][d*d]
+    const double* H;   // [Tt|1][p][d]   row j = j-th observation functional (emission.A[j, :])
+    const double* h;   // [Tt|1][p]
+    const double* R;   // [Tt|1][p]      diagonal of the emission noise
+    int64_t sA, sa, sQ, sH, sh, sR;  // stride in doubles per TIME step; 0 == Fill (shared)
+    const double* y;                 // [Tt][p]
+    const uint8_t* missing;          // [Tt][p] or nullptr; 1 => y := 0, R := 1e15 (missings.jl:55-101, lgc.jl:143-151)
+    // Time-tiled copies of the PER-STEP model arrays (general layout), in processing order, one lane per chunk:
+    //   tile_t[ ((chunk/64 * Lt + time_in_chunk) * nc_t + component) * 64 + chunk%64 ]   transitions (A, a, Q)
+    //   tile_e[ ((chunk/64 * L0 + step_in_chunk) * nc_e + component) * 64 + chunk%64 ]   emissions (H row, h, R)
+    // so that a wave (64 consecutive chunks) reads one component of one step as ONE coalesced 512-byte row.
+    // tile_mask says which arrays are tiled; the others are shared (Fill) and read from the pointers above.
+    const double* tile_t;
+    const double* tile_e;
+    int32_t nc_t, nc_e;
     uint32_t tile_mask;
+    int32_t small_out;   // emissions are SmallOutputLGC (affects rand: lgc.jl:84-87 adds 1e-9 to the noise)
+    int64_t Tt;          // time steps
 };
 
 enum : uint32_t { kTileA = 1u, kTilea = 2u, kTileQ = 4u, kTileH = 8u, kTileh = 16u, kTileR = 32u };
 
-// offset (in doubles) of array `bit` inside one step record
-TGP_HD int tile_offset(uint32_t mask, uint32_t bit, int d) {
+// offsets (in doubles) inside the transition record (A, a, Q) and the emission record (H row, h, R); bit 0 => size
+TGP_HD int tile_offset_t(uint32_t mask, uint32_t bit, int d) {
     int off = 0;
     if (bit == kTileA) return off;
     if (mask & kTileA) off += d * d;
@@ -52,39 +57,58 @@ TGP_HD int tile_offset(uint32_t mask, uint32_t bit, int d) {
     if (mask & kTilea) off += d;
     if (bit == kTileQ) return off;
     if (mask & kTileQ) off += d * d;
+    return off;
+}
+TGP_HD int tile_offset_e(uint32_t mask, uint32_t bit, int d) {
+    int off = 0;
     if (bit == kTileH) return off;
     if (mask & kTileH) off += d;
     if (bit == kTileh) return off;
     if (mask & kTileh) off += 1;
     if (bit == kTileR) return off;
     if (mask & kTileR) off += 1;
-    return off;  // bit == 0: total record size
+    return off;
 }
 
 TGP_HD int64_t fs_index(int64_t c, int i, int k, int L0, int NS) {
     return ((((c >> 6) * L0 + i) * NS + k) << 6) + (c & 63);
 }
 
-TGP_HD int64_t step_index(const ModelView& mv, int64_t r) { return mv.ordering == 0 ? r : mv.T - 1 - r; }
-// storage index of the TRANSITION applied at processing step r (Reverse: the previous step's, r >= 1)
-TGP_HD int64_t trans_index(const ModelView& mv, int64_t r) { return mv.ordering == 0 ? r : mv.T - r; }
+// Processing step r = tproc * p + j (tproc: processing TIME index, j: observation inside the time step).
+// Storage indices:  emission time index te, transition index ttr (Reverse: the previous step's), micro index tm.
+TGP_HD int64_t time_index(const ModelView& mv, int64_t tproc) { return mv.ordering == 0 ? tproc : mv.Tt - 1 - tproc; }
+TGP_HD int64_t trans_index(const ModelView& mv, int64_t tproc) { return mv.ordering == 0 ? tproc : mv.Tt - tproc; }
+// micro storage index (y, per-step R stream, mean / var outputs) of processing step r = cc*L0 + i, L0 % p == 0
+TGP_HD int64_t micro_index(const ModelView& mv, int64_t cc, int i, int L0) {
+    if (mv.p == 1) return time_index(mv, cc * (int64_t)L0 + i);
+    const int tl = i / mv.p, j = i - tl * mv.p;
+    return time_index(mv, cc * (int64_t)(L0 / mv.p) + tl) * mv.p + j;
+}
 
-// Writes processing step (c, i) of the per-step arrays of `raw` (reference layout: [T][...] blocks, strides
-// raw.s*) into the time-tiled record. Transitions are stored at the processing step that APPLIES them
-// (Reverse ordering: the previous storage index; the skipped predict at r = 0 is zero-filled).
-TGP_HD void tile_one_step(const ModelView& raw, int d, uint32_t mask, int nc, int L0, int64_t c, int i, double* tile) {
-    const int64_t r = c * (int64_t)L0 + i;
-    if (r >= raw.T) return;
-    const int64_t te = step_index(raw, r), tt = trans_index(raw, r);
-    const bool pred = !(raw.ordering != 0 && r == 0);
-    const int64_t base = fs_index(c, i, 0, L0, nc);
+// Tiling of the per-step arrays of `raw` (reference layout, strides raw.s*). Transitions are stored at the
+// processing time step that APPLIES them (Reverse: the previous storage index; the skipped predict at tproc = 0
+// is zero-filled).
+TGP_HD void tile_transition(const ModelView& raw, int d, uint32_t mask, int nc, int Lt, int64_t c, int tl, double* tile) {
+    const int64_t tproc = c * (int64_t)Lt + tl;
+    if (tproc >= raw.Tt || nc == 0) return;
+    const int64_t tt = trans_index(raw, tproc);
+    const bool pred = !(raw.ordering != 0 && tproc == 0);
+    const int64_t base = fs_index(c, tl, 0, Lt, nc);
     int off = 0;
     if (mask & kTileA) { for (int k = 0; k < d * d; ++k) tile[base + (int64_t)(off + k) * 64] = pred ? raw.A[tt * raw.sA + k] : 0.0; off += d * d; }
     if (mask & kTilea) { for (int k = 0; k < d; ++k) tile[base + (int64_t)(off + k) * 64] = pred ? raw.a[tt * raw.sa + k] : 0.0; off += d; }
     if (mask & kTileQ) { for (int k = 0; k < d * d; ++k) tile[base + (int64_t)(off + k) * 64] = pred ? raw.Q[tt * raw.sQ + k] : 0.0; off += d * d; }
-    if (mask & kTileH) { for (int k = 0; k < d; ++k) tile[base + (int64_t)(off + k) * 64] = raw.H[te * raw.sH + k]; off += d; }
-    if (mask & kTileh) { tile[base + (int64_t)off * 64] = raw.h[te * raw.sh]; off += 1; }
-    if (mask & kTileR) { tile[base + (int64_t)off * 64] = raw.R[te * raw.sR]; off += 1; }
+}
+TGP_HD void tile_emission(const ModelView& raw, int d, uint32_t mask, int nc, int L0, int64_t c, int i, double* tile) {
+    const int64_t r = c * (int64_t)L0 + i;
+    if (r >= raw.T || nc == 0) return;
+    const int tl = i / raw.p, j = i - tl * raw.p;
+    const int64_t te = time_index(raw, c * (int64_t)(L0 / raw.p) + tl);
+    const int64_t base = fs_index(c, i, 0, L0, nc);
+    int off = 0;
+    if (mask & kTileH) { for (int k = 0; k < d; ++k) tile[base + (int64_t)(off + k) * 64] = raw.H[te * raw.sH + j * d + k]; off += d; }
+    if (mask & kTileh) { tile[base + (int64_t)off * 64] = raw.h[te * raw.sh + j]; off += 1; }
+    if (mask & kTileR) { tile[base + (int64_t)off * 64] = raw.R[te * raw.sR + j]; off += 1; }
 }
 
 TGP_HD uint32_t tile_mask_of(const ModelView& raw) {
@@ -96,30 +120,31 @@ TGP_HD uint32_t tile_mask_of(const ModelView& raw) {
 // groups of G consecutive steps. A lane's chunk is contiguous in time, so lane-wise access is strided by
 // L0*8 bytes across the wave; the device IO (WaveIO, tgp_kernels.hpp) instead lets 8 lanes fetch / write
 // one chunk's 64 contiguous bytes and transposes through wave-private LDS. DirectIO is the plain form
-// (host emulation, and the reference semantics the staged form must reproduce).
+// (host emulation, and the reference semantics the staged form must reproduce). `tm` = micro storage index.
 struct DirectIO {
     static constexpr int G = 8;
-    const double* a0;  // y
+    const double* a0;  // y (or eps_e)
     const double* a1;  // per-step R (or R_new); only read when its stride is non-zero
     double* o0;
     double* o1;
     TGP_HD void begin(const ModelView&, int64_t, int, int) {}
-    TGP_HD double in0(int64_t te, int) const { return a0[te]; }
-    TGP_HD double in1(int64_t te, int) const { return a1[te]; }
-    TGP_HD void out(int64_t te, int, double x0, double x1) {
-        o0[te] = x0;
-        if (o1) o1[te] = x1;
+    TGP_HD double in0(int64_t tm, int) const { return a0[tm]; }
+    TGP_HD double in1(int64_t tm, int) const { return a1[tm]; }
+    TGP_HD void out(int64_t tm, int, double x0, double x1) {
+        o0[tm] = x0;
+        if (o1) o1[tm] = x1;
     }
     TGP_HD void flush(const ModelView&, int64_t, int, int) {}
 };
 
-// Loads one processing step. LTI == true: A, a, Q, H, h are shared and loaded once (hoisted); only y and,
-// when per-step, R stream (through the IO). LTI == false: per-step arrays come from the time-tiled
-// record (coalesced rows), arrays not in the record are shared and hoisted.
+// Loads one processing step. LTI == true: A, a, Q, H, h are shared (hoisted once when p == 1; for p > 1 the
+// observation row j is a wave-uniform load per step); only y and, when per-step, R stream (through the IO).
+// LTI == false: per-step arrays come from the time-tiled records (coalesced rows), the others are shared.
 template <int D, bool LTI> struct StepLoader {
     double A[D * D], a[D], Q[D * D], H[D], h, R, y;
     bool do_predict, is_missing;
-    int64_t te;
+    int64_t te, tm;   // time / micro storage index of the current step
+    int j, tl;        // observation inside the time step, time step inside the chunk
     int oA, oa, oQ, oH, oh, oR;
 
     TGP_HD void init(const ModelView& mv) {
@@ -127,48 +152,62 @@ template <int D, bool LTI> struct StepLoader {
         if (!(m & kTileA)) { TGP_UNROLL for (int i = 0; i < D * D; ++i) A[i] = mv.A[i]; }
         if (!(m & kTileQ)) { TGP_UNROLL for (int i = 0; i < D * D; ++i) Q[i] = mv.Q[i]; }
         if (!(m & kTilea)) { TGP_UNROLL for (int i = 0; i < D; ++i) a[i] = mv.a[i]; }
-        if (!(m & kTileH)) { TGP_UNROLL for (int i = 0; i < D; ++i) H[i] = mv.H[i]; }
-        if (!(m & kTileh)) h = mv.h[0];
+        if (!(m & kTileH) && mv.p == 1) { TGP_UNROLL for (int i = 0; i < D; ++i) H[i] = mv.H[i]; }
+        if (!(m & kTileh) && mv.p == 1) h = mv.h[0];
         if (!LTI) {
-            oA = tile_offset(m, kTileA, D); oa = tile_offset(m, kTilea, D); oQ = tile_offset(m, kTileQ, D);
-            oH = tile_offset(m, kTileH, D); oh = tile_offset(m, kTileh, D); oR = tile_offset(m, kTileR, D);
+            oA = tile_offset_t(m, kTileA, D); oa = tile_offset_t(m, kTilea, D); oQ = tile_offset_t(m, kTileQ, D);
+            oH = tile_offset_e(m, kTileH, D); oh = tile_offset_e(m, kTileh, D); oR = tile_offset_e(m, kTileR, D);
         }
     }
-    TGP_HD void index(const ModelView& mv, int64_t r) {
-        te = step_index(mv, r);
-        do_predict = !(mv.ordering != 0 && r == 0);
+    // c = chunk, i = step inside the chunk (L0 % p == 0)
+    TGP_HD void index(const ModelView& mv, int64_t c, int i, int L0) {
+        int64_t tproc;
+        if (mv.p == 1) {
+            tl = i; j = 0;
+            tproc = c * (int64_t)L0 + i;
+        } else {
+            tl = i / mv.p; j = i - tl * mv.p;
+            tproc = c * (int64_t)(L0 / mv.p) + tl;
+        }
+        te = time_index(mv, tproc);
+        tm = te * mv.p + j;
+        do_predict = (j == 0) && !(mv.ordering != 0 && tproc == 0);
     }
-    // c = chunk, i = step inside the chunk
-    TGP_HD void load_transition(const ModelView& mv, int64_t c, int i, int L0) {
-        if (!LTI && do_predict) {
-            const double* p = mv.tile + fs_index(c, i, 0, L0, mv.tile_nc);
-            if (mv.tile_mask & kTileA) { TGP_UNROLL for (int k = 0; k < D * D; ++k) A[k] = p[(oA + k) * 64]; }
-            if (mv.tile_mask & kTileQ) { TGP_UNROLL for (int k = 0; k < D * D; ++k) Q[k] = p[(oQ + k) * 64]; }
-            if (mv.tile_mask & kTilea) { TGP_UNROLL for (int k = 0; k < D; ++k) a[k] = p[(oa + k) * 64]; }
+    TGP_HD void load_transition(const ModelView& mv, int64_t c, int L0) {
+        if (!LTI && do_predict && mv.nc_t > 0) {
+            const double* q = mv.tile_t + fs_index(c, tl, 0, L0 / mv.p, mv.nc_t);
+            if (mv.tile_mask & kTileA) { TGP_UNROLL for (int k = 0; k < D * D; ++k) A[k] = q[(oA + k) * 64]; }
+            if (mv.tile_mask & kTileQ) { TGP_UNROLL for (int k = 0; k < D * D; ++k) Q[k] = q[(oQ + k) * 64]; }
+            if (mv.tile_mask & kTilea) { TGP_UNROLL for (int k = 0; k < D; ++k) a[k] = q[(oa + k) * 64]; }
         }
     }
     TGP_HD void load_emission(const ModelView& mv, int64_t c, int i, int L0) {
-        if (!LTI) {
-            const double* p = mv.tile + fs_index(c, i, 0, L0, mv.tile_nc);
-            if (mv.tile_mask & kTileH) { TGP_UNROLL for (int k = 0; k < D; ++k) H[k] = p[(oH + k) * 64]; }
-            if (mv.tile_mask & kTileh) h = p[oh * 64];
+        const uint32_t m = LTI ? 0u : mv.tile_mask;
+        if (m & (kTileH | kTileh)) {
+            const double* q = mv.tile_e + fs_index(c, i, 0, L0, mv.nc_e);
+            if (m & kTileH) { TGP_UNROLL for (int k = 0; k < D; ++k) H[k] = q[(oH + k) * 64]; }
+            if (m & kTileh) h = q[oh * 64];
+        }
+        if (mv.p > 1) {   // shared (Fill) emission with several rows: wave-uniform row j
+            if (!(m & kTileH)) { TGP_UNROLL for (int k = 0; k < D; ++k) H[k] = mv.H[j * D + k]; }
+            if (!(m & kTileh)) h = mv.h[j];
         }
     }
-    // R of this step: tiled record (general layout) / shared scalar / staged stream (LTI with per-step R)
+    // R of this step: tiled record (general layout) / shared / staged stream (LTI with per-step R)
     template <class IO> TGP_HD double load_R(const ModelView& mv, int64_t c, int i, int L0, const IO& io, int gi) const {
-        if (!LTI && (mv.tile_mask & kTileR)) return mv.tile[fs_index(c, i, oR, L0, mv.tile_nc)];
-        return (mv.sR == 0) ? mv.R[0] : io.in1(te, gi);
+        if (!LTI && (mv.tile_mask & kTileR)) return mv.tile_e[fs_index(c, i, oR, L0, mv.nc_e)];
+        return (mv.sR == 0) ? mv.R[j] : io.in1(tm, gi);
     }
     template <class IO> TGP_HD void load_obs(const ModelView& mv, int64_t c, int i, int L0, const IO& io, int gi) {
         R = load_R(mv, c, i, L0, io, gi);
-        y = io.in0(te, gi);
-        is_missing = (mv.missing != nullptr) && (mv.missing[te] != 0);
+        y = io.in0(tm, gi);
+        is_missing = (mv.missing != nullptr) && (mv.missing[tm] != 0);
         if (is_missing) { y = 0.0; R = kLargeVar; }
     }
-    // full step: i = step inside the chunk (r = c*L0 + i), gi = position inside the IO group
-    template <class IO> TGP_HD void load(const ModelView& mv, int64_t r, int64_t c, int i, int L0, const IO& io, int gi) {
-        index(mv, r);
-        load_transition(mv, c, i, L0);
+    // full step: i = step inside the chunk, gi = position inside the IO group
+    template <class IO> TGP_HD void load(const ModelView& mv, int64_t c, int i, int L0, const IO& io, int gi) {
+        index(mv, c, i, L0);
+        load_transition(mv, c, L0);
         load_emission(mv, c, i, L0);
         load_obs(mv, c, i, L0, io, gi);
     }
@@ -199,7 +238,7 @@ TGP_HD void chunk_reduce_filter(const ModelView& mv, int64_t c, int L0, IO& io, 
         const int64_t rg = r0 + g;
         const int gend = (int)((r1 - rg) < IO::G ? (r1 - rg) : IO::G);
         for (int i = 0; i < gend; ++i) {
-            sl.load(mv, rg + i, c, g + i, L0, io, i);
+            sl.load(mv, c, g + i, L0, io, i);
             f_extend<D>(e, sl.do_predict, sl.A, sl.a, sl.Q, sl.H, sl.h, sl.R, sl.y);
         }
     }
@@ -246,8 +285,8 @@ TGP_HD ChunkStats chunk_apply_filter(const ModelView& mv, int64_t c, int L0, Sta
       double sprod = 1.0, quad = 0.0;   // product of the group's innovation variances, sum of v^2 / S
       for (int gi = 0; gi < gend; ++gi) {
         const int64_t r = rg + gi;
-        sl.load(mv, r, c, g + gi, L0, io, gi);
-        if (MODE >= 2) {
+        sl.load(mv, c, g + gi, L0, io, gi);
+        if (MODE >= 2 && sl.do_predict) {
             double mf[D], Pf[D * D];
             copy_n<D>(x.m, mf);
             copy_n<D * D>(x.P, Pf);
@@ -270,10 +309,10 @@ TGP_HD ChunkStats chunk_apply_filter(const ModelView& mv, int64_t c, int L0, Sta
             sprod = 1.0;
         }
         cs.nmiss += sl.is_missing ? 1.0 : 0.0;
-        if (MODE >= 1 && out.m_out) {
+        if (MODE >= 1 && out.m_out && sl.j == mv.p - 1) {
             TGP_UNROLL for (int i = 0; i < D; ++i) out.m_out[sl.te * D + i] = x.m[i];
         }
-        if (MODE >= 1 && out.P_out) {
+        if (MODE >= 1 && out.P_out && sl.j == mv.p - 1) {
             TGP_UNROLL for (int i = 0; i < D * D; ++i) out.P_out[sl.te * D * D + i] = x.P[i];
         }
         if (MODE == 2 && out.fs) {
@@ -303,20 +342,21 @@ TGP_HD int chunk_smooth(const ModelView& mv, int64_t c, int L0, State<D>& xs, co
     StepLoader<D, LTI> sl;
     sl.init(mv);
     bool ok = true;
-    const double Rn_shared = (sRn == 0) ? io.a1[0] : 0.0;
+
     for (int g = ((L0 - 1) / IO::G) * IO::G; g >= 0; g -= IO::G) {
         io.begin(mv, c, g, L0);   // stages R_new (io.a1) when it is per-step
         const int64_t rg = r0 + g;
         const int gend = (int)((r1 - rg) < IO::G ? (r1 - rg) : IO::G);
         for (int gi = gend - 1; gi >= 0; --gi) {
             const int64_t r = rg + gi;
-            sl.index(mv, r);
-            sl.load_transition(mv, c, g + gi, L0);
+            sl.index(mv, c, g + gi, L0);
+            sl.load_transition(mv, c, L0);
             sl.load_emission(mv, c, g + gi, L0);
             double mean, var;
-            emit_scalar<D>(sl.H, sl.h, (sRn == 0) ? Rn_shared : io.in1(sl.te, gi), xs.m, xs.P, mean, var);
-            io.out(sl.te, gi, mean, var);
-            State<D> xf;  // filtered state before this step
+            emit_scalar<D>(sl.H, sl.h, (sRn == 0) ? io.a1[sl.j] : io.in1(sl.tm, gi), xs.m, xs.P, mean, var);
+            io.out(sl.tm, gi, mean, var);
+            if (!sl.do_predict) continue;   // inside a time step (or the skipped first predict): the state does not move
+            State<D> xf;  // filtered state before this time step
             if (r == r0) {
                 xf = carry;
             } else {
@@ -361,13 +401,13 @@ TGP_HD int chunk_reduce_affine(const ModelView& mv, int64_t c, int L0, const dou
     bool ok = true;
     if (RAND && LTI) ok = noise_factor<D>(sl.Q, Lq);
     for (int64_t r = r0; r < r1; ++r) {
-        sl.index(mv, r);
-        sl.load_transition(mv, c, (int)(r - r0), L0);
+        sl.index(mv, c, (int)(r - r0), L0);
+        sl.load_transition(mv, c, L0);
         if (!sl.do_predict) continue;
         if (RAND) {
             if (!LTI) ok = noise_factor<D>(sl.Q, Lq) && ok;
             double cvec[D];
-            const double* ep = eps_t + trans_index(mv, r) * D;
+            const double* ep = eps_t + trans_index(mv, c * (int64_t)(L0 / mv.p) + sl.tl) * D;
             TGP_UNROLL for (int i = 0; i < D; ++i) {
                 double acc = sl.a[i];
                 TGP_UNROLL for (int k = 0; k <= i; ++k) acc = fma(Lq[i + k * D], ep[k], acc);
@@ -397,14 +437,14 @@ TGP_HD int chunk_apply_affine(const ModelView& mv, int64_t c, int L0, State<D>& 
       const int gend = (int)((r1 - rg) < IO::G ? (r1 - rg) : IO::G);
       for (int gi = 0; gi < gend; ++gi) {
         const int64_t r = rg + gi;
-        sl.index(mv, r);
-        sl.load_transition(mv, c, g + gi, L0);
+        sl.index(mv, c, g + gi, L0);
+        sl.load_transition(mv, c, L0);
         sl.load_emission(mv, c, g + gi, L0);
         const double R = sl.load_R(mv, c, g + gi, L0, io, gi);
         if (sl.do_predict) {
             if (RAND) {
                 if (!LTI) ok = noise_factor<D>(sl.Q, Lq) && ok;
-                const double* ep = eps_t + trans_index(mv, r) * D;
+                const double* ep = eps_t + trans_index(mv, c * (int64_t)(L0 / mv.p) + sl.tl) * D;
                 double xn[D];
                 mat_vec<D>(sl.A, x.m, xn);
                 TGP_UNROLL for (int i = 0; i < D; ++i) {
@@ -419,11 +459,12 @@ TGP_HD int chunk_apply_affine(const ModelView& mv, int64_t c, int L0, State<D>& 
         if (RAND) {
             double yy = 0.0;
             TGP_UNROLL for (int i = 0; i < D; ++i) yy = fma(sl.H[i], x.m[i], yy);
-            io.out(sl.te, gi, (yy + sl.h) + sqrt(R) * io.in0(sl.te, gi), 0.0);   // lgc.jl:241-243
+            // scalar emission: sqrt(R) eps (lgc.jl:241-243); vector emission with diagonal R: chol(R + 1e-9 I).U' eps (lgc.jl:84-87)
+            io.out(sl.tm, gi, (yy + sl.h) + sqrt(mv.small_out ? R + 1e-9 : R) * io.in0(sl.tm, gi), 0.0);
         } else {
             double mean, var;
             emit_scalar<D>(sl.H, sl.h, R, x.m, x.P, mean, var);
-            io.out(sl.te, gi, mean, var);
+            io.out(sl.tm, gi, mean, var);
         }
       }
       io.flush(mv, c, g, L0);

@@ -90,9 +90,9 @@ template <bool IN0, bool IN1, bool OUT0, bool OUT1> struct WaveIO {
             const int row = j * 8 + (lane >> 3);
             const int64_t r = (c0 + row) * L0 + g + (lane & 7);
             if (r < mv.T) {
-                const int64_t te = step_index(mv, r);
-                if (IN0) tgp_lds[wb + kOff0 + row * kIoLD + (lane & 7)] = a0[te];
-                if (IN1 && st1) tgp_lds[wb + kOff1 + row * kIoLD + (lane & 7)] = a1[te];
+                const int64_t tm = micro_index(mv, c0 + row, g + (lane & 7), L0);
+                if (IN0) tgp_lds[wb + kOff0 + row * kIoLD + (lane & 7)] = a0[tm];
+                if (IN1 && st1) tgp_lds[wb + kOff1 + row * kIoLD + (lane & 7)] = a1[tm];
             }
         }
         wave_sync();
@@ -113,9 +113,9 @@ template <bool IN0, bool IN1, bool OUT0, bool OUT1> struct WaveIO {
             const int64_t r = cc * L0 + g + (lane & 7);
             const int64_t r1c = (cc + 1) * L0 < mv.T ? (cc + 1) * L0 : mv.T;
             if (r < r1c) {
-                const int64_t te = step_index(mv, r);
-                o0[te] = tgp_lds[wb + kOffO0 + row * kIoLD + (lane & 7)];
-                if (OUT1 && o1 != nullptr) o1[te] = tgp_lds[wb + kOffO1 + row * kIoLD + (lane & 7)];
+                const int64_t tm = micro_index(mv, cc, g + (lane & 7), L0);
+                o0[tm] = tgp_lds[wb + kOffO0 + row * kIoLD + (lane & 7)];
+                if (OUT1 && o1 != nullptr) o1[tm] = tgp_lds[wb + kOffO1 + row * kIoLD + (lane & 7)];
             }
         }
         wave_sync();

@@ -19,7 +19,7 @@ import numpy as np
 
 from . import _lib
 
-__all__ = ["Forward", "Reverse", "Gaussian", "GaussMarkovModel", "ScalarOutputLGC", "LGSSM", "logpdf", "_filter",
+__all__ = ["Forward", "Reverse", "Gaussian", "GaussMarkovModel", "ScalarOutputLGC", "SmallOutputLGC", "LGSSM", "logpdf", "_filter",
            "posterior", "marginals", "rand", "replace_observation_noise_cov", "posterior_marginals", "ε_randn"]
 
 
@@ -78,6 +78,25 @@ class ScalarOutputLGC:
         self.H, self.h, self.R = H, h, R
 
 
+class SmallOutputLGC:
+    """StructArray of vector-output emissions y | x ~ N(H x + h, R) (lgc.jl:113-141): H (T|1, p, d), h (T|1, p),
+    R (T|1, p) = the DIAGONAL of the noise covariance, or (T|1, p, p) dense. The engine absorbs the p
+    observations of a time step as p scalar updates (exactly the joint update for diagonal noise); a dense R is
+    whitened on the host first (H <- L^-1 H, h <- L^-1 h, y <- L^-1 y, R <- I), which supports logpdf / _filter /
+    posterior; marginals and rand need diagonal noise."""
+
+    def __init__(self, H, h, R):
+        self.H, self.h, self.R = H, h, R
+
+    @property
+    def p(self):
+        return int(self.H.shape[-2])
+
+    @property
+    def dense(self):
+        return self.R.ndim == 3
+
+
 class LGSSM:
     """lgssm.jl:9-12. `T` must be given when every array is a Fill."""
 
@@ -90,6 +109,11 @@ class LGSSM:
         self.device = device
         self._handle = None
         self._keep = None
+        self._whiten = None      # (Linv (T|1,p,p), logdet_half (T|1,)) when a dense R was whitened
+
+    @property
+    def p(self):
+        return self.emissions.p if isinstance(self.emissions, SmallOutputLGC) else 1
 
     def __len__(self):
         return self.T
@@ -128,13 +152,27 @@ class LGSSM:
         if self._handle is not None:
             return self._handle
         tr, em = self.transitions, self.emissions
-        d = self.dim
+        d, p = self.dim, self.p
+        small = isinstance(em, SmallOutputLGC)
+        eH, eh, eR = em.H, em.h, em.R
+        if small and em.dense:
+            # whiten: R = L L'  =>  H~ = L^-1 H, h~ = L^-1 h, R~ = I; logpdf gets - sum_t log det L_t (host arrays only)
+            Rn = np.asarray(_to_numpy(eR), dtype=np.float64)
+            Lc = np.linalg.cholesky(Rn)
+            Linv = np.linalg.inv(Lc)
+            eH = Linv @ np.asarray(_to_numpy(eH), dtype=np.float64)
+            eh = (Linv @ np.asarray(_to_numpy(eh), dtype=np.float64)[..., None])[..., 0]
+            n = max(eH.shape[0], eh.shape[0])
+            eH = eH if eH.shape[0] == n else np.repeat(eH, n, axis=0)
+            eh = eh if eh.shape[0] == n else np.repeat(eh, n, axis=0)
+            eR = np.ones((1, p))
+            self._whiten = (Linv, np.log(np.diagonal(Lc, axis1=-2, axis2=-1)).sum(axis=-1))
         A, sA = self._blocks(tr.As, d * d, transpose=True)   # column-major blocks == row-major of A'
         a, sa = self._blocks(tr.as_, d)
         Q, sQ = self._blocks(tr.Qs, d * d, transpose=True)
-        H, sH = self._blocks(em.H, d)
-        h, sh = self._blocks(em.h, 1)
-        R, sR = self._blocks(em.R, 1)
+        H, sH = self._blocks(eH, p * d)       # (T|1, p, d) row-major: row j contiguous
+        h, sh = self._blocks(eh, p)
+        R, sR = self._blocks(eR, p)
         arrs = (A, a, Q, H, h, R)
         on_dev = [_lib.is_device(x) for x in arrs]
         if any(on_dev):
@@ -147,10 +185,12 @@ class LGSSM:
             flags |= bit if s else 0
         if all(on_dev):
             flags |= _lib.DEVICE_PTRS
+        if small:
+            flags |= _lib.SMALL_OUTPUT
         hd = _lib.Handle(self.device)
         x0m = np.ascontiguousarray(np.asarray(_to_numpy(self.x0.m), dtype=np.float64))
         x0P = np.ascontiguousarray(np.asarray(_to_numpy(self.x0.P), dtype=np.float64).T)
-        hd.check(hd.lib.tgp_model_set(hd.h, self.T, d, 1, self.ordering.code, flags, _lib.ptr(A), _lib.ptr(a), _lib.ptr(Q),
+        hd.check(hd.lib.tgp_model_set(hd.h, self.T, d, p, self.ordering.code, flags, _lib.ptr(A), _lib.ptr(a), _lib.ptr(Q),
                                       _lib.ptr(H), _lib.ptr(h), _lib.ptr(R), _lib.ptr(x0m), _lib.ptr(x0P)))
         self._keep = arrs            # borrowed device pointers must outlive the handle
         self._handle = hd
@@ -177,12 +217,26 @@ def _check_inputs(model, y):
         raise ValueError(f"Dimension mismatch. length(prior) is {len(model)}, but length(y) is {len(y)}")
 
 
-def _obs(y):
+def _obs(y, model=None):
     """-> (y contiguous fp64, missing mask or None, in_device). NaN == missing (host arrays only;
-    for CUDA tensors pass a (y, mask) tuple)."""
+    for CUDA tensors pass a (y, mask) tuple). Vector observations: y (T, p); a (T,) mask marks whole steps."""
     mask = None
     if isinstance(y, tuple):
         y, mask = y
+    if model is not None and model.p > 1 and not (_is_torch(y) and y.is_cuda):
+        yy = np.array(_to_numpy(y), dtype=np.float64)
+        if yy.shape != (model.T, model.p):
+            raise ValueError(f"y must have shape ({model.T}, {model.p})")
+        mk = np.isnan(yy) if mask is None else np.asarray(_to_numpy(mask), dtype=bool)
+        if mk.ndim == 1:
+            mk = np.repeat(mk[:, None], model.p, axis=1)
+        if model._whiten is not None:
+            if mk.any() and not np.all(mk.all(axis=1) | ~mk.any(axis=1)):
+                raise TypeError("per-element missing observations need Diagonal noise (MethodError at lgc.jl:146)")
+            Linv = model._whiten[0]
+            yy = (Linv @ np.where(mk, 0.0, yy)[..., None])[..., 0]
+        yy = np.ascontiguousarray(np.where(mk, 0.0, yy))
+        return yy, (np.ascontiguousarray(mk.astype(np.uint8)) if mk.any() else None), False
     if _is_torch(y) and y.is_cuda:
         import torch
         yy = y.to(torch.float64).contiguous()
@@ -210,9 +264,13 @@ def logpdf(model, y):
     """lgssm.jl:147-151 (+ missings.jl:8-13)."""
     _check_inputs(model, y[0] if isinstance(y, tuple) else y)
     hd = model.handle()
-    yy, mm, dev = _obs(y)
+    yy, mm, dev = _obs(y, model)
     out = ctypes.c_double()
     hd.check(hd.lib.tgp_logpdf(hd.h, _lib.ptr(yy), _lib.ptr(mm), _lib.IN_DEVICE if dev else 0, ctypes.byref(out)))
+    if model._whiten is not None:        # log N(y; ., S) = log N(L^-1 y; ., L^-1 S L^-T) - log det L  (observed steps only)
+        ld = model._whiten[1]
+        obs = np.ones(model.T, dtype=bool) if mm is None else ~mm.reshape(model.T, -1).all(axis=1)
+        return out.value - float((ld if ld.shape[0] > 1 else np.repeat(ld, model.T))[obs].sum())
     return out.value
 
 
@@ -220,7 +278,7 @@ def _filter(model, y):
     """lgssm.jl:171-173: filtering distributions, returned as (means (T,d), covs (T,d,d))."""
     _check_inputs(model, y[0] if isinstance(y, tuple) else y)
     hd = model.handle()
-    yy, mm, dev = _obs(y)
+    yy, mm, dev = _obs(y, model)
     T, d = model.T, model.dim
     m, P = _out(model, (T, d), dev), _out(model, (T, d, d), dev)
     flags = (_lib.IN_DEVICE | _lib.OUT_DEVICE) if dev else 0
@@ -232,7 +290,7 @@ def posterior(model, y):
     """lgssm.jl:193-200: the posterior LGSSM (opposite ordering, transitions (G, g, L), x0 = final filtering state)."""
     _check_inputs(model, y[0] if isinstance(y, tuple) else y)
     hd = model.handle()
-    yy, mm, dev = _obs(y)
+    yy, mm, dev = _obs(y, model)
     T, d = model.T, model.dim
     G, g, L = _out(model, (T, d, d), dev), _out(model, (T, d), dev), _out(model, (T, d, d), dev)
     xfm, xfP = np.empty(d), np.empty((d, d))
@@ -245,27 +303,44 @@ def posterior(model, y):
 
 
 def replace_observation_noise_cov(model, R_new):
-    """missings.jl:35-41."""
+    """missings.jl:35-41. Vector observations: R_new (T|1, p) diagonal or (T|1, p, p) dense."""
     em = model.emissions
+    if isinstance(em, SmallOutputLGC):
+        R = R_new if _is_torch(R_new) else np.asarray(R_new, dtype=np.float64)
+        if R.ndim == 1:
+            R = R[None]
+        return LGSSM(model.transitions, SmallOutputLGC(em.H, em.h, R), T=model.T, device=model.device)
     R = R_new if _is_torch(R_new) else np.atleast_1d(np.asarray(R_new, dtype=np.float64))
     return LGSSM(model.transitions, ScalarOutputLGC(em.H, em.h, R), T=model.T, device=model.device)
 
 
+def _osh(model):
+    return (model.T,) if model.p == 1 else (model.T, model.p)
+
+
+def _need_diag(model, what):
+    if model._whiten is not None or (isinstance(model.emissions, SmallOutputLGC) and model.emissions.dense):
+        raise NotImplementedError(f"{what} with a dense observation-noise covariance is not implemented on the device "
+                                  "(diagonal noise only)")
+
+
 def marginals(model):
     """lgssm.jl:99-115: emission marginals of the model as given, returned as (mean (T,), var (T,))."""
+    _need_diag(model, "marginals")
     hd = model.handle()
     dev = model._on_device
-    mean, var = _out(model, (model.T,), dev), _out(model, (model.T,), dev)
+    mean, var = _out(model, _osh(model), dev), _out(model, _osh(model), dev)
     hd.check(hd.lib.tgp_marginals(hd.h, _lib.OUT_DEVICE if dev else 0, _lib.ptr(mean), _lib.ptr(var)))
-    return mean, var
+    return mean, var        # vector observations: var is the DIAGONAL of the p x p marginal covariance (marginals_diag)
 
 
 def posterior_marginals(model, y, R_new):
     """marginals(replace_observation_noise_cov(posterior(model, y), R_new)) without materialising the
     posterior model -- the `marginals(posterior(fx, y)(x))` path (posterior_lti_sde.jl:27-36)."""
     _check_inputs(model, y[0] if isinstance(y, tuple) else y)
+    _need_diag(model, "posterior_marginals")
     hd = model.handle()
-    yy, mm, dev = _obs(y)
+    yy, mm, dev = _obs(y, model)
     flags = (_lib.IN_DEVICE | _lib.OUT_DEVICE) if dev else 0
     if dev and _is_torch(R_new):
         Rn = R_new.contiguous()
@@ -274,11 +349,15 @@ def posterior_marginals(model, y, R_new):
         Rn = torch.as_tensor(np.atleast_1d(np.asarray(R_new, dtype=np.float64)), device=yy.device)
     else:
         Rn = np.ascontiguousarray(np.atleast_1d(_to_numpy(R_new)), dtype=np.float64)
+    if model.p > 1 and Rn.ndim == 1:
+        Rn = Rn[None]
     if Rn.shape[0] == 1:
         flags |= _lib.SHARED_R
     elif Rn.shape[0] != model.T:
         raise ValueError("R_new must have length 1 or T")
-    mean, var = _out(model, (model.T,), dev), _out(model, (model.T,), dev)
+    if model.p > 1 and tuple(Rn.shape[1:]) != (model.p,):
+        raise ValueError(f"R_new must be (T|1, {model.p}) (diagonal of the new noise)")
+    mean, var = _out(model, _osh(model), dev), _out(model, _osh(model), dev)
     hd.check(hd.lib.tgp_posterior_marginals(hd.h, _lib.ptr(yy), _lib.ptr(mm), _lib.ptr(Rn), flags, _lib.ptr(mean),
                                             _lib.ptr(var), None))
     return mean, var
@@ -288,7 +367,7 @@ def ε_randn(rng, model):
     """lgssm.jl:72-77: all the randomness one sample needs, drawn up front in the reference's order
     (T transition vectors, then T emission scalars; x0's draw comes after, lgssm.jl:67)."""
     T, d = model.T, model.dim
-    return rng.standard_normal((T, d)), rng.standard_normal(T)
+    return rng.standard_normal((T, d)), rng.standard_normal(_osh(model))
 
 
 def rand(rng_or_eps, model):
@@ -298,6 +377,7 @@ def rand(rng_or_eps, model):
     else:
         eps_t, eps_e = ε_randn(rng_or_eps, model)
         eps_0 = rng_or_eps.standard_normal(model.dim)
+    _need_diag(model, "rand")
     hd = model.handle()
     dev = _lib.is_device(eps_t)
     if dev:
@@ -307,7 +387,7 @@ def rand(rng_or_eps, model):
         et = np.ascontiguousarray(_to_numpy(eps_t), dtype=np.float64)
         ee = np.ascontiguousarray(_to_numpy(eps_e), dtype=np.float64)
     e0 = np.ascontiguousarray(_to_numpy(eps_0), dtype=np.float64)
-    y = _out(model, (model.T,), dev)
+    y = _out(model, _osh(model), dev)
     flags = (_lib.IN_DEVICE | _lib.OUT_DEVICE) if dev else 0
     hd.check(hd.lib.tgp_rand(hd.h, _lib.ptr(et), _lib.ptr(ee), _lib.ptr(e0), flags, _lib.ptr(y)))
     return y

@@ -15,8 +15,13 @@ _i64 = ctypes.c_int64
 
 
 def pack(model):
-    """dict model (oracle convention, kind 'scalar') -> flat column-major blocks + strides (0 == Fill)."""
+    """dict model (oracle convention; kind 'scalar', or 'small' with DIAGONAL R) -> flat blocks + strides (0 == Fill)."""
     d = len(model["x0m"])
+    if model["kind"] == "small":
+        p_ = model["H"].shape[-2]
+        R = np.atleast_3d(model["R"])
+        assert np.allclose(R, R * np.eye(p_)), "pack(): dense R must be whitened first"
+        model = dict(model, R=np.diagonal(R, axis1=-2, axis2=-1))
     A = np.ascontiguousarray(np.swapaxes(model["A"], -1, -2)).reshape(-1)
     Q = np.ascontiguousarray(np.swapaxes(model["Q"], -1, -2)).reshape(-1)
     a = np.ascontiguousarray(model["a"]).reshape(-1)
@@ -24,10 +29,11 @@ def pack(model):
     h = np.ascontiguousarray(np.atleast_1d(model["h"]), dtype=np.float64).reshape(-1)
     R = np.ascontiguousarray(np.atleast_1d(model["R"]), dtype=np.float64).reshape(-1)
     st = lambda arr, n: n if arr.shape[0] > 1 else 0
-    return dict(d=d, T=model["T"], ordering=0 if model["ordering"] == "F" else 1,
+    p = model["H"].shape[-2] if model["kind"] == "small" else 1
+    return dict(d=d, p=p, small=int(model["kind"] == "small"), T=model["T"], ordering=0 if model["ordering"] == "F" else 1,
                 A=A, sA=st(model["A"], d * d), a=a, sa=st(model["a"], d), Q=Q, sQ=st(model["Q"], d * d),
-                H=H, sH=st(model["H"], d), h=h, sh=st(np.atleast_1d(model["h"]), 1),
-                R=R, sR=st(np.atleast_1d(model["R"]), 1),
+                H=H, sH=st(model["H"], p * d), h=h, sh=st(np.atleast_1d(model["h"]), p),
+                R=R, sR=st(np.atleast_1d(model["R"]), p),
                 x0m=np.ascontiguousarray(model["x0m"], dtype=np.float64),
                 x0P=np.ascontiguousarray(model["x0P"].T, dtype=np.float64).reshape(-1))
 
@@ -83,7 +89,9 @@ def _p(x):
 def hostsim_run(model, what, y=None, missing=None, L0=4, BS=3, Rnew=None, eps=None, want_ggl=False, want_elem=False,
                 want_rev=False, xs=None):
     pk = pack(model)
-    d, T = pk["d"], pk["T"]
+    d, T, p_ = pk["d"], pk["T"], pk["p"]
+    L0 = ((L0 + p_ - 1) // p_) * p_          # whole time steps per chunk
+    osh = (T,) if p_ == 1 else (T, p_)
     out = {}
     lml = ctypes.c_double(0.0)
     m_out = P_out = G = g = L = xfm = xfP = mean = var = None
@@ -94,12 +102,12 @@ def hostsim_run(model, what, y=None, missing=None, L0=4, BS=3, Rnew=None, eps=No
         if want_ggl:
             G, g, L = np.zeros((T, d, d)), np.zeros((T, d)), np.zeros((T, d, d))
         if Rnew is not None:
-            mean, var = np.zeros(T), np.zeros(T)
+            mean, var = np.zeros(osh), np.zeros(osh)
     if what in (3, 4):
-        mean, var = np.zeros(T), np.zeros(T)
+        mean, var = np.zeros(osh), np.zeros(osh)
     Rn = None if Rnew is None else np.ascontiguousarray(np.atleast_1d(Rnew), dtype=np.float64)
     miss = None if missing is None else np.ascontiguousarray(missing, dtype=np.uint8)
-    yv = np.zeros(T) if y is None else np.ascontiguousarray(y, dtype=np.float64)
+    yv = np.zeros(osh) if y is None else np.ascontiguousarray(y, dtype=np.float64)
     et = ee = None
     x0m = pk["x0m"]
     x0P = pk["x0P"]
@@ -114,13 +122,31 @@ def hostsim_run(model, what, y=None, missing=None, L0=4, BS=3, Rnew=None, eps=No
     xs_m = None if xs is None else np.ascontiguousarray(xs[0], dtype=np.float64)
     xs_P = None if xs is None else np.ascontiguousarray(np.asarray(xs[1]).T, dtype=np.float64)
     rc = hostsim().hostsim_run(
-        d, int(is_lti(pk)), what, L0, BS, _i64(T), pk["ordering"], _p(pk["A"]), _i64(pk["sA"]), _p(pk["a"]), _i64(pk["sa"]),
+        d, p_, pk["small"], int(is_lti(pk)), what, L0, BS, _i64(T), pk["ordering"], _p(pk["A"]), _i64(pk["sA"]), _p(pk["a"]), _i64(pk["sa"]),
         _p(pk["Q"]), _i64(pk["sQ"]), _p(pk["H"]), _i64(pk["sH"]), _p(pk["h"]), _i64(pk["sh"]), _p(pk["R"]), _i64(pk["sR"]),
         _p(yv), None if miss is None else miss.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)),
         _p(x0m), _p(x0P), ctypes.byref(lml), _p(m_out), _p(P_out), _p(G), _p(g), _p(L), _p(xfm), _p(xfP),
-        _p(Rn), _i64(0 if Rn is None or Rn.shape[0] == 1 else 1), _p(mean), _p(var), _p(et), _p(ee),
+        _p(Rn), _i64(0 if Rn is None or Rn.size == p_ else 1), _p(mean), _p(var), _p(et), _p(ee),
         _p(elem), _p(rev), _p(xs_m), _p(xs_P))
     out.update(rc=rc, lml=lml.value, m=m_out, P=None if P_out is None else np.swapaxes(P_out, -1, -2),
                G=None if G is None else np.swapaxes(G, -1, -2), g=g, L=None if L is None else np.swapaxes(L, -1, -2),
                xfm=xfm, xfP=None if xfP is None else xfP.T, mean=mean, var=var, elem=elem, rev=rev)
     return out
+
+
+def random_lgssm_small(rng, tv, d, p, T, ordering="F", dense_R=False):
+    """SmallOutputLGC emissions (vector observations), test/models/model_test_utils.jl:187-230."""
+    m = random_lgssm(rng, tv, d, T, ordering)
+    n = T if tv else 1
+
+    def psd(k, lo, hi):
+        U_ = np.linalg.qr(rng.standard_normal((k, k)))[0]
+        return (U_ * (rng.random(k) * (hi - lo) + lo)) @ U_.T
+    m["kind"] = "small"
+    m["H"] = rng.standard_normal((n, p, d))
+    m["h"] = rng.standard_normal((n, p))
+    if dense_R:
+        m["R"] = np.stack([psd(p, 0.9, 1.1) for _ in range(n)])
+    else:
+        m["R"] = np.stack([np.diag(rng.random(p) + 0.1) for _ in range(n)])
+    return m

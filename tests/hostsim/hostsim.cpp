@@ -126,14 +126,21 @@ template <int D, class M> void total_elem(const SoA& E0, double* out) {
 template <int D, bool LTI> int run(const Args& a) {
     ModelView mv = a.mv;
     int64_t n0 = (mv.T + a.L0 - 1) / a.L0;
-    std::vector<double> tile;
-    if (!LTI) {   // general layout: time-tiled copy of the per-step arrays, as tgp_api.hip builds on the device
+    std::vector<double> tile_t, tile_e;
+    if (!LTI) {   // general layout: time-tiled copies of the per-step arrays, as tgp_api.hip builds on the device
         mv.tile_mask = tile_mask_of(mv);
-        mv.tile_nc = tile_offset(mv.tile_mask, 0u, D);
-        tile.assign((size_t)((n0 + 63) / 64) * 64 * a.L0 * (mv.tile_nc > 0 ? mv.tile_nc : 1), 0.0);
-        for (int64_t c = 0; c < n0; ++c)
-            for (int i = 0; i < a.L0; ++i) tile_one_step(a.mv, D, mv.tile_mask, mv.tile_nc, a.L0, c, i, tile.data());
-        mv.tile = tile.data();
+        mv.nc_t = tile_offset_t(mv.tile_mask, 0u, D);
+        mv.nc_e = tile_offset_e(mv.tile_mask, 0u, D);
+        const int Lt = a.L0 / mv.p;
+        const size_t nblk = (size_t)((n0 + 63) / 64) * 64;
+        tile_t.assign(nblk * Lt * mv.nc_t + 1, 0.0);
+        tile_e.assign(nblk * a.L0 * mv.nc_e + 1, 0.0);
+        for (int64_t c = 0; c < n0; ++c) {
+            for (int tl = 0; tl < Lt; ++tl) tile_transition(a.mv, D, mv.tile_mask, mv.nc_t, Lt, c, tl, tile_t.data());
+            for (int i = 0; i < a.L0; ++i) tile_emission(a.mv, D, mv.tile_mask, mv.nc_e, a.L0, c, i, tile_e.data());
+        }
+        mv.tile_t = tile_t.data();
+        mv.tile_e = tile_e.data();
     }
     State<D> x0 = make_state<D>(a.x0m, a.x0P);
     int bad = 0;
@@ -223,7 +230,7 @@ template <int D> int run_d(const Args& a, bool lti) { return lti ? run<D, true>(
 
 }  // namespace
 
-extern "C" int hostsim_run(int d, int lti, int what, int L0, int BS, int64_t T, int ordering, const double* A, int64_t sA,
+extern "C" int hostsim_run(int d, int p, int small_out, int lti, int what, int L0, int BS, int64_t T, int ordering, const double* A, int64_t sA,
                            const double* av, int64_t sa, const double* Q, int64_t sQ, const double* H, int64_t sH,
                            const double* h, int64_t sh, const double* R, int64_t sR, const double* y, const uint8_t* missing,
                            const double* x0m, const double* x0P, double* lml, double* m_out, double* P_out, double* G_out,
@@ -231,7 +238,7 @@ extern "C" int hostsim_run(int d, int lti, int what, int L0, int BS, int64_t T, 
                            double* mean_out, double* var_out, const double* eps_t, const double* eps_e, double* elem_out,
                            double* rev_out, const double* xs_m, const double* xs_P) {
     Args a;
-    a.mv = ModelView{T, ordering, 0, A, av, Q, H, h, R, sA, sa, sQ, sH, sh, sR, y, missing, nullptr, 0, 0u};
+    a.mv = ModelView{T * p, ordering, p, A, av, Q, H, h, R, sA, sa, sQ, sH, sh, sR, y, missing, nullptr, nullptr, 0, 0, 0u, small_out, T};
     a.x0m = x0m; a.x0P = x0P; a.L0 = L0; a.BS = BS; a.lml = lml; a.m_out = m_out; a.P_out = P_out;
     a.G_out = G_out; a.g_out = g_out; a.L_out = L_out; a.xfm = xfm; a.xfP = xfP; a.Rnew = Rnew; a.sRn = sRn;
     a.mean_out = mean_out; a.var_out = var_out; a.eps_t = eps_t; a.eps_e = eps_e; a.what = what;
