@@ -309,3 +309,26 @@ def posterior_logpdf(k, x_tr, sigma2_tr, y_tr, x_pr, sigma2_pr, y_pr, mean=None)
     miss_full = np.zeros(len(x), dtype=bool)
     miss_full[tr_idx] = True
     return ref.logpdf_missing(post, y_full, miss_full)
+
+
+# ------------------------------------------------------------------ separable space-time (space_time/to_gauss_markov.jl)
+def build_lgssm_separable(k_space, k_time, r, t, sigma2):
+    """Literal restatement of /root/reference/src/space_time/to_gauss_markov.jl:1-20 +
+    rectilinear_grid.jl:59-97: A = I (x) A_t, Q = (K_r + 1e-12 I) (x) Q_t, H = I (x) H_t', x0.P = K_r (x) P_t,
+    vector observations (SmallOutputLGC) with Diagonal noise. `sigma2`: scalar or (T, Nr). kind == 'small'."""
+    from . import dense_gp as dg
+    r = np.asarray(r, dtype=np.float64)
+    Nr = len(r)
+    Kr = dg.kernelmatrix(k_space, r)
+    A_t, a_t, Q_t, H_t, h_t, (m_t, P_t) = lgssm_components(k_time, t)
+    T = n_times(t)
+    ident = np.eye(Nr)
+    A = np.stack([np.kron(ident, Ai) for Ai in A_t])
+    a = np.stack([np.tile(ai, Nr) for ai in a_t])
+    Q = np.stack([np.kron(Kr + 1e-12 * ident, Qi) for Qi in Q_t])
+    H = np.stack([np.kron(ident, Hi[None, :]) for Hi in H_t])            # (n, Nr, Nr*d_t)
+    h = np.stack([np.full(Nr, hi) for hi in np.atleast_1d(h_t)])
+    s = np.asarray(sigma2, dtype=np.float64)
+    R = (s * ident)[None] if s.ndim == 0 else np.stack([np.diag(v) for v in s.reshape(T, Nr)])
+    return dict(ordering="F", kind="small", T=T, A=A, a=a, Q=Q, H=H, h=h, R=R,
+                x0m=np.tile(m_t, Nr), x0P=np.kron(Kr, P_t))

@@ -29,6 +29,8 @@ def kappa(k, tau):
         return (1 + np.sqrt(3.0) * at) * np.exp(-np.sqrt(3.0) * at)
     if name == "matern52":
         return (1 + np.sqrt(5.0) * at + 5.0 * at ** 2 / 3.0) * np.exp(-np.sqrt(5.0) * at)
+    if name == "se":                       # KernelFunctions SEKernel: exp(-tau^2 / 2)
+        return np.exp(-0.5 * at ** 2)
     if name == "cosine":
         return np.cos(at)
     if name == "constant":
@@ -101,3 +103,23 @@ def posterior_logpdf(k, x_tr, sigma2_tr, y_tr, x_pr, sigma2_pr, y_pr, mean=None)
     cc = cho_factor(C, lower=True)
     r = np.asarray(y_pr) - mu
     return float(-(npr * LOG2PI + 2 * np.sum(np.log(np.diag(cc[0]))) + r @ cho_solve(cc, r)) / 2.0)
+
+
+def separable_kernelmatrix(k_space, k_time, r, t):
+    """Separable kernel on a rectilinear grid, flat order = space fastest (rectilinear_grid.jl:5-9,31-33):
+    K[(q,p),(q',p')] = k_space(r_p, r_p') k_time(t_q, t_q')  ==  kron(K_t, K_r)."""
+    return np.kron(kernelmatrix(k_time, np.asarray(t, dtype=np.float64)), kernelmatrix(k_space, np.asarray(r, dtype=np.float64)))
+
+
+def mvn_logpdf(K, y):
+    c = cho_factor(K, lower=True)
+    n = len(y)
+    return float(-(n * LOG2PI + 2.0 * np.sum(np.log(np.diag(c[0]))) + y @ cho_solve(c, y)) / 2.0)
+
+
+def mvn_posterior_marginals(K, noise, y, noise_new):
+    """same-inputs posterior marginals of a zero-mean GP with prior covariance K and diagonal noise."""
+    c = cho_factor(K + np.diag(noise), lower=True)
+    mu = K @ cho_solve(c, y)
+    var = np.diag(K) - np.einsum("ij,ji->i", K, cho_solve(c, K))
+    return mu, var + noise_new
