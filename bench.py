@@ -5,10 +5,12 @@ posterior-marginals pass (forward filter + RTS smoother + emission predict) over
     python bench.py --gpus N --steps K --warmup W
 
 A "step" of the bench = logpdf(fx, y) + marginals(posterior(fx, y)(x)) over one synthetic RegularSpacing
-series of T points that is already resident in HBM (y is drawn from the model itself on the device, as
-bench/single_output_gps.jl:143-145 does on the CPU). value = N_gpus-aggregate T / seconds-per-step.
-N > 1: the series is time-sharded, one contiguous segment per rank, with one all_gather of the tiny
-per-segment scan elements per scan direction (RCCL via torch.distributed) -- strong scaling.
+series that is already resident in HBM (y is drawn from the model itself on the device, as
+bench/single_output_gps.jl:143-145 does on the CPU). value = whole-job Kalman steps / seconds-per-step.
+N > 1: ONE series is time-sharded, one contiguous segment per rank, with one all_gather of the tiny
+per-segment scan elements per scan direction plus one scalar all_reduce (RCCL via torch.distributed).
+Default scaling is WEAK: every GPU keeps the headline segment of --T = 1e7 points (the series has N * T points);
+`--scaling strong` keeps the total at --T (use --T 100000000 for BASELINE config 4).
 Prints ONE JSON line (rank 0).
 """
 import argparse
@@ -127,6 +129,7 @@ def main():
     ap.add_argument("--workload", default="matern52_d3", choices=list(WORKLOADS))
     ap.add_argument("--layout", default="lti", choices=["lti", "per_step"])
     ap.add_argument("--chunk", type=int, default=0)
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-general-leg", action="store_true", help="skip the per-step-layout roofline leg")
     ap.add_argument("--cpu-sample", type=int, default=2_000_000)
@@ -146,7 +149,7 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
-    T, name = args.T, args.workload
+    T, name = (args.T * world if args.scaling == "weak" else args.T), args.workload
     d = WORKLOADS[name][1]
 
     # this rank's time segment (strong scaling: the T-point series is split across ranks)
@@ -224,10 +227,10 @@ def main():
         out = dict(
             metric="Kalman steps/sec (logpdf + posterior marginals), T=10^7 Matern32 d=3",
             value=value, unit="Kalman steps/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step,
-            higher_is_better=True, scaling="strong", vs_baseline=None, dtype="f64", data="synthetic",
+            higher_is_better=True, scaling=args.scaling, vs_baseline=None, dtype="f64", data="synthetic",
             config=dict(workload=f"cfg2: {name}, RegularSpacing(0,0.1,T={T}), sigma2_obs=0.1, layout={args.layout}; one logpdf pass "
-                                 f"+ one posterior-marginals pass per step", T=T, d=d, layout=args.layout, chunk=hd_chunk(hd, model),
-                        parallelism=f"time-shard x{world}"),
+                                 f"+ one posterior-marginals pass per step", T=T, T_per_gpu=Tseg, d=d, layout=args.layout,
+                        parallelism=f"time-shard x{world} ({args.scaling}: {'T per GPU fixed' if args.scaling == 'weak' else 'total T fixed'})"),
             roofline=roof,
             kernels={k: dict(avg_ms=v["total_ms"] / max(1, v["calls"]), calls=v["calls"]) for k, v in prof.items()},
         )
@@ -238,10 +241,6 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
-
-
-def hd_chunk(hd, model):
-    return None
 
 
 if __name__ == "__main__":
