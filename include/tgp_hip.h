@@ -84,6 +84,16 @@ int tgp_model_set_x0(tgp_handle* h, const double* x0m, const double* x0P);
 /* ---- logpdf(model::LGSSM, y): lgssm.jl:147-165 (+ missings.jl:8-13 when `missing` != NULL) ------ */
 int tgp_logpdf(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t flags, double* out);
 
+/* ---- logpdf and its gradient w.r.t. `nparams` hyper-parameters, by forward-mode tangent scans (one pass of the
+ *      dual-number instantiation of the engine per parameter). The reference has no gradient code: Mooncake.jl
+ *      differentiates the generic Julia loop (test/gp/lti_sde.jl:203-206, bench/single_output_gps.jl:149-156).
+ *      Forward models with every block shared (Fill: regular spacing, homoscedastic noise), p == 1.
+ *      Tangents of the shared blocks per parameter k (host pointers): dA [np][d*d] column-major, da [np][d],
+ *      dQ [np][d*d], dH [np][d], dh [np], dR [np], dx0m [np][d], dx0P [np][d*d]. grad_out [np] (host). */
+int tgp_logpdf_grad(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t flags, int nparams,
+                    const double* dA, const double* da, const double* dQ, const double* dH, const double* dh,
+                    const double* dR, const double* dx0m, const double* dx0P, double* lml_out, double* grad_out);
+
 /* ---- _filter(model, y): lgssm.jl:171-187. m_out [T][d], P_out [T][d*d] (either may be NULL);
  *      lml_out (host, may be NULL) receives the log marginal likelihood as a by-product. */
 int tgp_filter(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t flags, double* m_out,

@@ -36,6 +36,7 @@ _SIGS = {
     "tgp_model_set": (ctypes.c_int, [_vp, _i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, _u32] + [_vp] * 8),
     "tgp_model_set_x0": (ctypes.c_int, [_vp, _vp, _vp]),
     "tgp_logpdf": (ctypes.c_int, [_vp, _vp, _vp, _u32, _dp]),
+    "tgp_logpdf_grad": (ctypes.c_int, [_vp, _vp, _vp, _u32, ctypes.c_int] + [_vp] * 8 + [_dp, _vp]),
     "tgp_filter": (ctypes.c_int, [_vp, _vp, _vp, _u32, _vp, _vp, _dp]),
     "tgp_posterior": (ctypes.c_int, [_vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp, _vp]),
     "tgp_posterior_marginals": (ctypes.c_int, [_vp, _vp, _vp, _vp, _u32, _vp, _vp, _dp]),
@@ -65,6 +66,10 @@ class TGPError(RuntimeError):
 
 class NotPositiveDefinite(TGPError):
     """Mirrors Julia's PosDefException / DomainError on this path (lgc.jl:135,250; lgssm.jl:235)."""
+
+
+class Unsupported(TGPError, NotImplementedError):
+    """TGP_EUNSUPPORTED: a combination the device engine does not implement (Julia: MethodError-class)."""
 
 
 def load():
@@ -143,6 +148,8 @@ class Handle:
             raise NotPositiveDefinite(rc, msg)
         if rc == EINVAL and "Dimension mismatch" in msg:
             raise ValueError(msg)
+        if rc == EUNSUPPORTED:
+            raise Unsupported(rc, msg)
         raise TGPError(rc, msg)
 
     def set_option(self, opt, value):

@@ -63,6 +63,28 @@ __global__ __launch_bounds__(256) void k_tile_model(ModelView raw, int d, uint32
     for (int i = 0; i < L0; ++i) tile_emission(raw, d, mask, nc_e, L0, c, i, tile_e);
 }
 
+// gradient pass: partial[4b + 0..3] -> result[0] lml (+ missing compensation), [1] n missing, [2] bad, [3] d lml / d theta
+__global__ __launch_bounds__(256) void k_finalize_ad(const double* __restrict__ partial, int64_t nblocks, double* __restrict__ result) {
+    __shared__ double sh[12];
+    __shared__ double sh2[4];
+    double a = 0.0, b = 0.0, dl = 0.0;
+    int c = 0;
+    for (int64_t i = threadIdx.x; i < nblocks; i += 256) {
+        a += partial[4 * i];
+        b += partial[4 * i + 1];
+        c |= partial[4 * i + 2] != 0.0;
+        dl += partial[4 * i + 3];
+    }
+    block_sum3(a, b, c, sh);
+    block_sum_d(dl, sh2);
+    if (threadIdx.x == 0) {
+        result[0] = a + b * 0.5 * (kLog2Pi + log(kLargeVar));
+        result[1] = b;
+        result[2] = (double)c;
+        result[3] = dl;
+    }
+}
+
 namespace {
 
 struct DevBuf {
@@ -126,7 +148,8 @@ struct tgp_handle {
     // per-call staging
     DevBuf by, bmiss, bRnew, beps_t, beps_e, bo1, bo2, bo3;
     // scans and scratch
-    ScanCtx F, Rv;
+    ScanCtx F, Rv, Fad;
+    DevBuf btan, bx0ad;
     DevBuf fs, partial, result, segtmp;
     double* host_result = nullptr;  // pinned, 8 doubles: [0] lml [1] nmiss [2] filter-bad ; int flags at [4]
     int64_t opt_chunk = 0;
@@ -300,11 +323,13 @@ void choose_chunk(tgp_handle* h) {
 
 int scan_prepare(tgp_handle* h, ScanCtx& c, int monoid, int64_t n0) {
     c.monoid = monoid;
-    c.NC = (monoid == kFilter) ? felem_size(h->d) : aelem_size(h->d);
-    c.NS = state_size(h->d);
+    c.NC = (monoid == kFilter) ? felem_size(h->d) : (monoid == kFilterAD) ? 2 * felem_size(h->d) : aelem_size(h->d);
+    c.NS = (monoid == kFilterAD) ? 2 * state_size(h->d) : state_size(h->d);
+    // the dual-number top-level scan runs in ONE 256-lane block (a 512-lane block caps it at 256 VGPRs and spills)
+    const int64_t top_cap = (monoid == kFilterAD) ? 256 : (int64_t)kTopBS * kScanE;
     c.n.clear();
     c.n.push_back(n0);
-    while (c.n.back() > (int64_t)kTopBS * kScanE) c.n.push_back((c.n.back() + 256 * kScanE - 1) / (256 * kScanE));
+    while (c.n.back() > top_cap) c.n.push_back((c.n.back() + 256 * kScanE - 1) / (256 * kScanE));
     size_t total = (size_t)c.NS;
     for (int64_t n : c.n) total += (size_t)(c.NC + c.NS) * (size_t)n;
     HIPCHK(c.slab.ensure(total * sizeof(double)));
@@ -323,7 +348,7 @@ int scan_prepare(tgp_handle* h, ScanCtx& c, int monoid, int64_t n0) {
 
 void scan_up(tgp_handle* h, ScanCtx& c) {
     for (size_t l = 0; l + 1 < c.n.size(); ++l) {
-        LaunchScope ls(h, c.monoid == kFilter ? "k_scan_reduce<filter>" : "k_scan_reduce<affine>");
+        LaunchScope ls(h, c.monoid == kFilter ? "k_scan_reduce<filter>" : c.monoid == kFilterAD ? "k_scan_reduce<filter,grad>" : "k_scan_reduce<affine>");
         h->kt->scan_reduce(c.monoid, c.E[l], c.n[l], c.E[l + 1], c.n[l + 1], h->stream);
     }
 }
@@ -331,11 +356,11 @@ void scan_up(tgp_handle* h, ScanCtx& c) {
 void scan_down(tgp_handle* h, ScanCtx& c, const double* x0dev) {
     const int top = (int)c.n.size() - 1;
     {
-        LaunchScope ls(h, c.monoid == kFilter ? "k_scan_apply<filter,top>" : "k_scan_apply<affine,top>");
+        LaunchScope ls(h, c.monoid == kFilter ? "k_scan_apply<filter,top>" : c.monoid == kFilterAD ? "k_scan_apply<filter,grad,top>" : "k_scan_apply<affine,top>");
         h->kt->scan_apply(c.monoid, c.n[top] <= 256 * kScanE ? 256 : kTopBS, c.E[top], c.n[top], x0dev, 1, c.S[top], c.fin, h->stream);
     }
     for (int l = top - 1; l >= 0; --l) {
-        LaunchScope ls(h, c.monoid == kFilter ? "k_scan_apply<filter>" : "k_scan_apply<affine>");
+        LaunchScope ls(h, c.monoid == kFilter ? "k_scan_apply<filter>" : c.monoid == kFilterAD ? "k_scan_apply<filter,grad>" : "k_scan_apply<affine>");
         h->kt->scan_apply(c.monoid, 256, c.E[l], c.n[l], c.S[l + 1], c.n[l + 1], c.S[l], nullptr, h->stream);
     }
 }
@@ -564,7 +589,7 @@ int tgp_destroy(tgp_handle* h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     for (DevBuf* b : {&h->bA, &h->ba, &h->bQ, &h->bH, &h->bh, &h->bR, &h->bx0, &h->bx0r, &h->by, &h->bmiss, &h->bRnew, &h->beps_t,
-                      &h->beps_e, &h->bo1, &h->bo2, &h->bo3, &h->F.slab, &h->Rv.slab, &h->fs, &h->partial, &h->result, &h->segtmp, &h->tile_t, &h->tile_e})
+                      &h->beps_e, &h->bo1, &h->bo2, &h->bo3, &h->F.slab, &h->Rv.slab, &h->fs, &h->partial, &h->result, &h->segtmp, &h->tile_t, &h->tile_e, &h->Fad.slab, &h->btan, &h->bx0ad})
         b->release();
     for (auto& e : h->ev)
         if (e) (void)hipEventDestroy(e);
@@ -899,6 +924,87 @@ int tgp_rand(tgp_handle* h, const double* eps_t, const double* eps_e, const doub
     tm.kernels_done();
     TRY(copy_back(h, y_out, dy, nT, odev));
     return tm.finish();
+}
+
+int tgp_logpdf_grad(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t flags, int nparams, const double* dA,
+                    const double* da, const double* dQ, const double* dH, const double* dh, const double* dR, const double* dx0m,
+                    const double* dx0P, double* lml_out, double* grad_out) {
+    TRY(check_ready(h));
+    if (nparams < 1 || !grad_out) return h->fail(TGP_EINVAL, "nparams must be >= 1 and grad_out non-null");
+    if (!dA || !da || !dQ || !dH || !dh || !dR || !dx0m || !dx0P) return h->fail(TGP_EINVAL, "null tangent array");
+    if (!h->lti || h->mv.sR != 0 || h->p != 1 || h->ordering != 0)
+        return h->fail(TGP_EUNSUPPORTED, "tgp_logpdf_grad: Forward model with all blocks shared (Fill) and scalar observations only");
+    const int d = h->d, dd = d * d, per = 2 * dd + 2 * d + 2;   // A, a, Q, H, h, R tangents of one parameter
+    CallTimer tm(h);
+    TRY(set_obs(h, y, missing, flags));
+    // stage all tangent blocks once: [param][A | a | Q | H | h | R]
+    std::vector<double> host((size_t)nparams * per);
+    for (int k = 0; k < nparams; ++k) {
+        double* q = host.data() + (size_t)k * per;
+        std::memcpy(q, dA + (size_t)k * dd, dd * sizeof(double)); q += dd;
+        std::memcpy(q, da + (size_t)k * d, d * sizeof(double)); q += d;
+        std::memcpy(q, dQ + (size_t)k * dd, dd * sizeof(double)); q += dd;
+        std::memcpy(q, dH + (size_t)k * d, d * sizeof(double)); q += d;
+        *q++ = dh[k];
+        *q++ = dR[k];
+    }
+    HIPCHK(h->btan.ensure(host.size() * sizeof(double)));
+    HIPCHK(hipMemcpyAsync(h->btan.p, host.data(), host.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    const int ns = state_size(d);
+    std::vector<double> x0ad((size_t)nparams * 2 * ns), pv, pt;
+    for (int k = 0; k < nparams; ++k) {
+        pack_state(d, h->x0m.data(), h->x0P.data(), pv);
+        pack_state(d, dx0m + (size_t)k * d, dx0P + (size_t)k * dd, pt);
+        for (int i = 0; i < ns; ++i) {
+            x0ad[(size_t)k * 2 * ns + 2 * i] = pv[i];
+            x0ad[(size_t)k * 2 * ns + 2 * i + 1] = pt[i];
+        }
+    }
+    HIPCHK(h->bx0ad.ensure(x0ad.size() * sizeof(double)));
+    HIPCHK(hipMemcpyAsync(h->bx0ad.p, x0ad.data(), x0ad.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));   // host staging vectors go out of scope
+    tm.inputs_done();
+    choose_chunk(h);
+    h->reduce_valid = false;
+    h->smoother_valid = false;
+    TRY(scan_prepare(h, h->Fad, kFilterAD, h->n0));
+    const int64_t nblocks = (h->n0 + 255) / 256;
+    HIPCHK(h->partial.ensure((size_t)nblocks * 4 * sizeof(double)));
+    int rc = TGP_OK;
+    for (int k = 0; k < nparams && rc == TGP_OK; ++k) {
+        ModelView mv = h->mv;
+        const double* t = h->btan.d() + (size_t)k * per;
+        mv.dA = t; t += dd;
+        mv.da = t; t += d;
+        mv.dQ = t; t += dd;
+        mv.dH = t; t += d;
+        mv.dh = t; t += 1;
+        mv.dR = t;
+        {
+            LaunchScope ls(h, "k_reduce_filter<lti,grad>");
+            h->kt->reduce_filter_ad(mv, h->L0, h->n0, h->Fad.E[0], h->stream);
+        }
+        scan_up(h, h->Fad);
+        scan_down(h, h->Fad, h->bx0ad.d() + (size_t)k * 2 * ns);
+        {
+            LaunchScope ls(h, "k_apply_filter<lti,grad>");
+            h->kt->apply_filter_ad(mv, h->L0, h->n0, h->Fad.S[0], h->partial.d(), h->stream);
+        }
+        {
+            LaunchScope ls(h, "k_finalize<grad>");
+            hipLaunchKernelGGL(k_finalize_ad, dim3(1), dim3(256), 0, h->stream, h->partial.d(), nblocks, h->result.d());
+        }
+        if (k + 1 < nparams) {   // results of this parameter, then reuse the result block for the next one
+            HIPCHK(hipMemcpyAsync(h->host_result, h->result.p, 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            grad_out[k] = h->host_result[3];
+            if (h->host_result[2] != 0.0) rc = h->fail(TGP_ENOTPD, "innovation variance not positive");
+        }
+    }
+    tm.kernels_done();
+    int rc2 = tm.finish(lml_out);
+    grad_out[nparams - 1] = h->host_result[3];
+    return rc != TGP_OK ? rc : rc2;
 }
 
 int tgp_elem_size(int kind, int d) { return kind == 0 ? felem_size(d) : aelem_size(d); }

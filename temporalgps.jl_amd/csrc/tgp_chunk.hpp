@@ -44,7 +44,13 @@ struct ModelView {
     uint32_t tile_mask;
     int32_t small_out;   // emissions are SmallOutputLGC (affects rand: lgc.jl:84-87 adds 1e-9 to the noise)
     int64_t Tt;          // time steps
+    // Tangents of the SHARED model blocks w.r.t. ONE hyper-parameter (forward-mode gradient pass, namespace
+    // tgp::ad); null => zero. Same shapes as A, a, Q, H, h, R above (one block each).
+    const double *dA, *da, *dQ, *dH, *dh, *dR;
 };
+
+TGP_HD void set_real(double& x, const double* v, const double*, int i) { x = v[i]; }
+TGP_HD void set_real(Dual& x, const double* v, const double* d, int i) { x = Dual(v[i], d ? d[i] : 0.0); }
 
 enum : uint32_t { kTileA = 1u, kTilea = 2u, kTileQ = 4u, kTileH = 8u, kTileh = 16u, kTileR = 32u };
 
@@ -137,86 +143,6 @@ struct DirectIO {
     TGP_HD void flush(const ModelView&, int64_t, int, int) {}
 };
 
-// Loads one processing step. LTI == true: A, a, Q, H, h are shared (hoisted once when p == 1; for p > 1 the
-// observation row j is a wave-uniform load per step); only y and, when per-step, R stream (through the IO).
-// LTI == false: per-step arrays come from the time-tiled records (coalesced rows), the others are shared.
-template <int D, bool LTI> struct StepLoader {
-    double A[D * D], a[D], Q[D * D], H[D], h, R, y;
-    bool do_predict, is_missing;
-    int64_t te, tm;   // time / micro storage index of the current step
-    int j, tl;        // observation inside the time step, time step inside the chunk
-    int oA, oa, oQ, oH, oh, oR;
-
-    TGP_HD void init(const ModelView& mv) {
-        const uint32_t m = LTI ? 0u : mv.tile_mask;
-        if (!(m & kTileA)) { TGP_UNROLL for (int i = 0; i < D * D; ++i) A[i] = mv.A[i]; }
-        if (!(m & kTileQ)) { TGP_UNROLL for (int i = 0; i < D * D; ++i) Q[i] = mv.Q[i]; }
-        if (!(m & kTilea)) { TGP_UNROLL for (int i = 0; i < D; ++i) a[i] = mv.a[i]; }
-        if (!(m & kTileH) && mv.p == 1) { TGP_UNROLL for (int i = 0; i < D; ++i) H[i] = mv.H[i]; }
-        if (!(m & kTileh) && mv.p == 1) h = mv.h[0];
-        if (!LTI) {
-            oA = tile_offset_t(m, kTileA, D); oa = tile_offset_t(m, kTilea, D); oQ = tile_offset_t(m, kTileQ, D);
-            oH = tile_offset_e(m, kTileH, D); oh = tile_offset_e(m, kTileh, D); oR = tile_offset_e(m, kTileR, D);
-        }
-    }
-    // c = chunk, i = step inside the chunk (L0 % p == 0)
-    TGP_HD void index(const ModelView& mv, int64_t c, int i, int L0) {
-        int64_t tproc;
-        if (mv.p == 1) {
-            tl = i; j = 0;
-            tproc = c * (int64_t)L0 + i;
-        } else {
-            tl = i / mv.p; j = i - tl * mv.p;
-            tproc = c * (int64_t)(L0 / mv.p) + tl;
-        }
-        te = time_index(mv, tproc);
-        tm = te * mv.p + j;
-        do_predict = (j == 0) && !(mv.ordering != 0 && tproc == 0);
-    }
-    TGP_HD void load_transition(const ModelView& mv, int64_t c, int L0) {
-        if (!LTI && do_predict && mv.nc_t > 0) {
-            const double* q = mv.tile_t + fs_index(c, tl, 0, L0 / mv.p, mv.nc_t);
-            if (mv.tile_mask & kTileA) { TGP_UNROLL for (int k = 0; k < D * D; ++k) A[k] = q[(oA + k) * 64]; }
-            if (mv.tile_mask & kTileQ) { TGP_UNROLL for (int k = 0; k < D * D; ++k) Q[k] = q[(oQ + k) * 64]; }
-            if (mv.tile_mask & kTilea) { TGP_UNROLL for (int k = 0; k < D; ++k) a[k] = q[(oa + k) * 64]; }
-        }
-    }
-    TGP_HD void load_emission(const ModelView& mv, int64_t c, int i, int L0) {
-        const uint32_t m = LTI ? 0u : mv.tile_mask;
-        if (m & (kTileH | kTileh)) {
-            const double* q = mv.tile_e + fs_index(c, i, 0, L0, mv.nc_e);
-            if (m & kTileH) { TGP_UNROLL for (int k = 0; k < D; ++k) H[k] = q[(oH + k) * 64]; }
-            if (m & kTileh) h = q[oh * 64];
-        }
-        if (mv.p > 1) {   // shared (Fill) emission with several rows: wave-uniform row j
-            if (!(m & kTileH)) { TGP_UNROLL for (int k = 0; k < D; ++k) H[k] = mv.H[j * D + k]; }
-            if (!(m & kTileh)) h = mv.h[j];
-        }
-    }
-    // R of this step: tiled record (general layout) / shared / staged stream (LTI with per-step R)
-    template <class IO> TGP_HD double load_R(const ModelView& mv, int64_t c, int i, int L0, const IO& io, int gi) const {
-        if (!LTI && (mv.tile_mask & kTileR)) return mv.tile_e[fs_index(c, i, oR, L0, mv.nc_e)];
-        return (mv.sR == 0) ? mv.R[j] : io.in1(tm, gi);
-    }
-    template <class IO> TGP_HD void load_obs(const ModelView& mv, int64_t c, int i, int L0, const IO& io, int gi) {
-        R = load_R(mv, c, i, L0, io, gi);
-        y = io.in0(tm, gi);
-        is_missing = (mv.missing != nullptr) && (mv.missing[tm] != 0);
-        if (is_missing) { y = 0.0; R = kLargeVar; }
-    }
-    // full step: i = step inside the chunk, gi = position inside the IO group
-    template <class IO> TGP_HD void load(const ModelView& mv, int64_t c, int i, int L0, const IO& io, int gi) {
-        index(mv, c, i, L0);
-        load_transition(mv, c, L0);
-        load_emission(mv, c, i, L0);
-        load_obs(mv, c, i, L0, io, gi);
-    }
-};
-
-// Whether the IO must stage mv.R: only the LTI family streams a per-step R through it.
-template <bool LTI> TGP_HD bool io_stages_R(const ModelView& mv) { return LTI && mv.sR != 0; }
-
-// ------------------------------------------------------------------------------------------ pass 1
 // Chunk bounds; lanes past the last chunk (c >= n0) get an empty range but still take part in the
 // wave-cooperative IO.
 TGP_HD void chunk_range(const ModelView& mv, int64_t c, int L0, int64_t& r0, int64_t& r1) {
@@ -225,27 +151,6 @@ TGP_HD void chunk_range(const ModelView& mv, int64_t c, int L0, int64_t& r0, int
     r1 = r0 + L0 < mv.T ? r0 + L0 : mv.T;
 }
 
-template <int D, bool LTI, class IO, typename Store>
-TGP_HD void chunk_reduce_filter(const ModelView& mv, int64_t c, int L0, IO& io, Store st) {
-    int64_t r0, r1;
-    chunk_range(mv, c, L0, r0, r1);
-    FElem<D> e;
-    e.identity();
-    StepLoader<D, LTI> sl;
-    sl.init(mv);
-    for (int g = 0; g < L0; g += IO::G) {
-        io.begin(mv, c, g, L0);
-        const int64_t rg = r0 + g;
-        const int gend = (int)((r1 - rg) < IO::G ? (r1 - rg) : IO::G);
-        for (int i = 0; i < gend; ++i) {
-            sl.load(mv, c, g + i, L0, io, i);
-            f_extend<D>(e, sl.do_predict, sl.A, sl.a, sl.Q, sl.H, sl.h, sl.R, sl.y);
-        }
-    }
-    if (r1 > r0) store_felem<D>(e, st);
-}
-
-// ------------------------------------------------------------------------------------------ pass 2
 struct FilterOut {
     double* m_out;  // [T][d]      filtering means      (MODE >= 1, may be null)
     double* P_out;  // [T][d*d]    filtering covariances
@@ -255,221 +160,12 @@ struct FilterOut {
     double* L_out;
 };
 
-struct ChunkStats {
-    double lml;
-    double nmiss;
-    int32_t bad;  // 1 => non-positive innovation variance / Cholesky failure inside this chunk
-};
+using real_t = double;
+#include "tgp_chunk_body.inc"
 
-// MODE 0: logpdf only. MODE 1: + filtering distributions. MODE 2: smoother forward pass -- filtering-state
-// scratch + the chunk's smoother element, composed step by step from the reference's own (jittered)
-// invert_dynamics and stored through `rst`. MODE 3: materialise the posterior model: per-step
-// invert_dynamics -> (G, g, L) outputs (lgssm.jl:215-221), no scratch, no element.
-// (A chunk-level closed form of the smoother element from the chunk's filter element -- chunk_smoother_element,
-// tgp_math.hpp -- needs no per-step work, but it is the EXACT smoother: it differs from the reference's
-// 1e-10-jittered recursion by up to 2.5e-8 on the bench parametrisation, so it is not used.)
-template <int D, bool LTI, int MODE, class IO, typename RStore>
-TGP_HD ChunkStats chunk_apply_filter(const ModelView& mv, int64_t c, int L0, State<D>& x, const FilterOut& out, IO& io, RStore rst) {
-    int64_t r0, r1;
-    chunk_range(mv, c, L0, r0, r1);
-    ChunkStats cs{0.0, 0.0, 0};
-    StepLoader<D, LTI> sl;
-    sl.init(mv);
-    AElem<D> rev;
-    if (MODE == 2) rev.identity();
-    bool ok = true;
-    for (int g = 0; g < L0; g += IO::G) {
-      io.begin(mv, c, g, L0);
-      const int64_t rg = r0 + g;
-      const int gend = (int)((r1 - rg) < IO::G ? (r1 - rg) : IO::G);
-      double sprod = 1.0, quad = 0.0;   // product of the group's innovation variances, sum of v^2 / S
-      for (int gi = 0; gi < gend; ++gi) {
-        const int64_t r = rg + gi;
-        sl.load(mv, c, g + gi, L0, io, gi);
-        if (MODE >= 2 && sl.do_predict) {
-            double mf[D], Pf[D * D];
-            copy_n<D>(x.m, mf);
-            copy_n<D * D>(x.P, Pf);
-            predict<D>(sl.A, sl.a, sl.Q, x.m, x.P);
-            double G[D * D], g_[D], L[D * D];
-            ok = invert_dynamics<D>(mf, Pf, x.m, x.P, sl.A, G, g_, L) && ok;
-            if (MODE == 2) a_extend_right<D>(rev, G, g_, L);
-            if (MODE == 3 && out.G_out) {
-                TGP_UNROLL for (int i = 0; i < D * D; ++i) { out.G_out[sl.te * D * D + i] = G[i]; out.L_out[sl.te * D * D + i] = L[i]; }
-                TGP_UNROLL for (int i = 0; i < D; ++i) out.g_out[sl.te * D + i] = g_[i];
-            }
-        } else if (sl.do_predict) {
-            predict<D>(sl.A, sl.a, sl.Q, x.m, x.P);
-        }
-        double S;
-        quad += update_scalar_nolog<D>(sl.H, sl.h, sl.R, sl.y, x.m, x.P, ok, S);
-        sprod *= S;
-        if (sprod > 1e100 || sprod < 1e-100) {   // keep the running product far from over/underflow
-            cs.lml -= 0.5 * log(sprod);
-            sprod = 1.0;
-        }
-        cs.nmiss += sl.is_missing ? 1.0 : 0.0;
-        if (MODE >= 1 && out.m_out && sl.j == mv.p - 1) {
-            TGP_UNROLL for (int i = 0; i < D; ++i) out.m_out[sl.te * D + i] = x.m[i];
-        }
-        if (MODE >= 1 && out.P_out && sl.j == mv.p - 1) {
-            TGP_UNROLL for (int i = 0; i < D * D; ++i) out.P_out[sl.te * D * D + i] = x.P[i];
-        }
-        if (MODE == 2 && out.fs) {
-            int i = (int)(r - r0);
-            double* fs = out.fs;
-            int L0_ = L0;
-            store_state<D>(x, [=](int k, double v) { fs[fs_index(c, i, k, L0_, Dim<D>::NS)] = v; });
-        }
-      }
-      // lml of the group: -(n log 2pi + log prod S + sum v^2/S) / 2   (lgc.jl:254 summed over the group)
-      if (gend > 0) cs.lml -= 0.5 * (gend * kLog2Pi + log(sprod) + quad);
-    }
-    if (MODE == 2 && r1 > r0) store_aelem<D>(rev, rst);
-    cs.bad = ok ? 0 : 1;
-    return cs;
-}
-
-// ------------------------------------------------------------------------------------------ pass 3
-// RTS smoother on chunk c. `xs` = smoothed state at the chunk's LAST step; `carry` = filtered state
-// just before the chunk's first step. Emits N(H x + h, H P H' + Rnew) for every step (lgssm.jl:111-115
-// on the posterior model with replace_observation_noise_cov, missings.jl:35-41).
-template <int D, bool LTI, class IO>
-TGP_HD int chunk_smooth(const ModelView& mv, int64_t c, int L0, State<D>& xs, const State<D>& carry, const double* fs,
-                        int64_t sRn, IO& io) {
-    int64_t r0, r1;
-    chunk_range(mv, c, L0, r0, r1);
-    StepLoader<D, LTI> sl;
-    sl.init(mv);
-    bool ok = true;
-
-    for (int g = ((L0 - 1) / IO::G) * IO::G; g >= 0; g -= IO::G) {
-        io.begin(mv, c, g, L0);   // stages R_new (io.a1) when it is per-step
-        const int64_t rg = r0 + g;
-        const int gend = (int)((r1 - rg) < IO::G ? (r1 - rg) : IO::G);
-        for (int gi = gend - 1; gi >= 0; --gi) {
-            const int64_t r = rg + gi;
-            sl.index(mv, c, g + gi, L0);
-            sl.load_transition(mv, c, L0);
-            sl.load_emission(mv, c, g + gi, L0);
-            double mean, var;
-            emit_scalar<D>(sl.H, sl.h, (sRn == 0) ? io.a1[sl.j] : io.in1(sl.tm, gi), xs.m, xs.P, mean, var);
-            io.out(sl.tm, gi, mean, var);
-            if (!sl.do_predict) continue;   // inside a time step (or the skipped first predict): the state does not move
-            State<D> xf;  // filtered state before this time step
-            if (r == r0) {
-                xf = carry;
-            } else {
-                int i = (int)(r - r0) - 1;
-                int L0_ = L0;
-                load_state<D>(xf, [=](int k) { return fs[fs_index(c, i, k, L0_, Dim<D>::NS)]; });
-            }
-            double mp[D], Pp[D * D];
-            copy_n<D>(xf.m, mp);
-            copy_n<D * D>(xf.P, Pp);
-            predict<D>(sl.A, sl.a, sl.Q, mp, Pp);
-            double G[D * D], g_[D], L[D * D];
-            ok = invert_dynamics<D>(xf.m, xf.P, mp, Pp, sl.A, G, g_, L) && ok;
-            predict<D>(G, g_, L, xs.m, xs.P);
-        }
-        io.flush(mv, c, g, L0);
-    }
-    return ok ? 0 : 1;
-}
-
-// ------------------------------------------------------------------------------------------ affine passes
-// Prior marginals (COV, !RAND): x' = A x + a, P' = A P A' + Q; emits N(H x + h, H P H' + R).
-// rand (RAND, !COV): x' = A x + a + chol(Q + 1e-9 I).U' eps_t ; y = H x' + h + sqrt(R) eps_e.
-template <int D> TGP_HD bool noise_factor(const double* Q, double* Lq) {  // lower factor, column-major
-    double Qj[D * D], U[D * D];
-    copy_n<D * D>(Q, Qj);
-    TGP_UNROLL for (int i = 0; i < D; ++i) Qj[i + i * D] += 1e-9;  // lgc.jl:86
-    bool ok = chol_upper<D>(Qj, U);
-    TGP_UNROLL for (int j = 0; j < D; ++j) TGP_UNROLL for (int i = 0; i < D; ++i) Lq[i + j * D] = U[j + i * D];
-    return ok;
-}
-
-template <int D, bool LTI, bool RAND, typename Store>
-TGP_HD int chunk_reduce_affine(const ModelView& mv, int64_t c, int L0, const double* eps_t, Store st) {
-    int64_t r0, r1;
-    chunk_range(mv, c, L0, r0, r1);
-    AElem<D> e;
-    e.identity();
-    StepLoader<D, LTI> sl;
-    sl.init(mv);
-    double Lq[D * D];
-    bool ok = true;
-    if (RAND && LTI) ok = noise_factor<D>(sl.Q, Lq);
-    for (int64_t r = r0; r < r1; ++r) {
-        sl.index(mv, c, (int)(r - r0), L0);
-        sl.load_transition(mv, c, L0);
-        if (!sl.do_predict) continue;
-        if (RAND) {
-            if (!LTI) ok = noise_factor<D>(sl.Q, Lq) && ok;
-            double cvec[D];
-            const double* ep = eps_t + trans_index(mv, c * (int64_t)(L0 / mv.p) + sl.tl) * D;
-            TGP_UNROLL for (int i = 0; i < D; ++i) {
-                double acc = sl.a[i];
-                TGP_UNROLL for (int k = 0; k <= i; ++k) acc = fma(Lq[i + k * D], ep[k], acc);
-                cvec[i] = acc;
-            }
-            a_extend<D, false>(e, sl.A, cvec, sl.Q);
-        } else {
-            a_extend<D, true>(e, sl.A, sl.a, sl.Q);
-        }
-    }
-    store_aelem<D>(e, st);
-    return ok ? 0 : 1;
-}
-
-template <int D, bool LTI, bool RAND, class IO>
-TGP_HD int chunk_apply_affine(const ModelView& mv, int64_t c, int L0, State<D>& x, const double* eps_t, IO& io) {
-    int64_t r0, r1;
-    chunk_range(mv, c, L0, r0, r1);
-    StepLoader<D, LTI> sl;
-    sl.init(mv);
-    double Lq[D * D];
-    bool ok = true;
-    if (RAND && LTI) ok = noise_factor<D>(sl.Q, Lq);
-    for (int g = 0; g < L0; g += IO::G) {
-      io.begin(mv, c, g, L0);   // RAND: stages eps_e (io.a0); per-step R (io.a1)
-      const int64_t rg = r0 + g;
-      const int gend = (int)((r1 - rg) < IO::G ? (r1 - rg) : IO::G);
-      for (int gi = 0; gi < gend; ++gi) {
-        const int64_t r = rg + gi;
-        sl.index(mv, c, g + gi, L0);
-        sl.load_transition(mv, c, L0);
-        sl.load_emission(mv, c, g + gi, L0);
-        const double R = sl.load_R(mv, c, g + gi, L0, io, gi);
-        if (sl.do_predict) {
-            if (RAND) {
-                if (!LTI) ok = noise_factor<D>(sl.Q, Lq) && ok;
-                const double* ep = eps_t + trans_index(mv, c * (int64_t)(L0 / mv.p) + sl.tl) * D;
-                double xn[D];
-                mat_vec<D>(sl.A, x.m, xn);
-                TGP_UNROLL for (int i = 0; i < D; ++i) {
-                    double nz = 0.0;
-                    TGP_UNROLL for (int k = 0; k <= i; ++k) nz = fma(Lq[i + k * D], ep[k], nz);
-                    x.m[i] = (xn[i] + sl.a[i]) + nz;
-                }
-            } else {
-                predict<D>(sl.A, sl.a, sl.Q, x.m, x.P);
-            }
-        }
-        if (RAND) {
-            double yy = 0.0;
-            TGP_UNROLL for (int i = 0; i < D; ++i) yy = fma(sl.H[i], x.m[i], yy);
-            // scalar emission: sqrt(R) eps (lgc.jl:241-243); vector emission with diagonal R: chol(R + 1e-9 I).U' eps (lgc.jl:84-87)
-            io.out(sl.tm, gi, (yy + sl.h) + sqrt(mv.small_out ? R + 1e-9 : R) * io.in0(sl.tm, gi), 0.0);
-        } else {
-            double mean, var;
-            emit_scalar<D>(sl.H, sl.h, R, x.m, x.P, mean, var);
-            io.out(sl.tm, gi, mean, var);
-        }
-      }
-      io.flush(mv, c, g, L0);
-    }
-    return ok ? 0 : 1;
-}
+namespace ad {
+using real_t = Dual;
+#include "tgp_chunk_body.inc"
+}  // namespace ad
 
 }  // namespace tgp

@@ -18,21 +18,48 @@
 namespace tgp {
 
 // ---------------------------------------------------------------- monoid traits (device)
+// E: scan element, S: carried state; NC / NS: doubles per element / state in the SoA scratch (planes [k][n]).
 template <int D> struct FilterMonoid {
     using E = FElem<D>;
-    static constexpr int NC = Dim<D>::NF;
+    using S = State<D>;
+    static constexpr int NC = Dim<D>::NF, NS = Dim<D>::NS;
     template <typename Ld> static __device__ __forceinline__ void load(E& e, Ld ld) { load_felem<D>(e, ld); }
     template <typename St> static __device__ __forceinline__ void store(const E& e, St st) { store_felem<D>(e, st); }
     static __device__ __forceinline__ void combine(const E& a, const E& b, E& o) { f_combine<D>(a, b, o); }
-    static __device__ __forceinline__ void apply(const E& e, const State<D>& in, State<D>& out) { f_apply<D>(e, in, out); }
+    static __device__ __forceinline__ void apply(const E& e, const S& in, S& out) { f_apply<D>(e, in, out); }
+    template <typename Ld> static __device__ __forceinline__ void load_s(S& s, Ld ld) { load_state<D>(s, ld); }
+    template <typename St> static __device__ __forceinline__ void store_s(const S& s, St st) { store_state<D>(s, st); }
 };
 template <int D, bool COV> struct AffineMonoid {
     using E = AElem<D>;
-    static constexpr int NC = Dim<D>::NA;
+    using S = State<D>;
+    static constexpr int NC = Dim<D>::NA, NS = Dim<D>::NS;
     template <typename Ld> static __device__ __forceinline__ void load(E& e, Ld ld) { load_aelem<D>(e, ld); }
     template <typename St> static __device__ __forceinline__ void store(const E& e, St st) { store_aelem<D>(e, st); }
     static __device__ __forceinline__ void combine(const E& a, const E& b, E& o) { a_combine<D, COV>(a, b, o); }
-    static __device__ __forceinline__ void apply(const E& e, const State<D>& in, State<D>& out) { a_apply<D, COV>(e, in, out); }
+    static __device__ __forceinline__ void apply(const E& e, const S& in, S& out) { a_apply<D, COV>(e, in, out); }
+    template <typename Ld> static __device__ __forceinline__ void load_s(S& s, Ld ld) { load_state<D>(s, ld); }
+    template <typename St> static __device__ __forceinline__ void store_s(const S& s, St st) { store_state<D>(s, st); }
+};
+// Forward-mode (dual number) filter monoid: value and tangent planes interleaved, [2k] value, [2k+1] tangent.
+template <int D> struct FilterMonoidAD {
+    using E = ad::FElem<D>;
+    using S = ad::State<D>;
+    static constexpr int NC = 2 * Dim<D>::NF, NS = 2 * Dim<D>::NS;
+    template <typename Ld> static __device__ __forceinline__ void load(E& e, Ld ld) {
+        ad::load_felem<D>(e, [&](int k) { return Dual(ld(2 * k), ld(2 * k + 1)); });
+    }
+    template <typename St> static __device__ __forceinline__ void store(const E& e, St st) {
+        ad::store_felem<D>(e, [&](int k, Dual v) { st(2 * k, v.v); st(2 * k + 1, v.d); });
+    }
+    static __device__ __forceinline__ void combine(const E& a, const E& b, E& o) { ad::f_combine<D>(a, b, o); }
+    static __device__ __forceinline__ void apply(const E& e, const S& in, S& out) { ad::f_apply<D>(e, in, out); }
+    template <typename Ld> static __device__ __forceinline__ void load_s(S& s, Ld ld) {
+        ad::load_state<D>(s, [&](int k) { return Dual(ld(2 * k), ld(2 * k + 1)); });
+    }
+    template <typename St> static __device__ __forceinline__ void store_s(const S& s, St st) {
+        ad::store_state<D>(s, [&](int k, Dual v) { st(2 * k, v.v); st(2 * k + 1, v.d); });
+    }
 };
 
 template <class E> __device__ __forceinline__ void shfl_up_elem(const E& in, E& out, int off) {
@@ -214,15 +241,15 @@ __global__ __launch_bounds__(BS) void k_scan_apply(const double* __restrict__ Ei
             e = t;
         }
     }
-    State<D> cs, st;
-    load_state<D>(cs, [=](int k) { return carry[(int64_t)k * ncarry + b]; });
+    typename M::S cs, st;
+    M::load_s(cs, [=](int k) { return carry[(int64_t)k * ncarry + b]; });
     if (idx < n) {
         M::apply(ex, cs, st);
-        store_state<D>(st, [=](int k, double v) { S[(int64_t)k * n + idx] = v; });
+        M::store_s(st, [=](int k, double v) { S[(int64_t)k * n + idx] = v; });
     }
     if (fin != nullptr && tid == BS - 1) {
         M::apply(e, cs, st);
-        store_state<D>(st, [=](int k, double v) { fin[k] = v; });
+        M::store_s(st, [=](int k, double v) { fin[k] = v; });
     }
 }
 
@@ -269,6 +296,57 @@ __global__ __launch_bounds__(256) void k_apply_filter(ModelView mv, int L0, int6
     }
 }
 
+// ---------------------------------------------------------------- gradient pass (forward-mode tangents, LTI models)
+__device__ __forceinline__ void block_sum_d(double& a, double* sh /* [4] */) {
+    TGP_UNROLL for (int off = 32; off >= 1; off >>= 1) a += __shfl_down(a, off, 64);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[wid] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) a = ((sh[0] + sh[1]) + (sh[2] + sh[3]));
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void k_reduce_filter_ad(ModelView mv, int L0, int64_t n0, double* __restrict__ E0) {
+    using IO = WaveIO<true, true, false, false>;
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    IO io{mv.y, mv.R, nullptr, nullptr, mv.sR != 0, IO::wave_base(), (int)(threadIdx.x & 63)};
+    ad::chunk_reduce_filter<D, true>(mv, c, L0, io, [=](int k, Dual v) {
+        E0[(int64_t)(2 * k) * n0 + c] = v.v;
+        E0[(int64_t)(2 * k + 1) * n0 + c] = v.d;
+    });
+}
+
+// partial[4b + 0..3] = sum lml value, n missing, bad flag, sum lml tangent
+template <int D>
+__global__ __launch_bounds__(256) void k_apply_filter_ad(ModelView mv, int L0, int64_t n0, const double* __restrict__ S0,
+                                                         double* __restrict__ partial) {
+    using IO = WaveIO<true, true, false, false>;
+    __shared__ double sh[12];
+    __shared__ double sh2[4];
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    IO io{mv.y, mv.R, nullptr, nullptr, mv.sR != 0, IO::wave_base(), (int)(threadIdx.x & 63)};
+    ad::State<D> x;
+    if (c < n0) {
+        ad::load_state<D>(x, [=](int k) { return Dual(S0[(int64_t)(2 * k) * n0 + c], S0[(int64_t)(2 * k + 1) * n0 + c]); });
+    } else {
+        TGP_UNROLL for (int i = 0; i < D; ++i) x.m[i] = Dual(0.0);
+        TGP_UNROLL for (int i = 0; i < D * D; ++i) x.P[i] = Dual((i % (D + 1)) == 0 ? 1.0 : 0.0);
+    }
+    FilterOut fo{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    ad::ChunkStats cs = ad::chunk_apply_filter<D, true, 0>(mv, c, L0, x, fo, io, [](int, Dual) {});
+    double lml = cs.lml.v, nmiss = cs.nmiss, dl = cs.lml.d;
+    int bad = cs.bad;
+    block_sum3(lml, nmiss, bad, sh);
+    block_sum_d(dl, sh2);
+    if (threadIdx.x == 0) {
+        partial[4 * (int64_t)blockIdx.x + 0] = lml;
+        partial[4 * (int64_t)blockIdx.x + 1] = nmiss;
+        partial[4 * (int64_t)blockIdx.x + 2] = (double)bad;
+        partial[4 * (int64_t)blockIdx.x + 3] = dl;
+    }
+}
+
 // ---------------------------------------------------------------- pass 3
 template <int D, bool LTI>
 __global__ __launch_bounds__(256) void k_smooth(ModelView mv, int L0, int64_t n0, const double* __restrict__ S0, const double* __restrict__ S0r,
@@ -311,7 +389,7 @@ __global__ __launch_bounds__(256) void k_apply_affine(ModelView mv, int L0, int6
 }
 
 // ---------------------------------------------------------------- per-D launch table (filled by tgp_inst_dN.hip)
-enum ScanMonoid { kFilter = 0, kAffineCov = 1, kAffineMean = 2 };
+enum ScanMonoid { kFilter = 0, kAffineCov = 1, kAffineMean = 2, kFilterAD = 3 };
 constexpr int kScanE = 1;   // elements per lane in the block scans
 
 struct KernelTable {
@@ -328,6 +406,9 @@ struct KernelTable {
     void (*scan_reduce)(int monoid, const double* Ein, int64_t n, double* Ehi, int64_t nhi, hipStream_t);
     void (*scan_apply)(int monoid, int bs, const double* Ein, int64_t n, const double* carry, int64_t ncarry, double* S, double* fin,
                        hipStream_t);
+    // forward-mode gradient pass (LTI models): elements / states carry (value, tangent) planes
+    void (*reduce_filter_ad)(const ModelView&, int L0, int64_t n0, double* E0, hipStream_t);
+    void (*apply_filter_ad)(const ModelView&, int L0, int64_t n0, const double* S0, double* partial, hipStream_t);
 };
 
 const KernelTable* kernel_table(int d);

@@ -20,7 +20,7 @@ import numpy as np
 from . import _lib
 
 __all__ = ["Forward", "Reverse", "Gaussian", "GaussMarkovModel", "ScalarOutputLGC", "SmallOutputLGC", "LGSSM", "logpdf", "_filter",
-           "posterior", "marginals", "rand", "replace_observation_noise_cov", "posterior_marginals", "ε_randn"]
+           "posterior", "marginals", "rand", "replace_observation_noise_cov", "posterior_marginals", "ε_randn", "logpdf_and_grad"]
 
 
 class _Ordering:
@@ -272,6 +272,31 @@ def logpdf(model, y):
         obs = np.ones(model.T, dtype=bool) if mm is None else ~mm.reshape(model.T, -1).all(axis=1)
         return out.value - float((ld if ld.shape[0] > 1 else np.repeat(ld, model.T))[obs].sum())
     return out.value
+
+
+def logpdf_and_grad(model, y, tangents):
+    """logpdf and d logpdf / d theta_k by forward-mode tangent scans on the device (tgp_logpdf_grad).
+    `tangents`: list (one entry per parameter) of dicts with the derivatives of the SHARED model blocks:
+    A (d,d), a (d,), Q (d,d), H (d,), h (), R (), x0m (d,), x0P (d,d) -- missing keys mean zero.
+    The reference obtains this gradient by AD of the sequential loop (bench/single_output_gps.jl:149-156)."""
+    _check_inputs(model, y[0] if isinstance(y, tuple) else y)
+    hd = model.handle()
+    yy, mm, dev = _obs(y, model)
+    d, n = model.dim, len(tangents)
+    get = lambda t, k, shape: np.asarray(t.get(k, np.zeros(shape)), dtype=np.float64).reshape(shape)
+    dA = np.ascontiguousarray(np.stack([get(t, "A", (d, d)).T for t in tangents]))       # column-major blocks
+    dQ = np.ascontiguousarray(np.stack([get(t, "Q", (d, d)).T for t in tangents]))
+    da = np.ascontiguousarray(np.stack([get(t, "a", (d,)) for t in tangents]))
+    dH = np.ascontiguousarray(np.stack([get(t, "H", (d,)) for t in tangents]))
+    dh = np.ascontiguousarray(np.array([float(get(t, "h", ())) for t in tangents]))
+    dR = np.ascontiguousarray(np.array([float(get(t, "R", ())) for t in tangents]))
+    dm = np.ascontiguousarray(np.stack([get(t, "x0m", (d,)) for t in tangents]))
+    dP = np.ascontiguousarray(np.stack([get(t, "x0P", (d, d)).T for t in tangents]))
+    lml, grad = ctypes.c_double(), np.zeros(n)
+    hd.check(hd.lib.tgp_logpdf_grad(hd.h, _lib.ptr(yy), _lib.ptr(mm), _lib.IN_DEVICE if dev else 0, n, _lib.ptr(dA), _lib.ptr(da),
+                                    _lib.ptr(dQ), _lib.ptr(dH), _lib.ptr(dh), _lib.ptr(dR), _lib.ptr(dm), _lib.ptr(dP),
+                                    ctypes.byref(lml), _lib.ptr(grad)))
+    return lml.value, grad
 
 
 def _filter(model, y):

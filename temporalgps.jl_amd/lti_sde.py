@@ -307,7 +307,9 @@ def build_lgssm(kernel, x, sigma2s, mean=None, device=0, force_per_step=False):
     A, a, Q, H, h, (m0, P0) = kernel.lgssm_components(x)
     T = len(x)
     mv = None if mean is None else mean(x)
-    if mv is not None:
+    if isinstance(mean, ConstMean):
+        h = h + mean.c                      # same values as hs .+ m (lti_sde.jl:126-127), but a Fill stays a Fill
+    elif mv is not None:
         h = (h if h.shape[0] == T else np.repeat(h, T, axis=0)) + mv          # lti_sde.jl:118-131
     R = np.atleast_1d(np.asarray(sigma2s, dtype=np.float64))
     if force_per_step:
@@ -455,3 +457,61 @@ class FinitePosteriorLTISDE:
         y_full = np.full(len(x), np.nan)             # build_prediction_obs :148-158: training points are missing
         y_full[pr] = y_pr
         return L.logpdf(post, y_full)
+
+
+# ------------------------------------------------------------------------------------------ gradient of logpdf
+def parameters(kernel, prefix="kernel"):
+    """Flat list of (name, owner, attribute) for the positive hyper-parameters of a kernel expression."""
+    out = []
+    if isinstance(kernel, ScaledKernel):
+        out.append((prefix + ".sigma2", kernel, "sigma2"))
+        out += parameters(kernel.kernel, prefix + ".kernel")
+    elif isinstance(kernel, StretchedKernel):
+        out.append((prefix + ".s", kernel, "s"))
+        out += parameters(kernel.kernel, prefix + ".kernel")
+    elif isinstance(kernel, ConstantKernel):
+        out.append((prefix + ".c", kernel, "c"))
+    elif isinstance(kernel, ApproxPeriodicKernel):
+        out.append((prefix + ".r", kernel, "r"))
+    elif isinstance(kernel, (KernelSum, KernelProduct)):
+        for i, k in enumerate(kernel.kernels):
+            out += parameters(k, f"{prefix}.kernels[{i}]")
+    return out
+
+
+def _shared_blocks(fx):
+    k, mean = fx.f.f.kernel, fx.f.f.mean
+    A, a, Q, H, h, (m0, P0) = k.lgssm_components(fx.x)
+    if any(z.shape[0] != 1 for z in (A, a, Q, H, h)) or fx.sigma2.shape[0] != 1:
+        raise NotImplementedError("logpdf_and_gradient: regular spacing and homoscedastic noise (all blocks shared) only")
+    hh = float(h[0])
+    if isinstance(mean, ConstMean):
+        hh += mean.c
+    elif not isinstance(mean, ZeroMean):
+        raise NotImplementedError("logpdf_and_gradient: ZeroMean or ConstMean only")
+    return dict(A=A[0], a=a[0], Q=Q[0], H=H[0], h=hh, R=float(fx.sigma2[0]), x0m=np.asarray(m0, float), x0P=np.asarray(P0, float))
+
+
+def logpdf_and_gradient(fx, y, rel_step=1e-6):
+    """(logpdf(fx, y), {name: d logpdf / d parameter}) for the kernel hyper-parameters (`parameters`), the noise
+    variance ("noise") and a ConstMean ("mean.c"). The T-step work -- value and tangents -- runs on the device as
+    forward-mode tangent scans; the derivative of the O(1) host map parameter -> (A, Q, H, ..., x0) is a central
+    finite difference of that tiny map (relative step 1e-6: truncation ~1e-12, rounding ~1e-10)."""
+    _shared_blocks(fx)                      # raises for layouts the gradient pass does not cover
+    plist = parameters(fx.f.f.kernel)
+    names = [n for n, _, _ in plist] + ["noise"] + (["mean.c"] if isinstance(fx.f.f.mean, ConstMean) else [])
+    tangents = []
+    for name, owner, attr in plist + [("noise", None, None)] + ([("mean.c", fx.f.f.mean, "c")] if "mean.c" in names else []):
+        if owner is None:
+            tangents.append(dict(R=1.0))
+            continue
+        v0 = getattr(owner, attr)
+        hstep = rel_step * max(1.0, abs(v0))
+        setattr(owner, attr, v0 + hstep)
+        bp = _shared_blocks(fx)
+        setattr(owner, attr, v0 - hstep)
+        bm = _shared_blocks(fx)
+        setattr(owner, attr, v0)
+        tangents.append({k: (np.asarray(bp[k]) - np.asarray(bm[k])) / (2 * hstep) for k in bp})
+    lp, g = L.logpdf_and_grad(fx.build_lgssm(), y, tangents)
+    return lp, dict(zip(names, g))

@@ -150,3 +150,30 @@ def random_lgssm_small(rng, tv, d, p, T, ordering="F", dense_R=False):
     else:
         m["R"] = np.stack([np.diag(rng.random(p) + 0.1) for _ in range(n)])
     return m
+
+
+def hostsim_grad(model, dmodel, y, L0=5, BS=3, missing=None):
+    """d logpdf / d theta for an LTI scalar model: `dmodel` holds the tangents of A, a, Q, H, h, R, x0m, x0P (same shapes)."""
+    pk, dk = pack(model), pack(dict(model, **dmodel))
+    assert is_lti(pk) and pk["sR"] == 0
+    lml, dl = ctypes.c_double(), ctypes.c_double()
+    miss = None if missing is None else np.ascontiguousarray(missing, dtype=np.uint8)
+    yv = np.ascontiguousarray(y, dtype=np.float64)
+    rc = hostsim().hostsim_grad(pk["d"], L0, BS, _i64(pk["T"]), _p(pk["A"]), _p(pk["a"]), _p(pk["Q"]), _p(pk["H"]), _p(pk["h"]), _p(pk["R"]),
+                                _p(yv), None if miss is None else miss.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)),
+                                _p(pk["x0m"]), _p(pk["x0P"]), _p(dk["A"]), _p(dk["a"]), _p(dk["Q"]), _p(dk["H"]), _p(dk["h"]), _p(dk["R"]),
+                                _p(dk["x0m"]), _p(dk["x0P"]), ctypes.byref(lml), ctypes.byref(dl))
+    assert rc == 0, rc
+    return lml.value, dl.value
+
+
+def model_tangent(build, theta, k, rel=1e-6):
+    """central finite difference of the (tiny, shared) model blocks w.r.t. theta[k]: d(A, a, Q, H, h, R, x0m, x0P)/d theta_k."""
+    th = np.array(theta, dtype=np.float64)
+    hstep = rel * max(1.0, abs(th[k]))
+    tp, tm = th.copy(), th.copy()
+    tp[k] += hstep
+    tm[k] -= hstep
+    mp, mm = build(tp), build(tm)
+    return {key: (np.asarray(mp[key], dtype=np.float64) - np.asarray(mm[key], dtype=np.float64)) / (2 * hstep)
+            for key in ("A", "a", "Q", "H", "h", "R", "x0m", "x0P")}

@@ -226,9 +226,88 @@ template <int D, bool LTI> int run(const Args& a) {
     return bad ? 2 : 0;
 }
 
+// ---- forward-mode gradient of logpdf w.r.t. ONE parameter (LTI models): the tgp::ad instantiation of the same
+// passes, with a hierarchical scan over Dual elements that mirrors the device structure.
+struct GradArgs {
+    const double *dx0m, *dx0P;
+    double* dlml;
+};
+
+template <int D> int run_grad(const Args& a, const GradArgs& ga) {
+    namespace A = tgp::ad;
+    const ModelView& mv = a.mv;
+    const int64_t n0 = (mv.T + a.L0 - 1) / a.L0;
+    std::vector<A::FElem<D>> E(n0);
+    for (int64_t c = 0; c < n0; ++c) {
+        DirectIO io{mv.y, mv.R, nullptr, nullptr};
+        double buf[2 * Dim<D>::NF];
+        A::chunk_reduce_filter<D, true>(mv, c, a.L0, io, [&](int k, Dual v) { buf[2 * k] = v.v; buf[2 * k + 1] = v.d; });
+        A::load_felem<D>(E[c], [&](int k) { return Dual(buf[2 * k], buf[2 * k + 1]); });
+    }
+    A::State<D> x0;
+    for (int i = 0; i < D; ++i) x0.m[i] = Dual(a.x0m[i], ga.dx0m ? ga.dx0m[i] : 0.0);
+    for (int i = 0; i < D * D; ++i) x0.P[i] = Dual(a.x0P[i], ga.dx0P ? ga.dx0P[i] : 0.0);
+    // two-level scan (blocks of BS): block totals, block carries, in-block carries
+    std::vector<A::State<D>> S(n0);
+    const int64_t nb = (n0 + a.BS - 1) / a.BS;
+    std::vector<A::FElem<D>> B(nb);
+    for (int64_t b = 0; b < nb; ++b) {
+        A::FElem<D> acc, tmp;
+        acc.identity();
+        for (int64_t i = b * a.BS; i < n0 && i < (b + 1) * a.BS; ++i) { A::f_combine<D>(acc, E[i], tmp); acc = tmp; }
+        B[b] = acc;
+    }
+    A::State<D> carry = x0, nxt;
+    for (int64_t b = 0; b < nb; ++b) {
+        A::FElem<D> acc, tmp;
+        acc.identity();
+        for (int64_t i = b * a.BS; i < n0 && i < (b + 1) * a.BS; ++i) {
+            A::f_apply<D>(acc, carry, S[i]);
+            A::f_combine<D>(acc, E[i], tmp);
+            acc = tmp;
+        }
+        A::f_apply<D>(B[b], carry, nxt);
+        carry = nxt;
+    }
+    Dual lml(0.0, 0.0);
+    double nmiss = 0.0;
+    int bad = 0;
+    FilterOut fo{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    for (int64_t c = 0; c < n0; ++c) {
+        DirectIO io{mv.y, mv.R, nullptr, nullptr};
+        A::State<D> x = S[c];
+        A::ChunkStats cs = A::chunk_apply_filter<D, true, 0>(mv, c, a.L0, x, fo, io, [](int, Dual) {});
+        lml += cs.lml;
+        nmiss += cs.nmiss;
+        bad |= cs.bad;
+    }
+    if (a.lml) *a.lml = lml.v + nmiss * 0.5 * (kLog2Pi + log(kLargeVar));
+    *ga.dlml = lml.d;
+    return bad ? 2 : 0;
+}
+
 template <int D> int run_d(const Args& a, bool lti) { return lti ? run<D, true>(a) : run<D, false>(a); }
 
 }  // namespace
+
+extern "C" int hostsim_grad(int d, int L0, int BS, int64_t T, const double* A, const double* av, const double* Q, const double* H,
+                            const double* h, const double* R, const double* y, const uint8_t* missing, const double* x0m,
+                            const double* x0P, const double* dA, const double* da, const double* dQ, const double* dH, const double* dh,
+                            const double* dR, const double* dx0m, const double* dx0P, double* lml, double* dlml) {
+    Args a{};
+    a.mv = ModelView{T, 0, 1, A, av, Q, H, h, R, 0, 0, 0, 0, 0, 0, y, missing, nullptr, nullptr, 0, 0, 0u, 0, T, dA, da, dQ, dH, dh, dR};
+    a.x0m = x0m; a.x0P = x0P; a.L0 = L0; a.BS = BS; a.lml = lml;
+    GradArgs ga{dx0m, dx0P, dlml};
+    switch (d) {
+        case 1: return run_grad<1>(a, ga);
+        case 2: return run_grad<2>(a, ga);
+        case 3: return run_grad<3>(a, ga);
+        case 4: return run_grad<4>(a, ga);
+        case 5: return run_grad<5>(a, ga);
+        case 6: return run_grad<6>(a, ga);
+        default: return 4;
+    }
+}
 
 extern "C" int hostsim_run(int d, int p, int small_out, int lti, int what, int L0, int BS, int64_t T, int ordering, const double* A, int64_t sA,
                            const double* av, int64_t sa, const double* Q, int64_t sQ, const double* H, int64_t sH,
@@ -238,7 +317,8 @@ extern "C" int hostsim_run(int d, int p, int small_out, int lti, int what, int L
                            double* mean_out, double* var_out, const double* eps_t, const double* eps_e, double* elem_out,
                            double* rev_out, const double* xs_m, const double* xs_P) {
     Args a;
-    a.mv = ModelView{T * p, ordering, p, A, av, Q, H, h, R, sA, sa, sQ, sH, sh, sR, y, missing, nullptr, nullptr, 0, 0, 0u, small_out, T};
+    a.mv = ModelView{T * p, ordering, p, A, av, Q, H, h, R, sA, sa, sQ, sH, sh, sR, y, missing, nullptr, nullptr, 0, 0, 0u, small_out, T,
+                     nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     a.x0m = x0m; a.x0P = x0P; a.L0 = L0; a.BS = BS; a.lml = lml; a.m_out = m_out; a.P_out = P_out;
     a.G_out = G_out; a.g_out = g_out; a.L_out = L_out; a.xfm = xfm; a.xfP = xfP; a.Rnew = Rnew; a.sRn = sRn;
     a.mean_out = mean_out; a.var_out = var_out; a.eps_t = eps_t; a.eps_e = eps_e; a.what = what;
