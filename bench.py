@@ -99,6 +99,45 @@ def general_layout_leg(tgp, torch, name, T, d, device, steps):
                 kernels={k: dict(avg_ms=v["total_ms"] / max(1, v["calls"]), calls=v["calls"]) for k, v in hd.profile().items()})
 
 
+def gradient_leg(tgp, torch, name, T, d, device, steps, y):
+    """logpdf + its gradient w.r.t. (kernel variance, inverse lengthscale, noise variance) -- the quantity the
+    north_star target is stated on (reference: Mooncake.gradient(logpdf, fx, y), bench/single_output_gps.jl:155-156)
+    -- by forward-mode tangent scans on the device. Same series as the headline leg."""
+    from temporalgps_jl_amd import lti_sde as P
+    k, _, dt, s2 = WORKLOADS[name]
+    fx = P.to_sde(P.GP(P.ScaledKernel(1.0, P.StretchedKernel(1.0, P.to_kernel(k)))), P.HIPStorage(device=device))(P.RegularSpacing(0.0, dt, T), s2)
+    for _ in range(2):
+        P.logpdf_and_gradient(fx, y)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        lp, g = P.logpdf_and_gradient(fx, y)
+    dt_s = (time.perf_counter() - t0) / steps
+    return dict(metric="Kalman steps/sec (logpdf + gradient w.r.t. 3 hyper-parameters)", value=T / dt_s, ms_per_eval=dt_s * 1e3,
+                n_params=len(g), method="forward-mode tangent scans (dual numbers), one pass per parameter", logpdf=lp,
+                gradient={kk: float(v) for kk, v in g.items()})
+
+
+def cpu_gradient_baseline(name, T_sample):
+    """CPU stand-in for logpdf + gradient: central finite differences of the sequential C restatement over the same 3
+    hyper-parameters = 6 logpdf evaluations on one core (the reference uses reverse-mode AD of the same loop, whose
+    published cost is ~5x one logpdf: README.md:79-86)."""
+    from oracle import components as oc
+    from oracle import seq_kalman as sk
+    k, d, dt, s2 = WORKLOADS[name]
+    build = lambda a, b, c: oc.build_lgssm(("scaled", a, ("stretched", b, k)), ("regular", 0.0, dt, T_sample), c)
+    y = np.random.default_rng(0).standard_normal(T_sample)
+    t0 = time.perf_counter()
+    for i in range(3):
+        for sgn in (1, -1):
+            th = [1.0, 1.0, s2]
+            th[i] *= 1 + sgn * 1e-5
+            sk.logpdf(build(*th), y)
+    t1 = time.perf_counter()
+    return dict(value=T_sample / (t1 - t0), unit="Kalman steps/s", cores=1, kind="port",
+                sample=f"6 sequential logpdf evaluations (central differences, 3 parameters), T={T_sample}: {t1 - t0:.3f}s")
+
+
 def pmc_traffic(kname, d, layout):
     """HBM bytes per launch of `kname` from the committed PMC summary (profiles/r01_pmc_traffic.json: separate
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command, FETCH doubled per
@@ -235,6 +274,9 @@ def main():
             kernels={k: dict(avg_ms=v["total_ms"] / max(1, v["calls"]), calls=v["calls"]) for k, v in prof.items()},
         )
         if args.layout == "lti" and world == 1 and not args.no_general_leg:
+            out["logpdf_and_grad"] = gradient_leg(tgp, torch, name, T, d, local, max(3, args.steps // 2), y)
+            if not args.no_cpu_baseline:
+                out["logpdf_and_grad"]["cpu_baseline"] = cpu_gradient_baseline(name, args.cpu_sample)
             out["roofline_general_layout"] = general_layout_leg(tgp, torch, name, T, d, local, max(3, args.steps // 2))
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(name, args.cpu_sample)
