@@ -348,11 +348,13 @@ __global__ __launch_bounds__(256) void k_apply_filter_ad(ModelView mv, int L0, i
 }
 
 // ---------------------------------------------------------------- pass 3
-template <int D, bool LTI>
+// RSTREAM: R_new is per-step and staged through the IO (one more LDS slot: 55 KB per block => 2 blocks per CU);
+// a shared R_new (the common case) needs only the two output slots (37 KB => 4 blocks per CU).
+template <int D, bool LTI, bool RSTREAM>
 __global__ __launch_bounds__(256) void k_smooth(ModelView mv, int L0, int64_t n0, const double* __restrict__ S0, const double* __restrict__ S0r,
                                                 const double* __restrict__ fs, const double* __restrict__ Rnew, int64_t sRn,
                                                 double* __restrict__ mean_out, double* __restrict__ var_out, int* __restrict__ bad) {
-    using IO = WaveIO<false, true, true, true>;
+    using IO = WaveIO<false, RSTREAM, true, true>;
     const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
     IO io{nullptr, Rnew, mean_out, var_out, sRn != 0, IO::wave_base(), (int)(threadIdx.x & 63)};
     State<D> xs, carry;

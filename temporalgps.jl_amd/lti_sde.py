@@ -241,10 +241,35 @@ def broadcast_components(FqH, x0, t):
         return A[None], np.zeros((1, d)), (P - A @ P @ A.T)[None], np.array(H, dtype=np.float64)[None], np.zeros(1)
     tt = np.asarray(t, dtype=np.float64)
     dts = np.diff(np.concatenate([[tt[0] - 1.0], tt]))
-    uniq, inv = np.unique(dts, return_inverse=True)          # one exponential per distinct dt
-    Au = np.stack([expm(F * dt) for dt in uniq])
-    Qu = np.stack([P - Ai @ P @ Ai.T for Ai in Au])
+    uniq, inv = np.unique(dts, return_inverse=True)          # one exponential per distinct dt ...
+    Au = expm_batch(F, uniq)                                  # ... all of them in one vectorised pass
+    Qu = P[None] - Au @ P[None] @ np.swapaxes(Au, -1, -2)
     return Au[inv], np.zeros((1, d)), Qu[inv], np.array(H, dtype=np.float64)[None], np.zeros(1)
+
+
+def expm_batch(F, dts):
+    """exp(F * dt) for a whole vector of dt at once (scaling and squaring around a degree-18 Taylor polynomial,
+    vectorised over the batch): irregular spacing -- every posterior query at new inputs -- needs T of them
+    (lti_sde.jl:140), and one scipy call per step is the host bottleneck at T ~ 1e6."""
+    dts = np.asarray(dts, dtype=np.float64)
+    if len(dts) <= 4:
+        return np.stack([expm(F * dt) for dt in dts])
+    d = F.shape[0]
+    nF = max(np.linalg.norm(F, 1), 1e-300)
+    svec = np.maximum(0, np.ceil(np.log2(np.maximum(nF * np.abs(dts), 1e-300) / 0.25))).astype(int)
+    out = np.empty((len(dts), d, d))
+    for sv in np.unique(svec):                      # one vectorised pass per squaring depth (<= ~20 groups)
+        idx = np.nonzero(svec == sv)[0]
+        X = F[None] * (dts[idx] / 2.0 ** sv)[:, None, None]
+        term = np.broadcast_to(np.eye(d), X.shape).copy()
+        acc = term.copy()
+        for k in range(1, 19):
+            term = term @ X / k
+            acc = acc + term
+        for _ in range(sv):
+            acc = acc @ acc
+        out[idx] = acc
+    return out
 
 
 def to_kernel(spec):

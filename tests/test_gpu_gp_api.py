@@ -1,0 +1,97 @@
+"""GPU tier: the GP-level API surface (to_sde / FiniteGP methods / posterior queries), i.e. the callers of the hot path
+(/root/reference/src/gp/lti_sde.jl:33-68, src/gp/posterior_lti_sde.jl:18-78), through the device engine, against the
+oracle's restatement of the same functions and against the dense GP (the reference's bar: rtol 1e-5 for posteriors at
+new inputs, test/gp/posterior_lti_sde.jl:82-89)."""
+import numpy as np
+import pytest
+
+from oracle import components as oc
+from oracle import dense_gp as dg
+from tests.test_oracle_identities import KERNELS
+
+pytestmark = pytest.mark.gpu
+NAMES = ["base-Matern12", "base-Matern32", "base-Matern52", "scaled-10.0", "stretched-0.1", "sum-12-32", "prod-52-32"]
+
+
+@pytest.fixture(scope="module")
+def P():
+    import temporalgps_jl_amd  # noqa: F401
+    from temporalgps_jl_amd import lti_sde
+    return lti_sde
+
+
+@pytest.mark.parametrize("kname", NAMES)
+@pytest.mark.parametrize("spacing", ["regular", "irregular"])
+def test_prior_api_equals_dense_gp(P, kname, spacing):
+    rng = np.random.default_rng(3)
+    spec = KERNELS[kname]
+    N = 40
+    x = P.RegularSpacing(0.0, 0.3, N) if spacing == "regular" else np.cumsum(rng.random(N) * 0.4 + 0.05)
+    xs = x.collect() if spacing == "regular" else x
+    s2 = rng.random(N) * 0.2 + 0.1
+    fx = P.to_sde(P.GP(P.CustomMean(lambda t: 0.5 * t), P.to_kernel(spec)), P.HIPStorage())(x, s2)
+    y = P.rand(rng, fx)
+    assert y.shape == (N,)
+    mean = ("custom", lambda t: 0.5 * t)
+    lp, lp_d = P.logpdf(fx, y), dg.logpdf(spec, xs, s2, y, mean)
+    assert abs(lp - lp_d) <= 1.5e-8 * abs(lp_d) + 1e-9
+    m, sd = P.marginals(fx)
+    md, vd = dg.marginals(spec, xs, s2, mean)
+    np.testing.assert_allclose(m, md, rtol=1.5e-8, atol=1e-10)
+    np.testing.assert_allclose(sd ** 2, vd, rtol=1.5e-8)
+    mv = P.mean_and_var(fx)
+    np.testing.assert_allclose(mv[0], P.mean(fx))
+    np.testing.assert_allclose(mv[1], P.var(fx))
+    ym = y.copy()
+    ym[[3, 17]] = np.nan                                       # missing observations (missings.jl)
+    keep = ~np.isnan(ym)
+    assert abs(P.logpdf(fx, ym) - dg.logpdf(spec, xs[keep], s2[keep], y[keep], mean)) <= 1.5e-8 * abs(lp_d) + 1e-8
+
+
+@pytest.mark.parametrize("kname", ["base-Matern32", "base-Matern52", "sum-12-32"])
+def test_posterior_api_same_and_new_inputs(P, kname):
+    rng = np.random.default_rng(7)
+    spec = KERNELS[kname]
+    x_tr = np.sort(rng.random(30)) * 5
+    s_tr = rng.random(30) * 0.2 + 0.05
+    y_tr = rng.standard_normal(30)
+    f = P.to_sde(P.GP(P.to_kernel(spec)), P.HIPStorage())
+    fpost = P.posterior(f(x_tr, s_tr), y_tr)
+    # same inputs (posterior_lti_sde.jl:27-36)
+    m, sd = P.marginals(fpost(x_tr, 0.3))
+    md, vd = dg.posterior_marginals(spec, x_tr, s_tr, y_tr, x_tr, 0.3)
+    np.testing.assert_allclose(m, md, rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(sd ** 2, vd, rtol=1e-5, atol=1e-7)
+    mo, vo = oc.posterior_marginals(spec, x_tr, s_tr, y_tr, None, 0.3)
+    np.testing.assert_allclose(m, mo, rtol=1e-8, atol=1e-8)      # vs the oracle's restatement of the same path
+    np.testing.assert_allclose(sd ** 2, vo, rtol=1e-8, atol=1e-9)
+    # new inputs (posterior_lti_sde.jl:19-26): merge + sort + missing
+    x_pr = np.sort(rng.random(9)) * 6 - 0.5
+    m, sd = P.marginals(fpost(x_pr, 0.2))
+    md, vd = dg.posterior_marginals(spec, x_tr, s_tr, y_tr, x_pr, 0.2)
+    np.testing.assert_allclose(m, md, rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(sd ** 2, vd, rtol=1e-5, atol=1e-7)
+    # logpdf of the posterior at new inputs (posterior_lti_sde.jl:62-78)
+    y_pr = rng.standard_normal(9)
+    s_pr = rng.random(9) * 0.1 + 0.1
+    lp = P.logpdf(fpost(x_pr, s_pr), y_pr)
+    lp_d = dg.posterior_logpdf(spec, x_tr, s_tr, y_tr, x_pr, s_pr, y_pr)
+    assert abs(lp - lp_d) <= 1e-5 * abs(lp_d)
+    assert abs(lp - oc.posterior_logpdf(spec, x_tr, s_tr, y_tr, x_pr, s_pr, y_pr)) <= 1e-7 * abs(lp_d)
+    # rand of the posterior at new inputs: shape + the same draw through the oracle given the same noise
+    ys = P.rand(np.random.default_rng(11), fpost(x_pr, 0.2))
+    assert ys.shape == (9,) and np.all(np.isfinite(ys))
+    g = np.random.default_rng(11)
+    T, d = 39, len(oc.build_lgssm(spec, x_tr, s_tr)["x0m"])
+    eps_t, eps_e = g.standard_normal((T, d)), g.standard_normal(T)
+    eps_0 = g.standard_normal(d)
+    np.testing.assert_allclose(ys, oc.posterior_rand(spec, x_tr, s_tr, y_tr, x_pr, 0.2, eps_t, eps_e, eps_0), rtol=1e-7, atol=1e-7)
+
+
+def test_rand_many_and_errors(P):
+    rng = np.random.default_rng(0)
+    fx = P.to_sde(P.GP(P.Matern32Kernel()))(P.RegularSpacing(0.0, 0.1, 25), 0.1)
+    Y = P.rand(rng, fx, 4)
+    assert Y.shape == (25, 4)
+    with pytest.raises(ValueError, match="Dimension mismatch"):
+        P.logpdf(fx, np.zeros(24))
