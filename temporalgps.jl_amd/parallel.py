@@ -117,9 +117,14 @@ class ShardedLGSSM:
         import torch.distributed as dist
         dev = "cuda" if dist.get_backend(self.group) == "nccl" else "cpu"
         t = torch.as_tensor(np.ascontiguousarray(vec), dtype=torch.float64).to(dev)
-        out = [torch.empty_like(t) for _ in range(self.world)]
-        dist.all_gather(out, t, group=self.group)
-        return [o.cpu().numpy() for o in out]
+        try:                                      # one flat buffer => ONE device-to-host copy for all W elements
+            flat = torch.empty(self.world * t.numel(), dtype=torch.float64, device=dev)
+            dist.all_gather_into_tensor(flat, t, group=self.group)
+            return list(flat.cpu().numpy().reshape(self.world, -1))
+        except (RuntimeError, AttributeError, NotImplementedError):
+            out = [torch.empty_like(t) for _ in range(self.world)]
+            dist.all_gather(out, t, group=self.group)
+            return [o.cpu().numpy() for o in out]
 
     def _all_reduce_sum(self, x):
         import torch
@@ -142,7 +147,7 @@ class ShardedLGSSM:
         return True
 
     def logpdf(self, y):
-        if self.world == 1:
+        if self.world == 1 and self.engine is None:
             return L.logpdf(self.model, y)
         if not hasattr(self, "_x0"):
             self._x0 = self.engine.x0()
@@ -151,7 +156,7 @@ class ShardedLGSSM:
 
     def posterior_marginals(self, y, R_new):
         """This rank's slice of marginals(posterior(fx, y)(x)); R_new is the slice's new noise (or a scalar)."""
-        if self.world == 1:
+        if self.world == 1 and self.engine is None:
             return L.posterior_marginals(self.model, y, R_new)
         if not hasattr(self, "_x0"):
             self._x0 = self.engine.x0()

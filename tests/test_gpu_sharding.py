@@ -56,3 +56,29 @@ def test_sharded_hip_engine_equals_sequential(world, layout):
         mean[lo:hi], var[lo:hi] = m, v
     assert np.max(np.abs(mean - pm)) <= 1e-8
     assert np.max(np.abs(var - pv)) <= 1e-8
+
+
+def test_sharded_path_over_rccl_single_rank():
+    """The sharded code path with the REAL collectives backend (nccl == RCCL) on the one GPU this box has: a 1-rank group
+    still goes through segment reduce -> all_gather_into_tensor -> fold -> local passes -> all_reduce."""
+    import torch
+    import temporalgps_jl_amd as tgp  # noqa: F401
+    from temporalgps_jl_amd import lti_sde, parallel
+    port = 29900 + (os.getpid() % 1000)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        T = 100_000
+        rng = np.random.default_rng(6)
+        y_np = rng.standard_normal(T)
+        model = lti_sde.build_lgssm(lti_sde.Matern52Kernel(), lti_sde.RegularSpacing(0.0, 0.1, T), 0.1)
+        sh = parallel.ShardedLGSSM(model, 1, 0, engine=parallel.HIPEngine(model))
+        y = torch.as_tensor(y_np, device="cuda:0")
+        lp = sh.logpdf(y)
+        mean, var = sh.posterior_marginals(y, np.array([0.05]))
+        ref_model = oc.build_lgssm(("matern52",), ("regular", 0.0, 0.1, T), 0.1)
+        lp_ref = sk.logpdf(ref_model, y_np)
+        pm, pv = sk.posterior_marginals(ref_model, y_np, np.array([0.05]))
+        assert abs(lp - lp_ref) <= 1e-10 * abs(lp_ref)
+        assert np.max(np.abs(mean.cpu().numpy() - pm)) <= 1e-8 and np.max(np.abs(var.cpu().numpy() - pv)) <= 1e-8
+    finally:
+        dist.destroy_process_group()
