@@ -34,6 +34,7 @@ _SIGS = {
     "tgp_set_stream": (ctypes.c_int, [_vp, _vp]),
     "tgp_version": (ctypes.c_char_p, []),
     "tgp_model_set": (ctypes.c_int, [_vp, _i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, _u32] + [_vp] * 8),
+    "tgp_model_set_sde": (ctypes.c_int, [_vp, _i64, ctypes.c_int, ctypes.c_int, _u32] + [_vp] * 10),
     "tgp_model_set_x0": (ctypes.c_int, [_vp, _vp, _vp]),
     "tgp_logpdf": (ctypes.c_int, [_vp, _vp, _vp, _u32, _dp]),
     "tgp_logpdf_grad": (ctypes.c_int, [_vp, _vp, _vp, _u32, ctypes.c_int] + [_vp] * 8 + [_dp, _vp]),

@@ -141,6 +141,12 @@ struct tgp_handle {
     ModelView raw{};      // the arrays as handed over (reference layout): source of the tiling
     DevBuf tile_t, tile_e;
     int tile_L0 = 0;
+    // SDE-described transitions (tgp_model_set_sde): A_k, Q_k are built on the device from the time stamps
+    bool sde = false;
+    DevBuf bF, bPinf, btimes, bAQ1;
+    bool have_AQ1 = false;
+    const double* times_dev = nullptr;
+    double normF = 0.0;
     const KernelTable* kt = nullptr;
     DevBuf bA, ba, bQ, bH, bh, bR;
     std::vector<double> x0m, x0P;
@@ -429,15 +435,22 @@ int check_ready(tgp_handle* h) {
 int ensure_tiled(tgp_handle* h) {
     if (h->lti) return TGP_OK;
     if (h->tile_L0 == h->L0 && h->mv.tile_mask != 0u) return TGP_OK;
-    const uint32_t mask = tile_mask_of(h->raw);
+    uint32_t mask = tile_mask_of(h->raw);
+    if (h->sde) mask |= kTileA | kTileQ;          // A, Q come from k_tile_sde, not from raw arrays
     const int nc_t = tile_offset_t(mask, 0u, h->d), nc_e = tile_offset_e(mask, 0u, h->d);
     const size_t nblk = (size_t)((h->n0 + 63) / 64) * 64;
     HIPCHK(h->tile_t.ensure((nblk * (size_t)(h->L0 / h->p) * (size_t)nc_t + 1) * sizeof(double)));
     HIPCHK(h->tile_e.ensure((nblk * (size_t)h->L0 * (size_t)nc_e + 1) * sizeof(double)));
+    if (h->sde) {
+        LaunchScope ls(h, "k_tile_sde");
+        h->kt->tile_sde(h->bF.d(), h->bPinf.d(), h->times_dev, h->have_AQ1 ? h->bAQ1.d() : nullptr, h->T, h->ordering, h->L0 / h->p, h->n0, h->normF, h->tile_t.d(), h->stream);
+    }
     {
         LaunchScope ls(h, "k_tile_model");
-        hipLaunchKernelGGL(k_tile_model, dim3((unsigned)((h->n0 + 255) / 256)), dim3(256), 0, h->stream, h->raw, h->d, mask, nc_t, nc_e,
-                           h->L0, h->n0, h->tile_t.d(), h->tile_e.d());
+        // in SDE mode the transition record is already written: tile only the (optional) per-step emission arrays
+        hipLaunchKernelGGL(k_tile_model, dim3((unsigned)((h->n0 + 255) / 256)), dim3(256), 0, h->stream, h->raw, h->d,
+                           h->sde ? (mask & ~(kTileA | kTilea | kTileQ)) : mask, h->sde ? 0 : nc_t, nc_e, h->L0, h->n0, h->tile_t.d(),
+                           h->tile_e.d());
     }
     h->mv.tile_t = h->tile_t.d();
     h->mv.tile_e = h->tile_e.d();
@@ -589,7 +602,7 @@ int tgp_destroy(tgp_handle* h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     for (DevBuf* b : {&h->bA, &h->ba, &h->bQ, &h->bH, &h->bh, &h->bR, &h->bx0, &h->bx0r, &h->by, &h->bmiss, &h->bRnew, &h->beps_t,
-                      &h->beps_e, &h->bo1, &h->bo2, &h->bo3, &h->F.slab, &h->Rv.slab, &h->fs, &h->partial, &h->result, &h->segtmp, &h->tile_t, &h->tile_e, &h->Fad.slab, &h->btan, &h->bx0ad})
+                      &h->beps_e, &h->bo1, &h->bo2, &h->bo3, &h->F.slab, &h->Rv.slab, &h->fs, &h->partial, &h->result, &h->segtmp, &h->tile_t, &h->tile_e, &h->Fad.slab, &h->btan, &h->bx0ad, &h->bF, &h->bPinf, &h->btimes, &h->bAQ1})
         b->release();
     for (auto& e : h->ev)
         if (e) (void)hipEventDestroy(e);
@@ -636,6 +649,7 @@ int tgp_model_set(tgp_handle* h, int64_t T, int d, int p, int ordering, uint32_t
     h->have_model = false;
     h->reduce_valid = false;
     h->smoother_valid = false;
+    h->sde = false;
     if (T <= 0) return h->fail(TGP_EINVAL, "T must be positive");
     if (p < 1 || p > 64) return h->fail(TGP_EUNSUPPORTED, "observation dimension p must be in 1..64 (diagonal noise)");
     if (ordering != 0 && ordering != 1) return h->fail(TGP_EINVAL, "ordering must be 0 (Forward) or 1 (Reverse)");
@@ -684,6 +698,45 @@ int tgp_model_set(tgp_handle* h, int64_t T, int d, int p, int ordering, uint32_t
     TRY(upload_x0(h, h->bx0, x0m, x0P));
     HIPCHK(hipStreamSynchronize(h->stream));
     h->have_model = true;
+    return TGP_OK;
+}
+
+int tgp_model_set_sde(tgp_handle* h, int64_t T, int d, int ordering, uint32_t flags, const double* F, const double* a, const double* H,
+                      const double* hh, const double* R, const double* times, const double* A1, const double* Q1, const double* x0m,
+                      const double* x0P) {
+    if (!h) return TGP_EINVAL;
+    if (!F || !times) return h->fail(TGP_EINVAL, "null F / times");
+    // shared placeholder blocks for A and Q (never read: the tiled record supplies them); a must be shared
+    if (!(flags & TGP_SHARED_a)) return h->fail(TGP_EUNSUPPORTED, "tgp_model_set_sde: the transition offset a must be shared");
+    std::vector<double> zero((size_t)d * d, 0.0);
+    const bool dev = (flags & TGP_DEVICE_PTRS) != 0;
+    if (dev) return h->fail(TGP_EUNSUPPORTED, "tgp_model_set_sde: model blocks are host pointers (times may be a device pointer via TGP_IN_DEVICE semantics is not offered)");
+    int rc = tgp_model_set(h, T, d, 1, ordering, flags | TGP_SHARED_A | TGP_SHARED_Q, zero.data(), a, zero.data(), H, hh, R, x0m, x0P);
+    if (rc != TGP_OK) return rc;
+    HIPCHK(h->bF.ensure((size_t)d * d * sizeof(double)));
+    HIPCHK(h->bPinf.ensure((size_t)d * d * sizeof(double)));
+    HIPCHK(h->btimes.ensure((size_t)T * sizeof(double)));
+    HIPCHK(hipMemcpyAsync(h->bF.p, F, (size_t)d * d * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->bPinf.p, x0P, (size_t)d * d * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->btimes.p, times, (size_t)T * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    h->have_AQ1 = (A1 != nullptr && Q1 != nullptr);
+    if (h->have_AQ1) {
+        HIPCHK(h->bAQ1.ensure((size_t)2 * d * d * sizeof(double)));
+        HIPCHK(hipMemcpyAsync(h->bAQ1.p, A1, (size_t)d * d * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->bAQ1.d() + (size_t)d * d, Q1, (size_t)d * d * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->times_dev = h->btimes.d();
+    double nrm = 0.0;     // 1-norm of F
+    for (int j = 0; j < d; ++j) {
+        double cs = 0.0;
+        for (int i = 0; i < d; ++i) cs += std::fabs(F[i + j * d]);
+        nrm = cs > nrm ? cs : nrm;
+    }
+    h->normF = nrm;
+    h->sde = true;
+    h->lti = false;        // transitions are per-step (tiled), whatever the emission flags say
+    h->tile_L0 = 0;
     return TGP_OK;
 }
 

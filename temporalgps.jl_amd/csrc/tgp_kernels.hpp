@@ -149,6 +149,66 @@ template <bool IN0, bool IN1, bool OUT0, bool OUT1> struct WaveIO {
     }
 };
 
+// ---------------------------------------------------------------- device-side component construction
+// Irregular spacing: A_k = exp(F dt_k), Q_k = Pinf - A_k Pinf A_k' (lti_sde.jl:135-146, dt_1 := 1) computed on the
+// device straight into the time-tiled transition record -- the T matrix exponentials never touch the host or HBM
+// in the reference layout; the model is described by F, Pinf and the 8 T bytes of time stamps.
+// exp: scaling and squaring around a degree-18 Taylor polynomial (|F dt| / 2^s <= 1/4), all in registers.
+template <int D> __device__ __forceinline__ void expm_scaled(const double* F, double dt, double normF, double* A) {
+    int s = 0;
+    double x = normF * fabs(dt);
+    while (x > 0.25 && s < 60) { x *= 0.5; ++s; }
+    const double sc = ldexp(dt, -s);
+    double X[D * D], term[D * D], tmp[D * D];
+    TGP_UNROLL for (int i = 0; i < D * D; ++i) X[i] = F[i] * sc;
+    set_identity<D>(term);
+    set_identity<D>(A);
+    for (int k = 1; k <= 18; ++k) {
+        mat_mul<D>(term, X, tmp);
+        const double ik = 1.0 / k;
+        TGP_UNROLL for (int i = 0; i < D * D; ++i) { term[i] = tmp[i] * ik; A[i] += term[i]; }
+    }
+    for (int q = 0; q < s; ++q) {
+        mat_mul<D>(A, A, tmp);
+        copy_n<D * D>(tmp, A);
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void k_tile_sde(const double* __restrict__ F, const double* __restrict__ Pinf, const double* __restrict__ times,
+                                                  const double* __restrict__ AQ1, int64_t Tt, int ordering, int Lt, int64_t n0, double normF,
+                                                  double* __restrict__ tile_t) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= n0) return;
+    double Fm[D * D], P[D * D];
+    TGP_UNROLL for (int i = 0; i < D * D; ++i) { Fm[i] = F[i]; P[i] = Pinf[i]; }
+    sym_upper<D>(P);
+    constexpr int NC = 2 * D * D;   // record: A then Q (a is shared)
+    for (int tl = 0; tl < Lt; ++tl) {
+        const int64_t tproc = c * (int64_t)Lt + tl;
+        if (tproc >= Tt) break;
+        const int64_t tt = ordering == 0 ? tproc : Tt - tproc;      // transition storage index (Reverse: previous step's)
+        const int64_t base = fs_index(c, tl, 0, Lt, NC);
+        if (ordering != 0 && tproc == 0) {
+            TGP_UNROLL for (int k = 0; k < NC; ++k) tile_t[base + (int64_t)k * 64] = 0.0;
+            continue;
+        }
+        if (tt == 0 && AQ1 != nullptr) {   // first transition supplied by the host (kernel algebra decides its dt, see tgp_hip.h)
+            TGP_UNROLL for (int k = 0; k < NC; ++k) tile_t[base + (int64_t)k * 64] = AQ1[k];
+            continue;
+        }
+        const double dt = (tt == 0) ? 1.0 : times[tt] - times[tt - 1];
+        double A[D * D], AP[D * D], Q[D * D];
+        expm_scaled<D>(Fm, dt, normF, A);
+        mat_mul<D>(A, P, AP);
+        mat_mul_nt<D>(AP, A, Q);
+        TGP_UNROLL for (int k = 0; k < D * D; ++k) {
+            tile_t[base + (int64_t)k * 64] = A[k];
+            tile_t[base + (int64_t)(D * D + k) * 64] = P[k] - Q[k];
+        }
+    }
+}
+
 // ---------------------------------------------------------------- pass 1
 template <int D, bool LTI>
 __global__ __launch_bounds__(256) void k_reduce_filter(ModelView mv, int L0, int64_t n0, double* __restrict__ E0) {
@@ -411,6 +471,9 @@ struct KernelTable {
     // forward-mode gradient pass (LTI models): elements / states carry (value, tangent) planes
     void (*reduce_filter_ad)(const ModelView&, int L0, int64_t n0, double* E0, hipStream_t);
     void (*apply_filter_ad)(const ModelView&, int L0, int64_t n0, const double* S0, double* partial, hipStream_t);
+    // device-side construction of the tiled transitions from time stamps (irregular spacing)
+    void (*tile_sde)(const double* F, const double* Pinf, const double* times, const double* AQ1, int64_t Tt, int ordering, int Lt,
+                     int64_t n0, double normF, double* tile_t, hipStream_t);
 };
 
 const KernelTable* kernel_table(int d);

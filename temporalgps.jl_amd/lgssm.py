@@ -19,7 +19,7 @@ import numpy as np
 
 from . import _lib
 
-__all__ = ["Forward", "Reverse", "Gaussian", "GaussMarkovModel", "ScalarOutputLGC", "SmallOutputLGC", "LGSSM", "logpdf", "_filter",
+__all__ = ["Forward", "Reverse", "Gaussian", "GaussMarkovModel", "SDETransitions", "ScalarOutputLGC", "SmallOutputLGC", "LGSSM", "logpdf", "_filter",
            "posterior", "marginals", "rand", "replace_observation_noise_cov", "posterior_marginals", "ε_randn", "logpdf_and_grad"]
 
 
@@ -71,6 +71,23 @@ class GaussMarkovModel:
         return int(self.As.shape[-1])
 
 
+class SDETransitions:
+    """Transitions of an LTI SDE sampled at irregular times: A_k = exp(F dt_k), Q_k = P_inf - A_k P_inf A_k'
+    (broadcast_components, lti_sde.jl:135-146, with the reference's dt_1 := 1), NOT materialised on the host:
+    the device builds them from the time stamps (tgp_model_set_sde). x0.P doubles as P_inf."""
+
+    def __init__(self, ordering, F, times, x0, A1=None, Q1=None):
+        self.ordering, self.F, self.times, self.x0 = ordering, np.asarray(F, dtype=np.float64), np.asarray(times, dtype=np.float64), x0
+        self.A1, self.Q1 = A1, Q1        # first transition (the reference takes dt_1 = 1 in each sub-kernel's own stretched time)
+
+    def __len__(self):
+        return len(self.times)
+
+    @property
+    def dim(self):
+        return int(self.F.shape[0])
+
+
 class ScalarOutputLGC:
     """StructArray of scalar-output emissions y | x ~ N(H'x + h, R) (lgc.jl:225-243): H (T|1, d), h (T|1,), R (T|1,)."""
 
@@ -103,6 +120,8 @@ class LGSSM:
     def __init__(self, transitions, emissions, T=None, device=0):
         self.transitions, self.emissions = transitions, emissions
         n = max(len(transitions), _lead(emissions.H), _lead(emissions.h), _lead(emissions.R))
+        if isinstance(transitions, SDETransitions):
+            T = len(transitions)
         self.T = int(T) if T is not None else n
         if n > 1 and n != self.T:
             raise ValueError(f"inconsistent lengths: arrays have {n} steps, T={self.T}")
@@ -153,6 +172,8 @@ class LGSSM:
             return self._handle
         tr, em = self.transitions, self.emissions
         d, p = self.dim, self.p
+        if isinstance(tr, SDETransitions):
+            return self._handle_sde()
         small = isinstance(em, SmallOutputLGC)
         eH, eh, eR = em.H, em.h, em.R
         if small and em.dense:
@@ -203,6 +224,33 @@ def _sync_torch(t):
     we are about to read has finished (torch ops are asynchronous on torch's current stream)."""
     import torch
     torch.cuda.current_stream(t.device).synchronize()
+
+
+def _handle_sde(self):
+    """Bind an SDE-described model: only F, P_inf, the emission blocks and the T time stamps go to the device."""
+    tr, em = self.transitions, self.emissions
+    if not isinstance(em, ScalarOutputLGC):
+        raise NotImplementedError("SDE-described transitions support scalar observations only")
+    d = tr.dim
+    H, sH = self._blocks(em.H, d)
+    h, sh = self._blocks(em.h, 1)
+    R, sR = self._blocks(em.R, 1)
+    flags = _lib.SHARED_a | (_lib.SHARED_H if sH else 0) | (_lib.SHARED_h if sh else 0) | (_lib.SHARED_R if sR else 0)
+    hd = _lib.Handle(self.device)
+    F = np.ascontiguousarray(tr.F.T)                                  # column-major
+    a = np.zeros(d)
+    times = np.ascontiguousarray(tr.times)
+    x0m = np.ascontiguousarray(np.asarray(_to_numpy(self.x0.m), dtype=np.float64))
+    x0P = np.ascontiguousarray(np.asarray(_to_numpy(self.x0.P), dtype=np.float64).T)
+    A1 = None if tr.A1 is None else np.ascontiguousarray(np.asarray(tr.A1, dtype=np.float64).T)
+    Q1 = None if tr.Q1 is None else np.ascontiguousarray(np.asarray(tr.Q1, dtype=np.float64).T)
+    hd.check(hd.lib.tgp_model_set_sde(hd.h, self.T, d, self.ordering.code, flags, _lib.ptr(F), _lib.ptr(a), _lib.ptr(H), _lib.ptr(h),
+                                      _lib.ptr(R), _lib.ptr(times), _lib.ptr(A1), _lib.ptr(Q1), _lib.ptr(x0m), _lib.ptr(x0P)))
+    self._handle, self._on_device, self._keep = hd, False, (H, h, R)
+    return hd
+
+
+LGSSM._handle_sde = _handle_sde
 
 
 def _to_numpy(x):

@@ -88,6 +88,12 @@ def _cm(n, vals):
 class SimpleKernel(Kernel):
     """to_sde -> (F, q, H); stationary_distribution -> (m, P)."""
 
+    def sde_blocks(self):
+        """(F, H, m0, P0) of the ONE LTI SDE the whole kernel expression corresponds to."""
+        F, _, H = self.to_sde()
+        m, P = self.stationary_distribution()
+        return F, H, m, P
+
     def lgssm_components(self, t):
         x0 = self.stationary_distribution()
         A, a, Q, H, h = broadcast_components(self.to_sde(), x0, t)
@@ -170,6 +176,10 @@ class ScaledKernel(Kernel):              # lti_sde.jl:324-346
         sig = np.sqrt(self.sigma2)
         return A, a, Q, sig * H, sig * h, x0
 
+    def sde_blocks(self):
+        F, H, m, P = self.kernel.sde_blocks()
+        return F, np.sqrt(self.sigma2) * H, m, P
+
 
 class StretchedKernel(Kernel):           # lti_sde.jl:350-373
     def __init__(self, s, kernel):
@@ -189,6 +199,10 @@ class StretchedKernel(Kernel):           # lti_sde.jl:350-373
             t2 = self.s * np.asarray(t, dtype=np.float64)
         return self.kernel.lgssm_components(t2)
 
+    def sde_blocks(self):
+        F, H, m, P = self.kernel.sde_blocks()
+        return F * self.s, H, m, P          # exp(F s dt) == the inner kernel on stretched inputs
+
 
 class KernelProduct(Kernel):             # lti_sde.jl:377-400
     def __init__(self, *kernels):
@@ -204,6 +218,14 @@ class KernelProduct(Kernel):             # lti_sde.jl:377-400
         q = float(np.prod([s[1] for s in sdes]))
         A, a, Q, Hs, hs = broadcast_components((F, q, H), (m0, P0), t)
         return A, a, Q, Hs, hs, (m0, P0)
+
+    def sde_blocks(self):
+        parts = [k.sde_blocks() for k in self.kernels]
+        F, H, m0, P0 = parts[0]
+        for Fb, Hb, mb, Pb in parts[1:]:
+            F = np.kron(F, np.eye(Fb.shape[0])) + np.kron(np.eye(F.shape[0]), Fb)
+            H, m0, P0 = np.kron(H, Hb), np.kron(m0, mb), np.kron(P0, Pb)
+        return F, H, m0, P0
 
 
 class KernelSum(Kernel):                 # lti_sde.jl:404-445
@@ -227,6 +249,11 @@ class KernelSum(Kernel):                 # lti_sde.jl:404-445
         P0 = block_diag(*[p[5][1] for p in parts])
         assert A.shape[0] in (1, T)
         return A, a, Q, H, h, (m0, P0)
+
+    def sde_blocks(self):
+        parts = [k.sde_blocks() for k in self.kernels]
+        return (block_diag(*[p[0] for p in parts]), np.concatenate([p[1] for p in parts]), np.concatenate([p[2] for p in parts]),
+                block_diag(*[p[3] for p in parts]))
 
 
 def broadcast_components(FqH, x0, t):
@@ -326,11 +353,30 @@ class GP:
             self.mean = ConstMean(m) if np.isscalar(m) else m
 
 
-def build_lgssm(kernel, x, sigma2s, mean=None, device=0, force_per_step=False):
+DEVICE_COMPONENTS_MIN_T = 2048      # irregular spacing: from this length on, exp(F dt) is evaluated on the device
+
+
+def build_lgssm(kernel, x, sigma2s, mean=None, device=0, force_per_step=False, device_components=None):
     """lti_sde.jl:71-80 -> device LGSSM. `sigma2s`: scalar (Fill) or length-T array.
-    force_per_step replicates Fill blocks to per-step arrays (the general layout, for benchmarking it)."""
-    A, a, Q, H, h, (m0, P0) = kernel.lgssm_components(x)
+    force_per_step replicates Fill blocks to per-step arrays (the general layout, for benchmarking it).
+    Irregular spacing with T >= DEVICE_COMPONENTS_MIN_T (or device_components=True): the per-step A_k = exp(F dt_k),
+    Q_k are built on the device from the time stamps (SDETransitions) instead of on the host."""
     T = len(x)
+    if device_components is None:
+        device_components = (not isinstance(x, RegularSpacing)) and T >= DEVICE_COMPONENTS_MIN_T and not force_per_step
+    if device_components and not isinstance(x, RegularSpacing) and hasattr(kernel, "sde_blocks"):
+        F, H, m0, P0 = kernel.sde_blocks()
+        if F.shape[0] <= 8:
+            hh = np.zeros(1)
+            if isinstance(mean, ConstMean):
+                hh = hh + mean.c
+            elif mean is not None and not isinstance(mean, ZeroMean):
+                hh = np.asarray(mean(x), dtype=np.float64)
+            R = np.atleast_1d(np.asarray(sigma2s, dtype=np.float64))
+            A1, _, Q1, _, _, _ = kernel.lgssm_components(_times(x)[:1])       # the reference's own first step (dt_1 rule)
+            trans = L.SDETransitions(L.Forward, F, _times(x), L.Gaussian(np.asarray(m0, float), np.asarray(P0, float)), A1[0], Q1[0])
+            return L.LGSSM(trans, L.ScalarOutputLGC(np.asarray(H, float)[None], hh, R), T=T, device=device)
+    A, a, Q, H, h, (m0, P0) = kernel.lgssm_components(x)
     mv = None if mean is None else mean(x)
     if isinstance(mean, ConstMean):
         h = h + mean.c                      # same values as hs .+ m (lti_sde.jl:126-127), but a Fill stays a Fill

@@ -95,3 +95,37 @@ def test_rand_many_and_errors(P):
     assert Y.shape == (25, 4)
     with pytest.raises(ValueError, match="Dimension mismatch"):
         P.logpdf(fx, np.zeros(24))
+
+
+@pytest.mark.parametrize("kname", ["base-Matern12", "base-Matern32", "base-Matern52", "scaled-10.0", "stretched-0.1", "sum-12-32",
+                                   "sum-32-52-const", "prod-52-32"])
+def test_device_side_components_for_irregular_spacing(P, kname):
+    """tgp_model_set_sde: A_k = exp(F dt_k), Q_k built on the device from the time stamps (lti_sde.jl:135-146) must give
+    the same model as the host construction / the oracle, for every kernel expression (one LTI SDE each)."""
+    rng = np.random.default_rng(21)
+    spec = KERNELS[kname]
+    N = 3000
+    x = np.cumsum(rng.random(N) * 0.4 + 1e-3)
+    s2 = rng.random(N) * 0.2 + 0.1
+    k = P.to_kernel(spec)
+    m_dev = P.build_lgssm(k, x, s2, P.ConstMean(0.3), device_components=True)
+    m_host = P.build_lgssm(k, x, s2, P.ConstMean(0.3), device_components=False)
+    import temporalgps_jl_amd as tgp
+    assert isinstance(m_dev.transitions, tgp.lgssm.SDETransitions) and not isinstance(m_host.transitions, tgp.lgssm.SDETransitions)
+    y = rng.standard_normal(N)
+    ym = y.copy()
+    ym[rng.random(N) < 0.1] = np.nan
+    lp_o = oc.gp_logpdf(spec, x, s2, y, ("const", 0.3), np.isnan(ym))
+    for m in (m_dev, m_host):
+        assert abs(tgp.logpdf(m, ym) - lp_o) <= 1e-9 * abs(lp_o)
+    a, b = tgp.posterior_marginals(m_dev, y, np.array([0.05])), tgp.posterior_marginals(m_host, y, np.array([0.05]))
+    np.testing.assert_allclose(a[0], b[0], rtol=1e-8, atol=1e-8)
+    np.testing.assert_allclose(a[1], b[1], rtol=1e-8, atol=1e-9)
+    fa, fb = tgp._filter(m_dev, y), tgp._filter(m_host, y)
+    np.testing.assert_allclose(fa[0], fb[0], rtol=1e-8, atol=1e-9)
+    pa, pb = tgp.posterior(m_dev, y), tgp.posterior(m_host, y)
+    np.testing.assert_allclose(pa.transitions.As, pb.transitions.As, rtol=1e-8, atol=1e-9)
+    eps = (rng.standard_normal((N, m_dev.dim)), rng.standard_normal(N), rng.standard_normal(m_dev.dim))
+    # Q_k = P - A P A' is a cancellation: at tiny dt two correctly-rounded exponentials give Q's that differ by ~1e-16 |P|,
+    # which chol(Q + 1e-9 I) turns into ~1e-9 in a sample
+    np.testing.assert_allclose(tgp.rand(eps, m_dev), tgp.rand(eps, m_host), rtol=1e-7, atol=1e-7)
