@@ -31,7 +31,9 @@ WORKLOADS = {
     # name: (kernel spec, d, dt, sigma2_obs)
     "matern52_d3": (("matern52",), 3, 0.1, 0.1),     # BASELINE "Matern32 d=3": d=3 is what Matern-5/2 produces
     "matern32_d2": (("matern32",), 2, 0.1, 0.1),     # the named kernel at the d the reference really produces
+    "sum52_12_d4": (("sum", ("matern52",), ("matern12",)), 4, 0.1, 0.1),   # BASELINE config 4's "Matern52, d=4"
     "sum52_32_d5": (("sum", ("matern52",), ("matern32",)), 5, 0.1, 0.1),
+    "sum52_52_d6": (("sum", ("matern52",), ("matern52",)), 6, 0.1, 0.1),   # BASELINE config 3's "d=6"
 }
 
 

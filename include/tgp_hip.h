@@ -62,6 +62,8 @@ typedef struct tgp_handle tgp_handle;
 /* ---- options (tgp_set_option) ------------------------------------------------------------------ */
 #define TGP_OPT_CHUNK 1   /* steps per lane in the chunked scan (0 = auto) */
 #define TGP_OPT_PROFILE 2 /* 1: bracket every kernel with hipEvents (see tgp_profile_*) */
+#define TGP_OPT_VARIANT 3 /* d = 5, 6 only: 0 auto (inlined build if it passes the run-time known-answer check against the
+                             out-of-line build), 1 force the out-of-line build, 2 force the inlined build */
 
 /* ---- lifetime ---------------------------------------------------------------------------------- */
 int tgp_create(tgp_handle** h, int device);
@@ -71,6 +73,8 @@ int tgp_set_option(tgp_handle* h, int option, int64_t value);
 /* run on a caller-provided hipStream_t (e.g. torch's current stream); NULL restores the handle's own */
 int tgp_set_stream(tgp_handle* h, void* hip_stream);
 const char* tgp_version(void);
+/* which build of the kernels the current model runs on: 1 out-of-line (safe), 2 fully inlined (d = 5, 6 after the check) */
+int tgp_kernel_variant(const tgp_handle* h);
 
 /* ---- model: replaces the LGSSM / GaussMarkovModel containers -----------------------------------
  * lgssm.jl:9-12, gauss_markov_model.jl:20-32 (As, as, Qs, x0) + emissions (A = H', a = h, Q = R).

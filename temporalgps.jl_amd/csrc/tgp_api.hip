@@ -31,7 +31,21 @@ const KernelTable* kernel_table(int d) {
 }
 }  // namespace tgp
 
+// fully-inlined builds of the big state dimensions (tgp_inst_d5i.hip, tgp_inst_d6i.hip): same struct layouts, other namespace
+namespace tgp_i {
+struct KernelTable;
+const KernelTable* kernel_table_d5_i();
+const KernelTable* kernel_table_d6_i();
+}  // namespace tgp_i
+
 using namespace tgp;
+
+static const KernelTable* fast_kernel_table(int d) {
+    if (d == 5) return reinterpret_cast<const KernelTable*>(tgp_i::kernel_table_d5_i());
+    if (d == 6) return reinterpret_cast<const KernelTable*>(tgp_i::kernel_table_d6_i());
+    return nullptr;
+}
+static int g_variant[16] = {0};   // per state dimension: 0 not decided, 1 out-of-line (safe) build, 2 inlined (fast) build
 
 // result[0] = sum lml + nmiss * log(2 pi 1e15)/2 (missings.jl:45-53); result[1] = nmiss; result[2] = bad.
 // Fixed-order summation: the result is bit-reproducible from run to run.
@@ -160,6 +174,7 @@ struct tgp_handle {
     double* host_result = nullptr;  // pinned, 8 doubles: [0] lml [1] nmiss [2] filter-bad ; int flags at [4]
     int64_t opt_chunk = 0;
     int profile = 0;
+    int variant_opt = 0;   // TGP_OPT_VARIANT: 0 auto (run-time check), 1 safe, 2 fast
     int L0 = 0;
     int64_t n0 = 0;
     bool reduce_valid = false, smoother_valid = false;
@@ -332,7 +347,8 @@ int scan_prepare(tgp_handle* h, ScanCtx& c, int monoid, int64_t n0) {
     c.NC = (monoid == kFilter) ? felem_size(h->d) : (monoid == kFilterAD) ? 2 * felem_size(h->d) : aelem_size(h->d);
     c.NS = (monoid == kFilterAD) ? 2 * state_size(h->d) : state_size(h->d);
     // the dual-number top-level scan runs in ONE 256-lane block (a 512-lane block caps it at 256 VGPRs and spills)
-    const int64_t top_cap = (monoid == kFilterAD) ? 256 : (int64_t)kTopBS * kScanE;
+    // likewise the d >= 5 elements (>= 60 doubles each): keep the top block at 256 lanes
+    const int64_t top_cap = (monoid == kFilterAD || h->d >= 5) ? 256 : (int64_t)kTopBS * kScanE;
     c.n.clear();
     c.n.push_back(n0);
     while (c.n.back() > top_cap) c.n.push_back((c.n.back() + 256 * kScanE - 1) / (256 * kScanE));
@@ -565,6 +581,13 @@ template <int D> int host_combine(int kind, const double* ei, const double* ej, 
 
 }  // namespace
 
+// ------------------------------------------------------------------------------------------ run-time variant check
+// d = 5, 6 exist in two builds: out-of-line building blocks with the matrices in private memory (safe, slow) and fully
+// inlined (fast, but the spill-heavy form hipcc has miscompiled for us). The first model of such a d on a process runs a
+// known-answer comparison of the two builds over every entry point and both layouts; the fast build is used only if it
+// reproduces the safe one to 1e-9.
+static bool variant_selftest(int device, int d);
+
 // =========================================================================================== C ABI
 extern "C" {
 
@@ -632,7 +655,24 @@ int tgp_set_option(tgp_handle* h, int option, int64_t value) {
         h->profile = value != 0;
         return TGP_OK;
     }
+    if (option == TGP_OPT_VARIANT) {
+        if (value < 0 || value > 2) return h->fail(TGP_EINVAL, "TGP_OPT_VARIANT must be 0, 1 or 2");
+        h->variant_opt = (int)value;
+        if (h->have_model) {
+            const KernelTable* fast = fast_kernel_table(h->d);
+            const int v = value == 0 ? g_variant[h->d] : (int)value;
+            h->kt = (v == 2 && fast) ? fast : kernel_table(h->d);
+            h->reduce_valid = false;
+            h->smoother_valid = false;
+        }
+        return TGP_OK;
+    }
     return h->fail(TGP_EINVAL, "unknown option");
+}
+
+int tgp_kernel_variant(const tgp_handle* h) {
+    if (!h || !h->have_model) return 0;
+    return (fast_kernel_table(h->d) != nullptr && h->kt == fast_kernel_table(h->d)) ? 2 : 1;
 }
 
 int tgp_set_stream(tgp_handle* h, void* hip_stream) {
@@ -655,6 +695,14 @@ int tgp_model_set(tgp_handle* h, int64_t T, int d, int p, int ordering, uint32_t
     if (ordering != 0 && ordering != 1) return h->fail(TGP_EINVAL, "ordering must be 0 (Forward) or 1 (Reverse)");
     const KernelTable* kt = kernel_table(d);
     if (!kt) return h->fail(TGP_EUNSUPPORTED, "state dimension d must be in 1..8 for the per-lane scan path");
+    if (const KernelTable* fast = fast_kernel_table(d)) {
+        int v = h->variant_opt;
+        if (v == 0) {
+            if (g_variant[d] == 0) g_variant[d] = variant_selftest(h->device, d) ? 2 : 1;
+            v = g_variant[d];
+        }
+        if (v == 2) kt = fast;
+    }
     if (!A || !a || !Q || !H || !hh || !R || !x0m || !x0P) return h->fail(TGP_EINVAL, "null model array");
     h->kt = kt;
     h->T = T;
@@ -1059,6 +1107,78 @@ int tgp_logpdf_grad(tgp_handle* h, const double* y, const uint8_t* missing, uint
     grad_out[nparams - 1] = h->host_result[3];
     return rc != TGP_OK ? rc : rc2;
 }
+
+}  // extern "C"
+
+static bool variant_selftest(int device, int d) {
+    const int64_t T = 3000;
+    uint64_t st = 0x9E3779B97F4A7C15ull ^ (uint64_t)d;
+    auto rnd = [&]() {   // uniform in (-1, 1)
+        st = st * 6364136223846793005ull + 1442695040888963407ull;
+        return ((double)(st >> 11) / 9007199254740992.0) * 2.0 - 1.0;
+    };
+    const int dd = d * d;
+    std::vector<double> A(T * dd), a(T * d), Q(T * dd), H(T * d), hh(T), R(T), y(T), x0m(d), x0P(dd, 0.0), Rn(T), et(T * d), ee(T), e0(d);
+    for (int64_t t = 0; t < T; ++t) {
+        for (int j = 0; j < d; ++j)
+            for (int i = 0; i < d; ++i) A[t * dd + i + j * d] = (i == j ? 0.6 : 0.0) + 0.25 * rnd() / d;
+        std::vector<double> B(dd);
+        for (auto& v : B) v = 0.4 * rnd();
+        for (int j = 0; j < d; ++j)
+            for (int i = 0; i < d; ++i) {
+                double acc = (i == j) ? 0.3 : 0.0;
+                for (int k = 0; k < d; ++k) acc += B[i + k * d] * B[j + k * d];
+                Q[t * dd + i + j * d] = acc;
+            }
+        for (int i = 0; i < d; ++i) { a[t * d + i] = 0.3 * rnd(); H[t * d + i] = rnd(); et[t * d + i] = rnd(); }
+        hh[t] = 0.2 * rnd(); R[t] = 0.2 + 0.3 * (rnd() + 1.0); y[t] = 2.0 * rnd(); Rn[t] = 0.05 * (rnd() + 1.0); ee[t] = rnd();
+    }
+    for (int i = 0; i < d; ++i) { x0m[i] = rnd(); x0P[i + i * d] = 1.0 + 0.3 * rnd(); e0[i] = rnd(); }
+    std::vector<uint8_t> miss(T, 0);
+    for (int64_t t = 0; t < T; t += 17) miss[t] = 1;
+    auto run = [&](int variant, bool lti, std::vector<double>& out) -> int {
+        tgp_handle* h = nullptr;
+        if (tgp_create(&h, device) != TGP_OK) return TGP_EHIP;
+        h->variant_opt = variant;
+        tgp_set_option(h, TGP_OPT_CHUNK, 4);
+        int rc = tgp_model_set(h, T, d, 1, 0, lti ? TGP_SHARED_ALL : 0u, A.data(), a.data(), Q.data(), H.data(), hh.data(), R.data(), x0m.data(),
+                               x0P.data());
+        out.assign(1, 0.0);
+        std::vector<double> b1(T * dd), b2(T * dd), b3(T * dd), xm(d), xP(dd);
+        auto push = [&](const std::vector<double>& v, size_t n) { out.insert(out.end(), v.begin(), v.begin() + n); };
+        if (rc == TGP_OK) rc = tgp_logpdf(h, y.data(), miss.data(), 0, &out[0]);
+        if (rc == TGP_OK) { rc = tgp_filter(h, y.data(), nullptr, 0, b1.data(), b2.data(), nullptr); push(b1, T * d); push(b2, T * dd); }
+        if (rc == TGP_OK) { rc = tgp_posterior(h, y.data(), nullptr, 0, b1.data(), b2.data(), b3.data(), xm.data(), xP.data()); push(b1, T * dd); push(b2, T * d); push(b3, T * dd); push(xm, d); push(xP, dd); }
+        if (rc == TGP_OK) { rc = tgp_posterior_marginals(h, y.data(), miss.data(), Rn.data(), 0, b1.data(), b2.data(), nullptr); push(b1, T); push(b2, T); }
+        if (rc == TGP_OK) { rc = tgp_marginals(h, 0, b1.data(), b2.data()); push(b1, T); push(b2, T); }
+        if (rc == TGP_OK) { rc = tgp_rand(h, et.data(), ee.data(), e0.data(), 0, b1.data()); push(b1, T); }
+        if (rc == TGP_OK && lti) {
+            std::vector<double> dA(dd), da(d), dQ(dd), dH(d), dm(d), dP(dd, 0.0);
+            for (auto& v : dA) v = 0.1 * rnd();
+            for (auto& v : dQ) v = 0.0;
+            for (int i = 0; i < d; ++i) { da[i] = 0.1; dH[i] = 0.2; dm[i] = 0.1; dQ[i + i * d] = 0.05; dP[i + i * d] = 0.1; }
+            double dh = 0.1, dR = 1.0, lml = 0.0, g = 0.0;
+            rc = tgp_logpdf_grad(h, y.data(), nullptr, 0, 1, dA.data(), da.data(), dQ.data(), dH.data(), &dh, &dR, dm.data(), dP.data(), &lml, &g);
+            out.push_back(lml); out.push_back(g);
+        }
+        tgp_destroy(h);
+        return rc;
+    };
+    for (int lti = 0; lti < 2; ++lti) {
+        uint64_t keep = st;
+        std::vector<double> ra, rb;
+        st = keep; const int rca = run(1, lti != 0, ra);
+        st = keep; const int rcb = run(2, lti != 0, rb);
+        if (rca != TGP_OK || rcb != TGP_OK || ra.size() != rb.size()) return false;
+        for (size_t i = 0; i < ra.size(); ++i) {
+            const double tol = 1e-9 * (1.0 + std::fabs(ra[i]));
+            if (!(std::fabs(ra[i] - rb[i]) <= tol)) return false;
+        }
+    }
+    return true;
+}
+
+extern "C" {
 
 int tgp_elem_size(int kind, int d) { return kind == 0 ? felem_size(d) : aelem_size(d); }
 

@@ -17,7 +17,7 @@
 #pragma once
 #include "tgp_math.hpp"
 
-namespace tgp {
+namespace TGP_NS {
 
 struct ModelView {
     int64_t T;         // number of PROCESSING steps = Tt * p (one scalar observation each)
@@ -168,4 +168,4 @@ using real_t = Dual;
 #include "tgp_chunk_body.inc"
 }  // namespace ad
 
-}  // namespace tgp
+}  // namespace TGP_NS

@@ -15,7 +15,7 @@
 
 #include "tgp_chunk.hpp"
 
-namespace tgp {
+namespace TGP_NS {
 
 // ---------------------------------------------------------------- monoid traits (device)
 // E: scan element, S: carried state; NC / NS: doubles per element / state in the SoA scratch (planes [k][n]).
@@ -478,4 +478,4 @@ struct KernelTable {
 
 const KernelTable* kernel_table(int d);
 
-}  // namespace tgp
+}  // namespace TGP_NS

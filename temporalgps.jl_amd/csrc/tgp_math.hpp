@@ -23,19 +23,28 @@
 
 #define TGP_UNROLL _Pragma("unroll")
 
+// Everything lives in namespace TGP_NS (default `tgp`). A translation unit may be compiled a second time under
+// another namespace with another inlining policy (TGP_BIG_D): see tgp_inst_d5i.hip and the run-time variant check
+// in tgp_api.hip.
+#ifndef TGP_NS
+#define TGP_NS tgp
+#endif
+
 // State dimensions >= TGP_BIG_D do not fit one lane's register file (d = 6: ~800 VGPRs of live matrices
 // against 512): fully inlined, hipcc 7.2 spills hundreds of VGPRs and SGPRs and we measured silently wrong
 // results from that path. For those D the per-step / per-combine building blocks are real (noinline)
 // device functions: each has a small register footprint and the matrices live in the lane's private
 // (scratch) memory by construction. d <= 4 stays fully inlined in registers.
+#ifndef TGP_BIG_D
 #define TGP_BIG_D 5
+#endif
 #if defined(__HIPCC__)
 #define TGP_NOINLINE __host__ __device__ __attribute__((noinline))
 #else
 #define TGP_NOINLINE __attribute__((noinline))
 #endif
 
-namespace tgp {
+namespace TGP_NS {
 
 constexpr double kLog2Pi = 1.8378770664093454835606594728112;
 constexpr double kLargeVar = 1e15;  // missings.jl:43
@@ -97,4 +106,4 @@ using real_t = Dual;
 #include "tgp_math_body.inc"
 }  // namespace ad
 
-}  // namespace tgp
+}  // namespace TGP_NS

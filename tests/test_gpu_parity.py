@@ -209,3 +209,35 @@ def test_device_resident_inputs(tgp):
     assert mean.is_cuda and var.is_cuda
     mr, vr = sk.posterior_marginals(model, y, np.array([0.0]))
     assert np.max(np.abs(mean.cpu().numpy() - mr)) <= 1e-8 and np.max(np.abs(var.cpu().numpy() - vr)) <= 1e-8
+
+
+@pytest.mark.parametrize("d", [5, 6])
+@pytest.mark.parametrize("variant", [1, 2])
+def test_kernel_variants_d5_d6(tgp, d, variant):
+    """d = 5, 6 exist as an out-of-line (safe) and a fully inlined (fast) build; both must match the oracle, and the
+    automatic choice must have passed the library's own run-time known-answer check."""
+    rng = np.random.default_rng(500 + d)
+    T = 2500
+    for tv in (True, False):
+        model = U.random_lgssm(rng, tv, d, T)
+        eps = (rng.standard_normal((T, d)), rng.standard_normal(T), rng.standard_normal(d))
+        y = sk.rand(model, *eps)
+        dm = to_device_model(tgp, model)
+        hd = dm.handle()
+        auto = hd.lib.tgp_kernel_variant(hd.h)
+        assert auto in (1, 2)
+        hd.set_option(tgp._lib.OPT_VARIANT, variant)
+        assert hd.lib.tgp_kernel_variant(hd.h) == variant
+        hd.set_option(tgp._lib.OPT_CHUNK, 3)
+        lp = sk.logpdf(model, y)
+        assert abs(tgp.logpdf(dm, y) - lp) <= 1e-10 * abs(lp)
+        Rn = rng.random(T) * 0.1
+        pm, pv = sk.posterior_marginals(model, y, Rn)
+        gm, gv = tgp.posterior_marginals(dm, y, Rn)
+        np.testing.assert_allclose(gm, pm, rtol=1e-8, atol=1e-8)
+        np.testing.assert_allclose(gv, pv, rtol=1e-8, atol=1e-9)
+        post_c = sk.posterior(model, y)
+        post = tgp.posterior(dm, y)
+        np.testing.assert_allclose(post.transitions.As, post_c["A"], rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(post.transitions.Qs, post_c["Q"], rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(tgp.rand(eps, dm), y, rtol=1e-9, atol=1e-9)
