@@ -3,6 +3,8 @@ reaches the device: there is NO CPU fallback -- if the HIP library is missing or
 product path raises."""
 import ctypes
 import os
+import shutil
+import subprocess
 
 import numpy as np
 
@@ -78,6 +80,9 @@ def load():
     """dlopen the in-tree HIP library; raises (never falls back) if it has not been built."""
     global _LIB
     if _LIB is None:
+        if not os.path.exists(LIB_PATH) and shutil.which("hipcc") and os.environ.get("TGP_NO_AUTOBUILD") != "1":
+            # a fresh checkout on a box with the ROCm toolchain: build the product in-tree (~3 minutes, once)
+            subprocess.call(["make", "-s", "-j", str(os.cpu_count() or 4), "-C", os.path.join(_HERE, "csrc")])
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
