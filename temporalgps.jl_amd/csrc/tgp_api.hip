@@ -15,7 +15,8 @@
 
 namespace tgp {
 const KernelTable *kernel_table_d1(), *kernel_table_d2(), *kernel_table_d3(), *kernel_table_d4(), *kernel_table_d5(),
-    *kernel_table_d6(), *kernel_table_d7(), *kernel_table_d8();
+    *kernel_table_d6(), *kernel_table_d7(), *kernel_table_d8(), *kernel_table_d9(), *kernel_table_d10(), *kernel_table_d11(),
+    *kernel_table_d12(), *kernel_table_d13(), *kernel_table_d14(), *kernel_table_d15(), *kernel_table_d16();
 const KernelTable* kernel_table(int d) {
     switch (d) {
         case 1: return kernel_table_d1();
@@ -26,6 +27,14 @@ const KernelTable* kernel_table(int d) {
         case 6: return kernel_table_d6();
         case 7: return kernel_table_d7();
         case 8: return kernel_table_d8();
+        case 9: return kernel_table_d9();
+        case 10: return kernel_table_d10();
+        case 11: return kernel_table_d11();
+        case 12: return kernel_table_d12();
+        case 13: return kernel_table_d13();
+        case 14: return kernel_table_d14();
+        case 15: return kernel_table_d15();
+        case 16: return kernel_table_d16();
         default: return nullptr;
     }
 }
@@ -578,6 +587,14 @@ template <int D> int host_combine(int kind, const double* ei, const double* ej, 
         case 6: return fn<6>(__VA_ARGS__);  \
         case 7: return fn<7>(__VA_ARGS__);  \
         case 8: return fn<8>(__VA_ARGS__);  \
+        case 9: return fn<9>(__VA_ARGS__);  \
+        case 10: return fn<10>(__VA_ARGS__); \
+        case 11: return fn<11>(__VA_ARGS__); \
+        case 12: return fn<12>(__VA_ARGS__); \
+        case 13: return fn<13>(__VA_ARGS__); \
+        case 14: return fn<14>(__VA_ARGS__); \
+        case 15: return fn<15>(__VA_ARGS__); \
+        case 16: return fn<16>(__VA_ARGS__); \
         default: return TGP_EUNSUPPORTED;   \
     }
 
@@ -696,7 +713,7 @@ int tgp_model_set(tgp_handle* h, int64_t T, int d, int p, int ordering, uint32_t
     if (p < 1 || p > 64) return h->fail(TGP_EUNSUPPORTED, "observation dimension p must be in 1..64 (diagonal noise)");
     if (ordering != 0 && ordering != 1) return h->fail(TGP_EINVAL, "ordering must be 0 (Forward) or 1 (Reverse)");
     const KernelTable* kt = kernel_table(d);
-    if (!kt) return h->fail(TGP_EUNSUPPORTED, "state dimension d must be in 1..8 for the per-lane scan path");
+    if (!kt) return h->fail(TGP_EUNSUPPORTED, "state dimension d must be in 1..16 for the per-lane scan path");
     if (const KernelTable* fast = fast_kernel_table(d)) {
         int v = h->variant_opt;
         if (v == 0) {
@@ -756,6 +773,7 @@ int tgp_model_set_sde(tgp_handle* h, int64_t T, int d, int ordering, uint32_t fl
                       const double* x0P) {
     if (!h) return TGP_EINVAL;
     if (!F || !times) return h->fail(TGP_EINVAL, "null F / times");
+    if (d > 8) return h->fail(TGP_EUNSUPPORTED, "tgp_model_set_sde: d <= 8 (build the per-step blocks on the host for larger d)");
     // shared placeholder blocks for A and Q (never read: the tiled record supplies them); a must be shared
     if (!(flags & TGP_SHARED_a)) return h->fail(TGP_EUNSUPPORTED, "tgp_model_set_sde: the transition offset a must be shared");
     std::vector<double> zero((size_t)d * d, 0.0);

@@ -1,0 +1,4 @@
+// d = 14: out-of-line building blocks, rolled loops (matrices in the lane's private memory)
+#define TGP_NO_UNROLL
+#define TGP_D 14
+#include "tgp_inst.inc"

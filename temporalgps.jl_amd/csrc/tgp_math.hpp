@@ -21,7 +21,14 @@
 #define TGP_HD inline
 #endif
 
+// d <= 8: fully unrolled (matrices in registers). The d = 9..16 translation units are compiled with TGP_NO_UNROLL: their
+// matrices live in private memory anyway (out-of-line building blocks), and rolled loops keep code size and compile
+// time sane.
+#if defined(TGP_NO_UNROLL)
+#define TGP_UNROLL _Pragma("nounroll")
+#else
 #define TGP_UNROLL _Pragma("unroll")
+#endif
 
 // Everything lives in namespace TGP_NS (default `tgp`). A translation unit may be compiled a second time under
 // another namespace with another inlining policy (TGP_BIG_D): see tgp_inst_d5i.hip and the run-time variant check

@@ -330,6 +330,11 @@ extern "C" int hostsim_run(int d, int p, int small_out, int lti, int what, int L
         case 4: return run_d<4>(a, lti);
         case 5: return run_d<5>(a, lti);
         case 6: return run_d<6>(a, lti);
+        case 7: return run_d<7>(a, lti);
+        case 8: return run_d<8>(a, lti);
+        case 10: return run_d<10>(a, lti);
+        case 14: return run_d<14>(a, lti);
+        case 16: return run_d<16>(a, lti);
         default: return 4;
     }
 }

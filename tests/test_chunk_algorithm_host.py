@@ -25,7 +25,7 @@ def test_gp_lti(i, L0, BS):
     _check_all(model, y, eps, L0, BS)
 
 
-@pytest.mark.parametrize("d", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("d", [1, 2, 3, 4, 5, 6, 8, 10, 16])
 @pytest.mark.parametrize("tv", [True, False])
 @pytest.mark.parametrize("hetero", [False, True])
 def test_random_lgssm(d, tv, hetero):

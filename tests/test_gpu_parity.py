@@ -241,3 +241,36 @@ def test_kernel_variants_d5_d6(tgp, d, variant):
         np.testing.assert_allclose(post.transitions.As, post_c["A"], rtol=1e-8, atol=1e-9)
         np.testing.assert_allclose(post.transitions.Qs, post_c["Q"], rtol=1e-8, atol=1e-9)
         np.testing.assert_allclose(tgp.rand(eps, dm), y, rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize("d", [9, 12, 16])
+@pytest.mark.parametrize("tv", [True, False])
+def test_larger_state_dimensions(tgp, d, tv):
+    """d = 9..16 (e.g. ApproxPeriodicKernel{7}: d = 14) run the out-of-line, private-memory build."""
+    rng = np.random.default_rng(900 + d + tv)
+    T = 600
+    model = U.random_lgssm(rng, tv, d, T)
+    eps = (rng.standard_normal((T, d)), rng.standard_normal(T), rng.standard_normal(d))
+    check_all(tgp, model, ref.rand(model, *eps), eps, chunk=2)
+
+
+def test_approx_periodic_default_kernel(tgp):
+    """ApproxPeriodicKernel() (7 cosine terms, d = 14; lti_sde.jl:255-307) against the dense GP with the true periodic
+    kernel (test/gp/lti_sde.jl:113-116) and against the oracle's state-space restatement."""
+    from oracle import dense_gp as dg
+    from temporalgps_jl_amd import lti_sde as P
+    rng = np.random.default_rng(14)
+    N = 300
+    spec = ("approx_periodic", 7, 1.0)
+    x = P.RegularSpacing(0.0, 0.13, N)
+    fx = P.to_sde(P.GP(P.ApproxPeriodicKernel()))(x, 0.1)
+    y = P.rand(rng, fx)
+    lp = P.logpdf(fx, y)
+    lp_o = oc.gp_logpdf(spec, ("regular", 0.0, 0.13, N), 0.1, y)
+    assert abs(lp - lp_o) <= 1e-9 * abs(lp_o)
+    lp_d = dg.logpdf(spec, x.collect(), 0.1, y)
+    assert abs(lp - lp_d) <= 1e-5 * abs(lp_d)                 # 7 terms approximate the periodic kernel to ~1e-7
+    m, sd = P.marginals(P.posterior(fx, y)(x, 0.05))
+    mo, vo = oc.posterior_marginals(spec, ("regular", 0.0, 0.13, N), 0.1, y, None, 0.05)
+    np.testing.assert_allclose(m, mo, rtol=1e-7, atol=1e-7)
+    np.testing.assert_allclose(sd ** 2, vo, rtol=1e-7, atol=1e-8)
