@@ -156,6 +156,29 @@ int tgp_smoother_forward(tgp_handle* h, const double* y, const uint8_t* missing,
 int tgp_smoother_backward(tgp_handle* h, const double* xs_m, const double* xs_P, const double* Rnew,
                           uint32_t flags, double* mean_out, double* var_out);
 
+/* ---- device-resident exchange for shards ----------------------------------------------------------
+ * The same protocol with NO host round trip between the phases: every call below only enqueues work on
+ * the handle's stream (tgp_set_stream: use the stream the caller's collectives are ordered against).
+ * `slot_dev` / `gathered_dev` / `stats_dev` are DEVICE buffers owned by the caller; `gathered_dev` is
+ * what an all-gather of one slot per rank leaves (rank-major, world * tgp_shard_slot_size doubles).
+ *   tgp_shard_reduce            pass 1 of this segment -> one filter element in slot_dev  (phase-0 slot)
+ *   [caller: all-gather phase-0 slots]
+ *   tgp_shard_fold              carry-in of this segment = elements 0..rank-1 folded onto the prior x0 (k_fold)
+ *   tgp_shard_logpdf            pass 2 -> stats_dev[0..3] = (lml, n missing, not-PD count, Cholesky flag)
+ *   [caller: all-reduce(sum) of stats, ONE device-to-host copy]
+ * or, for posterior marginals,
+ *   tgp_shard_smoother_forward  pass 2 + reverse elements -> (smoother element | final filtered state) (phase-1 slot)
+ *   [caller: all-gather phase-1 slots]
+ *   tgp_shard_smoother_backward folds ranks W-1..rank+1 onto the last rank's final state, smooths this segment;
+ *                               the ONE synchronisation of the whole call, reports the error flags of all phases */
+int tgp_shard_slot_size(int phase, int d);
+int tgp_shard_reduce(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t flags, double* slot_dev);
+int tgp_shard_fold(tgp_handle* h, const double* gathered_dev, int world, int rank);
+int tgp_shard_logpdf(tgp_handle* h, double* stats_dev);
+int tgp_shard_smoother_forward(tgp_handle* h, double* slot_dev);
+int tgp_shard_smoother_backward(tgp_handle* h, const double* gathered_dev, int world, int rank, const double* Rnew,
+                                uint32_t flags, double* mean_out, double* var_out, double* lml_out);
+
 /* ---- timing ------------------------------------------------------------------------------------ */
 /* device time of the last call (hipEvent, kernels only) and its host<->device copy times, ms */
 int tgp_last_timing(const tgp_handle* h, double* kernel_ms, double* h2d_ms, double* d2h_ms);

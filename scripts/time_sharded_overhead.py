@@ -17,6 +17,6 @@ def t(fn, n=10):
     torch.cuda.synchronize(); a = time.perf_counter()
     for _ in range(n): fn()
     torch.cuda.synchronize(); return (time.perf_counter() - a) / n * 1e3
-print("direct  logpdf %.3f ms  posterior_marginals %.3f ms" % (t(lambda: tgp.logpdf(model, y)), t(lambda: tgp.posterior_marginals(model, y, Rn))))
-print("sharded logpdf %.3f ms  posterior_marginals %.3f ms" % (t(lambda: sh.logpdf(y)), t(lambda: sh.posterior_marginals(y, Rn))))
+print("RESULT direct  logpdf %.3f ms  posterior_marginals %.3f ms" % (t(lambda: tgp.logpdf(model, y)), t(lambda: tgp.posterior_marginals(model, y, Rn))))
+print("RESULT sharded logpdf %.3f ms  posterior_marginals %.3f ms" % (t(lambda: sh.logpdf(y)), t(lambda: sh.posterior_marginals(y, Rn))))
 dist.destroy_process_group()

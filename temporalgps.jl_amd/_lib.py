@@ -52,6 +52,12 @@ _SIGS = {
     "tgp_elem_combine": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _vp, _vp, _vp]),
     "tgp_smoother_forward": (ctypes.c_int, [_vp, _vp, _vp, _u32, _vp, _vp, _vp, _dp]),
     "tgp_smoother_backward": (ctypes.c_int, [_vp, _vp, _vp, _vp, _u32, _vp, _vp]),
+    "tgp_shard_slot_size": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
+    "tgp_shard_reduce": (ctypes.c_int, [_vp, _vp, _vp, _u32, _vp]),
+    "tgp_shard_fold": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int]),
+    "tgp_shard_logpdf": (ctypes.c_int, [_vp, _vp]),
+    "tgp_shard_smoother_forward": (ctypes.c_int, [_vp, _vp]),
+    "tgp_shard_smoother_backward": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, _vp, _u32, _vp, _vp, _dp]),
     "tgp_last_timing": (ctypes.c_int, [_vp, _dp, _dp, _dp]),
     "tgp_profile_reset": (ctypes.c_int, [_vp]),
     "tgp_profile_count": (ctypes.c_int, [_vp]),

@@ -77,6 +77,15 @@ __global__ __launch_bounds__(256) void k_finalize(const double* __restrict__ par
     }
 }
 
+// time-sharded logpdf: (lml, n missing, not-PD count, Cholesky flag) as four doubles the ranks can all-reduce(sum)
+__global__ void k_pack_stats(const double* __restrict__ result, double* __restrict__ stats) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    stats[0] = result[0];
+    stats[1] = result[1];
+    stats[2] = result[2];
+    stats[3] = (double)(*reinterpret_cast<const int*>(result + 4) != 0);
+}
+
 // model re-layout (once per model / chunk size)
 // Lane = chunk, so the (slow, strided) reads happen once here and every later pass reads coalesced rows.
 __global__ __launch_bounds__(256) void k_tile_model(ModelView raw, int d, uint32_t mask, int nc_t, int nc_e, int L0, int64_t n0,
@@ -175,7 +184,8 @@ struct tgp_handle {
     const KernelTable* kt = nullptr;
     DevBuf bA, ba, bQ, bH, bh, bR;
     std::vector<double> x0m, x0P;
-    DevBuf bx0, bx0r;
+    DevBuf bx0, bx0r, bx0fold;
+    bool fold_valid = false;
     // per-call staging
     DevBuf by, bmiss, bRnew, beps_t, beps_e, bo1, bo2, bo3;
     // scans and scratch
@@ -398,8 +408,8 @@ void scan_down(tgp_handle* h, ScanCtx& c, const double* x0dev) {
     }
 }
 
-// reduce the top level of `c` to a single element and copy it to the host
-int scan_total_to_host(tgp_handle* h, ScanCtx& c, double* elem_out) {
+// reduce the top level of `c` to a single element (device resident; *elem_dev points into h->segtmp)
+int scan_total_dev(tgp_handle* h, ScanCtx& c, const double** elem_dev) {
     const int top = (int)c.n.size() - 1;
     const double* src = c.E[top];
     int64_t n = c.n[top];
@@ -417,6 +427,14 @@ int scan_total_to_host(tgp_handle* h, ScanCtx& c, double* elem_out) {
         n = nhi;
         std::swap(t0, t1);
     }
+    *elem_dev = t0;
+    return TGP_OK;
+}
+
+// ... and copy it to the host
+int scan_total_to_host(tgp_handle* h, ScanCtx& c, double* elem_out) {
+    const double* t0 = nullptr;
+    TRY(scan_total_dev(h, c, &t0));
     HIPCHK(hipMemcpyAsync(elem_out, t0, (size_t)c.NC * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return TGP_OK;
@@ -424,9 +442,10 @@ int scan_total_to_host(tgp_handle* h, ScanCtx& c, double* elem_out) {
 
 struct CallTimer {
     tgp_handle* h;
-    explicit CallTimer(tgp_handle* h_) : h(h_) {
+    // clear == false: a later phase of a multi-phase (time-sharded) call, the flags of the earlier phases are kept
+    explicit CallTimer(tgp_handle* h_, bool clear = true) : h(h_) {
         (void)hipEventRecord(h->ev[0], h->stream);
-        (void)hipMemsetAsync(h->result.p, 0, 8 * sizeof(double), h->stream);   // lml / flags of this call
+        if (clear) (void)hipMemsetAsync(h->result.p, 0, 8 * sizeof(double), h->stream);   // lml / flags of this call
     }
     void inputs_done() { (void)hipEventRecord(h->ev[1], h->stream); }
     void kernels_done() { (void)hipEventRecord(h->ev[2], h->stream); }
@@ -517,8 +536,8 @@ int set_obs(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t fla
 }
 
 // forward filter to the end. mode 0/1/2 as in chunk_apply_filter. Fills h->result (lml, nmiss, bad).
-int forward_apply(tgp_handle* h, int mode, const FilterOut& fo) {
-    scan_down(h, h->F, h->bx0.d());
+int forward_apply(tgp_handle* h, int mode, const FilterOut& fo, const double* x0dev = nullptr) {
+    scan_down(h, h->F, x0dev ? x0dev : h->bx0.d());
     const int64_t nblocks = (h->n0 + 255) / 256;
     HIPCHK(h->partial.ensure((size_t)nblocks * 3 * sizeof(double)));
     double* R0 = nullptr;
@@ -643,7 +662,7 @@ int tgp_destroy(tgp_handle* h) {
     if (!h) return TGP_OK;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
-    for (DevBuf* b : {&h->bA, &h->ba, &h->bQ, &h->bH, &h->bh, &h->bR, &h->bx0, &h->bx0r, &h->by, &h->bmiss, &h->bRnew, &h->beps_t,
+    for (DevBuf* b : {&h->bA, &h->ba, &h->bQ, &h->bH, &h->bh, &h->bR, &h->bx0, &h->bx0r, &h->bx0fold, &h->by, &h->bmiss, &h->bRnew, &h->beps_t,
                       &h->beps_e, &h->bo1, &h->bo2, &h->bo3, &h->F.slab, &h->Rv.slab, &h->fs, &h->partial, &h->result, &h->segtmp, &h->tile_t, &h->tile_e, &h->Fad.slab, &h->btan, &h->bx0ad, &h->bF, &h->bPinf, &h->btimes, &h->bAQ1})
         b->release();
     for (auto& e : h->ev)
@@ -706,6 +725,7 @@ int tgp_model_set(tgp_handle* h, int64_t T, int d, int p, int ordering, uint32_t
     if (!h) return TGP_EINVAL;
     TRY(bind_device(h));
     h->have_model = false;
+    h->fold_valid = false;
     h->reduce_valid = false;
     h->smoother_valid = false;
     h->sde = false;
@@ -813,6 +833,7 @@ int tgp_model_set_x0(tgp_handle* h, const double* x0m, const double* x0P) {
     if (!x0m || !x0P) return h->fail(TGP_EINVAL, "null x0");
     h->x0m.assign(x0m, x0m + h->d);
     h->x0P.assign(x0P, x0P + h->d * h->d);
+    h->fold_valid = false;
     h->smoother_valid = false;
     return upload_x0(h, h->bx0, x0m, x0P);
 }
@@ -877,13 +898,13 @@ int tgp_posterior(tgp_handle* h, const double* y, const uint8_t* missing, uint32
     return tm.finish();
 }
 
-static int smoother_forward_impl(tgp_handle* h, uint32_t flags) {
+static int smoother_forward_impl(tgp_handle* h, uint32_t flags, const double* x0dev = nullptr) {
     TRY(forward_reduce(h, flags));
     const size_t fsz = (size_t)((h->n0 + 63) / 64) * 64 * h->L0 * state_size(h->d) * sizeof(double);
     HIPCHK(h->fs.ensure(fsz));
     FilterOut fo{};
     fo.fs = h->fs.d();
-    TRY(forward_apply(h, 2, fo));
+    TRY(forward_apply(h, 2, fo, x0dev));
     scan_up(h, h->Rv);
     h->smoother_valid = true;
     return TGP_OK;
@@ -1214,6 +1235,94 @@ int tgp_segment_reduce(tgp_handle* h, const double* y, const uint8_t* missing, u
     return tm.finish();
 }
 
+// ---- device-resident exchange (include/tgp_hip.h): every phase only ENQUEUES work on the handle's stream
+int tgp_shard_slot_size(int phase, int d) {
+    if (d < 1 || d > 16) return 0;
+    return phase == 0 ? felem_size(d) : aelem_size(d) + state_size(d);
+}
+
+int tgp_shard_reduce(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t flags, double* slot_dev) {
+    TRY(check_ready(h));
+    if (!slot_dev) return h->fail(TGP_EINVAL, "slot_dev is NULL");
+    CallTimer tm(h);                                   // clears the result / flag words for the whole multi-phase call
+    h->fold_valid = false;
+    TRY(set_obs(h, y, missing, flags));
+    TRY(forward_reduce(h, flags));
+    const double* e = nullptr;
+    TRY(scan_total_dev(h, h->F, &e));
+    HIPCHK(hipMemcpyAsync(slot_dev, e, (size_t)h->F.NC * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    return TGP_OK;
+}
+
+int tgp_shard_fold(tgp_handle* h, const double* gathered_dev, int world, int rank) {
+    TRY(check_ready(h));
+    if (!gathered_dev || world < 1 || rank < 0 || rank >= world) return h->fail(TGP_EINVAL, "bad gathered buffer / world / rank");
+    if (!h->reduce_valid) return h->fail(TGP_EINVAL, "tgp_shard_fold needs a preceding tgp_shard_reduce");
+    HIPCHK(h->bx0fold.ensure((size_t)state_size(h->d) * sizeof(double)));
+    {
+        LaunchScope ls(h, "k_fold<filter>");
+        h->kt->fold(kFilter, gathered_dev, felem_size(h->d), 0, rank, 1, h->bx0.d(), h->bx0fold.d(), h->stream);
+    }
+    h->fold_valid = true;
+    return TGP_OK;
+}
+
+int tgp_shard_logpdf(tgp_handle* h, double* stats_dev) {
+    TRY(check_ready(h));
+    if (!stats_dev) return h->fail(TGP_EINVAL, "stats_dev is NULL");
+    if (!h->fold_valid || !h->reduce_valid) return h->fail(TGP_EINVAL, "tgp_shard_logpdf needs tgp_shard_reduce + tgp_shard_fold first");
+    FilterOut fo{};
+    TRY(forward_apply(h, 0, fo, h->bx0fold.d()));
+    hipLaunchKernelGGL(k_pack_stats, dim3(1), dim3(64), 0, h->stream, h->result.d(), stats_dev);
+    HIPCHK(hipGetLastError());
+    return TGP_OK;
+}
+
+int tgp_shard_smoother_forward(tgp_handle* h, double* slot_dev) {
+    TRY(check_ready(h));
+    if (!slot_dev) return h->fail(TGP_EINVAL, "slot_dev is NULL");
+    if (h->ordering != 0) return h->fail(TGP_EUNSUPPORTED, "posterior of a Reverse-ordered model is not implemented on the device");
+    if (!h->fold_valid || !h->reduce_valid) return h->fail(TGP_EINVAL, "tgp_shard_smoother_forward needs tgp_shard_reduce + tgp_shard_fold first");
+    TRY(smoother_forward_impl(h, TGP_REUSE_REDUCE, h->bx0fold.d()));
+    const double* e = nullptr;
+    TRY(scan_total_dev(h, h->Rv, &e));
+    const size_t na = (size_t)aelem_size(h->d), ns = (size_t)state_size(h->d);
+    HIPCHK(hipMemcpyAsync(slot_dev, e, na * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(slot_dev + na, h->F.fin, ns * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    return TGP_OK;
+}
+
+int tgp_shard_smoother_backward(tgp_handle* h, const double* gathered_dev, int world, int rank, const double* Rnew, uint32_t flags,
+                                double* mean_out, double* var_out, double* lml_out) {
+    TRY(check_ready(h));
+    if (!h->smoother_valid) return h->fail(TGP_EINVAL, "tgp_shard_smoother_backward needs a preceding tgp_shard_smoother_forward");
+    if (!gathered_dev || world < 1 || rank < 0 || rank >= world) return h->fail(TGP_EINVAL, "bad gathered buffer / world / rank");
+    if (!Rnew || !mean_out || !var_out) return h->fail(TGP_EINVAL, "null Rnew / output");
+    const bool idev = (flags & TGP_IN_DEVICE) != 0, odev = (flags & TGP_OUT_DEVICE) != 0;
+    const bool rshared = (flags & TGP_SHARED_R) != 0;
+    const size_t nT = (size_t)h->T * h->p * sizeof(double);
+    CallTimer tm(h, /*clear=*/false);
+    const void* pR = nullptr;
+    TRY(stage_in(h, h->bRnew, Rnew, rshared ? (size_t)h->p * sizeof(double) : nT, idev, &pR));
+    tm.inputs_done();
+    // x_{T_r | T}: the last rank's final filtered state pulled back through the smoother elements of ranks W-1 .. rank+1
+    const int64_t slot = aelem_size(h->d) + state_size(h->d);
+    HIPCHK(h->bx0r.ensure((size_t)state_size(h->d) * sizeof(double)));
+    {
+        LaunchScope ls(h, "k_fold<smoother>");
+        h->kt->fold(kAffineCov, gathered_dev, slot, world - 1, world - 1 - rank, -1,
+                    gathered_dev + (int64_t)(world - 1) * slot + aelem_size(h->d), h->bx0r.d(), h->stream);
+    }
+    double *dm = nullptr, *dv = nullptr;
+    TRY(stage_out(h, h->bo1, mean_out, nT, odev, &dm));
+    TRY(stage_out(h, h->bo2, var_out, nT, odev, &dv));
+    TRY(smoother_backward_impl(h, h->bx0r.d(), (const double*)pR, rshared ? 0 : 1, dm, dv));
+    tm.kernels_done();
+    TRY(copy_back(h, mean_out, dm, nT, odev));
+    TRY(copy_back(h, var_out, dv, nT, odev));
+    return tm.finish(lml_out);
+}
+
 int tgp_elem_apply(int kind, int d, const double* elem, const double* m, const double* P, double* m_out, double* P_out) {
     if (!elem || !m || !P || !m_out || !P_out) return TGP_EINVAL;
     DISPATCH_D(d, host_apply, kind, elem, m, P, m_out, P_out)
@@ -1238,7 +1347,14 @@ int tgp_profile_reset(tgp_handle* h) {
     h->prof.clear();
     return TGP_OK;
 }
-int tgp_profile_count(tgp_handle* h) { return h ? (int)h->prof.size() : 0; }
+int tgp_profile_count(tgp_handle* h) {
+    if (!h) return 0;
+    if (!h->pending.empty()) {                     // the tgp_shard_* phases enqueue without a closing synchronisation
+        (void)hipStreamSynchronize(h->stream);
+        resolve_profile(h);
+    }
+    return (int)h->prof.size();
+}
 int tgp_profile_get(tgp_handle* h, int idx, char* name, int name_cap, double* total_ms, int64_t* calls) {
     if (!h || idx < 0 || idx >= (int)h->prof.size()) return TGP_EINVAL;
     if (name && name_cap > 0) {

@@ -313,6 +313,26 @@ __global__ __launch_bounds__(BS) void k_scan_apply(const double* __restrict__ Ei
     }
 }
 
+// FOLD (time-sharded series, one element per rank): x_out = apply(E[first + (count-1) step], ... apply(E[first], x_in)).
+// `gathered` is rank-major (what an all-gather of one slot per rank leaves): element r starts at gathered + r * slot.
+// A handful of tiny applications: one lane does them; the point is that the carry-in never leaves the device.
+template <int D, class M>
+__global__ __launch_bounds__(64) void k_fold(const double* __restrict__ gathered, int64_t slot, int first, int count, int step,
+                                             const double* __restrict__ x_in, double* __restrict__ x_out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    typename M::S s, t;
+    M::load_s(s, [=](int k) { return x_in[k]; });
+    typename M::E e;
+    int r = first;
+    for (int i = 0; i < count; ++i, r += step) {
+        const double* src = gathered + (int64_t)r * slot;
+        M::load(e, [=](int k) { return src[k]; });
+        M::apply(e, s, t);
+        s = t;
+    }
+    M::store_s(s, [=](int k, double v) { x_out[k] = v; });
+}
+
 // ---------------------------------------------------------------- deterministic block reduction of (lml, nmiss, bad)
 __device__ __forceinline__ void block_sum3(double& a, double& b, int& c, double* sh /* [3*4] */) {
     TGP_UNROLL for (int off = 32; off >= 1; off >>= 1) {
@@ -474,6 +494,9 @@ struct KernelTable {
     // device-side construction of the tiled transitions from time stamps (irregular spacing)
     void (*tile_sde)(const double* F, const double* Pinf, const double* times, const double* AQ1, int64_t Tt, int ordering, int Lt,
                      int64_t n0, double normF, double* tile_t, hipStream_t);
+    // time-sharded series: fold the per-rank elements of an all-gather onto a state, on the device
+    void (*fold)(int monoid, const double* gathered, int64_t slot, int first, int count, int step, const double* x_in, double* x_out,
+                 hipStream_t);
 };
 
 const KernelTable* kernel_table(int d);

@@ -13,6 +13,14 @@ owns the contiguous segment [r T/W, (r+1) T/W) of the series and an LGSSM over j
              rank r folds elements W-1..r+1 onto x_T|T -> smoothed state at its segment end, then smooths locally
 
 No bulk data ever crosses xGMI: the exchange is latency-bound, outputs stay sharded.
+
+Two transports for the same protocol:
+  * device-resident (backend "nccl" == RCCL, the product path on GPUs): the elements never leave HBM. The
+    tgp_shard_* entry points only ENQUEUE on one HIP stream, the all-gathers / the all-reduce are RCCL
+    collectives ordered on that stream, k_fold applies the gathered elements on the device; the host
+    synchronises ONCE per call (to read 4 doubles for logpdf, or when the smoother has finished).
+  * host (backend "gloo": the CPU tests, and multi-rank tests on a single GPU): elements are copied to the
+    host, exchanged with gloo and folded with tgp_elem_apply.
 """
 import ctypes
 
@@ -83,6 +91,63 @@ class HIPEngine:
                                                        _lib.ptr(rev), _lib.ptr(xfm), _lib.ptr(xfP), ctypes.byref(lml)))
         return rev, xfm, xfP.T.copy(), lml.value
 
+    # -- device-resident exchange (tgp_shard_*): everything below only enqueues on self.stream()
+    def stream(self):
+        """The HIP stream the handle and this rank's collectives run on (created on first use)."""
+        import torch
+        if getattr(self, "_stream", None) is None:
+            self._stream = torch.cuda.Stream(device=torch.device("cuda", self.model.device))
+            self.hd.check(self.hd.lib.tgp_set_stream(self.hd.h, ctypes.c_void_p(self._stream.cuda_stream)))
+        return self._stream
+
+    def slot_size(self, phase):
+        return self.hd.lib.tgp_shard_slot_size(phase, self.d)
+
+    def device_obs(self, y):
+        """y (and an optional mask) as contiguous CUDA tensors; no host synchronisation."""
+        import torch
+        mask = None
+        if isinstance(y, tuple):
+            y, mask = y
+        dev = torch.device("cuda", self.model.device)
+        if isinstance(y, np.ma.MaskedArray):
+            mask = np.ma.getmaskarray(y) if mask is None else mask
+            y = y.filled(0.0)
+        if not L._is_torch(y):
+            y = np.asarray(y, dtype=np.float64)
+            if mask is None and np.isnan(y).any():
+                mask = np.isnan(y)
+        yy = torch.as_tensor(y, dtype=torch.float64, device=dev).contiguous()
+        mm = None if mask is None else torch.as_tensor(np.asarray(mask) if not L._is_torch(mask) else mask, device=dev).to(torch.uint8).contiguous()
+        if yy.shape[0] != self.model.T:
+            raise ValueError(f"y has {yy.shape[0]} entries, the segment model has {self.model.T}")
+        return yy, mm
+
+    def shard_reduce(self, yy, mm, slot):
+        self.hd.check(self.hd.lib.tgp_shard_reduce(self.hd.h, _lib.ptr(yy), _lib.ptr(mm), _lib.IN_DEVICE, _lib.ptr(slot)))
+
+    def shard_fold(self, gathered, world, rank):
+        self.hd.check(self.hd.lib.tgp_shard_fold(self.hd.h, _lib.ptr(gathered), int(world), int(rank)))
+
+    def shard_logpdf(self, stats):
+        self.hd.check(self.hd.lib.tgp_shard_logpdf(self.hd.h, _lib.ptr(stats)))
+
+    def shard_smoother_forward(self, slot):
+        self.hd.check(self.hd.lib.tgp_shard_smoother_forward(self.hd.h, _lib.ptr(slot)))
+
+    def shard_smoother_backward(self, gathered, world, rank, R_new, out_device):
+        import torch
+        dev = torch.device("cuda", self.model.device)
+        T = self.model.T
+        Rn = torch.as_tensor(np.atleast_1d(np.asarray(R_new, dtype=np.float64)) if not L._is_torch(R_new) else R_new,
+                             dtype=torch.float64, device=dev).reshape(-1).contiguous()
+        mean, var = L._out(self.model, (T,), out_device), L._out(self.model, (T,), out_device)
+        flags = _lib.IN_DEVICE | (_lib.OUT_DEVICE if out_device else 0) | (_lib.SHARED_R if Rn.shape[0] == 1 else 0)
+        lml = ctypes.c_double()
+        self.hd.check(self.hd.lib.tgp_shard_smoother_backward(self.hd.h, _lib.ptr(gathered), int(world), int(rank), _lib.ptr(Rn), flags,
+                                                              _lib.ptr(mean), _lib.ptr(var), ctypes.byref(lml)))
+        return mean, var
+
     def smoother_backward(self, xs, R_new, like):
         dev = _lib.is_device(like)
         T = self.model.T
@@ -102,14 +167,92 @@ class HIPEngine:
         return mean, var
 
 
+class DistComm:
+    """torch.distributed collectives on device tensors (RCCL): asynchronous, ordered on the current stream."""
+
+    def __init__(self, group=None):
+        self.group = group
+
+    def all_gather(self, gathered, slot):
+        import torch.distributed as dist
+        dist.all_gather_into_tensor(gathered, slot, group=self.group)
+
+    def all_reduce_sum(self, t):
+        import torch.distributed as dist
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+
+
 class ShardedLGSSM:
     """logpdf / posterior marginals of a series whose time axis is split across `world` ranks.
     `model` is this rank's segment LGSSM (x0 = the GLOBAL prior on every rank). With world == 1 this is
     exactly the single-GPU path. `engine` is injectable for the CPU (gloo) tests."""
 
-    def __init__(self, model, world=1, rank=0, engine=None, group=None):
+    def __init__(self, model, world=1, rank=0, engine=None, group=None, comm=None):
         self.model, self.world, self.rank, self.group = model, int(world), int(rank), group
         self.engine = engine if engine is not None else (HIPEngine(model) if self.world > 1 else None)
+        self.comm = comm          # device-resident transport; None => torch.distributed (chosen by backend)
+
+    # -- device-resident transport -----------------------------------------------------------------------
+    def _device_resident(self):
+        if not isinstance(self.engine, HIPEngine):
+            return False
+        if self.comm is not None:
+            return True
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_backend(self.group) == "nccl":
+            self.comm = DistComm(self.group)
+            return True
+        return False
+
+    def _buffers(self):
+        if not hasattr(self, "_slot"):
+            import torch
+            e, dev = self.engine, torch.device("cuda", self.model.device)
+            n0, n1 = e.slot_size(0), e.slot_size(1)
+            mk = lambda n: torch.zeros(n, dtype=torch.float64, device=dev)
+            self._slot = (mk(n0), mk(n1))
+            self._gath = (mk(self.world * n0), mk(self.world * n1))
+            self._stats = mk(4)
+        return self._slot, self._gath, self._stats
+
+    def _forward_device(self, y):
+        """enqueue pass 1, the all-gather of the filter elements and the carry-in fold"""
+        e = self.engine
+        slot, gath, _ = self._buffers()
+        yy, mm = e.device_obs(y)
+        e.shard_reduce(yy, mm, slot[0])
+        self.comm.all_gather(gath[0], slot[0])
+        e.shard_fold(gath[0], self.world, self.rank)
+        return yy
+
+    def _logpdf_device(self, y):
+        import torch
+        e = self.engine
+        st = e.stream()
+        st.wait_stream(torch.cuda.current_stream(st.device))
+        with torch.cuda.stream(st):
+            self._forward_device(y)
+            stats = self._buffers()[2]
+            e.shard_logpdf(stats)
+            self.comm.all_reduce_sum(stats)
+            s = stats.cpu()                                    # the one synchronisation of the call
+        if s[2] != 0 or s[3] != 0:
+            raise _lib.NotPositiveDefinite(_lib.ENOTPD, "innovation variance / predicted covariance not positive definite (some shard)")
+        return float(s[0])
+
+    def _posterior_marginals_device(self, y, R_new):
+        import torch
+        e = self.engine
+        st = e.stream()
+        st.wait_stream(torch.cuda.current_stream(st.device))
+        with torch.cuda.stream(st):
+            yy = self._forward_device(y)
+            slot, gath, _ = self._buffers()
+            e.shard_smoother_forward(slot[1])
+            self.comm.all_gather(gath[1], slot[1])
+            out_device = L._is_torch(y[0] if isinstance(y, tuple) else y)
+            mean, var = e.shard_smoother_backward(gath[1], self.world, self.rank, R_new, out_device)   # synchronises
+        return mean, var
 
     # -- collectives on tiny host vectors (the payload is a few hundred bytes; latency-bound)
     def _all_gather(self, vec):
@@ -149,6 +292,8 @@ class ShardedLGSSM:
     def logpdf(self, y):
         if self.world == 1 and self.engine is None:
             return L.logpdf(self.model, y)
+        if self._device_resident():
+            return self._logpdf_device(y)
         if not hasattr(self, "_x0"):
             self._x0 = self.engine.x0()
         reuse = self._forward_exchange(y)
@@ -158,6 +303,8 @@ class ShardedLGSSM:
         """This rank's slice of marginals(posterior(fx, y)(x)); R_new is the slice's new noise (or a scalar)."""
         if self.world == 1 and self.engine is None:
             return L.posterior_marginals(self.model, y, R_new)
+        if self._device_resident():
+            return self._posterior_marginals_device(y, R_new)
         if not hasattr(self, "_x0"):
             self._x0 = self.engine.x0()
         e = self.engine

@@ -82,3 +82,97 @@ def test_sharded_path_over_rccl_single_rank():
         assert np.max(np.abs(mean.cpu().numpy() - pm)) <= 1e-8 and np.max(np.abs(var.cpu().numpy() - pv)) <= 1e-8
     finally:
         dist.destroy_process_group()
+
+
+class _ThreadComm:
+    """In-process stand-in for RCCL so the DEVICE-RESIDENT exchange (tgp_shard_* + k_fold) can be exercised with W > 1
+    on the one GPU this box has: W ranks are W threads sharing cuda:0, each with its own HIP stream; a collective is a
+    device-to-device copy into a shared tensor between two barriers (the stream is drained before each barrier, which
+    RCCL would not need)."""
+
+    def __init__(self, world, rank, shared, barrier):
+        self.world, self.rank, self.shared, self.barrier = world, rank, shared, barrier
+
+    def all_gather(self, gathered, slot):
+        import torch
+        n = slot.numel()
+        buf = self.shared.setdefault(("g", n), torch.zeros(self.world * n, dtype=torch.float64, device=slot.device))
+        buf[self.rank * n:(self.rank + 1) * n].copy_(slot)
+        torch.cuda.current_stream().synchronize()
+        self.barrier.wait()
+        gathered.copy_(buf)
+        torch.cuda.current_stream().synchronize()
+        self.barrier.wait()
+
+    def all_reduce_sum(self, t):
+        import torch
+        n = t.numel()
+        buf = self.shared.setdefault(("r", n), torch.zeros(self.world, n, dtype=torch.float64, device=t.device))
+        buf[self.rank].copy_(t)
+        torch.cuda.current_stream().synchronize()
+        self.barrier.wait()
+        t.copy_(buf.sum(0))
+        torch.cuda.current_stream().synchronize()
+        self.barrier.wait()
+
+
+@pytest.mark.parametrize("world,layout,d_kernel", [(2, "lti", "matern52"), (4, "lti", "matern32"), (3, "per_step", "matern52"),
+                                                   (3, "lti", "sum52_52")])
+def test_device_resident_exchange_threads(world, layout, d_kernel):
+    import threading
+
+    import torch
+    import temporalgps_jl_amd as tgp  # noqa: F401
+    from temporalgps_jl_amd import lti_sde, parallel
+    T = 150_001
+    rng = np.random.default_rng(8)
+    y_all = rng.standard_normal(T)
+    y_all[rng.random(T) < 0.05] = np.nan
+    kern = {"matern52": lti_sde.Matern52Kernel(), "matern32": lti_sde.Matern32Kernel(),
+            "sum52_52": lti_sde.Matern52Kernel() + 0.5 * lti_sde.Matern52Kernel().stretch(0.3)}[d_kernel]
+    spec = {"matern52": ("matern52",), "matern32": ("matern32",),
+            "sum52_52": ("sum", ("matern52",), ("scaled", 0.5, ("stretched", 0.3, ("matern52",))))}[d_kernel]
+    ref_model = oc.build_lgssm(spec, ("regular", 0.0, 0.1, T), 0.1)
+    from oracle import lgssm_ref as ref
+    m2, y2, nmiss = ref.transform_model_and_obs(ref_model, y_all, np.isnan(y_all))      # missings.jl:25-33
+    lp_ref = sk.logpdf(m2, y2) + ref.volume_compensation(nmiss)
+    pm, pv = sk.posterior_marginals(m2, y2, np.array([0.05]))
+    shared, barrier, out, errs = {}, threading.Barrier(world), {}, []
+
+    def run(rank):
+        try:
+            torch.cuda.set_device(0)
+            lo, hi = parallel.segment_bounds(T, world, rank)
+            model = lti_sde.build_lgssm(kern, lti_sde.RegularSpacing(0.1 * lo, 0.1, hi - lo), 0.1, force_per_step=(layout == "per_step"))
+            sh = parallel.ShardedLGSSM(model, world, rank, engine=parallel.HIPEngine(model),
+                                       comm=_ThreadComm(world, rank, shared, barrier))
+            y = torch.as_tensor(np.nan_to_num(y_all[lo:hi]), device="cuda:0")
+            mask = torch.as_tensor(np.isnan(y_all[lo:hi]), device="cuda:0")
+            lp = sh.logpdf((y, mask))
+            mean, var = sh.posterior_marginals((y, mask), np.array([0.05]))
+            lp2 = sh.logpdf((y, mask))
+            out[rank] = (lp, lp2, lo, hi, mean.cpu().numpy(), var.cpu().numpy())
+        except Exception as ex:          # noqa: BLE001
+            errs.append(ex)
+            barrier.abort()
+
+    # the shared exchange tensors are created up front (dict.setdefault from several threads would race)
+    d = ref_model["A"].shape[-1]
+    from temporalgps_jl_amd import _lib
+    lib = _lib.load()
+    for ph in (0, 1):
+        n = lib.tgp_shard_slot_size(ph, d)
+        shared[("g", n)] = torch.zeros(world * n, dtype=torch.float64, device="cuda:0")
+    shared[("r", 4)] = torch.zeros(world, 4, dtype=torch.float64, device="cuda:0")
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    mean, var = np.zeros(T), np.zeros(T)
+    for r in range(world):
+        lp, lp2, lo, hi, m, v = out[r]
+        assert abs(lp - lp_ref) <= 1e-10 * abs(lp_ref)
+        assert lp2 == lp
+        mean[lo:hi], var[lo:hi] = m, v
+    assert np.max(np.abs(mean - pm)) <= 1e-8
+    assert np.max(np.abs(var - pv)) <= 1e-8
