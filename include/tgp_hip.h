@@ -65,6 +65,9 @@ typedef struct tgp_handle tgp_handle;
 #define TGP_OPT_VARIANT 3 /* d = 5, 6 only: 0 auto (inlined build if it passes the run-time known-answer check against the
                              out-of-line build), 1 force the out-of-line build, 2 force the inlined build */
 
+#define TGP_OPT_FUSE_SCAN 4 /* 1 (default): the level-0 scan reduce / apply of the forward scan run inside the chunk kernels;
+                               0: stand-alone k_scan_reduce / k_scan_apply launches (bit-identical results, for A/B timing) */
+
 /* ---- lifetime ---------------------------------------------------------------------------------- */
 int tgp_create(tgp_handle** h, int device);
 int tgp_destroy(tgp_handle* h);

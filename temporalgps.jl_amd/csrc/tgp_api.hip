@@ -199,6 +199,8 @@ struct tgp_handle {
     int L0 = 0;
     int64_t n0 = 0;
     bool reduce_valid = false, smoother_valid = false;
+    bool fused = false;          // the current forward elements were produced with the fused level-0 reduce
+    int opt_fuse = 1;            // TGP_OPT_FUSE_SCAN
     // timing
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     double kernel_ms = 0.0, h2d_ms = 0.0, d2h_ms = 0.0;
@@ -389,20 +391,22 @@ int scan_prepare(tgp_handle* h, ScanCtx& c, int monoid, int64_t n0) {
     return TGP_OK;
 }
 
-void scan_up(tgp_handle* h, ScanCtx& c) {
-    for (size_t l = 0; l + 1 < c.n.size(); ++l) {
+// first = 1: level 0 has been reduced by the producing chunk kernel itself (fused), start one level up
+void scan_up(tgp_handle* h, ScanCtx& c, size_t first = 0) {
+    for (size_t l = first; l + 1 < c.n.size(); ++l) {
         LaunchScope ls(h, c.monoid == kFilter ? "k_scan_reduce<filter>" : c.monoid == kFilterAD ? "k_scan_reduce<filter,grad>" : "k_scan_reduce<affine>");
         h->kt->scan_reduce(c.monoid, c.E[l], c.n[l], c.E[l + 1], c.n[l + 1], h->stream);
     }
 }
 
-void scan_down(tgp_handle* h, ScanCtx& c, const double* x0dev) {
+// last = 1: stop above level 0 (the consuming chunk kernel scans its own block against S[1], fused)
+void scan_down(tgp_handle* h, ScanCtx& c, const double* x0dev, int last = 0) {
     const int top = (int)c.n.size() - 1;
     {
         LaunchScope ls(h, c.monoid == kFilter ? "k_scan_apply<filter,top>" : c.monoid == kFilterAD ? "k_scan_apply<filter,grad,top>" : "k_scan_apply<affine,top>");
         h->kt->scan_apply(c.monoid, c.n[top] <= 256 * kScanE ? 256 : kTopBS, c.E[top], c.n[top], x0dev, 1, c.S[top], c.fin, h->stream);
     }
-    for (int l = top - 1; l >= 0; --l) {
+    for (int l = top - 1; l >= last; --l) {
         LaunchScope ls(h, c.monoid == kFilter ? "k_scan_apply<filter>" : c.monoid == kFilterAD ? "k_scan_apply<filter,grad>" : "k_scan_apply<affine>");
         h->kt->scan_apply(c.monoid, 256, c.E[l], c.n[l], c.S[l + 1], c.n[l + 1], c.S[l], nullptr, h->stream);
     }
@@ -513,11 +517,15 @@ int forward_reduce(tgp_handle* h, uint32_t flags) {
     choose_chunk(h);
     TRY(ensure_tiled(h));
     TRY(scan_prepare(h, h->F, kFilter, h->n0));
+    // two or more scan levels: the level-0 reduce / apply live inside the chunk kernels (256 chunks per block == the
+    // scan blocking), saving two launches and two passes over the element array per forward scan
+    const bool fused = h->F.n.size() >= 2 && h->opt_fuse;
     {
         LaunchScope ls(h, h->lti ? "k_reduce_filter<lti>" : "k_reduce_filter<per-step>");
-        h->kt->reduce_filter(h->lti, h->mv, h->L0, h->n0, h->F.E[0], h->stream);
+        h->kt->reduce_filter(h->lti, h->mv, h->L0, h->n0, h->F.E[0], fused ? h->F.E[1] : nullptr, fused ? h->F.n[1] : 0, h->stream);
     }
-    scan_up(h, h->F);
+    scan_up(h, h->F, fused ? 1 : 0);
+    h->fused = fused;
     h->reduce_valid = true;
     h->smoother_valid = false;
     return TGP_OK;
@@ -537,7 +545,7 @@ int set_obs(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t fla
 
 // forward filter to the end. mode 0/1/2 as in chunk_apply_filter. Fills h->result (lml, nmiss, bad).
 int forward_apply(tgp_handle* h, int mode, const FilterOut& fo, const double* x0dev = nullptr) {
-    scan_down(h, h->F, x0dev ? x0dev : h->bx0.d());
+    scan_down(h, h->F, x0dev ? x0dev : h->bx0.d(), h->fused ? 1 : 0);
     const int64_t nblocks = (h->n0 + 255) / 256;
     HIPCHK(h->partial.ensure((size_t)nblocks * 3 * sizeof(double)));
     double* R0 = nullptr;
@@ -551,7 +559,8 @@ int forward_apply(tgp_handle* h, int mode, const FilterOut& fo, const double* x0
                          : mode == 2 ? (h->lti ? "k_apply_filter<lti,posterior>" : "k_apply_filter<per-step,posterior>")
                                      : (h->lti ? "k_apply_filter<lti,materialise>" : "k_apply_filter<per-step,materialise>");
         LaunchScope ls(h, nm);
-        h->kt->apply_filter(h->lti, mode, h->mv, h->L0, h->n0, h->F.S[0], fo, R0, h->partial.d(), h->stream);
+        h->kt->apply_filter(h->lti, mode, h->mv, h->L0, h->n0, h->F.S[0], h->fused ? h->F.E[0] : nullptr, h->fused ? h->F.S[1] : nullptr,
+                            h->fused ? h->F.n[1] : 0, fo, R0, h->partial.d(), h->stream);
     }
     {
         LaunchScope ls(h, "k_finalize");
@@ -703,6 +712,12 @@ int tgp_set_option(tgp_handle* h, int option, int64_t value) {
             h->reduce_valid = false;
             h->smoother_valid = false;
         }
+        return TGP_OK;
+    }
+    if (option == TGP_OPT_FUSE_SCAN) {
+        h->opt_fuse = value != 0;
+        h->reduce_valid = false;
+        h->smoother_valid = false;
         return TGP_OK;
     }
     return h->fail(TGP_EINVAL, "unknown option");
@@ -1191,6 +1206,15 @@ static bool variant_selftest(int device, int d) {
         if (rc == TGP_OK) { rc = tgp_filter(h, y.data(), nullptr, 0, b1.data(), b2.data(), nullptr); push(b1, T * d); push(b2, T * dd); }
         if (rc == TGP_OK) { rc = tgp_posterior(h, y.data(), nullptr, 0, b1.data(), b2.data(), b3.data(), xm.data(), xP.data()); push(b1, T * dd); push(b2, T * d); push(b3, T * dd); push(xm, d); push(xP, dd); }
         if (rc == TGP_OK) { rc = tgp_posterior_marginals(h, y.data(), miss.data(), Rn.data(), 0, b1.data(), b2.data(), nullptr); push(b1, T); push(b2, T); }
+        // the shared-R_new smoother kernel (k_smooth<.., RSTREAM = false>) and a chunk size with a ragged last group
+        if (rc == TGP_OK) { rc = tgp_posterior_marginals(h, y.data(), miss.data(), Rn.data(), TGP_SHARED_R, b1.data(), b2.data(), nullptr); push(b1, T); push(b2, T); }
+        if (rc == TGP_OK) {
+            tgp_set_option(h, TGP_OPT_CHUNK, 11);
+            rc = tgp_posterior_marginals(h, y.data(), nullptr, Rn.data(), TGP_SHARED_R, b1.data(), b2.data(), nullptr);
+            push(b1, T); push(b2, T);
+            if (rc == TGP_OK) rc = tgp_logpdf(h, y.data(), miss.data(), 0, &out[0]);
+            tgp_set_option(h, TGP_OPT_CHUNK, 4);
+        }
         if (rc == TGP_OK) { rc = tgp_marginals(h, 0, b1.data(), b2.data()); push(b1, T); push(b2, T); }
         if (rc == TGP_OK) { rc = tgp_rand(h, et.data(), ee.data(), e0.data(), 0, b1.data()); push(b1, T); }
         if (rc == TGP_OK && lti) {

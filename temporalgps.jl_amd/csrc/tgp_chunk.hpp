@@ -127,6 +127,9 @@ TGP_HD uint32_t tile_mask_of(const ModelView& raw) {
 // L0*8 bytes across the wave; the device IO (WaveIO, tgp_kernels.hpp) instead lets 8 lanes fetch / write
 // one chunk's 64 contiguous bytes and transposes through wave-private LDS. DirectIO is the plain form
 // (host emulation, and the reference semantics the staged form must reproduce). `tm` = micro storage index.
+// Largest state dimension that gets the register-resident software prefetch (IO groups, smoother scratch, hoisted shared R).
+constexpr int kPrefetchMaxD = 4;
+
 struct DirectIO {
     static constexpr int G = 8;
     const double* a0;  // y (or eps_e)

@@ -92,7 +92,7 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
-template <bool IN0, bool IN1, bool OUT0, bool OUT1> struct WaveIO {
+template <bool IN0, bool IN1, bool OUT0, bool OUT1, bool PF = true> struct WaveIO {
     static constexpr int G = 8;
     static constexpr int kOff0 = 0;
     static constexpr int kOff1 = (IN0 ? 1 : 0) * kIoSlot;
@@ -106,23 +106,57 @@ template <bool IN0, bool IN1, bool OUT0, bool OUT1> struct WaveIO {
     bool st1;    // a1 is per-step (stage it); otherwise the caller reads a1[0]
     int wb;      // this wave's base index into tgp_lds
     int lane;
+    int step = G;              // group stride of the caller's loop (-G: the smoother walks backwards)
+    int pf_g = -(1 << 30);     // group held in the prefetch registers
+    double pf0[8], pf1[8];
     static constexpr size_t lds_bytes() { return 4 * (size_t)kSlots * kIoSlot * sizeof(double); }
     __device__ __forceinline__ static int wave_base() { return (int)(threadIdx.x >> 6) * kSlots * kIoSlot; }
 
-    __device__ __forceinline__ void begin(const ModelView& mv, int64_t c, int g, int L0) {
-        if (!IN0 && !(IN1 && st1)) return;
-        const int64_t c0 = c - lane;
-        wave_sync();
+    // Software prefetch: the global loads of group g + step are issued right after group g has been handed to LDS
+    // and stay in flight (8 registers per stream) while the wave computes group g. Without it every wave of the
+    // launch refills at the same moment and sits out a full burst-loaded HBM round trip every 8 steps.
+    __device__ __forceinline__ void fetch(const ModelView& mv, int64_t c0, int g, int L0) {
         TGP_UNROLL for (int j = 0; j < 8; ++j) {
             const int row = j * 8 + (lane >> 3);
             const int64_t r = (c0 + row) * L0 + g + (lane & 7);
+            pf0[j] = 0.0;
+            pf1[j] = 0.0;
             if (r < mv.T) {
                 const int64_t tm = micro_index(mv, c0 + row, g + (lane & 7), L0);
-                if (IN0) tgp_lds[wb + kOff0 + row * kIoLD + (lane & 7)] = a0[tm];
-                if (IN1 && st1) tgp_lds[wb + kOff1 + row * kIoLD + (lane & 7)] = a1[tm];
+                if (IN0) pf0[j] = a0[tm];
+                if (IN1 && st1) pf1[j] = a1[tm];
             }
         }
+        pf_g = g;
+    }
+    __device__ __forceinline__ void begin(const ModelView& mv, int64_t c, int g, int L0) {
+        if (!IN0 && !(IN1 && st1)) return;
+        const int64_t c0 = c - lane;
+        if (!PF) {                                     // plain refill (d >= 5: no registers to spare for a prefetch)
+            wave_sync();
+            TGP_UNROLL for (int j = 0; j < 8; ++j) {
+                const int row = j * 8 + (lane >> 3);
+                const int64_t r = (c0 + row) * L0 + g + (lane & 7);
+                if (r < mv.T) {
+                    const int64_t tm = micro_index(mv, c0 + row, g + (lane & 7), L0);
+                    if (IN0) tgp_lds[wb + kOff0 + row * kIoLD + (lane & 7)] = a0[tm];
+                    if (IN1 && st1) tgp_lds[wb + kOff1 + row * kIoLD + (lane & 7)] = a1[tm];
+                }
+            }
+            wave_sync();
+            return;
+        }
+        if (pf_g != g) fetch(mv, c0, g, L0);          // first group of the chunk
         wave_sync();
+        TGP_UNROLL for (int j = 0; j < 8; ++j) {
+            const int row = j * 8 + (lane >> 3);
+            if (IN0) tgp_lds[wb + kOff0 + row * kIoLD + (lane & 7)] = pf0[j];
+            if (IN1 && st1) tgp_lds[wb + kOff1 + row * kIoLD + (lane & 7)] = pf1[j];
+        }
+        wave_sync();
+        const int gn = g + step;
+        if (gn >= 0 && gn < L0) fetch(mv, c0, gn, L0);
+        TGP_ISSUE_BARRIER();
     }
     __device__ __forceinline__ double in0(int64_t, int i) const { return tgp_lds[wb + kOff0 + lane * kIoLD + i]; }
     __device__ __forceinline__ double in1(int64_t, int i) const { return tgp_lds[wb + kOff1 + lane * kIoLD + i]; }
@@ -209,13 +243,78 @@ __global__ __launch_bounds__(256) void k_tile_sde(const double* __restrict__ F, 
     }
 }
 
+// ---------------------------------------------------------------- block-level scan pieces (256 lanes, one element per lane)
+// Shared by the stand-alone scan kernels below and by the chunk kernels, which fuse the level-0 reduce (pass 1 epilogue)
+// and the level-0 apply (pass 2 prologue): two launches and two trips of the element array through HBM less per scan.
+// Same operation order as the stand-alone kernels, so fused and unfused scans agree bit for bit.
+template <class M, int BS>
+__device__ __forceinline__ void block_reduce_store(typename M::E& e, double (*wt)[M::NC], double* __restrict__ Ehi, int64_t nhi, int64_t b) {
+    using E = typename M::E;
+    constexpr int NW = BS / 64;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    E o, t;
+    // ordered tree reduction inside the wave: lane l absorbs lane l+off (later elements on the right)
+    TGP_UNROLL for (int off = 1; off < 64; off <<= 1) {
+        shfl_down_elem(e, o, off);
+        M::combine(e, o, t);
+        if ((lane & (2 * off - 1)) == 0) e = t;
+    }
+    if (lane == 0) M::store(e, [&](int k, double v) { wt[wid][k] = v; });
+    __syncthreads();
+    if (tid == 0) {
+        TGP_UNROLL for (int w = 1; w < NW; ++w) {
+            M::load(o, [&](int k) { return wt[w][k]; });
+            M::combine(e, o, t);
+            e = t;
+        }
+        M::store(e, [=](int k, double v) { Ehi[(int64_t)k * nhi + b] = v; });
+    }
+}
+
+// st = apply(E[b*BS] o ... o E[i-1], cs) for lane i of block b (exclusive prefix), e = this lane's own element (clobbered)
+template <class M, int BS>
+__device__ __forceinline__ void block_exclusive_apply(typename M::E& e, double (*wt)[M::NC], const typename M::S& cs, typename M::S& st) {
+    using E = typename M::E;
+    constexpr int NW = BS / 64;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    E o, t;
+    TGP_UNROLL for (int off = 1; off < 64; off <<= 1) {
+        shfl_up_elem(e, o, off);
+        M::combine(o, e, t);
+        if (lane >= off) e = t;
+    }
+    if (lane == 63) M::store(e, [&](int k, double v) { wt[wid][k] = v; });
+    __syncthreads();
+    E ex;
+    shfl_up_elem(e, ex, 1);
+    if (lane == 0) ex.identity();
+    if (NW > 1) {
+        E wp;
+        wp.identity();
+        for (int w = 0; w < wid; ++w) {
+            M::load(o, [&](int k) { return wt[w][k]; });
+            M::combine(wp, o, t);
+            wp = t;
+        }
+        M::combine(wp, ex, t);
+        ex = t;
+    }
+    M::apply(ex, cs, st);
+}
+
 // ---------------------------------------------------------------- pass 1
 template <int D, bool LTI>
-__global__ __launch_bounds__(256) void k_reduce_filter(ModelView mv, int L0, int64_t n0, double* __restrict__ E0) {
-    using IO = WaveIO<true, true, false, false>;
+__global__ __launch_bounds__(256) void k_reduce_filter(ModelView mv, int L0, int64_t n0, double* __restrict__ E0, double* __restrict__ E1,
+                                                       int64_t n1) {
+    using IO = WaveIO<true, true, false, false, (D <= kPrefetchMaxD)>;
+    using M = FilterMonoid<D>;
+    __shared__ double wt[4][M::NC];
     const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
     IO io{mv.y, mv.R, nullptr, nullptr, io_stages_R<LTI>(mv), IO::wave_base(), (int)(threadIdx.x & 63)};
-    chunk_reduce_filter<D, LTI>(mv, c, L0, io, [=](int k, double v) { E0[(int64_t)k * n0 + c] = v; });
+    FElem<D> e;
+    const bool nonempty = chunk_reduce_filter_elem<D, LTI>(mv, c, L0, io, e);   // identity for lanes past the last chunk
+    if (nonempty) store_felem<D>(e, [=](int k, double v) { E0[(int64_t)k * n0 + c] = v; });
+    if (E1 != nullptr) block_reduce_store<M, 256>(e, wt, E1, n1, (int64_t)blockIdx.x);   // fused level-0 reduce
 }
 
 template <int D, bool LTI, bool RAND>
@@ -239,26 +338,10 @@ __global__ __launch_bounds__(BS) void k_scan_reduce(const double* __restrict__ E
     __shared__ double wt[NW][M::NC];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int64_t idx = (int64_t)blockIdx.x * BS + tid;
-    E e, o, t;
+    E e;
     if (idx < n) M::load(e, [=](int k) { return Ein[(int64_t)k * n + idx]; });
     else e.identity();
-    // ordered tree reduction inside the wave: lane l absorbs lane l+off (later elements on the right)
-    TGP_UNROLL for (int off = 1; off < 64; off <<= 1) {
-        shfl_down_elem(e, o, off);
-        M::combine(e, o, t);
-        if ((lane & (2 * off - 1)) == 0) e = t;
-    }
-    if (lane == 0) M::store(e, [&](int k, double v) { wt[wid][k] = v; });
-    __syncthreads();
-    if (tid == 0) {
-        TGP_UNROLL for (int w = 1; w < NW; ++w) {
-            M::load(o, [&](int k) { return wt[w][k]; });
-            M::combine(e, o, t);
-            e = t;
-        }
-        const int64_t b = blockIdx.x;
-        M::store(e, [=](int k, double v) { Ehi[(int64_t)k * nhi + b] = v; });
-    }
+    block_reduce_store<M, BS>(e, wt, Ehi, nhi, (int64_t)blockIdx.x);
 }
 
 // APPLY: S[i] = apply(E[b*BS] o ... o E[i-1], carry[b]) ; optionally fin = apply(all of block 0.., carry) (top level)
@@ -352,14 +435,27 @@ __device__ __forceinline__ void block_sum3(double& a, double& b, int& c, double*
 
 // ---------------------------------------------------------------- pass 2
 template <int D, bool LTI, int MODE>
-__global__ __launch_bounds__(256) void k_apply_filter(ModelView mv, int L0, int64_t n0, const double* __restrict__ S0, FilterOut out,
-                                                      double* __restrict__ R0, double* __restrict__ partial) {
-    using IO = WaveIO<true, true, false, false>;
+__global__ __launch_bounds__(256) void k_apply_filter(ModelView mv, int L0, int64_t n0, double* __restrict__ S0, const double* __restrict__ E0,
+                                                      const double* __restrict__ S1, int64_t n1, FilterOut out, double* __restrict__ R0,
+                                                      double* __restrict__ partial) {
+    using IO = WaveIO<true, true, false, false, (D <= kPrefetchMaxD)>;
+    using M = FilterMonoid<D>;
     __shared__ double sh[12];
+    __shared__ double wt[4][M::NC];
     const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
     IO io{mv.y, mv.R, nullptr, nullptr, io_stages_R<LTI>(mv), IO::wave_base(), (int)(threadIdx.x & 63)};
     State<D> x;
-    if (c < n0) {
+    if (E0 != nullptr) {
+        // fused level-0 apply: carry-in of chunk c = (elements of this block before c) applied to the block's carry S1[b]
+        FElem<D> e;
+        if (c < n0) load_felem<D>(e, [=](int k) { return E0[(int64_t)k * n0 + c]; });
+        else e.identity();
+        State<D> cs;
+        const int64_t b = blockIdx.x;
+        load_state<D>(cs, [=](int k) { return S1[(int64_t)k * n1 + b]; });
+        block_exclusive_apply<M, 256>(e, wt, cs, x);
+        if (MODE == 2 && c < n0) store_state<D>(x, [=](int k, double v) { S0[(int64_t)k * n0 + c] = v; });   // the smoother reads it
+    } else if (c < n0) {
         load_state<D>(x, [=](int k) { return S0[(int64_t)k * n0 + c]; });
     } else {
         set_zero<D>(x.m);
@@ -388,7 +484,7 @@ __device__ __forceinline__ void block_sum_d(double& a, double* sh /* [4] */) {
 
 template <int D>
 __global__ __launch_bounds__(256) void k_reduce_filter_ad(ModelView mv, int L0, int64_t n0, double* __restrict__ E0) {
-    using IO = WaveIO<true, true, false, false>;
+    using IO = WaveIO<true, true, false, false, (D <= kPrefetchMaxD)>;
     const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
     IO io{mv.y, mv.R, nullptr, nullptr, mv.sR != 0, IO::wave_base(), (int)(threadIdx.x & 63)};
     ad::chunk_reduce_filter<D, true>(mv, c, L0, io, [=](int k, Dual v) {
@@ -401,7 +497,7 @@ __global__ __launch_bounds__(256) void k_reduce_filter_ad(ModelView mv, int L0, 
 template <int D>
 __global__ __launch_bounds__(256) void k_apply_filter_ad(ModelView mv, int L0, int64_t n0, const double* __restrict__ S0,
                                                          double* __restrict__ partial) {
-    using IO = WaveIO<true, true, false, false>;
+    using IO = WaveIO<true, true, false, false, (D <= kPrefetchMaxD)>;
     __shared__ double sh[12];
     __shared__ double sh2[4];
     const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -434,9 +530,10 @@ template <int D, bool LTI, bool RSTREAM>
 __global__ __launch_bounds__(256) void k_smooth(ModelView mv, int L0, int64_t n0, const double* __restrict__ S0, const double* __restrict__ S0r,
                                                 const double* __restrict__ fs, const double* __restrict__ Rnew, int64_t sRn,
                                                 double* __restrict__ mean_out, double* __restrict__ var_out, int* __restrict__ bad) {
-    using IO = WaveIO<false, RSTREAM, true, true>;
+    using IO = WaveIO<false, RSTREAM, true, true, (D <= kPrefetchMaxD)>;
     const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
     IO io{nullptr, Rnew, mean_out, var_out, sRn != 0, IO::wave_base(), (int)(threadIdx.x & 63)};
+    io.step = -IO::G;
     State<D> xs, carry;
     if (c < n0) {
         const int64_t q = n0 - 1 - c;
@@ -456,7 +553,7 @@ template <int D, bool LTI, bool RAND>
 __global__ __launch_bounds__(256) void k_apply_affine(ModelView mv, int L0, int64_t n0, const double* __restrict__ S0, const double* __restrict__ eps_t,
                                                       const double* __restrict__ eps_e, double* __restrict__ mean_out, double* __restrict__ var_out,
                                                       int* __restrict__ bad) {
-    using IO = WaveIO<RAND, true, true, !RAND>;
+    using IO = WaveIO<RAND, true, true, !RAND, (D <= kPrefetchMaxD)>;
     const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
     IO io{eps_e, mv.R, mean_out, var_out, io_stages_R<LTI>(mv), IO::wave_base(), (int)(threadIdx.x & 63)};
     State<D> x;
@@ -476,9 +573,11 @@ constexpr int kScanE = 1;   // elements per lane in the block scans
 
 struct KernelTable {
     int d;
-    void (*reduce_filter)(bool lti, const ModelView&, int L0, int64_t n0, double* E0, hipStream_t);
-    void (*apply_filter)(bool lti, int mode, const ModelView&, int L0, int64_t n0, const double* S0, const FilterOut&, double* R0,
-                         double* partial, hipStream_t);
+    // E1 != NULL: also reduce each block's 256 elements to E1[block] (fused level-0 scan reduce)
+    void (*reduce_filter)(bool lti, const ModelView&, int L0, int64_t n0, double* E0, double* E1, int64_t n1, hipStream_t);
+    // E0 != NULL: carry-in states come from an in-block scan of E0 against the level-1 states S1 (fused level-0 scan apply)
+    void (*apply_filter)(bool lti, int mode, const ModelView&, int L0, int64_t n0, double* S0, const double* E0, const double* S1,
+                         int64_t n1, const FilterOut&, double* R0, double* partial, hipStream_t);
     void (*smooth)(bool lti, const ModelView&, int L0, int64_t n0, const double* S0, const double* S0r, const double* fs,
                    const double* Rnew, int64_t sRn, double* mean_out, double* var_out, int* bad, hipStream_t);
     void (*reduce_affine)(bool lti, bool rnd, const ModelView&, int L0, int64_t n0, const double* eps_t, double* E0, int* bad, hipStream_t);

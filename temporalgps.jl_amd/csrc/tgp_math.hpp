@@ -14,6 +14,12 @@
 #include <math.h>
 #include <stdint.h>
 
+// Compiler-level barrier for memory operations: loads issued before it are not sunk past it (software prefetch).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TGP_ISSUE_BARRIER() asm volatile("" ::: "memory")
+#else
+#define TGP_ISSUE_BARRIER() ((void)0)
+#endif
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define TGP_HD __host__ __device__ __forceinline__
