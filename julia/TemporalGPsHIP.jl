@@ -173,4 +173,39 @@ function posterior_marginals(m::DeviceLGSSM{Forward}, y::AbstractVector, Σs_new
     return mean, var
 end
 
+"""`logpdf` and its derivative along `P` tangent directions of the packed model blocks (tgp_logpdf_grad; Forward models
+whose blocks are all shared -- RegularSpacing, homoscedastic noise). `tangents.dA` is `d*d x P` etc.; a Mooncake /
+ChainRules rule for `logpdf(::DeviceLGSSM, y)` contracts the returned vector with the parameter -> block Jacobian."""
+function logpdf_and_directional_derivatives(m::DeviceLGSSM{Forward}, y::AbstractVector, tangents::NamedTuple)
+    yv, mp, mask = _split_missing(y)
+    P = size(tangents.dA, 2)
+    lml, grad = Ref{Float64}(0.0), Vector{Float64}(undef, P)
+    t = map(x -> collect(Float64, vec(x)), tangents)
+    GC.@preserve yv mask t check(m.h, ccall((:tgp_logpdf_grad, libtgp), Cint,
+        (Ptr{Cvoid}, Ptr{Float64}, Ptr{UInt8}, UInt32, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+         Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ref{Float64}, Ptr{Float64}),
+        m.h.ptr, yv, mp, UInt32(0), P, t.dA, t.da, t.dQ, t.dH, t.dh, t.dR, t.dx0m, t.dx0P, lml, grad))
+    return lml[], grad
+end
+
+"""Irregularly spaced inputs without host-side matrix exponentials (tgp_model_set_sde): the device evaluates
+A_k = exp(F dt_k), Q_k = P_inf - A_k P_inf A_k' (lti_sde.jl:135-146) from F, P_inf and the time stamps.
+`A1`, `Q1` override the first transition (the reference fixes dt_1 := 1 per kernel component, lti_sde.jl:139)."""
+function DeviceLGSSM_sde(F, a, H, hh, Σs, times::AbstractVector{<:Real}, A1, Q1, x0::Gaussian, device::Int)
+    T, d = length(times), length(a)
+    (R, sR) = _flat(Σs)
+    flags = SHARED_a | SHARED_H | SHARED_h | (sR ? SHARED_R : UInt32(0))
+    h = Handle(device)
+    Fv, av, Hv, hv = collect(Float64, vec(F)), collect(Float64, a), collect(Float64, H), [Float64(hh)]
+    tv, A1v, Q1v = collect(Float64, times), collect(Float64, vec(A1)), collect(Float64, vec(Q1))
+    x0m, x0P = collect(Float64, x0.m), collect(Float64, vec(Array(x0.P)))
+    GC.@preserve Fv av Hv hv R tv A1v Q1v x0m x0P begin
+        check(h, ccall((:tgp_model_set_sde, libtgp), Cint,
+            (Ptr{Cvoid}, Int64, Cint, Cint, UInt32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+             Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+            h.ptr, T, d, 0, flags, Fv, av, Hv, hv, R, tv, A1v, Q1v, x0m, x0P))
+    end
+    return DeviceLGSSM(Forward(), h, T, d, (; F = Fv, a = av, H = Hv, hh = hv, R, times = tv), flags, x0)
+end
+
 end # module

@@ -7,7 +7,11 @@ import temporalgps_jl_amd as tgp
 from temporalgps_jl_amd import lti_sde, _lib
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
 model = lti_sde.build_lgssm(lti_sde.Matern52Kernel(), lti_sde.RegularSpacing(0.0, 0.1, T), 0.1)
-y = torch.randn(T, dtype=torch.float64, device="cuda:0")
+if len(sys.argv) > 2 and sys.argv[2] == "randn":
+    y = torch.randn(T, dtype=torch.float64, device="cuda:0")
+else:
+    y = tgp.rand((torch.randn((T, 3), dtype=torch.float64, device="cuda:0"), torch.randn(T, dtype=torch.float64, device="cuda:0"),
+                  np.random.default_rng(0).standard_normal(3)), model)
 Rn = torch.full((1,), 1e-18, dtype=torch.float64, device="cuda:0")
 hd = model.handle()
 def run(n=10):
