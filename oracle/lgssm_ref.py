@@ -23,7 +23,8 @@ analytically marginalised (test/models/missings.jl:94-115), Scalar == Small with
 Conventions: a model is a dict
     ordering : 'F' | 'R'                  (Forward / Reverse, gauss_markov_model.jl:1-9)
     A (T|1,d,d)  a (T|1,d)  Q (T|1,d,d)   transitions; leading dim 1 == FillArrays.Fill (shared)
-    kind : 'scalar' | 'small'             ScalarOutputLGC / SmallOutputLGC emissions
+    kind : 'scalar' | 'small' | 'large' | 'bottleneck'   Scalar/Small/LargeOutputLGC emissions (H, h, R) / BottleneckLGC
+                                           (Hb, hb = the projection; H, h, R = its fan-out LargeOutputLGC)
     H (T|1,d) [scalar]  or (T|1,p,d)      emission "A" (for scalar: the vector h with A = h')
     h (T|1,)  [scalar]  or (T|1,p)        emission "a"
     R (T|1,)  [scalar]  or (T|1,p,p)      emission "Q"
@@ -79,6 +80,9 @@ def predict_emission(model, m, P, t):
     if model["kind"] == "scalar":
         # A = H' is 1xd; result is a scalar Gaussian.
         return float(H @ m + h), float((H @ symmetric(P)) @ H + R)
+    if model["kind"] == "bottleneck":                           # lgc.jl:314
+        zm, zP = bottleneck_project(m, P, _at(model["Hb"], t), _at(model["hb"], t))
+        return predict(zm, zP, H, h, R)
     return predict(m, P, H, h, R)
 
 
@@ -103,10 +107,61 @@ def posterior_and_lml_small(m, P, H, h, R, y):
     return m + B.T @ alpha, P - B.T @ B, float(lml)
 
 
+def posterior_and_lml_large(m, P, A, a, Q, y):
+    """lgc.jl:179-204 (LargeOutputLGC): the same conditional as SmallOutputLGC computed through Cholesky factors of Q and
+    of P + 1e-10 I (that jitter makes it equal to the Small form only to the reference's own `isapprox` tolerance,
+    test/models/linear_gaussian_conditionals.jl:65-75)."""
+    d = len(m)
+    Qu = chol_upper(symmetric(Q))
+    Pu = chol_upper(symmetric(P + 1e-10 * np.eye(d)))
+    Bt = np.linalg.solve(Qu.T, A) @ Pu.T                      # Q.U' \ A * P.U'
+    Fu = chol_upper(symmetric(Bt.T @ Bt + np.eye(d)))
+    G = np.linalg.solve(Fu.T, Pu)
+    P_post = G.T @ G
+    delta = np.linalg.solve(Qu.T, y - (A @ m + a))
+    beta = np.linalg.solve(Fu.T, Bt.T @ delta)
+    m_post = m + G.T @ beta
+    c = len(y) * LOG2PI
+    logdetF = 2.0 * np.sum(np.log(np.diag(Fu)))
+    logdetQ = 2.0 * np.sum(np.log(np.diag(Qu)))
+    lml = -(delta @ delta - beta @ beta + c + logdetF + logdetQ) / 2.0     # lgc.jl:207
+    return m_post, P_post, float(lml)
+
+
+def bottleneck_project(m, P, Hb, hb):
+    """lgc.jl:308-312: Gaussian(H m + h, H P H' + 1e-12 I)."""
+    return Hb @ m + hb, Hb @ P @ Hb.T + 1e-12 * np.eye(Hb.shape[0])
+
+
+def posterior_and_lml_bottleneck(m, P, Hb, hb, A, a, Q, y):
+    """lgc.jl:320-336 (BottleneckLGC): posterior over z = Hb x + hb through the fan-out LargeOutputLGC, then
+    x | y by integrating x | z against z | y."""
+    zm, zP = bottleneck_project(m, P, Hb, hb)
+    zpm, zpP, lml = posterior_and_lml_large(zm, zP, A, a, Q, y)
+    U = chol_upper(symmetric(zP + 1e-12 * np.eye(len(zm))))
+    Gt = np.linalg.solve(U, np.linalg.solve(U.T, Hb @ P))
+    return m + Gt.T @ (zpm - zm), P + Gt.T @ (zpP - zP) @ Gt, lml
+
+
+def small_from_bottleneck(model):
+    """test/test_util.jl `small_output_lgc_from_bottleneck`: y | x ~ N(A (Hb x + hb) + a, Q) as one SmallOutputLGC."""
+    T = model["T"]
+    n = max(model[k].shape[0] for k in ("Hb", "hb", "H", "h"))
+    H = np.stack([_at(model["H"], t) @ _at(model["Hb"], t) for t in range(n)])
+    h = np.stack([_at(model["H"], t) @ _at(model["hb"], t) + _at(model["h"], t) for t in range(n)])
+    out = {k: v for k, v in model.items() if k not in ("Hb", "hb")}
+    out.update(kind="small", H=H, h=h)
+    return out
+
+
 def posterior_and_lml(model, m, P, t, y):
     H, h, R = emission(model, t)
     if model["kind"] == "scalar":
         return posterior_and_lml_scalar(m, P, H, h, R, y)
+    if model["kind"] == "large":
+        return posterior_and_lml_large(m, P, H, h, R, y)
+    if model["kind"] == "bottleneck":
+        return posterior_and_lml_bottleneck(m, P, _at(model["Hb"], t), _at(model["hb"], t), H, h, R, y)
     return posterior_and_lml_small(m, P, H, h, R, y)
 
 
@@ -237,6 +292,8 @@ def conditional_rand_emission(model, eps, t, x):
     H, h, R = emission(model, t)
     if model["kind"] == "scalar":
         return float((H @ x + h) + np.sqrt(R) * eps)          # lgc.jl:241-243
+    if model["kind"] == "bottleneck":                            # lgc.jl:297-300
+        x = _at(model["Hb"], t) @ x + _at(model["hb"], t)
     return conditional_rand_transition(eps, H, h, R, x)         # lgc.jl:84-87 (p-dim)
 
 
@@ -297,7 +354,7 @@ def transform_model_and_obs(model, ys, missing):
                 ys[t] = 0.0
         n_missing = int(missing.sum()) * (1 if model["kind"] == "scalar" else R.shape[-1])
     else:
-        if model["kind"] != "small":
+        if model["kind"] == "scalar":
             raise TypeError("per-element missing needs vector observations")
         for t, j in zip(*np.nonzero(missing)):
             off = R[t] - np.diag(np.diag(R[t]))

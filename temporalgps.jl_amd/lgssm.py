@@ -114,6 +114,30 @@ class SmallOutputLGC:
         return self.R.ndim == 3
 
 
+class LargeOutputLGC(SmallOutputLGC):
+    """lgc.jl:146-217: the same conditional y | x ~ N(A x + a, Q) as SmallOutputLGC, which the reference evaluates through
+    Cholesky factors of Q and P because dim_out > dim_in. On the device both are the same p scalar updates per time step
+    (cost O(p d^2), no p x p factorisation at all), so this is SmallOutputLGC under the reference's name. The reference's
+    Large form adds a 1e-10 jitter to P inside the update: results agree with it to the tolerance of its own
+    consistency test (test/models/linear_gaussian_conditionals.jl:65-75)."""
+
+    def __init__(self, A, a, Q):
+        super().__init__(A, a, Q)
+
+
+class BottleneckLGC(SmallOutputLGC):
+    """lgc.jl:262-336: y | x ~ N(f.A (H x + h) + f.a, f.Q) with `fan_out` a LargeOutputLGC. The reference exploits the
+    low-dimensional projection on the CPU; for the device the composition is folded into one vector-output emission
+    (H <- f.A H, h <- f.A h + f.a, test/test_util.jl small_output_lgc_from_bottleneck), O(T p dz d) host work once.
+    Agreement with the reference's own projected update: rtol 1e-6, its own test tolerance (:156-167)."""
+
+    def __init__(self, H, h, fan_out):
+        self.Hb, self.hb, self.fan_out = H, h, fan_out
+        A, a = np.asarray(_to_numpy(fan_out.H), dtype=np.float64), np.asarray(_to_numpy(fan_out.h), dtype=np.float64)
+        Hb, hb = np.asarray(_to_numpy(H), dtype=np.float64), np.asarray(_to_numpy(h), dtype=np.float64)
+        super().__init__(np.matmul(A, Hb), np.einsum("...ij,...j->...i", A, hb) + a, fan_out.R)
+
+
 class LGSSM:
     """lgssm.jl:9-12. `T` must be given when every array is a Fill."""
 
