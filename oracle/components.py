@@ -332,3 +332,96 @@ def build_lgssm_separable(k_space, k_time, r, t, sigma2):
     R = (s * ident)[None] if s.ndim == 0 else np.stack([np.diag(v) for v in s.reshape(T, Nr)])
     return dict(ordering="F", kind="small", T=T, A=A, a=a, Q=Q, H=H, h=h, R=R,
                 x0m=np.tile(m_t, Nr), x0P=np.kron(Kr, P_t))
+
+
+# ------------------------------------------------------------------ pseudo-point approximation (space_time/pseudo_point.jl)
+def _blkdiag(blocks):
+    n, m = sum(b.shape[0] for b in blocks), sum(b.shape[1] for b in blocks)
+    out = np.zeros((n, m))
+    i = j = 0
+    for b in blocks:
+        out[i:i + b.shape[0], j:j + b.shape[1]] = b
+        i, j = i + b.shape[0], j + b.shape[1]
+    return out
+
+
+def dtc_components(terms, z, r, t, jitter=1e-12):
+    """Literal restatement of lgssm_components(::DTCSeparable, ::RectilinearGrid) (pseudo_point.jl:107-144) for
+    k = sum_i s_i * Separable(k_space_i, k_time_i) with `terms` = [(s_i, k_space_i, k_time_i)]: the ScaledKernel
+    rule scales H_t (lti_sde.jl:344-346), the KernelSum rule stacks the components (lti_sde.jl:404-436).
+    Returns A, a, Q (n, D, D), the projection (Hb (n, Mtot, D), hb), the fan-out matrix C' (N, Mtot) and x0."""
+    from . import dense_gp as dg
+    z, r = np.asarray(z, dtype=np.float64), np.asarray(r, dtype=np.float64)
+    M = len(z)
+    ident = np.eye(M)
+    parts = []
+    for s, k_space, k_time in terms:
+        A_t, a_t, Q_t, H_t, h_t, (m_t, P_t) = lgssm_components(k_time, t)
+        Kz = dg.kernelmatrix(k_space, z)
+        Kzx = dg.kernelmatrix(k_space, z, r)
+        C = np.linalg.solve(Kz + jitter * ident, Kzx)                       # cholesky(K_z + 1e-12 I) \ K_zx   (M, N)
+        sig = np.sqrt(s)
+        parts.append(dict(
+            A=np.stack([np.kron(ident, Ai) for Ai in A_t]), a=np.stack([np.tile(ai, M) for ai in a_t]),
+            Q=np.stack([np.kron(Kz, Qi) for Qi in Q_t]),
+            Hb=np.stack([sig * np.kron(ident, Hi[None, :]) for Hi in H_t]),  # adjoint of kron(I_M, H_t)  (M, M d_t)
+            C=C, m=np.tile(m_t, M), P=np.kron(Kz, P_t)))
+    n = max(p["A"].shape[0] for p in parts)
+    ex = lambda arr: arr if arr.shape[0] == n else np.repeat(arr, n, axis=0)
+    A = np.stack([_blkdiag([ex(p["A"])[i] for p in parts]) for i in range(n)])
+    a = np.stack([np.concatenate([ex(p["a"])[i] for p in parts]) for i in range(n)])
+    Q = np.stack([_blkdiag([ex(p["Q"])[i] for p in parts]) for i in range(n)])
+    nh = max(p["Hb"].shape[0] for p in parts)
+    exh = lambda arr: arr if arr.shape[0] == nh else np.repeat(arr, nh, axis=0)
+    Hb = np.stack([_blkdiag([exh(p["Hb"])[i] for p in parts]) for i in range(nh)])
+    Ct = np.concatenate([p["C"] for p in parts], axis=0).T                  # map(vcat, Cs...) then adjoint: (N, Mtot)
+    x0m = np.concatenate([p["m"] for p in parts])
+    x0P = _blkdiag([p["P"] for p in parts])
+    return A, a, Q, Hb, np.zeros((1, Hb.shape[1])), Ct, x0m, x0P
+
+
+def build_lgssm_dtc(terms, z, r, t, sigma2):
+    """build_lgssm(dtcify(z, fx)) (pseudo_point.jl:33, 187-196): BottleneckLGC emissions whose fan-out is a LargeOutputLGC
+    (C', c = 0, Diagonal noise). kind == 'bottleneck' (oracle/lgssm_ref.py)."""
+    A, a, Q, Hb, hb, Ct, x0m, x0P = dtc_components(terms, z, r, t)
+    T, N = n_times(t), len(r)
+    s = np.asarray(sigma2, dtype=np.float64)
+    R = (s * np.eye(N))[None] if s.ndim == 0 else np.stack([np.diag(v) for v in s.reshape(T, N)])
+    return dict(ordering="F", kind="bottleneck", T=T, A=A, a=a, Q=Q, Hb=Hb, hb=hb, H=Ct[None], h=np.zeros((1, N)), R=R,
+                x0m=x0m, x0P=x0P)
+
+
+def dtc_kernel_diagonals(terms, r, t):
+    """kernel_diagonals (pseudo_point.jl:83-105): prior variances k((r_p, t_q), (r_p, t_q)), shape (T, N)."""
+    from . import dense_gp as dg
+    r = np.asarray(r, dtype=np.float64)
+    T = n_times(t)
+    out = np.zeros((T, len(r)))
+    for s, k_space, k_time in terms:
+        out += s * np.outer(np.full(T, float(dg.kappa(k_time, np.zeros(1))[0])), dg.kappa(k_space, np.zeros(len(r))))
+    return out
+
+
+def dtc_statespace(terms, z, r, t, sigma2, y, missing=None):
+    """dtc(fx, y, z_r) = logpdf(dtcify(z_r, fx), y) (pseudo_point.jl:52-54)."""
+    from . import lgssm_ref as ref
+    model = build_lgssm_dtc(terms, z, r, t, sigma2)
+    Y = np.asarray(y, dtype=np.float64).reshape(model["T"], len(r))
+    if missing is None:
+        return ref.logpdf(model, Y)
+    return ref.logpdf_missing(model, Y, np.asarray(missing, dtype=bool).reshape(Y.shape))
+
+
+def elbo_statespace(terms, z, r, t, sigma2, y):
+    """elbo(fx, y, z_r) (pseudo_point.jl:61-81) without missing data."""
+    from . import lgssm_ref as ref
+    model = build_lgssm_dtc(terms, z, r, t, sigma2)
+    T, N = model["T"], len(r)
+    Y = np.asarray(y, dtype=np.float64).reshape(T, N)
+    _, covs = ref.marginals(model)                                           # marginals_diag: emission marginals incl. noise
+    Cf = dtc_kernel_diagonals(terms, r, t)
+    tmp = 0.0
+    for q in range(T):
+        Sig = np.diag(ref._at(model["R"], q))
+        tmp += np.sum((Cf[q] - np.diag(covs[q])) / Sig) + N                  # sum(diag(S \ (Cf - marg.P))) - 0 + size(S, 1)
+    return ref.logpdf(model, Y) - tmp / 2.0

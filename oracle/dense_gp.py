@@ -123,3 +123,52 @@ def mvn_posterior_marginals(K, noise, y, noise_new):
     mu = K @ cho_solve(c, y)
     var = np.diag(K) - np.einsum("ij,ji->i", K, cho_solve(c, K))
     return mu, var + noise_new
+
+
+# ------------------------------------------------------------------ sparse (pseudo-point) approximations, dense form
+# AbstractGPs.jl (compat "0.5.17", not under /root/reference) sparse_approximations.jl, restated from the published
+# formulas (Titsias 2009; Quinonero-Candela & Rasmussen 2005): with u = f(z), Q_ff = K_fu K_uu^-1 K_uf,
+#   DTC  approx_log_evidence = log N(y; m, Q_ff + S)
+#   VFE  elbo                = DTC - tr(S^-1 (K_ff - Q_ff)) / 2
+#   VFE  posterior at x*     : mean K_*u B^-1 K_uf S^-1 y,  var k_** - K_*u K_uu^-1 K_u* + K_*u B^-1 K_u*,  B = K_uu + K_uf S^-1 K_fu
+# These play the role of `dtc_naive`, `elbo_naive`, `f_approx_post_naive` in test/space_time/pseudo_point.jl:92-108.
+def _sep_K(terms, x1, x2):
+    """x = (r (N,), t (N,)) flat space-time points; k = sum_i s_i k_space_i(r, r') k_time_i(t, t')."""
+    r1, t1 = x1
+    r2, t2 = x2
+    out = np.zeros((len(r1), len(r2)))
+    for s, ks, kt in terms:
+        out += s * kappa(ks, r1[:, None] - r2[None, :]) * kappa(kt, t1[:, None] - t2[None, :])
+    return out
+
+
+def grid_points(r, t):
+    """collect(RectilinearGrid(r, t)): space iterates fastest (rectilinear_grid.jl:31-33)."""
+    r, t = np.asarray(r, dtype=np.float64), np.asarray(t, dtype=np.float64)
+    return np.tile(r, len(t)), np.repeat(t, len(r))
+
+
+def dtc_dense(terms, x, z, noise, y, jitter=1e-18):
+    Kuu = _sep_K(terms, z, z) + jitter * np.eye(len(z[0]))
+    Kuf = _sep_K(terms, z, x)
+    Qff = Kuf.T @ np.linalg.solve(Kuu, Kuf)
+    return mvn_logpdf(Qff + np.diag(noise), np.asarray(y, dtype=np.float64))
+
+
+def elbo_dense(terms, x, z, noise, y, jitter=1e-18):
+    Kuu = _sep_K(terms, z, z) + jitter * np.eye(len(z[0]))
+    Kuf = _sep_K(terms, z, x)
+    Qff_diag = np.einsum("ij,ij->j", Kuf, np.linalg.solve(Kuu, Kuf))
+    kff = sum(s * kappa(ks, np.zeros(1))[0] * kappa(kt, np.zeros(1))[0] for s, ks, kt in terms)
+    return dtc_dense(terms, x, z, noise, y, jitter) - 0.5 * np.sum((kff - Qff_diag) / noise)
+
+
+def vfe_posterior_marginals(terms, x, z, noise, y, xs, jitter=1e-18):
+    Kuu = _sep_K(terms, z, z) + jitter * np.eye(len(z[0]))
+    Kuf = _sep_K(terms, z, x)
+    Ksu = _sep_K(terms, xs, z)
+    B = Kuu + (Kuf / noise) @ Kuf.T
+    mean = Ksu @ np.linalg.solve(B, Kuf @ (np.asarray(y, dtype=np.float64) / noise))
+    kss = sum(s * kappa(ks, np.zeros(1))[0] * kappa(kt, np.zeros(1))[0] for s, ks, kt in terms)
+    var = kss - np.einsum("ij,ji->i", Ksu, np.linalg.solve(Kuu, Ksu.T)) + np.einsum("ij,ji->i", Ksu, np.linalg.solve(B, Ksu.T))
+    return mean, var
