@@ -34,6 +34,7 @@ WORKLOADS = {
     "sum52_12_d4": (("sum", ("matern52",), ("matern12",)), 4, 0.1, 0.1),   # BASELINE config 4's "Matern52, d=4"
     "sum52_32_d5": (("sum", ("matern52",), ("matern32",)), 5, 0.1, 0.1),
     "sum52_52_d6": (("sum", ("matern52",), ("matern52",)), 6, 0.1, 0.1),   # BASELINE config 3's "d=6"
+    "sum52_32_32_d7": (("sum", ("matern52",), ("matern32",), ("matern32",)), 7, 0.1, 0.1),
     "sum52_52_32_d8": (("sum", ("matern52",), ("matern52",), ("matern32",)), 8, 0.1, 0.1),
 }
 

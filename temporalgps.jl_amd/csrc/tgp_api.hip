@@ -40,13 +40,14 @@ const KernelTable* kernel_table(int d) {
 }
 }  // namespace tgp
 
-// fully-inlined builds of d = 5, 6 (tgp_inst_d5i.hip, tgp_inst_d6i.hip): same struct layouts, other namespace.
-// (d = 7, 8 inlined also pass the run-time check and are ~3x faster than their out-of-line builds, but take ~20 minutes
-// of hipcc time; they are left out to keep build() at ~3 minutes.)
+// fully-inlined builds of d = 5..8 (tgp_inst_d5i.hip, tgp_inst_d6i.hip; d = 7, 8 as 13 parts each, tgp_inst_part.hip):
+// same struct layouts, other namespace.
 namespace tgp_i {
 struct KernelTable;
 const KernelTable* kernel_table_d5_i();
 const KernelTable* kernel_table_d6_i();
+const KernelTable* kernel_table_d7_i();
+const KernelTable* kernel_table_d8_i();
 }  // namespace tgp_i
 
 using namespace tgp;
@@ -54,9 +55,41 @@ using namespace tgp;
 static const KernelTable* fast_kernel_table(int d) {
     if (d == 5) return reinterpret_cast<const KernelTable*>(tgp_i::kernel_table_d5_i());
     if (d == 6) return reinterpret_cast<const KernelTable*>(tgp_i::kernel_table_d6_i());
+    if (d == 7) return reinterpret_cast<const KernelTable*>(tgp_i::kernel_table_d7_i());
+    if (d == 8) return reinterpret_cast<const KernelTable*>(tgp_i::kernel_table_d8_i());
     return nullptr;
 }
-static int g_variant[16] = {0};   // per state dimension: 0 not decided, 1 out-of-line (safe) build, 2 inlined (fast) build
+// Per (state dimension, LTI layout family?): which operations of the inlined (fast) build reproduced the out-of-line (safe)
+// build in the run-time known-answer check. Bit kOpDecided = the check has run.
+enum VariantOp { kOpM0 = 0, kOpM1, kOpM2, kOpM3, kOpAffine, kOpGrad, kOpCount, kOpDecided = 30 };
+static unsigned g_variant[17][2] = {{0u}};
+static const unsigned kAllOps = (1u << kOpCount) - 1u;
+
+// table = safe build with the entries whose operations passed replaced by the fast build's
+static void merge_tables(const KernelTable* safe, const KernelTable* fast, unsigned ok, KernelTable& out) {
+    out = *safe;
+    const bool any_fwd = (ok & ((1u << kOpM0) | (1u << kOpM1) | (1u << kOpM2) | (1u << kOpM3))) != 0;
+    if (any_fwd) {     // pass 1 and the filter-monoid scans are shared by every forward operation: validated by any that passed
+        out.reduce_filter = fast->reduce_filter;
+        out.scan_reduce_c[kScanFilter] = fast->scan_reduce_c[kScanFilter];
+        out.scan_apply_c[kScanFilter] = fast->scan_apply_c[kScanFilter];
+    }
+    for (int m = 0; m < 4; ++m)
+        if (ok & (1u << (kOpM0 + m))) out.apply_filter_m[m] = fast->apply_filter_m[m];
+    if (ok & (1u << kOpM2)) out.smooth = fast->smooth;
+    if (ok & (1u << kOpAffine)) { out.reduce_affine = fast->reduce_affine; out.apply_affine = fast->apply_affine; }
+    if (ok & ((1u << kOpAffine) | (1u << kOpM2))) {
+        out.scan_reduce_c[kScanAffine] = fast->scan_reduce_c[kScanAffine];
+        out.scan_apply_c[kScanAffine] = fast->scan_apply_c[kScanAffine];
+    }
+    if (ok & (1u << kOpGrad)) {
+        out.reduce_filter_ad = fast->reduce_filter_ad;
+        out.apply_filter_ad = fast->apply_filter_ad;
+        out.scan_reduce_c[kScanAD] = fast->scan_reduce_c[kScanAD];
+        out.scan_apply_c[kScanAD] = fast->scan_apply_c[kScanAD];
+    }
+}
+static void select_table(tgp_handle* h, int d, bool lti, int variant);
 
 // result[0] = sum lml + nmiss * log(2 pi 1e15)/2 (missings.jl:45-53); result[1] = nmiss; result[2] = bad.
 // Fixed-order summation: the result is bit-reproducible from run to run.
@@ -181,7 +214,8 @@ struct tgp_handle {
     bool have_AQ1 = false;
     const double* times_dev = nullptr;
     double normF = 0.0;
-    const KernelTable* kt = nullptr;
+    const KernelTable* kt = nullptr;   // -> ktm when the inlined and out-of-line builds are mixed entry by entry
+    KernelTable ktm{};
     DevBuf bA, ba, bQ, bH, bh, bR;
     std::vector<double> x0m, x0P;
     DevBuf bx0, bx0r, bx0fold;
@@ -350,11 +384,14 @@ void choose_chunk(tgp_handle* h) {
     int64_t L0 = h->opt_chunk;
     if (L0 <= 0) {
         // One lane per chunk, 256-lane workgroups, 256 CUs: kernel time goes with ceil(workgroups / 256), so
-        // size the chunk to land just under k full rounds of 256 workgroups (measured at T = 1e7, d = 3:
-        // L0 = 80 (k = 2) 1.12 ms/step; 96: 1.14; 128: 1.38; 160 (k = 1): 1.19; 39 (k = 4): 1.24).
+        // size the chunk to land just under k full rounds of 256 workgroups. Measured at T = 1e7 (ms per bench step,
+        // k = 1 (L0 = 153) against k = 2 (L0 = 77)):  d = 2: 0.78 / 0.66;  d = 3: 1.07 / 1.10;  d = 4: 1.71 / 2.05;
+        // d = 5: 3.02 / 3.78;  d = 6: 6.9 / 9.7;  d = 8: 150 / 180.  From d = 4 on the kernels spill: one wave per
+        // SIMD keeps the scratch working set cache-resident, and the block scans see half the elements.
         const int64_t round = 256LL * 256, Tm0 = h->T * h->p;
+        const int64_t kmin = h->d <= 2 ? 2 : 1;
         int64_t k = (Tm0 + round * 160 - 1) / (round * 160);
-        if (k < 2) k = 2;
+        if (k < kmin) k = kmin;
         L0 = (Tm0 + round * k - 1) / (round * k);
         if (L0 < 8) L0 = 8;
     }
@@ -571,61 +608,6 @@ int forward_apply(tgp_handle* h, int mode, const FilterOut& fo, const double* x0
 
 int* flag_ptr(tgp_handle* h) { return reinterpret_cast<int*>(h->result.d() + 4); }
 
-template <int D> int host_apply(int kind, const double* elem, const double* m, const double* P, double* mo, double* Po) {
-    State<D> in, out;
-    for (int i = 0; i < D; ++i) in.m[i] = m[i];
-    for (int i = 0; i < D * D; ++i) in.P[i] = P[i];
-    if (kind == 0) {
-        FElem<D> e;
-        load_felem<D>(e, [&](int k) { return elem[k]; });
-        f_apply<D>(e, in, out);
-    } else {
-        AElem<D> e;
-        load_aelem<D>(e, [&](int k) { return elem[k]; });
-        a_apply<D, true>(e, in, out);
-    }
-    for (int i = 0; i < D; ++i) mo[i] = out.m[i];
-    for (int i = 0; i < D * D; ++i) Po[i] = out.P[i];
-    return TGP_OK;
-}
-template <int D> int host_combine(int kind, const double* ei, const double* ej, double* out) {
-    if (kind == 0) {
-        FElem<D> a, b, o;
-        load_felem<D>(a, [&](int k) { return ei[k]; });
-        load_felem<D>(b, [&](int k) { return ej[k]; });
-        f_combine<D>(a, b, o);
-        store_felem<D>(o, [&](int k, double v) { out[k] = v; });
-    } else {
-        AElem<D> a, b, o;
-        load_aelem<D>(a, [&](int k) { return ei[k]; });
-        load_aelem<D>(b, [&](int k) { return ej[k]; });
-        a_combine<D, true>(a, b, o);
-        store_aelem<D>(o, [&](int k, double v) { out[k] = v; });
-    }
-    return TGP_OK;
-}
-
-#define DISPATCH_D(d, fn, ...)              \
-    switch (d) {                            \
-        case 1: return fn<1>(__VA_ARGS__);  \
-        case 2: return fn<2>(__VA_ARGS__);  \
-        case 3: return fn<3>(__VA_ARGS__);  \
-        case 4: return fn<4>(__VA_ARGS__);  \
-        case 5: return fn<5>(__VA_ARGS__);  \
-        case 6: return fn<6>(__VA_ARGS__);  \
-        case 7: return fn<7>(__VA_ARGS__);  \
-        case 8: return fn<8>(__VA_ARGS__);  \
-        case 9: return fn<9>(__VA_ARGS__);  \
-        case 10: return fn<10>(__VA_ARGS__); \
-        case 11: return fn<11>(__VA_ARGS__); \
-        case 12: return fn<12>(__VA_ARGS__); \
-        case 13: return fn<13>(__VA_ARGS__); \
-        case 14: return fn<14>(__VA_ARGS__); \
-        case 15: return fn<15>(__VA_ARGS__); \
-        case 16: return fn<16>(__VA_ARGS__); \
-        default: return TGP_EUNSUPPORTED;   \
-    }
-
 }  // namespace
 
 // ------------------------------------------------------------------------------------------ run-time variant check
@@ -633,7 +615,7 @@ template <int D> int host_combine(int kind, const double* ei, const double* ej, 
 // inlined (fast, but the spill-heavy form hipcc has miscompiled for us). The first model of such a d on a process runs a
 // known-answer comparison of the two builds over every entry point and both layouts; the fast build is used only if it
 // reproduces the safe one to 1e-9.
-static bool variant_selftest(int device, int d);
+static unsigned variant_selftest(int device, int d, bool lti);
 
 // =========================================================================================== C ABI
 extern "C" {
@@ -706,9 +688,7 @@ int tgp_set_option(tgp_handle* h, int option, int64_t value) {
         if (value < 0 || value > 2) return h->fail(TGP_EINVAL, "TGP_OPT_VARIANT must be 0, 1 or 2");
         h->variant_opt = (int)value;
         if (h->have_model) {
-            const KernelTable* fast = fast_kernel_table(h->d);
-            const int v = value == 0 ? g_variant[h->d] : (int)value;
-            h->kt = (v == 2 && fast) ? fast : kernel_table(h->d);
+            select_table(h, h->d, h->lti, (int)value);
             h->reduce_valid = false;
             h->smoother_valid = false;
         }
@@ -725,7 +705,8 @@ int tgp_set_option(tgp_handle* h, int option, int64_t value) {
 
 int tgp_kernel_variant(const tgp_handle* h) {
     if (!h || !h->have_model) return 0;
-    return (fast_kernel_table(h->d) != nullptr && h->kt == fast_kernel_table(h->d)) ? 2 : 1;
+    if (fast_kernel_table(h->d) != nullptr && h->kt == fast_kernel_table(h->d)) return 2;
+    return h->kt == &h->ktm ? 3 : 1;
 }
 
 int tgp_set_stream(tgp_handle* h, void* hip_stream) {
@@ -749,13 +730,10 @@ int tgp_model_set(tgp_handle* h, int64_t T, int d, int p, int ordering, uint32_t
     if (ordering != 0 && ordering != 1) return h->fail(TGP_EINVAL, "ordering must be 0 (Forward) or 1 (Reverse)");
     const KernelTable* kt = kernel_table(d);
     if (!kt) return h->fail(TGP_EUNSUPPORTED, "state dimension d must be in 1..16 for the per-lane scan path");
-    if (const KernelTable* fast = fast_kernel_table(d)) {
-        int v = h->variant_opt;
-        if (v == 0) {
-            if (g_variant[d] == 0) g_variant[d] = variant_selftest(h->device, d) ? 2 : 1;
-            v = g_variant[d];
-        }
-        if (v == 2) kt = fast;
+    {
+        const uint32_t lb = TGP_SHARED_A | TGP_SHARED_a | TGP_SHARED_Q | TGP_SHARED_H | TGP_SHARED_h;
+        select_table(h, d, (flags & lb) == lb, h->variant_opt);
+        kt = h->kt;
     }
     if (!A || !a || !Q || !H || !hh || !R || !x0m || !x0P) return h->fail(TGP_EINVAL, "null model array");
     h->kt = kt;
@@ -1166,7 +1144,7 @@ int tgp_logpdf_grad(tgp_handle* h, const double* y, const uint8_t* missing, uint
 
 }  // extern "C"
 
-static bool variant_selftest(int device, int d) {
+static unsigned variant_selftest(int device, int d, bool lti_layout) {
     const int64_t T = 3000;
     uint64_t st = 0x9E3779B97F4A7C15ull ^ (uint64_t)d;
     auto rnd = [&]() {   // uniform in (-1, 1)
@@ -1192,55 +1170,91 @@ static bool variant_selftest(int device, int d) {
     for (int i = 0; i < d; ++i) { x0m[i] = rnd(); x0P[i + i * d] = 1.0 + 0.3 * rnd(); e0[i] = rnd(); }
     std::vector<uint8_t> miss(T, 0);
     for (int64_t t = 0; t < T; t += 17) miss[t] = 1;
-    auto run = [&](int variant, bool lti, std::vector<double>& out) -> int {
+    // every operation on its own: (return code, outputs) per VariantOp
+    struct OpOut { int rc = TGP_OK; std::vector<double> v; };
+    auto run = [&](int variant, bool lti, OpOut* o) -> int {
         tgp_handle* h = nullptr;
         if (tgp_create(&h, device) != TGP_OK) return TGP_EHIP;
         h->variant_opt = variant;
         tgp_set_option(h, TGP_OPT_CHUNK, 4);
         int rc = tgp_model_set(h, T, d, 1, 0, lti ? TGP_SHARED_ALL : 0u, A.data(), a.data(), Q.data(), H.data(), hh.data(), R.data(), x0m.data(),
                                x0P.data());
-        out.assign(1, 0.0);
+        if (rc != TGP_OK) { tgp_destroy(h); return rc; }
         std::vector<double> b1(T * dd), b2(T * dd), b3(T * dd), xm(d), xP(dd);
-        auto push = [&](const std::vector<double>& v, size_t n) { out.insert(out.end(), v.begin(), v.begin() + n); };
-        if (rc == TGP_OK) rc = tgp_logpdf(h, y.data(), miss.data(), 0, &out[0]);
-        if (rc == TGP_OK) { rc = tgp_filter(h, y.data(), nullptr, 0, b1.data(), b2.data(), nullptr); push(b1, T * d); push(b2, T * dd); }
-        if (rc == TGP_OK) { rc = tgp_posterior(h, y.data(), nullptr, 0, b1.data(), b2.data(), b3.data(), xm.data(), xP.data()); push(b1, T * dd); push(b2, T * d); push(b3, T * dd); push(xm, d); push(xP, dd); }
-        if (rc == TGP_OK) { rc = tgp_posterior_marginals(h, y.data(), miss.data(), Rn.data(), 0, b1.data(), b2.data(), nullptr); push(b1, T); push(b2, T); }
-        // the shared-R_new smoother kernel (k_smooth<.., RSTREAM = false>) and a chunk size with a ragged last group
-        if (rc == TGP_OK) { rc = tgp_posterior_marginals(h, y.data(), miss.data(), Rn.data(), TGP_SHARED_R, b1.data(), b2.data(), nullptr); push(b1, T); push(b2, T); }
-        if (rc == TGP_OK) {
+        auto push = [&](OpOut& q, const std::vector<double>& v, size_t n) { q.v.insert(q.v.end(), v.begin(), v.begin() + n); };
+        double lp = 0.0;
+        {   // M0: logpdf, with missing data; also at a chunk size with a ragged last IO group
+            OpOut& q = o[kOpM0];
+            q.rc = tgp_logpdf(h, y.data(), miss.data(), 0, &lp); q.v.push_back(lp);
             tgp_set_option(h, TGP_OPT_CHUNK, 11);
-            rc = tgp_posterior_marginals(h, y.data(), nullptr, Rn.data(), TGP_SHARED_R, b1.data(), b2.data(), nullptr);
-            push(b1, T); push(b2, T);
-            if (rc == TGP_OK) rc = tgp_logpdf(h, y.data(), miss.data(), 0, &out[0]);
+            if (q.rc == TGP_OK) { q.rc = tgp_logpdf(h, y.data(), nullptr, 0, &lp); q.v.push_back(lp); }
             tgp_set_option(h, TGP_OPT_CHUNK, 4);
         }
-        if (rc == TGP_OK) { rc = tgp_marginals(h, 0, b1.data(), b2.data()); push(b1, T); push(b2, T); }
-        if (rc == TGP_OK) { rc = tgp_rand(h, et.data(), ee.data(), e0.data(), 0, b1.data()); push(b1, T); }
-        if (rc == TGP_OK && lti) {
+        { OpOut& q = o[kOpM1]; q.rc = tgp_filter(h, y.data(), nullptr, 0, b1.data(), b2.data(), &lp); push(q, b1, T * d); push(q, b2, T * dd); q.v.push_back(lp); }
+        {
+            OpOut& q = o[kOpM3];
+            q.rc = tgp_posterior(h, y.data(), nullptr, 0, b1.data(), b2.data(), b3.data(), xm.data(), xP.data());
+            push(q, b1, T * dd); push(q, b2, T * d); push(q, b3, T * dd); push(q, xm, d); push(q, xP, dd);
+        }
+        {   // M2 + smoother: per-step R_new, shared R_new (k_smooth<.., RSTREAM = false>), ragged chunk size
+            OpOut& q = o[kOpM2];
+            q.rc = tgp_posterior_marginals(h, y.data(), miss.data(), Rn.data(), 0, b1.data(), b2.data(), &lp); push(q, b1, T); push(q, b2, T); q.v.push_back(lp);
+            if (q.rc == TGP_OK) { q.rc = tgp_posterior_marginals(h, y.data(), miss.data(), Rn.data(), TGP_SHARED_R, b1.data(), b2.data(), nullptr); push(q, b1, T); push(q, b2, T); }
+            tgp_set_option(h, TGP_OPT_CHUNK, 11);
+            if (q.rc == TGP_OK) { q.rc = tgp_posterior_marginals(h, y.data(), nullptr, Rn.data(), TGP_SHARED_R, b1.data(), b2.data(), nullptr); push(q, b1, T); push(q, b2, T); }
+            tgp_set_option(h, TGP_OPT_CHUNK, 4);
+        }
+        {
+            OpOut& q = o[kOpAffine];
+            q.rc = tgp_marginals(h, 0, b1.data(), b2.data()); push(q, b1, T); push(q, b2, T);
+            if (q.rc == TGP_OK) { q.rc = tgp_rand(h, et.data(), ee.data(), e0.data(), 0, b1.data()); push(q, b1, T); }
+        }
+        if (lti) {
+            OpOut& q = o[kOpGrad];
             std::vector<double> dA(dd), da(d), dQ(dd), dH(d), dm(d), dP(dd, 0.0);
             for (auto& v : dA) v = 0.1 * rnd();
             for (auto& v : dQ) v = 0.0;
             for (int i = 0; i < d; ++i) { da[i] = 0.1; dH[i] = 0.2; dm[i] = 0.1; dQ[i + i * d] = 0.05; dP[i + i * d] = 0.1; }
             double dh = 0.1, dR = 1.0, lml = 0.0, g = 0.0;
-            rc = tgp_logpdf_grad(h, y.data(), nullptr, 0, 1, dA.data(), da.data(), dQ.data(), dH.data(), &dh, &dR, dm.data(), dP.data(), &lml, &g);
-            out.push_back(lml); out.push_back(g);
+            q.rc = tgp_logpdf_grad(h, y.data(), nullptr, 0, 1, dA.data(), da.data(), dQ.data(), dH.data(), &dh, &dR, dm.data(), dP.data(), &lml, &g);
+            q.v.push_back(lml); q.v.push_back(g);
         }
         tgp_destroy(h);
-        return rc;
+        return TGP_OK;
     };
-    for (int lti = 0; lti < 2; ++lti) {
-        uint64_t keep = st;
-        std::vector<double> ra, rb;
-        st = keep; const int rca = run(1, lti != 0, ra);
-        st = keep; const int rcb = run(2, lti != 0, rb);
-        if (rca != TGP_OK || rcb != TGP_OK || ra.size() != rb.size()) return false;
-        for (size_t i = 0; i < ra.size(); ++i) {
-            const double tol = 1e-9 * (1.0 + std::fabs(ra[i]));
-            if (!(std::fabs(ra[i] - rb[i]) <= tol)) return false;
+    OpOut ra[kOpCount], rb[kOpCount];
+    const uint64_t keep = st;
+    st = keep; const int rca = run(1, lti_layout, ra);
+    st = keep; const int rcb = run(2, lti_layout, rb);
+    unsigned ok = 0u;
+    if (rca != TGP_OK || rcb != TGP_OK) return ok;
+    for (int op = 0; op < kOpCount; ++op) {
+        if (op == kOpGrad && !lti_layout) continue;
+        bool pass = ra[op].rc == TGP_OK && rb[op].rc == TGP_OK && ra[op].v.size() == rb[op].v.size();
+        for (size_t i = 0; pass && i < ra[op].v.size(); ++i) {
+            const double tol = 1e-9 * (1.0 + std::fabs(ra[op].v[i]));
+            if (!(std::fabs(ra[op].v[i] - rb[op].v[i]) <= tol)) pass = false;
         }
+        if (pass) ok |= 1u << op;
     }
-    return true;
+    return ok;
+}
+
+static void select_table(tgp_handle* h, int d, bool lti, int variant) {
+    const KernelTable* safe = kernel_table(d);
+    const KernelTable* fast = fast_kernel_table(d);
+    h->kt = safe;
+    if (!fast || variant == 1) return;
+    if (variant == 2) { h->kt = fast; return; }
+    unsigned& g = g_variant[d][lti ? 1 : 0];
+    if (!(g & (1u << kOpDecided))) g = variant_selftest(h->device, d, lti) | (1u << kOpDecided);
+    unsigned ok = g & kAllOps;
+    if (!lti) ok &= ~(1u << kOpGrad);
+    const unsigned want = lti ? kAllOps : (kAllOps & ~(1u << kOpGrad));
+    if (ok == want) { h->kt = fast; return; }
+    if (ok == 0u) return;
+    merge_tables(safe, fast, ok, h->ktm);
+    h->kt = &h->ktm;
 }
 
 extern "C" {
@@ -1349,12 +1363,14 @@ int tgp_shard_smoother_backward(tgp_handle* h, const double* gathered_dev, int w
 
 int tgp_elem_apply(int kind, int d, const double* elem, const double* m, const double* P, double* m_out, double* P_out) {
     if (!elem || !m || !P || !m_out || !P_out) return TGP_EINVAL;
-    DISPATCH_D(d, host_apply, kind, elem, m, P, m_out, P_out)
+    const KernelTable* kt = kernel_table(d);
+    return kt ? kt->host_apply(kind, elem, m, P, m_out, P_out) : TGP_EUNSUPPORTED;
 }
 
 int tgp_elem_combine(int kind, int d, const double* earlier, const double* later, double* out) {
     if (!earlier || !later || !out) return TGP_EINVAL;
-    DISPATCH_D(d, host_combine, kind, earlier, later, out)
+    const KernelTable* kt = kernel_table(d);
+    return kt ? kt->host_combine(kind, earlier, later, out) : TGP_EUNSUPPORTED;
 }
 
 int tgp_last_timing(const tgp_handle* h, double* kernel_ms, double* h2d_ms, double* d2h_ms) {

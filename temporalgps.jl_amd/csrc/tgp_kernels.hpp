@@ -571,22 +571,25 @@ __global__ __launch_bounds__(256) void k_apply_affine(ModelView mv, int L0, int6
 enum ScanMonoid { kFilter = 0, kAffineCov = 1, kAffineMean = 2, kFilterAD = 3 };
 constexpr int kScanE = 1;   // elements per lane in the block scans
 
+// Launch table of one build of one state dimension. Entries are fine-grained (one per pass-2 mode, one per scan monoid
+// class) so that the run-time variant check can mix the inlined and the out-of-line build entry by entry.
+enum ScanClass { kScanFilter = 0, kScanAffine = 1, kScanAD = 2 };
 struct KernelTable {
     int d;
     // E1 != NULL: also reduce each block's 256 elements to E1[block] (fused level-0 scan reduce)
     void (*reduce_filter)(bool lti, const ModelView&, int L0, int64_t n0, double* E0, double* E1, int64_t n1, hipStream_t);
-    // E0 != NULL: carry-in states come from an in-block scan of E0 against the level-1 states S1 (fused level-0 scan apply)
-    void (*apply_filter)(bool lti, int mode, const ModelView&, int L0, int64_t n0, double* S0, const double* E0, const double* S1,
-                         int64_t n1, const FilterOut&, double* R0, double* partial, hipStream_t);
+    // per MODE 0..3. E0 != NULL: carry-in states come from an in-block scan of E0 against the level-1 states S1 (fused level-0 apply)
+    void (*apply_filter_m[4])(bool lti, const ModelView&, int L0, int64_t n0, double* S0, const double* E0, const double* S1, int64_t n1,
+                              const FilterOut&, double* R0, double* partial, hipStream_t);
     void (*smooth)(bool lti, const ModelView&, int L0, int64_t n0, const double* S0, const double* S0r, const double* fs,
                    const double* Rnew, int64_t sRn, double* mean_out, double* var_out, int* bad, hipStream_t);
     void (*reduce_affine)(bool lti, bool rnd, const ModelView&, int L0, int64_t n0, const double* eps_t, double* E0, int* bad, hipStream_t);
     void (*apply_affine)(bool lti, bool rnd, const ModelView&, int L0, int64_t n0, const double* S0, const double* eps_t,
                          const double* eps_e, double* mean_out, double* var_out, int* bad, hipStream_t);
-    // block scans: bs == 256 (intermediate levels) or 512 (single top block); kScanE elements per lane
-    void (*scan_reduce)(int monoid, const double* Ein, int64_t n, double* Ehi, int64_t nhi, hipStream_t);
-    void (*scan_apply)(int monoid, int bs, const double* Ein, int64_t n, const double* carry, int64_t ncarry, double* S, double* fin,
-                       hipStream_t);
+    // block scans per monoid class (ScanClass): bs == 256 (intermediate levels) or 512 (single top block)
+    void (*scan_reduce_c[3])(int monoid, const double* Ein, int64_t n, double* Ehi, int64_t nhi, hipStream_t);
+    void (*scan_apply_c[3])(int monoid, int bs, const double* Ein, int64_t n, const double* carry, int64_t ncarry, double* S, double* fin,
+                            hipStream_t);
     // forward-mode gradient pass (LTI models): elements / states carry (value, tangent) planes
     void (*reduce_filter_ad)(const ModelView&, int L0, int64_t n0, double* E0, hipStream_t);
     void (*apply_filter_ad)(const ModelView&, int L0, int64_t n0, const double* S0, double* partial, hipStream_t);
@@ -596,6 +599,20 @@ struct KernelTable {
     // time-sharded series: fold the per-rank elements of an all-gather onto a state, on the device
     void (*fold)(int monoid, const double* gathered, int64_t slot, int first, int count, int step, const double* x_in, double* x_out,
                  hipStream_t);
+    // host-side monoid operations on packed elements / states (m (d), P (d*d))
+    int (*host_apply)(int kind, const double* elem, const double* m, const double* P, double* m_out, double* P_out);
+    int (*host_combine)(int kind, const double* earlier, const double* later, double* out);
+    void scan_reduce(int monoid, const double* Ein, int64_t n, double* Ehi, int64_t nhi, hipStream_t s) const {
+        scan_reduce_c[monoid == kFilter ? kScanFilter : monoid == kFilterAD ? kScanAD : kScanAffine](monoid, Ein, n, Ehi, nhi, s);
+    }
+    void scan_apply(int monoid, int bs, const double* Ein, int64_t n, const double* carry, int64_t ncarry, double* S, double* fin,
+                    hipStream_t s) const {
+        scan_apply_c[monoid == kFilter ? kScanFilter : monoid == kFilterAD ? kScanAD : kScanAffine](monoid, bs, Ein, n, carry, ncarry, S, fin, s);
+    }
+    void apply_filter(bool lti, int mode, const ModelView& mv, int L0, int64_t n0, double* S0, const double* E0, const double* S1, int64_t n1,
+                      const FilterOut& out, double* R0, double* partial, hipStream_t s) const {
+        apply_filter_m[mode < 0 || mode > 3 ? 3 : mode](lti, mv, L0, n0, S0, E0, S1, n1, out, R0, partial, s);
+    }
 };
 
 const KernelTable* kernel_table(int d);
