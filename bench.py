@@ -273,7 +273,8 @@ def main():
             higher_is_better=True, scaling=args.scaling, vs_baseline=None, dtype="f64", data="synthetic",
             config=dict(workload=f"cfg2: {name}, RegularSpacing(0,0.1,T={T}), sigma2_obs=0.1, layout={args.layout}; one logpdf pass "
                                  f"+ one posterior-marginals pass per step", T=T, T_per_gpu=Tseg, d=d, layout=args.layout,
-                        parallelism=f"time-shard x{world} ({args.scaling}: {'T per GPU fixed' if args.scaling == 'weak' else 'total T fixed'})"),
+                        parallelism=f"time-shard x{world} ({args.scaling}: {'T per GPU fixed' if args.scaling == 'weak' else 'total T fixed'})",
+                        exchange=shard.transport),
             roofline=roof,
             kernels={k: dict(avg_ms=v["total_ms"] / max(1, v["calls"]), calls=v["calls"]) for k, v in prof.items()},
         )

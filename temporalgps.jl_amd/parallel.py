@@ -192,9 +192,16 @@ class ShardedLGSSM:
         self.engine = engine if engine is not None else (HIPEngine(model) if self.world > 1 else None)
         self.comm = comm          # device-resident transport; None => torch.distributed (chosen by backend)
 
+    @property
+    def transport(self):
+        """'device' (elements stay in HBM, RCCL collectives on the handle's stream), 'host', or 'none' (single GPU)."""
+        if self.engine is None:
+            return "none"
+        return "device" if self._device_resident() else "host"
+
     # -- device-resident transport -----------------------------------------------------------------------
     def _device_resident(self):
-        if not isinstance(self.engine, HIPEngine):
+        if not isinstance(self.engine, HIPEngine) or getattr(self, "_dx_disabled", False):
             return False
         if self.comm is not None:
             return True
@@ -293,7 +300,20 @@ class ShardedLGSSM:
         if self.world == 1 and self.engine is None:
             return L.logpdf(self.model, y)
         if self._device_resident():
-            return self._logpdf_device(y)
+            try:
+                out = self._logpdf_device(y)
+                self._dx_ok = True
+                return out
+            except _lib.TGPError:
+                raise
+            except (RuntimeError, TypeError, NotImplementedError) as ex:
+                # The collective layer refused the device-resident exchange on its FIRST use (every rank takes the same
+                # branch): keep computing on the GPU, exchange the elements through the host instead.
+                if getattr(self, "_dx_ok", False):
+                    raise
+                import warnings
+                warnings.warn(f"device-resident exchange unavailable ({ex!r}); using the host transport")
+                self._dx_disabled = True
         if not hasattr(self, "_x0"):
             self._x0 = self.engine.x0()
         reuse = self._forward_exchange(y)
@@ -304,7 +324,18 @@ class ShardedLGSSM:
         if self.world == 1 and self.engine is None:
             return L.posterior_marginals(self.model, y, R_new)
         if self._device_resident():
-            return self._posterior_marginals_device(y, R_new)
+            try:
+                out = self._posterior_marginals_device(y, R_new)
+                self._dx_ok = True
+                return out
+            except _lib.TGPError:
+                raise
+            except (RuntimeError, TypeError, NotImplementedError) as ex:
+                if getattr(self, "_dx_ok", False):
+                    raise
+                import warnings
+                warnings.warn(f"device-resident exchange unavailable ({ex!r}); using the host transport")
+                self._dx_disabled = True
         if not hasattr(self, "_x0"):
             self._x0 = self.engine.x0()
         e = self.engine
