@@ -153,8 +153,10 @@ def pmc_traffic(kname, d, layout):
     lti = "true" if layout == "lti" else "false"
     base = kname.split("<")[0]
     mode = {"logpdf": 0, "filter": 1, "posterior": 2, "materialise": 3}
-    if base in ("k_reduce_filter", "k_smooth"):
+    if base == "k_reduce_filter":
         key = f"{base}<{d}, {lti}>"
+    elif base == "k_smooth":
+        key = f"{base}<{d}, {lti}, false>"      # the bench passes ONE shared R_new (RSTREAM = false)
     elif base == "k_apply_filter":
         key = f"{base}<{d}, {lti}, {mode[kname.split(',')[1].rstrip('>')]}>"
     else:

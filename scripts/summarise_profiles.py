@@ -18,6 +18,12 @@ dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
 
 
+def newest(pattern):
+    """gpurun merges every call's files into the same directory: take the most recent run"""
+    files = sorted(glob.glob(pattern, recursive=True), key=os.path.getmtime)
+    return files[-1:] 
+
+
 def short(name):
     n = name.replace("void tgp::", "").split("(")[0]
     return n
@@ -25,7 +31,7 @@ def short(name):
 
 traffic = {}
 for lay in ("lti", "per_step"):
-    files = glob.glob(os.path.join(src, f"trace_{lay}", "**", "*kernel_trace.csv"), recursive=True)
+    files = newest(os.path.join(src, f"trace_{lay}", "**", "*kernel_trace.csv"))
     if files:
         acc = collections.defaultdict(list)
         for r in csv.DictReader(open(files[0])):
@@ -39,7 +45,7 @@ for lay in ("lti", "per_step"):
         open(os.path.join(dst, f"{tag}_{lay}_kernel_stats.md"), "w").write("\n".join(lines) + "\n")
     per = {}
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
-        files = glob.glob(os.path.join(src, f"pmc_{lay}_{c}", "**", "*counter_collection.csv"), recursive=True)
+        files = newest(os.path.join(src, f"pmc_{lay}_{c}", "**", "*counter_collection.csv"))
         if not files:
             continue
         acc = collections.defaultdict(list)
