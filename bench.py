@@ -165,6 +165,31 @@ def pmc_traffic(kname, d, layout):
     return None if ent is None else ent["hbm_bytes"]
 
 
+def valu_utilisation(prof, d, layout):
+    """fp64 vector-ALU issue-rate utilisation of the chunk kernels: SQ_INSTS_VALU per launch (rocprofv3 PMC pass committed
+    as profiles/r01_sq_counters_<layout>.json, T = 1e7) over the launch duration measured HERE, against the issue peak
+    256 CUs x 4 SIMDs x one wave64 fp64 instruction per 4 cycles at 2.4 GHz (= the 78.6 TFLOP/s datasheet figure counted
+    in instructions). The LTI kernels are bound by this, not by HBM."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r01_sq_counters_{layout}.json")
+    if not os.path.exists(path):
+        return None
+    table = json.load(open(path))
+    peak = 256 * 4 * 2.4e9 / 4.0
+    lti = "true" if layout == "lti" else "false"
+    names = {f"k_reduce_filter<{'lti' if layout == 'lti' else 'per-step'}>": f"k_reduce_filter<{d}, {lti}>",
+             f"k_apply_filter<{'lti' if layout == 'lti' else 'per-step'},logpdf>": f"k_apply_filter<{d}, {lti}, 0>",
+             f"k_apply_filter<{'lti' if layout == 'lti' else 'per-step'},posterior>": f"k_apply_filter<{d}, {lti}, 2>",
+             f"k_smooth<{'lti' if layout == 'lti' else 'per-step'}>": f"k_smooth<{d}, {lti}, false>"}
+    out = {}
+    for pk, ck in names.items():
+        if pk in prof and ck in table and "SQ_INSTS_VALU" in table[ck]:
+            dur = prof[pk]["total_ms"] / max(1, prof[pk]["calls"]) * 1e-3
+            n = table[ck]["SQ_INSTS_VALU"]
+            out[pk] = dict(valu_wave_instructions=n, achieved=n / dur, peak=peak, unit="wave64 fp64 VALU instructions/s", frac=n / dur / peak,
+                           wait_any_frac=table[ck].get("SQ_WAIT_ANY", 0.0) / max(1.0, table[ck].get("SQ_WAVE_CYCLES", 1.0)))
+    return out or None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -280,6 +305,8 @@ def main():
             roofline=roof,
             kernels={k: dict(avg_ms=v["total_ms"] / max(1, v["calls"]), calls=v["calls"]) for k, v in prof.items()},
         )
+        if T == 10_000_000 and world == 1 and d == 3 and not args.chunk:
+            out["valu"] = valu_utilisation(prof, d, args.layout)
         if args.layout == "lti" and world == 1 and not args.no_general_leg:
             out["logpdf_and_grad"] = gradient_leg(tgp, torch, name, T, d, local, max(3, args.steps // 2), y)
             if not args.no_cpu_baseline:

@@ -14,6 +14,11 @@ for r in csv.DictReader(open(f[0])):
     acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 names = ["SQ_WAVES","SQ_WAVE_CYCLES","SQ_BUSY_CYCLES","SQ_WAIT_ANY","SQ_WAIT_INST_ANY","SQ_ACTIVE_INST_ANY","SQ_ACTIVE_INST_VALU","SQ_INSTS_VALU"]
 print("kernel | " + " | ".join(names))
+import json
+out = {}
 for k, d in acc.items():
     print(k, "|", " | ".join("%.3g" % max(d[n]) if d[n] else "-" for n in names))
+    if k.startswith("k_"):
+        out[k] = {n: max(d[n]) for n in names if d[n]}
+json.dump(out, open("$GRAFT_REPO_ROOT/gpurun_out/sq_${1:-lti}.json", "w"), indent=1, sort_keys=True)
 PY
