@@ -1,0 +1,118 @@
+"""GPU tier at BASELINE.json's FULL sizes. The sequential C oracle (oracle/seq_kalman.c, ~1e7 steps/s on one core) is fast
+enough to be run at these sizes directly, so the checks are plain parity, plus two size-independent properties of the
+chunked scan: invariance under the chunk size (the scan blocking) and under time sharding.
+  cfg2: Matern-5/2 (d = 3), T = 1e7, LTI and per-step layouts   cfg3: sum kernel d = 6 (and d = 5), T = 1e7
+  cfg4: d = 4, T = 1e8 (logpdf; one GPU holds it)
+Tolerances: lml relative 1e-10 (it is a sum of 1e7..1e8 terms of mixed sign), marginals absolute 1e-8."""
+import numpy as np
+import pytest
+
+from oracle import components as oc
+from oracle import seq_kalman as sk
+
+pytestmark = pytest.mark.gpu
+
+SPECS = {
+    "matern52_d3": ("matern52",),
+    "sum52_32_d5": ("sum", ("matern52",), ("matern32",)),
+    "sum52_52_d6": ("sum", ("matern52",), ("matern52",)),
+    "sum52_12_d4": ("sum", ("matern52",), ("matern12",)),
+}
+
+
+@pytest.fixture(scope="module")
+def tgp():
+    import temporalgps_jl_amd as t
+    t._lib.load()
+    return t
+
+
+def _product_model(name, T, per_step=False):
+    from temporalgps_jl_amd import lti_sde
+    return lti_sde.build_lgssm(lti_sde.to_kernel(SPECS[name]), lti_sde.RegularSpacing(0.0, 0.1, T), 0.1, force_per_step=per_step)
+
+
+@pytest.mark.parametrize("name,per_step", [("matern52_d3", False), ("matern52_d3", True), ("sum52_32_d5", False), ("sum52_52_d6", False)])
+def test_full_size_parity_with_sequential_oracle(tgp, name, per_step):
+    import torch
+    T = 10_000_000
+    rng = np.random.default_rng(42)
+    y = rng.standard_normal(T)
+    ref_model = oc.build_lgssm(SPECS[name], ("regular", 0.0, 0.1, T), 0.1)
+    lp_ref = sk.logpdf(ref_model, y)
+    pm, pv = sk.posterior_marginals(ref_model, y, np.array([1e-18]))
+    model = _product_model(name, T, per_step)
+    yd = torch.as_tensor(y, device="cuda:0")
+    lp = tgp.logpdf(model, yd)
+    assert abs(lp - lp_ref) <= 1e-10 * abs(lp_ref)
+    Rn = torch.full((1,), 1e-18, dtype=torch.float64, device="cuda:0")
+    mean, var = tgp.posterior_marginals(model, yd, Rn)
+    assert np.max(np.abs(mean.cpu().numpy() - pm)) <= 1e-8
+    assert np.max(np.abs(var.cpu().numpy() - pv)) <= 1e-8
+    # chunk-size (scan blocking) invariance at full size
+    hd = model.handle()
+    for chunk in (61, 200):
+        hd.set_option(tgp._lib.OPT_CHUNK, chunk)
+        assert abs(tgp.logpdf(model, yd) - lp) <= 1e-11 * abs(lp)
+        m2, v2 = tgp.posterior_marginals(model, yd, Rn)
+        assert float((m2 - mean).abs().max()) <= 1e-9 and float((v2 - var).abs().max()) <= 1e-9
+
+
+def test_full_size_missing_data_and_sharding_invariance(tgp):
+    """cfg2 with 10 % missing observations; the same series through the time-sharded protocol (4 ranks as threads on the
+    one GPU, device-resident exchange) must reproduce the single-pass result."""
+    import threading
+
+    import torch
+    from temporalgps_jl_amd import lti_sde, parallel
+    from tests.test_gpu_sharding import _ThreadComm
+    from oracle import lgssm_ref as ref
+    T, world = 10_000_000, 4
+    rng = np.random.default_rng(7)
+    y = rng.standard_normal(T)
+    miss = rng.random(T) < 0.1
+    ref_model = oc.build_lgssm(SPECS["matern52_d3"], ("regular", 0.0, 0.1, T), 0.1)
+    R = np.full(T, 0.1)
+    R[miss] = 1e15                                                  # missings.jl:25-33
+    y0 = np.where(miss, 0.0, y)
+    lp_ref = sk.logpdf(dict(ref_model, R=R), y0) + ref.volume_compensation(int(miss.sum()))
+    model = _product_model("matern52_d3", T)
+    yd, md = torch.as_tensor(y0, device="cuda:0"), torch.as_tensor(miss, device="cuda:0")
+    lp = tgp.logpdf(model, (yd, md))
+    assert abs(lp - lp_ref) <= 1e-10 * abs(lp_ref)
+    shared, barrier, out, errs = {}, threading.Barrier(world), {}, []
+    lib = tgp._lib.load()
+    for ph in (0, 1):
+        n = lib.tgp_shard_slot_size(ph, 3)
+        shared[("g", n)] = torch.zeros(world * n, dtype=torch.float64, device="cuda:0")
+    shared[("r", 4)] = torch.zeros(world, 4, dtype=torch.float64, device="cuda:0")
+
+    def run(rank):
+        try:
+            torch.cuda.set_device(0)
+            lo, hi = parallel.segment_bounds(T, world, rank)
+            seg = lti_sde.build_lgssm(lti_sde.to_kernel(SPECS["matern52_d3"]), lti_sde.RegularSpacing(0.1 * lo, 0.1, hi - lo), 0.1)
+            sh = parallel.ShardedLGSSM(seg, world, rank, engine=parallel.HIPEngine(seg), comm=_ThreadComm(world, rank, shared, barrier))
+            out[rank] = sh.logpdf((yd[lo:hi], md[lo:hi]))
+        except Exception as ex:      # noqa: BLE001
+            errs.append(ex)
+            barrier.abort()
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    for r in range(world):
+        assert abs(out[r] - lp) <= 1e-11 * abs(lp)
+
+
+def test_cfg4_T1e8_d4_logpdf(tgp):
+    """BASELINE config 4's series on ONE GPU (it is time-sharded there): T = 1e8, d = 4."""
+    import torch
+    T = 100_000_000
+    rng = np.random.default_rng(3)
+    y = rng.standard_normal(T)
+    ref_model = oc.build_lgssm(SPECS["sum52_12_d4"], ("regular", 0.0, 0.1, T), 0.1)
+    lp_ref = sk.logpdf(ref_model, y)
+    model = _product_model("sum52_12_d4", T)
+    lp = tgp.logpdf(model, torch.as_tensor(y, device="cuda:0"))
+    assert abs(lp - lp_ref) <= 1e-10 * abs(lp_ref)
