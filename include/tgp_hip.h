@@ -62,9 +62,13 @@ typedef struct tgp_handle tgp_handle;
 /* ---- options (tgp_set_option) ------------------------------------------------------------------ */
 #define TGP_OPT_CHUNK 1   /* steps per lane in the chunked scan (0 = auto) */
 #define TGP_OPT_PROFILE 2 /* 1: bracket every kernel with hipEvents (see tgp_profile_*) */
-#define TGP_OPT_VARIANT 3 /* d = 5, 6 only: 0 auto (inlined build if it passes the run-time known-answer check against the
-                             out-of-line build), 1 force the out-of-line build, 2 force the inlined build */
+#define TGP_OPT_VARIANT 3 /* d = 5..8: 0 auto (per operation, the inlined build where it passes the run-time known-answer check
+                             against the out-of-line build), 1 out-of-line build only, 2 inlined build for everything,
+                             3 out-of-line build + the group-per-chunk logpdf kernels (used by the check itself) */
 
+#define TGP_OPT_GROUP 5 /* logpdf of d = 5..8 LTI models with eight lanes per chunk (tgp_group.hpp), once that path has reproduced
+                           the out-of-line build in the run-time check: 1 (default) where it is faster (d >= 7), 2 for every
+                           d = 5..8, 0 never */
 #define TGP_OPT_FUSE_SCAN 4 /* 1 (default): the level-0 scan reduce / apply of the forward scan run inside the chunk kernels;
                                0: stand-alone k_scan_reduce / k_scan_apply launches (bit-identical results, for A/B timing) */
 

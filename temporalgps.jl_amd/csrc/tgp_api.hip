@@ -61,7 +61,7 @@ static const KernelTable* fast_kernel_table(int d) {
 }
 // Per (state dimension, LTI layout family?): which operations of the inlined (fast) build reproduced the out-of-line (safe)
 // build in the run-time known-answer check. Bit kOpDecided = the check has run.
-enum VariantOp { kOpM0 = 0, kOpM1, kOpM2, kOpM3, kOpAffine, kOpGrad, kOpCount, kOpDecided = 30 };
+enum VariantOp { kOpM0 = 0, kOpM1, kOpM2, kOpM3, kOpAffine, kOpGrad, kOpCount, kOpGroup = 29, kOpDecided = 30 };
 static unsigned g_variant[17][2] = {{0u}};
 static const unsigned kAllOps = (1u << kOpCount) - 1u;
 
@@ -216,6 +216,7 @@ struct tgp_handle {
     double normF = 0.0;
     const KernelTable* kt = nullptr;   // -> ktm when the inlined and out-of-line builds are mixed entry by entry
     KernelTable ktm{};
+    int variant_code = 1;        // 1 out-of-line build, 2 every operation inlined, 3 mixed
     DevBuf bA, ba, bQ, bH, bh, bR;
     std::vector<double> x0m, x0P;
     DevBuf bx0, bx0r, bx0fold;
@@ -234,6 +235,9 @@ struct tgp_handle {
     int64_t n0 = 0;
     bool reduce_valid = false, smoother_valid = false;
     bool fused = false;          // the current forward elements were produced with the fused level-0 reduce
+    bool group_active = false;   // ... by the group-per-chunk pass 1 (32 chunks per block, its own chunking)
+    bool use_group = false;      // group-per-chunk logpdf kernels validated for this model (tgp_group.hpp)
+    int opt_group = 1;           // TGP_OPT_GROUP
     int opt_fuse = 1;            // TGP_OPT_FUSE_SCAN
     // timing
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -549,8 +553,37 @@ int ensure_tiled(tgp_handle* h) {
 }
 
 // forward pass 1 + upward scans (skipped when the caller vouches for reuse)
-int forward_reduce(tgp_handle* h, uint32_t flags) {
+// for_mode: the pass-2 mode the caller will run next (0 logpdf ...), -1 unknown (time-sharded protocol)
+int forward_reduce(tgp_handle* h, uint32_t flags, int for_mode = -1) {
     if ((flags & TGP_REUSE_REDUCE) && h->reduce_valid) return TGP_OK;
+    // Group-per-chunk logpdf kernels (tgp_group.hpp). Measured at T = 1e7 (pass 1 + pass 2, ms; lane-per-chunk inlined
+    // build in brackets): d = 5 1.9 (0.70), d = 6 2.2 (1.55), d = 7 2.9 (4.3), d = 8 3.4 (12.1) -- their time hardly
+    // depends on d (LDS exchanges and shuffles, not flops), so they pay from d = 7 on (TGP_OPT_GROUP = 2 forces them).
+    const bool group_pays = h->d >= 7 || h->opt_group == 2;
+    if (for_mode == 0 && h->use_group && h->opt_group && group_pays && h->kt->group_reduce_filter != nullptr && h->lti && h->p == 1) {
+        // 8 chunks per wave: 16384 chunks are two waves per SIMD; longer chunks also mean fewer scan elements, and the
+        // d >= 7 block scans (spill-bound, ~1.5 ms per launch) are what is left of the call
+        int64_t L0 = h->opt_chunk;
+        if (L0 <= 0) {
+            L0 = (h->T + 16383) / 16384;
+            if (L0 < 8) L0 = 8;
+        }
+        if (L0 > h->T) L0 = h->T;
+        h->L0 = (int)L0;
+        h->n0 = (h->T + L0 - 1) / L0;
+        TRY(scan_prepare(h, h->F, kFilter, h->n0));
+        {
+            LaunchScope ls(h, "k_group_reduce_filter<lti>");
+            h->kt->group_reduce_filter(h->mv, h->L0, h->n0, h->F.E[0], h->stream);
+        }
+        scan_up(h, h->F, 0);
+        h->fused = false;
+        h->group_active = true;
+        h->reduce_valid = true;
+        h->smoother_valid = false;
+        return TGP_OK;
+    }
+    h->group_active = false;
     choose_chunk(h);
     TRY(ensure_tiled(h));
     TRY(scan_prepare(h, h->F, kFilter, h->n0));
@@ -583,6 +616,20 @@ int set_obs(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t fla
 // forward filter to the end. mode 0/1/2 as in chunk_apply_filter. Fills h->result (lml, nmiss, bad).
 int forward_apply(tgp_handle* h, int mode, const FilterOut& fo, const double* x0dev = nullptr) {
     scan_down(h, h->F, x0dev ? x0dev : h->bx0.d(), h->fused ? 1 : 0);
+    if (h->group_active) {
+        if (mode != 0) return h->fail(TGP_EINVAL, "internal: group-per-chunk elements are only valid for the logpdf pass");
+        const int64_t nb = (h->n0 + 31) / 32;
+        HIPCHK(h->partial.ensure((size_t)nb * 3 * sizeof(double)));
+        {
+            LaunchScope ls(h, "k_group_apply_filter<lti,logpdf>");
+            h->kt->group_apply_logpdf(h->mv, h->L0, h->n0, h->F.S[0], h->partial.d(), h->stream);
+        }
+        {
+            LaunchScope ls(h, "k_finalize");
+            hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, h->stream, h->partial.d(), nb, h->result.d());
+        }
+        return TGP_OK;
+    }
     const int64_t nblocks = (h->n0 + 255) / 256;
     HIPCHK(h->partial.ensure((size_t)nblocks * 3 * sizeof(double)));
     double* R0 = nullptr;
@@ -685,13 +732,20 @@ int tgp_set_option(tgp_handle* h, int option, int64_t value) {
         return TGP_OK;
     }
     if (option == TGP_OPT_VARIANT) {
-        if (value < 0 || value > 2) return h->fail(TGP_EINVAL, "TGP_OPT_VARIANT must be 0, 1 or 2");
+        if (value < 0 || value > 3) return h->fail(TGP_EINVAL, "TGP_OPT_VARIANT must be 0, 1, 2 or 3");
         h->variant_opt = (int)value;
         if (h->have_model) {
             select_table(h, h->d, h->lti, (int)value);
             h->reduce_valid = false;
             h->smoother_valid = false;
         }
+        return TGP_OK;
+    }
+    if (option == TGP_OPT_GROUP) {
+        if (value < 0 || value > 2) return h->fail(TGP_EINVAL, "TGP_OPT_GROUP must be 0, 1 or 2");
+        h->opt_group = (int)value;
+        h->reduce_valid = false;
+        h->smoother_valid = false;
         return TGP_OK;
     }
     if (option == TGP_OPT_FUSE_SCAN) {
@@ -705,8 +759,7 @@ int tgp_set_option(tgp_handle* h, int option, int64_t value) {
 
 int tgp_kernel_variant(const tgp_handle* h) {
     if (!h || !h->have_model) return 0;
-    if (fast_kernel_table(h->d) != nullptr && h->kt == fast_kernel_table(h->d)) return 2;
-    return h->kt == &h->ktm ? 3 : 1;
+    return h->variant_code;
 }
 
 int tgp_set_stream(tgp_handle* h, void* hip_stream) {
@@ -837,7 +890,7 @@ int tgp_logpdf(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t 
     CallTimer tm(h);
     TRY(set_obs(h, y, missing, flags));
     tm.inputs_done();
-    TRY(forward_reduce(h, flags));
+    TRY(forward_reduce(h, flags, 0));
     FilterOut fo{};
     TRY(forward_apply(h, 0, fo));
     tm.kernels_done();
@@ -1222,12 +1275,24 @@ static unsigned variant_selftest(int device, int d, bool lti_layout) {
         tgp_destroy(h);
         return TGP_OK;
     };
-    OpOut ra[kOpCount], rb[kOpCount];
+    OpOut ra[kOpCount], rb[kOpCount], rg[kOpCount];
     const uint64_t keep = st;
+    const bool have_fast = fast_kernel_table(d) != nullptr;
     st = keep; const int rca = run(1, lti_layout, ra);
-    st = keep; const int rcb = run(2, lti_layout, rb);
+    st = keep; const int rcb = have_fast ? run(2, lti_layout, rb) : TGP_EUNSUPPORTED;
     unsigned ok = 0u;
-    if (rca != TGP_OK || rcb != TGP_OK) return ok;
+    if (rca != TGP_OK) return ok;
+    auto same = [&](const OpOut& x, const OpOut& z) {
+        if (x.rc != TGP_OK || z.rc != TGP_OK || x.v.size() != z.v.size()) return false;
+        for (size_t i = 0; i < x.v.size(); ++i)
+            if (!(std::fabs(x.v[i] - z.v[i]) <= 1e-9 * (1.0 + std::fabs(x.v[i])))) return false;
+        return true;
+    };
+    if (lti_layout && kernel_table(d)->group_reduce_filter != nullptr) {   // group-per-chunk logpdf kernels against the out-of-line build
+        st = keep;
+        if (run(3, true, rg) == TGP_OK && same(ra[kOpM0], rg[kOpM0])) ok |= 1u << kOpGroup;
+    }
+    if (rcb != TGP_OK) return ok;
     for (int op = 0; op < kOpCount; ++op) {
         if (op == kOpGrad && !lti_layout) continue;
         bool pass = ra[op].rc == TGP_OK && rb[op].rc == TGP_OK && ra[op].v.size() == rb[op].v.size();
@@ -1243,18 +1308,30 @@ static unsigned variant_selftest(int device, int d, bool lti_layout) {
 static void select_table(tgp_handle* h, int d, bool lti, int variant) {
     const KernelTable* safe = kernel_table(d);
     const KernelTable* fast = fast_kernel_table(d);
-    h->kt = safe;
-    if (!fast || variant == 1) return;
-    if (variant == 2) { h->kt = fast; return; }
+    h->ktm = *safe;                 // always a private copy: entries are replaced one by one below
+    h->kt = &h->ktm;
+    h->use_group = false;
+    h->variant_code = 1;
+    if (variant == 1) return;
+    if (variant == 3) {             // out-of-line build + the group-per-chunk logpdf kernels (used by the check itself)
+        h->use_group = safe->group_reduce_filter != nullptr && lti;
+        return;
+    }
+    if (variant == 2) {
+        if (fast) { merge_tables(safe, fast, kAllOps, h->ktm); h->variant_code = 2; }
+        return;
+    }
+    if (!fast && safe->group_reduce_filter == nullptr) return;
     unsigned& g = g_variant[d][lti ? 1 : 0];
     if (!(g & (1u << kOpDecided))) g = variant_selftest(h->device, d, lti) | (1u << kOpDecided);
     unsigned ok = g & kAllOps;
     if (!lti) ok &= ~(1u << kOpGrad);
     const unsigned want = lti ? kAllOps : (kAllOps & ~(1u << kOpGrad));
-    if (ok == want) { h->kt = fast; return; }
-    if (ok == 0u) return;
-    merge_tables(safe, fast, ok, h->ktm);
-    h->kt = &h->ktm;
+    if (fast && ok != 0u) {
+        merge_tables(safe, fast, ok, h->ktm);
+        h->variant_code = ok == want ? 2 : 3;
+    }
+    h->use_group = lti && ((g >> kOpGroup) & 1u) != 0u && safe->group_reduce_filter != nullptr;
 }
 
 extern "C" {

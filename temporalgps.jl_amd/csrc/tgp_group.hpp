@@ -1,0 +1,265 @@
+// Group-per-chunk kernels for state dimensions 5..8 (LTI family, scalar observations): EIGHT lanes share one chunk, lane j
+// holding column j of every matrix, so a lane carries ~10 d doubles instead of the 3 d^2 of the lane-per-chunk kernels --
+// no spills, full occupancy. (tgp_chunk_body.inc keeps every other case; the scan stages are shared: the element /
+// carry-state formats in HBM are the interface.)
+//
+// Building blocks, all inside one wave (a group never spans waves, so `wave_sync` is the only synchronisation):
+//   A X        lane-local: Y[:, j] = A X[:, j]; A (shared, LTI) is read from LDS as a broadcast
+//   A P A'     = A (A P)' for symmetric P: ONE transpose of W = A P through the group's LDS tile (lane j writes column j,
+//              reads row j), then column j of the result is A (row j of W)'
+//   P H        lane-local by symmetry: (P H)_j = H . P[:, j]
+//   H'x, sums  3-step xor butterfly over the 8 lanes (every lane ends with the same value)
+//   all-gather each lane contributes one value, all read the 8 of them back from the tile
+// Same recursions as predict / update_scalar_nolog / f_extend (tgp_math_body.inc), same operation order inside each
+// inner product; the results agree with the lane-per-chunk kernels to rounding.
+#pragma once
+
+namespace TGP_NS {
+
+constexpr int kGroup = 8;                  // lanes per chunk
+constexpr int kGroupsPerBlock = 32;        // 256 threads
+constexpr int kGroupTileLD = 66;           // doubles per group tile: 8 x 8 + 2 (8 groups of a wave on distinct banks)
+
+__device__ __forceinline__ double group_sum(double x) {
+    x += __shfl_xor(x, 1, 8);
+    x += __shfl_xor(x, 2, 8);
+    x += __shfl_xor(x, 4, 8);
+    return x;
+}
+
+template <int D> struct GroupLane {
+    int j;                   // lane inside the group == matrix column it owns
+    double* tile;            // the group's LDS tile [8][8] (+ pad)
+    const double* sA;        // A in LDS, [i + 8 k]
+    bool act;                // j < D
+    // y[:, j] = A x[:, j]
+    __device__ __forceinline__ void mul_A(const double* x, double* y) const {
+        TGP_UNROLL for (int i = 0; i < D; ++i) {
+            double acc = 0.0;
+            TGP_UNROLL for (int k = 0; k < D; ++k) acc = fma(sA[i + 8 * k], x[k], acc);
+            y[i] = acc;
+        }
+    }
+    // (A v)_j for a vector whose element j lives in lane j
+    __device__ __forceinline__ double mul_A_vec(double vj) const {
+        double v[D];
+        gather(vj, v);
+        double acc = 0.0;
+        TGP_UNROLL for (int k = 0; k < D; ++k) acc = fma(sA[(j & 7) + 8 * k], v[k], acc);
+        return acc;
+    }
+    // every lane gets all D elements of a vector distributed one element per lane
+    __device__ __forceinline__ void gather(double vj, double* v) const {
+        wave_sync();
+        tile[j] = vj;
+        wave_sync();
+        TGP_UNROLL for (int k = 0; k < D; ++k) v[k] = tile[k];
+    }
+    __device__ __forceinline__ void gather2(double vj, double wj, double* v, double* w) const {
+        wave_sync();
+        tile[j] = vj;
+        tile[8 + j] = wj;
+        wave_sync();
+        TGP_UNROLL for (int k = 0; k < D; ++k) { v[k] = tile[k]; w[k] = tile[8 + k]; }
+    }
+    // col = column j of W  ->  row[k] = W[j, k]
+    __device__ __forceinline__ void transpose(const double* col, double* row) const {
+        wave_sync();
+        TGP_UNROLL for (int i = 0; i < D; ++i) tile[i + 8 * j] = col[i];
+        wave_sync();
+        TGP_UNROLL for (int k = 0; k < D; ++k) row[k] = act ? tile[j + 8 * k] : 0.0;   // rows >= D of the tile are never written
+    }
+    // column j of A S A' + Q for symmetric S given by its column j
+    __device__ __forceinline__ void congruence(double* Sc, const double* Qc) const {
+        double W[D], row[D];
+        mul_A(Sc, W);
+        transpose(W, row);
+        mul_A(row, Sc);
+        TGP_UNROLL for (int i = 0; i < D; ++i) Sc[i] += Qc[i];
+    }
+};
+
+// observation stream of a group: 8 consecutive processing steps are loaded by the 8 lanes (one coalesced 64-byte row
+// per group) and handed out step by step with a shuffle
+struct GroupObs {
+    double yv, rv;
+    int mv_;
+    __device__ __forceinline__ void load(const ModelView& mv, int64_t c, int L0, int64_t r0, int64_t r1, int g, int j) {
+        const int64_t r = r0 + g + j;
+        yv = 0.0;
+        rv = 0.0;
+        mv_ = 0;
+        if (r < r1) {
+            const int64_t tm = micro_index(mv, c, g + j, L0);
+            yv = mv.y[tm];
+            if (mv.sR != 0) rv = mv.R[tm];
+            if (mv.missing != nullptr) mv_ = mv.missing[tm];
+        }
+    }
+    __device__ __forceinline__ void step(const ModelView& mv, double Rshared, int k, double& y, double& R, bool& miss) const {
+        y = __shfl(yv, k, 8);
+        R = mv.sR != 0 ? __shfl(rv, k, 8) : Rshared;
+        miss = __shfl(mv_, k, 8) != 0;
+        if (miss) { y = 0.0; R = kLargeVar; }
+    }
+};
+
+template <int D> __device__ __forceinline__ void group_setup(const ModelView& mv, double* sA, double* tiles, GroupLane<D>& gl, double* Qc,
+                                                             double* H, double& aj, double& hh, double& Rsh) {
+    const int tid = threadIdx.x;
+    if (tid < 64) {
+        const int i = tid & 7, k = tid >> 3;
+        sA[tid] = (i < D && k < D) ? mv.A[i + k * D] : 0.0;
+    }
+    __syncthreads();
+    gl.j = tid & 7;
+    gl.act = gl.j < D;
+    gl.tile = tiles + (tid >> 3) * kGroupTileLD;
+    gl.sA = sA;
+    const int jc = gl.act ? gl.j : 0;
+    TGP_UNROLL for (int i = 0; i < D; ++i) { Qc[i] = gl.act ? mv.Q[i + jc * D] : 0.0; H[i] = mv.H[i]; }
+    aj = gl.act ? mv.a[jc] : 0.0;
+    hh = mv.h[0];
+    Rsh = mv.sR == 0 ? mv.R[0] : 0.0;
+}
+
+// ---------------------------------------------------------------- pass 1: the chunk's filter element
+template <int D>
+__global__ __launch_bounds__(256) void k_group_reduce_filter(ModelView mv, int L0, int64_t n0, double* __restrict__ E0) {
+    __shared__ double sA[64];
+    __shared__ double tiles[kGroupsPerBlock * kGroupTileLD];
+    GroupLane<D> gl;
+    double Qc[D], H[D], aj, hh, Rsh;
+    group_setup<D>(mv, sA, tiles, gl, Qc, H, aj, hh, Rsh);
+    const int j = gl.j;
+    const int64_t c = (int64_t)blockIdx.x * kGroupsPerBlock + (threadIdx.x >> 3);
+    int64_t r0, r1;
+    chunk_range(mv, c < n0 ? c : n0, L0, r0, r1);
+    // element: identity
+    double Ac[D], Cc[D], Jc[D], bj = 0.0, etaj = 0.0;
+    TGP_UNROLL for (int i = 0; i < D; ++i) { Ac[i] = (i == j) ? 1.0 : 0.0; Cc[i] = 0.0; Jc[i] = 0.0; }
+    double Hj = 0.0;
+    TGP_UNROLL for (int i = 0; i < D; ++i) Hj = (i == j) ? H[i] : Hj;
+    GroupObs ob;
+    for (int g = 0; g < L0; g += 8) {
+        ob.load(mv, c, L0, r0, r1, g, j);
+        const int64_t rg = r0 + g;
+        const int gend = (int)((r1 - rg) < 8 ? (r1 - rg) : 8);
+        for (int k = 0; k < gend; ++k) {
+            double y, R;
+            bool miss;
+            ob.step(mv, Rsh, k, y, R, miss);
+            const bool do_predict = !(mv.ordering != 0 && (rg + k) == 0);
+            if (do_predict) {
+                double T1[D];
+                gl.mul_A(Ac, T1);                       // Abar <- A Abar
+                TGP_UNROLL for (int i = 0; i < D; ++i) Ac[i] = T1[i];
+                bj = gl.mul_A_vec(bj) + aj;             // b <- A b + a
+                gl.congruence(Cc, Qc);                  // C <- A C A' + Q
+            }
+            double wj = 0.0, cvj = 0.0;                 // w = Abar' H, Cv = C H
+            TGP_UNROLL for (int i = 0; i < D; ++i) { wj = fma(Ac[i], H[i], wj); cvj = fma(Cc[i], H[i], cvj); }
+            const double s = R + group_sum(Hj * cvj);
+            const double r = (y - hh) - group_sum(Hj * bj);
+            const double is = 1.0 / s;
+            etaj = fma(wj, r * is, etaj);
+            bj = fma(cvj, r * is, bj);
+            double w[D], Cv[D];
+            gl.gather2(wj, cvj, w, Cv);
+            TGP_UNROLL for (int i = 0; i < D; ++i) {
+                Jc[i] = fma(w[i] * is, wj, Jc[i]);
+                Ac[i] = fma(-Cv[i] * is, wj, Ac[i]);
+                Cc[i] = fma(-Cv[i] * is, cvj, Cc[i]);
+            }
+        }
+    }
+    if (c < n0 && r1 > r0 && gl.act) {
+        constexpr int DD = D * D, DS = Dim<D>::DS;
+        TGP_UNROLL for (int i = 0; i < D; ++i) E0[(int64_t)(i + j * D) * n0 + c] = Ac[i];
+        E0[(int64_t)(DD + j) * n0 + c] = bj;
+        E0[(int64_t)(DD + D + DS + j) * n0 + c] = etaj;
+        TGP_UNROLL for (int i = 0; i < D; ++i)
+            if (i <= j) {
+                E0[(int64_t)(DD + D + j * (j + 1) / 2 + i) * n0 + c] = Cc[i];
+                E0[(int64_t)(DD + 2 * D + DS + j * (j + 1) / 2 + i) * n0 + c] = Jc[i];
+            }
+    }
+}
+
+// ---------------------------------------------------------------- pass 2, logpdf: filter from the chunk's carry-in state
+template <int D>
+__global__ __launch_bounds__(256) void k_group_apply_logpdf(ModelView mv, int L0, int64_t n0, const double* __restrict__ S0,
+                                                            double* __restrict__ partial) {
+    __shared__ double sA[64];
+    __shared__ double tiles[kGroupsPerBlock * kGroupTileLD];
+    __shared__ double sh[12];
+    GroupLane<D> gl;
+    double Qc[D], H[D], aj, hh, Rsh;
+    group_setup<D>(mv, sA, tiles, gl, Qc, H, aj, hh, Rsh);
+    const int j = gl.j;
+    const int64_t c = (int64_t)blockIdx.x * kGroupsPerBlock + (threadIdx.x >> 3);
+    int64_t r0, r1;
+    chunk_range(mv, c < n0 ? c : n0, L0, r0, r1);
+    double Pc[D], mj = 0.0;
+    TGP_UNROLL for (int i = 0; i < D; ++i) Pc[i] = (i == j) ? 1.0 : 0.0;
+    if (c < n0 && gl.act) {
+        mj = S0[(int64_t)j * n0 + c];
+        TGP_UNROLL for (int i = 0; i < D; ++i) {
+            const int lo = i < j ? i : j, hi = i < j ? j : i;
+            Pc[i] = S0[(int64_t)(D + hi * (hi + 1) / 2 + lo) * n0 + c];
+        }
+    }
+    double Hj = 0.0;
+    TGP_UNROLL for (int i = 0; i < D; ++i) Hj = (i == j) ? H[i] : Hj;
+    double lml = 0.0, nmiss = 0.0;
+    bool ok = true;
+    GroupObs ob;
+    for (int g = 0; g < L0; g += 8) {
+        ob.load(mv, c, L0, r0, r1, g, j);
+        const int64_t rg = r0 + g;
+        const int gend = (int)((r1 - rg) < 8 ? (r1 - rg) : 8);
+        double sprod = 1.0, quad = 0.0;
+        for (int k = 0; k < gend; ++k) {
+            double y, R;
+            bool miss;
+            ob.step(mv, Rsh, k, y, R, miss);
+            const bool do_predict = !(mv.ordering != 0 && (rg + k) == 0);
+            if (do_predict) {
+                mj = gl.mul_A_vec(mj) + aj;             // m <- A m + a
+                gl.congruence(Pc, Qc);                  // P <- A P A' + Q
+            }
+            double vj = 0.0;                            // V = P H
+            TGP_UNROLL for (int i = 0; i < D; ++i) vj = fma(Pc[i], H[i], vj);
+            const double S = group_sum(Hj * vj) + R;
+            const double hm = group_sum(Hj * mj);
+            ok = ok && (S > 0.0);
+            const double iS = 1.0 / S;
+            const double v = y - (hm + hh);
+            const double viS = v * iS;
+            mj = fma(vj, viS, mj);
+            double V[D];
+            gl.gather(vj, V);
+            const double wgt = vj * iS;
+            TGP_UNROLL for (int i = 0; i < D; ++i) Pc[i] = fma(-V[i], wgt, Pc[i]);
+            quad += v * viS;
+            sprod *= S;
+            if (sprod > 1e100 || sprod < 1e-100) {
+                lml -= 0.5 * log(sprod);
+                sprod = 1.0;
+            }
+            nmiss += miss ? 1.0 : 0.0;
+        }
+        if (gend > 0) lml -= 0.5 * (gend * kLog2Pi + log(sprod) + quad);
+    }
+    // every lane of a group holds the same (lml, nmiss, ok): lane 0 of each group contributes
+    double a = (j == 0 && c < n0) ? lml : 0.0, b = (j == 0 && c < n0) ? nmiss : 0.0;
+    int bad = (j == 0 && c < n0 && !ok) ? 1 : 0;
+    block_sum3(a, b, bad, sh);
+    if (threadIdx.x == 0) {
+        partial[3 * (int64_t)blockIdx.x + 0] = a;
+        partial[3 * (int64_t)blockIdx.x + 1] = b;
+        partial[3 * (int64_t)blockIdx.x + 2] = (double)bad;
+    }
+}
+
+}  // namespace TGP_NS

@@ -3,6 +3,7 @@
 // therefore only used after it has reproduced the out-of-line build's results in the run-time variant check.
 #define TGP_NS tgp_i
 #define TGP_BIG_D 99
+#define TGP_NO_GROUP
 #define TGP_TABLE_SUFFIX _i
 #define TGP_D 6
 #include "tgp_inst.inc"

@@ -3,6 +3,7 @@
 // d = 5, 6 inlined builds they are only used after reproducing the out-of-line build in the run-time variant check.
 #define TGP_NS tgp_i
 #define TGP_BIG_D 99
+#define TGP_NO_GROUP
 #define TGP_TABLE_SUFFIX _i
 #define TGP_AD_SCAN_FROM_SAFE
 #include "tgp_inst.inc"

@@ -602,6 +602,9 @@ struct KernelTable {
     // host-side monoid operations on packed elements / states (m (d), P (d*d))
     int (*host_apply)(int kind, const double* elem, const double* m, const double* P, double* m_out, double* P_out);
     int (*host_combine)(int kind, const double* earlier, const double* later, double* out);
+    // group-per-chunk kernels (tgp_group.hpp; d = 5..8, LTI, scalar observations; NULL otherwise): 32 chunks per block
+    void (*group_reduce_filter)(const ModelView&, int L0, int64_t n0, double* E0, hipStream_t);
+    void (*group_apply_logpdf)(const ModelView&, int L0, int64_t n0, const double* S0, double* partial, hipStream_t);
     void scan_reduce(int monoid, const double* Ein, int64_t n, double* Ehi, int64_t nhi, hipStream_t s) const {
         scan_reduce_c[monoid == kFilter ? kScanFilter : monoid == kFilterAD ? kScanAD : kScanAffine](monoid, Ein, n, Ehi, nhi, s);
     }
@@ -618,3 +621,5 @@ struct KernelTable {
 const KernelTable* kernel_table(int d);
 
 }  // namespace TGP_NS
+
+#include "tgp_group.hpp"
