@@ -1,0 +1,68 @@
+"""GPU tier: the group-per-chunk logpdf kernels (tgp_group.hpp; eight lanes per chunk, d = 5..8, LTI family) forced on
+(TGP_OPT_GROUP = 2) against the oracle: random non-symmetric-free LTI models (shared A, a, Q, H, h), shared and per-step
+noise, missing data, both orderings, ragged chunk sizes and multi-level scans. Tolerance as in test_gpu_parity.py."""
+import numpy as np
+import pytest
+
+from oracle import lgssm_ref as ref
+from tests import _util as U
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tgp():
+    import temporalgps_jl_amd as t
+    t._lib.load()
+    return t
+
+
+@pytest.mark.parametrize("d", [5, 6, 7, 8])
+@pytest.mark.parametrize("ordering", ["F", "R"])
+@pytest.mark.parametrize("per_step_R", [False, True])
+def test_group_logpdf_equals_oracle(tgp, d, ordering, per_step_R):
+    rng = np.random.default_rng(17 * d + (ordering == "R") + 2 * per_step_R)
+    T = 1203
+    model = U.random_lgssm(rng, False, d, T, ordering)
+    if per_step_R:
+        model["R"] = rng.random(T) + 0.1
+    eps = (rng.standard_normal((T, d)), rng.standard_normal(T), rng.standard_normal(d))
+    y = ref.rand(model, *eps)
+    tr = tgp.GaussMarkovModel(tgp.Forward if ordering == "F" else tgp.Reverse, model["A"], model["a"], model["Q"],
+                              tgp.Gaussian(model["x0m"], model["x0P"]))
+    dm = tgp.LGSSM(tr, tgp.ScalarOutputLGC(model["H"], model["h"], model["R"]), T=T)
+    hd = dm.handle()
+    hd.set_option(tgp._lib.OPT_GROUP, 2)
+    lp = ref.logpdf(model, y)
+    missing = rng.random(T) < 0.3
+    lpm = ref.logpdf_missing(model, y, missing)
+    ym = y.copy()
+    ym[missing] = np.nan
+    for chunk in (0, 3, 8, 13, 64):          # 0 = auto; 3 / 13: ragged IO groups; small chunks: two and three scan levels
+        hd.set_option(tgp._lib.OPT_CHUNK, chunk)
+        assert abs(tgp.logpdf(dm, y) - lp) <= 1e-10 * abs(lp), chunk
+        assert abs(tgp.logpdf(dm, ym) - lpm) <= 1e-10 * abs(lpm), chunk
+    # the other operations of the same handle keep using the lane-per-chunk kernels
+    fm, fP = ref.filter_(model, y)
+    m, P = tgp._filter(dm, y)
+    np.testing.assert_allclose(m, fm, rtol=1e-8, atol=1e-9)
+    assert abs(tgp.logpdf(dm, y) - lp) <= 1e-10 * abs(lp)
+
+
+def test_group_path_is_selected_for_d8(tgp):
+    """the run-time check accepts the group kernels and logpdf of a d = 8 LTI model runs through them by default"""
+    rng = np.random.default_rng(1)
+    T, d = 20000, 8
+    model = U.random_lgssm(rng, False, d, T)
+    y = rng.standard_normal(T)
+    tr = tgp.GaussMarkovModel(tgp.Forward, model["A"], model["a"], model["Q"], tgp.Gaussian(model["x0m"], model["x0P"]))
+    dm = tgp.LGSSM(tr, tgp.ScalarOutputLGC(model["H"], model["h"], model["R"]), T=T)
+    hd = dm.handle()
+    hd.set_option(tgp._lib.OPT_PROFILE, 1)
+    hd.profile_reset()
+    lp = tgp.logpdf(dm, y)
+    names = set(hd.profile())
+    hd.set_option(tgp._lib.OPT_PROFILE, 0)
+    assert "k_group_reduce_filter<lti>" in names and "k_group_apply_filter<lti,logpdf>" in names, names
+    lp_ref = ref.logpdf(model, y)
+    assert abs(lp - lp_ref) <= 1e-10 * abs(lp_ref)
