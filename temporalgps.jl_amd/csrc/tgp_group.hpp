@@ -18,7 +18,7 @@ namespace TGP_NS {
 
 constexpr int kGroup = 8;                  // lanes per chunk
 constexpr int kGroupsPerBlock = 32;        // 256 threads
-constexpr int kGroupTileLD = 66;           // doubles per group tile: 8 x 8 + 2 (8 groups of a wave on distinct banks)
+constexpr int kGroupTileLD = 82;           // doubles per group tile: 8 x 8 matrix + two 8-vectors + 2 (the 8 groups of a wave on distinct banks)
 
 __device__ __forceinline__ double group_sum(double x) {
     x += __shfl_xor(x, 1, 8);
@@ -29,53 +29,50 @@ __device__ __forceinline__ double group_sum(double x) {
 
 template <int D> struct GroupLane {
     int j;                   // lane inside the group == matrix column it owns
-    double* tile;            // the group's LDS tile [8][8] (+ pad)
-    const double* sA;        // A in LDS, [i + 8 k]
+    double* tile;            // the group's LDS tile: [0, 64) an 8 x 8 matrix (i + 8 col), [64, 72) and [72, 80) two vectors
+    const double* sA;        // A in LDS, row-major [8 i + k] (a row is read with 16-byte loads, broadcast to the wave)
     bool act;                // j < D
     // y[:, j] = A x[:, j]
     __device__ __forceinline__ void mul_A(const double* x, double* y) const {
         TGP_UNROLL for (int i = 0; i < D; ++i) {
             double acc = 0.0;
-            TGP_UNROLL for (int k = 0; k < D; ++k) acc = fma(sA[i + 8 * k], x[k], acc);
+            TGP_UNROLL for (int k = 0; k < D; ++k) acc = fma(sA[8 * i + k], x[k], acc);
             y[i] = acc;
         }
-    }
-    // (A v)_j for a vector whose element j lives in lane j
-    __device__ __forceinline__ double mul_A_vec(double vj) const {
-        double v[D];
-        gather(vj, v);
-        double acc = 0.0;
-        TGP_UNROLL for (int k = 0; k < D; ++k) acc = fma(sA[(j & 7) + 8 * k], v[k], acc);
-        return acc;
     }
     // every lane gets all D elements of a vector distributed one element per lane
     __device__ __forceinline__ void gather(double vj, double* v) const {
         wave_sync();
-        tile[j] = vj;
+        tile[64 + j] = vj;
         wave_sync();
-        TGP_UNROLL for (int k = 0; k < D; ++k) v[k] = tile[k];
+        TGP_UNROLL for (int k = 0; k < D; ++k) v[k] = tile[64 + k];
     }
     __device__ __forceinline__ void gather2(double vj, double wj, double* v, double* w) const {
         wave_sync();
-        tile[j] = vj;
-        tile[8 + j] = wj;
+        tile[64 + j] = vj;
+        tile[72 + j] = wj;
         wave_sync();
-        TGP_UNROLL for (int k = 0; k < D; ++k) { v[k] = tile[k]; w[k] = tile[8 + k]; }
+        TGP_UNROLL for (int k = 0; k < D; ++k) { v[k] = tile[64 + k]; w[k] = tile[72 + k]; }
     }
-    // col = column j of W  ->  row[k] = W[j, k]
-    __device__ __forceinline__ void transpose(const double* col, double* row) const {
-        wave_sync();
-        TGP_UNROLL for (int i = 0; i < D; ++i) tile[i + 8 * j] = col[i];
-        wave_sync();
-        TGP_UNROLL for (int k = 0; k < D; ++k) row[k] = act ? tile[j + 8 * k] : 0.0;   // rows >= D of the tile are never written
-    }
-    // column j of A S A' + Q for symmetric S given by its column j
-    __device__ __forceinline__ void congruence(double* Sc, const double* Qc) const {
-        double W[D], row[D];
+    // One exchange for a whole predict:  v <- A v + a  (element j of v in lane j)  and  S <- A S A' + Q  (symmetric S by
+    // columns): W = A S is lane-local, its transpose and the gather of v share ONE trip through the tile, then column j of
+    // A S A' is A (row j of W)'.
+    __device__ __forceinline__ void predict(double& vj, double aj, double* Sc, const double* Qc) const {
+        double W[D], row[D], v[D];
         mul_A(Sc, W);
-        transpose(W, row);
+        wave_sync();
+        TGP_UNROLL for (int i = 0; i < D; ++i) tile[i + 8 * j] = W[i];
+        tile[64 + j] = vj;
+        wave_sync();
+        TGP_UNROLL for (int k = 0; k < D; ++k) {
+            row[k] = act ? tile[j + 8 * k] : 0.0;      // rows >= D of the tile are never written
+            v[k] = tile[64 + k];
+        }
         mul_A(row, Sc);
         TGP_UNROLL for (int i = 0; i < D; ++i) Sc[i] += Qc[i];
+        double acc = 0.0;
+        TGP_UNROLL for (int k = 0; k < D; ++k) acc = fma(sA[8 * (j & 7) + k], v[k], acc);
+        vj = acc + aj;
     }
 };
 
@@ -108,7 +105,7 @@ template <int D> __device__ __forceinline__ void group_setup(const ModelView& mv
                                                              double* H, double& aj, double& hh, double& Rsh) {
     const int tid = threadIdx.x;
     if (tid < 64) {
-        const int i = tid & 7, k = tid >> 3;
+        const int i = tid >> 3, k = tid & 7;
         sA[tid] = (i < D && k < D) ? mv.A[i + k * D] : 0.0;
     }
     __syncthreads();
@@ -126,7 +123,7 @@ template <int D> __device__ __forceinline__ void group_setup(const ModelView& mv
 // ---------------------------------------------------------------- pass 1: the chunk's filter element
 template <int D>
 __global__ __launch_bounds__(256) void k_group_reduce_filter(ModelView mv, int L0, int64_t n0, double* __restrict__ E0) {
-    __shared__ double sA[64];
+    __shared__ __attribute__((aligned(16))) double sA[64];
     __shared__ double tiles[kGroupsPerBlock * kGroupTileLD];
     GroupLane<D> gl;
     double Qc[D], H[D], aj, hh, Rsh;
@@ -154,8 +151,7 @@ __global__ __launch_bounds__(256) void k_group_reduce_filter(ModelView mv, int L
                 double T1[D];
                 gl.mul_A(Ac, T1);                       // Abar <- A Abar
                 TGP_UNROLL for (int i = 0; i < D; ++i) Ac[i] = T1[i];
-                bj = gl.mul_A_vec(bj) + aj;             // b <- A b + a
-                gl.congruence(Cc, Qc);                  // C <- A C A' + Q
+                gl.predict(bj, aj, Cc, Qc);             // b <- A b + a ; C <- A C A' + Q
             }
             double wj = 0.0, cvj = 0.0;                 // w = Abar' H, Cv = C H
             TGP_UNROLL for (int i = 0; i < D; ++i) { wj = fma(Ac[i], H[i], wj); cvj = fma(Cc[i], H[i], cvj); }
@@ -190,7 +186,7 @@ __global__ __launch_bounds__(256) void k_group_reduce_filter(ModelView mv, int L
 template <int D>
 __global__ __launch_bounds__(256) void k_group_apply_logpdf(ModelView mv, int L0, int64_t n0, const double* __restrict__ S0,
                                                             double* __restrict__ partial) {
-    __shared__ double sA[64];
+    __shared__ __attribute__((aligned(16))) double sA[64];
     __shared__ double tiles[kGroupsPerBlock * kGroupTileLD];
     __shared__ double sh[12];
     GroupLane<D> gl;
@@ -225,8 +221,7 @@ __global__ __launch_bounds__(256) void k_group_apply_logpdf(ModelView mv, int L0
             ob.step(mv, Rsh, k, y, R, miss);
             const bool do_predict = !(mv.ordering != 0 && (rg + k) == 0);
             if (do_predict) {
-                mj = gl.mul_A_vec(mj) + aj;             // m <- A m + a
-                gl.congruence(Pc, Qc);                  // P <- A P A' + Q
+                gl.predict(mj, aj, Pc, Qc);             // m <- A m + a ; P <- A P A' + Q
             }
             double vj = 0.0;                            // V = P H
             TGP_UNROLL for (int i = 0; i < D; ++i) vj = fma(Pc[i], H[i], vj);
