@@ -274,3 +274,34 @@ def test_approx_periodic_default_kernel(tgp):
     mo, vo = oc.posterior_marginals(spec, ("regular", 0.0, 0.13, N), 0.1, y, None, 0.05)
     np.testing.assert_allclose(m, mo, rtol=1e-7, atol=1e-7)
     np.testing.assert_allclose(sd ** 2, vo, rtol=1e-7, atol=1e-8)
+
+
+@pytest.mark.parametrize("T", [1, 2, 7, 8, 9])
+@pytest.mark.parametrize("d", [1, 3, 6, 8, 11])
+def test_tiny_series(tgp, T, d):
+    """degenerate lengths: one step, fewer steps than an IO group, exactly / just over one group -- every operation"""
+    rng = np.random.default_rng(1000 * T + d)
+    for tv in (False, True):
+        model = U.random_lgssm(rng, tv, d, T)
+        eps = (rng.standard_normal((T, d)), rng.standard_normal(T), rng.standard_normal(d))
+        check_all(tgp, model, ref.rand(model, *eps), eps)
+
+
+def test_all_missing_equals_prior(tgp):
+    """every observation missing: logpdf is the pure volume compensation (missings.jl:45-53 with innovations of y := 0 under
+    variance 1e15), the posterior marginals are the prior marginals"""
+    rng = np.random.default_rng(5)
+    T, d = 5000, 3
+    model = U.random_lgssm(rng, False, d, T)
+    y = rng.standard_normal(T)
+    missing = np.ones(T, dtype=bool)
+    dm = to_device_model(tgp, model)
+    yin = np.full(T, np.nan)
+    lp = ref.logpdf_missing(model, y, missing)
+    # the value is ~0: -T log(2 pi 1e15)/2 from the steps cancels against the compensation; compare on the scale of the terms
+    assert abs(tgp.logpdf(dm, yin) - lp) <= 1e-12 * T * np.log(2 * np.pi * 1e15) / 2
+    Rn = np.full(T, 0.3)
+    pm, pv = tgp.posterior_marginals(dm, yin, Rn)
+    mm, mC = ref.marginals(ref.replace_observation_noise_cov(model, Rn))
+    np.testing.assert_allclose(pm, mm, rtol=1e-7, atol=1e-8)
+    np.testing.assert_allclose(pv, mC, rtol=1e-7, atol=1e-8)
