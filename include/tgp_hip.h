@@ -116,6 +116,17 @@ int tgp_logpdf_grad(tgp_handle* h, const double* y, const uint8_t* missing, uint
                     const double* dA, const double* da, const double* dQ, const double* dH, const double* dh,
                     const double* dR, const double* dx0m, const double* dx0P, double* lml_out, double* grad_out);
 
+/* ---- the same for a model described by its SDE (tgp_model_set_sde: irregular spacing), d <= 4: the tangents of the per-step
+ *      A_k = exp(F dt_k), Q_k = Pinf - A_k Pinf A_k' are built ON THE DEVICE from the tangents of F and Pinf -- dA_k by a central
+ *      difference of the in-register exponential (relative step rel_step, 0 => 1e-6), dQ_k by the product rule -- into a
+ *      tangent copy of the tiled transition record; the dual-number scan then runs in the general layout.
+ *      dF, dPinf [nparams][d*d]; dA1, dQ1 [nparams][d*d] tangents of the explicit first transition (NULL if the model has
+ *      none); da, dH [nparams][d]; dh, dR [nparams] (dR must be 0 for a per-step noise variance); dx0m, dx0P as above. */
+int tgp_logpdf_grad_sde(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t flags, int nparams, const double* dF,
+                        const double* dPinf, const double* dA1, const double* dQ1, const double* da, const double* dH,
+                        const double* dh, const double* dR, const double* dx0m, const double* dx0P, double rel_step,
+                        double* lml_out, double* grad_out);
+
 /* ---- _filter(model, y): lgssm.jl:171-187. m_out [T][d], P_out [T][d*d] (either may be NULL);
  *      lml_out (host, may be NULL) receives the log marginal likelihood as a by-product. */
 int tgp_filter(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t flags, double* m_out,

@@ -41,6 +41,7 @@ _SIGS = {
     "tgp_model_set_x0": (ctypes.c_int, [_vp, _vp, _vp]),
     "tgp_logpdf": (ctypes.c_int, [_vp, _vp, _vp, _u32, _dp]),
     "tgp_logpdf_grad": (ctypes.c_int, [_vp, _vp, _vp, _u32, ctypes.c_int] + [_vp] * 8 + [_dp, _vp]),
+    "tgp_logpdf_grad_sde": (ctypes.c_int, [_vp, _vp, _vp, _u32, ctypes.c_int] + [_vp] * 10 + [ctypes.c_double, _dp, _vp]),
     "tgp_filter": (ctypes.c_int, [_vp, _vp, _vp, _u32, _vp, _vp, _dp]),
     "tgp_posterior": (ctypes.c_int, [_vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp, _vp]),
     "tgp_posterior_marginals": (ctypes.c_int, [_vp, _vp, _vp, _vp, _u32, _vp, _vp, _dp]),

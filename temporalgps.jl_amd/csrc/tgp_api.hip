@@ -6,6 +6,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <string>
@@ -225,7 +226,7 @@ struct tgp_handle {
     DevBuf by, bmiss, bRnew, beps_t, beps_e, bo1, bo2, bo3;
     // scans and scratch
     ScanCtx F, Rv, Fad;
-    DevBuf btan, bx0ad;
+    DevBuf btan, bx0ad, tile_tan;
     DevBuf fs, partial, result, segtmp;
     double* host_result = nullptr;  // pinned, 8 doubles: [0] lml [1] nmiss [2] filter-bad ; int flags at [4]
     int64_t opt_chunk = 0;
@@ -701,7 +702,7 @@ int tgp_destroy(tgp_handle* h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     for (DevBuf* b : {&h->bA, &h->ba, &h->bQ, &h->bH, &h->bh, &h->bR, &h->bx0, &h->bx0r, &h->bx0fold, &h->by, &h->bmiss, &h->bRnew, &h->beps_t,
-                      &h->beps_e, &h->bo1, &h->bo2, &h->bo3, &h->F.slab, &h->Rv.slab, &h->fs, &h->partial, &h->result, &h->segtmp, &h->tile_t, &h->tile_e, &h->Fad.slab, &h->btan, &h->bx0ad, &h->bF, &h->bPinf, &h->btimes, &h->bAQ1})
+                      &h->beps_e, &h->bo1, &h->bo2, &h->bo3, &h->F.slab, &h->Rv.slab, &h->fs, &h->partial, &h->result, &h->segtmp, &h->tile_t, &h->tile_e, &h->Fad.slab, &h->btan, &h->bx0ad, &h->tile_tan, &h->bF, &h->bPinf, &h->btimes, &h->bAQ1})
         b->release();
     for (auto& e : h->ev)
         if (e) (void)hipEventDestroy(e);
@@ -1170,19 +1171,125 @@ int tgp_logpdf_grad(tgp_handle* h, const double* y, const uint8_t* missing, uint
         mv.dR = t;
         {
             LaunchScope ls(h, "k_reduce_filter<lti,grad>");
-            h->kt->reduce_filter_ad(mv, h->L0, h->n0, h->Fad.E[0], h->stream);
+            (void)h->kt->reduce_filter_ad(true, mv, h->L0, h->n0, h->Fad.E[0], h->stream);
         }
         scan_up(h, h->Fad);
         scan_down(h, h->Fad, h->bx0ad.d() + (size_t)k * 2 * ns);
         {
             LaunchScope ls(h, "k_apply_filter<lti,grad>");
-            h->kt->apply_filter_ad(mv, h->L0, h->n0, h->Fad.S[0], h->partial.d(), h->stream);
+            (void)h->kt->apply_filter_ad(true, mv, h->L0, h->n0, h->Fad.S[0], h->partial.d(), h->stream);
         }
         {
             LaunchScope ls(h, "k_finalize<grad>");
             hipLaunchKernelGGL(k_finalize_ad, dim3(1), dim3(256), 0, h->stream, h->partial.d(), nblocks, h->result.d());
         }
         if (k + 1 < nparams) {   // results of this parameter, then reuse the result block for the next one
+            HIPCHK(hipMemcpyAsync(h->host_result, h->result.p, 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            grad_out[k] = h->host_result[3];
+            if (h->host_result[2] != 0.0) rc = h->fail(TGP_ENOTPD, "innovation variance not positive");
+        }
+    }
+    tm.kernels_done();
+    int rc2 = tm.finish(lml_out);
+    grad_out[nparams - 1] = h->host_result[3];
+    return rc != TGP_OK ? rc : rc2;
+}
+
+int tgp_logpdf_grad_sde(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t flags, int nparams, const double* dF,
+                        const double* dPinf, const double* dA1, const double* dQ1, const double* da, const double* dH, const double* dh,
+                        const double* dR, const double* dx0m, const double* dx0P, double rel_step, double* lml_out, double* grad_out) {
+    TRY(check_ready(h));
+    if (nparams < 1 || !grad_out) return h->fail(TGP_EINVAL, "nparams must be >= 1 and grad_out non-null");
+    if (!dF || !dPinf || !da || !dH || !dh || !dR || !dx0m || !dx0P) return h->fail(TGP_EINVAL, "null tangent array");
+    if (!h->sde || h->p != 1 || h->ordering != 0 || h->mv.sH != 0 || h->mv.sh != 0)
+        return h->fail(TGP_EUNSUPPORTED, "tgp_logpdf_grad_sde: Forward model set with tgp_model_set_sde, shared H and h, scalar observations");
+    if (h->d > 4) return h->fail(TGP_EUNSUPPORTED, "tgp_logpdf_grad_sde: d <= 4 (the dual-number kernels of the general layout are built for d <= 4)");
+    if (h->have_AQ1 && (!dA1 || !dQ1)) return h->fail(TGP_EINVAL, "the model has an explicit first transition: dA1 / dQ1 are needed");
+    if (!(rel_step > 0.0)) rel_step = 1e-6;
+    const int d = h->d, dd = d * d, per = 4 * dd + 2 * d + 2;   // dF, dPinf, dA1, dQ1, da, dH, dh, dR of one parameter
+    CallTimer tm(h);
+    TRY(set_obs(h, y, missing, flags));
+    std::vector<double> host((size_t)nparams * per, 0.0), eps(nparams);
+    for (int k = 0; k < nparams; ++k) {
+        double* q = host.data() + (size_t)k * per;
+        std::memcpy(q, dF + (size_t)k * dd, dd * sizeof(double));
+        double nd = 0.0;
+        for (int i = 0; i < dd; ++i) nd += q[i] * q[i];
+        nd = std::sqrt(nd);
+        eps[k] = nd > 0.0 ? rel_step * std::max(1.0, h->normF) / nd : 1.0;    // F +- eps dF is a RELATIVE perturbation of size rel_step
+        q += dd;
+        std::memcpy(q, dPinf + (size_t)k * dd, dd * sizeof(double)); q += dd;
+        if (dA1) std::memcpy(q, dA1 + (size_t)k * dd, dd * sizeof(double));
+        q += dd;
+        if (dQ1) std::memcpy(q, dQ1 + (size_t)k * dd, dd * sizeof(double));
+        q += dd;
+        std::memcpy(q, da + (size_t)k * d, d * sizeof(double)); q += d;
+        std::memcpy(q, dH + (size_t)k * d, d * sizeof(double)); q += d;
+        *q++ = dh[k];
+        *q++ = dR[k];
+        if (h->mv.sR != 0 && dR[k] != 0.0) return h->fail(TGP_EUNSUPPORTED, "tgp_logpdf_grad_sde: a per-step noise variance has no tangent (dR must be 0)");
+    }
+    HIPCHK(h->btan.ensure(host.size() * sizeof(double)));
+    HIPCHK(hipMemcpyAsync(h->btan.p, host.data(), host.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    const int ns = state_size(d);
+    std::vector<double> x0ad((size_t)nparams * 2 * ns), pv, pt;
+    for (int k = 0; k < nparams; ++k) {
+        pack_state(d, h->x0m.data(), h->x0P.data(), pv);
+        pack_state(d, dx0m + (size_t)k * d, dx0P + (size_t)k * dd, pt);
+        for (int i = 0; i < ns; ++i) {
+            x0ad[(size_t)k * 2 * ns + 2 * i] = pv[i];
+            x0ad[(size_t)k * 2 * ns + 2 * i + 1] = pt[i];
+        }
+    }
+    HIPCHK(h->bx0ad.ensure(x0ad.size() * sizeof(double)));
+    HIPCHK(hipMemcpyAsync(h->bx0ad.p, x0ad.data(), x0ad.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    tm.inputs_done();
+    h->group_active = false;
+    choose_chunk(h);
+    TRY(ensure_tiled(h));                       // the value tile (k_tile_sde) for this chunk size
+    h->reduce_valid = false;
+    h->smoother_valid = false;
+    const int Lt = h->L0;
+    const size_t nblk = (size_t)((h->n0 + 63) / 64) * 64;
+    HIPCHK(h->tile_tan.ensure((nblk * (size_t)Lt * (size_t)h->mv.nc_t + 1) * sizeof(double)));
+    TRY(scan_prepare(h, h->Fad, kFilterAD, h->n0));
+    const int64_t nblocks = (h->n0 + 255) / 256;
+    HIPCHK(h->partial.ensure((size_t)nblocks * 4 * sizeof(double)));
+    int rc = TGP_OK;
+    for (int k = 0; k < nparams && rc == TGP_OK; ++k) {
+        const double* t = h->btan.d() + (size_t)k * per;
+        {
+            LaunchScope ls(h, "k_tile_sde<grad>");
+            h->kt->tile_sde_tan(h->bF.d(), t, h->bPinf.d(), t + dd, h->times_dev, h->have_AQ1 ? t + 2 * dd : nullptr, h->T, Lt, h->n0, h->normF,
+                                eps[k], h->tile_tan.d(), h->stream);
+        }
+        ModelView mv = h->mv;
+        mv.tile_t_tan = h->tile_tan.d();
+        mv.dA = nullptr;                        // A, Q (and their tangents) come from the tiles
+        mv.dQ = nullptr;
+        mv.da = t + 4 * dd;
+        mv.dH = t + 4 * dd + d;
+        mv.dh = t + 4 * dd + 2 * d;
+        mv.dR = t + 4 * dd + 2 * d + 1;
+        bool okk;
+        {
+            LaunchScope ls(h, "k_reduce_filter<per-step,grad>");
+            okk = h->kt->reduce_filter_ad(false, mv, h->L0, h->n0, h->Fad.E[0], h->stream);
+        }
+        if (!okk) return h->fail(TGP_EUNSUPPORTED, "general-layout gradient kernels are not built for this d");
+        scan_up(h, h->Fad);
+        scan_down(h, h->Fad, h->bx0ad.d() + (size_t)k * 2 * ns);
+        {
+            LaunchScope ls(h, "k_apply_filter<per-step,grad>");
+            (void)h->kt->apply_filter_ad(false, mv, h->L0, h->n0, h->Fad.S[0], h->partial.d(), h->stream);
+        }
+        {
+            LaunchScope ls(h, "k_finalize<grad>");
+            hipLaunchKernelGGL(k_finalize_ad, dim3(1), dim3(256), 0, h->stream, h->partial.d(), nblocks, h->result.d());
+        }
+        if (k + 1 < nparams) {
             HIPCHK(hipMemcpyAsync(h->host_result, h->result.p, 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
             HIPCHK(hipStreamSynchronize(h->stream));
             grad_out[k] = h->host_result[3];

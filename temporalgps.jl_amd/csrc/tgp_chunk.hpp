@@ -47,10 +47,15 @@ struct ModelView {
     // Tangents of the SHARED model blocks w.r.t. ONE hyper-parameter (forward-mode gradient pass, namespace
     // tgp::ad); null => zero. Same shapes as A, a, Q, H, h, R above (one block each).
     const double *dA, *da, *dQ, *dH, *dh, *dR;
+    // Tangent of the tiled transition record (general layout, gradient pass): same layout as tile_t; null => zero.
+    const double* tile_t_tan;
 };
 
 TGP_HD void set_real(double& x, const double* v, const double*, int i) { x = v[i]; }
 TGP_HD void set_real(Dual& x, const double* v, const double* d, int i) { x = Dual(v[i], d ? d[i] : 0.0); }
+// element i of a tiled record and of its tangent record (same indexing)
+TGP_HD void tile_real(double& x, const double* v, const double*, int64_t i) { x = v[i]; }
+TGP_HD void tile_real(Dual& x, const double* v, const double* t, int64_t i) { x = Dual(v[i], t ? t[i] : 0.0); }
 
 enum : uint32_t { kTileA = 1u, kTilea = 2u, kTileQ = 4u, kTileH = 8u, kTileh = 16u, kTileR = 32u };
 

@@ -243,6 +243,57 @@ __global__ __launch_bounds__(256) void k_tile_sde(const double* __restrict__ F, 
     }
 }
 
+// Tangent of the tiled SDE transitions along a direction (dF, dPinf) of the model: dA_k = d exp(F dt_k) by a central
+// difference of the SAME in-register exponential (relative step eps; truncation ~eps^2, rounding ~1e-16 / eps), and
+// dQ_k = dPinf - (dA P A' + A dP A' + A P dA') exactly from it. Forward-ordered models (the gradient pass is Forward only).
+template <int D>
+__global__ __launch_bounds__(256) void k_tile_sde_tan(const double* __restrict__ F, const double* __restrict__ dF, const double* __restrict__ Pinf,
+                                                      const double* __restrict__ dPinf, const double* __restrict__ times,
+                                                      const double* __restrict__ dAQ1, int64_t Tt, int Lt, int64_t n0, double normF, double eps,
+                                                      double* __restrict__ tile_tan) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= n0) return;
+    double Fp[D * D], Fm[D * D], F0[D * D], P[D * D], dP[D * D];
+    TGP_UNROLL for (int i = 0; i < D * D; ++i) {
+        F0[i] = F[i];
+        Fp[i] = F[i] + eps * dF[i];
+        Fm[i] = F[i] - eps * dF[i];
+        P[i] = Pinf[i];
+        dP[i] = dPinf[i];
+    }
+    sym_upper<D>(P);
+    sym_upper<D>(dP);
+    constexpr int NC = 2 * D * D;
+    const double inv2e = 0.5 / eps;
+    for (int tl = 0; tl < Lt; ++tl) {
+        const int64_t tt = c * (int64_t)Lt + tl;
+        if (tt >= Tt) break;
+        const int64_t base = fs_index(c, tl, 0, Lt, NC);
+        if (tt == 0 && dAQ1 != nullptr) {
+            TGP_UNROLL for (int k = 0; k < NC; ++k) tile_tan[base + (int64_t)k * 64] = dAQ1[k];
+            continue;
+        }
+        const double dt = (tt == 0) ? 1.0 : times[tt] - times[tt - 1];
+        double A[D * D], Ap[D * D], Am[D * D], dA[D * D], T1[D * D], T2[D * D], S[D * D];
+        expm_scaled<D>(F0, dt, normF, A);
+        expm_scaled<D>(Fp, dt, normF, Ap);
+        expm_scaled<D>(Fm, dt, normF, Am);
+        TGP_UNROLL for (int k = 0; k < D * D; ++k) dA[k] = (Ap[k] - Am[k]) * inv2e;
+        // S = dA P A' + A dP A' + A P dA'
+        mat_mul<D>(dA, P, T1);
+        mat_mul_nt<D>(T1, A, S);
+        mat_mul<D>(A, dP, T1);
+        mat_mul_nt<D>(T1, A, T2);
+        TGP_UNROLL for (int k = 0; k < D * D; ++k) S[k] += T2[k];
+        mat_mul<D>(A, P, T1);
+        mat_mul_nt<D>(T1, dA, T2);
+        TGP_UNROLL for (int k = 0; k < D * D; ++k) {
+            tile_tan[base + (int64_t)k * 64] = dA[k];
+            tile_tan[base + (int64_t)(D * D + k) * 64] = dP[k] - (S[k] + T2[k]);
+        }
+    }
+}
+
 // ---------------------------------------------------------------- block-level scan pieces (256 lanes, one element per lane)
 // Shared by the stand-alone scan kernels below and by the chunk kernels, which fuse the level-0 reduce (pass 1 epilogue)
 // and the level-0 apply (pass 2 prologue): two launches and two trips of the element array through HBM less per scan.
@@ -482,26 +533,26 @@ __device__ __forceinline__ void block_sum_d(double& a, double* sh /* [4] */) {
     if (threadIdx.x == 0) a = ((sh[0] + sh[1]) + (sh[2] + sh[3]));
 }
 
-template <int D>
+template <int D, bool LTI>
 __global__ __launch_bounds__(256) void k_reduce_filter_ad(ModelView mv, int L0, int64_t n0, double* __restrict__ E0) {
     using IO = WaveIO<true, true, false, false, (D <= kPrefetchMaxD)>;
     const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    IO io{mv.y, mv.R, nullptr, nullptr, mv.sR != 0, IO::wave_base(), (int)(threadIdx.x & 63)};
-    ad::chunk_reduce_filter<D, true>(mv, c, L0, io, [=](int k, Dual v) {
+    IO io{mv.y, mv.R, nullptr, nullptr, ad::io_stages_R<LTI>(mv), IO::wave_base(), (int)(threadIdx.x & 63)};
+    ad::chunk_reduce_filter<D, LTI>(mv, c, L0, io, [=](int k, Dual v) {
         E0[(int64_t)(2 * k) * n0 + c] = v.v;
         E0[(int64_t)(2 * k + 1) * n0 + c] = v.d;
     });
 }
 
 // partial[4b + 0..3] = sum lml value, n missing, bad flag, sum lml tangent
-template <int D>
+template <int D, bool LTI>
 __global__ __launch_bounds__(256) void k_apply_filter_ad(ModelView mv, int L0, int64_t n0, const double* __restrict__ S0,
                                                          double* __restrict__ partial) {
     using IO = WaveIO<true, true, false, false, (D <= kPrefetchMaxD)>;
     __shared__ double sh[12];
     __shared__ double sh2[4];
     const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    IO io{mv.y, mv.R, nullptr, nullptr, mv.sR != 0, IO::wave_base(), (int)(threadIdx.x & 63)};
+    IO io{mv.y, mv.R, nullptr, nullptr, ad::io_stages_R<LTI>(mv), IO::wave_base(), (int)(threadIdx.x & 63)};
     ad::State<D> x;
     if (c < n0) {
         ad::load_state<D>(x, [=](int k) { return Dual(S0[(int64_t)(2 * k) * n0 + c], S0[(int64_t)(2 * k + 1) * n0 + c]); });
@@ -510,7 +561,7 @@ __global__ __launch_bounds__(256) void k_apply_filter_ad(ModelView mv, int L0, i
         TGP_UNROLL for (int i = 0; i < D * D; ++i) x.P[i] = Dual((i % (D + 1)) == 0 ? 1.0 : 0.0);
     }
     FilterOut fo{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    ad::ChunkStats cs = ad::chunk_apply_filter<D, true, 0>(mv, c, L0, x, fo, io, [](int, Dual) {});
+    ad::ChunkStats cs = ad::chunk_apply_filter<D, LTI, 0>(mv, c, L0, x, fo, io, [](int, Dual) {});
     double lml = cs.lml.v, nmiss = cs.nmiss, dl = cs.lml.d;
     int bad = cs.bad;
     block_sum3(lml, nmiss, bad, sh);
@@ -591,11 +642,15 @@ struct KernelTable {
     void (*scan_apply_c[3])(int monoid, int bs, const double* Ein, int64_t n, const double* carry, int64_t ncarry, double* S, double* fin,
                             hipStream_t);
     // forward-mode gradient pass (LTI models): elements / states carry (value, tangent) planes
-    void (*reduce_filter_ad)(const ModelView&, int L0, int64_t n0, double* E0, hipStream_t);
-    void (*apply_filter_ad)(const ModelView&, int L0, int64_t n0, const double* S0, double* partial, hipStream_t);
+    // (lti == false: general layout with a tangent tile, built for d <= 4 only -- returns false where it is not)
+    bool (*reduce_filter_ad)(bool lti, const ModelView&, int L0, int64_t n0, double* E0, hipStream_t);
+    bool (*apply_filter_ad)(bool lti, const ModelView&, int L0, int64_t n0, const double* S0, double* partial, hipStream_t);
     // device-side construction of the tiled transitions from time stamps (irregular spacing)
     void (*tile_sde)(const double* F, const double* Pinf, const double* times, const double* AQ1, int64_t Tt, int ordering, int Lt,
                      int64_t n0, double normF, double* tile_t, hipStream_t);
+    // ... and of its tangent along (dF, dPinf): central difference of exp(F dt) in-kernel, product rule for Q
+    void (*tile_sde_tan)(const double* F, const double* dF, const double* Pinf, const double* dPinf, const double* times, const double* dAQ1,
+                         int64_t Tt, int Lt, int64_t n0, double normF, double eps, double* tile_tan, hipStream_t);
     // time-sharded series: fold the per-rank elements of an all-gather onto a state, on the device
     void (*fold)(int monoid, const double* gathered, int64_t slot, int first, int count, int step, const double* x_in, double* x_out,
                  hipStream_t);

@@ -371,6 +371,34 @@ def logpdf_and_grad(model, y, tangents):
     return lml.value, grad
 
 
+def logpdf_and_grad_sde(model, y, tangents, rel_step=1e-6):
+    """The same for a model whose transitions are described by their SDE (SDETransitions: irregular spacing, d <= 4).
+    `tangents`: per parameter, the derivatives of F (d,d), x0P == P_inf (d,d), x0m (d,), H (d,), h (), R () and of the explicit
+    first transition A1, Q1 (d,d) -- missing keys mean zero. The per-step tangents dA_k, dQ_k are formed on the device
+    (tgp_logpdf_grad_sde)."""
+    _check_inputs(model, y[0] if isinstance(y, tuple) else y)
+    if not isinstance(model.transitions, SDETransitions):
+        raise _lib.Unsupported(_lib.EUNSUPPORTED, "logpdf_and_grad_sde needs SDE-described transitions")
+    hd = model.handle()
+    yy, mm, dev = _obs(y, model)
+    d, n = model.dim, len(tangents)
+    get = lambda t, k, shape: np.asarray(t.get(k, np.zeros(shape)), dtype=np.float64).reshape(shape)
+    colmaj = lambda key: np.ascontiguousarray(np.stack([get(t, key, (d, d)).T for t in tangents]))
+    dF, dP, dA1, dQ1 = colmaj("F"), colmaj("x0P"), colmaj("A1"), colmaj("Q1")
+    da = np.zeros((n, d))
+    dH = np.ascontiguousarray(np.stack([get(t, "H", (d,)) for t in tangents]))
+    dh = np.ascontiguousarray(np.array([float(get(t, "h", ())) for t in tangents]))
+    dR = np.ascontiguousarray(np.array([float(get(t, "R", ())) for t in tangents]))
+    dm = np.ascontiguousarray(np.stack([get(t, "x0m", (d,)) for t in tangents]))
+    has1 = model.transitions.A1 is not None
+    lml, grad = ctypes.c_double(), np.zeros(n)
+    hd.check(hd.lib.tgp_logpdf_grad_sde(hd.h, _lib.ptr(yy), _lib.ptr(mm), _lib.IN_DEVICE if dev else 0, n, _lib.ptr(dF), _lib.ptr(dP),
+                                        _lib.ptr(dA1) if has1 else None, _lib.ptr(dQ1) if has1 else None, _lib.ptr(da), _lib.ptr(dH),
+                                        _lib.ptr(dh), _lib.ptr(dR), _lib.ptr(dm), _lib.ptr(dP), ctypes.c_double(rel_step),
+                                        ctypes.byref(lml), _lib.ptr(grad)))
+    return lml.value, grad
+
+
 def _filter(model, y):
     """lgssm.jl:171-173: filtering distributions, returned as (means (T,d), covs (T,d,d))."""
     _check_inputs(model, y[0] if isinstance(y, tuple) else y)

@@ -563,11 +563,62 @@ def _shared_blocks(fx):
     return dict(A=A[0], a=a[0], Q=Q[0], H=H[0], h=hh, R=float(fx.sigma2[0]), x0m=np.asarray(m0, float), x0P=np.asarray(P0, float))
 
 
+def _sde_param_blocks(fx):
+    """the O(1) blocks an SDE-described (irregularly spaced) model is made of, as a function of the hyper-parameters"""
+    k, mean = fx.f.f.kernel, fx.f.f.mean
+    F, H, m0, P0 = k.sde_blocks()
+    A1, _, Q1, _, _, _ = k.lgssm_components(_times(fx.x)[:1])
+    if isinstance(mean, ConstMean):
+        hh = float(mean.c)
+    elif isinstance(mean, ZeroMean):
+        hh = 0.0
+    else:
+        raise NotImplementedError("logpdf_and_gradient: ZeroMean or ConstMean only")
+    out = dict(F=np.asarray(F, float), H=np.asarray(H, float), x0m=np.asarray(m0, float), x0P=np.asarray(P0, float),
+               A1=np.asarray(A1[0], float), Q1=np.asarray(Q1[0], float), h=hh)
+    if fx.sigma2.shape[0] == 1:
+        out["R"] = float(fx.sigma2[0])
+    return out
+
+
+def _logpdf_and_gradient_sde(fx, y, rel_step):
+    """irregular spacing: the model is bound through its SDE and the per-step tangents are formed on the device"""
+    kernel = fx.f.f.kernel
+    if not hasattr(kernel, "sde_blocks") or kernel.sde_blocks()[0].shape[0] > 4:
+        raise NotImplementedError("logpdf_and_gradient on irregular inputs: kernels with state dimension <= 4")
+    plist = parameters(kernel)
+    shared_noise = fx.sigma2.shape[0] == 1
+    names = [n for n, _, _ in plist] + (["noise"] if shared_noise else []) + (["mean.c"] if isinstance(fx.f.f.mean, ConstMean) else [])
+    tangents = []
+    for name in names:
+        if name == "noise":
+            tangents.append(dict(R=1.0))
+            continue
+        owner, attr = (fx.f.f.mean, "c") if name == "mean.c" else next((o, a) for n, o, a in plist if n == name)
+        v0 = getattr(owner, attr)
+        hstep = rel_step * max(1.0, abs(v0))
+        setattr(owner, attr, v0 + hstep)
+        bp = _sde_param_blocks(fx)
+        setattr(owner, attr, v0 - hstep)
+        bm = _sde_param_blocks(fx)
+        setattr(owner, attr, v0)
+        tangents.append({k: (np.asarray(bp[k]) - np.asarray(bm[k])) / (2 * hstep) for k in bp})
+    model = build_lgssm(kernel, fx.x, fx.sigma2, fx.f.f.mean, fx.f.storage.device, device_components=True)
+    if not isinstance(model.transitions, L.SDETransitions):
+        raise NotImplementedError("logpdf_and_gradient: could not bind the model through its SDE")
+    lp, g = L.logpdf_and_grad_sde(model, y, tangents, rel_step)
+    return lp, dict(zip(names, g))
+
+
 def logpdf_and_gradient(fx, y, rel_step=1e-6):
     """(logpdf(fx, y), {name: d logpdf / d parameter}) for the kernel hyper-parameters (`parameters`), the noise
     variance ("noise") and a ConstMean ("mean.c"). The T-step work -- value and tangents -- runs on the device as
     forward-mode tangent scans; the derivative of the O(1) host map parameter -> (A, Q, H, ..., x0) is a central
-    finite difference of that tiny map (relative step 1e-6: truncation ~1e-12, rounding ~1e-10)."""
+    finite difference of that tiny map (relative step 1e-6: truncation ~1e-12, rounding ~1e-10).
+    Regular spacing with homoscedastic noise: any supported state dimension. Irregular spacing: d <= 4, shared or per-step
+    noise; the per-step tangents of exp(F dt_k) are formed on the device (tgp_logpdf_grad_sde)."""
+    if not isinstance(fx.x, RegularSpacing) and len(np.unique(np.round(np.diff(_times(fx.x)), 14))) > 1:
+        return _logpdf_and_gradient_sde(fx, y, rel_step)          # irregular spacing
     _shared_blocks(fx)                      # raises for layouts the gradient pass does not cover
     plist = parameters(fx.f.f.kernel)
     names = [n for n, _, _ in plist] + ["noise"] + (["mean.c"] if isinstance(fx.f.f.mean, ConstMean) else [])
