@@ -66,9 +66,10 @@ typedef struct tgp_handle tgp_handle;
                              against the out-of-line build), 1 out-of-line build only, 2 inlined build for everything,
                              3 out-of-line build + the group-per-chunk logpdf kernels (used by the check itself) */
 
-#define TGP_OPT_GROUP 5 /* logpdf of d = 5..8 LTI models with eight lanes per chunk (tgp_group.hpp), once that path has reproduced
-                           the out-of-line build in the run-time check: 1 (default) where it is faster (d >= 7), 2 for every
-                           d = 5..8, 0 never */
+#define TGP_OPT_GROUP 5 /* d = 5..8 LTI models: logpdf with eight lanes per chunk (tgp_group.hpp) and block scans over filter
+                           elements with eight lanes per element (tgp_group_scan.hpp), once they have reproduced the out-of-line
+                           build in the run-time check: 1 (default) where they are faster (d >= 7), 2 for every d = 5..8,
+                           0 never; + 4 keeps the lane-per-element block scans */
 #define TGP_OPT_FUSE_SCAN 4 /* 1 (default): the level-0 scan reduce / apply of the forward scan run inside the chunk kernels;
                                0: stand-alone k_scan_reduce / k_scan_apply launches (bit-identical results, for A/B timing) */
 

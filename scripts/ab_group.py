@@ -23,7 +23,7 @@ for d, spec in SPECS.items():
     for grp in (0, 2):
         hd.set_option(_lib.OPT_GROUP, grp)
         res[grp] = tgp.logpdf(model, yd)
-    print(f"RESULT d={d} variant={hd.lib.tgp_kernel_variant(hd.h)} rel err lane {abs(res[0]-lp_ref)/abs(lp_ref):.2e} group {abs(res[1]-lp_ref)/abs(lp_ref):.2e}")
+    print(f"RESULT d={d} variant={hd.lib.tgp_kernel_variant(hd.h)} rel err lane {abs(res[0]-lp_ref)/abs(lp_ref):.2e} group {abs(res[2]-lp_ref)/abs(lp_ref):.2e}")
     T = 10_000_000
     model = lti_sde.build_lgssm(lti_sde.to_kernel(spec), lti_sde.RegularSpacing(0.0, 0.1, T), 0.1)
     hd = model.handle()

@@ -239,6 +239,7 @@ struct tgp_handle {
     bool group_active = false;   // ... by the group-per-chunk pass 1 (32 chunks per block, its own chunking)
     bool use_group = false;      // group-per-chunk logpdf kernels validated for this model (tgp_group.hpp)
     int opt_group = 1;           // TGP_OPT_GROUP
+    int opt_group_scan = 1;      // TGP_OPT_GROUP bit 2 (value & 4) switches the group-layout block scans off
     int opt_fuse = 1;            // TGP_OPT_FUSE_SCAN
     // timing
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -435,6 +436,15 @@ int scan_prepare(tgp_handle* h, ScanCtx& c, int monoid, int64_t n0) {
 
 // first = 1: level 0 has been reduced by the producing chunk kernel itself (fused), start one level up
 void scan_up(tgp_handle* h, ScanCtx& c, size_t first = 0) {
+    // group-layout block scans: always with the group-per-chunk passes, and for d >= 7 also under the lane-per-chunk
+    // passes (same element format; the lane-per-element scans cost ~1 ms per launch there)
+    const bool grp = &c == &h->F && h->opt_group_scan && h->kt->group_scan_reduce != nullptr &&
+                     (h->group_active || (h->use_group && h->opt_group && h->d >= 7));
+    for (size_t l = first; grp && l + 1 < c.n.size(); ++l) {
+        LaunchScope ls(h, "k_group_scan_reduce<filter>");
+        h->kt->group_scan_reduce(c.E[l], c.n[l], c.E[l + 1], c.n[l + 1], h->stream);
+    }
+    if (grp) return;
     for (size_t l = first; l + 1 < c.n.size(); ++l) {
         LaunchScope ls(h, c.monoid == kFilter ? "k_scan_reduce<filter>" : c.monoid == kFilterAD ? "k_scan_reduce<filter,grad>" : "k_scan_reduce<affine>");
         h->kt->scan_reduce(c.monoid, c.E[l], c.n[l], c.E[l + 1], c.n[l + 1], h->stream);
@@ -444,6 +454,18 @@ void scan_up(tgp_handle* h, ScanCtx& c, size_t first = 0) {
 // last = 1: stop above level 0 (the consuming chunk kernel scans its own block against S[1], fused)
 void scan_down(tgp_handle* h, ScanCtx& c, const double* x0dev, int last = 0) {
     const int top = (int)c.n.size() - 1;
+    if (&c == &h->F && h->opt_group_scan && h->kt->group_scan_apply != nullptr &&
+        (h->group_active || (h->use_group && h->opt_group && h->d >= 7))) {
+        {
+            LaunchScope ls(h, "k_group_scan_apply<filter,top>");
+            h->kt->group_scan_apply(c.E[top], c.n[top], x0dev, 1, c.S[top], c.fin, h->stream);
+        }
+        for (int l = top - 1; l >= last; --l) {
+            LaunchScope ls(h, "k_group_scan_apply<filter>");
+            h->kt->group_scan_apply(c.E[l], c.n[l], c.S[l + 1], c.n[l + 1], c.S[l], nullptr, h->stream);
+        }
+        return;
+    }
     {
         LaunchScope ls(h, c.monoid == kFilter ? "k_scan_apply<filter,top>" : c.monoid == kFilterAD ? "k_scan_apply<filter,grad,top>" : "k_scan_apply<affine,top>");
         h->kt->scan_apply(c.monoid, c.n[top] <= 256 * kScanE ? 256 : kTopBS, c.E[top], c.n[top], x0dev, 1, c.S[top], c.fin, h->stream);
@@ -743,8 +765,9 @@ int tgp_set_option(tgp_handle* h, int option, int64_t value) {
         return TGP_OK;
     }
     if (option == TGP_OPT_GROUP) {
-        if (value < 0 || value > 2) return h->fail(TGP_EINVAL, "TGP_OPT_GROUP must be 0, 1 or 2");
-        h->opt_group = (int)value;
+        if (value < 0 || value > 6 || (value & 3) == 3) return h->fail(TGP_EINVAL, "TGP_OPT_GROUP must be 0, 1 or 2 (+ 4)");
+        h->opt_group = (int)(value & 3);
+        h->opt_group_scan = (value & 4) ? 0 : 1;
         h->reduce_valid = false;
         h->smoother_valid = false;
         return TGP_OK;
