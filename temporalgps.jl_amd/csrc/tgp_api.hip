@@ -399,6 +399,17 @@ void choose_chunk(tgp_handle* h) {
         int64_t k = (Tm0 + round * 160 - 1) / (round * 160);
         if (k < kmin) k = kmin;
         L0 = (Tm0 + round * k - 1) / (round * k);
+        if (h->d >= 9) {
+            // The out-of-line d >= 9 kernels keep their matrices in private memory (~225 d^2 bytes per lane: 18 KB at d = 9,
+            // 55 KB at d = 16). The runtime sizes the scratch arena by the waves of a dispatch and ABORTS the queue
+            // (HSA_STATUS_ERROR_OUT_OF_RESOURCES) somewhere between 280 and 480 MB -- summed over the handles (HIP streams)
+            // alive in the process: keep a dispatch under ~115 MB.
+            int64_t cap = (int64_t)(0.5e6 / ((double)h->d * h->d));
+            cap = cap / 64 * 64;
+            if (cap < 256) cap = 256;
+            const int64_t Lmin = (Tm0 + cap - 1) / cap;
+            if (L0 < Lmin) L0 = Lmin;
+        }
         if (L0 < 8) L0 = 8;
     }
     const int64_t Tm = h->T * h->p;                       // processing steps (one scalar observation each)
@@ -588,7 +599,9 @@ int forward_reduce(tgp_handle* h, uint32_t flags, int for_mode = -1) {
         // d >= 7 block scans (spill-bound, ~1.5 ms per launch) are what is left of the call
         int64_t L0 = h->opt_chunk;
         if (L0 <= 0) {
-            L0 = (h->T + 16383) / 16384;
+            // (sixteen lanes per chunk: half as many chunks for the same number of waves)
+            const int64_t nch = h->kt->group_chunks_per_block == 32 ? 16384 : 8192;
+            L0 = (h->T + nch - 1) / nch;
             if (L0 < 8) L0 = 8;
         }
         if (L0 > h->T) L0 = h->T;
@@ -641,7 +654,8 @@ int forward_apply(tgp_handle* h, int mode, const FilterOut& fo, const double* x0
     scan_down(h, h->F, x0dev ? x0dev : h->bx0.d(), h->fused ? 1 : 0);
     if (h->group_active) {
         if (mode != 0) return h->fail(TGP_EINVAL, "internal: group-per-chunk elements are only valid for the logpdf pass");
-        const int64_t nb = (h->n0 + 31) / 32;
+        const int64_t cpb = h->kt->group_chunks_per_block;
+        const int64_t nb = (h->n0 + cpb - 1) / cpb;
         HIPCHK(h->partial.ensure((size_t)nb * 3 * sizeof(double)));
         {
             LaunchScope ls(h, "k_group_apply_filter<lti,logpdf>");

@@ -16,43 +16,50 @@
 
 namespace TGP_NS {
 
-constexpr int kGroup = 8;                  // lanes per chunk
-constexpr int kGroupsPerBlock = 32;        // 256 threads
-constexpr int kGroupTileLD = 82;           // doubles per group tile: 8 x 8 matrix + two 8-vectors + 2 (the 8 groups of a wave on distinct banks)
+// Geometry: G = 8 lanes per chunk for d <= 8, 16 for d <= 16. A group's LDS tile is a G x G matrix (i + G col), two
+// G-vectors and 2 doubles of padding (82 / 290 doubles: the groups of a wave start 4 banks apart).
+template <int D> struct GroupGeom {
+    static_assert(D >= 1 && D <= 16, "group kernels: d <= 16");
+    static constexpr int G = D <= 8 ? 8 : 16;
+    static constexpr int LOG2G = D <= 8 ? 3 : 4;
+    static constexpr int NGRP = 256 / G;           // groups (chunks) per 256-thread block
+    static constexpr int V0 = G * G, V1 = G * G + G;
+    static constexpr int LD = G * G + 2 * G + 2;
+};
+#define TGP_GUNROLL _Pragma("unroll")              // the group code keeps its (short) arrays in registers for every d
 
-__device__ __forceinline__ double group_sum(double x) {
-    x += __shfl_xor(x, 1, 8);
-    x += __shfl_xor(x, 2, 8);
-    x += __shfl_xor(x, 4, 8);
+template <int G> __device__ __forceinline__ double group_sum(double x) {
+    TGP_GUNROLL for (int m = 1; m < G; m <<= 1) x += __shfl_xor(x, m, G);
     return x;
 }
 
 template <int D> struct GroupLane {
+    static constexpr int G = GroupGeom<D>::G, V0 = GroupGeom<D>::V0, V1 = GroupGeom<D>::V1;
     int j;                   // lane inside the group == matrix column it owns
     double* tile;            // the group's LDS tile: [0, 64) an 8 x 8 matrix (i + 8 col), [64, 72) and [72, 80) two vectors
     const double* sA;        // A in LDS, row-major [8 i + k] (a row is read with 16-byte loads, broadcast to the wave)
     bool act;                // j < D
     // y[:, j] = A x[:, j]
     __device__ __forceinline__ void mul_A(const double* x, double* y) const {
-        TGP_UNROLL for (int i = 0; i < D; ++i) {
+        TGP_GUNROLL for (int i = 0; i < D; ++i) {
             double acc = 0.0;
-            TGP_UNROLL for (int k = 0; k < D; ++k) acc = fma(sA[8 * i + k], x[k], acc);
+            TGP_GUNROLL for (int k = 0; k < D; ++k) acc = fma(sA[G * i + k], x[k], acc);
             y[i] = acc;
         }
     }
     // every lane gets all D elements of a vector distributed one element per lane
     __device__ __forceinline__ void gather(double vj, double* v) const {
         wave_sync();
-        tile[64 + j] = vj;
+        tile[V0 + j] = vj;
         wave_sync();
-        TGP_UNROLL for (int k = 0; k < D; ++k) v[k] = tile[64 + k];
+        TGP_GUNROLL for (int k = 0; k < D; ++k) v[k] = tile[V0 + k];
     }
     __device__ __forceinline__ void gather2(double vj, double wj, double* v, double* w) const {
         wave_sync();
-        tile[64 + j] = vj;
-        tile[72 + j] = wj;
+        tile[V0 + j] = vj;
+        tile[V1 + j] = wj;
         wave_sync();
-        TGP_UNROLL for (int k = 0; k < D; ++k) { v[k] = tile[64 + k]; w[k] = tile[72 + k]; }
+        TGP_GUNROLL for (int k = 0; k < D; ++k) { v[k] = tile[V0 + k]; w[k] = tile[V1 + k]; }
     }
     // One exchange for a whole predict:  v <- A v + a  (element j of v in lane j)  and  S <- A S A' + Q  (symmetric S by
     // columns): W = A S is lane-local, its transpose and the gather of v share ONE trip through the tile, then column j of
@@ -61,24 +68,24 @@ template <int D> struct GroupLane {
         double W[D], row[D], v[D];
         mul_A(Sc, W);
         wave_sync();
-        TGP_UNROLL for (int i = 0; i < D; ++i) tile[i + 8 * j] = W[i];
-        tile[64 + j] = vj;
+        TGP_GUNROLL for (int i = 0; i < D; ++i) tile[i + G * j] = W[i];
+        tile[V0 + j] = vj;
         wave_sync();
-        TGP_UNROLL for (int k = 0; k < D; ++k) {
-            row[k] = act ? tile[j + 8 * k] : 0.0;      // rows >= D of the tile are never written
-            v[k] = tile[64 + k];
+        TGP_GUNROLL for (int k = 0; k < D; ++k) {
+            row[k] = act ? tile[j + G * k] : 0.0;      // rows >= D of the tile are never written
+            v[k] = tile[V0 + k];
         }
         mul_A(row, Sc);
-        TGP_UNROLL for (int i = 0; i < D; ++i) Sc[i] += Qc[i];
+        TGP_GUNROLL for (int i = 0; i < D; ++i) Sc[i] += Qc[i];
         double acc = 0.0;
-        TGP_UNROLL for (int k = 0; k < D; ++k) acc = fma(sA[8 * (j & 7) + k], v[k], acc);
+        TGP_GUNROLL for (int k = 0; k < D; ++k) acc = fma(sA[G * j + k], v[k], acc);
         vj = acc + aj;
     }
 };
 
 // observation stream of a group: 8 consecutive processing steps are loaded by the 8 lanes (one coalesced 64-byte row
 // per group) and handed out step by step with a shuffle
-struct GroupObs {
+template <int G> struct GroupObs {
     double yv, rv;
     int mv_;
     __device__ __forceinline__ void load(const ModelView& mv, int64_t c, int L0, int64_t r0, int64_t r1, int g, int j) {
@@ -94,27 +101,28 @@ struct GroupObs {
         }
     }
     __device__ __forceinline__ void step(const ModelView& mv, double Rshared, int k, double& y, double& R, bool& miss) const {
-        y = __shfl(yv, k, 8);
-        R = mv.sR != 0 ? __shfl(rv, k, 8) : Rshared;
-        miss = __shfl(mv_, k, 8) != 0;
+        y = __shfl(yv, k, G);
+        R = mv.sR != 0 ? __shfl(rv, k, G) : Rshared;
+        miss = __shfl(mv_, k, G) != 0;
         if (miss) { y = 0.0; R = kLargeVar; }
     }
 };
 
 template <int D> __device__ __forceinline__ void group_setup(const ModelView& mv, double* sA, double* tiles, GroupLane<D>& gl, double* Qc,
                                                              double* H, double& aj, double& hh, double& Rsh) {
+    constexpr int G = GroupGeom<D>::G;
     const int tid = threadIdx.x;
-    if (tid < 64) {
-        const int i = tid >> 3, k = tid & 7;
+    if (tid < G * G) {
+        const int i = tid / G, k = tid % G;
         sA[tid] = (i < D && k < D) ? mv.A[i + k * D] : 0.0;
     }
     __syncthreads();
-    gl.j = tid & 7;
+    gl.j = tid & (G - 1);
     gl.act = gl.j < D;
-    gl.tile = tiles + (tid >> 3) * kGroupTileLD;
+    gl.tile = tiles + (tid / G) * GroupGeom<D>::LD;
     gl.sA = sA;
     const int jc = gl.act ? gl.j : 0;
-    TGP_UNROLL for (int i = 0; i < D; ++i) { Qc[i] = gl.act ? mv.Q[i + jc * D] : 0.0; H[i] = mv.H[i]; }
+    TGP_GUNROLL for (int i = 0; i < D; ++i) { Qc[i] = gl.act ? mv.Q[i + jc * D] : 0.0; H[i] = mv.H[i]; }
     aj = gl.act ? mv.a[jc] : 0.0;
     hh = mv.h[0];
     Rsh = mv.sR == 0 ? mv.R[0] : 0.0;
@@ -123,25 +131,26 @@ template <int D> __device__ __forceinline__ void group_setup(const ModelView& mv
 // ---------------------------------------------------------------- pass 1: the chunk's filter element
 template <int D>
 __global__ __launch_bounds__(256) void k_group_reduce_filter(ModelView mv, int L0, int64_t n0, double* __restrict__ E0) {
-    __shared__ __attribute__((aligned(16))) double sA[64];
-    __shared__ double tiles[kGroupsPerBlock * kGroupTileLD];
+    constexpr int G = GroupGeom<D>::G, NGRP = GroupGeom<D>::NGRP;
+    __shared__ __attribute__((aligned(16))) double sA[G * G];
+    __shared__ double tiles[NGRP * GroupGeom<D>::LD];
     GroupLane<D> gl;
     double Qc[D], H[D], aj, hh, Rsh;
     group_setup<D>(mv, sA, tiles, gl, Qc, H, aj, hh, Rsh);
     const int j = gl.j;
-    const int64_t c = (int64_t)blockIdx.x * kGroupsPerBlock + (threadIdx.x >> 3);
+    const int64_t c = (int64_t)blockIdx.x * NGRP + (threadIdx.x / G);
     int64_t r0, r1;
     chunk_range(mv, c < n0 ? c : n0, L0, r0, r1);
     // element: identity
     double Ac[D], Cc[D], Jc[D], bj = 0.0, etaj = 0.0;
-    TGP_UNROLL for (int i = 0; i < D; ++i) { Ac[i] = (i == j) ? 1.0 : 0.0; Cc[i] = 0.0; Jc[i] = 0.0; }
+    TGP_GUNROLL for (int i = 0; i < D; ++i) { Ac[i] = (i == j) ? 1.0 : 0.0; Cc[i] = 0.0; Jc[i] = 0.0; }
     double Hj = 0.0;
-    TGP_UNROLL for (int i = 0; i < D; ++i) Hj = (i == j) ? H[i] : Hj;
-    GroupObs ob;
-    for (int g = 0; g < L0; g += 8) {
+    TGP_GUNROLL for (int i = 0; i < D; ++i) Hj = (i == j) ? H[i] : Hj;
+    GroupObs<G> ob;
+    for (int g = 0; g < L0; g += G) {
         ob.load(mv, c, L0, r0, r1, g, j);
         const int64_t rg = r0 + g;
-        const int gend = (int)((r1 - rg) < 8 ? (r1 - rg) : 8);
+        const int gend = (int)((r1 - rg) < G ? (r1 - rg) : G);
         for (int k = 0; k < gend; ++k) {
             double y, R;
             bool miss;
@@ -150,19 +159,19 @@ __global__ __launch_bounds__(256) void k_group_reduce_filter(ModelView mv, int L
             if (do_predict) {
                 double T1[D];
                 gl.mul_A(Ac, T1);                       // Abar <- A Abar
-                TGP_UNROLL for (int i = 0; i < D; ++i) Ac[i] = T1[i];
+                TGP_GUNROLL for (int i = 0; i < D; ++i) Ac[i] = T1[i];
                 gl.predict(bj, aj, Cc, Qc);             // b <- A b + a ; C <- A C A' + Q
             }
             double wj = 0.0, cvj = 0.0;                 // w = Abar' H, Cv = C H
-            TGP_UNROLL for (int i = 0; i < D; ++i) { wj = fma(Ac[i], H[i], wj); cvj = fma(Cc[i], H[i], cvj); }
-            const double s = R + group_sum(Hj * cvj);
-            const double r = (y - hh) - group_sum(Hj * bj);
+            TGP_GUNROLL for (int i = 0; i < D; ++i) { wj = fma(Ac[i], H[i], wj); cvj = fma(Cc[i], H[i], cvj); }
+            const double s = R + group_sum<G>(Hj * cvj);
+            const double r = (y - hh) - group_sum<G>(Hj * bj);
             const double is = 1.0 / s;
             etaj = fma(wj, r * is, etaj);
             bj = fma(cvj, r * is, bj);
             double w[D], Cv[D];
             gl.gather2(wj, cvj, w, Cv);
-            TGP_UNROLL for (int i = 0; i < D; ++i) {
+            TGP_GUNROLL for (int i = 0; i < D; ++i) {
                 Jc[i] = fma(w[i] * is, wj, Jc[i]);
                 Ac[i] = fma(-Cv[i] * is, wj, Ac[i]);
                 Cc[i] = fma(-Cv[i] * is, cvj, Cc[i]);
@@ -171,10 +180,10 @@ __global__ __launch_bounds__(256) void k_group_reduce_filter(ModelView mv, int L
     }
     if (c < n0 && r1 > r0 && gl.act) {
         constexpr int DD = D * D, DS = Dim<D>::DS;
-        TGP_UNROLL for (int i = 0; i < D; ++i) E0[(int64_t)(i + j * D) * n0 + c] = Ac[i];
+        TGP_GUNROLL for (int i = 0; i < D; ++i) E0[(int64_t)(i + j * D) * n0 + c] = Ac[i];
         E0[(int64_t)(DD + j) * n0 + c] = bj;
         E0[(int64_t)(DD + D + DS + j) * n0 + c] = etaj;
-        TGP_UNROLL for (int i = 0; i < D; ++i)
+        TGP_GUNROLL for (int i = 0; i < D; ++i)
             if (i <= j) {
                 E0[(int64_t)(DD + D + j * (j + 1) / 2 + i) * n0 + c] = Cc[i];
                 E0[(int64_t)(DD + 2 * D + DS + j * (j + 1) / 2 + i) * n0 + c] = Jc[i];
@@ -186,34 +195,35 @@ __global__ __launch_bounds__(256) void k_group_reduce_filter(ModelView mv, int L
 template <int D>
 __global__ __launch_bounds__(256) void k_group_apply_logpdf(ModelView mv, int L0, int64_t n0, const double* __restrict__ S0,
                                                             double* __restrict__ partial) {
-    __shared__ __attribute__((aligned(16))) double sA[64];
-    __shared__ double tiles[kGroupsPerBlock * kGroupTileLD];
+    constexpr int G = GroupGeom<D>::G, NGRP = GroupGeom<D>::NGRP;
+    __shared__ __attribute__((aligned(16))) double sA[G * G];
+    __shared__ double tiles[NGRP * GroupGeom<D>::LD];
     __shared__ double sh[12];
     GroupLane<D> gl;
     double Qc[D], H[D], aj, hh, Rsh;
     group_setup<D>(mv, sA, tiles, gl, Qc, H, aj, hh, Rsh);
     const int j = gl.j;
-    const int64_t c = (int64_t)blockIdx.x * kGroupsPerBlock + (threadIdx.x >> 3);
+    const int64_t c = (int64_t)blockIdx.x * NGRP + (threadIdx.x / G);
     int64_t r0, r1;
     chunk_range(mv, c < n0 ? c : n0, L0, r0, r1);
     double Pc[D], mj = 0.0;
-    TGP_UNROLL for (int i = 0; i < D; ++i) Pc[i] = (i == j) ? 1.0 : 0.0;
+    TGP_GUNROLL for (int i = 0; i < D; ++i) Pc[i] = (i == j) ? 1.0 : 0.0;
     if (c < n0 && gl.act) {
         mj = S0[(int64_t)j * n0 + c];
-        TGP_UNROLL for (int i = 0; i < D; ++i) {
+        TGP_GUNROLL for (int i = 0; i < D; ++i) {
             const int lo = i < j ? i : j, hi = i < j ? j : i;
             Pc[i] = S0[(int64_t)(D + hi * (hi + 1) / 2 + lo) * n0 + c];
         }
     }
     double Hj = 0.0;
-    TGP_UNROLL for (int i = 0; i < D; ++i) Hj = (i == j) ? H[i] : Hj;
+    TGP_GUNROLL for (int i = 0; i < D; ++i) Hj = (i == j) ? H[i] : Hj;
     double lml = 0.0, nmiss = 0.0;
     bool ok = true;
-    GroupObs ob;
-    for (int g = 0; g < L0; g += 8) {
+    GroupObs<G> ob;
+    for (int g = 0; g < L0; g += G) {
         ob.load(mv, c, L0, r0, r1, g, j);
         const int64_t rg = r0 + g;
-        const int gend = (int)((r1 - rg) < 8 ? (r1 - rg) : 8);
+        const int gend = (int)((r1 - rg) < G ? (r1 - rg) : G);
         double sprod = 1.0, quad = 0.0;
         for (int k = 0; k < gend; ++k) {
             double y, R;
@@ -224,9 +234,9 @@ __global__ __launch_bounds__(256) void k_group_apply_logpdf(ModelView mv, int L0
                 gl.predict(mj, aj, Pc, Qc);             // m <- A m + a ; P <- A P A' + Q
             }
             double vj = 0.0;                            // V = P H
-            TGP_UNROLL for (int i = 0; i < D; ++i) vj = fma(Pc[i], H[i], vj);
-            const double S = group_sum(Hj * vj) + R;
-            const double hm = group_sum(Hj * mj);
+            TGP_GUNROLL for (int i = 0; i < D; ++i) vj = fma(Pc[i], H[i], vj);
+            const double S = group_sum<G>(Hj * vj) + R;
+            const double hm = group_sum<G>(Hj * mj);
             ok = ok && (S > 0.0);
             const double iS = 1.0 / S;
             const double v = y - (hm + hh);
@@ -235,7 +245,7 @@ __global__ __launch_bounds__(256) void k_group_apply_logpdf(ModelView mv, int L0
             double V[D];
             gl.gather(vj, V);
             const double wgt = vj * iS;
-            TGP_UNROLL for (int i = 0; i < D; ++i) Pc[i] = fma(-V[i], wgt, Pc[i]);
+            TGP_GUNROLL for (int i = 0; i < D; ++i) Pc[i] = fma(-V[i], wgt, Pc[i]);
             quad += v * viS;
             sprod *= S;
             if (sprod > 1e100 || sprod < 1e-100) {

@@ -20,66 +20,67 @@ template <int D> struct GState {
 };
 
 template <int D> struct GroupOps {
+    static constexpr int G = GroupGeom<D>::G, V0 = GroupGeom<D>::V0, V1 = GroupGeom<D>::V1;
     int j;
     bool act;
     double* tile;    // [0, 64) matrix i + 8 col ; [64, 72) and [72, 80) vectors
     __device__ __forceinline__ void publish(const double* col) const {
         wave_sync();
-        TGP_UNROLL for (int i = 0; i < D; ++i) tile[i + 8 * j] = col[i];
+        TGP_GUNROLL for (int i = 0; i < D; ++i) tile[i + G * j] = col[i];
         wave_sync();
     }
     // with X published: out = X y[:, j]
     __device__ __forceinline__ void left(const double* y, double* out) const {
-        TGP_UNROLL for (int i = 0; i < D; ++i) {
+        TGP_GUNROLL for (int i = 0; i < D; ++i) {
             double acc = 0.0;
-            TGP_UNROLL for (int k = 0; k < D; ++k) acc = fma(tile[i + 8 * k], y[k], acc);
+            TGP_GUNROLL for (int k = 0; k < D; ++k) acc = fma(tile[i + G * k], y[k], acc);
             out[i] = acc;
         }
     }
     // out = X' y[:, j]
     __device__ __forceinline__ void left_t(const double* y, double* out) const {
-        TGP_UNROLL for (int i = 0; i < D; ++i) {
+        TGP_GUNROLL for (int i = 0; i < D; ++i) {
             double acc = 0.0;
-            TGP_UNROLL for (int k = 0; k < D; ++k) acc = fma(tile[k + 8 * i], y[k], acc);
+            TGP_GUNROLL for (int k = 0; k < D; ++k) acc = fma(tile[k + G * i], y[k], acc);
             out[i] = acc;
         }
     }
     // row j of the published matrix
     __device__ __forceinline__ void row(double* out) const {
-        TGP_UNROLL for (int k = 0; k < D; ++k) out[k] = act ? tile[j + 8 * k] : 0.0;
+        TGP_GUNROLL for (int k = 0; k < D; ++k) out[k] = act ? tile[j + G * k] : 0.0;
     }
     __device__ __forceinline__ void gather(double vj, double* v) const {
         wave_sync();
-        tile[64 + j] = vj;
+        tile[V0 + j] = vj;
         wave_sync();
-        TGP_UNROLL for (int k = 0; k < D; ++k) v[k] = tile[64 + k];
+        TGP_GUNROLL for (int k = 0; k < D; ++k) v[k] = tile[V0 + k];
     }
     __device__ __forceinline__ void gather2(double vj, double wj, double* v, double* w) const {
         wave_sync();
-        tile[64 + j] = vj;
-        tile[72 + j] = wj;
+        tile[V0 + j] = vj;
+        tile[V1 + j] = wj;
         wave_sync();
-        TGP_UNROLL for (int k = 0; k < D; ++k) { v[k] = tile[64 + k]; w[k] = tile[72 + k]; }
+        TGP_GUNROLL for (int k = 0; k < D; ++k) { v[k] = tile[V0 + k]; w[k] = tile[V1 + k]; }
     }
     // S <- (S + S') / 2 for a matrix given by columns
     __device__ __forceinline__ void symmetrize(double* Sc) const {
         publish(Sc);
-        TGP_UNROLL for (int i = 0; i < D; ++i) Sc[i] = act ? 0.5 * (Sc[i] + tile[j + 8 * i]) : 0.0;
+        TGP_GUNROLL for (int i = 0; i < D; ++i) Sc[i] = act ? 0.5 * (Sc[i] + tile[j + G * i]) : 0.0;
     }
     // X = M^-1 (columns); M destroyed. Gauss-Jordan, partial pivoting by rows (every lane swaps the same two rows).
     __device__ __forceinline__ void inverse(double* Mc, double* Xc) const {
-        TGP_UNROLL for (int i = 0; i < D; ++i) Xc[i] = (i == j) ? 1.0 : 0.0;
-        TGP_UNROLL for (int k = 0; k < D; ++k) {
+        TGP_GUNROLL for (int i = 0; i < D; ++i) Xc[i] = (i == j) ? 1.0 : 0.0;
+        TGP_GUNROLL for (int k = 0; k < D; ++k) {
             int piv = k;
             double best = fabs(Mc[k]);
-            TGP_UNROLL for (int i = k + 1; i < D; ++i) {
+            TGP_GUNROLL for (int i = k + 1; i < D; ++i) {
                 const double v = fabs(Mc[i]);
                 const bool gt = v > best;
                 best = gt ? v : best;
                 piv = gt ? i : piv;
             }
-            piv = __shfl(piv, k, 8);                     // lane k owns column k: its choice of pivot row
-            TGP_UNROLL for (int i = k + 1; i < D; ++i) {
+            piv = __shfl(piv, k, G);                     // lane k owns column k: its choice of pivot row
+            TGP_GUNROLL for (int i = k + 1; i < D; ++i) {
                 const bool sw = (piv == i);
                 const double t = Mc[k], u = Mc[i], t2 = Xc[k], u2 = Xc[i];
                 Mc[k] = sw ? u : t;
@@ -89,13 +90,13 @@ template <int D> struct GroupOps {
             }
             // column k (after the swap) to everybody
             wave_sync();
-            if (j == k) { TGP_UNROLL for (int i = 0; i < D; ++i) tile[64 + i] = Mc[i]; }
+            if (j == k) { TGP_GUNROLL for (int i = 0; i < D; ++i) tile[V0 + i] = Mc[i]; }
             wave_sync();
             double colk[D];
-            TGP_UNROLL for (int i = 0; i < D; ++i) colk[i] = tile[64 + i];
+            TGP_GUNROLL for (int i = 0; i < D; ++i) colk[i] = tile[V0 + i];
             const double inv = 1.0 / colk[k];
             const double rm = Mc[k] * inv, rx = Xc[k] * inv;
-            TGP_UNROLL for (int i = 0; i < D; ++i) {
+            TGP_GUNROLL for (int i = 0; i < D; ++i) {
                 if (i != k) {
                     Mc[i] = fma(-colk[i], rm, Mc[i]);
                     Xc[i] = fma(-colk[i], rx, Xc[i]);
@@ -111,33 +112,33 @@ template <int D> struct GroupOps {
         double M[D], X[D], T1[D], T2[D], t[D], v1[D], v2[D];
         publish(a.C);                                        // M = C_a J_b + I
         left(b.J, M);
-        TGP_UNROLL for (int i = 0; i < D; ++i) M[i] += (i == j) ? 1.0 : 0.0;
+        TGP_GUNROLL for (int i = 0; i < D; ++i) M[i] += (i == j) ? 1.0 : 0.0;
         inverse(M, X);                                       // X = (I + C_a J_b)^-1
         publish(b.A);                                        // T1 = A_b X
         left(X, T1);
         gather2(b.eta, a.b, v1, v2);                         // v1 = eta_b, v2 = b_a
         double uj = a.b, vj = b.eta;                         // u = b_a + C_a eta_b ; v = eta_b - J_b b_a  (C, J symmetric: rows = columns)
-        TGP_UNROLL for (int k = 0; k < D; ++k) { uj = fma(a.C[k], v1[k], uj); vj = fma(-b.J[k], v2[k], vj); }
+        TGP_GUNROLL for (int k = 0; k < D; ++k) { uj = fma(a.C[k], v1[k], uj); vj = fma(-b.J[k], v2[k], vj); }
         gather2(uj, vj, v1, v2);                             // v1 = u, v2 = v
         double zj = 0.0;                                     // z = X' v
-        TGP_UNROLL for (int k = 0; k < D; ++k) zj = fma(X[k], v2[k], zj);
+        TGP_GUNROLL for (int k = 0; k < D; ++k) zj = fma(X[k], v2[k], zj);
         publish(T1);                                         // w = T1 u ; nA = T1 A_a ; T2 = T1 C_a
         double wj = 0.0;
         row(t);
-        TGP_UNROLL for (int k = 0; k < D; ++k) wj = fma(t[k], v1[k], wj);
+        TGP_GUNROLL for (int k = 0; k < D; ++k) wj = fma(t[k], v1[k], wj);
         left(a.A, o.A);
         left(a.C, T2);
         o.b = wj + b.b;
         gather(zj, v1);                                      // eta = A_a' z + eta_a
         double ne = 0.0;
-        TGP_UNROLL for (int k = 0; k < D; ++k) ne = fma(a.A[k], v1[k], ne);
+        TGP_GUNROLL for (int k = 0; k < D; ++k) ne = fma(a.A[k], v1[k], ne);
         o.eta = ne + a.eta;
         publish(b.A);                                        // C = T2 A_b' + C_b : needs row j of A_b
         row(t);
         publish(T2);
-        TGP_UNROLL for (int i = 0; i < D; ++i) {
+        TGP_GUNROLL for (int i = 0; i < D; ++i) {
             double acc = 0.0;
-            TGP_UNROLL for (int k = 0; k < D; ++k) acc = fma(tile[i + 8 * k], t[k], acc);
+            TGP_GUNROLL for (int k = 0; k < D; ++k) acc = fma(tile[i + G * k], t[k], acc);
             o.C[i] = acc + b.C[i];
         }
         symmetrize(o.C);
@@ -147,7 +148,7 @@ template <int D> struct GroupOps {
         left_t(T1, T2);                                      // T2 := X' J_b A_a
         publish(a.A);
         left_t(T2, T1);                                      // T1 := A_a' X' J_b A_a
-        TGP_UNROLL for (int i = 0; i < D; ++i) o.J[i] = T1[i] + a.J[i];
+        TGP_GUNROLL for (int i = 0; i < D; ++i) o.J[i] = T1[i] + a.J[i];
         symmetrize(o.J);
     }
 
@@ -156,26 +157,26 @@ template <int D> struct GroupOps {
         double M[D], X[D], T1[D], T2[D], t[D], v1[D];
         publish(in.P);                                       // M = P J + I
         left(e.J, M);
-        TGP_UNROLL for (int i = 0; i < D; ++i) M[i] += (i == j) ? 1.0 : 0.0;
+        TGP_GUNROLL for (int i = 0; i < D; ++i) M[i] += (i == j) ? 1.0 : 0.0;
         inverse(M, X);
         publish(e.A);                                        // T1 = A X
         left(X, T1);
         gather(e.eta, v1);                                   // u = m + P eta
         double uj = in.m;
-        TGP_UNROLL for (int k = 0; k < D; ++k) uj = fma(in.P[k], v1[k], uj);
+        TGP_GUNROLL for (int k = 0; k < D; ++k) uj = fma(in.P[k], v1[k], uj);
         gather(uj, v1);
         publish(T1);                                         // m' = T1 u + b ; T2 = T1 P
         row(t);
         double wj = 0.0;
-        TGP_UNROLL for (int k = 0; k < D; ++k) wj = fma(t[k], v1[k], wj);
+        TGP_GUNROLL for (int k = 0; k < D; ++k) wj = fma(t[k], v1[k], wj);
         left(in.P, T2);
         out.m = wj + e.b;
         publish(e.A);                                        // P' = T2 A' + C
         row(t);
         publish(T2);
-        TGP_UNROLL for (int i = 0; i < D; ++i) {
+        TGP_GUNROLL for (int i = 0; i < D; ++i) {
             double acc = 0.0;
-            TGP_UNROLL for (int k = 0; k < D; ++k) acc = fma(tile[i + 8 * k], t[k], acc);
+            TGP_GUNROLL for (int k = 0; k < D; ++k) acc = fma(tile[i + G * k], t[k], acc);
             out.P[i] = acc + e.C[i];
         }
         symmetrize(out.P);
@@ -183,7 +184,7 @@ template <int D> struct GroupOps {
 };
 
 template <int D> __device__ __forceinline__ void gelem_identity(GElem<D>& e, int j) {
-    TGP_UNROLL for (int i = 0; i < D; ++i) { e.A[i] = (i == j) ? 1.0 : 0.0; e.C[i] = 0.0; e.J[i] = 0.0; }
+    TGP_GUNROLL for (int i = 0; i < D; ++i) { e.A[i] = (i == j) ? 1.0 : 0.0; e.C[i] = 0.0; e.J[i] = 0.0; }
     e.b = 0.0;
     e.eta = 0.0;
 }
@@ -192,10 +193,10 @@ template <int D> __device__ __forceinline__ void gelem_load(GElem<D>& e, const d
     constexpr int DD = D * D, DS = Dim<D>::DS;
     gelem_identity<D>(e, j);
     if (!act) {
-        TGP_UNROLL for (int i = 0; i < D; ++i) e.A[i] = 0.0;
+        TGP_GUNROLL for (int i = 0; i < D; ++i) e.A[i] = 0.0;
         return;
     }
-    TGP_UNROLL for (int i = 0; i < D; ++i) {
+    TGP_GUNROLL for (int i = 0; i < D; ++i) {
         const int lo = i < j ? i : j, hi = i < j ? j : i;
         e.A[i] = E[(int64_t)(i + j * D) * n + idx];
         e.C[i] = E[(int64_t)(DD + D + hi * (hi + 1) / 2 + lo) * n + idx];
@@ -206,7 +207,7 @@ template <int D> __device__ __forceinline__ void gelem_load(GElem<D>& e, const d
 }
 template <int D> __device__ __forceinline__ void gelem_store(const GElem<D>& e, double* __restrict__ E, int64_t n, int64_t idx, int j) {
     constexpr int DD = D * D, DS = Dim<D>::DS;
-    TGP_UNROLL for (int i = 0; i < D; ++i) {
+    TGP_GUNROLL for (int i = 0; i < D; ++i) {
         E[(int64_t)(i + j * D) * n + idx] = e.A[i];
         if (i <= j) {
             E[(int64_t)(DD + D + j * (j + 1) / 2 + i) * n + idx] = e.C[i];
@@ -218,50 +219,52 @@ template <int D> __device__ __forceinline__ void gelem_store(const GElem<D>& e, 
 }
 template <int D> __device__ __forceinline__ void gstate_load(GState<D>& s, const double* __restrict__ S, int64_t n, int64_t idx, int j, bool act) {
     s.m = 0.0;
-    TGP_UNROLL for (int i = 0; i < D; ++i) s.P[i] = 0.0;
+    TGP_GUNROLL for (int i = 0; i < D; ++i) s.P[i] = 0.0;
     if (!act) return;
     s.m = S[(int64_t)j * n + idx];
-    TGP_UNROLL for (int i = 0; i < D; ++i) {
+    TGP_GUNROLL for (int i = 0; i < D; ++i) {
         const int lo = i < j ? i : j, hi = i < j ? j : i;
         s.P[i] = S[(int64_t)(D + hi * (hi + 1) / 2 + lo) * n + idx];
     }
 }
 template <int D> __device__ __forceinline__ void gstate_store(const GState<D>& s, double* __restrict__ S, int64_t n, int64_t idx, int j) {
     S[(int64_t)j * n + idx] = s.m;
-    TGP_UNROLL for (int i = 0; i < D; ++i)
+    TGP_GUNROLL for (int i = 0; i < D; ++i)
         if (i <= j) S[(int64_t)(D + j * (j + 1) / 2 + i) * n + idx] = s.P[i];
 }
 
 // staging of one element per group in LDS for the cross-group steps: [group][3 D + 2 values per lane][8 lanes]
 template <int D> struct GStage {
+    static constexpr int G = GroupGeom<D>::G;
     static constexpr int kPerLane = 3 * D + 2;
-    static constexpr int kPerGroup = kPerLane * 8;
+    static constexpr int kPerGroup = kPerLane * G;
     __device__ __forceinline__ static void put(double* st, int g, int j, const GElem<D>& e) {
         double* p = st + g * kPerGroup + j;
-        TGP_UNROLL for (int i = 0; i < D; ++i) { p[(i) * 8] = e.A[i]; p[(D + i) * 8] = e.C[i]; p[(2 * D + i) * 8] = e.J[i]; }
-        p[(3 * D) * 8] = e.b;
-        p[(3 * D + 1) * 8] = e.eta;
+        TGP_GUNROLL for (int i = 0; i < D; ++i) { p[(i) * G] = e.A[i]; p[(D + i) * G] = e.C[i]; p[(2 * D + i) * G] = e.J[i]; }
+        p[(3 * D) * G] = e.b;
+        p[(3 * D + 1) * G] = e.eta;
     }
     __device__ __forceinline__ static void get(const double* st, int g, int j, GElem<D>& e) {
         const double* p = st + g * kPerGroup + j;
-        TGP_UNROLL for (int i = 0; i < D; ++i) { e.A[i] = p[(i) * 8]; e.C[i] = p[(D + i) * 8]; e.J[i] = p[(2 * D + i) * 8]; }
-        e.b = p[(3 * D) * 8];
-        e.eta = p[(3 * D + 1) * 8];
+        TGP_GUNROLL for (int i = 0; i < D; ++i) { e.A[i] = p[(i) * G]; e.C[i] = p[(D + i) * G]; e.J[i] = p[(2 * D + i) * G]; }
+        e.b = p[(3 * D) * G];
+        e.eta = p[(3 * D + 1) * G];
     }
 };
 
 // REDUCE: Ehi[b] = E[256 b] o ... o E[256 b + 255]. Each of the 32 groups folds 8 consecutive elements, then a 5-round tree.
 template <int D>
 __global__ __launch_bounds__(256) void k_group_scan_reduce(const double* __restrict__ Ein, int64_t n, double* __restrict__ Ehi, int64_t nhi) {
-    __shared__ double tiles[kGroupsPerBlock * kGroupTileLD];
-    __shared__ double stage[kGroupsPerBlock * GStage<D>::kPerGroup];
-    const int tid = threadIdx.x, j = tid & 7, g = tid >> 3;
-    GroupOps<D> op{j, j < D, tiles + g * kGroupTileLD};
-    const int64_t base = (int64_t)blockIdx.x * 256 + (int64_t)g * 8;
+    constexpr int G = GroupGeom<D>::G, NGRP = GroupGeom<D>::NGRP, EPG = 256 / NGRP;    // elements per group
+    __shared__ double tiles[NGRP * GroupGeom<D>::LD];
+    __shared__ double stage[NGRP * GStage<D>::kPerGroup];
+    const int tid = threadIdx.x, j = tid & (G - 1), g = tid / G;
+    GroupOps<D> op{j, j < D, tiles + g * GroupGeom<D>::LD};
+    const int64_t base = (int64_t)blockIdx.x * 256 + (int64_t)g * EPG;
     GElem<D> acc, e, t;
     gelem_identity<D>(acc, j);
-    if (!op.act) { TGP_UNROLL for (int i = 0; i < D; ++i) acc.A[i] = 0.0; }
-    for (int q = 0; q < 8; ++q) {
+    if (!op.act) { TGP_GUNROLL for (int i = 0; i < D; ++i) acc.A[i] = 0.0; }
+    for (int q = 0; q < EPG; ++q) {
         const int64_t idx = base + q;
         if (idx < n) {                       // uniform inside the group
             gelem_load<D>(e, Ein, n, idx, j, op.act);
@@ -269,11 +272,11 @@ __global__ __launch_bounds__(256) void k_group_scan_reduce(const double* __restr
             else { op.combine(acc, e, t); acc = t; }
         }
     }
-    for (int off = 1; off < kGroupsPerBlock; off <<= 1) {
+    for (int off = 1; off < NGRP; off <<= 1) {
         __syncthreads();
         GStage<D>::put(stage, g, j, acc);
         __syncthreads();
-        if ((g & (2 * off - 1)) == 0 && base + (int64_t)off * 8 < n) {      // the partner group holds at least one element
+        if ((g & (2 * off - 1)) == 0 && base + (int64_t)off * EPG < n) {      // the partner group holds at least one element
             GStage<D>::get(stage, g + off, j, e);
             op.combine(acc, e, t);
             acc = t;
@@ -288,15 +291,16 @@ __global__ __launch_bounds__(256) void k_group_scan_reduce(const double* __restr
 template <int D>
 __global__ __launch_bounds__(256) void k_group_scan_apply(const double* __restrict__ Ein, int64_t n, const double* __restrict__ carry,
                                                           int64_t ncarry, double* __restrict__ S, double* __restrict__ fin) {
-    __shared__ double tiles[kGroupsPerBlock * kGroupTileLD];
-    __shared__ double stage[kGroupsPerBlock * GStage<D>::kPerGroup];
-    const int tid = threadIdx.x, j = tid & 7, g = tid >> 3;
-    GroupOps<D> op{j, j < D, tiles + g * kGroupTileLD};
-    const int64_t base = (int64_t)blockIdx.x * 256 + (int64_t)g * 8;
+    constexpr int G = GroupGeom<D>::G, NGRP = GroupGeom<D>::NGRP, EPG = 256 / NGRP;    // elements per group
+    __shared__ double tiles[NGRP * GroupGeom<D>::LD];
+    __shared__ double stage[NGRP * GStage<D>::kPerGroup];
+    const int tid = threadIdx.x, j = tid & (G - 1), g = tid / G;
+    GroupOps<D> op{j, j < D, tiles + g * GroupGeom<D>::LD};
+    const int64_t base = (int64_t)blockIdx.x * 256 + (int64_t)g * EPG;
     GElem<D> tot, e, t;
     gelem_identity<D>(tot, j);
-    if (!op.act) { TGP_UNROLL for (int i = 0; i < D; ++i) tot.A[i] = 0.0; }
-    for (int q = 0; q < 8; ++q) {
+    if (!op.act) { TGP_GUNROLL for (int i = 0; i < D; ++i) tot.A[i] = 0.0; }
+    for (int q = 0; q < EPG; ++q) {
         const int64_t idx = base + q;
         if (idx < n) {
             gelem_load<D>(e, Ein, n, idx, j, op.act);
@@ -305,7 +309,7 @@ __global__ __launch_bounds__(256) void k_group_scan_apply(const double* __restri
         }
     }
     // inclusive scan of the group totals
-    for (int off = 1; off < kGroupsPerBlock; off <<= 1) {
+    for (int off = 1; off < NGRP; off <<= 1) {
         __syncthreads();                                     // everybody has finished reading the previous round
         GStage<D>::put(stage, g, j, tot);
         __syncthreads();
@@ -325,7 +329,7 @@ __global__ __launch_bounds__(256) void k_group_scan_apply(const double* __restri
         op.apply(e, s, s2);
         s = s2;
     }
-    for (int q = 0; q < 8; ++q) {
+    for (int q = 0; q < EPG; ++q) {
         const int64_t idx = base + q;
         if (idx < n) {
             if (op.act) gstate_store<D>(s, S, n, idx, j);
@@ -337,7 +341,7 @@ __global__ __launch_bounds__(256) void k_group_scan_apply(const double* __restri
     // the state after the block's last element: held by the group that owns element n - 1 (top level: one block)
     if (fin != nullptr) {
         const int64_t last = n - 1 - (int64_t)blockIdx.x * 256;
-        if (last >= 0 && last < 256 && (int)(last >> 3) == g && op.act) gstate_store<D>(s, fin, 1, 0, j);
+        if (last >= 0 && last < 256 && (int)(last / EPG) == g && op.act) gstate_store<D>(s, fin, 1, 0, j);
     }
 }
 

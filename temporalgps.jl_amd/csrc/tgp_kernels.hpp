@@ -657,12 +657,13 @@ struct KernelTable {
     // host-side monoid operations on packed elements / states (m (d), P (d*d))
     int (*host_apply)(int kind, const double* elem, const double* m, const double* P, double* m_out, double* P_out);
     int (*host_combine)(int kind, const double* earlier, const double* later, double* out);
-    // group-per-chunk kernels (tgp_group.hpp; d = 5..8, LTI, scalar observations; NULL otherwise): 32 chunks per block
+    // group-per-chunk kernels (tgp_group.hpp; d = 5..16, LTI, scalar observations; NULL otherwise)
     void (*group_reduce_filter)(const ModelView&, int L0, int64_t n0, double* E0, hipStream_t);
     void (*group_apply_logpdf)(const ModelView&, int L0, int64_t n0, const double* S0, double* partial, hipStream_t);
     // ... and block scans over filter elements in the same layout (tgp_group_scan.hpp), 256 elements per block
     void (*group_scan_reduce)(const double* Ein, int64_t n, double* Ehi, int64_t nhi, hipStream_t);
     void (*group_scan_apply)(const double* Ein, int64_t n, const double* carry, int64_t ncarry, double* S, double* fin, hipStream_t);
+    int group_chunks_per_block;      // 32 (eight lanes per chunk, d <= 8) or 16 (sixteen, d <= 16); 0 without group kernels
     void scan_reduce(int monoid, const double* Ein, int64_t n, double* Ehi, int64_t nhi, hipStream_t s) const {
         scan_reduce_c[monoid == kFilter ? kScanFilter : monoid == kFilterAD ? kScanAD : kScanAffine](monoid, Ein, n, Ehi, nhi, s);
     }

@@ -1,4 +1,5 @@
-"""GPU tier: the group-per-chunk logpdf kernels (tgp_group.hpp; eight lanes per chunk, d = 5..8, LTI family) forced on
+"""GPU tier: the group-per-chunk logpdf kernels and block scans (tgp_group.hpp, tgp_group_scan.hpp; eight / sixteen lanes per
+chunk, d = 5..16, LTI family) forced on
 (TGP_OPT_GROUP = 2) against the oracle: random non-symmetric-free LTI models (shared A, a, Q, H, h), shared and per-step
 noise, missing data, both orderings, ragged chunk sizes and multi-level scans. Tolerance as in test_gpu_parity.py."""
 import numpy as np
@@ -17,7 +18,7 @@ def tgp():
     return t
 
 
-@pytest.mark.parametrize("d", [5, 6, 7, 8])
+@pytest.mark.parametrize("d", [5, 6, 7, 8, 9, 12, 16])          # eight lanes per chunk up to d = 8, sixteen beyond
 @pytest.mark.parametrize("ordering", ["F", "R"])
 @pytest.mark.parametrize("per_step_R", [False, True])
 def test_group_logpdf_equals_oracle(tgp, d, ordering, per_step_R):
