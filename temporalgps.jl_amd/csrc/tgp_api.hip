@@ -62,7 +62,7 @@ static const KernelTable* fast_kernel_table(int d) {
 }
 // Per (state dimension, LTI layout family?): which operations of the inlined (fast) build reproduced the out-of-line (safe)
 // build in the run-time known-answer check. Bit kOpDecided = the check has run.
-enum VariantOp { kOpM0 = 0, kOpM1, kOpM2, kOpM3, kOpAffine, kOpGrad, kOpCount, kOpGroup = 29, kOpDecided = 30 };
+enum VariantOp { kOpM0 = 0, kOpM1, kOpM2, kOpM3, kOpAffine, kOpGrad, kOpCount, kOpGroupAff = 28, kOpGroup = 29, kOpDecided = 30 };
 static unsigned g_variant[17][2] = {{0u}};
 static const unsigned kAllOps = (1u << kOpCount) - 1u;
 
@@ -238,6 +238,7 @@ struct tgp_handle {
     bool fused = false;          // the current forward elements were produced with the fused level-0 reduce
     bool group_active = false;   // ... by the group-per-chunk pass 1 (32 chunks per block, its own chunking)
     bool use_group = false;      // group-per-chunk logpdf kernels validated for this model (tgp_group.hpp)
+    bool use_group_aff = false;  // ... and the group-layout scans over the smoother's affine elements
     int opt_group = 1;           // TGP_OPT_GROUP
     int opt_group_scan = 1;      // TGP_OPT_GROUP bit 2 (value & 4) switches the group-layout block scans off
     int opt_fuse = 1;            // TGP_OPT_FUSE_SCAN
@@ -445,15 +446,23 @@ int scan_prepare(tgp_handle* h, ScanCtx& c, int monoid, int64_t n0) {
     return TGP_OK;
 }
 
+static bool group_scan_ok(const tgp_handle* h, const ScanCtx& c) {
+    if (!h->opt_group_scan || h->kt->group_scan_reduce == nullptr) return false;
+    const bool pays = h->d >= 7 || h->opt_group == 2;
+    if (&c == &h->F && c.monoid == kFilter) return h->group_active || (h->use_group && h->opt_group && pays);
+    if (&c == &h->Rv && c.monoid == kAffineCov) return h->use_group_aff && h->opt_group && pays;
+    return false;
+}
+
 // first = 1: level 0 has been reduced by the producing chunk kernel itself (fused), start one level up
 void scan_up(tgp_handle* h, ScanCtx& c, size_t first = 0) {
-    // group-layout block scans: always with the group-per-chunk passes, and for d >= 7 also under the lane-per-chunk
-    // passes (same element format; the lane-per-element scans cost ~1 ms per launch there)
-    const bool grp = &c == &h->F && h->opt_group_scan && h->kt->group_scan_reduce != nullptr &&
-                     (h->group_active || (h->use_group && h->opt_group && h->d >= 7));
+    // group-layout block scans (filter elements; affine elements with covariance, i.e. the smoother's reverse scan): always
+    // with the group-per-chunk passes, and for d >= 7 also under the lane-per-chunk passes (same element formats; the
+    // lane-per-element scans cost ~1 ms per launch there)
+    const bool grp = group_scan_ok(h, c);
     for (size_t l = first; grp && l + 1 < c.n.size(); ++l) {
-        LaunchScope ls(h, "k_group_scan_reduce<filter>");
-        h->kt->group_scan_reduce(c.E[l], c.n[l], c.E[l + 1], c.n[l + 1], h->stream);
+        LaunchScope ls(h, c.monoid == kFilter ? "k_group_scan_reduce<filter>" : "k_group_scan_reduce<affine>");
+        h->kt->group_scan_reduce(c.monoid, c.E[l], c.n[l], c.E[l + 1], c.n[l + 1], h->stream);
     }
     if (grp) return;
     for (size_t l = first; l + 1 < c.n.size(); ++l) {
@@ -465,15 +474,15 @@ void scan_up(tgp_handle* h, ScanCtx& c, size_t first = 0) {
 // last = 1: stop above level 0 (the consuming chunk kernel scans its own block against S[1], fused)
 void scan_down(tgp_handle* h, ScanCtx& c, const double* x0dev, int last = 0) {
     const int top = (int)c.n.size() - 1;
-    if (&c == &h->F && h->opt_group_scan && h->kt->group_scan_apply != nullptr &&
-        (h->group_active || (h->use_group && h->opt_group && h->d >= 7))) {
+    if (group_scan_ok(h, c)) {
+        const bool flt = c.monoid == kFilter;
         {
-            LaunchScope ls(h, "k_group_scan_apply<filter,top>");
-            h->kt->group_scan_apply(c.E[top], c.n[top], x0dev, 1, c.S[top], c.fin, h->stream);
+            LaunchScope ls(h, flt ? "k_group_scan_apply<filter,top>" : "k_group_scan_apply<affine,top>");
+            h->kt->group_scan_apply(c.monoid, c.E[top], c.n[top], x0dev, 1, c.S[top], c.fin, h->stream);
         }
         for (int l = top - 1; l >= last; --l) {
-            LaunchScope ls(h, "k_group_scan_apply<filter>");
-            h->kt->group_scan_apply(c.E[l], c.n[l], c.S[l + 1], c.n[l + 1], c.S[l], nullptr, h->stream);
+            LaunchScope ls(h, flt ? "k_group_scan_apply<filter>" : "k_group_scan_apply<affine>");
+            h->kt->group_scan_apply(c.monoid, c.E[l], c.n[l], c.S[l + 1], c.n[l + 1], c.S[l], nullptr, h->stream);
         }
         return;
     }
@@ -1434,7 +1443,10 @@ static unsigned variant_selftest(int device, int d, bool lti_layout) {
     };
     if (lti_layout && kernel_table(d)->group_reduce_filter != nullptr) {   // group-per-chunk logpdf kernels against the out-of-line build
         st = keep;
-        if (run(3, true, rg) == TGP_OK && same(ra[kOpM0], rg[kOpM0])) ok |= 1u << kOpGroup;
+        if (run(3, true, rg) == TGP_OK) {
+            if (same(ra[kOpM0], rg[kOpM0])) ok |= 1u << kOpGroup;
+            if (same(ra[kOpM2], rg[kOpM2])) ok |= 1u << kOpGroupAff;     // smoother with the group-layout affine scans
+        }
     }
     if (rcb != TGP_OK) return ok;
     for (int op = 0; op < kOpCount; ++op) {
@@ -1455,10 +1467,12 @@ static void select_table(tgp_handle* h, int d, bool lti, int variant) {
     h->ktm = *safe;                 // always a private copy: entries are replaced one by one below
     h->kt = &h->ktm;
     h->use_group = false;
+    h->use_group_aff = false;
     h->variant_code = 1;
     if (variant == 1) return;
     if (variant == 3) {             // out-of-line build + the group-per-chunk logpdf kernels (used by the check itself)
         h->use_group = safe->group_reduce_filter != nullptr && lti;
+        h->use_group_aff = h->use_group;
         return;
     }
     if (variant == 2) {
@@ -1476,6 +1490,7 @@ static void select_table(tgp_handle* h, int d, bool lti, int variant) {
         h->variant_code = ok == want ? 2 : 3;
     }
     h->use_group = lti && ((g >> kOpGroup) & 1u) != 0u && safe->group_reduce_filter != nullptr;
+    h->use_group_aff = h->use_group && ((g >> kOpGroupAff) & 1u) != 0u;
 }
 
 extern "C" {

@@ -233,18 +233,28 @@ template <int D> __device__ __forceinline__ void gstate_store(const GState<D>& s
         if (i <= j) S[(int64_t)(D + j * (j + 1) / 2 + i) * n + idx] = s.P[i];
 }
 
-// staging of one element per group in LDS for the cross-group steps: [group][3 D + 2 values per lane][8 lanes]
-template <int D> struct GStage {
+// ---------------------------------------------------------------- monoid policies for the scan kernels
+// kPerLane doubles per lane are staged in LDS ([group][value][lane]) for the cross-group steps.
+template <int D> struct GFilterMO {
+    using Elem = GElem<D>;
+    using State = GState<D>;
     static constexpr int G = GroupGeom<D>::G;
-    static constexpr int kPerLane = 3 * D + 2;
-    static constexpr int kPerGroup = kPerLane * G;
-    __device__ __forceinline__ static void put(double* st, int g, int j, const GElem<D>& e) {
+    static constexpr int kPerLane = 3 * D + 2, kPerGroup = kPerLane * G;
+    __device__ __forceinline__ static void identity(Elem& e, int j, bool act) {
+        gelem_identity<D>(e, j);
+        if (!act) { TGP_GUNROLL for (int i = 0; i < D; ++i) e.A[i] = 0.0; }
+    }
+    __device__ __forceinline__ static void load(Elem& e, const double* E, int64_t n, int64_t idx, int j, bool act) { gelem_load<D>(e, E, n, idx, j, act); }
+    __device__ __forceinline__ static void store(const Elem& e, double* E, int64_t n, int64_t idx, int j) { gelem_store<D>(e, E, n, idx, j); }
+    __device__ __forceinline__ static void combine(const GroupOps<D>& op, const Elem& a, const Elem& b, Elem& o) { op.combine(a, b, o); }
+    __device__ __forceinline__ static void apply(const GroupOps<D>& op, const Elem& e, const State& s, State& o) { op.apply(e, s, o); }
+    __device__ __forceinline__ static void put(double* st, int g, int j, const Elem& e) {
         double* p = st + g * kPerGroup + j;
         TGP_GUNROLL for (int i = 0; i < D; ++i) { p[(i) * G] = e.A[i]; p[(D + i) * G] = e.C[i]; p[(2 * D + i) * G] = e.J[i]; }
         p[(3 * D) * G] = e.b;
         p[(3 * D + 1) * G] = e.eta;
     }
-    __device__ __forceinline__ static void get(const double* st, int g, int j, GElem<D>& e) {
+    __device__ __forceinline__ static void get(const double* st, int g, int j, Elem& e) {
         const double* p = st + g * kPerGroup + j;
         TGP_GUNROLL for (int i = 0; i < D; ++i) { e.A[i] = p[(i) * G]; e.C[i] = p[(D + i) * G]; e.J[i] = p[(2 * D + i) * G]; }
         e.b = p[(3 * D) * G];
@@ -252,89 +262,167 @@ template <int D> struct GStage {
     }
 };
 
-// REDUCE: Ehi[b] = E[256 b] o ... o E[256 b + 255]. Each of the 32 groups folds 8 consecutive elements, then a 5-round tree.
-template <int D>
+// affine monoid with covariance: x' = E x + g + N(0, L)  (a_combine_impl / a_apply_impl, COV = true)
+template <int D> struct GAElem {
+    double E[D], L[D], g;        // lane j: column j of E and L, element j of g
+};
+template <int D> struct GAffineMO {
+    using Elem = GAElem<D>;
+    using State = GState<D>;
+    static constexpr int G = GroupGeom<D>::G;
+    static constexpr int kPerLane = 2 * D + 1, kPerGroup = kPerLane * G;
+    __device__ __forceinline__ static void identity(Elem& e, int j, bool act) {
+        TGP_GUNROLL for (int i = 0; i < D; ++i) { e.E[i] = (act && i == j) ? 1.0 : 0.0; e.L[i] = 0.0; }
+        e.g = 0.0;
+    }
+    __device__ __forceinline__ static void load(Elem& e, const double* __restrict__ E, int64_t n, int64_t idx, int j, bool act) {
+        constexpr int DD = D * D;
+        identity(e, j, false);
+        if (!act) return;
+        TGP_GUNROLL for (int i = 0; i < D; ++i) {
+            const int lo = i < j ? i : j, hi = i < j ? j : i;
+            e.E[i] = E[(int64_t)(i + j * D) * n + idx];
+            e.L[i] = E[(int64_t)(DD + D + hi * (hi + 1) / 2 + lo) * n + idx];
+        }
+        e.g = E[(int64_t)(DD + j) * n + idx];
+    }
+    __device__ __forceinline__ static void store(const Elem& e, double* __restrict__ E, int64_t n, int64_t idx, int j) {
+        constexpr int DD = D * D;
+        TGP_GUNROLL for (int i = 0; i < D; ++i) {
+            E[(int64_t)(i + j * D) * n + idx] = e.E[i];
+            if (i <= j) E[(int64_t)(DD + D + j * (j + 1) / 2 + i) * n + idx] = e.L[i];
+        }
+        E[(int64_t)(DD + j) * n + idx] = e.g;
+    }
+    // out = later(b) o earlier(a):  E = E_b E_a ; g = E_b g_a + g_b ; L = E_b L_a E_b' + L_b
+    __device__ __forceinline__ static void combine(const GroupOps<D>& op, const Elem& a, const Elem& b, Elem& o) {
+        double t[D], v[D], T1[D];
+        op.gather(a.g, v);
+        op.publish(b.E);
+        op.row(t);                                           // row j of E_b
+        double gj = b.g;
+        TGP_GUNROLL for (int k = 0; k < D; ++k) gj = fma(t[k], v[k], gj);
+        op.left(a.E, o.E);
+        op.left(a.L, T1);
+        o.g = gj;
+        op.publish(T1);
+        TGP_GUNROLL for (int i = 0; i < D; ++i) {
+            double acc = 0.0;
+            TGP_GUNROLL for (int k = 0; k < D; ++k) acc = fma(op.tile[i + G * k], t[k], acc);
+            o.L[i] = acc + b.L[i];
+        }
+        op.symmetrize(o.L);
+    }
+    // m' = E m + g ; P' = E P E' + L
+    __device__ __forceinline__ static void apply(const GroupOps<D>& op, const Elem& e, const State& s, State& o) {
+        double t[D], v[D], T1[D];
+        op.gather(s.m, v);
+        op.publish(e.E);
+        op.row(t);
+        double mj = e.g;
+        TGP_GUNROLL for (int k = 0; k < D; ++k) mj = fma(t[k], v[k], mj);
+        op.left(s.P, T1);
+        o.m = mj;
+        op.publish(T1);
+        TGP_GUNROLL for (int i = 0; i < D; ++i) {
+            double acc = 0.0;
+            TGP_GUNROLL for (int k = 0; k < D; ++k) acc = fma(op.tile[i + G * k], t[k], acc);
+            o.P[i] = acc + e.L[i];
+        }
+        op.symmetrize(o.P);
+    }
+    __device__ __forceinline__ static void put(double* st, int g, int j, const Elem& e) {
+        double* p = st + g * kPerGroup + j;
+        TGP_GUNROLL for (int i = 0; i < D; ++i) { p[(i) * G] = e.E[i]; p[(D + i) * G] = e.L[i]; }
+        p[(2 * D) * G] = e.g;
+    }
+    __device__ __forceinline__ static void get(const double* st, int g, int j, Elem& e) {
+        const double* p = st + g * kPerGroup + j;
+        TGP_GUNROLL for (int i = 0; i < D; ++i) { e.E[i] = p[(i) * G]; e.L[i] = p[(D + i) * G]; }
+        e.g = p[(2 * D) * G];
+    }
+};
+
+// REDUCE: Ehi[b] = E[256 b] o ... o E[256 b + 255]. Each group folds its 256 / NGRP consecutive elements, then a tree over the groups.
+template <int D, class MO>
 __global__ __launch_bounds__(256) void k_group_scan_reduce(const double* __restrict__ Ein, int64_t n, double* __restrict__ Ehi, int64_t nhi) {
     constexpr int G = GroupGeom<D>::G, NGRP = GroupGeom<D>::NGRP, EPG = 256 / NGRP;    // elements per group
     __shared__ double tiles[NGRP * GroupGeom<D>::LD];
-    __shared__ double stage[NGRP * GStage<D>::kPerGroup];
+    __shared__ double stage[NGRP * MO::kPerGroup];
     const int tid = threadIdx.x, j = tid & (G - 1), g = tid / G;
     GroupOps<D> op{j, j < D, tiles + g * GroupGeom<D>::LD};
     const int64_t base = (int64_t)blockIdx.x * 256 + (int64_t)g * EPG;
-    GElem<D> acc, e, t;
-    gelem_identity<D>(acc, j);
-    if (!op.act) { TGP_GUNROLL for (int i = 0; i < D; ++i) acc.A[i] = 0.0; }
+    typename MO::Elem acc, e, t;
+    MO::identity(acc, j, op.act);
     for (int q = 0; q < EPG; ++q) {
         const int64_t idx = base + q;
         if (idx < n) {                       // uniform inside the group
-            gelem_load<D>(e, Ein, n, idx, j, op.act);
+            MO::load(e, Ein, n, idx, j, op.act);
             if (q == 0) acc = e;
-            else { op.combine(acc, e, t); acc = t; }
+            else { MO::combine(op, acc, e, t); acc = t; }
         }
     }
     for (int off = 1; off < NGRP; off <<= 1) {
         __syncthreads();
-        GStage<D>::put(stage, g, j, acc);
+        MO::put(stage, g, j, acc);
         __syncthreads();
         if ((g & (2 * off - 1)) == 0 && base + (int64_t)off * EPG < n) {      // the partner group holds at least one element
-            GStage<D>::get(stage, g + off, j, e);
-            op.combine(acc, e, t);
+            MO::get(stage, g + off, j, e);
+            MO::combine(op, acc, e, t);
             acc = t;
         }
     }
-    if (g == 0 && op.act) gelem_store<D>(acc, Ehi, nhi, (int64_t)blockIdx.x, j);
+    if (g == 0 && op.act) MO::store(acc, Ehi, nhi, (int64_t)blockIdx.x, j);
 }
 
 // APPLY: S[i] = apply(E[256 b] o ... o E[i-1], carry[b]); fin (top level, one block) = state after every element.
-// Group g folds its 8 elements, the 32 group totals are scanned (Kogge-Stone over LDS), the group's start state is the
-// exclusive prefix applied to the block carry, and its 8 states follow one f_apply at a time.
-template <int D>
+// Group g folds its elements, the group totals are scanned (Kogge-Stone over LDS), the group's start state is the
+// exclusive prefix applied to the block carry, and its states follow one apply at a time.
+template <int D, class MO>
 __global__ __launch_bounds__(256) void k_group_scan_apply(const double* __restrict__ Ein, int64_t n, const double* __restrict__ carry,
                                                           int64_t ncarry, double* __restrict__ S, double* __restrict__ fin) {
-    constexpr int G = GroupGeom<D>::G, NGRP = GroupGeom<D>::NGRP, EPG = 256 / NGRP;    // elements per group
+    constexpr int G = GroupGeom<D>::G, NGRP = GroupGeom<D>::NGRP, EPG = 256 / NGRP;
     __shared__ double tiles[NGRP * GroupGeom<D>::LD];
-    __shared__ double stage[NGRP * GStage<D>::kPerGroup];
+    __shared__ double stage[NGRP * MO::kPerGroup];
     const int tid = threadIdx.x, j = tid & (G - 1), g = tid / G;
     GroupOps<D> op{j, j < D, tiles + g * GroupGeom<D>::LD};
     const int64_t base = (int64_t)blockIdx.x * 256 + (int64_t)g * EPG;
-    GElem<D> tot, e, t;
-    gelem_identity<D>(tot, j);
-    if (!op.act) { TGP_GUNROLL for (int i = 0; i < D; ++i) tot.A[i] = 0.0; }
+    typename MO::Elem tot, e, t;
+    MO::identity(tot, j, op.act);
     for (int q = 0; q < EPG; ++q) {
         const int64_t idx = base + q;
         if (idx < n) {
-            gelem_load<D>(e, Ein, n, idx, j, op.act);
+            MO::load(e, Ein, n, idx, j, op.act);
             if (q == 0) tot = e;
-            else { op.combine(tot, e, t); tot = t; }
+            else { MO::combine(op, tot, e, t); tot = t; }
         }
     }
-    // inclusive scan of the group totals
-    for (int off = 1; off < NGRP; off <<= 1) {
+    for (int off = 1; off < NGRP; off <<= 1) {               // inclusive scan of the group totals
         __syncthreads();                                     // everybody has finished reading the previous round
-        GStage<D>::put(stage, g, j, tot);
+        MO::put(stage, g, j, tot);
         __syncthreads();
         if (g >= off) {
-            GStage<D>::get(stage, g - off, j, e);
-            op.combine(e, tot, t);
+            MO::get(stage, g - off, j, e);
+            MO::combine(op, e, tot, t);
             tot = t;
         }
     }
     __syncthreads();
-    GStage<D>::put(stage, g, j, tot);
+    MO::put(stage, g, j, tot);
     __syncthreads();
     GState<D> s, s2;
     gstate_load<D>(s, carry, ncarry, (int64_t)blockIdx.x, j, op.act);
     if (g > 0) {
-        GStage<D>::get(stage, g - 1, j, e);                  // exclusive prefix of this group
-        op.apply(e, s, s2);
+        MO::get(stage, g - 1, j, e);                         // exclusive prefix of this group
+        MO::apply(op, e, s, s2);
         s = s2;
     }
     for (int q = 0; q < EPG; ++q) {
         const int64_t idx = base + q;
         if (idx < n) {
             if (op.act) gstate_store<D>(s, S, n, idx, j);
-            gelem_load<D>(e, Ein, n, idx, j, op.act);
-            op.apply(e, s, s2);
+            MO::load(e, Ein, n, idx, j, op.act);
+            MO::apply(op, e, s, s2);
             s = s2;
         }
     }

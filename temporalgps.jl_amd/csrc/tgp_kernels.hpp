@@ -661,8 +661,9 @@ struct KernelTable {
     void (*group_reduce_filter)(const ModelView&, int L0, int64_t n0, double* E0, hipStream_t);
     void (*group_apply_logpdf)(const ModelView&, int L0, int64_t n0, const double* S0, double* partial, hipStream_t);
     // ... and block scans over filter elements in the same layout (tgp_group_scan.hpp), 256 elements per block
-    void (*group_scan_reduce)(const double* Ein, int64_t n, double* Ehi, int64_t nhi, hipStream_t);
-    void (*group_scan_apply)(const double* Ein, int64_t n, const double* carry, int64_t ncarry, double* S, double* fin, hipStream_t);
+    // (monoid: kFilter or kAffineCov)
+    void (*group_scan_reduce)(int monoid, const double* Ein, int64_t n, double* Ehi, int64_t nhi, hipStream_t);
+    void (*group_scan_apply)(int monoid, const double* Ein, int64_t n, const double* carry, int64_t ncarry, double* S, double* fin, hipStream_t);
     int group_chunks_per_block;      // 32 (eight lanes per chunk, d <= 8) or 16 (sixteen, d <= 16); 0 without group kernels
     void scan_reduce(int monoid, const double* Ein, int64_t n, double* Ehi, int64_t nhi, hipStream_t s) const {
         scan_reduce_c[monoid == kFilter ? kScanFilter : monoid == kFilterAD ? kScanAD : kScanAffine](monoid, Ein, n, Ehi, nhi, s);

@@ -67,3 +67,31 @@ def test_group_path_is_selected_for_d8(tgp):
     assert "k_group_reduce_filter<lti>" in names and "k_group_apply_filter<lti,logpdf>" in names, names
     lp_ref = ref.logpdf(model, y)
     assert abs(lp - lp_ref) <= 1e-10 * abs(lp_ref)
+
+
+@pytest.mark.parametrize("d", [5, 7, 8, 9, 14])
+def test_group_scans_under_the_smoother(tgp, d):
+    """posterior marginals with the group-layout block scans (filter elements forward, affine elements in reverse) under the
+    lane-per-chunk passes, forced on for every d (TGP_OPT_GROUP = 2), against the oracle; several scan levels"""
+    rng = np.random.default_rng(3 * d)
+    T = 2500
+    model = U.random_lgssm(rng, False, d, T)
+    eps = (rng.standard_normal((T, d)), rng.standard_normal(T), rng.standard_normal(d))
+    y = ref.rand(model, *eps)
+    tr = tgp.GaussMarkovModel(tgp.Forward, model["A"], model["a"], model["Q"], tgp.Gaussian(model["x0m"], model["x0P"]))
+    dm = tgp.LGSSM(tr, tgp.ScalarOutputLGC(model["H"], model["h"], model["R"]), T=T)
+    hd = dm.handle()
+    hd.set_option(tgp._lib.OPT_GROUP, 2)
+    post = ref.posterior(model, y)
+    Rn = rng.random(T) * 0.1
+    pm, pC = ref.marginals(ref.replace_observation_noise_cov(post, Rn))
+    for chunk in (2, 9):                       # 1250 / 278 chunks: three / two scan levels at d >= 5
+        hd.set_option(tgp._lib.OPT_CHUNK, chunk)
+        hd.set_option(tgp._lib.OPT_PROFILE, 1)
+        hd.profile_reset()
+        gm, gv = tgp.posterior_marginals(dm, y, Rn)
+        names = set(hd.profile())
+        hd.set_option(tgp._lib.OPT_PROFILE, 0)
+        assert "k_group_scan_apply<affine,top>" in names and "k_group_scan_apply<filter,top>" in names, names
+        np.testing.assert_allclose(gm, pm, rtol=1e-8, atol=1e-8)
+        np.testing.assert_allclose(gv, pC, rtol=1e-8, atol=1e-9)
