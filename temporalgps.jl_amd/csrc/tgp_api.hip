@@ -239,6 +239,7 @@ struct tgp_handle {
     bool group_active = false;   // ... by the group-per-chunk pass 1 (32 chunks per block, its own chunking)
     bool use_group = false;      // group-per-chunk logpdf kernels validated for this model (tgp_group.hpp)
     bool use_group_aff = false;  // ... and the group-layout scans over the smoother's affine elements
+    bool use_group_sm = false;   // ... and the group-per-chunk smoother passes (tgp_group_smooth.hpp)
     int opt_group = 1;           // TGP_OPT_GROUP
     int opt_group_scan = 1;      // TGP_OPT_GROUP bit 2 (value & 4) switches the group-layout block scans off
     int opt_fuse = 1;            // TGP_OPT_FUSE_SCAN
@@ -450,7 +451,7 @@ static bool group_scan_ok(const tgp_handle* h, const ScanCtx& c) {
     if (!h->opt_group_scan || h->kt->group_scan_reduce == nullptr) return false;
     const bool pays = h->d >= 7 || h->opt_group == 2;
     if (&c == &h->F && c.monoid == kFilter) return h->group_active || (h->use_group && h->opt_group && pays);
-    if (&c == &h->Rv && c.monoid == kAffineCov) return h->use_group_aff && h->opt_group && pays;
+    if (&c == &h->Rv && c.monoid == kAffineCov) return h->group_active || (h->use_group_aff && h->opt_group && pays);
     return false;
 }
 
@@ -603,7 +604,8 @@ int forward_reduce(tgp_handle* h, uint32_t flags, int for_mode = -1) {
     // build in brackets): d = 5 1.9 (0.70), d = 6 2.2 (1.55), d = 7 2.9 (4.3), d = 8 3.4 (12.1) -- their time hardly
     // depends on d (LDS exchanges and shuffles, not flops), so they pay from d = 7 on (TGP_OPT_GROUP = 2 forces them).
     const bool group_pays = h->d >= 7 || h->opt_group == 2;
-    if (for_mode == 0 && h->use_group && h->opt_group && group_pays && h->kt->group_reduce_filter != nullptr && h->lti && h->p == 1) {
+    const bool grp_post = for_mode == 2 && h->use_group_sm && h->ordering == 0 && h->kt->group_apply_posterior != nullptr;
+    if ((for_mode == 0 || grp_post) && h->use_group && h->opt_group && group_pays && h->kt->group_reduce_filter != nullptr && h->lti && h->p == 1) {
         // 8 chunks per wave: 16384 chunks are two waves per SIMD; longer chunks also mean fewer scan elements, and the
         // d >= 7 block scans (spill-bound, ~1.5 ms per launch) are what is left of the call
         int64_t L0 = h->opt_chunk;
@@ -662,11 +664,15 @@ int set_obs(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t fla
 int forward_apply(tgp_handle* h, int mode, const FilterOut& fo, const double* x0dev = nullptr) {
     scan_down(h, h->F, x0dev ? x0dev : h->bx0.d(), h->fused ? 1 : 0);
     if (h->group_active) {
-        if (mode != 0) return h->fail(TGP_EINVAL, "internal: group-per-chunk elements are only valid for the logpdf pass");
+        if (mode != 0 && mode != 2) return h->fail(TGP_EINVAL, "internal: group-per-chunk elements are only valid for the logpdf / smoother passes");
         const int64_t cpb = h->kt->group_chunks_per_block;
         const int64_t nb = (h->n0 + cpb - 1) / cpb;
         HIPCHK(h->partial.ensure((size_t)nb * 3 * sizeof(double)));
-        {
+        if (mode == 2) {
+            TRY(scan_prepare(h, h->Rv, kAffineCov, h->n0));
+            LaunchScope ls(h, "k_group_apply_filter<lti,posterior>");
+            h->kt->group_apply_posterior(h->mv, h->L0, h->n0, h->F.S[0], fo.fs, h->Rv.E[0], h->partial.d(), h->stream);
+        } else {
             LaunchScope ls(h, "k_group_apply_filter<lti,logpdf>");
             h->kt->group_apply_logpdf(h->mv, h->L0, h->n0, h->F.S[0], h->partial.d(), h->stream);
         }
@@ -991,8 +997,8 @@ int tgp_posterior(tgp_handle* h, const double* y, const uint8_t* missing, uint32
     return tm.finish();
 }
 
-static int smoother_forward_impl(tgp_handle* h, uint32_t flags, const double* x0dev = nullptr) {
-    TRY(forward_reduce(h, flags));
+static int smoother_forward_impl(tgp_handle* h, uint32_t flags, const double* x0dev = nullptr, bool allow_group = false) {
+    TRY(forward_reduce(h, flags, allow_group ? 2 : -1));
     const size_t fsz = (size_t)((h->n0 + 63) / 64) * 64 * h->L0 * state_size(h->d) * sizeof(double);
     HIPCHK(h->fs.ensure(fsz));
     FilterOut fo{};
@@ -1005,6 +1011,11 @@ static int smoother_forward_impl(tgp_handle* h, uint32_t flags, const double* x0
 
 static int smoother_backward_impl(tgp_handle* h, const double* xs_dev, const double* Rnew_dev, int64_t sRn, double* mean_dev, double* var_dev) {
     scan_down(h, h->Rv, xs_dev);
+    if (h->group_active) {
+        LaunchScope ls(h, "k_group_smooth<lti>");
+        h->kt->group_smooth(h->mv, h->L0, h->n0, h->F.S[0], h->Rv.S[0], h->fs.d(), Rnew_dev, sRn, mean_dev, var_dev, flag_ptr(h), h->stream);
+        return TGP_OK;
+    }
     {
         LaunchScope ls(h, h->lti ? "k_smooth<lti>" : "k_smooth<per-step>");
         h->kt->smooth(h->lti, h->mv, h->L0, h->n0, h->F.S[0], h->Rv.S[0], h->fs.d(), Rnew_dev, sRn, mean_dev, var_dev,
@@ -1026,7 +1037,7 @@ int tgp_posterior_marginals(tgp_handle* h, const double* y, const uint8_t* missi
     TRY(stage_in(h, h->bRnew, Rnew, rshared ? (size_t)h->p * sizeof(double) : nT, idev, &pR));
     TRY(set_obs(h, y, missing, flags));
     tm.inputs_done();
-    TRY(smoother_forward_impl(h, flags));
+    TRY(smoother_forward_impl(h, flags, nullptr, /*allow_group=*/true));
     double *dm = nullptr, *dv = nullptr;
     TRY(stage_out(h, h->bo1, mean_out, nT, odev, &dm));
     TRY(stage_out(h, h->bo2, var_out, nT, odev, &dv));
@@ -1468,11 +1479,13 @@ static void select_table(tgp_handle* h, int d, bool lti, int variant) {
     h->kt = &h->ktm;
     h->use_group = false;
     h->use_group_aff = false;
+    h->use_group_sm = false;
     h->variant_code = 1;
     if (variant == 1) return;
     if (variant == 3) {             // out-of-line build + the group-per-chunk logpdf kernels (used by the check itself)
         h->use_group = safe->group_reduce_filter != nullptr && lti;
         h->use_group_aff = h->use_group;
+        h->use_group_sm = h->use_group;
         return;
     }
     if (variant == 2) {
@@ -1491,6 +1504,7 @@ static void select_table(tgp_handle* h, int d, bool lti, int variant) {
     }
     h->use_group = lti && ((g >> kOpGroup) & 1u) != 0u && safe->group_reduce_filter != nullptr;
     h->use_group_aff = h->use_group && ((g >> kOpGroupAff) & 1u) != 0u;
+    h->use_group_sm = h->use_group_aff;      // the same known-answer operation (posterior marginals) exercises both
 }
 
 extern "C" {

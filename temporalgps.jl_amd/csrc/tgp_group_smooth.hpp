@@ -1,0 +1,307 @@
+// Posterior path in the group layout (G lanes per chunk, lane j = column j; LTI family, scalar observations, Forward):
+//   k_group_apply_posterior   pass 2, MODE 2: filter from the carry-in state, filtered states to scratch, and the chunk's
+//                             smoother element composed step by step from the reference's (jittered) invert_dynamics
+//   k_group_smooth            pass 3: RTS recursion inside the chunk from the smoothed state at its end, emitting
+//                             N(H x + h, H P H' + R_new) per step
+// Same recursions as chunk_apply_filter<MODE 2> / chunk_smooth (tgp_chunk_body.inc) and invert_dynamics_impl /
+// a_extend_right_impl (tgp_math_body.inc). Column-distributed pieces on top of tgp_group.hpp / tgp_group_scan.hpp:
+//   Cholesky   upper factor U of Pp + 1e-10 I by rows: at step i lane i finishes U[i][i] and broadcasts its column above the
+//              diagonal, the diagonal and its reciprocal; every lane j > i then has U[i][j]
+//   solves     U is published once; the two triangular solves for column j of (U'U)^-1 (A Pf) are lane-local
+//   G = Gt'    one transpose through the tile; L = Pf - (U Gt)'(U Gt) with one more publish
+#pragma once
+
+namespace TGP_NS {
+
+// scratch of filtered states in the group layout: [chunk][step][packed state]
+template <int D> __device__ __forceinline__ int64_t gfs_index(int64_t c, int i, int L0) { return (c * (int64_t)L0 + i) * Dim<D>::NS; }
+template <int D> __device__ __forceinline__ void gfs_store(double* __restrict__ fs, int64_t base, int j, double mj, const double* Pc) {
+    fs[base + j] = mj;
+    TGP_GUNROLL for (int i = 0; i < D; ++i)
+        if (i <= j) fs[base + D + j * (j + 1) / 2 + i] = Pc[i];
+}
+template <int D> __device__ __forceinline__ void gfs_load(const double* __restrict__ fs, int64_t base, int j, bool act, double& mj, double* Pc) {
+    mj = 0.0;
+    TGP_GUNROLL for (int i = 0; i < D; ++i) Pc[i] = 0.0;
+    if (!act) return;
+    mj = fs[base + j];
+    TGP_GUNROLL for (int i = 0; i < D; ++i) {
+        const int lo = i < j ? i : j, hi = i < j ? j : i;
+        Pc[i] = fs[base + D + hi * (hi + 1) / 2 + lo];
+    }
+}
+
+template <int D> struct GroupRts {
+    static constexpr int G = GroupGeom<D>::G, V0 = GroupGeom<D>::V0, V1 = GroupGeom<D>::V1;
+    GroupOps<D> op;
+    const double* sA;     // A in LDS, row-major [G i + k]
+
+    __device__ __forceinline__ void mul_A(const double* x, double* y) const {
+        TGP_GUNROLL for (int i = 0; i < D; ++i) {
+            double acc = 0.0;
+            TGP_GUNROLL for (int k = 0; k < D; ++k) acc = fma(sA[G * i + k], x[k], acc);
+            y[i] = acc;
+        }
+    }
+    // m <- A m + a ; P <- A P A' + Q     (GroupLane::predict)
+    __device__ __forceinline__ void predict(double& vj, double aj, double* Sc, const double* Qc) const {
+        double W[D], row[D], v[D];
+        mul_A(Sc, W);
+        wave_sync();
+        TGP_GUNROLL for (int i = 0; i < D; ++i) op.tile[i + G * op.j] = W[i];
+        op.tile[V0 + op.j] = vj;
+        wave_sync();
+        TGP_GUNROLL for (int k = 0; k < D; ++k) {
+            row[k] = op.act ? op.tile[op.j + G * k] : 0.0;
+            v[k] = op.tile[V0 + k];
+        }
+        mul_A(row, Sc);
+        TGP_GUNROLL for (int i = 0; i < D; ++i) Sc[i] += Qc[i];
+        double acc = 0.0;
+        TGP_GUNROLL for (int k = 0; k < D; ++k) acc = fma(sA[G * op.j + k], v[k], acc);
+        vj = acc + aj;
+    }
+
+    // invert_dynamics (lgssm.jl:231-238): filtered (mf, Pf), predicted (mp, Pp) -> x_{k-1} | x_k ~ N(G x_k + g, L).
+    // Outputs by columns: Gc = column j of G, Xc = column j of Gt = G' (i.e. ROW j of G), gj, Lc.
+    __device__ __forceinline__ bool invert_dynamics(double mfj, const double* Pfc, double mpj, const double* Ppc, double* Gc, double* Xc,
+                                                    double& gj, double* Lc) const {
+        const int j = op.j;
+        double Uc[D], rinv[D];
+        bool ok = true;
+        // ---- Cholesky of Pp + 1e-10 I (upper factor, U'U), one row per step
+        TGP_GUNROLL for (int i = 0; i < D; ++i) Uc[i] = 0.0;
+        TGP_GUNROLL for (int i = 0; i < D; ++i) {
+            // lane i: its column above the diagonal is complete; finish the diagonal and hand both to everybody
+            double acc = Ppc[i] + ((i == j) ? 1e-10 : 0.0);          // S[i][j] (row i of this lane's column)
+            wave_sync();
+            if (j == i) {
+                double dg = acc;
+                TGP_GUNROLL for (int k = 0; k < i; ++k) dg = fma(-Uc[k], Uc[k], dg);
+                const double di = sqrt(dg);
+                TGP_GUNROLL for (int k = 0; k < i; ++k) op.tile[V0 + k] = Uc[k];
+                op.tile[V1 + 0] = dg;
+                op.tile[V1 + 1] = di;
+                op.tile[V1 + 2] = 1.0 / di;
+            }
+            wave_sync();
+            const double dg = op.tile[V1 + 0], di = op.tile[V1 + 1];
+            rinv[i] = op.tile[V1 + 2];
+            ok = ok && (dg > 0.0);
+            TGP_GUNROLL for (int k = 0; k < i; ++k) acc = fma(-op.tile[V0 + k], Uc[k], acc);   // - sum_k U[k][i] U[k][j]
+            Uc[i] = (j == i) ? di : ((j > i && op.act) ? acc * rinv[i] : 0.0);
+        }
+        // ---- Gt = U \\ (U' \\ (A Pf)), column j
+        double Bc[D];
+        mul_A(Pfc, Bc);
+        op.publish(Uc);                                              // tile[i + G k] = U[i][k]
+        TGP_GUNROLL for (int i = 0; i < D; ++i) {                    // U' z = b
+            double acc = Bc[i];
+            TGP_GUNROLL for (int k = 0; k < i; ++k) acc = fma(-op.tile[k + G * i], Xc[k], acc);
+            Xc[i] = acc * rinv[i];
+        }
+        TGP_GUNROLL for (int i = D - 1; i >= 0; --i) {               // U w = z
+            double acc = Xc[i];
+            TGP_GUNROLL for (int k = i + 1; k < D; ++k) acc = fma(-op.tile[i + G * k], Xc[k], acc);
+            Xc[i] = acc * rinv[i];
+        }
+        if (!op.act) { TGP_GUNROLL for (int i = 0; i < D; ++i) Xc[i] = 0.0; }
+        // ---- UG = U Gt (U still published), then L = Pf - UG' UG
+        double UG[D];
+        TGP_GUNROLL for (int i = 0; i < D; ++i) {
+            double acc = 0.0;
+            TGP_GUNROLL for (int k = i; k < D; ++k) acc = fma(op.tile[i + G * k], Xc[k], acc);
+            UG[i] = acc;
+        }
+        // g = mf - G mp   with (G mp)_j = sum_k G[j][k] mp_k = sum_k Gt[k][j] mp_k
+        double mp[D];
+        op.gather(mpj, mp);
+        double acc = 0.0;
+        TGP_GUNROLL for (int k = 0; k < D; ++k) acc = fma(Xc[k], mp[k], acc);
+        gj = mfj - acc;
+        op.publish(UG);
+        TGP_GUNROLL for (int i = 0; i < D; ++i) {
+            double a2 = 0.0;
+            TGP_GUNROLL for (int k = 0; k < D; ++k) a2 = fma(op.tile[k + G * i], UG[k], a2);
+            Lc[i] = op.act ? Pfc[i] - a2 : 0.0;
+        }
+        // ---- G = Gt': column j of G is row j of Gt
+        op.publish(Xc);
+        op.row(Gc);
+        return ok;
+    }
+
+    // e <- e o (G, g, L)     (a_extend_right_impl): e.g += E g ; e.L += E L E' ; e.E = E G
+    __device__ __forceinline__ void extend_right(GAElem<D>& e, const double* Gc, double gj, const double* Lc) const {
+        double t[D], v[D], T1[D], EG[D];
+        op.gather(gj, v);
+        op.publish(e.E);
+        op.row(t);                                                   // row j of E
+        double acc = 0.0;
+        TGP_GUNROLL for (int k = 0; k < D; ++k) acc = fma(t[k], v[k], acc);
+        e.g += acc;
+        op.left(Lc, T1);                                             // E L
+        op.left(Gc, EG);                                             // E G
+        op.publish(T1);
+        TGP_GUNROLL for (int i = 0; i < D; ++i) {
+            double a2 = 0.0;
+            TGP_GUNROLL for (int k = 0; k < D; ++k) a2 = fma(op.tile[i + G * k], t[k], a2);
+            e.L[i] += a2;
+            e.E[i] = EG[i];
+        }
+    }
+
+    // xs <- N(G xs.m + g, G xs.P G' + L)      (predict with (G, g, L)); Xc = row j of G
+    __device__ __forceinline__ void smooth_step(double& mj, double* Pc, const double* Gc, const double* Xc, double gj, const double* Lc) const {
+        double v[D], T1[D];
+        op.gather(mj, v);
+        double acc = 0.0;
+        TGP_GUNROLL for (int k = 0; k < D; ++k) acc = fma(Xc[k], v[k], acc);
+        mj = acc + gj;
+        op.publish(Gc);
+        op.left(Pc, T1);                                             // G P
+        op.publish(T1);
+        TGP_GUNROLL for (int i = 0; i < D; ++i) {
+            double a2 = 0.0;
+            TGP_GUNROLL for (int k = 0; k < D; ++k) a2 = fma(op.tile[i + G * k], Xc[k], a2);
+            Pc[i] = a2 + Lc[i];
+        }
+    }
+};
+
+// ---------------------------------------------------------------- pass 2, MODE 2
+template <int D>
+__global__ __launch_bounds__(256) void k_group_apply_posterior(ModelView mv, int L0, int64_t n0, const double* __restrict__ S0,
+                                                               double* __restrict__ fs, double* __restrict__ R0, double* __restrict__ partial) {
+    constexpr int G = GroupGeom<D>::G, NGRP = GroupGeom<D>::NGRP;
+    __shared__ __attribute__((aligned(16))) double sA[G * G];
+    __shared__ double tiles[NGRP * GroupGeom<D>::LD];
+    __shared__ double sh[12];
+    GroupLane<D> gl;
+    double Qc[D], H[D], aj, hh, Rsh;
+    group_setup<D>(mv, sA, tiles, gl, Qc, H, aj, hh, Rsh);
+    const int j = gl.j;
+    GroupRts<D> rts{GroupOps<D>{j, gl.act, gl.tile}, sA};
+    const int64_t c = (int64_t)blockIdx.x * NGRP + (threadIdx.x / G);
+    int64_t r0, r1;
+    chunk_range(mv, c < n0 ? c : n0, L0, r0, r1);
+    double Pc[D], mj = 0.0;
+    TGP_GUNROLL for (int i = 0; i < D; ++i) Pc[i] = (i == j) ? 1.0 : 0.0;
+    if (c < n0 && gl.act) {
+        mj = S0[(int64_t)j * n0 + c];
+        TGP_GUNROLL for (int i = 0; i < D; ++i) {
+            const int lo = i < j ? i : j, hi = i < j ? j : i;
+            Pc[i] = S0[(int64_t)(D + hi * (hi + 1) / 2 + lo) * n0 + c];
+        }
+    }
+    double Hj = 0.0;
+    TGP_GUNROLL for (int i = 0; i < D; ++i) Hj = (i == j) ? H[i] : Hj;
+    GAElem<D> rev;
+    GAffineMO<D>::identity(rev, j, gl.act);
+    double lml = 0.0, nmiss = 0.0;
+    bool ok = true;
+    GroupObs<G> ob;
+    for (int g = 0; g < L0; g += G) {
+        ob.load(mv, c, L0, r0, r1, g, j);
+        const int64_t rg = r0 + g;
+        const int gend = (int)((r1 - rg) < G ? (r1 - rg) : G);
+        double sprod = 1.0, quad = 0.0;
+        for (int k = 0; k < gend; ++k) {
+            double y, R;
+            bool miss;
+            ob.step(mv, Rsh, k, y, R, miss);
+            {   // Forward models only: every step predicts
+                double Pf[D], Gc[D], Xc[D], Lc[D], gj;
+                const double mf = mj;
+                TGP_GUNROLL for (int i = 0; i < D; ++i) Pf[i] = Pc[i];
+                rts.predict(mj, aj, Pc, Qc);
+                ok = rts.invert_dynamics(mf, Pf, mj, Pc, Gc, Xc, gj, Lc) && ok;
+                rts.extend_right(rev, Gc, gj, Lc);
+            }
+            double vj = 0.0;
+            TGP_GUNROLL for (int i = 0; i < D; ++i) vj = fma(Pc[i], H[i], vj);
+            const double S = group_sum<G>(Hj * vj) + R;
+            const double hm = group_sum<G>(Hj * mj);
+            ok = ok && (S > 0.0);
+            const double iS = 1.0 / S;
+            const double v = y - (hm + hh);
+            const double viS = v * iS;
+            mj = fma(vj, viS, mj);
+            double V[D];
+            gl.gather(vj, V);
+            const double wgt = vj * iS;
+            TGP_GUNROLL for (int i = 0; i < D; ++i) Pc[i] = fma(-V[i], wgt, Pc[i]);
+            quad += v * viS;
+            sprod *= S;
+            if (sprod > 1e100 || sprod < 1e-100) {
+                lml -= 0.5 * log(sprod);
+                sprod = 1.0;
+            }
+            nmiss += miss ? 1.0 : 0.0;
+            if (gl.act) gfs_store<D>(fs, gfs_index<D>(c, g + k, L0), j, mj, Pc);
+        }
+        if (gend > 0) lml -= 0.5 * (gend * kLog2Pi + log(sprod) + quad);
+    }
+    if (c < n0 && r1 > r0 && gl.act) GAffineMO<D>::store(rev, R0, n0, n0 - 1 - c, j);
+    double a = (j == 0 && c < n0) ? lml : 0.0, b = (j == 0 && c < n0) ? nmiss : 0.0;
+    int bad = (j == 0 && c < n0 && !ok) ? 1 : 0;
+    block_sum3(a, b, bad, sh);
+    if (threadIdx.x == 0) {
+        partial[3 * (int64_t)blockIdx.x + 0] = a;
+        partial[3 * (int64_t)blockIdx.x + 1] = b;
+        partial[3 * (int64_t)blockIdx.x + 2] = (double)bad;
+    }
+}
+
+// ---------------------------------------------------------------- pass 3
+template <int D>
+__global__ __launch_bounds__(256) void k_group_smooth(ModelView mv, int L0, int64_t n0, const double* __restrict__ S0, const double* __restrict__ S0r,
+                                                      const double* __restrict__ fs, const double* __restrict__ Rnew, int64_t sRn,
+                                                      double* __restrict__ mean_out, double* __restrict__ var_out, int* __restrict__ bad) {
+    constexpr int G = GroupGeom<D>::G, NGRP = GroupGeom<D>::NGRP;
+    __shared__ __attribute__((aligned(16))) double sA[G * G];
+    __shared__ double tiles[NGRP * GroupGeom<D>::LD];
+    GroupLane<D> gl;
+    double Qc[D], H[D], aj, hh, Rsh;
+    group_setup<D>(mv, sA, tiles, gl, Qc, H, aj, hh, Rsh);
+    const int j = gl.j;
+    GroupRts<D> rts{GroupOps<D>{j, gl.act, gl.tile}, sA};
+    const int64_t c = (int64_t)blockIdx.x * NGRP + (threadIdx.x / G);
+    if (c >= n0) return;                        // whole groups leave together; no block-level barrier below
+    int64_t r0, r1;
+    chunk_range(mv, c, L0, r0, r1);
+    GState<D> xs, carry;
+    gstate_load<D>(xs, S0r, n0, n0 - 1 - c, j, gl.act);
+    gstate_load<D>(carry, S0, n0, c, j, gl.act);
+    double Hj = 0.0;
+    TGP_GUNROLL for (int i = 0; i < D; ++i) Hj = (i == j) ? H[i] : Hj;
+    bool ok = true;
+    for (int64_t r = r1 - 1; r >= r0; --r) {
+        // emission marginal of the smoothed state at step r with the NEW noise (lgssm.jl:111-115, missings.jl:35-41)
+        double pj = 0.0;
+        TGP_GUNROLL for (int i = 0; i < D; ++i) pj = fma(xs.P[i], H[i], pj);
+        const double mean = group_sum<G>(Hj * xs.m) + hh;
+        const double var = group_sum<G>(Hj * pj);
+        const int64_t tm = micro_index(mv, c, (int)(r - r0), L0);
+        if (j == 0) {
+            mean_out[tm] = mean;
+            var_out[tm] = var + (sRn == 0 ? Rnew[0] : Rnew[tm]);
+        }
+        // filtered state before this step, its prediction, the backward kernel, one RTS step
+        double mf, Pf[D];
+        if (r == r0) {
+            mf = carry.m;
+            TGP_GUNROLL for (int i = 0; i < D; ++i) Pf[i] = carry.P[i];
+        } else {
+            gfs_load<D>(fs, gfs_index<D>(c, (int)(r - r0) - 1, L0), j, gl.act, mf, Pf);
+        }
+        double mp = mf, Pp[D], Gc[D], Xc[D], Lc[D], gj;
+        TGP_GUNROLL for (int i = 0; i < D; ++i) Pp[i] = Pf[i];
+        rts.predict(mp, aj, Pp, Qc);
+        ok = rts.invert_dynamics(mf, Pf, mp, Pp, Gc, Xc, gj, Lc) && ok;
+        rts.smooth_step(xs.m, xs.P, Gc, Xc, gj, Lc);
+    }
+    if (!ok && j == 0) atomicOr(bad, 1);
+}
+
+}  // namespace TGP_NS

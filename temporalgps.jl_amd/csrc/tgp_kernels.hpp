@@ -664,6 +664,10 @@ struct KernelTable {
     // (monoid: kFilter or kAffineCov)
     void (*group_scan_reduce)(int monoid, const double* Ein, int64_t n, double* Ehi, int64_t nhi, hipStream_t);
     void (*group_scan_apply)(int monoid, const double* Ein, int64_t n, const double* carry, int64_t ncarry, double* S, double* fin, hipStream_t);
+    // ... and the posterior path: pass 2 MODE 2 (scratch in the group layout [chunk][step][state]) and pass 3
+    void (*group_apply_posterior)(const ModelView&, int L0, int64_t n0, const double* S0, double* fs, double* R0, double* partial, hipStream_t);
+    void (*group_smooth)(const ModelView&, int L0, int64_t n0, const double* S0, const double* S0r, const double* fs, const double* Rnew,
+                         int64_t sRn, double* mean_out, double* var_out, int* bad, hipStream_t);
     int group_chunks_per_block;      // 32 (eight lanes per chunk, d <= 8) or 16 (sixteen, d <= 16); 0 without group kernels
     void scan_reduce(int monoid, const double* Ein, int64_t n, double* Ehi, int64_t nhi, hipStream_t s) const {
         scan_reduce_c[monoid == kFilter ? kScanFilter : monoid == kFilterAD ? kScanAD : kScanAffine](monoid, Ein, n, Ehi, nhi, s);
@@ -684,3 +688,4 @@ const KernelTable* kernel_table(int d);
 
 #include "tgp_group.hpp"
 #include "tgp_group_scan.hpp"
+#include "tgp_group_smooth.hpp"

@@ -95,3 +95,41 @@ def test_group_scans_under_the_smoother(tgp, d):
         assert "k_group_scan_apply<affine,top>" in names and "k_group_scan_apply<filter,top>" in names, names
         np.testing.assert_allclose(gm, pm, rtol=1e-8, atol=1e-8)
         np.testing.assert_allclose(gv, pC, rtol=1e-8, atol=1e-9)
+
+
+@pytest.mark.parametrize("d", [5, 6, 7, 8, 9, 12, 16])
+@pytest.mark.parametrize("per_step_R", [False, True])
+def test_group_smoother_equals_oracle(tgp, d, per_step_R):
+    """posterior marginals through the group-per-chunk smoother (pass 2 MODE 2 + pass 3 + group scans; tgp_group_smooth.hpp),
+    forced on for every d, against the oracle: missing data, per-step noise and R_new, ragged chunks"""
+    rng = np.random.default_rng(5 * d + per_step_R)
+    T = 1501
+    model = U.random_lgssm(rng, False, d, T)
+    if per_step_R:
+        model["R"] = rng.random(T) + 0.1
+    eps = (rng.standard_normal((T, d)), rng.standard_normal(T), rng.standard_normal(d))
+    y = ref.rand(model, *eps)
+    missing = rng.random(T) < 0.2
+    ym = y.copy()
+    ym[missing] = np.nan
+    tr = tgp.GaussMarkovModel(tgp.Forward, model["A"], model["a"], model["Q"], tgp.Gaussian(model["x0m"], model["x0P"]))
+    dm = tgp.LGSSM(tr, tgp.ScalarOutputLGC(model["H"], model["h"], model["R"]), T=T)
+    hd = dm.handle()
+    hd.set_option(tgp._lib.OPT_GROUP, 2)
+    post = ref.posterior_missing(model, y, missing)
+    Rn = rng.random(T) * 0.1
+    pm, pC = ref.marginals(ref.replace_observation_noise_cov(post, Rn))
+    pm1, pC1 = ref.marginals(ref.replace_observation_noise_cov(post, np.full(T, 0.07)))
+    for chunk in (0, 5, 16, 37):
+        hd.set_option(tgp._lib.OPT_CHUNK, chunk)
+        hd.set_option(tgp._lib.OPT_PROFILE, 1)
+        hd.profile_reset()
+        gm, gv = tgp.posterior_marginals(dm, ym, Rn)
+        names = set(hd.profile())
+        hd.set_option(tgp._lib.OPT_PROFILE, 0)
+        assert "k_group_smooth<lti>" in names and "k_group_apply_filter<lti,posterior>" in names, names
+        np.testing.assert_allclose(gm, pm, rtol=1e-8, atol=1e-8)
+        np.testing.assert_allclose(gv, pC, rtol=1e-8, atol=1e-9)
+        gm1, gv1 = tgp.posterior_marginals(dm, ym, np.array([0.07]))
+        np.testing.assert_allclose(gm1, pm1, rtol=1e-8, atol=1e-8)
+        np.testing.assert_allclose(gv1, pC1, rtol=1e-8, atol=1e-9)
