@@ -604,7 +604,11 @@ int forward_reduce(tgp_handle* h, uint32_t flags, int for_mode = -1) {
     // build in brackets): d = 5 1.9 (0.70), d = 6 2.2 (1.55), d = 7 2.9 (4.3), d = 8 3.4 (12.1) -- their time hardly
     // depends on d (LDS exchanges and shuffles, not flops), so they pay from d = 7 on (TGP_OPT_GROUP = 2 forces them).
     const bool group_pays = h->d >= 7 || h->opt_group == 2;
-    const bool grp_post = for_mode == 2 && h->use_group_sm && h->ordering == 0 && h->kt->group_apply_posterior != nullptr;
+    // (posterior path in the group layout, tgp_group_smooth.hpp: pass 2 + pass 3 take 7.7 + 7.4 ms at T = 1e7 for d = 7 and 8
+    // alike -- 498 / 310 VGPRs, one wave per SIMD, bound by the D + 10 LDS exchanges of a step; the lane-per-chunk kernels
+    // need 6.3 + 1.8 (+ 1.8 for their own pass 1) at d = 7 and 15.4 + 5.3 (+ 6.7) at d = 8: group from d = 8 on)
+    const bool grp_post = for_mode == 2 && h->use_group_sm && h->ordering == 0 && h->kt->group_apply_posterior != nullptr &&
+                          (h->d >= 8 || h->opt_group == 2);
     if ((for_mode == 0 || grp_post) && h->use_group && h->opt_group && group_pays && h->kt->group_reduce_filter != nullptr && h->lti && h->p == 1) {
         // 8 chunks per wave: 16384 chunks are two waves per SIMD; longer chunks also mean fewer scan elements, and the
         // d >= 7 block scans (spill-bound, ~1.5 ms per launch) are what is left of the call
