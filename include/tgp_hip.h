@@ -70,6 +70,7 @@ typedef struct tgp_handle tgp_handle;
                            elements with eight lanes per element (tgp_group_scan.hpp), once they have reproduced the out-of-line
                            build in the run-time check: 1 (default) where they are faster (d >= 7), 2 for every d = 5..8,
                            0 never; + 4 keeps the lane-per-element block scans */
+#define TGP_OPT_TIMING 6 /* 1: record the hipEvents behind tgp_last_timing (off by default: ~30 us of host time per call) */
 #define TGP_OPT_FUSE_SCAN 4 /* 1 (default): the level-0 scan reduce / apply of the forward scan run inside the chunk kernels;
                                0: stand-alone k_scan_reduce / k_scan_apply launches (bit-identical results, for A/B timing) */
 
@@ -199,7 +200,7 @@ int tgp_shard_smoother_backward(tgp_handle* h, const double* gathered_dev, int w
                                 uint32_t flags, double* mean_out, double* var_out, double* lml_out);
 
 /* ---- timing ------------------------------------------------------------------------------------ */
-/* device time of the last call (hipEvent, kernels only) and its host<->device copy times, ms */
+/* device time of the last call (hipEvent, kernels only) and its host<->device copy times, ms; needs TGP_OPT_TIMING = 1 */
 int tgp_last_timing(const tgp_handle* h, double* kernel_ms, double* h2d_ms, double* d2h_ms);
 /* per-kernel hipEvent profile accumulated since tgp_profile_reset (TGP_OPT_PROFILE = 1) */
 int tgp_profile_reset(tgp_handle* h);

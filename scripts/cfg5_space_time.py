@@ -20,6 +20,7 @@ y = rng.standard_normal(T * Nr)
 lp = dec.logpdf(y)                       # includes model upload + tiling
 t2 = time.perf_counter()
 hd = dec.model.handle()
+hd.set_option(tgp._lib.OPT_TIMING, 1)
 res = {}
 for name, fn in (("logpdf", lambda: dec.logpdf(y)), ("posterior_marginals", lambda: dec.posterior_marginals(y, 0.1))):
     fn()

@@ -14,6 +14,7 @@ gen = torch.Generator(device="cuda:0"); gen.manual_seed(1)
 y = tgp.rand((torch.randn((T, d), dtype=torch.float64, device="cuda:0", generator=gen),
               torch.randn((T,), dtype=torch.float64, device="cuda:0", generator=gen), np.zeros(d)), model)
 hd = model.handle()
+hd.set_option(tgp._lib.OPT_TIMING, 1)
 for _ in range(2):
     lp, g = P.logpdf_and_gradient(fx, y)
 ts = []

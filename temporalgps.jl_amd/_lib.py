@@ -20,7 +20,7 @@ IN_DEVICE = 1 << 16
 OUT_DEVICE = 1 << 17
 REUSE_REDUCE = 1 << 18
 OK, EINVAL, ENOTPD, EHIP, EUNSUPPORTED = 0, 1, 2, 3, 4
-OPT_CHUNK, OPT_PROFILE, OPT_VARIANT, OPT_FUSE_SCAN, OPT_GROUP = 1, 2, 3, 4, 5
+OPT_CHUNK, OPT_PROFILE, OPT_VARIANT, OPT_FUSE_SCAN, OPT_GROUP, OPT_TIMING = 1, 2, 3, 4, 5, 6
 
 _dp = ctypes.POINTER(ctypes.c_double)
 _u8p = ctypes.POINTER(ctypes.c_uint8)
@@ -170,6 +170,7 @@ class Handle:
         self.check(self.lib.tgp_set_option(self.h, opt, int(value)))
 
     def last_timing(self):
+        """needs set_option(OPT_TIMING, 1) before the call that is being timed"""
         k, a, b = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
         self.lib.tgp_last_timing(self.h, ctypes.byref(k), ctypes.byref(a), ctypes.byref(b))
         return dict(kernel_ms=k.value, h2d_ms=a.value, d2h_ms=b.value)

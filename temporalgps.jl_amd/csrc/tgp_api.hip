@@ -231,6 +231,7 @@ struct tgp_handle {
     double* host_result = nullptr;  // pinned, 8 doubles: [0] lml [1] nmiss [2] filter-bad ; int flags at [4]
     int64_t opt_chunk = 0;
     int profile = 0;
+    int timing = 0;              // TGP_OPT_TIMING
     int variant_opt = 0;   // TGP_OPT_VARIANT: 0 auto (run-time check), 1 safe, 2 fast
     int L0 = 0;
     int64_t n0 = 0;
@@ -531,25 +532,29 @@ int scan_total_to_host(tgp_handle* h, ScanCtx& c, double* elem_out) {
 
 struct CallTimer {
     tgp_handle* h;
-    // clear == false: a later phase of a multi-phase (time-sharded) call, the flags of the earlier phases are kept
+    // clear == false: a later phase of a multi-phase (time-sharded) call, the flags of the earlier phases are kept.
+    // The four hipEvents of a call (h2d / kernels / d2h split of tgp_last_timing) are recorded only with TGP_OPT_TIMING:
+    // records and elapsed-time queries cost the host ~30 us per call, a few percent of a 0.4 ms logpdf.
     explicit CallTimer(tgp_handle* h_, bool clear = true) : h(h_) {
-        (void)hipEventRecord(h->ev[0], h->stream);
+        if (h->timing) (void)hipEventRecord(h->ev[0], h->stream);
         if (clear) (void)hipMemsetAsync(h->result.p, 0, 8 * sizeof(double), h->stream);   // lml / flags of this call
     }
-    void inputs_done() { (void)hipEventRecord(h->ev[1], h->stream); }
-    void kernels_done() { (void)hipEventRecord(h->ev[2], h->stream); }
+    void inputs_done() { if (h->timing) (void)hipEventRecord(h->ev[1], h->stream); }
+    void kernels_done() { if (h->timing) (void)hipEventRecord(h->ev[2], h->stream); }
     // one 64-byte D2H into pinned memory + ONE stream sync per call; then decode lml and the error flags
     int finish(double* lml_out = nullptr) {
         HIPCHK(hipMemcpyAsync(h->host_result, h->result.p, 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-        (void)hipEventRecord(h->ev[3], h->stream);
+        if (h->timing) (void)hipEventRecord(h->ev[3], h->stream);
         HIPCHK(hipStreamSynchronize(h->stream));
-        float a = 0.f, b = 0.f, c = 0.f;
-        (void)hipEventElapsedTime(&a, h->ev[0], h->ev[1]);
-        (void)hipEventElapsedTime(&b, h->ev[1], h->ev[2]);
-        (void)hipEventElapsedTime(&c, h->ev[2], h->ev[3]);
-        h->h2d_ms = a;
-        h->kernel_ms = b;
-        h->d2h_ms = c;
+        if (h->timing) {
+            float a = 0.f, b = 0.f, c = 0.f;
+            (void)hipEventElapsedTime(&a, h->ev[0], h->ev[1]);
+            (void)hipEventElapsedTime(&b, h->ev[1], h->ev[2]);
+            (void)hipEventElapsedTime(&c, h->ev[2], h->ev[3]);
+            h->h2d_ms = a;
+            h->kernel_ms = b;
+            h->d2h_ms = c;
+        }
         resolve_profile(h);
         if (lml_out) *lml_out = h->host_result[0];
         int flags = 0;
@@ -795,6 +800,10 @@ int tgp_set_option(tgp_handle* h, int option, int64_t value) {
             h->reduce_valid = false;
             h->smoother_valid = false;
         }
+        return TGP_OK;
+    }
+    if (option == TGP_OPT_TIMING) {
+        h->timing = value != 0;
         return TGP_OK;
     }
     if (option == TGP_OPT_GROUP) {
