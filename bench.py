@@ -122,6 +122,28 @@ def gradient_leg(tgp, torch, name, T, d, device, steps, y):
                 gradient={kk: float(v) for kk, v in g.items()})
 
 
+def split_leg(tgp, torch, model, y, Rnew, T, steps):
+    """the two passes of a step reported separately (resident data, wall clock per call), and the same two calls
+    END TO END from host memory -- y uploaded over PCIe, (mean, var) returned to the host -- which is never `value`."""
+    def timed(fn, n):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
+    t_lp = timed(lambda: tgp.logpdf(model, y), steps)
+    t_pm = timed(lambda: tgp.posterior_marginals(model, y, Rnew), steps)
+    y_host = y.cpu().numpy()
+    rn_host = Rnew.cpu().numpy()
+    t_lp_h = timed(lambda: tgp.logpdf(model, y_host), 3)
+    t_pm_h = timed(lambda: tgp.posterior_marginals(model, y_host, rn_host), 3)
+    return dict(logpdf_ms=t_lp * 1e3, posterior_marginals_ms=t_pm * 1e3, logpdf_steps_per_s=T / t_lp, posterior_marginals_steps_per_s=T / t_pm,
+                host_memory=dict(logpdf_ms=t_lp_h * 1e3, posterior_marginals_ms=t_pm_h * 1e3, steps_per_s=T / (t_lp_h + t_pm_h),
+                                 note="inputs in pageable host memory, outputs to host: 8 B/step in, 16 B/step out over PCIe"))
+
+
 def cpu_gradient_baseline(name, T_sample):
     """CPU stand-in for logpdf + gradient: central finite differences of the sequential C restatement over the same 3
     hyper-parameters = 6 logpdf evaluations on one core (the reference uses reverse-mode AD of the same loop, whose
@@ -307,6 +329,8 @@ def main():
         )
         if T == 10_000_000 and world == 1 and d == 3 and not args.chunk:
             out["valu"] = valu_utilisation(prof, d, args.layout)
+        if world == 1 and not args.no_general_leg:
+            out["split"] = split_leg(tgp, torch, model, y, Rnew, T, max(3, args.steps // 2))
         if args.layout == "lti" and world == 1 and not args.no_general_leg:
             out["logpdf_and_grad"] = gradient_leg(tgp, torch, name, T, d, local, max(3, args.steps // 2), y)
             if not args.no_cpu_baseline:
