@@ -17,6 +17,7 @@ SPECS = {
     "sum52_32_d5": ("sum", ("matern52",), ("matern32",)),
     "sum52_52_d6": ("sum", ("matern52",), ("matern52",)),
     "sum52_12_d4": ("sum", ("matern52",), ("matern12",)),
+    "sum52_52_32_d8": ("sum", ("matern52",), ("matern52",), ("matern32",)),     # eight lanes per chunk (tgp_group*.hpp)
 }
 
 
@@ -32,7 +33,8 @@ def _product_model(name, T, per_step=False):
     return lti_sde.build_lgssm(lti_sde.to_kernel(SPECS[name]), lti_sde.RegularSpacing(0.0, 0.1, T), 0.1, force_per_step=per_step)
 
 
-@pytest.mark.parametrize("name,per_step", [("matern52_d3", False), ("matern52_d3", True), ("sum52_32_d5", False), ("sum52_52_d6", False)])
+@pytest.mark.parametrize("name,per_step", [("matern52_d3", False), ("matern52_d3", True), ("sum52_32_d5", False), ("sum52_52_d6", False),
+                                           ("sum52_52_32_d8", False)])
 def test_full_size_parity_with_sequential_oracle(tgp, name, per_step):
     import torch
     T = 10_000_000
