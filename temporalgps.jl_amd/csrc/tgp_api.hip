@@ -614,19 +614,21 @@ int forward_reduce(tgp_handle* h, uint32_t flags, int for_mode = -1) {
     // need 6.3 + 1.8 (+ 1.8 for their own pass 1) at d = 7 and 15.4 + 5.3 (+ 6.7) at d = 8: group from d = 8 on)
     const bool grp_post = for_mode == 2 && h->use_group_sm && h->ordering == 0 && h->kt->group_apply_posterior != nullptr &&
                           (h->d >= 8 || h->opt_group == 2);
-    if ((for_mode == 0 || grp_post) && h->use_group && h->opt_group && group_pays && h->kt->group_reduce_filter != nullptr && h->lti && h->p == 1) {
+    if ((for_mode == 0 || grp_post) && h->use_group && h->opt_group && group_pays && h->kt->group_reduce_filter != nullptr && h->lti) {
         // 8 chunks per wave: 16384 chunks are two waves per SIMD; longer chunks also mean fewer scan elements, and the
         // d >= 7 block scans (spill-bound, ~1.5 ms per launch) are what is left of the call
         int64_t L0 = h->opt_chunk;
         if (L0 <= 0) {
             // (sixteen lanes per chunk: half as many chunks for the same number of waves)
             const int64_t nch = h->kt->group_chunks_per_block == 32 ? 16384 : 8192;
-            L0 = (h->T + nch - 1) / nch;
+            L0 = (h->T * h->p + nch - 1) / nch;
             if (L0 < 8) L0 = 8;
         }
-        if (L0 > h->T) L0 = h->T;
+        const int64_t Tm = h->T * h->p;                        // processing steps (one scalar observation each)
+        L0 = ((L0 + h->p - 1) / h->p) * h->p;                  // whole time steps per chunk
+        if (L0 > Tm) L0 = Tm;
         h->L0 = (int)L0;
-        h->n0 = (h->T + L0 - 1) / L0;
+        h->n0 = (Tm + L0 - 1) / L0;
         TRY(scan_prepare(h, h->F, kFilter, h->n0));
         {
             LaunchScope ls(h, "k_group_reduce_filter<lti>");

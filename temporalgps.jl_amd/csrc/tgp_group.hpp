@@ -128,6 +128,17 @@ template <int D> __device__ __forceinline__ void group_setup(const ModelView& mv
     Rsh = mv.sR == 0 ? mv.R[0] : 0.0;
 }
 
+// Vector observations (p > 1, shared emission block H [p][d], h [p], R [p]): processing step i of a chunk is observation
+// row i % p of its time step (chunks hold whole time steps); the row is re-read (wave-uniform, cached) per step.
+template <int D> __device__ __forceinline__ void group_obs_row(const ModelView& mv, int jj, int j, double* H, double& Hj, double& hh, double& Rsh) {
+    if (mv.p == 1) return;
+    TGP_GUNROLL for (int i = 0; i < D; ++i) H[i] = mv.H[jj * D + i];
+    Hj = 0.0;
+    TGP_GUNROLL for (int i = 0; i < D; ++i) Hj = (i == j) ? H[i] : Hj;
+    hh = mv.h[jj];
+    Rsh = mv.sR == 0 ? mv.R[jj] : 0.0;
+}
+
 // ---------------------------------------------------------------- pass 1: the chunk's filter element
 template <int D>
 __global__ __launch_bounds__(256) void k_group_reduce_filter(ModelView mv, int L0, int64_t n0, double* __restrict__ E0) {
@@ -154,8 +165,10 @@ __global__ __launch_bounds__(256) void k_group_reduce_filter(ModelView mv, int L
         for (int k = 0; k < gend; ++k) {
             double y, R;
             bool miss;
+            const int jj = mv.p == 1 ? 0 : (g + k) % mv.p;
+            group_obs_row<D>(mv, jj, j, H, Hj, hh, Rsh);
             ob.step(mv, Rsh, k, y, R, miss);
-            const bool do_predict = !(mv.ordering != 0 && (rg + k) == 0);
+            const bool do_predict = jj == 0 && !(mv.ordering != 0 && (rg + k) == 0);
             if (do_predict) {
                 double T1[D];
                 gl.mul_A(Ac, T1);                       // Abar <- A Abar
@@ -228,8 +241,10 @@ __global__ __launch_bounds__(256) void k_group_apply_logpdf(ModelView mv, int L0
         for (int k = 0; k < gend; ++k) {
             double y, R;
             bool miss;
+            const int jj = mv.p == 1 ? 0 : (g + k) % mv.p;
+            group_obs_row<D>(mv, jj, j, H, Hj, hh, Rsh);
             ob.step(mv, Rsh, k, y, R, miss);
-            const bool do_predict = !(mv.ordering != 0 && (rg + k) == 0);
+            const bool do_predict = jj == 0 && !(mv.ordering != 0 && (rg + k) == 0);
             if (do_predict) {
                 gl.predict(mj, aj, Pc, Qc);             // m <- A m + a ; P <- A P A' + Q
             }

@@ -209,8 +209,10 @@ __global__ __launch_bounds__(256) void k_group_apply_posterior(ModelView mv, int
         for (int k = 0; k < gend; ++k) {
             double y, R;
             bool miss;
+            const int jj = mv.p == 1 ? 0 : (g + k) % mv.p;
+            group_obs_row<D>(mv, jj, j, H, Hj, hh, Rsh);
             ob.step(mv, Rsh, k, y, R, miss);
-            {   // Forward models only: every step predicts
+            if (jj == 0) {   // Forward models only: every time step predicts (at its first observation)
                 double Pf[D], Gc[D], Xc[D], Lc[D], gj;
                 const double mf = mj;
                 TGP_GUNROLL for (int i = 0; i < D; ++i) Pf[i] = Pc[i];
@@ -277,6 +279,8 @@ __global__ __launch_bounds__(256) void k_group_smooth(ModelView mv, int L0, int6
     TGP_GUNROLL for (int i = 0; i < D; ++i) Hj = (i == j) ? H[i] : Hj;
     bool ok = true;
     for (int64_t r = r1 - 1; r >= r0; --r) {
+        const int jj = mv.p == 1 ? 0 : (int)((r - r0) % mv.p);
+        group_obs_row<D>(mv, jj, j, H, Hj, hh, Rsh);
         // emission marginal of the smoothed state at step r with the NEW noise (lgssm.jl:111-115, missings.jl:35-41)
         double pj = 0.0;
         TGP_GUNROLL for (int i = 0; i < D; ++i) pj = fma(xs.P[i], H[i], pj);
@@ -285,8 +289,9 @@ __global__ __launch_bounds__(256) void k_group_smooth(ModelView mv, int L0, int6
         const int64_t tm = micro_index(mv, c, (int)(r - r0), L0);
         if (j == 0) {
             mean_out[tm] = mean;
-            var_out[tm] = var + (sRn == 0 ? Rnew[0] : Rnew[tm]);
+            var_out[tm] = var + (sRn == 0 ? Rnew[jj] : Rnew[tm]);
         }
+        if (jj != 0) continue;                  // inside a time step the state does not move
         // filtered state before this step, its prediction, the backward kernel, one RTS step
         double mf, Pf[D];
         if (r == r0) {

@@ -133,3 +133,40 @@ def test_group_smoother_equals_oracle(tgp, d, per_step_R):
         gm1, gv1 = tgp.posterior_marginals(dm, ym, np.array([0.07]))
         np.testing.assert_allclose(gm1, pm1, rtol=1e-8, atol=1e-8)
         np.testing.assert_allclose(gv1, pC1, rtol=1e-8, atol=1e-9)
+
+
+@pytest.mark.parametrize("d,p", [(5, 2), (8, 3), (12, 5), (15, 4)])
+def test_group_vector_observations(tgp, d, p):
+    """p > 1 (SmallOutputLGC with diagonal noise, shared emission block) through the group kernels: p scalar micro-steps per
+    time step, predict only at the first; logpdf (with per-element missing data) and posterior marginals against the oracle's
+    joint update (lgc.jl:129-141)"""
+    rng = np.random.default_rng(11 * d + p)
+    T = 700
+    model = U.random_lgssm_small(rng, False, d, p, T)
+    eps = (rng.standard_normal((T, d)), rng.standard_normal((T, p)), rng.standard_normal(d))
+    y = ref.rand(model, *eps)
+    tr = tgp.GaussMarkovModel(tgp.Forward, model["A"], model["a"], model["Q"], tgp.Gaussian(model["x0m"], model["x0P"]))
+    dm = tgp.LGSSM(tr, tgp.SmallOutputLGC(model["H"], model["h"], np.diagonal(model["R"], axis1=-2, axis2=-1)), T=T)
+    hd = dm.handle()
+    hd.set_option(tgp._lib.OPT_GROUP, 2)
+    lp = ref.logpdf(model, y)
+    miss = rng.random((T, p)) < 0.2
+    lpm = ref.logpdf_missing(model, y, miss)
+    ym = y.copy()
+    ym[miss] = np.nan
+    post = ref.posterior(model, y)
+    Rn = rng.random((T, p)) * 0.1
+    pm, pC = ref.marginals(ref.replace_observation_noise_cov(post, np.stack([np.diag(v) for v in Rn])))
+    for chunk in (0, 4, 11):
+        hd.set_option(tgp._lib.OPT_CHUNK, chunk)
+        hd.set_option(tgp._lib.OPT_PROFILE, 1)
+        hd.profile_reset()
+        got = tgp.logpdf(dm, y)
+        gm, gv = tgp.posterior_marginals(dm, y, Rn)
+        names = set(hd.profile())
+        hd.set_option(tgp._lib.OPT_PROFILE, 0)
+        assert "k_group_reduce_filter<lti>" in names and "k_group_smooth<lti>" in names, names
+        assert abs(got - lp) <= 1e-10 * abs(lp)
+        assert abs(tgp.logpdf(dm, ym) - lpm) <= 1e-10 * abs(lpm)
+        np.testing.assert_allclose(gm, pm, rtol=1e-8, atol=1e-8)
+        np.testing.assert_allclose(gv, np.diagonal(pC, axis1=-2, axis2=-1), rtol=1e-8, atol=1e-9)
