@@ -62,7 +62,7 @@ static const KernelTable* fast_kernel_table(int d) {
 }
 // Per (state dimension, LTI layout family?): which operations of the inlined (fast) build reproduced the out-of-line (safe)
 // build in the run-time known-answer check. Bit kOpDecided = the check has run.
-enum VariantOp { kOpM0 = 0, kOpM1, kOpM2, kOpM3, kOpAffine, kOpGrad, kOpCount, kOpGroupAff = 28, kOpGroup = 29, kOpDecided = 30 };
+enum VariantOp { kOpM0 = 0, kOpM1, kOpM2, kOpM3, kOpAffine, kOpGrad, kOpCount, kOpGroupMarg = 27, kOpGroupAff = 28, kOpGroup = 29, kOpDecided = 30 };
 static unsigned g_variant[17][2] = {{0u}};
 static const unsigned kAllOps = (1u << kOpCount) - 1u;
 
@@ -241,6 +241,7 @@ struct tgp_handle {
     bool use_group = false;      // group-per-chunk logpdf kernels validated for this model (tgp_group.hpp)
     bool use_group_aff = false;  // ... and the group-layout scans over the smoother's affine elements
     bool use_group_sm = false;   // ... and the group-per-chunk smoother passes (tgp_group_smooth.hpp)
+    bool use_group_marg = false; // ... and the group-per-chunk prior-marginals passes
     int opt_group = 1;           // TGP_OPT_GROUP
     int opt_group_scan = 1;      // TGP_OPT_GROUP bit 2 (value & 4) switches the group-layout block scans off
     int opt_fuse = 1;            // TGP_OPT_FUSE_SCAN
@@ -1111,10 +1112,40 @@ int tgp_smoother_backward(tgp_handle* h, const double* xs_m, const double* xs_P,
 
 static int affine_impl(tgp_handle* h, bool rnd, const double* x0dev, const double* eps_t, const double* eps_e, double* mean_dev,
                        double* var_dev) {
-    choose_chunk(h);
-    TRY(ensure_tiled(h));
     h->reduce_valid = false;
     h->smoother_valid = false;
+    h->group_active = false;
+    if (!rnd && h->lti && h->ordering == 0 && h->use_group_marg && h->opt_group && (h->d >= 7 || h->opt_group == 2) &&
+        h->kt->group_reduce_marginals != nullptr) {
+        // prior marginals of a d >= 7 LTI model in the group layout (tgp_group_smooth.hpp)
+        const int64_t Tm = h->T * h->p;
+        int64_t L0 = h->opt_chunk;
+        if (L0 <= 0) {
+            const int64_t nch = h->kt->group_chunks_per_block == 32 ? 16384 : 8192;
+            L0 = (Tm + nch - 1) / nch;
+            if (L0 < 8) L0 = 8;
+        }
+        L0 = ((L0 + h->p - 1) / h->p) * h->p;
+        if (L0 > Tm) L0 = Tm;
+        h->L0 = (int)L0;
+        h->n0 = (Tm + L0 - 1) / L0;
+        TRY(scan_prepare(h, h->Rv, kAffineCov, h->n0));
+        h->group_active = true;                  // the scans over Rv run in the group layout too
+        {
+            LaunchScope ls(h, "k_group_reduce_affine<marginals>");
+            h->kt->group_reduce_marginals(h->mv, h->L0, h->n0, h->Rv.E[0], h->stream);
+        }
+        scan_up(h, h->Rv);
+        scan_down(h, h->Rv, x0dev);
+        {
+            LaunchScope ls(h, "k_group_apply_affine<marginals>");
+            h->kt->group_apply_marginals(h->mv, h->L0, h->n0, h->Rv.S[0], mean_dev, var_dev, h->stream);
+        }
+        h->group_active = false;
+        return TGP_OK;
+    }
+    choose_chunk(h);
+    TRY(ensure_tiled(h));
     const int monoid = rnd ? kAffineMean : kAffineCov;
     TRY(scan_prepare(h, h->Rv, monoid, h->n0));
     int* bad = flag_ptr(h);
@@ -1472,6 +1503,7 @@ static unsigned variant_selftest(int device, int d, bool lti_layout) {
         if (run(3, true, rg) == TGP_OK) {
             if (same(ra[kOpM0], rg[kOpM0])) ok |= 1u << kOpGroup;
             if (same(ra[kOpM2], rg[kOpM2])) ok |= 1u << kOpGroupAff;     // smoother with the group-layout affine scans
+            if (same(ra[kOpAffine], rg[kOpAffine])) ok |= 1u << kOpGroupMarg;   // prior marginals (and the unchanged rand)
         }
     }
     if (rcb != TGP_OK) return ok;
@@ -1495,12 +1527,14 @@ static void select_table(tgp_handle* h, int d, bool lti, int variant) {
     h->use_group = false;
     h->use_group_aff = false;
     h->use_group_sm = false;
+    h->use_group_marg = false;
     h->variant_code = 1;
     if (variant == 1) return;
     if (variant == 3) {             // out-of-line build + the group-per-chunk logpdf kernels (used by the check itself)
         h->use_group = safe->group_reduce_filter != nullptr && lti;
         h->use_group_aff = h->use_group;
         h->use_group_sm = h->use_group;
+        h->use_group_marg = h->use_group;
         return;
     }
     if (variant == 2) {
@@ -1520,6 +1554,7 @@ static void select_table(tgp_handle* h, int d, bool lti, int variant) {
     h->use_group = lti && ((g >> kOpGroup) & 1u) != 0u && safe->group_reduce_filter != nullptr;
     h->use_group_aff = h->use_group && ((g >> kOpGroupAff) & 1u) != 0u;
     h->use_group_sm = h->use_group_aff;      // the same known-answer operation (posterior marginals) exercises both
+    h->use_group_marg = h->use_group && ((g >> kOpGroupMarg) & 1u) != 0u;
 }
 
 extern "C" {

@@ -310,3 +310,69 @@ __global__ __launch_bounds__(256) void k_group_smooth(ModelView mv, int L0, int6
 }
 
 }  // namespace TGP_NS
+
+// ---------------------------------------------------------------- prior marginals (Forward, LTI family) in the group layout
+// marginals(model) (lgssm.jl:99-109): x <- predict(x) once per time step, N(H x + h, H P H' + R) per observation.
+// Pass 1 composes the chunk's affine element (E, g, L) <- (A E, A g + a, A L A' + Q); pass 2 propagates the state.
+namespace TGP_NS {
+
+template <int D>
+__global__ __launch_bounds__(256) void k_group_reduce_marginals(ModelView mv, int L0, int64_t n0, double* __restrict__ E0) {
+    constexpr int G = GroupGeom<D>::G, NGRP = GroupGeom<D>::NGRP;
+    __shared__ __attribute__((aligned(16))) double sA[G * G];
+    __shared__ double tiles[NGRP * GroupGeom<D>::LD];
+    GroupLane<D> gl;
+    double Qc[D], H[D], aj, hh, Rsh;
+    group_setup<D>(mv, sA, tiles, gl, Qc, H, aj, hh, Rsh);
+    const int j = gl.j;
+    const int64_t c = (int64_t)blockIdx.x * NGRP + (threadIdx.x / G);
+    if (c >= n0) return;
+    int64_t r0, r1;
+    chunk_range(mv, c, L0, r0, r1);
+    GAElem<D> e;
+    GAffineMO<D>::identity(e, j, gl.act);
+    const int64_t nt = (r1 - r0) / mv.p;            // whole time steps in the chunk
+    for (int64_t t = 0; t < nt; ++t) {
+        double T1[D];
+        gl.mul_A(e.E, T1);
+        TGP_GUNROLL for (int i = 0; i < D; ++i) e.E[i] = T1[i];
+        gl.predict(e.g, aj, e.L, Qc);
+    }
+    if (r1 > r0 && gl.act) GAffineMO<D>::store(e, E0, n0, c, j);
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void k_group_apply_marginals(ModelView mv, int L0, int64_t n0, const double* __restrict__ S0,
+                                                               double* __restrict__ mean_out, double* __restrict__ var_out) {
+    constexpr int G = GroupGeom<D>::G, NGRP = GroupGeom<D>::NGRP;
+    __shared__ __attribute__((aligned(16))) double sA[G * G];
+    __shared__ double tiles[NGRP * GroupGeom<D>::LD];
+    GroupLane<D> gl;
+    double Qc[D], H[D], aj, hh, Rsh;
+    group_setup<D>(mv, sA, tiles, gl, Qc, H, aj, hh, Rsh);
+    const int j = gl.j;
+    const int64_t c = (int64_t)blockIdx.x * NGRP + (threadIdx.x / G);
+    if (c >= n0) return;
+    int64_t r0, r1;
+    chunk_range(mv, c, L0, r0, r1);
+    GState<D> x;
+    gstate_load<D>(x, S0, n0, c, j, gl.act);
+    double Hj = 0.0;
+    TGP_GUNROLL for (int i = 0; i < D; ++i) Hj = (i == j) ? H[i] : Hj;
+    for (int64_t r = r0; r < r1; ++r) {
+        const int jj = mv.p == 1 ? 0 : (int)((r - r0) % mv.p);
+        group_obs_row<D>(mv, jj, j, H, Hj, hh, Rsh);
+        if (jj == 0) gl.predict(x.m, aj, x.P, Qc);
+        double pj = 0.0;
+        TGP_GUNROLL for (int i = 0; i < D; ++i) pj = fma(x.P[i], H[i], pj);
+        const double mean = group_sum<G>(Hj * x.m) + hh;
+        const double var = group_sum<G>(Hj * pj);
+        const int64_t tm = micro_index(mv, c, (int)(r - r0), L0);
+        if (j == 0) {
+            mean_out[tm] = mean;
+            var_out[tm] = var + (mv.sR != 0 ? mv.R[tm] : Rsh);
+        }
+    }
+}
+
+}  // namespace TGP_NS

@@ -668,6 +668,9 @@ struct KernelTable {
     void (*group_apply_posterior)(const ModelView&, int L0, int64_t n0, const double* S0, double* fs, double* R0, double* partial, hipStream_t);
     void (*group_smooth)(const ModelView&, int L0, int64_t n0, const double* S0, const double* S0r, const double* fs, const double* Rnew,
                          int64_t sRn, double* mean_out, double* var_out, int* bad, hipStream_t);
+    // ... and prior marginals (Forward): affine element per chunk, then state propagation + emission
+    void (*group_reduce_marginals)(const ModelView&, int L0, int64_t n0, double* E0, hipStream_t);
+    void (*group_apply_marginals)(const ModelView&, int L0, int64_t n0, const double* S0, double* mean_out, double* var_out, hipStream_t);
     int group_chunks_per_block;      // 32 (eight lanes per chunk, d <= 8) or 16 (sixteen, d <= 16); 0 without group kernels
     void scan_reduce(int monoid, const double* Ein, int64_t n, double* Ehi, int64_t nhi, hipStream_t s) const {
         scan_reduce_c[monoid == kFilter ? kScanFilter : monoid == kFilterAD ? kScanAD : kScanAffine](monoid, Ein, n, Ehi, nhi, s);

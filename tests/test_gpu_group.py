@@ -170,3 +170,37 @@ def test_group_vector_observations(tgp, d, p):
         assert abs(tgp.logpdf(dm, ym) - lpm) <= 1e-10 * abs(lpm)
         np.testing.assert_allclose(gm, pm, rtol=1e-8, atol=1e-8)
         np.testing.assert_allclose(gv, np.diagonal(pC, axis1=-2, axis2=-1), rtol=1e-8, atol=1e-9)
+
+
+@pytest.mark.parametrize("d,p", [(5, 1), (8, 1), (12, 1), (8, 3), (15, 4)])
+@pytest.mark.parametrize("per_step_R", [False, True])
+def test_group_prior_marginals(tgp, d, p, per_step_R):
+    """marginals(model) of a Forward LTI model (lgssm.jl:99-109) through the group kernels, scalar and vector observations"""
+    rng = np.random.default_rng(13 * d + p + per_step_R)
+    T = 900
+    if p == 1:
+        model = U.random_lgssm(rng, False, d, T)
+        if per_step_R:
+            model["R"] = rng.random(T) + 0.1
+        em = lambda: tgp.ScalarOutputLGC(model["H"], model["h"], model["R"])
+    else:
+        model = U.random_lgssm_small(rng, False, d, p, T)
+        if per_step_R:
+            model["R"] = np.stack([np.diag(rng.random(p) + 0.1) for _ in range(T)])
+        em = lambda: tgp.SmallOutputLGC(model["H"], model["h"], np.diagonal(model["R"], axis1=-2, axis2=-1))
+    tr = tgp.GaussMarkovModel(tgp.Forward, model["A"], model["a"], model["Q"], tgp.Gaussian(model["x0m"], model["x0P"]))
+    dm = tgp.LGSSM(tr, em(), T=T)
+    hd = dm.handle()
+    hd.set_option(tgp._lib.OPT_GROUP, 2)
+    mm, mC = ref.marginals(model)
+    want_v = mC if p == 1 else np.diagonal(mC, axis1=-2, axis2=-1)
+    for chunk in (0, 4, 12):
+        hd.set_option(tgp._lib.OPT_CHUNK, chunk)
+        hd.set_option(tgp._lib.OPT_PROFILE, 1)
+        hd.profile_reset()
+        gm, gv = tgp.marginals(dm)
+        names = set(hd.profile())
+        hd.set_option(tgp._lib.OPT_PROFILE, 0)
+        assert "k_group_apply_affine<marginals>" in names, names
+        np.testing.assert_allclose(gm, mm, rtol=1e-10, atol=1e-11)
+        np.testing.assert_allclose(gv, want_v, rtol=1e-10, atol=1e-11)
