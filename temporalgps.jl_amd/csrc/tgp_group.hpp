@@ -28,8 +28,19 @@ template <int D> struct GroupGeom {
 };
 #define TGP_GUNROLL _Pragma("unroll")              // the group code keeps its (short) arrays in registers for every d
 
+// Sum over the G lanes of a group, every lane ending with the same value. Data-parallel primitives instead of
+// ds_bpermute: quad_perm [1,0,3,2] and [2,3,0,1] inside quads, row_half_mirror across the two quads of 8 lanes, row_mirror
+// across the two halves of 16 (a + b == b + a bit for bit, so all lanes agree).
+template <int CTRL> __device__ __forceinline__ double dpp_move(double x) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
 template <int G> __device__ __forceinline__ double group_sum(double x) {
-    TGP_GUNROLL for (int m = 1; m < G; m <<= 1) x += __shfl_xor(x, m, G);
+    x += dpp_move<0xB1>(x);                 // quad_perm:[1,0,3,2]
+    x += dpp_move<0x4E>(x);                 // quad_perm:[2,3,0,1]
+    x += dpp_move<0x141>(x);                // row_half_mirror
+    if (G == 16) x += dpp_move<0x140>(x);   // row_mirror
     return x;
 }
 
