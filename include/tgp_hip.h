@@ -147,6 +147,16 @@ int tgp_posterior(tgp_handle* h, const double* y, const uint8_t* missing, uint32
 int tgp_posterior_marginals(tgp_handle* h, const double* y, const uint8_t* missing, const double* Rnew,
                             uint32_t flags, double* mean_out, double* var_out, double* lml_out);
 
+/* ---- posterior marginals through an ALTERNATIVE emission block: N(Hn x_t + hn, Hn P_t Hn' + Rn) under the smoothed
+ *      state, pn functionals per time step that are not the model's observations -- what the reference gets by swapping
+ *      the emissions of the posterior model (space_time/pseudo_point.jl:198-235 approx_posterior_marginals, and
+ *      posterior_lti_sde.jl's prediction at the training inputs with other outputs) without materialising that model.
+ *      Hn [pn][d], hn [pn] host; Rn [T][pn] (or [pn] with TGP_SHARED_R); mean_out, var_out [T][pn].
+ *      Forward LTI models served by the group-per-chunk smoother (d = 5..16); TGP_EUNSUPPORTED otherwise. */
+int tgp_posterior_marginals_at(tgp_handle* h, const double* y, const uint8_t* missing, int pn, const double* Hn,
+                               const double* hn, const double* Rn, uint32_t flags, double* mean_out, double* var_out,
+                               double* lml_out);
+
 /* ---- marginals(model): lgssm.jl:99-115 for the model as given (prior marginals for a Forward prior,
  *      smoothing marginals for a materialised Reverse posterior). */
 int tgp_marginals(tgp_handle* h, uint32_t flags, double* mean_out, double* var_out);

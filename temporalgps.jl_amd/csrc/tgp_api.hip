@@ -242,6 +242,11 @@ struct tgp_handle {
     bool use_group_aff = false;  // ... and the group-layout scans over the smoother's affine elements
     bool use_group_sm = false;   // ... and the group-per-chunk smoother passes (tgp_group_smooth.hpp)
     bool use_group_marg = false; // ... and the group-per-chunk prior-marginals passes
+    const double* alt_H = nullptr;   // alternative emission block of the current tgp_posterior_marginals_at call (device)
+    const double* alt_h = nullptr;
+    int alt_p = 0;
+    int force_group_post = 0;
+    DevBuf balt;
     int opt_group = 1;           // TGP_OPT_GROUP
     int opt_group_scan = 1;      // TGP_OPT_GROUP bit 2 (value & 4) switches the group-layout block scans off
     int opt_fuse = 1;            // TGP_OPT_FUSE_SCAN
@@ -609,12 +614,12 @@ int forward_reduce(tgp_handle* h, uint32_t flags, int for_mode = -1) {
     // Group-per-chunk logpdf kernels (tgp_group.hpp). Measured at T = 1e7 (pass 1 + pass 2, ms; lane-per-chunk inlined
     // build in brackets): d = 5 1.9 (0.70), d = 6 2.2 (1.55), d = 7 2.9 (4.3), d = 8 3.4 (12.1) -- their time hardly
     // depends on d (LDS exchanges and shuffles, not flops), so they pay from d = 7 on (TGP_OPT_GROUP = 2 forces them).
-    const bool group_pays = h->d >= 7 || h->opt_group == 2;
+    const bool group_pays = h->d >= 7 || h->opt_group == 2 || h->force_group_post;
     // (posterior path in the group layout, tgp_group_smooth.hpp: pass 2 + pass 3 take 7.7 + 7.4 ms at T = 1e7 for d = 7 and 8
     // alike -- 498 / 310 VGPRs, one wave per SIMD, bound by the D + 10 LDS exchanges of a step; the lane-per-chunk kernels
     // need 6.3 + 1.8 (+ 1.8 for their own pass 1) at d = 7 and 15.4 + 5.3 (+ 6.7) at d = 8: group from d = 8 on)
     const bool grp_post = for_mode == 2 && h->use_group_sm && h->ordering == 0 && h->kt->group_apply_posterior != nullptr &&
-                          (h->d >= 8 || h->opt_group == 2);
+                          (h->d >= 8 || h->opt_group == 2 || h->force_group_post);
     if ((for_mode == 0 || grp_post) && h->use_group && h->opt_group && group_pays && h->kt->group_reduce_filter != nullptr && h->lti) {
         // 8 chunks per wave: 16384 chunks are two waves per SIMD; longer chunks also mean fewer scan elements, and the
         // d >= 7 block scans (spill-bound, ~1.5 ms per launch) are what is left of the call
@@ -765,7 +770,7 @@ int tgp_destroy(tgp_handle* h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     for (DevBuf* b : {&h->bA, &h->ba, &h->bQ, &h->bH, &h->bh, &h->bR, &h->bx0, &h->bx0r, &h->bx0fold, &h->by, &h->bmiss, &h->bRnew, &h->beps_t,
-                      &h->beps_e, &h->bo1, &h->bo2, &h->bo3, &h->F.slab, &h->Rv.slab, &h->fs, &h->partial, &h->result, &h->segtmp, &h->tile_t, &h->tile_e, &h->Fad.slab, &h->btan, &h->bx0ad, &h->tile_tan, &h->bF, &h->bPinf, &h->btimes, &h->bAQ1})
+                      &h->beps_e, &h->bo1, &h->bo2, &h->bo3, &h->F.slab, &h->Rv.slab, &h->fs, &h->partial, &h->result, &h->segtmp, &h->tile_t, &h->tile_e, &h->Fad.slab, &h->btan, &h->bx0ad, &h->tile_tan, &h->balt, &h->bF, &h->bPinf, &h->btimes, &h->bAQ1})
         b->release();
     for (auto& e : h->ev)
         if (e) (void)hipEventDestroy(e);
@@ -1029,7 +1034,8 @@ static int smoother_backward_impl(tgp_handle* h, const double* xs_dev, const dou
     scan_down(h, h->Rv, xs_dev);
     if (h->group_active) {
         LaunchScope ls(h, "k_group_smooth<lti>");
-        h->kt->group_smooth(h->mv, h->L0, h->n0, h->F.S[0], h->Rv.S[0], h->fs.d(), Rnew_dev, sRn, mean_dev, var_dev, flag_ptr(h), h->stream);
+        h->kt->group_smooth(h->mv, h->L0, h->n0, h->F.S[0], h->Rv.S[0], h->fs.d(), Rnew_dev, sRn, mean_dev, var_dev, flag_ptr(h), h->alt_H, h->alt_h,
+                            h->alt_p, h->stream);
         return TGP_OK;
     }
     {
@@ -1061,6 +1067,49 @@ int tgp_posterior_marginals(tgp_handle* h, const double* y, const uint8_t* missi
     tm.kernels_done();
     TRY(copy_back(h, mean_out, dm, nT, odev));
     TRY(copy_back(h, var_out, dv, nT, odev));
+    return tm.finish(lml_out);
+}
+
+int tgp_posterior_marginals_at(tgp_handle* h, const double* y, const uint8_t* missing, int pn, const double* Hn, const double* hn,
+                               const double* Rn, uint32_t flags, double* mean_out, double* var_out, double* lml_out) {
+    TRY(check_ready(h));
+    if (pn < 1 || pn > 4096 || !Hn || !hn || !Rn || !mean_out || !var_out) return h->fail(TGP_EINVAL, "bad alternative emission block / output");
+    if (h->ordering != 0 || !h->lti || !h->use_group_sm || !h->opt_group || h->kt->group_smooth == nullptr)
+        return h->fail(TGP_EUNSUPPORTED, "tgp_posterior_marginals_at: Forward LTI models with the group-per-chunk smoother (d = 5..16) only");
+    const bool idev = (flags & TGP_IN_DEVICE) != 0, odev = (flags & TGP_OUT_DEVICE) != 0;
+    const bool rshared = (flags & TGP_SHARED_R) != 0;
+    const size_t nOut = (size_t)h->T * pn * sizeof(double);
+    CallTimer tm(h);
+    // Hn | hn always from the host (small); Rn as the flags say
+    const size_t nH = (size_t)pn * h->d, nAll = nH + pn;
+    std::vector<double> blk(nAll);
+    std::memcpy(blk.data(), Hn, nH * sizeof(double));
+    std::memcpy(blk.data() + nH, hn, (size_t)pn * sizeof(double));
+    HIPCHK(h->balt.ensure(nAll * sizeof(double)));
+    HIPCHK(hipMemcpyAsync(h->balt.p, blk.data(), nAll * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const void* pR = nullptr;
+    TRY(stage_in(h, h->bRnew, Rn, rshared ? (size_t)pn * sizeof(double) : nOut, idev, &pR));
+    TRY(set_obs(h, y, missing, flags));
+    tm.inputs_done();
+    h->force_group_post = 1;
+    int rc = smoother_forward_impl(h, flags, nullptr, /*allow_group=*/true);
+    h->force_group_post = 0;
+    if (rc != TGP_OK) return rc;
+    if (!h->group_active) return h->fail(TGP_EUNSUPPORTED, "tgp_posterior_marginals_at: the group-per-chunk smoother is not available for this model");
+    double *dm = nullptr, *dv = nullptr;
+    TRY(stage_out(h, h->bo1, mean_out, nOut, odev, &dm));
+    TRY(stage_out(h, h->bo2, var_out, nOut, odev, &dv));
+    h->alt_H = h->balt.d();
+    h->alt_h = h->balt.d() + nH;
+    h->alt_p = pn;
+    rc = smoother_backward_impl(h, h->F.fin, (const double*)pR, rshared ? 0 : 1, dm, dv);
+    h->alt_H = h->alt_h = nullptr;
+    h->alt_p = 0;
+    if (rc != TGP_OK) return rc;
+    tm.kernels_done();
+    TRY(copy_back(h, mean_out, dm, nOut, odev));
+    TRY(copy_back(h, var_out, dv, nOut, odev));
     return tm.finish(lml_out);
 }
 

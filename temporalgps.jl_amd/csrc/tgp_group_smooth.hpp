@@ -31,6 +31,16 @@ template <int D> __device__ __forceinline__ void gfs_load(const double* __restri
     }
 }
 
+// Alternative emission block for pass 3: marginals of N(Hn x_t + hn, Hn P_t Hn' + Rn) under the SMOOTHED state, for pn
+// functionals per time step that are not the model's own observations (predictions at new outputs / locations).
+struct GroupAltEmit {
+    const double* H;      // [pn][d] or NULL (use the model's emissions)
+    const double* h;      // [pn]
+    const double* R;      // [T|1][pn]
+    int64_t sR;           // 0: shared
+    int pn;
+};
+
 template <int D> struct GroupRts {
     static constexpr int G = GroupGeom<D>::G, V0 = GroupGeom<D>::V0, V1 = GroupGeom<D>::V1;
     GroupOps<D> op;
@@ -259,7 +269,8 @@ __global__ __launch_bounds__(256) void k_group_apply_posterior(ModelView mv, int
 template <int D>
 __global__ __launch_bounds__(256) void k_group_smooth(ModelView mv, int L0, int64_t n0, const double* __restrict__ S0, const double* __restrict__ S0r,
                                                       const double* __restrict__ fs, const double* __restrict__ Rnew, int64_t sRn,
-                                                      double* __restrict__ mean_out, double* __restrict__ var_out, int* __restrict__ bad) {
+                                                      double* __restrict__ mean_out, double* __restrict__ var_out, int* __restrict__ bad,
+                                                      GroupAltEmit alt) {
     constexpr int G = GroupGeom<D>::G, NGRP = GroupGeom<D>::NGRP;
     __shared__ __attribute__((aligned(16))) double sA[G * G];
     __shared__ double tiles[NGRP * GroupGeom<D>::LD];
@@ -280,6 +291,26 @@ __global__ __launch_bounds__(256) void k_group_smooth(ModelView mv, int L0, int6
     bool ok = true;
     for (int64_t r = r1 - 1; r >= r0; --r) {
         const int jj = mv.p == 1 ? 0 : (int)((r - r0) % mv.p);
+        if (alt.H != nullptr) {
+            // the smoothed state of this time step (its last observation is processed first) through the alternative block
+            if (jj == mv.p - 1) {
+                const int64_t tt = c * (int64_t)(L0 / mv.p) + (r - r0) / mv.p;
+                for (int q = 0; q < alt.pn; ++q) {
+                    double pq = 0.0, hq = 0.0;
+                    TGP_GUNROLL for (int i = 0; i < D; ++i) {
+                        const double hi = alt.H[q * D + i];
+                        pq = fma(xs.P[i], hi, pq);
+                        hq = (i == j) ? hi : hq;
+                    }
+                    const double mean = group_sum<G>(hq * xs.m) + alt.h[q];
+                    const double var = group_sum<G>(hq * pq);
+                    if (j == 0) {
+                        mean_out[tt * alt.pn + q] = mean;
+                        var_out[tt * alt.pn + q] = var + (alt.sR == 0 ? alt.R[q] : alt.R[tt * alt.pn + q]);
+                    }
+                }
+            }
+        } else {
         group_obs_row<D>(mv, jj, j, H, Hj, hh, Rsh);
         // emission marginal of the smoothed state at step r with the NEW noise (lgssm.jl:111-115, missings.jl:35-41)
         double pj = 0.0;
@@ -290,6 +321,7 @@ __global__ __launch_bounds__(256) void k_group_smooth(ModelView mv, int L0, int6
         if (j == 0) {
             mean_out[tm] = mean;
             var_out[tm] = var + (sRn == 0 ? Rnew[jj] : Rnew[tm]);
+        }
         }
         if (jj != 0) continue;                  // inside a time step the state does not move
         // filtered state before this step, its prediction, the backward kernel, one RTS step

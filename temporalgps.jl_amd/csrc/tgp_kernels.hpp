@@ -666,8 +666,9 @@ struct KernelTable {
     void (*group_scan_apply)(int monoid, const double* Ein, int64_t n, const double* carry, int64_t ncarry, double* S, double* fin, hipStream_t);
     // ... and the posterior path: pass 2 MODE 2 (scratch in the group layout [chunk][step][state]) and pass 3
     void (*group_apply_posterior)(const ModelView&, int L0, int64_t n0, const double* S0, double* fs, double* R0, double* partial, hipStream_t);
+    // (Hn != NULL: emit through the alternative block Hn [pn][d], hn [pn], Rn [T|1][pn] instead of the model's emissions)
     void (*group_smooth)(const ModelView&, int L0, int64_t n0, const double* S0, const double* S0r, const double* fs, const double* Rnew,
-                         int64_t sRn, double* mean_out, double* var_out, int* bad, hipStream_t);
+                         int64_t sRn, double* mean_out, double* var_out, int* bad, const double* Hn, const double* hn, int pn, hipStream_t);
     // ... and prior marginals (Forward): affine element per chunk, then state propagation + emission
     void (*group_reduce_marginals)(const ModelView&, int L0, int64_t n0, double* E0, hipStream_t);
     void (*group_apply_marginals)(const ModelView&, int L0, int64_t n0, const double* S0, double* mean_out, double* var_out, hipStream_t);

@@ -488,6 +488,30 @@ def posterior_marginals(model, y, R_new):
     return mean, var
 
 
+def posterior_marginals_at(model, y, H_new, h_new, R_new):
+    """Marginals of N(H_new x_t + h_new, H_new P_t H_new' + R_new) under the SMOOTHED state x_t | y: what the reference gets
+    by giving the posterior model other emissions (pseudo_point.jl:198-235) -- here without materialising that model
+    (tgp_posterior_marginals_at). H_new (pn, d), h_new (pn,), R_new (T|1, pn) diagonal noise. Host arrays.
+    Raises `_lib.Unsupported` where only the materialised route exists (d < 5, per-step transitions, Reverse models)."""
+    _check_inputs(model, y[0] if isinstance(y, tuple) else y)
+    hd = model.handle()
+    yy, mm, dev = _obs(y, model)
+    Hn = np.ascontiguousarray(_to_numpy(H_new), dtype=np.float64)
+    hn = np.ascontiguousarray(_to_numpy(h_new), dtype=np.float64)
+    pn = int(Hn.shape[0])
+    Rn = np.ascontiguousarray(np.atleast_2d(_to_numpy(R_new)), dtype=np.float64)
+    if Hn.shape != (pn, model.dim) or hn.shape != (pn,) or Rn.shape[1] != pn or Rn.shape[0] not in (1, model.T):
+        raise ValueError("H_new (pn, d), h_new (pn,), R_new (T|1, pn)")
+    if dev:
+        import torch
+        Rn = torch.as_tensor(Rn, device=yy.device)
+    flags = ((_lib.IN_DEVICE | _lib.OUT_DEVICE) if dev else 0) | (_lib.SHARED_R if Rn.shape[0] == 1 else 0)
+    mean, var = _out(model, (model.T, pn), dev), _out(model, (model.T, pn), dev)
+    hd.check(hd.lib.tgp_posterior_marginals_at(hd.h, _lib.ptr(yy), _lib.ptr(mm), pn, _lib.ptr(Hn), _lib.ptr(hn), _lib.ptr(Rn), flags,
+                                               _lib.ptr(mean), _lib.ptr(var), None))
+    return mean, var
+
+
 def ε_randn(rng, model):
     """lgssm.jl:72-77: all the randomness one sample needs, drawn up front in the reference's order
     (T transition vectors, then T emission scalars; x0's draw comes after, lgssm.jl:67)."""

@@ -167,10 +167,17 @@ def approx_posterior_marginals(k, grid, sigma2s, y, z, x_r, device=0):
     """approx_posterior_marginals(dtc, fx, y, z_r, x_r) (pseudo_point.jl:198-235): DTC posterior marginals at the
     times of `grid` and the NEW spatial locations x_r. Returns (mean, var), each (T, len(x_r)) (flat order: space fastest)."""
     model = build_lgssm(k, grid, z, sigma2s, device)
-    post = L.posterior(model, _obs(grid, y))                    # Reverse-ordered LGSSM (lgssm.jl:193-221), device pass
     k_dtc = dtcify(z, k)
     _, _, _, (Ct, Hb, hb), _ = lgssm_components(k_dtc, grid, x_space=x_r)
     Sig = build_emission_covs(k_dtc, grid, x_r)
+    if Hb.shape[0] == 1 and len(x_r) <= 4096:
+        # fast path: the smoothed state straight through the new emission block H = C_new' Hb (nothing is materialised);
+        # the engine offers it for the models its group-per-chunk smoother serves (state dimension 5..16)
+        try:
+            return L.posterior_marginals_at(model, _obs(grid, y), Ct @ Hb[0], Ct @ hb[0], Sig)
+        except L._lib.Unsupported:
+            pass
+    post = L.posterior(model, _obs(grid, y))                    # Reverse-ordered LGSSM (lgssm.jl:193-221), device pass
     fan_out = L.LargeOutputLGC(Ct[None], np.zeros((1, len(x_r))), Sig)
     new_post = L.LGSSM(post.transitions, L.BottleneckLGC(Hb, hb, fan_out), T=model.T, device=device)
     return L.marginals(new_post)

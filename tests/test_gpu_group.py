@@ -204,3 +204,45 @@ def test_group_prior_marginals(tgp, d, p, per_step_R):
         assert "k_group_apply_affine<marginals>" in names, names
         np.testing.assert_allclose(gm, mm, rtol=1e-10, atol=1e-11)
         np.testing.assert_allclose(gv, want_v, rtol=1e-10, atol=1e-11)
+
+
+@pytest.mark.parametrize("d,p,pn", [(5, 1, 3), (8, 1, 7), (12, 3, 5), (15, 4, 20)])
+def test_posterior_marginals_through_other_emissions(tgp, d, p, pn):
+    """tgp_posterior_marginals_at: the smoothed state through an alternative emission block, against the oracle's posterior model
+    with its emissions swapped (what pseudo_point.jl:198-235 does)"""
+    rng = np.random.default_rng(7 * d + p + pn)
+    T = 800
+    if p == 1:
+        model = U.random_lgssm(rng, False, d, T)
+        eps_e = rng.standard_normal(T)
+        em = tgp.ScalarOutputLGC(model["H"], model["h"], model["R"])
+    else:
+        model = U.random_lgssm_small(rng, False, d, p, T)
+        eps_e = rng.standard_normal((T, p))
+        em = tgp.SmallOutputLGC(model["H"], model["h"], np.diagonal(model["R"], axis1=-2, axis2=-1))
+    y = ref.rand(model, rng.standard_normal((T, d)), eps_e, rng.standard_normal(d))
+    tr = tgp.GaussMarkovModel(tgp.Forward, model["A"], model["a"], model["Q"], tgp.Gaussian(model["x0m"], model["x0P"]))
+    dm = tgp.LGSSM(tr, em, T=T)
+    Hn, hn = rng.standard_normal((pn, d)), rng.standard_normal(pn)
+    Rn = rng.random((T, pn)) * 0.1
+    post = ref.posterior(model, y)
+    swapped = dict(post, kind="small", H=Hn[None], h=hn[None], R=np.stack([np.diag(v) for v in Rn]))
+    pm, pC = ref.marginals(swapped)
+    for chunk in (0, 6):
+        dm.handle().set_option(tgp._lib.OPT_CHUNK, chunk * max(p, 1))
+        gm, gv = tgp.posterior_marginals_at(dm, y, Hn, hn, Rn)
+        np.testing.assert_allclose(gm, pm, rtol=1e-8, atol=1e-8)
+        np.testing.assert_allclose(gv, np.diagonal(pC, axis1=-2, axis2=-1), rtol=1e-8, atol=1e-9)
+    gm, gv = tgp.posterior_marginals_at(dm, y, Hn, hn, Rn[:1])                     # shared new noise
+    swapped1 = dict(swapped, R=np.diag(Rn[0])[None])
+    pm1, pC1 = ref.marginals(swapped1)
+    np.testing.assert_allclose(gv, np.diagonal(pC1, axis1=-2, axis2=-1), rtol=1e-8, atol=1e-9)
+
+
+def test_posterior_marginals_at_unsupported_for_small_d(tgp):
+    rng = np.random.default_rng(0)
+    model = U.random_lgssm(rng, False, 3, 100)
+    tr = tgp.GaussMarkovModel(tgp.Forward, model["A"], model["a"], model["Q"], tgp.Gaussian(model["x0m"], model["x0P"]))
+    dm = tgp.LGSSM(tr, tgp.ScalarOutputLGC(model["H"], model["h"], model["R"]), T=100)
+    with pytest.raises(tgp._lib.Unsupported):
+        tgp.posterior_marginals_at(dm, rng.standard_normal(100), np.ones((2, 3)), np.zeros(2), np.ones((1, 2)))
