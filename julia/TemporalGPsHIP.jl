@@ -208,4 +208,19 @@ function DeviceLGSSM_sde(F, a, H, hh, Σs, times::AbstractVector{<:Real}, A1, Q1
     return DeviceLGSSM(Forward(), h, T, d, (; F = Fv, a = av, H = Hv, hh = hv, R, times = tv), flags, x0)
 end
 
+"""Posterior marginals through other emissions (tgp_posterior_marginals_at): the fast path of
+`approx_posterior_marginals` (space_time/pseudo_point.jl:198-235). `Hn` is `pn x d`, `Σs_new` a vector of length-`pn` diagonals."""
+function posterior_marginals_at(m::DeviceLGSSM{Forward}, y::AbstractVector, Hn::AbstractMatrix, hn::AbstractVector, Σs_new::AbstractVector)
+    yv, mp, mask = _split_missing(y)
+    pn = size(Hn, 1)
+    H = collect(Float64, vec(permutedims(Hn)))            # row-major [pn][d]
+    hv = collect(Float64, hn)
+    R, fl = Σs_new isa Fill ? (collect(Float64, first(Σs_new)), SHARED_R) : (reduce(vcat, (collect(Float64, s) for s in Σs_new)), UInt32(0))
+    mean, var = Matrix{Float64}(undef, pn, m.T), Matrix{Float64}(undef, pn, m.T)
+    GC.@preserve yv mask H hv R check(m.h, ccall((:tgp_posterior_marginals_at, libtgp), Cint,
+        (Ptr{Cvoid}, Ptr{Float64}, Ptr{UInt8}, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, UInt32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+        m.h.ptr, yv, mp, pn, H, hv, R, fl, mean, var, C_NULL))
+    return mean, var                                       # column t = the pn marginals of time step t
+end
+
 end # module
