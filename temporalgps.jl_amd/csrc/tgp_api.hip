@@ -620,7 +620,10 @@ int forward_reduce(tgp_handle* h, uint32_t flags, int for_mode = -1) {
     // need 6.3 + 1.8 (+ 1.8 for their own pass 1) at d = 7 and 15.4 + 5.3 (+ 6.7) at d = 8: group from d = 8 on)
     const bool grp_post = for_mode == 2 && h->use_group_sm && h->ordering == 0 && h->kt->group_apply_posterior != nullptr &&
                           (h->d >= 8 || h->opt_group == 2 || h->force_group_post);
-    if ((for_mode == 0 || grp_post) && h->use_group && h->opt_group && group_pays && h->kt->group_reduce_filter != nullptr && h->lti) {
+    // filtering distributions (MODE 1) and the materialised posterior (MODE 3): group layout where the alternative is the
+    // out-of-line build (d >= 9); MODE 3 shares the smoother's validation, Forward models only
+    const bool grp_out = ((for_mode == 1) || (for_mode == 3 && h->use_group_sm && h->ordering == 0)) && (h->d >= 9 || h->opt_group == 2);
+    if ((for_mode == 0 || grp_post || grp_out) && h->use_group && h->opt_group && group_pays && h->kt->group_reduce_filter != nullptr && h->lti) {
         // 8 chunks per wave: 16384 chunks are two waves per SIMD; longer chunks also mean fewer scan elements, and the
         // d >= 7 block scans (spill-bound, ~1.5 ms per launch) are what is left of the call
         int64_t L0 = h->opt_chunk;
@@ -681,17 +684,21 @@ int set_obs(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t fla
 int forward_apply(tgp_handle* h, int mode, const FilterOut& fo, const double* x0dev = nullptr) {
     scan_down(h, h->F, x0dev ? x0dev : h->bx0.d(), h->fused ? 1 : 0);
     if (h->group_active) {
-        if (mode != 0 && mode != 2) return h->fail(TGP_EINVAL, "internal: group-per-chunk elements are only valid for the logpdf / smoother passes");
         const int64_t cpb = h->kt->group_chunks_per_block;
         const int64_t nb = (h->n0 + cpb - 1) / cpb;
         HIPCHK(h->partial.ensure((size_t)nb * 3 * sizeof(double)));
         if (mode == 2) {
             TRY(scan_prepare(h, h->Rv, kAffineCov, h->n0));
             LaunchScope ls(h, "k_group_apply_filter<lti,posterior>");
-            h->kt->group_apply_posterior(h->mv, h->L0, h->n0, h->F.S[0], fo.fs, h->Rv.E[0], h->partial.d(), h->stream);
+            h->kt->group_apply_posterior(h->mv, h->L0, h->n0, h->F.S[0], fo.fs, h->Rv.E[0], h->partial.d(), nullptr, nullptr, nullptr, h->stream);
+        } else if (mode == 3) {
+            if (h->ordering != 0 || !h->use_group_sm) return h->fail(TGP_EINVAL, "internal: group-per-chunk elements with an unsupported materialise pass");
+            LaunchScope ls(h, "k_group_apply_filter<lti,materialise>");
+            h->kt->group_apply_posterior(h->mv, h->L0, h->n0, h->F.S[0], nullptr, nullptr, h->partial.d(), fo.G_out, fo.g_out, fo.L_out, h->stream);
         } else {
-            LaunchScope ls(h, "k_group_apply_filter<lti,logpdf>");
-            h->kt->group_apply_logpdf(h->mv, h->L0, h->n0, h->F.S[0], h->partial.d(), h->stream);
+            LaunchScope ls(h, mode == 1 ? "k_group_apply_filter<lti,filter>" : "k_group_apply_filter<lti,logpdf>");
+            h->kt->group_apply_logpdf(h->mv, h->L0, h->n0, h->F.S[0], h->partial.d(), mode == 1 ? fo.m_out : nullptr, mode == 1 ? fo.P_out : nullptr,
+                                      h->stream);
         }
         {
             LaunchScope ls(h, "k_finalize");
@@ -978,7 +985,7 @@ int tgp_filter(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t 
     CallTimer tm(h);
     TRY(set_obs(h, y, missing, flags));
     tm.inputs_done();
-    TRY(forward_reduce(h, flags));
+    TRY(forward_reduce(h, flags, 1));
     FilterOut fo{};
     TRY(stage_out(h, h->bo1, m_out, nm, odev, &fo.m_out));
     TRY(stage_out(h, h->bo2, P_out, nP, odev, &fo.P_out));
@@ -999,7 +1006,7 @@ int tgp_posterior(tgp_handle* h, const double* y, const uint8_t* missing, uint32
     CallTimer tm(h);
     TRY(set_obs(h, y, missing, flags));
     tm.inputs_done();
-    TRY(forward_reduce(h, flags));
+    TRY(forward_reduce(h, flags, (G != nullptr) ? 3 : 0));
     FilterOut fo{};
     TRY(stage_out(h, h->bo1, G, nG, odev, &fo.G_out));
     TRY(stage_out(h, h->bo2, g, ng, odev, &fo.g_out));

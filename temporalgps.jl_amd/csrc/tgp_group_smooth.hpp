@@ -182,7 +182,8 @@ template <int D> struct GroupRts {
 // ---------------------------------------------------------------- pass 2, MODE 2
 template <int D>
 __global__ __launch_bounds__(256) void k_group_apply_posterior(ModelView mv, int L0, int64_t n0, const double* __restrict__ S0,
-                                                               double* __restrict__ fs, double* __restrict__ R0, double* __restrict__ partial) {
+                                                               double* __restrict__ fs, double* __restrict__ R0, double* __restrict__ partial,
+                                                               double* __restrict__ G_out, double* __restrict__ g_out, double* __restrict__ L_out) {
     constexpr int G = GroupGeom<D>::G, NGRP = GroupGeom<D>::NGRP;
     __shared__ __attribute__((aligned(16))) double sA[G * G];
     __shared__ double tiles[NGRP * GroupGeom<D>::LD];
@@ -228,7 +229,18 @@ __global__ __launch_bounds__(256) void k_group_apply_posterior(ModelView mv, int
                 TGP_GUNROLL for (int i = 0; i < D; ++i) Pf[i] = Pc[i];
                 rts.predict(mj, aj, Pc, Qc);
                 ok = rts.invert_dynamics(mf, Pf, mj, Pc, Gc, Xc, gj, Lc) && ok;
-                rts.extend_right(rev, Gc, gj, Lc);
+                if (G_out != nullptr) {       // MODE 3: the time-reversed transition of this step (lgssm.jl:215-221)
+                    if (gl.act) {
+                        const int64_t te = (rg + k) / mv.p;
+                        TGP_GUNROLL for (int i = 0; i < D; ++i) {
+                            G_out[te * D * D + i + j * D] = Gc[i];
+                            L_out[te * D * D + i + j * D] = Lc[i];
+                        }
+                        g_out[te * D + j] = gj;
+                    }
+                } else {
+                    rts.extend_right(rev, Gc, gj, Lc);
+                }
             }
             double vj = 0.0;
             TGP_GUNROLL for (int i = 0; i < D; ++i) vj = fma(Pc[i], H[i], vj);
@@ -250,11 +262,11 @@ __global__ __launch_bounds__(256) void k_group_apply_posterior(ModelView mv, int
                 sprod = 1.0;
             }
             nmiss += miss ? 1.0 : 0.0;
-            if (gl.act) gfs_store<D>(fs, gfs_index<D>(c, g + k, L0), j, mj, Pc);
+            if (fs != nullptr && gl.act) gfs_store<D>(fs, gfs_index<D>(c, g + k, L0), j, mj, Pc);
         }
         if (gend > 0) lml -= 0.5 * (gend * kLog2Pi + log(sprod) + quad);
     }
-    if (c < n0 && r1 > r0 && gl.act) GAffineMO<D>::store(rev, R0, n0, n0 - 1 - c, j);
+    if (R0 != nullptr && c < n0 && r1 > r0 && gl.act) GAffineMO<D>::store(rev, R0, n0, n0 - 1 - c, j);
     double a = (j == 0 && c < n0) ? lml : 0.0, b = (j == 0 && c < n0) ? nmiss : 0.0;
     int bad = (j == 0 && c < n0 && !ok) ? 1 : 0;
     block_sum3(a, b, bad, sh);

@@ -659,13 +659,16 @@ struct KernelTable {
     int (*host_combine)(int kind, const double* earlier, const double* later, double* out);
     // group-per-chunk kernels (tgp_group.hpp; d = 5..16, LTI, scalar observations; NULL otherwise)
     void (*group_reduce_filter)(const ModelView&, int L0, int64_t n0, double* E0, hipStream_t);
-    void (*group_apply_logpdf)(const ModelView&, int L0, int64_t n0, const double* S0, double* partial, hipStream_t);
+    // (m_out / P_out != NULL: MODE 1, the filtering distributions as well)
+    void (*group_apply_logpdf)(const ModelView&, int L0, int64_t n0, const double* S0, double* partial, double* m_out, double* P_out, hipStream_t);
     // ... and block scans over filter elements in the same layout (tgp_group_scan.hpp), 256 elements per block
     // (monoid: kFilter or kAffineCov)
     void (*group_scan_reduce)(int monoid, const double* Ein, int64_t n, double* Ehi, int64_t nhi, hipStream_t);
     void (*group_scan_apply)(int monoid, const double* Ein, int64_t n, const double* carry, int64_t ncarry, double* S, double* fin, hipStream_t);
     // ... and the posterior path: pass 2 MODE 2 (scratch in the group layout [chunk][step][state]) and pass 3
-    void (*group_apply_posterior)(const ModelView&, int L0, int64_t n0, const double* S0, double* fs, double* R0, double* partial, hipStream_t);
+    // (G_out != NULL: MODE 3, the per-step reversed transitions instead of the chunk element; fs / R0 may then be NULL)
+    void (*group_apply_posterior)(const ModelView&, int L0, int64_t n0, const double* S0, double* fs, double* R0, double* partial, double* G_out,
+                                  double* g_out, double* L_out, hipStream_t);
     // (Hn != NULL: emit through the alternative block Hn [pn][d], hn [pn], Rn [T|1][pn] instead of the model's emissions)
     void (*group_smooth)(const ModelView&, int L0, int64_t n0, const double* S0, const double* S0r, const double* fs, const double* Rnew,
                          int64_t sRn, double* mean_out, double* var_out, int* bad, const double* Hn, const double* hn, int pn, hipStream_t);

@@ -246,3 +246,43 @@ def test_posterior_marginals_at_unsupported_for_small_d(tgp):
     dm = tgp.LGSSM(tr, tgp.ScalarOutputLGC(model["H"], model["h"], model["R"]), T=100)
     with pytest.raises(tgp._lib.Unsupported):
         tgp.posterior_marginals_at(dm, rng.standard_normal(100), np.ones((2, 3)), np.zeros(2), np.ones((1, 2)))
+
+
+@pytest.mark.parametrize("d", [5, 8, 9, 13])
+@pytest.mark.parametrize("ordering", ["F", "R"])
+def test_group_filter_and_materialised_posterior(tgp, d, ordering):
+    """_filter (MODE 1) and posterior (MODE 3: the per-step reversed transitions) through the group kernels"""
+    rng = np.random.default_rng(19 * d + (ordering == "R"))
+    T = 1100
+    model = U.random_lgssm(rng, False, d, T, ordering)
+    eps = (rng.standard_normal((T, d)), rng.standard_normal(T), rng.standard_normal(d))
+    y = ref.rand(model, *eps)
+    tr = tgp.GaussMarkovModel(tgp.Forward if ordering == "F" else tgp.Reverse, model["A"], model["a"], model["Q"],
+                              tgp.Gaussian(model["x0m"], model["x0P"]))
+    dm = tgp.LGSSM(tr, tgp.ScalarOutputLGC(model["H"], model["h"], model["R"]), T=T)
+    hd = dm.handle()
+    hd.set_option(tgp._lib.OPT_GROUP, 2)
+    fm, fP = ref.filter_(model, y)
+    for chunk in (0, 7):
+        hd.set_option(tgp._lib.OPT_CHUNK, chunk)
+        hd.set_option(tgp._lib.OPT_PROFILE, 1)
+        hd.profile_reset()
+        m, P = tgp._filter(dm, y)
+        names = set(hd.profile())
+        hd.set_option(tgp._lib.OPT_PROFILE, 0)
+        assert "k_group_apply_filter<lti,filter>" in names, names
+        np.testing.assert_allclose(m, fm, rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(P, fP, rtol=1e-8, atol=1e-9)
+        if ordering == "F":
+            post = ref.posterior(model, y)
+            hd.set_option(tgp._lib.OPT_PROFILE, 1)
+            hd.profile_reset()
+            dpost = tgp.posterior(dm, y)
+            names = set(hd.profile())
+            hd.set_option(tgp._lib.OPT_PROFILE, 0)
+            assert "k_group_apply_filter<lti,materialise>" in names, names
+            np.testing.assert_allclose(dpost.transitions.As, post["A"], rtol=1e-8, atol=1e-9)
+            np.testing.assert_allclose(dpost.transitions.as_, post["a"], rtol=1e-8, atol=1e-9)
+            np.testing.assert_allclose(dpost.transitions.Qs, post["Q"], rtol=1e-8, atol=1e-9)
+            np.testing.assert_allclose(dpost.x0.m, post["x0m"], rtol=1e-8, atol=1e-9)
+            np.testing.assert_allclose(dpost.x0.P, post["x0P"], rtol=1e-8, atol=1e-9)
