@@ -62,7 +62,7 @@ static const KernelTable* fast_kernel_table(int d) {
 }
 // Per (state dimension, LTI layout family?): which operations of the inlined (fast) build reproduced the out-of-line (safe)
 // build in the run-time known-answer check. Bit kOpDecided = the check has run.
-enum VariantOp { kOpM0 = 0, kOpM1, kOpM2, kOpM3, kOpAffine, kOpGrad, kOpCount, kOpGroupMarg = 27, kOpGroupAff = 28, kOpGroup = 29, kOpDecided = 30 };
+enum VariantOp { kOpM0 = 0, kOpM1, kOpM2, kOpM3, kOpAffine, kOpGrad, kOpCount, kOpGroupM1 = 25, kOpGroupM3 = 26, kOpGroupMarg = 27, kOpGroupAff = 28, kOpGroup = 29, kOpDecided = 30 };
 static unsigned g_variant[17][2] = {{0u}};
 static const unsigned kAllOps = (1u << kOpCount) - 1u;
 
@@ -242,6 +242,7 @@ struct tgp_handle {
     bool use_group_aff = false;  // ... and the group-layout scans over the smoother's affine elements
     bool use_group_sm = false;   // ... and the group-per-chunk smoother passes (tgp_group_smooth.hpp)
     bool use_group_marg = false; // ... and the group-per-chunk prior-marginals passes
+    bool use_group_m1 = false, use_group_m3 = false;   // ... and the MODE 1 / MODE 3 output variants
     const double* alt_H = nullptr;   // alternative emission block of the current tgp_posterior_marginals_at call (device)
     const double* alt_h = nullptr;
     int alt_p = 0;
@@ -622,7 +623,8 @@ int forward_reduce(tgp_handle* h, uint32_t flags, int for_mode = -1) {
                           (h->d >= 8 || h->opt_group == 2 || h->force_group_post);
     // filtering distributions (MODE 1) and the materialised posterior (MODE 3): group layout where the alternative is the
     // out-of-line build (d >= 9); MODE 3 shares the smoother's validation, Forward models only
-    const bool grp_out = ((for_mode == 1) || (for_mode == 3 && h->use_group_sm && h->ordering == 0)) && (h->d >= 9 || h->opt_group == 2);
+    const bool grp_out = ((for_mode == 1 && h->use_group_m1) || (for_mode == 3 && h->use_group_m3 && h->ordering == 0)) &&
+                         (h->d >= 9 || h->opt_group == 2);
     if ((for_mode == 0 || grp_post || grp_out) && h->use_group && h->opt_group && group_pays && h->kt->group_reduce_filter != nullptr && h->lti) {
         // 8 chunks per wave: 16384 chunks are two waves per SIMD; longer chunks also mean fewer scan elements, and the
         // d >= 7 block scans (spill-bound, ~1.5 ms per launch) are what is left of the call
@@ -692,7 +694,7 @@ int forward_apply(tgp_handle* h, int mode, const FilterOut& fo, const double* x0
             LaunchScope ls(h, "k_group_apply_filter<lti,posterior>");
             h->kt->group_apply_posterior(h->mv, h->L0, h->n0, h->F.S[0], fo.fs, h->Rv.E[0], h->partial.d(), nullptr, nullptr, nullptr, h->stream);
         } else if (mode == 3) {
-            if (h->ordering != 0 || !h->use_group_sm) return h->fail(TGP_EINVAL, "internal: group-per-chunk elements with an unsupported materialise pass");
+            if (h->ordering != 0 || !h->use_group_m3) return h->fail(TGP_EINVAL, "internal: group-per-chunk elements with an unsupported materialise pass");
             LaunchScope ls(h, "k_group_apply_filter<lti,materialise>");
             h->kt->group_apply_posterior(h->mv, h->L0, h->n0, h->F.S[0], nullptr, nullptr, h->partial.d(), fo.G_out, fo.g_out, fo.L_out, h->stream);
         } else {
@@ -1560,6 +1562,8 @@ static unsigned variant_selftest(int device, int d, bool lti_layout) {
             if (same(ra[kOpM0], rg[kOpM0])) ok |= 1u << kOpGroup;
             if (same(ra[kOpM2], rg[kOpM2])) ok |= 1u << kOpGroupAff;     // smoother with the group-layout affine scans
             if (same(ra[kOpAffine], rg[kOpAffine])) ok |= 1u << kOpGroupMarg;   // prior marginals (and the unchanged rand)
+            if (same(ra[kOpM1], rg[kOpM1])) ok |= 1u << kOpGroupM1;             // filtering distributions
+            if (same(ra[kOpM3], rg[kOpM3])) ok |= 1u << kOpGroupM3;             // materialised posterior
         }
     }
     if (rcb != TGP_OK) return ok;
@@ -1584,6 +1588,7 @@ static void select_table(tgp_handle* h, int d, bool lti, int variant) {
     h->use_group_aff = false;
     h->use_group_sm = false;
     h->use_group_marg = false;
+    h->use_group_m1 = h->use_group_m3 = false;
     h->variant_code = 1;
     if (variant == 1) return;
     if (variant == 3) {             // out-of-line build + the group-per-chunk logpdf kernels (used by the check itself)
@@ -1591,6 +1596,7 @@ static void select_table(tgp_handle* h, int d, bool lti, int variant) {
         h->use_group_aff = h->use_group;
         h->use_group_sm = h->use_group;
         h->use_group_marg = h->use_group;
+        h->use_group_m1 = h->use_group_m3 = h->use_group;
         return;
     }
     if (variant == 2) {
@@ -1611,6 +1617,8 @@ static void select_table(tgp_handle* h, int d, bool lti, int variant) {
     h->use_group_aff = h->use_group && ((g >> kOpGroupAff) & 1u) != 0u;
     h->use_group_sm = h->use_group_aff;      // the same known-answer operation (posterior marginals) exercises both
     h->use_group_marg = h->use_group && ((g >> kOpGroupMarg) & 1u) != 0u;
+    h->use_group_m1 = h->use_group && ((g >> kOpGroupM1) & 1u) != 0u;
+    h->use_group_m3 = h->use_group_sm && ((g >> kOpGroupM3) & 1u) != 0u;
 }
 
 extern "C" {

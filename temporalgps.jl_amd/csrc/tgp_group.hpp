@@ -216,7 +216,8 @@ __global__ __launch_bounds__(256) void k_group_reduce_filter(ModelView mv, int L
 }
 
 // ---------------------------------------------------------------- pass 2, logpdf: filter from the chunk's carry-in state
-template <int D>
+// OUT == true: MODE 1, the filtering distributions are written as well (compile-time: see k_group_apply_posterior)
+template <int D, bool OUT>
 __global__ __launch_bounds__(256) void k_group_apply_logpdf(ModelView mv, int L0, int64_t n0, const double* __restrict__ S0,
                                                             double* __restrict__ partial, double* __restrict__ m_out,
                                                             double* __restrict__ P_out) {
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(256) void k_group_apply_logpdf(ModelView mv, int L0
                 sprod = 1.0;
             }
             nmiss += miss ? 1.0 : 0.0;
-            if (m_out != nullptr && jj == mv.p - 1 && gl.act) {     // MODE 1: filtering distribution of this time step
+            if (OUT && jj == mv.p - 1 && gl.act) {                  // MODE 1: filtering distribution of this time step
                 const int64_t te = time_index(mv, (rg + k) / mv.p);
                 m_out[te * D + j] = mj;
                 TGP_GUNROLL for (int i = 0; i < D; ++i) P_out[te * D * D + i + j * D] = Pc[i];

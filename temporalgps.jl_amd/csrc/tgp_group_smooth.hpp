@@ -180,7 +180,9 @@ template <int D> struct GroupRts {
 };
 
 // ---------------------------------------------------------------- pass 2, MODE 2
-template <int D>
+// MAT == false: MODE 2 (scratch + chunk element). MAT == true: MODE 3 (G_t, g_t, L_t per step to G_out / g_out / L_out; no scratch,
+// no element). A compile-time switch: the extra stores change the register allocation of this spill-prone kernel at d = 16.
+template <int D, bool MAT>
 __global__ __launch_bounds__(256) void k_group_apply_posterior(ModelView mv, int L0, int64_t n0, const double* __restrict__ S0,
                                                                double* __restrict__ fs, double* __restrict__ R0, double* __restrict__ partial,
                                                                double* __restrict__ G_out, double* __restrict__ g_out, double* __restrict__ L_out) {
@@ -229,7 +231,7 @@ __global__ __launch_bounds__(256) void k_group_apply_posterior(ModelView mv, int
                 TGP_GUNROLL for (int i = 0; i < D; ++i) Pf[i] = Pc[i];
                 rts.predict(mj, aj, Pc, Qc);
                 ok = rts.invert_dynamics(mf, Pf, mj, Pc, Gc, Xc, gj, Lc) && ok;
-                if (G_out != nullptr) {       // MODE 3: the time-reversed transition of this step (lgssm.jl:215-221)
+                if (MAT) {                    // MODE 3: the time-reversed transition of this step (lgssm.jl:215-221)
                     if (gl.act) {
                         const int64_t te = (rg + k) / mv.p;
                         TGP_GUNROLL for (int i = 0; i < D; ++i) {
@@ -262,11 +264,11 @@ __global__ __launch_bounds__(256) void k_group_apply_posterior(ModelView mv, int
                 sprod = 1.0;
             }
             nmiss += miss ? 1.0 : 0.0;
-            if (fs != nullptr && gl.act) gfs_store<D>(fs, gfs_index<D>(c, g + k, L0), j, mj, Pc);
+            if (!MAT && gl.act) gfs_store<D>(fs, gfs_index<D>(c, g + k, L0), j, mj, Pc);
         }
         if (gend > 0) lml -= 0.5 * (gend * kLog2Pi + log(sprod) + quad);
     }
-    if (R0 != nullptr && c < n0 && r1 > r0 && gl.act) GAffineMO<D>::store(rev, R0, n0, n0 - 1 - c, j);
+    if (!MAT && c < n0 && r1 > r0 && gl.act) GAffineMO<D>::store(rev, R0, n0, n0 - 1 - c, j);
     double a = (j == 0 && c < n0) ? lml : 0.0, b = (j == 0 && c < n0) ? nmiss : 0.0;
     int bad = (j == 0 && c < n0 && !ok) ? 1 : 0;
     block_sum3(a, b, bad, sh);
