@@ -338,6 +338,15 @@ def main():
             out["roofline_general_layout"] = general_layout_leg(tgp, torch, name, T, d, local, max(3, args.steps // 2))
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(name, args.cpu_sample)
+        if "split" in out:
+            # informational only (vs_baseline stays null: the reference publishes no number for the combined metric): what its
+            # README plots show for the two quantities it did time, read off the axes (unstated CPU, 1 thread)
+            pub = dict(source="BASELINE.md section 1 (reference README plots, approximate)", logpdf_steps_per_s=[2e7, 5e7],
+                       logpdf_and_gradient_steps_per_s=[4e6, 1e7])
+            pub["logpdf_speedup"] = [out["split"]["logpdf_steps_per_s"] / v for v in pub["logpdf_steps_per_s"][::-1]]
+            if "logpdf_and_grad" in out:
+                pub["logpdf_and_gradient_speedup"] = [out["logpdf_and_grad"]["value"] / v for v in pub["logpdf_and_gradient_steps_per_s"][::-1]]
+            out["published_reference"] = pub
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
