@@ -70,6 +70,8 @@ typedef struct tgp_handle tgp_handle;
                            elements with eight lanes per element (tgp_group_scan.hpp), once they have reproduced the out-of-line
                            build in the run-time check: 1 (default) where they are faster (d >= 7), 2 for every d = 5..8,
                            0 never; + 4 keeps the lane-per-element block scans */
+#define TGP_OPT_SPLIT_SMOOTHER 7 /* lane-per-chunk passes: pass 2 of the smoother as two kernels (filter + scratch, then the chunk smoother
+                                    elements from the scratch): 1 (default) for d = 6, 7, 2 also for d = 5, 0 never (fused MODE 2 kernel) */
 #define TGP_OPT_TIMING 6 /* 1: record the hipEvents behind tgp_last_timing (off by default: ~30 us of host time per call) */
 #define TGP_OPT_FUSE_SCAN 4 /* 1 (default): the level-0 scan reduce / apply of the forward scan run inside the chunk kernels;
                                0: stand-alone k_scan_reduce / k_scan_apply launches (bit-identical results, for A/B timing) */

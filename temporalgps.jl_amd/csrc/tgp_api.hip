@@ -77,7 +77,7 @@ static void merge_tables(const KernelTable* safe, const KernelTable* fast, unsig
     }
     for (int m = 0; m < 4; ++m)
         if (ok & (1u << (kOpM0 + m))) out.apply_filter_m[m] = fast->apply_filter_m[m];
-    if (ok & (1u << kOpM2)) out.smooth = fast->smooth;
+    if (ok & (1u << kOpM2)) { out.smooth = fast->smooth; out.apply_filter_m[4] = fast->apply_filter_m[4]; out.compose_smoother = fast->compose_smoother; }
     if (ok & (1u << kOpAffine)) { out.reduce_affine = fast->reduce_affine; out.apply_affine = fast->apply_affine; }
     if (ok & ((1u << kOpAffine) | (1u << kOpM2))) {
         out.scan_reduce_c[kScanAffine] = fast->scan_reduce_c[kScanAffine];
@@ -248,6 +248,7 @@ struct tgp_handle {
     int alt_p = 0;
     int force_group_post = 0;
     DevBuf balt;
+    int opt_split = 1;           // TGP_OPT_SPLIT_SMOOTHER
     int opt_group = 1;           // TGP_OPT_GROUP
     int opt_group_scan = 1;      // TGP_OPT_GROUP bit 2 (value & 4) switches the group-layout block scans off
     int opt_fuse = 1;            // TGP_OPT_FUSE_SCAN
@@ -712,7 +713,7 @@ int forward_apply(tgp_handle* h, int mode, const FilterOut& fo, const double* x0
     const int64_t nblocks = (h->n0 + 255) / 256;
     HIPCHK(h->partial.ensure((size_t)nblocks * 3 * sizeof(double)));
     double* R0 = nullptr;
-    if (mode == 2) {
+    if (mode == 2 || mode == 4) {
         TRY(scan_prepare(h, h->Rv, kAffineCov, h->n0));
         R0 = h->Rv.E[0];
     }
@@ -720,6 +721,7 @@ int forward_apply(tgp_handle* h, int mode, const FilterOut& fo, const double* x0
         const char* nm = mode == 0 ? (h->lti ? "k_apply_filter<lti,logpdf>" : "k_apply_filter<per-step,logpdf>")
                          : mode == 1 ? (h->lti ? "k_apply_filter<lti,filter>" : "k_apply_filter<per-step,filter>")
                          : mode == 2 ? (h->lti ? "k_apply_filter<lti,posterior>" : "k_apply_filter<per-step,posterior>")
+                         : mode == 4 ? (h->lti ? "k_apply_filter<lti,scratch>" : "k_apply_filter<per-step,scratch>")
                                      : (h->lti ? "k_apply_filter<lti,materialise>" : "k_apply_filter<per-step,materialise>");
         LaunchScope ls(h, nm);
         h->kt->apply_filter(h->lti, mode, h->mv, h->L0, h->n0, h->F.S[0], h->fused ? h->F.E[0] : nullptr, h->fused ? h->F.S[1] : nullptr,
@@ -818,6 +820,13 @@ int tgp_set_option(tgp_handle* h, int option, int64_t value) {
             h->reduce_valid = false;
             h->smoother_valid = false;
         }
+        return TGP_OK;
+    }
+    if (option == TGP_OPT_SPLIT_SMOOTHER) {
+        if (value < 0 || value > 2) return h->fail(TGP_EINVAL, "TGP_OPT_SPLIT_SMOOTHER must be 0, 1 or 2");
+        h->opt_split = (int)value;
+        h->reduce_valid = false;
+        h->smoother_valid = false;
         return TGP_OK;
     }
     if (option == TGP_OPT_TIMING) {
@@ -1034,7 +1043,18 @@ static int smoother_forward_impl(tgp_handle* h, uint32_t flags, const double* x0
     HIPCHK(h->fs.ensure(fsz));
     FilterOut fo{};
     fo.fs = h->fs.d();
-    TRY(forward_apply(h, 2, fo, x0dev));
+    // d >= 5, lane-per-chunk passes: MODE 2 split into filter + scratch (MODE 4) and a kernel that composes the chunk smoother
+    // elements from the scratch -- each half spills less than the fused kernel (d = 6, T = 1e7: 2.87 ms fused)
+    // (measured, T = 1e7: d = 5 0.92 fused / 0.50 + 0.53 split; d = 6 2.87 / 1.01 + 0.85; d = 7 6.3 / 1.77 + 1.87: split from d = 6;
+    // TGP_OPT_SPLIT_SMOOTHER = 2 forces it for d = 5 too; d >= 8 runs the group smoother, and the d = 8 compose kernel
+    // faults (memory aperture violation in the start-up self-test), so it is never launched)
+    const bool split = !h->group_active && h->opt_split && ((h->d >= 6 && h->d <= 7) || (h->opt_split == 2 && h->d == 5)) && h->kt->apply_filter_m[4] != nullptr &&
+                       h->kt->compose_smoother != nullptr;
+    TRY(forward_apply(h, split ? 4 : 2, fo, x0dev));
+    if (split) {
+        LaunchScope ls(h, h->lti ? "k_compose_smoother<lti>" : "k_compose_smoother<per-step>");
+        h->kt->compose_smoother(h->lti, h->mv, h->L0, h->n0, h->F.S[0], h->fs.d(), h->Rv.E[0], flag_ptr(h), h->stream);
+    }
     scan_up(h, h->Rv);
     h->smoother_valid = true;
     return TGP_OK;

@@ -505,7 +505,7 @@ __global__ __launch_bounds__(256) void k_apply_filter(ModelView mv, int L0, int6
         const int64_t b = blockIdx.x;
         load_state<D>(cs, [=](int k) { return S1[(int64_t)k * n1 + b]; });
         block_exclusive_apply<M, 256>(e, wt, cs, x);
-        if (MODE == 2 && c < n0) store_state<D>(x, [=](int k, double v) { S0[(int64_t)k * n0 + c] = v; });   // the smoother reads it
+        if ((MODE == 2 || MODE == 4) && c < n0) store_state<D>(x, [=](int k, double v) { S0[(int64_t)k * n0 + c] = v; });   // the smoother reads it
     } else if (c < n0) {
         load_state<D>(x, [=](int k) { return S0[(int64_t)k * n0 + c]; });
     } else {
@@ -599,6 +599,18 @@ __global__ __launch_bounds__(256) void k_smooth(ModelView mv, int L0, int64_t n0
     if (rc && c < n0) atomicOr(bad, 1);
 }
 
+// ---------------------------------------------------------------- pass 2b: chunk smoother elements from the scratch (d >= 5)
+template <int D, bool LTI>
+__global__ __launch_bounds__(256) void k_compose_smoother(ModelView mv, int L0, int64_t n0, const double* __restrict__ S0,
+                                                          const double* __restrict__ fs, double* __restrict__ R0, int* __restrict__ bad) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= n0) return;
+    State<D> carry;
+    load_state<D>(carry, [=](int k) { return S0[(int64_t)k * n0 + c]; });
+    const int rc = chunk_compose_smoother<D, LTI>(mv, c, L0, carry, fs, [=](int k, double v) { R0[(int64_t)k * n0 + (n0 - 1 - c)] = v; });
+    if (rc) atomicOr(bad, 1);
+}
+
 // ---------------------------------------------------------------- affine pass 2
 template <int D, bool LTI, bool RAND>
 __global__ __launch_bounds__(256) void k_apply_affine(ModelView mv, int L0, int64_t n0, const double* __restrict__ S0, const double* __restrict__ eps_t,
@@ -630,8 +642,10 @@ struct KernelTable {
     // E1 != NULL: also reduce each block's 256 elements to E1[block] (fused level-0 scan reduce)
     void (*reduce_filter)(bool lti, const ModelView&, int L0, int64_t n0, double* E0, double* E1, int64_t n1, hipStream_t);
     // per MODE 0..3. E0 != NULL: carry-in states come from an in-block scan of E0 against the level-1 states S1 (fused level-0 apply)
-    void (*apply_filter_m[4])(bool lti, const ModelView&, int L0, int64_t n0, double* S0, const double* E0, const double* S1, int64_t n1,
+    // (index 4: MODE 4 = filter + scratch only, followed by compose_smoother -- the d >= 5 form of MODE 2; NULL where not built)
+    void (*apply_filter_m[5])(bool lti, const ModelView&, int L0, int64_t n0, double* S0, const double* E0, const double* S1, int64_t n1,
                               const FilterOut&, double* R0, double* partial, hipStream_t);
+    void (*compose_smoother)(bool lti, const ModelView&, int L0, int64_t n0, const double* S0, const double* fs, double* R0, int* bad, hipStream_t);
     void (*smooth)(bool lti, const ModelView&, int L0, int64_t n0, const double* S0, const double* S0r, const double* fs,
                    const double* Rnew, int64_t sRn, double* mean_out, double* var_out, int* bad, hipStream_t);
     void (*reduce_affine)(bool lti, bool rnd, const ModelView&, int L0, int64_t n0, const double* eps_t, double* E0, int* bad, hipStream_t);
@@ -685,7 +699,7 @@ struct KernelTable {
     }
     void apply_filter(bool lti, int mode, const ModelView& mv, int L0, int64_t n0, double* S0, const double* E0, const double* S1, int64_t n1,
                       const FilterOut& out, double* R0, double* partial, hipStream_t s) const {
-        apply_filter_m[mode < 0 || mode > 3 ? 3 : mode](lti, mv, L0, n0, S0, E0, S1, n1, out, R0, partial, s);
+        apply_filter_m[mode < 0 || mode > 4 ? 3 : mode](lti, mv, L0, n0, S0, E0, S1, n1, out, R0, partial, s);
     }
 };
 
