@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "tgp_kernels.hpp"
+#include "tgp_dense.hpp"
 
 namespace tgp {
 const KernelTable *kernel_table_d1(), *kernel_table_d2(), *kernel_table_d3(), *kernel_table_d4(), *kernel_table_d5(),
@@ -201,6 +202,9 @@ struct tgp_handle {
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
     std::string err;
+    // dense large-state engine (d > 16, tgp_dense.hip): sequential in time, fp64 MFMA
+    tgp_dense::Engine* dense = nullptr;
+    bool is_dense = false;
     // model
     bool have_model = false, lti = false;
     int64_t T = 0;
@@ -579,6 +583,12 @@ int check_ready(tgp_handle* h) {
     if (!h->have_model) return h->fail(TGP_EINVAL, "no model set (call tgp_model_set first)");
     return bind_device(h);
 }
+// entry points the dense large-state engine (d > 16) does not serve
+int scan_only(tgp_handle* h, const char* what) {
+    if (h && h->is_dense) return h->fail(TGP_EUNSUPPORTED, std::string(what) + ": not available for state dimension d > 16 (dense path)");
+    return TGP_OK;
+}
+int dense_fail(tgp_handle* h, int rc) { return rc == TGP_OK ? TGP_OK : h->fail(rc, tgp_dense::last_error(h->dense)); }
 
 // General (per-step) layout: (re)build the time-tiled copy of the per-step arrays for the current chunk size.
 int ensure_tiled(tgp_handle* h) {
@@ -791,6 +801,7 @@ int tgp_destroy(tgp_handle* h) {
         (void)hipEventDestroy(pe.b);
     }
     for (auto& e : h->evpool) (void)hipEventDestroy(e);
+    if (h->dense) tgp_dense::destroy(h->dense);
     if (h->host_result) (void)hipHostFree(h->host_result);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
@@ -872,10 +883,46 @@ int tgp_model_set(tgp_handle* h, int64_t T, int d, int p, int ordering, uint32_t
     h->smoother_valid = false;
     h->sde = false;
     if (T <= 0) return h->fail(TGP_EINVAL, "T must be positive");
-    if (p < 1 || p > 64) return h->fail(TGP_EUNSUPPORTED, "observation dimension p must be in 1..64 (diagonal noise)");
     if (ordering != 0 && ordering != 1) return h->fail(TGP_EINVAL, "ordering must be 0 (Forward) or 1 (Reverse)");
+    h->is_dense = false;
+    if (d > 16) {
+        // dense large-state path (tgp_dense.hip): the arrays are re-packed into the padded MFMA layout, nothing is borrowed
+        if (p < 1) return h->fail(TGP_EINVAL, "p must be positive");
+        if (!A || !a || !Q || !H || !hh || !R || !x0m || !x0P) return h->fail(TGP_EINVAL, "null model array");
+        if (!h->dense) h->dense = tgp_dense::create(h->device);
+        const bool dev = (flags & TGP_DEVICE_PTRS) != 0;
+        auto cnt = [&](uint32_t bit, int64_t per) { return (size_t)((flags & bit) ? per : per * T) * sizeof(double); };
+        const void *pA, *pa, *pQ, *pH, *ph, *pR;
+        TRY(stage_in(h, h->bA, A, cnt(TGP_SHARED_A, (int64_t)d * d), dev, &pA));
+        TRY(stage_in(h, h->ba, a, cnt(TGP_SHARED_a, d), dev, &pa));
+        TRY(stage_in(h, h->bQ, Q, cnt(TGP_SHARED_Q, (int64_t)d * d), dev, &pQ));
+        TRY(stage_in(h, h->bH, H, cnt(TGP_SHARED_H, (int64_t)p * d), dev, &pH));
+        TRY(stage_in(h, h->bh, hh, cnt(TGP_SHARED_h, p), dev, &ph));
+        TRY(stage_in(h, h->bR, R, cnt(TGP_SHARED_R, p), dev, &pR));
+        tgp_dense::ModelDesc md{};
+        md.T = T; md.d = d; md.p = p; md.ordering = ordering;
+        md.A = (const double*)pA; md.a = (const double*)pa; md.Q = (const double*)pQ;
+        md.H = (const double*)pH; md.h = (const double*)ph; md.R = (const double*)pR;
+        md.sA = (flags & TGP_SHARED_A) ? 0 : (int64_t)d * d;
+        md.sa = (flags & TGP_SHARED_a) ? 0 : d;
+        md.sQ = (flags & TGP_SHARED_Q) ? 0 : (int64_t)d * d;
+        md.sH = (flags & TGP_SHARED_H) ? 0 : (int64_t)p * d;
+        md.sh = (flags & TGP_SHARED_h) ? 0 : p;
+        md.sR = (flags & TGP_SHARED_R) ? 0 : p;
+        md.x0m = x0m; md.x0P = x0P;
+        tgp_dense::set_profile(h->dense, h->profile);
+        TRY(dense_fail(h, tgp_dense::model_set(h->dense, md, h->stream)));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        for (DevBuf* b : {&h->bA, &h->bQ, &h->bH}) b->release();   // the packed copy is what the kernels read
+        h->T = T; h->d = d; h->p = p; h->ordering = ordering;
+        h->lti = false;
+        h->is_dense = true;
+        h->have_model = true;
+        return TGP_OK;
+    }
+    if (p < 1 || p > 64) return h->fail(TGP_EUNSUPPORTED, "observation dimension p must be in 1..64 (diagonal noise) on the scan path");
     const KernelTable* kt = kernel_table(d);
-    if (!kt) return h->fail(TGP_EUNSUPPORTED, "state dimension d must be in 1..16 for the per-lane scan path");
+    if (!kt) return h->fail(TGP_EUNSUPPORTED, "state dimension d must be positive");
     {
         const uint32_t lb = TGP_SHARED_A | TGP_SHARED_a | TGP_SHARED_Q | TGP_SHARED_H | TGP_SHARED_h;
         select_table(h, d, (flags & lb) == lb, h->variant_opt);
@@ -970,6 +1017,7 @@ int tgp_model_set_sde(tgp_handle* h, int64_t T, int d, int ordering, uint32_t fl
 int tgp_model_set_x0(tgp_handle* h, const double* x0m, const double* x0P) {
     TRY(check_ready(h));
     if (!x0m || !x0P) return h->fail(TGP_EINVAL, "null x0");
+    if (h->is_dense) return dense_fail(h, tgp_dense::set_x0(h->dense, x0m, x0P, h->stream));
     h->x0m.assign(x0m, x0m + h->d);
     h->x0P.assign(x0P, x0P + h->d * h->d);
     h->fold_valid = false;
@@ -983,6 +1031,12 @@ int tgp_logpdf(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t 
     CallTimer tm(h);
     TRY(set_obs(h, y, missing, flags));
     tm.inputs_done();
+    if (h->is_dense) {
+        tgp_dense::set_profile(h->dense, h->profile);
+        TRY(dense_fail(h, tgp_dense::filter(h->dense, h->mv.y, h->mv.missing, nullptr, nullptr, h->result.d(), h->stream)));
+        tm.kernels_done();
+        return tm.finish(out);
+    }
     TRY(forward_reduce(h, flags, 0));
     FilterOut fo{};
     TRY(forward_apply(h, 0, fo));
@@ -997,6 +1051,17 @@ int tgp_filter(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t 
     CallTimer tm(h);
     TRY(set_obs(h, y, missing, flags));
     tm.inputs_done();
+    if (h->is_dense) {
+        double *dm = nullptr, *dP = nullptr;
+        TRY(stage_out(h, h->bo1, m_out, nm, odev, &dm));
+        TRY(stage_out(h, h->bo2, P_out, nP, odev, &dP));
+        tgp_dense::set_profile(h->dense, h->profile);
+        TRY(dense_fail(h, tgp_dense::filter(h->dense, h->mv.y, h->mv.missing, dm, dP, h->result.d(), h->stream)));
+        tm.kernels_done();
+        TRY(copy_back(h, m_out, dm, nm, odev));
+        TRY(copy_back(h, P_out, dP, nP, odev));
+        return tm.finish(lml_out);
+    }
     TRY(forward_reduce(h, flags, 1));
     FilterOut fo{};
     TRY(stage_out(h, h->bo1, m_out, nm, odev, &fo.m_out));
@@ -1011,6 +1076,7 @@ int tgp_filter(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t 
 int tgp_posterior(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t flags, double* G, double* g, double* L,
                   double* xfm, double* xfP) {
     TRY(check_ready(h));
+    TRY(scan_only(h, "tgp_posterior"));
     if (h->ordering != 0) return h->fail(TGP_EUNSUPPORTED, "posterior of a Reverse-ordered model is not implemented on the device");
     if ((G || g || L) && !(G && g && L)) return h->fail(TGP_EINVAL, "G, g, L must be given together");
     const bool odev = (flags & TGP_OUT_DEVICE) != 0;
@@ -1089,6 +1155,18 @@ int tgp_posterior_marginals(tgp_handle* h, const double* y, const uint8_t* missi
     TRY(stage_in(h, h->bRnew, Rnew, rshared ? (size_t)h->p * sizeof(double) : nT, idev, &pR));
     TRY(set_obs(h, y, missing, flags));
     tm.inputs_done();
+    if (h->is_dense) {
+        double *dm2 = nullptr, *dv2 = nullptr;
+        TRY(stage_out(h, h->bo1, mean_out, nT, odev, &dm2));
+        TRY(stage_out(h, h->bo2, var_out, nT, odev, &dv2));
+        tgp_dense::set_profile(h->dense, h->profile);
+        TRY(dense_fail(h, tgp_dense::posterior_marginals(h->dense, h->mv.y, h->mv.missing, (const double*)pR, rshared ? 0 : h->p, dm2, dv2,
+                                                         h->result.d(), h->stream)));
+        tm.kernels_done();
+        TRY(copy_back(h, mean_out, dm2, nT, odev));
+        TRY(copy_back(h, var_out, dv2, nT, odev));
+        return tm.finish(lml_out);
+    }
     TRY(smoother_forward_impl(h, flags, nullptr, /*allow_group=*/true));
     double *dm = nullptr, *dv = nullptr;
     TRY(stage_out(h, h->bo1, mean_out, nT, odev, &dm));
@@ -1103,6 +1181,7 @@ int tgp_posterior_marginals(tgp_handle* h, const double* y, const uint8_t* missi
 int tgp_posterior_marginals_at(tgp_handle* h, const double* y, const uint8_t* missing, int pn, const double* Hn, const double* hn,
                                const double* Rn, uint32_t flags, double* mean_out, double* var_out, double* lml_out) {
     TRY(check_ready(h));
+    TRY(scan_only(h, "tgp_posterior_marginals_at"));
     if (pn < 1 || pn > 4096 || !Hn || !hn || !Rn || !mean_out || !var_out) return h->fail(TGP_EINVAL, "bad alternative emission block / output");
     if (h->ordering != 0 || !h->lti || !h->use_group_sm || !h->opt_group || h->kt->group_smooth == nullptr)
         return h->fail(TGP_EUNSUPPORTED, "tgp_posterior_marginals_at: Forward LTI models with the group-per-chunk smoother (d = 5..16) only");
@@ -1146,6 +1225,7 @@ int tgp_posterior_marginals_at(tgp_handle* h, const double* y, const uint8_t* mi
 int tgp_smoother_forward(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t flags, double* rev_elem_out, double* xfm,
                          double* xfP, double* lml_out) {
     TRY(check_ready(h));
+    TRY(scan_only(h, "tgp_smoother_forward"));
     if (h->ordering != 0) return h->fail(TGP_EUNSUPPORTED, "posterior of a Reverse-ordered model is not implemented on the device");
     CallTimer tm(h);
     TRY(set_obs(h, y, missing, flags));
@@ -1165,6 +1245,7 @@ int tgp_smoother_forward(tgp_handle* h, const double* y, const uint8_t* missing,
 int tgp_smoother_backward(tgp_handle* h, const double* xs_m, const double* xs_P, const double* Rnew, uint32_t flags, double* mean_out,
                           double* var_out) {
     TRY(check_ready(h));
+    TRY(scan_only(h, "tgp_smoother_backward"));
     if (!h->smoother_valid) return h->fail(TGP_EINVAL, "tgp_smoother_backward needs a preceding tgp_smoother_forward");
     if (!Rnew || !mean_out || !var_out) return h->fail(TGP_EINVAL, "null Rnew / output");
     const bool idev = (flags & TGP_IN_DEVICE) != 0, odev = (flags & TGP_OUT_DEVICE) != 0;
@@ -1251,6 +1332,13 @@ int tgp_marginals(tgp_handle* h, uint32_t flags, double* mean_out, double* var_o
     double *dm = nullptr, *dv = nullptr;
     TRY(stage_out(h, h->bo1, mean_out, nT, odev, &dm));
     TRY(stage_out(h, h->bo2, var_out, nT, odev, &dv));
+    if (h->is_dense) {
+        TRY(dense_fail(h, tgp_dense::marginals(h->dense, dm, dv, h->result.d(), h->stream)));
+        tm.kernels_done();
+        TRY(copy_back(h, mean_out, dm, nT, odev));
+        TRY(copy_back(h, var_out, dv, nT, odev));
+        return tm.finish();
+    }
     TRY(affine_impl(h, false, h->bx0.d(), nullptr, nullptr, dm, dv));
     tm.kernels_done();
     TRY(copy_back(h, mean_out, dm, nT, odev));
@@ -1260,6 +1348,7 @@ int tgp_marginals(tgp_handle* h, uint32_t flags, double* mean_out, double* var_o
 
 int tgp_rand(tgp_handle* h, const double* eps_t, const double* eps_e, const double* eps_0, uint32_t flags, double* y_out) {
     TRY(check_ready(h));
+    TRY(scan_only(h, "tgp_rand"));
     if (!eps_t || !eps_e || !eps_0 || !y_out) return h->fail(TGP_EINVAL, "null eps / output");
     const bool idev = (flags & TGP_IN_DEVICE) != 0, odev = (flags & TGP_OUT_DEVICE) != 0;
     const size_t nT = (size_t)h->T * h->p * sizeof(double);   // one value per (time step, observation)
@@ -1301,6 +1390,7 @@ int tgp_logpdf_grad(tgp_handle* h, const double* y, const uint8_t* missing, uint
                     const double* da, const double* dQ, const double* dH, const double* dh, const double* dR, const double* dx0m,
                     const double* dx0P, double* lml_out, double* grad_out) {
     TRY(check_ready(h));
+    TRY(scan_only(h, "tgp_logpdf_grad"));
     if (nparams < 1 || !grad_out) return h->fail(TGP_EINVAL, "nparams must be >= 1 and grad_out non-null");
     if (!dA || !da || !dQ || !dH || !dh || !dR || !dx0m || !dx0P) return h->fail(TGP_EINVAL, "null tangent array");
     if (!h->lti || h->mv.sR != 0 || h->p != 1 || h->ordering != 0)
@@ -1382,6 +1472,7 @@ int tgp_logpdf_grad_sde(tgp_handle* h, const double* y, const uint8_t* missing, 
                         const double* dPinf, const double* dA1, const double* dQ1, const double* da, const double* dH, const double* dh,
                         const double* dR, const double* dx0m, const double* dx0P, double rel_step, double* lml_out, double* grad_out) {
     TRY(check_ready(h));
+    TRY(scan_only(h, "tgp_logpdf_grad_sde"));
     if (nparams < 1 || !grad_out) return h->fail(TGP_EINVAL, "nparams must be >= 1 and grad_out non-null");
     if (!dF || !dPinf || !da || !dH || !dh || !dR || !dx0m || !dx0P) return h->fail(TGP_EINVAL, "null tangent array");
     if (!h->sde || h->p != 1 || h->ordering != 0 || h->mv.sH != 0 || h->mv.sh != 0)
@@ -1649,6 +1740,7 @@ int tgp_elem_size(int kind, int d) { return kind == 0 ? felem_size(d) : aelem_si
 
 int tgp_segment_reduce(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t flags, double* elem_out) {
     TRY(check_ready(h));
+    TRY(scan_only(h, "tgp_segment_reduce"));
     if (!elem_out) return h->fail(TGP_EINVAL, "elem_out is NULL");
     CallTimer tm(h);
     TRY(set_obs(h, y, missing, flags));
@@ -1667,6 +1759,7 @@ int tgp_shard_slot_size(int phase, int d) {
 
 int tgp_shard_reduce(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t flags, double* slot_dev) {
     TRY(check_ready(h));
+    TRY(scan_only(h, "tgp_shard_reduce"));
     if (!slot_dev) return h->fail(TGP_EINVAL, "slot_dev is NULL");
     CallTimer tm(h);                                   // clears the result / flag words for the whole multi-phase call
     h->fold_valid = false;
@@ -1680,6 +1773,7 @@ int tgp_shard_reduce(tgp_handle* h, const double* y, const uint8_t* missing, uin
 
 int tgp_shard_fold(tgp_handle* h, const double* gathered_dev, int world, int rank) {
     TRY(check_ready(h));
+    TRY(scan_only(h, "tgp_shard_fold"));
     if (!gathered_dev || world < 1 || rank < 0 || rank >= world) return h->fail(TGP_EINVAL, "bad gathered buffer / world / rank");
     if (!h->reduce_valid) return h->fail(TGP_EINVAL, "tgp_shard_fold needs a preceding tgp_shard_reduce");
     HIPCHK(h->bx0fold.ensure((size_t)state_size(h->d) * sizeof(double)));
@@ -1693,6 +1787,7 @@ int tgp_shard_fold(tgp_handle* h, const double* gathered_dev, int world, int ran
 
 int tgp_shard_logpdf(tgp_handle* h, double* stats_dev) {
     TRY(check_ready(h));
+    TRY(scan_only(h, "tgp_shard_logpdf"));
     if (!stats_dev) return h->fail(TGP_EINVAL, "stats_dev is NULL");
     if (!h->fold_valid || !h->reduce_valid) return h->fail(TGP_EINVAL, "tgp_shard_logpdf needs tgp_shard_reduce + tgp_shard_fold first");
     FilterOut fo{};
@@ -1704,6 +1799,7 @@ int tgp_shard_logpdf(tgp_handle* h, double* stats_dev) {
 
 int tgp_shard_smoother_forward(tgp_handle* h, double* slot_dev) {
     TRY(check_ready(h));
+    TRY(scan_only(h, "tgp_shard_smoother_forward"));
     if (!slot_dev) return h->fail(TGP_EINVAL, "slot_dev is NULL");
     if (h->ordering != 0) return h->fail(TGP_EUNSUPPORTED, "posterior of a Reverse-ordered model is not implemented on the device");
     if (!h->fold_valid || !h->reduce_valid) return h->fail(TGP_EINVAL, "tgp_shard_smoother_forward needs tgp_shard_reduce + tgp_shard_fold first");
@@ -1719,6 +1815,7 @@ int tgp_shard_smoother_forward(tgp_handle* h, double* slot_dev) {
 int tgp_shard_smoother_backward(tgp_handle* h, const double* gathered_dev, int world, int rank, const double* Rnew, uint32_t flags,
                                 double* mean_out, double* var_out, double* lml_out) {
     TRY(check_ready(h));
+    TRY(scan_only(h, "tgp_shard_smoother_backward"));
     if (!h->smoother_valid) return h->fail(TGP_EINVAL, "tgp_shard_smoother_backward needs a preceding tgp_shard_smoother_forward");
     if (!gathered_dev || world < 1 || rank < 0 || rank >= world) return h->fail(TGP_EINVAL, "bad gathered buffer / world / rank");
     if (!Rnew || !mean_out || !var_out) return h->fail(TGP_EINVAL, "null Rnew / output");
@@ -1771,6 +1868,7 @@ int tgp_profile_reset(tgp_handle* h) {
     if (!h) return TGP_EINVAL;
     resolve_profile(h);
     h->prof.clear();
+    if (h->dense) tgp_dense::profile_reset(h->dense);
     return TGP_OK;
 }
 int tgp_profile_count(tgp_handle* h) {
@@ -1779,10 +1877,22 @@ int tgp_profile_count(tgp_handle* h) {
         (void)hipStreamSynchronize(h->stream);
         resolve_profile(h);
     }
-    return (int)h->prof.size();
+    return (int)h->prof.size() + (h->dense ? tgp_dense::profile_count(h->dense) : 0);
 }
 int tgp_profile_get(tgp_handle* h, int idx, char* name, int name_cap, double* total_ms, int64_t* calls) {
-    if (!h || idx < 0 || idx >= (int)h->prof.size()) return TGP_EINVAL;
+    if (!h || idx < 0) return TGP_EINVAL;
+    if (idx >= (int)h->prof.size()) {
+        const int di = idx - (int)h->prof.size();
+        if (!h->dense || di >= tgp_dense::profile_count(h->dense)) return TGP_EINVAL;
+        const tgp_dense::KernelTime kt = tgp_dense::profile_get(h->dense, di);
+        if (name && name_cap > 0) {
+            std::strncpy(name, kt.name, (size_t)name_cap - 1);
+            name[name_cap - 1] = 0;
+        }
+        if (total_ms) *total_ms = kt.ms;
+        if (calls) *calls = kt.calls;
+        return TGP_OK;
+    }
     if (name && name_cap > 0) {
         std::strncpy(name, h->prof[idx].name.c_str(), (size_t)name_cap - 1);
         name[name_cap - 1] = 0;

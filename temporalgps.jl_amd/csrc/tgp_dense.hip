@@ -1,0 +1,957 @@
+// Dense large-state Kalman engine for gfx950 (see tgp_dense.hpp). One time step = a short fixed chain of kernels on the
+// handle's stream; every O(d^3) / O(p d^2) contraction runs on v_mfma_f64_16x16x4_f64.
+//
+// Layouts (all fp64, device): dimensions are padded to multiples of 16 (Dp >= d, Pq >= p) with zeros (R padded with ones), which
+// leaves every quantity of the recursion unchanged (the padded rows / columns of P stay zero, the padded block of S is I).
+//   Ak  [Dp x Dp]  column-major A (A[i][k] at Ak[i + k Dp])        Qc [Dp x Dp] column-major Q
+//   Hk  [Dp][Pq]   H transposed: H[i][k] at Hk[k Pq + i]           av [Dp], hv [Pq], Rv [Pq]
+//   P, Pp, T1 [Dp x Dp] column-major; V [Pq x (Dp + 16)] column-major (V[i][k] at V[i + k Pq]; column Dp holds the residual r)
+//   S, L [Pq x Pq] column-major;  Bm [Pq][Dp + 16] row-major (B[k][i] at Bm[k ldB + i]; column Dp holds alpha)
+// Every GEMM operand is therefore "k-major": Aop[i][k] at A[k lda + i], Bop[k][j] at B[k ldb + j] -- one coalesced row of the
+// free index per k -- and every output is written with its first index contiguous.
+#include "tgp_dense.hpp"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../include/tgp_hip.h"
+
+namespace tgp_dense {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+constexpr double kLargeVar = 1e15;                 // missings.jl:43
+constexpr double kLog2Pi = 1.8378770664093454836;  // log(2 pi)
+
+// ------------------------------------------------------------------------------------------------ riders
+// Small matrix-vector products that ride along a GEMM launch as extra workgroups (one kernel boundary less per product).
+struct GemvArgs {
+    int mode = 0;            // 0 none; 1 out = add + Mx x; 2 residual r = y - h - Mx x (+ missing count); 3 m = add + Mx x and lml_t
+    const double* Mx = nullptr;  // Mx[i][k] at Mx[i + k ld]
+    int64_t ld = 0;
+    int n = 0, K = 0;        // rows (padded), inner length
+    const double* x = nullptr;
+    int64_t xs = 1;
+    const double* add = nullptr;
+    double* out = nullptr;
+    double* out2 = nullptr;  // unpadded copy (first n2 rows), nullable
+    int n2 = 0;
+    const double* y = nullptr;       // mode 2
+    const uint8_t* mask = nullptr;   // mode 2 (nullable)
+    const double* hh = nullptr;      // mode 2
+    int p = 0;                       // true observation count
+    double* scal = nullptr;          // [0] logdet S (written by dk_chol), [1] missing elements of this step, [2] not-PD flag
+    double* stats = nullptr;         // the call's result8
+    int64_t tstep = 0;
+};
+
+__device__ inline void gemv_rider(const GemvArgs& v, int rb, double* lds) {
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = rb * 64 + lane;
+    const int kc = (v.K + 7) / 8;
+    const int k0 = w * kc, k1 = min(v.K, k0 + kc);
+    double s = 0.0;
+    if (r < v.n)
+        for (int k = k0; k < k1; ++k) s += v.Mx[r + (int64_t)k * v.ld] * v.x[(int64_t)k * v.xs];
+    lds[w * 64 + lane] = s;
+    __syncthreads();
+    if (w == 0 && r < v.n) {
+        double tot = 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) tot += lds[u * 64 + lane];
+        double o;
+        if (v.mode == 2) {
+            double yy = 0.0, hv = 0.0;
+            if (r < v.p) {
+                const bool miss = v.mask != nullptr && v.mask[r] != 0;
+                yy = miss ? 0.0 : v.y[r];
+                hv = v.hh[r];
+            }
+            o = r < v.p ? (yy - hv - tot) : 0.0;
+        } else {
+            o = tot + (v.add ? v.add[r] : 0.0);
+        }
+        v.out[r] = o;
+        if (v.out2 && r < v.n2) v.out2[r] = o;
+    }
+    if (rb != 0) return;
+    if (v.mode == 2) {   // count this step's missing elements
+        __syncthreads();
+        int* cnt = reinterpret_cast<int*>(lds);
+        if (tid == 0) *cnt = 0;
+        __syncthreads();
+        int c = 0;
+        if (v.mask)
+            for (int i = tid; i < v.p; i += blockDim.x) c += v.mask[i] != 0;
+        if (c) atomicAdd(cnt, c);
+        __syncthreads();
+        if (tid == 0) v.scal[1] = (double)*cnt;
+    } else if (v.mode == 3) {   // lml_t = -(p log 2pi + logdet S + alpha' alpha) / 2 (+ missing-data compensation, missings.jl:45-53)
+        __syncthreads();
+        double q = 0.0;
+        for (int k = tid; k < v.K; k += blockDim.x) {
+            const double a = v.x[(int64_t)k * v.xs];
+            q += a * a;
+        }
+        lds[tid] = q;
+        __syncthreads();
+        for (int st = blockDim.x / 2; st > 0; st >>= 1) {
+            if (tid < st) lds[tid] += lds[tid + st];
+            __syncthreads();
+        }
+        if (tid == 0) {
+            const double nm = v.scal[1];
+            const double lml = -0.5 * ((double)v.p * kLog2Pi + v.scal[0] + lds[0]) + nm * 0.5 * (kLog2Pi + log(kLargeVar));
+            v.stats[0] += lml;
+            v.stats[1] += nm;
+            if (v.scal[2] != 0.0 && v.stats[2] == 0.0) v.stats[2] = (double)(v.tstep + 1);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ GEMM on fp64 MFMA
+struct GemmArgs {
+    const double* A = nullptr;   // Aop[i][k] at A[k lda + i]
+    int64_t lda = 0;
+    const double* B = nullptr;   // Bop[k][j] at B[k ldb + j]
+    int64_t ldb = 0;
+    double* C = nullptr;         // C[i][j] at C[i + j ldc]
+    int64_t ldc = 0;
+    const double* E = nullptr;   // C = E + sign * (Aop Bop) (+ diag)
+    int64_t lde = 0;
+    double sign = 1.0;
+    const double* diag = nullptr;    // + diag (missing -> 1e15, rows >= ndiag -> 1): the S = V H' + R epilogue
+    const uint8_t* dmask = nullptr;
+    int ndiag = 0;
+    double* C2 = nullptr;        // optional second (unpadded) copy of the result: C2[i + j ldc2], i < M2, j < N2
+    int64_t ldc2 = 0;
+    int M2 = 0, N2 = 0;
+    int M = 0, N = 0, K = 0;
+    int nblk_tiles = 0;
+    GemvArgs v;
+};
+
+__device__ inline d4 mfma_f64(double a, double b, d4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+
+template <int TM, int TN> struct GemmCfg {
+    static constexpr int BK = 64, NT = 512;
+    static constexpr int BM = TM * 16, BN = TN * 16;
+    static constexpr int SA = (BM % 32 == 16) ? BM : BM + 16;   // LDS row strides (doubles): consecutive k rows 32 banks apart
+    static constexpr int SB = (BN % 32 == 16) ? BN : BN + 16;
+    static constexpr int STAGE = BK * (SA + SB);
+    static constexpr int NTILE = TM * TN;
+    static constexpr int RED = 4 * NTILE * 256;
+    static constexpr int LDS_DOUBLES = (2 * STAGE > RED ? 2 * STAGE : RED) > 512 ? (2 * STAGE > RED ? 2 * STAGE : RED) : 512;
+    static constexpr size_t LDS_BYTES = (size_t)LDS_DOUBLES * sizeof(double);
+};
+
+// One workgroup (8 waves) owns a (16 TM) x (16 TN) block of C. The K range is cut into slabs of 64 staged through LDS
+// (double-buffered, global loads of slab s+1 in flight while slab s is multiplied); inside a slab the 8 waves split K
+// (8 k-values each = two MFMA k-steps over all TM x TN tiles), so a wave carries TM*TN accumulators and no operand is read
+// twice from LDS. The 8 partial sums are then reduced through LDS in a fixed order (bit-reproducible).
+template <int TM, int TN> __global__ __launch_bounds__(512) void dk_gemm(const GemmArgs g) {
+    using Cfg = GemmCfg<TM, TN>;
+    constexpr int BK = Cfg::BK, NT = Cfg::NT, BM = Cfg::BM, BN = Cfg::BN, SA = Cfg::SA, SB = Cfg::SB, STAGE = Cfg::STAGE, NTILE = Cfg::NTILE;
+    extern __shared__ double lds[];
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if ((int)blockIdx.x >= g.nblk_tiles) {
+        gemv_rider(g.v, (int)blockIdx.x - g.nblk_tiles, lds);
+        return;
+    }
+    const int ntm = (g.M + BM - 1) / BM, ntn = (g.N + BN - 1) / BN, ntiles = ntm * ntn;
+    // XCD-aware tile order: workgroup b runs on XCD b % 8; each XCD gets a contiguous run of tiles, and tiles are numbered in
+    // bands of 4 tile rows, column by column inside a band, so that an XCD's run is a compact (4 rows x few columns) block.
+    const int per = g.nblk_tiles >> 3;
+    const int tl = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
+    if (tl >= ntiles) return;
+    const int band = tl / (4 * ntn), rem = tl - band * 4 * ntn;
+    const int rows_in_band = min(4, ntm - band * 4);
+    const int tn = rem / rows_in_band, tm = band * 4 + rem % rows_in_band;
+    const int i0 = tm * BM, j0 = tn * BN;
+
+    d4 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) acc[a][b] = d4{0.0, 0.0, 0.0, 0.0};
+
+    constexpr int CHA = BM / 2, CHB = BN / 2;
+    constexpr int NLA = (BK * CHA + NT - 1) / NT, NLB = (BK * CHB + NT - 1) / NT;
+    d2 ra[NLA], rb[NLB];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int it = 0; it < NLA; ++it) {
+            const int c = tid + it * NT, k = c / CHA, ch = c - k * CHA;
+            const bool ok = c < BK * CHA && k0 + k < g.K && i0 + 2 * ch < g.M;
+            ra[it] = ok ? *reinterpret_cast<const d2*>(g.A + (int64_t)(k0 + k) * g.lda + i0 + 2 * ch) : d2{0.0, 0.0};
+        }
+#pragma unroll
+        for (int it = 0; it < NLB; ++it) {
+            const int c = tid + it * NT, k = c / CHB, ch = c - k * CHB;
+            const bool ok = c < BK * CHB && k0 + k < g.K && j0 + 2 * ch < g.N;
+            rb[it] = ok ? *reinterpret_cast<const d2*>(g.B + (int64_t)(k0 + k) * g.ldb + j0 + 2 * ch) : d2{0.0, 0.0};
+        }
+    };
+    auto swrite = [&](int stage) {
+        double* As = lds + stage * STAGE;
+        double* Bs = As + BK * SA;
+#pragma unroll
+        for (int it = 0; it < NLA; ++it) {
+            const int c = tid + it * NT, k = c / CHA, ch = c - k * CHA;
+            if (c < BK * CHA) *reinterpret_cast<d2*>(As + k * SA + 2 * ch) = ra[it];
+        }
+#pragma unroll
+        for (int it = 0; it < NLB; ++it) {
+            const int c = tid + it * NT, k = c / CHB, ch = c - k * CHB;
+            if (c < BK * CHB) *reinterpret_cast<d2*>(Bs + k * SB + 2 * ch) = rb[it];
+        }
+    };
+
+    const int nslab = (g.K + BK - 1) / BK;
+    gload(0);
+    swrite(0);
+    __syncthreads();
+    for (int s = 0; s < nslab; ++s) {
+        if (s + 1 < nslab) gload((s + 1) * BK);
+        const double* As = lds + (s & 1) * STAGE;
+        const double* Bs = As + BK * SA;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int krow = w * 8 + kk * 4 + (lane >> 4);
+            double fa[TM], fb[TN];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) fa[a] = As[krow * SA + a * 16 + (lane & 15)];
+#pragma unroll
+            for (int b = 0; b < TN; ++b) fb[b] = Bs[krow * SB + b * 16 + (lane & 15)];
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b) acc[a][b] = mfma_f64(fb[b], fa[a], acc[a][b]);   // D'[j][i]: lanes run along i
+        }
+        if (s + 1 < nslab) swrite((s + 1) & 1);
+        __syncthreads();
+    }
+    // ---- split-K reduction: waves 4..7 -> LDS, waves 0..3 add their partner and publish, then every wave finishes tiles
+    double* red = lds;
+    if (w >= 4) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[(((w - 4) * NTILE + a * TN + b) * 4 + r) * 64 + lane] = acc[a][b][r];
+    }
+    __syncthreads();
+    if (w < 4) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    double* q = &red[((w * NTILE + a * TN + b) * 4 + r) * 64 + lane];
+                    *q = acc[a][b][r] + *q;
+                }
+    }
+    __syncthreads();
+    for (int q = w; q < NTILE; q += 8) {
+        const int a = q / TN, b = q - a * TN;
+        const int i = i0 + a * 16 + (lane & 15);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = j0 + b * 16 + (lane >> 4) + 4 * r;
+            const double s01 = red[((0 * NTILE + q) * 4 + r) * 64 + lane] + red[((1 * NTILE + q) * 4 + r) * 64 + lane];
+            const double s23 = red[((2 * NTILE + q) * 4 + r) * 64 + lane] + red[((3 * NTILE + q) * 4 + r) * 64 + lane];
+            double val = g.sign * (s01 + s23);
+            if (i < g.M && j < g.N) {
+                if (g.E) val += g.E[i + (int64_t)j * g.lde];
+                if (g.diag && i == j) val += i < g.ndiag ? ((g.dmask && g.dmask[i]) ? kLargeVar : g.diag[i]) : 1.0;
+                g.C[i + (int64_t)j * g.ldc] = val;
+                if (g.C2 && i < g.M2 && j < g.N2) g.C2[i + (int64_t)j * g.ldc2] = val;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ Cholesky of S (n <= 256)
+__device__ inline double rdlane(double v, int l) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, l);
+    hi = __builtin_amdgcn_readlane(hi, l);
+    return __hiloint2double(hi, lo);
+}
+
+// One workgroup of 8 waves factorises S = L L' (right-looking, 16-wide panels). The lower 16 x 16 tiles live in registers for the
+// whole factorisation, TRANSPOSED in the MFMA accumulator layout (lane l, register r holds T[l & 15][(l >> 4) + 4 r]), distributed
+// cyclically over the waves; a panel's tiles pass through LDS ([tile][k][row]) where (b) one wave factorises the diagonal tile,
+// (c) the rows below it are solved by substitution (one row per lane), and (d) every wave applies the rank-16 update to the
+// tiles it owns with 4 MFMAs per tile, operands straight from that LDS panel. L (lower, column-major), the inverses of the
+// diagonal tiles (Dinv[b][k][row], what dk_trsm multiplies with) and log det S go to global memory.
+constexpr int kCholMaxTiles = 16;   // n <= 256
+constexpr int kCholSlots = 17;      // 136 lower tiles over 8 waves
+
+__global__ __launch_bounds__(512) void dk_chol(const double* __restrict__ S, int n, double* __restrict__ L, double* __restrict__ Dinv,
+                                                double* __restrict__ scal) {
+    __shared__ double tbuf[2][kCholMaxTiles * 256];
+    __shared__ double dg[kCholMaxTiles * 16];
+    __shared__ double rinv[16];
+    __shared__ int bad;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nt = n / 16, ntot = nt * (nt + 1) / 2;
+    if (tid == 0) bad = 0;
+    // owned tiles: linear index q = i (i + 1) / 2 + j, q = w, w + 8, ...
+    int ti[kCholSlots], tj[kCholSlots];
+    d4 tile[kCholSlots];
+    {
+        int i = 0, base = 0;   // base = i (i + 1) / 2
+#pragma unroll
+        for (int s = 0; s < kCholSlots; ++s) {
+            const int q = w + 8 * s;
+            while (base + i + 1 <= q) {
+                base += i + 1;
+                ++i;
+            }
+            ti[s] = q < ntot ? i : -1;
+            tj[s] = q - base;
+            if (q < ntot) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    tile[s][r] = S[(ti[s] * 16 + (lane & 15)) + (int64_t)(tj[s] * 16 + (lane >> 4) + 4 * r) * n];
+            } else {
+                tile[s] = d4{0.0, 0.0, 0.0, 0.0};
+            }
+        }
+    }
+    for (int kb = 0; kb < nt; ++kb) {
+        double* buf = tbuf[kb & 1];
+        // (a) publish the panel's tiles
+#pragma unroll
+        for (int s = 0; s < kCholSlots; ++s)
+            if (ti[s] >= kb && tj[s] == kb) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) buf[ti[s] * 256 + r * 64 + lane] = tile[s][r];
+            }
+        __syncthreads();
+        // (b) diagonal tile: lanes 0..15 of wave 0 hold one row each
+        if (w == 0) {
+            double t[16];
+            const int row = lane & 15;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) t[k] = buf[kb * 256 + k * 16 + row];
+            int notpd = 0;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const double piv = rdlane(t[c], c);
+                notpd |= !(piv > 0.0);
+                const double rs = rsqrt(piv);
+                const double l = t[c] * rs;
+                t[c] = l;
+                if (lane == 0) {
+                    dg[kb * 16 + c] = piv;
+                    rinv[c] = rs;
+                }
+#pragma unroll
+                for (int j = c + 1; j < 16; ++j) t[j] -= l * rdlane(l, j);
+            }
+            if (lane < 16) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const double v = k <= row ? t[k] : 0.0;
+                    buf[kb * 256 + k * 16 + row] = v;
+                    L[(kb * 16 + row) + (int64_t)(kb * 16 + k) * n] = v;
+                }
+            }
+            if (lane == 0 && notpd) bad = 1;
+        }
+        __syncthreads();
+        // (c) rows below the diagonal tile: x L_kk' = t, one row per lane; wave 7 inverts L_kk meanwhile (lane = column)
+        {
+            const int rows = (nt - kb - 1) * 16;
+            if (tid < rows) {
+                const int i = kb + 1 + tid / 16, row = tid & 15;
+                double x[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) x[k] = buf[i * 256 + k * 16 + row];
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    double s = x[c];
+#pragma unroll
+                    for (int k = 0; k < c; ++k) s -= x[k] * buf[kb * 256 + k * 16 + c];
+                    x[c] = s * rinv[c];
+                }
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    buf[i * 256 + c * 16 + row] = x[c];
+                    L[(i * 16 + row) + (int64_t)(kb * 16 + c) * n] = x[c];
+                }
+            } else if (w == 7 && lane < 16) {
+                double wv[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    double s = i == lane ? 1.0 : 0.0;
+#pragma unroll
+                    for (int k = 0; k < i; ++k) s -= buf[kb * 256 + k * 16 + i] * wv[k];
+                    wv[i] = s * rinv[i];
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) Dinv[kb * 256 + lane * 16 + i] = wv[i];   // Dinv[row i][k = lane] at [k][row]
+            }
+        }
+        __syncthreads();
+        // (d) trailing update of the owned tiles: T_ij' -= L_jk L_ik'
+#pragma unroll
+        for (int s = 0; s < kCholSlots; ++s)
+            if (ti[s] >= 0 && tj[s] > kb) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int off = (ks * 4 + (lane >> 4)) * 16 + (lane & 15);
+                    const double a = -buf[tj[s] * 256 + off];
+                    const double b = buf[ti[s] * 256 + off];
+                    tile[s] = mfma_f64(a, b, tile[s]);
+                }
+            }
+    }
+    __syncthreads();
+    // log det S = sum log(pivot)
+    double* redl = tbuf[0];
+    redl[tid] = tid < n ? log(dg[tid]) : 0.0;
+    __syncthreads();
+    for (int st = 256; st > 0; st >>= 1) {
+        if (tid < st) redl[tid] += redl[tid + st];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        scal[0] = redl[0];
+        scal[2] = bad ? 1.0 : 0.0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ B = L^-1 V (16 columns per workgroup)
+// Right-looking block substitution with the D -> B-operand identity of the f64 MFMA layout: the accumulator of block row b
+// (lane l, register r = row (l >> 4) + 4 r, column l & 15) IS the B operand of k-step r, so X_b = Dinv_b acc_b and the updates
+// acc_b' -= L_b'b X_b chain through registers; only X_b crosses waves (LDS, double-buffered: one barrier per block row).
+__global__ __launch_bounds__(256) void dk_trsm(const double* __restrict__ L, const double* __restrict__ Dinv, const double* __restrict__ V,
+                                               int n, double* __restrict__ Bm, int64_t ldB) {
+    __shared__ double xb[2][256];
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nb = n / 16, c0 = blockIdx.x * 16;
+    d4 acc[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int b = w + 4 * s;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            acc[s][r] = b < nb ? V[(b * 16 + (lane >> 4) + 4 * r) + (int64_t)(c0 + (lane & 15)) * n] : 0.0;
+    }
+    double dn[4];
+    auto load_dinv = [&](int b) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) dn[ks] = b < nb ? Dinv[b * 256 + (ks * 4 + (lane >> 4)) * 16 + (lane & 15)] : 0.0;
+    };
+    load_dinv(w);
+    for (int b = 0; b < nb; ++b) {
+        // L fragments of this block column for the owned rows below b (independent of X_b: in flight across the barrier)
+        double lf[4][4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int bb = w + 4 * s;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                lf[s][ks] = (bb > b && bb < nb) ? L[(bb * 16 + (lane & 15)) + (int64_t)(b * 16 + ks * 4 + (lane >> 4)) * n] : 0.0;
+        }
+        if ((b & 3) == w) {
+            const int s = b >> 2;
+            d4 x = d4{0.0, 0.0, 0.0, 0.0};
+            d4 cur = acc[0];
+#pragma unroll
+            for (int u = 1; u < 4; ++u)
+                if (u == s) cur = acc[u];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) x = mfma_f64(dn[ks], cur[ks], x);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                xb[b & 1][r * 64 + lane] = x[r];
+                Bm[(int64_t)(b * 16 + (lane >> 4) + 4 * r) * ldB + c0 + (lane & 15)] = x[r];
+            }
+            load_dinv(b + 4);
+        }
+        __syncthreads();
+        double xr[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) xr[ks] = -xb[b & 1][ks * 64 + lane];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int bb = w + 4 * s;
+            if (bb > b && bb < nb) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) acc[s] = mfma_f64(lf[s][ks], xr[ks], acc[s]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ prior marginals of one step
+// mean_i = (H mp + h)_i (rider of the V = H Pp launch writes -r = H mp + h - 0 ... see host code), var_i = sum_k V[i][k] H[i][k] + R_i
+__global__ void dk_marg_diag(const double* __restrict__ V, const double* __restrict__ Hk, int Pq, int Dp, const double* __restrict__ R,
+                             const double* __restrict__ res, int p, double* __restrict__ mean_out, double* __restrict__ var_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p) return;
+    double s = 0.0;
+    for (int k = 0; k < Dp; ++k) s += V[i + (int64_t)k * Pq] * Hk[i + (int64_t)k * Pq];
+    var_out[i] = s + R[i];
+    mean_out[i] = -res[i];   // res = 0 - h - H mp
+}
+
+__global__ void dk_pack(const double* __restrict__ src, int64_t rs, int64_t cs, int rows, int cols, double* __restrict__ dst, int64_t ldd,
+                        int prow, int pcol, double padval_diag) {
+    // dst[i + j ldd] = (i < rows && j < cols) ? src[i rs + j cs] : (i == j ? padval_diag : 0), for i < prow, j < pcol
+    const int64_t n = (int64_t)prow * pcol;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        const int i = (int)(e % prow), j = (int)(e / prow);
+        dst[i + (int64_t)j * ldd] = (i < rows && j < cols) ? src[(int64_t)i * rs + (int64_t)j * cs] : ((i == j) ? padval_diag : 0.0);
+    }
+}
+
+// ================================================================================================ host side
+struct Buf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e == hipSuccess) cap = bytes;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    double* d() const { return static_cast<double*>(p); }
+};
+
+struct Prof {
+    std::string name;
+    double ms = 0.0;
+    int64_t calls = 0;
+};
+
+struct Engine {
+    int device = 0;
+    std::string err;
+    bool have_model = false;
+    int64_t T = 0;
+    int d = 0, p = 0, ordering = 0, Dp = 0, Pq = 0;
+    int64_t ldB = 0;
+    // packed model (padded); per-step arrays keep a stride
+    Buf bA, bQ, bH, ba, bh, bR, bx0;
+    int64_t sA = 0, sQ = 0, sH = 0, sa = 0, sh = 0, sR = 0;
+    // state and work buffers
+    Buf bm, bmp, bP, bPp, bT1, bV, bS, bL, bDinv, bB, bscal;
+    int profile = 0;
+    std::vector<Prof> prof;
+    struct Pending {
+        int idx;
+        hipEvent_t a, b;
+    };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> pool;
+    bool attrs_set = false;
+    int fail(int code, const std::string& m) {
+        err = m;
+        return code;
+    }
+};
+
+#define DCHK(expr)                                                                                   \
+    do {                                                                                             \
+        hipError_t e_ = (expr);                                                                      \
+        if (e_ != hipSuccess) return e->fail(TGP_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+Engine* create(int device) {
+    Engine* e = new Engine();
+    e->device = device;
+    return e;
+}
+void destroy(Engine* e) {
+    if (!e) return;
+    for (Buf* b : {&e->bA, &e->bQ, &e->bH, &e->ba, &e->bh, &e->bR, &e->bx0, &e->bm, &e->bmp, &e->bP, &e->bPp, &e->bT1, &e->bV, &e->bS,
+                   &e->bL, &e->bDinv, &e->bB, &e->bscal})
+        b->release();
+    for (auto& pe : e->pending) {
+        (void)hipEventDestroy(pe.a);
+        (void)hipEventDestroy(pe.b);
+    }
+    for (auto ev : e->pool) (void)hipEventDestroy(ev);
+    delete e;
+}
+const std::string& last_error(const Engine* e) { return e->err; }
+void set_profile(Engine* e, int on) { e->profile = on; }
+static void resolve_pending(Engine* e);
+int profile_count(Engine* e) {
+    resolve_pending(e);   // callers query after the call's closing stream synchronisation
+    return (int)e->prof.size();
+}
+KernelTime profile_get(const Engine* e, int idx) { return KernelTime{e->prof[idx].name.c_str(), e->prof[idx].ms, e->prof[idx].calls}; }
+void profile_reset(Engine* e) {
+    resolve_pending(e);
+    e->prof.clear();
+}
+
+namespace {
+
+struct Scope {   // hipEvent bracket of one launch (profile mode only)
+    Engine* e;
+    hipStream_t st;
+    int idx = -1;
+    hipEvent_t a = nullptr, b = nullptr;
+    Scope(Engine* e_, hipStream_t st_, const char* name, bool on) : e(e_), st(st_) {
+        if (!on) return;
+        for (size_t i = 0; i < e->prof.size(); ++i)
+            if (e->prof[i].name == name) idx = (int)i;
+        if (idx < 0) {
+            e->prof.push_back(Prof{name, 0.0, 0});
+            idx = (int)e->prof.size() - 1;
+        }
+        auto get = [&]() {
+            hipEvent_t ev = nullptr;
+            if (!e->pool.empty()) {
+                ev = e->pool.back();
+                e->pool.pop_back();
+            } else {
+                (void)hipEventCreate(&ev);
+            }
+            return ev;
+        };
+        a = get();
+        b = get();
+        (void)hipEventRecord(a, st);
+    }
+    ~Scope() {
+        if (idx < 0) return;
+        (void)hipEventRecord(b, st);
+        e->pending.push_back(Engine::Pending{idx, a, b});
+    }
+};
+
+}  // namespace
+static void resolve_pending(Engine* e) {
+    for (auto& pe : e->pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, pe.a, pe.b) == hipSuccess) {
+            e->prof[pe.idx].ms += ms;
+            e->prof[pe.idx].calls += 1;
+        }
+        e->pool.push_back(pe.a);
+        e->pool.push_back(pe.b);
+    }
+    e->pending.clear();
+}
+namespace {
+void resolve(Engine* e) { resolve_pending(e); }
+
+template <int TM, int TN> void launch_gemm_t(GemmArgs& g, hipStream_t st) {
+    using Cfg = GemmCfg<TM, TN>;
+    const int ntm = (g.M + Cfg::BM - 1) / Cfg::BM, ntn = (g.N + Cfg::BN - 1) / Cfg::BN;
+    const int per = (ntm * ntn + 7) / 8;
+    g.nblk_tiles = per * 8;
+    const int nrider = g.v.mode ? (g.v.n + 63) / 64 : 0;
+    hipLaunchKernelGGL((dk_gemm<TM, TN>), dim3(g.nblk_tiles + nrider), dim3(512), Cfg::LDS_BYTES, st, g);
+}
+
+// tile shape by problem size: 48 x 48 blocks once they fill the 256 CUs, 16 x 48 for the p x d products, else single tiles
+void launch_gemm(GemmArgs& g, hipStream_t st) {
+    const int t33 = ((g.M + 47) / 48) * ((g.N + 47) / 48);
+    const int t13 = ((g.M + 15) / 16) * ((g.N + 47) / 48);
+    if (t33 >= 160) launch_gemm_t<3, 3>(g, st);
+    else if (t13 >= 160) launch_gemm_t<1, 3>(g, st);
+    else launch_gemm_t<1, 1>(g, st);
+}
+
+int set_attrs(Engine* e) {
+    if (e->attrs_set) return TGP_OK;
+    DCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dk_gemm<3, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<3, 3>::LDS_BYTES));
+    DCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dk_gemm<1, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<1, 3>::LDS_BYTES));
+    DCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dk_gemm<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<1, 1>::LDS_BYTES));
+    e->attrs_set = true;
+    return TGP_OK;
+}
+
+inline int rup16(int x) { return (x + 15) / 16 * 16; }
+
+}  // namespace
+
+int model_set(Engine* e, const ModelDesc& m, hipStream_t st) {
+    e->have_model = false;
+    DCHK(hipSetDevice(e->device));
+    if (int rc = set_attrs(e)) return rc;
+    if (m.p > kCholMaxTiles * 16) return e->fail(TGP_EUNSUPPORTED, "dense path: observation dimension p must be <= 256");
+    if (m.p > m.d + 16 * 64) return e->fail(TGP_EUNSUPPORTED, "dense path: p too large");
+    e->T = m.T;
+    e->d = m.d;
+    e->p = m.p;
+    e->ordering = m.ordering;
+    const int Dp = rup16(m.d), Pq = rup16(m.p);
+    e->Dp = Dp;
+    e->Pq = Pq;
+    e->ldB = Dp + 16;
+    auto steps = [&](int64_t s) { return s ? m.T : (int64_t)1; };
+    const size_t DD = (size_t)Dp * Dp, PD = (size_t)Pq * Dp;
+    DCHK(e->bA.ensure(steps(m.sA) * DD * 8));
+    DCHK(e->bQ.ensure(steps(m.sQ) * DD * 8));
+    DCHK(e->bH.ensure(steps(m.sH) * PD * 8));
+    DCHK(e->ba.ensure(steps(m.sa) * (size_t)Dp * 8));
+    DCHK(e->bh.ensure(steps(m.sh) * (size_t)Pq * 8));
+    DCHK(e->bR.ensure(steps(m.sR) * (size_t)Pq * 8));
+    e->sA = m.sA ? (int64_t)DD : 0;
+    e->sQ = m.sQ ? (int64_t)DD : 0;
+    e->sH = m.sH ? (int64_t)PD : 0;
+    e->sa = m.sa ? Dp : 0;
+    e->sh = m.sh ? Pq : 0;
+    e->sR = m.sR ? Pq : 0;
+    auto pack = [&](const double* src, int64_t sstride, int64_t nsteps, int64_t rs, int64_t cs, int rows, int cols, double* dst, int64_t dstride,
+                    int prow, int pcol, double padv) {
+        for (int64_t t = 0; t < nsteps; ++t)
+            hipLaunchKernelGGL(dk_pack, dim3(64), dim3(256), 0, st, src + t * sstride, rs, cs, rows, cols, dst + t * dstride, (int64_t)prow, prow, pcol, padv);
+    };
+    // A, Q: column-major d x d -> column-major Dp x Dp
+    pack(m.A, m.sA, steps(m.sA), 1, m.d, m.d, m.d, e->bA.d(), DD, Dp, Dp, 0.0);
+    pack(m.Q, m.sQ, steps(m.sQ), 1, m.d, m.d, m.d, e->bQ.d(), DD, Dp, Dp, 0.0);
+    // H [p][d] row-major (H[i][k] at i d + k) -> Hk[k Pq + i]: "rows" = i (stride d), "cols" = k (stride 1)
+    pack(m.H, m.sH, steps(m.sH), m.d, 1, m.p, m.d, e->bH.d(), PD, Pq, Dp, 0.0);
+    pack(m.a, m.sa, steps(m.sa), 1, 0, m.d, 1, e->ba.d(), Dp, Dp, 1, 0.0);
+    pack(m.h, m.sh, steps(m.sh), 1, 0, m.p, 1, e->bh.d(), Pq, Pq, 1, 0.0);
+    // R: pad with ones (column vector: the "diagonal" pad rule of dk_pack only hits i == j == 0, so pad explicitly below)
+    {
+        std::vector<double> ones((size_t)Pq, 1.0);
+        for (int64_t t = 0; t < steps(m.sR); ++t) {
+            DCHK(hipMemcpyAsync(e->bR.d() + t * Pq, ones.data(), (size_t)Pq * 8, hipMemcpyHostToDevice, st));
+            DCHK(hipMemcpyAsync(e->bR.d() + t * Pq, m.R + t * m.sR, (size_t)m.p * 8, hipMemcpyDeviceToDevice, st));
+        }
+        DCHK(hipStreamSynchronize(st));
+    }
+    DCHK(e->bx0.ensure((DD + Dp) * 8));
+    DCHK(e->bm.ensure((size_t)Dp * 8));
+    DCHK(e->bmp.ensure((size_t)Dp * 8));
+    DCHK(e->bP.ensure(DD * 8));
+    DCHK(e->bPp.ensure(DD * 8));
+    DCHK(e->bT1.ensure(DD * 8));
+    DCHK(e->bV.ensure((size_t)Pq * (Dp + 16) * 8));
+    DCHK(e->bS.ensure((size_t)Pq * Pq * 8));
+    DCHK(e->bL.ensure((size_t)Pq * Pq * 8));
+    DCHK(e->bDinv.ensure((size_t)(Pq / 16) * 256 * 8));
+    DCHK(e->bB.ensure((size_t)Pq * e->ldB * 8));
+    DCHK(e->bscal.ensure(8 * 8));
+    DCHK(hipMemsetAsync(e->bV.p, 0, (size_t)Pq * (Dp + 16) * 8, st));
+    DCHK(hipMemsetAsync(e->bL.p, 0, (size_t)Pq * Pq * 8, st));
+    DCHK(hipMemsetAsync(e->bscal.p, 0, 64, st));
+    if (int rc = set_x0(e, m.x0m, m.x0P, st)) return rc;
+    e->have_model = true;
+    return TGP_OK;
+}
+
+int set_x0(Engine* e, const double* x0m, const double* x0P, hipStream_t st) {
+    const int Dp = e->Dp, d = e->d;
+    std::vector<double> buf((size_t)Dp * Dp + Dp, 0.0);
+    for (int j = 0; j < d; ++j)
+        for (int i = 0; i < d; ++i) buf[i + (size_t)j * Dp] = x0P[i + (size_t)j * d];
+    for (int i = 0; i < d; ++i) buf[(size_t)Dp * Dp + i] = x0m[i];
+    DCHK(hipMemcpyAsync(e->bx0.p, buf.data(), buf.size() * 8, hipMemcpyHostToDevice, st));
+    DCHK(hipStreamSynchronize(st));
+    return TGP_OK;
+}
+
+namespace {
+
+struct StepPtrs {
+    const double *A, *Q, *H, *a, *h, *R;
+};
+StepPtrs step_ptrs(const Engine* e, int64_t t) {
+    return StepPtrs{e->bA.d() + t * e->sA, e->bQ.d() + t * e->sQ, e->bH.d() + t * e->sH, e->ba.d() + t * e->sa, e->bh.d() + t * e->sh,
+                    e->bR.d() + t * e->sR};
+}
+
+// predict (lgc.jl:46-52): mp = A m + a, Pp = A P A' + Q
+void enqueue_predict(Engine* e, const StepPtrs& s, hipStream_t st, bool prof) {
+    const int Dp = e->Dp;
+    {
+        GemmArgs g;
+        g.A = s.A; g.lda = Dp;
+        g.B = e->bP.d(); g.ldb = Dp;
+        g.C = e->bT1.d(); g.ldc = Dp;
+        g.M = g.N = g.K = Dp;
+        g.v.mode = 1;
+        g.v.Mx = s.A; g.v.ld = Dp; g.v.n = Dp; g.v.K = Dp;
+        g.v.x = e->bm.d(); g.v.xs = 1; g.v.add = s.a; g.v.out = e->bmp.d();
+        Scope sc(e, st, "dk_gemm<A P>", prof);
+        launch_gemm(g, st);
+    }
+    {
+        GemmArgs g;
+        g.A = e->bT1.d(); g.lda = Dp;
+        g.B = s.A; g.ldb = Dp;           // Bop[k][j] = A[j][k] = Ak[j + k Dp]
+        g.C = e->bPp.d(); g.ldc = Dp;
+        g.E = s.Q; g.lde = Dp;
+        g.M = g.N = g.K = Dp;
+        Scope sc(e, st, "dk_gemm<(A P) A' + Q>", prof);
+        launch_gemm(g, st);
+    }
+}
+
+// posterior_and_lml (lgc.jl:129-151) on (mp, Pp) -> (m, P); lml_t accumulated into result8
+void enqueue_update(Engine* e, const StepPtrs& s, int64_t t, const double* y, const uint8_t* mask, double* m_out, double* P_out, double* result8,
+                    hipStream_t st, bool prof) {
+    const int Dp = e->Dp, Pq = e->Pq;
+    const double* yt = y + t * e->p;
+    const uint8_t* mt = mask ? mask + t * e->p : nullptr;
+    {   // V = H Pp; rider: r = y - h - H mp -> V[:, Dp]
+        GemmArgs g;
+        g.A = s.H; g.lda = Pq;
+        g.B = e->bPp.d(); g.ldb = Dp;
+        g.C = e->bV.d(); g.ldc = Pq;
+        g.M = Pq; g.N = Dp; g.K = Dp;
+        g.v.mode = 2;
+        g.v.Mx = s.H; g.v.ld = Pq; g.v.n = Pq; g.v.K = Dp;
+        g.v.x = e->bmp.d(); g.v.xs = 1;
+        g.v.out = e->bV.d() + (size_t)Dp * Pq;
+        g.v.y = yt; g.v.mask = mt; g.v.hh = s.h; g.v.p = e->p;
+        g.v.scal = e->bscal.d();
+        Scope sc(e, st, "dk_gemm<H Pp>", prof);
+        launch_gemm(g, st);
+    }
+    {   // S = V H' + R
+        GemmArgs g;
+        g.A = e->bV.d(); g.lda = Pq;
+        g.B = s.H; g.ldb = Pq;
+        g.C = e->bS.d(); g.ldc = Pq;
+        g.diag = s.R; g.dmask = mt; g.ndiag = e->p;
+        g.M = g.N = Pq; g.K = Dp;
+        Scope sc(e, st, "dk_gemm<V H' + R>", prof);
+        launch_gemm(g, st);
+    }
+    {
+        Scope sc(e, st, "dk_chol", prof);
+        hipLaunchKernelGGL(dk_chol, dim3(1), dim3(512), 0, st, e->bS.d(), Pq, e->bL.d(), e->bDinv.d(), e->bscal.d());
+    }
+    {
+        Scope sc(e, st, "dk_trsm", prof);
+        hipLaunchKernelGGL(dk_trsm, dim3((Dp + 16) / 16), dim3(256), 0, st, e->bL.d(), e->bDinv.d(), e->bV.d(), Pq, e->bB.d(), e->ldB);
+    }
+    {   // P = Pp - B'B; rider: m = mp + B' alpha, lml_t
+        GemmArgs g;
+        g.A = e->bB.d(); g.lda = e->ldB;
+        g.B = e->bB.d(); g.ldb = e->ldB;
+        g.C = e->bP.d(); g.ldc = Dp;
+        g.E = e->bPp.d(); g.lde = Dp;
+        g.sign = -1.0;
+        g.M = g.N = Dp; g.K = Pq;
+        if (P_out) {
+            g.C2 = P_out + t * (int64_t)e->d * e->d; g.ldc2 = e->d; g.M2 = g.N2 = e->d;
+        }
+        g.v.mode = 3;
+        g.v.Mx = e->bB.d(); g.v.ld = e->ldB; g.v.n = Dp; g.v.K = Pq;
+        g.v.x = e->bB.d() + Dp; g.v.xs = e->ldB;
+        g.v.add = e->bmp.d(); g.v.out = e->bm.d();
+        if (m_out) {
+            g.v.out2 = m_out + t * e->d; g.v.n2 = e->d;
+        }
+        g.v.p = e->p; g.v.scal = e->bscal.d(); g.v.stats = result8; g.v.tstep = t;
+        Scope sc(e, st, "dk_gemm<Pp - B'B>", prof);
+        launch_gemm(g, st);
+    }
+}
+
+}  // namespace
+
+int filter(Engine* e, const double* y, const uint8_t* mask, double* m_out, double* P_out, double* result8, hipStream_t st) {
+    if (!e->have_model) return e->fail(TGP_EINVAL, "no model");
+    DCHK(hipSetDevice(e->device));
+    const int Dp = e->Dp;
+    const size_t DD = (size_t)Dp * Dp;
+    DCHK(hipMemcpyAsync(e->bP.p, e->bx0.p, DD * 8, hipMemcpyDeviceToDevice, st));
+    DCHK(hipMemcpyAsync(e->bm.p, e->bx0.d() + DD, (size_t)Dp * 8, hipMemcpyDeviceToDevice, st));
+    for (int64_t step = 0; step < e->T; ++step) {
+        const int64_t t = e->ordering == 0 ? step : e->T - 1 - step;
+        const StepPtrs s = step_ptrs(e, t);
+        // profile mode: events on every 16th step (an event pair per launch slows the host enqueue)
+        const bool prof = e->profile && (step % 16 == 8 || e->T < 64);
+        if (e->ordering == 0) {
+            enqueue_predict(e, s, st, prof);
+            enqueue_update(e, s, t, y, mask, m_out, P_out, result8, st, prof);
+        } else {
+            // Reverse (lgssm.jl:161-165,183-187): update from the carried state, then predict with the same step's transition.
+            // The carried state lives in (m, P); the update reads (mp, Pp): swap roles by copying (d^2 doubles, L2-resident).
+            DCHK(hipMemcpyAsync(e->bPp.p, e->bP.p, DD * 8, hipMemcpyDeviceToDevice, st));
+            DCHK(hipMemcpyAsync(e->bmp.p, e->bm.p, (size_t)Dp * 8, hipMemcpyDeviceToDevice, st));
+            enqueue_update(e, s, t, y, mask, m_out, P_out, result8, st, prof);
+            enqueue_predict(e, s, st, prof);
+            DCHK(hipMemcpyAsync(e->bP.p, e->bPp.p, DD * 8, hipMemcpyDeviceToDevice, st));
+            DCHK(hipMemcpyAsync(e->bm.p, e->bmp.p, (size_t)Dp * 8, hipMemcpyDeviceToDevice, st));
+        }
+        if ((step & 1023) == 1023) {
+            DCHK(hipStreamSynchronize(st));   // bound the host's run-ahead (and the event pool in profile mode)
+            resolve(e);
+        }
+    }
+    DCHK(hipGetLastError());
+    return TGP_OK;
+}
+
+int marginals(Engine* e, double* mean_out, double* var_out, double* result8, hipStream_t st) {
+    if (!e->have_model) return e->fail(TGP_EINVAL, "no model");
+    DCHK(hipSetDevice(e->device));
+    const int Dp = e->Dp, Pq = e->Pq;
+    const size_t DD = (size_t)Dp * Dp;
+    (void)result8;
+    DCHK(hipMemcpyAsync(e->bP.p, e->bx0.p, DD * 8, hipMemcpyDeviceToDevice, st));
+    DCHK(hipMemcpyAsync(e->bm.p, e->bx0.d() + DD, (size_t)Dp * 8, hipMemcpyDeviceToDevice, st));
+    Buf zero;
+    DCHK(zero.ensure((size_t)e->p * 8));
+    DCHK(hipMemsetAsync(zero.p, 0, (size_t)e->p * 8, st));
+    for (int64_t step = 0; step < e->T; ++step) {
+        const int64_t t = e->ordering == 0 ? step : e->T - 1 - step;
+        const StepPtrs s = step_ptrs(e, t);
+        auto emit = [&](const double* mx, const double* Px) {
+            GemmArgs g;
+            g.A = s.H; g.lda = Pq;
+            g.B = Px; g.ldb = Dp;
+            g.C = e->bV.d(); g.ldc = Pq;
+            g.M = Pq; g.N = Dp; g.K = Dp;
+            g.v.mode = 2;
+            g.v.Mx = s.H; g.v.ld = Pq; g.v.n = Pq; g.v.K = Dp;
+            g.v.x = mx; g.v.xs = 1;
+            g.v.out = e->bV.d() + (size_t)Dp * Pq;
+            g.v.y = zero.d(); g.v.mask = nullptr; g.v.hh = s.h; g.v.p = e->p;
+            g.v.scal = e->bscal.d();
+            launch_gemm(g, st);
+            hipLaunchKernelGGL(dk_marg_diag, dim3((e->p + 255) / 256), dim3(256), 0, st, e->bV.d(), s.H, Pq, Dp, s.R,
+                               e->bV.d() + (size_t)Dp * Pq, e->p, mean_out + t * e->p, var_out + t * e->p);
+        };
+        if (e->ordering == 0) {
+            enqueue_predict(e, s, st, false);
+            emit(e->bmp.d(), e->bPp.d());
+        } else {
+            emit(e->bm.d(), e->bP.d());
+            enqueue_predict(e, s, st, false);
+        }
+        DCHK(hipMemcpyAsync(e->bP.p, e->bPp.p, DD * 8, hipMemcpyDeviceToDevice, st));
+        DCHK(hipMemcpyAsync(e->bm.p, e->bmp.p, (size_t)Dp * 8, hipMemcpyDeviceToDevice, st));
+        if ((step & 1023) == 1023) DCHK(hipStreamSynchronize(st));
+    }
+    DCHK(hipStreamSynchronize(st));
+    zero.release();
+    return TGP_OK;
+}
+
+int posterior_marginals(Engine* e, const double*, const uint8_t*, const double*, int64_t, double*, double*, double*, hipStream_t) {
+    return e->fail(TGP_EUNSUPPORTED, "dense path: posterior marginals not built yet");
+}
+
+}  // namespace tgp_dense
