@@ -25,6 +25,7 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 
 constexpr double kLargeVar = 1e15;                 // missings.jl:43
 constexpr double kLog2Pi = 1.8378770664093454836;  // log(2 pi)
+constexpr size_t kOperandSlack = 64;                // doubles of slack behind every GEMM operand buffer (see dk_gemm)
 
 // ------------------------------------------------------------------------------------------------ riders
 // Small matrix-vector products that ride along a GEMM launch as extra workgroups (one kernel boundary less per product).
@@ -48,20 +49,36 @@ struct GemvArgs {
     int64_t tstep = 0;
 };
 
+// workgroup barrier that only waits for this wave's LDS traffic (a plain __syncthreads() also drains every outstanding global
+// load / store, which would serialise the prefetches that are deliberately kept in flight across it)
+__device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// 16 rows per workgroup: thread = (row = tid & 15, K slice = tid >> 4 of 32), four independent accumulators per thread so that
+// the loads of a slice are in flight together; the 32 partial sums of a row are added in a fixed order.
 __device__ inline void gemv_rider(const GemvArgs& v, int rb, double* lds) {
-    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = rb * 64 + lane;
-    const int kc = (v.K + 7) / 8;
-    const int k0 = w * kc, k1 = min(v.K, k0 + kc);
-    double s = 0.0;
-    if (r < v.n)
-        for (int k = k0; k < k1; ++k) s += v.Mx[r + (int64_t)k * v.ld] * v.x[(int64_t)k * v.xs];
-    lds[w * 64 + lane] = s;
+    const int tid = threadIdx.x;
+    const int row = tid & 15, ks = tid >> 4;
+    const int r = rb * 16 + row;
+    const int kc = (v.K + 31) / 32;
+    const int k0 = ks * kc, k1 = min(v.K, k0 + kc);
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if (r < v.n) {
+        const double* mp = v.Mx + r;
+        int k = k0;
+        for (; k + 4 <= k1; k += 4) {
+            s0 += mp[(int64_t)k * v.ld] * v.x[(int64_t)k * v.xs];
+            s1 += mp[(int64_t)(k + 1) * v.ld] * v.x[(int64_t)(k + 1) * v.xs];
+            s2 += mp[(int64_t)(k + 2) * v.ld] * v.x[(int64_t)(k + 2) * v.xs];
+            s3 += mp[(int64_t)(k + 3) * v.ld] * v.x[(int64_t)(k + 3) * v.xs];
+        }
+        for (; k < k1; ++k) s0 += mp[(int64_t)k * v.ld] * v.x[(int64_t)k * v.xs];
+    }
+    lds[ks * 16 + row] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (w == 0 && r < v.n) {
+    if (tid < 16 && r < v.n) {
         double tot = 0.0;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) tot += lds[u * 64 + lane];
+        for (int u = 0; u < 32; ++u) tot += lds[u * 16 + row];
         double o;
         if (v.mode == 2) {
             double yy = 0.0, hv = 0.0;
@@ -137,24 +154,24 @@ struct GemmArgs {
 __device__ inline d4 mfma_f64(double a, double b, d4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
 
 template <int TM, int TN> struct GemmCfg {
-    static constexpr int BK = 64, NT = 512;
+    static constexpr int NT = 512;
     static constexpr int BM = TM * 16, BN = TN * 16;
-    static constexpr int SA = (BM % 32 == 16) ? BM : BM + 16;   // LDS row strides (doubles): consecutive k rows 32 banks apart
-    static constexpr int SB = (BN % 32 == 16) ? BN : BN + 16;
-    static constexpr int STAGE = BK * (SA + SB);
     static constexpr int NTILE = TM * TN;
+    static constexpr int PF = 24 / (TM + TN) < 2 ? 2 : 24 / (TM + TN);   // k-steps per register buffer (two buffers)
     static constexpr int RED = 4 * NTILE * 256;
-    static constexpr int LDS_DOUBLES = (2 * STAGE > RED ? 2 * STAGE : RED) > 512 ? (2 * STAGE > RED ? 2 * STAGE : RED) : 512;
+    static constexpr int LDS_DOUBLES = RED > 512 ? RED : 512;
     static constexpr size_t LDS_BYTES = (size_t)LDS_DOUBLES * sizeof(double);
 };
 
-// One workgroup (8 waves) owns a (16 TM) x (16 TN) block of C. The K range is cut into slabs of 64 staged through LDS
-// (double-buffered, global loads of slab s+1 in flight while slab s is multiplied); inside a slab the 8 waves split K
-// (8 k-values each = two MFMA k-steps over all TM x TN tiles), so a wave carries TM*TN accumulators and no operand is read
-// twice from LDS. The 8 partial sums are then reduced through LDS in a fixed order (bit-reproducible).
+// One workgroup (8 waves) owns a (16 TM) x (16 TN) block of C and its 8 waves split K (a contiguous eighth each), so a wave
+// carries TM*TN accumulators and streams its own operand fragments STRAIGHT from global memory into MFMA operand registers:
+// with the k-major layouts a fragment is four 128-byte rows (lanes 0-15 = 16 consecutive values of the free index, lanes
+// 16-31 the next k, ...), no operand is used by two waves, so LDS staging would add a copy, a barrier per slab and nothing
+// else. Two register buffers of PF k-steps: the loads of group g+1 are in flight while group g is multiplied. The 8 partial
+// sums are then reduced through LDS in a fixed order (bit-reproducible).
 template <int TM, int TN> __global__ __launch_bounds__(512) void dk_gemm(const GemmArgs g) {
     using Cfg = GemmCfg<TM, TN>;
-    constexpr int BK = Cfg::BK, NT = Cfg::NT, BM = Cfg::BM, BN = Cfg::BN, SA = Cfg::SA, SB = Cfg::SB, STAGE = Cfg::STAGE, NTILE = Cfg::NTILE;
+    constexpr int BM = Cfg::BM, BN = Cfg::BN, NTILE = Cfg::NTILE, PF = Cfg::PF;
     extern __shared__ double lds[];
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     if ((int)blockIdx.x >= g.nblk_tiles) {
@@ -178,61 +195,52 @@ template <int TM, int TN> __global__ __launch_bounds__(512) void dk_gemm(const G
 #pragma unroll
         for (int b = 0; b < TN; ++b) acc[a][b] = d4{0.0, 0.0, 0.0, 0.0};
 
-    constexpr int CHA = BM / 2, CHB = BN / 2;
-    constexpr int NLA = (BK * CHA + NT - 1) / NT, NLB = (BK * CHB + NT - 1) / NT;
-    d2 ra[NLA], rb[NLB];
-    auto gload = [&](int k0) {
+    const int nks = g.K >> 2;                       // MFMA k-steps (K is a multiple of 16)
+    const int kper = (nks + 7) >> 3;
+    const int ks_begin = w * kper, ks_end = min(nks, ks_begin + kper);
+    const double* Ap = g.A + i0 + (lane & 15) + (int64_t)(lane >> 4) * g.lda;
+    const double* Bp = g.B + j0 + (lane & 15) + (int64_t)(lane >> 4) * g.ldb;
+    // No predicates on the loads (a predicated load becomes a branch with a full wait behind it): tiles of this block that lie
+    // beyond M / N read whatever follows -- every operand buffer carries kOperandSlack doubles of slack -- into accumulators
+    // that are never stored; the k range is cut into whole groups of PF k-steps plus single steps.
+    double fa0[PF][TM], fb0[PF][TN], fa1[PF][TM], fb1[PF][TN];
+    auto load = [&](double (&fa)[PF][TM], double (&fb)[PF][TN], int ks0) {
 #pragma unroll
-        for (int it = 0; it < NLA; ++it) {
-            const int c = tid + it * NT, k = c / CHA, ch = c - k * CHA;
-            const bool ok = c < BK * CHA && k0 + k < g.K && i0 + 2 * ch < g.M;
-            ra[it] = ok ? *reinterpret_cast<const d2*>(g.A + (int64_t)(k0 + k) * g.lda + i0 + 2 * ch) : d2{0.0, 0.0};
-        }
+        for (int u = 0; u < PF; ++u) {
 #pragma unroll
-        for (int it = 0; it < NLB; ++it) {
-            const int c = tid + it * NT, k = c / CHB, ch = c - k * CHB;
-            const bool ok = c < BK * CHB && k0 + k < g.K && j0 + 2 * ch < g.N;
-            rb[it] = ok ? *reinterpret_cast<const d2*>(g.B + (int64_t)(k0 + k) * g.ldb + j0 + 2 * ch) : d2{0.0, 0.0};
-        }
-    };
-    auto swrite = [&](int stage) {
-        double* As = lds + stage * STAGE;
-        double* Bs = As + BK * SA;
+            for (int a = 0; a < TM; ++a) fa[u][a] = Ap[(int64_t)(ks0 + u) * 4 * g.lda + a * 16];
 #pragma unroll
-        for (int it = 0; it < NLA; ++it) {
-            const int c = tid + it * NT, k = c / CHA, ch = c - k * CHA;
-            if (c < BK * CHA) *reinterpret_cast<d2*>(As + k * SA + 2 * ch) = ra[it];
-        }
-#pragma unroll
-        for (int it = 0; it < NLB; ++it) {
-            const int c = tid + it * NT, k = c / CHB, ch = c - k * CHB;
-            if (c < BK * CHB) *reinterpret_cast<d2*>(Bs + k * SB + 2 * ch) = rb[it];
+            for (int b = 0; b < TN; ++b) fb[u][b] = Bp[(int64_t)(ks0 + u) * 4 * g.ldb + b * 16];
         }
     };
-
-    const int nslab = (g.K + BK - 1) / BK;
-    gload(0);
-    swrite(0);
-    __syncthreads();
-    for (int s = 0; s < nslab; ++s) {
-        if (s + 1 < nslab) gload((s + 1) * BK);
-        const double* As = lds + (s & 1) * STAGE;
-        const double* Bs = As + BK * SA;
+    auto compute = [&](double (&fa)[PF][TM], double (&fb)[PF][TN]) {
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const int krow = w * 8 + kk * 4 + (lane >> 4);
-            double fa[TM], fb[TN];
-#pragma unroll
-            for (int a = 0; a < TM; ++a) fa[a] = As[krow * SA + a * 16 + (lane & 15)];
-#pragma unroll
-            for (int b = 0; b < TN; ++b) fb[b] = Bs[krow * SB + b * 16 + (lane & 15)];
+        for (int u = 0; u < PF; ++u)
 #pragma unroll
             for (int a = 0; a < TM; ++a)
 #pragma unroll
-                for (int b = 0; b < TN; ++b) acc[a][b] = mfma_f64(fb[b], fa[a], acc[a][b]);   // D'[j][i]: lanes run along i
+                for (int b = 0; b < TN; ++b) acc[a][b] = mfma_f64(fb[u][b], fa[u][a], acc[a][b]);   // D'[j][i]: lanes run along i
+    };
+    const int nst = max(0, ks_end - ks_begin), ngroups = nst / PF;
+    if (ngroups > 0) load(fa0, fb0, ks_begin);
+    for (int gi = 0; gi < ngroups; gi += 2) {
+        if (gi + 1 < ngroups) load(fa1, fb1, ks_begin + (gi + 1) * PF);
+        compute(fa0, fb0);
+        if (gi + 1 < ngroups) {
+            if (gi + 2 < ngroups) load(fa0, fb0, ks_begin + (gi + 2) * PF);
+            compute(fa1, fb1);
         }
-        if (s + 1 < nslab) swrite((s + 1) & 1);
-        __syncthreads();
+    }
+    for (int ks = ks_begin + ngroups * PF; ks < ks_end; ++ks) {
+        double ta[TM], tb[TN];
+#pragma unroll
+        for (int a = 0; a < TM; ++a) ta[a] = Ap[(int64_t)ks * 4 * g.lda + a * 16];
+#pragma unroll
+        for (int b = 0; b < TN; ++b) tb[b] = Bp[(int64_t)ks * 4 * g.ldb + b * 16];
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b) acc[a][b] = mfma_f64(tb[b], ta[a], acc[a][b]);
     }
     // ---- split-K reduction: waves 4..7 -> LDS, waves 0..3 add their partner and publish, then every wave finishes tiles
     double* red = lds;
@@ -244,7 +252,7 @@ template <int TM, int TN> __global__ __launch_bounds__(512) void dk_gemm(const G
 #pragma unroll
                 for (int r = 0; r < 4; ++r) red[(((w - 4) * NTILE + a * TN + b) * 4 + r) * 64 + lane] = acc[a][b][r];
     }
-    __syncthreads();
+    lds_barrier();
     if (w < 4) {
 #pragma unroll
         for (int a = 0; a < TM; ++a)
@@ -256,7 +264,7 @@ template <int TM, int TN> __global__ __launch_bounds__(512) void dk_gemm(const G
                     *q = acc[a][b][r] + *q;
                 }
     }
-    __syncthreads();
+    lds_barrier();
     for (int q = w; q < NTILE; q += 8) {
         const int a = q / TN, b = q - a * TN;
         const int i = i0 + a * 16 + (lane & 15);
@@ -284,142 +292,175 @@ __device__ inline double rdlane(double v, int l) {
     return __hiloint2double(hi, lo);
 }
 
-// One workgroup of 8 waves factorises S = L L' (right-looking, 16-wide panels). The lower 16 x 16 tiles live in registers for the
-// whole factorisation, TRANSPOSED in the MFMA accumulator layout (lane l, register r holds T[l & 15][(l >> 4) + 4 r]), distributed
-// cyclically over the waves; a panel's tiles pass through LDS ([tile][k][row]) where (b) one wave factorises the diagonal tile,
-// (c) the rows below it are solved by substitution (one row per lane), and (d) every wave applies the rank-16 update to the
-// tiles it owns with 4 MFMAs per tile, operands straight from that LDS panel. L (lower, column-major), the inverses of the
-// diagonal tiles (Dinv[b][k][row], what dk_trsm multiplies with) and log det S go to global memory.
+// One workgroup of 16 waves factorises S = L L' (right-looking, 16-wide panels). Waves 1..15 keep the lower 16 x 16 tiles in
+// registers for the whole factorisation, TRANSPOSED in the MFMA accumulator layout (lane l, register r holds
+// T[l & 15][(l >> 4) + 4 r]) -- in that layout a tile is directly the B operand of the MFMA that solves it against the panel's
+// diagonal block, the accumulator of its rank-16 updates, and (once solved) BOTH operands of the update of the diagonal tile
+// to its right. Wave 0 owns nothing: it is the CHAIN wave that factorises and inverts the 16 x 16 diagonal tile of panel kb
+// while the other waves apply panel kb-1 to everything right of it. Per panel:
+//   barrier 1 | wave 0: L_kk, W = L_kk^-1 from `dtile`           | waves 1-15: rank-16 update with panel kb-1 (columns >= kb)
+//   barrier 2 | owners of (i, kb): L_ik' = W T_ik' (4 MFMAs) -> panel buffer (LDS, [tile][k][row]) and global L; the owner of
+//             | (kb+1, kb) also owns (kb+1, kb+1) -- adjacent slots -- updates it straight from its registers and hands it
+//             | to wave 0 through `dtile`
+// The tile -> (wave, slot) table comes from the host (chol_slot_table). L (lower, column-major), the inverses of the diagonal
+// tiles (Dinv[b][k][row], what dk_trsm multiplies with) and log det S go to global memory.
 constexpr int kCholMaxTiles = 16;   // n <= 256
-constexpr int kCholSlots = 17;      // 136 lower tiles over 8 waves
+constexpr int kCholWorkers = 15;     // waves 1..15 own tiles, wave 0 is the chain wave
+constexpr int kCholSlots = 10;       // ceil(136 / 15)
 
-__global__ __launch_bounds__(512) void dk_chol(const double* __restrict__ S, int n, double* __restrict__ L, double* __restrict__ Dinv,
-                                                double* __restrict__ scal) {
-    __shared__ double tbuf[2][kCholMaxTiles * 256];
+__device__ inline double rsqrt_fast(double x) {
+    // v_rsq_f64 (~2^-26) + one third-order correction: relative error ~1e-16 (the reference takes sqrt and divides)
+    const double y = __builtin_amdgcn_rsq(x);
+    const double e = fma(-x * y, y, 1.0);
+    return fma(y * e, fma(0.375, e, 0.5), y);
+}
+
+#ifdef DK_TRACE
+#define DK_STAMP(slot) do { if (lane == 0 && w < 2) trace[((kb) * 4 + (slot)) * 2 + w] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define DK_STAMP(slot) do { } while (0)
+#endif
+__global__ __launch_bounds__(1024) void dk_chol(const double* __restrict__ S, int n, const int* __restrict__ slots, double* __restrict__ L,
+                                                double* __restrict__ Dinv, double* __restrict__ scal
+#ifdef DK_TRACE
+                                                , long long* __restrict__ trace
+#endif
+                                                ) {
+    __shared__ double pan[2][kCholMaxTiles * 256];
+    __shared__ double dtile[256];
+    __shared__ double winv[256];
     __shared__ double dg[kCholMaxTiles * 16];
-    __shared__ double rinv[16];
     __shared__ int bad;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nt = n / 16, ntot = nt * (nt + 1) / 2;
+    const int nt = n / 16;
     if (tid == 0) bad = 0;
-    // owned tiles: linear index q = i (i + 1) / 2 + j, q = w, w + 8, ...
-    int ti[kCholSlots], tj[kCholSlots];
+    int tt[kCholSlots];   // owned tile of slot s: (i << 4) | j, or -1
+#define TI(s) (tt[s] >> 4)
+#define TJ(s) (tt[s] < 0 ? -1 : (tt[s] & 15))
     d4 tile[kCholSlots];
-    {
-        int i = 0, base = 0;   // base = i (i + 1) / 2
 #pragma unroll
-        for (int s = 0; s < kCholSlots; ++s) {
-            const int q = w + 8 * s;
-            while (base + i + 1 <= q) {
-                base += i + 1;
-                ++i;
-            }
-            ti[s] = q < ntot ? i : -1;
-            tj[s] = q - base;
-            if (q < ntot) {
+    for (int s = 0; s < kCholSlots; ++s) {
+        tt[s] = w > 0 ? slots[(w - 1) * kCholSlots + s] : -1;
+        if (tt[s] >= 0) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    tile[s][r] = S[(ti[s] * 16 + (lane & 15)) + (int64_t)(tj[s] * 16 + (lane >> 4) + 4 * r) * n];
-            } else {
-                tile[s] = d4{0.0, 0.0, 0.0, 0.0};
+            for (int r = 0; r < 4; ++r) tile[s][r] = S[(TI(s) * 16 + (lane & 15)) + (int64_t)(TJ(s) * 16 + (lane >> 4) + 4 * r) * n];
+            if (tt[s] == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dtile[r * 64 + lane] = tile[s][r];
             }
+        } else {
+            tile[s] = d4{0.0, 0.0, 0.0, 0.0};
         }
     }
+    if (w == 0) __builtin_amdgcn_s_setprio(3);   // the chain wave is the critical path: it wins issue arbitration on its SIMD
     for (int kb = 0; kb < nt; ++kb) {
-        double* buf = tbuf[kb & 1];
-        // (a) publish the panel's tiles
-#pragma unroll
-        for (int s = 0; s < kCholSlots; ++s)
-            if (ti[s] >= kb && tj[s] == kb) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) buf[ti[s] * 256 + r * 64 + lane] = tile[s][r];
-            }
-        __syncthreads();
-        // (b) diagonal tile: lanes 0..15 of wave 0 hold one row each
+        int ln = lane;   // opaque per panel: keeps the per-tile LDS addresses from being hoisted out of the panel loop
+        asm volatile("" : "+v"(ln));
+        lds_barrier();   // 1
+        DK_STAMP(0);
         if (w == 0) {
-            double t[16];
-            const int row = lane & 15;
+            // chain wave. Lanes 0-15 hold one ROW of the tile each (z[k] = T[row][k]); lanes 16-31 hold one COLUMN of
+            // W = L_kk^-1 each (z[k] = W[k][col], starting from the identity): both obey the same recurrence
+            // z[c] *= 1/L[c][c]; z[j] -= z[c] L[j][c], so one instruction stream factorises and inverts (lanes 32-63 repeat).
+            const int idx = lane & 15;
+            const bool is_w = (lane & 16) != 0;
+            double zz[16];
+#define Z(k) zz[k]
 #pragma unroll
-            for (int k = 0; k < 16; ++k) t[k] = buf[kb * 256 + k * 16 + row];
+            for (int k = 0; k < 16; ++k) {
+                const double tv = dtile[k * 16 + idx];
+                Z(k) = is_w ? (k == idx ? 1.0 : 0.0) : tv;
+            }
             int notpd = 0;
+            double mypiv = 1.0;
 #pragma unroll
             for (int c = 0; c < 16; ++c) {
-                const double piv = rdlane(t[c], c);
+                const double piv = rdlane(Z(c), c);
                 notpd |= !(piv > 0.0);
-                const double rs = rsqrt(piv);
-                const double l = t[c] * rs;
-                t[c] = l;
-                if (lane == 0) {
-                    dg[kb * 16 + c] = piv;
-                    rinv[c] = rs;
-                }
+                const double rs = rsqrt_fast(piv);
+                const double l = Z(c) * rs;        // rows: L[row][c]; columns: the final W[c][col]
+                Z(c) = l;
+                mypiv = lane == c ? piv : mypiv;
 #pragma unroll
-                for (int j = c + 1; j < 16; ++j) t[j] -= l * rdlane(l, j);
+                for (int j = c + 1; j < 16; ++j) {
+                    double zj = Z(j) - l * rdlane(l, j);      // L[j][c] comes from lane j (a row lane)
+                    // evaluate NOW: left to itself the compiler sinks these updates to their use (a left-looking order) and keeps
+                    // all 120 broadcast scalars alive in between
+                    asm volatile("" : "+v"(zj));
+                    Z(j) = zj;
+                }
             }
+            if (lane < 16) dg[kb * 16 + lane] = mypiv;
             if (lane < 16) {
 #pragma unroll
+                for (int k = 0; k < 16; ++k) L[(kb * 16 + idx) + (int64_t)(kb * 16 + k) * n] = k <= idx ? Z(k) : 0.0;
+            } else if (lane < 32) {
+#pragma unroll
                 for (int k = 0; k < 16; ++k) {
-                    const double v = k <= row ? t[k] : 0.0;
-                    buf[kb * 256 + k * 16 + row] = v;
-                    L[(kb * 16 + row) + (int64_t)(kb * 16 + k) * n] = v;
+                    winv[idx * 16 + k] = Z(k);                      // W[k][col] at [k' = col][row' = k]
+                    Dinv[kb * 256 + idx * 16 + k] = Z(k);
                 }
             }
+#undef Z
             if (lane == 0 && notpd) bad = 1;
+            // the chain wave's tile registers carry nothing: redefining them here ends their live ranges at the top of this
+            // branch, which leaves the register file to the factorisation (without it the allocator spills ~150 registers)
+#pragma unroll
+            for (int s = 0; s < kCholSlots; ++s) tile[s] = d4{0.0, 0.0, 0.0, 0.0};
+        } else if (kb > 0) {
+            // rank-16 update with panel kb-1 of every owned tile right of it (the diagonal tile (kb, kb) already has it)
+            const double* pb = pan[(kb - 1) & 1];
+            const int dcode = (kb << 4) | kb;
+#pragma unroll
+            for (int s = 0; s < kCholSlots; ++s)
+                if (TJ(s) >= kb && tt[s] != dcode) {
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        const int off = (ks * 4 + (ln >> 4)) * 16 + (ln & 15);
+                        tile[s] = mfma_f64(-pb[TJ(s) * 256 + off], pb[TI(s) * 256 + off], tile[s]);
+                    }
+                }
         }
-        __syncthreads();
-        // (c) rows below the diagonal tile: x L_kk' = t, one row per lane; wave 7 inverts L_kk meanwhile (lane = column)
-        {
-            const int rows = (nt - kb - 1) * 16;
-            if (tid < rows) {
-                const int i = kb + 1 + tid / 16, row = tid & 15;
-                double x[16];
+        DK_STAMP(1);
+        lds_barrier();   // 2
+        DK_STAMP(2);
+        if (w > 0) {
+            double* pb = pan[kb & 1];
+            double wa[4];
 #pragma unroll
-                for (int k = 0; k < 16; ++k) x[k] = buf[i * 256 + k * 16 + row];
+            for (int ks = 0; ks < 4; ++ks) wa[ks] = winv[(ks * 4 + (ln >> 4)) * 16 + (ln & 15)];
 #pragma unroll
-                for (int c = 0; c < 16; ++c) {
-                    double s = x[c];
+            for (int s = 0; s < kCholSlots; ++s)
+                if (TJ(s) == kb && TI(s) > kb) {
+                    d4 x = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                    for (int k = 0; k < c; ++k) s -= x[k] * buf[kb * 256 + k * 16 + c];
-                    x[c] = s * rinv[c];
+                    for (int ks = 0; ks < 4; ++ks) x = mfma_f64(wa[ks], tile[s][ks], x);   // L_ik' = W T_ik'
+                    tile[s] = x;
+                    if (s + 1 < kCholSlots) {
+                        if (TI(s) == kb + 1) {   // slot s + 1 is the diagonal tile (kb+1, kb+1): T -= L L' from registers, hand it over
+                            d4 dt = tile[s + 1 < kCholSlots ? s + 1 : s];
+#pragma unroll
+                            for (int ks = 0; ks < 4; ++ks) dt = mfma_f64(-x[ks], x[ks], dt);
+                            tile[s + 1 < kCholSlots ? s + 1 : s] = dt;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) dtile[r * 64 + ln] = dt[r];
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        pb[TI(s) * 256 + r * 64 + ln] = x[r];
+                        L[(TI(s) * 16 + (ln & 15)) + (int64_t)(kb * 16 + (ln >> 4) + 4 * r) * n] = x[r];
+                    }
                 }
-#pragma unroll
-                for (int c = 0; c < 16; ++c) {
-                    buf[i * 256 + c * 16 + row] = x[c];
-                    L[(i * 16 + row) + (int64_t)(kb * 16 + c) * n] = x[c];
-                }
-            } else if (w == 7 && lane < 16) {
-                double wv[16];
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    double s = i == lane ? 1.0 : 0.0;
-#pragma unroll
-                    for (int k = 0; k < i; ++k) s -= buf[kb * 256 + k * 16 + i] * wv[k];
-                    wv[i] = s * rinv[i];
-                }
-#pragma unroll
-                for (int i = 0; i < 16; ++i) Dinv[kb * 256 + lane * 16 + i] = wv[i];   // Dinv[row i][k = lane] at [k][row]
-            }
         }
-        __syncthreads();
-        // (d) trailing update of the owned tiles: T_ij' -= L_jk L_ik'
-#pragma unroll
-        for (int s = 0; s < kCholSlots; ++s)
-            if (ti[s] >= 0 && tj[s] > kb) {
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    const int off = (ks * 4 + (lane >> 4)) * 16 + (lane & 15);
-                    const double a = -buf[tj[s] * 256 + off];
-                    const double b = buf[ti[s] * 256 + off];
-                    tile[s] = mfma_f64(a, b, tile[s]);
-                }
-            }
+        DK_STAMP(3);
     }
     __syncthreads();
     // log det S = sum log(pivot)
-    double* redl = tbuf[0];
+    double* redl = pan[0];
     redl[tid] = tid < n ? log(dg[tid]) : 0.0;
     __syncthreads();
-    for (int st = 256; st > 0; st >>= 1) {
+    for (int st = 512; st > 0; st >>= 1) {
         if (tid < st) redl[tid] += redl[tid + st];
         __syncthreads();
     }
@@ -427,6 +468,30 @@ __global__ __launch_bounds__(512) void dk_chol(const double* __restrict__ S, int
         scal[0] = redl[0];
         scal[2] = bad ? 1.0 : 0.0;
     }
+}
+#undef TI
+#undef TJ
+
+// tile -> (wave, slot) table of dk_chol for an nt x nt tile grid: slots[kCholWorkers][kCholSlots], entries (i << 4) | j or -1. The pair
+// {(i, i-1), (i, i)} goes to one wave in ADJACENT slots (see dk_chol); the other tiles go, in row order, to the wave that holds
+// the fewest so far.
+static void chol_slot_table(int nt, std::vector<int>& out) {
+    std::vector<std::vector<int>> per(kCholWorkers);
+    for (int i = 0; i < nt; ++i) {
+        auto& v = per[i % kCholWorkers];
+        if (i > 0) v.push_back((i << 4) | (i - 1));
+        v.push_back((i << 4) | i);
+    }
+    for (int i = 2; i < nt; ++i)
+        for (int j = 0; j + 1 < i; ++j) {
+            int best = 0;
+            for (int wv = 1; wv < kCholWorkers; ++wv)
+                if (per[wv].size() < per[best].size()) best = wv;
+            per[best].push_back((i << 4) | j);
+        }
+    out.assign(kCholWorkers * kCholSlots, -1);
+    for (int wv = 0; wv < kCholWorkers; ++wv)
+        for (size_t s = 0; s < per[wv].size() && s < (size_t)kCholSlots; ++s) out[wv * kCholSlots + s] = per[wv][s];
 }
 
 // ------------------------------------------------------------------------------------------------ B = L^-1 V (16 columns per workgroup)
@@ -447,28 +512,30 @@ __global__ __launch_bounds__(256) void dk_trsm(const double* __restrict__ L, con
             acc[s][r] = b < nb ? V[(b * 16 + (lane >> 4) + 4 * r) + (int64_t)(c0 + (lane & 15)) * n] : 0.0;
     }
     double dn[4];
-    auto load_dinv = [&](int b) {
+    auto load_dinv = [&](int b) __attribute__((always_inline)) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) dn[ks] = b < nb ? Dinv[b * 256 + (ks * 4 + (lane >> 4)) * 16 + (lane & 15)] : 0.0;
     };
     load_dinv(w);
-    for (int b = 0; b < nb; ++b) {
-        // L fragments of this block column for the owned rows below b (independent of X_b: in flight across the barrier)
-        double lf[4][4];
+    // L fragments of block column b for the owned rows below b: loaded one stage ahead (they do not depend on X_b)
+    d4 lfa[4], lfb[4];
+    auto load_lf = [&](d4 (&lf)[4], int b) __attribute__((always_inline)) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int bb = w + 4 * s;
+            const bool ok = bb > b && bb < nb && b < nb;
+            const int bbc = ok ? bb : 0, bc = ok ? b : 0;     // unpredicated loads (clamped address), value selected
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-                lf[s][ks] = (bb > b && bb < nb) ? L[(bb * 16 + (lane & 15)) + (int64_t)(b * 16 + ks * 4 + (lane >> 4)) * n] : 0.0;
+            for (int ks = 0; ks < 4; ++ks) {
+                const double v = L[(bbc * 16 + (lane & 15)) + (int64_t)(bc * 16 + ks * 4 + (lane >> 4)) * n];
+                lf[s][ks] = ok ? v : 0.0;
+            }
         }
-        if ((b & 3) == w) {
-            const int s = b >> 2;
+    };
+    auto stage = [&](int b, int s, bool owner, d4 (&lf)[4]) __attribute__((always_inline)) {
+        if (owner) {
             d4 x = d4{0.0, 0.0, 0.0, 0.0};
-            d4 cur = acc[0];
-#pragma unroll
-            for (int u = 1; u < 4; ++u)
-                if (u == s) cur = acc[u];
+            const d4 cur = acc[s];
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) x = mfma_f64(dn[ks], cur[ks], x);
 #pragma unroll
@@ -478,7 +545,7 @@ __global__ __launch_bounds__(256) void dk_trsm(const double* __restrict__ L, con
             }
             load_dinv(b + 4);
         }
-        __syncthreads();
+        lds_barrier();
         double xr[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) xr[ks] = -xb[b & 1][ks * 64 + lane];
@@ -488,6 +555,22 @@ __global__ __launch_bounds__(256) void dk_trsm(const double* __restrict__ L, con
             if (bb > b && bb < nb) {
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) acc[s] = mfma_f64(lf[s][ks], xr[ks], acc[s]);
+            }
+        }
+    };
+    load_lf(lfa, 0);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {          // owned block row of this round: b = 4 s + w (static s keeps acc[] in registers)
+#pragma unroll
+        for (int u = 0; u < 4; u += 2) {
+            const int b = 4 * s + u;
+            if (b < nb) {
+                load_lf(lfb, b + 1);
+                stage(b, s, u == w, lfa);
+            }
+            if (b + 1 < nb) {
+                load_lf(lfa, b + 2);
+                stage(b + 1, s, u + 1 == w, lfb);
             }
         }
     }
@@ -524,7 +607,7 @@ struct Buf {
         if (p) (void)hipFree(p);
         p = nullptr;
         cap = 0;
-        hipError_t e = hipMalloc(&p, bytes);
+        hipError_t e = hipMalloc(&p, bytes + kOperandSlack * sizeof(double));   // see dk_gemm: unpredicated edge loads
         if (e == hipSuccess) cap = bytes;
         return e;
     }
@@ -553,7 +636,7 @@ struct Engine {
     Buf bA, bQ, bH, ba, bh, bR, bx0;
     int64_t sA = 0, sQ = 0, sH = 0, sa = 0, sh = 0, sR = 0;
     // state and work buffers
-    Buf bm, bmp, bP, bPp, bT1, bV, bS, bL, bDinv, bB, bscal;
+    Buf bm, bmp, bP, bPp, bT1, bV, bS, bL, bDinv, bB, bscal, bslots;
     int profile = 0;
     std::vector<Prof> prof;
     struct Pending {
@@ -583,7 +666,7 @@ Engine* create(int device) {
 void destroy(Engine* e) {
     if (!e) return;
     for (Buf* b : {&e->bA, &e->bQ, &e->bH, &e->ba, &e->bh, &e->bR, &e->bx0, &e->bm, &e->bmp, &e->bP, &e->bPp, &e->bT1, &e->bV, &e->bS,
-                   &e->bL, &e->bDinv, &e->bB, &e->bscal})
+                   &e->bL, &e->bDinv, &e->bB, &e->bscal, &e->bslots})
         b->release();
     for (auto& pe : e->pending) {
         (void)hipEventDestroy(pe.a);
@@ -662,7 +745,7 @@ template <int TM, int TN> void launch_gemm_t(GemmArgs& g, hipStream_t st) {
     const int ntm = (g.M + Cfg::BM - 1) / Cfg::BM, ntn = (g.N + Cfg::BN - 1) / Cfg::BN;
     const int per = (ntm * ntn + 7) / 8;
     g.nblk_tiles = per * 8;
-    const int nrider = g.v.mode ? (g.v.n + 63) / 64 : 0;
+    const int nrider = g.v.mode ? (g.v.n + 15) / 16 : 0;
     hipLaunchKernelGGL((dk_gemm<TM, TN>), dim3(g.nblk_tiles + nrider), dim3(512), Cfg::LDS_BYTES, st, g);
 }
 
@@ -749,6 +832,13 @@ int model_set(Engine* e, const ModelDesc& m, hipStream_t st) {
     DCHK(e->bDinv.ensure((size_t)(Pq / 16) * 256 * 8));
     DCHK(e->bB.ensure((size_t)Pq * e->ldB * 8));
     DCHK(e->bscal.ensure(8 * 8));
+    {
+        std::vector<int> tab;
+        chol_slot_table(Pq / 16, tab);
+        DCHK(e->bslots.ensure(tab.size() * sizeof(int)));
+        DCHK(hipMemcpyAsync(e->bslots.p, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice, st));
+        DCHK(hipStreamSynchronize(st));
+    }
     DCHK(hipMemsetAsync(e->bV.p, 0, (size_t)Pq * (Dp + 16) * 8, st));
     DCHK(hipMemsetAsync(e->bL.p, 0, (size_t)Pq * Pq * 8, st));
     DCHK(hipMemsetAsync(e->bscal.p, 0, 64, st));
@@ -838,7 +928,11 @@ void enqueue_update(Engine* e, const StepPtrs& s, int64_t t, const double* y, co
     }
     {
         Scope sc(e, st, "dk_chol", prof);
-        hipLaunchKernelGGL(dk_chol, dim3(1), dim3(512), 0, st, e->bS.d(), Pq, e->bL.d(), e->bDinv.d(), e->bscal.d());
+        hipLaunchKernelGGL(dk_chol, dim3(1), dim3(1024), 0, st, e->bS.d(), Pq, static_cast<const int*>(e->bslots.p), e->bL.d(), e->bDinv.d(), e->bscal.d()
+#ifdef DK_TRACE
+                           , (long long*)nullptr
+#endif
+        );
     }
     {
         Scope sc(e, st, "dk_trsm", prof);
