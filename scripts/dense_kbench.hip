@@ -48,15 +48,11 @@ int main(int argc, char** argv) {
     }
     std::vector<long long> tr(16 * 4 * 2);
     CK(hipMemcpy(tr.data(), dtr, tr.size() * 8, hipMemcpyDeviceToHost));
-    printf("panel: [wave0: F | wait2 | trsm-phase | d1-phase]  [wave1: d2 | wait2 | trsm | d1]  (cycles, s_memtime @100MHz? raw)\n");
-    for (int kb = 0; kb < 16; ++kb) {
-        for (int w = 0; w < 2; ++w) {
-            long long a = tr[(kb * 4 + 0) * 2 + w], b = tr[(kb * 4 + 1) * 2 + w], c = tr[(kb * 4 + 2) * 2 + w], d = tr[(kb * 4 + 3) * 2 + w];
-            long long nx = kb < 15 ? tr[((kb + 1) * 4 + 0) * 2 + w] : d;
-            printf("%s kb=%2d: %6lld %6lld %6lld %6lld", w ? "   |" : "", kb, b - a, c - b, d - c, nx - d);
-        }
-        printf("\n");
-    }
+    printf("panel:  F (chain wave) | gap to next F || worker wave 1: trsm phase + barrier | update (d2) + wait   [cycles]\n");
+    auto T = [&](int kb, int slot) { return tr[(kb * 4 + slot) * 2 + (slot >= 2 ? 1 : 0)]; };
+    for (int kb = 0; kb < 16; ++kb)
+        printf(" kb=%2d: %6lld %6lld || %6lld %6lld\n", kb, T(kb, 1) - T(kb, 0), kb < 15 ? T(kb + 1, 0) - T(kb, 1) : 0LL, T(kb, 3) - T(kb, 2),
+               kb < 15 ? T(kb + 1, 2) - T(kb, 3) : 0LL);
     std::vector<double> Lh(S.size());
     CK(hipMemcpy(Lh.data(), dL, S.size() * 8, hipMemcpyDeviceToHost));
     double err = 0;

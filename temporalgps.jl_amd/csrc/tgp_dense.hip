@@ -316,24 +316,37 @@ __device__ inline double rsqrt_fast(double x) {
 }
 
 #ifdef DK_TRACE
-#define DK_STAMP(slot) do { if (lane == 0 && w < 2) trace[((kb) * 4 + (slot)) * 2 + w] = (long long)__builtin_readcyclecounter(); } while (0)
+#define DK_STAMP(slot) do { if (lane == 0 && w < 2) trace[((kb) * 4 + (slot)) * 2 + (slot >= 2 ? 1 : 0)] = (long long)__builtin_readcyclecounter(); } while (0)
 #else
 #define DK_STAMP(slot) do { } while (0)
 #endif
 __global__ __launch_bounds__(1024) void dk_chol(const double* __restrict__ S, int n, const int* __restrict__ slots, double* __restrict__ L,
-                                                double* __restrict__ Dinv, double* __restrict__ scal
+                                                 double* __restrict__ Dinv, double* __restrict__ scal
 #ifdef DK_TRACE
-                                                , long long* __restrict__ trace
+                                                 , long long* __restrict__ trace
 #endif
-                                                ) {
-    __shared__ double pan[2][kCholMaxTiles * 256];
+                                                 ) {
+    __shared__ double pan[3][kCholMaxTiles * 256];
     __shared__ double dtile[256];
-    __shared__ double winv[256];
+    __shared__ double winv[2][256];
     __shared__ double dg[kCholMaxTiles * 16];
-    __shared__ int bad;
+    __shared__ int flag_w, flag_d, arrived, bad;   // monotonic: panels published by the chain wave / diagonal tiles handed over / worker arrivals
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nt = n / 16;
-    if (tid == 0) bad = 0;
+    if (tid == 0) {
+        bad = 0;
+        flag_w = 0;
+        flag_d = 0;
+        arrived = 0;
+    }
+    __syncthreads();
+    auto wait_ge = [&](int* f, int target) __attribute__((always_inline)) {
+        while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(2);
+    };
+    auto publish = [&](int* f, int value) __attribute__((always_inline)) {   // all of this wave's LDS writes first, then the flag
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) __hip_atomic_store(f, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
     int tt[kCholSlots];   // owned tile of slot s: (i << 4) | j, or -1
 #define TI(s) (tt[s] >> 4)
 #define TJ(s) (tt[s] < 0 ? -1 : (tt[s] & 15))
@@ -347,88 +360,75 @@ __global__ __launch_bounds__(1024) void dk_chol(const double* __restrict__ S, in
             if (tt[s] == 0) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) dtile[r * 64 + lane] = tile[s][r];
+                publish(&flag_d, 1);
             }
         } else {
             tile[s] = d4{0.0, 0.0, 0.0, 0.0};
         }
     }
-    if (w == 0) __builtin_amdgcn_s_setprio(3);   // the chain wave is the critical path: it wins issue arbitration on its SIMD
-    for (int kb = 0; kb < nt; ++kb) {
-        int ln = lane;   // opaque per panel: keeps the per-tile LDS addresses from being hoisted out of the panel loop
-        asm volatile("" : "+v"(ln));
-        lds_barrier();   // 1
-        DK_STAMP(0);
-        if (w == 0) {
-            // chain wave. Lanes 0-15 hold one ROW of the tile each (z[k] = T[row][k]); lanes 16-31 hold one COLUMN of
-            // W = L_kk^-1 each (z[k] = W[k][col], starting from the identity): both obey the same recurrence
-            // z[c] *= 1/L[c][c]; z[j] -= z[c] L[j][c], so one instruction stream factorises and inverts (lanes 32-63 repeat).
-            const int idx = lane & 15;
-            const bool is_w = (lane & 16) != 0;
-            double zz[16];
-#define Z(k) zz[k]
+    if (w == 0) {
+        // ---------------------------------------------------------------- chain wave: factorise + invert the diagonal tiles
+        __builtin_amdgcn_s_setprio(3);
+        const int idx = lane & 15;
+        const bool is_w = (lane & 16) != 0;
+        int notpd = 0;
+        for (int kb = 0; kb < nt; ++kb) {
+            wait_ge(&flag_d, kb + 1);
+            DK_STAMP(0);
+            // Lanes 0-15 hold one ROW of the tile each (z[k] = T[row][k]); lanes 16-31 hold one COLUMN of W = L_kk^-1 each
+            // (z[k] = W[k][col], starting from the identity): both obey the same recurrence z[c] *= 1/L[c][c];
+            // z[j] -= z[c] L[j][c], so one instruction stream factorises and inverts (lanes 32-63 repeat). (Broadcast LDS reads of
+            // the published column instead of readlane pairs were measured slower: 10.6K against 7.7K cycles per tile.)
+            double z[16];
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 const double tv = dtile[k * 16 + idx];
-                Z(k) = is_w ? (k == idx ? 1.0 : 0.0) : tv;
+                z[k] = is_w ? (k == idx ? 1.0 : 0.0) : tv;
             }
-            int notpd = 0;
             double mypiv = 1.0;
 #pragma unroll
             for (int c = 0; c < 16; ++c) {
-                const double piv = rdlane(Z(c), c);
+                const double piv = rdlane(z[c], c);
                 notpd |= !(piv > 0.0);
                 const double rs = rsqrt_fast(piv);
-                const double l = Z(c) * rs;        // rows: L[row][c]; columns: the final W[c][col]
-                Z(c) = l;
+                const double l = z[c] * rs;        // rows: L[row][c]; columns: the final W[c][col]
+                z[c] = l;
                 mypiv = lane == c ? piv : mypiv;
 #pragma unroll
                 for (int j = c + 1; j < 16; ++j) {
-                    double zj = Z(j) - l * rdlane(l, j);      // L[j][c] comes from lane j (a row lane)
+                    double zj = z[j] - l * rdlane(l, j);      // L[j][c] comes from lane j (a row lane)
                     // evaluate NOW: left to itself the compiler sinks these updates to their use (a left-looking order) and keeps
                     // all 120 broadcast scalars alive in between
                     asm volatile("" : "+v"(zj));
-                    Z(j) = zj;
+                    z[j] = zj;
                 }
             }
-            if (lane < 16) dg[kb * 16 + lane] = mypiv;
             if (lane < 16) {
+                dg[kb * 16 + lane] = mypiv;
 #pragma unroll
-                for (int k = 0; k < 16; ++k) L[(kb * 16 + idx) + (int64_t)(kb * 16 + k) * n] = k <= idx ? Z(k) : 0.0;
+                for (int k = 0; k < 16; ++k) L[(kb * 16 + idx) + (int64_t)(kb * 16 + k) * n] = k <= idx ? z[k] : 0.0;
             } else if (lane < 32) {
 #pragma unroll
                 for (int k = 0; k < 16; ++k) {
-                    winv[idx * 16 + k] = Z(k);                      // W[k][col] at [k' = col][row' = k]
-                    Dinv[kb * 256 + idx * 16 + k] = Z(k);
+                    winv[kb & 1][idx * 16 + k] = z[k];              // W[k][col] at [k' = col][row' = k]
+                    Dinv[kb * 256 + idx * 16 + k] = z[k];
                 }
             }
-#undef Z
-            if (lane == 0 && notpd) bad = 1;
-            // the chain wave's tile registers carry nothing: redefining them here ends their live ranges at the top of this
-            // branch, which leaves the register file to the factorisation (without it the allocator spills ~150 registers)
-#pragma unroll
-            for (int s = 0; s < kCholSlots; ++s) tile[s] = d4{0.0, 0.0, 0.0, 0.0};
-        } else if (kb > 0) {
-            // rank-16 update with panel kb-1 of every owned tile right of it (the diagonal tile (kb, kb) already has it)
-            const double* pb = pan[(kb - 1) & 1];
-            const int dcode = (kb << 4) | kb;
-#pragma unroll
-            for (int s = 0; s < kCholSlots; ++s)
-                if (TJ(s) >= kb && tt[s] != dcode) {
-#pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) {
-                        const int off = (ks * 4 + (ln >> 4)) * 16 + (ln & 15);
-                        tile[s] = mfma_f64(-pb[TJ(s) * 256 + off], pb[TI(s) * 256 + off], tile[s]);
-                    }
-                }
+            DK_STAMP(1);
+            publish(&flag_w, kb + 1);
         }
-        DK_STAMP(1);
-        lds_barrier();   // 2
-        DK_STAMP(2);
-        if (w > 0) {
-            double* pb = pan[kb & 1];
+        if (lane == 0 && notpd) bad = 1;
+    } else {
+        // ---------------------------------------------------------------- workers
+        // Software pipeline per panel kb: U(kb) = the URGENT part of panel kb's rank-16 update (column kb+1, which the next
+        // solve needs, and the diagonal tile after it), then the solve of column kb+1 as soon as the chain wave has published
+        // its diagonal block, and only then R(kb) = the rest of panel kb's update, which overlaps the chain wave's next
+        // factorisation. The panel buffer is a ring of three: panel kb is still read (R(kb)) after column kb+1 was written.
+        auto solve = [&](int kb, int ln) __attribute__((always_inline)) {
+            double* pb = pan[kb % 3];
             double wa[4];
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) wa[ks] = winv[(ks * 4 + (ln >> 4)) * 16 + (ln & 15)];
+            for (int ks = 0; ks < 4; ++ks) wa[ks] = winv[kb & 1][(ks * 4 + (ln >> 4)) * 16 + (ln & 15)];
 #pragma unroll
             for (int s = 0; s < kCholSlots; ++s)
                 if (TJ(s) == kb && TI(s) > kb) {
@@ -444,6 +444,7 @@ __global__ __launch_bounds__(1024) void dk_chol(const double* __restrict__ S, in
                             tile[s + 1 < kCholSlots ? s + 1 : s] = dt;
 #pragma unroll
                             for (int r = 0; r < 4; ++r) dtile[r * 64 + ln] = dt[r];
+                            publish(&flag_d, kb + 2);
                         }
                     }
 #pragma unroll
@@ -452,8 +453,45 @@ __global__ __launch_bounds__(1024) void dk_chol(const double* __restrict__ S, in
                         L[(TI(s) * 16 + (ln & 15)) + (int64_t)(kb * 16 + (ln >> 4) + 4 * r) * n] = x[r];
                     }
                 }
+            // arrive at the worker barrier of this panel: the whole panel is in the LDS buffer before anyone applies it
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) __hip_atomic_fetch_add(&arrived, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        };
+        // rank-16 update with panel kb: urgent == tiles of column kb+1 and the diagonal tile (kb+2, kb+2); the diagonal tile
+        // (kb+1, kb+1) got this update from its owner's registers during the solve
+        auto update = [&](int kb, int ln, bool urgent) __attribute__((always_inline)) {
+            const double* pb = pan[kb % 3];
+            const int dnext = ((kb + 2) << 4) | (kb + 2);
+#pragma unroll
+            for (int s = 0; s < kCholSlots; ++s) {
+                const bool urg = TJ(s) == kb + 1 || tt[s] == dnext;
+                if (TJ(s) > kb && TI(s) > kb + 1 && urg == urgent) {
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        const int off = (ks * 4 + (ln >> 4)) * 16 + (ln & 15);
+                        tile[s] = mfma_f64(-pb[TJ(s) * 256 + off], pb[TI(s) * 256 + off], tile[s]);
+                    }
+                }
+            }
+        };
+        {
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            wait_ge(&flag_w, 1);
+            solve(0, ln);
+            wait_ge(&arrived, kCholWorkers);
         }
-        DK_STAMP(3);
+        for (int kb = 0; kb + 1 < nt; ++kb) {
+            int ln = lane;   // opaque per panel: keeps the per-tile LDS addresses from being hoisted out of the panel loop
+            asm volatile("" : "+v"(ln));
+            DK_STAMP(2);
+            update(kb, ln, true);
+            wait_ge(&flag_w, kb + 2);
+            solve(kb + 1, ln);
+            DK_STAMP(3);
+            update(kb, ln, false);
+            wait_ge(&arrived, kCholWorkers * (kb + 2));
+        }
     }
     __syncthreads();
     // log det S = sum log(pivot)
