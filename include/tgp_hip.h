@@ -72,6 +72,9 @@ typedef struct tgp_handle tgp_handle;
                            0 never; + 4 keeps the lane-per-element block scans */
 #define TGP_OPT_SPLIT_SMOOTHER 7 /* lane-per-chunk passes: pass 2 of the smoother as two kernels (filter + scratch, then the chunk smoother
                                     elements from the scratch): 1 (default) for d = 6, 7, 2 also for d = 5, 0 never (fused MODE 2 kernel) */
+#define TGP_OPT_DENSE_STRUCTURE 8 /* dense path (d > 16): 1 (default) a shared A / H with at most 8 entries per row (what
+                                     lgssm_components(::Separable, ...) builds: I (x) A_t, I (x) H_t') is applied in sparse form; 0 the
+                                     reference's dense products on the fp64 MFMA GEMM kernels. Set before tgp_model_set. */
 #define TGP_OPT_TIMING 6 /* 1: record the hipEvents behind tgp_last_timing (off by default: ~30 us of host time per call) */
 #define TGP_OPT_FUSE_SCAN 4 /* 1 (default): the level-0 scan reduce / apply of the forward scan run inside the chunk kernels;
                                0: stand-alone k_scan_reduce / k_scan_apply launches (bit-identical results, for A/B timing) */
@@ -84,7 +87,8 @@ int tgp_set_option(tgp_handle* h, int option, int64_t value);
 /* run on a caller-provided hipStream_t (e.g. torch's current stream); NULL restores the handle's own */
 int tgp_set_stream(tgp_handle* h, void* hip_stream);
 const char* tgp_version(void);
-/* which build of the kernels the current model runs on: 1 out-of-line (safe), 2 fully inlined (d = 5, 6 after the check) */
+/* which build of the kernels the current model runs on: 1 out-of-line (safe), 2 fully inlined (d = 5, 6 after the check);
+   dense path (d > 16): 16 + (1 if A is applied in sparse form) + (2 if H is) */
 int tgp_kernel_variant(const tgp_handle* h);
 
 /* ---- model: replaces the LGSSM / GaussMarkovModel containers -----------------------------------

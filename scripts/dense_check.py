@@ -83,6 +83,12 @@ def main():
     lp = tgp.logpdf(dmod, Y)
     print(f"space-time d=768 p=256 T={T}: lml {lp:.10f} ref {lp_ref:.10f} rel {abs(lp - lp_ref) / abs(lp_ref):.2e} (oracle {t1 - t0:.2f} s)", flush=True)
     ok &= abs(lp - lp_ref) < 1e-9 * abs(lp_ref)
+    # the same with the reference's dense products (structure exploitation off)
+    dm2 = space_time.build_lgssm(k, grid, 0.1)
+    dm2.handle_options[_lib.OPT_DENSE_STRUCTURE] = 0
+    lp2 = tgp.logpdf(dm2, Y)
+    print(f"  dense products: lml {lp2:.10f} rel {abs(lp2 - lp_ref) / abs(lp_ref):.2e}; kernel variants {dmod.handle().lib.tgp_kernel_variant(dmod.handle().h)} / {dm2.handle().lib.tgp_kernel_variant(dm2.handle().h)}", flush=True)
+    ok &= abs(lp2 - lp_ref) < 1e-9 * abs(lp_ref)
     # timing
     T = 400
     grid = space_time.RectilinearGrid(r, lti_sde.RegularSpacing(0.0, 0.01, T))
@@ -94,11 +100,19 @@ def main():
     lp = tgp.logpdf(dmod, Y)
     dt = time.time() - t0
     print(f"timing: T={T} logpdf {dt * 1e3:.1f} ms -> {dt / T * 1e6:.1f} us/step, {2.57e9 * T / dt / 1e12:.2f} TF/s algorithmic", flush=True)
+    print("kernel variant", hd.lib.tgp_kernel_variant(hd.h))
     hd.set_option(_lib.OPT_PROFILE, 1)
     hd.profile_reset()
     tgp.logpdf(dmod, Y)
     for name, v in hd.profile().items():
         print(f"  {name:28s} {v['total_ms'] / max(1, v['calls']) * 1e3:9.2f} us x {v['calls']}")
+    dm3 = space_time.build_lgssm(k, grid, 0.1)
+    dm3.handle_options[_lib.OPT_DENSE_STRUCTURE] = 0
+    tgp.logpdf(dm3, Y)
+    t0 = time.time()
+    tgp.logpdf(dm3, Y)
+    dt = time.time() - t0
+    print(f"timing (dense products): T={T} logpdf {dt * 1e3:.1f} ms -> {dt / T * 1e6:.1f} us/step, {2.57e9 * T / dt / 1e12:.2f} TF/s algorithmic", flush=True)
     print("ALL OK" if ok else "SOME FAILED")
     return 0 if ok else 1
 

@@ -205,6 +205,7 @@ struct tgp_handle {
     // dense large-state engine (d > 16, tgp_dense.hip): sequential in time, fp64 MFMA
     tgp_dense::Engine* dense = nullptr;
     bool is_dense = false;
+    int dense_structure = 1;     // TGP_OPT_DENSE_STRUCTURE
     // model
     bool have_model = false, lti = false;
     int64_t T = 0;
@@ -840,6 +841,10 @@ int tgp_set_option(tgp_handle* h, int option, int64_t value) {
         h->smoother_valid = false;
         return TGP_OK;
     }
+    if (option == TGP_OPT_DENSE_STRUCTURE) {
+        h->dense_structure = value != 0;   // takes effect at the next tgp_model_set
+        return TGP_OK;
+    }
     if (option == TGP_OPT_TIMING) {
         h->timing = value != 0;
         return TGP_OK;
@@ -863,6 +868,7 @@ int tgp_set_option(tgp_handle* h, int option, int64_t value) {
 
 int tgp_kernel_variant(const tgp_handle* h) {
     if (!h || !h->have_model) return 0;
+    if (h->is_dense) return 16 + tgp_dense::structure(h->dense);   // dense path: 16 | (A sparse) | 2 (H sparse)
     return h->variant_code;
 }
 
@@ -911,6 +917,7 @@ int tgp_model_set(tgp_handle* h, int64_t T, int d, int p, int ordering, uint32_t
         md.sR = (flags & TGP_SHARED_R) ? 0 : p;
         md.x0m = x0m; md.x0P = x0P;
         tgp_dense::set_profile(h->dense, h->profile);
+        tgp_dense::set_structure(h->dense, h->dense_structure);
         TRY(dense_fail(h, tgp_dense::model_set(h->dense, md, h->stream)));
         HIPCHK(hipStreamSynchronize(h->stream));
         for (DevBuf* b : {&h->bA, &h->bQ, &h->bH}) b->release();   // the packed copy is what the kernels read

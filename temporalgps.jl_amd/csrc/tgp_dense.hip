@@ -614,6 +614,108 @@ __global__ __launch_bounds__(256) void dk_trsm(const double* __restrict__ L, con
     }
 }
 
+// ------------------------------------------------------------------------------------------------ structured (sparse) A and H
+// lgssm_components(::Separable, ...) builds A = I (x) A_t and H = I (x) H_t' as DENSE matrices (to_gauss_markov.jl:14-18) and the
+// reference multiplies them as such. When a shared A or H has at most kSparseMaxNnz entries per row the engine keeps it in ELL
+// form (col / val [nnz][rows], lanes run along rows) and forms A P, (A P) A' + Q, H Pp, V H' + R as row / column combinations:
+// O(nnz d^2) streamed work instead of an O(d^3) contraction. Same values up to the order of the few remaining additions.
+constexpr int kSparseMaxNnz = 8;
+
+struct SpVec {   // optional vector product riding along dk_spl (blockIdx.y == gridDim.y - 1)
+    int mode = 0;                    // 0 none; 1 out = add + Sp x; 2 residual out = y - h - Sp x (+ missing count)
+    const double* x = nullptr;
+    const double* add = nullptr;
+    double* out = nullptr;
+    const double* y = nullptr;
+    const uint8_t* mask = nullptr;
+    const double* hh = nullptr;
+    int p = 0;
+    double* scal = nullptr;
+};
+
+// out[i + k ldo] = sum_a val[a][i] in[col[a][i] + k ldi], k < ncols: every thread owns a row and walks KB columns
+template <int KB> __global__ __launch_bounds__(256) void dk_spl(const int* __restrict__ col, const double* __restrict__ val, int nnz, int rows,
+                                                                 const double* __restrict__ in, int64_t ldi, double* __restrict__ out,
+                                                                 int64_t ldo, int ncols, SpVec v) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    int ci[kSparseMaxNnz];
+    double cv[kSparseMaxNnz];
+#pragma unroll
+    for (int a = 0; a < kSparseMaxNnz; ++a) {
+        const bool ok = a < nnz && i < rows;
+        ci[a] = ok ? col[a * rows + i] : 0;
+        cv[a] = ok ? val[a * rows + i] : 0.0;
+    }
+    if (blockIdx.y == gridDim.y - 1) {   // vector rider
+        if (v.mode == 0) return;
+        double s = 0.0;
+#pragma unroll
+        for (int a = 0; a < kSparseMaxNnz; ++a)
+            if (a < nnz) s += cv[a] * v.x[ci[a]];
+        if (i < rows) {
+            if (v.mode == 2) {
+                double o = 0.0;
+                if (i < v.p) {
+                    const bool miss = v.mask != nullptr && v.mask[i] != 0;
+                    o = (miss ? 0.0 : v.y[i]) - v.hh[i] - s;
+                }
+                v.out[i] = o;
+            } else {
+                v.out[i] = s + (v.add ? v.add[i] : 0.0);
+            }
+        }
+        if (v.mode == 2 && blockIdx.x == 0) {
+            __shared__ int cnt;
+            if (threadIdx.x == 0) cnt = 0;
+            __syncthreads();
+            int c = 0;
+            if (v.mask)
+                for (int q = threadIdx.x; q < v.p; q += 256) c += v.mask[q] != 0;
+            if (c) atomicAdd(&cnt, c);
+            __syncthreads();
+            if (threadIdx.x == 0) v.scal[1] = (double)cnt;
+        }
+        return;
+    }
+    if (i >= rows) return;
+    const int k0 = blockIdx.y * KB;
+#pragma unroll
+    for (int u = 0; u < KB; ++u) {
+        const int k = k0 + u;
+        if (k < ncols) {
+            double s = 0.0;
+#pragma unroll
+            for (int a = 0; a < kSparseMaxNnz; ++a)
+                if (a < nnz) s += cv[a] * in[ci[a] + (int64_t)k * ldi];
+            out[i + (int64_t)k * ldo] = s;
+        }
+    }
+}
+
+// out[i + j ldo] = sum_b val[b][j] in[i + col[b][j] ldi] + E[i + j lde] (+ diag as in dk_gemm), i < M, j < N (N = rows of the
+// sparse factor); a block owns 256 rows i and JB output columns, the sparse row of a column is wave-uniform
+template <int JB> __global__ __launch_bounds__(256) void dk_spr(const int* __restrict__ col, const double* __restrict__ val, int nnz, int N,
+                                                                 const double* __restrict__ in, int64_t ldi, double* __restrict__ out,
+                                                                 int64_t ldo, int M, const double* __restrict__ E, int64_t lde,
+                                                                 const double* __restrict__ diag, const uint8_t* __restrict__ dmask, int ndiag) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= M) return;
+    const int j0 = blockIdx.y * JB;
+#pragma unroll
+    for (int u = 0; u < JB; ++u) {
+        const int j = j0 + u;
+        if (j < N) {
+            double s = 0.0;
+#pragma unroll
+            for (int b = 0; b < kSparseMaxNnz; ++b)
+                if (b < nnz) s += val[b * N + j] * in[i + (int64_t)col[b * N + j] * ldi];
+            if (E) s += E[i + (int64_t)j * lde];
+            if (diag && i == j) s += i < ndiag ? ((dmask && dmask[i]) ? kLargeVar : diag[i]) : 1.0;
+            out[i + (int64_t)j * ldo] = s;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ prior marginals of one step
 // mean_i = (H mp + h)_i (rider of the V = H Pp launch writes -r = H mp + h - 0 ... see host code), var_i = sum_k V[i][k] H[i][k] + R_i
 __global__ void dk_marg_diag(const double* __restrict__ V, const double* __restrict__ Hk, int Pq, int Dp, const double* __restrict__ R,
@@ -675,6 +777,10 @@ struct Engine {
     int64_t sA = 0, sQ = 0, sH = 0, sa = 0, sh = 0, sR = 0;
     // state and work buffers
     Buf bm, bmp, bP, bPp, bT1, bV, bS, bL, bDinv, bB, bscal, bslots;
+    // ELL form of a shared A / H with few entries per row (0 == dense)
+    int structure_opt = 1;
+    int nnzA = 0, nnzH = 0;
+    Buf bAcol, bAval, bHcol, bHval;
     int profile = 0;
     std::vector<Prof> prof;
     struct Pending {
@@ -704,7 +810,7 @@ Engine* create(int device) {
 void destroy(Engine* e) {
     if (!e) return;
     for (Buf* b : {&e->bA, &e->bQ, &e->bH, &e->ba, &e->bh, &e->bR, &e->bx0, &e->bm, &e->bmp, &e->bP, &e->bPp, &e->bT1, &e->bV, &e->bS,
-                   &e->bL, &e->bDinv, &e->bB, &e->bscal, &e->bslots})
+                   &e->bL, &e->bDinv, &e->bB, &e->bscal, &e->bslots, &e->bAcol, &e->bAval, &e->bHcol, &e->bHval})
         b->release();
     for (auto& pe : e->pending) {
         (void)hipEventDestroy(pe.a);
@@ -715,6 +821,8 @@ void destroy(Engine* e) {
 }
 const std::string& last_error(const Engine* e) { return e->err; }
 void set_profile(Engine* e, int on) { e->profile = on; }
+void set_structure(Engine* e, int on) { e->structure_opt = on; }
+int structure(const Engine* e) { return (e->nnzA ? 1 : 0) | (e->nnzH ? 2 : 0); }
 static void resolve_pending(Engine* e);
 int profile_count(Engine* e) {
     resolve_pending(e);   // callers query after the call's closing stream synchronisation
@@ -858,6 +966,44 @@ int model_set(Engine* e, const ModelDesc& m, hipStream_t st) {
         }
         DCHK(hipStreamSynchronize(st));
     }
+    // structure of a shared A / H (see dk_spl): ELL form when no row has more than kSparseMaxNnz entries
+    e->nnzA = e->nnzH = 0;
+    if (e->structure_opt) {
+        auto build = [&](const double* dev, bool shared, int rows, int cols, int64_t rs, int64_t cs, int prows, Buf& bcol, Buf& bval, int& nnz_out) -> int {
+            if (!shared) return TGP_OK;
+            std::vector<double> host((size_t)rows * cols);
+            DCHK(hipMemcpy(host.data(), dev, host.size() * 8, hipMemcpyDeviceToHost));
+            int mx = 0;
+            for (int i = 0; i < rows && mx <= kSparseMaxNnz; ++i) {
+                int c = 0;
+                for (int k = 0; k < cols; ++k) c += host[(size_t)i * rs + (size_t)k * cs] != 0.0;
+                mx = c > mx ? c : mx;
+            }
+            if (mx == 0 || mx > kSparseMaxNnz) return TGP_OK;
+            std::vector<int> col((size_t)mx * prows, 0);
+            std::vector<double> val((size_t)mx * prows, 0.0);
+            for (int i = 0; i < rows; ++i) {
+                int c = 0;
+                for (int k = 0; k < cols; ++k) {
+                    const double v = host[(size_t)i * rs + (size_t)k * cs];
+                    if (v != 0.0) {
+                        col[(size_t)c * prows + i] = k;
+                        val[(size_t)c * prows + i] = v;
+                        ++c;
+                    }
+                }
+            }
+            DCHK(bcol.ensure(col.size() * sizeof(int)));
+            DCHK(bval.ensure(val.size() * 8));
+            DCHK(hipMemcpy(bcol.p, col.data(), col.size() * sizeof(int), hipMemcpyHostToDevice));
+            DCHK(hipMemcpy(bval.p, val.data(), val.size() * 8, hipMemcpyHostToDevice));
+            nnz_out = mx;
+            return TGP_OK;
+        };
+        DCHK(hipStreamSynchronize(st));
+        if (int rc = build(m.A, m.sA == 0, m.d, m.d, 1, m.d, Dp, e->bAcol, e->bAval, e->nnzA)) return rc;      // A[i][k] at i + k d
+        if (int rc = build(m.H, m.sH == 0, m.p, m.d, m.d, 1, Pq, e->bHcol, e->bHval, e->nnzH)) return rc;      // H[i][k] at i d + k
+    }
     DCHK(e->bx0.ensure((DD + Dp) * 8));
     DCHK(e->bm.ensure((size_t)Dp * 8));
     DCHK(e->bmp.ensure((size_t)Dp * 8));
@@ -909,6 +1055,22 @@ StepPtrs step_ptrs(const Engine* e, int64_t t) {
 // predict (lgc.jl:46-52): mp = A m + a, Pp = A P A' + Q
 void enqueue_predict(Engine* e, const StepPtrs& s, hipStream_t st, bool prof) {
     const int Dp = e->Dp;
+    if (e->nnzA) {
+        {
+            SpVec v;
+            v.mode = 1; v.x = e->bm.d(); v.add = s.a; v.out = e->bmp.d();
+            Scope sc(e, st, "dk_spl<A P>", prof);
+            hipLaunchKernelGGL(dk_spl<2>, dim3((Dp + 255) / 256, (Dp + 1) / 2 + 1), dim3(256), 0, st, static_cast<const int*>(e->bAcol.p), e->bAval.d(),
+                               e->nnzA, Dp, e->bP.d(), (int64_t)Dp, e->bT1.d(), (int64_t)Dp, Dp, v);
+        }
+        {
+            Scope sc(e, st, "dk_spr<(A P) A' + Q>", prof);
+            hipLaunchKernelGGL(dk_spr<1>, dim3((Dp + 255) / 256, Dp), dim3(256), 0, st, static_cast<const int*>(e->bAcol.p), e->bAval.d(), e->nnzA,
+                               Dp, e->bT1.d(), (int64_t)Dp, e->bPp.d(), (int64_t)Dp, Dp, s.Q, (int64_t)Dp, (const double*)nullptr,
+                               (const uint8_t*)nullptr, 0);
+        }
+        return;
+    }
     {
         GemmArgs g;
         g.A = s.A; g.lda = Dp;
@@ -939,6 +1101,21 @@ void enqueue_update(Engine* e, const StepPtrs& s, int64_t t, const double* y, co
     const int Dp = e->Dp, Pq = e->Pq;
     const double* yt = y + t * e->p;
     const uint8_t* mt = mask ? mask + t * e->p : nullptr;
+    if (e->nnzH) {
+        {   // V = H Pp; rider: r = y - h - H mp -> V[:, Dp]
+            SpVec v;
+            v.mode = 2; v.x = e->bmp.d(); v.out = e->bV.d() + (size_t)Dp * Pq;
+            v.y = yt; v.mask = mt; v.hh = s.h; v.p = e->p; v.scal = e->bscal.d();
+            Scope sc(e, st, "dk_spl<H Pp>", prof);
+            hipLaunchKernelGGL(dk_spl<2>, dim3((Pq + 255) / 256, (Dp + 1) / 2 + 1), dim3(256), 0, st, static_cast<const int*>(e->bHcol.p), e->bHval.d(),
+                               e->nnzH, Pq, e->bPp.d(), (int64_t)Dp, e->bV.d(), (int64_t)Pq, Dp, v);
+        }
+        {   // S = V H' + R
+            Scope sc(e, st, "dk_spr<V H' + R>", prof);
+            hipLaunchKernelGGL(dk_spr<1>, dim3((Pq + 255) / 256, Pq), dim3(256), 0, st, static_cast<const int*>(e->bHcol.p), e->bHval.d(), e->nnzH,
+                               Pq, e->bV.d(), (int64_t)Pq, e->bS.d(), (int64_t)Pq, Pq, (const double*)nullptr, (int64_t)0, s.R, mt, e->p);
+        }
+    } else {
     {   // V = H Pp; rider: r = y - h - H mp -> V[:, Dp]
         GemmArgs g;
         g.A = s.H; g.lda = Pq;
@@ -963,6 +1140,7 @@ void enqueue_update(Engine* e, const StepPtrs& s, int64_t t, const double* y, co
         g.M = g.N = Pq; g.K = Dp;
         Scope sc(e, st, "dk_gemm<V H' + R>", prof);
         launch_gemm(g, st);
+    }
     }
     {
         Scope sc(e, st, "dk_chol", prof);

@@ -38,6 +38,9 @@ void destroy(Engine* e);
 const std::string& last_error(const Engine* e);
 // options: profile (per-kernel hipEvents on a sampled subset of steps)
 void set_profile(Engine* e, int on);
+// 1 (default): a shared A / H with at most 8 entries per row is applied in sparse (ELL) form; 0: always the dense MFMA GEMMs
+void set_structure(Engine* e, int on);
+int structure(const Engine* e);   // bit 0: A sparse, bit 1: H sparse (current model)
 int profile_count(Engine* e);
 KernelTime profile_get(const Engine* e, int idx);
 void profile_reset(Engine* e);

@@ -153,6 +153,7 @@ class LGSSM:
         self._handle = None
         self._keep = None
         self._whiten = None      # (Linv (T|1,p,p), logdet_half (T|1,)) when a dense R was whitened
+        self.handle_options = {}  # tgp_set_option values applied to the device handle before the model is bound
 
     @property
     def p(self):
@@ -233,6 +234,8 @@ class LGSSM:
         if small:
             flags |= _lib.SMALL_OUTPUT
         hd = _lib.Handle(self.device)
+        for opt, value in self.handle_options.items():
+            hd.set_option(opt, value)
         x0m = np.ascontiguousarray(np.asarray(_to_numpy(self.x0.m), dtype=np.float64))
         x0P = np.ascontiguousarray(np.asarray(_to_numpy(self.x0.P), dtype=np.float64).T)
         hd.check(hd.lib.tgp_model_set(hd.h, self.T, d, p, self.ordering.code, flags, _lib.ptr(A), _lib.ptr(a), _lib.ptr(Q),
