@@ -10,3 +10,21 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _gpu_visible():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    """A host without a GPU skips the gpu tier instead of failing it in tgp_create (plain `pytest` stays green here)."""
+    if _gpu_visible():
+        return
+    skip = pytest.mark.skip(reason="needs a real MI355X (no GPU visible)")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)

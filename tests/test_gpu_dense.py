@@ -1,0 +1,164 @@
+"""Dense large-state path (state dimension d > 16; tgp_dense.hip: fp64 MFMA GEMM / Cholesky / TRSM chain per time step) through the
+C ABI against the oracle's literal restatement of lgssm.jl:99-187 + linear_gaussian_conditionals.jl:46-52,129-151.
+Tolerances (fp64): logpdf rel 1e-10, filtering means / covariances 1e-9 relative to their scale."""
+import numpy as np
+import pytest
+
+from oracle import components as oc
+from oracle import lgssm_ref as ref
+
+pytestmark = pytest.mark.gpu
+
+
+def _spd(rng, n, scale=1.0):
+    X = rng.standard_normal((n, n)) / np.sqrt(n)
+    return scale * (X @ X.T + 0.5 * np.eye(n))
+
+
+def random_model(rng, T, d, p, ordering="F", per_step=False):
+    nA = T if per_step else 1
+    A = np.stack([np.linalg.qr(rng.standard_normal((d, d)))[0] * rng.uniform(0.4, 0.9) for _ in range(nA)])
+    a = rng.standard_normal((nA, d)) * 0.1
+    Q = np.stack([_spd(rng, d, 0.3) for _ in range(nA)])
+    H = rng.standard_normal((nA, p, d)) / np.sqrt(d)
+    h = rng.standard_normal((nA, p)) * 0.1
+    Rd = rng.uniform(0.05, 0.3, size=(T, p))
+    R = np.stack([np.diag(r) for r in Rd])
+    model = dict(ordering=ordering, kind="small", T=T, A=A, a=a, Q=Q, H=H, h=h, R=R, x0m=rng.standard_normal(d), x0P=_spd(rng, d))
+    return model, Rd
+
+
+def to_dev(tgp, model, Rd, **opts):
+    order = tgp.Forward if model["ordering"] == "F" else tgp.Reverse
+    dm = tgp.LGSSM(tgp.GaussMarkovModel(order, model["A"], model["a"], model["Q"], tgp.Gaussian(model["x0m"], model["x0P"])),
+                   tgp.SmallOutputLGC(model["H"], model["h"], Rd), T=model["T"])
+    dm.handle_options.update(opts)
+    return dm
+
+
+def with_missing(model, y, mk):
+    """The reference's rule for element-wise missing data with Diagonal noise (lgc.jl:143-151, missings.jl:43-53)."""
+    m2 = dict(model)
+    R2, y2 = model["R"].copy(), y.copy()
+    for t, i in zip(*np.nonzero(mk)):
+        R2[t][i, i] = 1e15
+        y2[t, i] = 0.0
+    m2["R"] = R2
+    return m2, y2, mk.sum() * 0.5 * np.log(2 * np.pi * 1e15)
+
+
+CASES = [  # T, d, p, ordering, per-step blocks, missing data
+    (5, 17, 1, "F", False, False),
+    (5, 20, 5, "F", False, False),
+    (6, 48, 16, "F", True, True),
+    (5, 40, 33, "R", False, False),
+    (4, 192, 64, "F", False, True),
+    (3, 300, 100, "R", True, False),
+    (3, 130, 256, "F", False, True),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: f"T{c[0]}-d{c[1]}-p{c[2]}-{c[3]}{'-ps' if c[4] else ''}{'-miss' if c[5] else ''}")
+def test_dense_logpdf_and_filter_match_oracle(case):
+    import temporalgps_jl_amd as tgp
+    T, d, p, ordering, per_step, miss = case
+    rng = np.random.default_rng(1000 + d + p)
+    model, Rd = random_model(rng, T, d, p, ordering, per_step)
+    y = rng.standard_normal((T, p))
+    dm = to_dev(tgp, model, Rd)
+    if miss:
+        mk = rng.random((T, p)) < 0.2
+        m2, y2, comp = with_missing(model, y, mk)
+        lp_ref = ref.logpdf(m2, y2) + comp
+        fm_ref, fP_ref = ref.filter_(m2, y2)
+        yin = np.where(mk, np.nan, y)
+    else:
+        lp_ref = ref.logpdf(model, y)
+        fm_ref, fP_ref = ref.filter_(model, y)
+        yin = y
+    lp = tgp.logpdf(dm, yin)
+    assert abs(lp - lp_ref) <= 1e-10 * abs(lp_ref)
+    fm, fP = tgp._filter(dm, yin)
+    np.testing.assert_allclose(fm, fm_ref, rtol=0, atol=1e-9 * max(1.0, np.abs(fm_ref).max()))
+    np.testing.assert_allclose(fP, fP_ref, rtol=0, atol=1e-9 * max(1.0, np.abs(fP_ref).max()))
+
+
+def test_dense_prior_marginals_match_oracle():
+    import temporalgps_jl_amd as tgp
+    rng = np.random.default_rng(7)
+    for ordering in ("F", "R"):
+        model, Rd = random_model(rng, 4, 40, 7, ordering)
+        mean, var = tgp.marginals(to_dev(tgp, model, Rd))
+        m_ref, C_ref = ref.marginals(model)
+        np.testing.assert_allclose(mean, m_ref, rtol=0, atol=1e-10)
+        np.testing.assert_allclose(var, np.diagonal(C_ref, axis1=-2, axis2=-1), rtol=1e-10, atol=1e-12)
+
+
+def _space_time(Nr, T, kt=("matern52",)):
+    from temporalgps_jl_amd import lti_sde, space_time
+    r = np.linspace(-3.0, 3.0, Nr)
+    k = space_time.Separable(space_time.SEKernel(), lti_sde.to_kernel(kt))
+    grid = space_time.RectilinearGrid(r, lti_sde.RegularSpacing(0.0, 0.01, T))
+    return r, k, grid
+
+
+@pytest.mark.parametrize("Nr,T", [(16, 12), (64, 8), (256, 5)], ids=["d48", "d192", "d768"])
+def test_space_time_dense_model_matches_posterior_and_lml_small(Nr, T):
+    """The reference's own (dense, Nr * d_t-dimensional) model of a Separable kernel (to_gauss_markov.jl:1-20) at
+    d = 48, 192, 768 (BASELINE config 5's step size), with the structured products and with the reference's dense ones."""
+    import temporalgps_jl_amd as tgp
+    from temporalgps_jl_amd import _lib, space_time
+    r, k, grid = _space_time(Nr, T)
+    model = oc.build_lgssm_separable(("se",), ("matern52",), r, ("regular", 0.0, 0.01, T), 0.1)
+    rng = np.random.default_rng(Nr)
+    Y = rng.standard_normal((T, Nr))
+    lp_ref = ref.logpdf(model, Y)
+    fm_ref, fP_ref = ref.filter_(model, Y)
+    for structure in (1, 0):
+        dm = space_time.build_lgssm(k, grid, 0.1)
+        dm.handle_options[_lib.OPT_DENSE_STRUCTURE] = structure
+        lp = tgp.logpdf(dm, Y)
+        assert abs(lp - lp_ref) <= 1e-10 * abs(lp_ref), (structure, lp, lp_ref)
+        hd = dm.handle()
+        assert hd.lib.tgp_kernel_variant(hd.h) == (19 if structure else 16)
+        fm, fP = tgp._filter(dm, Y)
+        np.testing.assert_allclose(fm, fm_ref, rtol=0, atol=1e-9 * np.abs(fm_ref).max())
+        np.testing.assert_allclose(fP, fP_ref, rtol=0, atol=1e-9 * np.abs(fP_ref).max())
+    # missing observations and heteroscedastic noise on the same model
+    s2 = rng.uniform(0.05, 0.2, size=(T, Nr))
+    mk = rng.random((T, Nr)) < 0.1
+    model2 = oc.build_lgssm_separable(("se",), ("matern52",), r, ("regular", 0.0, 0.01, T), s2)
+    m2, y2, comp = with_missing(model2, Y, mk)
+    dm = space_time.build_lgssm(k, grid, s2)
+    lp = tgp.logpdf(dm, np.where(mk, np.nan, Y))
+    lp_ref2 = ref.logpdf(m2, y2) + comp
+    assert abs(lp - lp_ref2) <= 1e-10 * abs(lp_ref2)
+
+
+def test_dense_not_positive_definite_is_reported():
+    import temporalgps_jl_amd as tgp
+    from temporalgps_jl_amd import _lib
+    rng = np.random.default_rng(3)
+    model, Rd = random_model(rng, 3, 24, 4)
+    Rd = Rd.copy()
+    Rd[1, 2] = -50.0        # S of step 1 loses positive definiteness: Julia's cholesky throws PosDefException (lgc.jl:135)
+    with pytest.raises(_lib.NotPositiveDefinite):
+        tgp.logpdf(to_dev(tgp, model, Rd), rng.standard_normal((3, 4)))
+
+
+def test_dense_full_size_config5_against_decoupled():
+    """BASELINE config 5 at full size: Separable(SE, Matern-5/2), 256 spatial points x T = 1e5, sigma^2 = 0.1. The dense
+    d = 768, p = 256 recursion (1e5 sequential steps of the MFMA kernel chain) against the eigen-decoupled evaluation
+    (2.56e7 scalar steps of the scan engine), which is pinned against the oracle at small sizes: 1e-9 relative."""
+    import temporalgps_jl_amd as tgp
+    from temporalgps_jl_amd import space_time
+    Nr, T = 256, 100_000
+    r, k, grid = _space_time(Nr, T)
+    rng = np.random.default_rng(5)
+    Y = rng.standard_normal((T, Nr)) * 0.7
+    dense = space_time.build_lgssm(k, grid, 0.1)
+    lp_dense = tgp.logpdf(dense, Y)
+    del dense
+    dec = space_time.DecoupledSpaceTime(k, grid, 0.1)
+    lp_dec = dec.logpdf(Y.reshape(-1))
+    assert abs(lp_dense - lp_dec) <= 1e-9 * abs(lp_dec), (lp_dense, lp_dec)
