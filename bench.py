@@ -9,8 +9,11 @@ series that is already resident in HBM (y is drawn from the model itself on the 
 bench/single_output_gps.jl:143-145 does on the CPU). value = whole-job Kalman steps / seconds-per-step.
 N > 1: ONE series is time-sharded, one contiguous segment per rank, with one all_gather of the tiny
 per-segment scan elements per scan direction plus one scalar all_reduce (RCCL via torch.distributed).
-Default scaling is WEAK: every GPU keeps the headline segment of --T = 1e7 points (the series has N * T points);
-`--scaling strong` keeps the total at --T (use --T 100000000 for BASELINE config 4).
+`--gpus N` without a torch.distributed environment re-launches itself under torch.distributed.run (one rank per GPU,
+rendezvous on 127.0.0.1). N > 1 defaults to BASELINE config 4: STRONG scaling of ONE T = 1e8, d = 4 series
+(`--scaling weak` keeps --T points per GPU instead; `--workload/--T` override the series).
+`--workload cfg5` runs BASELINE config 5 (Separable space-time, 256 spatial points, dense d = 768 / p = 256 recursion on the
+fp64 MFMA kernels; sequential in time: N > 1 means N independent replicas).
 Prints ONE JSON line (rank 0).
 """
 import argparse
@@ -219,35 +222,193 @@ def valu_utilisation(prof, d, layout):
     return out or None
 
 
+MFMA_F64_PEAK_TFS = 78.6     # MI355X datasheet fp64 matrix peak; v_mfma_f64_16x16x4_f64 measured at 64 cycles / SIMD = 77.7 TF/s (scripts/ubench_mfma_f64.hip)
+
+
+def respawn_under_torchrun(n):
+    """`python bench.py --gpus N` as the driver calls it: become `python -m torch.distributed.run ... bench.py <same args>`."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execv(sys.executable, cmd)
+
+
+def cfg5_cpu_baseline(Nr, sample_T):
+    """The oracle's literal restatement of the dense recursion (predict + posterior_and_lml(SmallOutputLGC), NumPy on the
+    host's BLAS threads) over a bounded number of steps of the same model."""
+    from oracle import components as oc
+    from oracle import lgssm_ref as ref
+    r = np.linspace(-3.0, 3.0, Nr)
+    model = oc.build_lgssm_separable(("se",), ("matern52",), r, ("regular", 0.0, 0.01, sample_T), 0.1)
+    Y = np.random.default_rng(0).standard_normal((sample_T, Nr))
+    ref.logpdf(dict(model, T=2), Y[:2])
+    t0 = time.perf_counter()
+    ref.logpdf(model, Y)
+    dt = time.perf_counter() - t0
+    return dict(value=sample_T / dt, unit="Kalman steps/s", cores=os.cpu_count(), kind="port",
+                sample=f"oracle/lgssm_ref.py (NumPy / BLAS, up to {os.cpu_count()} threads), same model, {sample_T} steps: {dt:.1f}s")
+
+
+def run_cfg5(args, torch, tgp, world, rank, local):
+    """BASELINE config 5: Separable(SE, Matern-5/2) on 256 spatial points x T regularly spaced times, sigma^2 = 0.1: the
+    reference's dense d = 768, p = 256 model (to_gauss_markov.jl:1-20), logpdf. One bench step = one logpdf pass."""
+    from temporalgps_jl_amd import lti_sde, space_time
+    Nr, T = 256, args.T
+    r = np.linspace(-3.0, 3.0, Nr)
+    k = space_time.Separable(space_time.SEKernel(), lti_sde.Matern52Kernel())
+    grid = space_time.RectilinearGrid(r, lti_sde.RegularSpacing(0.0, 0.01, T))
+    model = space_time.build_lgssm(k, grid, 0.1, device=local)
+    model.handle_options[tgp._lib.OPT_DENSE_STRUCTURE] = 0 if args.dense_products else 1
+    hd = model.handle()
+    gen = torch.Generator(device=f"cuda:{local}")
+    gen.manual_seed(5 + rank)
+    Y = torch.randn((T, Nr), dtype=torch.float64, device=f"cuda:{local}", generator=gen) * 0.7
+    for _ in range(args.warmup):
+        tgp.logpdf(model, Y)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        lp = tgp.logpdf(model, Y)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt_s = time.perf_counter() - t0
+    hd.set_option(tgp._lib.OPT_PROFILE, 1)
+    hd.profile_reset()
+    tgp.logpdf(model, Y)
+    hd.set_option(tgp._lib.OPT_PROFILE, 0)
+    prof = hd.profile()
+    if world > 1:
+        tmax = torch.tensor([dt_s], dtype=torch.float64, device=f"cuda:{local}")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt_s = float(tmax.item())
+    if rank != 0:
+        return
+    d, p = 3 * Nr, Nr
+    # algorithmic flops of the reference's dense step (SURVEY.md 8d): predict 2 x 2 d^3, update 2 p d^2 + 2 p^2 d + p^3 / 3 + p^2 d + 2 p d^2
+    flops = {"dk_gemm<A P>": 2.0 * d ** 3, "dk_gemm<(A P) A' + Q>": 2.0 * d ** 3, "dk_gemm<H Pp>": 2.0 * p * d * d,
+             "dk_gemm<V H' + R>": 2.0 * p * p * d, "dk_chol": p ** 3 / 3.0, "dk_trsm": 1.0 * p * p * d, "dk_gemm<Pp - B'B>": 2.0 * p * d * d}
+    step_flops = 2 * 2.0 * d ** 3 + 2.0 * p * d * d + 2.0 * p * p * d + p ** 3 / 3.0 + p * p * d + 2.0 * p * d * d
+    sec_per_step = dt_s / args.steps / T
+    kernels = {kn: dict(avg_us=v["total_ms"] / max(1, v["calls"]) * 1e3, calls=v["calls"],
+                        tflops=(flops[kn] / (v["total_ms"] / max(1, v["calls"]) * 1e-3) / 1e12) if kn in flops else None)
+               for kn, v in prof.items()}
+    dom = max(prof.items(), key=lambda kv: kv[1]["total_ms"] / max(1, kv[1]["calls"]))[0]
+    gemms = {kn: v for kn, v in kernels.items() if kn.startswith("dk_gemm")}
+    domg = max(gemms.items(), key=lambda kv: kv[1]["avg_us"])[0] if gemms else None
+    ach = step_flops / sec_per_step / 1e12
+    out = dict(
+        metric="Kalman steps/sec (logpdf), separable space-time 256 spatial x T, dense d=768 p=256", value=world * T / (dt_s / args.steps),
+        unit="Kalman steps/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=dt_s / args.steps * 1e3,
+        higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f64", data="synthetic",
+        config=dict(workload=f"cfg5: Separable(SE, Matern52), 256 spatial points x RegularSpacing(0,0.01,T={T}), sigma2_obs=0.1, "
+                             f"ArrayStorage-equivalent dense model d=768 p=256; one logpdf pass per step; "
+                             + ("dense A / H products (the reference's arithmetic)" if args.dense_products else "A = I (x) A_t, H = I (x) H_t applied in sparse form"),
+                    T=T, d=d, p=p, parallelism=f"replicas x{world} (sequential in time: the dense path does not time-shard)",
+                    us_per_kalman_step=sec_per_step * 1e6, logpdf=lp),
+        roofline=dict(bound="mfma", kernel="whole time step (kernel chain)", achieved=ach, peak=MFMA_F64_PEAK_TFS, unit="TFLOP/s", frac=ach / MFMA_F64_PEAK_TFS,
+                      traffic=None, algorithmic_flops_per_step=step_flops,
+                      note="algorithmic = the reference's dense step (2.57 GF); with the structured products the executed flops are ~0.76 GF per step",
+                      dominant_kernel=dom, dominant_kernel_avg_us=kernels[dom]["avg_us"], dominant_kernel_tflops=kernels[dom]["tflops"],
+                      dominant_gemm=domg, dominant_gemm_tflops=(gemms[domg]["tflops"] if domg else None),
+                      dominant_gemm_frac=(gemms[domg]["tflops"] / MFMA_F64_PEAK_TFS if domg else None)),
+        kernels=kernels)
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cfg5_cpu_baseline(Nr, 120)
+    print(json.dumps(out))
+
+
+def run_engine_factory(args, world, rank):
+    """Test hook (tests/test_bench_spawn.py): the N > 1 launch + sharding + collective path on a CPU box -- gloo backend, the
+    per-segment device work supplied by `module:function` (a host emulation). Never a measurement."""
+    import importlib
+    import torch.distributed as dist
+    from temporalgps_jl_amd import parallel
+    mod, fn = args.engine_factory.split(":")
+    if world == 1:   # a one-rank group: the engine interface always goes through the collectives
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    T = args.T
+    seg = parallel.segment_bounds(T, world, rank)
+    eng, y, Rnew = getattr(importlib.import_module(mod), fn)(args.workload, T, seg)
+    shard = parallel.ShardedLGSSM(None, world, rank, engine=eng)
+    for _ in range(args.warmup):
+        shard.logpdf(y)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        lp = shard.logpdf(y)
+        shard.posterior_marginals(y, Rnew)
+    if world > 1:
+        dist.barrier()
+    dt_s = time.perf_counter() - t0
+    if rank == 0:
+        print(json.dumps(dict(metric="(CPU test harness, not a measurement)", value=T / (dt_s / args.steps), unit="Kalman steps/s", n_gpus=world,
+                              steps=args.steps, warmup=args.warmup, ms_per_step=dt_s / args.steps * 1e3, higher_is_better=True,
+                              scaling=args.scaling, vs_baseline=None, dtype="f64", data="synthetic (host emulation engine)",
+                              config=dict(workload=args.workload, T=T, ranks=world, exchange=shard.transport, backend="gloo"), logpdf=lp)))
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--T", type=int, default=10_000_000)
-    ap.add_argument("--workload", default="matern52_d3", choices=list(WORKLOADS))
+    ap.add_argument("--T", type=int, default=None, help="series length (default: 1e7 on one GPU, 1e8 for the N > 1 strong-scaling series, 1e5 for cfg5)")
+    ap.add_argument("--workload", default=None, choices=list(WORKLOADS) + ["cfg5"])
     ap.add_argument("--layout", default="lti", choices=["lti", "per_step"])
     ap.add_argument("--chunk", type=int, default=0)
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-general-leg", action="store_true", help="skip the per-step-layout roofline leg")
+    ap.add_argument("--no-single-gpu-reference", action="store_true", help="N > 1 strong scaling: skip timing the whole series on rank 0 alone")
+    ap.add_argument("--dense-products", action="store_true", help="cfg5: the reference's dense A / H products (TGP_OPT_DENSE_STRUCTURE = 0)")
     ap.add_argument("--cpu-sample", type=int, default=2_000_000)
+    ap.add_argument("--engine-factory", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        respawn_under_torchrun(args.gpus)          # does not return
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # defaults: one GPU = the headline (cfg2); several GPUs = BASELINE config 4, strong scaling of one T = 1e8, d = 4 series
+    if args.workload is None:
+        args.workload = "matern52_d3" if world == 1 else "sum52_12_d4"
+    if args.scaling is None:
+        args.scaling = "weak" if (world == 1 or args.workload == "cfg5") else "strong"
+    if args.T is None:
+        args.T = 100_000 if args.workload == "cfg5" else (10_000_000 if (world == 1 or args.scaling == "weak") else 100_000_000)
+    if args.engine_factory:
+        return run_engine_factory(args, world, rank)
 
     import torch
     import temporalgps_jl_amd as tgp
     from temporalgps_jl_amd import parallel
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     torch.cuda.set_device(local)
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+    if args.workload == "cfg5":
+        run_cfg5(args, torch, tgp, world, rank, local)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     T, name = (args.T * world if args.scaling == "weak" else args.T), args.workload
     d = WORKLOADS[name][1]
 
@@ -327,13 +488,35 @@ def main():
             metric="Kalman steps/sec (logpdf + posterior marginals), T=10^7 Matern32 d=3",
             value=value, unit="Kalman steps/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step,
             higher_is_better=True, scaling=args.scaling, vs_baseline=None, dtype="f64", data="synthetic",
-            config=dict(workload=f"cfg2: {name}, RegularSpacing(0,0.1,T={T}), sigma2_obs=0.1, layout={args.layout}; one logpdf pass "
-                                 f"+ one posterior-marginals pass per step", T=T, T_per_gpu=Tseg, d=d, layout=args.layout,
+            config=dict(workload=f"{'cfg4' if (world > 1 and name == 'sum52_12_d4') else 'cfg2'}: {name}, RegularSpacing(0,0.1,T={T}), sigma2_obs=0.1, "
+                                 f"layout={args.layout}; one logpdf pass + one posterior-marginals pass per step", T=T, T_per_gpu=Tseg, d=d,
+                        layout=args.layout,
                         parallelism=f"time-shard x{world} ({args.scaling}: {'T per GPU fixed' if args.scaling == 'weak' else 'total T fixed'})",
-                        exchange=shard.transport),
+                        ranks=world, backend=("rccl" if world > 1 else "none"), exchange=shard.transport),
             roofline=roof,
             kernels={k: dict(avg_ms=v["total_ms"] / max(1, v["calls"]), calls=v["calls"]) for k, v in prof.items()},
         )
+        if world > 1 and args.scaling == "strong" and not args.no_single_gpu_reference:
+            # the SAME series on rank 0 alone (the other ranks idle): what the strong-scaling speed-up is measured against
+            try:
+                full = build_model(tgp, name, T, args.layout, local)
+                yf = torch.randn((T,), dtype=torch.float64, device=f"cuda:{local}")
+                for _ in range(2):
+                    tgp.logpdf(full, yf)
+                    tgp.posterior_marginals(full, yf, Rnew)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                n1 = max(2, args.steps // 4)
+                for _ in range(n1):
+                    tgp.logpdf(full, yf)
+                    tgp.posterior_marginals(full, yf, Rnew)
+                torch.cuda.synchronize()
+                one = T / ((time.perf_counter() - t1) / n1)
+                out["single_gpu_reference"] = dict(value=one, unit="Kalman steps/s", speedup=value / one,
+                                                   note="the whole T-point series on rank 0 alone, same process, same kernels")
+                del full, yf
+            except Exception as ex:      # noqa: BLE001 -- e.g. the whole series does not fit one GPU
+                out["single_gpu_reference"] = dict(error=repr(ex))
         if T == 10_000_000 and world == 1 and d == 3 and not args.chunk:
             out["valu"] = valu_utilisation(prof, d, args.layout)
         if world == 1 and not args.no_general_leg:
