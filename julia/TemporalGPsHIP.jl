@@ -54,6 +54,7 @@ struct DeviceLGSSM{Tord} <: AbstractLGSSM
     bufs::NamedTuple      # A, a, Q, H, hh, R :: Vector{Float64}; keeps the host copies alive
     flags::UInt32
     x0::Gaussian
+    device::Int           # the GPU this model lives on: every model derived from it stays there
 end
 
 Base.length(m::DeviceLGSSM) = m.T
@@ -85,7 +86,7 @@ function DeviceLGSSM(ord, As, as, Qs, Hs, hs, Σs, x0::Gaussian, device::Int)
              Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
             h.ptr, T, d, 1, ord isa Forward ? 0 : 1, flags, A, a, Q, H, hh, R, x0m, x0P))
     end
-    return DeviceLGSSM(ord, h, T, d, (; A, a, Q, H, hh, R), flags, x0)
+    return DeviceLGSSM(ord, h, T, d, (; A, a, Q, H, hh, R), flags, x0, device)
 end
 
 # The one method that selects the backend: components are built by the reference's own host code
@@ -95,10 +96,12 @@ function TemporalGPs.build_lgssm(f::LTISDE{<:GP,<:HIPStorage}, x::AbstractVector
     return DeviceLGSSM(Forward(), As, as, Qs, Hs, hs, Σys, x0, f.storage.device)
 end
 
-_split_missing(y::AbstractVector{<:Real}) = (collect(Float64, y), C_NULL, nothing)
+# (values, what to hand to ccall for the `missing` argument, the array to GC.@preserve). The mask ARRAY is passed to ccall
+# (converted to Ptr{UInt8} inside the preserved region), never a raw pointer taken outside it.
+_split_missing(y::AbstractVector{<:Real}) = (collect(Float64, y), Ptr{UInt8}(C_NULL), nothing)
 function _split_missing(y::AbstractVector{Union{Missing,T}}) where {T<:Real}
     mask = UInt8.(ismissing.(y))
-    return (Float64[ismissing(v) ? 0.0 : v for v in y], pointer(mask), mask)
+    return (Float64[ismissing(v) ? 0.0 : v for v in y], mask, mask)
 end
 
 function AbstractGPs.logpdf(m::DeviceLGSSM, y::AbstractVector{<:Union{Missing,Real}})
@@ -119,9 +122,49 @@ function TemporalGPs._filter(m::DeviceLGSSM, y::AbstractVector)
     return [Gaussian(ms[:, t], Ps[:, :, t]) for t in 1:m.T]
 end
 
+"""`posterior(model, ys)` on this backend is LAZY. The reference's unchanged callers (posterior_lti_sde.jl:27-36, :50-58, :62-78)
+chain `replace_observation_noise_cov(posterior(model, ys), Σs_new)` into `marginals` / `rand` / `logpdf`;
+`replace_observation_noise_cov` on a DevicePosterior only records Σs_new, and `marginals` of the result is ONE fused
+filter + RTS smoother call (`tgp_posterior_marginals`): nothing of size T x (2 d^2 + d) crosses PCIe. `rand`, `logpdf`,
+`_filter`, `getindex`-style access evaluate the reverse-time model once (`tgp_posterior`) on the SAME device."""
+mutable struct DevicePosterior <: AbstractLGSSM
+    prior::DeviceLGSSM{Forward}
+    y::AbstractVector
+    Σs_new::Union{Nothing,AbstractVector}
+    model::Union{Nothing,DeviceLGSSM{Reverse}}
+end
+
 function TemporalGPs.posterior(m::DeviceLGSSM{Forward}, y::AbstractVector)
     length(m) == length(y) || throw(error("Dimension mismatch. length(prior) is $(length(m)), but length(y) is $(length(y))"))
-    yv, mp, mask = _split_missing(y)
+    return DevicePosterior(m, y, nothing, nothing)
+end
+
+Base.length(p::DevicePosterior) = p.prior.T
+Base.eachindex(p::DevicePosterior) = reverse(1:p.prior.T)
+TemporalGPs.ordering(::DevicePosterior) = Reverse()
+TemporalGPs.storage_type(::DevicePosterior) = HIPStorage(Float64)
+TemporalGPs.x0(p::DevicePosterior) = materialise(p).x0
+
+TemporalGPs.replace_observation_noise_cov(p::DevicePosterior, Σs_new::AbstractVector) =
+    p.model === nothing ? DevicePosterior(p.prior, p.y, Σs_new, nothing) : replace_observation_noise_cov(p.model, Σs_new)
+
+_prior_noise(m::DeviceLGSSM) = m.flags & SHARED_R != 0 ? Fill(m.bufs.R[1], m.T) : m.bufs.R
+
+function AbstractGPs.marginals(p::DevicePosterior)
+    p.model === nothing || return marginals(p.model)
+    mean, var = posterior_marginals(p.prior, p.y, p.Σs_new === nothing ? _prior_noise(p.prior) : p.Σs_new)
+    return [Gaussian(mean[t], var[t]) for t in 1:p.prior.T]
+end
+AbstractGPs.rand(rng::AbstractRNG, p::DevicePosterior) = rand(rng, materialise(p))
+AbstractGPs.logpdf(p::DevicePosterior, y::AbstractVector{<:Union{Missing,Real}}) = logpdf(materialise(p), y)
+TemporalGPs._filter(p::DevicePosterior, y::AbstractVector) = _filter(materialise(p), y)
+
+"""Evaluate the reverse-time model (lgssm.jl:193-238) once, on the prior's device."""
+function materialise(p::DevicePosterior)
+    p.model === nothing || return p.model
+    m = p.prior
+    haskey(m.bufs, :A) || error("posterior of an SDE-described model: only marginals(replace_observation_noise_cov(posterior(m, y), Σ)) is available (the per-step A_k, Q_k exist on the device only)")
+    yv, mp, mask = _split_missing(p.y)
     G, g, L = Array{Float64,3}(undef, m.d, m.d, m.T), Matrix{Float64}(undef, m.d, m.T), Array{Float64,3}(undef, m.d, m.d, m.T)
     xfm, xfP = Vector{Float64}(undef, m.d), Matrix{Float64}(undef, m.d, m.d)
     GC.@preserve yv mask check(m.h, ccall((:tgp_posterior, libtgp), Cint,
@@ -130,18 +173,23 @@ function TemporalGPs.posterior(m::DeviceLGSSM{Forward}, y::AbstractVector)
     Gs, gs, Ls = [G[:, :, t] for t in 1:m.T], [g[:, t] for t in 1:m.T], [L[:, :, t] for t in 1:m.T]
     Hs = m.flags & SHARED_H != 0 ? Fill(m.bufs.H, m.T) : [m.bufs.H[(t-1)*m.d+1:t*m.d] for t in 1:m.T]
     hs = m.flags & SHARED_h != 0 ? Fill(m.bufs.hh[1], m.T) : m.bufs.hh
-    Rs = m.flags & SHARED_R != 0 ? Fill(m.bufs.R[1], m.T) : m.bufs.R
-    return DeviceLGSSM(Reverse(), Gs, gs, Ls, Hs, hs, Rs, Gaussian(xfm, xfP), 0)
+    Rs = p.Σs_new === nothing ? _prior_noise(m) : p.Σs_new
+    p.model = DeviceLGSSM(Reverse(), Gs, gs, Ls, Hs, hs, Rs, Gaussian(xfm, xfP), m.device)
+    return p.model
 end
 
 function TemporalGPs.replace_observation_noise_cov(m::DeviceLGSSM, Σs_new::AbstractVector)
-    # re-bind the model with the new noise; the transition blocks are reused as they are
+    # re-bind the model with the new noise ON THE SAME DEVICE; the transition blocks are reused as they are
     d, T = m.d, m.T
+    if haskey(m.bufs, :F)      # SDE-described transitions: re-describe them, the device rebuilds A_k, Q_k
+        return DeviceLGSSM_sde(reshape(m.bufs.F, d, d), m.bufs.a, m.bufs.H, m.bufs.hh[1], Σs_new, m.bufs.times,
+                               reshape(m.bufs.A1, d, d), reshape(m.bufs.Q1, d, d), m.x0, m.device)
+    end
     blk(v, n, shared) = shared ? Fill(v[1:n], T) : [v[(t-1)*n+1:t*n] for t in 1:T]
     mat(v, shared) = shared ? Fill(reshape(v[1:d*d], d, d), T) : [reshape(v[(t-1)*d*d+1:t*d*d], d, d) for t in 1:T]
     return DeviceLGSSM(m.ordering, mat(m.bufs.A, m.flags & SHARED_A != 0), blk(m.bufs.a, d, m.flags & SHARED_a != 0),
         mat(m.bufs.Q, m.flags & SHARED_Q != 0), blk(m.bufs.H, d, m.flags & SHARED_H != 0),
-        m.flags & SHARED_h != 0 ? Fill(m.bufs.hh[1], T) : m.bufs.hh, Σs_new, m.x0, 0)
+        m.flags & SHARED_h != 0 ? Fill(m.bufs.hh[1], T) : m.bufs.hh, Σs_new, m.x0, m.device)
 end
 
 function AbstractGPs.marginals(m::DeviceLGSSM)
@@ -161,8 +209,8 @@ function AbstractGPs.rand(rng::AbstractRNG, m::DeviceLGSSM)
     return y
 end
 
-"""Fused `marginals(replace_observation_noise_cov(posterior(model, y), Σs_new))` (posterior_lti_sde.jl:27-36):
-nothing is materialised on the host."""
+"""Fused `marginals(replace_observation_noise_cov(posterior(model, y), Σs_new))` (posterior_lti_sde.jl:27-36): nothing is
+materialised on the host. The reference's unchanged caller reaches it through DevicePosterior (above)."""
 function posterior_marginals(m::DeviceLGSSM{Forward}, y::AbstractVector, Σs_new::AbstractVector{<:Real})
     yv, mp, mask = _split_missing(y)
     R, fl = Σs_new isa Fill ? ([Float64(first(Σs_new))], SHARED_R) : (collect(Float64, Σs_new), UInt32(0))
@@ -205,7 +253,7 @@ function DeviceLGSSM_sde(F, a, H, hh, Σs, times::AbstractVector{<:Real}, A1, Q1
              Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
             h.ptr, T, d, 0, flags, Fv, av, Hv, hv, R, tv, A1v, Q1v, x0m, x0P))
     end
-    return DeviceLGSSM(Forward(), h, T, d, (; F = Fv, a = av, H = Hv, hh = hv, R, times = tv), flags, x0)
+    return DeviceLGSSM(Forward(), h, T, d, (; F = Fv, a = av, H = Hv, hh = hv, R, times = tv, A1 = A1v, Q1 = Q1v), flags, x0, device)
 end
 
 """Posterior marginals through other emissions (tgp_posterior_marginals_at): the fast path of

@@ -4,8 +4,8 @@ Import as `import temporalgps_jl_amd as tgp` (the directory name contains a dot,
 one-file import shim `temporalgps_jl_amd.py`).
 """
 from . import _lib
-from .lgssm import (LGSSM, Forward, Gaussian, GaussMarkovModel, Reverse, ScalarOutputLGC, SmallOutputLGC, LargeOutputLGC, BottleneckLGC, _filter, logpdf, marginals,
+from .lgssm import (LGSSM, PosteriorLGSSM, Forward, Gaussian, GaussMarkovModel, Reverse, ScalarOutputLGC, SmallOutputLGC, LargeOutputLGC, BottleneckLGC, _filter, logpdf, marginals,
                     posterior, posterior_marginals, posterior_marginals_at, rand, replace_observation_noise_cov)
 
-__all__ = ["LGSSM", "Forward", "Reverse", "Gaussian", "GaussMarkovModel", "ScalarOutputLGC", "SmallOutputLGC", "LargeOutputLGC", "BottleneckLGC", "logpdf", "_filter",
+__all__ = ["LGSSM", "PosteriorLGSSM", "Forward", "Reverse", "Gaussian", "GaussMarkovModel", "ScalarOutputLGC", "SmallOutputLGC", "LargeOutputLGC", "BottleneckLGC", "logpdf", "_filter",
            "posterior", "marginals", "posterior_marginals", "posterior_marginals_at", "rand", "replace_observation_noise_cov", "_lib"]

@@ -298,8 +298,26 @@ def _obs(y, model=None):
     mask = None
     if isinstance(y, tuple):
         y, mask = y
-    if model is not None and model.p > 1 and not (_is_torch(y) and y.is_cuda):
+    if model is not None and model._whiten is not None and _is_torch(y) and y.is_cuda:
+        # dense observation noise, observations on the device: whiten there (y <- L^-1 y), whole-step masks only
+        import torch
+        yy = y.to(torch.float64).reshape(model.T, model.p)
+        mm = None if mask is None else mask.to(torch.bool)
+        if mm is not None and mm.ndim == 2:
+            if not bool(torch.all(mm.all(dim=1) | ~mm.any(dim=1))):
+                raise TypeError("per-element missing observations need Diagonal noise (MethodError at lgc.jl:146)")
+            mm = mm.all(dim=1)
+        if mm is not None:
+            yy = torch.where(mm[:, None], torch.zeros_like(yy), yy)
+        Linv = torch.as_tensor(model._whiten[0], device=yy.device)
+        yy = torch.matmul(Linv, yy[..., None])[..., 0].contiguous()
+        mk = None if mm is None else mm[:, None].expand(model.T, model.p).to(torch.uint8).contiguous()
+        _sync_torch(yy)
+        return (yy if model.p > 1 else yy.reshape(model.T)), (mk if (mk is None or model.p > 1) else mk.reshape(model.T)), True
+    if model is not None and (model.p > 1 or model._whiten is not None) and not (_is_torch(y) and y.is_cuda):
         yy = np.array(_to_numpy(y), dtype=np.float64)
+        if model.p == 1 and yy.shape == (model.T,):
+            yy = yy[:, None]
         if yy.shape != (model.T, model.p):
             raise ValueError(f"y must have shape ({model.T}, {model.p})")
         mk = np.isnan(yy) if mask is None else np.asarray(_to_numpy(mask), dtype=bool)
@@ -311,6 +329,8 @@ def _obs(y, model=None):
             Linv = model._whiten[0]
             yy = (Linv @ np.where(mk, 0.0, yy)[..., None])[..., 0]
         yy = np.ascontiguousarray(np.where(mk, 0.0, yy))
+        if model.p == 1:
+            yy, mk = yy.reshape(model.T), mk.reshape(model.T)
         return yy, (np.ascontiguousarray(mk.astype(np.uint8)) if mk.any() else None), False
     if _is_torch(y) and y.is_cuda:
         import torch
@@ -337,6 +357,8 @@ def _out(model, shape, like_device):
 
 def logpdf(model, y):
     """lgssm.jl:147-151 (+ missings.jl:8-13)."""
+    if isinstance(model, PosteriorLGSSM):
+        model = model.materialise()
     _check_inputs(model, y[0] if isinstance(y, tuple) else y)
     hd = model.handle()
     yy, mm, dev = _obs(y, model)
@@ -404,6 +426,8 @@ def logpdf_and_grad_sde(model, y, tangents, rel_step=1e-6):
 
 def _filter(model, y):
     """lgssm.jl:171-173: filtering distributions, returned as (means (T,d), covs (T,d,d))."""
+    if isinstance(model, PosteriorLGSSM):
+        model = model.materialise()
     _check_inputs(model, y[0] if isinstance(y, tuple) else y)
     hd = model.handle()
     yy, mm, dev = _obs(y, model)
@@ -414,9 +438,8 @@ def _filter(model, y):
     return m, P   # P blocks are symmetric, so the column-major blocks read correctly as row-major
 
 
-def posterior(model, y):
-    """lgssm.jl:193-200: the posterior LGSSM (opposite ordering, transitions (G, g, L), x0 = final filtering state)."""
-    _check_inputs(model, y[0] if isinstance(y, tuple) else y)
+def _materialise_posterior(model, y):
+    """lgssm.jl:193-200 evaluated: the posterior LGSSM (opposite ordering, transitions (G, g, L), x0 = final filtering state)."""
     hd = model.handle()
     yy, mm, dev = _obs(y, model)
     T, d = model.T, model.dim
@@ -430,8 +453,91 @@ def posterior(model, y):
     return LGSSM(trans, model.emissions, T=T, device=model.device)
 
 
+class PosteriorLGSSM:
+    """What `posterior(prior, y)` returns: the posterior LGSSM of lgssm.jl:193-200, NOT YET EVALUATED. The reference's callers
+    (posterior_lti_sde.jl:27-36, :50-58, :62-78) chain
+
+        replace_observation_noise_cov(posterior(model, ys), S_new)  ->  marginals(.) | rand(rng, .) | logpdf(., ys_pr)
+
+    `replace_observation_noise_cov` on this object only records the new noise, and `marginals` of the result runs the fused
+    filter + RTS smoother (tgp_posterior_marginals: nothing of size T x (2 d^2 + d) is ever written). Anything else that
+    looks inside -- transitions, x0, rand, logpdf, _filter, a further posterior -- evaluates the reverse-time model once
+    (tgp_posterior) and then behaves as the plain LGSSM it stands for."""
+
+    def __init__(self, prior, y, R_new=None):
+        self._prior, self._y, self._R_new, self._model = prior, y, R_new, None
+        self.T, self.device = prior.T, prior.device
+
+    # -- lazy surface ------------------------------------------------------------------------------------
+    @property
+    def ordering(self):
+        return reverse(self._prior.ordering)
+
+    @property
+    def p(self):
+        return self._prior.p
+
+    @property
+    def dim(self):
+        return self._prior.dim
+
+    def __len__(self):
+        return self.T
+
+    def _emissions(self):
+        em = self._prior.emissions
+        if self._R_new is None:
+            return em
+        if isinstance(em, SmallOutputLGC):
+            R = self._R_new if _is_torch(self._R_new) else np.asarray(self._R_new, dtype=np.float64)
+            return SmallOutputLGC(em.H, em.h, R[None] if R.ndim == 1 else R)
+        R = self._R_new if _is_torch(self._R_new) else np.atleast_1d(np.asarray(self._R_new, dtype=np.float64))
+        return ScalarOutputLGC(em.H, em.h, R)
+
+    @property
+    def emissions(self):
+        return self._emissions()
+
+    # -- evaluation --------------------------------------------------------------------------------------
+    def materialise(self):
+        if self._model is None:
+            post = _materialise_posterior(self._prior, self._y)
+            self._model = LGSSM(post.transitions, self._emissions(), T=self.T, device=self.device)
+        return self._model
+
+    def __getattr__(self, name):            # transitions, x0, handle, _whiten, handle_options, ...
+        if name.startswith("__"):
+            raise AttributeError(name)
+        return getattr(self.materialise(), name)
+
+    def fused_marginals(self):
+        """marginals(self) without evaluating the posterior model; None when only the evaluated route exists."""
+        if self._model is not None:
+            return None
+        em = self._emissions()
+        if isinstance(em, SmallOutputLGC) and em.dense:
+            return None
+        try:
+            return posterior_marginals(self._prior, self._y, em.R)
+        except (_lib.Unsupported, NotImplementedError):
+            return None
+
+
+def posterior(model, y):
+    """lgssm.jl:193-200: the posterior LGSSM (opposite ordering, transitions (G, g, L), x0 = final filtering state),
+    returned unevaluated (PosteriorLGSSM)."""
+    _check_inputs(model, y[0] if isinstance(y, tuple) else y)
+    if isinstance(model, PosteriorLGSSM):
+        model = model.materialise()
+    return PosteriorLGSSM(model, y)
+
+
 def replace_observation_noise_cov(model, R_new):
     """missings.jl:35-41. Vector observations: R_new (T|1, p) diagonal or (T|1, p, p) dense."""
+    if isinstance(model, PosteriorLGSSM) and model._model is None:
+        return PosteriorLGSSM(model._prior, model._y, R_new)
+    if isinstance(model, PosteriorLGSSM):
+        model = model.materialise()
     em = model.emissions
     if isinstance(em, SmallOutputLGC):
         R = R_new if _is_torch(R_new) else np.asarray(R_new, dtype=np.float64)
@@ -453,7 +559,13 @@ def _need_diag(model, what):
 
 
 def marginals(model):
-    """lgssm.jl:99-115: emission marginals of the model as given, returned as (mean (T,), var (T,))."""
+    """lgssm.jl:99-115: emission marginals of the model as given, returned as (mean (T,), var (T,)). On an unevaluated
+    posterior this is the fused filter + RTS smoother (posterior_lti_sde.jl:27-36)."""
+    if isinstance(model, PosteriorLGSSM):
+        out = model.fused_marginals()
+        if out is not None:
+            return out
+        model = model.materialise()
     _need_diag(model, "marginals")
     hd = model.handle()
     dev = model._on_device
@@ -465,6 +577,8 @@ def marginals(model):
 def posterior_marginals(model, y, R_new):
     """marginals(replace_observation_noise_cov(posterior(model, y), R_new)) without materialising the
     posterior model -- the `marginals(posterior(fx, y)(x))` path (posterior_lti_sde.jl:27-36)."""
+    if isinstance(model, PosteriorLGSSM):
+        model = model.materialise()
     _check_inputs(model, y[0] if isinstance(y, tuple) else y)
     _need_diag(model, "posterior_marginals")
     hd = model.handle()
@@ -496,6 +610,8 @@ def posterior_marginals_at(model, y, H_new, h_new, R_new):
     by giving the posterior model other emissions (pseudo_point.jl:198-235) -- here without materialising that model
     (tgp_posterior_marginals_at). H_new (pn, d), h_new (pn,), R_new (T|1, pn) diagonal noise. Host arrays.
     Raises `_lib.Unsupported` where only the materialised route exists (d < 5, per-step transitions, Reverse models)."""
+    if isinstance(model, PosteriorLGSSM):
+        model = model.materialise()
     _check_inputs(model, y[0] if isinstance(y, tuple) else y)
     hd = model.handle()
     yy, mm, dev = _obs(y, model)
@@ -518,12 +634,16 @@ def posterior_marginals_at(model, y, H_new, h_new, R_new):
 def ε_randn(rng, model):
     """lgssm.jl:72-77: all the randomness one sample needs, drawn up front in the reference's order
     (T transition vectors, then T emission scalars; x0's draw comes after, lgssm.jl:67)."""
+    if isinstance(model, PosteriorLGSSM):
+        model = model.materialise()
     T, d = model.T, model.dim
     return rng.standard_normal((T, d)), rng.standard_normal(_osh(model))
 
 
 def rand(rng_or_eps, model):
     """lgssm.jl:65-69. `rng_or_eps` is a numpy Generator, or the explicit (eps_t (T,d), eps_e (T,), eps_0 (d,))."""
+    if isinstance(model, PosteriorLGSSM):
+        model = model.materialise()
     if isinstance(rng_or_eps, tuple):
         eps_t, eps_e, eps_0 = rng_or_eps
     else:

@@ -500,14 +500,17 @@ class FinitePosteriorLTISDE:
 
     def _mean_and_var(self):
         d = self.f.data
-        if _same_inputs(self.x, d["x"]):             # posterior_lti_sde.jl:27-36 -- the benchmarked path
+        # the reference's own call chain (posterior_lti_sde.jl:18-36): posterior(model, ys) is lazy on this backend and
+        # replace_observation_noise_cov only records the new noise, so marginals(...) is ONE fused filter + RTS smoother
+        if _same_inputs(self.x, d["x"]):             # :27-36 -- the benchmarked path
             model = self._posterior_model(d["x"], d["sigma2"], d["y"])
-            return L.posterior_marginals(model, d["y"], _noise(self.sigma2, len(self.x)) if len(self.sigma2) > 1 else self.sigma2)
+            S_new = _noise(self.sigma2, len(self.x)) if len(self.sigma2) > 1 else self.sigma2
+            return L.marginals(L.replace_observation_noise_cov(L.posterior(model, d["y"]), S_new))
         npr = len(self.x)
         x, S, y, _, pr = self._merge(np.full(npr, self.LARGE_VAR))
         s_full = np.zeros(len(x))
         s_full[pr] = _noise(self.sigma2, npr)        # build_prediction_obs_vars :136-144
-        m, v = L.posterior_marginals(self._posterior_model(x, S, y), y, s_full)
+        m, v = L.marginals(L.replace_observation_noise_cov(L.posterior(self._posterior_model(x, S, y), y), s_full))
         return m[pr], v[pr]
 
     def _rand(self, rng):

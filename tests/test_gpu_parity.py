@@ -168,8 +168,8 @@ def test_errors(tgp):
     with pytest.raises(tgp._lib.NotPositiveDefinite):
         tgp.logpdf(to_device_model(tgp, bad), rng.standard_normal(10))
     rev = dict(model, ordering="R")
-    with pytest.raises(tgp._lib.TGPError):                            # documented as unsupported
-        tgp.posterior(to_device_model(tgp, rev), np.zeros(10))
+    with pytest.raises(tgp._lib.TGPError):                            # documented as unsupported (raised when the lazy posterior is evaluated)
+        tgp.posterior(to_device_model(tgp, rev), np.zeros(10)).materialise()
 
 
 @pytest.mark.parametrize("kname,T", [("matern32", 1_000_000), ("matern52", 1_000_000)])
@@ -305,3 +305,35 @@ def test_all_missing_equals_prior(tgp):
     mm, mC = ref.marginals(ref.replace_observation_noise_cov(model, Rn))
     np.testing.assert_allclose(pm, mm, rtol=1e-7, atol=1e-8)
     np.testing.assert_allclose(pv, mC, rtol=1e-7, atol=1e-8)
+
+
+def test_reference_call_chain_runs_the_fused_smoother(tgp):
+    """posterior_lti_sde.jl:27-36 unchanged: marginals(replace_observation_noise_cov(posterior(model, ys), S_new)). On this
+    backend posterior() is lazy and replace_observation_noise_cov only records S_new, so the chain launches exactly the
+    kernels of the fused tgp_posterior_marginals call -- no materialise pass, no T x (2 d^2 + d) transfer."""
+    model, y, _ = U.gp_case(("matern52",), ("regular", 0.0, 0.1, 5000), 0.1, seed=11)
+    dm = to_device_model(tgp, model)
+    hd = dm.handle()
+    Rn = np.full(1, 1e-18)
+
+    def kernels(fn):
+        hd.set_option(tgp._lib.OPT_PROFILE, 1)
+        hd.profile_reset()
+        out = fn()
+        prof = hd.profile()
+        hd.set_option(tgp._lib.OPT_PROFILE, 0)
+        return out, {k: v["calls"] for k, v in prof.items()}
+
+    (m1, v1), k1 = kernels(lambda: tgp.posterior_marginals(dm, y, Rn))
+    (m2, v2), k2 = kernels(lambda: tgp.marginals(tgp.replace_observation_noise_cov(tgp.posterior(dm, y), Rn)))
+    assert k1 == k2 and not any("materialise" in k for k in k2), (k1, k2)
+    np.testing.assert_array_equal(m1, m2)
+    np.testing.assert_array_equal(v1, v2)
+    # without a replacement the posterior keeps the prior's noise (missings.jl:35-41 never called)
+    pm, pv = ref.marginals(ref.posterior(model, y))
+    gm, gv = tgp.marginals(tgp.posterior(dm, y))
+    np.testing.assert_allclose(gm, pm, rtol=1e-8, atol=1e-8)
+    np.testing.assert_allclose(gv, pv, rtol=1e-8, atol=1e-9)
+    # anything that looks inside evaluates the reverse-time model once, and the result is a plain LGSSM
+    post = tgp.posterior(dm, y)
+    assert post.transitions.As.shape == (5000, 3, 3) and post.ordering is tgp.Reverse

@@ -98,3 +98,37 @@ def test_vector_obs_missing(tgp, per_element):
     m, P = tgp._filter(dm, ym)
     np.testing.assert_allclose(m, fm, rtol=1e-8, atol=1e-9)
     np.testing.assert_allclose(P, fP, rtol=1e-8, atol=1e-9)
+
+
+def test_small_output_p1_dense_noise_is_whitened(tgp):
+    """A SmallOutputLGC with ONE output and a 1 x 1 dense noise matrix: handle() whitens H, h and R, so y must be whitened as
+    well (it was not: logpdf / _filter were silently wrong for this input)."""
+    rng = np.random.default_rng(5)
+    T, d, p = 300, 3, 1
+    model = U.random_lgssm_small(rng, False, d, p, T, dense_R=True)
+    y = rng.standard_normal((T, p))
+    dm = to_device(tgp, model, diag=False)
+    lp = ref.logpdf(model, y)
+    assert abs(tgp.logpdf(dm, y) - lp) <= 1e-10 * abs(lp)
+    assert abs(tgp.logpdf(dm, y[:, 0]) - lp) <= 1e-10 * abs(lp)
+    fm, fP = ref.filter_(model, y)
+    m, P = tgp._filter(dm, y)
+    np.testing.assert_allclose(m, fm, rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(P, fP, rtol=1e-8, atol=1e-9)
+
+
+def test_dense_noise_with_observations_on_the_device(tgp):
+    """The same whitening when y is a CUDA tensor (it was skipped there too)."""
+    import torch
+    rng = np.random.default_rng(6)
+    T, d, p = 200, 3, 3
+    model = U.random_lgssm_small(rng, True, d, p, T, dense_R=True)
+    y = rng.standard_normal((T, p))
+    dm = to_device(tgp, model, diag=False)
+    lp = ref.logpdf(model, y)
+    yd = torch.as_tensor(y, device="cuda:0")
+    assert abs(tgp.logpdf(dm, yd) - lp) <= 1e-10 * abs(lp)
+    missing = rng.random(T) < 0.2
+    lpm = ref.logpdf_missing(model, y, missing)
+    md = torch.as_tensor(np.repeat(missing[:, None], p, axis=1), device="cuda:0")
+    assert abs(tgp.logpdf(dm, (yd, md)) - lpm) <= 1e-10 * abs(lpm)
