@@ -374,6 +374,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-general-leg", action="store_true", help="skip the per-step-layout roofline leg")
     ap.add_argument("--no-single-gpu-reference", action="store_true", help="N > 1 strong scaling: skip timing the whole series on rank 0 alone")
+    ap.add_argument("--separate-calls", action="store_true", help="a step = logpdf(...) then posterior_marginals(...) as two independent calls "
+                    "(the forward filter runs twice) instead of the combined entry point")
     ap.add_argument("--dense-products", action="store_true", help="cfg5: the reference's dense A / H products (TGP_OPT_DENSE_STRUCTURE = 0)")
     ap.add_argument("--cpu-sample", type=int, default=2_000_000)
     ap.add_argument("--engine-factory", default=None, help=argparse.SUPPRESS)
@@ -430,9 +432,13 @@ def main():
     shard = parallel.ShardedLGSSM(model, world, rank)
 
     def step():
-        lp = shard.logpdf(y)
-        mean, var = shard.posterior_marginals(y, Rnew)
-        return lp, mean, var
+        # logpdf(fx, y) and marginals(posterior(fx, y)(x)) of the same series: one forward filter + RTS smoother delivers
+        # both (tgp_logpdf_and_posterior_marginals); --separate-calls issues the reference's two independent calls instead
+        if args.separate_calls:
+            lp = shard.logpdf(y)
+            mean, var = shard.posterior_marginals(y, Rnew)
+            return lp, mean, var
+        return shard.logpdf_and_posterior_marginals(y, Rnew)
 
     for _ in range(args.warmup):
         step()
@@ -489,7 +495,9 @@ def main():
             value=value, unit="Kalman steps/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step,
             higher_is_better=True, scaling=args.scaling, vs_baseline=None, dtype="f64", data="synthetic",
             config=dict(workload=f"{'cfg4' if (world > 1 and name == 'sum52_12_d4') else 'cfg2'}: {name}, RegularSpacing(0,0.1,T={T}), sigma2_obs=0.1, "
-                                 f"layout={args.layout}; one logpdf pass + one posterior-marginals pass per step", T=T, T_per_gpu=Tseg, d=d,
+                                 f"layout={args.layout}; per step: logpdf AND posterior marginals of the series "
+                                 + ("(two independent calls)" if args.separate_calls else "(one combined call: tgp_logpdf_and_posterior_marginals)"),
+                        T=T, T_per_gpu=Tseg, d=d, calls=("separate" if args.separate_calls else "combined"),
                         layout=args.layout,
                         parallelism=f"time-shard x{world} ({args.scaling}: {'T per GPU fixed' if args.scaling == 'weak' else 'total T fixed'})",
                         ranks=world, backend=("rccl" if world > 1 else "none"), exchange=shard.transport),

@@ -153,6 +153,13 @@ int tgp_posterior(tgp_handle* h, const double* y, const uint8_t* missing, uint32
 int tgp_posterior_marginals(tgp_handle* h, const double* y, const uint8_t* missing, const double* Rnew,
                             uint32_t flags, double* mean_out, double* var_out, double* lml_out);
 
+/* ---- logpdf(model, y) AND marginals(replace_observation_noise_cov(posterior(model, y), Rnew)) of the same (model, y) in ONE
+ *      forward filter + RTS smoother: the log marginal likelihood is a by-product of the filter that the posterior needs anyway
+ *      (lgssm.jl:147-165 and :193-238 run the same predict / posterior_and_lml recursion), so a caller that wants both -- model
+ *      fitting followed by prediction at the training inputs, the benchmarked pair -- pays for one pass 1 / pass 2, not two. */
+int tgp_logpdf_and_posterior_marginals(tgp_handle* h, const double* y, const uint8_t* missing, const double* Rnew, uint32_t flags,
+                                       double* lml_out, double* mean_out, double* var_out);
+
 /* ---- posterior marginals through an ALTERNATIVE emission block: N(Hn x_t + hn, Hn P_t Hn' + Rn) under the smoothed
  *      state, pn functionals per time step that are not the model's observations -- what the reference gets by swapping
  *      the emissions of the posterior model (space_time/pseudo_point.jl:198-235 approx_posterior_marginals, and

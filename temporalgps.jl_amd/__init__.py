@@ -5,7 +5,7 @@ one-file import shim `temporalgps_jl_amd.py`).
 """
 from . import _lib
 from .lgssm import (LGSSM, PosteriorLGSSM, Forward, Gaussian, GaussMarkovModel, Reverse, ScalarOutputLGC, SmallOutputLGC, LargeOutputLGC, BottleneckLGC, _filter, logpdf, marginals,
-                    posterior, posterior_marginals, posterior_marginals_at, rand, replace_observation_noise_cov)
+                    posterior, posterior_marginals, logpdf_and_posterior_marginals, posterior_marginals_at, rand, replace_observation_noise_cov)
 
 __all__ = ["LGSSM", "PosteriorLGSSM", "Forward", "Reverse", "Gaussian", "GaussMarkovModel", "ScalarOutputLGC", "SmallOutputLGC", "LargeOutputLGC", "BottleneckLGC", "logpdf", "_filter",
-           "posterior", "marginals", "posterior_marginals", "posterior_marginals_at", "rand", "replace_observation_noise_cov", "_lib"]
+           "posterior", "marginals", "posterior_marginals", "logpdf_and_posterior_marginals", "posterior_marginals_at", "rand", "replace_observation_noise_cov", "_lib"]

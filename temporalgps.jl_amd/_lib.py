@@ -45,6 +45,7 @@ _SIGS = {
     "tgp_filter": (ctypes.c_int, [_vp, _vp, _vp, _u32, _vp, _vp, _dp]),
     "tgp_posterior": (ctypes.c_int, [_vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp, _vp]),
     "tgp_posterior_marginals": (ctypes.c_int, [_vp, _vp, _vp, _vp, _u32, _vp, _vp, _dp]),
+    "tgp_logpdf_and_posterior_marginals": (ctypes.c_int, [_vp, _vp, _vp, _vp, _u32, _dp, _vp, _vp]),
     "tgp_posterior_marginals_at": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _vp, _vp, _vp, _u32, _vp, _vp, _dp]),
     "tgp_marginals": (ctypes.c_int, [_vp, _u32, _vp, _vp]),
     "tgp_rand": (ctypes.c_int, [_vp, _vp, _vp, _vp, _u32, _vp]),

@@ -1185,6 +1185,12 @@ int tgp_posterior_marginals(tgp_handle* h, const double* y, const uint8_t* missi
     return tm.finish(lml_out);
 }
 
+int tgp_logpdf_and_posterior_marginals(tgp_handle* h, const double* y, const uint8_t* missing, const double* Rnew, uint32_t flags,
+                                       double* lml_out, double* mean_out, double* var_out) {
+    if (h && !lml_out) return h->fail(TGP_EINVAL, "lml_out is NULL");
+    return tgp_posterior_marginals(h, y, missing, Rnew, flags, mean_out, var_out, lml_out);
+}
+
 int tgp_posterior_marginals_at(tgp_handle* h, const double* y, const uint8_t* missing, int pn, const double* Hn, const double* hn,
                                const double* Rn, uint32_t flags, double* mean_out, double* var_out, double* lml_out) {
     TRY(check_ready(h));

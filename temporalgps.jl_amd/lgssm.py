@@ -574,7 +574,7 @@ def marginals(model):
     return mean, var        # vector observations: var is the DIAGONAL of the p x p marginal covariance (marginals_diag)
 
 
-def posterior_marginals(model, y, R_new):
+def posterior_marginals(model, y, R_new, _with_lml=False):
     """marginals(replace_observation_noise_cov(posterior(model, y), R_new)) without materialising the
     posterior model -- the `marginals(posterior(fx, y)(x))` path (posterior_lti_sde.jl:27-36)."""
     if isinstance(model, PosteriorLGSSM):
@@ -600,9 +600,23 @@ def posterior_marginals(model, y, R_new):
     if model.p > 1 and tuple(Rn.shape[1:]) != (model.p,):
         raise ValueError(f"R_new must be (T|1, {model.p}) (diagonal of the new noise)")
     mean, var = _out(model, _osh(model), dev), _out(model, _osh(model), dev)
+    if _with_lml:
+        lml = ctypes.c_double()
+        hd.check(hd.lib.tgp_logpdf_and_posterior_marginals(hd.h, _lib.ptr(yy), _lib.ptr(mm), _lib.ptr(Rn), flags, ctypes.byref(lml),
+                                                           _lib.ptr(mean), _lib.ptr(var)))
+        return lml.value, mean, var
     hd.check(hd.lib.tgp_posterior_marginals(hd.h, _lib.ptr(yy), _lib.ptr(mm), _lib.ptr(Rn), flags, _lib.ptr(mean),
                                             _lib.ptr(var), None))
     return mean, var
+
+
+def logpdf_and_posterior_marginals(model, y, R_new):
+    """(logpdf(model, y), mean, var): logpdf and marginals(replace_observation_noise_cov(posterior(model, y), R_new)) of the
+    same series from ONE forward filter + RTS smoother (tgp_logpdf_and_posterior_marginals) -- the log marginal likelihood
+    is a by-product of the filter the posterior needs anyway. Diagonal noise (no whitening correction is applied here)."""
+    if model._whiten is not None:
+        raise NotImplementedError("logpdf_and_posterior_marginals with a dense observation-noise covariance")
+    return posterior_marginals(model, y, R_new, _with_lml=True)
 
 
 def posterior_marginals_at(model, y, H_new, h_new, R_new):

@@ -146,6 +146,7 @@ class HIPEngine:
         lml = ctypes.c_double()
         self.hd.check(self.hd.lib.tgp_shard_smoother_backward(self.hd.h, _lib.ptr(gathered), int(world), int(rank), _lib.ptr(Rn), flags,
                                                               _lib.ptr(mean), _lib.ptr(var), ctypes.byref(lml)))
+        self.last_segment_lml = lml.value      # this segment's share of the log marginal likelihood (by-product of pass 2)
         return mean, var
 
     def smoother_backward(self, xs, R_new, like):
@@ -318,6 +319,18 @@ class ShardedLGSSM:
             self._x0 = self.engine.x0()
         reuse = self._forward_exchange(y)
         return self._all_reduce_sum(self.engine.logpdf(y, reuse))
+
+    def logpdf_and_posterior_marginals(self, y, R_new):
+        """(logpdf of the WHOLE series, this rank's slice of the posterior marginals) from one forward filter + RTS smoother
+        (tgp_logpdf_and_posterior_marginals): the per-segment log-likelihood shares are by-products of the smoother's
+        forward pass and are summed across ranks with one scalar all-reduce."""
+        if self.world == 1 and self.engine is None:
+            return L.logpdf_and_posterior_marginals(self.model, y, R_new)
+        if self._device_resident():
+            mean, var = self._posterior_marginals_device(y, R_new)
+            return self._all_reduce_sum(self.engine.last_segment_lml), mean, var
+        # host transport (gloo groups, test engines): the two calls, sharing nothing
+        return (self.logpdf(y),) + tuple(self.posterior_marginals(y, R_new))
 
     def posterior_marginals(self, y, R_new):
         """This rank's slice of marginals(posterior(fx, y)(x)); R_new is the slice's new noise (or a scalar)."""

@@ -277,7 +277,7 @@ def test_group_filter_and_materialised_posterior(tgp, d, ordering):
             post = ref.posterior(model, y)
             hd.set_option(tgp._lib.OPT_PROFILE, 1)
             hd.profile_reset()
-            dpost = tgp.posterior(dm, y)
+            dpost = tgp.posterior(dm, y).materialise()      # posterior() is lazy: evaluate the reverse-time model
             names = set(hd.profile())
             hd.set_option(tgp._lib.OPT_PROFILE, 0)
             assert "k_group_apply_filter<lti,materialise>" in names, names
