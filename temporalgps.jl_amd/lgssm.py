@@ -366,7 +366,8 @@ def logpdf(model, y):
     hd.check(hd.lib.tgp_logpdf(hd.h, _lib.ptr(yy), _lib.ptr(mm), _lib.IN_DEVICE if dev else 0, ctypes.byref(out)))
     if model._whiten is not None:        # log N(y; ., S) = log N(L^-1 y; ., L^-1 S L^-T) - log det L  (observed steps only)
         ld = model._whiten[1]
-        obs = np.ones(model.T, dtype=bool) if mm is None else ~mm.reshape(model.T, -1).all(axis=1)
+        mh = None if mm is None else (mm.cpu().numpy() if _is_torch(mm) else mm).astype(bool)
+        obs = np.ones(model.T, dtype=bool) if mh is None else ~mh.reshape(model.T, -1).all(axis=1)
         return out.value - float((ld if ld.shape[0] > 1 else np.repeat(ld, model.T))[obs].sum())
     return out.value
 

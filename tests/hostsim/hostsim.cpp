@@ -147,6 +147,9 @@ template <int D, bool LTI> int run(const Args& a) {
     if (a.what <= 2 || a.what == 5) {
         SoA E0;
         E0.init(Dim<D>::NF, n0);
+        // (with -fopenmp -- the all-core CPU baseline build, oracle/omp_scan.py -- the three O(T) chunk loops run one chunk per
+        //  thread at a time; the block scans over the n0 chunk elements stay sequential)
+#pragma omp parallel for schedule(static)
         for (int64_t c = 0; c < n0; ++c)
         {
             DirectIO io{mv.y, mv.R, nullptr, nullptr};
@@ -166,6 +169,9 @@ template <int D, bool LTI> int run(const Args& a) {
             fo.fs = fs.data();
             R0.init(Dim<D>::NA, n0);
         }
+        std::vector<double> lml_c((size_t)n0, 0.0), nmiss_c((size_t)n0, 0.0);
+        std::vector<int> bad_c((size_t)n0, 0);
+#pragma omp parallel for schedule(static)
         for (int64_t c = 0; c < n0; ++c) {
             State<D> x = S0[c];
             ChunkStats cs;
@@ -178,14 +184,19 @@ template <int D, bool LTI> int run(const Args& a) {
                     State<D> x3 = x;
                     FilterOut f3{nullptr, nullptr, nullptr, a.G_out, a.g_out, a.L_out};
                     ChunkStats c3 = chunk_apply_filter<D, LTI, 3>(mv, c, a.L0, x3, f3, io, nost);
-                    bad |= c3.bad;
+                    bad_c[c] |= c3.bad;
                 }
                 FilterOut f2{nullptr, nullptr, fo.fs, nullptr, nullptr, nullptr};   // ... and the smoother forward pass (MODE 2)
                 cs = chunk_apply_filter<D, LTI, 2>(mv, c, a.L0, x, f2, io, [&](int k, double v) { R0.v[(size_t)k * n0 + (n0 - 1 - c)] = v; });
             }
-            lml += cs.lml;
-            nmiss += cs.nmiss;
-            bad |= cs.bad;
+            lml_c[c] = cs.lml;
+            nmiss_c[c] = cs.nmiss;
+            bad_c[c] |= cs.bad;
+        }
+        for (int64_t c = 0; c < n0; ++c) {      // fixed summation order
+            lml += lml_c[c];
+            nmiss += nmiss_c[c];
+            bad |= bad_c[c];
         }
         if (a.lml) *a.lml = lml + nmiss * 0.5 * (kLog2Pi + log(kLargeVar));
         if (a.xfm) {
@@ -198,11 +209,14 @@ template <int D, bool LTI> int run(const Args& a) {
             State<D> fin_r;
             State<D> seed = a.xs_m ? make_state<D>(a.xs_m, a.xs_P) : fin;
             hier_scan<D, AM<D, true>>(R0, seed, S0r, fin_r, a.BS);
+            std::vector<int> bad_s((size_t)n0, 0);
+#pragma omp parallel for schedule(static)
             for (int64_t c = 0; c < n0; ++c) {
                 State<D> xs = S0r[n0 - 1 - c];
                 DirectIO io{nullptr, a.Rnew, a.mean_out, a.var_out};
-                bad |= chunk_smooth<D, LTI>(mv, c, a.L0, xs, S0[c], fs.data(), a.sRn, io);
+                bad_s[c] = chunk_smooth<D, LTI>(mv, c, a.L0, xs, S0[c], fs.data(), a.sRn, io);
             }
+            for (int64_t c = 0; c < n0; ++c) bad |= bad_s[c];
         }
     } else {
         SoA E0;
