@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <mutex>
 #include <cmath>
 #include <cstring>
 #include <string>
@@ -64,7 +65,11 @@ static const KernelTable* fast_kernel_table(int d) {
 // Per (state dimension, LTI layout family?): which operations of the inlined (fast) build reproduced the out-of-line (safe)
 // build in the run-time known-answer check. Bit kOpDecided = the check has run.
 enum VariantOp { kOpM0 = 0, kOpM1, kOpM2, kOpM3, kOpAffine, kOpGrad, kOpCount, kOpGroupM1 = 25, kOpGroupM3 = 26, kOpGroupMarg = 27, kOpGroupAff = 28, kOpGroup = 29, kOpDecided = 30 };
-static unsigned g_variant[17][2] = {{0u}};
+// Keyed by DEVICE as well (the check runs on the device the model is bound to; a mixed-device process does not inherit another
+// GPU's verdict) and guarded by a mutex: two host threads binding their first model race neither the check nor the table.
+constexpr int kMaxVariantDevices = 16;
+static unsigned g_variant[kMaxVariantDevices][17][2] = {{{0u}}};
+static std::mutex g_variant_mutex;
 static const unsigned kAllOps = (1u << kOpCount) - 1u;
 
 // table = safe build with the entries whose operations passed replaced by the fast build's
@@ -1667,6 +1672,55 @@ static unsigned variant_selftest(int device, int d, bool lti_layout) {
             q.v.push_back(lml); q.v.push_back(g);
         }
         tgp_destroy(h);
+        // The verdict is applied to Reverse-ordered models, vector observations and the production chunk size as well, so
+        // those are checked too: the same series (i) Reverse-ordered at a chunk of 153 steps (what choose_chunk picks at
+        // T = 1e7), (ii) with p = 2 observations per time step (scalar micro-steps, whole time steps per chunk).
+        {
+            tgp_handle* h2 = nullptr;
+            if (tgp_create(&h2, device) != TGP_OK) return TGP_EHIP;
+            h2->variant_opt = variant;
+            if (variant == 3) h2->opt_group = 2;
+            tgp_set_option(h2, TGP_OPT_CHUNK, 153);
+            rc = tgp_model_set(h2, T, d, 1, 1, lti ? TGP_SHARED_ALL : 0u, A.data(), a.data(), Q.data(), H.data(), hh.data(), R.data(), x0m.data(), x0P.data());
+            if (rc == TGP_OK) {
+                OpOut& q0 = o[kOpM0];
+                if (q0.rc == TGP_OK) { q0.rc = tgp_logpdf(h2, y.data(), miss.data(), 0, &lp); q0.v.push_back(lp); }
+                OpOut& q1 = o[kOpM1];
+                if (q1.rc == TGP_OK) { q1.rc = tgp_filter(h2, y.data(), nullptr, 0, b1.data(), b2.data(), &lp); push(q1, b1, T * d); push(q1, b2, T * dd); }
+                OpOut& q4 = o[kOpAffine];
+                if (q4.rc == TGP_OK) { q4.rc = tgp_marginals(h2, 0, b1.data(), b2.data()); push(q4, b1, T); push(q4, b2, T); }
+                if (q4.rc == TGP_OK) { q4.rc = tgp_rand(h2, et.data(), ee.data(), e0.data(), 0, b1.data()); push(q4, b1, T); }
+            }
+            tgp_destroy(h2);
+            if (rc != TGP_OK) return rc;
+        }
+        {
+            const int64_t T2 = T / 2;                      // p = 2: the first 2 T2 scalars of y / R / hh / H rows are the observations
+            tgp_handle* h3 = nullptr;
+            if (tgp_create(&h3, device) != TGP_OK) return TGP_EHIP;
+            h3->variant_opt = variant;
+            if (variant == 3) h3->opt_group = 2;
+            tgp_set_option(h3, TGP_OPT_CHUNK, 154);
+            rc = tgp_model_set(h3, T2, d, 2, 0, lti ? TGP_SHARED_ALL : 0u, A.data(), a.data(), Q.data(), H.data(), hh.data(), R.data(), x0m.data(), x0P.data());
+            if (rc == TGP_OK) {
+                OpOut& q0 = o[kOpM0];
+                if (q0.rc == TGP_OK) { q0.rc = tgp_logpdf(h3, y.data(), miss.data(), 0, &lp); q0.v.push_back(lp); }
+                OpOut& q1 = o[kOpM1];
+                if (q1.rc == TGP_OK) { q1.rc = tgp_filter(h3, y.data(), nullptr, 0, b1.data(), b2.data(), &lp); push(q1, b1, T2 * d); push(q1, b2, T2 * dd); }
+                OpOut& q2 = o[kOpM2];
+                if (q2.rc == TGP_OK) {
+                    q2.rc = tgp_posterior_marginals(h3, y.data(), miss.data(), Rn.data(), 0, b1.data(), b2.data(), &lp);
+                    push(q2, b1, 2 * T2); push(q2, b2, 2 * T2); q2.v.push_back(lp);
+                }
+                OpOut& q3 = o[kOpM3];
+                if (q3.rc == TGP_OK) {
+                    q3.rc = tgp_posterior(h3, y.data(), nullptr, 0, b1.data(), b2.data(), b3.data(), xm.data(), xP.data());
+                    push(q3, b1, T2 * dd); push(q3, b2, T2 * d); push(q3, b3, T2 * dd);
+                }
+            }
+            tgp_destroy(h3);
+            if (rc != TGP_OK) return rc;
+        }
         return TGP_OK;
     };
     OpOut ra[kOpCount], rb[kOpCount], rg[kOpCount];
@@ -1730,8 +1784,13 @@ static void select_table(tgp_handle* h, int d, bool lti, int variant) {
         return;
     }
     if (!fast && safe->group_reduce_filter == nullptr) return;
-    unsigned& g = g_variant[d][lti ? 1 : 0];
-    if (!(g & (1u << kOpDecided))) g = variant_selftest(h->device, d, lti) | (1u << kOpDecided);
+    unsigned g;
+    {
+        std::lock_guard<std::mutex> lock(g_variant_mutex);
+        unsigned& slot = g_variant[h->device % kMaxVariantDevices][d][lti ? 1 : 0];
+        if (!(slot & (1u << kOpDecided))) slot = variant_selftest(h->device, d, lti) | (1u << kOpDecided);
+        g = slot;
+    }
     unsigned ok = g & kAllOps;
     if (!lti) ok &= ~(1u << kOpGrad);
     const unsigned want = lti ? kAllOps : (kAllOps & ~(1u << kOpGrad));
