@@ -4,7 +4,9 @@
 The reference (Julia) cannot run in this image and its test-suite holds no golden vectors for this path
 (SURVEY.md 8c), so these vectors are produced by the oracle's literal NumPy restatement
 (oracle/lgssm_ref.py, itself pinned by the reference tests' state-space == dense-GP identities). They freeze
-the oracle's behaviour (CPU tier: oracle vs golden) and give the GPU tier fixed known-answer cases.
+the oracle's behaviour (CPU tier: oracle vs golden) and give the GPU tier fixed known-answer cases. The `*_mp` entries are
+the same recursions evaluated in 50-digit arithmetic (oracle/lgssm_mp.py): they measure the fp64 oracle's own rounding error.
+PARITY UNPINNED stays: none of this is output of the reference itself.
 Run from the repo root:  python tests/golden/make_golden.py
 """
 import os
@@ -15,6 +17,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import components as oc   # noqa: E402
+from oracle import lgssm_mp          # noqa: E402
 from oracle import lgssm_ref as ref   # noqa: E402
 from tests import _util as U          # noqa: E402
 
@@ -71,6 +74,11 @@ def main():
             out[f"{name}/post_mean"], out[f"{name}/post_var"] = pm, pv
             pmm, pvm = ref.marginals(ref.replace_observation_noise_cov(ref.posterior_missing(model, y, missing), Rn))
             out[f"{name}/post_mean_missing"], out[f"{name}/post_var_missing"] = pmm, pvm
+            # the same recursions in 50-digit arithmetic (oracle/lgssm_mp.py): what the fp64 oracle's rounding error is measured against
+            xp = lgssm_mp.run(model, y, Rn)
+            out[f"{name}/logpdf_mp"] = np.array(xp["logpdf"])
+            out[f"{name}/post_mean_mp"], out[f"{name}/post_var_mp"] = xp["post_mean"], xp["post_var"]
+            out[f"{name}/logpdf_missing_mp"] = np.array(lgssm_mp.run(model, y, missing=missing)["logpdf"])
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "lgssm_golden.npz"), **out)
     print(f"wrote {len(CASES)} cases, {len(out)} arrays")
 

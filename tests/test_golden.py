@@ -35,6 +35,25 @@ def test_oracle_reproduces_golden(name):
         np.testing.assert_allclose(v, g("post_var"), rtol=1e-9, atol=1e-11)
 
 
+@pytest.mark.parametrize("name", [n for n in NAMES if f"{n}/logpdf_mp" in G.files])
+def test_oracle_rounding_error_against_extended_precision(name):
+    """The fp64 oracle against the SAME recursions in 50-digit arithmetic (oracle/lgssm_mp.py, frozen in the golden file): its
+    own rounding error is orders of magnitude below every parity tolerance stated against it (1e-10 logpdf, 1e-8 posterior)."""
+    model, g = load_case(name)
+    y = g("y")
+    lp = ref.logpdf(model, y)
+    assert abs(lp - float(g("logpdf_mp"))) <= 1e-12 * max(1.0, abs(lp))
+    lpm = ref.logpdf_missing(model, y, g("missing"))
+    assert abs(lpm - float(g("logpdf_missing_mp"))) <= 1e-12 * max(1.0, abs(lpm))
+    pm, pv = ref.marginals(ref.replace_observation_noise_cov(ref.posterior(model, y), g("Rnew")))
+    scale = max(1.0, np.abs(g("post_mean_mp")).max())
+    assert np.abs(pm - g("post_mean_mp")).max() <= 1e-11 * scale
+    assert np.abs(pv - g("post_var_mp")).max() <= 1e-11 * max(1.0, np.abs(g("post_var_mp")).max())
+    if len(model["x0m"]) <= 8:
+        m, v = sk.posterior_marginals(model, y, g("Rnew"))
+        assert np.abs(m - g("post_mean_mp")).max() <= 1e-10 * scale
+
+
 @pytest.mark.parametrize("name", NAMES)
 def test_engine_emulation_reproduces_golden(name):
     model, g = load_case(name)
@@ -76,6 +95,10 @@ def test_hip_reproduces_golden(name):
         pm, pv = tgp.posterior_marginals(dm, y, g("Rnew"))
         np.testing.assert_allclose(pm, g("post_mean"), rtol=1e-8, atol=1e-8)
         np.testing.assert_allclose(pv, g("post_var"), rtol=1e-8, atol=1e-9)
+        # ... and against the 50-digit evaluation of the same recursions (not the fp64 oracle)
+        assert tgp.logpdf(dm, y) == pytest.approx(float(g("logpdf_mp")), rel=1e-10)
+        np.testing.assert_allclose(pm, g("post_mean_mp"), rtol=1e-8, atol=1e-8)
+        np.testing.assert_allclose(pv, g("post_var_mp"), rtol=1e-8, atol=1e-9)
         pm, pv = tgp.posterior_marginals(dm, ym, g("Rnew"))
         np.testing.assert_allclose(pm, g("post_mean_missing"), rtol=1e-8, atol=1e-8)
         np.testing.assert_allclose(pv, g("post_var_missing"), rtol=1e-8, atol=1e-9)
