@@ -633,7 +633,11 @@ int forward_reduce(tgp_handle* h, uint32_t flags, int for_mode = -1) {
     // Group-per-chunk logpdf kernels (tgp_group.hpp). Measured at T = 1e7 (pass 1 + pass 2, ms; lane-per-chunk inlined
     // build in brackets): d = 5 1.9 (0.70), d = 6 2.2 (1.55), d = 7 2.9 (4.3), d = 8 3.4 (12.1) -- their time hardly
     // depends on d (LDS exchanges and shuffles, not flops), so they pay from d = 7 on (TGP_OPT_GROUP = 2 forces them).
-    const bool group_pays = h->d >= 7 || h->opt_group == 2 || h->force_group_post;
+    // General (per-step) layout, d = 5..8 (tgp_group.hpp GroupStep): the lane-per-chunk pass 1 holds the element AND the step's
+    // own A, Q per lane and is bound by its own spill traffic from d = 6 (7.9 ms at T = 1e7 against a 0.9 ms HBM floor); the group
+    // layout needs column j only. logpdf and filtering distributions; the posterior path of per-step models stays lane-per-chunk.
+    const bool ps_group = !h->lti && !h->sde && h->d >= 5 && h->d <= 8 && (for_mode == 0 || for_mode == 1);
+    const bool group_pays = h->d >= 7 || h->opt_group == 2 || h->force_group_post || (ps_group && h->d >= 6);
     // (posterior path in the group layout, tgp_group_smooth.hpp: pass 2 + pass 3 take 7.7 + 7.4 ms at T = 1e7 for d = 7 and 8
     // alike -- 498 / 310 VGPRs, one wave per SIMD, bound by the D + 10 LDS exchanges of a step; the lane-per-chunk kernels
     // need 6.3 + 1.8 (+ 1.8 for their own pass 1) at d = 7 and 15.4 + 5.3 (+ 6.7) at d = 8: group from d = 8 on)
@@ -643,7 +647,8 @@ int forward_reduce(tgp_handle* h, uint32_t flags, int for_mode = -1) {
     // out-of-line build (d >= 9); MODE 3 shares the smoother's validation, Forward models only
     const bool grp_out = ((for_mode == 1 && h->use_group_m1) || (for_mode == 3 && h->use_group_m3 && h->ordering == 0)) &&
                          (h->d >= 9 || h->opt_group == 2);
-    if ((for_mode == 0 || grp_post || grp_out) && h->use_group && h->opt_group && group_pays && h->kt->group_reduce_filter != nullptr && h->lti) {
+    if ((for_mode == 0 || grp_post || grp_out || (ps_group && for_mode == 1 && h->use_group_m1)) && h->use_group && h->opt_group && group_pays &&
+        h->kt->group_reduce_filter != nullptr && (h->lti || ps_group)) {
         // 8 chunks per wave: 16384 chunks are two waves per SIMD; longer chunks also mean fewer scan elements, and the
         // d >= 7 block scans (spill-bound, ~1.5 ms per launch) are what is left of the call
         int64_t L0 = h->opt_chunk;
@@ -660,7 +665,7 @@ int forward_reduce(tgp_handle* h, uint32_t flags, int for_mode = -1) {
         h->n0 = (Tm + L0 - 1) / L0;
         TRY(scan_prepare(h, h->F, kFilter, h->n0));
         {
-            LaunchScope ls(h, "k_group_reduce_filter<lti>");
+            LaunchScope ls(h, h->lti ? "k_group_reduce_filter<lti>" : "k_group_reduce_filter<per-step>");
             h->kt->group_reduce_filter(h->mv, h->L0, h->n0, h->F.E[0], h->stream);
         }
         scan_up(h, h->F, 0);
@@ -716,7 +721,8 @@ int forward_apply(tgp_handle* h, int mode, const FilterOut& fo, const double* x0
             LaunchScope ls(h, "k_group_apply_filter<lti,materialise>");
             h->kt->group_apply_posterior(h->mv, h->L0, h->n0, h->F.S[0], nullptr, nullptr, h->partial.d(), fo.G_out, fo.g_out, fo.L_out, h->stream);
         } else {
-            LaunchScope ls(h, mode == 1 ? "k_group_apply_filter<lti,filter>" : "k_group_apply_filter<lti,logpdf>");
+            LaunchScope ls(h, h->lti ? (mode == 1 ? "k_group_apply_filter<lti,filter>" : "k_group_apply_filter<lti,logpdf>")
+                                     : (mode == 1 ? "k_group_apply_filter<per-step,filter>" : "k_group_apply_filter<per-step,logpdf>"));
             h->kt->group_apply_logpdf(h->mv, h->L0, h->n0, h->F.S[0], h->partial.d(), mode == 1 ? fo.m_out : nullptr, mode == 1 ? fo.P_out : nullptr,
                                       h->stream);
         }
@@ -1736,14 +1742,18 @@ static unsigned variant_selftest(int device, int d, bool lti_layout) {
             if (!(std::fabs(x.v[i] - z.v[i]) <= 1e-9 * (1.0 + std::fabs(x.v[i])))) return false;
         return true;
     };
-    if (lti_layout && kernel_table(d)->group_reduce_filter != nullptr) {   // group-per-chunk logpdf kernels against the out-of-line build
+    if ((lti_layout || d <= 8) && kernel_table(d)->group_reduce_filter != nullptr) {   // group-per-chunk kernels against the out-of-line build
         st = keep;
-        if (run(3, true, rg) == TGP_OK) {
-            if (same(ra[kOpM0], rg[kOpM0])) ok |= 1u << kOpGroup;
-            if (same(ra[kOpM2], rg[kOpM2])) ok |= 1u << kOpGroupAff;     // smoother with the group-layout affine scans
-            if (same(ra[kOpAffine], rg[kOpAffine])) ok |= 1u << kOpGroupMarg;   // prior marginals (and the unchanged rand)
+        if (run(3, lti_layout, rg) == TGP_OK) {
+            // (general layout: the group-layout block scans then also serve the lane-per-chunk posterior passes -- operation M2 is
+            //  part of the verdict there)
+            if (same(ra[kOpM0], rg[kOpM0]) && (lti_layout || same(ra[kOpM2], rg[kOpM2]))) ok |= 1u << kOpGroup;
             if (same(ra[kOpM1], rg[kOpM1])) ok |= 1u << kOpGroupM1;             // filtering distributions
-            if (same(ra[kOpM3], rg[kOpM3])) ok |= 1u << kOpGroupM3;             // materialised posterior
+            if (lti_layout) {
+                if (same(ra[kOpM2], rg[kOpM2])) ok |= 1u << kOpGroupAff;     // smoother with the group-layout affine scans
+                if (same(ra[kOpAffine], rg[kOpAffine])) ok |= 1u << kOpGroupMarg;   // prior marginals (and the unchanged rand)
+                if (same(ra[kOpM3], rg[kOpM3])) ok |= 1u << kOpGroupM3;             // materialised posterior
+            }
         }
     }
     if (rcb != TGP_OK) return ok;
@@ -1772,11 +1782,12 @@ static void select_table(tgp_handle* h, int d, bool lti, int variant) {
     h->variant_code = 1;
     if (variant == 1) return;
     if (variant == 3) {             // out-of-line build + the group-per-chunk logpdf kernels (used by the check itself)
-        h->use_group = safe->group_reduce_filter != nullptr && lti;
-        h->use_group_aff = h->use_group;
-        h->use_group_sm = h->use_group;
-        h->use_group_marg = h->use_group;
-        h->use_group_m1 = h->use_group_m3 = h->use_group;
+        h->use_group = safe->group_reduce_filter != nullptr && (lti || d <= 8);
+        h->use_group_aff = h->use_group && lti;
+        h->use_group_sm = h->use_group_aff;
+        h->use_group_marg = h->use_group_aff;
+        h->use_group_m1 = h->use_group;
+        h->use_group_m3 = h->use_group_aff;
         return;
     }
     if (variant == 2) {
@@ -1798,10 +1809,10 @@ static void select_table(tgp_handle* h, int d, bool lti, int variant) {
         merge_tables(safe, fast, ok, h->ktm);
         h->variant_code = ok == want ? 2 : 3;
     }
-    h->use_group = lti && ((g >> kOpGroup) & 1u) != 0u && safe->group_reduce_filter != nullptr;
-    h->use_group_aff = h->use_group && ((g >> kOpGroupAff) & 1u) != 0u;
+    h->use_group = (lti || d <= 8) && ((g >> kOpGroup) & 1u) != 0u && safe->group_reduce_filter != nullptr;
+    h->use_group_aff = lti && h->use_group && ((g >> kOpGroupAff) & 1u) != 0u;
     h->use_group_sm = h->use_group_aff;      // the same known-answer operation (posterior marginals) exercises both
-    h->use_group_marg = h->use_group && ((g >> kOpGroupMarg) & 1u) != 0u;
+    h->use_group_marg = lti && h->use_group && ((g >> kOpGroupMarg) & 1u) != 0u;
     h->use_group_m1 = h->use_group && ((g >> kOpGroupM1) & 1u) != 0u;
     h->use_group_m3 = h->use_group_sm && ((g >> kOpGroupM3) & 1u) != 0u;
 }

@@ -125,7 +125,7 @@ template <int D> __device__ __forceinline__ void group_setup(const ModelView& mv
     const int tid = threadIdx.x;
     if (tid < G * G) {
         const int i = tid / G, k = tid % G;
-        sA[tid] = (i < D && k < D) ? mv.A[i + k * D] : 0.0;
+        sA[tid] = (i < D && k < D) ? mv.A[i + k * D] : 0.0;      // (per-step layouts: the first block; overwritten per step)
     }
     __syncthreads();
     gl.j = tid & (G - 1);
@@ -150,15 +150,55 @@ template <int D> __device__ __forceinline__ void group_obs_row(const ModelView& 
     Rsh = mv.sR == 0 ? mv.R[jj] : 0.0;
 }
 
+// ---------------------------------------------------------------- general (per-step) layout in the group kernels
+// Every time step carries its own A, a, Q and / or H, h (what irregular spacing and prediction at new inputs produce,
+// lti_sde.jl:135-146; the strides in ModelView say which). Lane j needs only COLUMN j of A and Q, a_j and the emission row, so a
+// step's record costs ~3 d + 2 registers per lane (the lane-per-chunk kernels hold 2 d^2 + ... per lane and spill from d = 6).
+// The record of step k+1 is loaded while step k is computed (one step of software prefetch: its HBM round trip would
+// otherwise head every iteration of a sequential loop); A goes through the group's own LDS tile (`sA`, row-major), where
+// GroupLane::mul_A reads it as a broadcast. The arrays are read in the reference layout (ModelView::A .. h + stride): a
+// group's 8 lanes touch one contiguous d x d block per array and step.
+template <int D> struct GroupStep {
+    double Ac[D], Qc[D], H[D], aj, hh;
+    bool pred;
+    // transition of processing time step `tproc` (column jc of A and Q, element jc of a) and emission row jj of the same step
+    __device__ __forceinline__ void load(const ModelView& mv, int64_t r, int jc, bool act) {
+        const int64_t tproc = r / mv.p;
+        const int jj = (int)(r - tproc * mv.p);
+        pred = jj == 0 && !(mv.ordering != 0 && tproc == 0);
+        const int64_t tt = trans_index(mv, tproc), te = time_index(mv, tproc);
+        if (pred) {
+            const double* Ap = mv.A + tt * mv.sA + jc * D;
+            const double* Qp = mv.Q + tt * mv.sQ + jc * D;
+            TGP_GUNROLL for (int i = 0; i < D; ++i) { Ac[i] = act ? Ap[i] : 0.0; Qc[i] = act ? Qp[i] : 0.0; }
+            aj = act ? mv.a[tt * mv.sa + jc] : 0.0;
+        }
+        const double* Hp = mv.H + te * mv.sH + jj * D;
+        TGP_GUNROLL for (int i = 0; i < D; ++i) H[i] = Hp[i];
+        hh = mv.h[te * mv.sh + jj];
+    }
+};
+
+// publish the step's A in the group's LDS tile (row-major [G i + k]): lane k owns column k
+template <int D> __device__ __forceinline__ void group_publish_A(double* sAg, const GroupStep<D>& st, int j, bool act) {
+    constexpr int G = GroupGeom<D>::G;
+    wave_sync();
+    if (act) {
+        TGP_GUNROLL for (int i = 0; i < D; ++i) sAg[G * i + j] = st.Ac[i];
+    }
+    wave_sync();
+}
+
 // ---------------------------------------------------------------- pass 1: the chunk's filter element
-template <int D>
+template <int D, bool LTI>
 __global__ __launch_bounds__(256) void k_group_reduce_filter(ModelView mv, int L0, int64_t n0, double* __restrict__ E0) {
     constexpr int G = GroupGeom<D>::G, NGRP = GroupGeom<D>::NGRP;
-    __shared__ __attribute__((aligned(16))) double sA[G * G];
+    __shared__ __attribute__((aligned(16))) double sA[(LTI ? 1 : NGRP) * G * G];
     __shared__ double tiles[NGRP * GroupGeom<D>::LD];
     GroupLane<D> gl;
     double Qc[D], H[D], aj, hh, Rsh;
     group_setup<D>(mv, sA, tiles, gl, Qc, H, aj, hh, Rsh);
+    if (!LTI) gl.sA = sA + (threadIdx.x / G) * G * G;      // the group's own A tile (rewritten per step)
     const int j = gl.j;
     const int64_t c = (int64_t)blockIdx.x * NGRP + (threadIdx.x / G);
     int64_t r0, r1;
@@ -169,6 +209,9 @@ __global__ __launch_bounds__(256) void k_group_reduce_filter(ModelView mv, int L
     double Hj = 0.0;
     TGP_GUNROLL for (int i = 0; i < D; ++i) Hj = (i == j) ? H[i] : Hj;
     GroupObs<G> ob;
+    GroupStep<D> nxt;
+    const int jcl = gl.act ? j : 0;
+    if (!LTI && r0 < r1) nxt.load(mv, r0, jcl, gl.act);
     for (int g = 0; g < L0; g += G) {
         ob.load(mv, c, L0, r0, r1, g, j);
         const int64_t rg = r0 + g;
@@ -177,9 +220,25 @@ __global__ __launch_bounds__(256) void k_group_reduce_filter(ModelView mv, int L
             double y, R;
             bool miss;
             const int jj = mv.p == 1 ? 0 : (g + k) % mv.p;
-            group_obs_row<D>(mv, jj, j, H, Hj, hh, Rsh);
+            bool do_predict;
+            if (LTI) {
+                group_obs_row<D>(mv, jj, j, H, Hj, hh, Rsh);
+                do_predict = jj == 0 && !(mv.ordering != 0 && (rg + k) == 0);
+            } else {
+                const GroupStep<D> cur = nxt;
+                if (rg + k + 1 < r1) nxt.load(mv, rg + k + 1, jcl, gl.act);      // in flight while this step is computed
+                do_predict = cur.pred;
+                if (do_predict) {
+                    group_publish_A<D>(const_cast<double*>(gl.sA), cur, j, gl.act);
+                    TGP_GUNROLL for (int i = 0; i < D; ++i) Qc[i] = cur.Qc[i];
+                    aj = cur.aj;
+                }
+                TGP_GUNROLL for (int i = 0; i < D; ++i) H[i] = cur.H[i];
+                Hj = 0.0;
+                TGP_GUNROLL for (int i = 0; i < D; ++i) Hj = (i == j) ? H[i] : Hj;
+                hh = cur.hh;
+            }
             ob.step(mv, Rsh, k, y, R, miss);
-            const bool do_predict = jj == 0 && !(mv.ordering != 0 && (rg + k) == 0);
             if (do_predict) {
                 double T1[D];
                 gl.mul_A(Ac, T1);                       // Abar <- A Abar
@@ -217,17 +276,18 @@ __global__ __launch_bounds__(256) void k_group_reduce_filter(ModelView mv, int L
 
 // ---------------------------------------------------------------- pass 2, logpdf: filter from the chunk's carry-in state
 // OUT == true: MODE 1, the filtering distributions are written as well (compile-time: see k_group_apply_posterior)
-template <int D, bool OUT>
+template <int D, bool OUT, bool LTI>
 __global__ __launch_bounds__(256) void k_group_apply_logpdf(ModelView mv, int L0, int64_t n0, const double* __restrict__ S0,
                                                             double* __restrict__ partial, double* __restrict__ m_out,
                                                             double* __restrict__ P_out) {
     constexpr int G = GroupGeom<D>::G, NGRP = GroupGeom<D>::NGRP;
-    __shared__ __attribute__((aligned(16))) double sA[G * G];
+    __shared__ __attribute__((aligned(16))) double sA[(LTI ? 1 : NGRP) * G * G];
     __shared__ double tiles[NGRP * GroupGeom<D>::LD];
     __shared__ double sh[12];
     GroupLane<D> gl;
     double Qc[D], H[D], aj, hh, Rsh;
     group_setup<D>(mv, sA, tiles, gl, Qc, H, aj, hh, Rsh);
+    if (!LTI) gl.sA = sA + (threadIdx.x / G) * G * G;
     const int j = gl.j;
     const int64_t c = (int64_t)blockIdx.x * NGRP + (threadIdx.x / G);
     int64_t r0, r1;
@@ -246,6 +306,9 @@ __global__ __launch_bounds__(256) void k_group_apply_logpdf(ModelView mv, int L0
     double lml = 0.0, nmiss = 0.0;
     bool ok = true;
     GroupObs<G> ob;
+    GroupStep<D> nxt;
+    const int jcl = gl.act ? j : 0;
+    if (!LTI && r0 < r1) nxt.load(mv, r0, jcl, gl.act);
     for (int g = 0; g < L0; g += G) {
         ob.load(mv, c, L0, r0, r1, g, j);
         const int64_t rg = r0 + g;
@@ -255,9 +318,25 @@ __global__ __launch_bounds__(256) void k_group_apply_logpdf(ModelView mv, int L0
             double y, R;
             bool miss;
             const int jj = mv.p == 1 ? 0 : (g + k) % mv.p;
-            group_obs_row<D>(mv, jj, j, H, Hj, hh, Rsh);
+            bool do_predict;
+            if (LTI) {
+                group_obs_row<D>(mv, jj, j, H, Hj, hh, Rsh);
+                do_predict = jj == 0 && !(mv.ordering != 0 && (rg + k) == 0);
+            } else {
+                const GroupStep<D> cur = nxt;
+                if (rg + k + 1 < r1) nxt.load(mv, rg + k + 1, jcl, gl.act);
+                do_predict = cur.pred;
+                if (do_predict) {
+                    group_publish_A<D>(const_cast<double*>(gl.sA), cur, j, gl.act);
+                    TGP_GUNROLL for (int i = 0; i < D; ++i) Qc[i] = cur.Qc[i];
+                    aj = cur.aj;
+                }
+                TGP_GUNROLL for (int i = 0; i < D; ++i) H[i] = cur.H[i];
+                Hj = 0.0;
+                TGP_GUNROLL for (int i = 0; i < D; ++i) Hj = (i == j) ? H[i] : Hj;
+                hh = cur.hh;
+            }
             ob.step(mv, Rsh, k, y, R, miss);
-            const bool do_predict = jj == 0 && !(mv.ordering != 0 && (rg + k) == 0);
             if (do_predict) {
                 gl.predict(mj, aj, Pc, Qc);             // m <- A m + a ; P <- A P A' + Q
             }

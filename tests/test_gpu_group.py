@@ -286,3 +286,67 @@ def test_group_filter_and_materialised_posterior(tgp, d, ordering):
             np.testing.assert_allclose(dpost.transitions.Qs, post["Q"], rtol=1e-8, atol=1e-9)
             np.testing.assert_allclose(dpost.x0.m, post["x0m"], rtol=1e-8, atol=1e-9)
             np.testing.assert_allclose(dpost.x0.P, post["x0P"], rtol=1e-8, atol=1e-9)
+
+
+@pytest.mark.parametrize("d", [5, 6, 7, 8])
+@pytest.mark.parametrize("ordering", ["F", "R"])
+@pytest.mark.parametrize("p", [1, 2])
+def test_group_per_step_layout_equals_oracle(tgp, d, ordering, p):
+    """General (per-step) layout in the group kernels (tgp_group.hpp GroupStep): every time step carries its own A, a, Q, H, h
+    (lti_sde.jl:135-146 inputs); logpdf and the filtering distributions, scalar and vector observations, both orderings,
+    missing data, ragged chunk sizes and multi-level scans, forced on for every d = 5..8 (default: from d = 6)."""
+    rng = np.random.default_rng(300 + 10 * d + 2 * p + (ordering == "R"))
+    T = 611
+    model = U.random_lgssm(rng, True, d, T, ordering) if p == 1 else U.random_lgssm_small(rng, True, d, p, T, ordering)
+    y = rng.standard_normal(T) if p == 1 else rng.standard_normal((T, p))
+    tr = tgp.GaussMarkovModel(tgp.Forward if ordering == "F" else tgp.Reverse, model["A"], model["a"], model["Q"],
+                              tgp.Gaussian(model["x0m"], model["x0P"]))
+    em = tgp.ScalarOutputLGC(model["H"], model["h"], model["R"]) if p == 1 else \
+        tgp.SmallOutputLGC(model["H"], model["h"], np.diagonal(model["R"], axis1=-2, axis2=-1))
+    dm = tgp.LGSSM(tr, em, T=T)
+    hd = dm.handle()
+    hd.set_option(tgp._lib.OPT_GROUP, 2)
+    lp = ref.logpdf(model, y)
+    missing = rng.random(T) < 0.3
+    lpm = ref.logpdf_missing(model, y, missing)
+    ym = y.copy()
+    ym[missing] = np.nan
+    fm, fP = ref.filter_(model, y)
+    for chunk in (0, 3 * p, 13 * p, 64 * p):
+        hd.set_option(tgp._lib.OPT_CHUNK, chunk)
+        hd.set_option(tgp._lib.OPT_PROFILE, 1)
+        hd.profile_reset()
+        got = tgp.logpdf(dm, y)
+        names = set(hd.profile())
+        hd.set_option(tgp._lib.OPT_PROFILE, 0)
+        assert "k_group_reduce_filter<per-step>" in names and "k_group_apply_filter<per-step,logpdf>" in names, names
+        assert abs(got - lp) <= 1e-10 * abs(lp), chunk
+        assert abs(tgp.logpdf(dm, ym) - lpm) <= 1e-10 * abs(lpm), chunk
+        m, P = tgp._filter(dm, y)
+        np.testing.assert_allclose(m, fm, rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(P, fP, rtol=1e-8, atol=1e-9)
+    # the posterior path of the same handle (lane-per-chunk passes, group-layout scans) is unaffected
+    if ordering == "F" and p == 1:
+        Rn = rng.random(T) * 0.1
+        pm, pv = ref.marginals(ref.replace_observation_noise_cov(ref.posterior(model, y), Rn))
+        gm, gv = tgp.posterior_marginals(dm, y, Rn)
+        np.testing.assert_allclose(gm, pm, rtol=1e-8, atol=1e-8)
+        np.testing.assert_allclose(gv, pv, rtol=1e-8, atol=1e-9)
+
+
+def test_group_per_step_layout_is_the_default_from_d6(tgp):
+    rng = np.random.default_rng(2)
+    for d, expect in ((5, False), (6, True), (8, True)):
+        T = 5000
+        model = U.random_lgssm(rng, True, d, T)
+        y = rng.standard_normal(T)
+        tr = tgp.GaussMarkovModel(tgp.Forward, model["A"], model["a"], model["Q"], tgp.Gaussian(model["x0m"], model["x0P"]))
+        dm = tgp.LGSSM(tr, tgp.ScalarOutputLGC(model["H"], model["h"], model["R"]), T=T)
+        hd = dm.handle()
+        hd.set_option(tgp._lib.OPT_PROFILE, 1)
+        hd.profile_reset()
+        lp = tgp.logpdf(dm, y)
+        names = set(hd.profile())
+        assert ("k_group_reduce_filter<per-step>" in names) == expect, (d, names)
+        lp_ref = ref.logpdf(model, y)
+        assert abs(lp - lp_ref) <= 1e-10 * abs(lp_ref)
