@@ -214,13 +214,13 @@ def pmc_traffic(kname, d, layout):
     table = json.load(open(path)).get(layout, {})
     lti = "true" if layout == "lti" else "false"
     base = kname.split("<")[0]
-    mode = {"logpdf": 0, "filter": 1, "posterior": 2, "materialise": 3}
+    mode = {"logpdf": 0, "filter": 1, "posterior": 2, "materialise": 3, "scratch": 4}
     if base == "k_reduce_filter":
         key = f"{base}<{d}, {lti}>"
     elif base == "k_smooth":
         key = f"{base}<{d}, {lti}, false>"      # the bench passes ONE shared R_new (RSTREAM = false)
     elif base == "k_apply_filter":
-        key = f"{base}<{d}, {lti}, {mode[kname.split(',')[1].rstrip('>')]}>"
+        key = f"{base}<{d}, {lti}, {mode.get(kname.split(',')[1].rstrip('>'), -1)}>"
     else:
         return None
     ent = table.get(key)

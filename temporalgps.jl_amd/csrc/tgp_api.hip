@@ -1095,8 +1095,9 @@ int tgp_posterior(tgp_handle* h, const double* y, const uint8_t* missing, uint32
                   double* xfm, double* xfP) {
     TRY(check_ready(h));
     TRY(scan_only(h, "tgp_posterior"));
-    if (h->ordering != 0) return h->fail(TGP_EUNSUPPORTED, "posterior of a Reverse-ordered model is not implemented on the device");
     if ((G || g || L) && !(G && g && L)) return h->fail(TGP_EINVAL, "G, g, L must be given together");
+    // Reverse-ordered prior (step_posterior(::Reverse), lgssm.jl:223-228): the lane-per-chunk materialise pass only
+    if (h->ordering != 0 && !G) return h->fail(TGP_EUNSUPPORTED, "posterior of a Reverse-ordered model: G, g, L must be requested");
     const bool odev = (flags & TGP_OUT_DEVICE) != 0;
     const size_t ng = (size_t)h->T * h->d * sizeof(double), nG = ng * h->d;
     CallTimer tm(h);
@@ -1107,6 +1108,10 @@ int tgp_posterior(tgp_handle* h, const double* y, const uint8_t* missing, uint32
     TRY(stage_out(h, h->bo1, G, nG, odev, &fo.G_out));
     TRY(stage_out(h, h->bo2, g, ng, odev, &fo.g_out));
     TRY(stage_out(h, h->bo3, L, nG, odev, &fo.L_out));
+    if (h->ordering != 0) {
+        HIPCHK(h->bx0r.ensure((size_t)state_size(h->d) * sizeof(double)));
+        fo.xfin = h->bx0r.d();
+    }
     TRY(forward_apply(h, (G != nullptr) ? 3 : 0, fo));
     tm.kernels_done();
     TRY(copy_back(h, G, fo.G_out, nG, odev));
@@ -1114,7 +1119,8 @@ int tgp_posterior(tgp_handle* h, const double* y, const uint8_t* missing, uint32
     TRY(copy_back(h, L, fo.L_out, nG, odev));
     if (xfm && xfP) {
         std::vector<double> pk(state_size(h->d));
-        HIPCHK(hipMemcpyAsync(pk.data(), h->F.fin, pk.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        // Forward prior: the final filtering state; Reverse prior: the state after the last step's predict (written by pass 2)
+        HIPCHK(hipMemcpyAsync(pk.data(), h->ordering != 0 ? fo.xfin : h->F.fin, pk.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
         unpack_state(h->d, pk.data(), xfm, xfP);
     }

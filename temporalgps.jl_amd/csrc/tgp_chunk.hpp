@@ -166,6 +166,7 @@ struct FilterOut {
     double* G_out;  // [T][d*d] [T][d] [T][d*d] materialised reverse model (MODE 2, may be null)
     double* g_out;
     double* L_out;
+    double* xfin;   // MODE 3 of a Reverse-ordered prior: x0 of the posterior (the state after the last step's predict), packed
 };
 
 using real_t = double;

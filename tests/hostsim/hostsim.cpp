@@ -172,6 +172,7 @@ template <int D, bool LTI> int run(const Args& a) {
         std::vector<double> lml_c((size_t)n0, 0.0), nmiss_c((size_t)n0, 0.0);
         std::vector<int> bad_c((size_t)n0, 0);
 #pragma omp parallel for schedule(static)
+        std::vector<double> xfin_buf(Dim<D>::NS, 0.0);   // Reverse prior, MODE 3: x0 of the posterior (written by the last chunk)
         for (int64_t c = 0; c < n0; ++c) {
             State<D> x = S0[c];
             ChunkStats cs;
@@ -182,7 +183,7 @@ template <int D, bool LTI> int run(const Args& a) {
             else {
                 if (a.G_out) {   // materialised posterior model (MODE 3) ...
                     State<D> x3 = x;
-                    FilterOut f3{nullptr, nullptr, nullptr, a.G_out, a.g_out, a.L_out};
+                    FilterOut f3{nullptr, nullptr, nullptr, a.G_out, a.g_out, a.L_out, xfin_buf.data()};
                     ChunkStats c3 = chunk_apply_filter<D, LTI, 3>(mv, c, a.L0, x3, f3, io, nost);
                     bad_c[c] |= c3.bad;
                 }
@@ -200,6 +201,7 @@ template <int D, bool LTI> int run(const Args& a) {
         }
         if (a.lml) *a.lml = lml + nmiss * 0.5 * (kLog2Pi + log(kLargeVar));
         if (a.xfm) {
+            if (mv.ordering != 0 && a.G_out) load_state<D>(fin, [&](int k) { return xfin_buf[k]; });   // posterior x0 of a Reverse prior
             for (int i = 0; i < D; ++i) a.xfm[i] = fin.m[i];
             for (int i = 0; i < D * D; ++i) a.xfP[i] = fin.P[i];
         }

@@ -111,3 +111,24 @@ def test_reverse_ordering(tv):
     np.testing.assert_allclose(r["var"], mv, rtol=1e-10, atol=1e-11)
     r = U.hostsim_run(model, 4, eps=eps)
     np.testing.assert_allclose(r["mean"], y, rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize("tv", [False, True])
+@pytest.mark.parametrize("d", [1, 2, 3, 5])
+def test_reverse_ordered_posterior_matches_oracle(tv, d):
+    """step_posterior(::Reverse) (lgssm.jl:223-228): update, then predict, then invert_dynamics(xp, xf, t) -- the reference passes
+    the predicted state in the filtered slot -- and the last step's trailing predict gives the posterior's x0. The engine's
+    MODE 3 pass (same chunk code as the HIP kernels, run on the host) against the oracle's literal restatement."""
+    rng = np.random.default_rng(40 + d + 10 * tv)
+    T = 41
+    model = U.random_lgssm(rng, tv, d, T, "R")
+    y = rng.standard_normal(T)
+    post = ref.posterior(model, y)
+    for L0, BS in ((5, 3), (8, 4), (64, 3)):
+        r = U.hostsim_run(model, 2, y=y, L0=L0, BS=BS, want_ggl=True)
+        assert r["rc"] == 0
+        np.testing.assert_allclose(r["G"], post["A"], rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(r["g"], post["a"], rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(r["L"], post["Q"], rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(r["xfm"], post["x0m"], rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(r["xfP"], post["x0P"], rtol=1e-10, atol=1e-12)

@@ -167,9 +167,6 @@ def test_errors(tgp):
     bad = dict(model, R=np.array([-10.0]))                            # S <= 0: Julia throws DomainError (sqrt)
     with pytest.raises(tgp._lib.NotPositiveDefinite):
         tgp.logpdf(to_device_model(tgp, bad), rng.standard_normal(10))
-    rev = dict(model, ordering="R")
-    with pytest.raises(tgp._lib.TGPError):                            # documented as unsupported (raised when the lazy posterior is evaluated)
-        tgp.posterior(to_device_model(tgp, rev), np.zeros(10)).materialise()
 
 
 @pytest.mark.parametrize("kname,T", [("matern32", 1_000_000), ("matern52", 1_000_000)])
@@ -337,3 +334,39 @@ def test_reference_call_chain_runs_the_fused_smoother(tgp):
     # anything that looks inside evaluates the reverse-time model once, and the result is a plain LGSSM
     post = tgp.posterior(dm, y)
     assert post.transitions.As.shape == (5000, 3, 3) and post.ordering is tgp.Reverse
+
+
+@pytest.mark.parametrize("tv", [False, True])
+@pytest.mark.parametrize("d", [1, 2, 3, 4, 6, 9])
+def test_posterior_of_a_reverse_ordered_model(tgp, tv, d):
+    """step_posterior(::Reverse), lgssm.jl:223-228 (the posterior of a posterior, for one): a Forward-ordered LGSSM whose
+    transitions come from invert_dynamics(xp, xf, t) and whose x0 is the state after the last step's predict."""
+    rng = np.random.default_rng(500 + d + 50 * tv)
+    T = 777
+    model = U.random_lgssm(rng, tv, d, T, "R")
+    y = rng.standard_normal(T)
+    post = ref.posterior(model, y)
+    dm = to_device_model(tgp, model)
+    for chunk in (0, 7):
+        dm.handle().set_option(tgp._lib.OPT_CHUNK, chunk)
+        dpost = tgp.posterior(dm, y)
+        assert dpost.ordering is tgp.Forward
+        np.testing.assert_allclose(dpost.transitions.As, post["A"], rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(dpost.transitions.as_, post["a"], rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(dpost.transitions.Qs, post["Q"], rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(dpost.x0.m, post["x0m"], rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(dpost.x0.P, post["x0P"], rtol=1e-8, atol=1e-9)
+    # the reference's chain on it: marginals(replace_observation_noise_cov(posterior(reverse_model, y), R)) (evaluated route).
+    # The swapped invert_dynamics of the Reverse step need not give a contractive G, so the forward recursion through T steps can
+    # amplify the 1e-9 agreement of the transitions: the marginals are compared on the DEVICE's own posterior model.
+    Rn = rng.random(T) * 0.1
+    dpost = tgp.posterior(dm, y)
+    same = dict(post, A=np.asarray(dpost.transitions.As), a=np.asarray(dpost.transitions.as_), Q=np.asarray(dpost.transitions.Qs),
+                x0m=np.asarray(dpost.x0.m), x0P=np.asarray(dpost.x0.P))
+    pm, pv = ref.marginals(ref.replace_observation_noise_cov(same, Rn))
+    gm, gv = tgp.marginals(tgp.replace_observation_noise_cov(dpost, Rn))
+    if not (np.all(np.isfinite(pm)) and np.all(np.isfinite(pv)) and np.abs(pm).max() < 1e100):
+        return          # an expansive G: the recursion overflows in the oracle as well -- nothing meaningful to compare
+    scale = max(1.0, np.abs(pm).max())
+    np.testing.assert_allclose(gm, pm, rtol=1e-7, atol=1e-8 * scale)
+    np.testing.assert_allclose(gv, pv, rtol=1e-7, atol=1e-8 * max(1.0, np.abs(pv).max()))
