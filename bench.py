@@ -555,6 +555,19 @@ def main():
                 del full, yf
             except Exception as ex:      # noqa: BLE001 -- e.g. the whole series does not fit one GPU
                 out["single_gpu_reference"] = dict(error=repr(ex))
+        if args.layout == "lti":
+            # The LTI layout streams 8-24 B per step against ~10^2-10^3 flop: its binding roofline is the fp64 vector ALU, not HBM.
+            # Algorithmic flops per step of the SEQUENTIAL recursion: Kalman step 4 d^3 + 7 d^2 + 8 d, RTS step
+            # 4 d^3 (predict) + d^3 / 3 (Cholesky) + 2 d^3 (two triangular solves) + 2 d^3 (L) + 4 d^3 (reverse predict); the
+            # parallel scan executes more (pass 1 + pass 2 + the RTS gain twice) and is charged against these.
+            kal = 4.0 * d ** 3 + 7.0 * d ** 2 + 8.0 * d
+            rts = (12.0 + 1.0 / 3.0) * d ** 3
+            per_step = kal + rts + (kal if args.separate_calls else 0.0)
+            ach = per_step * value / 1e12
+            out["roofline_fp64_valu"] = dict(bound="fp64_valu", achieved=ach, peak=78.6, unit="TFLOP/s", frac=ach / 78.6,
+                                             algorithmic_flops_per_step=per_step,
+                                             note="whole step (all kernels) against the MI355X fp64 vector peak; issue-slot utilisation of the "
+                                                  "individual kernels: `valu`")
         if T == 10_000_000 and world == 1 and d == 3 and not args.chunk:
             out["valu"] = valu_utilisation(prof, d, args.layout)
         if world == 1 and not args.no_general_leg:

@@ -142,7 +142,8 @@ int tgp_filter(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t 
 
 /* ---- posterior(model, y): lgssm.jl:193-238. Materialises the time-reversed model:
  *      G [T][d*d], g [T][d], L [T][d*d] (all three or none), xfm (d) / xfP (d*d): x0 of the posterior
- *      (host pointers). Forward priors only. */
+ *      (host pointers). Forward priors (step_posterior(::Forward), :215-221) and Reverse priors (step_posterior(::Reverse), :223-228:
+ *      invert_dynamics(xp, xf, t) as the reference calls it, x0 = the state after the last step's predict; G, g, L must be requested). */
 int tgp_posterior(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t flags, double* G,
                   double* g, double* L, double* xfm, double* xfP);
 
