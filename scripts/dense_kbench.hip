@@ -39,7 +39,7 @@ int main(int argc, char** argv) {
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int rep = 0; rep < 3; ++rep) {
         CK(hipEventRecord(e0));
-        for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(dk_chol, dim3(1), dim3(1024), 0, 0, dS, n, dslots, dL, dDinv, dscal, dtr);
+        for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(dk_chol, dim3(1), dim3(1024), 0, 0, dS, (int64_t)n, n, 0.0, dslots, dL, (int64_t)n, dDinv, dscal, dtr);
         CK(hipEventRecord(e1));
         CK(hipEventSynchronize(e1));
         float ms;
@@ -66,7 +66,7 @@ int main(int argc, char** argv) {
     // trsm
     for (int rep = 0; rep < 2; ++rep) {
         CK(hipEventRecord(e0));
-        for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(dk_trsm, dim3((D + 16) / 16), dim3(256), 0, 0, dL, dDinv, dV, n, dB, (int64_t)(D + 16));
+        for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(dk_trsm, dim3((D + 16) / 16), dim3(256), 0, 0, dL, (int64_t)n, dDinv, dV, (int64_t)n, n, dB, (int64_t)(D + 16));
         CK(hipEventRecord(e1));
         CK(hipEventSynchronize(e1));
         float ms;

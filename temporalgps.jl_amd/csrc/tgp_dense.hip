@@ -320,8 +320,8 @@ __device__ inline double rsqrt_fast(double x) {
 #else
 #define DK_STAMP(slot) do { } while (0)
 #endif
-__global__ __launch_bounds__(1024) void dk_chol(const double* __restrict__ S, int n, const int* __restrict__ slots, double* __restrict__ L,
-                                                 double* __restrict__ Dinv, double* __restrict__ scal
+__global__ __launch_bounds__(1024) void dk_chol(const double* __restrict__ S, int64_t ldS, int n, double jitter, const int* __restrict__ slots,
+                                                 double* __restrict__ L, int64_t ldL, double* __restrict__ Dinv, double* __restrict__ scal
 #ifdef DK_TRACE
                                                  , long long* __restrict__ trace
 #endif
@@ -356,7 +356,10 @@ __global__ __launch_bounds__(1024) void dk_chol(const double* __restrict__ S, in
         tt[s] = w > 0 ? slots[(w - 1) * kCholSlots + s] : -1;
         if (tt[s] >= 0) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) tile[s][r] = S[(TI(s) * 16 + (lane & 15)) + (int64_t)(TJ(s) * 16 + (lane >> 4) + 4 * r) * n];
+            for (int r = 0; r < 4; ++r) {
+                tile[s][r] = S[(TI(s) * 16 + (lane & 15)) + (int64_t)(TJ(s) * 16 + (lane >> 4) + 4 * r) * ldS];
+                if (TI(s) == TJ(s) && (lane & 15) == (lane >> 4) + 4 * r) tile[s][r] += jitter;   // S + jitter I (lgssm.jl:235)
+            }
             if (tt[s] == 0) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) dtile[r * 64 + lane] = tile[s][r];
@@ -406,7 +409,7 @@ __global__ __launch_bounds__(1024) void dk_chol(const double* __restrict__ S, in
             if (lane < 16) {
                 dg[kb * 16 + lane] = mypiv;
 #pragma unroll
-                for (int k = 0; k < 16; ++k) L[(kb * 16 + idx) + (int64_t)(kb * 16 + k) * n] = k <= idx ? z[k] : 0.0;
+                for (int k = 0; k < 16; ++k) L[(kb * 16 + idx) + (int64_t)(kb * 16 + k) * ldL] = k <= idx ? z[k] : 0.0;
             } else if (lane < 32) {
 #pragma unroll
                 for (int k = 0; k < 16; ++k) {
@@ -450,7 +453,7 @@ __global__ __launch_bounds__(1024) void dk_chol(const double* __restrict__ S, in
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         pb[TI(s) * 256 + r * 64 + ln] = x[r];
-                        L[(TI(s) * 16 + (ln & 15)) + (int64_t)(kb * 16 + (ln >> 4) + 4 * r) * n] = x[r];
+                        L[(TI(s) * 16 + (ln & 15)) + (int64_t)(kb * 16 + (ln >> 4) + 4 * r) * ldL] = x[r];
                     }
                 }
             // arrive at the worker barrier of this panel: the whole panel is in the LDS buffer before anyone applies it
@@ -505,6 +508,7 @@ __global__ __launch_bounds__(1024) void dk_chol(const double* __restrict__ S, in
     if (tid == 0) {
         scal[0] = redl[0];
         scal[2] = bad ? 1.0 : 0.0;
+        if (bad) scal[3] = 1.0;      // sticky: any factorisation of the call (the smoother's blocked d x d ones report through it)
     }
 }
 #undef TI
@@ -536,8 +540,8 @@ static void chol_slot_table(int nt, std::vector<int>& out) {
 // Right-looking block substitution with the D -> B-operand identity of the f64 MFMA layout: the accumulator of block row b
 // (lane l, register r = row (l >> 4) + 4 r, column l & 15) IS the B operand of k-step r, so X_b = Dinv_b acc_b and the updates
 // acc_b' -= L_b'b X_b chain through registers; only X_b crosses waves (LDS, double-buffered: one barrier per block row).
-__global__ __launch_bounds__(256) void dk_trsm(const double* __restrict__ L, const double* __restrict__ Dinv, const double* __restrict__ V,
-                                               int n, double* __restrict__ Bm, int64_t ldB) {
+__global__ __launch_bounds__(256) void dk_trsm(const double* __restrict__ L, int64_t ldL, const double* __restrict__ Dinv,
+                                               const double* __restrict__ V, int64_t ldV, int n, double* __restrict__ Bm, int64_t ldB) {
     __shared__ double xb[2][256];
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nb = n / 16, c0 = blockIdx.x * 16;
@@ -547,7 +551,7 @@ __global__ __launch_bounds__(256) void dk_trsm(const double* __restrict__ L, con
         const int b = w + 4 * s;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            acc[s][r] = b < nb ? V[(b * 16 + (lane >> 4) + 4 * r) + (int64_t)(c0 + (lane & 15)) * n] : 0.0;
+            acc[s][r] = b < nb ? V[(b * 16 + (lane >> 4) + 4 * r) + (int64_t)(c0 + (lane & 15)) * ldV] : 0.0;
     }
     double dn[4];
     auto load_dinv = [&](int b) __attribute__((always_inline)) {
@@ -565,7 +569,7 @@ __global__ __launch_bounds__(256) void dk_trsm(const double* __restrict__ L, con
             const int bbc = ok ? bb : 0, bc = ok ? b : 0;     // unpredicated loads (clamped address), value selected
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const double v = L[(bbc * 16 + (lane & 15)) + (int64_t)(bc * 16 + ks * 4 + (lane >> 4)) * n];
+                const double v = L[(bbc * 16 + (lane & 15)) + (int64_t)(bc * 16 + ks * 4 + (lane >> 4)) * ldL];
                 lf[s][ks] = ok ? v : 0.0;
             }
         }
@@ -777,6 +781,8 @@ struct Engine {
     int64_t sA = 0, sQ = 0, sH = 0, sa = 0, sh = 0, sR = 0;
     // state and work buffers
     Buf bm, bmp, bP, bPp, bT1, bV, bS, bL, bDinv, bB, bscal, bslots;
+    // RTS smoother (posterior_marginals): stored filtering states, the blocked d x d Cholesky factor, work matrices
+    Buf bPstore, bmstore, bLd, bDinvd, bW0, bW1, bW2, bW3, bslots_blk, bslots_tail, bzero;
     // ELL form of a shared A / H with few entries per row (0 == dense)
     int structure_opt = 1;
     int nnzA = 0, nnzH = 0;
@@ -810,7 +816,8 @@ Engine* create(int device) {
 void destroy(Engine* e) {
     if (!e) return;
     for (Buf* b : {&e->bA, &e->bQ, &e->bH, &e->ba, &e->bh, &e->bR, &e->bx0, &e->bm, &e->bmp, &e->bP, &e->bPp, &e->bT1, &e->bV, &e->bS,
-                   &e->bL, &e->bDinv, &e->bB, &e->bscal, &e->bslots, &e->bAcol, &e->bAval, &e->bHcol, &e->bHval})
+                   &e->bL, &e->bDinv, &e->bB, &e->bscal, &e->bslots, &e->bAcol, &e->bAval, &e->bHcol, &e->bHval, &e->bPstore, &e->bmstore, &e->bLd, &e->bDinvd, &e->bW0, &e->bW1, &e->bW2, &e->bW3,
+                   &e->bslots_blk, &e->bslots_tail, &e->bzero})
         b->release();
     for (auto& pe : e->pending) {
         (void)hipEventDestroy(pe.a);
@@ -1097,7 +1104,8 @@ void enqueue_predict(Engine* e, const StepPtrs& s, hipStream_t st, bool prof) {
 
 // posterior_and_lml (lgc.jl:129-151) on (mp, Pp) -> (m, P); lml_t accumulated into result8
 void enqueue_update(Engine* e, const StepPtrs& s, int64_t t, const double* y, const uint8_t* mask, double* m_out, double* P_out, double* result8,
-                    hipStream_t st, bool prof) {
+                    hipStream_t st, bool prof, int out_n = 0) {
+    if (out_n == 0) out_n = e->d;       // leading dimension / size of the per-step output blocks (d for the API, Dp for the smoother's store)
     const int Dp = e->Dp, Pq = e->Pq;
     const double* yt = y + t * e->p;
     const uint8_t* mt = mask ? mask + t * e->p : nullptr;
@@ -1144,7 +1152,8 @@ void enqueue_update(Engine* e, const StepPtrs& s, int64_t t, const double* y, co
     }
     {
         Scope sc(e, st, "dk_chol", prof);
-        hipLaunchKernelGGL(dk_chol, dim3(1), dim3(1024), 0, st, e->bS.d(), Pq, static_cast<const int*>(e->bslots.p), e->bL.d(), e->bDinv.d(), e->bscal.d()
+        hipLaunchKernelGGL(dk_chol, dim3(1), dim3(1024), 0, st, e->bS.d(), (int64_t)Pq, Pq, 0.0, static_cast<const int*>(e->bslots.p), e->bL.d(), (int64_t)Pq,
+                           e->bDinv.d(), e->bscal.d()
 #ifdef DK_TRACE
                            , (long long*)nullptr
 #endif
@@ -1152,7 +1161,7 @@ void enqueue_update(Engine* e, const StepPtrs& s, int64_t t, const double* y, co
     }
     {
         Scope sc(e, st, "dk_trsm", prof);
-        hipLaunchKernelGGL(dk_trsm, dim3((Dp + 16) / 16), dim3(256), 0, st, e->bL.d(), e->bDinv.d(), e->bV.d(), Pq, e->bB.d(), e->ldB);
+        hipLaunchKernelGGL(dk_trsm, dim3((Dp + 16) / 16), dim3(256), 0, st, e->bL.d(), (int64_t)Pq, e->bDinv.d(), e->bV.d(), (int64_t)Pq, Pq, e->bB.d(), e->ldB);
     }
     {   // P = Pp - B'B; rider: m = mp + B' alpha, lml_t
         GemmArgs g;
@@ -1163,14 +1172,14 @@ void enqueue_update(Engine* e, const StepPtrs& s, int64_t t, const double* y, co
         g.sign = -1.0;
         g.M = g.N = Dp; g.K = Pq;
         if (P_out) {
-            g.C2 = P_out + t * (int64_t)e->d * e->d; g.ldc2 = e->d; g.M2 = g.N2 = e->d;
+            g.C2 = P_out + t * (int64_t)out_n * out_n; g.ldc2 = out_n; g.M2 = g.N2 = out_n;
         }
         g.v.mode = 3;
         g.v.Mx = e->bB.d(); g.v.ld = e->ldB; g.v.n = Dp; g.v.K = Pq;
         g.v.x = e->bB.d() + Dp; g.v.xs = e->ldB;
         g.v.add = e->bmp.d(); g.v.out = e->bm.d();
         if (m_out) {
-            g.v.out2 = m_out + t * e->d; g.v.n2 = e->d;
+            g.v.out2 = m_out + t * out_n; g.v.n2 = out_n;
         }
         g.v.p = e->p; g.v.scal = e->bscal.d(); g.v.stats = result8; g.v.tstep = t;
         Scope sc(e, st, "dk_gemm<Pp - B'B>", prof);
@@ -1260,8 +1269,204 @@ int marginals(Engine* e, double* mean_out, double* var_out, double* result8, hip
     return TGP_OK;
 }
 
-int posterior_marginals(Engine* e, const double*, const uint8_t*, const double*, int64_t, double*, double*, double*, hipStream_t) {
-    return e->fail(TGP_EUNSUPPORTED, "dense path: posterior marginals not built yet");
+namespace {
+
+constexpr int kBlk = 256;     // diagonal block of the blocked d x d factorisation = what dk_chol / dk_trsm handle in one launch
+
+// emission marginals of the state (mx, Px): mean = H mx + h, var = diag(H Px H') + Rv  ->  mean_out / var_out (p values)
+void enqueue_emit(Engine* e, const StepPtrs& s, const double* mx, const double* Px, const double* Rv, double* mean_out, double* var_out, hipStream_t st) {
+    const int Dp = e->Dp, Pq = e->Pq;
+    if (e->nnzH) {
+        SpVec v;
+        v.mode = 2; v.x = mx; v.out = e->bV.d() + (size_t)Dp * Pq;
+        v.y = e->bzero.d(); v.mask = nullptr; v.hh = s.h; v.p = e->p; v.scal = e->bscal.d();
+        hipLaunchKernelGGL(dk_spl<2>, dim3((Pq + 255) / 256, (Dp + 1) / 2 + 1), dim3(256), 0, st, static_cast<const int*>(e->bHcol.p), e->bHval.d(), e->nnzH,
+                           Pq, Px, (int64_t)Dp, e->bV.d(), (int64_t)Pq, Dp, v);
+    } else {
+        GemmArgs g;
+        g.A = s.H; g.lda = Pq;
+        g.B = Px; g.ldb = Dp;
+        g.C = e->bV.d(); g.ldc = Pq;
+        g.M = Pq; g.N = Dp; g.K = Dp;
+        g.v.mode = 2;
+        g.v.Mx = s.H; g.v.ld = Pq; g.v.n = Pq; g.v.K = Dp;
+        g.v.x = mx; g.v.xs = 1;
+        g.v.out = e->bV.d() + (size_t)Dp * Pq;
+        g.v.y = e->bzero.d(); g.v.mask = nullptr; g.v.hh = s.h; g.v.p = e->p;
+        g.v.scal = e->bscal.d();
+        launch_gemm(g, st);
+    }
+    hipLaunchKernelGGL(dk_marg_diag, dim3((e->p + 255) / 256), dim3(256), 0, st, e->bV.d(), s.H, Pq, Dp, Rv, e->bV.d() + (size_t)Dp * Pq, e->p, mean_out,
+                       var_out);
+}
+
+// Blocked Cholesky of the Dp x Dp matrix Sm (column-major, ld Dp; overwritten by the trailing updates) + jitter I:
+// L -> e->bLd (column-major, ld Dp), inverses of its 16 x 16 diagonal tiles -> e->bDinvd. Diagonal blocks of 256 by dk_chol,
+// the panel below by dk_trsm (written in place: B = L_kk^-1 S_k,rest in row-major IS the column-major panel of L), the trailing
+// update by dk_gemm.
+void enqueue_chol_blocked(Engine* e, double* Sm, double jitter, hipStream_t st) {
+    const int n = e->Dp;
+    const int64_t ld = n;
+    double* Lb = e->bLd.d();
+    for (int k0 = 0; k0 < n; k0 += kBlk) {
+        const int nb = std::min(kBlk, n - k0);
+        const int* slots = static_cast<const int*>(nb == std::min(kBlk, n) ? e->bslots_blk.p : e->bslots_tail.p);
+        hipLaunchKernelGGL(dk_chol, dim3(1), dim3(1024), 0, st, Sm + k0 + (int64_t)k0 * ld, ld, nb, jitter, slots, Lb + k0 + (int64_t)k0 * ld, ld,
+                           e->bDinvd.d() + (size_t)(k0 / 16) * 256, e->bscal.d() + 4
+#ifdef DK_TRACE
+                           , (long long*)nullptr
+#endif
+        );
+        const int rest = n - k0 - nb;
+        if (rest <= 0) break;
+        hipLaunchKernelGGL(dk_trsm, dim3(rest / 16), dim3(256), 0, st, Lb + k0 + (int64_t)k0 * ld, ld, e->bDinvd.d() + (size_t)(k0 / 16) * 256,
+                           Sm + k0 + (int64_t)(k0 + nb) * ld, ld, nb, Lb + (k0 + nb) + (int64_t)k0 * ld, ld);
+        GemmArgs g;     // S[rest, rest] -= L[rest, k] L[rest, k]'
+        g.A = Lb + (k0 + nb) + (int64_t)k0 * ld; g.lda = ld;
+        g.B = g.A; g.ldb = ld;
+        g.C = Sm + (k0 + nb) + (int64_t)(k0 + nb) * ld; g.ldc = ld;
+        g.E = g.C; g.lde = ld; g.sign = -1.0;
+        g.M = g.N = rest; g.K = nb;
+        launch_gemm(g, st);
+    }
+}
+
+// X = L^-1 B with the blocked factor: B in the "V layout" (B[i][k] at Vb[i + k ldV], i < Dp, ncols columns; overwritten),
+// X row-major (X[i][k] at Xm[i ldX + k]).
+void enqueue_trsm_blocked(Engine* e, double* Vb, int64_t ldV, int ncols, double* Xm, int64_t ldX, hipStream_t st) {
+    const int n = e->Dp;
+    const int64_t ld = n;
+    const double* Lb = e->bLd.d();
+    for (int k0 = 0; k0 < n; k0 += kBlk) {
+        const int nb = std::min(kBlk, n - k0);
+        hipLaunchKernelGGL(dk_trsm, dim3(ncols / 16), dim3(256), 0, st, Lb + k0 + (int64_t)k0 * ld, ld, e->bDinvd.d() + (size_t)(k0 / 16) * 256, Vb + k0, ldV, nb,
+                           Xm + (int64_t)k0 * ldX, ldX);
+        const int rest = n - k0 - nb;
+        if (rest <= 0) break;
+        GemmArgs g;     // B[rest, :] -= L[rest, k] X[k, :]
+        g.A = Lb + (k0 + nb) + (int64_t)k0 * ld; g.lda = ld;
+        g.B = Xm + (int64_t)k0 * ldX; g.ldb = ldX;
+        g.C = Vb + (k0 + nb); g.ldc = ldV;
+        g.E = g.C; g.lde = ldV; g.sign = -1.0;
+        g.M = rest; g.N = ncols; g.K = nb;
+        launch_gemm(g, st);
+    }
+}
+
+__global__ void dk_copy_with_column(const double* __restrict__ P, int Dp, const double* __restrict__ ms, const double* __restrict__ mp, double* __restrict__ W) {
+    // W (Dp x (Dp + 16), ld Dp) = [P | ms - mp | 0 ...]
+    const int64_t n = (int64_t)Dp * (Dp + 16);
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t col = e / Dp;
+        const int i = (int)(e - col * Dp);
+        W[e] = col < Dp ? P[e] : (col == Dp ? ms[i] - mp[i] : 0.0);
+    }
+}
+
+}  // namespace
+
+// marginals(replace_observation_noise_cov(posterior(model, y), Rnew)) for the dense path: forward filter keeping the filtering
+// states, then per step the reference's invert_dynamics + Reverse step_marginals (lgssm.jl:111-115, 215-238) with
+//   Lc Lc' = Pp + 1e-10 I,  Z = Lc^-1 (A Pf),  G = Z' Lc^-1,  L = Pf - Z'Z,
+//   x <- G x + g = mf + Z' Lc^-1 (ms - mp),   P <- G Ps G' + L = Pf + Z' (W - I) Z  with  W = Lc^-1 Ps Lc^-T
+// so that only FORWARD substitutions with the blocked factor and MFMA GEMMs are needed.
+int posterior_marginals(Engine* e, const double* y, const uint8_t* mask, const double* Rnew, int64_t sRn, double* mean_out, double* var_out,
+                        double* result8, hipStream_t st) {
+    if (!e->have_model) return e->fail(TGP_EINVAL, "no model");
+    if (e->ordering != 0) return e->fail(TGP_EUNSUPPORTED, "dense path: posterior of a Reverse-ordered model is not implemented");
+    DCHK(hipSetDevice(e->device));
+    const int Dp = e->Dp, Pq = e->Pq;
+    const size_t DD = (size_t)Dp * Dp;
+    const int64_t ldW = Dp + 16;
+    size_t free_b = 0, total_b = 0;
+    DCHK(hipMemGetInfo(&free_b, &total_b));
+    const double need = (double)e->T * (double)(DD + Dp) * 8.0;
+    if (need > 0.8 * (double)(free_b + e->bPstore.cap + e->bmstore.cap))
+        return e->fail(TGP_EUNSUPPORTED, "dense path: the smoother keeps every filtering covariance (T d^2 doubles): T is too large for this GPU's free memory");
+    DCHK(e->bPstore.ensure((size_t)e->T * DD * 8));
+    DCHK(e->bmstore.ensure((size_t)e->T * Dp * 8));
+    DCHK(e->bLd.ensure(DD * 8));
+    DCHK(e->bDinvd.ensure((size_t)(Dp / 16) * 256 * 8));
+    for (Buf* b : {&e->bW0, &e->bW1, &e->bW2, &e->bW3}) DCHK(b->ensure((size_t)Dp * ldW * 8));
+    DCHK(e->bzero.ensure((size_t)Pq * 8));
+    DCHK(hipMemsetAsync(e->bzero.p, 0, (size_t)Pq * 8, st));
+    DCHK(hipMemsetAsync(e->bLd.p, 0, DD * 8, st));
+    DCHK(hipMemsetAsync(e->bscal.d() + 4, 0, 4 * sizeof(double), st));
+    {   // slot tables of dk_chol for the block sizes of the blocked factorisation (256, or Dp if smaller, and the tail)
+        std::vector<int> tab;
+        chol_slot_table(std::min(kBlk, Dp) / 16, tab);
+        DCHK(e->bslots_blk.ensure(tab.size() * sizeof(int)));
+        DCHK(hipMemcpyAsync(e->bslots_blk.p, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice, st));
+        std::vector<int> t2;
+        const int tail = Dp > kBlk ? Dp % kBlk : 0;
+        if (tail) {
+            chol_slot_table(tail / 16, t2);
+            DCHK(e->bslots_tail.ensure(t2.size() * sizeof(int)));
+            DCHK(hipMemcpyAsync(e->bslots_tail.p, t2.data(), t2.size() * sizeof(int), hipMemcpyHostToDevice, st));
+        }
+        DCHK(hipStreamSynchronize(st));     // the tables are host vectors on this frame
+    }
+    // ---- forward: filter, keeping (m_t, P_t) in the padded layout
+    {
+        DCHK(hipMemcpyAsync(e->bP.p, e->bx0.p, DD * 8, hipMemcpyDeviceToDevice, st));
+        DCHK(hipMemcpyAsync(e->bm.p, e->bx0.d() + DD, (size_t)Dp * 8, hipMemcpyDeviceToDevice, st));
+        for (int64_t t = 0; t < e->T; ++t) {
+            const StepPtrs s = step_ptrs(e, t);
+            enqueue_predict(e, s, st, false);
+            enqueue_update(e, s, t, y, mask, e->bmstore.d(), e->bPstore.d(), result8, st, false, Dp);
+            if ((t & 1023) == 1023) DCHK(hipStreamSynchronize(st));
+        }
+    }
+    // ---- backward: (bm, bP) hold the smoothed state of step t
+    int rc = TGP_OK;
+    for (int64_t t = e->T - 1; t >= 0; --t) {
+        const StepPtrs s = step_ptrs(e, t);
+        enqueue_emit(e, s, e->bm.d(), e->bP.d(), Rnew + (sRn ? t * e->p : 0), mean_out + t * e->p, var_out + t * e->p, st);
+        if (t == 0) break;
+        const double* Pf = e->bPstore.d() + (size_t)(t - 1) * DD;
+        const double* mf = e->bmstore.d() + (size_t)(t - 1) * Dp;
+        // predict from the filtering state of step t-1 with step t's transition: T1 = A Pf, Pp = T1 A' + Q, mp = A mf + a
+        DCHK(hipMemcpyAsync(e->bW3.p, e->bP.p, DD * 8, hipMemcpyDeviceToDevice, st));            // keep Ps
+        DCHK(hipMemcpyAsync(e->bW2.p, e->bm.p, (size_t)Dp * 8, hipMemcpyDeviceToDevice, st));    // keep ms (first Dp doubles of W2)
+        DCHK(hipMemcpyAsync(e->bP.p, Pf, DD * 8, hipMemcpyDeviceToDevice, st));
+        DCHK(hipMemcpyAsync(e->bm.p, mf, (size_t)Dp * 8, hipMemcpyDeviceToDevice, st));
+        enqueue_predict(e, s, st, false);                  // bT1 = A Pf, bPp, bmp
+        // W0 = [Ps | ms - mp | 0]
+        hipLaunchKernelGGL(dk_copy_with_column, dim3(512), dim3(256), 0, st, e->bW3.d(), Dp, e->bW2.d(), e->bmp.d(), e->bW0.d());
+        enqueue_chol_blocked(e, e->bPp.d(), 1e-10, st);    // Lc Lc' = Pp + 1e-10 I (lgssm.jl:235)
+        enqueue_trsm_blocked(e, e->bT1.d(), Dp, Dp, e->bW1.d(), ldW, st);            // Z  = Lc^-1 (A Pf)            -> W1 (row-major)
+        enqueue_trsm_blocked(e, e->bW0.d(), Dp, Dp + 16, e->bW2.d(), ldW, st);       // Y  = Lc^-1 [Ps | ms - mp]    -> W2; u = column Dp
+        enqueue_trsm_blocked(e, e->bW2.d(), ldW, Dp, e->bW3.d(), ldW, st);           // W  = Lc^-1 Y'                -> W3
+        {   // C' = Z' - Z' W  (= -((W - I) Z)')  -> bT1 (column-major, ld Dp)
+            GemmArgs g;
+            g.A = e->bW1.d(); g.lda = ldW;
+            g.B = e->bW3.d(); g.ldb = ldW;
+            g.C = e->bT1.d(); g.ldc = Dp;
+            g.E = e->bW1.d(); g.lde = ldW; g.sign = -1.0;
+            g.M = g.N = g.K = Dp;
+            launch_gemm(g, st);
+        }
+        {   // Ps <- Pf - Z' (-(W - I) Z) = G Ps G' + L ; rider: ms <- mf + Z' u
+            GemmArgs g;
+            g.A = e->bW1.d(); g.lda = ldW;
+            g.B = e->bT1.d(); g.ldb = Dp;
+            g.C = e->bP.d(); g.ldc = Dp;
+            g.E = Pf; g.lde = Dp; g.sign = -1.0;
+            g.M = g.N = g.K = Dp;
+            g.v.mode = 1;
+            g.v.Mx = e->bW1.d(); g.v.ld = ldW; g.v.n = Dp; g.v.K = Dp;
+            g.v.x = e->bW2.d() + Dp; g.v.xs = ldW; g.v.add = mf; g.v.out = e->bm.d();
+            launch_gemm(g, st);
+        }
+        if ((t & 255) == 255) DCHK(hipStreamSynchronize(st));
+    }
+    if (hipStreamSynchronize(st) != hipSuccess) rc = e->fail(TGP_EHIP, "dense smoother: stream error");
+    if (rc == TGP_OK) {
+        double flag[4] = {0, 0, 0, 0};
+        DCHK(hipMemcpy(flag, e->bscal.d() + 4, 4 * sizeof(double), hipMemcpyDeviceToHost));
+        if (flag[3] != 0.0) rc = e->fail(TGP_ENOTPD, "dense smoother: predicted covariance not positive definite (lgssm.jl:235)");
+    }
+    return rc;
 }
 
 }  // namespace tgp_dense

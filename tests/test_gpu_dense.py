@@ -135,6 +135,72 @@ def test_space_time_dense_model_matches_posterior_and_lml_small(Nr, T):
     assert abs(lp - lp_ref2) <= 1e-10 * abs(lp_ref2)
 
 
+SMOOTHER_CASES = [  # T, d, p, per-step blocks, missing data
+    (6, 17, 1, False, False),
+    (7, 20, 5, False, True),
+    (6, 48, 16, True, False),
+    (5, 192, 64, False, True),
+    (4, 272, 40, True, False),        # 272 = one 256-block + a 16-tail of the blocked d x d factorisation
+    (3, 528, 33, False, False),       # two full blocks + tail
+]
+
+
+@pytest.mark.parametrize("case", SMOOTHER_CASES, ids=lambda c: f"T{c[0]}-d{c[1]}-p{c[2]}{'-ps' if c[3] else ''}{'-miss' if c[4] else ''}")
+def test_dense_posterior_marginals_match_oracle(case):
+    """marginals(replace_observation_noise_cov(posterior(model, y), R_new)) (posterior_lti_sde.jl:27-36 -> lgssm.jl:193-238,
+    99-115) for d > 16: forward MFMA filter + RTS smoother with the blocked d x d Cholesky against the oracle's literal chain.
+    Tolerance 1e-8 (the 1e-10 jitter of invert_dynamics is the same on both sides; fp64 round-off only)."""
+    import temporalgps_jl_amd as tgp
+    T, d, p, per_step, miss = case
+    rng = np.random.default_rng(2000 + d + p)
+    model, Rd = random_model(rng, T, d, p, "F", per_step)
+    y = rng.standard_normal((T, p))
+    Rn = rng.uniform(0.01, 0.2, size=(T, p))
+    dm = to_dev(tgp, model, Rd)
+    if miss:
+        mk = rng.random((T, p)) < 0.2
+        m2, y2, comp = with_missing(model, y, mk)
+        yin = np.where(mk, np.nan, y)
+    else:
+        m2, y2, comp, yin = model, y, 0.0, y
+    pm, pC = ref.marginals(ref.replace_observation_noise_cov(ref.posterior(m2, y2), np.stack([np.diag(v) for v in Rn])))
+    pv = np.diagonal(pC, axis1=-2, axis2=-1)
+    sh = (T,) if p == 1 else (T, p)
+    pm, pv = pm.reshape(sh), pv.reshape(sh)
+    yin = yin.reshape(sh)
+    Rn = Rn.reshape(sh)
+    gm, gv = tgp.posterior_marginals(dm, yin, Rn)
+    np.testing.assert_allclose(gm, pm, rtol=0, atol=1e-8 * max(1.0, np.abs(pm).max()))
+    np.testing.assert_allclose(gv, pv, rtol=1e-8, atol=1e-10)
+    # the reference's call chain on the lazy posterior object reaches the same entry point; the combined call adds the lml
+    gm2, gv2 = tgp.marginals(tgp.replace_observation_noise_cov(tgp.posterior(dm, yin), Rn.reshape(T, p)))
+    np.testing.assert_array_equal(gm2, gm)
+    np.testing.assert_array_equal(gv2, gv)
+    lml, gm3, gv3 = tgp.logpdf_and_posterior_marginals(dm, yin, Rn)
+    lp_ref = ref.logpdf(m2, y2) + comp
+    assert abs(lml - lp_ref) <= 1e-10 * abs(lp_ref)
+    np.testing.assert_array_equal(gm3, gm)
+
+
+def test_space_time_dense_posterior_marginals_d768():
+    """BASELINE config 5's model (d = 768, p = 256) at short T: smoothed marginals with the structured and the dense products."""
+    import temporalgps_jl_amd as tgp
+    from temporalgps_jl_amd import _lib, space_time
+    Nr, T = 256, 4
+    r, k, grid = _space_time(Nr, T)
+    model = oc.build_lgssm_separable(("se",), ("matern52",), r, ("regular", 0.0, 0.01, T), 0.1)
+    rng = np.random.default_rng(11)
+    Y = rng.standard_normal((T, Nr))
+    pm, pC = ref.marginals(ref.replace_observation_noise_cov(ref.posterior(model, Y), np.stack([np.eye(Nr) * 0.05] * T)))
+    pv = np.diagonal(pC, axis1=-2, axis2=-1)
+    for structure in (1, 0):
+        dm = space_time.build_lgssm(k, grid, 0.1)
+        dm.handle_options[_lib.OPT_DENSE_STRUCTURE] = structure
+        gm, gv = tgp.posterior_marginals(dm, Y, np.full((1, Nr), 0.05))
+        np.testing.assert_allclose(gm, pm, rtol=0, atol=1e-7 * max(1.0, np.abs(pm).max()))
+        np.testing.assert_allclose(gv, pv, rtol=1e-7, atol=1e-9)
+
+
 def test_dense_not_positive_definite_is_reported():
     import temporalgps_jl_amd as tgp
     from temporalgps_jl_amd import _lib
