@@ -1184,6 +1184,7 @@ int tgp_posterior_marginals(tgp_handle* h, const double* y, const uint8_t* missi
         TRY(stage_out(h, h->bo1, mean_out, nT, odev, &dm2));
         TRY(stage_out(h, h->bo2, var_out, nT, odev, &dv2));
         tgp_dense::set_profile(h->dense, h->profile);
+        tgp_dense::set_segment(h->dense, h->opt_chunk);     // TGP_OPT_CHUNK: segment length of the checkpointed smoother
         TRY(dense_fail(h, tgp_dense::posterior_marginals(h->dense, h->mv.y, h->mv.missing, (const double*)pR, rshared ? 0 : h->p, dm2, dv2,
                                                          h->result.d(), h->stream)));
         tm.kernels_done();

@@ -722,14 +722,24 @@ template <int JB> __global__ __launch_bounds__(256) void dk_spr(const int* __res
 
 // ------------------------------------------------------------------------------------------------ prior marginals of one step
 // mean_i = (H mp + h)_i (rider of the V = H Pp launch writes -r = H mp + h - 0 ... see host code), var_i = sum_k V[i][k] H[i][k] + R_i
-__global__ void dk_marg_diag(const double* __restrict__ V, const double* __restrict__ Hk, int Pq, int Dp, const double* __restrict__ R,
-                             const double* __restrict__ res, int p, double* __restrict__ mean_out, double* __restrict__ var_out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= p) return;
+__global__ void __launch_bounds__(256) dk_marg_diag(const double* __restrict__ V, const double* __restrict__ Hk, int Pq, int Dp,
+                                                    const double* __restrict__ R, const double* __restrict__ res, int p,
+                                                    double* __restrict__ mean_out, double* __restrict__ var_out) {
+    // 16 rows x 16 K-slices per workgroup; the slices are summed in a fixed order
+    __shared__ double part[16][17];
+    const int r = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + r;            // < Pq (the grid covers ceil(p / 16) <= Pq / 16 row tiles)
     double s = 0.0;
-    for (int k = 0; k < Dp; ++k) s += V[i + (int64_t)k * Pq] * Hk[i + (int64_t)k * Pq];
-    var_out[i] = s + R[i];
-    mean_out[i] = -res[i];   // res = 0 - h - H mp
+    for (int k = sl; k < Dp; k += 16) s += V[i + (int64_t)k * Pq] * Hk[i + (int64_t)k * Pq];
+    part[sl][r] = s;
+    __syncthreads();
+    if (sl == 0 && i < p) {
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += part[q][r];
+        var_out[i] = t + R[i];
+        mean_out[i] = -res[i];   // res = 0 - h - H mp
+    }
 }
 
 __global__ void dk_pack(const double* __restrict__ src, int64_t rs, int64_t cs, int rows, int cols, double* __restrict__ dst, int64_t ldd,
@@ -782,7 +792,8 @@ struct Engine {
     // state and work buffers
     Buf bm, bmp, bP, bPp, bT1, bV, bS, bL, bDinv, bB, bscal, bslots;
     // RTS smoother (posterior_marginals): stored filtering states, the blocked d x d Cholesky factor, work matrices
-    Buf bPstore, bmstore, bLd, bDinvd, bW0, bW1, bW2, bW3, bslots_blk, bslots_tail, bzero;
+    Buf bPstore, bmstore, bLd, bDinvd, bW0, bW1, bW2, bW3, bslots_blk, bslots_tail, bzero, bPbound, bmbound;
+    int64_t segment_opt = 0;     // smoother segment length (0 = automatic); tests force small segments
     // ELL form of a shared A / H with few entries per row (0 == dense)
     int structure_opt = 1;
     int nnzA = 0, nnzH = 0;
@@ -817,7 +828,7 @@ void destroy(Engine* e) {
     if (!e) return;
     for (Buf* b : {&e->bA, &e->bQ, &e->bH, &e->ba, &e->bh, &e->bR, &e->bx0, &e->bm, &e->bmp, &e->bP, &e->bPp, &e->bT1, &e->bV, &e->bS,
                    &e->bL, &e->bDinv, &e->bB, &e->bscal, &e->bslots, &e->bAcol, &e->bAval, &e->bHcol, &e->bHval, &e->bPstore, &e->bmstore, &e->bLd, &e->bDinvd, &e->bW0, &e->bW1, &e->bW2, &e->bW3,
-                   &e->bslots_blk, &e->bslots_tail, &e->bzero})
+                   &e->bslots_blk, &e->bslots_tail, &e->bzero, &e->bPbound, &e->bmbound})
         b->release();
     for (auto& pe : e->pending) {
         (void)hipEventDestroy(pe.a);
@@ -829,6 +840,7 @@ void destroy(Engine* e) {
 const std::string& last_error(const Engine* e) { return e->err; }
 void set_profile(Engine* e, int on) { e->profile = on; }
 void set_structure(Engine* e, int on) { e->structure_opt = on; }
+void set_segment(Engine* e, int64_t steps) { e->segment_opt = steps; }
 int structure(const Engine* e) { return (e->nnzA ? 1 : 0) | (e->nnzH ? 2 : 0); }
 static void resolve_pending(Engine* e);
 int profile_count(Engine* e) {
@@ -1250,7 +1262,7 @@ int marginals(Engine* e, double* mean_out, double* var_out, double* result8, hip
             g.v.y = zero.d(); g.v.mask = nullptr; g.v.hh = s.h; g.v.p = e->p;
             g.v.scal = e->bscal.d();
             launch_gemm(g, st);
-            hipLaunchKernelGGL(dk_marg_diag, dim3((e->p + 255) / 256), dim3(256), 0, st, e->bV.d(), s.H, Pq, Dp, s.R,
+            hipLaunchKernelGGL(dk_marg_diag, dim3((e->p + 15) / 16), dim3(256), 0, st, e->bV.d(), s.H, Pq, Dp, s.R,
                                e->bV.d() + (size_t)Dp * Pq, e->p, mean_out + t * e->p, var_out + t * e->p);
         };
         if (e->ordering == 0) {
@@ -1296,7 +1308,7 @@ void enqueue_emit(Engine* e, const StepPtrs& s, const double* mx, const double* 
         g.v.scal = e->bscal.d();
         launch_gemm(g, st);
     }
-    hipLaunchKernelGGL(dk_marg_diag, dim3((e->p + 255) / 256), dim3(256), 0, st, e->bV.d(), s.H, Pq, Dp, Rv, e->bV.d() + (size_t)Dp * Pq, e->p, mean_out,
+    hipLaunchKernelGGL(dk_marg_diag, dim3((e->p + 15) / 16), dim3(256), 0, st, e->bV.d(), s.H, Pq, Dp, Rv, e->bV.d() + (size_t)Dp * Pq, e->p, mean_out,
                        var_out);
 }
 
@@ -1363,6 +1375,55 @@ __global__ void dk_copy_with_column(const double* __restrict__ P, int Dp, const 
     }
 }
 
+// One backward step: (bm, bP) = smoothed state of step t  ->  smoothed state of step t - 1, given the filtering state
+// (mf, Pf) of step t - 1 and step t's transition.
+int smoother_move(Engine* e, int64_t t, const double* Pf, const double* mf, hipStream_t st, bool prof) {
+    const int Dp = e->Dp;
+    const size_t DD = (size_t)Dp * Dp;
+    const int64_t ldW = Dp + 16;
+    const StepPtrs s = step_ptrs(e, t);
+    // predict from the filtering state of step t-1 with step t's transition: T1 = A Pf, Pp = T1 A' + Q, mp = A mf + a
+    DCHK(hipMemcpyAsync(e->bW3.p, e->bP.p, DD * 8, hipMemcpyDeviceToDevice, st));            // keep Ps
+    DCHK(hipMemcpyAsync(e->bW2.p, e->bm.p, (size_t)Dp * 8, hipMemcpyDeviceToDevice, st));    // keep ms (first Dp doubles of W2)
+    DCHK(hipMemcpyAsync(e->bP.p, Pf, DD * 8, hipMemcpyDeviceToDevice, st));
+    DCHK(hipMemcpyAsync(e->bm.p, mf, (size_t)Dp * 8, hipMemcpyDeviceToDevice, st));
+    enqueue_predict(e, s, st, prof);                   // bT1 = A Pf, bPp, bmp
+    hipLaunchKernelGGL(dk_copy_with_column, dim3(512), dim3(256), 0, st, e->bW3.d(), Dp, e->bW2.d(), e->bmp.d(), e->bW0.d());   // W0 = [Ps | ms - mp | 0]
+    {
+        Scope sc(e, st, "smoother: blocked chol(Pp)", prof);
+        enqueue_chol_blocked(e, e->bPp.d(), 1e-10, st);    // Lc Lc' = Pp + 1e-10 I (lgssm.jl:235)
+    }
+    {
+        Scope sc(e, st, "smoother: 3 blocked trsm", prof);
+        enqueue_trsm_blocked(e, e->bT1.d(), Dp, Dp, e->bW1.d(), ldW, st);            // Z  = Lc^-1 (A Pf)            -> W1 (row-major)
+        enqueue_trsm_blocked(e, e->bW0.d(), Dp, Dp + 16, e->bW2.d(), ldW, st);       // Y  = Lc^-1 [Ps | ms - mp]    -> W2; u = column Dp
+        enqueue_trsm_blocked(e, e->bW2.d(), ldW, Dp, e->bW3.d(), ldW, st);           // W  = Lc^-1 Y'                -> W3
+    }
+    Scope sc(e, st, "smoother: 2 dk_gemm (Pf + Z'(W - I)Z)", prof);
+    {   // C' = Z' - Z' W  (= -((W - I) Z)')  -> bT1 (column-major, ld Dp)
+        GemmArgs g;
+        g.A = e->bW1.d(); g.lda = ldW;
+        g.B = e->bW3.d(); g.ldb = ldW;
+        g.C = e->bT1.d(); g.ldc = Dp;
+        g.E = e->bW1.d(); g.lde = ldW; g.sign = -1.0;
+        g.M = g.N = g.K = Dp;
+        launch_gemm(g, st);
+    }
+    {   // Ps <- Pf - Z' (-(W - I) Z) = G Ps G' + L ; rider: ms <- mf + Z' u
+        GemmArgs g;
+        g.A = e->bW1.d(); g.lda = ldW;
+        g.B = e->bT1.d(); g.ldb = Dp;
+        g.C = e->bP.d(); g.ldc = Dp;
+        g.E = Pf; g.lde = Dp; g.sign = -1.0;
+        g.M = g.N = g.K = Dp;
+        g.v.mode = 1;
+        g.v.Mx = e->bW1.d(); g.v.ld = ldW; g.v.n = Dp; g.v.K = Dp;
+        g.v.x = e->bW2.d() + Dp; g.v.xs = ldW; g.v.add = mf; g.v.out = e->bm.d();
+        launch_gemm(g, st);
+    }
+    return TGP_OK;
+}
+
 }  // namespace
 
 // marginals(replace_observation_noise_cov(posterior(model, y), Rnew)) for the dense path: forward filter keeping the filtering
@@ -1378,18 +1439,30 @@ int posterior_marginals(Engine* e, const double* y, const uint8_t* mask, const d
     const int Dp = e->Dp, Pq = e->Pq;
     const size_t DD = (size_t)Dp * Dp;
     const int64_t ldW = Dp + 16;
+    const int64_t T = e->T;
+    // Storage of the filtering states the backward pass reads. All T of them when they fit in a quarter of the free memory;
+    // otherwise segments of S ~ sqrt(T) steps: pass 1 keeps the state at every segment boundary, the backward pass re-filters
+    // one segment at a time from its boundary (bit-identical: the kernels reduce in a fixed order), 2 filters + 1 smoother.
     size_t free_b = 0, total_b = 0;
     DCHK(hipMemGetInfo(&free_b, &total_b));
-    const double need = (double)e->T * (double)(DD + Dp) * 8.0;
-    if (need > 0.8 * (double)(free_b + e->bPstore.cap + e->bmstore.cap))
-        return e->fail(TGP_EUNSUPPORTED, "dense path: the smoother keeps every filtering covariance (T d^2 doubles): T is too large for this GPU's free memory");
-    DCHK(e->bPstore.ensure((size_t)e->T * DD * 8));
-    DCHK(e->bmstore.ensure((size_t)e->T * Dp * 8));
+    const double avail = (double)free_b + (double)e->bPstore.cap + (double)e->bmstore.cap + (double)e->bPbound.cap + (double)e->bmbound.cap;
+    const double per_step = (double)(DD + Dp) * 8.0;
+    int64_t S = T;
+    if (e->segment_opt > 0) S = std::min<int64_t>(T, e->segment_opt);
+    else if ((double)T * per_step > 0.25 * avail) S = std::max<int64_t>(16, (int64_t)std::ceil(std::sqrt((double)T)));
+    const int64_t nseg = (T + S - 1) / S;
+    if ((double)(S + nseg) * per_step > 0.8 * avail)
+        return e->fail(TGP_EUNSUPPORTED, "dense path: the smoother's stored filtering covariances (2 sqrt(T) d^2 doubles) do not fit in this GPU's free memory");
+    DCHK(e->bPstore.ensure((size_t)S * DD * 8));
+    DCHK(e->bmstore.ensure((size_t)S * Dp * 8));
+    DCHK(e->bPbound.ensure((size_t)nseg * DD * 8));
+    DCHK(e->bmbound.ensure((size_t)nseg * Dp * 8));
     DCHK(e->bLd.ensure(DD * 8));
     DCHK(e->bDinvd.ensure((size_t)(Dp / 16) * 256 * 8));
     for (Buf* b : {&e->bW0, &e->bW1, &e->bW2, &e->bW3}) DCHK(b->ensure((size_t)Dp * ldW * 8));
-    DCHK(e->bzero.ensure((size_t)Pq * 8));
-    DCHK(hipMemsetAsync(e->bzero.p, 0, (size_t)Pq * 8, st));
+    DCHK(e->bzero.ensure((size_t)Pq * 8 + 64));
+    DCHK(hipMemsetAsync(e->bzero.p, 0, (size_t)Pq * 8 + 64, st));
+    double* scratch8 = e->bzero.d() + Pq;       // lml / flags of the re-filtered segments (already counted in pass 1)
     DCHK(hipMemsetAsync(e->bLd.p, 0, DD * 8, st));
     DCHK(hipMemsetAsync(e->bscal.d() + 4, 0, 4 * sizeof(double), st));
     {   // slot tables of dk_chol for the block sizes of the blocked factorisation (256, or Dp if smaller, and the tail)
@@ -1406,61 +1479,66 @@ int posterior_marginals(Engine* e, const double* y, const uint8_t* mask, const d
         }
         DCHK(hipStreamSynchronize(st));     // the tables are host vectors on this frame
     }
-    // ---- forward: filter, keeping (m_t, P_t) in the padded layout
-    {
-        DCHK(hipMemcpyAsync(e->bP.p, e->bx0.p, DD * 8, hipMemcpyDeviceToDevice, st));
-        DCHK(hipMemcpyAsync(e->bm.p, e->bx0.d() + DD, (size_t)Dp * 8, hipMemcpyDeviceToDevice, st));
-        for (int64_t t = 0; t < e->T; ++t) {
+    // filter steps [t0, t1) from the state in (bm, bP); keep every state of the segment when `keep`
+    auto filter_range = [&](int64_t t0, int64_t t1, bool keep, double* res) -> int {
+        for (int64_t t = t0; t < t1; ++t) {
             const StepPtrs s = step_ptrs(e, t);
-            enqueue_predict(e, s, st, false);
-            enqueue_update(e, s, t, y, mask, e->bmstore.d(), e->bPstore.d(), result8, st, false, Dp);
-            if ((t & 1023) == 1023) DCHK(hipStreamSynchronize(st));
+            const bool prof = e->profile && res == result8 && (t % 16 == 8 || T < 64);
+            enqueue_predict(e, s, st, prof);
+            enqueue_update(e, s, t, y, mask, keep ? e->bmstore.d() - t0 * Dp : nullptr, keep ? e->bPstore.d() - t0 * (int64_t)DD : nullptr, res, st, prof,
+                           Dp);
+            if ((t & 1023) == 1023) {
+                DCHK(hipStreamSynchronize(st));
+                resolve(e);
+            }
         }
+        return TGP_OK;
+    };
+    // ---- pass 1: filter (lml into result8), keeping the state that enters every segment; the last segment is kept in full
+    DCHK(hipMemcpyAsync(e->bP.p, e->bx0.p, DD * 8, hipMemcpyDeviceToDevice, st));
+    DCHK(hipMemcpyAsync(e->bm.p, e->bx0.d() + DD, (size_t)Dp * 8, hipMemcpyDeviceToDevice, st));
+    for (int64_t seg = 0; seg < nseg; ++seg) {
+        DCHK(hipMemcpyAsync(e->bPbound.d() + seg * DD, e->bP.p, DD * 8, hipMemcpyDeviceToDevice, st));
+        DCHK(hipMemcpyAsync(e->bmbound.d() + seg * Dp, e->bm.p, (size_t)Dp * 8, hipMemcpyDeviceToDevice, st));
+        const int rcf = filter_range(seg * S, std::min(T, (seg + 1) * S), seg == nseg - 1, result8);
+        if (rcf != TGP_OK) return rcf;
     }
     // ---- backward: (bm, bP) hold the smoothed state of step t
-    int rc = TGP_OK;
-    for (int64_t t = e->T - 1; t >= 0; --t) {
-        const StepPtrs s = step_ptrs(e, t);
-        enqueue_emit(e, s, e->bm.d(), e->bP.d(), Rnew + (sRn ? t * e->p : 0), mean_out + t * e->p, var_out + t * e->p, st);
-        if (t == 0) break;
-        const double* Pf = e->bPstore.d() + (size_t)(t - 1) * DD;
-        const double* mf = e->bmstore.d() + (size_t)(t - 1) * Dp;
-        // predict from the filtering state of step t-1 with step t's transition: T1 = A Pf, Pp = T1 A' + Q, mp = A mf + a
-        DCHK(hipMemcpyAsync(e->bW3.p, e->bP.p, DD * 8, hipMemcpyDeviceToDevice, st));            // keep Ps
-        DCHK(hipMemcpyAsync(e->bW2.p, e->bm.p, (size_t)Dp * 8, hipMemcpyDeviceToDevice, st));    // keep ms (first Dp doubles of W2)
-        DCHK(hipMemcpyAsync(e->bP.p, Pf, DD * 8, hipMemcpyDeviceToDevice, st));
-        DCHK(hipMemcpyAsync(e->bm.p, mf, (size_t)Dp * 8, hipMemcpyDeviceToDevice, st));
-        enqueue_predict(e, s, st, false);                  // bT1 = A Pf, bPp, bmp
-        // W0 = [Ps | ms - mp | 0]
-        hipLaunchKernelGGL(dk_copy_with_column, dim3(512), dim3(256), 0, st, e->bW3.d(), Dp, e->bW2.d(), e->bmp.d(), e->bW0.d());
-        enqueue_chol_blocked(e, e->bPp.d(), 1e-10, st);    // Lc Lc' = Pp + 1e-10 I (lgssm.jl:235)
-        enqueue_trsm_blocked(e, e->bT1.d(), Dp, Dp, e->bW1.d(), ldW, st);            // Z  = Lc^-1 (A Pf)            -> W1 (row-major)
-        enqueue_trsm_blocked(e, e->bW0.d(), Dp, Dp + 16, e->bW2.d(), ldW, st);       // Y  = Lc^-1 [Ps | ms - mp]    -> W2; u = column Dp
-        enqueue_trsm_blocked(e, e->bW2.d(), ldW, Dp, e->bW3.d(), ldW, st);           // W  = Lc^-1 Y'                -> W3
-        {   // C' = Z' - Z' W  (= -((W - I) Z)')  -> bT1 (column-major, ld Dp)
-            GemmArgs g;
-            g.A = e->bW1.d(); g.lda = ldW;
-            g.B = e->bW3.d(); g.ldb = ldW;
-            g.C = e->bT1.d(); g.ldc = Dp;
-            g.E = e->bW1.d(); g.lde = ldW; g.sign = -1.0;
-            g.M = g.N = g.K = Dp;
-            launch_gemm(g, st);
+    for (int64_t seg = nseg - 1; seg >= 0; --seg) {
+        const int64_t t0 = seg * S, t1 = std::min(T, (seg + 1) * S);
+        if (seg != nseg - 1) {
+            // re-filter this segment from its boundary state; the smoothed state of step t1 - 1 waits in (W3, W2)
+            DCHK(hipMemcpyAsync(e->bW3.p, e->bP.p, DD * 8, hipMemcpyDeviceToDevice, st));
+            DCHK(hipMemcpyAsync(e->bW2.p, e->bm.p, (size_t)Dp * 8, hipMemcpyDeviceToDevice, st));
+            DCHK(hipMemcpyAsync(e->bP.p, e->bPbound.d() + seg * DD, DD * 8, hipMemcpyDeviceToDevice, st));
+            DCHK(hipMemcpyAsync(e->bm.p, e->bmbound.d() + seg * Dp, (size_t)Dp * 8, hipMemcpyDeviceToDevice, st));
+            const int rcf = filter_range(t0, t1, true, scratch8);
+            if (rcf != TGP_OK) return rcf;
+            DCHK(hipMemcpyAsync(e->bP.p, e->bW3.p, DD * 8, hipMemcpyDeviceToDevice, st));
+            DCHK(hipMemcpyAsync(e->bm.p, e->bW2.p, (size_t)Dp * 8, hipMemcpyDeviceToDevice, st));
         }
-        {   // Ps <- Pf - Z' (-(W - I) Z) = G Ps G' + L ; rider: ms <- mf + Z' u
-            GemmArgs g;
-            g.A = e->bW1.d(); g.lda = ldW;
-            g.B = e->bT1.d(); g.ldb = Dp;
-            g.C = e->bP.d(); g.ldc = Dp;
-            g.E = Pf; g.lde = Dp; g.sign = -1.0;
-            g.M = g.N = g.K = Dp;
-            g.v.mode = 1;
-            g.v.Mx = e->bW1.d(); g.v.ld = ldW; g.v.n = Dp; g.v.K = Dp;
-            g.v.x = e->bW2.d() + Dp; g.v.xs = ldW; g.v.add = mf; g.v.out = e->bm.d();
-            launch_gemm(g, st);
+        for (int64_t t = t1 - 1; t >= t0; --t) {
+            const bool prof = e->profile && (t % 16 == 8 || T < 64);
+            {
+                const StepPtrs se = step_ptrs(e, t);
+                Scope sc(e, st, "smoother: emission marginals", prof);
+                enqueue_emit(e, se, e->bm.d(), e->bP.d(), Rnew + (sRn ? t * e->p : 0), mean_out + t * e->p, var_out + t * e->p, st);
+            }
+            if (t == 0) break;
+            // filtering state of step t - 1: inside this segment's store, or the state that entered the segment
+            const double* Pf = t > t0 ? e->bPstore.d() + (size_t)(t - 1 - t0) * DD : e->bPbound.d() + (size_t)seg * DD;
+            const double* mf = t > t0 ? e->bmstore.d() + (size_t)(t - 1 - t0) * Dp : e->bmbound.d() + (size_t)seg * Dp;
+            const int rcm = smoother_move(e, t, Pf, mf, st, prof);
+            if (rcm != TGP_OK) return rcm;
+            if ((t & 255) == 255) {
+                DCHK(hipStreamSynchronize(st));
+                resolve(e);
+            }
         }
-        if ((t & 255) == 255) DCHK(hipStreamSynchronize(st));
     }
+    int rc = TGP_OK;
     if (hipStreamSynchronize(st) != hipSuccess) rc = e->fail(TGP_EHIP, "dense smoother: stream error");
+    resolve(e);
     if (rc == TGP_OK) {
         double flag[4] = {0, 0, 0, 0};
         DCHK(hipMemcpy(flag, e->bscal.d() + 4, 4 * sizeof(double), hipMemcpyDeviceToHost));

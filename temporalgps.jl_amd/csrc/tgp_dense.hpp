@@ -40,6 +40,8 @@ const std::string& last_error(const Engine* e);
 void set_profile(Engine* e, int on);
 // 1 (default): a shared A / H with at most 8 entries per row is applied in sparse (ELL) form; 0: always the dense MFMA GEMMs
 void set_structure(Engine* e, int on);
+// posterior_marginals: length of the re-filtered segments (0 = automatic: all T steps stored if they fit, else ~sqrt(T))
+void set_segment(Engine* e, int64_t steps);
 int structure(const Engine* e);   // bit 0: A sparse, bit 1: H sparse (current model)
 int profile_count(Engine* e);
 KernelTime profile_get(const Engine* e, int idx);

@@ -28,11 +28,11 @@ def random_model(rng, T, d, p, ordering="F", per_step=False):
     return model, Rd
 
 
-def to_dev(tgp, model, Rd, **opts):
+def to_dev(tgp, model, Rd, opts=None):
     order = tgp.Forward if model["ordering"] == "F" else tgp.Reverse
     dm = tgp.LGSSM(tgp.GaussMarkovModel(order, model["A"], model["a"], model["Q"], tgp.Gaussian(model["x0m"], model["x0P"])),
                    tgp.SmallOutputLGC(model["H"], model["h"], Rd), T=model["T"])
-    dm.handle_options.update(opts)
+    dm.handle_options.update(opts or {})
     return dm
 
 
@@ -180,6 +180,24 @@ def test_dense_posterior_marginals_match_oracle(case):
     lp_ref = ref.logpdf(m2, y2) + comp
     assert abs(lml - lp_ref) <= 1e-10 * abs(lp_ref)
     np.testing.assert_array_equal(gm3, gm)
+
+
+def test_dense_smoother_segments_are_bit_identical():
+    """The smoother stores all T filtering states when they fit, else re-filters segments from stored boundary states
+    (2 filters + 1 backward pass). TGP_OPT_CHUNK forces the segment length: any segmentation gives the same bits."""
+    import temporalgps_jl_amd as tgp
+    from temporalgps_jl_amd import _lib
+    rng = np.random.default_rng(99)
+    T, d, p = 23, 36, 6
+    model, Rd = random_model(rng, T, d, p, "F", True)
+    y = np.where(rng.random((T, p)) < 0.15, np.nan, rng.standard_normal((T, p)))
+    Rn = rng.uniform(0.01, 0.2, size=(T, p))
+    base = tgp.logpdf_and_posterior_marginals(to_dev(tgp, model, Rd), y, Rn)
+    for seg in (1, 4, 5, 22, 23, 64):
+        got = tgp.logpdf_and_posterior_marginals(to_dev(tgp, model, Rd, {_lib.OPT_CHUNK: seg}), y, Rn)
+        assert got[0] == base[0], seg
+        np.testing.assert_array_equal(got[1], base[1])
+        np.testing.assert_array_equal(got[2], base[2])
 
 
 def test_space_time_dense_posterior_marginals_d768():
