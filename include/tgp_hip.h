@@ -75,6 +75,12 @@ typedef struct tgp_handle tgp_handle;
 #define TGP_OPT_DENSE_STRUCTURE 8 /* dense path (d > 16): 1 (default) a shared A / H with at most 8 entries per row (what
                                      lgssm_components(::Separable, ...) builds: I (x) A_t, I (x) H_t') is applied in sparse form; 0 the
                                      reference's dense products on the fp64 MFMA GEMM kernels. Set before tgp_model_set. */
+#define TGP_OPT_GRAPH 9 /* hipGraph replay of the launch chain of tgp_logpdf / tgp_[logpdf_and_]posterior_marginals: a call with device
+                           pointers that repeats the previous call's arguments is recorded once (stream capture, kernel nodes only)
+                           and then replayed with one hipGraphLaunch. 0 (default) off, 1 on, -1 on for T <= 2^20. Measured on
+                           BASELINE config 1 (T = 1e4): 84 us per combined call with and without replay -- the chain is bound by
+                           the dependent dispatches on the device, not by the host's enqueue -- hence off by default. Any other
+                           entry point, option or model change in between drops the recording. */
 #define TGP_OPT_TIMING 6 /* 1: record the hipEvents behind tgp_last_timing (off by default: ~30 us of host time per call) */
 #define TGP_OPT_FUSE_SCAN 4 /* 1 (default): the level-0 scan reduce / apply of the forward scan run inside the chunk kernels;
                                0: stand-alone k_scan_reduce / k_scan_apply launches (bit-identical results, for A/B timing) */
@@ -90,6 +96,8 @@ const char* tgp_version(void);
 /* which build of the kernels the current model runs on: 1 out-of-line (safe), 2 fully inlined (d = 5, 6 after the check);
    dense path (d > 16): 16 + (1 if A is applied in sparse form) + (2 if H is) */
 int tgp_kernel_variant(const tgp_handle* h);
+/* number of calls served by replaying a recorded hipGraph since the handle was created (TGP_OPT_GRAPH; measurement / tests) */
+int64_t tgp_graph_replays(const tgp_handle* h);
 
 /* ---- model: replaces the LGSSM / GaussMarkovModel containers -----------------------------------
  * lgssm.jl:9-12, gauss_markov_model.jl:20-32 (As, as, Qs, x0) + emissions (A = H', a = h, Q = R).

@@ -20,7 +20,7 @@ IN_DEVICE = 1 << 16
 OUT_DEVICE = 1 << 17
 REUSE_REDUCE = 1 << 18
 OK, EINVAL, ENOTPD, EHIP, EUNSUPPORTED = 0, 1, 2, 3, 4
-OPT_CHUNK, OPT_PROFILE, OPT_VARIANT, OPT_FUSE_SCAN, OPT_GROUP, OPT_TIMING, OPT_SPLIT_SMOOTHER, OPT_DENSE_STRUCTURE = 1, 2, 3, 4, 5, 6, 7, 8
+OPT_CHUNK, OPT_PROFILE, OPT_VARIANT, OPT_FUSE_SCAN, OPT_GROUP, OPT_TIMING, OPT_SPLIT_SMOOTHER, OPT_DENSE_STRUCTURE, OPT_GRAPH = 1, 2, 3, 4, 5, 6, 7, 8, 9
 
 _dp = ctypes.POINTER(ctypes.c_double)
 _u8p = ctypes.POINTER(ctypes.c_uint8)
@@ -36,6 +36,7 @@ _SIGS = {
     "tgp_set_stream": (ctypes.c_int, [_vp, _vp]),
     "tgp_version": (ctypes.c_char_p, []),
     "tgp_kernel_variant": (ctypes.c_int, [_vp]),
+    "tgp_graph_replays": (_i64, [_vp]),
     "tgp_model_set": (ctypes.c_int, [_vp, _i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, _u32] + [_vp] * 8),
     "tgp_model_set_sde": (ctypes.c_int, [_vp, _i64, ctypes.c_int, ctypes.c_int, _u32] + [_vp] * 10),
     "tgp_model_set_x0": (ctypes.c_int, [_vp, _vp, _vp]),

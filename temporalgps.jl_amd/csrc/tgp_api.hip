@@ -259,6 +259,19 @@ struct tgp_handle {
     int force_group_post = 0;
     DevBuf balt;
     int opt_split = 1;           // TGP_OPT_SPLIT_SMOOTHER
+    // hipGraph replay of the launch chain of repeated calls (TGP_OPT_GRAPH): slot 0 tgp_logpdf, 1 tgp_posterior_marginals
+    struct GraphSlot {
+        uint64_t key[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        bool seen = false;           // the key was used by the previous call (buffers are sized): the next one captures
+        bool failed = false;         // capture was refused for this chain
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        int64_t replays = 0;
+        uint64_t last_seq = 0;
+    } gslot[2];
+    int opt_graph = 0;           // TGP_OPT_GRAPH: 0 off (default: measured, no gain -- see DESIGN 9), 1 on, -1 on for T <= kGraphAutoT
+    int64_t graph_replays = 0;
+    uint64_t call_seq = 0;       // counts the compute entry points (check_ready): a graph is replayed only by the call right after its own
     int opt_group = 1;           // TGP_OPT_GROUP
     int opt_group_scan = 1;      // TGP_OPT_GROUP bit 2 (value & 4) switches the group-layout block scans off
     int opt_fuse = 1;            // TGP_OPT_FUSE_SCAN
@@ -549,6 +562,10 @@ int scan_total_to_host(tgp_handle* h, ScanCtx& c, double* elem_out) {
     return TGP_OK;
 }
 
+__global__ void k_zero8(double* r) {
+    if (threadIdx.x < 8) r[threadIdx.x] = 0.0;
+}
+
 struct CallTimer {
     tgp_handle* h;
     // clear == false: a later phase of a multi-phase (time-sharded) call, the flags of the earlier phases are kept.
@@ -556,14 +573,22 @@ struct CallTimer {
     // records and elapsed-time queries cost the host ~30 us per call, a few percent of a 0.4 ms logpdf.
     explicit CallTimer(tgp_handle* h_, bool clear = true) : h(h_) {
         if (h->timing) (void)hipEventRecord(h->ev[0], h->stream);
-        if (clear) (void)hipMemsetAsync(h->result.p, 0, 8 * sizeof(double), h->stream);   // lml / flags of this call
+        // lml / flags of this call (a kernel, not a memset node: the chain is also recorded into hipGraphs, kernel nodes only)
+        if (clear) hipLaunchKernelGGL(k_zero8, dim3(1), dim3(64), 0, h->stream, h->result.d());
     }
     void inputs_done() { if (h->timing) (void)hipEventRecord(h->ev[1], h->stream); }
     void kernels_done() { if (h->timing) (void)hipEventRecord(h->ev[2], h->stream); }
     // one 64-byte D2H into pinned memory + ONE stream sync per call; then decode lml and the error flags
     int finish(double* lml_out = nullptr) {
+        TRY(finish_enqueue());
+        return finish_wait(h, lml_out);
+    }
+    int finish_enqueue() {
         HIPCHK(hipMemcpyAsync(h->host_result, h->result.p, 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         if (h->timing) (void)hipEventRecord(h->ev[3], h->stream);
+        return TGP_OK;
+    }
+    static int finish_wait(tgp_handle* h, double* lml_out) {
         HIPCHK(hipStreamSynchronize(h->stream));
         if (h->timing) {
             float a = 0.f, b = 0.f, c = 0.f;
@@ -587,6 +612,7 @@ struct CallTimer {
 int check_ready(tgp_handle* h) {
     if (!h) return TGP_EINVAL;
     if (!h->have_model) return h->fail(TGP_EINVAL, "no model set (call tgp_model_set first)");
+    ++h->call_seq;
     return bind_device(h);
 }
 // entry points the dense large-state engine (d > 16) does not serve
@@ -595,6 +621,76 @@ int scan_only(tgp_handle* h, const char* what) {
     return TGP_OK;
 }
 int dense_fail(tgp_handle* h, int rc) { return rc == TGP_OK ? TGP_OK : h->fail(rc, tgp_dense::last_error(h->dense)); }
+
+// ---- hipGraph replay (TGP_OPT_GRAPH) --------------------------------------------------------------------------------------
+// A logpdf / posterior-marginals call on a short series is a chain of ~10-15 dependent launches of a few microseconds each:
+// the host's enqueue cost and the per-launch dispatch dominate (BASELINE config 1, T = 1e4). The second call with the same
+// device pointers records the chain into a hipGraph (stream capture: the same host code path, nothing is launched twice), later
+// calls replay it with one hipGraphLaunch. Any change of model, option, stream or argument drops the graph.
+constexpr int64_t kGraphAutoT = 1 << 20;
+void drop_graphs(tgp_handle* h) {
+    for (auto& g : h->gslot) {
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        if (g.graph) (void)hipGraphDestroy(g.graph);
+        g = tgp_handle::GraphSlot{};
+    }
+}
+bool graph_eligible(const tgp_handle* h, uint32_t flags, bool outputs) {
+    if (h->is_dense || h->profile || h->timing || h->opt_graph == 0) return false;
+    if (h->opt_graph < 0 && h->T > kGraphAutoT) return false;
+    if (!(flags & TGP_IN_DEVICE) || (flags & TGP_REUSE_REDUCE)) return false;      // host buffers are staged with sizes the host decides per call
+    return !outputs || (flags & TGP_OUT_DEVICE) != 0;
+}
+// body(): enqueues the kernels of the whole call on h->stream, no host synchronisation; the 64-byte result copy follows the graph
+template <class Body>
+int graph_call(tgp_handle* h, int slot, const uint64_t (&key)[8], Body&& body, double* lml_out) {
+    auto& g = h->gslot[slot];
+    // valid only for the call that directly follows its own previous use: any other entry point in between may have re-tiled the
+    // model, re-sized a buffer or changed the chunking the recorded launches were made for
+    const bool same = g.seen && std::memcmp(g.key, key, sizeof key) == 0 && g.last_seq + 1 == h->call_seq;
+    g.last_seq = h->call_seq;
+    if (same && g.exec) {
+        HIPCHK(hipGraphLaunch(g.exec, h->stream));
+        ++g.replays;
+        ++h->graph_replays;
+        HIPCHK(hipMemcpyAsync(h->host_result, h->result.p, 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        return CallTimer::finish_wait(h, lml_out);
+    }
+    if (same && !g.failed) {
+        if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeRelaxed) == hipSuccess) {
+            const int rc = body();
+            hipGraph_t graph = nullptr;
+            const hipError_t e2 = hipStreamEndCapture(h->stream, &graph);
+            if (rc == TGP_OK && e2 == hipSuccess && graph) {
+                hipGraphExec_t ex = nullptr;
+                if (hipGraphInstantiate(&ex, graph, nullptr, nullptr, 0) == hipSuccess) {
+                    g.graph = graph;
+                    g.exec = ex;
+                    HIPCHK(hipGraphLaunch(ex, h->stream));
+                    HIPCHK(hipMemcpyAsync(h->host_result, h->result.p, 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+                    return CallTimer::finish_wait(h, lml_out);
+                }
+            }
+            if (graph) (void)hipGraphDestroy(graph);
+            (void)hipGetLastError();
+            if (rc != TGP_OK && e2 == hipSuccess) return rc;     // an argument error found by the host code: report it
+        }
+        g.failed = true;     // this chain cannot be captured: plain launches from now on
+    }
+    if (!same) {
+        const bool failed = false;
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        if (g.graph) (void)hipGraphDestroy(g.graph);
+        g = tgp_handle::GraphSlot{};
+        g.failed = failed;
+        std::memcpy(g.key, key, sizeof key);
+        g.seen = true;
+        g.last_seq = h->call_seq;
+    }
+    TRY(body());
+    HIPCHK(hipMemcpyAsync(h->host_result, h->result.p, 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    return CallTimer::finish_wait(h, lml_out);
+}
 
 // General (per-step) layout: (re)build the time-tiled copy of the per-step arrays for the current chunk size.
 int ensure_tiled(tgp_handle* h) {
@@ -803,6 +899,7 @@ int tgp_destroy(tgp_handle* h) {
     if (!h) return TGP_OK;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
+    drop_graphs(h);
     for (DevBuf* b : {&h->bA, &h->ba, &h->bQ, &h->bH, &h->bh, &h->bR, &h->bx0, &h->bx0r, &h->bx0fold, &h->by, &h->bmiss, &h->bRnew, &h->beps_t,
                       &h->beps_e, &h->bo1, &h->bo2, &h->bo3, &h->F.slab, &h->Rv.slab, &h->fs, &h->partial, &h->result, &h->segtmp, &h->tile_t, &h->tile_e, &h->Fad.slab, &h->btan, &h->bx0ad, &h->tile_tan, &h->balt, &h->bF, &h->bPinf, &h->btimes, &h->bAQ1})
         b->release();
@@ -824,6 +921,12 @@ const char* tgp_last_error(const tgp_handle* h) { return h ? h->err.c_str() : "n
 
 int tgp_set_option(tgp_handle* h, int option, int64_t value) {
     if (!h) return TGP_EINVAL;
+    drop_graphs(h);
+    if (option == TGP_OPT_GRAPH) {
+        if (value < -1 || value > 1) return h->fail(TGP_EINVAL, "TGP_OPT_GRAPH must be -1 (auto), 0 or 1");
+        h->opt_graph = (int)value;
+        return TGP_OK;
+    }
     if (option == TGP_OPT_CHUNK) {
         if (value < 0 || value > 4096) return h->fail(TGP_EINVAL, "TGP_OPT_CHUNK out of range");
         h->opt_chunk = value;
@@ -883,8 +986,11 @@ int tgp_kernel_variant(const tgp_handle* h) {
     return h->variant_code;
 }
 
+int64_t tgp_graph_replays(const tgp_handle* h) { return h ? h->graph_replays : 0; }
+
 int tgp_set_stream(tgp_handle* h, void* hip_stream) {
     if (!h) return TGP_EINVAL;
+    drop_graphs(h);
     (void)hipStreamSynchronize(h->stream);
     h->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->own_stream;
     return TGP_OK;
@@ -892,6 +998,7 @@ int tgp_set_stream(tgp_handle* h, void* hip_stream) {
 
 int tgp_model_set(tgp_handle* h, int64_t T, int d, int p, int ordering, uint32_t flags, const double* A, const double* a,
                   const double* Q, const double* H, const double* hh, const double* R, const double* x0m, const double* x0P) {
+    if (h) drop_graphs(h);
     if (!h) return TGP_EINVAL;
     TRY(bind_device(h));
     h->have_model = false;
@@ -995,6 +1102,7 @@ int tgp_model_set(tgp_handle* h, int64_t T, int d, int p, int ordering, uint32_t
 int tgp_model_set_sde(tgp_handle* h, int64_t T, int d, int ordering, uint32_t flags, const double* F, const double* a, const double* H,
                       const double* hh, const double* R, const double* times, const double* A1, const double* Q1, const double* x0m,
                       const double* x0P) {
+    if (h) drop_graphs(h);
     if (!h) return TGP_EINVAL;
     if (!F || !times) return h->fail(TGP_EINVAL, "null F / times");
     if (d > 8) return h->fail(TGP_EUNSUPPORTED, "tgp_model_set_sde: d <= 8 (build the per-step blocks on the host for larger d)");
@@ -1033,6 +1141,7 @@ int tgp_model_set_sde(tgp_handle* h, int64_t T, int d, int ordering, uint32_t fl
 }
 
 int tgp_model_set_x0(tgp_handle* h, const double* x0m, const double* x0P) {
+    if (h) drop_graphs(h);
     TRY(check_ready(h));
     if (!x0m || !x0P) return h->fail(TGP_EINVAL, "null x0");
     if (h->is_dense) return dense_fail(h, tgp_dense::set_x0(h->dense, x0m, x0P, h->stream));
@@ -1046,6 +1155,17 @@ int tgp_model_set_x0(tgp_handle* h, const double* x0m, const double* x0P) {
 int tgp_logpdf(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t flags, double* out) {
     TRY(check_ready(h));
     if (!out) return h->fail(TGP_EINVAL, "out is NULL");
+    if (graph_eligible(h, flags, false)) {
+        const uint64_t key[8] = {1, (uint64_t)(uintptr_t)y, (uint64_t)(uintptr_t)missing, flags, 0, 0, 0, 0};
+        return graph_call(h, 0, key, [&]() -> int {
+            CallTimer tm(h);
+            TRY(set_obs(h, y, missing, flags));
+            TRY(forward_reduce(h, flags, 0));
+            FilterOut fo{};
+            TRY(forward_apply(h, 0, fo));
+            return TGP_OK;
+        }, out);
+    }
     CallTimer tm(h);
     TRY(set_obs(h, y, missing, flags));
     tm.inputs_done();
@@ -1174,6 +1294,17 @@ int tgp_posterior_marginals(tgp_handle* h, const double* y, const uint8_t* missi
     const bool idev = (flags & TGP_IN_DEVICE) != 0, odev = (flags & TGP_OUT_DEVICE) != 0;
     const bool rshared = (flags & TGP_SHARED_R) != 0;
     const size_t nT = (size_t)h->T * h->p * sizeof(double);   // one value per (time step, observation)
+    if (graph_eligible(h, flags, true)) {
+        const uint64_t key[8] = {2, (uint64_t)(uintptr_t)y, (uint64_t)(uintptr_t)missing, flags, (uint64_t)(uintptr_t)Rnew, (uint64_t)(uintptr_t)mean_out,
+                                 (uint64_t)(uintptr_t)var_out, 0};
+        return graph_call(h, 1, key, [&]() -> int {
+            CallTimer tm(h);
+            TRY(set_obs(h, y, missing, flags));
+            TRY(smoother_forward_impl(h, flags, nullptr, /*allow_group=*/true));
+            TRY(smoother_backward_impl(h, h->F.fin, Rnew, rshared ? 0 : 1, mean_out, var_out));
+            return TGP_OK;
+        }, lml_out);
+    }
     CallTimer tm(h);
     const void* pR = nullptr;
     TRY(stage_in(h, h->bRnew, Rnew, rshared ? (size_t)h->p * sizeof(double) : nT, idev, &pR));

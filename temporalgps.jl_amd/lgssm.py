@@ -575,9 +575,11 @@ def marginals(model):
     return mean, var        # vector observations: var is the DIAGONAL of the p x p marginal covariance (marginals_diag)
 
 
-def posterior_marginals(model, y, R_new, _with_lml=False):
+def posterior_marginals(model, y, R_new, _with_lml=False, out=None):
     """marginals(replace_observation_noise_cov(posterior(model, y), R_new)) without materialising the
-    posterior model -- the `marginals(posterior(fx, y)(x))` path (posterior_lti_sde.jl:27-36)."""
+    posterior model -- the `marginals(posterior(fx, y)(x))` path (posterior_lti_sde.jl:27-36).
+    out = (mean, var): result buffers of an earlier call to write into (a repeated call with the same device
+    buffers is replayed from a recorded hipGraph, TGP_OPT_GRAPH)."""
     if isinstance(model, PosteriorLGSSM):
         model = model.materialise()
     _check_inputs(model, y[0] if isinstance(y, tuple) else y)
@@ -600,7 +602,9 @@ def posterior_marginals(model, y, R_new, _with_lml=False):
         raise ValueError("R_new must have length 1 or T")
     if model.p > 1 and tuple(Rn.shape[1:]) != (model.p,):
         raise ValueError(f"R_new must be (T|1, {model.p}) (diagonal of the new noise)")
-    mean, var = _out(model, _osh(model), dev), _out(model, _osh(model), dev)
+    mean, var = out if out is not None else (_out(model, _osh(model), dev), _out(model, _osh(model), dev))
+    if out is not None and (_lib.is_device(mean) != bool(dev) or tuple(mean.shape) != _osh(model) or tuple(var.shape) != _osh(model)):
+        raise ValueError("out: buffers of another call shape / memory space")
     if _with_lml:
         lml = ctypes.c_double()
         hd.check(hd.lib.tgp_logpdf_and_posterior_marginals(hd.h, _lib.ptr(yy), _lib.ptr(mm), _lib.ptr(Rn), flags, ctypes.byref(lml),
@@ -611,13 +615,13 @@ def posterior_marginals(model, y, R_new, _with_lml=False):
     return mean, var
 
 
-def logpdf_and_posterior_marginals(model, y, R_new):
+def logpdf_and_posterior_marginals(model, y, R_new, out=None):
     """(logpdf(model, y), mean, var): logpdf and marginals(replace_observation_noise_cov(posterior(model, y), R_new)) of the
     same series from ONE forward filter + RTS smoother (tgp_logpdf_and_posterior_marginals) -- the log marginal likelihood
     is a by-product of the filter the posterior needs anyway. Diagonal noise (no whitening correction is applied here)."""
     if model._whiten is not None:
         raise NotImplementedError("logpdf_and_posterior_marginals with a dense observation-noise covariance")
-    return posterior_marginals(model, y, R_new, _with_lml=True)
+    return posterior_marginals(model, y, R_new, _with_lml=True, out=out)
 
 
 def posterior_marginals_at(model, y, H_new, h_new, R_new):

@@ -320,12 +320,13 @@ class ShardedLGSSM:
         reuse = self._forward_exchange(y)
         return self._all_reduce_sum(self.engine.logpdf(y, reuse))
 
-    def logpdf_and_posterior_marginals(self, y, R_new):
+    def logpdf_and_posterior_marginals(self, y, R_new, out=None):
         """(logpdf of the WHOLE series, this rank's slice of the posterior marginals) from one forward filter + RTS smoother
         (tgp_logpdf_and_posterior_marginals): the per-segment log-likelihood shares are by-products of the smoother's
-        forward pass and are summed across ranks with one scalar all-reduce."""
+        forward pass and are summed across ranks with one scalar all-reduce. out = (mean, var) of an earlier call: written in
+        place (single GPU: lets the library replay the call from its recorded hipGraph)."""
         if self.world == 1 and self.engine is None:
-            return L.logpdf_and_posterior_marginals(self.model, y, R_new)
+            return L.logpdf_and_posterior_marginals(self.model, y, R_new, out=out)
         if self._device_resident():
             mean, var = self._posterior_marginals_device(y, R_new)
             return self._all_reduce_sum(self.engine.last_segment_lml), mean, var

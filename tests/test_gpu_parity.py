@@ -370,3 +370,57 @@ def test_posterior_of_a_reverse_ordered_model(tgp, tv, d):
     scale = max(1.0, np.abs(pm).max())
     np.testing.assert_allclose(gm, pm, rtol=1e-7, atol=1e-8 * scale)
     np.testing.assert_allclose(gv, pv, rtol=1e-7, atol=1e-8 * max(1.0, np.abs(pv).max()))
+
+
+def test_hip_graph_replay_of_repeated_calls(tgp):
+    """TGP_OPT_GRAPH: the second call with the same device pointers is recorded (stream capture of the same host code path), later
+    ones are replayed by one hipGraphLaunch. Same bits as plain launches; new data behind the same pointers is picked up; any
+    other entry point in between drops the recording."""
+    import torch
+    from temporalgps_jl_amd import _lib
+    rng = np.random.default_rng(321)
+    T, d = 10_000, 2
+    model = U.random_lgssm(rng, False, d, T)
+    y_host = ref.rand(model, rng.standard_normal((T, d)), rng.standard_normal(T), rng.standard_normal(d))
+    plain = to_device_model(tgp, model)
+    plain.handle_options[_lib.OPT_GRAPH] = 0
+    dm = to_device_model(tgp, model)
+    dm.handle_options[_lib.OPT_GRAPH] = 1
+    y = torch.as_tensor(y_host, device="cuda:0")
+    Rn = torch.full((1,), 0.07, dtype=torch.float64, device="cuda:0")
+    hd = dm.handle()
+    base = tgp.logpdf_and_posterior_marginals(plain, y, Rn)
+    assert plain.handle().lib.tgp_graph_replays(plain.handle().h) == 0
+    out = None
+    for it in range(5):
+        res = tgp.logpdf_and_posterior_marginals(dm, y, Rn, out=out)
+        out = res[1:]
+        assert res[0] == base[0]
+        assert torch.equal(res[1], base[1]) and torch.equal(res[2], base[2])
+    assert hd.lib.tgp_graph_replays(hd.h) == 3            # call 1 plain, call 2 recorded + launched, calls 3..5 replayed
+    # new observations behind the same pointer
+    y2 = torch.as_tensor(y_host[::-1].copy(), device="cuda:0")
+    base2 = tgp.logpdf_and_posterior_marginals(plain, y2, Rn)
+    y.copy_(y2)
+    res = tgp.logpdf_and_posterior_marginals(dm, y, Rn, out=out)
+    assert hd.lib.tgp_graph_replays(hd.h) == 4
+    assert res[0] == base2[0] and torch.equal(res[1], base2[1]) and torch.equal(res[2], base2[2])
+    # logpdf has its own recording
+    lps = [tgp.logpdf(dm, y) for _ in range(4)]
+    assert all(v == lps[0] for v in lps) and abs(lps[0] - base2[0]) <= 1e-12 * abs(base2[0])
+    assert hd.lib.tgp_graph_replays(hd.h) == 6
+    # another entry point in between: the smoother's recording is not replayed blindly
+    tgp._filter(dm, y)
+    res = tgp.logpdf_and_posterior_marginals(dm, y, Rn, out=out)
+    assert hd.lib.tgp_graph_replays(hd.h) == 6
+    assert res[0] == base2[0] and torch.equal(res[1], base2[1])
+    # missing data + per-step noise, recorded and replayed
+    mk = torch.as_tensor((rng.random(T) < 0.1).astype(np.uint8), device="cuda:0")
+    yn = (y, mk)                # device observations carry their missing mask as a second tensor
+    Rt = torch.as_tensor(rng.uniform(0.01, 0.1, T), device="cuda:0")
+    b3 = tgp.logpdf_and_posterior_marginals(plain, yn, Rt)
+    out = None
+    for it in range(4):
+        res = tgp.logpdf_and_posterior_marginals(dm, yn, Rt, out=out)
+        out = res[1:]
+        assert res[0] == b3[0] and torch.equal(res[1], b3[1]) and torch.equal(res[2], b3[2])
