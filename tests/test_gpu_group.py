@@ -18,7 +18,8 @@ def tgp():
     return t
 
 
-@pytest.mark.parametrize("d", [5, 6, 7, 8, 9, 12, 16])          # eight lanes per chunk up to d = 8, sixteen beyond
+@pytest.mark.parametrize("d", list(range(5, 17)))          # eight lanes per chunk up to d = 8, sixteen beyond; every d: many of these
+# kernels sit at the full 512-register budget with spills (scripts/list_kernel_resources.py), the regime of the hipcc defect of DESIGN 9
 @pytest.mark.parametrize("ordering", ["F", "R"])
 @pytest.mark.parametrize("per_step_R", [False, True])
 def test_group_logpdf_equals_oracle(tgp, d, ordering, per_step_R):
@@ -97,7 +98,7 @@ def test_group_scans_under_the_smoother(tgp, d):
         np.testing.assert_allclose(gv, pC, rtol=1e-8, atol=1e-9)
 
 
-@pytest.mark.parametrize("d", [5, 6, 7, 8, 9, 12, 16])
+@pytest.mark.parametrize("d", list(range(5, 17)))
 @pytest.mark.parametrize("per_step_R", [False, True])
 def test_group_smoother_equals_oracle(tgp, d, per_step_R):
     """posterior marginals through the group-per-chunk smoother (pass 2 MODE 2 + pass 3 + group scans; tgp_group_smooth.hpp),

@@ -1,0 +1,37 @@
+"""CPU tier: every shipped kernel that sits at the full 512-register budget WITH spills -- the regime in which hipcc (roc-7.2.0)
+mis-reloaded a split 64-bit spill (profiles/r02_compose8_miscompile.md) -- must belong to a family that a known-answer check
+pins: the inlined builds by the run-time variant_selftest, the others by the -m gpu parity tests named below."""
+import importlib.util
+import os
+import re
+import shutil
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "temporalgps.jl_amd", "libtgp_hip.so")
+
+COVERED = [  # (pattern of the demangled kernel name, where its values are checked)
+    (r"tgp_i::", "run-time variant_selftest (tgp_api.hip) + tests/test_gpu_split_smoother.py, test_gpu_parity.py"),
+    (r"tgp::k_group_\w+<(9|1[0-6])\b", "tests/test_gpu_group.py (every d = 5..16)"),
+    (r"tgp::k_group_\w+<(9|1[0-6]), tgp::G\w+MO<(9|1[0-6])>", "tests/test_gpu_group.py (every d = 5..16)"),
+    (r"tgp::k_smooth<8,", "tests/test_gpu_parity.py::test_state_dims / test_gpu_split_smoother.py (d = 8, group kernels off)"),
+    (r"tgp::k_tile_sde<8>", "tests/test_gpu_gp_api.py (irregular inputs, d = 8 sum kernels)"),
+    (r"tgp::k_(reduce|apply)_filter_ad<[78],", "tests/test_gpu_gradient.py (d up to 8)"),
+    (r"tgp::k_scan_(apply|reduce)<.*FilterMonoidAD<[34]>", "tests/test_gpu_gradient.py (d = 3, 4)"),
+]
+
+
+@pytest.mark.skipif(not os.path.exists(LIB) or not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf") or shutil.which("c++filt") is None,
+                    reason="needs the built library and the LLVM binutils")
+def test_kernels_at_full_register_budget_are_pinned_by_a_check():
+    spec = importlib.util.spec_from_file_location("list_kernel_resources", os.path.join(ROOT, "scripts", "list_kernel_resources.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    ks = [k for blob in mod.code_objects(LIB) for k in mod.kernels(blob)]
+    assert len(ks) > 500
+    risky = [k for k in ks if k["vgpr"] >= 512 and (k["vspill"] or k["sspill"])]
+    loose = [k["name"] for k in risky if not any(re.search(pat, k["name"]) for pat, _ in COVERED)]
+    assert not loose, f"kernels at 512 registers with spills outside the families pinned by a known-answer check: {loose}"
+    # the kernel whose miscompile was root-caused in round 2 must stay out of the library
+    assert not any("k_compose_smoother<8" in k["name"] for k in ks)
