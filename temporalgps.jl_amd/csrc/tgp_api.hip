@@ -1040,6 +1040,9 @@ int tgp_model_set(tgp_handle* h, int64_t T, int d, int p, int ordering, uint32_t
         HIPCHK(hipStreamSynchronize(h->stream));
         for (DevBuf* b : {&h->bA, &h->bQ, &h->bH}) b->release();   // the packed copy is what the kernels read
         h->T = T; h->d = d; h->p = p; h->ordering = ordering;
+        h->x0m.assign(x0m, x0m + d);                        // tgp_rand draws x0 on the host
+        h->x0P.assign(x0P, x0P + (size_t)d * d);
+        h->mv.small_out = (flags & TGP_SMALL_OUTPUT) != 0 || p > 1;
         h->lti = false;
         h->is_dense = true;
         h->have_model = true;
@@ -1144,9 +1147,9 @@ int tgp_model_set_x0(tgp_handle* h, const double* x0m, const double* x0P) {
     if (h) drop_graphs(h);
     TRY(check_ready(h));
     if (!x0m || !x0P) return h->fail(TGP_EINVAL, "null x0");
-    if (h->is_dense) return dense_fail(h, tgp_dense::set_x0(h->dense, x0m, x0P, h->stream));
     h->x0m.assign(x0m, x0m + h->d);
-    h->x0P.assign(x0P, x0P + h->d * h->d);
+    h->x0P.assign(x0P, x0P + (size_t)h->d * h->d);
+    if (h->is_dense) return dense_fail(h, tgp_dense::set_x0(h->dense, x0m, x0P, h->stream));
     h->fold_valid = false;
     h->smoother_valid = false;
     return upload_x0(h, h->bx0, x0m, x0P);
@@ -1214,8 +1217,25 @@ int tgp_filter(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t 
 int tgp_posterior(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t flags, double* G, double* g, double* L,
                   double* xfm, double* xfP) {
     TRY(check_ready(h));
-    TRY(scan_only(h, "tgp_posterior"));
     if ((G || g || L) && !(G && g && L)) return h->fail(TGP_EINVAL, "G, g, L must be given together");
+    if (h->is_dense) {
+        const bool odev_d = (flags & TGP_OUT_DEVICE) != 0;
+        const size_t ng_d = (size_t)h->T * h->d * sizeof(double), nG_d = ng_d * h->d;
+        CallTimer tm(h);
+        TRY(set_obs(h, y, missing, flags));
+        tm.inputs_done();
+        double *dG = nullptr, *dg = nullptr, *dL = nullptr;
+        TRY(stage_out(h, h->bo1, G, nG_d, odev_d, &dG));
+        TRY(stage_out(h, h->bo2, g, ng_d, odev_d, &dg));
+        TRY(stage_out(h, h->bo3, L, nG_d, odev_d, &dL));
+        tgp_dense::set_profile(h->dense, h->profile);
+        TRY(dense_fail(h, tgp_dense::posterior(h->dense, h->mv.y, h->mv.missing, dG, dg, dL, xfm, xfP, h->result.d(), h->stream)));
+        tm.kernels_done();
+        TRY(copy_back(h, G, dG, nG_d, odev_d));
+        TRY(copy_back(h, g, dg, ng_d, odev_d));
+        TRY(copy_back(h, L, dL, nG_d, odev_d));
+        return tm.finish();
+    }
     // Reverse-ordered prior (step_posterior(::Reverse), lgssm.jl:223-228): the lane-per-chunk materialise pass only
     if (h->ordering != 0 && !G) return h->fail(TGP_EUNSUPPORTED, "posterior of a Reverse-ordered model: G, g, L must be requested");
     const bool odev = (flags & TGP_OUT_DEVICE) != 0;
@@ -1510,7 +1530,6 @@ int tgp_marginals(tgp_handle* h, uint32_t flags, double* mean_out, double* var_o
 
 int tgp_rand(tgp_handle* h, const double* eps_t, const double* eps_e, const double* eps_0, uint32_t flags, double* y_out) {
     TRY(check_ready(h));
-    TRY(scan_only(h, "tgp_rand"));
     if (!eps_t || !eps_e || !eps_0 || !y_out) return h->fail(TGP_EINVAL, "null eps / output");
     const bool idev = (flags & TGP_IN_DEVICE) != 0, odev = (flags & TGP_OUT_DEVICE) != 0;
     const size_t nT = (size_t)h->T * h->p * sizeof(double);   // one value per (time step, observation)
@@ -1535,6 +1554,18 @@ int tgp_rand(tgp_handle* h, const double* eps_t, const double* eps_e, const doub
         x0[i] = h->x0m[i] + acc;
     }
     CallTimer tm(h);
+    if (h->is_dense) {
+        const void *pet_d = nullptr, *pee_d = nullptr;
+        TRY(stage_in(h, h->beps_t, eps_t, (size_t)h->T * d * sizeof(double), idev, &pet_d));
+        TRY(stage_in(h, h->beps_e, eps_e, nT, idev, &pee_d));
+        tm.inputs_done();
+        double* dy_d = nullptr;
+        TRY(stage_out(h, h->bo1, y_out, nT, odev, &dy_d));
+        TRY(dense_fail(h, tgp_dense::rand(h->dense, x0.data(), (const double*)pet_d, (const double*)pee_d, h->mv.small_out, dy_d, h->stream)));
+        tm.kernels_done();
+        TRY(copy_back(h, y_out, dy_d, nT, odev));
+        return tm.finish();
+    }
     TRY(upload_x0(h, h->bx0r, x0.data(), zeroP.data()));
     const void *pet = nullptr, *pee = nullptr;
     TRY(stage_in(h, h->beps_t, eps_t, (size_t)h->T * d * sizeof(double), idev, &pet));

@@ -1281,6 +1281,45 @@ int marginals(Engine* e, double* mean_out, double* var_out, double* result8, hip
     return TGP_OK;
 }
 
+// out[r] = add[r] + sign * sum_k M1[k ld1 + r] x1[k] + sum_k M2[k ld2 + r] x2[k] + sd(r) e[r],  sd = sqrt(var[r] + jit)
+// (16 rows x 16 K-slices per workgroup, fixed summation order): the vector products of rand (lgssm.jl:81-91) and of the
+// materialised posterior (g = mf - G mp, lgssm.jl:231-238).
+struct Gemv2 {
+    const double* M1 = nullptr; int64_t ld1 = 0; const double* x1 = nullptr; int K1 = 0; double sign = 1.0;
+    const double* M2 = nullptr; int64_t ld2 = 0; const double* x2 = nullptr; int K2 = 0;
+    const double* add = nullptr;
+    const double* var = nullptr; const double* e = nullptr; double jit = 0.0; int nvar = 0;
+    double* out = nullptr; int n = 0;        // rows computed (padded count: rows >= the matrices' true size read zeros)
+    double* out2 = nullptr; int n2 = 0;      // unpadded copy
+};
+__global__ void __launch_bounds__(256) dk_gemv2(Gemv2 g) {
+    __shared__ double part[16][17];
+    const int row = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int r = blockIdx.x * 16 + row;
+    double s = 0.0;
+    if (r < g.n) {
+        if (g.M1)
+            for (int k = sl; k < g.K1; k += 16) s += g.sign * g.M1[(int64_t)k * g.ld1 + r] * g.x1[k];
+        if (g.M2)
+            for (int k = sl; k < g.K2; k += 16) s += g.M2[(int64_t)k * g.ld2 + r] * g.x2[k];
+    }
+    part[sl][row] = s;
+    __syncthreads();
+    if (sl == 0 && r < g.n) {
+        double t = g.add ? g.add[r] : 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += part[q][row];
+        if (g.var && r < g.nvar) t += sqrt(g.var[r] + g.jit) * g.e[r];
+        g.out[r] = t;
+        if (g.out2 && r < g.n2) g.out2[r] = t;
+    }
+}
+
+__global__ void dk_identity(double* __restrict__ W, int n) {     // n x n identity, column-major, ld n
+    const int64_t tot = (int64_t)n * n;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < tot; e += (int64_t)gridDim.x * blockDim.x) W[e] = (e / n == e % n) ? 1.0 : 0.0;
+}
+
 namespace {
 
 constexpr int kBlk = 256;     // diagonal block of the blocked d x d factorisation = what dk_chol / dk_trsm handle in one launch
@@ -1375,6 +1414,38 @@ __global__ void dk_copy_with_column(const double* __restrict__ P, int Dp, const 
     }
 }
 
+// buffers and dk_chol slot tables of the blocked d x d factorisation (smoother, materialised posterior, rand)
+int ensure_blocked_workspace(Engine* e, hipStream_t st) {
+    const int Dp = e->Dp, Pq = e->Pq;
+    const size_t DD = (size_t)Dp * Dp;
+    const int64_t ldW = Dp + 16;
+    DCHK(e->bLd.ensure(DD * 8));
+    DCHK(e->bDinvd.ensure((size_t)(Dp / 16) * 256 * 8));
+    for (Buf* b : {&e->bW0, &e->bW1, &e->bW2, &e->bW3}) DCHK(b->ensure((size_t)Dp * ldW * 8));
+    DCHK(e->bzero.ensure((size_t)Pq * 8 + 64));
+    DCHK(hipMemsetAsync(e->bzero.p, 0, (size_t)Pq * 8 + 64, st));
+    DCHK(hipMemsetAsync(e->bLd.p, 0, DD * 8, st));
+    DCHK(hipMemsetAsync(e->bscal.d() + 4, 0, 4 * sizeof(double), st));
+    std::vector<int> tab, t2;
+    chol_slot_table(std::min(kBlk, Dp) / 16, tab);
+    DCHK(e->bslots_blk.ensure(tab.size() * sizeof(int)));
+    DCHK(hipMemcpyAsync(e->bslots_blk.p, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    const int tail = Dp > kBlk ? Dp % kBlk : 0;
+    if (tail) {
+        chol_slot_table(tail / 16, t2);
+        DCHK(e->bslots_tail.ensure(t2.size() * sizeof(int)));
+        DCHK(hipMemcpyAsync(e->bslots_tail.p, t2.data(), t2.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    }
+    DCHK(hipStreamSynchronize(st));     // the tables are host vectors on this frame
+    return TGP_OK;
+}
+int blocked_chol_status(Engine* e, const char* what) {
+    double flag[4] = {0, 0, 0, 0};
+    DCHK(hipMemcpy(flag, e->bscal.d() + 4, 4 * sizeof(double), hipMemcpyDeviceToHost));
+    if (flag[3] != 0.0) return e->fail(TGP_ENOTPD, what);
+    return TGP_OK;
+}
+
 // One backward step: (bm, bP) = smoothed state of step t  ->  smoothed state of step t - 1, given the filtering state
 // (mf, Pf) of step t - 1 and step t's transition.
 int smoother_move(Engine* e, int64_t t, const double* Pf, const double* mf, hipStream_t st, bool prof) {
@@ -1457,28 +1528,11 @@ int posterior_marginals(Engine* e, const double* y, const uint8_t* mask, const d
     DCHK(e->bmstore.ensure((size_t)S * Dp * 8));
     DCHK(e->bPbound.ensure((size_t)nseg * DD * 8));
     DCHK(e->bmbound.ensure((size_t)nseg * Dp * 8));
-    DCHK(e->bLd.ensure(DD * 8));
-    DCHK(e->bDinvd.ensure((size_t)(Dp / 16) * 256 * 8));
-    for (Buf* b : {&e->bW0, &e->bW1, &e->bW2, &e->bW3}) DCHK(b->ensure((size_t)Dp * ldW * 8));
-    DCHK(e->bzero.ensure((size_t)Pq * 8 + 64));
-    DCHK(hipMemsetAsync(e->bzero.p, 0, (size_t)Pq * 8 + 64, st));
-    double* scratch8 = e->bzero.d() + Pq;       // lml / flags of the re-filtered segments (already counted in pass 1)
-    DCHK(hipMemsetAsync(e->bLd.p, 0, DD * 8, st));
-    DCHK(hipMemsetAsync(e->bscal.d() + 4, 0, 4 * sizeof(double), st));
-    {   // slot tables of dk_chol for the block sizes of the blocked factorisation (256, or Dp if smaller, and the tail)
-        std::vector<int> tab;
-        chol_slot_table(std::min(kBlk, Dp) / 16, tab);
-        DCHK(e->bslots_blk.ensure(tab.size() * sizeof(int)));
-        DCHK(hipMemcpyAsync(e->bslots_blk.p, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice, st));
-        std::vector<int> t2;
-        const int tail = Dp > kBlk ? Dp % kBlk : 0;
-        if (tail) {
-            chol_slot_table(tail / 16, t2);
-            DCHK(e->bslots_tail.ensure(t2.size() * sizeof(int)));
-            DCHK(hipMemcpyAsync(e->bslots_tail.p, t2.data(), t2.size() * sizeof(int), hipMemcpyHostToDevice, st));
-        }
-        DCHK(hipStreamSynchronize(st));     // the tables are host vectors on this frame
+    {
+        const int rcw = ensure_blocked_workspace(e, st);
+        if (rcw != TGP_OK) return rcw;
     }
+    double* scratch8 = e->bzero.d() + Pq;       // lml / flags of the re-filtered segments (already counted in pass 1)
     // filter steps [t0, t1) from the state in (bm, bP); keep every state of the segment when `keep`
     auto filter_range = [&](int64_t t0, int64_t t1, bool keep, double* res) -> int {
         for (int64_t t = t0; t < t1; ++t) {
@@ -1539,12 +1593,150 @@ int posterior_marginals(Engine* e, const double* y, const uint8_t* mask, const d
     int rc = TGP_OK;
     if (hipStreamSynchronize(st) != hipSuccess) rc = e->fail(TGP_EHIP, "dense smoother: stream error");
     resolve(e);
-    if (rc == TGP_OK) {
-        double flag[4] = {0, 0, 0, 0};
-        DCHK(hipMemcpy(flag, e->bscal.d() + 4, 4 * sizeof(double), hipMemcpyDeviceToHost));
-        if (flag[3] != 0.0) rc = e->fail(TGP_ENOTPD, "dense smoother: predicted covariance not positive definite (lgssm.jl:235)");
-    }
+    if (rc == TGP_OK) rc = blocked_chol_status(e, "dense smoother: predicted covariance not positive definite (lgssm.jl:235)");
     return rc;
+}
+
+// posterior(prior, y) evaluated (lgssm.jl:193-238, Forward priors): per step the time-reversed transition
+//   G = Pf A' (Pp + 1e-10 I)^-1 = Z' Lc^-1,  g = mf - G mp,  L = Pf - Z'Z,   Z = Lc^-1 (A Pf),  Lc Lc' = Pp + 1e-10 I
+// (column-major d x d blocks / d vectors per step) and the final filtering state. Lc^-1 is formed explicitly (one blocked forward
+// substitution against the identity), so that G is an MFMA GEMM instead of a backward substitution.
+int posterior(Engine* e, const double* y, const uint8_t* mask, double* G_out, double* g_out, double* L_out, double* xfm_host, double* xfP_host,
+              double* result8, hipStream_t st) {
+    if (!e->have_model) return e->fail(TGP_EINVAL, "no model");
+    if (e->ordering != 0) return e->fail(TGP_EUNSUPPORTED, "dense path: posterior of a Reverse-ordered model is not implemented");
+    DCHK(hipSetDevice(e->device));
+    const int Dp = e->Dp, d = e->d;
+    const size_t DD = (size_t)Dp * Dp;
+    const int64_t ldW = Dp + 16;
+    {
+        const int rcw = ensure_blocked_workspace(e, st);
+        if (rcw != TGP_OK) return rcw;
+    }
+    DCHK(hipMemcpyAsync(e->bP.p, e->bx0.p, DD * 8, hipMemcpyDeviceToDevice, st));
+    DCHK(hipMemcpyAsync(e->bm.p, e->bx0.d() + DD, (size_t)Dp * 8, hipMemcpyDeviceToDevice, st));
+    for (int64_t t = 0; t < e->T; ++t) {
+        const StepPtrs s = step_ptrs(e, t);
+        const bool prof = e->profile && (t % 16 == 8 || e->T < 64);
+        enqueue_predict(e, s, st, prof);                                                             // bT1 = A Pf, bPp, bmp
+        if (G_out) {
+            Scope sc(e, st, "posterior: G, g, L of the step", prof);
+            DCHK(hipMemcpyAsync(e->bW0.p, e->bPp.p, DD * 8, hipMemcpyDeviceToDevice, st));
+            enqueue_chol_blocked(e, e->bW0.d(), 1e-10, st);                                          // Lc (lgssm.jl:235)
+            enqueue_trsm_blocked(e, e->bT1.d(), Dp, Dp, e->bW1.d(), ldW, st);                        // Z -> W1 (row-major)
+            hipLaunchKernelGGL(dk_identity, dim3(512), dim3(256), 0, st, e->bW2.d(), Dp);
+            enqueue_trsm_blocked(e, e->bW2.d(), Dp, Dp, e->bW3.d(), ldW, st);                        // Lc^-1 -> W3 (row-major)
+            {   // G = Z' Lc^-1 -> bT1 (padded, column-major) and G_out[t]
+                GemmArgs g;
+                g.A = e->bW1.d(); g.lda = ldW;
+                g.B = e->bW3.d(); g.ldb = ldW;
+                g.C = e->bT1.d(); g.ldc = Dp;
+                g.M = g.N = g.K = Dp;
+                g.C2 = G_out + t * (int64_t)d * d; g.ldc2 = d; g.M2 = g.N2 = d;
+                launch_gemm(g, st);
+            }
+            {   // L = Pf - Z'Z -> L_out[t]
+                GemmArgs g;
+                g.A = e->bW1.d(); g.lda = ldW;
+                g.B = e->bW1.d(); g.ldb = ldW;
+                g.C = e->bW0.d(); g.ldc = Dp;
+                g.E = e->bP.d(); g.lde = Dp; g.sign = -1.0;
+                g.M = g.N = g.K = Dp;
+                g.C2 = L_out + t * (int64_t)d * d; g.ldc2 = d; g.M2 = g.N2 = d;
+                launch_gemm(g, st);
+            }
+            Gemv2 v;     // g = mf - G mp
+            v.M1 = e->bT1.d(); v.ld1 = Dp; v.x1 = e->bmp.d(); v.K1 = Dp; v.sign = -1.0;
+            v.add = e->bm.d();
+            v.out = e->bW2.d(); v.n = Dp;
+            v.out2 = g_out + t * d; v.n2 = d;
+            hipLaunchKernelGGL(dk_gemv2, dim3(Dp / 16), dim3(256), 0, st, v);
+        }
+        enqueue_update(e, s, t, y, mask, nullptr, nullptr, result8, st, prof);
+        if ((t & 255) == 255) {
+            DCHK(hipStreamSynchronize(st));
+            resolve(e);
+        }
+    }
+    DCHK(hipStreamSynchronize(st));
+    resolve(e);
+    if (xfm_host && xfP_host) {
+        std::vector<double> hP(DD), hm(Dp);
+        DCHK(hipMemcpy(hP.data(), e->bP.p, DD * 8, hipMemcpyDeviceToHost));
+        DCHK(hipMemcpy(hm.data(), e->bm.p, (size_t)Dp * 8, hipMemcpyDeviceToHost));
+        for (int j = 0; j < d; ++j) {
+            xfm_host[j] = hm[j];
+            for (int i = 0; i < d; ++i) xfP_host[i + (size_t)j * d] = hP[i + (size_t)j * Dp];
+        }
+    }
+    return G_out ? blocked_chol_status(e, "dense posterior: predicted covariance not positive definite (lgssm.jl:235)") : TGP_OK;
+}
+
+// rand(rng, model) with the randomness supplied (lgssm.jl:65-91): x <- A x + a + chol(Q + 1e-9 I).L eps_t (lgc.jl:84-87),
+// y = H x + h + sqrt(R (+ 1e-9 for SmallOutputLGC)) .* eps_e (lgc.jl:84-87 with diagonal R / :241-243). x0 (drawn on the host,
+// gaussian.jl:35-43) comes in as a d-vector. One factorisation of Q when it is shared, one per step otherwise.
+int rand(Engine* e, const double* x0_host, const double* eps_t, const double* eps_e, int small_out, double* y_out, hipStream_t st) {
+    if (!e->have_model) return e->fail(TGP_EINVAL, "no model");
+    DCHK(hipSetDevice(e->device));
+    const int Dp = e->Dp, Pq = e->Pq, d = e->d, p = e->p;
+    const size_t DD = (size_t)Dp * Dp;
+    {
+        const int rcw = ensure_blocked_workspace(e, st);
+        if (rcw != TGP_OK) return rcw;
+    }
+    std::vector<double> xh(Dp, 0.0);
+    for (int i = 0; i < d; ++i) xh[i] = x0_host[i];
+    DCHK(hipMemcpyAsync(e->bm.p, xh.data(), (size_t)Dp * 8, hipMemcpyHostToDevice, st));
+    DCHK(hipStreamSynchronize(st));
+    auto factor_Q = [&](const double* Qt) -> int {
+        DCHK(hipMemcpyAsync(e->bW0.p, Qt, DD * 8, hipMemcpyDeviceToDevice, st));
+        enqueue_chol_blocked(e, e->bW0.d(), 1e-9, st);
+        return TGP_OK;
+    };
+    if (e->sQ == 0) {
+        const int rcq = factor_Q(e->bQ.d());
+        if (rcq != TGP_OK) return rcq;
+    }
+    for (int64_t step = 0; step < e->T; ++step) {
+        const int64_t t = e->ordering == 0 ? step : e->T - 1 - step;
+        const StepPtrs s = step_ptrs(e, t);
+        auto emit = [&](const double* x) {
+            Gemv2 v;
+            v.M1 = s.H; v.ld1 = Pq; v.x1 = x; v.K1 = Dp;
+            v.add = s.h;
+            v.var = s.R; v.e = eps_e + t * p; v.jit = small_out ? 1e-9 : 0.0; v.nvar = p;
+            v.out = e->bV.d(); v.n = p;
+            v.out2 = y_out + t * p; v.n2 = p;
+            hipLaunchKernelGGL(dk_gemv2, dim3((p + 15) / 16), dim3(256), 0, st, v);
+        };
+        auto move = [&]() -> int {
+            if (e->sQ != 0) {
+                const int rcq = factor_Q(s.Q);
+                if (rcq != TGP_OK) return rcq;
+            }
+            Gemv2 v;
+            v.M1 = s.A; v.ld1 = Dp; v.x1 = e->bm.d(); v.K1 = Dp;
+            v.M2 = e->bLd.d(); v.ld2 = Dp; v.x2 = eps_t + t * d; v.K2 = d;
+            v.add = s.a;
+            v.out = e->bmp.d(); v.n = Dp;
+            hipLaunchKernelGGL(dk_gemv2, dim3(Dp / 16), dim3(256), 0, st, v);
+            std::swap(e->bm.p, e->bmp.p);
+            std::swap(e->bm.cap, e->bmp.cap);
+            return TGP_OK;
+        };
+        if (e->ordering == 0) {
+            const int rcm = move();
+            if (rcm != TGP_OK) return rcm;
+            emit(e->bm.d());
+        } else {
+            emit(e->bm.d());
+            const int rcm = move();
+            if (rcm != TGP_OK) return rcm;
+        }
+        if ((step & 1023) == 1023) DCHK(hipStreamSynchronize(st));
+    }
+    DCHK(hipStreamSynchronize(st));
+    return blocked_chol_status(e, "dense rand: Q + 1e-9 I is not positive definite (lgc.jl:86)");
 }
 
 }  // namespace tgp_dense

@@ -62,6 +62,12 @@ int posterior_marginals(Engine* e, const double* y, const uint8_t* mask, const d
                         double* var_out, double* result8, hipStream_t stream);
 
 // marginals(model) of the model as given (prior marginals for a Forward model): diagonal of H P H' + R.
+// posterior(prior, y) evaluated: per-step (G, g, L) (column-major d x d / d, device pointers; all three or none) and the final
+// filtering state (host pointers, nullable)
+int posterior(Engine* e, const double* y, const uint8_t* mask, double* G_out, double* g_out, double* L_out, double* xfm_host, double* xfP_host,
+              double* result8, hipStream_t stream);
+// rand with supplied noise: x0_host the drawn initial state (d, host), eps_t (T x d), eps_e (T x p), y_out (T x p) device pointers
+int rand(Engine* e, const double* x0_host, const double* eps_t, const double* eps_e, int small_out, double* y_out, hipStream_t stream);
 int marginals(Engine* e, double* mean_out, double* var_out, double* result8, hipStream_t stream);
 
 }  // namespace tgp_dense

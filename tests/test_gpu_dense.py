@@ -182,6 +182,36 @@ def test_dense_posterior_marginals_match_oracle(case):
     np.testing.assert_array_equal(gm3, gm)
 
 
+@pytest.mark.parametrize("case", [(6, 20, 5, "F", False), (5, 48, 16, "F", True), (4, 40, 7, "R", True), (3, 272, 40, "F", False)],
+                         ids=lambda c: f"T{c[0]}-d{c[1]}-p{c[2]}-{c[3]}{'-ps' if c[4] else ''}")
+def test_dense_rand_and_posterior_match_oracle(case):
+    """rand with supplied noise (lgssm.jl:65-91; Cholesky of Q + 1e-9 I per step or once) and the evaluated posterior model
+    (lgssm.jl:193-238: per-step G, g, L through the blocked d x d factorisation and its explicit inverse) for d > 16."""
+    import temporalgps_jl_amd as tgp
+    T, d, p, ordering, per_step = case
+    rng = np.random.default_rng(3000 + d + p)
+    model, Rd = random_model(rng, T, d, p, ordering, per_step)
+    dm = to_dev(tgp, model, Rd)
+    eps = (rng.standard_normal((T, d)), rng.standard_normal((T, p)), rng.standard_normal(d))
+    y = ref.rand(model, *eps)
+    np.testing.assert_allclose(tgp.rand(eps, dm), y, rtol=1e-9, atol=1e-9)
+    if ordering == "F":
+        post = ref.posterior(model, y)
+        dpost = tgp.posterior(dm, y).materialise()
+        assert dpost.ordering is tgp.Reverse
+        np.testing.assert_allclose(dpost.transitions.As, post["A"], rtol=1e-7, atol=1e-8)
+        np.testing.assert_allclose(dpost.transitions.as_, post["a"], rtol=1e-7, atol=1e-8)
+        np.testing.assert_allclose(dpost.transitions.Qs, post["Q"], rtol=1e-7, atol=1e-8)
+        np.testing.assert_allclose(dpost.x0.m, post["x0m"], rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(dpost.x0.P, post["x0P"], rtol=1e-8, atol=1e-9)
+        # the evaluated model is an LGSSM like any other: its marginals (Reverse ordering, per-step G, g, L) are the smoother's
+        Rn = rng.uniform(0.01, 0.2, size=(T, p))
+        pm, pC = ref.marginals(ref.replace_observation_noise_cov(post, np.stack([np.diag(v) for v in Rn])))
+        gm, gv = tgp.marginals(tgp.replace_observation_noise_cov(dpost, Rn))
+        np.testing.assert_allclose(gm, pm, rtol=0, atol=1e-7 * max(1.0, np.abs(pm).max()))
+        np.testing.assert_allclose(gv, np.diagonal(pC, axis1=-2, axis2=-1), rtol=1e-7, atol=1e-9)
+
+
 def test_dense_smoother_segments_are_bit_identical():
     """The smoother stores all T filtering states when they fit, else re-filters segments from stored boundary states
     (2 filters + 1 backward pass). TGP_OPT_CHUNK forces the segment length: any segmentation gives the same bits."""

@@ -251,6 +251,21 @@ def test_larger_state_dimensions(tgp, d, tv):
     check_all(tgp, model, ref.rand(model, *eps), eps, chunk=2)
 
 
+@pytest.mark.parametrize("d", [24, 32])
+@pytest.mark.parametrize("tv", [True, False])
+def test_larger_state_dimensions_dense_engine(tgp, d, tv):
+    """d = 17..32 (and beyond) bind the dense fp64-MFMA engine (tgp_dense.hip): every operation of the interface -- logpdf,
+    filter, posterior (G, g, L), posterior marginals (segmented smoother: TGP_OPT_CHUNK = 7), prior marginals, rand -- against
+    the oracle, like the scan path's state dimensions above."""
+    rng = np.random.default_rng(1900 + d + tv)
+    T = 300
+    model = U.random_lgssm(rng, tv, d, T)
+    eps = (rng.standard_normal((T, d)), rng.standard_normal(T), rng.standard_normal(d))
+    check_all(tgp, model, ref.rand(model, *eps), eps, chunk=7)
+    hd = to_device_model(tgp, model).handle()
+    assert hd.lib.tgp_kernel_variant(hd.h) >= 16
+
+
 def test_approx_periodic_default_kernel(tgp):
     """ApproxPeriodicKernel() (7 cosine terms, d = 14; lti_sde.jl:255-307) against the dense GP with the true periodic
     kernel (test/gp/lti_sde.jl:113-116) and against the oracle's state-space restatement."""
