@@ -75,6 +75,10 @@ typedef struct tgp_handle tgp_handle;
 #define TGP_OPT_DENSE_STRUCTURE 8 /* dense path (d > 16): 1 (default) a shared A / H with at most 8 entries per row (what
                                      lgssm_components(::Separable, ...) builds: I (x) A_t, I (x) H_t') is applied in sparse form; 0 the
                                      reference's dense products on the fp64 MFMA GEMM kernels. Set before tgp_model_set. */
+#define TGP_OPT_DENSE_FUSED 10 /* dense path, 16 < d <= 64 and p <= 16: 1 (default) the whole filter / smoother pass runs as ONE persistent
+                                  kernel (P in LDS, fp64 MFMA products, scalar updates; backward pass in modified Bryson-Frazier form,
+                                  tgp_dense_fused.hpp) -- ~3 us per step instead of ~26 us of dependent launches; 0 the per-step
+                                  kernel chain that larger states use. Takes effect at the next tgp_model_set. */
 #define TGP_OPT_GRAPH 9 /* hipGraph replay of the launch chain of tgp_logpdf / tgp_[logpdf_and_]posterior_marginals: a call with device
                            pointers that repeats the previous call's arguments is recorded once (stream capture, kernel nodes only)
                            and then replayed with one hipGraphLaunch. 0 (default) off, 1 on, -1 on for T <= 2^20. Measured on
@@ -94,14 +98,19 @@ int tgp_set_option(tgp_handle* h, int option, int64_t value);
 int tgp_set_stream(tgp_handle* h, void* hip_stream);
 const char* tgp_version(void);
 /* which build of the kernels the current model runs on: 1 out-of-line (safe), 2 fully inlined (d = 5, 6 after the check);
-   dense path (d > 16): 16 + (1 if A is applied in sparse form) + (2 if H is) */
+   dense path (d > 16): 16 + (1 if A is applied in sparse form) + (2 if H is) + (4 if the passes run as one persistent
+   kernel, TGP_OPT_DENSE_FUSED) */
 int tgp_kernel_variant(const tgp_handle* h);
 /* number of calls served by replaying a recorded hipGraph since the handle was created (TGP_OPT_GRAPH; measurement / tests) */
 int64_t tgp_graph_replays(const tgp_handle* h);
 
 /* ---- model: replaces the LGSSM / GaussMarkovModel containers -----------------------------------
  * lgssm.jl:9-12, gauss_markov_model.jl:20-32 (As, as, Qs, x0) + emissions (A = H', a = h, Q = R).
- * x0m (d) and x0P (d*d) are always host pointers. */
+ * x0m (d) and x0P (d*d) are always host pointers.
+ * d <= 16 binds the time-parallel scan engine (p <= 64, diagonal noise). d > 16 (the ArrayStorage-sized models of
+ * space_time/to_gauss_markov.jl:1-20; p <= 256) binds the dense engine -- one fp64-MFMA kernel chain per time step -- which
+ * serves tgp_logpdf, tgp_filter, tgp_posterior (Forward priors), tgp_[logpdf_and_]posterior_marginals, tgp_marginals and
+ * tgp_rand; the gradient, time-sharding and *_at entry points return TGP_EUNSUPPORTED there. */
 int tgp_model_set(tgp_handle* h, int64_t T, int d, int p, int ordering, uint32_t flags, const double* A,
                   const double* a, const double* Q, const double* H, const double* hh, const double* R,
                   const double* x0m, const double* x0P);

@@ -211,6 +211,7 @@ struct tgp_handle {
     tgp_dense::Engine* dense = nullptr;
     bool is_dense = false;
     int dense_structure = 1;     // TGP_OPT_DENSE_STRUCTURE
+    int dense_fused = 1;         // TGP_OPT_DENSE_FUSED
     // model
     bool have_model = false, lti = false;
     int64_t T = 0;
@@ -955,6 +956,10 @@ int tgp_set_option(tgp_handle* h, int option, int64_t value) {
         h->smoother_valid = false;
         return TGP_OK;
     }
+    if (option == TGP_OPT_DENSE_FUSED) {
+        h->dense_fused = value != 0;       // takes effect at the next tgp_model_set
+        return TGP_OK;
+    }
     if (option == TGP_OPT_DENSE_STRUCTURE) {
         h->dense_structure = value != 0;   // takes effect at the next tgp_model_set
         return TGP_OK;
@@ -1036,6 +1041,7 @@ int tgp_model_set(tgp_handle* h, int64_t T, int d, int p, int ordering, uint32_t
         md.x0m = x0m; md.x0P = x0P;
         tgp_dense::set_profile(h->dense, h->profile);
         tgp_dense::set_structure(h->dense, h->dense_structure);
+        tgp_dense::set_fused(h->dense, h->dense_fused);
         TRY(dense_fail(h, tgp_dense::model_set(h->dense, md, h->stream)));
         HIPCHK(hipStreamSynchronize(h->stream));
         for (DevBuf* b : {&h->bA, &h->bQ, &h->bH}) b->release();   // the packed copy is what the kernels read

@@ -292,6 +292,8 @@ __device__ inline double rdlane(double v, int l) {
     return __hiloint2double(hi, lo);
 }
 
+#include "tgp_dense_fused.hpp"
+
 // One workgroup of 16 waves factorises S = L L' (right-looking, 16-wide panels). Waves 1..15 keep the lower 16 x 16 tiles in
 // registers for the whole factorisation, TRANSPOSED in the MFMA accumulator layout (lane l, register r holds
 // T[l & 15][(l >> 4) + 4 r]) -- in that layout a tile is directly the B operand of the MFMA that solves it against the panel's
@@ -793,6 +795,8 @@ struct Engine {
     Buf bm, bmp, bP, bPp, bT1, bV, bS, bL, bDinv, bB, bscal, bslots;
     // RTS smoother (posterior_marginals): stored filtering states, the blocked d x d Cholesky factor, work matrices
     Buf bPstore, bmstore, bLd, bDinvd, bW0, bW1, bW2, bW3, bslots_blk, bslots_tail, bzero, bPbound, bmbound;
+    int fused_opt = 1;           // mid-sized states (Dp <= 64, p <= 16): the persistent single-kernel passes of tgp_dense_fused.hpp
+    Buf bfin;                    // state handed from one launch of a persistent pass to the next
     int64_t segment_opt = 0;     // smoother segment length (0 = automatic); tests force small segments
     // ELL form of a shared A / H with few entries per row (0 == dense)
     int structure_opt = 1;
@@ -828,7 +832,7 @@ void destroy(Engine* e) {
     if (!e) return;
     for (Buf* b : {&e->bA, &e->bQ, &e->bH, &e->ba, &e->bh, &e->bR, &e->bx0, &e->bm, &e->bmp, &e->bP, &e->bPp, &e->bT1, &e->bV, &e->bS,
                    &e->bL, &e->bDinv, &e->bB, &e->bscal, &e->bslots, &e->bAcol, &e->bAval, &e->bHcol, &e->bHval, &e->bPstore, &e->bmstore, &e->bLd, &e->bDinvd, &e->bW0, &e->bW1, &e->bW2, &e->bW3,
-                   &e->bslots_blk, &e->bslots_tail, &e->bzero, &e->bPbound, &e->bmbound})
+                   &e->bslots_blk, &e->bslots_tail, &e->bzero, &e->bPbound, &e->bmbound, &e->bfin})
         b->release();
     for (auto& pe : e->pending) {
         (void)hipEventDestroy(pe.a);
@@ -841,7 +845,9 @@ const std::string& last_error(const Engine* e) { return e->err; }
 void set_profile(Engine* e, int on) { e->profile = on; }
 void set_structure(Engine* e, int on) { e->structure_opt = on; }
 void set_segment(Engine* e, int64_t steps) { e->segment_opt = steps; }
-int structure(const Engine* e) { return (e->nnzA ? 1 : 0) | (e->nnzH ? 2 : 0); }
+void set_fused(Engine* e, int on) { e->fused_opt = on; }
+int fused(const Engine* e) { return e->fused_opt && e->Dp <= 64 && e->p <= 16; }
+int structure(const Engine* e) { return (e->nnzA ? 1 : 0) | (e->nnzH ? 2 : 0) | ((e->fused_opt && e->Dp <= 64 && e->p <= 16) ? 4 : 0); }
 static void resolve_pending(Engine* e);
 int profile_count(Engine* e) {
     resolve_pending(e);   // callers query after the call's closing stream synchronisation
@@ -928,6 +934,12 @@ int set_attrs(Engine* e) {
     DCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dk_gemm<3, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<3, 3>::LDS_BYTES));
     DCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dk_gemm<1, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<1, 3>::LDS_BYTES));
     DCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dk_gemm<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmCfg<1, 1>::LDS_BYTES));
+    DCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dk_fused_filter<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FusedCfg<32>::LDS_BYTES));
+    DCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dk_fused_filter<48>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FusedCfg<48>::LDS_BYTES));
+    DCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dk_fused_filter<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FusedCfg<64>::LDS_BYTES));
+    DCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dk_fused_smooth<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FusedSmoothCfg<32>::LDS_BYTES));
+    DCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dk_fused_smooth<48>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FusedSmoothCfg<48>::LDS_BYTES));
+    DCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dk_fused_smooth<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FusedSmoothCfg<64>::LDS_BYTES));
     e->attrs_set = true;
     return TGP_OK;
 }
@@ -1201,9 +1213,83 @@ void enqueue_update(Engine* e, const StepPtrs& s, int64_t t, const double* y, co
 
 }  // namespace
 
+namespace {
+constexpr int64_t kFusedStepsPerLaunch = 1 << 21;      // ~1 s of a persistent pass per launch at most
+
+FusedArgs fused_args(const Engine* e, const double* y, const uint8_t* mask, double* result8) {
+    FusedArgs g;
+    g.T = e->T; g.d = e->d; g.p = e->p; g.Pq = e->Pq; g.ordering = e->ordering;
+    g.A = e->bA.d(); g.Q = e->bQ.d(); g.H = e->bH.d(); g.a = e->ba.d(); g.h = e->bh.d(); g.R = e->bR.d();
+    g.sA = e->sA; g.sQ = e->sQ; g.sH = e->sH; g.sa = e->sa; g.sh = e->sh; g.sR = e->sR;
+    g.y = y; g.mask = mask; g.result8 = result8;
+    return g;
+}
+
+// the filter pass as persistent launches of dk_fused_filter (the state travels through e->bfin between launches)
+int fused_filter(Engine* e, const double* y, const uint8_t* mask, double* m_out, double* P_out, double* result8, hipStream_t st, double* aux_out = nullptr) {
+    const size_t nst = ((size_t)e->Dp * e->Dp + e->Dp) * 8;
+    DCHK(e->bfin.ensure(nst));
+    FusedArgs g = fused_args(e, y, mask, result8);
+    g.m_out = m_out; g.P_out = P_out; g.aux_out = aux_out;
+    g.xfin = e->bfin.d();
+    for (int64_t s0 = 0; s0 < e->T; s0 += kFusedStepsPerLaunch) {
+        g.step0 = s0;
+        g.step1 = std::min(e->T, s0 + kFusedStepsPerLaunch);
+        g.x0 = s0 == 0 ? e->bx0.d() : e->bfin.d();
+        Scope sc(e, st, "dk_fused_filter", e->profile != 0);
+        if (e->Dp == 32) hipLaunchKernelGGL(dk_fused_filter<32>, dim3(1), dim3(256), FusedCfg<32>::LDS_BYTES, st, g);
+        else if (e->Dp == 48) hipLaunchKernelGGL(dk_fused_filter<48>, dim3(1), dim3(256), FusedCfg<48>::LDS_BYTES, st, g);
+        else hipLaunchKernelGGL(dk_fused_filter<64>, dim3(1), dim3(256), FusedCfg<64>::LDS_BYTES, st, g);
+    }
+    DCHK(hipGetLastError());
+    return TGP_OK;
+}
+// posterior marginals of a mid-sized Forward model: the persistent filter keeps (m_t, P_t) and the per-update records, the
+// persistent Bryson-Frazier pass walks back (tgp_dense_fused.hpp). Returns TGP_EUNSUPPORTED (quietly, no message) when the
+// stored states do not fit: the caller then runs the segmented chain.
+int fused_posterior_marginals(Engine* e, const double* y, const uint8_t* mask, const double* Rnew, int64_t sRn, double* mean_out, double* var_out,
+                              double* result8, hipStream_t st) {
+    const int d = e->d, p = e->p, Dp = e->Dp;
+    const size_t nP = (size_t)e->T * d * d * 8, nm = (size_t)e->T * d * 8, nx = (size_t)e->T * p * (d + 2) * 8;
+    size_t free_b = 0, total_b = 0;
+    DCHK(hipMemGetInfo(&free_b, &total_b));
+    if ((double)(nP + nm + nx) > 0.8 * ((double)free_b + (double)e->bPstore.cap + (double)e->bmstore.cap + (double)e->bPbound.cap)) return TGP_EUNSUPPORTED;
+    DCHK(e->bPstore.ensure(nP));
+    DCHK(e->bmstore.ensure(nm));
+    DCHK(e->bPbound.ensure(nx));            // (the boundary buffer of the segmented smoother doubles as the record store)
+    DCHK(e->bfin.ensure(((size_t)Dp * Dp + Dp) * 8));
+    const int rcf = fused_filter(e, y, mask, e->bmstore.d(), e->bPstore.d(), result8, st, e->bPbound.d());
+    if (rcf != TGP_OK) return rcf;
+    Buf adj;
+    DCHK(adj.ensure(((size_t)Dp * Dp + Dp) * 8));
+    FusedSmoothArgs g;
+    g.T = e->T; g.d = d; g.p = p; g.Pq = e->Pq;
+    g.A = e->bA.d(); g.H = e->bH.d(); g.h = e->bh.d();
+    g.sA = e->sA; g.sH = e->sH; g.sh = e->sh;
+    g.m_f = e->bmstore.d(); g.P_f = e->bPstore.d(); g.aux = e->bPbound.d();
+    g.Rnew = Rnew; g.sRn = sRn;
+    g.adj = adj.d();
+    g.mean_out = mean_out; g.var_out = var_out;
+    for (int64_t s1 = e->T; s1 > 0; s1 -= kFusedStepsPerLaunch) {
+        g.step1 = s1;
+        g.step0 = std::max<int64_t>(0, s1 - kFusedStepsPerLaunch);
+        g.first = s1 == e->T;
+        Scope sc(e, st, "dk_fused_smooth", e->profile != 0);
+        if (Dp == 32) hipLaunchKernelGGL(dk_fused_smooth<32>, dim3(1), dim3(256), FusedSmoothCfg<32>::LDS_BYTES, st, g);
+        else if (Dp == 48) hipLaunchKernelGGL(dk_fused_smooth<48>, dim3(1), dim3(256), FusedSmoothCfg<48>::LDS_BYTES, st, g);
+        else hipLaunchKernelGGL(dk_fused_smooth<64>, dim3(1), dim3(256), FusedSmoothCfg<64>::LDS_BYTES, st, g);
+    }
+    DCHK(hipStreamSynchronize(st));
+    resolve(e);
+    adj.release();
+    return TGP_OK;
+}
+}  // namespace
+
 int filter(Engine* e, const double* y, const uint8_t* mask, double* m_out, double* P_out, double* result8, hipStream_t st) {
     if (!e->have_model) return e->fail(TGP_EINVAL, "no model");
     DCHK(hipSetDevice(e->device));
+    if (fused(e)) return fused_filter(e, y, mask, m_out, P_out, result8, st);
     const int Dp = e->Dp;
     const size_t DD = (size_t)Dp * Dp;
     DCHK(hipMemcpyAsync(e->bP.p, e->bx0.p, DD * 8, hipMemcpyDeviceToDevice, st));
@@ -1507,6 +1593,10 @@ int posterior_marginals(Engine* e, const double* y, const uint8_t* mask, const d
     if (!e->have_model) return e->fail(TGP_EINVAL, "no model");
     if (e->ordering != 0) return e->fail(TGP_EUNSUPPORTED, "dense path: posterior of a Reverse-ordered model is not implemented");
     DCHK(hipSetDevice(e->device));
+    if (fused(e) && e->segment_opt == 0) {
+        const int rcq = fused_posterior_marginals(e, y, mask, Rnew, sRn ? 1 : 0, mean_out, var_out, result8, st);
+        if (rcq != TGP_EUNSUPPORTED) return rcq;
+    }
     const int Dp = e->Dp, Pq = e->Pq;
     const size_t DD = (size_t)Dp * Dp;
     const int64_t ldW = Dp + 16;

@@ -42,7 +42,9 @@ void set_profile(Engine* e, int on);
 void set_structure(Engine* e, int on);
 // posterior_marginals: length of the re-filtered segments (0 = automatic: all T steps stored if they fit, else ~sqrt(T))
 void set_segment(Engine* e, int64_t steps);
-int structure(const Engine* e);   // bit 0: A sparse, bit 1: H sparse (current model)
+// mid-sized states (d <= 64, p <= 16): 1 (default) the persistent single-kernel passes, 0 the per-step kernel chain
+void set_fused(Engine* e, int on);
+int structure(const Engine* e);   // bit 0: A sparse, bit 1: H sparse, bit 2: persistent single-kernel passes (current model)
 int profile_count(Engine* e);
 KernelTime profile_get(const Engine* e, int idx);
 void profile_reset(Engine* e);

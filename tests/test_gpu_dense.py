@@ -120,7 +120,7 @@ def test_space_time_dense_model_matches_posterior_and_lml_small(Nr, T):
         lp = tgp.logpdf(dm, Y)
         assert abs(lp - lp_ref) <= 1e-10 * abs(lp_ref), (structure, lp, lp_ref)
         hd = dm.handle()
-        assert hd.lib.tgp_kernel_variant(hd.h) == (19 if structure else 16)
+        assert hd.lib.tgp_kernel_variant(hd.h) & ~4 == (19 if structure else 16)      # (bit 2: d = 48 runs the persistent passes)
         fm, fP = tgp._filter(dm, Y)
         np.testing.assert_allclose(fm, fm_ref, rtol=0, atol=1e-9 * np.abs(fm_ref).max())
         np.testing.assert_allclose(fP, fP_ref, rtol=0, atol=1e-9 * np.abs(fP_ref).max())
@@ -212,6 +212,32 @@ def test_dense_rand_and_posterior_match_oracle(case):
         np.testing.assert_allclose(gv, np.diagonal(pC, axis1=-2, axis2=-1), rtol=1e-7, atol=1e-9)
 
 
+@pytest.mark.parametrize("d,p,ordering,per_step", [(24, 1, "F", False), (32, 3, "R", False), (40, 16, "F", True), (64, 2, "F", False)])
+def test_persistent_kernel_and_kernel_chain_agree(d, p, ordering, per_step):
+    """16 < d <= 64, p <= 16: the persistent single-kernel passes (tgp_dense_fused.hpp, default) against the per-step kernel chain
+    (TGP_OPT_DENSE_FUSED = 0) that larger states run: logpdf, filtering distributions, posterior marginals, with missing data."""
+    import temporalgps_jl_amd as tgp
+    from temporalgps_jl_amd import _lib
+    rng = np.random.default_rng(4000 + d)
+    T = 40
+    model, Rd = random_model(rng, T, d, p, ordering, per_step)
+    y = np.where(rng.random((T, p)) < 0.15, np.nan, rng.standard_normal((T, p)))
+    fused, chain = to_dev(tgp, model, Rd), to_dev(tgp, model, Rd, {_lib.OPT_DENSE_FUSED: 0})
+    assert fused.handle().lib.tgp_kernel_variant(fused.handle().h) & 4
+    assert not chain.handle().lib.tgp_kernel_variant(chain.handle().h) & 4
+    lf, lc = tgp.logpdf(fused, y), tgp.logpdf(chain, y)
+    assert abs(lf - lc) <= 1e-12 * abs(lc)
+    (mf, Pf), (mc, Pc) = tgp._filter(fused, y), tgp._filter(chain, y)
+    np.testing.assert_allclose(mf, mc, rtol=0, atol=1e-11 * max(1.0, np.abs(mc).max()))
+    np.testing.assert_allclose(Pf, Pc, rtol=0, atol=1e-11 * max(1.0, np.abs(Pc).max()))
+    if ordering == "F":
+        Rn = rng.uniform(0.01, 0.2, size=(T, p))
+        a, b = tgp.logpdf_and_posterior_marginals(fused, y, Rn), tgp.logpdf_and_posterior_marginals(chain, y, Rn)
+        assert abs(a[0] - b[0]) <= 1e-12 * abs(b[0])
+        np.testing.assert_allclose(a[1], b[1], rtol=0, atol=1e-8 * max(1.0, np.abs(b[1]).max()))
+        np.testing.assert_allclose(a[2], b[2], rtol=1e-8, atol=1e-10)
+
+
 def test_dense_smoother_segments_are_bit_identical():
     """The smoother stores all T filtering states when they fit, else re-filters segments from stored boundary states
     (2 filters + 1 backward pass). TGP_OPT_CHUNK forces the segment length: any segmentation gives the same bits."""
@@ -222,8 +248,13 @@ def test_dense_smoother_segments_are_bit_identical():
     model, Rd = random_model(rng, T, d, p, "F", True)
     y = np.where(rng.random((T, p)) < 0.15, np.nan, rng.standard_normal((T, p)))
     Rn = rng.uniform(0.01, 0.2, size=(T, p))
-    base = tgp.logpdf_and_posterior_marginals(to_dev(tgp, model, Rd), y, Rn)
-    for seg in (1, 4, 5, 22, 23, 64):
+    base = tgp.logpdf_and_posterior_marginals(to_dev(tgp, model, Rd, {_lib.OPT_CHUNK: T}), y, Rn)      # the kernel chain, one segment
+    # (without TGP_OPT_CHUNK a state this small runs the persistent Bryson-Frazier pass instead: same posterior to ~1e-10)
+    fused = tgp.logpdf_and_posterior_marginals(to_dev(tgp, model, Rd), y, Rn)
+    assert abs(fused[0] - base[0]) <= 1e-11 * abs(base[0])
+    np.testing.assert_allclose(fused[1], base[1], rtol=0, atol=1e-8 * max(1.0, np.abs(base[1]).max()))
+    np.testing.assert_allclose(fused[2], base[2], rtol=1e-8, atol=1e-10)
+    for seg in (1, 4, 5, 22, 64):
         got = tgp.logpdf_and_posterior_marginals(to_dev(tgp, model, Rd, {_lib.OPT_CHUNK: seg}), y, Rn)
         assert got[0] == base[0], seg
         np.testing.assert_array_equal(got[1], base[1])
