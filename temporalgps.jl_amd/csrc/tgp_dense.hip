@@ -13,6 +13,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -765,6 +766,13 @@ struct Buf {
         cap = 0;
         hipError_t e = hipMalloc(&p, bytes + kOperandSlack * sizeof(double));   // see dk_gemm: unpredicated edge loads
         if (e == hipSuccess) cap = bytes;
+        if (e == hipSuccess) {       // TGP_POISON=1: NaN-fill fresh allocations (debugging aid, see tgp_api.hip)
+            static const bool poison = [] { const char* v = std::getenv("TGP_POISON"); return v != nullptr && v[0] == '1'; }();
+            if (poison) {
+                e = hipMemset(p, 0xFF, bytes + kOperandSlack * sizeof(double));
+                (void)hipDeviceSynchronize();
+            }
+        }
         return e;
     }
     void release() {

@@ -179,6 +179,16 @@ template <int D> struct GroupStep {
     }
 };
 
+// The group's own A tile starts as zeros: group_publish_A below only ever writes rows and columns < D, but lane j >= D (inactive,
+// G > D) reads row j of the tile for its (discarded) mean element, and 0 * (a NaN left in LDS by an earlier kernel) would poison
+// the group sums. (Found in round 2: the run-time check rejected the per-step group kernels or not depending on what had run
+// before in the process.)
+template <int D> __device__ __forceinline__ void group_clear_A(double* sAg, int j) {
+    constexpr int G = GroupGeom<D>::G;
+    TGP_GUNROLL for (int i = 0; i < G; ++i) sAg[G * i + j] = 0.0;
+    wave_sync();
+}
+
 // publish the step's A in the group's LDS tile (row-major [G i + k]): lane k owns column k
 template <int D> __device__ __forceinline__ void group_publish_A(double* sAg, const GroupStep<D>& st, int j, bool act) {
     constexpr int G = GroupGeom<D>::G;
@@ -198,7 +208,10 @@ __global__ __launch_bounds__(256) void k_group_reduce_filter(ModelView mv, int L
     GroupLane<D> gl;
     double Qc[D], H[D], aj, hh, Rsh;
     group_setup<D>(mv, sA, tiles, gl, Qc, H, aj, hh, Rsh);
-    if (!LTI) gl.sA = sA + (threadIdx.x / G) * G * G;      // the group's own A tile (rewritten per step)
+    if (!LTI) {
+        gl.sA = sA + (threadIdx.x / G) * G * G;      // the group's own A tile (rewritten per step)
+        group_clear_A<D>(const_cast<double*>(gl.sA), gl.j);
+    }
     const int j = gl.j;
     const int64_t c = (int64_t)blockIdx.x * NGRP + (threadIdx.x / G);
     int64_t r0, r1;
@@ -287,7 +300,10 @@ __global__ __launch_bounds__(256) void k_group_apply_logpdf(ModelView mv, int L0
     GroupLane<D> gl;
     double Qc[D], H[D], aj, hh, Rsh;
     group_setup<D>(mv, sA, tiles, gl, Qc, H, aj, hh, Rsh);
-    if (!LTI) gl.sA = sA + (threadIdx.x / G) * G * G;
+    if (!LTI) {
+        gl.sA = sA + (threadIdx.x / G) * G * G;
+        group_clear_A<D>(const_cast<double*>(gl.sA), gl.j);
+    }
     const int j = gl.j;
     const int64_t c = (int64_t)blockIdx.x * NGRP + (threadIdx.x / G);
     int64_t r0, r1;
