@@ -20,9 +20,9 @@ _dp = ctypes.POINTER(ctypes.c_double)
 _i64 = ctypes.c_int64
 
 
-def build():
+def build(force=False):
     deps = [_SRC] + [os.path.join(_ROOT, "temporalgps.jl_amd", "csrc", f) for f in ("tgp_math.hpp", "tgp_math_body.inc", "tgp_chunk.hpp", "tgp_chunk_body.inc")]
-    if not os.path.exists(_SO) or any(os.path.getmtime(p) > os.path.getmtime(_SO) for p in deps):
+    if force or not os.path.exists(_SO) or any(os.path.getmtime(p) > os.path.getmtime(_SO) for p in deps):
         subprocess.check_call(["g++", "-O3", "-march=x86-64-v3", "-fopenmp", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-o", _SO, _SRC])
     return _SO
 

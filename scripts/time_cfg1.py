@@ -5,7 +5,7 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import temporalgps_jl_amd as tgp
 from temporalgps_jl_amd import _lib, lti_sde as P
 

@@ -5,7 +5,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import temporalgps_jl_amd as tgp
 from tests import _util as U
 from tests.test_gpu_parity import to_device_model

@@ -171,8 +171,8 @@ template <int D, bool LTI> int run(const Args& a) {
         }
         std::vector<double> lml_c((size_t)n0, 0.0), nmiss_c((size_t)n0, 0.0);
         std::vector<int> bad_c((size_t)n0, 0);
-#pragma omp parallel for schedule(static)
         std::vector<double> xfin_buf(Dim<D>::NS, 0.0);   // Reverse prior, MODE 3: x0 of the posterior (written by the last chunk)
+#pragma omp parallel for schedule(static)
         for (int64_t c = 0; c < n0; ++c) {
             State<D> x = S0[c];
             ChunkStats cs;

@@ -52,3 +52,16 @@ def test_c_matches_numpy(i):
     qm, qv = ref.marginals(model)
     np.testing.assert_allclose(pm, qm, rtol=1e-12, atol=1e-13)
     np.testing.assert_allclose(pv, qv, rtol=1e-12)
+
+
+def test_openmp_host_build_of_the_chunk_functions_compiles():
+    """bench.py's all-core CPU leg (oracle/omp_scan.py) compiles tests/hostsim/hostsim.cpp with -fopenmp; a pragma in front of
+    a non-loop statement only shows up in that build (the GPU box rebuilds it: file times differ there)."""
+    import shutil
+    import pytest
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    from oracle import omp_scan
+    so = omp_scan.build(force=True)
+    import os
+    assert os.path.exists(so)
