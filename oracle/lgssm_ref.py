@@ -385,3 +385,54 @@ def filter_missing(model, ys, missing):
 def posterior_missing(model, ys, missing):
     m2, y2, _ = transform_model_and_obs(model, ys, missing)
     return posterior(m2, y2)
+
+
+# ---------------------------------------------------------------------------- modified Bryson-Frazier form (checker of the
+# persistent mid-d backward pass, temporalgps.jl_amd/csrc/tgp_dense_fused.hpp; NOT a restatement of reference code)
+def bryson_frazier_marginals(model, ys, R_new, missing=None):
+    """Emission marginals of the smoothed states of a Forward scalar/diagonal-noise model by the adjoint recursion
+        per scalar update (reverse):  K = v / s,  Lam <- (I - K h)' Lam (I - K h) + h'h / s,  lam <- (I - K h)' lam - h' nu / s
+        per transition:               Lam <- A' Lam A,  lam <- A' lam
+        mean = h m_f + hh - w'lam,  var = h w - w' Lam w + R_new,   w = P_f h'
+    -- the exact posterior of the model; the reference's reverse-time form (lgssm.jl:193-238) differs from it by the effect of its
+    1e-10 jitter. Observations are applied one scalar at a time (diagonal noise), missing ones as y := 0, R := 1e15."""
+    T, d = model["T"], len(model["x0m"])
+    assert model["ordering"] == "F"
+    m, P = model["x0m"].copy(), model["x0P"].copy()
+    rec = []
+    for t in range(T):
+        A, a, Q = transition(model, t)
+        H, h, R = emission(model, t)
+        H, h = np.atleast_2d(H), np.atleast_1d(h)
+        Rd = np.atleast_1d(R) if np.ndim(R) < 2 else np.diagonal(R)
+        yt = np.atleast_1d(ys[t])
+        m = A @ m + a
+        P = A @ P @ A.T + Q
+        upd = []
+        for j in range(len(h)):
+            miss = missing is not None and bool(np.atleast_1d(missing[t])[j if np.ndim(missing[t]) else 0])
+            v = P @ H[j]
+            s = H[j] @ v + (1e15 if miss else Rd[j])
+            nu = (0.0 if miss else yt[j]) - H[j] @ m - h[j]
+            m = m + v * nu / s
+            P = P - np.outer(v, v) / s
+            upd.append((v, s, nu))
+        rec.append((m.copy(), P.copy(), upd, A, H, h))
+    lam, Lam = np.zeros(d), np.zeros((d, d))
+    p = len(rec[0][5])
+    mean, var = np.zeros((T, p)), np.zeros((T, p))
+    Rn = np.broadcast_to(np.asarray(R_new, dtype=np.float64).reshape(-1, p) if np.ndim(R_new) else np.full((1, p), float(R_new)), (T, p))
+    for t in range(T - 1, -1, -1):
+        mf, Pf, upd, A, H, h = rec[t]
+        for j in range(p):
+            w = Pf @ H[j]
+            mean[t, j] = H[j] @ mf + h[j] - w @ lam
+            var[t, j] = H[j] @ w - w @ Lam @ w + Rn[t, j]
+        for j in range(p - 1, -1, -1):
+            v, s, nu = upd[j]
+            C = np.eye(d) - np.outer(v / s, H[j])
+            Lam = C.T @ Lam @ C + np.outer(H[j], H[j]) / s
+            lam = C.T @ lam - H[j] * nu / s
+        Lam = A.T @ Lam @ A
+        lam = A.T @ lam
+    return (mean[:, 0], var[:, 0]) if p == 1 else (mean, var)
