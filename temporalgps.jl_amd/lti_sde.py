@@ -414,10 +414,21 @@ class FiniteLTISDE:
             raise ValueError("noise variances must be a scalar or one per input")
         self.sigma2 = s
         self._model = None
+        self._model_key = None
+
+    def _param_key(self):
+        """values of everything the cached device model was built from: kernel hyper-parameters (mutable through the
+        owner / attribute handles `parameters` returns), a ConstMean's constant, the noise variances"""
+        vals = [float(getattr(o, a)) for _, o, a in parameters(self.f.f.kernel)]
+        if isinstance(self.f.f.mean, ConstMean):
+            vals.append(float(self.f.f.mean.c))
+        return (tuple(vals), self.sigma2.tobytes())
 
     def build_lgssm(self):
-        if self._model is None:
+        key = self._param_key()
+        if self._model is None or self._model_key != key:      # parameters changed in place since the model was bound
             self._model = build_lgssm(self.f.f.kernel, self.x, self.sigma2, self.f.f.mean, self.f.storage.device)
+            self._model_key = key
         return self._model
 
 
@@ -620,8 +631,10 @@ def logpdf_and_gradient(fx, y, rel_step=1e-6):
     finite difference of that tiny map (relative step 1e-6: truncation ~1e-12, rounding ~1e-10).
     Regular spacing with homoscedastic noise: any supported state dimension. Irregular spacing: d <= 4, shared or per-step
     noise; the per-step tangents of exp(F dt_k) are formed on the device (tgp_logpdf_grad_sde)."""
-    if not isinstance(fx.x, RegularSpacing) and len(np.unique(np.round(np.diff(_times(fx.x)), 14))) > 1:
-        return _logpdf_and_gradient_sde(fx, y, rel_step)          # irregular spacing
+    if not isinstance(fx.x, RegularSpacing):
+        # any plain array of inputs -- uniformly spaced or not -- is the reference's AbstractVector path (lti_sde.jl:135-146:
+        # per-step blocks, dt_1 := 1), so its gradient goes through the SDE-described model; only RegularSpacing is LTI
+        return _logpdf_and_gradient_sde(fx, y, rel_step)
     _shared_blocks(fx)                      # raises for layouts the gradient pass does not cover
     plist = parameters(fx.f.f.kernel)
     names = [n for n, _, _ in plist] + ["noise"] + (["mean.c"] if isinstance(fx.f.f.mean, ConstMean) else [])

@@ -86,7 +86,8 @@ def test_gradient_vs_dense_gp_closed_form_and_missing():
 def test_gradient_unsupported_layouts_raise():
     import temporalgps_jl_amd as tgp  # noqa: F401
     from temporalgps_jl_amd import lti_sde as P
-    fx = P.to_sde(P.GP(P.Matern32Kernel()))(np.cumsum(np.ones(10) * 0.1), 0.1)      # irregular spacing => per-step blocks
+    # plain-array inputs (the reference's AbstractVector path) are served through the SDE-described model up to d = 4 only
+    fx = P.to_sde(P.GP(P.Matern52Kernel() + P.Matern52Kernel().stretch(0.5)))(np.cumsum(np.ones(10) * 0.1), 0.1)     # d = 6
     with pytest.raises(NotImplementedError):
         P.logpdf_and_gradient(fx, np.zeros(10))
 
@@ -146,3 +147,28 @@ def test_gradient_irregular_spacing_vs_oracle_fd(case):
         tm[i] -= hstep
         fd = (oracle_lp(tp) - oracle_lp(tm)) / (2 * hstep)
         assert abs(g[name] - fd) <= 2e-5 * max(1.0, abs(fd)), (name, g[name], fd)
+
+
+def test_uniform_plain_array_inputs_take_the_vector_path_and_cached_models_follow_parameter_changes():
+    """(i) A uniformly spaced plain array is still the reference's AbstractVector input (lti_sde.jl:135-146, dt_1 := 1): its
+    gradient goes through the SDE-described model, not the LTI blocks. (ii) The finite GP caches its device model; changing a
+    hyper-parameter in place through the handles `parameters` returns re-binds it."""
+    from temporalgps_jl_amd import lti_sde as S
+    T = 800
+    rng = np.random.default_rng(5)
+    t = 0.07 * np.arange(T)                       # uniform, but a plain array
+    y = rng.standard_normal(T)
+    k = ("scaled", 0.9, ("stretched", 1.3, ("matern52",)))
+    fx = S.to_sde(S.GP(S.to_kernel(k)))(t, 0.2)
+    lp, g = S.logpdf_and_gradient(fx, y)
+    lp_ref = oc.gp_logpdf(k, t, 0.2, y)
+    assert abs(lp - lp_ref) <= 1e-10 * abs(lp_ref)
+    eps = 1e-5
+    fd = (oc.gp_logpdf(("scaled", 0.9 + eps, k[2]), t, 0.2, y) - oc.gp_logpdf(("scaled", 0.9 - eps, k[2]), t, 0.2, y)) / (2 * eps)
+    assert abs(g["kernel.sigma2"] - fd) <= 1e-5 * max(1.0, abs(fd))
+    # in-place parameter change
+    name, owner, attr = S.parameters(fx.f.f.kernel)[0]
+    assert abs(S.logpdf(fx, y) - lp_ref) <= 1e-10 * abs(lp_ref)
+    setattr(owner, attr, 1.7)
+    lp2_ref = oc.gp_logpdf(("scaled", 1.7, k[2]), t, 0.2, y)
+    assert abs(S.logpdf(fx, y) - lp2_ref) <= 1e-10 * abs(lp2_ref)
