@@ -46,31 +46,40 @@ __device__ inline double wave_sum(double v) {
 template <int DP>
 struct FusedCfg {
     static constexpr int NT = DP / 16, KS = DP / 4, LD = DP + 4;
-    static constexpr int NG = 256 / DP;                         // K-slices of the thread-parallel matrix-vector products
-    static constexpr int TPW = (NT * NT + 3) / 4;               // output tiles per wave
+    static constexpr int NSL = 4 * NT;                          // partial sums per element of a matrix-vector product (row slices)
     static constexpr int HPT = (16 * DP) / 256;                 // emission-row elements per thread (per-step H prefetch)
-    // LDS (doubles): P | T1' | m | mp | a | v | partial sums | H rows | scalars of the step
-    static constexpr int oP = 0, oT = oP + DP * LD, oM = oT + DP * LD, oMP = oM + DP, oA = oMP + DP, oV = oA + DP, oRed = oV + DP,
-                         oH = oRed + NG * DP, oS = oH + 16 * DP, TOTAL = oS + 64;
+    // LDS (doubles): P | T1' | m | a | v | partial sums (v) | partial sums (A m) | H rows | scalars of the step
+    static constexpr int oP = 0, oT = oP + DP * LD, oM = oT + DP * LD, oA = oM + DP, oV = oA + DP, oRed = oV + DP, oRedM = oRed + NSL * DP,
+                         oH = oRedM + 4 * DP, oS = oH + 16 * DP, TOTAL = oS + 64;
     static constexpr size_t LDS_BYTES = (size_t)TOTAL * sizeof(double);
 };
 
+// The covariance lives in REGISTERS between the products. Wave w belongs to block index b = w % NT: in A P it computes tiles
+// (b, x) -- A operand = the fragments of A's block row b -- and in (A P)A' + Q the tiles (x, b) -- B operand = the SAME
+// fragments -- so a wave keeps one block row of A (KS doubles per lane) instead of all of A. The tiles (x, b) stay in the MFMA
+// accumulator layout (lane (lr, lq), register r <-> row 16 x + lq + 4 r, column 16 b + lr): v = h P is formed from them (each
+// lane: 4 rows of one column; the 4 NT row slices are summed by wave 0), the rank-1 downdate is 4 FMAs per tile and lane, and only
+// then a tile goes to LDS, where the next step's A P reads it as the B operand.
 template <int DP>
 __global__ __launch_bounds__(256) void dk_fused_filter(const FusedArgs g) {
     using C = FusedCfg<DP>;
-    constexpr int NT = C::NT, KS = C::KS, LD = C::LD, NG = C::NG, TPW = C::TPW, HPT = C::HPT;
+    constexpr int NT = C::NT, KS = C::KS, LD = C::LD, NSL = C::NSL, HPT = C::HPT;
+    constexpr int NGW = 4 / NT > 0 ? 4 / NT : 1;       // waves per block index (NT = 2: two waves share a block row, one x each)
+    constexpr int XPW = (NT + NGW - 1) / NGW;          // tiles per wave
     extern __shared__ double lds[];
     double* sP = lds + C::oP;
     double* sT = lds + C::oT;
     double* sm = lds + C::oM;
-    double* smp = lds + C::oMP;
     double* sa = lds + C::oA;
     double* sv = lds + C::oV;
-    double* red = lds + C::oRed;
+    double* red = lds + C::oRed;       // [NSL][DP] partial sums of v = h P
+    double* redm = lds + C::oRedM;     // [4][DP] partial sums of A m
     double* sH = lds + C::oH;
-    double* ss = lds + C::oS;      // [0] 1/s of the current scalar update; [16..31] h; [32..47] R
+    double* ss = lds + C::oS;          // [0] 1/s of the current scalar update; [16..31] h; [32..47] R
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, lq = lane >> 4;
+    const int b = w % NT, grp = w / NT;
+    const bool mfma_wave = w < NT * NGW;               // (NT = 3: wave 3 has no tiles)
     const bool fwd = g.ordering == 0;
     const bool H_shared = g.sH == 0 && g.sh == 0 && g.sR == 0;
     auto tstep = [&](int64_t step) { return fwd ? step : g.T - 1 - step; };
@@ -78,27 +87,25 @@ __global__ __launch_bounds__(256) void dk_fused_filter(const FusedArgs g) {
     // ---- state and the shared model blocks
     for (int e = tid; e < DP * DP; e += 256) sP[(e % DP) * LD + e / DP] = g.x0[e];      // sP[i][j] = P[i][j] (row i)
     if (tid < DP) sm[tid] = g.x0[DP * DP + tid];
-    double af[NT][KS];            // A fragments: af[I][ks] = A[16 I + lr][4 ks + lq] (A operand of row block I == B operand of A' column block I)
-    double qf[TPW][4];            // Q tiles of this wave's output tiles, in the MFMA accumulator layout
+    double af[KS];                // A fragments of block row b: af[ks] = A[16 b + lr][4 ks + lq]
+    double qf[XPW][4];            // Q tiles (x, b) of this wave
+    d4 pt[XPW];                   // the covariance tiles (x, b) themselves
     auto load_A = [&](const double* A) __attribute__((always_inline)) {
 #pragma unroll
-        for (int I = 0; I < NT; ++I)
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) af[I][ks] = A[(I * 16 + lr) + (int64_t)(ks * 4 + lq) * DP];
+        for (int ks = 0; ks < KS; ++ks) af[ks] = A[(b * 16 + lr) + (int64_t)(ks * 4 + lq) * DP];
     };
     auto load_Q = [&](const double* Q) __attribute__((always_inline)) {
 #pragma unroll
-        for (int tl = 0; tl < NT * NT; ++tl)
-            if ((tl & 3) == w) {
-                const int I = tl / NT, J = tl % NT;
+        for (int x = 0; x < NT; ++x)
+            if (x % NGW == grp) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) qf[tl >> 2][r] = Q[(I * 16 + lq + 4 * r) + (int64_t)(J * 16 + lr) * DP];
+                for (int r = 0; r < 4; ++r) qf[x / NGW][r] = Q[(x * 16 + lq + 4 * r) + (int64_t)(b * 16 + lr) * DP];
             }
     };
     // ---- per-step inputs travel one step ahead in registers: issued at the top of step s for step s + 1, so that their latency
     //      hides behind a whole step (barriers below only wait for LDS traffic: lds_barrier)
     double a_n = 0.0;                 // a[tid] (tid < DP)
-    double y_n = 0.0;                 // lane j < p of wave 0: y[t][j] (0 when missing), and its flag
+    double y_n = 0.0;                 // lane j < p of wave 0: y[t][j], and its missing flag
     int miss_n = 0;
     double hrow_n[HPT];               // emission rows (per-step H only)
     double hs_n = 0.0, rs_n = 0.0;    // h[j], R[j] for tid = j < p (per-step emissions only)
@@ -140,8 +147,25 @@ __global__ __launch_bounds__(256) void dk_fused_filter(const FusedArgs g) {
     }
     fetch(tstep(g.step0));
     if (!H_shared) stage_H();
-    double lml = 0.0, nmiss = 0.0, bad = 0.0;
+    double lml = 0.0, nmiss = 0.0, bad = 0.0, sprod = 1.0;      // (wave 0, lane 0) log det via a running product, as the scan kernels do
     __syncthreads();
+    auto tiles_from_lds = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int x = 0; x < NT; ++x)
+            if (x % NGW == grp && mfma_wave) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pt[x / NGW][r] = sP[(x * 16 + lq + 4 * r) * LD + b * 16 + lr];
+            }
+    };
+    auto tiles_to_lds = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int x = 0; x < NT; ++x)
+            if (x % NGW == grp && mfma_wave) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sP[(x * 16 + lq + 4 * r) * LD + b * 16 + lr] = pt[x / NGW][r];
+            }
+    };
+    tiles_from_lds();
 
     for (int64_t step = g.step0; step < g.step1; ++step) {
         const int64_t t = tstep(step);
@@ -151,64 +175,63 @@ __global__ __launch_bounds__(256) void dk_fused_filter(const FusedArgs g) {
         if (tid < DP) sa[tid] = a_n;          // read after the barrier inside predict
         if (step + 1 < g.step1) fetch(tstep(step + 1));
 
-        // predict (lgc.jl:46-52) of the state in (sm, sP) with step t's transition -> (sm, sP)
+        // predict (lgc.jl:46-52): (sm, sP) hold the state; afterwards sm holds A m + a and the tiles hold A P A' + Q (registers only)
         auto predict = [&]() __attribute__((always_inline)) {
             if (g.sA != 0) load_A(g.A + t * g.sA);
             if (g.sQ != 0) load_Q(g.Q + t * g.sQ);
-            // T1 = A [P | m]   (tile (I, J) of T1 stored TRANSPOSED: sT[col][row]; the mean rides as column block NT)
+            // T1 = A P: tiles (b, x), stored TRANSPOSED (sT[col][row])
 #pragma unroll
-            for (int tl = 0; tl < NT * (NT + 1); ++tl)
-                if ((tl & 3) == w) {
-                    const int I = tl / (NT + 1), J = tl % (NT + 1);
+            for (int x = 0; x < NT; ++x)
+                if (x % NGW == grp && mfma_wave) {
                     d4 acc = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                    for (int ks = 0; ks < KS; ++ks) {
-                        double b;
-                        if (J < NT) b = sP[(ks * 4 + lq) * LD + J * 16 + lr];
-                        else b = lr == 0 ? sm[ks * 4 + lq] : 0.0;
-                        acc = mfma_f64(af[I][ks], b, acc);
-                    }
-                    if (J < NT) {
+                    for (int ks = 0; ks < KS; ++ks) acc = mfma_f64(af[ks], sP[(ks * 4 + lq) * LD + x * 16 + lr], acc);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) sT[(J * 16 + lr) * LD + I * 16 + lq + 4 * r] = acc[r];
-                    } else if (lr == 0) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) smp[I * 16 + lq + 4 * r] = acc[r];
-                    }
+                    for (int r = 0; r < 4; ++r) sT[(x * 16 + lr) * LD + b * 16 + lq + 4 * r] = acc[r];
                 }
+            // A m on the vector pipe while the matrix pipe works: block row b by its first wave, lane (lr, lq) sums its k = 4 ks + lq
+            if (grp == 0 && mfma_wave) {
+                double sacc = 0.0;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) sacc = fma(af[ks], sm[ks * 4 + lq], sacc);
+                redm[lq * DP + b * 16 + lr] = sacc;
+            }
             lds_barrier();
-            // Pp = T1 A' + Q
+            // Pp = T1 A' + Q: tiles (x, b) -> registers
 #pragma unroll
-            for (int tl = 0; tl < NT * NT; ++tl)
-                if ((tl & 3) == w) {
-                    const int I = tl / NT, J = tl % NT;
-                    d4 acc = d4{qf[tl >> 2][0], qf[tl >> 2][1], qf[tl >> 2][2], qf[tl >> 2][3]};
+            for (int x = 0; x < NT; ++x)
+                if (x % NGW == grp && mfma_wave) {
+                    d4 acc = d4{qf[x / NGW][0], qf[x / NGW][1], qf[x / NGW][2], qf[x / NGW][3]};
 #pragma unroll
-                    for (int ks = 0; ks < KS; ++ks) acc = mfma_f64(sT[(ks * 4 + lq) * LD + I * 16 + lr], af[J][ks], acc);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) sP[(I * 16 + lq + 4 * r) * LD + J * 16 + lr] = acc[r];
+                    for (int ks = 0; ks < KS; ++ks) acc = mfma_f64(sT[(ks * 4 + lq) * LD + x * 16 + lr], af[ks], acc);
+                    pt[x / NGW] = acc;
                 }
-            if (tid < DP) sm[tid] = smp[tid] + sa[tid];
-            lds_barrier();
+            if (tid < DP) sm[tid] = ((redm[tid] + redm[DP + tid]) + (redm[2 * DP + tid] + redm[3 * DP + tid])) + sa[tid];
         };
 
-        // the p scalar updates of step t (lgc.jl:247-257 each) on (sm, sP); lml, missing count, not-PD flag accumulate in wave 0
+        // partial sums of v = h_j P from the register tiles (lgc.jl:249: V = h'P, i.e. column sums): lane (lr, lq) of tile (x, b)
+        // adds its 4 rows of column 16 b + lr; slice (x, lq) of the NSL = 4 NT partial sums
+        auto v_partials = [&](int j) __attribute__((always_inline)) {
+            const double* hj = sH + j * DP;
+#pragma unroll
+            for (int x = 0; x < NT; ++x)
+                if (x % NGW == grp && mfma_wave) {
+                    double sacc = 0.0;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sacc = fma(pt[x / NGW][r], hj[x * 16 + lq + 4 * r], sacc);
+                    red[(x * 4 + lq) * DP + b * 16 + lr] = sacc;
+                }
+        };
+        // the p scalar updates of step t (lgc.jl:247-257 each); lml, missing count, not-PD flag accumulate in wave 0
         auto update = [&]() __attribute__((always_inline)) {
             for (int j = 0; j < g.p; ++j) {
-                {   // v = h_j P (lgc.jl:249: V = h'P reads column i of P for v_i): thread (i, slice) sums its K-slice
-                    const int i = tid % DP, sl = tid / DP;
-                    if (sl < NG) {
-                        double s = 0.0;
-                        for (int k = sl; k < DP; k += NG) s += sP[k * LD + i] * sH[j * DP + k];
-                        red[sl * DP + i] = s;
-                    }
-                }
+                v_partials(j);
                 lds_barrier();
                 if (w == 0) {
                     double v = 0.0, hi = 0.0, mi = 0.0;
                     if (lane < DP) {
 #pragma unroll
-                        for (int q = 0; q < NG; ++q) v += red[q * DP + lane];
+                        for (int q = 0; q < NSL; ++q) v += red[q * DP + lane];
                         hi = sH[j * DP + lane];
                         mi = sm[lane];
                     }
@@ -230,25 +253,34 @@ __global__ __launch_bounds__(256) void dk_fused_filter(const FusedArgs g) {
                     }
                     if (lane == 0) {
                         ss[0] = sinv;
-                        lml += -0.5 * (kLog2Pi + log(s) + nu * nu * sinv) + (miss ? 0.5 * (kLog2Pi + log(kLargeVar)) : 0.0);
+                        lml += -0.5 * (kLog2Pi + nu * nu * sinv) + (miss ? 0.5 * (kLog2Pi + log(kLargeVar)) : 0.0);
+                        sprod *= s;
+                        if (sprod > 1e100 || sprod < 1e-100) {
+                            lml -= 0.5 * log(sprod);
+                            sprod = 1.0;
+                        }
                         nmiss += miss ? 1.0 : 0.0;
                         if (!(s > 0.0) && bad == 0.0) bad = (double)(t + 1);
                     }
                 }
                 lds_barrier();
-                {
-                    const double sinv = ss[0];
-                    for (int e = tid; e < DP * DP; e += 256) {
-                        const int a = e / DP, b = e % DP;
-                        sP[a * LD + b] -= sv[a] * sv[b] * sinv;
-                    }
+                {   // P -= v v' / s in the register tiles
+                    const double vc = sv[b * 16 + lr] * ss[0];
+#pragma unroll
+                    for (int x = 0; x < NT; ++x)
+                        if (x % NGW == grp && mfma_wave) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) pt[x / NGW][r] = fma(-sv[x * 16 + lq + 4 * r], vc, pt[x / NGW][r]);
+                        }
                 }
                 // the emission block of the NEXT step may replace this one once its last reader (wave 0 above) is done
                 if (!H_shared && j == g.p - 1 && step + 1 < g.step1) stage_H();
-                lds_barrier();
+                if (j + 1 < g.p) lds_barrier();      // (sv, ss[0] and red are rewritten by the next scalar update)
             }
+            tiles_to_lds();
+            lds_barrier();
         };
-        auto emit = [&]() __attribute__((always_inline)) {       // filtering distribution of step t
+        auto emit = [&]() __attribute__((always_inline)) {       // filtering distribution of step t (sP, sm are current)
             if (g.m_out && tid < g.d) g.m_out[t * g.d + tid] = sm[tid];
             if (g.P_out) {
                 double* Po = g.P_out + t * (int64_t)g.d * g.d;
@@ -256,34 +288,39 @@ __global__ __launch_bounds__(256) void dk_fused_filter(const FusedArgs g) {
             }
         };
 #ifdef FUSED_SKIP      // development: time the phases in isolation (scripts/fused_kbench.hip)
-        if (!(FUSED_SKIP & 1)) predict();
+        if (!(FUSED_SKIP & 1)) { predict(); lds_barrier(); }
         if (!(FUSED_SKIP & 2)) update();
         emit();
 #else
         if (fwd) {
             predict();
+            lds_barrier();        // sm complete (A m + a) before wave 0 reads it
             update();
             emit();
         } else {      // Reverse (lgssm.jl:161-165, 183-187): update the carried state, then predict with the same step's transition
             update();
             emit();
-            lds_barrier();      // sa of this step was written above, the carried (sm, sP) are final: predict may overwrite
+            lds_barrier();        // everybody is done with sP / sm of the filtering state before predict's results replace them
             predict();
+            lds_barrier();
         }
 #endif
     }
     __syncthreads();
+    if (!fwd) {                   // Reverse: the carried (predicted) covariance is in the register tiles only
+        tiles_to_lds();
+        __syncthreads();
+    }
     if (g.xfin) {
         for (int e = tid; e < DP * DP; e += 256) g.xfin[e] = sP[(e % DP) * LD + e / DP];
         if (tid < DP) g.xfin[DP * DP + tid] = sm[tid];
     }
     if (tid == 0) {
-        g.result8[0] += lml;
+        g.result8[0] += lml - 0.5 * log(sprod);
         g.result8[1] += nmiss;
         if (bad != 0.0 && g.result8[2] == 0.0) g.result8[2] = bad;
     }
 }
-
 
 // ------------------------------------------------------------------------------------------------ backward pass
 // marginals(replace_observation_noise_cov(posterior(model, y), Rnew)) for mid-sized states WITHOUT the d x d Cholesky of the
