@@ -747,7 +747,7 @@ int forward_reduce(tgp_handle* h, uint32_t flags, int for_mode = -1) {
     // General (per-step) layout, d = 5..8 (tgp_group.hpp GroupStep): the lane-per-chunk pass 1 holds the element AND the step's
     // own A, Q per lane and is bound by its own spill traffic from d = 6 (7.9 ms at T = 1e7 against a 0.9 ms HBM floor); the group
     // layout needs column j only. logpdf and filtering distributions; the posterior path of per-step models stays lane-per-chunk.
-    const bool ps_group = !h->lti && !h->sde && h->d >= 5 && h->d <= 8 && (for_mode == 0 || for_mode == 1);
+    const bool ps_group = !h->lti && !h->sde && h->d >= 5 && h->d <= 16 && (for_mode == 0 || for_mode == 1);
     const bool group_pays = h->d >= 7 || h->opt_group == 2 || h->force_group_post || (ps_group && h->d >= 6);
     // (posterior path in the group layout, tgp_group_smooth.hpp: pass 2 + pass 3 take 7.7 + 7.4 ms at T = 1e7 for d = 7 and 8
     // alike -- 498 / 310 VGPRs, one wave per SIMD, bound by the D + 10 LDS exchanges of a step; the lane-per-chunk kernels
@@ -1944,7 +1944,7 @@ static unsigned variant_selftest(int device, int d, bool lti_layout) {
                          what, x.rc, z.rc, x.v.size(), z.v.size(), nbad, first, worst);
         return good && nbad == 0;
     };
-    if ((lti_layout || d <= 8) && kernel_table(d)->group_reduce_filter != nullptr) {   // group-per-chunk kernels against the out-of-line build
+    if (kernel_table(d)->group_reduce_filter != nullptr) {   // group-per-chunk kernels against the out-of-line build
         st = keep;
         if (run(3, lti_layout, rg) == TGP_OK) {
             // (general layout: the group-layout block scans then also serve the lane-per-chunk posterior passes -- operation M2 is
@@ -1984,7 +1984,7 @@ static void select_table(tgp_handle* h, int d, bool lti, int variant) {
     h->variant_code = 1;
     if (variant == 1) return;
     if (variant == 3) {             // out-of-line build + the group-per-chunk logpdf kernels (used by the check itself)
-        h->use_group = safe->group_reduce_filter != nullptr && (lti || d <= 8);
+        h->use_group = safe->group_reduce_filter != nullptr;
         h->use_group_aff = h->use_group && lti;
         h->use_group_sm = h->use_group_aff;
         h->use_group_marg = h->use_group_aff;
@@ -2011,7 +2011,7 @@ static void select_table(tgp_handle* h, int d, bool lti, int variant) {
         merge_tables(safe, fast, ok, h->ktm);
         h->variant_code = ok == want ? 2 : 3;
     }
-    h->use_group = (lti || d <= 8) && ((g >> kOpGroup) & 1u) != 0u && safe->group_reduce_filter != nullptr;
+    h->use_group = ((g >> kOpGroup) & 1u) != 0u && safe->group_reduce_filter != nullptr;
     h->use_group_aff = lti && h->use_group && ((g >> kOpGroupAff) & 1u) != 0u;
     h->use_group_sm = h->use_group_aff;      // the same known-answer operation (posterior marginals) exercises both
     h->use_group_marg = lti && h->use_group && ((g >> kOpGroupMarg) & 1u) != 0u;

@@ -223,8 +223,9 @@ __global__ __launch_bounds__(256) void k_group_reduce_filter(ModelView mv, int L
     TGP_GUNROLL for (int i = 0; i < D; ++i) Hj = (i == j) ? H[i] : Hj;
     GroupObs<G> ob;
     GroupStep<D> nxt;
+    constexpr bool PF = D <= 8;       // one step of register prefetch; d >= 9 (spill-bound already) loads the step when it is used
     const int jcl = gl.act ? j : 0;
-    if (!LTI && r0 < r1) nxt.load(mv, r0, jcl, gl.act);
+    if (!LTI && PF && r0 < r1) nxt.load(mv, r0, jcl, gl.act);
     for (int g = 0; g < L0; g += G) {
         ob.load(mv, c, L0, r0, r1, g, j);
         const int64_t rg = r0 + g;
@@ -238,18 +239,24 @@ __global__ __launch_bounds__(256) void k_group_reduce_filter(ModelView mv, int L
                 group_obs_row<D>(mv, jj, j, H, Hj, hh, Rsh);
                 do_predict = jj == 0 && !(mv.ordering != 0 && (rg + k) == 0);
             } else {
-                const GroupStep<D> cur = nxt;
-                if (rg + k + 1 < r1) nxt.load(mv, rg + k + 1, jcl, gl.act);      // in flight while this step is computed
-                do_predict = cur.pred;
-                if (do_predict) {
-                    group_publish_A<D>(const_cast<double*>(gl.sA), cur, j, gl.act);
-                    TGP_GUNROLL for (int i = 0; i < D; ++i) Qc[i] = cur.Qc[i];
-                    aj = cur.aj;
+                if (!PF) nxt.load(mv, rg + k, jcl, gl.act);
+                const GroupStep<D>& cur = nxt;
+                GroupStep<D> held;
+                if (PF) {
+                    held = nxt;
+                    if (rg + k + 1 < r1) nxt.load(mv, rg + k + 1, jcl, gl.act);      // in flight while this step is computed
                 }
-                TGP_GUNROLL for (int i = 0; i < D; ++i) H[i] = cur.H[i];
+                const GroupStep<D>& use = PF ? held : cur;
+                do_predict = use.pred;
+                if (do_predict) {
+                    group_publish_A<D>(const_cast<double*>(gl.sA), use, j, gl.act);
+                    TGP_GUNROLL for (int i = 0; i < D; ++i) Qc[i] = use.Qc[i];
+                    aj = use.aj;
+                }
+                TGP_GUNROLL for (int i = 0; i < D; ++i) H[i] = use.H[i];
                 Hj = 0.0;
                 TGP_GUNROLL for (int i = 0; i < D; ++i) Hj = (i == j) ? H[i] : Hj;
-                hh = cur.hh;
+                hh = use.hh;
             }
             ob.step(mv, Rsh, k, y, R, miss);
             if (do_predict) {
@@ -323,8 +330,9 @@ __global__ __launch_bounds__(256) void k_group_apply_logpdf(ModelView mv, int L0
     bool ok = true;
     GroupObs<G> ob;
     GroupStep<D> nxt;
+    constexpr bool PF = D <= 8;       // one step of register prefetch; d >= 9 (spill-bound already) loads the step when it is used
     const int jcl = gl.act ? j : 0;
-    if (!LTI && r0 < r1) nxt.load(mv, r0, jcl, gl.act);
+    if (!LTI && PF && r0 < r1) nxt.load(mv, r0, jcl, gl.act);
     for (int g = 0; g < L0; g += G) {
         ob.load(mv, c, L0, r0, r1, g, j);
         const int64_t rg = r0 + g;
@@ -339,18 +347,24 @@ __global__ __launch_bounds__(256) void k_group_apply_logpdf(ModelView mv, int L0
                 group_obs_row<D>(mv, jj, j, H, Hj, hh, Rsh);
                 do_predict = jj == 0 && !(mv.ordering != 0 && (rg + k) == 0);
             } else {
-                const GroupStep<D> cur = nxt;
-                if (rg + k + 1 < r1) nxt.load(mv, rg + k + 1, jcl, gl.act);
-                do_predict = cur.pred;
-                if (do_predict) {
-                    group_publish_A<D>(const_cast<double*>(gl.sA), cur, j, gl.act);
-                    TGP_GUNROLL for (int i = 0; i < D; ++i) Qc[i] = cur.Qc[i];
-                    aj = cur.aj;
+                if (!PF) nxt.load(mv, rg + k, jcl, gl.act);
+                const GroupStep<D>& cur = nxt;
+                GroupStep<D> held;
+                if (PF) {
+                    held = nxt;
+                    if (rg + k + 1 < r1) nxt.load(mv, rg + k + 1, jcl, gl.act);
                 }
-                TGP_GUNROLL for (int i = 0; i < D; ++i) H[i] = cur.H[i];
+                const GroupStep<D>& use = PF ? held : cur;
+                do_predict = use.pred;
+                if (do_predict) {
+                    group_publish_A<D>(const_cast<double*>(gl.sA), use, j, gl.act);
+                    TGP_GUNROLL for (int i = 0; i < D; ++i) Qc[i] = use.Qc[i];
+                    aj = use.aj;
+                }
+                TGP_GUNROLL for (int i = 0; i < D; ++i) H[i] = use.H[i];
                 Hj = 0.0;
                 TGP_GUNROLL for (int i = 0; i < D; ++i) Hj = (i == j) ? H[i] : Hj;
-                hh = cur.hh;
+                hh = use.hh;
             }
             ob.step(mv, Rsh, k, y, R, miss);
             if (do_predict) {

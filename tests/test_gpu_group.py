@@ -289,13 +289,14 @@ def test_group_filter_and_materialised_posterior(tgp, d, ordering):
             np.testing.assert_allclose(dpost.x0.P, post["x0P"], rtol=1e-8, atol=1e-9)
 
 
-@pytest.mark.parametrize("d", [5, 6, 7, 8])
+@pytest.mark.parametrize("d", [5, 6, 7, 8, 9, 12, 14, 16])
 @pytest.mark.parametrize("ordering", ["F", "R"])
 @pytest.mark.parametrize("p", [1, 2])
 def test_group_per_step_layout_equals_oracle(tgp, d, ordering, p):
     """General (per-step) layout in the group kernels (tgp_group.hpp GroupStep): every time step carries its own A, a, Q, H, h
     (lti_sde.jl:135-146 inputs); logpdf and the filtering distributions, scalar and vector observations, both orderings,
-    missing data, ragged chunk sizes and multi-level scans, forced on for every d = 5..8 (default: from d = 6)."""
+    missing data, ragged chunk sizes and multi-level scans, forced on for every d = 5..16 (default: from d = 6; d >= 9 without
+    the register prefetch)."""
     rng = np.random.default_rng(300 + 10 * d + 2 * p + (ordering == "R"))
     T = 611
     model = U.random_lgssm(rng, True, d, T, ordering) if p == 1 else U.random_lgssm_small(rng, True, d, p, T, ordering)
