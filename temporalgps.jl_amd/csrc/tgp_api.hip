@@ -744,16 +744,18 @@ int forward_reduce(tgp_handle* h, uint32_t flags, int for_mode = -1) {
     // Group-per-chunk logpdf kernels (tgp_group.hpp). Measured at T = 1e7 (pass 1 + pass 2, ms; lane-per-chunk inlined
     // build in brackets): d = 5 1.9 (0.70), d = 6 2.2 (1.55), d = 7 2.9 (4.3), d = 8 3.4 (12.1) -- their time hardly
     // depends on d (LDS exchanges and shuffles, not flops), so they pay from d = 7 on (TGP_OPT_GROUP = 2 forces them).
-    // General (per-step) layout, d = 5..8 (tgp_group.hpp GroupStep): the lane-per-chunk pass 1 holds the element AND the step's
+    // General (per-step) layout, d = 5..16 (tgp_group.hpp GroupStep): the lane-per-chunk pass 1 holds the element AND the step's
     // own A, Q per lane and is bound by its own spill traffic from d = 6 (7.9 ms at T = 1e7 against a 0.9 ms HBM floor); the group
-    // layout needs column j only. logpdf and filtering distributions; the posterior path of per-step models stays lane-per-chunk.
-    const bool ps_group = !h->lti && !h->sde && h->d >= 5 && h->d <= 16 && (for_mode == 0 || for_mode == 1);
-    const bool group_pays = h->d >= 7 || h->opt_group == 2 || h->force_group_post || (ps_group && h->d >= 6);
+    // layout needs column j only. logpdf, filtering distributions and (pass 2 MODE 2 + pass 3) the posterior marginals.
     // (posterior path in the group layout, tgp_group_smooth.hpp: pass 2 + pass 3 take 7.7 + 7.4 ms at T = 1e7 for d = 7 and 8
     // alike -- 498 / 310 VGPRs, one wave per SIMD, bound by the D + 10 LDS exchanges of a step; the lane-per-chunk kernels
-    // need 6.3 + 1.8 (+ 1.8 for their own pass 1) at d = 7 and 15.4 + 5.3 (+ 6.7) at d = 8: group from d = 8 on)
-    const bool grp_post = for_mode == 2 && h->use_group_sm && h->ordering == 0 && h->kt->group_apply_posterior != nullptr &&
-                          (h->d >= 8 || h->opt_group == 2 || h->force_group_post);
+    // need 6.3 + 1.8 (+ 1.8 for their own pass 1) at d = 7 and 15.4 + 5.3 (+ 6.7) at d = 8: group from d = 8 on. Per-step layout:
+    // the lane-per-chunk passes are spill-bound from d = 6 and out-of-line private-memory code from d = 9 -- group from d = 6)
+    const bool ps_layout = !h->lti && !h->sde && h->d >= 5 && h->d <= 16;
+    const bool grp_post = for_mode == 2 && h->use_group_sm && h->ordering == 0 && h->kt->group_apply_posterior != nullptr && (h->lti || ps_layout) &&
+                          (h->d >= 8 || (ps_layout && h->d >= 6) || h->opt_group == 2 || h->force_group_post);
+    const bool ps_group = ps_layout && (for_mode == 0 || for_mode == 1 || grp_post);
+    const bool group_pays = h->d >= 7 || h->opt_group == 2 || h->force_group_post || (ps_group && h->d >= 6);
     // filtering distributions (MODE 1) and the materialised posterior (MODE 3): group layout where the alternative is the
     // out-of-line build (d >= 9); MODE 3 shares the smoother's validation, Forward models only
     const bool grp_out = ((for_mode == 1 && h->use_group_m1) || (for_mode == 3 && h->use_group_m3 && h->ordering == 0)) &&
@@ -825,7 +827,7 @@ int forward_apply(tgp_handle* h, int mode, const FilterOut& fo, const double* x0
         HIPCHK(h->partial.ensure((size_t)nb * 3 * sizeof(double)));
         if (mode == 2) {
             TRY(scan_prepare(h, h->Rv, kAffineCov, h->n0));
-            LaunchScope ls(h, "k_group_apply_filter<lti,posterior>");
+            LaunchScope ls(h, h->lti ? "k_group_apply_filter<lti,posterior>" : "k_group_apply_filter<per-step,posterior>");
             h->kt->group_apply_posterior(h->mv, h->L0, h->n0, h->F.S[0], fo.fs, h->Rv.E[0], h->partial.d(), nullptr, nullptr, nullptr, h->stream);
         } else if (mode == 3) {
             if (h->ordering != 0 || !h->use_group_m3) return h->fail(TGP_EINVAL, "internal: group-per-chunk elements with an unsupported materialise pass");
@@ -1313,7 +1315,7 @@ static int smoother_forward_impl(tgp_handle* h, uint32_t flags, const double* x0
 static int smoother_backward_impl(tgp_handle* h, const double* xs_dev, const double* Rnew_dev, int64_t sRn, double* mean_dev, double* var_dev) {
     scan_down(h, h->Rv, xs_dev);
     if (h->group_active) {
-        LaunchScope ls(h, "k_group_smooth<lti>");
+        LaunchScope ls(h, h->lti ? "k_group_smooth<lti>" : "k_group_smooth<per-step>");
         h->kt->group_smooth(h->mv, h->L0, h->n0, h->F.S[0], h->Rv.S[0], h->fs.d(), Rnew_dev, sRn, mean_dev, var_dev, flag_ptr(h), h->alt_H, h->alt_h,
                             h->alt_p, h->stream);
         return TGP_OK;
@@ -1986,7 +1988,7 @@ static void select_table(tgp_handle* h, int d, bool lti, int variant) {
     if (variant == 3) {             // out-of-line build + the group-per-chunk logpdf kernels (used by the check itself)
         h->use_group = safe->group_reduce_filter != nullptr;
         h->use_group_aff = h->use_group && lti;
-        h->use_group_sm = h->use_group_aff;
+        h->use_group_sm = h->use_group;                  // (per-step layout: pass 2 MODE 2 + pass 3 in the group layout too)
         h->use_group_marg = h->use_group_aff;
         h->use_group_m1 = h->use_group;
         h->use_group_m3 = h->use_group_aff;
@@ -2013,7 +2015,8 @@ static void select_table(tgp_handle* h, int d, bool lti, int variant) {
     }
     h->use_group = ((g >> kOpGroup) & 1u) != 0u && safe->group_reduce_filter != nullptr;
     h->use_group_aff = lti && h->use_group && ((g >> kOpGroupAff) & 1u) != 0u;
-    h->use_group_sm = h->use_group_aff;      // the same known-answer operation (posterior marginals) exercises both
+    // the same known-answer operation (posterior marginals) exercises both; per-step layout: M2 is part of the kOpGroup verdict
+    h->use_group_sm = lti ? h->use_group_aff : h->use_group;
     h->use_group_marg = lti && h->use_group && ((g >> kOpGroupMarg) & 1u) != 0u;
     h->use_group_m1 = h->use_group && ((g >> kOpGroupM1) & 1u) != 0u;
     h->use_group_m3 = h->use_group_sm && ((g >> kOpGroupM3) & 1u) != 0u;

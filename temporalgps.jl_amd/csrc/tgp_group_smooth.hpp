@@ -182,19 +182,26 @@ template <int D> struct GroupRts {
 // ---------------------------------------------------------------- pass 2, MODE 2
 // MAT == false: MODE 2 (scratch + chunk element). MAT == true: MODE 3 (G_t, g_t, L_t per step to G_out / g_out / L_out; no scratch,
 // no element). A compile-time switch: the extra stores change the register allocation of this spill-prone kernel at d = 16.
-template <int D, bool MAT>
+// LTI == false: the general (per-step) layout -- every time step loads column j of its own A, Q, its a_j and its emission row
+// (GroupStep, tgp_group.hpp), A through the group's own LDS tile; no register prefetch here (these kernels are register-bound)
+template <int D, bool MAT, bool LTI>
 __global__ __launch_bounds__(256) void k_group_apply_posterior(ModelView mv, int L0, int64_t n0, const double* __restrict__ S0,
                                                                double* __restrict__ fs, double* __restrict__ R0, double* __restrict__ partial,
                                                                double* __restrict__ G_out, double* __restrict__ g_out, double* __restrict__ L_out) {
     constexpr int G = GroupGeom<D>::G, NGRP = GroupGeom<D>::NGRP;
-    __shared__ __attribute__((aligned(16))) double sA[G * G];
+    __shared__ __attribute__((aligned(16))) double sA[(LTI ? 1 : NGRP) * G * G];
     __shared__ double tiles[NGRP * GroupGeom<D>::LD];
     __shared__ double sh[12];
     GroupLane<D> gl;
     double Qc[D], H[D], aj, hh, Rsh;
     group_setup<D>(mv, sA, tiles, gl, Qc, H, aj, hh, Rsh);
+    if (!LTI) {
+        gl.sA = sA + (threadIdx.x / G) * G * G;
+        group_clear_A<D>(const_cast<double*>(gl.sA), gl.j);
+    }
     const int j = gl.j;
-    GroupRts<D> rts{GroupOps<D>{j, gl.act, gl.tile}, sA};
+    const int jcl = gl.act ? j : 0;
+    GroupRts<D> rts{GroupOps<D>{j, gl.act, gl.tile}, gl.sA};
     const int64_t c = (int64_t)blockIdx.x * NGRP + (threadIdx.x / G);
     int64_t r0, r1;
     chunk_range(mv, c < n0 ? c : n0, L0, r0, r1);
@@ -223,7 +230,21 @@ __global__ __launch_bounds__(256) void k_group_apply_posterior(ModelView mv, int
             double y, R;
             bool miss;
             const int jj = mv.p == 1 ? 0 : (g + k) % mv.p;
-            group_obs_row<D>(mv, jj, j, H, Hj, hh, Rsh);
+            if (LTI) {
+                group_obs_row<D>(mv, jj, j, H, Hj, hh, Rsh);
+            } else {
+                GroupStep<D> st;
+                st.load(mv, rg + k, jcl, gl.act);
+                if (st.pred) {
+                    group_publish_A<D>(const_cast<double*>(gl.sA), st, j, gl.act);
+                    TGP_GUNROLL for (int i = 0; i < D; ++i) Qc[i] = st.Qc[i];
+                    aj = st.aj;
+                }
+                TGP_GUNROLL for (int i = 0; i < D; ++i) H[i] = st.H[i];
+                Hj = 0.0;
+                TGP_GUNROLL for (int i = 0; i < D; ++i) Hj = (i == j) ? H[i] : Hj;
+                hh = st.hh;
+            }
             ob.step(mv, Rsh, k, y, R, miss);
             if (jj == 0) {   // Forward models only: every time step predicts (at its first observation)
                 double Pf[D], Gc[D], Xc[D], Lc[D], gj;
@@ -280,19 +301,24 @@ __global__ __launch_bounds__(256) void k_group_apply_posterior(ModelView mv, int
 }
 
 // ---------------------------------------------------------------- pass 3
-template <int D>
+template <int D, bool LTI>
 __global__ __launch_bounds__(256) void k_group_smooth(ModelView mv, int L0, int64_t n0, const double* __restrict__ S0, const double* __restrict__ S0r,
                                                       const double* __restrict__ fs, const double* __restrict__ Rnew, int64_t sRn,
                                                       double* __restrict__ mean_out, double* __restrict__ var_out, int* __restrict__ bad,
                                                       GroupAltEmit alt) {
     constexpr int G = GroupGeom<D>::G, NGRP = GroupGeom<D>::NGRP;
-    __shared__ __attribute__((aligned(16))) double sA[G * G];
+    __shared__ __attribute__((aligned(16))) double sA[(LTI ? 1 : NGRP) * G * G];
     __shared__ double tiles[NGRP * GroupGeom<D>::LD];
     GroupLane<D> gl;
     double Qc[D], H[D], aj, hh, Rsh;
     group_setup<D>(mv, sA, tiles, gl, Qc, H, aj, hh, Rsh);
+    if (!LTI) {
+        gl.sA = sA + (threadIdx.x / G) * G * G;
+        group_clear_A<D>(const_cast<double*>(gl.sA), gl.j);      // (before any group leaves: whole groups return together below)
+    }
     const int j = gl.j;
-    GroupRts<D> rts{GroupOps<D>{j, gl.act, gl.tile}, sA};
+    const int jcl = gl.act ? j : 0;
+    GroupRts<D> rts{GroupOps<D>{j, gl.act, gl.tile}, gl.sA};
     const int64_t c = (int64_t)blockIdx.x * NGRP + (threadIdx.x / G);
     if (c >= n0) return;                        // whole groups leave together; no block-level barrier below
     int64_t r0, r1;
@@ -325,7 +351,21 @@ __global__ __launch_bounds__(256) void k_group_smooth(ModelView mv, int L0, int6
                 }
             }
         } else {
-        group_obs_row<D>(mv, jj, j, H, Hj, hh, Rsh);
+        if (LTI) {
+            group_obs_row<D>(mv, jj, j, H, Hj, hh, Rsh);
+        } else {
+            GroupStep<D> st;          // this step's emission row and (first observation of a time step) its transition
+            st.load(mv, r, jcl, gl.act);
+            if (st.pred) {
+                group_publish_A<D>(const_cast<double*>(gl.sA), st, j, gl.act);
+                TGP_GUNROLL for (int i = 0; i < D; ++i) Qc[i] = st.Qc[i];
+                aj = st.aj;
+            }
+            TGP_GUNROLL for (int i = 0; i < D; ++i) H[i] = st.H[i];
+            Hj = 0.0;
+            TGP_GUNROLL for (int i = 0; i < D; ++i) Hj = (i == j) ? H[i] : Hj;
+            hh = st.hh;
+        }
         // emission marginal of the smoothed state at step r with the NEW noise (lgssm.jl:111-115, missings.jl:35-41)
         double pj = 0.0;
         TGP_GUNROLL for (int i = 0; i < D; ++i) pj = fma(xs.P[i], H[i], pj);

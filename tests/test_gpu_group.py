@@ -327,13 +327,26 @@ def test_group_per_step_layout_equals_oracle(tgp, d, ordering, p):
         m, P = tgp._filter(dm, y)
         np.testing.assert_allclose(m, fm, rtol=1e-8, atol=1e-9)
         np.testing.assert_allclose(P, fP, rtol=1e-8, atol=1e-9)
-    # the posterior path of the same handle (lane-per-chunk passes, group-layout scans) is unaffected
-    if ordering == "F" and p == 1:
-        Rn = rng.random(T) * 0.1
-        pm, pv = ref.marginals(ref.replace_observation_noise_cov(ref.posterior(model, y), Rn))
-        gm, gv = tgp.posterior_marginals(dm, y, Rn)
-        np.testing.assert_allclose(gm, pm, rtol=1e-8, atol=1e-8)
-        np.testing.assert_allclose(gv, pv, rtol=1e-8, atol=1e-9)
+    # the posterior path of the same handle: pass 2 (MODE 2) and pass 3 in the per-step group layout as well (forced on here;
+    # default from d = 6), with missing data, per-step R_new, ragged chunks
+    if ordering == "F":
+        post = ref.posterior_missing(model, y, missing)
+        sh = (T,) if p == 1 else (T, p)
+        Rn = rng.random(sh) * 0.1
+        Rn_or = Rn if p == 1 else np.stack([np.diag(v) for v in Rn])
+        pm, pv = ref.marginals(ref.replace_observation_noise_cov(post, Rn_or))
+        if p > 1:
+            pv = np.diagonal(pv, axis1=-2, axis2=-1)
+        for chunk in (0, 5 * p, 64 * p):
+            hd.set_option(tgp._lib.OPT_CHUNK, chunk)
+            hd.set_option(tgp._lib.OPT_PROFILE, 1)
+            hd.profile_reset()
+            gm, gv = tgp.posterior_marginals(dm, ym, Rn)
+            names = set(hd.profile())
+            hd.set_option(tgp._lib.OPT_PROFILE, 0)
+            assert "k_group_smooth<per-step>" in names and "k_group_apply_filter<per-step,posterior>" in names, names
+            np.testing.assert_allclose(gm, pm, rtol=1e-8, atol=1e-8)
+            np.testing.assert_allclose(gv, pv, rtol=1e-8, atol=1e-9)
 
 
 def test_group_per_step_layout_is_the_default_from_d6(tgp):
