@@ -750,10 +750,11 @@ int forward_reduce(tgp_handle* h, uint32_t flags, int for_mode = -1) {
     // (posterior path in the group layout, tgp_group_smooth.hpp: pass 2 + pass 3 take 7.7 + 7.4 ms at T = 1e7 for d = 7 and 8
     // alike -- 498 / 310 VGPRs, one wave per SIMD, bound by the D + 10 LDS exchanges of a step; the lane-per-chunk kernels
     // need 6.3 + 1.8 (+ 1.8 for their own pass 1) at d = 7 and 15.4 + 5.3 (+ 6.7) at d = 8: group from d = 8 on. Per-step layout:
-    // the lane-per-chunk passes are spill-bound from d = 6 and out-of-line private-memory code from d = 9 -- group from d = 6)
+    // measured at T = 1e7 -- d = 6: 7.2 + 5.6 ms in the group layout against ~11 ms lane-per-chunk, d = 7: 8.5 + 9.9 against ~30 ms;
+    // from d = 9 the lane-per-chunk passes are out-of-line private-memory code (d = 14, T = 2e5: 1150 -> 13.8 ms) -- group from d = 7)
     const bool ps_layout = !h->lti && !h->sde && h->d >= 5 && h->d <= 16;
     const bool grp_post = for_mode == 2 && h->use_group_sm && h->ordering == 0 && h->kt->group_apply_posterior != nullptr && (h->lti || ps_layout) &&
-                          (h->d >= 8 || (ps_layout && h->d >= 6) || h->opt_group == 2 || h->force_group_post);
+                          (h->d >= 8 || (ps_layout && h->d >= 7) || h->opt_group == 2 || h->force_group_post);
     const bool ps_group = ps_layout && (for_mode == 0 || for_mode == 1 || grp_post);
     const bool group_pays = h->d >= 7 || h->opt_group == 2 || h->force_group_post || (ps_group && h->d >= 6);
     // filtering distributions (MODE 1) and the materialised posterior (MODE 3): group layout where the alternative is the
