@@ -338,6 +338,7 @@ def test_reference_call_chain_runs_the_fused_smoother(tgp):
 
     (m1, v1), k1 = kernels(lambda: tgp.posterior_marginals(dm, y, Rn))
     (m2, v2), k2 = kernels(lambda: tgp.marginals(tgp.replace_observation_noise_cov(tgp.posterior(dm, y), Rn)))
+    k1.pop("k_filter_table", None)        # one-time set-up of the first call on a bound model (pass 1's shared matrix parts)
     assert k1 == k2 and not any("materialise" in k for k in k2), (k1, k2)
     np.testing.assert_array_equal(m1, m2)
     np.testing.assert_array_equal(v1, v2)
@@ -439,3 +440,40 @@ def test_hip_graph_replay_of_repeated_calls(tgp):
         res = tgp.logpdf_and_posterior_marginals(dm, yn, Rt, out=out)
         out = res[1:]
         assert res[0] == b3[0] and torch.equal(res[1], b3[1]) and torch.equal(res[2], b3[2])
+
+
+@pytest.mark.parametrize("d_case", [0, 2, 3, 4, 5])
+def test_pass1_with_shared_matrix_parts_is_bit_identical(tgp, d_case):
+    """TGP_OPT_SHARED_PARTS (default on): Forward LTI model, one noise variance, no missing data -- the matrix parts of every
+    chunk's filter element come from one table, pass 1 runs only the vector half of the recursion. Same bits as the general
+    pass 1 (the same operations in the same order), for ragged last chunks and several chunk lengths; models that do not qualify
+    (missing data, per-step noise) keep the general pass."""
+    k, t, s2 = GP_CASES[d_case]
+    model, y, _ = U.gp_case(k, t, s2, seed=40 + d_case)
+    T = model["T"]
+    Rn = np.full(1, 0.05)
+    for chunk in (0, 7, 64):
+        outs = []
+        for opt in (0, 1):
+            dm = to_device_model(tgp, model)
+            dm.handle_options[tgp._lib.OPT_SHARED_PARTS] = opt
+            hd = dm.handle()
+            if chunk:
+                hd.set_option(tgp._lib.OPT_CHUNK, chunk)
+            hd.set_option(tgp._lib.OPT_PROFILE, 1)
+            hd.profile_reset()
+            lp = tgp.logpdf(dm, y)
+            names = set(hd.profile())
+            hd.set_option(tgp._lib.OPT_PROFILE, 0)
+            d = len(model["x0m"])
+            if d <= 6:
+                assert ("k_reduce_filter<lti,shared parts>" in names) == bool(opt), names
+            m, P = tgp._filter(dm, y)
+            pm, pv = tgp.posterior_marginals(dm, y, Rn)
+            ym = y.copy()
+            ym[::9] = np.nan
+            outs.append((lp, m, P, pm, pv, tgp.logpdf(dm, ym), tgp.posterior_marginals(dm, y, np.full(T, 0.05))[0]))
+        for a, b in zip(outs[0], outs[1]):
+            np.testing.assert_array_equal(np.asarray(a), np.asarray(b))
+    lp_ref = ref.logpdf(model, y)
+    assert abs(outs[1][0] - lp_ref) <= 1e-10 * abs(lp_ref)
