@@ -79,10 +79,14 @@ typedef struct tgp_handle tgp_handle;
                                   kernel (P in LDS, fp64 MFMA products, scalar updates; backward pass in modified Bryson-Frazier form,
                                   tgp_dense_fused.hpp) -- ~3 us per step instead of ~26 us of dependent launches; 0 the per-step
                                   kernel chain that larger states use. Takes effect at the next tgp_model_set. */
-#define TGP_OPT_SHARED_PARTS 11 /* scan path, pass 1 (1 default / 0): for a Forward model with every block shared (LTI), ONE noise variance,
-                                   scalar observations and no missing data, the matrix parts (Abar, C, J) of a chunk's filter element
-                                   and its per-step (w, Cv, 1/s) do not depend on the observations; they are computed once per call
-                                   configuration and pass 1 runs only the vector half of the recursion per chunk (d <= 6). */
+#define TGP_OPT_SHARED_PARTS 11 /* scan path, pass 1 (1 default / 0 off / 2): for a Forward model with every block shared (LTI), ONE noise
+                                   variance, scalar observations and no missing data, the matrix parts (Abar, C, J) of a chunk's filter
+                                   element and its per-step (w, Cv, 1/s) do not depend on the observations: every chunk has the same.
+                                   They are tabulated once per bound model and chunk length (one lane, ~150 sequential steps: 1.4 ms
+                                   at d = 3, longer than a whole call) and pass 1 then runs only the vector half of the recursion
+                                   (d <= 6; bit-identical results). The table is never built on the caller's critical path: the second
+                                   eligible call on a bound model launches the build on a side stream and still runs the general pass;
+                                   later calls use the table once it is complete. 2 = build it in line on the first call (tests). */
 #define TGP_OPT_GRAPH 9 /* hipGraph replay of the launch chain of tgp_logpdf / tgp_[logpdf_and_]posterior_marginals: a call with device
                            pointers that repeats the previous call's arguments is recorded once (stream capture, kernel nodes only)
                            and then replayed with one hipGraphLaunch. 0 (default) off, 1 on, -1 on for T <= 2^20. Measured on

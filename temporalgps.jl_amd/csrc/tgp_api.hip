@@ -282,6 +282,14 @@ struct tgp_handle {
     int opt_table = 1;           // TGP_OPT_SHARED_PARTS: pass 1 with the chunks' shared matrix parts from a table
     DevBuf ftab;                 // ... the table (k_filter_table), valid for (tab_L0, tab_nlast) of the bound model
     int tab_L0 = 0, tab_nlast = 0;
+    // The table costs one lane ~150 sequential steps (1.4 ms at d = 3: more than the whole call), so it is never built on the
+    // caller's critical path: the SECOND eligible call on a bound model launches k_filter_table on a side stream and still runs the
+    // general pass; calls use the table once its event has completed. A model that is evaluated once (a hyper-parameter search
+    // binds a new model per evaluation) never builds one.
+    hipStream_t side_stream = nullptr;
+    hipEvent_t tab_ev = nullptr, tab_dep = nullptr;
+    int tab_state = 0;           // 0 none, 1 being built on side_stream, 2 ready
+    int tab_calls = 0;           // eligible calls seen with the current (model, chunk length)
     // hipGraph replay of the launch chain of repeated calls (TGP_OPT_GRAPH): slot 0 tgp_logpdf, 1 tgp_posterior_marginals
     struct GraphSlot {
         uint64_t key[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -810,16 +818,41 @@ int forward_reduce(tgp_handle* h, uint32_t flags, int for_mode = -1) {
     // (d^2 + 3 d multiply-adds per step instead of ~6 d^3): T = 1e7, d = 3: 131 -> ~30 us.
     const bool shared_parts = h->opt_table && h->lti && !h->sde && h->p == 1 && h->ordering == 0 && h->mv.sR == 0 && h->mv.missing == nullptr &&
                               h->kt->reduce_filter_tab != nullptr && (int64_t)h->L0 * (2 * h->d + 1) <= kFilterTableLds;
+    bool use_tab = false;
     if (shared_parts) {
         const int64_t Tm = h->T * h->p;
         const int nlast = (int)(Tm - (h->n0 - 1) * (int64_t)h->L0);
-        if (h->tab_L0 != h->L0 || h->tab_nlast != nlast || h->ftab.p == nullptr) {
-            HIPCHK(h->ftab.ensure((size_t)h->kt->filter_table_size(h->L0) * sizeof(double)));
-            LaunchScope ls(h, "k_filter_table");
-            h->kt->filter_table(h->mv, h->L0, nlast, h->ftab.d(), h->stream);
+        if (h->tab_L0 != h->L0 || h->tab_nlast != nlast) {          // another chunking: start over
+            if (h->tab_state == 1) (void)hipStreamSynchronize(h->side_stream);
+            h->tab_state = 0;
+            h->tab_calls = 0;
             h->tab_L0 = h->L0;
             h->tab_nlast = nlast;
         }
+        if (h->tab_state == 1 && hipEventQuery(h->tab_ev) == hipSuccess) h->tab_state = 2;
+        if (h->tab_state == 0 && h->opt_table == 2) {                 // (tests: table built in line, on the handle's own stream)
+            HIPCHK(h->ftab.ensure((size_t)h->kt->filter_table_size(h->L0) * sizeof(double)));
+            LaunchScope ls(h, "k_filter_table");
+            h->kt->filter_table(h->mv, h->L0, nlast, h->ftab.d(), h->stream);
+            h->tab_state = 2;
+        }
+        if (h->tab_state == 2) {
+            use_tab = true;
+        } else if (h->tab_state == 0 && ++h->tab_calls >= 2) {
+            if (!h->side_stream) {
+                HIPCHK(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
+                HIPCHK(hipEventCreateWithFlags(&h->tab_ev, hipEventDisableTiming));
+                HIPCHK(hipEventCreateWithFlags(&h->tab_dep, hipEventDisableTiming));
+            }
+            HIPCHK(h->ftab.ensure((size_t)h->kt->filter_table_size(h->L0) * sizeof(double)));
+            HIPCHK(hipEventRecord(h->tab_dep, h->stream));           // the model blocks were uploaded on the handle's stream
+            HIPCHK(hipStreamWaitEvent(h->side_stream, h->tab_dep, 0));
+            h->kt->filter_table(h->mv, h->L0, nlast, h->ftab.d(), h->side_stream);
+            HIPCHK(hipEventRecord(h->tab_ev, h->side_stream));
+            h->tab_state = 1;
+        }
+    }
+    if (use_tab) {
         LaunchScope ls(h, "k_reduce_filter<lti,shared parts>");
         h->kt->reduce_filter_tab(h->mv, h->L0, h->n0, h->ftab.d(), h->F.E[0], fused ? h->F.E[1] : nullptr, fused ? h->F.n[1] : 0, h->stream);
     } else {
@@ -943,6 +976,12 @@ int tgp_destroy(tgp_handle* h) {
     if (!h) return TGP_OK;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
+    if (h->side_stream) {
+        (void)hipStreamSynchronize(h->side_stream);
+        (void)hipEventDestroy(h->tab_ev);
+        (void)hipEventDestroy(h->tab_dep);
+        (void)hipStreamDestroy(h->side_stream);
+    }
     drop_graphs(h);
     for (DevBuf* b : {&h->bA, &h->ba, &h->bQ, &h->bH, &h->bh, &h->bR, &h->bx0, &h->bx0r, &h->bx0fold, &h->by, &h->bmiss, &h->bRnew, &h->beps_t,
                       &h->beps_e, &h->bo1, &h->bo2, &h->bo3, &h->F.slab, &h->Rv.slab, &h->fs, &h->partial, &h->result, &h->segtmp, &h->tile_t, &h->tile_e, &h->Fad.slab, &h->btan, &h->bx0ad, &h->tile_tan, &h->balt, &h->bF, &h->bPinf, &h->btimes, &h->bAQ1, &h->ftab})
@@ -1000,7 +1039,7 @@ int tgp_set_option(tgp_handle* h, int option, int64_t value) {
         return TGP_OK;
     }
     if (option == TGP_OPT_SHARED_PARTS) {
-        h->opt_table = value != 0;
+        h->opt_table = value != 0 ? (int)value : 0;      // 1 default policy; 2 build the table synchronously on the first call (tests)
         h->reduce_valid = false;
         h->smoother_valid = false;
         return TGP_OK;
@@ -1060,6 +1099,9 @@ int tgp_model_set(tgp_handle* h, int64_t T, int d, int p, int ordering, uint32_t
     h->reduce_valid = false;
     h->smoother_valid = false;
     h->sde = false;
+    if (h->tab_state == 1) (void)hipStreamSynchronize(h->side_stream);       // a table of the previous model may still be in flight
+    h->tab_state = 0;
+    h->tab_calls = 0;
     h->tab_L0 = 0;
     if (T <= 0) return h->fail(TGP_EINVAL, "T must be positive");
     if (ordering != 0 && ordering != 1) return h->fail(TGP_EINVAL, "ordering must be 0 (Forward) or 1 (Reverse)");
@@ -1164,6 +1206,8 @@ int tgp_model_set_sde(tgp_handle* h, int64_t T, int d, int ordering, uint32_t fl
     if (h) drop_graphs(h);
     if (!h) return TGP_EINVAL;
     if (!F || !times) return h->fail(TGP_EINVAL, "null F / times");
+    if (h && h->tab_state == 1) (void)hipStreamSynchronize(h->side_stream);
+    if (h) { h->tab_state = 0; h->tab_calls = 0; h->tab_L0 = 0; }
     if (d > 8) return h->fail(TGP_EUNSUPPORTED, "tgp_model_set_sde: d <= 8 (build the per-step blocks on the host for larger d)");
     // shared placeholder blocks for A and Q (never read: the tiled record supplies them); a must be shared
     if (!(flags & TGP_SHARED_a)) return h->fail(TGP_EUNSUPPORTED, "tgp_model_set_sde: the transition offset a must be shared");

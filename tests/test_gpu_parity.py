@@ -338,7 +338,6 @@ def test_reference_call_chain_runs_the_fused_smoother(tgp):
 
     (m1, v1), k1 = kernels(lambda: tgp.posterior_marginals(dm, y, Rn))
     (m2, v2), k2 = kernels(lambda: tgp.marginals(tgp.replace_observation_noise_cov(tgp.posterior(dm, y), Rn)))
-    k1.pop("k_filter_table", None)        # one-time set-up of the first call on a bound model (pass 1's shared matrix parts)
     assert k1 == k2 and not any("materialise" in k for k in k2), (k1, k2)
     np.testing.assert_array_equal(m1, m2)
     np.testing.assert_array_equal(v1, v2)
@@ -456,7 +455,7 @@ def test_pass1_with_shared_matrix_parts_is_bit_identical(tgp, d_case):
         outs = []
         for opt in (0, 1):
             dm = to_device_model(tgp, model)
-            dm.handle_options[tgp._lib.OPT_SHARED_PARTS] = opt
+            dm.handle_options[tgp._lib.OPT_SHARED_PARTS] = 2 * opt          # 2: table built in line on the first call
             hd = dm.handle()
             if chunk:
                 hd.set_option(tgp._lib.OPT_CHUNK, chunk)
@@ -477,3 +476,23 @@ def test_pass1_with_shared_matrix_parts_is_bit_identical(tgp, d_case):
             np.testing.assert_array_equal(np.asarray(a), np.asarray(b))
     lp_ref = ref.logpdf(model, y)
     assert abs(outs[1][0] - lp_ref) <= 1e-10 * abs(lp_ref)
+
+
+def test_shared_parts_table_is_built_off_the_critical_path(tgp):
+    """Default policy of TGP_OPT_SHARED_PARTS: the first call on a bound model runs the general pass 1, the second launches the
+    table build on a side stream (and still runs the general pass), later calls use the table -- with identical results."""
+    import time as _time
+    model, y, _ = U.gp_case(("matern52",), ("regular", 0.0, 0.1, 4000), 0.1, seed=77)
+    dm = to_device_model(tgp, model)
+    hd = dm.handle()
+    seen, vals = [], []
+    for it in range(5):
+        hd.set_option(tgp._lib.OPT_PROFILE, 1)
+        hd.profile_reset()
+        vals.append(tgp.logpdf(dm, y))
+        seen.append(set(hd.profile()))
+        hd.set_option(tgp._lib.OPT_PROFILE, 0)
+        _time.sleep(0.05)          # (the side-stream build takes ~1 ms)
+    assert "k_reduce_filter<lti>" in seen[0] and "k_reduce_filter<lti>" in seen[1]
+    assert "k_reduce_filter<lti,shared parts>" in seen[-1]
+    assert all(v == vals[0] for v in vals)
