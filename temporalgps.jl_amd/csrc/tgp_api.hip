@@ -1557,9 +1557,12 @@ static int affine_impl(tgp_handle* h, bool rnd, const double* x0dev, const doubl
     h->reduce_valid = false;
     h->smoother_valid = false;
     h->group_active = false;
-    if (!rnd && h->lti && h->ordering == 0 && h->use_group_marg && h->opt_group && (h->d >= 7 || h->opt_group == 2) &&
-        h->kt->group_reduce_marginals != nullptr) {
-        // prior marginals of a d >= 7 LTI model in the group layout (tgp_group_smooth.hpp)
+    // group layout (tgp_group_smooth.hpp): prior marginals and rand, both orderings, LTI and per-step layouts. LTI Forward marginals
+    // from d = 7 (measured in round 1); everything else from d = 9, where the lane-per-chunk alternative is out-of-line
+    // private-memory code (d = 14, T = 2e5: rand 60-150 ms, Reverse / per-step marginals 176-270 ms)
+    const bool grp_affine = h->use_group_marg && h->opt_group && h->kt->group_reduce_marginals != nullptr && !h->sde &&
+                            (h->opt_group == 2 || h->d >= 9 || (!rnd && h->lti && h->ordering == 0 && h->d >= 7));
+    if (grp_affine) {
         const int64_t Tm = h->T * h->p;
         int64_t L0 = h->opt_chunk;
         if (L0 <= 0) {
@@ -1571,17 +1574,18 @@ static int affine_impl(tgp_handle* h, bool rnd, const double* x0dev, const doubl
         if (L0 > Tm) L0 = Tm;
         h->L0 = (int)L0;
         h->n0 = (Tm + L0 - 1) / L0;
-        TRY(scan_prepare(h, h->Rv, kAffineCov, h->n0));
+        TRY(scan_prepare(h, h->Rv, kAffineCov, h->n0));      // (rand: the covariance part of the elements stays zero)
         h->group_active = true;                  // the scans over Rv run in the group layout too
+        int* badg = flag_ptr(h);
         {
-            LaunchScope ls(h, "k_group_reduce_affine<marginals>");
-            h->kt->group_reduce_marginals(h->mv, h->L0, h->n0, h->Rv.E[0], h->stream);
+            LaunchScope ls(h, rnd ? "k_group_reduce_affine<rand>" : "k_group_reduce_affine<marginals>");
+            h->kt->group_reduce_marginals(rnd, h->mv, h->L0, h->n0, eps_t, h->Rv.E[0], badg, h->stream);
         }
         scan_up(h, h->Rv);
         scan_down(h, h->Rv, x0dev);
         {
-            LaunchScope ls(h, "k_group_apply_affine<marginals>");
-            h->kt->group_apply_marginals(h->mv, h->L0, h->n0, h->Rv.S[0], mean_dev, var_dev, h->stream);
+            LaunchScope ls(h, rnd ? "k_group_apply_affine<rand>" : "k_group_apply_affine<marginals>");
+            h->kt->group_apply_marginals(rnd, h->mv, h->L0, h->n0, h->Rv.S[0], eps_t, eps_e, mean_dev, var_dev, badg, h->stream);
         }
         h->group_active = false;
         return TGP_OK;
@@ -2031,9 +2035,9 @@ static unsigned variant_selftest(int device, int d, bool lti_layout) {
             //  part of the verdict there)
             if (same(ra[kOpM0], rg[kOpM0], "group logpdf") && (lti_layout || same(ra[kOpM2], rg[kOpM2], "group scans under the posterior passes"))) ok |= 1u << kOpGroup;
             if (same(ra[kOpM1], rg[kOpM1], "group filter")) ok |= 1u << kOpGroupM1;             // filtering distributions
+            if (same(ra[kOpAffine], rg[kOpAffine], "group marginals / rand")) ok |= 1u << kOpGroupMarg;   // prior marginals and rand, both orderings
             if (lti_layout) {
                 if (same(ra[kOpM2], rg[kOpM2])) ok |= 1u << kOpGroupAff;     // smoother with the group-layout affine scans
-                if (same(ra[kOpAffine], rg[kOpAffine])) ok |= 1u << kOpGroupMarg;   // prior marginals (and the unchanged rand)
                 if (same(ra[kOpM3], rg[kOpM3])) ok |= 1u << kOpGroupM3;             // materialised posterior
             }
         }
@@ -2067,7 +2071,7 @@ static void select_table(tgp_handle* h, int d, bool lti, int variant) {
         h->use_group = safe->group_reduce_filter != nullptr;
         h->use_group_aff = h->use_group && lti;
         h->use_group_sm = h->use_group;                  // (per-step layout: pass 2 MODE 2 + pass 3 in the group layout too)
-        h->use_group_marg = h->use_group_aff;
+        h->use_group_marg = h->use_group;
         h->use_group_m1 = h->use_group;
         h->use_group_m3 = h->use_group_aff;
         return;
@@ -2095,7 +2099,7 @@ static void select_table(tgp_handle* h, int d, bool lti, int variant) {
     h->use_group_aff = lti && h->use_group && ((g >> kOpGroupAff) & 1u) != 0u;
     // the same known-answer operation (posterior marginals) exercises both; per-step layout: M2 is part of the kOpGroup verdict
     h->use_group_sm = lti ? h->use_group_aff : h->use_group;
-    h->use_group_marg = lti && h->use_group && ((g >> kOpGroupMarg) & 1u) != 0u;
+    h->use_group_marg = h->use_group && ((g >> kOpGroupMarg) & 1u) != 0u;
     h->use_group_m1 = h->use_group && ((g >> kOpGroupM1) & 1u) != 0u;
     h->use_group_m3 = h->use_group_sm && ((g >> kOpGroupM3) & 1u) != 0u;
 }

@@ -397,46 +397,132 @@ __global__ __launch_bounds__(256) void k_group_smooth(ModelView mv, int L0, int6
 
 }  // namespace TGP_NS
 
-// ---------------------------------------------------------------- prior marginals (Forward, LTI family) in the group layout
-// marginals(model) (lgssm.jl:99-109): x <- predict(x) once per time step, N(H x + h, H P H' + R) per observation.
-// Pass 1 composes the chunk's affine element (E, g, L) <- (A E, A g + a, A L A' + Q); pass 2 propagates the state.
+// ---------------------------------------------------------------- affine passes in the group layout: prior marginals and rand
+// marginals(model) (lgssm.jl:99-115): x <- predict(x) once per time step, N(H x + h, H P H' + R) per observation.
+// rand(rng, model) with supplied noise (lgssm.jl:65-91): x <- A x + a + chol(Q + 1e-9 I).U' eps_t (lgc.jl:84-87),
+// y = H x + h + sqrt(R [+ 1e-9]) eps_e. Pass 1 composes the chunk's affine element (E, g, L) <- (A E, A g + c, A L A' + Q)
+// (rand: c = a + noise, L stays 0); pass 2 propagates the state. Both orderings (the first processed time step of a
+// Reverse-ordered model does not predict; GroupStep / trans_index pick the blocks) and both layouts (LTI: blocks from
+// group_setup; per-step: GroupStep loads, A through the group's own LDS tile).
 namespace TGP_NS {
 
+// upper Cholesky factor of S + jitter I, column j per lane (Uc[i] = U[i][j]); S given by columns (Sc[i] = S[i][j])
 template <int D>
-__global__ __launch_bounds__(256) void k_group_reduce_marginals(ModelView mv, int L0, int64_t n0, double* __restrict__ E0) {
+__device__ __forceinline__ bool group_chol_upper(const GroupOps<D>& op, const double* Sc, double jitter, double* Uc) {
+    constexpr int V0 = GroupGeom<D>::V0, V1 = GroupGeom<D>::V1;
+    const int j = op.j;
+    bool ok = true;
+    TGP_GUNROLL for (int i = 0; i < D; ++i) Uc[i] = 0.0;
+    TGP_GUNROLL for (int i = 0; i < D; ++i) {
+        double acc = Sc[i] + ((i == j) ? jitter : 0.0);
+        wave_sync();
+        if (j == i) {
+            double dg = acc;
+            TGP_GUNROLL for (int k = 0; k < i; ++k) dg = fma(-Uc[k], Uc[k], dg);
+            const double di = sqrt(dg);
+            TGP_GUNROLL for (int k = 0; k < i; ++k) op.tile[V0 + k] = Uc[k];
+            op.tile[V1 + 0] = dg;
+            op.tile[V1 + 1] = di;
+            op.tile[V1 + 2] = 1.0 / di;
+        }
+        wave_sync();
+        const double dg = op.tile[V1 + 0], di = op.tile[V1 + 1], ri = op.tile[V1 + 2];
+        ok = ok && (dg > 0.0);
+        TGP_GUNROLL for (int k = 0; k < i; ++k) acc = fma(-op.tile[V0 + k], Uc[k], acc);
+        Uc[i] = (j == i) ? di : ((j > i && op.act) ? acc * ri : 0.0);
+    }
+    return ok;
+}
+
+// vj <- sum_k A[j][k] v_k + add   (v distributed one element per lane; A in the LDS tile, row-major [G i + k])
+template <int D>
+__device__ __forceinline__ void group_affine_mean(const GroupLane<D>& gl, double& vj, double add) {
+    constexpr int G = GroupGeom<D>::G;
+    double v[D];
+    gl.gather(vj, v);
+    double acc = 0.0;
+    TGP_GUNROLL for (int k = 0; k < D; ++k) acc = fma(gl.sA[G * gl.j + k], v[k], acc);
+    vj = acc + add;
+}
+
+// (U' eps)_j = sum_{i <= j} U[i][j] eps_i: lane-local with the lane's own column of U
+template <int D> __device__ __forceinline__ double group_noise(const double* Uc, const double* __restrict__ ep, int j, bool act) {
+    double nz = 0.0;
+    TGP_GUNROLL for (int i = 0; i < D; ++i) nz = (i <= j && act) ? fma(Uc[i], ep[i], nz) : nz;
+    return nz;
+}
+
+template <int D, bool LTI, bool RAND>
+__global__ __launch_bounds__(256) void k_group_reduce_marginals(ModelView mv, int L0, int64_t n0, const double* __restrict__ eps_t,
+                                                                double* __restrict__ E0, int* __restrict__ bad) {
     constexpr int G = GroupGeom<D>::G, NGRP = GroupGeom<D>::NGRP;
-    __shared__ __attribute__((aligned(16))) double sA[G * G];
+    __shared__ __attribute__((aligned(16))) double sA[(LTI ? 1 : NGRP) * G * G];
     __shared__ double tiles[NGRP * GroupGeom<D>::LD];
     GroupLane<D> gl;
     double Qc[D], H[D], aj, hh, Rsh;
     group_setup<D>(mv, sA, tiles, gl, Qc, H, aj, hh, Rsh);
+    if (!LTI) {
+        gl.sA = sA + (threadIdx.x / G) * G * G;
+        group_clear_A<D>(const_cast<double*>(gl.sA), gl.j);
+    }
     const int j = gl.j;
+    const int jcl = gl.act ? j : 0;
+    const GroupOps<D> op{j, gl.act, gl.tile};
     const int64_t c = (int64_t)blockIdx.x * NGRP + (threadIdx.x / G);
     if (c >= n0) return;
     int64_t r0, r1;
     chunk_range(mv, c, L0, r0, r1);
     GAElem<D> e;
     GAffineMO<D>::identity(e, j, gl.act);
-    const int64_t nt = (r1 - r0) / mv.p;            // whole time steps in the chunk
-    for (int64_t t = 0; t < nt; ++t) {
+    double Uc[D];
+    bool ok = true;
+    if (RAND && LTI) ok = group_chol_upper<D>(op, Qc, 1e-9, Uc);
+    for (int64_t r = r0; r < r1; r += mv.p) {           // one iteration per time step of the chunk (chunks hold whole time steps)
+        const int64_t tproc = r / mv.p;
+        bool pred = !(mv.ordering != 0 && tproc == 0);
+        if (!LTI) {
+            GroupStep<D> st;
+            st.load(mv, r, jcl, gl.act);
+            pred = st.pred;
+            if (pred) {
+                group_publish_A<D>(const_cast<double*>(gl.sA), st, j, gl.act);
+                TGP_GUNROLL for (int i = 0; i < D; ++i) Qc[i] = st.Qc[i];
+                aj = st.aj;
+            }
+        }
+        if (!pred) continue;
         double T1[D];
         gl.mul_A(e.E, T1);
         TGP_GUNROLL for (int i = 0; i < D; ++i) e.E[i] = T1[i];
-        gl.predict(e.g, aj, e.L, Qc);
+        if (RAND) {
+            if (!LTI) ok = group_chol_upper<D>(op, Qc, 1e-9, Uc) && ok;
+            const double* ep = eps_t + trans_index(mv, tproc) * D;
+            group_affine_mean<D>(gl, e.g, aj + group_noise<D>(Uc, ep, j, gl.act));
+        } else {
+            gl.predict(e.g, aj, e.L, Qc);
+        }
     }
     if (r1 > r0 && gl.act) GAffineMO<D>::store(e, E0, n0, c, j);
+    if (RAND && !ok && j == 0) atomicOr(bad, 1);
 }
 
-template <int D>
+template <int D, bool LTI, bool RAND>
 __global__ __launch_bounds__(256) void k_group_apply_marginals(ModelView mv, int L0, int64_t n0, const double* __restrict__ S0,
-                                                               double* __restrict__ mean_out, double* __restrict__ var_out) {
+                                                               const double* __restrict__ eps_t, const double* __restrict__ eps_e,
+                                                               double* __restrict__ mean_out, double* __restrict__ var_out, int* __restrict__ bad) {
     constexpr int G = GroupGeom<D>::G, NGRP = GroupGeom<D>::NGRP;
-    __shared__ __attribute__((aligned(16))) double sA[G * G];
+    __shared__ __attribute__((aligned(16))) double sA[(LTI ? 1 : NGRP) * G * G];
     __shared__ double tiles[NGRP * GroupGeom<D>::LD];
     GroupLane<D> gl;
     double Qc[D], H[D], aj, hh, Rsh;
     group_setup<D>(mv, sA, tiles, gl, Qc, H, aj, hh, Rsh);
+    if (!LTI) {
+        gl.sA = sA + (threadIdx.x / G) * G * G;
+        group_clear_A<D>(const_cast<double*>(gl.sA), gl.j);
+    }
     const int j = gl.j;
+    const int jcl = gl.act ? j : 0;
+    const GroupOps<D> op{j, gl.act, gl.tile};
     const int64_t c = (int64_t)blockIdx.x * NGRP + (threadIdx.x / G);
     if (c >= n0) return;
     int64_t r0, r1;
@@ -445,20 +531,55 @@ __global__ __launch_bounds__(256) void k_group_apply_marginals(ModelView mv, int
     gstate_load<D>(x, S0, n0, c, j, gl.act);
     double Hj = 0.0;
     TGP_GUNROLL for (int i = 0; i < D; ++i) Hj = (i == j) ? H[i] : Hj;
+    double Uc[D];
+    bool ok = true;
+    if (RAND && LTI) ok = group_chol_upper<D>(op, Qc, 1e-9, Uc);
     for (int64_t r = r0; r < r1; ++r) {
-        const int jj = mv.p == 1 ? 0 : (int)((r - r0) % mv.p);
-        group_obs_row<D>(mv, jj, j, H, Hj, hh, Rsh);
-        if (jj == 0) gl.predict(x.m, aj, x.P, Qc);
-        double pj = 0.0;
-        TGP_GUNROLL for (int i = 0; i < D; ++i) pj = fma(x.P[i], H[i], pj);
-        const double mean = group_sum<G>(Hj * x.m) + hh;
-        const double var = group_sum<G>(Hj * pj);
+        const int64_t tproc = r / mv.p;
+        const int jj = (int)(r - tproc * mv.p);
+        bool pred = jj == 0 && !(mv.ordering != 0 && tproc == 0);
+        if (LTI) {
+            group_obs_row<D>(mv, jj, j, H, Hj, hh, Rsh);
+        } else {
+            GroupStep<D> st;
+            st.load(mv, r, jcl, gl.act);
+            pred = st.pred;
+            if (pred) {
+                group_publish_A<D>(const_cast<double*>(gl.sA), st, j, gl.act);
+                TGP_GUNROLL for (int i = 0; i < D; ++i) Qc[i] = st.Qc[i];
+                aj = st.aj;
+            }
+            TGP_GUNROLL for (int i = 0; i < D; ++i) H[i] = st.H[i];
+            Hj = 0.0;
+            TGP_GUNROLL for (int i = 0; i < D; ++i) Hj = (i == j) ? H[i] : Hj;
+            hh = st.hh;
+        }
+        if (pred) {
+            if (RAND) {
+                if (!LTI) ok = group_chol_upper<D>(op, Qc, 1e-9, Uc) && ok;
+                const double* ep = eps_t + trans_index(mv, tproc) * D;
+                group_affine_mean<D>(gl, x.m, aj + group_noise<D>(Uc, ep, j, gl.act));
+            } else {
+                gl.predict(x.m, aj, x.P, Qc);
+            }
+        }
         const int64_t tm = micro_index(mv, c, (int)(r - r0), L0);
-        if (j == 0) {
-            mean_out[tm] = mean;
-            var_out[tm] = var + (mv.sR != 0 ? mv.R[tm] : Rsh);
+        const double Rv = mv.sR != 0 ? mv.R[tm] : Rsh;
+        const double mean = group_sum<G>(Hj * x.m) + hh;
+        if (RAND) {
+            // scalar emission: sqrt(R) eps (lgc.jl:241-243); vector emission with diagonal R: chol(R + 1e-9 I).U' eps (lgc.jl:84-87)
+            if (j == 0) mean_out[tm] = mean + sqrt(mv.small_out ? Rv + 1e-9 : Rv) * eps_e[tm];
+        } else {
+            double pj = 0.0;
+            TGP_GUNROLL for (int i = 0; i < D; ++i) pj = fma(x.P[i], H[i], pj);
+            const double var = group_sum<G>(Hj * pj);
+            if (j == 0) {
+                mean_out[tm] = mean;
+                var_out[tm] = var + Rv;
+            }
         }
     }
+    if (RAND && !ok && j == 0) atomicOr(bad, 1);
 }
 
 }  // namespace TGP_NS

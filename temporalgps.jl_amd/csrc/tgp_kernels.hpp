@@ -765,9 +765,11 @@ struct KernelTable {
     // (Hn != NULL: emit through the alternative block Hn [pn][d], hn [pn], Rn [T|1][pn] instead of the model's emissions)
     void (*group_smooth)(const ModelView&, int L0, int64_t n0, const double* S0, const double* S0r, const double* fs, const double* Rnew,
                          int64_t sRn, double* mean_out, double* var_out, int* bad, const double* Hn, const double* hn, int pn, hipStream_t);
-    // ... and prior marginals (Forward): affine element per chunk, then state propagation + emission
-    void (*group_reduce_marginals)(const ModelView&, int L0, int64_t n0, double* E0, hipStream_t);
-    void (*group_apply_marginals)(const ModelView&, int L0, int64_t n0, const double* S0, double* mean_out, double* var_out, hipStream_t);
+    // ... and the affine passes (prior marginals / rand; both orderings, LTI and per-step layouts): affine element per chunk,
+    // then state propagation + emission (rand: mean_out receives y, var_out is unused)
+    void (*group_reduce_marginals)(bool rnd, const ModelView&, int L0, int64_t n0, const double* eps_t, double* E0, int* bad, hipStream_t);
+    void (*group_apply_marginals)(bool rnd, const ModelView&, int L0, int64_t n0, const double* S0, const double* eps_t, const double* eps_e,
+                                  double* mean_out, double* var_out, int* bad, hipStream_t);
     int group_chunks_per_block;      // 32 (eight lanes per chunk, d <= 8) or 16 (sixteen, d <= 16); 0 without group kernels
     void scan_reduce(int monoid, const double* Ein, int64_t n, double* Ehi, int64_t nhi, hipStream_t s) const {
         scan_reduce_c[monoid == kFilter ? kScanFilter : monoid == kFilterAD ? kScanAD : kScanAffine](monoid, Ein, n, Ehi, nhi, s);
