@@ -290,6 +290,7 @@ struct tgp_handle {
     hipEvent_t tab_ev = nullptr, tab_dep = nullptr;
     int tab_state = 0;           // 0 none, 1 being built on side_stream, 2 ready
     int tab_calls = 0;           // eligible calls seen with the current (model, chunk length)
+    bool capturing = false;      // inside graph_call's stream capture: no cross-stream work may be started
     // hipGraph replay of the launch chain of repeated calls (TGP_OPT_GRAPH): slot 0 tgp_logpdf, 1 tgp_posterior_marginals
     struct GraphSlot {
         uint64_t key[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -689,7 +690,9 @@ int graph_call(tgp_handle* h, int slot, const uint64_t (&key)[8], Body&& body, d
     }
     if (same && !g.failed) {
         if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeRelaxed) == hipSuccess) {
+            h->capturing = true;
             const int rc = body();
+            h->capturing = false;
             hipGraph_t graph = nullptr;
             const hipError_t e2 = hipStreamEndCapture(h->stream, &graph);
             if (rc == TGP_OK && e2 == hipSuccess && graph) {
@@ -830,7 +833,7 @@ int forward_reduce(tgp_handle* h, uint32_t flags, int for_mode = -1) {
             h->tab_nlast = nlast;
         }
         if (h->tab_state == 1 && hipEventQuery(h->tab_ev) == hipSuccess) h->tab_state = 2;
-        if (h->tab_state == 0 && h->opt_table == 2) {                 // (tests: table built in line, on the handle's own stream)
+        if (h->tab_state == 0 && h->opt_table == 2 && !h->capturing) {   // (tests: table built in line, on the handle's own stream)
             HIPCHK(h->ftab.ensure((size_t)h->kt->filter_table_size(h->L0) * sizeof(double)));
             LaunchScope ls(h, "k_filter_table");
             h->kt->filter_table(h->mv, h->L0, nlast, h->ftab.d(), h->stream);
@@ -838,7 +841,7 @@ int forward_reduce(tgp_handle* h, uint32_t flags, int for_mode = -1) {
         }
         if (h->tab_state == 2) {
             use_tab = true;
-        } else if (h->tab_state == 0 && ++h->tab_calls >= 2) {
+        } else if (h->tab_state == 0 && !h->capturing && ++h->tab_calls >= 2) {
             if (!h->side_stream) {
                 HIPCHK(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
                 HIPCHK(hipEventCreateWithFlags(&h->tab_ev, hipEventDisableTiming));
