@@ -945,6 +945,9 @@ int set_attrs(Engine* e) {
     DCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dk_fused_filter<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FusedCfg<32>::LDS_BYTES));
     DCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dk_fused_filter<48>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FusedCfg<48>::LDS_BYTES));
     DCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dk_fused_filter<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FusedCfg<64>::LDS_BYTES));
+    DCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dk_fused_rand<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FusedRandCfg<32>::LDS_BYTES));
+    DCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dk_fused_rand<48>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FusedRandCfg<48>::LDS_BYTES));
+    DCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dk_fused_rand<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FusedRandCfg<64>::LDS_BYTES));
     DCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dk_fused_smooth<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FusedSmoothCfg<32>::LDS_BYTES));
     DCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dk_fused_smooth<48>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FusedSmoothCfg<48>::LDS_BYTES));
     DCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dk_fused_smooth<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FusedSmoothCfg<64>::LDS_BYTES));
@@ -1332,6 +1335,24 @@ int filter(Engine* e, const double* y, const uint8_t* mask, double* m_out, doubl
 int marginals(Engine* e, double* mean_out, double* var_out, double* result8, hipStream_t st) {
     if (!e->have_model) return e->fail(TGP_EINVAL, "no model");
     DCHK(hipSetDevice(e->device));
+    if (fused(e)) {       // mid-sized state: the persistent pass in its marginals mode (predict + emission marginal per step)
+        DCHK(e->bfin.ensure(((size_t)e->Dp * e->Dp + e->Dp) * 8));
+        FusedArgs g = fused_args(e, nullptr, nullptr, result8);
+        g.marg_mean = mean_out; g.marg_var = var_out;
+        g.xfin = e->bfin.d();
+        for (int64_t s0 = 0; s0 < e->T; s0 += kFusedStepsPerLaunch) {
+            g.step0 = s0;
+            g.step1 = std::min(e->T, s0 + kFusedStepsPerLaunch);
+            g.x0 = s0 == 0 ? e->bx0.d() : e->bfin.d();
+            Scope sc(e, st, "dk_fused_filter<marginals>", e->profile != 0);
+            if (e->Dp == 32) hipLaunchKernelGGL(dk_fused_filter<32>, dim3(1), dim3(256), FusedCfg<32>::LDS_BYTES, st, g);
+            else if (e->Dp == 48) hipLaunchKernelGGL(dk_fused_filter<48>, dim3(1), dim3(256), FusedCfg<48>::LDS_BYTES, st, g);
+            else hipLaunchKernelGGL(dk_fused_filter<64>, dim3(1), dim3(256), FusedCfg<64>::LDS_BYTES, st, g);
+        }
+        DCHK(hipStreamSynchronize(st));
+        resolve(e);
+        return TGP_OK;
+    }
     const int Dp = e->Dp, Pq = e->Pq;
     const size_t DD = (size_t)Dp * Dp;
     (void)result8;
@@ -1794,6 +1815,22 @@ int rand(Engine* e, const double* x0_host, const double* eps_t, const double* ep
     if (e->sQ == 0) {
         const int rcq = factor_Q(e->bQ.d());
         if (rcq != TGP_OK) return rcq;
+    }
+    if (fused(e) && e->sA == 0 && e->sa == 0 && e->sQ == 0) {      // mid-sized state, shared transition: one persistent kernel
+        FusedRandArgs g;
+        g.T = e->T; g.d = d; g.p = p; g.Pq = Pq; g.ordering = e->ordering; g.small_out = small_out;
+        g.A = e->bA.d(); g.Lq = e->bLd.d(); g.a = e->ba.d(); g.H = e->bH.d(); g.h = e->bh.d(); g.R = e->bR.d();
+        g.sH = e->sH; g.sh = e->sh; g.sR = e->sR;
+        g.x0 = e->bm.d(); g.eps_t = eps_t; g.eps_e = eps_e; g.y_out = y_out;
+        {
+            Scope sc(e, st, "dk_fused_rand", e->profile != 0);
+            if (Dp == 32) hipLaunchKernelGGL(dk_fused_rand<32>, dim3(1), dim3(256), FusedRandCfg<32>::LDS_BYTES, st, g);
+            else if (Dp == 48) hipLaunchKernelGGL(dk_fused_rand<48>, dim3(1), dim3(256), FusedRandCfg<48>::LDS_BYTES, st, g);
+            else hipLaunchKernelGGL(dk_fused_rand<64>, dim3(1), dim3(256), FusedRandCfg<64>::LDS_BYTES, st, g);
+        }
+        DCHK(hipStreamSynchronize(st));
+        resolve(e);
+        return blocked_chol_status(e, "dense rand: Q + 1e-9 I is not positive definite (lgc.jl:86)");
     }
     for (int64_t step = 0; step < e->T; ++step) {
         const int64_t t = e->ordering == 0 ? step : e->T - 1 - step;

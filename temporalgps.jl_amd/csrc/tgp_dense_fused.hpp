@@ -23,6 +23,8 @@ struct FusedArgs {
     double* P_out = nullptr;           // [T][d*d] filtering covariances, column-major (nullable)
     double* result8 = nullptr;         // [0] += lml, [1] += missing count, [2] = first step with a non-positive innovation variance + 1
     double* xfin = nullptr;            // final state, same layout as x0 (nullable)
+    double* marg_mean = nullptr;       // prior marginals instead of filtering (marginals(model), lgssm.jl:99-115): [T][p] mean and
+    double* marg_var = nullptr;        // variance of every emission; y / mask are not read, the state is only predicted
     double* aux_out = nullptr;         // [T][p][d + 2]: per scalar update v = P h' (d), s = h v + R, nu = y - h m - hh: what the
                                        // backward pass (dk_fused_smooth) needs of the filter (nullable)
 };
@@ -81,6 +83,7 @@ __global__ __launch_bounds__(256) void dk_fused_filter(const FusedArgs g) {
     const int b = w % NT, grp = w / NT;
     const bool mfma_wave = w < NT * NGW;               // (NT = 3: wave 3 has no tiles)
     const bool fwd = g.ordering == 0;
+    const bool marg = g.marg_mean != nullptr;
     const bool H_shared = g.sH == 0 && g.sh == 0 && g.sR == 0;
     auto tstep = [&](int64_t step) { return fwd ? step : g.T - 1 - step; };
 
@@ -111,7 +114,7 @@ __global__ __launch_bounds__(256) void dk_fused_filter(const FusedArgs g) {
     double hs_n = 0.0, rs_n = 0.0;    // h[j], R[j] for tid = j < p (per-step emissions only)
     auto fetch = [&](int64_t t) __attribute__((always_inline)) {
         if (tid < DP) a_n = g.a[t * g.sa + tid];
-        if (tid < g.p) {
+        if (tid < g.p && !marg) {
             miss_n = g.mask != nullptr && g.mask[t * g.p + tid] != 0;
             y_n = g.y[t * g.p + tid];
         }
@@ -228,6 +231,7 @@ __global__ __launch_bounds__(256) void dk_fused_filter(const FusedArgs g) {
                 v_partials(j);
                 lds_barrier();
                 if (w == 0) {
+                    bool continue_marg = false;
                     double v = 0.0, hi = 0.0, mi = 0.0;
                     if (lane < DP) {
 #pragma unroll
@@ -235,15 +239,25 @@ __global__ __launch_bounds__(256) void dk_fused_filter(const FusedArgs g) {
                         hi = sH[j * DP + lane];
                         mi = sm[lane];
                     }
-                    const bool miss = __builtin_amdgcn_readlane(miss_c, j) != 0;
-                    const double s = wave_sum(hi * v) + (miss ? kLargeVar : ss[32 + j]);
-                    const double nu = (miss ? 0.0 : rdlane(y_c, j)) - wave_sum(hi * mi) - ss[16 + j];
+                    if (marg) {          // emission marginal of the (predicted) state: N(h m + hh, h P h' + R); the state does not move
+                        const double var = wave_sum(hi * v) + ss[32 + j], mean = wave_sum(hi * mi) + ss[16 + j];
+                        if (lane == 0) {
+                            g.marg_mean[t * g.p + j] = mean;
+                            g.marg_var[t * g.p + j] = var;
+                            ss[0] = 0.0;
+                        }
+                        if (lane < DP) sv[lane] = 0.0;
+                        continue_marg = true;
+                    }
+                    const bool miss = !marg && __builtin_amdgcn_readlane(miss_c, j) != 0;
+                    const double s = marg ? 1.0 : wave_sum(hi * v) + (miss ? kLargeVar : ss[32 + j]);
+                    const double nu = marg ? 0.0 : (miss ? 0.0 : rdlane(y_c, j)) - wave_sum(hi * mi) - ss[16 + j];
                     const double sinv = 1.0 / s;
-                    if (lane < DP) {
+                    if (lane < DP && !continue_marg) {
                         sv[lane] = v;
                         sm[lane] = mi + v * sinv * nu;
                     }
-                    if (g.aux_out) {
+                    if (g.aux_out && !continue_marg) {
                         double* ax = g.aux_out + (t * g.p + j) * (int64_t)(g.d + 2);
                         if (lane < g.d) ax[lane] = v;
                         if (lane == 0) {
@@ -251,7 +265,7 @@ __global__ __launch_bounds__(256) void dk_fused_filter(const FusedArgs g) {
                             ax[g.d + 1] = nu;
                         }
                     }
-                    if (lane == 0) {
+                    if (lane == 0 && !continue_marg) {
                         ss[0] = sinv;
                         lml += -0.5 * (kLog2Pi + nu * nu * sinv) + (miss ? 0.5 * (kLog2Pi + log(kLargeVar)) : 0.0);
                         sprod *= s;
@@ -319,6 +333,87 @@ __global__ __launch_bounds__(256) void dk_fused_filter(const FusedArgs g) {
         g.result8[0] += lml - 0.5 * log(sprod);
         g.result8[1] += nmiss;
         if (bad != 0.0 && g.result8[2] == 0.0) g.result8[2] = bad;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ rand (shared A, a, Q)
+// rand(rng, model) with supplied noise for mid-sized states (lgssm.jl:65-91): x <- A x + a + Lq eps_t with Lq = chol(Q + 1e-9 I)
+// (lower factor, computed beforehand by the blocked factorisation), y = H x + h + sqrt(R [+ 1e-9]) .* eps_e. One workgroup
+// walks the steps; A' and Lq' live in LDS so that thread (i, slice) reads consecutive addresses.
+struct FusedRandArgs {
+    int64_t T = 0;
+    int d = 0, p = 0, Pq = 0, ordering = 0, small_out = 0;
+    const double *A = nullptr, *Lq = nullptr, *a = nullptr, *H = nullptr, *h = nullptr, *R = nullptr;     // padded; A, a, Lq shared
+    int64_t sH = 0, sh = 0, sR = 0;
+    const double* x0 = nullptr;        // [DP] drawn initial state (padded with zeros)
+    const double* eps_t = nullptr;     // [T][d]
+    const double* eps_e = nullptr;     // [T][p]
+    double* y_out = nullptr;           // [T][p]
+};
+template <int DP>
+struct FusedRandCfg {
+    static constexpr int LD = DP + 1, NG = 256 / DP;
+    static constexpr int oA = 0, oL = oA + DP * LD, oX = oL + DP * LD, oE = oX + DP, oRed = oE + DP, TOTAL = oRed + NG * DP;
+    static constexpr size_t LDS_BYTES = (size_t)TOTAL * sizeof(double);
+};
+template <int DP>
+__global__ __launch_bounds__(256) void dk_fused_rand(const FusedRandArgs g) {
+    using C = FusedRandCfg<DP>;
+    constexpr int LD = C::LD, NG = C::NG;
+    extern __shared__ double lds[];
+    double* sAt = lds + C::oA;      // sAt[k LD + i] = A[i][k]
+    double* sLt = lds + C::oL;      // sLt[k LD + i] = Lq[i][k]
+    double* sx = lds + C::oX;
+    double* se = lds + C::oE;
+    double* red = lds + C::oRed;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int e = tid; e < DP * DP; e += 256) {
+        const int i = e % DP, k = e / DP;
+        sAt[k * LD + i] = g.A[e];                                 // column-major A: element e = A[i][k]
+        sLt[k * LD + i] = i >= k ? g.Lq[e] : 0.0;                 // lower factor (entries above the diagonal are not part of it)
+    }
+    if (tid < DP) sx[tid] = g.x0[tid];
+    __syncthreads();
+    const bool fwd = g.ordering == 0;
+    auto emit = [&](int64_t t) __attribute__((always_inline)) {     // y[t][j] = h_j x + hh_j + sqrt(R_j) eps_e[t][j]: wave j % 4, lanes over k
+        for (int j = w; j < g.p; j += 4) {
+            double acc = 0.0;
+            if (lane < DP) acc = g.H[t * g.sH + j + (int64_t)lane * g.Pq] * sx[lane];
+            const double hx = wave_sum(acc);
+            if (lane == 0) {
+                const double Rv = g.R[t * g.sR + j];
+                g.y_out[t * g.p + j] = hx + g.h[t * g.sh + j] + sqrt(g.small_out ? Rv + 1e-9 : Rv) * g.eps_e[t * g.p + j];
+            }
+        }
+    };
+    auto move = [&](int64_t t) __attribute__((always_inline)) {     // x <- A x + a + Lq eps_t[trans index]
+        if (tid < DP) se[tid] = tid < g.d ? g.eps_t[t * g.d + tid] : 0.0;
+        lds_barrier();
+        const int i = tid % DP, sl = tid / DP;
+        if (sl < NG) {
+            double s = 0.0;
+            for (int k = sl; k < DP; k += NG) s += sAt[k * LD + i] * sx[k] + sLt[k * LD + i] * se[k];
+            red[sl * DP + i] = s;
+        }
+        lds_barrier();
+        if (tid < DP) {
+            double v = g.a[tid];
+#pragma unroll
+            for (int q = 0; q < NG; ++q) v += red[q * DP + tid];
+            sx[tid] = v;
+        }
+        lds_barrier();
+    };
+    for (int64_t step = 0; step < g.T; ++step) {
+        const int64_t t = fwd ? step : g.T - 1 - step;
+        if (fwd) {
+            move(t);
+            emit(t);
+        } else {
+            emit(t);
+            lds_barrier();
+            move(t);
+        }
     }
 }
 

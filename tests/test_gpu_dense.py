@@ -230,6 +230,18 @@ def test_persistent_kernel_and_kernel_chain_agree(d, p, ordering, per_step):
     (mf, Pf), (mc, Pc) = tgp._filter(fused, y), tgp._filter(chain, y)
     np.testing.assert_allclose(mf, mc, rtol=0, atol=1e-11 * max(1.0, np.abs(mc).max()))
     np.testing.assert_allclose(Pf, Pc, rtol=0, atol=1e-11 * max(1.0, np.abs(Pc).max()))
+    # prior marginals (persistent pass in its marginals mode) and rand (persistent vector recursion; shared transition only)
+    (ma, va), (mb, vb) = tgp.marginals(fused), tgp.marginals(chain)
+    np.testing.assert_allclose(ma, mb, rtol=0, atol=1e-12 * max(1.0, np.abs(mb).max()))
+    np.testing.assert_allclose(va, vb, rtol=1e-12, atol=1e-14)
+    eps = (rng.standard_normal((T, d)), rng.standard_normal((T, p)), rng.standard_normal(d))
+    if p == 1:
+        eps = (eps[0], eps[1].reshape(T), eps[2])
+    ya, yb = tgp.rand(eps, fused), tgp.rand(eps, chain)
+    np.testing.assert_allclose(ya, yb, rtol=0, atol=1e-12 * max(1.0, np.abs(yb).max()))
+    np.testing.assert_allclose(np.asarray(yb).reshape(T, p), ref.rand(model, eps[0], eps[1].reshape(T, p), eps[2]), rtol=1e-9, atol=1e-9)
+    m_ref, C_ref = ref.marginals(model)
+    np.testing.assert_allclose(np.asarray(ma).reshape(T, p), m_ref, rtol=0, atol=1e-10)
     if ordering == "F":
         Rn = rng.uniform(0.01, 0.2, size=(T, p))
         a, b = tgp.logpdf_and_posterior_marginals(fused, y, Rn), tgp.logpdf_and_posterior_marginals(chain, y, Rn)
