@@ -5,6 +5,8 @@
 #include "../../include/tgp_hip.h"
 
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <sys/stat.h>
 
 #include <algorithm>
 #include <mutex>
@@ -2058,6 +2060,73 @@ static unsigned variant_selftest(int device, int d, bool lti_layout) {
     return ok;
 }
 
+// ---- verdict cache on disk ------------------------------------------------------------------------------------------------
+// The known-answer check compares the fast / group kernels with the out-of-line build, and the out-of-line kernels of d >= 8 are
+// slow enough that the first model of such a d costs 5-17 s per process (d = 14: 17 s). Its verdict is a property of this binary
+// on this device, so it is kept in $TGP_CACHE_DIR (default ~/.cache/tgp_hip), keyed by the library file (path, size, mtime), the
+// HIP runtime version and the device name; TGP_NO_CACHE=1 disables both reading and writing. A fresh machine (every CI box) has no
+// cache and runs the check.
+static std::string verdict_cache_key(int device) {
+    Dl_info info{};
+    std::string lib = "?";
+    struct stat st{};
+    long long size = 0, mtime = 0;
+    if (dladdr(reinterpret_cast<const void*>(&verdict_cache_key), &info) != 0 && info.dli_fname != nullptr) {
+        lib = info.dli_fname;
+        if (stat(info.dli_fname, &st) == 0) { size = (long long)st.st_size; mtime = (long long)st.st_mtime; }
+    }
+    hipDeviceProp_t prop{};
+    int rt = 0;
+    (void)hipGetDeviceProperties(&prop, device);
+    (void)hipRuntimeGetVersion(&rt);
+    return lib + "|" + std::to_string(size) + "|" + std::to_string(mtime) + "|" + std::to_string(rt) + "|" + prop.name + "|" + prop.gcnArchName;
+}
+static std::string verdict_cache_path() {
+    const char* off = std::getenv("TGP_NO_CACHE");
+    if (off != nullptr && off[0] == '1') return "";
+    const char* dir = std::getenv("TGP_CACHE_DIR");
+    std::string base;
+    if (dir != nullptr && dir[0] != 0) base = dir;
+    else {
+        const char* home = std::getenv("HOME");
+        if (home == nullptr || home[0] == 0) return "";
+        base = std::string(home) + "/.cache/tgp_hip";
+    }
+    return base;
+}
+static bool verdict_cache_get(int device, int d, bool lti, unsigned& bits) {
+    const std::string dir = verdict_cache_path();
+    if (dir.empty()) return false;
+    FILE* f = std::fopen((dir + "/variant_verdicts.txt").c_str(), "r");
+    if (!f) return false;
+    const std::string key = verdict_cache_key(device);
+    char line[2048];
+    bool found = false;
+    while (std::fgets(line, sizeof line, f)) {
+        std::string l(line);
+        const size_t tab = l.rfind('\t');
+        if (tab == std::string::npos || l.compare(0, tab, key) != 0) continue;
+        int dd = 0, ll = 0;
+        unsigned b = 0;
+        if (std::sscanf(l.c_str() + tab + 1, "%d %d %u", &dd, &ll, &b) == 3 && dd == d && ll == (lti ? 1 : 0)) {
+            bits = b;
+            found = true;            // (keep reading: the last entry wins)
+        }
+    }
+    std::fclose(f);
+    return found;
+}
+static void verdict_cache_put(int device, int d, bool lti, unsigned bits) {
+    const std::string dir = verdict_cache_path();
+    if (dir.empty()) return;
+    (void)mkdir(dir.substr(0, dir.rfind('/')).c_str(), 0755);
+    (void)mkdir(dir.c_str(), 0755);
+    FILE* f = std::fopen((dir + "/variant_verdicts.txt").c_str(), "a");
+    if (!f) return;
+    std::fprintf(f, "%s\t%d %d %u\n", verdict_cache_key(device).c_str(), d, lti ? 1 : 0, bits);
+    std::fclose(f);
+}
+
 static void select_table(tgp_handle* h, int d, bool lti, int variant) {
     const KernelTable* safe = kernel_table(d);
     const KernelTable* fast = fast_kernel_table(d);
@@ -2088,7 +2157,14 @@ static void select_table(tgp_handle* h, int d, bool lti, int variant) {
     {
         std::lock_guard<std::mutex> lock(g_variant_mutex);
         unsigned& slot = g_variant[h->device % kMaxVariantDevices][d][lti ? 1 : 0];
-        if (!(slot & (1u << kOpDecided))) slot = variant_selftest(h->device, d, lti) | (1u << kOpDecided);
+        if (!(slot & (1u << kOpDecided))) {
+            unsigned bits = 0u;
+            if (!verdict_cache_get(h->device, d, lti, bits)) {
+                bits = variant_selftest(h->device, d, lti);
+                verdict_cache_put(h->device, d, lti, bits);
+            }
+            slot = bits | (1u << kOpDecided);
+        }
         g = slot;
     }
     unsigned ok = g & kAllOps;
