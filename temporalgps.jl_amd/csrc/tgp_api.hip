@@ -2161,7 +2161,7 @@ static void select_table(tgp_handle* h, int d, bool lti, int variant) {
             unsigned bits = 0u;
             if (!verdict_cache_get(h->device, d, lti, bits)) {
                 bits = variant_selftest(h->device, d, lti);
-                verdict_cache_put(h->device, d, lti, bits);
+                if (bits != 0u) verdict_cache_put(h->device, d, lti, bits);      // (an all-zero verdict may be a failed check run: never kept)
             }
             slot = bits | (1u << kOpDecided);
         }
