@@ -357,3 +357,34 @@ def test_dense_full_size_config5_against_decoupled():
     dec = space_time.DecoupledSpaceTime(k, grid, 0.1)
     lp_dec = dec.logpdf(Y.reshape(-1))
     assert abs(lp_dense - lp_dec) <= 1e-9 * abs(lp_dec), (lp_dense, lp_dec)
+
+
+def test_dense_engine_limits_and_unsupported_entry_points_fail_loudly():
+    """What the dense engine does not serve returns TGP_EUNSUPPORTED (Julia: MethodError-class), never a wrong number:
+    p > 256, the posterior of a Reverse-ordered prior, the *_at entry point, the tangent-scan gradient."""
+    import ctypes
+    import temporalgps_jl_amd as tgp
+    from temporalgps_jl_amd import _lib
+    rng = np.random.default_rng(8)
+    model, Rd = random_model(rng, 3, 20, 300, "F")
+    with pytest.raises(_lib.Unsupported):
+        to_dev(tgp, model, Rd).handle()
+    model, Rd = random_model(rng, 4, 24, 3, "R")
+    dm = to_dev(tgp, model, Rd)
+    y = rng.standard_normal((4, 3))
+    assert np.isfinite(tgp.logpdf(dm, y))
+    with pytest.raises(_lib.Unsupported):
+        tgp.posterior_marginals(dm, y, np.full((1, 3), 0.1))
+    model, Rd = random_model(rng, 4, 24, 1, "F")
+    dm = to_dev(tgp, model, Rd)
+    hd = dm.handle()
+    y1 = rng.standard_normal(4)
+    out = np.empty(4)
+    rc = hd.lib.tgp_posterior_marginals_at(hd.h, _lib.ptr(y1), None, 1, _lib.ptr(np.ones(24)), _lib.ptr(np.zeros(1)), _lib.ptr(np.ones(1)),
+                                           _lib.SHARED_R, _lib.ptr(out), _lib.ptr(out.copy()), None)
+    assert rc == _lib.EUNSUPPORTED
+    z = np.zeros(24 * 24)
+    lml, g = ctypes.c_double(), np.zeros(1)
+    rc = hd.lib.tgp_logpdf_grad(hd.h, _lib.ptr(y1), None, 0, 1, _lib.ptr(z), _lib.ptr(np.zeros(24)), _lib.ptr(z), _lib.ptr(np.zeros(24)),
+                                _lib.ptr(np.zeros(1)), _lib.ptr(np.zeros(1)), _lib.ptr(np.zeros(24)), _lib.ptr(z), ctypes.byref(lml), _lib.ptr(g))
+    assert rc == _lib.EUNSUPPORTED
