@@ -454,7 +454,7 @@ int state_size(int d) { return d + d * (d + 1) / 2; }
 int felem_size(int d) { return d * d + 2 * d + d * (d + 1); }
 int aelem_size(int d) { return d * d + d + d * (d + 1) / 2; }
 
-void choose_chunk(tgp_handle* h) {
+void choose_chunk(tgp_handle* h, int for_mode = -1) {
     int64_t L0 = h->opt_chunk;
     if (L0 <= 0) {
         // One lane per chunk, 256-lane workgroups, 256 CUs: kernel time goes with ceil(workgroups / 256), so
@@ -463,7 +463,9 @@ void choose_chunk(tgp_handle* h) {
         // d = 5: 3.02 / 3.78;  d = 6: 6.9 / 9.7;  d = 8: 150 / 180.  From d = 4 on the kernels spill: one wave per
         // SIMD keeps the scratch working set cache-resident, and the block scans see half the elements.
         const int64_t round = 256LL * 256, Tm0 = h->T * h->p;
-        const int64_t kmin = h->d <= 2 ? 2 : 1;
+        // (round 2, T = 1e7, d = 3: logpdf alone 0.270 ms at k = 1 against 0.245 ms at k = 2 -- its two passes run two workgroups per CU;
+        //  the combined call is the same either way. LTI layout only: a per-step model would be re-tiled at every change of L0.)
+        const int64_t kmin = (h->d <= 2 || (h->d == 3 && for_mode == 0 && h->lti)) ? 2 : 1;
         int64_t k = (Tm0 + round * 160 - 1) / (round * 160);
         if (k < kmin) k = kmin;
         L0 = (Tm0 + round * k - 1) / (round * k);
@@ -811,7 +813,7 @@ int forward_reduce(tgp_handle* h, uint32_t flags, int for_mode = -1) {
         return TGP_OK;
     }
     h->group_active = false;
-    choose_chunk(h);
+    choose_chunk(h, for_mode);
     TRY(ensure_tiled(h));
     TRY(scan_prepare(h, h->F, kFilter, h->n0));
     // two or more scan levels: the level-0 reduce / apply live inside the chunk kernels (256 chunks per block == the
