@@ -116,28 +116,31 @@ def general_layout_leg(tgp, torch, name, T, d, device, steps):
     gen.manual_seed(99)
     y = torch.randn((T,), dtype=torch.float64, device=f"cuda:{device}", generator=gen)
     Rnew = torch.full((1,), 1e-18, dtype=torch.float64, device=f"cuda:{device}")
+    # one combined call per step, as in the headline: the model is read by three passes (pass 1, pass 2, pass 3), not five
     for _ in range(2):
-        tgp.logpdf(model, y)
-        tgp.posterior_marginals(model, y, Rnew)
+        tgp.logpdf_and_posterior_marginals(model, y, Rnew)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        tgp.logpdf(model, y)
-        tgp.posterior_marginals(model, y, Rnew)
+        tgp.logpdf_and_posterior_marginals(model, y, Rnew)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     hd.set_option(tgp._lib.OPT_PROFILE, 1)
     hd.profile_reset()
     for _ in range(steps):
-        tgp.logpdf(model, y)
-        tgp.posterior_marginals(model, y, Rnew)
+        tgp.logpdf_and_posterior_marginals(model, y, Rnew)
     hd.set_option(tgp._lib.OPT_PROFILE, 0)
     prof = {k: v for k, v in hd.profile().items() if k.startswith(("k_reduce_filter", "k_apply_filter", "k_smooth"))}
     kname, st = max(prof.items(), key=lambda kv: kv[1]["total_ms"])
     avg_ms = st["total_ms"] / st["calls"]
     per_unit = 8 * (2 * d * d + 2 * d + 3) + (24 if ("posterior" in kname or "smooth" in kname) else 0)
     ach = per_unit * T / (avg_ms * 1e-3) / 1e9
-    return dict(bound="hbm", kernel=kname, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
+    p1 = next((v for k, v in prof.items() if k.startswith("k_reduce_filter")), None)
+    pass1 = None
+    if p1 is not None:      # the scan kernel proper (pass 1: one read of the step blocks, 8 (2 d^2 + 2 d + 3) B per step)
+        a1 = 8 * (2 * d * d + 2 * d + 3) * T / (p1["total_ms"] / p1["calls"] * 1e-3) / 1e9
+        pass1 = dict(kernel="k_reduce_filter<per-step>", achieved=a1, frac=a1 / HBM_PEAK_GBS, avg_kernel_ms=p1["total_ms"] / p1["calls"])
+    return dict(bound="hbm", kernel=kname, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, pass1=pass1,
                 traffic=pmc_traffic(kname, d, "per_step") if T == 10_000_000 else None, algorithmic_bytes=per_unit * T,
                 avg_kernel_ms=avg_ms, algorithmic_bytes_per_step=per_unit, steps_per_s=T / dt, ms_per_step=dt * 1e3,
                 kernels={k: dict(avg_ms=v["total_ms"] / max(1, v["calls"]), calls=v["calls"]) for k, v in hd.profile().items()})
