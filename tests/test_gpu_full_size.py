@@ -2,7 +2,7 @@
 enough to be run at these sizes directly, so the checks are plain parity, plus two size-independent properties of the
 chunked scan: invariance under the chunk size (the scan blocking) and under time sharding.
   cfg2: Matern-5/2 (d = 3), T = 1e7, LTI and per-step layouts   cfg3: sum kernel d = 6 (and d = 5), T = 1e7
-  cfg4: d = 4, T = 1e8 (logpdf; one GPU holds it)
+  cfg4: d = 4, T = 1e8 (logpdf and posterior marginals; one GPU holds it)
 Tolerances: lml relative 1e-10 (it is a sum of 1e7..1e8 terms of mixed sign), marginals absolute 1e-8."""
 import numpy as np
 import pytest
@@ -107,7 +107,7 @@ def test_full_size_missing_data_and_sharding_invariance(tgp):
         assert abs(out[r] - lp) <= 1e-11 * abs(lp)
 
 
-def test_cfg4_T1e8_d4_logpdf(tgp):
+def test_cfg4_T1e8_d4_logpdf_and_posterior_marginals(tgp):
     """BASELINE config 4's series on ONE GPU (it is time-sharded there): T = 1e8, d = 4."""
     import torch
     T = 100_000_000
@@ -116,5 +116,13 @@ def test_cfg4_T1e8_d4_logpdf(tgp):
     ref_model = oc.build_lgssm(SPECS["sum52_12_d4"], ("regular", 0.0, 0.1, T), 0.1)
     lp_ref = sk.logpdf(ref_model, y)
     model = _product_model("sum52_12_d4", T)
-    lp = tgp.logpdf(model, torch.as_tensor(y, device="cuda:0"))
+    yd = torch.as_tensor(y, device="cuda:0")
+    lp = tgp.logpdf(model, yd)
     assert abs(lp - lp_ref) <= 1e-10 * abs(lp_ref)
+    # ... and the posterior marginals of the same 1e8-step series (one combined call), against the sequential oracle
+    pm, pv = sk.posterior_marginals(ref_model, y, np.array([1e-18]))
+    Rn = torch.full((1,), 1e-18, dtype=torch.float64, device="cuda:0")
+    lp2, mean, var = tgp.logpdf_and_posterior_marginals(model, yd, Rn)
+    assert lp2 == lp or abs(lp2 - lp_ref) <= 1e-10 * abs(lp_ref)
+    assert float(torch.max(torch.abs(mean - torch.as_tensor(pm, device="cuda:0")))) <= 1e-8
+    assert float(torch.max(torch.abs(var - torch.as_tensor(pv, device="cuda:0")))) <= 1e-8
