@@ -14,7 +14,7 @@ module TemporalGPsHIP
 using TemporalGPs, AbstractGPs, FillArrays, StaticArrays, LinearAlgebra, Random
 import TemporalGPs: StorageType, AbstractLGSSM, LTISDE, build_lgssm, lgssm_components, get_mean, get_kernel,
     posterior, marginals_diag, replace_observation_noise_cov, _filter, x0, ordering, Forward, Reverse, Gaussian,
-    SArrayStorage
+    SArrayStorage, ArrayStorage
 
 const libtgp = get(ENV, "TGP_HIP_LIB", "libtgp_hip.so")
 
@@ -51,6 +51,7 @@ struct DeviceLGSSM{Tord} <: AbstractLGSSM
     h::Handle
     T::Int
     d::Int
+    p::Int                # observations per time step (1: scalar outputs; > 1: SmallOutputLGC / space-time models)
     bufs::NamedTuple      # A, a, Q, H, hh, R :: Vector{Float64}; keeps the host copies alive
     flags::UInt32
     x0::Gaussian
@@ -70,10 +71,24 @@ _flat(x::AbstractVector) = (reduce(vcat, (collect(Float64, vec(Array(xi))) for x
 _flat(x::Fill{<:Real}) = ([Float64(first(x))], true)
 _flat(x::AbstractVector{<:Real}) = (collect(Float64, x), false)
 
+# emission rows: the ABI wants H as [p][d] per step, row j = the j-th observation functional (row-major), i.e. the column-major
+# layout of H'. Scalar outputs carry an adjoint d-vector (p = 1); vector outputs (SmallOutputLGC, space-time models) a p x d matrix.
+_flat_rows(x::Fill) = (collect(Float64, vec(permutedims(Array(first(x))))), true)
+_flat_rows(x::AbstractVector) = (reduce(vcat, (collect(Float64, vec(permutedims(Array(xi)))) for xi in x)), false)
+# diagonal of the emission noise: a real per step (scalar outputs) or a Diagonal / vector of p variances (vector outputs)
+_diag(x::Real) = Float64[x]
+_diag(x::Diagonal) = collect(Float64, x.diag)
+_diag(x::AbstractVector{<:Real}) = collect(Float64, x)
+_flat_diag(x::Fill) = (_diag(first(x)), true)
+_flat_diag(x::AbstractVector) = (reduce(vcat, (_diag(xi) for xi in x)), false)
+
 function DeviceLGSSM(ord, As, as, Qs, Hs, hs, Σs, x0::Gaussian, device::Int)
     T, d = length(As), length(first(as))
+    p = length(first(hs))          # 1 for ScalarOutputLGC; the number of observations per time step otherwise
     (A, sA), (a, sa), (Q, sQ) = _flat(As), _flat(as), _flat(Qs)
-    (H, sH), (hh, sh), (R, sR) = _flat(Hs), _flat(hs), _flat(Σs)
+    (H, sH) = p == 1 ? _flat(Hs) : _flat_rows(Hs)
+    (hh, sh) = _flat(hs)
+    (R, sR) = p == 1 ? _flat(Σs) : _flat_diag(Σs)
     flags = UInt32(0)
     for (bit, s) in zip((SHARED_A, SHARED_a, SHARED_Q, SHARED_H, SHARED_h, SHARED_R), (sA, sa, sQ, sH, sh, sR))
         s && (flags |= bit)
@@ -84,15 +99,23 @@ function DeviceLGSSM(ord, As, as, Qs, Hs, hs, Σs, x0::Gaussian, device::Int)
         check(h, ccall((:tgp_model_set, libtgp), Cint,
             (Ptr{Cvoid}, Int64, Cint, Cint, Cint, UInt32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
              Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
-            h.ptr, T, d, 1, ord isa Forward ? 0 : 1, flags, A, a, Q, H, hh, R, x0m, x0P))
+            h.ptr, T, d, p, ord isa Forward ? 0 : 1, flags, A, a, Q, H, hh, R, x0m, x0P))
     end
-    return DeviceLGSSM(ord, h, T, d, (; A, a, Q, H, hh, R), flags, x0, device)
+    return DeviceLGSSM(ord, h, T, d, p, (; A, a, Q, H, hh, R), flags, x0, device)
 end
 
 # The one method that selects the backend: components are built by the reference's own host code
 # (SArrayStorage flavour), then packed (lti_sde.jl:71-80).
 function TemporalGPs.build_lgssm(f::LTISDE{<:GP,<:HIPStorage}, x::AbstractVector, Σys::AbstractVector)
     As, as, Qs, (Hs, hs), x0 = lgssm_components(get_mean(f), get_kernel(f), x, SArrayStorage(Float64))
+    return DeviceLGSSM(Forward(), As, as, Qs, Hs, hs, Σys, x0, f.storage.device)
+end
+
+# Space-time GPs (Separable kernels on a RectilinearGrid / RegularInTime): the reference's own dense components
+# (space_time/to_gauss_markov.jl:1-20, ArrayStorage) go to the same constructor; d = Nr * d_t > 16 binds the dense fp64-MFMA engine
+# behind the same entry points (tgp_model_set picks it by state dimension).
+function TemporalGPs.build_lgssm(f::LTISDE{<:GP,<:HIPStorage}, x::TemporalGPs.SpaceTimeGrid, Σys::AbstractVector)
+    As, as, Qs, (Hs, hs), x0 = lgssm_components(get_mean(f), get_kernel(f), x, ArrayStorage(Float64))
     return DeviceLGSSM(Forward(), As, as, Qs, Hs, hs, Σys, x0, f.storage.device)
 end
 
@@ -104,7 +127,18 @@ function _split_missing(y::AbstractVector{Union{Missing,T}}) where {T<:Real}
     return (Float64[ismissing(v) ? 0.0 : v for v in y], mask, mask)
 end
 
-function AbstractGPs.logpdf(m::DeviceLGSSM, y::AbstractVector{<:Union{Missing,Real}})
+# vector observations: y[t] is a p-vector (possibly with missing entries, missings.jl:25-40); the ABI takes [T][p] = a p x T matrix
+function _split_missing(y::AbstractVector{<:AbstractVector})
+    Y = reduce(hcat, y)
+    any(ismissing, Y) || return (collect(Float64, vec(Y)), Ptr{UInt8}(C_NULL), nothing)
+    mask = UInt8.(vec(ismissing.(Y)))
+    return (Float64[ismissing(v) ? 0.0 : v for v in vec(Y)], mask, mask)
+end
+
+# [T][p] results of the device as the reference's container: reals for scalar outputs, p-vectors otherwise
+_per_step(v::Vector{Float64}, m) = m.p == 1 ? v : [v[(t-1)*m.p+1:t*m.p] for t in 1:m.T]
+
+function AbstractGPs.logpdf(m::DeviceLGSSM, y::AbstractVector)
     length(m) == length(y) || throw(error("Dimension mismatch. length(prior) is $(length(m)), but length(y) is $(length(y))"))
     yv, mp, mask = _split_missing(y)
     out = Ref{Float64}(0.0)
@@ -148,15 +182,16 @@ TemporalGPs.x0(p::DevicePosterior) = materialise(p).x0
 TemporalGPs.replace_observation_noise_cov(p::DevicePosterior, Σs_new::AbstractVector) =
     p.model === nothing ? DevicePosterior(p.prior, p.y, Σs_new, nothing) : replace_observation_noise_cov(p.model, Σs_new)
 
-_prior_noise(m::DeviceLGSSM) = m.flags & SHARED_R != 0 ? Fill(m.bufs.R[1], m.T) : m.bufs.R
+_prior_noise(m::DeviceLGSSM) = m.p == 1 ? (m.flags & SHARED_R != 0 ? Fill(m.bufs.R[1], m.T) : m.bufs.R) :
+    (m.flags & SHARED_R != 0 ? Fill(m.bufs.R[1:m.p], m.T) : [m.bufs.R[(t-1)*m.p+1:t*m.p] for t in 1:m.T])
 
 function AbstractGPs.marginals(p::DevicePosterior)
     p.model === nothing || return marginals(p.model)
     mean, var = posterior_marginals(p.prior, p.y, p.Σs_new === nothing ? _prior_noise(p.prior) : p.Σs_new)
-    return [Gaussian(mean[t], var[t]) for t in 1:p.prior.T]
+    return _marginal_gaussians(p.prior, mean, var)
 end
 AbstractGPs.rand(rng::AbstractRNG, p::DevicePosterior) = rand(rng, materialise(p))
-AbstractGPs.logpdf(p::DevicePosterior, y::AbstractVector{<:Union{Missing,Real}}) = logpdf(materialise(p), y)
+AbstractGPs.logpdf(p::DevicePosterior, y::AbstractVector) = logpdf(materialise(p), y)
 TemporalGPs._filter(p::DevicePosterior, y::AbstractVector) = _filter(materialise(p), y)
 
 """Evaluate the reverse-time model (lgssm.jl:193-238) once, on the prior's device."""
@@ -171,11 +206,20 @@ function materialise(p::DevicePosterior)
         (Ptr{Cvoid}, Ptr{Float64}, Ptr{UInt8}, UInt32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
         m.h.ptr, yv, mp, UInt32(0), G, g, L, xfm, xfP))
     Gs, gs, Ls = [G[:, :, t] for t in 1:m.T], [g[:, t] for t in 1:m.T], [L[:, :, t] for t in 1:m.T]
-    Hs = m.flags & SHARED_H != 0 ? Fill(m.bufs.H, m.T) : [m.bufs.H[(t-1)*m.d+1:t*m.d] for t in 1:m.T]
-    hs = m.flags & SHARED_h != 0 ? Fill(m.bufs.hh[1], m.T) : m.bufs.hh
+    Hs, hs = _emission_blocks(m)
     Rs = p.Σs_new === nothing ? _prior_noise(m) : p.Σs_new
     p.model = DeviceLGSSM(Reverse(), Gs, gs, Ls, Hs, hs, Rs, Gaussian(xfm, xfP), m.device)
     return p.model
+end
+
+# the packed emission blocks back as per-step containers the constructor accepts (H rows are stored row-major: [p][d])
+function _emission_blocks(m::DeviceLGSSM)
+    d, p, T = m.d, m.p, m.T
+    Hblk(v) = p == 1 ? v[1:d] : permutedims(reshape(v[1:p*d], d, p))
+    Hs = m.flags & SHARED_H != 0 ? Fill(Hblk(m.bufs.H), T) : [Hblk(@view m.bufs.H[(t-1)*p*d+1:t*p*d]) for t in 1:T]
+    hblk(v) = p == 1 ? v[1] : v[1:p]
+    hs = m.flags & SHARED_h != 0 ? Fill(hblk(m.bufs.hh), T) : [hblk(@view m.bufs.hh[(t-1)*p+1:t*p]) for t in 1:T]
+    return Hs, hs
 end
 
 function TemporalGPs.replace_observation_noise_cov(m::DeviceLGSSM, Σs_new::AbstractVector)
@@ -187,34 +231,40 @@ function TemporalGPs.replace_observation_noise_cov(m::DeviceLGSSM, Σs_new::Abst
     end
     blk(v, n, shared) = shared ? Fill(v[1:n], T) : [v[(t-1)*n+1:t*n] for t in 1:T]
     mat(v, shared) = shared ? Fill(reshape(v[1:d*d], d, d), T) : [reshape(v[(t-1)*d*d+1:t*d*d], d, d) for t in 1:T]
+    Hs, hs = _emission_blocks(m)
     return DeviceLGSSM(m.ordering, mat(m.bufs.A, m.flags & SHARED_A != 0), blk(m.bufs.a, d, m.flags & SHARED_a != 0),
-        mat(m.bufs.Q, m.flags & SHARED_Q != 0), blk(m.bufs.H, d, m.flags & SHARED_H != 0),
-        m.flags & SHARED_h != 0 ? Fill(m.bufs.hh[1], T) : m.bufs.hh, Σs_new, m.x0, m.device)
+        mat(m.bufs.Q, m.flags & SHARED_Q != 0), Hs, hs, Σs_new, m.x0, m.device)
 end
 
+# marginals_diag semantics (lgssm.jl:128-137, linear_gaussian_conditionals.jl `posterior_and_lml` callers): mean and the DIAGONAL of
+# the covariance of every emission; p-variate steps come back as Gaussians with Diagonal covariance
+_marginal_gaussians(m, mean, var) = m.p == 1 ? [Gaussian(mean[t], var[t]) for t in 1:m.T] :
+    [Gaussian(mean[(t-1)*m.p+1:t*m.p], Diagonal(var[(t-1)*m.p+1:t*m.p])) for t in 1:m.T]
+
 function AbstractGPs.marginals(m::DeviceLGSSM)
-    mean, var = Vector{Float64}(undef, m.T), Vector{Float64}(undef, m.T)
+    mean, var = Vector{Float64}(undef, m.p * m.T), Vector{Float64}(undef, m.p * m.T)
     check(m.h, ccall((:tgp_marginals, libtgp), Cint, (Ptr{Cvoid}, UInt32, Ptr{Float64}, Ptr{Float64}),
         m.h.ptr, UInt32(0), mean, var))
-    return [Gaussian(mean[t], var[t]) for t in 1:m.T]      # marginals(::Gaussian) -> Normal(mean, sqrt(var)), gaussian.jl:61-63
+    return _marginal_gaussians(m, mean, var)      # marginals(::Gaussian) -> Normal(mean, sqrt(var)), gaussian.jl:61-63
 end
 
 function AbstractGPs.rand(rng::AbstractRNG, m::DeviceLGSSM)
     # randomness drawn in the reference's order (lgssm.jl:65-77): T transition vectors, T emission scalars, then x0
-    eps_t = randn(rng, m.d, m.T); eps_e = randn(rng, m.T); eps_0 = randn(rng, m.d)
-    y = Vector{Float64}(undef, m.T)
+    eps_t = randn(rng, m.d, m.T); eps_e = randn(rng, m.p, m.T); eps_0 = randn(rng, m.d)
+    y = Vector{Float64}(undef, m.p * m.T)
     check(m.h, ccall((:tgp_rand, libtgp), Cint,
         (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, UInt32, Ptr{Float64}),
         m.h.ptr, eps_t, eps_e, eps_0, UInt32(0), y))
-    return y
+    return _per_step(y, m)
 end
 
 """Fused `marginals(replace_observation_noise_cov(posterior(model, y), Σs_new))` (posterior_lti_sde.jl:27-36): nothing is
 materialised on the host. The reference's unchanged caller reaches it through DevicePosterior (above)."""
-function posterior_marginals(m::DeviceLGSSM{Forward}, y::AbstractVector, Σs_new::AbstractVector{<:Real})
+function posterior_marginals(m::DeviceLGSSM{Forward}, y::AbstractVector, Σs_new::AbstractVector)
     yv, mp, mask = _split_missing(y)
-    R, fl = Σs_new isa Fill ? ([Float64(first(Σs_new))], SHARED_R) : (collect(Float64, Σs_new), UInt32(0))
-    mean, var = Vector{Float64}(undef, m.T), Vector{Float64}(undef, m.T)
+    (R, shared) = m.p == 1 ? _flat(Σs_new) : _flat_diag(Σs_new)
+    fl = shared ? SHARED_R : UInt32(0)
+    mean, var = Vector{Float64}(undef, m.p * m.T), Vector{Float64}(undef, m.p * m.T)
     GC.@preserve yv mask R check(m.h, ccall((:tgp_posterior_marginals, libtgp), Cint,
         (Ptr{Cvoid}, Ptr{Float64}, Ptr{UInt8}, Ptr{Float64}, UInt32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
         m.h.ptr, yv, mp, R, fl, mean, var, C_NULL))
@@ -253,7 +303,7 @@ function DeviceLGSSM_sde(F, a, H, hh, Σs, times::AbstractVector{<:Real}, A1, Q1
              Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
             h.ptr, T, d, 0, flags, Fv, av, Hv, hv, R, tv, A1v, Q1v, x0m, x0P))
     end
-    return DeviceLGSSM(Forward(), h, T, d, (; F = Fv, a = av, H = Hv, hh = hv, R, times = tv, A1 = A1v, Q1 = Q1v), flags, x0, device)
+    return DeviceLGSSM(Forward(), h, T, d, 1, (; F = Fv, a = av, H = Hv, hh = hv, R, times = tv, A1 = A1v, Q1 = Q1v), flags, x0, device)
 end
 
 """Posterior marginals through other emissions (tgp_posterior_marginals_at): the fast path of
