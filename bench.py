@@ -510,6 +510,34 @@ def main():
         step()
     torch.cuda.synchronize()
     hd.set_option(tgp._lib.OPT_PROFILE, 0)
+    # how many of the series' steps passes 2 / 3 ran in the mean-only form (TGP_OPT_STEADY; decided at run time, bit for bit)
+    import ctypes as _ct
+    st_fast, st_total = _ct.c_int64(0), _ct.c_int64(0)
+    hd.check(hd.lib.tgp_steady_steps(hd.h, _ct.byref(st_fast), _ct.byref(st_total)))
+    no_steady = None
+    if st_fast.value > 0:
+        # the same K steps with every step run in full (TGP_OPT_STEADY = 0): identical results, bit for bit
+        hd.set_option(tgp._lib.OPT_STEADY, 0)
+        for _ in range(max(2, args.warmup)):
+            step()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt_n = time.perf_counter() - t1
+        if world > 1:
+            tn = torch.tensor([dt_n], dtype=torch.float64, device=f"cuda:{local}")
+            dist.all_reduce(tn, op=dist.ReduceOp.MAX)
+            dt_n = float(tn.item())
+        no_steady = dict(value=T / (dt_n / args.steps), ms_per_step=dt_n / args.steps * 1e3,
+                         note="TGP_OPT_STEADY = 0: every step of passes 2 / 3 in full (what a model with per-step blocks, per-step noise or "
+                              "missing data gets); same results bit for bit")
+        hd.set_option(tgp._lib.OPT_STEADY, 1)
     reuse = None
     if not args.model_reuse and args.layout != "per_step":
         # the same K steps with the per-model table of pass 1 reused across calls (what repeated calls on one bound model get)
@@ -577,6 +605,11 @@ def main():
                         parallelism=f"time-shard x{world} ({args.scaling}: {'T per GPU fixed' if args.scaling == 'weak' else 'total T fixed'})",
                         ranks=world, backend=("rccl" if world > 1 else "none"), exchange=shard.transport,
                         hip_graph_replays=int(hd.lib.tgp_graph_replays(hd.h)),
+                        stationary_covariance_steps=dict(
+                            mean_only=int(st_fast.value), total=int(st_total.value),
+                            note="passes 2 / 3, rank 0's segment: steps run in the mean-only form after the chunk's covariance was found to "
+                                 "repeat with period 2 bit for bit (TGP_OPT_STEADY; decided inside the timed call, nothing carried over "
+                                 "between calls; results identical in every bit to the full steps, see `with_full_steps`)"),
                         pass1=("shared matrix parts (TGP_OPT_SHARED_PARTS): the observation-independent half of the chunk recursion is tabulated "
                                "once per bound model -- on a side stream, launched by the second call, 1.4 ms at d = 3 -- and reused by later "
                                "calls on the same model; the warm-up steps bind and warm the model, the timed steps reuse the table"
@@ -584,6 +617,8 @@ def main():
             roofline=roof,
             kernels={k: dict(avg_ms=v["total_ms"] / max(1, v["calls"]), calls=v["calls"]) for k, v in prof.items()},
         )
+        if no_steady is not None:
+            out["with_full_steps"] = no_steady
         if reuse is not None:
             out["with_model_reuse"] = reuse
         if world > 1 and args.scaling == "strong" and not args.no_single_gpu_reference:

@@ -87,6 +87,13 @@ typedef struct tgp_handle tgp_handle;
                                    (d <= 6; bit-identical results). The table is never built on the caller's critical path: the second
                                    eligible call on a bound model launches the build on a side stream and still runs the general pass;
                                    later calls use the table once it is complete. 2 = build it in line on the first call (tests). */
+#define TGP_OPT_STEADY 12 /* scan path, passes 2 and 3, d <= 4 (1 default / 0 off): for a model with every block shared (LTI), ONE noise
+                             variance, scalar observations and no missing data the covariance half of a Kalman step is the same
+                             map at every step; in floating point a chunk's covariance lands on a fixed point or 2-cycle of it
+                             (P_t == P_{t-2} bit for bit) within ~15 steps of the chunk's start. From there on the steps keep only
+                             their mean half (gain, innovation variance, smoother gain taken from the two remembered steps) and the
+                             smoother scratch only the filtered means. Decided per wave at run time by comparing bits, so no
+                             result changes in any bit; a model that never settles simply keeps the full steps. */
 #define TGP_OPT_GRAPH 9 /* hipGraph replay of the launch chain of tgp_logpdf / tgp_[logpdf_and_]posterior_marginals: a call with device
                            pointers that repeats the previous call's arguments is recorded once (stream capture, kernel nodes only)
                            and then replayed with one hipGraphLaunch. 0 (default) off, 1 on, -1 on for T <= 2^20. Measured on
@@ -111,6 +118,9 @@ const char* tgp_version(void);
 int tgp_kernel_variant(const tgp_handle* h);
 /* number of calls served by replaying a recorded hipGraph since the handle was created (TGP_OPT_GRAPH; measurement / tests) */
 int64_t tgp_graph_replays(const tgp_handle* h);
+/* Diagnostics of TGP_OPT_STEADY: how many of the series' steps the forward pass of the last posterior-path call
+   (tgp_[logpdf_and_]posterior_marginals, tgp_smoother_forward) ran in the mean-only form, out of `total` = T * p. */
+int tgp_steady_steps(tgp_handle* h, int64_t* mean_only, int64_t* total);
 
 /* ---- model: replaces the LGSSM / GaussMarkovModel containers -----------------------------------
  * lgssm.jl:9-12, gauss_markov_model.jl:20-32 (As, as, Qs, x0) + emissions (A = H', a = h, Q = R).

@@ -20,7 +20,7 @@ IN_DEVICE = 1 << 16
 OUT_DEVICE = 1 << 17
 REUSE_REDUCE = 1 << 18
 OK, EINVAL, ENOTPD, EHIP, EUNSUPPORTED = 0, 1, 2, 3, 4
-OPT_CHUNK, OPT_PROFILE, OPT_VARIANT, OPT_FUSE_SCAN, OPT_GROUP, OPT_TIMING, OPT_SPLIT_SMOOTHER, OPT_DENSE_STRUCTURE, OPT_GRAPH, OPT_DENSE_FUSED, OPT_SHARED_PARTS = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
+OPT_CHUNK, OPT_PROFILE, OPT_VARIANT, OPT_FUSE_SCAN, OPT_GROUP, OPT_TIMING, OPT_SPLIT_SMOOTHER, OPT_DENSE_STRUCTURE, OPT_GRAPH, OPT_DENSE_FUSED, OPT_SHARED_PARTS, OPT_STEADY = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12
 
 _dp = ctypes.POINTER(ctypes.c_double)
 _u8p = ctypes.POINTER(ctypes.c_uint8)
@@ -37,6 +37,7 @@ _SIGS = {
     "tgp_version": (ctypes.c_char_p, []),
     "tgp_kernel_variant": (ctypes.c_int, [_vp]),
     "tgp_graph_replays": (_i64, [_vp]),
+    "tgp_steady_steps": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),
     "tgp_model_set": (ctypes.c_int, [_vp, _i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, _u32] + [_vp] * 8),
     "tgp_model_set_sde": (ctypes.c_int, [_vp, _i64, ctypes.c_int, ctypes.c_int, _u32] + [_vp] * 10),
     "tgp_model_set_x0": (ctypes.c_int, [_vp, _vp, _vp]),

@@ -282,6 +282,9 @@ struct tgp_handle {
     DevBuf balt;
     int opt_split = 1;           // TGP_OPT_SPLIT_SMOOTHER
     int opt_table = 1;           // TGP_OPT_SHARED_PARTS: pass 1 with the chunks' shared matrix parts from a table
+    int opt_steady = 1;          // TGP_OPT_STEADY: mean-only steps of passes 2 / 3 once a chunk's covariance repeats with period 2
+    DevBuf steady_rec;           // ... the chunks' records (ModelView::steady)
+    int steady_calls = 0;        // 1: the last posterior-path forward pass (mode 2) wrote the records
     DevBuf ftab;                 // ... the table (k_filter_table), valid for (tab_L0, tab_nlast) of the bound model
     int tab_L0 = 0, tab_nlast = 0;
     // The table costs one lane ~150 sequential steps (1.4 ms at d = 3: more than the whole call), so it is never built on the
@@ -888,6 +891,16 @@ int set_obs(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t fla
 // forward filter to the end. mode 0/1/2 as in chunk_apply_filter. Fills h->result (lml, nmiss, bad).
 int forward_apply(tgp_handle* h, int mode, const FilterOut& fo, const double* x0dev = nullptr) {
     scan_down(h, h->F, x0dev ? x0dev : h->bx0.d(), h->fused ? 1 : 0);
+    // stationary-covariance steps (tgp_chunk_body.inc): lane-per-chunk passes of a shared-layout model, one shared R, scalar
+    // observations, no missing data
+    h->mv.steady = nullptr;
+    if (mode == 2) h->steady_calls = 0;
+    if (h->opt_steady && !h->group_active && h->lti && h->d <= kSteadyMaxD && h->p == 1 && h->mv.sR == 0 && h->mv.missing == nullptr &&
+        (mode == 0 || mode == 1 || mode == 2)) {
+        HIPCHK(h->steady_rec.ensure((size_t)(1 + h->d * (h->d + 1)) * (size_t)h->n0 * sizeof(double)));
+        h->mv.steady = h->steady_rec.d();
+        if (mode == 2) h->steady_calls = 1;
+    }
     if (h->group_active) {
         const int64_t cpb = h->kt->group_chunks_per_block;
         const int64_t nb = (h->n0 + cpb - 1) / cpb;
@@ -932,6 +945,17 @@ int forward_apply(tgp_handle* h, int mode, const FilterOut& fo, const double* x0
     {
         LaunchScope ls(h, "k_finalize");
         hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, h->stream, h->partial.d(), nblocks, h->result.d());
+    }
+    if (mode == 2 && h->mv.steady != nullptr && getenv("TGP_STEADY_DEBUG") != nullptr) {
+        // debug aid: where in their chunks the waves switched to the mean-only steps (histogram over the chunks, by 8 steps)
+        std::vector<double> ks((size_t)h->n0);
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipMemcpy(ks.data(), h->mv.steady, ks.size() * sizeof(double), hipMemcpyDeviceToHost));
+        std::vector<int64_t> hist((size_t)h->L0 / 8 + 2, 0);
+        for (double k : ks) ++hist[(size_t)std::min<double>(k, (double)h->L0) / 8];
+        fprintf(stderr, "[tgp steady] L0 = %d, n0 = %lld; first mean-only step of the chunks (bins of 8; last bin = never):", h->L0, (long long)h->n0);
+        for (size_t i = 0; i < hist.size(); ++i) if (hist[i]) fprintf(stderr, " [%zu..]:%lld", i * 8, (long long)hist[i]);
+        fprintf(stderr, "\n");
     }
     return TGP_OK;
 }
@@ -1051,6 +1075,11 @@ int tgp_set_option(tgp_handle* h, int option, int64_t value) {
         h->smoother_valid = false;
         return TGP_OK;
     }
+    if (option == TGP_OPT_STEADY) {
+        h->opt_steady = value != 0;
+        h->smoother_valid = false;
+        return TGP_OK;
+    }
     if (option == TGP_OPT_DENSE_FUSED) {
         h->dense_fused = value != 0;       // takes effect at the next tgp_model_set
         return TGP_OK;
@@ -1087,6 +1116,23 @@ int tgp_kernel_variant(const tgp_handle* h) {
 }
 
 int64_t tgp_graph_replays(const tgp_handle* h) { return h ? h->graph_replays : 0; }
+
+int tgp_steady_steps(tgp_handle* h, int64_t* mean_only, int64_t* total) {
+    if (!h || !mean_only || !total) return TGP_EINVAL;
+    *mean_only = 0;
+    *total = h->T * h->p;
+    if (h->steady_calls == 0 || h->mv.steady == nullptr) return TGP_OK;     // the last forward pass of a posterior path ran full steps only
+    HIPCHK(hipSetDevice(h->device));
+    std::vector<double> ks((size_t)h->n0);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(ks.data(), h->mv.steady, ks.size() * sizeof(double), hipMemcpyDeviceToHost));
+    const int64_t Tm = h->T * h->p;
+    for (int64_t c = 0; c < h->n0; ++c) {
+        const int64_t len = std::min<int64_t>(h->L0, Tm - c * (int64_t)h->L0), k = (int64_t)ks[(size_t)c];
+        if (k < len) *mean_only += len - k;
+    }
+    return TGP_OK;
+}
 
 int tgp_set_stream(tgp_handle* h, void* hip_stream) {
     if (!h) return TGP_EINVAL;

@@ -49,7 +49,35 @@ struct ModelView {
     const double *dA, *da, *dQ, *dH, *dh, *dR;
     // Tangent of the tiled transition record (general layout, gradient pass): same layout as tile_t; null => zero.
     const double* tile_t_tan;
+    // Stationary-covariance record of the posterior path (see "stationary covariance" in tgp_chunk_body.inc), [1 + 2 DS][n0]:
+    // row 0 = first step of the chunk that pass 2 ran in the mean-only form (as a double; >= L0: none), rows 1.. = the packed
+    // upper triangles of the two filtering covariances the chunk alternates between from there on. Non-null enables the
+    // mean-only steps of passes 2 and 3 (the API sets it for shared-layout models with one shared R, p = 1, no missing data, d <= 4).
+    double* steady;
 };
+
+// Wave-level helpers of the stationary-covariance steps: a vote over the ACTIVE lanes of the wave, and a wave-uniform integer
+// the compiler may keep in an SGPR. The host emulation runs one chunk at a time.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TGP_WAVE_ALL(pred) (__builtin_amdgcn_ballot_w64(!(pred)) == 0ull)
+#define TGP_WAVE_UNIFORM_INT(x) __builtin_amdgcn_readfirstlane(x)
+#else
+#define TGP_WAVE_ALL(pred) (pred)
+#define TGP_WAVE_UNIFORM_INT(x) (x)
+#endif
+TGP_HD bool same_bits(double a, double b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __double_as_longlong(a) == __double_as_longlong(b);
+#else
+    int64_t x, y;
+    __builtin_memcpy(&x, &a, 8);
+    __builtin_memcpy(&y, &b, 8);
+    return x == y;
+#endif
+}
+TGP_HD bool same_bits(const Dual&, const Dual&) { return false; }
+template <class T> struct steady_capable { static constexpr bool value = false; };
+template <> struct steady_capable<double> { static constexpr bool value = true; };
 
 TGP_HD void set_real(double& x, const double* v, const double*, int i) { x = v[i]; }
 TGP_HD void set_real(Dual& x, const double* v, const double* d, int i) { x = Dual(v[i], d ? d[i] : 0.0); }
@@ -134,6 +162,9 @@ TGP_HD uint32_t tile_mask_of(const ModelView& raw) {
 // (host emulation, and the reference semantics the staged form must reproduce). `tm` = micro storage index.
 // Largest state dimension that gets the register-resident software prefetch (IO groups, smoother scratch, hoisted shared R).
 constexpr int kPrefetchMaxD = 4;
+// Largest state dimension with the stationary-covariance steps (tgp_chunk_body.inc): the two remembered steps cost 2 x (2 d^2 + d + 2)
+// registers in pass 2; at d = 4 that build sits at the 512-register budget with spills.
+constexpr int kSteadyMaxD = 3;
 
 struct DirectIO {
     static constexpr int G = 8;

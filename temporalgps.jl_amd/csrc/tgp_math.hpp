@@ -23,8 +23,10 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define TGP_HD __host__ __device__ __forceinline__
+#define TGP_LAMBDA_INLINE __attribute__((always_inline))
 #else
 #define TGP_HD inline
+#define TGP_LAMBDA_INLINE
 #endif
 
 // d <= 8: fully unrolled (matrices in registers). The d = 9..16 translation units are compiled with TGP_NO_UNROLL: their

@@ -75,7 +75,7 @@ def hostsim():
     if _HOSTSIM is None:
         src = os.path.join(HERE, "hostsim", "hostsim.cpp")
         so = os.path.join(HERE, "hostsim", "libhostsim.so")
-        deps = [src] + [os.path.join(ROOT, "temporalgps.jl_amd", "csrc", f) for f in ("tgp_math.hpp", "tgp_chunk.hpp")]
+        deps = [src] + [os.path.join(ROOT, "temporalgps.jl_amd", "csrc", f) for f in ("tgp_math.hpp", "tgp_chunk.hpp", "tgp_math_body.inc", "tgp_chunk_body.inc")]
         if not os.path.exists(so) or any(os.path.getmtime(p) > os.path.getmtime(so) for p in deps):
             subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-o", so, src])
         _HOSTSIM = ctypes.CDLL(so)

@@ -8,6 +8,9 @@
 #include <cstdint>
 #include <cstring>
 #include <vector>
+#include <cstdio>
+#include <algorithm>
+#include <cstdlib>
 
 #include "../../temporalgps.jl_amd/csrc/tgp_chunk.hpp"
 
@@ -127,6 +130,13 @@ template <int D, bool LTI> int run(const Args& a) {
     ModelView mv = a.mv;
     int64_t n0 = (mv.T + a.L0 - 1) / a.L0;
     std::vector<double> tile_t, tile_e;
+    // HOSTSIM_STEADY=1: the stationary-covariance steps of passes 2 / 3 (tgp_chunk_body.inc), as tgp_api.hip enables them
+    std::vector<double> steady_rec;
+    const char* steady_env = getenv("HOSTSIM_STEADY");
+    if (steady_env != nullptr && LTI && D <= kSteadyMaxD && mv.p == 1 && mv.sR == 0 && mv.missing == nullptr) {
+        steady_rec.assign((size_t)(1 + D * (D + 1)) * (size_t)n0, 0.0);
+        mv.steady = steady_rec.data();
+    }
     if (!LTI) {   // general layout: time-tiled copies of the per-step arrays, as tgp_api.hip builds on the device
         mv.tile_mask = tile_mask_of(mv);
         mv.nc_t = tile_offset_t(mv.tile_mask, 0u, D);
@@ -219,6 +229,14 @@ template <int D, bool LTI> int run(const Args& a) {
                 bad_s[c] = chunk_smooth<D, LTI>(mv, c, a.L0, xs, S0[c], fs.data(), a.sRn, io);
             }
             for (int64_t c = 0; c < n0; ++c) bad |= bad_s[c];
+            if (mv.steady != nullptr && steady_env[0] == '2') {   // how many steps of the series pass 2 ran in the mean-only form
+                int64_t fast = 0;
+                for (int64_t c = 0; c < n0; ++c) {
+                    const int64_t len = std::min<int64_t>(a.L0, mv.T - c * (int64_t)a.L0), k = (int64_t)mv.steady[c];
+                    if (k < len) fast += len - k;
+                }
+                fprintf(stderr, "hostsim steady: %lld of %lld steps mean-only\n", (long long)fast, (long long)mv.T);
+            }
         }
     } else {
         SoA E0;

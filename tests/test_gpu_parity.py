@@ -496,3 +496,68 @@ def test_shared_parts_table_is_built_off_the_critical_path(tgp):
     assert "k_reduce_filter<lti>" in seen[0] and "k_reduce_filter<lti>" in seen[1]
     assert "k_reduce_filter<lti,shared parts>" in seen[-1]
     assert all(v == vals[0] for v in vals)
+
+
+@pytest.mark.parametrize("spec,dt", [(("matern12",), 0.1), (("matern32",), 0.1), (("matern52",), 0.1), (("matern52",), 0.02)])
+@pytest.mark.parametrize("chunk", [8, 40, 153])
+def test_stationary_covariance_steps_change_no_bit(tgp, spec, dt, chunk):
+    """TGP_OPT_STEADY (default on): once a chunk's covariance repeats with period 2 bit for bit, passes 2 and 3 keep only the
+    mean half of their steps. Same bits with the option on and off -- logpdf, filtering distributions, posterior marginals with a
+    shared and a per-step new noise -- and the mean-only form is really taken (tgp_steady_steps)."""
+    import ctypes
+    T = 60000
+    model, y, _ = U.gp_case(spec, ("regular", 0.0, dt, T), 0.1, seed=31)
+    res = {}
+    for on in (0, 1):
+        dm = to_device_model(tgp, model)
+        hd = dm.handle()
+        hd.set_option(tgp._lib.OPT_STEADY, on)
+        if chunk is not None:
+            hd.set_option(tgp._lib.OPT_CHUNK, chunk)
+        lp = tgp.logpdf(dm, y)
+        m, P = tgp._filter(dm, y)
+        lp2, mean, var = tgp.logpdf_and_posterior_marginals(dm, y, np.array([1e-18]))
+        fast, total = ctypes.c_int64(0), ctypes.c_int64(0)
+        hd.check(hd.lib.tgp_steady_steps(hd.h, ctypes.byref(fast), ctypes.byref(total)))
+        Rn = np.random.default_rng(5).random(T) + 0.05
+        mean2, var2 = tgp.posterior_marginals(dm, y, Rn)
+        res[on] = (lp, m, P, lp2, mean, var, mean2, var2, fast.value, total.value)
+    a, b = res[0], res[1]
+    assert a[0] == b[0] and a[3] == b[3]
+    for i in (1, 2, 4, 5, 6, 7):
+        assert np.array_equal(a[i], b[i]), i
+    assert a[8] == 0 and b[9] == T
+    if chunk == 153 or (chunk == 40 and dt == 0.1):
+        # every chunk but the ones inside the filter's initial transient settles within ~15 steps at dt = 0.1, ~30 at dt = 0.02
+        assert b[8] > 0.5 * T, (b[8], T)
+    lp_ref = sk.logpdf(model, y)
+    assert abs(b[0] - lp_ref) <= 1e-10 * abs(lp_ref)
+    mean_ref, var_ref = sk.posterior_marginals(model, y, np.array([1e-18]))
+    np.testing.assert_allclose(b[4], mean_ref, rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(b[5], var_ref, rtol=1e-8, atol=1e-9)
+
+
+def test_stationary_covariance_steps_are_left_alone_where_they_do_not_apply(tgp):
+    """Missing data, per-step noise and per-step models change the map from step to step: tgp_steady_steps reports 0 of T."""
+    import ctypes
+    T = 20000
+    model, y, _ = U.gp_case(("matern52",), ("regular", 0.0, 0.1, T), 0.1, seed=32)
+    ym = y.copy()
+    ym[[7, 5000, 5001, 19999]] = np.nan
+    dm = to_device_model(tgp, model)
+    hd = dm.handle()
+    hd.set_option(tgp._lib.OPT_CHUNK, 64)
+    tgp.posterior_marginals(dm, ym, np.array([0.1]))
+    fast, total = ctypes.c_int64(-1), ctypes.c_int64(-1)
+    hd.check(hd.lib.tgp_steady_steps(hd.h, ctypes.byref(fast), ctypes.byref(total)))
+    assert fast.value == 0 and total.value == T
+    tgp.posterior_marginals(dm, y, np.array([0.1]))
+    hd.check(hd.lib.tgp_steady_steps(hd.h, ctypes.byref(fast), ctypes.byref(total)))
+    assert fast.value > 0.5 * T
+    noisy = dict(model, R=np.full(T, 0.1))      # the same noise, but per step: general handling
+    dn = to_device_model(tgp, noisy)
+    dn.handle().set_option(tgp._lib.OPT_CHUNK, 64)
+    tgp.posterior_marginals(dn, y, np.array([0.1]))
+    hd2 = dn.handle()
+    hd2.check(hd2.lib.tgp_steady_steps(hd2.h, ctypes.byref(fast), ctypes.byref(total)))
+    assert fast.value == 0
