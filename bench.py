@@ -211,7 +211,7 @@ def pmc_traffic(kname, d, layout):
     """HBM bytes per launch of `kname` from the committed PMC summary (profiles/r01_pmc_traffic.json: separate
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command, FETCH doubled per
     MI355X_MICROARCH.md). None when the summary has no entry (other d / workload)."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r02s_pmc_traffic.json")      # (r01_pmc_traffic.json: the kernels before the stationary-covariance steps)
     if not os.path.exists(path):
         return None
     table = json.load(open(path)).get(layout, {})
@@ -226,7 +226,9 @@ def pmc_traffic(kname, d, layout):
         key = f"{base}<{d}, {lti}, {mode.get(kname.split(',')[1].rstrip('>'), -1)}>"
     else:
         return None
-    ent = table.get(key)
+    # kernels that exist in two builds carry one more template argument (plain / with the stationary-covariance steps): the bench
+    # workload runs the latter
+    ent = table.get(key[:-1] + ", true>") or table.get(key)
     return None if ent is None else ent["hbm_bytes"]
 
 
@@ -235,7 +237,9 @@ def valu_utilisation(prof, d, layout):
     as profiles/r01_sq_counters_<layout>.json, T = 1e7) over the launch duration measured HERE, against the issue peak
     256 CUs x 4 SIMDs x one wave64 fp64 instruction per 4 cycles at 2.4 GHz (= the 78.6 TFLOP/s datasheet figure counted
     in instructions). The LTI kernels are bound by this, not by HBM."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r01_sq_counters_{layout}.json")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r02s_sq_counters_{layout}.json")
+    if not os.path.exists(path):
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r01_sq_counters_{layout}.json")
     if not os.path.exists(path):
         return None
     table = json.load(open(path))
@@ -247,6 +251,8 @@ def valu_utilisation(prof, d, layout):
              f"k_smooth<{'lti' if layout == 'lti' else 'per-step'}>": f"k_smooth<{d}, {lti}, false>"}
     out = {}
     for pk, ck in names.items():
+        if ck[:-1] + ", true>" in table and layout == "lti":       # the build with the stationary-covariance steps (what the bench workload runs)
+            ck = ck[:-1] + ", true>"
         if pk in prof and ck in table and "SQ_INSTS_VALU" in table[ck]:
             dur = prof[pk]["total_ms"] / max(1, prof[pk]["calls"]) * 1e-3
             n = table[ck]["SQ_INSTS_VALU"]

@@ -109,7 +109,8 @@ static void select_table(tgp_handle* h, int d, bool lti, int variant);
 
 // result[0] = sum lml + nmiss * log(2 pi 1e15)/2 (missings.jl:45-53); result[1] = nmiss; result[2] = bad.
 // Fixed-order summation: the result is bit-reproducible from run to run.
-__global__ __launch_bounds__(256) void k_finalize(const double* __restrict__ partial, int64_t nblocks, double* __restrict__ result) {
+__global__ __launch_bounds__(256) void k_finalize(const double* __restrict__ partial, int64_t nblocks, double* __restrict__ result,
+                                                  const double* __restrict__ steady_rec = nullptr) {
     __shared__ double sh[12];
     double a = 0.0, b = 0.0;
     int c = 0;
@@ -123,6 +124,7 @@ __global__ __launch_bounds__(256) void k_finalize(const double* __restrict__ par
         result[0] = a + b * 0.5 * (kLog2Pi + log(kLargeVar));
         result[1] = b;
         result[2] = (double)c;
+        if (steady_rec != nullptr) result[5] = steady_rec[0];     // first mean-only step of chunk 0 (TGP_OPT_STEADY policy, finish_wait)
     }
 }
 
@@ -285,6 +287,13 @@ struct tgp_handle {
     int opt_steady = 1;          // TGP_OPT_STEADY: mean-only steps of passes 2 / 3 once a chunk's covariance repeats with period 2
     DevBuf steady_rec;           // ... the chunks' records (ModelView::steady)
     int steady_calls = 0;        // 1: the last posterior-path forward pass (mode 2) wrote the records
+    // Policy of the posterior path: the build with these steps has slightly longer full steps, and a pass takes as long as its slowest
+    // wave -- the one holding chunk 0, which starts from x0 and settles last. The first call on a bound model / chunk length returns
+    // that chunk's first mean-only step with its results (k_finalize -> result[5]); if it lies beyond half of the chunk (a filter
+    // that takes hundreds of steps to converge), later calls run the plain build. A choice of kernel, not of results: both are
+    // bit-identical.
+    bool steady_known = false, steady_pays = true, steady_result_pending = false;
+    int steady_known_L0 = 0;
     DevBuf ftab;                 // ... the table (k_filter_table), valid for (tab_L0, tab_nlast) of the bound model
     int tab_L0 = 0, tab_nlast = 0;
     // The table costs one lane ~150 sequential steps (1.4 ms at d = 3: more than the whole call), so it is never built on the
@@ -639,6 +648,11 @@ struct CallTimer {
             h->d2h_ms = c;
         }
         resolve_profile(h);
+        if (h->steady_result_pending) {
+            h->steady_result_pending = false;
+            h->steady_known = true;
+            h->steady_pays = h->host_result[5] < 0.5 * (double)h->L0;
+        }
         if (lml_out) *lml_out = h->host_result[0];
         int flags = 0;
         std::memcpy(&flags, &h->host_result[4], sizeof flags);
@@ -895,7 +909,11 @@ int forward_apply(tgp_handle* h, int mode, const FilterOut& fo, const double* x0
     // observations, no missing data
     h->mv.steady = nullptr;
     if (mode == 2) h->steady_calls = 0;
-    if (h->opt_steady && !h->group_active && h->lti && h->d <= kSteadyMaxD && h->p == 1 && h->mv.sR == 0 && h->mv.missing == nullptr &&
+    if (h->steady_known_L0 != h->L0) {
+        h->steady_known = false;
+        h->steady_known_L0 = h->L0;
+    }
+    if (h->opt_steady && !(mode == 2 && h->steady_known && !h->steady_pays) && !h->group_active && h->lti && h->d <= kSteadyMaxD && h->p == 1 && h->mv.sR == 0 && h->mv.missing == nullptr &&
         (mode == 0 || mode == 1 || mode == 2)) {
         HIPCHK(h->steady_rec.ensure((size_t)(1 + h->d * (h->d + 1)) * (size_t)h->n0 * sizeof(double)));
         h->mv.steady = h->steady_rec.d();
@@ -921,7 +939,7 @@ int forward_apply(tgp_handle* h, int mode, const FilterOut& fo, const double* x0
         }
         {
             LaunchScope ls(h, "k_finalize");
-            hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, h->stream, h->partial.d(), nb, h->result.d());
+            hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, h->stream, h->partial.d(), nb, h->result.d(), (const double*)nullptr);
         }
         return TGP_OK;
     }
@@ -944,7 +962,9 @@ int forward_apply(tgp_handle* h, int mode, const FilterOut& fo, const double* x0
     }
     {
         LaunchScope ls(h, "k_finalize");
-        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, h->stream, h->partial.d(), nblocks, h->result.d());
+        const double* rec = (mode == 2 && h->mv.steady != nullptr && !h->steady_known) ? h->mv.steady : nullptr;
+        if (rec != nullptr) h->steady_result_pending = true;
+        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, h->stream, h->partial.d(), nblocks, h->result.d(), rec);
     }
     if (mode == 2 && h->mv.steady != nullptr && getenv("TGP_STEADY_DEBUG") != nullptr) {
         // debug aid: where in their chunks the waves switched to the mean-only steps (histogram over the chunks, by 8 steps)
@@ -1077,6 +1097,7 @@ int tgp_set_option(tgp_handle* h, int option, int64_t value) {
     }
     if (option == TGP_OPT_STEADY) {
         h->opt_steady = value != 0;
+        h->steady_known = false;
         h->smoother_valid = false;
         return TGP_OK;
     }
@@ -1148,6 +1169,7 @@ int tgp_model_set(tgp_handle* h, int64_t T, int d, int p, int ordering, uint32_t
     if (!h) return TGP_EINVAL;
     TRY(bind_device(h));
     h->have_model = false;
+    h->steady_known = false;
     h->fold_valid = false;
     h->reduce_valid = false;
     h->smoother_valid = false;
@@ -1302,6 +1324,7 @@ int tgp_model_set_x0(tgp_handle* h, const double* x0m, const double* x0P) {
     if (!x0m || !x0P) return h->fail(TGP_EINVAL, "null x0");
     h->x0m.assign(x0m, x0m + h->d);
     h->x0P.assign(x0P, x0P + (size_t)h->d * h->d);
+    h->steady_known = false;
     if (h->is_dense) return dense_fail(h, tgp_dense::set_x0(h->dense, x0m, x0P, h->stream));
     h->fold_valid = false;
     h->smoother_valid = false;

@@ -560,7 +560,7 @@ __device__ __forceinline__ void block_sum3(double& a, double& b, int& c, double*
 }
 
 // ---------------------------------------------------------------- pass 2
-template <int D, bool LTI, int MODE>
+template <int D, bool LTI, int MODE, bool ST = false>
 __global__ __launch_bounds__(256) void k_apply_filter(ModelView mv, int L0, int64_t n0, double* __restrict__ S0, const double* __restrict__ E0,
                                                       const double* __restrict__ S1, int64_t n1, FilterOut out, double* __restrict__ R0,
                                                       double* __restrict__ partial) {
@@ -587,7 +587,7 @@ __global__ __launch_bounds__(256) void k_apply_filter(ModelView mv, int L0, int6
         set_zero<D>(x.m);
         set_identity<D>(x.P);
     }
-    ChunkStats cs = chunk_apply_filter<D, LTI, MODE>(mv, c, L0, x, out, io, [=](int k, double v) { R0[(int64_t)k * n0 + (n0 - 1 - c)] = v; });
+    ChunkStats cs = chunk_apply_filter<D, LTI, MODE, ST>(mv, c, L0, x, out, io, [=](int k, double v) { R0[(int64_t)k * n0 + (n0 - 1 - c)] = v; });
     double lml = cs.lml, nmiss = cs.nmiss;
     int bad = cs.bad;
     block_sum3(lml, nmiss, bad, sh);
@@ -652,7 +652,7 @@ __global__ __launch_bounds__(256) void k_apply_filter_ad(ModelView mv, int L0, i
 // ---------------------------------------------------------------- pass 3
 // RSTREAM: R_new is per-step and staged through the IO (one more LDS slot: 55 KB per block => 2 blocks per CU);
 // a shared R_new (the common case) needs only the two output slots (37 KB => 4 blocks per CU).
-template <int D, bool LTI, bool RSTREAM>
+template <int D, bool LTI, bool RSTREAM, bool ST = false>
 __global__ __launch_bounds__(256) void k_smooth(ModelView mv, int L0, int64_t n0, const double* __restrict__ S0, const double* __restrict__ S0r,
                                                 const double* __restrict__ fs, const double* __restrict__ Rnew, int64_t sRn,
                                                 double* __restrict__ mean_out, double* __restrict__ var_out, int* __restrict__ bad) {
@@ -670,7 +670,7 @@ __global__ __launch_bounds__(256) void k_smooth(ModelView mv, int L0, int64_t n0
         set_identity<D>(xs.P);
         carry = xs;
     }
-    int rc = chunk_smooth<D, LTI>(mv, c, L0, xs, carry, fs, sRn, io);
+    int rc = chunk_smooth<D, LTI, ST>(mv, c, L0, xs, carry, fs, sRn, io);
     if (rc && c < n0) atomicOr(bad, 1);
 }
 

@@ -132,6 +132,7 @@ template <int D, bool LTI> int run(const Args& a) {
     std::vector<double> tile_t, tile_e;
     // HOSTSIM_STEADY=1: the stationary-covariance steps of passes 2 / 3 (tgp_chunk_body.inc), as tgp_api.hip enables them
     std::vector<double> steady_rec;
+    constexpr bool HS = LTI && D <= kSteadyMaxD;     // the build of passes 2 / 3 with the stationary-covariance steps exists
     const char* steady_env = getenv("HOSTSIM_STEADY");
     if (steady_env != nullptr && LTI && D <= kSteadyMaxD && mv.p == 1 && mv.sR == 0 && mv.missing == nullptr) {
         steady_rec.assign((size_t)(1 + D * (D + 1)) * (size_t)n0, 0.0);
@@ -188,8 +189,8 @@ template <int D, bool LTI> int run(const Args& a) {
             ChunkStats cs;
             auto nost = [](int, double) {};
             DirectIO io{mv.y, mv.R, nullptr, nullptr};
-            if (a.what == 0) cs = chunk_apply_filter<D, LTI, 0>(mv, c, a.L0, x, fo, io, nost);
-            else if (a.what == 1) cs = chunk_apply_filter<D, LTI, 1>(mv, c, a.L0, x, fo, io, nost);
+            if (a.what == 0) cs = mv.steady ? chunk_apply_filter<D, LTI, 0, HS>(mv, c, a.L0, x, fo, io, nost) : chunk_apply_filter<D, LTI, 0>(mv, c, a.L0, x, fo, io, nost);
+            else if (a.what == 1) cs = mv.steady ? chunk_apply_filter<D, LTI, 1, HS>(mv, c, a.L0, x, fo, io, nost) : chunk_apply_filter<D, LTI, 1>(mv, c, a.L0, x, fo, io, nost);
             else {
                 if (a.G_out) {   // materialised posterior model (MODE 3) ...
                     State<D> x3 = x;
@@ -198,7 +199,8 @@ template <int D, bool LTI> int run(const Args& a) {
                     bad_c[c] |= c3.bad;
                 }
                 FilterOut f2{nullptr, nullptr, fo.fs, nullptr, nullptr, nullptr};   // ... and the smoother forward pass (MODE 2)
-                cs = chunk_apply_filter<D, LTI, 2>(mv, c, a.L0, x, f2, io, [&](int k, double v) { R0.v[(size_t)k * n0 + (n0 - 1 - c)] = v; });
+                auto rst = [&](int k, double v) { R0.v[(size_t)k * n0 + (n0 - 1 - c)] = v; };
+                cs = mv.steady ? chunk_apply_filter<D, LTI, 2, HS>(mv, c, a.L0, x, f2, io, rst) : chunk_apply_filter<D, LTI, 2>(mv, c, a.L0, x, f2, io, rst);
             }
             lml_c[c] = cs.lml;
             nmiss_c[c] = cs.nmiss;
@@ -226,7 +228,8 @@ template <int D, bool LTI> int run(const Args& a) {
             for (int64_t c = 0; c < n0; ++c) {
                 State<D> xs = S0r[n0 - 1 - c];
                 DirectIO io{nullptr, a.Rnew, a.mean_out, a.var_out};
-                bad_s[c] = chunk_smooth<D, LTI>(mv, c, a.L0, xs, S0[c], fs.data(), a.sRn, io);
+                bad_s[c] = mv.steady ? chunk_smooth<D, LTI, HS>(mv, c, a.L0, xs, S0[c], fs.data(), a.sRn, io)
+                                     : chunk_smooth<D, LTI>(mv, c, a.L0, xs, S0[c], fs.data(), a.sRn, io);
             }
             for (int64_t c = 0; c < n0; ++c) bad |= bad_s[c];
             if (mv.steady != nullptr && steady_env[0] == '2') {   // how many steps of the series pass 2 ran in the mean-only form

@@ -561,3 +561,32 @@ def test_stationary_covariance_steps_are_left_alone_where_they_do_not_apply(tgp)
     hd2 = dn.handle()
     hd2.check(hd2.lib.tgp_steady_steps(hd2.h, ctypes.byref(fast), ctypes.byref(total)))
     assert fast.value == 0
+
+
+def test_stationary_covariance_build_is_dropped_where_chunk_0_settles_late(tgp):
+    """Kernel choice of the posterior path (tgp_api.hip, `steady_pays`): a pass takes as long as its slowest wave -- the one that holds
+    chunk 0, which starts from x0 and settles last. The first call on a bound model reports where chunk 0 switched; if that is
+    beyond half of the chunk (a filter that needs hundreds of steps to converge: dt = 0.002 here) later calls run the plain build.
+    Same bits either way; a quickly converging model (dt = 0.1) keeps the mean-only steps."""
+    import ctypes
+    T = 40000
+    for dt, keeps in ((0.002, False), (0.1, True)):
+        model, y, _ = U.gp_case(("matern52",), ("regular", 0.0, dt, T), 0.1, seed=33)
+        dm = to_device_model(tgp, model)
+        hd = dm.handle()
+        hd.set_option(tgp._lib.OPT_CHUNK, 153)
+        outs, fast = [], []
+        for _ in range(3):
+            outs.append(tgp.logpdf_and_posterior_marginals(dm, y, np.array([1e-18])))
+            f, t = ctypes.c_int64(0), ctypes.c_int64(0)
+            hd.check(hd.lib.tgp_steady_steps(hd.h, ctypes.byref(f), ctypes.byref(t)))
+            fast.append(f.value)
+        assert fast[0] > 0                                    # the first call always tries
+        assert (fast[1] > 0) == keeps and (fast[2] > 0) == keeps, (dt, fast)
+        for o in outs[1:]:
+            assert o[0] == outs[0][0] and np.array_equal(o[1], outs[0][1]) and np.array_equal(o[2], outs[0][2])
+        hd.set_option(tgp._lib.OPT_CHUNK, 100)                # another chunk length: decided afresh
+        tgp.logpdf_and_posterior_marginals(dm, y, np.array([1e-18]))
+        f, t = ctypes.c_int64(0), ctypes.c_int64(0)
+        hd.check(hd.lib.tgp_steady_steps(hd.h, ctypes.byref(f), ctypes.byref(t)))
+        assert f.value > 0
