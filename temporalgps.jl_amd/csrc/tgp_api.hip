@@ -620,6 +620,7 @@ struct CallTimer {
     // The four hipEvents of a call (h2d / kernels / d2h split of tgp_last_timing) are recorded only with TGP_OPT_TIMING:
     // records and elapsed-time queries cost the host ~30 us per call, a few percent of a 0.4 ms logpdf.
     explicit CallTimer(tgp_handle* h_, bool clear = true) : h(h_) {
+        h->steady_result_pending = false;      // (left set by a device-resident shard call that never reads its result record back)
         if (h->timing) (void)hipEventRecord(h->ev[0], h->stream);
         // lml / flags of this call (a kernel, not a memset node: the chain is also recorded into hipGraphs, kernel nodes only)
         if (clear) hipLaunchKernelGGL(k_zero8, dim3(1), dim3(64), 0, h->stream, h->result.d());
