@@ -32,6 +32,7 @@
 // d <= 8: fully unrolled (matrices in registers). The d = 9..16 translation units are compiled with TGP_NO_UNROLL: their
 // matrices live in private memory anyway (out-of-line building blocks), and rolled loops keep code size and compile
 // time sane.
+#define TGP_NOUNROLL_LOOP _Pragma("nounroll")
 #if defined(TGP_NO_UNROLL)
 #define TGP_UNROLL _Pragma("nounroll")
 #else
