@@ -597,8 +597,9 @@ def main():
             roof = dict(bound="hbm", kernel=kname, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
                         traffic=traffic, traffic_unit="bytes per launch (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, profiles/)",
                         algorithmic_bytes=per_unit * Tseg, avg_kernel_ms=avg_ms, algorithmic_bytes_per_step=per_unit,
-                        note=("LTI (Fill) layout streams only y in / (mean,var) out: this kernel is fp64-VALU bound, the HBM "
-                              "fraction is reported for completeness" if lti else "per-step layout: HBM bound"))
+                        note=("LTI (Fill) layout streams only y in / (mean,var) out (plus the smoother scratch: `traffic`): the launch is not "
+                              "HBM bound -- one wave per SIMD, it lasts as long as the dependent fp64 chain of its slowest wave "
+                              "(DESIGN 3.10, `valu`); the HBM fraction is reported for completeness" if lti else "per-step layout: HBM bound"))
         out = dict(
             metric="Kalman steps/sec (logpdf + posterior marginals), T=10^7 Matern32 d=3",
             value=value, unit="Kalman steps/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step,
