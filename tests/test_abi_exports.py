@@ -22,6 +22,22 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(tgp._lib.EXPORTS), declared ^ set(tgp._lib.EXPORTS)
 
 
+def test_option_and_flag_constants_of_the_binding_match_the_header():
+    """tgp_set_option takes bare integers: the ctypes binding's OPT_* / flag constants must be the header's #defines."""
+    import temporalgps_jl_amd as tgp
+    header = open(os.path.join(ROOT, "include", "tgp_hip.h")).read()
+    defs = {}
+    for name, val in re.findall(r"#define\s+(TGP_[A-Za-z0-9_]+)\s+(\(?[0-9a-fx]+u?\s*(?:<<\s*[0-9]+)?\)?)", header):
+        defs[name] = eval(val.replace("u", ""))
+    opts = {k: v for k, v in vars(tgp._lib).items() if k.startswith("OPT_")}
+    assert len(opts) >= 12
+    for k, v in opts.items():
+        assert defs.get("TGP_" + k) == v, (k, v, defs.get("TGP_" + k))
+    for k in ("SHARED_A", "SHARED_a", "SHARED_Q", "SHARED_H", "SHARED_h", "SHARED_R"):
+        assert defs["TGP_" + k] == getattr(tgp._lib, k), k
+    assert len(set(opts.values())) == len(opts)          # no two options share a number
+
+
 def test_host_side_monoid_ops_match_definition():
     """tgp_elem_apply / tgp_elem_combine are pure host functions of the ABI (no GPU needed)."""
     import ctypes
