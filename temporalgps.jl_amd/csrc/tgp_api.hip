@@ -19,6 +19,7 @@
 
 #include "tgp_kernels.hpp"
 #include "tgp_dense.hpp"
+#include "tgp_steady.hpp"
 
 namespace tgp {
 const KernelTable *kernel_table_d1(), *kernel_table_d2(), *kernel_table_d3(), *kernel_table_d4(), *kernel_table_d5(),
@@ -284,7 +285,16 @@ struct tgp_handle {
     DevBuf balt;
     int opt_split = 1;           // TGP_OPT_SPLIT_SMOOTHER
     int opt_table = 1;           // TGP_OPT_SHARED_PARTS: pass 1 with the chunks' shared matrix parts from a table
-    int opt_steady = 1;          // TGP_OPT_STEADY: mean-only steps of passes 2 / 3 once a chunk's covariance repeats with period 2
+    int opt_steady = 1;          // TGP_OPT_STEADY (bit 0): mean-only steps of passes 2 / 3 once a chunk's covariance repeats with period 2
+    // TGP_OPT_STEADY = 2 (default): the stationary-gain scan engine (tgp_steady.hip) serves tgp_logpdf / tgp_[logpdf_and_]posterior_marginals of
+    // Forward LTI models with one noise variance, scalar observations and no missing data.  Whether it applies (the covariance settles
+    // within the head tables, the series is longer than head + tail) is decided on the device inside every call; a call that finds it
+    // does not is re-run on the general path and the bound model is remembered as such (steady2_state = -1).
+    int opt_steady2 = 1;
+    tgp_steady::Engine* steady2 = nullptr;
+    int steady2_state = 0;       // 0 untried for the bound model, 1 served the last call, -1 does not apply
+    bool steady2_last = false;   // the last logpdf / posterior-marginals call was served by it
+    void* steady2_scope = nullptr;
     DevBuf steady_rec;           // ... the chunks' records (ModelView::steady)
     int steady_calls = 0;        // 1: the last posterior-path forward pass (mode 2) wrote the records
     // Policy of the posterior path: the build with these steps has slightly longer full steps, and a pass takes as long as its slowest
@@ -983,6 +993,57 @@ int forward_apply(tgp_handle* h, int mode, const FilterOut& fo, const double* x0
 
 int* flag_ptr(tgp_handle* h) { return reinterpret_cast<int*>(h->result.d() + 4); }
 
+// ---- stationary-gain scan engine (tgp_steady.hip) ------------------------------------------------------------------------------------
+bool steady2_eligible(const tgp_handle* h, const uint8_t* missing, uint32_t flags) {
+    return h->opt_steady2 && h->steady2_state >= 0 && !h->is_dense && !h->sde && h->lti && h->p == 1 && h->mv.sR == 0 && h->ordering == 0 &&
+           missing == nullptr && !(flags & TGP_REUSE_REDUCE) && tgp_steady::supports(h->d) && h->mv.T == h->T;
+}
+void steady2_begin(void* ctx, const char* name) {
+    tgp_handle* h = static_cast<tgp_handle*>(ctx);
+    h->steady2_scope = new LaunchScope(h, name);
+}
+void steady2_end(void* ctx) {
+    tgp_handle* h = static_cast<tgp_handle*>(ctx);
+    delete static_cast<LaunchScope*>(h->steady2_scope);
+    h->steady2_scope = nullptr;
+}
+// Enqueues the call on the engine (y already staged in h->mv.y). mean_dev == nullptr: logpdf only.
+int steady2_enqueue(tgp_handle* h, const double* Rnew_dev, bool rnew_per_step, double* mean_dev, double* var_dev) {
+    if (!h->steady2) h->steady2 = tgp_steady::create();
+    tgp_steady::ModelDev md;
+    md.d = h->d;
+    md.A = h->mv.A; md.a = h->mv.a; md.Q = h->mv.Q; md.H = h->mv.H; md.hh = h->mv.h; md.R = h->mv.R;
+    md.x0 = h->bx0.d();
+    tgp_steady::CallDev cd;
+    cd.T = h->T;
+    cd.y = h->mv.y;
+    cd.Rnew = Rnew_dev;
+    cd.rnew_per_step = rnew_per_step ? 1 : 0;
+    cd.mean = mean_dev;
+    cd.var = var_dev;
+    cd.result = h->result.d();
+    tgp_steady::Hooks hk;
+    if (h->profile) {
+        hk.ctx = h;
+        hk.begin = steady2_begin;
+        hk.end = steady2_end;
+    }
+    std::string err;
+    if (tgp_steady::enqueue(h->steady2, h->stream, md, cd, hk, &err) != 0) return h->fail(TGP_EHIP, err);
+    return TGP_OK;
+}
+// After CallTimer::finish: did the engine serve the call? (host_result[6]; 2 = it found on the device that it does not apply)
+bool steady2_served(tgp_handle* h) {
+    const bool ran = h->host_result[6] == tgp_steady::kStatusRan;
+    h->steady2_state = ran ? 1 : -1;
+    h->steady2_last = ran;
+    if (ran) {
+        h->reduce_valid = false;        // (the general path's pass-1 elements belong to an earlier call's observations)
+        h->smoother_valid = false;
+    }
+    return ran;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------ run-time variant check
@@ -1046,6 +1107,7 @@ int tgp_destroy(tgp_handle* h) {
     }
     for (auto& e : h->evpool) (void)hipEventDestroy(e);
     if (h->dense) tgp_dense::destroy(h->dense);
+    if (h->steady2) tgp_steady::destroy(h->steady2);
     if (h->host_result) (void)hipHostFree(h->host_result);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
@@ -1098,6 +1160,8 @@ int tgp_set_option(tgp_handle* h, int option, int64_t value) {
     }
     if (option == TGP_OPT_STEADY) {
         h->opt_steady = value != 0;
+        h->opt_steady2 = value == 2;
+        h->steady2_state = 0;
         h->steady_known = false;
         h->smoother_valid = false;
         return TGP_OK;
@@ -1143,6 +1207,14 @@ int tgp_steady_steps(tgp_handle* h, int64_t* mean_only, int64_t* total) {
     if (!h || !mean_only || !total) return TGP_EINVAL;
     *mean_only = 0;
     *total = h->T * h->p;
+    if (h->is_dense) return TGP_OK;
+    if (h->steady2_last && h->steady2) {      // stationary-gain engine: every step beyond the head's n0 ran with the stationary gains
+        int64_t info[4] = {0, 0, 0, 0};
+        HIPCHK(hipSetDevice(h->device));
+        if (tgp_steady::last_info(h->steady2, h->stream, info) != 0) return h->fail(TGP_EHIP, "tgp_steady::last_info");
+        if (info[3] == 1) *mean_only = h->T - info[0];
+        return TGP_OK;
+    }
     if (h->steady_calls == 0 || h->mv.steady == nullptr) return TGP_OK;     // the last forward pass of a posterior path ran full steps only
     HIPCHK(hipSetDevice(h->device));
     std::vector<double> ks((size_t)h->n0);
@@ -1171,6 +1243,10 @@ int tgp_model_set(tgp_handle* h, int64_t T, int d, int p, int ordering, uint32_t
     TRY(bind_device(h));
     h->have_model = false;
     h->steady_known = false;
+    h->steady_calls = 0;
+    h->mv.steady = nullptr;
+    h->steady2_state = 0;
+    h->steady2_last = false;
     h->fold_valid = false;
     h->reduce_valid = false;
     h->smoother_valid = false;
@@ -1335,6 +1411,17 @@ int tgp_model_set_x0(tgp_handle* h, const double* x0m, const double* x0P) {
 int tgp_logpdf(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t flags, double* out) {
     TRY(check_ready(h));
     if (!out) return h->fail(TGP_EINVAL, "out is NULL");
+    h->steady2_last = false;
+    if (steady2_eligible(h, missing, flags)) {
+        CallTimer tm(h);
+        TRY(set_obs(h, y, missing, flags));
+        tm.inputs_done();
+        TRY(steady2_enqueue(h, nullptr, false, nullptr, nullptr));
+        tm.kernels_done();
+        const int rc = tm.finish(out);
+        if (rc != TGP_OK || steady2_served(h)) return rc;
+        // not applicable to this model (decided on the device): the general path below serves this and every later call
+    }
     if (graph_eligible(h, flags, false)) {
         const uint64_t key[8] = {1, (uint64_t)(uintptr_t)y, (uint64_t)(uintptr_t)missing, flags, 0, 0, 0, 0};
         return graph_call(h, 0, key, [&]() -> int {
@@ -1491,6 +1578,26 @@ int tgp_posterior_marginals(tgp_handle* h, const double* y, const uint8_t* missi
     const bool idev = (flags & TGP_IN_DEVICE) != 0, odev = (flags & TGP_OUT_DEVICE) != 0;
     const bool rshared = (flags & TGP_SHARED_R) != 0;
     const size_t nT = (size_t)h->T * h->p * sizeof(double);   // one value per (time step, observation)
+    h->steady2_last = false;
+    if (steady2_eligible(h, missing, flags)) {
+        CallTimer tm(h);
+        const void* pR = nullptr;
+        TRY(stage_in(h, h->bRnew, Rnew, rshared ? sizeof(double) : nT, idev, &pR));
+        TRY(set_obs(h, y, missing, flags));
+        tm.inputs_done();
+        double *dm = nullptr, *dv = nullptr;
+        TRY(stage_out(h, h->bo1, mean_out, nT, odev, &dm));
+        TRY(stage_out(h, h->bo2, var_out, nT, odev, &dv));
+        TRY(steady2_enqueue(h, (const double*)pR, !rshared, dm, dv));
+        tm.kernels_done();
+        TRY(copy_back(h, mean_out, dm, nT, odev));
+        TRY(copy_back(h, var_out, dv, nT, odev));
+        const int rc = tm.finish(lml_out);
+        if (rc != TGP_OK || steady2_served(h)) {
+            h->smoother_valid = false;
+            return rc;
+        }
+    }
     if (graph_eligible(h, flags, true)) {
         const uint64_t key[8] = {2, (uint64_t)(uintptr_t)y, (uint64_t)(uintptr_t)missing, flags, (uint64_t)(uintptr_t)Rnew, (uint64_t)(uintptr_t)mean_out,
                                  (uint64_t)(uintptr_t)var_out, 0};

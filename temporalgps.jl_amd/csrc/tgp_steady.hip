@@ -1,0 +1,1511 @@
+// Stationary-gain scan engine: see tgp_steady.hpp for what it computes and why.  gfx950 only (wave64, LDS as the lane exchange of the
+// one-wave setup kernel, __shfl for the in-tile scans).
+#include "tgp_steady.hpp"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+namespace tgp_steady {
+
+namespace {
+
+constexpr double kLog2Pi = 1.8378770664093454835606594728112;
+constexpr double kTol = 4.5e-16;   // "no longer changes": 2 ulp relative to the element's natural scale
+
+// ---- layout of the steady-coefficient block (doubles) ---------------------------------------------------------------------------
+template <int D>
+struct SS {
+    static constexpr int A = 0;             // [D][D] row-major
+    static constexpr int a = A + D * D;     // [D]
+    static constexpr int h = a + D;         // [D]
+    static constexpr int hh = h + D;
+    static constexpr int kA = hh + 1;       // [D]  A K
+    static constexpr int rS = kA + D;       // R / S
+    static constexpr int iS = rS + 1;       // 1 / S
+    static constexpr int logS = iS + 1;
+    static constexpr int G = logS + 1;      // [D][D] row-major: smoother gain (x_{t-1} = G x_t + g)
+    static constexpr int c = G + D * D;     // [D]  G K
+    static constexpr int vb = c + D;        // H Ps H'  (smoothed variance without Rnew)
+    static constexpr int mu0 = vb + 1;      // [D]  A x0.m + a
+    static constexpr int LS = mu0 + D;      // sum of log S_t over the n0 head steps
+    static constexpr int size = LS + 1;
+};
+
+constexpr int kPowN = 26;          // powers Phi^(2^k), G^(2^k), k < kPowN (the scans need k <= 23, whatever T)
+constexpr int kBlk = 4;            // tiles (waves) per workgroup of the tile passes: one carry element per workgroup, 2048 steps
+
+// ---- the constant block: everything the tile passes read through SCALAR loads (written by k_setup only) -------------------------------
+template <int D>
+struct CL {
+    static constexpr int DD = D * D;
+    static constexpr int ss = 0;
+    static constexpr int pphi = (SS<D>::size + 7) & ~7;      // [kPowN][DD] row-major: (A - kA h')^(2^k)
+    static constexpr int pg = pphi + kPowN * DD;             // [kPowN][DD]: G^(2^k)
+    static constexpr int B512 = pg + kPowN * DD;             // coupling of a full tile: d(lam at tile start) / d(mu at tile start) = -B
+    static constexpr int Blt = B512 + DD;                    // ... of the LAST tile (nv <= 512 valid steps)
+    static constexpr int B2048 = Blt + DD;                   // ... of a full workgroup (kBlk tiles)
+    static constexpr int Blb = B2048 + DD;                   // ... of the last workgroup
+    static constexpr int size = Blb + DD;
+};
+
+struct Tab {
+    long long* hdr;      // [0] applies (1/0), [1] th (head tiles), [2] n0, [3] n1, [4] not PD
+    double* cst;         // CL<D>
+    double* ssc;         // = cst + CL::ss
+    double* pw_phi;      // = cst + CL::pphi
+    double* pw_g;        // = cst + CL::pg
+    double *Fb, *B0b;    // [nblk] workgroup elements (zero carries)
+    double *MUb, *LAMb;  // [nblk + 1] carries of the workgroups: mu at the first step; lam after the first step has been absorbed
+    // head tables: nhmax = kHeadMaxTiles * kTile entries
+    double *h_kA, *h_rS, *h_iS, *h_G, *h_c, *h_vb, *h_r;
+    double *s_Pf, *s_Pp, *s_L, *s_Ps;    // [nhmax + 1][D*D] scratch of the setup kernel
+    double* t_vb;        // [kTailMax]: H Ps H' at step T-1-j
+    double* t_Ps;        // [kTailMax][D*D]
+    double *F, *B0;      // [ntiles][D] tile elements (zero carries)
+    double* SSQ;         // [nblk] sum r^2 of a workgroup's tiles
+    double* misc;        // [0] sum r^2 / S over the head; [8..] cycle stamps of k_setup's phases
+};
+
+// workgroups of the stationary tiles: the launch is sized for one head tile (ntiles1 = ntiles - 1 tiles), the device knows th
+__device__ __forceinline__ long long nblk_max_for(long long th, long long ntiles) { return (ntiles - th + kBlk - 1) / kBlk; }
+__device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
+__device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
+
+// =================================================================================================================================
+// k_setup: one wave, lane (i, j) owns element (i, j) of every d x d matrix; LDS is the exchange.  Sequential in time, but only over the
+// head (n0 steps), the tail (n1 steps) and log2(T) squarings.
+// =================================================================================================================================
+
+// reverse-time dynamics of one step, one lane: lgssm.jl:231-238 with Pf = filtered covariance before the step, Pp = predicted.
+template <int D>
+__device__ bool invert_dynamics_lane(const double* __restrict__ A /*col-major*/, const double (&Pf)[D][D], const double (&Pp)[D][D],
+                                     double (&G)[D][D], double (&L)[D][D]) {
+    double U[D][D];
+    bool ok = true;
+    // U'U = Symmetric(Pp) + 1e-10 I  (upper triangle of Pp)
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        double s = Pp[i][i] + 1e-10;
+#pragma unroll
+        for (int k = 0; k < i; ++k) s -= U[k][i] * U[k][i];
+        ok = ok && (s > 0.0);
+        const double u = sqrt(s);
+        U[i][i] = u;
+        const double ru = 1.0 / u;
+#pragma unroll
+        for (int j = i + 1; j < D; ++j) {
+            double v = Pp[i][j];
+#pragma unroll
+            for (int k = 0; k < i; ++k) v -= U[k][i] * U[k][j];
+            U[i][j] = v * ru;
+        }
+#pragma unroll
+        for (int j = 0; j < i; ++j) U[i][j] = 0.0;
+    }
+    // M = A * Pf (full Pf, as the reference), X = U' \ M, Gt = U \ X
+    double X[D][D];
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            double v = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) v = fma(A[i + k * D], Pf[k][c], v);
+#pragma unroll
+            for (int k = 0; k < i; ++k) v -= U[k][i] * X[k][c];
+            X[i][c] = v / U[i][i];
+        }
+#pragma unroll
+        for (int i = D - 1; i >= 0; --i) {
+            double v = X[i][c];
+#pragma unroll
+            for (int k = i + 1; k < D; ++k) v -= U[i][k] * X[k][c];
+            X[i][c] = v / U[i][i];          // X now holds Gt
+        }
+    }
+    // G = Gt', L = Pf - (U Gt)'(U Gt)
+    double W[D][D];
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+            double v = 0.0;
+#pragma unroll
+            for (int k = i; k < D; ++k) v = fma(U[i][k], X[k][c], v);
+            W[i][c] = v;
+        }
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            G[i][j] = X[j][i];
+            double v = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) v = fma(W[k][i], W[k][j], v);
+            L[i][j] = Pf[i][j] - v;
+        }
+    return ok;
+}
+
+// LDS exchange inside ONE wave: DS instructions of a wave execute in order, so a write is visible to the reads that follow it in
+// program order; all that is needed is that the compiler keeps that order (no s_barrier, and -- unlike __syncthreads -- no wait for the
+// global stores that are in flight: the tables are written fire-and-forget from inside the sequential loops).
+__device__ __forceinline__ void lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int D>
+__global__ __launch_bounds__(64) void k_setup(ModelDev m, Tab tb, long long T) {
+    constexpr int DD = D * D;
+    constexpr int nhmax = kHeadMaxTiles * kTile;
+    constexpr int SB = D <= 6 ? 64 : 32;          // steps of the head staged in LDS at a time (phase d)
+    __shared__ double sP[DD], sT[DD], sPp[DD], sB[DD], sXa[DD], sGa[DD], sXb[DD], sGb[DD];
+    __shared__ double sGt[SB * DD], sLt[SB * DD];
+    const int lane = threadIdx.x;
+    const bool act = lane < DD;
+    const int e = act ? lane : 0;
+    const int i = e / D, j = e % D;
+    double Ai[D], Aj[D], hv[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        Ai[k] = m.A[i + k * D];
+        Aj[k] = m.A[j + k * D];
+        hv[k] = m.H[k];
+    }
+    const double Qij = m.Q[i + j * D];
+    const double R = m.R[0];
+    {
+        const int r = imin(i, j), c = imax(i, j);
+        if (act) sP[e] = m.x0[D + c * (c + 1) / 2 + r];
+    }
+    if (lane == 0) {
+        tb.hdr[4] = 0;
+        tb.misc[8] = (double)wall_clock64();
+    }
+    lds_sync();
+
+    // ---- (a) filter covariance until it no longer changes ------------------------------------------------------------------------
+    double Pold2 = 0.0, LS = 0.0;
+    int tc = -1, n0 = -1;
+    bool bad = false;
+    double V[D], iS = 0.0, S = 0.0, kAi = 0.0;
+    for (int t = 0; t <= nhmax; ++t) {
+        const double Pf = sP[e];
+        double t1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) t1 = fma(Ai[k], sP[imin(k, j) * D + imax(k, j)], t1);     // A * Symmetric(P): upper triangle
+        if (act) sT[e] = t1;
+        lds_sync();
+        double pp = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) pp = fma(sT[i * D + k], Aj[k], pp);
+        pp += Qij;
+        if (act) sPp[e] = pp;
+        lds_sync();
+        S = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            double v = 0.0;
+#pragma unroll
+            for (int l = 0; l < D; ++l) v = fma(hv[l], sPp[l * D + k], v);      // V = H * Pp
+            V[k] = v;
+            S = fma(v, hv[k], S);
+        }
+        S += R;
+        bad = bad || !(S > 0.0);
+        iS = 1.0 / S;
+        const double rs = 1.0 / sqrt(S);
+        const double Pn = pp - (V[i] * rs) * (V[j] * rs);
+        kAi = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) kAi = fma(Ai[k], V[k] * iS, kAi);
+        if (t < nhmax) {
+            if (act && j == 0) tb.h_kA[t * D + i] = kAi;
+            if (lane == 0) {
+                tb.h_rS[t] = R * iS;
+                tb.h_iS[t] = iS;
+            }
+        }
+        if (act) {
+            tb.s_Pf[(size_t)t * DD + e] = Pf;
+            tb.s_Pp[(size_t)t * DD + e] = pp;
+        }
+        if (tc >= 0) {           // this was the extra iteration from the settled covariance: the stationary step
+            n0 = t;
+            break;
+        }
+        if (t == nhmax) break;
+        LS += log(S);
+        const double scale = 0.5 * (sPp[i * D + i] + sPp[j * D + j]);
+        const bool moved = act && fabs(Pn - Pf) > kTol * scale;
+        const bool nocyc = act && !(Pn == Pold2);
+        const bool conv = !__any(moved) || (t >= 1 && !__any(nocyc));
+        Pold2 = Pf;
+        lds_sync();
+        if (act) sP[e] = Pn;
+        lds_sync();
+        if (conv) tc = t;
+    }
+    const bool settled = n0 >= 0 && n0 < nhmax;      // the head tables hold nhmax steps: th <= kHeadMaxTiles
+    const int th = settled ? n0 / kTile + 1 : 0;
+    const int nh = th * kTile;
+    if (!settled || bad) {
+        if (lane == 0) {
+            tb.hdr[0] = 0;
+            tb.hdr[1] = 0;
+            tb.hdr[2] = -1;
+            tb.hdr[3] = -1;
+            tb.hdr[4] = bad ? 1 : 0;
+        }
+        return;
+    }
+    if (lane == 0) tb.misc[9] = (double)wall_clock64();
+    // stationary coefficients (entry n0)
+    double* ss = tb.ssc;
+    if (act) ss[SS<D>::A + e] = Ai[j];
+    if (act && j == 0) {
+        ss[SS<D>::a + i] = m.a[i];
+        ss[SS<D>::h + i] = hv[i];
+        ss[SS<D>::kA + i] = kAi;
+        double v = m.a[i];
+#pragma unroll
+        for (int k = 0; k < D; ++k) v = fma(Ai[k], m.x0[k], v);
+        ss[SS<D>::mu0 + i] = v;
+    }
+    if (lane == 0) {
+        ss[SS<D>::hh] = m.hh[0];
+        ss[SS<D>::rS] = R * iS;
+        ss[SS<D>::iS] = iS;
+        ss[SS<D>::logS] = log(S);
+        ss[SS<D>::LS] = LS;
+    }
+    __threadfence();
+    __syncthreads();
+
+    // ---- (b) reverse-time gains of the head steps 0..n0, one step per lane ---------------------------------------------------------
+    for (int t0 = 0; t0 <= n0; t0 += 64) {
+        const int t = t0 + lane;
+        if (t <= n0) {
+            double Pf[D][D], Pp[D][D], G[D][D], L[D][D];
+#pragma unroll
+            for (int r = 0; r < D; ++r)
+#pragma unroll
+                for (int c = 0; c < D; ++c) {
+                    Pf[r][c] = tb.s_Pf[(size_t)t * DD + r * D + c];
+                    Pp[r][c] = tb.s_Pp[(size_t)t * DD + r * D + c];
+                }
+            const bool ok = invert_dynamics_lane<D>(m.A, Pf, Pp, G, L);
+            if (!ok) tb.hdr[4] = 1;
+            // K = Pp' H / S (as V above), c = G K
+            double K[D], Sv = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                double v = 0.0;
+#pragma unroll
+                for (int l = 0; l < D; ++l) v = fma(hv[l], Pp[l][k], v);
+                K[k] = v;
+                Sv = fma(v, hv[k], Sv);
+            }
+            Sv += R;
+            const double iSv = 1.0 / Sv;
+#pragma unroll
+            for (int r = 0; r < D; ++r) {
+                double v = 0.0;
+#pragma unroll
+                for (int c = 0; c < D; ++c) {
+                    v = fma(G[r][c], K[c] * iSv, v);
+                    if (t < nhmax) tb.h_G[(size_t)t * DD + r * D + c] = G[r][c];
+                    tb.s_L[(size_t)t * DD + r * D + c] = L[r][c];
+                    if (t == n0) ss[SS<D>::G + r * D + c] = G[r][c];
+                }
+                if (t < nhmax) tb.h_c[t * D + r] = v;
+                if (t == n0) ss[SS<D>::c + r] = v;
+            }
+        }
+    }
+    __threadfence();
+    __syncthreads();
+    bad = tb.hdr[4] != 0;
+    if (lane == 0) tb.misc[10] = (double)wall_clock64();
+
+    // ---- (c) smoothed covariance backwards from the final filtered state (Ps_{T-1} = P_ss) until it no longer changes --------------
+    double Gi[D], Gj[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        Gi[k] = ss[SS<D>::G + i * D + k];
+        Gj[k] = ss[SS<D>::G + j * D + k];
+    }
+    const double Lij = tb.s_L[(size_t)n0 * DD + e];
+    // (sP still holds P_ss: the stationary iteration did not store its result)
+    int n1 = -1;
+    Pold2 = 0.0;
+    for (int jt = 0; jt < kTailMax; ++jt) {
+        const double Ps = sP[e];
+        if (act) tb.t_Ps[(size_t)jt * DD + e] = Ps;
+        double t1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) t1 = fma(Gi[k], sP[imin(k, j) * D + imax(k, j)], t1);
+        const double dii = fabs(sP[i * D + i]), djj = fabs(sP[j * D + j]);
+        if (act) sT[e] = t1;
+        lds_sync();
+        double pn = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) pn = fma(sT[i * D + k], Gj[k], pn);
+        pn += Lij;
+        const bool moved = act && fabs(pn - Ps) > kTol * 0.5 * (dii + djj);
+        const bool nocyc = act && !(pn == Pold2);
+        const bool conv = !__any(moved) || (jt >= 1 && !__any(nocyc));
+        Pold2 = Ps;
+        lds_sync();
+        if (act) sP[e] = pn;
+        lds_sync();
+        if (conv) {
+            n1 = jt + 1;
+            break;
+        }
+    }
+    const bool applies = !bad && n1 >= 0 && (long long)nh + n1 + 1 <= T;
+    if (lane == 0) {
+        tb.hdr[0] = applies ? 1 : 0;
+        tb.hdr[1] = th;
+        tb.hdr[2] = n0;
+        tb.hdr[3] = n1;
+    }
+    if (!applies) return;
+    if (lane == 0) tb.misc[11] = (double)wall_clock64();
+
+    // ---- (d) smoothed covariance of the head: Ps_{n0} = stationary, Ps_{t-1} = G_t Ps_t G_t' + L_t; the gains of SB steps at a time
+    //      are staged in LDS (a dependent global load per step would cost more than the step) --------------------------------------
+    if (act) tb.s_Ps[(size_t)n0 * DD + e] = sP[e];
+    for (int thi = n0; thi >= 1; thi -= SB) {
+        const int tlo = imax(thi - SB + 1, 1);          // steps tlo..thi, thi first
+        const int cnt = thi - tlo + 1;
+        for (int idx = lane; idx < cnt * DD; idx += 64) {
+            sGt[idx] = tb.h_G[(size_t)tlo * DD + idx];
+            sLt[idx] = tb.s_L[(size_t)tlo * DD + idx];
+        }
+        lds_sync();
+        for (int t = thi; t >= tlo; --t) {
+            const double* gt = &sGt[(t - tlo) * DD];
+            double t1 = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) t1 = fma(gt[i * D + k], sP[imin(k, j) * D + imax(k, j)], t1);
+            if (act) sT[e] = t1;
+            lds_sync();
+            double pn = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) pn = fma(sT[i * D + k], gt[j * D + k], pn);
+            pn += sLt[(t - tlo) * DD + e];
+            lds_sync();
+            if (act) {
+                sP[e] = pn;
+                tb.s_Ps[(size_t)(t - 1) * DD + e] = pn;
+            }
+            lds_sync();
+        }
+    }
+    __threadfence();
+    __syncthreads();
+
+    // ---- (d2) variances, one step per lane; head entries beyond n0 repeat the stationary one -----------------------------------------
+    auto quad = [&](const double* Pm) {     // H Symmetric(P) H'
+        double s = 0.0;
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+            double v = 0.0;
+#pragma unroll
+            for (int r = 0; r < D; ++r) v = fma(hv[r], Pm[imin(r, c) * D + imax(r, c)], v);
+            s = fma(v, hv[c], s);
+        }
+        return s;
+    };
+    const double vb_ss = quad(&tb.s_Ps[(size_t)n0 * DD]);
+    if (lane == 0) ss[SS<D>::vb] = vb_ss;
+    for (int t = lane; t < n1; t += 64) tb.t_vb[t] = quad(&tb.t_Ps[(size_t)t * DD]);
+    for (int t = lane; t < nh; t += 64) {
+        if (t <= n0) {
+            tb.h_vb[t] = quad(&tb.s_Ps[(size_t)t * DD]);
+        } else {
+            tb.h_vb[t] = vb_ss;
+            tb.h_rS[t] = R * iS;
+            tb.h_iS[t] = iS;
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                tb.h_kA[t * D + k] = ss[SS<D>::kA + k];
+                tb.h_c[t * D + k] = ss[SS<D>::c + k];
+            }
+#pragma unroll
+            for (int k = 0; k < DD; ++k) tb.h_G[(size_t)t * DD + k] = ss[SS<D>::G + k];
+        }
+    }
+
+    if (lane == 0) tb.misc[12] = (double)wall_clock64();
+    // ---- (e) powers Phi^(2^k), G^(2^k); the couplings B_n = sum_{j < n} G^j c h' Phi^j by doubling, B_2n = B_n + G^n B_n Phi^n:
+    //      B_512 (a tile), B_2048 (a workgroup), and the two ragged ones -- the last tile's nv valid steps and the last workgroup's nvb --
+    //      composed from the B_(2^k) of the bits of nv / nvb --------------------------------------------------------------------------------
+    {
+        const long long ntiles = (T + kTile - 1) / kTile;
+        const long long nblk = (ntiles - th + kBlk - 1) / kBlk;
+        const int nv = (int)(T - (ntiles - 1) * kTile);                                  // 1..512
+        const int nvb = (int)(T - ((long long)th + (nblk - 1) * kBlk) * kTile);          // 1..2048
+        const double ci = ss[SS<D>::c + i];
+        double x = Ai[j] - kAi * hv[j];        // Phi = A - kA h'
+        double g = Gi[j];
+        double b = ci * hv[j];
+        double bl[2] = {0.0, 0.0};
+        const int want[2] = {nv, nvb};
+        double* sXq[2] = {sXa, sXb};
+        double* sGq[2] = {sGa, sGb};
+        if (act) {
+            sXa[e] = sGa[e] = sXb[e] = sGb[e] = (i == j) ? 1.0 : 0.0;
+        }
+        lds_sync();
+        double* cst = tb.cst;
+        for (int k = 0; k < kPowN; ++k) {
+            if (act) {
+                cst[CL<D>::pphi + k * DD + e] = x;
+                cst[CL<D>::pg + k * DD + e] = g;
+                if (k == 9) cst[CL<D>::B512 + e] = b;
+                if (k == 11) cst[CL<D>::B2048 + e] = b;
+                sP[e] = x;
+                sT[e] = g;
+                sB[e] = b;
+            }
+            lds_sync();
+            if (k < 11) {
+#pragma unroll
+                for (int w = 0; w < 2; ++w) {
+                    if ((want[w] >> k) & 1) {       // append a block of 2^k steps to the composition: Bl += Ga B_(2^k) Xa
+                        double u = 0.0, xa = 0.0, ga = 0.0;
+#pragma unroll
+                        for (int l = 0; l < D; ++l) {
+                            u = fma(sB[i * D + l], sXq[w][l * D + j], u);
+                            xa = fma(sP[i * D + l], sXq[w][l * D + j], xa);
+                            ga = fma(sT[i * D + l], sGq[w][l * D + j], ga);
+                        }
+                        if (act) sPp[e] = u;
+                        lds_sync();
+                        double v = 0.0;
+#pragma unroll
+                        for (int l = 0; l < D; ++l) v = fma(sGq[w][i * D + l], sPp[l * D + j], v);
+                        bl[w] += v;
+                        lds_sync();
+                        if (act) {
+                            sXq[w][e] = xa;
+                            sGq[w][e] = ga;
+                        }
+                        lds_sync();
+                    }
+                }
+                double u = 0.0;
+#pragma unroll
+                for (int l = 0; l < D; ++l) u = fma(sB[i * D + l], sP[l * D + j], u);      // B Phi^m
+                if (act) sPp[e] = u;
+                lds_sync();
+                double v = 0.0;
+#pragma unroll
+                for (int l = 0; l < D; ++l) v = fma(sT[i * D + l], sPp[l * D + j], v);     // G^m (B Phi^m)
+                b += v;
+            }
+            double x2 = 0.0, g2 = 0.0;
+#pragma unroll
+            for (int l = 0; l < D; ++l) {
+                x2 = fma(sP[i * D + l], sP[l * D + j], x2);
+                g2 = fma(sT[i * D + l], sT[l * D + j], g2);
+            }
+            x = x2;
+            g = g2;
+            lds_sync();
+        }
+        __threadfence();
+        __syncthreads();
+        if (act) {
+            cst[CL<D>::Blt + e] = (nv == kTile) ? cst[CL<D>::B512 + e] : bl[0];
+            cst[CL<D>::Blb + e] = (nvb == kBlk * kTile) ? cst[CL<D>::B2048 + e] : bl[1];
+        }
+    }
+    if (lane == 0) tb.misc[13] = (double)wall_clock64();
+}
+
+// =================================================================================================================================
+// tile passes
+// =================================================================================================================================
+template <int D>
+struct Coef {
+    double A[D][D], a[D], h[D], hh, kA[D], rS, G[D][D], c[D];
+    __device__ __forceinline__ void load(const double* __restrict__ ss) {
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                A[i][k] = ss[SS<D>::A + i * D + k];
+                G[i][k] = ss[SS<D>::G + i * D + k];
+            }
+            a[i] = ss[SS<D>::a + i];
+            h[i] = ss[SS<D>::h + i];
+            kA[i] = ss[SS<D>::kA + i];
+            c[i] = ss[SS<D>::c + i];
+        }
+        hh = ss[SS<D>::hh];
+        rS = ss[SS<D>::rS];
+    }
+};
+
+__device__ __forceinline__ void load8(const double* __restrict__ p, long long t0, long long T, double (&v)[kSub]) {
+    if (t0 + kSub <= T) {
+        if ((reinterpret_cast<uintptr_t>(p) & 15) == 0) {
+            const double2* q = reinterpret_cast<const double2*>(p + t0);
+#pragma unroll
+            for (int j = 0; j < kSub / 2; ++j) {
+                const double2 w = q[j];
+                v[2 * j] = w.x;
+                v[2 * j + 1] = w.y;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < kSub; ++j) v[j] = p[t0 + j];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < kSub; ++j) v[j] = (t0 + j < T) ? p[t0 + j] : 0.0;
+    }
+}
+
+__device__ __forceinline__ void store8(double* __restrict__ p, long long t0, long long T, const double (&v)[kSub]) {
+    if (t0 + kSub <= T) {
+        if ((reinterpret_cast<uintptr_t>(p) & 15) == 0) {
+            double2* q = reinterpret_cast<double2*>(p + t0);
+#pragma unroll
+            for (int j = 0; j < kSub / 2; ++j) q[j] = make_double2(v[2 * j], v[2 * j + 1]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < kSub; ++j) p[t0 + j] = v[j];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < kSub; ++j)
+            if (t0 + j < T) p[t0 + j] = v[j];
+    }
+}
+
+// forward half of a stationary tile: local recursion from `mu` (lane 0: the tile's carry, others: zero), wave scan with Phi^(8 2^k),
+// second local recursion from the scanned start -> the innovations r[8].  Returns the lane's inclusive scan value (lane 63: tile end).
+template <int D>
+__device__ __forceinline__ void tile_forward(const Coef<D>& cf, const double* __restrict__ pw_phi, const double (&y)[kSub], int nvalid,
+                                             int lane, const double (&mu_in)[D], double (&r)[kSub], double (&fend)[D]) {
+    constexpr int DD = D * D;
+    double mu[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) mu[i] = mu_in[i];
+#pragma unroll
+    for (int j = 0; j < kSub; ++j) {
+        double rr = y[j] - cf.hh;
+#pragma unroll
+        for (int k = 0; k < D; ++k) rr = fma(-cf.h[k], mu[k], rr);
+        rr = (j < nvalid) ? rr : 0.0;
+        double nm[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            double v = fma(cf.kA[i], rr, cf.a[i]);
+#pragma unroll
+            for (int k = 0; k < D; ++k) v = fma(cf.A[i][k], mu[k], v);
+            nm[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < D; ++i) mu[i] = nm[i];
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const int off = 1 << k;
+        double g[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) g[i] = __shfl_up(mu[i], off);
+        const double* __restrict__ M = pw_phi + (size_t)(3 + k) * DD;
+        if (lane >= off) {
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                double v = mu[i];
+#pragma unroll
+                for (int l = 0; l < D; ++l) v = fma(M[i * D + l], g[l], v);
+                mu[i] = v;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < D; ++i) fend[i] = mu[i];
+    // start state of this lane: the inclusive value of the lane before it (lane 0: the carry)
+    double st[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        const double v = __shfl_up(mu[i], 1);
+        st[i] = (lane == 0) ? mu_in[i] : v;
+    }
+#pragma unroll
+    for (int j = 0; j < kSub; ++j) {
+        double rr = y[j] - cf.hh;
+#pragma unroll
+        for (int k = 0; k < D; ++k) rr = fma(-cf.h[k], st[k], rr);
+        rr = (j < nvalid) ? rr : 0.0;
+        r[j] = rr;
+        double nm[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            double v = fma(cf.kA[i], rr, cf.a[i]);
+#pragma unroll
+            for (int k = 0; k < D; ++k) v = fma(cf.A[i][k], st[k], v);
+            nm[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < D; ++i) st[i] = nm[i];
+    }
+}
+
+// backward half: local recursion lam <- G lam + c r from `lam_in` (lane 63: the tile's carry, others zero), reverse wave scan.
+// Returns the lane's inclusive value (lane 0: lam after the tile's first step) and the lane's start value.
+template <int D>
+__device__ __forceinline__ void tile_backward(const Coef<D>& cf, const double* __restrict__ pw_g, const double (&r)[kSub], int lane,
+                                              const double (&lam_in)[D], double (&bend)[D], double (&lstart)[D]) {
+    constexpr int DD = D * D;
+    double lam[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) lam[i] = lam_in[i];
+#pragma unroll
+    for (int j = kSub - 1; j >= 0; --j) {
+        double nl[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            double v = cf.c[i] * r[j];
+#pragma unroll
+            for (int k = 0; k < D; ++k) v = fma(cf.G[i][k], lam[k], v);
+            nl[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < D; ++i) lam[i] = nl[i];
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const int off = 1 << k;
+        double g[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) g[i] = __shfl_down(lam[i], off);
+        const double* __restrict__ M = pw_g + (size_t)(3 + k) * DD;
+        if (lane + off < 64) {
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                double v = lam[i];
+#pragma unroll
+                for (int l = 0; l < D; ++l) v = fma(M[i * D + l], g[l], v);
+                lam[i] = v;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        bend[i] = lam[i];
+        const double v = __shfl_down(lam[i], 1);
+        lstart[i] = (lane == 63) ? lam_in[i] : v;
+    }
+}
+
+// ---- head tiles: per-step gains from the tables, general affine wave scan (matrix, vector) -------------------------------------------
+// One wave walks the th head tiles in order.  Forward: innovations of the head -> tb.h_r, carry into the first stationary workgroup -> MUb[0],
+// sum r^2 / S -> misc[0].
+template <int D>
+__device__ void head_forward(const Tab& tb, const double* __restrict__ y, long long T, int lane) {
+    const int th = (int)tb.hdr[1];
+    const double* __restrict__ ss = tb.ssc;
+    double A[D][D], a[D], h[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) A[i][k] = ss[SS<D>::A + i * D + k];
+        a[i] = ss[SS<D>::a + i];
+        h[i] = ss[SS<D>::h + i];
+    }
+    const double hh = ss[SS<D>::hh];
+    double carry[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) carry[i] = ss[SS<D>::mu0 + i];
+    double acc = 0.0;
+    for (int tile = 0; tile < th; ++tile) {
+        const long long t0 = (long long)tile * kTile + lane * kSub;
+        double yv[kSub];
+        load8(y, t0, T, yv);
+        double M[D][D], mu[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            mu[i] = (lane == 0) ? carry[i] : 0.0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) M[i][k] = (i == k) ? 1.0 : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < kSub; ++j) {
+            double kA[D];
+#pragma unroll
+            for (int i = 0; i < D; ++i) kA[i] = tb.h_kA[(t0 + j) * D + i];
+            double rr = yv[j] - hh;
+#pragma unroll
+            for (int k = 0; k < D; ++k) rr = fma(-h[k], mu[k], rr);
+            double nm[D], hM[D], nM[D][D];
+#pragma unroll
+            for (int c = 0; c < D; ++c) {
+                double v = 0.0;
+#pragma unroll
+                for (int k = 0; k < D; ++k) v = fma(h[k], M[k][c], v);
+                hM[c] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                double v = fma(kA[i], rr, a[i]);
+#pragma unroll
+                for (int k = 0; k < D; ++k) v = fma(A[i][k], mu[k], v);
+                nm[i] = v;
+#pragma unroll
+                for (int c = 0; c < D; ++c) {
+                    double w = -kA[i] * hM[c];
+#pragma unroll
+                    for (int k = 0; k < D; ++k) w = fma(A[i][k], M[k][c], w);
+                    nM[i][c] = w;               // (A - kA h') M
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                mu[i] = nm[i];
+#pragma unroll
+                for (int c = 0; c < D; ++c) M[i][c] = nM[i][c];
+            }
+        }
+        // inclusive scan of (M, mu): later o earlier = (M_l M_e, M_l mu_e + mu_l)
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int off = 1 << k;
+            double g[D], Mg[D][D];
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                g[i] = __shfl_up(mu[i], off);
+#pragma unroll
+                for (int c = 0; c < D; ++c) Mg[i][c] = __shfl_up(M[i][c], off);
+            }
+            if (lane >= off) {
+                double nM[D][D];
+#pragma unroll
+                for (int i = 0; i < D; ++i) {
+                    double v = mu[i];
+#pragma unroll
+                    for (int l = 0; l < D; ++l) v = fma(M[i][l], g[l], v);
+                    mu[i] = v;
+#pragma unroll
+                    for (int c = 0; c < D; ++c) {
+                        double w = 0.0;
+#pragma unroll
+                        for (int l = 0; l < D; ++l) w = fma(M[i][l], Mg[l][c], w);
+                        nM[i][c] = w;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < D; ++i)
+#pragma unroll
+                    for (int c = 0; c < D; ++c) M[i][c] = nM[i][c];
+            }
+        }
+        double st[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            const double v = __shfl_up(mu[i], 1);
+            st[i] = (lane == 0) ? carry[i] : v;
+            carry[i] = __shfl(mu[i], 63);
+        }
+#pragma unroll
+        for (int j = 0; j < kSub; ++j) {
+            double rr = yv[j] - hh;
+#pragma unroll
+            for (int k = 0; k < D; ++k) rr = fma(-h[k], st[k], rr);
+            tb.h_r[t0 + j] = rr;
+            acc = fma(rr * rr, tb.h_iS[t0 + j], acc);
+            double nm[D];
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                double v = fma(tb.h_kA[(t0 + j) * D + i], rr, a[i]);
+#pragma unroll
+                for (int k = 0; k < D; ++k) v = fma(A[i][k], st[k], v);
+                nm[i] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < D; ++i) st[i] = nm[i];
+        }
+    }
+    // fixed-order wave sum
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_down(acc, off);
+    if (lane == 0) {
+        tb.misc[0] = acc;
+#pragma unroll
+        for (int i = 0; i < D; ++i) tb.MUb[i] = carry[i];
+    }
+}
+
+// Backward over the head tiles from LAMb[0]: posterior marginals of the head.
+template <int D>
+__device__ void head_backward(const Tab& tb, const double* __restrict__ y, const double* __restrict__ Rnew, int rnew_per_step,
+                              double* __restrict__ mean, double* __restrict__ var, long long T, int lane) {
+    constexpr int DD = D * D;
+    const int th = (int)tb.hdr[1];
+    const double* __restrict__ ss = tb.ssc;
+    double h[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) h[i] = ss[SS<D>::h + i];
+    double carry[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) carry[i] = tb.LAMb[i];
+    const double rn0 = Rnew[0];
+    for (int tile = th - 1; tile >= 0; --tile) {
+        const long long t0 = (long long)tile * kTile + lane * kSub;
+        double yv[kSub], rv[kSub];
+        load8(y, t0, T, yv);
+        load8(tb.h_r, t0, T, rv);
+        double M[D][D], lam[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            lam[i] = (lane == 63) ? carry[i] : 0.0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) M[i][k] = (i == k) ? 1.0 : 0.0;
+        }
+#pragma unroll
+        for (int j = kSub - 1; j >= 0; --j) {
+            const double* __restrict__ Gt = tb.h_G + (size_t)(t0 + j) * DD;
+            double nl[D], nM[D][D];
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                double v = tb.h_c[(t0 + j) * D + i] * rv[j];
+#pragma unroll
+                for (int k = 0; k < D; ++k) v = fma(Gt[i * D + k], lam[k], v);
+                nl[i] = v;
+#pragma unroll
+                for (int c = 0; c < D; ++c) {
+                    double w = 0.0;
+#pragma unroll
+                    for (int k = 0; k < D; ++k) w = fma(Gt[i * D + k], M[k][c], w);
+                    nM[i][c] = w;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                lam[i] = nl[i];
+#pragma unroll
+                for (int c = 0; c < D; ++c) M[i][c] = nM[i][c];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int off = 1 << k;
+            double g[D], Mg[D][D];
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                g[i] = __shfl_down(lam[i], off);
+#pragma unroll
+                for (int c = 0; c < D; ++c) Mg[i][c] = __shfl_down(M[i][c], off);
+            }
+            if (lane + off < 64) {
+                double nM[D][D];
+#pragma unroll
+                for (int i = 0; i < D; ++i) {
+                    double v = lam[i];
+#pragma unroll
+                    for (int l = 0; l < D; ++l) v = fma(M[i][l], g[l], v);
+                    lam[i] = v;
+#pragma unroll
+                    for (int c = 0; c < D; ++c) {
+                        double w = 0.0;
+#pragma unroll
+                        for (int l = 0; l < D; ++l) w = fma(M[i][l], Mg[l][c], w);
+                        nM[i][c] = w;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < D; ++i)
+#pragma unroll
+                    for (int c = 0; c < D; ++c) M[i][c] = nM[i][c];
+            }
+        }
+        double st[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            const double v = __shfl_down(lam[i], 1);
+            st[i] = (lane == 63) ? carry[i] : v;
+            carry[i] = __shfl(lam[i], 0);
+        }
+        double mo[kSub], vo[kSub];
+        if (rnew_per_step) load8(Rnew, t0, T, vo);
+#pragma unroll
+        for (int j = kSub - 1; j >= 0; --j) {
+            const double* __restrict__ Gt = tb.h_G + (size_t)(t0 + j) * DD;
+            double m = fma(-tb.h_rS[t0 + j], rv[j], yv[j]);
+#pragma unroll
+            for (int k = 0; k < D; ++k) m = fma(h[k], st[k], m);
+            mo[j] = m;
+            vo[j] = tb.h_vb[t0 + j] + (rnew_per_step ? vo[j] : rn0);
+            double nl[D];
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                double v = tb.h_c[(t0 + j) * D + i] * rv[j];
+#pragma unroll
+                for (int k = 0; k < D; ++k) v = fma(Gt[i * D + k], st[k], v);
+                nl[i] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < D; ++i) st[i] = nl[i];
+        }
+        store8(mean, t0, T, mo);
+        store8(var, t0, T, vo);
+    }
+}
+
+// the head's two recursions as kernels of their own (one wave): their matrix scans need ~4x the registers of the stationary tiles
+template <int D>
+__global__ __launch_bounds__(64) void k_head_forward(Tab tb, const double* __restrict__ y, long long T) {
+    if (tb.hdr[0] == 0) return;
+    head_forward<D>(tb, y, T, threadIdx.x);
+}
+template <int D>
+__global__ __launch_bounds__(64) void k_head_backward(Tab tb, const double* __restrict__ y, const double* __restrict__ Rnew, int rnew_per_step,
+                                                      double* __restrict__ mean, double* __restrict__ var, long long T) {
+    if (tb.hdr[0] == 0) return;
+    head_backward<D>(tb, y, Rnew, rnew_per_step, mean, var, T, threadIdx.x);
+}
+
+template <int D>
+__device__ __forceinline__ void matvec_acc(const double* __restrict__ M, const double (&x)[D], double (&y)[D]) {     // y += M x
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        double v = y[i];
+#pragma unroll
+        for (int l = 0; l < D; ++l) v = fma(M[i * D + l], x[l], v);
+        y[i] = v;
+    }
+}
+
+// Carries of the kBlk tiles of a workgroup from the workgroup's own (mu at its first step, lam behind its last step) and the tiles'
+// zero-carry elements F, B0: mu_{w+1} = Phi^512 mu_w + F_w; lam_w (behind tile w) = G^512 lam_{w+1} + B0_{w+1} - C_{w+1} mu_{w+1}, where
+// the coupling C is B_512 for a full tile, Blt for the last (ragged) tile of the series and nothing for a tile beyond the end.
+// Run by ONE thread; sMu [kBlk + 1][D] and sLam [kBlk][D] live in LDS (a handful of wave-uniform values would otherwise occupy a
+// vector register each in all 64 lanes).  Returns mu behind the last tile in sMu[kBlk] and lam in front of the first in lam_out.
+template <int D, class FGet, class BGet>
+__device__ __forceinline__ void block_carries(const double* __restrict__ cst, FGet F, BGet B0, long long tile0, long long ntiles,
+                                              const double (&mu_in)[D], const double (&lam_in)[D], double (*sMu)[D], double (*sLam)[D],
+                                              double (&lam_out)[D]) {
+    constexpr int DD = D * D;
+    const double* __restrict__ M = cst + CL<D>::pphi + 9 * DD;
+    const double* __restrict__ G = cst + CL<D>::pg + 9 * DD;
+    double mu[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) mu[i] = sMu[0][i] = mu_in[i];
+#pragma unroll
+    for (int w = 0; w < kBlk; ++w) {
+        double n[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) n[i] = F(w, i);
+        matvec_acc<D>(M, mu, n);
+#pragma unroll
+        for (int i = 0; i < D; ++i) mu[i] = sMu[w + 1][i] = n[i];
+    }
+    double l[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) l[i] = lam_in[i];
+#pragma unroll
+    for (int w = kBlk - 1; w >= 0; --w) {
+        double n[D], m[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            sLam[w][i] = l[i];          // behind tile w
+            n[i] = B0(w, i);
+            m[i] = sMu[w][i];
+        }
+        const long long tile = tile0 + w;
+        if (tile < ntiles) {
+            const double* __restrict__ C = cst + (tile == ntiles - 1 ? CL<D>::Blt : CL<D>::B512);
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int k = 0; k < D; ++k) n[i] = fma(-C[i * D + k], m[k], n[i]);
+        }
+        matvec_acc<D>(G, l, n);
+#pragma unroll
+        for (int i = 0; i < D; ++i) l[i] = n[i];
+    }
+#pragma unroll
+    for (int i = 0; i < D; ++i) lam_out[i] = l[i];
+}
+
+// pass 1: the stationary tiles with zero carries -> per-tile elements F, B0 and the workgroup's element (Fb, B0b)
+template <int D, bool POST>
+__global__ __launch_bounds__(256) void k_reduce(const long long* __restrict__ hdr, const double* __restrict__ cst, const double* __restrict__ y,
+                                                double* __restrict__ F, double* __restrict__ B0, double* __restrict__ Fb,
+                                                double* __restrict__ B0b, long long T, long long ntiles) {
+    if (hdr[0] == 0) return;
+    __shared__ double sF[kBlk][D], sB0[kBlk][D], sMu[kBlk + 1][D], sLam[kBlk][D];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long tile0 = hdr[1] + (long long)blockIdx.x * kBlk;
+    if (tile0 >= ntiles) return;            // (the launch is sized for one head tile)
+    const long long tile = tile0 + wave;
+    double fend[D], bend[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) fend[i] = bend[i] = 0.0;
+    if (tile < ntiles) {
+        Coef<D> cf;
+        cf.load(cst);
+        const long long t0 = tile * kTile + lane * kSub;
+        double yv[kSub], r[kSub], zero[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) zero[i] = 0.0;
+        load8(y, t0, T, yv);
+        const long long left = T - t0;
+        const int nvalid = left >= kSub ? kSub : (left > 0 ? (int)left : 0);
+        tile_forward<D>(cf, cst + CL<D>::pphi, yv, nvalid, lane, zero, r, fend);
+        if (POST) {
+            double lst[D];
+            tile_backward<D>(cf, cst + CL<D>::pg, r, lane, zero, bend, lst);
+        }
+    }
+    if (lane == 63) {
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            sF[wave][i] = fend[i];
+            F[tile * D + i] = fend[i];
+        }
+    }
+    if (POST && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            sB0[wave][i] = bend[i];
+            B0[tile * D + i] = bend[i];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double zero[D], lout[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) zero[i] = 0.0;
+        block_carries<D>(cst, [&](int w, int i) { return sF[w][i]; }, [&](int w, int i) { return POST ? sB0[w][i] : 0.0; }, tile0, ntiles, zero,
+                         zero, sMu, sLam, lout);
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            Fb[(long long)blockIdx.x * D + i] = sMu[kBlk][i];
+            if (POST) B0b[(long long)blockIdx.x * D + i] = lout[i];
+        }
+    }
+}
+
+// carries of the workgroups: MUb[b+1] = Phi^2048 MUb[b] + Fb[b] from MUb[0] (head_forward); LAMb[b] = G^2048 LAMb[b+1] + B0b[b] - C MUb[b]
+// from LAMb[nblk] = 0 (C = B_2048, the last workgroup: Blb).  One block of 512 lanes (256 registers each), kQ consecutive elements per lane held in registers
+// (one round trip to memory per direction), Hillis-Steele over the lanes with the powers 2^(11 + log2 kQ + k); series with more than
+// 512 kQ workgroups (T > 1.6e7 at d <= 4) are walked in slices of that many, chained through the slice's end state.
+template <int D, bool POST>
+__global__ __launch_bounds__(512) void k_carry(const long long* __restrict__ hdr, const double* __restrict__ cst, const double* __restrict__ Fb,
+                                                const double* __restrict__ B0b, double* MUb, double* __restrict__ LAMb, long long ntiles) {
+    if (hdr[0] == 0) return;
+    constexpr int DD = D * D;
+    constexpr int kLanes = 512, kRounds = 9;
+    constexpr int lQ = D <= 4 ? 3 : 2, kQ = 1 << lQ;
+    __shared__ double sv[D][kLanes];
+    const int tid = threadIdx.x;
+    const long long N = nblk_max_for(hdr[1], ntiles);
+    const long long slice = (long long)kLanes * kQ;
+    const long long nslices = (N + slice - 1) / slice;
+    auto step = [&](const double* __restrict__ M, double (&s)[D], const double (&el)[D]) {
+        double n[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) n[i] = el[i];
+        matvec_acc<D>(M, s, n);
+#pragma unroll
+        for (int i = 0; i < D; ++i) s[i] = n[i];
+    };
+    auto block_scan = [&](double (&s)[D], const double* __restrict__ pw, bool up) {
+        for (int k = 0; k < kRounds; ++k) {
+            const int off = 1 << k;
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < D; ++i) sv[i][tid] = s[i];
+            __syncthreads();
+            const int src = up ? tid - off : tid + off;
+            if (src >= 0 && src < kLanes) {
+                double g[D];
+#pragma unroll
+                for (int i = 0; i < D; ++i) g[i] = sv[i][src];
+                matvec_acc<D>(pw + (11 + lQ + k) * DD, g, s);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < D; ++i) sv[i][tid] = s[i];
+        __syncthreads();
+    };
+    // ---- forward
+    const double* __restrict__ M = cst + CL<D>::pphi + 11 * DD;
+    double carry[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) carry[i] = MUb[i];
+    for (long long sl = 0; sl < nslices; ++sl) {
+        const long long base = sl * slice + (long long)tid * kQ;
+        double el[kQ][D], s[D];
+#pragma unroll
+        for (int g = 0; g < kQ; ++g) {
+            const long long idx = base + g < N ? base + g : N - 1;         // clamped: unconditional loads, all in flight together
+#pragma unroll
+            for (int i = 0; i < D; ++i) el[g][i] = Fb[idx * D + i];
+        }
+#pragma unroll
+        for (int i = 0; i < D; ++i) s[i] = (tid == 0) ? carry[i] : 0.0;
+#pragma unroll
+        for (int g = 0; g < kQ; ++g)
+            if (base + g < N) step(M, s, el[g]);
+        block_scan(s, cst + CL<D>::pphi, true);
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            s[i] = (tid == 0) ? carry[i] : sv[i][tid > 0 ? tid - 1 : 0];
+            carry[i] = sv[i][kLanes - 1];
+        }
+#pragma unroll
+        for (int g = 0; g < kQ; ++g)
+            if (base + g < N) {
+                if (base + g > 0) {
+#pragma unroll
+                    for (int i = 0; i < D; ++i) MUb[(base + g) * D + i] = s[i];
+                }
+                step(M, s, el[g]);
+            }
+        __syncthreads();
+    }
+    if (!POST) return;
+    __threadfence();
+    __syncthreads();
+    // ---- backward
+    const double* __restrict__ G = cst + CL<D>::pg + 11 * DD;
+#pragma unroll
+    for (int i = 0; i < D; ++i) carry[i] = 0.0;
+    if (tid == 0) {
+#pragma unroll
+        for (int i = 0; i < D; ++i) LAMb[N * D + i] = 0.0;
+    }
+    for (long long sl = nslices - 1; sl >= 0; --sl) {
+        const long long base = sl * slice + (long long)tid * kQ;
+        double el[kQ][D], s[D];
+#pragma unroll
+        for (int g = 0; g < kQ; ++g) {
+            const long long idx = base + g < N ? base + g : N - 1;
+            double mu[D];
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                mu[i] = MUb[idx * D + i];
+                el[g][i] = B0b[idx * D + i];
+            }
+            const double* __restrict__ C = cst + (idx == N - 1 ? CL<D>::Blb : CL<D>::B2048);
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int l = 0; l < D; ++l) el[g][i] = fma(-C[i * D + l], mu[l], el[g][i]);
+        }
+#pragma unroll
+        for (int i = 0; i < D; ++i) s[i] = (tid == kLanes - 1) ? carry[i] : 0.0;
+#pragma unroll
+        for (int g = kQ - 1; g >= 0; --g)
+            if (base + g < N) step(G, s, el[g]);
+        block_scan(s, cst + CL<D>::pg, false);
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            s[i] = (tid == kLanes - 1) ? carry[i] : sv[i][tid < kLanes - 1 ? tid + 1 : kLanes - 1];
+            carry[i] = sv[i][0];
+        }
+#pragma unroll
+        for (int g = kQ - 1; g >= 0; --g)
+            if (base + g < N) {
+                step(G, s, el[g]);
+#pragma unroll
+                for (int i = 0; i < D; ++i) LAMb[(base + g) * D + i] = s[i];
+            }
+        __syncthreads();
+    }
+}
+
+// pass 2: the stationary tiles with their carries -> sum r^2, posterior marginals
+template <int D, bool POST>
+__global__ __launch_bounds__(256, (D <= 3 ? 4 : 1)) void k_apply(const long long* __restrict__ hdr, const double* __restrict__ cst, const double* __restrict__ y,
+                                               const double* __restrict__ Rnew, int rnew_per_step, const double* __restrict__ F,
+                                               const double* __restrict__ B0, const double* __restrict__ MUb, const double* __restrict__ LAMb,
+                                               const double* __restrict__ t_vb, double* __restrict__ mean, double* __restrict__ var,
+                                               double* __restrict__ SSQ, long long T, long long ntiles) {
+    if (hdr[0] == 0) return;
+    __shared__ double sacc[kBlk], sMu[kBlk + 1][D], sLam[kBlk][D];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long tile0 = hdr[1] + (long long)blockIdx.x * kBlk;
+    if (tile0 >= ntiles) return;
+    const long long tile = tile0 + wave;
+    double acc = 0.0;
+    if (threadIdx.x == 0) {      // the workgroup's carries -> its tiles'
+        double mu_in[D], lam_in[D], lout[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            mu_in[i] = MUb[(long long)blockIdx.x * D + i];
+            lam_in[i] = POST ? LAMb[((long long)blockIdx.x + 1) * D + i] : 0.0;
+        }
+        block_carries<D>(cst, [&](int w, int i) { return F[(tile0 + w) * D + i]; }, [&](int w, int i) { return POST ? B0[(tile0 + w) * D + i] : 0.0; },
+                         tile0, ntiles, mu_in, lam_in, sMu, sLam, lout);
+    }
+    __syncthreads();
+    if (tile < ntiles) {
+        double cin[D], lin[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            cin[i] = (lane == 0) ? sMu[wave][i] : 0.0;
+            lin[i] = (lane == 63) ? sLam[wave][i] : 0.0;
+        }
+        Coef<D> cf;
+        cf.load(cst);
+        const long long t0 = tile * kTile + lane * kSub;
+        double yv[kSub], r[kSub], fend[D];
+        load8(y, t0, T, yv);
+        const long long left = T - t0;
+        const int nvalid = left >= kSub ? kSub : (left > 0 ? (int)left : 0);
+        tile_forward<D>(cf, cst + CL<D>::pphi, yv, nvalid, lane, cin, r, fend);
+#pragma unroll
+        for (int j = 0; j < kSub; ++j) acc = fma(r[j], r[j], acc);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) acc += __shfl_down(acc, off);
+        if (POST) {
+            double bend[D], lst[D];
+            tile_backward<D>(cf, cst + CL<D>::pg, r, lane, lin, bend, lst);
+            double mo[kSub], vo[kSub];
+            if (rnew_per_step) load8(Rnew, t0, T, vo);
+            const double rn0 = Rnew[0];
+            const double vb = cst[SS<D>::vb];
+            const long long n1 = hdr[3];
+#pragma unroll
+            for (int j = kSub - 1; j >= 0; --j) {
+                double m = fma(-cf.rS, r[j], yv[j]);
+#pragma unroll
+                for (int k = 0; k < D; ++k) m = fma(cf.h[k], lst[k], m);
+                mo[j] = m;
+                const long long back = T - 1 - (t0 + j);
+                const double vbt = (back >= 0 && back < n1) ? t_vb[back] : vb;
+                vo[j] = vbt + (rnew_per_step ? vo[j] : rn0);
+                double nl[D];
+#pragma unroll
+                for (int i = 0; i < D; ++i) {
+                    double v = cf.c[i] * r[j];
+#pragma unroll
+                    for (int k = 0; k < D; ++k) v = fma(cf.G[i][k], lst[k], v);
+                    nl[i] = v;
+                }
+#pragma unroll
+                for (int i = 0; i < D; ++i) lst[i] = nl[i];
+            }
+            store8(mean, t0, T, mo);
+            store8(var, t0, T, vo);
+        }
+    }
+    if (lane == 0) sacc[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) SSQ[blockIdx.x] = ((sacc[0] + sacc[1]) + sacc[2]) + sacc[3];
+}
+
+// log marginal likelihood from the pieces (fixed summation order) and the status of the call
+template <int D>
+__global__ __launch_bounds__(1024) void k_final(Tab tb, long long T, long long ntiles, double* result) {
+    __shared__ double sm[1024];
+    const int tid = threadIdx.x;
+    if (tb.hdr[0] == 0) {
+        if (tid == 0) {
+            result[6] = kStatusNotApplicable;
+            result[7] = (double)tb.hdr[2];
+            if (tb.hdr[4] != 0) result[2] = 1.0;
+        }
+        return;
+    }
+    const long long N = nblk_max_for(tb.hdr[1], ntiles);
+    double acc = 0.0;
+    for (long long i = tid; i < N; i += 8 * 1024) {     // eight loads in flight per lane, fixed summation order
+        double v[8];
+#pragma unroll
+        for (int g = 0; g < 8; ++g) v[g] = (i + g * 1024 < N) ? tb.SSQ[i + g * 1024] : 0.0;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) acc += v[g];
+    }
+    sm[tid] = acc;
+    __syncthreads();
+    for (int off = 512; off >= 1; off >>= 1) {
+        if (tid < off) sm[tid] += sm[tid + off];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const double* ss = tb.ssc;
+        const long long n0 = tb.hdr[2];
+        const double quad = tb.misc[0] + ss[SS<D>::iS] * sm[0];
+        const double logdet = ss[SS<D>::LS] + (double)(T - n0) * ss[SS<D>::logS];
+        result[0] = -0.5 * ((double)T * kLog2Pi + logdet + quad);
+        result[6] = kStatusRan;
+        result[7] = (double)n0;
+    }
+}
+
+}  // namespace
+
+// =================================================================================================================================
+// host side
+// =================================================================================================================================
+struct Engine {
+    void* slab = nullptr;
+    size_t cap = 0;
+    int d = 0;
+    long long ntiles = 0;
+    Tab tb{};
+};
+
+Engine* create() { return new Engine(); }
+void destroy(Engine* e) {
+    if (!e) return;
+    if (e->slab) (void)hipFree(e->slab);
+    delete e;
+}
+bool supports(int d) { return d >= 1 && d <= kMaxD; }
+
+namespace {
+
+hipError_t ensure(Engine* e, int d, long long ntiles) {
+    if (e->slab && e->d == d && e->ntiles >= ntiles) return hipSuccess;
+    const size_t DD = (size_t)d * d;
+    const size_t nhmax = (size_t)kHeadMaxTiles * kTile;
+    size_t off = 0;
+    auto take = [&](size_t ndoubles) {
+        const size_t o = off;
+        off += (ndoubles + 7) & ~(size_t)7;      // 64-byte granules
+        return o;
+    };
+    // constant block, as CL<D> lays it out
+    const size_t ss_size = 2 * DD + 5 * (size_t)d + 6, c_pphi = (ss_size + 7) & ~(size_t)7, c_pg = c_pphi + kPowN * DD, c_size = c_pg + kPowN * DD + 4 * DD;
+    const size_t o_hdr = take(8), o_cst = take(c_size);
+    const size_t o_hkA = take(nhmax * d), o_hrS = take(nhmax), o_hiS = take(nhmax), o_hG = take(nhmax * DD), o_hc = take(nhmax * d),
+                 o_hvb = take(nhmax), o_hr = take(nhmax);
+    const size_t o_sPf = take((nhmax + 1) * DD), o_sPp = take((nhmax + 1) * DD), o_sL = take((nhmax + 1) * DD), o_sPs = take((nhmax + 1) * DD);
+    const size_t o_tvb = take(kTailMax), o_tPs = take((size_t)kTailMax * DD);
+    const size_t nt = (size_t)ntiles + 8, nb = (size_t)(ntiles + kBlk - 1) / kBlk + 2;
+    const size_t o_F = take(nt * d), o_B0 = take(nt * d), o_Fb = take(nb * d), o_B0b = take(nb * d), o_MUb = take(nb * d), o_LAMb = take(nb * d),
+                 o_SSQ = take(nb), o_misc = take(16);
+    const size_t bytes = off * sizeof(double);
+    if (bytes > e->cap) {
+        if (e->slab) (void)hipFree(e->slab);
+        e->slab = nullptr;
+        e->cap = 0;
+        hipError_t rc = hipMalloc(&e->slab, bytes);
+        if (rc != hipSuccess) return rc;
+        e->cap = bytes;
+    }
+    double* b = static_cast<double*>(e->slab);
+    Tab& tb = e->tb;
+    tb.hdr = reinterpret_cast<long long*>(b + o_hdr);
+    tb.cst = b + o_cst; tb.ssc = tb.cst; tb.pw_phi = tb.cst + c_pphi; tb.pw_g = tb.cst + c_pg;
+    tb.h_kA = b + o_hkA; tb.h_rS = b + o_hrS; tb.h_iS = b + o_hiS; tb.h_G = b + o_hG; tb.h_c = b + o_hc; tb.h_vb = b + o_hvb; tb.h_r = b + o_hr;
+    tb.s_Pf = b + o_sPf; tb.s_Pp = b + o_sPp; tb.s_L = b + o_sL; tb.s_Ps = b + o_sPs;
+    tb.t_vb = b + o_tvb; tb.t_Ps = b + o_tPs;
+    tb.F = b + o_F; tb.B0 = b + o_B0; tb.Fb = b + o_Fb; tb.B0b = b + o_B0b; tb.MUb = b + o_MUb; tb.LAMb = b + o_LAMb; tb.SSQ = b + o_SSQ;
+    tb.misc = b + o_misc;
+    e->d = d;
+    e->ntiles = ntiles;
+    return hipSuccess;
+}
+
+struct Scope {
+    const Hooks& hk;
+    Scope(const Hooks& h, const char* name) : hk(h) { if (hk.begin) hk.begin(hk.ctx, name); }
+    ~Scope() { if (hk.end) hk.end(hk.ctx); }
+};
+
+template <int D>
+int enqueue_d(Engine* e, hipStream_t st, const ModelDev& m, const CallDev& c, const Hooks& hk) {
+    static_assert(CL<D>::pphi == ((2 * D * D + 5 * D + 6 + 7) & ~7), "ensure() mirrors CL<D>");
+    const long long T = c.T;
+    const long long ntiles = (T + kTile - 1) / kTile;
+    const bool post = c.mean != nullptr;
+    const Tab tb = e->tb;
+    const unsigned blocks = (unsigned)((ntiles - 1 + kBlk - 1) / kBlk);      // workgroups of the stationary tiles if the head is one tile
+    {
+        Scope s(hk, "k_steady_setup");
+        hipLaunchKernelGGL(k_setup<D>, dim3(1), dim3(64), 0, st, m, tb, T);
+    }
+    if (blocks == 0) {      // a series of one tile: k_setup has found that the engine does not apply
+        Scope s(hk, "k_steady_final");
+        hipLaunchKernelGGL(k_final<D>, dim3(1), dim3(1024), 0, st, tb, T, ntiles, c.result);
+        return (int)hipGetLastError();
+    }
+    {
+        Scope s(hk, "k_steady_head_forward");
+        hipLaunchKernelGGL(k_head_forward<D>, dim3(1), dim3(64), 0, st, tb, c.y, T);
+    }
+    if (post) {
+        { Scope s(hk, "k_steady_reduce<post>"); hipLaunchKernelGGL((k_reduce<D, true>), dim3(blocks), dim3(256), 0, st, tb.hdr, tb.cst, c.y, tb.F, tb.B0, tb.Fb, tb.B0b, T, ntiles); }
+        { Scope s(hk, "k_steady_carry<post>"); hipLaunchKernelGGL((k_carry<D, true>), dim3(1), dim3(512), 0, st, tb.hdr, tb.cst, tb.Fb, tb.B0b, tb.MUb, tb.LAMb, ntiles); }
+        { Scope s(hk, "k_steady_apply<post>"); hipLaunchKernelGGL((k_apply<D, true>), dim3(blocks), dim3(256), 0, st, tb.hdr, tb.cst, c.y, c.Rnew, c.rnew_per_step, tb.F, tb.B0, tb.MUb, tb.LAMb, tb.t_vb, c.mean, c.var, tb.SSQ, T, ntiles); }
+        { Scope s(hk, "k_steady_head_backward"); hipLaunchKernelGGL(k_head_backward<D>, dim3(1), dim3(64), 0, st, tb, c.y, c.Rnew, c.rnew_per_step, c.mean, c.var, T); }
+    } else {
+        { Scope s(hk, "k_steady_reduce<lml>"); hipLaunchKernelGGL((k_reduce<D, false>), dim3(blocks), dim3(256), 0, st, tb.hdr, tb.cst, c.y, tb.F, tb.B0, tb.Fb, tb.B0b, T, ntiles); }
+        { Scope s(hk, "k_steady_carry<lml>"); hipLaunchKernelGGL((k_carry<D, false>), dim3(1), dim3(512), 0, st, tb.hdr, tb.cst, tb.Fb, tb.B0b, tb.MUb, tb.LAMb, ntiles); }
+        { Scope s(hk, "k_steady_apply<lml>"); hipLaunchKernelGGL((k_apply<D, false>), dim3(blocks), dim3(256), 0, st, tb.hdr, tb.cst, c.y, (const double*)nullptr, 0, tb.F, tb.B0, tb.MUb, tb.LAMb, tb.t_vb, (double*)nullptr, (double*)nullptr, tb.SSQ, T, ntiles); }
+    }
+    {
+        Scope s(hk, "k_steady_final");
+        hipLaunchKernelGGL(k_final<D>, dim3(1), dim3(1024), 0, st, tb, T, ntiles, c.result);
+    }
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+int enqueue(Engine* e, hipStream_t stream, const ModelDev& m, const CallDev& c, const Hooks& hk, std::string* err) {
+    if (!e || !supports(m.d) || c.T <= 0 || !c.y || !c.result || (c.mean && (!c.var || !c.Rnew))) {
+        if (err) *err = "tgp_steady::enqueue: bad argument";
+        return (int)hipErrorInvalidValue;
+    }
+    const long long ntiles = (c.T + kTile - 1) / kTile;
+    hipError_t rc = ensure(e, m.d, ntiles);
+    if (rc != hipSuccess) {
+        if (err) *err = std::string("tgp_steady: hipMalloc: ") + hipGetErrorString(rc);
+        return (int)rc;
+    }
+    int r = 0;
+    switch (m.d) {
+        case 1: r = enqueue_d<1>(e, stream, m, c, hk); break;
+        case 2: r = enqueue_d<2>(e, stream, m, c, hk); break;
+        case 3: r = enqueue_d<3>(e, stream, m, c, hk); break;
+        case 4: r = enqueue_d<4>(e, stream, m, c, hk); break;
+        case 5: r = enqueue_d<5>(e, stream, m, c, hk); break;
+        case 6: r = enqueue_d<6>(e, stream, m, c, hk); break;
+        case 7: r = enqueue_d<7>(e, stream, m, c, hk); break;
+        case 8: r = enqueue_d<8>(e, stream, m, c, hk); break;
+        default: r = (int)hipErrorInvalidValue;
+    }
+    if (r != 0 && err) *err = std::string("tgp_steady: launch: ") + hipGetErrorString((hipError_t)r);
+    return r;
+}
+
+int last_info(Engine* e, hipStream_t stream, int64_t out[4]) {
+    if (!e || !e->slab) return (int)hipErrorInvalidValue;
+    long long h[8];
+    double misc[16];
+    hipError_t rc = hipMemcpyAsync(h, e->tb.hdr, sizeof h, hipMemcpyDeviceToHost, stream);
+    if (rc == hipSuccess) rc = hipMemcpyAsync(misc, e->tb.misc, sizeof misc, hipMemcpyDeviceToHost, stream);
+    if (rc == hipSuccess) rc = hipStreamSynchronize(stream);
+    if (rc != hipSuccess) return (int)rc;
+    if (std::getenv("TGP_STEADY_DEBUG") != nullptr)      // phases of k_setup in microseconds (100 MHz wall clock)
+        fprintf(stderr, "[tgp steady2] n0 %lld n1 %lld head tiles %lld applies %lld | setup: filter cov %.1f us, gains %.1f, tail %.1f, head cov %.1f, variances %.1f, powers %.1f\n",
+                h[2], h[3], h[1], h[0], (misc[9] - misc[8]) * 0.01, (misc[10] - misc[9]) * 0.01, (misc[11] - misc[10]) * 0.01, (misc[12] - misc[11]) * 0.01,
+                0.0, (misc[13] - misc[12]) * 0.01);
+    out[0] = h[2];
+    out[1] = h[3];
+    out[2] = h[1];
+    out[3] = h[0];
+    return 0;
+}
+
+}  // namespace tgp_steady
