@@ -98,22 +98,26 @@ if __name__ == "__main__":
     ok &= case(("matern32",), 0.1, 2100)
     ok &= case(("matern12",), 0.1, 700)
     ok &= case(("matern52",), 0.1, 10_000, mean=("const", 1.5))
-    ok &= case(("matern52", "matern32"), 0.1, 5000)
-    ok &= case(("matern52", "matern52"), 0.1, 5000)
-    ok &= case(("matern52", "matern12"), 0.1, 4099)
+    ok &= case(("sum", ("matern52",), ("matern32",)), 0.1, 5000)
+    ok &= case(("sum", ("matern52",), ("matern52",)), 0.1, 5000)
+    ok &= case(("sum", ("matern52",), ("matern12",)), 0.1, 4099)
+    ok &= case(("matern52",), 0.1, 4099)
     ok &= case(("matern52",), 0.03, 5000)
     ok &= case(("matern52",), 0.01, 20_000)
     ok &= case(("matern32",), 0.1, 10_000, per_step_rnew=True, rnew=0.1)
     ok &= case(("matern52",), 0.1, 600)          # shorter than head + tail: general path
-    ok &= case(("matern52", "matern32", "matern32"), 0.1, 3000)
-    ok &= case(("matern52", "matern52", "matern32"), 0.1, 3000)
+    ok &= case(("sum", ("matern52",), ("matern32",), ("matern32",)), 0.1, 3000)
+    ok &= case(("sum", ("matern52",), ("matern52",), ("matern32",)), 0.1, 3000)
+    ok &= case(("scaled", 2.5, ("stretched", 0.7, ("matern32",))), 0.1, 2500, s2=0.5)
     ok &= case(("matern52",), 0.1, 1_000_003)
     print("ALL OK" if ok else "SOME BAD", flush=True)
     timing(("matern52",), 0.1, 10_000_000)
     timing(("matern52",), 0.1, 10_000_000, steady=1)
     timing(("matern32",), 0.1, 10_000_000)
-    timing(("matern52", "matern32"), 0.1, 10_000_000)
-    timing(("matern52", "matern52"), 0.1, 10_000_000)
+    timing(("sum", ("matern52",), ("matern12",)), 0.1, 10_000_000)
+    timing(("sum", ("matern52",), ("matern32",)), 0.1, 10_000_000)
+    timing(("sum", ("matern52",), ("matern52",)), 0.1, 10_000_000)
+    timing(("sum", ("matern52",), ("matern52",)), 0.1, 10_000_000, steady=1)
     timing(("matern52",), 0.1, 10_000)
     if big:
-        timing(("matern52", "matern12"), 0.1, 100_000_000)
+        timing(("sum", ("matern52",), ("matern12",)), 0.1, 100_000_000)

@@ -34,7 +34,9 @@ struct SS {
 };
 
 constexpr int kPowN = 26;          // powers Phi^(2^k), G^(2^k), k < kPowN (the scans need k <= 23, whatever T)
-constexpr int kBlk = 4;            // tiles (waves) per workgroup of the tile passes: one carry element per workgroup, 2048 steps
+constexpr int kBlk = 8;            // tiles (waves) per workgroup of the tile passes: one carry element per workgroup, 4096 steps
+constexpr int kLogTile = 9, kLogBlk = 12;      // kTile = 2^9, kBlk kTile = 2^12
+constexpr int kBlkThreads = kBlk * 64;
 
 // ---- the constant block: everything the tile passes read through SCALAR loads (written by k_setup only) -------------------------------
 template <int D>
@@ -45,9 +47,12 @@ struct CL {
     static constexpr int pg = pphi + kPowN * DD;             // [kPowN][DD]: G^(2^k)
     static constexpr int B512 = pg + kPowN * DD;             // coupling of a full tile: d(lam at tile start) / d(mu at tile start) = -B
     static constexpr int Blt = B512 + DD;                    // ... of the LAST tile (nv <= 512 valid steps)
-    static constexpr int B2048 = Blt + DD;                   // ... of a full workgroup (kBlk tiles)
-    static constexpr int Blb = B2048 + DD;                   // ... of the last workgroup
-    static constexpr int size = Blb + DD;
+    static constexpr int Bblk = Blt + DD;                   // ... of a full workgroup (kBlk tiles)
+    static constexpr int Blb = Bblk + DD;                   // ... of the last workgroup
+    static constexpr int PT = Blb + DD;                      // [kBlk][DD]: Phi^(512 w), w = 0..kBlk-1   (tile carries inside a workgroup,
+    static constexpr int GT = PT + kBlk * DD;                // [kBlk][DD]: G^(512 w)                      k_apply)
+    static constexpr int KW = GT + kBlk * DD;                // [kBlk][DD]: K_w = G^512 K_{w+1} + B_512 Phi^(512 (w+1)), K_{kBlk-1} = 0
+    static constexpr int size = KW + kBlk * DD;
 };
 
 struct Tab {
@@ -64,6 +69,7 @@ struct Tab {
     double* t_vb;        // [kTailMax]: H Ps H' at step T-1-j
     double* t_Ps;        // [kTailMax][D*D]
     double *F, *B0;      // [ntiles][D] tile elements (zero carries)
+    double *Pw, *Lw;     // [ntiles][D] tile carries when the WORKGROUP's carries are zero (mu at the tile's first step; lam behind its last)
     double* SSQ;         // [nblk] sum r^2 of a workgroup's tiles
     double* misc;        // [0] sum r^2 / S over the head; [8..] cycle stamps of k_setup's phases
 };
@@ -158,18 +164,156 @@ __device__ __forceinline__ void lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// ---- phase (a) + (b), d <= 3: everything in registers, every lane runs the same covariance recursion (no exchange, no memory in the
+// dependent chain); lane (t mod 64) keeps step t's (Pf, Pp), and after every 64 steps the lanes turn them into that step's reverse-time
+// gains (invert_dynamics_lane) in parallel.  Writes the head tables; returns n0 (-1: not settled), the stationary step's values.
 template <int D>
-__global__ __launch_bounds__(64) void k_setup(ModelDev m, Tab tb, long long T) {
+__device__ __forceinline__ int filter_cov_reg(const ModelDev& m, const Tab& tb, int lane, bool& bad, double (&Pss)[D][D], double (&kAss)[D],
+                                              double& Sss, double& LS) {
     constexpr int DD = D * D;
     constexpr int nhmax = kHeadMaxTiles * kTile;
-    constexpr int SB = D <= 6 ? 64 : 32;          // steps of the head staged in LDS at a time (phase d)
-    __shared__ double sP[DD], sT[DD], sPp[DD], sB[DD], sXa[DD], sGa[DD], sXb[DD], sGb[DD];
-    __shared__ double sGt[SB * DD], sLt[SB * DD];
-    const int lane = threadIdx.x;
+    double A[D][D], Q[D][D], hv[D], P[D][D], Pold2[D][D], cPf[D][D], cPp[D][D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        hv[i] = m.H[i];
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            A[i][k] = m.A[i + k * D];
+            Q[i][k] = m.Q[i + k * D];
+            const int r = i < k ? i : k, c = i < k ? k : i;
+            P[i][k] = m.x0[D + c * (c + 1) / 2 + r];
+            Pold2[i][k] = 0.0;
+            cPf[i][k] = cPp[i][k] = 0.0;
+        }
+    }
+    const double R = m.R[0];
+    double* ss = tb.ssc;
+    auto gains = [&](int t) {        // phase (b) for the step this lane has kept
+        double G[D][D], L[D][D];
+        const bool ok = invert_dynamics_lane<D>(m.A, cPf, cPp, G, L);
+        if (!ok) tb.hdr[4] = 1;
+        double K[D], Sv = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            double v = 0.0;
+#pragma unroll
+            for (int l = 0; l < D; ++l) v = fma(hv[l], cPp[l][k], v);
+            K[k] = v;
+            Sv = fma(v, hv[k], Sv);
+        }
+        Sv += R;
+        const double iSv = 1.0 / Sv;
+#pragma unroll
+        for (int r = 0; r < D; ++r) {
+            double v = 0.0;
+#pragma unroll
+            for (int c = 0; c < D; ++c) {
+                v = fma(G[r][c], K[c] * iSv, v);
+                if (t < nhmax) tb.h_G[(size_t)t * DD + r * D + c] = G[r][c];
+                tb.s_L[(size_t)t * DD + r * D + c] = L[r][c];
+            }
+            if (t < nhmax) tb.h_c[t * D + r] = v;
+        }
+    };
+    int tc = -1, n0 = -1;
+    double prod = 1.0;
+    LS = 0.0;
+    for (int t = 0; t <= nhmax; ++t) {
+        double t1[D][D], pp[D][D], V[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                double v = 0.0;
+#pragma unroll
+                for (int k = 0; k < D; ++k) v = fma(A[i][k], (k <= j ? P[k][j] : P[j][k]), v);       // A * Symmetric(P)
+                t1[i][j] = v;
+            }
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                double v = 0.0;
+#pragma unroll
+                for (int k = 0; k < D; ++k) v = fma(t1[i][k], A[j][k], v);
+                pp[i][j] = v + Q[i][j];
+            }
+        double S = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            double v = 0.0;
+#pragma unroll
+            for (int l = 0; l < D; ++l) v = fma(hv[l], pp[l][k], v);
+            V[k] = v;
+            S = fma(v, hv[k], S);
+        }
+        S += R;
+        bad = bad || !(S > 0.0);
+        const double iS = 1.0 / S, rs = 1.0 / sqrt(S);
+        const bool mine = (t & 63) == lane;
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            double v = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) v = fma(A[i][k], V[k] * iS, v);
+            kAss[i] = v;
+            if (mine && t < nhmax) tb.h_kA[t * D + i] = v;
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                cPf[i][j] = mine ? P[i][j] : cPf[i][j];
+                cPp[i][j] = mine ? pp[i][j] : cPp[i][j];
+            }
+        }
+        if (mine && t < nhmax) {
+            tb.h_rS[t] = R * iS;
+            tb.h_iS[t] = iS;
+        }
+        Sss = S;
+        if (tc >= 0) {           // this was the extra iteration from the settled covariance: the stationary step
+            n0 = t;
+            break;
+        }
+        if (t == nhmax) break;
+        prod *= S;
+        if ((t & 3) == 3) {      // log of the product of four innovation variances at a time
+            LS += log(prod);
+            prod = 1.0;
+        }
+        bool moved = false, cyc = t >= 1;
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                const double Pn = pp[i][j] - (V[i] * rs) * (V[j] * rs);
+                moved = moved || fabs(Pn - P[i][j]) > kTol * 0.5 * (pp[i][i] + pp[j][j]);
+                cyc = cyc && (Pn == Pold2[i][j]);
+                Pold2[i][j] = P[i][j];
+                P[i][j] = Pn;
+            }
+        if ((t & 63) == 63) gains(t - 63 + lane);
+        if (!moved || cyc) tc = t;
+    }
+    LS += log(prod);
+    if (n0 >= 0 && (n0 & ~63) + lane <= n0) gains((n0 & ~63) + lane);
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = 0; j < D; ++j) Pss[i][j] = P[i][j];
+    (void)ss;
+    return n0;
+}
+
+// ---- phase (a) + (b), d >= 4: lane (i, j) owns element (i, j) of every matrix, LDS is the exchange (a d x d product costs a lane d
+// multiply-adds instead of d^3); the steps' (Pf, Pp) go to scratch and the gains are computed afterwards, one step per lane.
+template <int D>
+__device__ __forceinline__ int filter_cov_lds(const ModelDev& m, const Tab& tb, int lane, bool& bad, double* sP, double* sT, double* sPp,
+                                              double (&kAss)[D], double& Sss, double& LS) {
+    constexpr int DD = D * D;
+    constexpr int nhmax = kHeadMaxTiles * kTile;
     const bool act = lane < DD;
     const int e = act ? lane : 0;
     const int i = e / D, j = e % D;
-    double Ai[D], Aj[D], hv[D];
+    double Ai[D], Aj[D], hv[D], Arow[D];
 #pragma unroll
     for (int k = 0; k < D; ++k) {
         Ai[k] = m.A[i + k * D];
@@ -182,17 +326,10 @@ __global__ __launch_bounds__(64) void k_setup(ModelDev m, Tab tb, long long T) {
         const int r = imin(i, j), c = imax(i, j);
         if (act) sP[e] = m.x0[D + c * (c + 1) / 2 + r];
     }
-    if (lane == 0) {
-        tb.hdr[4] = 0;
-        tb.misc[8] = (double)wall_clock64();
-    }
     lds_sync();
-
-    // ---- (a) filter covariance until it no longer changes ------------------------------------------------------------------------
-    double Pold2 = 0.0, LS = 0.0;
+    double Pold2 = 0.0, prod = 1.0;
     int tc = -1, n0 = -1;
-    bool bad = false;
-    double V[D], iS = 0.0, S = 0.0, kAi = 0.0;
+    LS = 0.0;
     for (int t = 0; t <= nhmax; ++t) {
         const double Pf = sP[e];
         double t1 = 0.0;
@@ -206,7 +343,7 @@ __global__ __launch_bounds__(64) void k_setup(ModelDev m, Tab tb, long long T) {
         pp += Qij;
         if (act) sPp[e] = pp;
         lds_sync();
-        S = 0.0;
+        double V[D], S = 0.0;
 #pragma unroll
         for (int k = 0; k < D; ++k) {
             double v = 0.0;
@@ -217,14 +354,20 @@ __global__ __launch_bounds__(64) void k_setup(ModelDev m, Tab tb, long long T) {
         }
         S += R;
         bad = bad || !(S > 0.0);
-        iS = 1.0 / S;
-        const double rs = 1.0 / sqrt(S);
+        const double iS = 1.0 / S, rs = 1.0 / sqrt(S);
         const double Pn = pp - (V[i] * rs) * (V[j] * rs);
-        kAi = 0.0;
+        // (every lane needs the whole stationary kA afterwards: rows of A from memory, d^2 multiply-adds, only d of them new per lane)
 #pragma unroll
-        for (int k = 0; k < D; ++k) kAi = fma(Ai[k], V[k] * iS, kAi);
+        for (int r = 0; r < D; ++r) {
+#pragma unroll
+            for (int k = 0; k < D; ++k) Arow[k] = (r == i) ? Ai[k] : ((r == j) ? Aj[k] : m.A[r + k * D]);
+            double v = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) v = fma(Arow[k], V[k] * iS, v);
+            kAss[r] = v;
+        }
         if (t < nhmax) {
-            if (act && j == 0) tb.h_kA[t * D + i] = kAi;
+            if (act && j == 0) tb.h_kA[t * D + i] = kAss[i];
             if (lane == 0) {
                 tb.h_rS[t] = R * iS;
                 tb.h_iS[t] = iS;
@@ -234,12 +377,17 @@ __global__ __launch_bounds__(64) void k_setup(ModelDev m, Tab tb, long long T) {
             tb.s_Pf[(size_t)t * DD + e] = Pf;
             tb.s_Pp[(size_t)t * DD + e] = pp;
         }
-        if (tc >= 0) {           // this was the extra iteration from the settled covariance: the stationary step
+        Sss = S;
+        if (tc >= 0) {
             n0 = t;
             break;
         }
         if (t == nhmax) break;
-        LS += log(S);
+        prod *= S;
+        if ((t & 3) == 3) {
+            LS += log(prod);
+            prod = 1.0;
+        }
         const double scale = 0.5 * (sPp[i * D + i] + sPp[j * D + j]);
         const bool moved = act && fabs(Pn - Pf) > kTol * scale;
         const bool nocyc = act && !(Pn == Pold2);
@@ -250,43 +398,10 @@ __global__ __launch_bounds__(64) void k_setup(ModelDev m, Tab tb, long long T) {
         lds_sync();
         if (conv) tc = t;
     }
-    const bool settled = n0 >= 0 && n0 < nhmax;      // the head tables hold nhmax steps: th <= kHeadMaxTiles
-    const int th = settled ? n0 / kTile + 1 : 0;
-    const int nh = th * kTile;
-    if (!settled || bad) {
-        if (lane == 0) {
-            tb.hdr[0] = 0;
-            tb.hdr[1] = 0;
-            tb.hdr[2] = -1;
-            tb.hdr[3] = -1;
-            tb.hdr[4] = bad ? 1 : 0;
-        }
-        return;
-    }
-    if (lane == 0) tb.misc[9] = (double)wall_clock64();
-    // stationary coefficients (entry n0)
-    double* ss = tb.ssc;
-    if (act) ss[SS<D>::A + e] = Ai[j];
-    if (act && j == 0) {
-        ss[SS<D>::a + i] = m.a[i];
-        ss[SS<D>::h + i] = hv[i];
-        ss[SS<D>::kA + i] = kAi;
-        double v = m.a[i];
-#pragma unroll
-        for (int k = 0; k < D; ++k) v = fma(Ai[k], m.x0[k], v);
-        ss[SS<D>::mu0 + i] = v;
-    }
-    if (lane == 0) {
-        ss[SS<D>::hh] = m.hh[0];
-        ss[SS<D>::rS] = R * iS;
-        ss[SS<D>::iS] = iS;
-        ss[SS<D>::logS] = log(S);
-        ss[SS<D>::LS] = LS;
-    }
-    __threadfence();
+    LS += log(prod);
+    if (n0 < 0) return n0;
+    __threadfence_block();
     __syncthreads();
-
-    // ---- (b) reverse-time gains of the head steps 0..n0, one step per lane ---------------------------------------------------------
     for (int t0 = 0; t0 <= n0; t0 += 64) {
         const int t = t0 + lane;
         if (t <= n0) {
@@ -300,7 +415,6 @@ __global__ __launch_bounds__(64) void k_setup(ModelDev m, Tab tb, long long T) {
                 }
             const bool ok = invert_dynamics_lane<D>(m.A, Pf, Pp, G, L);
             if (!ok) tb.hdr[4] = 1;
-            // K = Pp' H / S (as V above), c = G K
             double K[D], Sv = 0.0;
 #pragma unroll
             for (int k = 0; k < D; ++k) {
@@ -320,130 +434,99 @@ __global__ __launch_bounds__(64) void k_setup(ModelDev m, Tab tb, long long T) {
                     v = fma(G[r][c], K[c] * iSv, v);
                     if (t < nhmax) tb.h_G[(size_t)t * DD + r * D + c] = G[r][c];
                     tb.s_L[(size_t)t * DD + r * D + c] = L[r][c];
-                    if (t == n0) ss[SS<D>::G + r * D + c] = G[r][c];
                 }
                 if (t < nhmax) tb.h_c[t * D + r] = v;
-                if (t == n0) ss[SS<D>::c + r] = v;
             }
         }
     }
-    __threadfence();
-    __syncthreads();
-    bad = tb.hdr[4] != 0;
-    if (lane == 0) tb.misc[10] = (double)wall_clock64();
+    return n0;
+}
 
-    // ---- (c) smoothed covariance backwards from the final filtered state (Ps_{T-1} = P_ss) until it no longer changes --------------
-    double Gi[D], Gj[D];
-#pragma unroll
-    for (int k = 0; k < D; ++k) {
-        Gi[k] = ss[SS<D>::G + i * D + k];
-        Gj[k] = ss[SS<D>::G + j * D + k];
-    }
-    const double Lij = tb.s_L[(size_t)n0 * DD + e];
-    // (sP still holds P_ss: the stationary iteration did not store its result)
-    int n1 = -1;
-    Pold2 = 0.0;
-    for (int jt = 0; jt < kTailMax; ++jt) {
-        const double Ps = sP[e];
-        if (act) tb.t_Ps[(size_t)jt * DD + e] = Ps;
-        double t1 = 0.0;
-#pragma unroll
-        for (int k = 0; k < D; ++k) t1 = fma(Gi[k], sP[imin(k, j) * D + imax(k, j)], t1);
-        const double dii = fabs(sP[i * D + i]), djj = fabs(sP[j * D + j]);
-        if (act) sT[e] = t1;
-        lds_sync();
-        double pn = 0.0;
-#pragma unroll
-        for (int k = 0; k < D; ++k) pn = fma(sT[i * D + k], Gj[k], pn);
-        pn += Lij;
-        const bool moved = act && fabs(pn - Ps) > kTol * 0.5 * (dii + djj);
-        const bool nocyc = act && !(pn == Pold2);
-        const bool conv = !__any(moved) || (jt >= 1 && !__any(nocyc));
-        Pold2 = Ps;
-        lds_sync();
-        if (act) sP[e] = pn;
-        lds_sync();
-        if (conv) {
-            n1 = jt + 1;
-            break;
-        }
-    }
-    const bool applies = !bad && n1 >= 0 && (long long)nh + n1 + 1 <= T;
+template <int D>
+__device__ void head_forward(const Tab& tb, const double* __restrict__ y, long long T, int lane);
+
+// k_setup_core: what the tile passes wait for -- the filter covariance to its stationary value with the head's per-step gains (a, b),
+// the constant block with the powers and couplings (e), and the head's forward recursion (its carry starts the stationary tiles).
+template <int D>
+__global__ __launch_bounds__(64) void k_setup_core(ModelDev m, Tab tb, const double* __restrict__ y, long long T) {
+    constexpr int DD = D * D;
+    constexpr int nhmax = kHeadMaxTiles * kTile;
+    __shared__ double sP[DD], sT[DD], sPp[DD], sB[DD], sXa[DD], sGa[DD], sXb[DD], sGb[DD];
+    const int lane = threadIdx.x;
+    const bool act = lane < DD;
+    const int e = act ? lane : 0;
+    const int i = e / D, j = e % D;
     if (lane == 0) {
-        tb.hdr[0] = applies ? 1 : 0;
-        tb.hdr[1] = th;
-        tb.hdr[2] = n0;
-        tb.hdr[3] = n1;
+        tb.hdr[4] = 0;
+        tb.misc[8] = (double)wall_clock64();
     }
-    if (!applies) return;
-    if (lane == 0) tb.misc[11] = (double)wall_clock64();
-
-    // ---- (d) smoothed covariance of the head: Ps_{n0} = stationary, Ps_{t-1} = G_t Ps_t G_t' + L_t; the gains of SB steps at a time
-    //      are staged in LDS (a dependent global load per step would cost more than the step) --------------------------------------
-    if (act) tb.s_Ps[(size_t)n0 * DD + e] = sP[e];
-    for (int thi = n0; thi >= 1; thi -= SB) {
-        const int tlo = imax(thi - SB + 1, 1);          // steps tlo..thi, thi first
-        const int cnt = thi - tlo + 1;
-        for (int idx = lane; idx < cnt * DD; idx += 64) {
-            sGt[idx] = tb.h_G[(size_t)tlo * DD + idx];
-            sLt[idx] = tb.s_L[(size_t)tlo * DD + idx];
-        }
-        lds_sync();
-        for (int t = thi; t >= tlo; --t) {
-            const double* gt = &sGt[(t - tlo) * DD];
-            double t1 = 0.0;
-#pragma unroll
-            for (int k = 0; k < D; ++k) t1 = fma(gt[i * D + k], sP[imin(k, j) * D + imax(k, j)], t1);
-            if (act) sT[e] = t1;
-            lds_sync();
-            double pn = 0.0;
-#pragma unroll
-            for (int k = 0; k < D; ++k) pn = fma(sT[i * D + k], gt[j * D + k], pn);
-            pn += sLt[(t - tlo) * DD + e];
-            lds_sync();
-            if (act) {
-                sP[e] = pn;
-                tb.s_Ps[(size_t)(t - 1) * DD + e] = pn;
-            }
-            lds_sync();
-        }
-    }
-    __threadfence();
     __syncthreads();
-
-    // ---- (d2) variances, one step per lane; head entries beyond n0 repeat the stationary one -----------------------------------------
-    auto quad = [&](const double* Pm) {     // H Symmetric(P) H'
-        double s = 0.0;
-#pragma unroll
-        for (int c = 0; c < D; ++c) {
+    bool bad = false;
+    double kAss[D], Sss = 1.0, LS = 0.0;
+    int n0;
+    if constexpr (D <= 3) {
+        double Pss[D][D];
+        n0 = filter_cov_reg<D>(m, tb, lane, bad, Pss, kAss, Sss, LS);
+        if (act) {      // the stationary filtered covariance, for k_setup_side
             double v = 0.0;
 #pragma unroll
-            for (int r = 0; r < D; ++r) v = fma(hv[r], Pm[imin(r, c) * D + imax(r, c)], v);
-            s = fma(v, hv[c], s);
-        }
-        return s;
-    };
-    const double vb_ss = quad(&tb.s_Ps[(size_t)n0 * DD]);
-    if (lane == 0) ss[SS<D>::vb] = vb_ss;
-    for (int t = lane; t < n1; t += 64) tb.t_vb[t] = quad(&tb.t_Ps[(size_t)t * DD]);
-    for (int t = lane; t < nh; t += 64) {
-        if (t <= n0) {
-            tb.h_vb[t] = quad(&tb.s_Ps[(size_t)t * DD]);
-        } else {
-            tb.h_vb[t] = vb_ss;
-            tb.h_rS[t] = R * iS;
-            tb.h_iS[t] = iS;
+            for (int r = 0; r < D; ++r)
 #pragma unroll
-            for (int k = 0; k < D; ++k) {
-                tb.h_kA[t * D + k] = ss[SS<D>::kA + k];
-                tb.h_c[t * D + k] = ss[SS<D>::c + k];
-            }
-#pragma unroll
-            for (int k = 0; k < DD; ++k) tb.h_G[(size_t)t * DD + k] = ss[SS<D>::G + k];
+                for (int c = 0; c < D; ++c) v = (r == i && c == j) ? Pss[r][c] : v;
+            tb.s_Pf[(size_t)(n0 >= 0 ? n0 : 0) * DD + e] = v;
         }
+    } else {
+        n0 = filter_cov_lds<D>(m, tb, lane, bad, sP, sT, sPp, kAss, Sss, LS);
     }
-
-    if (lane == 0) tb.misc[12] = (double)wall_clock64();
+    __threadfence_block();
+    __syncthreads();
+    bad = bad || tb.hdr[4] != 0;
+    const bool settled = n0 >= 0 && n0 < nhmax;      // the head tables hold nhmax steps: th <= kHeadMaxTiles
+    const int th = settled ? n0 / kTile + 1 : 0;
+    const int nh = th * kTile;
+    if (lane == 0) {
+        tb.hdr[0] = (settled && !bad && (long long)nh + 2 <= T) ? 1 : 0;      // (k_setup_side may still find the series too short)
+        tb.hdr[1] = th;
+        tb.hdr[2] = settled ? n0 : -1;
+        tb.hdr[3] = -1;
+        tb.hdr[4] = bad ? 1 : 0;
+        tb.misc[9] = (double)wall_clock64();
+    }
+    if (!settled || bad || (long long)nh + 2 > T) return;
+    // stationary coefficients (entry n0; the head recursions read the tables at min(t, n0))
+    double* ss = tb.ssc;
+    const double iS = 1.0 / Sss, R = m.R[0];
+    double hv[D], Ai[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        hv[k] = m.H[k];
+        Ai[k] = m.A[i + k * D];
+    }
+    if (act) {
+        ss[SS<D>::A + e] = Ai[j];
+        ss[SS<D>::G + e] = tb.h_G[(size_t)n0 * DD + e];
+    }
+    if (act && j == 0) {
+        ss[SS<D>::a + i] = m.a[i];
+        ss[SS<D>::h + i] = hv[i];
+        double v = m.a[i];
+#pragma unroll
+        for (int k = 0; k < D; ++k) v = fma(Ai[k], m.x0[k], v);
+        ss[SS<D>::mu0 + i] = v;
+        ss[SS<D>::c + i] = tb.h_c[n0 * D + i];
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) ss[SS<D>::kA + k] = kAss[k];
+        ss[SS<D>::hh] = m.hh[0];
+        ss[SS<D>::rS] = R * iS;
+        ss[SS<D>::iS] = iS;
+        ss[SS<D>::logS] = log(Sss);
+        ss[SS<D>::LS] = LS;
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (lane == 0) tb.misc[10] = (double)wall_clock64();
     // ---- (e) powers Phi^(2^k), G^(2^k); the couplings B_n = sum_{j < n} G^j c h' Phi^j by doubling, B_2n = B_n + G^n B_n Phi^n:
     //      B_512 (a tile), B_2048 (a workgroup), and the two ragged ones -- the last tile's nv valid steps and the last workgroup's nvb --
     //      composed from the B_(2^k) of the bits of nv / nvb --------------------------------------------------------------------------------
@@ -453,8 +536,8 @@ __global__ __launch_bounds__(64) void k_setup(ModelDev m, Tab tb, long long T) {
         const int nv = (int)(T - (ntiles - 1) * kTile);                                  // 1..512
         const int nvb = (int)(T - ((long long)th + (nblk - 1) * kBlk) * kTile);          // 1..2048
         const double ci = ss[SS<D>::c + i];
-        double x = Ai[j] - kAi * hv[j];        // Phi = A - kA h'
-        double g = Gi[j];
+        double x = Ai[j] - kAss[i] * hv[j];        // Phi = A - kA h'
+        double g = ss[SS<D>::G + e];
         double b = ci * hv[j];
         double bl[2] = {0.0, 0.0};
         const int want[2] = {nv, nvb};
@@ -469,14 +552,14 @@ __global__ __launch_bounds__(64) void k_setup(ModelDev m, Tab tb, long long T) {
             if (act) {
                 cst[CL<D>::pphi + k * DD + e] = x;
                 cst[CL<D>::pg + k * DD + e] = g;
-                if (k == 9) cst[CL<D>::B512 + e] = b;
-                if (k == 11) cst[CL<D>::B2048 + e] = b;
+                if (k == kLogTile) cst[CL<D>::B512 + e] = b;
+                if (k == kLogBlk) cst[CL<D>::Bblk + e] = b;
                 sP[e] = x;
                 sT[e] = g;
                 sB[e] = b;
             }
             lds_sync();
-            if (k < 11) {
+            if (k < kLogBlk) {
 #pragma unroll
                 for (int w = 0; w < 2; ++w) {
                     if ((want[w] >> k) & 1) {       // append a block of 2^k steps to the composition: Bl += Ga B_(2^k) Xa
@@ -521,14 +604,186 @@ __global__ __launch_bounds__(64) void k_setup(ModelDev m, Tab tb, long long T) {
             g = g2;
             lds_sync();
         }
-        __threadfence();
+        __threadfence_block();
         __syncthreads();
         if (act) {
             cst[CL<D>::Blt + e] = (nv == kTile) ? cst[CL<D>::B512 + e] : bl[0];
-            cst[CL<D>::Blb + e] = (nvb == kBlk * kTile) ? cst[CL<D>::B2048 + e] : bl[1];
+            cst[CL<D>::Blb + e] = (nvb == kBlk * kTile) ? cst[CL<D>::Bblk + e] : bl[1];
+        }
+        // (e2) tile carries inside a workgroup in closed form (k_apply): PT[w] = Phi^(512 w), GT[w] = G^(512 w), and the coupling of the
+        //      workgroup's mu into the lam behind tile w, K_w = G^512 K_{w+1} + B_512 PT[w+1], K_{kBlk-1} = 0
+        {
+            const double x5 = cst[CL<D>::pphi + kLogTile * DD + e], g5 = cst[CL<D>::pg + kLogTile * DD + e], b5 = cst[CL<D>::B512 + e];
+            if (act) {
+                sP[e] = x5;
+                sT[e] = g5;
+                sB[e] = b5;
+                sXa[e] = sGa[e] = (i == j) ? 1.0 : 0.0;      // running PT, GT
+                sXb[e] = 0.0;                                // running K
+            }
+            lds_sync();
+            double ptw[kBlk];                                // this lane's element of PT[w]
+            for (int w = 0; w < kBlk; ++w) {
+                const double pt = sXa[e], gt = sGa[e];
+                ptw[w] = pt;
+                if (act) {
+                    cst[CL<D>::PT + w * DD + e] = pt;
+                    cst[CL<D>::GT + w * DD + e] = gt;
+                }
+                double pn = 0.0, gn = 0.0;
+#pragma unroll
+                for (int l = 0; l < D; ++l) {
+                    pn = fma(sXa[i * D + l], sP[l * D + j], pn);
+                    gn = fma(sGa[i * D + l], sT[l * D + j], gn);
+                }
+                lds_sync();
+                if (act) {
+                    sXa[e] = pn;
+                    sGa[e] = gn;
+                }
+                lds_sync();
+            }
+            if (act) cst[CL<D>::KW + (kBlk - 1) * DD + e] = 0.0;
+            for (int w = kBlk - 2; w >= 0; --w) {
+                if (act) sXa[e] = ptw[w + 1];
+                lds_sync();
+                double kn = 0.0;
+#pragma unroll
+                for (int l = 0; l < D; ++l) {
+                    kn = fma(sT[i * D + l], sXb[l * D + j], kn);        // G^512 K_{w+1}
+                    kn = fma(sB[i * D + l], sXa[l * D + j], kn);        // + B_512 PT[w+1]
+                }
+                lds_sync();
+                if (act) {
+                    sXb[e] = kn;
+                    cst[CL<D>::KW + w * DD + e] = kn;
+                }
+                lds_sync();
+            }
         }
     }
+    __threadfence_block();
+    __syncthreads();
+    if (lane == 0) tb.misc[11] = (double)wall_clock64();
+    head_forward<D>(tb, y, T, lane);
+    if (lane == 0) tb.misc[12] = (double)wall_clock64();
+}
+
+// setup_side: the smoothed VARIANCES of the head and of the tail (c, d) -- needed by the output pass only, so ONE wave of an extra
+// workgroup of pass 1 computes them beside the tiles (lane per matrix element: few registers, it does not lower pass 1's occupancy).
+template <int D>
+__device__ void setup_side(const ModelDev& m, const Tab& tb, long long T) {
+    constexpr int DD = D * D;
+    constexpr int SB = D <= 6 ? 64 : 32;          // steps of the head staged in LDS at a time (phase d)
+    __shared__ double sP[DD], sT[DD];
+    __shared__ double sGt[SB * DD], sLt[SB * DD];
+    const int lane = threadIdx.x;
+    const bool act = lane < DD;
+    const int e = act ? lane : 0;
+    const int i = e / D, j = e % D;
+    const int th = (int)tb.hdr[1], n0 = (int)tb.hdr[2];
+    const int nh = th * kTile;
+    const double* ss = tb.ssc;
+    double hv[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) hv[k] = m.H[k];
     if (lane == 0) tb.misc[13] = (double)wall_clock64();
+    if (act) sP[e] = tb.s_Pf[(size_t)n0 * DD + e];         // P_ss
+    lds_sync();
+    double Pold2 = 0.0;
+    const bool bad = false;
+    // ---- (c) smoothed covariance backwards from the final filtered state (Ps_{T-1} = P_ss) until it no longer changes --------------
+    double Gi[D], Gj[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        Gi[k] = ss[SS<D>::G + i * D + k];
+        Gj[k] = ss[SS<D>::G + j * D + k];
+    }
+    const double Lij = tb.s_L[(size_t)n0 * DD + e];
+    int n1 = -1;
+    for (int jt = 0; jt < kTailMax; ++jt) {
+        const double Ps = sP[e];
+        if (act) tb.t_Ps[(size_t)jt * DD + e] = Ps;
+        double t1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) t1 = fma(Gi[k], sP[imin(k, j) * D + imax(k, j)], t1);
+        const double dii = fabs(sP[i * D + i]), djj = fabs(sP[j * D + j]);
+        if (act) sT[e] = t1;
+        lds_sync();
+        double pn = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) pn = fma(sT[i * D + k], Gj[k], pn);
+        pn += Lij;
+        const bool moved = act && fabs(pn - Ps) > kTol * 0.5 * (dii + djj);
+        const bool nocyc = act && !(pn == Pold2);
+        const bool conv = !__any(moved) || (jt >= 1 && !__any(nocyc));
+        Pold2 = Ps;
+        lds_sync();
+        if (act) sP[e] = pn;
+        lds_sync();
+        if (conv) {
+            n1 = jt + 1;
+            break;
+        }
+    }
+    const bool applies = !bad && n1 >= 0 && (long long)nh + n1 + 1 <= T;
+    if (lane == 0) {
+        tb.hdr[3] = n1;
+        if (!applies) tb.hdr[0] = 0;
+    }
+    if (!applies) return;
+
+    // ---- (d) smoothed covariance of the head: Ps_{n0} = stationary, Ps_{t-1} = G_t Ps_t G_t' + L_t; the gains of SB steps at a time
+    //      are staged in LDS (a dependent global load per step would cost more than the step) --------------------------------------
+    if (act) tb.s_Ps[(size_t)n0 * DD + e] = sP[e];
+    for (int thi = n0; thi >= 1; thi -= SB) {
+        const int tlo = imax(thi - SB + 1, 1);          // steps tlo..thi, thi first
+        const int cnt = thi - tlo + 1;
+        for (int idx = lane; idx < cnt * DD; idx += 64) {
+            sGt[idx] = tb.h_G[(size_t)tlo * DD + idx];
+            sLt[idx] = tb.s_L[(size_t)tlo * DD + idx];
+        }
+        lds_sync();
+        for (int t = thi; t >= tlo; --t) {
+            const double* gt = &sGt[(t - tlo) * DD];
+            double t1 = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) t1 = fma(gt[i * D + k], sP[imin(k, j) * D + imax(k, j)], t1);
+            if (act) sT[e] = t1;
+            lds_sync();
+            double pn = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) pn = fma(sT[i * D + k], gt[j * D + k], pn);
+            pn += sLt[(t - tlo) * DD + e];
+            lds_sync();
+            if (act) {
+                sP[e] = pn;
+                tb.s_Ps[(size_t)(t - 1) * DD + e] = pn;
+            }
+            lds_sync();
+        }
+    }
+    __threadfence_block();
+    lds_sync();
+
+    if (lane == 0) tb.misc[14] = (double)wall_clock64();
+    // ---- (d2) variances, one step per lane; head entries beyond n0 repeat the stationary one -----------------------------------------
+    auto quad = [&](const double* Pm) {     // H Symmetric(P) H'
+        double s = 0.0;
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+            double v = 0.0;
+#pragma unroll
+            for (int r = 0; r < D; ++r) v = fma(hv[r], Pm[imin(r, c) * D + imax(r, c)], v);
+            s = fma(v, hv[c], s);
+        }
+        return s;
+    };
+    const double vb_ss = quad(&tb.s_Ps[(size_t)n0 * DD]);
+    if (lane == 0) tb.ssc[SS<D>::vb] = vb_ss;
+    for (int t = lane; t < n1; t += 64) tb.t_vb[t] = quad(&tb.t_Ps[(size_t)t * DD]);
+    for (int t = lane; t <= n0; t += 64) tb.h_vb[t] = quad(&tb.s_Ps[(size_t)t * DD]);
+    if (lane == 0) tb.misc[15] = (double)wall_clock64();
 }
 
 // =================================================================================================================================
@@ -717,6 +972,8 @@ __device__ __forceinline__ void tile_backward(const Coef<D>& cf, const double* _
 template <int D>
 __device__ void head_forward(const Tab& tb, const double* __restrict__ y, long long T, int lane) {
     const int th = (int)tb.hdr[1];
+    const long long n0c = tb.hdr[2];
+    auto tix = [&](long long t) { return t < n0c ? t : n0c; };       // the per-step tables end with the stationary step n0
     const double* __restrict__ ss = tb.ssc;
     double A[D][D], a[D], h[D];
 #pragma unroll
@@ -746,7 +1003,7 @@ __device__ void head_forward(const Tab& tb, const double* __restrict__ y, long l
         for (int j = 0; j < kSub; ++j) {
             double kA[D];
 #pragma unroll
-            for (int i = 0; i < D; ++i) kA[i] = tb.h_kA[(t0 + j) * D + i];
+            for (int i = 0; i < D; ++i) kA[i] = tb.h_kA[tix(t0 + j) * D + i];
             double rr = yv[j] - hh;
 #pragma unroll
             for (int k = 0; k < D; ++k) rr = fma(-h[k], mu[k], rr);
@@ -825,11 +1082,11 @@ __device__ void head_forward(const Tab& tb, const double* __restrict__ y, long l
 #pragma unroll
             for (int k = 0; k < D; ++k) rr = fma(-h[k], st[k], rr);
             tb.h_r[t0 + j] = rr;
-            acc = fma(rr * rr, tb.h_iS[t0 + j], acc);
+            acc = fma(rr * rr, tb.h_iS[tix(t0 + j)], acc);
             double nm[D];
 #pragma unroll
             for (int i = 0; i < D; ++i) {
-                double v = fma(tb.h_kA[(t0 + j) * D + i], rr, a[i]);
+                double v = fma(tb.h_kA[tix(t0 + j) * D + i], rr, a[i]);
 #pragma unroll
                 for (int k = 0; k < D; ++k) v = fma(A[i][k], st[k], v);
                 nm[i] = v;
@@ -854,6 +1111,8 @@ __device__ void head_backward(const Tab& tb, const double* __restrict__ y, const
                               double* __restrict__ mean, double* __restrict__ var, long long T, int lane) {
     constexpr int DD = D * D;
     const int th = (int)tb.hdr[1];
+    const long long n0c = tb.hdr[2];
+    auto tix = [&](long long t) { return t < n0c ? t : n0c; };
     const double* __restrict__ ss = tb.ssc;
     double h[D];
 #pragma unroll
@@ -876,11 +1135,11 @@ __device__ void head_backward(const Tab& tb, const double* __restrict__ y, const
         }
 #pragma unroll
         for (int j = kSub - 1; j >= 0; --j) {
-            const double* __restrict__ Gt = tb.h_G + (size_t)(t0 + j) * DD;
+            const double* __restrict__ Gt = tb.h_G + (size_t)tix(t0 + j) * DD;
             double nl[D], nM[D][D];
 #pragma unroll
             for (int i = 0; i < D; ++i) {
-                double v = tb.h_c[(t0 + j) * D + i] * rv[j];
+                double v = tb.h_c[tix(t0 + j) * D + i] * rv[j];
 #pragma unroll
                 for (int k = 0; k < D; ++k) v = fma(Gt[i * D + k], lam[k], v);
                 nl[i] = v;
@@ -942,16 +1201,16 @@ __device__ void head_backward(const Tab& tb, const double* __restrict__ y, const
         if (rnew_per_step) load8(Rnew, t0, T, vo);
 #pragma unroll
         for (int j = kSub - 1; j >= 0; --j) {
-            const double* __restrict__ Gt = tb.h_G + (size_t)(t0 + j) * DD;
-            double m = fma(-tb.h_rS[t0 + j], rv[j], yv[j]);
+            const double* __restrict__ Gt = tb.h_G + (size_t)tix(t0 + j) * DD;
+            double m = fma(-tb.h_rS[tix(t0 + j)], rv[j], yv[j]);
 #pragma unroll
             for (int k = 0; k < D; ++k) m = fma(h[k], st[k], m);
             mo[j] = m;
-            vo[j] = tb.h_vb[t0 + j] + (rnew_per_step ? vo[j] : rn0);
+            vo[j] = tb.h_vb[tix(t0 + j)] + (rnew_per_step ? vo[j] : rn0);
             double nl[D];
 #pragma unroll
             for (int i = 0; i < D; ++i) {
-                double v = tb.h_c[(t0 + j) * D + i] * rv[j];
+                double v = tb.h_c[tix(t0 + j) * D + i] * rv[j];
 #pragma unroll
                 for (int k = 0; k < D; ++k) v = fma(Gt[i * D + k], st[k], v);
                 nl[i] = v;
@@ -962,19 +1221,6 @@ __device__ void head_backward(const Tab& tb, const double* __restrict__ y, const
         store8(mean, t0, T, mo);
         store8(var, t0, T, vo);
     }
-}
-
-// the head's two recursions as kernels of their own (one wave): their matrix scans need ~4x the registers of the stationary tiles
-template <int D>
-__global__ __launch_bounds__(64) void k_head_forward(Tab tb, const double* __restrict__ y, long long T) {
-    if (tb.hdr[0] == 0) return;
-    head_forward<D>(tb, y, T, threadIdx.x);
-}
-template <int D>
-__global__ __launch_bounds__(64) void k_head_backward(Tab tb, const double* __restrict__ y, const double* __restrict__ Rnew, int rnew_per_step,
-                                                      double* __restrict__ mean, double* __restrict__ var, long long T) {
-    if (tb.hdr[0] == 0) return;
-    head_backward<D>(tb, y, Rnew, rnew_per_step, mean, var, T, threadIdx.x);
 }
 
 template <int D>
@@ -998,8 +1244,8 @@ __device__ __forceinline__ void block_carries(const double* __restrict__ cst, FG
                                               const double (&mu_in)[D], const double (&lam_in)[D], double (*sMu)[D], double (*sLam)[D],
                                               double (&lam_out)[D]) {
     constexpr int DD = D * D;
-    const double* __restrict__ M = cst + CL<D>::pphi + 9 * DD;
-    const double* __restrict__ G = cst + CL<D>::pg + 9 * DD;
+    const double* __restrict__ M = cst + CL<D>::pphi + kLogTile * DD;
+    const double* __restrict__ G = cst + CL<D>::pg + kLogTile * DD;
     double mu[D];
 #pragma unroll
     for (int i = 0; i < D; ++i) mu[i] = sMu[0][i] = mu_in[i];
@@ -1042,13 +1288,18 @@ __device__ __forceinline__ void block_carries(const double* __restrict__ cst, FG
 
 // pass 1: the stationary tiles with zero carries -> per-tile elements F, B0 and the workgroup's element (Fb, B0b)
 template <int D, bool POST>
-__global__ __launch_bounds__(256) void k_reduce(const long long* __restrict__ hdr, const double* __restrict__ cst, const double* __restrict__ y,
+__global__ __launch_bounds__(kBlkThreads) void k_reduce(const long long* __restrict__ hdr, const double* __restrict__ cst, const double* __restrict__ y,
                                                 double* __restrict__ F, double* __restrict__ B0, double* __restrict__ Fb,
-                                                double* __restrict__ B0b, long long T, long long ntiles) {
+                                                double* __restrict__ B0b, long long T, long long ntiles, ModelDev m, Tab tb) {
     if (hdr[0] == 0) return;
+    if (POST && blockIdx.x == 0) {      // the extra workgroup (dispatched first): variance tables for pass 2
+        if (threadIdx.x < 64) setup_side<D>(m, tb, T);
+        return;
+    }
+    const long long wg = (long long)blockIdx.x - (POST ? 1 : 0);
     __shared__ double sF[kBlk][D], sB0[kBlk][D], sMu[kBlk + 1][D], sLam[kBlk][D];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long long tile0 = hdr[1] + (long long)blockIdx.x * kBlk;
+    const long long tile0 = hdr[1] + wg * kBlk;
     if (tile0 >= ntiles) return;            // (the launch is sized for one head tile)
     const long long tile = tile0 + wave;
     double fend[D], bend[D];
@@ -1093,28 +1344,42 @@ __global__ __launch_bounds__(256) void k_reduce(const long long* __restrict__ hd
                          zero, sMu, sLam, lout);
 #pragma unroll
         for (int i = 0; i < D; ++i) {
-            Fb[(long long)blockIdx.x * D + i] = sMu[kBlk][i];
-            if (POST) B0b[(long long)blockIdx.x * D + i] = lout[i];
+            Fb[wg * D + i] = sMu[kBlk][i];
+            if (POST) B0b[wg * D + i] = lout[i];
         }
+    }
+    __syncthreads();
+    if (threadIdx.x < kBlk * D) {          // the tiles' carries under zero workgroup carries, for pass 2's closed form
+        const int w = threadIdx.x / D, i = threadIdx.x % D;
+        tb.Pw[(tile0 + w) * D + i] = sMu[w][i];
+        if (POST) tb.Lw[(tile0 + w) * D + i] = sLam[w][i];
     }
 }
 
-// carries of the workgroups: MUb[b+1] = Phi^2048 MUb[b] + Fb[b] from MUb[0] (head_forward); LAMb[b] = G^2048 LAMb[b+1] + B0b[b] - C MUb[b]
-// from LAMb[nblk] = 0 (C = B_2048, the last workgroup: Blb).  One block of 512 lanes (256 registers each), kQ consecutive elements per lane held in registers
-// (one round trip to memory per direction), Hillis-Steele over the lanes with the powers 2^(11 + log2 kQ + k); series with more than
-// 512 kQ workgroups (T > 1.6e7 at d <= 4) are walked in slices of that many, chained through the slice's end state.
+// carries of the workgroups: MUb[b+1] = Phi^4096 MUb[b] + Fb[b] from MUb[0] (head_forward); LAMb[b] = G^4096 LAMb[b+1] + B0b[b] - C MUb[b]
+// from LAMb[nblk] = 0 (C = B_4096, the last workgroup: Blb).  One block of 512 lanes, kQ consecutive elements per lane.  A series of
+// one slice (512 kQ workgroups: T <= 1.6e7 at d <= 6) makes ONE round trip to memory -- Fb and B0b are fetched together at the start and
+// the carries never leave the registers between the two directions -- plus the two scans: Hillis-Steele over the lanes with the powers
+// 2^(12 + log2 kQ + k) from LDS, through two alternating buffers (one barrier per round).  Longer series walk the slices, chained through
+// the slice's end state, and read the elements again on the way back.
 template <int D, bool POST>
 __global__ __launch_bounds__(512) void k_carry(const long long* __restrict__ hdr, const double* __restrict__ cst, const double* __restrict__ Fb,
                                                 const double* __restrict__ B0b, double* MUb, double* __restrict__ LAMb, long long ntiles) {
     if (hdr[0] == 0) return;
     constexpr int DD = D * D;
     constexpr int kLanes = 512, kRounds = 9;
-    constexpr int lQ = D <= 4 ? 3 : 2, kQ = 1 << lQ;
-    __shared__ double sv[D][kLanes];
+    constexpr int lQ = D <= 6 ? 3 : 2, kQ = 1 << lQ;
+    __shared__ double sv[2][D][kLanes];
+    __shared__ double sPw[2][kRounds][DD];      // the scans' matrices, fetched once (a scalar load per round would cost a memory round trip each)
     const int tid = threadIdx.x;
     const long long N = nblk_max_for(hdr[1], ntiles);
     const long long slice = (long long)kLanes * kQ;
     const long long nslices = (N + slice - 1) / slice;
+    const bool one = nslices == 1;
+    for (int idx = tid; idx < 2 * kRounds * DD; idx += kLanes) {
+        const int w = idx / (kRounds * DD), r = idx % (kRounds * DD);
+        sPw[w][r / DD][r % DD] = cst[(w == 0 ? CL<D>::pphi : CL<D>::pg) + (kLogBlk + lQ) * DD + r];
+    }
     auto step = [&](const double* __restrict__ M, double (&s)[D], const double (&el)[D]) {
         double n[D];
 #pragma unroll
@@ -1123,50 +1388,74 @@ __global__ __launch_bounds__(512) void k_carry(const long long* __restrict__ hdr
 #pragma unroll
         for (int i = 0; i < D; ++i) s[i] = n[i];
     };
-    auto block_scan = [&](double (&s)[D], const double* __restrict__ pw, bool up) {
+    // inclusive scan over the lanes; the result is also left in sv[1] (kRounds is odd: the last round reads sv[0])
+    auto block_scan = [&](double (&s)[D], int which, bool up) {
+#pragma unroll 1
         for (int k = 0; k < kRounds; ++k) {
             const int off = 1 << k;
-            __syncthreads();
 #pragma unroll
-            for (int i = 0; i < D; ++i) sv[i][tid] = s[i];
+            for (int i = 0; i < D; ++i) sv[k & 1][i][tid] = s[i];
             __syncthreads();
             const int src = up ? tid - off : tid + off;
             if (src >= 0 && src < kLanes) {
                 double g[D];
 #pragma unroll
-                for (int i = 0; i < D; ++i) g[i] = sv[i][src];
-                matvec_acc<D>(pw + (11 + lQ + k) * DD, g, s);
+                for (int i = 0; i < D; ++i) g[i] = sv[k & 1][i][src];
+                matvec_acc<D>(&sPw[which][k][0], g, s);
             }
         }
-        __syncthreads();
 #pragma unroll
-        for (int i = 0; i < D; ++i) sv[i][tid] = s[i];
+        for (int i = 0; i < D; ++i) sv[1][i][tid] = s[i];
         __syncthreads();
     };
-    // ---- forward
-    const double* __restrict__ M = cst + CL<D>::pphi + 11 * DD;
-    double carry[D];
-#pragma unroll
-    for (int i = 0; i < D; ++i) carry[i] = MUb[i];
-    for (long long sl = 0; sl < nslices; ++sl) {
-        const long long base = sl * slice + (long long)tid * kQ;
-        double el[kQ][D], s[D];
+    auto fetch = [&](const double* __restrict__ src, long long first, double (&el)[kQ][D]) {      // clamped: unconditional loads, all in flight
 #pragma unroll
         for (int g = 0; g < kQ; ++g) {
-            const long long idx = base + g < N ? base + g : N - 1;         // clamped: unconditional loads, all in flight together
+            const long long idx = first + g < N ? first + g : N - 1;
 #pragma unroll
-            for (int i = 0; i < D; ++i) el[g][i] = Fb[idx * D + i];
+            for (int i = 0; i < D; ++i) el[g][i] = src[idx * D + i];
         }
+    };
+    auto couple = [&](long long idx, const double (&mu)[D], double (&el)[D]) {                     // el -= C mu
+        const double* __restrict__ C = cst + CL<D>::Bblk;                // (wave-uniform: scalar loads)
+        const double* __restrict__ Cl = cst + CL<D>::Blb;
+        const bool last = idx == N - 1;                                  // one lane: the ragged last workgroup
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            double v = el[i];
+#pragma unroll
+            for (int l = 0; l < D; ++l) v = fma(-C[i * D + l], mu[l], v);
+            if (__builtin_expect(last, 0)) {
+                v = el[i];
+#pragma unroll
+                for (int l = 0; l < D; ++l) v = fma(-Cl[i * D + l], mu[l], v);
+            }
+            el[i] = v;
+        }
+    };
+    const double* __restrict__ M = cst + CL<D>::pphi + kLogBlk * DD;
+    const double* __restrict__ G = cst + CL<D>::pg + kLogBlk * DD;
+    double carry[D], s[D], elb[kQ][D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) carry[i] = MUb[i];
+    if (POST && one) fetch(B0b, (long long)tid * kQ, elb);
+    __syncthreads();
+    // ---- forward
+#pragma unroll 1
+    for (long long sl = 0; sl < nslices; ++sl) {
+        const long long base = sl * slice + (long long)tid * kQ;
+        double el[kQ][D];
+        fetch(Fb, base, el);
 #pragma unroll
         for (int i = 0; i < D; ++i) s[i] = (tid == 0) ? carry[i] : 0.0;
 #pragma unroll
         for (int g = 0; g < kQ; ++g)
             if (base + g < N) step(M, s, el[g]);
-        block_scan(s, cst + CL<D>::pphi, true);
+        block_scan(s, 0, true);
 #pragma unroll
         for (int i = 0; i < D; ++i) {
-            s[i] = (tid == 0) ? carry[i] : sv[i][tid > 0 ? tid - 1 : 0];
-            carry[i] = sv[i][kLanes - 1];
+            s[i] = (tid == 0) ? carry[i] : sv[1][i][tid > 0 ? tid - 1 : 0];
+            carry[i] = sv[1][i][kLanes - 1];
         }
 #pragma unroll
         for (int g = 0; g < kQ; ++g)
@@ -1175,54 +1464,48 @@ __global__ __launch_bounds__(512) void k_carry(const long long* __restrict__ hdr
 #pragma unroll
                     for (int i = 0; i < D; ++i) MUb[(base + g) * D + i] = s[i];
                 }
+                if (POST && one) couple(base + g, s, elb[g]);
                 step(M, s, el[g]);
             }
         __syncthreads();
     }
     if (!POST) return;
-    __threadfence();
-    __syncthreads();
+    if (!one) {
+        __threadfence_block();
+        __syncthreads();
+    }
     // ---- backward
-    const double* __restrict__ G = cst + CL<D>::pg + 11 * DD;
 #pragma unroll
     for (int i = 0; i < D; ++i) carry[i] = 0.0;
     if (tid == 0) {
 #pragma unroll
         for (int i = 0; i < D; ++i) LAMb[N * D + i] = 0.0;
     }
+#pragma unroll 1
     for (long long sl = nslices - 1; sl >= 0; --sl) {
         const long long base = sl * slice + (long long)tid * kQ;
-        double el[kQ][D], s[D];
+        if (!one) {
+            double mu[kQ][D];
+            fetch(MUb, base, mu);
+            fetch(B0b, base, elb);
 #pragma unroll
-        for (int g = 0; g < kQ; ++g) {
-            const long long idx = base + g < N ? base + g : N - 1;
-            double mu[D];
-#pragma unroll
-            for (int i = 0; i < D; ++i) {
-                mu[i] = MUb[idx * D + i];
-                el[g][i] = B0b[idx * D + i];
-            }
-            const double* __restrict__ C = cst + (idx == N - 1 ? CL<D>::Blb : CL<D>::B2048);
-#pragma unroll
-            for (int i = 0; i < D; ++i)
-#pragma unroll
-                for (int l = 0; l < D; ++l) el[g][i] = fma(-C[i * D + l], mu[l], el[g][i]);
+            for (int g = 0; g < kQ; ++g) couple(base + g, mu[g], elb[g]);
         }
 #pragma unroll
         for (int i = 0; i < D; ++i) s[i] = (tid == kLanes - 1) ? carry[i] : 0.0;
 #pragma unroll
         for (int g = kQ - 1; g >= 0; --g)
-            if (base + g < N) step(G, s, el[g]);
-        block_scan(s, cst + CL<D>::pg, false);
+            if (base + g < N) step(G, s, elb[g]);
+        block_scan(s, 1, false);
 #pragma unroll
         for (int i = 0; i < D; ++i) {
-            s[i] = (tid == kLanes - 1) ? carry[i] : sv[i][tid < kLanes - 1 ? tid + 1 : kLanes - 1];
-            carry[i] = sv[i][0];
+            s[i] = (tid == kLanes - 1) ? carry[i] : sv[1][i][tid < kLanes - 1 ? tid + 1 : kLanes - 1];
+            carry[i] = sv[1][i][0];
         }
 #pragma unroll
         for (int g = kQ - 1; g >= 0; --g)
             if (base + g < N) {
-                step(G, s, el[g]);
+                step(G, s, elb[g]);
 #pragma unroll
                 for (int i = 0; i < D; ++i) LAMb[(base + g) * D + i] = s[i];
             }
@@ -1232,9 +1515,10 @@ __global__ __launch_bounds__(512) void k_carry(const long long* __restrict__ hdr
 
 // pass 2: the stationary tiles with their carries -> sum r^2, posterior marginals
 template <int D, bool POST>
-__global__ __launch_bounds__(256, (D <= 3 ? 4 : 1)) void k_apply(const long long* __restrict__ hdr, const double* __restrict__ cst, const double* __restrict__ y,
+__global__ __launch_bounds__(kBlkThreads, (D <= 4 ? 4 : 2)) void k_apply(const long long* __restrict__ hdr, const double* __restrict__ cst, const double* __restrict__ y,
                                                const double* __restrict__ Rnew, int rnew_per_step, const double* __restrict__ F,
-                                               const double* __restrict__ B0, const double* __restrict__ MUb, const double* __restrict__ LAMb,
+                                               const double* __restrict__ B0, const double* __restrict__ Pw, const double* __restrict__ Lw,
+                                               const double* __restrict__ MUb, const double* __restrict__ LAMb,
                                                const double* __restrict__ t_vb, double* __restrict__ mean, double* __restrict__ var,
                                                double* __restrict__ SSQ, long long T, long long ntiles) {
     if (hdr[0] == 0) return;
@@ -1244,23 +1528,54 @@ __global__ __launch_bounds__(256, (D <= 3 ? 4 : 1)) void k_apply(const long long
     if (tile0 >= ntiles) return;
     const long long tile = tile0 + wave;
     double acc = 0.0;
-    if (threadIdx.x == 0) {      // the workgroup's carries -> its tiles'
-        double mu_in[D], lam_in[D], lout[D];
+    const bool lastwg = (long long)blockIdx.x == nblk_max_for(hdr[1], ntiles) - 1;
+    if (lastwg) {                // the ragged last workgroup: its tiles' carries by the sequential chain (one thread)
+        if (threadIdx.x == 0) {
+            double mu_in[D], lam_in[D], lout[D];
 #pragma unroll
-        for (int i = 0; i < D; ++i) {
-            mu_in[i] = MUb[(long long)blockIdx.x * D + i];
-            lam_in[i] = POST ? LAMb[((long long)blockIdx.x + 1) * D + i] : 0.0;
+            for (int i = 0; i < D; ++i) {
+                mu_in[i] = MUb[(long long)blockIdx.x * D + i];
+                lam_in[i] = POST ? LAMb[((long long)blockIdx.x + 1) * D + i] : 0.0;
+            }
+            block_carries<D>(cst, [&](int w, int i) { return F[(tile0 + w) * D + i]; }, [&](int w, int i) { return POST ? B0[(tile0 + w) * D + i] : 0.0; },
+                             tile0, ntiles, mu_in, lam_in, sMu, sLam, lout);
         }
-        block_carries<D>(cst, [&](int w, int i) { return F[(tile0 + w) * D + i]; }, [&](int w, int i) { return POST ? B0[(tile0 + w) * D + i] : 0.0; },
-                         tile0, ntiles, mu_in, lam_in, sMu, sLam, lout);
+        __syncthreads();
     }
-    __syncthreads();
     if (tile < ntiles) {
         double cin[D], lin[D];
+        if (lastwg) {
 #pragma unroll
-        for (int i = 0; i < D; ++i) {
-            cin[i] = (lane == 0) ? sMu[wave][i] : 0.0;
-            lin[i] = (lane == 63) ? sLam[wave][i] : 0.0;
+            for (int i = 0; i < D; ++i) {
+                cin[i] = (lane == 0) ? sMu[wave][i] : 0.0;
+                lin[i] = (lane == 63) ? sLam[wave][i] : 0.0;
+            }
+        } else {
+            // every tile of the workgroup is full: mu_w = Phi^(512 w) mu_b + Pw, lam_w = G^(512 (kBlk-1-w)) lam_b - K_w mu_b + Lw (wave-uniform)
+            constexpr int DD = D * D;
+            double mub[D], lamb[D], mw[D], lw[D];
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                mub[i] = MUb[(long long)blockIdx.x * D + i];
+                lamb[i] = POST ? LAMb[((long long)blockIdx.x + 1) * D + i] : 0.0;
+                mw[i] = Pw[tile * D + i];
+                lw[i] = POST ? Lw[tile * D + i] : 0.0;
+            }
+            const int wu = __builtin_amdgcn_readfirstlane(wave);
+            matvec_acc<D>(cst + CL<D>::PT + wu * DD, mub, mw);
+            if (POST) {
+                matvec_acc<D>(cst + CL<D>::GT + (kBlk - 1 - wu) * DD, lamb, lw);
+                const double* __restrict__ K = cst + CL<D>::KW + wu * DD;
+#pragma unroll
+                for (int i = 0; i < D; ++i)
+#pragma unroll
+                    for (int l = 0; l < D; ++l) lw[i] = fma(-K[i * D + l], mub[l], lw[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                cin[i] = (lane == 0) ? mw[i] : 0.0;
+                lin[i] = (lane == 63) ? lw[i] : 0.0;
+            }
         }
         Coef<D> cf;
         cf.load(cst);
@@ -1308,14 +1623,27 @@ __global__ __launch_bounds__(256, (D <= 3 ? 4 : 1)) void k_apply(const long long
     }
     if (lane == 0) sacc[wave] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) SSQ[blockIdx.x] = ((sacc[0] + sacc[1]) + sacc[2]) + sacc[3];
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < kBlk; ++w) t += sacc[w];
+        SSQ[blockIdx.x] = t;
+    }
 }
 
 // log marginal likelihood from the pieces (fixed summation order) and the status of the call
+// (second workgroup, posterior calls: the head's backward recursion -- one wave, beside nothing but this reduction)
 template <int D>
-__global__ __launch_bounds__(1024) void k_final(Tab tb, long long T, long long ntiles, double* result) {
-    __shared__ double sm[1024];
+__global__ __launch_bounds__(256) void k_final(Tab tb, long long T, long long ntiles, double* result, const double* __restrict__ y,
+                                               const double* __restrict__ Rnew, int rnew_per_step, double* __restrict__ mean,
+                                               double* __restrict__ var) {
+    constexpr int NT = 256;
+    __shared__ double sm[NT];
     const int tid = threadIdx.x;
+    if (blockIdx.x == 1) {
+        if (tb.hdr[0] != 0 && tid < 64) head_backward<D>(tb, y, Rnew, rnew_per_step, mean, var, T, tid);
+        return;
+    }
     if (tb.hdr[0] == 0) {
         if (tid == 0) {
             result[6] = kStatusNotApplicable;
@@ -1326,16 +1654,16 @@ __global__ __launch_bounds__(1024) void k_final(Tab tb, long long T, long long n
     }
     const long long N = nblk_max_for(tb.hdr[1], ntiles);
     double acc = 0.0;
-    for (long long i = tid; i < N; i += 8 * 1024) {     // eight loads in flight per lane, fixed summation order
+    for (long long i = tid; i < N; i += 8 * NT) {     // eight loads in flight per lane, fixed summation order
         double v[8];
 #pragma unroll
-        for (int g = 0; g < 8; ++g) v[g] = (i + g * 1024 < N) ? tb.SSQ[i + g * 1024] : 0.0;
+        for (int g = 0; g < 8; ++g) v[g] = (i + g * NT < N) ? tb.SSQ[i + g * NT] : 0.0;
 #pragma unroll
         for (int g = 0; g < 8; ++g) acc += v[g];
     }
     sm[tid] = acc;
     __syncthreads();
-    for (int off = 512; off >= 1; off >>= 1) {
+    for (int off = NT / 2; off >= 1; off >>= 1) {
         if (tid < off) sm[tid] += sm[tid + off];
         __syncthreads();
     }
@@ -1384,14 +1712,14 @@ hipError_t ensure(Engine* e, int d, long long ntiles) {
         return o;
     };
     // constant block, as CL<D> lays it out
-    const size_t ss_size = 2 * DD + 5 * (size_t)d + 6, c_pphi = (ss_size + 7) & ~(size_t)7, c_pg = c_pphi + kPowN * DD, c_size = c_pg + kPowN * DD + 4 * DD;
+    const size_t ss_size = 2 * DD + 5 * (size_t)d + 6, c_pphi = (ss_size + 7) & ~(size_t)7, c_pg = c_pphi + kPowN * DD, c_size = c_pg + kPowN * DD + 4 * DD + 3 * kBlk * DD;
     const size_t o_hdr = take(8), o_cst = take(c_size);
     const size_t o_hkA = take(nhmax * d), o_hrS = take(nhmax), o_hiS = take(nhmax), o_hG = take(nhmax * DD), o_hc = take(nhmax * d),
                  o_hvb = take(nhmax), o_hr = take(nhmax);
     const size_t o_sPf = take((nhmax + 1) * DD), o_sPp = take((nhmax + 1) * DD), o_sL = take((nhmax + 1) * DD), o_sPs = take((nhmax + 1) * DD);
     const size_t o_tvb = take(kTailMax), o_tPs = take((size_t)kTailMax * DD);
     const size_t nt = (size_t)ntiles + 8, nb = (size_t)(ntiles + kBlk - 1) / kBlk + 2;
-    const size_t o_F = take(nt * d), o_B0 = take(nt * d), o_Fb = take(nb * d), o_B0b = take(nb * d), o_MUb = take(nb * d), o_LAMb = take(nb * d),
+    const size_t o_F = take(nt * d), o_B0 = take(nt * d), o_Pw = take(nt * d), o_Lw = take(nt * d), o_Fb = take(nb * d), o_B0b = take(nb * d), o_MUb = take(nb * d), o_LAMb = take(nb * d),
                  o_SSQ = take(nb), o_misc = take(16);
     const size_t bytes = off * sizeof(double);
     if (bytes > e->cap) {
@@ -1409,7 +1737,7 @@ hipError_t ensure(Engine* e, int d, long long ntiles) {
     tb.h_kA = b + o_hkA; tb.h_rS = b + o_hrS; tb.h_iS = b + o_hiS; tb.h_G = b + o_hG; tb.h_c = b + o_hc; tb.h_vb = b + o_hvb; tb.h_r = b + o_hr;
     tb.s_Pf = b + o_sPf; tb.s_Pp = b + o_sPp; tb.s_L = b + o_sL; tb.s_Ps = b + o_sPs;
     tb.t_vb = b + o_tvb; tb.t_Ps = b + o_tPs;
-    tb.F = b + o_F; tb.B0 = b + o_B0; tb.Fb = b + o_Fb; tb.B0b = b + o_B0b; tb.MUb = b + o_MUb; tb.LAMb = b + o_LAMb; tb.SSQ = b + o_SSQ;
+    tb.F = b + o_F; tb.B0 = b + o_B0; tb.Pw = b + o_Pw; tb.Lw = b + o_Lw; tb.Fb = b + o_Fb; tb.B0b = b + o_B0b; tb.MUb = b + o_MUb; tb.LAMb = b + o_LAMb; tb.SSQ = b + o_SSQ;
     tb.misc = b + o_misc;
     e->d = d;
     e->ntiles = ntiles;
@@ -1432,30 +1760,23 @@ int enqueue_d(Engine* e, hipStream_t st, const ModelDev& m, const CallDev& c, co
     const unsigned blocks = (unsigned)((ntiles - 1 + kBlk - 1) / kBlk);      // workgroups of the stationary tiles if the head is one tile
     {
         Scope s(hk, "k_steady_setup");
-        hipLaunchKernelGGL(k_setup<D>, dim3(1), dim3(64), 0, st, m, tb, T);
+        hipLaunchKernelGGL(k_setup_core<D>, dim3(1), dim3(64), 0, st, m, tb, c.y, T);
     }
-    if (blocks == 0) {      // a series of one tile: k_setup has found that the engine does not apply
+    if (blocks == 0) {      // a series of one tile: the engine does not apply (k_setup_core: nh + 2 > T)
         Scope s(hk, "k_steady_final");
-        hipLaunchKernelGGL(k_final<D>, dim3(1), dim3(1024), 0, st, tb, T, ntiles, c.result);
+        hipLaunchKernelGGL(k_final<D>, dim3(1), dim3(256), 0, st, tb, T, ntiles, c.result, c.y, c.Rnew, 0, (double*)nullptr, (double*)nullptr);
         return (int)hipGetLastError();
     }
-    {
-        Scope s(hk, "k_steady_head_forward");
-        hipLaunchKernelGGL(k_head_forward<D>, dim3(1), dim3(64), 0, st, tb, c.y, T);
-    }
     if (post) {
-        { Scope s(hk, "k_steady_reduce<post>"); hipLaunchKernelGGL((k_reduce<D, true>), dim3(blocks), dim3(256), 0, st, tb.hdr, tb.cst, c.y, tb.F, tb.B0, tb.Fb, tb.B0b, T, ntiles); }
+        { Scope s(hk, "k_steady_reduce<post>"); hipLaunchKernelGGL((k_reduce<D, true>), dim3(blocks + 1), dim3(kBlkThreads), 0, st, tb.hdr, tb.cst, c.y, tb.F, tb.B0, tb.Fb, tb.B0b, T, ntiles, m, tb); }
         { Scope s(hk, "k_steady_carry<post>"); hipLaunchKernelGGL((k_carry<D, true>), dim3(1), dim3(512), 0, st, tb.hdr, tb.cst, tb.Fb, tb.B0b, tb.MUb, tb.LAMb, ntiles); }
-        { Scope s(hk, "k_steady_apply<post>"); hipLaunchKernelGGL((k_apply<D, true>), dim3(blocks), dim3(256), 0, st, tb.hdr, tb.cst, c.y, c.Rnew, c.rnew_per_step, tb.F, tb.B0, tb.MUb, tb.LAMb, tb.t_vb, c.mean, c.var, tb.SSQ, T, ntiles); }
-        { Scope s(hk, "k_steady_head_backward"); hipLaunchKernelGGL(k_head_backward<D>, dim3(1), dim3(64), 0, st, tb, c.y, c.Rnew, c.rnew_per_step, c.mean, c.var, T); }
+        { Scope s(hk, "k_steady_apply<post>"); hipLaunchKernelGGL((k_apply<D, true>), dim3(blocks), dim3(kBlkThreads), 0, st, tb.hdr, tb.cst, c.y, c.Rnew, c.rnew_per_step, tb.F, tb.B0, tb.Pw, tb.Lw, tb.MUb, tb.LAMb, tb.t_vb, c.mean, c.var, tb.SSQ, T, ntiles); }
+        { Scope s(hk, "k_steady_final<post>"); hipLaunchKernelGGL(k_final<D>, dim3(2), dim3(256), 0, st, tb, T, ntiles, c.result, c.y, c.Rnew, c.rnew_per_step, c.mean, c.var); }
     } else {
-        { Scope s(hk, "k_steady_reduce<lml>"); hipLaunchKernelGGL((k_reduce<D, false>), dim3(blocks), dim3(256), 0, st, tb.hdr, tb.cst, c.y, tb.F, tb.B0, tb.Fb, tb.B0b, T, ntiles); }
+        { Scope s(hk, "k_steady_reduce<lml>"); hipLaunchKernelGGL((k_reduce<D, false>), dim3(blocks), dim3(kBlkThreads), 0, st, tb.hdr, tb.cst, c.y, tb.F, tb.B0, tb.Fb, tb.B0b, T, ntiles, m, tb); }
         { Scope s(hk, "k_steady_carry<lml>"); hipLaunchKernelGGL((k_carry<D, false>), dim3(1), dim3(512), 0, st, tb.hdr, tb.cst, tb.Fb, tb.B0b, tb.MUb, tb.LAMb, ntiles); }
-        { Scope s(hk, "k_steady_apply<lml>"); hipLaunchKernelGGL((k_apply<D, false>), dim3(blocks), dim3(256), 0, st, tb.hdr, tb.cst, c.y, (const double*)nullptr, 0, tb.F, tb.B0, tb.MUb, tb.LAMb, tb.t_vb, (double*)nullptr, (double*)nullptr, tb.SSQ, T, ntiles); }
-    }
-    {
-        Scope s(hk, "k_steady_final");
-        hipLaunchKernelGGL(k_final<D>, dim3(1), dim3(1024), 0, st, tb, T, ntiles, c.result);
+        { Scope s(hk, "k_steady_apply<lml>"); hipLaunchKernelGGL((k_apply<D, false>), dim3(blocks), dim3(kBlkThreads), 0, st, tb.hdr, tb.cst, c.y, (const double*)nullptr, 0, tb.F, tb.B0, tb.Pw, tb.Lw, tb.MUb, tb.LAMb, tb.t_vb, (double*)nullptr, (double*)nullptr, tb.SSQ, T, ntiles); }
+        { Scope s(hk, "k_steady_final<lml>"); hipLaunchKernelGGL(k_final<D>, dim3(1), dim3(256), 0, st, tb, T, ntiles, c.result, c.y, c.Rnew, 0, (double*)nullptr, (double*)nullptr); }
     }
     return (int)hipGetLastError();
 }
@@ -1498,9 +1819,9 @@ int last_info(Engine* e, hipStream_t stream, int64_t out[4]) {
     if (rc == hipSuccess) rc = hipStreamSynchronize(stream);
     if (rc != hipSuccess) return (int)rc;
     if (std::getenv("TGP_STEADY_DEBUG") != nullptr)      // phases of k_setup in microseconds (100 MHz wall clock)
-        fprintf(stderr, "[tgp steady2] n0 %lld n1 %lld head tiles %lld applies %lld | setup: filter cov %.1f us, gains %.1f, tail %.1f, head cov %.1f, variances %.1f, powers %.1f\n",
+        fprintf(stderr, "[tgp steady2] n0 %lld n1 %lld head tiles %lld applies %lld | core: filter cov + gains %.1f us, tables %.1f, powers %.1f, head forward %.1f | side: tail + head cov %.1f, variances %.1f (starts %.1f after core's start)\n",
                 h[2], h[3], h[1], h[0], (misc[9] - misc[8]) * 0.01, (misc[10] - misc[9]) * 0.01, (misc[11] - misc[10]) * 0.01, (misc[12] - misc[11]) * 0.01,
-                0.0, (misc[13] - misc[12]) * 0.01);
+                (misc[14] - misc[13]) * 0.01, (misc[15] - misc[14]) * 0.01, (misc[13] - misc[8]) * 0.01);
     out[0] = h[2];
     out[1] = h[3];
     out[2] = h[1];

@@ -60,6 +60,7 @@ def test_group_path_is_selected_for_d8(tgp):
     tr = tgp.GaussMarkovModel(tgp.Forward, model["A"], model["a"], model["Q"], tgp.Gaussian(model["x0m"], model["x0P"]))
     dm = tgp.LGSSM(tr, tgp.ScalarOutputLGC(model["H"], model["h"], model["R"]), T=T)
     hd = dm.handle()
+    hd.set_option(tgp._lib.OPT_STEADY, 1)         # the general (chunked-scan) engine: the stationary-gain engine would serve this model
     hd.set_option(tgp._lib.OPT_PROFILE, 1)
     hd.profile_reset()
     lp = tgp.logpdf(dm, y)
@@ -83,6 +84,7 @@ def test_group_scans_under_the_smoother(tgp, d):
     dm = tgp.LGSSM(tr, tgp.ScalarOutputLGC(model["H"], model["h"], model["R"]), T=T)
     hd = dm.handle()
     hd.set_option(tgp._lib.OPT_GROUP, 2)
+    hd.set_option(tgp._lib.OPT_STEADY, 1)         # the general (chunked-scan) engine
     post = ref.posterior(model, y)
     Rn = rng.random(T) * 0.1
     pm, pC = ref.marginals(ref.replace_observation_noise_cov(post, Rn))

@@ -399,8 +399,10 @@ def test_hip_graph_replay_of_repeated_calls(tgp):
     y_host = ref.rand(model, rng.standard_normal((T, d)), rng.standard_normal(T), rng.standard_normal(d))
     plain = to_device_model(tgp, model)
     plain.handle_options[_lib.OPT_GRAPH] = 0
+    plain.handle_options[_lib.OPT_STEADY] = 1       # (the recorded chain is the general engine's)
     dm = to_device_model(tgp, model)
     dm.handle_options[_lib.OPT_GRAPH] = 1
+    dm.handle_options[_lib.OPT_STEADY] = 1
     y = torch.as_tensor(y_host, device="cuda:0")
     Rn = torch.full((1,), 0.07, dtype=torch.float64, device="cuda:0")
     hd = dm.handle()
@@ -456,6 +458,7 @@ def test_pass1_with_shared_matrix_parts_is_bit_identical(tgp, d_case):
         for opt in (0, 1):
             dm = to_device_model(tgp, model)
             dm.handle_options[tgp._lib.OPT_SHARED_PARTS] = 2 * opt          # 2: table built in line on the first call
+            dm.handle_options[tgp._lib.OPT_STEADY] = 1                      # pass 1 of the general engine is what is under test
             hd = dm.handle()
             if chunk:
                 hd.set_option(tgp._lib.OPT_CHUNK, chunk)
@@ -484,6 +487,7 @@ def test_shared_parts_table_is_built_off_the_critical_path(tgp):
     import time as _time
     model, y, _ = U.gp_case(("matern52",), ("regular", 0.0, 0.1, 4000), 0.1, seed=77)
     dm = to_device_model(tgp, model)
+    dm.handle_options[tgp._lib.OPT_STEADY] = 1        # the general engine
     hd = dm.handle()
     seen, vals = [], []
     for it in range(5):
@@ -573,6 +577,7 @@ def test_stationary_covariance_build_is_dropped_where_chunk_0_settles_late(tgp):
     for dt, keeps in ((0.002, False), (0.1, True)):
         model, y, _ = U.gp_case(("matern52",), ("regular", 0.0, dt, T), 0.1, seed=33)
         dm = to_device_model(tgp, model)
+        dm.handle_options[tgp._lib.OPT_STEADY] = 1    # the general engine's per-chunk stationary steps
         hd = dm.handle()
         hd.set_option(tgp._lib.OPT_CHUNK, 153)
         outs, fast = [], []
