@@ -211,6 +211,10 @@ def pmc_traffic(kname, d, layout):
     """HBM bytes per launch of `kname` from the committed PMC summary (profiles/r01_pmc_traffic.json: separate
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command, FETCH doubled per
     MI355X_MICROARCH.md). None when the summary has no entry (other d / workload)."""
+    p3 = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")         # round 3: keyed by the profile label, "d=<d>" -> label -> bytes
+    if kname.startswith("k_steady") and os.path.exists(p3):
+        ent = json.load(open(p3)).get(layout, {}).get(f"d={d}", {}).get(kname)
+        return None if ent is None else ent["hbm_bytes"]
     path = os.path.join(ROOT, "profiles", "r02s_pmc_traffic.json")      # (r01_pmc_traffic.json: the kernels before the stationary-covariance steps)
     if not os.path.exists(path):
         return None
@@ -237,6 +241,18 @@ def valu_utilisation(prof, d, layout):
     as profiles/r01_sq_counters_<layout>.json, T = 1e7) over the launch duration measured HERE, against the issue peak
     256 CUs x 4 SIMDs x one wave64 fp64 instruction per 4 cycles at 2.4 GHz (= the 78.6 TFLOP/s datasheet figure counted
     in instructions). The LTI kernels are bound by this, not by HBM."""
+    p3 = os.path.join(ROOT, "profiles", f"r03_sq_counters_{layout}.json")        # round 3 (stationary-gain engine): keyed by the profile label
+    if os.path.exists(p3) and any(k.startswith("k_steady") for k in prof):
+        table = json.load(open(p3)).get(f"d={d}", {})
+        peak = 256 * 4 * 2.4e9 / 4.0
+        out = {}
+        for pk, ent in table.items():
+            if pk in prof and "SQ_INSTS_VALU" in ent:
+                dur = prof[pk]["total_ms"] / max(1, prof[pk]["calls"]) * 1e-3
+                n = ent["SQ_INSTS_VALU"]
+                out[pk] = dict(valu_wave_instructions=n, achieved=n / dur, peak=peak, unit="wave64 fp64 VALU instructions/s", frac=n / dur / peak,
+                               waves=ent.get("SQ_WAVES"), wait_any_frac=ent.get("SQ_WAIT_ANY", 0.0) / max(1.0, ent.get("SQ_WAVE_CYCLES", 1.0)))
+        return out or None
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r02s_sq_counters_{layout}.json")
     if not os.path.exists(path):
         path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r01_sq_counters_{layout}.json")
@@ -520,10 +536,13 @@ def main():
     import ctypes as _ct
     st_fast, st_total = _ct.c_int64(0), _ct.c_int64(0)
     hd.check(hd.lib.tgp_steady_steps(hd.h, _ct.byref(st_fast), _ct.byref(st_total)))
-    no_steady = None
-    if st_fast.value > 0:
-        # the same K steps with every step run in full (TGP_OPT_STEADY = 0): identical results, bit for bit
-        hd.set_option(tgp._lib.OPT_STEADY, 0)
+    prof = hd.profile()
+    steady_engine = any(k.startswith("k_steady") for k in prof)
+
+    def timed_leg(option_value):
+        """the same K steps with TGP_OPT_STEADY = option_value (1: the general chunked-scan engine with its per-chunk stationary steps,
+        0: the general engine with every step in full)"""
+        hd.set_option(tgp._lib.OPT_STEADY, option_value)
         for _ in range(max(2, args.warmup)):
             step()
         if world > 1:
@@ -540,41 +559,21 @@ def main():
             tn = torch.tensor([dt_n], dtype=torch.float64, device=f"cuda:{local}")
             dist.all_reduce(tn, op=dist.ReduceOp.MAX)
             dt_n = float(tn.item())
-        no_steady = dict(value=T / (dt_n / args.steps), ms_per_step=dt_n / args.steps * 1e3,
-                         note="TGP_OPT_STEADY = 0: every step of passes 2 / 3 in full (what a model with per-step blocks, per-step noise or "
-                              "missing data gets); same results bit for bit")
-        hd.set_option(tgp._lib.OPT_STEADY, 1)
+        return dict(value=T / (dt_n / args.steps), ms_per_step=dt_n / args.steps * 1e3)
+
+    general, no_steady = None, None
+    if st_fast.value > 0 and args.layout == "lti":
+        if steady_engine:
+            general = dict(timed_leg(1), note="TGP_OPT_STEADY = 1: the general chunked-scan engine (round 2's path: full Kalman / RTS steps per chunk, "
+                                              "mean-only once a chunk's covariance repeats bit for bit); agrees with the headline path to rounding")
+        no_steady = dict(timed_leg(0), note="TGP_OPT_STEADY = 0: the general engine with every step in full (what a model with per-step blocks, per-step "
+                                            "noise or missing data gets)")
+        hd.set_option(tgp._lib.OPT_STEADY, 2)
     reuse = None
-    if not args.model_reuse and args.layout != "per_step":
-        # the same K steps with the per-model table of pass 1 reused across calls (what repeated calls on one bound model get)
-        hd.set_option(tgp._lib.OPT_SHARED_PARTS, 1)
-        for _ in range(max(3, args.warmup)):
-            step()
-            torch.cuda.synchronize()
-            time.sleep(0.02)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        dt_r = time.perf_counter() - t1
-        if world > 1:
-            tr = torch.tensor([dt_r], dtype=torch.float64, device=f"cuda:{local}")
-            dist.all_reduce(tr, op=dist.ReduceOp.MAX)
-            dt_r = float(tr.item())
-        reuse = dict(value=T / (dt_r / args.steps), ms_per_step=dt_r / args.steps * 1e3,
-                     note="TGP_OPT_SHARED_PARTS: the observation-independent half of pass 1 tabulated once per bound model (side stream) and reused "
-                          "by the timed calls; bit-identical results; NOT the headline")
-        hd.set_option(tgp._lib.OPT_SHARED_PARTS, 0)
     if world > 1:
         tmax = torch.tensor([dt_s], dtype=torch.float64, device=f"cuda:{local}")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt_s = float(tmax.item())
-    prof = hd.profile()
 
     if rank == 0:
         ms_per_step = dt_s / args.steps * 1e3
@@ -597,9 +596,11 @@ def main():
             roof = dict(bound="hbm", kernel=kname, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
                         traffic=traffic, traffic_unit="bytes per launch (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, profiles/)",
                         algorithmic_bytes=per_unit * Tseg, avg_kernel_ms=avg_ms, algorithmic_bytes_per_step=per_unit,
-                        note=("LTI (Fill) layout streams only y in / (mean,var) out (plus the smoother scratch: `traffic`): the launch is not "
-                              "HBM bound -- one wave per SIMD, it lasts as long as the dependent fp64 chain of its slowest wave "
-                              "(DESIGN 3.10, `valu`); the HBM fraction is reported for completeness" if lti else "per-step layout: HBM bound"))
+                        note=(("stationary-gain engine (DESIGN 3.11): the output pass reads y (8 B/step) and writes mean, var (16 B/step), nothing else "
+                               "of size T moves; pass 1 reads y once more (`traffic` = PMC bytes of this kernel alone)" if kname.startswith("k_steady") else
+                               "LTI (Fill) layout, general engine: streams only y in / (mean,var) out (plus the smoother scratch: `traffic`): the launch "
+                               "is not HBM bound -- one wave per SIMD, it lasts as long as the dependent fp64 chain of its slowest wave (DESIGN 3.10)")
+                              if lti else "per-step layout: HBM bound"))
         out = dict(
             metric="Kalman steps/sec (logpdf + posterior marginals), T=10^7 Matern32 d=3",
             value=value, unit="Kalman steps/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step,
@@ -614,9 +615,9 @@ def main():
                         hip_graph_replays=int(hd.lib.tgp_graph_replays(hd.h)),
                         stationary_covariance_steps=dict(
                             mean_only=int(st_fast.value), total=int(st_total.value),
-                            note="passes 2 / 3, rank 0's segment: steps run in the mean-only form after the chunk's covariance was found to "
-                                 "repeat with period 2 bit for bit (TGP_OPT_STEADY; decided inside the timed call, nothing carried over "
-                                 "between calls; results identical in every bit to the full steps, see `with_full_steps`)"),
+                            note="steps served with the stationary gains: every step behind the head of n0 steps over which the filter covariance "
+                                 "is iterated until it no longer changes (k_steady_setup, inside every timed call; nothing is carried over between "
+                                 "calls). `with_general_engine` / `with_full_steps`: the same steps on the general engine"),
                         pass1=("shared matrix parts (TGP_OPT_SHARED_PARTS): the observation-independent half of the chunk recursion is tabulated "
                                "once per bound model -- on a side stream, launched by the second call, 1.4 ms at d = 3 -- and reused by later "
                                "calls on the same model; the warm-up steps bind and warm the model, the timed steps reuse the table"
@@ -624,10 +625,10 @@ def main():
             roofline=roof,
             kernels={k: dict(avg_ms=v["total_ms"] / max(1, v["calls"]), calls=v["calls"]) for k, v in prof.items()},
         )
+        if general is not None:
+            out["with_general_engine"] = general
         if no_steady is not None:
             out["with_full_steps"] = no_steady
-        if reuse is not None:
-            out["with_model_reuse"] = reuse
         if world > 1 and args.scaling == "strong" and not args.no_single_gpu_reference:
             # the SAME series on rank 0 alone (the other ranks idle): what the strong-scaling speed-up is measured against
             try:

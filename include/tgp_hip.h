@@ -75,10 +75,13 @@ typedef struct tgp_handle tgp_handle;
 #define TGP_OPT_DENSE_STRUCTURE 8 /* dense path (d > 16): 1 (default) a shared A / H with at most 8 entries per row (what
                                      lgssm_components(::Separable, ...) builds: I (x) A_t, I (x) H_t') is applied in sparse form; 0 the
                                      reference's dense products on the fp64 MFMA GEMM kernels. Set before tgp_model_set. */
-#define TGP_OPT_DENSE_FUSED 10 /* dense path, 16 < d <= 64 and p <= 16: 1 (default) the whole filter / smoother pass runs as ONE persistent
-                                  kernel (P in LDS, fp64 MFMA products, scalar updates; backward pass in modified Bryson-Frazier form,
-                                  tgp_dense_fused.hpp) -- ~3 us per step instead of ~26 us of dependent launches; 0 the per-step
-                                  kernel chain that larger states use. Takes effect at the next tgp_model_set. */
+#define TGP_OPT_DENSE_FUSED 10 /* dense path, 16 < d <= 64 and p <= 16: 1 (default) the filter pass (logpdf, filtering distributions, prior marginals,
+                                  rand) runs as ONE persistent kernel (P in LDS, fp64 MFMA products, scalar updates, tgp_dense_fused.hpp) -- ~3 us per
+                                  step instead of ~26 us of dependent launches; posterior marginals keep the reference's RTS chain (with its
+                                  1e-10 jitter, lgssm.jl:235). 2: posterior marginals too, by a persistent backward pass in modified
+                                  Bryson-Frazier form -- no counterpart of that jitter, variances by a difference: agrees with the chain to
+                                  ~1e-6 relative only, hence opt-in. 0: the per-step kernel chain that larger states use, for everything.
+                                  Takes effect at the next tgp_model_set. */
 #define TGP_OPT_SHARED_PARTS 11 /* scan path, pass 1 (1 default / 0 off / 2): for a Forward model with every block shared (LTI), ONE noise
                                    variance, scalar observations and no missing data, the matrix parts (Abar, C, J) of a chunk's filter
                                    element and its per-step (w, Cv, 1/s) do not depend on the observations: every chunk has the same.
@@ -87,13 +90,22 @@ typedef struct tgp_handle tgp_handle;
                                    (d <= 6; bit-identical results). The table is never built on the caller's critical path: the second
                                    eligible call on a bound model launches the build on a side stream and still runs the general pass;
                                    later calls use the table once it is complete. 2 = build it in line on the first call (tests). */
-#define TGP_OPT_STEADY 12 /* scan path, passes 2 and 3, d <= 4 (1 default / 0 off): for a model with every block shared (LTI), ONE noise
-                             variance, scalar observations and no missing data the covariance half of a Kalman step is the same
-                             map at every step; in floating point a chunk's covariance lands on a fixed point or 2-cycle of it
-                             (P_t == P_{t-2} bit for bit) within ~15 steps of the chunk's start. From there on the steps keep only
-                             their mean half (gain, innovation variance, smoother gain taken from the two remembered steps) and the
-                             smoother scratch only the filtered means. Decided per wave at run time by comparing bits, so no
-                             result changes in any bit; a model that never settles simply keeps the full steps. */
+#define TGP_OPT_STEADY 12 /* Forward LTI models (every block shared) with ONE noise variance, scalar observations, no missing data -- the
+                             reference's Fill layout for RegularSpacing inputs, lti_sde.jl:148-160. For such a model the covariance half
+                             of the Kalman / RTS recursion never sees the data.
+                             2 (default): the stationary-gain scan engine (tgp_steady.hip, d <= 8) serves tgp_logpdf and
+                               tgp_[logpdf_and_]posterior_marginals: the covariance recursion is run once per call until it no longer
+                               changes (n0 steps, ~60 at the bench model; per-step gains of that head are tabulated), and the T steps
+                               are left with two linear recursions of the MEAN (forward: innovations; backward: smoothed minus filtered
+                               mean) that a wave scans over tiles of 512 steps, two passes over y, no scratch of size T. Re-associated,
+                               not approximated: results agree with the sequential recursion to rounding (tolerances as everywhere:
+                               logpdf 1e-10 relative, marginals 1e-8). Whether it applies (the covariance settles within 2048 steps, the
+                               series is longer than head + tail) is decided on the device inside the call; a call that finds it does
+                               not is re-run on the general path and the bound model is remembered as such.
+                             1: the general chunked-scan engine, passes 2 and 3 (d <= 3) switching to mean-only steps once a chunk's
+                               covariance repeats with period 2 bit for bit (decided per wave at run time by comparing bits, so no
+                               result changes in any bit against 0).
+                             0: the general engine, every step in full. */
 #define TGP_OPT_GRAPH 9 /* hipGraph replay of the launch chain of tgp_logpdf / tgp_[logpdf_and_]posterior_marginals: a call with device
                            pointers that repeats the previous call's arguments is recorded once (stream capture, kernel nodes only)
                            and then replayed with one hipGraphLaunch. 0 (default) off, 1 on, -1 on for T <= 2^20. Measured on
@@ -118,8 +130,9 @@ const char* tgp_version(void);
 int tgp_kernel_variant(const tgp_handle* h);
 /* number of calls served by replaying a recorded hipGraph since the handle was created (TGP_OPT_GRAPH; measurement / tests) */
 int64_t tgp_graph_replays(const tgp_handle* h);
-/* Diagnostics of TGP_OPT_STEADY: how many of the series' steps the forward pass of the last posterior-path call
-   (tgp_[logpdf_and_]posterior_marginals, tgp_smoother_forward) ran in the mean-only form, out of `total` = T * p. */
+/* Diagnostics of TGP_OPT_STEADY: how many of the series' steps the last call ran with stationary gains, out of `total` = T * p --
+   the stationary-gain engine: T - n0 (tgp_logpdf, tgp_[logpdf_and_]posterior_marginals); the general engine: the steps the forward pass of
+   the last posterior-path call ran in the mean-only form. */
 int tgp_steady_steps(tgp_handle* h, int64_t* mean_only, int64_t* total);
 
 /* ---- model: replaces the LGSSM / GaussMarkovModel containers -----------------------------------

@@ -995,8 +995,9 @@ int* flag_ptr(tgp_handle* h) { return reinterpret_cast<int*>(h->result.d() + 4);
 
 // ---- stationary-gain scan engine (tgp_steady.hip) ------------------------------------------------------------------------------------
 bool steady2_eligible(const tgp_handle* h, const uint8_t* missing, uint32_t flags) {
+    // (an explicit TGP_OPT_CHUNK asks for the chunked-scan engine: the chunk length means nothing here)
     return h->opt_steady2 && h->steady2_state >= 0 && !h->is_dense && !h->sde && h->lti && h->p == 1 && h->mv.sR == 0 && h->ordering == 0 &&
-           missing == nullptr && !(flags & TGP_REUSE_REDUCE) && tgp_steady::supports(h->d) && h->mv.T == h->T;
+           missing == nullptr && !(flags & TGP_REUSE_REDUCE) && tgp_steady::supports(h->d) && h->mv.T == h->T && h->opt_chunk == 0;
 }
 void steady2_begin(void* ctx, const char* name) {
     tgp_handle* h = static_cast<tgp_handle*>(ctx);
@@ -1167,7 +1168,7 @@ int tgp_set_option(tgp_handle* h, int option, int64_t value) {
         return TGP_OK;
     }
     if (option == TGP_OPT_DENSE_FUSED) {
-        h->dense_fused = value != 0;       // takes effect at the next tgp_model_set
+        h->dense_fused = value < 0 ? 0 : (value > 2 ? 2 : (int)value);       // 0 / 1 / 2; takes effect at the next tgp_model_set
         return TGP_OK;
     }
     if (option == TGP_OPT_DENSE_STRUCTURE) {

@@ -1622,7 +1622,10 @@ int posterior_marginals(Engine* e, const double* y, const uint8_t* mask, const d
     if (!e->have_model) return e->fail(TGP_EINVAL, "no model");
     if (e->ordering != 0) return e->fail(TGP_EUNSUPPORTED, "dense path: posterior of a Reverse-ordered model is not implemented");
     DCHK(hipSetDevice(e->device));
-    if (fused(e) && e->segment_opt == 0) {
+    // The persistent backward pass is a modified Bryson-Frazier recursion: it has no counterpart of the reference's 1e-10 jitter on the
+    // predicted covariance in invert_dynamics (lgssm.jl:235) and forms variances by a difference, so it agrees with the reference's RTS
+    // chain to ~1e-6 relative only. It is therefore opt-in (TGP_OPT_DENSE_FUSED = 2); the default is the jitter-faithful chain below.
+    if (fused(e) && e->fused_opt >= 2 && e->segment_opt == 0) {
         const int rcq = fused_posterior_marginals(e, y, mask, Rnew, sRn ? 1 : 0, mean_out, var_out, result8, st);
         if (rcq != TGP_EUNSUPPORTED) return rcq;
     }

@@ -1768,15 +1768,15 @@ int enqueue_d(Engine* e, hipStream_t st, const ModelDev& m, const CallDev& c, co
         return (int)hipGetLastError();
     }
     if (post) {
-        { Scope s(hk, "k_steady_reduce<post>"); hipLaunchKernelGGL((k_reduce<D, true>), dim3(blocks + 1), dim3(kBlkThreads), 0, st, tb.hdr, tb.cst, c.y, tb.F, tb.B0, tb.Fb, tb.B0b, T, ntiles, m, tb); }
-        { Scope s(hk, "k_steady_carry<post>"); hipLaunchKernelGGL((k_carry<D, true>), dim3(1), dim3(512), 0, st, tb.hdr, tb.cst, tb.Fb, tb.B0b, tb.MUb, tb.LAMb, ntiles); }
-        { Scope s(hk, "k_steady_apply<post>"); hipLaunchKernelGGL((k_apply<D, true>), dim3(blocks), dim3(kBlkThreads), 0, st, tb.hdr, tb.cst, c.y, c.Rnew, c.rnew_per_step, tb.F, tb.B0, tb.Pw, tb.Lw, tb.MUb, tb.LAMb, tb.t_vb, c.mean, c.var, tb.SSQ, T, ntiles); }
-        { Scope s(hk, "k_steady_final<post>"); hipLaunchKernelGGL(k_final<D>, dim3(2), dim3(256), 0, st, tb, T, ntiles, c.result, c.y, c.Rnew, c.rnew_per_step, c.mean, c.var); }
+        { Scope s(hk, "k_steady_reduce<posterior>"); hipLaunchKernelGGL((k_reduce<D, true>), dim3(blocks + 1), dim3(kBlkThreads), 0, st, tb.hdr, tb.cst, c.y, tb.F, tb.B0, tb.Fb, tb.B0b, T, ntiles, m, tb); }
+        { Scope s(hk, "k_steady_carry<posterior>"); hipLaunchKernelGGL((k_carry<D, true>), dim3(1), dim3(512), 0, st, tb.hdr, tb.cst, tb.Fb, tb.B0b, tb.MUb, tb.LAMb, ntiles); }
+        { Scope s(hk, "k_steady_apply<posterior>"); hipLaunchKernelGGL((k_apply<D, true>), dim3(blocks), dim3(kBlkThreads), 0, st, tb.hdr, tb.cst, c.y, c.Rnew, c.rnew_per_step, tb.F, tb.B0, tb.Pw, tb.Lw, tb.MUb, tb.LAMb, tb.t_vb, c.mean, c.var, tb.SSQ, T, ntiles); }
+        { Scope s(hk, "k_steady_final<posterior>"); hipLaunchKernelGGL(k_final<D>, dim3(2), dim3(256), 0, st, tb, T, ntiles, c.result, c.y, c.Rnew, c.rnew_per_step, c.mean, c.var); }
     } else {
-        { Scope s(hk, "k_steady_reduce<lml>"); hipLaunchKernelGGL((k_reduce<D, false>), dim3(blocks), dim3(kBlkThreads), 0, st, tb.hdr, tb.cst, c.y, tb.F, tb.B0, tb.Fb, tb.B0b, T, ntiles, m, tb); }
-        { Scope s(hk, "k_steady_carry<lml>"); hipLaunchKernelGGL((k_carry<D, false>), dim3(1), dim3(512), 0, st, tb.hdr, tb.cst, tb.Fb, tb.B0b, tb.MUb, tb.LAMb, ntiles); }
-        { Scope s(hk, "k_steady_apply<lml>"); hipLaunchKernelGGL((k_apply<D, false>), dim3(blocks), dim3(kBlkThreads), 0, st, tb.hdr, tb.cst, c.y, (const double*)nullptr, 0, tb.F, tb.B0, tb.Pw, tb.Lw, tb.MUb, tb.LAMb, tb.t_vb, (double*)nullptr, (double*)nullptr, tb.SSQ, T, ntiles); }
-        { Scope s(hk, "k_steady_final<lml>"); hipLaunchKernelGGL(k_final<D>, dim3(1), dim3(256), 0, st, tb, T, ntiles, c.result, c.y, c.Rnew, 0, (double*)nullptr, (double*)nullptr); }
+        { Scope s(hk, "k_steady_reduce<logpdf>"); hipLaunchKernelGGL((k_reduce<D, false>), dim3(blocks), dim3(kBlkThreads), 0, st, tb.hdr, tb.cst, c.y, tb.F, tb.B0, tb.Fb, tb.B0b, T, ntiles, m, tb); }
+        { Scope s(hk, "k_steady_carry<logpdf>"); hipLaunchKernelGGL((k_carry<D, false>), dim3(1), dim3(512), 0, st, tb.hdr, tb.cst, tb.Fb, tb.B0b, tb.MUb, tb.LAMb, ntiles); }
+        { Scope s(hk, "k_steady_apply<logpdf>"); hipLaunchKernelGGL((k_apply<D, false>), dim3(blocks), dim3(kBlkThreads), 0, st, tb.hdr, tb.cst, c.y, (const double*)nullptr, 0, tb.F, tb.B0, tb.Pw, tb.Lw, tb.MUb, tb.LAMb, tb.t_vb, (double*)nullptr, (double*)nullptr, tb.SSQ, T, ntiles); }
+        { Scope s(hk, "k_steady_final<logpdf>"); hipLaunchKernelGGL(k_final<D>, dim3(1), dim3(256), 0, st, tb, T, ntiles, c.result, c.y, c.Rnew, 0, (double*)nullptr, (double*)nullptr); }
     }
     return (int)hipGetLastError();
 }

@@ -506,10 +506,15 @@ class PosteriorLGSSM:
             self._model = LGSSM(post.transitions, self._emissions(), T=self.T, device=self.device)
         return self._model
 
-    def __getattr__(self, name):            # transitions, x0, handle, _whiten, handle_options, ...
-        if name.startswith("__"):
-            raise AttributeError(name)
-        return getattr(self.materialise(), name)
+    # what evaluates the reverse-time model when looked at (T x (2 d^2 + d) doubles through tgp_posterior): the fields and helpers of the
+    # plain LGSSM it stands for -- and nothing else, so that a hasattr / getattr probe for an unrelated name stays an AttributeError
+    # instead of a multi-GB evaluation
+    _EVALUATED = frozenset({"transitions", "x0", "handle", "_whiten", "handle_options", "_on_device", "_handle", "_bound", "small_out"})
+
+    def __getattr__(self, name):
+        if name in PosteriorLGSSM._EVALUATED:
+            return getattr(self.materialise(), name)
+        raise AttributeError(f"{type(self).__name__!s} has no attribute {name!r}")
 
     def fused_marginals(self):
         """marginals(self) without evaluating the posterior model; None when only the evaluated route exists."""
@@ -517,11 +522,13 @@ class PosteriorLGSSM:
             return None
         em = self._emissions()
         if isinstance(em, SmallOutputLGC) and em.dense:
-            return None
-        try:
-            return posterior_marginals(self._prior, self._y, em.R)
-        except (_lib.Unsupported, NotImplementedError):
-            return None
+            return None                 # dense new noise: the evaluated route (marginals of the materialised model)
+        if self._prior.ordering is not Forward:
+            return None                 # tgp_posterior_marginals smooths Forward priors only (lgssm.jl:223-228 is the evaluated route)
+        pem = self._prior.emissions
+        if isinstance(pem, SmallOutputLGC) and pem.dense:
+            return None                 # a prior with dense observation noise is whitened on the host: evaluated route
+        return posterior_marginals(self._prior, self._y, em.R)      # anything else that is unsupported is an ERROR, not a silent fallback
 
 
 def posterior(model, y):

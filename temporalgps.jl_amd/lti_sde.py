@@ -610,7 +610,7 @@ def _logpdf_and_gradient_sde(fx, y, rel_step):
             continue
         owner, attr = (fx.f.f.mean, "c") if name == "mean.c" else next((o, a) for n, o, a in plist if n == name)
         v0 = getattr(owner, attr)
-        hstep = rel_step * max(1.0, abs(v0))
+        hstep = rel_step * abs(v0) if v0 != 0.0 else rel_step          # relative: a small positive parameter is never stepped across zero
         setattr(owner, attr, v0 + hstep)
         bp = _sde_param_blocks(fx)
         setattr(owner, attr, v0 - hstep)
@@ -627,39 +627,50 @@ def _logpdf_and_gradient_sde(fx, y, rel_step):
 def _logpdf_and_gradient_fd(fx, y, rel_step=1e-4):
     """Central differences of the device logpdf: 2 evaluations per parameter, each a re-bind of the (O(1), shared-block) model
     plus one logpdf on the group kernels. Relative accuracy ~1e-7 (the h^2 truncation term and the 1e-11 rounding of logpdf
-    divided by 2 h balance around h = 1e-4)."""
+    divided by 2 h balance around h = 1e-4 |v|). The step is RELATIVE to the parameter (never larger than half of it), so that a
+    small positive parameter -- a noise variance of 1e-6 -- is never evaluated at a negative value; whatever happens in an
+    evaluation, the perturbed attribute is restored."""
+    if fx.sigma2.shape[0] != 1:
+        raise NotImplementedError("logpdf_and_gradient: heteroscedastic noise needs per-step tangents; use equal noise variances")
     plist = parameters(fx.f.f.kernel)
     entries = list(plist) + [("noise", None, None)] + ([("mean.c", fx.f.f.mean, "c")] if isinstance(fx.f.f.mean, ConstMean) else [])
-    if fx.sigma2.shape[0] != 1:
-        entries = [e for e in entries if e[0] != "noise"]
     lp = logpdf(fx, y)
     grad = {}
+
+    def step_for(v0):
+        return rel_step * abs(v0) if v0 != 0.0 else rel_step
+
     for name, owner, attr in entries:
         if owner is None:
             v0 = float(fx.sigma2[0])
-            hstep = rel_step * max(1.0, abs(v0))
+            hstep = step_for(v0)
             vals = []
-            for sgn in (1.0, -1.0):
-                fx.sigma2 = np.array([v0 + sgn * hstep])
-                vals.append(logpdf(fx, y))
-            fx.sigma2 = np.array([v0])
+            try:
+                for sgn in (1.0, -1.0):
+                    fx.sigma2 = np.array([v0 + sgn * hstep])
+                    vals.append(logpdf(fx, y))
+            finally:
+                fx.sigma2 = np.array([v0])
         else:
             v0 = getattr(owner, attr)
-            hstep = rel_step * max(1.0, abs(v0))
+            hstep = step_for(v0)
             vals = []
-            for sgn in (1.0, -1.0):
-                setattr(owner, attr, v0 + sgn * hstep)
-                vals.append(logpdf(fx, y))
-            setattr(owner, attr, v0)
+            try:
+                for sgn in (1.0, -1.0):
+                    setattr(owner, attr, v0 + sgn * hstep)
+                    vals.append(logpdf(fx, y))
+            finally:
+                setattr(owner, attr, v0)
         grad[name] = (vals[0] - vals[1]) / (2 * hstep)
     return lp, grad
 
 
-def logpdf_and_gradient(fx, y, rel_step=1e-6, method=None):
+def logpdf_and_gradient(fx, y, rel_step=None, method=None):
     """(logpdf(fx, y), {name: d logpdf / d parameter}) for the kernel hyper-parameters (`parameters`), the noise
     variance ("noise") and a ConstMean ("mean.c"). The T-step work -- value and tangents -- runs on the device as
     forward-mode tangent scans; the derivative of the O(1) host map parameter -> (A, Q, H, ..., x0) is a central
-    finite difference of that tiny map (relative step 1e-6: truncation ~1e-12, rounding ~1e-10).
+    finite difference of that tiny map (relative step `rel_step`, default 1e-6: truncation ~1e-12, rounding ~1e-10; the "fd" method
+    differences the logpdf itself and defaults to 1e-4).
     Regular spacing with homoscedastic noise: any supported state dimension. Irregular spacing: d <= 4, shared or per-step
     noise; the per-step tangents of exp(F dt_k) are formed on the device (tgp_logpdf_grad_sde).
     method: None (default policy), "tangent" (the forward-mode scans) or "fd" (central differences of the device logpdf).
@@ -669,7 +680,8 @@ def logpdf_and_gradient(fx, y, rel_step=1e-6, method=None):
     if method not in (None, "tangent", "fd"):
         raise ValueError("method must be None, 'tangent' or 'fd'")
     if method == "fd" or (method is None and isinstance(fx.x, RegularSpacing) and fx.build_lgssm().dim >= 9):
-        return _logpdf_and_gradient_fd(fx, y)
+        return _logpdf_and_gradient_fd(fx, y, rel_step=1e-4 if rel_step is None else rel_step)
+    rel_step = 1e-6 if rel_step is None else rel_step
     if not isinstance(fx.x, RegularSpacing):
         # any plain array of inputs -- uniformly spaced or not -- is the reference's AbstractVector path (lti_sde.jl:135-146:
         # per-step blocks, dt_1 := 1), so its gradient goes through the SDE-described model; only RegularSpacing is LTI
@@ -683,7 +695,7 @@ def logpdf_and_gradient(fx, y, rel_step=1e-6, method=None):
             tangents.append(dict(R=1.0))
             continue
         v0 = getattr(owner, attr)
-        hstep = rel_step * max(1.0, abs(v0))
+        hstep = rel_step * abs(v0) if v0 != 0.0 else rel_step          # relative: a small positive parameter is never stepped across zero
         setattr(owner, attr, v0 + hstep)
         bp = _shared_blocks(fx)
         setattr(owner, attr, v0 - hstep)

@@ -63,6 +63,12 @@ def random_lgssm(rng, tv, d, T, ordering="F"):
     a = rng.standard_normal((n, d))
     Q = np.stack([psd(d, 0.2, 1.5) for _ in range(n)])
     H, h, R = rng.standard_normal((n, d)), rng.standard_normal(n), rng.random(n) + 0.1
+    if ordering == "R":
+        # step_posterior(::Reverse) (lgssm.jl:223-228) calls invert_dynamics with predicted and filtered state swapped: its G is
+        # (A Pf A' + Q) A' Pf^-1, contractive only for weak transitions and weakly informative observations. Models are drawn there, so
+        # that the posterior of a Reverse model can be run forward over hundreds of steps without overflow (in the oracle as well).
+        A = 0.3 * A
+        R = R + 2.0
     return dict(ordering=ordering, kind="scalar", T=T, A=A, a=a, Q=Q, H=H, h=h, R=R, x0m=x0m, x0P=x0P)
 
 

@@ -222,7 +222,7 @@ def test_persistent_kernel_and_kernel_chain_agree(d, p, ordering, per_step):
     T = 40
     model, Rd = random_model(rng, T, d, p, ordering, per_step)
     y = np.where(rng.random((T, p)) < 0.15, np.nan, rng.standard_normal((T, p)))
-    fused, chain = to_dev(tgp, model, Rd), to_dev(tgp, model, Rd, {_lib.OPT_DENSE_FUSED: 0})
+    fused, chain = to_dev(tgp, model, Rd, {_lib.OPT_DENSE_FUSED: 2}), to_dev(tgp, model, Rd, {_lib.OPT_DENSE_FUSED: 0})     # 2: the backward pass too
     assert fused.handle().lib.tgp_kernel_variant(fused.handle().h) & 4
     assert not chain.handle().lib.tgp_kernel_variant(chain.handle().h) & 4
     lf, lc = tgp.logpdf(fused, y), tgp.logpdf(chain, y)
@@ -252,8 +252,9 @@ def test_persistent_kernel_and_kernel_chain_agree(d, p, ordering, per_step):
 
 def test_mid_d_gp_posterior_persistent_pass_vs_the_reference_algorithm():
     """A real GP of mid-sized state: sum of six stretched Matern-5/2 kernels (d = 18), dt = 0.05. The kernel chain
-    (TGP_OPT_DENSE_FUSED = 0) is the reference's own RTS algebra, jitter included, and matches the oracle to 1e-8. The default
-    persistent passes run the Bryson-Frazier form, which has NO counterpart of the 1e-10 jitter on the predicted covariance
+    (TGP_OPT_DENSE_FUSED = 0) is the reference's own RTS algebra, jitter included, and matches the oracle to 1e-8; so does the default
+    (persistent filter pass, the same RTS chain backwards). The opt-in persistent backward pass (TGP_OPT_DENSE_FUSED = 2) runs the
+    Bryson-Frazier form, which has NO counterpart of the 1e-10 jitter on the predicted covariance
     (lgssm.jl:235): they agree with the oracle to the size of that jitter's own effect on the reference's result (measured here:
     a few 1e-9 of the mean's scale; bound asserted: 1e-6, the reference's own bar against the dense GP being rtol 1e-5,
     test/gp/posterior_lti_sde.jl:82-89), and the log marginal likelihood (filter only) to 1e-10 either way."""
@@ -281,7 +282,13 @@ def test_mid_d_gp_posterior_persistent_pass_vs_the_reference_algorithm():
     assert abs(lc - lp_ref) <= 1e-10 * abs(lp_ref)
     np.testing.assert_allclose(mc, pm, rtol=0, atol=1e-8 * np.abs(pm).max())
     np.testing.assert_allclose(vc, pv, rtol=1e-8, atol=1e-10)
-    lf, mf, vf = dev({})
+    # the default: persistent filter pass, the reference's jittered RTS chain backwards -- relative check of every variance
+    ld, md, vd = dev({})
+    assert abs(ld - lp_ref) <= 1e-10 * abs(lp_ref)
+    np.testing.assert_allclose(md, pm, rtol=0, atol=1e-8 * np.abs(pm).max())
+    np.testing.assert_allclose(vd, pv, rtol=1e-8, atol=1e-10)
+    # opt-in (TGP_OPT_DENSE_FUSED = 2): the persistent Bryson-Frazier backward pass, no jitter: looser by construction
+    lf, mf, vf = dev({_lib.OPT_DENSE_FUSED: 2})
     assert abs(lf - lp_ref) <= 1e-10 * abs(lp_ref)
     print("persistent pass vs jittered RTS: mean", np.abs(mf - pm).max() / np.abs(pm).max(), "var", np.abs(vf - pv).max() / pv.max())
     np.testing.assert_allclose(mf, pm, rtol=0, atol=1e-6 * np.abs(pm).max())

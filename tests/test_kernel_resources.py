@@ -19,6 +19,8 @@ COVERED = [  # (pattern of the demangled kernel name, where its values are check
     (r"tgp::k_tile_sde<8>", "tests/test_gpu_gp_api.py (irregular inputs, d = 8 sum kernels)"),
     (r"tgp::k_(reduce|apply)_filter_ad<[78],", "tests/test_gpu_gradient.py (d up to 8)"),
     (r"tgp::k_scan_(apply|reduce)<.*FilterMonoidAD<[34]>", "tests/test_gpu_gradient.py (d = 3, 4)"),
+    (r"tgp_steady::", "tests/test_gpu_steady_scan.py::test_every_state_dimension_against_the_oracle (every d = 1..8: the one-wave setup and "
+                      "head kernels of d >= 6 hold whole d x d matrices per lane)"),
 ]
 
 
