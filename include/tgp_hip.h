@@ -123,6 +123,8 @@ const char* tgp_last_error(const tgp_handle* h);
 int tgp_set_option(tgp_handle* h, int option, int64_t value);
 /* run on a caller-provided hipStream_t (e.g. torch's current stream); NULL restores the handle's own */
 int tgp_set_stream(tgp_handle* h, void* hip_stream);
+/* the stream the handle's work is enqueued on (its own unless tgp_set_stream replaced it), as a hipStream_t */
+int tgp_get_stream(tgp_handle* h, void** hip_stream);
 const char* tgp_version(void);
 /* which build of the kernels the current model runs on: 1 out-of-line (safe), 2 fully inlined (d = 5, 6 after the check);
    dense path (d > 16): 16 + (1 if A is applied in sparse form) + (2 if H is) + (4 if the passes run as one persistent
@@ -270,6 +272,42 @@ int tgp_shard_logpdf(tgp_handle* h, double* stats_dev);
 int tgp_shard_smoother_forward(tgp_handle* h, double* slot_dev);
 int tgp_shard_smoother_backward(tgp_handle* h, const double* gathered_dev, int world, int rank, const double* Rnew,
                                 uint32_t flags, double* mean_out, double* var_out, double* lml_out);
+
+/* ---- multi-GPU handle: the same protocol inside ONE process (SURVEY.md 8b "Threading", 8e) -----------
+ * tgp_create_multi owns, per listed device, one tgp_handle with its own HIP stream, one host worker thread and
+ * one RCCL communicator (ncclCommInitAll; librccl is opened at run time). Rank r serves the contiguous time
+ * segment [t0_r, t1_r) of tgp_multi_segment. A call runs the tgp_shard_* phases of every rank concurrently
+ * and exchanges the per-segment scan elements with ncclAllGather on the ranks' streams -- twice per posterior
+ * call, once per logpdf; the W x 4 result words are summed on the host (one process: no all-reduce needed).
+ * No bulk data crosses xGMI; inputs and outputs stay sharded: every per-call array argument is an ARRAY OF
+ * ndev POINTERS, entry r addressing rank r's segment (host memory: `y + t0_r`; or, with TGP_IN_DEVICE /
+ * TGP_OUT_DEVICE, memory of rank r's device). `missing` may be NULL; with TGP_SHARED_R each Rnew[r] points to
+ * one value. devices == NULL: devices 0..ndev-1 (ndev == 0: every visible device). A device listed more than
+ * once (several ranks on one GPU: tests) or TGP_MULTI_TRANSPORT=copy replaces RCCL by event-ordered peer copies.
+ * Scan engine only (d <= 16, Forward ordering); the dense path (d > 16) does not time-shard.
+ * Replaces: the sequential loop of src/util/scan.jl:15-28 behind logpdf (lgssm.jl:147-151) and
+ * marginals(posterior(...)) (lgssm.jl:193-200, :111-115) for a series that spans the GPUs of a node. */
+typedef struct tgp_multi tgp_multi;
+int tgp_create_multi(tgp_multi** m, int ndev, const int* devices);
+int tgp_destroy_multi(tgp_multi* m);
+const char* tgp_multi_last_error(const tgp_multi* m);
+int tgp_multi_ndev(const tgp_multi* m);
+const char* tgp_multi_transport(const tgp_multi* m); /* "rccl" or "copy (<why>)" */
+tgp_handle* tgp_multi_handle(tgp_multi* m, int rank); /* borrowed: options, profile, diagnostics of one rank */
+int tgp_multi_segment(int64_t T, int ndev, int rank, int64_t* t0, int64_t* t1);
+int tgp_multi_set_option(tgp_multi* m, int option, int64_t value);
+/* as tgp_model_set, host pointers for the WHOLE series: shared (Fill) blocks go to every rank, per-step arrays are
+ * sliced per segment; x0 is the prior of the whole series */
+int tgp_multi_model_set(tgp_multi* m, int64_t T, int d, int p, int ordering, uint32_t flags, const double* A,
+                        const double* a, const double* Q, const double* H, const double* hh, const double* R,
+                        const double* x0m, const double* x0P);
+int tgp_multi_logpdf(tgp_multi* m, const double* const* y, const uint8_t* const* missing, uint32_t flags, double* out);
+int tgp_multi_posterior_marginals(tgp_multi* m, const double* const* y, const uint8_t* const* missing,
+                                  const double* const* Rnew, uint32_t flags, double* const* mean_out,
+                                  double* const* var_out);
+int tgp_multi_logpdf_and_posterior_marginals(tgp_multi* m, const double* const* y, const uint8_t* const* missing,
+                                             const double* const* Rnew, uint32_t flags, double* lml_out,
+                                             double* const* mean_out, double* const* var_out);
 
 /* ---- timing ------------------------------------------------------------------------------------ */
 /* device time of the last call (hipEvent, kernels only) and its host<->device copy times, ms; needs TGP_OPT_TIMING = 1 */

@@ -7,5 +7,7 @@ from . import _lib
 from .lgssm import (LGSSM, PosteriorLGSSM, Forward, Gaussian, GaussMarkovModel, Reverse, ScalarOutputLGC, SmallOutputLGC, LargeOutputLGC, BottleneckLGC, _filter, logpdf, marginals,
                     posterior, posterior_marginals, logpdf_and_posterior_marginals, posterior_marginals_at, rand, replace_observation_noise_cov)
 
-__all__ = ["LGSSM", "PosteriorLGSSM", "Forward", "Reverse", "Gaussian", "GaussMarkovModel", "ScalarOutputLGC", "SmallOutputLGC", "LargeOutputLGC", "BottleneckLGC", "logpdf", "_filter",
+from .multi import MultiLGSSM
+
+__all__ = ["MultiLGSSM", "LGSSM", "PosteriorLGSSM", "Forward", "Reverse", "Gaussian", "GaussMarkovModel", "ScalarOutputLGC", "SmallOutputLGC", "LargeOutputLGC", "BottleneckLGC", "logpdf", "_filter",
            "posterior", "marginals", "posterior_marginals", "logpdf_and_posterior_marginals", "posterior_marginals_at", "rand", "replace_observation_noise_cov", "_lib"]

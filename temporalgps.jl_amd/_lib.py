@@ -34,6 +34,7 @@ _SIGS = {
     "tgp_last_error": (ctypes.c_char_p, [_vp]),
     "tgp_set_option": (ctypes.c_int, [_vp, ctypes.c_int, _i64]),
     "tgp_set_stream": (ctypes.c_int, [_vp, _vp]),
+    "tgp_get_stream": (ctypes.c_int, [_vp, ctypes.POINTER(_vp)]),
     "tgp_version": (ctypes.c_char_p, []),
     "tgp_kernel_variant": (ctypes.c_int, [_vp]),
     "tgp_graph_replays": (_i64, [_vp]),
@@ -63,6 +64,18 @@ _SIGS = {
     "tgp_shard_logpdf": (ctypes.c_int, [_vp, _vp]),
     "tgp_shard_smoother_forward": (ctypes.c_int, [_vp, _vp]),
     "tgp_shard_smoother_backward": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, _vp, _u32, _vp, _vp, _dp]),
+    "tgp_create_multi": (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),
+    "tgp_destroy_multi": (ctypes.c_int, [_vp]),
+    "tgp_multi_last_error": (ctypes.c_char_p, [_vp]),
+    "tgp_multi_ndev": (ctypes.c_int, [_vp]),
+    "tgp_multi_transport": (ctypes.c_char_p, [_vp]),
+    "tgp_multi_handle": (_vp, [_vp, ctypes.c_int]),
+    "tgp_multi_segment": (ctypes.c_int, [_i64, ctypes.c_int, ctypes.c_int, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
+    "tgp_multi_set_option": (ctypes.c_int, [_vp, ctypes.c_int, _i64]),
+    "tgp_multi_model_set": (ctypes.c_int, [_vp, _i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, _u32] + [_vp] * 8),
+    "tgp_multi_logpdf": (ctypes.c_int, [_vp, _vp, _vp, _u32, _dp]),
+    "tgp_multi_posterior_marginals": (ctypes.c_int, [_vp, _vp, _vp, _vp, _u32, _vp, _vp]),
+    "tgp_multi_logpdf_and_posterior_marginals": (ctypes.c_int, [_vp, _vp, _vp, _vp, _u32, _dp, _vp, _vp]),
     "tgp_last_timing": (ctypes.c_int, [_vp, _dp, _dp, _dp]),
     "tgp_profile_reset": (ctypes.c_int, [_vp]),
     "tgp_profile_count": (ctypes.c_int, [_vp]),

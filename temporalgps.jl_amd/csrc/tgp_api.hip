@@ -1237,6 +1237,12 @@ int tgp_set_stream(tgp_handle* h, void* hip_stream) {
     return TGP_OK;
 }
 
+int tgp_get_stream(tgp_handle* h, void** hip_stream) {
+    if (!h || !hip_stream) return TGP_EINVAL;
+    *hip_stream = static_cast<void*>(h->stream);
+    return TGP_OK;
+}
+
 int tgp_model_set(tgp_handle* h, int64_t T, int d, int p, int ordering, uint32_t flags, const double* A, const double* a,
                   const double* Q, const double* H, const double* hh, const double* R, const double* x0m, const double* x0P) {
     if (h) drop_graphs(h);

@@ -1,0 +1,146 @@
+"""GPU tier: the in-library multi-GPU handle (tgp_create_multi ..., csrc/tgp_multi.hip) against the unsharded oracle.
+
+The box has ONE GPU: ranks that share cuda:0 exercise the whole protocol (worker threads, phase boundaries, the
+event-ordered copy transport, folds on the device); a 1-rank handle goes through RCCL proper (ncclCommInitAll,
+ncclAllGather on the handle's stream); distinct devices are used when the box has them."""
+import numpy as np
+import pytest
+
+from oracle import components as oc
+from oracle import lgssm_ref as ref
+from oracle import seq_kalman as sk
+from tests import _util as U
+
+pytestmark = pytest.mark.gpu
+
+LOGPDF_RTOL, MARGINAL_ATOL = 1e-10, 1e-8
+
+
+def _dev_model(tgp, model):
+    tr = tgp.GaussMarkovModel(tgp.Forward, model["A"], model["a"], model["Q"], tgp.Gaussian(model["x0m"], model["x0P"]))
+    return tgp.LGSSM(tr, tgp.ScalarOutputLGC(model["H"], np.atleast_1d(model["h"]), np.atleast_1d(model["R"])), T=model["T"])
+
+
+def _check(ms, model, y, Rnew, mask=None):
+    yy = y if mask is None else (y, mask)
+    if mask is None:
+        lp_ref = sk.logpdf(model, y)
+        pm, pv = sk.posterior_marginals(model, y, Rnew)
+    else:
+        lp_ref = ref.logpdf_missing(model, y, mask)
+        post = ref.posterior_missing(model, y, mask)
+        pm, pv = ref.marginals(ref.replace_observation_noise_cov(post, np.broadcast_to(Rnew, (model["T"],))))
+    lp = ms.logpdf(yy)
+    assert abs(lp - lp_ref) <= LOGPDF_RTOL * abs(lp_ref), (lp, lp_ref)
+    mean, var = ms.posterior_marginals(yy, Rnew)
+    assert np.max(np.abs(mean - pm)) <= MARGINAL_ATOL and np.max(np.abs(var - pv)) <= MARGINAL_ATOL
+    lp2, mean2, var2 = ms.logpdf_and_posterior_marginals(yy, Rnew)
+    assert abs(lp2 - lp_ref) <= LOGPDF_RTOL * abs(lp_ref)
+    assert np.array_equal(mean2, mean) and np.array_equal(var2, var)
+    assert ms.logpdf(yy) == lp          # a second round on the same handles (carry-ins replaced again)
+
+
+@pytest.mark.parametrize("ndev", [1, 2, 3, 5])
+def test_lti_series_over_ranks_sharing_one_gpu(ndev):
+    import temporalgps_jl_amd as tgp
+    T = 120_007
+    model = oc.build_lgssm(("matern52",), ("regular", 0.0, 0.1, T), 0.1)
+    y = np.random.default_rng(11).standard_normal(T)
+    ms = tgp.MultiLGSSM(_dev_model(tgp, model), devices=[0] * ndev)
+    assert ms.transport.startswith("rccl" if ndev == 1 else "copy"), ms.transport
+    _check(ms, model, y, np.array([0.05]))
+
+
+def test_rccl_transport_single_rank_goes_through_ncclAllGather():
+    """ndev = 1 on distinct devices [0]: ncclCommInitAll + ncclAllGather on the handle's stream (the transport string says which)."""
+    import temporalgps_jl_amd as tgp
+    T = 50_000
+    model = oc.build_lgssm(("sum", ("matern52",), ("matern12",)), ("regular", 0.0, 0.1, T), 0.1)      # d = 4 (BASELINE config 4's model)
+    y = np.random.default_rng(12).standard_normal(T)
+    ms = tgp.MultiLGSSM(_dev_model(tgp, model), devices=[0])
+    assert ms.transport == "rccl", ms.transport
+    _check(ms, model, y, np.array([1e-18]))
+
+
+def test_distinct_devices_when_the_box_has_them():
+    import torch
+    import temporalgps_jl_amd as tgp
+    n = min(2, torch.cuda.device_count())
+    if n < 2:
+        pytest.skip("one GPU visible: the distinct-device RCCL group needs two")
+    T = 200_001
+    model = oc.build_lgssm(("matern52",), ("regular", 0.0, 0.1, T), 0.1)
+    y = np.random.default_rng(13).standard_normal(T)
+    ms = tgp.MultiLGSSM(_dev_model(tgp, model), devices=list(range(n)))
+    assert ms.transport == "rccl", ms.transport
+    _check(ms, model, y, np.array([0.05]))
+
+
+@pytest.mark.parametrize("d", [1, 2, 5])
+def test_per_step_model_with_missing_observations(d):
+    """explicit per-step blocks (sliced per segment by tgp_multi_model_set), per-step R_new, a missing mask"""
+    import temporalgps_jl_amd as tgp
+    T, ndev = 4_001, 3
+    rng = np.random.default_rng(20 + d)
+    model = U.random_lgssm(rng, True, d, T)
+    y = ref.rand(model, rng.standard_normal((T, d)), rng.standard_normal(T), rng.standard_normal(d))
+    mask = rng.random(T) < 0.1
+    Rnew = rng.random(T) + 0.05
+    ms = tgp.MultiLGSSM(_dev_model(tgp, model), devices=[0] * ndev)
+    lp_ref = ref.logpdf_missing(model, y, mask)
+    lp = ms.logpdf((y, mask))
+    assert abs(lp - lp_ref) <= LOGPDF_RTOL * abs(lp_ref)
+    post = ref.posterior_missing(model, y, mask)
+    pm, pv = ref.marginals(ref.replace_observation_noise_cov(post, Rnew))
+    mean, var = ms.posterior_marginals((y, mask), Rnew)
+    assert np.max(np.abs(mean - pm)) <= MARGINAL_ATOL and np.max(np.abs(var - pv)) <= MARGINAL_ATOL
+
+
+def test_device_resident_segments():
+    """one CUDA tensor per rank in, one per rank out (TGP_IN_DEVICE | TGP_OUT_DEVICE)"""
+    import torch
+    import temporalgps_jl_amd as tgp
+    T, ndev = 90_001, 3
+    model = oc.build_lgssm(("matern32",), ("regular", 0.0, 0.1, T), 0.1)
+    y = np.random.default_rng(14).standard_normal(T)
+    ms = tgp.MultiLGSSM(_dev_model(tgp, model), devices=[0] * ndev)
+    parts = [torch.as_tensor(y[lo:hi], device="cuda:0") for lo, hi in ms.bounds]
+    lp_ref = sk.logpdf(model, y)
+    pm, pv = sk.posterior_marginals(model, y, np.array([0.05]))
+    lp, mean, var = ms.logpdf_and_posterior_marginals(parts, np.array([0.05]))
+    assert abs(lp - lp_ref) <= LOGPDF_RTOL * abs(lp_ref)
+    mean, var = (np.concatenate([t.cpu().numpy() for t in x]) for x in (mean, var))
+    assert np.max(np.abs(mean - pm)) <= MARGINAL_ATOL and np.max(np.abs(var - pv)) <= MARGINAL_ATOL
+
+
+@pytest.mark.timeout(120)
+def test_a_failing_rank_stops_every_rank():
+    """a segment whose innovation variance is not positive: TGP_ENOTPD from the call, no rank left waiting at a phase boundary,
+    and the handle serves the next (valid) call"""
+    import temporalgps_jl_amd as tgp
+    T, ndev, d = 3_000, 3, 2
+    rng = np.random.default_rng(15)
+    model = U.random_lgssm(rng, True, d, T)
+    y = rng.standard_normal(T)
+    bad = dict(model, R=model["R"].copy())
+    bad["R"][T // 2] = -1e6           # inside rank 1's segment
+    ms = tgp.MultiLGSSM(_dev_model(tgp, bad), devices=[0] * ndev)
+    with pytest.raises(tgp._lib.NotPositiveDefinite):
+        ms.logpdf(y)
+    with pytest.raises(tgp._lib.NotPositiveDefinite):
+        ms.posterior_marginals(y, np.array([0.1]))
+    good = tgp.MultiLGSSM(_dev_model(tgp, model), devices=[0] * ndev)
+    lp_ref = ref.logpdf(model, y)
+    assert abs(good.logpdf(y) - lp_ref) <= LOGPDF_RTOL * abs(lp_ref)
+
+
+def test_unsupported_models_are_refused():
+    import temporalgps_jl_amd as tgp
+    rng = np.random.default_rng(16)
+    rev = U.random_lgssm(rng, False, 2, 100, "R")
+    tr = tgp.GaussMarkovModel(tgp.Reverse, rev["A"], rev["a"], rev["Q"], tgp.Gaussian(rev["x0m"], rev["x0P"]))
+    with pytest.raises(tgp._lib.Unsupported):
+        tgp.MultiLGSSM(tgp.LGSSM(tr, tgp.ScalarOutputLGC(rev["H"], rev["h"], rev["R"]), T=100), devices=[0, 0])
+    m = U.random_lgssm(rng, False, 2, 3)
+    with pytest.raises(tgp._lib.TGPError):          # fewer steps than ranks
+        tgp.MultiLGSSM(_dev_model(tgp, m), devices=[0] * 4)
