@@ -185,6 +185,24 @@ int tgp_logpdf_grad_sde(tgp_handle* h, const double* y, const uint8_t* missing, 
                         const double* dh, const double* dR, const double* dx0m, const double* dx0P, double rel_step,
                         double* lml_out, double* grad_out);
 
+/* ---- logpdf and its gradient with respect to the MODEL BLOCKS by one adjoint (reverse-time) pass -------------------
+ * Forward LTI models (every block shared: the reference's Fill layout of RegularSpacing inputs, lti_sde.jl:148-160) with
+ * one noise variance, scalar observations, no missing data, d <= 8 -- the models of the stationary-gain engine. One
+ * forward and one backward mean recursion over the series (the cost of a posterior-marginals call, whatever the number
+ * of hyper-parameters) leave the sums behind d logpdf / d (A, a, Q, H, h, R, x0m, x0P); the host finishes with the head's
+ * steps and a reverse sweep through the ~n0 steps of the covariance recursion. The caller contracts the block gradients
+ * with d block / d theta of its own parametrisation (the O(1) host map lti_sde.jl:148-160). Any output may be NULL.
+ * gA, gQ, gx0P [d*d] column-major (gQ, gx0P symmetrised), ga, gH, gx0m [d], ghh, gR [1]; all host pointers.
+ * Replaces Mooncake's reverse mode over the sequential loop (bench/single_output_gps.jl:149-156, test/gp/lti_sde.jl:203-206).
+ * TGP_EUNSUPPORTED when the engine does not apply (use tgp_logpdf_grad). */
+int tgp_logpdf_adjoint(tgp_handle* h, const double* y, uint32_t flags, double* lml_out, double* gA, double* ga,
+                       double* gQ, double* gH, double* ghh, double* gR, double* gx0m, double* gx0P);
+/* the host half of it, a pure host function (tests; callers that keep the device record): rec = tgp_adjoint_record_size(d)
+ * doubles as tgp_steady.hpp lays them out, y_head = the first n_head observations (n_head >= 512 * head tiles) */
+int tgp_adjoint_record_size(int d);
+int tgp_adjoint_finish(int d, const double* rec, const double* y_head, int64_t n_head, double* gA, double* ga, double* gQ,
+                       double* gH, double* ghh, double* gR, double* gx0m, double* gx0P);
+
 /* ---- _filter(model, y): lgssm.jl:171-187. m_out [T][d], P_out [T][d*d] (either may be NULL);
  *      lml_out (host, may be NULL) receives the log marginal likelihood as a by-product. */
 int tgp_filter(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t flags, double* m_out,

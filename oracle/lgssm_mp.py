@@ -114,3 +114,68 @@ def run(model, y, R_new=None, missing=None):
             x, Px = G * x + g, (G * _sym_upper(Px)) * G.T + Lq
         out.update(post_mean=mean, post_var=var)
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# 50-digit logpdf of a sum of scaled, stretched Matern kernels on a regular grid, INCLUDING the map hyper-parameters -> blocks
+# (lti_sde.jl:148-160: A = exp(F s dt), Q = P - A P A'; :205-235 the Matern tables; :324-346 scaling; :350-373 stretching; :404-422 sums),
+# and its gradient by central differences in the same arithmetic (step 1e-20 relative: truncation ~1e-40, rounding ~1e-30) -- the
+# reference value the device gradients are held against (tests/test_gpu_gradient.py). Test infrastructure.
+def _matern_mp(name):
+    if name == "matern12":
+        return mp.matrix([[-1]]), mp.matrix([[1]])
+    if name == "matern32":
+        lam = mp.sqrt(3)
+        return mp.matrix([[0, 1], [-3, -2 * lam]]), mp.matrix([[1, 0], [0, 3]])
+    if name == "matern52":
+        lam, kap = mp.sqrt(5), mp.mpf(5) / 3
+        return mp.matrix([[0, 1, 0], [0, 0, 1], [-lam ** 3, -3 * lam ** 2, -3 * lam]]), mp.matrix([[1, 0, -kap], [0, kap, 0], [-kap, 0, 25]])
+    raise ValueError(name)
+
+
+def lti_blocks_mp(terms, dt):
+    """terms: [(name, sigma2, stretch), ...] -> (A, Q, H, P0) as mp matrices (block diagonal / concatenated)"""
+    parts = []
+    for name, s2, s in terms:
+        F, P = _matern_mp(name)
+        A = mp.expm(F * (mp.mpf(s) * mp.mpf(dt)))
+        parts.append((A, P - A * P * A.T, mp.sqrt(mp.mpf(s2)), P))
+    d = sum(p[0].rows for p in parts)
+    A, Q, P0, H = mp.zeros(d, d), mp.zeros(d, d), mp.zeros(d, d), mp.zeros(d, 1)
+    o = 0
+    for Ai, Qi, sig, Pi in parts:
+        n = Ai.rows
+        for i in range(n):
+            for j in range(n):
+                A[o + i, o + j], Q[o + i, o + j], P0[o + i, o + j] = Ai[i, j], Qi[i, j], Pi[i, j]
+        H[o, 0] = sig
+        o += n
+    return A, Q, H, P0
+
+
+def lti_logpdf_mp(terms, dt, sigma2, y):
+    A, Q, H, P = lti_blocks_mp(terms, dt)
+    d = A.rows
+    m, a, R, h = mp.zeros(d, 1), mp.zeros(d, 1), mp.mpf(sigma2), mp.mpf(0)
+    lml = mp.mpf(0)
+    for yt in y:
+        mpred, Ppred = predict(m, P, A, a, Q)
+        m, P, l = update_scalar(mpred, Ppred, H, h, R, mp.mpf(float(yt)))
+        lml += l
+    return lml
+
+
+def lti_gradient_mp(terms, dt, sigma2, y, rel=mp.mpf("1e-20")):
+    """-> (logpdf, [d / d sigma2_i, d / d stretch_i for every term ..., d / d noise]) as Python floats"""
+    def f(vec):
+        tt = [(terms[i][0], vec[2 * i], vec[2 * i + 1]) for i in range(len(terms))]
+        return lti_logpdf_mp(tt, dt, vec[-1], y)
+    v0 = [mp.mpf(x) for t in terms for x in (t[1], t[2])] + [mp.mpf(sigma2)]
+    grad = []
+    for k in range(len(v0)):
+        hs = rel * v0[k]
+        vp, vm = list(v0), list(v0)
+        vp[k] += hs
+        vm[k] -= hs
+        grad.append(float((f(vp) - f(vm)) / (2 * hs)))
+    return float(f(v0)), grad

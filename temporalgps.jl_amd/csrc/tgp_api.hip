@@ -20,6 +20,7 @@
 #include "tgp_kernels.hpp"
 #include "tgp_dense.hpp"
 #include "tgp_steady.hpp"
+#include "tgp_adjoint_host.hpp"
 
 namespace tgp {
 const KernelTable *kernel_table_d1(), *kernel_table_d2(), *kernel_table_d3(), *kernel_table_d4(), *kernel_table_d5(),
@@ -295,6 +296,7 @@ struct tgp_handle {
     int steady2_state = 0;       // 0 untried for the bound model, 1 served the last call, -1 does not apply
     bool steady2_last = false;   // the last logpdf / posterior-marginals call was served by it
     void* steady2_scope = nullptr;
+    double* adj_host = nullptr;  // pinned: the record + the head's observations of an adjoint call
     DevBuf steady_rec;           // ... the chunks' records (ModelView::steady)
     int steady_calls = 0;        // 1: the last posterior-path forward pass (mode 2) wrote the records
     // Policy of the posterior path: the build with these steps has slightly longer full steps, and a pass takes as long as its slowest
@@ -1009,7 +1011,7 @@ void steady2_end(void* ctx) {
     h->steady2_scope = nullptr;
 }
 // Enqueues the call on the engine (y already staged in h->mv.y). mean_dev == nullptr: logpdf only.
-int steady2_enqueue(tgp_handle* h, const double* Rnew_dev, bool rnew_per_step, double* mean_dev, double* var_dev) {
+int steady2_enqueue(tgp_handle* h, const double* Rnew_dev, bool rnew_per_step, double* mean_dev, double* var_dev, bool grad = false) {
     if (!h->steady2) h->steady2 = tgp_steady::create();
     tgp_steady::ModelDev md;
     md.d = h->d;
@@ -1023,6 +1025,7 @@ int steady2_enqueue(tgp_handle* h, const double* Rnew_dev, bool rnew_per_step, d
     cd.mean = mean_dev;
     cd.var = var_dev;
     cd.result = h->result.d();
+    cd.grad = grad;
     tgp_steady::Hooks hk;
     if (h->profile) {
         hk.ctx = h;
@@ -1110,6 +1113,7 @@ int tgp_destroy(tgp_handle* h) {
     if (h->dense) tgp_dense::destroy(h->dense);
     if (h->steady2) tgp_steady::destroy(h->steady2);
     if (h->host_result) (void)hipHostFree(h->host_result);
+    if (h->adj_host) (void)hipHostFree(h->adj_host);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
     return TGP_OK;
@@ -1454,6 +1458,49 @@ int tgp_logpdf(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t 
     TRY(forward_apply(h, 0, fo));
     tm.kernels_done();
     return tm.finish(out);
+}
+
+int tgp_adjoint_record_size(int d) { return (d >= 1 && d <= tgp_steady::kMaxD) ? tgp_adjoint::record_size(d) : 0; }
+
+int tgp_adjoint_finish(int d, const double* rec, const double* y_head, int64_t n_head, double* gA, double* ga, double* gQ, double* gH,
+                       double* ghh, double* gR, double* gx0m, double* gx0P) {
+    if (d < 1 || d > tgp_steady::kMaxD || !rec || !y_head) return TGP_EINVAL;
+    const tgp_adjoint::Out o{gA, ga, gQ, gH, ghh, gR, gx0m, gx0P};
+    return tgp_adjoint::finish(d, rec, y_head, n_head, o) == 0 ? TGP_OK : TGP_EINVAL;
+}
+
+int tgp_logpdf_adjoint(tgp_handle* h, const double* y, uint32_t flags, double* lml_out, double* gA, double* ga, double* gQ, double* gH,
+                       double* ghh, double* gR, double* gx0m, double* gx0P) {
+    TRY(check_ready(h));
+    h->steady2_last = false;
+    const int keep_state = h->steady2_state;
+    h->steady2_state = 0;            // (an earlier "does not apply" verdict of a posterior call -- series shorter than head + tail -- does not bind this one)
+    const bool ok = steady2_eligible(h, nullptr, flags);
+    h->steady2_state = keep_state;
+    if (!ok)
+        return h->fail(TGP_EUNSUPPORTED, "tgp_logpdf_adjoint: Forward LTI models (every block shared), one noise variance, scalar observations, d <= 8 "
+                                         "(the stationary-gain engine); use tgp_logpdf_grad otherwise");
+    constexpr int64_t kHead = (int64_t)tgp_steady::kHeadMaxTiles * tgp_steady::kTile;
+    const size_t nrec = tgp_steady::grad_record_size(h->d);
+    const int64_t nyh = h->T < kHead ? h->T : kHead;
+    if (!h->adj_host && hipHostMalloc(reinterpret_cast<void**>(&h->adj_host), (tgp_steady::grad_record_size(tgp_steady::kMaxD) + kHead) * sizeof(double), hipHostMallocDefault) != hipSuccess)
+        return h->fail(TGP_EHIP, "hipHostMalloc");
+    CallTimer tm(h);
+    TRY(set_obs(h, y, nullptr, flags));
+    tm.inputs_done();
+    TRY(steady2_enqueue(h, nullptr, false, nullptr, nullptr, true));
+    tm.kernels_done();
+    HIPCHK(hipMemcpyAsync(h->adj_host, tgp_steady::grad_record(h->steady2), nrec * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(h->adj_host + nrec, h->mv.y, (size_t)nyh * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    TRY(tm.finish(lml_out));
+    if (h->host_result[6] != tgp_steady::kStatusRan)
+        return h->fail(TGP_EUNSUPPORTED, "tgp_logpdf_adjoint: the filter covariance of this model does not settle within the head (or the series is shorter "
+                                         "than the head); use tgp_logpdf_grad");
+    h->reduce_valid = false;
+    h->smoother_valid = false;
+    const tgp_adjoint::Out o{gA, ga, gQ, gH, ghh, gR, gx0m, gx0P};
+    if (tgp_adjoint::finish(h->d, h->adj_host, h->adj_host + nrec, nyh, o) != 0) return h->fail(TGP_EHIP, "tgp_logpdf_adjoint: inconsistent record");
+    return TGP_OK;
 }
 
 int tgp_filter(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t flags, double* m_out, double* P_out, double* lml_out) {

@@ -55,6 +55,16 @@ struct CL {
     static constexpr int size = KW + kBlk * DD;
 };
 
+// record of an adjoint call (doubles): the sums of the stationary tiles, then what the host's half needs (k_final_grad)
+template <int D>
+struct GradRec {
+    static constexpr int DD = D * D;
+    static constexpr int SA = 0, Sa = DD, Sk = DD + D, Srm = DD + 2 * D, Sr = DD + 3 * D, SSQ = DD + 3 * D + 1;
+    static constexpr int NS = DD + 3 * D + 2;
+    static constexpr int psi = NS, mu = NS + D, meta = NS + 2 * D, model = meta + 4;
+    static constexpr int size = model + 2 * DD + 2 * D + 2 + D + D * (D + 1) / 2;
+};
+
 struct Tab {
     long long* hdr;      // [0] applies (1/0), [1] th (head tiles), [2] n0, [3] n1, [4] not PD
     double* cst;         // CL<D>
@@ -72,6 +82,7 @@ struct Tab {
     double *Pw, *Lw;     // [ntiles][D] tile carries when the WORKGROUP's carries are zero (mu at the tile's first step; lam behind its last)
     double* SSQ;         // [nblk] sum r^2 of a workgroup's tiles
     double* misc;        // [0] sum r^2 / S over the head; [8..] cycle stamps of k_setup's phases
+    double *GS, *grec;   // adjoint calls: [nblk][NS] sums of the workgroups; the call's record (GradRec<D>)
 };
 
 // workgroups of the stationary tiles: the launch is sized for one head tile (ntiles1 = ntiles - 1 tiles), the device knows th
@@ -448,7 +459,7 @@ __device__ void head_forward(const Tab& tb, const double* __restrict__ y, long l
 // k_setup_core: what the tile passes wait for -- the filter covariance to its stationary value with the head's per-step gains (a, b),
 // the constant block with the powers and couplings (e), and the head's forward recursion (its carry starts the stationary tiles).
 template <int D>
-__global__ __launch_bounds__(64) void k_setup_core(ModelDev m, Tab tb, const double* __restrict__ y, long long T) {
+__global__ __launch_bounds__(64) void k_setup_core(ModelDev m, Tab tb, const double* __restrict__ y, long long T, int grad) {
     constexpr int DD = D * D;
     constexpr int nhmax = kHeadMaxTiles * kTile;
     __shared__ double sP[DD], sT[DD], sPp[DD], sB[DD], sXa[DD], sGa[DD], sXb[DD], sGb[DD];
@@ -502,9 +513,12 @@ __global__ __launch_bounds__(64) void k_setup_core(ModelDev m, Tab tb, const dou
         hv[k] = m.H[k];
         Ai[k] = m.A[i + k * D];
     }
+    // Adjoint (gradient) calls run the SAME backward machinery on the adjoint of the predicted mean instead of the smoother's lam:
+    //   psi_t = Phi' psi_{t+1} + h r_t / S   (psi_t = d logpdf / d mu_t at fixed gains)   <->   lam <- G lam + c r
+    // so the block's (G, c) become (Phi', h / S) and every power / coupling below follows from them unchanged.
     if (act) {
         ss[SS<D>::A + e] = Ai[j];
-        ss[SS<D>::G + e] = tb.h_G[(size_t)n0 * DD + e];
+        ss[SS<D>::G + e] = grad ? (m.A[j + i * D] - kAss[j] * hv[i]) : tb.h_G[(size_t)n0 * DD + e];
     }
     if (act && j == 0) {
         ss[SS<D>::a + i] = m.a[i];
@@ -513,7 +527,7 @@ __global__ __launch_bounds__(64) void k_setup_core(ModelDev m, Tab tb, const dou
 #pragma unroll
         for (int k = 0; k < D; ++k) v = fma(Ai[k], m.x0[k], v);
         ss[SS<D>::mu0 + i] = v;
-        ss[SS<D>::c + i] = tb.h_c[n0 * D + i];
+        ss[SS<D>::c + i] = grad ? hv[i] * iS : tb.h_c[n0 * D + i];
     }
     if (lane == 0) {
 #pragma unroll
@@ -849,9 +863,10 @@ __device__ __forceinline__ void store8(double* __restrict__ p, long long t0, lon
 
 // forward half of a stationary tile: local recursion from `mu` (lane 0: the tile's carry, others: zero), wave scan with Phi^(8 2^k),
 // second local recursion from the scanned start -> the innovations r[8].  Returns the lane's inclusive scan value (lane 63: tile end).
-template <int D>
+template <int D, bool KEEP = false>
 __device__ __forceinline__ void tile_forward(const Coef<D>& cf, const double* __restrict__ pw_phi, const double (&y)[kSub], int nvalid,
-                                             int lane, const double (&mu_in)[D], double (&r)[kSub], double (&fend)[D]) {
+                                             int lane, const double (&mu_in)[D], double (&r)[kSub], double (&fend)[D],
+                                             double (*mus)[D] = nullptr /* KEEP: the predicted mean before each of the lane's steps */) {
     constexpr int DD = D * D;
     double mu[D];
 #pragma unroll
@@ -906,6 +921,10 @@ __device__ __forceinline__ void tile_forward(const Coef<D>& cf, const double* __
         for (int k = 0; k < D; ++k) rr = fma(-cf.h[k], st[k], rr);
         rr = (j < nvalid) ? rr : 0.0;
         r[j] = rr;
+        if (KEEP) {
+#pragma unroll
+            for (int k = 0; k < D; ++k) mus[j][k] = st[k];
+        }
         double nm[D];
 #pragma unroll
         for (int i = 0; i < D; ++i) {
@@ -1290,10 +1309,10 @@ __device__ __forceinline__ void block_carries(const double* __restrict__ cst, FG
 template <int D, bool POST>
 __global__ __launch_bounds__(kBlkThreads) void k_reduce(const long long* __restrict__ hdr, const double* __restrict__ cst, const double* __restrict__ y,
                                                 double* __restrict__ F, double* __restrict__ B0, double* __restrict__ Fb,
-                                                double* __restrict__ B0b, long long T, long long ntiles, ModelDev m, Tab tb) {
+                                                double* __restrict__ B0b, long long T, long long ntiles, ModelDev m, Tab tb, int side) {
     if (hdr[0] == 0) return;
-    if (POST && blockIdx.x == 0) {      // the extra workgroup (dispatched first): variance tables for pass 2
-        if (threadIdx.x < 64) setup_side<D>(m, tb, T);
+    if (POST && blockIdx.x == 0) {      // the extra workgroup (dispatched first): variance tables for pass 2 (not for adjoint calls)
+        if (side && threadIdx.x < 64) setup_side<D>(m, tb, T);
         return;
     }
     const long long wg = (long long)blockIdx.x - (POST ? 1 : 0);
@@ -1678,6 +1697,166 @@ __global__ __launch_bounds__(256) void k_final(Tab tb, long long T, long long nt
     }
 }
 
+
+// =================================================================================================================================
+// adjoint (gradient) pass: d logpdf / d (model blocks) of the stationary tiles by ONE backward recursion (see tgp_steady.hpp)
+// =================================================================================================================================
+// With psi_{t+1} = d logpdf / d mu_{t+1} behind step t, mu_t and r_t of every step of the stationary tiles, the gradient needs
+//   SA = sum psi_{t+1} mu_t'   Sa = sum psi_{t+1}   Sk = sum psi_{t+1} r_t   Srm = sum r_t mu_t   Sr = sum r_t   SSQ = sum r_t^2
+// (GradRec<D>: the order of the record).  A lane accumulates its 8 steps, a wave / a workgroup reduce in a fixed order, k_final_grad
+// sums the workgroups.  The head's steps and the reverse sweep through the covariance recursion are the host's (tgp_api.hip).
+template <int D>
+__global__ __launch_bounds__(kBlkThreads, (D <= 4 ? 2 : 1)) void k_apply_grad(const long long* __restrict__ hdr, const double* __restrict__ cst, const double* __restrict__ y,
+                                                    const double* __restrict__ F, const double* __restrict__ B0, const double* __restrict__ Pw,
+                                                    const double* __restrict__ Lw, const double* __restrict__ MUb, const double* __restrict__ LAMb,
+                                                    double* __restrict__ GS, double* __restrict__ SSQ, long long T, long long ntiles) {
+    if (hdr[0] == 0) return;
+    constexpr int DD = D * D, NS = GradRec<D>::NS;
+    __shared__ double sMu[kBlk + 1][D], sLam[kBlk][D], sred[kBlk][NS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long tile0 = hdr[1] + (long long)blockIdx.x * kBlk;
+    if (tile0 >= ntiles) return;
+    const long long tile = tile0 + wave;
+    const bool lastwg = (long long)blockIdx.x == nblk_max_for(hdr[1], ntiles) - 1;
+    if (lastwg) {
+        if (threadIdx.x == 0) {
+            double mu_in[D], lam_in[D], lout[D];
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                mu_in[i] = MUb[(long long)blockIdx.x * D + i];
+                lam_in[i] = LAMb[((long long)blockIdx.x + 1) * D + i];
+            }
+            block_carries<D>(cst, [&](int w, int i) { return F[(tile0 + w) * D + i]; }, [&](int w, int i) { return B0[(tile0 + w) * D + i]; }, tile0,
+                             ntiles, mu_in, lam_in, sMu, sLam, lout);
+        }
+        __syncthreads();
+    }
+    double acc[NS];
+#pragma unroll
+    for (int q = 0; q < NS; ++q) acc[q] = 0.0;
+    if (tile < ntiles) {
+        double cin[D], lin[D];
+        if (lastwg) {
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                cin[i] = (lane == 0) ? sMu[wave][i] : 0.0;
+                lin[i] = (lane == 63) ? sLam[wave][i] : 0.0;
+            }
+        } else {
+            double mub[D], lamb[D], mw[D], lw[D];
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                mub[i] = MUb[(long long)blockIdx.x * D + i];
+                lamb[i] = LAMb[((long long)blockIdx.x + 1) * D + i];
+                mw[i] = Pw[tile * D + i];
+                lw[i] = Lw[tile * D + i];
+            }
+            const int wu = __builtin_amdgcn_readfirstlane(wave);
+            matvec_acc<D>(cst + CL<D>::PT + wu * DD, mub, mw);
+            matvec_acc<D>(cst + CL<D>::GT + (kBlk - 1 - wu) * DD, lamb, lw);
+            const double* __restrict__ K = cst + CL<D>::KW + wu * DD;
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int l = 0; l < D; ++l) lw[i] = fma(-K[i * D + l], mub[l], lw[i]);
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                cin[i] = (lane == 0) ? mw[i] : 0.0;
+                lin[i] = (lane == 63) ? lw[i] : 0.0;
+            }
+        }
+        Coef<D> cf;
+        cf.load(cst);
+        const long long t0 = tile * kTile + lane * kSub;
+        double yv[kSub], r[kSub], fend[D], mus[kSub][D];
+        load8(y, t0, T, yv);
+        const long long left = T - t0;
+        const int nvalid = left >= kSub ? kSub : (left > 0 ? (int)left : 0);
+        tile_forward<D, true>(cf, cst + CL<D>::pphi, yv, nvalid, lane, cin, r, fend, mus);
+        double bend[D], psi[D];
+        tile_backward<D>(cf, cst + CL<D>::pg, r, lane, lin, bend, psi);      // psi: behind the lane's last step
+#pragma unroll
+        for (int j = kSub - 1; j >= 0; --j) {
+            const double rr = r[j];
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+#pragma unroll
+                for (int k = 0; k < D; ++k) acc[GradRec<D>::SA + i * D + k] = fma(psi[i], mus[j][k], acc[GradRec<D>::SA + i * D + k]);
+                acc[GradRec<D>::Sa + i] += psi[i];
+                acc[GradRec<D>::Sk + i] = fma(psi[i], rr, acc[GradRec<D>::Sk + i]);
+                acc[GradRec<D>::Srm + i] = fma(rr, mus[j][i], acc[GradRec<D>::Srm + i]);
+            }
+            acc[GradRec<D>::Sr] += rr;
+            acc[GradRec<D>::SSQ] = fma(rr, rr, acc[GradRec<D>::SSQ]);
+            double nl[D];
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                double v = cf.c[i] * rr;
+#pragma unroll
+                for (int k = 0; k < D; ++k) v = fma(cf.G[i][k], psi[k], v);
+                nl[i] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < D; ++i) psi[i] = nl[i];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NS; ++q) {
+        double v = acc[q];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_down(v, off);
+        if (lane == 0) sred[wave][q] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < NS) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < kBlk; ++w) t += sred[w][threadIdx.x];
+        GS[(long long)threadIdx.x * gridDim.x + blockIdx.x] = t;      // [NS][workgroups]: k_final_grad reads each sum's row contiguously
+        if (threadIdx.x == GradRec<D>::SSQ) SSQ[blockIdx.x] = t;      // (k_final's reduction of the value reads it there)
+    }
+}
+
+// sums of the workgroups (fixed order: wave q mod 16 takes sum q, its lanes stride over the workgroups) + everything else the host's half
+// of the gradient needs, in ONE record: psi and mu at the head's end, n0 / head tiles / T, and the model blocks as they are bound.
+template <int D>
+__global__ __launch_bounds__(1024) void k_final_grad(Tab tb, ModelDev m, long long T, long long ntiles, const double* __restrict__ GS, long long nbs, double* __restrict__ rec) {
+    constexpr int DD = D * D, NS = GradRec<D>::NS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool ok = tb.hdr[0] != 0;
+    const long long N = ok ? nblk_max_for(tb.hdr[1], ntiles) : 0;
+    for (int q = wave; q < NS; q += 16) {
+        double v = 0.0;
+        for (long long b = lane; b < N; b += 64) v += GS[q * nbs + b];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_down(v, off);
+        if (lane == 0) rec[q] = v;
+    }
+    if (tid < D) {
+        rec[GradRec<D>::psi + tid] = ok ? tb.LAMb[tid] : 0.0;
+        rec[GradRec<D>::mu + tid] = ok ? tb.MUb[tid] : 0.0;
+    }
+    if (tid == 0) {
+        rec[GradRec<D>::meta + 0] = (double)tb.hdr[2];      // n0
+        rec[GradRec<D>::meta + 1] = (double)tb.hdr[1];      // head tiles
+        rec[GradRec<D>::meta + 2] = (double)T;
+        rec[GradRec<D>::meta + 3] = ok ? 1.0 : 0.0;
+    }
+    double* md = rec + GradRec<D>::model;
+    if (tid < DD) {
+        md[tid] = m.A[tid];
+        md[DD + D + tid] = m.Q[tid];
+    }
+    if (tid < D) {
+        md[DD + tid] = m.a[tid];
+        md[2 * DD + D + tid] = m.H[tid];
+    }
+    if (tid == 0) {
+        md[2 * DD + 2 * D] = m.hh[0];
+        md[2 * DD + 2 * D + 1] = m.R[0];
+    }
+    if (tid < D + D * (D + 1) / 2) md[2 * DD + 2 * D + 2 + tid] = m.x0[tid];
+}
 }  // namespace
 
 // =================================================================================================================================
@@ -1720,7 +1899,7 @@ hipError_t ensure(Engine* e, int d, long long ntiles) {
     const size_t o_tvb = take(kTailMax), o_tPs = take((size_t)kTailMax * DD);
     const size_t nt = (size_t)ntiles + 8, nb = (size_t)(ntiles + kBlk - 1) / kBlk + 2;
     const size_t o_F = take(nt * d), o_B0 = take(nt * d), o_Pw = take(nt * d), o_Lw = take(nt * d), o_Fb = take(nb * d), o_B0b = take(nb * d), o_MUb = take(nb * d), o_LAMb = take(nb * d),
-                 o_SSQ = take(nb), o_misc = take(16);
+                 o_SSQ = take(nb), o_misc = take(16), o_GS = take(nb * (DD + 3 * (size_t)d + 2)), o_grec = take(grad_record_size(d));
     const size_t bytes = off * sizeof(double);
     if (bytes > e->cap) {
         if (e->slab) (void)hipFree(e->slab);
@@ -1739,6 +1918,8 @@ hipError_t ensure(Engine* e, int d, long long ntiles) {
     tb.t_vb = b + o_tvb; tb.t_Ps = b + o_tPs;
     tb.F = b + o_F; tb.B0 = b + o_B0; tb.Pw = b + o_Pw; tb.Lw = b + o_Lw; tb.Fb = b + o_Fb; tb.B0b = b + o_B0b; tb.MUb = b + o_MUb; tb.LAMb = b + o_LAMb; tb.SSQ = b + o_SSQ;
     tb.misc = b + o_misc;
+    tb.GS = b + o_GS;
+    tb.grec = b + o_grec;
     e->d = d;
     e->ntiles = ntiles;
     return hipSuccess;
@@ -1760,20 +1941,31 @@ int enqueue_d(Engine* e, hipStream_t st, const ModelDev& m, const CallDev& c, co
     const unsigned blocks = (unsigned)((ntiles - 1 + kBlk - 1) / kBlk);      // workgroups of the stationary tiles if the head is one tile
     {
         Scope s(hk, "k_steady_setup");
-        hipLaunchKernelGGL(k_setup_core<D>, dim3(1), dim3(64), 0, st, m, tb, c.y, T);
+        hipLaunchKernelGGL(k_setup_core<D>, dim3(1), dim3(64), 0, st, m, tb, c.y, T, c.grad ? 1 : 0);
     }
     if (blocks == 0) {      // a series of one tile: the engine does not apply (k_setup_core: nh + 2 > T)
         Scope s(hk, "k_steady_final");
         hipLaunchKernelGGL(k_final<D>, dim3(1), dim3(256), 0, st, tb, T, ntiles, c.result, c.y, c.Rnew, 0, (double*)nullptr, (double*)nullptr);
+        if (c.grad) hipLaunchKernelGGL(k_final_grad<D>, dim3(1), dim3(1024), 0, st, tb, m, T, ntiles, tb.GS, 1LL, tb.grec);
+        return (int)hipGetLastError();
+    }
+    if (c.grad) {
+        static_assert(GradRec<D>::size == 3 * D * D + 8 * D + 8 + D * (D + 1) / 2, "grad_record_size() mirrors GradRec<D>");
+        { Scope s(hk, "k_steady_reduce<adjoint>"); hipLaunchKernelGGL((k_reduce<D, true>), dim3(blocks + 1), dim3(kBlkThreads), 0, st, tb.hdr, tb.cst, c.y, tb.F, tb.B0, tb.Fb, tb.B0b, T, ntiles, m, tb, 0); }
+        { Scope s(hk, "k_steady_carry<adjoint>"); hipLaunchKernelGGL((k_carry<D, true>), dim3(1), dim3(512), 0, st, tb.hdr, tb.cst, tb.Fb, tb.B0b, tb.MUb, tb.LAMb, ntiles); }
+        { Scope s(hk, "k_steady_apply<adjoint>"); hipLaunchKernelGGL(k_apply_grad<D>, dim3(blocks), dim3(kBlkThreads), 0, st, tb.hdr, tb.cst, c.y, tb.F, tb.B0, tb.Pw, tb.Lw, tb.MUb, tb.LAMb, tb.GS, tb.SSQ, T, ntiles); }
+        { Scope s(hk, "k_steady_final<adjoint>"); hipLaunchKernelGGL(k_final_grad<D>, dim3(1), dim3(1024), 0, st, tb, m, T, ntiles, tb.GS, (long long)blocks, tb.grec); }
+        // (the value of the call: the usual reduction -- misc[0], LS and logS do not depend on the (G, c) of the block)
+        { Scope s(hk, "k_steady_final<logpdf>"); hipLaunchKernelGGL(k_final<D>, dim3(1), dim3(256), 0, st, tb, T, ntiles, c.result, c.y, c.Rnew, 0, (double*)nullptr, (double*)nullptr); }
         return (int)hipGetLastError();
     }
     if (post) {
-        { Scope s(hk, "k_steady_reduce<posterior>"); hipLaunchKernelGGL((k_reduce<D, true>), dim3(blocks + 1), dim3(kBlkThreads), 0, st, tb.hdr, tb.cst, c.y, tb.F, tb.B0, tb.Fb, tb.B0b, T, ntiles, m, tb); }
+        { Scope s(hk, "k_steady_reduce<posterior>"); hipLaunchKernelGGL((k_reduce<D, true>), dim3(blocks + 1), dim3(kBlkThreads), 0, st, tb.hdr, tb.cst, c.y, tb.F, tb.B0, tb.Fb, tb.B0b, T, ntiles, m, tb, 1); }
         { Scope s(hk, "k_steady_carry<posterior>"); hipLaunchKernelGGL((k_carry<D, true>), dim3(1), dim3(512), 0, st, tb.hdr, tb.cst, tb.Fb, tb.B0b, tb.MUb, tb.LAMb, ntiles); }
         { Scope s(hk, "k_steady_apply<posterior>"); hipLaunchKernelGGL((k_apply<D, true>), dim3(blocks), dim3(kBlkThreads), 0, st, tb.hdr, tb.cst, c.y, c.Rnew, c.rnew_per_step, tb.F, tb.B0, tb.Pw, tb.Lw, tb.MUb, tb.LAMb, tb.t_vb, c.mean, c.var, tb.SSQ, T, ntiles); }
         { Scope s(hk, "k_steady_final<posterior>"); hipLaunchKernelGGL(k_final<D>, dim3(2), dim3(256), 0, st, tb, T, ntiles, c.result, c.y, c.Rnew, c.rnew_per_step, c.mean, c.var); }
     } else {
-        { Scope s(hk, "k_steady_reduce<logpdf>"); hipLaunchKernelGGL((k_reduce<D, false>), dim3(blocks), dim3(kBlkThreads), 0, st, tb.hdr, tb.cst, c.y, tb.F, tb.B0, tb.Fb, tb.B0b, T, ntiles, m, tb); }
+        { Scope s(hk, "k_steady_reduce<logpdf>"); hipLaunchKernelGGL((k_reduce<D, false>), dim3(blocks), dim3(kBlkThreads), 0, st, tb.hdr, tb.cst, c.y, tb.F, tb.B0, tb.Fb, tb.B0b, T, ntiles, m, tb, 0); }
         { Scope s(hk, "k_steady_carry<logpdf>"); hipLaunchKernelGGL((k_carry<D, false>), dim3(1), dim3(512), 0, st, tb.hdr, tb.cst, tb.Fb, tb.B0b, tb.MUb, tb.LAMb, ntiles); }
         { Scope s(hk, "k_steady_apply<logpdf>"); hipLaunchKernelGGL((k_apply<D, false>), dim3(blocks), dim3(kBlkThreads), 0, st, tb.hdr, tb.cst, c.y, (const double*)nullptr, 0, tb.F, tb.B0, tb.Pw, tb.Lw, tb.MUb, tb.LAMb, tb.t_vb, (double*)nullptr, (double*)nullptr, tb.SSQ, T, ntiles); }
         { Scope s(hk, "k_steady_final<logpdf>"); hipLaunchKernelGGL(k_final<D>, dim3(1), dim3(256), 0, st, tb, T, ntiles, c.result, c.y, c.Rnew, 0, (double*)nullptr, (double*)nullptr); }
@@ -1809,6 +2001,9 @@ int enqueue(Engine* e, hipStream_t stream, const ModelDev& m, const CallDev& c, 
     if (r != 0 && err) *err = std::string("tgp_steady: launch: ") + hipGetErrorString((hipError_t)r);
     return r;
 }
+
+size_t grad_record_size(int d) { return (size_t)(3 * d * d + 8 * d + 8 + d * (d + 1) / 2); }
+const double* grad_record(const Engine* e) { return (e && e->slab) ? e->tb.grec : nullptr; }
 
 int last_info(Engine* e, hipStream_t stream, int64_t out[4]) {
     if (!e || !e->slab) return (int)hipErrorInvalidValue;

@@ -54,6 +54,7 @@ struct CallDev {
     int rnew_per_step = 0;
     double *mean = nullptr, *var = nullptr;   // nullptr: logpdf only
     double* result = nullptr;
+    bool grad = false;             // adjoint call: logpdf + the record behind d logpdf / d (model blocks) (grad_record; mean / var unused)
 };
 
 struct Engine;
@@ -62,6 +63,14 @@ void destroy(Engine*);
 bool supports(int d);
 // Enqueues the whole call on `stream` (no synchronisation).  Returns 0, or a hipError_t cast to int with *err set.
 int enqueue(Engine*, hipStream_t stream, const ModelDev&, const CallDev&, const Hooks&, std::string* err);
+// Adjoint calls (CallDev::grad).  The record (device memory of the engine, grad_record_size(d) doubles, valid once the stream has
+// passed the call) holds, in this order: the sums over the stationary tiles  SA [d][d] = sum psi_{t+1} mu_t', Sa [d] = sum psi_{t+1},
+// Sk [d] = sum psi_{t+1} r_t, Srm [d] = sum r_t mu_t, Sr = sum r_t, SSQ = sum r_t^2  (psi_{t+1} = d logpdf / d mu_{t+1}, mu_t the predicted
+// mean, r_t the innovation);  psi [d] and mu [d] at the end of the head;  n0, head tiles, T, applies (as doubles);  the model blocks
+// A [d*d] a [d] Q [d*d] H [d] hh R x0 (packed) as bound.  tgp_api.hip finishes the gradient on the host (head steps + the reverse sweep
+// through the n0 steps of the covariance recursion).
+size_t grad_record_size(int d);
+const double* grad_record(const Engine*);
 // diagnostics of the last enqueued call (synchronises the stream): n0, n1, head tiles, applicable
 int last_info(Engine*, hipStream_t stream, int64_t out[4]);
 

@@ -397,6 +397,28 @@ def logpdf_and_grad(model, y, tangents):
     return lml.value, grad
 
 
+def logpdf_adjoint(model, y):
+    """logpdf and its gradient with respect to the SHARED model blocks by ONE adjoint pass on the device (tgp_logpdf_adjoint): the cost
+    of a posterior-marginals call whatever the number of hyper-parameters. Returns (lml, dict A (d,d), a (d,), Q (d,d), H (d,), h (),
+    R (), x0m (d,), x0P (d,d)); Q and x0P gradients are symmetrised (pair them with symmetric tangents). Forward LTI models with one
+    noise variance, scalar observations, no missing data, d <= 8 -- raises Unsupported otherwise (use logpdf_and_grad).
+    The reference obtains this gradient by reverse-mode AD of the sequential loop (bench/single_output_gps.jl:149-156)."""
+    _check_inputs(model, y[0] if isinstance(y, tuple) else y)
+    hd = model.handle()
+    yy, mm, dev = _obs(y, model)
+    if mm is not None:
+        raise _lib.Unsupported(_lib.EUNSUPPORTED, "logpdf_adjoint: missing observations are not served by the adjoint pass")
+    d = model.dim
+    g = dict(A=np.zeros((d, d)), a=np.zeros(d), Q=np.zeros((d, d)), H=np.zeros(d), h=np.zeros(1), R=np.zeros(1), x0m=np.zeros(d), x0P=np.zeros((d, d)))
+    lml = ctypes.c_double()
+    hd.check(hd.lib.tgp_logpdf_adjoint(hd.h, _lib.ptr(yy), _lib.IN_DEVICE if dev else 0, ctypes.byref(lml),
+                                       *[_lib.ptr(g[k]) for k in ("A", "a", "Q", "H", "h", "R", "x0m", "x0P")]))
+    for k in ("A", "Q", "x0P"):
+        g[k] = g[k].T.copy()          # column-major blocks -> [i][k]
+    g["h"], g["R"] = float(g["h"][0]), float(g["R"][0])
+    return lml.value, g
+
+
 def logpdf_and_grad_sde(model, y, tangents, rel_step=1e-6):
     """The same for a model whose transitions are described by their SDE (SDETransitions: irregular spacing, d <= 4).
     `tangents`: per parameter, the derivatives of F (d,d), x0P == P_inf (d,d), x0m (d,), H (d,), h (), R () and of the explicit

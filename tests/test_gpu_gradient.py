@@ -194,3 +194,117 @@ def test_gradient_policy_from_d9_is_central_differences_of_the_device_logpdf():
     for name in g_t:
         assert abs(g_fd[name] - g_t[name]) <= 2e-6 * max(1.0, abs(g_t[name])), (name, g_fd[name], g_t[name])
     assert abs(S.logpdf(fx, y) - lp_t) <= 1e-12 * abs(lp_t)          # the parameters are restored
+
+
+# ------------------------------------------------------------------------------------------------ adjoint (reverse-time) gradient
+ADJ_CASES = {"matern32": [("matern32", 1.3, 0.8)], "matern52": [("matern52", 0.9, 1.2)],
+             "sum52_32_12": [("matern52", 1.3, 0.8), ("matern32", 0.6, 1.7), ("matern12", 0.4, 0.5)]}      # 6 kernel parameters + noise, d = 6
+
+
+def _adj_fx(P, terms, dt, T, noise):
+    ks = [P.ScaledKernel(s2, P.StretchedKernel(s, P.to_kernel((name,)))) for name, s2, s in terms]
+    k = ks[0]
+    for kk in ks[1:]:
+        k = k + kk
+    names = (["kernel.sigma2", "kernel.kernel.s"] if len(ks) == 1 else
+             [f"kernel.kernels[{i}].{leaf}" for i in range(len(ks)) for leaf in ("sigma2", "kernel.s")]) + ["noise"]
+    return P.to_sde(P.GP(k))(P.RegularSpacing(0.0, dt, T), noise), names
+
+
+@pytest.mark.parametrize("case", list(ADJ_CASES))
+def test_adjoint_and_tangent_gradients_vs_mpmath_gradient_of_the_oracle(case):
+    """d logpdf / d (every kernel variance, every inverse lengthscale, the noise variance) by ONE adjoint pass (tgp_logpdf_adjoint +
+    exact block tangents), and by the tangent scans, against the 50-digit gradient of the oracle's recursion (oracle/lgssm_mp.py:
+    the whole map hyper-parameters -> logpdf in mpmath, central differences with step 1e-20). Tolerance 1e-8 relative to the
+    largest gradient entry."""
+    import temporalgps_jl_amd as tgp  # noqa: F401
+    from temporalgps_jl_amd import lti_sde as P
+    from oracle import lgssm_mp as M
+    terms = ADJ_CASES[case]
+    T, dt, noise = 640, 0.2, 0.25
+    spec = tuple(("scaled", s2, ("stretched", s, (name,))) for name, s2, s in terms)
+    model = oc.build_lgssm(spec[0] if len(spec) == 1 else ("sum",) + spec, ("regular", 0.0, dt, T), noise)
+    d = len(model["x0m"])
+    rng = np.random.default_rng(7)
+    y = sk.rand(model, rng.standard_normal((T, d)), rng.standard_normal(T), rng.standard_normal(d))
+    lp_mp, g_mp = M.lti_gradient_mp(terms, dt, noise, y)
+    scale = max(abs(v) for v in g_mp)
+    for method in ("adjoint", "tangent"):
+        fx, names = _adj_fx(P, terms, dt, T, noise)
+        lp, g = P.logpdf_and_gradient(fx, y, method=method)
+        assert abs(lp - lp_mp) <= 1e-10 * abs(lp_mp)
+        assert list(g) == names
+        for name, want in zip(names, g_mp):
+            assert abs(g[name] - want) <= 1e-8 * scale, (method, name, g[name], want)
+    fx, _ = _adj_fx(P, terms, dt, T, noise)
+    assert P.logpdf_and_gradient(fx, y)[1] == P.logpdf_and_gradient(fx, y, method="adjoint")[1]      # the default policy takes the adjoint pass
+
+
+@pytest.mark.parametrize("d", [1, 2, 3, 4, 5, 6, 7, 8])
+def test_adjoint_block_gradients_vs_oracle_finite_differences(d):
+    """tgp_logpdf_adjoint on random LTI models: the directional derivative along a random direction in the space of ALL blocks
+    (A, a, Q, H, h, R, x0m, x0P; symmetric directions for Q and x0P) against central differences of the oracle's sequential logpdf."""
+    import temporalgps_jl_amd as tgp
+    from tests import _util as U
+    rng = np.random.default_rng(100 + d)
+    T = 5_003
+    model = U.random_lgssm(rng, False, d, T)
+    y = ref.rand(model, rng.standard_normal((T, d)), rng.standard_normal(T), rng.standard_normal(d))
+    tr = tgp.GaussMarkovModel(tgp.Forward, model["A"], model["a"], model["Q"], tgp.Gaussian(model["x0m"], model["x0P"]))
+    dm = tgp.LGSSM(tr, tgp.ScalarOutputLGC(model["H"], model["h"], model["R"]), T=T)
+    from temporalgps_jl_amd import lgssm as L
+    lp, g = L.logpdf_adjoint(dm, y)
+    lp_ref = sk.logpdf(model, y)
+    assert abs(lp - lp_ref) <= 1e-10 * abs(lp_ref)
+    sym = lambda X: 0.5 * (X + X.T)
+    for trial in range(3):
+        dirs = dict(A=rng.standard_normal((d, d)), a=rng.standard_normal(d), Q=sym(rng.standard_normal((d, d))), H=rng.standard_normal(d),
+                    h=rng.standard_normal(), R=rng.standard_normal(), x0m=rng.standard_normal(d), x0P=sym(rng.standard_normal((d, d))))
+        want = sum(float(np.sum(np.asarray(g[k]) * np.asarray(v))) for k, v in dirs.items())
+        gross = sum(float(np.sum(np.abs(np.asarray(g[k]) * np.asarray(v)))) for k, v in dirs.items())      # before the terms cancel
+        eps = 1e-6
+
+        def shifted(sgn):
+            m = dict(model)
+            for k in ("A", "a", "Q", "H"):
+                m[k] = model[k] + sgn * eps * dirs[k][None]
+            m["h"] = model["h"] + sgn * eps * dirs["h"]
+            m["R"] = model["R"] + sgn * eps * dirs["R"]
+            m["x0m"] = model["x0m"] + sgn * eps * dirs["x0m"]
+            m["x0P"] = model["x0P"] + sgn * eps * dirs["x0P"]
+            return sk.logpdf(m, y)
+        fd = (shifted(1.0) - shifted(-1.0)) / (2 * eps)
+        # (the finite-difference side limits it: the oracle's logpdf carries ~1e-10 of rounding, divided by 2 eps)
+        assert abs(want - fd) <= 2e-6 * max(1.0, abs(fd), gross), (trial, want, fd, gross)
+
+
+def test_adjoint_equals_tangent_scans_on_a_long_series_and_refuses_what_it_does_not_serve():
+    import temporalgps_jl_amd as tgp
+    from temporalgps_jl_amd import lti_sde as P
+    T, dt = 1_000_003, 0.1
+    terms = [("matern52", 1.1, 0.9), ("matern12", 0.5, 2.0)]
+    fx, names = _adj_fx(P, terms, dt, T, 0.1)
+    rng = np.random.default_rng(8)
+    y = rng.standard_normal(T) * 0.8
+    lp_a, g_a = P.logpdf_and_gradient(fx, y, method="adjoint")
+    lp_t, g_t = P.logpdf_and_gradient(fx, y, method="tangent")
+    assert abs(lp_a - lp_t) <= 1e-11 * abs(lp_t)
+    scale = max(abs(v) for v in g_t.values())
+    for n in names:
+        assert abs(g_a[n] - g_t[n]) <= 1e-8 * scale, (n, g_a[n], g_t[n])
+    # heteroscedastic noise, missing observations, irregular inputs: not the adjoint pass's models
+    fxh = P.to_sde(P.GP(P.Matern32Kernel()))(P.RegularSpacing(0.0, 0.1, 2000), np.linspace(0.1, 0.2, 2000))
+    with pytest.raises((NotImplementedError, tgp._lib.Unsupported)):
+        P.logpdf_and_gradient(fxh, np.zeros(2000), method="adjoint")
+    fxm = P.to_sde(P.GP(P.Matern32Kernel()))(P.RegularSpacing(0.0, 0.1, 2000), 0.1)
+    ym = np.zeros(2000)
+    ym[5] = np.nan
+    with pytest.raises((NotImplementedError, tgp._lib.Unsupported)):
+        P.logpdf_and_gradient(fxm, ym, method="adjoint")
+    lp, g = P.logpdf_and_gradient(fxm, ym)          # the default policy falls back to the tangent scans
+    assert np.isfinite(lp) and set(g) == {"noise"}
+    # a series shorter than the head: refused by the device, served by the tangent scans under the default policy
+    fxs = P.to_sde(P.GP(P.Matern32Kernel()))(P.RegularSpacing(0.0, 0.1, 300), 0.1)
+    with pytest.raises(tgp._lib.Unsupported):
+        P.logpdf_and_gradient(fxs, np.zeros(300), method="adjoint")
+    assert set(P.logpdf_and_gradient(fxs, np.zeros(300))[1]) == {"noise"}
