@@ -286,6 +286,121 @@ function logpdf_and_directional_derivatives(m::DeviceLGSSM{Forward}, y::Abstract
     return lml[], grad
 end
 
+"""`logpdf` and its gradient with respect to the packed model blocks by ONE adjoint pass (tgp_logpdf_adjoint: Forward models whose
+blocks are all shared, one noise variance, scalar outputs, no missing data, d <= 8) -- the pullback a ChainRules / Mooncake rule for
+`logpdf(::DeviceLGSSM, y)` needs: the rule returns `lml` and contracts the named tuple with the cotangent (the reference differentiates
+the sequential loop itself, bench/single_output_gps.jl:149-156). Matrices come back d x d (column-major, as Julia stores them)."""
+function logpdf_and_block_gradients(m::DeviceLGSSM{Forward}, y::AbstractVector{<:Real})
+    d = m.d
+    yv = collect(Float64, y)
+    lml = Ref{Float64}(0.0)
+    gA, gQ, gP = (Matrix{Float64}(undef, d, d) for _ in 1:3)
+    ga, gH, gm = (Vector{Float64}(undef, d) for _ in 1:3)
+    gh, gR = Ref{Float64}(0.0), Ref{Float64}(0.0)
+    GC.@preserve yv check(m.h, ccall((:tgp_logpdf_adjoint, libtgp), Cint,
+        (Ptr{Cvoid}, Ptr{Float64}, UInt32, Ref{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ref{Float64},
+         Ref{Float64}, Ptr{Float64}, Ptr{Float64}),
+        m.h.ptr, yv, UInt32(0), lml, gA, ga, gQ, gH, gh, gR, gm, gP))
+    return lml[], (A = gA, a = ga, Q = gQ, H = gH, h = gh[], R = gR[], x0m = gm, x0P = gP)
+end
+
+# ---- one series over the GPUs of a node, one process (tgp_create_multi: one handle + stream + RCCL communicator per device inside
+#      the library; SURVEY.md 8b "Threading", 8e). Rank r owns the contiguous segment tgp_multi_segment gives it; inputs and outputs
+#      are addressed per segment (pointer + offset into the caller's arrays: nothing is copied on the host).
+mutable struct MultiHandle
+    ptr::Ptr{Cvoid}
+    ndev::Int
+    function MultiHandle(devices::AbstractVector{<:Integer})
+        r = Ref{Ptr{Cvoid}}(C_NULL)
+        devs = collect(Cint, devices)
+        rc = ccall((:tgp_create_multi, libtgp), Cint, (Ref{Ptr{Cvoid}}, Cint, Ptr{Cint}), r, length(devs), devs)
+        rc == 0 || throw(error("tgp_create_multi failed ($rc)"))
+        h = new(r[], length(devs))
+        finalizer(x -> ccall((:tgp_destroy_multi, libtgp), Cint, (Ptr{Cvoid},), x.ptr), h)
+        return h
+    end
+end
+
+function check(h::MultiHandle, rc::Cint)
+    rc == 0 && return nothing
+    msg = unsafe_string(ccall((:tgp_multi_last_error, libtgp), Cstring, (Ptr{Cvoid},), h.ptr))
+    rc == 1 && occursin("Dimension mismatch", msg) && throw(DimensionMismatch(msg))
+    throw(error("libtgp_hip error $rc: $msg"))
+end
+
+"""A DeviceLGSSM whose time axis is sharded over `devices` (Forward, diagonal noise, d <= 16)."""
+struct MultiDeviceLGSSM <: AbstractLGSSM
+    h::MultiHandle
+    T::Int
+    d::Int
+    p::Int
+    bufs::NamedTuple
+    x0::Gaussian
+end
+Base.length(m::MultiDeviceLGSSM) = m.T
+Base.eachindex(m::MultiDeviceLGSSM) = 1:m.T
+TemporalGPs.ordering(::MultiDeviceLGSSM) = Forward()
+TemporalGPs.x0(m::MultiDeviceLGSSM) = m.x0
+TemporalGPs.storage_type(::MultiDeviceLGSSM) = HIPStorage(Float64)
+
+function MultiDeviceLGSSM(As, as, Qs, Hs, hs, Σs, x0::Gaussian, devices::AbstractVector{<:Integer})
+    T, d = length(As), length(first(as))
+    p = length(first(hs))
+    (A, sA), (a, sa), (Q, sQ) = _flat(As), _flat(as), _flat(Qs)
+    (H, sH) = p == 1 ? _flat(Hs) : _flat_rows(Hs)
+    (hh, sh) = _flat(hs)
+    (R, sR) = p == 1 ? _flat(Σs) : _flat_diag(Σs)
+    flags = UInt32(0)
+    for (bit, s) in zip((SHARED_A, SHARED_a, SHARED_Q, SHARED_H, SHARED_h, SHARED_R), (sA, sa, sQ, sH, sh, sR))
+        s && (flags |= bit)
+    end
+    h = MultiHandle(devices)
+    x0m, x0P = collect(Float64, x0.m), collect(Float64, vec(Array(x0.P)))
+    GC.@preserve A a Q H hh R x0m x0P check(h, ccall((:tgp_multi_model_set, libtgp), Cint,
+        (Ptr{Cvoid}, Int64, Cint, Cint, Cint, UInt32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+         Ptr{Float64}, Ptr{Float64}), h.ptr, T, d, p, 0, flags, A, a, Q, H, hh, R, x0m, x0P))
+    return MultiDeviceLGSSM(h, T, d, p, (; A, a, Q, H, hh, R), x0)
+end
+
+"""`DeviceLGSSM(...; ndev)`: the same components, sharded over the first `ndev` GPUs."""
+DeviceLGSSM(ord::Forward, As, as, Qs, Hs, hs, Σs, x0::Gaussian; ndev::Int) = MultiDeviceLGSSM(As, as, Qs, Hs, hs, Σs, x0, 0:(ndev - 1))
+
+# per-rank addresses of one host array: element offset t0_r * width
+function _parts(m::MultiDeviceLGSSM, v::Vector{Float64}, width::Int)
+    t0, t1 = Ref{Int64}(0), Ref{Int64}(0)
+    return [begin
+                ccall((:tgp_multi_segment, libtgp), Cint, (Int64, Cint, Cint, Ref{Int64}, Ref{Int64}), m.T, m.h.ndev, r, t0, t1)
+                pointer(v, t0[] * width + 1)
+            end for r in 0:(m.h.ndev - 1)]
+end
+
+function AbstractGPs.logpdf(m::MultiDeviceLGSSM, y::AbstractVector{<:Real})
+    yv, out = collect(Float64, y), Ref{Float64}(0.0)
+    GC.@preserve yv begin
+        ys = _parts(m, yv, m.p)
+        check(m.h, ccall((:tgp_multi_logpdf, libtgp), Cint, (Ptr{Cvoid}, Ptr{Ptr{Float64}}, Ptr{Ptr{UInt8}}, UInt32, Ref{Float64}),
+            m.h.ptr, ys, C_NULL, UInt32(0), out))
+    end
+    return out[]
+end
+
+"""(logpdf, mean, var) of `marginals(replace_observation_noise_cov(posterior(model, y), Σs_new))` over all the GPUs of the handle."""
+function logpdf_and_posterior_marginals(m::MultiDeviceLGSSM, y::AbstractVector{<:Real}, Σs_new::AbstractVector)
+    yv = collect(Float64, y)
+    (R, shared) = m.p == 1 ? _flat(Σs_new) : _flat_diag(Σs_new)
+    mean, var = Vector{Float64}(undef, m.p * m.T), Vector{Float64}(undef, m.p * m.T)
+    lml = Ref{Float64}(0.0)
+    GC.@preserve yv R mean var begin
+        ys, ms, vs = _parts(m, yv, m.p), _parts(m, mean, m.p), _parts(m, var, m.p)
+        Rs = shared ? fill(pointer(R), m.h.ndev) : _parts(m, R, m.p)
+        check(m.h, ccall((:tgp_multi_logpdf_and_posterior_marginals, libtgp), Cint,
+            (Ptr{Cvoid}, Ptr{Ptr{Float64}}, Ptr{Ptr{UInt8}}, Ptr{Ptr{Float64}}, UInt32, Ref{Float64}, Ptr{Ptr{Float64}}, Ptr{Ptr{Float64}}),
+            m.h.ptr, ys, C_NULL, Rs, shared ? SHARED_R : UInt32(0), lml, ms, vs))
+    end
+    return lml[], mean, var
+end
+posterior_marginals(m::MultiDeviceLGSSM, y::AbstractVector{<:Real}, Σs_new::AbstractVector) = logpdf_and_posterior_marginals(m, y, Σs_new)[2:3]
+
 """Irregularly spaced inputs without host-side matrix exponentials (tgp_model_set_sde): the device evaluates
 A_k = exp(F dt_k), Q_k = P_inf - A_k P_inf A_k' (lti_sde.jl:135-146) from F, P_inf and the time stamps.
 `A1`, `Q1` override the first transition (the reference fixes dt_1 := 1 per kernel component, lti_sde.jl:139)."""

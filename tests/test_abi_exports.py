@@ -77,3 +77,36 @@ def test_product_fails_loudly_without_gpu():
     import temporalgps_jl_amd as tgp
     with pytest.raises(tgp._lib.TGPError):
         tgp._lib.Handle(0)
+
+
+def test_every_ccall_of_the_julia_glue_names_a_declared_symbol_with_the_declared_number_of_arguments():
+    """julia/TemporalGPsHIP.jl cannot run here (no Julia in the image): at least hold each `ccall((:sym, libtgp), Ret, (types...), args...)`
+    against include/tgp_hip.h -- the symbol is declared and the ccall's type tuple has as many entries as the C prototype has parameters."""
+    header = open(os.path.join(ROOT, "include", "tgp_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    protos = {}
+    for name, args in re.findall(r"\b(tgp_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", header, flags=re.S):
+        args = args.strip()
+        protos[name] = 0 if args in ("", "void") else args.count(",") + 1
+    src = open(os.path.join(ROOT, "julia", "TemporalGPsHIP.jl")).read()
+    calls = list(re.finditer(r"ccall\(\(:(tgp_[a-z0-9_]+), libtgp\),\s*[A-Za-z]+,\s*\(", src))
+    assert len(calls) >= 15
+    for m in calls:
+        name = m.group(1)
+        assert name in protos, f"{name}: ccall'ed by the Julia glue, not declared in include/tgp_hip.h"
+        depth, i, n, seen = 1, m.end(), 0, False          # walk the type tuple "(T1, T2, ...)"
+        while depth:
+            ch = src[i]
+            if ch in "({[":
+                depth += 1
+            elif ch in ")}]":
+                depth -= 1
+            elif ch == "," and depth == 1:
+                n += 1
+            elif not ch.isspace():
+                seen = True
+            i += 1
+        body = src[m.end():i - 1].strip()
+        ntypes = 0 if not body else n + (0 if body.endswith(",") else 1)
+        assert seen or ntypes == 0
+        assert ntypes == protos[name], f"{name}: the ccall passes {ntypes} argument types, the header declares {protos[name]}"
