@@ -9,8 +9,8 @@ series that is already resident in HBM (y is drawn from the model itself on the 
 bench/single_output_gps.jl:143-145 does on the CPU). value = whole-job Kalman steps / seconds-per-step.
 N > 1: ONE series is time-sharded, one contiguous segment per rank, with one all_gather of the tiny
 per-segment scan elements per scan direction plus one scalar all_reduce (RCCL via torch.distributed).
-`--gpus N` without a torch.distributed environment re-launches itself under torch.distributed.run (one rank per GPU,
-rendezvous on 127.0.0.1). N > 1 defaults to BASELINE config 4: STRONG scaling of ONE T = 1e8, d = 4 series
+`--gpus N` launched directly (no torch.distributed environment) drives the N GPUs from ONE process through the in-library multi-GPU
+handle (tgp_create_multi: RCCL inside the library); under the driver's torchrun launch -- or with --torchrun -- it is one rank per GPU. N > 1 defaults to BASELINE config 4: STRONG scaling of ONE T = 1e8, d = 4 series
 (`--scaling weak` keeps --T points per GPU instead; `--workload/--T` override the series).
 `--workload cfg5` runs BASELINE config 5 (Separable space-time, 256 spatial points, dense d = 768 / p = 256 recursion on the
 fp64 MFMA kernels; sequential in time: N > 1 means N independent replicas).
@@ -404,6 +404,75 @@ def run_cfg5(args, torch, tgp, world, rank, local):
     print(json.dumps(out))
 
 
+def run_multi_inprocess(args):
+    """`python bench.py --gpus N` launched directly (no torch.distributed environment): ONE process drives the N GPUs through the
+    in-library multi-GPU handle (tgp_create_multi: one device handle, HIP stream, worker thread and RCCL communicator per GPU; the
+    per-segment scan elements are exchanged with ncclAllGather inside the library). Strong scaling of BASELINE config 4 by default
+    (one T = 1e8, d = 4 series; --scaling weak keeps --T per GPU). `--devices 0,0` puts several ranks on one GPU (a test hook:
+    the event-ordered copy transport instead of RCCL)."""
+    import torch
+    import temporalgps_jl_amd as tgp
+    from temporalgps_jl_amd import lti_sde
+    devices = [int(x) for x in args.devices.split(",")] if args.devices else list(range(args.gpus))
+    W = len(devices)
+    name = args.workload
+    k, d, dt, s2 = WORKLOADS[name]
+    T = args.T * W if args.scaling == "weak" else args.T
+    model = lti_sde.build_lgssm(lti_sde.to_kernel(k), lti_sde.RegularSpacing(0.0, dt, T), s2, device=devices[0], force_per_step=(args.layout == "per_step"))
+    ms = tgp.MultiLGSSM(model, devices=devices)
+    parts = []
+    for r, (lo, hi) in enumerate(ms.bounds):
+        gen = torch.Generator(device=f"cuda:{devices[r]}")
+        gen.manual_seed(123456 + r)
+        parts.append(torch.randn((hi - lo,), dtype=torch.float64, device=f"cuda:{devices[r]}", generator=gen) * 0.8)
+    Rnew = np.array([1e-18])
+
+    def step():
+        return ms.logpdf_and_posterior_marginals(parts, Rnew)
+    for _ in range(args.warmup):
+        step()
+    for dv in set(devices):
+        torch.cuda.synchronize(dv)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        lp, mean, var = step()
+    for dv in set(devices):
+        torch.cuda.synchronize(dv)
+    dt_s = time.perf_counter() - t0
+    ms.mh.set_option(tgp._lib.OPT_PROFILE, 1)
+    step()
+    ms.mh.set_option(tgp._lib.OPT_PROFILE, 0)
+    prof = ms.mh.rank_profile(0)
+    out = dict(metric="Kalman steps/sec (logpdf + posterior marginals), T=10^7 Matern32 d=3", value=T / (dt_s / args.steps), unit="Kalman steps/s",
+               n_gpus=W, steps=args.steps, warmup=args.warmup, ms_per_step=dt_s / args.steps * 1e3, higher_is_better=True, scaling=args.scaling,
+               vs_baseline=None, dtype="f64", data="synthetic",
+               config=dict(workload=f"{'cfg4' if name == 'sum52_12_d4' else 'cfg2'}: {name}, RegularSpacing(0,0.1,T={T}), sigma2_obs=0.1, layout={args.layout}; per step: "
+                                    "logpdf AND posterior marginals of the series (one combined call: tgp_multi_logpdf_and_posterior_marginals)",
+                           T=T, T_per_gpu=T // W, d=d, layout=args.layout, devices=devices,
+                           parallelism=f"time-shard x{W} in ONE process (tgp_create_multi), {args.scaling}", ranks=W, backend=ms.transport, logpdf=lp),
+               kernels_rank0={kk: dict(avg_ms=v["total_ms"] / max(1, v["calls"]), calls=v["calls"]) for kk, v in prof.items()})
+    if not args.no_single_gpu_reference and args.scaling == "strong":
+        try:
+            full = lti_sde.build_lgssm(lti_sde.to_kernel(k), lti_sde.RegularSpacing(0.0, dt, T), s2, device=devices[0])
+            yf = torch.randn((T,), dtype=torch.float64, device=f"cuda:{devices[0]}")
+            rn = torch.full((1,), 1e-18, dtype=torch.float64, device=f"cuda:{devices[0]}")
+            for _ in range(2):
+                tgp.logpdf_and_posterior_marginals(full, yf, rn)
+            torch.cuda.synchronize(devices[0])
+            t1 = time.perf_counter()
+            n1 = max(2, args.steps // 4)
+            for _ in range(n1):
+                tgp.logpdf_and_posterior_marginals(full, yf, rn)
+            torch.cuda.synchronize(devices[0])
+            one = T / ((time.perf_counter() - t1) / n1)
+            out["single_gpu_reference"] = dict(value=one, unit="Kalman steps/s", speedup=out["value"] / one,
+                                               note="the whole series on ONE GPU with the single-GPU entry point (the stationary-gain engine for an LTI model; "
+                                                    "the shards run the general chunked-scan engine)")
+        except Exception as ex:      # noqa: BLE001
+            out["single_gpu_reference"] = dict(error=repr(ex))
+    print(json.dumps(out))
+
+
 def run_engine_factory(args, world, rank):
     """Test hook (tests/test_bench_spawn.py): the N > 1 launch + sharding + collective path on a CPU box -- gloo backend, the
     per-segment device work supplied by `module:function` (a host emulation). Never a measurement."""
@@ -461,12 +530,23 @@ def main():
                     "(the forward filter runs twice) instead of the combined entry point")
     ap.add_argument("--dense-products", action="store_true", help="cfg5: the reference's dense A / H products (TGP_OPT_DENSE_STRUCTURE = 0)")
     ap.add_argument("--cpu-sample", type=int, default=2_000_000)
+    ap.add_argument("--torchrun", action="store_true", help="N > 1 launched directly: re-launch under torch.distributed.run (one PROCESS per GPU, collectives "
+                    "through torch.distributed) instead of driving the N GPUs from this process through the in-library multi-GPU handle")
+    ap.add_argument("--devices", default=None, help="in-process multi-GPU path: comma-separated device ordinals, one per rank (repeat one to share a GPU)")
     ap.add_argument("--engine-factory", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    inproc = (args.gpus > 1 or args.devices) and "WORLD_SIZE" not in os.environ and not args.torchrun and not args.engine_factory and args.workload != "cfg5"
+    if inproc:
+        # launched directly: ONE process, the library owns the N GPUs (tgp_create_multi). The driver's torchrun launch (WORLD_SIZE set) and
+        # --torchrun take the one-process-per-GPU path below.
+        args.workload = args.workload or "sum52_12_d4"
+        args.scaling = args.scaling or "strong"
+        args.T = args.T or (10_000_000 if args.scaling == "weak" else 100_000_000)
+        return run_multi_inprocess(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         respawn_under_torchrun(args.gpus)          # does not return
     if args.gpus != world:

@@ -296,6 +296,7 @@ struct tgp_handle {
     int steady2_state = 0;       // 0 untried for the bound model, 1 served the last call, -1 does not apply
     bool steady2_last = false;   // the last logpdf / posterior-marginals call was served by it
     void* steady2_scope = nullptr;
+    bool table_pending = false;  // the kernel-variant choice (and its run-time check) of the general engine is deferred to its first use
     double* adj_host = nullptr;  // pinned: the record + the head's observations of an adjoint call
     DevBuf steady_rec;           // ... the chunks' records (ModelView::steady)
     int steady_calls = 0;        // 1: the last posterior-path forward pass (mode 2) wrote the records
@@ -675,11 +676,24 @@ struct CallTimer {
     }
 };
 
-int check_ready(tgp_handle* h) {
+// The general (chunked-scan) engine's kernel table of a d = 5..8 model is chosen by a run-time known-answer check (variant_selftest:
+// seconds on a machine that has not cached its verdict). A model the stationary-gain engine serves may never need it: tgp_model_set
+// leaves the choice pending and the first entry point that really runs the general engine resolves it.
+void resolve_table(tgp_handle* h) {
+    if (!h->table_pending) return;
+    h->table_pending = false;
+    select_table(h, h->d, h->lti, h->variant_opt);
+    h->reduce_valid = false;
+    h->smoother_valid = false;
+}
+// general == false: the caller tries the stationary-gain engine first and calls resolve_table itself before the general path
+int check_ready(tgp_handle* h, bool general = true) {
     if (!h) return TGP_EINVAL;
     if (!h->have_model) return h->fail(TGP_EINVAL, "no model set (call tgp_model_set first)");
     ++h->call_seq;
-    return bind_device(h);
+    TRY(bind_device(h));
+    if (general) resolve_table(h);
+    return TGP_OK;
 }
 // entry points the dense large-state engine (d > 16) does not serve
 int scan_only(tgp_handle* h, const char* what) {
@@ -1144,6 +1158,7 @@ int tgp_set_option(tgp_handle* h, int option, int64_t value) {
         if (value < 0 || value > 3) return h->fail(TGP_EINVAL, "TGP_OPT_VARIANT must be 0, 1, 2 or 3");
         h->variant_opt = (int)value;
         if (h->have_model) {
+            h->table_pending = false;
             select_table(h, h->d, h->lti, (int)value);
             h->reduce_valid = false;
             h->smoother_valid = false;
@@ -1203,6 +1218,7 @@ int tgp_set_option(tgp_handle* h, int option, int64_t value) {
 int tgp_kernel_variant(const tgp_handle* h) {
     if (!h || !h->have_model) return 0;
     if (h->is_dense) return 16 + tgp_dense::structure(h->dense);   // dense path: 16 | (A sparse) | 2 (H sparse)
+    if (h->table_pending && bind_device(const_cast<tgp_handle*>(h)) == TGP_OK) resolve_table(const_cast<tgp_handle*>(h));   // a diagnostic of the general engine
     return h->variant_code;
 }
 
@@ -1314,7 +1330,10 @@ int tgp_model_set(tgp_handle* h, int64_t T, int d, int p, int ordering, uint32_t
     if (!kt) return h->fail(TGP_EUNSUPPORTED, "state dimension d must be positive");
     {
         const uint32_t lb = TGP_SHARED_A | TGP_SHARED_a | TGP_SHARED_Q | TGP_SHARED_H | TGP_SHARED_h;
-        select_table(h, d, (flags & lb) == lb, h->variant_opt);
+        const bool lti_model = (flags & lb) == lb;
+        // (what steady2_eligible will ask of the model: such a model's logpdf / posterior-marginals / adjoint calls never touch the table)
+        h->table_pending = h->variant_opt == 0 && h->opt_steady2 && lti_model && p == 1 && (flags & TGP_SHARED_R) && ordering == 0 && tgp_steady::supports(d);
+        select_table(h, d, lti_model, h->table_pending ? 1 : h->variant_opt);
         kt = h->kt;
     }
     if (!A || !a || !Q || !H || !hh || !R || !x0m || !x0P) return h->fail(TGP_EINVAL, "null model array");
@@ -1420,7 +1439,7 @@ int tgp_model_set_x0(tgp_handle* h, const double* x0m, const double* x0P) {
 }
 
 int tgp_logpdf(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t flags, double* out) {
-    TRY(check_ready(h));
+    TRY(check_ready(h, /*general=*/false));
     if (!out) return h->fail(TGP_EINVAL, "out is NULL");
     h->steady2_last = false;
     if (steady2_eligible(h, missing, flags)) {
@@ -1433,6 +1452,7 @@ int tgp_logpdf(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t 
         if (rc != TGP_OK || steady2_served(h)) return rc;
         // not applicable to this model (decided on the device): the general path below serves this and every later call
     }
+    resolve_table(h);
     if (graph_eligible(h, flags, false)) {
         const uint64_t key[8] = {1, (uint64_t)(uintptr_t)y, (uint64_t)(uintptr_t)missing, flags, 0, 0, 0, 0};
         return graph_call(h, 0, key, [&]() -> int {
@@ -1471,7 +1491,7 @@ int tgp_adjoint_finish(int d, const double* rec, const double* y_head, int64_t n
 
 int tgp_logpdf_adjoint(tgp_handle* h, const double* y, uint32_t flags, double* lml_out, double* gA, double* ga, double* gQ, double* gH,
                        double* ghh, double* gR, double* gx0m, double* gx0P) {
-    TRY(check_ready(h));
+    TRY(check_ready(h, /*general=*/false));
     h->steady2_last = false;
     const int keep_state = h->steady2_state;
     h->steady2_state = 0;            // (an earlier "does not apply" verdict of a posterior call -- series shorter than head + tail -- does not bind this one)
@@ -1626,7 +1646,7 @@ static int smoother_backward_impl(tgp_handle* h, const double* xs_dev, const dou
 
 int tgp_posterior_marginals(tgp_handle* h, const double* y, const uint8_t* missing, const double* Rnew, uint32_t flags,
                             double* mean_out, double* var_out, double* lml_out) {
-    TRY(check_ready(h));
+    TRY(check_ready(h, /*general=*/false));
     if (!Rnew || !mean_out || !var_out) return h->fail(TGP_EINVAL, "null Rnew / output");
     if (h->ordering != 0) return h->fail(TGP_EUNSUPPORTED, "posterior of a Reverse-ordered model is not implemented on the device");
     const bool idev = (flags & TGP_IN_DEVICE) != 0, odev = (flags & TGP_OUT_DEVICE) != 0;
@@ -1652,6 +1672,7 @@ int tgp_posterior_marginals(tgp_handle* h, const double* y, const uint8_t* missi
             return rc;
         }
     }
+    resolve_table(h);
     if (graph_eligible(h, flags, true)) {
         const uint64_t key[8] = {2, (uint64_t)(uintptr_t)y, (uint64_t)(uintptr_t)missing, flags, (uint64_t)(uintptr_t)Rnew, (uint64_t)(uintptr_t)mean_out,
                                  (uint64_t)(uintptr_t)var_out, 0};

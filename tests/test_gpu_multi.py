@@ -144,3 +144,20 @@ def test_unsupported_models_are_refused():
     m = U.random_lgssm(rng, False, 2, 3)
     with pytest.raises(tgp._lib.TGPError):          # fewer steps than ranks
         tgp.MultiLGSSM(_dev_model(tgp, m), devices=[0] * 4)
+
+
+def test_bench_launched_directly_with_several_gpus_uses_the_in_library_handle():
+    """`python bench.py --gpus 2` without a torch.distributed environment: ONE process, tgp_create_multi (here both ranks on cuda:0)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(U.ROOT, "bench.py"), "--gpus", "2", "--devices", "0,0", "--steps", "2", "--warmup", "1", "--T", "400000"]
+    res = subprocess.run(cmd, env=env, cwd=U.ROOT, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["config"]["T"] == 400000
+    assert out["config"]["backend"].startswith("copy") and "tgp_create_multi" in out["config"]["parallelism"]
+    assert out["value"] > 0 and np.isfinite(out["config"]["logpdf"])
+    assert out["single_gpu_reference"]["value"] > 0
