@@ -292,9 +292,16 @@ def _check_inputs(model, y):
         raise ValueError(f"Dimension mismatch. length(prior) is {len(model)}, but length(y) is {len(y)}")
 
 
-def _obs(y, model=None):
+_LAZY_NAN_MIN = 1 << 16
+
+
+def _obs(y, model=None, lazy_nan=False):
     """-> (y contiguous fp64, missing mask or None, in_device). NaN == missing (host arrays only;
-    for CUDA tensors pass a (y, mask) tuple). Vector observations: y (T, p); a (T,) mask marks whole steps."""
+    for CUDA tensors pass a (y, mask) tuple). Vector observations: y (T, p); a (T,) mask marks whole steps.
+    lazy_nan: a large scalar-output host series is NOT scanned for NaNs here (the scan costs more than its PCIe transfer: ~2-10 ms per
+    1e7 values); a NaN reaches the device, comes back as a NaN log-likelihood, and the caller then calls again without lazy_nan
+    (`_lazy_obs_call`). _obs.unchecked tells the caller whether the scan was skipped."""
+    _obs.unchecked = False
     mask = None
     if isinstance(y, tuple):
         y, mask = y
@@ -342,10 +349,30 @@ def _obs(y, model=None):
         mask = np.ma.getmaskarray(y) if mask is None else mask
         y = y.filled(0.0)
     yy = np.ascontiguousarray(_to_numpy(y), dtype=np.float64)
+    if mask is None and lazy_nan and yy.size >= _LAZY_NAN_MIN:
+        _obs.unchecked = True
+        return yy, None, False
     if mask is None and np.isnan(yy).any():
         mask = np.isnan(yy)
     mm = None if mask is None else np.ascontiguousarray(_to_numpy(mask).astype(np.uint8))
     return yy, mm, False
+
+
+def _lazy_obs_call(model, y, call):
+    """call(yy, mm, dev) -> (lml, result). Large host series go to the device unscanned; a NaN log-likelihood (or a not-positive-
+    definite report a NaN can cause) brings the NaN == missing scan back and, if it finds any, the call is repeated with the mask."""
+    yy, mm, dev = _obs(y, model, lazy_nan=True)
+    if not _obs.unchecked:
+        return call(yy, mm, dev)[1]
+    try:
+        lml, res = call(yy, mm, dev)
+        if not np.isnan(lml):
+            return res
+    except _lib.NotPositiveDefinite:
+        if not np.isnan(yy).any():
+            raise
+    yy, mm, dev = _obs(y, model)
+    return call(yy, mm, dev)[1]
 
 
 def _out(model, shape, like_device):
@@ -361,6 +388,12 @@ def logpdf(model, y):
         model = model.materialise()
     _check_inputs(model, y[0] if isinstance(y, tuple) else y)
     hd = model.handle()
+    if model._whiten is None and model.p == 1:
+        def call(yy, mm, dev):
+            out = ctypes.c_double()
+            hd.check(hd.lib.tgp_logpdf(hd.h, _lib.ptr(yy), _lib.ptr(mm), _lib.IN_DEVICE if dev else 0, ctypes.byref(out)))
+            return out.value, out.value
+        return _lazy_obs_call(model, y, call)
     yy, mm, dev = _obs(y, model)
     out = ctypes.c_double()
     hd.check(hd.lib.tgp_logpdf(hd.h, _lib.ptr(yy), _lib.ptr(mm), _lib.IN_DEVICE if dev else 0, ctypes.byref(out)))
@@ -614,34 +647,35 @@ def posterior_marginals(model, y, R_new, _with_lml=False, out=None):
     _check_inputs(model, y[0] if isinstance(y, tuple) else y)
     _need_diag(model, "posterior_marginals")
     hd = model.handle()
-    yy, mm, dev = _obs(y, model)
-    flags = (_lib.IN_DEVICE | _lib.OUT_DEVICE) if dev else 0
-    if dev and _is_torch(R_new):
-        Rn = R_new.contiguous()
-    elif dev:
-        import torch
-        Rn = torch.as_tensor(np.atleast_1d(np.asarray(R_new, dtype=np.float64)), device=yy.device)
-    else:
-        Rn = np.ascontiguousarray(np.atleast_1d(_to_numpy(R_new)), dtype=np.float64)
-    if model.p > 1 and Rn.ndim == 1:
-        Rn = Rn[None]
-    if Rn.shape[0] == 1:
-        flags |= _lib.SHARED_R
-    elif Rn.shape[0] != model.T:
-        raise ValueError("R_new must have length 1 or T")
-    if model.p > 1 and tuple(Rn.shape[1:]) != (model.p,):
-        raise ValueError(f"R_new must be (T|1, {model.p}) (diagonal of the new noise)")
-    mean, var = out if out is not None else (_out(model, _osh(model), dev), _out(model, _osh(model), dev))
-    if out is not None and (_lib.is_device(mean) != bool(dev) or tuple(mean.shape) != _osh(model) or tuple(var.shape) != _osh(model)):
-        raise ValueError("out: buffers of another call shape / memory space")
-    if _with_lml:
+
+    def call(yy, mm, dev):
+        flags = (_lib.IN_DEVICE | _lib.OUT_DEVICE) if dev else 0
+        if dev and _is_torch(R_new):
+            Rn = R_new.contiguous()
+        elif dev:
+            import torch
+            Rn = torch.as_tensor(np.atleast_1d(np.asarray(R_new, dtype=np.float64)), device=yy.device)
+        else:
+            Rn = np.ascontiguousarray(np.atleast_1d(_to_numpy(R_new)), dtype=np.float64)
+        if model.p > 1 and Rn.ndim == 1:
+            Rn = Rn[None]
+        if Rn.shape[0] == 1:
+            flags |= _lib.SHARED_R
+        elif Rn.shape[0] != model.T:
+            raise ValueError("R_new must have length 1 or T")
+        if model.p > 1 and tuple(Rn.shape[1:]) != (model.p,):
+            raise ValueError(f"R_new must be (T|1, {model.p}) (diagonal of the new noise)")
+        mean, var = out if out is not None else (_out(model, _osh(model), dev), _out(model, _osh(model), dev))
+        if out is not None and (_lib.is_device(mean) != bool(dev) or tuple(mean.shape) != _osh(model) or tuple(var.shape) != _osh(model)):
+            raise ValueError("out: buffers of another call shape / memory space")
+        # (the log marginal likelihood is always asked for: it is a by-product, and a NaN in it reports a NaN observation)
         lml = ctypes.c_double()
         hd.check(hd.lib.tgp_logpdf_and_posterior_marginals(hd.h, _lib.ptr(yy), _lib.ptr(mm), _lib.ptr(Rn), flags, ctypes.byref(lml),
                                                            _lib.ptr(mean), _lib.ptr(var)))
-        return lml.value, mean, var
-    hd.check(hd.lib.tgp_posterior_marginals(hd.h, _lib.ptr(yy), _lib.ptr(mm), _lib.ptr(Rn), flags, _lib.ptr(mean),
-                                            _lib.ptr(var), None))
-    return mean, var
+        return lml.value, ((lml.value, mean, var) if _with_lml else (mean, var))
+    if model._whiten is None and model.p == 1:
+        return _lazy_obs_call(model, y, call)
+    return call(*_obs(y, model))[1]
 
 
 def logpdf_and_posterior_marginals(model, y, R_new, out=None):

@@ -590,3 +590,49 @@ def test_stationary_covariance_build_is_dropped_where_chunk_0_settles_late(tgp):
         f, t = ctypes.c_int64(0), ctypes.c_int64(0)
         hd.check(hd.lib.tgp_steady_steps(hd.h, ctypes.byref(f), ctypes.byref(t)))
         assert f.value > 0
+
+
+def test_large_pageable_host_arrays_give_the_results_of_device_resident_data(tgp):
+    """y in / (mean, var) and filter states out as PAGEABLE host arrays of tens of MB (what a Julia Vector{Float64} caller hands over):
+    bitwise the results of the same calls on device-resident data."""
+    import torch
+    from temporalgps_jl_amd import lti_sde
+    T = 3_100_003                      # 23.65 MiB of observations: two full chunks + a ragged one
+    model = lti_sde.build_lgssm(lti_sde.Matern32Kernel(), lti_sde.RegularSpacing(0.0, 0.1, T), 0.1)
+    y = np.random.default_rng(31).standard_normal(T)
+    yd = torch.as_tensor(y, device="cuda:0")
+    rn = np.array([0.05])
+    assert tgp.logpdf(model, y) == tgp.logpdf(model, yd)
+    mean, var = tgp.posterior_marginals(model, y, rn)
+    md, vd = tgp.posterior_marginals(model, yd, torch.as_tensor(rn, device="cuda:0"))
+    assert np.array_equal(mean, md.cpu().numpy()) and np.array_equal(var, vd.cpu().numpy())
+    mf, Pf = tgp._filter(model, y)
+    mfd, Pfd = tgp._filter(model, yd)
+    assert np.array_equal(mf, mfd.cpu().numpy()) and np.array_equal(Pf, Pfd.cpu().numpy())
+
+
+def test_nan_observations_in_a_large_host_series_are_found_without_scanning_every_call(tgp):
+    """NaN == missing for host arrays. Large scalar-output series are not scanned on the host before the call (the scan costs more than
+    the PCIe transfer): the NaN comes back as a NaN log-likelihood and the call is repeated with the mask -- same results as an explicit
+    mask, for the stationary-gain engine's models (LTI) and the general engine's (per-step) alike."""
+    from temporalgps_jl_amd import lgssm as L, lti_sde
+    T = 200_000
+    assert T >= L._LAZY_NAN_MIN
+    rng = np.random.default_rng(41)
+    y = rng.standard_normal(T)
+    miss = rng.random(T) < 0.01
+    yn = y.copy()
+    yn[miss] = np.nan
+    rn = np.array([0.05])
+    for per_step in (False, True):
+        model = lti_sde.build_lgssm(lti_sde.Matern32Kernel(), lti_sde.RegularSpacing(0.0, 0.1, T), 0.1, force_per_step=per_step)
+        want = tgp.logpdf(model, (y, miss))
+        assert np.isfinite(want)
+        assert tgp.logpdf(model, yn) == want
+        m0, v0 = tgp.posterior_marginals(model, (y, miss), rn)
+        m1, v1 = tgp.posterior_marginals(model, yn, rn)
+        assert np.array_equal(m0, m1) and np.array_equal(v0, v1)
+        lp, m2, v2 = tgp.logpdf_and_posterior_marginals(model, yn, rn)
+        assert lp == want and np.array_equal(m0, m2)
+        # no NaN: one call, no mask (an explicit all-false mask takes the LTI model off the stationary-gain engine: equal to rounding)
+        assert abs(tgp.logpdf(model, y) - tgp.logpdf(model, (y, np.zeros(T, dtype=bool)))) <= 1e-12 * abs(want)
