@@ -466,8 +466,7 @@ def run_multi_inprocess(args):
             torch.cuda.synchronize(devices[0])
             one = T / ((time.perf_counter() - t1) / n1)
             out["single_gpu_reference"] = dict(value=one, unit="Kalman steps/s", speedup=out["value"] / one,
-                                               note="the whole series on ONE GPU with the single-GPU entry point (the stationary-gain engine for an LTI model; "
-                                                    "the shards run the general chunked-scan engine)")
+                                               note="the whole series on ONE GPU with the single-GPU entry point (LTI model: the stationary-gain engine, as the shards)")
         except Exception as ex:      # noqa: BLE001
             out["single_gpu_reference"] = dict(error=repr(ex))
     print(json.dumps(out))

@@ -291,6 +291,19 @@ int tgp_shard_smoother_forward(tgp_handle* h, double* slot_dev);
 int tgp_shard_smoother_backward(tgp_handle* h, const double* gathered_dev, int world, int rank, const double* Rnew,
                                 uint32_t flags, double* mean_out, double* var_out, double* lml_out);
 
+/* ---- time shards of the stationary-gain engine (LTI models of tgp_logpdf_adjoint's class; csrc/tgp_steady.hpp) ----------------------
+ * Two halves around ONE all-gather. begin: covariance set-up, pass 1 and a provisional carry pass of this segment; leaves the segment's
+ * element (mu behind it, lam in front of it, Phi^L, G^L, B_L, an "applies" word) in slot_dev (tgp_shard_steady_slot_size(d) doubles).
+ * finish: the chain of gathered elements -> this segment's real boundary, carry pass, pass 2 (posterior marginals when begin was
+ * called with posterior != 0), reduction; *served = 0 when ANY rank found that the engine does not apply to its segment (covariance
+ * not settled, segment shorter than head / tail, a segment that hands its end on but is not a whole number of 512-step tiles):
+ * outputs are then undefined and the caller runs the tgp_shard_* protocol above. first / last: the segment starts / ends the series.
+ * lml_out: this segment's share of the log marginal likelihood. Only enqueues until finish's one synchronisation. */
+int tgp_shard_steady_slot_size(int d);
+int tgp_shard_steady_begin(tgp_handle* h, const double* y, uint32_t flags, int first, int last, int posterior, double* slot_dev);
+int tgp_shard_steady_finish(tgp_handle* h, const double* gathered_dev, int world, int rank, const double* Rnew, uint32_t flags,
+                            double* mean_out, double* var_out, double* lml_out, int* served);
+
 /* ---- multi-GPU handle: the same protocol inside ONE process (SURVEY.md 8b "Threading", 8e) -----------
  * tgp_create_multi owns, per listed device, one tgp_handle with its own HIP stream, one host worker thread and
  * one RCCL communicator (ncclCommInitAll; librccl is opened at run time). Rank r serves the contiguous time

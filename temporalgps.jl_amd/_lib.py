@@ -67,6 +67,9 @@ _SIGS = {
     "tgp_shard_logpdf": (ctypes.c_int, [_vp, _vp]),
     "tgp_shard_smoother_forward": (ctypes.c_int, [_vp, _vp]),
     "tgp_shard_smoother_backward": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, _vp, _u32, _vp, _vp, _dp]),
+    "tgp_shard_steady_slot_size": (ctypes.c_int, [ctypes.c_int]),
+    "tgp_shard_steady_begin": (ctypes.c_int, [_vp, _vp, _u32, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp]),
+    "tgp_shard_steady_finish": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, _vp, _u32, _vp, _vp, _dp, ctypes.POINTER(ctypes.c_int)]),
     "tgp_create_multi": (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),
     "tgp_destroy_multi": (ctypes.c_int, [_vp]),
     "tgp_multi_last_error": (ctypes.c_char_p, [_vp]),

@@ -297,6 +297,8 @@ struct tgp_handle {
     bool steady2_last = false;   // the last logpdf / posterior-marginals call was served by it
     void* steady2_scope = nullptr;
     bool table_pending = false;  // the kernel-variant choice (and its run-time check) of the general engine is deferred to its first use
+    int shard2_first = 1, shard2_last = 1, shard2_post = 0;      // the open two-half call of a stationary-gain time shard
+    bool shard2_open = false;
     double* adj_host = nullptr;  // pinned: the record + the head's observations of an adjoint call
     DevBuf steady_rec;           // ... the chunks' records (ModelView::steady)
     int steady_calls = 0;        // 1: the last posterior-path forward pass (mode 2) wrote the records
@@ -1025,7 +1027,8 @@ void steady2_end(void* ctx) {
     h->steady2_scope = nullptr;
 }
 // Enqueues the call on the engine (y already staged in h->mv.y). mean_dev == nullptr: logpdf only.
-int steady2_enqueue(tgp_handle* h, const double* Rnew_dev, bool rnew_per_step, double* mean_dev, double* var_dev, bool grad = false) {
+int steady2_enqueue(tgp_handle* h, const double* Rnew_dev, bool rnew_per_step, double* mean_dev, double* var_dev, bool grad = false,
+                    const tgp_steady::ShardDev* shard = nullptr, int phase = 0) {
     if (!h->steady2) h->steady2 = tgp_steady::create();
     tgp_steady::ModelDev md;
     md.d = h->d;
@@ -1047,6 +1050,10 @@ int steady2_enqueue(tgp_handle* h, const double* Rnew_dev, bool rnew_per_step, d
         hk.end = steady2_end;
     }
     std::string err;
+    if (shard) {
+        if (tgp_steady::enqueue_shard(h->steady2, h->stream, md, cd, *shard, phase, hk, &err) != 0) return h->fail(TGP_EHIP, err);
+        return TGP_OK;
+    }
     if (tgp_steady::enqueue(h->steady2, h->stream, md, cd, hk, &err) != 0) return h->fail(TGP_EHIP, err);
     return TGP_OK;
 }
@@ -2545,6 +2552,71 @@ int tgp_shard_smoother_backward(tgp_handle* h, const double* gathered_dev, int w
     TRY(copy_back(h, mean_out, dm, nT, odev));
     TRY(copy_back(h, var_out, dv, nT, odev));
     return tm.finish(lml_out);
+}
+
+// ---- time shards on the stationary-gain engine (tgp_steady.hpp: ShardDev) ----------------------------------------------------------------
+int tgp_shard_steady_slot_size(int d) { return tgp_steady::supports(d) ? (int)tgp_steady::shard_slot_size(d) : 0; }
+
+int tgp_shard_steady_begin(tgp_handle* h, const double* y, uint32_t flags, int first, int last, int posterior, double* slot_dev) {
+    TRY(check_ready(h, /*general=*/false));
+    h->shard2_open = false;
+    if (!slot_dev) return h->fail(TGP_EINVAL, "slot_dev is NULL");
+    if (!steady2_eligible(h, nullptr, flags) || h->T <= tgp_steady::kTile)
+        return h->fail(TGP_EUNSUPPORTED, "tgp_shard_steady_begin: not a model / segment of the stationary-gain engine (use the tgp_shard_* protocol of the general engine)");
+    CallTimer tm(h);
+    TRY(set_obs(h, y, nullptr, flags));
+    tgp_steady::ShardDev sd;
+    sd.first = first ? 1 : 0;
+    sd.last = last ? 1 : 0;
+    sd.post = posterior ? 1 : 0;
+    sd.slot = slot_dev;
+    TRY(steady2_enqueue(h, nullptr, false, nullptr, nullptr, false, &sd, 0));
+    h->shard2_first = sd.first;
+    h->shard2_last = sd.last;
+    h->shard2_post = sd.post;
+    h->shard2_open = true;
+    return TGP_OK;
+}
+
+int tgp_shard_steady_finish(tgp_handle* h, const double* gathered_dev, int world, int rank, const double* Rnew, uint32_t flags, double* mean_out,
+                            double* var_out, double* lml_out, int* served) {
+    TRY(check_ready(h, /*general=*/false));
+    if (!h->shard2_open) return h->fail(TGP_EINVAL, "tgp_shard_steady_finish needs a preceding tgp_shard_steady_begin");
+    h->shard2_open = false;
+    if (!gathered_dev || world < 1 || world > 64 || rank < 0 || rank >= world || !served) return h->fail(TGP_EINVAL, "bad gathered buffer / world / rank / served");
+    const bool post = h->shard2_post != 0;
+    if (post && (!Rnew || !mean_out || !var_out)) return h->fail(TGP_EINVAL, "null Rnew / output");
+    const bool idev = (flags & TGP_IN_DEVICE) != 0, odev = (flags & TGP_OUT_DEVICE) != 0;
+    const bool rshared = (flags & TGP_SHARED_R) != 0;
+    const size_t nT = (size_t)h->T * sizeof(double);
+    CallTimer tm(h, /*clear=*/false);
+    tgp_steady::ShardDev sd;
+    sd.first = h->shard2_first;
+    sd.last = h->shard2_last;
+    sd.post = h->shard2_post;
+    sd.gathered = gathered_dev;
+    sd.world = world;
+    sd.rank = rank;
+    const void* pR = nullptr;
+    double *dm = nullptr, *dv = nullptr;
+    if (post) {
+        TRY(stage_in(h, h->bRnew, Rnew, rshared ? sizeof(double) : nT, idev, &pR));
+        TRY(stage_out(h, h->bo1, mean_out, nT, odev, &dm));
+        TRY(stage_out(h, h->bo2, var_out, nT, odev, &dv));
+    }
+    tm.inputs_done();
+    TRY(steady2_enqueue(h, (const double*)pR, !rshared, dm, dv, false, &sd, 1));
+    tm.kernels_done();
+    if (post) {
+        TRY(copy_back(h, mean_out, dm, nT, odev));
+        TRY(copy_back(h, var_out, dv, nT, odev));
+    }
+    TRY(tm.finish(lml_out));
+    *served = h->host_result[6] == tgp_steady::kStatusRan ? 1 : 0;
+    h->reduce_valid = false;
+    h->smoother_valid = false;
+    h->fold_valid = false;
+    return TGP_OK;
 }
 
 int tgp_elem_apply(int kind, int d, const double* elem, const double* m, const double* P, double* m_out, double* P_out) {

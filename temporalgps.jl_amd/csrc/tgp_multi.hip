@@ -13,6 +13,10 @@
 //                                                         all-gather of W elements
 //   tgp_shard_smoother_backward   smoothed state at the segment end, local smoother; the rank's ONE stream synchronisation
 //
+// LTI models of the stationary-gain engine (tgp_steady.hip) take its two-half shard calls instead (tgp_shard_steady_begin / _finish: ONE
+// all-gather of a (1 + 2 d + 3 d^2)-double element per rank, segments aligned to its 512-step tiles); if any rank reports that the engine
+// does not apply, the call is repeated on the protocol above and the handle remembers it for the bound model.
+//
 // Transports of the all-gather: RCCL (ncclAllGather on the rank's stream; librccl is opened at run time, so that a process that already
 // holds an RCCL -- torch -- shares it) when the devices are distinct; peer copies ordered by HIP events ("copy") when a device is
 // listed more than once (ranks sharing a GPU: the single-GPU tests), when RCCL cannot be opened, or with TGP_MULTI_TRANSPORT=copy.
@@ -105,7 +109,10 @@ struct tgp_multi {
     int d = 0, p = 0;
     bool have_model = false;
     // exchange buffers, per rank (on the rank's device)
-    std::vector<double*> slot[2], gath[2], stats;
+    std::vector<double*> slot[3], gath[3], stats;      // phase 0 / 1: the general engine's elements; 2: the stationary-gain engine's
+    size_t slot_n[3] = {0, 0, 0};
+    bool try_steady = false;
+    std::vector<int> served;
     std::vector<hipEvent_t> ev_slot, ev_done;
     double* host_stats = nullptr;      // pinned, [W][4]
     std::vector<double> lml;           // per-rank share of the last combined call
@@ -129,10 +136,19 @@ struct tgp_multi {
 
 namespace {
 
-void segment(int64_t T, int W, int r, int64_t& lo, int64_t& hi) {      // = parallel.segment_bounds
+// Balanced contiguous segments. Long series: interior boundaries on multiples of 512 steps -- a segment of the stationary-gain engine
+// that hands its end state to the next one must be a whole number of that engine's tiles (the general engine does not care).
+constexpr int64_t kAlign = 512;
+int64_t seg_lo(int64_t T, int W, int r) {
+    if (r <= 0) return 0;
+    if (r >= W) return T;
     const int64_t base = T / W, rem = T % W;
-    lo = r * base + (r < rem ? r : rem);
-    hi = lo + base + (r < rem ? 1 : 0);
+    const int64_t lo = r * base + (r < rem ? r : rem);      // = parallel.segment_bounds
+    return base >= 8 * kAlign ? lo / kAlign * kAlign : lo;
+}
+void segment(int64_t T, int W, int r, int64_t& lo, int64_t& hi) {
+    lo = seg_lo(T, W, r);
+    hi = seg_lo(T, W, r + 1);
 }
 
 void worker(tgp_multi* m, int r) {
@@ -185,7 +201,7 @@ bool sync_ok(tgp_multi* m, int my_rc) { return !m->bar.arrive(my_rc != TGP_OK); 
 
 // all-gather of the phase's slot of every rank into every rank's gathered buffer, ordered on the rank's stream
 int all_gather(tgp_multi* m, int r, int phase) {
-    const size_t n = (size_t)tgp_shard_slot_size(phase, m->d);
+    const size_t n = m->slot_n[phase];
     if (m->use_rccl)
         return m->rccl.AllGather(m->slot[phase][r], m->gath[phase][r], n, kNcclFloat64, m->comm[r], m->st[r]) == 0 ? TGP_OK : TGP_EHIP;
     // copy transport: my slot is complete at ev_slot[r]; once every rank has recorded its event, pull the W slots.  (Every rank passes
@@ -216,6 +232,26 @@ int forward(tgp_multi* m, int r, const double* y, const uint8_t* miss, uint32_t 
     if (!sync_ok(m, rc)) return rc != TGP_OK ? rc : -1;
     stopped = false;
     return tgp_shard_fold(m->h[r], m->gath[0][r], m->W, r);
+}
+
+// One call on the stationary-gain engine's shards. TGP_OK with *all_served: done. TGP_OK without: some rank's segment is not the
+// engine's (every rank knows: the gathered elements carry it) -- run the general protocol. TGP_EUNSUPPORTED: not one of its models.
+int steady_call(tgp_multi* m, const double* const* y, const double* const* Rnew, uint32_t flags, bool post, double* const* mean_out,
+                double* const* var_out, bool* all_served) {
+    *all_served = false;
+    const int rc = run_all(m, [&](int r) {
+        int c = tgp_shard_steady_begin(m->h[r], y[r], flags & TGP_IN_DEVICE, r == 0, r == m->W - 1, post ? 1 : 0, m->slot[2][r]);
+        if (!sync_ok(m, c)) return c != TGP_OK ? c : -1;
+        c = all_gather(m, r, 2);
+        if (!sync_ok(m, c)) return c != TGP_OK ? c : -1;
+        return tgp_shard_steady_finish(m->h[r], m->gath[2][r], m->W, r, post ? Rnew[r] : nullptr, flags, post ? mean_out[r] : nullptr,
+                                       post ? var_out[r] : nullptr, &m->lml[r], &m->served[r]);
+    });
+    if (rc != TGP_OK) return rc;
+    bool all = true;
+    for (int r = 0; r < m->W; ++r) all = all && m->served[r] != 0;
+    *all_served = all;
+    return TGP_OK;
 }
 
 int check_call(tgp_multi* m, const void* y) {
@@ -319,7 +355,7 @@ int tgp_destroy_multi(tgp_multi* m) {
         (void)hipSetDevice(m->dev[r]);
         if (m->st[r]) (void)hipStreamSynchronize(m->st[r]);
         if (m->use_rccl && r < (int)m->comm.size() && m->comm[r]) (void)m->rccl.CommDestroy(m->comm[r]);
-        for (int ph = 0; ph < 2; ++ph) {
+        for (int ph = 0; ph < 3; ++ph) {
             if (r < (int)m->slot[ph].size() && m->slot[ph][r]) (void)hipFree(m->slot[ph][r]);
             if (r < (int)m->gath[ph].size() && m->gath[ph][r]) (void)hipFree(m->gath[ph][r]);
         }
@@ -382,16 +418,21 @@ int tgp_multi_model_set(tgp_multi* m, int64_t T, int d, int p, int ordering, uin
         if (rc != TGP_OK) return rc;
     }
     // exchange buffers
-    for (int ph = 0; ph < 2; ++ph) {
+    for (int ph = 0; ph < 3; ++ph) {
         m->slot[ph].resize(m->W, nullptr);
         m->gath[ph].resize(m->W, nullptr);
     }
     m->stats.resize(m->W, nullptr);
+    m->served.assign(m->W, 0);
+    m->try_steady = tgp_shard_steady_slot_size(d) > 0 && p == 1;      // (tgp_shard_steady_begin decides per call whether the model is one of the engine's)
     if (d != m->d) {
+        m->slot_n[0] = (size_t)tgp_shard_slot_size(0, d);
+        m->slot_n[1] = (size_t)tgp_shard_slot_size(1, d);
+        m->slot_n[2] = (size_t)(tgp_shard_steady_slot_size(d) > 0 ? tgp_shard_steady_slot_size(d) : 1);
         for (int r = 0; r < m->W; ++r) {
             if (hipSetDevice(m->dev[r]) != hipSuccess) return m->fail(TGP_EHIP, "hipSetDevice");
-            for (int ph = 0; ph < 2; ++ph) {
-                const size_t n = (size_t)tgp_shard_slot_size(ph, d) * sizeof(double);
+            for (int ph = 0; ph < 3; ++ph) {
+                const size_t n = m->slot_n[ph] * sizeof(double);
                 if (m->slot[ph][r]) (void)hipFree(m->slot[ph][r]);
                 if (m->gath[ph][r]) (void)hipFree(m->gath[ph][r]);
                 m->slot[ph][r] = m->gath[ph][r] = nullptr;
@@ -412,6 +453,19 @@ int tgp_multi_logpdf(tgp_multi* m, const double* const* y, const uint8_t* const*
     int rc = check_call(m, y);
     if (rc != TGP_OK) return rc;
     if (!out) return m->fail(TGP_EINVAL, "out is NULL");
+    if (m->try_steady && !missing) {
+        bool served = false;
+        rc = steady_call(m, y, nullptr, flags, false, nullptr, nullptr, &served);
+        if (rc == TGP_OK && served) {
+            double sum = 0.0;
+            for (int r = 0; r < m->W; ++r) sum += m->lml[r];
+            *out = sum;
+            return TGP_OK;
+        }
+        if (rc != TGP_OK && rc != TGP_EUNSUPPORTED) return rc;
+        m->err.clear();
+        m->try_steady = false;      // (remembered for the bound model)
+    }
     rc = run_all(m, [&](int r) {
         bool stopped = false;
         int c = forward(m, r, y[r], missing ? missing[r] : nullptr, flags, stopped);
@@ -438,6 +492,21 @@ static int multi_posterior(tgp_multi* m, const double* const* y, const uint8_t* 
     int rc = check_call(m, y);
     if (rc != TGP_OK) return rc;
     if (!Rnew || !mean_out || !var_out) return m->fail(TGP_EINVAL, "Rnew / mean_out / var_out is NULL (expected arrays of one pointer per rank)");
+    if (m->try_steady && !missing) {
+        bool served = false;
+        rc = steady_call(m, y, Rnew, flags, true, mean_out, var_out, &served);
+        if (rc == TGP_OK && served) {
+            if (lml_out) {
+                double sum = 0.0;
+                for (int r = 0; r < m->W; ++r) sum += m->lml[r];
+                *lml_out = sum;
+            }
+            return TGP_OK;
+        }
+        if (rc != TGP_OK && rc != TGP_EUNSUPPORTED) return rc;
+        m->err.clear();
+        m->try_steady = false;
+    }
     rc = run_all(m, [&](int r) {
         bool stopped = false;
         int c = forward(m, r, y[r], missing ? missing[r] : nullptr, flags, stopped);

@@ -52,7 +52,19 @@ struct CL {
     static constexpr int PT = Blb + DD;                      // [kBlk][DD]: Phi^(512 w), w = 0..kBlk-1   (tile carries inside a workgroup,
     static constexpr int GT = PT + kBlk * DD;                // [kBlk][DD]: G^(512 w)                      k_apply)
     static constexpr int KW = GT + kBlk * DD;                // [kBlk][DD]: K_w = G^512 K_{w+1} + B_512 Phi^(512 (w+1)), K_{kBlk-1} = 0
-    static constexpr int size = KW + kBlk * DD;
+    // time shards (tgp_multi): the whole run of stationary steps of THIS segment (L = T - head steps) as one element
+    static constexpr int PSeg = KW + kBlk * DD;              // Phi^L
+    static constexpr int GSeg = PSeg + DD;                   // G^L
+    static constexpr int BSeg = GSeg + DD;                   // B_L
+    static constexpr int GLb = BSeg + DD;                    // G^(steps of the ragged last workgroup): the lam a shard receives enters there
+    static constexpr int size = GLb + DD;
+};
+// slot a time shard hands to the exchange: [0] applies, then F (mu behind the segment under a zero carry-in; rank 0: the mu itself),
+// B0 (lam in front of the segment's stationary steps under zero carries), Phi^L, G^L, B_L
+template <int D>
+struct ShardSlot {
+    static constexpr int DD = D * D;
+    static constexpr int F = 1, B0 = 1 + D, P = 1 + 2 * D, G = P + DD, B = G + DD, size = B + DD;
 };
 
 // record of an adjoint call (doubles): the sums of the stationary tiles, then what the host's half needs (k_final_grad)
@@ -459,10 +471,10 @@ __device__ void head_forward(const Tab& tb, const double* __restrict__ y, long l
 // k_setup_core: what the tile passes wait for -- the filter covariance to its stationary value with the head's per-step gains (a, b),
 // the constant block with the powers and couplings (e), and the head's forward recursion (its carry starts the stationary tiles).
 template <int D>
-__global__ __launch_bounds__(64) void k_setup_core(ModelDev m, Tab tb, const double* __restrict__ y, long long T, int grad) {
+__global__ __launch_bounds__(64) void k_setup_core(ModelDev m, Tab tb, const double* __restrict__ y, long long T, int grad, int shard) {
     constexpr int DD = D * D;
     constexpr int nhmax = kHeadMaxTiles * kTile;
-    __shared__ double sP[DD], sT[DD], sPp[DD], sB[DD], sXa[DD], sGa[DD], sXb[DD], sGb[DD];
+    __shared__ double sP[DD], sT[DD], sPp[DD], sB[DD], sXa[DD], sGa[DD], sXb[DD], sGb[DD], sXc[DD], sGc[DD];
     const int lane = threadIdx.x;
     const bool act = lane < DD;
     const int e = act ? lane : 0;
@@ -493,17 +505,25 @@ __global__ __launch_bounds__(64) void k_setup_core(ModelDev m, Tab tb, const dou
     __syncthreads();
     bad = bad || tb.hdr[4] != 0;
     const bool settled = n0 >= 0 && n0 < nhmax;      // the head tables hold nhmax steps: th <= kHeadMaxTiles
-    const int th = settled ? n0 / kTile + 1 : 0;
+    // A time shard that does not start the series (shard & 1) has no head: every one of its steps is stationary, its first predicted
+    // mean comes from the exchange. One that does not end it (shard & 2) hands its end state on: that needs whole tiles, and the whole
+    // run of stationary steps as ONE element (Phi^L, G^L, B_L below: L < 2^kPowN).
+    const bool notfirst = (shard & 1) != 0, notlast = (shard & 2) != 0;
+    const int th = settled ? (notfirst ? 0 : n0 / kTile + 1) : 0;
     const int nh = th * kTile;
+    const long long Lseg = T - nh;
+    const bool fits = (long long)nh + 2 <= T && (!shard || Lseg < (1LL << kPowN)) && (!notlast || T % kTile == 0);
     if (lane == 0) {
-        tb.hdr[0] = (settled && !bad && (long long)nh + 2 <= T) ? 1 : 0;      // (k_setup_side may still find the series too short)
+        tb.hdr[0] = (settled && !bad && fits) ? 1 : 0;      // (k_setup_side may still find the series too short)
         tb.hdr[1] = th;
-        tb.hdr[2] = settled ? n0 : -1;
+        tb.hdr[2] = settled ? (notfirst ? 0 : n0) : -1;      // head steps with gains of their own (what the passes and the caller see)
         tb.hdr[3] = -1;
         tb.hdr[4] = bad ? 1 : 0;
+        tb.hdr[5] = n0;                                     // row of the tables that holds the stationary step
+        tb.hdr[6] = shard;
         tb.misc[9] = (double)wall_clock64();
     }
-    if (!settled || bad || (long long)nh + 2 > T) return;
+    if (!settled || bad || !fits) return;
     // stationary coefficients (entry n0; the head recursions read the tables at min(t, n0))
     double* ss = tb.ssc;
     const double iS = 1.0 / Sss, R = m.R[0];
@@ -536,7 +556,7 @@ __global__ __launch_bounds__(64) void k_setup_core(ModelDev m, Tab tb, const dou
         ss[SS<D>::rS] = R * iS;
         ss[SS<D>::iS] = iS;
         ss[SS<D>::logS] = log(Sss);
-        ss[SS<D>::LS] = LS;
+        ss[SS<D>::LS] = notfirst ? 0.0 : LS;
     }
     __threadfence_block();
     __syncthreads();
@@ -553,12 +573,12 @@ __global__ __launch_bounds__(64) void k_setup_core(ModelDev m, Tab tb, const dou
         double x = Ai[j] - kAss[i] * hv[j];        // Phi = A - kA h'
         double g = ss[SS<D>::G + e];
         double b = ci * hv[j];
-        double bl[2] = {0.0, 0.0};
-        const int want[2] = {nv, nvb};
-        double* sXq[2] = {sXa, sXb};
-        double* sGq[2] = {sGa, sGb};
+        double bl[3] = {0.0, 0.0, 0.0};
+        const long long want[3] = {nv, nvb, shard ? Lseg : 0LL};
+        double* sXq[3] = {sXa, sXb, sXc};
+        double* sGq[3] = {sGa, sGb, sGc};
         if (act) {
-            sXa[e] = sGa[e] = sXb[e] = sGb[e] = (i == j) ? 1.0 : 0.0;
+            sXa[e] = sGa[e] = sXb[e] = sGb[e] = sXc[e] = sGc[e] = (i == j) ? 1.0 : 0.0;
         }
         lds_sync();
         double* cst = tb.cst;
@@ -573,9 +593,9 @@ __global__ __launch_bounds__(64) void k_setup_core(ModelDev m, Tab tb, const dou
                 sB[e] = b;
             }
             lds_sync();
-            if (k < kLogBlk) {
+            if (k < kLogBlk || shard) {             // (the tile / workgroup targets have no bits from 2^kLogBlk on)
 #pragma unroll
-                for (int w = 0; w < 2; ++w) {
+                for (int w = 0; w < 3; ++w) {
                     if ((want[w] >> k) & 1) {       // append a block of 2^k steps to the composition: Bl += Ga B_(2^k) Xa
                         double u = 0.0, xa = 0.0, ga = 0.0;
 #pragma unroll
@@ -623,6 +643,10 @@ __global__ __launch_bounds__(64) void k_setup_core(ModelDev m, Tab tb, const dou
         if (act) {
             cst[CL<D>::Blt + e] = (nv == kTile) ? cst[CL<D>::B512 + e] : bl[0];
             cst[CL<D>::Blb + e] = (nvb == kBlk * kTile) ? cst[CL<D>::Bblk + e] : bl[1];
+            cst[CL<D>::PSeg + e] = sXc[e];
+            cst[CL<D>::GSeg + e] = sGc[e];
+            cst[CL<D>::BSeg + e] = bl[2];
+            cst[CL<D>::GLb + e] = (nvb == kBlk * kTile) ? cst[CL<D>::pg + kLogBlk * DD + e] : sGb[e];
         }
         // (e2) tile carries inside a workgroup in closed form (k_apply): PT[w] = Phi^(512 w), GT[w] = G^(512 w), and the coupling of the
         //      workgroup's mu into the lam behind tile w, K_w = G^512 K_{w+1} + B_512 PT[w+1], K_{kBlk-1} = 0
@@ -679,7 +703,15 @@ __global__ __launch_bounds__(64) void k_setup_core(ModelDev m, Tab tb, const dou
     __threadfence_block();
     __syncthreads();
     if (lane == 0) tb.misc[11] = (double)wall_clock64();
-    head_forward<D>(tb, y, T, lane);
+    if (notfirst) {      // no head: a zero carry-in until the exchange supplies the real one (k_shard_fold)
+        if (lane == 0) {
+            tb.misc[0] = 0.0;
+#pragma unroll
+            for (int q = 0; q < D; ++q) tb.MUb[q] = 0.0;
+        }
+    } else {
+        head_forward<D>(tb, y, T, lane);
+    }
     if (lane == 0) tb.misc[12] = (double)wall_clock64();
 }
 
@@ -695,7 +727,8 @@ __device__ void setup_side(const ModelDev& m, const Tab& tb, long long T) {
     const bool act = lane < DD;
     const int e = act ? lane : 0;
     const int i = e / D, j = e % D;
-    const int th = (int)tb.hdr[1], n0 = (int)tb.hdr[2];
+    const int th = (int)tb.hdr[1], n0 = (int)tb.hdr[5];
+    const bool notfirst = (tb.hdr[6] & 1) != 0, notlast = (tb.hdr[6] & 2) != 0;      // time shards: no head / no tail of its own
     const int nh = th * kTile;
     const double* ss = tb.ssc;
     double hv[D];
@@ -740,9 +773,9 @@ __device__ void setup_side(const ModelDev& m, const Tab& tb, long long T) {
             break;
         }
     }
-    const bool applies = !bad && n1 >= 0 && (long long)nh + n1 + 1 <= T;
+    const bool applies = !bad && n1 >= 0 && (long long)nh + (notlast ? 0 : n1) + 1 <= T;
     if (lane == 0) {
-        tb.hdr[3] = n1;
+        tb.hdr[3] = notlast ? 0 : n1;      // (a segment that does not end the series: the smoothed covariance is stationary to its last step)
         if (!applies) tb.hdr[0] = 0;
     }
     if (!applies) return;
@@ -750,7 +783,7 @@ __device__ void setup_side(const ModelDev& m, const Tab& tb, long long T) {
     // ---- (d) smoothed covariance of the head: Ps_{n0} = stationary, Ps_{t-1} = G_t Ps_t G_t' + L_t; the gains of SB steps at a time
     //      are staged in LDS (a dependent global load per step would cost more than the step) --------------------------------------
     if (act) tb.s_Ps[(size_t)n0 * DD + e] = sP[e];
-    for (int thi = n0; thi >= 1; thi -= SB) {
+    for (int thi = notfirst ? 0 : n0; thi >= 1; thi -= SB) {
         const int tlo = imax(thi - SB + 1, 1);          // steps tlo..thi, thi first
         const int cnt = thi - tlo + 1;
         for (int idx = lane; idx < cnt * DD; idx += 64) {
@@ -1290,7 +1323,8 @@ __device__ __forceinline__ void block_carries(const double* __restrict__ cst, FG
             m[i] = sMu[w][i];
         }
         const long long tile = tile0 + w;
-        if (tile < ntiles) {
+        if (tile >= ntiles) continue;          // (beyond the end: nothing to absorb -- a time shard's lam must not be advanced across it)
+        {
             const double* __restrict__ C = cst + (tile == ntiles - 1 ? CL<D>::Blt : CL<D>::B512);
 #pragma unroll
             for (int i = 0; i < D; ++i)
@@ -1383,7 +1417,8 @@ __global__ __launch_bounds__(kBlkThreads) void k_reduce(const long long* __restr
 // the slice's end state, and read the elements again on the way back.
 template <int D, bool POST>
 __global__ __launch_bounds__(512) void k_carry(const long long* __restrict__ hdr, const double* __restrict__ cst, const double* __restrict__ Fb,
-                                                const double* __restrict__ B0b, double* MUb, double* __restrict__ LAMb, long long ntiles) {
+                                                const double* __restrict__ B0b, double* MUb, double* LAMb, long long ntiles,
+                                                int lam_given /* time shards: LAMb[N] holds the lam behind the segment (else zero) */) {
     if (hdr[0] == 0) return;
     constexpr int DD = D * D;
     constexpr int kLanes = 512, kRounds = 9;
@@ -1495,8 +1530,8 @@ __global__ __launch_bounds__(512) void k_carry(const long long* __restrict__ hdr
     }
     // ---- backward
 #pragma unroll
-    for (int i = 0; i < D; ++i) carry[i] = 0.0;
-    if (tid == 0) {
+    for (int i = 0; i < D; ++i) carry[i] = lam_given ? LAMb[N * D + i] : 0.0;
+    if (!lam_given && tid == 0) {
 #pragma unroll
         for (int i = 0; i < D; ++i) LAMb[N * D + i] = 0.0;
     }
@@ -1510,21 +1545,25 @@ __global__ __launch_bounds__(512) void k_carry(const long long* __restrict__ hdr
 #pragma unroll
             for (int g = 0; g < kQ; ++g) couple(base + g, mu[g], elb[g]);
         }
+        // the carry enters at the lane that owns the slice's LAST element (the last slice is ragged: the lanes behind it hold nothing, and
+        // the scan's fixed powers would carry a non-zero lam -- a time shard's -- across them as if they held whole elements)
+        const int inj = sl == nslices - 1 ? (int)((N - 1 - sl * slice) / kQ) : kLanes - 1;
 #pragma unroll
-        for (int i = 0; i < D; ++i) s[i] = (tid == kLanes - 1) ? carry[i] : 0.0;
+        for (int i = 0; i < D; ++i) s[i] = (tid == inj) ? carry[i] : 0.0;
+        const double* __restrict__ Glast = cst + CL<D>::GLb;      // (the series' last workgroup holds nvb <= 4096 steps)
 #pragma unroll
         for (int g = kQ - 1; g >= 0; --g)
-            if (base + g < N) step(G, s, elb[g]);
+            if (base + g < N) step(base + g == N - 1 ? Glast : G, s, elb[g]);
         block_scan(s, 1, false);
 #pragma unroll
         for (int i = 0; i < D; ++i) {
-            s[i] = (tid == kLanes - 1) ? carry[i] : sv[1][i][tid < kLanes - 1 ? tid + 1 : kLanes - 1];
+            s[i] = (tid == inj) ? carry[i] : sv[1][i][tid < kLanes - 1 ? tid + 1 : kLanes - 1];
             carry[i] = sv[1][i][0];
         }
 #pragma unroll
         for (int g = kQ - 1; g >= 0; --g)
             if (base + g < N) {
-                step(G, s, elb[g]);
+                step(base + g == N - 1 ? Glast : G, s, elb[g]);
 #pragma unroll
                 for (int i = 0; i < D; ++i) LAMb[(base + g) * D + i] = s[i];
             }
@@ -1857,6 +1896,106 @@ __global__ __launch_bounds__(1024) void k_final_grad(Tab tb, ModelDev m, long lo
     }
     if (tid < D + D * (D + 1) / 2) md[2 * DD + 2 * D + 2 + tid] = m.x0[tid];
 }
+
+// =================================================================================================================================
+// time shards (tgp_multi.hip): the segment as ONE element of the two recursions, and the carries the exchange brings back
+// =================================================================================================================================
+// After pass 1 and a carry pass under the segment's provisional boundary (rank 0: the head's mu, zero lam; other ranks: zero both): the
+// predicted mean behind the segment's last step (the last workgroup's tiles walked by one thread: a segment that hands on its end has
+// whole tiles only), the lam in front of its stationary steps, and the segment-level matrices of the constant block.
+template <int D>
+__global__ __launch_bounds__(64) void k_shard_pack(Tab tb, long long ntiles, int post, double* __restrict__ slot) {
+    constexpr int DD = D * D;
+    const int tid = threadIdx.x;
+    const bool ok = tb.hdr[0] != 0;
+    if (tid == 0) slot[0] = ok ? 1.0 : 0.0;
+    if (!ok) {
+        for (int q = 1 + tid; q < ShardSlot<D>::size; q += 64) slot[q] = 0.0;
+        return;
+    }
+    const double* __restrict__ cst = tb.cst;
+    if (tid < DD) {
+        slot[ShardSlot<D>::P + tid] = cst[CL<D>::PSeg + tid];
+        slot[ShardSlot<D>::G + tid] = cst[CL<D>::GSeg + tid];
+        slot[ShardSlot<D>::B + tid] = cst[CL<D>::BSeg + tid];
+    }
+    if (tid == 0) {
+        const long long th = tb.hdr[1], N = nblk_max_for(th, ntiles);
+        const long long tile0 = th + (N - 1) * kBlk;
+        const double* __restrict__ M = cst + CL<D>::pphi + kLogTile * DD;
+        double mu[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) mu[i] = tb.MUb[(N - 1) * D + i];
+        for (long long tile = tile0; tile < ntiles; ++tile) {
+            double n[D];
+#pragma unroll
+            for (int i = 0; i < D; ++i) n[i] = tb.F[tile * D + i];
+            matvec_acc<D>(M, mu, n);
+#pragma unroll
+            for (int i = 0; i < D; ++i) mu[i] = n[i];
+        }
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            slot[ShardSlot<D>::F + i] = mu[i];
+            slot[ShardSlot<D>::B0 + i] = post ? tb.LAMb[i] : 0.0;
+        }
+    }
+}
+
+// From the gathered slots of all ranks: this segment's real boundary -- mu at its first stationary step (ranks > 0; rank 0 keeps its
+// head's), lam behind its last step -- by walking the chain of segment elements (W <= 64: one thread).  If ANY rank reports that the
+// engine does not apply to its segment, this rank stops as well (every later kernel returns at once, k_final reports it).
+//   mu_in(1) = F_0,  mu_in(q+1) = Phi^L_q mu_in(q) + F_q;     lam_in(W-1) = 0,  lam_in(q-1) = G^L_q lam_in(q) + B0_q - B_L_q mu_in(q)
+template <int D>
+__global__ __launch_bounds__(64) void k_shard_fold(Tab tb, long long ntiles, const double* __restrict__ gathered, int world, int rank, int post) {
+    constexpr int NS = ShardSlot<D>::size;
+    __shared__ double smu[64][D];
+    if (threadIdx.x != 0) return;
+    bool ok = tb.hdr[0] != 0;
+    for (int q = 0; q < world; ++q) ok = ok && gathered[(size_t)q * NS] != 0.0;
+    if (!ok) {
+        tb.hdr[0] = 0;
+        return;
+    }
+    double mu[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) mu[i] = 0.0;
+    for (int q = 0; q + 1 < world; ++q) {          // mu_in of rank q + 1
+        const double* __restrict__ sl = gathered + (size_t)q * NS;
+        double n[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) n[i] = sl[ShardSlot<D>::F + i];
+        if (q > 0) matvec_acc<D>(sl + ShardSlot<D>::P, mu, n);      // (rank 0's F is the mean itself)
+#pragma unroll
+        for (int i = 0; i < D; ++i) mu[i] = smu[q + 1][i] = n[i];
+    }
+    const long long N = nblk_max_for(tb.hdr[1], ntiles);
+    if (rank > 0) {
+#pragma unroll
+        for (int i = 0; i < D; ++i) tb.MUb[i] = smu[rank][i];
+    }
+    double lam[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) lam[i] = 0.0;
+    if (post) {
+        for (int q = world - 1; q > rank; --q) {      // lam_in of rank q - 1
+            const double* __restrict__ sl = gathered + (size_t)q * NS;
+            double n[D];
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                double v = sl[ShardSlot<D>::B0 + i];
+#pragma unroll
+                for (int l = 0; l < D; ++l) v = fma(-sl[ShardSlot<D>::B + i * D + l], smu[q][l], v);
+                n[i] = v;
+            }
+            matvec_acc<D>(sl + ShardSlot<D>::G, lam, n);
+#pragma unroll
+            for (int i = 0; i < D; ++i) lam[i] = n[i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < D; ++i) tb.LAMb[N * D + i] = lam[i];
+}
 }  // namespace
 
 // =================================================================================================================================
@@ -1891,7 +2030,7 @@ hipError_t ensure(Engine* e, int d, long long ntiles) {
         return o;
     };
     // constant block, as CL<D> lays it out
-    const size_t ss_size = 2 * DD + 5 * (size_t)d + 6, c_pphi = (ss_size + 7) & ~(size_t)7, c_pg = c_pphi + kPowN * DD, c_size = c_pg + kPowN * DD + 4 * DD + 3 * kBlk * DD;
+    const size_t ss_size = 2 * DD + 5 * (size_t)d + 6, c_pphi = (ss_size + 7) & ~(size_t)7, c_pg = c_pphi + kPowN * DD, c_size = c_pg + kPowN * DD + 4 * DD + 3 * kBlk * DD + 4 * DD;
     const size_t o_hdr = take(8), o_cst = take(c_size);
     const size_t o_hkA = take(nhmax * d), o_hrS = take(nhmax), o_hiS = take(nhmax), o_hG = take(nhmax * DD), o_hc = take(nhmax * d),
                  o_hvb = take(nhmax), o_hr = take(nhmax);
@@ -1932,16 +2071,47 @@ struct Scope {
 };
 
 template <int D>
-int enqueue_d(Engine* e, hipStream_t st, const ModelDev& m, const CallDev& c, const Hooks& hk) {
+int enqueue_d(Engine* e, hipStream_t st, const ModelDev& m, const CallDev& c, const Hooks& hk, const ShardDev* sh, int phase) {
     static_assert(CL<D>::pphi == ((2 * D * D + 5 * D + 6 + 7) & ~7), "ensure() mirrors CL<D>");
+    static_assert(CL<D>::size == CL<D>::pphi + 2 * kPowN * D * D + 4 * D * D + 3 * kBlk * D * D + 4 * D * D, "ensure() mirrors CL<D>");
+    static_assert(ShardSlot<D>::size == 1 + 2 * D + 3 * D * D, "shard_slot_size() mirrors ShardSlot<D>");
     const long long T = c.T;
     const long long ntiles = (T + kTile - 1) / kTile;
-    const bool post = c.mean != nullptr;
+    const bool post = c.mean != nullptr || (sh && sh->post);
     const Tab tb = e->tb;
-    const unsigned blocks = (unsigned)((ntiles - 1 + kBlk - 1) / kBlk);      // workgroups of the stationary tiles if the head is one tile
+    // workgroups of the stationary tiles if the head is one tile (a shard that does not start the series has no head)
+    const unsigned blocks = (unsigned)((ntiles - ((sh && !sh->first) ? 0 : 1) + kBlk - 1) / kBlk);
+    if (sh) {
+        // ---- a time shard, in two halves around the exchange of the segments' elements (tgp_multi.hip)
+        if (blocks == 0) return (int)hipErrorInvalidValue;      // (the caller sends series of one tile to the general path)
+        const int flags = (sh->first ? 0 : 1) | (sh->last ? 0 : 2);
+        if (phase == 0) {
+            { Scope s(hk, "k_steady_setup"); hipLaunchKernelGGL(k_setup_core<D>, dim3(1), dim3(64), 0, st, m, tb, c.y, T, 0, flags); }
+            if (post) {
+                { Scope s(hk, "k_steady_reduce<posterior>"); hipLaunchKernelGGL((k_reduce<D, true>), dim3(blocks + 1), dim3(kBlkThreads), 0, st, tb.hdr, tb.cst, c.y, tb.F, tb.B0, tb.Fb, tb.B0b, T, ntiles, m, tb, 1); }
+                { Scope s(hk, "k_steady_carry<segment>"); hipLaunchKernelGGL((k_carry<D, true>), dim3(1), dim3(512), 0, st, tb.hdr, tb.cst, tb.Fb, tb.B0b, tb.MUb, tb.LAMb, ntiles, 0); }
+            } else {
+                { Scope s(hk, "k_steady_reduce<logpdf>"); hipLaunchKernelGGL((k_reduce<D, false>), dim3(blocks), dim3(kBlkThreads), 0, st, tb.hdr, tb.cst, c.y, tb.F, tb.B0, tb.Fb, tb.B0b, T, ntiles, m, tb, 0); }
+                { Scope s(hk, "k_steady_carry<segment>"); hipLaunchKernelGGL((k_carry<D, false>), dim3(1), dim3(512), 0, st, tb.hdr, tb.cst, tb.Fb, tb.B0b, tb.MUb, tb.LAMb, ntiles, 0); }
+            }
+            { Scope s(hk, "k_steady_shard_pack"); hipLaunchKernelGGL(k_shard_pack<D>, dim3(1), dim3(64), 0, st, tb, ntiles, post ? 1 : 0, sh->slot); }
+            return (int)hipGetLastError();
+        }
+        { Scope s(hk, "k_steady_shard_fold"); hipLaunchKernelGGL(k_shard_fold<D>, dim3(1), dim3(64), 0, st, tb, ntiles, sh->gathered, sh->world, sh->rank, post ? 1 : 0); }
+        if (post) {
+            { Scope s(hk, "k_steady_carry<posterior>"); hipLaunchKernelGGL((k_carry<D, true>), dim3(1), dim3(512), 0, st, tb.hdr, tb.cst, tb.Fb, tb.B0b, tb.MUb, tb.LAMb, ntiles, 1); }
+            { Scope s(hk, "k_steady_apply<posterior>"); hipLaunchKernelGGL((k_apply<D, true>), dim3(blocks), dim3(kBlkThreads), 0, st, tb.hdr, tb.cst, c.y, c.Rnew, c.rnew_per_step, tb.F, tb.B0, tb.Pw, tb.Lw, tb.MUb, tb.LAMb, tb.t_vb, c.mean, c.var, tb.SSQ, T, ntiles); }
+            { Scope s(hk, "k_steady_final<posterior>"); hipLaunchKernelGGL(k_final<D>, dim3(2), dim3(256), 0, st, tb, T, ntiles, c.result, c.y, c.Rnew, c.rnew_per_step, c.mean, c.var); }
+        } else {
+            { Scope s(hk, "k_steady_carry<logpdf>"); hipLaunchKernelGGL((k_carry<D, false>), dim3(1), dim3(512), 0, st, tb.hdr, tb.cst, tb.Fb, tb.B0b, tb.MUb, tb.LAMb, ntiles, 0); }
+            { Scope s(hk, "k_steady_apply<logpdf>"); hipLaunchKernelGGL((k_apply<D, false>), dim3(blocks), dim3(kBlkThreads), 0, st, tb.hdr, tb.cst, c.y, (const double*)nullptr, 0, tb.F, tb.B0, tb.Pw, tb.Lw, tb.MUb, tb.LAMb, tb.t_vb, (double*)nullptr, (double*)nullptr, tb.SSQ, T, ntiles); }
+            { Scope s(hk, "k_steady_final<logpdf>"); hipLaunchKernelGGL(k_final<D>, dim3(1), dim3(256), 0, st, tb, T, ntiles, c.result, c.y, c.Rnew, 0, (double*)nullptr, (double*)nullptr); }
+        }
+        return (int)hipGetLastError();
+    }
     {
         Scope s(hk, "k_steady_setup");
-        hipLaunchKernelGGL(k_setup_core<D>, dim3(1), dim3(64), 0, st, m, tb, c.y, T, c.grad ? 1 : 0);
+        hipLaunchKernelGGL(k_setup_core<D>, dim3(1), dim3(64), 0, st, m, tb, c.y, T, c.grad ? 1 : 0, 0);
     }
     if (blocks == 0) {      // a series of one tile: the engine does not apply (k_setup_core: nh + 2 > T)
         Scope s(hk, "k_steady_final");
@@ -1952,7 +2122,7 @@ int enqueue_d(Engine* e, hipStream_t st, const ModelDev& m, const CallDev& c, co
     if (c.grad) {
         static_assert(GradRec<D>::size == 3 * D * D + 8 * D + 8 + D * (D + 1) / 2, "grad_record_size() mirrors GradRec<D>");
         { Scope s(hk, "k_steady_reduce<adjoint>"); hipLaunchKernelGGL((k_reduce<D, true>), dim3(blocks + 1), dim3(kBlkThreads), 0, st, tb.hdr, tb.cst, c.y, tb.F, tb.B0, tb.Fb, tb.B0b, T, ntiles, m, tb, 0); }
-        { Scope s(hk, "k_steady_carry<adjoint>"); hipLaunchKernelGGL((k_carry<D, true>), dim3(1), dim3(512), 0, st, tb.hdr, tb.cst, tb.Fb, tb.B0b, tb.MUb, tb.LAMb, ntiles); }
+        { Scope s(hk, "k_steady_carry<adjoint>"); hipLaunchKernelGGL((k_carry<D, true>), dim3(1), dim3(512), 0, st, tb.hdr, tb.cst, tb.Fb, tb.B0b, tb.MUb, tb.LAMb, ntiles, 0); }
         { Scope s(hk, "k_steady_apply<adjoint>"); hipLaunchKernelGGL(k_apply_grad<D>, dim3(blocks), dim3(kBlkThreads), 0, st, tb.hdr, tb.cst, c.y, tb.F, tb.B0, tb.Pw, tb.Lw, tb.MUb, tb.LAMb, tb.GS, tb.SSQ, T, ntiles); }
         { Scope s(hk, "k_steady_final<adjoint>"); hipLaunchKernelGGL(k_final_grad<D>, dim3(1), dim3(1024), 0, st, tb, m, T, ntiles, tb.GS, (long long)blocks, tb.grec); }
         // (the value of the call: the usual reduction -- misc[0], LS and logS do not depend on the (G, c) of the block)
@@ -1961,12 +2131,12 @@ int enqueue_d(Engine* e, hipStream_t st, const ModelDev& m, const CallDev& c, co
     }
     if (post) {
         { Scope s(hk, "k_steady_reduce<posterior>"); hipLaunchKernelGGL((k_reduce<D, true>), dim3(blocks + 1), dim3(kBlkThreads), 0, st, tb.hdr, tb.cst, c.y, tb.F, tb.B0, tb.Fb, tb.B0b, T, ntiles, m, tb, 1); }
-        { Scope s(hk, "k_steady_carry<posterior>"); hipLaunchKernelGGL((k_carry<D, true>), dim3(1), dim3(512), 0, st, tb.hdr, tb.cst, tb.Fb, tb.B0b, tb.MUb, tb.LAMb, ntiles); }
+        { Scope s(hk, "k_steady_carry<posterior>"); hipLaunchKernelGGL((k_carry<D, true>), dim3(1), dim3(512), 0, st, tb.hdr, tb.cst, tb.Fb, tb.B0b, tb.MUb, tb.LAMb, ntiles, 0); }
         { Scope s(hk, "k_steady_apply<posterior>"); hipLaunchKernelGGL((k_apply<D, true>), dim3(blocks), dim3(kBlkThreads), 0, st, tb.hdr, tb.cst, c.y, c.Rnew, c.rnew_per_step, tb.F, tb.B0, tb.Pw, tb.Lw, tb.MUb, tb.LAMb, tb.t_vb, c.mean, c.var, tb.SSQ, T, ntiles); }
         { Scope s(hk, "k_steady_final<posterior>"); hipLaunchKernelGGL(k_final<D>, dim3(2), dim3(256), 0, st, tb, T, ntiles, c.result, c.y, c.Rnew, c.rnew_per_step, c.mean, c.var); }
     } else {
         { Scope s(hk, "k_steady_reduce<logpdf>"); hipLaunchKernelGGL((k_reduce<D, false>), dim3(blocks), dim3(kBlkThreads), 0, st, tb.hdr, tb.cst, c.y, tb.F, tb.B0, tb.Fb, tb.B0b, T, ntiles, m, tb, 0); }
-        { Scope s(hk, "k_steady_carry<logpdf>"); hipLaunchKernelGGL((k_carry<D, false>), dim3(1), dim3(512), 0, st, tb.hdr, tb.cst, tb.Fb, tb.B0b, tb.MUb, tb.LAMb, ntiles); }
+        { Scope s(hk, "k_steady_carry<logpdf>"); hipLaunchKernelGGL((k_carry<D, false>), dim3(1), dim3(512), 0, st, tb.hdr, tb.cst, tb.Fb, tb.B0b, tb.MUb, tb.LAMb, ntiles, 0); }
         { Scope s(hk, "k_steady_apply<logpdf>"); hipLaunchKernelGGL((k_apply<D, false>), dim3(blocks), dim3(kBlkThreads), 0, st, tb.hdr, tb.cst, c.y, (const double*)nullptr, 0, tb.F, tb.B0, tb.Pw, tb.Lw, tb.MUb, tb.LAMb, tb.t_vb, (double*)nullptr, (double*)nullptr, tb.SSQ, T, ntiles); }
         { Scope s(hk, "k_steady_final<logpdf>"); hipLaunchKernelGGL(k_final<D>, dim3(1), dim3(256), 0, st, tb, T, ntiles, c.result, c.y, c.Rnew, 0, (double*)nullptr, (double*)nullptr); }
     }
@@ -1975,7 +2145,19 @@ int enqueue_d(Engine* e, hipStream_t st, const ModelDev& m, const CallDev& c, co
 
 }  // namespace
 
+static int enqueue_any(Engine* e, hipStream_t stream, const ModelDev& m, const CallDev& c, const Hooks& hk, std::string* err, const ShardDev* sh, int phase);
 int enqueue(Engine* e, hipStream_t stream, const ModelDev& m, const CallDev& c, const Hooks& hk, std::string* err) {
+    return enqueue_any(e, stream, m, c, hk, err, nullptr, 0);
+}
+int enqueue_shard(Engine* e, hipStream_t stream, const ModelDev& m, const CallDev& c, const ShardDev& sh, int phase, const Hooks& hk, std::string* err) {
+    if (phase == 0 ? sh.slot == nullptr : (sh.gathered == nullptr || sh.world < 1 || sh.world > 64 || sh.rank < 0 || sh.rank >= sh.world)) {
+        if (err) *err = "tgp_steady::enqueue_shard: bad exchange buffer / world / rank";
+        return (int)hipErrorInvalidValue;
+    }
+    return enqueue_any(e, stream, m, c, hk, err, &sh, phase);
+}
+size_t shard_slot_size(int d) { return (size_t)(1 + 2 * d + 3 * d * d); }
+static int enqueue_any(Engine* e, hipStream_t stream, const ModelDev& m, const CallDev& c, const Hooks& hk, std::string* err, const ShardDev* sh, int phase) {
     if (!e || !supports(m.d) || c.T <= 0 || !c.y || !c.result || (c.mean && (!c.var || !c.Rnew))) {
         if (err) *err = "tgp_steady::enqueue: bad argument";
         return (int)hipErrorInvalidValue;
@@ -1988,14 +2170,14 @@ int enqueue(Engine* e, hipStream_t stream, const ModelDev& m, const CallDev& c, 
     }
     int r = 0;
     switch (m.d) {
-        case 1: r = enqueue_d<1>(e, stream, m, c, hk); break;
-        case 2: r = enqueue_d<2>(e, stream, m, c, hk); break;
-        case 3: r = enqueue_d<3>(e, stream, m, c, hk); break;
-        case 4: r = enqueue_d<4>(e, stream, m, c, hk); break;
-        case 5: r = enqueue_d<5>(e, stream, m, c, hk); break;
-        case 6: r = enqueue_d<6>(e, stream, m, c, hk); break;
-        case 7: r = enqueue_d<7>(e, stream, m, c, hk); break;
-        case 8: r = enqueue_d<8>(e, stream, m, c, hk); break;
+        case 1: r = enqueue_d<1>(e, stream, m, c, hk, sh, phase); break;
+        case 2: r = enqueue_d<2>(e, stream, m, c, hk, sh, phase); break;
+        case 3: r = enqueue_d<3>(e, stream, m, c, hk, sh, phase); break;
+        case 4: r = enqueue_d<4>(e, stream, m, c, hk, sh, phase); break;
+        case 5: r = enqueue_d<5>(e, stream, m, c, hk, sh, phase); break;
+        case 6: r = enqueue_d<6>(e, stream, m, c, hk, sh, phase); break;
+        case 7: r = enqueue_d<7>(e, stream, m, c, hk, sh, phase); break;
+        case 8: r = enqueue_d<8>(e, stream, m, c, hk, sh, phase); break;
         default: r = (int)hipErrorInvalidValue;
     }
     if (r != 0 && err) *err = std::string("tgp_steady: launch: ") + hipGetErrorString((hipError_t)r);

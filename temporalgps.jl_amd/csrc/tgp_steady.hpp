@@ -57,12 +57,26 @@ struct CallDev {
     bool grad = false;             // adjoint call: logpdf + the record behind d logpdf / d (model blocks) (grad_record; mean / var unused)
 };
 
+// A time shard of a longer series (tgp_multi.hip): the call runs in two halves around ONE exchange. Half 0 (setup, pass 1, a carry pass
+// under a provisional boundary) leaves the segment's element in `slot` (shard_slot_size(d) doubles, device memory); after an all-gather
+// of the slots, half 1 folds the chain of elements into this segment's real boundary and runs the carry pass, pass 2 and the reduction.
+// `first`: the segment starts the series (it owns the head; the others have stationary steps only and start from the exchanged mean);
+// `last`: it ends the series (it owns the smoother's tail; the others hand their end state on and need T % 512 == 0).
+struct ShardDev {
+    int first = 1, last = 1, post = 0;
+    double* slot = nullptr;
+    const double* gathered = nullptr;      // [world][shard_slot_size(d)], rank-major
+    int world = 1, rank = 0;
+};
+
 struct Engine;
 Engine* create();
 void destroy(Engine*);
 bool supports(int d);
 // Enqueues the whole call on `stream` (no synchronisation).  Returns 0, or a hipError_t cast to int with *err set.
 int enqueue(Engine*, hipStream_t stream, const ModelDev&, const CallDev&, const Hooks&, std::string* err);
+int enqueue_shard(Engine*, hipStream_t stream, const ModelDev&, const CallDev&, const ShardDev&, int phase, const Hooks&, std::string* err);
+size_t shard_slot_size(int d);
 // Adjoint calls (CallDev::grad).  The record (device memory of the engine, grad_record_size(d) doubles, valid once the stream has
 // passed the call) holds, in this order: the sums over the stationary tiles  SA [d][d] = sum psi_{t+1} mu_t', Sa [d] = sum psi_{t+1},
 // Sk [d] = sum psi_{t+1} r_t, Srm [d] = sum r_t mu_t, Sr = sum r_t, SSQ = sum r_t^2  (psi_{t+1} = d logpdf / d mu_{t+1}, mu_t the predicted

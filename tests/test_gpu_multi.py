@@ -161,3 +161,67 @@ def test_bench_launched_directly_with_several_gpus_uses_the_in_library_handle():
     assert out["config"]["backend"].startswith("copy") and "tgp_create_multi" in out["config"]["parallelism"]
     assert out["value"] > 0 and np.isfinite(out["config"]["logpdf"])
     assert out["single_gpu_reference"]["value"] > 0
+
+
+def _kernels_of_rank(ms, tgp, rank, fn):
+    ms.mh.set_option(tgp._lib.OPT_PROFILE, 1)
+    for r in range(ms.W):
+        ms.mh.lib.tgp_profile_reset(ms.mh.lib.tgp_multi_handle(ms.mh.m, r))
+    out = fn()
+    ms.mh.set_option(tgp._lib.OPT_PROFILE, 0)
+    return out, set(ms.mh.rank_profile(rank))
+
+
+@pytest.mark.parametrize("d", [1, 2, 3, 4, 5, 6, 7, 8])
+def test_lti_shards_run_on_the_stationary_gain_engine(d):
+    """An LTI model's shards take the stationary-gain engine's two-half calls (ONE all-gather; head on rank 0 only, tail on the last
+    rank only, segments aligned to 512-step tiles): same results as the oracle, and the kernels that ran say which engine it was."""
+    import temporalgps_jl_amd as tgp
+    rng = np.random.default_rng(60 + d)
+    T, ndev = 70_001, 3
+    model = U.random_lgssm(rng, False, d, T)
+    y = ref.rand(model, rng.standard_normal((T, d)), rng.standard_normal(T), rng.standard_normal(d))
+    ms = tgp.MultiLGSSM(_dev_model(tgp, model), devices=[0] * ndev)
+    assert all(lo % 512 == 0 for lo, _ in ms.bounds)
+    lp_ref = sk.logpdf(model, y)
+    Rnew = rng.random(T) + 0.05
+    pm, pv = sk.posterior_marginals(model, y, Rnew)
+    for rank in (0, 1, 2):
+        lp, names = _kernels_of_rank(ms, tgp, rank, lambda: ms.logpdf(y))
+        assert "k_steady_shard_fold" in names and not any(n.startswith("k_reduce_filter") for n in names), names
+        assert abs(lp - lp_ref) <= LOGPDF_RTOL * abs(lp_ref)
+    (lp, mean, var), names = _kernels_of_rank(ms, tgp, 1, lambda: ms.logpdf_and_posterior_marginals(y, Rnew))
+    assert "k_steady_apply<posterior>" in names and "k_steady_shard_pack" in names, names
+    assert abs(lp - lp_ref) <= LOGPDF_RTOL * abs(lp_ref)
+    assert np.max(np.abs(mean - pm)) <= MARGINAL_ATOL and np.max(np.abs(var - pv)) <= MARGINAL_ATOL
+    mean1, var1 = ms.posterior_marginals(y, np.array([0.3]))
+    pm1, pv1 = sk.posterior_marginals(model, y, np.array([0.3]))
+    assert np.max(np.abs(mean1 - pm1)) <= MARGINAL_ATOL and np.max(np.abs(var1 - pv1)) <= MARGINAL_ATOL
+
+
+def test_segments_the_stationary_gain_engine_cannot_take_fall_back_to_the_general_protocol():
+    """short segments (interior boundaries not on tile multiples) and a series with missing observations: every rank agrees through the
+    gathered elements that the engine does not apply, the general protocol serves the call, later calls go there directly"""
+    import temporalgps_jl_amd as tgp
+    T, ndev = 9_000, 3                 # 3000-step segments: not aligned (alignment starts at 4096 steps per rank)
+    model = oc.build_lgssm(("matern52",), ("regular", 0.0, 0.1, T), 0.1)
+    y = np.random.default_rng(17).standard_normal(T)
+    ms = tgp.MultiLGSSM(_dev_model(tgp, model), devices=[0] * ndev)
+    assert any(lo % 512 for lo, _ in ms.bounds)
+    lp, names = _kernels_of_rank(ms, tgp, 1, lambda: ms.logpdf(y))
+    assert any(n.startswith("k_reduce_filter") for n in names), names          # the general engine served it ...
+    lp2, names2 = _kernels_of_rank(ms, tgp, 1, lambda: ms.logpdf(y))
+    assert not any(n.startswith("k_steady") for n in names2), names2           # ... and the second call does not try again
+    lp_ref = sk.logpdf(model, y)
+    assert abs(lp - lp_ref) <= LOGPDF_RTOL * abs(lp_ref) and lp2 == lp
+    _check(ms, model, y, np.array([0.05]))
+    # missing data on aligned segments: the general protocol at once
+    T = 60_000
+    model = oc.build_lgssm(("matern32",), ("regular", 0.0, 0.1, T), 0.1)
+    y = np.random.default_rng(18).standard_normal(T)
+    mask = np.random.default_rng(19).random(T) < 0.05
+    ms = tgp.MultiLGSSM(_dev_model(tgp, model), devices=[0] * ndev)
+    lp, names = _kernels_of_rank(ms, tgp, 0, lambda: ms.logpdf((y, mask)))
+    assert not any(n.startswith("k_steady") for n in names)
+    lp_ref = ref.logpdf_missing(model, y, mask)
+    assert abs(lp - lp_ref) <= LOGPDF_RTOL * abs(lp_ref)
