@@ -31,10 +31,20 @@ from . import lgssm as L
 
 
 def segment_bounds(T, world, rank):
-    """Contiguous, balanced split of 0..T into `world` segments."""
-    base, rem = divmod(int(T), int(world))
-    lo = rank * base + min(rank, rem)
-    return lo, lo + base + (1 if rank < rem else 0)
+    """Contiguous, balanced split of 0..T into `world` segments. Long series: interior boundaries on multiples of 512 steps (a shard
+    of the stationary-gain engine that hands its end state on must be a whole number of that engine's tiles) -- the rule of
+    tgp_multi_segment (csrc/tgp_multi.hip)."""
+    T, world = int(T), int(world)
+    base, rem = divmod(T, world)
+
+    def lo(r):
+        if r <= 0:
+            return 0
+        if r >= world:
+            return T
+        v = r * base + min(r, rem)
+        return v // 512 * 512 if base >= 8 * 512 else v
+    return lo(rank), lo(rank + 1)
 
 
 class HIPEngine:
@@ -233,12 +243,65 @@ class ShardedLGSSM:
         e.shard_fold(gath[0], self.world, self.rank)
         return yy
 
+    def _steady_device(self, y, R_new, post):
+        """The same call on the stationary-gain engine's shards (LTI models; tgp_shard_steady_begin / _finish: two halves around ONE
+        all-gather). Returns None when it does not apply -- agreed by every rank through the gathered elements, so that all of them
+        then take the general protocol together. Must be called inside the handle's stream context."""
+        import torch
+        e = self.engine
+        lib, hd = e.hd.lib, e.hd
+        n = lib.tgp_shard_steady_slot_size(e.d)
+        if n == 0 or self.model.p != 1 or getattr(self, "_steady_off", False) or isinstance(y, tuple):
+            return None
+        if not hasattr(self, "_sslot"):
+            dev = torch.device("cuda", self.model.device)
+            self._sslot = torch.zeros(n, dtype=torch.float64, device=dev)
+            self._sgath = torch.zeros(self.world * n, dtype=torch.float64, device=dev)
+        yy, mm = e.device_obs(y)
+        if mm is not None:
+            return None                  # (NaN == missing is a property of the data every rank sees alike only by luck: callers with
+                                         #  missing data pass a (y, mask) tuple on EVERY rank, which is refused above on every rank)
+        rc = lib.tgp_shard_steady_begin(hd.h, _lib.ptr(yy), _lib.IN_DEVICE, int(self.rank == 0), int(self.rank == self.world - 1), int(post),
+                                        _lib.ptr(self._sslot))
+        began = rc == _lib.OK
+        if not began:
+            if rc != _lib.EUNSUPPORTED:
+                hd.check(rc)
+            self._sslot.zero_()          # "does not apply" travels with the element: every rank learns it from the gathered words
+        self.comm.all_gather(self._sgath, self._sslot)
+        if not began:
+            self._steady_off = True
+            return None
+        out_device = L._is_torch(y)
+        mean = var = Rn = None
+        flags = _lib.IN_DEVICE
+        if post:
+            dev = torch.device("cuda", self.model.device)
+            Rn = torch.as_tensor(np.atleast_1d(np.asarray(R_new, dtype=np.float64)) if not L._is_torch(R_new) else R_new,
+                                 dtype=torch.float64, device=dev).reshape(-1).contiguous()
+            mean, var = L._out(self.model, (self.model.T,), out_device), L._out(self.model, (self.model.T,), out_device)
+            flags |= (_lib.OUT_DEVICE if out_device else 0) | (_lib.SHARED_R if Rn.shape[0] == 1 else 0)
+        lml, served = ctypes.c_double(), ctypes.c_int(0)
+        hd.check(lib.tgp_shard_steady_finish(hd.h, _lib.ptr(self._sgath), self.world, self.rank, _lib.ptr(Rn), flags, _lib.ptr(mean), _lib.ptr(var),
+                                             ctypes.byref(lml), ctypes.byref(served)))        # the rank's one synchronisation
+        if not served.value:
+            self._steady_off = True
+            return None
+        return lml.value, mean, var
+
     def _logpdf_device(self, y):
         import torch
         e = self.engine
         st = e.stream()
         st.wait_stream(torch.cuda.current_stream(st.device))
         with torch.cuda.stream(st):
+            res = self._steady_device(y, None, False)
+            if res is not None:
+                stats = self._buffers()[2]
+                stats.zero_()
+                stats[0] = res[0]
+                self.comm.all_reduce_sum(stats)
+                return float(stats.cpu()[0])
             self._forward_device(y)
             stats = self._buffers()[2]
             e.shard_logpdf(stats)
@@ -254,6 +317,10 @@ class ShardedLGSSM:
         st = e.stream()
         st.wait_stream(torch.cuda.current_stream(st.device))
         with torch.cuda.stream(st):
+            res = self._steady_device(y, R_new, True)
+            if res is not None:
+                e.last_segment_lml = res[0]
+                return res[1], res[2]
             yy = self._forward_device(y)
             slot, gath, _ = self._buffers()
             e.shard_smoother_forward(slot[1])
@@ -328,8 +395,16 @@ class ShardedLGSSM:
         if self.world == 1 and self.engine is None:
             return L.logpdf_and_posterior_marginals(self.model, y, R_new, out=out)
         if self._device_resident():
+            import torch
             mean, var = self._posterior_marginals_device(y, R_new)
-            return self._all_reduce_sum(self.engine.last_segment_lml), mean, var
+            st = self.engine.stream()
+            with torch.cuda.stream(st):          # the W shares of the log marginal likelihood: one more 4-double collective on the same transport
+                stats = self._buffers()[2]
+                stats.zero_()
+                stats[0] = self.engine.last_segment_lml
+                self.comm.all_reduce_sum(stats)
+                total = float(stats.cpu()[0])
+            return total, mean, var
         # host transport (gloo groups, test engines): the two calls, sharing nothing
         return (self.logpdf(y),) + tuple(self.posterior_marginals(y, R_new))
 

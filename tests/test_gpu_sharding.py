@@ -176,3 +176,63 @@ def test_device_resident_exchange_threads(world, layout, d_kernel):
         mean[lo:hi], var[lo:hi] = m, v
     assert np.max(np.abs(mean - pm)) <= 1e-8
     assert np.max(np.abs(var - pv)) <= 1e-8
+
+
+@pytest.mark.parametrize("world,d_kernel", [(2, "matern52"), (4, "matern32"), (3, "sum52_52")])
+def test_device_resident_exchange_threads_on_the_stationary_gain_engine(world, d_kernel):
+    """The one-process-per-GPU driver (parallel.ShardedLGSSM) with an LTI series and no missing data: the shards run the stationary-gain
+    engine's two-half calls (tgp_shard_steady_begin / _finish, ONE all-gather) -- checked through the kernels' names -- and a second
+    case whose segments are too short for it agrees, through the gathered elements, to take the general protocol."""
+    import threading
+
+    import torch
+    import temporalgps_jl_amd as tgp
+    from temporalgps_jl_amd import _lib, lti_sde, parallel
+    kern = {"matern52": lti_sde.Matern52Kernel(), "matern32": lti_sde.Matern32Kernel(),
+            "sum52_52": lti_sde.Matern52Kernel() + 0.5 * lti_sde.Matern52Kernel().stretch(0.3)}[d_kernel]
+    spec = {"matern52": ("matern52",), "matern32": ("matern32",),
+            "sum52_52": ("sum", ("matern52",), ("scaled", 0.5, ("stretched", 0.3, ("matern52",))))}[d_kernel]
+    lib = _lib.load()
+    for T, expect_steady in ((150_001, True), (6_000, False)):
+        rng = np.random.default_rng(9)
+        y_all = rng.standard_normal(T)
+        ref_model = oc.build_lgssm(spec, ("regular", 0.0, 0.1, T), 0.1)
+        d = ref_model["A"].shape[-1]
+        lp_ref = sk.logpdf(ref_model, y_all)
+        pm, pv = sk.posterior_marginals(ref_model, y_all, np.array([0.05]))
+        shared, barrier, out, errs = {}, threading.Barrier(world), {}, []
+
+        def run(rank):
+            try:
+                torch.cuda.set_device(0)
+                lo, hi = parallel.segment_bounds(T, world, rank)
+                model = lti_sde.build_lgssm(kern, lti_sde.RegularSpacing(0.1 * lo, 0.1, hi - lo), 0.1)
+                sh = parallel.ShardedLGSSM(model, world, rank, engine=parallel.HIPEngine(model), comm=_ThreadComm(world, rank, shared, barrier))
+                hd = model.handle()
+                hd.set_option(tgp._lib.OPT_PROFILE, 1)
+                y = torch.as_tensor(y_all[lo:hi], device="cuda:0")
+                lp = sh.logpdf(y)
+                lp3, mean, var = sh.logpdf_and_posterior_marginals(y, np.array([0.05]))
+                out[rank] = (lp, lp3, lo, hi, mean.cpu().numpy(), var.cpu().numpy(), set(hd.profile()))
+            except Exception as ex:          # noqa: BLE001
+                errs.append(ex)
+                barrier.abort()
+        for n in (lib.tgp_shard_slot_size(0, d), lib.tgp_shard_slot_size(1, d), lib.tgp_shard_steady_slot_size(d)):
+            shared[("g", n)] = torch.zeros(world * n, dtype=torch.float64, device="cuda:0")
+        shared[("r", 4)] = torch.zeros(world, 4, dtype=torch.float64, device="cuda:0")
+        shared[("r", 1)] = torch.zeros(world, 1, dtype=torch.float64, device="cuda:0")
+        th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        assert not errs, errs
+        mean, var = np.zeros(T), np.zeros(T)
+        for r in range(world):
+            lp, lp3, lo, hi, m, v, names = out[r]
+            assert abs(lp - lp_ref) <= 1e-10 * abs(lp_ref) and abs(lp3 - lp_ref) <= 1e-10 * abs(lp_ref)
+            general = any(n.startswith("k_reduce_filter") for n in names)
+            if expect_steady:
+                assert "k_steady_shard_fold" in names and not general, (T, r, names)
+            else:            # (the first call tried the engine -- its kernels are in the profile -- and every rank fell back together)
+                assert general, (T, r, names)
+            mean[lo:hi], var[lo:hi] = m, v
+        assert np.max(np.abs(mean - pm)) <= 1e-8 and np.max(np.abs(var - pv)) <= 1e-8

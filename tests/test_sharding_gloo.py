@@ -114,4 +114,13 @@ def test_segment_bounds_cover_and_balance():
         assert segs[0][0] == 0 and segs[-1][1] == T
         assert all(segs[i][1] == segs[i + 1][0] for i in range(W - 1))
         sizes = [b - a for a, b in segs]
-        assert max(sizes) - min(sizes) <= 1
+        # balanced to one step for short series; long ones put interior boundaries on multiples of 512 steps (whole tiles of the
+        # stationary-gain engine for every segment that hands its end state on)
+        if T // W >= 8 * 512:
+            assert all(a % 512 == 0 for a, _ in segs) and max(sizes) - min(sizes) <= 2 * 512
+        else:
+            assert max(sizes) - min(sizes) <= 1
+    # the in-library handle splits the same way (tgp_multi_segment)
+    from temporalgps_jl_amd import multi
+    for T, W in [(10, 3), (10_000_000, 8), (100_000_001, 8), (9000, 3)]:
+        assert [multi.segment_bounds(T, W, r) for r in range(W)] == [parallel.segment_bounds(T, W, r) for r in range(W)]
