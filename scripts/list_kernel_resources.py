@@ -44,7 +44,7 @@ def kernels(blob):
         g = lambda key: re.search(rf"\.{key}:\s*(\S+)", blk)
         name = g("name").group(1)
         dem = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip()
-        out.append(dict(name=dem.split("(")[0], agpr=int(blk.split()[0]), vgpr=int(g("vgpr_count").group(1)), vspill=int(g("vgpr_spill_count").group(1)),
+        out.append(dict(name=dem.replace("(anonymous namespace)::", "").split("(")[0], agpr=int(blk.split()[0]), vgpr=int(g("vgpr_count").group(1)), vspill=int(g("vgpr_spill_count").group(1)),
                         sspill=int(g("sgpr_spill_count").group(1)), scratch=int(g("private_segment_fixed_size").group(1))))
     return out
 

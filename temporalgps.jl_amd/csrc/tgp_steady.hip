@@ -13,6 +13,7 @@ namespace {
 
 constexpr double kLog2Pi = 1.8378770664093454835606594728112;
 constexpr double kTol = 4.5e-16;   // "no longer changes": 2 ulp relative to the element's natural scale
+constexpr int kCovScanMaxD = 4;    // filter_cov_scan / filter_cov_reg (matrices in one lane's registers) up to here, filter_cov_lds beyond
 
 // ---- layout of the steady-coefficient block (doubles) ---------------------------------------------------------------------------
 template <int D>
@@ -326,6 +327,391 @@ __device__ __forceinline__ int filter_cov_reg(const ModelDev& m, const Tab& tb, 
     return n0;
 }
 
+// ---- phase (a) + (b), d <= 4, time-parallel: the filtered covariances of 64 consecutive steps at once --------------------------------
+// The covariance recursion of an LTI model applies the SAME Riccati map at every step, and t-fold compositions of it are the
+// covariance parts (A, C, J) of the filter scan's element E^t (Sarkka & Garcia-Fernandez 2021; the general engine's FilterMonoid):
+//     P_t = A_t (I + P_in J_t)^-1 P_in A_t' + C_t.
+// One wave forms E^1 .. E^64 by a Hillis-Steele scan over its lanes (six combines per lane instead of 63 dependent steps); lane l
+// applies E^(l+1) to the covariance the block starts from and owns step 64 b + l: its predicted covariance, innovation variance, gains
+// and reverse-time dynamics. The block that contains the first step whose filtered covariance has stopped moving to ~1e-14 hands over to
+// the sequential recursion, which runs the last few steps to the exact fixed point (the criterion of filter_cov_reg, 2 ulp): the head is
+// the same sequence of covariances to rounding, n0 the same kind of index, and only ~10 of its ~60 steps are sequential.
+template <int D>
+struct CovElem {
+    double A[D][D], C[D][D], J[D][D];
+};
+template <int D>
+__device__ __forceinline__ void ce_inverse(double (&M)[D][D], double (&X)[D][D]) {      // X = M^-1 (partial pivoting by selects); M destroyed
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = 0; j < D; ++j) X[i][j] = (i == j) ? 1.0 : 0.0;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        int piv = k;
+        double best = fabs(M[k][k]);
+#pragma unroll
+        for (int i = k + 1; i < D; ++i) {
+            const double v = fabs(M[i][k]);
+            const bool gt = v > best;
+            best = gt ? v : best;
+            piv = gt ? i : piv;
+        }
+#pragma unroll
+        for (int i = k + 1; i < D; ++i) {
+            const bool sw = piv == i;
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                const double t = M[k][j], u = M[i][j], t2 = X[k][j], u2 = X[i][j];
+                M[k][j] = sw ? u : t;
+                M[i][j] = sw ? t : u;
+                X[k][j] = sw ? u2 : t2;
+                X[i][j] = sw ? t2 : u2;
+            }
+        }
+        const double inv = 1.0 / M[k][k];
+#pragma unroll
+        for (int i = k + 1; i < D; ++i) {
+            const double f = M[i][k] * inv;
+#pragma unroll
+            for (int j = k + 1; j < D; ++j) M[i][j] = fma(-f, M[k][j], M[i][j]);
+#pragma unroll
+            for (int j = 0; j < D; ++j) X[i][j] = fma(-f, X[k][j], X[i][j]);
+        }
+    }
+#pragma unroll
+    for (int k = D - 1; k >= 0; --k) {
+        const double inv = 1.0 / M[k][k];
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            double acc = X[k][j];
+#pragma unroll
+            for (int i = k + 1; i < D; ++i) acc = fma(-M[k][i], X[i][j], acc);
+            X[k][j] = acc * inv;
+        }
+    }
+}
+template <int D, bool TX, bool TY>
+__device__ __forceinline__ void ce_mul(const double (&X)[D][D], const double (&Y)[D][D], double (&Z)[D][D]) {      // Z = op(X) op(Y)
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            double v = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) v = fma(TX ? X[k][i] : X[i][k], TY ? Y[j][k] : Y[k][j], v);
+            Z[i][j] = v;
+        }
+}
+template <int D>
+__device__ __forceinline__ void ce_sym(double (&P)[D][D]) {
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = i + 1; j < D; ++j) {
+            const double v = 0.5 * (P[i][j] + P[j][i]);
+            P[i][j] = P[j][i] = v;
+        }
+}
+// out = later o earlier
+template <int D>
+__device__ __forceinline__ void ce_combine(const CovElem<D>& ei, const CovElem<D>& ej, CovElem<D>& out) {
+    double M[D][D], Mi[D][D], T1[D][D], T2[D][D], JA[D][D], MJA[D][D];
+    ce_mul<D, false, false>(ei.C, ej.J, M);
+#pragma unroll
+    for (int i = 0; i < D; ++i) M[i][i] += 1.0;
+    ce_inverse<D>(M, Mi);                                 // (I + C_i J_j)^-1
+    ce_mul<D, false, false>(ej.A, Mi, T1);                // A_j M
+    ce_mul<D, false, false>(ej.J, ei.A, JA);              // J_j A_i
+    ce_mul<D, true, false>(Mi, JA, MJA);                  // M' J_j A_i
+    double nA[D][D], nC[D][D], nJ[D][D];
+    ce_mul<D, true, false>(ei.A, MJA, nJ);                // A_i' M' J_j A_i
+    ce_mul<D, false, false>(T1, ei.A, nA);
+    ce_mul<D, false, false>(T1, ei.C, T2);
+    ce_mul<D, false, true>(T2, ej.A, nC);
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            out.A[i][j] = nA[i][j];
+            out.C[i][j] = nC[i][j] + ej.C[i][j];
+            out.J[i][j] = nJ[i][j] + ei.J[i][j];
+        }
+    ce_sym<D>(out.C);
+    ce_sym<D>(out.J);
+}
+template <int D>
+__device__ __forceinline__ void ce_apply(const CovElem<D>& e, const double (&P)[D][D], double (&out)[D][D]) {
+    double M[D][D], Mi[D][D], T1[D][D], T2[D][D];
+    ce_mul<D, false, false>(P, e.J, M);
+#pragma unroll
+    for (int i = 0; i < D; ++i) M[i][i] += 1.0;
+    ce_inverse<D>(M, Mi);
+    ce_mul<D, false, false>(e.A, Mi, T1);
+    ce_mul<D, false, false>(T1, P, T2);
+    ce_mul<D, false, true>(T2, e.A, out);
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = 0; j < D; ++j) out[i][j] += e.C[i][j];
+    ce_sym<D>(out);
+}
+
+template <int D>
+__device__ __forceinline__ int filter_cov_scan(const ModelDev& m, const Tab& tb, int lane, bool& bad, double (&Pss)[D][D], double (&kAss)[D],
+                                               double& Sss, double& LS) {
+    constexpr int DD = D * D;
+    constexpr int nhmax = kHeadMaxTiles * kTile;
+    constexpr double kTolScan = 256.0 * kTol, kTolFine = 16.0 * kTol;
+    double A[D][D], Q[D][D], hv[D], P[D][D], Pold2[D][D], cPf[D][D], cPp[D][D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        hv[i] = m.H[i];
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            A[i][k] = m.A[i + k * D];
+            const int r = i < k ? i : k, c = i < k ? k : i;
+            Q[i][k] = m.Q[r + c * D];                        // Symmetric(Q), Symmetric(x0P): upper triangles
+            P[i][k] = m.x0[D + c * (c + 1) / 2 + r];
+            Pold2[i][k] = 0.0;
+            cPf[i][k] = cPp[i][k] = 0.0;
+        }
+    }
+    const double R = m.R[0];
+    auto gains = [&](int t) {        // reverse-time dynamics and smoother gain of the step this lane has kept
+        double G[D][D], L[D][D];
+        const bool ok = invert_dynamics_lane<D>(m.A, cPf, cPp, G, L);
+        if (!ok) tb.hdr[4] = 1;
+        double K[D], Sv = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            double v = 0.0;
+#pragma unroll
+            for (int l = 0; l < D; ++l) v = fma(hv[l], cPp[l][k], v);
+            K[k] = v;
+            Sv = fma(v, hv[k], Sv);
+        }
+        Sv += R;
+        const double iSv = 1.0 / Sv;
+#pragma unroll
+        for (int r = 0; r < D; ++r) {
+            double v = 0.0;
+#pragma unroll
+            for (int c = 0; c < D; ++c) {
+                v = fma(G[r][c], K[c] * iSv, v);
+                if (t < nhmax) tb.h_G[(size_t)t * DD + r * D + c] = G[r][c];
+                tb.s_L[(size_t)t * DD + r * D + c] = L[r][c];
+            }
+            if (t < nhmax) tb.h_c[t * D + r] = v;
+        }
+    };
+    // one step from the filtered covariance Pin: predicted covariance, V = Pp h, S
+    auto one_step = [&](const double (&Pin)[D][D], double (&pp)[D][D], double (&V)[D], double& S) {
+        double t1[D][D];
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                double v = 0.0;
+#pragma unroll
+                for (int k = 0; k < D; ++k) v = fma(A[i][k], (k <= j ? Pin[k][j] : Pin[j][k]), v);       // A * Symmetric(P)
+                t1[i][j] = v;
+            }
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                double v = 0.0;
+#pragma unroll
+                for (int k = 0; k < D; ++k) v = fma(t1[i][k], A[j][k], v);
+                pp[i][j] = v + Q[i][j];
+            }
+        S = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            double v = 0.0;
+#pragma unroll
+            for (int l = 0; l < D; ++l) v = fma(hv[l], pp[l][k], v);
+            V[k] = v;
+            S = fma(v, hv[k], S);
+        }
+        S += R;
+    };
+    // ---- the one-step element and its powers E^(lane + 1)
+    CovElem<D> pre;
+    {
+        double Qh[D], S1 = R;
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            double v = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) v = fma(Q[i][k], hv[k], v);
+            Qh[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < D; ++i) S1 = fma(hv[i], Qh[i], S1);
+        bad = bad || !(S1 > 0.0);
+        const double iS1 = 1.0 / S1;
+        double Ath[D];                       // A' h
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            double v = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) v = fma(A[k][i], hv[k], v);
+            Ath[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                // (I - K h') X = X - K (h' X),  K = Q h / S1
+                pre.A[i][j] = fma(-Qh[i] * iS1, Ath[j], A[i][j]);
+                pre.C[i][j] = fma(-Qh[i] * iS1, Qh[j], Q[i][j]);
+                pre.J[i][j] = Ath[i] * Ath[j] * iS1;
+            }
+    }
+#pragma unroll 1
+    for (int k = 0; k < 6; ++k) {
+        const int off = 1 << k;
+        CovElem<D> other, res;
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                other.A[i][j] = __shfl_up(pre.A[i][j], off);
+                other.C[i][j] = __shfl_up(pre.C[i][j], off);
+                other.J[i][j] = __shfl_up(pre.J[i][j], off);
+            }
+        ce_combine<D>(other, pre, res);      // (every lane computes; lanes below `off` keep their own)
+        if (lane >= off) pre = res;
+    }
+    // ---- blocks of 64 steps until the covariance has (nearly) stopped moving
+    int tstar = -1;
+    LS = 0.0;
+#pragma unroll 1
+    for (int b = 0; b * 64 < nhmax; ++b) {
+        const int t = b * 64 + lane;
+        double Pf[D][D], Pprev[D][D], pp[D][D], V[D], S;
+        ce_apply<D>(pre, P, Pf);                                   // filtered covariance behind step t
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                const double up = __shfl_up(Pf[i][j], 1);
+                Pprev[i][j] = lane == 0 ? P[i][j] : up;             // ... and in front of it
+            }
+        one_step(Pprev, pp, V, S);
+        const bool okS = S > 0.0;
+        bool moved = false, moved_fine = false;
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                const double dlt = fabs(Pf[i][j] - Pprev[i][j]), sc = 0.5 * (pp[i][i] + pp[j][j]);
+                moved = moved || !(dlt <= kTolScan * sc);
+                moved_fine = moved_fine || !(dlt <= kTolFine * sc);
+                cPf[i][j] = Pprev[i][j];
+                cPp[i][j] = pp[i][j];
+            }
+        bad = bad || __any(!okS);
+        // the first step of the block that no longer moves at the fine tolerance (few sequential steps are left from there); if the
+        // block's values only agree to the coarse one -- rounding of the composed elements -- its last step (the most converged one)
+        const unsigned long long still_fine = __ballot(!moved_fine), still = __ballot(!moved);
+        const int lstar = still_fine ? __ffsll((long long)still_fine) - 1 : (still ? 63 : 64);
+        const double iS = 1.0 / S;
+        if (lane <= lstar && lane < 64) {
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                double v = 0.0;
+#pragma unroll
+                for (int k = 0; k < D; ++k) v = fma(A[i][k], V[k] * iS, v);
+                tb.h_kA[t * D + i] = v;
+            }
+            tb.h_rS[t] = R * iS;
+            tb.h_iS[t] = iS;
+        }
+        double ls = (lane <= lstar) ? log(S) : 0.0;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) ls += __shfl_xor(ls, off);
+        LS += ls;
+        if (lstar < 64) {
+            tstar = b * 64 + lstar;
+            if (lstar == 63) gains(t);                              // (the block is complete: the sequential steps start in the next one)
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int j = 0; j < D; ++j) P[i][j] = __shfl(Pf[i][j], lstar);
+            break;
+        }
+        gains(t);                                                   // the block is complete
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = 0; j < D; ++j) P[i][j] = __shfl(Pf[i][j], 63);
+    }
+    if (tstar < 0 || bad) return -1;
+    // ---- the last steps to the exact fixed point, sequentially (every lane the same arithmetic; lane t & 63 keeps step t)
+    int tc = -1, n0 = -1, done = 0;
+    double prod = 1.0;
+#pragma unroll 1
+    for (int t = tstar + 1; t <= nhmax; ++t) {
+        double pp[D][D], V[D], S;
+        one_step(P, pp, V, S);
+        bad = bad || !(S > 0.0);
+        const double iS = 1.0 / S, rs = 1.0 / sqrt(S);
+        const bool mine = (t & 63) == lane;
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            double v = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) v = fma(A[i][k], V[k] * iS, v);
+            kAss[i] = v;
+            if (mine && t < nhmax) tb.h_kA[t * D + i] = v;
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                cPf[i][j] = mine ? P[i][j] : cPf[i][j];
+                cPp[i][j] = mine ? pp[i][j] : cPp[i][j];
+            }
+        }
+        if (mine && t < nhmax) {
+            tb.h_rS[t] = R * iS;
+            tb.h_iS[t] = iS;
+        }
+        Sss = S;
+        if (tc >= 0) {           // the extra iteration from the settled covariance: the stationary step
+            n0 = t;
+            break;
+        }
+        if (t == nhmax) break;
+        prod *= S;
+        if ((done & 3) == 3) {
+            LS += log(prod);
+            prod = 1.0;
+        }
+        bool moved = false, cyc = done >= 1;
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                const double Pn = pp[i][j] - (V[i] * rs) * (V[j] * rs);
+                moved = moved || fabs(Pn - P[i][j]) > kTol * 0.5 * (pp[i][i] + pp[j][j]);
+                cyc = cyc && (Pn == Pold2[i][j]);
+                Pold2[i][j] = P[i][j];
+                P[i][j] = Pn;
+            }
+        if ((t & 63) == 63) gains(t - 63 + lane);
+        if (!moved || cyc) tc = t;
+        ++done;
+    }
+    LS += log(prod);
+    if (n0 >= 0 && (n0 & ~63) + lane <= n0) gains((n0 & ~63) + lane);
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = 0; j < D; ++j) Pss[i][j] = P[i][j];
+    return n0;
+}
+
 // ---- phase (a) + (b), d >= 4: lane (i, j) owns element (i, j) of every matrix, LDS is the exchange (a d x d product costs a lane d
 // multiply-adds instead of d^3); the steps' (Pf, Pp) go to scratch and the gains are computed afterwards, one step per lane.
 template <int D>
@@ -487,9 +873,16 @@ __global__ __launch_bounds__(64) void k_setup_core(ModelDev m, Tab tb, const dou
     bool bad = false;
     double kAss[D], Sss = 1.0, LS = 0.0;
     int n0;
-    if constexpr (D <= 3) {
+    const bool scan_cov = (shard & 4) == 0;      // (bit 2 of the mode word: the sequential covariance iteration, for A/B runs)
+    if (D <= kCovScanMaxD && (scan_cov || D <= 3)) {
         double Pss[D][D];
-        n0 = filter_cov_reg<D>(m, tb, lane, bad, Pss, kAss, Sss, LS);
+        if constexpr (D <= kCovScanMaxD) {
+            if (scan_cov) n0 = filter_cov_scan<D>(m, tb, lane, bad, Pss, kAss, Sss, LS);
+            else if constexpr (D <= 3) n0 = filter_cov_reg<D>(m, tb, lane, bad, Pss, kAss, Sss, LS);
+            else n0 = -1;
+        } else {
+            n0 = -1;
+        }
         if (act) {      // the stationary filtered covariance, for k_setup_side
             double v = 0.0;
 #pragma unroll
@@ -509,6 +902,7 @@ __global__ __launch_bounds__(64) void k_setup_core(ModelDev m, Tab tb, const dou
     // mean comes from the exchange. One that does not end it (shard & 2) hands its end state on: that needs whole tiles, and the whole
     // run of stationary steps as ONE element (Phi^L, G^L, B_L below: L < 2^kPowN).
     const bool notfirst = (shard & 1) != 0, notlast = (shard & 2) != 0;
+    shard &= 3;
     const int th = settled ? (notfirst ? 0 : n0 / kTile + 1) : 0;
     const int nh = th * kTile;
     const long long Lseg = T - nh;
@@ -2009,6 +2403,13 @@ struct Engine {
     Tab tb{};
 };
 
+static int cov_mode_bits() {      // TGP_STEADY_COV=seq: the sequential covariance iteration in k_setup_core (default: the time-parallel one, d <= 4)
+    static const int bits = [] {
+        const char* v = std::getenv("TGP_STEADY_COV");
+        return (v && std::strcmp(v, "seq") == 0) ? 4 : 0;
+    }();
+    return bits;
+}
 Engine* create() { return new Engine(); }
 void destroy(Engine* e) {
     if (!e) return;
@@ -2086,7 +2487,7 @@ int enqueue_d(Engine* e, hipStream_t st, const ModelDev& m, const CallDev& c, co
         if (blocks == 0) return (int)hipErrorInvalidValue;      // (the caller sends series of one tile to the general path)
         const int flags = (sh->first ? 0 : 1) | (sh->last ? 0 : 2);
         if (phase == 0) {
-            { Scope s(hk, "k_steady_setup"); hipLaunchKernelGGL(k_setup_core<D>, dim3(1), dim3(64), 0, st, m, tb, c.y, T, 0, flags); }
+            { Scope s(hk, "k_steady_setup"); hipLaunchKernelGGL(k_setup_core<D>, dim3(1), dim3(64), 0, st, m, tb, c.y, T, 0, flags | cov_mode_bits()); }
             if (post) {
                 { Scope s(hk, "k_steady_reduce<posterior>"); hipLaunchKernelGGL((k_reduce<D, true>), dim3(blocks + 1), dim3(kBlkThreads), 0, st, tb.hdr, tb.cst, c.y, tb.F, tb.B0, tb.Fb, tb.B0b, T, ntiles, m, tb, 1); }
                 { Scope s(hk, "k_steady_carry<segment>"); hipLaunchKernelGGL((k_carry<D, true>), dim3(1), dim3(512), 0, st, tb.hdr, tb.cst, tb.Fb, tb.B0b, tb.MUb, tb.LAMb, ntiles, 0); }
@@ -2111,7 +2512,7 @@ int enqueue_d(Engine* e, hipStream_t st, const ModelDev& m, const CallDev& c, co
     }
     {
         Scope s(hk, "k_steady_setup");
-        hipLaunchKernelGGL(k_setup_core<D>, dim3(1), dim3(64), 0, st, m, tb, c.y, T, c.grad ? 1 : 0, 0);
+        hipLaunchKernelGGL(k_setup_core<D>, dim3(1), dim3(64), 0, st, m, tb, c.y, T, c.grad ? 1 : 0, cov_mode_bits());
     }
     if (blocks == 0) {      // a series of one tile: the engine does not apply (k_setup_core: nh + 2 > T)
         Scope s(hk, "k_steady_final");
