@@ -182,6 +182,12 @@ __device__ bool invert_dynamics_lane(const double* __restrict__ A /*col-major*/,
 // LDS exchange inside ONE wave: DS instructions of a wave execute in order, so a write is visible to the reads that follow it in
 // program order; all that is needed is that the compiler keeps that order (no s_barrier, and -- unlike __syncthreads -- no wait for the
 // global stores that are in flight: the tables are written fire-and-forget from inside the sequential loops).
+// one wave talking to itself through GLOBAL memory as well (what a single-wave workgroup used __syncthreads for)
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
 __device__ __forceinline__ void lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -857,10 +863,22 @@ __device__ void head_forward(const Tab& tb, const double* __restrict__ y, long l
 // k_setup_core: what the tile passes wait for -- the filter covariance to its stationary value with the head's per-step gains (a, b),
 // the constant block with the powers and couplings (e), and the head's forward recursion (its carry starts the stationary tiles).
 template <int D>
-__global__ __launch_bounds__(64) void k_setup_core(ModelDev m, Tab tb, const double* __restrict__ y, long long T, int grad, int shard) {
+__device__ void setup_side_scan(const ModelDev& m, const Tab& tb, long long T);
+// (d <= kCovScanMaxD: launched with TWO waves. Wave 1 waits at the one workgroup barrier for the head's covariances and gains and then
+//  builds the variance tables of a posterior call -- setup_side_scan -- beside wave 0's later phases; everything else in here is wave 0
+//  talking to itself, hence wave_sync, not __syncthreads.)
+template <int D>
+__global__ __launch_bounds__(128) void k_setup_core(ModelDev m, Tab tb, const double* __restrict__ y, long long T, int grad, int shard, int with_side) {
     constexpr int DD = D * D;
     constexpr int nhmax = kHeadMaxTiles * kTile;
     __shared__ double sP[DD], sT[DD], sPp[DD], sB[DD], sXa[DD], sGa[DD], sXb[DD], sGb[DD], sXc[DD], sGc[DD];
+    if (threadIdx.x >= 64) {
+        __syncthreads();
+        if constexpr (D <= kCovScanMaxD) {
+            if (with_side && tb.hdr[0] != 0 && (tb.hdr[6] & 4) == 0) setup_side_scan<D>(m, tb, T);
+        }
+        return;
+    }
     const int lane = threadIdx.x;
     const bool act = lane < DD;
     const int e = act ? lane : 0;
@@ -869,7 +887,7 @@ __global__ __launch_bounds__(64) void k_setup_core(ModelDev m, Tab tb, const dou
         tb.hdr[4] = 0;
         tb.misc[8] = (double)wall_clock64();
     }
-    __syncthreads();
+    wave_sync();
     bool bad = false;
     double kAss[D], Sss = 1.0, LS = 0.0;
     int n0;
@@ -895,7 +913,7 @@ __global__ __launch_bounds__(64) void k_setup_core(ModelDev m, Tab tb, const dou
         n0 = filter_cov_lds<D>(m, tb, lane, bad, sP, sT, sPp, kAss, Sss, LS);
     }
     __threadfence_block();
-    __syncthreads();
+    wave_sync();
     bad = bad || tb.hdr[4] != 0;
     const bool settled = n0 >= 0 && n0 < nhmax;      // the head tables hold nhmax steps: th <= kHeadMaxTiles
     // A time shard that does not start the series (shard & 1) has no head: every one of its steps is stationary, its first predicted
@@ -914,9 +932,11 @@ __global__ __launch_bounds__(64) void k_setup_core(ModelDev m, Tab tb, const dou
         tb.hdr[3] = -1;
         tb.hdr[4] = bad ? 1 : 0;
         tb.hdr[5] = n0;                                     // row of the tables that holds the stationary step
-        tb.hdr[6] = shard;
+        tb.hdr[6] = shard | (scan_cov ? 0 : 4);          // bits 0, 1: the shard's missing ends; bit 2: sequential covariance recursions (A/B)
         tb.misc[9] = (double)wall_clock64();
     }
+    __threadfence_block();
+    __syncthreads();          // the head's covariances and gains are in memory: wave 1 (if the launch has one) starts on the variance tables
     if (!settled || bad || !fits) return;
     // stationary coefficients (entry n0; the head recursions read the tables at min(t, n0))
     double* ss = tb.ssc;
@@ -953,7 +973,7 @@ __global__ __launch_bounds__(64) void k_setup_core(ModelDev m, Tab tb, const dou
         ss[SS<D>::LS] = notfirst ? 0.0 : LS;
     }
     __threadfence_block();
-    __syncthreads();
+    wave_sync();
     if (lane == 0) tb.misc[10] = (double)wall_clock64();
     // ---- (e) powers Phi^(2^k), G^(2^k); the couplings B_n = sum_{j < n} G^j c h' Phi^j by doubling, B_2n = B_n + G^n B_n Phi^n:
     //      B_512 (a tile), B_2048 (a workgroup), and the two ragged ones -- the last tile's nv valid steps and the last workgroup's nvb --
@@ -1033,7 +1053,7 @@ __global__ __launch_bounds__(64) void k_setup_core(ModelDev m, Tab tb, const dou
             lds_sync();
         }
         __threadfence_block();
-        __syncthreads();
+        wave_sync();
         if (act) {
             cst[CL<D>::Blt + e] = (nv == kTile) ? cst[CL<D>::B512 + e] : bl[0];
             cst[CL<D>::Blb + e] = (nvb == kBlk * kTile) ? cst[CL<D>::Bblk + e] : bl[1];
@@ -1041,6 +1061,14 @@ __global__ __launch_bounds__(64) void k_setup_core(ModelDev m, Tab tb, const dou
             cst[CL<D>::GSeg + e] = sGc[e];
             cst[CL<D>::BSeg + e] = bl[2];
             cst[CL<D>::GLb + e] = (nvb == kBlk * kTile) ? cst[CL<D>::pg + kLogBlk * DD + e] : sGb[e];
+        }
+        {
+            // Short memory: when Phi^4096 and G^4096 (a whole workgroup's steps) have decayed to nothing, a workgroup's carries depend on
+            // its neighbours' elements only and k_carry needs no scan (hdr[7]; every well-mixing model: 0.99^4096 = 1e-18, 0.98^4096 = 1e-36).
+            const double px = act ? fabs(cst[CL<D>::pphi + kLogBlk * DD + e]) : 0.0, gx = act ? fabs(cst[CL<D>::pg + kLogBlk * DD + e]) : 0.0;
+            const bool tiny = !(px > 1e-30) && !(gx > 1e-30);
+            const bool all_tiny = !__any(!tiny);
+            if (lane == 0) tb.hdr[7] = all_tiny ? 1 : 0;
         }
         // (e2) tile carries inside a workgroup in closed form (k_apply): PT[w] = Phi^(512 w), GT[w] = G^(512 w), and the coupling of the
         //      workgroup's mu into the lam behind tile w, K_w = G^512 K_{w+1} + B_512 PT[w+1], K_{kBlk-1} = 0
@@ -1095,7 +1123,7 @@ __global__ __launch_bounds__(64) void k_setup_core(ModelDev m, Tab tb, const dou
         }
     }
     __threadfence_block();
-    __syncthreads();
+    wave_sync();
     if (lane == 0) tb.misc[11] = (double)wall_clock64();
     if (notfirst) {      // no head: a zero carry-in until the exchange supplies the real one (k_shard_fold)
         if (lane == 0) {
@@ -1224,6 +1252,170 @@ __device__ void setup_side(const ModelDev& m, const Tab& tb, long long T) {
     if (lane == 0) tb.ssc[SS<D>::vb] = vb_ss;
     for (int t = lane; t < n1; t += 64) tb.t_vb[t] = quad(&tb.t_Ps[(size_t)t * DD]);
     for (int t = lane; t <= n0; t += 64) tb.h_vb[t] = quad(&tb.s_Ps[(size_t)t * DD]);
+    if (lane == 0) tb.misc[15] = (double)wall_clock64();
+}
+
+// setup_side for d <= kCovScanMaxD, time-parallel: both covariance recursions of the smoother are LINEAR in the covariance,
+//     Ps_{t-1} = G_t Ps_t G_t' + L_t,
+// so a run of steps composes to one (M, S) pair -- Ps_out = M Ps_in M' + S, later o earlier = (M_l M_e, M_l S_e M_l' + S_l) -- and a
+// wave forms the 64 prefix compositions of a block by a Hillis-Steele scan over its lanes. The tail uses the stationary (G, L) in every
+// lane, the head each step's own (G_t, L_t) from the tables; lane l then evaluates its own step's variance H Ps H'.
+template <int D>
+struct AffCov {
+    double M[D][D], S[D][D];
+};
+template <int D>
+__device__ __forceinline__ void ac_combine(const AffCov<D>& e, const AffCov<D>& l, AffCov<D>& out) {      // out = l o e
+    double T1[D][D], T2[D][D];
+    ce_mul<D, false, false>(l.M, e.M, out.M);
+    ce_mul<D, false, false>(l.M, e.S, T1);
+    ce_mul<D, false, true>(T1, l.M, T2);
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = 0; j < D; ++j) out.S[i][j] = T2[i][j] + l.S[i][j];
+    ce_sym<D>(out.S);
+}
+template <int D>
+__device__ __forceinline__ void ac_apply(const AffCov<D>& e, const double (&P)[D][D], double (&out)[D][D]) {
+    double T1[D][D];
+    ce_mul<D, false, false>(e.M, P, T1);
+    ce_mul<D, false, true>(T1, e.M, out);
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = 0; j < D; ++j) out[i][j] += e.S[i][j];
+    ce_sym<D>(out);
+}
+template <int D>
+__device__ __forceinline__ void ac_scan(AffCov<D>& pre, int lane) {      // inclusive, lane order = order of application
+#pragma unroll 1
+    for (int k = 0; k < 6; ++k) {
+        const int off = 1 << k;
+        AffCov<D> other, res;
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                other.M[i][j] = __shfl_up(pre.M[i][j], off);
+                other.S[i][j] = __shfl_up(pre.S[i][j], off);
+            }
+        ac_combine<D>(other, pre, res);
+        if (lane >= off) pre = res;
+    }
+}
+
+template <int D>
+__device__ void setup_side_scan(const ModelDev& m, const Tab& tb, long long T) {
+    constexpr int DD = D * D;
+    constexpr double kTolFine = 16.0 * kTol, kTolCoarse = 256.0 * kTol;
+    const int lane = threadIdx.x & 63;
+    const int th = (int)tb.hdr[1], n0 = (int)tb.hdr[5];
+    const bool notfirst = (tb.hdr[6] & 1) != 0, notlast = (tb.hdr[6] & 2) != 0;
+    const int nh = th * kTile;
+    double hv[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) hv[k] = m.H[k];
+    if (lane == 0) tb.misc[13] = (double)wall_clock64();
+    auto quad = [&](const double (&Pm)[D][D]) {     // H Symmetric(P) H'
+        double s = 0.0;
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+            double v = 0.0;
+#pragma unroll
+            for (int r = 0; r < D; ++r) v = fma(hv[r], (r <= c ? Pm[r][c] : Pm[c][r]), v);
+            s = fma(v, hv[c], s);
+        }
+        return s;
+    };
+    // ---- (c) the tail: Ps behind the last step is the stationary filtered covariance; backwards with the stationary (G, L)
+    double base[D][D];
+    AffCov<D> pre;
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            const int r = i < j ? i : j, c = i < j ? j : i;
+            base[i][j] = tb.s_Pf[(size_t)n0 * DD + r * D + c];
+            pre.M[i][j] = tb.h_G[(size_t)n0 * DD + i * D + j];      // (the stationary gain: the constant block is still being written)
+            pre.S[i][j] = tb.s_L[(size_t)n0 * DD + r * D + c];
+        }
+    ac_scan<D>(pre, lane);                  // lane j: (G^(j+1), sum_{i <= j} G^i L G^i')
+    if (lane == 0) tb.t_vb[0] = quad(base);
+    int n1 = -1;
+    double Pinf[D][D];
+#pragma unroll 1
+    for (int b = 0; b * 64 < kTailMax; ++b) {
+        double Ps[D][D], prev[D][D];
+        ac_apply<D>(pre, base, Ps);                                 // Ps at distance 64 b + lane + 1 from the end
+        bool moved = false, moved_fine = false;
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                const double up = __shfl_up(Ps[i][j], 1);
+                prev[i][j] = lane == 0 ? base[i][j] : up;
+            }
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                const double dlt = fabs(Ps[i][j] - prev[i][j]), sc = 0.5 * (fabs(prev[i][i]) + fabs(prev[j][j]));
+                moved = moved || !(dlt <= kTolCoarse * sc);
+                moved_fine = moved_fine || !(dlt <= kTolFine * sc);
+            }
+        const unsigned long long still_fine = __ballot(!moved_fine), still = __ballot(!moved);
+        const int lstar = still_fine ? __ffsll((long long)still_fine) - 1 : (still ? 63 : 64);
+        const int k = b * 64 + lane + 1;
+        if (k < kTailMax && lane <= lstar) tb.t_vb[k] = quad(Ps);
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = 0; j < D; ++j) base[i][j] = __shfl(Ps[i][j], 63);       // next block's start; the most converged value of this one
+        if (lstar < 64) {
+            n1 = b * 64 + lstar + 1;
+            break;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = 0; j < D; ++j) Pinf[i][j] = base[i][j];
+    const bool applies = n1 >= 0 && n1 < kTailMax && (long long)nh + (notlast ? 0 : n1) + 1 <= T;
+    if (lane == 0) {
+        tb.hdr[3] = notlast ? 0 : n1;
+        if (!applies) tb.hdr[0] = 0;
+    }
+    if (!applies) return;
+    if (lane == 0) tb.misc[14] = (double)wall_clock64();
+    const double vb_ss = quad(Pinf);
+    if (lane == 0) {
+        tb.ssc[SS<D>::vb] = vb_ss;
+        tb.h_vb[n0] = vb_ss;
+    }
+    // ---- (d) the head: from Ps_{n0} = stationary backwards through the steps' own (G_t, L_t); lane l of a block holds step hi - l
+    if (!notfirst) {
+#pragma unroll 1
+        for (int hi = n0; hi >= 1; hi -= 64) {
+            const int t = hi - lane;
+            AffCov<D> el;
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int j = 0; j < D; ++j) {
+                    el.M[i][j] = t >= 1 ? tb.h_G[(size_t)t * DD + i * D + j] : (i == j ? 1.0 : 0.0);
+                    el.S[i][j] = t >= 1 ? tb.s_L[(size_t)t * DD + (i < j ? i : j) * D + (i < j ? j : i)] : 0.0;
+                }
+            ac_scan<D>(el, lane);
+            double Ps[D][D];
+            ac_apply<D>(el, Pinf, Ps);                              // Ps_{t-1}
+            if (t >= 1) tb.h_vb[t - 1] = quad(Ps);
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int j = 0; j < D; ++j) Pinf[i][j] = __shfl(Ps[i][j], 63);
+        }
+    }
     if (lane == 0) tb.misc[15] = (double)wall_clock64();
 }
 
@@ -1740,7 +1932,8 @@ __global__ __launch_bounds__(kBlkThreads) void k_reduce(const long long* __restr
                                                 double* __restrict__ B0b, long long T, long long ntiles, ModelDev m, Tab tb, int side) {
     if (hdr[0] == 0) return;
     if (POST && blockIdx.x == 0) {      // the extra workgroup (dispatched first): variance tables for pass 2 (not for adjoint calls)
-        if (side && threadIdx.x < 64) setup_side<D>(m, tb, T);
+        // (d <= kCovScanMaxD: the tables were built by the set-up kernel's second wave, unless the sequential recursions were asked for)
+        if (side && threadIdx.x < 64 && (D > kCovScanMaxD || (tb.hdr[6] & 4) != 0)) setup_side<D>(m, tb, T);
         return;
     }
     const long long wg = (long long)blockIdx.x - (POST ? 1 : 0);
@@ -1816,6 +2009,43 @@ __global__ __launch_bounds__(512) void k_carry(const long long* __restrict__ hdr
     if (hdr[0] == 0) return;
     constexpr int DD = D * D;
     constexpr int kLanes = 512, kRounds = 9;
+    if (hdr[7] != 0) {
+        // short memory (k_setup_core): mu into workgroup b is the element of workgroup b - 1, lam in front of workgroup b its own element
+        // coupled to that mu -- plus, for the series' last workgroup only, what the boundary lam leaves after its (few) steps
+        const long long N = nblk_max_for(hdr[1], ntiles);
+        for (long long b = (long long)blockIdx.x * kLanes + threadIdx.x; b < N; b += (long long)gridDim.x * kLanes) {
+            double mu[D];
+#pragma unroll
+            for (int i = 0; i < D; ++i) mu[i] = (b == 0) ? MUb[i] : Fb[(b - 1) * D + i];
+            if (b > 0) {
+#pragma unroll
+                for (int i = 0; i < D; ++i) MUb[b * D + i] = mu[i];
+            }
+            if (POST) {
+                const bool last = b == N - 1;
+                const double* __restrict__ C = cst + (last ? CL<D>::Blb : CL<D>::Bblk);
+                double l[D];
+#pragma unroll
+                for (int i = 0; i < D; ++i) {
+                    double v = B0b[b * D + i];
+#pragma unroll
+                    for (int k = 0; k < D; ++k) v = fma(-C[i * D + k], mu[k], v);
+                    l[i] = v;
+                }
+                if (last && lam_given) {
+                    double lin[D];
+#pragma unroll
+                    for (int i = 0; i < D; ++i) lin[i] = LAMb[N * D + i];
+                    matvec_acc<D>(cst + CL<D>::GLb, lin, l);
+                }
+#pragma unroll
+                for (int i = 0; i < D; ++i) LAMb[b * D + i] = l[i];
+            }
+        }
+        if (POST && !lam_given && blockIdx.x == 0 && threadIdx.x < D) LAMb[N * D + threadIdx.x] = 0.0;
+        return;
+    }
+    if (blockIdx.x != 0) return;      // (the scans below are one workgroup's; the other workgroups of the launch exist for the short-memory path)
     constexpr int lQ = D <= 6 ? 3 : 2, kQ = 1 << lQ;
     __shared__ double sv[2][D][kLanes];
     __shared__ double sPw[2][kRounds][DD];      // the scans' matrices, fetched once (a scalar load per round would cost a memory round trip each)
@@ -2482,29 +2712,30 @@ int enqueue_d(Engine* e, hipStream_t st, const ModelDev& m, const CallDev& c, co
     const Tab tb = e->tb;
     // workgroups of the stationary tiles if the head is one tile (a shard that does not start the series has no head)
     const unsigned blocks = (unsigned)((ntiles - ((sh && !sh->first) ? 0 : 1) + kBlk - 1) / kBlk);
+    const unsigned cblocks = blocks <= 512 ? 1u : (blocks / 512 < 32 ? blocks / 512 : 32u);      // k_carry: one workgroup per 512 elements, at most 32
     if (sh) {
         // ---- a time shard, in two halves around the exchange of the segments' elements (tgp_multi.hip)
         if (blocks == 0) return (int)hipErrorInvalidValue;      // (the caller sends series of one tile to the general path)
         const int flags = (sh->first ? 0 : 1) | (sh->last ? 0 : 2);
         if (phase == 0) {
-            { Scope s(hk, "k_steady_setup"); hipLaunchKernelGGL(k_setup_core<D>, dim3(1), dim3(64), 0, st, m, tb, c.y, T, 0, flags | cov_mode_bits()); }
+            { Scope s(hk, "k_steady_setup"); hipLaunchKernelGGL(k_setup_core<D>, dim3(1), dim3(D <= kCovScanMaxD ? 128 : 64), 0, st, m, tb, c.y, T, 0, flags | cov_mode_bits(), post ? 1 : 0); }
             if (post) {
                 { Scope s(hk, "k_steady_reduce<posterior>"); hipLaunchKernelGGL((k_reduce<D, true>), dim3(blocks + 1), dim3(kBlkThreads), 0, st, tb.hdr, tb.cst, c.y, tb.F, tb.B0, tb.Fb, tb.B0b, T, ntiles, m, tb, 1); }
-                { Scope s(hk, "k_steady_carry<segment>"); hipLaunchKernelGGL((k_carry<D, true>), dim3(1), dim3(512), 0, st, tb.hdr, tb.cst, tb.Fb, tb.B0b, tb.MUb, tb.LAMb, ntiles, 0); }
+                { Scope s(hk, "k_steady_carry<segment>"); hipLaunchKernelGGL((k_carry<D, true>), dim3(cblocks), dim3(512), 0, st, tb.hdr, tb.cst, tb.Fb, tb.B0b, tb.MUb, tb.LAMb, ntiles, 0); }
             } else {
                 { Scope s(hk, "k_steady_reduce<logpdf>"); hipLaunchKernelGGL((k_reduce<D, false>), dim3(blocks), dim3(kBlkThreads), 0, st, tb.hdr, tb.cst, c.y, tb.F, tb.B0, tb.Fb, tb.B0b, T, ntiles, m, tb, 0); }
-                { Scope s(hk, "k_steady_carry<segment>"); hipLaunchKernelGGL((k_carry<D, false>), dim3(1), dim3(512), 0, st, tb.hdr, tb.cst, tb.Fb, tb.B0b, tb.MUb, tb.LAMb, ntiles, 0); }
+                { Scope s(hk, "k_steady_carry<segment>"); hipLaunchKernelGGL((k_carry<D, false>), dim3(cblocks), dim3(512), 0, st, tb.hdr, tb.cst, tb.Fb, tb.B0b, tb.MUb, tb.LAMb, ntiles, 0); }
             }
             { Scope s(hk, "k_steady_shard_pack"); hipLaunchKernelGGL(k_shard_pack<D>, dim3(1), dim3(64), 0, st, tb, ntiles, post ? 1 : 0, sh->slot); }
             return (int)hipGetLastError();
         }
         { Scope s(hk, "k_steady_shard_fold"); hipLaunchKernelGGL(k_shard_fold<D>, dim3(1), dim3(64), 0, st, tb, ntiles, sh->gathered, sh->world, sh->rank, post ? 1 : 0); }
         if (post) {
-            { Scope s(hk, "k_steady_carry<posterior>"); hipLaunchKernelGGL((k_carry<D, true>), dim3(1), dim3(512), 0, st, tb.hdr, tb.cst, tb.Fb, tb.B0b, tb.MUb, tb.LAMb, ntiles, 1); }
+            { Scope s(hk, "k_steady_carry<posterior>"); hipLaunchKernelGGL((k_carry<D, true>), dim3(cblocks), dim3(512), 0, st, tb.hdr, tb.cst, tb.Fb, tb.B0b, tb.MUb, tb.LAMb, ntiles, 1); }
             { Scope s(hk, "k_steady_apply<posterior>"); hipLaunchKernelGGL((k_apply<D, true>), dim3(blocks), dim3(kBlkThreads), 0, st, tb.hdr, tb.cst, c.y, c.Rnew, c.rnew_per_step, tb.F, tb.B0, tb.Pw, tb.Lw, tb.MUb, tb.LAMb, tb.t_vb, c.mean, c.var, tb.SSQ, T, ntiles); }
             { Scope s(hk, "k_steady_final<posterior>"); hipLaunchKernelGGL(k_final<D>, dim3(2), dim3(256), 0, st, tb, T, ntiles, c.result, c.y, c.Rnew, c.rnew_per_step, c.mean, c.var); }
         } else {
-            { Scope s(hk, "k_steady_carry<logpdf>"); hipLaunchKernelGGL((k_carry<D, false>), dim3(1), dim3(512), 0, st, tb.hdr, tb.cst, tb.Fb, tb.B0b, tb.MUb, tb.LAMb, ntiles, 0); }
+            { Scope s(hk, "k_steady_carry<logpdf>"); hipLaunchKernelGGL((k_carry<D, false>), dim3(cblocks), dim3(512), 0, st, tb.hdr, tb.cst, tb.Fb, tb.B0b, tb.MUb, tb.LAMb, ntiles, 0); }
             { Scope s(hk, "k_steady_apply<logpdf>"); hipLaunchKernelGGL((k_apply<D, false>), dim3(blocks), dim3(kBlkThreads), 0, st, tb.hdr, tb.cst, c.y, (const double*)nullptr, 0, tb.F, tb.B0, tb.Pw, tb.Lw, tb.MUb, tb.LAMb, tb.t_vb, (double*)nullptr, (double*)nullptr, tb.SSQ, T, ntiles); }
             { Scope s(hk, "k_steady_final<logpdf>"); hipLaunchKernelGGL(k_final<D>, dim3(1), dim3(256), 0, st, tb, T, ntiles, c.result, c.y, c.Rnew, 0, (double*)nullptr, (double*)nullptr); }
         }
@@ -2512,7 +2743,7 @@ int enqueue_d(Engine* e, hipStream_t st, const ModelDev& m, const CallDev& c, co
     }
     {
         Scope s(hk, "k_steady_setup");
-        hipLaunchKernelGGL(k_setup_core<D>, dim3(1), dim3(64), 0, st, m, tb, c.y, T, c.grad ? 1 : 0, cov_mode_bits());
+        hipLaunchKernelGGL(k_setup_core<D>, dim3(1), dim3(D <= kCovScanMaxD ? 128 : 64), 0, st, m, tb, c.y, T, c.grad ? 1 : 0, cov_mode_bits(), (post && !c.grad) ? 1 : 0);
     }
     if (blocks == 0) {      // a series of one tile: the engine does not apply (k_setup_core: nh + 2 > T)
         Scope s(hk, "k_steady_final");
@@ -2523,7 +2754,7 @@ int enqueue_d(Engine* e, hipStream_t st, const ModelDev& m, const CallDev& c, co
     if (c.grad) {
         static_assert(GradRec<D>::size == 3 * D * D + 8 * D + 8 + D * (D + 1) / 2, "grad_record_size() mirrors GradRec<D>");
         { Scope s(hk, "k_steady_reduce<adjoint>"); hipLaunchKernelGGL((k_reduce<D, true>), dim3(blocks + 1), dim3(kBlkThreads), 0, st, tb.hdr, tb.cst, c.y, tb.F, tb.B0, tb.Fb, tb.B0b, T, ntiles, m, tb, 0); }
-        { Scope s(hk, "k_steady_carry<adjoint>"); hipLaunchKernelGGL((k_carry<D, true>), dim3(1), dim3(512), 0, st, tb.hdr, tb.cst, tb.Fb, tb.B0b, tb.MUb, tb.LAMb, ntiles, 0); }
+        { Scope s(hk, "k_steady_carry<adjoint>"); hipLaunchKernelGGL((k_carry<D, true>), dim3(cblocks), dim3(512), 0, st, tb.hdr, tb.cst, tb.Fb, tb.B0b, tb.MUb, tb.LAMb, ntiles, 0); }
         { Scope s(hk, "k_steady_apply<adjoint>"); hipLaunchKernelGGL(k_apply_grad<D>, dim3(blocks), dim3(kBlkThreads), 0, st, tb.hdr, tb.cst, c.y, tb.F, tb.B0, tb.Pw, tb.Lw, tb.MUb, tb.LAMb, tb.GS, tb.SSQ, T, ntiles); }
         { Scope s(hk, "k_steady_final<adjoint>"); hipLaunchKernelGGL(k_final_grad<D>, dim3(1), dim3(1024), 0, st, tb, m, T, ntiles, tb.GS, (long long)blocks, tb.grec); }
         // (the value of the call: the usual reduction -- misc[0], LS and logS do not depend on the (G, c) of the block)
@@ -2532,12 +2763,12 @@ int enqueue_d(Engine* e, hipStream_t st, const ModelDev& m, const CallDev& c, co
     }
     if (post) {
         { Scope s(hk, "k_steady_reduce<posterior>"); hipLaunchKernelGGL((k_reduce<D, true>), dim3(blocks + 1), dim3(kBlkThreads), 0, st, tb.hdr, tb.cst, c.y, tb.F, tb.B0, tb.Fb, tb.B0b, T, ntiles, m, tb, 1); }
-        { Scope s(hk, "k_steady_carry<posterior>"); hipLaunchKernelGGL((k_carry<D, true>), dim3(1), dim3(512), 0, st, tb.hdr, tb.cst, tb.Fb, tb.B0b, tb.MUb, tb.LAMb, ntiles, 0); }
+        { Scope s(hk, "k_steady_carry<posterior>"); hipLaunchKernelGGL((k_carry<D, true>), dim3(cblocks), dim3(512), 0, st, tb.hdr, tb.cst, tb.Fb, tb.B0b, tb.MUb, tb.LAMb, ntiles, 0); }
         { Scope s(hk, "k_steady_apply<posterior>"); hipLaunchKernelGGL((k_apply<D, true>), dim3(blocks), dim3(kBlkThreads), 0, st, tb.hdr, tb.cst, c.y, c.Rnew, c.rnew_per_step, tb.F, tb.B0, tb.Pw, tb.Lw, tb.MUb, tb.LAMb, tb.t_vb, c.mean, c.var, tb.SSQ, T, ntiles); }
         { Scope s(hk, "k_steady_final<posterior>"); hipLaunchKernelGGL(k_final<D>, dim3(2), dim3(256), 0, st, tb, T, ntiles, c.result, c.y, c.Rnew, c.rnew_per_step, c.mean, c.var); }
     } else {
         { Scope s(hk, "k_steady_reduce<logpdf>"); hipLaunchKernelGGL((k_reduce<D, false>), dim3(blocks), dim3(kBlkThreads), 0, st, tb.hdr, tb.cst, c.y, tb.F, tb.B0, tb.Fb, tb.B0b, T, ntiles, m, tb, 0); }
-        { Scope s(hk, "k_steady_carry<logpdf>"); hipLaunchKernelGGL((k_carry<D, false>), dim3(1), dim3(512), 0, st, tb.hdr, tb.cst, tb.Fb, tb.B0b, tb.MUb, tb.LAMb, ntiles, 0); }
+        { Scope s(hk, "k_steady_carry<logpdf>"); hipLaunchKernelGGL((k_carry<D, false>), dim3(cblocks), dim3(512), 0, st, tb.hdr, tb.cst, tb.Fb, tb.B0b, tb.MUb, tb.LAMb, ntiles, 0); }
         { Scope s(hk, "k_steady_apply<logpdf>"); hipLaunchKernelGGL((k_apply<D, false>), dim3(blocks), dim3(kBlkThreads), 0, st, tb.hdr, tb.cst, c.y, (const double*)nullptr, 0, tb.F, tb.B0, tb.Pw, tb.Lw, tb.MUb, tb.LAMb, tb.t_vb, (double*)nullptr, (double*)nullptr, tb.SSQ, T, ntiles); }
         { Scope s(hk, "k_steady_final<logpdf>"); hipLaunchKernelGGL(k_final<D>, dim3(1), dim3(256), 0, st, tb, T, ntiles, c.result, c.y, c.Rnew, 0, (double*)nullptr, (double*)nullptr); }
     }
