@@ -1450,7 +1450,7 @@ int tgp_logpdf(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t 
     if (!out) return h->fail(TGP_EINVAL, "out is NULL");
     h->steady2_last = false;
     if (steady2_eligible(h, missing, flags)) {
-        CallTimer tm(h);
+        CallTimer tm(h, /*clear=*/false);      // (the engine's set-up kernel clears the result record itself: one launch less)
         TRY(set_obs(h, y, missing, flags));
         tm.inputs_done();
         TRY(steady2_enqueue(h, nullptr, false, nullptr, nullptr));
@@ -1512,7 +1512,7 @@ int tgp_logpdf_adjoint(tgp_handle* h, const double* y, uint32_t flags, double* l
     const int64_t nyh = h->T < kHead ? h->T : kHead;
     if (!h->adj_host && hipHostMalloc(reinterpret_cast<void**>(&h->adj_host), (tgp_steady::grad_record_size(tgp_steady::kMaxD) + kHead) * sizeof(double), hipHostMallocDefault) != hipSuccess)
         return h->fail(TGP_EHIP, "hipHostMalloc");
-    CallTimer tm(h);
+    CallTimer tm(h, /*clear=*/false);
     TRY(set_obs(h, y, nullptr, flags));
     tm.inputs_done();
     TRY(steady2_enqueue(h, nullptr, false, nullptr, nullptr, true));
@@ -1661,7 +1661,7 @@ int tgp_posterior_marginals(tgp_handle* h, const double* y, const uint8_t* missi
     const size_t nT = (size_t)h->T * h->p * sizeof(double);   // one value per (time step, observation)
     h->steady2_last = false;
     if (steady2_eligible(h, missing, flags)) {
-        CallTimer tm(h);
+        CallTimer tm(h, /*clear=*/false);
         const void* pR = nullptr;
         TRY(stage_in(h, h->bRnew, Rnew, rshared ? sizeof(double) : nT, idev, &pR));
         TRY(set_obs(h, y, missing, flags));
@@ -2563,7 +2563,7 @@ int tgp_shard_steady_begin(tgp_handle* h, const double* y, uint32_t flags, int f
     if (!slot_dev) return h->fail(TGP_EINVAL, "slot_dev is NULL");
     if (!steady2_eligible(h, nullptr, flags) || h->T <= tgp_steady::kTile)
         return h->fail(TGP_EUNSUPPORTED, "tgp_shard_steady_begin: not a model / segment of the stationary-gain engine (use the tgp_shard_* protocol of the general engine)");
-    CallTimer tm(h);
+    CallTimer tm(h, /*clear=*/false);
     TRY(set_obs(h, y, nullptr, flags));
     tgp_steady::ShardDev sd;
     sd.first = first ? 1 : 0;

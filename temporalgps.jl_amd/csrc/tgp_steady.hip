@@ -868,7 +868,8 @@ __device__ void setup_side_scan(const ModelDev& m, const Tab& tb, long long T);
 //  builds the variance tables of a posterior call -- setup_side_scan -- beside wave 0's later phases; everything else in here is wave 0
 //  talking to itself, hence wave_sync, not __syncthreads.)
 template <int D>
-__global__ __launch_bounds__(128) void k_setup_core(ModelDev m, Tab tb, const double* __restrict__ y, long long T, int grad, int shard, int with_side) {
+__device__ __forceinline__ void setup_body(const ModelDev& m, const Tab& tb, const double* __restrict__ y, long long T, int grad, int shard, int with_side,
+                                           double* __restrict__ result) {
     constexpr int DD = D * D;
     constexpr int nhmax = kHeadMaxTiles * kTile;
     __shared__ double sP[DD], sT[DD], sPp[DD], sB[DD], sXa[DD], sGa[DD], sXb[DD], sGb[DD], sXc[DD], sGc[DD];
@@ -883,6 +884,7 @@ __global__ __launch_bounds__(128) void k_setup_core(ModelDev m, Tab tb, const do
     const bool act = lane < DD;
     const int e = act ? lane : 0;
     const int i = e / D, j = e % D;
+    if (result != nullptr && lane < 8) result[lane] = 0.0;      // the call's result record (the API layer then skips its own clearing launch)
     if (lane == 0) {
         tb.hdr[4] = 0;
         tb.misc[8] = (double)wall_clock64();
@@ -997,6 +999,11 @@ __global__ __launch_bounds__(128) void k_setup_core(ModelDev m, Tab tb, const do
         lds_sync();
         double* cst = tb.cst;
         for (int k = 0; k < kPowN; ++k) {
+            if (k == kLogBlk + 1 && !shard) {
+                // short memory (hdr[7] below): nothing behind a whole workgroup's power is ever read -- k_carry needs no scan
+                const double px = act ? fabs(cst[CL<D>::pphi + kLogBlk * DD + e]) : 0.0, gx = act ? fabs(cst[CL<D>::pg + kLogBlk * DD + e]) : 0.0;
+                if (!__any((px > 1e-30) || (gx > 1e-30))) break;
+            }
             if (act) {
                 cst[CL<D>::pphi + k * DD + e] = x;
                 cst[CL<D>::pg + k * DD + e] = g;
@@ -1135,6 +1142,12 @@ __global__ __launch_bounds__(128) void k_setup_core(ModelDev m, Tab tb, const do
         head_forward<D>(tb, y, T, lane);
     }
     if (lane == 0) tb.misc[12] = (double)wall_clock64();
+}
+
+template <int D>
+__global__ __launch_bounds__(128) void k_setup_core(ModelDev m, Tab tb, const double* __restrict__ y, long long T, int grad, int shard, int with_side,
+                                                    double* __restrict__ result) {
+    setup_body<D>(m, tb, y, T, grad, shard, with_side, result);
 }
 
 // setup_side: the smoothed VARIANCES of the head and of the tail (c, d) -- needed by the output pass only, so ONE wave of an extra
@@ -2718,7 +2731,7 @@ int enqueue_d(Engine* e, hipStream_t st, const ModelDev& m, const CallDev& c, co
         if (blocks == 0) return (int)hipErrorInvalidValue;      // (the caller sends series of one tile to the general path)
         const int flags = (sh->first ? 0 : 1) | (sh->last ? 0 : 2);
         if (phase == 0) {
-            { Scope s(hk, "k_steady_setup"); hipLaunchKernelGGL(k_setup_core<D>, dim3(1), dim3(D <= kCovScanMaxD ? 128 : 64), 0, st, m, tb, c.y, T, 0, flags | cov_mode_bits(), post ? 1 : 0); }
+            { Scope s(hk, "k_steady_setup"); hipLaunchKernelGGL(k_setup_core<D>, dim3(1), dim3(D <= kCovScanMaxD ? 128 : 64), 0, st, m, tb, c.y, T, 0, flags | cov_mode_bits(), post ? 1 : 0, c.result); }
             if (post) {
                 { Scope s(hk, "k_steady_reduce<posterior>"); hipLaunchKernelGGL((k_reduce<D, true>), dim3(blocks + 1), dim3(kBlkThreads), 0, st, tb.hdr, tb.cst, c.y, tb.F, tb.B0, tb.Fb, tb.B0b, T, ntiles, m, tb, 1); }
                 { Scope s(hk, "k_steady_carry<segment>"); hipLaunchKernelGGL((k_carry<D, true>), dim3(cblocks), dim3(512), 0, st, tb.hdr, tb.cst, tb.Fb, tb.B0b, tb.MUb, tb.LAMb, ntiles, 0); }
@@ -2743,7 +2756,7 @@ int enqueue_d(Engine* e, hipStream_t st, const ModelDev& m, const CallDev& c, co
     }
     {
         Scope s(hk, "k_steady_setup");
-        hipLaunchKernelGGL(k_setup_core<D>, dim3(1), dim3(D <= kCovScanMaxD ? 128 : 64), 0, st, m, tb, c.y, T, c.grad ? 1 : 0, cov_mode_bits(), (post && !c.grad) ? 1 : 0);
+        hipLaunchKernelGGL(k_setup_core<D>, dim3(1), dim3(D <= kCovScanMaxD ? 128 : 64), 0, st, m, tb, c.y, T, c.grad ? 1 : 0, cov_mode_bits(), (post && !c.grad) ? 1 : 0, c.result);
     }
     if (blocks == 0) {      // a series of one tile: the engine does not apply (k_setup_core: nh + 2 > T)
         Scope s(hk, "k_steady_final");
