@@ -58,7 +58,8 @@ struct CL {
     static constexpr int GSeg = PSeg + DD;                   // G^L
     static constexpr int BSeg = GSeg + DD;                   // B_L
     static constexpr int GLb = BSeg + DD;                    // G^(steps of the ragged last workgroup): the lam a shard receives enters there
-    static constexpr int size = GLb + DD;
+    static constexpr int WJ = GLb + DD;                      // [kSub][D]: h' Phi^j -- the innovation j steps behind a lane's start state st is r0_j - WJ[j] . st
+    static constexpr int size = WJ + kSub * D;
 };
 // slot a time shard hands to the exchange: [0] applies, then F (mu behind the segment under a zero carry-in; rank 0: the mu itself),
 // B0 (lam in front of the segment's stationary steps under zero carries), Phi^L, G^L, B_L
@@ -977,6 +978,25 @@ __device__ __forceinline__ void setup_body(const ModelDev& m, const Tab& tb, con
     __threadfence_block();
     wave_sync();
     if (lane == 0) tb.misc[10] = (double)wall_clock64();
+    // ---- rows h' Phi^j, j < 8 (tile_forward: the lanes' innovations from their scanned start state without a second recursion) --------
+    if (lane < D) {
+        double w[D], nw[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) w[k] = hv[k];
+#pragma unroll
+        for (int jj = 0; jj < kSub; ++jj) {
+#pragma unroll
+            for (int c = 0; c < D; ++c) {
+                if (c == lane) tb.cst[CL<D>::WJ + jj * D + c] = w[c];
+                double v = 0.0;
+#pragma unroll
+                for (int k = 0; k < D; ++k) v = fma(w[k], m.A[k + c * D] - kAss[k] * hv[c], v);      // (w' Phi)_c
+                nw[c] = v;
+            }
+#pragma unroll
+            for (int c = 0; c < D; ++c) w[c] = nw[c];
+        }
+    }
     // ---- (e) powers Phi^(2^k), G^(2^k); the couplings B_n = sum_{j < n} G^j c h' Phi^j by doubling, B_2n = B_n + G^n B_n Phi^n:
     //      B_512 (a tile), B_2048 (a workgroup), and the two ragged ones -- the last tile's nv valid steps and the last workgroup's nvb --
     //      composed from the B_(2^k) of the bits of nv / nvb --------------------------------------------------------------------------------
@@ -1519,6 +1539,7 @@ __device__ __forceinline__ void tile_forward(const Coef<D>& cf, const double* __
 #pragma unroll
         for (int k = 0; k < D; ++k) rr = fma(-cf.h[k], mu[k], rr);
         rr = (j < nvalid) ? rr : 0.0;
+        r[j] = rr;
         double nm[D];
 #pragma unroll
         for (int i = 0; i < D; ++i) {
@@ -1555,6 +1576,19 @@ __device__ __forceinline__ void tile_forward(const Coef<D>& cf, const double* __
     for (int i = 0; i < D; ++i) {
         const double v = __shfl_up(mu[i], 1);
         st[i] = (lane == 0) ? mu_in[i] : v;
+    }
+    if constexpr (!KEEP) {
+        // the first recursion's innovations r0 were computed from a zero start (lane 0: from the carry itself); the start state moves
+        // step j's predicted mean by Phi^j st, its innovation by -h' Phi^j st: eight dot products instead of a second recursion
+        const double* __restrict__ W = pw_phi - CL<D>::pphi + CL<D>::WJ;      // (pw_phi = cst + CL::pphi)
+#pragma unroll
+        for (int j = 0; j < kSub; ++j) {
+            double rr = r[j];
+#pragma unroll
+            for (int k = 0; k < D; ++k) rr = fma(-W[j * D + k], (lane == 0) ? 0.0 : st[k], rr);
+            r[j] = (j < nvalid) ? rr : 0.0;
+        }
+        return;
     }
 #pragma unroll
     for (int j = 0; j < kSub; ++j) {
@@ -2717,7 +2751,7 @@ hipError_t ensure(Engine* e, int d, long long ntiles) {
         return o;
     };
     // constant block, as CL<D> lays it out
-    const size_t ss_size = 2 * DD + 5 * (size_t)d + 6, c_pphi = (ss_size + 7) & ~(size_t)7, c_pg = c_pphi + kPowN * DD, c_size = c_pg + kPowN * DD + 4 * DD + 3 * kBlk * DD + 4 * DD;
+    const size_t ss_size = 2 * DD + 5 * (size_t)d + 6, c_pphi = (ss_size + 7) & ~(size_t)7, c_pg = c_pphi + kPowN * DD, c_size = c_pg + kPowN * DD + 4 * DD + 3 * kBlk * DD + 4 * DD + (size_t)kSub * d;
     const size_t o_hdr = take(8), o_cst = take(c_size);
     const size_t o_hkA = take(nhmax * d), o_hrS = take(nhmax), o_hiS = take(nhmax), o_hG = take(nhmax * DD), o_hc = take(nhmax * d),
                  o_hvb = take(nhmax), o_hr = take(nhmax);
@@ -2760,7 +2794,7 @@ struct Scope {
 template <int D>
 int enqueue_d(Engine* e, hipStream_t st, const ModelDev& m, const CallDev& c, const Hooks& hk, const ShardDev* sh, int phase) {
     static_assert(CL<D>::pphi == ((2 * D * D + 5 * D + 6 + 7) & ~7), "ensure() mirrors CL<D>");
-    static_assert(CL<D>::size == CL<D>::pphi + 2 * kPowN * D * D + 4 * D * D + 3 * kBlk * D * D + 4 * D * D, "ensure() mirrors CL<D>");
+    static_assert(CL<D>::size == CL<D>::pphi + 2 * kPowN * D * D + 4 * D * D + 3 * kBlk * D * D + 4 * D * D + kSub * D, "ensure() mirrors CL<D>");
     static_assert(ShardSlot<D>::size == 1 + 2 * D + 3 * D * D, "shard_slot_size() mirrors ShardSlot<D>");
     const long long T = c.T;
     const long long ntiles = (T + kTile - 1) / kTile;
