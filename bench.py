@@ -206,10 +206,14 @@ def split_leg(tgp, torch, model, y, Rnew, T, steps):
     y_host = y.cpu().numpy()
     rn_host = Rnew.cpu().numpy()
     t_lp_h = timed(lambda: tgp.logpdf(model, y_host), 3)
-    t_pm_h = timed(lambda: tgp.posterior_marginals(model, y_host, rn_host), 3)
+    t_pm_fresh = timed(lambda: tgp.posterior_marginals(model, y_host, rn_host), 3)
+    outs = (np.empty(T), np.empty(T))
+    t_pm_h = timed(lambda: tgp.posterior_marginals(model, y_host, rn_host, out=outs), 3)
     return dict(logpdf_ms=t_lp * 1e3, posterior_marginals_ms=t_pm * 1e3, logpdf_steps_per_s=T / t_lp, posterior_marginals_steps_per_s=T / t_pm,
                 host_memory=dict(logpdf_ms=t_lp_h * 1e3, posterior_marginals_ms=t_pm_h * 1e3, steps_per_s=T / (t_lp_h + t_pm_h),
-                                 note="inputs in pageable host memory, outputs to host: 8 B/step in, 16 B/step out over PCIe"))
+                                 posterior_marginals_into_fresh_arrays_ms=t_pm_fresh * 1e3,
+                                 note="inputs in pageable host memory, outputs to host arrays the caller reuses: 8 B/step in, 16 B/step out over PCIe "
+                                      "(profiles/r03_host_memory.md); freshly allocated output arrays add their first-touch page faults on the caller's side"))
 
 
 def cpu_gradient_baseline(name, T_sample):

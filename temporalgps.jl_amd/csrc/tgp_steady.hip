@@ -2573,18 +2573,26 @@ __global__ __launch_bounds__(kBlkThreads, (D <= 4 ? 2 : 1)) void k_apply_grad(co
 // sums of the workgroups (fixed order: wave q mod 16 takes sum q, its lanes stride over the workgroups) + everything else the host's half
 // of the gradient needs, in ONE record: psi and mu at the head's end, n0 / head tiles / T, and the model blocks as they are bound.
 template <int D>
-__global__ __launch_bounds__(1024) void k_final_grad(Tab tb, ModelDev m, long long T, long long ntiles, const double* __restrict__ GS, long long nbs, double* __restrict__ rec) {
+__global__ __launch_bounds__(256) void k_final_grad(Tab tb, ModelDev m, long long T, long long ntiles, const double* __restrict__ GS, long long nbs, double* __restrict__ rec) {
     constexpr int DD = D * D, NS = GradRec<D>::NS;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x;
     const bool ok = tb.hdr[0] != 0;
     const long long N = ok ? nblk_max_for(tb.hdr[1], ntiles) : 0;
-    for (int q = wave; q < NS; q += 16) {
+    // workgroup q < NS sums row q of GS (fixed order: strided partial sums, then a tree); workgroup 0 also packs the rest of the record
+    {
+        __shared__ double sm[256];
+        const int q = blockIdx.x;
         double v = 0.0;
-        for (long long b = lane; b < N; b += 64) v += GS[q * nbs + b];
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) v += __shfl_down(v, off);
-        if (lane == 0) rec[q] = v;
+        for (long long b = tid; b < N; b += 256) v += GS[q * nbs + b];
+        sm[tid] = v;
+        __syncthreads();
+        for (int off = 128; off >= 1; off >>= 1) {
+            if (tid < off) sm[tid] += sm[tid + off];
+            __syncthreads();
+        }
+        if (tid == 0) rec[q] = sm[0];
     }
+    if (blockIdx.x != 0) return;
     if (tid < D) {
         rec[GradRec<D>::psi + tid] = ok ? tb.LAMb[tid] : 0.0;
         rec[GradRec<D>::mu + tid] = ok ? tb.MUb[tid] : 0.0;
@@ -2838,7 +2846,7 @@ int enqueue_d(Engine* e, hipStream_t st, const ModelDev& m, const CallDev& c, co
     if (blocks == 0) {      // a series of one tile: the engine does not apply (k_setup_core: nh + 2 > T)
         Scope s(hk, "k_steady_final");
         hipLaunchKernelGGL(k_final<D>, dim3(1), dim3(256), 0, st, tb, T, ntiles, c.result, c.y, c.Rnew, 0, (double*)nullptr, (double*)nullptr);
-        if (c.grad) hipLaunchKernelGGL(k_final_grad<D>, dim3(1), dim3(1024), 0, st, tb, m, T, ntiles, tb.GS, 1LL, tb.grec);
+        if (c.grad) hipLaunchKernelGGL(k_final_grad<D>, dim3(GradRec<D>::NS), dim3(256), 0, st, tb, m, T, ntiles, tb.GS, 1LL, tb.grec);
         return (int)hipGetLastError();
     }
     if (c.grad) {
@@ -2846,7 +2854,7 @@ int enqueue_d(Engine* e, hipStream_t st, const ModelDev& m, const CallDev& c, co
         { Scope s(hk, "k_steady_reduce<adjoint>"); hipLaunchKernelGGL((k_reduce<D, true>), dim3(blocks + 1), dim3(kBlkThreads), 0, st, tb.hdr, tb.cst, c.y, tb.F, tb.B0, tb.Fb, tb.B0b, T, ntiles, m, tb, 0); }
         { Scope s(hk, "k_steady_carry<adjoint>"); hipLaunchKernelGGL((k_carry<D, true>), dim3(cblocks), dim3(512), 0, st, tb.hdr, tb.cst, tb.Fb, tb.B0b, tb.MUb, tb.LAMb, ntiles, 0); }
         { Scope s(hk, "k_steady_apply<adjoint>"); hipLaunchKernelGGL(k_apply_grad<D>, dim3(blocks), dim3(kBlkThreads), 0, st, tb.hdr, tb.cst, c.y, tb.F, tb.B0, tb.Pw, tb.Lw, tb.MUb, tb.LAMb, tb.GS, tb.SSQ, T, ntiles); }
-        { Scope s(hk, "k_steady_final<adjoint>"); hipLaunchKernelGGL(k_final_grad<D>, dim3(1), dim3(1024), 0, st, tb, m, T, ntiles, tb.GS, (long long)blocks, tb.grec); }
+        { Scope s(hk, "k_steady_final<adjoint>"); hipLaunchKernelGGL(k_final_grad<D>, dim3(GradRec<D>::NS), dim3(256), 0, st, tb, m, T, ntiles, tb.GS, (long long)blocks, tb.grec); }
         // (the value of the call: the usual reduction -- misc[0], LS and logS do not depend on the (G, c) of the block)
         { Scope s(hk, "k_steady_final<logpdf>"); hipLaunchKernelGGL(k_final<D>, dim3(1), dim3(256), 0, st, tb, T, ntiles, c.result, c.y, c.Rnew, 0, (double*)nullptr, (double*)nullptr); }
         return (int)hipGetLastError();

@@ -100,7 +100,8 @@ class SmallOutputLGC:
     R (T|1, p) = the DIAGONAL of the noise covariance, or (T|1, p, p) dense. The engine absorbs the p
     observations of a time step as p scalar updates (exactly the joint update for diagonal noise); a dense R is
     whitened on the host first (H <- L^-1 H, h <- L^-1 h, y <- L^-1 y, R <- I), which supports logpdf / _filter /
-    posterior; marginals and rand need diagonal noise."""
+    posterior; `marginals` (the diagonal, as for every vector-output model) and `rand` go through a diagonal-noise twin of the
+    model, the correlated emission draw of `rand` being added on the host (`_diagonal_twin`)."""
 
     def __init__(self, H, h, R):
         self.H, self.h, self.R = H, h, R
@@ -621,6 +622,25 @@ def _need_diag(model, what):
                                   "(diagonal noise only)")
 
 
+def _dense_noise(model):
+    return isinstance(model, LGSSM) and isinstance(model.emissions, SmallOutputLGC) and model.emissions.dense
+
+
+def _diagonal_twin(model):
+    """For a model with a DENSE observation-noise covariance: the same transitions and emission maps with only diag(R) as noise, bound on
+    the same device (cached on the model). Prior marginals and samples do not involve the Kalman update, so R enters them only
+    additively: marginals_diag = diag(H P H') + diag(R) is what this twin's tgp_marginals returns, and rand = the twin's noise-free
+    H x + h plus chol(R + 1e-9 I)' eps added on the host (lgc.jl:84-87)."""
+    if getattr(model, "_twin", None) is None:
+        em = model.emissions
+        Rn = np.asarray(_to_numpy(em.R), dtype=np.float64)
+        twin = LGSSM(model.transitions, SmallOutputLGC(em.H, em.h, np.ascontiguousarray(np.diagonal(Rn, axis1=-2, axis2=-1))), T=model.T,
+                     device=model.device)
+        twin.handle_options = dict(model.handle_options)
+        model._twin = twin
+    return model._twin
+
+
 def marginals(model):
     """lgssm.jl:99-115: emission marginals of the model as given, returned as (mean (T,), var (T,)). On an unevaluated
     posterior this is the fused filter + RTS smoother (posterior_lti_sde.jl:27-36)."""
@@ -629,6 +649,8 @@ def marginals(model):
         if out is not None:
             return out
         model = model.materialise()
+    if _dense_noise(model):
+        return marginals(_diagonal_twin(model))      # (mean, DIAGONAL of H P H' + R): the marginals_diag contract for vector outputs
     _need_diag(model, "marginals")
     hd = model.handle()
     dev = model._on_device
@@ -731,6 +753,22 @@ def rand(rng_or_eps, model):
     else:
         eps_t, eps_e = ε_randn(rng_or_eps, model)
         eps_0 = rng_or_eps.standard_normal(model.dim)
+    if _dense_noise(model):
+        # y_t = (H x_t + h) + chol(Symmetric(R_t + 1e-9 I)).U' eps_t (lgc.jl:84-87): the latent path and H x + h on the device with a zero
+        # emission draw, the correlated noise (T small p x p products) on the host
+        ee = np.asarray(_to_numpy(eps_e), dtype=np.float64).reshape(model.T, model.p)
+        zero = np.zeros_like(ee)
+        if _lib.is_device(eps_t):
+            import torch
+            zero = torch.zeros((model.T, model.p), dtype=torch.float64, device=eps_t.device)
+        y0 = rand((eps_t, zero, eps_0), _diagonal_twin(model))
+        Rn = np.asarray(_to_numpy(model.emissions.R), dtype=np.float64)
+        Lc = np.linalg.cholesky(Rn + 1e-9 * np.eye(model.p))                       # (T|1, p, p) lower: U' = L
+        noise = np.einsum("tij,tj->ti", np.broadcast_to(Lc, (model.T, model.p, model.p)), ee)
+        if _is_torch(y0):
+            import torch
+            return y0 + torch.as_tensor(noise, device=y0.device).reshape(y0.shape)
+        return y0 + noise.reshape(y0.shape)
     _need_diag(model, "rand")
     hd = model.handle()
     dev = _lib.is_device(eps_t)

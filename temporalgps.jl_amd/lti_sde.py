@@ -565,8 +565,24 @@ def parameters(kernel, prefix="kernel"):
 
 
 # ---- exact derivatives of the O(1) host map hyper-parameter -> shared blocks (regular spacing) ---------------------------------------
-def _expm_and_tangent(X, E):
-    """exp(X) and its Frechet derivative in direction E (Van Loan: the upper-right block of exp([[X, E], [0, X]]))."""
+def _expm_and_tangent(X, E, cache=None):
+    """exp(X) and its Frechet derivative in direction E. E = 0: no derivative; E commuting with X (every rule of `_sde_jet`: a stretch
+    scales F, a product's factor enters as a Kronecker summand): dexp = E exp(X); otherwise Van Loan (the upper-right block of
+    exp([[X, E], [0, X]])). `cache`: exp(X) of a kernel expression is the same for every hyper-parameter of one gradient."""
+    key = None if cache is None else X.tobytes()
+    A = None if key is None else cache.get(key)
+    if not np.any(E):
+        if A is None:
+            A = expm(X)
+            if key is not None:
+                cache[key] = A
+        return A, np.zeros_like(X)
+    if np.max(np.abs(X @ E - E @ X)) <= 1e-14 * max(1e-300, np.max(np.abs(X)) * np.max(np.abs(E))):
+        if A is None:
+            A = expm(X)
+            if key is not None:
+                cache[key] = A
+        return A, E @ A
     n = X.shape[0]
     M = np.zeros((2 * n, 2 * n))
     M[:n, :n] = M[n:, n:] = X
@@ -619,30 +635,30 @@ def _sde_jet(kernel, target):
     return np.asarray(F, float), np.zeros_like(np.asarray(F, float)), np.asarray(H, float), np.zeros_like(np.asarray(H, float)), m, np.asarray(P, float), dP
 
 
-def _components_jet(kernel, dt, ddt, target, first=False):
+def _components_jet(kernel, dt, ddt, target, first=False, cache=None):
     """Shared blocks (A, Q, H, m0, P0) of `lgssm_components(RegularSpacing(., dt, .))` and their derivatives (dA, dQ, dH, dP0)
     w.r.t. the target hyper-parameter; `ddt` is the derivative of this sub-expression's (stretched) time step.
     first=True: the FIRST transition of an irregularly spaced input (lti_sde.jl:139: dt_1 := 1 in each sub-kernel's own stretched
     time, so a ScaleTransform does not reach it -- except through the F of a product's factors, as in the reference)."""
     if isinstance(kernel, ScaledKernel):
-        A, dA, Q, dQ, H, dH, m, P, dP = _components_jet(kernel.kernel, dt, ddt, target, first)
+        A, dA, Q, dQ, H, dH, m, P, dP = _components_jet(kernel.kernel, dt, ddt, target, first, cache)
         sig = np.sqrt(kernel.sigma2)
         own = target[0] is kernel and target[1] == "sigma2"
         return A, dA, Q, dQ, sig * H, sig * dH + (H / (2.0 * sig) if own else 0.0), m, P, dP
     if isinstance(kernel, StretchedKernel):
         own = target[0] is kernel and target[1] == "s"
         if first:
-            return _components_jet(kernel.kernel, dt, ddt, target, True)
-        return _components_jet(kernel.kernel, kernel.s * dt, kernel.s * ddt + (dt if own else 0.0), target)
+            return _components_jet(kernel.kernel, dt, ddt, target, True, cache)
+        return _components_jet(kernel.kernel, kernel.s * dt, kernel.s * ddt + (dt if own else 0.0), target, False, cache)
     if isinstance(kernel, KernelSum):
-        parts = [_components_jet(k, dt, ddt, target, first) for k in kernel.kernels]
+        parts = [_components_jet(k, dt, ddt, target, first, cache) for k in kernel.kernels]
         bd = lambda i: block_diag(*[p[i] for p in parts])
         cat = lambda i: np.concatenate([p[i] for p in parts])
         return bd(0), bd(1), bd(2), bd(3), cat(4), cat(5), cat(6), bd(7), bd(8)
     F, dF, H, dH, m, P0, dP = _sde_jet(kernel, target)          # simple kernels and products: one SDE, one exponential
     P = np.triu(P0) + np.triu(P0, 1).T
     dPs = np.triu(dP) + np.triu(dP, 1).T
-    A, dA = _expm_and_tangent(F * dt, dF * dt + F * ddt)
+    A, dA = _expm_and_tangent(F * dt, dF * dt + F * ddt, cache)
     Q = P - A @ P @ A.T
     dQ = dPs - dA @ P @ A.T - A @ dPs @ A.T - A @ P @ dA.T
     return A, dA, Q, dQ, H, dH, m, P0, dP
@@ -650,7 +666,7 @@ def _components_jet(kernel, dt, ddt, target, first=False):
 
 def _shared_block_tangents(fx, names, plist):
     """exact d (A, a, Q, H, h, R, x0m, x0P) / d parameter for every name in `names` (regular spacing, homoscedastic noise)"""
-    kernel, d = fx.f.f.kernel, None
+    kernel, cache = fx.f.f.kernel, {}
     out = []
     for name in names:
         if name == "noise":
@@ -660,7 +676,7 @@ def _shared_block_tangents(fx, names, plist):
             out.append(dict(h=1.0))
             continue
         owner, attr = next((o, a) for n, o, a in plist if n == name)
-        A, dA, Q, dQ, H, dH, m, P, dP = _components_jet(kernel, fx.x.dt, 0.0, (owner, attr))
+        A, dA, Q, dQ, H, dH, m, P, dP = _components_jet(kernel, fx.x.dt, 0.0, (owner, attr), cache=cache)
         out.append(dict(A=dA, Q=dQ, H=dH, x0P=dP))
     return out
 

@@ -14,8 +14,9 @@ marginals -- run on the device through the vector-observation path (`lgssm.Bottl
 
 Covered: k = sum_i s_i * Separable(k_space_i, k_time_i) on a RectilinearGrid, diagonal noise, missing observations,
 state dimension sum_i M * d_t,i <= 16 and N <= 64 observations per time step (the engine's per-lane limits).
-Not covered: RegularInTime inputs with a different number of points per time step (the device path has a fixed number
-of observations per step), and the per-time `approx_posterior_marginals(..., t)` convenience method.
+`space_time.RegularInTime` inputs -- a different number of points (at different locations) per time step,
+regular_in_time.jl:8-89 -- are padded to the longest slice with the padding marked missing: per-step emission blocks, the same
+device recursions. Not covered: the per-time `approx_posterior_marginals(..., t)` convenience method.
 """
 import numpy as np
 from scipy.linalg import block_diag
@@ -69,14 +70,19 @@ def lgssm_components(k_dtc, grid, x_space=None, jitter=1e-12):
     """pseudo_point.jl:107-144 with the ScaledKernel / KernelSum rules of lti_sde.jl:344-346, 424-436.
     Returns A, a, Q, (Ct (N, Mtot), Hb (n, Mtot, D), hb (1, Mtot)), (m0, P0). `x_space` overrides the grid's spatial
     points (new prediction locations)."""
-    xr = grid.xl if x_space is None else np.asarray(x_space, dtype=np.float64)
+    ragged = isinstance(grid, ST.RegularInTime) and x_space is None
+    xr = (grid.points() if ragged else grid.xl) if x_space is None else np.asarray(x_space, dtype=np.float64)
     As, as_, Qs, Hbs, Cs, ms, Ps = [], [], [], [], [], [], []
     for s, kd in _terms(k_dtc):
         A_t, a_t, Q_t, H_t, h_t, (m_t, P_t) = kd.k.r.lgssm_components(grid.xr)
         M = len(kd.z)
         ident = np.eye(M)
         Kz = _cross(kd.k.l, kd.z, kd.z)
-        Cs.append(np.linalg.solve(Kz + jitter * ident, _cross(kd.k.l, kd.z, xr)))
+        if ragged:      # one cross-covariance block per time slice (the padding slots' columns are never used: they are missing)
+            Kzx = ST.kappa(kd.k.l, np.abs(kd.z[None, :, None] - xr[:, None, :]))           # (T, M, nmax)
+            Cs.append(np.linalg.solve((Kz + jitter * ident)[None], Kzx))
+        else:
+            Cs.append(np.linalg.solve(Kz + jitter * ident, _cross(kd.k.l, kd.z, xr)))
         As.append(np.stack([np.kron(ident, Ai) for Ai in A_t]))
         as_.append(np.stack([np.tile(ai, M) for ai in a_t]))
         Qs.append(np.stack([np.kron(Kz, Qi) for Qi in Q_t]))
@@ -87,17 +93,17 @@ def lgssm_components(k_dtc, grid, x_space=None, jitter=1e-12):
     a = _stack(as_, np.concatenate)
     Q = _stack(Qs, lambda bs: block_diag(*bs))
     Hb = _stack(Hbs, lambda bs: block_diag(*bs))
-    Ct = np.concatenate(Cs, axis=0).T
+    Ct = np.swapaxes(np.concatenate(Cs, axis=1), 1, 2) if ragged else np.concatenate(Cs, axis=0).T      # ragged: (T, nmax, Mtot)
     return A, a, Q, (Ct, Hb, np.zeros((1, Hb.shape[1]))), (np.concatenate(ms), block_diag(*Ps))
 
 
 def kernel_diagonals(k_dtc, grid, x_space=None):
     """pseudo_point.jl:83-105: prior variances at the grid points, (T, N)."""
-    xr = grid.xl if x_space is None else np.asarray(x_space, dtype=np.float64)
     T = len(grid.xr)
-    out = np.zeros((T, len(xr)))
+    n = grid.shape2[1] if x_space is None else len(np.asarray(x_space).reshape(-1))      # (stationary kernels: k(x, x) is the same at every point)
+    out = np.zeros((T, n))
     for s, kd in _terms(k_dtc):
-        out += s * float(S_kappa0(kd.k.r)) * ST.kappa(kd.k.l, np.zeros(len(xr)))[None, :]
+        out += s * float(S_kappa0(kd.k.r)) * ST.kappa(kd.k.l, np.zeros(n))[None, :]
     return out
 
 
@@ -110,7 +116,9 @@ def S_kappa0(k_time):
 def _noise(grid, sigma2s):
     T, N = grid.shape2
     s = np.asarray(sigma2s, dtype=np.float64)
-    return np.full((1, N), float(s)) if s.ndim == 0 else s.reshape(T, N)
+    if s.ndim == 0:
+        return np.full((1, N), float(s))
+    return grid.pad(s, 1.0) if isinstance(grid, ST.RegularInTime) else s.reshape(T, N)
 
 
 def build_lgssm(k, grid, z, sigma2s, device=0):
@@ -118,13 +126,15 @@ def build_lgssm(k, grid, z, sigma2s, device=0):
     k_dtc = dtcify(z, k)
     A, a, Q, (Ct, Hb, hb), (m0, P0) = lgssm_components(k_dtc, grid)
     T, N = grid.shape2
-    fan_out = L.LargeOutputLGC(Ct[None], np.zeros((1, N)), _noise(grid, sigma2s))
+    fan_out = L.LargeOutputLGC(Ct if Ct.ndim == 3 else Ct[None], np.zeros((1, N)), _noise(grid, sigma2s))
     trans = L.GaussMarkovModel(L.Forward, A, a, Q, L.Gaussian(m0, P0))
     return L.LGSSM(trans, L.BottleneckLGC(Hb, hb, fan_out), T=T, device=device)
 
 
 def _obs(grid, y):
     T, N = grid.shape2
+    if isinstance(grid, ST.RegularInTime):
+        return grid.pad(y, np.nan)                                # the padding slots are missing observations
     return np.asarray(y, dtype=np.float64).reshape(T, N)        # NaN == missing
 
 

@@ -85,6 +85,53 @@ class RectilinearGrid:
         return len(self.xr), len(self.xl)      # (T, Nr): observations reshape to this, row-major
 
 
+class RegularInTime:
+    """regular_in_time.jl:8-89: several observations at each of a collection of time slices, a DIFFERENT number (and different
+    locations) per slice allowed. ts: the times (RegularSpacing or array), vs: one array of spatial points per time.
+    Flat order of observations / noise variances: slice after slice (`collect`, regular_in_time.jl:22-26).
+    The device path has a fixed number of observations per step: slices are padded to the longest one, the padding marked missing
+    (`pad` / `pad_mask`), which is exactly marginalising it out (missings.jl:8-33)."""
+
+    def __init__(self, ts, vs):
+        self.xr = ts
+        self.vs = [np.asarray(v, dtype=np.float64).reshape(-1) for v in vs]
+        if len(self.vs) != len(ts):
+            raise ValueError("RegularInTime: one array of spatial points per time")
+        self.lengths = np.array([len(v) for v in self.vs])
+        self.nmax = int(self.lengths.max())
+
+    def __len__(self):
+        return int(self.lengths.sum())
+
+    @property
+    def shape2(self):
+        return len(self.vs), self.nmax
+
+    @property
+    def pad_mask(self):
+        """(T, nmax) True where a slot holds no observation"""
+        return np.arange(self.nmax)[None, :] >= self.lengths[:, None]
+
+    def pad(self, flat, fill):
+        """observations_to_time_form / noise_var_to_time_form (regular_in_time.jl:53-63), then padded to (T, nmax)"""
+        flat = np.asarray(flat, dtype=np.float64).reshape(-1)
+        if flat.size != len(self):
+            raise ValueError(f"expected {len(self)} values (one per observation), got {flat.size}")
+        out = np.full(self.shape2, fill, dtype=np.float64)
+        out[~self.pad_mask] = flat
+        return out
+
+    def unpad(self, padded):
+        """destructure (regular_in_time.jl:65): back to the flat order"""
+        return np.asarray(padded)[~self.pad_mask]
+
+    def points(self, fill=0.0):
+        """(T, nmax) spatial points, padding slots at `fill`"""
+        out = np.full(self.shape2, fill, dtype=np.float64)
+        out[~self.pad_mask] = np.concatenate(self.vs)
+        return out
+
+
 def lgssm_components(k, grid):
     """to_gauss_markov.jl:1-20."""
     Kr = kernelmatrix(k.l, grid.xl)

@@ -78,8 +78,16 @@ def test_vector_obs_dense_noise_whitened(tgp, tv):
     ym[missing] = np.nan
     lpm = ref.logpdf_missing(model, y, missing)
     assert abs(tgp.logpdf(dm, ym) - lpm) <= 1e-10 * abs(lpm)
-    with pytest.raises(NotImplementedError):
-        tgp.marginals(dm)
+    # prior marginals and samples do not involve the update: the correlated noise enters additively (lgc.jl:46-52, :84-87)
+    mm, mC = ref.marginals(model)
+    gm, gv = tgp.marginals(dm)
+    np.testing.assert_allclose(gm, mm, rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(gv, np.diagonal(mC, axis1=-2, axis2=-1), rtol=1e-9, atol=1e-9)       # marginals_diag (lgssm.jl:128-137)
+    eps = (rng.standard_normal((T, d)), rng.standard_normal((T, p)), rng.standard_normal(d))
+    np.testing.assert_allclose(tgp.rand(eps, dm), ref.rand(model, *eps), rtol=1e-9, atol=1e-9)
+    import torch
+    eps_dev = (torch.as_tensor(eps[0], device="cuda:0"), torch.as_tensor(eps[1], device="cuda:0"), eps[2])
+    np.testing.assert_allclose(tgp.rand(eps_dev, dm).cpu().numpy(), ref.rand(model, *eps), rtol=1e-9, atol=1e-9)
 
 
 @pytest.mark.parametrize("per_element", [False, True])
@@ -115,6 +123,12 @@ def test_small_output_p1_dense_noise_is_whitened(tgp):
     m, P = tgp._filter(dm, y)
     np.testing.assert_allclose(m, fm, rtol=1e-8, atol=1e-9)
     np.testing.assert_allclose(P, fP, rtol=1e-8, atol=1e-9)
+    mm, mC = ref.marginals(model)
+    gm, gv = tgp.marginals(dm)
+    np.testing.assert_allclose(np.asarray(gm).reshape(T), mm.reshape(T), rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(np.asarray(gv).reshape(T), mC.reshape(T), rtol=1e-9, atol=1e-9)
+    eps = (rng.standard_normal((T, d)), rng.standard_normal((T, p)), rng.standard_normal(d))
+    np.testing.assert_allclose(np.asarray(tgp.rand(eps, dm)).reshape(T), np.asarray(ref.rand(model, *eps)).reshape(T), rtol=1e-9, atol=1e-9)
 
 
 def test_dense_noise_with_observations_on_the_device(tgp):

@@ -130,3 +130,46 @@ def test_gpu_dtc_long_series_with_missing_against_oracle_statespace():
     assert abs(got - want) <= 1e-6 * abs(want)
     want_e = oc.elbo_statespace(terms, z, r, t, 0.2, y)
     assert abs(pp.elbo(k, grid, 0.2, y, z) - want_e) <= 1e-6 * abs(want_e)
+
+
+@pytest.mark.gpu
+def test_gpu_regular_in_time_with_ragged_slices_equals_the_grid_with_those_points_missing():
+    """RegularInTime (regular_in_time.jl:8-89) with a different number of points, at different places, per time slice: the slices are
+    padded to the longest one and the padding marked missing. Identity the reference's tests rest on (missing == marginalised,
+    test/models/missings.jl:94-115): dtc, elbo and the approximate posterior marginals of the ragged data set equal those of the
+    full rectilinear grid whose absent points are missing -- the oracle's literal BottleneckLGC recursion on that grid."""
+    from temporalgps_jl_amd import lti_sde as S
+    from temporalgps_jl_amd import pseudo_point as pp
+    from temporalgps_jl_amd import space_time as ST
+    terms = [(0.8, ("se",), ("matern32",)), (0.3, ("se",), ("matern12",))]
+    rng = np.random.default_rng(12)
+    N, M, T = 9, 3, 80
+    r, z = np.sort(rng.standard_normal(N)), np.linspace(-1.2, 1.2, M)
+    t = ("regular", 0.0, 0.15, T)
+    keep = rng.random((T, N)) < 0.7
+    keep[5] = False                       # a time slice with no observation at all
+    keep[6, :] = True
+    y_full = rng.standard_normal((T, N))
+    sig_full = 0.1 + 0.2 * rng.random((T, N))
+    k = _product_kernel(terms)
+    times = S.RegularSpacing(0.0, 0.15, T)
+    ragged = ST.RegularInTime(times, [r[keep[i]] for i in range(T)])
+    assert len(ragged) == keep.sum() and ragged.shape2 == (T, N)
+    y_r, sig_r = y_full[keep], sig_full[keep]              # flat, slice after slice
+    want = oc.dtc_statespace(terms, z, r, t, sig_full.reshape(-1), y_full.reshape(-1), missing=(~keep).reshape(-1))
+    got = pp.dtc(k, ragged, sig_r, y_r, z)
+    assert abs(got - want) <= 1e-8 * abs(want)
+    # the same through the rectilinear-grid code path with NaN == missing (the padding changes nothing but the slots' positions)
+    grid = ST.RectilinearGrid(r, times)
+    ym = np.where(keep, y_full, np.nan)
+    assert abs(pp.dtc(k, grid, sig_full, ym, z) - want) <= 1e-8 * abs(want)
+    e_grid = pp.elbo(k, grid, sig_full, ym, z)
+    e_ragged = pp.elbo(k, ragged, sig_r, y_r, z)
+    assert abs(e_ragged - e_grid) <= 1e-8 * abs(e_grid)
+    x_pr = np.array([-0.9, 0.05, 0.7, 1.4])
+    m_g, v_g = pp.approx_posterior_marginals(k, grid, sig_full, ym, z, x_pr)
+    m_r, v_r = pp.approx_posterior_marginals(k, ragged, sig_r, y_r, z, x_pr)
+    np.testing.assert_allclose(m_r, m_g, rtol=0, atol=1e-8)
+    np.testing.assert_allclose(v_r, v_g, rtol=0, atol=1e-8)
+    # flat <-> time form round trip (regular_in_time.jl:53-65)
+    np.testing.assert_array_equal(ragged.unpad(ragged.pad(y_r, np.nan)), y_r)
