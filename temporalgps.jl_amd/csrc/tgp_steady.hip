@@ -729,7 +729,8 @@ __device__ __forceinline__ int filter_cov_lds(const ModelDev& m, const Tab& tb, 
     const bool act = lane < DD;
     const int e = act ? lane : 0;
     const int i = e / D, j = e % D;
-    double Ai[D], Aj[D], hv[D], Arow[D];
+    __shared__ double sKA[D], sV[D];
+    double Ai[D], Aj[D], hv[D];
 #pragma unroll
     for (int k = 0; k < D; ++k) {
         Ai[k] = m.A[i + k * D];
@@ -760,30 +761,30 @@ __device__ __forceinline__ int filter_cov_lds(const ModelDev& m, const Tab& tb, 
         if (act) sPp[e] = pp;
         lds_sync();
         double V[D], S = 0.0;
+        {
+            double v = 0.0;                                                      // V = H * Pp: lane (0, k) forms V_k, everybody reads the d values
+#pragma unroll
+            for (int l = 0; l < D; ++l) v = fma(hv[l], sPp[l * D + j], v);
+            if (act && i == 0) sV[j] = v;
+        }
+        lds_sync();
 #pragma unroll
         for (int k = 0; k < D; ++k) {
-            double v = 0.0;
-#pragma unroll
-            for (int l = 0; l < D; ++l) v = fma(hv[l], sPp[l * D + k], v);      // V = H * Pp
-            V[k] = v;
-            S = fma(v, hv[k], S);
+            V[k] = sV[k];
+            S = fma(V[k], hv[k], S);
         }
         S += R;
         bad = bad || !(S > 0.0);
         const double iS = 1.0 / S, rs = 1.0 / sqrt(S);
         const double Pn = pp - (V[i] * rs) * (V[j] * rs);
-        // (every lane needs the whole stationary kA afterwards: rows of A from memory, d^2 multiply-adds, only d of them new per lane)
+        // the step's gain row by row: lane (i, 0) owns (A K)_i (its own row of A is in registers); the lanes pick up the whole
+        // stationary vector once, behind the loop (a d x d product and d^2 loads of A per step in EVERY lane cost a third of the step)
+        double kAi = 0.0;
 #pragma unroll
-        for (int r = 0; r < D; ++r) {
-#pragma unroll
-            for (int k = 0; k < D; ++k) Arow[k] = (r == i) ? Ai[k] : ((r == j) ? Aj[k] : m.A[r + k * D]);
-            double v = 0.0;
-#pragma unroll
-            for (int k = 0; k < D; ++k) v = fma(Arow[k], V[k] * iS, v);
-            kAss[r] = v;
-        }
+        for (int k = 0; k < D; ++k) kAi = fma(Ai[k], V[k] * iS, kAi);
+        if (act && j == 0) sKA[i] = kAi;
         if (t < nhmax) {
-            if (act && j == 0) tb.h_kA[t * D + i] = kAss[i];
+            if (act && j == 0) tb.h_kA[t * D + i] = kAi;
             if (lane == 0) {
                 tb.h_rS[t] = R * iS;
                 tb.h_iS[t] = iS;
@@ -815,6 +816,9 @@ __device__ __forceinline__ int filter_cov_lds(const ModelDev& m, const Tab& tb, 
         if (conv) tc = t;
     }
     LS += log(prod);
+    lds_sync();
+#pragma unroll
+    for (int r = 0; r < D; ++r) kAss[r] = sKA[r];            // (the last step's: the stationary one when the loop ended by convergence)
     if (n0 < 0) return n0;
     __threadfence_block();
     __syncthreads();
