@@ -13,22 +13,52 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
 
 
+CMAGIC = b"CCOB"      # compressed bundle (--offload-compress): magic, u16 version, u16 method, then (v2: u32, v3: u64) total size, ...
+
+
+def _bundle_entries(data, i):
+    n = struct.unpack_from("<Q", data, i + 24)[0]
+    q = i + 32
+    out = []
+    for _ in range(n):
+        off, size, tl = struct.unpack_from("<QQQ", data, q)
+        triple = data[q + 24:q + 24 + tl].decode()
+        q += 24 + tl
+        if "gfx950" in triple and size:
+            out.append(data[i + off:i + off + size])
+    return out
+
+
 def code_objects(path):
+    """every gfx950 code object of a fat binary: plain offload bundles are parsed here; zstd-compressed ones (CCOB) are cut out
+    and handed to clang-offload-bundler, which unpacks them"""
     data = open(path, "rb").read()
     out, pos = [], 0
     while True:
         i = data.find(MAGIC, pos)
         if i < 0:
-            return out
-        n = struct.unpack_from("<Q", data, i + 24)[0]
-        q = i + 32
-        for _ in range(n):
-            off, size, tl = struct.unpack_from("<QQQ", data, q)
-            triple = data[q + 24:q + 24 + tl].decode()
-            q += 24 + tl
-            if "gfx950" in triple and size:
-                out.append(data[i + off:i + off + size])
+            break
+        out += _bundle_entries(data, i)
         pos = i + 24
+    pos = 0
+    while True:
+        i = data.find(CMAGIC, pos)
+        if i < 0:
+            break
+        ver = struct.unpack_from("<H", data, i + 4)[0]
+        total = struct.unpack_from("<Q", data, i + 8)[0] if ver >= 3 else struct.unpack_from("<I", data, i + 8)[0]
+        if ver not in (1, 2, 3) or total <= 24 or i + total > len(data):
+            pos = i + 4
+            continue
+        with tempfile.TemporaryDirectory() as td:
+            src, dst = os.path.join(td, "in.bundle"), os.path.join(td, "out.co")
+            open(src, "wb").write(data[i:i + total])
+            r = subprocess.run([f"{LLVM}/clang-offload-bundler", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={src}",
+                                f"--output={dst}", "--unbundle"], capture_output=True, text=True)
+            if r.returncode == 0 and os.path.exists(dst) and os.path.getsize(dst):
+                out.append(open(dst, "rb").read())
+        pos = i + total
+    return out
 
 
 def kernels(blob):

@@ -225,3 +225,23 @@ def test_segments_the_stationary_gain_engine_cannot_take_fall_back_to_the_genera
     assert not any(n.startswith("k_steady") for n in names)
     lp_ref = ref.logpdf_missing(model, y, mask)
     assert abs(lp - lp_ref) <= LOGPDF_RTOL * abs(lp_ref)
+
+
+@pytest.mark.parametrize("dt,ndev", [(0.004, 3), (0.01, 2)])
+def test_slowly_mixing_lti_shards_take_the_scanned_carries(dt, ndev):
+    """A filter that forgets slowly (dt = 0.004 at unit length scale: Phi^4096 has NOT decayed, the covariance needs ~1000 steps to
+    settle, the head spans several tiles): the workgroup carries come from k_carry's scans, a shard's lam enters them at the ragged end
+    (G^(last workgroup's steps), the lane that owns the last element). Against the oracle, and the engine must really have served it."""
+    import temporalgps_jl_amd as tgp
+    T = 150_011
+    model = oc.build_lgssm(("matern52",), ("regular", 0.0, dt, T), 0.1)
+    rng = np.random.default_rng(71)
+    y = sk.rand(model, rng.standard_normal((T, 3)), rng.standard_normal(T), rng.standard_normal(3))
+    ms = tgp.MultiLGSSM(_dev_model(tgp, model), devices=[0] * ndev)
+    (lp, mean, var), names = _kernels_of_rank(ms, tgp, ndev - 1, lambda: ms.logpdf_and_posterior_marginals(y, np.array([0.02])))
+    assert "k_steady_shard_fold" in names and not any(n.startswith("k_reduce_filter") for n in names), names
+    lp_ref = sk.logpdf(model, y)
+    pm, pv = sk.posterior_marginals(model, y, np.array([0.02]))
+    assert abs(lp - lp_ref) <= LOGPDF_RTOL * abs(lp_ref)
+    assert np.max(np.abs(mean - pm)) <= MARGINAL_ATOL and np.max(np.abs(var - pv)) <= MARGINAL_ATOL
+    assert abs(ms.logpdf(y) - lp_ref) <= LOGPDF_RTOL * abs(lp_ref)
