@@ -112,6 +112,11 @@ typedef struct tgp_handle tgp_handle;
                            BASELINE config 1 (T = 1e4): 84 us per combined call with and without replay -- the chain is bound by
                            the dependent dispatches on the device, not by the host's enqueue -- hence off by default. Any other
                            entry point, option or model change in between drops the recording. */
+#define TGP_OPT_SDE_CLOSED_FORM 13 /* models set with tgp_model_set_sde, d <= 8: 1 (default) when the drift matrix is block diagonal with one
+                           eigenvalue per block and nilpotency <= 3 (sums of scaled / stretched Matern-1/2, -3/2, -5/2 terms), the passes
+                           evaluate A_k = exp(F dt_k) in closed form and Q_k = Pinf - A_k Pinf A_k' in registers from the 8-byte gap dt_k
+                           (lti_sde.jl:135-146) instead of reading a tiled [T][2 d^2] record three times; 0: always the tiled record
+                           (A/B timing, tests). Other drift matrices and the gradient passes use the tiled record either way. */
 #define TGP_OPT_TIMING 6 /* 1: record the hipEvents behind tgp_last_timing (off by default: ~30 us of host time per call) */
 #define TGP_OPT_FUSE_SCAN 4 /* 1 (default): the level-0 scan reduce / apply of the forward scan run inside the chunk kernels;
                                0: stand-alone k_scan_reduce / k_scan_apply launches (bit-identical results, for A/B timing) */

@@ -59,6 +59,12 @@ const KernelTable* kernel_table_d7_i();
 const KernelTable* kernel_table_d8_i();
 }  // namespace tgp_i
 
+// the per-step passes built for closed-form SDE transitions (tgp_inst_sde.hip; d <= kSdeBuildMaxD): same struct layouts, other namespace
+namespace tgp_s {
+struct KernelTable;
+const KernelTable* sde_kernel_table(int d);
+}  // namespace tgp_s
+
 using namespace tgp;
 
 static const KernelTable* fast_kernel_table(int d) {
@@ -148,6 +154,21 @@ __global__ __launch_bounds__(256) void k_tile_model(ModelView raw, int d, uint32
     const int Lt = L0 / raw.p;
     for (int tl = 0; tl < Lt; ++tl) tile_transition(raw, d, mask, nc_t, Lt, c, tl, tile_t);
     for (int i = 0; i < L0; ++i) tile_emission(raw, d, mask, nc_e, L0, c, i, tile_e);
+}
+
+// closed-form SDE transitions (ModelView::sde): the transition record is the step's tau alone, in processing order
+// (tau < 0 marks the first transition; the skipped predict of a Reverse model's first processing step gets 0)
+__global__ __launch_bounds__(256) void k_tile_dt(const double* __restrict__ times, int64_t Tt, int ordering, int Lt, int64_t n0, double* __restrict__ tile_t) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= n0) return;
+    for (int tl = 0; tl < Lt; ++tl) {
+        const int64_t tproc = c * (int64_t)Lt + tl;
+        if (tproc >= Tt) break;
+        const int64_t tt = ordering == 0 ? tproc : Tt - tproc;
+        double tau = 0.0;
+        if (!(ordering != 0 && tproc == 0)) tau = (tt == 0) ? -1.0 : times[tt] - times[tt - 1];
+        tile_t[fs_index(c, tl, 0, Lt, 1)] = tau;
+    }
 }
 
 // gradient pass: partial[4b + 0..3] -> result[0] lml (+ missing compensation), [1] n missing, [2] bad, [3] d lml / d theta
@@ -247,8 +268,10 @@ struct tgp_handle {
     int tile_L0 = 0;
     // SDE-described transitions (tgp_model_set_sde): A_k, Q_k are built on the device from the time stamps
     bool sde = false;
-    DevBuf bF, bPinf, btimes, bAQ1;
+    DevBuf bF, bPinf, btimes, bAQ1, bsde;
     bool have_AQ1 = false;
+    bool sde_closed = false;     // the drift matrix has the closed-form exponential of ModelView::sde (bsde holds the coefficients)
+    bool tile_is_dt = false;     // the transition record currently holds tau alone (value passes); false: A_k, Q_k (gradient passes, d > kSdeInKernelMaxD)
     const double* times_dev = nullptr;
     double normF = 0.0;
     const KernelTable* kt = nullptr;   // -> ktm when the inlined and out-of-line builds are mixed entry by entry
@@ -292,6 +315,7 @@ struct tgp_handle {
     // within the head tables, the series is longer than head + tail) is decided on the device inside every call; a call that finds it
     // does not is re-run on the general path and the bound model is remembered as such (steady2_state = -1).
     int opt_steady2 = 1;
+    bool opt_sde_closed = true;
     tgp_steady::Engine* steady2 = nullptr;
     int steady2_state = 0;       // 0 untried for the bound model, 1 served the last call, -1 does not apply
     bool steady2_last = false;   // the last logpdf / posterior-marginals call was served by it
@@ -492,7 +516,9 @@ void choose_chunk(tgp_handle* h, int for_mode = -1) {
         const int64_t round = 256LL * 256, Tm0 = h->T * h->p;
         // (round 2, T = 1e7, d = 3: logpdf alone 0.270 ms at k = 1 against 0.245 ms at k = 2 -- its two passes run two workgroups per CU;
         //  the combined call is the same either way. LTI layout only: a per-step model would be re-tiled at every change of L0.)
-        const int64_t kmin = (h->d <= 2 || (h->d == 3 && for_mode == 0 && h->lti)) ? 2 : 1;
+        // (closed-form SDE transitions at d = 3: passes capped at 256 registers, two workgroups per CU -- T = 1e7 combined call 1.49 -> 1.34 ms)
+        const bool sde_cf3 = h->d == 3 && h->sde && h->sde_closed && h->opt_sde_closed;
+        const int64_t kmin = (h->d <= 2 || (h->d == 3 && for_mode == 0 && h->lti) || sde_cf3) ? 2 : 1;
         int64_t k = (Tm0 + round * 160 - 1) / (round * 160);
         if (k < kmin) k = kmin;
         L0 = (Tm0 + round * k - 1) / (round * k);
@@ -777,16 +803,22 @@ int graph_call(tgp_handle* h, int slot, const uint64_t (&key)[8], Body&& body, d
 }
 
 // General (per-step) layout: (re)build the time-tiled copy of the per-step arrays for the current chunk size.
-int ensure_tiled(tgp_handle* h) {
+// full: the transition record must hold A_k, Q_k themselves (the gradient passes read them beside their tangents)
+int ensure_tiled(tgp_handle* h, bool full = false) {
     if (h->lti) return TGP_OK;
-    if (h->tile_L0 == h->L0 && h->mv.tile_mask != 0u) return TGP_OK;
+    const bool dt_mode = h->sde && h->sde_closed && !full && h->opt_sde_closed;
+    if (h->tile_L0 == h->L0 && h->mv.tile_mask != 0u && h->tile_is_dt == dt_mode) return TGP_OK;
     uint32_t mask = tile_mask_of(h->raw);
-    if (h->sde) mask |= kTileA | kTileQ;          // A, Q come from k_tile_sde, not from raw arrays
+    if (h->sde) mask |= dt_mode ? kTileDt : (kTileA | kTileQ);          // A, Q come from the time stamps, not from raw arrays
     const int nc_t = tile_offset_t(mask, 0u, h->d), nc_e = tile_offset_e(mask, 0u, h->d);
     const size_t nblk = (size_t)((h->n0 + 63) / 64) * 64;
     HIPCHK(h->tile_t.ensure((nblk * (size_t)(h->L0 / h->p) * (size_t)nc_t + 1) * sizeof(double)));
     HIPCHK(h->tile_e.ensure((nblk * (size_t)h->L0 * (size_t)nc_e + 1) * sizeof(double)));
-    if (h->sde) {
+    if (dt_mode) {
+        LaunchScope ls(h, "k_tile_dt");
+        hipLaunchKernelGGL(k_tile_dt, dim3((unsigned)((h->n0 + 255) / 256)), dim3(256), 0, h->stream, h->times_dev, h->T, h->ordering, h->L0 / h->p, h->n0,
+                           h->tile_t.d());
+    } else if (h->sde) {
         LaunchScope ls(h, "k_tile_sde");
         h->kt->tile_sde(h->bF.d(), h->bPinf.d(), h->times_dev, h->have_AQ1 ? h->bAQ1.d() : nullptr, h->T, h->ordering, h->L0 / h->p, h->n0, h->normF, h->tile_t.d(), h->stream);
     }
@@ -794,9 +826,27 @@ int ensure_tiled(tgp_handle* h) {
         LaunchScope ls(h, "k_tile_model");
         // in SDE mode the transition record is already written: tile only the (optional) per-step emission arrays
         hipLaunchKernelGGL(k_tile_model, dim3((unsigned)((h->n0 + 255) / 256)), dim3(256), 0, h->stream, h->raw, h->d,
-                           h->sde ? (mask & ~(kTileA | kTilea | kTileQ)) : mask, h->sde ? 0 : nc_t, nc_e, h->L0, h->n0, h->tile_t.d(),
+                           h->sde ? (mask & ~(kTileA | kTilea | kTileQ | kTileDt)) : mask, h->sde ? 0 : nc_t, nc_e, h->L0, h->n0, h->tile_t.d(),
                            h->tile_e.d());
     }
+    h->tile_is_dt = dt_mode;
+    if (h->sde && h->d <= kSdeBuildMaxD) {     // d <= 4: the passes that evaluate the transitions are a build of their own
+        const KernelTable* base = kernel_table(h->d);
+        const KernelTable* cf = dt_mode ? reinterpret_cast<const KernelTable*>(tgp_s::sde_kernel_table(h->d)) : nullptr;
+        if (cf) {
+            h->ktm = *base;
+            h->ktm.reduce_filter = cf->reduce_filter;
+            for (int m = 0; m < 4; ++m) h->ktm.apply_filter_m[m] = cf->apply_filter_m[m];
+            h->ktm.smooth = cf->smooth;
+            h->ktm.reduce_affine = cf->reduce_affine;
+            h->ktm.apply_affine = cf->apply_affine;
+            h->kt = &h->ktm;
+        } else {
+            h->kt = base;
+        }
+    }
+    h->mv.sde = dt_mode ? h->bsde.d() : nullptr;
+    h->mv.sde_first = h->have_AQ1 ? 1 : 0;
     h->mv.tile_t = h->tile_t.d();
     h->mv.tile_e = h->tile_e.d();
     h->mv.nc_t = nc_t;
@@ -1122,7 +1172,7 @@ int tgp_destroy(tgp_handle* h) {
     }
     drop_graphs(h);
     for (DevBuf* b : {&h->bA, &h->ba, &h->bQ, &h->bH, &h->bh, &h->bR, &h->bx0, &h->bx0r, &h->bx0fold, &h->by, &h->bmiss, &h->bRnew, &h->beps_t,
-                      &h->beps_e, &h->bo1, &h->bo2, &h->bo3, &h->F.slab, &h->Rv.slab, &h->fs, &h->partial, &h->result, &h->segtmp, &h->tile_t, &h->tile_e, &h->Fad.slab, &h->btan, &h->bx0ad, &h->tile_tan, &h->balt, &h->bF, &h->bPinf, &h->btimes, &h->bAQ1, &h->ftab})
+                      &h->beps_e, &h->bo1, &h->bo2, &h->bo3, &h->F.slab, &h->Rv.slab, &h->fs, &h->partial, &h->result, &h->segtmp, &h->tile_t, &h->tile_e, &h->Fad.slab, &h->btan, &h->bx0ad, &h->tile_tan, &h->balt, &h->bF, &h->bPinf, &h->btimes, &h->bAQ1, &h->bsde, &h->ftab})
         b->release();
     for (auto& e : h->ev)
         if (e) (void)hipEventDestroy(e);
@@ -1190,6 +1240,12 @@ int tgp_set_option(tgp_handle* h, int option, int64_t value) {
         h->opt_steady2 = value == 2;
         h->steady2_state = 0;
         h->steady_known = false;
+        h->smoother_valid = false;
+        return TGP_OK;
+    }
+    if (option == TGP_OPT_SDE_CLOSED_FORM) {
+        h->opt_sde_closed = value != 0;
+        h->reduce_valid = false;
         h->smoother_valid = false;
         return TGP_OK;
     }
@@ -1389,6 +1445,77 @@ int tgp_model_set(tgp_handle* h, int64_t T, int d, int p, int ordering, uint32_t
     return TGP_OK;
 }
 
+// Does exp(F tau) have the closed form of ModelView::sde? The indices split into the connected components of F's sparsity pattern; a
+// component S qualifies when F_SS = -lambda I + N with N^min(|S|, 3) = 0 (one eigenvalue, nilpotency <= 3: what Matern-1/2, -3/2 and
+// -5/2 terms and their scaled / stretched sums produce; lambda = 0 covers integrated white noise). Rows of one component must be
+// contiguous (the loader shares one exponential between neighbouring rows of equal lambda, so equal lambdas of DIFFERENT components
+// are fine too: the exponential is the same number). coef <- [lambda per row | N | N^2 / 2 | Pinf (symmetrised) | A1 | Q1].
+static bool sde_closed_form(int d, const double* F, const double* Pinf, const double* A1, const double* Q1, std::vector<double>& coef) {
+    std::vector<int> comp(d);
+    for (int i = 0; i < d; ++i) comp[i] = i;
+    auto find = [&](int i) { while (comp[i] != i) i = comp[i] = comp[comp[i]]; return i; };
+    for (int j = 0; j < d; ++j)
+        for (int i = 0; i < d; ++i)
+            if (i != j && F[i + j * d] != 0.0) comp[find(i)] = find(j);
+    for (int i = 0; i < d * d; ++i)
+        if (!std::isfinite(F[i])) return false;
+    std::vector<double> lam(d, 0.0), N((size_t)d * d, 0.0), N2((size_t)d * d, 0.0);
+    std::vector<char> seen(d, 0);
+    for (int r = 0; r < d; ++r) {
+        const int root = find(r);
+        if (seen[root]) continue;
+        seen[root] = 1;
+        std::vector<int> S;
+        for (int i = 0; i < d; ++i)
+            if (find(i) == root) S.push_back(i);
+        const int n = (int)S.size();
+        if (n > 3 || S.back() - S.front() != n - 1) return false;
+        double tr = 0.0;
+        for (int i : S) tr += F[i + i * d];
+        const double l = -tr / n;
+        std::vector<double> Nb((size_t)n * n), Nb2((size_t)n * n, 0.0), Nb3((size_t)n * n, 0.0), Ab((size_t)n * n), Ab2((size_t)n * n, 0.0), Ab3((size_t)n * n, 0.0);
+        for (int jj = 0; jj < n; ++jj)
+            for (int ii = 0; ii < n; ++ii) {
+                Nb[ii + jj * n] = F[S[ii] + S[jj] * d] + (ii == jj ? l : 0.0);
+                Ab[ii + jj * n] = std::fabs(F[S[ii] + S[jj] * d]) + (ii == jj ? std::fabs(l) : 0.0);
+            }
+        for (int jj = 0; jj < n; ++jj)
+            for (int ii = 0; ii < n; ++ii)
+                for (int k = 0; k < n; ++k) {
+                    Nb2[ii + jj * n] += Nb[ii + k * n] * Nb[k + jj * n];
+                    Ab2[ii + jj * n] += Ab[ii + k * n] * Ab[k + jj * n];
+                }
+        for (int jj = 0; jj < n; ++jj)
+            for (int ii = 0; ii < n; ++ii)
+                for (int k = 0; k < n; ++k) {
+                    Nb3[ii + jj * n] += Nb2[ii + k * n] * Nb[k + jj * n];
+                    Ab3[ii + jj * n] += Ab2[ii + k * n] * Ab[k + jj * n];
+                }
+        // N^n must vanish: to rounding, measured against the size of the terms that cancel in it (the same product of absolute values)
+        const std::vector<double>& top = n == 1 ? Nb : (n == 2 ? Nb2 : Nb3);
+        const std::vector<double>& mag = n == 1 ? Ab : (n == 2 ? Ab2 : Ab3);
+        double mmax = 0.0;
+        for (double v : mag) mmax = std::max(mmax, v);
+        for (double v : top)
+            if (!(std::fabs(v) <= 1e-13 * mmax)) return false;
+        for (int ii = 0; ii < n; ++ii) lam[S[ii]] = l;
+        for (int jj = 0; jj < n; ++jj)
+            for (int ii = 0; ii < n; ++ii) {
+                N[S[ii] + S[jj] * d] = n >= 2 ? Nb[ii + jj * n] : 0.0;
+                N2[S[ii] + S[jj] * d] = n >= 3 ? 0.5 * Nb2[ii + jj * n] : 0.0;
+            }
+    }
+    coef.assign((size_t)d + 5 * (size_t)d * d, 0.0);
+    double* q = coef.data();
+    for (int i = 0; i < d; ++i) q[i] = lam[i];
+    for (int i = 0; i < d * d; ++i) { q[d + i] = N[i]; q[d + d * d + i] = N2[i]; }
+    for (int j = 0; j < d; ++j)
+        for (int i = 0; i < d; ++i) q[d + 2 * d * d + i + j * d] = 0.5 * (Pinf[i + j * d] + Pinf[j + i * d]);
+    if (A1 && Q1)
+        for (int i = 0; i < d * d; ++i) { q[d + 3 * d * d + i] = A1[i]; q[d + 4 * d * d + i] = Q1[i]; }
+    return true;
+}
+
 int tgp_model_set_sde(tgp_handle* h, int64_t T, int d, int ordering, uint32_t flags, const double* F, const double* a, const double* H,
                       const double* hh, const double* R, const double* times, const double* A1, const double* Q1, const double* x0m,
                       const double* x0P) {
@@ -1427,6 +1554,17 @@ int tgp_model_set_sde(tgp_handle* h, int64_t T, int d, int ordering, uint32_t fl
     }
     h->normF = nrm;
     h->sde = true;
+    h->sde_closed = false;
+    h->tile_is_dt = false;
+    if (d <= kSdeInKernelMaxD) {
+        std::vector<double> coef;
+        if (sde_closed_form(d, F, x0P, h->have_AQ1 ? A1 : nullptr, h->have_AQ1 ? Q1 : nullptr, coef)) {
+            HIPCHK(h->bsde.ensure(coef.size() * sizeof(double)));
+            HIPCHK(hipMemcpyAsync(h->bsde.p, coef.data(), coef.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            h->sde_closed = true;
+        }
+    }
     h->lti = false;        // transitions are per-step (tiled), whatever the emission flags say
     h->tile_L0 = 0;
     return TGP_OK;
@@ -2084,7 +2222,7 @@ int tgp_logpdf_grad_sde(tgp_handle* h, const double* y, const uint8_t* missing, 
     tm.inputs_done();
     h->group_active = false;
     choose_chunk(h);
-    TRY(ensure_tiled(h));                       // the value tile (k_tile_sde) for this chunk size
+    TRY(ensure_tiled(h, /*full=*/true));        // the value tile (k_tile_sde) for this chunk size
     h->reduce_valid = false;
     h->smoother_valid = false;
     const int Lt = h->L0;

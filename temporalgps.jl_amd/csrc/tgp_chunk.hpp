@@ -54,6 +54,14 @@ struct ModelView {
     // upper triangles of the two filtering covariances the chunk alternates between from there on. Non-null enables the
     // mean-only steps of passes 2 and 3 (the API sets it for shared-layout models with one shared R, p = 1, no missing data, d <= 4).
     double* steady;
+    // Closed-form SDE transitions (tile_mask & kTileDt; the API sets it for models given by tgp_model_set_sde whose drift matrix is
+    // block diagonal with ONE eigenvalue -lambda_b per block and nilpotency <= 3 -- sums of scaled / stretched Matern-1/2, -3/2, -5/2
+    // terms): the transition record holds ONE double per step, tau_k = t_k - t_{k-1} (< 0: the first transition), and the loader
+    // evaluates A_k = exp(F tau_k) = e^{-lambda tau} (I + tau N + tau^2 / 2 N^2) per block and Q_k = Pinf - A_k Pinf A_k' in
+    // registers (lti_sde.jl:135-146) -- the passes stream 8 B per step instead of 16 d^2.
+    //   sde = [ lambda per row: d | N: d^2 | N^2 / 2: d^2 | Pinf: d^2 | A1: d^2 | Q1: d^2 ]   (column-major, wave-uniform loads)
+    const double* sde;
+    int32_t sde_first;   // 1: the first transition is (A1, Q1) as given; 0: the reference's dt_1 := 1
 };
 
 // Wave-level helpers of the stationary-covariance steps: a vote over the ACTIVE lanes of the wave, and a wave-uniform integer
@@ -85,11 +93,17 @@ TGP_HD void set_real(Dual& x, const double* v, const double* d, int i) { x = Dua
 TGP_HD void tile_real(double& x, const double* v, const double*, int64_t i) { x = v[i]; }
 TGP_HD void tile_real(Dual& x, const double* v, const double* t, int64_t i) { x = Dual(v[i], t ? t[i] : 0.0); }
 
-enum : uint32_t { kTileA = 1u, kTilea = 2u, kTileQ = 4u, kTileH = 8u, kTileh = 16u, kTileR = 32u };
+enum : uint32_t { kTileA = 1u, kTilea = 2u, kTileQ = 4u, kTileH = 8u, kTileh = 16u, kTileR = 32u, kTileDt = 64u };
+// Largest state dimension whose per-step passes evaluate closed-form SDE transitions in registers (above it the transitions stay a tiled record)
+constexpr int kSdeInKernelMaxD = 8;
+// ... and up to this dimension by a build of the per-step passes of their own (tgp_inst_sde.hip: no run-time branch in the passes that read
+// tiled records -- measured at d = 3, T = 1e7: the branch alone cost them 8 % -- and two waves per SIMD at d = 3)
+constexpr int kSdeBuildMaxD = 4;
 
 // offsets (in doubles) inside the transition record (A, a, Q) and the emission record (H row, h, R); bit 0 => size
 TGP_HD int tile_offset_t(uint32_t mask, uint32_t bit, int d) {
     int off = 0;
+    if (mask & kTileDt) return bit == 0u ? 1 : 0;      // the record is the step's tau alone
     if (bit == kTileA) return off;
     if (mask & kTileA) off += d * d;
     if (bit == kTilea) return off;
@@ -199,6 +213,48 @@ struct FilterOut {
     double* L_out;
     double* xfin;   // MODE 3 of a Reverse-ordered prior: x0 of the posterior (the state after the last step's predict), packed
 };
+
+// The closed-form transition of one step (see ModelView::sde): tau >= 0 the gap to the previous time stamp, tau < 0 the first one.
+template <int D> TGP_HD void sde_transition(const ModelView& mv, double tau, double* A, double* Q) {
+    const double* q = mv.sde;
+    if (tau < 0.0) {
+        if (mv.sde_first) {     // (A1, Q1) as the host evaluated them (kernel algebra decides each term's own dt_1, tgp_hip.h)
+            TGP_UNROLL for (int k = 0; k < D * D; ++k) { A[k] = q[D + 3 * D * D + k]; Q[k] = q[D + 4 * D * D + k]; }
+            return;
+        }
+        tau = 1.0;              // lti_sde.jl:139
+    }
+    double e[D];
+    e[0] = ::exp(-q[0] * tau);
+    TGP_UNROLL for (int i = 1; i < D; ++i) e[i] = (q[i] == q[i - 1]) ? e[i - 1] : ::exp(-q[i] * tau);     // (wave-uniform: one exp per block)
+    const double t2 = tau * tau;
+    TGP_UNROLL for (int j = 0; j < D; ++j) {
+        TGP_UNROLL for (int i = 0; i < D; ++i) {
+            const double c = ::fma(t2, q[D + D * D + i + j * D], ::fma(tau, q[D + i + j * D], i == j ? 1.0 : 0.0));
+            A[i + j * D] = e[i] * c;
+        }
+    }
+    // Q = Pinf - A Pinf A' (upper triangle, mirrored)
+    const double* P = q + D + 2 * D * D;
+    double AP[D * D];
+    TGP_UNROLL for (int j = 0; j < D; ++j) {
+        TGP_UNROLL for (int i = 0; i < D; ++i) {
+            double acc = 0.0;
+            TGP_UNROLL for (int k = 0; k < D; ++k) acc = ::fma(A[i + k * D], P[k + j * D], acc);
+            AP[i + j * D] = acc;
+        }
+    }
+    TGP_UNROLL for (int j = 0; j < D; ++j) {
+        TGP_UNROLL for (int i = 0; i <= j; ++i) {
+            double acc = 0.0;
+            TGP_UNROLL for (int k = 0; k < D; ++k) acc = ::fma(AP[i + k * D], A[j + k * D], acc);
+            const double v = P[i + j * D] - acc;
+            Q[i + j * D] = v;
+            Q[j + i * D] = v;
+        }
+    }
+}
+template <int D> TGP_HD void sde_transition(const ModelView&, double, Dual*, Dual*) {}   // (the gradient pass reads tiled tangents instead)
 
 using real_t = double;
 #include "tgp_chunk_body.inc"

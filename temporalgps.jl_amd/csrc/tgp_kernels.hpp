@@ -354,8 +354,16 @@ __device__ __forceinline__ void block_exclusive_apply(typename M::E& e, double (
 }
 
 // ---------------------------------------------------------------- pass 1
+// Waves per SIMD the lane-per-chunk passes are compiled for. The closed-form SDE build at d = 3 sits just above 256 registers (250-318);
+// capped there, two waves share a SIMD and hide each other's dependent-FMA latency (with chunks half as long: choose_chunk). The passes that
+// read tiled records are NOT capped: measured at T = 1e7, d = 3, explicit per-step arrays, 1.62 -> 2.04 ms with the cap.
+#if defined(TGP_SDE_BUILD)
+constexpr int lane_min_waves(int D, bool steady_steps = false) { return (D == 3 && !steady_steps) ? 2 : 1; }
+#else
+constexpr int lane_min_waves(int, bool = false) { return 1; }
+#endif
 template <int D, bool LTI>
-__global__ __launch_bounds__(256) void k_reduce_filter(ModelView mv, int L0, int64_t n0, double* __restrict__ E0, double* __restrict__ E1,
+__global__ __launch_bounds__(256, lane_min_waves(D)) void k_reduce_filter(ModelView mv, int L0, int64_t n0, double* __restrict__ E0, double* __restrict__ E1,
                                                        int64_t n1) {
     using IO = WaveIO<true, true, false, false, (D <= kPrefetchMaxD)>;
     using M = FilterMonoid<D>;
@@ -444,7 +452,7 @@ __global__ __launch_bounds__(256) void k_reduce_filter_tab(ModelView mv, int L0,
 }
 
 template <int D, bool LTI, bool RAND>
-__global__ __launch_bounds__(256) void k_reduce_affine(ModelView mv, int L0, int64_t n0, const double* __restrict__ eps_t,
+__global__ __launch_bounds__(256, lane_min_waves(D)) void k_reduce_affine(ModelView mv, int L0, int64_t n0, const double* __restrict__ eps_t,
                                                        double* __restrict__ E0, int* __restrict__ bad) {
     int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (c >= n0) return;
@@ -561,7 +569,7 @@ __device__ __forceinline__ void block_sum3(double& a, double& b, int& c, double*
 
 // ---------------------------------------------------------------- pass 2
 template <int D, bool LTI, int MODE, bool ST = false>
-__global__ __launch_bounds__(256) void k_apply_filter(ModelView mv, int L0, int64_t n0, double* __restrict__ S0, const double* __restrict__ E0,
+__global__ __launch_bounds__(256, lane_min_waves(D, ST)) void k_apply_filter(ModelView mv, int L0, int64_t n0, double* __restrict__ S0, const double* __restrict__ E0,
                                                       const double* __restrict__ S1, int64_t n1, FilterOut out, double* __restrict__ R0,
                                                       double* __restrict__ partial) {
     using IO = WaveIO<true, true, false, false, (D <= kPrefetchMaxD)>;
@@ -653,7 +661,7 @@ __global__ __launch_bounds__(256) void k_apply_filter_ad(ModelView mv, int L0, i
 // RSTREAM: R_new is per-step and staged through the IO (one more LDS slot: 55 KB per block => 2 blocks per CU);
 // a shared R_new (the common case) needs only the two output slots (37 KB => 4 blocks per CU).
 template <int D, bool LTI, bool RSTREAM, bool ST = false>
-__global__ __launch_bounds__(256) void k_smooth(ModelView mv, int L0, int64_t n0, const double* __restrict__ S0, const double* __restrict__ S0r,
+__global__ __launch_bounds__(256, lane_min_waves(D, ST)) void k_smooth(ModelView mv, int L0, int64_t n0, const double* __restrict__ S0, const double* __restrict__ S0r,
                                                 const double* __restrict__ fs, const double* __restrict__ Rnew, int64_t sRn,
                                                 double* __restrict__ mean_out, double* __restrict__ var_out, int* __restrict__ bad) {
     using IO = WaveIO<false, RSTREAM, true, true, (D <= kPrefetchMaxD)>;
@@ -688,7 +696,7 @@ __global__ __launch_bounds__(256) void k_compose_smoother(ModelView mv, int L0, 
 
 // ---------------------------------------------------------------- affine pass 2
 template <int D, bool LTI, bool RAND>
-__global__ __launch_bounds__(256) void k_apply_affine(ModelView mv, int L0, int64_t n0, const double* __restrict__ S0, const double* __restrict__ eps_t,
+__global__ __launch_bounds__(256, lane_min_waves(D)) void k_apply_affine(ModelView mv, int L0, int64_t n0, const double* __restrict__ S0, const double* __restrict__ eps_t,
                                                       const double* __restrict__ eps_e, double* __restrict__ mean_out, double* __restrict__ var_out,
                                                       int* __restrict__ bad) {
     using IO = WaveIO<RAND, true, true, !RAND, (D <= kPrefetchMaxD)>;
