@@ -219,3 +219,26 @@ def test_gradient_call_between_value_calls(tgp):
     _, g_fd = P.logpdf_and_gradient(fx, y, method="fd")
     for n in g:
         assert abs(g[n] - g_fd[n]) <= 1e-5 * max(1.0, abs(g_fd[n])), (n, g[n], g_fd[n])
+
+
+@pytest.mark.parametrize("key", [5, 6, 7, 8])
+def test_per_step_noise_runs_the_kernels_of_the_per_step_verdict(tgp, key):
+    """d = 5..8 choose between two builds of the passes by a run-time known-answer check with one verdict per layout family. A model
+    bound through tgp_model_set_sde belongs to the per-step family whatever its emission flags say: until round 3 it got the LTI
+    family's verdict when the noise was per-step, and at d = 8 with more than 256 chunks ran inlined kernels the per-step check had
+    rejected (log-likelihood wrong in the fourth digit, or a spurious not-positive-definite error; scripts/stress_sde.py, seed 2).
+    No option is touched here: options re-select the table."""
+    from temporalgps_jl_amd import lti_sde as P
+    terms = SUMS[key]
+    rng = np.random.default_rng(40 + key)
+    T = 4097
+    x = np.cumsum(np.exp(rng.normal(np.log(0.1), 2.0 / 3.0, T)))
+    s2 = rng.random(T) * 0.3 + 0.02
+    y = rng.standard_normal(T)
+    lp_o = oc.gp_logpdf(_spec(terms), x, s2, y, None, None)
+    m = P.build_lgssm(_kernel(P, terms), x, s2, device_components=True)
+    lp = tgp.logpdf(m, y)
+    assert abs(lp - lp_o) <= 1e-10 * abs(lp_o), (lp, lp_o)
+    m2 = P.build_lgssm(_kernel(P, terms), x, s2, device_components=False)       # host-built per-step blocks: the same family
+    lp2 = tgp.logpdf(m2, y)
+    assert abs(lp2 - lp_o) <= 1e-10 * abs(lp_o), (lp2, lp_o)
