@@ -257,6 +257,7 @@ __global__ __launch_bounds__(256) void k_group_reduce_filter(ModelView mv, int L
                 Hj = 0.0;
                 TGP_GUNROLL for (int i = 0; i < D; ++i) Hj = (i == j) ? H[i] : Hj;
                 hh = use.hh;
+                if (mv.p > 1 && mv.sR == 0) Rsh = mv.R[jj];      // shared diagonal noise of a vector observation: row jj (group_setup left R[0])
             }
             ob.step(mv, Rsh, k, y, R, miss);
             if (do_predict) {
@@ -365,6 +366,7 @@ __global__ __launch_bounds__(256) void k_group_apply_logpdf(ModelView mv, int L0
                 Hj = 0.0;
                 TGP_GUNROLL for (int i = 0; i < D; ++i) Hj = (i == j) ? H[i] : Hj;
                 hh = use.hh;
+                if (mv.p > 1 && mv.sR == 0) Rsh = mv.R[jj];      // shared diagonal noise of a vector observation: row jj (group_setup left R[0])
             }
             ob.step(mv, Rsh, k, y, R, miss);
             if (do_predict) {

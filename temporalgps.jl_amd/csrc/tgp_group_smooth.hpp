@@ -244,6 +244,7 @@ __global__ __launch_bounds__(256) void k_group_apply_posterior(ModelView mv, int
                 Hj = 0.0;
                 TGP_GUNROLL for (int i = 0; i < D; ++i) Hj = (i == j) ? H[i] : Hj;
                 hh = st.hh;
+                if (mv.p > 1 && mv.sR == 0) Rsh = mv.R[jj];      // shared diagonal noise of a vector observation: row jj (group_setup left R[0])
             }
             ob.step(mv, Rsh, k, y, R, miss);
             if (jj == 0) {   // Forward models only: every time step predicts (at its first observation)
@@ -365,6 +366,7 @@ __global__ __launch_bounds__(256) void k_group_smooth(ModelView mv, int L0, int6
             Hj = 0.0;
             TGP_GUNROLL for (int i = 0; i < D; ++i) Hj = (i == j) ? H[i] : Hj;
             hh = st.hh;
+            if (mv.p > 1 && mv.sR == 0) Rsh = mv.R[jj];      // shared diagonal noise of a vector observation: row jj (group_setup left R[0])
         }
         // emission marginal of the smoothed state at step r with the NEW noise (lgssm.jl:111-115, missings.jl:35-41)
         double pj = 0.0;
@@ -553,6 +555,7 @@ __global__ __launch_bounds__(256) void k_group_apply_marginals(ModelView mv, int
             Hj = 0.0;
             TGP_GUNROLL for (int i = 0; i < D; ++i) Hj = (i == j) ? H[i] : Hj;
             hh = st.hh;
+            if (mv.p > 1 && mv.sR == 0) Rsh = mv.R[jj];      // shared diagonal noise of a vector observation: row jj (group_setup left R[0])
         }
         if (pred) {
             if (RAND) {

@@ -146,3 +146,41 @@ def test_dense_noise_with_observations_on_the_device(tgp):
     lpm = ref.logpdf_missing(model, y, missing)
     md = torch.as_tensor(np.repeat(missing[:, None], p, axis=1), device="cuda:0")
     assert abs(tgp.logpdf(dm, (yd, md)) - lpm) <= 1e-10 * abs(lpm)
+
+
+@pytest.mark.parametrize("d,p", [(5, 2), (6, 3), (8, 2), (9, 4), (13, 3), (16, 5)])
+@pytest.mark.parametrize("ordering", ["F", "R"])
+@pytest.mark.parametrize("per", ["A", "ah", "AaQ"])
+def test_vector_obs_partly_shared_blocks_share_the_noise_diagonal(tgp, d, p, ordering, per):
+    """Per-step transitions (or offsets) with ONE shared emission block whose noise diagonal has p different entries: the group-per-chunk
+    passes (d >= 5 in the per-step layout) took R[0] for every row of such a model until round 3 (scripts/stress_general2.py) -- the
+    all-per-step and all-shared models of the tests above never reach that branch."""
+    rng = np.random.default_rng(1000 * d + 10 * p + (ordering == "R") + len(per))
+    T = 300
+    tv = U.random_lgssm_small(rng, True, d, p, T, ordering)
+    model = dict(tv)
+    for k_ in ("A", "a", "Q", "H", "h", "R"):
+        if k_ not in per:
+            model[k_] = tv[k_][:1]
+    model["R"] = np.diag(rng.random(p) * 2.0 + 0.05)[None]              # clearly different entries
+    eps = (rng.standard_normal((T, d)), rng.standard_normal((T, p)), rng.standard_normal(d))
+    y = ref.rand(model, *eps)
+    dm = to_device(tgp, model)
+    lp = ref.logpdf(model, y)
+    assert abs(tgp.logpdf(dm, y) - lp) <= 1e-10 * abs(lp)
+    fm, fP = ref.filter_(model, y)
+    m, P = tgp._filter(dm, y)
+    np.testing.assert_allclose(m, fm, rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(P, fP, rtol=1e-8, atol=1e-9)
+    mm, mC = ref.marginals(model)
+    gm, gv = tgp.marginals(dm)
+    np.testing.assert_allclose(gm, mm, rtol=1e-10, atol=1e-11)
+    np.testing.assert_allclose(gv, np.diagonal(mC, axis1=-2, axis2=-1), rtol=1e-10, atol=1e-11)
+    np.testing.assert_allclose(tgp.rand(eps, dm), y, rtol=1e-8, atol=1e-8)
+    if ordering == "F":
+        post = ref.posterior(model, y)
+        Rn = rng.random((T, p)) * 0.1
+        pm, pC = ref.marginals(ref.replace_observation_noise_cov(post, np.stack([np.diag(v) for v in Rn])))
+        gm, gv = tgp.posterior_marginals(dm, y, Rn)
+        np.testing.assert_allclose(gm, pm, rtol=1e-8, atol=1e-8)
+        np.testing.assert_allclose(gv, np.diagonal(pC, axis1=-2, axis2=-1), rtol=1e-8, atol=1e-9)
