@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Randomised check of the in-library multi-device handle (tgp_create_multi; here 2-5 ranks on ONE GPU, copy transport) on the general
+engine's time shards: random models of d = 1..8 with every shared / per-step combination, missing data, lengths from W to 70 000 --
+logpdf, posterior marginals and the combined call against the sequential C oracle.   usage: stress_multi.py [n_cases] [seed]"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import temporalgps_jl_amd as tgp  # noqa: E402
+from oracle import seq_kalman as sk  # noqa: E402
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+LENGTHS = [5, 9, 64, 257, 1000, 4097, 16385, 70_001]
+bad = 0
+for case in range(int(os.environ.get("START", "0")), min(n_cases, int(os.environ.get("END", "1000000")))):
+    rng = np.random.default_rng([seed, case])
+    d = int(rng.integers(1, 9))
+    T = int(LENGTHS[rng.integers(len(LENGTHS))])
+    W = int(rng.integers(2, 6))
+    lti = rng.random() < 0.3                      # every block shared: the stationary-gain shards (or their fall-back)
+    per = {k: (not lti) and bool(rng.random() < 0.5) for k in "AaQHhR"}
+
+    def psd(n, lo, hi):
+        U = np.linalg.qr(rng.standard_normal((n, n)))[0]
+        return (U * (rng.random(n) * (hi - lo) + lo)) @ U.T
+    nA, na, nQ, nH, nh, nR = (T if per[k] else 1 for k in "AaQHhR")
+    A = np.stack([-psd(d, 0.1, 0.9) + 0.2 * rng.standard_normal((d, d)) for _ in range(nA)])
+    A = np.stack([Ai / max(1.0, 1.1 * np.abs(np.linalg.eigvals(Ai)).max()) for Ai in A])
+    model = dict(ordering="F", kind="scalar", T=T, A=A, a=0.3 * rng.standard_normal((na, d)), Q=np.stack([psd(d, 0.2, 1.5) for _ in range(nQ)]),
+                 H=rng.standard_normal((nH, d)), h=rng.standard_normal(nh), R=np.exp(rng.uniform(np.log(1e-3), np.log(2.0), nR)),
+                 x0m=rng.standard_normal(d), x0P=psd(d, 0.5, 1.5))
+    eps = (rng.standard_normal((T, d)), rng.standard_normal(T), rng.standard_normal(d))
+    y = sk.rand(model, *eps)
+    Rn = np.exp(rng.uniform(np.log(1e-3), np.log(0.5), T if rng.random() < 0.5 else 1))
+    lp_o = sk.logpdf(model, y)
+    pm, pv = sk.posterior_marginals(model, y, Rn)
+    tr = tgp.GaussMarkovModel(tgp.Forward, model["A"], model["a"], model["Q"], tgp.Gaussian(model["x0m"], model["x0P"]))
+    dm = tgp.LGSSM(tr, tgp.ScalarOutputLGC(model["H"], model["h"], model["R"]), T=T)
+    msgs = []
+
+    def close(name, got, want, rtol=1e-8):
+        got, want = np.asarray(got, dtype=np.float64).reshape(-1), np.asarray(want, dtype=np.float64).reshape(-1)
+        sc = max(1.0, float(np.max(np.abs(want)))) if want.size else 1.0
+        if got.shape != want.shape or not np.all(np.abs(got - want) <= rtol * sc):
+            msgs.append(f"{name}: max err {np.max(np.abs(got - want)) / sc if got.shape == want.shape else (got.shape, want.shape)}")
+    try:
+        ms = tgp.MultiLGSSM(dm, devices=[0] * W)
+        lp = ms.logpdf(y)
+        if not abs(lp - lp_o) <= 1e-10 * max(1.0, abs(lp_o)):
+            msgs.append(f"logpdf {lp} vs {lp_o}")
+        gm, gv = ms.posterior_marginals(y, Rn)
+        close("posterior mean", gm, pm)
+        close("posterior var", gv, pv)
+        lp2, gm2, gv2 = ms.logpdf_and_posterior_marginals(y, Rn)
+        close("combined call", np.concatenate([[lp2], gm2, gv2]), np.concatenate([[lp_o], pm, pv]))
+        del ms
+    except Exception as ex:      # noqa: BLE001
+        import traceback
+        msgs.append(f"{type(ex).__name__}: {ex} @ {traceback.extract_tb(ex.__traceback__)[-1].lineno}")
+    bad += bool(msgs)
+    print(f"[{case:3d}] {'FAIL' if msgs else 'ok'} d={d} T={T} W={W} per-step={''.join(k for k in 'AaQHhR' if per[k]) or '-'} Rn={'T' if Rn.shape[0] > 1 else '1'} {'; '.join(msgs)}", flush=True)
+print(f"{bad} failing cases of {n_cases}")
