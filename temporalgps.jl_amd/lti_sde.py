@@ -209,6 +209,9 @@ class KernelProduct(Kernel):             # lti_sde.jl:377-400
         self.kernels = kernels
 
     def lgssm_components(self, t):
+        for k in self.kernels:       # the reference multiplies the factors' SDEs (to_sde.(k.kernels)): sums and products have no to_sde method there
+            if not hasattr(k, "to_sde"):
+                raise TypeError(f"a factor of a KernelProduct must have an SDE form (to_sde); {type(k).__name__} has none (lti_sde.jl:377-400)")
         sdes = [k.to_sde() for k in self.kernels]
         x0s = [k.stationary_distribution() for k in self.kernels]
         F, H, m0, P0 = sdes[0][0], sdes[0][2], x0s[0][0], x0s[0][1]
