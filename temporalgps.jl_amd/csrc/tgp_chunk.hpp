@@ -215,10 +215,9 @@ struct FilterOut {
 };
 
 // The closed-form transition of one step (see ModelView::sde): tau >= 0 the gap to the previous time stamp, tau < 0 the first one.
-template <int D> TGP_HD void sde_transition(const ModelView& mv, double tau, double* A, double* Q) {
-    const double* q = mv.sde;
+template <int D> TGP_HD void sde_transition_impl(const double* q, int sde_first, double tau, double* A, double* Q) {
     if (tau < 0.0) {
-        if (mv.sde_first) {     // (A1, Q1) as the host evaluated them (kernel algebra decides each term's own dt_1, tgp_hip.h)
+        if (sde_first) {     // (A1, Q1) as the host evaluated them (kernel algebra decides each term's own dt_1, tgp_hip.h)
             TGP_UNROLL for (int k = 0; k < D * D; ++k) { A[k] = q[D + 3 * D * D + k]; Q[k] = q[D + 4 * D * D + k]; }
             return;
         }
@@ -253,6 +252,11 @@ template <int D> TGP_HD void sde_transition(const ModelView& mv, double tau, dou
             Q[j + i * D] = v;
         }
     }
+}
+// (out-of-line from TGP_BIG_D on, like every other building block of that build: its temporaries must not join the caller's register budget)
+template <int D> TGP_NOINLINE void sde_transition_out(const double* q, int sde_first, double tau, double* A, double* Q) { sde_transition_impl<D>(q, sde_first, tau, A, Q); }
+template <int D> TGP_HD void sde_transition(const ModelView& mv, double tau, double* A, double* Q) {
+    if constexpr (D >= TGP_BIG_D) { sde_transition_out<D>(mv.sde, mv.sde_first, tau, A, Q); } else { sde_transition_impl<D>(mv.sde, mv.sde_first, tau, A, Q); }
 }
 template <int D> TGP_HD void sde_transition(const ModelView&, double, Dual*, Dual*) {}   // (the gradient pass reads tiled tangents instead)
 
