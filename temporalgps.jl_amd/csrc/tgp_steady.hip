@@ -2263,22 +2263,27 @@ __global__ __launch_bounds__(kBlkThreads, (D <= 4 ? 4 : 2)) void k_apply(const l
                                                const double* __restrict__ B0, const double* __restrict__ Pw, const double* __restrict__ Lw,
                                                const double* __restrict__ MUb, const double* __restrict__ LAMb,
                                                const double* __restrict__ t_vb, double* __restrict__ mean, double* __restrict__ var,
-                                               double* __restrict__ SSQ, long long T, long long ntiles) {
+                                               double* __restrict__ SSQ, long long T, long long ntiles, Tab tb) {
     if (hdr[0] == 0) return;
+    if (POST && blockIdx.x == 0) {      // the extra workgroup (dispatched first): the head's backward recursion, one wave, beside the stationary tiles
+        if (threadIdx.x < 64) head_backward<D>(tb, y, Rnew, rnew_per_step, mean, var, T, threadIdx.x);
+        return;
+    }
+    const long long wg = (long long)blockIdx.x - (POST ? 1 : 0);
     __shared__ double sacc[kBlk], sMu[kBlk + 1][D], sLam[kBlk][D];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long long tile0 = hdr[1] + (long long)blockIdx.x * kBlk;
+    const long long tile0 = hdr[1] + wg * kBlk;
     if (tile0 >= ntiles) return;
     const long long tile = tile0 + wave;
     double acc = 0.0;
-    const bool lastwg = (long long)blockIdx.x == nblk_max_for(hdr[1], ntiles) - 1;
+    const bool lastwg = wg == nblk_max_for(hdr[1], ntiles) - 1;
     if (lastwg) {                // the ragged last workgroup: its tiles' carries by the sequential chain (one thread)
         if (threadIdx.x == 0) {
             double mu_in[D], lam_in[D], lout[D];
 #pragma unroll
             for (int i = 0; i < D; ++i) {
-                mu_in[i] = MUb[(long long)blockIdx.x * D + i];
-                lam_in[i] = POST ? LAMb[((long long)blockIdx.x + 1) * D + i] : 0.0;
+                mu_in[i] = MUb[wg * D + i];
+                lam_in[i] = POST ? LAMb[(wg + 1) * D + i] : 0.0;
             }
             block_carries<D>(cst, [&](int w, int i) { return F[(tile0 + w) * D + i]; }, [&](int w, int i) { return POST ? B0[(tile0 + w) * D + i] : 0.0; },
                              tile0, ntiles, mu_in, lam_in, sMu, sLam, lout);
@@ -2299,8 +2304,8 @@ __global__ __launch_bounds__(kBlkThreads, (D <= 4 ? 4 : 2)) void k_apply(const l
             double mub[D], lamb[D], mw[D], lw[D];
 #pragma unroll
             for (int i = 0; i < D; ++i) {
-                mub[i] = MUb[(long long)blockIdx.x * D + i];
-                lamb[i] = POST ? LAMb[((long long)blockIdx.x + 1) * D + i] : 0.0;
+                mub[i] = MUb[wg * D + i];
+                lamb[i] = POST ? LAMb[(wg + 1) * D + i] : 0.0;
                 mw[i] = Pw[tile * D + i];
                 lw[i] = POST ? Lw[tile * D + i] : 0.0;
             }
@@ -2403,12 +2408,12 @@ __global__ __launch_bounds__(kBlkThreads, (D <= 4 ? 4 : 2)) void k_apply(const l
         double t = 0.0;
 #pragma unroll
         for (int w = 0; w < kBlk; ++w) t += sacc[w];
-        SSQ[blockIdx.x] = t;
+        SSQ[wg] = t;
     }
 }
 
 // log marginal likelihood from the pieces (fixed summation order) and the status of the call
-// (second workgroup, posterior calls: the head's backward recursion -- one wave, beside nothing but this reduction)
+// (the head's backward recursion of a posterior call runs as the extra workgroup of k_apply)
 template <int D>
 __global__ __launch_bounds__(256) void k_final(Tab tb, long long T, long long ntiles, double* result, const double* __restrict__ y,
                                                const double* __restrict__ Rnew, int rnew_per_step, double* __restrict__ mean,
@@ -2416,10 +2421,6 @@ __global__ __launch_bounds__(256) void k_final(Tab tb, long long T, long long nt
     constexpr int NT = 256;
     __shared__ double sm[NT];
     const int tid = threadIdx.x;
-    if (blockIdx.x == 1) {
-        if (tb.hdr[0] != 0 && tid < 64) head_backward<D>(tb, y, Rnew, rnew_per_step, mean, var, T, tid);
-        return;
-    }
     if (tb.hdr[0] == 0) {
         if (tid == 0) {
             result[6] = kStatusNotApplicable;
@@ -2834,11 +2835,11 @@ int enqueue_d(Engine* e, hipStream_t st, const ModelDev& m, const CallDev& c, co
         { Scope s(hk, "k_steady_shard_fold"); hipLaunchKernelGGL(k_shard_fold<D>, dim3(1), dim3(64), 0, st, tb, ntiles, sh->gathered, sh->world, sh->rank, post ? 1 : 0); }
         if (post) {
             { Scope s(hk, "k_steady_carry<posterior>"); hipLaunchKernelGGL((k_carry<D, true>), dim3(cblocks), dim3(512), 0, st, tb.hdr, tb.cst, tb.Fb, tb.B0b, tb.MUb, tb.LAMb, ntiles, 1); }
-            { Scope s(hk, "k_steady_apply<posterior>"); hipLaunchKernelGGL((k_apply<D, true>), dim3(blocks), dim3(kBlkThreads), 0, st, tb.hdr, tb.cst, c.y, c.Rnew, c.rnew_per_step, tb.F, tb.B0, tb.Pw, tb.Lw, tb.MUb, tb.LAMb, tb.t_vb, c.mean, c.var, tb.SSQ, T, ntiles); }
-            { Scope s(hk, "k_steady_final<posterior>"); hipLaunchKernelGGL(k_final<D>, dim3(2), dim3(256), 0, st, tb, T, ntiles, c.result, c.y, c.Rnew, c.rnew_per_step, c.mean, c.var); }
+            { Scope s(hk, "k_steady_apply<posterior>"); hipLaunchKernelGGL((k_apply<D, true>), dim3(blocks + 1), dim3(kBlkThreads), 0, st, tb.hdr, tb.cst, c.y, c.Rnew, c.rnew_per_step, tb.F, tb.B0, tb.Pw, tb.Lw, tb.MUb, tb.LAMb, tb.t_vb, c.mean, c.var, tb.SSQ, T, ntiles, tb); }
+            { Scope s(hk, "k_steady_final<posterior>"); hipLaunchKernelGGL(k_final<D>, dim3(1), dim3(256), 0, st, tb, T, ntiles, c.result, c.y, c.Rnew, c.rnew_per_step, c.mean, c.var); }
         } else {
             { Scope s(hk, "k_steady_carry<logpdf>"); hipLaunchKernelGGL((k_carry<D, false>), dim3(cblocks), dim3(512), 0, st, tb.hdr, tb.cst, tb.Fb, tb.B0b, tb.MUb, tb.LAMb, ntiles, 0); }
-            { Scope s(hk, "k_steady_apply<logpdf>"); hipLaunchKernelGGL((k_apply<D, false>), dim3(blocks), dim3(kBlkThreads), 0, st, tb.hdr, tb.cst, c.y, (const double*)nullptr, 0, tb.F, tb.B0, tb.Pw, tb.Lw, tb.MUb, tb.LAMb, tb.t_vb, (double*)nullptr, (double*)nullptr, tb.SSQ, T, ntiles); }
+            { Scope s(hk, "k_steady_apply<logpdf>"); hipLaunchKernelGGL((k_apply<D, false>), dim3(blocks), dim3(kBlkThreads), 0, st, tb.hdr, tb.cst, c.y, (const double*)nullptr, 0, tb.F, tb.B0, tb.Pw, tb.Lw, tb.MUb, tb.LAMb, tb.t_vb, (double*)nullptr, (double*)nullptr, tb.SSQ, T, ntiles, tb); }
             { Scope s(hk, "k_steady_final<logpdf>"); hipLaunchKernelGGL(k_final<D>, dim3(1), dim3(256), 0, st, tb, T, ntiles, c.result, c.y, c.Rnew, 0, (double*)nullptr, (double*)nullptr); }
         }
         return (int)hipGetLastError();
@@ -2866,12 +2867,12 @@ int enqueue_d(Engine* e, hipStream_t st, const ModelDev& m, const CallDev& c, co
     if (post) {
         { Scope s(hk, "k_steady_reduce<posterior>"); hipLaunchKernelGGL((k_reduce<D, true>), dim3(blocks + 1), dim3(kBlkThreads), 0, st, tb.hdr, tb.cst, c.y, tb.F, tb.B0, tb.Fb, tb.B0b, T, ntiles, m, tb, 1); }
         { Scope s(hk, "k_steady_carry<posterior>"); hipLaunchKernelGGL((k_carry<D, true>), dim3(cblocks), dim3(512), 0, st, tb.hdr, tb.cst, tb.Fb, tb.B0b, tb.MUb, tb.LAMb, ntiles, 0); }
-        { Scope s(hk, "k_steady_apply<posterior>"); hipLaunchKernelGGL((k_apply<D, true>), dim3(blocks), dim3(kBlkThreads), 0, st, tb.hdr, tb.cst, c.y, c.Rnew, c.rnew_per_step, tb.F, tb.B0, tb.Pw, tb.Lw, tb.MUb, tb.LAMb, tb.t_vb, c.mean, c.var, tb.SSQ, T, ntiles); }
-        { Scope s(hk, "k_steady_final<posterior>"); hipLaunchKernelGGL(k_final<D>, dim3(2), dim3(256), 0, st, tb, T, ntiles, c.result, c.y, c.Rnew, c.rnew_per_step, c.mean, c.var); }
+        { Scope s(hk, "k_steady_apply<posterior>"); hipLaunchKernelGGL((k_apply<D, true>), dim3(blocks + 1), dim3(kBlkThreads), 0, st, tb.hdr, tb.cst, c.y, c.Rnew, c.rnew_per_step, tb.F, tb.B0, tb.Pw, tb.Lw, tb.MUb, tb.LAMb, tb.t_vb, c.mean, c.var, tb.SSQ, T, ntiles, tb); }
+        { Scope s(hk, "k_steady_final<posterior>"); hipLaunchKernelGGL(k_final<D>, dim3(1), dim3(256), 0, st, tb, T, ntiles, c.result, c.y, c.Rnew, c.rnew_per_step, c.mean, c.var); }
     } else {
         { Scope s(hk, "k_steady_reduce<logpdf>"); hipLaunchKernelGGL((k_reduce<D, false>), dim3(blocks), dim3(kBlkThreads), 0, st, tb.hdr, tb.cst, c.y, tb.F, tb.B0, tb.Fb, tb.B0b, T, ntiles, m, tb, 0); }
         { Scope s(hk, "k_steady_carry<logpdf>"); hipLaunchKernelGGL((k_carry<D, false>), dim3(cblocks), dim3(512), 0, st, tb.hdr, tb.cst, tb.Fb, tb.B0b, tb.MUb, tb.LAMb, ntiles, 0); }
-        { Scope s(hk, "k_steady_apply<logpdf>"); hipLaunchKernelGGL((k_apply<D, false>), dim3(blocks), dim3(kBlkThreads), 0, st, tb.hdr, tb.cst, c.y, (const double*)nullptr, 0, tb.F, tb.B0, tb.Pw, tb.Lw, tb.MUb, tb.LAMb, tb.t_vb, (double*)nullptr, (double*)nullptr, tb.SSQ, T, ntiles); }
+        { Scope s(hk, "k_steady_apply<logpdf>"); hipLaunchKernelGGL((k_apply<D, false>), dim3(blocks), dim3(kBlkThreads), 0, st, tb.hdr, tb.cst, c.y, (const double*)nullptr, 0, tb.F, tb.B0, tb.Pw, tb.Lw, tb.MUb, tb.LAMb, tb.t_vb, (double*)nullptr, (double*)nullptr, tb.SSQ, T, ntiles, tb); }
         { Scope s(hk, "k_steady_final<logpdf>"); hipLaunchKernelGGL(k_final<D>, dim3(1), dim3(256), 0, st, tb, T, ntiles, c.result, c.y, c.Rnew, 0, (double*)nullptr, (double*)nullptr); }
     }
     return (int)hipGetLastError();
