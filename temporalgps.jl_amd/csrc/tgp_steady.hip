@@ -1517,6 +1517,34 @@ __device__ __forceinline__ void store8(double* __restrict__ p, long long t0, lon
     }
 }
 
+// A wave's tile of 512 consecutive output values, eight per lane, leaves through the wave's own LDS row (kTileRow doubles): lane l's pairs go
+// in at 16-byte slots 4 l + l / 4 + j / 2 as the backward walk produces them (no array of eight held in registers; the pad keeps the
+// 128-bit writes of sixteen lanes on distinct banks) and come out transposed, so that every store instruction writes 1 KB of consecutive
+// bytes -- eight whole lines -- instead of 64 sixteen-byte pieces 64 bytes apart that the L2 has to merge (pass 2 at T = 1e7: 75 -> 61 us
+// at d = 3, 69 -> 47 us at d = 2).  Ragged tiles and pointers off a 16-byte boundary store each lane's own slots, element by element.
+constexpr int kTileRow = kTile + 32;
+typedef double v2d __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int tile_slot(int lane) { return lane * 4 + (lane >> 2); }
+__device__ __forceinline__ void flush_tile(double* __restrict__ p, long long tile_t0, long long T, const v2d* r2, int lane) {
+    if (tile_t0 + kTile <= T && (reinterpret_cast<uintptr_t>(p) & 15) == 0) {      // (wave-uniform)
+        v2d* q = reinterpret_cast<v2d*>(p + tile_t0);
+#pragma unroll
+        for (int k = 0; k < kSub / 2; ++k) {
+            const int e = k * 64 + lane, ls = e >> 2;
+            q[e] = r2[ls * 4 + (ls >> 2) + (e & 3)];
+        }
+    } else {
+        const long long t0 = tile_t0 + lane * kSub;
+        const int wb = tile_slot(lane);
+#pragma unroll
+        for (int j = 0; j < kSub / 2; ++j) {
+            const v2d w = r2[wb + j];
+            if (t0 + 2 * j < T) p[t0 + 2 * j] = w.x;
+            if (t0 + 2 * j + 1 < T) p[t0 + 2 * j + 1] = w.y;
+        }
+    }
+}
+
 // two consecutive values at t (even offset inside the lane's eight): one 16-byte store where the pointer allows
 __device__ __forceinline__ void store2(double* __restrict__ p, long long t, long long T, double a, double b) {
     if (t + 1 < T && (reinterpret_cast<uintptr_t>(p + t) & 15) == 0) {
@@ -2343,63 +2371,44 @@ __global__ __launch_bounds__(kBlkThreads, (D <= 4 ? 4 : 2)) void k_apply(const l
             const double rn0 = Rnew[0];
             const double vb = cst[SS<D>::vb];
             const long long n1 = hdr[3];
-            if constexpr (D == 4) {
-                // d = 4: the outputs leave in pairs as the backward walk produces them (sixteen fewer live doubles: no spills, 105 -> 92 us
-                // at T = 1e7). Elsewhere two arrays of eight and each lane's 64 contiguous bytes stored back to back are faster: pairs spread
-                // over the walk measured 10-25 % slower at d = 2, 3, 5 (partial-line writes).
-                double mhi = 0.0, vhi = 0.0;
+            // the outputs leave in pairs, as the backward walk produces them, through the wave's LDS rows (flush_tile)
+            __shared__ __attribute__((aligned(16))) double sOutM[kBlk][kTileRow], sOutV[kBlk][kTileRow];
+            v2d* rm = reinterpret_cast<v2d*>(sOutM[wave]);
+            v2d* rv = reinterpret_cast<v2d*>(sOutV[wave]);
+            const int wb = tile_slot(lane);
+            double mhi = 0.0, vhi = 0.0;
 #pragma unroll
-                for (int j = kSub - 1; j >= 0; --j) {
-                    double m = fma(-cf.rS, r[j], yv[j]);
+            for (int j = kSub - 1; j >= 0; --j) {
+                double m = fma(-cf.rS, r[j], yv[j]);
 #pragma unroll
-                    for (int k = 0; k < D; ++k) m = fma(cf.h[k], lst[k], m);
-                    const long long back = T - 1 - (t0 + j);
-                    const double vbt = (back >= 0 && back < n1) ? t_vb[back] : vb;
-                    const double v = vbt + (rnew_per_step ? ((t0 + j < T) ? Rnew[t0 + j] : 0.0) : rn0);
-                    if (j & 1) {
-                        mhi = m;
-                        vhi = v;
-                    } else {
-                        store2(mean, t0 + j, T, m, mhi);
-                        store2(var, t0 + j, T, v, vhi);
-                    }
-                    double nl[D];
-#pragma unroll
-                    for (int i = 0; i < D; ++i) {
-                        double w = cf.c[i] * r[j];
-#pragma unroll
-                        for (int k = 0; k < D; ++k) w = fma(cf.G[i][k], lst[k], w);
-                        nl[i] = w;
-                    }
-#pragma unroll
-                    for (int i = 0; i < D; ++i) lst[i] = nl[i];
+                for (int k = 0; k < D; ++k) m = fma(cf.h[k], lst[k], m);
+                const long long back = T - 1 - (t0 + j);
+                const double vbt = (back >= 0 && back < n1) ? t_vb[back] : vb;
+                const double v = vbt + (rnew_per_step ? ((t0 + j < T) ? Rnew[t0 + j] : 0.0) : rn0);
+                if (j & 1) {
+                    mhi = m;
+                    vhi = v;
+                } else {
+                    v2d wm, wv;
+                    wm.x = m; wm.y = mhi;
+                    wv.x = v; wv.y = vhi;
+                    rm[wb + (j >> 1)] = wm;
+                    rv[wb + (j >> 1)] = wv;
                 }
-            } else {
-                double mo[kSub], vo[kSub];
-                if (rnew_per_step) load8(Rnew, t0, T, vo);
+                double nl[D];
 #pragma unroll
-                for (int j = kSub - 1; j >= 0; --j) {
-                    double m = fma(-cf.rS, r[j], yv[j]);
+                for (int i = 0; i < D; ++i) {
+                    double w = cf.c[i] * r[j];
 #pragma unroll
-                    for (int k = 0; k < D; ++k) m = fma(cf.h[k], lst[k], m);
-                    mo[j] = m;
-                    const long long back = T - 1 - (t0 + j);
-                    const double vbt = (back >= 0 && back < n1) ? t_vb[back] : vb;
-                    vo[j] = vbt + (rnew_per_step ? vo[j] : rn0);
-                    double nl[D];
-#pragma unroll
-                    for (int i = 0; i < D; ++i) {
-                        double v = cf.c[i] * r[j];
-#pragma unroll
-                        for (int k = 0; k < D; ++k) v = fma(cf.G[i][k], lst[k], v);
-                        nl[i] = v;
-                    }
-#pragma unroll
-                    for (int i = 0; i < D; ++i) lst[i] = nl[i];
+                    for (int k = 0; k < D; ++k) w = fma(cf.G[i][k], lst[k], w);
+                    nl[i] = w;
                 }
-                store8(mean, t0, T, mo);
-                store8(var, t0, T, vo);
+#pragma unroll
+                for (int i = 0; i < D; ++i) lst[i] = nl[i];
             }
+            lds_sync();
+            flush_tile(mean, tile * kTile, T, rm, lane);
+            flush_tile(var, tile * kTile, T, rv, lane);
         }
     }
     if (lane == 0) sacc[wave] = acc;
