@@ -272,3 +272,39 @@ def test_cfg1_exact_size(tgp):
         assert abs(lp - lp_ref) <= 1e-10 * abs(lp_ref)
         np.testing.assert_allclose(mean, pm, rtol=0, atol=1e-8)
         np.testing.assert_allclose(var, pv, rtol=1e-8, atol=1e-10)
+
+
+@pytest.mark.parametrize("d", [2, 3, 4, 6])
+@pytest.mark.parametrize("T", [9 * 512, 9 * 512 + 5, 40_001])
+def test_device_pointers_off_the_16_byte_boundary(tgp, d, T):
+    """Pass 2 writes a tile's outputs as whole 1 KB rows (transposed through LDS) and pass 1 / 2 read 16-byte pairs -- behind pointers that
+    sit on a 16-byte boundary. Views into larger device arrays start wherever the caller's offset puts them: observations, per-step new
+    noise and both outputs at an odd multiple of 8 bytes, whole and ragged last tiles."""
+    import torch
+    k = {2: ("matern32",), 3: ("matern52",), 4: ("sum", ("matern52",), ("matern12",)), 6: ("sum", ("matern52",), ("matern52",))}[d]
+    model = oc.build_lgssm(k, ("regular", 0.0, 0.1, T), 0.1)
+    rng = np.random.default_rng(d + T)
+    eps = (rng.standard_normal((T, d)), rng.standard_normal(T), rng.standard_normal(d))
+    y = sk.rand(model, *eps)
+    Rn = rng.random(T) * 0.1 + 0.01
+    lp_o = sk.logpdf(model, y)
+    pm, pv = sk.posterior_marginals(model, y, Rn)
+    dm = device_model(tgp, model)
+    dev = torch.device("cuda:0")
+    for off in (1, 0, 3):
+        ybig = torch.zeros(T + 8, dtype=torch.float64, device=dev)
+        rbig = torch.zeros(T + 8, dtype=torch.float64, device=dev)
+        mbig = torch.full((T + 8,), 7.0, dtype=torch.float64, device=dev)
+        vbig = torch.full((T + 8,), 7.0, dtype=torch.float64, device=dev)
+        ybig[off:off + T] = torch.as_tensor(y, device=dev)
+        rbig[off:off + T] = torch.as_tensor(Rn, device=dev)
+        out = (mbig[off:off + T], vbig[off:off + T])
+        assert (out[0].data_ptr() % 16 == 8) == (off % 2 == 1)
+        lp, gm, gv = tgp.logpdf_and_posterior_marginals(dm, ybig[off:off + T], rbig[off:off + T], out=out)
+        assert served(dm) > 0
+        assert abs(lp - lp_o) <= 1e-10 * abs(lp_o)
+        np.testing.assert_allclose(gm.cpu().numpy(), pm, rtol=1e-8, atol=1e-8)
+        np.testing.assert_allclose(gv.cpu().numpy(), pv, rtol=1e-8, atol=1e-9)
+        for big in (mbig, vbig):                     # nothing written outside the view
+            assert torch.all(big[:off] == 7.0) and torch.all(big[off + T:] == 7.0)
+        assert abs(tgp.logpdf(dm, ybig[off:off + T]) - lp_o) <= 1e-10 * abs(lp_o)
