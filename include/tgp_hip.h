@@ -156,7 +156,8 @@ int tgp_model_set(tgp_handle* h, int64_t T, int d, int p, int ordering, uint32_t
  *      AbstractVector inputs, src/gp/lti_sde.jl:135-146 -- A_k = exp(F dt_k), Q_k = x0P - A_k x0P A_k' with
  *      dt_1 := 1 -- computed ON THE DEVICE into the tiled layout (no T host-side matrix exponentials, no [T][d*d]
  *      arrays). F [d*d] column-major, a [d] (shared), H / hh / R as in tgp_model_set (flags say shared or per-step),
- *      times [T] increasing, x0P doubles as the stationary covariance. p == 1. All host pointers.
+ *      times [T] non-decreasing (checked: TGP_EINVAL otherwise; equal stamps are a step with A = I, Q = 0), x0P doubles as the
+ *      stationary covariance. p == 1. All host pointers.
  *      A1, Q1 [d*d] (nullable): the FIRST transition. The reference's dt_1 := 1 is taken in each sub-kernel's own
  *      (stretched) time (lti_sde.jl:139 under :350-373,:404-418), so kernel algebra with ScaleTransforms has no
  *      single dt_1; the host evaluates that one block with the reference's rule and passes it here. */

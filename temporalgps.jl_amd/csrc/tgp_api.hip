@@ -1526,6 +1526,10 @@ int tgp_model_set_sde(tgp_handle* h, int64_t T, int d, int ordering, uint32_t fl
     if (h && h->tab_state == 1) (void)hipStreamSynchronize(h->side_stream);
     if (h) { h->tab_state = 0; h->tab_calls = 0; h->tab_L0 = 0; }
     if (d > 8) return h->fail(TGP_EUNSUPPORTED, "tgp_model_set_sde: d <= 8 (build the per-step blocks on the host for larger d)");
+    // (time stamps in non-decreasing order: a negative gap would make exp(F dt) expansive and Q indefinite in the tiled record, and is the
+    //  marker of the first transition in the closed-form record)
+    for (int64_t k = 1; k < T; ++k)
+        if (!(times[k] >= times[k - 1])) return h->fail(TGP_EINVAL, "tgp_model_set_sde: the time stamps must be non-decreasing (and finite)");
     // shared placeholder blocks for A and Q (never read: the tiled record supplies them); a must be shared
     if (!(flags & TGP_SHARED_a)) return h->fail(TGP_EUNSUPPORTED, "tgp_model_set_sde: the transition offset a must be shared");
     std::vector<double> zero((size_t)d * d, 0.0);

@@ -242,3 +242,25 @@ def test_per_step_noise_runs_the_kernels_of_the_per_step_verdict(tgp, key):
     m2 = P.build_lgssm(_kernel(P, terms), x, s2, device_components=False)       # host-built per-step blocks: the same family
     lp2 = tgp.logpdf(m2, y)
     assert abs(lp2 - lp_o) <= 1e-10 * abs(lp_o), (lp2, lp_o)
+
+
+def test_repeated_and_unsorted_time_stamps(tgp):
+    """two observations at the same time (dt = 0: A = I, Q = 0 in both forms) are a valid model; time stamps out of order are refused at
+    tgp_model_set_sde (the reference would exponentiate a negative gap)."""
+    from temporalgps_jl_amd import lti_sde as P
+    rng = np.random.default_rng(2)
+    T = 2000
+    x = np.cumsum(rng.uniform(0.05, 0.15, T))
+    x[100] = x[99]
+    x[1500] = x[1499]
+    y = rng.standard_normal(T)
+    spec = ("scaled", 1.2, ("stretched", 0.8, ("matern52",)))
+    lp_o = oc.gp_logpdf(spec, x, 0.1, y, None, None)
+    for cf in (1, 0):
+        m = P.build_lgssm(P.to_kernel(spec), x, 0.1, device_components=True)
+        m.handle().set_option(tgp._lib.OPT_SDE_CLOSED_FORM, cf)
+        assert abs(tgp.logpdf(m, y) - lp_o) <= 1e-10 * abs(lp_o)
+    xb = x.copy()
+    xb[700], xb[701] = xb[701] + 0.01, xb[700]
+    with pytest.raises(tgp._lib.TGPError, match="non-decreasing"):
+        P.build_lgssm(P.to_kernel(spec), xb, 0.1, device_components=True).handle()
