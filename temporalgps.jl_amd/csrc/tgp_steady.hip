@@ -58,8 +58,8 @@ struct CL {
     static constexpr int GSeg = PSeg + DD;                   // G^L
     static constexpr int BSeg = GSeg + DD;                   // B_L
     static constexpr int GLb = BSeg + DD;                    // G^(steps of the ragged last workgroup): the lam a shard receives enters there
-    static constexpr int WJ = GLb + DD;                      // [kSub][D]: h' Phi^j -- the innovation j steps behind a lane's start state st is r0_j - WJ[j] . st
-    static constexpr int size = WJ + kSub * D;
+    static constexpr int WJ = GLb + DD;                      // [2 kSub][D]: h' Phi^j -- the innovation j steps behind a lane's start state st is r0_j - WJ[j] . st
+    static constexpr int size = WJ + 2 * kSub * D;             //   (pass 2 uses the first eight rows, pass 1 -- sixteen steps per lane -- all of them)
 };
 // slot a time shard hands to the exchange: [0] applies, then F (mu behind the segment under a zero carry-in; rank 0: the mu itself),
 // B0 (lam in front of the segment's stationary steps under zero carries), Phi^L, G^L, B_L
@@ -982,13 +982,13 @@ __device__ __forceinline__ void setup_body(const ModelDev& m, const Tab& tb, con
     __threadfence_block();
     wave_sync();
     if (lane == 0) tb.misc[10] = (double)wall_clock64();
-    // ---- rows h' Phi^j, j < 8 (tile_forward: the lanes' innovations from their scanned start state without a second recursion) --------
+    // ---- rows h' Phi^j, j < 16 (tile_forward / half_tile_forward: the lanes' innovations from their scanned start state without a second recursion)
     if (lane < D) {
         double w[D], nw[D];
 #pragma unroll
         for (int k = 0; k < D; ++k) w[k] = hv[k];
 #pragma unroll
-        for (int jj = 0; jj < kSub; ++jj) {
+        for (int jj = 0; jj < 2 * kSub; ++jj) {
 #pragma unroll
             for (int c = 0; c < D; ++c) {
                 if (c == lane) tb.cst[CL<D>::WJ + jj * D + c] = w[c];
@@ -1693,6 +1693,109 @@ __device__ __forceinline__ void tile_backward(const Coef<D>& cf, const double* _
     }
 }
 
+// ---- pass 1's form of the two halves: a tile is HALF a wave -- 32 lanes of sixteen steps -- with zero carries.  The in-tile scans cost the
+// same per level whatever a lane holds, so sixteen steps per lane halve them per step (five levels with Phi^(16 2^k) instead of six with
+// Phi^(8 2^k)); pass 1 keeps nothing but y and r per lane, so the registers are there (pass 2, with its outputs, stays at eight).  The two
+// halves of a wave are two tiles: the scans never cross lane 32.
+constexpr int kSub2 = 2 * kSub;
+template <int D>
+__device__ __forceinline__ void half_tile_forward(const Coef<D>& cf, const double* __restrict__ pw_phi, const double (&y)[kSub2], int nvalid, int sl,
+                                                  double (&r)[kSub2], double (&fend)[D]) {
+    constexpr int DD = D * D;
+    double mu[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) mu[i] = 0.0;
+#pragma unroll
+    for (int j = 0; j < kSub2; ++j) {
+        double rr = y[j] - cf.hh;
+#pragma unroll
+        for (int k = 0; k < D; ++k) rr = fma(-cf.h[k], mu[k], rr);
+        rr = (j < nvalid) ? rr : 0.0;
+        r[j] = rr;
+        double nm[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            double v = fma(cf.kA[i], rr, cf.a[i]);
+#pragma unroll
+            for (int k = 0; k < D; ++k) v = fma(cf.A[i][k], mu[k], v);
+            nm[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < D; ++i) mu[i] = nm[i];
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const int off = 1 << k;
+        double g[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) g[i] = __shfl_up(mu[i], off);
+        const double* __restrict__ M = pw_phi + (size_t)(4 + k) * DD;
+        if (sl >= off) {
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                double v = mu[i];
+#pragma unroll
+                for (int l = 0; l < D; ++l) v = fma(M[i * D + l], g[l], v);
+                mu[i] = v;
+            }
+        }
+    }
+    double st[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        fend[i] = mu[i];
+        const double v = __shfl_up(mu[i], 1);
+        st[i] = (sl == 0) ? 0.0 : v;
+    }
+    const double* __restrict__ W = pw_phi - CL<D>::pphi + CL<D>::WJ;
+#pragma unroll
+    for (int j = 0; j < kSub2; ++j) {
+        double rr = r[j];
+#pragma unroll
+        for (int k = 0; k < D; ++k) rr = fma(-W[j * D + k], st[k], rr);
+        r[j] = (j < nvalid) ? rr : 0.0;
+    }
+}
+template <int D>
+__device__ __forceinline__ void half_tile_backward(const Coef<D>& cf, const double* __restrict__ pw_g, const double (&r)[kSub2], int sl, double (&bend)[D]) {
+    constexpr int DD = D * D;
+    double lam[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) lam[i] = 0.0;
+#pragma unroll
+    for (int j = kSub2 - 1; j >= 0; --j) {
+        double nl[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            double v = cf.c[i] * r[j];
+#pragma unroll
+            for (int k = 0; k < D; ++k) v = fma(cf.G[i][k], lam[k], v);
+            nl[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < D; ++i) lam[i] = nl[i];
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const int off = 1 << k;
+        double g[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) g[i] = __shfl_down(lam[i], off);
+        const double* __restrict__ M = pw_g + (size_t)(4 + k) * DD;
+        if (sl + off < 32) {
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                double v = lam[i];
+#pragma unroll
+                for (int l = 0; l < D; ++l) v = fma(M[i * D + l], g[l], v);
+                lam[i] = v;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < D; ++i) bend[i] = lam[i];
+}
+
 // ---- head tiles: per-step gains from the tables, general affine wave scan (matrix, vector) -------------------------------------------
 // One wave walks the th head tiles in order.  Forward: innovations of the head -> tb.h_r, carry into the first stationary workgroup -> MUb[0],
 // sum r^2 / S -> misc[0].
@@ -2016,7 +2119,7 @@ __device__ __forceinline__ void block_carries(const double* __restrict__ cst, FG
 
 // pass 1: the stationary tiles with zero carries -> per-tile elements F, B0 and the workgroup's element (Fb, B0b)
 template <int D, bool POST>
-__global__ __launch_bounds__(kBlkThreads) void k_reduce(const long long* __restrict__ hdr, const double* __restrict__ cst, const double* __restrict__ y,
+__global__ __launch_bounds__(kBlkThreads / 2) void k_reduce(const long long* __restrict__ hdr, const double* __restrict__ cst, const double* __restrict__ y,
                                                 double* __restrict__ F, double* __restrict__ B0, double* __restrict__ Fb,
                                                 double* __restrict__ B0b, long long T, long long ntiles, ModelDev m, Tab tb, int side) {
     if (hdr[0] == 0) return;
@@ -2027,41 +2130,44 @@ __global__ __launch_bounds__(kBlkThreads) void k_reduce(const long long* __restr
     }
     const long long wg = (long long)blockIdx.x - (POST ? 1 : 0);
     __shared__ double sF[kBlk][D], sB0[kBlk][D], sMu[kBlk + 1][D], sLam[kBlk][D];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // (kBlkThreads / 2 threads: four waves, a wave's two halves are two tiles of 32 lanes x 16 steps)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sl = lane & 31, wt = 2 * wave + (lane >> 5);
     const long long tile0 = hdr[1] + wg * kBlk;
     if (tile0 >= ntiles) return;            // (the launch is sized for one head tile)
-    const long long tile = tile0 + wave;
+    const long long tile = tile0 + wt;
     double fend[D], bend[D];
 #pragma unroll
     for (int i = 0; i < D; ++i) fend[i] = bend[i] = 0.0;
-    if (tile < ntiles) {
+    {
+        // (both halves run the same instructions; a half whose tile lies behind the series' end has no valid step)
         Coef<D> cf;
         cf.load(cst);
-        const long long t0 = tile * kTile + lane * kSub;
-        double yv[kSub], r[kSub], zero[D];
+        const long long t0 = tile * kTile + sl * kSub2;
+        double yv[kSub2], r[kSub2], ya[kSub], yb[kSub];
+        load8(y, t0, T, ya);
+        load8(y, t0 + kSub, T, yb);
 #pragma unroll
-        for (int i = 0; i < D; ++i) zero[i] = 0.0;
-        load8(y, t0, T, yv);
+        for (int j = 0; j < kSub; ++j) {
+            yv[j] = ya[j];
+            yv[kSub + j] = yb[j];
+        }
         const long long left = T - t0;
-        const int nvalid = left >= kSub ? kSub : (left > 0 ? (int)left : 0);
-        tile_forward<D>(cf, cst + CL<D>::pphi, yv, nvalid, lane, zero, r, fend);
-        if (POST) {
-            double lst[D];
-            tile_backward<D>(cf, cst + CL<D>::pg, r, lane, zero, bend, lst);
-        }
+        const int nvalid = (tile < ntiles) ? (left >= kSub2 ? kSub2 : (left > 0 ? (int)left : 0)) : 0;
+        half_tile_forward<D>(cf, cst + CL<D>::pphi, yv, nvalid, sl, r, fend);
+        if (POST) half_tile_backward<D>(cf, cst + CL<D>::pg, r, sl, bend);
     }
-    if (lane == 63) {
+    if (sl == 31) {
 #pragma unroll
         for (int i = 0; i < D; ++i) {
-            sF[wave][i] = fend[i];
-            F[tile * D + i] = fend[i];
+            sF[wt][i] = fend[i];
+            if (tile < ntiles) F[tile * D + i] = fend[i];
         }
     }
-    if (POST && lane == 0) {
+    if (POST && sl == 0) {
 #pragma unroll
         for (int i = 0; i < D; ++i) {
-            sB0[wave][i] = bend[i];
-            B0[tile * D + i] = bend[i];
+            sB0[wt][i] = bend[i];
+            if (tile < ntiles) B0[tile * D + i] = bend[i];
         }
     }
     __syncthreads();
@@ -2773,7 +2879,7 @@ hipError_t ensure(Engine* e, int d, long long ntiles) {
         return o;
     };
     // constant block, as CL<D> lays it out
-    const size_t ss_size = 2 * DD + 5 * (size_t)d + 6, c_pphi = (ss_size + 7) & ~(size_t)7, c_pg = c_pphi + kPowN * DD, c_size = c_pg + kPowN * DD + 4 * DD + 3 * kBlk * DD + 4 * DD + (size_t)kSub * d;
+    const size_t ss_size = 2 * DD + 5 * (size_t)d + 6, c_pphi = (ss_size + 7) & ~(size_t)7, c_pg = c_pphi + kPowN * DD, c_size = c_pg + kPowN * DD + 4 * DD + 3 * kBlk * DD + 4 * DD + (size_t)2 * kSub * d;
     const size_t o_hdr = take(8), o_cst = take(c_size);
     const size_t o_hkA = take(nhmax * d), o_hrS = take(nhmax), o_hiS = take(nhmax), o_hG = take(nhmax * DD), o_hc = take(nhmax * d),
                  o_hvb = take(nhmax), o_hr = take(nhmax);
@@ -2816,7 +2922,7 @@ struct Scope {
 template <int D>
 int enqueue_d(Engine* e, hipStream_t st, const ModelDev& m, const CallDev& c, const Hooks& hk, const ShardDev* sh, int phase) {
     static_assert(CL<D>::pphi == ((2 * D * D + 5 * D + 6 + 7) & ~7), "ensure() mirrors CL<D>");
-    static_assert(CL<D>::size == CL<D>::pphi + 2 * kPowN * D * D + 4 * D * D + 3 * kBlk * D * D + 4 * D * D + kSub * D, "ensure() mirrors CL<D>");
+    static_assert(CL<D>::size == CL<D>::pphi + 2 * kPowN * D * D + 4 * D * D + 3 * kBlk * D * D + 4 * D * D + 2 * kSub * D, "ensure() mirrors CL<D>");
     static_assert(ShardSlot<D>::size == 1 + 2 * D + 3 * D * D, "shard_slot_size() mirrors ShardSlot<D>");
     const long long T = c.T;
     const long long ntiles = (T + kTile - 1) / kTile;
@@ -2832,10 +2938,10 @@ int enqueue_d(Engine* e, hipStream_t st, const ModelDev& m, const CallDev& c, co
         if (phase == 0) {
             { Scope s(hk, "k_steady_setup"); hipLaunchKernelGGL(k_setup_core<D>, dim3(1), dim3(D <= kCovScanMaxD ? 128 : 64), 0, st, m, tb, c.y, T, 0, flags | cov_mode_bits(), post ? 1 : 0, c.result); }
             if (post) {
-                { Scope s(hk, "k_steady_reduce<posterior>"); hipLaunchKernelGGL((k_reduce<D, true>), dim3(blocks + 1), dim3(kBlkThreads), 0, st, tb.hdr, tb.cst, c.y, tb.F, tb.B0, tb.Fb, tb.B0b, T, ntiles, m, tb, 1); }
+                { Scope s(hk, "k_steady_reduce<posterior>"); hipLaunchKernelGGL((k_reduce<D, true>), dim3(blocks + 1), dim3(kBlkThreads / 2), 0, st, tb.hdr, tb.cst, c.y, tb.F, tb.B0, tb.Fb, tb.B0b, T, ntiles, m, tb, 1); }
                 { Scope s(hk, "k_steady_carry<segment>"); hipLaunchKernelGGL((k_carry<D, true>), dim3(cblocks), dim3(512), 0, st, tb.hdr, tb.cst, tb.Fb, tb.B0b, tb.MUb, tb.LAMb, ntiles, 0); }
             } else {
-                { Scope s(hk, "k_steady_reduce<logpdf>"); hipLaunchKernelGGL((k_reduce<D, false>), dim3(blocks), dim3(kBlkThreads), 0, st, tb.hdr, tb.cst, c.y, tb.F, tb.B0, tb.Fb, tb.B0b, T, ntiles, m, tb, 0); }
+                { Scope s(hk, "k_steady_reduce<logpdf>"); hipLaunchKernelGGL((k_reduce<D, false>), dim3(blocks), dim3(kBlkThreads / 2), 0, st, tb.hdr, tb.cst, c.y, tb.F, tb.B0, tb.Fb, tb.B0b, T, ntiles, m, tb, 0); }
                 { Scope s(hk, "k_steady_carry<segment>"); hipLaunchKernelGGL((k_carry<D, false>), dim3(cblocks), dim3(512), 0, st, tb.hdr, tb.cst, tb.Fb, tb.B0b, tb.MUb, tb.LAMb, ntiles, 0); }
             }
             { Scope s(hk, "k_steady_shard_pack"); hipLaunchKernelGGL(k_shard_pack<D>, dim3(1), dim3(64), 0, st, tb, ntiles, post ? 1 : 0, sh->slot); }
@@ -2865,7 +2971,7 @@ int enqueue_d(Engine* e, hipStream_t st, const ModelDev& m, const CallDev& c, co
     }
     if (c.grad) {
         static_assert(GradRec<D>::size == 3 * D * D + 8 * D + 8 + D * (D + 1) / 2, "grad_record_size() mirrors GradRec<D>");
-        { Scope s(hk, "k_steady_reduce<adjoint>"); hipLaunchKernelGGL((k_reduce<D, true>), dim3(blocks + 1), dim3(kBlkThreads), 0, st, tb.hdr, tb.cst, c.y, tb.F, tb.B0, tb.Fb, tb.B0b, T, ntiles, m, tb, 0); }
+        { Scope s(hk, "k_steady_reduce<adjoint>"); hipLaunchKernelGGL((k_reduce<D, true>), dim3(blocks + 1), dim3(kBlkThreads / 2), 0, st, tb.hdr, tb.cst, c.y, tb.F, tb.B0, tb.Fb, tb.B0b, T, ntiles, m, tb, 0); }
         { Scope s(hk, "k_steady_carry<adjoint>"); hipLaunchKernelGGL((k_carry<D, true>), dim3(cblocks), dim3(512), 0, st, tb.hdr, tb.cst, tb.Fb, tb.B0b, tb.MUb, tb.LAMb, ntiles, 0); }
         { Scope s(hk, "k_steady_apply<adjoint>"); hipLaunchKernelGGL(k_apply_grad<D>, dim3(blocks), dim3(kBlkThreads), 0, st, tb.hdr, tb.cst, c.y, tb.F, tb.B0, tb.Pw, tb.Lw, tb.MUb, tb.LAMb, tb.GS, tb.SSQ, T, ntiles); }
         { Scope s(hk, "k_steady_final<adjoint>"); hipLaunchKernelGGL(k_final_grad<D>, dim3(GradRec<D>::NS), dim3(256), 0, st, tb, m, T, ntiles, tb.GS, (long long)blocks, tb.grec); }
@@ -2874,12 +2980,12 @@ int enqueue_d(Engine* e, hipStream_t st, const ModelDev& m, const CallDev& c, co
         return (int)hipGetLastError();
     }
     if (post) {
-        { Scope s(hk, "k_steady_reduce<posterior>"); hipLaunchKernelGGL((k_reduce<D, true>), dim3(blocks + 1), dim3(kBlkThreads), 0, st, tb.hdr, tb.cst, c.y, tb.F, tb.B0, tb.Fb, tb.B0b, T, ntiles, m, tb, 1); }
+        { Scope s(hk, "k_steady_reduce<posterior>"); hipLaunchKernelGGL((k_reduce<D, true>), dim3(blocks + 1), dim3(kBlkThreads / 2), 0, st, tb.hdr, tb.cst, c.y, tb.F, tb.B0, tb.Fb, tb.B0b, T, ntiles, m, tb, 1); }
         { Scope s(hk, "k_steady_carry<posterior>"); hipLaunchKernelGGL((k_carry<D, true>), dim3(cblocks), dim3(512), 0, st, tb.hdr, tb.cst, tb.Fb, tb.B0b, tb.MUb, tb.LAMb, ntiles, 0); }
         { Scope s(hk, "k_steady_apply<posterior>"); hipLaunchKernelGGL((k_apply<D, true>), dim3(blocks + 1), dim3(kBlkThreads), 0, st, tb.hdr, tb.cst, c.y, c.Rnew, c.rnew_per_step, tb.F, tb.B0, tb.Pw, tb.Lw, tb.MUb, tb.LAMb, tb.t_vb, c.mean, c.var, tb.SSQ, T, ntiles, tb); }
         { Scope s(hk, "k_steady_final<posterior>"); hipLaunchKernelGGL(k_final<D>, dim3(1), dim3(256), 0, st, tb, T, ntiles, c.result, c.y, c.Rnew, c.rnew_per_step, c.mean, c.var); }
     } else {
-        { Scope s(hk, "k_steady_reduce<logpdf>"); hipLaunchKernelGGL((k_reduce<D, false>), dim3(blocks), dim3(kBlkThreads), 0, st, tb.hdr, tb.cst, c.y, tb.F, tb.B0, tb.Fb, tb.B0b, T, ntiles, m, tb, 0); }
+        { Scope s(hk, "k_steady_reduce<logpdf>"); hipLaunchKernelGGL((k_reduce<D, false>), dim3(blocks), dim3(kBlkThreads / 2), 0, st, tb.hdr, tb.cst, c.y, tb.F, tb.B0, tb.Fb, tb.B0b, T, ntiles, m, tb, 0); }
         { Scope s(hk, "k_steady_carry<logpdf>"); hipLaunchKernelGGL((k_carry<D, false>), dim3(cblocks), dim3(512), 0, st, tb.hdr, tb.cst, tb.Fb, tb.B0b, tb.MUb, tb.LAMb, ntiles, 0); }
         { Scope s(hk, "k_steady_apply<logpdf>"); hipLaunchKernelGGL((k_apply<D, false>), dim3(blocks), dim3(kBlkThreads), 0, st, tb.hdr, tb.cst, c.y, (const double*)nullptr, 0, tb.F, tb.B0, tb.Pw, tb.Lw, tb.MUb, tb.LAMb, tb.t_vb, (double*)nullptr, (double*)nullptr, tb.SSQ, T, ntiles, tb); }
         { Scope s(hk, "k_steady_final<logpdf>"); hipLaunchKernelGGL(k_final<D>, dim3(1), dim3(256), 0, st, tb, T, ntiles, c.result, c.y, c.Rnew, 0, (double*)nullptr, (double*)nullptr); }
