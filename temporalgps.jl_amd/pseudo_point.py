@@ -150,6 +150,7 @@ def elbo(k, grid, sigma2s, y, z, device=0):
     Y = _obs(grid, y)
     T, N = grid.shape2
     _, var = L.marginals(model)                                 # H P H' + noise, (T, N)
+    var = np.asarray(var, dtype=np.float64).reshape(T, N)       # (one space point: the device hands back (T,), and (T, 1) - (T,) would broadcast to (T, T))
     Sig = np.broadcast_to(_noise(grid, sigma2s), (T, N))
     miss = np.isnan(Y)
     Sig_f = np.where(miss, 1e15, Sig)                           # fill_in_missings (missings.jl:43)

@@ -173,3 +173,23 @@ def test_gpu_regular_in_time_with_ragged_slices_equals_the_grid_with_those_point
     np.testing.assert_allclose(v_r, v_g, rtol=0, atol=1e-8)
     # flat <-> time form round trip (regular_in_time.jl:53-65)
     np.testing.assert_array_equal(ragged.unpad(ragged.pad(y_r, np.nan)), y_r)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["separable-2", "sum-separable-2"])
+def test_gpu_elbo_with_one_space_point(name):
+    """N = 1: the device returns the prior marginals of a scalar-observation model as (T,), and the trace term subtracted a (T,) from
+    a (T, 1) array (broadcast to (T, T)) until round 3 (scripts/stress_pseudo_point.py)."""
+    from temporalgps_jl_amd import lti_sde as S
+    from temporalgps_jl_amd import pseudo_point as pp
+    from temporalgps_jl_amd import space_time as ST
+    terms = KERNELS[name]
+    rng, r, z, t, tt = _case(seed=5, N=1, M=3, T=9)
+    k = _product_kernel(terms)
+    grid = ST.RectilinearGrid(r, S.RegularSpacing(0.0, 0.3, 9))
+    x, zz = dg.grid_points(r, tt), dg.grid_points(z, tt)
+    y = rng.standard_normal(len(x[0]))
+    noise = np.full(len(y), 0.1)
+    d_dense, e_dense = dg.dtc_dense(terms, x, zz, noise, y), dg.elbo_dense(terms, x, zz, noise, y)
+    assert abs(pp.dtc(k, grid, 0.1, y, z) - d_dense) <= 1e-6 * abs(d_dense)
+    assert abs(pp.elbo(k, grid, 0.1, y, z) - e_dense) <= 1e-6 * abs(e_dense)
