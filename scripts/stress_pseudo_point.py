@@ -109,6 +109,33 @@ for case in range(int(os.environ.get("START", "0")), min(n_cases, int(os.environ
                 msgs.append(f"posterior std {np.max(np.abs(np.sqrt(gv.reshape(-1)) - np.sqrt(pv))):.2e}")
     except StopIteration:
         pass
+    # RegularInTime with a different number of points per time slice (regular_in_time.jl:8-89) == the grid with the absent points missing
+    try:
+        if regular and T * N > 2 and not msgs:
+            keep2 = rng.random((T, N)) < 0.7
+            if T > 2:
+                keep2[T // 2] = False               # a slice with no observation at all
+            keep2[0, 0] = True
+            sig_full = 0.05 + 0.2 * rng.random((T, N)) if rng.random() < 0.5 else np.full((T, N), s2)
+            y_full = rng.standard_normal((T, N))
+            times = S.RegularSpacing(0.1, dt, T)
+            ragged = ST.RegularInTime(times, [r[keep2[i]] for i in range(T)])
+            g2 = ST.RectilinearGrid(r, times)
+            ym2 = np.where(keep2, y_full, np.nan)
+            a_, b_ = pp.dtc(k, ragged, sig_full[keep2], y_full[keep2], z), pp.dtc(k, g2, sig_full, ym2, z)
+            if not abs(a_ - b_) <= 1e-8 * max(1.0, abs(b_)):
+                msgs.append(f"ragged dtc {a_} vs grid with missing {b_}")
+            a_, b_ = pp.elbo(k, ragged, sig_full[keep2], y_full[keep2], z), pp.elbo(k, g2, sig_full, ym2, z)
+            if not abs(a_ - b_) <= 1e-8 * max(1.0, abs(b_)):
+                msgs.append(f"ragged elbo {a_} vs grid with missing {b_}")
+            x_pr = rng.standard_normal(3)
+            m_r, v_r = pp.approx_posterior_marginals(k, ragged, sig_full[keep2], y_full[keep2], z, x_pr)
+            m_g, v_g = pp.approx_posterior_marginals(k, g2, sig_full, ym2, z, x_pr)
+            if not (np.allclose(m_r, m_g, rtol=0, atol=1e-8) and np.allclose(v_r, v_g, rtol=0, atol=1e-8)):
+                msgs.append(f"ragged posterior {np.max(np.abs(m_r - m_g)):.2e} {np.max(np.abs(v_r - v_g)):.2e}")
+    except Exception as ex:      # noqa: BLE001
+        import traceback
+        msgs.append(f"ragged: {type(ex).__name__}: {ex} @ {traceback.extract_tb(ex.__traceback__)[-1].lineno}")
     except Exception as ex:      # noqa: BLE001
         import traceback
         msgs.append(f"{type(ex).__name__}: {ex} @ {traceback.extract_tb(ex.__traceback__)[-1].lineno}")
