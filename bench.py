@@ -708,14 +708,17 @@ def main():
             dt_n = float(tn.item())
         return dict(value=T / (dt_n / args.steps), ms_per_step=dt_n / args.steps * 1e3)
 
-    general, no_steady = None, None
+    general, no_steady, five = None, None, None
     if st_fast.value > 0 and args.layout == "lti":
+        if any(k.startswith("k_steady_one") for k in prof):
+            five = dict(timed_leg(2), note="TGP_OPT_STEADY = 2: round 3's form of the stationary-gain engine (set-up kernel, two passes over y, carry "
+                                           "and reduction kernels: five launches)")
         if steady_engine:
             general = dict(timed_leg(1), note="TGP_OPT_STEADY = 1: the general chunked-scan engine (round 2's path: full Kalman / RTS steps per chunk, "
                                               "mean-only once a chunk's covariance repeats bit for bit); agrees with the headline path to rounding")
         no_steady = dict(timed_leg(0), note="TGP_OPT_STEADY = 0: the general engine with every step in full (what a model with per-step blocks, per-step "
                                             "noise or missing data gets)")
-        hd.set_option(tgp._lib.OPT_STEADY, 2)
+        hd.set_option(tgp._lib.OPT_STEADY, 3)
     reuse = None
     if world > 1:
         tmax = torch.tensor([dt_s], dtype=torch.float64, device=f"cuda:{local}")
@@ -772,6 +775,8 @@ def main():
             roofline=roof,
             kernels={k: dict(avg_ms=v["total_ms"] / max(1, v["calls"]), calls=v["calls"]) for k, v in prof.items()},
         )
+        if five is not None:
+            out["with_five_launch_engine"] = five
         if general is not None:
             out["with_general_engine"] = general
         if no_steady is not None:

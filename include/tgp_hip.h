@@ -93,7 +93,14 @@ typedef struct tgp_handle tgp_handle;
 #define TGP_OPT_STEADY 12 /* Forward LTI models (every block shared) with ONE noise variance, scalar observations, no missing data -- the
                              reference's Fill layout for RegularSpacing inputs, lti_sde.jl:148-160. For such a model the covariance half
                              of the Kalman / RTS recursion never sees the data.
-                             2 (default): the stationary-gain scan engine (tgp_steady.hip, d <= 8) serves tgp_logpdf and
+                             3 (default since round 4): as 2, with the engine's ONE-LAUNCH form (tgp_modal.hip) tried first: the host runs the
+                               covariance recursion to its fixed point inside the call (microseconds in double; see tgp_steady_plan), puts the
+                               stationary closed loop into modal form (O(d) per step), and ONE kernel over y does the rest: every workgroup
+                               starts `halo` steps early from a zero state and stops `halo` steps late (both mean recursions have forgotten a
+                               state by then: |eigenvalue|^halo <= 2^-64), so there is no pass over y before it and no carry between
+                               workgroups; the workgroups' partial sums of squares land in pinned host memory and the host adds them.
+                               Models it declines (ill-conditioned modal form, slow mixing, long heads) go on as with 2.
+                             2: the stationary-gain scan engine (tgp_steady.hip, d <= 8) serves tgp_logpdf and
                                tgp_[logpdf_and_]posterior_marginals: the covariance recursion is run once per call until it no longer
                                changes (n0 steps, ~60 at the bench model; per-step gains of that head are tabulated), and the T steps
                                are left with two linear recursions of the MEAN (forward: innovations; backward: smoothed minus filtered
@@ -203,6 +210,22 @@ int tgp_logpdf_grad_sde(tgp_handle* h, const double* y, const uint8_t* missing, 
  * TGP_EUNSUPPORTED when the engine does not apply (use tgp_logpdf_grad). */
 int tgp_logpdf_adjoint(tgp_handle* h, const double* y, uint32_t flags, double* lml_out, double* gA, double* ga,
                        double* gQ, double* gH, double* ghh, double* gR, double* gx0m, double* gx0P);
+/* The plan of the stationary-gain engine's ONE-LAUNCH path (TGP_OPT_STEADY = 3, the default), a pure host function: what
+ * tgp_logpdf / tgp_[logpdf_and_]posterior_marginals build inside every call of a Forward LTI model with one noise variance and scalar
+ * observations (d <= 8) before their single kernel -- the covariance half of lgssm.jl:99-238 (predict lgc.jl:46-52, update lgc.jl:247-257,
+ * invert_dynamics lgssm.jl:231-238) run to its fixed point on the host, and the stationary mean recursions in modal form.
+ * Model blocks as for tgp_model_set (host pointers, column-major, every block shared). Outputs (host):
+ *   info_i [8]: why (0 applies, 1 covariance not settled within 623 steps, 2 not positive definite, 3 series shorter than head + tail,
+ *               4 closed loop ill-conditioned in modal form, 5 mixes too slowly for a 1536-step halo, 6 smoother transient > 2048 steps,
+ *               7 eigenvalue iteration failed), n0, n1, head steps, halo steps, complex pairs, waves per workgroup, 0
+ *   info_d [4]: condition numbers of the two eigenvector matrices, spectral radius, residual of the rejected check
+ *   modal_out [270] (may be NULL; 8-strided arrays): fd fo fb fa fw | gd go gc gw | M^8 re, im fwd, bwd | M^512 re, im fwd, bwd | WJ [8][8] |
+ *               WG [8][8] | hh, R/S, 1/S, log S, sum of log S over the head, smoothed stationary variance
+ *   tables_out (may be NULL; capacity 624 (d d + 2 d + 3) + 2048 + 80): h [8], modal mu0 [8], W [64], then per head step t <= n0:
+ *               V^-1 (A K_t - A K) [d], 1/S_t, R/S_t, G_t [d d], c_t [d], smoothed variance, and the n1 tail variances. */
+int tgp_steady_plan(int d, const double* A, const double* a, const double* Q, const double* H, const double* hh, const double* R,
+                    const double* x0m, const double* x0P, int64_t T, int32_t* info_i, double* info_d, double* modal_out,
+                    double* tables_out);
 /* the host half of it, a pure host function (tests; callers that keep the device record): rec = tgp_adjoint_record_size(d)
  * doubles as tgp_steady.hpp lays them out, y_head = the first n_head observations (n_head >= 512 * head tiles) */
 int tgp_adjoint_record_size(int d);

@@ -47,6 +47,7 @@ _SIGS = {
     "tgp_logpdf_grad_sde": (ctypes.c_int, [_vp, _vp, _vp, _u32, ctypes.c_int] + [_vp] * 10 + [ctypes.c_double, _dp, _vp]),
     "tgp_logpdf_adjoint": (ctypes.c_int, [_vp, _vp, _u32, _dp] + [_vp] * 8),
     "tgp_adjoint_record_size": (ctypes.c_int, [ctypes.c_int]),
+    "tgp_steady_plan": (ctypes.c_int, [ctypes.c_int] + [_vp] * 8 + [_i64, _vp, _vp, _vp, _vp]),
     "tgp_adjoint_finish": (ctypes.c_int, [ctypes.c_int, _vp, _vp, _i64] + [_vp] * 8),
     "tgp_filter": (ctypes.c_int, [_vp, _vp, _vp, _u32, _vp, _vp, _dp]),
     "tgp_posterior": (ctypes.c_int, [_vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp, _vp]),

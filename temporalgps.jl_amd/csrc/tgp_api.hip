@@ -20,6 +20,7 @@
 #include "tgp_kernels.hpp"
 #include "tgp_dense.hpp"
 #include "tgp_steady.hpp"
+#include "tgp_modal.hpp"
 #include "tgp_adjoint_host.hpp"
 
 namespace tgp {
@@ -320,6 +321,13 @@ struct tgp_handle {
     tgp_steady::Engine* steady2 = nullptr;
     int steady2_state = 0;       // 0 untried for the bound model, 1 served the last call, -1 does not apply
     bool steady2_last = false;   // the last logpdf / posterior-marginals call was served by it
+    // TGP_OPT_STEADY = 3 (default since round 4): the ONE-LAUNCH form of that engine (tgp_modal.hip) is tried first -- host plan + one kernel
+    // over y + the host's sum of the workgroups' partial sums; a model / series it does not serve (tgp_plan::Info::why) goes on as with 2.
+    int opt_modal = 1;
+    tgp_modal::Engine* modal = nullptr;
+    int modal_state = 0;         // 0 untried for the bound model, 1 served the last call, -1 does not apply
+    bool modal_last = false;
+    std::vector<double> hostm;   // host copy of the shared blocks of an LTI model: A | a | Q | H | hh | R (what the host plan reads)
     void* steady2_scope = nullptr;
     bool table_pending = false;  // the kernel-variant choice (and its run-time check) of the general engine is deferred to its first use
     int shard2_first = 1, shard2_last = 1, shard2_post = 0;      // the open two-half call of a stationary-gain time shard
@@ -1109,6 +1117,86 @@ int steady2_enqueue(tgp_handle* h, const double* Rnew_dev, bool rnew_per_step, d
     return TGP_OK;
 }
 // After CallTimer::finish: did the engine serve the call? (host_result[6]; 2 = it found on the device that it does not apply)
+// ---- the one-launch form (tgp_modal.hip). Returns TGP_OK with *served = true when it ran the call (lml in *lml_out, outputs written);
+// *served = false: it does not apply to this model / series -- nothing was enqueued.
+int modal_call(tgp_handle* h, const double* y, uint32_t flags, const double* Rnew, double* mean_out, double* var_out, double* lml_out, bool* served) {
+    *served = false;
+    h->modal_last = false;
+    if (!h->opt_modal || h->modal_state < 0 || h->hostm.empty()) return TGP_OK;
+    if (!h->modal) h->modal = tgp_modal::create();
+    const int d = h->d;
+    const size_t dd = (size_t)d * d;
+    const double* q = h->hostm.data();
+    tgp_plan::ModelHost mh;
+    mh.d = d;
+    mh.A = q; mh.a = q + dd; mh.Q = q + dd + d; mh.H = q + 2 * dd + d; mh.hh = q + 2 * dd + 2 * d; mh.R = q + 2 * dd + 2 * d + 1;
+    mh.x0m = h->x0m.data();
+    mh.x0P = h->x0P.data();
+    if (!tgp_modal::plan(h->modal, mh, h->T)) {
+        h->modal_state = -1;
+        if (getenv("TGP_STEADY_DEBUG") != nullptr) {
+            const tgp_plan::Info& in = tgp_modal::last_plan(h->modal);
+            fprintf(stderr, "[tgp modal] does not apply: why %d, n0 %d n1 %d halo %d cond %.3g / %.3g rho %.6f resid %.3g\n", in.why, in.n0, in.n1, in.halo, in.cond_f, in.cond_g, in.rho, in.resid);
+        }
+        return TGP_OK;
+    }
+    const bool idev = (flags & TGP_IN_DEVICE) != 0, odev = (flags & TGP_OUT_DEVICE) != 0;
+    const bool rshared = (flags & TGP_SHARED_R) != 0;
+    const size_t nT = (size_t)h->T * sizeof(double);
+    CallTimer tm(h, /*clear=*/false);
+    const void* pR = nullptr;
+    if (mean_out) TRY(stage_in(h, h->bRnew, Rnew, rshared ? sizeof(double) : nT, idev, &pR));
+    TRY(set_obs(h, y, nullptr, flags));
+    tm.inputs_done();
+    double *dm = nullptr, *dv = nullptr;
+    TRY(stage_out(h, h->bo1, mean_out, nT, odev, &dm));
+    TRY(stage_out(h, h->bo2, var_out, nT, odev, &dv));
+    tgp_modal::Call c;
+    c.T = h->T;
+    c.y = h->mv.y;
+    c.Rnew = static_cast<const double*>(pR);
+    c.rnew_per_step = (mean_out && !rshared) ? 1 : 0;
+    c.mean = dm;
+    c.var = dv;
+    {
+        std::string err;
+        const char* kname = "k_steady_one";
+        // (the name is known only after the launch has picked its variant: bracket with a provisional scope name chosen the same way)
+        const tgp_plan::Modal& md = tgp_modal::last_modal(h->modal);
+        const bool wide = 2 * md.halo * 10 > 3 * 8 * 512;
+        LaunchScope ls(h, dm ? (wide ? "k_steady_one16<posterior>" : "k_steady_one<posterior>") : (wide ? "k_steady_one16<logpdf>" : "k_steady_one<logpdf>"));
+        if (tgp_modal::enqueue(h->modal, h->stream, c, &kname, &err) != 0) return h->fail(TGP_EHIP, err);
+    }
+    tm.kernels_done();
+    TRY(copy_back(h, mean_out, dm, nT, odev));
+    TRY(copy_back(h, var_out, dv, nT, odev));
+    if (h->timing) (void)hipEventRecord(h->ev[3], h->stream);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->timing) {
+        float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+        (void)hipEventElapsedTime(&t0, h->ev[0], h->ev[1]);
+        (void)hipEventElapsedTime(&t1, h->ev[1], h->ev[2]);
+        (void)hipEventElapsedTime(&t2, h->ev[2], h->ev[3]);
+        h->h2d_ms = t0;
+        h->kernel_ms = t1;
+        h->d2h_ms = t2;
+    }
+    resolve_profile(h);
+    const double lml = tgp_modal::finish(h->modal, h->T);
+    for (int i = 0; i < 8; ++i) h->host_result[i] = 0.0;
+    h->host_result[0] = lml;
+    h->host_result[6] = tgp_steady::kStatusRan;
+    h->host_result[7] = (double)tgp_modal::last_plan(h->modal).n0;
+    if (lml_out) *lml_out = lml;
+    h->modal_state = 1;
+    h->modal_last = true;
+    h->steady2_last = false;
+    h->reduce_valid = false;
+    h->smoother_valid = false;
+    *served = true;
+    return TGP_OK;
+}
+
 bool steady2_served(tgp_handle* h) {
     const bool ran = h->host_result[6] == tgp_steady::kStatusRan;
     h->steady2_state = ran ? 1 : -1;
@@ -1184,6 +1272,7 @@ int tgp_destroy(tgp_handle* h) {
     for (auto& e : h->evpool) (void)hipEventDestroy(e);
     if (h->dense) tgp_dense::destroy(h->dense);
     if (h->steady2) tgp_steady::destroy(h->steady2);
+    if (h->modal) tgp_modal::destroy(h->modal);
     if (h->host_result) (void)hipHostFree(h->host_result);
     if (h->adj_host) (void)hipHostFree(h->adj_host);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -1238,8 +1327,10 @@ int tgp_set_option(tgp_handle* h, int option, int64_t value) {
     }
     if (option == TGP_OPT_STEADY) {
         h->opt_steady = value != 0;
-        h->opt_steady2 = value == 2;
+        h->opt_steady2 = value >= 2;
+        h->opt_modal = value >= 3;
         h->steady2_state = 0;
+        h->modal_state = 0;
         h->steady_known = false;
         h->smoother_valid = false;
         return TGP_OK;
@@ -1293,6 +1384,10 @@ int tgp_steady_steps(tgp_handle* h, int64_t* mean_only, int64_t* total) {
     *mean_only = 0;
     *total = h->T * h->p;
     if (h->is_dense) return TGP_OK;
+    if (h->modal_last && h->modal) {          // one-launch path: every step beyond the head's n0 ran with the stationary gains
+        *mean_only = h->T - tgp_modal::last_plan(h->modal).n0;
+        return TGP_OK;
+    }
     if (h->steady2_last && h->steady2) {      // stationary-gain engine: every step beyond the head's n0 ran with the stationary gains
         int64_t info[4] = {0, 0, 0, 0};
         HIPCHK(hipSetDevice(h->device));
@@ -1338,6 +1433,9 @@ int tgp_model_set(tgp_handle* h, int64_t T, int d, int p, int ordering, uint32_t
     h->mv.steady = nullptr;
     h->steady2_state = 0;
     h->steady2_last = false;
+    h->modal_state = 0;
+    h->modal_last = false;
+    h->hostm.clear();
     h->fold_valid = false;
     h->reduce_valid = false;
     h->smoother_valid = false;
@@ -1442,6 +1540,19 @@ int tgp_model_set(tgp_handle* h, int64_t T, int d, int p, int ordering, uint32_t
     h->x0P.assign(x0P, x0P + d * d);
     TRY(upload_x0(h, h->bx0, x0m, x0P));
     HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->lti && !h->binding_sde && p == 1 && (flags & TGP_SHARED_R) && ordering == 0 && tgp_steady::supports(d)) {
+        // what the one-launch path's host plan reads (tgp_steady_plan.hpp): the shared blocks, on the host
+        const size_t dd = (size_t)d * d;
+        h->hostm.assign(2 * dd + 2 * (size_t)d + 2, 0.0);
+        double* q = h->hostm.data();
+        const struct { const double* src; size_t n; } parts[6] = {{A, dd}, {a, (size_t)d}, {Q, dd}, {H, (size_t)d}, {hh, 1}, {R, 1}};
+        size_t off = 0;
+        for (const auto& pt : parts) {
+            if (dev) HIPCHK(hipMemcpy(q + off, pt.src, pt.n * sizeof(double), hipMemcpyDeviceToHost));
+            else std::memcpy(q + off, pt.src, pt.n * sizeof(double));
+            off += pt.n;
+        }
+    }
     h->have_model = true;
     return TGP_OK;
 }
@@ -1586,6 +1697,7 @@ int tgp_model_set_x0(tgp_handle* h, const double* x0m, const double* x0P) {
     h->x0m.assign(x0m, x0m + h->d);
     h->x0P.assign(x0P, x0P + (size_t)h->d * h->d);
     h->steady_known = false;
+    h->modal_state = 0;
     if (h->is_dense) return dense_fail(h, tgp_dense::set_x0(h->dense, x0m, x0P, h->stream));
     h->fold_valid = false;
     h->smoother_valid = false;
@@ -1596,6 +1708,12 @@ int tgp_logpdf(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t 
     TRY(check_ready(h, /*general=*/false));
     if (!out) return h->fail(TGP_EINVAL, "out is NULL");
     h->steady2_last = false;
+    h->modal_last = false;
+    if (steady2_eligible(h, missing, flags)) {
+        bool served = false;
+        TRY(modal_call(h, y, flags, nullptr, nullptr, nullptr, out, &served));
+        if (served) return TGP_OK;
+    }
     if (steady2_eligible(h, missing, flags)) {
         CallTimer tm(h, /*clear=*/false);      // (the engine's set-up kernel clears the result record itself: one launch less)
         TRY(set_obs(h, y, missing, flags));
@@ -1632,6 +1750,49 @@ int tgp_logpdf(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t 
     TRY(forward_apply(h, 0, fo));
     tm.kernels_done();
     return tm.finish(out);
+}
+
+// Host-only (no GPU needed): the plan the one-launch path of the stationary-gain engine builds inside every call (tgp_steady_plan.hpp).
+int tgp_steady_plan(int d, const double* A, const double* a, const double* Q, const double* H, const double* hh, const double* R, const double* x0m,
+                    const double* x0P, int64_t T, int32_t* info_i, double* info_d, double* modal_out, double* tables_out) {
+    if (d < 1 || d > tgp_plan::kMaxD || !A || !a || !Q || !H || !hh || !R || !x0m || !x0P || T <= 0 || !info_i || !info_d) return TGP_EINVAL;
+    static thread_local tgp_plan::HeadTables tab;
+    tgp_plan::Modal md{};
+    tgp_plan::ModelHost mh;
+    mh.d = d;
+    mh.A = A; mh.a = a; mh.Q = Q; mh.H = H; mh.hh = hh; mh.R = R; mh.x0m = x0m; mh.x0P = x0P;
+    const tgp_plan::Info in = tgp_plan::build_any(mh, T, md, tab);
+    info_i[0] = in.why; info_i[1] = in.n0; info_i[2] = in.n1; info_i[3] = in.why == 0 ? md.nhs : 0; info_i[4] = in.halo; info_i[5] = in.why == 0 ? md.npair : 0;
+    info_i[6] = (2 * in.halo * 10 <= 3 * 8 * 512) ? 8 : 16;
+    info_i[7] = 0;
+    info_d[0] = in.cond_f; info_d[1] = in.cond_g; info_d[2] = in.rho; info_d[3] = in.resid;
+    if (in.why != 0) return TGP_OK;
+    if (modal_out) {
+        double* q = modal_out;
+        const double* arrs[17] = {md.fd, md.fo, md.fb, md.fa, md.fw, md.gd, md.go, md.gc, md.gw, md.fp8r, md.fp8i, md.gp8r, md.gp8i, md.fp512r, md.fp512i, md.gp512r, md.gp512i};
+        for (const double* ar : arrs)
+            for (int i = 0; i < tgp_plan::kMaxD; ++i) *q++ = ar[i];
+        for (int j = 0; j < tgp_plan::kSub; ++j)
+            for (int i = 0; i < tgp_plan::kMaxD; ++i) *q++ = md.WJ[j][i];
+        for (int j = 0; j < tgp_plan::kSub; ++j)
+            for (int i = 0; i < tgp_plan::kMaxD; ++i) *q++ = md.WG[j][i];
+        *q++ = md.hh; *q++ = md.rS; *q++ = md.iS; *q++ = md.logS; *q++ = md.LS; *q++ = md.vb;
+    }
+    if (tables_out) {
+        double* q = tables_out;
+        const int n = md.n0 + 1, dd = d * d;
+        for (int i = 0; i < tgp_plan::kMaxD; ++i) *q++ = tab.h[i];
+        for (int i = 0; i < tgp_plan::kMaxD; ++i) *q++ = tab.mu0[i];
+        for (int i = 0; i < tgp_plan::kMaxD * tgp_plan::kMaxD; ++i) *q++ = tab.Wm[i];
+        for (int i = 0; i < n * d; ++i) *q++ = tab.kA[i];
+        for (int i = 0; i < n; ++i) *q++ = tab.iS[i];
+        for (int i = 0; i < n; ++i) *q++ = tab.rS[i];
+        for (int i = 0; i < n * dd; ++i) *q++ = tab.G[i];
+        for (int i = 0; i < n * d; ++i) *q++ = tab.c[i];
+        for (int i = 0; i < n; ++i) *q++ = tab.vb[i];
+        for (int i = 0; i < md.n1; ++i) *q++ = tab.tvb[i];
+    }
+    return TGP_OK;
 }
 
 int tgp_adjoint_record_size(int d) { return (d >= 1 && d <= tgp_steady::kMaxD) ? tgp_adjoint::record_size(d) : 0; }
@@ -1807,6 +1968,12 @@ int tgp_posterior_marginals(tgp_handle* h, const double* y, const uint8_t* missi
     const bool rshared = (flags & TGP_SHARED_R) != 0;
     const size_t nT = (size_t)h->T * h->p * sizeof(double);   // one value per (time step, observation)
     h->steady2_last = false;
+    h->modal_last = false;
+    if (steady2_eligible(h, missing, flags)) {
+        bool served = false;
+        TRY(modal_call(h, y, flags, Rnew, mean_out, var_out, lml_out, &served));
+        if (served) return TGP_OK;
+    }
     if (steady2_eligible(h, missing, flags)) {
         CallTimer tm(h, /*clear=*/false);
         const void* pR = nullptr;

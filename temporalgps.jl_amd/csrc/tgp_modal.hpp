@@ -1,0 +1,38 @@
+// Stationary-gain engine, ONE-LAUNCH path (round 4): logpdf and posterior marginals of an LTI model with one noise variance,
+// scalar observations and no missing data -- the reference's `Fill` layout for RegularSpacing inputs (src/gp/lti_sde.jl:148-160) -- as
+//     host plan (tgp_steady_plan.hpp: covariance recursion to its fixed point, gains, variance tables, modal form; a few microseconds)
+//   + ONE kernel over y (k_steady_one: reads y once, writes mean and var once; no pass before it, no carry kernel, no reduction kernel)
+//   + the host's sum of the workgroups' partial sums of squares (they land in pinned host memory; the call synchronises anyway).
+// It computes what tgp_steady.hip computes (same re-association of lgssm.jl:99-238, lgc.jl:46-52,247-257), in the modal coordinates of
+// the stationary closed loop.  Applies when the plan says so (tgp_plan::Info::why == kOk); every other case stays on tgp_steady.hip /
+// the general engine.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#include "tgp_steady_plan.hpp"
+
+namespace tgp_modal {
+
+struct Call {
+    long long T = 0;
+    const double* y = nullptr;      // device
+    const double* Rnew = nullptr;   // device: one value, or T values when rnew_per_step
+    int rnew_per_step = 0;
+    double *mean = nullptr, *var = nullptr;      // device; nullptr: logpdf only
+};
+
+struct Engine;
+Engine* create();
+void destroy(Engine*);
+// Host half: builds the plan of a T-step call of the model (nothing is kept from earlier calls).  false: the path does not apply (last_plan().why).
+bool plan(Engine*, const tgp_plan::ModelHost&, long long T);
+// Enqueues the kernel of the planned call on `stream` (no synchronisation); *kname names it for the profile.
+int enqueue(Engine*, hipStream_t stream, const Call&, const char** kname, std::string* err);
+// Once the stream has passed the kernel: the log marginal likelihood.
+double finish(const Engine*, long long T);
+const tgp_plan::Info& last_plan(const Engine*);
+const tgp_plan::Modal& last_modal(const Engine*);
+
+}  // namespace tgp_modal

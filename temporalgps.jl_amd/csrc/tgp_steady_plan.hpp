@@ -1,0 +1,820 @@
+// Host half of the stationary-gain engine's one-launch path (round 4): everything about a call that does not depend on the observations.
+//
+// For an LTI model with one noise variance the covariance half of the reference recursion (predict lgc.jl:46-52, the scalar update
+// lgc.jl:247-257, invert_dynamics lgssm.jl:231-238, the Reverse step_marginals lgssm.jl:111-115) never sees y.  Round 3 ran it in a
+// one-wave kernel (36 us at d = 3, 222 us at d = 8: a dependent chain on a 2.4 GHz lane); here the host runs it in double, inside the
+// call (nothing is kept between calls), in a few microseconds:
+//   * the filtered covariance to its fixed point (n0 steps, the 2-ulp criterion of tgp_steady.hip) with the per-step gains of that head,
+//   * the smoothed variances of the head and of the last n1 steps (the smoother's transient from the final filtered state),
+//   * the stationary closed-loop matrices Phi = A - (A K) h' and G (smoother gain) in MODAL form: Phi = V M V^-1 with M block diagonal
+//     (1 x 1 blocks for real eigenvalues, 2 x 2 rotation-scaling blocks for complex pairs), so that both mean recursions cost O(d) per
+//     step instead of O(d^2) and every power M^n is an element-wise (complex) power.  The decomposition is accepted only if the
+//     eigenvector matrices are well conditioned and reproduce Phi, G and the impulse response h' Phi^j (A K) to ~1e-13; otherwise
+//     (near-defective closed loops, e.g. a sum of two IDENTICAL kernels) the call stays on the dense kernels of tgp_steady.hip.
+//   * the halo length h: the number of steps after which Phi^h, G^h have decayed below 2^-64 -- a workgroup of the one-launch kernel
+//     starts h steps early from a zero state and stops h steps late.
+// Plain C++ (no HIP): compiled into libtgp_hip.so and exercised on the CPU tier through tgp_steady_plan_debug (tests/test_steady_plan.py).
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+
+namespace tgp_plan {
+
+constexpr int kMaxD = 8;
+constexpr int kN0Max = 623;        // head steps with gains of their own the one-launch path accepts (nhs <= 640)
+constexpr int kHeadMax = 640;      // nhs <= kHeadMax
+constexpr int kTailMax = 2048;
+constexpr int kHaloMax = 1536;     // longest halo (steps) served by the one-launch kernel
+constexpr double kTol = 4.5e-16;   // "no longer changes": 2 ulp relative to the element's natural scale (as tgp_steady.hip)
+constexpr double kCondMax = 1e5;
+constexpr int kSub = 8;            // steps per lane of a tile
+
+enum Why : int { kOk = 0, kNotSettled = 1, kNotPD = 2, kTooShort = 3, kIllConditioned = 4, kSlowMixing = 5, kTailLong = 6, kEigFail = 7 };
+
+// Everything the one-launch kernel reads through its kernel arguments (uniform values: scalar loads).  Components are ordered complex
+// pairs first -- positions (0, 1), (2, 3), ... -- then real modes; partner(i) = i ^ 1 where that exists, else i.
+//   forward   z' = fd z + fo z_partner + fb u + fa,  u = y - hh,  r = u - fw . z          (z = V^-1 mu, mu the predicted mean)
+//   backward  zeta' = gd zeta + go zeta_partner + gc r,  mean = y - rS r + gw . zeta      (zeta = W^-1 lam)
+struct Modal {
+    int d, n0, nhs, n1, halo, npair;
+    double hh, rS, iS, logS, LS, vb;
+    double fd[kMaxD], fo[kMaxD], fb[kMaxD], fa[kMaxD], fw[kMaxD];
+    double gd[kMaxD], go[kMaxD], gc[kMaxD], gw[kMaxD];
+    double fp8r[kMaxD], fp8i[kMaxD], gp8r[kMaxD], gp8i[kMaxD];              // M^8 (re, signed im), forward / backward
+    double fp512r[kMaxD], fp512i[kMaxD], gp512r[kMaxD], gp512i[kMaxD];      // M^512
+    double WJ[kSub][kMaxD];        // fw' M^j: the innovation j steps behind a lane's start state st is r0_j - WJ[j] . st
+    double WG[kSub][kMaxD];        // gw' Mg^(7-j): the output of the lane's step j sees the lane's right-hand input through it
+};
+
+// What only the head wave of workgroup 0 and the last tiles read (pinned host memory, read by the device in place).
+struct HeadTables {
+    double h[kMaxD];
+    double mu0[kMaxD];             // V^-1 (A x0.m + a): the predicted mean of step 0 in the modal coordinates of the stationary closed loop
+    double Wm[kMaxD * kMaxD];      // lam = Wm zeta (row-major)
+    // per-step tables, t = 0..n0 (entry n0 is the stationary step), rows of d (d d) values packed by the model's d
+    double kA[(kN0Max + 1) * kMaxD];      // V^-1 (A K_t - A K): what the head's forward recursion adds to the stationary one (zero at n0)
+    double iS[kN0Max + 1], rS[kN0Max + 1];
+    double G[(kN0Max + 1) * kMaxD * kMaxD], c[(kN0Max + 1) * kMaxD], vb[kN0Max + 1];
+    double tvb[kTailMax];          // H Ps H' at step T-1-j, j < n1
+};
+
+struct Info {
+    int why = 0, n0 = -1, n1 = -1, halo = 0;
+    double cond_f = 0, cond_g = 0, rho = 0, resid = 0;
+};
+
+struct ModelHost {      // shared blocks, column-major as handed to tgp_model_set; x0P full d x d (upper triangle used)
+    int d = 0;
+    const double *A = nullptr, *a = nullptr, *Q = nullptr, *H = nullptr, *hh = nullptr, *R = nullptr, *x0m = nullptr, *x0P = nullptr;
+};
+
+namespace detail {
+
+// (plain multiply-add: without -mfma std::fma is a libm call on x86-64 -- 40x the cost of the whole plan)
+inline double pfma(double a, double b, double c) { return a * b + c; }
+
+// (a bare complex type: std::complex multiplies and divides through __muldc3 / __divdc3 and takes moduli through hypot -- together
+//  three quarters of the time of a 3 x 3 decomposition)
+struct cplx {
+    double re, im;
+    cplx() : re(0.0), im(0.0) {}
+    cplx(double r) : re(r), im(0.0) {}
+    cplx(double r, double i) : re(r), im(i) {}
+    double real() const { return re; }
+    double imag() const { return im; }
+    cplx& operator+=(const cplx& o) { re += o.re; im += o.im; return *this; }
+    cplx& operator-=(const cplx& o) { re -= o.re; im -= o.im; return *this; }
+    cplx& operator*=(const cplx& o) { const double r = re * o.re - im * o.im; im = re * o.im + im * o.re; re = r; return *this; }
+    cplx& operator*=(double f) { re *= f; im *= f; return *this; }
+    cplx& operator/=(double f) { const double g = 1.0 / f; re *= g; im *= g; return *this; }
+};
+inline cplx operator+(const cplx& a, const cplx& b) { return cplx(a.re + b.re, a.im + b.im); }
+inline cplx operator-(const cplx& a, const cplx& b) { return cplx(a.re - b.re, a.im - b.im); }
+inline cplx operator-(const cplx& a) { return cplx(-a.re, -a.im); }
+inline cplx operator*(const cplx& a, const cplx& b) { return cplx(a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re); }
+inline cplx operator*(double f, const cplx& a) { return cplx(f * a.re, f * a.im); }
+inline cplx operator*(const cplx& a, double f) { return cplx(f * a.re, f * a.im); }
+inline cplx operator/(const cplx& a, double f) { const double g = 1.0 / f; return cplx(a.re * g, a.im * g); }
+inline cplx operator/(const cplx& a, const cplx& b) {
+    const double g = 1.0 / (b.re * b.re + b.im * b.im);
+    return cplx((a.re * b.re + a.im * b.im) * g, (a.im * b.re - a.re * b.im) * g);
+}
+inline cplx conj(const cplx& a) { return cplx(a.re, -a.im); }
+inline double norm(const cplx& a) { return a.re * a.re + a.im * a.im; }
+inline double cabs(const cplx& a) { return std::sqrt(a.re * a.re + a.im * a.im); }
+inline cplx csqrt(const cplx& a) {      // principal square root
+    const double m = cabs(a);
+    if (m == 0.0) return cplx(0.0, 0.0);
+    const double sr = std::sqrt(0.5 * (m + std::fabs(a.re)));
+    const double si = 0.5 * a.im / sr;
+    return (a.re >= 0.0) ? cplx(sr, si) : cplx(std::fabs(si), a.im >= 0.0 ? sr : -sr);
+}
+
+// Complex Schur form of a real n x n matrix (row-major in, n <= 8): Hessenberg reduction by Householder reflections, then single-shift QR
+// with Wilkinson shifts and deflation.  T upper triangular, Q unitary, M = Q T Q^H.  Returns false if an eigenvalue does not converge.
+inline bool complex_schur(int n, const double* M, cplx* T, cplx* Q) {
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+            T[i * n + j] = M[i * n + j];
+            Q[i * n + j] = (i == j) ? 1.0 : 0.0;
+        }
+    // Hessenberg
+    for (int k = 0; k + 2 < n; ++k) {
+        double alpha = 0.0;
+        for (int i = k + 1; i < n; ++i) alpha += norm(T[i * n + k]);
+        alpha = std::sqrt(alpha);
+        if (alpha == 0.0) continue;
+        cplx v[kMaxD];
+        const cplx x0 = T[(k + 1) * n + k];
+        const cplx ph = (cabs(x0) == 0.0) ? cplx(1.0) : x0 / cabs(x0);
+        for (int i = 0; i < n; ++i) v[i] = (i > k) ? T[i * n + k] : cplx(0.0);
+        v[k + 1] += ph * alpha;
+        double vn = 0.0;
+        for (int i = k + 1; i < n; ++i) vn += norm(v[i]);
+        if (vn == 0.0) continue;
+        // H = I - 2 v v^H / (v^H v): T <- H T H, Q <- Q H
+        for (int j = 0; j < n; ++j) {
+            cplx s = 0.0;
+            for (int i = k + 1; i < n; ++i) s += conj(v[i]) * T[i * n + j];
+            s *= 2.0 / vn;
+            for (int i = k + 1; i < n; ++i) T[i * n + j] -= v[i] * s;
+        }
+        for (int i = 0; i < n; ++i) {
+            cplx s = 0.0, sq = 0.0;
+            for (int j = k + 1; j < n; ++j) {
+                s += T[i * n + j] * v[j];
+                sq += Q[i * n + j] * v[j];
+            }
+            s *= 2.0 / vn;
+            sq *= 2.0 / vn;
+            for (int j = k + 1; j < n; ++j) {
+                T[i * n + j] -= s * conj(v[j]);
+                Q[i * n + j] -= sq * conj(v[j]);
+            }
+        }
+    }
+    for (int i = 2; i < n; ++i)
+        for (int j = 0; j + 1 < i; ++j) T[i * n + j] = 0.0;
+    int hi = n - 1, iter = 0;
+    const double eps = 2.220446049250313e-16;
+    while (hi > 0) {
+        // deflation: smallest l with a negligible subdiagonal below it
+        int l = hi;
+        while (l > 0) {
+            const double s = cabs(T[(l - 1) * n + l - 1]) + cabs(T[l * n + l]);
+            if (cabs(T[l * n + l - 1]) <= eps * (s == 0.0 ? 1.0 : s)) {
+                T[l * n + l - 1] = 0.0;
+                break;
+            }
+            --l;
+        }
+        if (l == hi) {
+            --hi;
+            iter = 0;
+            continue;
+        }
+        if (++iter > 60) return false;
+        // Wilkinson shift: eigenvalue of the trailing 2 x 2 closer to T[hi][hi]
+        const cplx a = T[(hi - 1) * n + hi - 1], b = T[(hi - 1) * n + hi], c = T[hi * n + hi - 1], dd = T[hi * n + hi];
+        const cplx tr = a + dd, det = a * dd - b * c;
+        const cplx disc = csqrt(tr * tr - 4.0 * det);
+        const cplx e1 = 0.5 * (tr + disc), e2 = 0.5 * (tr - disc);
+        cplx sh = (cabs(e1 - dd) < cabs(e2 - dd)) ? e1 : e2;
+        if (iter % 11 == 10) sh += cplx(cabs(c), cabs(c) * 0.5);      // exceptional shift
+        // QR step on rows / columns l..hi by Givens rotations
+        for (int i = l; i <= hi; ++i) T[i * n + i] -= sh;
+        cplx cs[kMaxD], sn[kMaxD];
+        for (int k = l; k < hi; ++k) {
+            const cplx x = T[k * n + k], y = T[(k + 1) * n + k];
+            const double r = std::sqrt(norm(x) + norm(y));
+            cplx cc = 1.0, ss = 0.0;
+            if (r != 0.0) {
+                cc = x / r;
+                ss = y / r;
+            }
+            cs[k] = cc;
+            sn[k] = ss;
+            for (int j = k; j < n; ++j) {      // rows k, k+1 <- G^H rows
+                const cplx t1 = T[k * n + j], t2 = T[(k + 1) * n + j];
+                T[k * n + j] = conj(cc) * t1 + conj(ss) * t2;
+                T[(k + 1) * n + j] = -ss * t1 + cc * t2;
+            }
+        }
+        for (int k = l; k < hi; ++k) {
+            const cplx cc = cs[k], ss = sn[k];
+            const int top = std::min(hi, k + 2);
+            for (int i = 0; i <= top; ++i) {      // columns k, k+1 <- columns G
+                const cplx t1 = T[i * n + k], t2 = T[i * n + k + 1];
+                T[i * n + k] = t1 * cc + t2 * ss;
+                T[i * n + k + 1] = -t1 * conj(ss) + t2 * conj(cc);
+            }
+            for (int i = 0; i < n; ++i) {
+                const cplx t1 = Q[i * n + k], t2 = Q[i * n + k + 1];
+                Q[i * n + k] = t1 * cc + t2 * ss;
+                Q[i * n + k + 1] = -t1 * conj(ss) + t2 * conj(cc);
+            }
+        }
+        for (int i = l; i <= hi; ++i) T[i * n + i] += sh;
+    }
+    return true;
+}
+
+// Real block-diagonal (modal) form of a real matrix: M = V B V^-1, B with 2 x 2 blocks [[re, im], [-im, re]] for complex pairs (first)
+// and 1 x 1 blocks for real eigenvalues.  Outputs: re[i], im[i] (signed: +im for the first member of a pair, -im for the second, 0 for
+// real modes), V and V^-1 (row-major), the number of pairs, the 1-norm condition number of V, the relative residual of M V = V B.
+inline bool modal_form(int n, const double* M, double* re, double* im, double* V, double* Vinv, int* npair, double* cond, double* resid) {
+    cplx T[kMaxD * kMaxD], Q[kMaxD * kMaxD];
+    if (!complex_schur(n, M, T, Q)) return false;
+    cplx lam[kMaxD], vec[kMaxD][kMaxD];
+    double scale = 0.0;
+    for (int i = 0; i < n * n; ++i) scale = std::max(scale, std::fabs(M[i]));
+    if (!(scale > 0.0) || !std::isfinite(scale)) return false;
+    for (int k = 0; k < n; ++k) {
+        lam[k] = T[k * n + k];
+        cplx x[kMaxD];
+        for (int j = 0; j < n; ++j) x[j] = 0.0;
+        x[k] = 1.0;
+        for (int j = k - 1; j >= 0; --j) {
+            cplx s = 0.0;
+            for (int m = j + 1; m <= k; ++m) s += T[j * n + m] * x[m];
+            cplx den = T[j * n + j] - lam[k];
+            if (cabs(den) < 1e-300 + 2.3e-16 * scale) den = 2.3e-16 * scale;      // (a repeated eigenvalue: the conditioning check rejects the result)
+            x[j] = -s / den;
+        }
+        double nn = 0.0;
+        for (int i = 0; i < n; ++i) {
+            cplx s = 0.0;
+            for (int j = 0; j <= k; ++j) s += Q[i * n + j] * x[j];
+            vec[k][i] = s;
+            nn += norm(s);
+        }
+        nn = std::sqrt(nn);
+        if (!(nn > 0.0) || !std::isfinite(nn)) return false;
+        for (int i = 0; i < n; ++i) vec[k][i] /= nn;
+    }
+    // classify: complex pairs (im > 0 member keeps the vector) and real modes
+    bool used[kMaxD];
+    for (int k = 0; k < n; ++k) used[k] = false;
+    int pos = 0, np = 0;
+    double Vc[kMaxD][kMaxD];      // Vc[col][row]
+    double rre[kMaxD], rim[kMaxD];
+    for (int k = 0; k < n; ++k) {
+        if (used[k]) continue;
+        const double tol = 1e-10 * std::max(cabs(lam[k]), 1e-300);
+        if (std::fabs(lam[k].imag()) <= tol) continue;
+        // partner: the unused eigenvalue closest to the conjugate
+        int best = -1;
+        double bd = 1e300;
+        for (int m = 0; m < n; ++m) {
+            if (m == k || used[m]) continue;
+            const double dist = cabs(lam[m] - conj(lam[k]));
+            if (dist < bd) {
+                bd = dist;
+                best = m;
+            }
+        }
+        if (best < 0 || bd > 1e-8 * cabs(lam[k])) return false;
+        used[k] = used[best] = true;
+        const int src = lam[k].imag() > 0.0 ? k : best;
+        if (pos + 2 > n) return false;
+        for (int i = 0; i < n; ++i) {
+            Vc[pos][i] = vec[src][i].real();
+            Vc[pos + 1][i] = vec[src][i].imag();
+        }
+        rre[pos] = rre[pos + 1] = lam[src].real();
+        rim[pos] = lam[src].imag();
+        rim[pos + 1] = -lam[src].imag();
+        pos += 2;
+        ++np;
+    }
+    for (int k = 0; k < n; ++k) {
+        if (used[k]) continue;
+        used[k] = true;
+        // rotate the vector so that its largest component is real; the rest must then be real too
+        int big = 0;
+        for (int i = 1; i < n; ++i)
+            if (cabs(vec[k][i]) > cabs(vec[k][big])) big = i;
+        const cplx ph = conj(vec[k][big]) / cabs(vec[k][big]);
+        double imax = 0.0;
+        for (int i = 0; i < n; ++i) {
+            const cplx w = vec[k][i] * ph;
+            Vc[pos][i] = w.real();
+            imax = std::max(imax, std::fabs(w.imag()));
+        }
+        if (imax > 1e-7) return false;
+        rre[pos] = lam[k].real();
+        rim[pos] = 0.0;
+        ++pos;
+    }
+    if (pos != n) return false;
+    // an odd number of components behind the pairs is fine; a pair must start at an even position (it does: pairs come first)
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) V[i * n + j] = Vc[j][i];
+    // inverse by Gauss-Jordan with partial pivoting
+    double Aug[kMaxD][2 * kMaxD];
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+            Aug[i][j] = V[i * n + j];
+            Aug[i][n + j] = (i == j) ? 1.0 : 0.0;
+        }
+    for (int c = 0; c < n; ++c) {
+        int p = c;
+        for (int i = c + 1; i < n; ++i)
+            if (std::fabs(Aug[i][c]) > std::fabs(Aug[p][c])) p = i;
+        if (!(std::fabs(Aug[p][c]) > 0.0)) return false;
+        if (p != c)
+            for (int j = 0; j < 2 * n; ++j) std::swap(Aug[p][j], Aug[c][j]);
+        const double inv = 1.0 / Aug[c][c];
+        for (int j = 0; j < 2 * n; ++j) Aug[c][j] *= inv;
+        for (int i = 0; i < n; ++i) {
+            if (i == c) continue;
+            const double f = Aug[i][c];
+            if (f == 0.0) continue;
+            for (int j = 0; j < 2 * n; ++j) Aug[i][j] -= f * Aug[c][j];
+        }
+    }
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) Vinv[i * n + j] = Aug[i][n + j];
+    double n1 = 0.0, n1i = 0.0;
+    for (int j = 0; j < n; ++j) {
+        double s = 0.0, si = 0.0;
+        for (int i = 0; i < n; ++i) {
+            s += std::fabs(V[i * n + j]);
+            si += std::fabs(Vinv[i * n + j]);
+        }
+        n1 = std::max(n1, s);
+        n1i = std::max(n1i, si);
+    }
+    *cond = n1 * n1i;
+    // residual of M V = V B
+    double rmax = 0.0;
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+            double mv = 0.0;
+            for (int k = 0; k < n; ++k) mv += M[i * n + k] * V[k * n + j];
+            // (V B)_ij = V_ij re_j + V_i,partner * B[partner][j];  B[p][j] for a pair (0, 1): B = [[re, im], [-im, re]]
+            const int pj = (j < 2 * np) ? (j ^ 1) : j;
+            double vb = V[i * n + j] * rre[j];
+            if (pj != j) vb += V[i * n + pj] * (-rim[j]);      // column j of B: B[pj][j] = -rim[j]  (j even: -im; j odd: +im)
+            rmax = std::max(rmax, std::fabs(mv - vb));
+        }
+    *resid = rmax / scale;
+    for (int i = 0; i < n; ++i) {
+        re[i] = rre[i];
+        im[i] = rim[i];
+    }
+    *npair = np;
+    return true;
+}
+
+// reverse-time dynamics of one step (lgssm.jl:231-238): U'U = Symmetric(Pp) + 1e-10 I, G = (U \ (U' \ (A Pf)))', L = Pf - (U Gt)'(U Gt)
+template <int D>
+inline bool invert_dynamics(const double (&A)[D][D], const double (&Pf)[D][D], const double (&Pp)[D][D], double (&G)[D][D], double (&L)[D][D]) {
+    double U[D][D], ru[D];      // (reciprocals of the pivots: a division costs as much as a 3 x 3 product here)
+    bool ok = true;
+    for (int i = 0; i < D; ++i) {
+        double s = Pp[i][i] + 1e-10;
+        for (int k = 0; k < i; ++k) s -= U[k][i] * U[k][i];
+        ok = ok && (s > 0.0);
+        const double u = std::sqrt(s);
+        ru[i] = 1.0 / u;
+        U[i][i] = u;
+        for (int j = i + 1; j < D; ++j) {
+            double v = Pp[i][j];
+            for (int k = 0; k < i; ++k) v -= U[k][i] * U[k][j];
+            U[i][j] = v * ru[i];
+        }
+        for (int j = 0; j < i; ++j) U[i][j] = 0.0;
+    }
+    // M = A Pf (full Pf, as the reference), X = U' \ M, Gt = U \ X
+    double X[D][D];
+    for (int i = 0; i < D; ++i)
+        for (int c = 0; c < D; ++c) {
+            double v = 0.0;
+            for (int k = 0; k < D; ++k) v = pfma(A[i][k], Pf[k][c], v);
+            X[i][c] = v;
+        }
+    for (int i = 0; i < D; ++i)
+        for (int c = 0; c < D; ++c) {
+            double v = X[i][c];
+            for (int k = 0; k < i; ++k) v -= U[k][i] * X[k][c];
+            X[i][c] = v * ru[i];
+        }
+    for (int i = D - 1; i >= 0; --i)
+        for (int c = 0; c < D; ++c) {
+            double v = X[i][c];
+            for (int k = i + 1; k < D; ++k) v -= U[i][k] * X[k][c];
+            X[i][c] = v * ru[i];
+        }
+    double W[D][D];
+    for (int i = 0; i < D; ++i)
+        for (int c = 0; c < D; ++c) {
+            double v = 0.0;
+            for (int k = i; k < D; ++k) v = pfma(U[i][k], X[k][c], v);
+            W[i][c] = v;
+        }
+    for (int i = 0; i < D; ++i)
+        for (int j = 0; j < D; ++j) {
+            G[i][j] = X[j][i];
+            double v = 0.0;
+            for (int k = 0; k < D; ++k) v = pfma(W[k][i], W[k][j], v);
+            L[i][j] = Pf[i][j] - v;
+        }
+    return ok;
+}
+
+template <int D>
+inline double quad_sym(const double (&h)[D], const double (&P)[D][D]) {      // h' Symmetric(P) h (upper triangle)
+    double s = 0.0;
+    for (int c = 0; c < D; ++c) {
+        double v = 0.0;
+        for (int r = 0; r < D; ++r) v = pfma(h[r], (r <= c ? P[r][c] : P[c][r]), v);
+        s = pfma(v, h[c], s);
+    }
+    return s;
+}
+
+// P <- G Symmetric(P) G' + L
+template <int D>
+inline void smooth_cov_step(const double (&G)[D][D], const double (&L)[D][D], const double (&P)[D][D], double (&out)[D][D]) {
+    double t1[D][D];
+    for (int i = 0; i < D; ++i)
+        for (int j = 0; j < D; ++j) {
+            double v = 0.0;
+            for (int k = 0; k < D; ++k) v = pfma(G[i][k], (k <= j ? P[k][j] : P[j][k]), v);
+            t1[i][j] = v;
+        }
+    for (int i = 0; i < D; ++i)
+        for (int j = 0; j < D; ++j) {
+            double v = 0.0;
+            for (int k = 0; k < D; ++k) v = pfma(t1[i][k], G[j][k], v);
+            out[i][j] = v + L[i][j];
+        }
+}
+
+// element-wise power of the block-diagonal form: (re, im) -> (re, im)^n by repeated squaring; the sign convention of `im` is preserved
+inline void modal_power(int d, const double* re, const double* im, long long n, double* pr, double* pi) {
+    for (int i = 0; i < d; ++i) {
+        cplx b(re[i], im[i]), acc(1.0, 0.0);
+        long long e = n;
+        while (e > 0) {
+            if (e & 1) acc *= b;
+            b *= b;
+            e >>= 1;
+        }
+        pr[i] = acc.real();
+        pi[i] = acc.imag();
+    }
+}
+
+}  // namespace detail
+
+// Builds the plan of a call of T steps.  Returns Info::why == kOk when the one-launch path applies; `md` and `tab` are then complete.
+template <int D>
+inline Info build(const ModelHost& m, long long T, Modal& md, HeadTables& tab) {
+    using namespace detail;
+    Info info;
+    double A[D][D], Q[D][D], hv[D], P[D][D], Pold2[D][D];
+    for (int i = 0; i < D; ++i) {
+        hv[i] = m.H[i];
+        for (int k = 0; k < D; ++k) {
+            A[i][k] = m.A[i + k * D];
+            const int r = i < k ? i : k, c = i < k ? k : i;
+            Q[i][k] = m.Q[r + c * D];            // Symmetric(Q), Symmetric(x0.P): upper triangles (as the device set-up)
+            P[i][k] = m.x0P[r + c * D];
+            Pold2[i][k] = 0.0;
+        }
+    }
+    const double R = m.R[0];
+    // ---- (a) filtered covariance to its fixed point; per-step (Pf, Pp) kept for the reverse-time dynamics
+    static thread_local double sPf[kN0Max + 2][D][D], sPp[kN0Max + 2][D][D];
+    int tc = -1, n0 = -1;
+    double LS = 0.0, Sss = 1.0, kAss[D];
+    bool bad = false;
+    for (int t = 0; t <= kN0Max; ++t) {
+        double t1[D][D], pp[D][D], V[D];
+        for (int i = 0; i < D; ++i)
+            for (int j = 0; j < D; ++j) {
+                double v = 0.0;
+                for (int k = 0; k < D; ++k) v = pfma(A[i][k], (k <= j ? P[k][j] : P[j][k]), v);
+                t1[i][j] = v;
+            }
+        for (int i = 0; i < D; ++i)
+            for (int j = 0; j < D; ++j) {
+                double v = 0.0;
+                for (int k = 0; k < D; ++k) v = pfma(t1[i][k], A[j][k], v);
+                pp[i][j] = v + Q[i][j];
+            }
+        double S = 0.0;
+        for (int k = 0; k < D; ++k) {
+            double v = 0.0;
+            for (int l = 0; l < D; ++l) v = pfma(hv[l], pp[l][k], v);
+            V[k] = v;
+            S = pfma(v, hv[k], S);
+        }
+        S += R;
+        if (!(S > 0.0)) {
+            bad = true;
+            break;
+        }
+        const double iS = 1.0 / S, rs = 1.0 / std::sqrt(S);
+        for (int i = 0; i < D; ++i) {
+            double v = 0.0;
+            for (int k = 0; k < D; ++k) v = pfma(A[i][k], V[k] * iS, v);
+            kAss[i] = v;
+            tab.kA[t * D + i] = v;
+        }
+        tab.rS[t] = R * iS;
+        tab.iS[t] = iS;
+        std::memcpy(sPf[t], P, sizeof P);
+        std::memcpy(sPp[t], pp, sizeof pp);
+        Sss = S;
+        if (tc >= 0) {      // the extra iteration from the settled covariance: the stationary step
+            n0 = t;
+            break;
+        }
+        LS += std::log(S);
+        bool moved = false, cyc = t >= 1;
+        for (int i = 0; i < D; ++i)
+            for (int j = 0; j < D; ++j) {
+                const double Pn = pp[i][j] - (V[i] * rs) * (V[j] * rs);
+                moved = moved || std::fabs(Pn - P[i][j]) > kTol * 0.5 * (pp[i][i] + pp[j][j]);
+                cyc = cyc && (Pn == Pold2[i][j]);
+                Pold2[i][j] = P[i][j];
+                P[i][j] = Pn;
+            }
+        if (!moved || cyc) tc = t;
+    }
+    if (bad) {
+        info.why = kNotPD;
+        return info;
+    }
+    if (n0 < 0) {
+        info.why = kNotSettled;
+        return info;
+    }
+    info.n0 = n0;
+    // ---- (b) reverse-time dynamics of the head steps and of the stationary step (row n0)
+    static thread_local double sG[kN0Max + 2][D][D], sL[kN0Max + 2][D][D];
+    for (int t = 0; t <= n0; ++t) {
+        if (!invert_dynamics<D>(A, sPf[t], sPp[t], sG[t], sL[t])) {
+            info.why = kNotPD;
+            return info;
+        }
+        double K[D], Sv = 0.0;
+        for (int k = 0; k < D; ++k) {
+            double v = 0.0;
+            for (int l = 0; l < D; ++l) v = pfma(hv[l], sPp[t][l][k], v);
+            K[k] = v;
+            Sv = pfma(v, hv[k], Sv);
+        }
+        Sv += R;
+        const double iSv = 1.0 / Sv;
+        for (int r = 0; r < D; ++r) {
+            double v = 0.0;
+            for (int c = 0; c < D; ++c) {
+                v = pfma(sG[t][r][c], K[c] * iSv, v);
+                tab.G[(size_t)t * D * D + r * D + c] = sG[t][r][c];
+            }
+            tab.c[t * D + r] = v;
+        }
+    }
+    // ---- (c) smoothed covariance backwards from the final filtered state (Ps_{T-1} = P_ss) until it no longer changes
+    double Ps[D][D], Po2[D][D];
+    std::memcpy(Ps, P, sizeof P);      // the settled filtered covariance
+    for (int i = 0; i < D; ++i)
+        for (int j = 0; j < D; ++j) Po2[i][j] = 0.0;
+    int n1 = -1;
+    for (int jt = 0; jt < kTailMax; ++jt) {
+        tab.tvb[jt] = quad_sym<D>(hv, Ps);
+        double pn[D][D];
+        smooth_cov_step<D>(sG[n0], sL[n0], Ps, pn);
+        bool moved = false, cyc = jt >= 1;
+        for (int i = 0; i < D; ++i)
+            for (int j = 0; j < D; ++j) {
+                moved = moved || std::fabs(pn[i][j] - Ps[i][j]) > kTol * 0.5 * (std::fabs(Ps[i][i]) + std::fabs(Ps[j][j]));
+                cyc = cyc && (pn[i][j] == Po2[i][j]);
+            }
+        std::memcpy(Po2, Ps, sizeof Ps);
+        std::memcpy(Ps, pn, sizeof pn);
+        if (!moved || cyc) {
+            n1 = jt + 1;
+            break;
+        }
+    }
+    if (n1 < 0) {
+        info.why = kTailLong;
+        return info;
+    }
+    info.n1 = n1;
+    const int nhs = 16 * ((n0 + 1 + 15) / 16);      // the head: [0, nhs), a whole number of 128-byte lines
+    if ((long long)nhs + n1 + 1 > T) {
+        info.why = kTooShort;
+        return info;
+    }
+    // ---- (d) smoothed variances of the head: Ps_{n0} = stationary, Ps_{t-1} = G_t Ps_t G_t' + L_t
+    const double vb_ss = quad_sym<D>(hv, Ps);
+    tab.vb[n0] = vb_ss;
+    {
+        double Pc[D][D];
+        std::memcpy(Pc, Ps, sizeof Ps);
+        for (int t = n0; t >= 1; --t) {
+            double pn[D][D];
+            smooth_cov_step<D>(sG[t], sL[t], Pc, pn);
+            std::memcpy(Pc, pn, sizeof pn);
+            tab.vb[t - 1] = quad_sym<D>(hv, Pc);
+        }
+    }
+    // ---- (e) the stationary closed loop in modal form
+    double Phi[D * D], Gs[D * D];
+    for (int i = 0; i < D; ++i)
+        for (int j = 0; j < D; ++j) {
+            Phi[i * D + j] = A[i][j] - kAss[i] * hv[j];
+            Gs[i * D + j] = sG[n0][i][j];
+        }
+    double fre[kMaxD], fim[kMaxD], gre[kMaxD], gim[kMaxD], V[kMaxD * kMaxD], Vi[kMaxD * kMaxD], W[kMaxD * kMaxD], Wi[kMaxD * kMaxD];
+    int npf = 0, npg = 0;
+    double cf = 0, cg = 0, rf = 0, rg = 0;
+    if (!modal_form(D, Phi, fre, fim, V, Vi, &npf, &cf, &rf) || !modal_form(D, Gs, gre, gim, W, Wi, &npg, &cg, &rg)) {
+        info.why = kEigFail;
+        return info;
+    }
+    info.cond_f = cf;
+    info.cond_g = cg;
+    info.resid = std::max(rf, rg);
+    if (!(cf <= kCondMax) || !(cg <= kCondMax) || !(rf <= 1e-13 * cf) || !(rg <= 1e-13 * cg)) {
+        info.why = kIllConditioned;
+        return info;
+    }
+    double rho = 0.0;
+    for (int i = 0; i < D; ++i) {
+        rho = std::max(rho, std::hypot(fre[i], fim[i]));
+        rho = std::max(rho, std::hypot(gre[i], gim[i]));
+    }
+    info.rho = rho;
+    if (!(rho < 1.0)) {
+        info.why = kSlowMixing;
+        return info;
+    }
+    // halo: rho^h <= 2^-64
+    int halo = 16;
+    if (rho > 0.0) {
+        const double need = std::ceil(-64.0 * std::log(2.0) / std::log(rho));
+        if (!(need <= (double)kHaloMax)) {
+            info.why = kSlowMixing;
+            return info;
+        }
+        halo = 16 * (((int)need + 15) / 16);
+        if (halo < 16) halo = 16;
+    }
+    info.halo = halo;
+    // ---- (f) pack
+    md.d = D;
+    md.n0 = n0;
+    md.nhs = nhs;
+    md.n1 = n1;
+    md.halo = halo;
+    md.npair = npf;
+    md.hh = m.hh[0];
+    md.rS = R / Sss;
+    md.iS = 1.0 / Sss;
+    md.logS = std::log(Sss);
+    md.LS = LS;
+    md.vb = vb_ss;
+    for (int i = 0; i < D; ++i) {
+        md.fd[i] = fre[i];
+        md.fo[i] = fim[i];
+        md.gd[i] = gre[i];
+        md.go[i] = gim[i];
+        double b = 0.0, av = 0.0, w = 0.0, c = 0.0, o = 0.0;
+        for (int k = 0; k < D; ++k) {
+            b = pfma(Vi[i * D + k], kAss[k], b);
+            av = pfma(Vi[i * D + k], m.a[k], av);
+            w = pfma(hv[k], V[k * D + i], w);
+            c = pfma(Wi[i * D + k], tab.c[n0 * D + k], c);
+            o = pfma(hv[k], W[k * D + i], o);
+        }
+        md.fb[i] = b;
+        md.fa[i] = av;
+        md.fw[i] = w;
+        md.gc[i] = c;
+        md.gw[i] = o;
+    }
+    modal_power(D, fre, fim, 8, md.fp8r, md.fp8i);
+    modal_power(D, gre, gim, 8, md.gp8r, md.gp8i);
+    modal_power(D, fre, fim, 512, md.fp512r, md.fp512i);
+    modal_power(D, gre, gim, 512, md.gp512r, md.gp512i);
+    // row vector times the block form: (x B)_j = x_j re_j + x_partner B[partner][j], B[partner][j] = -im_j
+    auto row_times = [&](const double* re, const double* im, int np, const double* x, double* out) {
+        for (int j = 0; j < D; ++j) {
+            const int pj = (j < 2 * np) ? (j ^ 1) : j;
+            double v = x[j] * re[j];
+            if (pj != j) v = pfma(x[pj], -im[j], v);
+            out[j] = v;
+        }
+    };
+    {
+        double x[kMaxD] = {0.0}, nx[kMaxD] = {0.0};
+        for (int i = 0; i < D; ++i) x[i] = md.fw[i];
+        for (int j = 0; j < kSub; ++j) {
+            for (int i = 0; i < D; ++i) md.WJ[j][i] = x[i];
+            row_times(fre, fim, npf, x, nx);
+            for (int i = 0; i < D; ++i) x[i] = nx[i];
+        }
+        for (int i = 0; i < D; ++i) x[i] = md.gw[i];
+        for (int j = kSub - 1; j >= 0; --j) {
+            for (int i = 0; i < D; ++i) md.WG[j][i] = x[i];
+            row_times(gre, gim, npg, x, nx);
+            for (int i = 0; i < D; ++i) x[i] = nx[i];
+        }
+    }
+    // the backward block form must use the same pair layout as its own decomposition (the kernel's partner rule is positional, and
+    // the two decompositions may have different numbers of pairs only if one is mis-classified: reject)
+    if (npf != npg) {
+        info.why = kIllConditioned;
+        return info;
+    }
+    // impulse response check: h' Phi^j (A K) against fw' B^j fb, j < 32
+    {
+        double x[D], gmax = 0.0, emax = 0.0;
+        for (int i = 0; i < D; ++i) x[i] = kAss[i];
+        double zr[kMaxD] = {0.0};
+        for (int i = 0; i < D; ++i) zr[i] = md.fb[i];
+        for (int j = 0; j < 32; ++j) {
+            double g = 0.0, gm = 0.0;
+            for (int i = 0; i < D; ++i) {
+                g = pfma(hv[i], x[i], g);
+                gm = pfma(md.fw[i], zr[i], gm);
+            }
+            gmax = std::max(gmax, std::fabs(g));
+            emax = std::max(emax, std::fabs(g - gm));
+            double nx[D], nz[kMaxD];
+            for (int i = 0; i < D; ++i) {
+                double v = 0.0;
+                for (int k = 0; k < D; ++k) v = pfma(Phi[i * D + k], x[k], v);
+                nx[i] = v;
+                const int pi_ = (i < 2 * npf) ? (i ^ 1) : i;
+                nz[i] = pfma(fre[i], zr[i], (pi_ != i) ? fim[i] * zr[pi_] : 0.0);
+            }
+            for (int i = 0; i < D; ++i) {
+                x[i] = nx[i];
+                zr[i] = nz[i];
+            }
+        }
+        if (!(emax <= 1e-12 * std::max(gmax, 1e-300))) {
+            info.why = kIllConditioned;
+            info.resid = emax / std::max(gmax, 1e-300);
+            return info;
+        }
+    }
+    // the head's forward recursion in the modal coordinates: z' = M z + fa + fb u + db_t r, db_t = V^-1 (A K_t - A K)
+    {
+        double m0[D];
+        for (int i = 0; i < D; ++i) {
+            tab.h[i] = hv[i];
+            double v = m.a[i];
+            for (int k = 0; k < D; ++k) {
+                tab.Wm[i * D + k] = W[i * D + k];
+                v = pfma(A[i][k], m.x0m[k], v);
+            }
+            m0[i] = v;
+        }
+        for (int i = 0; i < D; ++i) {
+            double v = 0.0;
+            for (int k = 0; k < D; ++k) v = pfma(Vi[i * D + k], m0[k], v);
+            tab.mu0[i] = v;
+        }
+        for (int t = 0; t <= n0; ++t) {
+            double dk[D], db[D];
+            for (int k = 0; k < D; ++k) dk[k] = tab.kA[t * D + k] - kAss[k];
+            for (int i = 0; i < D; ++i) {
+                double v = 0.0;
+                for (int k = 0; k < D; ++k) v = pfma(Vi[i * D + k], dk[k], v);
+                db[i] = v;
+            }
+            for (int i = 0; i < D; ++i) tab.kA[t * D + i] = (t == n0) ? 0.0 : db[i];
+        }
+    }
+    info.why = kOk;
+    return info;
+}
+
+inline Info build_any(const ModelHost& m, long long T, Modal& md, HeadTables& tab) {
+    switch (m.d) {
+        case 1: return build<1>(m, T, md, tab);
+        case 2: return build<2>(m, T, md, tab);
+        case 3: return build<3>(m, T, md, tab);
+        case 4: return build<4>(m, T, md, tab);
+        case 5: return build<5>(m, T, md, tab);
+        case 6: return build<6>(m, T, md, tab);
+        case 7: return build<7>(m, T, md, tab);
+        case 8: return build<8>(m, T, md, tab);
+    }
+    Info bad;
+    bad.why = kEigFail;
+    return bad;
+}
+
+}  // namespace tgp_plan

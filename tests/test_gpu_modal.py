@@ -1,0 +1,180 @@
+"""GPU tier: the ONE-LAUNCH form of the stationary-gain engine (csrc/tgp_modal.hip + the host plan csrc/tgp_steady_plan.hpp;
+TGP_OPT_STEADY = 3, the default for Forward LTI models with one noise variance, scalar observations and no missing data -- the reference's
+Fill layout, lti_sde.jl:148-160) against the oracle's sequential restatement of lgssm.jl:99-238, through the C ABI.
+Tolerances as everywhere: logpdf 1e-10 relative, marginals 1e-8."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from oracle import components as oc
+from oracle import seq_kalman as sk
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tgp():
+    import temporalgps_jl_amd as t
+    t._lib.load()
+    return t
+
+
+def device_model(tgp, model, steady=None):
+    tr = tgp.GaussMarkovModel(tgp.Forward, model["A"], model["a"], model["Q"], tgp.Gaussian(model["x0m"], model["x0P"]))
+    dm = tgp.LGSSM(tr, tgp.ScalarOutputLGC(model["H"], np.atleast_1d(model["h"]), np.atleast_1d(model["R"])), T=model["T"])
+    if steady is not None:
+        dm.handle_options[tgp._lib.OPT_STEADY] = steady
+    return dm
+
+
+def served(dm):
+    hd = dm.handle()
+    a, b = ctypes.c_int64(), ctypes.c_int64()
+    hd.check(hd.lib.tgp_steady_steps(hd.h, ctypes.byref(a), ctypes.byref(b)))
+    return a.value
+
+
+def kernels_of(tgp, dm, fn):
+    hd = dm.handle()
+    hd.set_option(tgp._lib.OPT_PROFILE, 1)
+    hd.profile_reset()
+    out = fn()
+    names = set(hd.profile())
+    hd.set_option(tgp._lib.OPT_PROFILE, 0)
+    return out, names
+
+
+def draw(model, seed):
+    T, d = model["T"], len(model["x0m"])
+    rng = np.random.default_rng(seed)
+    return sk.rand(model, rng.standard_normal((T, d)), rng.standard_normal(T), rng.standard_normal(d))
+
+
+# one kernel per state dimension whose stationary closed loop has a well-conditioned modal form (distinct length scales)
+KERNELS = {
+    1: ("matern12",),
+    2: ("matern32",),
+    3: ("matern52",),
+    4: ("sum", ("matern52",), ("matern12",)),
+    5: ("sum", ("matern52",), ("matern32",)),
+    6: ("sum", ("matern52",), ("stretched", 0.4, ("matern52",))),
+    7: ("sum", ("matern52",), ("stretched", 0.5, ("matern32",)), ("scaled", 0.3, ("matern32",))),
+    8: ("sum", ("matern52",), ("stretched", 2.0, ("matern52",)), ("stretched", 0.5, ("matern32",))),
+}
+
+
+def check(tgp, model, y, Rn, T, expect_one=True, tol_m=1e-8):
+    lp_ref = sk.logpdf(model, y)
+    m_ref, v_ref = sk.posterior_marginals(model, y, Rn)
+    dm = device_model(tgp, model)
+    lp, names = kernels_of(tgp, dm, lambda: tgp.logpdf(dm, y))
+    if expect_one:
+        assert any(n.startswith("k_steady_one") and "logpdf" in n for n in names) and len(names) == 1, names
+        assert served(dm) > T - 300
+    assert abs(lp - lp_ref) <= 1e-10 * abs(lp_ref), (lp, lp_ref)
+    (mean, var), names = kernels_of(tgp, dm, lambda: tgp.posterior_marginals(dm, y, Rn))
+    if expect_one:
+        assert any(n.startswith("k_steady_one") and "posterior" in n for n in names) and len(names) == 1, names
+    assert np.max(np.abs(mean - m_ref)) <= tol_m, np.max(np.abs(mean - m_ref))
+    assert np.max(np.abs(var - v_ref)) <= tol_m, np.max(np.abs(var - v_ref))
+    lp2, mean2, var2 = tgp.logpdf_and_posterior_marginals(dm, y, Rn)
+    assert abs(lp2 - lp_ref) <= 1e-10 * abs(lp_ref)
+    assert np.array_equal(mean2, mean) and np.array_equal(var2, var)
+    return dm
+
+
+@pytest.mark.parametrize("d", sorted(KERNELS))
+def test_every_state_dimension_against_the_oracle(tgp, d):
+    T = 21000 + 37 * d
+    model = oc.build_lgssm(KERNELS[d], ("regular", 0.0, 0.1, T), 0.1)
+    y = draw(model, d)
+    check(tgp, model, y, np.array([0.02]), T)
+
+
+@pytest.mark.parametrize("T", [401, 512, 513, 1000, 3583, 3584, 3585, 3776, 3777, 4096, 4097, 7551, 7552, 7553, 8191, 12345])
+def test_series_lengths_around_every_boundary(tgp, T):
+    """whole and ragged last tiles, one / two / several workgroups (the core of a workgroup is 8 x 512 - 2 halo steps)"""
+    model = oc.build_lgssm(("matern52",), ("regular", 0.0, 0.1, T), 0.1)
+    y = draw(model, T)
+    check(tgp, model, y, np.array([0.05]), T)
+
+
+@pytest.mark.parametrize("dt,s2", [(0.03, 0.5), (0.3, 0.01), (1.0, 1e-3), (0.1, 3.0), (0.02, 0.05)])
+def test_spacings_and_noise_levels(tgp, dt, s2):
+    """halo lengths from one tile's worth to several (slow mixing: 16 waves per workgroup), heads of 20 to 200 steps"""
+    T = 60011
+    model = oc.build_lgssm(("sum", ("matern52",), ("matern32",)), ("regular", 0.0, dt, T), s2)
+    y = draw(model, 3)
+    check(tgp, model, y, np.array([0.1]), T)
+
+
+def test_per_step_new_noise_and_offsets(tgp):
+    """R_new per step; a model with a transition offset a and an emission offset h"""
+    T = 17001
+    model = oc.build_lgssm(("matern52",), ("regular", 0.0, 0.1, T), 0.2)
+    rng = np.random.default_rng(5)
+    model["a"] = np.broadcast_to(0.1 * rng.standard_normal(3), np.asarray(model["a"]).shape).copy()
+    model["h"] = np.broadcast_to(np.array(0.7), np.asarray(model["h"]).shape).copy()
+    y = draw(model, 9)
+    Rn = 0.01 + rng.random(T)
+    check(tgp, model, y, Rn, T)
+
+
+def test_device_pointers_off_the_16_byte_boundary(tgp):
+    import torch
+    T = 20000
+    model = oc.build_lgssm(("matern52",), ("regular", 0.0, 0.1, T), 0.1)
+    y = draw(model, 2)
+    Rn = np.array([0.03])
+    m_ref, v_ref = sk.posterior_marginals(model, y, Rn)
+    lp_ref = sk.logpdf(model, y)
+    dm = device_model(tgp, model)
+    buf = torch.zeros(T + 1, dtype=torch.float64, device="cuda")
+    buf[1:] = torch.from_numpy(y).cuda()
+    yo = buf[1:]                                     # 8 bytes past a 16-byte boundary
+    outm = torch.zeros(T + 1, dtype=torch.float64, device="cuda")
+    outv = torch.zeros(T + 1, dtype=torch.float64, device="cuda")
+    lp, mean, var = tgp.logpdf_and_posterior_marginals(dm, yo, torch.tensor(Rn, device="cuda"), out=(outm[1:], outv[1:]))
+    assert abs(lp - lp_ref) <= 1e-10 * abs(lp_ref)
+    assert np.max(np.abs(mean.cpu().numpy() - m_ref)) <= 1e-8 and np.max(np.abs(var.cpu().numpy() - v_ref)) <= 1e-8
+    assert float(outm[0]) == 0.0 and float(outv[0]) == 0.0
+
+
+def test_models_the_plan_declines_go_to_the_older_engines(tgp):
+    """a sum of two identical kernels has no well-conditioned modal form: tgp_steady.hip serves it; the verdict is remembered"""
+    T = 9000
+    model = oc.build_lgssm(("sum", ("matern52",), ("matern52",)), ("regular", 0.0, 0.1, T), 0.1)
+    y = draw(model, 1)
+    dm = device_model(tgp, model)
+    lp, names = kernels_of(tgp, dm, lambda: tgp.logpdf(dm, y))
+    assert "k_steady_apply<logpdf>" in names and not any(n.startswith("k_steady_one") for n in names), names
+    lp_ref = sk.logpdf(model, y)
+    assert abs(lp - lp_ref) <= 1e-10 * abs(lp_ref)
+
+
+def test_option_2_keeps_the_five_launch_engine(tgp):
+    T = 9000
+    model = oc.build_lgssm(("matern52",), ("regular", 0.0, 0.1, T), 0.1)
+    y = draw(model, 1)
+    dm = device_model(tgp, model, steady=2)
+    lp, names = kernels_of(tgp, dm, lambda: tgp.logpdf(dm, y))
+    assert "k_steady_apply<logpdf>" in names and not any(n.startswith("k_steady_one") for n in names), names
+    d3 = device_model(tgp, model)
+    lp3 = tgp.logpdf(d3, y)
+    assert abs(lp - lp3) <= 1e-11 * abs(lp)
+
+
+def test_nan_observation_gives_nan(tgp):
+    """(the lazy missing-data path of the Python mirror relies on a NaN observation surfacing as a NaN log-likelihood)"""
+    T = 9000
+    model = oc.build_lgssm(("matern52",), ("regular", 0.0, 0.1, T), 0.1)
+    y = draw(model, 1)
+    y[5000] = np.nan
+    import torch
+    dm = device_model(tgp, model)
+    hd = dm.handle()
+    yd = torch.from_numpy(y).cuda()
+    out = ctypes.c_double()
+    rc = hd.lib.tgp_logpdf(hd.h, ctypes.c_void_p(yd.data_ptr()), None, tgp._lib.IN_DEVICE, ctypes.byref(out))
+    assert rc != 0 or np.isnan(out.value)

@@ -21,7 +21,7 @@ def tgp():
     return t
 
 
-def device_model(tgp, model, steady=None):
+def device_model(tgp, model, steady=2):      # (TGP_OPT_STEADY = 2: this file tests tgp_steady.hip; the one-launch form of round 4 has tests/test_gpu_modal.py)
     tr = tgp.GaussMarkovModel(tgp.Forward, model["A"], model["a"], model["Q"], tgp.Gaussian(model["x0m"], model["x0P"]))
     dm = tgp.LGSSM(tr, tgp.ScalarOutputLGC(model["H"], np.atleast_1d(model["h"]), np.atleast_1d(model["R"])), T=model["T"])
     if steady is not None:
