@@ -39,6 +39,11 @@ WORKLOADS = {
     "sum52_52_d6": (("sum", ("matern52",), ("matern52",)), 6, 0.1, 0.1),   # BASELINE config 3's "d=6"
     "sum52_32_32_d7": (("sum", ("matern52",), ("matern32",), ("matern32",)), 7, 0.1, 0.1),
     "sum52_52_32_d8": (("sum", ("matern52",), ("matern52",), ("matern32",)), 8, 0.1, 0.1),
+    # the same state dimensions with DISTINCT length scales (two identical summands make the difference of the components unobservable:
+    # the closed loop keeps a defective eigenvalue and the one-launch path declines; these are the models a user fits)
+    "sum52_52s_d6": (("sum", ("matern52",), ("stretched", 2.0, ("matern52",))), 6, 0.1, 0.1),
+    "sum52_32s_32_d7": (("sum", ("matern52",), ("stretched", 2.0, ("matern32",)), ("matern32",)), 7, 0.1, 0.1),
+    "sum52_52s_32_d8": (("sum", ("matern52",), ("stretched", 2.0, ("matern52",)), ("stretched", 0.5, ("matern32",))), 8, 0.1, 0.1),
 }
 
 

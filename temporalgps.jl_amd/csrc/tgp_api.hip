@@ -19,6 +19,7 @@
 
 #include "tgp_kernels.hpp"
 #include "tgp_dense.hpp"
+#include <chrono>
 #include "tgp_steady.hpp"
 #include "tgp_modal.hpp"
 #include "tgp_adjoint_host.hpp"
@@ -1124,6 +1125,8 @@ int modal_call(tgp_handle* h, const double* y, uint32_t flags, const double* Rne
     h->modal_last = false;
     if (!h->opt_modal || h->modal_state < 0 || h->hostm.empty()) return TGP_OK;
     if (!h->modal) h->modal = tgp_modal::create();
+    static const bool dbg = getenv("TGP_STEADY_DEBUG") != nullptr;
+    const auto tp0 = std::chrono::steady_clock::now();
     const int d = h->d;
     const size_t dd = (size_t)d * d;
     const double* q = h->hostm.data();
@@ -1140,6 +1143,7 @@ int modal_call(tgp_handle* h, const double* y, uint32_t flags, const double* Rne
         }
         return TGP_OK;
     }
+    const auto tp1 = std::chrono::steady_clock::now();
     const bool idev = (flags & TGP_IN_DEVICE) != 0, odev = (flags & TGP_OUT_DEVICE) != 0;
     const bool rshared = (flags & TGP_SHARED_R) != 0;
     const size_t nT = (size_t)h->T * sizeof(double);
@@ -1160,18 +1164,23 @@ int modal_call(tgp_handle* h, const double* y, uint32_t flags, const double* Rne
     c.var = dv;
     {
         std::string err;
-        const char* kname = "k_steady_one";
-        // (the name is known only after the launch has picked its variant: bracket with a provisional scope name chosen the same way)
-        const tgp_plan::Modal& md = tgp_modal::last_modal(h->modal);
-        const bool wide = 2 * md.halo * 10 > 3 * 8 * 512;
-        LaunchScope ls(h, dm ? (wide ? "k_steady_one16<posterior>" : "k_steady_one<posterior>") : (wide ? "k_steady_one16<logpdf>" : "k_steady_one<logpdf>"));
+        const char* kname = tgp_modal::kernel_name(h->modal, dm != nullptr);
+        LaunchScope ls(h, kname);
         if (tgp_modal::enqueue(h->modal, h->stream, c, &kname, &err) != 0) return h->fail(TGP_EHIP, err);
     }
+    const auto tp2 = std::chrono::steady_clock::now();
+    const bool tables_ok = tgp_modal::complete(h->modal, h->T);      // (the tables half of the plan, beside the kernel)
+    const auto tp3 = std::chrono::steady_clock::now();
     tm.kernels_done();
     TRY(copy_back(h, mean_out, dm, nT, odev));
     TRY(copy_back(h, var_out, dv, nT, odev));
     if (h->timing) (void)hipEventRecord(h->ev[3], h->stream);
     HIPCHK(hipStreamSynchronize(h->stream));
+    if (dbg) {
+        const auto tp4 = std::chrono::steady_clock::now();
+        auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+        fprintf(stderr, "[tgp modal host] plan core %.1f us, staging + launch %.1f, tables + copies %.1f, wait %.1f\n", us(tp0, tp1), us(tp1, tp2), us(tp2, tp3), us(tp3, tp4));
+    }
     if (h->timing) {
         float t0 = 0.f, t1 = 0.f, t2 = 0.f;
         (void)hipEventElapsedTime(&t0, h->ev[0], h->ev[1]);
@@ -1182,6 +1191,10 @@ int modal_call(tgp_handle* h, const double* y, uint32_t flags, const double* Rne
         h->d2h_ms = t2;
     }
     resolve_profile(h);
+    if (!tables_ok) {      // declined behind the launch (a head step not positive definite, a smoother transient beyond the table): the older engines serve the call
+        h->modal_state = -1;
+        return TGP_OK;
+    }
     const double lml = tgp_modal::finish(h->modal, h->T);
     for (int i = 0; i < 8; ++i) h->host_result[i] = 0.0;
     h->host_result[0] = lml;
@@ -1763,8 +1776,12 @@ int tgp_steady_plan(int d, const double* A, const double* a, const double* Q, co
     mh.A = A; mh.a = a; mh.Q = Q; mh.H = H; mh.hh = hh; mh.R = R; mh.x0m = x0m; mh.x0P = x0P;
     const tgp_plan::Info in = tgp_plan::build_any(mh, T, md, tab);
     info_i[0] = in.why; info_i[1] = in.n0; info_i[2] = in.n1; info_i[3] = in.why == 0 ? md.nhs : 0; info_i[4] = in.halo; info_i[5] = in.why == 0 ? md.npair : 0;
-    info_i[6] = (2 * in.halo * 10 <= 3 * 8 * 512) ? 8 : 16;
-    info_i[7] = 0;
+    {
+        int nw = 8, sub = 8;
+        tgp_modal::choose_geometry(d, in.halo, &nw, &sub);
+        info_i[6] = nw;
+        info_i[7] = sub;
+    }
     info_d[0] = in.cond_f; info_d[1] = in.cond_g; info_d[2] = in.rho; info_d[3] = in.resid;
     if (in.why != 0) return TGP_OK;
     if (modal_out) {

@@ -15,29 +15,38 @@ namespace {
 using tgp_plan::HeadTables;
 using tgp_plan::Modal;
 
-constexpr int kTile = 512, kSub = 8;
-constexpr int kTileRow = kTile + 32;      // padded LDS row of a tile's outputs (see flush_row)
+constexpr int kWJ = 8;      // rows of the WJ / WG tables (a lane of sixteen steps applies them in two halves)
 constexpr double kLog2Pi = 1.8378770664093454835606594728112;
 typedef double v2d __attribute__((ext_vector_type(2)));
+
+// ---- the packed tables of a call (doubles): [0] n1, then the fields at these offsets.  Per-step tables have n0 + 1 rows (row n0: the
+// stationary step; the head's steps behind n0 read that row).
+struct TabOff {
+    int h, mu0, Wm, db, iS, rS, G, c, vb, tvb;
+};
 
 // ---- kernel arguments: every coefficient is wave-uniform and reaches the lanes through scalar loads ---------------------------------
 template <int D>
 struct KArgs {
     double fd[D], fo[D], fb[D], fa[D], fw[D];      // forward:  z' = fd z + fo z_partner + fb u + fa,  r = u - fw . z
     double gd[D], go[D], gc[D], gw[D];             // backward: zeta' = gd zeta + go zeta_partner + gc r,  mean = y - rS r + gw . zeta
-    double fpr[6][D], fpi[6][D];                   // M^(8 2^k), k < 6 (forward block form: re, signed im)
+    double fpr[6][D], fpi[6][D];                   // M^(SUB 2^k), k < 6 (forward block form: re, signed im; SUB = steps per lane)
     double gpr[6][D], gpi[6][D];
-    double ftr[2][D], fti[2][D];                   // M^512, M^1024
+    double f8r[D], f8i[D], g8r[D], g8i[D];         // M^8 (the second half of a sixteen-step lane)
+    double ftr[2][D], fti[2][D];                   // M^TILE, M^(2 TILE)
     double gtr[2][D], gti[2][D];
-    double WJ[kSub][D], WG[kSub][D];
+    double WJ[kWJ][D], WG[kWJ][D];
     double hh, rS, vb;
-    int n0, nhs, n1, halo, post, rnew_per_step;
-    long long T, C, nwg;
+    int n0, nhs, halo, post, rnew_per_step;
+    long long T, C, nwg, seq;
     const double* y;
     const double* Rnew;
     double* mean;
     double* var;
-    const HeadTables* tab;      // pinned host memory, read in place
+    const double* htab;         // pinned host memory: the packed head / tail tables of this call (TabOff), written by the host beside the kernel
+    double* tab;                // device memory: workgroup 0 pulls them in here for its head wave
+    const long long* flag;      // pinned host memory: 2 seq (+ 1) once `htab` is complete
+    TabOff to;
     double* part;               // pinned host memory: [nwg] sum r^2 over the workgroups' core ranges, [nwg] the head's sum r^2 / S
 };
 
@@ -58,45 +67,66 @@ __device__ __forceinline__ void lds_sync() {      // one wave talking to itself 
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__device__ __forceinline__ void load8(const double* __restrict__ p, long long t0, long long T, double (&v)[kSub]) {
-    if (t0 + kSub <= T && t0 >= 0) {
+// The tables half of the host plan (per-step gains of the head, tail variances) may still be in the making when the kernel starts: the host
+// writes the packed tables into pinned memory and then the flag 2 seq (+ 1 if that half declined: the call is then re-run elsewhere and
+// whatever this kernel writes is discarded).  Workgroup 0 pulls them into device memory, all its waves at once (one PCIe round trip with
+// every load in flight; a DMA copy of the same bytes reaches the device ~20 us after the API call)
+__device__ __noinline__ void wait_tables(const long long* flagc, long long seq) {
+    long long* flag = const_cast<long long*>(flagc);
+    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < 2 * seq) __builtin_amdgcn_s_sleep(16);
+}
+
+template <int SUB>
+__device__ __forceinline__ void load_lane(const double* __restrict__ p, long long t0, long long T, double (&v)[SUB]) {
+    if (t0 + SUB <= T && t0 >= 0) {
         if ((reinterpret_cast<uintptr_t>(p) & 15) == 0) {
             const double2* q = reinterpret_cast<const double2*>(p + t0);
 #pragma unroll
-            for (int j = 0; j < kSub / 2; ++j) {
+            for (int j = 0; j < SUB / 2; ++j) {
                 const double2 w = q[j];
                 v[2 * j] = w.x;
                 v[2 * j + 1] = w.y;
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < kSub; ++j) v[j] = p[t0 + j];
+            for (int j = 0; j < SUB; ++j) v[j] = p[t0 + j];
         }
     } else {
 #pragma unroll
-        for (int j = 0; j < kSub; ++j) v[j] = (t0 + j < T && t0 + j >= 0) ? p[t0 + j] : 0.0;
+        for (int j = 0; j < SUB; ++j) v[j] = (t0 + j < T && t0 + j >= 0) ? p[t0 + j] : 0.0;
     }
 }
 
-// A wave's tile of 512 consecutive output values, eight per lane, leaves through the wave's own LDS row: lane l's pairs go in at
-// 16-byte slots 4 l + l / 4 + j / 2 (the pad keeps the 128-bit writes of sixteen lanes on distinct banks) and come out transposed, so
-// that every store instruction writes 1 KB of consecutive bytes (as k_apply of tgp_steady.hip).  [lo, hi): the steps this workgroup owns.
-__device__ __forceinline__ int tile_slot(int lane) { return lane * 4 + (lane >> 2); }
+// A wave's tile of 64 SUB consecutive output values, SUB per lane, leaves through the wave's own LDS row: lane l's SUB / 2 pairs go in at
+// 16-byte slots PPL l + l PPL / 16 + j (the pad keeps the 128-bit writes of sixteen lanes on distinct banks) and come out transposed, so that
+// every store instruction writes 1 KB of consecutive bytes (as k_apply of tgp_steady.hip).  [lo, hi): the steps this workgroup owns.
+template <int SUB>
+struct Row {
+    static constexpr int PPL = SUB / 2;                  // pairs per lane
+    static constexpr int slots = PPL * 68;               // 16-byte slots of a row
+    __device__ static __forceinline__ int lane_slot(int lane) { return PPL * lane + lane * PPL / 16; }
+    __device__ static __forceinline__ int pair_slot(int e) {      // pair e of the tile (time order)
+        const int ls = e / PPL;
+        return PPL * ls + ls * PPL / 16 + e % PPL;
+    }
+};
+template <int SUB>
 __device__ __forceinline__ void flush_row(double* __restrict__ p, long long tile_t0, long long lo, long long hi, const v2d* r2, int lane) {
+    constexpr int TILE = 64 * SUB;
     const bool aligned = (reinterpret_cast<uintptr_t>(p) & 15) == 0;
-    if (tile_t0 >= lo && tile_t0 + kTile <= hi && aligned) {      // (wave-uniform)
+    if (tile_t0 >= lo && tile_t0 + TILE <= hi && aligned) {      // (wave-uniform)
         v2d* q = reinterpret_cast<v2d*>(p + tile_t0);
 #pragma unroll
-        for (int k = 0; k < kSub / 2; ++k) {
-            const int e = k * 64 + lane, ls = e >> 2;
-            q[e] = r2[ls * 4 + (ls >> 2) + (e & 3)];
+        for (int k = 0; k < SUB / 2; ++k) {
+            const int e = k * 64 + lane;
+            q[e] = r2[Row<SUB>::pair_slot(e)];
         }
         return;
     }
 #pragma unroll
-    for (int k = 0; k < kSub / 2; ++k) {
-        const int e = k * 64 + lane, ls = e >> 2;
-        const v2d w = r2[ls * 4 + (ls >> 2) + (e & 3)];
+    for (int k = 0; k < SUB / 2; ++k) {
+        const int e = k * 64 + lane;
+        const v2d w = r2[Row<SUB>::pair_slot(e)];
         const long long t = tile_t0 + 2 * e;
         if (t >= lo && t + 1 < hi && aligned) {
             *reinterpret_cast<v2d*>(p + t) = w;
@@ -107,46 +137,55 @@ __device__ __forceinline__ void flush_row(double* __restrict__ p, long long tile
     }
 }
 
-// ---- the head: steps [0, nhs) with gains of their own, sequentially, by ONE wave (every lane the same arithmetic; the lanes share the
-// loads and stores).  In the modal coordinates of the stationary closed loop the forward recursion costs O(d) per step:
+// ---- the head: steps [0, nhs) with gains of their own, sequentially, by ONE wave.  Nothing in the dependent chain of a step waits for memory:
+// the lanes fetch a block's per-step data ahead (lane l the data of step l of the block; the tables are read in place from pinned host memory, so a
+// fetch costs a PCIe round trip -- it overlaps the block in work) and a step picks its values out of the lanes' registers with v_readlane.
+__device__ __forceinline__ double readlane_d(double x, int l) {      // l wave-uniform
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), l), hi = __builtin_amdgcn_readlane(__double2hiint(x), l);
+    return __hiloint2double(hi, lo);
+}
+
+// Forward, in the modal coordinates of the stationary closed loop (O(d) per step; every lane the same arithmetic):
 //     z' = M z + fa + fb u + db_t r,   r = u - fw . z,   db_t = V^-1 (A K_t - A K)   (zero from step n0 on)
-template <int D, int CH>
-__device__ void head_forward(const KArgs<D>& ka, double* __restrict__ sY /*[kHeadMax]: y*/, double* __restrict__ sR /*[kHeadMax]: r*/,
-                             double* __restrict__ sTab /*[CH (D + 1)]*/, int lane, double (&z0)[D], double& quad) {
-    const HeadTables* __restrict__ tb = ka.tab;
+// Leaves r_t in sR, the end state in z0, sum r^2 / S_t in quad.
+template <int D>
+__device__ void head_forward(const KArgs<D>& ka, double* __restrict__ sR /*[kHeadMax]*/, int lane, double (&z0)[D], double& quad) {
+    const double* __restrict__ tb = ka.tab;
     const int nhs = ka.nhs, n0 = ka.n0;
-    for (int t = lane; t < nhs; t += 64) sY[t] = ka.y[t];
     double z[D];
 #pragma unroll
-    for (int i = 0; i < D; ++i) z[i] = tb->mu0[i];      // (already in modal coordinates: V^-1 (A x0.m + a))
+    for (int i = 0; i < D; ++i) z[i] = tb[ka.to.mu0 + i];      // (already in modal coordinates: V^-1 (A x0.m + a))
     double acc = 0.0;
-    for (int c0 = 0; c0 < nhs; c0 += CH) {
-        lds_sync();
-        for (int idx = lane; idx < CH * (D + 1); idx += 64) {
-            const int s = idx / (D + 1), q = idx % (D + 1);
-            const int t = c0 + s < n0 ? c0 + s : n0;
-            sTab[idx] = (q < D) ? tb->kA[t * D + q] : tb->iS[t];
-        }
-        lds_sync();
-        const int cend = (nhs - c0 < CH) ? nhs - c0 : CH;
-        for (int s = 0; s < cend; ++s) {
-            const double u = sY[c0 + s] - ka.hh;
+    const int nblk = (nhs + 63) >> 6;
+    for (int b = 0; b < nblk; ++b) {
+        // lane l: the data of step 64 b + l
+        const int t = b * 64 + lane, ti = t < n0 ? t : n0;
+        const double cy = t < nhs ? ka.y[t] : 0.0, cis = tb[ka.to.iS + ti];
+        double cdb[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) cdb[i] = tb[ka.to.db + ti * D + i];
+        const int cnt = nhs - b * 64 < 64 ? nhs - b * 64 : 64;
+        double rk = 0.0;
+        for (int s = 0; s < cnt; ++s) {
+            const int su = __builtin_amdgcn_readfirstlane(s);
+            const double u = readlane_d(cy, su) - ka.hh, is = readlane_d(cis, su);
             double r = u;
 #pragma unroll
             for (int i = 0; i < D; ++i) r = fma(-ka.fw[i], z[i], r);
-            acc = fma(r * r, sTab[s * (D + 1) + D], acc);
+            acc = fma(r * r, is, acc);
             double nz[D];
 #pragma unroll
             for (int i = 0; i < D; ++i) {
                 double v = fma(ka.fb[i], u, ka.fa[i]);
-                v = fma(sTab[s * (D + 1) + i], r, v);
+                v = fma(readlane_d(cdb[i], su), r, v);
                 v = fma(ka.fo[i], z[partner<D>(i)], v);
                 nz[i] = fma(ka.fd[i], z[i], v);
             }
 #pragma unroll
             for (int i = 0; i < D; ++i) z[i] = nz[i];
-            if (lane == 0) sR[c0 + s] = r;
+            rk = (lane == su) ? r : rk;
         }
+        if (lane < cnt) sR[b * 64 + lane] = rk;
     }
     lds_sync();
 #pragma unroll
@@ -154,75 +193,92 @@ __device__ void head_forward(const KArgs<D>& ka, double* __restrict__ sY /*[kHea
     quad = acc;
 }
 
-// Backward over the head from the lam in front of the first stationary step: lam <- G_t lam + c_t r_t (original coordinates: G_t is
-// dense and changes per step), mean_t = y_t - (R / S_t) r_t + h . lam.  sR holds r_t on entry, the means on exit.
+// Backward over the head from the lam in front of the first stationary step: lam <- G_t lam + c_t r_t (original coordinates: G_t is dense and
+// changes per step), mean_t = y_t - (R / S_t) r_t + h . lam.  Lane i < D owns row i of the product; lam goes round by v_readlane.  The rows of
+// a chunk of CH steps are staged in LDS (the tables are in device memory by now: a chunk costs an L2 round trip).  sR holds r_t on entry.
 template <int D, int CH>
-__device__ void head_backward(const KArgs<D>& ka, const double* __restrict__ sY, double* __restrict__ sR, double* __restrict__ sTab /*[CH (D D + D + 1)]*/, int lane,
-                              const double (&zeta)[D]) {
-    constexpr int DD = D * D, ROW = DD + D + 1;
-    const HeadTables* __restrict__ tb = ka.tab;
+__device__ void head_backward(const KArgs<D>& ka, const double* __restrict__ sR, double* __restrict__ sTab /*[CH (D D + D)]*/, int lane, const double (&zeta)[D]) {
+    constexpr int DD = D * D, ROW = DD + D;
+    const double* __restrict__ tb = ka.tab;
     const int nhs = ka.nhs, n0 = ka.n0;
-    double lam[D], h[D];
+    const int row = lane < D ? lane : D - 1;
+    double lam = 0.0, h[D];
 #pragma unroll
-    for (int i = 0; i < D; ++i) {
-        double v = 0.0;
-#pragma unroll
-        for (int k = 0; k < D; ++k) v = fma(tb->Wm[i * D + k], zeta[k], v);
-        lam[i] = v;
-        h[i] = tb->h[i];
+    for (int k = 0; k < D; ++k) {
+        lam = fma(tb[ka.to.Wm + row * D + k], zeta[k], lam);
+        h[k] = tb[ka.to.h + k];
     }
-    for (int hi = nhs; hi > 0; hi -= CH) {
-        const int lo = hi - CH > 0 ? hi - CH : 0;
-        lds_sync();
-        for (int idx = lane; idx < (hi - lo) * ROW; idx += 64) {
-            const int s = idx / ROW, q = idx % ROW;
-            const int t = lo + s < n0 ? lo + s : n0;
-            sTab[idx] = (q < DD) ? tb->G[(size_t)t * DD + q] : (q < DD + D ? tb->c[t * D + (q - DD)] : tb->rS[t]);
-        }
-        lds_sync();
-        for (int t = hi - 1; t >= lo; --t) {
-            const double* __restrict__ row = sTab + (t - lo) * ROW;
-            const double r = sR[t];
-            const double yv = sY[t];
-            double m = fma(-row[DD + D], r, yv);
-#pragma unroll
-            for (int k = 0; k < D; ++k) m = fma(h[k], lam[k], m);
-            double nl[D];
-#pragma unroll
-            for (int i = 0; i < D; ++i) {
-                double v = row[DD + i] * r;
-#pragma unroll
-                for (int k = 0; k < D; ++k) v = fma(row[i * D + k], lam[k], v);
-                nl[i] = v;
-            }
-#pragma unroll
-            for (int i = 0; i < D; ++i) lam[i] = nl[i];
-            if (lane == 0) sR[t] = m;
-        }
-    }
-    lds_sync();
     const double rn0 = ka.Rnew[0];
-    for (int t = lane; t < nhs; t += 64) {
-        ka.mean[t] = sR[t];
-        ka.var[t] = tb->vb[t < n0 ? t : n0] + (ka.rnew_per_step ? ka.Rnew[t] : rn0);
+    for (int hi = nhs; hi > 0; hi -= CH) {
+        const int lo = hi - CH > 0 ? hi - CH : 0, cnt = hi - lo;
+        lds_sync();
+        for (int idx = lane; idx < cnt * ROW; idx += 64) {
+            const int sidx = idx / ROW, e = idx % ROW;
+            const int tt = lo + sidx < n0 ? lo + sidx : n0;
+            sTab[idx] = e < DD ? tb[ka.to.G + (size_t)tt * DD + e] : tb[ka.to.c + tt * D + (e - DD)];
+        }
+        const int t = lo + lane, ti = t < n0 ? t : n0;
+        const double cy = (lane < cnt) ? ka.y[t] : 0.0, crs = tb[ka.to.rS + ti], cr = (lane < cnt) ? sR[t] : 0.0;
+        lds_sync();
+        double mk = 0.0;
+        // the row of the first step to be processed (the chunk's last)
+        double g[D], cc;
+        {
+            const double* __restrict__ rw = sTab + (cnt - 1) * ROW;
+#pragma unroll
+            for (int k = 0; k < D; ++k) g[k] = rw[row * D + k];
+            cc = rw[DD + row];
+        }
+        for (int s = cnt - 1; s >= 0; --s) {
+            const int su = __builtin_amdgcn_readfirstlane(s);
+            double gn[D], cn = 0.0;                  // the next step's row, in flight while this one's chain runs
+            {
+                const double* __restrict__ rw = sTab + (su > 0 ? su - 1 : 0) * ROW;
+#pragma unroll
+                for (int k = 0; k < D; ++k) gn[k] = rw[row * D + k];
+                cn = rw[DD + row];
+            }
+            const double r = readlane_d(cr, su), yv = readlane_d(cy, su), rs = readlane_d(crs, su);
+            double m = fma(-rs, r, yv), nl = cc * r;
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                const double lk = readlane_d(lam, k);
+                m = fma(h[k], lk, m);
+                nl = fma(g[k], lk, nl);
+            }
+            lam = nl;
+            mk = (lane == su) ? m : mk;
+#pragma unroll
+            for (int k = 0; k < D; ++k) g[k] = gn[k];
+            cc = cn;
+        }
+        if (lane < cnt) {
+            ka.mean[t] = mk;
+            ka.var[t] = tb[ka.to.vb + ti] + (ka.rnew_per_step ? ka.Rnew[t] : rn0);
+        }
     }
 }
 
 // =================================================================================================================================
-// The kernel.  Workgroup g owns the steps [nhs + g C, nhs + (g + 1) C) (its core); its NW waves are NW consecutive tiles of 512 steps that
-// start `halo` steps earlier (g = 0: at nhs, with the head's exact end state) and end `halo` steps later.  Both mean recursions have
+// The kernel.  Workgroup g owns the steps [nhs + g C, nhs + (g + 1) C) (its core); its NW waves are NW consecutive tiles of 64 SUB steps
+// that start `halo` steps earlier (g = 0: at nhs, with the head's exact end state) and end `halo` steps later.  Both mean recursions have
 // forgotten a state after `halo` steps (tgp_steady_plan.hpp: |eigenvalue|^halo <= 2^-64), so a zero state at the start of the span and
 // a zero lam at its end give every core step the same values, to rounding, as the recursion over the whole series: no pass over y
 // before this one, no carries between workgroups.  Inside the workgroup the tiles are chained exactly (through LDS, over the at most
 // three preceding / following tiles -- whatever lies further back has decayed as well).
+// A lane holds SUB consecutive steps: 8, or 16 (the in-tile scans cost the same per level whatever a lane holds, so sixteen halve them
+// per step -- at the price of 32 more registers).
 // =================================================================================================================================
-template <int D, int NW>
+template <int D, int NW, int SUB>
 __global__ __launch_bounds__(NW * 64) void k_steady_one(const KArgs<D> ka) {
-    constexpr int CHF = 32, CHB = (NW > 8 ? 8 : 16);
-    constexpr int kStage = (CHB * (D * D + D + 1) > CHF * (D + 1)) ? CHB * (D * D + D + 1) : CHF * (D + 1);
+    constexpr int TILE = 64 * SUB;
+    constexpr int CHB = D <= 4 ? 64 : (D <= 6 ? 32 : 16);      // steps of the head's backward recursion staged in LDS at a time (~10 KB)
     __shared__ double sF[NW][D], sB[NW][D], sHead[D], sAcc[NW];
-    __shared__ double sY[tgp_plan::kHeadMax], sR[tgp_plan::kHeadMax], sTab[kStage];
-    __shared__ __attribute__((aligned(16))) double sOut[NW][kTileRow];
+    __shared__ double sR[tgp_plan::kHeadMax], sTab[CHB * (D * D + D)];
+    __shared__ __attribute__((aligned(16))) double sOut[NW][2 * Row<SUB>::slots];
+    // M^(SUB l) (forward) and Mg^(SUB (63 - l)) (backward) for the lanes l of a tile: what carries a tile's start state / right-hand input to
+    // its lanes.  The same for every wave: the last two waves of the workgroup build them (by the bits of the lane number) for all
+    __shared__ double sPw[2][2][D][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // XCD-aware order: consecutive workgroups (which share their halos' lines of y) land on the same XCD, hence the same L2
     long long wg;
@@ -234,34 +290,45 @@ __global__ __launch_bounds__(NW * 64) void k_steady_one(const KArgs<D> ka) {
     const long long T = ka.T;
     const long long c_lo = ka.nhs + wg * ka.C, c_hi_raw = c_lo + ka.C, c_hi = c_hi_raw < T ? c_hi_raw : T;
     const long long s0 = (wg == 0) ? (long long)ka.nhs : c_lo - ka.halo;
-    const long long tile_t0 = s0 + (long long)wave * kTile, t0 = tile_t0 + (long long)lane * kSub;
+    const long long tile_t0 = s0 + (long long)wave * TILE, t0 = tile_t0 + (long long)lane * SUB;
     const bool head_wave = wg == 0 && wave == 0;
     const bool any_valid = tile_t0 < T;                              // (wave-uniform)
-    const bool need_back = any_valid && tile_t0 + kTile > c_lo;      // a tile wholly inside the left halo only hands its end state on
+    const bool need_back = any_valid && tile_t0 + TILE > c_lo;       // a tile wholly inside the left halo only hands its end state on
     const bool has_out = ka.post && need_back && tile_t0 < c_hi;
 
     double head_quad = 0.0;
-    if (head_wave) {
-        double z0[D];
-        head_forward<D, CHF>(ka, sY, sR, sTab, lane, z0, head_quad);
-        if (lane == 0) {
+    if (wg == 0) {
+        // the head's tables: wait for the host, pull them into device memory (all waves), then the head wave runs the head forward
+        if (threadIdx.x == 0) ka.part[ka.nwg + 1] = (double)wall_clock64();      // (phases of workgroup 0, 100 MHz: TGP_STEADY_DEBUG prints them)
+        wait_tables(ka.flag, ka.seq);
+        if (threadIdx.x == 0) ka.part[ka.nwg + 2] = (double)wall_clock64();
+        const int used = ka.to.tvb + (int)ka.htab[0];                               // doubles
+        const v2d* __restrict__ src = reinterpret_cast<const v2d*>(ka.htab);
+        v2d* __restrict__ dst = reinterpret_cast<v2d*>(ka.tab);
+        for (int idx = threadIdx.x; idx < (used + 1) / 2; idx += NW * 64) dst[idx] = src[idx];
+        __syncthreads();
+        if (head_wave) {
+            double z0[D];
+            head_forward<D>(ka, sR, lane, z0, head_quad);
+            if (lane == 0) {
 #pragma unroll
-            for (int i = 0; i < D; ++i) sHead[i] = z0[i];
+                for (int i = 0; i < D; ++i) sHead[i] = z0[i];
+                ka.part[ka.nwg + 3] = (double)wall_clock64();
+            }
         }
     }
-
-    // ---- forward, zero start: innovations r0 of the lane's eight steps, the lane's end state, inclusive scan over the lanes
-    double yv[kSub], r[kSub], st[D];
+    // ---- forward, zero start: innovations r0 of the lane's steps, the lane's end state, inclusive scan over the lanes
+    double yv[SUB], r[SUB], st[D];
     const long long left = T - t0;
-    const int nvalid = left >= kSub ? kSub : (left > 0 ? (int)left : 0);
+    const int nvalid = left >= SUB ? SUB : (left > 0 ? (int)left : 0);
     {
         double z[D];
 #pragma unroll
         for (int i = 0; i < D; ++i) z[i] = 0.0;
         if (any_valid) {
-            load8(ka.y, t0, T, yv);
+            load_lane<SUB>(ka.y, t0, T, yv);
 #pragma unroll
-            for (int j = 0; j < kSub; ++j) {
+            for (int j = 0; j < SUB; ++j) {
                 const double u = yv[j] - ka.hh;
                 double rr = u;
 #pragma unroll
@@ -276,12 +343,12 @@ __global__ __launch_bounds__(NW * 64) void k_steady_one(const KArgs<D> ka) {
 #pragma unroll
             for (int k = 0; k < 6; ++k) {
                 const int off = 1 << k;
-                double g[D], pg[D];
+                const double keep = (lane >= off) ? 1.0 : 0.0;      // (a neighbour that does not exist contributes nothing: one multiply instead of two selects)
+                double g[D];
 #pragma unroll
-                for (int i = 0; i < D; ++i) g[i] = __shfl_up(z[i], off);
-                bmul<D>(ka.fpr[k], ka.fpi[k], g, pg);
+                for (int i = 0; i < D; ++i) g[i] = __shfl_up(z[i], off) * keep;
 #pragma unroll
-                for (int i = 0; i < D; ++i) z[i] = (lane >= off) ? z[i] + pg[i] : z[i];
+                for (int i = 0; i < D; ++i) z[i] = fma(ka.fpr[k][i], g[i], fma(ka.fpi[k][i], g[partner<D>(i)], z[i]));
             }
         }
 #pragma unroll
@@ -292,6 +359,34 @@ __global__ __launch_bounds__(NW * 64) void k_steady_one(const KArgs<D> ka) {
         if (lane == 63) {
 #pragma unroll
             for (int i = 0; i < D; ++i) sF[wave][i] = any_valid ? z[i] : 0.0;
+        }
+    }
+    if (wave >= NW - 2) {
+        const int dir = wave - (NW - 2);      // 0: forward, 1: backward
+        const int e = dir == 0 ? lane : 63 - lane;
+        double xr[D], xi[D];                  // the block form of M^(SUB e): (re, signed im) per component, from the identity
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            xr[i] = 1.0;
+            xi[i] = 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const double* __restrict__ pr = dir == 0 ? ka.fpr[k] : ka.gpr[k];
+            const double* __restrict__ pi = dir == 0 ? ka.fpi[k] : ka.gpi[k];
+            const bool bit = ((e >> k) & 1) != 0;
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                // (a + i b)(c + i d) with the signed-imaginary convention: re = a c - b d, im = a d + b c (the sign of the pair's second member follows)
+                const double nr = fma(xr[i], pr[i], -(xi[i] * pi[i])), ni = fma(xr[i], pi[i], xi[i] * pr[i]);
+                xr[i] = bit ? nr : xr[i];
+                xi[i] = bit ? ni : xi[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            sPw[dir][0][i][lane] = xr[i];
+            sPw[dir][1][i][lane] = xi[i];
         }
     }
     __syncthreads();
@@ -321,30 +416,31 @@ __global__ __launch_bounds__(NW * 64) void k_steady_one(const KArgs<D> ka) {
                 for (int i = 0; i < D; ++i) zin[i] += px[i];
             }
         }
-        // the lane's start state: st + M^(8 lane) zin, by the bits of the lane number
-        {
-            double x[D];
+        // the lane's start state: st + M^(SUB lane) zin
 #pragma unroll
-            for (int i = 0; i < D; ++i) x[i] = zin[i];
+        for (int i = 0; i < D; ++i) st[i] = fma(sPw[0][0][i][lane], zin[i], fma(sPw[0][1][i][lane], zin[partner<D>(i)], st[i]));
+        const bool in_core = t0 >= c_lo && t0 < c_hi_raw;
+        // the start state moves step j's innovation by -fw' M^j st: WJ holds eight rows; the second half of a sixteen-step lane uses them
+        // on M^8 st
 #pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                double px[D];
-                bmul<D>(ka.fpr[k], ka.fpi[k], x, px);
+        for (int half = 0; half < SUB / kWJ; ++half) {
+            double sh[D];
+            if (half == 0) {
 #pragma unroll
-                for (int i = 0; i < D; ++i) x[i] = ((lane >> k) & 1) ? px[i] : x[i];
+                for (int i = 0; i < D; ++i) sh[i] = st[i];
+            } else {
+                bmul<D>(ka.f8r, ka.f8i, st, sh);
             }
 #pragma unroll
-            for (int i = 0; i < D; ++i) st[i] += x[i];
-        }
-        const bool in_core = t0 >= c_lo && t0 < c_hi_raw;
+            for (int jj = 0; jj < kWJ; ++jj) {
+                const int j = half * kWJ + jj;
+                double rr = r[j];
 #pragma unroll
-        for (int j = 0; j < kSub; ++j) {
-            double rr = r[j];
-#pragma unroll
-            for (int i = 0; i < D; ++i) rr = fma(-ka.WJ[j][i], st[i], rr);
-            rr = (j < nvalid) ? rr : 0.0;
-            r[j] = rr;
-            acc = fma(rr, rr, acc);
+                for (int i = 0; i < D; ++i) rr = fma(-ka.WJ[jj][i], sh[i], rr);
+                rr = (j < nvalid) ? rr : 0.0;
+                r[j] = rr;
+                acc = fma(rr, rr, acc);
+            }
         }
         acc = in_core ? acc : 0.0;
     }
@@ -369,7 +465,7 @@ __global__ __launch_bounds__(NW * 64) void k_steady_one(const KArgs<D> ka) {
 #pragma unroll
         for (int i = 0; i < D; ++i) zeta[i] = 0.0;
 #pragma unroll
-        for (int j = kSub - 1; j >= 0; --j) {
+        for (int j = SUB - 1; j >= 0; --j) {
             double m = fma(-ka.rS, r[j], yv[j]);
 #pragma unroll
             for (int i = 0; i < D; ++i) m = fma(ka.gw[i], zeta[i], m);
@@ -383,12 +479,12 @@ __global__ __launch_bounds__(NW * 64) void k_steady_one(const KArgs<D> ka) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
             const int off = 1 << k;
-            double g[D], pg[D];
+            const double keep = (lane + off < 64) ? 1.0 : 0.0;
+            double g[D];
 #pragma unroll
-            for (int i = 0; i < D; ++i) g[i] = __shfl_down(zeta[i], off);
-            bmul<D>(ka.gpr[k], ka.gpi[k], g, pg);
+            for (int i = 0; i < D; ++i) g[i] = __shfl_down(zeta[i], off) * keep;
 #pragma unroll
-            for (int i = 0; i < D; ++i) zeta[i] = (lane + off < 64) ? zeta[i] + pg[i] : zeta[i];
+            for (int i = 0; i < D; ++i) zeta[i] = fma(ka.gpr[k][i], g[i], fma(ka.gpi[k][i], g[partner<D>(i)], zeta[i]));
         }
 #pragma unroll
         for (int i = 0; i < D; ++i) {
@@ -429,46 +525,50 @@ __global__ __launch_bounds__(NW * 64) void k_steady_one(const KArgs<D> ka) {
     if (has_out) {
         double zin[D];
         right_input(wave, zin);
-        {
-            double x[D];
 #pragma unroll
-            for (int i = 0; i < D; ++i) x[i] = zin[i];
-            const int back = 63 - lane;
-#pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                double px[D];
-                bmul<D>(ka.gpr[k], ka.gpi[k], x, px);
-#pragma unroll
-                for (int i = 0; i < D; ++i) x[i] = ((back >> k) & 1) ? px[i] : x[i];
-            }
-#pragma unroll
-            for (int i = 0; i < D; ++i) zst[i] += x[i];
-        }
+        for (int i = 0; i < D; ++i) zst[i] = fma(sPw[1][0][i][lane], zin[i], fma(sPw[1][1][i][lane], zin[partner<D>(i)], zst[i]));
         v2d* row = reinterpret_cast<v2d*>(sOut[wave]);
-        const int wb = tile_slot(lane);
+        const int wb = Row<SUB>::lane_slot(lane);
+        // the lam behind the lane's last step reaches step j through Mg^(SUB - 1 - j): WG holds gw' Mg^(7 - j); the first half of a
+        // sixteen-step lane sees Mg^8 zst
 #pragma unroll
-        for (int j = 0; j < kSub; j += 2) {
-            double m0 = yv[j], m1 = yv[j + 1];
+        for (int half = SUB / kWJ - 1; half >= 0; --half) {
+            double sh[D];
+            if (half == SUB / kWJ - 1) {
 #pragma unroll
-            for (int i = 0; i < D; ++i) {
-                m0 = fma(ka.WG[j][i], zst[i], m0);
-                m1 = fma(ka.WG[j + 1][i], zst[i], m1);
+                for (int i = 0; i < D; ++i) sh[i] = zst[i];
+            } else {
+                bmul<D>(ka.g8r, ka.g8i, zst, sh);
             }
-            v2d w;
-            w.x = m0;
-            w.y = m1;
-            row[wb + (j >> 1)] = w;
+#pragma unroll
+            for (int jj = 0; jj < kWJ; jj += 2) {
+                const int j = half * kWJ + jj;
+                double m0 = yv[j], m1 = yv[j + 1];
+#pragma unroll
+                for (int i = 0; i < D; ++i) {
+                    m0 = fma(ka.WG[jj][i], sh[i], m0);
+                    m1 = fma(ka.WG[jj + 1][i], sh[i], m1);
+                }
+                v2d w;
+                w.x = m0;
+                w.y = m1;
+                row[wb + (j >> 1)] = w;
+            }
         }
         lds_sync();
-        flush_row(ka.mean, tile_t0, c_lo, c_hi, row, lane);
+        flush_row<SUB>(ka.mean, tile_t0, c_lo, c_hi, row, lane);
         // the variances do not depend on the data: a constant outside the last n1 steps (plus the new noise); written transposed as well
         {
             const double rn0 = ka.Rnew[0];
-            const long long n1 = ka.n1;
-            const double* __restrict__ tvb = ka.tab->tvb;
+            long long n1 = 0;
+            if (T - tile_t0 <= (long long)tgp_plan::kTailMax + TILE) {      // (wave-uniform: the last few tiles of the series)
+                wait_tables(ka.flag, ka.seq);
+                n1 = (long long)ka.htab[0];
+            }
+            const double* __restrict__ tvb = ka.htab + ka.to.tvb;      // (in place from pinned memory: the last few tiles, a handful of values)
             const bool aligned = (reinterpret_cast<uintptr_t>(ka.var) & 15) == 0 && (!ka.rnew_per_step || (reinterpret_cast<uintptr_t>(ka.Rnew) & 15) == 0);
 #pragma unroll
-            for (int k = 0; k < kSub / 2; ++k) {
+            for (int k = 0; k < SUB / 2; ++k) {
                 const long long t = tile_t0 + 2 * (k * 64 + lane);
                 if (t + 1 < c_lo || t >= c_hi) continue;
                 double v0 = ka.vb, v1 = ka.vb;
@@ -501,7 +601,9 @@ __global__ __launch_bounds__(NW * 64) void k_steady_one(const KArgs<D> ka) {
     if (head_wave) {
         double zin[D];
         right_input(-1, zin);
-        head_backward<D, CHB>(ka, sY, sR, sTab, lane, zin);
+        if (lane == 0) ka.part[ka.nwg + 4] = (double)wall_clock64();
+        head_backward<D, CHB>(ka, sR, sTab, lane, zin);
+        if (lane == 0) ka.part[ka.nwg + 5] = (double)wall_clock64();
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) acc += __shfl_down(acc, off);
@@ -513,107 +615,240 @@ __global__ __launch_bounds__(NW * 64) void k_steady_one(const KArgs<D> ka) {
         for (int w = 0; w < NW; ++w) t += sAcc[w];
         ka.part[wg] = t;
         if (wg == 0) ka.part[ka.nwg] = head_quad;
+        if (wg == ka.nwg - 1) ka.part[ka.nwg + 6] = (double)wall_clock64();
+    }
+}
+
+// block-form helpers of the host side (the sign convention of the imaginary parts is preserved by squaring: re^2 - im^2, 2 re im)
+static void bsquare(int d, const double* ar, const double* ai, double* outr, double* outi) {
+    for (int i = 0; i < d; ++i) {
+        const double r = ar[i] * ar[i] - ai[i] * ai[i], im = 2.0 * ar[i] * ai[i];
+        outr[i] = r;
+        outi[i] = im;
     }
 }
 
 template <int D>
-void fill_args(KArgs<D>& ka, const Modal& md) {
+void fill_args(KArgs<D>& ka, const Modal& md, int sub) {
     for (int i = 0; i < D; ++i) {
         ka.fd[i] = md.fd[i]; ka.fo[i] = md.fo[i]; ka.fb[i] = md.fb[i]; ka.fa[i] = md.fa[i]; ka.fw[i] = md.fw[i];
         ka.gd[i] = md.gd[i]; ka.go[i] = md.go[i]; ka.gc[i] = md.gc[i]; ka.gw[i] = md.gw[i];
-        ka.fpr[0][i] = md.fp8r[i]; ka.fpi[0][i] = md.fp8i[i];
-        ka.gpr[0][i] = md.gp8r[i]; ka.gpi[0][i] = md.gp8i[i];
-        ka.ftr[0][i] = md.fp512r[i]; ka.fti[0][i] = md.fp512i[i];
-        ka.gtr[0][i] = md.gp512r[i]; ka.gti[0][i] = md.gp512i[i];
-        // squares (the sign convention of the imaginary parts is preserved: re^2 - im^2, 2 re im)
-        for (int k = 1; k < 6; ++k) {
-            ka.fpr[k][i] = ka.fpr[k - 1][i] * ka.fpr[k - 1][i] - ka.fpi[k - 1][i] * ka.fpi[k - 1][i];
-            ka.fpi[k][i] = 2.0 * ka.fpr[k - 1][i] * ka.fpi[k - 1][i];
-            ka.gpr[k][i] = ka.gpr[k - 1][i] * ka.gpr[k - 1][i] - ka.gpi[k - 1][i] * ka.gpi[k - 1][i];
-            ka.gpi[k][i] = 2.0 * ka.gpr[k - 1][i] * ka.gpi[k - 1][i];
-        }
-        ka.ftr[1][i] = ka.ftr[0][i] * ka.ftr[0][i] - ka.fti[0][i] * ka.fti[0][i];
-        ka.fti[1][i] = 2.0 * ka.ftr[0][i] * ka.fti[0][i];
-        ka.gtr[1][i] = ka.gtr[0][i] * ka.gtr[0][i] - ka.gti[0][i] * ka.gti[0][i];
-        ka.gti[1][i] = 2.0 * ka.gtr[0][i] * ka.gti[0][i];
-        for (int j = 0; j < kSub; ++j) {
+        ka.f8r[i] = md.fp8r[i]; ka.f8i[i] = md.fp8i[i];
+        ka.g8r[i] = md.gp8r[i]; ka.g8i[i] = md.gp8i[i];
+        for (int j = 0; j < kWJ; ++j) {
             ka.WJ[j][i] = md.WJ[j][i];
             ka.WG[j][i] = md.WG[j][i];
         }
     }
+    // in-tile scan levels M^(sub 2^k)
+    if (sub == 8) {
+        std::memcpy(ka.fpr[0], md.fp8r, sizeof(double) * D); std::memcpy(ka.fpi[0], md.fp8i, sizeof(double) * D);
+        std::memcpy(ka.gpr[0], md.gp8r, sizeof(double) * D); std::memcpy(ka.gpi[0], md.gp8i, sizeof(double) * D);
+    } else {
+        bsquare(D, md.fp8r, md.fp8i, ka.fpr[0], ka.fpi[0]);
+        bsquare(D, md.gp8r, md.gp8i, ka.gpr[0], ka.gpi[0]);
+    }
+    for (int k = 1; k < 6; ++k) {
+        bsquare(D, ka.fpr[k - 1], ka.fpi[k - 1], ka.fpr[k], ka.fpi[k]);
+        bsquare(D, ka.gpr[k - 1], ka.gpi[k - 1], ka.gpr[k], ka.gpi[k]);
+    }
+    // tile powers M^TILE, M^(2 TILE)
+    if (sub == 8) {
+        std::memcpy(ka.ftr[0], md.fp512r, sizeof(double) * D); std::memcpy(ka.fti[0], md.fp512i, sizeof(double) * D);
+        std::memcpy(ka.gtr[0], md.gp512r, sizeof(double) * D); std::memcpy(ka.gti[0], md.gp512i, sizeof(double) * D);
+    } else {
+        bsquare(D, md.fp512r, md.fp512i, ka.ftr[0], ka.fti[0]);
+        bsquare(D, md.gp512r, md.gp512i, ka.gtr[0], ka.gti[0]);
+    }
+    bsquare(D, ka.ftr[0], ka.fti[0], ka.ftr[1], ka.fti[1]);
+    bsquare(D, ka.gtr[0], ka.gti[0], ka.gtr[1], ka.gti[1]);
     ka.hh = md.hh; ka.rS = md.rS; ka.vb = md.vb;
-    ka.n0 = md.n0; ka.nhs = md.nhs; ka.n1 = md.n1; ka.halo = md.halo;
+    ka.n0 = md.n0; ka.nhs = md.nhs; ka.halo = md.halo;
 }
 
 }  // namespace
 
 struct Engine {
-    HeadTables* tab = nullptr;      // pinned host memory
+    HeadTables* tab = nullptr;      // host scratch of the plan
+    double* hflat = nullptr;        // pinned host memory: the packed tables of the call (TabOff) + the flag word behind them
+    double* dflat = nullptr;        // device memory: where workgroup 0 puts them
+    size_t flat_cap = 0;            // doubles
+    TabOff to{};
+    size_t flat_used = 0;
     double* part = nullptr;         // pinned host memory
     size_t part_cap = 0;
     Modal md{};
     tgp_plan::Info info{};
-    long long nwg = 0;
-    int nw = 8;
-    bool began = false;
+    long long nwg = 0, seq = 0;
+    int nw = 8, sub = 8;
+    bool began = false, deferred = false;
 };
 
 Engine* create() { return new Engine(); }
 void destroy(Engine* e) {
     if (!e) return;
-    if (e->tab) (void)hipHostFree(e->tab);
+    delete e->tab;
+    if (e->hflat) (void)hipHostFree(e->hflat);
+    if (e->dflat) (void)hipFree(e->dflat);
     if (e->part) (void)hipHostFree(e->part);
     delete e;
 }
 
 const tgp_plan::Info& last_plan(const Engine* e) { return e->info; }
+const char* kernel_name(const Engine* e, bool post) {
+    if (e->sub == 16) return e->nw == 4 ? (post ? "k_steady_one<4x16,posterior>" : "k_steady_one<4x16,logpdf>") : (post ? "k_steady_one<8x16,posterior>" : "k_steady_one<8x16,logpdf>");
+    return e->nw == 8 ? (post ? "k_steady_one<8x8,posterior>" : "k_steady_one<8x8,logpdf>") : (post ? "k_steady_one<16x8,posterior>" : "k_steady_one<16x8,logpdf>");
+}
 const tgp_plan::Modal& last_modal(const Engine* e) { return e->md; }
 
 namespace {
 template <int D>
 int launch(Engine* e, hipStream_t st, const Call& c, const char** kname) {
     KArgs<D> ka;
+    static_assert(sizeof(KArgs<D>) <= 4096, "the kernel-argument segment");
     std::memset(&ka, 0, sizeof ka);
-    fill_args<D>(ka, e->md);
+    fill_args<D>(ka, e->md, e->sub);
     ka.post = c.mean != nullptr ? 1 : 0;
     ka.rnew_per_step = c.rnew_per_step;
     ka.T = c.T;
-    const int nw = e->nw;
-    ka.C = (long long)nw * kTile - 2LL * e->md.halo;
+    const int nw = e->nw, tile = 64 * e->sub;
+    ka.C = (long long)nw * tile - 2LL * e->md.halo;
     ka.nwg = e->nwg;
+    ka.seq = e->seq;
     ka.y = c.y;
     ka.Rnew = c.Rnew;
     ka.mean = c.mean;
     ka.var = c.var;
-    ka.tab = e->tab;
+    ka.htab = e->hflat;
+    ka.tab = e->dflat;
+    ka.flag = reinterpret_cast<const long long*>(e->hflat + e->flat_cap);
+    ka.to = e->to;
     ka.part = e->part;
     const long long per = (e->nwg + 7) / 8;
     const unsigned grid = (unsigned)(per * 8);
-    if (nw == 8) {
-        *kname = ka.post ? "k_steady_one<posterior>" : "k_steady_one<logpdf>";
-        hipLaunchKernelGGL((k_steady_one<D, 8>), dim3(grid), dim3(8 * 64), 0, st, ka);
-    } else {
-        *kname = ka.post ? "k_steady_one16<posterior>" : "k_steady_one16<logpdf>";
-        hipLaunchKernelGGL((k_steady_one<D, 16>), dim3(grid), dim3(16 * 64), 0, st, ka);
-    }
+    *kname = kernel_name(e, ka.post != 0);
+    if (e->sub == 16 && nw == 4) hipLaunchKernelGGL((k_steady_one<D, 4, 16>), dim3(grid), dim3(4 * 64), 0, st, ka);
+    else if (e->sub == 16 && nw == 8) hipLaunchKernelGGL((k_steady_one<D, 8, 16>), dim3(grid), dim3(8 * 64), 0, st, ka);
+    else if (nw == 8) hipLaunchKernelGGL((k_steady_one<D, 8, 8>), dim3(grid), dim3(8 * 64), 0, st, ka);
+    else hipLaunchKernelGGL((k_steady_one<D, 16, 8>), dim3(grid), dim3(16 * 64), 0, st, ka);
     return (int)hipGetLastError();
 }
 }  // namespace
 
+// TGP_MODAL_GEOMETRY=<waves>x<steps per lane> (8x8, 16x8, 4x16, 8x16) overrides the choice (A/B runs)
+void choose_geometry(int d, int halo, int* nw, int* sub) {
+    static const int forced = [] {
+        const char* v = std::getenv("TGP_MODAL_GEOMETRY");
+        int a = 0, b = 0;
+        if (v && std::sscanf(v, "%dx%d", &a, &b) == 2 && ((b == 8 && (a == 8 || a == 16)) || (b == 16 && (a == 4 || a == 8)))) return a * 100 + b;
+        return 0;
+    }();
+    const bool wide = 2 * halo * 10 > 3 * 4096;      // halos beyond ~30 % of a 4096-step span: spans of 8192 steps
+    *sub = 8;
+    *nw = wide ? 16 : 8;
+    (void)d;
+    if (forced) {
+        *nw = forced / 100;
+        *sub = forced % 100;
+        if (halo * 2 >= *nw * 64 * *sub) {      // (a forced geometry too small for the halo: the wide default)
+            *sub = 8;
+            *nw = 16;
+        }
+    }
+}
+
+static bool overlap_tables() {      // TGP_MODAL_OVERLAP=0: the whole plan before the launch (A/B runs)
+    static const bool on = [] {
+        const char* v = std::getenv("TGP_MODAL_OVERLAP");
+        return !(v && v[0] == '0');
+    }();
+    return on;
+}
+
+// the layout of the packed tables (fixed by d and n0: known when the kernel is launched, before the tables themselves)
+static void layout_tables(Engine* e) {
+    const int d = e->md.d, dd = d * d, n = e->md.n0 + 1;
+    TabOff& to = e->to;
+    int off = 1;
+    auto take = [&](int cnt) {
+        const int o = off;
+        off += cnt;
+        return o;
+    };
+    to.h = take(d);
+    to.mu0 = take(d);
+    to.Wm = take(dd);
+    to.db = take(n * d);
+    to.iS = take(n);
+    to.rS = take(n);
+    to.G = take(n * dd);
+    to.c = take(n * d);
+    to.vb = take(n);
+    to.tvb = take(0);
+}
+
+// packs the plan's tables for the device (pinned memory) and raises the flag
+static bool ship_tables(Engine* e, int why) {
+    const Modal& md = e->md;
+    const HeadTables& tb = *e->tab;
+    const int d = md.d, dd = d * d, n = md.n0 + 1;
+    const TabOff& to = e->to;
+    double* q = e->hflat;
+    std::memcpy(q + to.h, tb.h, sizeof(double) * d);
+    std::memcpy(q + to.mu0, tb.mu0, sizeof(double) * d);
+    std::memcpy(q + to.Wm, tb.Wm, sizeof(double) * dd);
+    std::memcpy(q + to.db, tb.kA, sizeof(double) * n * d);
+    std::memcpy(q + to.iS, tb.iS, sizeof(double) * n);
+    std::memcpy(q + to.rS, tb.rS, sizeof(double) * n);
+    std::memcpy(q + to.G, tb.G, sizeof(double) * n * dd);
+    std::memcpy(q + to.c, tb.c, sizeof(double) * n * d);
+    std::memcpy(q + to.vb, tb.vb, sizeof(double) * n);
+    const int n1 = md.n1 > 0 ? md.n1 : 0;
+    std::memcpy(q + to.tvb, tb.tvb, sizeof(double) * n1);
+    q[0] = (double)n1;
+    e->flat_used = (size_t)to.tvb + n1;
+    long long* hflag = reinterpret_cast<long long*>(e->hflat + e->flat_cap);
+    __atomic_store_n(hflag, 2 * e->seq + (why != tgp_plan::kOk ? 1 : 0), __ATOMIC_RELEASE);
+    return true;
+}
+
 bool plan(Engine* e, const tgp_plan::ModelHost& m, long long T) {
     e->began = false;
-    if (!e->tab && hipHostMalloc(reinterpret_cast<void**>(&e->tab), sizeof(HeadTables), hipHostMallocDefault) != hipSuccess) {
-        e->tab = nullptr;
-        e->info = tgp_plan::Info{};
-        e->info.why = tgp_plan::kEigFail;
-        return false;
+    if (!e->tab) {
+        e->tab = new HeadTables();
+        // the layout of ship_tables at its largest: d = 8, n0 = kN0Max, n1 = kTailMax
+        e->flat_cap = (size_t)(tgp_plan::kN0Max + 1) * (64 + 2 * 8 + 3) + tgp_plan::kTailMax + 64 + 2 * 8 + 8;
+        e->flat_cap = (e->flat_cap + 1) & ~(size_t)1;
+        if (hipHostMalloc(reinterpret_cast<void**>(&e->hflat), (e->flat_cap + 2) * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void**>(&e->dflat), (e->flat_cap + 2) * sizeof(double)) != hipSuccess) {
+            e->info = tgp_plan::Info{};
+            e->info.why = tgp_plan::kEigFail;
+            return false;
+        }
+        *reinterpret_cast<long long*>(e->hflat + e->flat_cap) = 0;
     }
-    e->info = tgp_plan::build_any(m, T, e->md, *e->tab);
+    ++e->seq;
+    e->info = tgp_plan::build_core_any(m, T, e->md, *e->tab);
     if (e->info.why != tgp_plan::kOk) return false;
-    // workgroups of 8 tiles unless the halos would eat more than ~30 % of them; then 16
+    layout_tables(e);
+    // the tables half: behind the launch when the series is certainly longer than head + tail (the kernel's head wave and last tiles wait
+    // for the flag), else right here
+    e->deferred = overlap_tables() && T >= (long long)e->md.nhs + tgp_plan::kTailMax + 1;
+    if (!e->deferred) {
+        const int why = tgp_plan::build_tables_any(e->md.d, T, e->md, *e->tab, e->info);
+        if (why != tgp_plan::kOk) {
+            e->info.why = why;
+            return false;
+        }
+        if (!ship_tables(e, tgp_plan::kOk)) {
+            e->info.why = tgp_plan::kEigFail;
+            return false;
+        }
+    }
+    // geometry: steps per lane (8 or 16) and tiles per workgroup; spans of 4096 steps unless the halos would eat more than ~30 % of them, then 8192
     const int halo = e->md.halo;
-    e->nw = (2 * halo * 10 <= 3 * 8 * kTile) ? 8 : 16;
-    const long long C = (long long)e->nw * kTile - 2LL * halo;
+    choose_geometry(e->md.d, halo, &e->nw, &e->sub);
+    const long long C = (long long)e->nw * 64 * e->sub - 2LL * halo;
     e->nwg = (T - e->md.nhs + C - 1) / C;
     const size_t need = (size_t)e->nwg + 8;
     if (need > e->part_cap) {
@@ -627,6 +862,20 @@ bool plan(Engine* e, const tgp_plan::ModelHost& m, long long T) {
         e->part_cap = need;
     }
     e->began = true;
+    return true;
+}
+
+// Behind the launch: the tables half of the plan, if it was deferred.  false: it declined (the kernel has been released all the same -- whatever
+// it writes is to be discarded, the caller re-runs the call elsewhere after synchronising).
+bool complete(Engine* e, long long T) {
+    if (!e->began || !e->deferred) return true;
+    e->deferred = false;
+    const int why = tgp_plan::build_tables_any(e->md.d, T, e->md, *e->tab, e->info);
+    const bool sent = ship_tables(e, why);
+    if (why != tgp_plan::kOk || !sent) {
+        e->info.why = why != tgp_plan::kOk ? why : tgp_plan::kEigFail;
+        return false;
+    }
     return true;
 }
 
@@ -654,6 +903,11 @@ int enqueue(Engine* e, hipStream_t stream, const Call& c, const char** kname, st
 // After the stream has passed the kernel: the log marginal likelihood from the workgroups' sums (fixed order).
 double finish(const Engine* e, long long T) {
     const Modal& md = e->md;
+    if (std::getenv("TGP_STEADY_DEBUG") != nullptr) {
+        const double* q = e->part + e->nwg;
+        fprintf(stderr, "[tgp modal] d %d n0 %d nhs %d n1 %d halo %d geometry %dx%d workgroups %lld | workgroup 0 (us from its start): tables ready %.1f, head forward done %.1f, head backward starts %.1f, done %.1f; last workgroup done %.1f\n",
+                md.d, md.n0, md.nhs, md.n1, md.halo, e->nw, e->sub, e->nwg, (q[2] - q[1]) * 0.01, (q[3] - q[1]) * 0.01, (q[4] - q[1]) * 0.01, (q[5] - q[1]) * 0.01, (q[6] - q[1]) * 0.01);
+    }
     double s = 0.0;
     for (long long g = 0; g < e->nwg; ++g) s += e->part[g];
     const double quad = e->part[e->nwg] + md.iS * s;

@@ -30,9 +30,15 @@ void destroy(Engine*);
 bool plan(Engine*, const tgp_plan::ModelHost&, long long T);
 // Enqueues the kernel of the planned call on `stream` (no synchronisation); *kname names it for the profile.
 int enqueue(Engine*, hipStream_t stream, const Call&, const char** kname, std::string* err);
+// Right behind enqueue: the tables half of the plan when plan() left it for now (the kernel's head wave and last tiles wait for it).
+// false: that half declined -- synchronise, discard the outputs, run the call elsewhere.
+bool complete(Engine*, long long T);
 // Once the stream has passed the kernel: the log marginal likelihood.
 double finish(const Engine*, long long T);
 const tgp_plan::Info& last_plan(const Engine*);
 const tgp_plan::Modal& last_modal(const Engine*);
+// the kernel variant plan() chose for the call (profile label)
+const char* kernel_name(const Engine*, bool posterior);
+void choose_geometry(int d, int halo, int* waves, int* steps_per_lane);
 
 }  // namespace tgp_modal

@@ -50,6 +50,8 @@ struct Modal {
 
 // What only the head wave of workgroup 0 and the last tiles read (pinned host memory, read by the device in place).
 struct HeadTables {
+    long long ready;               // 2 seq (+ 1: the tables half declined) once the tables of call `seq` are complete: written by the host AFTER the launch
+    long long n1;                  // steps at the end of the series whose smoothed variance is still in its transient (tvb)
     double h[kMaxD];
     double mu0[kMaxD];             // V^-1 (A x0.m + a): the predicted mean of step 0 in the modal coordinates of the stationary closed loop
     double Wm[kMaxD * kMaxD];      // lam = Wm zeta (row-major)
@@ -471,12 +473,35 @@ inline void modal_power(int d, const double* re, const double* im, long long n, 
 
 }  // namespace detail
 
-// Builds the plan of a call of T steps.  Returns Info::why == kOk when the one-launch path applies; `md` and `tab` are then complete.
+// The plan of a call of T steps, in two halves.
+//   build_core:   what the kernel needs before it can start -- the filtered covariance to its fixed point (tables kA, iS, rS as it goes), the
+//                 stationary step's reverse-time dynamics, the stationary smoothed covariance (a Lyapunov equation, by doubling), the modal
+//                 forms, the halo.  Info::why == kOk: the one-launch path applies as far as the core can tell.
+//   build_tables: what only the head wave and the last tiles read -- the reverse-time dynamics of every head step, the smoothed variances of
+//                 the head and of the last n1 steps, the head's gains in modal coordinates.  The caller may run it AFTER the launch (the
+//                 kernel's head wave and last tiles wait for HeadTables::ready); it can still decline (a head step not positive definite,
+//                 a smoother transient longer than kTailMax): returns a Why.
 template <int D>
-inline Info build(const ModelHost& m, long long T, Modal& md, HeadTables& tab) {
+struct Work {
+    double A[D][D], hv[D], R, kAss[D], Pss[D][D];
+    double Pf[kN0Max + 2][D][D], Pp[kN0Max + 2][D][D];
+    double Gss[D][D], Lss[D][D], Psinf[D][D];
+    double Vi[kMaxD * kMaxD];
+    int n0, nhs;
+};
+template <int D>
+inline Work<D>& work() {
+    static thread_local Work<D> w;
+    return w;
+}
+
+template <int D>
+inline Info build_core(const ModelHost& m, long long T, Modal& md, HeadTables& tab) {
     using namespace detail;
     Info info;
-    double A[D][D], Q[D][D], hv[D], P[D][D], Pold2[D][D];
+    Work<D>& wk = work<D>();
+    double A[D][D], hv[D];      // (locals: the compiler keeps them in registers; copies go to `wk` for build_tables)
+    double Q[D][D], P[D][D], Pold2[D][D];
     for (int i = 0; i < D; ++i) {
         hv[i] = m.H[i];
         for (int k = 0; k < D; ++k) {
@@ -488,8 +513,10 @@ inline Info build(const ModelHost& m, long long T, Modal& md, HeadTables& tab) {
         }
     }
     const double R = m.R[0];
+    wk.R = R;
+    std::memcpy(wk.A, A, sizeof A);
+    std::memcpy(wk.hv, hv, sizeof hv);
     // ---- (a) filtered covariance to its fixed point; per-step (Pf, Pp) kept for the reverse-time dynamics
-    static thread_local double sPf[kN0Max + 2][D][D], sPp[kN0Max + 2][D][D];
     int tc = -1, n0 = -1;
     double LS = 0.0, Sss = 1.0, kAss[D];
     bool bad = false;
@@ -528,8 +555,8 @@ inline Info build(const ModelHost& m, long long T, Modal& md, HeadTables& tab) {
         }
         tab.rS[t] = R * iS;
         tab.iS[t] = iS;
-        std::memcpy(sPf[t], P, sizeof P);
-        std::memcpy(sPp[t], pp, sizeof pp);
+        std::memcpy(wk.Pf[t], P, sizeof P);
+        std::memcpy(wk.Pp[t], pp, sizeof pp);
         Sss = S;
         if (tc >= 0) {      // the extra iteration from the settled covariance: the stationary step
             n0 = t;
@@ -556,17 +583,26 @@ inline Info build(const ModelHost& m, long long T, Modal& md, HeadTables& tab) {
         return info;
     }
     info.n0 = n0;
-    // ---- (b) reverse-time dynamics of the head steps and of the stationary step (row n0)
-    static thread_local double sG[kN0Max + 2][D][D], sL[kN0Max + 2][D][D];
-    for (int t = 0; t <= n0; ++t) {
-        if (!invert_dynamics<D>(A, sPf[t], sPp[t], sG[t], sL[t])) {
-            info.why = kNotPD;
-            return info;
-        }
+    wk.n0 = n0;
+    std::memcpy(wk.kAss, kAss, sizeof kAss);
+    std::memcpy(wk.Pss, P, sizeof P);      // the settled filtered covariance
+    const int nhs = 16 * ((n0 + 1 + 15) / 16);      // the head: [0, nhs), a whole number of 128-byte lines
+    wk.nhs = nhs;
+    if ((long long)nhs + 2 > T) {
+        info.why = kTooShort;
+        return info;
+    }
+    // ---- (b0) reverse-time dynamics of the stationary step
+    if (!invert_dynamics<D>(A, wk.Pf[n0], wk.Pp[n0], wk.Gss, wk.Lss)) {
+        info.why = kNotPD;
+        return info;
+    }
+    double css[D];
+    {
         double K[D], Sv = 0.0;
         for (int k = 0; k < D; ++k) {
             double v = 0.0;
-            for (int l = 0; l < D; ++l) v = pfma(hv[l], sPp[t][l][k], v);
+            for (int l = 0; l < D; ++l) v = pfma(hv[l], wk.Pp[n0][l][k], v);
             K[k] = v;
             Sv = pfma(v, hv[k], Sv);
         }
@@ -574,67 +610,60 @@ inline Info build(const ModelHost& m, long long T, Modal& md, HeadTables& tab) {
         const double iSv = 1.0 / Sv;
         for (int r = 0; r < D; ++r) {
             double v = 0.0;
-            for (int c = 0; c < D; ++c) {
-                v = pfma(sG[t][r][c], K[c] * iSv, v);
-                tab.G[(size_t)t * D * D + r * D + c] = sG[t][r][c];
-            }
-            tab.c[t * D + r] = v;
+            for (int c = 0; c < D; ++c) v = pfma(wk.Gss[r][c], K[c] * iSv, v);
+            css[r] = v;
         }
     }
-    // ---- (c) smoothed covariance backwards from the final filtered state (Ps_{T-1} = P_ss) until it no longer changes
-    double Ps[D][D], Po2[D][D];
-    std::memcpy(Ps, P, sizeof P);      // the settled filtered covariance
-    for (int i = 0; i < D; ++i)
-        for (int j = 0; j < D; ++j) Po2[i][j] = 0.0;
-    int n1 = -1;
-    for (int jt = 0; jt < kTailMax; ++jt) {
-        tab.tvb[jt] = quad_sym<D>(hv, Ps);
-        double pn[D][D];
-        smooth_cov_step<D>(sG[n0], sL[n0], Ps, pn);
-        bool moved = false, cyc = jt >= 1;
-        for (int i = 0; i < D; ++i)
-            for (int j = 0; j < D; ++j) {
-                moved = moved || std::fabs(pn[i][j] - Ps[i][j]) > kTol * 0.5 * (std::fabs(Ps[i][i]) + std::fabs(Ps[j][j]));
-                cyc = cyc && (pn[i][j] == Po2[i][j]);
-            }
-        std::memcpy(Po2, Ps, sizeof Ps);
-        std::memcpy(Ps, pn, sizeof pn);
-        if (!moved || cyc) {
-            n1 = jt + 1;
-            break;
-        }
-    }
-    if (n1 < 0) {
-        info.why = kTailLong;
-        return info;
-    }
-    info.n1 = n1;
-    const int nhs = 16 * ((n0 + 1 + 15) / 16);      // the head: [0, nhs), a whole number of 128-byte lines
-    if ((long long)nhs + n1 + 1 > T) {
-        info.why = kTooShort;
-        return info;
-    }
-    // ---- (d) smoothed variances of the head: Ps_{n0} = stationary, Ps_{t-1} = G_t Ps_t G_t' + L_t
-    const double vb_ss = quad_sym<D>(hv, Ps);
-    tab.vb[n0] = vb_ss;
+    // ---- (c0) the stationary smoothed covariance: Ps = G Ps G' + L, i.e. sum_k G^k L G'^k, by doubling
     {
-        double Pc[D][D];
-        std::memcpy(Pc, Ps, sizeof Ps);
-        for (int t = n0; t >= 1; --t) {
-            double pn[D][D];
-            smooth_cov_step<D>(sG[t], sL[t], Pc, pn);
-            std::memcpy(Pc, pn, sizeof pn);
-            tab.vb[t - 1] = quad_sym<D>(hv, Pc);
+        double S[D][D], M[D][D];
+        std::memcpy(S, wk.Lss, sizeof S);
+        std::memcpy(M, wk.Gss, sizeof M);
+        bool done = false;
+        for (int it = 0; it < 48 && !done; ++it) {
+            double t1[D][D], t2[D][D], M2[D][D];
+            double mmax = 0.0;
+            for (int i = 0; i < D; ++i)
+                for (int j = 0; j < D; ++j) {
+                    double v = 0.0, w = 0.0;
+                    for (int k = 0; k < D; ++k) {
+                        v = pfma(M[i][k], S[k][j], v);
+                        w = pfma(M[i][k], M[k][j], w);
+                    }
+                    t1[i][j] = v;
+                    M2[i][j] = w;
+                    mmax = std::max(mmax, std::fabs(M[i][j]));
+                }
+            for (int i = 0; i < D; ++i)
+                for (int j = 0; j < D; ++j) {
+                    double v = 0.0;
+                    for (int k = 0; k < D; ++k) v = pfma(t1[i][k], M[j][k], v);
+                    t2[i][j] = v;
+                }
+            for (int i = 0; i < D; ++i)
+                for (int j = i; j < D; ++j) {
+                    const double v = S[i][j] + 0.5 * (t2[i][j] + t2[j][i]);
+                    S[i][j] = S[j][i] = v;
+                }
+            std::memcpy(M, M2, sizeof M);
+            done = mmax < 1e-10;      // (the term just added carried mmax^2)
         }
+        if (!done) {
+            info.why = kSlowMixing;
+            return info;
+        }
+        std::memcpy(wk.Psinf, S, sizeof S);
     }
+    const double vb_ss = quad_sym<D>(hv, wk.Psinf);
     // ---- (e) the stationary closed loop in modal form
     double Phi[D * D], Gs[D * D];
     for (int i = 0; i < D; ++i)
         for (int j = 0; j < D; ++j) {
             Phi[i * D + j] = A[i][j] - kAss[i] * hv[j];
-            Gs[i * D + j] = sG[n0][i][j];
+            Gs[i * D + j] = wk.Gss[i][j];
         }
-    double fre[kMaxD], fim[kMaxD], gre[kMaxD], gim[kMaxD], V[kMaxD * kMaxD], Vi[kMaxD * kMaxD], W[kMaxD * kMaxD], Wi[kMaxD * kMaxD];
+    double fre[kMaxD], fim[kMaxD], gre[kMaxD], gim[kMaxD], V[kMaxD * kMaxD], W[kMaxD * kMaxD], Wi[kMaxD * kMaxD];
+    double(&Vi)[kMaxD * kMaxD] = wk.Vi;
     int npf = 0, npg = 0;
     double cf = 0, cg = 0, rf = 0, rg = 0;
     if (!modal_form(D, Phi, fre, fim, V, Vi, &npf, &cf, &rf) || !modal_form(D, Gs, gre, gim, W, Wi, &npg, &cg, &rg)) {
@@ -644,14 +673,14 @@ inline Info build(const ModelHost& m, long long T, Modal& md, HeadTables& tab) {
     info.cond_f = cf;
     info.cond_g = cg;
     info.resid = std::max(rf, rg);
-    if (!(cf <= kCondMax) || !(cg <= kCondMax) || !(rf <= 1e-13 * cf) || !(rg <= 1e-13 * cg)) {
+    if (!(cf <= kCondMax) || !(cg <= kCondMax) || !(rf <= 1e-13 * cf) || !(rg <= 1e-13 * cg) || npf != npg) {
         info.why = kIllConditioned;
         return info;
     }
     double rho = 0.0;
     for (int i = 0; i < D; ++i) {
-        rho = std::max(rho, std::hypot(fre[i], fim[i]));
-        rho = std::max(rho, std::hypot(gre[i], gim[i]));
+        rho = std::max(rho, std::sqrt(fre[i] * fre[i] + fim[i] * fim[i]));
+        rho = std::max(rho, std::sqrt(gre[i] * gre[i] + gim[i] * gim[i]));
     }
     info.rho = rho;
     if (!(rho < 1.0)) {
@@ -674,7 +703,7 @@ inline Info build(const ModelHost& m, long long T, Modal& md, HeadTables& tab) {
     md.d = D;
     md.n0 = n0;
     md.nhs = nhs;
-    md.n1 = n1;
+    md.n1 = -1;      // (build_tables)
     md.halo = halo;
     md.npair = npf;
     md.hh = m.hh[0];
@@ -693,7 +722,7 @@ inline Info build(const ModelHost& m, long long T, Modal& md, HeadTables& tab) {
             b = pfma(Vi[i * D + k], kAss[k], b);
             av = pfma(Vi[i * D + k], m.a[k], av);
             w = pfma(hv[k], V[k * D + i], w);
-            c = pfma(Wi[i * D + k], tab.c[n0 * D + k], c);
+            c = pfma(Wi[i * D + k], css[k], c);
             o = pfma(hv[k], W[k * D + i], o);
         }
         md.fb[i] = b;
@@ -730,12 +759,6 @@ inline Info build(const ModelHost& m, long long T, Modal& md, HeadTables& tab) {
             for (int i = 0; i < D; ++i) x[i] = nx[i];
         }
     }
-    // the backward block form must use the same pair layout as its own decomposition (the kernel's partner rule is positional, and
-    // the two decompositions may have different numbers of pairs only if one is mis-classified: reject)
-    if (npf != npg) {
-        info.why = kIllConditioned;
-        return info;
-    }
     // impulse response check: h' Phi^j (A K) against fw' B^j fb, j < 32
     {
         double x[D], gmax = 0.0, emax = 0.0;
@@ -769,7 +792,7 @@ inline Info build(const ModelHost& m, long long T, Modal& md, HeadTables& tab) {
             return info;
         }
     }
-    // the head's forward recursion in the modal coordinates: z' = M z + fa + fb u + db_t r, db_t = V^-1 (A K_t - A K)
+    // what the head needs of the modal forms: h, the first predicted mean in modal coordinates, W (lam = W zeta)
     {
         double m0[D];
         for (int i = 0; i < D; ++i) {
@@ -786,35 +809,135 @@ inline Info build(const ModelHost& m, long long T, Modal& md, HeadTables& tab) {
             for (int k = 0; k < D; ++k) v = pfma(Vi[i * D + k], m0[k], v);
             tab.mu0[i] = v;
         }
-        for (int t = 0; t <= n0; ++t) {
-            double dk[D], db[D];
-            for (int k = 0; k < D; ++k) dk[k] = tab.kA[t * D + k] - kAss[k];
-            for (int i = 0; i < D; ++i) {
-                double v = 0.0;
-                for (int k = 0; k < D; ++k) v = pfma(Vi[i * D + k], dk[k], v);
-                db[i] = v;
-            }
-            for (int i = 0; i < D; ++i) tab.kA[t * D + i] = (t == n0) ? 0.0 : db[i];
-        }
     }
     info.why = kOk;
     return info;
 }
 
-inline Info build_any(const ModelHost& m, long long T, Modal& md, HeadTables& tab) {
-    switch (m.d) {
-        case 1: return build<1>(m, T, md, tab);
-        case 2: return build<2>(m, T, md, tab);
-        case 3: return build<3>(m, T, md, tab);
-        case 4: return build<4>(m, T, md, tab);
-        case 5: return build<5>(m, T, md, tab);
-        case 6: return build<6>(m, T, md, tab);
-        case 7: return build<7>(m, T, md, tab);
-        case 8: return build<8>(m, T, md, tab);
+template <int D>
+inline int build_tables(long long T, Modal& md, HeadTables& tab, Info& info) {
+    using namespace detail;
+    Work<D>& wk = work<D>();
+    const int n0 = wk.n0;
+    const double R = wk.R;
+    double A[D][D], hv[D], kAss[D], Gss[D][D], Lss[D][D];
+    std::memcpy(A, wk.A, sizeof A);
+    std::memcpy(hv, wk.hv, sizeof hv);
+    std::memcpy(kAss, wk.kAss, sizeof kAss);
+    std::memcpy(Gss, wk.Gss, sizeof Gss);
+    std::memcpy(Lss, wk.Lss, sizeof Lss);
+    // ---- (b) reverse-time dynamics of the head steps (row n0: the stationary step's, from the core)
+    static thread_local double sG[kN0Max + 2][D][D], sL[kN0Max + 2][D][D];
+    std::memcpy(sG[n0], wk.Gss, sizeof wk.Gss);
+    std::memcpy(sL[n0], wk.Lss, sizeof wk.Lss);
+    for (int t = 0; t <= n0; ++t) {
+        if (t < n0 && !invert_dynamics<D>(A, wk.Pf[t], wk.Pp[t], sG[t], sL[t])) return kNotPD;
+        double K[D], Sv = 0.0;
+        for (int k = 0; k < D; ++k) {
+            double v = 0.0;
+            for (int l = 0; l < D; ++l) v = pfma(hv[l], wk.Pp[t][l][k], v);
+            K[k] = v;
+            Sv = pfma(v, hv[k], Sv);
+        }
+        Sv += R;
+        const double iSv = 1.0 / Sv;
+        for (int r = 0; r < D; ++r) {
+            double v = 0.0;
+            for (int c = 0; c < D; ++c) {
+                v = pfma(sG[t][r][c], K[c] * iSv, v);
+                tab.G[(size_t)t * D * D + r * D + c] = sG[t][r][c];
+            }
+            tab.c[t * D + r] = v;
+        }
     }
+    // ---- (c) smoothed covariance backwards from the final filtered state (Ps_{T-1} = P_ss) until it no longer changes
+    double Ps[D][D], Po2[D][D];
+    std::memcpy(Ps, wk.Pss, sizeof Ps);
+    for (int i = 0; i < D; ++i)
+        for (int j = 0; j < D; ++j) Po2[i][j] = 0.0;
+    int n1 = -1;
+    for (int jt = 0; jt < kTailMax; ++jt) {
+        tab.tvb[jt] = quad_sym<D>(hv, Ps);
+        double pn[D][D];
+        smooth_cov_step<D>(Gss, Lss, Ps, pn);
+        bool moved = false, cyc = jt >= 1;
+        for (int i = 0; i < D; ++i)
+            for (int j = 0; j < D; ++j) {
+                moved = moved || std::fabs(pn[i][j] - Ps[i][j]) > kTol * 0.5 * (std::fabs(Ps[i][i]) + std::fabs(Ps[j][j]));
+                cyc = cyc && (pn[i][j] == Po2[i][j]);
+            }
+        std::memcpy(Po2, Ps, sizeof Ps);
+        std::memcpy(Ps, pn, sizeof pn);
+        if (!moved || cyc) {
+            n1 = jt + 1;
+            break;
+        }
+    }
+    if (n1 < 0) return kTailLong;
+    info.n1 = n1;
+    md.n1 = n1;
+    tab.n1 = n1;
+    if ((long long)wk.nhs + n1 + 1 > T) return kTooShort;
+    // ---- (d) smoothed variances of the head: Ps_{n0} = stationary, Ps_{t-1} = G_t Ps_t G_t' + L_t
+    tab.vb[n0] = md.vb;
+    {
+        double Pc[D][D];
+        std::memcpy(Pc, wk.Psinf, sizeof Pc);
+        for (int t = n0; t >= 1; --t) {
+            double pn[D][D];
+            smooth_cov_step<D>(sG[t], sL[t], Pc, pn);
+            std::memcpy(Pc, pn, sizeof pn);
+            tab.vb[t - 1] = quad_sym<D>(hv, Pc);
+        }
+    }
+    // ---- the head's gains in the modal coordinates: z' = M z + fa + fb u + db_t r, db_t = V^-1 (A K_t - A K)
+    for (int t = 0; t <= n0; ++t) {
+        double dk[D], db[D];
+        for (int k = 0; k < D; ++k) dk[k] = tab.kA[t * D + k] - kAss[k];
+        for (int i = 0; i < D; ++i) {
+            double v = 0.0;
+            for (int k = 0; k < D; ++k) v = pfma(wk.Vi[i * D + k], dk[k], v);
+            db[i] = v;
+        }
+        for (int i = 0; i < D; ++i) tab.kA[t * D + i] = (t == n0) ? 0.0 : db[i];
+    }
+    return kOk;
+}
+
+template <int D>
+inline Info build(const ModelHost& m, long long T, Modal& md, HeadTables& tab) {
+    Info info = build_core<D>(m, T, md, tab);
+    if (info.why == kOk) info.why = build_tables<D>(T, md, tab, info);
+    return info;
+}
+
+#define TGP_PLAN_DISPATCH(d, expr)                                 \
+    switch (d) {                                                   \
+        case 1: { constexpr int D = 1; return expr; }              \
+        case 2: { constexpr int D = 2; return expr; }              \
+        case 3: { constexpr int D = 3; return expr; }              \
+        case 4: { constexpr int D = 4; return expr; }              \
+        case 5: { constexpr int D = 5; return expr; }              \
+        case 6: { constexpr int D = 6; return expr; }              \
+        case 7: { constexpr int D = 7; return expr; }              \
+        case 8: { constexpr int D = 8; return expr; }              \
+    }
+inline Info build_core_any(const ModelHost& m, long long T, Modal& md, HeadTables& tab) {
+    TGP_PLAN_DISPATCH(m.d, build_core<D>(m, T, md, tab))
     Info bad;
     bad.why = kEigFail;
     return bad;
 }
+inline int build_tables_any(int d, long long T, Modal& md, HeadTables& tab, Info& info) {
+    TGP_PLAN_DISPATCH(d, build_tables<D>(T, md, tab, info))
+    return kEigFail;
+}
+inline Info build_any(const ModelHost& m, long long T, Modal& md, HeadTables& tab) {
+    TGP_PLAN_DISPATCH(m.d, build<D>(m, T, md, tab))
+    Info bad;
+    bad.why = kEigFail;
+    return bad;
+}
+#undef TGP_PLAN_DISPATCH
 
 }  // namespace tgp_plan
