@@ -258,16 +258,18 @@ class ShardedLGSSM:
             self._sslot = torch.zeros(n, dtype=torch.float64, device=dev)
             self._sgath = torch.zeros(self.world * n, dtype=torch.float64, device=dev)
         yy, mm = e.device_obs(y)
-        if mm is not None:
-            return None                  # (NaN == missing is a property of the data every rank sees alike only by luck: callers with
-                                         #  missing data pass a (y, mask) tuple on EVERY rank, which is refused above on every rank)
-        rc = lib.tgp_shard_steady_begin(hd.h, _lib.ptr(yy), _lib.IN_DEVICE, int(self.rank == 0), int(self.rank == self.world - 1), int(post),
-                                        _lib.ptr(self._sslot))
-        began = rc == _lib.OK
-        if not began:
-            if rc != _lib.EUNSUPPORTED:
+        began = False
+        if mm is None:
+            rc = lib.tgp_shard_steady_begin(hd.h, _lib.ptr(yy), _lib.IN_DEVICE, int(self.rank == 0), int(self.rank == self.world - 1), int(post),
+                                            _lib.ptr(self._sslot))
+            began = rc == _lib.OK
+            if not began and rc != _lib.EUNSUPPORTED:
                 hd.check(rc)
-            self._sslot.zero_()          # "does not apply" travels with the element: every rank learns it from the gathered words
+        # A segment with missing data (NaN == missing: a property of THIS rank's slice of a host series, which the other ranks cannot see)
+        # or one the engine declines takes part in the gather all the same, with a zero element: "does not apply" travels with the element,
+        # every rank learns it from the gathered words and all of them take the general protocol together.
+        if not began:
+            self._sslot.zero_()
         self.comm.all_gather(self._sgath, self._sslot)
         if not began:
             self._steady_off = True

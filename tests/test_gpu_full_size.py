@@ -18,7 +18,13 @@ SPECS = {
     "sum52_52_d6": ("sum", ("matern52",), ("matern52",)),
     "sum52_12_d4": ("sum", ("matern52",), ("matern12",)),
     "sum52_52_32_d8": ("sum", ("matern52",), ("matern52",), ("matern32",)),     # eight lanes per chunk (tgp_group*.hpp)
+    # the same state dimensions with distinct length scales (the one-launch path; two identical summands have no well-conditioned modal form)
+    "sum52_52s_d6": ("sum", ("matern52",), ("stretched", 2.0, ("matern52",))),
+    "sum52_52s_32_d8": ("sum", ("matern52",), ("stretched", 2.0, ("matern52",)), ("stretched", 0.5, ("matern32",))),
 }
+# which engine must serve the LTI call of each model (asserted through the kernels' names: a silent fall-back to the general engine
+# would still pass the parity checks)
+ONE_LAUNCH = {"matern52_d3", "sum52_32_d5", "sum52_12_d4", "sum52_52s_d6", "sum52_52s_32_d8"}
 
 
 @pytest.fixture(scope="module")
@@ -28,13 +34,42 @@ def tgp():
     return t
 
 
+def _served(model):
+    import ctypes
+    hd = model.handle()
+    a, b = ctypes.c_int64(), ctypes.c_int64()
+    hd.check(hd.lib.tgp_steady_steps(hd.h, ctypes.byref(a), ctypes.byref(b)))
+    return a.value
+
+
+def _kernels_of(tgp, model, fn):
+    hd = model.handle()
+    hd.set_option(tgp._lib.OPT_PROFILE, 1)
+    hd.profile_reset()
+    out = fn()
+    names = set(hd.profile())
+    hd.set_option(tgp._lib.OPT_PROFILE, 0)
+    return out, names
+
+
+def _assert_engine(name, per_step, names, model, T):
+    if per_step:
+        assert any(n.startswith("k_reduce_filter") or n.startswith("k_group_reduce") for n in names) and not any(n.startswith("k_steady") for n in names), names
+    elif name in ONE_LAUNCH:
+        assert len(names) == 1 and next(iter(names)).startswith("k_steady_one"), names
+        assert _served(model) > T - 700
+    else:
+        assert any(n.startswith("k_steady_apply") for n in names) and not any(n.startswith("k_reduce_filter") for n in names), names
+        assert _served(model) > T - 700
+
+
 def _product_model(name, T, per_step=False):
     from temporalgps_jl_amd import lti_sde
     return lti_sde.build_lgssm(lti_sde.to_kernel(SPECS[name]), lti_sde.RegularSpacing(0.0, 0.1, T), 0.1, force_per_step=per_step)
 
 
 @pytest.mark.parametrize("name,per_step", [("matern52_d3", False), ("matern52_d3", True), ("sum52_32_d5", False), ("sum52_52_d6", False),
-                                           ("sum52_52_32_d8", False)])
+                                           ("sum52_52_32_d8", False), ("sum52_52s_d6", False), ("sum52_52s_32_d8", False)])
 def test_full_size_parity_with_sequential_oracle(tgp, name, per_step):
     import torch
     T = 10_000_000
@@ -45,13 +80,15 @@ def test_full_size_parity_with_sequential_oracle(tgp, name, per_step):
     pm, pv = sk.posterior_marginals(ref_model, y, np.array([1e-18]))
     model = _product_model(name, T, per_step)
     yd = torch.as_tensor(y, device="cuda:0")
-    lp = tgp.logpdf(model, yd)
+    lp, names = _kernels_of(tgp, model, lambda: tgp.logpdf(model, yd))
+    _assert_engine(name, per_step, names, model, T)
     assert abs(lp - lp_ref) <= 1e-10 * abs(lp_ref)
     Rn = torch.full((1,), 1e-18, dtype=torch.float64, device="cuda:0")
-    mean, var = tgp.posterior_marginals(model, yd, Rn)
+    (mean, var), names = _kernels_of(tgp, model, lambda: tgp.posterior_marginals(model, yd, Rn))
+    _assert_engine(name, per_step, names, model, T)
     assert np.max(np.abs(mean.cpu().numpy() - pm)) <= 1e-8
     assert np.max(np.abs(var.cpu().numpy() - pv)) <= 1e-8
-    # chunk-size (scan blocking) invariance at full size
+    # chunk-size (scan blocking) invariance at full size (a chunk size set by hand selects the general chunked-scan engine)
     hd = model.handle()
     for chunk in (61, 200):
         hd.set_option(tgp._lib.OPT_CHUNK, chunk)
@@ -117,7 +154,8 @@ def test_cfg4_T1e8_d4_logpdf_and_posterior_marginals(tgp):
     lp_ref = sk.logpdf(ref_model, y)
     model = _product_model("sum52_12_d4", T)
     yd = torch.as_tensor(y, device="cuda:0")
-    lp = tgp.logpdf(model, yd)
+    lp, names = _kernels_of(tgp, model, lambda: tgp.logpdf(model, yd))
+    _assert_engine("sum52_12_d4", False, names, model, T)
     assert abs(lp - lp_ref) <= 1e-10 * abs(lp_ref)
     # ... and the posterior marginals of the same 1e8-step series (one combined call), against the sequential oracle
     pm, pv = sk.posterior_marginals(ref_model, y, np.array([1e-18]))

@@ -236,3 +236,55 @@ def test_device_resident_exchange_threads_on_the_stationary_gain_engine(world, d
                 assert general, (T, r, names)
             mean[lo:hi], var[lo:hi] = m, v
         assert np.max(np.abs(mean - pm)) <= 1e-8 and np.max(np.abs(var - pv)) <= 1e-8
+
+
+def test_nan_in_one_segment_only_sends_every_rank_to_the_general_protocol():
+    """A host series whose NaNs (== missing) fall in ONE rank's segment: that rank cannot take the stationary-gain shard call, the others could
+    -- all of them must agree (through the gathered elements) on the general protocol, or the collectives that follow differ in size."""
+    import threading
+
+    import torch
+    import temporalgps_jl_amd as tgp
+    from temporalgps_jl_amd import _lib, lti_sde, parallel
+    lib = _lib.load()
+    from oracle import lgssm_ref as ref
+    world, T = 3, 12_000                                       # (the pure-Python oracle handles the missing mask: a short series)
+    rng = np.random.default_rng(4)
+    y_all = rng.standard_normal(T)
+    miss = np.zeros(T, dtype=bool)
+    miss[T // 2 + 17] = miss[T // 2 + 400] = True           # the middle rank's segment only
+    y_nan = y_all.copy()
+    y_nan[miss] = np.nan
+    ref_model = oc.build_lgssm(("matern52",), ("regular", 0.0, 0.1, T), 0.1)
+    d = 3
+    lp_ref = ref.logpdf_missing(ref_model, y_all, miss)
+    pm, pv = ref.marginals(ref.replace_observation_noise_cov(ref.posterior_missing(ref_model, y_all, miss), np.array([0.05])))
+    shared, barrier, out, errs = {}, threading.Barrier(world), {}, []
+
+    def run(rank):
+        try:
+            torch.cuda.set_device(0)
+            lo, hi = parallel.segment_bounds(T, world, rank)
+            model = lti_sde.build_lgssm(lti_sde.Matern52Kernel(), lti_sde.RegularSpacing(0.1 * lo, 0.1, hi - lo), 0.1)
+            sh = parallel.ShardedLGSSM(model, world, rank, engine=parallel.HIPEngine(model), comm=_ThreadComm(world, rank, shared, barrier))
+            lp = sh.logpdf(y_nan[lo:hi])                      # host slices: NaN == missing
+            lp3, mean, var = sh.logpdf_and_posterior_marginals(y_nan[lo:hi], np.array([0.05]))
+            out[rank] = (lp, lp3, lo, hi, np.asarray(mean), np.asarray(var))
+        except Exception as ex:          # noqa: BLE001
+            errs.append(ex)
+            barrier.abort()
+    for n in (lib.tgp_shard_slot_size(0, d), lib.tgp_shard_slot_size(1, d), lib.tgp_shard_steady_slot_size(d)):
+        shared[("g", n)] = torch.zeros(world * n, dtype=torch.float64, device="cuda:0")
+    shared[("r", 4)] = torch.zeros(world, 4, dtype=torch.float64, device="cuda:0")
+    shared[("r", 1)] = torch.zeros(world, 1, dtype=torch.float64, device="cuda:0")
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join(timeout=120) for t in th]
+    assert not any(t.is_alive() for t in th), "a rank hangs in a collective the others never entered"
+    assert not errs, errs
+    mean, var = np.zeros(T), np.zeros(T)
+    for r in range(world):
+        lp, lp3, lo, hi, m, v = out[r]
+        assert abs(lp - lp_ref) <= 1e-10 * abs(lp_ref) and abs(lp3 - lp_ref) <= 1e-10 * abs(lp_ref)
+        mean[lo:hi], var[lo:hi] = m, v
+    assert np.max(np.abs(mean - pm)) <= 1e-8 and np.max(np.abs(var - pv)) <= 1e-8
