@@ -226,6 +226,23 @@ int tgp_logpdf_adjoint(tgp_handle* h, const double* y, uint32_t flags, double* l
 int tgp_steady_plan(int d, const double* A, const double* a, const double* Q, const double* H, const double* hh, const double* R,
                     const double* x0m, const double* x0P, int64_t T, int32_t* info_i, double* info_d, double* modal_out,
                     double* tables_out);
+/* ---- time segments of ONE series on the one-launch path (TGP_OPT_STEADY = 3): what a rank of a multi-GPU run calls (tgp_multi_* and the
+ * one-process-per-GPU driver use them).  Both mean recursions of the stationary region forget a state within `halo` steps, so a segment needs
+ * nothing of its neighbours but their `halo` observations next to the boundary: ONE all-gather of 2 halo observations per rank before the
+ * call, one sum of the ranks' shares of the log marginal likelihood after it; no exchange of filter elements, no carry between ranks
+ * (the reference has no counterpart: src/util/scan.jl:15-28 is one sequential loop).
+ * tgp_segment_plan: host only. bounds [nseg + 1] (bounds[0] = 0, bounds[nseg] = T_total; interior ones multiples of 16). *applies = 1 when the
+ *   one-launch path serves EVERY segment of this model and series (the plan is a function of the model blocks and T_total alone: every rank
+ *   computes the same answer without communication), *halo = the number of neighbour observations a segment needs on each side.
+ * tgp_segment_logpdf_and_posterior_marginals: the handle is bound to the segment's model (T = seg_hi - seg_lo, every block shared, the
+ *   SERIES' x0); y_seg [T] the segment's observations, y_left [halo] those in front of it (NULL for the first segment), y_right [halo] those
+ *   behind it (NULL for the last; fewer than halo exist only if the series ends there: pass what exists) -- device pointers (TGP_IN_DEVICE).
+ *   mean_out / var_out [T] (NULL: logpdf only) as in tgp_posterior_marginals. *lml_share: this segment's share; the shares of all segments
+ *   add up to logpdf(model, y) of lgssm.jl:147-165. A NaN observation makes the share NaN (callers fall back to the general protocol). */
+int tgp_segment_plan(tgp_handle* h, int64_t T_total, int nseg, const int64_t* bounds, int32_t* applies, int32_t* halo);
+int tgp_segment_logpdf_and_posterior_marginals(tgp_handle* h, int64_t T_total, int64_t seg_lo, int64_t seg_hi, const double* y_seg,
+                                               const double* y_left, const double* y_right, const double* Rnew, uint32_t flags,
+                                               double* mean_out, double* var_out, double* lml_share);
 /* the host half of it, a pure host function (tests; callers that keep the device record): rec = tgp_adjoint_record_size(d)
  * doubles as tgp_steady.hpp lays them out, y_head = the first n_head observations (n_head >= 512 * head tiles) */
 int tgp_adjoint_record_size(int d);

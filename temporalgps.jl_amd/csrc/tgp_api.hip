@@ -1765,6 +1765,110 @@ int tgp_logpdf(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t 
     return tm.finish(out);
 }
 
+// ---- time segments on the one-launch path (one rank of several; tgp_multi.hip and the one-process-per-GPU driver) ----------------------
+// Both mean recursions forget a state within `halo` steps, so a rank needs nothing of its neighbours but their `halo` observations next to
+// the boundary: no exchange of filter elements, no carry between ranks.  The plan is a function of the model blocks and the series' length
+// only -- every rank computes the same one, and the same verdict for every segment.
+static bool modal_host_model(tgp_handle* h, tgp_plan::ModelHost& mh) {
+    if (!h->opt_modal || h->hostm.empty()) return false;
+    const int d = h->d;
+    const size_t dd = (size_t)d * d;
+    const double* q = h->hostm.data();
+    mh.d = d;
+    mh.A = q; mh.a = q + dd; mh.Q = q + dd + d; mh.H = q + 2 * dd + d; mh.hh = q + 2 * dd + 2 * d; mh.R = q + 2 * dd + 2 * d + 1;
+    mh.x0m = h->x0m.data();
+    mh.x0P = h->x0P.data();
+    return true;
+}
+
+int tgp_segment_plan(tgp_handle* h, int64_t T_total, int nseg, const int64_t* bounds, int32_t* applies, int32_t* halo) {
+    if (!h || !bounds || !applies || !halo || nseg < 1 || T_total <= 0) return TGP_EINVAL;
+    TRY(check_ready(h, /*general=*/false));
+    *applies = 0;
+    *halo = 0;
+    tgp_plan::ModelHost mh;
+    if (!modal_host_model(h, mh) || h->ordering != 0 || h->p != 1 || h->sde) return TGP_OK;
+    if (bounds[0] != 0 || bounds[nseg] != T_total) return h->fail(TGP_EINVAL, "tgp_segment_plan: the segments must tile [0, T)");
+    if (!h->modal) h->modal = tgp_modal::create();
+    if (!tgp_modal::plan(h->modal, mh, T_total)) return TGP_OK;
+    (void)tgp_modal::complete(h->modal, T_total);      // (the verdict of the tables half is part of the answer: every rank must give the same one)
+    if (tgp_modal::last_plan(h->modal).why != 0) return TGP_OK;
+    const tgp_plan::Modal& md = tgp_modal::last_modal(h->modal);
+    bool ok = true;
+    for (int r = 0; r < nseg && ok; ++r) {
+        const int64_t lo = bounds[r], hi = bounds[r + 1];
+        ok = hi > lo && lo % 16 == 0 && (hi % 16 == 0 || hi == T_total) && hi - lo >= md.halo;
+        if (r > 0) ok = ok && lo >= (int64_t)md.nhs + md.halo;
+        if (r == 0) ok = ok && hi >= (int64_t)md.nhs + 16;
+        if (r == nseg - 1) ok = ok && hi - lo >= md.n1 + 16;
+    }
+    *applies = ok ? 1 : 0;
+    *halo = md.halo;
+    return TGP_OK;
+}
+
+int tgp_segment_logpdf_and_posterior_marginals(tgp_handle* h, int64_t T_total, int64_t seg_lo, int64_t seg_hi, const double* y_seg, const double* y_left,
+                                               const double* y_right, const double* Rnew, uint32_t flags, double* mean_out, double* var_out,
+                                               double* lml_share) {
+    if (!h || !lml_share) return TGP_EINVAL;
+    TRY(check_ready(h, /*general=*/false));
+    tgp_plan::ModelHost mh;
+    if (!modal_host_model(h, mh)) return h->fail(TGP_EUNSUPPORTED, "tgp_segment_*: not a model of the one-launch path (ask tgp_segment_plan first)");
+    if (!(flags & TGP_IN_DEVICE)) return h->fail(TGP_EUNSUPPORTED, "tgp_segment_*: device inputs only");
+    if (h->T != seg_hi - seg_lo || seg_lo < 0 || seg_hi > T_total || !y_seg) return h->fail(TGP_EINVAL, "tgp_segment_*: the bound model has not the segment's length");
+    if ((mean_out != nullptr) != (var_out != nullptr) || (mean_out && !Rnew)) return h->fail(TGP_EINVAL, "tgp_segment_*: mean, var and Rnew go together");
+    if (!h->modal) h->modal = tgp_modal::create();
+    h->modal_last = false;
+    h->steady2_last = false;
+    if (!tgp_modal::plan(h->modal, mh, T_total)) return h->fail(TGP_EUNSUPPORTED, "tgp_segment_*: the one-launch path does not apply to this model / series");
+    const tgp_plan::Modal& md = tgp_modal::last_modal(h->modal);
+    if ((seg_lo > 0 && !y_left) || (seg_hi < T_total && !y_right)) return h->fail(TGP_EINVAL, "tgp_segment_*: the neighbours' observations are missing");
+    const bool odev = (flags & TGP_OUT_DEVICE) != 0, rshared = (flags & TGP_SHARED_R) != 0;
+    const size_t nT = (size_t)h->T * sizeof(double);
+    CallTimer tm(h, /*clear=*/false);
+    const void* pR = nullptr;
+    if (mean_out) TRY(stage_in(h, h->bRnew, Rnew, rshared ? sizeof(double) : nT, true, &pR));
+    h->mv.y = y_seg;
+    h->mv.missing = nullptr;
+    tm.inputs_done();
+    double *dm = nullptr, *dv = nullptr;
+    TRY(stage_out(h, h->bo1, mean_out, nT, odev, &dm));
+    TRY(stage_out(h, h->bo2, var_out, nT, odev, &dv));
+    tgp_modal::Call c;
+    c.T = T_total;
+    c.y = y_seg;
+    c.Rnew = static_cast<const double*>(pR);
+    c.rnew_per_step = (mean_out && !rshared) ? 1 : 0;
+    c.mean = dm;
+    c.var = dv;
+    c.seg_lo = seg_lo;
+    c.seg_hi = seg_hi;
+    c.yl = y_left;
+    c.yr = y_right;
+    {
+        std::string err;
+        const char* kname = tgp_modal::kernel_name(h->modal, dm != nullptr);
+        LaunchScope ls(h, kname);
+        if (tgp_modal::enqueue(h->modal, h->stream, c, &kname, &err) != 0) return h->fail(TGP_EHIP, err);
+    }
+    const bool tables_ok = tgp_modal::complete(h->modal, T_total);
+    tm.kernels_done();
+    TRY(copy_back(h, mean_out, dm, nT, odev));
+    TRY(copy_back(h, var_out, dv, nT, odev));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    resolve_profile(h);
+    if (!tables_ok) return h->fail(TGP_EUNSUPPORTED, "tgp_segment_*: the plan's tables half declined (tgp_segment_plan would have said so)");
+    double ssq = 0.0, hq = 0.0;
+    tgp_modal::finish_parts(h->modal, &ssq, &hq);
+    double share = -0.5 * (hq + md.iS * ssq);
+    if (seg_lo == 0) share += -0.5 * ((double)T_total * 1.8378770664093454835606594728112 + md.LS + (double)(T_total - md.n0) * md.logS);
+    *lml_share = share;
+    h->modal_last = true;
+    h->reduce_valid = false;
+    h->smoother_valid = false;
+    return TGP_OK;
+}
+
 // Host-only (no GPU needed): the plan the one-launch path of the stationary-gain engine builds inside every call (tgp_steady_plan.hpp).
 int tgp_steady_plan(int d, const double* A, const double* a, const double* Q, const double* H, const double* hh, const double* R, const double* x0m,
                     const double* x0P, int64_t T, int32_t* info_i, double* info_d, double* modal_out, double* tables_out) {

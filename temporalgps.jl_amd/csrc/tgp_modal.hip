@@ -32,15 +32,20 @@ struct KArgs {
     double gd[D], go[D], gc[D], gw[D];             // backward: zeta' = gd zeta + go zeta_partner + gc r,  mean = y - rS r + gw . zeta
     double fpr[6][D], fpi[6][D];                   // M^(SUB 2^k), k < 6 (forward block form: re, signed im; SUB = steps per lane)
     double gpr[6][D], gpi[6][D];
-    double f8r[D], f8i[D], g8r[D], g8i[D];         // M^8 (the second half of a sixteen-step lane)
     double ftr[2][D], fti[2][D];                   // M^TILE, M^(2 TILE)
     double gtr[2][D], gti[2][D];
     double WJ[kWJ][D], WG[kWJ][D];
     double hh, rS, vb;
     int n0, nhs, halo, post, rnew_per_step;
     long long T, C, nwg, seq;
+    // a time segment of a longer series (one rank of several; single device: wg0 = 0, seg = [0, T), T_eff = T): this launch owns the outputs
+    // of [seg_lo, seg_hi) and runs the workgroups wg0 .. wg0 + nwg - 1 of the series; y, mean, var, Rnew (per step) are indexed by the
+    // GLOBAL step (the pointers are moved back by seg_lo), the `halo` observations in front of / behind the segment come in yl / yr
+    long long wg0, seg_lo, seg_hi, T_eff;
+    const double *yl, *yr;
     const double* y;
-    const double* Rnew;
+    const double* Rnew;         // [0]: the shared new noise
+    const double* RnewT;        // per-step new noise, indexed by the global step
     double* mean;
     double* var;
     const double* htab;         // pinned host memory: the packed head / tail tables of this call (TabOff), written by the host beside the kernel
@@ -76,9 +81,11 @@ __device__ __noinline__ void wait_tables(const long long* flagc, long long seq) 
     while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < 2 * seq) __builtin_amdgcn_s_sleep(16);
 }
 
-template <int SUB>
-__device__ __forceinline__ void load_lane(const double* __restrict__ p, long long t0, long long T, double (&v)[SUB]) {
-    if (t0 + SUB <= T && t0 >= 0) {
+template <int SUB, int D>
+__device__ __forceinline__ void load_lane(const KArgs<D>& ka, long long t0, double (&v)[SUB]) {
+    const double* __restrict__ p = ka.y;
+    const long long hi = ka.seg_hi < ka.T_eff ? ka.seg_hi : ka.T_eff;
+    if (t0 >= ka.seg_lo && t0 + SUB <= hi) {
         if ((reinterpret_cast<uintptr_t>(p) & 15) == 0) {
             const double2* q = reinterpret_cast<const double2*>(p + t0);
 #pragma unroll
@@ -92,8 +99,18 @@ __device__ __forceinline__ void load_lane(const double* __restrict__ p, long lon
             for (int j = 0; j < SUB; ++j) v[j] = p[t0 + j];
         }
     } else {
+        // (the ends of the series, and the few lanes of a segment's first / last workgroup that read its neighbours' observations)
 #pragma unroll
-        for (int j = 0; j < SUB; ++j) v[j] = (t0 + j < T && t0 + j >= 0) ? p[t0 + j] : 0.0;
+        for (int j = 0; j < SUB; ++j) {
+            const long long t = t0 + j;
+            double x = 0.0;
+            if (t < ka.T_eff) {
+                if (t < ka.seg_lo) x = ka.yl[t - (ka.seg_lo - ka.halo)];
+                else if (t >= ka.seg_hi) x = ka.yr[t - ka.seg_hi];
+                else x = p[t];
+            }
+            v[j] = x;
+        }
     }
 }
 
@@ -254,7 +271,7 @@ __device__ void head_backward(const KArgs<D>& ka, const double* __restrict__ sR,
         }
         if (lane < cnt) {
             ka.mean[t] = mk;
-            ka.var[t] = tb[ka.to.vb + ti] + (ka.rnew_per_step ? ka.Rnew[t] : rn0);
+            ka.var[t] = tb[ka.to.vb + ti] + (ka.rnew_per_step ? ka.RnewT[t] : rn0);
         }
     }
 }
@@ -271,6 +288,7 @@ __device__ void head_backward(const KArgs<D>& ka, const double* __restrict__ sR,
 // =================================================================================================================================
 template <int D, int NW, int SUB>
 __global__ __launch_bounds__(NW * 64) void k_steady_one(const KArgs<D> ka) {
+    static_assert(SUB == kWJ, "eight steps per lane (sixteen were built and measured in round 4: the 32 more registers cost more occupancy than the halved scans save)");
     constexpr int TILE = 64 * SUB;
     constexpr int CHB = D <= 4 ? 64 : (D <= 6 ? 32 : 16);      // steps of the head's backward recursion staged in LDS at a time (~10 KB)
     __shared__ double sF[NW][D], sB[NW][D], sHead[D], sAcc[NW];
@@ -287,17 +305,22 @@ __global__ __launch_bounds__(NW * 64) void k_steady_one(const KArgs<D> ka) {
         wg = (long long)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
         if ((long long)(blockIdx.x >> 3) >= per || wg >= ka.nwg) return;
     }
-    const long long T = ka.T;
-    const long long c_lo = ka.nhs + wg * ka.C, c_hi_raw = c_lo + ka.C, c_hi = c_hi_raw < T ? c_hi_raw : T;
-    const long long s0 = (wg == 0) ? (long long)ka.nhs : c_lo - ka.halo;
+    const long long T = ka.T, Tv = ka.T_eff;      // Tv: the steps this launch may read (a segment: its own and `halo` beyond)
+    const long long g = ka.wg0 + wg;               // the workgroup's number in the series
+    long long c_lo = ka.nhs + g * ka.C, c_hi_raw = c_lo + ka.C;
+    c_lo = c_lo > ka.seg_lo ? c_lo : ka.seg_lo;
+    c_hi_raw = c_hi_raw < ka.seg_hi ? c_hi_raw : ka.seg_hi;
+    const long long c_hi = c_hi_raw < T ? c_hi_raw : T;
+    const bool first = g == 0 && ka.seg_lo == 0;      // the workgroup behind the head (a later segment may begin inside the series' first core range)
+    const long long s0 = first ? (long long)ka.nhs : c_lo - ka.halo;
     const long long tile_t0 = s0 + (long long)wave * TILE, t0 = tile_t0 + (long long)lane * SUB;
-    const bool head_wave = wg == 0 && wave == 0;
-    const bool any_valid = tile_t0 < T;                              // (wave-uniform)
+    const bool head_wave = first && wave == 0;
+    const bool any_valid = tile_t0 < Tv;                             // (wave-uniform)
     const bool need_back = any_valid && tile_t0 + TILE > c_lo;       // a tile wholly inside the left halo only hands its end state on
     const bool has_out = ka.post && need_back && tile_t0 < c_hi;
 
     double head_quad = 0.0;
-    if (wg == 0) {
+    if (first) {
         // the head's tables: wait for the host, pull them into device memory (all waves), then the head wave runs the head forward
         if (threadIdx.x == 0) ka.part[ka.nwg + 1] = (double)wall_clock64();      // (phases of workgroup 0, 100 MHz: TGP_STEADY_DEBUG prints them)
         wait_tables(ka.flag, ka.seq);
@@ -319,14 +342,14 @@ __global__ __launch_bounds__(NW * 64) void k_steady_one(const KArgs<D> ka) {
     }
     // ---- forward, zero start: innovations r0 of the lane's steps, the lane's end state, inclusive scan over the lanes
     double yv[SUB], r[SUB], st[D];
-    const long long left = T - t0;
+    const long long left = Tv - t0;
     const int nvalid = left >= SUB ? SUB : (left > 0 ? (int)left : 0);
     {
         double z[D];
 #pragma unroll
         for (int i = 0; i < D; ++i) z[i] = 0.0;
         if (any_valid) {
-            load_lane<SUB>(ka.y, t0, T, yv);
+            load_lane<SUB, D>(ka, t0, yv);
 #pragma unroll
             for (int j = 0; j < SUB; ++j) {
                 const double u = yv[j] - ka.hh;
@@ -402,7 +425,7 @@ __global__ __launch_bounds__(NW * 64) void k_steady_one(const KArgs<D> ka) {
 #pragma unroll
         for (int k = 1; k <= 3; ++k) {
             const int src = wave - k;
-            if (src < -1 || (src == -1 && wg != 0)) continue;      // (wave-uniform)
+            if (src < -1 || (src == -1 && !first)) continue;      // (wave-uniform)
             double x[D];
 #pragma unroll
             for (int i = 0; i < D; ++i) x[i] = (src >= 0) ? sF[src][i] : sHead[i];
@@ -420,27 +443,15 @@ __global__ __launch_bounds__(NW * 64) void k_steady_one(const KArgs<D> ka) {
 #pragma unroll
         for (int i = 0; i < D; ++i) st[i] = fma(sPw[0][0][i][lane], zin[i], fma(sPw[0][1][i][lane], zin[partner<D>(i)], st[i]));
         const bool in_core = t0 >= c_lo && t0 < c_hi_raw;
-        // the start state moves step j's innovation by -fw' M^j st: WJ holds eight rows; the second half of a sixteen-step lane uses them
-        // on M^8 st
+        // the start state moves step j's innovation by -fw' M^j st
 #pragma unroll
-        for (int half = 0; half < SUB / kWJ; ++half) {
-            double sh[D];
-            if (half == 0) {
+        for (int j = 0; j < SUB; ++j) {
+            double rr = r[j];
 #pragma unroll
-                for (int i = 0; i < D; ++i) sh[i] = st[i];
-            } else {
-                bmul<D>(ka.f8r, ka.f8i, st, sh);
-            }
-#pragma unroll
-            for (int jj = 0; jj < kWJ; ++jj) {
-                const int j = half * kWJ + jj;
-                double rr = r[j];
-#pragma unroll
-                for (int i = 0; i < D; ++i) rr = fma(-ka.WJ[jj][i], sh[i], rr);
-                rr = (j < nvalid) ? rr : 0.0;
-                r[j] = rr;
-                acc = fma(rr, rr, acc);
-            }
+            for (int i = 0; i < D; ++i) rr = fma(-ka.WJ[j][i], st[i], rr);
+            rr = (j < nvalid) ? rr : 0.0;
+            r[j] = rr;
+            acc = fma(rr, rr, acc);
         }
         acc = in_core ? acc : 0.0;
     }
@@ -455,7 +466,7 @@ __global__ __launch_bounds__(NW * 64) void k_steady_one(const KArgs<D> ka) {
 #pragma unroll
             for (int w = 0; w < NW; ++w) t += sAcc[w];
             ka.part[wg] = t;
-            if (wg == 0) ka.part[ka.nwg] = head_quad;
+            if (first) ka.part[ka.nwg] = head_quad;
         }
         return;
     }
@@ -529,31 +540,19 @@ __global__ __launch_bounds__(NW * 64) void k_steady_one(const KArgs<D> ka) {
         for (int i = 0; i < D; ++i) zst[i] = fma(sPw[1][0][i][lane], zin[i], fma(sPw[1][1][i][lane], zin[partner<D>(i)], zst[i]));
         v2d* row = reinterpret_cast<v2d*>(sOut[wave]);
         const int wb = Row<SUB>::lane_slot(lane);
-        // the lam behind the lane's last step reaches step j through Mg^(SUB - 1 - j): WG holds gw' Mg^(7 - j); the first half of a
-        // sixteen-step lane sees Mg^8 zst
+        // the lam behind the lane's last step reaches step j through Mg^(SUB - 1 - j): WG holds gw' Mg^(7 - j)
 #pragma unroll
-        for (int half = SUB / kWJ - 1; half >= 0; --half) {
-            double sh[D];
-            if (half == SUB / kWJ - 1) {
+        for (int j = 0; j < SUB; j += 2) {
+            double m0 = yv[j], m1 = yv[j + 1];
 #pragma unroll
-                for (int i = 0; i < D; ++i) sh[i] = zst[i];
-            } else {
-                bmul<D>(ka.g8r, ka.g8i, zst, sh);
+            for (int i = 0; i < D; ++i) {
+                m0 = fma(ka.WG[j][i], zst[i], m0);
+                m1 = fma(ka.WG[j + 1][i], zst[i], m1);
             }
-#pragma unroll
-            for (int jj = 0; jj < kWJ; jj += 2) {
-                const int j = half * kWJ + jj;
-                double m0 = yv[j], m1 = yv[j + 1];
-#pragma unroll
-                for (int i = 0; i < D; ++i) {
-                    m0 = fma(ka.WG[jj][i], sh[i], m0);
-                    m1 = fma(ka.WG[jj + 1][i], sh[i], m1);
-                }
-                v2d w;
-                w.x = m0;
-                w.y = m1;
-                row[wb + (j >> 1)] = w;
-            }
+            v2d w;
+            w.x = m0;
+            w.y = m1;
+            row[wb + (j >> 1)] = w;
         }
         lds_sync();
         flush_row<SUB>(ka.mean, tile_t0, c_lo, c_hi, row, lane);
@@ -566,7 +565,7 @@ __global__ __launch_bounds__(NW * 64) void k_steady_one(const KArgs<D> ka) {
                 n1 = (long long)ka.htab[0];
             }
             const double* __restrict__ tvb = ka.htab + ka.to.tvb;      // (in place from pinned memory: the last few tiles, a handful of values)
-            const bool aligned = (reinterpret_cast<uintptr_t>(ka.var) & 15) == 0 && (!ka.rnew_per_step || (reinterpret_cast<uintptr_t>(ka.Rnew) & 15) == 0);
+            const bool aligned = (reinterpret_cast<uintptr_t>(ka.var) & 15) == 0 && (!ka.rnew_per_step || (reinterpret_cast<uintptr_t>(ka.RnewT) & 15) == 0);
 #pragma unroll
             for (int k = 0; k < SUB / 2; ++k) {
                 const long long t = tile_t0 + 2 * (k * 64 + lane);
@@ -582,7 +581,7 @@ __global__ __launch_bounds__(NW * 64) void k_steady_one(const KArgs<D> ka) {
                 if (t >= c_lo && t + 1 < c_hi && aligned) {
                     v2d rn;
                     if (ka.rnew_per_step) {
-                        rn = *reinterpret_cast<const v2d*>(ka.Rnew + t);
+                        rn = *reinterpret_cast<const v2d*>(ka.RnewT + t);
                     } else {
                         rn.x = rn0;
                         rn.y = rn0;
@@ -592,8 +591,8 @@ __global__ __launch_bounds__(NW * 64) void k_steady_one(const KArgs<D> ka) {
                     w.y = v1 + rn.y;
                     *reinterpret_cast<v2d*>(ka.var + t) = w;
                 } else {
-                    if (t >= c_lo && t < c_hi) ka.var[t] = v0 + (ka.rnew_per_step ? ka.Rnew[t] : rn0);
-                    if (t + 1 >= c_lo && t + 1 < c_hi) ka.var[t + 1] = v1 + (ka.rnew_per_step ? ka.Rnew[t + 1] : rn0);
+                    if (t >= c_lo && t < c_hi) ka.var[t] = v0 + (ka.rnew_per_step ? ka.RnewT[t] : rn0);
+                    if (t + 1 >= c_lo && t + 1 < c_hi) ka.var[t + 1] = v1 + (ka.rnew_per_step ? ka.RnewT[t + 1] : rn0);
                 }
             }
         }
@@ -614,7 +613,7 @@ __global__ __launch_bounds__(NW * 64) void k_steady_one(const KArgs<D> ka) {
 #pragma unroll
         for (int w = 0; w < NW; ++w) t += sAcc[w];
         ka.part[wg] = t;
-        if (wg == 0) ka.part[ka.nwg] = head_quad;
+        if (first) ka.part[ka.nwg] = head_quad;
         if (wg == ka.nwg - 1) ka.part[ka.nwg + 6] = (double)wall_clock64();
     }
 }
@@ -633,8 +632,6 @@ void fill_args(KArgs<D>& ka, const Modal& md, int sub) {
     for (int i = 0; i < D; ++i) {
         ka.fd[i] = md.fd[i]; ka.fo[i] = md.fo[i]; ka.fb[i] = md.fb[i]; ka.fa[i] = md.fa[i]; ka.fw[i] = md.fw[i];
         ka.gd[i] = md.gd[i]; ka.go[i] = md.go[i]; ka.gc[i] = md.gc[i]; ka.gw[i] = md.gw[i];
-        ka.f8r[i] = md.fp8r[i]; ka.f8i[i] = md.fp8i[i];
-        ka.g8r[i] = md.gp8r[i]; ka.g8i[i] = md.gp8i[i];
         for (int j = 0; j < kWJ; ++j) {
             ka.WJ[j][i] = md.WJ[j][i];
             ka.WG[j][i] = md.WG[j][i];
@@ -679,7 +676,9 @@ struct Engine {
     size_t part_cap = 0;
     Modal md{};
     tgp_plan::Info info{};
-    long long nwg = 0, seq = 0;
+    long long nwg = 0, seq = 0;      // workgroups of the whole series
+    long long nwg_local = 0, wg0 = 0;      // ... of the last launch (a time segment runs a slice of them)
+    bool owns_head = true;
     int nw = 8, sub = 8;
     bool began = false, deferred = false;
 };
@@ -696,7 +695,6 @@ void destroy(Engine* e) {
 
 const tgp_plan::Info& last_plan(const Engine* e) { return e->info; }
 const char* kernel_name(const Engine* e, bool post) {
-    if (e->sub == 16) return e->nw == 4 ? (post ? "k_steady_one<4x16,posterior>" : "k_steady_one<4x16,logpdf>") : (post ? "k_steady_one<8x16,posterior>" : "k_steady_one<8x16,logpdf>");
     return e->nw == 8 ? (post ? "k_steady_one<8x8,posterior>" : "k_steady_one<8x8,logpdf>") : (post ? "k_steady_one<16x8,posterior>" : "k_steady_one<16x8,logpdf>");
 }
 const tgp_plan::Modal& last_modal(const Engine* e) { return e->md; }
@@ -713,34 +711,46 @@ int launch(Engine* e, hipStream_t st, const Call& c, const char** kname) {
     ka.T = c.T;
     const int nw = e->nw, tile = 64 * e->sub;
     ka.C = (long long)nw * tile - 2LL * e->md.halo;
-    ka.nwg = e->nwg;
+    // the launch's slice of the series' workgroups: all of them, or those that own outputs of the segment [seg_lo, seg_hi)
+    const long long seg_lo = c.seg_lo, seg_hi = (c.seg_hi < 0 || c.seg_hi > c.T) ? c.T : c.seg_hi;
+    const long long nhs = e->md.nhs;
+    const long long g0 = seg_lo <= nhs ? 0 : (seg_lo - nhs) / ka.C, g1 = (seg_hi - nhs + ka.C - 1) / ka.C;
+    e->wg0 = g0;
+    e->nwg_local = g1 - g0;
+    e->owns_head = seg_lo == 0;
+    ka.nwg = e->nwg_local;
+    ka.wg0 = g0;
+    ka.seg_lo = seg_lo;
+    ka.seg_hi = seg_hi;
+    ka.T_eff = (seg_hi + e->md.halo < c.T) ? seg_hi + e->md.halo : c.T;
+    ka.yl = c.yl;
+    ka.yr = c.yr;
     ka.seq = e->seq;
-    ka.y = c.y;
+    ka.y = c.y - seg_lo;
     ka.Rnew = c.Rnew;
-    ka.mean = c.mean;
-    ka.var = c.var;
+    ka.RnewT = (c.Rnew && c.rnew_per_step) ? c.Rnew - seg_lo : c.Rnew;
+    ka.mean = c.mean ? c.mean - seg_lo : nullptr;
+    ka.var = c.var ? c.var - seg_lo : nullptr;
     ka.htab = e->hflat;
     ka.tab = e->dflat;
     ka.flag = reinterpret_cast<const long long*>(e->hflat + e->flat_cap);
     ka.to = e->to;
     ka.part = e->part;
-    const long long per = (e->nwg + 7) / 8;
+    const long long per = (e->nwg_local + 7) / 8;
     const unsigned grid = (unsigned)(per * 8);
     *kname = kernel_name(e, ka.post != 0);
-    if (e->sub == 16 && nw == 4) hipLaunchKernelGGL((k_steady_one<D, 4, 16>), dim3(grid), dim3(4 * 64), 0, st, ka);
-    else if (e->sub == 16 && nw == 8) hipLaunchKernelGGL((k_steady_one<D, 8, 16>), dim3(grid), dim3(8 * 64), 0, st, ka);
-    else if (nw == 8) hipLaunchKernelGGL((k_steady_one<D, 8, 8>), dim3(grid), dim3(8 * 64), 0, st, ka);
+    if (nw == 8) hipLaunchKernelGGL((k_steady_one<D, 8, 8>), dim3(grid), dim3(8 * 64), 0, st, ka);
     else hipLaunchKernelGGL((k_steady_one<D, 16, 8>), dim3(grid), dim3(16 * 64), 0, st, ka);
     return (int)hipGetLastError();
 }
 }  // namespace
 
-// TGP_MODAL_GEOMETRY=<waves>x<steps per lane> (8x8, 16x8, 4x16, 8x16) overrides the choice (A/B runs)
+// TGP_MODAL_GEOMETRY=<waves>x<steps per lane> (8x8, 16x8) overrides the choice (A/B runs)
 void choose_geometry(int d, int halo, int* nw, int* sub) {
     static const int forced = [] {
         const char* v = std::getenv("TGP_MODAL_GEOMETRY");
         int a = 0, b = 0;
-        if (v && std::sscanf(v, "%dx%d", &a, &b) == 2 && ((b == 8 && (a == 8 || a == 16)) || (b == 16 && (a == 4 || a == 8)))) return a * 100 + b;
+        if (v && std::sscanf(v, "%dx%d", &a, &b) == 2 && b == 8 && (a == 8 || a == 16)) return a * 100 + b;
         return 0;
     }();
     const bool wide = 2 * halo * 10 > 3 * 4096;      // halos beyond ~30 % of a 4096-step span: spans of 8192 steps
@@ -900,17 +910,26 @@ int enqueue(Engine* e, hipStream_t stream, const Call& c, const char** kname, st
     return r;
 }
 
-// After the stream has passed the kernel: the log marginal likelihood from the workgroups' sums (fixed order).
+// After the stream has passed the kernel: the launch's share of the quadratic form -- the sum of r^2 over the steps it owns behind the head
+// and (the launch that holds the head) the head's sum of r^2 / S_t; fixed summation order.
+void finish_parts(const Engine* e, double* ssq, double* head_quad) {
+    double s = 0.0;
+    for (long long g = 0; g < e->nwg_local; ++g) s += e->part[g];
+    *ssq = s;
+    *head_quad = e->owns_head ? e->part[e->nwg_local] : 0.0;
+}
+
+// ... and the log marginal likelihood of a call that ran the whole series.
 double finish(const Engine* e, long long T) {
     const Modal& md = e->md;
     if (std::getenv("TGP_STEADY_DEBUG") != nullptr) {
-        const double* q = e->part + e->nwg;
+        const double* q = e->part + e->nwg_local;
         fprintf(stderr, "[tgp modal] d %d n0 %d nhs %d n1 %d halo %d geometry %dx%d workgroups %lld | workgroup 0 (us from its start): tables ready %.1f, head forward done %.1f, head backward starts %.1f, done %.1f; last workgroup done %.1f\n",
-                md.d, md.n0, md.nhs, md.n1, md.halo, e->nw, e->sub, e->nwg, (q[2] - q[1]) * 0.01, (q[3] - q[1]) * 0.01, (q[4] - q[1]) * 0.01, (q[5] - q[1]) * 0.01, (q[6] - q[1]) * 0.01);
+                md.d, md.n0, md.nhs, md.n1, md.halo, e->nw, e->sub, e->nwg_local, (q[2] - q[1]) * 0.01, (q[3] - q[1]) * 0.01, (q[4] - q[1]) * 0.01, (q[5] - q[1]) * 0.01, (q[6] - q[1]) * 0.01);
     }
-    double s = 0.0;
-    for (long long g = 0; g < e->nwg; ++g) s += e->part[g];
-    const double quad = e->part[e->nwg] + md.iS * s;
+    double s = 0.0, hq = 0.0;
+    finish_parts(e, &s, &hq);
+    const double quad = hq + md.iS * s;
     const double logdet = md.LS + (double)(T - md.n0) * md.logS;
     return -0.5 * ((double)T * kLog2Pi + logdet + quad);
 }

@@ -21,6 +21,10 @@ struct Call {
     const double* Rnew = nullptr;   // device: one value, or T values when rnew_per_step
     int rnew_per_step = 0;
     double *mean = nullptr, *var = nullptr;      // device; nullptr: logpdf only
+    // A time segment of the series (one rank of several): y, Rnew (per step), mean, var hold the steps [seg_lo, seg_hi) only; yl / yr the
+    // `halo` observations in front of / behind them (device; unused at the series' ends).  Default: the whole series.
+    long long seg_lo = 0, seg_hi = -1;
+    const double *yl = nullptr, *yr = nullptr;
 };
 
 struct Engine;
@@ -33,8 +37,10 @@ int enqueue(Engine*, hipStream_t stream, const Call&, const char** kname, std::s
 // Right behind enqueue: the tables half of the plan when plan() left it for now (the kernel's head wave and last tiles wait for it).
 // false: that half declined -- synchronise, discard the outputs, run the call elsewhere.
 bool complete(Engine*, long long T);
-// Once the stream has passed the kernel: the log marginal likelihood.
+// Once the stream has passed the kernel: the log marginal likelihood (a call over the whole series) ...
 double finish(const Engine*, long long T);
+// ... or the launch's share of the quadratic form (a segment): lml = -(T log 2pi + LS + (T - n0) logS + sum head_quad + iS sum ssq) / 2
+void finish_parts(const Engine*, double* ssq, double* head_quad);
 const tgp_plan::Info& last_plan(const Engine*);
 const tgp_plan::Modal& last_modal(const Engine*);
 // the kernel variant plan() chose for the call (profile label)

@@ -243,7 +243,72 @@ class ShardedLGSSM:
         e.shard_fold(gath[0], self.world, self.rank)
         return yy
 
+    def _one_launch_device(self, y, R_new, post):
+        """The call on the one-launch path's time segments (tgp_segment_*, round 4): both mean recursions of the stationary region forget a
+        state within `halo` steps, so a rank needs nothing of its neighbours but their `halo` observations next to the boundary -- ONE
+        all-gather of 2 halo observations per rank, the segment's single kernel, and the sum of the ranks' shares of the log marginal
+        likelihood.  Whether it applies is a function of the model blocks and the segment bounds alone: every rank evaluates it for every
+        segment and reaches the same verdict without communication.  Data that only some ranks see (a NaN == missing value) surfaces as
+        a NaN total, which every rank sees: all of them then take the general protocol together.  Returns None when it does not apply,
+        else (share, mean, var) with shares that add up to the log marginal likelihood.  Must be called inside the handle's stream context."""
+        import torch
+        e = self.engine
+        lib, hd = e.hd.lib, e.hd
+        if getattr(self, "_one_off", False) or self.model.p != 1 or isinstance(y, tuple):
+            return None
+        dev = torch.device("cuda", self.model.device)
+        if not hasattr(self, "_geom"):
+            mine = torch.tensor([float(self.model.T)], dtype=torch.float64, device=dev)
+            allT = torch.zeros(self.world, dtype=torch.float64, device=dev)
+            self.comm.all_gather(allT, mine)
+            Ts = [int(v) for v in allT.cpu().tolist()]          # (one synchronisation, once per bound model)
+            self._geom = np.concatenate([[0], np.cumsum(Ts)]).astype(np.int64)
+            self._halo = None
+        bounds = self._geom
+        T, lo, hi = int(bounds[-1]), int(bounds[self.rank]), int(bounds[self.rank + 1])
+        ok, halo = ctypes.c_int32(0), ctypes.c_int32(0)
+        hd.check(lib.tgp_segment_plan(hd.h, T, self.world, bounds.ctypes.data, ctypes.byref(ok), ctypes.byref(halo)))
+        if not ok.value:
+            self._one_off = True          # (the same verdict on every rank)
+            return None
+        H = int(halo.value)
+        yy, _ = e.device_obs(y)          # (a NaN == missing value stays in: it surfaces as a NaN total below)
+        if self._halo != H:
+            self._edge = torch.zeros(2 * H, dtype=torch.float64, device=dev)
+            self._edges = torch.zeros(self.world * 2 * H, dtype=torch.float64, device=dev)
+            self._tot = torch.zeros(1, dtype=torch.float64, device=dev)
+            self._halo = H
+        self._edge[:H].copy_(yy[:H])
+        self._edge[H:].copy_(yy[-H:])
+        self.comm.all_gather(self._edges, self._edge)
+        left = self._edges[(self.rank - 1) * 2 * H + H:(self.rank - 1) * 2 * H + 2 * H] if self.rank > 0 else None
+        right = self._edges[(self.rank + 1) * 2 * H:(self.rank + 1) * 2 * H + H] if self.rank < self.world - 1 else None
+        out_device = L._is_torch(y)
+        mean = var = Rn = None
+        flags = _lib.IN_DEVICE
+        if post:
+            Rn = torch.as_tensor(np.atleast_1d(np.asarray(R_new, dtype=np.float64)) if not L._is_torch(R_new) else R_new,
+                                 dtype=torch.float64, device=dev).reshape(-1).contiguous()
+            mean, var = L._out(self.model, (self.model.T,), out_device), L._out(self.model, (self.model.T,), out_device)
+            flags |= (_lib.OUT_DEVICE if out_device else 0) | (_lib.SHARED_R if Rn.shape[0] == 1 else 0)
+        share = ctypes.c_double()
+        hd.check(lib.tgp_segment_logpdf_and_posterior_marginals(hd.h, T, lo, hi, _lib.ptr(yy), _lib.ptr(left), _lib.ptr(right), _lib.ptr(Rn), flags,
+                                                                _lib.ptr(mean), _lib.ptr(var), ctypes.byref(share)))        # the rank's synchronisation
+        self._tot[0] = share.value
+        self.comm.all_reduce_sum(self._tot)
+        total = float(self._tot.cpu()[0])
+        if not np.isfinite(total):            # (every rank sees the same total)
+            self._one_off = True
+            return None
+        return total / self.world, mean, var
+
     def _steady_device(self, y, R_new, post):
+        res = self._one_launch_device(y, R_new, post)
+        if res is not None:
+            return res
+        return self._steady_shards_device(y, R_new, post)
+
+    def _steady_shards_device(self, y, R_new, post):
         """The same call on the stationary-gain engine's shards (LTI models; tgp_shard_steady_begin / _finish: two halves around ONE
         all-gather). Returns None when it does not apply -- agreed by every rank through the gathered elements, so that all of them
         then take the general protocol together. Must be called inside the handle's stream context."""

@@ -178,8 +178,8 @@ def test_device_resident_exchange_threads(world, layout, d_kernel):
     assert np.max(np.abs(var - pv)) <= 1e-8
 
 
-@pytest.mark.parametrize("world,d_kernel", [(2, "matern52"), (4, "matern32"), (3, "sum52_52")])
-def test_device_resident_exchange_threads_on_the_stationary_gain_engine(world, d_kernel):
+@pytest.mark.parametrize("world,d_kernel,steady_opt", [(2, "matern52", 3), (4, "matern32", 3), (3, "sum52_52", 3), (3, "matern52", 2), (2, "sum52_52", 2)])
+def test_device_resident_exchange_threads_on_the_stationary_gain_engine(world, d_kernel, steady_opt):
     """The one-process-per-GPU driver (parallel.ShardedLGSSM) with an LTI series and no missing data: the shards run the stationary-gain
     engine's two-half calls (tgp_shard_steady_begin / _finish, ONE all-gather) -- checked through the kernels' names -- and a second
     case whose segments are too short for it agrees, through the gathered elements, to take the general protocol."""
@@ -207,6 +207,7 @@ def test_device_resident_exchange_threads_on_the_stationary_gain_engine(world, d
                 torch.cuda.set_device(0)
                 lo, hi = parallel.segment_bounds(T, world, rank)
                 model = lti_sde.build_lgssm(kern, lti_sde.RegularSpacing(0.1 * lo, 0.1, hi - lo), 0.1)
+                model.handle_options[tgp._lib.OPT_STEADY] = steady_opt      # 3: the one-launch path's segments; 2: the five-launch engine's shards
                 sh = parallel.ShardedLGSSM(model, world, rank, engine=parallel.HIPEngine(model), comm=_ThreadComm(world, rank, shared, barrier))
                 hd = model.handle()
                 hd.set_option(tgp._lib.OPT_PROFILE, 1)
@@ -217,8 +218,10 @@ def test_device_resident_exchange_threads_on_the_stationary_gain_engine(world, d
             except Exception as ex:          # noqa: BLE001
                 errs.append(ex)
                 barrier.abort()
-        for n in (lib.tgp_shard_slot_size(0, d), lib.tgp_shard_slot_size(1, d), lib.tgp_shard_steady_slot_size(d)):
+        for n in (lib.tgp_shard_slot_size(0, d), lib.tgp_shard_slot_size(1, d), lib.tgp_shard_steady_slot_size(d), 1):
             shared[("g", n)] = torch.zeros(world * n, dtype=torch.float64, device="cuda:0")
+        for hh in range(16, 1537, 16):          # (the edge exchange of the one-launch segments: 2 halo values per rank)
+            shared[("g", 2 * hh)] = torch.zeros(world * 2 * hh, dtype=torch.float64, device="cuda:0")
         shared[("r", 4)] = torch.zeros(world, 4, dtype=torch.float64, device="cuda:0")
         shared[("r", 1)] = torch.zeros(world, 1, dtype=torch.float64, device="cuda:0")
         th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
@@ -230,7 +233,9 @@ def test_device_resident_exchange_threads_on_the_stationary_gain_engine(world, d
             lp, lp3, lo, hi, m, v, names = out[r]
             assert abs(lp - lp_ref) <= 1e-10 * abs(lp_ref) and abs(lp3 - lp_ref) <= 1e-10 * abs(lp_ref)
             general = any(n.startswith("k_reduce_filter") for n in names)
-            if expect_steady:
+            if steady_opt == 3 and any(n.startswith("k_steady_one") for n in names):      # ONE kernel per rank and call, nothing of the shard protocol
+                assert all(n.startswith("k_steady_one") for n in names), (T, r, names)           # (its segments may be shorter than the shards')
+            elif expect_steady:
                 assert "k_steady_shard_fold" in names and not general, (T, r, names)
             else:            # (the first call tried the engine -- its kernels are in the profile -- and every rank fell back together)
                 assert general, (T, r, names)
@@ -273,8 +278,10 @@ def test_nan_in_one_segment_only_sends_every_rank_to_the_general_protocol():
         except Exception as ex:          # noqa: BLE001
             errs.append(ex)
             barrier.abort()
-    for n in (lib.tgp_shard_slot_size(0, d), lib.tgp_shard_slot_size(1, d), lib.tgp_shard_steady_slot_size(d)):
+    for n in (lib.tgp_shard_slot_size(0, d), lib.tgp_shard_slot_size(1, d), lib.tgp_shard_steady_slot_size(d), 1):
         shared[("g", n)] = torch.zeros(world * n, dtype=torch.float64, device="cuda:0")
+    for hh in range(16, 1537, 16):
+        shared[("g", 2 * hh)] = torch.zeros(world * 2 * hh, dtype=torch.float64, device="cuda:0")
     shared[("r", 4)] = torch.zeros(world, 4, dtype=torch.float64, device="cuda:0")
     shared[("r", 1)] = torch.zeros(world, 1, dtype=torch.float64, device="cuda:0")
     th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
