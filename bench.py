@@ -284,10 +284,14 @@ def pmc_traffic(kname, d, layout):
     """HBM bytes per launch of `kname` from the committed PMC summary (profiles/r01_pmc_traffic.json: separate
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command, FETCH doubled per
     MI355X_MICROARCH.md). None when the summary has no entry (other d / workload)."""
-    p3 = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")         # round 3: keyed by the profile label, "d=<d>" -> label -> bytes
-    if kname.startswith("k_steady") and os.path.exists(p3):
-        ent = json.load(open(p3)).get(layout, {}).get(f"d={d}", {}).get(kname)
-        return None if ent is None else ent["hbm_bytes"]
+    for pj in ("r04_pmc_traffic.json", "r03_pmc_traffic.json"):         # keyed by the profile label, "d=<d>" -> label -> bytes
+        p3 = os.path.join(ROOT, "profiles", pj)
+        if kname.startswith("k_steady") and os.path.exists(p3):
+            ent = json.load(open(p3)).get(layout, {}).get(f"d={d}", {}).get(kname)
+            if ent is not None:
+                return ent["hbm_bytes"]
+    if kname.startswith("k_steady"):
+        return None
     path = os.path.join(ROOT, "profiles", "r02s_pmc_traffic.json")      # (r01_pmc_traffic.json: the kernels before the stationary-covariance steps)
     if not os.path.exists(path):
         return None
@@ -314,7 +318,9 @@ def valu_utilisation(prof, d, layout):
     as profiles/r01_sq_counters_<layout>.json, T = 1e7) over the launch duration measured HERE, against the issue peak
     256 CUs x 4 SIMDs x one wave64 fp64 instruction per 4 cycles at 2.4 GHz (= the 78.6 TFLOP/s datasheet figure counted
     in instructions). The LTI kernels are bound by this, not by HBM."""
-    p3 = os.path.join(ROOT, "profiles", f"r03_sq_counters_{layout}.json")        # round 3 (stationary-gain engine): keyed by the profile label
+    p3 = os.path.join(ROOT, "profiles", f"r04_sq_counters_{layout}.json")        # rounds 3, 4 (stationary-gain engine): keyed by the profile label
+    if not (os.path.exists(p3) and any(k in json.load(open(p3)).get(f"d={d}", {}) for k in prof)):
+        p3 = os.path.join(ROOT, "profiles", f"r03_sq_counters_{layout}.json")
     if os.path.exists(p3) and any(k.startswith("k_steady") for k in prof):
         table = json.load(open(p3)).get(f"d={d}", {})
         peak = 256 * 4 * 2.4e9 / 4.0
