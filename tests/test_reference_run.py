@@ -1,0 +1,86 @@
+"""Reference-run fixtures (tests/golden/reference_run.npz, written by julia/make_reference_fixtures.jl from the UNMODIFIED reference).
+
+Neither this repository's build image nor the GPU box has Julia, and the reference's own tests hold no golden vectors for the LGSSM path,
+so the file is absent until a maintainer with Julia runs the script -- these tests then SKIP, and the oracle stays "parity unpinned"
+(DESIGN 2).  When the file is present they hold the oracle (CPU tier) and the device path (GPU tier) against the reference's own outputs at
+the tolerances of every other parity test: logpdf 1e-10 relative, marginals 1e-8 absolute."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import components as oc
+from oracle import seq_kalman as sk
+
+PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_run.npz")
+needs_file = pytest.mark.skipif(not os.path.exists(PATH), reason="tests/golden/reference_run.npz absent: run julia/make_reference_fixtures.jl "
+                                                                  "where Julia and TemporalGPs.jl exist (no Julia in this image)")
+
+
+def parse_spec(s):
+    """'sum(matern52,stretched(2.0,matern52))' -> the oracle's nested-tuple kernel spec"""
+    s = s.strip()
+    m = re.match(r"^(\w+)\((.*)\)$", s)
+    if not m:
+        return (s,)
+    head, body = m.group(1), m.group(2)
+    parts, depth, cur = [], 0, ""
+    for ch in body:
+        if ch == "," and depth == 0:
+            parts.append(cur)
+            cur = ""
+        else:
+            depth += ch == "("
+            depth -= ch == ")"
+            cur += ch
+    parts.append(cur)
+    if head == "sum":
+        return ("sum",) + tuple(parse_spec(p) for p in parts)
+    if head in ("scaled", "stretched"):
+        return (head, float(parts[0]), parse_spec(parts[1]))
+    raise ValueError(s)
+
+
+def cases():
+    if not os.path.exists(PATH):
+        return []
+    z = np.load(PATH)
+    return [c.split("|") for c in bytes(z["cases_bytes"]).decode().split(";")]
+
+
+def test_spec_parser():
+    assert parse_spec("sum(matern52,stretched(2.0,matern52))") == ("sum", ("matern52",), ("stretched", 2.0, ("matern52",)))
+    assert parse_spec("scaled(1.7,stretched(0.6,matern52))") == ("scaled", 1.7, ("stretched", 0.6, ("matern52",)))
+
+
+@needs_file
+@pytest.mark.parametrize("name,spec", cases())
+def test_oracle_reproduces_the_reference_run(name, spec):
+    z = np.load(PATH)
+    t0, dt, T, s2 = z[name + "/meta"]
+    model = oc.build_lgssm(parse_spec(spec), ("regular", float(t0), float(dt), int(T)), float(s2))
+    y = z[name + "/y"]
+    lp = sk.logpdf(model, y)
+    assert abs(lp - z[name + "/logpdf"][0]) <= 1e-10 * abs(lp)
+    pm, pv = sk.posterior_marginals(model, y, np.array([0.0]))      # (the latent posterior: replaced noise 0)
+    assert np.max(np.abs(pm - z[name + "/post_mean"])) <= 1e-8 and np.max(np.abs(pv - z[name + "/post_var"])) <= 1e-8
+
+
+@needs_file
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,spec", cases())
+def test_device_path_reproduces_the_reference_run(name, spec):
+    import temporalgps_jl_amd as tgp
+    from temporalgps_jl_amd import lti_sde
+    z = np.load(PATH)
+    t0, dt, T, s2 = z[name + "/meta"]
+    y = z[name + "/y"]
+    fx = lti_sde.to_sde(lti_sde.GP(lti_sde.to_kernel(parse_spec(spec))))(lti_sde.RegularSpacing(float(t0), float(dt), int(T)), float(s2))
+    lp = lti_sde.logpdf(fx, y)
+    assert abs(lp - z[name + "/logpdf"][0]) <= 1e-10 * abs(lp)
+    post = lti_sde.posterior(fx, y)
+    m, v = lti_sde.mean_and_var(post(lti_sde.RegularSpacing(float(t0), float(dt), int(T))))
+    assert np.max(np.abs(np.asarray(m) - z[name + "/post_mean"])) <= 1e-8 and np.max(np.abs(np.asarray(v) - z[name + "/post_var"])) <= 1e-8
+    pm, pv = lti_sde.mean_and_var(fx)
+    assert np.max(np.abs(np.asarray(pm) - z[name + "/prior_mean"])) <= 1e-8 and np.max(np.abs(np.asarray(pv) - z[name + "/prior_var"])) <= 1e-8
