@@ -1553,7 +1553,7 @@ int tgp_model_set(tgp_handle* h, int64_t T, int d, int p, int ordering, uint32_t
     h->x0P.assign(x0P, x0P + d * d);
     TRY(upload_x0(h, h->bx0, x0m, x0P));
     HIPCHK(hipStreamSynchronize(h->stream));
-    if (h->lti && !h->binding_sde && p == 1 && (flags & TGP_SHARED_R) && ordering == 0 && tgp_steady::supports(d)) {
+    if (h->lti && !h->binding_sde && p == 1 && (flags & TGP_SHARED_R) && tgp_steady::supports(d)) {
         // what the one-launch path's host plan reads (tgp_steady_plan.hpp): the shared blocks, on the host
         const size_t dd = (size_t)d * d;
         h->hostm.assign(2 * dd + 2 * (size_t)d + 2, 0.0);
@@ -2309,11 +2309,115 @@ static int affine_impl(tgp_handle* h, bool rnd, const double* x0dev, const doubl
     return TGP_OK;
 }
 
+// Prior marginals of an LTI model (every block shared, scalar observations): lgssm.jl:99-109 never sees data, and with constant blocks the
+// predicted state (m_t, P_t) runs into its fixed point -- at once for a GP prior, whose x0 IS the stationary distribution.  The host runs
+// the recursion until it no longer changes (2 ulp, or a 2-cycle of the last bits), the device writes the head and the constant: the
+// call is bound by its 16 B/step of output.
+__global__ __launch_bounds__(256) void k_fill_marginals(double* __restrict__ mean, double* __restrict__ var, long long T, const double* __restrict__ tab, int n,
+                                                        int reverse) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < T; t += stride) {
+        const long long k = reverse ? T - 1 - t : t;
+        const int i = k < n ? (int)k : n - 1;
+        mean[t] = tab[i];
+        var[t] = tab[n + i];
+    }
+}
+
+static int lti_marginals(tgp_handle* h, double* dm, double* dv, bool* served) {
+    *served = false;
+    if (!h->opt_modal || h->hostm.empty() || h->p != 1 || h->sde) return TGP_OK;
+    const int d = h->d;
+    const size_t dd = (size_t)d * d;
+    const double* q = h->hostm.data();
+    const double *A = q, *a = q + dd, *Q = q + dd + d, *H = q + 2 * dd + d, hh = q[2 * dd + 2 * d], R = q[2 * dd + 2 * d + 1];
+    constexpr int kMax = 4096;
+    std::vector<double> m(h->x0m), P(dd), Pn(dd), t1(dd), mn(d), tab_m, tab_v;
+    for (int i = 0; i < d; ++i)
+        for (int j = 0; j < d; ++j) P[i * d + j] = h->x0P[(i < j ? i : j) + (size_t)(i < j ? j : i) * d];      // Symmetric(x0.P), row-major
+    double pm2 = 0.0, pv2 = 0.0;
+    bool settled = false;
+    for (int t = 0; t < kMax && (int64_t)t < h->T; ++t) {
+        for (int i = 0; i < d; ++i) {
+            double v = a[i];
+            for (int k = 0; k < d; ++k) v += A[i + k * d] * m[k];
+            mn[i] = v;
+            for (int j = 0; j < d; ++j) {
+                double w = 0.0;
+                for (int k = 0; k < d; ++k) w += A[i + k * d] * P[(k <= j ? k * d + j : j * d + k)];
+                t1[i * d + j] = w;
+            }
+        }
+        for (int i = 0; i < d; ++i)
+            for (int j = 0; j < d; ++j) {
+                double w = 0.0;
+                for (int k = 0; k < d; ++k) w += t1[i * d + k] * A[j + k * d];
+                Pn[i * d + j] = w + Q[(i < j ? i : j) + (size_t)(i < j ? j : i) * d];
+            }
+        // Forward: the emission of the PREDICTED state (lgssm.jl:99-103); Reverse: of the state before the transition (:111-115)
+        const std::vector<double>&mE = h->ordering == 0 ? mn : m, &PE = h->ordering == 0 ? Pn : P;
+        double mu = hh, va = R;
+        for (int i = 0; i < d; ++i) {
+            mu += H[i] * mE[i];
+            double w = 0.0;
+            for (int k = 0; k < d; ++k) w += H[k] * PE[(k <= i ? k * d + i : i * d + k)];
+            va += w * H[i];
+        }
+        tab_m.push_back(mu);
+        tab_v.push_back(va);
+        bool moved = false;
+        for (int i = 0; i < d; ++i) {
+            moved = moved || std::fabs(mn[i] - m[i]) > 4.5e-16 * (std::fabs(mn[i]) + std::sqrt(std::fabs(Pn[i * d + i])));
+            for (int j = 0; j < d; ++j) moved = moved || std::fabs(Pn[i * d + j] - P[i * d + j]) > 4.5e-16 * 0.5 * (std::fabs(Pn[i * d + i]) + std::fabs(Pn[j * d + j]));
+        }
+        const bool cyc = t >= 2 && mu == pm2 && va == pv2 && !moved;
+        pm2 = tab_m.size() >= 2 ? tab_m[tab_m.size() - 2] : 0.0;
+        pv2 = tab_v.size() >= 2 ? tab_v[tab_v.size() - 2] : 0.0;
+        m = mn;
+        P = Pn;
+        if (!moved || cyc) {
+            settled = true;
+            break;
+        }
+    }
+    if (!settled && (int64_t)tab_m.size() < h->T) return TGP_OK;      // (does not settle within the table: the general engine)
+    const int n = (int)tab_m.size();
+    std::vector<double> tab(2 * (size_t)n);
+    std::memcpy(tab.data(), tab_m.data(), sizeof(double) * n);
+    std::memcpy(tab.data() + n, tab_v.data(), sizeof(double) * n);
+    HIPCHK(h->balt.ensure(tab.size() * sizeof(double)));
+    HIPCHK(hipMemcpyAsync(h->balt.p, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));      // (tab is a temporary)
+    {
+        LaunchScope ls(h, "k_fill_marginals<lti>");
+        const long long want = (h->T + 255) / 256;
+        const unsigned blocks = (unsigned)(want < 4096 ? want : 4096);
+        hipLaunchKernelGGL(k_fill_marginals, dim3(blocks), dim3(256), 0, h->stream, dm, dv, (long long)h->T, static_cast<const double*>(h->balt.p), n, h->ordering);
+    }
+    *served = true;
+    return TGP_OK;
+}
+
 int tgp_marginals(tgp_handle* h, uint32_t flags, double* mean_out, double* var_out) {
-    TRY(check_ready(h));
+    TRY(check_ready(h, /*general=*/false));
     if (!mean_out || !var_out) return h->fail(TGP_EINVAL, "null output");
     const bool odev = (flags & TGP_OUT_DEVICE) != 0;
     const size_t nT = (size_t)h->T * h->p * sizeof(double);   // one value per (time step, observation)
+    if (!h->is_dense) {
+        double *dm0 = nullptr, *dv0 = nullptr;
+        TRY(stage_out(h, h->bo1, mean_out, nT, odev, &dm0));
+        TRY(stage_out(h, h->bo2, var_out, nT, odev, &dv0));
+        bool served = false;
+        TRY(lti_marginals(h, dm0, dv0, &served));
+        if (served) {
+            TRY(copy_back(h, mean_out, dm0, nT, odev));
+            TRY(copy_back(h, var_out, dv0, nT, odev));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            resolve_profile(h);
+            return TGP_OK;
+        }
+        resolve_table(h);
+    }
     CallTimer tm(h);
     tm.inputs_done();
     double *dm = nullptr, *dv = nullptr;

@@ -229,10 +229,25 @@ __device__ void head_backward(const KArgs<D>& ka, const double* __restrict__ sR,
     for (int hi = nhs; hi > 0; hi -= CH) {
         const int lo = hi - CH > 0 ? hi - CH : 0, cnt = hi - lo;
         lds_sync();
-        for (int idx = lane; idx < cnt * ROW; idx += 64) {
-            const int sidx = idx / ROW, e = idx % ROW;
-            const int tt = lo + sidx < n0 ? lo + sidx : n0;
-            sTab[idx] = e < DD ? tb[ka.to.G + (size_t)tt * DD + e] : tb[ka.to.c + tt * D + (e - DD)];
+        {
+            // the chunk's rows [G_t | c_t] are contiguous in the packed tables: 16-byte pieces, four loads in flight per lane and round
+            // (a load-store-load chain would cost an L2 round trip per kilobyte; more in flight would cost the kernel's occupancy)
+            const v2d* __restrict__ src = reinterpret_cast<const v2d*>(tb + ka.to.G + (size_t)lo * ROW);
+            v2d* __restrict__ dst = reinterpret_cast<v2d*>(sTab);
+            const int n2 = cnt * ROW / 2;
+            for (int base = 0; base < n2; base += 4 * 64) {
+                v2d b[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int idx = base + q * 64 + lane;
+                    b[q] = src[idx < n2 ? idx : n2 - 1];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int idx = base + q * 64 + lane;
+                    if (idx < n2) dst[idx] = b[q];
+                }
+            }
         }
         const int t = lo + lane, ti = t < n0 ? t : n0;
         const double cy = (lane < cnt) ? ka.y[t] : 0.0, crs = tb[ka.to.rS + ti], cr = (lane < cnt) ? sR[t] : 0.0;
@@ -287,12 +302,13 @@ __device__ void head_backward(const KArgs<D>& ka, const double* __restrict__ sR,
 // per step -- at the price of 32 more registers).
 // =================================================================================================================================
 template <int D, int NW, int SUB>
-__global__ __launch_bounds__(NW * 64) void k_steady_one(const KArgs<D> ka) {
+__global__ __launch_bounds__(NW * 64, (NW == 8 ? 2 : 1)) void k_steady_one(const KArgs<D> ka) {
     static_assert(SUB == kWJ, "eight steps per lane (sixteen were built and measured in round 4: the 32 more registers cost more occupancy than the halved scans save)");
     constexpr int TILE = 64 * SUB;
     constexpr int CHB = D <= 4 ? 64 : (D <= 6 ? 32 : 16);      // steps of the head's backward recursion staged in LDS at a time (~10 KB)
     __shared__ double sF[NW][D], sB[NW][D], sHead[D], sAcc[NW];
-    __shared__ double sR[tgp_plan::kHeadMax], sTab[CHB * (D * D + D)];
+    __shared__ double sR[tgp_plan::kHeadMax];
+    __shared__ __attribute__((aligned(16))) double sTab[CHB * (D * D + D)];
     __shared__ __attribute__((aligned(16))) double sOut[NW][2 * Row<SUB>::slots];
     // M^(SUB l) (forward) and Mg^(SUB (63 - l)) (backward) for the lanes l of a tile: what carries a tile's start state / right-hand input to
     // its lanes.  The same for every wave: the last two waves of the workgroup build them (by the bits of the lane number) for all
@@ -791,8 +807,9 @@ static void layout_tables(Engine* e) {
     to.db = take(n * d);
     to.iS = take(n);
     to.rS = take(n);
-    to.G = take(n * dd);
-    to.c = take(n * d);
+    off += off & 1;                                   // (16-byte pieces)
+    to.G = take(e->md.nhs * (dd + d));                // rows [G_t | c_t], one per head step t < nhs (steps behind n0: the stationary row)
+    to.c = to.G;
     to.vb = take(n);
     to.tvb = take(0);
 }
@@ -810,8 +827,11 @@ static bool ship_tables(Engine* e, int why) {
     std::memcpy(q + to.db, tb.kA, sizeof(double) * n * d);
     std::memcpy(q + to.iS, tb.iS, sizeof(double) * n);
     std::memcpy(q + to.rS, tb.rS, sizeof(double) * n);
-    std::memcpy(q + to.G, tb.G, sizeof(double) * n * dd);
-    std::memcpy(q + to.c, tb.c, sizeof(double) * n * d);
+    for (int t = 0; t < md.nhs; ++t) {
+        const int tt = t < md.n0 ? t : md.n0;
+        std::memcpy(q + to.G + (size_t)t * (dd + d), tb.G + (size_t)tt * dd, sizeof(double) * dd);
+        std::memcpy(q + to.G + (size_t)t * (dd + d) + dd, tb.c + (size_t)tt * d, sizeof(double) * d);
+    }
     std::memcpy(q + to.vb, tb.vb, sizeof(double) * n);
     const int n1 = md.n1 > 0 ? md.n1 : 0;
     std::memcpy(q + to.tvb, tb.tvb, sizeof(double) * n1);
@@ -827,7 +847,7 @@ bool plan(Engine* e, const tgp_plan::ModelHost& m, long long T) {
     if (!e->tab) {
         e->tab = new HeadTables();
         // the layout of ship_tables at its largest: d = 8, n0 = kN0Max, n1 = kTailMax
-        e->flat_cap = (size_t)(tgp_plan::kN0Max + 1) * (64 + 2 * 8 + 3) + tgp_plan::kTailMax + 64 + 2 * 8 + 8;
+        e->flat_cap = (size_t)tgp_plan::kHeadMax * (64 + 8) + (size_t)(tgp_plan::kN0Max + 1) * (8 + 3) + tgp_plan::kTailMax + 64 + 2 * 8 + 8;
         e->flat_cap = (e->flat_cap + 1) & ~(size_t)1;
         if (hipHostMalloc(reinterpret_cast<void**>(&e->hflat), (e->flat_cap + 2) * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess ||
             hipMalloc(reinterpret_cast<void**>(&e->dflat), (e->flat_cap + 2) * sizeof(double)) != hipSuccess) {

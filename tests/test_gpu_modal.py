@@ -178,3 +178,29 @@ def test_nan_observation_gives_nan(tgp):
     out = ctypes.c_double()
     rc = hd.lib.tgp_logpdf(hd.h, ctypes.c_void_p(yd.data_ptr()), None, tgp._lib.IN_DEVICE, ctypes.byref(out))
     assert rc != 0 or np.isnan(out.value)
+
+
+@pytest.mark.parametrize("ordering", ["F", "R"])
+@pytest.mark.parametrize("d", [1, 3, 6, 8])
+def test_prior_marginals_of_an_lti_model_are_a_head_and_a_constant(tgp, d, ordering):
+    """tgp_marginals of an LTI model (lgssm.jl:99-115): the host runs the data-free recursion to its fixed point, the device writes the head and
+    the constant (k_fill_marginals).  Random LTI models (x0 is NOT the stationary distribution: a real head), both orderings; a GP prior."""
+    from oracle import lgssm_ref as ref
+    from tests import _util as U
+    rng = np.random.default_rng(100 * d + (ordering == "R"))
+    T = 3000
+    model = U.random_lgssm(rng, False, d, T, ordering)
+    tr = tgp.GaussMarkovModel(tgp.Forward if ordering == "F" else tgp.Reverse, model["A"], model["a"], model["Q"], tgp.Gaussian(model["x0m"], model["x0P"]))
+    dm = tgp.LGSSM(tr, tgp.ScalarOutputLGC(model["H"], np.atleast_1d(model["h"]), np.atleast_1d(model["R"])), T=T)
+    (gm, gv), names = kernels_of(tgp, dm, lambda: tgp.marginals(dm))
+    assert names == {"k_fill_marginals<lti>"}, names
+    qm, qv = ref.marginals(model)
+    np.testing.assert_allclose(gm, qm, rtol=1e-10, atol=1e-10)
+    np.testing.assert_allclose(gv, qv, rtol=1e-10, atol=1e-10)
+    if ordering == "F" and d in (3, 6):
+        gp = oc.build_lgssm(KERNELS[d], ("regular", 0.0, 0.1, 50_000), 0.1)
+        dg = device_model(tgp, gp)
+        (pm, pv), names = kernels_of(tgp, dg, lambda: tgp.marginals(dg))
+        assert names == {"k_fill_marginals<lti>"}, names
+        rm, rv = ref.marginals(dict(gp, T=2000))
+        assert np.max(np.abs(pm[:2000] - rm)) <= 1e-10 and np.max(np.abs(pv[:2000] - rv)) <= 1e-10 and np.ptp(pv[100:]) <= 1e-12
