@@ -236,7 +236,7 @@ int tgp_steady_plan(int d, const double* A, const double* a, const double* Q, co
  *   computes the same answer without communication), *halo = the number of neighbour observations a segment needs on each side.
  * tgp_segment_logpdf_and_posterior_marginals: the handle is bound to the segment's model (T = seg_hi - seg_lo, every block shared, the
  *   SERIES' x0); y_seg [T] the segment's observations, y_left [halo] those in front of it (NULL for the first segment), y_right [halo] those
- *   behind it (NULL for the last; fewer than halo exist only if the series ends there: pass what exists) -- device pointers (TGP_IN_DEVICE).
+ *   behind it (NULL for the last) -- ALWAYS device pointers (TGP_IN_DEVICE says where Rnew lives, TGP_OUT_DEVICE where mean / var go).
  *   mean_out / var_out [T] (NULL: logpdf only) as in tgp_posterior_marginals. *lml_share: this segment's share; the shares of all segments
  *   add up to logpdf(model, y) of lgssm.jl:147-165. A NaN observation makes the share NaN (callers fall back to the general protocol). */
 int tgp_segment_plan(tgp_handle* h, int64_t T_total, int nseg, const int64_t* bounds, int32_t* applies, int32_t* halo);

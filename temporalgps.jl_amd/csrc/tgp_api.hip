@@ -1814,7 +1814,6 @@ int tgp_segment_logpdf_and_posterior_marginals(tgp_handle* h, int64_t T_total, i
     TRY(check_ready(h, /*general=*/false));
     tgp_plan::ModelHost mh;
     if (!modal_host_model(h, mh)) return h->fail(TGP_EUNSUPPORTED, "tgp_segment_*: not a model of the one-launch path (ask tgp_segment_plan first)");
-    if (!(flags & TGP_IN_DEVICE)) return h->fail(TGP_EUNSUPPORTED, "tgp_segment_*: device inputs only");
     if (h->T != seg_hi - seg_lo || seg_lo < 0 || seg_hi > T_total || !y_seg) return h->fail(TGP_EINVAL, "tgp_segment_*: the bound model has not the segment's length");
     if ((mean_out != nullptr) != (var_out != nullptr) || (mean_out && !Rnew)) return h->fail(TGP_EINVAL, "tgp_segment_*: mean, var and Rnew go together");
     if (!h->modal) h->modal = tgp_modal::create();
@@ -1827,7 +1826,7 @@ int tgp_segment_logpdf_and_posterior_marginals(tgp_handle* h, int64_t T_total, i
     const size_t nT = (size_t)h->T * sizeof(double);
     CallTimer tm(h, /*clear=*/false);
     const void* pR = nullptr;
-    if (mean_out) TRY(stage_in(h, h->bRnew, Rnew, rshared ? sizeof(double) : nT, true, &pR));
+    if (mean_out) TRY(stage_in(h, h->bRnew, Rnew, rshared ? sizeof(double) : nT, (flags & TGP_IN_DEVICE) != 0, &pR));
     h->mv.y = y_seg;
     h->mv.missing = nullptr;
     tm.inputs_done();

@@ -112,6 +112,9 @@ struct tgp_multi {
     std::vector<double*> slot[3], gath[3], stats;      // phase 0 / 1: the general engine's elements; 2: the stationary-gain engine's
     size_t slot_n[3] = {0, 0, 0};
     bool try_steady = false;
+    bool try_one = false;                  // the one-launch path's time segments (tgp_segment_*): tried first
+    std::vector<double*> ybuf;             // per rank, on its device: the neighbours' halo observations (+ the segment itself for host inputs)
+    std::vector<size_t> ybuf_n;
     std::vector<int> served;
     std::vector<hipEvent_t> ev_slot, ev_done;
     double* host_stats = nullptr;      // pinned, [W][4]
@@ -254,6 +257,69 @@ int steady_call(tgp_multi* m, const double* const* y, const double* const* Rnew,
     return TGP_OK;
 }
 
+// One call on the one-launch path's time segments (tgp_segment_*, round 4): a rank needs its neighbours' `halo` observations next to the
+// boundary and nothing else -- no exchange of filter elements, no phase boundary between the ranks; the shares of the log marginal
+// likelihood are added on the host.  TGP_OK with *served: done.  TGP_OK without: the plan declines the model / the segments (the same verdict
+// whatever the data), or the data holds a NaN -- the caller goes on to the older protocols.
+int one_launch_call(tgp_multi* m, const double* const* y, const double* const* Rnew, uint32_t flags, bool post, double* const* mean_out,
+                    double* const* var_out, double* lml_out, bool* served) {
+    *served = false;
+    std::vector<int64_t> b((size_t)m->W + 1);
+    for (int r = 0; r <= m->W; ++r) b[r] = seg_lo(m->T, m->W, r);
+    int32_t ok = 0, halo = 0;
+    (void)hipSetDevice(m->dev[0]);
+    int rc = tgp_segment_plan(m->h[0], m->T, m->W, b.data(), &ok, &halo);
+    if (rc != TGP_OK) return m->fail(rc, std::string("rank 0: ") + tgp_last_error(m->h[0]));
+    if (!ok) {
+        m->try_one = false;          // (a property of the bound model and the series' length)
+        return TGP_OK;
+    }
+    const bool idev = (flags & TGP_IN_DEVICE) != 0;
+    rc = run_all(m, [&](int r) {
+        const int64_t lo = b[r], hi = b[r + 1], Ts = hi - lo;
+        const size_t need = (size_t)2 * halo + (idev ? 0 : (size_t)Ts);
+        if (m->ybuf_n[r] < need) {
+            if (m->ybuf[r]) (void)hipFree(m->ybuf[r]);
+            m->ybuf[r] = nullptr;
+            m->ybuf_n[r] = 0;
+            if (hipMalloc(reinterpret_cast<void**>(&m->ybuf[r]), need * sizeof(double)) != hipSuccess) return (int)TGP_EHIP;
+            m->ybuf_n[r] = need;
+        }
+        double* buf = m->ybuf[r];
+        const double *yseg = nullptr, *yl = nullptr, *yr = nullptr;
+        hipError_t e = hipSuccess;
+        const size_t hb = (size_t)halo * sizeof(double);
+        if (!idev) {         // [left halo | segment | right halo] from the ranks' host arrays
+            if (r > 0) e = hipMemcpyAsync(buf, y[r - 1] + (b[r] - b[r - 1] - halo), hb, hipMemcpyHostToDevice, m->st[r]);
+            if (e == hipSuccess) e = hipMemcpyAsync(buf + halo, y[r], (size_t)Ts * sizeof(double), hipMemcpyHostToDevice, m->st[r]);
+            if (e == hipSuccess && r + 1 < m->W) e = hipMemcpyAsync(buf + halo + Ts, y[r + 1], hb, hipMemcpyHostToDevice, m->st[r]);
+            yseg = buf + halo;
+            yl = r > 0 ? buf : nullptr;
+            yr = r + 1 < m->W ? buf + halo + Ts : nullptr;
+        } else {             // the neighbours' edges come over the fabric (or from the same device)
+            auto pull = [&](double* dst, const double* src, int q) {
+                return m->dev[q] == m->dev[r] ? hipMemcpyAsync(dst, src, hb, hipMemcpyDeviceToDevice, m->st[r])
+                                              : hipMemcpyPeerAsync(dst, m->dev[r], src, m->dev[q], hb, m->st[r]);
+            };
+            if (r > 0) e = pull(buf, y[r - 1] + (b[r] - b[r - 1] - halo), r - 1);
+            if (e == hipSuccess && r + 1 < m->W) e = pull(buf + halo, y[r + 1], r + 1);
+            yseg = y[r];
+            yl = r > 0 ? buf : nullptr;
+            yr = r + 1 < m->W ? buf + halo : nullptr;
+        }
+        if (e != hipSuccess) return (int)TGP_EHIP;
+        return tgp_segment_logpdf_and_posterior_marginals(m->h[r], m->T, lo, hi, yseg, yl, yr, post ? Rnew[r] : nullptr, flags, post ? mean_out[r] : nullptr,
+                                                          post ? var_out[r] : nullptr, &m->lml[r]);
+    });
+    if (rc != TGP_OK) return rc;
+    double sum = 0.0;
+    for (int r = 0; r < m->W; ++r) sum += m->lml[r];
+    if (!(sum == sum) || sum - sum != 0.0) return TGP_OK;          // a NaN / infinite total (an observation that is not a number): the general protocol
+    if (lml_out) *lml_out = sum;
+    *served = true;
+    return TGP_OK;
+}
+
 int check_call(tgp_multi* m, const void* y) {
     if (!m) return TGP_EINVAL;
     m->err.clear();
@@ -360,6 +426,7 @@ int tgp_destroy_multi(tgp_multi* m) {
             if (r < (int)m->gath[ph].size() && m->gath[ph][r]) (void)hipFree(m->gath[ph][r]);
         }
         if (r < (int)m->stats.size() && m->stats[r]) (void)hipFree(m->stats[r]);
+        if (r < (int)m->ybuf.size() && m->ybuf[r]) (void)hipFree(m->ybuf[r]);
         if (r < (int)m->ev_slot.size() && m->ev_slot[r]) (void)hipEventDestroy(m->ev_slot[r]);
         if (r < (int)m->ev_done.size() && m->ev_done[r]) (void)hipEventDestroy(m->ev_done[r]);
         if (m->h[r]) (void)tgp_destroy(m->h[r]);
@@ -425,6 +492,9 @@ int tgp_multi_model_set(tgp_multi* m, int64_t T, int d, int p, int ordering, uin
     m->stats.resize(m->W, nullptr);
     m->served.assign(m->W, 0);
     m->try_steady = tgp_shard_steady_slot_size(d) > 0 && p == 1;      // (tgp_shard_steady_begin decides per call whether the model is one of the engine's)
+    m->try_one = m->try_steady;                                       // (tgp_segment_plan decides)
+    m->ybuf.resize(m->W, nullptr);
+    m->ybuf_n.resize(m->W, 0);
     if (d != m->d) {
         m->slot_n[0] = (size_t)tgp_shard_slot_size(0, d);
         m->slot_n[1] = (size_t)tgp_shard_slot_size(1, d);
@@ -453,6 +523,12 @@ int tgp_multi_logpdf(tgp_multi* m, const double* const* y, const uint8_t* const*
     int rc = check_call(m, y);
     if (rc != TGP_OK) return rc;
     if (!out) return m->fail(TGP_EINVAL, "out is NULL");
+    if (m->try_one && !missing) {
+        bool served = false;
+        rc = one_launch_call(m, y, nullptr, flags, false, nullptr, nullptr, out, &served);
+        if (rc != TGP_OK || served) return rc;
+        m->err.clear();
+    }
     if (m->try_steady && !missing) {
         bool served = false;
         rc = steady_call(m, y, nullptr, flags, false, nullptr, nullptr, &served);
@@ -492,6 +568,12 @@ static int multi_posterior(tgp_multi* m, const double* const* y, const uint8_t* 
     int rc = check_call(m, y);
     if (rc != TGP_OK) return rc;
     if (!Rnew || !mean_out || !var_out) return m->fail(TGP_EINVAL, "Rnew / mean_out / var_out is NULL (expected arrays of one pointer per rank)");
+    if (m->try_one && !missing) {
+        bool served = false;
+        rc = one_launch_call(m, y, Rnew, flags, true, mean_out, var_out, lml_out, &served);
+        if (rc != TGP_OK || served) return rc;
+        m->err.clear();
+    }
     if (m->try_steady && !missing) {
         bool served = false;
         rc = steady_call(m, y, Rnew, flags, true, mean_out, var_out, &served);

@@ -172,8 +172,9 @@ def _kernels_of_rank(ms, tgp, rank, fn):
     return out, set(ms.mh.rank_profile(rank))
 
 
+@pytest.mark.parametrize("steady_opt", [2, 3])
 @pytest.mark.parametrize("d", [1, 2, 3, 4, 5, 6, 7, 8])
-def test_lti_shards_run_on_the_stationary_gain_engine(d):
+def test_lti_shards_run_on_the_stationary_gain_engine(d, steady_opt):
     """An LTI model's shards take the stationary-gain engine's two-half calls (ONE all-gather; head on rank 0 only, tail on the last
     rank only, segments aligned to 512-step tiles): same results as the oracle, and the kernels that ran say which engine it was."""
     import temporalgps_jl_amd as tgp
@@ -182,16 +183,27 @@ def test_lti_shards_run_on_the_stationary_gain_engine(d):
     model = U.random_lgssm(rng, False, d, T)
     y = ref.rand(model, rng.standard_normal((T, d)), rng.standard_normal(T), rng.standard_normal(d))
     ms = tgp.MultiLGSSM(_dev_model(tgp, model), devices=[0] * ndev)
+    ms.mh.set_option(tgp._lib.OPT_STEADY, steady_opt)      # 3 (default): the one-launch path's segments first; 2: the five-launch engine's shards
     assert all(lo % 512 == 0 for lo, _ in ms.bounds)
     lp_ref = sk.logpdf(model, y)
     Rnew = rng.random(T) + 0.05
     pm, pv = sk.posterior_marginals(model, y, Rnew)
+    one = None
     for rank in (0, 1, 2):
         lp, names = _kernels_of_rank(ms, tgp, rank, lambda: ms.logpdf(y))
-        assert "k_steady_shard_fold" in names and not any(n.startswith("k_reduce_filter") for n in names), names
+        assert not any(n.startswith("k_reduce_filter") for n in names), names
+        if one is None:
+            one = all(n.startswith("k_steady_one") for n in names)
+        if one:      # ONE kernel per rank, nothing of the shard protocol (the plan's verdict is the same for every rank)
+            assert steady_opt == 3 and names and all(n.startswith("k_steady_one") for n in names), names
+        else:
+            assert "k_steady_shard_fold" in names, names
         assert abs(lp - lp_ref) <= LOGPDF_RTOL * abs(lp_ref)
     (lp, mean, var), names = _kernels_of_rank(ms, tgp, 1, lambda: ms.logpdf_and_posterior_marginals(y, Rnew))
-    assert "k_steady_apply<posterior>" in names and "k_steady_shard_pack" in names, names
+    if one:
+        assert all(n.startswith("k_steady_one") and "posterior" in n for n in names), names
+    else:
+        assert "k_steady_apply<posterior>" in names and "k_steady_shard_pack" in names, names
     assert abs(lp - lp_ref) <= LOGPDF_RTOL * abs(lp_ref)
     assert np.max(np.abs(mean - pm)) <= MARGINAL_ATOL and np.max(np.abs(var - pv)) <= MARGINAL_ATOL
     mean1, var1 = ms.posterior_marginals(y, np.array([0.3]))
@@ -238,6 +250,7 @@ def test_slowly_mixing_lti_shards_take_the_scanned_carries(dt, ndev):
     rng = np.random.default_rng(71)
     y = sk.rand(model, rng.standard_normal((T, 3)), rng.standard_normal(T), rng.standard_normal(3))
     ms = tgp.MultiLGSSM(_dev_model(tgp, model), devices=[0] * ndev)
+    ms.mh.set_option(tgp._lib.OPT_STEADY, 2)          # (the five-launch engine's shards are what is under test; the one-launch path serves dt = 0.01 too)
     (lp, mean, var), names = _kernels_of_rank(ms, tgp, ndev - 1, lambda: ms.logpdf_and_posterior_marginals(y, np.array([0.02])))
     assert "k_steady_shard_fold" in names and not any(n.startswith("k_reduce_filter") for n in names), names
     lp_ref = sk.logpdf(model, y)
