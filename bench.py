@@ -757,7 +757,10 @@ def main():
             roof = dict(bound="hbm", kernel=kname, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
                         traffic=traffic, traffic_unit="bytes per launch (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, profiles/)",
                         algorithmic_bytes=per_unit * Tseg, avg_kernel_ms=avg_ms, algorithmic_bytes_per_step=per_unit,
-                        note=(("stationary-gain engine (DESIGN 3.11): the output pass reads y (8 B/step) and writes mean, var (16 B/step), nothing else "
+                        note=(("stationary-gain engine, one-launch form (DESIGN 3.13): ONE kernel per call reads y once (8 B/step, plus the workgroups' "
+                               "halos out of L2) and writes mean, var (16 B/step); nothing else of size T moves, no other kernel runs "
+                               "(`traffic` = PMC bytes of this kernel)" if kname.startswith("k_steady_one") else
+                               "stationary-gain engine (DESIGN 3.11): the output pass reads y (8 B/step) and writes mean, var (16 B/step), nothing else "
                                "of size T moves; pass 1 reads y once more (`traffic` = PMC bytes of this kernel alone)" if kname.startswith("k_steady") else
                                "LTI (Fill) layout, general engine: streams only y in / (mean,var) out (plus the smoother scratch: `traffic`): the launch "
                                "is not HBM bound -- one wave per SIMD, it lasts as long as the dependent fp64 chain of its slowest wave (DESIGN 3.10)")
@@ -777,8 +780,9 @@ def main():
                         stationary_covariance_steps=dict(
                             mean_only=int(st_fast.value), total=int(st_total.value),
                             note="steps served with the stationary gains: every step behind the head of n0 steps over which the filter covariance "
-                                 "is iterated until it no longer changes (k_steady_setup, inside every timed call; nothing is carried over between "
-                                 "calls). `with_general_engine` / `with_full_steps`: the same steps on the general engine"),
+                                 "is iterated until it no longer changes (on the host, inside every timed call: tgp_steady_plan.hpp; nothing is carried "
+                                 "over between calls). `with_five_launch_engine`: round 3's form of the same engine; `with_general_engine` / "
+                                 "`with_full_steps`: the same steps on the general engine"),
                         pass1=("shared matrix parts (TGP_OPT_SHARED_PARTS): the observation-independent half of the chunk recursion is tabulated "
                                "once per bound model -- on a side stream, launched by the second call, 1.4 ms at d = 3 -- and reused by later "
                                "calls on the same model; the warm-up steps bind and warm the model, the timed steps reuse the table"
