@@ -1877,7 +1877,7 @@ int tgp_steady_plan(int d, const double* A, const double* a, const double* Q, co
     tgp_plan::ModelHost mh;
     mh.d = d;
     mh.A = A; mh.a = a; mh.Q = Q; mh.H = H; mh.hh = hh; mh.R = R; mh.x0m = x0m; mh.x0P = x0P;
-    const tgp_plan::Info in = tgp_plan::build_any(mh, T, md, tab);
+    const tgp_plan::Info in = tgp_modal::plan_only(mh, T, md, tab);
     info_i[0] = in.why; info_i[1] = in.n0; info_i[2] = in.n1; info_i[3] = in.why == 0 ? md.nhs : 0; info_i[4] = in.halo; info_i[5] = in.why == 0 ? md.npair : 0;
     {
         int nw = 8, sub = 8;

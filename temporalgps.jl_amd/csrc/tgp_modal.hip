@@ -302,7 +302,7 @@ __device__ void head_backward(const KArgs<D>& ka, const double* __restrict__ sR,
 // per step -- at the price of 32 more registers).
 // =================================================================================================================================
 template <int D, int NW, int SUB>
-__global__ __launch_bounds__(NW * 64, (NW == 8 ? 2 : 1)) void k_steady_one(const KArgs<D> ka) {
+__global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void k_steady_one(const KArgs<D> ka) {
     static_assert(SUB == kWJ, "eight steps per lane (sixteen were built and measured in round 4: the 32 more registers cost more occupancy than the halved scans save)");
     constexpr int TILE = 64 * SUB;
     constexpr int CHB = D <= 4 ? 64 : (D <= 6 ? 32 : 16);      // steps of the head's backward recursion staged in LDS at a time (~10 KB)
@@ -783,6 +783,22 @@ void choose_geometry(int d, int halo, int* nw, int* sub) {
     }
 }
 
+// This translation unit's host code is compiled for AVX2 + FMA (Makefile: the plan's small matrix products vectorise 4-wide -- an 8 x 8
+// product 36 ns instead of 150); a host without them gets the five-launch engine.
+static bool host_cpu_ok() {
+    static const bool ok = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma");
+    return ok;
+}
+
+tgp_plan::Info plan_only(const tgp_plan::ModelHost& m, long long T, tgp_plan::Modal& md, tgp_plan::HeadTables& tab) {
+    if (!host_cpu_ok()) {
+        tgp_plan::Info in;
+        in.why = tgp_plan::kEigFail;
+        return in;
+    }
+    return tgp_plan::build_any(m, T, md, tab);
+}
+
 static bool overlap_tables() {      // TGP_MODAL_OVERLAP=0: the whole plan before the launch (A/B runs)
     static const bool on = [] {
         const char* v = std::getenv("TGP_MODAL_OVERLAP");
@@ -844,6 +860,11 @@ static bool ship_tables(Engine* e, int why) {
 
 bool plan(Engine* e, const tgp_plan::ModelHost& m, long long T) {
     e->began = false;
+    if (!host_cpu_ok()) {
+        e->info = tgp_plan::Info{};
+        e->info.why = tgp_plan::kEigFail;
+        return false;
+    }
     if (!e->tab) {
         e->tab = new HeadTables();
         // the layout of ship_tables at its largest: d = 8, n0 = kN0Max, n1 = kTailMax

@@ -41,6 +41,8 @@ bool complete(Engine*, long long T);
 double finish(const Engine*, long long T);
 // ... or the launch's share of the quadratic form (a segment): lml = -(T log 2pi + LS + (T - n0) logS + sum head_quad + iS sum ssq) / 2
 void finish_parts(const Engine*, double* ssq, double* head_quad);
+// the whole plan (both halves) without an engine: the pure host function tgp_steady_plan of the ABI
+tgp_plan::Info plan_only(const tgp_plan::ModelHost&, long long T, tgp_plan::Modal&, tgp_plan::HeadTables&);
 const tgp_plan::Info& last_plan(const Engine*);
 const tgp_plan::Modal& last_modal(const Engine*);
 // the kernel variant plan() chose for the call (profile label)

@@ -372,58 +372,89 @@ inline bool modal_form(int n, const double* M, double* re, double* im, double* V
 }
 
 // reverse-time dynamics of one step (lgssm.jl:231-238): U'U = Symmetric(Pp) + 1e-10 I, G = (U \ (U' \ (A Pf)))', L = Pf - (U Gt)'(U Gt)
+// C = A B, rows of C as sums of rows of B (the inner loop runs over a contiguous row: the host compiler vectorises it)
+template <int D>
+inline void mm(const double (&A)[D][D], const double (&B)[D][D], double (&C)[D][D]) {
+    for (int i = 0; i < D; ++i) {
+        double row[D];
+        for (int j = 0; j < D; ++j) row[j] = 0.0;
+        for (int k = 0; k < D; ++k) {
+            const double a = A[i][k];
+            for (int j = 0; j < D; ++j) row[j] += a * B[k][j];
+        }
+        for (int j = 0; j < D; ++j) C[i][j] = row[j];
+    }
+}
+template <int D>
+inline void transpose(const double (&A)[D][D], double (&At)[D][D]) {
+    for (int i = 0; i < D; ++i)
+        for (int j = 0; j < D; ++j) At[j][i] = A[i][j];
+}
+template <int D>
+inline void mirror_upper(double (&P)[D][D]) {      // Symmetric(P): the upper triangle is the matrix
+    for (int i = 0; i < D; ++i)
+        for (int j = 0; j < i; ++j) P[i][j] = P[j][i];
+}
+
 template <int D>
 inline bool invert_dynamics(const double (&A)[D][D], const double (&Pf)[D][D], const double (&Pp)[D][D], double (&G)[D][D], double (&L)[D][D]) {
+    // (every loop below runs over whole rows: U' U = Symmetric(Pp) + 1e-10 I by rows, the two triangular solves as row eliminations)
     double U[D][D], ru[D];      // (reciprocals of the pivots: a division costs as much as a 3 x 3 product here)
     bool ok = true;
     for (int i = 0; i < D; ++i) {
-        double s = Pp[i][i] + 1e-10;
-        for (int k = 0; k < i; ++k) s -= U[k][i] * U[k][i];
+        double row[D];
+        for (int j = 0; j < D; ++j) row[j] = (j >= i) ? Pp[i][j] : 0.0;
+        row[i] += 1e-10;
+        for (int k = 0; k < i; ++k) {
+            const double f = U[k][i];
+            for (int j = 0; j < D; ++j) row[j] -= f * U[k][j];      // (U[k][j] = 0 for j < k <= i: the lower part stays zero)
+        }
+        const double s = row[i];
         ok = ok && (s > 0.0);
         const double u = std::sqrt(s);
         ru[i] = 1.0 / u;
+        for (int j = 0; j < D; ++j) U[i][j] = (j > i) ? row[j] * ru[i] : 0.0;
         U[i][i] = u;
-        for (int j = i + 1; j < D; ++j) {
-            double v = Pp[i][j];
-            for (int k = 0; k < i; ++k) v -= U[k][i] * U[k][j];
-            U[i][j] = v * ru[i];
-        }
-        for (int j = 0; j < i; ++j) U[i][j] = 0.0;
     }
     // M = A Pf (full Pf, as the reference), X = U' \ M, Gt = U \ X
     double X[D][D];
-    for (int i = 0; i < D; ++i)
-        for (int c = 0; c < D; ++c) {
-            double v = 0.0;
-            for (int k = 0; k < D; ++k) v = pfma(A[i][k], Pf[k][c], v);
-            X[i][c] = v;
+    mm<D>(A, Pf, X);
+    for (int i = 0; i < D; ++i) {
+        for (int k = 0; k < i; ++k) {
+            const double f = U[k][i];
+            for (int c = 0; c < D; ++c) X[i][c] -= f * X[k][c];
         }
-    for (int i = 0; i < D; ++i)
-        for (int c = 0; c < D; ++c) {
-            double v = X[i][c];
-            for (int k = 0; k < i; ++k) v -= U[k][i] * X[k][c];
-            X[i][c] = v * ru[i];
+        for (int c = 0; c < D; ++c) X[i][c] *= ru[i];
+    }
+    for (int i = D - 1; i >= 0; --i) {
+        for (int k = i + 1; k < D; ++k) {
+            const double f = U[i][k];
+            for (int c = 0; c < D; ++c) X[i][c] -= f * X[k][c];
         }
-    for (int i = D - 1; i >= 0; --i)
-        for (int c = 0; c < D; ++c) {
-            double v = X[i][c];
-            for (int k = i + 1; k < D; ++k) v -= U[i][k] * X[k][c];
-            X[i][c] = v * ru[i];
+        for (int c = 0; c < D; ++c) X[i][c] *= ru[i];
+    }
+    double W[D][D];      // U Gt
+    for (int i = 0; i < D; ++i) {
+        double row[D];
+        for (int c = 0; c < D; ++c) row[c] = 0.0;
+        for (int k = i; k < D; ++k) {
+            const double f = U[i][k];
+            for (int c = 0; c < D; ++c) row[c] += f * X[k][c];
         }
-    double W[D][D];
-    for (int i = 0; i < D; ++i)
-        for (int c = 0; c < D; ++c) {
-            double v = 0.0;
-            for (int k = i; k < D; ++k) v = pfma(U[i][k], X[k][c], v);
-            W[i][c] = v;
+        for (int c = 0; c < D; ++c) W[i][c] = row[c];
+    }
+    for (int i = 0; i < D; ++i) {      // L = Pf - W' W, G = Gt'
+        double row[D];
+        for (int j = 0; j < D; ++j) row[j] = 0.0;
+        for (int k = 0; k < D; ++k) {
+            const double f = W[k][i];
+            for (int j = 0; j < D; ++j) row[j] += f * W[k][j];
         }
-    for (int i = 0; i < D; ++i)
         for (int j = 0; j < D; ++j) {
-            G[i][j] = X[j][i];
-            double v = 0.0;
-            for (int k = 0; k < D; ++k) v = pfma(W[k][i], W[k][j], v);
-            L[i][j] = Pf[i][j] - v;
+            L[i][j] = Pf[i][j] - row[j];
+            G[j][i] = X[i][j];
         }
+    }
     return ok;
 }
 
@@ -441,19 +472,14 @@ inline double quad_sym(const double (&h)[D], const double (&P)[D][D]) {      // 
 // P <- G Symmetric(P) G' + L
 template <int D>
 inline void smooth_cov_step(const double (&G)[D][D], const double (&L)[D][D], const double (&P)[D][D], double (&out)[D][D]) {
-    double t1[D][D];
+    double Ps[D][D], Gt[D][D], t1[D][D];
     for (int i = 0; i < D; ++i)
-        for (int j = 0; j < D; ++j) {
-            double v = 0.0;
-            for (int k = 0; k < D; ++k) v = pfma(G[i][k], (k <= j ? P[k][j] : P[j][k]), v);
-            t1[i][j] = v;
-        }
+        for (int j = 0; j < D; ++j) Ps[i][j] = (i <= j) ? P[i][j] : P[j][i];
+    transpose<D>(G, Gt);
+    mm<D>(G, Ps, t1);
+    mm<D>(t1, Gt, out);
     for (int i = 0; i < D; ++i)
-        for (int j = 0; j < D; ++j) {
-            double v = 0.0;
-            for (int k = 0; k < D; ++k) v = pfma(t1[i][k], G[j][k], v);
-            out[i][j] = v + L[i][j];
-        }
+        for (int j = 0; j < D; ++j) out[i][j] += L[i][j];
 }
 
 // element-wise power of the block-diagonal form: (re, im) -> (re, im)^n by repeated squaring; the sign convention of `im` is preserved
@@ -520,20 +546,15 @@ inline Info build_core(const ModelHost& m, long long T, Modal& md, HeadTables& t
     int tc = -1, n0 = -1;
     double LS = 0.0, Sss = 1.0, kAss[D];
     bool bad = false;
+    double At[D][D];
+    transpose<D>(A, At);
+    mirror_upper<D>(P);
     for (int t = 0; t <= kN0Max; ++t) {
         double t1[D][D], pp[D][D], V[D];
+        mm<D>(A, P, t1);                  // A * Symmetric(P) (P is kept mirrored)
+        mm<D>(t1, At, pp);
         for (int i = 0; i < D; ++i)
-            for (int j = 0; j < D; ++j) {
-                double v = 0.0;
-                for (int k = 0; k < D; ++k) v = pfma(A[i][k], (k <= j ? P[k][j] : P[j][k]), v);
-                t1[i][j] = v;
-            }
-        for (int i = 0; i < D; ++i)
-            for (int j = 0; j < D; ++j) {
-                double v = 0.0;
-                for (int k = 0; k < D; ++k) v = pfma(t1[i][k], A[j][k], v);
-                pp[i][j] = v + Q[i][j];
-            }
+            for (int j = 0; j < D; ++j) pp[i][j] += Q[i][j];
         double S = 0.0;
         for (int k = 0; k < D; ++k) {
             double v = 0.0;
@@ -572,6 +593,7 @@ inline Info build_core(const ModelHost& m, long long T, Modal& md, HeadTables& t
                 Pold2[i][j] = P[i][j];
                 P[i][j] = Pn;
             }
+        mirror_upper<D>(P);
         if (!moved || cyc) tc = t;
     }
     if (bad) {
@@ -850,27 +872,47 @@ inline int build_tables(long long T, Modal& md, HeadTables& tab, Info& info) {
             tab.c[t * D + r] = v;
         }
     }
-    // ---- (c) smoothed covariance backwards from the final filtered state (Ps_{T-1} = P_ss) until it no longer changes
-    double Ps[D][D], Po2[D][D];
-    std::memcpy(Ps, wk.Pss, sizeof Ps);
-    for (int i = 0; i < D; ++i)
-        for (int j = 0; j < D; ++j) Po2[i][j] = 0.0;
+    // ---- (c) smoothed VARIANCES backwards from the final filtered state: Ps_j = sum_{k < j} G^k L G'^k + G^j P_ss G'^j, of which only
+    //      h' Ps_j h is wanted -- with g_k = h' G^k (a row: O(d^2) per step instead of the O(d^3) of the matrix recursion)
+    //      tvb_j = sum_{k < j} g_k L g_k' + g_j P_ss g_j'.  It has run into the stationary value once it no longer changes (2 ulp of it; the
+    //      comparison with the Lyapunov solution only guards against a plateau far from the limit).
     int n1 = -1;
-    for (int jt = 0; jt < kTailMax; ++jt) {
-        tab.tvb[jt] = quad_sym<D>(hv, Ps);
-        double pn[D][D];
-        smooth_cov_step<D>(Gss, Lss, Ps, pn);
-        bool moved = false, cyc = jt >= 1;
-        for (int i = 0; i < D; ++i)
+    {
+        double g[D], Lsym[D][D], Psym[D][D];
+        for (int i = 0; i < D; ++i) {
+            g[i] = hv[i];
             for (int j = 0; j < D; ++j) {
-                moved = moved || std::fabs(pn[i][j] - Ps[i][j]) > kTol * 0.5 * (std::fabs(Ps[i][i]) + std::fabs(Ps[j][j]));
-                cyc = cyc && (pn[i][j] == Po2[i][j]);
+                Lsym[i][j] = (i <= j) ? Lss[i][j] : Lss[j][i];
+                Psym[i][j] = (i <= j) ? wk.Pss[i][j] : wk.Pss[j][i];
             }
-        std::memcpy(Po2, Ps, sizeof Ps);
-        std::memcpy(Ps, pn, sizeof pn);
-        if (!moved || cyc) {
-            n1 = jt + 1;
-            break;
+        }
+        auto quad = [&](const double (&M)[D][D], const double (&x)[D]) {
+            double s = 0.0;
+            for (int i = 0; i < D; ++i) {
+                double v = 0.0;
+                for (int j = 0; j < D; ++j) v += M[i][j] * x[j];
+                s += x[i] * v;
+            }
+            return s;
+        };
+        double acc = 0.0, prev = 0.0, prev2 = 0.0;
+        for (int jt = 0; jt < kTailMax; ++jt) {
+            const double v = acc + quad(Psym, g);
+            tab.tvb[jt] = v;
+            if (jt >= 1 && (std::fabs(v - prev) <= kTol * std::fabs(v) || (jt >= 2 && v == prev2)) && std::fabs(v - md.vb) <= 1e-9 * std::fabs(md.vb)) {
+                n1 = jt + 1;
+                break;
+            }
+            prev2 = prev;
+            prev = v;
+            acc += quad(Lsym, g);
+            double ng[D];
+            for (int j = 0; j < D; ++j) ng[j] = 0.0;
+            for (int i = 0; i < D; ++i) {
+                const double f = g[i];
+                for (int j = 0; j < D; ++j) ng[j] += f * Gss[i][j];
+            }
+            for (int j = 0; j < D; ++j) g[j] = ng[j];
         }
     }
     if (n1 < 0) return kTailLong;
