@@ -93,7 +93,7 @@ for case in range(n_cases):
                 msgs.append(f"gradient adjoint vs tangent {err:.2e}")
         elif not abs(lpa - lp_ref) <= 1e-10 * abs(lp_ref):
             msgs.append(f"adjoint logpdf {lpa} vs {lp_ref}")
-    except tgp._lib.Unsupported:
+    except tgp._lib.Unsupported as refusal:
         # (the adjoint runs on the five-launch form of the engine: it may refuse what the one-launch form served -- a series shorter than that
         #  form's head and tail tiles -- but nothing the five-launch form itself serves)
         tr2 = tgp.GaussMarkovModel(tgp.Forward, model["A"], model["a"], model["Q"], tgp.Gaussian(model["x0m"], model["x0P"]))
@@ -103,7 +103,7 @@ for case in range(n_cases):
         h2.set_option(tgp._lib.OPT_PROFILE, 1)
         tgp.logpdf_and_posterior_marginals(d2, y, Rn)
         if any(n.startswith("k_steady_apply") for n in h2.profile()):
-            msgs.append("adjoint refused a model the five-launch engine served")
+            msgs.append(f"adjoint refused a model the five-launch engine served: {refusal}")
         del d2
     del dm, fx
     gc.collect()          # (handles own HIP streams: the runtime's per-queue scratch arenas add up over the handles alive in a process)

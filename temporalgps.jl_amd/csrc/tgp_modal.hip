@@ -50,7 +50,7 @@ struct KArgs {
     double* var;
     const double* htab;         // pinned host memory: the packed head / tail tables of this call (TabOff), written by the host beside the kernel
     double* tab;                // device memory: workgroup 0 pulls them in here for its head wave
-    const long long* flag;      // pinned host memory: 2 seq (+ 1) once `htab` is complete
+    const long long* flag;      // pinned host memory, one word per stage of the tables: 2 seq (+ 1: declined) once that stage is in `htab`
     TabOff to;
     double* part;               // pinned host memory: [nwg] sum r^2 over the workgroups' core ranges, [nwg] the head's sum r^2 / S
 };
@@ -127,6 +127,7 @@ struct Row {
         return PPL * ls + ls * PPL / 16 + e % PPL;
     }
 };
+__device__ __forceinline__ void store_pair(v2d* q, const v2d w) { *q = w; }      // (non-temporal stores: measured, no difference)
 template <int SUB>
 __device__ __forceinline__ void flush_row(double* __restrict__ p, long long tile_t0, long long lo, long long hi, const v2d* r2, int lane) {
     constexpr int TILE = 64 * SUB;
@@ -136,7 +137,7 @@ __device__ __forceinline__ void flush_row(double* __restrict__ p, long long tile
 #pragma unroll
         for (int k = 0; k < SUB / 2; ++k) {
             const int e = k * 64 + lane;
-            q[e] = r2[Row<SUB>::pair_slot(e)];
+            store_pair(q + e, r2[Row<SUB>::pair_slot(e)]);
         }
         return;
     }
@@ -146,7 +147,7 @@ __device__ __forceinline__ void flush_row(double* __restrict__ p, long long tile
         const v2d w = r2[Row<SUB>::pair_slot(e)];
         const long long t = tile_t0 + 2 * e;
         if (t >= lo && t + 1 < hi && aligned) {
-            *reinterpret_cast<v2d*>(p + t) = w;
+            store_pair(reinterpret_cast<v2d*>(p + t), w);
         } else {
             if (t >= lo && t < hi) p[t] = w.x;
             if (t + 1 >= lo && t + 1 < hi) p[t + 1] = w.y;
@@ -162,11 +163,41 @@ __device__ __forceinline__ double readlane_d(double x, int l) {      // l wave-u
     return __hiloint2double(hi, lo);
 }
 
+// Data-parallel-primitive moves of a double (two 32-bit v_mov_dpp: no LDS round trip as ds_bpermute has).  Lanes without a source, and the
+// rows the mask leaves out, read zero.  gfx9 controls: row_shl:n 0x100 + n (lane l reads l + n of its row of 16), row_shr:n 0x110 + n
+// (reads l - n), wave_shl:1 0x130 / wave_shr:1 0x138 (the same across the whole wave), row_bcast:15 0x142 (lane 15 of a row to the next row),
+// row_bcast:31 0x143 (lane 31 to rows 2, 3), row_newbcast:n 0x150 + n (lane n of a row to its own row)
+template <int CTRL, int ROWMASK = 0xF>
+__device__ __forceinline__ double dpp_mov(double x) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, ROWMASK, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, ROWMASK, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+// the sum over the wave, in lane 63 (rows by row_shr adds, then row_bcast:15 / :31 across them)
+__device__ __forceinline__ double wave_sum_to_lane63(double x) {
+    x += dpp_mov<0x111>(x);
+    x += dpp_mov<0x112>(x);
+    x += dpp_mov<0x114>(x);
+    x += dpp_mov<0x118>(x);
+    x += dpp_mov<0x142, 0xA>(x);
+    x += dpp_mov<0x143, 0xC>(x);
+    return x;
+}
+// one level of the in-row scans: z += (pr, pi) (*) z shifted by OFF lanes inside the row of 16 (DIR 0: from below, 1: from above)
+// (level K: OFF = 2^K lanes, the power M^(SUB 2^K) of the kernel arguments -- read member by member: a pointer into the by-value argument
+//  struct would make the compiler keep a copy of it in scratch memory)
+#define TGP_ROW_LEVEL(DIR, K, PR, PI, Z)                                                                          \
+    do {                                                                                                          \
+        double g_[D];                                                                                             \
+        _Pragma("unroll") for (int i = 0; i < D; ++i) g_[i] = dpp_mov<((DIR) == 0 ? 0x110 : 0x100) + (1 << (K))>(Z[i]); \
+        _Pragma("unroll") for (int i = 0; i < D; ++i) Z[i] = fma(ka.PR[K][i], g_[i], fma(ka.PI[K][i], g_[partner<D>(i)], Z[i])); \
+    } while (0)
+
 // Forward, in the modal coordinates of the stationary closed loop (O(d) per step; every lane the same arithmetic):
 //     z' = M z + fa + fb u + db_t r,   r = u - fw . z,   db_t = V^-1 (A K_t - A K)   (zero from step n0 on)
 // Leaves r_t in sR, the end state in z0, sum r^2 / S_t in quad.
 template <int D>
-__device__ void head_forward(const KArgs<D>& ka, double* __restrict__ sR /*[kHeadMax]*/, int lane, double (&z0)[D], double& quad) {
+__device__ __forceinline__ void head_forward(const KArgs<D>& ka, double* __restrict__ sR /*[kHeadMax]*/, int lane, double (&z0)[D], double& quad) {
     const double* __restrict__ tb = ka.tab;
     const int nhs = ka.nhs, n0 = ka.n0;
     double z[D];
@@ -214,7 +245,7 @@ __device__ void head_forward(const KArgs<D>& ka, double* __restrict__ sR /*[kHea
 // changes per step), mean_t = y_t - (R / S_t) r_t + h . lam.  Lane i < D owns row i of the product; lam goes round by v_readlane.  The rows of
 // a chunk of CH steps are staged in LDS (the tables are in device memory by now: a chunk costs an L2 round trip).  sR holds r_t on entry.
 template <int D, int CH>
-__device__ void head_backward(const KArgs<D>& ka, const double* __restrict__ sR, double* __restrict__ sTab /*[CH (D D + D)]*/, int lane, const double (&zeta)[D]) {
+__device__ __forceinline__ void head_backward(const KArgs<D>& ka, const double* __restrict__ sR, double* __restrict__ sTab /*[CH (D D + D)]*/, int lane, const double (&zeta)[D]) {
     constexpr int DD = D * D, ROW = DD + D;
     const double* __restrict__ tb = ka.tab;
     const int nhs = ka.nhs, n0 = ka.n0;
@@ -225,7 +256,6 @@ __device__ void head_backward(const KArgs<D>& ka, const double* __restrict__ sR,
         lam = fma(tb[ka.to.Wm + row * D + k], zeta[k], lam);
         h[k] = tb[ka.to.h + k];
     }
-    const double rn0 = ka.Rnew[0];
     for (int hi = nhs; hi > 0; hi -= CH) {
         const int lo = hi - CH > 0 ? hi - CH : 0, cnt = hi - lo;
         lds_sync();
@@ -284,11 +314,17 @@ __device__ void head_backward(const KArgs<D>& ka, const double* __restrict__ sR,
             for (int k = 0; k < D; ++k) g[k] = gn[k];
             cc = cn;
         }
-        if (lane < cnt) {
-            ka.mean[t] = mk;
-            ka.var[t] = tb[ka.to.vb + ti] + (ka.rnew_per_step ? ka.RnewT[t] : rn0);
-        }
+        if (lane < cnt) ka.mean[t] = mk;
     }
+}
+
+// The head's variances: data-independent, the last stage of the tables (read in place from pinned memory: at most kHeadMax values)
+template <int D>
+__device__ __forceinline__ void head_variances(const KArgs<D>& ka, int lane) {
+    wait_tables(ka.flag + 2, ka.seq);
+    const double rn0 = ka.Rnew[0];
+    const double* __restrict__ vb = ka.htab + ka.to.vb;
+    for (int t = lane; t < ka.nhs; t += 64) ka.var[t] = vb[t < ka.n0 ? t : ka.n0] + (ka.rnew_per_step ? ka.RnewT[t] : rn0);
 }
 
 // =================================================================================================================================
@@ -301,8 +337,56 @@ __device__ void head_backward(const KArgs<D>& ka, const double* __restrict__ sR,
 // A lane holds SUB consecutive steps: 8, or 16 (the in-tile scans cost the same per level whatever a lane holds, so sixteen halve them
 // per step -- at the price of 32 more registers).
 // =================================================================================================================================
+// The per-lane power table sPw[dir][re / im][component][lane]: job (dir, i) is one chain of 6 conditional complex multiplications by the bits of
+// the lane's exponent; wave JOB mod NW runs it.  Direction and component are compile-time constants: every coefficient is a scalar load from
+// the kernel arguments (a run-time index into the by-value argument struct would make the compiler keep a copy of it in scratch memory)
+template <int D, int NW, int JOB>
+struct PowerJobs {
+    __device__ static __forceinline__ void run(const KArgs<D>& ka, double (*sPw)[2][D][64], int lane, int uw) {
+        if constexpr (JOB < 2 * D) {
+            if (uw == JOB % NW) {      // (wave-uniform)
+                constexpr int dir = JOB / D, i = JOB % D;      // direction (0: forward, 1: backward), component
+                const int e = dir == 0 ? lane : 63 - lane;
+                double xr = 1.0, xi = 0.0;                      // the block form of M^(SUB e): (re, signed im) of the component, from the identity
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    const double pr = dir == 0 ? ka.fpr[k][i] : ka.gpr[k][i], pi = dir == 0 ? ka.fpi[k][i] : ka.gpi[k][i];
+                    const bool bit = ((e >> k) & 1) != 0;
+                    // (a + i b)(c + i d) with the signed-imaginary convention: re = a c - b d, im = a d + b c (the sign of the pair's second member follows)
+                    const double nr = fma(xr, pr, -(xi * pi)), ni = fma(xr, pi, xi * pr);
+                    xr = bit ? nr : xr;
+                    xi = bit ? ni : xi;
+                }
+                sPw[dir][0][i][lane] = xr;
+                sPw[dir][1][i][lane] = xi;
+            }
+            PowerJobs<D, NW, JOB + 1>::run(ka, sPw, lane, uw);
+        }
+    }
+};
+
+// Development build (-DTGP_MODAL_PROBE): wave 0 of a mid-series workgroup stamps its phases (shader clock) into part[nwg + 12 ..]
+#ifdef TGP_MODAL_PROBE
+#define TGP_STAMP(k)                                                                     \
+    do {                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                               \
+        if (probe_wave) {                                                                \
+            const double now = (double)clock64();                                        \
+            if (lane == 0) ka.part[ka.nwg + 12 + (k)] = now;                             \
+        }                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                               \
+    } while (0)
+#else
+#define TGP_STAMP(k) do { } while (0)
+#endif
+#define TGP_MIN_WAVES(D, NW) ((NW) == 8 ? 4 : 2)
 template <int D, int NW, int SUB>
-__global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void k_steady_one(const KArgs<D> ka) {
+__global__ __launch_bounds__(NW * 64, TGP_MIN_WAVES(D, NW)) void k_steady_one(const KArgs<D> ka_by_value) {
+    // The arguments are read where they lie, in the kernel-argument segment (scalar loads, any index): a by-value struct is first copied to a
+    // private variable, and one access pattern the optimiser cannot take apart (a run-time index, or identical blocks it merges into one
+    // with the offsets in a phi) leaves the whole 3 KB struct in scratch memory -- 20 x the kernel's time, from one build to the next
+    (void)ka_by_value;
+    const KArgs<D>& ka = *(const KArgs<D>*)__builtin_amdgcn_kernarg_segment_ptr();      // (an address-space cast: C style)
     static_assert(SUB == kWJ, "eight steps per lane (sixteen were built and measured in round 4: the 32 more registers cost more occupancy than the halved scans save)");
     constexpr int TILE = 64 * SUB;
     constexpr int CHB = D <= 4 ? 64 : (D <= 6 ? 32 : 16);      // steps of the head's backward recursion staged in LDS at a time (~10 KB)
@@ -311,7 +395,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void k_steady_one(const
     __shared__ __attribute__((aligned(16))) double sTab[CHB * (D * D + D)];
     __shared__ __attribute__((aligned(16))) double sOut[NW][2 * Row<SUB>::slots];
     // M^(SUB l) (forward) and Mg^(SUB (63 - l)) (backward) for the lanes l of a tile: what carries a tile's start state / right-hand input to
-    // its lanes.  The same for every wave: the last two waves of the workgroup build them (by the bits of the lane number) for all
+    // its lanes.  The same for every wave: the waves share the building (by the bits of the lane number) between them
     __shared__ double sPw[2][2][D][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // XCD-aware order: consecutive workgroups (which share their halos' lines of y) land on the same XCD, hence the same L2
@@ -335,37 +419,59 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void k_steady_one(const
     const bool need_back = any_valid && tile_t0 + TILE > c_lo;       // a tile wholly inside the left halo only hands its end state on
     const bool has_out = ka.post && need_back && tile_t0 < c_hi;
 
+    const bool probe_wave = wg == (ka.nwg >> 1) && wave == 0;
+    (void)probe_wave;
+    const bool probe = wg == (ka.nwg >> 1) && threadIdx.x == 0;      // (TGP_STEADY_DEBUG: a mid-series workgroup's lifetime in shader cycles and in 100 MHz ticks)
+    if (probe) {
+        ka.part[ka.nwg + 8] = (double)clock64();
+        ka.part[ka.nwg + 9] = (double)wall_clock64();
+    }
     double head_quad = 0.0;
     if (first) {
         // the head's tables: wait for the host, pull them into device memory (all waves), then the head wave runs the head forward
         if (threadIdx.x == 0) ka.part[ka.nwg + 1] = (double)wall_clock64();      // (phases of workgroup 0, 100 MHz: TGP_STEADY_DEBUG prints them)
         wait_tables(ka.flag, ka.seq);
         if (threadIdx.x == 0) ka.part[ka.nwg + 2] = (double)wall_clock64();
-        const int used = ka.to.tvb + (int)ka.htab[0];                               // doubles
         const v2d* __restrict__ src = reinterpret_cast<const v2d*>(ka.htab);
         v2d* __restrict__ dst = reinterpret_cast<v2d*>(ka.tab);
-        for (int idx = threadIdx.x; idx < (used + 1) / 2; idx += NW * 64) dst[idx] = src[idx];
+        for (int idx = threadIdx.x; idx < ka.to.G / 2; idx += NW * 64) dst[idx] = src[idx];      // (stage 0: everything in front of the rows [G_t | c_t])
         __syncthreads();
         if (head_wave) {
             double z0[D];
+            __builtin_amdgcn_s_setprio(3);      // (the one sequential wave of the launch: ahead of the tiles' waves it shares its SIMD with)
             head_forward<D>(ka, sR, lane, z0, head_quad);
+            __builtin_amdgcn_s_setprio(0);
             if (lane == 0) {
 #pragma unroll
                 for (int i = 0; i < D; ++i) sHead[i] = z0[i];
                 ka.part[ka.nwg + 3] = (double)wall_clock64();
             }
+        } else if (ka.post) {
+            // meanwhile the other waves fetch stage 1, the rows of the head's backward recursion (the barrier below hands them to the head wave)
+            wait_tables(ka.flag + 1, ka.seq);
+            for (int idx = ka.to.G / 2 + (int)threadIdx.x - 64; idx < ka.to.vb / 2; idx += (NW - 1) * 64) dst[idx] = src[idx];
         }
     }
     // ---- forward, zero start: innovations r0 of the lane's steps, the lane's end state, inclusive scan over the lanes
     double yv[SUB], r[SUB], st[D];
     const long long left = Tv - t0;
     const int nvalid = left >= SUB ? SUB : (left > 0 ? (int)left : 0);
+    // (2 D chains of 6 conditional complex multiplications -- shared out over the waves, one component of one direction each, while the
+    //  observations are on their way; two waves doing all of it made the other six wait at the barrier: 9 000 cycles at d = 6)
+    auto build_powers = [&]() { PowerJobs<D, NW, 0>::run(ka, sPw, lane, __builtin_amdgcn_readfirstlane(wave)); };
+    TGP_STAMP(0);
+    if (any_valid) load_lane<SUB, D>(ka, t0, yv);
+    build_powers();
+    __syncthreads();      // (the in-tile scans below read the table; the observations are still on their way)
     {
         double z[D];
 #pragma unroll
         for (int i = 0; i < D; ++i) z[i] = 0.0;
         if (any_valid) {
-            load_lane<SUB, D>(ka, t0, yv);
+#ifdef TGP_MODAL_PROBE
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+            TGP_STAMP(1);
 #pragma unroll
             for (int j = 0; j < SUB; ++j) {
                 const double u = yv[j] - ka.hh;
@@ -379,56 +485,40 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void k_steady_one(const
 #pragma unroll
                 for (int i = 0; i < D; ++i) z[i] = nz[i];
             }
-#pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                const int off = 1 << k;
-                const double keep = (lane >= off) ? 1.0 : 0.0;      // (a neighbour that does not exist contributes nothing: one multiply instead of two selects)
+            TGP_STAMP(2);
+            // inclusive scan over the lanes without an LDS round trip: four levels inside the rows of 16 lanes (row_shr moves), then the rows'
+            // end states across (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3) through the per-lane powers of the table
+            TGP_ROW_LEVEL(0, 0, fpr, fpi, z);
+            TGP_ROW_LEVEL(0, 1, fpr, fpi, z);
+            TGP_ROW_LEVEL(0, 2, fpr, fpi, z);
+            TGP_ROW_LEVEL(0, 3, fpr, fpi, z);
+            {
+                const int e1 = (lane & 15) + 1;                 // lane 16 r + p takes M^(SUB (p + 1)) times the state behind lane 16 r - 1
                 double g[D];
 #pragma unroll
-                for (int i = 0; i < D; ++i) g[i] = __shfl_up(z[i], off) * keep;
+                for (int i = 0; i < D; ++i) g[i] = dpp_mov<0x142, 0xA>(z[i]);
 #pragma unroll
-                for (int i = 0; i < D; ++i) z[i] = fma(ka.fpr[k][i], g[i], fma(ka.fpi[k][i], g[partner<D>(i)], z[i]));
+                for (int i = 0; i < D; ++i) z[i] = fma(sPw[0][0][i][e1], g[i], fma(sPw[0][1][i][e1], g[partner<D>(i)], z[i]));
+                const int e2 = lane >= 32 ? lane - 31 : 0;      // lane l >= 32 takes M^(SUB (l - 31)) times the state behind lane 31
+#pragma unroll
+                for (int i = 0; i < D; ++i) g[i] = dpp_mov<0x143, 0xC>(z[i]);
+#pragma unroll
+                for (int i = 0; i < D; ++i) z[i] = fma(sPw[0][0][i][e2], g[i], fma(sPw[0][1][i][e2], g[partner<D>(i)], z[i]));
             }
         }
 #pragma unroll
-        for (int i = 0; i < D; ++i) {
-            const double up = __shfl_up(z[i], 1);
-            st[i] = (lane == 0) ? 0.0 : up;
-        }
+        for (int i = 0; i < D; ++i) st[i] = dpp_mov<0x138>(z[i]);      // the state in front of the lane's steps: its left neighbour's (lane 0: zero)
         if (lane == 63) {
 #pragma unroll
             for (int i = 0; i < D; ++i) sF[wave][i] = any_valid ? z[i] : 0.0;
         }
     }
-    if (wave >= NW - 2) {
-        const int dir = wave - (NW - 2);      // 0: forward, 1: backward
-        const int e = dir == 0 ? lane : 63 - lane;
-        double xr[D], xi[D];                  // the block form of M^(SUB e): (re, signed im) per component, from the identity
-#pragma unroll
-        for (int i = 0; i < D; ++i) {
-            xr[i] = 1.0;
-            xi[i] = 0.0;
-        }
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            const double* __restrict__ pr = dir == 0 ? ka.fpr[k] : ka.gpr[k];
-            const double* __restrict__ pi = dir == 0 ? ka.fpi[k] : ka.gpi[k];
-            const bool bit = ((e >> k) & 1) != 0;
-#pragma unroll
-            for (int i = 0; i < D; ++i) {
-                // (a + i b)(c + i d) with the signed-imaginary convention: re = a c - b d, im = a d + b c (the sign of the pair's second member follows)
-                const double nr = fma(xr[i], pr[i], -(xi[i] * pi[i])), ni = fma(xr[i], pi[i], xi[i] * pr[i]);
-                xr[i] = bit ? nr : xr[i];
-                xi[i] = bit ? ni : xi[i];
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < D; ++i) {
-            sPw[dir][0][i][lane] = xr[i];
-            sPw[dir][1][i][lane] = xi[i];
-        }
-    }
+    TGP_STAMP(3);
+#ifdef TGP_MODAL_PROBE
+    if (wg == (ka.nwg >> 1) && lane == 0) ka.part[ka.nwg + 28 + wave] = (double)clock64();      // every wave's arrival at barrier 1 ...
+#endif
     __syncthreads();
+    TGP_STAMP(4);
     double acc = 0.0;
     double zst[D];
 #pragma unroll
@@ -473,9 +563,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void k_steady_one(const
     }
     if (!ka.post) {
         // logpdf only: the sum of squares is all that is wanted
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) acc += __shfl_down(acc, off);
-        if (lane == 0) sAcc[wave] = acc;
+        acc = wave_sum_to_lane63(acc);
+        if (lane == 63) sAcc[wave] = acc;
         __syncthreads();
         if (threadIdx.x == 0) {
             double t = 0.0;
@@ -487,6 +576,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void k_steady_one(const
         return;
     }
     // ---- backward, zero lam behind the tile: m0_j = y_j - rS r_j + gw . zeta (zeta from the lane's own later steps), reverse scan
+    TGP_STAMP(5);
     if (need_back) {
         double zeta[D];
 #pragma unroll
@@ -503,21 +593,29 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void k_steady_one(const
 #pragma unroll
             for (int i = 0; i < D; ++i) zeta[i] = nz[i];
         }
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            const int off = 1 << k;
-            const double keep = (lane + off < 64) ? 1.0 : 0.0;
+        TGP_STAMP(6);
+        // the reverse scan: rows by row_shl moves; then rows 0 and 2 take the first lane of the row above them (wave_shl:1 brings it to their
+        // lane 15, row_newbcast:15 spreads it), then the lower half takes lane 32 (a scalar by v_readlane)
+        TGP_ROW_LEVEL(1, 0, gpr, gpi, zeta);
+        TGP_ROW_LEVEL(1, 1, gpr, gpi, zeta);
+        TGP_ROW_LEVEL(1, 2, gpr, gpi, zeta);
+        TGP_ROW_LEVEL(1, 3, gpr, gpi, zeta);
+        {
+            const int e1 = 47 + (lane & 15);                  // Mg^(SUB (16 - p)) sits at position 63 - (16 - p) of the backward table
             double g[D];
 #pragma unroll
-            for (int i = 0; i < D; ++i) g[i] = __shfl_down(zeta[i], off) * keep;
+            for (int i = 0; i < D; ++i) g[i] = dpp_mov<0x15F, 0x5>(dpp_mov<0x130>(zeta[i]));
 #pragma unroll
-            for (int i = 0; i < D; ++i) zeta[i] = fma(ka.gpr[k][i], g[i], fma(ka.gpi[k][i], g[partner<D>(i)], zeta[i]));
+            for (int i = 0; i < D; ++i) zeta[i] = fma(sPw[1][0][i][e1], g[i], fma(sPw[1][1][i][e1], g[partner<D>(i)], zeta[i]));
+            const int e2 = lane < 32 ? 31 + lane : 63;        // Mg^(SUB (32 - l)) at position 63 - (32 - l); the upper half: the identity's place, times zero
+            const double keep = lane < 32 ? 1.0 : 0.0;
+#pragma unroll
+            for (int i = 0; i < D; ++i) g[i] = readlane_d(zeta[i], 32) * keep;
+#pragma unroll
+            for (int i = 0; i < D; ++i) zeta[i] = fma(sPw[1][0][i][e2], g[i], fma(sPw[1][1][i][e2], g[partner<D>(i)], zeta[i]));
         }
 #pragma unroll
-        for (int i = 0; i < D; ++i) {
-            const double dn = __shfl_down(zeta[i], 1);
-            zst[i] = (lane == 63) ? 0.0 : dn;
-        }
+        for (int i = 0; i < D; ++i) zst[i] = dpp_mov<0x130>(zeta[i]);      // the lam behind the lane's steps: its right neighbour's (lane 63: zero)
         if (lane == 0) {
 #pragma unroll
             for (int i = 0; i < D; ++i) sB[wave][i] = zeta[i];
@@ -526,7 +624,12 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void k_steady_one(const
 #pragma unroll
         for (int i = 0; i < D; ++i) sB[wave][i] = 0.0;
     }
+    TGP_STAMP(7);
+#ifdef TGP_MODAL_PROBE
+    if (wg == (ka.nwg >> 1) && lane == 0) ka.part[ka.nwg + 28 + NW + wave] = (double)clock64();      // ... and at barrier 2
+#endif
     __syncthreads();
+    TGP_STAMP(8);
     // the lam entering a tile from the right: from the (at most three) tiles behind it
     auto right_input = [&](int w, double (&zin)[D]) {
 #pragma unroll
@@ -570,14 +673,16 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void k_steady_one(const
             w.y = m1;
             row[wb + (j >> 1)] = w;
         }
+        TGP_STAMP(9);
         lds_sync();
         flush_row<SUB>(ka.mean, tile_t0, c_lo, c_hi, row, lane);
+        TGP_STAMP(10);
         // the variances do not depend on the data: a constant outside the last n1 steps (plus the new noise); written transposed as well
         {
             const double rn0 = ka.Rnew[0];
             long long n1 = 0;
             if (T - tile_t0 <= (long long)tgp_plan::kTailMax + TILE) {      // (wave-uniform: the last few tiles of the series)
-                wait_tables(ka.flag, ka.seq);
+                wait_tables(ka.flag + 2, ka.seq);
                 n1 = (long long)ka.htab[0];
             }
             const double* __restrict__ tvb = ka.htab + ka.to.tvb;      // (in place from pinned memory: the last few tiles, a handful of values)
@@ -605,7 +710,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void k_steady_one(const
                     v2d w;
                     w.x = v0 + rn.x;
                     w.y = v1 + rn.y;
-                    *reinterpret_cast<v2d*>(ka.var + t) = w;
+                    store_pair(reinterpret_cast<v2d*>(ka.var + t), w);
                 } else {
                     if (t >= c_lo && t < c_hi) ka.var[t] = v0 + (ka.rnew_per_step ? ka.RnewT[t] : rn0);
                     if (t + 1 >= c_lo && t + 1 < c_hi) ka.var[t + 1] = v1 + (ka.rnew_per_step ? ka.RnewT[t + 1] : rn0);
@@ -613,17 +718,22 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void k_steady_one(const
             }
         }
     }
+    TGP_STAMP(11);
     if (head_wave) {
         double zin[D];
         right_input(-1, zin);
         if (lane == 0) ka.part[ka.nwg + 4] = (double)wall_clock64();
+        __builtin_amdgcn_s_setprio(3);
         head_backward<D, CHB>(ka, sR, sTab, lane, zin);
+        __builtin_amdgcn_s_setprio(0);
         if (lane == 0) ka.part[ka.nwg + 5] = (double)wall_clock64();
+        head_variances<D>(ka, lane);
     }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_down(acc, off);
-    if (lane == 0) sAcc[wave] = acc;
+    acc = wave_sum_to_lane63(acc);
+    if (lane == 63) sAcc[wave] = acc;
+    TGP_STAMP(12);
     __syncthreads();
+    TGP_STAMP(13);
     if (threadIdx.x == 0) {
         double t = 0.0;
 #pragma unroll
@@ -631,6 +741,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void k_steady_one(const
         ka.part[wg] = t;
         if (first) ka.part[ka.nwg] = head_quad;
         if (wg == ka.nwg - 1) ka.part[ka.nwg + 6] = (double)wall_clock64();
+        if (probe) {
+            ka.part[ka.nwg + 10] = (double)clock64();
+            ka.part[ka.nwg + 11] = (double)wall_clock64();
+        }
     }
 }
 
@@ -688,6 +802,7 @@ struct Engine {
     size_t flat_cap = 0;            // doubles
     TabOff to{};
     size_t flat_used = 0;
+    bool post = true;               // the launched call wants the posterior marginals (complete(): which stages of the tables)
     double* part = nullptr;         // pinned host memory
     size_t part_cap = 0;
     Modal md{};
@@ -723,6 +838,7 @@ int launch(Engine* e, hipStream_t st, const Call& c, const char** kname) {
     std::memset(&ka, 0, sizeof ka);
     fill_args<D>(ka, e->md, e->sub);
     ka.post = c.mean != nullptr ? 1 : 0;
+    e->post = ka.post != 0;
     ka.rnew_per_step = c.rnew_per_step;
     ka.T = c.T;
     const int nw = e->nw, tile = 64 * e->sub;
@@ -830,32 +946,51 @@ static void layout_tables(Engine* e) {
     to.tvb = take(0);
 }
 
-// packs the plan's tables for the device (pinned memory) and raises the flag
-static bool ship_tables(Engine* e, int why) {
+// packs one stage of the plan's tables for the device (pinned memory) and raises the stage's flag: 0 what the head's forward recursion
+// reads, 1 the rows [G_t | c_t] of its backward recursion, 2 the smoothed variances of the head and of the last n1 steps.  A stage that
+// declined (why != kOk) raises its flag and the later ones with the failure bit: the kernel never waits for a stage that will not come
+static void ship_stage(Engine* e, int stage, int why) {
     const Modal& md = e->md;
     const HeadTables& tb = *e->tab;
     const int d = md.d, dd = d * d, n = md.n0 + 1;
     const TabOff& to = e->to;
     double* q = e->hflat;
-    std::memcpy(q + to.h, tb.h, sizeof(double) * d);
-    std::memcpy(q + to.mu0, tb.mu0, sizeof(double) * d);
-    std::memcpy(q + to.Wm, tb.Wm, sizeof(double) * dd);
-    std::memcpy(q + to.db, tb.kA, sizeof(double) * n * d);
-    std::memcpy(q + to.iS, tb.iS, sizeof(double) * n);
-    std::memcpy(q + to.rS, tb.rS, sizeof(double) * n);
-    for (int t = 0; t < md.nhs; ++t) {
-        const int tt = t < md.n0 ? t : md.n0;
-        std::memcpy(q + to.G + (size_t)t * (dd + d), tb.G + (size_t)tt * dd, sizeof(double) * dd);
-        std::memcpy(q + to.G + (size_t)t * (dd + d) + dd, tb.c + (size_t)tt * d, sizeof(double) * d);
-    }
-    std::memcpy(q + to.vb, tb.vb, sizeof(double) * n);
-    const int n1 = md.n1 > 0 ? md.n1 : 0;
-    std::memcpy(q + to.tvb, tb.tvb, sizeof(double) * n1);
-    q[0] = (double)n1;
-    e->flat_used = (size_t)to.tvb + n1;
     long long* hflag = reinterpret_cast<long long*>(e->hflat + e->flat_cap);
-    __atomic_store_n(hflag, 2 * e->seq + (why != tgp_plan::kOk ? 1 : 0), __ATOMIC_RELEASE);
-    return true;
+    if (why != tgp_plan::kOk) {
+        for (int s2 = stage; s2 < 3; ++s2) __atomic_store_n(hflag + s2, 2 * e->seq + 1, __ATOMIC_RELEASE);
+        return;
+    }
+    if (stage == 0) {
+        std::memcpy(q + to.h, tb.h, sizeof(double) * d);
+        std::memcpy(q + to.mu0, tb.mu0, sizeof(double) * d);
+        std::memcpy(q + to.Wm, tb.Wm, sizeof(double) * dd);
+        std::memcpy(q + to.db, tb.kA, sizeof(double) * n * d);
+        std::memcpy(q + to.iS, tb.iS, sizeof(double) * n);
+        std::memcpy(q + to.rS, tb.rS, sizeof(double) * n);
+    } else if (stage == 1) {
+        for (int t = 0; t < md.nhs; ++t) {
+            const int tt = t < md.n0 ? t : md.n0;
+            std::memcpy(q + to.G + (size_t)t * (dd + d), tb.G + (size_t)tt * dd, sizeof(double) * dd);
+            std::memcpy(q + to.G + (size_t)t * (dd + d) + dd, tb.c + (size_t)tt * d, sizeof(double) * d);
+        }
+    } else {
+        std::memcpy(q + to.vb, tb.vb, sizeof(double) * n);
+        const int n1 = md.n1 > 0 ? md.n1 : 0;
+        std::memcpy(q + to.tvb, tb.tvb, sizeof(double) * n1);
+        q[0] = (double)n1;
+        e->flat_used = (size_t)to.tvb + n1;
+    }
+    __atomic_store_n(hflag + stage, 2 * e->seq, __ATOMIC_RELEASE);
+}
+
+// the tables half of the plan, stage by stage, each shipped as soon as it exists.  Returns the Why of the first stage that declined
+static int build_and_ship_tables(Engine* e, long long T, int nstages = 3) {
+    for (int stage = 0; stage < nstages; ++stage) {
+        const int why = tgp_plan::build_tables_stage_any(e->md.d, stage, T, e->md, *e->tab, e->info);
+        ship_stage(e, stage, why);
+        if (why != tgp_plan::kOk) return why;
+    }
+    return tgp_plan::kOk;
 }
 
 bool plan(Engine* e, const tgp_plan::ModelHost& m, long long T) {
@@ -870,13 +1005,13 @@ bool plan(Engine* e, const tgp_plan::ModelHost& m, long long T) {
         // the layout of ship_tables at its largest: d = 8, n0 = kN0Max, n1 = kTailMax
         e->flat_cap = (size_t)tgp_plan::kHeadMax * (64 + 8) + (size_t)(tgp_plan::kN0Max + 1) * (8 + 3) + tgp_plan::kTailMax + 64 + 2 * 8 + 8;
         e->flat_cap = (e->flat_cap + 1) & ~(size_t)1;
-        if (hipHostMalloc(reinterpret_cast<void**>(&e->hflat), (e->flat_cap + 2) * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess ||
-            hipMalloc(reinterpret_cast<void**>(&e->dflat), (e->flat_cap + 2) * sizeof(double)) != hipSuccess) {
+        if (hipHostMalloc(reinterpret_cast<void**>(&e->hflat), (e->flat_cap + 4) * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void**>(&e->dflat), (e->flat_cap + 4) * sizeof(double)) != hipSuccess) {
             e->info = tgp_plan::Info{};
             e->info.why = tgp_plan::kEigFail;
             return false;
         }
-        *reinterpret_cast<long long*>(e->hflat + e->flat_cap) = 0;
+        for (int s2 = 0; s2 < 3; ++s2) reinterpret_cast<long long*>(e->hflat + e->flat_cap)[s2] = 0;      // (the stages' flags)
     }
     ++e->seq;
     e->info = tgp_plan::build_core_any(m, T, e->md, *e->tab);
@@ -886,13 +1021,9 @@ bool plan(Engine* e, const tgp_plan::ModelHost& m, long long T) {
     // for the flag), else right here
     e->deferred = overlap_tables() && T >= (long long)e->md.nhs + tgp_plan::kTailMax + 1;
     if (!e->deferred) {
-        const int why = tgp_plan::build_tables_any(e->md.d, T, e->md, *e->tab, e->info);
+        const int why = build_and_ship_tables(e, T);
         if (why != tgp_plan::kOk) {
             e->info.why = why;
-            return false;
-        }
-        if (!ship_tables(e, tgp_plan::kOk)) {
-            e->info.why = tgp_plan::kEigFail;
             return false;
         }
     }
@@ -901,7 +1032,7 @@ bool plan(Engine* e, const tgp_plan::ModelHost& m, long long T) {
     choose_geometry(e->md.d, halo, &e->nw, &e->sub);
     const long long C = (long long)e->nw * 64 * e->sub - 2LL * halo;
     e->nwg = (T - e->md.nhs + C - 1) / C;
-    const size_t need = (size_t)e->nwg + 8;
+    const size_t need = (size_t)e->nwg + 64;
     if (need > e->part_cap) {
         if (e->part) (void)hipHostFree(e->part);
         e->part = nullptr;
@@ -921,10 +1052,9 @@ bool plan(Engine* e, const tgp_plan::ModelHost& m, long long T) {
 bool complete(Engine* e, long long T) {
     if (!e->began || !e->deferred) return true;
     e->deferred = false;
-    const int why = tgp_plan::build_tables_any(e->md.d, T, e->md, *e->tab, e->info);
-    const bool sent = ship_tables(e, why);
-    if (why != tgp_plan::kOk || !sent) {
-        e->info.why = why != tgp_plan::kOk ? why : tgp_plan::kEigFail;
+    const int why = build_and_ship_tables(e, T, e->post ? 3 : 1);      // (a logpdf-only launch reads the forward stage alone)
+    if (why != tgp_plan::kOk) {
+        e->info.why = why;
         return false;
     }
     return true;
@@ -967,6 +1097,22 @@ double finish(const Engine* e, long long T) {
         const double* q = e->part + e->nwg_local;
         fprintf(stderr, "[tgp modal] d %d n0 %d nhs %d n1 %d halo %d geometry %dx%d workgroups %lld | workgroup 0 (us from its start): tables ready %.1f, head forward done %.1f, head backward starts %.1f, done %.1f; last workgroup done %.1f\n",
                 md.d, md.n0, md.nhs, md.n1, md.halo, e->nw, e->sub, e->nwg_local, (q[2] - q[1]) * 0.01, (q[3] - q[1]) * 0.01, (q[4] - q[1]) * 0.01, (q[5] - q[1]) * 0.01, (q[6] - q[1]) * 0.01);
+        if (q[11] > q[9])
+            fprintf(stderr, "[tgp modal] a mid-series workgroup lived %.2f us = %.0f shader cycles (%.0f MHz); it started %.1f us after workgroup 0\n", (q[11] - q[9]) * 0.01, q[10] - q[8],
+                    (q[10] - q[8]) / ((q[11] - q[9]) * 0.01), (q[9] - q[1]) * 0.01);
+#ifdef TGP_MODAL_PROBE
+        {
+            static const char* nm[14] = {"entry", "y loaded", "forward steps", "forward scan", "barrier 1", "corrections", "backward steps", "backward scan", "barrier 2", "mean rows in LDS",
+                                         "mean stores issued", "variance stores issued", "wave sum", "barrier 3"};
+            fprintf(stderr, "[tgp modal] phases of its wave 0 (shader cycles since entry):");
+            for (int k = 1; k < 14; ++k) fprintf(stderr, " %s %.0f;", nm[k], q[12 + k] - q[12]);
+            fprintf(stderr, "\n[tgp modal] its waves reached barrier 1 at");
+            for (int w = 0; w < e->nw; ++w) fprintf(stderr, " %.0f", q[28 + w] - q[12]);
+            fprintf(stderr, "; barrier 2 at");
+            for (int w = 0; w < e->nw; ++w) fprintf(stderr, " %.0f", q[28 + e->nw + w] - q[12]);
+            fprintf(stderr, "\n");
+        }
+#endif
     }
     double s = 0.0, hq = 0.0;
     finish_parts(e, &s, &hq);

@@ -836,24 +836,55 @@ inline Info build_core(const ModelHost& m, long long T, Modal& md, HeadTables& t
     return info;
 }
 
+// The tables half in three stages, in the order the kernel's head wave wants them (the caller ships each as soon as it exists):
+//   forward:  the head's gains in modal coordinates (cheap: one d x d product per step) -- the head's forward recursion can start;
+//   backward: the reverse-time dynamics (G_t, c_t) of every head step (one d x d factorisation per step) -- its backward recursion;
+//   variances: the smoothed variances of the head and of the last n1 steps -- only the writes of `var` at the two ends wait for them.
 template <int D>
-inline int build_tables(long long T, Modal& md, HeadTables& tab, Info& info) {
+struct TablesWork {
+    double sG[kN0Max + 2][D][D], sL[kN0Max + 2][D][D];
+};
+template <int D>
+inline TablesWork<D>& tables_work() {
+    static thread_local TablesWork<D> w;
+    return w;
+}
+
+template <int D>
+inline int build_tables_forward(Modal& md, HeadTables& tab) {
     using namespace detail;
     Work<D>& wk = work<D>();
     const int n0 = wk.n0;
+    // the head's gains in the modal coordinates: z' = M z + fa + fb u + db_t r, db_t = V^-1 (A K_t - A K)
+    for (int t = 0; t <= n0; ++t) {
+        double dk[D], db[D];
+        for (int k = 0; k < D; ++k) dk[k] = tab.kA[t * D + k] - wk.kAss[k];
+        for (int i = 0; i < D; ++i) {
+            double v = 0.0;
+            for (int k = 0; k < D; ++k) v = pfma(wk.Vi[i * D + k], dk[k], v);
+            db[i] = v;
+        }
+        for (int i = 0; i < D; ++i) tab.kA[t * D + i] = (t == n0) ? 0.0 : db[i];
+    }
+    (void)md;
+    return kOk;
+}
+
+template <int D>
+inline int build_tables_backward(Modal& md, HeadTables& tab) {
+    using namespace detail;
+    Work<D>& wk = work<D>();
+    TablesWork<D>& tw = tables_work<D>();
+    const int n0 = wk.n0;
     const double R = wk.R;
-    double A[D][D], hv[D], kAss[D], Gss[D][D], Lss[D][D];
+    double A[D][D], hv[D];
     std::memcpy(A, wk.A, sizeof A);
     std::memcpy(hv, wk.hv, sizeof hv);
-    std::memcpy(kAss, wk.kAss, sizeof kAss);
-    std::memcpy(Gss, wk.Gss, sizeof Gss);
-    std::memcpy(Lss, wk.Lss, sizeof Lss);
     // ---- (b) reverse-time dynamics of the head steps (row n0: the stationary step's, from the core)
-    static thread_local double sG[kN0Max + 2][D][D], sL[kN0Max + 2][D][D];
-    std::memcpy(sG[n0], wk.Gss, sizeof wk.Gss);
-    std::memcpy(sL[n0], wk.Lss, sizeof wk.Lss);
+    std::memcpy(tw.sG[n0], wk.Gss, sizeof wk.Gss);
+    std::memcpy(tw.sL[n0], wk.Lss, sizeof wk.Lss);
     for (int t = 0; t <= n0; ++t) {
-        if (t < n0 && !invert_dynamics<D>(A, wk.Pf[t], wk.Pp[t], sG[t], sL[t])) return kNotPD;
+        if (t < n0 && !invert_dynamics<D>(A, wk.Pf[t], wk.Pp[t], tw.sG[t], tw.sL[t])) return kNotPD;
         double K[D], Sv = 0.0;
         for (int k = 0; k < D; ++k) {
             double v = 0.0;
@@ -866,12 +897,26 @@ inline int build_tables(long long T, Modal& md, HeadTables& tab, Info& info) {
         for (int r = 0; r < D; ++r) {
             double v = 0.0;
             for (int c = 0; c < D; ++c) {
-                v = pfma(sG[t][r][c], K[c] * iSv, v);
-                tab.G[(size_t)t * D * D + r * D + c] = sG[t][r][c];
+                v = pfma(tw.sG[t][r][c], K[c] * iSv, v);
+                tab.G[(size_t)t * D * D + r * D + c] = tw.sG[t][r][c];
             }
             tab.c[t * D + r] = v;
         }
     }
+    (void)md;
+    return kOk;
+}
+
+template <int D>
+inline int build_tables_variances(long long T, Modal& md, HeadTables& tab, Info& info) {
+    using namespace detail;
+    Work<D>& wk = work<D>();
+    TablesWork<D>& tw = tables_work<D>();
+    const int n0 = wk.n0;
+    double hv[D], Gss[D][D], Lss[D][D];
+    std::memcpy(hv, wk.hv, sizeof hv);
+    std::memcpy(Gss, wk.Gss, sizeof Gss);
+    std::memcpy(Lss, wk.Lss, sizeof Lss);
     // ---- (c) smoothed VARIANCES backwards from the final filtered state: Ps_j = sum_{k < j} G^k L G'^k + G^j P_ss G'^j, of which only
     //      h' Ps_j h is wanted -- with g_k = h' G^k (a row: O(d^2) per step instead of the O(d^3) of the matrix recursion)
     //      tvb_j = sum_{k < j} g_k L g_k' + g_j P_ss g_j'.  It has run into the stationary value once it no longer changes (2 ulp of it; the
@@ -927,21 +972,27 @@ inline int build_tables(long long T, Modal& md, HeadTables& tab, Info& info) {
         std::memcpy(Pc, wk.Psinf, sizeof Pc);
         for (int t = n0; t >= 1; --t) {
             double pn[D][D];
-            smooth_cov_step<D>(sG[t], sL[t], Pc, pn);
+            smooth_cov_step<D>(tw.sG[t], tw.sL[t], Pc, pn);
             std::memcpy(Pc, pn, sizeof pn);
             tab.vb[t - 1] = quad_sym<D>(hv, Pc);
         }
     }
-    // ---- the head's gains in the modal coordinates: z' = M z + fa + fb u + db_t r, db_t = V^-1 (A K_t - A K)
-    for (int t = 0; t <= n0; ++t) {
-        double dk[D], db[D];
-        for (int k = 0; k < D; ++k) dk[k] = tab.kA[t * D + k] - kAss[k];
-        for (int i = 0; i < D; ++i) {
-            double v = 0.0;
-            for (int k = 0; k < D; ++k) v = pfma(wk.Vi[i * D + k], dk[k], v);
-            db[i] = v;
-        }
-        for (int i = 0; i < D; ++i) tab.kA[t * D + i] = (t == n0) ? 0.0 : db[i];
+    return kOk;
+}
+
+// stage: 0 forward, 1 backward, 2 variances (in this order; each may decline)
+template <int D>
+inline int build_tables_stage(int stage, long long T, Modal& md, HeadTables& tab, Info& info) {
+    if (stage == 0) return build_tables_forward<D>(md, tab);
+    if (stage == 1) return build_tables_backward<D>(md, tab);
+    return build_tables_variances<D>(T, md, tab, info);
+}
+
+template <int D>
+inline int build_tables(long long T, Modal& md, HeadTables& tab, Info& info) {
+    for (int stage = 0; stage < 3; ++stage) {
+        const int why = build_tables_stage<D>(stage, T, md, tab, info);
+        if (why != kOk) return why;
     }
     return kOk;
 }
@@ -972,6 +1023,10 @@ inline Info build_core_any(const ModelHost& m, long long T, Modal& md, HeadTable
 }
 inline int build_tables_any(int d, long long T, Modal& md, HeadTables& tab, Info& info) {
     TGP_PLAN_DISPATCH(d, build_tables<D>(T, md, tab, info))
+    return kEigFail;
+}
+inline int build_tables_stage_any(int d, int stage, long long T, Modal& md, HeadTables& tab, Info& info) {
+    TGP_PLAN_DISPATCH(d, build_tables_stage<D>(stage, T, md, tab, info))
     return kEigFail;
 }
 inline Info build_any(const ModelHost& m, long long T, Modal& md, HeadTables& tab) {

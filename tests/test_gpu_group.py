@@ -195,6 +195,7 @@ def test_group_prior_marginals(tgp, d, p, per_step_R):
     dm = tgp.LGSSM(tr, em(), T=T)
     hd = dm.handle()
     hd.set_option(tgp._lib.OPT_GROUP, 2)
+    hd.set_option(tgp._lib.OPT_STEADY, 2)      # (the default would serve the scalar, one-variance case by the LTI fill: tests/test_gpu_modal.py holds that path)
     mm, mC = ref.marginals(model)
     want_v = mC if p == 1 else np.diagonal(mC, axis1=-2, axis2=-1)
     for chunk in (0, 4, 12):
