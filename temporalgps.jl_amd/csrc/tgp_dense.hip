@@ -286,6 +286,23 @@ template <int TM, int TN> __global__ __launch_bounds__(512) void dk_gemm(const G
 }
 
 // ------------------------------------------------------------------------------------------------ Cholesky of S (n <= 256)
+// lane J (< 16, a compile-time constant after unrolling) of the wave to the lanes 0 .. 31: row_newbcast:J within the first row of 16 lanes, then
+// row_bcast:15 (lane 15 of a row to the next row) into the second -- DPP moves, no v_readlane (which costs 16 cycles a piece on this part)
+__device__ __forceinline__ double first_row_lane(double v, int j) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+#define DK_BC(J)                                                                   \
+    case J:                                                                        \
+        lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + J, 0xF, 0xF, true);        \
+        hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + J, 0xF, 0xF, true);        \
+        break;
+    switch (j) {
+        DK_BC(0) DK_BC(1) DK_BC(2) DK_BC(3) DK_BC(4) DK_BC(5) DK_BC(6) DK_BC(7) DK_BC(8) DK_BC(9) DK_BC(10) DK_BC(11) DK_BC(12) DK_BC(13) DK_BC(14) DK_BC(15)
+    }
+#undef DK_BC
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x142, 0xA, 0xF, false);      // (rows 1 and 3 take over; the others keep their own)
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x142, 0xA, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
 __device__ inline double rdlane(double v, int l) {
     int lo = __double2loint(v), hi = __double2hiint(v);
     lo = __builtin_amdgcn_readlane(lo, l);
@@ -382,9 +399,12 @@ __global__ __launch_bounds__(1024) void dk_chol(const double* __restrict__ S, in
             wait_ge(&flag_d, kb + 1);
             DK_STAMP(0);
             // Lanes 0-15 hold one ROW of the tile each (z[k] = T[row][k]); lanes 16-31 hold one COLUMN of W = L_kk^-1 each
-            // (z[k] = W[k][col], starting from the identity): both obey the same recurrence z[c] *= 1/L[c][c];
-            // z[j] -= z[c] L[j][c], so one instruction stream factorises and inverts (lanes 32-63 repeat). (Broadcast LDS reads of
-            // the published column instead of readlane pairs were measured slower: 10.6K against 7.7K cycles per tile.)
+            // (z[k] = W[k][col], starting from the identity): both obey the same recurrence z[c] *= 1 / L[c][c];
+            // z[j] -= z[c] L[j][c], so one instruction stream factorises and inverts (lanes 32-63 repeat).  L[j][c] is lane j's z[c] of
+            // the FIRST row of lanes: row_newbcast:j spreads it over that row, row_bcast:15 hands it on to the second -- four 32-bit DPP
+            // moves, 16 cycles.  (Round 3 fetched it with a v_readlane pair: 16 cycles EACH on this part, 240 pairs per tile, 7.7K
+            // cycles per tile on the kernel's critical path; broadcast LDS reads: 10.6K.  Rows and columns in the same lanes -- two
+            // moves, two FMAs per value -- need 64 registers here and spill.)
             double z[16];
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
@@ -394,7 +414,7 @@ __global__ __launch_bounds__(1024) void dk_chol(const double* __restrict__ S, in
             double mypiv = 1.0;
 #pragma unroll
             for (int c = 0; c < 16; ++c) {
-                const double piv = rdlane(z[c], c);
+                const double piv = first_row_lane(z[c], c);
                 notpd |= !(piv > 0.0);
                 const double rs = rsqrt_fast(piv);
                 const double l = z[c] * rs;        // rows: L[row][c]; columns: the final W[c][col]
@@ -402,9 +422,9 @@ __global__ __launch_bounds__(1024) void dk_chol(const double* __restrict__ S, in
                 mypiv = lane == c ? piv : mypiv;
 #pragma unroll
                 for (int j = c + 1; j < 16; ++j) {
-                    double zj = z[j] - l * rdlane(l, j);      // L[j][c] comes from lane j (a row lane)
+                    double zj = fma(-l, first_row_lane(l, j), z[j]);      // L[j][c] comes from lane j (a row lane)
                     // evaluate NOW: left to itself the compiler sinks these updates to their use (a left-looking order) and keeps
-                    // all 120 broadcast scalars alive in between
+                    // all 120 broadcast values alive in between
                     asm volatile("" : "+v"(zj));
                     z[j] = zj;
                 }

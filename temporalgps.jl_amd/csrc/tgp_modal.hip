@@ -461,6 +461,8 @@ __global__ __launch_bounds__(NW * 64, TGP_MIN_WAVES(D, NW)) void k_steady_one(co
     auto build_powers = [&]() { PowerJobs<D, NW, 0>::run(ka, sPw, lane, __builtin_amdgcn_readfirstlane(wave)); };
     TGP_STAMP(0);
     if (any_valid) load_lane<SUB, D>(ka, t0, yv);
+    // (the new noise is wanted at the very end, by the variance stores: fetched here, beside the observations, not in front of those stores)
+    const double rn0 = (ka.post && !ka.rnew_per_step) ? ka.Rnew[0] : 0.0;
     build_powers();
     __syncthreads();      // (the in-tile scans below read the table; the observations are still on their way)
     {
@@ -679,7 +681,6 @@ __global__ __launch_bounds__(NW * 64, TGP_MIN_WAVES(D, NW)) void k_steady_one(co
         TGP_STAMP(10);
         // the variances do not depend on the data: a constant outside the last n1 steps (plus the new noise); written transposed as well
         {
-            const double rn0 = ka.Rnew[0];
             long long n1 = 0;
             if (T - tile_t0 <= (long long)tgp_plan::kTailMax + TILE) {      // (wave-uniform: the last few tiles of the series)
                 wait_tables(ka.flag + 2, ka.seq);
