@@ -287,7 +287,7 @@ template <int TM, int TN> __global__ __launch_bounds__(512) void dk_gemm(const G
 
 // ------------------------------------------------------------------------------------------------ Cholesky of S (n <= 256)
 // lane J (< 16, a compile-time constant after unrolling) of the wave to the lanes 0 .. 31: row_newbcast:J within the first row of 16 lanes, then
-// row_bcast:15 (lane 15 of a row to the next row) into the second -- DPP moves, no v_readlane (which costs 16 cycles a piece on this part)
+// row_bcast:15 (lane 15 of a row to the next row) into the second -- DPP moves (as fast as a v_readlane pair here, no faster: see dk_chol)
 __device__ __forceinline__ double first_row_lane(double v, int j) {
     int lo = __double2loint(v), hi = __double2hiint(v);
 #define DK_BC(J)                                                                   \
@@ -402,9 +402,10 @@ __global__ __launch_bounds__(1024) void dk_chol(const double* __restrict__ S, in
             // (z[k] = W[k][col], starting from the identity): both obey the same recurrence z[c] *= 1 / L[c][c];
             // z[j] -= z[c] L[j][c], so one instruction stream factorises and inverts (lanes 32-63 repeat).  L[j][c] is lane j's z[c] of
             // the FIRST row of lanes: row_newbcast:j spreads it over that row, row_bcast:15 hands it on to the second -- four 32-bit DPP
-            // moves, 16 cycles.  (Round 3 fetched it with a v_readlane pair: 16 cycles EACH on this part, 240 pairs per tile, 7.7K
-            // cycles per tile on the kernel's critical path; broadcast LDS reads: 10.6K.  Rows and columns in the same lanes -- two
-            // moves, two FMAs per value -- need 64 registers here and spill.)
+            // moves.  Measured per tile (scripts/dense_kbench.hip, 5.8K - 10K cycles depending on what the workers on the same SIMD do):
+            // the same as round 3's v_readlane pair + FMA with a scalar operand -- about 40 cycles per (c, j) pair either way, 120 pairs
+            // and 16 pivots per tile; broadcast LDS reads: 10.6K; rows and columns in the SAME lanes (two moves, two FMAs per pair):
+            // 64 registers here, spills.  The chain stays the kernel's critical path.
             double z[16];
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
