@@ -361,6 +361,8 @@ int tgp_shard_steady_finish(tgp_handle* h, const double* gathered_dev, int world
  * TGP_OUT_DEVICE, memory of rank r's device). `missing` may be NULL; with TGP_SHARED_R each Rnew[r] points to
  * one value. devices == NULL: devices 0..ndev-1 (ndev == 0: every visible device). A device listed more than
  * once (several ranks on one GPU: tests) or TGP_MULTI_TRANSPORT=copy replaces RCCL by event-ordered peer copies.
+ * (Tests only: TGP_MULTI_RCCL_LIB names another library with librccl's four entry points, TGP_MULTI_TRANSPORT=rccl asks for the
+ * RCCL branch even when ranks share a device -- tests/stub_rccl.cpp.)
  * Scan engine only (d <= 16, Forward ordering); the dense path (d > 16) does not time-shard.
  * Replaces: the sequential loop of src/util/scan.jl:15-28 behind logpdf (lgssm.jl:147-151) and
  * marginals(posterior(...)) (lgssm.jl:193-200, :111-115) for a series that spans the GPUs of a node. */

@@ -20,6 +20,7 @@
 // Transports of the all-gather: RCCL (ncclAllGather on the rank's stream; librccl is opened at run time, so that a process that already
 // holds an RCCL -- torch -- shares it) when the devices are distinct; peer copies ordered by HIP events ("copy") when a device is
 // listed more than once (ranks sharing a GPU: the single-GPU tests), when RCCL cannot be opened, or with TGP_MULTI_TRANSPORT=copy.
+// (tests/stub_rccl.cpp through TGP_MULTI_RCCL_LIB + TGP_MULTI_TRANSPORT=rccl: the RCCL branch with W > 1 on a box with one GPU.)
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
@@ -47,10 +48,14 @@ struct Rccl {
     int (*AllGather)(const void*, void*, size_t, int, comm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
     bool open(std::string& why) {
-        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
-            lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-            if (lib) break;
-        }
+        // TGP_MULTI_RCCL_LIB: another library with the four entry points (tests/stub_rccl.cpp: W > 1 ranks through the RCCL branch on a
+        // box with one GPU)
+        if (const char* other = std::getenv("TGP_MULTI_RCCL_LIB")) lib = dlopen(other, RTLD_NOW | RTLD_LOCAL);
+        else
+            for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+                lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+                if (lib) break;
+            }
         if (!lib) {
             why = std::string("librccl not found: ") + (dlerror() ? dlerror() : "?");
             return false;
@@ -376,8 +381,9 @@ int tgp_create_multi(tgp_multi** out, int ndev, const int* devices) {
     // transport
     const char* want = std::getenv("TGP_MULTI_TRANSPORT");
     const bool distinct = std::set<int>(m->dev.begin(), m->dev.end()).size() == (size_t)ndev;
+    const bool force_rccl = want != nullptr && std::strcmp(want, "rccl") == 0;      // (ranks that share a device: only a stub library accepts them)
     if (want != nullptr && std::strcmp(want, "copy") == 0) m->transport_note = "copy (TGP_MULTI_TRANSPORT)";
-    else if (!distinct) m->transport_note = "copy (a device is listed more than once)";
+    else if (!distinct && !force_rccl) m->transport_note = "copy (a device is listed more than once)";
     else {
         std::string why;
         if (m->rccl.open(why)) {

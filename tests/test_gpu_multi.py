@@ -258,3 +258,53 @@ def test_slowly_mixing_lti_shards_take_the_scanned_carries(dt, ndev):
     assert abs(lp - lp_ref) <= LOGPDF_RTOL * abs(lp_ref)
     assert np.max(np.abs(mean - pm)) <= MARGINAL_ATOL and np.max(np.abs(var - pv)) <= MARGINAL_ATOL
     assert abs(ms.logpdf(y) - lp_ref) <= LOGPDF_RTOL * abs(lp_ref)
+
+
+@pytest.mark.parametrize("ndev,steady_opt", [(2, 2), (3, 2), (4, 3)])
+def test_rccl_branch_with_several_ranks_through_a_stub_library(ndev, steady_opt, tmp_path):
+    """The RCCL branch of the handle with W > 1 -- one worker thread per rank calling ncclAllGather on its own communicator and stream, no
+    group call -- on a box with one GPU: tests/stub_rccl.cpp stands in for librccl (TGP_MULTI_RCCL_LIB, TGP_MULTI_TRANSPORT=rccl; a
+    subprocess, so that the environment reaches the library's first look at it).  What it checks: the handle's side of the protocol --
+    slots, counts, stream ordering, the fold of the gathered elements -- not RCCL itself."""
+    import os
+    import shutil
+    import subprocess
+    import sys
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc to build the stub library")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    stub = str(tmp_path / "libstub_rccl.so")
+    subprocess.run([hipcc, "-shared", "-fPIC", "-o", stub, os.path.join(root, "tests", "stub_rccl.cpp")], check=True, capture_output=True)
+    code = f"""
+import ctypes, sys
+import numpy as np
+sys.path.insert(0, {root!r})
+import temporalgps_jl_amd as tgp
+from oracle import components as oc
+from oracle import seq_kalman as sk
+from tests.test_gpu_multi import _dev_model, _check
+T = 90_011
+model = oc.build_lgssm(("sum", ("matern52",), ("matern12",)), ("regular", 0.0, 0.1, T), 0.1)
+y = np.random.default_rng(21).standard_normal(T)
+ms = tgp.MultiLGSSM(_dev_model(tgp, model), devices=[0] * {ndev})
+ms.mh.set_option(tgp._lib.OPT_STEADY, {steady_opt})
+assert ms.transport == "rccl", ms.transport
+_check(ms, model, y, np.array([0.05]))
+# a per-step model with missing observations: the general protocol (two all-gathers per call)
+from tests import _util as U
+T2 = 4_001
+m2 = U.random_lgssm(np.random.default_rng(22), True, 2, T2)
+y2 = np.random.default_rng(23).standard_normal(T2)
+mask = np.random.default_rng(24).random(T2) < 0.1
+ms2 = tgp.MultiLGSSM(_dev_model(tgp, m2), devices=[0] * {ndev})
+assert ms2.transport == "rccl", ms2.transport
+_check(ms2, m2, y2, np.array([0.05]), mask=mask)
+calls = ctypes.CDLL({stub!r}).stub_rccl_total_calls()
+print("ncclAllGather calls:", calls)
+assert calls >= 2 * {ndev}, calls
+"""
+    env = dict(os.environ, TGP_MULTI_RCCL_LIB=stub, TGP_MULTI_TRANSPORT="rccl")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert "ncclAllGather calls:" in r.stdout
