@@ -318,6 +318,180 @@ __device__ __forceinline__ void head_backward(const KArgs<D>& ka, const double* 
     }
 }
 
+// ---- the head by SCANS over its steps (d <= 4): a tile of 64 head steps at a time, lane t the affine map of step t -- (P_t, c_t) with
+// P_t = M - db_t fw', c_t = (fb + db_t) u_t + fa forwards, (G_t, c_t r_t) backwards -- composed over the lanes in six levels of DPP moves
+// (rows of 16 by row_shr / row_shl, then across the rows), d^2 + d values moved and d^3 + d^2 FMAs per level: ~400 instructions per
+// 64 steps at d = 3 where the sequential form above spends 64 x 40 and a 64-step dependent chain (12.8 us against ~2).  From d = 5
+// on an element no longer fits the registers the tiles' code leaves (3 (d^2 + d) doubles): those heads stay sequential.
+// new <- mine o neighbour:  P <- P Pn,  c <- P cn + c   (row by row: a row of P is replaced once it has been used)
+template <int D>
+__device__ __forceinline__ void compose_after(double (&P)[D][D], double (&c)[D], const double (&Pn)[D][D], const double (&cn)[D]) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        double row[D], ci = c[i];
+#pragma unroll
+        for (int k = 0; k < D; ++k) row[k] = 0.0;
+#pragma unroll
+        for (int m = 0; m < D; ++m) {
+            ci = fma(P[i][m], cn[m], ci);
+#pragma unroll
+            for (int k = 0; k < D; ++k) row[k] = fma(P[i][m], Pn[m][k], row[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < D; ++k) P[i][k] = row[k];
+        c[i] = ci;
+    }
+}
+// the neighbour's element by one DPP control (lanes without a source, rows outside the mask: the identity), composed into mine
+template <int D, int CTRL, int ROWMASK>
+__device__ __forceinline__ void scan_level(double (&P)[D][D], double (&c)[D], bool has) {
+    double Pn[D][D], cn[D];
+    const double one = has ? 0.0 : 1.0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        cn[i] = dpp_mov<CTRL, ROWMASK>(c[i]);
+#pragma unroll
+        for (int k = 0; k < D; ++k) Pn[i][k] = dpp_mov<CTRL, ROWMASK>(P[i][k]) + (i == k ? one : 0.0);
+    }
+    compose_after<D>(P, c, Pn, cn);
+}
+
+template <int D>
+__device__ __forceinline__ void head_forward_scan(const KArgs<D>& ka, double* __restrict__ sR /*[kHeadMax]*/, int lane, double (&z0out)[D], double& quad) {
+    const double* __restrict__ tb = ka.tab;
+    const int nhs = ka.nhs, n0 = ka.n0;
+    double z0[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) z0[i] = tb[ka.to.mu0 + i];      // (already in modal coordinates: V^-1 (A x0.m + a))
+    double acc = 0.0;
+    for (int t0 = 0; t0 < nhs; t0 += 64) {
+        const int cnt = nhs - t0 < 64 ? nhs - t0 : 64;
+        const bool valid = lane < cnt;
+        const int t = valid ? t0 + lane : t0, ti = t < n0 ? t : n0;
+        const double u = ka.y[t] - ka.hh, is = tb[ka.to.iS + ti];
+        double P[D][D], c[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            const double db = tb[ka.to.db + ti * D + i];
+            c[i] = valid ? fma(ka.fb[i] + db, u, ka.fa[i]) : 0.0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                const double m = (k == i) ? ka.fd[i] : ((k == partner<D>(i)) ? ka.fo[i] : 0.0);
+                P[i][k] = valid ? fma(-db, ka.fw[k], m) : (i == k ? 1.0 : 0.0);
+            }
+        }
+        const int p = lane & 15;
+        scan_level<D, 0x111, 0xF>(P, c, p >= 1);
+        scan_level<D, 0x112, 0xF>(P, c, p >= 2);
+        scan_level<D, 0x114, 0xF>(P, c, p >= 4);
+        scan_level<D, 0x118, 0xF>(P, c, p >= 8);
+        scan_level<D, 0x142, 0xA>(P, c, (lane & 16) != 0);      // rows 1, 3: everything up to the end of the row below
+        scan_level<D, 0x143, 0xC>(P, c, lane >= 32);            // rows 2, 3: everything up to lane 31
+        // the state behind step t, in front of it (the left neighbour's; lane 0: the tile's start state), the innovation
+        double za[D], r = u;
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            double v = c[i];
+#pragma unroll
+            for (int k = 0; k < D; ++k) v = fma(P[i][k], z0[k], v);
+            za[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            const double sh = dpp_mov<0x138>(za[i]);
+            r = fma(-ka.fw[i], lane == 0 ? z0[i] : sh, r);
+        }
+        if (valid) {
+            acc = fma(r * r, is, acc);
+            sR[t0 + lane] = r;
+        }
+#pragma unroll
+        for (int i = 0; i < D; ++i) z0[i] = readlane_d(za[i], cnt - 1);
+    }
+    lds_sync();
+#pragma unroll
+    for (int i = 0; i < D; ++i) z0out[i] = z0[i];
+    quad = readlane_d(wave_sum_to_lane63(acc), 63);
+}
+
+template <int D>
+__device__ __forceinline__ void head_backward_scan(const KArgs<D>& ka, const double* __restrict__ sR, int lane, const double (&zeta)[D]) {
+    constexpr int DD = D * D, ROW = DD + D;
+    const double* __restrict__ tb = ka.tab;
+    const int nhs = ka.nhs, n0 = ka.n0;
+    double lamR[D], h[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) v = fma(tb[ka.to.Wm + i * D + k], zeta[k], v);
+        lamR[i] = v;
+        h[i] = tb[ka.to.h + i];
+    }
+    for (int t0 = ((nhs - 1) >> 6) << 6; t0 >= 0; t0 -= 64) {
+        const int cnt = nhs - t0 < 64 ? nhs - t0 : 64;
+        const bool valid = lane < cnt;
+        const int t = valid ? t0 + lane : t0, ti = t < n0 ? t : n0;
+        const double yt = ka.y[t], rs = tb[ka.to.rS + ti], r = sR[t];
+        const double* __restrict__ rw = tb + ka.to.G + (size_t)t * ROW;      // [G_t | c_t], one row of the packed tables per head step
+        double P[D][D], c[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            c[i] = valid ? rw[DD + i] * r : 0.0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) P[i][k] = valid ? rw[i * D + k] : (i == k ? 1.0 : 0.0);
+        }
+        // suffix scan: lane t <- the steps t .. end of the tile (the neighbour holds the LATER steps, applied first)
+        const int p = lane & 15;
+        scan_level<D, 0x101, 0xF>(P, c, p + 1 < 16);
+        scan_level<D, 0x102, 0xF>(P, c, p + 2 < 16);
+        scan_level<D, 0x104, 0xF>(P, c, p + 4 < 16);
+        scan_level<D, 0x108, 0xF>(P, c, p + 8 < 16);
+        {
+            // rows 0 and 2 take the first lane of the row above them: wave_shl:1 brings it to their lane 15, row_newbcast:15 spreads it
+            double Pn[D][D], cn[D];
+            const double one = (lane & 16) == 0 ? 0.0 : 1.0;
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                cn[i] = dpp_mov<0x15F, 0x5>(dpp_mov<0x130>(c[i]));
+#pragma unroll
+                for (int k = 0; k < D; ++k) Pn[i][k] = dpp_mov<0x15F, 0x5>(dpp_mov<0x130>(P[i][k])) + (i == k ? one : 0.0);
+            }
+            compose_after<D>(P, c, Pn, cn);
+            // the lower half takes lane 32 (complete by now)
+            const bool lower = lane < 32;
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                const double x = readlane_d(c[i], 32);
+                cn[i] = lower ? x : 0.0;
+#pragma unroll
+                for (int k = 0; k < D; ++k) {
+                    const double v = readlane_d(P[i][k], 32);
+                    Pn[i][k] = lower ? v : (i == k ? 1.0 : 0.0);
+                }
+            }
+            compose_after<D>(P, c, Pn, cn);
+        }
+        // lam behind step t (what the steps t .. end make of the tile's right-hand input); in front of it: the right neighbour's
+        double lo[D], m = fma(-rs, r, yt);
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            double v = c[i];
+#pragma unroll
+            for (int k = 0; k < D; ++k) v = fma(P[i][k], lamR[k], v);
+            lo[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            const double sh = dpp_mov<0x130>(lo[i]);
+            m = fma(h[i], lane == 63 ? lamR[i] : sh, m);
+        }
+        if (valid) ka.mean[t0 + lane] = m;
+#pragma unroll
+        for (int i = 0; i < D; ++i) lamR[i] = readlane_d(lo[i], 0);
+    }
+}
+
 // The head's variances: data-independent, the last stage of the tables (read in place from pinned memory: at most kHeadMax values)
 template <int D>
 __device__ __forceinline__ void head_variances(const KArgs<D>& ka, int lane) {
@@ -380,7 +554,7 @@ struct PowerJobs {
 #define TGP_STAMP(k) do { } while (0)
 #endif
 #define TGP_MIN_WAVES(D, NW) ((NW) == 8 ? 4 : 2)
-template <int D, int NW, int SUB>
+template <int D, int NW, int SUB, bool HEAD_SCANS>
 __global__ __launch_bounds__(NW * 64, TGP_MIN_WAVES(D, NW)) void k_steady_one(const KArgs<D> ka_by_value) {
     // The arguments are read where they lie, in the kernel-argument segment (scalar loads, any index): a by-value struct is first copied to a
     // private variable, and one access pattern the optimiser cannot take apart (a run-time index, or identical blocks it merges into one
@@ -392,7 +566,7 @@ __global__ __launch_bounds__(NW * 64, TGP_MIN_WAVES(D, NW)) void k_steady_one(co
     constexpr int CHB = D <= 4 ? 64 : (D <= 6 ? 32 : 16);      // steps of the head's backward recursion staged in LDS at a time (~10 KB)
     __shared__ double sF[NW][D], sB[NW][D], sHead[D], sAcc[NW];
     __shared__ double sR[tgp_plan::kHeadMax];
-    __shared__ __attribute__((aligned(16))) double sTab[CHB * (D * D + D)];
+    __shared__ __attribute__((aligned(16))) double sTab[(HEAD_SCANS && D <= 4) ? 2 : CHB * (D * D + D)];      // (the head as scans: nothing staged)
     __shared__ __attribute__((aligned(16))) double sOut[NW][2 * Row<SUB>::slots];
     // M^(SUB l) (forward) and Mg^(SUB (63 - l)) (backward) for the lanes l of a tile: what carries a tile's start state / right-hand input to
     // its lanes.  The same for every wave: the waves share the building (by the bits of the lane number) between them
@@ -439,7 +613,8 @@ __global__ __launch_bounds__(NW * 64, TGP_MIN_WAVES(D, NW)) void k_steady_one(co
         if (head_wave) {
             double z0[D];
             __builtin_amdgcn_s_setprio(3);      // (the one sequential wave of the launch: ahead of the tiles' waves it shares its SIMD with)
-            head_forward<D>(ka, sR, lane, z0, head_quad);
+            if constexpr (HEAD_SCANS && D <= 4) head_forward_scan<D>(ka, sR, lane, z0, head_quad);
+            else head_forward<D>(ka, sR, lane, z0, head_quad);
             __builtin_amdgcn_s_setprio(0);
             if (lane == 0) {
 #pragma unroll
@@ -725,7 +900,8 @@ __global__ __launch_bounds__(NW * 64, TGP_MIN_WAVES(D, NW)) void k_steady_one(co
         right_input(-1, zin);
         if (lane == 0) ka.part[ka.nwg + 4] = (double)wall_clock64();
         __builtin_amdgcn_s_setprio(3);
-        head_backward<D, CHB>(ka, sR, sTab, lane, zin);
+        if constexpr (HEAD_SCANS && D <= 4) head_backward_scan<D>(ka, sR, lane, zin);
+        else head_backward<D, CHB>(ka, sR, sTab, lane, zin);
         __builtin_amdgcn_s_setprio(0);
         if (lane == 0) ka.part[ka.nwg + 5] = (double)wall_clock64();
         head_variances<D>(ka, lane);
@@ -832,6 +1008,14 @@ const char* kernel_name(const Engine* e, bool post) {
 const tgp_plan::Modal& last_modal(const Engine* e) { return e->md; }
 
 namespace {
+static bool head_scans_enabled() {      // TGP_MODAL_HEAD_SCANS=0: the sequential head everywhere (A/B runs)
+    static const bool on = [] {
+        const char* v = std::getenv("TGP_MODAL_HEAD_SCANS");
+        return !(v && v[0] == '0');
+    }();
+    return on;
+}
+
 template <int D>
 int launch(Engine* e, hipStream_t st, const Call& c, const char** kname) {
     KArgs<D> ka;
@@ -872,8 +1056,15 @@ int launch(Engine* e, hipStream_t st, const Call& c, const char** kname) {
     const long long per = (e->nwg_local + 7) / 8;
     const unsigned grid = (unsigned)(per * 8);
     *kname = kernel_name(e, ka.post != 0);
-    if (nw == 8) hipLaunchKernelGGL((k_steady_one<D, 8, 8>), dim3(grid), dim3(8 * 64), 0, st, ka);
-    else hipLaunchKernelGGL((k_steady_one<D, 16, 8>), dim3(grid), dim3(16 * 64), 0, st, ka);
+    // the head as scans (d <= 4) needs ~30 more registers per lane than the tiles' code: taken where the launch leaves the CUs room anyway
+    // (at most two workgroups per CU: every series up to ~2e6 steps -- there the head IS the call), not where occupancy is the kernel's time
+    const bool head_scans = D <= 4 && e->owns_head && e->nwg_local <= 512 && head_scans_enabled();
+    if (nw == 8) {
+        if (head_scans) hipLaunchKernelGGL((k_steady_one<D, 8, 8, (D <= 4)>), dim3(grid), dim3(8 * 64), 0, st, ka);
+        else hipLaunchKernelGGL((k_steady_one<D, 8, 8, false>), dim3(grid), dim3(8 * 64), 0, st, ka);
+    } else {
+        hipLaunchKernelGGL((k_steady_one<D, 16, 8, false>), dim3(grid), dim3(16 * 64), 0, st, ka);
+    }
     return (int)hipGetLastError();
 }
 }  // namespace
