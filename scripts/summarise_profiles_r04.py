@@ -36,7 +36,7 @@ def short(name):
 def label(name):
     """rocprof kernel name -> bench.py profile label (None: not one of the engine's kernels)"""
     n = short(name)
-    m = re.match(r"tgp_modal::k_steady_one<(\d+), (\d+), (\d+)>", n)
+    m = re.match(r"tgp_modal::k_steady_one<(\d+), (\d+), (\d+)(?:, \w+)?>", n)
     if m:      # (logpdf and posterior calls run the same kernel: the bench step is the posterior call)
         return f"k_steady_one<{m.group(2)}x{m.group(3)},posterior>"
     m = re.match(r"tgp_steady::k_(reduce|carry|apply)<(\d+), (true|false)>", n)
