@@ -863,6 +863,16 @@ __global__ __launch_bounds__(NW * 64, TGP_MIN_WAVES(D, NW)) void k_steady_one(co
             }
             const double* __restrict__ tvb = ka.htab + ka.to.tvb;      // (in place from pinned memory: the last few tiles, a handful of values)
             const bool aligned = (reinterpret_cast<uintptr_t>(ka.var) & 15) == 0 && (!ka.rnew_per_step || (reinterpret_cast<uintptr_t>(ka.RnewT) & 15) == 0);
+            // (wave-uniform: a tile inside the workgroup's range, away from the series' end, one shared new noise -- nearly every tile: one constant)
+            const bool plain = aligned && !ka.rnew_per_step && n1 == 0 && tile_t0 >= c_lo && tile_t0 + TILE <= c_hi;
+            if (plain) {
+                v2d w;
+                w.x = ka.vb + rn0;
+                w.y = w.x;
+                v2d* q = reinterpret_cast<v2d*>(ka.var + tile_t0);
+#pragma unroll
+                for (int k = 0; k < SUB / 2; ++k) store_pair(q + k * 64 + lane, w);
+            } else
 #pragma unroll
             for (int k = 0; k < SUB / 2; ++k) {
                 const long long t = tile_t0 + 2 * (k * 64 + lane);
