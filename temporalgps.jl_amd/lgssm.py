@@ -301,8 +301,13 @@ def _obs(y, model=None, lazy_nan=False):
     for CUDA tensors pass a (y, mask) tuple). Vector observations: y (T, p); a (T,) mask marks whole steps.
     lazy_nan: a large scalar-output host series is NOT scanned for NaNs here (the scan costs more than its PCIe transfer: ~2-10 ms per
     1e7 values); a NaN reaches the device, comes back as a NaN log-likelihood, and the caller then calls again without lazy_nan
-    (`_lazy_obs_call`). _obs.unchecked tells the caller whether the scan was skipped."""
-    _obs.unchecked = False
+    (`_lazy_obs_call`). With lazy_nan the result has a fourth element: whether the scan was skipped."""
+    if lazy_nan:
+        return _obs_impl(y, model, True)
+    return _obs_impl(y, model, False)[:3]
+
+
+def _obs_impl(y, model, lazy_nan):
     mask = None
     if isinstance(y, tuple):
         y, mask = y
@@ -321,7 +326,7 @@ def _obs(y, model=None, lazy_nan=False):
         yy = torch.matmul(Linv, yy[..., None])[..., 0].contiguous()
         mk = None if mm is None else mm[:, None].expand(model.T, model.p).to(torch.uint8).contiguous()
         _sync_torch(yy)
-        return (yy if model.p > 1 else yy.reshape(model.T)), (mk if (mk is None or model.p > 1) else mk.reshape(model.T)), True
+        return (yy if model.p > 1 else yy.reshape(model.T)), (mk if (mk is None or model.p > 1) else mk.reshape(model.T)), True, False
     if model is not None and (model.p > 1 or model._whiten is not None) and not (_is_torch(y) and y.is_cuda):
         yy = np.array(_to_numpy(y), dtype=np.float64)
         if model.p == 1 and yy.shape == (model.T,):
@@ -339,31 +344,30 @@ def _obs(y, model=None, lazy_nan=False):
         yy = np.ascontiguousarray(np.where(mk, 0.0, yy))
         if model.p == 1:
             yy, mk = yy.reshape(model.T), mk.reshape(model.T)
-        return yy, (np.ascontiguousarray(mk.astype(np.uint8)) if mk.any() else None), False
+        return yy, (np.ascontiguousarray(mk.astype(np.uint8)) if mk.any() else None), False, False
     if _is_torch(y) and y.is_cuda:
         import torch
         yy = y.to(torch.float64).contiguous()
         mm = None if mask is None else mask.to(torch.uint8).contiguous()
         _sync_torch(yy)
-        return yy, mm, True
+        return yy, mm, True, False
     if isinstance(y, np.ma.MaskedArray):
         mask = np.ma.getmaskarray(y) if mask is None else mask
         y = y.filled(0.0)
     yy = np.ascontiguousarray(_to_numpy(y), dtype=np.float64)
     if mask is None and lazy_nan and yy.size >= _LAZY_NAN_MIN:
-        _obs.unchecked = True
-        return yy, None, False
+        return yy, None, False, True
     if mask is None and np.isnan(yy).any():
         mask = np.isnan(yy)
     mm = None if mask is None else np.ascontiguousarray(_to_numpy(mask).astype(np.uint8))
-    return yy, mm, False
+    return yy, mm, False, False
 
 
 def _lazy_obs_call(model, y, call):
     """call(yy, mm, dev) -> (lml, result). Large host series go to the device unscanned; a NaN log-likelihood (or a not-positive-
     definite report a NaN can cause) brings the NaN == missing scan back and, if it finds any, the call is repeated with the mask."""
-    yy, mm, dev = _obs(y, model, lazy_nan=True)
-    if not _obs.unchecked:
+    yy, mm, dev, unchecked = _obs(y, model, lazy_nan=True)
+    if not unchecked:
         return call(yy, mm, dev)[1]
     try:
         lml, res = call(yy, mm, dev)

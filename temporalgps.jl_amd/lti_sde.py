@@ -768,10 +768,11 @@ def _logpdf_and_gradient_fd(fx, y, rel_step=1e-4):
     divided by 2 h balance around h = 1e-4 |v|). The step is RELATIVE to the parameter (never larger than half of it), so that a
     small positive parameter -- a noise variance of 1e-6 -- is never evaluated at a negative value; whatever happens in an
     evaluation, the perturbed attribute is restored."""
-    if fx.sigma2.shape[0] != 1:
-        raise NotImplementedError("logpdf_and_gradient: heteroscedastic noise needs per-step tangents; use equal noise variances")
+    # heteroscedastic noise (one variance per observation): the kernel's and the mean's parameters are differenced as always; there is no
+    # single "noise" parameter, so that entry is left out (T per-step derivatives are not what a hyper-parameter search asks for)
+    shared_noise = fx.sigma2.shape[0] == 1
     plist = parameters(fx.f.f.kernel)
-    entries = list(plist) + [("noise", None, None)] + ([("mean.c", fx.f.f.mean, "c")] if isinstance(fx.f.f.mean, ConstMean) else [])
+    entries = list(plist) + ([("noise", None, None)] if shared_noise else []) + ([("mean.c", fx.f.f.mean, "c")] if isinstance(fx.f.f.mean, ConstMean) else [])
     lp = logpdf(fx, y)
     grad = {}
 
@@ -817,7 +818,9 @@ def logpdf_and_gradient(fx, y, rel_step=None, method=None):
     or "fd" (central differences of the device logpdf).
     Default: the adjoint pass where it applies, else tangent scans up to state dimension 8; from d = 9 (e.g. ApproxPeriodicKernel, d = 14) the dual-number kernels are
     out-of-line private-memory code (d = 14, T = 2e5: 2.4 s for 4 parameters against 5.7 ms per logpdf), so central differences
-    of the logpdf -- 9 evaluations on the group kernels, ~50 ms, relative accuracy ~1e-7 -- are used instead."""
+    of the logpdf -- 9 evaluations on the group kernels, ~50 ms, relative accuracy ~1e-7 -- are used instead.
+    Heteroscedastic noise (one variance per observation) on the "fd" route: the kernel's and the mean's parameters only -- there is no
+    single noise parameter to differentiate, the result has no "noise" entry."""
     if method not in (None, "tangent", "fd", "adjoint"):
         raise ValueError("method must be None, 'adjoint', 'tangent' or 'fd'")
     if method == "adjoint" or (method is None and isinstance(fx.x, RegularSpacing) and fx.sigma2.shape[0] == 1

@@ -160,10 +160,20 @@ class MultiLGSSM:
         if mask is not None:
             if dev:
                 import torch
+                if len(mask) != self.W:
+                    raise ValueError(f"mask: one CUDA tensor per rank ({self.W}), got {len(mask)}")
                 mk = [m.to(torch.uint8).contiguous() for m in mask]
+                for r, m in enumerate(mk):
+                    if m.numel() != (self.bounds[r][1] - self.bounds[r][0]) * self.p:
+                        raise ValueError(f"mask of rank {r}: {m.numel()} values for a segment of {self.bounds[r][1] - self.bounds[r][0]} steps x {self.p}")
                 mptrs = [m.data_ptr() for m in mk]
             else:
-                mk = np.ascontiguousarray(np.asarray(L._to_numpy(mask)).astype(np.uint8))
+                mk = np.asarray(L._to_numpy(mask)).astype(np.uint8)
+                if self.p > 1 and mk.shape == (self.T,):      # a whole-step mask of vector observations (as lgssm._obs accepts it)
+                    mk = np.repeat(mk[:, None], self.p, axis=1)
+                if mk.size != self.T * self.p:
+                    raise ValueError(f"mask: {mk.size} values for a series of {self.T} steps x {self.p}")
+                mk = np.ascontiguousarray(mk)
                 mptrs = [mk.ctypes.data + self.bounds[r][0] * self.p for r in range(self.W)]
         return (keep, mk), ptrs, mptrs, dev
 
@@ -173,7 +183,7 @@ class MultiLGSSM:
             keep, ptrs, _ = self._split(R_new, 0 if shared else self.p, "R_new")
             return keep, ptrs, shared
         arr = np.ascontiguousarray(np.asarray(L._to_numpy(R_new), dtype=np.float64)).reshape(-1)
-        shared = arr.size == self.p
+        shared = arr.size == self.p and not (self.T == 1 and np.ndim(R_new) > 1 + (self.p > 1))      # (T == 1: a per-step array says so by its leading axis)
         if dev:      # a host scalar with device observations: one copy per rank
             import torch
             keep = [torch.as_tensor(arr, device=f"cuda:{self.devices[r]}") for r in range(self.W)]

@@ -51,7 +51,7 @@ def gp_case(k, t, s2, seed, mean=None):
     return model, ref.rand(model, *eps), eps
 
 
-def random_lgssm(rng, tv, d, T, ordering="F"):
+def random_lgssm(rng, tv, d, T, ordering="F", tame_reverse=False):
     """test/models/model_test_utils.jl:163-263 (scalar-output variants), stable transitions."""
     def psd(n, lo, hi):
         U = np.linalg.qr(rng.standard_normal((n, n)))[0]
@@ -63,7 +63,8 @@ def random_lgssm(rng, tv, d, T, ordering="F"):
     a = rng.standard_normal((n, d))
     Q = np.stack([psd(d, 0.2, 1.5) for _ in range(n)])
     H, h, R = rng.standard_normal((n, d)), rng.standard_normal(n), rng.random(n) + 0.1
-    if ordering == "R":
+    if ordering == "R" and tame_reverse:
+        # (asked for by the one test that runs the POSTERIOR of a Reverse model forward; the other Reverse tests keep the plain draw)
         # step_posterior(::Reverse) (lgssm.jl:223-228) calls invert_dynamics with predicted and filtered state swapped: its G is
         # (A Pf A' + Q) A' Pf^-1, contractive only for weak transitions and weakly informative observations. Models are drawn there, so
         # that the posterior of a Reverse model can be run forward over hundreds of steps without overflow (in the oracle as well).

@@ -358,7 +358,7 @@ def test_posterior_of_a_reverse_ordered_model(tgp, tv, d):
     transitions come from invert_dynamics(xp, xf, t) and whose x0 is the state after the last step's predict."""
     rng = np.random.default_rng(500 + d + 50 * tv)
     T = 777
-    model = U.random_lgssm(rng, tv, d, T, "R")
+    model = U.random_lgssm(rng, tv, d, T, "R", tame_reverse=True)
     y = rng.standard_normal(T)
     post = ref.posterior(model, y)
     dm = to_device_model(tgp, model)
@@ -372,7 +372,7 @@ def test_posterior_of_a_reverse_ordered_model(tgp, tv, d):
         np.testing.assert_allclose(dpost.x0.m, post["x0m"], rtol=1e-8, atol=1e-9)
         np.testing.assert_allclose(dpost.x0.P, post["x0P"], rtol=1e-8, atol=1e-9)
     # the reference's chain on it: marginals(replace_observation_noise_cov(posterior(reverse_model, y), R)) (evaluated route), against the
-    # ORACLE's posterior model (U.random_lgssm draws Reverse models whose posterior transitions are contractive: nothing overflows)
+    # ORACLE's posterior model (tame_reverse: a Reverse model whose posterior transitions are contractive, nothing overflows)
     Rn = rng.random(T) * 0.1
     dpost = tgp.posterior(dm, y)
     pm, pv = ref.marginals(ref.replace_observation_noise_cov(post, Rn))
