@@ -117,35 +117,38 @@ __device__ __forceinline__ void load_lane(const KArgs<D>& ka, long long t0, doub
 // A wave's tile of 64 SUB consecutive output values, SUB per lane, leaves through the wave's own LDS row: lane l's SUB / 2 pairs go in at
 // 16-byte slots PPL l + l PPL / 16 + j (the pad keeps the 128-bit writes of sixteen lanes on distinct banks) and come out transposed, so that
 // every store instruction writes 1 KB of consecutive bytes (as k_apply of tgp_steady.hip).  [lo, hi): the steps this workgroup owns.
+// The row holds HALF a tile (the values of 32 lanes: 2 KB + padding); a tile leaves in two rounds -- the LDS a full row would take
+// (35 KB per workgroup) cost a workgroup per CU at d = 2, 4 (and would at d = 3 once its registers fit four).
 template <int SUB>
 struct Row {
     static constexpr int PPL = SUB / 2;                  // pairs per lane
-    static constexpr int slots = PPL * 68;               // 16-byte slots of a row
-    __device__ static __forceinline__ int lane_slot(int lane) { return PPL * lane + lane * PPL / 16; }
-    __device__ static __forceinline__ int pair_slot(int e) {      // pair e of the tile (time order)
+    static constexpr int slots = PPL * 34;               // 16-byte slots of a row: the pairs of 32 lanes, padded
+    __device__ static __forceinline__ int lane_slot(int l32) { return PPL * l32 + l32 * PPL / 16; }      // l32: the lane within its half
+    __device__ static __forceinline__ int pair_slot(int e) {      // pair e of the half tile (time order)
         const int ls = e / PPL;
         return PPL * ls + ls * PPL / 16 + e % PPL;
     }
 };
 __device__ __forceinline__ void store_pair(v2d* q, const v2d w) { *q = w; }      // (non-temporal stores: measured, no difference)
+// half_t0: the first step of the half tile in the row
 template <int SUB>
-__device__ __forceinline__ void flush_row(double* __restrict__ p, long long tile_t0, long long lo, long long hi, const v2d* r2, int lane) {
-    constexpr int TILE = 64 * SUB;
+__device__ __forceinline__ void flush_row(double* __restrict__ p, long long half_t0, long long lo, long long hi, const v2d* r2, int lane) {
+    constexpr int HALF = 32 * SUB;
     const bool aligned = (reinterpret_cast<uintptr_t>(p) & 15) == 0;
-    if (tile_t0 >= lo && tile_t0 + TILE <= hi && aligned) {      // (wave-uniform)
-        v2d* q = reinterpret_cast<v2d*>(p + tile_t0);
+    if (half_t0 >= lo && half_t0 + HALF <= hi && aligned) {      // (wave-uniform)
+        v2d* q = reinterpret_cast<v2d*>(p + half_t0);
 #pragma unroll
-        for (int k = 0; k < SUB / 2; ++k) {
+        for (int k = 0; k < SUB / 4; ++k) {
             const int e = k * 64 + lane;
             store_pair(q + e, r2[Row<SUB>::pair_slot(e)]);
         }
         return;
     }
 #pragma unroll
-    for (int k = 0; k < SUB / 2; ++k) {
+    for (int k = 0; k < SUB / 4; ++k) {
         const int e = k * 64 + lane;
         const v2d w = r2[Row<SUB>::pair_slot(e)];
-        const long long t = tile_t0 + 2 * e;
+        const long long t = half_t0 + 2 * e;
         if (t >= lo && t + 1 < hi && aligned) {
             store_pair(reinterpret_cast<v2d*>(p + t), w);
         } else {
@@ -553,9 +556,13 @@ struct PowerJobs {
 #else
 #define TGP_STAMP(k) do { } while (0)
 #endif
-#define TGP_MIN_WAVES(D, NW) ((NW) == 8 ? 4 : 2)
+// waves per SIMD the register allocation is held to (a workgroup of 8 waves puts two on each SIMD): d <= 2 fit four workgroups per CU as they
+// are (64 registers), d = 3, 4 are held to three; beyond, what the code needs (d = 5 would spill at 80).  Measured with the half rows that
+// freed the LDS for it: a fourth workgroup at d = 2 and a third at d = 4 change nothing -- in its steady state the kernel moves ~6 TB/s,
+// what a copy reaches; its time at T = 1e7 is that plus the ramps at both ends
+#define TGP_MIN_WAVES(D, NW, HS) ((NW) == 8 ? ((HS) ? 4 : (((D) == 3 || (D) == 4) ? 6 : 4)) : 2)
 template <int D, int NW, int SUB, bool HEAD_SCANS>
-__global__ __launch_bounds__(NW * 64, TGP_MIN_WAVES(D, NW)) void k_steady_one(const KArgs<D> ka_by_value) {
+__global__ __launch_bounds__(NW * 64, TGP_MIN_WAVES(D, NW, HEAD_SCANS)) void k_steady_one(const KArgs<D> ka_by_value) {
     // The arguments are read where they lie, in the kernel-argument segment (scalar loads, any index): a by-value struct is first copied to a
     // private variable, and one access pattern the optimiser cannot take apart (a run-time index, or identical blocks it merges into one
     // with the offsets in a phi) leaves the whole 3 KB struct in scratch memory -- 20 x the kernel's time, from one build to the next
@@ -835,24 +842,32 @@ __global__ __launch_bounds__(NW * 64, TGP_MIN_WAVES(D, NW)) void k_steady_one(co
 #pragma unroll
         for (int i = 0; i < D; ++i) zst[i] = fma(sPw[1][0][i][lane], zin[i], fma(sPw[1][1][i][lane], zin[partner<D>(i)], zst[i]));
         v2d* row = reinterpret_cast<v2d*>(sOut[wave]);
-        const int wb = Row<SUB>::lane_slot(lane);
+        const int wb = Row<SUB>::lane_slot(lane & 31);
         // the lam behind the lane's last step reaches step j through Mg^(SUB - 1 - j): WG holds gw' Mg^(7 - j)
 #pragma unroll
-        for (int j = 0; j < SUB; j += 2) {
-            double m0 = yv[j], m1 = yv[j + 1];
+        for (int j = 0; j < SUB; ++j) {
+            double m = yv[j];
 #pragma unroll
-            for (int i = 0; i < D; ++i) {
-                m0 = fma(ka.WG[j][i], zst[i], m0);
-                m1 = fma(ka.WG[j + 1][i], zst[i], m1);
-            }
-            v2d w;
-            w.x = m0;
-            w.y = m1;
-            row[wb + (j >> 1)] = w;
+            for (int i = 0; i < D; ++i) m = fma(ka.WG[j][i], zst[i], m);
+            yv[j] = m;
         }
         TGP_STAMP(9);
-        lds_sync();
-        flush_row<SUB>(ka.mean, tile_t0, c_lo, c_hi, row, lane);
+        // out through the wave's LDS row, half a tile at a time (the lower 32 lanes' values, then the upper 32's)
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            if ((lane >> 5) == half) {
+#pragma unroll
+                for (int j = 0; j < SUB; j += 2) {
+                    v2d w;
+                    w.x = yv[j];
+                    w.y = yv[j + 1];
+                    row[wb + (j >> 1)] = w;
+                }
+            }
+            lds_sync();
+            flush_row<SUB>(ka.mean, tile_t0 + half * (TILE / 2), c_lo, c_hi, row, lane);
+            lds_sync();
+        }
         TGP_STAMP(10);
         // the variances do not depend on the data: a constant outside the last n1 steps (plus the new noise); written transposed as well
         {
