@@ -129,7 +129,7 @@ struct Row {
         return PPL * ls + ls * PPL / 16 + e % PPL;
     }
 };
-__device__ __forceinline__ void store_pair(v2d* q, const v2d w) { *q = w; }      // (non-temporal stores: measured, no difference)
+__device__ __forceinline__ void store_pair(v2d* q, const v2d w) { *q = w; }      // (non-temporal and write-through (sc0 sc1) stores: measured, no difference)
 // half_t0: the first step of the half tile in the row
 template <int SUB>
 __device__ __forceinline__ void flush_row(double* __restrict__ p, long long half_t0, long long lo, long long hi, const v2d* r2, int lane) {
