@@ -204,3 +204,31 @@ def test_prior_marginals_of_an_lti_model_are_a_head_and_a_constant(tgp, d, order
         assert names == {"k_fill_marginals<lti>"}, names
         rm, rv = ref.marginals(dict(gp, T=2000))
         assert np.max(np.abs(pm[:2000] - rm)) <= 1e-10 and np.max(np.abs(pv[:2000] - rv)) <= 1e-10 and np.ptp(pv[100:]) <= 1e-12
+
+
+def test_both_forms_of_the_head_for_small_state_dimensions():
+    """d <= 4 and at most 512 workgroups: the head runs as scans over its steps (the kernel's second instantiation); longer series keep the
+    sequential head.  Both against the oracle on the same short series -- the sequential form through TGP_MODAL_HEAD_SCANS=0 in a
+    process of its own (the library reads the variable once) --, and a long head (slow covariance: several 64-step tiles of scans)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = f"""
+import sys
+import numpy as np
+sys.path.insert(0, {root!r})
+import temporalgps_jl_amd as tgp
+from oracle import components as oc
+from tests.test_gpu_modal import KERNELS, check, draw
+for d in (1, 2, 3, 4):
+    for T, dt, noise in ((3000, 0.1, 0.1), (20011, 0.02, 0.003)):
+        model = oc.build_lgssm(KERNELS[d], ("regular", 0.0, dt, T), noise)
+        y = draw(model, 400 + d)
+        check(tgp, model, y, np.random.default_rng(d).random(T) + 0.01, T, expect_one=False)
+print("checked")
+"""
+    for scans in ("1", "0"):
+        env = dict(os.environ, TGP_MODAL_HEAD_SCANS=scans)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+        assert r.returncode == 0 and "checked" in r.stdout, (scans, (r.stdout + r.stderr)[-3000:])
