@@ -394,10 +394,86 @@ __global__ __launch_bounds__(1024) void dk_chol(const double* __restrict__ S, in
         __builtin_amdgcn_s_setprio(3);
         const int idx = lane & 15;
         const bool is_w = (lane & 16) != 0;
+        (void)idx;
+        (void)is_w;
         int notpd = 0;
         for (int kb = 0; kb < nt; ++kb) {
             wait_ge(&flag_d, kb + 1);
             DK_STAMP(0);
+#ifndef DK_CHAIN_SCALAR
+            // Blocked by 4 columns, the tile in the MFMA accumulator layout it arrives in (t[r], lane l: T[row l & 15][col (l >> 4) + 4 r]):
+            // REGISTER p of that layout IS the panel of columns 4p .. 4p + 3 as an MFMA operand (lane l: row l & 15, k = l >> 4) -- both
+            // operands of the rank-4 update of the columns to its right, and the B operand of W_pp X' that turns the panel into L's columns.
+            // Per panel: the 4 x 4 diagonal block to every lane (one LDS round trip), its Cholesky factor and inverse as uniform arithmetic
+            // (four v_rsq chains), then four MFMAs: the panel, the trailing update, and the same two eliminations applied to W = L^-1
+            // (kept in the D layout: w[r], lane l: W[(l >> 4) + 4 r][l & 15], from the identity).  Measured (scripts/dense_kbench.hip): 4.6K
+            // cycles per tile with the workers idle, 5.2 - 7.7K beside their MFMAs, where the scalar recurrence over all 16 columns (below,
+            // -DDK_CHAIN_SCALAR: 120 broadcast-and-update pairs per tile) takes 5.8K / 7 - 10.6K; the factorisation 68.7 -> 65.4 us -- the
+            // workers' solve + urgent update + hand-over between two diagonal tiles (2 - 8K cycles) is now as long as the chain.
+            d4 t, wv;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                t[r] = dtile[r * 64 + lane];
+                wv[r] = ((lane >> 4) + 4 * r == (lane & 15)) ? 1.0 : 0.0;
+            }
+            const int row = lane & 15, grp = lane >> 4;
+            double* sx = dtile;      // (free until the next diagonal tile is handed over, which waits for this panel's flag)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const double x = t[p];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                sx[lane] = x;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const double* q = sx + 4 * p;      // D[a][b] = T[4p + a][4p + b] = sx[16 b + 4p + a]
+                const double D00 = q[0], D10 = q[1], D20 = q[2], D30 = q[3], D11 = q[17], D21 = q[18], D31 = q[19], D22 = q[34], D32 = q[35], D33 = q[51];
+                // Cholesky of the 4 x 4 block (1 / L[a][a] = rsqrt(pivot)) and its inverse, the same in every lane
+                const double r0 = rsqrt_fast(D00), l10 = D10 * r0, l20 = D20 * r0, l30 = D30 * r0;
+                const double p1 = fma(-l10, l10, D11), r1 = rsqrt_fast(p1), l21 = fma(-l20, l10, D21) * r1, l31 = fma(-l30, l10, D31) * r1;
+                const double p2 = fma(-l21, l21, fma(-l20, l20, D22)), r2 = rsqrt_fast(p2), l32 = fma(-l31, l21, fma(-l30, l20, D32)) * r2;
+                const double p3 = fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, D33))), r3 = rsqrt_fast(p3);
+                notpd |= !(D00 > 0.0) | !(p1 > 0.0) | !(p2 > 0.0) | !(p3 > 0.0);
+                const double w10 = -(l10 * r0) * r1, w21 = -(l21 * r1) * r2, w32 = -(l32 * r2) * r3;
+                const double w20 = -fma(l21, w10, l20 * r0) * r2, w31 = -fma(l32, w21, l31 * r1) * r3;
+                const double w30 = -fma(l32, w20, fma(l31, w10, l30 * r0)) * r3;
+                // W_pp as the A operand of a 16 x 16 x 4 product: lane l holds A[I = l & 15][k = l >> 4], zero outside the 4 x 4 lower triangle
+                double wp = 0.0;
+                {
+                    const double c0 = row == 0 ? r0 : (row == 1 ? w10 : (row == 2 ? w20 : w30));
+                    const double c1 = row == 1 ? r1 : (row == 2 ? w21 : w31);
+                    const double c2 = row == 2 ? r2 : w32;
+                    const double v = grp == 0 ? c0 : (grp == 1 ? c1 : (grp == 2 ? c2 : r3));
+                    wp = (row < 4 && grp <= row) ? v : 0.0;
+                }
+                // the panel: L[:, 4p + g] = X W_pp' -- as (W_pp X')', which lands in register 0 in the operand layout again
+                const d4 zero4 = d4{0.0, 0.0, 0.0, 0.0};
+                const double lp = mfma_f64(wp, x, zero4)[0];
+                const int col = 4 * p + grp;
+                const double lm = row >= col ? lp : 0.0;            // L is lower triangular (rows above: what earlier updates left there)
+                t[p] = lm;
+                if (p < 3) {
+                    const d4 u = mfma_f64(-lm, lm, t);                 // T[:, > 4p + 3] -= L_p L_p'
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (r > p) t[r] = u[r];
+                }
+                // W <- L_p^-1 W: its rows 4p .. 4p + 3 times W_pp, then the rows below minus L[below, panel] times those
+                wv[p] = mfma_f64(wp, wv[p], zero4)[0];
+                if (p < 3) {
+                    const double lb = row > 4 * p + 3 ? lp : 0.0;
+                    wv = mfma_f64(-lb, wv[p], wv);
+                }
+                if (lane < 4) dg[kb * 16 + 4 * p + lane] = lane == 0 ? D00 : (lane == 1 ? p1 : (lane == 2 ? p2 : p3));
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                L[(kb * 16 + row) + (int64_t)(kb * 16 + grp + 4 * r) * ldL] = t[r];
+                winv[kb & 1][row * 16 + grp + 4 * r] = wv[r];      // W[k = grp + 4 r][col = row] at [k' = col][row' = k]
+                Dinv[kb * 256 + row * 16 + grp + 4 * r] = wv[r];
+            }
+#else
             // Lanes 0-15 hold one ROW of the tile each (z[k] = T[row][k]); lanes 16-31 hold one COLUMN of W = L_kk^-1 each
             // (z[k] = W[k][col], starting from the identity): both obey the same recurrence z[c] *= 1 / L[c][c];
             // z[j] -= z[c] L[j][c], so one instruction stream factorises and inverts (lanes 32-63 repeat).  L[j][c] is lane j's z[c] of
@@ -441,6 +517,7 @@ __global__ __launch_bounds__(1024) void dk_chol(const double* __restrict__ S, in
                     Dinv[kb * 256 + idx * 16 + k] = z[k];
                 }
             }
+#endif
             DK_STAMP(1);
             publish(&flag_w, kb + 1);
         }
