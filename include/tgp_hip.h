@@ -290,7 +290,9 @@ int tgp_posterior_marginals_at(tgp_handle* h, const double* y, const uint8_t* mi
 int tgp_marginals(tgp_handle* h, uint32_t flags, double* mean_out, double* var_out);
 
 /* ---- rand(rng, model) with the randomness supplied: lgssm.jl:65-91, lgc.jl:84-87,241-243,
- *      gaussian.jl:35-43. eps_t [T][d], eps_e [T], eps_0 [d] (eps_0 always host). y_out [T]. */
+ *      gaussian.jl:35-43. eps_t [T][d], eps_e [T], eps_0 [d] (eps_0 always host). y_out [T].
+ *      A Forward LTI model (every block shared) with scalar observations and d <= 6 runs as ONE kernel over the draws
+ *      (TGP_OPT_STEADY = 3, the default); everything else on the general engine's affine scan. */
 int tgp_rand(tgp_handle* h, const double* eps_t, const double* eps_e, const double* eps_0, uint32_t flags,
              double* y_out);
 

@@ -2437,7 +2437,7 @@ int tgp_marginals(tgp_handle* h, uint32_t flags, double* mean_out, double* var_o
 }
 
 int tgp_rand(tgp_handle* h, const double* eps_t, const double* eps_e, const double* eps_0, uint32_t flags, double* y_out) {
-    TRY(check_ready(h));
+    TRY(check_ready(h, /*general=*/false));
     if (!eps_t || !eps_e || !eps_0 || !y_out) return h->fail(TGP_EINVAL, "null eps / output");
     const bool idev = (flags & TGP_IN_DEVICE) != 0, odev = (flags & TGP_OUT_DEVICE) != 0;
     const size_t nT = (size_t)h->T * h->p * sizeof(double);   // one value per (time step, observation)
@@ -2462,6 +2462,31 @@ int tgp_rand(tgp_handle* h, const double* eps_t, const double* eps_e, const doub
         x0[i] = h->x0m[i] + acc;
     }
     CallTimer tm(h);
+    // LTI, Forward, scalar observations, d <= 6: ONE kernel over the draws on the dense powers of the transition (tgp_modal::rand_lti)
+    if (!h->is_dense && h->opt_modal && h->lti && h->p == 1 && h->ordering == 0 && !h->sde && d <= tgp_plan::kRandMaxD && !h->hostm.empty()) {
+        tgp_plan::ModelHost mh;
+        tgp_plan::RandPlan rp;
+        if (modal_host_model(h, mh)) {
+            tgp_plan::build_rand_any(mh, rp);
+            if (rp.why == tgp_plan::kOk && h->T >= 2) {
+                const void *pet = nullptr, *pee = nullptr;
+                TRY(stage_in(h, h->beps_t, eps_t, (size_t)h->T * d * sizeof(double), idev, &pet));
+                TRY(stage_in(h, h->beps_e, eps_e, nT, idev, &pee));
+                tm.inputs_done();
+                double* dy = nullptr;
+                TRY(stage_out(h, h->bo1, y_out, nT, odev, &dy));
+                {
+                    LaunchScope ls(h, "k_rand_one");
+                    const int rc = tgp_modal::rand_lti(h->stream, rp, x0.data(), (const double*)pet, (const double*)pee, h->T, dy, nullptr);
+                    if (rc != 0) return h->fail(TGP_EHIP, std::string("tgp_rand: launch: ") + hipGetErrorString((hipError_t)rc));
+                }
+                tm.kernels_done();
+                TRY(copy_back(h, y_out, dy, nT, odev));
+                return tm.finish();
+            }
+        }
+    }
+    resolve_table(h);
     if (h->is_dense) {
         const void *pet_d = nullptr, *pee_d = nullptr;
         TRY(stage_in(h, h->beps_t, eps_t, (size_t)h->T * d * sizeof(double), idev, &pet_d));

@@ -1338,4 +1338,286 @@ double finish(const Engine* e, long long T) {
     return -0.5 * ((double)T * kLog2Pi + logdet + quad);
 }
 
+// =================================================================================================================================
+// rand of an LTI model (lgssm.jl:65-91, the draws supplied): x_t = A x_{t-1} + a + Lq eps_t,  y_t = h' x_t + hh + sqrt(R) eta_t.
+// The same one-launch structure as k_steady_one, forwards only and on DENSE powers (the open-loop transition of a Matern-3/2 / -5/2 block is
+// a Jordan block: no modal form).  Workgroup g owns the outputs [g C, (g + 1) C), C = 8 tiles of 512 steps minus the halo; its tiles start
+// `halo` steps earlier from a zero state (g = 0: at step 0 from the drawn x0); a lane runs its 8 steps from zero, the lanes' end states are
+// scanned (rows of 16 by DPP moves with A^(8 2^k), across the rows through a per-lane table of A^(8 e) in LDS), the tiles are chained over
+// the <= 3 tiles before them, and the lane's start state reaches its 8 outputs through the rows h' A^(j+1).  Reads eps_t (8 d B/step) and
+// eps_e once, writes y once.
+// =================================================================================================================================
+namespace {
+template <int D>
+struct RArgs {
+    double A[D][D], a[D], Lq[D][D], h[D], hh, sR;
+    double P[6][D][D];       // A^(8 2^k)
+    double PT[2][D][D];      // A^512, A^1024
+    double WJ[kWJ][D];       // h' A^(j+1)
+    double x0[D];
+    long long T, C, nwg;
+    int halo;
+    const double *eps_t, *eps_e;
+    double* y;
+};
+
+// y <- M x (dense, M from the kernel arguments)
+#define TGP_MATVEC_ACC(M, X, Y)                                   \
+    _Pragma("unroll") for (int i_ = 0; i_ < D; ++i_) {            \
+        double v_ = Y[i_];                                        \
+        _Pragma("unroll") for (int k_ = 0; k_ < D; ++k_) v_ = fma(M[i_][k_], X[k_], v_); \
+        Y[i_] = v_;                                               \
+    }
+
+template <int D, int NW>
+__global__ __launch_bounds__(NW * 64, (D <= 4 ? 4 : 2)) void k_rand_one(const RArgs<D> by_value) {
+    (void)by_value;
+    const RArgs<D>& ka = *(const RArgs<D>*)__builtin_amdgcn_kernarg_segment_ptr();      // (read in place: see k_steady_one)
+    constexpr int SUB = kWJ, TILE = 64 * SUB;
+    __shared__ double sF[NW][D];
+    __shared__ double sPw[D][D][64];      // A^(8 e), e = 0 .. 63: entry [i][k][e]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    long long g;
+    {
+        const long long per = (ka.nwg + 7) / 8;      // consecutive workgroups (they share their halos' lines) on the same XCD
+        g = (long long)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+        if ((long long)(blockIdx.x >> 3) >= per || g >= ka.nwg) return;
+    }
+    const long long T = ka.T, c_lo = g * ka.C, c_hi = (c_lo + ka.C < T) ? c_lo + ka.C : T;
+    const bool first = g == 0;
+    const long long s0 = first ? 0 : c_lo - ka.halo;
+    const long long tile_t0 = s0 + (long long)wave * TILE, t0 = tile_t0 + (long long)lane * SUB;
+    const bool any_valid = tile_t0 < c_hi;      // (wave-uniform: a tile wholly behind the workgroup's range has nothing to do)
+    // ---- the per-lane power table: row i of A^(8 e) by the bits of e, rows shared out over the waves
+    {
+        const int uw = __builtin_amdgcn_readfirstlane(wave);
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            if (uw != i % NW) continue;      // (wave-uniform)
+            double row[D];
+#pragma unroll
+            for (int k = 0; k < D; ++k) row[k] = (k == i) ? 1.0 : 0.0;
+#pragma unroll
+            for (int b = 0; b < 6; ++b) {
+                double nr[D];
+#pragma unroll
+                for (int k = 0; k < D; ++k) {
+                    double v = 0.0;
+#pragma unroll
+                    for (int m = 0; m < D; ++m) v = fma(row[m], ka.P[b][m][k], v);
+                    nr[k] = v;
+                }
+                const bool bit = ((lane >> b) & 1) != 0;
+#pragma unroll
+                for (int k = 0; k < D; ++k) row[k] = bit ? nr[k] : row[k];
+            }
+#pragma unroll
+            for (int k = 0; k < D; ++k) sPw[i][k][lane] = row[k];
+        }
+    }
+    // ---- the lane's eight steps from a zero state
+    double y0[SUB], x[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) x[i] = 0.0;
+#pragma unroll
+    for (int j = 0; j < SUB; ++j) y0[j] = 0.0;
+    if (any_valid) {
+        const bool whole = t0 + SUB <= T && (reinterpret_cast<uintptr_t>(ka.eps_t) & 15) == 0 && (reinterpret_cast<uintptr_t>(ka.eps_e) & 15) == 0;
+        double ee[SUB];
+        if (whole) {
+            const v2d* q = reinterpret_cast<const v2d*>(ka.eps_e + t0);
+#pragma unroll
+            for (int j = 0; j < SUB / 2; ++j) {
+                const v2d w = q[j];
+                ee[2 * j] = w.x;
+                ee[2 * j + 1] = w.y;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < SUB; ++j) ee[j] = t0 + j < T ? ka.eps_e[t0 + j] : 0.0;
+        }
+#pragma unroll
+        for (int j2 = 0; j2 < SUB; j2 += 2) {
+            // the draws of two steps: 2 d consecutive doubles (16-byte pieces where the series allows)
+            double ev[2 * D];
+            if (whole) {
+                const v2d* q = reinterpret_cast<const v2d*>(ka.eps_t + (t0 + j2) * D);
+#pragma unroll
+                for (int k = 0; k < D; ++k) {
+                    const v2d w = q[k];
+                    ev[2 * k] = w.x;
+                    ev[2 * k + 1] = w.y;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 2 * D; ++k) ev[k] = (t0 + j2) * D + k < T * D ? ka.eps_t[(t0 + j2) * D + k] : 0.0;
+            }
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int j = j2 + jj;
+                double nx[D];
+#pragma unroll
+                for (int i = 0; i < D; ++i) {
+                    double v = ka.a[i];
+#pragma unroll
+                    for (int k = 0; k <= i; ++k) v = fma(ka.Lq[i][k], ev[jj * D + k], v);      // (lower factor)
+                    nx[i] = v;
+                }
+                TGP_MATVEC_ACC(ka.A, x, nx);
+                double yy = fma(ka.sR, ee[j], ka.hh);
+#pragma unroll
+                for (int i = 0; i < D; ++i) {
+                    x[i] = nx[i];
+                    yy = fma(ka.h[i], nx[i], yy);
+                }
+                y0[j] = yy;
+            }
+        }
+    }
+    __syncthreads();      // (the table)
+    // ---- inclusive scan of the lanes' end states: x_l <- sum_{m <= l} A^(8 (l - m)) x_m
+    double st[D];
+    if (any_valid) {
+#define TGP_RAND_LEVEL(K)                                                                  \
+    do {                                                                                   \
+        double g_[D], n_[D];                                                               \
+        _Pragma("unroll") for (int i = 0; i < D; ++i) {                                    \
+            g_[i] = dpp_mov<0x110 + (1 << (K))>(x[i]);                                     \
+            n_[i] = x[i];                                                                  \
+        }                                                                                  \
+        TGP_MATVEC_ACC(ka.P[K], g_, n_);                                                   \
+        _Pragma("unroll") for (int i = 0; i < D; ++i) x[i] = n_[i];                        \
+    } while (0)
+        TGP_RAND_LEVEL(0);
+        TGP_RAND_LEVEL(1);
+        TGP_RAND_LEVEL(2);
+        TGP_RAND_LEVEL(3);
+#undef TGP_RAND_LEVEL
+        {
+            const int e1 = (lane & 15) + 1, e2 = lane >= 32 ? lane - 31 : 0;
+            double gv[D], nv[D];
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                gv[i] = dpp_mov<0x142, 0xA>(x[i]);
+                nv[i] = x[i];
+            }
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int k = 0; k < D; ++k) nv[i] = fma(sPw[i][k][e1], gv[k], nv[i]);
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                x[i] = nv[i];
+                gv[i] = dpp_mov<0x143, 0xC>(nv[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int k = 0; k < D; ++k) nv[i] = fma(sPw[i][k][e2], gv[k], nv[i]);
+#pragma unroll
+            for (int i = 0; i < D; ++i) x[i] = nv[i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < D; ++i) st[i] = dpp_mov<0x138>(x[i]);      // the state in front of the lane's steps (lane 0: zero)
+    if (lane == 63) {
+#pragma unroll
+        for (int i = 0; i < D; ++i) sF[wave][i] = any_valid ? x[i] : 0.0;
+    }
+    __syncthreads();
+    if (!any_valid) return;
+    // ---- the tile's start state from the <= 3 tiles before it (workgroup 0: the drawn x0 sits at position -1), then the outputs
+    double zin[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) zin[i] = 0.0;
+#pragma unroll
+    for (int k = 1; k <= 3; ++k) {
+        const int src = wave - k;
+        if (src < -1 || (src == -1 && !first)) continue;      // (wave-uniform)
+        double xs[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) xs[i] = src >= 0 ? sF[src][i] : ka.x0[i];
+        if (k == 1) {
+#pragma unroll
+            for (int i = 0; i < D; ++i) zin[i] += xs[i];
+        } else {
+            TGP_MATVEC_ACC(ka.PT[k - 2], xs, zin);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int k = 0; k < D; ++k) st[i] = fma(sPw[i][k][lane], zin[k], st[i]);
+    const bool aligned = (reinterpret_cast<uintptr_t>(ka.y) & 15) == 0;
+#pragma unroll
+    for (int j = 0; j < SUB; j += 2) {
+        double m0 = y0[j], m1 = y0[j + 1];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            m0 = fma(ka.WJ[j][i], st[i], m0);
+            m1 = fma(ka.WJ[j + 1][i], st[i], m1);
+        }
+        const long long t = t0 + j;
+        if (t >= c_lo && t + 1 < c_hi && aligned) {
+            v2d w;
+            w.x = m0;
+            w.y = m1;
+            *reinterpret_cast<v2d*>(ka.y + t) = w;
+        } else {
+            if (t >= c_lo && t < c_hi) ka.y[t] = m0;
+            if (t + 1 >= c_lo && t + 1 < c_hi) ka.y[t + 1] = m1;
+        }
+    }
+}
+#undef TGP_MATVEC_ACC
+
+template <int D>
+int launch_rand(hipStream_t st, const tgp_plan::RandPlan& rp, const double* x0, const double* eps_t, const double* eps_e, long long T, double* y) {
+    constexpr int NW = 8, M = tgp_plan::kRandMaxD;
+    RArgs<D> ka;
+    static_assert(sizeof(RArgs<D>) <= 4096, "the kernel-argument segment");
+    std::memset(&ka, 0, sizeof ka);
+    for (int i = 0; i < D; ++i) {
+        ka.a[i] = rp.a[i];
+        ka.h[i] = rp.h[i];
+        ka.x0[i] = x0[i];
+        for (int k = 0; k < D; ++k) {
+            ka.A[i][k] = rp.A[i * D + k];
+            ka.Lq[i][k] = rp.Lq[i * D + k];
+            for (int b = 0; b < 6; ++b) ka.P[b][i][k] = rp.P[b][i * D + k];
+            for (int b = 0; b < 2; ++b) ka.PT[b][i][k] = rp.PT[b][i * D + k];
+        }
+    }
+    (void)M;
+    for (int j = 0; j < kWJ; ++j)
+        for (int i = 0; i < D; ++i) ka.WJ[j][i] = rp.WJ[j][i];
+    ka.hh = rp.hh;
+    ka.sR = rp.sR;
+    ka.T = T;
+    ka.halo = rp.halo;
+    ka.C = (long long)NW * 64 * kWJ - rp.halo;
+    ka.nwg = (T + ka.C - 1) / ka.C;
+    ka.eps_t = eps_t;
+    ka.eps_e = eps_e;
+    ka.y = y;
+    const long long per = (ka.nwg + 7) / 8;
+    hipLaunchKernelGGL((k_rand_one<D, NW>), dim3((unsigned)(per * 8)), dim3(NW * 64), 0, st, ka);
+    return (int)hipGetLastError();
+}
+}  // namespace
+
+int rand_lti(hipStream_t stream, const tgp_plan::RandPlan& plan, const double* x0, const double* eps_t, const double* eps_e, long long T, double* y,
+             const char** kname) {
+    if (kname) *kname = "k_rand_one";
+    switch (plan.d) {
+        case 1: return launch_rand<1>(stream, plan, x0, eps_t, eps_e, T, y);
+        case 2: return launch_rand<2>(stream, plan, x0, eps_t, eps_e, T, y);
+        case 3: return launch_rand<3>(stream, plan, x0, eps_t, eps_e, T, y);
+        case 4: return launch_rand<4>(stream, plan, x0, eps_t, eps_e, T, y);
+        case 5: return launch_rand<5>(stream, plan, x0, eps_t, eps_e, T, y);
+        case 6: return launch_rand<6>(stream, plan, x0, eps_t, eps_e, T, y);
+    }
+    return (int)hipErrorInvalidValue;
+}
+
 }  // namespace tgp_modal

@@ -49,4 +49,10 @@ const tgp_plan::Modal& last_modal(const Engine*);
 const char* kernel_name(const Engine*, bool posterior);
 void choose_geometry(int d, int halo, int* waves, int* steps_per_lane);
 
+// rand of an LTI model with the draws supplied (lgssm.jl:65-91; Forward, scalar observations, d <= tgp_plan::kRandMaxD): ONE kernel over the
+// draws -- eps_t [T][d], eps_e [T] read once, y [T] written once -- by the same span / halo / in-tile-scan structure, on the dense powers
+// of the open-loop transition (tgp_plan::build_rand).  x0: the drawn initial state (host).  Enqueues on `stream`; 0 or a hipError_t.
+int rand_lti(hipStream_t stream, const tgp_plan::RandPlan& plan, const double* x0, const double* eps_t, const double* eps_e, long long T, double* y,
+             const char** kname);
+
 }  // namespace tgp_modal

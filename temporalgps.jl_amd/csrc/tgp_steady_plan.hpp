@@ -1004,6 +1004,130 @@ inline Info build(const ModelHost& m, long long T, Modal& md, HeadTables& tab) {
     return info;
 }
 
+// ---- rand of an LTI model (lgssm.jl:65-91 with the draws supplied): x_t = A x_{t-1} + a + Lq eps_t, y_t = h' x_t + hh + sqrt(R) eta_t, a pure
+// affine recursion.  Its matrix is the OPEN-loop transition -- for a Matern-3/2 or -5/2 block a Jordan block: no modal form -- so the plan
+// keeps dense powers: A^(8 2^k) for the in-tile scan, A^512 and A^1024 for the tile chaining, the rows h' A^(j+1) that carry a lane's
+// start state to its eight outputs, and the halo after which A^n has decayed below 2^-60 (found by multiplying, not from the spectral
+// radius: ||A^n|| of a Jordan block carries a polynomial factor).  d <= kRandMaxD: everything is a kernel argument.
+constexpr int kRandMaxD = 6;
+struct RandPlan {
+    int d = 0, halo = 0, why = kOk;
+    double A[kRandMaxD * kRandMaxD], a[kRandMaxD], Lq[kRandMaxD * kRandMaxD], h[kRandMaxD], hh = 0.0, sR = 0.0;      // row-major; Lq lower
+    double P[6][kRandMaxD * kRandMaxD], PT[2][kRandMaxD * kRandMaxD], WJ[kSub][kRandMaxD];
+};
+
+template <int D>
+inline void build_rand(const ModelHost& m, RandPlan& rp) {
+    using namespace detail;
+    static_assert(D <= kRandMaxD, "");
+    rp.d = D;
+    rp.why = kOk;
+    double A[D][D], Qs[D][D];
+    for (int i = 0; i < D; ++i) {
+        rp.a[i] = m.a[i];
+        rp.h[i] = m.H[i];
+        for (int k = 0; k < D; ++k) {
+            A[i][k] = m.A[i + k * D];
+            const int r = i < k ? i : k, c = i < k ? k : i;
+            Qs[i][k] = m.Q[r + c * D] + (i == k ? 1e-9 : 0.0);      // Symmetric(Q + 1e-9 I) (lgc.jl:84-87)
+        }
+    }
+    rp.hh = m.hh[0];
+    if (!(m.R[0] >= 0.0)) {
+        rp.why = kNotPD;
+        return;
+    }
+    rp.sR = std::sqrt(m.R[0]);
+    // lower Cholesky factor: cholesky(Symmetric(Q + 1e-9 I)).U'
+    double Lc[D][D];
+    for (int i = 0; i < D; ++i)
+        for (int j = 0; j < D; ++j) Lc[i][j] = 0.0;
+    for (int j = 0; j < D; ++j) {
+        double v = Qs[j][j];
+        for (int k = 0; k < j; ++k) v -= Lc[j][k] * Lc[j][k];
+        if (!(v > 0.0)) {
+            rp.why = kNotPD;
+            return;
+        }
+        Lc[j][j] = std::sqrt(v);
+        for (int i = j + 1; i < D; ++i) {
+            double w = Qs[i][j];
+            for (int k = 0; k < j; ++k) w -= Lc[i][k] * Lc[j][k];
+            Lc[i][j] = w / Lc[j][j];
+        }
+    }
+    auto put = [](const double (&M)[D][D], double* out) {
+        for (int i = 0; i < D; ++i)
+            for (int k = 0; k < D; ++k) out[i * D + k] = M[i][k];
+    };
+    put(A, rp.A);
+    put(Lc, rp.Lq);
+    // powers by squaring: A^8, then A^(8 2^k), A^512, A^1024
+    double X[D][D], Y[D][D];
+    std::memcpy(X, A, sizeof X);
+    for (int q = 0; q < 3; ++q) {      // A^2, A^4, A^8
+        mm<D>(X, X, Y);
+        std::memcpy(X, Y, sizeof X);
+    }
+    double A16[D][D];
+    for (int k = 0; k < 8; ++k) {
+        if (k < 6) put(X, rp.P[k]);
+        else put(X, rp.PT[k - 6]);
+        if (k == 1) std::memcpy(A16, X, sizeof X);
+        mm<D>(X, X, Y);
+        std::memcpy(X, Y, sizeof X);
+    }
+    // the rows h' A^(j+1)
+    {
+        double x[D], nx[D];
+        for (int i = 0; i < D; ++i) x[i] = m.H[i];
+        for (int j = 0; j < kSub; ++j) {
+            for (int k = 0; k < D; ++k) {
+                double v = 0.0;
+                for (int i = 0; i < D; ++i) v = pfma(x[i], A[i][k], v);
+                nx[k] = v;
+            }
+            for (int k = 0; k < D; ++k) rp.WJ[j][k] = x[k] = nx[k];
+        }
+    }
+    // halo: the smallest multiple of 16 with max |A^n| <= 2^-60 (relative to the states it multiplies: of the order of the stationary scale)
+    {
+        double M[D][D];
+        std::memcpy(M, A16, sizeof M);
+        int n = 16;
+        const double tiny = std::ldexp(1.0, -60);
+        for (;;) {
+            double mx = 0.0;
+            for (int i = 0; i < D; ++i)
+                for (int k = 0; k < D; ++k) mx = std::max(mx, std::fabs(M[i][k]));
+            if (!std::isfinite(mx)) {
+                rp.why = kSlowMixing;
+                return;
+            }
+            if (mx <= tiny) break;
+            if (n >= kHaloMax) {
+                rp.why = kSlowMixing;
+                return;
+            }
+            mm<D>(M, A16, Y);
+            std::memcpy(M, Y, sizeof M);
+            n += 16;
+        }
+        rp.halo = n;
+    }
+}
+inline void build_rand_any(const ModelHost& m, RandPlan& rp) {
+    switch (m.d) {
+        case 1: build_rand<1>(m, rp); return;
+        case 2: build_rand<2>(m, rp); return;
+        case 3: build_rand<3>(m, rp); return;
+        case 4: build_rand<4>(m, rp); return;
+        case 5: build_rand<5>(m, rp); return;
+        case 6: build_rand<6>(m, rp); return;
+    }
+    rp.why = kEigFail;
+}
+
 #define TGP_PLAN_DISPATCH(d, expr)                                 \
     switch (d) {                                                   \
         case 1: { constexpr int D = 1; return expr; }              \

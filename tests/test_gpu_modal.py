@@ -232,3 +232,44 @@ print("checked")
         env = dict(os.environ, TGP_MODAL_HEAD_SCANS=scans)
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=root)
         assert r.returncode == 0 and "checked" in r.stdout, (scans, (r.stdout + r.stderr)[-3000:])
+
+
+@pytest.mark.parametrize("d", [1, 2, 3, 4, 5, 6])
+def test_rand_of_an_lti_model_in_one_launch(tgp, d):
+    """rand(rng, model) with the draws supplied (lgssm.jl:65-91) for LTI models up to d = 6: ONE kernel over the draws (k_rand_one: dense
+    powers of the open-loop transition, spans with a run-in of `halo` steps) against the oracle's sequential loop, at lengths around every
+    tile / span boundary; a slowly mixing model (halo beyond the cap) falls back to the general engine's affine scan."""
+    rng = np.random.default_rng(900 + d)
+    for T, dt in ((2, 0.1), (77, 0.1), (513, 0.1), (4096, 0.05), (4097, 0.3), (60011, 0.1), (200_003, 0.05)):
+        model = oc.build_lgssm(KERNELS[d], ("regular", 0.0, dt, T), 0.05)
+        eps = (rng.standard_normal((T, d)), rng.standard_normal(T), rng.standard_normal(d))
+        y_ref = sk.rand(model, *eps)
+        dm = device_model(tgp, model)
+        y, names = kernels_of(tgp, dm, lambda: tgp.rand(eps, dm))
+        assert names == {"k_rand_one"}, (T, dt, names)
+        scale = max(1.0, float(np.max(np.abs(y_ref))))
+        assert np.max(np.abs(y - y_ref)) <= 1e-9 * scale, (T, dt, np.max(np.abs(y - y_ref)))
+    # halo beyond the cap: the general engine
+    T = 30_000
+    model = oc.build_lgssm(KERNELS[d], ("regular", 0.0, 0.0005, T), 0.05)
+    eps = (rng.standard_normal((T, d)), rng.standard_normal(T), rng.standard_normal(d))
+    dm = device_model(tgp, model)
+    y, names = kernels_of(tgp, dm, lambda: tgp.rand(eps, dm))
+    assert "k_rand_one" not in names, names
+    y_ref = sk.rand(model, *eps)
+    assert np.max(np.abs(y - y_ref)) <= 1e-9 * max(1.0, float(np.max(np.abs(y_ref))))
+
+
+def test_rand_of_an_lti_model_with_device_resident_draws(tgp):
+    import torch
+    T, d = 1_000_003, 3
+    model = oc.build_lgssm(KERNELS[d], ("regular", 0.0, 0.1, T), 0.1)
+    rng = np.random.default_rng(77)
+    eps = (rng.standard_normal((T, d)), rng.standard_normal(T), rng.standard_normal(d))
+    y_ref = sk.rand(model, *eps)
+    dm = device_model(tgp, model)
+    dev = (torch.as_tensor(eps[0], device="cuda:0"), torch.as_tensor(eps[1], device="cuda:0"), eps[2])
+    y, names = kernels_of(tgp, dm, lambda: tgp.rand(dev, dm))
+    assert names == {"k_rand_one"}, names
+    yy = y.cpu().numpy() if hasattr(y, "cpu") else y
+    assert np.max(np.abs(yy - y_ref)) <= 1e-9 * max(1.0, float(np.max(np.abs(y_ref))))
