@@ -264,7 +264,7 @@ def broadcast_components(FqH, x0, t):
     irregular -> per-step blocks with dt_1 = 1 (t0 := t1 - 1, lti_sde.jl:139)."""
     F, _, H = FqH
     _, P0 = x0
-    P = np.triu(P0) + np.triu(P0, 1).T
+    P = _symmetric_from_upper(P0)
     d = F.shape[0]
     if isinstance(t, RegularSpacing):
         A = expm(F * t.dt)
@@ -638,6 +638,21 @@ def _sde_jet(kernel, target):
     return np.asarray(F, float), np.zeros_like(np.asarray(F, float)), np.asarray(H, float), np.zeros_like(np.asarray(H, float)), m, np.asarray(P, float), dP
 
 
+_UPPER = {}
+
+
+def _symmetric_from_upper(M):
+    """Symmetric(M): the upper triangle mirrored (np.triu twice costs ~10 us per small matrix -- ten of them per gradient evaluation)"""
+    M = np.asarray(M, float)
+    n = M.shape[0]
+    iu = _UPPER.get(n)
+    if iu is None:
+        iu = _UPPER[n] = np.triu_indices(n, 1)
+    S = M.copy()
+    S[iu[1], iu[0]] = M[iu]
+    return S
+
+
 def _components_jet(kernel, dt, ddt, target, first=False, cache=None):
     """Shared blocks (A, Q, H, m0, P0) of `lgssm_components(RegularSpacing(., dt, .))` and their derivatives (dA, dQ, dH, dP0)
     w.r.t. the target hyper-parameter; `ddt` is the derivative of this sub-expression's (stretched) time step.
@@ -659,8 +674,8 @@ def _components_jet(kernel, dt, ddt, target, first=False, cache=None):
         cat = lambda i: np.concatenate([p[i] for p in parts])
         return bd(0), bd(1), bd(2), bd(3), cat(4), cat(5), cat(6), bd(7), bd(8)
     F, dF, H, dH, m, P0, dP = _sde_jet(kernel, target)          # simple kernels and products: one SDE, one exponential
-    P = np.triu(P0) + np.triu(P0, 1).T
-    dPs = np.triu(dP) + np.triu(dP, 1).T
+    P = _symmetric_from_upper(P0)
+    dPs = _symmetric_from_upper(dP)
     A, dA = _expm_and_tangent(F * dt, dF * dt + F * ddt, cache)
     Q = P - A @ P @ A.T
     dQ = dPs - dA @ P @ A.T - A @ dPs @ A.T - A @ P @ dA.T
