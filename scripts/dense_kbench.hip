@@ -79,12 +79,13 @@ int main(int argc, char** argv) {
     CK(hipMemset(dA, 0, (size_t)D * D * 8)); CK(hipMemset(dP, 0, (size_t)D * D * 8));
     Engine* e = create(0);
     set_attrs(e);
-    for (int cfg = 0; cfg < 3; ++cfg) {
+    for (int cfg = 0; cfg < 4; ++cfg) {
         GemmArgs g;
         g.A = dA; g.lda = D; g.B = dP; g.ldb = D; g.C = dC; g.ldc = D;
         if (cfg == 0) { g.M = g.N = g.K = D; }
         if (cfg == 1) { g.M = 256; g.N = D; g.K = D; g.lda = 256; g.ldc = 256; }
         if (cfg == 2) { g.M = 256; g.N = 256; g.K = D; g.lda = 256; g.ldb = 256; g.ldc = 256; }
+        if (cfg == 3) { g.M = D; g.N = D; g.K = 256; g.E = dC; g.lde = D; g.sign = -1.0; }      // the shape of P = Pp - B'B (without its rider)
         for (int rep = 0; rep < 2; ++rep) {
             CK(hipEventRecord(e0));
             for (int i = 0; i < 20; ++i) launch_gemm(g, 0);
