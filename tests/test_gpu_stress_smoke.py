@@ -24,6 +24,7 @@ SWEEPS = [            # (script, cases, seed)
     ("stress_gradient.py", 8, 18),
     ("stress_space_time.py", 12, 19),
     ("stress_pseudo_point.py", 16, 20),
+    ("stress_long.py", 5, 21),      # series of 1e6 - 6e6 steps: thousands of workgroups, the sequential head, rand in one launch
 ]
 
 
