@@ -250,7 +250,9 @@ int tgp_adjoint_finish(int d, const double* rec, const double* y_head, int64_t n
                        double* gH, double* ghh, double* gR, double* gx0m, double* gx0P);
 
 /* ---- _filter(model, y): lgssm.jl:171-187. m_out [T][d], P_out [T][d*d] (either may be NULL);
- *      lml_out (host, may be NULL) receives the log marginal likelihood as a by-product. */
+ *      lml_out (host, may be NULL) receives the log marginal likelihood as a by-product.
+ *      A Forward LTI model with scalar observations, one noise variance, no missing data and d <= 6 runs its head on the host and
+ *      everything behind it as ONE kernel (TGP_OPT_STEADY = 3, the default). */
 int tgp_filter(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t flags, double* m_out,
                double* P_out, double* lml_out);
 

@@ -334,6 +334,8 @@ struct tgp_handle {
     int shard2_first = 1, shard2_last = 1, shard2_post = 0;      // the open two-half call of a stationary-gain time shard
     bool shard2_open = false;
     double* adj_host = nullptr;  // pinned: the record + the head's observations of an adjoint call
+    double* flt_host = nullptr;  // pinned: head observations, head outputs and the workgroups' partial sums of an LTI filter call
+    size_t flt_cap = 0;
     DevBuf steady_rec;           // ... the chunks' records (ModelView::steady)
     int steady_calls = 0;        // 1: the last posterior-path forward pass (mode 2) wrote the records
     // Policy of the posterior path: the build with these steps has slightly longer full steps, and a pass takes as long as its slowest
@@ -1288,6 +1290,7 @@ int tgp_destroy(tgp_handle* h) {
     if (h->modal) tgp_modal::destroy(h->modal);
     if (h->host_result) (void)hipHostFree(h->host_result);
     if (h->adj_host) (void)hipHostFree(h->adj_host);
+    if (h->flt_host) (void)hipHostFree(h->flt_host);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
     return TGP_OK;
@@ -1958,8 +1961,72 @@ int tgp_logpdf_adjoint(tgp_handle* h, const double* y, uint32_t flags, double* l
     return TGP_OK;
 }
 
+// _filter of an LTI model (Forward, scalar observations, one noise variance, no missing data, d <= 6): the head on the host from its few
+// observations, everything behind it in ONE kernel (tgp_modal::filter_lti).  *served = false: the caller runs the general engine.
+static int filter_lti_call(tgp_handle* h, const double* y, uint32_t flags, double* m_out, double* P_out, double* lml_out, bool* served) {
+    *served = false;
+    tgp_plan::ModelHost mh;
+    if (!h->opt_modal || h->is_dense || !h->lti || h->p != 1 || h->ordering != 0 || h->sde || h->d > tgp_plan::kRandMaxD || !modal_host_model(h, mh)) return TGP_OK;
+    tgp_plan::FilterPlan fp;
+    tgp_plan::build_filter_any(mh, h->T, fp);
+    if (fp.why != tgp_plan::kOk) return TGP_OK;
+    const int d = h->d;
+    const size_t dd = (size_t)d * d, nhs = (size_t)fp.nhs;
+    const long long nwg = tgp_modal::filter_workgroups(fp, h->T);
+    const size_t need = nhs * (1 + d + dd) + (size_t)nwg + 8;
+    if (need > h->flt_cap) {
+        if (h->flt_host) (void)hipHostFree(h->flt_host);
+        h->flt_host = nullptr;
+        h->flt_cap = 0;
+        if (hipHostMalloc(reinterpret_cast<void**>(&h->flt_host), need * sizeof(double), hipHostMallocDefault) != hipSuccess) return h->fail(TGP_EHIP, "hipHostMalloc");
+        h->flt_cap = need;
+    }
+    double *yh = h->flt_host, *mh_out = yh + nhs, *Ph_out = mh_out + nhs * d, *part = Ph_out + nhs * dd;
+    const bool odev = (flags & TGP_OUT_DEVICE) != 0;
+    const size_t nm = (size_t)h->T * d * sizeof(double), nP = nm * d;
+    CallTimer tm(h, /*clear=*/false);
+    TRY(set_obs(h, y, nullptr, flags));
+    tm.inputs_done();
+    HIPCHK(hipMemcpyAsync(yh, h->mv.y, nhs * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    double mu_end[tgp_plan::kRandMaxD], quad_head = 0.0;
+    tgp_plan::filter_head_any(mh, fp, yh, m_out ? mh_out : nullptr, P_out ? Ph_out : nullptr, mu_end, &quad_head);
+    double *dm = nullptr, *dP = nullptr;
+    TRY(stage_out(h, h->bo1, m_out, nm, odev, &dm));
+    TRY(stage_out(h, h->bo2, P_out, nP, odev, &dP));
+    if (dm) HIPCHK(hipMemcpyAsync(dm, mh_out, nhs * d * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (dP) HIPCHK(hipMemcpyAsync(dP, Ph_out, nhs * dd * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    {
+        LaunchScope ls(h, "k_filter_one");
+        const int rc = tgp_modal::filter_lti(h->stream, fp, mu_end, h->mv.y, h->T, dm, dP, part);
+        if (rc != 0) return h->fail(TGP_EHIP, std::string("tgp_filter: launch: ") + hipGetErrorString((hipError_t)rc));
+    }
+    tm.kernels_done();
+    TRY(copy_back(h, m_out, dm, nm, odev));
+    TRY(copy_back(h, P_out, dP, nP, odev));
+    if (h->timing) (void)hipEventRecord(h->ev[3], h->stream);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    resolve_profile(h);
+    double ssq = 0.0;
+    for (long long g = 0; g < nwg; ++g) ssq += part[g];
+    const double lml = -0.5 * ((double)h->T * 1.8378770664093454835606594728112 + fp.LS + (double)(h->T - fp.n0) * fp.logS + quad_head + fp.iS * ssq);
+    for (int i = 0; i < 8; ++i) h->host_result[i] = 0.0;
+    h->host_result[0] = lml;
+    if (lml_out) *lml_out = lml;
+    h->reduce_valid = false;
+    h->smoother_valid = false;
+    *served = true;
+    return TGP_OK;
+}
+
 int tgp_filter(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t flags, double* m_out, double* P_out, double* lml_out) {
-    TRY(check_ready(h));
+    TRY(check_ready(h, /*general=*/false));
+    if (missing == nullptr && y != nullptr) {
+        bool served = false;
+        TRY(filter_lti_call(h, y, flags, m_out, P_out, lml_out, &served));
+        if (served) return TGP_OK;
+    }
+    resolve_table(h);
     const bool odev = (flags & TGP_OUT_DEVICE) != 0;
     const size_t nm = (size_t)h->T * h->d * sizeof(double), nP = nm * h->d;
     CallTimer tm(h);

@@ -1620,4 +1620,312 @@ int rand_lti(hipStream_t stream, const tgp_plan::RandPlan& plan, const double* x
     return (int)hipErrorInvalidValue;
 }
 
+// =================================================================================================================================
+// _filter of an LTI model behind its head (lgssm.jl:171-187): mu' = Phi mu + a + (A K) u, r = u - h' mu, m_t = mu_t + K r_t, P_t = P_ss.
+// k_rand_one's structure on the dense powers of the closed loop Phi = A - (A K) h': a first sweep of a lane's 8 steps from a zero state gives
+// its end state, the scan and the tile chaining its true start state, a second sweep from there the outputs.  Workgroup 0 starts at nhs from
+// the head's end state (computed on the host).  Reads y once, writes 8 (d + d^2) bytes per step.
+// =================================================================================================================================
+namespace {
+template <int D>
+struct FArgs {
+    double Phi[D][D], a[D], kA[D], K[D], h[D], hh;
+    double P[6][D][D], PT[2][D][D];
+    double Pss[D * D];
+    double mu0[D];
+    long long T, C, nwg, nhs;
+    int halo;
+    const double* y;
+    double *m, *Pc, *part;
+};
+
+template <int D, int NW>
+__global__ __launch_bounds__(NW * 64, (D <= 4 ? 4 : 2)) void k_filter_one(const FArgs<D> by_value) {
+    (void)by_value;
+    const FArgs<D>& ka = *(const FArgs<D>*)__builtin_amdgcn_kernarg_segment_ptr();
+    constexpr int SUB = kWJ, TILE = 64 * SUB;
+    __shared__ double sF[NW][D], sAcc[NW];
+    __shared__ double sPw[D][D][64];      // Phi^(8 e), e = 0 .. 63
+    __shared__ double sP[D * D];          // the settled covariance (the fill below indexes it per lane)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    long long g;
+    {
+        const long long per = (ka.nwg + 7) / 8;
+        g = (long long)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+        if ((long long)(blockIdx.x >> 3) >= per || g >= ka.nwg) return;
+    }
+    if (threadIdx.x < D * D) sP[threadIdx.x] = ka.Pss[threadIdx.x];
+    const long long T = ka.T, c_lo = ka.nhs + g * ka.C, c_hi = (c_lo + ka.C < T) ? c_lo + ka.C : T;
+    const bool first = g == 0;
+    const long long s0 = first ? ka.nhs : c_lo - ka.halo;
+    const long long tile_t0 = s0 + (long long)wave * TILE, t0 = tile_t0 + (long long)lane * SUB;
+    const bool any_valid = tile_t0 < c_hi;
+    {
+        const int uw = __builtin_amdgcn_readfirstlane(wave);
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            if (uw != i % NW) continue;
+            double row[D];
+#pragma unroll
+            for (int k = 0; k < D; ++k) row[k] = (k == i) ? 1.0 : 0.0;
+#pragma unroll
+            for (int b = 0; b < 6; ++b) {
+                double nr[D];
+#pragma unroll
+                for (int k = 0; k < D; ++k) {
+                    double v = 0.0;
+#pragma unroll
+                    for (int m = 0; m < D; ++m) v = fma(row[m], ka.P[b][m][k], v);
+                    nr[k] = v;
+                }
+                const bool bit = ((lane >> b) & 1) != 0;
+#pragma unroll
+                for (int k = 0; k < D; ++k) row[k] = bit ? nr[k] : row[k];
+            }
+#pragma unroll
+            for (int k = 0; k < D; ++k) sPw[i][k][lane] = row[k];
+        }
+    }
+    // ---- first sweep: the lane's 8 steps from a zero state
+    double u[SUB], x[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) x[i] = 0.0;
+#pragma unroll
+    for (int j = 0; j < SUB; ++j) u[j] = 0.0;
+    if (any_valid) {
+        if (t0 + SUB <= T && (reinterpret_cast<uintptr_t>(ka.y) & 15) == 0) {
+            const v2d* q = reinterpret_cast<const v2d*>(ka.y + t0);
+#pragma unroll
+            for (int j = 0; j < SUB / 2; ++j) {
+                const v2d w = q[j];
+                u[2 * j] = w.x - ka.hh;
+                u[2 * j + 1] = w.y - ka.hh;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < SUB; ++j) u[j] = t0 + j < T ? ka.y[t0 + j] - ka.hh : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < SUB; ++j) {
+            double nx[D];
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                double v = fma(ka.kA[i], u[j], ka.a[i]);
+#pragma unroll
+                for (int k = 0; k < D; ++k) v = fma(ka.Phi[i][k], x[k], v);
+                nx[i] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < D; ++i) x[i] = nx[i];
+        }
+    }
+    __syncthreads();
+    double st[D];
+    if (any_valid) {
+#define TGP_FILT_LEVEL(K)                                                                  \
+    do {                                                                                   \
+        double g_[D], n_[D];                                                               \
+        _Pragma("unroll") for (int i = 0; i < D; ++i) {                                    \
+            g_[i] = dpp_mov<0x110 + (1 << (K))>(x[i]);                                     \
+            n_[i] = x[i];                                                                  \
+        }                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < D; ++i)                                      \
+            _Pragma("unroll") for (int k = 0; k < D; ++k) n_[i] = fma(ka.P[K][i][k], g_[k], n_[i]); \
+        _Pragma("unroll") for (int i = 0; i < D; ++i) x[i] = n_[i];                        \
+    } while (0)
+        TGP_FILT_LEVEL(0);
+        TGP_FILT_LEVEL(1);
+        TGP_FILT_LEVEL(2);
+        TGP_FILT_LEVEL(3);
+#undef TGP_FILT_LEVEL
+        const int e1 = (lane & 15) + 1, e2 = lane >= 32 ? lane - 31 : 0;
+        double gv[D], nv[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            gv[i] = dpp_mov<0x142, 0xA>(x[i]);
+            nv[i] = x[i];
+        }
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int k = 0; k < D; ++k) nv[i] = fma(sPw[i][k][e1], gv[k], nv[i]);
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            x[i] = nv[i];
+            gv[i] = dpp_mov<0x143, 0xC>(nv[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int k = 0; k < D; ++k) nv[i] = fma(sPw[i][k][e2], gv[k], nv[i]);
+#pragma unroll
+        for (int i = 0; i < D; ++i) x[i] = nv[i];
+    }
+#pragma unroll
+    for (int i = 0; i < D; ++i) st[i] = dpp_mov<0x138>(x[i]);
+    if (lane == 63) {
+#pragma unroll
+        for (int i = 0; i < D; ++i) sF[wave][i] = any_valid ? x[i] : 0.0;
+    }
+    __syncthreads();
+    double acc = 0.0;
+    if (any_valid) {
+        double zin[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) zin[i] = 0.0;
+#pragma unroll
+        for (int k = 1; k <= 3; ++k) {
+            const int src = wave - k;
+            if (src < -1 || (src == -1 && !first)) continue;
+            double xs[D];
+#pragma unroll
+            for (int i = 0; i < D; ++i) xs[i] = src >= 0 ? sF[src][i] : ka.mu0[i];
+            if (k == 1) {
+#pragma unroll
+                for (int i = 0; i < D; ++i) zin[i] += xs[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < D; ++i)
+#pragma unroll
+                    for (int m = 0; m < D; ++m) zin[i] = fma(ka.PT[k - 2][i][m], xs[m], zin[i]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int k = 0; k < D; ++k) st[i] = fma(sPw[i][k][lane], zin[k], st[i]);
+        // ---- second sweep from the true start state: innovations, filtered means
+        const bool whole = t0 >= c_lo && t0 + SUB <= c_hi;
+        const bool m_al = ka.m != nullptr && (reinterpret_cast<uintptr_t>(ka.m) & 15) == 0;
+#pragma unroll
+        for (int j2 = 0; j2 < SUB; j2 += 2) {
+            double mf[2 * D];
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int j = j2 + jj;
+                double r = u[j];
+#pragma unroll
+                for (int k = 0; k < D; ++k) r = fma(-ka.h[k], st[k], r);
+                const long long t = t0 + j;
+                if (t >= c_lo && t < c_hi) acc = fma(r, r, acc);
+                double nx[D];
+#pragma unroll
+                for (int i = 0; i < D; ++i) {
+                    mf[jj * D + i] = fma(ka.K[i], r, st[i]);
+                    double v = fma(ka.kA[i], u[j], ka.a[i]);
+#pragma unroll
+                    for (int k = 0; k < D; ++k) v = fma(ka.Phi[i][k], st[k], v);
+                    nx[i] = v;
+                }
+#pragma unroll
+                for (int i = 0; i < D; ++i) st[i] = nx[i];
+            }
+            if (ka.m != nullptr) {
+                const long long t = t0 + j2;
+                if (whole && m_al) {      // (t D is even: 16-byte pieces)
+                    v2d* q = reinterpret_cast<v2d*>(ka.m + t * D);
+#pragma unroll
+                    for (int k = 0; k < D; ++k) {
+                        v2d w;
+                        w.x = mf[2 * k];
+                        w.y = mf[2 * k + 1];
+                        q[k] = w;
+                    }
+                } else {
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj)
+                        if (t + jj >= c_lo && t + jj < c_hi)
+#pragma unroll
+                            for (int i = 0; i < D; ++i) ka.m[(t + jj) * D + i] = mf[jj * D + i];
+                }
+            }
+        }
+        // the covariances: the settled one, for every step the workgroup owns -- a whole tile as one run of 512 D^2 doubles, every store
+        // instruction 1 KB of consecutive bytes (a lane writing its own 8 D^2 values, 16 bytes at a 64 D^2-byte stride: 40 % slower)
+        if (ka.Pc != nullptr) {
+            constexpr int DD = D * D;
+            const bool tile_whole = tile_t0 >= c_lo && tile_t0 + TILE <= c_hi;      // (wave-uniform)
+            if (tile_whole && (reinterpret_cast<uintptr_t>(ka.Pc) & 15) == 0) {
+                v2d* q = reinterpret_cast<v2d*>(ka.Pc + tile_t0 * DD);
+#pragma unroll 4
+                for (int k = 0; k < SUB * DD / 2; ++k) {
+                    const int e = k * 64 + lane;
+                    v2d w;
+                    w.x = sP[(2 * e) % DD];
+                    w.y = sP[(2 * e + 1) % DD];
+                    q[e] = w;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < SUB; ++j)
+                    if (t0 + j >= c_lo && t0 + j < c_hi)
+#pragma unroll
+                        for (int e = 0; e < DD; ++e) ka.Pc[(t0 + j) * DD + e] = ka.Pss[e];
+            }
+        }
+    }
+    acc = wave_sum_to_lane63(acc);
+    if (lane == 63) sAcc[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tsum = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) tsum += sAcc[w];
+        ka.part[g] = tsum;
+    }
+}
+
+template <int D>
+int launch_filter(hipStream_t st, const tgp_plan::FilterPlan& fp, const double* mu0, const double* y, long long T, double* m, double* Pc, double* part) {
+    constexpr int NW = 8;
+    FArgs<D> ka;
+    static_assert(sizeof(FArgs<D>) <= 4096, "the kernel-argument segment");
+    std::memset(&ka, 0, sizeof ka);
+    for (int i = 0; i < D; ++i) {
+        ka.a[i] = fp.a[i];
+        ka.kA[i] = fp.kA[i];
+        ka.K[i] = fp.K[i];
+        ka.h[i] = fp.h[i];
+        ka.mu0[i] = mu0[i];
+        for (int k = 0; k < D; ++k) {
+            ka.Phi[i][k] = fp.Phi[i * D + k];
+            ka.Pss[i * D + k] = fp.Pss[i * D + k];
+            for (int b = 0; b < 6; ++b) ka.P[b][i][k] = fp.P[b][i * D + k];
+            for (int b = 0; b < 2; ++b) ka.PT[b][i][k] = fp.PT[b][i * D + k];
+        }
+    }
+    ka.hh = fp.hh;
+    ka.T = T;
+    ka.nhs = fp.nhs;
+    ka.halo = fp.halo;
+    ka.C = (long long)NW * 64 * kWJ - fp.halo;
+    ka.nwg = (T - fp.nhs + ka.C - 1) / ka.C;
+    ka.y = y;
+    ka.m = m;
+    ka.Pc = Pc;
+    ka.part = part;
+    const long long per = (ka.nwg + 7) / 8;
+    hipLaunchKernelGGL((k_filter_one<D, NW>), dim3((unsigned)(per * 8)), dim3(NW * 64), 0, st, ka);
+    return (int)hipGetLastError();
+}
+}  // namespace
+
+long long filter_workgroups(const tgp_plan::FilterPlan& fp, long long T) {
+    const long long C = 8LL * 64 * kWJ - fp.halo;
+    return (T - fp.nhs + C - 1) / C;
+}
+
+int filter_lti(hipStream_t stream, const tgp_plan::FilterPlan& fp, const double* mu_start, const double* y, long long T, double* m_out, double* P_out,
+               double* part) {
+    switch (fp.d) {
+        case 1: return launch_filter<1>(stream, fp, mu_start, y, T, m_out, P_out, part);
+        case 2: return launch_filter<2>(stream, fp, mu_start, y, T, m_out, P_out, part);
+        case 3: return launch_filter<3>(stream, fp, mu_start, y, T, m_out, P_out, part);
+        case 4: return launch_filter<4>(stream, fp, mu_start, y, T, m_out, P_out, part);
+        case 5: return launch_filter<5>(stream, fp, mu_start, y, T, m_out, P_out, part);
+        case 6: return launch_filter<6>(stream, fp, mu_start, y, T, m_out, P_out, part);
+    }
+    return (int)hipErrorInvalidValue;
+}
+
 }  // namespace tgp_modal

@@ -52,6 +52,12 @@ void choose_geometry(int d, int halo, int* waves, int* steps_per_lane);
 // rand of an LTI model with the draws supplied (lgssm.jl:65-91; Forward, scalar observations, d <= tgp_plan::kRandMaxD): ONE kernel over the
 // draws -- eps_t [T][d], eps_e [T] read once, y [T] written once -- by the same span / halo / in-tile-scan structure, on the dense powers
 // of the open-loop transition (tgp_plan::build_rand).  x0: the drawn initial state (host).  Enqueues on `stream`; 0 or a hipError_t.
+// _filter of an LTI model behind its head (tgp_plan::build_filter / filter_head; d <= tgp_plan::kRandMaxD): the steps [nhs, T) in ONE kernel --
+// y read once, the filtered means [T][d] and covariances [T][d d] written once (either may be nullptr), sum r^2 per workgroup into `part`
+// (pinned host memory, at least filter_workgroups() values).  mu_start: the predicted mean of step nhs (host).
+long long filter_workgroups(const tgp_plan::FilterPlan& plan, long long T);
+int filter_lti(hipStream_t stream, const tgp_plan::FilterPlan& plan, const double* mu_start, const double* y, long long T, double* m_out, double* P_out,
+               double* part);
 int rand_lti(hipStream_t stream, const tgp_plan::RandPlan& plan, const double* x0, const double* eps_t, const double* eps_e, long long T, double* y,
              const char** kname);
 

@@ -1128,6 +1128,214 @@ inline void build_rand_any(const ModelHost& m, RandPlan& rp) {
     rp.why = kEigFail;
 }
 
+// ---- _filter of an LTI model (lgssm.jl:171-187: the filtered means and covariances of every step, logpdf as a by-product).  The covariance
+// half never sees the data: filtered covariances and gains run into their fixed point after n0 steps (the criterion of build_core); from
+// there on the filtered mean is m_t = mu_t + K r_t with the predicted mean's stationary recursion mu' = Phi mu + a + (A K) u, Phi = A - (A K) h'
+// -- a constant-coefficient affine recursion in u = y - hh, run by k_filter_one like rand's on DENSE powers of Phi.  The head (the first nhs
+// steps, gains of their own) is run HERE, on the host, from the head's observations: a few microseconds beside a call that writes
+// 8 (d + d^2) bytes per step.  d <= kRandMaxD (the powers are kernel arguments).
+struct FilterPlan {
+    int d = 0, n0 = -1, nhs = 0, halo = 0, why = kOk;
+    double Phi[kRandMaxD * kRandMaxD], a[kRandMaxD], kA[kRandMaxD], K[kRandMaxD], h[kRandMaxD], hh = 0.0, iS = 0.0, logS = 0.0, LS = 0.0;
+    double Pss[kRandMaxD * kRandMaxD];      // the settled filtered covariance (row-major; symmetric)
+    double P[6][kRandMaxD * kRandMaxD], PT[2][kRandMaxD * kRandMaxD];      // Phi^(8 2^k); Phi^512, Phi^1024
+};
+template <int D>
+struct FilterWork {      // the head's per-step tables, t = 0 .. n0
+    double A[D][D], kA[kN0Max + 2][D], K[kN0Max + 2][D], iS[kN0Max + 2], Pf[kN0Max + 2][D][D];
+};
+template <int D>
+inline FilterWork<D>& filter_work() {
+    static thread_local FilterWork<D> w;
+    return w;
+}
+
+template <int D>
+inline void build_filter(const ModelHost& m, long long T, FilterPlan& fp) {
+    using namespace detail;
+    static_assert(D <= kRandMaxD, "");
+    FilterWork<D>& fw = filter_work<D>();
+    fp.d = D;
+    fp.why = kOk;
+    double A[D][D], At[D][D], Q[D][D], P[D][D], Pold2[D][D], hv[D];
+    for (int i = 0; i < D; ++i) {
+        hv[i] = m.H[i];
+        fp.h[i] = m.H[i];
+        fp.a[i] = m.a[i];
+        for (int k = 0; k < D; ++k) {
+            A[i][k] = m.A[i + k * D];
+            const int r = i < k ? i : k, c = i < k ? k : i;
+            Q[i][k] = m.Q[r + c * D];
+            P[i][k] = m.x0P[r + c * D];
+            Pold2[i][k] = 0.0;
+        }
+    }
+    std::memcpy(fw.A, A, sizeof A);
+    fp.hh = m.hh[0];
+    const double R = m.R[0];
+    transpose<D>(A, At);
+    int tc = -1, n0 = -1;
+    double LS = 0.0, Sss = 1.0;
+    for (int t = 0; t <= kN0Max; ++t) {      // (the recursion and the criterion of build_core)
+        double t1[D][D], pp[D][D], V[D];
+        mm<D>(A, P, t1);
+        mm<D>(t1, At, pp);
+        for (int i = 0; i < D; ++i)
+            for (int j = 0; j < D; ++j) pp[i][j] += Q[i][j];
+        double S = 0.0;
+        for (int k = 0; k < D; ++k) {
+            double v = 0.0;
+            for (int l = 0; l < D; ++l) v = pfma(hv[l], pp[l][k], v);
+            V[k] = v;
+            S = pfma(v, hv[k], S);
+        }
+        S += R;
+        if (!(S > 0.0)) {
+            fp.why = kNotPD;
+            return;
+        }
+        const double iS = 1.0 / S, rs = 1.0 / std::sqrt(S);
+        for (int i = 0; i < D; ++i) {
+            double v = 0.0;
+            for (int k = 0; k < D; ++k) v = pfma(A[i][k], V[k] * iS, v);
+            fw.kA[t][i] = v;
+            fw.K[t][i] = V[i] * iS;
+        }
+        fw.iS[t] = iS;
+        Sss = S;
+        bool moved = false, cyc = t >= 1;
+        double Pn[D][D];
+        for (int i = 0; i < D; ++i)
+            for (int j = 0; j < D; ++j) {
+                Pn[i][j] = pp[i][j] - (V[i] * rs) * (V[j] * rs);
+                moved = moved || std::fabs(Pn[i][j] - P[i][j]) > kTol * 0.5 * (pp[i][i] + pp[j][j]);
+                cyc = cyc && (Pn[i][j] == Pold2[i][j]);
+            }
+        std::memcpy(fw.Pf[t], Pn, sizeof Pn);      // the filtered covariance of step t
+        if (tc >= 0) {      // the extra iteration from the settled covariance: the stationary step
+            n0 = t;
+            break;
+        }
+        LS += std::log(S);
+        std::memcpy(Pold2, P, sizeof P);
+        std::memcpy(P, Pn, sizeof P);
+        mirror_upper<D>(P);
+        if (!moved || cyc) tc = t;
+    }
+    if (n0 < 0) {
+        fp.why = kNotSettled;
+        return;
+    }
+    fp.n0 = n0;
+    fp.nhs = 16 * ((n0 + 1 + 15) / 16);
+    if ((long long)fp.nhs + 2 > T) {
+        fp.why = kTooShort;
+        return;
+    }
+    fp.iS = 1.0 / Sss;
+    fp.logS = std::log(Sss);
+    fp.LS = LS;
+    double Phi[D][D];
+    for (int i = 0; i < D; ++i) {
+        fp.kA[i] = fw.kA[n0][i];
+        fp.K[i] = fw.K[n0][i];
+        for (int k = 0; k < D; ++k) {
+            Phi[i][k] = A[i][k] - fw.kA[n0][i] * hv[k];
+            fp.Phi[i * D + k] = Phi[i][k];
+            fp.Pss[i * D + k] = 0.5 * (fw.Pf[n0][i][k] + fw.Pf[n0][k][i]);
+        }
+    }
+    auto put = [](const double (&M)[D][D], double* out) {
+        for (int i = 0; i < D; ++i)
+            for (int k = 0; k < D; ++k) out[i * D + k] = M[i][k];
+    };
+    double X[D][D], Y[D][D], P16[D][D];
+    std::memcpy(X, Phi, sizeof X);
+    for (int q = 0; q < 3; ++q) {
+        mm<D>(X, X, Y);
+        std::memcpy(X, Y, sizeof X);
+    }
+    for (int k = 0; k < 8; ++k) {
+        if (k < 6) put(X, fp.P[k]);
+        else put(X, fp.PT[k - 6]);
+        if (k == 1) std::memcpy(P16, X, sizeof X);
+        mm<D>(X, X, Y);
+        std::memcpy(X, Y, sizeof X);
+    }
+    {
+        double M[D][D];
+        std::memcpy(M, P16, sizeof M);
+        int n = 16;
+        const double tiny = std::ldexp(1.0, -60);
+        for (;;) {
+            double mx = 0.0;
+            for (int i = 0; i < D; ++i)
+                for (int k = 0; k < D; ++k) mx = std::max(mx, std::fabs(M[i][k]));
+            if (!std::isfinite(mx) || n > kHaloMax) {
+                fp.why = kSlowMixing;
+                return;
+            }
+            if (mx <= tiny) break;
+            mm<D>(M, P16, Y);
+            std::memcpy(M, Y, sizeof M);
+            n += 16;
+        }
+        fp.halo = n;
+    }
+}
+
+// The head on the host: y [nhs] -> filtered means m [nhs][D], covariances Pc [nhs][D D], the predicted mean of step nhs, sum r^2 / S_t
+template <int D>
+inline void filter_head(const ModelHost& m, const FilterPlan& fp, const double* y, double* mout, double* Pout, double* mu_end, double* quad) {
+    const FilterWork<D>& fw = filter_work<D>();
+    double mu[D], nm[D];
+    for (int i = 0; i < D; ++i) {
+        double v = m.a[i];
+        for (int k = 0; k < D; ++k) v += fw.A[i][k] * m.x0m[k];
+        mu[i] = v;
+    }
+    double q = 0.0;
+    for (int t = 0; t < fp.nhs; ++t) {
+        const int ti = t < fp.n0 ? t : fp.n0;
+        double r = y[t] - fp.hh;
+        for (int k = 0; k < D; ++k) r -= fp.h[k] * mu[k];
+        q += r * r * fw.iS[ti];
+        for (int i = 0; i < D; ++i) {
+            if (mout) mout[(size_t)t * D + i] = mu[i] + fw.K[ti][i] * r;
+            double v = m.a[i] + fw.kA[ti][i] * r;
+            for (int k = 0; k < D; ++k) v += fw.A[i][k] * mu[k];
+            nm[i] = v;
+        }
+        if (Pout)
+            for (int i = 0; i < D; ++i)
+                for (int k = 0; k < D; ++k) Pout[(size_t)t * D * D + i * D + k] = 0.5 * (fw.Pf[ti][i][k] + fw.Pf[ti][k][i]);
+        for (int i = 0; i < D; ++i) mu[i] = nm[i];
+    }
+    for (int i = 0; i < D; ++i) mu_end[i] = mu[i];
+    *quad = q;
+}
+inline void build_filter_any(const ModelHost& m, long long T, FilterPlan& fp) {
+    switch (m.d) {
+        case 1: build_filter<1>(m, T, fp); return;
+        case 2: build_filter<2>(m, T, fp); return;
+        case 3: build_filter<3>(m, T, fp); return;
+        case 4: build_filter<4>(m, T, fp); return;
+        case 5: build_filter<5>(m, T, fp); return;
+        case 6: build_filter<6>(m, T, fp); return;
+    }
+    fp.why = kEigFail;
+}
+inline void filter_head_any(const ModelHost& m, const FilterPlan& fp, const double* y, double* mout, double* Pout, double* mu_end, double* quad) {
+    switch (m.d) {
+        case 1: filter_head<1>(m, fp, y, mout, Pout, mu_end, quad); return;
+        case 2: filter_head<2>(m, fp, y, mout, Pout, mu_end, quad); return;
+        case 3: filter_head<3>(m, fp, y, mout, Pout, mu_end, quad); return;
+        case 4: filter_head<4>(m, fp, y, mout, Pout, mu_end, quad); return;
+        case 5: filter_head<5>(m, fp, y, mout, Pout, mu_end, quad); return;
+        case 6: filter_head<6>(m, fp, y, mout, Pout, mu_end, quad); return;
+    }
+}
+
 #define TGP_PLAN_DISPATCH(d, expr)                                 \
     switch (d) {                                                   \
         case 1: { constexpr int D = 1; return expr; }              \

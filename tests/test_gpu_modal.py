@@ -273,3 +273,38 @@ def test_rand_of_an_lti_model_with_device_resident_draws(tgp):
     assert names == {"k_rand_one"}, names
     yy = y.cpu().numpy() if hasattr(y, "cpu") else y
     assert np.max(np.abs(yy - y_ref)) <= 1e-9 * max(1.0, float(np.max(np.abs(y_ref))))
+
+
+@pytest.mark.parametrize("d", [1, 2, 3, 4, 5, 6])
+def test_filter_of_an_lti_model_in_one_launch(tgp, d):
+    """_filter(model, y) (lgssm.jl:171-187) of LTI models up to d = 6: the head on the host, everything behind it in ONE kernel
+    (k_filter_one: dense powers of the stationary closed loop) -- against the oracle's literal loop on a short series, against the general
+    engine (TGP_OPT_STEADY = 2) on long ones, lengths around every tile / span boundary, and the log marginal likelihood it returns."""
+    import ctypes as ct
+    from oracle import lgssm_ref as ref
+    rng = np.random.default_rng(700 + d)
+    T = 1500
+    model = oc.build_lgssm(KERNELS[d], ("regular", 0.0, 0.1, T), 0.07)
+    y = draw(model, 800 + d)
+    fm, fP = ref.filter_(model, y)
+    dm = device_model(tgp, model)
+    (gm, gP), names = kernels_of(tgp, dm, lambda: tgp._filter(dm, y))
+    assert names == {"k_filter_one"}, names
+    np.testing.assert_allclose(gm, fm, rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(gP, fP, rtol=1e-8, atol=1e-9)
+    for T, dt in ((4097, 0.1), (8192, 0.3), (60_011, 0.1), (300_007, 0.05)):
+        model = oc.build_lgssm(KERNELS[d], ("regular", 0.0, dt, T), float(np.exp(rng.uniform(np.log(0.003), np.log(0.5)))))
+        y = draw(model, 900 + d)
+        dm, dg = device_model(tgp, model), device_model(tgp, model, steady=2)
+        (gm, gP), names = kernels_of(tgp, dm, lambda: tgp._filter(dm, y))
+        assert names == {"k_filter_one"}, (T, names)
+        rm, rP = tgp._filter(dg, y)
+        assert np.max(np.abs(gm - rm)) <= 1e-8 * max(1.0, float(np.max(np.abs(rm)))), (T, np.max(np.abs(gm - rm)))
+        assert np.max(np.abs(gP - rP)) <= 1e-8 * max(1.0, float(np.max(np.abs(rP)))), (T, np.max(np.abs(gP - rP)))
+        # the by-product: logpdf
+        hd = dm.handle()
+        lml = ct.c_double()
+        yy = np.ascontiguousarray(y)
+        hd.check(hd.lib.tgp_filter(hd.h, yy.ctypes.data, None, 0, None, None, ct.byref(lml)))
+        lp_ref = sk.logpdf(model, y)
+        assert abs(lml.value - lp_ref) <= 1e-10 * abs(lp_ref), (T, lml.value, lp_ref)
