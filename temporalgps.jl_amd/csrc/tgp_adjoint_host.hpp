@@ -24,14 +24,15 @@ inline int record_size(int d) { return 3 * d * d + 8 * d + 8 + d * (d + 1) / 2; 
 
 // rec: the engine's record (record_size(d) doubles); yh: the first nyh observations (nyh >= 512 * head tiles).  Returns 0, or 1 when the
 // record says the engine did not apply / the arguments do not fit it.
-inline int finish(int d, const double* rec, const double* yh, int64_t nyh, const Out& out) {
+// head_steps >= 0: the head's length in steps when it is not a whole number of 512-step tiles (the one-launch adjoint, tgp_modal::adjoint_lti)
+inline int finish(int d, const double* rec, const double* yh, int64_t nyh, const Out& out, int64_t head_steps = -1) {
     const int DD = d * d, NS = DD + 3 * d + 2;
     const double *SA = rec, *Sa = rec + DD, *Sk = rec + DD + d, *Srm = rec + DD + 2 * d;
     const double Sr = rec[DD + 3 * d], SSQ = rec[DD + 3 * d + 1];
     const double *psi_nh = rec + NS, *meta = rec + NS + 2 * d, *md = meta + 4;
     const int64_t n0 = (int64_t)meta[0], th = (int64_t)meta[1], T = (int64_t)meta[2];
-    if (meta[3] != 1.0 || n0 < 0 || th < 1) return 1;
-    const int64_t nh = th * 512;
+    if (meta[3] != 1.0 || n0 < 0 || (th < 1 && head_steps < 0)) return 1;
+    const int64_t nh = head_steps >= 0 ? head_steps : th * 512;
     if (nyh < nh || nh > T) return 1;
     // model blocks, row-major copies
     std::vector<double> A(DD), Q(DD), a(d), h(d), x0m(d), P(DD);

@@ -1927,9 +1927,82 @@ int tgp_adjoint_finish(int d, const double* rec, const double* y_head, int64_t n
     return tgp_adjoint::finish(d, rec, y_head, n_head, o) == 0 ? TGP_OK : TGP_EINVAL;
 }
 
+// The adjoint pass in ONE launch (d <= 4): plan and head on the host (tgp_plan::build_filter / filter_head: the covariance half, the head's
+// forward recursion from its few observations), forward and reverse recursions + the sums behind the head in k_adjoint_one, the head's
+// reverse part and the sweep through the covariance recursion in tgp_adjoint::finish as before.  *served = false: the five-launch form runs.
+static int adjoint_lti_call(tgp_handle* h, const double* y, uint32_t flags, double* lml_out, const tgp_adjoint::Out& o, bool* served) {
+    *served = false;
+    tgp_plan::ModelHost mh;
+    if (!h->opt_modal || h->is_dense || !h->lti || h->p != 1 || h->ordering != 0 || h->sde || h->d > tgp_modal::kAdjointMaxD || !modal_host_model(h, mh)) return TGP_OK;
+    tgp_plan::FilterPlan fp;
+    tgp_plan::build_filter_any(mh, h->T, fp);
+    if (fp.why != tgp_plan::kOk) return TGP_OK;
+    const long long nwg = tgp_modal::adjoint_workgroups(fp, h->T);
+    if (nwg < 1) return TGP_OK;
+    const int d = h->d, ns = tgp_modal::adjoint_sums(d);
+    const size_t dd = (size_t)d * d, nhs = (size_t)fp.nhs, nrec = tgp_adjoint::record_size(d);
+    const size_t need = nhs + (size_t)nwg * ns + d + nrec + 16;
+    if (need > h->flt_cap) {
+        if (h->flt_host) (void)hipHostFree(h->flt_host);
+        h->flt_host = nullptr;
+        h->flt_cap = 0;
+        if (hipHostMalloc(reinterpret_cast<void**>(&h->flt_host), need * sizeof(double), hipHostMallocDefault) != hipSuccess) return h->fail(TGP_EHIP, "hipHostMalloc");
+        h->flt_cap = need;
+    }
+    double *yh = h->flt_host, *part = yh + nhs, *psi = part + (size_t)nwg * ns, *rec = psi + d;
+    CallTimer tm(h, /*clear=*/false);
+    TRY(set_obs(h, y, nullptr, flags));
+    tm.inputs_done();
+    HIPCHK(hipMemcpyAsync(yh, h->mv.y, nhs * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    double mu_end[tgp_plan::kRandMaxD], quad_head = 0.0;
+    tgp_plan::filter_head_any(mh, fp, yh, nullptr, nullptr, mu_end, &quad_head);
+    {
+        LaunchScope ls(h, "k_adjoint_one");
+        const int rc = tgp_modal::adjoint_lti(h->stream, fp, mu_end, h->mv.y, h->T, part, psi);
+        if (rc != 0) return h->fail(TGP_EHIP, std::string("tgp_logpdf_adjoint: launch: ") + hipGetErrorString((hipError_t)rc));
+    }
+    tm.kernels_done();
+    if (h->timing) (void)hipEventRecord(h->ev[3], h->stream);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    resolve_profile(h);
+    // the record tgp_adjoint::finish reads: the sums (fixed order over the workgroups), psi at the head's end, n0 / T, the model blocks
+    for (size_t e = 0; e < nrec; ++e) rec[e] = 0.0;
+    for (long long g = 0; g < nwg; ++g)
+        for (int e = 0; e < ns; ++e) rec[e] += part[(size_t)g * ns + e];
+    for (int i = 0; i < d; ++i) rec[ns + i] = psi[i];
+    double* meta = rec + ns + 2 * d;
+    meta[0] = (double)fp.n0;
+    meta[1] = 0.0;
+    meta[2] = (double)h->T;
+    meta[3] = 1.0;
+    double* md = meta + 4;
+    std::memcpy(md, h->hostm.data(), (2 * dd + 2 * d + 2) * sizeof(double));
+    double* x0 = md + 2 * dd + 2 * d + 2;
+    for (int i = 0; i < d; ++i) x0[i] = h->x0m[i];
+    for (int c = 0; c < d; ++c)
+        for (int r = 0; r <= c; ++r) x0[d + c * (c + 1) / 2 + r] = h->x0P[r + (size_t)c * d];
+    if (tgp_adjoint::finish(d, rec, yh, (int64_t)nhs, o, (int64_t)nhs) != 0) return h->fail(TGP_EHIP, "tgp_logpdf_adjoint: inconsistent record");
+    const double ssq = rec[dd + 3 * d + 1];
+    const double lml = -0.5 * ((double)h->T * 1.8378770664093454835606594728112 + fp.LS + (double)(h->T - fp.n0) * fp.logS + quad_head + fp.iS * ssq);
+    for (int i = 0; i < 8; ++i) h->host_result[i] = 0.0;
+    h->host_result[0] = lml;
+    if (lml_out) *lml_out = lml;
+    h->reduce_valid = false;
+    h->smoother_valid = false;
+    *served = true;
+    return TGP_OK;
+}
+
 int tgp_logpdf_adjoint(tgp_handle* h, const double* y, uint32_t flags, double* lml_out, double* gA, double* ga, double* gQ, double* gH,
                        double* ghh, double* gR, double* gx0m, double* gx0P) {
     TRY(check_ready(h, /*general=*/false));
+    if (y != nullptr) {
+        bool served = false;
+        const tgp_adjoint::Out o1{gA, ga, gQ, gH, ghh, gR, gx0m, gx0P};
+        TRY(adjoint_lti_call(h, y, flags, lml_out, o1, &served));
+        if (served) return TGP_OK;
+    }
     h->steady2_last = false;
     const int keep_state = h->steady2_state;
     h->steady2_state = 0;            // (an earlier "does not apply" verdict of a posterior call -- series shorter than head + tail -- does not bind this one)

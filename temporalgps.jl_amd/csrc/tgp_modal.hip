@@ -1928,4 +1928,393 @@ int filter_lti(hipStream_t stream, const tgp_plan::FilterPlan& fp, const double*
     return (int)hipErrorInvalidValue;
 }
 
+// =================================================================================================================================
+// The adjoint (gradient) pass of an LTI model behind its head, in one launch.  k_filter_one's forward half gives a lane
+// its true start state; a second forward sweep keeps mu_j and r_j of its 8 steps; the adjoint psi = Phi' psi + h r / S runs the same way
+// backwards (zero-start sweep, reverse scan by DPP moves on the TRANSPOSED powers -- the same table read the other way --, chaining over the
+// <= 3 tiles behind); the last sweep walks the 8 steps backwards with the true psi and accumulates the d^2 + 3 d + 2 sums.  Spans carry a
+// halo at both ends.
+// =================================================================================================================================
+namespace {
+template <int D>
+struct GArgs {
+    double Phi[D][D], a[D], kA[D], h[D], hh, iS;
+    double P[6][D][D], PT[2][D][D];
+    double mu0[D];
+    long long T, C, nwg, nhs;
+    int halo;
+    const double* y;
+    double *part, *psi_out;
+};
+
+template <int D, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void k_adjoint_one(const GArgs<D> by_value) {
+    (void)by_value;
+    const GArgs<D>& ka = *(const GArgs<D>*)__builtin_amdgcn_kernarg_segment_ptr();
+    constexpr int SUB = kWJ, TILE = 64 * SUB, NS = D * D + 3 * D + 2;
+    __shared__ double sF[NW][D], sB[NW][D], sAcc[NW][NS];
+    __shared__ double sPw[D][D][64];      // Phi^(8 e), e = 0 .. 63
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    long long g;
+    {
+        const long long per = (ka.nwg + 7) / 8;
+        g = (long long)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+        if ((long long)(blockIdx.x >> 3) >= per || g >= ka.nwg) return;
+    }
+    const long long T = ka.T, c_lo = ka.nhs + g * ka.C, c_hi = (c_lo + ka.C < T) ? c_lo + ka.C : T;
+    const bool first = g == 0;
+    const long long s0 = first ? ka.nhs : c_lo - ka.halo;
+    const long long tile_t0 = s0 + (long long)wave * TILE, t0 = tile_t0 + (long long)lane * SUB;
+    const bool any_valid = tile_t0 < T && tile_t0 < c_hi + ka.halo;      // (wave-uniform: tiles behind the right-hand halo have nothing to do)
+    {
+        const int uw = __builtin_amdgcn_readfirstlane(wave);
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            if (uw != i % NW) continue;
+            double row[D];
+#pragma unroll
+            for (int k = 0; k < D; ++k) row[k] = (k == i) ? 1.0 : 0.0;
+#pragma unroll
+            for (int b = 0; b < 6; ++b) {
+                double nr[D];
+#pragma unroll
+                for (int k = 0; k < D; ++k) {
+                    double v = 0.0;
+#pragma unroll
+                    for (int m = 0; m < D; ++m) v = fma(row[m], ka.P[b][m][k], v);
+                    nr[k] = v;
+                }
+                const bool bit = ((lane >> b) & 1) != 0;
+#pragma unroll
+                for (int k = 0; k < D; ++k) row[k] = bit ? nr[k] : row[k];
+            }
+#pragma unroll
+            for (int k = 0; k < D; ++k) sPw[i][k][lane] = row[k];
+        }
+    }
+    // ---- forward, zero start
+    double u[SUB], x[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) x[i] = 0.0;
+#pragma unroll
+    for (int j = 0; j < SUB; ++j) u[j] = 0.0;
+    if (any_valid) {
+        if (t0 + SUB <= T && (reinterpret_cast<uintptr_t>(ka.y) & 15) == 0) {
+            const v2d* q = reinterpret_cast<const v2d*>(ka.y + t0);
+#pragma unroll
+            for (int j = 0; j < SUB / 2; ++j) {
+                const v2d w = q[j];
+                u[2 * j] = w.x - ka.hh;
+                u[2 * j + 1] = w.y - ka.hh;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < SUB; ++j) u[j] = t0 + j < T ? ka.y[t0 + j] - ka.hh : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < SUB; ++j) {
+            double nx[D];
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                double v = fma(ka.kA[i], u[j], ka.a[i]);
+#pragma unroll
+                for (int k = 0; k < D; ++k) v = fma(ka.Phi[i][k], x[k], v);
+                nx[i] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < D; ++i) x[i] = nx[i];
+        }
+    }
+    __syncthreads();
+    double st[D];
+    if (any_valid) {
+#define TGP_ADJ_FWD(K)                                                                     \
+    do {                                                                                   \
+        double g_[D], n_[D];                                                               \
+        _Pragma("unroll") for (int i = 0; i < D; ++i) {                                    \
+            g_[i] = dpp_mov<0x110 + (1 << (K))>(x[i]);                                     \
+            n_[i] = x[i];                                                                  \
+        }                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < D; ++i)                                      \
+            _Pragma("unroll") for (int k = 0; k < D; ++k) n_[i] = fma(ka.P[K][i][k], g_[k], n_[i]); \
+        _Pragma("unroll") for (int i = 0; i < D; ++i) x[i] = n_[i];                        \
+    } while (0)
+        TGP_ADJ_FWD(0);
+        TGP_ADJ_FWD(1);
+        TGP_ADJ_FWD(2);
+        TGP_ADJ_FWD(3);
+#undef TGP_ADJ_FWD
+        const int e1 = (lane & 15) + 1, e2 = lane >= 32 ? lane - 31 : 0;
+        double gv[D], nv[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            gv[i] = dpp_mov<0x142, 0xA>(x[i]);
+            nv[i] = x[i];
+        }
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int k = 0; k < D; ++k) nv[i] = fma(sPw[i][k][e1], gv[k], nv[i]);
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            x[i] = nv[i];
+            gv[i] = dpp_mov<0x143, 0xC>(nv[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int k = 0; k < D; ++k) nv[i] = fma(sPw[i][k][e2], gv[k], nv[i]);
+#pragma unroll
+        for (int i = 0; i < D; ++i) x[i] = nv[i];
+    }
+#pragma unroll
+    for (int i = 0; i < D; ++i) st[i] = dpp_mov<0x138>(x[i]);
+    if (lane == 63) {
+#pragma unroll
+        for (int i = 0; i < D; ++i) sF[wave][i] = any_valid ? x[i] : 0.0;
+    }
+    __syncthreads();
+    // ---- the true start state, then the lane's predicted means and innovations
+    double mus[SUB][D], r[SUB], psi[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) psi[i] = 0.0;
+#pragma unroll
+    for (int j = 0; j < SUB; ++j) {
+        r[j] = 0.0;
+#pragma unroll
+        for (int i = 0; i < D; ++i) mus[j][i] = 0.0;
+    }
+    if (any_valid) {
+        double zin[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) zin[i] = 0.0;
+#pragma unroll
+        for (int k = 1; k <= 3; ++k) {
+            const int src = wave - k;
+            if (src < -1 || (src == -1 && !first)) continue;
+            double xs[D];
+#pragma unroll
+            for (int i = 0; i < D; ++i) xs[i] = src >= 0 ? sF[src][i] : ka.mu0[i];
+            if (k == 1) {
+#pragma unroll
+                for (int i = 0; i < D; ++i) zin[i] += xs[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < D; ++i)
+#pragma unroll
+                    for (int m = 0; m < D; ++m) zin[i] = fma(ka.PT[k - 2][i][m], xs[m], zin[i]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int k = 0; k < D; ++k) st[i] = fma(sPw[i][k][lane], zin[k], st[i]);
+#pragma unroll
+        for (int j = 0; j < SUB; ++j) {
+            double rr = u[j];
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                mus[j][k] = st[k];
+                rr = fma(-ka.h[k], st[k], rr);
+            }
+            r[j] = t0 + j < T ? rr : 0.0;      // (steps behind the series' end: no innovation, no adjoint)
+            double nx[D];
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                double v = fma(ka.kA[i], u[j], ka.a[i]);
+#pragma unroll
+                for (int k = 0; k < D; ++k) v = fma(ka.Phi[i][k], st[k], v);
+                nx[i] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < D; ++i) st[i] = nx[i];
+        }
+        // ---- backward, zero psi behind the lane: psi <- Phi' psi + h r / S
+#pragma unroll
+        for (int j = SUB - 1; j >= 0; --j) {
+            const double c = r[j] * ka.iS;
+            double np[D];
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                double v = ka.h[i] * c;
+#pragma unroll
+                for (int k = 0; k < D; ++k) v = fma(ka.Phi[k][i], psi[k], v);
+                np[i] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < D; ++i) psi[i] = np[i];
+        }
+        // reverse scan: lane l <- sum_{m >= l} (Phi')^(8 (m - l)) psi_m
+#define TGP_ADJ_BWD(K)                                                                     \
+    do {                                                                                   \
+        double g_[D], n_[D];                                                               \
+        _Pragma("unroll") for (int i = 0; i < D; ++i) {                                    \
+            g_[i] = dpp_mov<0x100 + (1 << (K))>(psi[i]);                                   \
+            n_[i] = psi[i];                                                                \
+        }                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < D; ++i)                                      \
+            _Pragma("unroll") for (int k = 0; k < D; ++k) n_[i] = fma(ka.P[K][k][i], g_[k], n_[i]); \
+        _Pragma("unroll") for (int i = 0; i < D; ++i) psi[i] = n_[i];                      \
+    } while (0)
+        TGP_ADJ_BWD(0);
+        TGP_ADJ_BWD(1);
+        TGP_ADJ_BWD(2);
+        TGP_ADJ_BWD(3);
+#undef TGP_ADJ_BWD
+        {
+            const int e1 = 16 - (lane & 15);      // rows 0 and 2 take the first lane of the row above them, 16 - p lanes away
+            double gv[D], nv[D];
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                gv[i] = dpp_mov<0x15F, 0x5>(dpp_mov<0x130>(psi[i]));
+                nv[i] = psi[i];
+            }
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int k = 0; k < D; ++k) nv[i] = fma(sPw[k][i][e1], gv[k], nv[i]);
+#pragma unroll
+            for (int i = 0; i < D; ++i) psi[i] = nv[i];
+            const int e2 = lane < 32 ? 32 - lane : 0;      // the lower half takes lane 32
+            const double keep = lane < 32 ? 1.0 : 0.0;
+#pragma unroll
+            for (int i = 0; i < D; ++i) gv[i] = readlane_d(psi[i], 32) * keep;
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int k = 0; k < D; ++k) nv[i] = fma(sPw[k][i][e2], gv[k], nv[i]);
+#pragma unroll
+            for (int i = 0; i < D; ++i) psi[i] = nv[i];
+        }
+    }
+    double pin[D];      // the adjoint behind the lane's last step: its right neighbour's (lane 63: zero)
+#pragma unroll
+    for (int i = 0; i < D; ++i) pin[i] = dpp_mov<0x130>(psi[i]);
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < D; ++i) sB[wave][i] = any_valid ? psi[i] : 0.0;
+    }
+    __syncthreads();
+    double acc[NS];
+#pragma unroll
+    for (int e = 0; e < NS; ++e) acc[e] = 0.0;
+    if (any_valid) {
+        double zin[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) zin[i] = 0.0;
+#pragma unroll
+        for (int k = 1; k <= 3; ++k) {
+            const int src = wave + k;
+            if (src >= NW) continue;
+            if (k == 1) {
+#pragma unroll
+                for (int i = 0; i < D; ++i) zin[i] += sB[src][i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < D; ++i)
+#pragma unroll
+                    for (int m = 0; m < D; ++m) zin[i] = fma(ka.PT[k - 2][m][i], sB[src][m], zin[i]);
+            }
+        }
+        const int eb = 63 - lane;
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int k = 0; k < D; ++k) pin[i] = fma(sPw[k][i][eb], zin[k], pin[i]);
+        // ---- the last sweep: the lane's steps backwards with the true adjoint; sums over the steps the workgroup owns
+#pragma unroll
+        for (int j = SUB - 1; j >= 0; --j) {
+            const long long t = t0 + j;
+            const double own = (t >= c_lo && t < c_hi) ? 1.0 : 0.0;
+            const double rj = r[j];
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                const double pw = pin[i] * own;
+#pragma unroll
+                for (int k = 0; k < D; ++k) acc[i * D + k] = fma(pw, mus[j][k], acc[i * D + k]);
+                acc[D * D + i] += pw;
+                acc[D * D + D + i] = fma(pw, rj, acc[D * D + D + i]);
+                acc[D * D + 2 * D + i] = fma(rj * own, mus[j][i], acc[D * D + 2 * D + i]);
+            }
+            acc[D * D + 3 * D] = fma(rj, own, acc[D * D + 3 * D]);
+            acc[D * D + 3 * D + 1] = fma(rj * own, rj, acc[D * D + 3 * D + 1]);
+            const double c = rj * ka.iS;
+            double np[D];
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                double v = ka.h[i] * c;
+#pragma unroll
+                for (int k = 0; k < D; ++k) v = fma(ka.Phi[k][i], pin[k], v);
+                np[i] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < D; ++i) pin[i] = np[i];
+        }
+        if (first && wave == 0 && lane == 0) {
+#pragma unroll
+            for (int i = 0; i < D; ++i) ka.psi_out[i] = pin[i];      // d logpdf / d mu at step nhs: where the host's half takes over
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < NS; ++e) {
+        const double s = wave_sum_to_lane63(acc[e]);
+        if (lane == 63) sAcc[wave][e] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < NS) {
+        double tsum = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) tsum += sAcc[w][threadIdx.x];
+        ka.part[g * NS + threadIdx.x] = tsum;
+    }
+}
+
+template <int D>
+int launch_adjoint(hipStream_t st, const tgp_plan::FilterPlan& fp, const double* mu0, const double* y, long long T, double* part, double* psi_out) {
+    constexpr int NW = 8;
+    GArgs<D> ka;
+    static_assert(sizeof(GArgs<D>) <= 4096, "the kernel-argument segment");
+    std::memset(&ka, 0, sizeof ka);
+    for (int i = 0; i < D; ++i) {
+        ka.a[i] = fp.a[i];
+        ka.kA[i] = fp.kA[i];
+        ka.h[i] = fp.h[i];
+        ka.mu0[i] = mu0[i];
+        for (int k = 0; k < D; ++k) {
+            ka.Phi[i][k] = fp.Phi[i * D + k];
+            for (int b = 0; b < 6; ++b) ka.P[b][i][k] = fp.P[b][i * D + k];
+            for (int b = 0; b < 2; ++b) ka.PT[b][i][k] = fp.PT[b][i * D + k];
+        }
+    }
+    ka.hh = fp.hh;
+    ka.iS = fp.iS;
+    ka.T = T;
+    ka.nhs = fp.nhs;
+    ka.halo = fp.halo;
+    ka.C = (long long)NW * 64 * kWJ - 2LL * fp.halo;
+    ka.nwg = (T - fp.nhs + ka.C - 1) / ka.C;
+    ka.y = y;
+    ka.part = part;
+    ka.psi_out = psi_out;
+    const long long per = (ka.nwg + 7) / 8;
+    hipLaunchKernelGGL((k_adjoint_one<D, NW>), dim3((unsigned)(per * 8)), dim3(NW * 64), 0, st, ka);
+    return (int)hipGetLastError();
+}
+}  // namespace
+
+long long adjoint_workgroups(const tgp_plan::FilterPlan& fp, long long T) {
+    const long long C = 8LL * 64 * kWJ - 2LL * fp.halo;
+    return C > 0 ? (T - fp.nhs + C - 1) / C : -1;
+}
+
+int adjoint_lti(hipStream_t stream, const tgp_plan::FilterPlan& fp, const double* mu_start, const double* y, long long T, double* part, double* psi_out) {
+    switch (fp.d) {
+        case 1: return launch_adjoint<1>(stream, fp, mu_start, y, T, part, psi_out);
+        case 2: return launch_adjoint<2>(stream, fp, mu_start, y, T, part, psi_out);
+        case 3: return launch_adjoint<3>(stream, fp, mu_start, y, T, part, psi_out);
+        case 4: return launch_adjoint<4>(stream, fp, mu_start, y, T, part, psi_out);
+    }
+    return (int)hipErrorInvalidValue;
+}
+
 }  // namespace tgp_modal

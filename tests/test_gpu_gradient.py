@@ -303,8 +303,14 @@ def test_adjoint_equals_tangent_scans_on_a_long_series_and_refuses_what_it_does_
         P.logpdf_and_gradient(fxm, ym, method="adjoint")
     lp, g = P.logpdf_and_gradient(fxm, ym)          # the default policy falls back to the tangent scans
     assert np.isfinite(lp) and set(g) == {"noise"}
-    # a series shorter than the head: refused by the device, served by the tangent scans under the default policy
+    # a short series: the one-launch form of the pass (head on the host, d <= 4) serves it as long as it is longer than the head ...
     fxs = P.to_sde(P.GP(P.Matern32Kernel()))(P.RegularSpacing(0.0, 0.1, 300), 0.1)
+    ys = np.random.default_rng(3).standard_normal(300)
+    lp_a, g_a = P.logpdf_and_gradient(fxs, ys, method="adjoint")
+    lp_t, g_t = P.logpdf_and_gradient(fxs, ys, method="tangent")
+    assert abs(lp_a - lp_t) <= 1e-11 * abs(lp_t) and abs(g_a["noise"] - g_t["noise"]) <= 1e-8 * abs(g_t["noise"])
+    # ... one shorter than the head is refused by the device, served by the tangent scans under the default policy
+    fxs = P.to_sde(P.GP(P.Matern32Kernel()))(P.RegularSpacing(0.0, 0.1, 12), 0.1)
     with pytest.raises(tgp._lib.Unsupported):
-        P.logpdf_and_gradient(fxs, np.zeros(300), method="adjoint")
-    assert set(P.logpdf_and_gradient(fxs, np.zeros(300))[1]) == {"noise"}
+        P.logpdf_and_gradient(fxs, np.zeros(12), method="adjoint")
+    assert set(P.logpdf_and_gradient(fxs, np.zeros(12))[1]) == {"noise"}
