@@ -266,6 +266,7 @@ def test_group_filter_and_materialised_posterior(tgp, d, ordering):
     dm = tgp.LGSSM(tr, tgp.ScalarOutputLGC(model["H"], model["h"], model["R"]), T=T)
     hd = dm.handle()
     hd.set_option(tgp._lib.OPT_GROUP, 2)
+    hd.set_option(tgp._lib.OPT_STEADY, 2)      # (the default would serve a Forward LTI filter of d <= 6 by the one-launch kernel: tests/test_gpu_modal.py holds that path)
     fm, fP = ref.filter_(model, y)
     for chunk in (0, 7):
         hd.set_option(tgp._lib.OPT_CHUNK, chunk)
