@@ -207,7 +207,7 @@ int tgp_logpdf_grad_sde(tgp_handle* h, const double* y, const uint8_t* missing, 
  * with d block / d theta of its own parametrisation (the O(1) host map lti_sde.jl:148-160). Any output may be NULL.
  * gA, gQ, gx0P [d*d] column-major (gQ, gx0P symmetrised), ga, gH, gx0m [d], ghh, gR [1]; all host pointers.
  * Replaces Mooncake's reverse mode over the sequential loop (bench/single_output_gps.jl:149-156, test/gp/lti_sde.jl:203-206).
- * d <= 4 (TGP_OPT_STEADY = 3, the default): plan and head on the host, ONE kernel behind the head.
+ * d <= 6 (TGP_OPT_STEADY = 3, the default): plan and head on the host, ONE kernel behind the head.
  * TGP_EUNSUPPORTED when the engine does not apply (use tgp_logpdf_grad). */
 int tgp_logpdf_adjoint(tgp_handle* h, const double* y, uint32_t flags, double* lml_out, double* gA, double* ga,
                        double* gQ, double* gH, double* ghh, double* gR, double* gx0m, double* gx0P);

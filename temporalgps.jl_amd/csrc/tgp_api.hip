@@ -1927,7 +1927,7 @@ int tgp_adjoint_finish(int d, const double* rec, const double* y_head, int64_t n
     return tgp_adjoint::finish(d, rec, y_head, n_head, o) == 0 ? TGP_OK : TGP_EINVAL;
 }
 
-// The adjoint pass in ONE launch (d <= 4): plan and head on the host (tgp_plan::build_filter / filter_head: the covariance half, the head's
+// The adjoint pass in ONE launch (d <= 6): plan and head on the host (tgp_plan::build_filter / filter_head: the covariance half, the head's
 // forward recursion from its few observations), forward and reverse recursions + the sums behind the head in k_adjoint_one, the head's
 // reverse part and the sweep through the covariance recursion in tgp_adjoint::finish as before.  *served = false: the five-launch form runs.
 static int adjoint_lti_call(tgp_handle* h, const double* y, uint32_t flags, double* lml_out, const tgp_adjoint::Out& o, bool* served) {

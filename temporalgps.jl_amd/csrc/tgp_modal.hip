@@ -2313,6 +2313,8 @@ int adjoint_lti(hipStream_t stream, const tgp_plan::FilterPlan& fp, const double
         case 2: return launch_adjoint<2>(stream, fp, mu_start, y, T, part, psi_out);
         case 3: return launch_adjoint<3>(stream, fp, mu_start, y, T, part, psi_out);
         case 4: return launch_adjoint<4>(stream, fp, mu_start, y, T, part, psi_out);
+        case 5: return launch_adjoint<5>(stream, fp, mu_start, y, T, part, psi_out);
+        case 6: return launch_adjoint<6>(stream, fp, mu_start, y, T, part, psi_out);
     }
     return (int)hipErrorInvalidValue;
 }

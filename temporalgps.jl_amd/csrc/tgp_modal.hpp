@@ -58,11 +58,11 @@ void choose_geometry(int d, int halo, int* waves, int* steps_per_lane);
 long long filter_workgroups(const tgp_plan::FilterPlan& plan, long long T);
 int filter_lti(hipStream_t stream, const tgp_plan::FilterPlan& plan, const double* mu_start, const double* y, long long T, double* m_out, double* P_out,
                double* part);
-// The device half of d logpdf / d (model blocks) of an LTI model by ONE reverse-time pass behind the head, in ONE kernel (d <= 4):
+// The device half of d logpdf / d (model blocks) of an LTI model by ONE reverse-time pass behind the head, in ONE kernel (d <= 6):
 // forwards mu' = Phi mu + a + (A K) u, backwards psi = Phi' psi + h r / S, and the sums SA = sum psi_{t+1} mu_t', Sa, Sk = sum psi_{t+1} r_t,
 // Srm = sum r_t mu_t, Sr, sum r^2 over the steps [nhs, T) -- d^2 + 3 d + 2 values per workgroup into `part` (pinned host memory,
 // adjoint_workgroups() x adjoint_sums(d) values), psi at step nhs into psi_out (pinned, d values).  tgp_adjoint::finish does the head and the rest.
-constexpr int kAdjointMaxD = 4;
+constexpr int kAdjointMaxD = 6;
 inline int adjoint_sums(int d) { return d * d + 3 * d + 2; }
 long long adjoint_workgroups(const tgp_plan::FilterPlan& plan, long long T);
 int adjoint_lti(hipStream_t stream, const tgp_plan::FilterPlan& plan, const double* mu_start, const double* y, long long T, double* part, double* psi_out);
