@@ -328,6 +328,7 @@ struct tgp_handle {
     tgp_modal::Engine* modal = nullptr;
     int modal_state = 0;         // 0 untried for the bound model, 1 served the last call, -1 does not apply
     bool modal_last = false;
+    int64_t dense_last_n0 = -1;   // >= 0: the last call ran on the dense-power one-launch kernels behind a head of that many steps with gains of their own
     std::vector<double> hostm;   // host copy of the shared blocks of an LTI model: A | a | Q | H | hh | R (what the host plan reads)
     void* steady2_scope = nullptr;
     bool table_pending = false;  // the kernel-variant choice (and its run-time check) of the general engine is deferred to its first use
@@ -1125,6 +1126,7 @@ int steady2_enqueue(tgp_handle* h, const double* Rnew_dev, bool rnew_per_step, d
 int modal_call(tgp_handle* h, const double* y, uint32_t flags, const double* Rnew, double* mean_out, double* var_out, double* lml_out, bool* served) {
     *served = false;
     h->modal_last = false;
+    h->dense_last_n0 = -1;
     if (!h->opt_modal || h->modal_state < 0 || h->hostm.empty()) return TGP_OK;
     if (!h->modal) h->modal = tgp_modal::create();
     static const bool dbg = getenv("TGP_STEADY_DEBUG") != nullptr;
@@ -1400,6 +1402,10 @@ int tgp_steady_steps(tgp_handle* h, int64_t* mean_only, int64_t* total) {
     *mean_only = 0;
     *total = h->T * h->p;
     if (h->is_dense) return TGP_OK;
+    if (h->dense_last_n0 >= 0) {              // k_filter_one / k_adjoint_one: the same, on dense powers
+        *mean_only = h->T - h->dense_last_n0;
+        return TGP_OK;
+    }
     if (h->modal_last && h->modal) {          // one-launch path: every step beyond the head's n0 ran with the stationary gains
         *mean_only = h->T - tgp_modal::last_plan(h->modal).n0;
         return TGP_OK;
@@ -1451,6 +1457,7 @@ int tgp_model_set(tgp_handle* h, int64_t T, int d, int p, int ordering, uint32_t
     h->steady2_last = false;
     h->modal_state = 0;
     h->modal_last = false;
+    h->dense_last_n0 = -1;
     h->hostm.clear();
     h->fold_valid = false;
     h->reduce_valid = false;
@@ -1720,15 +1727,24 @@ int tgp_model_set_x0(tgp_handle* h, const double* x0m, const double* x0P) {
     return upload_x0(h, h->bx0, x0m, x0P);
 }
 
+static int filter_lti_call(tgp_handle* h, const double* y, uint32_t flags, double* m_out, double* P_out, double* lml_out, bool* served);
+
 int tgp_logpdf(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t flags, double* out) {
     TRY(check_ready(h, /*general=*/false));
     if (!out) return h->fail(TGP_EINVAL, "out is NULL");
     h->steady2_last = false;
     h->modal_last = false;
+    h->dense_last_n0 = -1;
     if (steady2_eligible(h, missing, flags)) {
         bool served = false;
         TRY(modal_call(h, y, flags, nullptr, nullptr, nullptr, out, &served));
         if (served) return TGP_OK;
+        // no well-conditioned modal form (two summands with one length scale, ...): logpdf is the by-product of the filter's forward
+        // recursion, which needs none -- ONE kernel on the dense powers of the closed loop (d <= 6; k_filter_one without its outputs)
+        if (h->opt_modal && missing == nullptr && y != nullptr) {
+            TRY(filter_lti_call(h, y, flags, nullptr, nullptr, out, &served));
+            if (served) return TGP_OK;
+        }
     }
     if (steady2_eligible(h, missing, flags)) {
         CallTimer tm(h, /*clear=*/false);      // (the engine's set-up kernel clears the result record itself: one launch less)
@@ -1821,6 +1837,7 @@ int tgp_segment_logpdf_and_posterior_marginals(tgp_handle* h, int64_t T_total, i
     if ((mean_out != nullptr) != (var_out != nullptr) || (mean_out && !Rnew)) return h->fail(TGP_EINVAL, "tgp_segment_*: mean, var and Rnew go together");
     if (!h->modal) h->modal = tgp_modal::create();
     h->modal_last = false;
+    h->dense_last_n0 = -1;
     h->steady2_last = false;
     if (!tgp_modal::plan(h->modal, mh, T_total)) return h->fail(TGP_EUNSUPPORTED, "tgp_segment_*: the one-launch path does not apply to this model / series");
     const tgp_plan::Modal& md = tgp_modal::last_modal(h->modal);
@@ -1990,6 +2007,9 @@ static int adjoint_lti_call(tgp_handle* h, const double* y, uint32_t flags, doub
     if (lml_out) *lml_out = lml;
     h->reduce_valid = false;
     h->smoother_valid = false;
+    h->modal_last = false;
+    h->steady2_last = false;
+    h->dense_last_n0 = fp.n0;
     *served = true;
     return TGP_OK;
 }
@@ -1997,6 +2017,8 @@ static int adjoint_lti_call(tgp_handle* h, const double* y, uint32_t flags, doub
 int tgp_logpdf_adjoint(tgp_handle* h, const double* y, uint32_t flags, double* lml_out, double* gA, double* ga, double* gQ, double* gH,
                        double* ghh, double* gR, double* gx0m, double* gx0P) {
     TRY(check_ready(h, /*general=*/false));
+    h->dense_last_n0 = -1;
+    h->modal_last = false;
     if (y != nullptr) {
         bool served = false;
         const tgp_adjoint::Out o1{gA, ga, gQ, gH, ghh, gR, gx0m, gx0P};
@@ -2088,12 +2110,18 @@ static int filter_lti_call(tgp_handle* h, const double* y, uint32_t flags, doubl
     if (lml_out) *lml_out = lml;
     h->reduce_valid = false;
     h->smoother_valid = false;
+    h->modal_last = false;
+    h->steady2_last = false;
+    h->dense_last_n0 = fp.n0;
     *served = true;
     return TGP_OK;
 }
 
 int tgp_filter(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t flags, double* m_out, double* P_out, double* lml_out) {
     TRY(check_ready(h, /*general=*/false));
+    h->dense_last_n0 = -1;
+    h->modal_last = false;
+    h->steady2_last = false;
     if (missing == nullptr && y != nullptr) {
         bool served = false;
         TRY(filter_lti_call(h, y, flags, m_out, P_out, lml_out, &served));
@@ -2229,6 +2257,7 @@ int tgp_posterior_marginals(tgp_handle* h, const double* y, const uint8_t* missi
     const size_t nT = (size_t)h->T * h->p * sizeof(double);   // one value per (time step, observation)
     h->steady2_last = false;
     h->modal_last = false;
+    h->dense_last_n0 = -1;
     if (steady2_eligible(h, missing, flags)) {
         bool served = false;
         TRY(modal_call(h, y, flags, Rnew, mean_out, var_out, lml_out, &served));

@@ -148,7 +148,23 @@ def test_models_the_plan_declines_go_to_the_older_engines(tgp):
     y = draw(model, 1)
     dm = device_model(tgp, model)
     lp, names = kernels_of(tgp, dm, lambda: tgp.logpdf(dm, y))
-    assert "k_steady_apply<logpdf>" in names and not any(n.startswith("k_steady_one") for n in names), names
+    # logpdf needs no modal form: the filter's forward recursion on the dense powers of the closed loop, one kernel (d <= 6)
+    assert names == {"k_filter_one"}, names
+    assert served(dm) > T - 700
+    lp_ref = sk.logpdf(model, y)
+    assert abs(lp - lp_ref) <= 1e-10 * abs(lp_ref)
+    Rn = np.array([0.2])
+    (mean, var), names = kernels_of(tgp, dm, lambda: tgp.posterior_marginals(dm, y, Rn))
+    assert "k_steady_apply<posterior>" in names and not any(n.startswith("k_steady_one") for n in names), names
+    m_ref, v_ref = sk.posterior_marginals(model, y, Rn)
+    assert np.max(np.abs(mean - m_ref)) <= 1e-8 and np.max(np.abs(var - v_ref)) <= 1e-8
+    assert abs(tgp.logpdf(dm, y) - lp_ref) <= 1e-10 * abs(lp_ref)      # (and again behind a posterior call)
+    # d = 8 without a modal form: the five-launch engine serves logpdf too
+    model = oc.build_lgssm(("sum", ("matern52",), ("matern52",), ("matern32",)), ("regular", 0.0, 0.1, T), 0.1)
+    y = draw(model, 2)
+    dm = device_model(tgp, model)
+    lp, names = kernels_of(tgp, dm, lambda: tgp.logpdf(dm, y))
+    assert "k_steady_apply<logpdf>" in names and not any(n.startswith(("k_steady_one", "k_filter_one")) for n in names), names
     lp_ref = sk.logpdf(model, y)
     assert abs(lp - lp_ref) <= 1e-10 * abs(lp_ref)
 
