@@ -260,7 +260,9 @@ int tgp_filter(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t 
 /* ---- posterior(model, y): lgssm.jl:193-238. Materialises the time-reversed model:
  *      G [T][d*d], g [T][d], L [T][d*d] (all three or none), xfm (d) / xfP (d*d): x0 of the posterior
  *      (host pointers). Forward priors (step_posterior(::Forward), :215-221) and Reverse priors (step_posterior(::Reverse), :223-228:
- *      invert_dynamics(xp, xf, t) as the reference calls it, x0 = the state after the last step's predict; G, g, L must be requested). */
+ *      invert_dynamics(xp, xf, t) as the reference calls it, x0 = the state after the last step's predict; G, g, L must be requested).
+ *      A Forward LTI model with scalar observations, one noise variance, no missing data and d <= 6: the head's transitions on the host,
+ *      everything behind it by the filter's ONE kernel (G, L constant there; TGP_OPT_STEADY = 3, the default). */
 int tgp_posterior(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t flags, double* G,
                   double* g, double* L, double* xfm, double* xfP);
 

@@ -2155,10 +2155,89 @@ int tgp_filter(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t 
     return tm.finish(lml_out);
 }
 
+// posterior(model, y) of a Forward LTI model (lgssm.jl:193-221; scalar observations, one noise variance, no missing data, d <= 6): the
+// reverse-time transitions of the head on the host, everything behind it -- two constant fills and g_(t+1) = m_t - G mu_(t+1) -- by the
+// filter's ONE kernel (tgp_modal.hpp: PosteriorOut).
+static int posterior_lti_call(tgp_handle* h, const double* y, uint32_t flags, double* G, double* g, double* L, double* xfm, double* xfP, bool* served) {
+    *served = false;
+    tgp_plan::ModelHost mh;
+    if (!h->opt_modal || h->is_dense || !h->lti || h->p != 1 || h->ordering != 0 || h->sde || h->d > tgp_plan::kRandMaxD || !modal_host_model(h, mh)) return TGP_OK;
+    tgp_plan::FilterPlan fp;
+    tgp_plan::build_filter_any(mh, h->T, fp);
+    if (fp.why != tgp_plan::kOk) return TGP_OK;
+    const int d = h->d;
+    const size_t dd = (size_t)d * d, nhs = (size_t)fp.nhs;
+    const long long nwg = tgp_modal::filter_workgroups(fp, h->T);
+    const size_t need = nhs * (1 + 2 * dd) + (nhs + 1) * d + 2 * dd + (size_t)nwg + d + 8;
+    if (need > h->flt_cap) {
+        if (h->flt_host) (void)hipHostFree(h->flt_host);
+        h->flt_host = nullptr;
+        h->flt_cap = 0;
+        if (hipHostMalloc(reinterpret_cast<void**>(&h->flt_host), need * sizeof(double), hipHostMallocDefault) != hipSuccess) return h->fail(TGP_EHIP, "hipHostMalloc");
+        h->flt_cap = need;
+    }
+    double *yh = h->flt_host, *Gh = yh + nhs, *Lh = Gh + nhs * dd, *gh = Lh + nhs * dd, *Gss = gh + (nhs + 1) * d, *Lss = Gss + dd, *fin = Lss + dd,
+           *part = fin + d;
+    const bool odev = (flags & TGP_OUT_DEVICE) != 0;
+    const size_t ng = (size_t)h->T * d * sizeof(double), nG = ng * d;
+    CallTimer tm(h, /*clear=*/false);
+    TRY(set_obs(h, y, nullptr, flags));
+    tm.inputs_done();
+    HIPCHK(hipMemcpyAsync(yh, h->mv.y, nhs * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    double mu_end[tgp_plan::kRandMaxD], quad_head = 0.0;
+    if (!tgp_plan::posterior_head_any(mh, fp, yh, Gh, gh, Lh, Gss, Lss, mu_end, &quad_head)) return TGP_OK;      // (the general engine reports it)
+    double *dG = nullptr, *dg = nullptr, *dL = nullptr;
+    TRY(stage_out(h, h->bo1, G, nG, odev, &dG));
+    TRY(stage_out(h, h->bo2, g, ng, odev, &dg));
+    TRY(stage_out(h, h->bo3, L, nG, odev, &dL));
+    HIPCHK(hipMemcpyAsync(dG, Gh, nhs * dd * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(dL, Lh, nhs * dd * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(dg, gh, (nhs + 1) * d * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    {
+        LaunchScope ls(h, "k_filter_one");
+        const tgp_modal::PosteriorOut po{Gss, Lss, dG, dg, dL, fin};
+        const int rc = tgp_modal::filter_lti(h->stream, fp, mu_end, h->mv.y, h->T, nullptr, nullptr, part, &po);
+        if (rc != 0) return h->fail(TGP_EHIP, std::string("tgp_posterior: launch: ") + hipGetErrorString((hipError_t)rc));
+    }
+    tm.kernels_done();
+    TRY(copy_back(h, G, dG, nG, odev));
+    TRY(copy_back(h, g, dg, ng, odev));
+    TRY(copy_back(h, L, dL, nG, odev));
+    if (h->timing) (void)hipEventRecord(h->ev[3], h->stream);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    resolve_profile(h);
+    double ssq = 0.0;
+    for (long long w = 0; w < nwg; ++w) ssq += part[w];
+    const double lml = -0.5 * ((double)h->T * 1.8378770664093454835606594728112 + fp.LS + (double)(h->T - fp.n0) * fp.logS + quad_head + fp.iS * ssq);
+    for (int i = 0; i < 8; ++i) h->host_result[i] = 0.0;
+    h->host_result[0] = lml;
+    if (xfm)
+        for (int i = 0; i < d; ++i) xfm[i] = fin[i];
+    if (xfP)
+        for (size_t e = 0; e < dd; ++e) xfP[e] = fp.Pss[e];      // (symmetric: either storage order)
+    h->reduce_valid = false;
+    h->smoother_valid = false;
+    h->modal_last = false;
+    h->steady2_last = false;
+    h->dense_last_n0 = fp.n0;
+    *served = true;
+    return TGP_OK;
+}
+
 int tgp_posterior(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t flags, double* G, double* g, double* L,
                   double* xfm, double* xfP) {
-    TRY(check_ready(h));
+    TRY(check_ready(h, /*general=*/false));
     if ((G || g || L) && !(G && g && L)) return h->fail(TGP_EINVAL, "G, g, L must be given together");
+    h->dense_last_n0 = -1;
+    h->modal_last = false;
+    h->steady2_last = false;
+    if (G && missing == nullptr && y != nullptr) {
+        bool served = false;
+        TRY(posterior_lti_call(h, y, flags, G, g, L, xfm, xfP, &served));
+        if (served) return TGP_OK;
+    }
+    resolve_table(h);
     if (h->is_dense) {
         const bool odev_d = (flags & TGP_OUT_DEVICE) != 0;
         const size_t ng_d = (size_t)h->T * h->d * sizeof(double), nG_d = ng_d * h->d;

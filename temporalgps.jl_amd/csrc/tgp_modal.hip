@@ -1632,11 +1632,13 @@ struct FArgs {
     double Phi[D][D], a[D], kA[D], K[D], h[D], hh;
     double P[6][D][D], PT[2][D][D];
     double Pss[D * D];
+    double Gss[D * D], Lss[D * D];      // posterior(model, y): the settled reverse-time transition and its noise, COLUMN-major as they leave
     double mu0[D];
     long long T, C, nwg, nhs;
     int halo;
     const double* y;
     double *m, *Pc, *part;
+    double *Gc, *gc, *Lc, *fin;      // (all four or none) G, L [T][D D], g [T][D]; fin [D]: the last filtered mean
 };
 
 template <int D, int NW>
@@ -1646,7 +1648,7 @@ __global__ __launch_bounds__(NW * 64, (D <= 4 ? 4 : 2)) void k_filter_one(const 
     constexpr int SUB = kWJ, TILE = 64 * SUB;
     __shared__ double sF[NW][D], sAcc[NW];
     __shared__ double sPw[D][D][64];      // Phi^(8 e), e = 0 .. 63
-    __shared__ double sP[D * D];          // the settled covariance (the fill below indexes it per lane)
+    __shared__ double sP[3][D * D];       // the settled covariance, G, L (the fills below index them per lane)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     long long g;
     {
@@ -1654,7 +1656,11 @@ __global__ __launch_bounds__(NW * 64, (D <= 4 ? 4 : 2)) void k_filter_one(const 
         g = (long long)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
         if ((long long)(blockIdx.x >> 3) >= per || g >= ka.nwg) return;
     }
-    if (threadIdx.x < D * D) sP[threadIdx.x] = ka.Pss[threadIdx.x];
+    if (threadIdx.x < D * D) {
+        sP[0][threadIdx.x] = ka.Pss[threadIdx.x];
+        sP[1][threadIdx.x] = ka.Gss[threadIdx.x];
+        sP[2][threadIdx.x] = ka.Lss[threadIdx.x];
+    }
     const long long T = ka.T, c_lo = ka.nhs + g * ka.C, c_hi = (c_lo + ka.C < T) ? c_lo + ka.C : T;
     const bool first = g == 0;
     const long long s0 = first ? ka.nhs : c_lo - ka.halo;
@@ -1819,6 +1825,21 @@ __global__ __launch_bounds__(NW * 64, (D <= 4 ? 4 : 2)) void k_filter_one(const 
                 }
 #pragma unroll
                 for (int i = 0; i < D; ++i) st[i] = nx[i];
+                if (ka.gc != nullptr && t >= c_lo && t < c_hi) {
+                    // step t + 1 of the reverse-time model (lgssm.jl:215-221, :231-238): g = m_t - G mu_(t+1)
+                    if (t + 1 < T) {
+#pragma unroll
+                        for (int i = 0; i < D; ++i) {
+                            double v = mf[jj * D + i];
+#pragma unroll
+                            for (int k = 0; k < D; ++k) v = fma(-ka.Gss[k * D + i], nx[k], v);
+                            ka.gc[(t + 1) * D + i] = v;
+                        }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < D; ++i) ka.fin[i] = mf[jj * D + i];
+                    }
+                }
             }
             if (ka.m != nullptr) {
                 const long long t = t0 + j2;
@@ -1842,17 +1863,20 @@ __global__ __launch_bounds__(NW * 64, (D <= 4 ? 4 : 2)) void k_filter_one(const 
         }
         // the covariances: the settled one, for every step the workgroup owns -- a whole tile as one run of 512 D^2 doubles, every store
         // instruction 1 KB of consecutive bytes (a lane writing its own 8 D^2 values, 16 bytes at a 64 D^2-byte stride: 40 % slower)
-        if (ka.Pc != nullptr) {
-            constexpr int DD = D * D;
-            const bool tile_whole = tile_t0 >= c_lo && tile_t0 + TILE <= c_hi;      // (wave-uniform)
-            if (tile_whole && (reinterpret_cast<uintptr_t>(ka.Pc) & 15) == 0) {
-                v2d* q = reinterpret_cast<v2d*>(ka.Pc + tile_t0 * DD);
+        constexpr int DD = D * D;
+        const bool tile_whole = tile_t0 >= c_lo && tile_t0 + TILE <= c_hi;      // (wave-uniform)
+#pragma unroll
+        for (int which = 0; which < 3; ++which) {
+            double* dst = which == 0 ? ka.Pc : (which == 1 ? ka.Gc : ka.Lc);
+            if (dst == nullptr) continue;
+            if (tile_whole && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+                v2d* q = reinterpret_cast<v2d*>(dst + tile_t0 * DD);
 #pragma unroll 4
                 for (int k = 0; k < SUB * DD / 2; ++k) {
                     const int e = k * 64 + lane;
                     v2d w;
-                    w.x = sP[(2 * e) % DD];
-                    w.y = sP[(2 * e + 1) % DD];
+                    w.x = sP[which][(2 * e) % DD];
+                    w.y = sP[which][(2 * e + 1) % DD];
                     q[e] = w;
                 }
             } else {
@@ -1860,7 +1884,7 @@ __global__ __launch_bounds__(NW * 64, (D <= 4 ? 4 : 2)) void k_filter_one(const 
                 for (int j = 0; j < SUB; ++j)
                     if (t0 + j >= c_lo && t0 + j < c_hi)
 #pragma unroll
-                        for (int e = 0; e < DD; ++e) ka.Pc[(t0 + j) * DD + e] = ka.Pss[e];
+                        for (int e = 0; e < DD; ++e) dst[(t0 + j) * DD + e] = sP[which][e];
             }
         }
     }
@@ -1876,7 +1900,8 @@ __global__ __launch_bounds__(NW * 64, (D <= 4 ? 4 : 2)) void k_filter_one(const 
 }
 
 template <int D>
-int launch_filter(hipStream_t st, const tgp_plan::FilterPlan& fp, const double* mu0, const double* y, long long T, double* m, double* Pc, double* part) {
+int launch_filter(hipStream_t st, const tgp_plan::FilterPlan& fp, const double* mu0, const double* y, long long T, double* m, double* Pc, double* part,
+                  const PosteriorOut* po) {
     constexpr int NW = 8;
     FArgs<D> ka;
     static_assert(sizeof(FArgs<D>) <= 4096, "the kernel-argument segment");
@@ -1890,6 +1915,10 @@ int launch_filter(hipStream_t st, const tgp_plan::FilterPlan& fp, const double* 
         for (int k = 0; k < D; ++k) {
             ka.Phi[i][k] = fp.Phi[i * D + k];
             ka.Pss[i * D + k] = fp.Pss[i * D + k];
+            if (po) {
+                ka.Gss[i * D + k] = po->Gss[i * D + k];
+                ka.Lss[i * D + k] = po->Lss[i * D + k];
+            }
             for (int b = 0; b < 6; ++b) ka.P[b][i][k] = fp.P[b][i * D + k];
             for (int b = 0; b < 2; ++b) ka.PT[b][i][k] = fp.PT[b][i * D + k];
         }
@@ -1904,6 +1933,12 @@ int launch_filter(hipStream_t st, const tgp_plan::FilterPlan& fp, const double* 
     ka.m = m;
     ka.Pc = Pc;
     ka.part = part;
+    if (po) {
+        ka.Gc = po->G;
+        ka.gc = po->g;
+        ka.Lc = po->L;
+        ka.fin = po->fin;
+    }
     const long long per = (ka.nwg + 7) / 8;
     hipLaunchKernelGGL((k_filter_one<D, NW>), dim3((unsigned)(per * 8)), dim3(NW * 64), 0, st, ka);
     return (int)hipGetLastError();
@@ -1916,14 +1951,14 @@ long long filter_workgroups(const tgp_plan::FilterPlan& fp, long long T) {
 }
 
 int filter_lti(hipStream_t stream, const tgp_plan::FilterPlan& fp, const double* mu_start, const double* y, long long T, double* m_out, double* P_out,
-               double* part) {
+               double* part, const PosteriorOut* po) {
     switch (fp.d) {
-        case 1: return launch_filter<1>(stream, fp, mu_start, y, T, m_out, P_out, part);
-        case 2: return launch_filter<2>(stream, fp, mu_start, y, T, m_out, P_out, part);
-        case 3: return launch_filter<3>(stream, fp, mu_start, y, T, m_out, P_out, part);
-        case 4: return launch_filter<4>(stream, fp, mu_start, y, T, m_out, P_out, part);
-        case 5: return launch_filter<5>(stream, fp, mu_start, y, T, m_out, P_out, part);
-        case 6: return launch_filter<6>(stream, fp, mu_start, y, T, m_out, P_out, part);
+        case 1: return launch_filter<1>(stream, fp, mu_start, y, T, m_out, P_out, part, po);
+        case 2: return launch_filter<2>(stream, fp, mu_start, y, T, m_out, P_out, part, po);
+        case 3: return launch_filter<3>(stream, fp, mu_start, y, T, m_out, P_out, part, po);
+        case 4: return launch_filter<4>(stream, fp, mu_start, y, T, m_out, P_out, part, po);
+        case 5: return launch_filter<5>(stream, fp, mu_start, y, T, m_out, P_out, part, po);
+        case 6: return launch_filter<6>(stream, fp, mu_start, y, T, m_out, P_out, part, po);
     }
     return (int)hipErrorInvalidValue;
 }

@@ -55,9 +55,17 @@ void choose_geometry(int d, int halo, int* waves, int* steps_per_lane);
 // _filter of an LTI model behind its head (tgp_plan::build_filter / filter_head; d <= tgp_plan::kRandMaxD): the steps [nhs, T) in ONE kernel --
 // y read once, the filtered means [T][d] and covariances [T][d d] written once (either may be nullptr), sum r^2 per workgroup into `part`
 // (pinned host memory, at least filter_workgroups() values).  mu_start: the predicted mean of step nhs (host).
+// posterior(model, y) (lgssm.jl:193-221, :231-238) rides on it: behind the head the reverse-time transition G and its noise L are constants
+// (Gss, Lss: d d doubles each, column-major, host) -- two more fills -- and g_(t+1) = m_t - G mu_(t+1) is at hand where m_t is; `fin` (pinned
+// host memory, d doubles) receives the last filtered mean.  G, L [T][d d], g [T][d] (device); the steps [0, nhs) of G, L and [0, nhs] of g
+// are the caller's (tgp_plan::posterior_head).
+struct PosteriorOut {
+    const double *Gss, *Lss;
+    double *G, *g, *L, *fin;
+};
 long long filter_workgroups(const tgp_plan::FilterPlan& plan, long long T);
 int filter_lti(hipStream_t stream, const tgp_plan::FilterPlan& plan, const double* mu_start, const double* y, long long T, double* m_out, double* P_out,
-               double* part);
+               double* part, const PosteriorOut* posterior = nullptr);
 // The device half of d logpdf / d (model blocks) of an LTI model by ONE reverse-time pass behind the head, in ONE kernel (d <= 6):
 // forwards mu' = Phi mu + a + (A K) u, backwards psi = Phi' psi + h r / S, and the sums SA = sum psi_{t+1} mu_t', Sa, Sk = sum psi_{t+1} r_t,
 // Srm = sum r_t mu_t, Sr, sum r^2 over the steps [nhs, T) -- d^2 + 3 d + 2 values per workgroup into `part` (pinned host memory,

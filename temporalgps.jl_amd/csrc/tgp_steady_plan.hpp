@@ -1314,6 +1314,78 @@ inline void filter_head(const ModelHost& m, const FilterPlan& fp, const double* 
     for (int i = 0; i < D; ++i) mu_end[i] = mu[i];
     *quad = q;
 }
+// posterior(model, y) of the head (lgssm.jl:193-221): the reverse-time transitions of the steps [0, nhs) -- G_t, L_t from
+// invert_dynamics(x_(t-1), predict(x_(t-1))) (:231-238), g_t = m_(t-1) - G_t mu_t -- COLUMN-major blocks Gh, Lh [nhs][D D], gh [nhs + 1][D]
+// (g of step nhs belongs to the settled transition but needs the head's last filtered mean), the settled Gss, Lss [D D], the predicted mean of
+// step nhs and the head's sum r^2 / S_t.  false: a predicted covariance is not positive definite.
+template <int D>
+inline bool posterior_head(const ModelHost& m, const FilterPlan& fp, const double* y, double* Gh, double* gh, double* Lh, double* Gss, double* Lss,
+                           double* mu_end, double* quad) {
+    using namespace detail;
+    const FilterWork<D>& fw = filter_work<D>();
+    double A[D][D], At[D][D], Q[D][D], Pf[D][D], mprev[D], mu[D];
+    for (int i = 0; i < D; ++i) {
+        mprev[i] = m.x0m[i];
+        for (int k = 0; k < D; ++k) {
+            A[i][k] = fw.A[i][k];
+            const int r = i < k ? i : k, c = i < k ? k : i;
+            Q[i][k] = m.Q[r + c * D];
+            Pf[i][k] = m.x0P[r + c * D];
+        }
+    }
+    transpose<D>(A, At);
+    auto put = [](const double (&M)[D][D], double* out) {      // column-major
+        for (int i = 0; i < D; ++i)
+            for (int k = 0; k < D; ++k) out[k * D + i] = M[i][k];
+    };
+    double q = 0.0, G[D][D], L[D][D];
+    for (int t = 0; t <= fp.nhs; ++t) {
+        double t1[D][D], Pp[D][D];
+        mm<D>(A, Pf, t1);
+        mm<D>(t1, At, Pp);
+        for (int i = 0; i < D; ++i)
+            for (int k = 0; k < D; ++k) Pp[i][k] += Q[i][k];
+        if (!invert_dynamics<D>(A, Pf, Pp, G, L)) return false;
+        for (int i = 0; i < D; ++i) {
+            double v = m.a[i];
+            for (int k = 0; k < D; ++k) v += A[i][k] * mprev[k];
+            mu[i] = v;
+        }
+        for (int i = 0; i < D; ++i) {
+            double v = mprev[i];
+            for (int k = 0; k < D; ++k) v -= G[i][k] * mu[k];
+            gh[(size_t)t * D + i] = v;
+        }
+        if (t == fp.nhs) break;
+        put(G, Gh + (size_t)t * D * D);
+        put(L, Lh + (size_t)t * D * D);
+        const int ti = t < fp.n0 ? t : fp.n0;
+        double r = y[t] - fp.hh;
+        for (int k = 0; k < D; ++k) r -= fp.h[k] * mu[k];
+        q += r * r * fw.iS[ti];
+        for (int i = 0; i < D; ++i) {
+            mprev[i] = mu[i] + fw.K[ti][i] * r;
+            for (int k = 0; k < D; ++k) Pf[i][k] = 0.5 * (fw.Pf[ti][i][k] + fw.Pf[ti][k][i]);
+        }
+    }
+    put(G, Gss);
+    put(L, Lss);
+    for (int i = 0; i < D; ++i) mu_end[i] = mu[i];
+    *quad = q;
+    return true;
+}
+inline bool posterior_head_any(const ModelHost& m, const FilterPlan& fp, const double* y, double* Gh, double* gh, double* Lh, double* Gss, double* Lss,
+                               double* mu_end, double* quad) {
+    switch (m.d) {
+        case 1: return posterior_head<1>(m, fp, y, Gh, gh, Lh, Gss, Lss, mu_end, quad);
+        case 2: return posterior_head<2>(m, fp, y, Gh, gh, Lh, Gss, Lss, mu_end, quad);
+        case 3: return posterior_head<3>(m, fp, y, Gh, gh, Lh, Gss, Lss, mu_end, quad);
+        case 4: return posterior_head<4>(m, fp, y, Gh, gh, Lh, Gss, Lss, mu_end, quad);
+        case 5: return posterior_head<5>(m, fp, y, Gh, gh, Lh, Gss, Lss, mu_end, quad);
+        case 6: return posterior_head<6>(m, fp, y, Gh, gh, Lh, Gss, Lss, mu_end, quad);
+    }
+    return false;
+}
 inline void build_filter_any(const ModelHost& m, long long T, FilterPlan& fp) {
     switch (m.d) {
         case 1: build_filter<1>(m, T, fp); return;

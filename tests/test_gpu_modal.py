@@ -324,3 +324,44 @@ def test_filter_of_an_lti_model_in_one_launch(tgp, d):
         hd.check(hd.lib.tgp_filter(hd.h, yy.ctypes.data, None, 0, None, None, ct.byref(lml)))
         lp_ref = sk.logpdf(model, y)
         assert abs(lml.value - lp_ref) <= 1e-10 * abs(lp_ref), (T, lml.value, lp_ref)
+
+
+@pytest.mark.parametrize("d", [1, 2, 3, 4, 5, 6])
+def test_posterior_of_an_lti_model_in_one_launch(tgp, d):
+    """posterior(model, y) (lgssm.jl:193-221, invert_dynamics :231-238) of Forward LTI models up to d = 6, evaluated: the reverse-time
+    transitions of the head on the host, behind it two constant fills and g_(t+1) = m_t - G mu_(t+1) by the filter's ONE kernel -- against the
+    oracle's literal loop on a short series, against the general engine (TGP_OPT_STEADY = 2) on long ones (host and device outputs), and
+    the smoothing marginals of the evaluated model against the fused call."""
+    import torch
+    from oracle import lgssm_ref as ref
+    rng = np.random.default_rng(1700 + d)
+    T = 1500
+    model = oc.build_lgssm(KERNELS[d], ("regular", 0.0, 0.1, T), 0.07)
+    y = draw(model, 1800 + d)
+    post = ref.posterior(model, y)
+    dm = device_model(tgp, model)
+    dpost, names = kernels_of(tgp, dm, lambda: tgp.posterior(dm, y).materialise())
+    assert names == {"k_filter_one"}, names
+    for got, want in ((dpost.transitions.As, post["A"]), (dpost.transitions.as_, post["a"]), (dpost.transitions.Qs, post["Q"]),
+                      (dpost.x0.m, post["x0m"]), (dpost.x0.P, post["x0P"])):
+        np.testing.assert_allclose(got, want, rtol=1e-8, atol=1e-9)
+    for T, dt, dev in ((4097, 0.1, False), (8192, 0.3, True), (60_011, 0.1, False), (300_007, 0.05, True)):
+        model = oc.build_lgssm(KERNELS[d], ("regular", 0.0, dt, T), float(np.exp(rng.uniform(np.log(0.003), np.log(0.5)))))
+        y = draw(model, 1900 + d)
+        dm, dg = device_model(tgp, model), device_model(tgp, model, steady=2)
+        yy = torch.as_tensor(y, device="cuda:0") if dev else y
+        dpost, names = kernels_of(tgp, dm, lambda: tgp.posterior(dm, yy).materialise())
+        assert names == {"k_filter_one"}, (T, names)
+        rpost = tgp.posterior(dg, yy).materialise()
+        for name in ("As", "as_", "Qs"):
+            a, b = getattr(dpost.transitions, name), getattr(rpost.transitions, name)
+            a, b = (a.cpu().numpy(), b.cpu().numpy()) if dev else (a, b)
+            assert a.shape == b.shape and np.max(np.abs(a - b)) <= 1e-8 * max(1.0, float(np.max(np.abs(b)))), (T, name, np.max(np.abs(a - b)))
+        assert np.max(np.abs(dpost.x0.m - rpost.x0.m)) <= 1e-8 and np.max(np.abs(dpost.x0.P - rpost.x0.P)) <= 1e-8
+        # marginals of the evaluated reverse-time model = the fused smoother's (lgssm.jl:111-115 on what :193-221 built)
+        if dev:
+            continue      # (the model's emission blocks are host arrays: an evaluated model with device transitions does not bind)
+        Rn = np.array([0.3])
+        mean, var = tgp.posterior_marginals(dm, y, Rn)
+        em, ev = tgp.marginals(tgp.replace_observation_noise_cov(dpost, Rn))
+        assert np.max(np.abs(em - mean)) <= 1e-7 and np.max(np.abs(ev - var)) <= 1e-7, (T, np.max(np.abs(em - mean)), np.max(np.abs(ev - var)))
