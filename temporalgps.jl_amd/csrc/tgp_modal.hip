@@ -1376,6 +1376,9 @@ __global__ __launch_bounds__(NW * 64, (D <= 4 ? 4 : 2)) void k_rand_one(const RA
     constexpr int SUB = kWJ, TILE = 64 * SUB;
     __shared__ double sF[NW][D];
     __shared__ double sPw[D][D][64];      // A^(8 e), e = 0 .. 63: entry [i][k][e]
+    constexpr int LV = SUB * D / 2;       // 16-byte pieces of draws per lane
+    __shared__ v2d sT[NW][16 * (LV + 1)];      // a quarter of a tile's draws on their way from memory order to the lanes (one spare piece per lane:
+                                               // the 16 reading lanes then start in 16 different groups of four banks)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     long long g;
     {
@@ -1423,6 +1426,37 @@ __global__ __launch_bounds__(NW * 64, (D <= 4 ? 4 : 2)) void k_rand_one(const RA
     for (int j = 0; j < SUB; ++j) y0[j] = 0.0;
     if (any_valid) {
         const bool whole = t0 + SUB <= T && (reinterpret_cast<uintptr_t>(ka.eps_t) & 15) == 0 && (reinterpret_cast<uintptr_t>(ka.eps_e) & 15) == 0;
+        // a whole tile's draws are 64 SUB D consecutive doubles: fetched in memory order (every load instruction 1 KB of consecutive bytes;
+        // a lane fetching its own SUB D values, 16 bytes at a stride of 8 SUB D, keeps the address path busy four to eight times as long)
+        // and handed to their lanes through LDS, sixteen lanes' worth at a time
+        const bool tile_whole = tile_t0 + TILE <= T && (reinterpret_cast<uintptr_t>(ka.eps_t) & 15) == 0 && ((tile_t0 * D) & 1) == 0;      // (wave-uniform)
+        double evt[SUB * D];
+        if (tile_whole) {
+            const v2d* src = reinterpret_cast<const v2d*>(ka.eps_t + tile_t0 * D);
+            v2d ld[4][D];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int i = 0; i < D; ++i) ld[r][i] = src[r * 16 * LV + i * 64 + lane];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int i = 0; i < D; ++i) {
+                    const int idx = i * 64 + lane;
+                    sT[wave][idx + idx / LV] = ld[r][i];
+                }
+                lds_sync();
+                if ((lane >> 4) == r) {
+#pragma unroll
+                    for (int k = 0; k < LV; ++k) {
+                        const v2d w = sT[wave][(lane & 15) * (LV + 1) + k];
+                        evt[2 * k] = w.x;
+                        evt[2 * k + 1] = w.y;
+                    }
+                }
+                lds_sync();
+            }
+        }
         double ee[SUB];
         if (whole) {
             const v2d* q = reinterpret_cast<const v2d*>(ka.eps_e + t0);
@@ -1440,7 +1474,10 @@ __global__ __launch_bounds__(NW * 64, (D <= 4 ? 4 : 2)) void k_rand_one(const RA
         for (int j2 = 0; j2 < SUB; j2 += 2) {
             // the draws of two steps: 2 d consecutive doubles (16-byte pieces where the series allows)
             double ev[2 * D];
-            if (whole) {
+            if (tile_whole) {
+#pragma unroll
+                for (int k = 0; k < 2 * D; ++k) ev[k] = evt[j2 * D + k];
+            } else if (whole) {
                 const v2d* q = reinterpret_cast<const v2d*>(ka.eps_t + (t0 + j2) * D);
 #pragma unroll
                 for (int k = 0; k < D; ++k) {
