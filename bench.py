@@ -234,6 +234,46 @@ def gradient_leg(tgp, torch, name, T, d, device, steps, y):
                                       cost_in_logpdf_evaluations=dt8 * 1e3 / lp8_ms, logpdf=lp8))
 
 
+def lti_interface_leg(tgp, torch, model, y, T, d, local, steps):
+    """The rest of the LTI interface on the same model and series, device-resident: rand with the draws supplied
+    (lgssm.jl:65-91), _filter (:171-187), the evaluated posterior (:193-221) -- wall clock per call and the kernels each one launched."""
+    hd = model.handle()
+
+    def timed(fn, n):
+        for _ in range(2):
+            r = fn()
+        del r
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            r = fn()
+        del r
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        hd.set_option(tgp._lib.OPT_PROFILE, 1)
+        hd.profile_reset()
+        r = fn()
+        del r
+        torch.cuda.synchronize()
+        hd.set_option(tgp._lib.OPT_PROFILE, 0)
+        return dt, {k: v["total_ms"] / v["calls"] for k, v in hd.profile().items()}
+
+    out = {}
+    gen = torch.Generator(device=f"cuda:{local}")
+    gen.manual_seed(99)
+    eps_t = torch.randn((T, d), dtype=torch.float64, device=f"cuda:{local}", generator=gen)
+    eps_e = torch.randn((T,), dtype=torch.float64, device=f"cuda:{local}", generator=gen)
+    x0 = np.random.default_rng(5).standard_normal(d)
+    t, k = timed(lambda: tgp.rand((eps_t, eps_e, x0), model), steps)
+    out["rand"] = dict(ms=t * 1e3, steps_per_s=T / t, bytes_per_step=8 * (d + 2), kernels_ms=k)
+    del eps_t, eps_e
+    t, k = timed(lambda: tgp._filter(model, y), steps)
+    out["filter"] = dict(ms=t * 1e3, steps_per_s=T / t, bytes_per_step=8 * (1 + d + d * d), kernels_ms=k)
+    t, k = timed(lambda: tgp.posterior(model, y).materialise(), steps)
+    out["posterior_evaluated"] = dict(ms=t * 1e3, steps_per_s=T / t, bytes_per_step=8 * (1 + d + 2 * d * d), kernels_ms=k)
+    return out
+
+
 def split_leg(tgp, torch, model, y, Rnew, T, steps):
     """the two passes of a step reported separately (resident data, wall clock per call), and the same two calls
     END TO END from host memory -- y uploaded over PCIe, (mean, var) returned to the host -- which is never `value`."""
@@ -835,6 +875,10 @@ def main():
         if world == 1 and not args.no_general_leg:
             out["split"] = split_leg(tgp, torch, model, y, Rnew, T, max(3, args.steps // 2))
         if args.layout == "lti" and world == 1 and not args.no_general_leg:
+            try:
+                out["lti_interface"] = lti_interface_leg(tgp, torch, model, y, T, d, local, max(3, args.steps // 2))
+            except Exception as ex:      # (an extra leg: never at the cost of the line)
+                out["lti_interface"] = dict(error=repr(ex))
             out["logpdf_and_grad"] = gradient_leg(tgp, torch, name, T, d, local, max(3, args.steps // 2), y)
             if not args.no_cpu_baseline:
                 out["logpdf_and_grad"]["cpu_baseline"] = cpu_gradient_baseline(name, args.cpu_sample)

@@ -1686,6 +1686,8 @@ __global__ __launch_bounds__(NW * 64, (D <= 4 ? 4 : 2)) void k_filter_one(const 
     __shared__ double sF[NW][D], sAcc[NW];
     __shared__ double sPw[D][D][64];      // Phi^(8 e), e = 0 .. 63
     __shared__ double sP[3][D * D];       // the settled covariance, G, L (the fills below index them per lane)
+    constexpr int LV = SUB * D / 2;        // 16-byte pieces of means per lane
+    __shared__ v2d sT[NW][16 * (LV + 1)];      // a quarter of a tile's means (or g) on their way from the lanes to memory order
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     long long g;
     {
@@ -1840,6 +1842,12 @@ __global__ __launch_bounds__(NW * 64, (D <= 4 ? 4 : 2)) void k_filter_one(const 
         // ---- second sweep from the true start state: innovations, filtered means
         const bool whole = t0 >= c_lo && t0 + SUB <= c_hi;
         const bool m_al = ka.m != nullptr && (reinterpret_cast<uintptr_t>(ka.m) & 15) == 0;
+        // a tile wholly inside the workgroup's range (and short of the series' last step): its 512 D means -- or the 512 D values of g, one step
+        // to the right -- are one run of consecutive doubles; they leave in memory order through LDS (below) instead of lane by lane
+        const bool run_whole = tile_t0 >= c_lo && tile_t0 + TILE <= c_hi && tile_t0 + TILE < T;      // (wave-uniform)
+        double* const run = !run_whole ? nullptr : (ka.gc != nullptr ? ka.gc + (tile_t0 + 1) * D : (ka.m != nullptr ? ka.m + tile_t0 * D : nullptr));
+        const bool want_g = ka.gc != nullptr;
+        double oall[SUB * D];
 #pragma unroll
         for (int j2 = 0; j2 < SUB; j2 += 2) {
             double mf[2 * D];
@@ -1862,7 +1870,17 @@ __global__ __launch_bounds__(NW * 64, (D <= 4 ? 4 : 2)) void k_filter_one(const 
                 }
 #pragma unroll
                 for (int i = 0; i < D; ++i) st[i] = nx[i];
-                if (ka.gc != nullptr && t >= c_lo && t < c_hi) {
+                if (run != nullptr) {
+#pragma unroll
+                    for (int i = 0; i < D; ++i) {
+                        double v = mf[jj * D + i];
+                        if (want_g) {
+#pragma unroll
+                            for (int k = 0; k < D; ++k) v = fma(-ka.Gss[k * D + i], nx[k], v);
+                        }
+                        oall[j * D + i] = v;
+                    }
+                } else if (ka.gc != nullptr && t >= c_lo && t < c_hi) {
                     // step t + 1 of the reverse-time model (lgssm.jl:215-221, :231-238): g = m_t - G mu_(t+1)
                     if (t + 1 < T) {
 #pragma unroll
@@ -1878,7 +1896,7 @@ __global__ __launch_bounds__(NW * 64, (D <= 4 ? 4 : 2)) void k_filter_one(const 
                     }
                 }
             }
-            if (ka.m != nullptr) {
+            if (ka.m != nullptr && run == nullptr) {
                 const long long t = t0 + j2;
                 if (whole && m_al) {      // (t D is even: 16-byte pieces)
                     v2d* q = reinterpret_cast<v2d*>(ka.m + t * D);
@@ -1896,6 +1914,30 @@ __global__ __launch_bounds__(NW * 64, (D <= 4 ? 4 : 2)) void k_filter_one(const 
 #pragma unroll
                             for (int i = 0; i < D; ++i) ka.m[(t + jj) * D + i] = mf[jj * D + i];
                 }
+            }
+        }
+        if (run != nullptr) {
+            // sixteen lanes' values at a time: in at 16-byte pieces per lane (one spare piece per lane: no bank conflicts), out as doubles in
+            // memory order -- every store instruction 512 consecutive bytes (g sits D doubles off the tile's start: 8-byte granularity)
+            const double* sTd = reinterpret_cast<const double*>(&sT[wave][0]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if ((lane >> 4) == r) {
+#pragma unroll
+                    for (int k = 0; k < LV; ++k) {
+                        v2d w;
+                        w.x = oall[2 * k];
+                        w.y = oall[2 * k + 1];
+                        sT[wave][(lane & 15) * (LV + 1) + k] = w;
+                    }
+                }
+                lds_sync();
+#pragma unroll
+                for (int i = 0; i < 2 * D; ++i) {
+                    const int e = i * 64 + lane;      // of the 16 lanes' 128 D doubles
+                    run[r * 128 * D + e] = sTd[e + 2 * (e / (SUB * D))];
+                }
+                lds_sync();
             }
         }
         // the covariances: the settled one, for every step the workgroup owns -- a whole tile as one run of 512 D^2 doubles, every store
