@@ -1944,6 +1944,17 @@ int tgp_adjoint_finish(int d, const double* rec, const double* y_head, int64_t n
     return tgp_adjoint::finish(d, rec, y_head, n_head, o) == 0 ? TGP_OK : TGP_EINVAL;
 }
 
+// the pinned host buffer of the head-on-the-host paths (head observations in, head outputs and the workgroups' partial sums out)
+static int ensure_pinned(tgp_handle* h, size_t need) {
+    if (need <= h->flt_cap) return TGP_OK;
+    if (h->flt_host) (void)hipHostFree(h->flt_host);
+    h->flt_host = nullptr;
+    h->flt_cap = 0;
+    if (hipHostMalloc(reinterpret_cast<void**>(&h->flt_host), need * sizeof(double), hipHostMallocDefault) != hipSuccess) return h->fail(TGP_EHIP, "hipHostMalloc");
+    h->flt_cap = need;
+    return TGP_OK;
+}
+
 // The adjoint pass in ONE launch (d <= 6): plan and head on the host (tgp_plan::build_filter / filter_head: the covariance half, the head's
 // forward recursion from its few observations), forward and reverse recursions + the sums behind the head in k_adjoint_one, the head's
 // reverse part and the sweep through the covariance recursion in tgp_adjoint::finish as before.  *served = false: the five-launch form runs.
@@ -1959,13 +1970,7 @@ static int adjoint_lti_call(tgp_handle* h, const double* y, uint32_t flags, doub
     const int d = h->d, ns = tgp_modal::adjoint_sums(d);
     const size_t dd = (size_t)d * d, nhs = (size_t)fp.nhs, nrec = tgp_adjoint::record_size(d);
     const size_t need = nhs + (size_t)nwg * ns + d + nrec + 16;
-    if (need > h->flt_cap) {
-        if (h->flt_host) (void)hipHostFree(h->flt_host);
-        h->flt_host = nullptr;
-        h->flt_cap = 0;
-        if (hipHostMalloc(reinterpret_cast<void**>(&h->flt_host), need * sizeof(double), hipHostMallocDefault) != hipSuccess) return h->fail(TGP_EHIP, "hipHostMalloc");
-        h->flt_cap = need;
-    }
+    TRY(ensure_pinned(h, need));
     double *yh = h->flt_host, *part = yh + nhs, *psi = part + (size_t)nwg * ns, *rec = psi + d;
     CallTimer tm(h, /*clear=*/false);
     TRY(set_obs(h, y, nullptr, flags));
@@ -2069,13 +2074,7 @@ static int filter_lti_call(tgp_handle* h, const double* y, uint32_t flags, doubl
     const size_t dd = (size_t)d * d, nhs = (size_t)fp.nhs;
     const long long nwg = tgp_modal::filter_workgroups(fp, h->T);
     const size_t need = nhs * (1 + d + dd) + (size_t)nwg + 8;
-    if (need > h->flt_cap) {
-        if (h->flt_host) (void)hipHostFree(h->flt_host);
-        h->flt_host = nullptr;
-        h->flt_cap = 0;
-        if (hipHostMalloc(reinterpret_cast<void**>(&h->flt_host), need * sizeof(double), hipHostMallocDefault) != hipSuccess) return h->fail(TGP_EHIP, "hipHostMalloc");
-        h->flt_cap = need;
-    }
+    TRY(ensure_pinned(h, need));
     double *yh = h->flt_host, *mh_out = yh + nhs, *Ph_out = mh_out + nhs * d, *part = Ph_out + nhs * dd;
     const bool odev = (flags & TGP_OUT_DEVICE) != 0;
     const size_t nm = (size_t)h->T * d * sizeof(double), nP = nm * d;
@@ -2169,13 +2168,7 @@ static int posterior_lti_call(tgp_handle* h, const double* y, uint32_t flags, do
     const size_t dd = (size_t)d * d, nhs = (size_t)fp.nhs;
     const long long nwg = tgp_modal::filter_workgroups(fp, h->T);
     const size_t need = nhs * (1 + 2 * dd) + (nhs + 1) * d + 2 * dd + (size_t)nwg + d + 8;
-    if (need > h->flt_cap) {
-        if (h->flt_host) (void)hipHostFree(h->flt_host);
-        h->flt_host = nullptr;
-        h->flt_cap = 0;
-        if (hipHostMalloc(reinterpret_cast<void**>(&h->flt_host), need * sizeof(double), hipHostMallocDefault) != hipSuccess) return h->fail(TGP_EHIP, "hipHostMalloc");
-        h->flt_cap = need;
-    }
+    TRY(ensure_pinned(h, need));
     double *yh = h->flt_host, *Gh = yh + nhs, *Lh = Gh + nhs * dd, *gh = Lh + nhs * dd, *Gss = gh + (nhs + 1) * d, *Lss = Gss + dd, *fin = Lss + dd,
            *part = fin + d;
     const bool odev = (flags & TGP_OUT_DEVICE) != 0;
