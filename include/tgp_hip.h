@@ -252,7 +252,7 @@ int tgp_adjoint_finish(int d, const double* rec, const double* y_head, int64_t n
 
 /* ---- _filter(model, y): lgssm.jl:171-187. m_out [T][d], P_out [T][d*d] (either may be NULL);
  *      lml_out (host, may be NULL) receives the log marginal likelihood as a by-product.
- *      A Forward LTI model with scalar observations, one noise variance, no missing data and d <= 6 runs its head on the host and
+ *      A Forward LTI model with scalar observations, one noise variance, no missing data and d <= 8 runs its head on the host and
  *      everything behind it as ONE kernel (TGP_OPT_STEADY = 3, the default). */
 int tgp_filter(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t flags, double* m_out,
                double* P_out, double* lml_out);
@@ -261,7 +261,7 @@ int tgp_filter(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t 
  *      G [T][d*d], g [T][d], L [T][d*d] (all three or none), xfm (d) / xfP (d*d): x0 of the posterior
  *      (host pointers). Forward priors (step_posterior(::Forward), :215-221) and Reverse priors (step_posterior(::Reverse), :223-228:
  *      invert_dynamics(xp, xf, t) as the reference calls it, x0 = the state after the last step's predict; G, g, L must be requested).
- *      A Forward LTI model with scalar observations, one noise variance, no missing data and d <= 6: the head's transitions on the host,
+ *      A Forward LTI model with scalar observations, one noise variance, no missing data and d <= 8: the head's transitions on the host,
  *      everything behind it by the filter's ONE kernel (G, L constant there; TGP_OPT_STEADY = 3, the default). */
 int tgp_posterior(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t flags, double* G,
                   double* g, double* L, double* xfm, double* xfP);
@@ -296,7 +296,7 @@ int tgp_marginals(tgp_handle* h, uint32_t flags, double* mean_out, double* var_o
 
 /* ---- rand(rng, model) with the randomness supplied: lgssm.jl:65-91, lgc.jl:84-87,241-243,
  *      gaussian.jl:35-43. eps_t [T][d], eps_e [T], eps_0 [d] (eps_0 always host). y_out [T].
- *      A Forward LTI model (every block shared) with scalar observations and d <= 6 runs as ONE kernel over the draws
+ *      A Forward LTI model (every block shared) with scalar observations and d <= 8 runs as ONE kernel over the draws
  *      (TGP_OPT_STEADY = 3, the default); everything else on the general engine's affine scan. */
 int tgp_rand(tgp_handle* h, const double* eps_t, const double* eps_e, const double* eps_0, uint32_t flags,
              double* y_out);

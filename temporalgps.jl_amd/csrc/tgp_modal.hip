@@ -1612,7 +1612,7 @@ template <int D>
 int launch_rand(hipStream_t st, const tgp_plan::RandPlan& rp, const double* x0, const double* eps_t, const double* eps_e, long long T, double* y) {
     constexpr int NW = 8, M = tgp_plan::kRandMaxD;
     RArgs<D> ka;
-    static_assert(sizeof(RArgs<D>) <= 4096, "the kernel-argument segment");
+    static_assert(sizeof(RArgs<D>) <= 8192, "the kernel-argument segment (12 KB launch on gfx950: scripts/micro/bigarg.hip)");
     std::memset(&ka, 0, sizeof ka);
     for (int i = 0; i < D; ++i) {
         ka.a[i] = rp.a[i];
@@ -1653,6 +1653,8 @@ int rand_lti(hipStream_t stream, const tgp_plan::RandPlan& plan, const double* x
         case 4: return launch_rand<4>(stream, plan, x0, eps_t, eps_e, T, y);
         case 5: return launch_rand<5>(stream, plan, x0, eps_t, eps_e, T, y);
         case 6: return launch_rand<6>(stream, plan, x0, eps_t, eps_e, T, y);
+        case 7: return launch_rand<7>(stream, plan, x0, eps_t, eps_e, T, y);
+        case 8: return launch_rand<8>(stream, plan, x0, eps_t, eps_e, T, y);
     }
     return (int)hipErrorInvalidValue;
 }
@@ -1679,7 +1681,7 @@ struct FArgs {
 };
 
 template <int D, int NW>
-__global__ __launch_bounds__(NW * 64, (D <= 4 ? 4 : 2)) void k_filter_one(const FArgs<D> by_value) {
+__global__ __launch_bounds__(NW * 64, (D <= 3 ? 4 : 2)) void k_filter_one(const FArgs<D> by_value) {      // (d = 4 at four waves per SIMD: 18 registers spilled)
     (void)by_value;
     const FArgs<D>& ka = *(const FArgs<D>*)__builtin_amdgcn_kernarg_segment_ptr();
     constexpr int SUB = kWJ, TILE = 64 * SUB;
@@ -1983,7 +1985,7 @@ int launch_filter(hipStream_t st, const tgp_plan::FilterPlan& fp, const double* 
                   const PosteriorOut* po) {
     constexpr int NW = 8;
     FArgs<D> ka;
-    static_assert(sizeof(FArgs<D>) <= 4096, "the kernel-argument segment");
+    static_assert(sizeof(FArgs<D>) <= 8192, "the kernel-argument segment (12 KB launch on gfx950: scripts/micro/bigarg.hip)");
     std::memset(&ka, 0, sizeof ka);
     for (int i = 0; i < D; ++i) {
         ka.a[i] = fp.a[i];
@@ -2038,6 +2040,8 @@ int filter_lti(hipStream_t stream, const tgp_plan::FilterPlan& fp, const double*
         case 4: return launch_filter<4>(stream, fp, mu_start, y, T, m_out, P_out, part, po);
         case 5: return launch_filter<5>(stream, fp, mu_start, y, T, m_out, P_out, part, po);
         case 6: return launch_filter<6>(stream, fp, mu_start, y, T, m_out, P_out, part, po);
+        case 7: return launch_filter<7>(stream, fp, mu_start, y, T, m_out, P_out, part, po);
+        case 8: return launch_filter<8>(stream, fp, mu_start, y, T, m_out, P_out, part, po);
     }
     return (int)hipErrorInvalidValue;
 }

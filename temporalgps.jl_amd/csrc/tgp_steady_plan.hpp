@@ -1009,7 +1009,7 @@ inline Info build(const ModelHost& m, long long T, Modal& md, HeadTables& tab) {
 // keeps dense powers: A^(8 2^k) for the in-tile scan, A^512 and A^1024 for the tile chaining, the rows h' A^(j+1) that carry a lane's
 // start state to its eight outputs, and the halo after which A^n has decayed below 2^-60 (found by multiplying, not from the spectral
 // radius: ||A^n|| of a Jordan block carries a polynomial factor).  d <= kRandMaxD: everything is a kernel argument.
-constexpr int kRandMaxD = 6;
+constexpr int kRandMaxD = 8;
 struct RandPlan {
     int d = 0, halo = 0, why = kOk;
     double A[kRandMaxD * kRandMaxD], a[kRandMaxD], Lq[kRandMaxD * kRandMaxD], h[kRandMaxD], hh = 0.0, sR = 0.0;      // row-major; Lq lower
@@ -1124,6 +1124,8 @@ inline void build_rand_any(const ModelHost& m, RandPlan& rp) {
         case 4: build_rand<4>(m, rp); return;
         case 5: build_rand<5>(m, rp); return;
         case 6: build_rand<6>(m, rp); return;
+        case 7: build_rand<7>(m, rp); return;
+        case 8: build_rand<8>(m, rp); return;
     }
     rp.why = kEigFail;
 }
@@ -1383,6 +1385,8 @@ inline bool posterior_head_any(const ModelHost& m, const FilterPlan& fp, const d
         case 4: return posterior_head<4>(m, fp, y, Gh, gh, Lh, Gss, Lss, mu_end, quad);
         case 5: return posterior_head<5>(m, fp, y, Gh, gh, Lh, Gss, Lss, mu_end, quad);
         case 6: return posterior_head<6>(m, fp, y, Gh, gh, Lh, Gss, Lss, mu_end, quad);
+        case 7: return posterior_head<7>(m, fp, y, Gh, gh, Lh, Gss, Lss, mu_end, quad);
+        case 8: return posterior_head<8>(m, fp, y, Gh, gh, Lh, Gss, Lss, mu_end, quad);
     }
     return false;
 }
@@ -1394,6 +1398,8 @@ inline void build_filter_any(const ModelHost& m, long long T, FilterPlan& fp) {
         case 4: build_filter<4>(m, T, fp); return;
         case 5: build_filter<5>(m, T, fp); return;
         case 6: build_filter<6>(m, T, fp); return;
+        case 7: build_filter<7>(m, T, fp); return;
+        case 8: build_filter<8>(m, T, fp); return;
     }
     fp.why = kEigFail;
 }
@@ -1405,6 +1411,8 @@ inline void filter_head_any(const ModelHost& m, const FilterPlan& fp, const doub
         case 4: filter_head<4>(m, fp, y, mout, Pout, mu_end, quad); return;
         case 5: filter_head<5>(m, fp, y, mout, Pout, mu_end, quad); return;
         case 6: filter_head<6>(m, fp, y, mout, Pout, mu_end, quad); return;
+        case 7: filter_head<7>(m, fp, y, mout, Pout, mu_end, quad); return;
+        case 8: filter_head<8>(m, fp, y, mout, Pout, mu_end, quad); return;
     }
 }
 

@@ -159,12 +159,12 @@ def test_models_the_plan_declines_go_to_the_older_engines(tgp):
     m_ref, v_ref = sk.posterior_marginals(model, y, Rn)
     assert np.max(np.abs(mean - m_ref)) <= 1e-8 and np.max(np.abs(var - v_ref)) <= 1e-8
     assert abs(tgp.logpdf(dm, y) - lp_ref) <= 1e-10 * abs(lp_ref)      # (and again behind a posterior call)
-    # d = 8 without a modal form: the five-launch engine serves logpdf too
+    # d = 8 without a modal form: the same
     model = oc.build_lgssm(("sum", ("matern52",), ("matern52",), ("matern32",)), ("regular", 0.0, 0.1, T), 0.1)
     y = draw(model, 2)
     dm = device_model(tgp, model)
     lp, names = kernels_of(tgp, dm, lambda: tgp.logpdf(dm, y))
-    assert "k_steady_apply<logpdf>" in names and not any(n.startswith(("k_steady_one", "k_filter_one")) for n in names), names
+    assert names == {"k_filter_one"}, names
     lp_ref = sk.logpdf(model, y)
     assert abs(lp - lp_ref) <= 1e-10 * abs(lp_ref)
 
@@ -250,9 +250,9 @@ print("checked")
         assert r.returncode == 0 and "checked" in r.stdout, (scans, (r.stdout + r.stderr)[-3000:])
 
 
-@pytest.mark.parametrize("d", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("d", [1, 2, 3, 4, 5, 6, 7, 8])
 def test_rand_of_an_lti_model_in_one_launch(tgp, d):
-    """rand(rng, model) with the draws supplied (lgssm.jl:65-91) for LTI models up to d = 6: ONE kernel over the draws (k_rand_one: dense
+    """rand(rng, model) with the draws supplied (lgssm.jl:65-91) for LTI models up to d = 8: ONE kernel over the draws (k_rand_one: dense
     powers of the open-loop transition, spans with a run-in of `halo` steps) against the oracle's sequential loop, at lengths around every
     tile / span boundary; a slowly mixing model (halo beyond the cap) falls back to the general engine's affine scan."""
     rng = np.random.default_rng(900 + d)
@@ -291,9 +291,9 @@ def test_rand_of_an_lti_model_with_device_resident_draws(tgp):
     assert np.max(np.abs(yy - y_ref)) <= 1e-9 * max(1.0, float(np.max(np.abs(y_ref))))
 
 
-@pytest.mark.parametrize("d", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("d", [1, 2, 3, 4, 5, 6, 7, 8])
 def test_filter_of_an_lti_model_in_one_launch(tgp, d):
-    """_filter(model, y) (lgssm.jl:171-187) of LTI models up to d = 6: the head on the host, everything behind it in ONE kernel
+    """_filter(model, y) (lgssm.jl:171-187) of LTI models up to d = 8: the head on the host, everything behind it in ONE kernel
     (k_filter_one: dense powers of the stationary closed loop) -- against the oracle's literal loop on a short series, against the general
     engine (TGP_OPT_STEADY = 2) on long ones, lengths around every tile / span boundary, and the log marginal likelihood it returns."""
     import ctypes as ct
@@ -326,9 +326,9 @@ def test_filter_of_an_lti_model_in_one_launch(tgp, d):
         assert abs(lml.value - lp_ref) <= 1e-10 * abs(lp_ref), (T, lml.value, lp_ref)
 
 
-@pytest.mark.parametrize("d", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("d", [1, 2, 3, 4, 5, 6, 7, 8])
 def test_posterior_of_an_lti_model_in_one_launch(tgp, d):
-    """posterior(model, y) (lgssm.jl:193-221, invert_dynamics :231-238) of Forward LTI models up to d = 6, evaluated: the reverse-time
+    """posterior(model, y) (lgssm.jl:193-221, invert_dynamics :231-238) of Forward LTI models up to d = 8, evaluated: the reverse-time
     transitions of the head on the host, behind it two constant fills and g_(t+1) = m_t - G mu_(t+1) by the filter's ONE kernel -- against the
     oracle's literal loop on a short series, against the general engine (TGP_OPT_STEADY = 2) on long ones (host and device outputs), and
     the smoothing marginals of the evaluated model against the fused call."""
