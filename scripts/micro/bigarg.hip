@@ -1,4 +1,4 @@
-// Development: does a kernel-argument segment beyond 4 KB launch on gfx950?  (a by-value struct of N doubles, read in place)
+// Development: does a kernel-argument segment beyond 4 KB launch on gfx950?  (a by-value struct of N doubles, read in place; hipcc --offload-arch=gfx950 -O2 -o bigarg bigarg.hip: 3.2 ... 12 KB all launch and sum correctly)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 template <int N> struct Big { double v[N]; double* out; };
