@@ -164,3 +164,35 @@ def test_cfg4_T1e8_d4_logpdf_and_posterior_marginals(tgp):
     assert lp2 == lp or abs(lp2 - lp_ref) <= 1e-10 * abs(lp_ref)
     assert float(torch.max(torch.abs(mean - torch.as_tensor(pm, device="cuda:0")))) <= 1e-8
     assert float(torch.max(torch.abs(var - torch.as_tensor(pv, device="cuda:0")))) <= 1e-8
+
+
+def test_full_size_filter_and_evaluated_posterior(tgp):
+    """cfg2's series through the rest of the LTI interface (one launch each): `_filter` (lgssm.jl:171-187) and the evaluated
+    `posterior` (lgssm.jl:193-221).  Size-independent ties instead of a second oracle: behind the head the reverse-time transition is ONE
+    matrix and its offsets are g_(t+1) = (I - G A) m_t - G a in the filter's own means; the marginals of the evaluated model
+    (lgssm.jl:111-115, the general engine on T x (2 d^2 + d) doubles) are the smoother's -- checked against the sequential C oracle; the
+    last smoothed marginal is the last filtered one."""
+    T, name = 10_000_000, "matern52_d3"
+    rng = np.random.default_rng(4242)
+    y = rng.standard_normal(T)
+    ref_model = oc.build_lgssm(SPECS[name], ("regular", 0.0, 0.1, T), 0.1)
+    Rn = np.array([0.3])
+    pm, pv = sk.posterior_marginals(ref_model, y, Rn)
+    model = _product_model(name, T)
+    (m, P), names = _kernels_of(tgp, model, lambda: tgp._filter(model, y))
+    assert names == {"k_filter_one"}, names
+    dpost, names = _kernels_of(tgp, model, lambda: tgp.posterior(model, y).materialise())
+    assert names == {"k_filter_one"}, names
+    G, g, L = dpost.transitions.As, dpost.transitions.as_, dpost.transitions.Qs
+    assert G.shape == (T, 3, 3) and g.shape == (T, 3) and L.shape == (T, 3, 3)
+    assert np.array_equal(G[1000:], np.broadcast_to(G[-1], G[1000:].shape)) and np.array_equal(L[1000:], np.broadcast_to(L[-1], L[1000:].shape))
+    A, a = np.asarray(ref_model["A"]).reshape(-1, 3, 3)[0], np.asarray(ref_model["a"]).reshape(-1, 3)[0]
+    M = np.eye(3) - G[-1] @ A
+    tie = m[999:-1] @ M.T - G[-1] @ a
+    assert np.max(np.abs(g[1000:] - tie)) <= 1e-9 * max(1.0, float(np.max(np.abs(g)))), np.max(np.abs(g[1000:] - tie))
+    np.testing.assert_allclose(dpost.x0.m, m[-1], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(dpost.x0.P, P[-1], rtol=0, atol=1e-12)
+    mean, var = tgp.marginals(tgp.replace_observation_noise_cov(dpost, Rn))
+    assert np.max(np.abs(mean - pm)) <= 1e-8 and np.max(np.abs(var - pv)) <= 1e-8, (np.max(np.abs(mean - pm)), np.max(np.abs(var - pv)))
+    H, h = np.asarray(ref_model["H"]).reshape(-1, 3)[0], float(np.asarray(ref_model["h"]).reshape(-1)[0])
+    assert abs(H @ m[-1] + h - pm[-1]) <= 1e-9 and abs(H @ P[-1] @ H + Rn[0] - pv[-1]) <= 1e-9
