@@ -196,3 +196,16 @@ def test_full_size_filter_and_evaluated_posterior(tgp):
     assert np.max(np.abs(mean - pm)) <= 1e-8 and np.max(np.abs(var - pv)) <= 1e-8, (np.max(np.abs(mean - pm)), np.max(np.abs(var - pv)))
     H, h = np.asarray(ref_model["H"]).reshape(-1, 3)[0], float(np.asarray(ref_model["h"]).reshape(-1)[0])
     assert abs(H @ m[-1] + h - pm[-1]) <= 1e-9 and abs(H @ P[-1] @ H + Rn[0] - pv[-1]) <= 1e-9
+
+
+def test_full_size_rand_against_the_sequential_oracle(tgp):
+    """rand with the draws supplied (lgssm.jl:65-91) at cfg2's size: the one-launch kernel on 1e7 x (d + 1) draws against the oracle's loop."""
+    T, name, d = 10_000_000, "matern52_d3", 3
+    rng = np.random.default_rng(777)
+    eps = (rng.standard_normal((T, d)), rng.standard_normal(T), rng.standard_normal(d))
+    ref_model = oc.build_lgssm(SPECS[name], ("regular", 0.0, 0.1, T), 0.1)
+    y_ref = sk.rand(ref_model, *eps)
+    model = _product_model(name, T)
+    y, names = _kernels_of(tgp, model, lambda: tgp.rand(eps, model))
+    assert names == {"k_rand_one"}, names
+    assert np.max(np.abs(y - y_ref)) <= 1e-9 * max(1.0, float(np.max(np.abs(y_ref))))
