@@ -124,6 +124,19 @@ typedef struct tgp_handle tgp_handle;
                            evaluate A_k = exp(F dt_k) in closed form and Q_k = Pinf - A_k Pinf A_k' in registers from the 8-byte gap dt_k
                            (lti_sde.jl:135-146) instead of reading a tiled [T][2 d^2] record three times; 0: always the tiled record
                            (A/B timing, tests). Other drift matrices and the gradient passes use the tiled record either way. */
+#define TGP_OPT_SWEEP 14 /* 1 (default): Forward models with scalar observations and d <= 4 whose GAINS vary in time -- a missing-data mask, a noise
+                           variance or an emission offset per step (shared A, a, Q, H), or irregular spacing (tgp_model_set_sde with closed-form
+                           transitions) -- run tgp_logpdf / tgp_[logpdf_and_]posterior_marginals on the sweep engine (tgp_sweep.hip):
+                           ONE kernel; a lane owns a chunk of consecutive steps and runs the reference's sequential recursion over it in registers;
+                           a chunk's start state comes from a warm-up over the steps in front of it (the filter forgets), its smoothing state at
+                           the end from the next chunk's backward warm-up; the filtering states a backward step needs are recomputed from
+                           checkpoints.  Every hand-over is checked (the run from the handed-over state must reproduce the warm-up's end state
+                           to 1e-12 of a state's size): a call whose warm-ups prove too short is repeated with longer ones, a model that mixes
+                           too slowly goes to the general engine.  What the reference's predict path produces: posterior_lti_sde.jl:20-37,97-131,
+                           missings.jl:25-41, lti_sde.jl:135-146.  0: the general chunked-scan engine as before. */
+#define TGP_OPT_SWEEP_CHUNK 15       /* tests: steps per chunk of the sweep engine (0 automatic) */
+#define TGP_OPT_SWEEP_WARMUP 16      /* tests: forward warm-up steps (0 automatic); a forced geometry is never repaired by longer warm-ups */
+#define TGP_OPT_SWEEP_WARMUP_BACK 17 /* tests: backward warm-up steps (0 automatic) */
 #define TGP_OPT_TIMING 6 /* 1: record the hipEvents behind tgp_last_timing (off by default: ~30 us of host time per call) */
 #define TGP_OPT_FUSE_SCAN 4 /* 1 (default): the level-0 scan reduce / apply of the forward scan run inside the chunk kernels;
                                0: stand-alone k_scan_reduce / k_scan_apply launches (bit-identical results, for A/B timing) */
@@ -148,6 +161,11 @@ int64_t tgp_graph_replays(const tgp_handle* h);
    the stationary-gain engine: T - n0 (tgp_logpdf, tgp_[logpdf_and_]posterior_marginals); the general engine: the steps the forward pass of
    the last posterior-path call ran in the mean-only form. */
 int tgp_steady_steps(tgp_handle* h, int64_t* mean_only, int64_t* total);
+/* Diagnostics of TGP_OPT_SWEEP for the last tgp_logpdf / tgp_[logpdf_and_]posterior_marginals call. info [8]: served by the sweep engine (0 / 1),
+   steps per chunk, forward warm-up, backward warm-up, waves, attempts (launches), status bits of the last attempt (1 forward / 2 backward warm-up
+   too short, 4 not positive definite, 8 non-finite), state for the bound model (0 untried, 1 serves, -1 declined).  dist [2]: the largest
+   relative distance between a warm-up's end state and the run that reproduces it, forwards / backwards (the checks' 1e-12). Either may be NULL. */
+int tgp_sweep_info(tgp_handle* h, int64_t* info, double* dist);
 
 /* ---- model: replaces the LGSSM / GaussMarkovModel containers -----------------------------------
  * lgssm.jl:9-12, gauss_markov_model.jl:20-32 (As, as, Qs, x0) + emissions (A = H', a = h, Q = R).

@@ -21,6 +21,7 @@ OUT_DEVICE = 1 << 17
 REUSE_REDUCE = 1 << 18
 OK, EINVAL, ENOTPD, EHIP, EUNSUPPORTED = 0, 1, 2, 3, 4
 OPT_CHUNK, OPT_PROFILE, OPT_VARIANT, OPT_FUSE_SCAN, OPT_GROUP, OPT_TIMING, OPT_SPLIT_SMOOTHER, OPT_DENSE_STRUCTURE, OPT_GRAPH, OPT_DENSE_FUSED, OPT_SHARED_PARTS, OPT_STEADY, OPT_SDE_CLOSED_FORM = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13
+OPT_SWEEP, OPT_SWEEP_CHUNK, OPT_SWEEP_WARMUP, OPT_SWEEP_WARMUP_BACK = 14, 15, 16, 17
 
 _dp = ctypes.POINTER(ctypes.c_double)
 _u8p = ctypes.POINTER(ctypes.c_uint8)
@@ -39,6 +40,7 @@ _SIGS = {
     "tgp_kernel_variant": (ctypes.c_int, [_vp]),
     "tgp_graph_replays": (_i64, [_vp]),
     "tgp_steady_steps": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),
+    "tgp_sweep_info": (ctypes.c_int, [_vp, _vp, _vp]),
     "tgp_model_set": (ctypes.c_int, [_vp, _i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, _u32] + [_vp] * 8),
     "tgp_model_set_sde": (ctypes.c_int, [_vp, _i64, ctypes.c_int, ctypes.c_int, _u32] + [_vp] * 10),
     "tgp_model_set_x0": (ctypes.c_int, [_vp, _vp, _vp]),
@@ -200,6 +202,16 @@ class Handle:
         k, a, b = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
         self.lib.tgp_last_timing(self.h, ctypes.byref(k), ctypes.byref(a), ctypes.byref(b))
         return dict(kernel_ms=k.value, h2d_ms=a.value, d2h_ms=b.value)
+
+    def sweep_info(self):
+        """diagnostics of the sweep engine (TGP_OPT_SWEEP) for the last logpdf / posterior-marginals call"""
+        import numpy as np
+        info, dist = np.zeros(8, dtype=np.int64), np.zeros(2)
+        self.check(self.lib.tgp_sweep_info(self.h, info.ctypes.data, dist.ctypes.data))
+        keys = ("served", "C", "W", "Wb", "waves", "attempts", "status", "state")
+        out = {k: int(v) for k, v in zip(keys, info)}
+        out["dist_f"], out["dist_b"] = float(dist[0]), float(dist[1])
+        return out
 
     def profile_reset(self):
         self.lib.tgp_profile_reset(self.h)

@@ -22,6 +22,7 @@
 #include <chrono>
 #include "tgp_steady.hpp"
 #include "tgp_modal.hpp"
+#include "tgp_sweep.hpp"
 #include "tgp_adjoint_host.hpp"
 
 namespace tgp {
@@ -329,7 +330,25 @@ struct tgp_handle {
     int modal_state = 0;         // 0 untried for the bound model, 1 served the last call, -1 does not apply
     bool modal_last = false;
     int64_t dense_last_n0 = -1;   // >= 0: the last call ran on the dense-power one-launch kernels behind a head of that many steps with gains of their own
+    // TGP_OPT_SWEEP (default 1): the sweep engine (tgp_sweep.hip) serves tgp_logpdf / tgp_[logpdf_and_]posterior_marginals of Forward
+    // models with scalar observations, d <= 4, shared A / a / Q / H (or closed-form SDE transitions) whose gains vary in time: a mask, a noise
+    // variance or an emission offset per step, irregular spacing.  One launch; a call whose warm-ups prove too short is repeated with longer
+    // ones (remembered for the bound model), a model it does not serve goes on to the general engine.
+    int opt_sweep = 1;
+    tgp_sweep::Engine* sweep = nullptr;
+    int sweep_state = 0;          // 0 untried for the bound model, 1 served the last call, -1 does not apply
+    bool sweep_last = false;
+    int sweep_W = 0, sweep_Wb = 0;     // warm-ups the bound model's last served call needed (0: estimate)
+    int sweep_fC = 0, sweep_fW = 0, sweep_fWb = 0;   // TGP_OPT_SWEEP_CHUNK / _WARMUP / _WARMUP_BACK (tests; 0 automatic)
+    int64_t sweep_info[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // tgp_sweep_info
+    double sweep_dist[2] = {0.0, 0.0};
+    double sweep_Rrep = 1.0;      // a representative noise variance of the bound model (the warm-up estimate)
+    double sweep_tau = 0.0;       // SDE: median gap
+    std::vector<double> sde_coef_host, sde_A1Q1_host;   // SDE: closed-form coefficients and the first transition, on the host
+    DevBuf btau;                  // SDE: tau_k = t_k - t_(k-1), [T] (tau_0 unused: the first transition is explicit)
+    int num_cu = 0;
     std::vector<double> hostm;   // host copy of the shared blocks of an LTI model: A | a | Q | H | hh | R (what the host plan reads)
+    std::vector<double> sweepm;  // the same for every model with shared A, a, Q, H and scalar observations (hh, R: the first step's where they are per step)
     void* steady2_scope = nullptr;
     bool table_pending = false;  // the kernel-variant choice (and its run-time check) of the general engine is deferred to its first use
     int shard2_first = 1, shard2_last = 1, shard2_post = 0;      // the open two-half call of a stationary-gain time shard
@@ -1214,6 +1233,129 @@ int modal_call(tgp_handle* h, const double* y, uint32_t flags, const double* Rne
     return TGP_OK;
 }
 
+// ---- the sweep engine (tgp_sweep.hip): time-varying gains -------------------------------------------------------------------
+// Forward models with scalar observations, d <= 4, whose transitions are one shared block (A, a, Q) or closed-form SDE transitions from the
+// time stamps, H shared; the noise variance and the emission offset may be per step, steps may be missing.  The stationary-gain engines
+// take what they can serve first (every block shared, one noise variance, nothing missing).
+bool sweep_eligible(const tgp_handle* h, uint32_t flags) {
+    if (!h->opt_sweep || h->sweep_state < 0 || h->is_dense || h->p != 1 || h->ordering != 0 || h->d > tgp_sweep::kMaxD) return false;
+    if ((flags & TGP_REUSE_REDUCE) || h->opt_chunk != 0 || h->variant_opt != 0) return false;      // (explicit requests for the chunked-scan engine)
+    if (h->T < tgp_sweep::kMinT || h->mv.T != h->T || h->mv.sH != 0 || h->sweepm.empty()) return false;
+    if (h->sde) return h->sde_closed && h->opt_sde_closed && !h->sde_coef_host.empty() && h->mv.sa == 0;
+    return h->mv.sA == 0 && h->mv.sa == 0 && h->mv.sQ == 0;
+}
+// Runs the call on the engine.  *served = false: it declined (nothing the caller must undo); the caller goes on to the general engine.
+int sweep_call(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t flags, const double* Rnew, double* mean_out, double* var_out,
+               double* lml_out, bool* served) {
+    *served = false;
+    h->sweep_last = false;
+    if (!h->sweep) h->sweep = tgp_sweep::create();
+    static const bool dbg = getenv("TGP_STEADY_DEBUG") != nullptr;
+    const int d = h->d;
+    const size_t dd = (size_t)d * d;
+    const double* q = h->sweepm.data();
+    tgp_sweep::ModelHost mh;
+    mh.d = d;
+    mh.sde = h->sde;
+    mh.A = h->sde ? h->sde_A1Q1_host.data() : q;
+    mh.a = q + dd;
+    mh.Q = h->sde ? h->sde_A1Q1_host.data() + dd : q + dd + d;
+    mh.H = q + 2 * dd + d;
+    mh.hh = q[2 * dd + 2 * d];
+    mh.R = h->sweep_Rrep;
+    mh.x0m = h->x0m.data();
+    mh.x0P = h->x0P.data();
+    mh.coef = h->sde ? h->sde_coef_host.data() : nullptr;
+    mh.tau_typ = h->sweep_tau;
+    const bool idev = (flags & TGP_IN_DEVICE) != 0, odev = (flags & TGP_OUT_DEVICE) != 0;
+    const bool rshared = (flags & TGP_SHARED_R) != 0;
+    const size_t nT = (size_t)h->T * sizeof(double);
+    int W = h->sweep_W, Wb = h->sweep_Wb;
+    for (int64_t& v : h->sweep_info) v = 0;
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        std::string why;
+        tgp_sweep::force_geometry(h->sweep, h->sweep_fC, h->sweep_fW, h->sweep_fWb);
+        if (!tgp_sweep::plan(h->sweep, mh, h->T, W, Wb, h->num_cu, &why)) {
+            if (dbg) fprintf(stderr, "[tgp sweep] does not apply: %s\n", why.c_str());
+            h->sweep_state = -1;
+            return TGP_OK;
+        }
+        CallTimer tm(h, /*clear=*/false);
+        const void* pR = nullptr;
+        if (mean_out) TRY(stage_in(h, h->bRnew, Rnew, rshared ? sizeof(double) : nT, idev, &pR));
+        TRY(set_obs(h, y, missing, flags));
+        tm.inputs_done();
+        double *dm = nullptr, *dv = nullptr;
+        TRY(stage_out(h, h->bo1, mean_out, nT, odev, &dm));
+        TRY(stage_out(h, h->bo2, var_out, nT, odev, &dv));
+        tgp_sweep::Call c;
+        c.T = h->T;
+        c.y = h->mv.y;
+        c.mask = h->mv.missing;
+        c.R = h->mv.sR != 0 ? h->mv.R : nullptr;
+        c.hh = h->mv.sh != 0 ? h->mv.h : nullptr;
+        c.tau = h->sde ? h->btau.d() : nullptr;
+        c.Rnew = static_cast<const double*>(pR);
+        c.rnew_per_step = (mean_out && !rshared) ? 1 : 0;
+        c.mean = dm;
+        c.var = dv;
+        {
+            std::string err;
+            const char* kname = tgp_sweep::kernel_name(d, h->sde, dm != nullptr);
+            LaunchScope ls(h, kname);
+            if (tgp_sweep::enqueue(h->sweep, h->stream, c, &kname, &err) != 0) return h->fail(TGP_EHIP, err);
+        }
+        tm.kernels_done();
+        if (h->timing) (void)hipEventRecord(h->ev[3], h->stream);
+        HIPCHK(hipStreamSynchronize(h->stream));
+        resolve_profile(h);
+        int status = 0, w = 0, wb = 0;
+        const double lml = tgp_sweep::finish(h->sweep, &status, &w, &wb, &h->sweep_dist[0], &h->sweep_dist[1]);
+        int C = 0;
+        int64_t nw = 0;
+        tgp_sweep::geometry(h->sweep, &C, nullptr, nullptr, &nw);
+        h->sweep_info[1] = C; h->sweep_info[2] = w; h->sweep_info[3] = wb; h->sweep_info[4] = nw; h->sweep_info[5] = attempt + 1; h->sweep_info[6] = status;
+        if (dbg) fprintf(stderr, "[tgp sweep] attempt %d: C %d W %d Wb %d waves %lld status %d dist %.3g / %.3g\n", attempt, C, w, wb, (long long)nw, status, h->sweep_dist[0], h->sweep_dist[1]);
+        if (status & 12) {      // not positive definite / non-finite values: the general engine reports it the way it always has
+            return TGP_OK;
+        }
+        if (status & 3) {       // a warm-up was too short: longer ones (a forced geometry is a test's: report, do not repair)
+            if (h->sweep_fW || h->sweep_fWb || h->sweep_fC) return TGP_OK;
+            if (status & 1) W = 2 * w;
+            if (status & 2) Wb = 2 * wb;
+            continue;
+        }
+        TRY(copy_back(h, mean_out, dm, nT, odev));
+        TRY(copy_back(h, var_out, dv, nT, odev));
+        if ((mean_out && !odev)) HIPCHK(hipStreamSynchronize(h->stream));
+        if (h->timing) {
+            float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+            (void)hipEventElapsedTime(&t0, h->ev[0], h->ev[1]);
+            (void)hipEventElapsedTime(&t1, h->ev[1], h->ev[2]);
+            (void)hipEventElapsedTime(&t2, h->ev[2], h->ev[3]);
+            h->h2d_ms = t0;
+            h->kernel_ms = t1;
+            h->d2h_ms = t2;
+        }
+        for (int i = 0; i < 8; ++i) h->host_result[i] = 0.0;
+        h->host_result[0] = lml;
+        if (lml_out) *lml_out = lml;
+        h->sweep_W = w;
+        h->sweep_Wb = wb;
+        h->sweep_state = 1;
+        h->sweep_last = true;
+        h->sweep_info[0] = 1;
+        h->steady2_last = false;
+        h->modal_last = false;
+        h->reduce_valid = false;
+        h->smoother_valid = false;
+        *served = true;
+        return TGP_OK;
+    }
+    h->sweep_state = -1;      // four attempts, warm-ups still too short: a model that mixes too slowly for this engine
+    return TGP_OK;
+}
+
 bool steady2_served(tgp_handle* h) {
     const bool ran = h->host_result[6] == tgp_steady::kStatusRan;
     h->steady2_state = ran ? 1 : -1;
@@ -1262,6 +1404,11 @@ int tgp_create(tgp_handle** out, int device) {
         delete h;
         return TGP_EHIP;
     }
+    {
+        int ncu = 0;
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || ncu <= 0) ncu = 256;
+        h->num_cu = ncu;
+    }
     *out = h;
     return TGP_OK;
 }
@@ -1278,7 +1425,7 @@ int tgp_destroy(tgp_handle* h) {
     }
     drop_graphs(h);
     for (DevBuf* b : {&h->bA, &h->ba, &h->bQ, &h->bH, &h->bh, &h->bR, &h->bx0, &h->bx0r, &h->bx0fold, &h->by, &h->bmiss, &h->bRnew, &h->beps_t,
-                      &h->beps_e, &h->bo1, &h->bo2, &h->bo3, &h->F.slab, &h->Rv.slab, &h->fs, &h->partial, &h->result, &h->segtmp, &h->tile_t, &h->tile_e, &h->Fad.slab, &h->btan, &h->bx0ad, &h->tile_tan, &h->balt, &h->bF, &h->bPinf, &h->btimes, &h->bAQ1, &h->bsde, &h->ftab})
+                      &h->beps_e, &h->bo1, &h->bo2, &h->bo3, &h->F.slab, &h->Rv.slab, &h->fs, &h->partial, &h->result, &h->segtmp, &h->tile_t, &h->tile_e, &h->Fad.slab, &h->btan, &h->bx0ad, &h->tile_tan, &h->balt, &h->bF, &h->bPinf, &h->btimes, &h->bAQ1, &h->bsde, &h->ftab, &h->btau})
         b->release();
     for (auto& e : h->ev)
         if (e) (void)hipEventDestroy(e);
@@ -1290,6 +1437,7 @@ int tgp_destroy(tgp_handle* h) {
     if (h->dense) tgp_dense::destroy(h->dense);
     if (h->steady2) tgp_steady::destroy(h->steady2);
     if (h->modal) tgp_modal::destroy(h->modal);
+    if (h->sweep) tgp_sweep::destroy(h->sweep);
     if (h->host_result) (void)hipHostFree(h->host_result);
     if (h->adj_host) (void)hipHostFree(h->adj_host);
     if (h->flt_host) (void)hipHostFree(h->flt_host);
@@ -1351,6 +1499,18 @@ int tgp_set_option(tgp_handle* h, int option, int64_t value) {
         h->modal_state = 0;
         h->steady_known = false;
         h->smoother_valid = false;
+        return TGP_OK;
+    }
+    if (option == TGP_OPT_SWEEP) {
+        h->opt_sweep = value != 0;
+        h->sweep_state = 0;
+        return TGP_OK;
+    }
+    if (option == TGP_OPT_SWEEP_CHUNK || option == TGP_OPT_SWEEP_WARMUP || option == TGP_OPT_SWEEP_WARMUP_BACK) {
+        if (value < 0 || value > (1 << 20)) return h->fail(TGP_EINVAL, "sweep geometry out of range");
+        (option == TGP_OPT_SWEEP_CHUNK ? h->sweep_fC : option == TGP_OPT_SWEEP_WARMUP ? h->sweep_fW : h->sweep_fWb) = (int)value;
+        h->sweep_state = 0;
+        h->sweep_W = h->sweep_Wb = 0;
         return TGP_OK;
     }
     if (option == TGP_OPT_SDE_CLOSED_FORM) {
@@ -1430,6 +1590,17 @@ int tgp_steady_steps(tgp_handle* h, int64_t* mean_only, int64_t* total) {
     return TGP_OK;
 }
 
+int tgp_sweep_info(tgp_handle* h, int64_t* info, double* dist) {
+    if (!h) return TGP_EINVAL;
+    if (info) {
+        for (int i = 0; i < 8; ++i) info[i] = h->sweep_info[i];
+        info[0] = h->sweep_last ? 1 : 0;
+        info[7] = h->sweep_state;
+    }
+    if (dist) { dist[0] = h->sweep_dist[0]; dist[1] = h->sweep_dist[1]; }
+    return TGP_OK;
+}
+
 int tgp_set_stream(tgp_handle* h, void* hip_stream) {
     if (!h) return TGP_EINVAL;
     drop_graphs(h);
@@ -1459,6 +1630,10 @@ int tgp_model_set(tgp_handle* h, int64_t T, int d, int p, int ordering, uint32_t
     h->modal_last = false;
     h->dense_last_n0 = -1;
     h->hostm.clear();
+    h->sweep_state = 0;
+    h->sweep_last = false;
+    h->sweep_W = h->sweep_Wb = 0;
+    if (!h->binding_sde) { h->sde_coef_host.clear(); h->sde_A1Q1_host.clear(); }
     h->fold_valid = false;
     h->reduce_valid = false;
     h->smoother_valid = false;
@@ -1563,11 +1738,15 @@ int tgp_model_set(tgp_handle* h, int64_t T, int d, int p, int ordering, uint32_t
     h->x0P.assign(x0P, x0P + d * d);
     TRY(upload_x0(h, h->bx0, x0m, x0P));
     HIPCHK(hipStreamSynchronize(h->stream));
-    if (h->lti && !h->binding_sde && p == 1 && (flags & TGP_SHARED_R) && tgp_steady::supports(d)) {
-        // what the one-launch path's host plan reads (tgp_steady_plan.hpp): the shared blocks, on the host
+    // (the shared blocks of a model the host plans read -- tgp_steady_plan.hpp: every block shared; tgp_sweep_plan.hpp: noise / offset may be per step,
+    //  SDE-bound models bring their A1, Q1 through tgp_model_set_sde)
+    const uint32_t host_bits = TGP_SHARED_A | TGP_SHARED_a | TGP_SHARED_Q | TGP_SHARED_H;
+    const bool one_launch_model = h->lti && !h->binding_sde && p == 1 && (flags & TGP_SHARED_R) && tgp_steady::supports(d);      // what `hostm` stands for
+    h->sweepm.clear();
+    if ((flags & host_bits) == host_bits && p == 1 && tgp_steady::supports(d)) {
         const size_t dd = (size_t)d * d;
-        h->hostm.assign(2 * dd + 2 * (size_t)d + 2, 0.0);
-        double* q = h->hostm.data();
+        h->sweepm.assign(2 * dd + 2 * (size_t)d + 2, 0.0);
+        double* q = h->sweepm.data();
         const struct { const double* src; size_t n; } parts[6] = {{A, dd}, {a, (size_t)d}, {Q, dd}, {H, (size_t)d}, {hh, 1}, {R, 1}};
         size_t off = 0;
         for (const auto& pt : parts) {
@@ -1575,6 +1754,25 @@ int tgp_model_set(tgp_handle* h, int64_t T, int d, int p, int ordering, uint32_t
             else std::memcpy(q + off, pt.src, pt.n * sizeof(double));
             off += pt.n;
         }
+        // a representative noise variance (the sweep engine's warm-up estimate): the median of a sample of the per-step values below the
+        // "missing" level of missings.jl:43
+        h->sweep_Rrep = q[2 * dd + 2 * (size_t)d + 1];
+        if (!(flags & TGP_SHARED_R)) {
+            const size_t ns = (size_t)std::min<int64_t>(T, 4096);
+            std::vector<double> smp(ns);
+            if (dev) HIPCHK(hipMemcpy(smp.data(), R, ns * sizeof(double), hipMemcpyDeviceToHost));
+            else std::memcpy(smp.data(), R, ns * sizeof(double));
+            std::vector<double> okv;
+            for (double v : smp)
+                if (v > 0.0 && v < 1e14) okv.push_back(v);
+            if (!okv.empty()) {
+                std::nth_element(okv.begin(), okv.begin() + okv.size() / 2, okv.end());
+                h->sweep_Rrep = okv[okv.size() / 2];
+            } else {
+                h->sweep_Rrep = 1.0;
+            }
+        }
+        if (one_launch_model) h->hostm = h->sweepm;
     }
     h->have_model = true;
     return TGP_OK;
@@ -1710,6 +1908,48 @@ int tgp_model_set_sde(tgp_handle* h, int64_t T, int d, int ordering, uint32_t fl
     }
     h->lti = false;        // transitions are per-step (tiled), whatever the emission flags say
     h->tile_L0 = 0;
+    // what the sweep engine reads (tgp_sweep.hpp): the gaps as one plain array, the closed-form coefficients and the first transition on the host
+    h->sde_coef_host.clear();
+    h->sde_A1Q1_host.clear();
+    if (h->sde_closed && d <= tgp_sweep::kMaxD) {
+        std::vector<double> coef;
+        (void)sde_closed_form(d, F, x0P, nullptr, nullptr, coef);
+        h->sde_coef_host = coef;
+        std::vector<double> tau((size_t)T);
+        tau[0] = -1.0;
+        for (int64_t k = 1; k < T; ++k) tau[(size_t)k] = times[k] - times[k - 1];
+        HIPCHK(h->btau.ensure((size_t)T * sizeof(double)));
+        HIPCHK(hipMemcpyAsync(h->btau.p, tau.data(), (size_t)T * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        {
+            const size_t ns = (size_t)std::min<int64_t>(T - 1, 4096);
+            std::vector<double> smp(tau.begin() + 1, tau.begin() + 1 + ns);
+            h->sweep_tau = 1.0;
+            if (!smp.empty()) {
+                std::nth_element(smp.begin(), smp.begin() + smp.size() / 2, smp.end());
+                h->sweep_tau = smp[smp.size() / 2];
+            }
+        }
+        // the first transition: as given, else the reference's dt_1 := 1 (lti_sde.jl:139) by the same closed form
+        h->sde_A1Q1_host.assign((size_t)2 * d * d, 0.0);
+        double* A1h = h->sde_A1Q1_host.data();
+        double* Q1h = A1h + (size_t)d * d;
+        if (h->have_AQ1) {
+            std::memcpy(A1h, A1, (size_t)d * d * sizeof(double));
+            std::memcpy(Q1h, Q1, (size_t)d * d * sizeof(double));
+        } else {
+            const double* q = coef.data();
+            for (int j = 0; j < d; ++j)
+                for (int i = 0; i < d; ++i) A1h[i + j * d] = std::exp(-q[i]) * (q[d + d * d + i + j * d] + q[d + i + j * d] + (i == j ? 1.0 : 0.0));
+            for (int j = 0; j < d; ++j)
+                for (int i = 0; i < d; ++i) {
+                    double acc = 0.0;
+                    for (int k = 0; k < d; ++k)
+                        for (int l = 0; l < d; ++l) acc += A1h[i + k * d] * 0.5 * (x0P[k + l * d] + x0P[l + k * d]) * A1h[j + l * d];
+                    Q1h[i + j * d] = 0.5 * (x0P[i + j * d] + x0P[j + i * d]) - acc;
+                }
+        }
+    }
     return TGP_OK;
 }
 
@@ -1755,6 +1995,12 @@ int tgp_logpdf(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t 
         const int rc = tm.finish(out);
         if (rc != TGP_OK || steady2_served(h)) return rc;
         // not applicable to this model (decided on the device): the general path below serves this and every later call
+    }
+    h->sweep_last = false;
+    if (sweep_eligible(h, flags)) {
+        bool served = false;
+        TRY(sweep_call(h, y, missing, flags, nullptr, nullptr, nullptr, out, &served));
+        if (served) return TGP_OK;
     }
     resolve_table(h);
     if (graph_eligible(h, flags, false)) {
@@ -2353,6 +2599,12 @@ int tgp_posterior_marginals(tgp_handle* h, const double* y, const uint8_t* missi
             h->smoother_valid = false;
             return rc;
         }
+    }
+    h->sweep_last = false;
+    if (sweep_eligible(h, flags)) {
+        bool served = false;
+        TRY(sweep_call(h, y, missing, flags, Rnew, mean_out, var_out, lml_out, &served));
+        if (served) return TGP_OK;
     }
     resolve_table(h);
     if (graph_eligible(h, flags, true)) {

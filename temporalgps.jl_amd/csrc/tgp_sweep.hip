@@ -1,0 +1,262 @@
+// The sweep engine: see tgp_sweep.hpp (what and why) and tgp_sweep_body.hpp (the per-lane arithmetic, shared with tests/hostsim).
+// gfx950 only.  One wave per workgroup, one wave per SIMD (the kernel is bound by its fp64 instruction stream, not by memory: every
+// lane carries the full covariance recursion of its chunk), 4 workgroups per CU by their LDS (the filtering states of a block).
+#include "tgp_sweep.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "tgp_sweep_body.hpp"
+
+namespace tgp_sweep {
+
+__device__ __forceinline__ double shfl_up1(double v) { return __shfl_up(v, 1, 64); }
+__device__ __forceinline__ double shfl_dn1(double v) { return __shfl_down(v, 1, 64); }
+
+template <int D> __device__ __forceinline__ bool state_finite(const State<D>& x) {
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < D; ++k) s += ::fabs(x.m[k]);
+#pragma unroll
+    for (int k = 0; k < SD<D>::DS; ++k) s += ::fabs(x.P[k]);
+    return s < 1e300;      // (false for NaN as well)
+}
+
+template <int D, bool SDE, bool POST>
+__global__ __launch_bounds__(64, 1) void k_sweep(const KArgs<D> by_value) {
+    (void)by_value;
+    const KArgs<D>& ka = *(const KArgs<D>*)__builtin_amdgcn_kernarg_segment_ptr();      // (read in place, scalar loads: tgp_modal.hip k_steady_one)
+    constexpr int B = Geo<D>::B, NS = SD<D>::NS, DS = SD<D>::DS;
+    __shared__ double sF[POST ? B * NS * 64 : 64];
+    const int lane = threadIdx.x;
+    const long long wave = blockIdx.x;
+    const long long T = ka.T;
+    const int C = ka.C;
+    const long long c = wave * kOwned + lane - 1;
+    const bool active = c >= 0 && c < ka.nchunks;
+    const long long t0 = active ? c * C : 0;
+    long long t1 = active ? t0 + C : 0;
+    t1 = t1 < T ? t1 : (active ? T : 0);
+    const bool runs = active && lane >= 1;                    // lane 0 only warms up for lane 1
+    const bool owned = runs && lane <= kOwned;                // lane 63 only warms up (backwards) for lane 62
+    bool ok = true;
+
+    State<D> gen, x0;
+    set_state<D>(gen, ka.mc.gm, ka.mc.gP);
+    set_state<D>(x0, ka.mc.x0m, ka.mc.x0P);
+    double* ck = POST ? ka.ckpt + (size_t)wave * (size_t)(C / B) * NS * 64 : nullptr;
+
+    // ---- forwards.  Pass 0: the last W steps of the chunk from the stationary prior (from x0 where they reach the series' first step); its
+    // end state is the NEXT lane's start state.  Pass 1: the chunk from the previous lane's end state (checkpoints, log marginal likelihood).
+    State<D> x, e1;
+    LmlAcc acc;
+    {
+        const long long tw = t1 - ka.W;
+        x = tw <= 0 ? x0 : gen;
+        for (int pass = 0; pass < 2; ++pass) {
+            const long long ts = pass == 0 ? tw : t0;
+            const long long lo = pass == 0 ? (tw > 0 ? tw : 0) : t0;
+            const long long hi = pass == 0 ? t1 : (runs ? t1 : t0);
+            acc = LmlAcc();
+            forward_run<D, SDE, B>(ka, ts, (pass == 0 ? ka.W : C) / B, lo, hi, x, acc, pass == 1, pass == 1 ? ck : (double*)nullptr, lane, ok);
+            if (pass == 0) {
+                e1 = x;
+#pragma unroll
+                for (int k = 0; k < D; ++k) x.m[k] = shfl_up1(e1.m[k]);
+#pragma unroll
+                for (int k = 0; k < DS; ++k) x.P[k] = shfl_up1(e1.P[k]);
+                if (t0 == 0) x = x0;
+            }
+        }
+    }
+    double dist_f = 0.0, dist_b = 0.0;
+    bool finite = true;
+    if (owned) {
+        dist_f = state_distance<D>(ka.mc, x, e1);
+        finite = state_finite<D>(x) && state_finite<D>(e1);
+    }
+
+    if (POST) {
+        // ---- backwards.  Pass 0: the first Wb steps of the chunk from the filtering state behind them (the smoothing state where they reach
+        // the series' last step); its end state, the smoothing state of the chunk's first step, is what the PREVIOUS lane continues from.
+        // Pass 1: the chunk, mean and variance of every step.
+        const long long te = (t0 + ka.Wb < t1) ? t0 + ka.Wb : t1;
+        State<D> xs = gen, b1 = gen;
+        for (int pass = 0; pass < 2; ++pass) {
+            const long long hi = pass == 0 ? (runs ? te : t0) : (owned ? t1 : t0);
+            const bool fresh = pass == 0 ? true : (t1 == T);
+            backward_run<D, SDE, B>(ka, t0, t1, (pass == 0 ? ka.Wb : C) / B, hi, fresh, xs, pass == 1, ck, sF, lane, ok);
+            if (pass == 0) {
+                b1 = xs;
+#pragma unroll
+                for (int k = 0; k < D; ++k) xs.m[k] = shfl_dn1(b1.m[k]);
+#pragma unroll
+                for (int k = 0; k < DS; ++k) xs.P[k] = shfl_dn1(b1.P[k]);
+            }
+        }
+        if (owned) {
+            dist_b = state_distance<D>(ka.mc, xs, b1);
+            finite = finite && state_finite<D>(xs) && state_finite<D>(b1);
+        }
+    }
+
+    // ---- the wave's share: fixed-order sums over the lanes
+    double lml = owned ? acc.total() : 0.0;
+    finite = finite && (::fabs(lml) < 1e300);
+    unsigned bits = 0;
+    if (owned && !(dist_f <= ka.mc.tol)) bits |= 1u;
+    if (owned && POST && !(dist_b <= ka.mc.tol)) bits |= 2u;
+    if (!ok) bits |= 4u;
+    if (!finite) bits |= 8u;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        lml += __shfl_xor(lml, off, 64);
+        bits |= (unsigned)__shfl_xor((int)bits, off, 64);
+        const double of = __shfl_xor(dist_f, off, 64), ob = __shfl_xor(dist_b, off, 64);
+        dist_f = (of > dist_f) ? of : dist_f;
+        dist_b = (ob > dist_b) ? ob : dist_b;
+    }
+    if (lane == 0) {
+        double* p = ka.part + (size_t)wave * 4;
+        p[0] = lml;
+        p[1] = (double)bits;
+        p[2] = dist_f;
+        p[3] = dist_b;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------ host side
+struct Engine {
+    Plan p;
+    Forced forced;
+    double* part = nullptr;             // pinned: the waves' shares
+    size_t part_cap = 0;
+    void* ckpt = nullptr;
+    size_t ckpt_cap = 0;
+};
+
+Engine* create() { return new Engine(); }
+void destroy(Engine* e) {
+    if (!e) return;
+    if (e->part) (void)hipHostFree(e->part);
+    if (e->ckpt) (void)hipFree(e->ckpt);
+    delete e;
+}
+void force_geometry(Engine* e, int C, int W, int Wb) {
+    e->forced.C = C;
+    e->forced.W = W;
+    e->forced.Wb = Wb;
+}
+void geometry(const Engine* e, int* C, int* W, int* Wb, int64_t* nwaves) {
+    if (C) *C = e->p.C;
+    if (W) *W = e->p.W;
+    if (Wb) *Wb = e->p.Wb;
+    if (nwaves) *nwaves = e->p.nwaves;
+}
+bool plan(Engine* e, const ModelHost& m, int64_t T, int w_hint, int wb_hint, int num_cu, std::string* why) {
+    return make_plan(&e->p, e->forced, m, T, w_hint, wb_hint, num_cu, why);
+}
+
+namespace {
+
+template <int D, bool SDE, bool POST> void launch(Engine* e, hipStream_t stream, const Call& c) {
+    KArgs<D> ka;
+    std::memcpy(&ka.mc, e->p.mc, sizeof ka.mc);
+    ka.st.y = c.y;
+    ka.st.mask = c.mask;
+    ka.st.R = c.R;
+    ka.st.hh = c.hh;
+    ka.st.tau = c.tau;
+    ka.st.Rnew = c.Rnew;
+    ka.st.rnew_per_step = c.rnew_per_step;
+    ka.T = c.T;
+    ka.C = e->p.C;
+    ka.W = e->p.W;
+    ka.Wb = e->p.Wb;
+    ka.nchunks = e->p.nchunks;
+    ka.mean = c.mean;
+    ka.var = c.var;
+    ka.ckpt = static_cast<double*>(e->ckpt);
+    ka.part = e->part;
+    hipLaunchKernelGGL((k_sweep<D, SDE, POST>), dim3((unsigned)e->p.nwaves), dim3(64), 0, stream, ka);
+}
+
+template <int D> void launch_d(Engine* e, hipStream_t stream, const Call& c) {
+    const bool post = c.mean != nullptr;
+    if (e->p.sde) {
+        if (post) launch<D, true, true>(e, stream, c);
+        else launch<D, true, false>(e, stream, c);
+    } else {
+        if (post) launch<D, false, true>(e, stream, c);
+        else launch<D, false, false>(e, stream, c);
+    }
+}
+
+}  // namespace
+
+const char* kernel_name(int, bool sde, bool post) {
+    return sde ? (post ? "k_sweep<sde,posterior>" : "k_sweep<sde,logpdf>") : (post ? "k_sweep<lti,posterior>" : "k_sweep<lti,logpdf>");
+}
+
+int enqueue(Engine* e, hipStream_t stream, const Call& c, const char** kname, std::string* err) {
+    auto fail = [&](const char* what, hipError_t rc) {
+        if (err) *err = std::string(what) + ": " + hipGetErrorString(rc);
+        return 1;
+    };
+    const Plan& p = e->p;
+    const bool post = c.mean != nullptr;
+    const size_t need_part = (size_t)p.nwaves * 4 * sizeof(double);
+    if (need_part > e->part_cap) {
+        if (e->part) (void)hipHostFree(e->part);
+        e->part = nullptr;
+        e->part_cap = 0;
+        const size_t cap = std::max<size_t>(need_part, 1 << 16);
+        hipError_t rc = hipHostMalloc((void**)&e->part, cap, hipHostMallocDefault);
+        if (rc != hipSuccess) return fail("hipHostMalloc", rc);
+        e->part_cap = cap;
+    }
+    if (post) {
+        const int B = p.d <= 3 ? 8 : 4, NS = p.d + p.d * (p.d + 1) / 2;
+        const size_t need = (size_t)p.nwaves * (size_t)(p.C / B) * NS * 64 * sizeof(double);
+        if (need > e->ckpt_cap) {
+            if (e->ckpt) (void)hipFree(e->ckpt);
+            e->ckpt = nullptr;
+            e->ckpt_cap = 0;
+            hipError_t rc = hipMalloc(&e->ckpt, need);
+            if (rc != hipSuccess) return fail("hipMalloc", rc);
+            e->ckpt_cap = need;
+        }
+    }
+    if (kname) *kname = kernel_name(p.d, p.sde, post);
+    switch (p.d) {
+        case 1: launch_d<1>(e, stream, c); break;
+        case 2: launch_d<2>(e, stream, c); break;
+        case 3: launch_d<3>(e, stream, c); break;
+        default: launch_d<4>(e, stream, c); break;
+    }
+    hipError_t rc = hipGetLastError();
+    if (rc != hipSuccess) return fail("k_sweep launch", rc);
+    return 0;
+}
+
+double finish(Engine* e, int* status, int* w, int* wb, double* dist_f, double* dist_b) {
+    double lml = 0.0, df = 0.0, db = 0.0;
+    unsigned bits = 0;
+    for (int64_t i = 0; i < e->p.nwaves; ++i) {      // fixed order: the same sum for the same geometry
+        const double* q = e->part + (size_t)i * 4;
+        lml += q[0];
+        bits |= (unsigned)q[1];
+        df = std::max(df, q[2]);
+        db = std::max(db, q[3]);
+    }
+    if (status) *status = (int)bits;
+    if (w) *w = e->p.W;
+    if (wb) *wb = e->p.Wb;
+    if (dist_f) *dist_f = df;
+    if (dist_b) *dist_b = db;
+    return lml;
+}
+
+}  // namespace tgp_sweep

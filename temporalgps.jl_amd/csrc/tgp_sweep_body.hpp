@@ -1,0 +1,504 @@
+// Per-lane arithmetic of the sweep engine (tgp_sweep.hip): the reference's sequential recursions for ONE chunk of consecutive
+// steps with time-varying gains -- a missing-data mask, a noise variance per step, irregular spacing -- on a state (m, packed upper P) in
+// registers.  Host- and device-callable: tests/hostsim runs the very same functions lane by lane on the CPU (tests/test_sweep_host.py).
+//
+// Reference semantics restated here (file:line under /root/reference/src):
+//   predict              models/linear_gaussian_conditionals.jl:46-52     (A Symmetric(P)) A' + Q  (upper triangle kept)
+//   posterior_and_lml    models/linear_gaussian_conditionals.jl:247-257   ScalarOutputLGC; a missing step is skipped (missings.jl:8-23:
+//                        y := 0, R := 1e15 and the compensated volume term agree with skipping to ~1e-15 relative)
+//   invert_dynamics      models/lgssm.jl:231-238                           G = Pf A' (Pp + 1e-10 I)^-1 by Cholesky, as there
+//   step_marginals       models/lgssm.jl:111-115 (Reverse)                 x <- G x + g, P <- G P G' + L, in gain form:
+//                        ms = mf + G (ms+ - mp),  Ps = Pf + G (Ps+ - Pp - 1e-10 I) G'   (L = Pf - G (Pp + 1e-10 I) G' substituted)
+//   broadcast_components gp/lti_sde.jl:135-146                             A_k = exp(F tau_k) in closed form per Matern block;
+//                        Q_k = Pinf - A_k Pinf A_k' is never formed: A P A' + Q_k = A (P - Pinf) A' + Pinf
+#pragma once
+#include "tgp_math.hpp"
+
+namespace tgp_sweep {
+
+constexpr double kJitter = 1e-10;      // lgssm.jl:235
+constexpr double kLog2Pi = 1.8378770664093454835606594728112;
+
+template <int D> struct SD {
+    static constexpr int DD = D * D, DS = D * (D + 1) / 2, NS = D + DS;
+};
+// packed upper triangle, column by column (tgp_math_body.inc store_sym): entry (i, j), i <= j, sits at j (j + 1) / 2 + i
+TGP_HD constexpr int pidx(int i, int j) { return i <= j ? j * (j + 1) / 2 + i : i * (i + 1) / 2 + j; }
+
+// 1 / x and (sqrt x, 1 / sqrt x) from the hardware's approximate v_rcp_f64 / v_rsq_f64 and two Newton (Goldschmidt) steps each: ~1 ulp,
+// 5 / 8 instructions instead of the 12 / 25 of an IEEE division / sqrt + division (the passes are bound by their instruction stream).
+TGP_HD double fast_rcp(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r = __builtin_amdgcn_rcp(x);
+    double e = ::fma(-x, r, 1.0);
+    r = ::fma(r, e, r);
+    e = ::fma(-x, r, 1.0);
+    r = ::fma(r, e, r);
+    return r;
+#else
+    return 1.0 / x;
+#endif
+}
+TGP_HD void fast_sqrt_rsqrt(double x, double& s, double& rs) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double r0 = __builtin_amdgcn_rsq(x);
+    double g = x * r0, hh = 0.5 * r0;
+    double e = ::fma(-hh, g, 0.5);
+    g = ::fma(g, e, g);
+    hh = ::fma(hh, e, hh);
+    e = ::fma(-hh, g, 0.5);
+    g = ::fma(g, e, g);
+    hh = ::fma(hh, e, hh);
+    s = g;
+    rs = hh + hh;
+#else
+    s = ::sqrt(x);
+    rs = 1.0 / s;
+#endif
+}
+
+// ---- the model's shared blocks, as the kernel reads them from its argument segment (scalar loads) ----------------------------------
+template <int D> struct ModelC {
+    double A[D * D], a[D], Q[SD<D>::DS];      // LTI transition.  SDE: A = A1, the series' FIRST transition (lti_sde.jl:139; its Q1 must be
+                                              // Pinf - A1 Pinf A1', which the host checks), Q unused
+    double H[D];
+    double x0m[D], x0P[SD<D>::DS];            // the prior of the series
+    double gm[D], gP[SD<D>::DS];              // where a warm-up starts from: the stationary prior (SDE: Pinf)
+    double lam[D], N1[D * D], N2[D * D];      // SDE: exp(F tau) = e^(-lam tau) (I + tau N1 + tau^2 N2) per block (ModelView::sde)
+    double hh, R;                             // shared emission offset / noise variance (used where no per-step stream is given)
+    double tol;                               // relative size of a forgotten start state (the checks of the two directions)
+};
+
+template <int D> struct State {
+    double m[D];
+    double P[SD<D>::DS];
+};
+
+template <int D> TGP_HD void set_state(State<D>& x, const double* m, const double* P) {
+    TGP_UNROLL for (int i = 0; i < D; ++i) x.m[i] = m[i];
+    TGP_UNROLL for (int i = 0; i < SD<D>::DS; ++i) x.P[i] = P[i];
+}
+
+// A = exp(F tau) in closed form (tgp_chunk.hpp sde_transition_impl, without its Q)
+template <int D> TGP_HD void sde_A(const ModelC<D>& mc, double tau, double* A) {
+    double e[D];
+    e[0] = ::exp(-mc.lam[0] * tau);
+    TGP_UNROLL for (int i = 1; i < D; ++i) e[i] = (mc.lam[i] == mc.lam[i - 1]) ? e[i - 1] : ::exp(-mc.lam[i] * tau);     // (wave-uniform: one exp per block)
+    const double t2 = tau * tau;
+    TGP_UNROLL for (int j = 0; j < D; ++j)
+        TGP_UNROLL for (int i = 0; i < D; ++i) A[i + j * D] = e[i] * ::fma(t2, mc.N2[i + j * D], ::fma(tau, mc.N1[i + j * D], i == j ? 1.0 : 0.0));
+}
+
+// AX = A Symmetric(X) (full d x d), X packed
+template <int D> TGP_HD void mul_A_sym(const double* A, const double* X, double* AX) {
+    TGP_UNROLL for (int j = 0; j < D; ++j)
+        TGP_UNROLL for (int i = 0; i < D; ++i) {
+            double acc = 0.0;
+            TGP_UNROLL for (int k = 0; k < D; ++k) acc = ::fma(A[i + k * D], X[pidx(k, j)], acc);
+            AX[i + j * D] = acc;
+        }
+}
+// out (packed upper) = AX A' + C (packed)
+template <int D> TGP_HD void mul_AXAt_plus(const double* AX, const double* A, const double* C, double* out) {
+    TGP_UNROLL for (int j = 0; j < D; ++j)
+        TGP_UNROLL for (int i = 0; i <= j; ++i) {
+            double acc = C[pidx(i, j)];
+            TGP_UNROLL for (int k = 0; k < D; ++k) acc = ::fma(AX[i + k * D], A[j + k * D], acc);
+            out[pidx(i, j)] = acc;
+        }
+}
+
+// The transition of one step, in the form the predict needs: LTI -> (A, a, Q) of the model; SDE -> A from tau, covariance through Pinf.
+template <int D, bool SDE> struct Trans {
+    double A[D * D];
+    TGP_HD void set(const ModelC<D>& mc, double tau, bool first) {
+        if constexpr (SDE) {
+            sde_A<D>(mc, first ? 0.0 : tau, A);
+            TGP_UNROLL for (int i = 0; i < D * D; ++i) A[i] = first ? mc.A[i] : A[i];
+        } else {
+            TGP_UNROLL for (int i = 0; i < D * D; ++i) A[i] = mc.A[i];
+        }
+    }
+};
+
+// predict (lgc.jl:46-52).
+// AP_out (optional, full d x d): A Symmetric(P) of the INCOMING covariance -- what invert_dynamics multiplies again (lgssm.jl:234).
+template <int D, bool SDE> TGP_HD void predict(const ModelC<D>& mc, const double* A, double* m, double* P, double* AP_out = nullptr) {
+    double mp[D];
+    TGP_UNROLL for (int i = 0; i < D; ++i) {
+        double acc = mc.a[i];
+        TGP_UNROLL for (int k = 0; k < D; ++k) acc = ::fma(A[i + k * D], m[k], acc);
+        mp[i] = acc;
+    }
+    TGP_UNROLL for (int i = 0; i < D; ++i) m[i] = mp[i];
+    double AX[D * D], Pn[SD<D>::DS];
+    if constexpr (SDE) {
+        if (AP_out) {      // A P and A Pinf separately: the smoother needs A P itself
+            double AG[D * D];
+            mul_A_sym<D>(A, P, AP_out);
+            mul_A_sym<D>(A, mc.gP, AG);
+            TGP_UNROLL for (int i = 0; i < D * D; ++i) AX[i] = AP_out[i] - AG[i];
+        } else {
+            double Dm[SD<D>::DS];
+            TGP_UNROLL for (int i = 0; i < SD<D>::DS; ++i) Dm[i] = P[i] - mc.gP[i];
+            mul_A_sym<D>(A, Dm, AX);
+        }
+        mul_AXAt_plus<D>(AX, A, mc.gP, Pn);
+    } else {
+        mul_A_sym<D>(A, P, AX);
+        if (AP_out) { TGP_UNROLL for (int i = 0; i < D * D; ++i) AP_out[i] = AX[i]; }
+        mul_AXAt_plus<D>(AX, A, mc.Q, Pn);
+    }
+    TGP_UNROLL for (int i = 0; i < SD<D>::DS; ++i) P[i] = Pn[i];
+}
+
+// The log marginal likelihood's running sums of one lane: sum of r^2 / S, the product of the S of up to eight steps (ONE log per eight
+// steps: log prod = sum log to rounding), the observed steps.
+struct LmlAcc {
+    double q = 0.0, logs = 0.0, prod = 1.0, n = 0.0;
+    TGP_HD void flush() {
+        logs += ::log(prod);
+        prod = 1.0;
+    }
+    TGP_HD double total() const { return -0.5 * (n * kLog2Pi + logs + q); }
+};
+
+// posterior_and_lml of a ScalarOutputLGC (lgc.jl:247-257); obs == false: the step is missing, nothing changes.
+template <int D> TGP_HD void update(const double* H, double hh, double R, double y, bool obs, double* m, double* P, LmlAcc* acc, bool& ok) {
+    double V[D];
+    TGP_UNROLL for (int j = 0; j < D; ++j) {
+        double a = 0.0;
+        TGP_UNROLL for (int k = 0; k < D; ++k) a = ::fma(H[k], P[pidx(k, j)], a);
+        V[j] = a;
+    }
+    double s2 = R, hm = hh;
+    TGP_UNROLL for (int k = 0; k < D; ++k) {
+        s2 = ::fma(V[k], H[k], s2);
+        hm = ::fma(H[k], m[k], hm);
+    }
+    const double S = obs ? s2 : 1.0;
+    ok = ok && (S > 0.0);
+    const double iS = obs ? fast_rcp(S) : 0.0;
+    const double v = obs ? (y - hm) : 0.0;
+    const double viS = v * iS;
+    TGP_UNROLL for (int i = 0; i < D; ++i) m[i] = ::fma(V[i], viS, m[i]);
+    TGP_UNROLL for (int j = 0; j < D; ++j) {
+        const double w = V[j] * iS;
+        TGP_UNROLL for (int i = 0; i <= j; ++i) P[pidx(i, j)] = ::fma(-V[i], w, P[pidx(i, j)]);
+    }
+    if (acc) {
+        acc->q = ::fma(v, viS, acc->q);
+        acc->prod *= S;
+        acc->n += obs ? 1.0 : 0.0;
+    }
+}
+
+// One step of the reverse-time recursion (lgssm.jl:231-238 + :111-115): xf = filtering state of step t, A = transition of step t + 1,
+// xs = smoothing state of step t + 1 on entry, of step t on return.
+template <int D, bool SDE> TGP_HD void smooth_step(const ModelC<D>& mc, const double* A, const State<D>& xf, State<D>& xs, bool& ok) {
+    constexpr int DS = SD<D>::DS;
+    double mp[D], Pp[DS], AP[D * D];
+    TGP_UNROLL for (int i = 0; i < D; ++i) mp[i] = xf.m[i];
+    TGP_UNROLL for (int i = 0; i < DS; ++i) Pp[i] = xf.P[i];
+    predict<D, SDE>(mc, A, mp, Pp, AP);
+    // upper Cholesky factor of Pp + jitter I (rows of U, reciprocal pivots)
+    double U[D * D], inv[D];
+    TGP_UNROLL for (int j = 0; j < D; ++j) {
+        TGP_UNROLL for (int i = 0; i < j; ++i) {
+            double acc = Pp[pidx(i, j)];
+            TGP_UNROLL for (int k = 0; k < i; ++k) acc = ::fma(-U[k + i * D], U[k + j * D], acc);
+            U[i + j * D] = acc * inv[i];
+        }
+        double acc = Pp[pidx(j, j)] + kJitter;
+        TGP_UNROLL for (int k = 0; k < j; ++k) acc = ::fma(-U[k + j * D], U[k + j * D], acc);
+        ok = ok && (acc > 0.0);
+        double s, rs;
+        fast_sqrt_rsqrt(acc, s, rs);
+        U[j + j * D] = s;
+        inv[j] = rs;
+    }
+    // W = (Pp + jitter I)^-1 (A Pf) = G'   (column j of W: U' z = AP[:, j], U w = z)
+    double W[D * D];
+    TGP_UNROLL for (int j = 0; j < D; ++j) {
+        TGP_UNROLL for (int i = 0; i < D; ++i) {
+            double acc = AP[i + j * D];
+            TGP_UNROLL for (int k = 0; k < i; ++k) acc = ::fma(-U[k + i * D], W[k + j * D], acc);
+            W[i + j * D] = acc * inv[i];
+        }
+        TGP_UNROLL for (int i = D - 1; i >= 0; --i) {
+            double acc = W[i + j * D];
+            TGP_UNROLL for (int k = i + 1; k < D; ++k) acc = ::fma(-U[i + k * D], W[k + j * D], acc);
+            W[i + j * D] = acc * inv[i];
+        }
+    }
+    // gain form: ms = mf + G (ms+ - mp);  Ps = Pf + G (Ps+ - Pp - jitter I) G'     (G[i][k] = W[k + i D])
+    double dm[D], Dm[DS];
+    TGP_UNROLL for (int i = 0; i < D; ++i) dm[i] = xs.m[i] - mp[i];
+    TGP_UNROLL for (int j = 0; j < D; ++j)
+        TGP_UNROLL for (int i = 0; i <= j; ++i) Dm[pidx(i, j)] = xs.P[pidx(i, j)] - Pp[pidx(i, j)] - (i == j ? kJitter : 0.0);
+    TGP_UNROLL for (int i = 0; i < D; ++i) {
+        double acc = xf.m[i];
+        TGP_UNROLL for (int k = 0; k < D; ++k) acc = ::fma(W[k + i * D], dm[k], acc);
+        xs.m[i] = acc;
+    }
+    double GD[D * D];
+    TGP_UNROLL for (int j = 0; j < D; ++j)
+        TGP_UNROLL for (int i = 0; i < D; ++i) {
+            double acc = 0.0;
+            TGP_UNROLL for (int k = 0; k < D; ++k) acc = ::fma(W[k + i * D], Dm[pidx(k, j)], acc);
+            GD[i + j * D] = acc;
+        }
+    TGP_UNROLL for (int j = 0; j < D; ++j)
+        TGP_UNROLL for (int i = 0; i <= j; ++i) {
+            double acc = xf.P[pidx(i, j)];
+            TGP_UNROLL for (int k = 0; k < D; ++k) acc = ::fma(GD[i + k * D], W[k + j * D], acc);
+            xs.P[pidx(i, j)] = acc;
+        }
+}
+
+// emission predict of a smoothing state (lgssm.jl:111-113 through lgc.jl:46-52 with the replaced noise): mean = H' m + h, var = H' P H + R'
+template <int D> TGP_HD void emit(const double* H, double hh, double Rn, const State<D>& xs, double& mean, double& var) {
+    double mu = hh, v = Rn;
+    TGP_UNROLL for (int j = 0; j < D; ++j) {
+        double acc = 0.0;
+        TGP_UNROLL for (int k = 0; k < D; ++k) acc = ::fma(H[k], xs.P[pidx(k, j)], acc);
+        v = ::fma(acc, H[j], v);
+        mu = ::fma(H[j], xs.m[j], mu);
+    }
+    mean = mu;
+    var = v;
+}
+
+// How far apart two states are, relative to the size of a state: what the checks of a forgotten start compare with mc.tol.
+template <int D> TGP_HD double state_distance(const ModelC<D>& mc, const State<D>& a, const State<D>& b) {
+    double worst = 0.0;
+    TGP_UNROLL for (int i = 0; i < D; ++i) {
+        const double sc = ::sqrt(mc.gP[pidx(i, i)]) + ::fabs(a.m[i]) + ::fabs(b.m[i]);
+        const double r = ::fabs(a.m[i] - b.m[i]) / sc;
+        worst = r > worst ? r : worst;      // (a NaN on either side compares false everywhere: caught by the caller's finite test)
+    }
+    TGP_UNROLL for (int j = 0; j < D; ++j)
+        TGP_UNROLL for (int i = 0; i <= j; ++i) {
+            const double sc = ::sqrt(mc.gP[pidx(i, i)] * mc.gP[pidx(j, j)]);
+            const double r = ::fabs(a.P[pidx(i, j)] - b.P[pidx(i, j)]) / sc;
+            worst = r > worst ? r : worst;
+        }
+    return worst;
+}
+
+// ---- the inputs of one step, as every pass sees them ------------------------------------------------------------------------------
+struct Streams {
+    const double* y = nullptr;
+    const uint8_t* mask = nullptr;      // 1 = missing (nullptr: none)
+    const double* R = nullptr;          // per step (nullptr: mc.R)
+    const double* hh = nullptr;         // per step (nullptr: mc.hh)
+    const double* tau = nullptr;        // SDE: gap to the previous time stamp (entry 0 unused: the first transition is explicit)
+    const double* Rnew = nullptr;       // per step, or one value (rnew_per_step == 0)
+    int rnew_per_step = 0;
+};
+
+// ---- the runs of one lane (the kernel of tgp_sweep.hip and tests/hostsim/sweepsim.cpp call the same code) ---------------------------------
+template <int D> struct KArgs {
+    ModelC<D> mc;
+    Streams st;
+    long long T;
+    int C, W, Wb;               // steps per chunk, forward / backward warm-up: multiples of the block length
+    long long nchunks;
+    double* mean;
+    double* var;
+    double* ckpt;               // [wave][block][component][lane]
+    double* part;               // [wave][4]: share of the log marginal likelihood, status bits, forward / backward distance (pinned host memory)
+};
+
+// steps per block: a checkpoint of the forward run every B steps; the block's B filtering states sit in LDS during the backward run
+template <int D> struct Geo {
+    static constexpr int B = D <= 3 ? 8 : 4;
+};
+
+template <int D, int B> struct InBlk {
+    double y[B], R[B], hh[B], tau[B];
+    bool obs[B];
+};
+
+// the inputs of the B steps from tb on (per lane; indices clamped into the series: steps outside it are never processed)
+template <int D, bool SDE, int B> TGP_HD void load_blk(const KArgs<D>& ka, long long tb, InBlk<D, B>& ib) {
+    const long long T = ka.T;
+TGP_UNROLL
+    for (int j = 0; j < B; ++j) {
+        long long t = tb + j;
+        t = t < 0 ? 0 : (t >= T ? T - 1 : t);
+        ib.y[j] = ka.st.y[t];
+        if (SDE) ib.tau[j] = ka.st.tau[t];
+        ib.obs[j] = true;
+    }
+    if (ka.st.R != nullptr) {
+TGP_UNROLL
+        for (int j = 0; j < B; ++j) {
+            long long t = tb + j;
+            t = t < 0 ? 0 : (t >= T ? T - 1 : t);
+            ib.R[j] = ka.st.R[t];
+        }
+    } else {
+TGP_UNROLL
+        for (int j = 0; j < B; ++j) ib.R[j] = ka.mc.R;
+    }
+    if (ka.st.hh != nullptr) {
+TGP_UNROLL
+        for (int j = 0; j < B; ++j) {
+            long long t = tb + j;
+            t = t < 0 ? 0 : (t >= T ? T - 1 : t);
+            ib.hh[j] = ka.st.hh[t];
+        }
+    } else {
+TGP_UNROLL
+        for (int j = 0; j < B; ++j) ib.hh[j] = ka.mc.hh;
+    }
+    if (ka.st.mask != nullptr) {
+TGP_UNROLL
+        for (int j = 0; j < B; ++j) {
+            long long t = tb + j;
+            t = t < 0 ? 0 : (t >= T ? T - 1 : t);
+            ib.obs[j] = ka.st.mask[t] == 0;
+        }
+    }
+}
+
+// One forward run of a lane: `nblk` blocks from step ts on, of which the steps in [lo, hi) are processed.  x: filtering state in front of
+// step max(ts, lo) on entry, behind step hi - 1 on return.  acc: the log marginal likelihood's sums (want_lml: the logs are taken).
+// ckpt (null: none): the state in front of every block is kept, [block][component][lane].
+template <int D, bool SDE, int B>
+TGP_HD void forward_run(const KArgs<D>& ka, long long ts, int nblk, long long lo, long long hi, State<D>& x, LmlAcc& acc,
+                                            bool want_lml, double* ckpt, int lane, bool& ok) {
+    constexpr int NS = SD<D>::NS;
+    InBlk<D, B> cur, nxt;
+    load_blk<D, SDE, B>(ka, ts, cur);
+    for (int b = 0; b < nblk; ++b) {
+        const long long tb = ts + (long long)b * B;
+        if (b + 1 < nblk) load_blk<D, SDE, B>(ka, tb + B, nxt);      // in flight while this block computes
+        TGP_ISSUE_BARRIER();
+        if (ckpt != nullptr) {
+            double* q = ckpt + (size_t)b * NS * 64 + lane;
+TGP_UNROLL
+            for (int k = 0; k < D; ++k) q[(size_t)k * 64] = x.m[k];
+TGP_UNROLL
+            for (int k = 0; k < SD<D>::DS; ++k) q[(size_t)(D + k) * 64] = x.P[k];
+        }
+TGP_UNROLL
+        for (int j = 0; j < B; ++j) {
+            const long long t = tb + j;
+            if (t >= lo && t < hi) {
+                Trans<D, SDE> tr;
+                tr.set(ka.mc, cur.tau[j], t == 0);
+                predict<D, SDE>(ka.mc, tr.A, x.m, x.P);
+                update<D>(ka.mc.H, cur.hh[j], cur.R[j], cur.y[j], cur.obs[j], x.m, x.P, &acc, ok);
+            }
+        }
+        if (want_lml) acc.flush();      // (wave-uniform)
+        else acc.prod = 1.0;
+        if (b + 1 < nblk) cur = nxt;
+    }
+}
+
+// One backward run of a lane over the blocks nblk - 1 .. 0 of its chunk [t0, t1): the steps in [t0, hi) are smoothed.  fresh: the run starts
+// at step hi - 1 from that step's filtering state (the end of the series, or a warm-up); otherwise xs holds the smoothing state of step hi
+// (the next lane's first step).  On return xs is the smoothing state of step t0.  emit_out: write mean / var of the steps.
+template <int D, bool SDE, int B>
+TGP_HD void backward_run(const KArgs<D>& ka, long long t0, long long t1, int nblk, long long hi, bool fresh, State<D>& xs,
+                                             bool emit_out, const double* ckpt, double* sF, int lane, bool& ok) {
+    constexpr int NS = SD<D>::NS, DS = SD<D>::DS;
+    const long long T = ka.T;
+    double tau_next = 0.0;      // gap in front of the step behind the block in hand
+    if (SDE) {
+        const long long tn = t0 + (long long)nblk * B;
+        tau_next = ka.st.tau[tn < T ? tn : T - 1];
+    }
+    InBlk<D, B> cur, nxt;
+    double rn[B], rn_nxt[B];
+    load_blk<D, SDE, B>(ka, t0 + (long long)(nblk - 1) * B, cur);
+    auto load_rn = [&](long long tb, double* dst) __attribute__((always_inline)) {
+        if (ka.st.rnew_per_step) {
+TGP_UNROLL
+            for (int j = 0; j < B; ++j) {
+                long long t = tb + j;
+                t = t >= T ? T - 1 : t;
+                dst[j] = ka.st.Rnew[t];
+            }
+        } else {
+            const double r = ka.st.Rnew[0];
+TGP_UNROLL
+            for (int j = 0; j < B; ++j) dst[j] = r;
+        }
+    };
+    if (emit_out) load_rn(t0 + (long long)(nblk - 1) * B, rn);
+    for (int b = nblk - 1; b >= 0; --b) {
+        const long long tb = t0 + (long long)b * B;
+        if (b > 0) {
+            load_blk<D, SDE, B>(ka, tb - B, nxt);
+            if (emit_out) load_rn(tb - B, rn_nxt);
+        }
+        // the filtering states of the block, recomputed from its checkpoint into LDS ([step][component][lane])
+        State<D> x;
+        {
+            const double* q = ckpt + (size_t)b * NS * 64 + lane;
+TGP_UNROLL
+            for (int k = 0; k < D; ++k) x.m[k] = q[(size_t)k * 64];
+TGP_UNROLL
+            for (int k = 0; k < DS; ++k) x.P[k] = q[(size_t)(D + k) * 64];
+        }
+        TGP_ISSUE_BARRIER();
+TGP_UNROLL
+        for (int j = 0; j < B; ++j) {
+            const long long t = tb + j;
+            if (t < t1) {
+                Trans<D, SDE> tr;
+                tr.set(ka.mc, cur.tau[j], t == 0);
+                predict<D, SDE>(ka.mc, tr.A, x.m, x.P);
+                update<D>(ka.mc.H, cur.hh[j], cur.R[j], cur.y[j], cur.obs[j], x.m, x.P, (LmlAcc*)nullptr, ok);
+            }
+TGP_UNROLL
+            for (int k = 0; k < D; ++k) sF[(j * NS + k) * 64 + lane] = x.m[k];
+TGP_UNROLL
+            for (int k = 0; k < DS; ++k) sF[(j * NS + D + k) * 64 + lane] = x.P[k];
+        }
+        double om[B], ov[B];
+TGP_UNROLL
+        for (int j = B - 1; j >= 0; --j) {
+            const long long t = tb + j;
+            om[j] = 0.0;
+            ov[j] = 0.0;
+            if (t < hi) {
+                State<D> xf;
+TGP_UNROLL
+                for (int k = 0; k < D; ++k) xf.m[k] = sF[(j * NS + k) * 64 + lane];
+TGP_UNROLL
+                for (int k = 0; k < DS; ++k) xf.P[k] = sF[(j * NS + D + k) * 64 + lane];
+                if (fresh && t == hi - 1) {
+                    xs = xf;
+                } else {
+                    Trans<D, SDE> tr;
+                    tr.set(ka.mc, j == B - 1 ? tau_next : cur.tau[j + 1 < B ? j + 1 : j], false);
+                    smooth_step<D, SDE>(ka.mc, tr.A, xf, xs, ok);
+                }
+                if (emit_out) emit<D>(ka.mc.H, cur.hh[j], rn[j], xs, om[j], ov[j]);
+            }
+        }
+        if (emit_out) {
+TGP_UNROLL
+            for (int j = 0; j < B; ++j) {
+                const long long t = tb + j;
+                if (t < hi) {
+                    ka.mean[t] = om[j];
+                    ka.var[t] = ov[j];
+                }
+            }
+        }
+        if (SDE) tau_next = cur.tau[0];
+        if (b > 0) cur = nxt;
+        if (emit_out && b > 0) {
+TGP_UNROLL
+            for (int j = 0; j < B; ++j) rn[j] = rn_nxt[j];
+        }
+    }
+}
+
+}  // namespace tgp_sweep

@@ -184,3 +184,99 @@ def model_tangent(build, theta, k, rel=1e-6):
     mp, mm = build(tp), build(tm)
     return {key: (np.asarray(mp[key], dtype=np.float64) - np.asarray(mm[key], dtype=np.float64)) / (2 * hstep)
             for key in ("A", "a", "Q", "H", "h", "R", "x0m", "x0P")}
+
+
+# --------------------------------------------------------------------------- sweepsim (CPU emulation of the sweep engine, tgp_sweep.hpp)
+_SWEEPSIM = None
+
+
+def sweepsim():
+    global _SWEEPSIM
+    if _SWEEPSIM is None:
+        src = os.path.join(HERE, "hostsim", "sweepsim.cpp")
+        so = os.path.join(HERE, "hostsim", "libsweepsim.so")
+        deps = [src] + [os.path.join(ROOT, "temporalgps.jl_amd", "csrc", f) for f in ("tgp_math.hpp", "tgp_sweep_body.hpp", "tgp_sweep_plan.hpp")]
+        if not os.path.exists(so) or any(os.path.getmtime(p) > os.path.getmtime(so) for p in deps):
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-o", so, src])
+        _SWEEPSIM = ctypes.CDLL(so)
+        _SWEEPSIM.sweepsim_run.restype = ctypes.c_int
+    return _SWEEPSIM
+
+
+def kernel_sde(k):
+    """(F, H) of a kernel expression built from Matern terms with scaled / stretched / sum (what the closed-form transitions cover)."""
+    from scipy.linalg import block_diag
+    if k[0] == "sum":
+        parts = [kernel_sde(kk) for kk in k[1:]]
+        return block_diag(*[p[0] for p in parts]), np.concatenate([p[1] for p in parts])
+    if k[0] == "scaled":
+        F, H = kernel_sde(k[2])
+        return F, np.sqrt(k[1]) * H
+    if k[0] == "stretched":
+        F, H = kernel_sde(k[2])
+        return F * k[1], H
+    F, _, H = oc.to_sde(k)
+    return F, H
+
+
+def sde_coef(F):
+    """[lambda per row | N | N^2 / 2] of a block-diagonal drift with one eigenvalue per block (ModelView::sde; tgp_api.hip sde_closed_form)."""
+    d = F.shape[0]
+    lam, N, N2 = np.zeros(d), np.zeros((d, d)), np.zeros((d, d))
+    seen, i = set(), 0
+    while i < d:
+        S = [i]
+        grow = True
+        while grow:
+            grow = False
+            for j in range(d):
+                if j not in S and any(F[j, s] != 0 or F[s, j] != 0 for s in S):
+                    S.append(j)
+                    grow = True
+        S = sorted(S)
+        n = len(S)
+        l = -np.trace(F[np.ix_(S, S)]) / n
+        Nb = F[np.ix_(S, S)] + l * np.eye(n)
+        assert np.allclose(np.linalg.matrix_power(Nb, n), 0.0, atol=1e-12 * max(1.0, np.abs(F).max()) ** n)
+        lam[S] = l
+        if n >= 2:
+            N[np.ix_(S, S)] = Nb
+        if n >= 3:
+            N2[np.ix_(S, S)] = 0.5 * Nb @ Nb
+        seen.update(S)
+        i = max(S) + 1
+    return np.concatenate([lam, N.T.reshape(-1), N2.T.reshape(-1)])     # column-major blocks
+
+
+def sweepsim_run(model, y, missing=None, Rnew=None, post=True, sde=None, C=0, W=0, Wb=0, num_cu=1, w_hint=0, wb_hint=0):
+    """model: oracle dict with SHARED A, a, Q, H (or, with sde = (F, times): transitions by the closed form from the gaps); R / h may be
+    per step.  Returns dict(rc, lml, status, dist_f, dist_b, C, W, Wb, nwaves, mean, var)."""
+    T, d = model["T"], len(model["x0m"])
+    cm = lambda M: np.ascontiguousarray(np.asarray(M, dtype=np.float64).T).reshape(-1)
+    R = np.atleast_1d(np.asarray(model["R"], dtype=np.float64))
+    h = np.atleast_1d(np.asarray(model["h"], dtype=np.float64))
+    Rstep = np.ascontiguousarray(R) if R.shape[0] > 1 else None
+    hstep = np.ascontiguousarray(h) if h.shape[0] > 1 else None
+    Rrep = float(np.median(R[R < 1e14])) if np.any(R < 1e14) else 1.0
+    coef, tau, tau_typ = None, None, 0.0
+    if sde is not None:
+        F, times_ = sde
+        coef = sde_coef(F)
+        tau = np.concatenate([[-1.0], np.diff(np.asarray(times_, dtype=np.float64))])
+        tau_typ = float(np.median(tau[1:])) if T > 1 else 1.0
+    A, Q = cm(model["A"][0]), cm(model["Q"][0])
+    a = np.ascontiguousarray(model["a"][0], dtype=np.float64)
+    H = np.ascontiguousarray(model["H"][0], dtype=np.float64)
+    x0m = np.ascontiguousarray(model["x0m"], dtype=np.float64)
+    x0P = cm(model["x0P"])
+    yv = np.ascontiguousarray(y, dtype=np.float64)
+    mk = None if missing is None else np.ascontiguousarray(missing, dtype=np.uint8)
+    rn = np.ascontiguousarray(np.atleast_1d(Rnew if Rnew is not None else 0.0), dtype=np.float64)
+    mean, var, out = np.zeros(T), np.zeros(T), np.zeros(8)
+    u8 = ctypes.POINTER(ctypes.c_uint8)
+    rc = sweepsim().sweepsim_run(
+        d, int(sde is not None), _i64(T), _p(A), _p(a), _p(Q), _p(H), ctypes.c_double(float(h[0])), ctypes.c_double(Rrep), _p(x0m), _p(x0P),
+        _p(coef), ctypes.c_double(tau_typ), _p(yv), None if mk is None else mk.ctypes.data_as(u8), _p(Rstep), _p(hstep), _p(tau), _p(rn),
+        int(rn.shape[0] > 1), int(post), C, W, Wb, w_hint, wb_hint, num_cu, _p(mean), _p(var), _p(out))
+    return dict(rc=rc, lml=out[0], status=int(out[1]), dist_f=out[2], dist_b=out[3], C=int(out[4]), W=int(out[5]), Wb=int(out[6]),
+                nwaves=int(out[7]), mean=mean, var=var)
