@@ -24,7 +24,7 @@ template <int D> __device__ __forceinline__ bool state_finite(const State<D>& x)
     return s < 1e300;      // (false for NaN as well)
 }
 
-template <int D, bool SDE, bool POST>
+template <int D, bool SDE, int XS, bool POST>
 __global__ __launch_bounds__(64, 1) void k_sweep(const KArgs<D> by_value) {
     (void)by_value;
     const KArgs<D>& ka = *(const KArgs<D>*)__builtin_amdgcn_kernarg_segment_ptr();      // (read in place, scalar loads: tgp_modal.hip k_steady_one)
@@ -39,10 +39,13 @@ __global__ __launch_bounds__(64, 1) void k_sweep(const KArgs<D> by_value) {
     const long long t0 = active ? c * C : 0;
     long long t1 = active ? t0 + C : 0;
     t1 = t1 < T ? t1 : (active ? T : 0);
+    const long long t1r = (t1 + 7) & ~7ll;                    // the runs work in whole blocks: the steps behind the series' end are missing ones
     const bool runs = active && lane >= 1;                    // lane 0 only warms up for lane 1
     const bool owned = runs && lane <= kOwned;                // lane 63 only warms up (backwards) for lane 62
     bool ok = true;
 
+    ModelR<D, SDE> mr;
+    mr.init(ka.mc);
     State<D> gen, x0;
     set_state<D>(gen, ka.mc.gm, ka.mc.gP);
     set_state<D>(x0, ka.mc.x0m, ka.mc.x0P);
@@ -53,14 +56,14 @@ __global__ __launch_bounds__(64, 1) void k_sweep(const KArgs<D> by_value) {
     State<D> x, e1;
     LmlAcc acc;
     {
-        const long long tw = t1 - ka.W;
+        const long long tw = t1r - ka.W;
         x = tw <= 0 ? x0 : gen;
         for (int pass = 0; pass < 2; ++pass) {
             const long long ts = pass == 0 ? tw : t0;
             const long long lo = pass == 0 ? (tw > 0 ? tw : 0) : t0;
-            const long long hi = pass == 0 ? t1 : (runs ? t1 : t0);
+            const long long hi = pass == 0 ? t1r : (runs ? t1r : t0);
             acc = LmlAcc();
-            forward_run<D, SDE, B>(ka, ts, (pass == 0 ? ka.W : C) / B, lo, hi, x, acc, pass == 1, pass == 1 ? ck : (double*)nullptr, lane, ok);
+            forward_run<D, SDE, XS, B>(ka, mr, ts, (pass == 0 ? ka.W : C) / B, lo, hi, x, acc, pass == 1, pass == 1 ? ck : (double*)nullptr, lane, ok);
             if (pass == 0) {
                 e1 = x;
 #pragma unroll
@@ -87,7 +90,7 @@ __global__ __launch_bounds__(64, 1) void k_sweep(const KArgs<D> by_value) {
         for (int pass = 0; pass < 2; ++pass) {
             const long long hi = pass == 0 ? (runs ? te : t0) : (owned ? t1 : t0);
             const bool fresh = pass == 0 ? true : (t1 == T);
-            backward_run<D, SDE, B>(ka, t0, t1, (pass == 0 ? ka.Wb : C) / B, hi, fresh, xs, pass == 1, ck, sF, lane, ok);
+            backward_run<D, SDE, XS, B>(ka, mr, t0, (pass == 0 ? ka.Wb : C) / B, hi, fresh, xs, pass == 1, ck, sF, lane, ok);
             if (pass == 0) {
                 b1 = xs;
 #pragma unroll
@@ -161,7 +164,7 @@ bool plan(Engine* e, const ModelHost& m, int64_t T, int w_hint, int wb_hint, int
 
 namespace {
 
-template <int D, bool SDE, bool POST> void launch(Engine* e, hipStream_t stream, const Call& c) {
+template <int D, bool SDE, int XS, bool POST> void launch(Engine* e, hipStream_t stream, const Call& c) {
     KArgs<D> ka;
     std::memcpy(&ka.mc, e->p.mc, sizeof ka.mc);
     ka.st.y = c.y;
@@ -180,18 +183,25 @@ template <int D, bool SDE, bool POST> void launch(Engine* e, hipStream_t stream,
     ka.var = c.var;
     ka.ckpt = static_cast<double*>(e->ckpt);
     ka.part = e->part;
-    hipLaunchKernelGGL((k_sweep<D, SDE, POST>), dim3((unsigned)e->p.nwaves), dim3(64), 0, stream, ka);
+    hipLaunchKernelGGL((k_sweep<D, SDE, XS, POST>), dim3((unsigned)e->p.nwaves), dim3(64), 0, stream, ka);
 }
 
-template <int D> void launch_d(Engine* e, hipStream_t stream, const Call& c) {
-    const bool post = c.mean != nullptr;
-    if (e->p.sde) {
-        if (post) launch<D, true, true>(e, stream, c);
-        else launch<D, true, false>(e, stream, c);
-    } else {
-        if (post) launch<D, false, true>(e, stream, c);
-        else launch<D, false, false>(e, stream, c);
+template <int D, bool SDE, int XS> void launch_x(Engine* e, hipStream_t stream, const Call& c) {
+    if (c.mean != nullptr) launch<D, SDE, XS, true>(e, stream, c);
+    else launch<D, SDE, XS, false>(e, stream, c);
+}
+template <int D, bool SDE> void launch_s(Engine* e, hipStream_t stream, const Call& c) {
+    const int xs = (c.R != nullptr ? 1 : 0) | (c.hh != nullptr ? 2 : 0);
+    switch (xs) {
+        case 0: launch_x<D, SDE, 0>(e, stream, c); break;
+        case 1: launch_x<D, SDE, 1>(e, stream, c); break;
+        case 2: launch_x<D, SDE, 2>(e, stream, c); break;
+        default: launch_x<D, SDE, 3>(e, stream, c); break;
     }
+}
+template <int D> void launch_d(Engine* e, hipStream_t stream, const Call& c) {
+    if (e->p.sde) launch_s<D, true>(e, stream, c);
+    else launch_s<D, false>(e, stream, c);
 }
 
 }  // namespace

@@ -302,7 +302,7 @@ template <int D> struct KArgs {
     ModelC<D> mc;
     Streams st;
     long long T;
-    int C, W, Wb;               // steps per chunk, forward / backward warm-up: multiples of the block length
+    int C, W, Wb;               // steps per chunk, forward / backward warm-up: multiples of 8
     long long nchunks;
     double* mean;
     double* var;
@@ -315,189 +315,284 @@ template <int D> struct Geo {
     static constexpr int B = D <= 3 ? 8 : 4;
 };
 
-template <int D, int B> struct InBlk {
-    double y[B], R[B], hh[B], tau[B];
-    bool obs[B];
+// Register residency of the model's shared blocks inside the runs.  Measured (scripts/ubench/fp64_issue.hip, one wave per SIMD): dependent
+// v_fma_f64 issue back to back at 4.6 cycles, but a scalar load whose value is used right away costs ~100 cycles -- and the first version of
+// this engine re-read its constants from the argument segment in every step (the compiler prefers re-loading an invariant value to keeping
+// it).  A value that went through one of these statements is opaque to the optimiser: it stays in a register of the named file.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TGP_PIN_V(x) asm volatile("" : "+v"(x))
+#define TGP_PIN_S(x) asm volatile("" : "+s"(x))
+#else
+#define TGP_PIN_V(x) ((void)0)
+#define TGP_PIN_S(x) ((void)0)
+#endif
+
+// The model as the runs hold it: multipliers wave-uniform (scalar registers), addends in vector registers (an instruction takes ONE scalar
+// operand).  SDE models: `A` is not kept (a step builds its own from tau; the series' first transition is read from the arguments where needed).
+template <int D, bool SDE> struct ModelR {
+    double A[SDE ? 1 : D * D];
+    double a[D];
+    double Qg[SD<D>::DS];                 // LTI: Q;  SDE: Pinf
+    double H[D];
+    double lam[SDE ? D : 1], N1[SDE ? D * D : 1], N2[SDE ? D * D : 1];
+    double hh, R;
+    TGP_HD void init(const ModelC<D>& mc) {
+        if constexpr (!SDE) {
+            TGP_UNROLL for (int i = 0; i < D * D; ++i) { A[i] = mc.A[i]; TGP_PIN_S(A[i]); }
+            lam[0] = N1[0] = N2[0] = 0.0;
+        } else {
+            A[0] = 0.0;
+            TGP_UNROLL for (int i = 0; i < D; ++i) { lam[i] = mc.lam[i]; TGP_PIN_S(lam[i]); }
+            TGP_UNROLL for (int i = 0; i < D * D; ++i) { N1[i] = mc.N1[i]; N2[i] = mc.N2[i]; TGP_PIN_S(N1[i]); TGP_PIN_S(N2[i]); }
+        }
+        TGP_UNROLL for (int i = 0; i < D; ++i) { a[i] = mc.a[i]; H[i] = mc.H[i]; TGP_PIN_V(a[i]); TGP_PIN_S(H[i]); }
+        TGP_UNROLL for (int i = 0; i < SD<D>::DS; ++i) { Qg[i] = SDE ? mc.gP[i] : mc.Q[i]; TGP_PIN_V(Qg[i]); }
+        hh = mc.hh;
+        R = mc.R;
+        TGP_PIN_V(hh);
+        TGP_PIN_V(R);
+    }
 };
 
-// the inputs of the B steps from tb on (per lane; indices clamped into the series: steps outside it are never processed)
-template <int D, bool SDE, int B> TGP_HD void load_blk(const KArgs<D>& ka, long long tb, InBlk<D, B>& ib) {
-    const long long T = ka.T;
-TGP_UNROLL
-    for (int j = 0; j < B; ++j) {
-        long long t = tb + j;
-        t = t < 0 ? 0 : (t >= T ? T - 1 : t);
-        ib.y[j] = ka.st.y[t];
-        if (SDE) ib.tau[j] = ka.st.tau[t];
-        ib.obs[j] = true;
-    }
-    if (ka.st.R != nullptr) {
-TGP_UNROLL
-        for (int j = 0; j < B; ++j) {
-            long long t = tb + j;
-            t = t < 0 ? 0 : (t >= T ? T - 1 : t);
-            ib.R[j] = ka.st.R[t];
+// the transition matrix of step t (tau: the gap in front of it)
+template <int D, bool SDE> TGP_HD void step_A(const ModelC<D>& mc, const ModelR<D, SDE>& mr, double tau, bool first, double* A) {
+    if constexpr (SDE) {
+        double e[D];
+        e[0] = ::exp(-mr.lam[0] * tau);
+        TGP_UNROLL for (int i = 1; i < D; ++i) e[i] = (mr.lam[i] == mr.lam[i - 1]) ? e[i - 1] : ::exp(-mr.lam[i] * tau);     // (wave-uniform: one exp per block)
+        const double t2 = tau * tau;
+        TGP_UNROLL for (int j = 0; j < D; ++j)
+            TGP_UNROLL for (int i = 0; i < D; ++i) A[i + j * D] = e[i] * ::fma(t2, mr.N2[i + j * D], ::fma(tau, mr.N1[i + j * D], i == j ? 1.0 : 0.0));
+        if (first) {      // (the series' first step only: one lane of one wave, once)
+            TGP_UNROLL for (int i = 0; i < D * D; ++i) A[i] = mc.A[i];
         }
     } else {
-TGP_UNROLL
-        for (int j = 0; j < B; ++j) ib.R[j] = ka.mc.R;
-    }
-    if (ka.st.hh != nullptr) {
-TGP_UNROLL
-        for (int j = 0; j < B; ++j) {
-            long long t = tb + j;
-            t = t < 0 ? 0 : (t >= T ? T - 1 : t);
-            ib.hh[j] = ka.st.hh[t];
-        }
-    } else {
-TGP_UNROLL
-        for (int j = 0; j < B; ++j) ib.hh[j] = ka.mc.hh;
-    }
-    if (ka.st.mask != nullptr) {
-TGP_UNROLL
-        for (int j = 0; j < B; ++j) {
-            long long t = tb + j;
-            t = t < 0 ? 0 : (t >= T ? T - 1 : t);
-            ib.obs[j] = ka.st.mask[t] == 0;
-        }
+        TGP_UNROLL for (int i = 0; i < D * D; ++i) A[i] = mr.A[i];
     }
 }
 
-// One forward run of a lane: `nblk` blocks from step ts on, of which the steps in [lo, hi) are processed.  x: filtering state in front of
-// step max(ts, lo) on entry, behind step hi - 1 on return.  acc: the log marginal likelihood's sums (want_lml: the logs are taken).
+// predict (lgc.jl:46-52) on the register-resident model.  AP_out (optional, full d x d): A Symmetric(P) of the INCOMING covariance -- what
+// invert_dynamics multiplies again (lgssm.jl:234).
+template <int D, bool SDE> TGP_HD void predict_r(const ModelR<D, SDE>& mr, const double* A, double* m, double* P, double* AP_out = nullptr) {
+    double mp[D];
+    TGP_UNROLL for (int i = 0; i < D; ++i) {
+        double acc = mr.a[i];
+        TGP_UNROLL for (int k = 0; k < D; ++k) acc = ::fma(A[i + k * D], m[k], acc);
+        mp[i] = acc;
+    }
+    TGP_UNROLL for (int i = 0; i < D; ++i) m[i] = mp[i];
+    double AX[D * D], Pn[SD<D>::DS];
+    if constexpr (SDE) {
+        if (AP_out) {      // A P and A Pinf separately: the smoother needs A P itself
+            double AG[D * D];
+            mul_A_sym<D>(A, P, AP_out);
+            mul_A_sym<D>(A, mr.Qg, AG);
+            TGP_UNROLL for (int i = 0; i < D * D; ++i) AX[i] = AP_out[i] - AG[i];
+        } else {
+            double Dm[SD<D>::DS];
+            TGP_UNROLL for (int i = 0; i < SD<D>::DS; ++i) Dm[i] = P[i] - mr.Qg[i];
+            mul_A_sym<D>(A, Dm, AX);
+        }
+    } else {
+        mul_A_sym<D>(A, P, AX);
+        if (AP_out) { TGP_UNROLL for (int i = 0; i < D * D; ++i) AP_out[i] = AX[i]; }
+    }
+    mul_AXAt_plus<D>(AX, A, mr.Qg, Pn);
+    TGP_UNROLL for (int i = 0; i < SD<D>::DS; ++i) P[i] = Pn[i];
+}
+
+// One step of the reverse-time recursion on the register-resident model (see smooth_step above: the same arithmetic)
+template <int D, bool SDE> TGP_HD void smooth_step_r(const ModelR<D, SDE>& mr, const double* A, const State<D>& xf, State<D>& xs, bool& ok) {
+    constexpr int DS = SD<D>::DS;
+    double mp[D], Pp[DS], AP[D * D];
+    TGP_UNROLL for (int i = 0; i < D; ++i) mp[i] = xf.m[i];
+    TGP_UNROLL for (int i = 0; i < DS; ++i) Pp[i] = xf.P[i];
+    predict_r<D, SDE>(mr, A, mp, Pp, AP);
+    double U[D * D], inv[D];
+    TGP_UNROLL for (int j = 0; j < D; ++j) {
+        TGP_UNROLL for (int i = 0; i < j; ++i) {
+            double acc = Pp[pidx(i, j)];
+            TGP_UNROLL for (int k = 0; k < i; ++k) acc = ::fma(-U[k + i * D], U[k + j * D], acc);
+            U[i + j * D] = acc * inv[i];
+        }
+        double acc = Pp[pidx(j, j)] + kJitter;
+        TGP_UNROLL for (int k = 0; k < j; ++k) acc = ::fma(-U[k + j * D], U[k + j * D], acc);
+        ok = ok && (acc > 0.0);
+        double s, rs;
+        fast_sqrt_rsqrt(acc, s, rs);
+        U[j + j * D] = s;
+        inv[j] = rs;
+    }
+    double W[D * D];
+    TGP_UNROLL for (int j = 0; j < D; ++j) {
+        TGP_UNROLL for (int i = 0; i < D; ++i) {
+            double acc = AP[i + j * D];
+            TGP_UNROLL for (int k = 0; k < i; ++k) acc = ::fma(-U[k + i * D], W[k + j * D], acc);
+            W[i + j * D] = acc * inv[i];
+        }
+        TGP_UNROLL for (int i = D - 1; i >= 0; --i) {
+            double acc = W[i + j * D];
+            TGP_UNROLL for (int k = i + 1; k < D; ++k) acc = ::fma(-U[i + k * D], W[k + j * D], acc);
+            W[i + j * D] = acc * inv[i];
+        }
+    }
+    double dm[D], Dm[DS];
+    TGP_UNROLL for (int i = 0; i < D; ++i) dm[i] = xs.m[i] - mp[i];
+    TGP_UNROLL for (int j = 0; j < D; ++j)
+        TGP_UNROLL for (int i = 0; i <= j; ++i) Dm[pidx(i, j)] = xs.P[pidx(i, j)] - Pp[pidx(i, j)] - (i == j ? kJitter : 0.0);
+    TGP_UNROLL for (int i = 0; i < D; ++i) {
+        double acc = xf.m[i];
+        TGP_UNROLL for (int k = 0; k < D; ++k) acc = ::fma(W[k + i * D], dm[k], acc);
+        xs.m[i] = acc;
+    }
+    double GD[D * D];
+    TGP_UNROLL for (int j = 0; j < D; ++j)
+        TGP_UNROLL for (int i = 0; i < D; ++i) {
+            double acc = 0.0;
+            TGP_UNROLL for (int k = 0; k < D; ++k) acc = ::fma(W[k + i * D], Dm[pidx(k, j)], acc);
+            GD[i + j * D] = acc;
+        }
+    TGP_UNROLL for (int j = 0; j < D; ++j)
+        TGP_UNROLL for (int i = 0; i <= j; ++i) {
+            double acc = xf.P[pidx(i, j)];
+            TGP_UNROLL for (int k = 0; k < D; ++k) acc = ::fma(GD[i + k * D], W[k + j * D], acc);
+            xs.P[pidx(i, j)] = acc;
+        }
+}
+
+// Inputs of the B steps of a block.  XS bit 0: the noise variance is per step, bit 1: the emission offset is.  A lane's B steps are B
+// consecutive values of each stream: the loads of a block are issued together (one cache line per lane and stream: the first load brings
+// it, the others hit -- one load per step, spread over the block, was measured 25 % slower: the line is gone from the 32 KB L1 by then),
+// a whole block ahead of their use (cur / nxt).
+template <int D, bool SDE, int XS, int B> struct Inputs {
+    double y[B];
+    double R[(XS & 1) ? B : 1];
+    double hh[(XS & 2) ? B : 1];
+    double tau[SDE ? B : 1];
+    unsigned mk[B];      // the steps' mask bytes as loaded (compared where a step uses them: a comparison at the load would wait for it)
+    TGP_HD bool obs(int j, long long t, long long T) const { return t < T && mk[j] == 0u; }      // (steps behind the series are missing: the runs pad their last block)
+};
+TGP_HD long long clamp_t(long long t, long long T) { return t < 0 ? 0 : (t >= T ? T - 1 : t); }
+
+template <int D, bool SDE, int XS, int B> TGP_HD void load_inputs(const KArgs<D>& ka, long long tb, Inputs<D, SDE, XS, B>& in) {
+    long long tc[B];
+    TGP_UNROLL for (int j = 0; j < B; ++j) tc[j] = clamp_t(tb + j, ka.T);
+    TGP_UNROLL for (int j = 0; j < B; ++j) in.y[j] = ka.st.y[tc[j]];
+    if constexpr (SDE) { TGP_UNROLL for (int j = 0; j < B; ++j) in.tau[j] = ka.st.tau[tc[j]]; }
+    if constexpr ((XS & 1) != 0) { TGP_UNROLL for (int j = 0; j < B; ++j) in.R[j] = ka.st.R[tc[j]]; }
+    if constexpr ((XS & 2) != 0) { TGP_UNROLL for (int j = 0; j < B; ++j) in.hh[j] = ka.st.hh[tc[j]]; }
+    TGP_UNROLL for (int j = 0; j < B; ++j) in.mk[j] = 0u;
+    if (ka.st.mask != nullptr) { TGP_UNROLL for (int j = 0; j < B; ++j) in.mk[j] = ka.st.mask[tc[j]]; }
+}
+
+// One forward run of a lane: `nblk` blocks of B steps from step ts on (ts a multiple of 8, possibly negative); the blocks that start in
+// [lo, hi) are processed, whole (lo, hi multiples of 8; steps behind the series' end are missing).  x: filtering state in front of step
+// max(ts, lo) on entry, behind the last processed step on return.  acc: the log marginal likelihood's sums (want_lml: the logs are taken).
 // ckpt (null: none): the state in front of every block is kept, [block][component][lane].
-template <int D, bool SDE, int B>
-TGP_HD void forward_run(const KArgs<D>& ka, long long ts, int nblk, long long lo, long long hi, State<D>& x, LmlAcc& acc,
-                                            bool want_lml, double* ckpt, int lane, bool& ok) {
+template <int D, bool SDE, int XS, int B>
+TGP_HD void forward_run(const KArgs<D>& ka, const ModelR<D, SDE>& mr, long long ts, int nblk, long long lo, long long hi, State<D>& x, LmlAcc& acc,
+                        bool want_lml, double* ckpt, int lane, bool& ok) {
     constexpr int NS = SD<D>::NS;
-    InBlk<D, B> cur, nxt;
-    load_blk<D, SDE, B>(ka, ts, cur);
+    Inputs<D, SDE, XS, B> in, nx;
+    load_inputs<D, SDE, XS, B>(ka, ts, in);
     for (int b = 0; b < nblk; ++b) {
         const long long tb = ts + (long long)b * B;
-        if (b + 1 < nblk) load_blk<D, SDE, B>(ka, tb + B, nxt);      // in flight while this block computes
+        load_inputs<D, SDE, XS, B>(ka, tb + B, nx);      // in flight while this block computes (behind the last block: clamped, unused)
         TGP_ISSUE_BARRIER();
         if (ckpt != nullptr) {
             double* q = ckpt + (size_t)b * NS * 64 + lane;
-TGP_UNROLL
-            for (int k = 0; k < D; ++k) q[(size_t)k * 64] = x.m[k];
-TGP_UNROLL
-            for (int k = 0; k < SD<D>::DS; ++k) q[(size_t)(D + k) * 64] = x.P[k];
+            TGP_UNROLL for (int k = 0; k < D; ++k) q[(size_t)k * 64] = x.m[k];
+            TGP_UNROLL for (int k = 0; k < SD<D>::DS; ++k) q[(size_t)(D + k) * 64] = x.P[k];
         }
-TGP_UNROLL
-        for (int j = 0; j < B; ++j) {
-            const long long t = tb + j;
-            if (t >= lo && t < hi) {
-                Trans<D, SDE> tr;
-                tr.set(ka.mc, cur.tau[j], t == 0);
-                predict<D, SDE>(ka.mc, tr.A, x.m, x.P);
-                update<D>(ka.mc.H, cur.hh[j], cur.R[j], cur.y[j], cur.obs[j], x.m, x.P, &acc, ok);
+        if (tb >= lo && tb < hi) {
+            TGP_UNROLL for (int j = 0; j < B; ++j) {
+                double A[D * D];
+                step_A<D, SDE>(ka.mc, mr, SDE ? in.tau[j] : 0.0, SDE && tb + j == 0, A);
+                predict_r<D, SDE>(mr, A, x.m, x.P);
+                update<D>(mr.H, (XS & 2) ? in.hh[j] : mr.hh, (XS & 1) ? in.R[j] : mr.R, in.y[j], in.obs(j, tb + j, ka.T), x.m, x.P, &acc, ok);
             }
         }
         if (want_lml) acc.flush();      // (wave-uniform)
         else acc.prod = 1.0;
-        if (b + 1 < nblk) cur = nxt;
+        in = nx;
     }
 }
 
-// One backward run of a lane over the blocks nblk - 1 .. 0 of its chunk [t0, t1): the steps in [t0, hi) are smoothed.  fresh: the run starts
-// at step hi - 1 from that step's filtering state (the end of the series, or a warm-up); otherwise xs holds the smoothing state of step hi
-// (the next lane's first step).  On return xs is the smoothing state of step t0.  emit_out: write mean / var of the steps.
-template <int D, bool SDE, int B>
-TGP_HD void backward_run(const KArgs<D>& ka, long long t0, long long t1, int nblk, long long hi, bool fresh, State<D>& xs,
-                                             bool emit_out, const double* ckpt, double* sF, int lane, bool& ok) {
+// One backward run of a lane over the blocks nblk - 1 .. 0 of its chunk (first step t0, a multiple of 8): the steps below hi are smoothed.
+// fresh: the run starts at step hi - 1 from that step's filtering state (the end of the series, or a warm-up); otherwise xs holds the smoothing
+// state of step hi (the next lane's first step).  On return xs is the smoothing state of step t0.  emit_out: write mean / var of the steps.
+// The filtering states of a block are recomputed from its checkpoint into LDS (sF: [step][component][lane]) -- with the steps behind the
+// series' end as missing ones, exactly as the forward run took them.
+template <int D, bool SDE, int XS, int B>
+TGP_HD void backward_run(const KArgs<D>& ka, const ModelR<D, SDE>& mr, long long t0, int nblk, long long hi, bool fresh, State<D>& xs, bool emit_out,
+                         const double* ckpt, double* sF, int lane, bool& ok) {
     constexpr int NS = SD<D>::NS, DS = SD<D>::DS;
     const long long T = ka.T;
+    Inputs<D, SDE, XS, B> in, nx;
     double tau_next = 0.0;      // gap in front of the step behind the block in hand
-    if (SDE) {
-        const long long tn = t0 + (long long)nblk * B;
-        tau_next = ka.st.tau[tn < T ? tn : T - 1];
+    const long long tlast = t0 + (long long)(nblk - 1) * B;
+    if (SDE) tau_next = ka.st.tau[clamp_t(tlast + B, T)];
+    load_inputs<D, SDE, XS, B>(ka, tlast, in);
+    State<D> ck, ckN;
+    {
+        const double* q = ckpt + (size_t)(nblk - 1) * NS * 64 + lane;
+        TGP_UNROLL for (int k = 0; k < D; ++k) ck.m[k] = q[(size_t)k * 64];
+        TGP_UNROLL for (int k = 0; k < DS; ++k) ck.P[k] = q[(size_t)(D + k) * 64];
     }
-    InBlk<D, B> cur, nxt;
-    double rn[B], rn_nxt[B];
-    load_blk<D, SDE, B>(ka, t0 + (long long)(nblk - 1) * B, cur);
-    auto load_rn = [&](long long tb, double* dst) __attribute__((always_inline)) {
-        if (ka.st.rnew_per_step) {
-TGP_UNROLL
-            for (int j = 0; j < B; ++j) {
-                long long t = tb + j;
-                t = t >= T ? T - 1 : t;
-                dst[j] = ka.st.Rnew[t];
-            }
-        } else {
-            const double r = ka.st.Rnew[0];
-TGP_UNROLL
-            for (int j = 0; j < B; ++j) dst[j] = r;
-        }
-    };
-    if (emit_out) load_rn(t0 + (long long)(nblk - 1) * B, rn);
     for (int b = nblk - 1; b >= 0; --b) {
         const long long tb = t0 + (long long)b * B;
-        if (b > 0) {
-            load_blk<D, SDE, B>(ka, tb - B, nxt);
-            if (emit_out) load_rn(tb - B, rn_nxt);
-        }
-        // the filtering states of the block, recomputed from its checkpoint into LDS ([step][component][lane])
-        State<D> x;
+        load_inputs<D, SDE, XS, B>(ka, tb - B, nx);      // the next block (block b - 1): in flight through this one
         {
-            const double* q = ckpt + (size_t)b * NS * 64 + lane;
-TGP_UNROLL
-            for (int k = 0; k < D; ++k) x.m[k] = q[(size_t)k * 64];
-TGP_UNROLL
-            for (int k = 0; k < DS; ++k) x.P[k] = q[(size_t)(D + k) * 64];
+            const double* q = ckpt + (size_t)(b > 0 ? b - 1 : 0) * NS * 64 + lane;
+            TGP_UNROLL for (int k = 0; k < D; ++k) ckN.m[k] = q[(size_t)k * 64];
+            TGP_UNROLL for (int k = 0; k < DS; ++k) ckN.P[k] = q[(size_t)(D + k) * 64];
         }
         TGP_ISSUE_BARRIER();
-TGP_UNROLL
-        for (int j = 0; j < B; ++j) {
-            const long long t = tb + j;
-            if (t < t1) {
-                Trans<D, SDE> tr;
-                tr.set(ka.mc, cur.tau[j], t == 0);
-                predict<D, SDE>(ka.mc, tr.A, x.m, x.P);
-                update<D>(ka.mc.H, cur.hh[j], cur.R[j], cur.y[j], cur.obs[j], x.m, x.P, (LmlAcc*)nullptr, ok);
-            }
-TGP_UNROLL
-            for (int k = 0; k < D; ++k) sF[(j * NS + k) * 64 + lane] = x.m[k];
-TGP_UNROLL
-            for (int k = 0; k < DS; ++k) sF[(j * NS + D + k) * 64 + lane] = x.P[k];
+        // ---- the block's filtering states, forwards from its checkpoint
+        State<D> x = ck;
+        TGP_UNROLL for (int j = 0; j < B; ++j) {
+            double A[D * D];
+            step_A<D, SDE>(ka.mc, mr, SDE ? in.tau[j] : 0.0, SDE && tb + j == 0, A);
+            predict_r<D, SDE>(mr, A, x.m, x.P);
+            update<D>(mr.H, (XS & 2) ? in.hh[j] : mr.hh, (XS & 1) ? in.R[j] : mr.R, in.y[j], in.obs(j, tb + j, T), x.m, x.P, (LmlAcc*)nullptr, ok);
+            TGP_UNROLL for (int k = 0; k < D; ++k) sF[(j * NS + k) * 64 + lane] = x.m[k];
+            TGP_UNROLL for (int k = 0; k < DS; ++k) sF[(j * NS + D + k) * 64 + lane] = x.P[k];
         }
+        // ---- backwards through the block (the barrier: the states are to be READ BACK from LDS -- without it the optimiser forwards the eight
+        // states of the first half to the second through registers, which is the register pressure the LDS buffer is there to remove)
+        TGP_ISSUE_BARRIER();
         double om[B], ov[B];
-TGP_UNROLL
-        for (int j = B - 1; j >= 0; --j) {
+        TGP_UNROLL for (int j = B - 1; j >= 0; --j) {
             const long long t = tb + j;
             om[j] = 0.0;
             ov[j] = 0.0;
             if (t < hi) {
+                double rn = 0.0;
+                if (emit_out) rn = ka.st.Rnew[ka.st.rnew_per_step ? t : 0];      // (asked for here, used at the end of the step)
                 State<D> xf;
-TGP_UNROLL
-                for (int k = 0; k < D; ++k) xf.m[k] = sF[(j * NS + k) * 64 + lane];
-TGP_UNROLL
-                for (int k = 0; k < DS; ++k) xf.P[k] = sF[(j * NS + D + k) * 64 + lane];
+                TGP_UNROLL for (int k = 0; k < D; ++k) xf.m[k] = sF[(j * NS + k) * 64 + lane];
+                TGP_UNROLL for (int k = 0; k < DS; ++k) xf.P[k] = sF[(j * NS + D + k) * 64 + lane];
                 if (fresh && t == hi - 1) {
                     xs = xf;
                 } else {
-                    Trans<D, SDE> tr;
-                    tr.set(ka.mc, j == B - 1 ? tau_next : cur.tau[j + 1 < B ? j + 1 : j], false);
-                    smooth_step<D, SDE>(ka.mc, tr.A, xf, xs, ok);
+                    double A[D * D];
+                    step_A<D, SDE>(ka.mc, mr, SDE ? (j == B - 1 ? tau_next : in.tau[j + 1 < B ? j + 1 : j]) : 0.0, false, A);
+                    smooth_step_r<D, SDE>(mr, A, xf, xs, ok);
                 }
-                if (emit_out) emit<D>(ka.mc.H, cur.hh[j], rn[j], xs, om[j], ov[j]);
+                if (emit_out) emit<D>(mr.H, (XS & 2) ? in.hh[j] : mr.hh, rn, xs, om[j], ov[j]);
             }
         }
-        if (emit_out) {
-TGP_UNROLL
-            for (int j = 0; j < B; ++j) {
-                const long long t = tb + j;
-                if (t < hi) {
-                    ka.mean[t] = om[j];
-                    ka.var[t] = ov[j];
+        if (emit_out) {      // a lane's B outputs are B consecutive values of each array: stored together (one line: the L2 merges the pieces)
+            TGP_UNROLL for (int j = 0; j < B; ++j) {
+                if (tb + j < hi) {
+                    ka.mean[tb + j] = om[j];
+                    ka.var[tb + j] = ov[j];
                 }
             }
         }
-        if (SDE) tau_next = cur.tau[0];
-        if (b > 0) cur = nxt;
-        if (emit_out && b > 0) {
-TGP_UNROLL
-            for (int j = 0; j < B; ++j) rn[j] = rn_nxt[j];
-        }
+        if (SDE) tau_next = in.tau[0];
+        in = nx;
+        ck = ckN;
     }
 }
 

@@ -21,7 +21,7 @@ template <int D> bool finite_state(const State<D>& x) {
     return s < 1e300;
 }
 
-template <int D, bool SDE> void run_d(const Plan& p, const Streams& st, bool post, double* mean, double* var, double* out) {
+template <int D, bool SDE, int XS> void run_d(const Plan& p, const Streams& st, bool post, double* mean, double* var, double* out) {
     constexpr int B = Geo<D>::B, NS = SD<D>::NS;
     KArgs<D> ka;
     std::memcpy(&ka.mc, p.mc, sizeof ka.mc);
@@ -38,11 +38,13 @@ template <int D, bool SDE> void run_d(const Plan& p, const Streams& st, bool pos
     std::vector<double> ckpt((size_t)(C / B) * NS * 64), sF((size_t)B * NS * 64);
     double lml_total = 0.0, dfw = 0.0, dbw = 0.0;
     unsigned bits_total = 0;
+    ModelR<D, SDE> mr;
+    mr.init(ka.mc);
     State<D> gen, x0;
     set_state<D>(gen, ka.mc.gm, ka.mc.gP);
     set_state<D>(x0, ka.mc.x0m, ka.mc.x0P);
     for (long long wave = 0; wave < p.nwaves; ++wave) {
-        long long t0[64], t1[64];
+        long long t0[64], t1[64], t1r[64];
         bool runs[64], owned[64], ok[64];
         State<D> e1[64], x[64], b1[64], xs[64];
         LmlAcc acc[64];
@@ -52,16 +54,17 @@ template <int D, bool SDE> void run_d(const Plan& p, const Streams& st, bool pos
             t0[lane] = active ? c * C : 0;
             long long e = active ? t0[lane] + C : 0;
             t1[lane] = e < T ? e : (active ? T : 0);
+            t1r[lane] = (t1[lane] + 7) & ~7ll;
             runs[lane] = active && lane >= 1;
             owned[lane] = runs[lane] && lane <= kOwned;
             ok[lane] = true;
         }
         // forwards, pass 0
         for (int lane = 0; lane < 64; ++lane) {
-            const long long tw = t1[lane] - ka.W;
+            const long long tw = t1r[lane] - ka.W;
             State<D> s = tw <= 0 ? x0 : gen;
             LmlAcc dummy;
-            forward_run<D, SDE, B>(ka, tw, ka.W / B, tw > 0 ? tw : 0, t1[lane], s, dummy, false, (double*)nullptr, lane, ok[lane]);
+            forward_run<D, SDE, XS, B>(ka, mr, tw, ka.W / B, tw > 0 ? tw : 0, t1r[lane], s, dummy, false, (double*)nullptr, lane, ok[lane]);
             e1[lane] = s;
         }
         // the shift, pass 1
@@ -69,8 +72,8 @@ template <int D, bool SDE> void run_d(const Plan& p, const Streams& st, bool pos
             x[lane] = lane > 0 ? e1[lane - 1] : e1[0];
             if (t0[lane] == 0) x[lane] = x0;
             acc[lane] = LmlAcc();
-            forward_run<D, SDE, B>(ka, t0[lane], C / B, t0[lane], runs[lane] ? t1[lane] : t0[lane], x[lane], acc[lane], true, post ? ckpt.data() : (double*)nullptr,
-                                   lane, ok[lane]);
+            forward_run<D, SDE, XS, B>(ka, mr, t0[lane], C / B, t0[lane], runs[lane] ? t1r[lane] : t0[lane], x[lane], acc[lane], true,
+                                       post ? ckpt.data() : (double*)nullptr, lane, ok[lane]);
         }
         double df[64] = {}, db[64] = {};
         bool fin[64];
@@ -85,13 +88,13 @@ template <int D, bool SDE> void run_d(const Plan& p, const Streams& st, bool pos
             for (int lane = 0; lane < 64; ++lane) {
                 const long long te = (t0[lane] + ka.Wb < t1[lane]) ? t0[lane] + ka.Wb : t1[lane];
                 State<D> s = gen;
-                backward_run<D, SDE, B>(ka, t0[lane], t1[lane], ka.Wb / B, runs[lane] ? te : t0[lane], true, s, false, ckpt.data(), sF.data(), lane, ok[lane]);
+                backward_run<D, SDE, XS, B>(ka, mr, t0[lane], ka.Wb / B, runs[lane] ? te : t0[lane], true, s, false, ckpt.data(), sF.data(), lane, ok[lane]);
                 b1[lane] = s;
             }
             for (int lane = 0; lane < 64; ++lane) {
                 xs[lane] = lane < 63 ? b1[lane + 1] : b1[63];
-                backward_run<D, SDE, B>(ka, t0[lane], t1[lane], C / B, owned[lane] ? t1[lane] : t0[lane], t1[lane] == T, xs[lane], true, ckpt.data(), sF.data(), lane,
-                                        ok[lane]);
+                backward_run<D, SDE, XS, B>(ka, mr, t0[lane], C / B, owned[lane] ? t1[lane] : t0[lane], t1[lane] == T, xs[lane], true, ckpt.data(), sF.data(),
+                                            lane, ok[lane]);
                 if (owned[lane]) {
                     db[lane] = state_distance<D>(ka.mc, xs[lane], b1[lane]);
                     fin[lane] = fin[lane] && finite_state<D>(xs[lane]) && finite_state<D>(b1[lane]);
@@ -120,9 +123,17 @@ template <int D, bool SDE> void run_d(const Plan& p, const Streams& st, bool pos
     out[3] = dbw;
 }
 
+template <int D, bool SDE> void run_x(const Plan& p, const Streams& st, bool post, double* mean, double* var, double* out) {
+    switch ((st.R != nullptr ? 1 : 0) | (st.hh != nullptr ? 2 : 0)) {
+        case 0: run_d<D, SDE, 0>(p, st, post, mean, var, out); break;
+        case 1: run_d<D, SDE, 1>(p, st, post, mean, var, out); break;
+        case 2: run_d<D, SDE, 2>(p, st, post, mean, var, out); break;
+        default: run_d<D, SDE, 3>(p, st, post, mean, var, out); break;
+    }
+}
 template <int D> void run_s(const Plan& p, const Streams& st, bool post, double* mean, double* var, double* out) {
-    if (p.sde) run_d<D, true>(p, st, post, mean, var, out);
-    else run_d<D, false>(p, st, post, mean, var, out);
+    if (p.sde) run_x<D, true>(p, st, post, mean, var, out);
+    else run_x<D, false>(p, st, post, mean, var, out);
 }
 
 }  // namespace
