@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -29,7 +30,8 @@ __global__ __launch_bounds__(64, 1) void k_sweep(const KArgs<D> by_value) {
     (void)by_value;
     const KArgs<D>& ka = *(const KArgs<D>*)__builtin_amdgcn_kernarg_segment_ptr();      // (read in place, scalar loads: tgp_modal.hip k_steady_one)
     constexpr int B = Geo<D>::B, NS = SD<D>::NS, DS = SD<D>::DS;
-    __shared__ double sF[POST ? B * NS * 64 : 64];
+    constexpr int kStates = B * NS * 64, kTiles = 2 * 64 * (B + 1);      // the block's filtering states; later in a block, its two output tiles
+    __shared__ double sF[POST ? (kStates > kTiles ? kStates : kTiles) : 64];
     const int lane = threadIdx.x;
     const long long wave = blockIdx.x;
     const long long T = ka.T;
@@ -110,7 +112,7 @@ __global__ __launch_bounds__(64, 1) void k_sweep(const KArgs<D> by_value) {
     finite = finite && (::fabs(lml) < 1e300);
     unsigned bits = 0;
     if (owned && !(dist_f <= ka.mc.tol)) bits |= 1u;
-    if (owned && POST && !(dist_b <= ka.mc.tol)) bits |= 2u;
+    if (owned && POST && !(dist_b <= ka.mc.tol_b)) bits |= 2u;
     if (!ok) bits |= 4u;
     if (!finite) bits |= 8u;
 #pragma unroll

@@ -66,7 +66,7 @@ template <int D> struct ModelC {
     double gm[D], gP[SD<D>::DS];              // where a warm-up starts from: the stationary prior (SDE: Pinf)
     double lam[D], N1[D * D], N2[D * D];      // SDE: exp(F tau) = e^(-lam tau) (I + tau N1 + tau^2 N2) per block (ModelView::sde)
     double hh, R;                             // shared emission offset / noise variance (used where no per-step stream is given)
-    double tol;                               // relative size of a forgotten start state (the checks of the two directions)
+    double tol, tol_b;                        // relative size of a forgotten start state: the checks of the forward / backward hand-overs
 };
 
 template <int D> struct State {
@@ -582,13 +582,68 @@ TGP_HD void backward_run(const KArgs<D>& ka, const ModelR<D, SDE>& mr, long long
                 if (emit_out) emit<D>(mr.H, (XS & 2) ? in.hh[j] : mr.hh, rn, xs, om[j], ov[j]);
             }
         }
-        if (emit_out) {      // a lane's B outputs are B consecutive values of each array: stored together (one line: the L2 merges the pieces)
+        if (emit_out) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            // A lane's B outputs are B consecutive values of each array, 8 C bytes from its neighbour's: stored by their owners they are
+            // 64 pieces of 8 bytes per instruction (measured: the main backward pass took 2.4 x the warm-up pass, which stores nothing).
+            // Through LDS instead (the block's states have been read: their buffer is free): rows of B values, B lanes store one row's
+            // B x 8 consecutive bytes.
+            constexpr int LD = B + 1, RPI = 64 / B;      // row stride in doubles (bank spread), rows per store instruction
+            const unsigned long long emits = __builtin_amdgcn_ballot_w64(hi > t0);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            TGP_UNROLL for (int j = 0; j < B; ++j) {
+                sF[lane * LD + j] = om[j];
+                sF[64 * LD + lane * LD + j] = ov[j];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // first step of lane 0's chunk, from lane 1's (always a chunk of the series; a lane without one has t0 = 0)
+            const long long tw0 = (((long long)__builtin_amdgcn_readlane((int)(t0 >> 32), 1) << 32) | (unsigned)__builtin_amdgcn_readlane((int)t0, 1)) - ka.C;
+            const bool wide = (((unsigned long long)ka.mean | (unsigned long long)ka.var) & 15ull) == 0ull;      // (wave-uniform)
+            if (wide) {      // 16-byte pieces: B / 2 lanes per row, 128 / B rows per instruction
+                constexpr int PPR = B / 2, RPW = 64 / PPR;
+                const int pc = lane % PPR, rw = lane / PPR;
+                TGP_UNROLL for (int k = 0; k < PPR; ++k) {
+                    const int r = rw + RPW * k;
+                    const long long t = tw0 + (long long)r * ka.C + (tb - t0) + 2 * pc;
+                    double2 vm, vv;
+                    vm.x = sF[r * LD + 2 * pc];
+                    vm.y = sF[r * LD + 2 * pc + 1];
+                    vv.x = sF[64 * LD + r * LD + 2 * pc];
+                    vv.y = sF[64 * LD + r * LD + 2 * pc + 1];
+                    if (((emits >> r) & 1ull) != 0ull) {
+                        if (t + 1 < T) {
+                            *reinterpret_cast<double2*>(ka.mean + t) = vm;
+                            *reinterpret_cast<double2*>(ka.var + t) = vv;
+                        } else if (t < T) {
+                            ka.mean[t] = vm.x;
+                            ka.var[t] = vv.x;
+                        }
+                    }
+                }
+            } else {
+                const int e = lane % B, r0 = lane / B;
+                TGP_UNROLL for (int k = 0; k < B; ++k) {
+                    const int r = r0 + RPI * k;
+                    const long long t = tw0 + (long long)r * ka.C + (tb - t0) + e;
+                    const double vm = sF[r * LD + e], vv = sF[64 * LD + r * LD + e];
+                    if (((emits >> r) & 1ull) != 0ull && t < T) {
+                        ka.mean[t] = vm;
+                        ka.var[t] = vv;
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#else
             TGP_UNROLL for (int j = 0; j < B; ++j) {
                 if (tb + j < hi) {
                     ka.mean[tb + j] = om[j];
                     ka.var[tb + j] = ov[j];
                 }
             }
+#endif
         }
         if (SDE) tau_next = in.tau[0];
         in = nx;

@@ -185,7 +185,9 @@ template <int D> inline void host_sde_A(const double* q, double tau, double* A) 
             A[i + j * D] = std::exp(-q[i] * tau) * (tau * tau * q[D + D * D + i + j * D] + tau * q[D + i + j * D] + (i == j ? 1.0 : 0.0));
 }
 
-constexpr double kTol = 1e-12;
+// What a handed-over state may be off by, relative to the size of a state.  Forwards 1e-12: the log marginal likelihood is held to 1e-10 relative
+// and the innovations behind a hand-over inherit its error.  Backwards 1e-11: the marginals are held to 1e-8 of their scale.
+constexpr double kTol = 1e-12, kTolBack = 1e-11;
 constexpr int kMaxWarm = 4096;
 
 template <int D> inline bool plan_d(Plan* e, const Forced& f, const ModelHost& m, int64_t T, int w_hint, int wb_hint, int num_cu, std::string* why) {
@@ -193,6 +195,7 @@ template <int D> inline bool plan_d(Plan* e, const Forced& f, const ModelHost& m
     ModelC<D> mc;
     fill_model<D>(m, mc);
     mc.tol = kTol;
+    mc.tol_b = kTolBack;
     double Aty[D * D], Qty[D * D];      // a typical step's transition (the warm-up estimate)
     if (m.sde) {
         // the warm-up starts from Pinf = x0P; the first transition must be consistent with it (Q1 = Pinf - A1 Pinf A1')
@@ -252,14 +255,18 @@ template <int D> inline bool plan_d(Plan* e, const Forced& f, const ModelHost& m
     }
     int W = w_hint, Wb = wb_hint;
     if (W <= 0 || Wb <= 0) {
-        const int n = forget_steps<D>(Aty, Qty, m.H, m.R > 0.0 && m.R < 1e14 ? m.R : 1.0, kTol, kMaxWarm);
-        if (n == 0) {
+        // (the estimate is for a series observed at every step with the representative noise: missing steps and larger noise slow the forgetting
+        //  -- hence the margin -- and the checks decide: a call that finds its warm-ups short is repeated with longer ones and the bound model
+        //  remembers them.  Measured at the bench model with 10 % missing: 1e-12 forwards needs 100 steps, the estimate says 96 + margin.)
+        const double Rrep = m.R > 0.0 && m.R < 1e14 ? m.R : 1.0;
+        const int nf = forget_steps<D>(Aty, Qty, m.H, Rrep, kTol, kMaxWarm);
+        const int nb = forget_steps<D>(Aty, Qty, m.H, Rrep, kTolBack, kMaxWarm);
+        if (nf == 0 || nb == 0) {
             if (why) *why = "the filter does not forget a state within 4096 steps";
             return false;
         }
-        const int est = n + n / 4 + 16;      // (margin: missing steps and larger noise slow the forgetting; the checks decide)
-        if (W <= 0) W = est;
-        if (Wb <= 0) Wb = est;
+        if (W <= 0) W = nf + nf / 8 + 8;
+        if (Wb <= 0) Wb = nb + nb / 8 + 8;
     }
     auto up = [](int v, int q) { return (v + q - 1) / q * q; };
     W = up(W, 8);

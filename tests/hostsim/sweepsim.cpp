@@ -108,7 +108,7 @@ template <int D, bool SDE, int XS> void run_d(const Plan& p, const Streams& st, 
             lml += l;
             if (!(std::fabs(l) < 1e300)) fin[lane] = false;
             if (owned[lane] && !(df[lane] <= ka.mc.tol)) bits |= 1u;
-            if (owned[lane] && post && !(db[lane] <= ka.mc.tol)) bits |= 2u;
+            if (owned[lane] && post && !(db[lane] <= ka.mc.tol_b)) bits |= 2u;
             if (!ok[lane]) bits |= 4u;
             if (!fin[lane]) bits |= 8u;
             dfw = std::max(dfw, df[lane]);
