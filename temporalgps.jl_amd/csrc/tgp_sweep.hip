@@ -57,22 +57,34 @@ __global__ __launch_bounds__(64, 1) void k_sweep(const KArgs<D> by_value) {
     // end state is the NEXT lane's start state.  Pass 1: the chunk from the previous lane's end state (checkpoints, log marginal likelihood).
     State<D> x, e1;
     LmlAcc acc;
+    // (POST) the smoothing state of the chunk's first step as its first Wb steps give it -- what the PREVIOUS lane continues from -- is composed
+    // during the forward run (RevAcc): from the filtering state behind those steps (the smoothing state where they reach the series' last step)
+    const long long te = (t0 + ka.Wb < t1) ? t0 + ka.Wb : t1;
+    RevAcc<D> rev;
+    rev.reset();
+    State<D> b1 = gen;
     {
         const long long tw = t1r - ka.W;
         x = tw <= 0 ? x0 : gen;
-        for (int pass = 0; pass < 2; ++pass) {
-            const long long ts = pass == 0 ? tw : t0;
-            const long long lo = pass == 0 ? (tw > 0 ? tw : 0) : t0;
-            const long long hi = pass == 0 ? t1r : (runs ? t1r : t0);
-            acc = LmlAcc();
-            forward_run<D, SDE, XS, B>(ka, mr, ts, (pass == 0 ? ka.W : C) / B, lo, hi, x, acc, pass == 1, pass == 1 ? ck : (double*)nullptr, lane, ok);
-            if (pass == 0) {
-                e1 = x;
+        // segment 0: the warm-up; 1: (POST) the chunk's first Wb steps, with the reverse-time composition; 2: the rest of the chunk
+        const int nwin = POST ? ka.Wb / B : 0;
+        for (int seg = 0; seg < 3; ++seg) {
+            if (seg == 1) {
+                if constexpr (POST) forward_run<D, SDE, XS, B, true>(ka, mr, t0, nwin, t0, runs ? t1r : t0, x, acc, true, ck, lane, ok, &rev, t0, te, &b1);
+            } else {      // (ONE call site for both plain runs: the loop body exists once)
+                const bool warm = seg == 0;
+                const long long ts = warm ? tw : t0 + (long long)nwin * B;
+                forward_run<D, SDE, XS, B>(ka, mr, ts, warm ? ka.W / B : C / B - nwin, warm ? (tw > 0 ? tw : 0) : t0, warm ? t1r : (runs ? t1r : t0), x, acc, !warm,
+                                           (POST && !warm) ? ck + (size_t)nwin * NS * 64 : (double*)nullptr, lane, ok);
+                if (warm) {
+                    e1 = x;
 #pragma unroll
-                for (int k = 0; k < D; ++k) x.m[k] = shfl_up1(e1.m[k]);
+                    for (int k = 0; k < D; ++k) x.m[k] = shfl_up1(e1.m[k]);
 #pragma unroll
-                for (int k = 0; k < DS; ++k) x.P[k] = shfl_up1(e1.P[k]);
-                if (t0 == 0) x = x0;
+                    for (int k = 0; k < DS; ++k) x.P[k] = shfl_up1(e1.P[k]);
+                    if (t0 == 0) x = x0;
+                    acc = LmlAcc();
+                }
             }
         }
     }
@@ -84,23 +96,13 @@ __global__ __launch_bounds__(64, 1) void k_sweep(const KArgs<D> by_value) {
     }
 
     if (POST) {
-        // ---- backwards.  Pass 0: the first Wb steps of the chunk from the filtering state behind them (the smoothing state where they reach
-        // the series' last step); its end state, the smoothing state of the chunk's first step, is what the PREVIOUS lane continues from.
-        // Pass 1: the chunk, mean and variance of every step.
-        const long long te = (t0 + ka.Wb < t1) ? t0 + ka.Wb : t1;
-        State<D> xs = gen, b1 = gen;
-        for (int pass = 0; pass < 2; ++pass) {
-            const long long hi = pass == 0 ? (runs ? te : t0) : (owned ? t1 : t0);
-            const bool fresh = pass == 0 ? true : (t1 == T);
-            backward_run<D, SDE, XS, B>(ka, mr, t0, (pass == 0 ? ka.Wb : C) / B, hi, fresh, xs, pass == 1, ck, sF, lane, ok);
-            if (pass == 0) {
-                b1 = xs;
+        // ---- backwards: the chunk from the next lane's smoothing state of ITS first step; mean and variance of every step.
+        State<D> xs;
 #pragma unroll
-                for (int k = 0; k < D; ++k) xs.m[k] = shfl_dn1(b1.m[k]);
+        for (int k = 0; k < D; ++k) xs.m[k] = shfl_dn1(b1.m[k]);
 #pragma unroll
-                for (int k = 0; k < DS; ++k) xs.P[k] = shfl_dn1(b1.P[k]);
-            }
-        }
+        for (int k = 0; k < DS; ++k) xs.P[k] = shfl_dn1(b1.P[k]);
+        backward_run<D, SDE, XS, B>(ka, mr, t0, C / B, owned ? t1 : t0, t1 == T, xs, true, ck, sF, lane, ok);
         if (owned) {
             dist_b = state_distance<D>(ka.mc, xs, b1);
             finite = finite && state_finite<D>(xs) && state_finite<D>(b1);

@@ -460,6 +460,93 @@ template <int D, bool SDE> TGP_HD void smooth_step_r(const ModelR<D, SDE>& mr, c
         }
 }
 
+// The reverse-time recursion over a window of steps [t0, te), composed FORWARDS (round 5, later): xs_(t0) = E xs_(te-1) + g,
+// Ps_(t0) = E Ps_(te-1) E' + L.  The forward run has, at step t, everything step t - 1's reverse-time element needs (the filtering state in
+// front of the predict, A P, the predicted state: invert_dynamics lgssm.jl:231-238), so the smoothing state a chunk hands to the lane before
+// it -- the backward warm-up's result -- comes out of the forward run of the chunk's first Wb steps at ~190 instructions per step, instead
+// of a backward pass of its own over them (recompute + reverse step: ~330).
+template <int D> struct RevAcc {
+    double E[D * D], g[D], L[SD<D>::DS];
+    TGP_HD void reset() {
+        TGP_UNROLL for (int j = 0; j < D; ++j) TGP_UNROLL for (int i = 0; i < D; ++i) E[i + j * D] = i == j ? 1.0 : 0.0;
+        TGP_UNROLL for (int i = 0; i < D; ++i) g[i] = 0.0;
+        TGP_UNROLL for (int i = 0; i < SD<D>::DS; ++i) L[i] = 0.0;
+    }
+    // xs_(t0) from the window's last filtering state
+    TGP_HD void finish(const State<D>& xl, State<D>& out) const {
+        TGP_UNROLL for (int i = 0; i < D; ++i) {
+            double acc = g[i];
+            TGP_UNROLL for (int k = 0; k < D; ++k) acc = ::fma(E[i + k * D], xl.m[k], acc);
+            out.m[i] = acc;
+        }
+        double EP[D * D];
+        mul_A_sym<D>(E, xl.P, EP);
+        mul_AXAt_plus<D>(EP, E, L, out.P);
+    }
+};
+// xf: filtering state of step t - 1; (mp, Pp): predicted state of step t; AP = A Symmetric(xf.P).  Appends step t - 1's element.
+template <int D> TGP_HD void rev_append(const State<D>& xf, const double* mp, const double* Pp, const double* AP, RevAcc<D>& ra, bool& ok) {
+    constexpr int DS = SD<D>::DS;
+    double U[D * D], inv[D];
+    TGP_UNROLL for (int j = 0; j < D; ++j) {
+        TGP_UNROLL for (int i = 0; i < j; ++i) {
+            double acc = Pp[pidx(i, j)];
+            TGP_UNROLL for (int k = 0; k < i; ++k) acc = ::fma(-U[k + i * D], U[k + j * D], acc);
+            U[i + j * D] = acc * inv[i];
+        }
+        double acc = Pp[pidx(j, j)] + kJitter;
+        TGP_UNROLL for (int k = 0; k < j; ++k) acc = ::fma(-U[k + j * D], U[k + j * D], acc);
+        ok = ok && (acc > 0.0);
+        double sq, rs;
+        fast_sqrt_rsqrt(acc, sq, rs);
+        U[j + j * D] = sq;
+        inv[j] = rs;
+    }
+    double W[D * D], Z[D * D];      // Z = U^-T (A Pf) = U G';  W = U^-1 Z = G'
+    TGP_UNROLL for (int j = 0; j < D; ++j) {
+        TGP_UNROLL for (int i = 0; i < D; ++i) {
+            double acc = AP[i + j * D];
+            TGP_UNROLL for (int k = 0; k < i; ++k) acc = ::fma(-U[k + i * D], Z[k + j * D], acc);
+            Z[i + j * D] = acc * inv[i];
+        }
+        TGP_UNROLL for (int i = D - 1; i >= 0; --i) {
+            double acc = Z[i + j * D];
+            TGP_UNROLL for (int k = i + 1; k < D; ++k) acc = ::fma(-U[i + k * D], W[k + j * D], acc);
+            W[i + j * D] = acc * inv[i];
+        }
+    }
+    // g_t = mf - G mp;  L_t = Pf - (U G')'(U G')   (lgssm.jl:236-237)
+    double gt[D], Lt[DS];
+    TGP_UNROLL for (int i = 0; i < D; ++i) {
+        double acc = xf.m[i];
+        TGP_UNROLL for (int k = 0; k < D; ++k) acc = ::fma(-W[k + i * D], mp[k], acc);
+        gt[i] = acc;
+    }
+    TGP_UNROLL for (int j = 0; j < D; ++j)
+        TGP_UNROLL for (int i = 0; i <= j; ++i) {
+            double acc = xf.P[pidx(i, j)];
+            TGP_UNROLL for (int k = 0; k < D; ++k) acc = ::fma(-Z[k + i * D], Z[k + j * D], acc);
+            Lt[pidx(i, j)] = acc;
+        }
+    // g += E g_t;  L += E L_t E';  E <- E G      (G[i][k] = W[k + i D])
+    TGP_UNROLL for (int i = 0; i < D; ++i) {
+        double acc = ra.g[i];
+        TGP_UNROLL for (int k = 0; k < D; ++k) acc = ::fma(ra.E[i + k * D], gt[k], acc);
+        ra.g[i] = acc;
+    }
+    double EL[D * D], Ln[DS], En[D * D];
+    mul_A_sym<D>(ra.E, Lt, EL);
+    mul_AXAt_plus<D>(EL, ra.E, ra.L, Ln);
+    TGP_UNROLL for (int i = 0; i < DS; ++i) ra.L[i] = Ln[i];
+    TGP_UNROLL for (int j = 0; j < D; ++j)
+        TGP_UNROLL for (int i = 0; i < D; ++i) {
+            double acc = 0.0;
+            TGP_UNROLL for (int k = 0; k < D; ++k) acc = ::fma(ra.E[i + k * D], W[j + k * D], acc);      // (E G)[i][j] = sum_k E[i][k] G[k][j], G[k][j] = W[j + k D]
+            En[i + j * D] = acc;
+        }
+    TGP_UNROLL for (int i = 0; i < D * D; ++i) ra.E[i] = En[i];
+}
+
 // Inputs of the B steps of a block.  XS bit 0: the noise variance is per step, bit 1: the emission offset is.  A lane's B steps are B
 // consecutive values of each stream: the loads of a block are issued together (one cache line per lane and stream: the first load brings
 // it, the others hit -- one load per step, spread over the block, was measured 25 % slower: the line is gone from the 32 KB L1 by then),
@@ -489,9 +576,12 @@ template <int D, bool SDE, int XS, int B> TGP_HD void load_inputs(const KArgs<D>
 // [lo, hi) are processed, whole (lo, hi multiples of 8; steps behind the series' end are missing).  x: filtering state in front of step
 // max(ts, lo) on entry, behind the last processed step on return.  acc: the log marginal likelihood's sums (want_lml: the logs are taken).
 // ckpt (null: none): the state in front of every block is kept, [block][component][lane].
-template <int D, bool SDE, int XS, int B>
+// REV: the reverse-time recursion over the steps (rev_t0, rev_te) is composed on the way (see RevAcc: rev holds the composition so far, the run may
+// be one of several over the window); *rev_out = the smoothing state of step rev_t0 it gives from the filtering state of step rev_te - 1.
+template <int D, bool SDE, int XS, int B, bool REV = false>
 TGP_HD void forward_run(const KArgs<D>& ka, const ModelR<D, SDE>& mr, long long ts, int nblk, long long lo, long long hi, State<D>& x, LmlAcc& acc,
-                        bool want_lml, double* ckpt, int lane, bool& ok) {
+                        bool want_lml, double* ckpt, int lane, bool& ok, RevAcc<D>* rev = nullptr, long long rev_t0 = 0, long long rev_te = 0,
+                        State<D>* rev_out = nullptr) {
     constexpr int NS = SD<D>::NS;
     Inputs<D, SDE, XS, B> in, nx;
     load_inputs<D, SDE, XS, B>(ka, ts, in);
@@ -508,8 +598,18 @@ TGP_HD void forward_run(const KArgs<D>& ka, const ModelR<D, SDE>& mr, long long 
             TGP_UNROLL for (int j = 0; j < B; ++j) {
                 double A[D * D];
                 step_A<D, SDE>(ka.mc, mr, SDE ? in.tau[j] : 0.0, SDE && tb + j == 0, A);
-                predict_r<D, SDE>(mr, A, x.m, x.P);
-                update<D>(mr.H, (XS & 2) ? in.hh[j] : mr.hh, (XS & 1) ? in.R[j] : mr.R, in.y[j], in.obs(j, tb + j, ka.T), x.m, x.P, &acc, ok);
+                if constexpr (REV) {
+                    const long long t = tb + j;
+                    State<D> xf = x;
+                    double AP[D * D];
+                    predict_r<D, SDE>(mr, A, x.m, x.P, AP);
+                    if (t > rev_t0 && t < rev_te) rev_append<D>(xf, x.m, x.P, AP, *rev, ok);
+                    update<D>(mr.H, (XS & 2) ? in.hh[j] : mr.hh, (XS & 1) ? in.R[j] : mr.R, in.y[j], in.obs(j, t, ka.T), x.m, x.P, &acc, ok);
+                    if (t == rev_te - 1) rev->finish(x, *rev_out);
+                } else {
+                    predict_r<D, SDE>(mr, A, x.m, x.P);
+                    update<D>(mr.H, (XS & 2) ? in.hh[j] : mr.hh, (XS & 1) ? in.R[j] : mr.R, in.y[j], in.obs(j, tb + j, ka.T), x.m, x.P, &acc, ok);
+                }
             }
         }
         if (want_lml) acc.flush();      // (wave-uniform)

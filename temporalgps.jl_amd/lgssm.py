@@ -348,7 +348,12 @@ def _obs_impl(y, model, lazy_nan):
     if _is_torch(y) and y.is_cuda:
         import torch
         yy = y.to(torch.float64).contiguous()
-        mm = None if mask is None else mask.to(torch.uint8).contiguous()
+        if mask is None:
+            mm = None
+        elif mask.dtype == torch.bool:
+            mm = mask.contiguous().view(torch.uint8)      # (a bool tensor IS one byte per step, 0 / 1: no conversion kernel per call)
+        else:
+            mm = mask.to(torch.uint8).contiguous()
         _sync_torch(yy)
         return yy, mm, True, False
     if isinstance(y, np.ma.MaskedArray):

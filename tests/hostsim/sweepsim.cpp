@@ -72,8 +72,15 @@ template <int D, bool SDE, int XS> void run_d(const Plan& p, const Streams& st, 
             x[lane] = lane > 0 ? e1[lane - 1] : e1[0];
             if (t0[lane] == 0) x[lane] = x0;
             acc[lane] = LmlAcc();
-            forward_run<D, SDE, XS, B>(ka, mr, t0[lane], C / B, t0[lane], runs[lane] ? t1r[lane] : t0[lane], x[lane], acc[lane], true,
-                                       post ? ckpt.data() : (double*)nullptr, lane, ok[lane]);
+            const long long te = (t0[lane] + ka.Wb < t1[lane]) ? t0[lane] + ka.Wb : t1[lane];
+            RevAcc<D> rev;
+            rev.reset();
+            b1[lane] = gen;
+            const int nwin = post ? ka.Wb / B : 0;
+            const long long hi1 = runs[lane] ? t1r[lane] : t0[lane];
+            if (post) forward_run<D, SDE, XS, B, true>(ka, mr, t0[lane], nwin, t0[lane], hi1, x[lane], acc[lane], true, ckpt.data(), lane, ok[lane], &rev, t0[lane], te, &b1[lane]);
+            forward_run<D, SDE, XS, B>(ka, mr, t0[lane] + (long long)nwin * B, C / B - nwin, t0[lane], hi1, x[lane], acc[lane], true,
+                                       post ? ckpt.data() + (size_t)nwin * NS * 64 : (double*)nullptr, lane, ok[lane]);
         }
         double df[64] = {}, db[64] = {};
         bool fin[64];
@@ -85,12 +92,6 @@ template <int D, bool SDE, int XS> void run_d(const Plan& p, const Streams& st, 
             }
         }
         if (post) {
-            for (int lane = 0; lane < 64; ++lane) {
-                const long long te = (t0[lane] + ka.Wb < t1[lane]) ? t0[lane] + ka.Wb : t1[lane];
-                State<D> s = gen;
-                backward_run<D, SDE, XS, B>(ka, mr, t0[lane], ka.Wb / B, runs[lane] ? te : t0[lane], true, s, false, ckpt.data(), sF.data(), lane, ok[lane]);
-                b1[lane] = s;
-            }
             for (int lane = 0; lane < 64; ++lane) {
                 xs[lane] = lane < 63 ? b1[lane + 1] : b1[63];
                 backward_run<D, SDE, XS, B>(ka, mr, t0[lane], C / B, owned[lane] ? t1[lane] : t0[lane], t1[lane] == T, xs[lane], true, ckpt.data(), sF.data(),
