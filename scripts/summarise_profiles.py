@@ -1,61 +1,134 @@
 #!/usr/bin/env python3
-"""Turn gpurun_out/prof_<tag>/ (scripts/collect_profiles.sh) into the committed summaries under profiles/:
-   <tag>_<layout>_kernel_stats.md   per-kernel calls / avg / total from rocprofv3 --kernel-trace
-   <tag>_pmc_traffic.json           per-kernel HBM bytes per launch: 2*FETCH_SIZE + WRITE_SIZE (KB -> bytes).
-FETCH_SIZE is doubled as MI355X_MICROARCH.md (HBM section) prescribes for gfx950 coalesced streaming reads;
-WRITE_SIZE is taken as reported (uncalibrated there)."""
+"""gpurun_out/prof_<tag>_<class>[_<workload>]/ (scripts/collect_profiles.sh) -> the committed summaries under profiles/ (one script for every round):
+   <tag>_<class>_kernel_stats[_<wl>].md   per-kernel calls / avg / min / max of `rocprofv3 --kernel-trace --stats -- <command>`
+   <tag>_pmc_traffic.json                 {class: {key: {bench label: {fetch_bytes_reported, write_bytes_reported, hbm_bytes}}}}
+                                          HBM bytes per launch = 2 * FETCH_SIZE + WRITE_SIZE (KB -> bytes; FETCH doubled as
+                                          MI355X_MICROARCH.md's HBM section prescribes for gfx950; separate --pmc passes)
+   <tag>_sq_counters_<class>[_<wl>].txt / .json   SQ_* counters of the largest launch of each kernel
+Keys are the labels bench.py's hipEvent profile uses, so that bench.py can join them with live durations.
+`--from-box`: called at the end of collect_profiles.sh on the GPU box -- writes the summaries NEXT TO the raw traces (gpurun_out/...), from where
+a second call here (without the flag) copies them into profiles/."""
 import collections
 import csv
 import glob
 import json
 import os
+import re
+import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(root, "gpurun_out", f"prof_{tag}")
-dst = os.path.join(root, "profiles")
-os.makedirs(dst, exist_ok=True)
+tag, cls = sys.argv[1], sys.argv[2]
+wl = sys.argv[3] if len(sys.argv) > 3 and not sys.argv[3].startswith("--") and sys.argv[3] else ""
+from_box = "--from-box" in sys.argv
+WL_D = {"matern52_d3": 3, "matern32_d2": 2, "sum52_12_d4": 4, "sum52_32_d5": 5, "sum52_52_d6": 6, "sum52_32_32_d7": 7, "sum52_52_32_d8": 8,
+        "sum52_52s_d6": 6, "sum52_32s_32_d7": 7, "sum52_52s_32_d8": 8}
+if cls == "lti":
+    wl = wl or "matern52_d3"
+suf = "" if (cls != "lti" or wl == "matern52_d3") else "_" + wl
+src = os.path.join(root, "gpurun_out", f"prof_{tag}_{cls}{suf}")
+dst = src if from_box else os.path.join(root, "profiles")
+key = f"d={WL_D.get(wl, 3)}" if cls != "cfg5" else "d=768"
+
+if not from_box:      # the box already summarised: copy what it wrote
+    n = 0
+    for f in glob.glob(os.path.join(src, f"{tag}_*")):
+        shutil.copy(f, os.path.join(dst, os.path.basename(f)))
+        n += 1
+    # the traffic / counter tables are merged (several classes and workloads share one file)
+    for name in (f"{tag}_pmc_traffic.json",):
+        part = os.path.join(src, "part_" + name)
+        if os.path.exists(part):
+            full = os.path.join(dst, name)
+            table = json.load(open(full)) if os.path.exists(full) else {}
+            for c, sub in json.load(open(part)).items():
+                table.setdefault(c, {}).update(sub)
+            json.dump(table, open(full, "w"), indent=1, sort_keys=True)
+            n += 1
+    print(f"copied {n} summaries from {src}")
+    sys.exit(0)
 
 
 def newest(pattern):
-    """gpurun merges every call's files into the same directory: take the most recent run"""
     files = sorted(glob.glob(pattern, recursive=True), key=os.path.getmtime)
-    return files[-1:] 
+    return files[-1] if files else None
 
 
 def short(name):
-    n = name.replace("void tgp::", "").split("(")[0]
-    return n
+    return re.sub(r"\(anonymous namespace\)::", "", name.replace("void ", "")).split("(")[0]
 
 
-traffic = {}
-for lay in ("lti", "per_step"):
-    files = newest(os.path.join(src, f"trace_{lay}", "**", "*kernel_trace.csv"))
-    if files:
-        acc = collections.defaultdict(list)
-        for r in csv.DictReader(open(files[0])):
-            acc[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-        tot = sum(sum(v) for v in acc.values())
-        lines = [f"# rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 2 --layout {lay} (T=1e7, d=3)", "",
-                 "| kernel | calls | total_ms | avg_us | min_us | max_us | pct |", "|---|---|---|---|---|---|---|"]
-        for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
-            lines.append(f"| `{short(k)[:90]}` | {len(v)} | {sum(v) / 1e6:.3f} | {sum(v) / len(v) / 1e3:.1f} | {min(v) / 1e3:.1f} | "
-                         f"{max(v) / 1e3:.1f} | {100 * sum(v) / tot:.1f} |")
-        open(os.path.join(dst, f"{tag}_{lay}_kernel_stats.md"), "w").write("\n".join(lines) + "\n")
-    per = {}
-    for c in ("FETCH_SIZE", "WRITE_SIZE"):
-        files = newest(os.path.join(src, f"pmc_{lay}_{c}", "**", "*counter_collection.csv"))
-        if not files:
-            continue
-        acc = collections.defaultdict(list)
-        for r in csv.DictReader(open(files[0])):
-            if r["Counter_Name"] == c and "tgp::" in r["Kernel_Name"]:
-                acc[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
-        for k, v in acc.items():
-            # the big (level-0) launches dominate; report the MAX launch (scan kernels run at several sizes)
-            per.setdefault(k, {})[c] = max(v) * 1024.0
-    traffic[lay] = {k: dict(fetch_bytes_reported=v.get("FETCH_SIZE"), write_bytes_reported=v.get("WRITE_SIZE"),
-                            hbm_bytes=2 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) for k, v in per.items()}
-json.dump(traffic, open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w"), indent=1, sort_keys=True)
-print(json.dumps({lay: {k: round(v["hbm_bytes"] / 1e6, 1) for k, v in t.items()} for lay, t in traffic.items()}, indent=1))
+def label(name):
+    """rocprof kernel name -> bench.py profile label (None: not one of the engine's kernels)"""
+    n = short(name)
+    m = re.match(r"tgp_modal::k_steady_one<(\d+), (\d+), (\d+)(?:, \w+)?>", n)
+    if m:      # (logpdf and posterior calls run the same kernel: the larger launch is the posterior call)
+        return f"k_steady_one<{m.group(2)}x{m.group(3)},posterior>"
+    m = re.match(r"tgp_sweep::k_sweep<(\d+), (true|false), (\d+), (true|false)>", n)
+    if m:
+        return f"k_sweep<{'sde' if m.group(2) == 'true' else 'lti'},{'posterior' if m.group(4) == 'true' else 'logpdf'}>" + (f"[xs={m.group(3)}]" if m.group(3) != "0" else "")
+    m = re.match(r"tgp_steady::k_(reduce|carry|apply)<(\d+), (true|false)>", n)
+    if m:
+        return f"k_steady_{m.group(1)}<{'posterior' if m.group(3) == 'true' else 'logpdf'}>"
+    if re.match(r"tgp_steady::k_setup_core<", n):
+        return "k_steady_setup"
+    if re.match(r"tgp_steady::k_final<", n):
+        return "k_steady_final"
+    m = re.match(r"tgp_dense::(dk_\w+)", n)
+    if m:
+        return m.group(1)
+    return None
+
+
+cmd = open(os.path.join(src, "command.txt")).read().strip() if os.path.exists(os.path.join(src, "command.txt")) else "?"
+f = newest(os.path.join(src, "trace", "**", "*kernel_trace.csv"))
+if f:
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        acc[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    tot = sum(sum(v) for v in acc.values())
+    lines = [f"# rocprofv3 --kernel-trace --stats -- {cmd.replace(root, '.')}", "",
+             "| kernel | bench label | calls | total_ms | avg_us | min_us | median_us | max_us | pct |", "|---|---|---|---|---|---|---|---|---|"]
+    for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1]))[:40]:
+        vs = sorted(v)
+        lines.append(f"| `{short(k)[:90]}` | {label(k) or ''} | {len(v)} | {sum(v) / 1e6:.3f} | {sum(v) / len(v) / 1e3:.1f} | {vs[0] / 1e3:.1f} | "
+                     f"{vs[len(vs) // 2] / 1e3:.1f} | {vs[-1] / 1e3:.1f} | {100 * sum(v) / tot:.1f} |")
+    open(os.path.join(dst, f"{tag}_{cls}_kernel_stats{suf}.md"), "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines[:16]))
+
+per = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    f = newest(os.path.join(src, f"pmc_{c}", "**", "*counter_collection.csv"))
+    if not f:
+        continue
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        lb = label(r["Kernel_Name"])
+        if r["Counter_Name"] == c and lb:
+            acc[lb].append(float(r["Counter_Value"]))
+    for k, v in acc.items():
+        per.setdefault(k, {})[c] = max(v) * 1024.0
+if per:
+    table = {cls: {key: {k: dict(fetch_bytes_reported=v.get("FETCH_SIZE"), write_bytes_reported=v.get("WRITE_SIZE"),
+                                 hbm_bytes=2 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) for k, v in per.items()}}}
+    json.dump(table, open(os.path.join(dst, f"part_{tag}_pmc_traffic.json"), "w"), indent=1, sort_keys=True)
+    print(json.dumps({k: round(v["hbm_bytes"] / 1e6, 1) for k, v in table[cls][key].items()}, indent=1))
+
+f = newest(os.path.join(src, "sq", "**", "*counter_collection.csv"))
+if f:
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    names = []
+    for r in csv.DictReader(open(f)):
+        lb = label(r["Kernel_Name"])
+        if lb:
+            acc[lb][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            if r["Counter_Name"] not in names:
+                names.append(r["Counter_Name"])
+    table = {key: {k: {n: max(v[n]) for n in names if v[n]} for k, v in acc.items()}}
+    json.dump(table, open(os.path.join(dst, f"{tag}_sq_counters_{cls}{suf}.json"), "w"), indent=1, sort_keys=True)
+    lines = [f"rocprofv3 --pmc {' '.join(names)} --kernel-trace -- (the same command, fewer steps)",
+             "(largest launch of each kernel; SQ_*_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* count quad-cycles, summed over the SQs)", "", "kernel | " + " | ".join(names)]
+    for k, v in sorted(table[key].items()):
+        lines.append(k + " | " + " | ".join("%.4g" % v[n] if n in v else "-" for n in names))
+    open(os.path.join(dst, f"{tag}_sq_counters_{cls}{suf}.txt"), "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines))

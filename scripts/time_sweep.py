@@ -11,7 +11,7 @@ from temporalgps_jl_amd import lti_sde as P
 
 T = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10_000_000
 kname = sys.argv[2] if len(sys.argv) > 2 else "matern52"
-steps = 5
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 dev = "cuda:0"
 k = P.to_kernel((kname,))
 dt, s2 = 0.1, 0.1

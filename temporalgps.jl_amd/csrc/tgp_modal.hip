@@ -76,9 +76,21 @@ __device__ __forceinline__ void lds_sync() {      // one wave talking to itself 
 // writes the packed tables into pinned memory and then the flag 2 seq (+ 1 if that half declined: the call is then re-run elsewhere and
 // whatever this kernel writes is discarded).  Workgroup 0 pulls them into device memory, all its waves at once (one PCIe round trip with
 // every load in flight; a DMA copy of the same bytes reaches the device ~20 us after the API call)
-__device__ __noinline__ void wait_tables(const long long* flagc, long long seq) {
+// The wait is BOUNDED (round-4 advice): a host thread that dies between the launch and the flag, or a tool that makes the launch synchronous,
+// would otherwise leave the queue spinning for ever.  After kWaitTicks of the 100 MHz clock (two seconds: the host half takes microseconds)
+// the kernel goes on with whatever the table memory holds -- finite garbage at worst, every index comes from the arguments -- and poisons
+// its share of the sum of squares (`poison`, when given), so that the call's result is NaN and is discarded.
+constexpr long long kWaitTicks = 200000000ll;
+__device__ __noinline__ void wait_tables(const long long* flagc, long long seq, double* poison = nullptr) {
     long long* flag = const_cast<long long*>(flagc);
-    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < 2 * seq) __builtin_amdgcn_s_sleep(16);
+    const long long t0 = (long long)wall_clock64();
+    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < 2 * seq) {
+        __builtin_amdgcn_s_sleep(16);
+        if ((long long)wall_clock64() - t0 > kWaitTicks) {
+            if (poison != nullptr) *poison = __builtin_nan("");
+            return;
+        }
+    }
 }
 
 template <int SUB, int D>
@@ -611,7 +623,7 @@ __global__ __launch_bounds__(NW * 64, TGP_MIN_WAVES(D, NW, HEAD_SCANS)) void k_s
     if (first) {
         // the head's tables: wait for the host, pull them into device memory (all waves), then the head wave runs the head forward
         if (threadIdx.x == 0) ka.part[ka.nwg + 1] = (double)wall_clock64();      // (phases of workgroup 0, 100 MHz: TGP_STEADY_DEBUG prints them)
-        wait_tables(ka.flag, ka.seq);
+        wait_tables(ka.flag, ka.seq, threadIdx.x == 0 ? &ka.part[ka.nwg] : nullptr);      // (timed out: the head's share becomes NaN)
         if (threadIdx.x == 0) ka.part[ka.nwg + 2] = (double)wall_clock64();
         const v2d* __restrict__ src = reinterpret_cast<const v2d*>(ka.htab);
         v2d* __restrict__ dst = reinterpret_cast<v2d*>(ka.tab);
@@ -1123,6 +1135,32 @@ static bool host_cpu_ok() {
     return ok;
 }
 
+// The host plans other translation units need (tgp_api.hip: the filter / posterior / rand one-launch paths).  Defined HERE and only here: this
+// object's host code is built with -mavx2 -mfma, and the inline functions of tgp_steady_plan.hpp instantiated in a second object built with
+// other flags would be two definitions of one entity -- the linker keeps either (round-4 advice).  All behind the run-time CPU check: a
+// host without AVX2 gets a plan that declines (the older engines serve the call).
+void plan_filter(const tgp_plan::ModelHost& m, long long T, tgp_plan::FilterPlan& fp) {
+    if (!host_cpu_ok()) {
+        fp.why = tgp_plan::kEigFail;
+        return;
+    }
+    tgp_plan::build_filter_any(m, T, fp);
+}
+void plan_filter_head(const tgp_plan::ModelHost& m, const tgp_plan::FilterPlan& fp, const double* y, double* mout, double* Pout, double* mu_end, double* quad) {
+    tgp_plan::filter_head_any(m, fp, y, mout, Pout, mu_end, quad);      // (only ever called with a plan plan_filter accepted)
+}
+bool plan_posterior_head(const tgp_plan::ModelHost& m, const tgp_plan::FilterPlan& fp, const double* y, double* Gh, double* gh, double* Lh, double* Gss,
+                         double* Lss, double* mu_end, double* quad) {
+    return tgp_plan::posterior_head_any(m, fp, y, Gh, gh, Lh, Gss, Lss, mu_end, quad);
+}
+void plan_rand(const tgp_plan::ModelHost& m, tgp_plan::RandPlan& rp) {
+    if (!host_cpu_ok()) {
+        rp.why = tgp_plan::kEigFail;
+        return;
+    }
+    tgp_plan::build_rand_any(m, rp);
+}
+
 tgp_plan::Info plan_only(const tgp_plan::ModelHost& m, long long T, tgp_plan::Modal& md, tgp_plan::HeadTables& tab) {
     if (!host_cpu_ok()) {
         tgp_plan::Info in;
@@ -1132,10 +1170,18 @@ tgp_plan::Info plan_only(const tgp_plan::ModelHost& m, long long T, tgp_plan::Mo
     return tgp_plan::build_any(m, T, md, tab);
 }
 
-static bool overlap_tables() {      // TGP_MODAL_OVERLAP=0: the whole plan before the launch (A/B runs)
+// TGP_MODAL_OVERLAP=0: the whole plan before the launch (A/B runs).  Also when the process runs with synchronous launches (the usual ROCm /
+// PyTorch debugging switches): the kernel waits for flags the host raises AFTER hipLaunchKernelGGL returns -- a launch that does not return
+// until the kernel has finished would wait for itself (round-4 advice; the wait is bounded as well, see wait_tables).
+static bool overlap_tables() {
     static const bool on = [] {
         const char* v = std::getenv("TGP_MODAL_OVERLAP");
-        return !(v && v[0] == '0');
+        if (v && v[0] == '0') return false;
+        for (const char* name : {"HIP_LAUNCH_BLOCKING", "CUDA_LAUNCH_BLOCKING", "AMD_SERIALIZE_KERNEL", "AMD_SERIALIZE_COPY"}) {
+            const char* b = std::getenv(name);
+            if (b && b[0] != '\0' && !(b[0] == '0' && b[1] == '\0')) return false;
+        }
+        return true;
     }();
     return on;
 }
@@ -1275,6 +1321,15 @@ bool complete(Engine* e, long long T) {
         return false;
     }
     return true;
+}
+
+// A caller that leaves between enqueue() and complete() (an error return in between) must not leave the kernel waiting: raises the flags of
+// a deferred plan with the failure bit (what the kernel writes is then discarded by whoever reads it).  Harmless otherwise.
+void abandon(Engine* e) {
+    if (!e || !e->began || !e->deferred || !e->hflat) return;
+    e->deferred = false;
+    long long* hflag = reinterpret_cast<long long*>(e->hflat + e->flat_cap);
+    for (int s2 = 0; s2 < 3; ++s2) __atomic_store_n(hflag + s2, 2 * e->seq + 1, __ATOMIC_RELEASE);
 }
 
 int enqueue(Engine* e, hipStream_t stream, const Call& c, const char** kname, std::string* err) {

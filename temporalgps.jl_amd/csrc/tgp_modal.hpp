@@ -36,7 +36,15 @@ bool plan(Engine*, const tgp_plan::ModelHost&, long long T);
 int enqueue(Engine*, hipStream_t stream, const Call&, const char** kname, std::string* err);
 // Right behind enqueue: the tables half of the plan when plan() left it for now (the kernel's head wave and last tiles wait for it).
 // false: that half declined -- synchronise, discard the outputs, run the call elsewhere.
+// host plans of the filter / posterior / rand one-launch paths (defined in tgp_modal.hip only: one set of host compile flags, one CPU check)
+void plan_filter(const tgp_plan::ModelHost& m, long long T, tgp_plan::FilterPlan& fp);
+void plan_filter_head(const tgp_plan::ModelHost& m, const tgp_plan::FilterPlan& fp, const double* y, double* mout, double* Pout, double* mu_end, double* quad);
+bool plan_posterior_head(const tgp_plan::ModelHost& m, const tgp_plan::FilterPlan& fp, const double* y, double* Gh, double* gh, double* Lh, double* Gss,
+                         double* Lss, double* mu_end, double* quad);
+void plan_rand(const tgp_plan::ModelHost& m, tgp_plan::RandPlan& rp);
 bool complete(Engine*, long long T);
+// Leaving between enqueue and complete (an error path): raise the flags the kernel may be waiting for, with the failure bit.  Harmless otherwise.
+void abandon(Engine*);
 // Once the stream has passed the kernel: the log marginal likelihood (a call over the whole series) ...
 double finish(const Engine*, long long T);
 // ... or the launch's share of the quadratic form (a segment): lml = -(T log 2pi + LS + (T - n0) logS + sum head_quad + iS sum ssq) / 2

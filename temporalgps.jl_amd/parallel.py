@@ -289,6 +289,8 @@ class ShardedLGSSM:
         if post:
             Rn = torch.as_tensor(np.atleast_1d(np.asarray(R_new, dtype=np.float64)) if not L._is_torch(R_new) else R_new,
                                  dtype=torch.float64, device=dev).reshape(-1).contiguous()
+            if Rn.numel() not in (1, self.model.T):      # (the C side reads T values of a per-step array: never hand it fewer)
+                raise ValueError(f"R_new must hold one value or one per step of this rank's segment ({self.model.T}), got {Rn.numel()}")
             mean, var = L._out(self.model, (self.model.T,), out_device), L._out(self.model, (self.model.T,), out_device)
             flags |= (_lib.OUT_DEVICE if out_device else 0) | (_lib.SHARED_R if Rn.shape[0] == 1 else 0)
         share = ctypes.c_double()

@@ -28,13 +28,3 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
-
-
-@pytest.fixture(autouse=True)
-def _release_device_handles():
-    """Device handles own HIP streams (and, for the out-of-line d >= 9 kernels, per-queue scratch arenas of tens of MB): the runtime aborts a
-    queue when the arenas of the queues alive in ONE process add up to a few hundred MB.  Collect after every test so that the
-    handles of finished tests are gone before the next one binds its models, whatever order the files run in."""
-    yield
-    import gc
-    gc.collect()

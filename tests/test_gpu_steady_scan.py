@@ -264,14 +264,25 @@ def test_cfg1_exact_size(tgp):
     lp_ref = ref.logpdf(model, y)
     post = ref.posterior(model, y)
     pm, pv = ref.marginals(ref.replace_observation_noise_cov(post, np.array([1e-18])))
-    for steady in (2, 1):
+    for steady in (3, 2, 1):      # 3: the default -- the one-launch engine, at this length with the head as scans (what bench.py times for cfg1)
         dm = device_model(tgp, model, steady)
+        hd = dm.handle()
+        hd.set_option(tgp._lib.OPT_PROFILE, 1)
+        hd.profile_reset()
         lp = tgp.logpdf(dm, y)
         mean, var = tgp.posterior_marginals(dm, y, np.array([1e-18]))
-        assert (served(dm) > 9900) == (steady == 2)
-        assert abs(lp - lp_ref) <= 1e-10 * abs(lp_ref)
-        np.testing.assert_allclose(mean, pm, rtol=0, atol=1e-8)
-        np.testing.assert_allclose(var, pv, rtol=1e-8, atol=1e-10)
+        lp2, mean2, var2 = tgp.logpdf_and_posterior_marginals(dm, y, np.array([1e-18]))
+        names = set(hd.profile())
+        hd.set_option(tgp._lib.OPT_PROFILE, 0)
+        assert (served(dm) > 9900) == (steady >= 2)
+        if steady == 3:
+            assert names and all(n.startswith("k_steady_one") for n in names), names
+        elif steady == 2:
+            assert not any(n.startswith("k_steady_one") for n in names) and any(n.startswith("k_steady") for n in names), names
+        assert abs(lp - lp_ref) <= 1e-10 * abs(lp_ref) and abs(lp2 - lp_ref) <= 1e-10 * abs(lp_ref)
+        for mm, vv in ((mean, var), (mean2, var2)):
+            np.testing.assert_allclose(mm, pm, rtol=0, atol=1e-8)
+            np.testing.assert_allclose(vv, pv, rtol=1e-8, atol=1e-10)
 
 
 @pytest.mark.parametrize("d", [2, 3, 4, 6])

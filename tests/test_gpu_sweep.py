@@ -131,6 +131,24 @@ def test_irregular_spacing(tgp, i, with_missing):
     _check(tgp, dm, yin, np.array([1e-18]), lp, pm, pv, "sde")
 
 
+@pytest.mark.parametrize("i", [2, 3, 4])
+def test_irregular_spacing_with_per_step_noise_and_offset(tgp, i):
+    """every input stream at once (gaps, noise variance, emission offset of a mean function at the inputs, mask, new noise per step): the
+    kernel variant with the largest register footprint (tests/test_kernel_resources.py names this test for it), d = 3 and 4"""
+    from temporalgps_jl_amd import lti_sde as P
+    k, dt, s2 = KERNELS[i]
+    T = 5000
+    rng = np.random.default_rng(60 + i)
+    t = np.cumsum(rng.uniform(0.5 * dt, 1.5 * dt, T))
+    S = s2 * (0.5 + rng.random(T))
+    model, y, _ = U.gp_case(k, t, S, seed=i, mean=("custom", lambda tt: np.cos(0.3 * tt)))
+    missing = rng.random(T) < 0.1
+    Rn = rng.random(T) * 0.05
+    lp, pm, pv = _reference(model, y, missing, Rn)
+    dm = P.build_lgssm(P.to_kernel(k), t, S, mean=P.CustomMean(lambda v: np.cos(0.3 * v)), device_components=True)
+    _check(tgp, dm, np.where(missing, np.nan, y), Rn, lp, pm, pv, "sde")
+
+
 def test_prediction_at_new_inputs_runs_the_sweep_engine(tgp):
     """the reference's predict path (posterior_lti_sde.jl:20-37,97-131): training and prediction inputs merged and sorted, the prediction
     points missing with the large noise variance of missings.jl:43"""

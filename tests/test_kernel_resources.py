@@ -19,6 +19,8 @@ COVERED = [  # (pattern of the demangled kernel name, where its values are check
     (r"tgp::k_tile_sde<8>", "tests/test_gpu_gp_api.py (irregular inputs, d = 8 sum kernels)"),
     (r"tgp::k_(reduce|apply)_filter_ad<[78],", "tests/test_gpu_gradient.py (d up to 8)"),
     (r"tgp::k_scan_(apply|reduce)<.*FilterMonoidAD<[34]>", "tests/test_gpu_gradient.py (d = 3, 4)"),
+    (r"tgp_sweep::k_sweep<[34], true, 3, true>", "tests/test_gpu_sweep.py::test_irregular_spacing_with_per_step_noise_and_offset (d = 3, 4: the variant with all four "
+                                                 "input streams -- gaps, noise variance and emission offset per step -- double-buffered)"),
     (r"tgp_steady::", "tests/test_gpu_steady_scan.py::test_every_state_dimension_against_the_oracle (every d = 1..8: the one-wave setup and "
                       "head kernels of d >= 6 hold whole d x d matrices per lane)"),
 ]

@@ -85,6 +85,21 @@ def test_irregular_spacing_closed_form_transitions(i):
     _check(r, lp, pm, pv)
 
 
+@pytest.mark.parametrize("i", [2, 3])
+def test_irregular_spacing_with_per_step_noise_and_offset(i):
+    k, dt, s2 = CASES[i]
+    T = 900
+    rng = np.random.default_rng(60 + i)
+    t = np.cumsum(rng.uniform(0.5 * dt, 1.5 * dt, T))
+    S = s2 * (0.5 + rng.random(T))
+    model, y, _ = U.gp_case(k, t, S, seed=i, mean=("custom", lambda tt: np.cos(0.3 * tt)))
+    missing = rng.random(T) < 0.1
+    Rn = rng.random(T) * 0.05
+    lp, pm, pv = _reference(model, y, missing, Rn)
+    F, _ = U.kernel_sde(k)
+    _check(U.sweepsim_run(model, y, missing=missing, Rnew=Rn, sde=(F, t)), lp, pm, pv)
+
+
 def test_short_warm_up_is_detected_and_a_longer_one_passes():
     k, dt, s2 = CASES[5]                    # the bench parametrisation: slow mixing (dt = 0.05, l = 2.3)
     T = 3000
