@@ -151,45 +151,6 @@ def general_layout_leg(tgp, torch, name, T, d, device, steps):
                 kernels={k: dict(avg_ms=v["total_ms"] / max(1, v["calls"]), calls=v["calls"]) for k, v in hd.profile().items()})
 
 
-def irregular_leg(tgp, torch, name, T, d, device, steps):
-    """The same kernel on IRREGULARLY spaced inputs (dt ~ U(0.05, 0.15): broadcast_components for AbstractVector inputs, lti_sde.jl:135-146):
-    every step has its own A_k = exp(F dt_k), Q_k, which the passes evaluate in registers from the 8-byte gap (closed form per Matern
-    block; TGP_OPT_SDE_CLOSED_FORM) -- beside the same call with the transitions read from a tiled [T][2 d^2] record."""
-    import numpy as np
-    from temporalgps_jl_amd import lti_sde as P
-    k, _, dt, s2 = WORKLOADS[name]
-    rng = np.random.default_rng(3)
-    t = np.cumsum(rng.uniform(0.5 * dt, 1.5 * dt, T))
-    gen = torch.Generator(device=f"cuda:{device}")
-    gen.manual_seed(98)
-    y = torch.randn((T,), dtype=torch.float64, device=f"cuda:{device}", generator=gen)
-    Rnew = torch.full((1,), 1e-18, dtype=torch.float64, device=f"cuda:{device}")
-    out = {}
-    for label, cf in (("closed_form", 1), ("tiled_record", 0)):
-        model = P.build_lgssm(P.to_kernel(k), t, s2, device=device, device_components=True)
-        hd = model.handle()
-        hd.set_option(tgp._lib.OPT_SDE_CLOSED_FORM, cf)
-        for _ in range(2):
-            lp, _, _ = tgp.logpdf_and_posterior_marginals(model, y, Rnew)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            tgp.logpdf_and_posterior_marginals(model, y, Rnew)
-        torch.cuda.synchronize()
-        dts = (time.perf_counter() - t0) / steps
-        hd.set_option(tgp._lib.OPT_PROFILE, 1)
-        hd.profile_reset()
-        tgp.logpdf_and_posterior_marginals(model, y, Rnew)
-        hd.set_option(tgp._lib.OPT_PROFILE, 0)
-        out[label] = dict(steps_per_s=T / dts, ms_per_step=dts * 1e3, lml=float(lp),
-                          transition_bytes_per_step=8 if cf else 16 * d * d,
-                          kernels={kk: dict(avg_ms=v["total_ms"] / max(1, v["calls"])) for kk, v in hd.profile().items()})
-        del model
-    out["lml_rel_diff"] = abs(out["closed_form"]["lml"] - out["tiled_record"]["lml"]) / abs(out["tiled_record"]["lml"])
-    out["workload"] = f"{name}, T = {T}, dt ~ U({0.5 * dt:g}, {1.5 * dt:g}), one logpdf + posterior-marginals call per step"
-    return out
-
-
 def predict_path_legs(tgp, torch, name, T, d, device, steps):
     """The reference's predict path on the same kernel (round-4 verdict, item 1): models whose GAINS vary in time -- 10 % of the steps missing
     (missings.jl:25-41), a noise variance per step (lti_sde.jl:71-80 with a vector of variances), irregular spacing (lti_sde.jl:135-146) --

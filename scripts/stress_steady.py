@@ -104,7 +104,7 @@ for case in range(n_cases):
         tgp.logpdf_and_posterior_marginals(d2, y, Rn)
         names = set(h2.profile())
         # (the engine's kernels are enqueued either way; where it did not apply the general engine's passes follow them)
-        if any(n.startswith("k_steady_apply") for n in names) and not any(n.startswith(("k_reduce_filter", "k_apply_filter", "k_smooth", "k_group_")) for n in names):
+        if any(n.startswith("k_steady_apply") for n in names) and not any(n.startswith(("k_reduce_filter", "k_apply_filter", "k_smooth", "k_group_", "k_sweep")) for n in names):
             msgs.append(f"adjoint refused a model the five-launch engine served: {refusal}")
         del d2
     del dm, fx

@@ -394,6 +394,7 @@ struct tgp_handle {
     int opt_fuse = 1;            // TGP_OPT_FUSE_SCAN
     // timing
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t dep_ev = nullptr;      // tgp_wait_stream
     double kernel_ms = 0.0, h2d_ms = 0.0, d2h_ms = 0.0;
     std::vector<ProfEntry> prof;
     std::vector<PendingEvt> pending;
@@ -1403,21 +1404,36 @@ const char* tgp_version(void) { return "tgp_hip 0.1 (gfx950)"; }
 // after synchronising it; two handles that share a stream serialise on the device (their calls were independent anyway), and a
 // synchronisation may wait for the other handle's call as well.  tgp_set_stream still substitutes the caller's own stream.
 namespace {
-constexpr int kStreamPool = 8;
+// Two classes: kernels with next to no scratch (d <= 4, the dense MFMA engine) share kStreamPool streams; the scan engine's d = 5 .. 16 kernels --
+// inlined builds with kilobytes, out-of-line builds with up to 55 KB of private memory per lane -- share kHeavyPool: the runtime sizes a queue's
+// scratch arena for its hungriest kernel times every wave slot of the device and KEEPS it, and more than two or three such arenas alive abort the
+// process from the runtime's queue-event thread (measured: the variant self-test of d = 9 with pools of 4 and 8 streams; 1 and 2 pass).
+constexpr int kStreamPool = 8, kHeavyPool = 2;
 constexpr int kStreamPoolDevices = 64;
 std::mutex g_stream_mutex;
-hipStream_t g_streams[kStreamPoolDevices][kStreamPool] = {};
-unsigned g_stream_next[kStreamPoolDevices] = {};
-hipError_t pool_stream(int device, hipStream_t* out) {
+hipStream_t g_streams[kStreamPoolDevices][kStreamPool + kHeavyPool] = {};
+unsigned g_stream_next[kStreamPoolDevices][2] = {};
+hipError_t pool_stream(int device, hipStream_t* out, bool heavy = false) {
     if (device < 0 || device >= kStreamPoolDevices) return hipStreamCreateWithFlags(out, hipStreamNonBlocking);      // (never pooled: destroyed with the handle)
     std::lock_guard<std::mutex> lock(g_stream_mutex);
-    const unsigned k = g_stream_next[device]++ % kStreamPool;
+    static const unsigned pool = [] {
+        const char* v = std::getenv("TGP_STREAM_POOL");      // (1 .. kStreamPool; measurements)
+        const int n = v ? std::atoi(v) : kStreamPool;
+        return (unsigned)(n < 1 ? 1 : (n > kStreamPool ? kStreamPool : n));
+    }();
+    const unsigned k = heavy ? kStreamPool + g_stream_next[device][1]++ % kHeavyPool : g_stream_next[device][0]++ % pool;
     if (g_streams[device][k] == nullptr) {
         hipError_t rc = hipStreamCreateWithFlags(&g_streams[device][k], hipStreamNonBlocking);
         if (rc != hipSuccess) return rc;
     }
     *out = g_streams[device][k];
     return hipSuccess;
+}
+bool heavy_stream(int device, hipStream_t s) {
+    if (device < 0 || device >= kStreamPoolDevices) return false;
+    for (int k = kStreamPool; k < kStreamPool + kHeavyPool; ++k)
+        if (g_streams[device][k] == s && s != nullptr) return true;
+    return false;
 }
 bool pooled_stream(int device) { return device >= 0 && device < kStreamPoolDevices; }
 }  // namespace
@@ -1477,6 +1493,7 @@ int tgp_destroy(tgp_handle* h) {
         (void)hipEventDestroy(pe.b);
     }
     for (auto& e : h->evpool) (void)hipEventDestroy(e);
+    if (h->dep_ev) (void)hipEventDestroy(h->dep_ev);
     if (h->dense) tgp_dense::destroy(h->dense);
     if (h->steady2) tgp_steady::destroy(h->steady2);
     if (h->modal) tgp_modal::destroy(h->modal);
@@ -1652,6 +1669,17 @@ int tgp_set_stream(tgp_handle* h, void* hip_stream) {
     return TGP_OK;
 }
 
+// The handle's stream waits (on the DEVICE) for everything enqueued so far on `hip_stream` -- the stream that produced the caller's device
+// arrays (torch's current stream) -- instead of the caller synchronising that stream on the host before every call.
+int tgp_wait_stream(tgp_handle* h, void* hip_stream) {
+    if (!h) return TGP_EINVAL;
+    TRY(bind_device(h));
+    if (!h->dep_ev) HIPCHK(hipEventCreateWithFlags(&h->dep_ev, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(h->dep_ev, static_cast<hipStream_t>(hip_stream)));
+    HIPCHK(hipStreamWaitEvent(h->stream, h->dep_ev, 0));
+    return TGP_OK;
+}
+
 int tgp_get_stream(tgp_handle* h, void** hip_stream) {
     if (!h || !hip_stream) return TGP_EINVAL;
     *hip_stream = static_cast<void*>(h->stream);
@@ -1687,6 +1715,15 @@ int tgp_model_set(tgp_handle* h, int64_t T, int d, int p, int ordering, uint32_t
     h->tab_L0 = 0;
     if (T <= 0) return h->fail(TGP_EINVAL, "T must be positive");
     if (ordering != 0 && ordering != 1) return h->fail(TGP_EINVAL, "ordering must be 0 (Forward) or 1 (Reverse)");
+    if (pooled_stream(h->device)) {      // the stream class of the model's kernels (see pool_stream): calls are blocking, nothing is in flight here
+        const bool heavy = d >= 5 && d <= 16;
+        if (heavy != heavy_stream(h->device, h->own_stream)) {
+            hipStream_t ns = nullptr;
+            HIPCHK(pool_stream(h->device, &ns, heavy));
+            if (h->stream == h->own_stream) h->stream = ns;
+            h->own_stream = ns;
+        }
+    }
     h->is_dense = false;
     if (d > 16) {
         // dense large-state path (tgp_dense.hip): the arrays are re-packed into the padded MFMA layout, nothing is borrowed

@@ -1282,6 +1282,8 @@ bool plan(Engine* e, const tgp_plan::ModelHost& m, long long T) {
     layout_tables(e);
     // the tables half: behind the launch when the series is certainly longer than head + tail (the kernel's head wave and last tiles wait
     // for the flag), else right here
+    // (measured again in round 5, d = 3: with the tables behind the launch a call takes 63.5 us against 68.7 with them in front of it, the
+    //  kernel 47 us either way: scripts/call_overhead.py; TGP_MODAL_OVERLAP=0 is the switch)
     e->deferred = overlap_tables() && T >= (long long)e->md.nhs + tgp_plan::kTailMax + 1;
     if (!e->deferred) {
         const int why = build_and_ship_tables(e, T);

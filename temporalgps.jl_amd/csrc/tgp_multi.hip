@@ -365,9 +365,10 @@ int tgp_create_multi(tgp_multi** out, int ndev, const int* devices) {
     };
     for (int r = 0; r < ndev; ++r) {
         if (tgp_create(&m->h[r], m->dev[r]) != TGP_OK) return cleanup(TGP_EHIP);
-        void* s = nullptr;
-        if (tgp_get_stream(m->h[r], &s) != TGP_OK) return cleanup(TGP_EHIP);
-        m->st[r] = static_cast<hipStream_t>(s);
+        // a stream of the rank's OWN (single handles share a per-device pool since round 5: ranks that meet on one device must not -- the
+        // exchange orders the ranks' streams against each other with events)
+        if (hipSetDevice(m->dev[r]) != hipSuccess || hipStreamCreateWithFlags(&m->st[r], hipStreamNonBlocking) != hipSuccess) return cleanup(TGP_EHIP);
+        if (tgp_set_stream(m->h[r], m->st[r]) != TGP_OK) return cleanup(TGP_EHIP);
     }
     m->ev_slot.assign(ndev, nullptr);
     m->ev_done.assign(ndev, nullptr);
@@ -436,6 +437,7 @@ int tgp_destroy_multi(tgp_multi* m) {
         if (r < (int)m->ev_slot.size() && m->ev_slot[r]) (void)hipEventDestroy(m->ev_slot[r]);
         if (r < (int)m->ev_done.size() && m->ev_done[r]) (void)hipEventDestroy(m->ev_done[r]);
         if (m->h[r]) (void)tgp_destroy(m->h[r]);
+        if (m->st[r]) (void)hipStreamDestroy(m->st[r]);
     }
     if (m->host_stats) (void)hipHostFree(m->host_stats);
     delete m;

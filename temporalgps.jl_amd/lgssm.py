@@ -247,11 +247,16 @@ class LGSSM:
         return hd
 
 
-def _sync_torch(t):
-    """The library runs on its own HIP stream: make sure whatever torch has queued to produce a CUDA tensor
-    we are about to read has finished (torch ops are asynchronous on torch's current stream)."""
+def _sync_torch(t, model=None):
+    """The library runs on its own HIP stream: whatever torch has queued to produce a CUDA tensor we are about to read (torch ops are
+    asynchronous on torch's current stream) must be ordered in front of the call.  With the model's handle at hand that is an event the
+    handle's stream waits for ON THE DEVICE (tgp_wait_stream); without one, a host synchronisation of torch's stream."""
     import torch
-    torch.cuda.current_stream(t.device).synchronize()
+    hd = getattr(model, "_handle", None) if model is not None else None
+    if hd is not None and t.device.index == hd.device:
+        hd.wait_stream(torch.cuda.current_stream(t.device).cuda_stream)
+    else:
+        torch.cuda.current_stream(t.device).synchronize()
 
 
 def _handle_sde(self):
@@ -325,7 +330,7 @@ def _obs_impl(y, model, lazy_nan):
         Linv = torch.as_tensor(model._whiten[0], device=yy.device)
         yy = torch.matmul(Linv, yy[..., None])[..., 0].contiguous()
         mk = None if mm is None else mm[:, None].expand(model.T, model.p).to(torch.uint8).contiguous()
-        _sync_torch(yy)
+        _sync_torch(yy, model)
         return (yy if model.p > 1 else yy.reshape(model.T)), (mk if (mk is None or model.p > 1) else mk.reshape(model.T)), True, False
     if model is not None and (model.p > 1 or model._whiten is not None) and not (_is_torch(y) and y.is_cuda):
         yy = np.array(_to_numpy(y), dtype=np.float64)
@@ -354,7 +359,7 @@ def _obs_impl(y, model, lazy_nan):
             mm = mask.contiguous().view(torch.uint8)      # (a bool tensor IS one byte per step, 0 / 1: no conversion kernel per call)
         else:
             mm = mask.to(torch.uint8).contiguous()
-        _sync_torch(yy)
+        _sync_torch(yy, model)
         return yy, mm, True, False
     if isinstance(y, np.ma.MaskedArray):
         mask = np.ma.getmaskarray(y) if mask is None else mask
