@@ -148,9 +148,6 @@ const char* tgp_last_error(const tgp_handle* h);
 int tgp_set_option(tgp_handle* h, int option, int64_t value);
 /* run on a caller-provided hipStream_t (e.g. torch's current stream); NULL restores the handle's own */
 int tgp_set_stream(tgp_handle* h, void* hip_stream);
-/* the handle's stream waits, on the device, for everything enqueued so far on `hip_stream` (the stream that produced the caller's device arrays,
-   e.g. torch's current stream): the ordering a caller would otherwise get by synchronising that stream on the host before every call */
-int tgp_wait_stream(tgp_handle* h, void* hip_stream);
 /* the stream the handle's work is enqueued on (its own unless tgp_set_stream replaced it), as a hipStream_t */
 int tgp_get_stream(tgp_handle* h, void** hip_stream);
 const char* tgp_version(void);

@@ -36,7 +36,6 @@ _SIGS = {
     "tgp_set_option": (ctypes.c_int, [_vp, ctypes.c_int, _i64]),
     "tgp_set_stream": (ctypes.c_int, [_vp, _vp]),
     "tgp_get_stream": (ctypes.c_int, [_vp, ctypes.POINTER(_vp)]),
-    "tgp_wait_stream": (ctypes.c_int, [_vp, _vp]),
     "tgp_version": (ctypes.c_char_p, []),
     "tgp_kernel_variant": (ctypes.c_int, [_vp]),
     "tgp_graph_replays": (_i64, [_vp]),
@@ -203,10 +202,6 @@ class Handle:
         k, a, b = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
         self.lib.tgp_last_timing(self.h, ctypes.byref(k), ctypes.byref(a), ctypes.byref(b))
         return dict(kernel_ms=k.value, h2d_ms=a.value, d2h_ms=b.value)
-
-    def wait_stream(self, raw_stream):
-        """order the handle's stream behind the work already enqueued on `raw_stream` (a hipStream_t as an int; 0 = the null stream)"""
-        self.check(self.lib.tgp_wait_stream(self.h, ctypes.c_void_p(raw_stream)))
 
     def sweep_info(self):
         """diagnostics of the sweep engine (TGP_OPT_SWEEP) for the last logpdf / posterior-marginals call"""

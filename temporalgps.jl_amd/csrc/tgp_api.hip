@@ -394,7 +394,6 @@ struct tgp_handle {
     int opt_fuse = 1;            // TGP_OPT_FUSE_SCAN
     // timing
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t dep_ev = nullptr;      // tgp_wait_stream
     double kernel_ms = 0.0, h2d_ms = 0.0, d2h_ms = 0.0;
     std::vector<ProfEntry> prof;
     std::vector<PendingEvt> pending;
@@ -1493,7 +1492,6 @@ int tgp_destroy(tgp_handle* h) {
         (void)hipEventDestroy(pe.b);
     }
     for (auto& e : h->evpool) (void)hipEventDestroy(e);
-    if (h->dep_ev) (void)hipEventDestroy(h->dep_ev);
     if (h->dense) tgp_dense::destroy(h->dense);
     if (h->steady2) tgp_steady::destroy(h->steady2);
     if (h->modal) tgp_modal::destroy(h->modal);
@@ -1666,17 +1664,6 @@ int tgp_set_stream(tgp_handle* h, void* hip_stream) {
     drop_graphs(h);
     (void)hipStreamSynchronize(h->stream);
     h->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->own_stream;
-    return TGP_OK;
-}
-
-// The handle's stream waits (on the DEVICE) for everything enqueued so far on `hip_stream` -- the stream that produced the caller's device
-// arrays (torch's current stream) -- instead of the caller synchronising that stream on the host before every call.
-int tgp_wait_stream(tgp_handle* h, void* hip_stream) {
-    if (!h) return TGP_EINVAL;
-    TRY(bind_device(h));
-    if (!h->dep_ev) HIPCHK(hipEventCreateWithFlags(&h->dep_ev, hipEventDisableTiming));
-    HIPCHK(hipEventRecord(h->dep_ev, static_cast<hipStream_t>(hip_stream)));
-    HIPCHK(hipStreamWaitEvent(h->stream, h->dep_ev, 0));
     return TGP_OK;
 }
 

@@ -248,15 +248,12 @@ class LGSSM:
 
 
 def _sync_torch(t, model=None):
-    """The library runs on its own HIP stream: whatever torch has queued to produce a CUDA tensor we are about to read (torch ops are
-    asynchronous on torch's current stream) must be ordered in front of the call.  With the model's handle at hand that is an event the
-    handle's stream waits for ON THE DEVICE (tgp_wait_stream); without one, a host synchronisation of torch's stream."""
+    """The library runs on its own HIP stream: make sure whatever torch has queued to produce a CUDA tensor
+    we are about to read has finished (torch ops are asynchronous on torch's current stream).  (An event the handle's stream waits for on
+    the device instead -- no host synchronisation -- was measured in round 5: the cross-stream dependency delays the kernel's start by
+    ~10 us, three times what this synchronisation costs.)"""
     import torch
-    hd = getattr(model, "_handle", None) if model is not None else None
-    if hd is not None and t.device.index == hd.device:
-        hd.wait_stream(torch.cuda.current_stream(t.device).cuda_stream)
-    else:
-        torch.cuda.current_stream(t.device).synchronize()
+    torch.cuda.current_stream(t.device).synchronize()
 
 
 def _handle_sde(self):
