@@ -43,7 +43,7 @@ for case in range(min(n_cases, int(os.environ.get("END", "1000000")))):
     if skip:
         continue
     lp_o = oc.gp_logpdf(spec, x, s2, y, None, np.isnan(ym))
-    res = {}
+    res, sweep = {}, {1: 0, 0: 0}
     chunk = int(rng.choice([0, 1, 5, 33]))
     for cf in (1, 0):
         m = P.build_lgssm(k, x, s2, device_components=True)
@@ -54,6 +54,7 @@ for case in range(min(n_cases, int(os.environ.get("END", "1000000")))):
         try:
             op = "logpdf"
             r0 = tgp.logpdf(m, ym)
+            sweep[cf] = hd.sweep_info()["served"]
             op = "posterior_marginals"
             r1 = tgp.posterior_marginals(m, ym, np.array([0.01]))
             op = "marginals"
@@ -80,5 +81,5 @@ for case in range(min(n_cases, int(os.environ.get("END", "1000000")))):
             msgs.append(f"{nm} marginals closed form vs tiled: mean {em:.2e} var {ev:.2e}")
     bad += bool(msgs)
     d = sum(DIM[t[0]] for t in terms)
-    print(f"[{case:3d}] {'FAIL' if msgs else 'ok'} d={d} T={T} width={width} chunk={chunk} terms={[(t[0][6:], round(t[1], 2), round(t[2], 2)) for t in terms]} {'; '.join(msgs)}", flush=True)
+    print(f"[{case:3d}] {'FAIL' if msgs else 'ok'} d={d} T={T} width={width} chunk={chunk} sweep={sweep[1]} terms={[(t[0][6:], round(t[1], 2), round(t[2], 2)) for t in terms]} {'; '.join(msgs)}", flush=True)
 print(f"{bad} failing cases of {n_cases}")

@@ -117,8 +117,19 @@ def test_full_size_missing_data_and_sharding_invariance(tgp):
     lp_ref = sk.logpdf(dict(ref_model, R=R), y0) + ref.volume_compensation(int(miss.sum()))
     model = _product_model("matern52_d3", T)
     yd, md = torch.as_tensor(y0, device="cuda:0"), torch.as_tensor(miss, device="cuda:0")
-    lp = tgp.logpdf(model, (yd, md))
+    lp, names = _kernels_of(tgp, model, lambda: tgp.logpdf(model, (yd, md)))
+    info = model.handle().sweep_info()
+    assert info["served"] == 1 and info["attempts"] == 1 and names == {"k_sweep<lti,logpdf>"}, (info, names)    # the sweep engine, one launch
     assert abs(lp - lp_ref) <= 1e-10 * abs(lp_ref)
+    # ... and the posterior marginals of the same masked series (missings.jl:25-41 + posterior_lti_sde.jl:27-36), one launch as well
+    pm, pv = sk.posterior_marginals(dict(ref_model, R=R), y0, np.array([1e-18]))
+    Rn = torch.full((1,), 1e-18, dtype=torch.float64, device="cuda:0")
+    (mean, var), names = _kernels_of(tgp, model, lambda: tgp.posterior_marginals(model, (yd, md), Rn))
+    info = model.handle().sweep_info()
+    assert info["served"] == 1 and info["attempts"] == 1 and names == {"k_sweep<lti,posterior>"}, (info, names)
+    assert np.max(np.abs(mean.cpu().numpy() - pm)) <= 1e-8
+    assert np.max(np.abs(var.cpu().numpy() - pv)) <= 1e-8
+    del mean, var, pm, pv
     shared, barrier, out, errs = {}, threading.Barrier(world), {}, []
     lib = tgp._lib.load()
     for ph in (0, 1):

@@ -94,6 +94,50 @@ def test_closed_form_against_oracle_and_tiled_record(tgp, key, spacing):
         np.testing.assert_allclose(a[5], b[5], rtol=1e-7, atol=1e-7)
 
 
+@pytest.mark.parametrize("key", [1, 2, 3, "3b", 4, 6])
+@pytest.mark.parametrize("spacing", ["uniform", "wild"])
+def test_default_engine_selection_on_the_same_cases(tgp, key, spacing):
+    """The same cases with nothing forced: d <= 4 goes to the sweep engine (TGP_OPT_SWEEP, one launch per call: k_sweep<sde,...>), which
+    must either serve the call or -- gaps over nine decades: no common forgetting length -- hand it to the general engine's closed-form
+    passes; larger d stays on those. Same tolerances as above either way."""
+    from temporalgps_jl_amd import lti_sde as P
+    terms = SUMS[key]
+    d = sum({"matern12": 1, "matern32": 2, "matern52": 3}[t[0]] for t in terms)
+    rng = np.random.default_rng(100 * list(SUMS).index(key) + (spacing == "wild"))
+    T = 5000
+    x = _times(rng, T, spacing)
+    s2 = rng.random(T) * 0.2 + 0.05 if key in (2, "3b") else 0.1
+    y = rng.standard_normal(T)
+    ym = y.copy()
+    if key in (3, 4):
+        ym[rng.random(T) < 0.1] = np.nan
+    Rn = np.array([0.03])
+    lp_o = oc.gp_logpdf(_spec(terms), x, s2, y, None, np.isnan(ym))
+    m = P.build_lgssm(_kernel(P, terms), x, s2, device_components=True)
+    hd = m.handle()
+    hd.set_option(tgp._lib.OPT_PROFILE, 1)
+    lp = tgp.logpdf(m, ym)
+    info, names = hd.sweep_info(), set(hd.profile())
+    assert abs(lp - lp_o) <= 1e-10 * abs(lp_o), (lp, lp_o, info)
+    if d <= 4 and spacing == "uniform":
+        assert info["served"] == 1 and names == {"k_sweep<sde,logpdf>"}, (info, names)
+    elif info["served"] == 0:
+        assert "k_tile_dt" in names, names
+    hd.profile_reset()
+    pm = tgp.posterior_marginals(m, ym, Rn)
+    info2, names2 = hd.sweep_info(), set(hd.profile())
+    if d <= 4 and spacing == "uniform":
+        assert info2["served"] == 1 and names2 == {"k_sweep<sde,posterior>"}, (info2, names2)
+    ref_m = P.build_lgssm(_kernel(P, terms), x, s2, device_components=True)
+    hr = ref_m.handle()
+    hr.set_option(tgp._lib.OPT_SWEEP, 0)
+    hr.set_option(tgp._lib.OPT_SDE_CLOSED_FORM, 0)
+    pr = tgp.posterior_marginals(ref_m, ym, Rn)
+    assert hr.sweep_info()["served"] == 0
+    np.testing.assert_allclose(pm[0], pr[0], rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(pm[1], pr[1], rtol=1e-8, atol=1e-10)
+
+
 def _host_model(F, Pinf, H, R, times, ordering, first=None):
     """per-step blocks on the host: A_k = expm(F dt_k), Q_k = Pinf - A_k Pinf A_k', dt_1 := 1 (lti_sde.jl:139) unless `first` is given"""
     T, d = len(times), F.shape[0]
