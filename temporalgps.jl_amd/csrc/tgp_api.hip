@@ -328,6 +328,7 @@ struct tgp_handle {
     int opt_modal = 1;
     tgp_modal::Engine* modal = nullptr;
     int modal_state = 0;         // 0 untried for the bound model, 1 served the last call, -1 does not apply
+    int smooth_state = 0;        // the dense-powers one-launch smoother (smooth_lti_call): 0 untried / applies, -1 does not apply
     bool modal_last = false;
     int64_t dense_last_n0 = -1;   // >= 0: the last call ran on the dense-power one-launch kernels behind a head of that many steps with gains of their own
     // TGP_OPT_SWEEP (default 1): the sweep engine (tgp_sweep.hip) serves tgp_logpdf / tgp_[logpdf_and_]posterior_marginals of Forward
@@ -1555,6 +1556,7 @@ int tgp_set_option(tgp_handle* h, int option, int64_t value) {
         h->opt_modal = value >= 3;
         h->steady2_state = 0;
         h->modal_state = 0;
+        h->smooth_state = 0;
         h->steady_known = false;
         h->smoother_valid = false;
         return TGP_OK;
@@ -1685,6 +1687,7 @@ int tgp_model_set(tgp_handle* h, int64_t T, int d, int p, int ordering, uint32_t
     h->steady2_state = 0;
     h->steady2_last = false;
     h->modal_state = 0;
+    h->smooth_state = 0;
     h->modal_last = false;
     h->dense_last_n0 = -1;
     h->hostm.clear();
@@ -2028,6 +2031,7 @@ int tgp_model_set_x0(tgp_handle* h, const double* x0m, const double* x0P) {
     h->x0P.assign(x0P, x0P + (size_t)h->d * h->d);
     h->steady_known = false;
     h->modal_state = 0;
+    h->smooth_state = 0;
     if (h->is_dense) return dense_fail(h, tgp_dense::set_x0(h->dense, x0m, x0P, h->stream));
     h->fold_valid = false;
     h->smoother_valid = false;
@@ -2437,6 +2441,107 @@ static int filter_lti_call(tgp_handle* h, const double* y, uint32_t flags, doubl
     return TGP_OK;
 }
 
+// logpdf + posterior marginals of an LTI model WITHOUT a modal form (Forward, scalar observations, one noise variance, no missing data,
+// d <= 8; a defective closed loop: two summands with one length scale, ...): the head on the host, everything behind it in ONE kernel on the
+// dense powers of the closed loop and of the settled reverse-time transition (tgp_modal::smooth_lti).  *served = false: the
+// five-launch engine runs the call.
+static int smooth_lti_call(tgp_handle* h, const double* y, uint32_t flags, const double* Rnew, double* mean_out, double* var_out, double* lml_out, bool* served) {
+    *served = false;
+    tgp_plan::ModelHost mh;
+    if (!h->opt_modal || h->smooth_state < 0 || chunk_engine_requested(h) || h->is_dense || !h->lti || h->p != 1 || h->ordering != 0 || h->sde ||
+        h->d > tgp_plan::kRandMaxD || !modal_host_model(h, mh) || !mean_out || !var_out || !Rnew)
+        return TGP_OK;
+    const size_t nwg_max = (size_t)(h->T / 1024) + 2;
+    TRY(ensure_pinned(h, 3 * (size_t)tgp_plan::kHeadMax + nwg_max + 8 + tgp_plan::kTailMax + 8));
+    double *yh = h->flt_host, *hm = yh + tgp_plan::kHeadMax, *hv = hm + tgp_plan::kHeadMax, *tvb = hv + tgp_plan::kHeadMax, *xi = tvb + tgp_plan::kTailMax,
+           *part = xi + 8;
+    tgp_plan::SmoothPlan sp;
+    tgp_modal::plan_smooth(mh, h->T, sp, tvb);
+    if (sp.why != tgp_plan::kOk) {
+        h->smooth_state = -1;      // (a function of the model and T alone: the next call need not ask again)
+        return TGP_OK;
+    }
+    const tgp_plan::FilterPlan& fp = sp.fp;
+    const size_t nhs = (size_t)fp.nhs;
+    const long long nwg = tgp_modal::smooth_workgroups(sp, h->T);
+    if (nwg < 1 || (size_t)nwg > nwg_max) return TGP_OK;
+    const bool idev = (flags & TGP_IN_DEVICE) != 0, odev = (flags & TGP_OUT_DEVICE) != 0, rshared = (flags & TGP_SHARED_R) != 0;
+    const size_t nT = (size_t)h->T * sizeof(double);
+    CallTimer tm(h, /*clear=*/false);
+    const void* pR = nullptr;
+    TRY(stage_in(h, h->bRnew, Rnew, rshared ? sizeof(double) : nT, idev, &pR));
+    TRY(set_obs(h, y, nullptr, flags));
+    tm.inputs_done();
+    HIPCHK(hipMemcpyAsync(yh, h->mv.y, nhs * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    double mu_end[tgp_plan::kRandMaxD], quad_head = 0.0;
+    tgp_modal::plan_smooth_head_forward(mh, sp, yh, mu_end, &quad_head);
+    double *dm = nullptr, *dv = nullptr;
+    TRY(stage_out(h, h->bo1, mean_out, nT, odev, &dm));
+    TRY(stage_out(h, h->bo2, var_out, nT, odev, &dv));
+    tgp_modal::SmoothCall c;
+    c.T = h->T;
+    c.y = h->mv.y;
+    c.Rnew = static_cast<const double*>(pR);
+    c.rnew_per_step = rshared ? 0 : 1;
+    c.tvb = tvb;
+    c.mean = dm;
+    c.var = dv;
+    c.part = part;
+    c.xi_out = xi;
+    {
+        LaunchScope ls(h, "k_smooth_one");
+        const int rc = tgp_modal::smooth_lti(h->stream, sp, mu_end, c);
+        if (rc != 0) return h->fail(TGP_EHIP, std::string("tgp_posterior_marginals: launch: ") + hipGetErrorString((hipError_t)rc));
+    }
+    const bool tables_ok = tgp_modal::plan_smooth_head_tables(mh, sp);      // (beside the kernel)
+    tm.kernels_done();
+    TRY(copy_back(h, mean_out, dm, nT, odev));
+    TRY(copy_back(h, var_out, dv, nT, odev));
+    if (h->timing) (void)hipEventRecord(h->ev[3], h->stream);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    resolve_profile(h);
+    if (!tables_ok) {      // a head step's predicted covariance not positive definite: the older engines give the verdict
+        h->smooth_state = -1;
+        return TGP_OK;
+    }
+    // the head backwards from the kernel's xi at step nhs; its nhs outputs go where the rest went
+    tgp_modal::plan_smooth_head_backward(mh, sp, yh, xi, hm, hv);
+    if (rshared) {
+        double rn = 0.0;
+        if (idev) HIPCHK(hipMemcpy(&rn, Rnew, sizeof(double), hipMemcpyDeviceToHost));
+        else rn = Rnew[0];
+        for (size_t t = 0; t < nhs; ++t) hv[t] += rn;
+    } else if (idev) {
+        std::vector<double> tmp(nhs);
+        HIPCHK(hipMemcpy(tmp.data(), Rnew, nhs * sizeof(double), hipMemcpyDeviceToHost));
+        for (size_t t = 0; t < nhs; ++t) hv[t] += tmp[t];
+    } else {
+        for (size_t t = 0; t < nhs; ++t) hv[t] += Rnew[t];
+    }
+    if (odev) {
+        HIPCHK(hipMemcpyAsync(dm, hm, nhs * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(dv, hv, nhs * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    } else {
+        std::memcpy(mean_out, hm, nhs * sizeof(double));
+        std::memcpy(var_out, hv, nhs * sizeof(double));
+    }
+    double ssq = 0.0;
+    for (long long g = 0; g < nwg; ++g) ssq += part[g];
+    const double lml = -0.5 * ((double)h->T * 1.8378770664093454835606594728112 + fp.LS + (double)(h->T - fp.n0) * fp.logS + quad_head + fp.iS * ssq);
+    for (int i = 0; i < 8; ++i) h->host_result[i] = 0.0;
+    h->host_result[0] = lml;
+    if (lml_out) *lml_out = lml;
+    h->reduce_valid = false;
+    h->smoother_valid = false;
+    h->modal_last = false;
+    h->steady2_last = false;
+    h->dense_last_n0 = fp.n0;
+    *served = true;
+    return TGP_OK;
+}
+
 int tgp_filter(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t flags, double* m_out, double* P_out, double* lml_out) {
     TRY(check_ready(h, /*general=*/false));
     h->dense_last_n0 = -1;
@@ -2655,6 +2760,11 @@ int tgp_posterior_marginals(tgp_handle* h, const double* y, const uint8_t* missi
         bool served = false;
         TRY(modal_call(h, y, flags, Rnew, mean_out, var_out, lml_out, &served));
         if (served) return TGP_OK;
+        // no well-conditioned modal form: both recursions on dense powers, still ONE kernel
+        if (missing == nullptr && y != nullptr) {
+            TRY(smooth_lti_call(h, y, flags, Rnew, mean_out, var_out, lml_out, &served));
+            if (served) return TGP_OK;
+        }
     }
     if (steady2_eligible(h, missing, flags)) {
         CallTimer tm(h, /*clear=*/false);

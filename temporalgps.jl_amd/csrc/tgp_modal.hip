@@ -2494,4 +2494,465 @@ int adjoint_lti(hipStream_t stream, const tgp_plan::FilterPlan& fp, const double
     return (int)hipErrorInvalidValue;
 }
 
+// =================================================================================================================================
+// logpdf + posterior marginals of an LTI model behind its head on DENSE powers in BOTH directions (round 5): the models the modal
+// plan declines (a defective closed loop: two summands with one length scale, ...).  k_adjoint_one's skeleton -- spans with a halo at both ends,
+// forward sweep from zero + DPP scan on the powers of Phi, reverse sweep from zero + reverse DPP scan, tiles chained through LDS -- with the
+// smoother's recursion in the innovations going backwards, xi_t = c r_t + G xi_(t+1), on the powers of G (a second per-lane table), and no
+// second sweep in either direction: the lane's true start state reaches its innovations through the rows h' Phi^j, its right-hand xi reaches
+// its outputs through the rows h' G^(7-j) (the WJ / WG trick of k_steady_one, dense).  mean_t = y_t - (R/S) r_t + h' xi_(t+1);
+// var_t = h' Ps h + R_new (constant but for the last n1 steps: tvb, pinned host memory, read in place by the last tiles).
+// =================================================================================================================================
+namespace {
+template <int D>
+struct SArgs {
+    double Phi[D][D], a[D], kA[D], h[D], hh, rS, vb;
+    double P[6][D][D], PT[2][D][D];
+    double G[D][D], c[D];
+    double GP[6][D][D], GPT[2][D][D];
+    double WJ[kWJ][D], WG[kWJ][D];
+    double mu0[D];
+    long long T, C, nwg, nhs, n1;
+    int halo, rnew_per_step;
+    const double *y, *Rnew, *tvb;
+    double *mean, *var, *part, *xi_out;
+};
+
+template <int D, int NW, int MINW>
+__global__ __launch_bounds__(NW * 64, MINW) void k_smooth_one(const SArgs<D> by_value) {
+    (void)by_value;
+    const SArgs<D>& ka = *(const SArgs<D>*)__builtin_amdgcn_kernarg_segment_ptr();
+    constexpr int SUB = kWJ, TILE = 64 * SUB;
+    __shared__ double sF[NW][D], sB[NW][D], sAcc[NW];
+    __shared__ double sPw[D][D][64];       // Phi^(8 e), e = 0 .. 63
+    __shared__ double sPg[D][D][64];       // G^(8 e)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    long long g;
+    {
+        const long long per = (ka.nwg + 7) / 8;
+        g = (long long)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+        if ((long long)(blockIdx.x >> 3) >= per || g >= ka.nwg) return;
+    }
+    const long long T = ka.T, c_lo = ka.nhs + g * ka.C, c_hi = (c_lo + ka.C < T) ? c_lo + ka.C : T;
+    const bool first = g == 0;
+    const long long s0 = first ? ka.nhs : c_lo - ka.halo;
+    const long long tile_t0 = s0 + (long long)wave * TILE, t0 = tile_t0 + (long long)lane * SUB;
+    const bool any_valid = tile_t0 < T && tile_t0 < c_hi + ka.halo;      // (wave-uniform: tiles behind the right-hand halo have nothing to do)
+    // ---- the observations first (they are on their way while the tables are built)
+    double u[SUB];
+#pragma unroll
+    for (int j = 0; j < SUB; ++j) u[j] = 0.0;
+    if (any_valid) {
+        if (t0 + SUB <= T && (reinterpret_cast<uintptr_t>(ka.y) & 15) == 0) {
+            const v2d* q = reinterpret_cast<const v2d*>(ka.y + t0);
+#pragma unroll
+            for (int j = 0; j < SUB / 2; ++j) {
+                const v2d w = q[j];
+                u[2 * j] = w.x - ka.hh;
+                u[2 * j + 1] = w.y - ka.hh;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < SUB; ++j) u[j] = t0 + j < T ? ka.y[t0 + j] - ka.hh : 0.0;
+        }
+    }
+    {   // the per-lane power tables: row i of Phi^(8 lane) and of G^(8 lane), the 2 D rows dealt over the waves
+        const int uw = __builtin_amdgcn_readfirstlane(wave);
+#pragma unroll
+        for (int i2 = 0; i2 < 2 * D; ++i2) {
+            if (uw != i2 % NW) continue;
+            const int i = i2 % D;
+            const bool isg = i2 >= D;
+            double row[D];
+#pragma unroll
+            for (int k = 0; k < D; ++k) row[k] = (k == i) ? 1.0 : 0.0;
+#pragma unroll
+            for (int b = 0; b < 6; ++b) {
+                double nr[D];
+#pragma unroll
+                for (int k = 0; k < D; ++k) {
+                    double v = 0.0;
+#pragma unroll
+                    for (int m = 0; m < D; ++m) v = fma(row[m], isg ? ka.GP[b][m][k] : ka.P[b][m][k], v);
+                    nr[k] = v;
+                }
+                const bool bit = ((lane >> b) & 1) != 0;
+#pragma unroll
+                for (int k = 0; k < D; ++k) row[k] = bit ? nr[k] : row[k];
+            }
+            if (isg) {
+#pragma unroll
+                for (int k = 0; k < D; ++k) sPg[i][k][lane] = row[k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < D; ++k) sPw[i][k][lane] = row[k];
+            }
+        }
+    }
+    // ---- forward, zero start: the lane's innovations r0 and its end state
+    double r[SUB], x[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) x[i] = 0.0;
+#pragma unroll
+    for (int j = 0; j < SUB; ++j) r[j] = 0.0;
+    if (any_valid) {
+#pragma unroll
+        for (int j = 0; j < SUB; ++j) {
+            double rr = u[j];
+#pragma unroll
+            for (int k = 0; k < D; ++k) rr = fma(-ka.h[k], x[k], rr);
+            r[j] = rr;
+            double nx[D];
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                double v = fma(ka.kA[i], u[j], ka.a[i]);
+#pragma unroll
+                for (int k = 0; k < D; ++k) v = fma(ka.Phi[i][k], x[k], v);
+                nx[i] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < D; ++i) x[i] = nx[i];
+        }
+    }
+    __syncthreads();
+    double st[D];
+    if (any_valid) {
+#define TGP_SM_FWD(K)                                                                      \
+    do {                                                                                   \
+        double g_[D], n_[D];                                                               \
+        _Pragma("unroll") for (int i = 0; i < D; ++i) {                                    \
+            g_[i] = dpp_mov<0x110 + (1 << (K))>(x[i]);                                     \
+            n_[i] = x[i];                                                                  \
+        }                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < D; ++i)                                      \
+            _Pragma("unroll") for (int k = 0; k < D; ++k) n_[i] = fma(ka.P[K][i][k], g_[k], n_[i]); \
+        _Pragma("unroll") for (int i = 0; i < D; ++i) x[i] = n_[i];                        \
+    } while (0)
+        TGP_SM_FWD(0);
+        TGP_SM_FWD(1);
+        TGP_SM_FWD(2);
+        TGP_SM_FWD(3);
+#undef TGP_SM_FWD
+        const int e1 = (lane & 15) + 1, e2 = lane >= 32 ? lane - 31 : 0;
+        double gv[D], nv[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            gv[i] = dpp_mov<0x142, 0xA>(x[i]);
+            nv[i] = x[i];
+        }
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int k = 0; k < D; ++k) nv[i] = fma(sPw[i][k][e1], gv[k], nv[i]);
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            x[i] = nv[i];
+            gv[i] = dpp_mov<0x143, 0xC>(nv[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int k = 0; k < D; ++k) nv[i] = fma(sPw[i][k][e2], gv[k], nv[i]);
+#pragma unroll
+        for (int i = 0; i < D; ++i) x[i] = nv[i];
+    }
+#pragma unroll
+    for (int i = 0; i < D; ++i) st[i] = dpp_mov<0x138>(x[i]);
+    if (lane == 63) {
+#pragma unroll
+        for (int i = 0; i < D; ++i) sF[wave][i] = any_valid ? x[i] : 0.0;
+    }
+    __syncthreads();
+    // ---- the true start state -> the true innovations (r = r0 - h' Phi^j st); the reverse sweep from zero
+    double xi[D], o0[SUB], acc = 0.0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) xi[i] = 0.0;
+#pragma unroll
+    for (int j = 0; j < SUB; ++j) o0[j] = 0.0;
+    if (any_valid) {
+        double zin[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) zin[i] = 0.0;
+#pragma unroll
+        for (int k = 1; k <= 3; ++k) {
+            const int src = wave - k;
+            if (src < -1 || (src == -1 && !first)) continue;
+            double xs[D];
+#pragma unroll
+            for (int i = 0; i < D; ++i) xs[i] = src >= 0 ? sF[src][i] : ka.mu0[i];
+            if (k == 1) {
+#pragma unroll
+                for (int i = 0; i < D; ++i) zin[i] += xs[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < D; ++i)
+#pragma unroll
+                    for (int m = 0; m < D; ++m) zin[i] = fma(ka.PT[k - 2][i][m], xs[m], zin[i]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int k = 0; k < D; ++k) st[i] = fma(sPw[i][k][lane], zin[k], st[i]);
+#pragma unroll
+        for (int j = 0; j < SUB; ++j) {
+            double rr = r[j];
+#pragma unroll
+            for (int k = 0; k < D; ++k) rr = fma(-ka.WJ[j][k], st[k], rr);
+            const long long t = t0 + j;
+            rr = t < T ? rr : 0.0;      // (steps behind the series' end: no innovation)
+            r[j] = rr;
+            if (t >= c_lo && t < c_hi) acc = fma(rr, rr, acc);
+            o0[j] = fma(-ka.rS, rr, u[j] + ka.hh);      // h' m_t + hh = y_t - (R / S) r_t: what the smoother adds h' xi_(t+1) to
+        }
+        if (ka.mean != nullptr) {
+#pragma unroll
+            for (int j = SUB - 1; j >= 0; --j) {
+                double o = o0[j];
+#pragma unroll
+                for (int k = 0; k < D; ++k) o = fma(ka.h[k], xi[k], o);
+                o0[j] = o;
+                double np[D];
+#pragma unroll
+                for (int i = 0; i < D; ++i) {
+                    double v = ka.c[i] * r[j];
+#pragma unroll
+                    for (int k = 0; k < D; ++k) v = fma(ka.G[i][k], xi[k], v);
+                    np[i] = v;
+                }
+#pragma unroll
+                for (int i = 0; i < D; ++i) xi[i] = np[i];
+            }
+            // reverse scan: lane l <- sum_{m >= l} G^(8 (m - l)) xi_m
+#define TGP_SM_BWD(K)                                                                      \
+    do {                                                                                   \
+        double g_[D], n_[D];                                                               \
+        _Pragma("unroll") for (int i = 0; i < D; ++i) {                                    \
+            g_[i] = dpp_mov<0x100 + (1 << (K))>(xi[i]);                                    \
+            n_[i] = xi[i];                                                                 \
+        }                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < D; ++i)                                      \
+            _Pragma("unroll") for (int k = 0; k < D; ++k) n_[i] = fma(ka.GP[K][i][k], g_[k], n_[i]); \
+        _Pragma("unroll") for (int i = 0; i < D; ++i) xi[i] = n_[i];                       \
+    } while (0)
+            TGP_SM_BWD(0);
+            TGP_SM_BWD(1);
+            TGP_SM_BWD(2);
+            TGP_SM_BWD(3);
+#undef TGP_SM_BWD
+            {
+                const int e1 = 16 - (lane & 15);      // rows 0 and 2 take the first lane of the row above them, 16 - p lanes away
+                double gv[D], nv[D];
+#pragma unroll
+                for (int i = 0; i < D; ++i) {
+                    gv[i] = dpp_mov<0x15F, 0x5>(dpp_mov<0x130>(xi[i]));
+                    nv[i] = xi[i];
+                }
+#pragma unroll
+                for (int i = 0; i < D; ++i)
+#pragma unroll
+                    for (int k = 0; k < D; ++k) nv[i] = fma(sPg[i][k][e1], gv[k], nv[i]);
+#pragma unroll
+                for (int i = 0; i < D; ++i) xi[i] = nv[i];
+                const int e2 = lane < 32 ? 32 - lane : 0;      // the lower half takes lane 32
+                const double keep = lane < 32 ? 1.0 : 0.0;
+#pragma unroll
+                for (int i = 0; i < D; ++i) gv[i] = readlane_d(xi[i], 32) * keep;
+#pragma unroll
+                for (int i = 0; i < D; ++i)
+#pragma unroll
+                    for (int k = 0; k < D; ++k) nv[i] = fma(sPg[i][k][e2], gv[k], nv[i]);
+#pragma unroll
+                for (int i = 0; i < D; ++i) xi[i] = nv[i];
+            }
+        }
+    }
+    if (ka.mean != nullptr) {      // (kernel-uniform)
+        double pin[D];      // xi behind the lane's last step: its right neighbour's (lane 63: zero)
+#pragma unroll
+        for (int i = 0; i < D; ++i) pin[i] = dpp_mov<0x130>(xi[i]);
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < D; ++i) sB[wave][i] = any_valid ? xi[i] : 0.0;
+        }
+        __syncthreads();
+        if (any_valid) {
+            double zin[D];
+#pragma unroll
+            for (int i = 0; i < D; ++i) zin[i] = 0.0;
+#pragma unroll
+            for (int k = 1; k <= 3; ++k) {
+                const int src = wave + k;
+                if (src >= NW) continue;
+                if (k == 1) {
+#pragma unroll
+                    for (int i = 0; i < D; ++i) zin[i] += sB[src][i];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < D; ++i)
+#pragma unroll
+                        for (int m = 0; m < D; ++m) zin[i] = fma(ka.GPT[k - 2][i][m], sB[src][m], zin[i]);
+                }
+            }
+            const int eb = 63 - lane;
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int k = 0; k < D; ++k) pin[i] = fma(sPg[i][k][eb], zin[k], pin[i]);
+            if (first && wave == 0 && lane == 0) {      // xi at step nhs: where the host's half takes over (G^512 zin + the tile's own)
+#pragma unroll
+                for (int i = 0; i < D; ++i) {
+                    double v = xi[i];
+#pragma unroll
+                    for (int k = 0; k < D; ++k) v = fma(ka.GPT[0][i][k], zin[k], v);
+                    ka.xi_out[i] = v;
+                }
+            }
+            // ---- outputs of the steps the workgroup owns
+            const bool whole = t0 >= c_lo && t0 + SUB <= c_hi;
+            const bool al = ((reinterpret_cast<uintptr_t>(ka.mean) | reinterpret_cast<uintptr_t>(ka.var)) & 15) == 0;
+            const double rn0 = ka.rnew_per_step ? 0.0 : ka.Rnew[0];
+            const bool in_tail = t0 + SUB > T - ka.n1;
+            const bool wide = whole && al;      // (t0 is a multiple of 8: spans start on multiples of 16 behind nhs, itself one)
+#pragma unroll
+            for (int j2 = 0; j2 < SUB; j2 += 2) {
+                double om[2], ov[2];
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int j = j2 + jj;
+                    const long long t = t0 + j;
+                    double o = o0[j];
+#pragma unroll
+                    for (int k = 0; k < D; ++k) o = fma(ka.WG[j][k], pin[k], o);
+                    om[jj] = o;
+                    double v = ka.vb;
+                    if (in_tail && t < T && T - 1 - t < ka.n1) v = ka.tvb[T - 1 - t];
+                    if (ka.rnew_per_step) v += (t < T ? ka.Rnew[t] : 0.0);
+                    else v += rn0;
+                    ov[jj] = v;
+                }
+                if (wide) {
+                    v2d w;
+                    w.x = om[0];
+                    w.y = om[1];
+                    reinterpret_cast<v2d*>(ka.mean + t0)[j2 / 2] = w;
+                    w.x = ov[0];
+                    w.y = ov[1];
+                    reinterpret_cast<v2d*>(ka.var + t0)[j2 / 2] = w;
+                } else {
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        const long long t = t0 + j2 + jj;
+                        if (t >= c_lo && t < c_hi) {
+                            ka.mean[t] = om[jj];
+                            ka.var[t] = ov[jj];
+                        }
+                    }
+                }
+            }
+        }
+    }
+    acc = wave_sum_to_lane63(acc);
+    if (lane == 63) sAcc[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tsum = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) tsum += sAcc[w];
+        ka.part[g] = tsum;
+    }
+}
+
+template <int D>
+int launch_smooth(hipStream_t st, const tgp_plan::SmoothPlan& sp, const double* mu0, const SmoothCall& c) {
+    constexpr int NW = 8;
+    const tgp_plan::FilterPlan& fp = sp.fp;
+    SArgs<D> ka;
+    static_assert(sizeof(SArgs<D>) <= 11264, "the kernel-argument segment (12 KB launch on gfx950: scripts/micro/bigarg.hip)");
+    std::memset(&ka, 0, sizeof ka);
+    for (int i = 0; i < D; ++i) {
+        ka.a[i] = fp.a[i];
+        ka.kA[i] = fp.kA[i];
+        ka.h[i] = fp.h[i];
+        ka.c[i] = sp.c[i];
+        ka.mu0[i] = mu0[i];
+        for (int j = 0; j < kWJ; ++j) {
+            ka.WJ[j][i] = sp.WJ[j][i];
+            ka.WG[j][i] = sp.WG[j][i];
+        }
+        for (int k = 0; k < D; ++k) {
+            ka.Phi[i][k] = fp.Phi[i * D + k];
+            ka.G[i][k] = sp.G[i * D + k];
+            for (int b = 0; b < 6; ++b) {
+                ka.P[b][i][k] = fp.P[b][i * D + k];
+                ka.GP[b][i][k] = sp.GP[b][i * D + k];
+            }
+            for (int b = 0; b < 2; ++b) {
+                ka.PT[b][i][k] = fp.PT[b][i * D + k];
+                ka.GPT[b][i][k] = sp.GPT[b][i * D + k];
+            }
+        }
+    }
+    ka.hh = fp.hh;
+    ka.rS = sp.rS;
+    ka.vb = sp.vb;
+    ka.T = c.T;
+    ka.nhs = fp.nhs;
+    ka.n1 = sp.n1;
+    ka.halo = sp.halo;
+    ka.C = smooth_span(sp);
+    ka.nwg = (c.T - fp.nhs + ka.C - 1) / ka.C;
+    ka.rnew_per_step = c.rnew_per_step;
+    ka.y = c.y;
+    ka.Rnew = c.Rnew;
+    ka.tvb = c.tvb;
+    ka.mean = c.mean;
+    ka.var = c.var;
+    ka.part = c.part;
+    ka.xi_out = c.xi_out;
+    const long long per = (ka.nwg + 7) / 8;
+    static const int minw_env = [] { const char* v = std::getenv("TGP_SMOOTH_MINW"); return v ? std::atoi(v) : 0; }();
+    const bool four = minw_env ? minw_env >= 4 : D <= 6;
+    if (four && D <= 6) hipLaunchKernelGGL((k_smooth_one<D, NW, (D <= 6 ? 4 : 2)>), dim3((unsigned)(per * 8)), dim3(NW * 64), 0, st, ka);
+    else hipLaunchKernelGGL((k_smooth_one<D, NW, 2>), dim3((unsigned)(per * 8)), dim3(NW * 64), 0, st, ka);
+    return (int)hipGetLastError();
+}
+}  // namespace
+
+long long smooth_span(const tgp_plan::SmoothPlan& sp) { return 8LL * 64 * kWJ - 2LL * sp.halo; }
+long long smooth_workgroups(const tgp_plan::SmoothPlan& sp, long long T) {
+    const long long C = smooth_span(sp);
+    return C > 0 ? (T - sp.fp.nhs + C - 1) / C : -1;
+}
+
+int smooth_lti(hipStream_t stream, const tgp_plan::SmoothPlan& sp, const double* mu_start, const SmoothCall& c) {
+    switch (sp.fp.d) {
+        case 1: return launch_smooth<1>(stream, sp, mu_start, c);
+        case 2: return launch_smooth<2>(stream, sp, mu_start, c);
+        case 3: return launch_smooth<3>(stream, sp, mu_start, c);
+        case 4: return launch_smooth<4>(stream, sp, mu_start, c);
+        case 5: return launch_smooth<5>(stream, sp, mu_start, c);
+        case 6: return launch_smooth<6>(stream, sp, mu_start, c);
+        case 7: return launch_smooth<7>(stream, sp, mu_start, c);
+        case 8: return launch_smooth<8>(stream, sp, mu_start, c);
+    }
+    return (int)hipErrorInvalidValue;
+}
+
+void plan_smooth(const tgp_plan::ModelHost& m, long long T, tgp_plan::SmoothPlan& sp, double* tvb) {
+    if (!host_cpu_ok()) {
+        sp.why = tgp_plan::kEigFail;
+        return;
+    }
+    tgp_plan::build_smooth_any(m, T, sp, tvb);
+    if (sp.why == tgp_plan::kOk && smooth_span(sp) < 1024) sp.why = tgp_plan::kSlowMixing;      // (halos would eat three quarters of a span)
+}
+void plan_smooth_head_forward(const tgp_plan::ModelHost& m, const tgp_plan::SmoothPlan& sp, const double* y, double* mu_end, double* quad) {
+    tgp_plan::smooth_head_forward_any(m, sp, y, mu_end, quad);
+}
+bool plan_smooth_head_tables(const tgp_plan::ModelHost& m, const tgp_plan::SmoothPlan& sp) { return tgp_plan::smooth_head_tables_any(m, sp); }
+void plan_smooth_head_backward(const tgp_plan::ModelHost& m, const tgp_plan::SmoothPlan& sp, const double* y, const double* lam, double* mean, double* vb) {
+    tgp_plan::smooth_head_backward_any(m, sp, y, lam, mean, vb);
+}
+
 }  // namespace tgp_modal

@@ -82,6 +82,25 @@ constexpr int kAdjointMaxD = 6;
 inline int adjoint_sums(int d) { return d * d + 3 * d + 2; }
 long long adjoint_workgroups(const tgp_plan::FilterPlan& plan, long long T);
 int adjoint_lti(hipStream_t stream, const tgp_plan::FilterPlan& plan, const double* mu_start, const double* y, long long T, double* part, double* psi_out);
+// logpdf + posterior marginals of an LTI model behind its head in ONE kernel on DENSE powers of the closed loop (forwards) and of the settled
+// reverse-time transition (backwards): the models the modal plan declines (d <= tgp_plan::kRandMaxD).  The head runs on the host
+// (plan_smooth_head_*: forwards before the launch, its data-free tables beside the kernel, backwards behind it from xi_out).
+// mean == nullptr: logpdf only.  part: smooth_workgroups() values, xi_out: d values, tvb: tgp_plan::kTailMax values -- pinned host memory.
+struct SmoothCall {
+    long long T = 0;
+    const double *y = nullptr, *Rnew = nullptr;      // device
+    int rnew_per_step = 0;
+    const double* tvb = nullptr;
+    double *mean = nullptr, *var = nullptr;          // device
+    double *part = nullptr, *xi_out = nullptr;
+};
+void plan_smooth(const tgp_plan::ModelHost& m, long long T, tgp_plan::SmoothPlan& sp, double* tvb);
+void plan_smooth_head_forward(const tgp_plan::ModelHost& m, const tgp_plan::SmoothPlan& sp, const double* y, double* mu_end, double* quad);
+bool plan_smooth_head_tables(const tgp_plan::ModelHost& m, const tgp_plan::SmoothPlan& sp);
+void plan_smooth_head_backward(const tgp_plan::ModelHost& m, const tgp_plan::SmoothPlan& sp, const double* y, const double* lam, double* mean, double* vb);
+long long smooth_span(const tgp_plan::SmoothPlan& sp);
+long long smooth_workgroups(const tgp_plan::SmoothPlan& sp, long long T);
+int smooth_lti(hipStream_t stream, const tgp_plan::SmoothPlan& sp, const double* mu_start, const SmoothCall& c);
 int rand_lti(hipStream_t stream, const tgp_plan::RandPlan& plan, const double* x0, const double* eps_t, const double* eps_e, long long T, double* y,
              const char** kname);
 

@@ -1416,6 +1416,312 @@ inline void filter_head_any(const ModelHost& m, const FilterPlan& fp, const doub
     }
 }
 
+// ---- logpdf + posterior marginals of an LTI model on DENSE powers in both directions (round 5; k_smooth_one).  For the models
+// build_core declines for want of a modal form (kIllConditioned: two summands with one length scale, ...; kEigFail).  Forwards the filter's
+// plan above (mu' = Phi mu + a + (A K) u, r = u - h' mu); backwards the smoother in the innovations (lgssm.jl:111-115 re-associated as in
+// build_core):  xi_t = c r_t + G xi_(t+1),  c = G K,  G the settled reverse-time transition of invert_dynamics (:231-238, jitter included),
+// mean_t = y_t - (R / S) r_t + h' xi_(t+1) -- an affine recursion with ONE matrix, run by the kernel on the dense powers of G.  The head's two
+// recursions (gains of their own) run on the host: forwards before the launch, backwards behind it from the xi the kernel hands back.
+struct SmoothPlan {
+    FilterPlan fp;
+    int why = kOk, halo = 0, n1 = -1;
+    double G[kRandMaxD * kRandMaxD], c[kRandMaxD], rS = 0.0, vb = 0.0;       // G row-major
+    double GP[6][kRandMaxD * kRandMaxD], GPT[2][kRandMaxD * kRandMaxD];      // G^(8 2^k); G^512, G^1024
+    double WJ[kSub][kRandMaxD];      // h' Phi^j: the innovation j steps behind a lane's start state st is r0_j - WJ[j] . st
+    double WG[kSub][kRandMaxD];      // h' G^(7-j): the output of the lane's step j sees the lane's right-hand input through it
+};
+template <int D>
+struct SmoothWork {
+    double Gss[D][D], Lss[D][D], Psinf[D][D];
+    double r[kHeadMax], G[kHeadMax + 1][D][D], vb[kHeadMax + 1];      // head: innovations, G_t (step t -> t - 1), h' Ps_t h
+};
+template <int D>
+inline SmoothWork<D>& smooth_work() {
+    static thread_local SmoothWork<D> w;
+    return w;
+}
+
+// tvb [kTailMax]: h' Ps h of the steps T - 1 - j, j < n1 (the smoothed covariance's transient at the series' end)
+template <int D>
+inline void build_smooth(const ModelHost& m, long long T, SmoothPlan& sp, double* tvb) {
+    using namespace detail;
+    build_filter<D>(m, T, sp.fp);
+    sp.why = sp.fp.why;
+    if (sp.why != kOk) return;
+    const FilterPlan& fp = sp.fp;
+    const FilterWork<D>& fw = filter_work<D>();
+    SmoothWork<D>& sw = smooth_work<D>();
+    const int n0 = fp.n0;
+    double A[D][D], At[D][D], Q[D][D], Pf[D][D], Pp[D][D], t1[D][D], hv[D];
+    for (int i = 0; i < D; ++i) {
+        hv[i] = fp.h[i];
+        for (int k = 0; k < D; ++k) {
+            A[i][k] = fw.A[i][k];
+            const int r = i < k ? i : k, c = i < k ? k : i;
+            Q[i][k] = m.Q[r + c * D];
+            Pf[i][k] = 0.5 * (fw.Pf[n0][i][k] + fw.Pf[n0][k][i]);
+        }
+    }
+    transpose<D>(A, At);
+    mm<D>(A, Pf, t1);
+    mm<D>(t1, At, Pp);
+    for (int i = 0; i < D; ++i)
+        for (int k = 0; k < D; ++k) Pp[i][k] += Q[i][k];
+    if (!invert_dynamics<D>(A, Pf, Pp, sw.Gss, sw.Lss)) {
+        sp.why = kNotPD;
+        return;
+    }
+    sp.rS = m.R[0] * fp.iS;
+    for (int i = 0; i < D; ++i) {
+        double v = 0.0;
+        for (int k = 0; k < D; ++k) {
+            v = pfma(sw.Gss[i][k], fp.K[k], v);
+            sp.G[i * D + k] = sw.Gss[i][k];
+        }
+        sp.c[i] = v;
+    }
+    // the stationary smoothed covariance: Ps = G Ps G' + L by doubling (as build_core)
+    {
+        double S[D][D], M[D][D];
+        std::memcpy(S, sw.Lss, sizeof S);
+        std::memcpy(M, sw.Gss, sizeof M);
+        bool done = false;
+        for (int it = 0; it < 48 && !done; ++it) {
+            double u1[D][D], u2[D][D], M2[D][D], Mt[D][D];
+            double mmax = 0.0;
+            for (int i = 0; i < D; ++i)
+                for (int j = 0; j < D; ++j) mmax = std::max(mmax, std::fabs(M[i][j]));
+            mm<D>(M, S, u1);
+            transpose<D>(M, Mt);
+            mm<D>(u1, Mt, u2);
+            mm<D>(M, M, M2);
+            for (int i = 0; i < D; ++i)
+                for (int j = i; j < D; ++j) {
+                    const double v = S[i][j] + 0.5 * (u2[i][j] + u2[j][i]);
+                    S[i][j] = S[j][i] = v;
+                }
+            std::memcpy(M, M2, sizeof M);
+            done = mmax < 1e-10;
+        }
+        if (!done) {
+            sp.why = kSlowMixing;
+            return;
+        }
+        std::memcpy(sw.Psinf, S, sizeof S);
+    }
+    sp.vb = quad_sym<D>(hv, sw.Psinf);
+    // the smoothed variances backwards from the final filtered state (build_tables_variances): tvb_j = sum_{k < j} g_k L g_k' + g_j Pss g_j', g_k = h' G^k
+    {
+        int n1 = -1;
+        double g[D], Lsym[D][D], Psym[D][D];
+        for (int i = 0; i < D; ++i) {
+            g[i] = hv[i];
+            for (int j = 0; j < D; ++j) {
+                Lsym[i][j] = (i <= j) ? sw.Lss[i][j] : sw.Lss[j][i];
+                Psym[i][j] = Pf[i][j];
+            }
+        }
+        auto quad = [&](const double (&M)[D][D], const double (&x)[D]) {
+            double s = 0.0;
+            for (int i = 0; i < D; ++i) {
+                double v = 0.0;
+                for (int j = 0; j < D; ++j) v += M[i][j] * x[j];
+                s += x[i] * v;
+            }
+            return s;
+        };
+        double acc = 0.0, prev = 0.0, prev2 = 0.0;
+        for (int jt = 0; jt < kTailMax; ++jt) {
+            const double v = acc + quad(Psym, g);
+            tvb[jt] = v;
+            if (jt >= 1 && (std::fabs(v - prev) <= kTol * std::fabs(v) || (jt >= 2 && v == prev2)) && std::fabs(v - sp.vb) <= 1e-9 * std::fabs(sp.vb)) {
+                n1 = jt + 1;
+                break;
+            }
+            prev2 = prev;
+            prev = v;
+            acc += quad(Lsym, g);
+            double ng[D];
+            for (int j = 0; j < D; ++j) ng[j] = 0.0;
+            for (int i = 0; i < D; ++i) {
+                const double f = g[i];
+                for (int j = 0; j < D; ++j) ng[j] += f * sw.Gss[i][j];
+            }
+            for (int j = 0; j < D; ++j) g[j] = ng[j];
+        }
+        if (n1 < 0) {
+            sp.why = kTailLong;
+            return;
+        }
+        sp.n1 = n1;
+        if ((long long)fp.nhs + n1 + 16 > T) {
+            sp.why = kTooShort;
+            return;
+        }
+    }
+    // dense powers of G, its halo; the rows WJ, WG
+    auto put = [](const double (&M)[D][D], double* out) {
+        for (int i = 0; i < D; ++i)
+            for (int k = 0; k < D; ++k) out[i * D + k] = M[i][k];
+    };
+    double X[D][D], Y[D][D], P16[D][D];
+    std::memcpy(X, sw.Gss, sizeof X);
+    for (int q = 0; q < 3; ++q) {
+        mm<D>(X, X, Y);
+        std::memcpy(X, Y, sizeof X);
+    }
+    for (int k = 0; k < 8; ++k) {
+        if (k < 6) put(X, sp.GP[k]);
+        else put(X, sp.GPT[k - 6]);
+        if (k == 1) std::memcpy(P16, X, sizeof X);
+        mm<D>(X, X, Y);
+        std::memcpy(X, Y, sizeof X);
+    }
+    {
+        double M[D][D];
+        std::memcpy(M, P16, sizeof M);
+        int n = 16;
+        const double tiny = std::ldexp(1.0, -60);
+        for (;;) {
+            double mx = 0.0;
+            for (int i = 0; i < D; ++i)
+                for (int k = 0; k < D; ++k) mx = std::max(mx, std::fabs(M[i][k]));
+            if (!std::isfinite(mx) || n > kHaloMax) {
+                sp.why = kSlowMixing;
+                return;
+            }
+            if (mx <= tiny) break;
+            mm<D>(M, P16, Y);
+            std::memcpy(M, Y, sizeof M);
+            n += 16;
+        }
+        sp.halo = std::max(n, fp.halo);
+    }
+    {
+        double x[D], nx[D];
+        for (int i = 0; i < D; ++i) x[i] = hv[i];
+        for (int j = 0; j < kSub; ++j) {      // row times Phi
+            for (int i = 0; i < D; ++i) sp.WJ[j][i] = x[i];
+            for (int k = 0; k < D; ++k) {
+                double v = 0.0;
+                for (int i = 0; i < D; ++i) v = pfma(x[i], fp.Phi[i * D + k], v);
+                nx[k] = v;
+            }
+            for (int i = 0; i < D; ++i) x[i] = nx[i];
+        }
+        for (int i = 0; i < D; ++i) x[i] = hv[i];
+        for (int j = kSub - 1; j >= 0; --j) {
+            for (int i = 0; i < D; ++i) sp.WG[j][i] = x[i];
+            for (int k = 0; k < D; ++k) {
+                double v = 0.0;
+                for (int i = 0; i < D; ++i) v = pfma(x[i], sw.Gss[i][k], v);
+                nx[k] = v;
+            }
+            for (int i = 0; i < D; ++i) x[i] = nx[i];
+        }
+    }
+}
+
+// The head forwards (before the launch): y [nhs] -> the innovations (kept for the way back), the predicted mean of step nhs, sum r^2 / S_t
+template <int D>
+inline void smooth_head_forward(const ModelHost& m, const SmoothPlan& sp, const double* y, double* mu_end, double* quad) {
+    const FilterPlan& fp = sp.fp;
+    const FilterWork<D>& fw = filter_work<D>();
+    SmoothWork<D>& sw = smooth_work<D>();
+    double mu[D], nm[D];
+    for (int i = 0; i < D; ++i) {
+        double v = m.a[i];
+        for (int k = 0; k < D; ++k) v += fw.A[i][k] * m.x0m[k];
+        mu[i] = v;
+    }
+    double q = 0.0;
+    for (int t = 0; t < fp.nhs; ++t) {
+        const int ti = t < fp.n0 ? t : fp.n0;
+        double r = y[t] - fp.hh;
+        for (int k = 0; k < D; ++k) r -= fp.h[k] * mu[k];
+        sw.r[t] = r;
+        q += r * r * fw.iS[ti];
+        for (int i = 0; i < D; ++i) {
+            double v = m.a[i] + fw.kA[ti][i] * r;
+            for (int k = 0; k < D; ++k) v += fw.A[i][k] * mu[k];
+            nm[i] = v;
+        }
+        for (int i = 0; i < D; ++i) mu[i] = nm[i];
+    }
+    for (int i = 0; i < D; ++i) mu_end[i] = mu[i];
+    *quad = q;
+}
+// The head's data-free tables (beside the kernel): G_t of every head step with gains of its own, the smoothed variances h' Ps_t h, t < nhs.
+// false: a predicted covariance is not positive definite.
+template <int D>
+inline bool smooth_head_tables(const ModelHost& m, const SmoothPlan& sp) {
+    using namespace detail;
+    const FilterPlan& fp = sp.fp;
+    const FilterWork<D>& fw = filter_work<D>();
+    SmoothWork<D>& sw = smooth_work<D>();
+    double A[D][D], At[D][D], Q[D][D], hv[D];
+    for (int i = 0; i < D; ++i) {
+        hv[i] = fp.h[i];
+        for (int k = 0; k < D; ++k) {
+            A[i][k] = fw.A[i][k];
+            const int r = i < k ? i : k, c = i < k ? k : i;
+            Q[i][k] = m.Q[r + c * D];
+        }
+    }
+    transpose<D>(A, At);
+    // G_t, t = 1 .. nhs - 1, takes step t to step t - 1: invert_dynamics(filtered t - 1, predicted t); settled once t - 1 >= n0
+    const int tset = std::min(fp.nhs - 1, fp.n0 + 1);      // G_t = Gss for t >= tset
+    double Pc[D][D];
+    std::memcpy(Pc, sw.Psinf, sizeof Pc);
+    for (int t = fp.nhs - 1; t >= tset; --t) {
+        std::memcpy(sw.G[t], sw.Gss, sizeof sw.Gss);
+        sw.vb[t] = sp.vb;
+    }
+    // (Ps_t = Psinf for t >= tset - 1: the steps behind are settled and the series' end is more than n1 steps away)
+    for (int t = tset - 1; t >= 1; --t) {
+        double Pf[D][D], Pp[D][D], t1[D][D], L[D][D], pn[D][D];
+        for (int i = 0; i < D; ++i)
+            for (int k = 0; k < D; ++k) Pf[i][k] = 0.5 * (fw.Pf[t - 1][i][k] + fw.Pf[t - 1][k][i]);
+        mm<D>(A, Pf, t1);
+        mm<D>(t1, At, Pp);
+        for (int i = 0; i < D; ++i)
+            for (int k = 0; k < D; ++k) Pp[i][k] += Q[i][k];
+        if (!invert_dynamics<D>(A, Pf, Pp, sw.G[t], L)) return false;
+        sw.vb[t] = quad_sym<D>(hv, Pc);
+        smooth_cov_step<D>(sw.G[t], L, Pc, pn);
+        std::memcpy(Pc, pn, sizeof pn);
+    }
+    sw.vb[0] = quad_sym<D>(hv, Pc);
+    if (tset - 1 < 1 && fp.nhs >= 1) sw.vb[0] = sp.vb;
+    return true;
+}
+// The head backwards (behind the kernel): lam = xs - m of step nhs - 1 (the kernel's xi at step nhs) -> mean [nhs], vb [nhs] = h' Ps_t h
+template <int D>
+inline void smooth_head_backward(const ModelHost& m, const SmoothPlan& sp, const double* y, const double* lam_in, double* mean, double* vb) {
+    const FilterPlan& fp = sp.fp;
+    const FilterWork<D>& fw = filter_work<D>();
+    const SmoothWork<D>& sw = smooth_work<D>();
+    double lam[D], nl[D];
+    for (int i = 0; i < D; ++i) lam[i] = lam_in[i];
+    const double R = m.R[0];
+    for (int t = fp.nhs - 1; t >= 0; --t) {
+        const int ti = t < fp.n0 ? t : fp.n0;
+        double o = y[t] - R * fw.iS[ti] * sw.r[t];
+        for (int k = 0; k < D; ++k) o += fp.h[k] * lam[k];
+        mean[t] = o;
+        vb[t] = sw.vb[t];
+        if (t == 0) break;
+        double w[D];
+        for (int k = 0; k < D; ++k) w[k] = fw.K[ti][k] * sw.r[t] + lam[k];
+        for (int i = 0; i < D; ++i) {
+            double v = 0.0;
+            for (int k = 0; k < D; ++k) v += sw.G[t][i][k] * w[k];
+            nl[i] = v;
+        }
+        for (int i = 0; i < D; ++i) lam[i] = nl[i];
+    }
+}
+
 #define TGP_PLAN_DISPATCH(d, expr)                                 \
     switch (d) {                                                   \
         case 1: { constexpr int D = 1; return expr; }              \
@@ -1446,6 +1752,29 @@ inline Info build_any(const ModelHost& m, long long T, Modal& md, HeadTables& ta
     Info bad;
     bad.why = kEigFail;
     return bad;
+}
+inline void build_smooth_any(const ModelHost& m, long long T, SmoothPlan& sp, double* tvb) {
+    switch (m.d) {
+        case 1: build_smooth<1>(m, T, sp, tvb); return;
+        case 2: build_smooth<2>(m, T, sp, tvb); return;
+        case 3: build_smooth<3>(m, T, sp, tvb); return;
+        case 4: build_smooth<4>(m, T, sp, tvb); return;
+        case 5: build_smooth<5>(m, T, sp, tvb); return;
+        case 6: build_smooth<6>(m, T, sp, tvb); return;
+        case 7: build_smooth<7>(m, T, sp, tvb); return;
+        case 8: build_smooth<8>(m, T, sp, tvb); return;
+    }
+    sp.why = kEigFail;
+}
+inline void smooth_head_forward_any(const ModelHost& m, const SmoothPlan& sp, const double* y, double* mu_end, double* quad) {
+    TGP_PLAN_DISPATCH(m.d, smooth_head_forward<D>(m, sp, y, mu_end, quad))
+}
+inline bool smooth_head_tables_any(const ModelHost& m, const SmoothPlan& sp) {
+    TGP_PLAN_DISPATCH(m.d, smooth_head_tables<D>(m, sp))
+    return false;
+}
+inline void smooth_head_backward_any(const ModelHost& m, const SmoothPlan& sp, const double* y, const double* lam, double* mean, double* vb) {
+    TGP_PLAN_DISPATCH(m.d, smooth_head_backward<D>(m, sp, y, lam, mean, vb))
 }
 #undef TGP_PLAN_DISPATCH
 

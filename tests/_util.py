@@ -203,6 +203,42 @@ def sweepsim():
     return _SWEEPSIM
 
 
+_SMOOTHSIM = None
+
+
+def smoothsim():
+    global _SMOOTHSIM
+    if _SMOOTHSIM is None:
+        src = os.path.join(HERE, "hostsim", "smoothsim.cpp")
+        so = os.path.join(HERE, "hostsim", "libsmoothsim.so")
+        deps = [src, os.path.join(ROOT, "temporalgps.jl_amd", "csrc", "tgp_steady_plan.hpp")]
+        if not os.path.exists(so) or any(os.path.getmtime(p) > os.path.getmtime(so) for p in deps):
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-o", so, src])
+        _SMOOTHSIM = ctypes.CDLL(so)
+        _SMOOTHSIM.smoothsim_run.restype = ctypes.c_int
+    return _SMOOTHSIM
+
+
+def smoothsim_run(model, y, Rnew):
+    """model: oracle dict with SHARED blocks and one noise variance (an LTI model).  The dense-powers one-launch smoother on the host
+    (tests/hostsim/smoothsim.cpp).  Returns dict(rc, lml, why, n0, nhs, n1, halo, nwg, mean, var)."""
+    T, d = model["T"], len(model["x0m"])
+    cm = lambda M: np.ascontiguousarray(np.asarray(M, dtype=np.float64).T).reshape(-1)
+    A, Q = cm(model["A"][0]), cm(model["Q"][0])
+    a = np.ascontiguousarray(model["a"][0], dtype=np.float64)
+    H = np.ascontiguousarray(model["H"][0], dtype=np.float64)
+    x0m = np.ascontiguousarray(model["x0m"], dtype=np.float64)
+    x0P = cm(model["x0P"])
+    yv = np.ascontiguousarray(y, dtype=np.float64)
+    rn = np.ascontiguousarray(np.atleast_1d(Rnew), dtype=np.float64)
+    mean, var, out = np.zeros(T), np.zeros(T), np.zeros(8)
+    rc = smoothsim().smoothsim_run(d, _p(A), _p(a), _p(Q), _p(H), ctypes.c_double(float(np.atleast_1d(model["h"])[0])),
+                                   ctypes.c_double(float(np.atleast_1d(model["R"])[0])), _p(x0m), _p(x0P), _i64(T), _p(yv), _p(rn),
+                                   int(rn.shape[0] > 1), _p(mean), _p(var), _p(out))
+    return dict(rc=rc, lml=out[0], why=int(out[1]), n0=int(out[2]), nhs=int(out[3]), n1=int(out[4]), halo=int(out[5]), nwg=int(out[6]),
+                mean=mean, var=var)
+
+
 def kernel_sde(k):
     """(F, H) of a kernel expression built from Matern terms with scaled / stretched / sum (what the closed-form transitions cover)."""
     from scipy.linalg import block_diag

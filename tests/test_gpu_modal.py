@@ -141,32 +141,90 @@ def test_device_pointers_off_the_16_byte_boundary(tgp):
     assert float(outm[0]) == 0.0 and float(outv[0]) == 0.0
 
 
-def test_models_the_plan_declines_go_to_the_older_engines(tgp):
-    """a sum of two identical kernels has no well-conditioned modal form: tgp_steady.hip serves it; the verdict is remembered"""
+DECLINED = {      # no well-conditioned modal form: summands with ONE length scale (a defective closed loop)
+    4: ("sum", ("matern32",), ("matern32",)),      # (two Matern-1/2 with one length scale: a double eigenvalue, but diagonalisable -- the modal plan takes it)
+    6: ("sum", ("matern52",), ("matern52",)),      # SURVEY 8d's own cfg3 at d = 6
+    7: ("sum", ("matern32",), ("matern32",), ("matern52",)),
+    8: ("sum", ("matern52",), ("matern52",), ("matern32",)),
+}
+
+
+@pytest.mark.parametrize("d", sorted(DECLINED))
+def test_models_the_plan_declines_run_in_one_launch_on_dense_powers(tgp, d):
+    """a sum of two identical kernels has no well-conditioned modal form: logpdf by k_filter_one, posterior marginals (+ logpdf) by
+    k_smooth_one -- both recursions on DENSE powers (closed loop forwards, settled reverse-time transition backwards), ONE launch each
+    (lgssm.jl:111-115, :215-238)"""
     T = 9000
-    model = oc.build_lgssm(("sum", ("matern52",), ("matern52",)), ("regular", 0.0, 0.1, T), 0.1)
-    y = draw(model, 1)
+    model = oc.build_lgssm(DECLINED[d], ("regular", 0.0, 0.1, T), 0.1)
+    assert len(model["x0m"]) == d
+    y = draw(model, d)
     dm = device_model(tgp, model)
     lp, names = kernels_of(tgp, dm, lambda: tgp.logpdf(dm, y))
-    # logpdf needs no modal form: the filter's forward recursion on the dense powers of the closed loop, one kernel (d <= 6)
     assert names == {"k_filter_one"}, names
     assert served(dm) > T - 700
     lp_ref = sk.logpdf(model, y)
     assert abs(lp - lp_ref) <= 1e-10 * abs(lp_ref)
     Rn = np.array([0.2])
     (mean, var), names = kernels_of(tgp, dm, lambda: tgp.posterior_marginals(dm, y, Rn))
-    assert "k_steady_apply<posterior>" in names and not any(n.startswith("k_steady_one") for n in names), names
+    assert names == {"k_smooth_one"}, names
+    assert served(dm) > T - 700
     m_ref, v_ref = sk.posterior_marginals(model, y, Rn)
     assert np.max(np.abs(mean - m_ref)) <= 1e-8 and np.max(np.abs(var - v_ref)) <= 1e-8
+    lp2, mean2, var2 = tgp.logpdf_and_posterior_marginals(dm, y, Rn)
+    assert abs(lp2 - lp_ref) <= 1e-10 * abs(lp_ref)
+    assert np.array_equal(mean2, mean) and np.array_equal(var2, var)
     assert abs(tgp.logpdf(dm, y) - lp_ref) <= 1e-10 * abs(lp_ref)      # (and again behind a posterior call)
-    # d = 8 without a modal form: the same
-    model = oc.build_lgssm(("sum", ("matern52",), ("matern52",), ("matern32",)), ("regular", 0.0, 0.1, T), 0.1)
-    y = draw(model, 2)
-    dm = device_model(tgp, model)
-    lp, names = kernels_of(tgp, dm, lambda: tgp.logpdf(dm, y))
-    assert names == {"k_filter_one"}, names
+    # TGP_OPT_STEADY = 2 keeps the five-launch engine for the same model
+    d2 = device_model(tgp, model, steady=2)
+    (mean5, var5), names = kernels_of(tgp, d2, lambda: tgp.posterior_marginals(d2, y, Rn))
+    assert "k_steady_apply<posterior>" in names and "k_smooth_one" not in names, names
+    assert np.max(np.abs(mean5 - mean)) <= 1e-9 and np.max(np.abs(var5 - var)) <= 1e-9
+
+
+@pytest.mark.parametrize("T", [700, 1999, 3584, 3585, 4096, 4097, 7000, 8191, 12289, 40000, 300007])
+def test_dense_powers_smoother_lengths_around_every_boundary(tgp, T):
+    """series ending inside / at the edge of a tile, a span, the variance transient; per-step new noise; device-resident inputs and outputs"""
+    import torch
+    model = oc.build_lgssm(DECLINED[6], ("regular", 0.0, 0.1, T), 0.1)
+    y = draw(model, T)
+    rng = np.random.default_rng(T)
+    Rn = rng.random(T) * 0.1
     lp_ref = sk.logpdf(model, y)
-    assert abs(lp - lp_ref) <= 1e-10 * abs(lp_ref)
+    m_ref, v_ref = sk.posterior_marginals(model, y, Rn)
+    dm = device_model(tgp, model)
+    (mean, var), names = kernels_of(tgp, dm, lambda: tgp.posterior_marginals(dm, y, Rn))
+    assert names == {"k_smooth_one"}, names
+    assert np.max(np.abs(mean - m_ref)) <= 1e-8 and np.max(np.abs(var - v_ref)) <= 1e-8
+    # device pointers (off the 16-byte boundary as well)
+    hd = dm.handle()
+    L = tgp._lib
+    for off in (0, 1):
+        yd = torch.zeros(T + 2, dtype=torch.float64, device="cuda")
+        yd[off:off + T] = torch.from_numpy(y).cuda()
+        rd = torch.from_numpy(Rn).cuda()
+        md = torch.zeros(T + 2, dtype=torch.float64, device="cuda")
+        vd = torch.zeros(T + 2, dtype=torch.float64, device="cuda")
+        out = ctypes.c_double()
+        ptr = lambda t, o=0: ctypes.c_void_p(t.data_ptr() + 8 * o)
+        hd.check(hd.lib.tgp_logpdf_and_posterior_marginals(hd.h, ptr(yd, off), None, ptr(rd), L.IN_DEVICE | L.OUT_DEVICE, ctypes.byref(out),
+                                                          ptr(md, off), ptr(vd, off)))
+        torch.cuda.synchronize()
+        assert abs(out.value - lp_ref) <= 1e-10 * abs(lp_ref)
+        assert np.max(np.abs(md[off:off + T].cpu().numpy() - m_ref)) <= 1e-8
+        assert np.max(np.abs(vd[off:off + T].cpu().numpy() - v_ref)) <= 1e-8
+        assert float(md[off + T:].abs().max()) == 0.0 and float(vd[off + T:].abs().max()) == 0.0      # (nothing written behind the series)
+
+
+def test_dense_powers_smoother_steps_aside(tgp):
+    """a series too short for head + transient, and an explicit chunk length: the older engines serve the call"""
+    model = oc.build_lgssm(DECLINED[6], ("regular", 0.0, 0.1, 90), 0.1)
+    y = draw(model, 5)
+    dm = device_model(tgp, model)
+    Rn = np.array([0.1])
+    (mean, var), names = kernels_of(tgp, dm, lambda: tgp.posterior_marginals(dm, y, Rn))
+    assert "k_smooth_one" not in names, names
+    m_ref, v_ref = sk.posterior_marginals(model, y, Rn)
+    assert np.max(np.abs(mean - m_ref)) <= 1e-8 and np.max(np.abs(var - v_ref)) <= 1e-8
 
 
 def test_option_2_keeps_the_five_launch_engine(tgp):
