@@ -357,6 +357,8 @@ struct tgp_handle {
     double* adj_host = nullptr;  // pinned: the record + the head's observations of an adjoint call
     double* flt_host = nullptr;  // pinned: head observations, head outputs and the workgroups' partial sums of an LTI filter call
     size_t flt_cap = 0;
+    double* sm_sync = nullptr;   // pinned, 32 doubles: [0..7] the head's end state, [8..15] the kernel's xi at the head's end, [16], [17] their flags (smooth_lti_call)
+    long long smooth_seq = 0;
     DevBuf steady_rec;           // ... the chunks' records (ModelView::steady)
     int steady_calls = 0;        // 1: the last posterior-path forward pass (mode 2) wrote the records
     // Policy of the posterior path: the build with these steps has slightly longer full steps, and a pass takes as long as its slowest
@@ -1500,6 +1502,7 @@ int tgp_destroy(tgp_handle* h) {
     if (h->host_result) (void)hipHostFree(h->host_result);
     if (h->adj_host) (void)hipHostFree(h->adj_host);
     if (h->flt_host) (void)hipHostFree(h->flt_host);
+    if (h->sm_sync) (void)hipHostFree(h->sm_sync);
     if (h->own_stream && !pooled_stream(h->device)) (void)hipStreamDestroy(h->own_stream);      // (pool streams live as long as the process)
     delete h;
     return TGP_OK;
@@ -2039,6 +2042,7 @@ int tgp_model_set_x0(tgp_handle* h, const double* x0m, const double* x0P) {
 }
 
 static int filter_lti_call(tgp_handle* h, const double* y, uint32_t flags, double* m_out, double* P_out, double* lml_out, bool* served);
+static int smooth_lti_call(tgp_handle* h, const double* y, uint32_t flags, const double* Rnew, double* mean_out, double* var_out, double* lml_out, bool* served);
 
 int tgp_logpdf(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t flags, double* out) {
     TRY(check_ready(h, /*general=*/false));
@@ -2053,6 +2057,8 @@ int tgp_logpdf(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t 
         // no well-conditioned modal form (two summands with one length scale, ...): logpdf is the by-product of the filter's forward
         // recursion, which needs none -- ONE kernel on the dense powers of the closed loop (d <= 6; k_filter_one without its outputs)
         if (h->opt_modal && missing == nullptr && y != nullptr) {
+            TRY(smooth_lti_call(h, y, flags, nullptr, nullptr, nullptr, out, &served));      // (k_smooth_one's forward half: one sweep, no outputs)
+            if (served) return TGP_OK;
             TRY(filter_lti_call(h, y, flags, nullptr, nullptr, out, &served));
             if (served) return TGP_OK;
         }
@@ -2449,36 +2455,47 @@ static int smooth_lti_call(tgp_handle* h, const double* y, uint32_t flags, const
     *served = false;
     tgp_plan::ModelHost mh;
     if (!h->opt_modal || h->smooth_state < 0 || chunk_engine_requested(h) || h->is_dense || !h->lti || h->p != 1 || h->ordering != 0 || h->sde ||
-        h->d > tgp_plan::kRandMaxD || !modal_host_model(h, mh) || !mean_out || !var_out || !Rnew)
+        h->d > tgp_plan::kRandMaxD || !modal_host_model(h, mh) || (mean_out != nullptr) != (var_out != nullptr) || (mean_out && !Rnew))
         return TGP_OK;
+    const bool post = mean_out != nullptr;      // (false: logpdf only -- the forward half alone, no halo behind a span)
+    constexpr size_t HM = tgp_plan::kHeadMax;
     const size_t nwg_max = (size_t)(h->T / 1024) + 2;
-    TRY(ensure_pinned(h, 3 * (size_t)tgp_plan::kHeadMax + nwg_max + 8 + tgp_plan::kTailMax + 8));
-    double *yh = h->flt_host, *hm = yh + tgp_plan::kHeadMax, *hv = hm + tgp_plan::kHeadMax, *tvb = hv + tgp_plan::kHeadMax, *xi = tvb + tgp_plan::kTailMax,
-           *part = xi + 8;
+    TRY(ensure_pinned(h, 4 * HM + nwg_max + tgp_plan::kTailMax + 8));
+    double *hin = h->flt_host, *hout = hin + 2 * HM, *tvb = hout + 2 * HM, *part = tvb + tgp_plan::kTailMax;      // hin: y | Rnew of the head; hout: mean | var
+    if (!h->sm_sync) {
+        if (hipHostMalloc(reinterpret_cast<void**>(&h->sm_sync), 32 * sizeof(double), hipHostMallocDefault) != hipSuccess) return h->fail(TGP_EHIP, "hipHostMalloc");
+        std::memset(h->sm_sync, 0, 32 * sizeof(double));
+    }
+    double *mu_end = h->sm_sync, *xi = h->sm_sync + 8;
+    long long* sflag = reinterpret_cast<long long*>(h->sm_sync + 16);      // [0] head inputs on the host, [1] mu_end, [2] xi, [3] head outputs
     tgp_plan::SmoothPlan sp;
-    tgp_modal::plan_smooth(mh, h->T, sp, tvb);
+    tgp_modal::plan_smooth(mh, h->T, sp, tvb, post);
     if (sp.why != tgp_plan::kOk) {
-        h->smooth_state = -1;      // (a function of the model and T alone: the next call need not ask again)
+        if (post) h->smooth_state = -1;      // (a function of the model and T alone: the next call need not ask again)
         return TGP_OK;
     }
     const tgp_plan::FilterPlan& fp = sp.fp;
     const size_t nhs = (size_t)fp.nhs;
-    const long long nwg = tgp_modal::smooth_workgroups(sp, h->T);
+    const long long nwg = tgp_modal::smooth_workgroups(sp, h->T, post);
     if (nwg < 1 || (size_t)nwg > nwg_max) return TGP_OK;
     const bool idev = (flags & TGP_IN_DEVICE) != 0, odev = (flags & TGP_OUT_DEVICE) != 0, rshared = (flags & TGP_SHARED_R) != 0;
     const size_t nT = (size_t)h->T * sizeof(double);
+    // The head BESIDE the kernel (tgp_modal.hpp SmoothCall): the launch goes first; workgroup 0 hands the head's inputs to the host through
+    // pinned memory, the host answers with the head's end state, runs the head backwards once workgroup 0 has raised xi, and the last workgroup
+    // writes the head's outputs: one launch, one synchronisation, no copy on any stream in between.  With synchronous launches: the same
+    // steps one after the other, copies on the handle's stream.
+    const bool overlap = tgp_modal::overlap_allowed();
+    const long long seq = ++h->smooth_seq;
     CallTimer tm(h, /*clear=*/false);
     const void* pR = nullptr;
-    TRY(stage_in(h, h->bRnew, Rnew, rshared ? sizeof(double) : nT, idev, &pR));
+    if (post) TRY(stage_in(h, h->bRnew, Rnew, rshared ? sizeof(double) : nT, idev, &pR));
     TRY(set_obs(h, y, nullptr, flags));
     tm.inputs_done();
-    HIPCHK(hipMemcpyAsync(yh, h->mv.y, nhs * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    double mu_end[tgp_plan::kRandMaxD], quad_head = 0.0;
-    tgp_modal::plan_smooth_head_forward(mh, sp, yh, mu_end, &quad_head);
     double *dm = nullptr, *dv = nullptr;
     TRY(stage_out(h, h->bo1, mean_out, nT, odev, &dm));
     TRY(stage_out(h, h->bo2, var_out, nT, odev, &dv));
+    double quad_head = 0.0;
+    const double *yhead = idev ? hin : y, *rnhead = idev ? hin + nhs : Rnew;
     tgp_modal::SmoothCall c;
     c.T = h->T;
     c.y = h->mv.y;
@@ -2489,47 +2506,100 @@ static int smooth_lti_call(tgp_handle* h, const double* y, uint32_t flags, const
     c.var = dv;
     c.part = part;
     c.xi_out = xi;
+    c.seq = seq;
+    if (overlap) {
+        if (idev) {
+            c.head_in = hin;
+            c.head_in_flag = sflag;
+        }
+        c.mu0 = mu_end;
+        c.mu0_flag = sflag + 1;
+        if (post) {
+            c.xi_flag = sflag + 2;
+            c.head_out = hout;
+            c.head_out_flag = sflag + 3;
+        }
+    } else {
+        if (idev) {
+            HIPCHK(hipMemcpyAsync(hin, y, nhs * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+            if (post) HIPCHK(hipMemcpyAsync(hin + nhs, Rnew, (rshared ? 1 : nhs) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+        }
+        tgp_modal::plan_smooth_head_forward(mh, sp, yhead, mu_end, &quad_head);
+    }
     {
         LaunchScope ls(h, "k_smooth_one");
-        const int rc = tgp_modal::smooth_lti(h->stream, sp, mu_end, c);
+        const int rc = tgp_modal::smooth_lti(h->stream, sp, overlap ? nullptr : mu_end, c);
         if (rc != 0) return h->fail(TGP_EHIP, std::string("tgp_posterior_marginals: launch: ") + hipGetErrorString((hipError_t)rc));
     }
-    const bool tables_ok = tgp_modal::plan_smooth_head_tables(mh, sp);      // (beside the kernel)
+    struct FlagGuard {      // (whatever path leaves from here on: no workgroup is left waiting for the host)
+        long long* f;
+        long long v;
+        ~FlagGuard() {
+            if (!f) return;
+            for (int k : {1, 3})
+                if (__atomic_load_n(f + k, __ATOMIC_RELAXED) < v) __atomic_store_n(f + k, v, __ATOMIC_RELEASE);
+        }
+    } guard{overlap ? sflag : nullptr, 2 * seq};
+    auto await = [&](const long long* f) {      // bounded (the kernel's own waits give up after two seconds): false = the flag never came
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int spin = 0;; ++spin) {
+            if (__atomic_load_n(f, __ATOMIC_ACQUIRE) >= 2 * seq) return true;
+            if ((spin & 255) == 255 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(1500)) return false;
+            __builtin_ia32_pause();
+        }
+    };
+    bool handshake_ok = true;
+    if (overlap) {
+        if (idev) handshake_ok = await(sflag);
+        if (handshake_ok) {
+            tgp_modal::plan_smooth_head_forward(mh, sp, yhead, mu_end, &quad_head);
+            __atomic_store_n(sflag + 1, 2 * seq, __ATOMIC_RELEASE);
+        }
+    }
+    const bool tables_ok = !post || tgp_modal::plan_smooth_head_tables(mh, sp);      // (beside the kernel)
+    auto head_back = [&]() {
+        tgp_modal::plan_smooth_head_backward(mh, sp, yhead, xi, hout, hout + nhs);
+        for (size_t t = 0; t < nhs; ++t) hout[nhs + t] += rnhead[rshared ? 0 : t];
+    };
+    if (overlap && post && tables_ok && handshake_ok) {      // workgroup 0 is among the first to finish: its xi arrives long before the grid is through
+        handshake_ok = await(sflag + 2);
+        if (handshake_ok) {
+            head_back();
+            __atomic_store_n(sflag + 3, 2 * seq, __ATOMIC_RELEASE);
+        }
+    }
     tm.kernels_done();
-    TRY(copy_back(h, mean_out, dm, nT, odev));
-    TRY(copy_back(h, var_out, dv, nT, odev));
+    if (overlap) {
+        for (int k : {1, 3})      // (a hand-over that failed, head tables that declined: no workgroup waits for what will not come; the outputs are discarded)
+            if (__atomic_load_n(sflag + k, __ATOMIC_RELAXED) < 2 * seq) __atomic_store_n(sflag + k, 2 * seq, __ATOMIC_RELEASE);
+        TRY(copy_back(h, mean_out, dm, nT, odev));
+        TRY(copy_back(h, var_out, dv, nT, odev));
+    }
     if (h->timing) (void)hipEventRecord(h->ev[3], h->stream);
     HIPCHK(hipStreamSynchronize(h->stream));
     resolve_profile(h);
+    if (!handshake_ok) return h->fail(TGP_EHIP, "the one-launch smoother's host / device hand-over timed out");
     if (!tables_ok) {      // a head step's predicted covariance not positive definite: the older engines give the verdict
         h->smooth_state = -1;
         return TGP_OK;
     }
-    // the head backwards from the kernel's xi at step nhs; its nhs outputs go where the rest went
-    tgp_modal::plan_smooth_head_backward(mh, sp, yh, xi, hm, hv);
-    if (rshared) {
-        double rn = 0.0;
-        if (idev) HIPCHK(hipMemcpy(&rn, Rnew, sizeof(double), hipMemcpyDeviceToHost));
-        else rn = Rnew[0];
-        for (size_t t = 0; t < nhs; ++t) hv[t] += rn;
-    } else if (idev) {
-        std::vector<double> tmp(nhs);
-        HIPCHK(hipMemcpy(tmp.data(), Rnew, nhs * sizeof(double), hipMemcpyDeviceToHost));
-        for (size_t t = 0; t < nhs; ++t) hv[t] += tmp[t];
-    } else {
-        for (size_t t = 0; t < nhs; ++t) hv[t] += Rnew[t];
-    }
-    if (odev) {
-        HIPCHK(hipMemcpyAsync(dm, hm, nhs * sizeof(double), hipMemcpyHostToDevice, h->stream));
-        HIPCHK(hipMemcpyAsync(dv, hv, nhs * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (!overlap) {
+        if (post) {
+            head_back();
+            HIPCHK(hipMemcpyAsync(dm, hout, nhs * sizeof(double), hipMemcpyHostToDevice, h->stream));
+            HIPCHK(hipMemcpyAsync(dv, hout + nhs, nhs * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        }
+        TRY(copy_back(h, mean_out, dm, nT, odev));
+        TRY(copy_back(h, var_out, dv, nT, odev));
         HIPCHK(hipStreamSynchronize(h->stream));
-    } else {
-        std::memcpy(mean_out, hm, nhs * sizeof(double));
-        std::memcpy(var_out, hv, nhs * sizeof(double));
     }
     double ssq = 0.0;
     for (long long g = 0; g < nwg; ++g) ssq += part[g];
     const double lml = -0.5 * ((double)h->T * 1.8378770664093454835606594728112 + fp.LS + (double)(h->T - fp.n0) * fp.logS + quad_head + fp.iS * ssq);
+    if (getenv("TGP_STEADY_DEBUG") != nullptr)
+        fprintf(stderr, "[tgp smooth] T %lld post %d overlap %d idev %d odev %d nwg %lld nhs %d halo %d n1 %d seq %lld quad_head %.6g ssq %.6g lml %.10g\n", (long long)h->T,
+                (int)post, (int)overlap, (int)idev, (int)odev, nwg, fp.nhs, sp.halo, sp.n1, seq, quad_head, ssq, lml);
     for (int i = 0; i < 8; ++i) h->host_result[i] = 0.0;
     h->host_result[0] = lml;
     if (lml_out) *lml_out = lml;

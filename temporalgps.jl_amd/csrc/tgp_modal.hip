@@ -2513,9 +2513,18 @@ struct SArgs {
     double WJ[kWJ][D], WG[kWJ][D];
     double mu0[D];
     long long T, C, nwg, nhs, n1;
-    int halo, rnew_per_step;
+    int halo, halo_r, rnew_per_step;      // halo_r: the halo behind a span (0 without the backward half)
     const double *y, *Rnew, *tvb;
     double *mean, *var, *part, *xi_out;
+    // the head beside the kernel (tgp_modal.hpp SmoothCall): all pinned host memory, flags hold 2 seq once raised
+    const double* mu0p;
+    const long long* mu0_flag;
+    long long* xi_flag;
+    double* head_in;
+    long long* head_in_flag;
+    const double* head_out;
+    const long long* head_out_flag;
+    long long seq;
 };
 
 template <int D, int NW, int MINW>
@@ -2526,7 +2535,9 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_smooth_one(const SArgs<D> by_
     __shared__ double sF[NW][D], sB[NW][D], sAcc[NW];
     __shared__ double sPw[D][D][64];       // Phi^(8 e), e = 0 .. 63
     __shared__ double sPg[D][D][64];       // G^(8 e)
+    __shared__ double sPoison;             // NaN once a bounded wait ran out (wait_tables): the call's result is then discarded
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) sPoison = 0.0;
     long long g;
     {
         const long long per = (ka.nwg + 7) / 8;
@@ -2537,7 +2548,16 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_smooth_one(const SArgs<D> by_
     const bool first = g == 0;
     const long long s0 = first ? ka.nhs : c_lo - ka.halo;
     const long long tile_t0 = s0 + (long long)wave * TILE, t0 = tile_t0 + (long long)lane * SUB;
-    const bool any_valid = tile_t0 < T && tile_t0 < c_hi + ka.halo;      // (wave-uniform: tiles behind the right-hand halo have nothing to do)
+    const bool any_valid = tile_t0 < T && tile_t0 < c_hi + ka.halo_r;      // (wave-uniform: tiles behind the right-hand halo have nothing to do)
+    if (first && wave == NW - 1 && ka.head_in != nullptr) {      // the head's inputs to the host, first thing: its forward recursion runs there
+        for (long long t = lane; t < ka.nhs; t += 64) {
+            ka.head_in[t] = ka.y[t];
+            if (ka.rnew_per_step && ka.mean != nullptr) ka.head_in[ka.nhs + t] = ka.Rnew[t];
+        }
+        if (!ka.rnew_per_step && ka.mean != nullptr && lane == 0) ka.head_in[ka.nhs] = ka.Rnew[0];
+        __threadfence_system();
+        if (lane == 0) __hip_atomic_store(ka.head_in_flag, 2 * ka.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     // ---- the observations first (they are on their way while the tables are built)
     double u[SUB];
 #pragma unroll
@@ -2563,6 +2583,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_smooth_one(const SArgs<D> by_
             if (uw != i2 % NW) continue;
             const int i = i2 % D;
             const bool isg = i2 >= D;
+            if (isg && ka.mean == nullptr) continue;      // (logpdf only: no backward half)
             double row[D];
 #pragma unroll
             for (int k = 0; k < D; ++k) row[k] = (k == i) ? 1.0 : 0.0;
@@ -2670,16 +2691,24 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_smooth_one(const SArgs<D> by_
 #pragma unroll
     for (int j = 0; j < SUB; ++j) o0[j] = 0.0;
     if (any_valid) {
-        double zin[D];
+        double zin[D], mu0v[D];
 #pragma unroll
-        for (int i = 0; i < D; ++i) zin[i] = 0.0;
+        for (int i = 0; i < D; ++i) {
+            zin[i] = 0.0;
+            mu0v[i] = ka.mu0[i];
+        }
+        if (first && wave < 3 && ka.mu0_flag != nullptr) {      // (wave-uniform) the head's end state comes from the host, beside the kernel
+            wait_tables(ka.mu0_flag, ka.seq, &sPoison);
+#pragma unroll
+            for (int i = 0; i < D; ++i) mu0v[i] = ka.mu0p[i];
+        }
 #pragma unroll
         for (int k = 1; k <= 3; ++k) {
             const int src = wave - k;
             if (src < -1 || (src == -1 && !first)) continue;
             double xs[D];
 #pragma unroll
-            for (int i = 0; i < D; ++i) xs[i] = src >= 0 ? sF[src][i] : ka.mu0[i];
+            for (int i = 0; i < D; ++i) xs[i] = src >= 0 ? sF[src][i] : mu0v[i];
             if (k == 1) {
 #pragma unroll
                 for (int i = 0; i < D; ++i) zin[i] += xs[i];
@@ -2807,6 +2836,10 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_smooth_one(const SArgs<D> by_
                     for (int k = 0; k < D; ++k) v = fma(ka.GPT[0][i][k], zin[k], v);
                     ka.xi_out[i] = v;
                 }
+                if (ka.xi_flag != nullptr) {
+                    __threadfence_system();
+                    __hip_atomic_store(ka.xi_flag, 2 * ka.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
             }
             // ---- outputs of the steps the workgroup owns
             const bool whole = t0 >= c_lo && t0 + SUB <= c_hi;
@@ -2852,6 +2885,14 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_smooth_one(const SArgs<D> by_
             }
         }
     }
+    if (ka.head_out_flag != nullptr && ka.mean != nullptr && g == ka.nwg - 1) {      // the head's outputs: the host has had the whole kernel to make them
+        if (wave < 2) {
+            wait_tables(ka.head_out_flag, ka.seq, &sPoison);
+            double* dst = wave == 0 ? ka.mean : ka.var;
+            const double* src = ka.head_out + (wave == 0 ? 0 : ka.nhs);
+            for (long long t = lane; t < ka.nhs; t += 64) dst[t] = src[t];
+        }
+    }
     acc = wave_sum_to_lane63(acc);
     if (lane == 63) sAcc[wave] = acc;
     __syncthreads();
@@ -2859,13 +2900,12 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_smooth_one(const SArgs<D> by_
         double tsum = 0.0;
 #pragma unroll
         for (int w = 0; w < NW; ++w) tsum += sAcc[w];
-        ka.part[g] = tsum;
+        ka.part[g] = tsum + sPoison;
     }
 }
 
-template <int D>
+template <int D, int NW>
 int launch_smooth(hipStream_t st, const tgp_plan::SmoothPlan& sp, const double* mu0, const SmoothCall& c) {
-    constexpr int NW = 8;
     const tgp_plan::FilterPlan& fp = sp.fp;
     SArgs<D> ka;
     static_assert(sizeof(SArgs<D>) <= 11264, "the kernel-argument segment (12 KB launch on gfx950: scripts/micro/bigarg.hip)");
@@ -2875,7 +2915,7 @@ int launch_smooth(hipStream_t st, const tgp_plan::SmoothPlan& sp, const double* 
         ka.kA[i] = fp.kA[i];
         ka.h[i] = fp.h[i];
         ka.c[i] = sp.c[i];
-        ka.mu0[i] = mu0[i];
+        ka.mu0[i] = mu0 != nullptr ? mu0[i] : 0.0;
         for (int j = 0; j < kWJ; ++j) {
             ka.WJ[j][i] = sp.WJ[j][i];
             ka.WG[j][i] = sp.WG[j][i];
@@ -2899,8 +2939,10 @@ int launch_smooth(hipStream_t st, const tgp_plan::SmoothPlan& sp, const double* 
     ka.T = c.T;
     ka.nhs = fp.nhs;
     ka.n1 = sp.n1;
+    const bool post = c.mean != nullptr;
     ka.halo = sp.halo;
-    ka.C = smooth_span(sp);
+    ka.halo_r = post ? sp.halo : 0;
+    ka.C = smooth_span(sp, post);
     ka.nwg = (c.T - fp.nhs + ka.C - 1) / ka.C;
     ka.rnew_per_step = c.rnew_per_step;
     ka.y = c.y;
@@ -2910,6 +2952,14 @@ int launch_smooth(hipStream_t st, const tgp_plan::SmoothPlan& sp, const double* 
     ka.var = c.var;
     ka.part = c.part;
     ka.xi_out = c.xi_out;
+    ka.mu0p = c.mu0;
+    ka.mu0_flag = c.mu0_flag;
+    ka.xi_flag = c.xi_flag;
+    ka.head_in = c.head_in;
+    ka.head_in_flag = c.head_in_flag;
+    ka.head_out = c.head_out;
+    ka.head_out_flag = c.head_out_flag;
+    ka.seq = c.seq;
     const long long per = (ka.nwg + 7) / 8;
     static const int minw_env = [] { const char* v = std::getenv("TGP_SMOOTH_MINW"); return v ? std::atoi(v) : 0; }();
     const bool four = minw_env ? minw_env >= 4 : D <= 6;
@@ -2919,33 +2969,37 @@ int launch_smooth(hipStream_t st, const tgp_plan::SmoothPlan& sp, const double* 
 }
 }  // namespace
 
-long long smooth_span(const tgp_plan::SmoothPlan& sp) { return 8LL * 64 * kWJ - 2LL * sp.halo; }
-long long smooth_workgroups(const tgp_plan::SmoothPlan& sp, long long T) {
-    const long long C = smooth_span(sp);
+// (sixteen waves per workgroup -- spans of 8192 steps, half the halo overhead, the tables' rows dealt over sixteen waves -- were measured
+//  SLOWER: fused call 0.228 against 0.177 ms at d = 6, T = 1e7: one workgroup per CU leaves nothing to run beside its barriers)
+long long smooth_span(const tgp_plan::SmoothPlan& sp, bool post) { return 8LL * 64 * kWJ - (post ? 2LL : 1LL) * sp.halo; }
+long long smooth_workgroups(const tgp_plan::SmoothPlan& sp, long long T, bool post) {
+    const long long C = smooth_span(sp, post);
     return C > 0 ? (T - sp.fp.nhs + C - 1) / C : -1;
 }
 
 int smooth_lti(hipStream_t stream, const tgp_plan::SmoothPlan& sp, const double* mu_start, const SmoothCall& c) {
     switch (sp.fp.d) {
-        case 1: return launch_smooth<1>(stream, sp, mu_start, c);
-        case 2: return launch_smooth<2>(stream, sp, mu_start, c);
-        case 3: return launch_smooth<3>(stream, sp, mu_start, c);
-        case 4: return launch_smooth<4>(stream, sp, mu_start, c);
-        case 5: return launch_smooth<5>(stream, sp, mu_start, c);
-        case 6: return launch_smooth<6>(stream, sp, mu_start, c);
-        case 7: return launch_smooth<7>(stream, sp, mu_start, c);
-        case 8: return launch_smooth<8>(stream, sp, mu_start, c);
+        case 1: return launch_smooth<1, 8>(stream, sp, mu_start, c);
+        case 2: return launch_smooth<2, 8>(stream, sp, mu_start, c);
+        case 3: return launch_smooth<3, 8>(stream, sp, mu_start, c);
+        case 4: return launch_smooth<4, 8>(stream, sp, mu_start, c);
+        case 5: return launch_smooth<5, 8>(stream, sp, mu_start, c);
+        case 6: return launch_smooth<6, 8>(stream, sp, mu_start, c);
+        case 7: return launch_smooth<7, 8>(stream, sp, mu_start, c);
+        case 8: return launch_smooth<8, 8>(stream, sp, mu_start, c);
     }
     return (int)hipErrorInvalidValue;
 }
 
-void plan_smooth(const tgp_plan::ModelHost& m, long long T, tgp_plan::SmoothPlan& sp, double* tvb) {
+bool overlap_allowed() { return overlap_tables(); }
+
+void plan_smooth(const tgp_plan::ModelHost& m, long long T, tgp_plan::SmoothPlan& sp, double* tvb, bool post) {
     if (!host_cpu_ok()) {
         sp.why = tgp_plan::kEigFail;
         return;
     }
-    tgp_plan::build_smooth_any(m, T, sp, tvb);
-    if (sp.why == tgp_plan::kOk && smooth_span(sp) < 1024) sp.why = tgp_plan::kSlowMixing;      // (halos would eat three quarters of a span)
+    tgp_plan::build_smooth_any(m, T, sp, tvb, post);
+    if (sp.why == tgp_plan::kOk && smooth_span(sp, post) < 1024) sp.why = tgp_plan::kSlowMixing;      // (halos would eat three quarters of a span)
 }
 void plan_smooth_head_forward(const tgp_plan::ModelHost& m, const tgp_plan::SmoothPlan& sp, const double* y, double* mu_end, double* quad) {
     tgp_plan::smooth_head_forward_any(m, sp, y, mu_end, quad);

@@ -93,13 +93,33 @@ struct SmoothCall {
     const double* tvb = nullptr;
     double *mean = nullptr, *var = nullptr;          // device
     double *part = nullptr, *xi_out = nullptr;
+    // The head beside the kernel (overlap_allowed()): the launch does not wait for the head's forward recursion, and nothing between the launch
+    // and the end of the kernel goes through a stream (a copy on a second stream may share the kernel's hardware queue and wait for it: measured --
+    // the kernel would wait for the host, the host for the copy, the copy for the kernel).  Everything is handed over through pinned memory:
+    //   head_in / head_in_flag   workgroup 0 copies the head's nhs observations (and, with rnew_per_step, its nhs new noise variances) there
+    //                            first thing (nullptr: the caller's inputs are host arrays already);
+    //   mu0 / mu0_flag           the host's answer: the predicted mean of step nhs (workgroup 0 waits for it, bounded);
+    //   xi_out / xi_flag         raised by workgroup 0 once xi at step nhs is known: the host runs the head backwards;
+    //   head_out / head_out_flag the head's nhs means and nhs variances from the host; the LAST workgroup waits for them (bounded) and writes
+    //                            them to mean / var [0, nhs).
+    // Flags hold 2 seq once raised.  mu0_flag == nullptr: mu_start by value, head outputs are the caller's to write.
+    double* head_in = nullptr;
+    const double* mu0 = nullptr;
+    const double* head_out = nullptr;
+    long long *head_in_flag = nullptr, *xi_flag = nullptr;
+    const long long *mu0_flag = nullptr, *head_out_flag = nullptr;
+    long long seq = 0;
 };
-void plan_smooth(const tgp_plan::ModelHost& m, long long T, tgp_plan::SmoothPlan& sp, double* tvb);
+// false when the process runs with synchronous launches (HIP_LAUNCH_BLOCKING, AMD_SERIALIZE_KERNEL, ...) or TGP_MODAL_OVERLAP=0: a kernel
+// that waits for a flag the host raises behind the launch would wait for itself
+bool overlap_allowed();
+void plan_smooth(const tgp_plan::ModelHost& m, long long T, tgp_plan::SmoothPlan& sp, double* tvb, bool post = true);      // post = false: logpdf only (tvb unused)
 void plan_smooth_head_forward(const tgp_plan::ModelHost& m, const tgp_plan::SmoothPlan& sp, const double* y, double* mu_end, double* quad);
 bool plan_smooth_head_tables(const tgp_plan::ModelHost& m, const tgp_plan::SmoothPlan& sp);
 void plan_smooth_head_backward(const tgp_plan::ModelHost& m, const tgp_plan::SmoothPlan& sp, const double* y, const double* lam, double* mean, double* vb);
-long long smooth_span(const tgp_plan::SmoothPlan& sp);
-long long smooth_workgroups(const tgp_plan::SmoothPlan& sp, long long T);
+// steps a workgroup owns (its tiles minus the halo in front and -- with the backward half -- behind), and the workgroups of a T-step call
+long long smooth_span(const tgp_plan::SmoothPlan& sp, bool post = true);
+long long smooth_workgroups(const tgp_plan::SmoothPlan& sp, long long T, bool post = true);
 int smooth_lti(hipStream_t stream, const tgp_plan::SmoothPlan& sp, const double* mu_start, const SmoothCall& c);
 int rand_lti(hipStream_t stream, const tgp_plan::RandPlan& plan, const double* x0, const double* eps_t, const double* eps_e, long long T, double* y,
              const char** kname);

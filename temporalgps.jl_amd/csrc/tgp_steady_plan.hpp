@@ -1443,12 +1443,28 @@ inline SmoothWork<D>& smooth_work() {
 
 // tvb [kTailMax]: h' Ps h of the steps T - 1 - j, j < n1 (the smoothed covariance's transient at the series' end)
 template <int D>
-inline void build_smooth(const ModelHost& m, long long T, SmoothPlan& sp, double* tvb) {
+inline void build_smooth(const ModelHost& m, long long T, SmoothPlan& sp, double* tvb, bool post = true) {
     using namespace detail;
     build_filter<D>(m, T, sp.fp);
     sp.why = sp.fp.why;
     if (sp.why != kOk) return;
     const FilterPlan& fp = sp.fp;
+    if (!post) {      // logpdf only: the forward half and the rows h' Phi^j
+        sp.halo = fp.halo;
+        sp.n1 = 0;
+        double x[D], nx[D];
+        for (int i = 0; i < D; ++i) x[i] = fp.h[i];
+        for (int j = 0; j < kSub; ++j) {
+            for (int i = 0; i < D; ++i) sp.WJ[j][i] = x[i];
+            for (int k = 0; k < D; ++k) {
+                double v = 0.0;
+                for (int i = 0; i < D; ++i) v = pfma(x[i], fp.Phi[i * D + k], v);
+                nx[k] = v;
+            }
+            for (int i = 0; i < D; ++i) x[i] = nx[i];
+        }
+        return;
+    }
     const FilterWork<D>& fw = filter_work<D>();
     SmoothWork<D>& sw = smooth_work<D>();
     const int n0 = fp.n0;
@@ -1753,16 +1769,16 @@ inline Info build_any(const ModelHost& m, long long T, Modal& md, HeadTables& ta
     bad.why = kEigFail;
     return bad;
 }
-inline void build_smooth_any(const ModelHost& m, long long T, SmoothPlan& sp, double* tvb) {
+inline void build_smooth_any(const ModelHost& m, long long T, SmoothPlan& sp, double* tvb, bool post = true) {
     switch (m.d) {
-        case 1: build_smooth<1>(m, T, sp, tvb); return;
-        case 2: build_smooth<2>(m, T, sp, tvb); return;
-        case 3: build_smooth<3>(m, T, sp, tvb); return;
-        case 4: build_smooth<4>(m, T, sp, tvb); return;
-        case 5: build_smooth<5>(m, T, sp, tvb); return;
-        case 6: build_smooth<6>(m, T, sp, tvb); return;
-        case 7: build_smooth<7>(m, T, sp, tvb); return;
-        case 8: build_smooth<8>(m, T, sp, tvb); return;
+        case 1: build_smooth<1>(m, T, sp, tvb, post); return;
+        case 2: build_smooth<2>(m, T, sp, tvb, post); return;
+        case 3: build_smooth<3>(m, T, sp, tvb, post); return;
+        case 4: build_smooth<4>(m, T, sp, tvb, post); return;
+        case 5: build_smooth<5>(m, T, sp, tvb, post); return;
+        case 6: build_smooth<6>(m, T, sp, tvb, post); return;
+        case 7: build_smooth<7>(m, T, sp, tvb, post); return;
+        case 8: build_smooth<8>(m, T, sp, tvb, post); return;
     }
     sp.why = kEigFail;
 }

@@ -58,8 +58,8 @@ def _assert_engine(name, per_step, names, model, T):
     elif name in ONE_LAUNCH:
         assert len(names) == 1 and next(iter(names)).startswith("k_steady_one"), names
         assert _served(model) > T - 700
-    else:      # no modal form: the five-launch engine -- logpdf alone of d <= 6: the filter's one kernel on dense powers
-        assert names == {"k_filter_one"} or (any(n.startswith("k_steady_apply") for n in names) and not any(n.startswith("k_reduce_filter") for n in names)), names
+    else:      # no modal form: ONE kernel on dense powers in both directions (k_smooth_one)
+        assert names == {"k_smooth_one"}, names
         assert _served(model) > T - 700
 
 

@@ -151,7 +151,7 @@ DECLINED = {      # no well-conditioned modal form: summands with ONE length sca
 
 @pytest.mark.parametrize("d", sorted(DECLINED))
 def test_models_the_plan_declines_run_in_one_launch_on_dense_powers(tgp, d):
-    """a sum of two identical kernels has no well-conditioned modal form: logpdf by k_filter_one, posterior marginals (+ logpdf) by
+    """a sum of two identical kernels has no well-conditioned modal form: logpdf by k_smooth_one's forward half, posterior marginals (+ logpdf) by
     k_smooth_one -- both recursions on DENSE powers (closed loop forwards, settled reverse-time transition backwards), ONE launch each
     (lgssm.jl:111-115, :215-238)"""
     T = 9000
@@ -160,7 +160,7 @@ def test_models_the_plan_declines_run_in_one_launch_on_dense_powers(tgp, d):
     y = draw(model, d)
     dm = device_model(tgp, model)
     lp, names = kernels_of(tgp, dm, lambda: tgp.logpdf(dm, y))
-    assert names == {"k_filter_one"}, names
+    assert names == {"k_smooth_one"}, names      # (its forward half alone)
     assert served(dm) > T - 700
     lp_ref = sk.logpdf(model, y)
     assert abs(lp - lp_ref) <= 1e-10 * abs(lp_ref)
@@ -206,6 +206,7 @@ def test_dense_powers_smoother_lengths_around_every_boundary(tgp, T):
         vd = torch.zeros(T + 2, dtype=torch.float64, device="cuda")
         out = ctypes.c_double()
         ptr = lambda t, o=0: ctypes.c_void_p(t.data_ptr() + 8 * o)
+        torch.cuda.synchronize()      # (device inputs are the caller's to complete: the library's streams do not wait for torch's)
         hd.check(hd.lib.tgp_logpdf_and_posterior_marginals(hd.h, ptr(yd, off), None, ptr(rd), L.IN_DEVICE | L.OUT_DEVICE, ctypes.byref(out),
                                                           ptr(md, off), ptr(vd, off)))
         torch.cuda.synchronize()
