@@ -15,7 +15,8 @@ from temporalgps_jl_amd import lti_sde as P
 T = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10_000_000
 kname = sys.argv[2] if len(sys.argv) > 2 else "matern52"
 dev = "cuda:0"
-model = P.build_lgssm(P.to_kernel((kname,)), P.RegularSpacing(0.0, 0.1, T), 0.1)
+spec = eval(kname) if kname.startswith("(") else (kname,)      # a kernel expression as bench.py writes them, e.g. '("sum", ("matern52",), ("stretched", 2.0, ("matern52",)))'
+model = P.build_lgssm(P.to_kernel(spec), P.RegularSpacing(0.0, 0.1, T), 0.1)
 hd = model.handle()
 y = torch.randn((T,), dtype=torch.float64, device=dev)
 Rnew = torch.full((1,), 1e-18, dtype=torch.float64, device=dev)

@@ -3,6 +3,7 @@
 // whole-line output stores, uniform coefficients through the kernel-argument segment).
 #include "tgp_modal.hpp"
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -53,6 +54,16 @@ struct KArgs {
     const long long* flag;      // pinned host memory, one word per stage of the tables: 2 seq (+ 1: declined) once that stage is in `htab`
     TabOff to;
     double* part;               // pinned host memory: [nwg] sum r^2 over the workgroups' core ranges, [nwg] the head's sum r^2 / S
+    // The head ON THE HOST (round 5): pinned host memory, flags hold 2 seq once raised.  Workgroup 0 hands the head's nhs observations
+    // (and new noise variances) over first thing (hflag[0]), waits -- bounded -- for the head's end state z0 in modal coordinates (hflag[1]) where
+    // it used to run the head forwards, hands back the backward state entering the head (zeta_out, hflag[2]) where it used to run it backwards,
+    // and a workgroup from the middle of the dispatch writes the head's outputs once the host has them (head_out: nhs means, nhs variances; hflag[3]).
+    int hosthead;
+    double* head_in;
+    const double* z0p;
+    double* zeta_out;
+    const double* head_out;
+    long long* hflag;
 };
 
 template <int D>
@@ -590,7 +601,9 @@ __global__ __launch_bounds__(NW * 64, TGP_MIN_WAVES(D, NW, HEAD_SCANS)) void k_s
     // M^(SUB l) (forward) and Mg^(SUB (63 - l)) (backward) for the lanes l of a tile: what carries a tile's start state / right-hand input to
     // its lanes.  The same for every wave: the waves share the building (by the bits of the lane number) between them
     __shared__ double sPw[2][2][D][64];
+    __shared__ double sPoison;      // NaN once a bounded wait for the host ran out (host head): the call's result is then discarded
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) sPoison = 0.0;
     // XCD-aware order: consecutive workgroups (which share their halos' lines of y) land on the same XCD, hence the same L2
     long long wg;
     {
@@ -620,7 +633,17 @@ __global__ __launch_bounds__(NW * 64, TGP_MIN_WAVES(D, NW, HEAD_SCANS)) void k_s
         ka.part[ka.nwg + 9] = (double)wall_clock64();
     }
     double head_quad = 0.0;
-    if (first) {
+    if (first && ka.hosthead) {
+        if (wave == NW - 1) {      // the head's inputs to the host, first thing: its forward recursion runs there
+            for (int t = lane; t < ka.nhs; t += 64) {
+                ka.head_in[t] = ka.y[t];
+                if (ka.post && ka.rnew_per_step) ka.head_in[ka.nhs + t] = ka.RnewT[t];
+            }
+            if (ka.post && !ka.rnew_per_step && lane == 0) ka.head_in[ka.nhs] = ka.Rnew[0];
+            __threadfence_system();
+            if (lane == 0) __hip_atomic_store(ka.hflag, 2 * ka.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    } else if (first) {
         // the head's tables: wait for the host, pull them into device memory (all waves), then the head wave runs the head forward
         if (threadIdx.x == 0) ka.part[ka.nwg + 1] = (double)wall_clock64();      // (phases of workgroup 0, 100 MHz: TGP_STEADY_DEBUG prints them)
         wait_tables(ka.flag, ka.seq, threadIdx.x == 0 ? &ka.part[ka.nwg] : nullptr);      // (timed out: the head's share becomes NaN)
@@ -724,13 +747,14 @@ __global__ __launch_bounds__(NW * 64, TGP_MIN_WAVES(D, NW, HEAD_SCANS)) void k_s
         double zin[D];
 #pragma unroll
         for (int i = 0; i < D; ++i) zin[i] = 0.0;
+        if (first && ka.hosthead && wave < 3) wait_tables(ka.hflag + 1, ka.seq, &sPoison);      // (wave-uniform) the head's end state comes from the host: z0p below
 #pragma unroll
         for (int k = 1; k <= 3; ++k) {
             const int src = wave - k;
             if (src < -1 || (src == -1 && !first)) continue;      // (wave-uniform)
             double x[D];
 #pragma unroll
-            for (int i = 0; i < D; ++i) x[i] = (src >= 0) ? sF[src][i] : sHead[i];
+            for (int i = 0; i < D; ++i) x[i] = (src >= 0) ? sF[src][i] : (ka.hosthead ? ka.z0p[i] : sHead[i]);
             if (k == 1) {
 #pragma unroll
                 for (int i = 0; i < D; ++i) zin[i] += x[i];
@@ -766,7 +790,7 @@ __global__ __launch_bounds__(NW * 64, TGP_MIN_WAVES(D, NW, HEAD_SCANS)) void k_s
             double t = 0.0;
 #pragma unroll
             for (int w = 0; w < NW; ++w) t += sAcc[w];
-            ka.part[wg] = t;
+            ka.part[wg] = t + sPoison;
             if (first) ka.part[ka.nwg] = head_quad;
         }
         return;
@@ -932,7 +956,16 @@ __global__ __launch_bounds__(NW * 64, TGP_MIN_WAVES(D, NW, HEAD_SCANS)) void k_s
         }
     }
     TGP_STAMP(11);
-    if (head_wave) {
+    if (head_wave && ka.hosthead) {
+        double zin[D];
+        right_input(-1, zin);
+        if (lane == 0) {      // the backward state entering the head: the host runs the head backwards from it
+#pragma unroll
+            for (int i = 0; i < D; ++i) ka.zeta_out[i] = zin[i];
+            __threadfence_system();
+            __hip_atomic_store(ka.hflag + 2, 2 * ka.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    } else if (head_wave) {
         double zin[D];
         right_input(-1, zin);
         if (lane == 0) ka.part[ka.nwg + 4] = (double)wall_clock64();
@@ -943,6 +976,15 @@ __global__ __launch_bounds__(NW * 64, TGP_MIN_WAVES(D, NW, HEAD_SCANS)) void k_s
         if (lane == 0) ka.part[ka.nwg + 5] = (double)wall_clock64();
         head_variances<D>(ka, lane);
     }
+    // the head's outputs come from the host: a workgroup from the MIDDLE of the dispatch writes them -- the host has them tens of microseconds after
+    // workgroup 0 has handed zeta back, so it does not wait, and its read over PCIe is not the kernel's tail (the last workgroup doing it was
+    // measured: + 4 us on the kernel)
+    if (ka.hosthead && ka.head_out != nullptr && wg == ((ka.nwg + 7) / 8) / 2 && wave < 2) {
+        wait_tables(ka.hflag + 3, ka.seq, &sPoison);
+        double* dst = wave == 0 ? ka.mean : ka.var;
+        const double* src = ka.head_out + (wave == 0 ? 0 : ka.nhs);
+        for (int t = lane; t < ka.nhs; t += 64) dst[t] = src[t];
+    }
     acc = wave_sum_to_lane63(acc);
     if (lane == 63) sAcc[wave] = acc;
     TGP_STAMP(12);
@@ -952,7 +994,7 @@ __global__ __launch_bounds__(NW * 64, TGP_MIN_WAVES(D, NW, HEAD_SCANS)) void k_s
         double t = 0.0;
 #pragma unroll
         for (int w = 0; w < NW; ++w) t += sAcc[w];
-        ka.part[wg] = t;
+        ka.part[wg] = t + sPoison;
         if (first) ka.part[ka.nwg] = head_quad;
         if (wg == ka.nwg - 1) ka.part[ka.nwg + 6] = (double)wall_clock64();
         if (probe) {
@@ -1026,13 +1068,31 @@ struct Engine {
     bool owns_head = true;
     int nw = 8, sub = 8;
     bool began = false, deferred = false;
+    // the head on the host (hosthead): pinned [0, 2 kHeadMax) head inputs y | Rnew, [2, 4 kHeadMax) head outputs mean | var, then z0 [8], zeta [8],
+    // four flag words; hr: the head's innovations (host scratch)
+    double* hhead = nullptr;
+    double hr[tgp_plan::kHeadMax];
+    bool hosthead = false, hh_pending = false;
+    int rnew_per_step = 0;
+    double host_quad = 0.0;
+    tgp_plan::ModelHost mh{};
+    long long hh_T = 0;
 };
+namespace {
+constexpr size_t kHH = tgp_plan::kHeadMax;
+inline double* hh_in(Engine* e) { return e->hhead; }
+inline double* hh_out(Engine* e) { return e->hhead + 2 * kHH; }
+inline double* hh_z0(Engine* e) { return e->hhead + 4 * kHH; }
+inline double* hh_zeta(Engine* e) { return e->hhead + 4 * kHH + 8; }
+inline long long* hh_flag(Engine* e) { return reinterpret_cast<long long*>(e->hhead + 4 * kHH + 16); }
+}  // namespace
 
 Engine* create() { return new Engine(); }
 void destroy(Engine* e) {
     if (!e) return;
     delete e->tab;
     if (e->hflat) (void)hipHostFree(e->hflat);
+    if (e->hhead) (void)hipHostFree(e->hhead);
     if (e->dflat) (void)hipFree(e->dflat);
     if (e->part) (void)hipHostFree(e->part);
     delete e;
@@ -1090,12 +1150,23 @@ int launch(Engine* e, hipStream_t st, const Call& c, const char** kname) {
     ka.flag = reinterpret_cast<const long long*>(e->hflat + e->flat_cap);
     ka.to = e->to;
     ka.part = e->part;
+    e->hh_pending = false;
+    e->rnew_per_step = c.rnew_per_step;
+    if (e->hosthead && e->owns_head) {
+        ka.hosthead = 1;
+        ka.head_in = hh_in(e);
+        ka.z0p = hh_z0(e);
+        ka.zeta_out = hh_zeta(e);
+        ka.head_out = ka.post ? hh_out(e) : nullptr;
+        ka.hflag = hh_flag(e);
+        e->hh_pending = true;
+    }
     const long long per = (e->nwg_local + 7) / 8;
     const unsigned grid = (unsigned)(per * 8);
     *kname = kernel_name(e, ka.post != 0);
     // the head as scans (d <= 4) needs ~30 more registers per lane than the tiles' code: taken where the launch leaves the CUs room anyway
     // (at most two workgroups per CU: every series up to ~2e6 steps -- there the head IS the call), not where occupancy is the kernel's time
-    const bool head_scans = D <= 4 && e->owns_head && e->nwg_local <= 512 && head_scans_enabled();
+    const bool head_scans = D <= 4 && e->owns_head && e->nwg_local <= 512 && head_scans_enabled() && !ka.hosthead;
     if (nw == 8) {
         if (head_scans) hipLaunchKernelGGL((k_steady_one<D, 8, 8, (D <= 4)>), dim3(grid), dim3(8 * 64), 0, st, ka);
         else hipLaunchKernelGGL((k_steady_one<D, 8, 8, false>), dim3(grid), dim3(8 * 64), 0, st, ka);
@@ -1173,6 +1244,13 @@ tgp_plan::Info plan_only(const tgp_plan::ModelHost& m, long long T, tgp_plan::Mo
 // TGP_MODAL_OVERLAP=0: the whole plan before the launch (A/B runs).  Also when the process runs with synchronous launches (the usual ROCm /
 // PyTorch debugging switches): the kernel waits for flags the host raises AFTER hipLaunchKernelGGL returns -- a launch that does not return
 // until the kernel has finished would wait for itself (round-4 advice; the wait is bounded as well, see wait_tables).
+static bool hosthead_enabled() {      // TGP_MODAL_HOSTHEAD=0: the head inside the kernel as in round 4 (A/B runs)
+    static const bool on = [] {
+        const char* v = std::getenv("TGP_MODAL_HOSTHEAD");
+        return !(v && v[0] == '0');
+    }();
+    return on;
+}
 static bool overlap_tables() {
     static const bool on = [] {
         const char* v = std::getenv("TGP_MODAL_OVERLAP");
@@ -1276,15 +1354,28 @@ bool plan(Engine* e, const tgp_plan::ModelHost& m, long long T) {
         }
         for (int s2 = 0; s2 < 3; ++s2) reinterpret_cast<long long*>(e->hflat + e->flat_cap)[s2] = 0;      // (the stages' flags)
     }
+    if (!e->hhead) {
+        const size_t n = 4 * kHH + 16 + 4;
+        if (hipHostMalloc(reinterpret_cast<void**>(&e->hhead), n * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) {
+            e->info = tgp_plan::Info{};
+            e->info.why = tgp_plan::kEigFail;
+            return false;
+        }
+        std::memset(e->hhead, 0, n * sizeof(double));
+    }
     ++e->seq;
     e->info = tgp_plan::build_core_any(m, T, e->md, *e->tab);
     if (e->info.why != tgp_plan::kOk) return false;
     layout_tables(e);
+    e->mh = m;
+    e->hh_T = T;
     // the tables half: behind the launch when the series is certainly longer than head + tail (the kernel's head wave and last tiles wait
     // for the flag), else right here
     // (measured again in round 5, d = 3: with the tables behind the launch a call takes 63.5 us against 68.7 with them in front of it, the
     //  kernel 47 us either way: scripts/call_overhead.py; TGP_MODAL_OVERLAP=0 is the switch)
     e->deferred = overlap_tables() && T >= (long long)e->md.nhs + tgp_plan::kTailMax + 1;
+    // the head on the host wherever the tables may follow the launch: workgroup 0 waits for the head's end state, not for tables
+    e->hosthead = e->deferred && hosthead_enabled();
     if (!e->deferred) {
         const int why = build_and_ship_tables(e, T);
         if (why != tgp_plan::kOk) {
@@ -1314,12 +1405,67 @@ bool plan(Engine* e, const tgp_plan::ModelHost& m, long long T) {
 
 // Behind the launch: the tables half of the plan, if it was deferred.  false: it declined (the kernel has been released all the same -- whatever
 // it writes is to be discarded, the caller re-runs the call elsewhere after synchronising).
+namespace {
+// bounded (the kernel's own waits give up after two seconds): false = the flag never came
+bool await_flag(const long long* f, long long v) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int spin = 0;; ++spin) {
+        if (__atomic_load_n(f, __ATOMIC_ACQUIRE) >= v) return true;
+        if ((spin & 255) == 255 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(1500)) return false;
+        __builtin_ia32_pause();
+    }
+}
+void raise_flag(long long* f, long long v) {
+    if (__atomic_load_n(f, __ATOMIC_RELAXED) < v) __atomic_store_n(f, v, __ATOMIC_RELEASE);
+}
+}  // namespace
+
 bool complete(Engine* e, long long T) {
     if (!e->began || !e->deferred) return true;
     e->deferred = false;
-    const int why = build_and_ship_tables(e, T, e->post ? 3 : 1);      // (a logpdf-only launch reads the forward stage alone)
+    if (!e->hosthead) {
+        const int why = build_and_ship_tables(e, T, e->post ? 3 : 1);      // (a logpdf-only launch reads the forward stage alone)
+        if (why != tgp_plan::kOk) {
+            e->info.why = why;
+            return false;
+        }
+        return true;
+    }
+    // ---- the head on the host: its forward recursion as soon as workgroup 0 has handed the observations over, the tables of stages 1 and 2
+    // beside the kernel (stage 2 is shipped: the last tiles read the tail variances), the backward recursion once the kernel has handed zeta back
+    long long* f = hh_flag(e);
+    const long long v = 2 * e->seq;
+    const bool head = e->hh_pending;
+    e->hh_pending = false;
+    bool ok = true;
+    if (head) {
+        ok = await_flag(f, v);
+        if (ok) tgp_plan::modal_head_forward_any(e->mh, e->md, *e->tab, hh_in(e), e->hr, hh_z0(e), &e->host_quad);
+        raise_flag(f + 1, v);
+    }
+    int why = tgp_plan::kOk;
+    if (e->post) {
+        why = tgp_plan::build_tables_stage_any(e->md.d, 1, T, e->md, *e->tab, e->info);
+        if (why == tgp_plan::kOk) why = tgp_plan::build_tables_stage_any(e->md.d, 2, T, e->md, *e->tab, e->info);
+        ship_stage(e, 2, why);
+    }
+    if (head && e->post) {
+        if (ok && why == tgp_plan::kOk) ok = await_flag(f + 2, v);
+        if (ok && why == tgp_plan::kOk) {
+            const int nhs = e->md.nhs;
+            double *om = hh_out(e), *ov = om + nhs;
+            const double* in = hh_in(e);
+            tgp_plan::modal_head_backward_any(e->md, *e->tab, in, e->hr, hh_zeta(e), om, ov);
+            for (int t = 0; t < nhs; ++t) ov[t] += in[nhs + (e->rnew_per_step ? t : 0)];
+        }
+        raise_flag(f + 3, v);      // (also when something declined: the last workgroup never waits for what will not come; the outputs are discarded)
+    }
     if (why != tgp_plan::kOk) {
         e->info.why = why;
+        return false;
+    }
+    if (!ok) {
+        e->info.why = tgp_plan::kEigFail;      // (the host / device hand-over timed out)
         return false;
     }
     return true;
@@ -1332,6 +1478,11 @@ void abandon(Engine* e) {
     e->deferred = false;
     long long* hflag = reinterpret_cast<long long*>(e->hflat + e->flat_cap);
     for (int s2 = 0; s2 < 3; ++s2) __atomic_store_n(hflag + s2, 2 * e->seq + 1, __ATOMIC_RELEASE);
+    if (e->hhead) {
+        raise_flag(hh_flag(e) + 1, 2 * e->seq);
+        raise_flag(hh_flag(e) + 3, 2 * e->seq);
+    }
+    e->hh_pending = false;
 }
 
 int enqueue(Engine* e, hipStream_t stream, const Call& c, const char** kname, std::string* err) {
@@ -1361,7 +1512,7 @@ void finish_parts(const Engine* e, double* ssq, double* head_quad) {
     double s = 0.0;
     for (long long g = 0; g < e->nwg_local; ++g) s += e->part[g];
     *ssq = s;
-    *head_quad = e->owns_head ? e->part[e->nwg_local] : 0.0;
+    *head_quad = e->owns_head ? (e->hosthead ? e->host_quad : e->part[e->nwg_local]) : 0.0;
 }
 
 // ... and the log marginal likelihood of a call that ran the whole series.
@@ -2885,7 +3036,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_smooth_one(const SArgs<D> by_
             }
         }
     }
-    if (ka.head_out_flag != nullptr && ka.mean != nullptr && g == ka.nwg - 1) {      // the head's outputs: the host has had the whole kernel to make them
+    if (ka.head_out_flag != nullptr && ka.mean != nullptr && g == ((ka.nwg + 7) / 8) / 2) {      // the head's outputs, by a workgroup from the middle of the dispatch (see k_steady_one)
         if (wave < 2) {
             wait_tables(ka.head_out_flag, ka.seq, &sPoison);
             double* dst = wave == 0 ? ka.mean : ka.var;

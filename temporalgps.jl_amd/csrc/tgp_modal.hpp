@@ -100,7 +100,7 @@ struct SmoothCall {
     //                            first thing (nullptr: the caller's inputs are host arrays already);
     //   mu0 / mu0_flag           the host's answer: the predicted mean of step nhs (workgroup 0 waits for it, bounded);
     //   xi_out / xi_flag         raised by workgroup 0 once xi at step nhs is known: the host runs the head backwards;
-    //   head_out / head_out_flag the head's nhs means and nhs variances from the host; the LAST workgroup waits for them (bounded) and writes
+    //   head_out / head_out_flag the head's nhs means and nhs variances from the host; a workgroup from the middle of the dispatch waits for them (bounded) and writes
     //                            them to mean / var [0, nhs).
     // Flags hold 2 seq once raised.  mu0_flag == nullptr: mu_start by value, head outputs are the caller's to write.
     double* head_in = nullptr;

@@ -980,6 +980,68 @@ inline int build_tables_variances(long long T, Modal& md, HeadTables& tab, Info&
     return kOk;
 }
 
+// ---- the head ON THE HOST (round 5): the kernel hands the head's observations over through pinned memory, the host runs the head's two
+// recursions in the original coordinates with the per-step gains build_core left in `tab` (kA = A K_t, iS, rS -- build_tables_forward must NOT
+// have run: it rewrites kA in modal coordinates) and the rows [G_t | c_t], vb of stages 1 and 2, and hands back the head's end state (modal:
+// z0 = V^-1 mu_nhs) and the head's outputs.  What k_steady_one's head wave computed (head_forward / head_backward / head_variances), minus
+// the PCIe pull of the tables and the one-wave dependent chains.
+template <int D>
+inline void modal_head_forward(const ModelHost& m, const Modal& md, const HeadTables& tab, const double* y, double* r_out, double* z0, double* quad) {
+    using namespace detail;
+    const Work<D>& wk = work<D>();
+    double mu[D], nm[D];
+    for (int i = 0; i < D; ++i) {
+        double v = m.a[i];
+        for (int k = 0; k < D; ++k) v = pfma(wk.A[i][k], m.x0m[k], v);
+        mu[i] = v;
+    }
+    double q = 0.0;
+    for (int t = 0; t < md.nhs; ++t) {
+        const int ti = t < md.n0 ? t : md.n0;
+        double r = y[t] - md.hh;
+        for (int k = 0; k < D; ++k) r -= wk.hv[k] * mu[k];
+        r_out[t] = r;
+        q += r * r * tab.iS[ti];
+        for (int i = 0; i < D; ++i) {
+            double v = pfma(tab.kA[ti * D + i], r, m.a[i]);
+            for (int k = 0; k < D; ++k) v = pfma(wk.A[i][k], mu[k], v);
+            nm[i] = v;
+        }
+        for (int i = 0; i < D; ++i) mu[i] = nm[i];
+    }
+    for (int i = 0; i < D; ++i) {
+        double v = 0.0;
+        for (int k = 0; k < D; ++k) v = pfma(wk.Vi[i * D + k], mu[k], v);
+        z0[i] = v;
+    }
+    *quad = q;
+}
+// zeta: the kernel's backward state entering the head from the right (modal); mean, vb [nhs]: y_t - (R / S_t) r_t + h' lam_t and h' Ps_t h
+template <int D>
+inline void modal_head_backward(const Modal& md, const HeadTables& tab, const double* y, const double* r, const double* zeta, double* mean, double* vb) {
+    using namespace detail;
+    double lam[D], nl[D];
+    for (int i = 0; i < D; ++i) {
+        double v = 0.0;
+        for (int k = 0; k < D; ++k) v = pfma(tab.Wm[i * D + k], zeta[k], v);
+        lam[i] = v;
+    }
+    for (int t = md.nhs - 1; t >= 0; --t) {
+        const int ti = t < md.n0 ? t : md.n0;
+        double o = y[t] - tab.rS[ti] * r[t];
+        for (int k = 0; k < D; ++k) o = pfma(tab.h[k], lam[k], o);
+        mean[t] = o;
+        vb[t] = tab.vb[ti];
+        const double* G = tab.G + (size_t)ti * D * D;
+        for (int i = 0; i < D; ++i) {
+            double v = tab.c[ti * D + i] * r[t];
+            for (int k = 0; k < D; ++k) v = pfma(G[i * D + k], lam[k], v);
+            nl[i] = v;
+        }
+        for (int i = 0; i < D; ++i) lam[i] = nl[i];
+    }
+}
+
 // stage: 0 forward, 1 backward, 2 variances (in this order; each may decline)
 template <int D>
 inline int build_tables_stage(int stage, long long T, Modal& md, HeadTables& tab, Info& info) {
@@ -1768,6 +1830,12 @@ inline Info build_any(const ModelHost& m, long long T, Modal& md, HeadTables& ta
     Info bad;
     bad.why = kEigFail;
     return bad;
+}
+inline void modal_head_forward_any(const ModelHost& m, const Modal& md, const HeadTables& tab, const double* y, double* r_out, double* z0, double* quad) {
+    TGP_PLAN_DISPATCH(m.d, modal_head_forward<D>(m, md, tab, y, r_out, z0, quad))
+}
+inline void modal_head_backward_any(const Modal& md, const HeadTables& tab, const double* y, const double* r, const double* zeta, double* mean, double* vb) {
+    TGP_PLAN_DISPATCH(md.d, modal_head_backward<D>(md, tab, y, r, zeta, mean, vb))
 }
 inline void build_smooth_any(const ModelHost& m, long long T, SmoothPlan& sp, double* tvb, bool post = true) {
     switch (m.d) {
