@@ -880,6 +880,9 @@ def main():
                         note=(("stationary-gain engine, one-launch form (DESIGN 3.13): ONE kernel per call reads y once (8 B/step, plus the workgroups' "
                                "halos out of L2) and writes mean, var (16 B/step); nothing else of size T moves, no other kernel runs "
                                "(`traffic` = PMC bytes of this kernel)" if kname.startswith("k_steady_one") else
+                               "no modal form (a defective closed loop): ONE kernel per call on DENSE powers of the closed loop and of the settled "
+                               "reverse-time transition (DESIGN 3.15); reads y once, writes mean, var once -- bound by its fp64 instruction stream "
+                               "(~230 FMAs per step at d = 6), not by HBM" if kname.startswith("k_smooth_one") else
                                "stationary-gain engine (DESIGN 3.11): the output pass reads y (8 B/step) and writes mean, var (16 B/step), nothing else "
                                "of size T moves; pass 1 reads y once more (`traffic` = PMC bytes of this kernel alone)" if kname.startswith("k_steady") else
                                "LTI (Fill) layout, general engine: streams only y in / (mean,var) out (plus the smoother scratch: `traffic`): the launch "

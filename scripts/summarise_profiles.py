@@ -64,6 +64,12 @@ def label(name):
     m = re.match(r"tgp_modal::k_steady_one<(\d+), (\d+), (\d+)(?:, \w+)?>", n)
     if m:      # (logpdf and posterior calls run the same kernel: the larger launch is the posterior call)
         return f"k_steady_one<{m.group(2)}x{m.group(3)},posterior>"
+    m = re.match(r"tgp_modal::k_smooth_one<", n)
+    if m:      # (as above: the larger launch is the posterior call)
+        return "k_smooth_one<posterior>"
+    m = re.match(r"tgp_modal::(k_filter_one|k_rand_one|k_adjoint_one)<", n)
+    if m:
+        return m.group(1)
     m = re.match(r"tgp_sweep::k_sweep<(\d+), (true|false), (\d+), (true|false)>", n)
     if m:
         return f"k_sweep<{'sde' if m.group(2) == 'true' else 'lti'},{'posterior' if m.group(4) == 'true' else 'logpdf'}>" + (f"[xs={m.group(3)}]" if m.group(3) != "0" else "")

@@ -2528,7 +2528,7 @@ static int smooth_lti_call(tgp_handle* h, const double* y, uint32_t flags, const
         tgp_modal::plan_smooth_head_forward(mh, sp, yhead, mu_end, &quad_head);
     }
     {
-        LaunchScope ls(h, "k_smooth_one");
+        LaunchScope ls(h, post ? "k_smooth_one<posterior>" : "k_smooth_one<logpdf>");
         const int rc = tgp_modal::smooth_lti(h->stream, sp, overlap ? nullptr : mu_end, c);
         if (rc != 0) return h->fail(TGP_EHIP, std::string("tgp_posterior_marginals: launch: ") + hipGetErrorString((hipError_t)rc));
     }
