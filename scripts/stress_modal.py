@@ -22,10 +22,13 @@ NAMES = ["matern12", "matern32", "matern52"]
 DIM = dict(matern12=1, matern32=2, matern52=3)
 LENGTHS = [300, 513, 600, 1023, 1024, 1025, 3583, 3584, 3585, 4095, 4096, 4097, 4608, 5000, 7552, 8192, 8193, 12345, 40960, 65536 + 511, 100_003, 250_000]
 WHY = ["applies", "covariance not settled", "not positive definite", "series too short", "ill-conditioned modal form", "mixes too slowly", "tail too long", "eigenvalues"]
-bad, one_launch = 0, 0
+bad, one_launch, dense_one = 0, 0, 0
 for case in range(n_cases):
     while True:
         terms = [(NAMES[rng.integers(3)], float(np.exp(rng.normal(0, 0.7))), float(np.exp(rng.normal(0, 0.7)))) for _ in range(rng.integers(1, 4))]
+        if rng.random() < 0.35:      # a second summand with the SAME length scale (another variance): a defective closed loop -- no modal form,
+            k = int(rng.integers(len(terms)))      # both recursions on dense powers (k_smooth_one)
+            terms.append((terms[k][0], float(np.exp(rng.normal(0, 0.7))), terms[k][2]))
         if sum(DIM[t[0]] for t in terms) <= 8:
             break
     dt = float(np.exp(rng.uniform(np.log(0.003), np.log(1.0))))
@@ -64,7 +67,8 @@ for case in range(n_cases):
                 lp, mean, var = tgp.logpdf_and_posterior_marginals(dm, yb[off:off + T], torch.from_numpy(Rn).cuda(), out=(om[off:off + T], ov[off:off + T]))
                 mean, var = mean.cpu().numpy(), var.cpu().numpy()
             names = set(hd.profile())
-            served[opt] = "one-launch" if any(n.startswith("k_steady_one") for n in names) else ("five-launch" if any(n.startswith("k_steady_apply") for n in names) else "general")
+            served[opt] = ("one-launch" if any(n.startswith("k_steady_one") for n in names) else "dense one-launch" if any(n.startswith("k_smooth_one") for n in names) and len(names) <= 2
+                           else ("five-launch" if any(n.startswith("k_steady_apply") for n in names) else "general"))
             scale = max(1.0, float(np.max(np.abs(pm))))
             if not abs(lp - lp_ref) <= 1e-10 * abs(lp_ref):
                 msgs.append(f"[{opt}] logpdf {lp} vs {lp_ref}")
@@ -80,6 +84,7 @@ for case in range(n_cases):
         del dm
         gc.collect()
     one_launch += served.get(3) == "one-launch"
+    dense_one += served.get(3) == "dense one-launch"
     # the plan's own verdict for the record
     A = np.asarray(model["A"]).reshape(-1, d, d)[0]
     Q = np.asarray(model["Q"]).reshape(-1, d, d)[0]
@@ -94,4 +99,4 @@ for case in range(n_cases):
     bad += bool(msgs)
     print(f"[{case:3d}] {'FAIL' if msgs else 'ok'} d={d} T={T} dt={dt:.4f} noise={noise:.2e} Rn={'T' if Rn.shape[0] > 1 else '1'} mode={mode} terms={[(t[0][6:], round(t[1], 2), round(t[2], 2)) for t in terms]} "
           f"served={served.get(3)}/{served.get(2)} plan={WHY[ii[0]]} n0={ii[1]} halo={ii[4]} {'; '.join(msgs)}", flush=True)
-print(f"{bad} failing cases of {n_cases}  ({one_launch} served by the one-launch path)")
+print(f"{bad} failing cases of {n_cases}  ({one_launch} served by the one-launch path, {dense_one} by the dense-powers one-launch path)")
