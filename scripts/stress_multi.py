@@ -21,6 +21,11 @@ for case in range(int(os.environ.get("START", "0")), min(n_cases, int(os.environ
     T = int(LENGTHS[rng.integers(len(LENGTHS))])
     W = int(rng.integers(2, 6))
     lti = rng.random() < 0.3                      # every block shared: the stationary-gain shards (or their fall-back)
+    if d >= 5 and not lti:
+        # ranks that meet on ONE device (this script's configuration, not a deployment's: one rank per GPU there) each hold a stream of their own,
+        # and the general engine's d >= 5 kernels make the runtime keep a scratch arena per queue: more than two of them and the HSA runtime
+        # aborts the process (HSA_STATUS_ERROR_OUT_OF_RESOURCES) -- the same limit the heavy stream pool of single handles observes
+        W = min(W, 2)
     per = {k: (not lti) and bool(rng.random() < 0.5) for k in "AaQHhR"}
 
     def psd(n, lo, hi):
