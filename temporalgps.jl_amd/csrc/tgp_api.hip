@@ -2303,22 +2303,56 @@ static int adjoint_lti_call(tgp_handle* h, const double* y, uint32_t flags, doub
     const size_t need = nhs + (size_t)nwg * ns + d + nrec + 16;
     TRY(ensure_pinned(h, need));
     double *yh = h->flt_host, *part = yh + nhs, *psi = part + (size_t)nwg * ns, *rec = psi + d;
+    if (!h->sm_sync) {
+        if (hipHostMalloc(reinterpret_cast<void**>(&h->sm_sync), 32 * sizeof(double), hipHostMallocDefault) != hipSuccess) return h->fail(TGP_EHIP, "hipHostMalloc");
+        std::memset(h->sm_sync, 0, 32 * sizeof(double));
+    }
     CallTimer tm(h, /*clear=*/false);
     TRY(set_obs(h, y, nullptr, flags));
     tm.inputs_done();
-    HIPCHK(hipMemcpyAsync(yh, h->mv.y, nhs * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    double mu_end[tgp_plan::kRandMaxD], quad_head = 0.0;
-    tgp_modal::plan_filter_head(mh, fp, yh, nullptr, nullptr, mu_end, &quad_head);
+    // The head beside the kernel: the launch goes first, workgroup 0 hands the head's observations over through pinned memory,
+    // the host answers with the head's end state.  With synchronous launches: copy, synchronise, head, launch.
+    const bool overlap = tgp_modal::overlap_allowed();
+    double* mu_end = h->sm_sync;
+    long long* sflag = reinterpret_cast<long long*>(h->sm_sync + 16);
+    const long long seq = ++h->smooth_seq;
+    double quad_head = 0.0;
+    tgp_modal::HeadHandover hh;
+    if (overlap) {
+        hh.head_in = yh;
+        hh.head_in_flag = sflag;
+        hh.mu0 = mu_end;
+        hh.mu0_flag = sflag + 1;
+        hh.seq = seq;
+    } else {
+        HIPCHK(hipMemcpyAsync(yh, h->mv.y, nhs * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        tgp_modal::plan_filter_head(mh, fp, yh, nullptr, nullptr, mu_end, &quad_head);
+    }
     {
         LaunchScope ls(h, "k_adjoint_one");
-        const int rc = tgp_modal::adjoint_lti(h->stream, fp, mu_end, h->mv.y, h->T, part, psi);
+        const int rc = tgp_modal::adjoint_lti(h->stream, fp, overlap ? nullptr : mu_end, h->mv.y, h->T, part, psi, overlap ? &hh : nullptr);
         if (rc != 0) return h->fail(TGP_EHIP, std::string("tgp_logpdf_adjoint: launch: ") + hipGetErrorString((hipError_t)rc));
+    }
+    bool handshake_ok = true;
+    if (overlap) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int spin = 0;; ++spin) {      // (bounded: the kernel's own wait gives up after two seconds)
+            if (__atomic_load_n(sflag, __ATOMIC_ACQUIRE) >= 2 * seq) break;
+            if ((spin & 255) == 255 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(1500)) {
+                handshake_ok = false;
+                break;
+            }
+            __builtin_ia32_pause();
+        }
+        if (handshake_ok) tgp_modal::plan_filter_head(mh, fp, yh, nullptr, nullptr, mu_end, &quad_head);
+        __atomic_store_n(sflag + 1, 2 * seq, __ATOMIC_RELEASE);      // (also when the hand-over failed: workgroup 0 never waits for what will not come)
     }
     tm.kernels_done();
     if (h->timing) (void)hipEventRecord(h->ev[3], h->stream);
     HIPCHK(hipStreamSynchronize(h->stream));
     resolve_profile(h);
+    if (!handshake_ok) return h->fail(TGP_EHIP, "tgp_logpdf_adjoint: the host / device hand-over timed out");
     // the record tgp_adjoint::finish reads: the sums (fixed order over the workgroups), psi at the head's end, n0 / T, the model blocks
     for (size_t e = 0; e < nrec; ++e) rec[e] = 0.0;
     for (long long g = 0; g < nwg; ++g)

@@ -2271,6 +2271,13 @@ struct GArgs {
     int halo;
     const double* y;
     double *part, *psi_out;
+    // the head beside the kernel (SmoothCall in tgp_modal.hpp): workgroup 0 hands the head's observations over through pinned memory and waits
+    // (bounded) for the predicted mean of step nhs; nullptr: mu0 above by value
+    double* head_in;
+    long long* head_in_flag;
+    const double* mu0p;
+    const long long* mu0_flag;
+    long long seq;
 };
 
 template <int D, int NW>
@@ -2280,7 +2287,9 @@ __global__ __launch_bounds__(NW * 64, 2) void k_adjoint_one(const GArgs<D> by_va
     constexpr int SUB = kWJ, TILE = 64 * SUB, NS = D * D + 3 * D + 2;
     __shared__ double sF[NW][D], sB[NW][D], sAcc[NW][NS];
     __shared__ double sPw[D][D][64];      // Phi^(8 e), e = 0 .. 63
+    __shared__ double sPoison;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) sPoison = 0.0;
     long long g;
     {
         const long long per = (ka.nwg + 7) / 8;
@@ -2292,6 +2301,11 @@ __global__ __launch_bounds__(NW * 64, 2) void k_adjoint_one(const GArgs<D> by_va
     const long long s0 = first ? ka.nhs : c_lo - ka.halo;
     const long long tile_t0 = s0 + (long long)wave * TILE, t0 = tile_t0 + (long long)lane * SUB;
     const bool any_valid = tile_t0 < T && tile_t0 < c_hi + ka.halo;      // (wave-uniform: tiles behind the right-hand halo have nothing to do)
+    if (first && wave == NW - 1 && ka.head_in != nullptr) {      // the head's observations to the host, first thing
+        for (long long t = lane; t < ka.nhs; t += 64) ka.head_in[t] = ka.y[t];
+        __threadfence_system();
+        if (lane == 0) __hip_atomic_store(ka.head_in_flag, 2 * ka.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     {
         const int uw = __builtin_amdgcn_readfirstlane(wave);
 #pragma unroll
@@ -2414,13 +2428,15 @@ __global__ __launch_bounds__(NW * 64, 2) void k_adjoint_one(const GArgs<D> by_va
         double zin[D];
 #pragma unroll
         for (int i = 0; i < D; ++i) zin[i] = 0.0;
+        const bool from_host = first && wave < 3 && ka.mu0_flag != nullptr;      // (wave-uniform) the head's end state comes from the host, beside the kernel
+        if (from_host) wait_tables(ka.mu0_flag, ka.seq, &sPoison);
 #pragma unroll
         for (int k = 1; k <= 3; ++k) {
             const int src = wave - k;
             if (src < -1 || (src == -1 && !first)) continue;
             double xs[D];
 #pragma unroll
-            for (int i = 0; i < D; ++i) xs[i] = src >= 0 ? sF[src][i] : ka.mu0[i];
+            for (int i = 0; i < D; ++i) xs[i] = src >= 0 ? sF[src][i] : (from_host ? ka.mu0p[i] : ka.mu0[i]);
             if (k == 1) {
 #pragma unroll
                 for (int i = 0; i < D; ++i) zin[i] += xs[i];
@@ -2591,12 +2607,12 @@ __global__ __launch_bounds__(NW * 64, 2) void k_adjoint_one(const GArgs<D> by_va
         double tsum = 0.0;
 #pragma unroll
         for (int w = 0; w < NW; ++w) tsum += sAcc[w][threadIdx.x];
-        ka.part[g * NS + threadIdx.x] = tsum;
+        ka.part[g * NS + threadIdx.x] = tsum + sPoison;      // (NaN once a bounded wait for the host ran out: the call's result is discarded)
     }
 }
 
 template <int D>
-int launch_adjoint(hipStream_t st, const tgp_plan::FilterPlan& fp, const double* mu0, const double* y, long long T, double* part, double* psi_out) {
+int launch_adjoint(hipStream_t st, const tgp_plan::FilterPlan& fp, const double* mu0, const double* y, long long T, double* part, double* psi_out, const HeadHandover* hh) {
     constexpr int NW = 8;
     GArgs<D> ka;
     static_assert(sizeof(GArgs<D>) <= 4096, "the kernel-argument segment");
@@ -2605,7 +2621,7 @@ int launch_adjoint(hipStream_t st, const tgp_plan::FilterPlan& fp, const double*
         ka.a[i] = fp.a[i];
         ka.kA[i] = fp.kA[i];
         ka.h[i] = fp.h[i];
-        ka.mu0[i] = mu0[i];
+        ka.mu0[i] = mu0 != nullptr ? mu0[i] : 0.0;
         for (int k = 0; k < D; ++k) {
             ka.Phi[i][k] = fp.Phi[i * D + k];
             for (int b = 0; b < 6; ++b) ka.P[b][i][k] = fp.P[b][i * D + k];
@@ -2622,6 +2638,13 @@ int launch_adjoint(hipStream_t st, const tgp_plan::FilterPlan& fp, const double*
     ka.y = y;
     ka.part = part;
     ka.psi_out = psi_out;
+    if (hh != nullptr) {
+        ka.head_in = hh->head_in;
+        ka.head_in_flag = hh->head_in_flag;
+        ka.mu0p = hh->mu0;
+        ka.mu0_flag = hh->mu0_flag;
+        ka.seq = hh->seq;
+    }
     const long long per = (ka.nwg + 7) / 8;
     hipLaunchKernelGGL((k_adjoint_one<D, NW>), dim3((unsigned)(per * 8)), dim3(NW * 64), 0, st, ka);
     return (int)hipGetLastError();
@@ -2633,14 +2656,15 @@ long long adjoint_workgroups(const tgp_plan::FilterPlan& fp, long long T) {
     return C > 0 ? (T - fp.nhs + C - 1) / C : -1;
 }
 
-int adjoint_lti(hipStream_t stream, const tgp_plan::FilterPlan& fp, const double* mu_start, const double* y, long long T, double* part, double* psi_out) {
+int adjoint_lti(hipStream_t stream, const tgp_plan::FilterPlan& fp, const double* mu_start, const double* y, long long T, double* part, double* psi_out,
+                const HeadHandover* hh) {
     switch (fp.d) {
-        case 1: return launch_adjoint<1>(stream, fp, mu_start, y, T, part, psi_out);
-        case 2: return launch_adjoint<2>(stream, fp, mu_start, y, T, part, psi_out);
-        case 3: return launch_adjoint<3>(stream, fp, mu_start, y, T, part, psi_out);
-        case 4: return launch_adjoint<4>(stream, fp, mu_start, y, T, part, psi_out);
-        case 5: return launch_adjoint<5>(stream, fp, mu_start, y, T, part, psi_out);
-        case 6: return launch_adjoint<6>(stream, fp, mu_start, y, T, part, psi_out);
+        case 1: return launch_adjoint<1>(stream, fp, mu_start, y, T, part, psi_out, hh);
+        case 2: return launch_adjoint<2>(stream, fp, mu_start, y, T, part, psi_out, hh);
+        case 3: return launch_adjoint<3>(stream, fp, mu_start, y, T, part, psi_out, hh);
+        case 4: return launch_adjoint<4>(stream, fp, mu_start, y, T, part, psi_out, hh);
+        case 5: return launch_adjoint<5>(stream, fp, mu_start, y, T, part, psi_out, hh);
+        case 6: return launch_adjoint<6>(stream, fp, mu_start, y, T, part, psi_out, hh);
     }
     return (int)hipErrorInvalidValue;
 }

@@ -81,7 +81,17 @@ int filter_lti(hipStream_t stream, const tgp_plan::FilterPlan& plan, const doubl
 constexpr int kAdjointMaxD = 6;
 inline int adjoint_sums(int d) { return d * d + 3 * d + 2; }
 long long adjoint_workgroups(const tgp_plan::FilterPlan& plan, long long T);
-int adjoint_lti(hipStream_t stream, const tgp_plan::FilterPlan& plan, const double* mu_start, const double* y, long long T, double* part, double* psi_out);
+// The head beside the kernel (as SmoothCall's): workgroup 0 copies the head's nhs observations to head_in (pinned) and raises head_in_flag; the
+// host runs the head forwards and answers with the predicted mean of step nhs in mu0 (pinned) + mu0_flag; flags hold 2 seq.  mu_start is then unused.
+struct HeadHandover {
+    double* head_in = nullptr;
+    long long* head_in_flag = nullptr;
+    const double* mu0 = nullptr;
+    const long long* mu0_flag = nullptr;
+    long long seq = 0;
+};
+int adjoint_lti(hipStream_t stream, const tgp_plan::FilterPlan& plan, const double* mu_start, const double* y, long long T, double* part, double* psi_out,
+                const HeadHandover* handover = nullptr);
 // logpdf + posterior marginals of an LTI model behind its head in ONE kernel on DENSE powers of the closed loop (forwards) and of the settled
 // reverse-time transition (backwards): the models the modal plan declines (d <= tgp_plan::kRandMaxD).  The head runs on the host
 // (plan_smooth_head_*: forwards before the launch, its data-free tables beside the kernel, backwards behind it from xi_out).
