@@ -26,6 +26,13 @@
  *     the next tgp_model_set / tgp_destroy, per-call arrays until the call returns.
  *   - threading: calls on one handle are serialised by the caller; one HIP stream per handle; every call
  *     returns with its results complete (blocking). Distinct handles are independent.
+ *   - device inputs (TGP_IN_DEVICE) must be COMPLETE when the call is made: the library's streams do not wait
+ *     for the stream that produced them (the Python mirror synchronises torch's current stream before a call on
+ *     torch tensors; the Julia glue passes host arrays). Several one-launch paths talk to the host through pinned memory while
+ *     their kernel runs (the head of an LTI series is computed on the host beside the kernel); under the
+ *     runtime's synchronous-launch switches (HIP_LAUNCH_BLOCKING, AMD_SERIALIZE_KERNEL, ...) they run the same
+ *     steps one after the other. Environment switches for A/B runs: TGP_MODAL_OVERLAP=0 (no host / device
+ *     hand-over at all), TGP_MODAL_HOSTHEAD=0 (the head of the one-launch kernel inside the kernel).
  */
 #ifndef TGP_HIP_H
 #define TGP_HIP_H
