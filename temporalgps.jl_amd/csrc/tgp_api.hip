@@ -2336,15 +2336,7 @@ static int adjoint_lti_call(tgp_handle* h, const double* y, uint32_t flags, doub
     }
     bool handshake_ok = true;
     if (overlap) {
-        const auto t0 = std::chrono::steady_clock::now();
-        for (int spin = 0;; ++spin) {      // (bounded: the kernel's own wait gives up after two seconds)
-            if (__atomic_load_n(sflag, __ATOMIC_ACQUIRE) >= 2 * seq) break;
-            if ((spin & 255) == 255 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(1500)) {
-                handshake_ok = false;
-                break;
-            }
-            __builtin_ia32_pause();
-        }
+        handshake_ok = tgp_modal::await_host_flag(sflag, 2 * seq, h->stream);
         if (handshake_ok) tgp_modal::plan_filter_head(mh, fp, yh, nullptr, nullptr, mu_end, &quad_head);
         __atomic_store_n(sflag + 1, 2 * seq, __ATOMIC_RELEASE);      // (also when the hand-over failed: workgroup 0 never waits for what will not come)
     }
@@ -2575,14 +2567,7 @@ static int smooth_lti_call(tgp_handle* h, const double* y, uint32_t flags, const
                 if (__atomic_load_n(f + k, __ATOMIC_RELAXED) < v) __atomic_store_n(f + k, v, __ATOMIC_RELEASE);
         }
     } guard{overlap ? sflag : nullptr, 2 * seq};
-    auto await = [&](const long long* f) {      // bounded (the kernel's own waits give up after two seconds): false = the flag never came
-        const auto t0 = std::chrono::steady_clock::now();
-        for (int spin = 0;; ++spin) {
-            if (__atomic_load_n(f, __ATOMIC_ACQUIRE) >= 2 * seq) return true;
-            if ((spin & 255) == 255 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(1500)) return false;
-            __builtin_ia32_pause();
-        }
-    };
+    auto await = [&](const long long* f) { return tgp_modal::await_host_flag(f, 2 * seq, h->stream); };
     bool handshake_ok = true;
     if (overlap) {
         if (idev) handshake_ok = await(sflag);

@@ -1074,6 +1074,7 @@ struct Engine {
     double hr[tgp_plan::kHeadMax];
     bool hosthead = false, hh_pending = false;
     int rnew_per_step = 0;
+    hipStream_t stream = nullptr;      // of the last launch (the host's waits watch it)
     double host_quad = 0.0;
     tgp_plan::ModelHost mh{};
     long long hh_T = 0;
@@ -1152,6 +1153,7 @@ int launch(Engine* e, hipStream_t st, const Call& c, const char** kname) {
     ka.part = e->part;
     e->hh_pending = false;
     e->rnew_per_step = c.rnew_per_step;
+    e->stream = st;
     if (e->hosthead && e->owns_head) {
         ka.hosthead = 1;
         ka.head_in = hh_in(e);
@@ -1406,15 +1408,23 @@ bool plan(Engine* e, const tgp_plan::ModelHost& m, long long T) {
 // Behind the launch: the tables half of the plan, if it was deferred.  false: it declined (the kernel has been released all the same -- whatever
 // it writes is to be discarded, the caller re-runs the call elsewhere after synchronising).
 namespace {
-// bounded (the kernel's own waits give up after two seconds): false = the flag never came
-bool await_flag(const long long* f, long long v) {
-    const auto t0 = std::chrono::steady_clock::now();
-    for (int spin = 0;; ++spin) {
+}  // namespace
+// The host's side of a hand-over: spins on a flag in pinned memory the kernel raises.  Not bounded by the clock -- the kernel may not even
+// have started (a stream with work of the caller's in front of it) -- but by the stream: once it has drained (hipStreamQuery, every few
+// thousand spins) the kernel is through, and the flag is there or will never be (the kernel's own waits give up after two seconds and
+// poison its result).  false: the stream is done, or in error, and the flag never came.
+bool await_host_flag(const long long* f, long long v, hipStream_t stream) {
+    for (unsigned spin = 1;; ++spin) {
         if (__atomic_load_n(f, __ATOMIC_ACQUIRE) >= v) return true;
-        if ((spin & 255) == 255 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(1500)) return false;
+        if ((spin & 4095u) == 0) {
+            const hipError_t q = hipStreamQuery(stream);
+            (void)hipGetLastError();      // (hipErrorNotReady is not an error of ours: it must not surface in the next launch's check)
+            if (q != hipErrorNotReady) return __atomic_load_n(f, __ATOMIC_ACQUIRE) >= v;
+        }
         __builtin_ia32_pause();
     }
 }
+namespace {
 void raise_flag(long long* f, long long v) {
     if (__atomic_load_n(f, __ATOMIC_RELAXED) < v) __atomic_store_n(f, v, __ATOMIC_RELEASE);
 }
@@ -1439,7 +1449,7 @@ bool complete(Engine* e, long long T) {
     e->hh_pending = false;
     bool ok = true;
     if (head) {
-        ok = await_flag(f, v);
+        ok = await_host_flag(f, v, e->stream);
         if (ok) tgp_plan::modal_head_forward_any(e->mh, e->md, *e->tab, hh_in(e), e->hr, hh_z0(e), &e->host_quad);
         raise_flag(f + 1, v);
     }
@@ -1450,7 +1460,7 @@ bool complete(Engine* e, long long T) {
         ship_stage(e, 2, why);
     }
     if (head && e->post) {
-        if (ok && why == tgp_plan::kOk) ok = await_flag(f + 2, v);
+        if (ok && why == tgp_plan::kOk) ok = await_host_flag(f + 2, v, e->stream);
         if (ok && why == tgp_plan::kOk) {
             const int nhs = e->md.nhs;
             double *om = hh_out(e), *ov = om + nhs;

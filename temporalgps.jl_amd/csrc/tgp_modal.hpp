@@ -123,6 +123,8 @@ struct SmoothCall {
 // false when the process runs with synchronous launches (HIP_LAUNCH_BLOCKING, AMD_SERIALIZE_KERNEL, ...) or TGP_MODAL_OVERLAP=0: a kernel
 // that waits for a flag the host raises behind the launch would wait for itself
 bool overlap_allowed();
+// the host's wait for a flag in pinned memory the kernel on `stream` raises (value >= v): returns false once the stream has drained without it
+bool await_host_flag(const long long* flag, long long v, hipStream_t stream);
 void plan_smooth(const tgp_plan::ModelHost& m, long long T, tgp_plan::SmoothPlan& sp, double* tvb, bool post = true);      // post = false: logpdf only (tvb unused)
 void plan_smooth_head_forward(const tgp_plan::ModelHost& m, const tgp_plan::SmoothPlan& sp, const double* y, double* mu_end, double* quad);
 bool plan_smooth_head_tables(const tgp_plan::ModelHost& m, const tgp_plan::SmoothPlan& sp);

@@ -424,3 +424,33 @@ def test_posterior_of_an_lti_model_in_one_launch(tgp, d):
         mean, var = tgp.posterior_marginals(dm, y, Rn)
         em, ev = tgp.marginals(tgp.replace_observation_noise_cov(dpost, Rn))
         assert np.max(np.abs(em - mean)) <= 1e-7 and np.max(np.abs(ev - var)) <= 1e-7, (T, np.max(np.abs(em - mean)), np.max(np.abs(ev - var)))
+
+
+def test_a_stream_with_work_of_the_callers_in_front_of_the_kernel(tgp):
+    """the one-launch paths talk to the host while their kernel runs (the head of the series is computed on the host: DESIGN 3.15, 3.16); on a
+    stream of the caller's with seconds of work queued in front of it the kernel starts late -- the host's side of the hand-over must wait for it
+    (it watches the stream, not the clock) and the call must come back with the right numbers"""
+    import torch
+    T = 20000
+    for spec in (KERNELS[3], DECLINED[6]):
+        model = oc.build_lgssm(spec, ("regular", 0.0, 0.1, T), 0.1)
+        y = draw(model, 3)
+        Rn = np.array([0.1])
+        lp_ref = sk.logpdf(model, y)
+        m_ref, v_ref = sk.posterior_marginals(model, y, Rn)
+        dm = device_model(tgp, model)
+        hd = dm.handle()
+        s = torch.cuda.Stream()
+        hd.check(hd.lib.tgp_set_stream(hd.h, ctypes.c_void_p(s.cuda_stream)))
+        a = torch.randn(6144, 6144, dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        with torch.cuda.stream(s):
+            for _ in range(8):        # a few seconds of fp64 GEMMs in front of the library's kernel (~0.35 s each on an MI355X)
+                a = (a @ a) * 1e-4
+        lp, mean, var = tgp.logpdf_and_posterior_marginals(dm, y, Rn)
+        assert abs(lp - lp_ref) <= 1e-10 * abs(lp_ref)
+        assert np.max(np.abs(mean - m_ref)) <= 1e-8 and np.max(np.abs(var - v_ref)) <= 1e-8
+        assert served(dm) > T - 700      # (served by the one-launch path, not a fall-back after a timed-out hand-over)
+        torch.cuda.synchronize()
+        hd.check(hd.lib.tgp_set_stream(hd.h, None))
+        del a
