@@ -267,7 +267,7 @@ def broadcast_components(FqH, x0, t):
     P = _symmetric_from_upper(P0)
     d = F.shape[0]
     if isinstance(t, RegularSpacing):
-        A = expm(F * t.dt)
+        A = _expm_small(np.asarray(F, dtype=np.float64) * t.dt)      # (closed form for a Matern block, scipy's expm otherwise)
         return A[None], np.zeros((1, d)), (P - A @ P @ A.T)[None], np.array(H, dtype=np.float64)[None], np.zeros(1)
     tt = np.asarray(t, dtype=np.float64)
     dts = np.diff(np.concatenate([[tt[0] - 1.0], tt]))
@@ -568,6 +568,33 @@ def parameters(kernel, prefix="kernel"):
 
 
 # ---- exact derivatives of the O(1) host map hyper-parameter -> shared blocks (regular spacing) ---------------------------------------
+_EYE = {}
+
+
+def _expm_small(X):
+    """exp(X) of a small matrix.  X = -lam I + N with N nilpotent -- every Matern block's F dt, stretched or not -- has
+    exp(X) = e^(-lam) (I + N + N^2 / 2 + ...) in closed form (what the device evaluates per step on irregular inputs): a few
+    products of 3 x 3 matrices against scipy's Pade approximant with its norm estimates (~30 us a piece: a quarter of the host's share of a
+    gradient evaluation).  Anything else goes to scipy.linalg.expm."""
+    n = X.shape[0]
+    if n <= 4 and X.shape[1] == n:
+        I = _EYE.get(n)
+        if I is None:
+            I = _EYE[n] = np.eye(n)
+        lam = -float(np.trace(X)) / n
+        N = X + lam * I
+        S, Nk, f = I + N, N, 1.0
+        for k in range(2, n):
+            Nk = Nk @ N
+            f *= k
+            S = S + Nk / f
+        Nn = Nk @ N if n > 1 else N
+        scale = float(np.max(np.abs(N))) if n > 1 else 0.0
+        if float(np.max(np.abs(Nn))) <= 1e-14 * max(scale, 1e-300) ** n:
+            return np.exp(-lam) * S
+    return expm(X)
+
+
 def _expm_and_tangent(X, E, cache=None):
     """exp(X) and its Frechet derivative in direction E. E = 0: no derivative; E commuting with X (every rule of `_sde_jet`: a stretch
     scales F, a product's factor enters as a Kronecker summand): dexp = E exp(X); otherwise Van Loan (the upper-right block of
@@ -576,13 +603,13 @@ def _expm_and_tangent(X, E, cache=None):
     A = None if key is None else cache.get(key)
     if not np.any(E):
         if A is None:
-            A = expm(X)
+            A = _expm_small(X)
             if key is not None:
                 cache[key] = A
         return A, np.zeros_like(X)
     if np.max(np.abs(X @ E - E @ X)) <= 1e-14 * max(1e-300, np.max(np.abs(X)) * np.max(np.abs(E))):
         if A is None:
-            A = expm(X)
+            A = _expm_small(X)
             if key is not None:
                 cache[key] = A
         return A, E @ A
@@ -740,7 +767,10 @@ def _sde_param_tangents(fx, names, plist):
 def _logpdf_and_gradient_adjoint(fx, y):
     """One adjoint pass on the device (block gradients) contracted with the exact block tangents: cost independent of the number of
     hyper-parameters."""
-    _shared_blocks(fx)                      # raises for layouts the pass does not cover
+    # (layouts the pass does not cover raise; regular spacing with one noise variance and a zero / constant mean is all-shared by construction:
+    #  evaluating the components -- a matrix exponential -- only to look at their shapes was a fifth of the host's share of a gradient)
+    if not (isinstance(fx.x, RegularSpacing) and fx.sigma2.shape[0] == 1 and isinstance(fx.f.f.mean, (ZeroMean, ConstMean))):
+        _shared_blocks(fx)
     plist = parameters(fx.f.f.kernel)
     names = [n for n, _, _ in plist] + ["noise"] + (["mean.c"] if isinstance(fx.f.f.mean, ConstMean) else [])
     lp, g = L.logpdf_adjoint(fx.build_lgssm(), y)
