@@ -319,6 +319,18 @@ int tgp_posterior_marginals_at(tgp_handle* h, const double* y, const uint8_t* mi
  *      smoothing marginals for a materialised Reverse posterior). */
 int tgp_marginals(tgp_handle* h, uint32_t flags, double* mean_out, double* var_out);
 
+/* ---- rand(rng, replace_observation_noise_cov(posterior(model, y), Rnew)) with the randomness supplied
+ *      (posterior_lti_sde.jl:48-58 -> lgssm.jl:65-91 on the reverse-time model of lgssm.jl:193-221) WITHOUT
+ *      evaluating that model (T x (2 d^2 + d) doubles): Forward LTI models with scalar observations, one noise
+ *      variance, no missing data and d <= 4 run the filter and the reverse-time draw in ONE kernel over
+ *      y and the draws. eps_t [T][d], eps_e [T] where TGP_IN_DEVICE says (as y and Rnew),
+ *      eps_0 [d] host; eps_t[t] / eps_e[t] drive the transition / emission of step t and eps_0 the draw of the
+ *      final filtering state, exactly as tgp_rand on the evaluated posterior uses them. Rnew: one value
+ *      (TGP_SHARED_R) or T. y_out [T]. TGP_EUNSUPPORTED: not a model of this path -- evaluate the posterior
+ *      (tgp_posterior), bind it as a Reverse model and call tgp_rand (what the Python mirror does). */
+int tgp_posterior_rand(tgp_handle* h, const double* y, const double* Rnew, const double* eps_t, const double* eps_e,
+                       const double* eps_0, uint32_t flags, double* y_out);
+
 /* ---- rand(rng, model) with the randomness supplied: lgssm.jl:65-91, lgc.jl:84-87,241-243,
  *      gaussian.jl:35-43. eps_t [T][d], eps_e [T], eps_0 [d] (eps_0 always host). y_out [T].
  *      A Forward LTI model (every block shared) with scalar observations and d <= 8 runs as ONE kernel over the draws

@@ -60,6 +60,7 @@ _SIGS = {
     "tgp_posterior_marginals_at": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _vp, _vp, _vp, _u32, _vp, _vp, _dp]),
     "tgp_marginals": (ctypes.c_int, [_vp, _u32, _vp, _vp]),
     "tgp_rand": (ctypes.c_int, [_vp, _vp, _vp, _vp, _u32, _vp]),
+    "tgp_posterior_rand": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp]),
     "tgp_elem_size": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
     "tgp_segment_reduce": (ctypes.c_int, [_vp, _vp, _vp, _u32, _vp]),
     "tgp_elem_apply": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, _vp, _vp]),

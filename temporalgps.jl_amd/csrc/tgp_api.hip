@@ -2042,7 +2042,11 @@ int tgp_model_set_x0(tgp_handle* h, const double* x0m, const double* x0P) {
 }
 
 static int filter_lti_call(tgp_handle* h, const double* y, uint32_t flags, double* m_out, double* P_out, double* lml_out, bool* served);
-static int smooth_lti_call(tgp_handle* h, const double* y, uint32_t flags, const double* Rnew, double* mean_out, double* var_out, double* lml_out, bool* served);
+struct SmoothRand {      // a draw from the posterior instead of its marginals: eps_t [T][d], eps_e [T] (where TGP_IN_DEVICE says), eps_0 [d] (host)
+    const double *eps_t, *eps_e, *eps_0;
+};
+static int smooth_lti_call(tgp_handle* h, const double* y, uint32_t flags, const double* Rnew, double* mean_out, double* var_out, double* lml_out, bool* served,
+                           const SmoothRand* rnd = nullptr);
 
 int tgp_logpdf(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t flags, double* out) {
     TRY(check_ready(h, /*general=*/false));
@@ -2477,17 +2481,20 @@ static int filter_lti_call(tgp_handle* h, const double* y, uint32_t flags, doubl
 // d <= 8; a defective closed loop: two summands with one length scale, ...): the head on the host, everything behind it in ONE kernel on the
 // dense powers of the closed loop and of the settled reverse-time transition (tgp_modal::smooth_lti).  *served = false: the
 // five-launch engine runs the call.
-static int smooth_lti_call(tgp_handle* h, const double* y, uint32_t flags, const double* Rnew, double* mean_out, double* var_out, double* lml_out, bool* served) {
+static int smooth_lti_call(tgp_handle* h, const double* y, uint32_t flags, const double* Rnew, double* mean_out, double* var_out, double* lml_out, bool* served,
+                           const SmoothRand* rnd) {
     *served = false;
     tgp_plan::ModelHost mh;
     if (!h->opt_modal || h->smooth_state < 0 || chunk_engine_requested(h) || h->is_dense || !h->lti || h->p != 1 || h->ordering != 0 || h->sde ||
-        h->d > tgp_plan::kRandMaxD || !modal_host_model(h, mh) || (mean_out != nullptr) != (var_out != nullptr) || (mean_out && !Rnew))
+        h->d > tgp_plan::kRandMaxD || !modal_host_model(h, mh) || (!rnd && (mean_out != nullptr) != (var_out != nullptr)) || (mean_out && !Rnew))
         return TGP_OK;
+    if (rnd && (h->d > tgp_modal::kSmoothRandMaxD || !mean_out || var_out || !rnd->eps_t || !rnd->eps_e || !rnd->eps_0)) return TGP_OK;
     const bool post = mean_out != nullptr;      // (false: logpdf only -- the forward half alone, no halo behind a span)
     constexpr size_t HM = tgp_plan::kHeadMax;
     const size_t nwg_max = (size_t)(h->T / 1024) + 2;
-    TRY(ensure_pinned(h, 4 * HM + nwg_max + tgp_plan::kTailMax + 8));
-    double *hin = h->flt_host, *hout = hin + 2 * HM, *tvb = hout + 2 * HM, *part = tvb + tgp_plan::kTailMax;      // hin: y | Rnew of the head; hout: mean | var
+    TRY(ensure_pinned(h, 10 * HM + nwg_max + tgp_plan::kTailMax + 8));
+    // hin: y | Rnew (| eta | eps [nhs][d] of a draw) of the head; hout: mean | var
+    double *hin = h->flt_host, *hout = hin + 8 * HM, *tvb = hout + 2 * HM, *part = tvb + tgp_plan::kTailMax;
     if (!h->sm_sync) {
         if (hipHostMalloc(reinterpret_cast<void**>(&h->sm_sync), 32 * sizeof(double), hipHostMallocDefault) != hipSuccess) return h->fail(TGP_EHIP, "hipHostMalloc");
         std::memset(h->sm_sync, 0, 32 * sizeof(double));
@@ -2512,9 +2519,15 @@ static int smooth_lti_call(tgp_handle* h, const double* y, uint32_t flags, const
     // steps one after the other, copies on the handle's stream.
     const bool overlap = tgp_modal::overlap_allowed();
     const long long seq = ++h->smooth_seq;
+    double rU[tgp_modal::kSmoothRandMaxD * tgp_modal::kSmoothRandMaxD], rv0[tgp_modal::kSmoothRandMaxD], rs0 = 0.0;
+    if (rnd && !tgp_modal::plan_smooth_rand_factors(sp, rnd->eps_0, rU, rv0, &rs0)) return TGP_OK;      // (a noise factor not positive definite: the evaluated route gives the verdict)
     CallTimer tm(h, /*clear=*/false);
-    const void* pR = nullptr;
+    const void *pR = nullptr, *pet = nullptr, *pee = nullptr;
     if (post) TRY(stage_in(h, h->bRnew, Rnew, rshared ? sizeof(double) : nT, idev, &pR));
+    if (rnd) {
+        TRY(stage_in(h, h->beps_t, rnd->eps_t, (size_t)h->T * h->d * sizeof(double), idev, &pet));
+        TRY(stage_in(h, h->beps_e, rnd->eps_e, nT, idev, &pee));
+    }
     TRY(set_obs(h, y, nullptr, flags));
     tm.inputs_done();
     double *dm = nullptr, *dv = nullptr;
@@ -2522,6 +2535,7 @@ static int smooth_lti_call(tgp_handle* h, const double* y, uint32_t flags, const
     TRY(stage_out(h, h->bo2, var_out, nT, odev, &dv));
     double quad_head = 0.0;
     const double *yhead = idev ? hin : y, *rnhead = idev ? hin + nhs : Rnew;
+    const double *eehead = rnd ? (idev ? hin + 2 * nhs : rnd->eps_e) : nullptr, *ethead = rnd ? (idev ? hin + 3 * nhs : rnd->eps_t) : nullptr;
     tgp_modal::SmoothCall c;
     c.T = h->T;
     c.y = h->mv.y;
@@ -2533,6 +2547,13 @@ static int smooth_lti_call(tgp_handle* h, const double* y, uint32_t flags, const
     c.part = part;
     c.xi_out = xi;
     c.seq = seq;
+    if (rnd) {
+        c.eps_t = static_cast<const double*>(pet);
+        c.eps_e = static_cast<const double*>(pee);
+        c.U = rU;
+        c.v0 = rv0;
+        c.s0 = rs0;
+    }
     if (overlap) {
         if (idev) {
             c.head_in = hin;
@@ -2549,12 +2570,16 @@ static int smooth_lti_call(tgp_handle* h, const double* y, uint32_t flags, const
         if (idev) {
             HIPCHK(hipMemcpyAsync(hin, y, nhs * sizeof(double), hipMemcpyDeviceToHost, h->stream));
             if (post) HIPCHK(hipMemcpyAsync(hin + nhs, Rnew, (rshared ? 1 : nhs) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+            if (rnd) {
+                HIPCHK(hipMemcpyAsync(hin + 2 * nhs, rnd->eps_e, nhs * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+                HIPCHK(hipMemcpyAsync(hin + 3 * nhs, rnd->eps_t, nhs * h->d * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+            }
             HIPCHK(hipStreamSynchronize(h->stream));
         }
         tgp_modal::plan_smooth_head_forward(mh, sp, yhead, mu_end, &quad_head);
     }
     {
-        LaunchScope ls(h, post ? "k_smooth_one<posterior>" : "k_smooth_one<logpdf>");
+        LaunchScope ls(h, rnd ? "k_smooth_one<rand>" : (post ? "k_smooth_one<posterior>" : "k_smooth_one<logpdf>"));
         const int rc = tgp_modal::smooth_lti(h->stream, sp, overlap ? nullptr : mu_end, c);
         if (rc != 0) return h->fail(TGP_EHIP, std::string("tgp_posterior_marginals: launch: ") + hipGetErrorString((hipError_t)rc));
     }
@@ -2578,6 +2603,10 @@ static int smooth_lti_call(tgp_handle* h, const double* y, uint32_t flags, const
     }
     const bool tables_ok = !post || tgp_modal::plan_smooth_head_tables(mh, sp);      // (beside the kernel)
     auto head_back = [&]() {
+        if (rnd) {
+            tgp_modal::plan_smooth_head_backward_rand(mh, sp, yhead, xi, eehead, ethead, rnhead, !rshared, hout);
+            return;
+        }
         tgp_modal::plan_smooth_head_backward(mh, sp, yhead, xi, hout, hout + nhs);
         for (size_t t = 0; t < nhs; ++t) hout[nhs + t] += rnhead[rshared ? 0 : t];
     };
@@ -2607,7 +2636,7 @@ static int smooth_lti_call(tgp_handle* h, const double* y, uint32_t flags, const
         if (post) {
             head_back();
             HIPCHK(hipMemcpyAsync(dm, hout, nhs * sizeof(double), hipMemcpyHostToDevice, h->stream));
-            HIPCHK(hipMemcpyAsync(dv, hout + nhs, nhs * sizeof(double), hipMemcpyHostToDevice, h->stream));
+            if (dv) HIPCHK(hipMemcpyAsync(dv, hout + nhs, nhs * sizeof(double), hipMemcpyHostToDevice, h->stream));
         }
         TRY(copy_back(h, mean_out, dm, nT, odev));
         TRY(copy_back(h, var_out, dv, nT, odev));
@@ -2628,6 +2657,23 @@ static int smooth_lti_call(tgp_handle* h, const double* y, uint32_t flags, const
     h->steady2_last = false;
     h->dense_last_n0 = fp.n0;
     *served = true;
+    return TGP_OK;
+}
+
+// rand of posterior(model, y) with replaced observation noise (lgssm.jl:65-91 on the reverse-time model of :193-221; posterior_lti_sde.jl:48-58)
+// WITHOUT evaluating that model: Forward LTI models with scalar observations, one noise variance, no missing data, d <= 4 -- k_smooth_one with a
+// noise input.  TGP_EUNSUPPORTED: the caller takes the evaluated route (tgp_posterior, then tgp_rand on the Reverse model).
+int tgp_posterior_rand(tgp_handle* h, const double* y, const double* Rnew, const double* eps_t, const double* eps_e, const double* eps_0, uint32_t flags,
+                       double* y_out) {
+    TRY(check_ready(h, /*general=*/false));
+    if (!y || !Rnew || !eps_t || !eps_e || !eps_0 || !y_out) return h->fail(TGP_EINVAL, "tgp_posterior_rand: null argument");
+    h->steady2_last = false;
+    h->modal_last = false;
+    h->dense_last_n0 = -1;
+    bool served = false;
+    const SmoothRand rnd{eps_t, eps_e, eps_0};
+    if (steady2_eligible(h, nullptr, flags)) TRY(smooth_lti_call(h, y, flags, Rnew, y_out, nullptr, nullptr, &served, &rnd));
+    if (!served) return h->fail(TGP_EUNSUPPORTED, "tgp_posterior_rand: Forward LTI models with scalar observations, one noise variance and d <= 4 (take tgp_posterior + tgp_rand)");
     return TGP_OK;
 }
 

@@ -2710,10 +2710,17 @@ struct SArgs {
     const double* head_out;
     const long long* head_out_flag;
     long long seq;
+    // RAND: a draw from the posterior instead of its marginals (lgssm.jl:65-91 on the reverse-time model of :193-221).  With delta_t = x_t - m_t the
+    // reverse-time step x_(t-1) = G x_t + g_t + U' eps_t is the smoother's recursion with a noise input: xi_t = c r_t + G xi_(t+1) + U' eps_t,
+    // y_t = y_obs_t - (R / S) r_t + h' xi_(t+1) + sqrt(Rnew_t) eta_t.  U: the upper Cholesky factor of the settled L + 1e-9 I (U[k][i], k <= i);
+    // xi_T = U0' eps_0 (the draw of the final filtering state) enters step T - 1 as v0 = G xi_T and its output as s0 = h' xi_T.
+    const double *eps_t, *eps_e;
+    static constexpr int RD = D <= kSmoothRandMaxD ? D : 1;      // (the kernel-argument segment is full at d = 8: no room for what d > 4 never uses)
+    double U[RD][RD], v0[RD], s0;
 };
 
-template <int D, int NW, int MINW>
-__global__ __launch_bounds__(NW * 64, MINW) void k_smooth_one(const SArgs<D> by_value) {
+template <int D, int NW, int MINW, bool RAND>
+__global__ __launch_bounds__(NW * 64, MINW) void k_smooth_one(const SArgs<D> by_value) {      // (RAND: `mean` receives the draw, `var` is unused)
     (void)by_value;
     const SArgs<D>& ka = *(const SArgs<D>*)__builtin_amdgcn_kernarg_segment_ptr();
     constexpr int SUB = kWJ, TILE = 64 * SUB;
@@ -2740,6 +2747,10 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_smooth_one(const SArgs<D> by_
             if (ka.rnew_per_step && ka.mean != nullptr) ka.head_in[ka.nhs + t] = ka.Rnew[t];
         }
         if (!ka.rnew_per_step && ka.mean != nullptr && lane == 0) ka.head_in[ka.nhs] = ka.Rnew[0];
+        if constexpr (RAND) {      // the head's draws: eta [nhs] behind y | Rnew, then eps [nhs][D]
+            for (long long t = lane; t < ka.nhs; t += 64) ka.head_in[2 * ka.nhs + t] = ka.eps_e[t];
+            for (long long e = lane; e < ka.nhs * D; e += 64) ka.head_in[3 * ka.nhs + e] = ka.eps_t[e];
+        }
         __threadfence_system();
         if (lane == 0) __hip_atomic_store(ka.head_in_flag, 2 * ka.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
@@ -2920,6 +2931,13 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_smooth_one(const SArgs<D> by_
             o0[j] = fma(-ka.rS, rr, u[j] + ka.hh);      // h' m_t + hh = y_t - (R / S) r_t: what the smoother adds h' xi_(t+1) to
         }
         if (ka.mean != nullptr) {
+            double ee[RAND ? SUB : 1][RAND ? D : 1];      // (RAND) the lane's transition draws: 8 D consecutive doubles of eps_t
+            if constexpr (RAND) {
+#pragma unroll
+                for (int j = 0; j < SUB; ++j)
+#pragma unroll
+                    for (int k = 0; k < D; ++k) ee[j][k] = (t0 + j < T) ? ka.eps_t[(t0 + j) * D + k] : 0.0;
+            }
 #pragma unroll
             for (int j = SUB - 1; j >= 0; --j) {
                 double o = o0[j];
@@ -2932,6 +2950,11 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_smooth_one(const SArgs<D> by_
                     double v = ka.c[i] * r[j];
 #pragma unroll
                     for (int k = 0; k < D; ++k) v = fma(ka.G[i][k], xi[k], v);
+                    if constexpr (RAND) {      // + (U' eps)_i; the series' last step also takes G xi_T
+#pragma unroll
+                        for (int k = 0; k <= i; ++k) v = fma(ka.U[k][i], ee[j][k], v);
+                        if (t0 + j == T - 1) v += ka.v0[i];
+                    }
                     np[i] = v;
                 }
 #pragma unroll
@@ -3028,7 +3051,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_smooth_one(const SArgs<D> by_
             }
             // ---- outputs of the steps the workgroup owns
             const bool whole = t0 >= c_lo && t0 + SUB <= c_hi;
-            const bool al = ((reinterpret_cast<uintptr_t>(ka.mean) | reinterpret_cast<uintptr_t>(ka.var)) & 15) == 0;
+            const bool al = ((reinterpret_cast<uintptr_t>(ka.mean) | (RAND ? (uintptr_t)0 : reinterpret_cast<uintptr_t>(ka.var))) & 15) == 0;
             const double rn0 = ka.rnew_per_step ? 0.0 : ka.Rnew[0];
             const bool in_tail = t0 + SUB > T - ka.n1;
             const bool wide = whole && al;      // (t0 is a multiple of 8: spans start on multiples of 16 behind nhs, itself one)
@@ -3042,11 +3065,17 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_smooth_one(const SArgs<D> by_
                     double o = o0[j];
 #pragma unroll
                     for (int k = 0; k < D; ++k) o = fma(ka.WG[j][k], pin[k], o);
+                    double v = 0.0;
+                    if constexpr (RAND) {      // the draw: + h' xi_T at the series' last step, + sqrt(Rnew_t) eta_t
+                        if (t == T - 1) o += ka.s0;
+                        if (t < T) o = fma(sqrt(ka.rnew_per_step ? ka.Rnew[t] : rn0), ka.eps_e[t], o);
+                    } else {
+                        v = ka.vb;
+                        if (in_tail && t < T && T - 1 - t < ka.n1) v = ka.tvb[T - 1 - t];
+                        if (ka.rnew_per_step) v += (t < T ? ka.Rnew[t] : 0.0);
+                        else v += rn0;
+                    }
                     om[jj] = o;
-                    double v = ka.vb;
-                    if (in_tail && t < T && T - 1 - t < ka.n1) v = ka.tvb[T - 1 - t];
-                    if (ka.rnew_per_step) v += (t < T ? ka.Rnew[t] : 0.0);
-                    else v += rn0;
                     ov[jj] = v;
                 }
                 if (wide) {
@@ -3054,16 +3083,18 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_smooth_one(const SArgs<D> by_
                     w.x = om[0];
                     w.y = om[1];
                     reinterpret_cast<v2d*>(ka.mean + t0)[j2 / 2] = w;
-                    w.x = ov[0];
-                    w.y = ov[1];
-                    reinterpret_cast<v2d*>(ka.var + t0)[j2 / 2] = w;
+                    if constexpr (!RAND) {
+                        w.x = ov[0];
+                        w.y = ov[1];
+                        reinterpret_cast<v2d*>(ka.var + t0)[j2 / 2] = w;
+                    }
                 } else {
 #pragma unroll
                     for (int jj = 0; jj < 2; ++jj) {
                         const long long t = t0 + j2 + jj;
                         if (t >= c_lo && t < c_hi) {
                             ka.mean[t] = om[jj];
-                            ka.var[t] = ov[jj];
+                            if constexpr (!RAND) ka.var[t] = ov[jj];
                         }
                     }
                 }
@@ -3071,7 +3102,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_smooth_one(const SArgs<D> by_
         }
     }
     if (ka.head_out_flag != nullptr && ka.mean != nullptr && g == ((ka.nwg + 7) / 8) / 2) {      // the head's outputs, by a workgroup from the middle of the dispatch (see k_steady_one)
-        if (wave < 2) {
+        if (wave < (RAND ? 1 : 2)) {
             wait_tables(ka.head_out_flag, ka.seq, &sPoison);
             double* dst = wave == 0 ? ka.mean : ka.var;
             const double* src = ka.head_out + (wave == 0 ? 0 : ka.nhs);
@@ -3148,8 +3179,23 @@ int launch_smooth(hipStream_t st, const tgp_plan::SmoothPlan& sp, const double* 
     const long long per = (ka.nwg + 7) / 8;
     static const int minw_env = [] { const char* v = std::getenv("TGP_SMOOTH_MINW"); return v ? std::atoi(v) : 0; }();
     const bool four = minw_env ? minw_env >= 4 : D <= 6;
-    if (four && D <= 6) hipLaunchKernelGGL((k_smooth_one<D, NW, (D <= 6 ? 4 : 2)>), dim3((unsigned)(per * 8)), dim3(NW * 64), 0, st, ka);
-    else hipLaunchKernelGGL((k_smooth_one<D, NW, 2>), dim3((unsigned)(per * 8)), dim3(NW * 64), 0, st, ka);
+    if (c.eps_t != nullptr) {      // a draw from the posterior (d <= kSmoothRandMaxD: the lane's 8 d draws sit in registers)
+        if constexpr (D <= kSmoothRandMaxD) {
+            ka.eps_t = c.eps_t;
+            ka.eps_e = c.eps_e;
+            for (int i = 0; i < D; ++i) {
+                ka.v0[i] = c.v0[i];
+                for (int k = 0; k < D; ++k) ka.U[i][k] = c.U[i * D + k];
+            }
+            ka.s0 = c.s0;
+            hipLaunchKernelGGL((k_smooth_one<D, NW, 2, true>), dim3((unsigned)(per * 8)), dim3(NW * 64), 0, st, ka);
+            return (int)hipGetLastError();
+        } else {
+            return (int)hipErrorInvalidValue;
+        }
+    }
+    if (four && D <= 6) hipLaunchKernelGGL((k_smooth_one<D, NW, (D <= 6 ? 4 : 2), false>), dim3((unsigned)(per * 8)), dim3(NW * 64), 0, st, ka);
+    else hipLaunchKernelGGL((k_smooth_one<D, NW, 2, false>), dim3((unsigned)(per * 8)), dim3(NW * 64), 0, st, ka);
     return (int)hipGetLastError();
 }
 }  // namespace
@@ -3192,6 +3238,13 @@ void plan_smooth_head_forward(const tgp_plan::ModelHost& m, const tgp_plan::Smoo
 bool plan_smooth_head_tables(const tgp_plan::ModelHost& m, const tgp_plan::SmoothPlan& sp) { return tgp_plan::smooth_head_tables_any(m, sp); }
 void plan_smooth_head_backward(const tgp_plan::ModelHost& m, const tgp_plan::SmoothPlan& sp, const double* y, const double* lam, double* mean, double* vb) {
     tgp_plan::smooth_head_backward_any(m, sp, y, lam, mean, vb);
+}
+bool plan_smooth_rand_factors(const tgp_plan::SmoothPlan& sp, const double* eps0, double* U, double* v0, double* s0) {
+    return tgp_plan::smooth_rand_factors_any(sp, eps0, U, v0, s0);
+}
+void plan_smooth_head_backward_rand(const tgp_plan::ModelHost& m, const tgp_plan::SmoothPlan& sp, const double* y, const double* delta, const double* eps_e,
+                                    const double* eps_t, const double* rn, bool rn_per_step, double* out) {
+    tgp_plan::smooth_head_backward_rand_any(m, sp, y, delta, eps_e, eps_t, rn, rn_per_step, out);
 }
 
 }  // namespace tgp_modal

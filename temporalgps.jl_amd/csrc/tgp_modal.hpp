@@ -119,7 +119,15 @@ struct SmoothCall {
     long long *head_in_flag = nullptr, *xi_flag = nullptr;
     const long long *mu0_flag = nullptr, *head_out_flag = nullptr;
     long long seq = 0;
+    // A DRAW from the posterior instead of its marginals (rand of the reverse-time model, lgssm.jl:65-91 / :193-221; d <= kSmoothRandMaxD):
+    // eps_t [T][d], eps_e [T] (device), `mean` receives the draw, `var` stays unused; U (d d, row-major, upper): chol(L_settled + 1e-9 I).U,
+    // v0 = G xi_T, s0 = h' xi_T with xi_T = chol(P_final + 1e-12 I).U' eps_0 (tgp_plan::smooth_rand_factors).  With the head beside the kernel,
+    // head_in also receives the head's eta [nhs] and eps [nhs][d] behind y | Rnew (offsets 2 nhs, 3 nhs).
+    const double *eps_t = nullptr, *eps_e = nullptr;
+    const double *U = nullptr, *v0 = nullptr;
+    double s0 = 0.0;
 };
+constexpr int kSmoothRandMaxD = 4;
 // false when the process runs with synchronous launches (HIP_LAUNCH_BLOCKING, AMD_SERIALIZE_KERNEL, ...) or TGP_MODAL_OVERLAP=0: a kernel
 // that waits for a flag the host raises behind the launch would wait for itself
 bool overlap_allowed();
@@ -130,6 +138,9 @@ void plan_smooth_head_forward(const tgp_plan::ModelHost& m, const tgp_plan::Smoo
 bool plan_smooth_head_tables(const tgp_plan::ModelHost& m, const tgp_plan::SmoothPlan& sp);
 void plan_smooth_head_backward(const tgp_plan::ModelHost& m, const tgp_plan::SmoothPlan& sp, const double* y, const double* lam, double* mean, double* vb);
 // steps a workgroup owns (its tiles minus the halo in front and -- with the backward half -- behind), and the workgroups of a T-step call
+bool plan_smooth_rand_factors(const tgp_plan::SmoothPlan& sp, const double* eps0, double* U, double* v0, double* s0);      // (behind plan_smooth; false: not positive definite)
+void plan_smooth_head_backward_rand(const tgp_plan::ModelHost& m, const tgp_plan::SmoothPlan& sp, const double* y, const double* delta, const double* eps_e,
+                                    const double* eps_t, const double* rn, bool rn_per_step, double* out);
 long long smooth_span(const tgp_plan::SmoothPlan& sp, bool post = true);
 long long smooth_workgroups(const tgp_plan::SmoothPlan& sp, long long T, bool post = true);
 int smooth_lti(hipStream_t stream, const tgp_plan::SmoothPlan& sp, const double* mu_start, const SmoothCall& c);

@@ -1496,7 +1496,29 @@ template <int D>
 struct SmoothWork {
     double Gss[D][D], Lss[D][D], Psinf[D][D];
     double r[kHeadMax], G[kHeadMax + 1][D][D], vb[kHeadMax + 1];      // head: innovations, G_t (step t -> t - 1), h' Ps_t h
+    double Uss[D][D], Ut[kHeadMax + 1][D][D];      // draws from the posterior: chol(L + 1e-9 I).U of the settled step and of every head step
+    bool u_ok;
 };
+// U'U = Symmetric(M) + jitter I (the upper triangle of M is the matrix); U upper, zeros below.  false: not positive definite.
+template <int D>
+inline bool chol_upper(const double (&M)[D][D], double jitter, double (&U)[D][D]) {
+    bool ok = true;
+    for (int i = 0; i < D; ++i)
+        for (int j = 0; j < D; ++j) U[i][j] = 0.0;
+    for (int j = 0; j < D; ++j) {
+        for (int i = 0; i <= j; ++i) {
+            double acc = M[i][j] + (i == j ? jitter : 0.0);
+            for (int k = 0; k < i; ++k) acc -= U[k][i] * U[k][j];
+            if (i == j) {
+                ok = ok && (acc > 0.0);
+                U[j][j] = std::sqrt(acc > 0.0 ? acc : 1.0);
+            } else {
+                U[i][j] = acc / U[i][i];
+            }
+        }
+    }
+    return ok;
+}
 template <int D>
 inline SmoothWork<D>& smooth_work() {
     static thread_local SmoothWork<D> w;
@@ -1558,6 +1580,7 @@ inline void build_smooth(const ModelHost& m, long long T, SmoothPlan& sp, double
         }
         sp.c[i] = v;
     }
+    sw.u_ok = chol_upper<D>(sw.Lss, 1e-9, sw.Uss);      // (conditional_rand, lgc.jl:84-87: the noise of a reverse-time step of a posterior draw)
     // the stationary smoothed covariance: Ps = G Ps G' + L by doubling (as build_core)
     {
         double S[D][D], M[D][D];
@@ -1753,6 +1776,7 @@ inline bool smooth_head_tables(const ModelHost& m, const SmoothPlan& sp) {
     std::memcpy(Pc, sw.Psinf, sizeof Pc);
     for (int t = fp.nhs - 1; t >= tset; --t) {
         std::memcpy(sw.G[t], sw.Gss, sizeof sw.Gss);
+        std::memcpy(sw.Ut[t], sw.Uss, sizeof sw.Uss);
         sw.vb[t] = sp.vb;
     }
     // (Ps_t = Psinf for t >= tset - 1: the steps behind are settled and the series' end is more than n1 steps away)
@@ -1765,6 +1789,7 @@ inline bool smooth_head_tables(const ModelHost& m, const SmoothPlan& sp) {
         for (int i = 0; i < D; ++i)
             for (int k = 0; k < D; ++k) Pp[i][k] += Q[i][k];
         if (!invert_dynamics<D>(A, Pf, Pp, sw.G[t], L)) return false;
+        sw.u_ok = chol_upper<D>(L, 1e-9, sw.Ut[t]) && sw.u_ok;
         sw.vb[t] = quad_sym<D>(hv, Pc);
         smooth_cov_step<D>(sw.G[t], L, Pc, pn);
         std::memcpy(Pc, pn, sizeof pn);
@@ -1773,6 +1798,60 @@ inline bool smooth_head_tables(const ModelHost& m, const SmoothPlan& sp) {
     if (tset - 1 < 1 && fp.nhs >= 1) sw.vb[0] = sp.vb;
     return true;
 }
+// A draw from the posterior: what the kernel needs of the final filtering state's draw x_(T-1) = m_(T-1) + chol(P + 1e-12 I).U' eps_0
+// (gaussian.jl:35-43) -- xi_T = U0' eps_0, v0 = G xi_T, s0 = h' xi_T -- and the settled noise factor U (row-major).  false: not positive definite.
+template <int D>
+inline bool smooth_rand_factors(const SmoothPlan& sp, const double* eps0, double* U_out, double* v0, double* s0) {
+    const SmoothWork<D>& sw = smooth_work<D>();
+    double P[D][D], U0[D][D], xiT[D];
+    for (int i = 0; i < D; ++i)
+        for (int k = 0; k < D; ++k) P[i][k] = sp.fp.Pss[i * D + k];
+    if (!sw.u_ok || !chol_upper<D>(P, 1e-12, U0)) return false;
+    for (int i = 0; i < D; ++i) {
+        double v = 0.0;
+        for (int k = 0; k <= i; ++k) v += U0[k][i] * eps0[k];
+        xiT[i] = v;
+    }
+    double s = 0.0;
+    for (int i = 0; i < D; ++i) {
+        double v = 0.0;
+        for (int k = 0; k < D; ++k) v += sw.Gss[i][k] * xiT[k];
+        v0[i] = v;
+        s += sp.fp.h[i] * xiT[i];
+        for (int k = 0; k < D; ++k) U_out[i * D + k] = sw.Uss[i][k];
+    }
+    *s0 = s;
+    return true;
+}
+// The head of a draw, backwards (behind the kernel): delta = x - m of step nhs - 1 (the kernel's xi at step nhs), the head's draws eps_e [nhs],
+// eps_t [nhs][D], its emission noise variances rn (one, or nhs with rn_per_step) -> y_draw [nhs]
+template <int D>
+inline void smooth_head_backward_rand(const ModelHost& m, const SmoothPlan& sp, const double* y, const double* delta_in, const double* eps_e, const double* eps_t,
+                                      const double* rn, bool rn_per_step, double* out) {
+    const FilterPlan& fp = sp.fp;
+    const FilterWork<D>& fw = filter_work<D>();
+    const SmoothWork<D>& sw = smooth_work<D>();
+    double dl[D], nl[D];
+    for (int i = 0; i < D; ++i) dl[i] = delta_in[i];
+    const double R = m.R[0];
+    for (int t = fp.nhs - 1; t >= 0; --t) {
+        const int ti = t < fp.n0 ? t : fp.n0;
+        double o = y[t] - R * fw.iS[ti] * sw.r[t];
+        for (int k = 0; k < D; ++k) o += fp.h[k] * dl[k];
+        out[t] = o + std::sqrt(rn[rn_per_step ? t : 0]) * eps_e[t];
+        if (t == 0) break;
+        double w[D];
+        for (int k = 0; k < D; ++k) w[k] = fw.K[ti][k] * sw.r[t] + dl[k];
+        for (int i = 0; i < D; ++i) {
+            double v = 0.0;
+            for (int k = 0; k < D; ++k) v += sw.G[t][i][k] * w[k];
+            for (int k = 0; k <= i; ++k) v += sw.Ut[t][k][i] * eps_t[(size_t)t * D + k];
+            nl[i] = v;
+        }
+        for (int i = 0; i < D; ++i) dl[i] = nl[i];
+    }
+}
+
 // The head backwards (behind the kernel): lam = xs - m of step nhs - 1 (the kernel's xi at step nhs) -> mean [nhs], vb [nhs] = h' Ps_t h
 template <int D>
 inline void smooth_head_backward(const ModelHost& m, const SmoothPlan& sp, const double* y, const double* lam_in, double* mean, double* vb) {
@@ -1859,6 +1938,14 @@ inline bool smooth_head_tables_any(const ModelHost& m, const SmoothPlan& sp) {
 }
 inline void smooth_head_backward_any(const ModelHost& m, const SmoothPlan& sp, const double* y, const double* lam, double* mean, double* vb) {
     TGP_PLAN_DISPATCH(m.d, smooth_head_backward<D>(m, sp, y, lam, mean, vb))
+}
+inline bool smooth_rand_factors_any(const SmoothPlan& sp, const double* eps0, double* U_out, double* v0, double* s0) {
+    TGP_PLAN_DISPATCH(sp.fp.d, smooth_rand_factors<D>(sp, eps0, U_out, v0, s0))
+    return false;
+}
+inline void smooth_head_backward_rand_any(const ModelHost& m, const SmoothPlan& sp, const double* y, const double* delta, const double* eps_e, const double* eps_t,
+                                          const double* rn, bool rn_per_step, double* out) {
+    TGP_PLAN_DISPATCH(m.d, smooth_head_backward_rand<D>(m, sp, y, delta, eps_e, eps_t, rn, rn_per_step, out))
 }
 #undef TGP_PLAN_DISPATCH
 

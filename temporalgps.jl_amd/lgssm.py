@@ -755,8 +755,53 @@ def ε_randn(rng, model):
     return rng.standard_normal((T, d)), rng.standard_normal(_osh(model))
 
 
+def _posterior_rand_one_launch(post, eps_t, eps_e, eps_0):
+    """rand of a posterior that has not been evaluated, on the prior's handle (tgp_posterior_rand: filter + reverse-time draw in one kernel,
+    nothing of size T x (2 d^2 + d) written).  None: not a model of that path -- the caller evaluates the posterior."""
+    prior = post._prior
+    if (post._model is not None or isinstance(prior, PosteriorLGSSM) or prior.ordering is not Forward or prior.p != 1 or prior.dim > 4
+            or prior._whiten is not None or isinstance(post._y, tuple)):
+        return None
+    y = post._y
+    R_new = post._R_new if post._R_new is not None else prior.emissions.R
+    dev = _lib.is_device(eps_t)
+    if dev != _lib.is_device(y) or (not dev and np.isnan(np.asarray(_to_numpy(y), dtype=np.float64)).any()):
+        return None
+    hd = prior.handle()
+    if dev:
+        import torch
+        et, ee, yy = eps_t.contiguous(), eps_e.contiguous(), y.contiguous()
+        Rn = R_new.contiguous() if _is_torch(R_new) else torch.as_tensor(np.atleast_1d(np.asarray(_to_numpy(R_new), dtype=np.float64)), device=yy.device)
+        _sync_torch(et)
+    else:
+        et = np.ascontiguousarray(_to_numpy(eps_t), dtype=np.float64)
+        ee = np.ascontiguousarray(_to_numpy(eps_e), dtype=np.float64)
+        yy = np.ascontiguousarray(_to_numpy(y), dtype=np.float64)
+        Rn = np.ascontiguousarray(np.atleast_1d(_to_numpy(R_new)), dtype=np.float64)
+    if Rn.ndim != 1 or Rn.shape[0] not in (1, prior.T) or tuple(ee.shape) != (prior.T,):
+        return None
+    e0 = np.ascontiguousarray(_to_numpy(eps_0), dtype=np.float64)
+    out = _out(prior, _osh(prior), dev)
+    flags = ((_lib.IN_DEVICE | _lib.OUT_DEVICE) if dev else 0) | (_lib.SHARED_R if Rn.shape[0] == 1 else 0)
+    try:
+        hd.check(hd.lib.tgp_posterior_rand(hd.h, _lib.ptr(yy), _lib.ptr(Rn), _lib.ptr(et), _lib.ptr(ee), _lib.ptr(e0), flags, _lib.ptr(out)))
+    except _lib.Unsupported:
+        return None
+    return out
+
+
 def rand(rng_or_eps, model):
     """lgssm.jl:65-69. `rng_or_eps` is a numpy Generator, or the explicit (eps_t (T,d), eps_e (T,), eps_0 (d,))."""
+    if isinstance(model, PosteriorLGSSM) and model._model is None:
+        if isinstance(rng_or_eps, tuple):
+            eps = rng_or_eps
+        else:       # (the reference's order of draws: lgssm.jl:72-77, then x0's)
+            et, ee = rng_or_eps.standard_normal((model.T, model.dim)), rng_or_eps.standard_normal((model.T,) if model.p == 1 else (model.T, model.p))
+            eps = (et, ee, rng_or_eps.standard_normal(model.dim))
+        y1 = _posterior_rand_one_launch(model, *eps)
+        if y1 is not None:
+            return y1
+        rng_or_eps = eps
     if isinstance(model, PosteriorLGSSM):
         model = model.materialise()
     if isinstance(rng_or_eps, tuple):

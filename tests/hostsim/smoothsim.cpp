@@ -57,7 +57,9 @@ void matvec_acc2(const double (&M)[D][D], const double* x, double* y) {
 }
 
 template <int D>
-int run_d(const ModelHost& m, long long T, const double* y, const double* Rnew, int rnew_per_step, double* mean, double* var, double* out) {
+int run_d(const ModelHost& m, long long T, const double* y, const double* Rnew, int rnew_per_step, double* mean, double* var, double* out,
+          const double* eps_t = nullptr, const double* eps_e = nullptr, const double* eps_0 = nullptr) {
+    const bool rnd = eps_t != nullptr;      // a draw from the posterior (k_smooth_one<..., RAND>): `mean` receives it
     static thread_local double tvb[kTailMax];
     SmoothPlan sp;
     build_smooth<D>(m, T, sp, tvb);
@@ -73,6 +75,8 @@ int run_d(const ModelHost& m, long long T, const double* y, const double* Rnew, 
     double mu_end[D], quad = 0.0;
     smooth_head_forward<D>(m, sp, y, mu_end, &quad);
     if (!smooth_head_tables<D>(m, sp)) { out[1] = kNotPD; return 0; }
+    double rU[D * D], rv0[D], rs0 = 0.0;
+    if (rnd && !smooth_rand_factors<D>(sp, eps_0, rU, rv0, &rs0)) { out[1] = kNotPD; return 0; }
     static thread_local Tables<D> tb;
     lane_table<D>(fp.P, tb.pw);
     lane_table<D>(sp.GP, tb.pg);
@@ -179,6 +183,11 @@ int run_d(const ModelHost& m, long long T, const double* y, const double* Rnew, 
                     for (int i = 0; i < D; ++i) {
                         double v = sp.c[i] * r[e];
                         for (int k = 0; k < D; ++k) v = std::fma(sp.G[i * D + k], xi[k], v);
+                        if (rnd) {
+                            const long long t = t0 + j;
+                            for (int k = 0; k <= i; ++k) v = std::fma(rU[k * D + i], t < T ? eps_t[t * D + k] : 0.0, v);
+                            if (t == T - 1) v += rv0[i];
+                        }
                         np[i] = v;
                     }
                     for (int i = 0; i < D; ++i) xi[i] = np[i];
@@ -239,6 +248,11 @@ int run_d(const ModelHost& m, long long T, const double* y, const double* Rnew, 
                     const int e = (w * 64 + l) * SUB + j;
                     double o = u[e] + fp.hh - sp.rS * r[e] + o0[e];
                     for (int k = 0; k < D; ++k) o = std::fma(sp.WG[j][k], pin[k], o);
+                    if (rnd) {
+                        if (t == T - 1) o += rs0;
+                        mean[t] = std::fma(std::sqrt(rnew_per_step ? Rnew[t] : Rnew[0]), eps_e[t], o);
+                        continue;
+                    }
                     mean[t] = o;
                     double v = sp.vb;
                     if (T - 1 - t < sp.n1) v = tvb[T - 1 - t];
@@ -248,6 +262,12 @@ int run_d(const ModelHost& m, long long T, const double* y, const double* Rnew, 
         }
     }
     std::vector<double> hm(fp.nhs), hv(fp.nhs);
+    if (rnd) {
+        smooth_head_backward_rand<D>(m, sp, y, xi_out, eps_e, eps_t, Rnew, rnew_per_step != 0, hm.data());
+        for (int t = 0; t < fp.nhs; ++t) mean[t] = hm[t];
+        out[0] = 0.0;
+        return 0;
+    }
     smooth_head_backward<D>(m, sp, y, xi_out, hm.data(), hv.data());
     for (int t = 0; t < fp.nhs; ++t) {
         mean[t] = hm[t];
@@ -261,20 +281,20 @@ int run_d(const ModelHost& m, long long T, const double* y, const double* Rnew, 
 
 extern "C" int smoothsim_run(int d, const double* A, const double* a, const double* Q, const double* H, double hh, double R, const double* x0m,
                              const double* x0P, long long T, const double* y, const double* Rnew, int rnew_per_step, double* mean, double* var,
-                             double* out /*[8]: lml, why, n0, nhs, n1, halo, workgroups*/) {
+                             double* out /*[8]: lml, why, n0, nhs, n1, halo, workgroups*/, const double* eps_t, const double* eps_e, const double* eps_0) {
     ModelHost m;
     m.d = d;
     m.A = A; m.a = a; m.Q = Q; m.H = H; m.hh = &hh; m.R = &R; m.x0m = x0m; m.x0P = x0P;
     for (int i = 0; i < 8; ++i) out[i] = 0.0;
     switch (d) {
-        case 1: return run_d<1>(m, T, y, Rnew, rnew_per_step, mean, var, out);
-        case 2: return run_d<2>(m, T, y, Rnew, rnew_per_step, mean, var, out);
-        case 3: return run_d<3>(m, T, y, Rnew, rnew_per_step, mean, var, out);
-        case 4: return run_d<4>(m, T, y, Rnew, rnew_per_step, mean, var, out);
-        case 5: return run_d<5>(m, T, y, Rnew, rnew_per_step, mean, var, out);
-        case 6: return run_d<6>(m, T, y, Rnew, rnew_per_step, mean, var, out);
-        case 7: return run_d<7>(m, T, y, Rnew, rnew_per_step, mean, var, out);
-        case 8: return run_d<8>(m, T, y, Rnew, rnew_per_step, mean, var, out);
+        case 1: return run_d<1>(m, T, y, Rnew, rnew_per_step, mean, var, out, eps_t, eps_e, eps_0);
+        case 2: return run_d<2>(m, T, y, Rnew, rnew_per_step, mean, var, out, eps_t, eps_e, eps_0);
+        case 3: return run_d<3>(m, T, y, Rnew, rnew_per_step, mean, var, out, eps_t, eps_e, eps_0);
+        case 4: return run_d<4>(m, T, y, Rnew, rnew_per_step, mean, var, out, eps_t, eps_e, eps_0);
+        case 5: return run_d<5>(m, T, y, Rnew, rnew_per_step, mean, var, out, eps_t, eps_e, eps_0);
+        case 6: return run_d<6>(m, T, y, Rnew, rnew_per_step, mean, var, out, eps_t, eps_e, eps_0);
+        case 7: return run_d<7>(m, T, y, Rnew, rnew_per_step, mean, var, out, eps_t, eps_e, eps_0);
+        case 8: return run_d<8>(m, T, y, Rnew, rnew_per_step, mean, var, out, eps_t, eps_e, eps_0);
     }
     return 1;
 }

@@ -454,3 +454,62 @@ def test_a_stream_with_work_of_the_callers_in_front_of_the_kernel(tgp):
         torch.cuda.synchronize()
         hd.check(hd.lib.tgp_set_stream(hd.h, None))
         del a
+
+
+@pytest.mark.parametrize("d", [1, 2, 3, 4])
+def test_a_draw_from_the_posterior_in_one_launch(tgp, d):
+    """rand(rng, replace_observation_noise_cov(posterior(model, y), Rn)) (posterior_lti_sde.jl:48-58; lgssm.jl:65-91 on the reverse-time model
+    of :193-221) of a Forward LTI model WITHOUT evaluating that model: tgp_posterior_rand = k_smooth_one with a noise input, ONE kernel
+    (DESIGN 3.17).  Against the oracle's literal loop over the evaluated posterior (T = 5000) and against the product's own evaluated route."""
+    from oracle import lgssm_ref as ref
+    import torch
+    for T in (5000, 9000 + d):
+        model = oc.build_lgssm(KERNELS[d], ("regular", 0.0, 0.1, T), 0.1)
+        y = draw(model, 10 + d)
+        rng = np.random.default_rng(d)
+        eps = (rng.standard_normal((T, d)), rng.standard_normal(T), rng.standard_normal(d))
+        for Rn in (np.array([0.05]), rng.random(T) * 0.1, None):
+            dm = device_model(tgp, model)
+            post = tgp.posterior(dm, y)
+            if Rn is not None:
+                post = tgp.replace_observation_noise_cov(post, Rn)
+            got, names = kernels_of(tgp, dm, lambda: tgp.rand(eps, post))
+            assert names == {"k_smooth_one<rand>"}, names
+            # the evaluated route (tgp_posterior, then tgp_rand on the Reverse model) on a second model object
+            dm2 = device_model(tgp, model)
+            post2 = tgp.posterior(dm2, y)
+            if Rn is not None:
+                post2 = tgp.replace_observation_noise_cov(post2, Rn)
+            post2.materialise()
+            want2 = tgp.rand(eps, post2)
+            assert np.max(np.abs(got - want2)) <= 1e-8 * max(1.0, np.max(np.abs(want2)))
+            if T == 5000:
+                opost = ref.posterior(model, y)
+                if Rn is not None:
+                    opost = ref.replace_observation_noise_cov(opost, np.broadcast_to(Rn, (T,)).copy())
+                want = ref.rand(opost, *eps)
+                assert np.max(np.abs(got - want)) <= 1e-8 * max(1.0, np.max(np.abs(want)))
+        # device-resident series and draws
+        yd = torch.from_numpy(y).cuda()
+        ed = (torch.from_numpy(eps[0]).cuda(), torch.from_numpy(eps[1]).cuda(), eps[2])
+        dm = device_model(tgp, model)
+        gd = tgp.rand(ed, tgp.replace_observation_noise_cov(tgp.posterior(dm, yd), np.array([0.05])))
+        dm2 = device_model(tgp, model)
+        p2 = tgp.replace_observation_noise_cov(tgp.posterior(dm2, y), np.array([0.05]))
+        p2.materialise()
+        assert np.max(np.abs(gd.cpu().numpy() - tgp.rand(eps, p2))) <= 1e-8 * max(1.0, float(gd.abs().max()))
+
+
+def test_a_draw_from_the_posterior_beyond_the_one_launch_path(tgp):
+    """d = 6 (the lane's draws no longer fit its registers), a series too short for head + transient: the evaluated route serves the call"""
+    from oracle import lgssm_ref as ref
+    for spec, T in ((KERNELS[6], 3000), (KERNELS[3], 90)):
+        model = oc.build_lgssm(spec, ("regular", 0.0, 0.1, T), 0.1)
+        d = len(model["x0m"])
+        y = draw(model, 4)
+        rng = np.random.default_rng(8)
+        eps = (rng.standard_normal((T, d)), rng.standard_normal(T), rng.standard_normal(d))
+        dm = device_model(tgp, model)
+        got = tgp.rand(eps, tgp.posterior(dm, y))
+        want = ref.rand(ref.posterior(model, y), *eps)
+        assert np.max(np.abs(got - want)) <= 1e-8 * max(1.0, np.max(np.abs(want)))
