@@ -282,7 +282,8 @@ def gradient_leg(tgp, torch, name, T, d, device, steps, y):
 
 def lti_interface_leg(tgp, torch, model, y, T, d, local, steps):
     """The rest of the LTI interface on the same model and series, device-resident: rand with the draws supplied
-    (lgssm.jl:65-91), _filter (:171-187), the evaluated posterior (:193-221) -- wall clock per call and the kernels each one launched."""
+    (lgssm.jl:65-91), a draw from the posterior (rand of the reverse-time model, not evaluated), _filter (:171-187), the evaluated posterior
+    (:193-221) -- wall clock per call and the kernels each one launched."""
     hd = model.handle()
 
     def timed(fn, n):
@@ -312,6 +313,9 @@ def lti_interface_leg(tgp, torch, model, y, T, d, local, steps):
     x0 = np.random.default_rng(5).standard_normal(d)
     t, k = timed(lambda: tgp.rand((eps_t, eps_e, x0), model), steps)
     out["rand"] = dict(ms=t * 1e3, steps_per_s=T / t, bytes_per_step=8 * (d + 2), kernels_ms=k)
+    if d <= 4:      # a draw from the posterior without evaluating it (posterior_lti_sde.jl:48-58; tgp_posterior_rand)
+        t, k = timed(lambda: tgp.rand((eps_t, eps_e, x0), tgp.posterior(model, y)), steps)
+        out["posterior_rand"] = dict(ms=t * 1e3, steps_per_s=T / t, bytes_per_step=8 * (d + 3), kernels_ms=k)
     del eps_t, eps_e
     t, k = timed(lambda: tgp._filter(model, y), steps)
     out["filter"] = dict(ms=t * 1e3, steps_per_s=T / t, bytes_per_step=8 * (1 + d + d * d), kernels_ms=k)

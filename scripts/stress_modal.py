@@ -22,7 +22,7 @@ NAMES = ["matern12", "matern32", "matern52"]
 DIM = dict(matern12=1, matern32=2, matern52=3)
 LENGTHS = [300, 513, 600, 1023, 1024, 1025, 3583, 3584, 3585, 4095, 4096, 4097, 4608, 5000, 7552, 8192, 8193, 12345, 40960, 65536 + 511, 100_003, 250_000]
 WHY = ["applies", "covariance not settled", "not positive definite", "series too short", "ill-conditioned modal form", "mixes too slowly", "tail too long", "eigenvalues"]
-bad, one_launch, dense_one = 0, 0, 0
+bad, one_launch, dense_one, draws = 0, 0, 0, 0
 for case in range(n_cases):
     while True:
         terms = [(NAMES[rng.integers(3)], float(np.exp(rng.normal(0, 0.7))), float(np.exp(rng.normal(0, 0.7)))) for _ in range(rng.integers(1, 4))]
@@ -79,6 +79,21 @@ for case in range(n_cases):
             lp1 = tgp.logpdf(dm, y)
             if not abs(lp1 - lp_ref) <= 1e-10 * abs(lp_ref):
                 msgs.append(f"[{opt}] logpdf-only {lp1} vs {lp_ref}")
+            if opt == 3 and d <= 4 and T <= 70000:
+                # a draw from the posterior: the one-launch path (tgp_posterior_rand) against the evaluated route (tgp_posterior, then
+                # tgp_rand on the Reverse model -- the general engine), the same draws
+                e2 = (rng.standard_normal((T, d)), rng.standard_normal(T), rng.standard_normal(d))
+                hd.profile_reset()
+                got = tgp.rand(e2, tgp.replace_observation_noise_cov(tgp.posterior(dm, y), Rn))
+                drew = "k_smooth_one<rand>" in set(hd.profile())
+                dm_e = tgp.LGSSM(tr, tgp.ScalarOutputLGC(model["H"], np.atleast_1d(model["h"]), np.atleast_1d(model["R"])), T=T)
+                pe = tgp.replace_observation_noise_cov(tgp.posterior(dm_e, y), Rn)
+                pe.materialise()
+                want = tgp.rand(e2, pe)
+                if not np.max(np.abs(got - want)) <= 1e-8 * max(1.0, float(np.max(np.abs(want)))):
+                    msgs.append(f"posterior draw err {np.max(np.abs(got - want)):.2e} (one launch: {drew})")
+                draws += drew
+                del dm_e, pe
         except Exception as ex:      # noqa: BLE001
             msgs.append(f"[{opt}] {type(ex).__name__}: {ex}")
         del dm
@@ -99,4 +114,4 @@ for case in range(n_cases):
     bad += bool(msgs)
     print(f"[{case:3d}] {'FAIL' if msgs else 'ok'} d={d} T={T} dt={dt:.4f} noise={noise:.2e} Rn={'T' if Rn.shape[0] > 1 else '1'} mode={mode} terms={[(t[0][6:], round(t[1], 2), round(t[2], 2)) for t in terms]} "
           f"served={served.get(3)}/{served.get(2)} plan={WHY[ii[0]]} n0={ii[1]} halo={ii[4]} {'; '.join(msgs)}", flush=True)
-print(f"{bad} failing cases of {n_cases}  ({one_launch} served by the one-launch path, {dense_one} by the dense-powers one-launch path)")
+print(f"{bad} failing cases of {n_cases}  ({one_launch} served by the one-launch path, {dense_one} by the dense-powers one-launch path; {draws} posterior draws in one launch)")
