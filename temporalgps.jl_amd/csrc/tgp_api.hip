@@ -2645,6 +2645,7 @@ static int smooth_lti_call(tgp_handle* h, const double* y, uint32_t flags, const
     double ssq = 0.0;
     for (long long g = 0; g < nwg; ++g) ssq += part[g];
     const double lml = -0.5 * ((double)h->T * 1.8378770664093454835606594728112 + fp.LS + (double)(h->T - fp.n0) * fp.logS + quad_head + fp.iS * ssq);
+    if (rnd && !(lml == lml)) return TGP_OK;      // (a NaN in the series -- NaN == missing in the mirrors' convention --: the evaluated route serves the draw)
     if (getenv("TGP_STEADY_DEBUG") != nullptr)
         fprintf(stderr, "[tgp smooth] T %lld post %d overlap %d idev %d odev %d nwg %lld nhs %d halo %d n1 %d seq %lld quad_head %.6g ssq %.6g lml %.10g\n", (long long)h->T,
                 (int)post, (int)overlap, (int)idev, (int)odev, nwg, fp.nhs, sp.halo, sp.n1, seq, quad_head, ssq, lml);

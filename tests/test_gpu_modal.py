@@ -513,3 +513,36 @@ def test_a_draw_from_the_posterior_beyond_the_one_launch_path(tgp):
         got = tgp.rand(eps, tgp.posterior(dm, y))
         want = ref.rand(ref.posterior(model, y), *eps)
         assert np.max(np.abs(got - want)) <= 1e-8 * max(1.0, np.max(np.abs(want)))
+
+
+def test_a_draw_from_the_posterior_with_missing_observations_takes_the_evaluated_route(tgp):
+    """NaN == missing in the mirror's convention: the one-launch draw does not cover missing data -- it must step aside (host arrays: the mirror
+    sees the NaN; device arrays: the library sees a NaN log marginal likelihood), not return NaNs"""
+    from oracle import lgssm_ref as ref
+    import torch
+    T = 6000
+    model = oc.build_lgssm(KERNELS[3], ("regular", 0.0, 0.1, T), 0.1)
+    y = draw(model, 4)
+    miss = np.zeros(T, dtype=bool)
+    miss[[700, 701, 3000]] = True
+    yn = np.where(miss, np.nan, y)
+    rng = np.random.default_rng(8)
+    eps = (rng.standard_normal((T, 3)), rng.standard_normal(T), rng.standard_normal(3))
+    want = ref.rand(ref.posterior_missing(model, y, miss), *eps)
+    dm = device_model(tgp, model)
+    got, names = kernels_of(tgp, dm, lambda: tgp.rand(eps, tgp.posterior(dm, yn)))
+    assert "k_smooth_one<rand>" not in names, names
+    # (at the missing steps themselves the reference's posterior keeps the 1e15 stand-in variance of missings.jl:55-101 as its emission noise -- its
+    #  draws there are ~1e7 eta -- while the mirror's posterior object keeps the prior's noise until replace_observation_noise_cov is called, which
+    #  every caller in posterior_lti_sde.jl does: the observed steps are what both define alike)
+    assert np.max(np.abs(got - want)[~miss]) <= 1e-8 * max(1.0, np.max(np.abs(want[~miss])))
+    # the C entry point itself on a device series with NaNs: unsupported, not NaN
+    hd = device_model(tgp, model).handle()
+    yd = torch.from_numpy(yn).cuda()
+    et, ee = torch.from_numpy(eps[0]).cuda(), torch.from_numpy(eps[1]).cuda()
+    out = torch.zeros(T, dtype=torch.float64, device="cuda")
+    Rn = torch.tensor([0.1], dtype=torch.float64, device="cuda")
+    L = tgp._lib
+    torch.cuda.synchronize()
+    rc = hd.lib.tgp_posterior_rand(hd.h, L.ptr(yd), L.ptr(Rn), L.ptr(et), L.ptr(ee), L.ptr(np.ascontiguousarray(eps[2])), L.IN_DEVICE | L.OUT_DEVICE | L.SHARED_R, L.ptr(out))
+    assert rc == 4, rc      # TGP_EUNSUPPORTED
