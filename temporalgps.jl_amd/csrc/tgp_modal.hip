@@ -2663,7 +2663,7 @@ int launch_adjoint(hipStream_t st, const tgp_plan::FilterPlan& fp, const double*
 
 long long adjoint_workgroups(const tgp_plan::FilterPlan& fp, long long T) {
     const long long C = 8LL * 64 * kWJ - 2LL * fp.halo;
-    return C > 0 ? (T - fp.nhs + C - 1) / C : -1;
+    return C >= fp.halo && C > 0 ? (T - fp.nhs + C - 1) / C : -1;      // (a span at least a halo long: the run-in of workgroup 1 must not reach back into the head)
 }
 
 int adjoint_lti(hipStream_t stream, const tgp_plan::FilterPlan& fp, const double* mu_start, const double* y, long long T, double* part, double* psi_out,
@@ -3230,7 +3230,10 @@ void plan_smooth(const tgp_plan::ModelHost& m, long long T, tgp_plan::SmoothPlan
         return;
     }
     tgp_plan::build_smooth_any(m, T, sp, tvb, post);
-    if (sp.why == tgp_plan::kOk && smooth_span(sp, post) < 1024) sp.why = tgp_plan::kSlowMixing;      // (halos would eat three quarters of a span)
+    // (halos would eat three quarters of a span; and a span must be at least a halo long: workgroup g >= 1 starts `halo` steps in front of its
+    //  range, which must not reach back into the head -- or in front of the series: a memory fault found by the randomised sweep, T = 250 000,
+    //  two Matern-1/2 of one length scale, halo 1520 against spans of 1056)
+    if (sp.why == tgp_plan::kOk && (smooth_span(sp, post) < 1024 || smooth_span(sp, post) < sp.halo)) sp.why = tgp_plan::kSlowMixing;
 }
 void plan_smooth_head_forward(const tgp_plan::ModelHost& m, const tgp_plan::SmoothPlan& sp, const double* y, double* mu_end, double* quad) {
     tgp_plan::smooth_head_forward_any(m, sp, y, mu_end, quad);

@@ -69,7 +69,7 @@ int run_d(const ModelHost& m, long long T, const double* y, const double* Rnew, 
     out[2] = fp.n0; out[3] = fp.nhs; out[4] = sp.n1; out[5] = sp.halo;
     constexpr int SUB = kSub, TILE = 64 * SUB, NW = 8;
     const long long C = (long long)NW * TILE - 2LL * sp.halo;
-    if (C < 1024) { out[1] = kSlowMixing; return 0; }
+    if (C < 1024 || C < sp.halo) { out[1] = kSlowMixing; return 0; }      // (tgp_modal::plan_smooth: a span at least a halo long)
     const long long nwg = (T - fp.nhs + C - 1) / C;
     out[6] = (double)nwg;
     double mu_end[D], quad = 0.0;
