@@ -2308,7 +2308,8 @@ __global__ __launch_bounds__(NW * 64, 2) void k_adjoint_one(const GArgs<D> by_va
     }
     const long long T = ka.T, c_lo = ka.nhs + g * ka.C, c_hi = (c_lo + ka.C < T) ? c_lo + ka.C : T;
     const bool first = g == 0;
-    const long long s0 = first ? ka.nhs : c_lo - ka.halo;
+    const bool from_head = first || c_lo - ka.halo < ka.nhs;      // (a span shorter than a halo: the second workgroup starts behind the head too -- see k_smooth_one)
+    const long long s0 = from_head ? ka.nhs : c_lo - ka.halo;
     const long long tile_t0 = s0 + (long long)wave * TILE, t0 = tile_t0 + (long long)lane * SUB;
     const bool any_valid = tile_t0 < T && tile_t0 < c_hi + ka.halo;      // (wave-uniform: tiles behind the right-hand halo have nothing to do)
     if (first && wave == NW - 1 && ka.head_in != nullptr) {      // the head's observations to the host, first thing
@@ -2438,12 +2439,12 @@ __global__ __launch_bounds__(NW * 64, 2) void k_adjoint_one(const GArgs<D> by_va
         double zin[D];
 #pragma unroll
         for (int i = 0; i < D; ++i) zin[i] = 0.0;
-        const bool from_host = first && wave < 3 && ka.mu0_flag != nullptr;      // (wave-uniform) the head's end state comes from the host, beside the kernel
+        const bool from_host = from_head && wave < 3 && ka.mu0_flag != nullptr;      // (wave-uniform) the head's end state comes from the host, beside the kernel
         if (from_host) wait_tables(ka.mu0_flag, ka.seq, &sPoison);
 #pragma unroll
         for (int k = 1; k <= 3; ++k) {
             const int src = wave - k;
-            if (src < -1 || (src == -1 && !first)) continue;
+            if (src < -1 || (src == -1 && !from_head)) continue;
             double xs[D];
 #pragma unroll
             for (int i = 0; i < D; ++i) xs[i] = src >= 0 ? sF[src][i] : (from_host ? ka.mu0p[i] : ka.mu0[i]);
@@ -2663,7 +2664,7 @@ int launch_adjoint(hipStream_t st, const tgp_plan::FilterPlan& fp, const double*
 
 long long adjoint_workgroups(const tgp_plan::FilterPlan& fp, long long T) {
     const long long C = 8LL * 64 * kWJ - 2LL * fp.halo;
-    return C >= fp.halo && C > 0 ? (T - fp.nhs + C - 1) / C : -1;      // (a span at least a halo long: the run-in of workgroup 1 must not reach back into the head)
+    return C > 0 ? (T - fp.nhs + C - 1) / C : -1;
 }
 
 int adjoint_lti(hipStream_t stream, const tgp_plan::FilterPlan& fp, const double* mu_start, const double* y, long long T, double* part, double* psi_out,
@@ -2738,7 +2739,10 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_smooth_one(const SArgs<D> by_
     }
     const long long T = ka.T, c_lo = ka.nhs + g * ka.C, c_hi = (c_lo + ka.C < T) ? c_lo + ka.C : T;
     const bool first = g == 0;
-    const long long s0 = first ? ka.nhs : c_lo - ka.halo;
+    // a workgroup whose run-in would reach back into the head (a span shorter than a halo: the second workgroup) starts behind the head like the
+    // first, from the head's exact end state: its tiles still cover its range and the halo behind it
+    const bool from_head = first || c_lo - ka.halo < ka.nhs;
+    const long long s0 = from_head ? ka.nhs : c_lo - ka.halo;
     const long long tile_t0 = s0 + (long long)wave * TILE, t0 = tile_t0 + (long long)lane * SUB;
     const bool any_valid = tile_t0 < T && tile_t0 < c_hi + ka.halo_r;      // (wave-uniform: tiles behind the right-hand halo have nothing to do)
     if (first && wave == NW - 1 && ka.head_in != nullptr) {      // the head's inputs to the host, first thing: its forward recursion runs there
@@ -2893,7 +2897,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_smooth_one(const SArgs<D> by_
             zin[i] = 0.0;
             mu0v[i] = ka.mu0[i];
         }
-        if (first && wave < 3 && ka.mu0_flag != nullptr) {      // (wave-uniform) the head's end state comes from the host, beside the kernel
+        if (from_head && wave < 3 && ka.mu0_flag != nullptr) {      // (wave-uniform) the head's end state comes from the host, beside the kernel
             wait_tables(ka.mu0_flag, ka.seq, &sPoison);
 #pragma unroll
             for (int i = 0; i < D; ++i) mu0v[i] = ka.mu0p[i];
@@ -2901,7 +2905,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_smooth_one(const SArgs<D> by_
 #pragma unroll
         for (int k = 1; k <= 3; ++k) {
             const int src = wave - k;
-            if (src < -1 || (src == -1 && !first)) continue;
+            if (src < -1 || (src == -1 && !from_head)) continue;
             double xs[D];
 #pragma unroll
             for (int i = 0; i < D; ++i) xs[i] = src >= 0 ? sF[src][i] : mu0v[i];
@@ -3230,10 +3234,12 @@ void plan_smooth(const tgp_plan::ModelHost& m, long long T, tgp_plan::SmoothPlan
         return;
     }
     tgp_plan::build_smooth_any(m, T, sp, tvb, post);
-    // (halos would eat three quarters of a span; and a span must be at least a halo long: workgroup g >= 1 starts `halo` steps in front of its
-    //  range, which must not reach back into the head -- or in front of the series: a memory fault found by the randomised sweep, T = 250 000,
-    //  two Matern-1/2 of one length scale, halo 1520 against spans of 1056)
-    if (sp.why == tgp_plan::kOk && (smooth_span(sp, post) < 1024 || smooth_span(sp, post) < sp.halo)) sp.why = tgp_plan::kSlowMixing;
+    // (halos would eat three quarters of a span.  Workgroup g >= 1 starts `halo` steps in front of its range; with a span shorter than a halo that
+    //  reaches back into the head -- or in front of the series: a memory fault found by the randomised sweep, T = 250 000, two Matern-1/2 of one
+    //  length scale, halo 1520 against spans of 1056.
+    //  Such a workgroup -- only the second one can be: 2 spans + a halo fit its tiles exactly when a span is shorter than a halo -- starts behind
+    //  the head like the first, from the head's exact end state (`from_head` in the kernels).
+    if (sp.why == tgp_plan::kOk && smooth_span(sp, post) < 1024) sp.why = tgp_plan::kSlowMixing;
 }
 void plan_smooth_head_forward(const tgp_plan::ModelHost& m, const tgp_plan::SmoothPlan& sp, const double* y, double* mu_end, double* quad) {
     tgp_plan::smooth_head_forward_any(m, sp, y, mu_end, quad);

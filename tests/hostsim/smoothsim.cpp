@@ -69,7 +69,7 @@ int run_d(const ModelHost& m, long long T, const double* y, const double* Rnew, 
     out[2] = fp.n0; out[3] = fp.nhs; out[4] = sp.n1; out[5] = sp.halo;
     constexpr int SUB = kSub, TILE = 64 * SUB, NW = 8;
     const long long C = (long long)NW * TILE - 2LL * sp.halo;
-    if (C < 1024 || C < sp.halo) { out[1] = kSlowMixing; return 0; }      // (tgp_modal::plan_smooth: a span at least a halo long)
+    if (C < 1024) { out[1] = kSlowMixing; return 0; }
     const long long nwg = (T - fp.nhs + C - 1) / C;
     out[6] = (double)nwg;
     double mu_end[D], quad = 0.0;
@@ -85,7 +85,8 @@ int run_d(const ModelHost& m, long long T, const double* y, const double* Rnew, 
     for (long long g = 0; g < nwg; ++g) {
         const long long c_lo = fp.nhs + g * C, c_hi = (c_lo + C < T) ? c_lo + C : T;
         const bool first = g == 0;
-        const long long s0 = first ? fp.nhs : c_lo - sp.halo;
+        const bool from_head = first || c_lo - sp.halo < fp.nhs;      // (a span shorter than a halo: the second workgroup starts behind the head as well)
+        const long long s0 = from_head ? fp.nhs : c_lo - sp.halo;
         double sF[NW][D], sB[NW][D], X[NW][64][D], ST[NW][64][D], XI[NW][64][D];
         bool valid[NW];
         for (int w = 0; w < NW; ++w) {
@@ -153,7 +154,7 @@ int run_d(const ModelHost& m, long long T, const double* y, const double* Rnew, 
             for (int i = 0; i < D; ++i) zin[i] = 0.0;
             for (int k = 1; k <= 3; ++k) {
                 const int src = w - k;
-                if (src < -1 || (src == -1 && !first)) continue;
+                if (src < -1 || (src == -1 && !from_head)) continue;
                 const double* xs = src >= 0 ? sF[src] : mu_end;
                 if (k == 1) for (int i = 0; i < D; ++i) zin[i] += xs[i];
                 else matvec_acc<D>(fp.PT[k - 2], xs, zin);
