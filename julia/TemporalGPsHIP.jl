@@ -190,7 +190,31 @@ function AbstractGPs.marginals(p::DevicePosterior)
     mean, var = posterior_marginals(p.prior, p.y, p.Σs_new === nothing ? _prior_noise(p.prior) : p.Σs_new)
     return _marginal_gaussians(p.prior, mean, var)
 end
-AbstractGPs.rand(rng::AbstractRNG, p::DevicePosterior) = rand(rng, materialise(p))
+# rand of a posterior that has not been evaluated: `tgp_posterior_rand` (the filter and the reverse-time draw in one kernel, nothing of size
+# T x (2 d^2 + d) written; Forward LTI models with scalar observations, d <= 4, no missing data) -- TGP_EUNSUPPORTED (4): the evaluated route
+function AbstractGPs.rand(rng::AbstractRNG, p::DevicePosterior)
+    m = p.prior
+    if p.model === nothing && m.p == 1 && m.d <= 4 && !any(ismissing, p.y)
+        # the randomness in the reference's order (lgssm.jl:65-77): T transition vectors, T emission scalars, then x0's
+        eps_t = randn(rng, m.d, m.T); eps_e = randn(rng, m.T); eps_0 = randn(rng, m.d)
+        Σ = p.Σs_new === nothing ? _prior_noise(m) : p.Σs_new
+        Rn = Σ isa Fill ? Float64[first(Σ)] : collect(Float64, Σ)
+        yv = collect(Float64, p.y)
+        out = Vector{Float64}(undef, m.T)
+        rc = GC.@preserve yv Rn ccall((:tgp_posterior_rand, libtgp), Cint,
+            (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, UInt32, Ptr{Float64}),
+            m.h.ptr, yv, Rn, eps_t, eps_e, eps_0, length(Rn) == 1 ? SHARED_R : UInt32(0), out)
+        rc == 0 && return out
+        rc == 4 || check(m.h, rc)
+        # (not a model of the one-launch path: the same draws through the evaluated model)
+        y = Vector{Float64}(undef, m.T)
+        pm = materialise(p)
+        check(pm.h, ccall((:tgp_rand, libtgp), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, UInt32, Ptr{Float64}),
+            pm.h.ptr, eps_t, eps_e, eps_0, UInt32(0), y))
+        return y
+    end
+    return rand(rng, materialise(p))
+end
 AbstractGPs.logpdf(p::DevicePosterior, y::AbstractVector) = logpdf(materialise(p), y)
 TemporalGPs._filter(p::DevicePosterior, y::AbstractVector) = _filter(materialise(p), y)
 
