@@ -313,7 +313,7 @@ def lti_interface_leg(tgp, torch, model, y, T, d, local, steps):
     x0 = np.random.default_rng(5).standard_normal(d)
     t, k = timed(lambda: tgp.rand((eps_t, eps_e, x0), model), steps)
     out["rand"] = dict(ms=t * 1e3, steps_per_s=T / t, bytes_per_step=8 * (d + 2), kernels_ms=k)
-    if d <= 4:      # a draw from the posterior without evaluating it (posterior_lti_sde.jl:48-58; tgp_posterior_rand)
+    if d <= 6:      # a draw from the posterior without evaluating it (posterior_lti_sde.jl:48-58; tgp_posterior_rand)
         t, k = timed(lambda: tgp.rand((eps_t, eps_e, x0), tgp.posterior(model, y)), steps)
         out["posterior_rand"] = dict(ms=t * 1e3, steps_per_s=T / t, bytes_per_step=8 * (d + 3), kernels_ms=k)
     del eps_t, eps_e

@@ -322,7 +322,7 @@ int tgp_marginals(tgp_handle* h, uint32_t flags, double* mean_out, double* var_o
 /* ---- rand(rng, replace_observation_noise_cov(posterior(model, y), Rnew)) with the randomness supplied
  *      (posterior_lti_sde.jl:48-58 -> lgssm.jl:65-91 on the reverse-time model of lgssm.jl:193-221) WITHOUT
  *      evaluating that model (T x (2 d^2 + d) doubles): Forward LTI models with scalar observations, one noise
- *      variance, no missing data and d <= 4 run the filter and the reverse-time draw in ONE kernel over
+ *      variance, no missing data and d <= 6 run the filter and the reverse-time draw in ONE kernel over
  *      y and the draws. eps_t [T][d], eps_e [T] where TGP_IN_DEVICE says (as y and Rnew),
  *      eps_0 [d] host; eps_t[t] / eps_e[t] drive the transition / emission of step t and eps_0 the draw of the
  *      final filtering state, exactly as tgp_rand on the evaluated posterior uses them. Rnew: one value

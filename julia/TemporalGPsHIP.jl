@@ -191,10 +191,10 @@ function AbstractGPs.marginals(p::DevicePosterior)
     return _marginal_gaussians(p.prior, mean, var)
 end
 # rand of a posterior that has not been evaluated: `tgp_posterior_rand` (the filter and the reverse-time draw in one kernel, nothing of size
-# T x (2 d^2 + d) written; Forward LTI models with scalar observations, d <= 4, no missing data) -- TGP_EUNSUPPORTED (4): the evaluated route
+# T x (2 d^2 + d) written; Forward LTI models with scalar observations, d <= 6, no missing data) -- TGP_EUNSUPPORTED (4): the evaluated route
 function AbstractGPs.rand(rng::AbstractRNG, p::DevicePosterior)
     m = p.prior
-    if p.model === nothing && m.p == 1 && m.d <= 4 && !any(ismissing, p.y)
+    if p.model === nothing && m.p == 1 && m.d <= 6 && !any(ismissing, p.y)
         # the randomness in the reference's order (lgssm.jl:65-77): T transition vectors, T emission scalars, then x0's
         eps_t = randn(rng, m.d, m.T); eps_e = randn(rng, m.T); eps_0 = randn(rng, m.d)
         Σ = p.Σs_new === nothing ? _prior_noise(m) : p.Σs_new

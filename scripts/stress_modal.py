@@ -47,7 +47,7 @@ for case in range(n_cases):
     Rn = np.exp(rng.normal(-2, 1, size=T)) if rng.random() < 0.3 else np.array([float(np.exp(rng.normal(-2, 1)))])
     mode = int(rng.integers(3))          # 0 host arrays, 1 device arrays, 2 device arrays 8 bytes past a 16-byte boundary
     if case < START:      # (replaying a sweep up to a case: the generator's draws of the cases skipped, none of their device work)
-        if d <= 4 and T <= 70000:
+        if d <= 6 and T <= 70000:
             rng.standard_normal((T, d)), rng.standard_normal(T), rng.standard_normal(d)
         continue
     if VERBOSE:
@@ -87,7 +87,7 @@ for case in range(n_cases):
             lp1 = tgp.logpdf(dm, y)
             if not abs(lp1 - lp_ref) <= 1e-10 * abs(lp_ref):
                 msgs.append(f"[{opt}] logpdf-only {lp1} vs {lp_ref}")
-            if opt == 3 and d <= 4 and T <= 70000:
+            if opt == 3 and d <= 6 and T <= 70000:
                 # a draw from the posterior: the one-launch path (tgp_posterior_rand) against the evaluated route (tgp_posterior, then
                 # tgp_rand on the Reverse model -- the general engine), the same draws
                 e2 = (rng.standard_normal((T, d)), rng.standard_normal(T), rng.standard_normal(d))

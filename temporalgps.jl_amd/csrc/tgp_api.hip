@@ -2662,7 +2662,7 @@ static int smooth_lti_call(tgp_handle* h, const double* y, uint32_t flags, const
 }
 
 // rand of posterior(model, y) with replaced observation noise (lgssm.jl:65-91 on the reverse-time model of :193-221; posterior_lti_sde.jl:48-58)
-// WITHOUT evaluating that model: Forward LTI models with scalar observations, one noise variance, no missing data, d <= 4 -- k_smooth_one with a
+// WITHOUT evaluating that model: Forward LTI models with scalar observations, one noise variance, no missing data, d <= 6 -- k_smooth_one with a
 // noise input.  TGP_EUNSUPPORTED: the caller takes the evaluated route (tgp_posterior, then tgp_rand on the Reverse model).
 int tgp_posterior_rand(tgp_handle* h, const double* y, const double* Rnew, const double* eps_t, const double* eps_e, const double* eps_0, uint32_t flags,
                        double* y_out) {
@@ -2674,7 +2674,7 @@ int tgp_posterior_rand(tgp_handle* h, const double* y, const double* Rnew, const
     bool served = false;
     const SmoothRand rnd{eps_t, eps_e, eps_0};
     if (steady2_eligible(h, nullptr, flags)) TRY(smooth_lti_call(h, y, flags, Rnew, y_out, nullptr, nullptr, &served, &rnd));
-    if (!served) return h->fail(TGP_EUNSUPPORTED, "tgp_posterior_rand: Forward LTI models with scalar observations, one noise variance and d <= 4 (take tgp_posterior + tgp_rand)");
+    if (!served) return h->fail(TGP_EUNSUPPORTED, "tgp_posterior_rand: Forward LTI models with scalar observations, one noise variance and d <= 6 (take tgp_posterior + tgp_rand)");
     return TGP_OK;
 }
 

@@ -127,7 +127,7 @@ struct SmoothCall {
     const double *U = nullptr, *v0 = nullptr;
     double s0 = 0.0;
 };
-constexpr int kSmoothRandMaxD = 4;
+constexpr int kSmoothRandMaxD = 6;
 // false when the process runs with synchronous launches (HIP_LAUNCH_BLOCKING, AMD_SERIALIZE_KERNEL, ...) or TGP_MODAL_OVERLAP=0: a kernel
 // that waits for a flag the host raises behind the launch would wait for itself
 bool overlap_allowed();

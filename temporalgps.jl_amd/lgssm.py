@@ -759,7 +759,7 @@ def _posterior_rand_one_launch(post, eps_t, eps_e, eps_0):
     """rand of a posterior that has not been evaluated, on the prior's handle (tgp_posterior_rand: filter + reverse-time draw in one kernel,
     nothing of size T x (2 d^2 + d) written).  None: not a model of that path -- the caller evaluates the posterior."""
     prior = post._prior
-    if (post._model is not None or isinstance(prior, PosteriorLGSSM) or prior.ordering is not Forward or prior.p != 1 or prior.dim > 4
+    if (post._model is not None or isinstance(prior, PosteriorLGSSM) or prior.ordering is not Forward or prior.p != 1 or prior.dim > 6
             or prior._whiten is not None or isinstance(post._y, tuple)):
         return None
     y = post._y

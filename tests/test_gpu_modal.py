@@ -456,7 +456,7 @@ def test_a_stream_with_work_of_the_callers_in_front_of_the_kernel(tgp):
         del a
 
 
-@pytest.mark.parametrize("d", [1, 2, 3, 4])
+@pytest.mark.parametrize("d", [1, 2, 3, 4, 5, 6])
 def test_a_draw_from_the_posterior_in_one_launch(tgp, d):
     """rand(rng, replace_observation_noise_cov(posterior(model, y), Rn)) (posterior_lti_sde.jl:48-58; lgssm.jl:65-91 on the reverse-time model
     of :193-221) of a Forward LTI model WITHOUT evaluating that model: tgp_posterior_rand = k_smooth_one with a noise input, ONE kernel
@@ -501,9 +501,9 @@ def test_a_draw_from_the_posterior_in_one_launch(tgp, d):
 
 
 def test_a_draw_from_the_posterior_beyond_the_one_launch_path(tgp):
-    """d = 6 (the lane's draws no longer fit its registers), a series too short for head + transient: the evaluated route serves the call"""
+    """d = 8 (the lane's draws no longer fit its registers), a series too short for head + transient: the evaluated route serves the call"""
     from oracle import lgssm_ref as ref
-    for spec, T in ((KERNELS[6], 3000), (KERNELS[3], 90)):
+    for spec, T in ((KERNELS[8], 3000), (KERNELS[3], 90)):
         model = oc.build_lgssm(spec, ("regular", 0.0, 0.1, T), 0.1)
         d = len(model["x0m"])
         y = draw(model, 4)
