@@ -24,6 +24,106 @@
 #include "tgp_modal.hpp"
 #include "tgp_sweep.hpp"
 #include "tgp_adjoint_host.hpp"
+#include "tgp_alloc.hpp"
+#include <map>
+#include <unordered_map>
+
+// ---- tgp_alloc.hpp: the caching allocator ------------------------------------------------------------------------------------------------
+namespace tgp_alloc {
+namespace {
+constexpr size_t kCacheMax = size_t(4) << 20;      // blocks beyond 4 MiB are not parked
+constexpr size_t kParkedPerClass = 64;
+struct Block {
+    size_t cls;         // size class (bytes actually allocated); 0: not cacheable
+    int device;
+    unsigned kind;      // 0 device, 1 + flags: pinned host with those flags
+};
+struct Key {
+    int device;
+    unsigned kind;
+    size_t cls;
+    bool operator<(const Key& o) const { return device != o.device ? device < o.device : (kind != o.kind ? kind < o.kind : cls < o.cls); }
+};
+std::mutex g_mu;
+std::unordered_map<void*, Block> g_live;
+std::map<Key, std::vector<void*>> g_parked;
+long long g_reused = 0, g_fresh = 0;
+bool enabled() {
+    static const bool on = [] { const char* v = std::getenv("TGP_ALLOC_CACHE"); return !(v && v[0] == '0'); }();
+    return on;
+}
+size_t size_class(size_t bytes) {
+    if (!enabled() || bytes > kCacheMax) return 0;
+    size_t c = 256;
+    while (c < bytes) c <<= 1;
+    return c;
+}
+hipError_t get(void** p, size_t bytes, unsigned kind) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const size_t cls = size_class(bytes);
+    if (cls) {
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto it = g_parked.find(Key{dev, kind, cls});
+        if (it != g_parked.end() && !it->second.empty()) {
+            *p = it->second.back();
+            it->second.pop_back();
+            g_live[*p] = Block{cls, dev, kind};
+            ++g_reused;
+            return hipSuccess;
+        }
+    }
+    const size_t n = cls ? cls : bytes;
+    const hipError_t e = kind == 0 ? hipMalloc(p, n) : hipHostMalloc(p, n, kind - 1);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_live[*p] = Block{cls, dev, kind};
+    ++g_fresh;
+    return hipSuccess;
+}
+hipError_t put(void* p) {
+    if (!p) return hipSuccess;
+    Block b{0, 0, 0};
+    bool known = false;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto it = g_live.find(p);
+        if (it != g_live.end()) {
+            b = it->second;
+            known = true;
+            g_live.erase(it);
+            if (b.cls) {
+                auto& v = g_parked[Key{b.device, b.kind, b.cls}];
+                if (v.size() < kParkedPerClass) {
+                    v.push_back(p);
+                    return hipSuccess;
+                }
+            }
+        }
+    }
+    (void)known;
+    return b.kind == 0 ? hipFree(p) : hipHostFree(p);
+}
+}  // namespace
+hipError_t dev_malloc(void** p, size_t bytes) { return get(p, bytes, 0); }
+hipError_t dev_free(void* p) { return put(p); }
+hipError_t host_malloc(void** p, size_t bytes, unsigned flags) { return get(p, bytes, 1 + flags); }
+hipError_t host_free(void* p) { return put(p); }
+void trim() {
+    std::map<Key, std::vector<void*>> parked;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        parked.swap(g_parked);
+    }
+    for (auto& kv : parked)
+        for (void* q : kv.second) (void)(kv.first.kind == 0 ? hipFree(q) : hipHostFree(q));
+}
+void stats(long long* reused, long long* fresh) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (reused) *reused = g_reused;
+    if (fresh) *fresh = g_fresh;
+}
+}  // namespace tgp_alloc
 
 namespace tgp {
 const KernelTable *kernel_table_d1(), *kernel_table_d2(), *kernel_table_d3(), *kernel_table_d4(), *kernel_table_d5(),
@@ -211,10 +311,10 @@ struct DevBuf {
     size_t cap = 0;
     hipError_t ensure(size_t bytes) {
         if (bytes <= cap) return hipSuccess;
-        if (p) (void)hipFree(p);
+        if (p) (void)tgp_alloc::dev_free(p);
         p = nullptr;
         cap = 0;
-        hipError_t e = hipMalloc(&p, bytes);
+        hipError_t e = tgp_alloc::dev_malloc(&p, bytes);
         if (e == hipSuccess) cap = bytes;
         if (e == hipSuccess && poison_allocations()) {
             e = hipMemset(p, 0xFF, bytes);
@@ -223,7 +323,7 @@ struct DevBuf {
         return e;
     }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p) (void)tgp_alloc::dev_free(p);
         p = nullptr;
         cap = 0;
     }
@@ -1460,7 +1560,7 @@ int tgp_create(tgp_handle** out, int device) {
             delete h;
             return TGP_EHIP;
         }
-    if (hipHostMalloc(reinterpret_cast<void**>(&h->host_result), 8 * sizeof(double), hipHostMallocDefault) != hipSuccess ||
+    if (tgp_alloc::host_malloc(reinterpret_cast<void**>(&h->host_result), 8 * sizeof(double), hipHostMallocDefault) != hipSuccess ||
         h->result.ensure(8 * sizeof(double)) != hipSuccess) {
         delete h;
         return TGP_EHIP;
@@ -1499,10 +1599,10 @@ int tgp_destroy(tgp_handle* h) {
     if (h->steady2) tgp_steady::destroy(h->steady2);
     if (h->modal) tgp_modal::destroy(h->modal);
     if (h->sweep) tgp_sweep::destroy(h->sweep);
-    if (h->host_result) (void)hipHostFree(h->host_result);
-    if (h->adj_host) (void)hipHostFree(h->adj_host);
-    if (h->flt_host) (void)hipHostFree(h->flt_host);
-    if (h->sm_sync) (void)hipHostFree(h->sm_sync);
+    if (h->host_result) (void)tgp_alloc::host_free(h->host_result);
+    if (h->adj_host) (void)tgp_alloc::host_free(h->adj_host);
+    if (h->flt_host) (void)tgp_alloc::host_free(h->flt_host);
+    if (h->sm_sync) (void)tgp_alloc::host_free(h->sm_sync);
     if (h->own_stream && !pooled_stream(h->device)) (void)hipStreamDestroy(h->own_stream);      // (pool streams live as long as the process)
     delete h;
     return TGP_OK;
@@ -2282,10 +2382,10 @@ int tgp_adjoint_finish(int d, const double* rec, const double* y_head, int64_t n
 // the pinned host buffer of the head-on-the-host paths (head observations in, head outputs and the workgroups' partial sums out)
 static int ensure_pinned(tgp_handle* h, size_t need) {
     if (need <= h->flt_cap) return TGP_OK;
-    if (h->flt_host) (void)hipHostFree(h->flt_host);
+    if (h->flt_host) (void)tgp_alloc::host_free(h->flt_host);
     h->flt_host = nullptr;
     h->flt_cap = 0;
-    if (hipHostMalloc(reinterpret_cast<void**>(&h->flt_host), need * sizeof(double), hipHostMallocDefault) != hipSuccess) return h->fail(TGP_EHIP, "hipHostMalloc");
+    if (tgp_alloc::host_malloc(reinterpret_cast<void**>(&h->flt_host), need * sizeof(double), hipHostMallocDefault) != hipSuccess) return h->fail(TGP_EHIP, "hipHostMalloc");
     h->flt_cap = need;
     return TGP_OK;
 }
@@ -2308,7 +2408,7 @@ static int adjoint_lti_call(tgp_handle* h, const double* y, uint32_t flags, doub
     TRY(ensure_pinned(h, need));
     double *yh = h->flt_host, *part = yh + nhs, *psi = part + (size_t)nwg * ns, *rec = psi + d;
     if (!h->sm_sync) {
-        if (hipHostMalloc(reinterpret_cast<void**>(&h->sm_sync), 32 * sizeof(double), hipHostMallocDefault) != hipSuccess) return h->fail(TGP_EHIP, "hipHostMalloc");
+        if (tgp_alloc::host_malloc(reinterpret_cast<void**>(&h->sm_sync), 32 * sizeof(double), hipHostMallocDefault) != hipSuccess) return h->fail(TGP_EHIP, "hipHostMalloc");
         std::memset(h->sm_sync, 0, 32 * sizeof(double));
     }
     CallTimer tm(h, /*clear=*/false);
@@ -2402,7 +2502,7 @@ int tgp_logpdf_adjoint(tgp_handle* h, const double* y, uint32_t flags, double* l
     constexpr int64_t kHead = (int64_t)tgp_steady::kHeadMaxTiles * tgp_steady::kTile;
     const size_t nrec = tgp_steady::grad_record_size(h->d);
     const int64_t nyh = h->T < kHead ? h->T : kHead;
-    if (!h->adj_host && hipHostMalloc(reinterpret_cast<void**>(&h->adj_host), (tgp_steady::grad_record_size(tgp_steady::kMaxD) + kHead) * sizeof(double), hipHostMallocDefault) != hipSuccess)
+    if (!h->adj_host && tgp_alloc::host_malloc(reinterpret_cast<void**>(&h->adj_host), (tgp_steady::grad_record_size(tgp_steady::kMaxD) + kHead) * sizeof(double), hipHostMallocDefault) != hipSuccess)
         return h->fail(TGP_EHIP, "hipHostMalloc");
     CallTimer tm(h, /*clear=*/false);
     TRY(set_obs(h, y, nullptr, flags));
@@ -2496,7 +2596,7 @@ static int smooth_lti_call(tgp_handle* h, const double* y, uint32_t flags, const
     // hin: y | Rnew (| eta | eps [nhs][d] of a draw) of the head; hout: mean | var
     double *hin = h->flt_host, *hout = hin + 8 * HM, *tvb = hout + 2 * HM, *part = tvb + tgp_plan::kTailMax;
     if (!h->sm_sync) {
-        if (hipHostMalloc(reinterpret_cast<void**>(&h->sm_sync), 32 * sizeof(double), hipHostMallocDefault) != hipSuccess) return h->fail(TGP_EHIP, "hipHostMalloc");
+        if (tgp_alloc::host_malloc(reinterpret_cast<void**>(&h->sm_sync), 32 * sizeof(double), hipHostMallocDefault) != hipSuccess) return h->fail(TGP_EHIP, "hipHostMalloc");
         std::memset(h->sm_sync, 0, 32 * sizeof(double));
     }
     double *mu_end = h->sm_sync, *xi = h->sm_sync + 8;

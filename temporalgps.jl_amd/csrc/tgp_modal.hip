@@ -2,6 +2,7 @@
 // observations and no missing data in a single kernel over y -- see tgp_modal.hpp.  gfx950 only (wave64, __shfl scans, LDS rows for
 // whole-line output stores, uniform coefficients through the kernel-argument segment).
 #include "tgp_modal.hpp"
+#include "tgp_alloc.hpp"
 
 #include <chrono>
 #include <cmath>
@@ -1092,10 +1093,10 @@ Engine* create() { return new Engine(); }
 void destroy(Engine* e) {
     if (!e) return;
     delete e->tab;
-    if (e->hflat) (void)hipHostFree(e->hflat);
-    if (e->hhead) (void)hipHostFree(e->hhead);
-    if (e->dflat) (void)hipFree(e->dflat);
-    if (e->part) (void)hipHostFree(e->part);
+    if (e->hflat) (void)tgp_alloc::host_free(e->hflat);
+    if (e->hhead) (void)tgp_alloc::host_free(e->hhead);
+    if (e->dflat) (void)tgp_alloc::dev_free(e->dflat);
+    if (e->part) (void)tgp_alloc::host_free(e->part);
     delete e;
 }
 
@@ -1348,8 +1349,8 @@ bool plan(Engine* e, const tgp_plan::ModelHost& m, long long T) {
         // the layout of ship_tables at its largest: d = 8, n0 = kN0Max, n1 = kTailMax
         e->flat_cap = (size_t)tgp_plan::kHeadMax * (64 + 8) + (size_t)(tgp_plan::kN0Max + 1) * (8 + 3) + tgp_plan::kTailMax + 64 + 2 * 8 + 8;
         e->flat_cap = (e->flat_cap + 1) & ~(size_t)1;
-        if (hipHostMalloc(reinterpret_cast<void**>(&e->hflat), (e->flat_cap + 4) * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess ||
-            hipMalloc(reinterpret_cast<void**>(&e->dflat), (e->flat_cap + 4) * sizeof(double)) != hipSuccess) {
+        if (tgp_alloc::host_malloc(reinterpret_cast<void**>(&e->hflat), (e->flat_cap + 4) * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess ||
+            tgp_alloc::dev_malloc(reinterpret_cast<void**>(&e->dflat), (e->flat_cap + 4) * sizeof(double)) != hipSuccess) {
             e->info = tgp_plan::Info{};
             e->info.why = tgp_plan::kEigFail;
             return false;
@@ -1358,7 +1359,7 @@ bool plan(Engine* e, const tgp_plan::ModelHost& m, long long T) {
     }
     if (!e->hhead) {
         const size_t n = 4 * kHH + 16 + 4;
-        if (hipHostMalloc(reinterpret_cast<void**>(&e->hhead), n * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) {
+        if (tgp_alloc::host_malloc(reinterpret_cast<void**>(&e->hhead), n * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) {
             e->info = tgp_plan::Info{};
             e->info.why = tgp_plan::kEigFail;
             return false;
@@ -1392,10 +1393,10 @@ bool plan(Engine* e, const tgp_plan::ModelHost& m, long long T) {
     e->nwg = (T - e->md.nhs + C - 1) / C;
     const size_t need = (size_t)e->nwg + 64;
     if (need > e->part_cap) {
-        if (e->part) (void)hipHostFree(e->part);
+        if (e->part) (void)tgp_alloc::host_free(e->part);
         e->part = nullptr;
         e->part_cap = 0;
-        if (hipHostMalloc(reinterpret_cast<void**>(&e->part), need * sizeof(double), hipHostMallocDefault) != hipSuccess) {
+        if (tgp_alloc::host_malloc(reinterpret_cast<void**>(&e->part), need * sizeof(double), hipHostMallocDefault) != hipSuccess) {
             e->info.why = tgp_plan::kEigFail;
             return false;
         }

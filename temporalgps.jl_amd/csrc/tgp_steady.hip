@@ -1,6 +1,7 @@
 // Stationary-gain scan engine: see tgp_steady.hpp for what it computes and why.  gfx950 only (wave64, LDS as the lane exchange of the
 // one-wave setup kernel, __shfl for the in-tile scans).
 #include "tgp_steady.hpp"
+#include "tgp_alloc.hpp"
 
 #include <cmath>
 #include <cstdio>
@@ -2861,7 +2862,7 @@ static int cov_mode_bits() {      // TGP_STEADY_COV=seq: the sequential covarian
 Engine* create() { return new Engine(); }
 void destroy(Engine* e) {
     if (!e) return;
-    if (e->slab) (void)hipFree(e->slab);
+    if (e->slab) (void)tgp_alloc::dev_free(e->slab);
     delete e;
 }
 bool supports(int d) { return d >= 1 && d <= kMaxD; }
@@ -2890,10 +2891,10 @@ hipError_t ensure(Engine* e, int d, long long ntiles) {
                  o_SSQ = take(nb), o_misc = take(16), o_GS = take(nb * (DD + 3 * (size_t)d + 2)), o_grec = take(grad_record_size(d));
     const size_t bytes = off * sizeof(double);
     if (bytes > e->cap) {
-        if (e->slab) (void)hipFree(e->slab);
+        if (e->slab) (void)tgp_alloc::dev_free(e->slab);
         e->slab = nullptr;
         e->cap = 0;
-        hipError_t rc = hipMalloc(&e->slab, bytes);
+        hipError_t rc = tgp_alloc::dev_malloc(&e->slab, bytes);
         if (rc != hipSuccess) return rc;
         e->cap = bytes;
     }

@@ -2,6 +2,7 @@
 // gfx950 only.  One wave per workgroup, one wave per SIMD (the kernel is bound by its fp64 instruction stream, not by memory: every
 // lane carries the full covariance recursion of its chunk), 4 workgroups per CU by their LDS (the filtering states of a block).
 #include "tgp_sweep.hpp"
+#include "tgp_alloc.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -147,8 +148,8 @@ struct Engine {
 Engine* create() { return new Engine(); }
 void destroy(Engine* e) {
     if (!e) return;
-    if (e->part) (void)hipHostFree(e->part);
-    if (e->ckpt) (void)hipFree(e->ckpt);
+    if (e->part) (void)tgp_alloc::host_free(e->part);
+    if (e->ckpt) (void)tgp_alloc::dev_free(e->ckpt);
     delete e;
 }
 void force_geometry(Engine* e, int C, int W, int Wb) {
@@ -223,11 +224,11 @@ int enqueue(Engine* e, hipStream_t stream, const Call& c, const char** kname, st
     const bool post = c.mean != nullptr;
     const size_t need_part = (size_t)p.nwaves * 4 * sizeof(double);
     if (need_part > e->part_cap) {
-        if (e->part) (void)hipHostFree(e->part);
+        if (e->part) (void)tgp_alloc::host_free(e->part);
         e->part = nullptr;
         e->part_cap = 0;
         const size_t cap = std::max<size_t>(need_part, 1 << 16);
-        hipError_t rc = hipHostMalloc((void**)&e->part, cap, hipHostMallocDefault);
+        hipError_t rc = tgp_alloc::host_malloc((void**)&e->part, cap, hipHostMallocDefault);
         if (rc != hipSuccess) return fail("hipHostMalloc", rc);
         e->part_cap = cap;
     }
@@ -235,10 +236,10 @@ int enqueue(Engine* e, hipStream_t stream, const Call& c, const char** kname, st
         const int B = p.d <= 3 ? 8 : 4, NS = p.d + p.d * (p.d + 1) / 2;
         const size_t need = (size_t)p.nwaves * (size_t)(p.C / B) * NS * 64 * sizeof(double);
         if (need > e->ckpt_cap) {
-            if (e->ckpt) (void)hipFree(e->ckpt);
+            if (e->ckpt) (void)tgp_alloc::dev_free(e->ckpt);
             e->ckpt = nullptr;
             e->ckpt_cap = 0;
-            hipError_t rc = hipMalloc(&e->ckpt, need);
+            hipError_t rc = tgp_alloc::dev_malloc(&e->ckpt, need);
             if (rc != hipSuccess) return fail("hipMalloc", rc);
             e->ckpt_cap = need;
         }
