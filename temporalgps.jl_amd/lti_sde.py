@@ -501,6 +501,19 @@ class FinitePosteriorLTISDE:
         d = self.f.data
         xt, xp = _times(d["x"]), _times(self.x)
         ntr, npr = len(xt), len(xp)
+        if ntr and npr and np.all(xt[1:] >= xt[:-1]) and np.all(xp[1:] >= xp[:-1]):
+            # both already in temporal order (the usual case): the stable sort of the joined inputs is a MERGE -- a prediction input goes behind
+            # every training input that is not later than it (ties keep the joined order: training first).  O(n) instead of two argsorts of the
+            # joined array (a third of a prediction call's wall clock at a million inputs)
+            pos = np.searchsorted(xt, xp, side="right")
+            pr = pos + np.arange(npr)
+            tr = np.arange(ntr) + np.cumsum(np.bincount(pos, minlength=ntr + 1))[:ntr]
+            n = ntr + npr
+            x, S, y = np.empty(n), np.empty(n), np.empty(n)
+            x[tr], x[pr] = xt, xp
+            S[tr], S[pr] = _noise(d["sigma2"], ntr), sigma2_pr
+            y[tr], y[pr] = d["y"], np.nan
+            return x, S, y, tr, pr
         x_raw = np.concatenate([xt, xp])
         order = np.argsort(x_raw, kind="stable")
         inv = np.argsort(order, kind="stable")
