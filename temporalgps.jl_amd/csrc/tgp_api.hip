@@ -33,6 +33,7 @@ namespace tgp_alloc {
 namespace {
 constexpr size_t kCacheMax = size_t(4) << 20;      // blocks beyond 4 MiB are not parked
 constexpr size_t kParkedPerClass = 64;
+constexpr size_t kParkedBytesMax = size_t(128) << 20;      // per kind of memory (device / pinned host), over all devices: beyond it a freed block goes to the runtime
 struct Block {
     size_t cls;         // size class (bytes actually allocated); 0: not cacheable
     int device;
@@ -48,6 +49,7 @@ std::mutex g_mu;
 std::unordered_map<void*, Block> g_live;
 std::map<Key, std::vector<void*>> g_parked;
 long long g_reused = 0, g_fresh = 0;
+size_t g_parked_bytes[2] = {0, 0};
 bool enabled() {
     static const bool on = [] { const char* v = std::getenv("TGP_ALLOC_CACHE"); return !(v && v[0] == '0'); }();
     return on;
@@ -68,6 +70,7 @@ hipError_t get(void** p, size_t bytes, unsigned kind) {
         if (it != g_parked.end() && !it->second.empty()) {
             *p = it->second.back();
             it->second.pop_back();
+            g_parked_bytes[kind != 0] -= cls;
             g_live[*p] = Block{cls, dev, kind};
             ++g_reused;
             return hipSuccess;
@@ -94,8 +97,9 @@ hipError_t put(void* p) {
             g_live.erase(it);
             if (b.cls) {
                 auto& v = g_parked[Key{b.device, b.kind, b.cls}];
-                if (v.size() < kParkedPerClass) {
+                if (v.size() < kParkedPerClass && g_parked_bytes[b.kind != 0] + b.cls <= kParkedBytesMax) {
                     v.push_back(p);
+                    g_parked_bytes[b.kind != 0] += b.cls;
                     return hipSuccess;
                 }
             }
@@ -114,6 +118,7 @@ void trim() {
     {
         std::lock_guard<std::mutex> lk(g_mu);
         parked.swap(g_parked);
+        g_parked_bytes[0] = g_parked_bytes[1] = 0;
     }
     for (auto& kv : parked)
         for (void* q : kv.second) (void)(kv.first.kind == 0 ? hipFree(q) : hipHostFree(q));
