@@ -2152,6 +2152,7 @@ struct SmoothRand {      // a draw from the posterior instead of its marginals: 
 };
 static int smooth_lti_call(tgp_handle* h, const double* y, uint32_t flags, const double* Rnew, double* mean_out, double* var_out, double* lml_out, bool* served,
                            const SmoothRand* rnd = nullptr);
+static bool lti_but_offset(const tgp_handle* h);
 
 int tgp_logpdf(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t flags, double* out) {
     TRY(check_ready(h, /*general=*/false));
@@ -2181,6 +2182,11 @@ int tgp_logpdf(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t 
         const int rc = tm.finish(out);
         if (rc != TGP_OK || steady2_served(h)) return rc;
         // not applicable to this model (decided on the device): the general path below serves this and every later call
+    }
+    if (lti_but_offset(h) && missing == nullptr && y != nullptr && !(flags & TGP_REUSE_REDUCE)) {      // a mean function on a regular grid: stationary gains
+        bool served = false;
+        TRY(smooth_lti_call(h, y, flags, nullptr, nullptr, nullptr, out, &served));
+        if (served) return TGP_OK;
     }
     h->sweep_last = false;
     if (sweep_eligible(h, flags)) {
@@ -2586,20 +2592,36 @@ static int filter_lti_call(tgp_handle* h, const double* y, uint32_t flags, doubl
 // d <= 8; a defective closed loop: two summands with one length scale, ...): the head on the host, everything behind it in ONE kernel on the
 // dense powers of the closed loop and of the settled reverse-time transition (tgp_modal::smooth_lti).  *served = false: the
 // five-launch engine runs the call.
+// Every block shared but the emission offset: a GP with a mean function on a regular grid (lti_sde.jl:118-131).  The gains never see the offset, so the
+// stationary structure holds; the dense-powers kernel subtracts it per step (SmoothCall::hh_t).
+static bool lti_but_offset(const tgp_handle* h) {
+    return !h->lti && !h->is_dense && !h->sde && h->p == 1 && h->ordering == 0 && h->mv.sA == 0 && h->mv.sa == 0 && h->mv.sQ == 0 && h->mv.sH == 0 && h->mv.sR == 0 &&
+           h->mv.sh != 0 && h->mv.T == h->T && !h->sweepm.empty() && h->opt_steady2 && h->opt_chunk == 0;
+}
 static int smooth_lti_call(tgp_handle* h, const double* y, uint32_t flags, const double* Rnew, double* mean_out, double* var_out, double* lml_out, bool* served,
                            const SmoothRand* rnd) {
     *served = false;
     tgp_plan::ModelHost mh;
-    if (!h->opt_modal || h->smooth_state < 0 || chunk_engine_requested(h) || h->is_dense || !h->lti || h->p != 1 || h->ordering != 0 || h->sde ||
-        h->d > tgp_plan::kRandMaxD || !modal_host_model(h, mh) || (!rnd && (mean_out != nullptr) != (var_out != nullptr)) || (mean_out && !Rnew))
+    const bool offs = lti_but_offset(h);
+    if (offs && h->opt_modal && !rnd) {      // (the plans read the shared blocks the sweep engine's record holds: the same layout as hostm)
+        const int d = h->d;
+        const size_t dd = (size_t)d * d;
+        const double* q = h->sweepm.data();
+        mh.d = d;
+        mh.A = q; mh.a = q + dd; mh.Q = q + dd + d; mh.H = q + 2 * dd + d; mh.hh = q + 2 * dd + 2 * d; mh.R = q + 2 * dd + 2 * d + 1;
+        mh.x0m = h->x0m.data();
+        mh.x0P = h->x0P.data();
+    }
+    if (!h->opt_modal || h->smooth_state < 0 || chunk_engine_requested(h) || h->is_dense || !(h->lti || (offs && !rnd)) || h->p != 1 || h->ordering != 0 || h->sde ||
+        h->d > tgp_plan::kRandMaxD || (!offs && !modal_host_model(h, mh)) || (!rnd && (mean_out != nullptr) != (var_out != nullptr)) || (mean_out && !Rnew))
         return TGP_OK;
     if (rnd && (h->d > tgp_modal::kSmoothRandMaxD || !mean_out || var_out || !rnd->eps_t || !rnd->eps_e || !rnd->eps_0)) return TGP_OK;
     const bool post = mean_out != nullptr;      // (false: logpdf only -- the forward half alone, no halo behind a span)
     constexpr size_t HM = tgp_plan::kHeadMax;
     const size_t nwg_max = (size_t)(h->T / 1024) + 2;
-    TRY(ensure_pinned(h, 10 * HM + nwg_max + tgp_plan::kTailMax + 8));
-    // hin: y | Rnew (| eta | eps [nhs][d] of a draw) of the head; hout: mean | var
-    double *hin = h->flt_host, *hout = hin + 8 * HM, *tvb = hout + 2 * HM, *part = tvb + tgp_plan::kTailMax;
+    TRY(ensure_pinned(h, 14 * HM + nwg_max + tgp_plan::kTailMax + 8));
+    // hin: y | Rnew (| eta | eps [nhs][d <= 6] of a draw) of the head, its emission offsets at 10 nhs; hout: mean | var
+    double *hin = h->flt_host, *hout = hin + 12 * HM, *tvb = hout + 2 * HM, *part = tvb + tgp_plan::kTailMax;
     if (!h->sm_sync) {
         if (tgp_alloc::host_malloc(reinterpret_cast<void**>(&h->sm_sync), 32 * sizeof(double), hipHostMallocDefault) != hipSuccess) return h->fail(TGP_EHIP, "hipHostMalloc");
         std::memset(h->sm_sync, 0, 32 * sizeof(double));
@@ -2639,8 +2661,10 @@ static int smooth_lti_call(tgp_handle* h, const double* y, uint32_t flags, const
     TRY(stage_out(h, h->bo1, mean_out, nT, odev, &dm));
     TRY(stage_out(h, h->bo2, var_out, nT, odev, &dv));
     double quad_head = 0.0;
-    const double *yhead = idev ? hin : y, *rnhead = idev ? hin + nhs : Rnew;
-    const double *eehead = rnd ? (idev ? hin + 2 * nhs : rnd->eps_e) : nullptr, *ethead = rnd ? (idev ? hin + 3 * nhs : rnd->eps_t) : nullptr;
+    const bool hand = idev || offs;      // the kernel hands the head's inputs over (a per-step offset lives on the device whatever the call's arrays are)
+    const double *yhead = hand ? hin : y, *rnhead = hand ? hin + nhs : Rnew;
+    const double* hhhead = offs ? hin + 10 * nhs : nullptr;
+    const double *eehead = rnd ? (hand ? hin + 2 * nhs : rnd->eps_e) : nullptr, *ethead = rnd ? (hand ? hin + 3 * nhs : rnd->eps_t) : nullptr;
     tgp_modal::SmoothCall c;
     c.T = h->T;
     c.y = h->mv.y;
@@ -2652,6 +2676,7 @@ static int smooth_lti_call(tgp_handle* h, const double* y, uint32_t flags, const
     c.part = part;
     c.xi_out = xi;
     c.seq = seq;
+    c.hh_t = offs ? h->mv.h : nullptr;
     if (rnd) {
         c.eps_t = static_cast<const double*>(pet);
         c.eps_e = static_cast<const double*>(pee);
@@ -2660,7 +2685,7 @@ static int smooth_lti_call(tgp_handle* h, const double* y, uint32_t flags, const
         c.s0 = rs0;
     }
     if (overlap) {
-        if (idev) {
+        if (hand) {
             c.head_in = hin;
             c.head_in_flag = sflag;
         }
@@ -2672,16 +2697,17 @@ static int smooth_lti_call(tgp_handle* h, const double* y, uint32_t flags, const
             c.head_out_flag = sflag + 3;
         }
     } else {
-        if (idev) {
-            HIPCHK(hipMemcpyAsync(hin, y, nhs * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-            if (post) HIPCHK(hipMemcpyAsync(hin + nhs, Rnew, (rshared ? 1 : nhs) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        if (hand) {
+            HIPCHK(hipMemcpyAsync(hin, h->mv.y, nhs * sizeof(double), hipMemcpyDeviceToHost, h->stream));      // (the staged copies: device whatever the call's arrays are)
+            if (post) HIPCHK(hipMemcpyAsync(hin + nhs, pR, (rshared ? 1 : nhs) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+            if (offs) HIPCHK(hipMemcpyAsync(hin + 10 * nhs, h->mv.h, nhs * sizeof(double), hipMemcpyDeviceToHost, h->stream));
             if (rnd) {
                 HIPCHK(hipMemcpyAsync(hin + 2 * nhs, rnd->eps_e, nhs * sizeof(double), hipMemcpyDeviceToHost, h->stream));
                 HIPCHK(hipMemcpyAsync(hin + 3 * nhs, rnd->eps_t, nhs * h->d * sizeof(double), hipMemcpyDeviceToHost, h->stream));
             }
             HIPCHK(hipStreamSynchronize(h->stream));
         }
-        tgp_modal::plan_smooth_head_forward(mh, sp, yhead, mu_end, &quad_head);
+        tgp_modal::plan_smooth_head_forward(mh, sp, yhead, mu_end, &quad_head, hhhead);
     }
     {
         LaunchScope ls(h, rnd ? "k_smooth_one<rand>" : (post ? "k_smooth_one<posterior>" : "k_smooth_one<logpdf>"));
@@ -2700,9 +2726,9 @@ static int smooth_lti_call(tgp_handle* h, const double* y, uint32_t flags, const
     auto await = [&](const long long* f) { return tgp_modal::await_host_flag(f, 2 * seq, h->stream); };
     bool handshake_ok = true;
     if (overlap) {
-        if (idev) handshake_ok = await(sflag);
+        if (hand) handshake_ok = await(sflag);
         if (handshake_ok) {
-            tgp_modal::plan_smooth_head_forward(mh, sp, yhead, mu_end, &quad_head);
+            tgp_modal::plan_smooth_head_forward(mh, sp, yhead, mu_end, &quad_head, hhhead);
             __atomic_store_n(sflag + 1, 2 * seq, __ATOMIC_RELEASE);
         }
     }
@@ -3025,6 +3051,11 @@ int tgp_posterior_marginals(tgp_handle* h, const double* y, const uint8_t* missi
             h->smoother_valid = false;
             return rc;
         }
+    }
+    if (lti_but_offset(h) && missing == nullptr && y != nullptr && !(flags & TGP_REUSE_REDUCE)) {      // a mean function on a regular grid: stationary gains
+        bool served = false;
+        TRY(smooth_lti_call(h, y, flags, Rnew, mean_out, var_out, lml_out, &served));
+        if (served) return TGP_OK;
     }
     h->sweep_last = false;
     if (sweep_eligible(h, flags)) {

@@ -2716,6 +2716,7 @@ struct SArgs {
     // reverse-time step x_(t-1) = G x_t + g_t + U' eps_t is the smoother's recursion with a noise input: xi_t = c r_t + G xi_(t+1) + U' eps_t,
     // y_t = y_obs_t - (R / S) r_t + h' xi_(t+1) + sqrt(Rnew_t) eta_t.  U: the upper Cholesky factor of the settled L + 1e-9 I (U[k][i], k <= i);
     // xi_T = U0' eps_0 (the draw of the final filtering state) enters step T - 1 as v0 = G xi_T and its output as s0 = h' xi_T.
+    const double* hhT;      // the emission offset per step (a mean function at the inputs, lti_sde.jl:118-131), or nullptr: hh above.  The gains do not see it.
     const double *eps_t, *eps_e;
     static constexpr int RD = D <= kSmoothRandMaxD ? D : 1;      // (the kernel-argument segment is full at d = 8: no room for what d > 4 never uses)
     double U[RD][RD], v0[RD], s0;
@@ -2756,6 +2757,9 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_smooth_one(const SArgs<D> by_
             for (long long t = lane; t < ka.nhs; t += 64) ka.head_in[2 * ka.nhs + t] = ka.eps_e[t];
             for (long long e = lane; e < ka.nhs * D; e += 64) ka.head_in[3 * ka.nhs + e] = ka.eps_t[e];
         }
+        if (ka.hhT != nullptr) {      // the head's emission offsets, behind everything else (offset 10 nhs)
+            for (long long t = lane; t < ka.nhs; t += 64) ka.head_in[10 * ka.nhs + t] = ka.hhT[t];
+        }
         __threadfence_system();
         if (lane == 0) __hip_atomic_store(ka.head_in_flag, 2 * ka.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
@@ -2764,7 +2768,10 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_smooth_one(const SArgs<D> by_
 #pragma unroll
     for (int j = 0; j < SUB; ++j) u[j] = 0.0;
     if (any_valid) {
-        if (t0 + SUB <= T && (reinterpret_cast<uintptr_t>(ka.y) & 15) == 0) {
+        if (ka.hhT != nullptr) {      // (kernel-uniform) an emission offset per step
+#pragma unroll
+            for (int j = 0; j < SUB; ++j) u[j] = t0 + j < T ? ka.y[t0 + j] - ka.hhT[t0 + j] : 0.0;
+        } else if (t0 + SUB <= T && (reinterpret_cast<uintptr_t>(ka.y) & 15) == 0) {
             const v2d* q = reinterpret_cast<const v2d*>(ka.y + t0);
 #pragma unroll
             for (int j = 0; j < SUB / 2; ++j) {
@@ -2933,7 +2940,8 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_smooth_one(const SArgs<D> by_
             rr = t < T ? rr : 0.0;      // (steps behind the series' end: no innovation)
             r[j] = rr;
             if (t >= c_lo && t < c_hi) acc = fma(rr, rr, acc);
-            o0[j] = fma(-ka.rS, rr, u[j] + ka.hh);      // h' m_t + hh = y_t - (R / S) r_t: what the smoother adds h' xi_(t+1) to
+            // h' m_t + hh_t = y_t - (R / S) r_t: what the smoother adds h' xi_(t+1) to  (a per-step offset is fetched again: the L2 has it)
+            o0[j] = fma(-ka.rS, rr, u[j] + ((ka.hhT != nullptr && t < T) ? ka.hhT[t] : ka.hh));
         }
         if (ka.mean != nullptr) {
             double ee[RAND ? SUB : 1][RAND ? D : 1];      // (RAND) the lane's transition draws: 8 D consecutive doubles of eps_t
@@ -3173,6 +3181,7 @@ int launch_smooth(hipStream_t st, const tgp_plan::SmoothPlan& sp, const double* 
     ka.var = c.var;
     ka.part = c.part;
     ka.xi_out = c.xi_out;
+    ka.hhT = c.hh_t;
     ka.mu0p = c.mu0;
     ka.mu0_flag = c.mu0_flag;
     ka.xi_flag = c.xi_flag;
@@ -3242,8 +3251,8 @@ void plan_smooth(const tgp_plan::ModelHost& m, long long T, tgp_plan::SmoothPlan
     //  the head like the first, from the head's exact end state (`from_head` in the kernels).
     if (sp.why == tgp_plan::kOk && smooth_span(sp, post) < 1024) sp.why = tgp_plan::kSlowMixing;
 }
-void plan_smooth_head_forward(const tgp_plan::ModelHost& m, const tgp_plan::SmoothPlan& sp, const double* y, double* mu_end, double* quad) {
-    tgp_plan::smooth_head_forward_any(m, sp, y, mu_end, quad);
+void plan_smooth_head_forward(const tgp_plan::ModelHost& m, const tgp_plan::SmoothPlan& sp, const double* y, double* mu_end, double* quad, const double* hh_t) {
+    tgp_plan::smooth_head_forward_any(m, sp, y, mu_end, quad, hh_t);
 }
 bool plan_smooth_head_tables(const tgp_plan::ModelHost& m, const tgp_plan::SmoothPlan& sp) { return tgp_plan::smooth_head_tables_any(m, sp); }
 void plan_smooth_head_backward(const tgp_plan::ModelHost& m, const tgp_plan::SmoothPlan& sp, const double* y, const double* lam, double* mean, double* vb) {

@@ -123,6 +123,9 @@ struct SmoothCall {
     // eps_t [T][d], eps_e [T] (device), `mean` receives the draw, `var` stays unused; U (d d, row-major, upper): chol(L_settled + 1e-9 I).U,
     // v0 = G xi_T, s0 = h' xi_T with xi_T = chol(P_final + 1e-12 I).U' eps_0 (tgp_plan::smooth_rand_factors).  With the head beside the kernel,
     // head_in also receives the head's eta [nhs] and eps [nhs][d] behind y | Rnew (offsets 2 nhs, 3 nhs).
+    // an emission offset per step (device, [T]; a mean function at the inputs: lti_sde.jl:118-131) instead of the plan's one value; the gains do not
+    // see it.  With the head beside the kernel head_in receives the head's offsets at offset 10 nhs (the host's head functions take them as `hh_t`).
+    const double* hh_t = nullptr;
     const double *eps_t = nullptr, *eps_e = nullptr;
     const double *U = nullptr, *v0 = nullptr;
     double s0 = 0.0;
@@ -134,7 +137,7 @@ bool overlap_allowed();
 // the host's wait for a flag in pinned memory the kernel on `stream` raises (value >= v): returns false once the stream has drained without it
 bool await_host_flag(const long long* flag, long long v, hipStream_t stream);
 void plan_smooth(const tgp_plan::ModelHost& m, long long T, tgp_plan::SmoothPlan& sp, double* tvb, bool post = true);      // post = false: logpdf only (tvb unused)
-void plan_smooth_head_forward(const tgp_plan::ModelHost& m, const tgp_plan::SmoothPlan& sp, const double* y, double* mu_end, double* quad);
+void plan_smooth_head_forward(const tgp_plan::ModelHost& m, const tgp_plan::SmoothPlan& sp, const double* y, double* mu_end, double* quad, const double* hh_t = nullptr);
 bool plan_smooth_head_tables(const tgp_plan::ModelHost& m, const tgp_plan::SmoothPlan& sp);
 void plan_smooth_head_backward(const tgp_plan::ModelHost& m, const tgp_plan::SmoothPlan& sp, const double* y, const double* lam, double* mean, double* vb);
 // steps a workgroup owns (its tiles minus the halo in front and -- with the backward half -- behind), and the workgroups of a T-step call

@@ -1725,7 +1725,7 @@ inline void build_smooth(const ModelHost& m, long long T, SmoothPlan& sp, double
 
 // The head forwards (before the launch): y [nhs] -> the innovations (kept for the way back), the predicted mean of step nhs, sum r^2 / S_t
 template <int D>
-inline void smooth_head_forward(const ModelHost& m, const SmoothPlan& sp, const double* y, double* mu_end, double* quad) {
+inline void smooth_head_forward(const ModelHost& m, const SmoothPlan& sp, const double* y, double* mu_end, double* quad, const double* hh_t = nullptr) {      // hh_t: the head's emission offsets when the model has one per step
     const FilterPlan& fp = sp.fp;
     const FilterWork<D>& fw = filter_work<D>();
     SmoothWork<D>& sw = smooth_work<D>();
@@ -1738,7 +1738,7 @@ inline void smooth_head_forward(const ModelHost& m, const SmoothPlan& sp, const 
     double q = 0.0;
     for (int t = 0; t < fp.nhs; ++t) {
         const int ti = t < fp.n0 ? t : fp.n0;
-        double r = y[t] - fp.hh;
+        double r = y[t] - (hh_t ? hh_t[t] : fp.hh);
         for (int k = 0; k < D; ++k) r -= fp.h[k] * mu[k];
         sw.r[t] = r;
         q += r * r * fw.iS[ti];
@@ -1929,8 +1929,8 @@ inline void build_smooth_any(const ModelHost& m, long long T, SmoothPlan& sp, do
     }
     sp.why = kEigFail;
 }
-inline void smooth_head_forward_any(const ModelHost& m, const SmoothPlan& sp, const double* y, double* mu_end, double* quad) {
-    TGP_PLAN_DISPATCH(m.d, smooth_head_forward<D>(m, sp, y, mu_end, quad))
+inline void smooth_head_forward_any(const ModelHost& m, const SmoothPlan& sp, const double* y, double* mu_end, double* quad, const double* hh_t = nullptr) {
+    TGP_PLAN_DISPATCH(m.d, smooth_head_forward<D>(m, sp, y, mu_end, quad, hh_t))
 }
 inline bool smooth_head_tables_any(const ModelHost& m, const SmoothPlan& sp) {
     TGP_PLAN_DISPATCH(m.d, smooth_head_tables<D>(m, sp))

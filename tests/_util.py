@@ -219,7 +219,7 @@ def smoothsim():
     return _SMOOTHSIM
 
 
-def smoothsim_run(model, y, Rnew, eps=None):
+def smoothsim_run(model, y, Rnew, eps=None, hh_t=None):
     """model: oracle dict with SHARED blocks and one noise variance (an LTI model).  The dense-powers one-launch smoother on the host
     (tests/hostsim/smoothsim.cpp).  Returns dict(rc, lml, why, n0, nhs, n1, halo, nwg, mean, var).
     eps = (eps_t (T, d), eps_e (T,), eps_0 (d,)): a DRAW from the posterior instead (returned as `mean`)."""
@@ -235,9 +235,10 @@ def smoothsim_run(model, y, Rnew, eps=None):
     mean, var, out = np.zeros(T), np.zeros(T), np.zeros(8)
     keep = [np.ascontiguousarray(e, dtype=np.float64) for e in eps] if eps is not None else []
     ee = [_p(k) for k in keep] if keep else [None, None, None]
+    hk = None if hh_t is None else np.ascontiguousarray(hh_t, dtype=np.float64)      # an emission offset per step (the model dict's h may then be per step too)
     rc = smoothsim().smoothsim_run(d, _p(A), _p(a), _p(Q), _p(H), ctypes.c_double(float(np.atleast_1d(model["h"])[0])),
                                    ctypes.c_double(float(np.atleast_1d(model["R"])[0])), _p(x0m), _p(x0P), _i64(T), _p(yv), _p(rn),
-                                   int(rn.shape[0] > 1), _p(mean), _p(var), _p(out), *ee)
+                                   int(rn.shape[0] > 1), _p(mean), _p(var), _p(out), *ee, _p(hk))
     return dict(rc=rc, lml=out[0], why=int(out[1]), n0=int(out[2]), nhs=int(out[3]), n1=int(out[4]), halo=int(out[5]), nwg=int(out[6]),
                 mean=mean, var=var)
 

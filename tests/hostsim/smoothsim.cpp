@@ -58,7 +58,7 @@ void matvec_acc2(const double (&M)[D][D], const double* x, double* y) {
 
 template <int D>
 int run_d(const ModelHost& m, long long T, const double* y, const double* Rnew, int rnew_per_step, double* mean, double* var, double* out,
-          const double* eps_t = nullptr, const double* eps_e = nullptr, const double* eps_0 = nullptr) {
+          const double* eps_t = nullptr, const double* eps_e = nullptr, const double* eps_0 = nullptr, const double* hh_t = nullptr) {      // hh_t: an emission offset per step
     const bool rnd = eps_t != nullptr;      // a draw from the posterior (k_smooth_one<..., RAND>): `mean` receives it
     static thread_local double tvb[kTailMax];
     SmoothPlan sp;
@@ -73,7 +73,7 @@ int run_d(const ModelHost& m, long long T, const double* y, const double* Rnew, 
     const long long nwg = (T - fp.nhs + C - 1) / C;
     out[6] = (double)nwg;
     double mu_end[D], quad = 0.0;
-    smooth_head_forward<D>(m, sp, y, mu_end, &quad);
+    smooth_head_forward<D>(m, sp, y, mu_end, &quad, hh_t);
     if (!smooth_head_tables<D>(m, sp)) { out[1] = kNotPD; return 0; }
     double rU[D * D], rv0[D], rs0 = 0.0;
     if (rnd && !smooth_rand_factors<D>(sp, eps_0, rU, rv0, &rs0)) { out[1] = kNotPD; return 0; }
@@ -98,7 +98,7 @@ int run_d(const ModelHost& m, long long T, const double* y, const double* Rnew, 
                 for (int i = 0; i < D; ++i) x[i] = 0.0;
                 for (int j = 0; j < SUB; ++j) {
                     const int e = (w * 64 + l) * SUB + j;
-                    u[e] = (valid[w] && t0 + j < T) ? y[t0 + j] - fp.hh : 0.0;
+                    u[e] = (valid[w] && t0 + j < T) ? y[t0 + j] - (hh_t ? hh_t[t0 + j] : fp.hh) : 0.0;
                     r[e] = 0.0;
                     if (!valid[w]) continue;
                     double rr = u[e];
@@ -247,7 +247,7 @@ int run_d(const ModelHost& m, long long T, const double* y, const double* Rnew, 
                     const long long t = t0 + j;
                     if (t < c_lo || t >= c_hi) continue;
                     const int e = (w * 64 + l) * SUB + j;
-                    double o = u[e] + fp.hh - sp.rS * r[e] + o0[e];
+                    double o = u[e] + (hh_t ? hh_t[t] : fp.hh) - sp.rS * r[e] + o0[e];
                     for (int k = 0; k < D; ++k) o = std::fma(sp.WG[j][k], pin[k], o);
                     if (rnd) {
                         if (t == T - 1) o += rs0;
@@ -282,20 +282,20 @@ int run_d(const ModelHost& m, long long T, const double* y, const double* Rnew, 
 
 extern "C" int smoothsim_run(int d, const double* A, const double* a, const double* Q, const double* H, double hh, double R, const double* x0m,
                              const double* x0P, long long T, const double* y, const double* Rnew, int rnew_per_step, double* mean, double* var,
-                             double* out /*[8]: lml, why, n0, nhs, n1, halo, workgroups*/, const double* eps_t, const double* eps_e, const double* eps_0) {
+                             double* out /*[8]: lml, why, n0, nhs, n1, halo, workgroups*/, const double* eps_t, const double* eps_e, const double* eps_0, const double* hh_t) {
     ModelHost m;
     m.d = d;
     m.A = A; m.a = a; m.Q = Q; m.H = H; m.hh = &hh; m.R = &R; m.x0m = x0m; m.x0P = x0P;
     for (int i = 0; i < 8; ++i) out[i] = 0.0;
     switch (d) {
-        case 1: return run_d<1>(m, T, y, Rnew, rnew_per_step, mean, var, out, eps_t, eps_e, eps_0);
-        case 2: return run_d<2>(m, T, y, Rnew, rnew_per_step, mean, var, out, eps_t, eps_e, eps_0);
-        case 3: return run_d<3>(m, T, y, Rnew, rnew_per_step, mean, var, out, eps_t, eps_e, eps_0);
-        case 4: return run_d<4>(m, T, y, Rnew, rnew_per_step, mean, var, out, eps_t, eps_e, eps_0);
-        case 5: return run_d<5>(m, T, y, Rnew, rnew_per_step, mean, var, out, eps_t, eps_e, eps_0);
-        case 6: return run_d<6>(m, T, y, Rnew, rnew_per_step, mean, var, out, eps_t, eps_e, eps_0);
-        case 7: return run_d<7>(m, T, y, Rnew, rnew_per_step, mean, var, out, eps_t, eps_e, eps_0);
-        case 8: return run_d<8>(m, T, y, Rnew, rnew_per_step, mean, var, out, eps_t, eps_e, eps_0);
+        case 1: return run_d<1>(m, T, y, Rnew, rnew_per_step, mean, var, out, eps_t, eps_e, eps_0, hh_t);
+        case 2: return run_d<2>(m, T, y, Rnew, rnew_per_step, mean, var, out, eps_t, eps_e, eps_0, hh_t);
+        case 3: return run_d<3>(m, T, y, Rnew, rnew_per_step, mean, var, out, eps_t, eps_e, eps_0, hh_t);
+        case 4: return run_d<4>(m, T, y, Rnew, rnew_per_step, mean, var, out, eps_t, eps_e, eps_0, hh_t);
+        case 5: return run_d<5>(m, T, y, Rnew, rnew_per_step, mean, var, out, eps_t, eps_e, eps_0, hh_t);
+        case 6: return run_d<6>(m, T, y, Rnew, rnew_per_step, mean, var, out, eps_t, eps_e, eps_0, hh_t);
+        case 7: return run_d<7>(m, T, y, Rnew, rnew_per_step, mean, var, out, eps_t, eps_e, eps_0, hh_t);
+        case 8: return run_d<8>(m, T, y, Rnew, rnew_per_step, mean, var, out, eps_t, eps_e, eps_0, hh_t);
     }
     return 1;
 }

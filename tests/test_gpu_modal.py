@@ -563,3 +563,29 @@ def test_a_halo_longer_than_a_span(tgp):
         m_ref, v_ref = sk.posterior_marginals(model, y, Rn)
         assert abs(lp - lp_ref) <= 1e-10 * abs(lp_ref)
         assert np.max(np.abs(mean - m_ref)) <= 1e-8 and np.max(np.abs(var - v_ref)) <= 1e-8
+
+
+@pytest.mark.parametrize("d", [1, 3, 4, 6, 8])
+def test_a_mean_function_on_a_regular_grid_keeps_the_stationary_gains(tgp, d):
+    """every block shared but the emission offset h_t = m(x_t) (lti_sde.jl:118-131): the gains never see the offset, so the model stays on the
+    one-launch structure -- k_smooth_one subtracts the offset per step -- instead of the sweep engine (d <= 4) or the general engine"""
+    import torch
+    for T in (6000, 20003):
+        model = oc.build_lgssm(KERNELS[d], ("regular", 0.0, 0.1, T), 0.1, ("custom", lambda t: np.sin(0.7 * t) + 0.05 * t))
+        assert np.asarray(model["h"]).shape[0] == T
+        y = draw(model, 30 + d)
+        Rn = np.random.default_rng(d).random(T) * 0.1
+        lp_ref = sk.logpdf(model, y)
+        m_ref, v_ref = sk.posterior_marginals(model, y, Rn)
+        dm = device_model(tgp, model)
+        lp, names = kernels_of(tgp, dm, lambda: tgp.logpdf(dm, y))
+        assert names == {"k_smooth_one<logpdf>"}, names
+        assert abs(lp - lp_ref) <= 1e-10 * abs(lp_ref)
+        (mean, var), names = kernels_of(tgp, dm, lambda: tgp.posterior_marginals(dm, y, Rn))
+        assert names == {"k_smooth_one<posterior>"}, names
+        sc = max(1.0, float(np.max(np.abs(m_ref))))
+        assert np.max(np.abs(mean - m_ref)) <= 1e-8 * sc and np.max(np.abs(var - v_ref)) <= 1e-8
+        yd, rd = torch.from_numpy(y).cuda(), torch.from_numpy(Rn).cuda()
+        lp2, mean2, var2 = tgp.logpdf_and_posterior_marginals(dm, yd, rd)
+        assert abs(lp2 - lp_ref) <= 1e-10 * abs(lp_ref)
+        assert np.max(np.abs(mean2.cpu().numpy() - m_ref)) <= 1e-8 * sc and np.max(np.abs(var2.cpu().numpy() - v_ref)) <= 1e-8

@@ -96,3 +96,18 @@ def test_a_halo_longer_than_a_span():
     r = U.smoothsim_run(model, y, Rn)
     assert r["halo"] > 1365 and r["nwg"] > 3, r
     _check(r, lp, pm, pv)
+
+
+@pytest.mark.parametrize("i", [0, 3, 4, 6])
+def test_an_emission_offset_per_step(i):
+    """a GP with a mean function on a regular grid (lti_sde.jl:118-131): every block shared but the emission offset h_t = m(x_t).  The gains never see
+    the offset: the stationary structure holds, the kernel subtracts the offset per step (SmoothCall::hh_t)"""
+    k, dt, s2 = CASES[i]
+    T = 6000
+    model, y, _ = U.gp_case(k, ("regular", 0.0, dt, T), s2, seed=40 + i, mean=("custom", lambda t: np.sin(0.7 * t) + 0.1 * t))
+    hh = np.asarray(model["h"], dtype=np.float64)
+    assert hh.shape[0] == T
+    Rn = np.random.default_rng(i).random(T) * 0.1
+    lp, pm, pv = _reference(model, y, Rn)
+    r = U.smoothsim_run(model, y, Rn, hh_t=hh)
+    _check(r, lp, pm, pv)
