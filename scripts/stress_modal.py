@@ -43,6 +43,9 @@ for case in range(n_cases):
     if rng.random() < 0.3:          # offsets
         model["a"] = np.broadcast_to(0.05 * rng.standard_normal(d), np.asarray(model["a"]).shape).copy()
         model["h"] = np.broadcast_to(np.array(rng.standard_normal()), np.asarray(model["h"]).shape).copy()
+    per_step_h = rng.random() < 0.2
+    if per_step_h:                  # an emission offset PER STEP (a mean function at the inputs): the gains do not see it -- the one-launch structure holds
+        model["h"] = np.sin(0.37 * np.arange(T)) * float(rng.standard_normal()) + 0.01 * np.arange(T) * float(rng.standard_normal())
     eps = (rng.standard_normal((T, d)), rng.standard_normal(T), rng.standard_normal(d))
     Rn = np.exp(rng.normal(-2, 1, size=T)) if rng.random() < 0.3 else np.array([float(np.exp(rng.normal(-2, 1)))])
     mode = int(rng.integers(3))          # 0 host arrays, 1 device arrays, 2 device arrays 8 bytes past a 16-byte boundary
@@ -117,7 +120,10 @@ for case in range(n_cases):
             np.asarray(model["h"]).reshape(-1)[:1].copy(), np.asarray(model["R"]).reshape(-1)[:1].copy(), np.asarray(model["x0m"], dtype=np.float64).copy(),
             np.ascontiguousarray(np.asarray(model["x0P"]).reshape(d, d).T).reshape(-1)]
     tgp._lib.load().tgp_steady_plan(d, *[k.ctypes.data for k in keep], ctypes.c_int64(T), ii.ctypes.data, dd.ctypes.data, None, None)
-    if (ii[0] == 0) != (served.get(3) == "one-launch"):
+    if per_step_h:
+        if served.get(3) != "dense one-launch" and ii[0] == 0 and T >= 1000:
+            msgs.append(f"per-step emission offset served by {served.get(3)}")
+    elif (ii[0] == 0) != (served.get(3) == "one-launch"):
         msgs.append(f"plan verdict {WHY[ii[0]]} but served by {served.get(3)}")
     bad += bool(msgs)
     print(f"[{case:3d}] {'FAIL' if msgs else 'ok'} d={d} T={T} dt={dt:.4f} noise={noise:.2e} Rn={'T' if Rn.shape[0] > 1 else '1'} mode={mode} terms={[(t[0][6:], round(t[1], 2), round(t[2], 2)) for t in terms]} "
