@@ -489,6 +489,28 @@ def _noise(s, n):
     return s if s.shape[0] == n else np.full(n, s[0])
 
 
+def _pair_statistic(y, R, ys, Rs):
+    """Two observations y ~ N(f, R), y* ~ N(f, R*) of the same latent value with independent noise:
+        N(y; f, R) N(y*; f, R*) = N(ybar; f, Rbar) N(y - y*; 0, R + R*),   Rbar = R R* / (R + R*),  ybar = Rbar (y / R + y* / R*)
+    -> (ybar, Rbar, sum_t log N(y_t - y*_t; 0, R_t + R*_t)).  NaN (missing, missings.jl:25-33) on one side leaves the other observation as
+    it is; on both sides the joint step is missing.  R, R*: one variance each (-> one Rbar unless something is missing) or one per step."""
+    y, ys = np.asarray(y, dtype=np.float64), np.asarray(ys, dtype=np.float64)
+    R, Rs = np.atleast_1d(np.asarray(R, dtype=np.float64)), np.atleast_1d(np.asarray(Rs, dtype=np.float64))
+    my, ms = np.isnan(y), np.isnan(ys)
+    tot = R + Rs
+    diff = y - ys
+    both = ~(my | ms)
+    const = -0.5 * float(np.sum((np.log(2 * np.pi * tot) + diff * diff / tot)[both] if tot.shape[0] > 1
+                                else np.log(2 * np.pi * tot[0]) + diff[both] ** 2 / tot[0]))
+    Rbar = R * Rs / tot
+    ybar = (Rs * y + R * ys) / tot                   # = Rbar (y / R + y* / R*) without the divisions by a tiny jitter R*
+    if my.any() or ms.any():
+        n = y.shape[0]
+        Rbar = np.where(ms, np.broadcast_to(R, (n,)), np.where(my, np.broadcast_to(Rs, (n,)), np.broadcast_to(Rbar, (n,))))
+        ybar = np.where(ms, y, np.where(my, ys, ybar))
+    return ybar, Rbar, const
+
+
 class FinitePosteriorLTISDE:
     LARGE_VAR = 1e15                                 # missings.jl:43
 
@@ -541,6 +563,18 @@ class FinitePosteriorLTISDE:
         return m[pr], v[pr]
 
     def _rand(self, rng):
+        d = self.f.data
+        if _same_inputs(self.x, d["x"]) and not np.isnan(d["y"]).any():
+            # prediction inputs = training inputs: each joined pair of steps shares ONE latent state (dt = 0: A = I, Q = 0), so the draw at
+            # the prediction step is h'x_t + sqrt(s_t) eps of the posterior's reverse-time chain over the T training steps -- the posterior
+            # with its observation noise replaced, which is one launch on the prior's stationary structure (tgp_posterior_rand) instead
+            # of 2T steps of the general engine.  Same distribution; the draws of one rng are consumed in a different order
+            model = self._posterior_model(d["x"], d["sigma2"], d["y"])
+            S_new = _noise(self.sigma2, len(self.x)) if len(self.sigma2) > 1 else self.sigma2
+            return L.rand(rng, L.replace_observation_noise_cov(L.posterior(model, d["y"]), S_new))
+        return self._rand_merged(rng)
+
+    def _rand_merged(self, rng):
         npr = len(self.x)
         x, S, y, _, pr = self._merge(np.full(npr, self.LARGE_VAR))
         s_full = np.zeros(len(x))
@@ -549,6 +583,21 @@ class FinitePosteriorLTISDE:
         return L.rand(rng, post)[pr]
 
     def _logpdf(self, y_pr):
+        d = self.f.data
+        y_pr = np.asarray(y_pr, dtype=np.float64)
+        if y_pr.shape != (len(self.x),):
+            raise ValueError("Dimension mismatch: one observation per prediction input")
+        if _same_inputs(self.x, d["x"]):
+            # prediction inputs = training inputs: log p(y* | y) = log p(y, y*) - log p(y), and two noisy observations of the same latent value
+            # are one observation of it (`_pair_statistic`) -- two prior logpdf calls over T steps on whatever engine the prior has (one launch
+            # each for an LTI model) instead of the evaluated posterior over 2T joined steps
+            ybar, Rbar, const = _pair_statistic(d["y"], _noise(d["sigma2"], len(y_pr)) if len(d["sigma2"]) > 1 else d["sigma2"],
+                                                y_pr, _noise(self.sigma2, len(y_pr)) if len(self.sigma2) > 1 else self.sigma2)
+            joint = L.logpdf(self._posterior_model(d["x"], Rbar, ybar), ybar)
+            return joint + const - L.logpdf(self._posterior_model(d["x"], d["sigma2"], d["y"]), d["y"])
+        return self._logpdf_merged(y_pr)
+
+    def _logpdf_merged(self, y_pr):
         npr = len(self.x)
         s_pr = _noise(self.sigma2, npr)
         x, S, y, tr, pr = self._merge(s_pr)

@@ -65,6 +65,18 @@ def test_posterior_api_same_and_new_inputs(P, kname):
     mo, vo = oc.posterior_marginals(spec, x_tr, s_tr, y_tr, None, 0.3)
     np.testing.assert_allclose(m, mo, rtol=1e-8, atol=1e-8)      # vs the oracle's restatement of the same path
     np.testing.assert_allclose(sd ** 2, vo, rtol=1e-8, atol=1e-9)
+    # logpdf and rand at the same inputs (:48-78): the mirror's pair-statistic / one-launch routes against the joined 2T-step route and the dense GP
+    y_same, s_same = rng.standard_normal(30), rng.random(30) * 0.1 + 0.02
+    for s_new in (s_same, 0.15):
+        lp = P.logpdf(fpost(x_tr, s_new), y_same)
+        lp_d = dg.posterior_logpdf(spec, x_tr, s_tr, y_tr, x_tr, s_new, y_same)
+        assert abs(lp - lp_d) <= 1e-6 * abs(lp_d)
+        assert abs(lp - fpost(x_tr, s_new)._logpdf_merged(y_same)) <= 1e-8 * abs(lp_d)
+    y_gap = y_same.copy()
+    y_gap[[0, 7]] = np.nan
+    assert abs(P.logpdf(fpost(x_tr, 0.15), y_gap) - fpost(x_tr, 0.15)._logpdf_merged(y_gap)) <= 1e-8 * abs(lp_d)
+    ys = P.rand(np.random.default_rng(5), fpost(x_tr, 0.15))
+    assert ys.shape == (30,) and np.all(np.isfinite(ys))
     # new inputs (posterior_lti_sde.jl:19-26): merge + sort + missing
     x_pr = np.sort(rng.random(9)) * 6 - 0.5
     m, sd = P.marginals(fpost(x_pr, 0.2))
@@ -129,3 +141,46 @@ def test_device_side_components_for_irregular_spacing(P, kname):
     # Q_k = P - A P A' is a cancellation: at tiny dt two correctly-rounded exponentials give Q's that differ by ~1e-16 |P|,
     # which chol(Q + 1e-9 I) turns into ~1e-9 in a sample
     np.testing.assert_allclose(tgp.rand(eps, m_dev), tgp.rand(eps, m_host), rtol=1e-7, atol=1e-7)
+
+
+@pytest.mark.parametrize("kname,d", [("base-Matern52", 3), ("sum-12-32", 3)])
+def test_posterior_consumers_at_the_training_inputs_on_a_regular_grid(P, kname, d, monkeypatch):
+    """logpdf / rand of posterior(fx, y)(fx.x, s) (posterior_lti_sde.jl:48-78) on a regular grid: both run on the prior's stationary structure
+    (logpdf: two stationary-gain calls through the pair statistic; rand: tgp_posterior_rand) and equal the joined 2T-step route / have its moments."""
+    import ctypes
+    rng = np.random.default_rng(21)
+    T = 20_000
+    spec = KERNELS[kname]
+    x = P.RegularSpacing(0.0, 0.05, T)
+    f = P.to_sde(P.GP(P.to_kernel(spec)), P.HIPStorage())
+    fx = f(x, 0.4)
+    y = P.rand(rng, fx)
+    fpost = P.posterior(fx, y)
+    ys = y + 0.3 * rng.standard_normal(T)
+    built, real = [], P.build_lgssm
+    monkeypatch.setattr(P, "build_lgssm", lambda *a, **k: built.append(real(*a, **k)) or built[-1])
+
+    def stationary_steps(dm):
+        hd = dm.handle()
+        a, b = ctypes.c_int64(), ctypes.c_int64()
+        hd.check(hd.lib.tgp_steady_steps(hd.h, ctypes.byref(a), ctypes.byref(b)))
+        return a.value
+
+    lp = P.logpdf(fpost(x, 0.25), ys)
+    assert len(built) == 2 and all(m.T == T and stationary_steps(m) > T - 700 for m in built)     # T steps each, none on the general engine
+    del built[:]
+    lp_m = fpost(x, 0.25)._logpdf_merged(ys)
+    # (the joined route filters T steps of dt = 0 with singular predicted covariances and carries the reference's own jitter there: it sits 1-2e-9
+    #  relative from the dense GP, the pair-statistic route 1e-15 -- measured at T = 2000 / 6000 -- so the two agree to the joined route's error)
+    assert abs(lp - lp_m) <= 1e-7 * abs(lp_m)
+    xs, k = x.collect()[:1500], slice(0, 1500)
+    fp_s = P.posterior(f(xs, 0.4), y[k])(xs, 0.25)
+    lp_d = dg.posterior_logpdf(spec, xs, 0.4, y[k], xs, 0.25, ys[k])
+    assert abs(P.logpdf(fp_s, ys[k]) - lp_d) <= 1e-12 * abs(lp_d)
+    # a draw: its residual against the posterior mean has the posterior's variance (a z-score over T steps), and the emission noise is in it
+    m, sd = P.marginals(fpost(x, 0.25))
+    del built[:]
+    draw = P.rand(np.random.default_rng(1), fpost(x, 0.25))
+    assert len(built) == 1 and built[0].T == T and stationary_steps(built[0]) > T - 700
+    z = (draw - m) / sd
+    assert abs(np.mean(z * z) - 1.0) < 0.05 and abs(np.mean(z)) < 0.1

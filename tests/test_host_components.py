@@ -72,3 +72,26 @@ def test_posterior_merge_bookkeeping():
     np.testing.assert_array_equal(x[pr], x_pr)
     np.testing.assert_array_equal(y[tr], y_tr)
     assert np.all(np.isnan(y[pr])) and np.all(S[pr] == 1e15) and np.all(S[tr] == 0.1)
+
+
+@pytest.mark.parametrize("noise", ["scalars", "per-step", "missing"])
+def test_pair_statistic_gives_the_posterior_logpdf_at_the_training_inputs(noise):
+    """`_pair_statistic` (the same-inputs route of posterior_lti_sde.jl:62-78 in the mirror): with two observations per input,
+    log p(y* | y) = log N(ybar; m, K + Rbar) + const - log N(y; m, K + R) -- held against the dense GP's posterior logpdf."""
+    rng = np.random.default_rng(3)
+    n = 25
+    spec = KERNELS["sum-12-32"]
+    x = np.sort(rng.random(n)) * 4
+    y, ys = rng.standard_normal(n), rng.standard_normal(n)
+    R, Rs = (np.array([0.3]), np.array([0.07])) if noise == "scalars" else (rng.random(n) * 0.3 + 0.05, rng.random(n) * 0.2 + 0.01)
+    ym, ysm = y.copy(), ys.copy()
+    if noise == "missing":
+        ym[[2, 9, 11]] = np.nan
+        ysm[[4, 9, 20]] = np.nan
+    ybar, Rbar, const = P._pair_statistic(ym, R, ysm, Rs)
+    assert (Rbar.shape == (1,)) == (noise == "scalars")
+    kt, kp, kj = ~np.isnan(ym), ~np.isnan(ysm), ~np.isnan(ybar)
+    Rf, Rsf, Rbf = np.broadcast_to(R, (n,)), np.broadcast_to(Rs, (n,)), np.broadcast_to(Rbar, (n,))
+    got = dg.logpdf(spec, x[kj], Rbf[kj], ybar[kj]) + const - dg.logpdf(spec, x[kt], Rf[kt], y[kt])
+    want = dg.posterior_logpdf(spec, x[kt], Rf[kt], y[kt], x[kp], Rsf[kp], ys[kp])
+    assert abs(got - want) <= 1e-9 * abs(want)
