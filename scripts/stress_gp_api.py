@@ -109,8 +109,21 @@ for case in range(int(os.environ.get("START", "0")), min(n_cases, int(os.environ
             y_pr = rng.standard_normal(M)
             lpp = P.logpdf(fpost(x_pr, s_pr), y_pr)
             lpp_d = dg.posterior_logpdf(spec, xs[keep], s2v[keep], y[keep], x_pr, s_pr, y_pr, mean_o)
-            if not abs(lpp - lpp_d) <= 1e-5 * max(1.0, abs(lpp_d)):
+            if not abs(lpp - lpp_d) <= 1e-7 * max(1.0, abs(lpp_d)):
                 msgs.append(f"posterior logpdf {lpp} vs dense GP {lpp_d}")
+            lpp_m = fpost(x_pr, s_pr)._logpdf_merged(y_pr)        # the reference's chain spelled out: the evaluated posterior over the joined inputs
+            if not abs(lpp - lpp_m) <= 1e-5 * max(1.0, abs(lpp_d)):
+                msgs.append(f"posterior logpdf {lpp} vs the evaluated-posterior route {lpp_m}")
+            y_same = rng.standard_normal(int(keep.sum()))
+            if rng.random() < 0.3:
+                y_same[rng.random(y_same.shape[0]) < 0.2] = np.nan
+            s_same = 0.1 if rng.random() < 0.5 else rng.random(y_same.shape[0]) * 0.2 + 0.02
+            ks = ~np.isnan(y_same)
+            if ks.any():
+                lps = P.logpdf(fpost(xs[keep], s_same), y_same)       # at the training inputs: the pair statistic
+                lps_d = dg.posterior_logpdf(spec, xs[keep], s2v[keep], y[keep], xs[keep][ks], np.broadcast_to(s_same, ks.shape)[ks], y_same[ks], mean_o)
+                if not abs(lps - lps_d) <= 1e-7 * max(1.0, abs(lps_d)):
+                    msgs.append(f"posterior logpdf at the training inputs {lps} vs dense GP {lps_d}")
     except Exception as ex:      # noqa: BLE001
         import traceback
         msgs.append(f"{type(ex).__name__}: {ex} @ {traceback.extract_tb(ex.__traceback__)[-1].lineno}")

@@ -595,7 +595,18 @@ class FinitePosteriorLTISDE:
                                                 y_pr, _noise(self.sigma2, len(y_pr)) if len(self.sigma2) > 1 else self.sigma2)
             joint = L.logpdf(self._posterior_model(d["x"], Rbar, ybar), ybar)
             return joint + const - L.logpdf(self._posterior_model(d["x"], d["sigma2"], d["y"]), d["y"])
-        return self._logpdf_merged(y_pr)
+        return self._logpdf_joint(y_pr)
+
+    def _logpdf_joint(self, y_pr):
+        """log p(y* | y) = log p(y, y*) - log p(y): the PRIOR's logpdf over the joined inputs with both data sets observed, minus the prior's
+        logpdf of the training data -- no posterior evaluated, no reverse-time model of T x (2 d^2 + d) doubles filtered.  The joined series is
+        merge_datasets' (posterior_lti_sde.jl:97-123) with the prediction observations in place of `missing`."""
+        d = self.f.data
+        npr = len(self.x)
+        x, S, y, tr, pr = self._merge(_noise(self.sigma2, npr))
+        y[pr] = y_pr
+        joint = L.logpdf(self._posterior_model(x, S, y), y)
+        return joint - L.logpdf(self._posterior_model(d["x"], d["sigma2"], d["y"]), d["y"])
 
     def _logpdf_merged(self, y_pr):
         npr = len(self.x)
