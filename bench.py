@@ -317,6 +317,14 @@ def lti_interface_leg(tgp, torch, model, y, T, d, local, steps):
         t, k = timed(lambda: tgp.rand((eps_t, eps_e, x0), tgp.posterior(model, y)), steps)
         out["posterior_rand"] = dict(ms=t * 1e3, steps_per_s=T / t, bytes_per_step=8 * (d + 3), kernels_ms=k)
     del eps_t, eps_e
+    # logpdf of the posterior at the training inputs (posterior_lti_sde.jl:62-78's last line) without a posterior: tgp_pair_statistic + two
+    # logpdf calls of the prior, the second on a model bound inside the call
+    y_new = y + 0.3 * torch.randn((T,), dtype=torch.float64, device=f"cuda:{local}", generator=gen)
+    R_new = np.array([0.05])
+    t, k = timed(lambda: tgp.logpdf(tgp.replace_observation_noise_cov(tgp.posterior(model, y), R_new), y_new), steps)
+    out["posterior_logpdf"] = dict(ms=t * 1e3, steps_per_s=T / t, bytes_per_step=40, kernels_ms=k,
+                                   note="kernels_ms lists the prior handle's kernel only; the pair pass and the joint model's logpdf run beside it")
+    del y_new
     t, k = timed(lambda: tgp._filter(model, y), steps)
     out["filter"] = dict(ms=t * 1e3, steps_per_s=T / t, bytes_per_step=8 * (1 + d + d * d), kernels_ms=k)
     t, k = timed(lambda: tgp.posterior(model, y).materialise(), steps)

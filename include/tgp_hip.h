@@ -331,6 +331,25 @@ int tgp_marginals(tgp_handle* h, uint32_t flags, double* mean_out, double* var_o
 int tgp_posterior_rand(tgp_handle* h, const double* y, const double* Rnew, const double* eps_t, const double* eps_e,
                        const double* eps_0, uint32_t flags, double* y_out);
 
+/* ---- logpdf(replace_observation_noise_cov(posterior(model, y), R_new), y_new) (posterior_lti_sde.jl:62-78 ->
+ *      lgssm.jl:147-151 on the reverse-time model of lgssm.jl:193-221) without a posterior: two observations of
+ *      one latent value with independent noise are one observation of it,
+ *          N(y; f, R) N(y_new; f, R_new) = N(ybar; f, Rbar) N(y - y_new; 0, R + R_new),
+ *          Rbar = R R_new / (R + R_new),  ybar = (R_new y + R y_new) / (R + R_new),
+ *      so the posterior's logpdf of a Forward model with scalar observations is
+ *          tgp_logpdf(model with Rbar, ybar) + pair - tgp_logpdf(model, y)
+ *      -- two calls on whatever engine the prior has. This entry point is the one pass over the two
+ *      series that forms ybar, Rbar and pair = sum_t log N(y_t - y_new_t; 0, R_t + R_new_t) over the steps observed on
+ *      both sides. ALL series pointers are DEVICE pointers on h's device (n doubles / n bytes): y, y_new, the masks
+ *      (optional; 1 = missing), ybar, Rbar, missing_bar. R, R_new: nR / nR_new = 1 (one variance, host or device
+ *      pointer) or n (per step, device). A step missing on one side keeps the other side's observation and variance;
+ *      on both sides it is missing in the result (missing_bar, needed only with two masks). Rbar may be NULL when both
+ *      variances are single numbers and nothing is missing (Rbar = R R_new / (R + R_new) for the caller to form).
+ *      pair_out: host. h needs no model; its stream orders the pass. */
+int tgp_pair_statistic(tgp_handle* h, int64_t n, const double* y, const uint8_t* missing, const double* R, int64_t nR,
+                       const double* y_new, const uint8_t* missing_new, const double* R_new, int64_t nR_new, double* ybar,
+                       double* Rbar, uint8_t* missing_bar, double* pair_out);
+
 /* ---- rand(rng, model) with the randomness supplied: lgssm.jl:65-91, lgc.jl:84-87,241-243,
  *      gaussian.jl:35-43. eps_t [T][d], eps_e [T], eps_0 [d] (eps_0 always host). y_out [T].
  *      A Forward LTI model (every block shared) with scalar observations and d <= 8 runs as ONE kernel over the draws

@@ -215,7 +215,33 @@ function AbstractGPs.rand(rng::AbstractRNG, p::DevicePosterior)
     end
     return rand(rng, materialise(p))
 end
-AbstractGPs.logpdf(p::DevicePosterior, y::AbstractVector) = logpdf(materialise(p), y)
+# logpdf of a posterior that has not been evaluated (posterior_lti_sde.jl:62-78's last line): log p(y* | y) = log p(y, y*) - log p(y), and two
+# observations of one latent value with independent noise are one observation of it (DESIGN 3.18) -- two tgp_logpdf calls of the PRIOR, no
+# reverse-time model of T x (2 d^2 + d) doubles evaluated or filtered.  (`lgssm.py::_posterior_logpdf_pair` is this function.)
+function AbstractGPs.logpdf(p::DevicePosterior, y::AbstractVector)
+    m = p.prior
+    (p.model === nothing && m.p == 1 && length(y) == m.T) || return logpdf(materialise(p), y)
+    R = _prior_noise(m)
+    Rs = p.Σs_new === nothing ? R : p.Σs_new
+    ȳ = Vector{Union{Missing,Float64}}(missing, m.T)
+    R̄ = Vector{Float64}(undef, m.T)
+    pair = 0.0
+    for t in 1:m.T
+        a, b, r, rs = p.y[t], y[t], Float64(R[t]), Float64(Rs[t])
+        if !ismissing(a) && !ismissing(b)
+            pair -= (log(2π * (r + rs)) + (a - b)^2 / (r + rs)) / 2
+            ȳ[t], R̄[t] = (rs * a + r * b) / (r + rs), r * rs / (r + rs)
+        elseif !ismissing(a)
+            ȳ[t], R̄[t] = a, r
+        else
+            R̄[t] = rs                    # (missing on both sides stays missing)
+            ismissing(b) || (ȳ[t] = b)
+        end
+    end
+    Σ̄ = all(==(R̄[1]), R̄) ? Fill(R̄[1], m.T) : R̄     # one variance keeps the model on its one-launch path
+    ȳv = any(ismissing, ȳ) ? ȳ : Float64.(ȳ)
+    return logpdf(replace_observation_noise_cov(m, Σ̄), ȳv) + pair - logpdf(m, p.y)
+end
 TemporalGPs._filter(p::DevicePosterior, y::AbstractVector) = _filter(materialise(p), y)
 
 """Evaluate the reverse-time model (lgssm.jl:193-238) once, on the prior's device."""

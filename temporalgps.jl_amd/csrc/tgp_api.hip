@@ -2809,6 +2809,95 @@ int tgp_posterior_rand(tgp_handle* h, const double* y, const double* Rnew, const
     return TGP_OK;
 }
 
+// Two observations per step of ONE latent value with independent noise are one observation of it:
+//     N(y; f, R) N(y*; f, R*) = N(ybar; f, Rbar) N(y - y*; 0, R + R*),   Rbar = R R* / (R + R*),   ybar = (R* y + R y*) / (R + R*)
+// -- what turns logpdf(replace_observation_noise_cov(posterior(model, y), R*), y*) (posterior_lti_sde.jl:62-78 -> lgssm.jl:147-151 on the
+// reverse-time model of lgssm.jl:193-221) into two logpdf calls of the PRIOR: logpdf(model(Rbar), ybar) + pair - logpdf(model(R), y), DESIGN 3.18.
+// One pass over the two series: 16 bytes read and 8 written per step (+ 8 per per-step variance read or written, + the masks).
+namespace {
+struct PairArgs {
+    const double *y, *R, *ys, *Rs;
+    const uint8_t *m, *ms;
+    double *ybar, *Rbar, *part;
+    uint8_t* mbar;
+    long long n;
+    double R0, Rs0;
+};
+static __global__ __launch_bounds__(256) void k_pair_statistic(const PairArgs a) {
+    const long long stride = (long long)gridDim.x * 256;
+    const double tot0 = a.R0 + a.Rs0, lg0 = log(6.283185307179586 * tot0);
+    double acc = 0.0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.n; i += stride) {
+        const double y = a.y[i], ys = a.ys[i];
+        const double R = a.R ? a.R[i] : a.R0, Rs = a.Rs ? a.Rs[i] : a.Rs0;
+        const bool my = a.m && a.m[i] != 0, mn = a.ms && a.ms[i] != 0;
+        double yb, Rb;
+        if (!my && !mn) {
+            const double tot = R + Rs, df = y - ys;
+            acc -= 0.5 * (((a.R || a.Rs) ? log(6.283185307179586 * tot) : lg0) + df * df / tot);
+            yb = (Rs * y + R * ys) / tot;       // (no division by a jitter-sized R*)
+            Rb = R * Rs / tot;
+        } else if (!my) {
+            yb = y, Rb = R;
+        } else if (!mn) {
+            yb = ys, Rb = Rs;
+        } else {
+            yb = 0.0, Rb = R;                   // missing on both sides: the joint step is missing
+        }
+        a.ybar[i] = yb;
+        if (a.Rbar) a.Rbar[i] = Rb;
+        if (a.mbar) a.mbar[i] = (my && mn) ? 1 : 0;
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    __shared__ double sw[4];
+    if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) a.part[blockIdx.x] = (sw[0] + sw[1]) + (sw[2] + sw[3]);
+}
+}  // namespace
+
+int tgp_pair_statistic(tgp_handle* h, int64_t n, const double* y, const uint8_t* missing, const double* R, int64_t nR, const double* y_new,
+                       const uint8_t* missing_new, const double* R_new, int64_t nR_new, double* ybar, double* Rbar, uint8_t* missing_bar,
+                       double* pair_out) {
+    if (!h) return TGP_EINVAL;
+    if (n < 0 || !y || !y_new || !R || !R_new || !ybar || !pair_out || (nR != 1 && nR != n) || (nR_new != 1 && nR_new != n))
+        return h->fail(TGP_EINVAL, "tgp_pair_statistic: null argument, or a variance count that is neither 1 nor n");
+    const bool per_step = nR == n && n > 1, per_step_new = nR_new == n && n > 1;
+    if (!Rbar && (per_step || per_step_new || missing || missing_new))
+        return h->fail(TGP_EINVAL, "tgp_pair_statistic: Rbar [n] is needed when a variance is per step or anything is missing");
+    if (!missing_bar && missing && missing_new) return h->fail(TGP_EINVAL, "tgp_pair_statistic: missing_bar [n] is needed with two masks");
+    *pair_out = 0.0;
+    if (n == 0) return TGP_OK;
+    TRY(bind_device(h));
+    PairArgs a{};
+    a.y = y, a.ys = y_new, a.m = missing, a.ms = missing_new, a.ybar = ybar, a.Rbar = Rbar, a.mbar = (missing && missing_new) ? missing_bar : nullptr, a.n = n;
+    a.R = per_step ? R : nullptr;
+    a.Rs = per_step_new ? R_new : nullptr;
+    a.R0 = a.Rs0 = 1.0;
+    // (a single variance is read on the host: a device value when n == 1 says both are per step -- one 8-byte copy each)
+    if (!per_step) {
+        hipPointerAttribute_t at{};
+        if (hipPointerGetAttributes(&at, R) == hipSuccess && at.type == hipMemoryTypeDevice) HIPCHK(hipMemcpy(&a.R0, R, sizeof(double), hipMemcpyDeviceToHost));
+        else { (void)hipGetLastError(); a.R0 = R[0]; }
+    }
+    if (!per_step_new) {
+        hipPointerAttribute_t at{};
+        if (hipPointerGetAttributes(&at, R_new) == hipSuccess && at.type == hipMemoryTypeDevice) HIPCHK(hipMemcpy(&a.Rs0, R_new, sizeof(double), hipMemcpyDeviceToHost));
+        else { (void)hipGetLastError(); a.Rs0 = R_new[0]; }
+    }
+    if (!(a.R0 + a.Rs0 > 0.0)) return h->fail(TGP_EINVAL, "tgp_pair_statistic: R + R_new must be positive");
+    const int nblk = (int)std::min<long long>(2048, (n + 1023) / 1024);
+    TRY(ensure_pinned(h, (size_t)nblk));
+    a.part = h->flt_host;
+    hipLaunchKernelGGL(k_pair_statistic, dim3(nblk), dim3(256), 0, h->stream, a);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    double sum = 0.0;
+    for (int b = 0; b < nblk; ++b) sum += h->flt_host[b];
+    *pair_out = sum;
+    return TGP_OK;
+}
+
 int tgp_filter(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t flags, double* m_out, double* P_out, double* lml_out) {
     TRY(check_ready(h, /*general=*/false));
     h->dense_last_n0 = -1;

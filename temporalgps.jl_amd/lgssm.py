@@ -225,7 +225,15 @@ class LGSSM:
         if any(on_dev):
             _sync_torch(next(x for x in arrs if _lib.is_device(x)))
         if any(on_dev) and not all(on_dev):
-            raise ValueError("model arrays must be all NumPy or all CUDA tensors")
+            # SHARED blocks on the host beside per-step blocks on the device (a per-step noise that lives there, the blocks of an LTI model):
+            # the few shared doubles follow to the device; a per-step host array beside device ones stays an error (T doubles would be uploaded)
+            if any(not od and (x.numel() if _is_torch(x) else x.size) > 4096 for od, x in zip(on_dev, arrs)):
+                raise ValueError("model arrays must be all NumPy or all CUDA tensors (shared blocks on the host may stand beside CUDA tensors)")
+            import torch
+            where = next(x for x in arrs if _lib.is_device(x)).device
+            arrs = tuple(x if od else torch.as_tensor(x).to(where) for od, x in zip(on_dev, arrs))
+            A, a, Q, H, h, R = arrs
+            on_dev = [True] * len(arrs)
         flags = 0
         for bit, s in zip((_lib.SHARED_A, _lib.SHARED_a, _lib.SHARED_Q, _lib.SHARED_H, _lib.SHARED_h, _lib.SHARED_R),
                           (sA, sa, sQ, sH, sh, sR)):
@@ -394,8 +402,92 @@ def _out(model, shape, like_device):
     return np.empty(shape, dtype=np.float64)
 
 
+def _pair_statistic(y, R, ys, Rs):
+    """Two observations y ~ N(f, R), y* ~ N(f, R*) of the same latent value with independent noise:
+        N(y; f, R) N(y*; f, R*) = N(ybar; f, Rbar) N(y - y*; 0, R + R*),   Rbar = R R* / (R + R*),  ybar = Rbar (y / R + y* / R*)
+    -> (ybar, Rbar, sum_t log N(y_t - y*_t; 0, R_t + R*_t)).  NaN (missing, missings.jl:25-33) on one side leaves the other observation as
+    it is; on both sides the joint step is missing.  R, R*: one variance each (-> one Rbar unless something is missing) or one per step.
+    Host arrays (the device counterpart is tgp_pair_statistic)."""
+    y, ys = np.asarray(y, dtype=np.float64), np.asarray(ys, dtype=np.float64)
+    R, Rs = np.atleast_1d(np.asarray(R, dtype=np.float64)), np.atleast_1d(np.asarray(Rs, dtype=np.float64))
+    my, ms = np.isnan(y), np.isnan(ys)
+    tot = R + Rs
+    diff = y - ys
+    both = ~(my | ms)
+    const = -0.5 * float(np.sum((np.log(2 * np.pi * tot) + diff * diff / tot)[both] if tot.shape[0] > 1
+                                else np.log(2 * np.pi * tot[0]) + diff[both] ** 2 / tot[0]))
+    with np.errstate(invalid="ignore", divide="ignore"):     # (a zero variance on a side that is missing: the entry is replaced below)
+        Rbar = R * Rs / tot
+        ybar = (Rs * y + R * ys) / tot               # = Rbar (y / R + y* / R*) without the divisions by a tiny jitter R*
+    if my.any() or ms.any():
+        n = y.shape[0]
+        Rbar = np.where(ms, np.broadcast_to(R, (n,)), np.where(my, np.broadcast_to(Rs, (n,)), np.broadcast_to(Rbar, (n,))))
+        ybar = np.where(ms, y, np.where(my, ys, ybar))
+    return ybar, Rbar, const
+
+
+def _posterior_logpdf_pair(post, y_new):
+    """logpdf(replace_observation_noise_cov(posterior(prior, y), R_new), y_new) of a posterior that has not been evaluated, WITHOUT evaluating
+    it: log p(y_new | y) = log p(y, y_new) - log p(y), and the two observations per step are one (`_pair_statistic` / tgp_pair_statistic) --
+    two logpdf calls of the PRIOR on whatever engine it has instead of the filter of a T x (2 d^2 + d) reverse-time model.  Forward priors
+    with scalar observations; None: the caller evaluates the posterior (lgssm.jl:193-221, then :147-151)."""
+    prior = post._prior
+    if (post._model is not None or isinstance(prior, PosteriorLGSSM) or prior.ordering is not Forward or prior.p != 1
+            or prior._whiten is not None or not isinstance(prior.emissions, ScalarOutputLGC)):
+        return None
+    T = prior.T
+    yy, my, dev = _obs(post._y, prior)
+    yn, mn, devn = _obs(y_new, prior)
+    if dev != devn or tuple(yy.shape) != (T,) or tuple(yn.shape) != (T,):
+        return None
+    em = prior.emissions
+    R = em.R
+    Rn = post._R_new if post._R_new is not None else R
+    if dev:
+        import torch
+        hd = prior.handle()
+        as_dev = lambda v: (v.to(torch.float64).reshape(-1).contiguous() if _is_torch(v) and v.is_cuda
+                            else np.ascontiguousarray(np.atleast_1d(_to_numpy(v)), dtype=np.float64).reshape(-1))
+        Rd, Rnd = as_dev(R), as_dev(Rn)
+        to_dev = lambda v: v if _is_torch(v) or v.shape[0] == 1 else torch.as_tensor(v, device=yy.device)
+        Rd, Rnd = to_dev(Rd), to_dev(Rnd)
+        if Rd.shape[0] not in (1, T) or Rnd.shape[0] not in (1, T):
+            return None
+        shared = Rd.shape[0] == 1 and Rnd.shape[0] == 1 and my is None and mn is None and T > 1
+        ybar = torch.empty(T, dtype=torch.float64, device=yy.device)
+        Rbar = None if shared else torch.empty(T, dtype=torch.float64, device=yy.device)
+        mbar = torch.empty(T, dtype=torch.uint8, device=yy.device) if (my is not None and mn is not None) else None
+        pair = ctypes.c_double()
+        _sync_torch(yy)
+        hd.check(hd.lib.tgp_pair_statistic(hd.h, T, _lib.ptr(yy), _lib.ptr(my), _lib.ptr(Rd), int(Rd.shape[0]), _lib.ptr(yn), _lib.ptr(mn),
+                                           _lib.ptr(Rnd), int(Rnd.shape[0]), _lib.ptr(ybar), _lib.ptr(Rbar), _lib.ptr(mbar), ctypes.byref(pair)))
+        if shared:
+            r, rn = float(_to_numpy(Rd)[0]), float(_to_numpy(Rnd)[0])
+            Rbar = np.array([r * rn / (r + rn)])
+        if _is_torch(Rbar) and (isinstance(prior.transitions, SDETransitions) or any(not _is_torch(b) and np.size(b) > 4096 for b in (
+                prior.transitions.As, prior.transitions.as_, prior.transitions.Qs, em.H, em.h))):
+            Rbar = _to_numpy(Rbar)       # (per-step blocks of the prior on the host, or time stamps: its noise joins them there)
+        joint = LGSSM(prior.transitions, ScalarOutputLGC(em.H, em.h, Rbar), T=T, device=prior.device)
+        return logpdf(joint, ybar if mbar is None else (ybar, mbar)) + pair.value - logpdf(prior, post._y)
+    yh, ynh = np.array(yy, dtype=np.float64), np.array(yn, dtype=np.float64)
+    if my is not None:
+        yh[np.asarray(my, dtype=bool)] = np.nan
+    if mn is not None:
+        ynh[np.asarray(mn, dtype=bool)] = np.nan
+    Rh, Rnh = np.atleast_1d(_to_numpy(R)).astype(np.float64).reshape(-1), np.atleast_1d(_to_numpy(Rn)).astype(np.float64).reshape(-1)
+    if Rh.shape[0] not in (1, T) or Rnh.shape[0] not in (1, T):
+        return None
+    ybar, Rbar, pair = _pair_statistic(yh, Rh, ynh, Rnh)
+    joint = LGSSM(prior.transitions, ScalarOutputLGC(em.H, em.h, Rbar), T=T, device=prior.device)
+    return logpdf(joint, ybar) + pair - logpdf(prior, yh)
+
+
 def logpdf(model, y):
     """lgssm.jl:147-151 (+ missings.jl:8-13)."""
+    if isinstance(model, PosteriorLGSSM) and model._model is None:
+        lp = _posterior_logpdf_pair(model, y)
+        if lp is not None:
+            return lp
     if isinstance(model, PosteriorLGSSM):
         model = model.materialise()
     _check_inputs(model, y[0] if isinstance(y, tuple) else y)

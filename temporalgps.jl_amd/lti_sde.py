@@ -489,26 +489,7 @@ def _noise(s, n):
     return s if s.shape[0] == n else np.full(n, s[0])
 
 
-def _pair_statistic(y, R, ys, Rs):
-    """Two observations y ~ N(f, R), y* ~ N(f, R*) of the same latent value with independent noise:
-        N(y; f, R) N(y*; f, R*) = N(ybar; f, Rbar) N(y - y*; 0, R + R*),   Rbar = R R* / (R + R*),  ybar = Rbar (y / R + y* / R*)
-    -> (ybar, Rbar, sum_t log N(y_t - y*_t; 0, R_t + R*_t)).  NaN (missing, missings.jl:25-33) on one side leaves the other observation as
-    it is; on both sides the joint step is missing.  R, R*: one variance each (-> one Rbar unless something is missing) or one per step."""
-    y, ys = np.asarray(y, dtype=np.float64), np.asarray(ys, dtype=np.float64)
-    R, Rs = np.atleast_1d(np.asarray(R, dtype=np.float64)), np.atleast_1d(np.asarray(Rs, dtype=np.float64))
-    my, ms = np.isnan(y), np.isnan(ys)
-    tot = R + Rs
-    diff = y - ys
-    both = ~(my | ms)
-    const = -0.5 * float(np.sum((np.log(2 * np.pi * tot) + diff * diff / tot)[both] if tot.shape[0] > 1
-                                else np.log(2 * np.pi * tot[0]) + diff[both] ** 2 / tot[0]))
-    Rbar = R * Rs / tot
-    ybar = (Rs * y + R * ys) / tot                   # = Rbar (y / R + y* / R*) without the divisions by a tiny jitter R*
-    if my.any() or ms.any():
-        n = y.shape[0]
-        Rbar = np.where(ms, np.broadcast_to(R, (n,)), np.where(my, np.broadcast_to(Rs, (n,)), np.broadcast_to(Rbar, (n,))))
-        ybar = np.where(ms, y, np.where(my, ys, ybar))
-    return ybar, Rbar, const
+_pair_statistic = L._pair_statistic
 
 
 class FinitePosteriorLTISDE:
@@ -598,15 +579,20 @@ class FinitePosteriorLTISDE:
         return self._logpdf_joint(y_pr)
 
     def _logpdf_joint(self, y_pr):
-        """log p(y* | y) = log p(y, y*) - log p(y): the PRIOR's logpdf over the joined inputs with both data sets observed, minus the prior's
-        logpdf of the training data -- no posterior evaluated, no reverse-time model of T x (2 d^2 + d) doubles filtered.  The joined series is
-        merge_datasets' (posterior_lti_sde.jl:97-123) with the prediction observations in place of `missing`."""
-        d = self.f.data
+        """The reference's chain (posterior_lti_sde.jl:62-78) as it stands: posterior of the prior over merge_datasets' joined inputs with
+        the prediction inputs missing, the noise replaced, logpdf of the prediction observations with the training inputs missing.  The
+        posterior is lazy and its logpdf is log p(y, y*) - log p(y) (lgssm.py `_posterior_logpdf_pair`: every joined step is observed on
+        exactly one side): the PRIOR's logpdf over the joined inputs with both data sets in place, minus the prior's logpdf of the
+        training data over the same steps -- no reverse-time model of T x (2 d^2 + d) doubles evaluated or filtered."""
         npr = len(self.x)
-        x, S, y, tr, pr = self._merge(_noise(self.sigma2, npr))
-        y[pr] = y_pr
-        joint = L.logpdf(self._posterior_model(x, S, y), y)
-        return joint - L.logpdf(self._posterior_model(d["x"], d["sigma2"], d["y"]), d["y"])
+        s_pr = _noise(self.sigma2, npr)
+        x, S, y, tr, pr = self._merge(s_pr)
+        s_full = np.zeros(len(x))
+        s_full[pr] = s_pr
+        post = L.replace_observation_noise_cov(L.posterior(self._posterior_model(x, S, y), y), s_full)
+        y_full = np.full(len(x), np.nan)             # build_prediction_obs :148-158: training points are missing
+        y_full[pr] = y_pr
+        return L.logpdf(post, y_full)
 
     def _logpdf_merged(self, y_pr):
         npr = len(self.x)
@@ -617,7 +603,7 @@ class FinitePosteriorLTISDE:
         post = L.replace_observation_noise_cov(L.posterior(self._posterior_model(x, S, y), y), s_full)
         y_full = np.full(len(x), np.nan)             # build_prediction_obs :148-158: training points are missing
         y_full[pr] = y_pr
-        return L.logpdf(post, y_full)
+        return L.logpdf(post.materialise(), y_full)  # (the EVALUATED posterior: what the chain costs without the lazy object; tests hold the two together)
 
 
 # ------------------------------------------------------------------------------------------ gradient of logpdf

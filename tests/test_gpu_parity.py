@@ -636,3 +636,64 @@ def test_nan_observations_in_a_large_host_series_are_found_without_scanning_ever
         assert lp == want and np.array_equal(m0, m2)
         # no NaN: one call, no mask (an explicit all-false mask takes the LTI model off the stationary-gain engine: equal to rounding)
         assert abs(tgp.logpdf(model, y) - tgp.logpdf(model, (y, np.zeros(T, dtype=bool)))) <= 1e-12 * abs(want)
+
+
+@pytest.mark.parametrize("kernel,d", [(("matern32",), 2), (("matern52",), 3), (("sum", ("matern32",), ("matern52",)), 5)])
+@pytest.mark.parametrize("noise", ["shared", "per-step"])
+def test_logpdf_of_an_unevaluated_posterior_needs_no_posterior(tgp, kernel, d, noise):
+    """posterior_lti_sde.jl:62-78's last line, logpdf(replace_observation_noise_cov(posterior(model, ys), S_new), ys_new): on this backend two
+    logpdf calls of the PRIOR through the pair statistic (tgp_pair_statistic for device-resident series) -- held against the
+    oracle's literal chain (posterior evaluated, lgssm.jl:193-221, then filtered, :147-151) and against the product's own evaluated route."""
+    import torch
+    rng = np.random.default_rng(5)
+    T = 3000
+    s2 = 0.3 if noise == "shared" else rng.random(T) * 0.3 + 0.1
+    model, y, _ = U.gp_case(kernel, ("regular", 0.0, 0.1, T), s2, seed=3)
+    assert len(model["x0m"]) == d
+    dm = to_device_model(tgp, model)
+    y_new = y + 0.4 * rng.standard_normal(T)
+    R_new = np.full(1, 0.2) if noise == "shared" else rng.random(T) * 0.2 + 0.05
+    want = ref.logpdf(ref.replace_observation_noise_cov(ref.posterior(model, y), R_new), y_new)
+    chain = lambda yy, yn, Rn: tgp.logpdf(tgp.replace_observation_noise_cov(tgp.posterior(dm, yy), Rn), yn)
+    post = tgp.replace_observation_noise_cov(tgp.posterior(dm, y), R_new)
+    got = tgp.logpdf(post, y_new)
+    assert post._model is None                                     # no reverse-time model evaluated
+    assert abs(got - want) <= 1e-8 * abs(want)
+    evaluated = tgp.logpdf(tgp.replace_observation_noise_cov(tgp.posterior(dm, y), R_new).materialise(), y_new)
+    assert abs(got - evaluated) <= 1e-8 * abs(want)
+    # device-resident series (and a device-resident per-step noise): the statistic by tgp_pair_statistic
+    dev = torch.device("cuda:0")
+    yd, ynd = torch.as_tensor(y, device=dev), torch.as_tensor(y_new, device=dev)
+    Rnd = R_new if noise == "shared" else torch.as_tensor(R_new, device=dev)
+    got_dev = chain(yd, ynd, Rnd)
+    assert abs(got_dev - got) <= 1e-12 * abs(want)
+    # missing entries on either side, on both, host (NaN) and device (masks)
+    ym, ynm = y.copy(), y_new.copy()
+    ym[[5, 700, 701]] = np.nan
+    ynm[[9, 700, 2999]] = np.nan
+    miss, miss_new = np.isnan(ym), np.isnan(ynm)
+    post_o = ref.replace_observation_noise_cov(ref.posterior_missing(model, np.nan_to_num(ym), miss), R_new)
+    want_m = ref.logpdf_missing(post_o, np.nan_to_num(ynm), miss_new)
+    got_m = chain(ym, ynm, R_new)
+    assert abs(got_m - want_m) <= 1e-8 * abs(want_m)
+    got_md = chain((yd, torch.as_tensor(miss, device=dev)), (ynd, torch.as_tensor(miss_new, device=dev)), Rnd)
+    assert abs(got_md - got_m) <= 1e-12 * abs(want_m)
+
+
+def test_pair_statistic_abi_argument_checks(tgp):
+    import ctypes
+    import torch
+    dm = to_device_model(tgp, U.gp_case(("matern32",), ("regular", 0.0, 0.1, 50), 0.1, seed=1)[0])
+    hd = dm.handle()
+    dev = torch.device("cuda:0")
+    y = torch.zeros(50, dtype=torch.float64, device=dev)
+    out, pair = torch.empty_like(y), ctypes.c_double()
+    ptr, R = tgp._lib.ptr, np.array([0.5])
+    call = lambda *a: hd.lib.tgp_pair_statistic(hd.h, *a)
+    assert call(50, ptr(y), None, ptr(R), 7, ptr(y), None, ptr(R), 1, ptr(out), None, None, ctypes.byref(pair)) == tgp._lib.EINVAL     # 7 variances for 50 steps
+    Rt = torch.full((50,), 0.5, dtype=torch.float64, device=dev)
+    assert call(50, ptr(y), None, ptr(Rt), 50, ptr(y), None, ptr(R), 1, ptr(out), None, None, ctypes.byref(pair)) == tgp._lib.EINVAL   # per-step noise without Rbar
+    assert call(0, ptr(y), None, ptr(R), 1, ptr(y), None, ptr(R), 1, ptr(out), None, None, ctypes.byref(pair)) == 0 and pair.value == 0.0
+    assert call(50, ptr(y), None, ptr(R), 1, ptr(y), None, ptr(R), 1, ptr(out), None, None, ctypes.byref(pair)) == 0
+    torch.cuda.synchronize()
+    assert abs(pair.value + 25 * np.log(2 * np.pi)) < 1e-12 and float(out.abs().max()) == 0.0
