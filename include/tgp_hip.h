@@ -350,6 +350,13 @@ int tgp_pair_statistic(tgp_handle* h, int64_t n, const double* y, const uint8_t*
                        const double* y_new, const uint8_t* missing_new, const double* R_new, int64_t nR_new, double* ybar,
                        double* Rbar, uint8_t* missing_bar, double* pair_out);
 
+/* ---- tgp_logpdf of the bound model with ANOTHER noise variance R (one number; every other block as bound): the joint
+ *      model of the identity above is the prior with Rbar, and replace_observation_noise_cov (missings.jl:35-41) of an
+ *      LTI model changes nothing else -- no second model bound. Served by the one-launch paths only (their plans are host
+ *      functions of the blocks, rebuilt per call): Forward LTI models with scalar observations, no missing data;
+ *      TGP_EUNSUPPORTED otherwise (bind the model with the new variance and call tgp_logpdf). y as TGP_IN_DEVICE says. */
+int tgp_logpdf_noise(tgp_handle* h, const double* y, uint32_t flags, double R, double* out);
+
 /* ---- rand(rng, model) with the randomness supplied: lgssm.jl:65-91, lgc.jl:84-87,241-243,
  *      gaussian.jl:35-43. eps_t [T][d], eps_e [T], eps_0 [d] (eps_0 always host). y_out [T].
  *      A Forward LTI model (every block shared) with scalar observations and d <= 8 runs as ONE kernel over the draws

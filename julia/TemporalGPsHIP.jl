@@ -240,6 +240,13 @@ function AbstractGPs.logpdf(p::DevicePosterior, y::AbstractVector)
     end
     Σ̄ = all(==(R̄[1]), R̄) ? Fill(R̄[1], m.T) : R̄     # one variance keeps the model on its one-launch path
     ȳv = any(ismissing, ȳ) ? ȳ : Float64.(ȳ)
+    if Σ̄ isa Fill && ȳv isa Vector{Float64}             # the prior with another noise variance, on the prior's own handle (tgp_logpdf_noise)
+        out = Ref{Float64}(0.0)
+        rc = GC.@preserve ȳv ccall((:tgp_logpdf_noise, libtgp), Cint, (Ptr{Cvoid}, Ptr{Float64}, UInt32, Float64, Ref{Float64}),
+                                   m.h.ptr, ȳv, UInt32(0), R̄[1], out)
+        rc == 0 && return out[] + pair - logpdf(m, p.y)
+        rc == 4 || check(m.h, rc)                        # TGP_EUNSUPPORTED: bind the joint model
+    end
     return logpdf(replace_observation_noise_cov(m, Σ̄), ȳv) + pair - logpdf(m, p.y)
 end
 TemporalGPs._filter(p::DevicePosterior, y::AbstractVector) = _filter(materialise(p), y)

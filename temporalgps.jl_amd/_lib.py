@@ -61,6 +61,7 @@ _SIGS = {
     "tgp_marginals": (ctypes.c_int, [_vp, _u32, _vp, _vp]),
     "tgp_rand": (ctypes.c_int, [_vp, _vp, _vp, _vp, _u32, _vp]),
     "tgp_posterior_rand": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp]),
+    "tgp_logpdf_noise": (ctypes.c_int, [_vp, _vp, _u32, ctypes.c_double, _vp]),
     "tgp_pair_statistic": (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "tgp_elem_size": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
     "tgp_segment_reduce": (ctypes.c_int, [_vp, _vp, _vp, _u32, _vp]),

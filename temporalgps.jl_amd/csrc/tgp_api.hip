@@ -433,6 +433,8 @@ struct tgp_handle {
     int opt_modal = 1;
     tgp_modal::Engine* modal = nullptr;
     int modal_state = 0;         // 0 untried for the bound model, 1 served the last call, -1 does not apply
+    bool has_R_over = false;     // tgp_logpdf_noise: the host plans of THIS call read R_over instead of the bound model's noise variance
+    double R_over = 0.0;
     int smooth_state = 0;        // the dense-powers one-launch smoother (smooth_lti_call): 0 untried / applies, -1 does not apply
     bool modal_last = false;
     int64_t dense_last_n0 = -1;   // >= 0: the last call ran on the dense-power one-launch kernels behind a head of that many steps with gains of their own
@@ -1269,7 +1271,7 @@ int modal_call(tgp_handle* h, const double* y, uint32_t flags, const double* Rne
     const double* q = h->hostm.data();
     tgp_plan::ModelHost mh;
     mh.d = d;
-    mh.A = q; mh.a = q + dd; mh.Q = q + dd + d; mh.H = q + 2 * dd + d; mh.hh = q + 2 * dd + 2 * d; mh.R = q + 2 * dd + 2 * d + 1;
+    mh.A = q; mh.a = q + dd; mh.Q = q + dd + d; mh.H = q + 2 * dd + d; mh.hh = q + 2 * dd + 2 * d; mh.R = h->has_R_over ? &h->R_over : q + 2 * dd + 2 * d + 1;
     mh.x0m = h->x0m.data();
     mh.x0P = h->x0P.data();
     if (!tgp_modal::plan(h->modal, mh, h->T)) {
@@ -2222,6 +2224,35 @@ int tgp_logpdf(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t 
     return tm.finish(out);
 }
 
+// logpdf of the bound model with ANOTHER noise variance (everything else as bound): what the joint model of DESIGN 3.18 is -- the prior's blocks
+// with Rbar -- without binding a second model.  The one-launch paths only (their plans are host functions of the blocks, rebuilt per call):
+// Forward LTI models, scalar observations, no missing data; TGP_EUNSUPPORTED otherwise (bind the model with the new variance instead).
+int tgp_logpdf_noise(tgp_handle* h, const double* y, uint32_t flags, double R, double* out) {
+    TRY(check_ready(h, /*general=*/false));
+    if (!out || !y) return h->fail(TGP_EINVAL, "tgp_logpdf_noise: null argument");
+    if (!(R > 0.0) || !std::isfinite(R)) return h->fail(TGP_EINVAL, "tgp_logpdf_noise: the noise variance must be positive");
+    h->steady2_last = false;
+    h->modal_last = false;
+    h->dense_last_n0 = -1;
+    if (!steady2_eligible(h, nullptr, flags) || !h->opt_modal || h->hostm.empty())
+        return h->fail(TGP_EUNSUPPORTED, "tgp_logpdf_noise: Forward LTI models with scalar observations on the one-launch paths only");
+    const int modal_state = h->modal_state, smooth_state = h->smooth_state;       // (the verdicts are the BOUND model's: kept for it)
+    h->modal_state = 0;
+    h->smooth_state = 0;
+    h->R_over = R;
+    h->has_R_over = true;
+    bool served = false;
+    int rc = modal_call(h, y, flags, nullptr, nullptr, nullptr, out, &served);
+    if (rc == TGP_OK && !served) rc = smooth_lti_call(h, y, flags, nullptr, nullptr, nullptr, out, &served);
+    if (rc == TGP_OK && !served) rc = filter_lti_call(h, y, flags, nullptr, nullptr, out, &served);
+    h->has_R_over = false;
+    h->modal_state = modal_state;
+    h->smooth_state = smooth_state;
+    if (rc != TGP_OK) return rc;
+    if (!served) return h->fail(TGP_EUNSUPPORTED, "tgp_logpdf_noise: no one-launch path takes this model with this noise variance");
+    return TGP_OK;
+}
+
 // ---- time segments on the one-launch path (one rank of several; tgp_multi.hip and the one-process-per-GPU driver) ----------------------
 // Both mean recursions forget a state within `halo` steps, so a rank needs nothing of its neighbours but their `halo` observations next to
 // the boundary: no exchange of filter elements, no carry between ranks.  The plan is a function of the model blocks and the series' length
@@ -2232,7 +2263,7 @@ static bool modal_host_model(tgp_handle* h, tgp_plan::ModelHost& mh) {
     const size_t dd = (size_t)d * d;
     const double* q = h->hostm.data();
     mh.d = d;
-    mh.A = q; mh.a = q + dd; mh.Q = q + dd + d; mh.H = q + 2 * dd + d; mh.hh = q + 2 * dd + 2 * d; mh.R = q + 2 * dd + 2 * d + 1;
+    mh.A = q; mh.a = q + dd; mh.Q = q + dd + d; mh.H = q + 2 * dd + d; mh.hh = q + 2 * dd + 2 * d; mh.R = h->has_R_over ? &h->R_over : q + 2 * dd + 2 * d + 1;
     mh.x0m = h->x0m.data();
     mh.x0P = h->x0P.data();
     return true;

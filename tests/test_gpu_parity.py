@@ -697,3 +697,32 @@ def test_pair_statistic_abi_argument_checks(tgp):
     assert call(50, ptr(y), None, ptr(R), 1, ptr(y), None, ptr(R), 1, ptr(out), None, None, ctypes.byref(pair)) == 0
     torch.cuda.synchronize()
     assert abs(pair.value + 25 * np.log(2 * np.pi)) < 1e-12 and float(out.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("kernel", [("matern52",), ("sum", ("matern52",), ("matern52",)), ("sum", ("matern32",), ("matern12",))])
+def test_logpdf_with_another_noise_variance_on_the_bound_handle(tgp, kernel):
+    """tgp_logpdf_noise: logpdf of the bound LTI model with ONE other noise variance == tgp_logpdf of the model bound with it (oracle beside
+    both), modal and dense-powers one-launch paths; the bound model's own calls are untouched by it; models off those paths are refused."""
+    import ctypes
+    T = 6000
+    model, y, _ = U.gp_case(kernel, ("regular", 0.0, 0.1, T), 0.3, seed=8)
+    dm = to_device_model(tgp, model)
+    hd = dm.handle()
+    before = tgp.logpdf(dm, y)
+    for R in (0.07, 2.5, 1e-6):
+        other = dict(model, R=np.array([R]))
+        want = ref.logpdf(other, y)
+        out = ctypes.c_double()
+        rc = hd.lib.tgp_logpdf_noise(hd.h, tgp._lib.ptr(y), 0, R, ctypes.byref(out))
+        if rc == tgp._lib.EUNSUPPORTED and R < 1e-3:       # (a nearly noise-free model may be declined by every one-launch plan: the caller binds it)
+            assert tgp.logpdf(dm, y) == before
+            continue
+        assert rc == 0
+        assert abs(out.value - want) <= 1e-9 * abs(want)
+        assert abs(out.value - tgp.logpdf(to_device_model(tgp, other), y)) <= 1e-12 * abs(want)
+        assert tgp.logpdf(dm, y) == before
+    out = ctypes.c_double()
+    assert hd.lib.tgp_logpdf_noise(hd.h, tgp._lib.ptr(y), 0, -1.0, ctypes.byref(out)) == tgp._lib.EINVAL
+    per_step = to_device_model(tgp, dict(model, R=np.full(T, 0.3)))
+    hp = per_step.handle()
+    assert hp.lib.tgp_logpdf_noise(hp.h, tgp._lib.ptr(y), 0, 0.1, ctypes.byref(out)) == tgp._lib.EUNSUPPORTED
