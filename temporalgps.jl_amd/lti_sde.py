@@ -569,13 +569,13 @@ class FinitePosteriorLTISDE:
         if y_pr.shape != (len(self.x),):
             raise ValueError("Dimension mismatch: one observation per prediction input")
         if _same_inputs(self.x, d["x"]):
-            # prediction inputs = training inputs: log p(y* | y) = log p(y, y*) - log p(y), and two noisy observations of the same latent value
-            # are one observation of it (`_pair_statistic`) -- two prior logpdf calls over T steps on whatever engine the prior has (one launch
-            # each for an LTI model) instead of the evaluated posterior over 2T joined steps
-            ybar, Rbar, const = _pair_statistic(d["y"], _noise(d["sigma2"], len(y_pr)) if len(d["sigma2"]) > 1 else d["sigma2"],
-                                                y_pr, _noise(self.sigma2, len(y_pr)) if len(self.sigma2) > 1 else self.sigma2)
-            joint = L.logpdf(self._posterior_model(d["x"], Rbar, ybar), ybar)
-            return joint + const - L.logpdf(self._posterior_model(d["x"], d["sigma2"], d["y"]), d["y"])
+            # prediction inputs = training inputs: every joined pair of steps is ONE latent value observed twice (dt = 0: A = I, Q = 0), so the
+            # posterior over the T training steps with its noise replaced IS the model the chain below would build over 2T steps -- and its logpdf
+            # needs no posterior: log p(y* | y) = log p(ybar) + pair - log p(y) (lgssm.py `_posterior_logpdf_pair`), two logpdf calls on the prior's
+            # own handle for an LTI model instead of the evaluated posterior over 2T joined steps
+            model = self._posterior_model(d["x"], d["sigma2"], d["y"])
+            S_new = _noise(self.sigma2, len(self.x)) if len(self.sigma2) > 1 else self.sigma2
+            return L.logpdf(L.replace_observation_noise_cov(L.posterior(model, d["y"]), S_new), y_pr)
         return self._logpdf_joint(y_pr)
 
     def _logpdf_joint(self, y_pr):

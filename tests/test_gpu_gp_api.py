@@ -167,7 +167,7 @@ def test_posterior_consumers_at_the_training_inputs_on_a_regular_grid(P, kname, 
         return a.value
 
     lp = P.logpdf(fpost(x, 0.25), ys)
-    assert len(built) == 2 and all(m.T == T and stationary_steps(m) > T - 700 for m in built)     # T steps each, none on the general engine
+    assert len(built) == 1 and built[0].T == T and stationary_steps(built[0]) > T - 700     # ONE model of T steps bound, its calls on the stationary engine
     del built[:]
     lp_m = fpost(x, 0.25)._logpdf_merged(ys)
     # (the joined route filters T steps of dt = 0 with singular predicted covariances and carries the reference's own jitter there: it sits 1-2e-9

@@ -95,3 +95,43 @@ def test_pair_statistic_gives_the_posterior_logpdf_at_the_training_inputs(noise)
     got = dg.logpdf(spec, x[kj], Rbf[kj], ybar[kj]) + const - dg.logpdf(spec, x[kt], Rf[kt], y[kt])
     want = dg.posterior_logpdf(spec, x[kt], Rf[kt], y[kt], x[kp], Rsf[kp], ys[kp])
     assert abs(got - want) <= 1e-9 * abs(want)
+
+
+@pytest.mark.parametrize("noise", ["scalars", "per-step"])
+@pytest.mark.parametrize("gaps", [False, True])
+def test_posterior_logpdf_pair_host_logic_against_the_oracles_literal_chain(monkeypatch, noise, gaps):
+    """lgssm.py `_posterior_logpdf_pair` (host arrays) with the device calls replaced by the oracle's logpdf: the value of
+    logpdf(replace_observation_noise_cov(posterior(model, y), R_new), y_new) against the oracle's literal chain -- posterior evaluated
+    (lgssm.jl:193-221), noise replaced (missings.jl:35-41), filtered (lgssm.jl:147-151) -- with gaps on either side and on both."""
+    from oracle import lgssm_ref as ref
+    from temporalgps_jl_amd import lgssm as L
+    rng = np.random.default_rng(12)
+    T = 300
+    s2 = 0.3 if noise == "scalars" else rng.random(T) * 0.3 + 0.1
+    model = oc.build_lgssm(KERNELS["sum-12-32"], ("regular", 0.0, 0.2, T), s2)
+    d = len(model["x0m"])
+    y = ref.rand(model, rng.standard_normal((T, d)), rng.standard_normal(T), rng.standard_normal(d))
+    y_new = y + 0.4 * rng.standard_normal(T)
+    R_new = np.array([0.2]) if noise == "scalars" else rng.random(T) * 0.2 + 0.05
+    miss, miss_new = np.zeros(T, dtype=bool), np.zeros(T, dtype=bool)
+    if gaps:
+        miss[[3, 100, 101]] = True
+        miss_new[[7, 100, 299]] = True
+
+    def as_oracle(m):
+        em = m.emissions
+        return dict(model, R=np.asarray(em.R, dtype=np.float64).reshape(-1))
+
+    def oracle_logpdf(m, yy):
+        yy = np.asarray(yy, dtype=np.float64)
+        return ref.logpdf_missing(as_oracle(m), np.nan_to_num(yy), np.isnan(yy))
+
+    monkeypatch.setattr(L, "logpdf", oracle_logpdf)
+    monkeypatch.setattr(L, "_logpdf_with_noise", lambda prior, ybar, Rbar: None)
+    tr = L.GaussMarkovModel(L.Forward, model["A"], model["a"], model["Q"], L.Gaussian(model["x0m"], model["x0P"]))
+    prior = L.LGSSM(tr, L.ScalarOutputLGC(model["H"], np.atleast_1d(model["h"]), np.atleast_1d(model["R"])), T=T)
+    ym, ynm = np.where(miss, np.nan, y), np.where(miss_new, np.nan, y_new)
+    got = L._posterior_logpdf_pair(L.replace_observation_noise_cov(L.posterior(prior, ym), R_new), ynm)
+    post = ref.replace_observation_noise_cov(ref.posterior_missing(model, y, miss), R_new)
+    want = ref.logpdf_missing(post, y_new, miss_new)
+    assert got is not None and abs(got - want) <= 1e-8 * abs(want)
