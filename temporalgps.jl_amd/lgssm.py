@@ -410,6 +410,14 @@ def _pair_statistic(y, R, ys, Rs):
     Host arrays (the device counterpart is tgp_pair_statistic)."""
     y, ys = np.asarray(y, dtype=np.float64), np.asarray(ys, dtype=np.float64)
     R, Rs = np.atleast_1d(np.asarray(R, dtype=np.float64)), np.atleast_1d(np.asarray(Rs, dtype=np.float64))
+    if R.shape[0] == 1 and Rs.shape[0] == 1 and y.shape[0] > 1 and np.isfinite(y.sum()) and np.isfinite(ys.sum()):
+        # one variance on each side, nothing missing (a NaN would have made its sum one): four passes over the series instead of a dozen
+        tot = float(R[0] + Rs[0])
+        ybar = y - ys
+        const = -0.5 * (y.shape[0] * np.log(2 * np.pi * tot) + float(ybar @ ybar) / tot)
+        ybar *= Rs[0] / tot                          # ybar = y* + (y - y*) R* / (R + R*)
+        ybar += ys
+        return ybar, R * Rs / tot, const
     my, ms = np.isnan(y), np.isnan(ys)
     tot = R + Rs
     diff = y - ys
@@ -451,13 +459,38 @@ def _posterior_logpdf_pair(post, y_new):
             or prior._whiten is not None or not isinstance(prior.emissions, ScalarOutputLGC)):
         return None
     T = prior.T
-    yy, my, dev = _obs(post._y, prior)
-    yn, mn, devn = _obs(y_new, prior)
-    if dev != devn or tuple(yy.shape) != (T,) or tuple(yn.shape) != (T,):
-        return None
     em = prior.emissions
     R = em.R
     Rn = post._R_new if post._R_new is not None else R
+    on_dev = lambda v: _lib.is_device(v[0] if isinstance(v, tuple) else v)
+    if on_dev(post._y) != on_dev(y_new):
+        return None
+    if not on_dev(y_new):
+        # host arrays: NaN == missing straight into the statistic (no mask built and undone, no second NaN scan)
+        def series(v):
+            v, mask = v if isinstance(v, tuple) else (v, None)
+            a = np.asarray(_to_numpy(v), dtype=np.float64)
+            if a.shape != (T,):
+                return None
+            if mask is not None:
+                a = a.copy()
+                a[np.asarray(_to_numpy(mask), dtype=bool).reshape(T)] = np.nan
+            return a
+        yh, ynh = series(post._y), series(y_new)
+        Rh, Rnh = np.atleast_1d(_to_numpy(R)).astype(np.float64).reshape(-1), np.atleast_1d(_to_numpy(Rn)).astype(np.float64).reshape(-1)
+        if yh is None or ynh is None or Rh.shape[0] not in (1, T) or Rnh.shape[0] not in (1, T):
+            return None
+        ybar, Rbar, pair = _pair_statistic(yh, Rh, ynh, Rnh)
+        if Rbar.shape[0] == 1 and T > 1:     # (one variance on each side and nothing missing: the joint model is the prior with another noise variance)
+            lp = _logpdf_with_noise(prior, np.ascontiguousarray(ybar), Rbar)
+            if lp is not None:
+                return lp + pair - logpdf(prior, yh)
+        joint = LGSSM(prior.transitions, ScalarOutputLGC(em.H, em.h, Rbar), T=T, device=prior.device)
+        return logpdf(joint, ybar) + pair - logpdf(prior, yh)
+    yy, my, dev = _obs(post._y, prior)
+    yn, mn, devn = _obs(y_new, prior)
+    if not (dev and devn) or tuple(yy.shape) != (T,) or tuple(yn.shape) != (T,):
+        return None
     if dev:
         import torch
         hd = prior.handle()
@@ -488,21 +521,7 @@ def _posterior_logpdf_pair(post, y_new):
             Rbar = _to_numpy(Rbar)       # (per-step blocks of the prior on the host, or time stamps: its noise joins them there)
         joint = LGSSM(prior.transitions, ScalarOutputLGC(em.H, em.h, Rbar), T=T, device=prior.device)
         return logpdf(joint, ybar if mbar is None else (ybar, mbar)) + pair.value - logpdf(prior, post._y)
-    yh, ynh = np.array(yy, dtype=np.float64), np.array(yn, dtype=np.float64)
-    if my is not None:
-        yh[np.asarray(my, dtype=bool)] = np.nan
-    if mn is not None:
-        ynh[np.asarray(mn, dtype=bool)] = np.nan
-    Rh, Rnh = np.atleast_1d(_to_numpy(R)).astype(np.float64).reshape(-1), np.atleast_1d(_to_numpy(Rn)).astype(np.float64).reshape(-1)
-    if Rh.shape[0] not in (1, T) or Rnh.shape[0] not in (1, T):
-        return None
-    ybar, Rbar, pair = _pair_statistic(yh, Rh, ynh, Rnh)
-    if Rbar.shape[0] == 1 and T > 1:     # (one variance on each side and nothing missing: the joint model is the prior with another noise variance)
-        lp = _logpdf_with_noise(prior, np.ascontiguousarray(ybar), Rbar)
-        if lp is not None:
-            return lp + pair - logpdf(prior, yh)
-    joint = LGSSM(prior.transitions, ScalarOutputLGC(em.H, em.h, Rbar), T=T, device=prior.device)
-    return logpdf(joint, ybar) + pair - logpdf(prior, yh)
+    return None
 
 
 def logpdf(model, y):
