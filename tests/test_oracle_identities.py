@@ -184,3 +184,22 @@ def test_posterior_dimension_mismatch_raises():
     model = _random_lgssm(np.random.default_rng(0), False, "scalar", 2, 1, 4)
     with pytest.raises(ValueError, match="Dimension mismatch"):
         ref.posterior(model, np.zeros(5))
+
+
+@pytest.mark.parametrize("kname", ["base-Matern52", "sum-12-32"])
+def test_reverse_ordering_of_a_stationary_lti_model_is_the_forward_model_on_the_flipped_series(kname):
+    """gauss_markov_model.jl:38-40 / lgssm.jl:147-165: a Reverse model observes, then predicts; a Forward one predicts, then observes.  When x0
+    is stationary under (A, a, Q) -- every to_sde model: x0 = the SDE's stationary distribution -- the Forward model's first predict changes
+    nothing, so logpdf(Reverse, y) == logpdf(Forward, flip(y)) and the prior marginals are each other's flips: the route by which Reverse LTI
+    priors can reach the stationary-gain engines (not built)."""
+    rng = np.random.default_rng(0)
+    T = 200
+    model = oc.build_lgssm(KERNELS[kname], ("regular", 0.0, 0.3, T), 0.2)
+    d = len(model["x0m"])
+    y = ref.rand(model, rng.standard_normal((T, d)), rng.standard_normal(T), rng.standard_normal(d))
+    rev = dict(model, ordering="R")
+    a, b = ref.logpdf(rev, y), ref.logpdf(model, y[::-1].copy())
+    assert abs(a - b) <= 1e-13 * abs(a)
+    (mr, vr), (mf, vf) = ref.marginals(rev), ref.marginals(model)
+    np.testing.assert_allclose(np.asarray(vr), np.asarray(vf)[::-1], rtol=1e-13)
+    np.testing.assert_allclose(np.asarray(mr), np.asarray(mf)[::-1], rtol=1e-13, atol=1e-15)
