@@ -323,7 +323,7 @@ def lti_interface_leg(tgp, torch, model, y, T, d, local, steps):
     R_new = np.array([0.05])
     t, k = timed(lambda: tgp.logpdf(tgp.replace_observation_noise_cov(tgp.posterior(model, y), R_new), y_new), steps)
     out["posterior_logpdf"] = dict(ms=t * 1e3, steps_per_s=T / t, bytes_per_step=40, kernels_ms=k,
-                                   note="kernels_ms lists the prior handle's kernel only; the pair pass and the joint model's logpdf run beside it")
+                                   note="two logpdf launches on the prior's handle (the joint model through tgp_logpdf_noise) + the pair pass (k_pair_statistic, not in kernels_ms)")
     del y_new
     t, k = timed(lambda: tgp._filter(model, y), steps)
     out["filter"] = dict(ms=t * 1e3, steps_per_s=T / t, bytes_per_step=8 * (1 + d + d * d), kernels_ms=k)
