@@ -24,8 +24,14 @@
  *   - ownership: host pointers are read/written during the call only and never retained. Device pointers
  *     (TGP_DEVICE_PTRS / TGP_IN_DEVICE / TGP_OUT_DEVICE) are BORROWED: model arrays must stay alive until
  *     the next tgp_model_set / tgp_destroy, per-call arrays until the call returns.
- *   - threading: calls on one handle are serialised by the caller; one HIP stream per handle; every call
- *     returns with its results complete (blocking). Distinct handles are independent.
+ *   - threading: calls on one handle are serialised by the caller; every call returns with its results complete
+ *     (blocking). Distinct handles may be used from distinct threads. A handle's HIP stream comes from a small
+ *     per-device POOL (8 light + 2 heavy streams, handed out round robin: a stream is an HSA queue, and a process
+ *     that keeps thousands of models alive must not hold thousands of them): handles k and k + 8 share a stream,
+ *     and calls of handles that share one serialise -- on the device, and on the host through the stream's lock,
+ *     which a call holds from entry to return (so graph capture, the pinned-memory hand-overs of the one-launch
+ *     paths and the caching allocator never see a second thread on their stream). A stream substituted with
+ *     tgp_set_stream is outside the pool and its lock: keep it to one thread at a time.
  *   - device inputs (TGP_IN_DEVICE) must be COMPLETE when the call is made: the library's streams do not wait
  *     for the stream that produced them (the Python mirror synchronises torch's current stream before a call on
  *     torch tensors; the Julia glue passes host arrays). Several one-launch paths talk to the host through pinned memory while

@@ -511,6 +511,12 @@ struct tgp_handle {
 
     int fail(int code, const std::string& msg) {
         err = msg;
+        // a runtime error may leave a kernel of this call in flight: drain the stream before the caller can drop the handle, so that no block the
+        // caching allocator parks (tgp_alloc.hpp) is still in use by the device (round-5 advice)
+        if (code == TGP_EHIP && stream != nullptr) {
+            (void)hipStreamSynchronize(stream);
+            (void)hipGetLastError();
+        }
         return code;
     }
 };
@@ -1274,7 +1280,7 @@ int modal_call(tgp_handle* h, const double* y, uint32_t flags, const double* Rne
     mh.A = q; mh.a = q + dd; mh.Q = q + dd + d; mh.H = q + 2 * dd + d; mh.hh = q + 2 * dd + 2 * d; mh.R = h->has_R_over ? &h->R_over : q + 2 * dd + 2 * d + 1;
     mh.x0m = h->x0m.data();
     mh.x0P = h->x0P.data();
-    if (!tgp_modal::plan(h->modal, mh, h->T)) {
+    if (!tgp_modal::plan(h->modal, mh, h->T, /*logpdf_only=*/mean_out == nullptr && var_out == nullptr)) {
         h->modal_state = -1;
         if (getenv("TGP_STEADY_DEBUG") != nullptr) {
             const tgp_plan::Info& in = tgp_modal::last_plan(h->modal);
@@ -1315,7 +1321,8 @@ int modal_call(tgp_handle* h, const double* y, uint32_t flags, const double* Rne
     TRY(copy_back(h, mean_out, dm, nT, odev));
     TRY(copy_back(h, var_out, dv, nT, odev));
     if (h->timing) (void)hipEventRecord(h->ev[3], h->stream);
-    HIPCHK(hipStreamSynchronize(h->stream));
+    // (a logpdf-only call on the streaming kernel with the end-of-kernel flag: nothing but the triples in pinned memory to wait for)
+    if (h->timing || h->profile || !tgp_modal::await_done(h->modal)) HIPCHK(hipStreamSynchronize(h->stream));
     if (dbg) {
         const auto tp4 = std::chrono::steady_clock::now();
         auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
@@ -1394,7 +1401,8 @@ int sweep_call(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t 
     const size_t nT = (size_t)h->T * sizeof(double);
     int W = h->sweep_W, Wb = h->sweep_Wb;
     for (int64_t& v : h->sweep_info) v = 0;
-    for (int attempt = 0; attempt < 4; ++attempt) {
+    // inputs and outputs are staged ONCE, in front of the attempts (round-5 advice: a host-resident series was uploaded again by every retry)
+    {
         std::string why;
         tgp_sweep::force_geometry(h->sweep, h->sweep_fC, h->sweep_fW, h->sweep_fWb);
         if (!tgp_sweep::plan(h->sweep, mh, h->T, W, Wb, h->num_cu, &why)) {
@@ -1402,14 +1410,25 @@ int sweep_call(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t 
             h->sweep_state = -1;
             return TGP_OK;
         }
-        CallTimer tm(h, /*clear=*/false);
-        const void* pR = nullptr;
-        if (mean_out) TRY(stage_in(h, h->bRnew, Rnew, rshared ? sizeof(double) : nT, idev, &pR));
-        TRY(set_obs(h, y, missing, flags));
-        tm.inputs_done();
-        double *dm = nullptr, *dv = nullptr;
-        TRY(stage_out(h, h->bo1, mean_out, nT, odev, &dm));
-        TRY(stage_out(h, h->bo2, var_out, nT, odev, &dv));
+    }
+    CallTimer tm(h, /*clear=*/false);
+    const void* pR = nullptr;
+    if (mean_out) TRY(stage_in(h, h->bRnew, Rnew, rshared ? sizeof(double) : nT, idev, &pR));
+    TRY(set_obs(h, y, missing, flags));
+    tm.inputs_done();
+    double *dm = nullptr, *dv = nullptr;
+    TRY(stage_out(h, h->bo1, mean_out, nT, odev, &dm));
+    TRY(stage_out(h, h->bo2, var_out, nT, odev, &dv));
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        if (attempt > 0) {
+            std::string why;
+            tgp_sweep::force_geometry(h->sweep, h->sweep_fC, h->sweep_fW, h->sweep_fWb);
+            if (!tgp_sweep::plan(h->sweep, mh, h->T, W, Wb, h->num_cu, &why)) {
+                if (dbg) fprintf(stderr, "[tgp sweep] does not apply: %s\n", why.c_str());
+                h->sweep_state = -1;
+                return TGP_OK;
+            }
+        }
         tgp_sweep::Call c;
         c.T = h->T;
         c.y = h->mv.y;
@@ -1439,6 +1458,7 @@ int sweep_call(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t 
         h->sweep_info[1] = C; h->sweep_info[2] = w; h->sweep_info[3] = wb; h->sweep_info[4] = nw; h->sweep_info[5] = attempt + 1; h->sweep_info[6] = status;
         if (dbg) fprintf(stderr, "[tgp sweep] attempt %d: C %d W %d Wb %d waves %lld status %d dist %.3g / %.3g\n", attempt, C, w, wb, (long long)nw, status, h->sweep_dist[0], h->sweep_dist[1]);
         if (status & 12) {      // not positive definite / non-finite values: the general engine reports it the way it always has
+            if (status & 4) h->sweep_state = -1;      // (a property of the model, not of this series: later calls do not pay for a launch that cannot serve them)
             return TGP_OK;
         }
         if (status & 3) {       // a warm-up was too short: longer ones (a forced geometry is a test's: report, do not repair)
@@ -1545,6 +1565,30 @@ bool heavy_stream(int device, hipStream_t s) {
     return false;
 }
 bool pooled_stream(int device) { return device >= 0 && device < kStreamPoolDevices; }
+// Handles that share a pooled stream also share its LOCK for the length of a call (round-5 advice): the one-launch kernels and their host halves
+// talk through pinned flags and watch the stream with hipStreamQuery, graph capture owns the stream while it lasts, and the caching allocator
+// assumes that a parked block is not in use -- none of which holds if a second thread enqueues on the same stream mid-call.  Calls of handles on
+// one stream serialise on the device anyway; with the lock they serialise on the host as well.  A stream the caller substituted (tgp_set_stream)
+// is the caller's to keep to one thread at a time.
+std::recursive_mutex g_stream_locks[kStreamPoolDevices][kStreamPool + kHeavyPool];
+std::recursive_mutex* stream_lock_of(int device, hipStream_t s) {
+    if (device < 0 || device >= kStreamPoolDevices || s == nullptr) return nullptr;
+    for (int k = 0; k < kStreamPool + kHeavyPool; ++k)
+        if (g_streams[device][k] == s) return &g_stream_locks[device][k];
+    return nullptr;
+}
+struct StreamGuard {
+    std::recursive_mutex* m = nullptr;
+    explicit StreamGuard(const tgp_handle* h) {
+        if (h && h->stream != nullptr && h->stream == h->own_stream) m = stream_lock_of(h->device, h->stream);
+        if (m) m->lock();
+    }
+    ~StreamGuard() {
+        if (m) m->unlock();
+    }
+    StreamGuard(const StreamGuard&) = delete;
+    StreamGuard& operator=(const StreamGuard&) = delete;
+};
 }  // namespace
 
 extern "C" {
@@ -2135,6 +2179,7 @@ int tgp_model_set_sde(tgp_handle* h, int64_t T, int d, int ordering, uint32_t fl
 
 int tgp_model_set_x0(tgp_handle* h, const double* x0m, const double* x0P) {
     if (h) drop_graphs(h);
+    StreamGuard stream_guard_(h);
     TRY(check_ready(h));
     if (!x0m || !x0P) return h->fail(TGP_EINVAL, "null x0");
     h->x0m.assign(x0m, x0m + h->d);
@@ -2157,6 +2202,7 @@ static int smooth_lti_call(tgp_handle* h, const double* y, uint32_t flags, const
 static bool lti_but_offset(const tgp_handle* h);
 
 int tgp_logpdf(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t flags, double* out) {
+    StreamGuard stream_guard_(h);
     TRY(check_ready(h, /*general=*/false));
     if (!out) return h->fail(TGP_EINVAL, "out is NULL");
     h->steady2_last = false;
@@ -2228,6 +2274,7 @@ int tgp_logpdf(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t 
 // with Rbar -- without binding a second model.  The one-launch paths only (their plans are host functions of the blocks, rebuilt per call):
 // Forward LTI models, scalar observations, no missing data; TGP_EUNSUPPORTED otherwise (bind the model with the new variance instead).
 int tgp_logpdf_noise(tgp_handle* h, const double* y, uint32_t flags, double R, double* out) {
+    StreamGuard stream_guard_(h);
     TRY(check_ready(h, /*general=*/false));
     if (!out || !y) return h->fail(TGP_EINVAL, "tgp_logpdf_noise: null argument");
     if (!(R > 0.0) || !std::isfinite(R)) return h->fail(TGP_EINVAL, "tgp_logpdf_noise: the noise variance must be positive");
@@ -2271,6 +2318,7 @@ static bool modal_host_model(tgp_handle* h, tgp_plan::ModelHost& mh) {
 
 int tgp_segment_plan(tgp_handle* h, int64_t T_total, int nseg, const int64_t* bounds, int32_t* applies, int32_t* halo) {
     if (!h || !bounds || !applies || !halo || nseg < 1 || T_total <= 0) return TGP_EINVAL;
+    StreamGuard stream_guard_(h);
     TRY(check_ready(h, /*general=*/false));
     *applies = 0;
     *halo = 0;
@@ -2300,6 +2348,7 @@ int tgp_segment_logpdf_and_posterior_marginals(tgp_handle* h, int64_t T_total, i
                                                const double* y_right, const double* Rnew, uint32_t flags, double* mean_out, double* var_out,
                                                double* lml_share) {
     if (!h || !lml_share) return TGP_EINVAL;
+    StreamGuard stream_guard_(h);
     TRY(check_ready(h, /*general=*/false));
     tgp_plan::ModelHost mh;
     if (!modal_host_model(h, mh)) return h->fail(TGP_EUNSUPPORTED, "tgp_segment_*: not a model of the one-launch path (ask tgp_segment_plan first)");
@@ -2524,6 +2573,7 @@ static int adjoint_lti_call(tgp_handle* h, const double* y, uint32_t flags, doub
 
 int tgp_logpdf_adjoint(tgp_handle* h, const double* y, uint32_t flags, double* lml_out, double* gA, double* ga, double* gQ, double* gH,
                        double* ghh, double* gR, double* gx0m, double* gx0P) {
+    StreamGuard stream_guard_(h);
     TRY(check_ready(h, /*general=*/false));
     h->dense_last_n0 = -1;
     h->modal_last = false;
@@ -2828,6 +2878,7 @@ static int smooth_lti_call(tgp_handle* h, const double* y, uint32_t flags, const
 // noise input.  TGP_EUNSUPPORTED: the caller takes the evaluated route (tgp_posterior, then tgp_rand on the Reverse model).
 int tgp_posterior_rand(tgp_handle* h, const double* y, const double* Rnew, const double* eps_t, const double* eps_e, const double* eps_0, uint32_t flags,
                        double* y_out) {
+    StreamGuard stream_guard_(h);
     TRY(check_ready(h, /*general=*/false));
     if (!y || !Rnew || !eps_t || !eps_e || !eps_0 || !y_out) return h->fail(TGP_EINVAL, "tgp_posterior_rand: null argument");
     h->steady2_last = false;
@@ -2930,6 +2981,7 @@ int tgp_pair_statistic(tgp_handle* h, int64_t n, const double* y, const uint8_t*
 }
 
 int tgp_filter(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t flags, double* m_out, double* P_out, double* lml_out) {
+    StreamGuard stream_guard_(h);
     TRY(check_ready(h, /*general=*/false));
     h->dense_last_n0 = -1;
     h->modal_last = false;
@@ -3033,6 +3085,7 @@ static int posterior_lti_call(tgp_handle* h, const double* y, uint32_t flags, do
 
 int tgp_posterior(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t flags, double* G, double* g, double* L,
                   double* xfm, double* xfP) {
+    StreamGuard stream_guard_(h);
     TRY(check_ready(h, /*general=*/false));
     if ((G || g || L) && !(G && g && L)) return h->fail(TGP_EINVAL, "G, g, L must be given together");
     h->dense_last_n0 = -1;
@@ -3134,6 +3187,7 @@ static int smoother_backward_impl(tgp_handle* h, const double* xs_dev, const dou
 
 int tgp_posterior_marginals(tgp_handle* h, const double* y, const uint8_t* missing, const double* Rnew, uint32_t flags,
                             double* mean_out, double* var_out, double* lml_out) {
+    StreamGuard stream_guard_(h);
     TRY(check_ready(h, /*general=*/false));
     if (!Rnew || !mean_out || !var_out) return h->fail(TGP_EINVAL, "null Rnew / output");
     if (h->ordering != 0) return h->fail(TGP_EUNSUPPORTED, "posterior of a Reverse-ordered model is not implemented on the device");
@@ -3232,6 +3286,7 @@ int tgp_logpdf_and_posterior_marginals(tgp_handle* h, const double* y, const uin
 
 int tgp_posterior_marginals_at(tgp_handle* h, const double* y, const uint8_t* missing, int pn, const double* Hn, const double* hn,
                                const double* Rn, uint32_t flags, double* mean_out, double* var_out, double* lml_out) {
+    StreamGuard stream_guard_(h);
     TRY(check_ready(h));
     TRY(scan_only(h, "tgp_posterior_marginals_at"));
     if (pn < 1 || pn > 4096 || !Hn || !hn || !Rn || !mean_out || !var_out) return h->fail(TGP_EINVAL, "bad alternative emission block / output");
@@ -3276,6 +3331,7 @@ int tgp_posterior_marginals_at(tgp_handle* h, const double* y, const uint8_t* mi
 
 int tgp_smoother_forward(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t flags, double* rev_elem_out, double* xfm,
                          double* xfP, double* lml_out) {
+    StreamGuard stream_guard_(h);
     TRY(check_ready(h));
     TRY(scan_only(h, "tgp_smoother_forward"));
     if (h->ordering != 0) return h->fail(TGP_EUNSUPPORTED, "posterior of a Reverse-ordered model is not implemented on the device");
@@ -3296,6 +3352,7 @@ int tgp_smoother_forward(tgp_handle* h, const double* y, const uint8_t* missing,
 
 int tgp_smoother_backward(tgp_handle* h, const double* xs_m, const double* xs_P, const double* Rnew, uint32_t flags, double* mean_out,
                           double* var_out) {
+    StreamGuard stream_guard_(h);
     TRY(check_ready(h));
     TRY(scan_only(h, "tgp_smoother_backward"));
     if (!h->smoother_valid) return h->fail(TGP_EINVAL, "tgp_smoother_backward needs a preceding tgp_smoother_forward");
@@ -3481,6 +3538,7 @@ static int lti_marginals(tgp_handle* h, double* dm, double* dv, bool* served) {
 }
 
 int tgp_marginals(tgp_handle* h, uint32_t flags, double* mean_out, double* var_out) {
+    StreamGuard stream_guard_(h);
     TRY(check_ready(h, /*general=*/false));
     if (!mean_out || !var_out) return h->fail(TGP_EINVAL, "null output");
     const bool odev = (flags & TGP_OUT_DEVICE) != 0;
@@ -3520,6 +3578,7 @@ int tgp_marginals(tgp_handle* h, uint32_t flags, double* mean_out, double* var_o
 }
 
 int tgp_rand(tgp_handle* h, const double* eps_t, const double* eps_e, const double* eps_0, uint32_t flags, double* y_out) {
+    StreamGuard stream_guard_(h);
     TRY(check_ready(h, /*general=*/false));
     if (!eps_t || !eps_e || !eps_0 || !y_out) return h->fail(TGP_EINVAL, "null eps / output");
     const bool idev = (flags & TGP_IN_DEVICE) != 0, odev = (flags & TGP_OUT_DEVICE) != 0;
@@ -3600,6 +3659,7 @@ int tgp_rand(tgp_handle* h, const double* eps_t, const double* eps_e, const doub
 int tgp_logpdf_grad(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t flags, int nparams, const double* dA,
                     const double* da, const double* dQ, const double* dH, const double* dh, const double* dR, const double* dx0m,
                     const double* dx0P, double* lml_out, double* grad_out) {
+    StreamGuard stream_guard_(h);
     TRY(check_ready(h));
     TRY(scan_only(h, "tgp_logpdf_grad"));
     if (nparams < 1 || !grad_out) return h->fail(TGP_EINVAL, "nparams must be >= 1 and grad_out non-null");
@@ -3682,6 +3742,7 @@ int tgp_logpdf_grad(tgp_handle* h, const double* y, const uint8_t* missing, uint
 int tgp_logpdf_grad_sde(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t flags, int nparams, const double* dF,
                         const double* dPinf, const double* dA1, const double* dQ1, const double* da, const double* dH, const double* dh,
                         const double* dR, const double* dx0m, const double* dx0P, double rel_step, double* lml_out, double* grad_out) {
+    StreamGuard stream_guard_(h);
     TRY(check_ready(h));
     TRY(scan_only(h, "tgp_logpdf_grad_sde"));
     if (nparams < 1 || !grad_out) return h->fail(TGP_EINVAL, "nparams must be >= 1 and grad_out non-null");
@@ -4204,6 +4265,7 @@ extern "C" {
 int tgp_elem_size(int kind, int d) { return kind == 0 ? felem_size(d) : aelem_size(d); }
 
 int tgp_segment_reduce(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t flags, double* elem_out) {
+    StreamGuard stream_guard_(h);
     TRY(check_ready(h));
     TRY(scan_only(h, "tgp_segment_reduce"));
     if (!elem_out) return h->fail(TGP_EINVAL, "elem_out is NULL");
@@ -4223,6 +4285,7 @@ int tgp_shard_slot_size(int phase, int d) {
 }
 
 int tgp_shard_reduce(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t flags, double* slot_dev) {
+    StreamGuard stream_guard_(h);
     TRY(check_ready(h));
     TRY(scan_only(h, "tgp_shard_reduce"));
     if (!slot_dev) return h->fail(TGP_EINVAL, "slot_dev is NULL");
@@ -4237,6 +4300,7 @@ int tgp_shard_reduce(tgp_handle* h, const double* y, const uint8_t* missing, uin
 }
 
 int tgp_shard_fold(tgp_handle* h, const double* gathered_dev, int world, int rank) {
+    StreamGuard stream_guard_(h);
     TRY(check_ready(h));
     TRY(scan_only(h, "tgp_shard_fold"));
     if (!gathered_dev || world < 1 || rank < 0 || rank >= world) return h->fail(TGP_EINVAL, "bad gathered buffer / world / rank");
@@ -4251,6 +4315,7 @@ int tgp_shard_fold(tgp_handle* h, const double* gathered_dev, int world, int ran
 }
 
 int tgp_shard_logpdf(tgp_handle* h, double* stats_dev) {
+    StreamGuard stream_guard_(h);
     TRY(check_ready(h));
     TRY(scan_only(h, "tgp_shard_logpdf"));
     if (!stats_dev) return h->fail(TGP_EINVAL, "stats_dev is NULL");
@@ -4263,6 +4328,7 @@ int tgp_shard_logpdf(tgp_handle* h, double* stats_dev) {
 }
 
 int tgp_shard_smoother_forward(tgp_handle* h, double* slot_dev) {
+    StreamGuard stream_guard_(h);
     TRY(check_ready(h));
     TRY(scan_only(h, "tgp_shard_smoother_forward"));
     if (!slot_dev) return h->fail(TGP_EINVAL, "slot_dev is NULL");
@@ -4279,6 +4345,7 @@ int tgp_shard_smoother_forward(tgp_handle* h, double* slot_dev) {
 
 int tgp_shard_smoother_backward(tgp_handle* h, const double* gathered_dev, int world, int rank, const double* Rnew, uint32_t flags,
                                 double* mean_out, double* var_out, double* lml_out) {
+    StreamGuard stream_guard_(h);
     TRY(check_ready(h));
     TRY(scan_only(h, "tgp_shard_smoother_backward"));
     if (!h->smoother_valid) return h->fail(TGP_EINVAL, "tgp_shard_smoother_backward needs a preceding tgp_shard_smoother_forward");
@@ -4313,6 +4380,7 @@ int tgp_shard_smoother_backward(tgp_handle* h, const double* gathered_dev, int w
 int tgp_shard_steady_slot_size(int d) { return tgp_steady::supports(d) ? (int)tgp_steady::shard_slot_size(d) : 0; }
 
 int tgp_shard_steady_begin(tgp_handle* h, const double* y, uint32_t flags, int first, int last, int posterior, double* slot_dev) {
+    StreamGuard stream_guard_(h);
     TRY(check_ready(h, /*general=*/false));
     h->shard2_open = false;
     if (!slot_dev) return h->fail(TGP_EINVAL, "slot_dev is NULL");
@@ -4335,6 +4403,7 @@ int tgp_shard_steady_begin(tgp_handle* h, const double* y, uint32_t flags, int f
 
 int tgp_shard_steady_finish(tgp_handle* h, const double* gathered_dev, int world, int rank, const double* Rnew, uint32_t flags, double* mean_out,
                             double* var_out, double* lml_out, int* served) {
+    StreamGuard stream_guard_(h);
     TRY(check_ready(h, /*general=*/false));
     if (!h->shard2_open) return h->fail(TGP_EINVAL, "tgp_shard_steady_finish needs a preceding tgp_shard_steady_begin");
     h->shard2_open = false;

@@ -3,6 +3,7 @@
 // whole-line output stores, uniform coefficients through the kernel-argument segment).
 #include "tgp_modal.hpp"
 #include "tgp_alloc.hpp"
+#include "tgp_lml.hpp"
 
 #include <chrono>
 #include <cmath>
@@ -1079,6 +1080,12 @@ struct Engine {
     double host_quad = 0.0;
     tgp_plan::ModelHost mh{};
     long long hh_T = 0;
+    // the streaming logpdf kernel (tgp_lml.hip): a logpdf-only call over the whole series
+    bool lml = false;
+    tgp_lml::Geometry lg{};
+    double lWt[tgp_plan::kMaxD * tgp_plan::kMaxD];
+    unsigned* lcounter = nullptr;      // device memory: the workgroups' arrival count (zero between launches)
+    bool lml_flagged = false;          // the launched kernel raises flags[1] at its end
 };
 namespace {
 constexpr size_t kHH = tgp_plan::kHeadMax;
@@ -1097,11 +1104,13 @@ void destroy(Engine* e) {
     if (e->hhead) (void)tgp_alloc::host_free(e->hhead);
     if (e->dflat) (void)tgp_alloc::dev_free(e->dflat);
     if (e->part) (void)tgp_alloc::host_free(e->part);
+    if (e->lcounter) (void)tgp_alloc::dev_free(e->lcounter);
     delete e;
 }
 
 const tgp_plan::Info& last_plan(const Engine* e) { return e->info; }
 const char* kernel_name(const Engine* e, bool post) {
+    if (e->lml && !post) return e->lg.n == 32 ? "k_lml_stream<32>" : "k_lml_stream<16>";
     return e->nw == 8 ? (post ? "k_steady_one<8x8,posterior>" : "k_steady_one<8x8,logpdf>") : (post ? "k_steady_one<16x8,posterior>" : "k_steady_one<16x8,logpdf>");
 }
 const tgp_plan::Modal& last_modal(const Engine* e) { return e->md; }
@@ -1337,8 +1346,25 @@ static int build_and_ship_tables(Engine* e, long long T, int nstages = 3) {
     return tgp_plan::kOk;
 }
 
-bool plan(Engine* e, const tgp_plan::ModelHost& m, long long T) {
+static bool lml_stream_enabled() {      // TGP_LML_STREAM=0: logpdf on k_steady_one as in round 5 (A/B runs)
+    static const bool on = [] {
+        const char* v = std::getenv("TGP_LML_STREAM");
+        return !(v && v[0] == '0');
+    }();
+    return on;
+}
+
+static bool lml_done_flag_enabled() {      // TGP_LML_DONE_FLAG=1: the kernel's last workgroup reports the end through pinned memory (A/B runs; default off)
+    static const bool on = [] {
+        const char* v = std::getenv("TGP_LML_DONE_FLAG");
+        return v && v[0] == '1';
+    }();
+    return on;
+}
+
+bool plan(Engine* e, const tgp_plan::ModelHost& m, long long T, bool logpdf_only) {
     e->began = false;
+    e->lml = false;
     if (!host_cpu_ok()) {
         e->info = tgp_plan::Info{};
         e->info.why = tgp_plan::kEigFail;
@@ -1372,6 +1398,35 @@ bool plan(Engine* e, const tgp_plan::ModelHost& m, long long T) {
     layout_tables(e);
     e->mh = m;
     e->hh_T = T;
+    if (logpdf_only && lml_stream_enabled()) {
+        // the streaming logpdf kernel: no tables (the head runs on the host from build_core's gains), no wait inside the kernel
+        e->lg = tgp_lml::choose_geometry(e->md, T);
+        const size_t need = tgp_lml::part_doubles(e->md.d) + 64;
+        if (need > e->part_cap) {
+            if (e->part) (void)tgp_alloc::host_free(e->part);
+            e->part = nullptr;
+            e->part_cap = 0;
+            if (tgp_alloc::host_malloc(reinterpret_cast<void**>(&e->part), need * sizeof(double), hipHostMallocDefault) != hipSuccess) {
+                e->info.why = tgp_plan::kEigFail;
+                return false;
+            }
+            e->part_cap = need;
+        }
+        if (!e->lcounter) {
+            if (tgp_alloc::dev_malloc(reinterpret_cast<void**>(&e->lcounter), 64) != hipSuccess || hipMemset(e->lcounter, 0, 64) != hipSuccess) {
+                e->lcounter = nullptr;
+                e->info.why = tgp_plan::kEigFail;
+                return false;
+            }
+        }
+        tgp_lml::quad_table(e->md, e->lg.first_tile, e->lWt);
+        e->deferred = false;
+        e->hosthead = false;
+        e->lml = true;
+        e->nwg = e->lg.nwg;
+        e->began = true;
+        return true;
+    }
     // the tables half: behind the launch when the series is certainly longer than head + tail (the kernel's head wave and last tiles wait
     // for the flag), else right here
     // (measured again in round 5, d = 3: with the tables behind the launch a call takes 63.5 us against 68.7 with them in front of it, the
@@ -1432,6 +1487,16 @@ void raise_flag(long long* f, long long v) {
 }  // namespace
 
 bool complete(Engine* e, long long T) {
+    if (e->began && e->lml) {
+        // the head's forward recursion, as soon as the kernel has handed its observations over (or the stream has drained)
+        const bool ok = await_host_flag(hh_flag(e), 2 * e->seq, e->stream);
+        if (!ok) {
+            e->info.why = tgp_plan::kEigFail;
+            return false;
+        }
+        tgp_plan::modal_head_forward_any(e->mh, e->md, *e->tab, hh_in(e), e->hr, hh_z0(e), &e->host_quad);
+        return true;
+    }
     if (!e->began || !e->deferred) return true;
     e->deferred = false;
     if (!e->hosthead) {
@@ -1482,6 +1547,13 @@ bool complete(Engine* e, long long T) {
     return true;
 }
 
+// The kernel of a logpdf-only call produces nothing but the workgroups' triples in pinned memory; its last workgroup says so there as well
+// (flags[1]): the host needs no hipStreamSynchronize to read them (the stream itself stays ordered: whatever is enqueued next runs behind the kernel).
+bool await_done(Engine* e) {
+    if (!e || !e->began || !e->lml || !e->lml_flagged) return false;
+    return await_host_flag(hh_flag(e) + 1, 2 * e->seq, e->stream);
+}
+
 // A caller that leaves between enqueue() and complete() (an error return in between) must not leave the kernel waiting: raises the flags of
 // a deferred plan with the failure bit (what the kernel writes is then discarded by whoever reads it).  Harmless otherwise.
 void abandon(Engine* e) {
@@ -1502,6 +1574,26 @@ int enqueue(Engine* e, hipStream_t stream, const Call& c, const char** kname, st
         return (int)hipErrorInvalidValue;
     }
     int r = 0;
+    if (e->lml) {
+        if (c.mean != nullptr || c.seg_lo != 0 || (c.seg_hi >= 0 && c.seg_hi < c.T)) {
+            if (err) *err = "tgp_modal::enqueue: the plan was made for a logpdf-only call over the whole series";
+            return (int)hipErrorInvalidValue;
+        }
+        tgp_lml::Buffers b;
+        b.part = e->part;
+        b.head_in = hh_in(e);
+        b.flags = hh_flag(e);
+        b.counter = e->lcounter;
+        b.done_flag = lml_done_flag_enabled();
+        e->lml_flagged = b.done_flag;
+        e->post = false;
+        e->stream = stream;
+        e->owns_head = true;
+        e->nwg_local = e->lg.nwg;
+        r = tgp_lml::enqueue(stream, e->md, e->lg, c.T, c.y, b, e->seq, e->lWt, kname);
+        if (r != 0 && err) *err = std::string("tgp_lml: launch: ") + hipGetErrorString((hipError_t)r);
+        return r;
+    }
     switch (e->md.d) {
         case 1: r = launch<1>(e, stream, c, kname); break;
         case 2: r = launch<2>(e, stream, c, kname); break;
@@ -1520,6 +1612,11 @@ int enqueue(Engine* e, hipStream_t stream, const Call& c, const char** kname, st
 // After the stream has passed the kernel: the launch's share of the quadratic form -- the sum of r^2 over the steps it owns behind the head
 // and (the launch that holds the head) the head's sum of r^2 / S_t; fixed summation order.
 void finish_parts(const Engine* e, double* ssq, double* head_quad) {
+    if (e->lml) {
+        *ssq = tgp_lml::finish(e->md, e->lg, e->part, e->hhead + 4 * kHH, e->lWt);
+        *head_quad = e->host_quad;
+        return;
+    }
     double s = 0.0;
     for (long long g = 0; g < e->nwg_local; ++g) s += e->part[g];
     *ssq = s;
@@ -1529,7 +1626,7 @@ void finish_parts(const Engine* e, double* ssq, double* head_quad) {
 // ... and the log marginal likelihood of a call that ran the whole series.
 double finish(const Engine* e, long long T) {
     const Modal& md = e->md;
-    if (std::getenv("TGP_STEADY_DEBUG") != nullptr) {
+    if (!e->lml && std::getenv("TGP_STEADY_DEBUG") != nullptr) {
         const double* q = e->part + e->nwg_local;
         fprintf(stderr, "[tgp modal] d %d n0 %d nhs %d n1 %d halo %d geometry %dx%d workgroups %lld | workgroup 0 (us from its start): tables ready %.1f, head forward done %.1f, head backward starts %.1f, done %.1f; last workgroup done %.1f\n",
                 md.d, md.n0, md.nhs, md.n1, md.halo, e->nw, e->sub, e->nwg_local, (q[2] - q[1]) * 0.01, (q[3] - q[1]) * 0.01, (q[4] - q[1]) * 0.01, (q[5] - q[1]) * 0.01, (q[6] - q[1]) * 0.01);

@@ -31,7 +31,10 @@ struct Engine;
 Engine* create();
 void destroy(Engine*);
 // Host half: builds the plan of a T-step call of the model (nothing is kept from earlier calls).  false: the path does not apply (last_plan().why).
-bool plan(Engine*, const tgp_plan::ModelHost&, long long T);
+// logpdf_only: the call will be a logpdf over the whole series (no outputs, no segment) -- served by the streaming kernel of tgp_lml.hip.
+bool plan(Engine*, const tgp_plan::ModelHost&, long long T, bool logpdf_only = false);
+// the host's wait for a logpdf-only call's kernel: true once its last workgroup has said so through pinned memory (false: use the stream)
+bool await_done(Engine*);
 // Enqueues the kernel of the planned call on `stream` (no synchronisation); *kname names it for the profile.
 int enqueue(Engine*, hipStream_t stream, const Call&, const char** kname, std::string* err);
 // Right behind enqueue: the tables half of the plan when plan() left it for now (the kernel's head wave and last tiles wait for it).

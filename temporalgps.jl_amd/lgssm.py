@@ -902,19 +902,35 @@ def _posterior_rand_one_launch(post, eps_t, eps_e, eps_0):
     if dev != _lib.is_device(y) or (not dev and np.isnan(np.asarray(_to_numpy(y), dtype=np.float64)).any()):
         return None
     hd = prior.handle()
+    T, d = prior.T, prior.dim
     if dev:
         import torch
-        et, ee, yy = eps_t.contiguous(), eps_e.contiguous(), y.contiguous()
-        Rn = R_new.contiguous() if _is_torch(R_new) else torch.as_tensor(np.atleast_1d(np.asarray(_to_numpy(R_new), dtype=np.float64)), device=yy.device)
+        # every buffer the kernel reads is float64, contiguous, of exactly the size it indexes, and on ONE device (round-5 advice: a float32 y or a
+        # short eps_t would be read past its end)
+        if not (_is_torch(eps_e) and _lib.is_device(eps_e)) or eps_t.numel() != T * d or y.numel() != T or eps_e.numel() != T:
+            return None
+        et = eps_t.to(torch.float64).reshape(T, d).contiguous()
+        ee = eps_e.to(torch.float64).reshape(T).contiguous()
+        yy = y.to(torch.float64).reshape(T).contiguous()
+        if _is_torch(R_new):
+            Rn = R_new.to(device=yy.device, dtype=torch.float64).reshape(-1).contiguous()
+        else:
+            Rn = torch.as_tensor(np.atleast_1d(np.asarray(_to_numpy(R_new), dtype=np.float64)).reshape(-1), device=yy.device)
+        if et.device != yy.device or ee.device != yy.device:
+            return None
         _sync_torch(et)
     else:
-        et = np.ascontiguousarray(_to_numpy(eps_t), dtype=np.float64)
+        if np.size(_to_numpy(eps_t)) != T * d or np.size(_to_numpy(y)) != T:
+            return None
+        et = np.ascontiguousarray(_to_numpy(eps_t), dtype=np.float64).reshape(T, d)
         ee = np.ascontiguousarray(_to_numpy(eps_e), dtype=np.float64)
-        yy = np.ascontiguousarray(_to_numpy(y), dtype=np.float64)
+        yy = np.ascontiguousarray(_to_numpy(y), dtype=np.float64).reshape(T)
         Rn = np.ascontiguousarray(np.atleast_1d(_to_numpy(R_new)), dtype=np.float64)
     if Rn.ndim != 1 or Rn.shape[0] not in (1, prior.T) or tuple(ee.shape) != (prior.T,):
         return None
-    e0 = np.ascontiguousarray(_to_numpy(eps_0), dtype=np.float64)
+    e0 = np.ascontiguousarray(_to_numpy(eps_0), dtype=np.float64).reshape(-1)
+    if e0.shape[0] != d:
+        return None
     out = _out(prior, _osh(prior), dev)
     flags = ((_lib.IN_DEVICE | _lib.OUT_DEVICE) if dev else 0) | (_lib.SHARED_R if Rn.shape[0] == 1 else 0)
     try:

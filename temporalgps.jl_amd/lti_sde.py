@@ -61,6 +61,17 @@ def _same_inputs(x1, x2):
     return a.shape == b.shape and np.array_equal(a, b)
 
 
+def _same_sorted_inputs(x1, x2):
+    """the same inputs AND in time order: what the shortcuts of `rand` / `logpdf` of a posterior need -- the reference's chain
+    (posterior_lti_sde.jl:48-78) sorts the joined inputs (merge_datasets), the shortcuts bind the training inputs as they stand (round-5 advice)"""
+    if not _same_inputs(x1, x2):
+        return False
+    if isinstance(x1, RegularSpacing):
+        return x1.dt >= 0
+    t = _times(x1)
+    return bool(np.all(t[1:] >= t[:-1]))
+
+
 # ------------------------------------------------------------------------------------------ kernels
 class Kernel:
     def __add__(self, other):
@@ -545,7 +556,7 @@ class FinitePosteriorLTISDE:
 
     def _rand(self, rng):
         d = self.f.data
-        if _same_inputs(self.x, d["x"]) and not np.isnan(d["y"]).any():
+        if _same_sorted_inputs(self.x, d["x"]) and not np.isnan(d["y"]).any():
             # prediction inputs = training inputs: each joined pair of steps shares ONE latent state (dt = 0: A = I, Q = 0), so the draw at
             # the prediction step is h'x_t + sqrt(s_t) eps of the posterior's reverse-time chain over the T training steps -- the posterior
             # with its observation noise replaced, which is one launch on the prior's stationary structure (tgp_posterior_rand) instead
@@ -568,7 +579,7 @@ class FinitePosteriorLTISDE:
         y_pr = np.asarray(y_pr, dtype=np.float64)
         if y_pr.shape != (len(self.x),):
             raise ValueError("Dimension mismatch: one observation per prediction input")
-        if _same_inputs(self.x, d["x"]):
+        if _same_sorted_inputs(self.x, d["x"]):
             # prediction inputs = training inputs: every joined pair of steps is ONE latent value observed twice (dt = 0: A = I, Q = 0), so the
             # posterior over the T training steps with its noise replaced IS the model the chain below would build over 2T steps -- and its logpdf
             # needs no posterior: log p(y* | y) = log p(ybar) + pair - log p(y) (lgssm.py `_posterior_logpdf_pair`), two logpdf calls on the prior's
@@ -648,8 +659,13 @@ def _expm_small(X):
             f *= k
             S = S + Nk / f
         Nn = Nk @ N if n > 1 else N
-        scale = float(np.max(np.abs(N))) if n > 1 else 0.0
-        if float(np.max(np.abs(Nn))) <= 1e-14 * max(scale, 1e-300) ** n:
+        # the series stops at N^(n-1): what it leaves out is N^n / n! + N^(n+1) / (n+1)! + ...  Accepted only when its first two terms are below
+        # the rounding of exp(X)'s own entries -- an ABSOLUTE bound tied to S, not a ratio to max|N|^n (round-5 advice: a block-diagonal sum
+        # of two nearly equal stiff blocks can pass a ratio test while N is not nilpotent); beyond them the terms fall by |N| / k or, for a
+        # structurally nilpotent N, are rounding residue of the products themselves
+        nn = float(np.max(np.abs(Nn))) if n > 1 else 0.0
+        tol = 1e-13 * float(np.max(np.abs(S)))
+        if nn == 0.0 or (nn / (f * n) <= tol and nn * float(np.max(np.sum(np.abs(N), axis=1))) / (f * n * (n + 1)) <= tol):
             return np.exp(-lam) * S
     return expm(X)
 

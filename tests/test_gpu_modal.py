@@ -70,7 +70,7 @@ def check(tgp, model, y, Rn, T, expect_one=True, tol_m=1e-8):
     dm = device_model(tgp, model)
     lp, names = kernels_of(tgp, dm, lambda: tgp.logpdf(dm, y))
     if expect_one:
-        assert any(n.startswith("k_steady_one") and "logpdf" in n for n in names) and len(names) == 1, names
+        assert any(n.startswith("k_lml_stream") or (n.startswith("k_steady_one") and "logpdf" in n) for n in names) and len(names) == 1, names
         assert served(dm) > T - 700
     assert abs(lp - lp_ref) <= 1e-10 * abs(lp_ref), (lp, lp_ref)
     (mean, var), names = kernels_of(tgp, dm, lambda: tgp.posterior_marginals(dm, y, Rn))
