@@ -1,8 +1,10 @@
 """Round 6: a bare loop of headline calls for the profilers: python scripts/r06_lml_loop.py [logpdf|post|both] [n] [d]"""
 import ctypes
+import os
 import sys
 
-import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
 import torch
 
 import temporalgps_jl_amd as tgp

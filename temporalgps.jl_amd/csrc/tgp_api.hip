@@ -1309,7 +1309,7 @@ int modal_call(tgp_handle* h, const double* y, uint32_t flags, const double* Rne
     c.var = dv;
     {
         std::string err;
-        const char* kname = tgp_modal::kernel_name(h->modal, dm != nullptr);
+        const char* kname = tgp_modal::kernel_name(h->modal, c);
         LaunchScope ls(h, kname);
         if (tgp_modal::enqueue(h->modal, h->stream, c, &kname, &err) != 0) return h->fail(TGP_EHIP, err);
     }

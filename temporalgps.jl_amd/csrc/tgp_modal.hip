@@ -4,7 +4,9 @@
 #include "tgp_modal.hpp"
 #include "tgp_alloc.hpp"
 #include "tgp_lml.hpp"
+#include "tgp_post.hpp"
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -1086,6 +1088,7 @@ struct Engine {
     double lWt[tgp_plan::kMaxD * tgp_plan::kMaxD];
     unsigned* lcounter = nullptr;      // device memory: the workgroups' arrival count (zero between launches)
     bool lml_flagged = false;          // the launched kernel raises flags[1] at its end
+    void* pxch = nullptr;              // device memory: the exchange records of the streaming posterior kernel's runs (tgp_post.hpp)
 };
 namespace {
 constexpr size_t kHH = tgp_plan::kHeadMax;
@@ -1105,6 +1108,7 @@ void destroy(Engine* e) {
     if (e->dflat) (void)tgp_alloc::dev_free(e->dflat);
     if (e->part) (void)tgp_alloc::host_free(e->part);
     if (e->lcounter) (void)tgp_alloc::dev_free(e->lcounter);
+    if (e->pxch) (void)tgp_alloc::dev_free(e->pxch);
     delete e;
 }
 
@@ -1124,8 +1128,50 @@ static bool head_scans_enabled() {      // TGP_MODAL_HEAD_SCANS=0: the sequentia
     return on;
 }
 
+// The streaming posterior kernel (tgp_post.hip) serves a call over the WHOLE series with the head on the host and every series-sized
+// buffer on a 16-byte boundary; segments, in-kernel heads and odd pointers stay on k_steady_one.
+static bool use_post_stream(const Engine* e, const Call& c) {
+    if (c.mean == nullptr || !e->hosthead || c.seg_lo != 0 || (c.seg_hi >= 0 && c.seg_hi < c.T)) return false;
+    if (!tgp_post::applies(e->md, c.T)) return false;
+    auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    return al(c.y) && al(c.mean) && al(c.var) && (!c.rnew_per_step || al(c.Rnew));
+}
+
 template <int D>
 int launch(Engine* e, hipStream_t st, const Call& c, const char** kname) {
+    if (use_post_stream(e, c)) {
+        if (!e->pxch) {
+            if (tgp_alloc::dev_malloc(&e->pxch, tgp_post::xch_bytes()) != hipSuccess) return (int)hipErrorOutOfMemory;
+            if (hipMemsetAsync(e->pxch, 0, tgp_post::xch_bytes(), st) != hipSuccess) return (int)hipGetLastError();
+        }
+        const tgp_post::Geometry g = tgp_post::choose_geometry(e->md, c.T);
+        tgp_post::Call pc;
+        pc.T = c.T;
+        pc.y = c.y;
+        pc.Rnew = c.Rnew;
+        pc.rnew_per_step = c.rnew_per_step;
+        pc.mean = c.mean;
+        pc.var = c.var;
+        pc.htab = e->hflat;
+        pc.tvb_off = e->to.tvb;
+        pc.flag = reinterpret_cast<const long long*>(e->hflat + e->flat_cap);
+        pc.part = e->part;
+        pc.head_in = hh_in(e);
+        pc.z0p = hh_z0(e);
+        pc.zeta_out = hh_zeta(e);
+        pc.head_out = hh_out(e);
+        pc.hflag = hh_flag(e);
+        pc.seq = e->seq;
+        pc.xch = e->pxch;
+        e->post = true;
+        e->rnew_per_step = c.rnew_per_step;
+        e->stream = st;
+        e->wg0 = 0;
+        e->nwg_local = g.nwg;
+        e->owns_head = true;
+        e->hh_pending = true;
+        return tgp_post::enqueue(st, e->md, g, pc, kname);
+    }
     KArgs<D> ka;
     static_assert(sizeof(KArgs<D>) <= 4096, "the kernel-argument segment");
     std::memset(&ka, 0, sizeof ka);
@@ -1188,6 +1234,11 @@ int launch(Engine* e, hipStream_t st, const Call& c, const char** kname) {
     return (int)hipGetLastError();
 }
 }  // namespace
+
+const char* kernel_name(const Engine* e, const Call& c) {
+    if (use_post_stream(e, c)) return "k_post_stream";
+    return kernel_name(e, c.mean != nullptr);
+}
 
 // TGP_MODAL_GEOMETRY=<waves>x<steps per lane> (8x8, 16x8) overrides the choice (A/B runs)
 void choose_geometry(int d, int halo, int* nw, int* sub) {
@@ -1446,7 +1497,7 @@ bool plan(Engine* e, const tgp_plan::ModelHost& m, long long T, bool logpdf_only
     choose_geometry(e->md.d, halo, &e->nw, &e->sub);
     const long long C = (long long)e->nw * 64 * e->sub - 2LL * halo;
     e->nwg = (T - e->md.nhs + C - 1) / C;
-    const size_t need = (size_t)e->nwg + 64;
+    const size_t need = std::max<size_t>((size_t)e->nwg + 64, 8192);      // (room for the streaming kernels' triples and development stamps)
     if (need > e->part_cap) {
         if (e->part) (void)tgp_alloc::host_free(e->part);
         e->part = nullptr;
@@ -1514,16 +1565,21 @@ bool complete(Engine* e, long long T) {
     const bool head = e->hh_pending;
     e->hh_pending = false;
     bool ok = true;
+    int why = tgp_plan::kOk;
+    // the tail variances FIRST (round 6): the runs / workgroups at the series' end wait for them from the moment they start, and they need nothing of
+    // the head (measured on k_post_stream: shipped behind the head's tables they left the series' last run waiting until 50 us into a 35 us kernel)
+    if (e->post) {
+        why = tgp_plan::build_tables_tail_any(e->md.d, T, e->md, *e->tab, e->info);
+        ship_stage(e, 2, why);      // (the head's variances in that stage are not there yet: with the head on the host nobody on the device reads them)
+    }
     if (head) {
         ok = await_host_flag(f, v, e->stream);
         if (ok) tgp_plan::modal_head_forward_any(e->mh, e->md, *e->tab, hh_in(e), e->hr, hh_z0(e), &e->host_quad);
         raise_flag(f + 1, v);
     }
-    int why = tgp_plan::kOk;
-    if (e->post) {
+    if (e->post && why == tgp_plan::kOk) {
         why = tgp_plan::build_tables_stage_any(e->md.d, 1, T, e->md, *e->tab, e->info);
-        if (why == tgp_plan::kOk) why = tgp_plan::build_tables_stage_any(e->md.d, 2, T, e->md, *e->tab, e->info);
-        ship_stage(e, 2, why);
+        if (why == tgp_plan::kOk) why = tgp_plan::build_tables_headvar_any(e->md.d, e->md, *e->tab);
     }
     if (head && e->post) {
         if (ok && why == tgp_plan::kOk) ok = await_host_flag(f + 2, v, e->stream);
@@ -1626,6 +1682,44 @@ void finish_parts(const Engine* e, double* ssq, double* head_quad) {
 // ... and the log marginal likelihood of a call that ran the whole series.
 double finish(const Engine* e, long long T) {
     const Modal& md = e->md;
+    if (std::getenv("TGP_POST_DBG") != nullptr && (std::atoi(std::getenv("TGP_POST_DBG")) & 16) && e->post && e->nwg_local <= 256) {
+        // development: the runs' start / end stamps of k_post_stream (100 MHz ticks)
+        const double* q = e->part + 512;
+        const long long R = e->nwg_local * 8;
+        double s0 = 1e300, s1 = -1e300, e0 = 1e300, e1 = -1e300, esum = 0.0;
+        long long elast = -1, n = 0;
+        for (long long r = 0; r < R; ++r) {
+            if (q[2 * r] == 0.0) continue;
+            ++n;
+            s0 = std::min(s0, q[2 * r]); s1 = std::max(s1, q[2 * r]);
+            e0 = std::min(e0, q[2 * r + 1]);
+            esum += q[2 * r + 1];
+            if (q[2 * r + 1] > e1) { e1 = q[2 * r + 1]; elast = r; }
+        }
+        {
+            // histogram of the ends (2 us bins), mean end by XCD (workgroup number mod 8) and by wave slot
+            int hist[64] = {0};
+            double xs[8] = {0}, ws[8] = {0};
+            int xn[8] = {0}, wn[8] = {0};
+            for (long long r = 0; r < R; ++r) {
+                if (q[2 * r] == 0.0) continue;
+                const double en = (q[2 * r + 1] - s0) * 0.01;
+                const int b = (int)(en / 2.0);
+                ++hist[b < 63 ? b : 63];
+                xs[(r / 8) % 8] += en; ++xn[(r / 8) % 8];
+                ws[r % 8] += en; ++wn[r % 8];
+            }
+            fprintf(stderr, "[tgp post] ends by 2 us:");
+            for (int b = 0; b < 40; ++b) if (hist[b]) fprintf(stderr, " %d:%d", 2 * b, hist[b]);
+            fprintf(stderr, "\n[tgp post] mean end by XCD:");
+            for (int x = 0; x < 8; ++x) fprintf(stderr, " %.1f", xs[x] / std::max(1, xn[x]));
+            fprintf(stderr, "; by wave of the workgroup:");
+            for (int x = 0; x < 8; ++x) fprintf(stderr, " %.1f", ws[x] / std::max(1, wn[x]));
+            fprintf(stderr, "\n");
+        }
+        fprintf(stderr, "[tgp post] %lld runs: starts within %.2f us; ends: first %.2f, mean %.2f, last %.2f us after the first start (run %lld); run 0 ends %.2f, run R/2 ends %.2f\n", n,
+                (s1 - s0) * 0.01, (e0 - s0) * 0.01, (esum / n - s0) * 0.01, (e1 - s0) * 0.01, elast, (q[1] - s0) * 0.01, (q[2 * (R / 2) + 1] - s0) * 0.01);
+    }
     if (!e->lml && std::getenv("TGP_STEADY_DEBUG") != nullptr) {
         const double* q = e->part + e->nwg_local;
         fprintf(stderr, "[tgp modal] d %d n0 %d nhs %d n1 %d halo %d geometry %dx%d workgroups %lld | workgroup 0 (us from its start): tables ready %.1f, head forward done %.1f, head backward starts %.1f, done %.1f; last workgroup done %.1f\n",

@@ -58,6 +58,7 @@ const tgp_plan::Info& last_plan(const Engine*);
 const tgp_plan::Modal& last_modal(const Engine*);
 // the kernel variant plan() chose for the call (profile label)
 const char* kernel_name(const Engine*, bool posterior);
+const char* kernel_name(const Engine*, const Call&);      // ... for this very call (pointer alignment and segment bounds are part of the choice)
 void choose_geometry(int d, int halo, int* waves, int* steps_per_lane);
 
 // rand of an LTI model with the draws supplied (lgssm.jl:65-91; Forward, scalar observations, d <= tgp_plan::kRandMaxD): ONE kernel over the

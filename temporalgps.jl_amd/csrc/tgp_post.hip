@@ -1,0 +1,696 @@
+// Streaming posterior kernel of the stationary-gain engine (round 6) -- see tgp_post.hpp.  gfx950 only (wave64, DPP scans, uniform coefficients
+// through the kernel-argument segment).
+#include "tgp_post.hpp"
+
+#include <cstdlib>
+#include <cstring>
+
+namespace tgp_post {
+
+namespace {
+
+typedef double v2d __attribute__((ext_vector_type(2)));
+constexpr int N = kN, PPL = kN / 2, TILE = kTile;
+
+// ---- kernel arguments: every coefficient is wave-uniform and reaches the lanes through scalar loads ---------------------------------
+template <int D>
+struct PArgs {
+    double fd[D], fo[D], fb[D], fa[D], fw[D];      // forward:  z' = fd z + fo z_partner + fb u + fa,  r = u - fw . z
+    double gd[D], go[D], gc[D], gw[D];             // backward: zeta' = gd zeta + go zeta_partner + gc r,  mean = y - rS r + gw . zeta
+    double lfr[6][D], lfi[6][D];                   // M^(N 2^k), k < 6: the block form (re, signed im)
+    double lgr[6][D], lgi[6][D];                   // Mg^(N 2^k)
+    double WJ[N][D], WG[N][D];                     // fw' M^j; gw' Mg^(N-1-j)
+    double hh, rS, vb;
+    int nhs, halo, rnew_per_step, tvb_off, nwg, dbg;
+    long long T, G, R, C, seq;      // G tiles behind the head, R runs, C tiles per run in the middle of the series
+    const double *y, *Rnew, *RnewT, *htab, *z0p, *head_out;
+    double *mean, *var, *part, *head_in, *zeta_out;
+    v2d* xch;      // device memory, [R][D] (value, sequence number) pairs: a run's first tile leaves its left-edge backward state for the run before it
+    const long long* flag;
+    long long* hflag;
+};
+
+template <int D>
+__device__ __forceinline__ constexpr int partner(int i) {
+    return ((i ^ 1) < D) ? (i ^ 1) : i;
+}
+__device__ __forceinline__ void lds_sync() {      // one wave talking to itself through LDS (DS operations of a wave execute in order)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ double readlane_d(double x, int l) {      // l wave-uniform
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), l), hi = __builtin_amdgcn_readlane(__double2hiint(x), l);
+    return __hiloint2double(hi, lo);
+}
+// DPP moves of a double (lanes without a source and rows outside the mask read zero).  gfx9 controls: row_shl:n 0x100 + n, row_shr:n 0x110 + n,
+// wave_shl:1 0x130, wave_shr:1 0x138, row_bcast:15 0x142, row_bcast:31 0x143, row_newbcast:n 0x150 + n
+template <int CTRL, int ROWMASK = 0xF>
+__device__ __forceinline__ double dpp_mov(double x) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, ROWMASK, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, ROWMASK, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum(double x) {
+    x += dpp_mov<0x111>(x);
+    x += dpp_mov<0x112>(x);
+    x += dpp_mov<0x114>(x);
+    x += dpp_mov<0x118>(x);
+    x += dpp_mov<0x142, 0xA>(x);
+    x += dpp_mov<0x143, 0xC>(x);
+    return readlane_d(x, 63);
+}
+// the 16-byte slot of piece j of lane L in a wave's LDS slice (tgp_lml.hip slot_of, eight pieces per lane)
+__device__ __forceinline__ int slot_of(int L, int j) { return L * PPL + (j ^ ((L >> 1) & (PPL - 1))); }
+
+// a bounded wait for a flag in pinned host memory (tgp_modal.hip wait_tables): two seconds of the 100 MHz clock, then on with a poisoned sum
+constexpr long long kWaitTicks = 200000000ll;
+__device__ __noinline__ bool wait_flag(const long long* flagc, long long seq) {      // false: timed out
+    long long* flag = const_cast<long long*>(flagc);
+    const long long t0 = (long long)wall_clock64();
+    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < 2 * seq) {
+        __builtin_amdgcn_s_sleep(16);
+        if ((long long)wall_clock64() - t0 > kWaitTicks) return false;
+    }
+    return true;
+}
+
+template <int D>
+__global__ __launch_bounds__(kNW * 64, 2) void k_post_stream(const PArgs<D> by_value) {
+    (void)by_value;
+    typedef const __attribute__((address_space(4))) PArgs<D>* KaPtr;      // (the kernel-argument segment: scalar loads, tgp_lml.hip)
+    KaPtr kap = (KaPtr)__builtin_amdgcn_kernarg_segment_ptr();
+#define ka (*kap)
+    // two 8 KB slices per wave: the tile in work and the next one on its way (global -> LDS directly: no staging registers)
+    __shared__ __attribute__((aligned(16))) v2d sSlice[kNW][2][64 * PPL];
+    __shared__ double sAcc[kNW];
+    // per-lane powers of the block forms (the same for every wave; kept in LDS, not in thirty-six registers): [0] M^(N (p + 1)), p the lane's place in
+    // its row of sixteen (what carries a row's entering state to the lane), [1] Mg^(N (16 - p)) (the same from the right), [2] Mg^(N (63 - lane)) (the
+    // tile's right-hand input at the lane); re / im per component
+    __shared__ double sPw[3][2][D][64];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    {
+        // wave w builds the chains w, w + 8, ... of the 3 D (table, component) pairs: six conditional complex multiplications by the bits of the exponent
+        for (int job = wave; job < 3 * D; job += kNW) {
+            const int tb = job / D, i = job % D;
+            const int ex = tb == 0 ? (lane & 15) + 1 : (tb == 1 ? 16 - (lane & 15) : 63 - lane);
+            double xr = 1.0, xi = 0.0;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const double lr = tb == 0 ? ka.lfr[k][i] : ka.lgr[k][i], li = tb == 0 ? ka.lfi[k][i] : ka.lgi[k][i];
+                const bool bit = ((ex >> k) & 1) != 0;
+                const double nr = fma(xr, lr, -(xi * li)), ni = fma(xr, li, xi * lr);
+                xr = bit ? nr : xr;
+                xi = bit ? ni : xi;
+            }
+            sPw[tb][0][i][lane] = xr;
+            sPw[tb][1][i][lane] = xi;
+        }
+        __syncthreads();
+    }
+    const long long run = (long long)blockIdx.x * kNW + wave;
+    const bool active = run < ka.R;
+    const long long T = ka.T;
+    // the head's inputs to the host, first thing (its forward recursion runs there; tgp_modal.hip k_steady_one)
+    if (blockIdx.x == 0 && wave == kNW - 1) {
+        for (int t = lane; t < ka.nhs; t += 64) {
+            ka.head_in[t] = ka.y[t];
+            if (ka.rnew_per_step) ka.head_in[ka.nhs + t] = ka.RnewT[t];
+        }
+        if (!ka.rnew_per_step && lane == 0) ka.head_in[ka.nhs] = ka.Rnew[0];
+        __threadfence_system();
+        if (lane == 0) __hip_atomic_store(ka.hflag, 2 * ka.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    double acc = 0.0, poison = 0.0;
+    const long long dbg_t0 = (ka.dbg & 16) ? (long long)wall_clock64() : 0;
+    if (active) {
+        const bool first = run == 0, last = run == ka.R - 1;
+        // The tiles are dealt out evenly -- but for the two ends of the series, whose runs wait for the host: run 0 (the head's end state, microseconds
+        // after the kernel has started) takes ONE tile, and each of the last three tiles (the tail variances out of pinned memory, behind their stage's
+        // flag, element by element) is a run of its own.  Measured with three tail tiles at the end of one full run: that run ended at 68 us, the mean at 35.
+        long long g0, g1;
+        {
+            const long long n_tail = ka.G - 1 < 3 ? ka.G - 1 : 3, Rm = ka.R - 1 - n_tail, Gm = ka.G - 1 - n_tail;
+            if (first) {
+                g0 = 0;
+                g1 = 1;
+            } else if (run <= Rm) {      // every run of the middle holds C tiles (the last one what is left): equal work, the kernel ends with its mean wave
+                g0 = 1 + (run - 1) * ka.C;
+                g1 = g0 + ka.C < 1 + Gm ? g0 + ka.C : 1 + Gm;
+            } else {
+                g0 = ka.G - n_tail + (run - Rm - 1);
+                g1 = g0 + 1;
+            }
+        }
+        const long long t_lo = ka.nhs + g0 * TILE;
+        const double* __restrict__ y = ka.y;
+        // (every value loaded in front of the tile loop is USED in front of it -- an empty asm statement -- so that the compiler's wait for it stands there
+        //  and not inside the loop, where a wait for one vector-memory load is a wait for all of them: the next tile's observations, the last tile's stores)
+        double rn0 = ka.rnew_per_step ? 0.0 : ka.Rnew[0];
+        asm volatile("" : "+v"(rn0));
+        // Rows [k_lo, k_hi) of the tile at tile_t0 into a slice, straight from global memory (global_load_lds_dwordx4: every instruction 1 KB of
+        // consecutive bytes, no staging registers); the other rows are zeroed.  The LDS side of such a load is linear -- slot 64 k + lane -- so the
+        // XOR swizzle of slot_of() goes on the SOURCE address: slot 64 k + i belongs to lane L = 8 k + i / 8 and holds its piece (i % 8) ^ ((L / 2) % 8).
+        auto issue_loads = [&](v2d* slice, long long tile_t0, int k_lo, int k_hi) {
+            const double* __restrict__ base = y + tile_t0;
+#pragma unroll 1
+            for (int k = 0; k < PPL; ++k) {      // (rolled: eight unrolled address pairs around eight asm statements cost more registers than the loop has)
+                if (k >= k_lo && k < k_hi) {      // (wave-uniform)
+                    const int L = 8 * k + (lane >> 3), j = (lane & 7) ^ ((L >> 1) & 7);
+                    const double* src = base + 2 * (8 * L + j);
+                    // (inline assembly: the compiler does not count these loads -- a builtin's would make it wait for EVERY vector-memory operation,
+                    //  the previous tile's output stores included, before the slice is read; `landed` below waits for exactly these)
+                    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(slice + 64 * k));
+                    unsigned keep;
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+                } else {
+                    slice[64 * k + lane] = v2d{0.0, 0.0};
+                }
+            }
+        };
+        // a tile that reaches beyond the series' end: element by element (the series' last tile: one wave, once -- or twice: its ghost)
+        auto load_tail = [&](v2d* slice, long long tile_t0, int k_lo, int k_hi) {
+#pragma unroll 1
+            for (int k = 0; k < PPL; ++k) {
+                const unsigned q = (unsigned)(k * 64 + lane);
+                const long long t = tile_t0 + 2 * (long long)q;
+                v2d w = v2d{0.0, 0.0};
+                if (k >= k_lo && k < k_hi) {
+                    if (t < T) w.x = y[t];
+                    if (t + 1 < T) w.y = y[t + 1];
+                }
+                slice[slot_of((int)(q >> 3), (int)(q & 7))] = w;
+            }
+        };
+        auto fetch = [&](v2d* slice, long long tile_t0, int k_lo, int k_hi) {
+            if (tile_t0 + TILE <= T) issue_loads(slice, tile_t0, k_lo, k_hi);      // (wave-uniform)
+            else load_tail(slice, tile_t0, k_lo, k_hi);
+        };
+        // The loads into LDS are counted with the vector-memory operations, which complete in the order they were issued: with `behind` such operations
+        // issued after them (the sixteen whole-line stores of a finished tile) the slice is complete once all but those have returned.
+        auto landed = [&](int behind) {
+            if (behind == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            lds_sync();
+        };
+        // ---- the scans.  Forward: the lanes' zero-start end states -> every lane's start state (in z), the tile's end state (returned in `end`)
+        auto fwd_scan = [&](double (&z)[D], const double (&zin)[D], double (&end)[D]) {
+            {
+                double add[D];
+#pragma unroll
+                for (int i = 0; i < D; ++i) add[i] = fma(ka.lfr[0][i], zin[i], ka.lfi[0][i] * zin[partner<D>(i)]);
+#pragma unroll
+                for (int i = 0; i < D; ++i) z[i] += (lane == 0) ? add[i] : 0.0;
+            }
+#define TGP_POST_ROW_LEVEL(CTRL, LR, LI, K, Z)                                                                          \
+    do {                                                                                                               \
+        double g_[D];                                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < D; ++i) g_[i] = dpp_mov<(CTRL) + (1 << (K))>(Z[i]);                     \
+        _Pragma("unroll") for (int i = 0; i < D; ++i) Z[i] = fma(ka.LR[K][i], g_[i], fma(ka.LI[K][i], g_[partner<D>(i)], Z[i])); \
+    } while (0)
+            TGP_POST_ROW_LEVEL(0x110, lfr, lfi, 0, z);
+            TGP_POST_ROW_LEVEL(0x110, lfr, lfi, 1, z);
+            TGP_POST_ROW_LEVEL(0x110, lfr, lfi, 2, z);
+            TGP_POST_ROW_LEVEL(0x110, lfr, lfi, 3, z);
+            double g[D], g3[D];
+#pragma unroll
+            for (int i = 0; i < D; ++i) g[i] = dpp_mov<0x142, 0xA>(z[i]);      // rows 1, 3: the total of the row below
+#pragma unroll
+            for (int i = 0; i < D; ++i) z[i] = fma(sPw[0][0][i][lane], g[i], fma(sPw[0][1][i][lane], g[partner<D>(i)], z[i]));
+#pragma unroll
+            for (int i = 0; i < D; ++i) g[i] = dpp_mov<0x143, 0xC>(z[i]);      // rows 2, 3: everything up to lane 31 ...
+#pragma unroll
+            for (int i = 0; i < D; ++i) g3[i] = fma(ka.lfr[4][i], g[i], ka.lfi[4][i] * g[partner<D>(i)]);      // ... which row 3 sees through M^(16 N) more
+#pragma unroll
+            for (int i = 0; i < D; ++i) g[i] = lane >= 48 ? g3[i] : g[i];
+#pragma unroll
+            for (int i = 0; i < D; ++i) z[i] = fma(sPw[0][0][i][lane], g[i], fma(sPw[0][1][i][lane], g[partner<D>(i)], z[i]));
+#pragma unroll
+            for (int i = 0; i < D; ++i) end[i] = readlane_d(z[i], 63);
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                const double sh = dpp_mov<0x138>(z[i]);
+                z[i] = lane == 0 ? zin[i] : sh;
+            }
+        };
+        // Backward: the lanes' left-edge states from a zero right-hand input -> what enters every lane from its right within the tile (in zeta), the
+        // tile's left-edge state (returned in `left`)
+        auto bwd_scan = [&](double (&zeta)[D], double (&left)[D]) {
+            TGP_POST_ROW_LEVEL(0x100, lgr, lgi, 0, zeta);
+            TGP_POST_ROW_LEVEL(0x100, lgr, lgi, 1, zeta);
+            TGP_POST_ROW_LEVEL(0x100, lgr, lgi, 2, zeta);
+            TGP_POST_ROW_LEVEL(0x100, lgr, lgi, 3, zeta);
+#undef TGP_POST_ROW_LEVEL
+            double g[D], g3[D];
+            // rows 0 and 2 take the first lane of the row above them: wave_shl:1 brings it to their lane 15, row_newbcast:15 spreads it
+#pragma unroll
+            for (int i = 0; i < D; ++i) g[i] = dpp_mov<0x15F, 0x5>(dpp_mov<0x130>(zeta[i]));
+#pragma unroll
+            for (int i = 0; i < D; ++i) zeta[i] = fma(sPw[1][0][i][lane], g[i], fma(sPw[1][1][i][lane], g[partner<D>(i)], zeta[i]));
+            // the lower half takes lane 32 (complete by now); row 0 sees it through Mg^(16 N) more
+#pragma unroll
+            for (int i = 0; i < D; ++i) g[i] = readlane_d(zeta[i], 32);
+#pragma unroll
+            for (int i = 0; i < D; ++i) g3[i] = fma(ka.lgr[4][i], g[i], ka.lgi[4][i] * g[partner<D>(i)]);
+#pragma unroll
+            for (int i = 0; i < D; ++i) g[i] = lane < 16 ? g3[i] : (lane < 32 ? g[i] : 0.0);
+#pragma unroll
+            for (int i = 0; i < D; ++i) zeta[i] = fma(sPw[1][0][i][lane], g[i], fma(sPw[1][1][i][lane], g[partner<D>(i)], zeta[i]));
+#pragma unroll
+            for (int i = 0; i < D; ++i) left[i] = readlane_d(zeta[i], 0);
+#pragma unroll
+            for (int i = 0; i < D; ++i) zeta[i] = dpp_mov<0x130>(zeta[i]);      // what enters the lane from its right: its right neighbour's (lane 63: zero)
+        };
+
+        // ---- the state entering the run: the head's end state from the host (run 0; waited for where it is first used), else a state-only pass over
+        // the `halo` steps in front of the run (a zero state `halo` steps back gives the same, to 2^-64)
+        double zin[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) zin[i] = 0.0;
+        if (!first && !(ka.dbg & 8)) {
+            v2d* sY = sSlice[wave][1];
+            fetch(sY, t_lo - TILE, (TILE - ka.halo) / 128, PPL);
+            landed(0);
+            double z[D];
+#pragma unroll
+            for (int i = 0; i < D; ++i) z[i] = 0.0;
+#pragma unroll 1
+            for (int jc = 0; jc < N; jc += 8) {
+                double u[8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const v2d w = sY[slot_of(lane, jc / 2 + j)];
+                    u[2 * j] = w.x - ka.hh;
+                    u[2 * j + 1] = w.y - ka.hh;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    double nz[D];
+#pragma unroll
+                    for (int i = 0; i < D; ++i) nz[i] = fma(ka.fd[i], z[i], fma(ka.fo[i], z[partner<D>(i)], fma(ka.fb[i], u[j], ka.fa[i])));
+#pragma unroll
+                    for (int i = 0; i < D; ++i) z[i] = nz[i];
+                }
+            }
+            // (lanes in front of the halo ran on zeros: what they leave is attenuated by M^halo like everything else back there)
+            double zero[D], end[D];
+#pragma unroll
+            for (int i = 0; i < D; ++i) zero[i] = 0.0;
+            fwd_scan(z, zero, end);
+#pragma unroll
+            for (int i = 0; i < D; ++i) zin[i] = end[i];
+            lds_sync();
+        }
+
+        // ---- the tiles of the run, and behind them (unless the series ends there) the ghost pass over the first halo steps of the next run
+        // (TGP_POST_DBG & 32: the ghost pass of the first version -- the run computes the next run's first halo steps itself -- instead of the exchange)
+        const bool use_ghost = (ka.dbg & 32) != 0;
+        const long long n_own = g1 - g0, n_pass = n_own + ((last || (ka.dbg & 4) || !use_ghost) ? 0 : 1);
+        const int kh = (ka.halo + 127) / 128;
+        double mh[N], zh[D];      // the previous tile, waiting for its right-hand input: means so far, what enters each lane from its right within the tile
+#pragma unroll
+        for (int j = 0; j < N; ++j) mh[j] = 0.0;
+#pragma unroll
+        for (int i = 0; i < D; ++i) zh[i] = 0.0;
+        // A finished tile leaves: the means through the slice as whole-line stores, the variances straight (they do not depend on the data).
+        // (y, mean, var and a per-step Rnew are on 16-byte boundaries: tgp_modal.hip sends everything else to k_steady_one.)
+        // (`ln`: the lane number behind an optimisation barrier of the current pass -- the slice addresses are recomputed per pass, a handful of integer
+        //  instructions, instead of living in forty registers across the whole loop)
+        auto flush = [&](v2d* sY, long long tile_t0, const double (&mm)[N], int ln) -> int {
+            int issued = -1;      // 16: exactly the sixteen plain stores; -1: something else (the caller then waits for everything)
+            lds_sync();
+#pragma unroll
+            for (int j = 0; j < PPL; ++j) {
+                v2d w;
+                w.x = mm[2 * j];
+                w.y = mm[2 * j + 1];
+                sY[slot_of(ln, j)] = w;
+            }
+            lds_sync();
+            // the plain tile: whole, away from the series' end (the variances are one constant), one shared new noise -- sixteen whole-line stores, no loads
+            const bool plain = tile_t0 + TILE <= T && T - tile_t0 > (long long)tgp_plan::kTailMax + TILE && !ka.rnew_per_step;
+            if (plain) {
+                if (!(ka.dbg & 1)) {
+                    v2d* __restrict__ q = reinterpret_cast<v2d*>(ka.mean + tile_t0);
+#pragma unroll
+                    for (int k = 0; k < PPL; ++k) {
+                        const unsigned e = (unsigned)(k * 64 + ln);
+                        q[e] = sY[slot_of((int)(e >> 3), (int)(e & 7))];
+                    }
+                }
+                lds_sync();
+                if (!(ka.dbg & 2)) {
+                    v2d w;
+                    w.x = ka.vb + rn0;
+                    w.y = w.x;
+                    v2d* __restrict__ q = reinterpret_cast<v2d*>(ka.var + tile_t0);
+#pragma unroll
+                    for (int k = 0; k < PPL; ++k) q[k * 64 + ln] = w;
+                }
+                if (!(ka.dbg & 3)) issued = 16;
+                return issued;
+            }
+            // every other tile (the series' last few, a new noise per step): element by element; what it loads it uses here.  The tail variances are read
+            // in place from pinned host memory: all of a tile's reads are issued before the first is used (one PCIe round trip, not eight)
+            {
+                long long n1 = 0;
+                if (T - tile_t0 <= (long long)tgp_plan::kTailMax + TILE) {      // (wave-uniform)
+                    (void)wait_flag(ka.flag + 2, ka.seq);
+                    n1 = (long long)ka.htab[0];
+                }
+                const double* __restrict__ tvb = ka.htab + ka.tvb_off;
+                double tv0[PPL], tv1[PPL];
+#pragma unroll
+                for (int k = 0; k < PPL; ++k) {
+                    const long long t = tile_t0 + 2 * (long long)(k * 64 + ln);
+                    const long long b0 = T - 1 - t, b1 = b0 - 1;
+                    tv0[k] = (b0 >= 0 && b0 < n1) ? tvb[b0] : ka.vb;
+                    tv1[k] = (b1 >= 0 && b1 < n1) ? tvb[b1] : ka.vb;
+                }
+#pragma unroll
+                for (int k = 0; k < PPL; ++k) {
+                    const unsigned e = (unsigned)(k * 64 + ln);
+                    const v2d w = sY[slot_of((int)(e >> 3), (int)(e & 7))];
+                    const long long t = tile_t0 + 2 * (long long)e;
+                    if (t < T) {
+                        ka.mean[t] = w.x;
+                        ka.var[t] = tv0[k] + (ka.rnew_per_step ? ka.RnewT[t] : rn0);
+                    }
+                    if (t + 1 < T) {
+                        ka.mean[t + 1] = w.y;
+                        ka.var[t + 1] = tv1[k] + (ka.rnew_per_step ? ka.RnewT[t + 1] : rn0);
+                    }
+                }
+                lds_sync();
+            }
+            return issued;
+        };
+        // the previous tile's outputs, now that the state entering it from the right is known
+        auto finish_prev = [&](v2d* sY, long long tile_t0, const double (&zr)[D], int ln) -> int {
+            double zst[D];
+#pragma unroll
+            for (int i = 0; i < D; ++i) zst[i] = fma(sPw[2][0][i][lane], zr[i], fma(sPw[2][1][i][lane], zr[partner<D>(i)], zh[i]));
+            double mm[N];
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                double m = mh[j];
+#pragma unroll
+                for (int i = 0; i < D; ++i) m = fma(ka.WG[j][i], zst[i], m);
+                mm[j] = m;
+            }
+            return flush(sY, tile_t0, mm, ln);
+        };
+
+        if (first) {      // the head's end state comes from the host (run 0 holds one tile: the wait is not the kernel's critical path)
+            if (!wait_flag(ka.hflag + 1, ka.seq)) poison = __builtin_nan("");
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                zin[i] = ka.z0p[i];
+                asm volatile("" : "+v"(zin[i]));
+            }
+        }
+        int buf = 0, behind = 0;      // behind: vector-memory operations issued after the loads of the tile about to be worked on (16: the plain output stores)
+        fetch(sSlice[wave][0], t_lo, 0, n_own > 0 ? PPL : kh);
+        for (long long p = 0; p < n_pass; ++p) {
+            // (the coefficients are re-read through the scalar cache every tile: hoisted out of the loop they would not fit the SGPRs)
+            asm volatile("" : "+s"(kap));
+            const long long tile_t0 = t_lo + p * TILE;
+            const bool ghost = p >= n_own;
+            // The arbiter prefers the older wave of a SIMD: left alone, the workgroup's waves 0-3 (first on their SIMDs) finish 5 us before waves 4-7
+            // (measured: 32 against 37 us) and the kernel ends with the late half.  The two waves of a SIMD take turns at the higher priority, tile by tile.
+            if (!(ka.dbg & 64)) {
+                if (((int)p ^ (wave >> 2)) & 1) __builtin_amdgcn_s_setprio(1);
+                else __builtin_amdgcn_s_setprio(0);
+            }
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            v2d* sY = sSlice[wave][buf];
+            landed(behind);
+            behind = 0;
+            if (p + 1 < n_pass) fetch(sSlice[wave][buf ^ 1], tile_t0 + TILE, 0, p + 1 >= n_own ? kh : PPL);      // the next pass's observations travel while this one is in work
+            buf ^= 1;
+            double yv[N], r[N];
+#pragma unroll
+            for (int j = 0; j < PPL; ++j) {
+                const v2d w = sY[slot_of(ln, j)];
+                yv[2 * j] = w.x;
+                yv[2 * j + 1] = w.y;
+            }
+            const long long left_steps = T - (tile_t0 + (long long)lane * N);
+            const int nvalid = left_steps >= N ? N : (left_steps > 0 ? (int)left_steps : 0);
+            // ---- forward from zero: the innovations r0 of the lane's steps, the lane's end state
+            double z[D];
+#pragma unroll
+            for (int i = 0; i < D; ++i) z[i] = 0.0;
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                const double u = yv[j] - ka.hh;
+                double rr = u;
+#pragma unroll
+                for (int i = 0; i < D; ++i) rr = fma(-ka.fw[i], z[i], rr);
+                r[j] = rr;
+                double nz[D];
+#pragma unroll
+                for (int i = 0; i < D; ++i) nz[i] = fma(ka.fd[i], z[i], fma(ka.fo[i], z[partner<D>(i)], fma(ka.fb[i], u, ka.fa[i])));
+#pragma unroll
+                for (int i = 0; i < D; ++i) z[i] = nz[i];
+                if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // (left alone, the scheduler computes every fb u + fa ahead and spills)
+            }
+            double zend[D];
+            fwd_scan(z, zin, zend);      // (z: the lane's start state)
+#pragma unroll
+            for (int i = 0; i < D; ++i) zin[i] = zend[i];
+            // the start state moves step j's innovation by -fw' M^j st
+            asm volatile("" : "+s"(kap));
+            double a2 = 0.0;
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                double rr = r[j];
+#pragma unroll
+                for (int i = 0; i < D; ++i) rr = fma(-ka.WJ[j][i], z[i], rr);
+                rr = j < nvalid ? rr : 0.0;
+                r[j] = rr;
+                a2 = fma(rr, rr, a2);
+                if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+            if (!ghost) acc += a2;
+            // ---- backward from a zero right-hand input: m0_j = y_j - rS r_j + gw . zeta (zeta from the lane's own later steps)
+            asm volatile("" : "+s"(kap));
+            double zeta[D];
+#pragma unroll
+            for (int i = 0; i < D; ++i) zeta[i] = 0.0;
+#pragma unroll
+            for (int j = N - 1; j >= 0; --j) {
+                const double rj = r[j];
+                double m = fma(-ka.rS, rj, yv[j]);
+#pragma unroll
+                for (int i = 0; i < D; ++i) m = fma(ka.gw[i], zeta[i], m);
+                yv[j] = m;
+                double nz[D];
+#pragma unroll
+                for (int i = 0; i < D; ++i) nz[i] = fma(ka.gd[i], zeta[i], fma(ka.go[i], zeta[partner<D>(i)], ka.gc[i] * rj));
+#pragma unroll
+                for (int i = 0; i < D; ++i) zeta[i] = nz[i];
+                if ((j & 3) == 0) __builtin_amdgcn_sched_barrier(0);
+            }
+            double left[D];
+            bwd_scan(zeta, left);      // (zeta: what enters the lane from its right within the tile)
+            // the tile before this one is complete now: its right-hand input is this tile's left edge (tiles outlast the halo)
+            asm volatile("" : "+s"(kap));
+            if (p == 0 && !first && !use_ghost) {
+                // this run's first tile: its left-edge state is what enters the last tile of the run before it.  One 16-byte write-through store per
+                // component -- (value, sequence number of the call): a reader that sees the number sees the value; no fence, no flag
+                double v = left[0];
+#pragma unroll
+                for (int i = 1; i < D; ++i) v = lane == i ? left[i] : v;
+                if (lane < D) {
+                    v2d w;
+                    w.x = v;
+                    w.y = __longlong_as_double(ka.seq);
+                    v2d* dst = ka.xch + run * D + lane;
+                    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(w) : "memory");
+                }
+            }
+            if (p > 0) behind = finish_prev(sY, tile_t0 - TILE, left, ln);
+            else if (first) {
+                // the backward state entering the head: the host runs the head backwards from it (k_steady_one's zeta_out)
+                if (lane == 0) {
+#pragma unroll
+                    for (int i = 0; i < D; ++i) ka.zeta_out[i] = left[i];
+                    __threadfence_system();
+                    __hip_atomic_store(ka.hflag + 2, 2 * ka.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < N; ++j) mh[j] = yv[j];
+#pragma unroll
+            for (int i = 0; i < D; ++i) zh[i] = zeta[i];
+        }
+        if (last || !use_ghost) {
+            // the run's last tile: what enters it from the right is the left-edge state of the next run's first tile -- computed by that run microseconds
+            // after the kernel started, read here tens of microseconds later (bounded wait: a run whose neighbour never came poisons its sum); the
+            // series' last tile: nothing
+            double zr[D];
+#pragma unroll
+            for (int i = 0; i < D; ++i) zr[i] = 0.0;
+            if (!last) {
+                const v2d* src = ka.xch + (run + 1) * D + (lane < D ? lane : 0);
+                v2d w;
+                const long long t0w = (long long)wall_clock64();
+                for (;;) {
+                    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(w) : "v"(src) : "memory");
+                    const bool ok = __double_as_longlong(w.y) == ka.seq;
+                    if (__builtin_amdgcn_ballot_w64(!ok && lane < D) == 0ull) break;
+                    if ((long long)wall_clock64() - t0w > kWaitTicks) {
+                        poison = __builtin_nan("");
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(8);
+                }
+#pragma unroll
+                for (int i = 0; i < D; ++i) zr[i] = readlane_d(w.x, i);
+            }
+            (void)finish_prev(sSlice[wave][0], t_lo + (n_own - 1) * TILE, zr, lane);
+        }
+        // the head's outputs come from the host: a run from the middle of the series writes them at its end (the host has had them for long by then)
+        if (ka.head_out != nullptr && run == ka.R / 2) {
+            if (!wait_flag(ka.hflag + 3, ka.seq)) poison = __builtin_nan("");
+            for (int t = lane; t < ka.nhs; t += 64) {
+                ka.mean[t] = ka.head_out[t];
+                ka.var[t] = ka.head_out[ka.nhs + t];
+            }
+        }
+        acc = wave_sum(acc) + poison;
+        if ((ka.dbg & 16) && lane == 0) {      // (development: every run's start and end on the 100 MHz clock, behind the workgroups' sums)
+            ka.part[512 + 2 * run] = (double)dbg_t0;
+            ka.part[512 + 2 * run + 1] = (double)wall_clock64();
+        }
+    }
+    if (lane == 0) sAcc[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < kNW; ++w) t += sAcc[w];
+        ka.part[blockIdx.x] = t;
+    }
+#undef ka
+}
+
+// ---- host: block-form helpers (the plan's convention, tgp_lml.hip)
+inline int hpartner(int i, int np) { return i < 2 * np ? (i ^ 1) : i; }
+void bsq(int d, double* pr, double* pi) {
+    for (int i = 0; i < d; ++i) {
+        const double r = pr[i] * pr[i] - pi[i] * pi[i], im = 2.0 * pr[i] * pi[i];
+        pr[i] = r;
+        pi[i] = im;
+    }
+}
+void vmulb(int d, int np, const double* pr, const double* pi, const double* x, double* out) {      // out = x P (a row vector)
+    for (int j = 0; j < d; ++j) {
+        const int p = hpartner(j, np);
+        out[j] = x[j] * pr[j] + (p != j ? x[p] * pi[p] : 0.0);
+    }
+}
+
+template <int D>
+int launch(hipStream_t st, const tgp_plan::Modal& md, const Geometry& g, const Call& c) {
+    static_assert(sizeof(PArgs<D>) <= 8192, "the kernel-argument segment");
+    PArgs<D> a;
+    std::memset(&a, 0, sizeof a);
+    const int np = md.npair;
+    for (int i = 0; i < D; ++i) {
+        a.fd[i] = md.fd[i]; a.fo[i] = md.fo[i]; a.fb[i] = md.fb[i]; a.fa[i] = md.fa[i]; a.fw[i] = md.fw[i];
+        a.gd[i] = md.gd[i]; a.go[i] = md.go[i]; a.gc[i] = md.gc[i]; a.gw[i] = md.gw[i];
+    }
+    double pr[kMaxD], pi[kMaxD], qr[kMaxD], qi[kMaxD];
+    for (int i = 0; i < D; ++i) {
+        pr[i] = md.fd[i]; pi[i] = md.fo[i];
+        qr[i] = md.gd[i]; qi[i] = md.go[i];
+    }
+    for (int s = 1; s < N; s <<= 1) {
+        bsq(D, pr, pi);
+        bsq(D, qr, qi);
+    }
+    for (int k = 0; k < 6; ++k) {
+        for (int i = 0; i < D; ++i) {
+            a.lfr[k][i] = pr[i]; a.lfi[k][i] = pi[i];
+            a.lgr[k][i] = qr[i]; a.lgi[k][i] = qi[i];
+        }
+        bsq(D, pr, pi);
+        bsq(D, qr, qi);
+    }
+    {
+        double x[kMaxD], nx[kMaxD];
+        for (int i = 0; i < D; ++i) x[i] = md.fw[i];
+        for (int j = 0; j < N; ++j) {
+            for (int i = 0; i < D; ++i) a.WJ[j][i] = x[i];
+            vmulb(D, np, md.fd, md.fo, x, nx);
+            for (int i = 0; i < D; ++i) x[i] = nx[i];
+        }
+        for (int i = 0; i < D; ++i) x[i] = md.gw[i];
+        for (int j = N - 1; j >= 0; --j) {
+            for (int i = 0; i < D; ++i) a.WG[j][i] = x[i];
+            vmulb(D, np, md.gd, md.go, x, nx);
+            for (int i = 0; i < D; ++i) x[i] = nx[i];
+        }
+    }
+    a.hh = md.hh; a.rS = md.rS; a.vb = md.vb;
+    a.nhs = md.nhs; a.halo = md.halo; a.rnew_per_step = c.rnew_per_step; a.tvb_off = c.tvb_off; a.nwg = g.nwg;
+    a.T = c.T; a.G = g.G; a.R = g.R; a.C = g.C; a.seq = c.seq;
+    a.y = c.y; a.Rnew = c.Rnew; a.RnewT = c.Rnew; a.htab = c.htab; a.z0p = c.z0p; a.head_out = c.head_out;
+    a.mean = c.mean; a.var = c.var; a.part = c.part; a.head_in = c.head_in; a.zeta_out = c.zeta_out;
+    a.flag = c.flag; a.hflag = c.hflag; a.xch = reinterpret_cast<v2d*>(c.xch);
+    {
+        static const int dbg = [] {      // TGP_POST_DBG: development switches (1 no mean stores, 2 no variance stores, 4 no ghost pass, 8 no run-in): timing only
+            const char* v = std::getenv("TGP_POST_DBG");
+            return v ? std::atoi(v) : 0;
+        }();
+        a.dbg = dbg;
+    }
+    hipLaunchKernelGGL((k_post_stream<D>), dim3(g.nwg), dim3(kNW * 64), 0, st, a);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+bool applies(const tgp_plan::Modal& md, long long T) {
+    static const int dmax = [] {      // TGP_POST_STREAM=0: k_steady_one as in round 5 (A/B runs); =<d>: up to that state dimension
+        const char* v = std::getenv("TGP_POST_STREAM");
+        if (!v) return 3;      // (d = 3 takes every register of the two-waves-per-SIMD budget; from d = 4 the kernel spills)
+        const int n = std::atoi(v);
+        return n < 0 ? 0 : (n > kMaxD ? kMaxD : n);
+    }();
+    return md.d <= dmax && md.halo <= kTile && T - md.nhs >= 1;
+}
+
+Geometry choose_geometry(const tgp_plan::Modal& md, long long T) {
+    Geometry g;
+    const long long Tp = T - md.nhs;
+    g.G = (Tp + kTile - 1) / kTile;
+    // run 0: the first tile; the last three tiles: a run each; the Gm tiles between them: runs of C tiles each, C the smallest that fits the slots
+    const long long rmax = (long long)kMaxWG * kNW;
+    const long long n_tail = g.G - 1 < 3 ? g.G - 1 : 3, Gm = g.G - 1 - n_tail, slots = rmax - 1 - n_tail;
+    g.C = Gm > 0 ? (Gm + slots - 1) / slots : 1;
+    const long long Rm = Gm > 0 ? (Gm + g.C - 1) / g.C : 0;
+    g.R = 1 + Rm + n_tail;
+    g.nwg = (int)((g.R + kNW - 1) / kNW);
+    return g;
+}
+
+int enqueue(hipStream_t stream, const tgp_plan::Modal& md, const Geometry& g, const Call& c, const char** kname) {
+    if (kname) *kname = "k_post_stream";
+    switch (md.d) {
+        case 1: return launch<1>(stream, md, g, c);
+        case 2: return launch<2>(stream, md, g, c);
+        case 3: return launch<3>(stream, md, g, c);
+        case 4: return launch<4>(stream, md, g, c);
+        case 5: return launch<5>(stream, md, g, c);
+        case 6: return launch<6>(stream, md, g, c);
+        case 7: return launch<7>(stream, md, g, c);
+        case 8: return launch<8>(stream, md, g, c);
+    }
+    return (int)hipErrorInvalidValue;
+}
+
+}  // namespace tgp_post

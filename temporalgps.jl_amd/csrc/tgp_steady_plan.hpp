@@ -907,12 +907,12 @@ inline int build_tables_backward(Modal& md, HeadTables& tab) {
     return kOk;
 }
 
+// The variances stage in its two halves: the TAIL (the smoothed variances of the last n1 steps: needs nothing of the backward stage -- the callers
+// that have a kernel waiting for it, tgp_modal.hip `complete`, run it first) and the HEAD's (from the reverse-time dynamics of the backward stage).
 template <int D>
-inline int build_tables_variances(long long T, Modal& md, HeadTables& tab, Info& info) {
+inline int build_tables_tail(long long T, Modal& md, HeadTables& tab, Info& info) {
     using namespace detail;
     Work<D>& wk = work<D>();
-    TablesWork<D>& tw = tables_work<D>();
-    const int n0 = wk.n0;
     double hv[D], Gss[D][D], Lss[D][D];
     std::memcpy(hv, wk.hv, sizeof hv);
     std::memcpy(Gss, wk.Gss, sizeof Gss);
@@ -965,6 +965,16 @@ inline int build_tables_variances(long long T, Modal& md, HeadTables& tab, Info&
     md.n1 = n1;
     tab.n1 = n1;
     if ((long long)wk.nhs + n1 + 1 > T) return kTooShort;
+    return kOk;
+}
+template <int D>
+inline int build_tables_headvar(Modal& md, HeadTables& tab) {
+    using namespace detail;
+    Work<D>& wk = work<D>();
+    TablesWork<D>& tw = tables_work<D>();
+    const int n0 = wk.n0;
+    double hv[D];
+    std::memcpy(hv, wk.hv, sizeof hv);
     // ---- (d) smoothed variances of the head: Ps_{n0} = stationary, Ps_{t-1} = G_t Ps_t G_t' + L_t
     tab.vb[n0] = md.vb;
     {
@@ -978,6 +988,11 @@ inline int build_tables_variances(long long T, Modal& md, HeadTables& tab, Info&
         }
     }
     return kOk;
+}
+template <int D>
+inline int build_tables_variances(long long T, Modal& md, HeadTables& tab, Info& info) {
+    const int why = build_tables_tail<D>(T, md, tab, info);
+    return why != kOk ? why : build_tables_headvar<D>(md, tab);
 }
 
 // ---- the head ON THE HOST (round 5): the kernel hands the head's observations over through pinned memory, the host runs the head's two
@@ -1898,6 +1913,14 @@ inline Info build_core_any(const ModelHost& m, long long T, Modal& md, HeadTable
 }
 inline int build_tables_any(int d, long long T, Modal& md, HeadTables& tab, Info& info) {
     TGP_PLAN_DISPATCH(d, build_tables<D>(T, md, tab, info))
+    return kEigFail;
+}
+inline int build_tables_tail_any(int d, long long T, Modal& md, HeadTables& tab, Info& info) {
+    TGP_PLAN_DISPATCH(d, build_tables_tail<D>(T, md, tab, info))
+    return kEigFail;
+}
+inline int build_tables_headvar_any(int d, Modal& md, HeadTables& tab) {
+    TGP_PLAN_DISPATCH(d, build_tables_headvar<D>(md, tab))
     return kEigFail;
 }
 inline int build_tables_stage_any(int d, int stage, long long T, Modal& md, HeadTables& tab, Info& info) {

@@ -56,7 +56,7 @@ def _assert_engine(name, per_step, names, model, T):
     if per_step:
         assert any(n.startswith("k_reduce_filter") or n.startswith("k_group_reduce") for n in names) and not any(n.startswith("k_steady") for n in names), names
     elif name in ONE_LAUNCH:
-        assert len(names) == 1 and next(iter(names)).startswith(("k_steady_one", "k_lml_stream")), names      # (logpdf alone: the streaming kernel)
+        assert len(names) == 1 and next(iter(names)).startswith(("k_steady_one", "k_lml_stream", "k_post_stream")), names      # (the streaming kernels: logpdf alone, posterior at d <= 3)
         assert _served(model) > T - 700
     else:      # no modal form: ONE kernel on dense powers in both directions (k_smooth_one)
         assert len(names) == 1 and next(iter(names)).startswith("k_smooth_one"), names

@@ -75,7 +75,7 @@ def check(tgp, model, y, Rn, T, expect_one=True, tol_m=1e-8):
     assert abs(lp - lp_ref) <= 1e-10 * abs(lp_ref), (lp, lp_ref)
     (mean, var), names = kernels_of(tgp, dm, lambda: tgp.posterior_marginals(dm, y, Rn))
     if expect_one:
-        assert any(n.startswith("k_steady_one") and "posterior" in n for n in names) and len(names) == 1, names
+        assert any(n.startswith("k_post_stream") or (n.startswith("k_steady_one") and "posterior" in n) for n in names) and len(names) == 1, names
     assert np.max(np.abs(mean - m_ref)) <= tol_m, np.max(np.abs(mean - m_ref))
     assert np.max(np.abs(var - v_ref)) <= tol_m, np.max(np.abs(var - v_ref))
     lp2, mean2, var2 = tgp.logpdf_and_posterior_marginals(dm, y, Rn)
@@ -234,7 +234,7 @@ def test_option_2_keeps_the_five_launch_engine(tgp):
     y = draw(model, 1)
     dm = device_model(tgp, model, steady=2)
     lp, names = kernels_of(tgp, dm, lambda: tgp.logpdf(dm, y))
-    assert "k_steady_apply<logpdf>" in names and not any(n.startswith("k_steady_one") for n in names), names
+    assert "k_steady_apply<logpdf>" in names and not any(n.startswith(("k_steady_one", "k_lml_stream", "k_post_stream")) for n in names), names
     d3 = device_model(tgp, model)
     lp3 = tgp.logpdf(d3, y)
     assert abs(lp - lp3) <= 1e-11 * abs(lp)

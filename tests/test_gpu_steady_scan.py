@@ -276,9 +276,9 @@ def test_cfg1_exact_size(tgp):
         hd.set_option(tgp._lib.OPT_PROFILE, 0)
         assert (served(dm) > 9900) == (steady >= 2)
         if steady == 3:
-            assert names and all(n.startswith(("k_steady_one", "k_lml_stream")) for n in names), names
+            assert names and all(n.startswith(("k_steady_one", "k_lml_stream", "k_post_stream")) for n in names), names
         elif steady == 2:
-            assert not any(n.startswith(("k_steady_one", "k_lml_stream")) for n in names) and any(n.startswith("k_steady") for n in names), names
+            assert not any(n.startswith(("k_steady_one", "k_lml_stream", "k_post_stream")) for n in names) and any(n.startswith("k_steady") for n in names), names
         assert abs(lp - lp_ref) <= 1e-10 * abs(lp_ref) and abs(lp2 - lp_ref) <= 1e-10 * abs(lp_ref)
         for mm, vv in ((mean, var), (mean2, var2)):
             np.testing.assert_allclose(mm, pm, rtol=0, atol=1e-8)
