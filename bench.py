@@ -136,18 +136,27 @@ def general_layout_leg(tgp, torch, name, T, d, device, steps):
         tgp.logpdf_and_posterior_marginals(model, y, Rnew)
     hd.set_option(tgp._lib.OPT_PROFILE, 0)
     prof = {k: v for k, v in hd.profile().items() if k.startswith(("k_reduce_filter", "k_apply_filter", "k_smooth"))}
-    kname, st = max(prof.items(), key=lambda kv: kv[1]["total_ms"])
-    avg_ms = st["total_ms"] / st["calls"]
-    per_unit = 8 * (2 * d * d + 2 * d + 3) + (24 if ("posterior" in kname or "smooth" in kname) else 0)
-    ach = per_unit * T / (avg_ms * 1e-3) / 1e9
-    p1 = next((v for k, v in prof.items() if k.startswith("k_reduce_filter")), None)
-    pass1 = None
-    if p1 is not None:      # the scan kernel proper (pass 1: one read of the step blocks, 8 (2 d^2 + 2 d + 3) B per step)
-        a1 = 8 * (2 * d * d + 2 * d + 3) * T / (p1["total_ms"] / p1["calls"] * 1e-3) / 1e9
-        pass1 = dict(kernel="k_reduce_filter<per-step>", achieved=a1, frac=a1 / HBM_PEAK_GBS, avg_kernel_ms=p1["total_ms"] / p1["calls"])
-    return dict(bound="hbm", kernel=kname, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, pass1=pass1,
-                traffic=pmc_traffic(kname, d, "per_step") if T == 10_000_000 else None, algorithmic_bytes=per_unit * T,
-                avg_kernel_ms=avg_ms, algorithmic_bytes_per_step=per_unit, steps_per_s=T / dt, ms_per_step=dt * 1e3,
+    # The PATH is three passes over the step records (reduce, apply, smooth); each re-reads the model.  Whole-path figure: the path's algorithmic
+    # bytes (the step record once + y + the outputs) over the SUM of its kernels; per kernel: the bytes THAT kernel must move at least
+    # (the step record + y, plus the scan elements / outputs it writes) over its own duration, and its measured traffic (rocprofv3 PMC, profiles/)
+    rec = 8 * (2 * d * d + 2 * d + 3)
+    per_unit = rec + 24
+    sum_ms = sum(v["total_ms"] / v["calls"] for v in prof.values())
+    ach = per_unit * T / (sum_ms * 1e-3) / 1e9
+    per_kernel = {}
+    for k, v in prof.items():
+        ms = v["total_ms"] / v["calls"]
+        own = rec + (24 if k.startswith("k_smooth") else 8)      # the record + y (+ mean, var out: the smoother); scratch between the passes is not algorithmic
+        tr = pmc_traffic(k, d, "per_step") if T == 10_000_000 else None
+        per_kernel[k] = dict(avg_kernel_ms=ms, algorithmic_bytes_per_step=own, achieved=own * T / (ms * 1e-3) / 1e9, frac=own * T / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             traffic=tr, traffic_over_algorithmic=(tr / (own * T) if tr else None),
+                             moved_GBs=(tr / (ms * 1e-3) / 1e9 if tr else None))
+    return dict(bound="hbm", path="k_reduce_filter + k_apply_filter + k_smooth (one combined call)", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
+                frac=ach / HBM_PEAK_GBS, sum_kernel_ms=sum_ms, algorithmic_bytes=per_unit * T, algorithmic_bytes_per_step=per_unit,
+                per_kernel=per_kernel, steps_per_s=T / dt, ms_per_step=dt * 1e3,
+                traffic=(sum(v["traffic"] for v in per_kernel.values()) if all(v["traffic"] for v in per_kernel.values()) else None),
+                note="whole path: algorithmic bytes of the PATH over the SUM of its kernels' durations (round-5 verdict: dividing them by one kernel's "
+                     "time overstated the fraction); `per_kernel`: each pass against the bytes it must move itself, with its PMC traffic",
                 kernels={k: dict(avg_ms=v["total_ms"] / max(1, v["calls"]), calls=v["calls"]) for k, v in hd.profile().items()})
 
 
@@ -382,13 +391,13 @@ def pmc_traffic(kname, d, layout):
     """HBM bytes per launch of `kname` from the committed PMC summary (profiles/r01_pmc_traffic.json: separate
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command, FETCH doubled per
     MI355X_MICROARCH.md). None when the summary has no entry (other d / workload)."""
-    for pj in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json"):         # keyed by the profile label, "d=<d>" -> label -> bytes
+    for pj in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json"):         # keyed by the profile label, "d=<d>" -> label -> bytes
         p3 = os.path.join(ROOT, "profiles", pj)
-        if kname.startswith(("k_steady", "k_sweep")) and os.path.exists(p3):
+        if kname.startswith(("k_steady", "k_sweep", "k_post_stream", "k_lml_stream", "k_reduce_filter", "k_apply_filter", "k_smooth<")) and os.path.exists(p3):
             ent = json.load(open(p3)).get("sweep" if kname.startswith("k_sweep") else layout, {}).get(f"d={d}", {}).get(kname)
             if ent is not None:
                 return ent["hbm_bytes"]
-    if kname.startswith(("k_steady", "k_sweep")):
+    if kname.startswith(("k_steady", "k_sweep", "k_post_stream", "k_lml_stream")):
         return None
     path = os.path.join(ROOT, "profiles", "r02s_pmc_traffic.json")      # (r01_pmc_traffic.json: the kernels before the stationary-covariance steps)
     if not os.path.exists(path):
@@ -416,10 +425,11 @@ def valu_utilisation(prof, d, layout):
     as profiles/r01_sq_counters_<layout>.json, T = 1e7) over the launch duration measured HERE, against the issue peak
     256 CUs x 4 SIMDs x one wave64 fp64 instruction per 4 cycles at 2.4 GHz (= the 78.6 TFLOP/s datasheet figure counted
     in instructions). The LTI kernels are bound by this, not by HBM."""
-    p3 = os.path.join(ROOT, "profiles", f"r04_sq_counters_{layout}.json")        # rounds 3, 4 (stationary-gain engine): keyed by the profile label
-    if not (os.path.exists(p3) and any(k in json.load(open(p3)).get(f"d={d}", {}) for k in prof)):
-        p3 = os.path.join(ROOT, "profiles", f"r03_sq_counters_{layout}.json")
-    if os.path.exists(p3) and any(k.startswith("k_steady") for k in prof):
+    p3 = os.path.join(ROOT, "profiles", f"r06_sq_counters_{layout}.json")        # keyed by the profile label
+    for older in (f"r04_sq_counters_{layout}.json", f"r03_sq_counters_{layout}.json"):
+        if not (os.path.exists(p3) and any(k in json.load(open(p3)).get(f"d={d}", {}) for k in prof)):
+            p3 = os.path.join(ROOT, "profiles", older)
+    if os.path.exists(p3) and any(k.startswith(("k_steady", "k_post_stream", "k_lml_stream")) for k in prof):
         table = json.load(open(p3)).get(f"d={d}", {})
         peak = 256 * 4 * 2.4e9 / 4.0
         out = {}
@@ -428,7 +438,10 @@ def valu_utilisation(prof, d, layout):
                 dur = prof[pk]["total_ms"] / max(1, prof[pk]["calls"]) * 1e-3
                 n = ent["SQ_INSTS_VALU"]
                 out[pk] = dict(valu_wave_instructions=n, achieved=n / dur, peak=peak, unit="wave64 fp64 VALU instructions/s", frac=n / dur / peak,
-                               waves=ent.get("SQ_WAVES"), wait_any_frac=ent.get("SQ_WAIT_ANY", 0.0) / max(1.0, ent.get("SQ_WAVE_CYCLES", 1.0)))
+                               waves=ent.get("SQ_WAVES"), wait_any_frac=ent.get("SQ_WAIT_ANY", 0.0) / max(1.0, ent.get("SQ_WAVE_CYCLES", 1.0)),
+                               executed_tflops_if_every_instruction_were_an_fma=n * 64 * 2 / dur / 1e12,
+                               note="EXECUTED instructions (SQ_INSTS_VALU of the committed PMC pass, profiles/) over this run's kernel time -- not the "
+                                    "sequential recursion's flop count")
         return out or None
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r02s_sq_counters_{layout}.json")
     if not os.path.exists(path):
@@ -484,7 +497,7 @@ def cfg5_cpu_baseline(Nr, sample_T):
                 sample=f"oracle/lgssm_ref.py (NumPy / BLAS, up to {os.cpu_count()} threads), same model, {sample_T} steps: {dt:.1f}s")
 
 
-def run_cfg5(args, torch, tgp, world, rank, local):
+def run_cfg5(args, torch, tgp, world, rank, local, emit=True):
     """BASELINE config 5: Separable(SE, Matern-5/2) on 256 spatial points x T regularly spaced times, sigma^2 = 0.1: the
     reference's dense d = 768, p = 256 model (to_gauss_markov.jl:1-20), logpdf. One bench step = one logpdf pass."""
     from temporalgps_jl_amd import lti_sde, space_time
@@ -535,6 +548,11 @@ def run_cfg5(args, torch, tgp, world, rank, local):
     gemms = {kn: v for kn, v in kernels.items() if kn.startswith("dk_gemm")}
     domg = max(gemms.items(), key=lambda kv: kv[1]["avg_us"])[0] if gemms else None
     ach = step_flops / sec_per_step / 1e12
+    # what the kernels EXECUTE with A = I (x) A_t, H = I (x) H_t applied in sparse form (three non-zeros per row): the two dense products that
+    # remain (B = U'\\V: p^2 d, Pp - B'B: 2 p d^2), the Cholesky factorisation and the sparse products -- 0.367 GF at d = 768, p = 256, against
+    # 0.364 GF counted on the device (SQ_INSTS_VALU_MFMA_MOPS_F64 x 512: profiles/r05_sq_counters_cfg5.txt); the dense-products run executes step_flops
+    exec_flops = step_flops if args.dense_products else (2 * 2.0 * 3 * d * d + 2.0 * 3 * p * d + 2.0 * 3 * p * p + p ** 3 / 3.0 + 1.0 * p * p * d + 2.0 * p * d * d)
+    ach_exec = exec_flops / sec_per_step / 1e12
     out = dict(
         metric="Kalman steps/sec (logpdf), separable space-time 256 spatial x T, dense d=768 p=256", value=world * T / (dt_s / args.steps),
         unit="Kalman steps/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=dt_s / args.steps * 1e3,
@@ -546,14 +564,64 @@ def run_cfg5(args, torch, tgp, world, rank, local):
                     us_per_kalman_step=sec_per_step * 1e6, logpdf=lp),
         roofline=dict(bound="mfma", kernel="whole time step (kernel chain)", achieved=ach, peak=MFMA_F64_PEAK_TFS, unit="TFLOP/s", frac=ach / MFMA_F64_PEAK_TFS,
                       traffic=None, algorithmic_flops_per_step=step_flops,
-                      note="algorithmic = the reference's dense step (2.57 GF); with the structured products the executed flops are ~0.76 GF per step",
+                      executed_flops_per_step=exec_flops, executed_achieved=ach_exec, executed_frac=ach_exec / MFMA_F64_PEAK_TFS,
+                      note="`frac` divides the REFERENCE's dense step (2.57 GF) by the step time: flops the structured kernels do not execute. "
+                           "`executed_frac`: the flops they do execute (0.37 GF per step, MFMA counter-checked) -- the utilisation figure",
                       dominant_kernel=dom, dominant_kernel_avg_us=kernels[dom]["avg_us"], dominant_kernel_tflops=kernels[dom]["tflops"],
                       dominant_gemm=domg, dominant_gemm_tflops=(gemms[domg]["tflops"] if domg else None),
                       dominant_gemm_frac=(gemms[domg]["tflops"] / MFMA_F64_PEAK_TFS if domg else None)),
         kernels=kernels)
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cfg5_cpu_baseline(Nr, 120)
+    if not emit:
+        return out
     print(json.dumps(out))
+
+
+def other_config_legs(args, torch, tgp, local):
+    """Short samples of BASELINE configs 3 and 5 inside the default line (round-5 verdict: the driver's record should see them): cfg3 = posterior
+    marginals (+ logpdf) of the d = 5 / d = 6 sum kernels at T = 10^6 (the full-size runs: profiles/r06_bench_sum52_*.json), cfg5 = the dense
+    d = 768, p = 256 space-time model over T = 2000 steps (full size: profiles/r06_bench_cfg5.json)."""
+    import copy
+    legs = {}
+    for name in ("sum52_32_d5", "sum52_52s_d6"):
+        try:
+            T3 = 1_000_000
+            model = build_model(tgp, name, T3, "lti", local)
+            hd = model.handle()
+            y3 = torch.randn((T3,), dtype=torch.float64, device=f"cuda:{local}")
+            R3 = torch.full((1,), 1e-18, dtype=torch.float64, device=f"cuda:{local}")
+            for _ in range(3):
+                tgp.logpdf(model, y3)
+                tgp.posterior_marginals(model, y3, R3)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n = 10
+            for _ in range(n):
+                tgp.logpdf(model, y3)
+                tgp.posterior_marginals(model, y3, R3)
+            torch.cuda.synchronize()
+            dt3 = (time.perf_counter() - t0) / n
+            hd.set_option(tgp._lib.OPT_PROFILE, 1)
+            hd.profile_reset()
+            tgp.logpdf(model, y3)
+            tgp.posterior_marginals(model, y3, R3)
+            hd.set_option(tgp._lib.OPT_PROFILE, 0)
+            legs[f"cfg3_{name}"] = dict(workload=f"cfg3: {name}, RegularSpacing(0,0.1,T={T3}), the reference's two calls", T=T3, ms_per_step=dt3 * 1e3,
+                                        steps_per_s=T3 / dt3, kernels_ms={k: v["total_ms"] / max(1, v["calls"]) for k, v in hd.profile().items()})
+            del model, y3
+        except Exception as ex:      # (an extra leg: never at the cost of the line)
+            legs[f"cfg3_{name}"] = dict(error=repr(ex))
+    try:
+        a5 = copy.copy(args)
+        a5.T, a5.steps, a5.warmup, a5.no_cpu_baseline, a5.dense_products = 2000, 1, 1, True, False
+        o5 = run_cfg5(a5, torch, tgp, 1, 0, local, emit=False)
+        legs["cfg5"] = dict(workload=o5["config"]["workload"], T=2000, ms_per_step=o5["ms_per_step"], steps_per_s=o5["value"],
+                            us_per_kalman_step=o5["config"]["us_per_kalman_step"], roofline=o5["roofline"],
+                            kernels_us={k: v["avg_us"] for k, v in o5["kernels"].items()})
+    except Exception as ex:
+        legs["cfg5"] = dict(error=repr(ex))
+    return legs
 
 
 def run_multi_inprocess(args):
@@ -879,7 +947,7 @@ def main():
             # algorithmic bytes per time step of the PATH the kernel belongs to:
             #   logpdf: inputs only; posterior marginals: inputs + R_new + (mean, var) out
             per_unit = bytes_per_step_in + (24 if ("posterior" in kname or "smooth" in kname) and not lti else 0)
-            if lti and ("posterior" in kname or "smooth" in kname):
+            if lti and ("posterior" in kname or "smooth" in kname or kname.startswith("k_post_stream")):
                 per_unit = 24
             ach = per_unit * Tseg / (avg_ms * 1e-3) / 1e9
             traffic = pmc_traffic(kname, d, args.layout) if (T == 10_000_000 and world == 1) else None
@@ -889,7 +957,10 @@ def main():
                         frac_min_median_max=[per_unit * Tseg / (v * 1e-3) / 1e9 / HBM_PEAK_GBS for v in (smp[-1], smp[len(smp) // 2], smp[0])],
                         traffic=traffic, traffic_unit="bytes per launch (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, profiles/)",
                         algorithmic_bytes=per_unit * Tseg, avg_kernel_ms=avg_ms, algorithmic_bytes_per_step=per_unit,
-                        note=(("stationary-gain engine, one-launch form (DESIGN 3.13): ONE kernel per call reads y once (8 B/step, plus the workgroups' "
+                        note=(("stationary-gain engine, STREAMING posterior kernel (DESIGN 3.20): ONE kernel per call, 2048 persistent waves, each a run of "
+                               "1024-step tiles; reads y once (8 B/step) plus one halo per run, writes mean, var (16 B/step); nothing else of size T moves "
+                               "(`traffic` = PMC bytes of this kernel)" if kname.startswith("k_post_stream") else
+                               "stationary-gain engine, one-launch form (DESIGN 3.13): ONE kernel per call reads y once (8 B/step, plus the workgroups' "
                                "halos out of L2) and writes mean, var (16 B/step); nothing else of size T moves, no other kernel runs "
                                "(`traffic` = PMC bytes of this kernel)" if kname.startswith("k_steady_one") else
                                "no modal form (a defective closed loop): ONE kernel per call on DENSE powers of the closed loop and of the settled "
@@ -900,6 +971,18 @@ def main():
                                "LTI (Fill) layout, general engine: streams only y in / (mean,var) out (plus the smoother scratch: `traffic`): the launch "
                                "is not HBM bound -- one wave per SIMD, it lasts as long as the dependent fp64 chain of its slowest wave (DESIGN 3.10)")
                               if lti else "per-step layout: HBM bound"))
+        roof_lp = None
+        lp_names = [k for k in prof if k.startswith("k_lml_stream") or (k.startswith("k_steady_one") and "logpdf" in k)]
+        if lti and lp_names and roof is not None and lp_names[0] != roof["kernel"]:
+            kn = lp_names[0]
+            smp = sorted(per_step_ms.get(kn, [prof[kn]["total_ms"] / max(1, prof[kn]["calls"])]))
+            avg = prof[kn]["total_ms"] / max(1, prof[kn]["calls"])
+            ach_lp = 8 * Tseg / (avg * 1e-3) / 1e9
+            roof_lp = dict(bound="hbm", kernel=kn, achieved=ach_lp, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach_lp / HBM_PEAK_GBS,
+                           kernel_ms_min_median_max=[smp[0], smp[len(smp) // 2], smp[-1]], avg_kernel_ms=avg, algorithmic_bytes=8 * Tseg,
+                           algorithmic_bytes_per_step=8, traffic=pmc_traffic(kn, d, args.layout) if (T == 10_000_000 and world == 1) else None,
+                           note="the logpdf call's ONE kernel: reads y once (8 B/step), writes nothing of size T; 80 MB per launch -- a launch this short "
+                                "is bound by its fp64 instruction stream and its ramps as much as by HBM (DESIGN 3.19)")
         out = dict(
             metric="Kalman steps/sec (logpdf + posterior marginals), T=10^7 Matern32 d=3",
             value=value, unit="Kalman steps/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step,
@@ -926,6 +1009,8 @@ def main():
             roofline=roof,
             kernels={k: dict(avg_ms=v["total_ms"] / max(1, v["calls"]), calls=v["calls"]) for k, v in prof.items()},
         )
+        if roof_lp is not None:
+            out["roofline_logpdf_kernel"] = roof_lp
         if fused is not None:
             out["with_fused_call"] = fused
         if five is not None:
@@ -957,17 +1042,9 @@ def main():
                 out["single_gpu_reference"] = dict(error=repr(ex))
         if args.layout == "lti":
             # The LTI layout streams 8-24 B per step against ~10^2-10^3 flop: its binding roofline is the fp64 vector ALU, not HBM.
-            # Algorithmic flops per step of the SEQUENTIAL recursion: Kalman step 4 d^3 + 7 d^2 + 8 d, RTS step
-            # 4 d^3 (predict) + d^3 / 3 (Cholesky) + 2 d^3 (two triangular solves) + 2 d^3 (L) + 4 d^3 (reverse predict); the
-            # parallel scan executes more (pass 1 + pass 2 + the RTS gain twice) and is charged against these.
-            kal = 4.0 * d ** 3 + 7.0 * d ** 2 + 8.0 * d
-            rts = (12.0 + 1.0 / 3.0) * d ** 3
-            per_step = kal + rts + (kal if args.separate_calls else 0.0)
-            ach = per_step * value / 1e12
-            out["roofline_fp64_valu"] = dict(bound="fp64_valu", achieved=ach, peak=78.6, unit="TFLOP/s", frac=ach / 78.6,
-                                             algorithmic_flops_per_step=per_step,
-                                             note="whole step (all kernels) against the MI355X fp64 vector peak; issue-slot utilisation of the "
-                                                  "individual kernels: `valu`")
+            # (round 6: the `roofline_fp64_valu` entry of rounds 3-5 charged the SEQUENTIAL recursion's flops to kernels that execute an O(d) modal
+            #  recursion -- not evidence, the round-5 verdict said; `valu` below counts the instructions the kernels EXECUTE)
+            pass
         if T == 10_000_000 and world == 1 and d == 3 and not args.chunk:
             out["valu"] = valu_utilisation(prof, d, args.layout)
         if world == 1 and not args.no_general_leg:
@@ -988,6 +1065,8 @@ def main():
                     out[kk]["general_engine_ms_per_step"] = out["predict_path"][kk]["general_engine"]["ms_per_step"]
             except Exception as ex:      # (an extra leg: never at the cost of the line)
                 out["predict_path"] = dict(error=repr(ex))
+            if name == "matern52_d3" and T == 10_000_000:
+                out["other_configs"] = other_config_legs(args, torch, tgp, local)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(name, args.cpu_sample)
             if world == 1 and args.layout == "lti":

@@ -186,7 +186,12 @@ int tgp_sweep_info(tgp_handle* h, int64_t* info, double* dist);
  * d <= 16 binds the time-parallel scan engine (p <= 64, diagonal noise). d > 16 (the ArrayStorage-sized models of
  * space_time/to_gauss_markov.jl:1-20; p <= 256) binds the dense engine -- one fp64-MFMA kernel chain per time step -- which
  * serves tgp_logpdf, tgp_filter, tgp_posterior (Forward priors), tgp_[logpdf_and_]posterior_marginals, tgp_marginals and
- * tgp_rand; the gradient, time-sharding and *_at entry points return TGP_EUNSUPPORTED there. */
+ * tgp_rand; the gradient, time-sharding and *_at entry points return TGP_EUNSUPPORTED there.
+ * TOLERANCE OF THE LARGE-OUTPUT / BOTTLENECK EMISSIONS: the host side folds LargeOutputLGC and BottleneckLGC
+ * (lgc.jl:179-204, :320-336) into ONE SmallOutput emission before it reaches this entry point -- an algebraic equivalence, not a restatement:
+ * the reference's jitters on the predicted covariance (1e-10, lgc.jl:183) and on the bottleneck's projected noise (1e-12, lgc.jl:308-312)
+ * are not carried through the p scalar updates.  Results agree with the reference's literal recursion to 1e-6 relative (the tolerance of the
+ * reference's own tests for these types, test/models/linear_gaussian_conditionals.jl), against 1e-8 / 1e-10 for every other emission type. */
 int tgp_model_set(tgp_handle* h, int64_t T, int d, int p, int ordering, uint32_t flags, const double* A,
                   const double* a, const double* Q, const double* H, const double* hh, const double* R,
                   const double* x0m, const double* x0P);

@@ -78,7 +78,7 @@ for case in range(n_cases):
                 lp, mean, var = tgp.logpdf_and_posterior_marginals(dm, yb[off:off + T], torch.from_numpy(Rn).cuda(), out=(om[off:off + T], ov[off:off + T]))
                 mean, var = mean.cpu().numpy(), var.cpu().numpy()
             names = set(hd.profile())
-            served[opt] = ("one-launch" if any(n.startswith("k_steady_one") for n in names) else "dense one-launch" if any(n.startswith("k_smooth_one") for n in names) and len(names) <= 2
+            served[opt] = ("one-launch" if any(n.startswith(("k_steady_one", "k_post_stream", "k_lml_stream")) for n in names) else "dense one-launch" if any(n.startswith("k_smooth_one") for n in names) and len(names) <= 2
                            else ("five-launch" if any(n.startswith("k_steady_apply") for n in names) else "general"))
             scale = max(1.0, float(np.max(np.abs(pm))))
             if not abs(lp - lp_ref) <= 1e-10 * abs(lp_ref):

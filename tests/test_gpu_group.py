@@ -8,7 +8,15 @@ import pytest
 from oracle import lgssm_ref as ref
 from tests import _util as U
 
+import os
+
 pytestmark = pytest.mark.gpu
+
+# The first launch of a state dimension's kernels costs 10-50 s of code-object loading and (d >= 9) the variant self-test: the driver's GPU tier
+# (20 minutes for everything) runs a spread of dimensions on both sides of every layout boundary; TGP_TEST_ALL_D=1 runs d = 5..16 (round-5 verdict,
+# housekeeping: the tier stood at 671 of 1200 s).  scripts/stress_general*.py draw every d.
+ALL_D = os.environ.get("TGP_TEST_ALL_D") == "1"
+GROUP_D = list(range(5, 17)) if ALL_D else [5, 6, 7, 8, 9, 11, 13, 16]
 
 
 @pytest.fixture(scope="module")
@@ -18,7 +26,7 @@ def tgp():
     return t
 
 
-@pytest.mark.parametrize("d", list(range(5, 17)))          # eight lanes per chunk up to d = 8, sixteen beyond; every d: many of these
+@pytest.mark.parametrize("d", GROUP_D)          # eight lanes per chunk up to d = 8, sixteen beyond; every d: many of these
 # kernels sit at the full 512-register budget with spills (scripts/list_kernel_resources.py), the regime of the hipcc defect of DESIGN 9
 @pytest.mark.parametrize("ordering", ["F", "R"])
 @pytest.mark.parametrize("per_step_R", [False, True])
@@ -71,7 +79,7 @@ def test_group_path_is_selected_for_d8(tgp):
     assert abs(lp - lp_ref) <= 1e-10 * abs(lp_ref)
 
 
-@pytest.mark.parametrize("d", [5, 7, 8, 9, 14])
+@pytest.mark.parametrize("d", [5, 7, 8, 9, 14] if ALL_D else [5, 7, 8, 9, 13])
 def test_group_scans_under_the_smoother(tgp, d):
     """posterior marginals with the group-layout block scans (filter elements forward, affine elements in reverse) under the
     lane-per-chunk passes, forced on for every d (TGP_OPT_GROUP = 2), against the oracle; several scan levels"""
@@ -100,7 +108,7 @@ def test_group_scans_under_the_smoother(tgp, d):
         np.testing.assert_allclose(gv, pC, rtol=1e-8, atol=1e-9)
 
 
-@pytest.mark.parametrize("d", list(range(5, 17)))
+@pytest.mark.parametrize("d", GROUP_D)
 @pytest.mark.parametrize("per_step_R", [False, True])
 def test_group_smoother_equals_oracle(tgp, d, per_step_R):
     """posterior marginals through the group-per-chunk smoother (pass 2 MODE 2 + pass 3 + group scans; tgp_group_smooth.hpp),
@@ -138,7 +146,7 @@ def test_group_smoother_equals_oracle(tgp, d, per_step_R):
         np.testing.assert_allclose(gv1, pC1, rtol=1e-8, atol=1e-9)
 
 
-@pytest.mark.parametrize("d,p", [(5, 2), (8, 3), (12, 5), (15, 4)])
+@pytest.mark.parametrize("d,p", [(5, 2), (8, 3), (12, 5), (15, 4)] if ALL_D else [(5, 2), (8, 3), (11, 5), (16, 4)])
 def test_group_vector_observations(tgp, d, p):
     """p > 1 (SmallOutputLGC with diagonal noise, shared emission block) through the group kernels: p scalar micro-steps per
     time step, predict only at the first; logpdf (with per-element missing data) and posterior marginals against the oracle's
@@ -175,7 +183,7 @@ def test_group_vector_observations(tgp, d, p):
         np.testing.assert_allclose(gv, np.diagonal(pC, axis1=-2, axis2=-1), rtol=1e-8, atol=1e-9)
 
 
-@pytest.mark.parametrize("d,p", [(5, 1), (8, 1), (12, 1), (8, 3), (15, 4)])
+@pytest.mark.parametrize("d,p", [(5, 1), (8, 1), (12, 1), (8, 3), (15, 4)] if ALL_D else [(5, 1), (8, 1), (11, 1), (8, 3), (16, 4)])
 @pytest.mark.parametrize("per_step_R", [False, True])
 def test_group_prior_marginals(tgp, d, p, per_step_R):
     """marginals(model) of a Forward LTI model (lgssm.jl:99-109) through the group kernels, scalar and vector observations"""
@@ -210,7 +218,7 @@ def test_group_prior_marginals(tgp, d, p, per_step_R):
         np.testing.assert_allclose(gv, want_v, rtol=1e-10, atol=1e-11)
 
 
-@pytest.mark.parametrize("d,p,pn", [(5, 1, 3), (8, 1, 7), (12, 3, 5), (15, 4, 20)])
+@pytest.mark.parametrize("d,p,pn", [(5, 1, 3), (8, 1, 7), (12, 3, 5), (15, 4, 20)] if ALL_D else [(5, 1, 3), (8, 1, 7), (11, 3, 5), (16, 4, 20)])
 def test_posterior_marginals_through_other_emissions(tgp, d, p, pn):
     """tgp_posterior_marginals_at: the smoothed state through an alternative emission block, against the oracle's posterior model
     with its emissions swapped (what pseudo_point.jl:198-235 does)"""
@@ -293,7 +301,7 @@ def test_group_filter_and_materialised_posterior(tgp, d, ordering):
             np.testing.assert_allclose(dpost.x0.P, post["x0P"], rtol=1e-8, atol=1e-9)
 
 
-@pytest.mark.parametrize("d", [5, 6, 7, 8, 9, 12, 14, 16])
+@pytest.mark.parametrize("d", [5, 6, 7, 8, 9, 12, 14, 16] if ALL_D else [5, 6, 7, 8, 9, 13, 16])
 @pytest.mark.parametrize("ordering", ["F", "R"])
 @pytest.mark.parametrize("p", [1, 2])
 def test_group_per_step_layout_equals_oracle(tgp, d, ordering, p):
