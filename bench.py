@@ -827,7 +827,11 @@ def main():
         # both (tgp_logpdf_and_posterior_marginals); --separate-calls issues the reference's two independent calls instead
         if args.separate_calls:
             lp = shard.logpdf(y)
-            mean, var = shard.posterior_marginals(y, Rnew)
+            if world == 1:      # (the result buffers of the previous step are reused, as in the combined call below: no allocation inside the timed region)
+                mean, var = shard.posterior_marginals(y, Rnew, out=step.out)
+                step.out = (mean, var)
+            else:
+                mean, var = shard.posterior_marginals(y, Rnew)
             return lp, mean, var
         if world == 1:
             # the result buffers of the previous step are reused (a repeated call with identical device pointers is what

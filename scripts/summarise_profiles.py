@@ -64,6 +64,15 @@ def label(name):
     m = re.match(r"tgp_modal::k_steady_one<(\d+), (\d+), (\d+)(?:, \w+)?>", n)
     if m:      # (logpdf and posterior calls run the same kernel: the larger launch is the posterior call)
         return f"k_steady_one<{m.group(2)}x{m.group(3)},posterior>"
+    m = re.match(r"tgp_post::k_post_stream<", n)
+    if m:
+        return "k_post_stream"
+    m = re.match(r"tgp_lml::k_lml_stream<(\d+), (\d+), ", n)
+    if m:
+        return f"k_lml_stream<{m.group(2)}>"
+    m = re.match(r"k_(reduce_filter|apply_filter|smooth)<", n)
+    if m:      # (the general engine's passes: bench.py labels them with their layout)
+        return None
     m = re.match(r"tgp_modal::k_smooth_one<", n)
     if m:      # (as above: the larger launch is the posterior call)
         return "k_smooth_one<posterior>"

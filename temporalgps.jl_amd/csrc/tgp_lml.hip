@@ -17,6 +17,8 @@ struct LArgs {
     double fd[D], fo[D], fb[D], fc[D], fw[D];      // z' = fd z + fo z_partner + fb y + fc (fc = fa - fb hh),  r = (y - hh) - fw . z
     double hh;
     double lvr[6][D], lvi[6][D];                   // M^(N 2^k), k < 6: the block form (re, signed im)
+    double wj[N][D];                               // fw' M^j (a row): step j of a lane sees the lane's start state through it
+    double WN[D][D];                               // sum_{j < N} w_j' w_j: what a lane's start state adds to its sum of squares
     double Wt[D][D];                               // sum_t w_t' w_t over a run's first tile
     long long T, nhs, G, R;
     const double* y;
@@ -161,9 +163,9 @@ __global__ __launch_bounds__(kNW * 64, (N == 16 ? 4 : 2)) void k_lml_stream(cons
             }
         };
 
-        double zin[D], acc = 0.0, vacc[D];
+        double zin[D], acc = 0.0;
 #pragma unroll
-        for (int i = 0; i < D; ++i) zin[i] = vacc[i] = 0.0;
+        for (int i = 0; i < D; ++i) zin[i] = 0.0;
         bool staged = t_lo + TILE <= t_hi;      // the tile about to be worked on travels through `stage` (a whole tile) -- wave-uniform
         if (staged) issue_loads(t_lo);
         bool first_tile = true;
@@ -175,12 +177,18 @@ __global__ __launch_bounds__(kNW * 64, (N == 16 ? 4 : 2)) void k_lml_stream(cons
             lds_sync();
             staged = tile_t0 + 2 * TILE <= t_hi;
             if (staged) issue_loads(tile_t0 + TILE);      // the next tile's observations travel while this one is in work
-            // ---- sweep 1: the lane's end state from a zero start (the recursion itself: no tables, every coefficient a register for the whole tile);
-            // CH steps per trip of the rolled loops -- unrolled whole, the scheduler computes every fb u + fc ahead and spills
-            constexpr int CH = 8;
-            double z[D];
+            // ---- ONE sweep from a zero start (a whole tile): the innovations r0 of the lane's steps are never kept -- what the lane's true
+            // start state st makes of them is a quadratic form,  sum_j (r0_j - w_j . st)^2 = q - 2 st . v + st' WN st  with  q = sum r0^2,
+            // v = sum_j w_j r0_j (w_j = fw' M^j from the argument table, WN = sum_j w_j' w_j data-free) -- 17 instructions per step at d = 3 where the
+            // two-sweep form below spends 23.  A tile with steps beyond the series' end (one per launch at most) takes the two sweeps.
+            constexpr int CH = N == 16 ? 4 : 8;
+            const long long nv = t_hi - tile_t0;      // valid steps of the tile (wave-uniform)
+            const bool full = nv >= TILE;
+            const long long left_steps = nv - (long long)lane * N;
+            const int nvalid = left_steps >= N ? N : (left_steps > 0 ? (int)left_steps : 0);
+            double z[D], q = 0.0, v[D];
 #pragma unroll
-            for (int i = 0; i < D; ++i) z[i] = 0.0;
+            for (int i = 0; i < D; ++i) z[i] = v[i] = 0.0;
 #pragma unroll 1
             for (int jc = 0; jc < N; jc += CH) {
                 double u[CH];
@@ -190,13 +198,37 @@ __global__ __launch_bounds__(kNW * 64, (N == 16 ? 4 : 2)) void k_lml_stream(cons
                     u[2 * j] = w.x;
                     u[2 * j + 1] = w.y;
                 }
+                if (full) {      // (wave-uniform)
 #pragma unroll
-                for (int j = 0; j < CH; ++j) {
-                    double nz[D];
+                    for (int j = 0; j < CH; ++j) {
+                        double r = u[j] - ka.hh;
 #pragma unroll
-                    for (int i = 0; i < D; ++i) nz[i] = fma(ka.fd[i], z[i], fma(ka.fo[i], z[partner<D>(i)], fma(ka.fb[i], u[j], ka.fc[i])));
+                        for (int i = 0; i < D; ++i) r = fma(-ka.fw[i], z[i], r);
+                        q = fma(r, r, q);
 #pragma unroll
-                    for (int i = 0; i < D; ++i) z[i] = nz[i];
+                        for (int i = 0; i < D; ++i) v[i] = fma(ka.wj[jc + j][i], r, v[i]);
+                        double nz[D];
+#pragma unroll
+                        for (int i = 0; i < D; ++i) nz[i] = fma(ka.fd[i], z[i], fma(ka.fo[i], z[partner<D>(i)], fma(ka.fb[i], u[j], ka.fc[i])));
+#pragma unroll
+                        for (int i = 0; i < D; ++i) z[i] = nz[i];
+                    }
+                } else {         // the series' last tile: innovations of steps that do not exist do not count
+#pragma unroll
+                    for (int j = 0; j < CH; ++j) {
+                        double r = u[j] - ka.hh;
+#pragma unroll
+                        for (int i = 0; i < D; ++i) r = fma(-ka.fw[i], z[i], r);
+                        r = jc + j < nvalid ? r : 0.0;
+                        q = fma(r, r, q);
+#pragma unroll
+                        for (int i = 0; i < D; ++i) v[i] = fma(ka.wj[jc + j][i], r, v[i]);
+                        double nz[D];
+#pragma unroll
+                        for (int i = 0; i < D; ++i) nz[i] = fma(ka.fd[i], z[i], fma(ka.fo[i], z[partner<D>(i)], fma(ka.fb[i], u[j], ka.fc[i])));
+#pragma unroll
+                        for (int i = 0; i < D; ++i) z[i] = nz[i];
+                    }
                 }
             }
             // the state entering the tile goes in behind lane 0's steps: e_0 += M^N zin
@@ -235,73 +267,72 @@ __global__ __launch_bounds__(kNW * 64, (N == 16 ? 4 : 2)) void k_lml_stream(cons
 #pragma unroll
                 for (int i = 0; i < D; ++i) z[i] = fma(mpr[i], g[i], fma(mpi[i], g[partner<D>(i)], z[i]));
             }
+            // the tile's true end state: the inclusive value of its last lane with a step in it
+            const int le = full ? 63 : (int)((nv - 1) / N);
+            double zend[D];
+#pragma unroll
+            for (int i = 0; i < D; ++i) zend[i] = readlane_d(z[i], le);
             // the state in front of the lane's steps: its left neighbour's (lane 0: the tile's)
 #pragma unroll
             for (int i = 0; i < D; ++i) {
                 const double sh = dpp_mov<0x138>(z[i]);
                 z[i] = lane == 0 ? zin[i] : sh;
             }
-            // ---- sweep 2: the recursion itself from the true start state.  GENERAL: a run's first tile (V is accumulated) or a tile with
-            // steps beyond the run's end (their innovations do not count)
-            const long long nv = t_hi - tile_t0;      // valid steps of the tile (wave-uniform)
-            const bool full = nv >= TILE;
-            auto sweep2 = [&](auto general_tag) {
-                constexpr bool GENERAL = decltype(general_tag)::value;
-                const long long left = nv - (long long)lane * N;
-                const int nvalid = left >= N ? N : (left > 0 ? (int)left : 0);
-                double wr[D];      // fw' M^j, the row through which step j sees the lane's start state (GENERAL)
+            {
+                // what the start state makes of the lane's sum of squares: q - 2 st . v + st' W st, W the sum of w_j' w_j over the lane's steps
+                double ws[D], lin = 0.0, quad = 0.0;
 #pragma unroll
-                for (int i = 0; i < D; ++i) wr[i] = ka.fw[i];
+                for (int i = 0; i < D; ++i) {
+                    double t = 0.0;
+#pragma unroll
+                    for (int k = 0; k < D; ++k) t = fma(ka.WN[i][k], z[k], t);
+                    ws[i] = t;
+                    lin = fma(z[i], v[i], lin);
+                    quad = fma(z[i], t, quad);
+                }
+                if (!full) {      // (the series' last tile: lanes with fewer than N steps sum over the steps they have)
+                    double qp = 0.0;
 #pragma unroll 1
-                for (int jc = 0; jc < N; jc += CH) {
-                    double u[CH];
+                    for (int j = 0; j < N; ++j) {
+                        double t = 0.0;
 #pragma unroll
-                    for (int j = 0; j < CH / 2; ++j) {
-                        const v2d w = sY[slot_of<PPL>(lane, jc / 2 + j)];
-                        u[2 * j] = w.x;
-                        u[2 * j + 1] = w.y;
+                        for (int i = 0; i < D; ++i) t = fma(ka.wj[j][i], z[i], t);
+                        qp = j < nvalid ? fma(t, t, qp) : qp;
                     }
+                    quad = nvalid == N ? quad : qp;
+                    // (V of a partial FIRST tile -- a series shorter than one tile -- would need the partial lanes' own W st: ws is used below as it is
+                    //  for whole lanes; the one partial lane's share is recomputed from its steps)
+                    if (nvalid != N) {
 #pragma unroll
-                    for (int j = 0; j < CH; ++j) {
-                        double r = u[j] - ka.hh;
+                        for (int i = 0; i < D; ++i) ws[i] = 0.0;
+#pragma unroll 1
+                        for (int j = 0; j < N; ++j) {
+                            double t = 0.0;
 #pragma unroll
-                        for (int i = 0; i < D; ++i) r = fma(-ka.fw[i], z[i], r);
-                        if (GENERAL) {
-                            r = jc + j < nvalid ? r : 0.0;
-                            double nw[D];
+                            for (int i = 0; i < D; ++i) t = fma(ka.wj[j][i], z[i], t);
+                            t = j < nvalid ? t : 0.0;
 #pragma unroll
-                            for (int i = 0; i < D; ++i) {
-                                vacc[i] = fma(wr[i], r, vacc[i]);
-                                nw[i] = fma(wr[i], ka.fd[i], partner<D>(i) != i ? wr[partner<D>(i)] * ka.fo[partner<D>(i)] : 0.0);
-                            }
-#pragma unroll
-                            for (int i = 0; i < D; ++i) wr[i] = nw[i];
+                            for (int i = 0; i < D; ++i) ws[i] = fma(ka.wj[j][i], t, ws[i]);
                         }
-                        acc = fma(r, r, acc);
-                        double nz[D];
-#pragma unroll
-                        for (int i = 0; i < D; ++i) nz[i] = fma(ka.fd[i], z[i], fma(ka.fo[i], z[partner<D>(i)], fma(ka.fb[i], u[j], ka.fc[i])));
-#pragma unroll
-                        for (int i = 0; i < D; ++i) z[i] = nz[i];
                     }
                 }
-            };
-            if (!full || first_tile) sweep2(std::true_type{});
-            else sweep2(std::false_type{});
-            if (first_tile) {
-                // V = sum_l v_l M^(N l): a row vector times the block form, (x P)_j = x_j pr_j + x_partner pi_partner
-                double pr[D], pi[D], x[D];
-                lane_power(lane, pr, pi);
+                acc += fma(-2.0, lin, q) + quad;
+                if (first_tile) {
+                    // the run's own start state (zero for now) moves the tile's innovations through V = sum_l (v_l - W st_l) M^(N l) (st_l: from a
+                    // zero tile start, which is what this tile ran with): a row vector times the block form, (x P)_j = x_j pr_j + x_partner pi_partner
+                    double pr[D], pi[D], x[D], xm[D];
+                    lane_power(lane, pr, pi);
 #pragma unroll
-                for (int i = 0; i < D; ++i) x[i] = fma(vacc[i], pr[i], partner<D>(i) != i ? vacc[partner<D>(i)] * pi[partner<D>(i)] : 0.0);
+                    for (int i = 0; i < D; ++i) x[i] = v[i] - ws[i];
 #pragma unroll
-                for (int i = 0; i < D; ++i) V[i] = wave_sum(x[i]);
-                first_tile = false;
+                    for (int i = 0; i < D; ++i) xm[i] = fma(x[i], pr[i], partner<D>(i) != i ? x[partner<D>(i)] * pi[partner<D>(i)] : 0.0);
+#pragma unroll
+                    for (int i = 0; i < D; ++i) V[i] = wave_sum(xm[i]);
+                    first_tile = false;
+                }
             }
-            // the state behind the tile's last valid lane enters the next tile
-            const int le = full ? 63 : (int)((nv - 1) / N);
 #pragma unroll
-            for (int i = 0; i < D; ++i) zin[i] = readlane_d(z[i], le);
+            for (int i = 0; i < D; ++i) zin[i] = zend[i];
             lds_sync();      // (the slice may be overwritten from here on)
         }
         Q = wave_sum(acc);
@@ -406,6 +437,23 @@ void fill(LArgs<D, N>& ka, const tgp_plan::Modal& md) {
         }
         bsq(D, pr, pi);
     }
+    // wj[j] = fw' M^j; WN = sum_j wj[j]' wj[j]
+    {
+        const int np = md.npair;
+        double x[tgp_plan::kMaxD], nx[tgp_plan::kMaxD];
+        for (int i = 0; i < D; ++i) {
+            x[i] = md.fw[i];
+            for (int k = 0; k < D; ++k) ka.WN[i][k] = 0.0;
+        }
+        for (int j = 0; j < N; ++j) {
+            for (int i = 0; i < D; ++i) {
+                ka.wj[j][i] = x[i];
+                for (int k = 0; k < D; ++k) ka.WN[i][k] += x[i] * x[k];
+            }
+            vmulb(D, np, md.fd, md.fo, x, nx);
+            for (int i = 0; i < D; ++i) x[i] = nx[i];
+        }
+    }
 }
 
 template <int D, int N>
@@ -454,8 +502,8 @@ Geometry choose_geometry(const tgp_plan::Modal& md, long long T) {
         const int n = v ? std::atoi(v) : 0;
         return (n == 16 || n == 32) ? n : 0;
     }();
-    // sixteen steps per lane and four waves per SIMD where the registers allow it (d <= 4), thirty-two and two beyond
-    g.n = forced ? forced : (md.d <= 4 ? 16 : 32);
+    // sixteen steps per lane and four waves per SIMD where the registers allow it (d <= 2), thirty-two and two beyond
+    g.n = forced ? forced : (md.d <= 2 ? 16 : 32);      // (d = 3 at sixteen steps per lane: 28 registers spilled under the four-waves budget)
     if (64 * g.n < md.halo) g.n = 32;      // (a tile must outlast the halo: 2048 >= kHaloMax)
     const long long Tp = T - md.nhs, tile = 64LL * g.n;
     g.G = (Tp + tile - 1) / tile;          // tiles behind the head; the last one may be partial

@@ -477,10 +477,11 @@ class ShardedLGSSM:
         # host transport (gloo groups, test engines): the two calls, sharing nothing
         return (self.logpdf(y),) + tuple(self.posterior_marginals(y, R_new))
 
-    def posterior_marginals(self, y, R_new):
-        """This rank's slice of marginals(posterior(fx, y)(x)); R_new is the slice's new noise (or a scalar)."""
+    def posterior_marginals(self, y, R_new, out=None):
+        """This rank's slice of marginals(posterior(fx, y)(x)); R_new is the slice's new noise (or a scalar).  out = (mean, var) of an earlier call:
+        written in place (single GPU)."""
         if self.world == 1 and self.engine is None:
-            return L.posterior_marginals(self.model, y, R_new)
+            return L.posterior_marginals(self.model, y, R_new, out=out)
         if self._device_resident():
             try:
                 out = self._posterior_marginals_device(y, R_new)
