@@ -1,6 +1,7 @@
 #!/bin/bash
 # Profile collection on the GPU box (run through gpurun); one script for every round and every workload class (it replaces the per-round copies).
 #   collect_profiles.sh <tag> lti   [workload] [bench args...]   the headline command: bench.py on the stationary-gain engines
+#   collect_profiles.sh <tag> per_step [workload]               the general (per-step) layout: the monoid scan proper
 #   collect_profiles.sh <tag> sweep                              the predict-path legs (sweep engine): scripts/time_sweep.py
 #   collect_profiles.sh <tag> cfg5  [T]                          BASELINE config 5 (dense engine): bench.py --workload cfg5
 # Each class: 1. rocprofv3 --kernel-trace --stats of the command; 2. PMC passes, each in its OWN run with --kernel-trace only (never with
@@ -17,6 +18,11 @@ case $CLASS in
     OUT=$ROOT/gpurun_out/prof_${TAG}_lti$SUF; mkdir -p $OUT
     B="python $ROOT/bench.py --workload $WL --no-cpu-baseline --no-general-leg ${@:2}"
     FULL="$B --steps 10 --warmup 2"; SHORT="$B --steps 3 --warmup 1" ;;
+  per_step)
+    WL=${1:-matern52_d3}; SUF=""; [ "$WL" != matern52_d3 ] && SUF="_$WL"
+    OUT=$ROOT/gpurun_out/prof_${TAG}_per_step$SUF; mkdir -p $OUT
+    B="python $ROOT/bench.py --workload $WL --layout per_step --no-cpu-baseline --no-general-leg ${@:2}"
+    FULL="$B --steps 6 --warmup 2"; SHORT="$B --steps 2 --warmup 1" ;;
   sweep)
     OUT=$ROOT/gpurun_out/prof_${TAG}_sweep; mkdir -p $OUT
     FULL="python $ROOT/scripts/time_sweep.py 1e7 matern52 3"; SHORT="python $ROOT/scripts/time_sweep.py 1e7 matern52 1" ;;

@@ -23,9 +23,9 @@ wl = sys.argv[3] if len(sys.argv) > 3 and not sys.argv[3].startswith("--") and s
 from_box = "--from-box" in sys.argv
 WL_D = {"matern52_d3": 3, "matern32_d2": 2, "sum52_12_d4": 4, "sum52_32_d5": 5, "sum52_52_d6": 6, "sum52_32_32_d7": 7, "sum52_52_32_d8": 8,
         "sum52_52s_d6": 6, "sum52_32s_32_d7": 7, "sum52_52s_32_d8": 8}
-if cls == "lti":
+if cls in ("lti", "per_step"):
     wl = wl or "matern52_d3"
-suf = "" if (cls != "lti" or wl == "matern52_d3") else "_" + wl
+suf = "" if (cls not in ("lti", "per_step") or wl == "matern52_d3") else "_" + wl
 src = os.path.join(root, "gpurun_out", f"prof_{tag}_{cls}{suf}")
 dst = src if from_box else os.path.join(root, "profiles")
 key = f"d={WL_D.get(wl, 3)}" if cls != "cfg5" else "d=768"
@@ -70,9 +70,13 @@ def label(name):
     m = re.match(r"tgp_lml::k_lml_stream<(\d+), (\d+), ", n)
     if m:
         return f"k_lml_stream<{m.group(2)}>"
-    m = re.match(r"k_(reduce_filter|apply_filter|smooth)<", n)
-    if m:      # (the general engine's passes: bench.py labels them with their layout)
-        return None
+    m = re.match(r"(?:\w+::)*k_(reduce_filter|apply_filter|smooth)<(\d+), (true|false)(?:, (\w+))?", n)
+    if m:      # the general engine's passes: bench.py labels them with their layout (and pass 2 with its mode)
+        lay = "lti" if m.group(3) == "true" else "per-step"
+        if m.group(1) == "apply_filter":
+            mode = {"0": "logpdf", "1": "filter", "2": "posterior", "3": "materialise", "4": "scratch"}.get(m.group(4) or "", m.group(4) or "?")
+            return f"k_apply_filter<{lay},{mode}>"
+        return f"k_{m.group(1)}<{lay}>"
     m = re.match(r"tgp_modal::k_smooth_one<", n)
     if m:      # (as above: the larger launch is the posterior call)
         return "k_smooth_one<posterior>"
