@@ -150,6 +150,9 @@ typedef struct tgp_handle tgp_handle;
 #define TGP_OPT_SWEEP_CHUNK 15       /* tests: steps per chunk of the sweep engine (0 automatic) */
 #define TGP_OPT_SWEEP_WARMUP 16      /* tests: forward warm-up steps (0 automatic); a forced geometry is never repaired by longer warm-ups */
 #define TGP_OPT_SWEEP_WARMUP_BACK 17 /* tests: backward warm-up steps (0 automatic) */
+#define TGP_OPT_STREAM_MIN_T 18 /* series length from which the STREAMING kernels of the stationary-gain engine serve a call: persistent
+                                   waves with ~7 us more fixed latency and 1.3 - 2.7 x the throughput of k_steady_one.  -1 (default): the measured
+                                   crossovers (logpdf 5e6, posterior marginals 3e6 steps at d = 3); 0: always (the tests); a length: from there on */
 #define TGP_OPT_TIMING 6 /* 1: record the hipEvents behind tgp_last_timing (off by default: ~30 us of host time per call) */
 #define TGP_OPT_FUSE_SCAN 4 /* 1 (default): the level-0 scan reduce / apply of the forward scan run inside the chunk kernels;
                                0: stand-alone k_scan_reduce / k_scan_apply launches (bit-identical results, for A/B timing) */

@@ -443,6 +443,7 @@ struct tgp_handle {
     // variance or an emission offset per step, irregular spacing.  One launch; a call whose warm-ups prove too short is repeated with longer
     // ones (remembered for the bound model), a model it does not serve goes on to the general engine.
     int opt_sweep = 1;
+    long long opt_stream_min_T = -1;      // TGP_OPT_STREAM_MIN_T
     tgp_sweep::Engine* sweep = nullptr;
     int sweep_state = 0;          // 0 untried for the bound model, 1 served the last call, -1 does not apply
     bool sweep_last = false;
@@ -1280,6 +1281,7 @@ int modal_call(tgp_handle* h, const double* y, uint32_t flags, const double* Rne
     mh.A = q; mh.a = q + dd; mh.Q = q + dd + d; mh.H = q + 2 * dd + d; mh.hh = q + 2 * dd + 2 * d; mh.R = h->has_R_over ? &h->R_over : q + 2 * dd + 2 * d + 1;
     mh.x0m = h->x0m.data();
     mh.x0P = h->x0P.data();
+    tgp_modal::set_stream_min_T(h->modal, h->opt_stream_min_T);
     if (!tgp_modal::plan(h->modal, mh, h->T, /*logpdf_only=*/mean_out == nullptr && var_out == nullptr)) {
         h->modal_state = -1;
         if (getenv("TGP_STEADY_DEBUG") != nullptr) {
@@ -1718,6 +1720,10 @@ int tgp_set_option(tgp_handle* h, int option, int64_t value) {
     if (option == TGP_OPT_SWEEP) {
         h->opt_sweep = value != 0;
         h->sweep_state = 0;
+        return TGP_OK;
+    }
+    if (option == TGP_OPT_STREAM_MIN_T) {
+        h->opt_stream_min_T = value < 0 ? -1 : (long long)value;
         return TGP_OK;
     }
     if (option == TGP_OPT_SWEEP_CHUNK || option == TGP_OPT_SWEEP_WARMUP || option == TGP_OPT_SWEEP_WARMUP_BACK) {

@@ -20,7 +20,7 @@ struct LArgs {
     double wj[N][D];                               // fw' M^j (a row): step j of a lane sees the lane's start state through it
     double WN[D][D];                               // sum_{j < N} w_j' w_j: what a lane's start state adds to its sum of squares
     double Wt[D][D];                               // sum_t w_t' w_t over a run's first tile
-    long long T, nhs, G, R;
+    long long T, nhs, G, R, C;      // G tiles behind the head, R runs of C tiles
     const double* y;
     double* part;
     double* head_in;
@@ -28,6 +28,7 @@ struct LArgs {
     unsigned* counter;
     long long seq;
     int nwg;
+    int dbg;            // development: 1 = wave 0 of every workgroup stamps its phases (100 MHz) into part[4096 + 8 wg ...]
     int done_flag;      // 1: the last workgroup to finish says so in flags[1] (the host then needs no stream synchronisation to read `part`)
 };
 
@@ -80,6 +81,17 @@ __global__ __launch_bounds__(kNW * 64, (N == 16 ? 4 : 2)) void k_lml_stream(cons
     typedef const __attribute__((address_space(4))) LArgs<D, N>* KaPtr;
     KaPtr kap = (KaPtr)__builtin_amdgcn_kernarg_segment_ptr();
 #define ka (*kap)
+    {
+        // Touch every 64-byte line of the argument segment in ONE batch of scalar loads: the segment lives in host memory, a cold line is a PCIe round
+        // trip (~2 us), and the optimisation barriers below make the waves read the coefficients phase by phase -- five or six cold batches in a
+        // row were ~8 us of every wave's life, the whole launch at small T (k_steady_one reads its arguments in one batch by construction)
+        typedef const __attribute__((address_space(4))) unsigned* WordPtr;
+        WordPtr w = (WordPtr)kap;
+        unsigned warm = 0u;
+#pragma unroll
+        for (unsigned o = 0; o < sizeof(LArgs<D, N>); o += 64) warm ^= w[o / 4];
+        asm volatile("" ::"s"(warm));
+    }
     constexpr int PPL = N / 2, TILE = 64 * N;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -89,18 +101,38 @@ __global__ __launch_bounds__(kNW * 64, (N == 16 ? 4 : 2)) void k_lml_stream(cons
 
     const long long run = (long long)blockIdx.x * kNW + wave;
     const bool active = run < ka.R;
+    const bool stamp = ka.dbg && wave == 0 && lane == 0 && blockIdx.x < 512;
+    if (stamp) ka.part[4096 + 8 * blockIdx.x + 0] = (double)wall_clock64();
     // the head's observations to the host, first thing (its forward recursion runs there, beside the kernel)
-    if (blockIdx.x == 0 && wave == kNW - 1) {
-        for (int t = lane; t < (int)ka.nhs; t += 64) ka.head_in[t] = ka.y[t];
-        __threadfence_system();
-        if (lane == 0) __hip_atomic_store(ka.flags, 2 * ka.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    // The head's observations to the host (its forward recursion runs there, beside the kernel): write-through stores now, the flag at the END of this
+    // wave's run -- the stores' acknowledgement from host memory takes ~7 us (measured: the workgroup's barrier stood that long behind this wave when
+    // it waited for it up here); a head wave without a run (a short series) raises no flag at all: the kernel's end delivers the data
+    const bool head_wave = blockIdx.x == 0 && wave == kNW - 1;
+    bool head_flag_due = false;
+    if (head_wave) {
+        for (int t = lane; t < (int)ka.nhs; t += 64) {
+            const double v = ka.y[t];
+            double* dst = ka.head_in + t;
+            asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(dst), "v"(v) : "memory");
+        }
+        head_flag_due = true;
     }
+    auto raise_head_flag = [&]() {      // (every vector-memory operation of the wave has returned when this is called)
+        if (lane == 0) {
+            const long long fv = 2 * ka.seq;
+            long long* fp = ka.flags;
+            asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(fp), "v"(fv) : "memory");
+        }
+        head_flag_due = false;
+    };
     double Q = 0.0, V[D], E[D];
 #pragma unroll
     for (int i = 0; i < D; ++i) V[i] = E[i] = 0.0;
     if (active) {
         // the run's tiles: the G tiles behind the head are dealt out evenly; only the series' last tile can be a partial one
-        const long long g0 = run * ka.G / ka.R, g1 = (run + 1) * ka.G / ka.R;
+        // every run holds C tiles (the last one what is left): with 2.4 tiles per wave slot dealt out as 2 or 3, the three-tile runs ended 7 us
+        // behind the two-tile ones and the machine stood half empty meanwhile
+        const long long g0 = run * ka.C, g1 = run == ka.R - 1 ? ka.G : g0 + ka.C;      // (the last run takes what is left, a partial last tile included)
         const long long t_lo = ka.nhs + g0 * TILE;
         long long t_hi = ka.nhs + g1 * TILE;
         t_hi = t_hi < ka.T ? t_hi : ka.T;
@@ -175,6 +207,10 @@ __global__ __launch_bounds__(kNW * 64, (N == 16 ? 4 : 2)) void k_lml_stream(cons
             if (staged) stage_to_lds();      // (waits for the loads)
             else load_tail(tile_t0);
             lds_sync();
+            if (stamp && first_tile) ka.part[4096 + 8 * blockIdx.x + 1] = (double)wall_clock64();
+            // the two waves of a SIMD take turns at the higher priority, tile by tile (tgp_post.hip: the arbiter prefers the older wave)
+            if ((((int)((tile_t0 - t_lo) / TILE)) ^ (wave >> 2)) & 1) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
             staged = tile_t0 + 2 * TILE <= t_hi;
             if (staged) issue_loads(tile_t0 + TILE);      // the next tile's observations travel while this one is in work
             // ---- ONE sweep from a zero start (a whole tile): the innovations r0 of the lane's steps are never kept -- what the lane's true
@@ -338,7 +374,13 @@ __global__ __launch_bounds__(kNW * 64, (N == 16 ? 4 : 2)) void k_lml_stream(cons
         Q = wave_sum(acc);
 #pragma unroll
         for (int i = 0; i < D; ++i) E[i] = zin[i];
+        if (stamp) ka.part[4096 + 8 * blockIdx.x + 2] = (double)wall_clock64();
     }
+    if (head_flag_due && active) {      // (the stores were issued a whole run ago: nothing to wait for)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        raise_head_flag();
+    }
+    __builtin_amdgcn_s_setprio(0);
     if (lane == 0) {
         double* p = sPost + wave * PW;
         p[0] = Q;
@@ -350,6 +392,7 @@ __global__ __launch_bounds__(kNW * 64, (N == 16 ? 4 : 2)) void k_lml_stream(cons
         }
     }
     __syncthreads();
+    if (stamp) ka.part[4096 + 8 * blockIdx.x + 3] = (double)wall_clock64();
     if (threadIdx.x == 0) {
         // the runs of this workgroup close each other: run w starts from the end state of run w - 1; run 0 is the host's to close
         double tot = sPost[0], el[D];
@@ -378,6 +421,7 @@ __global__ __launch_bounds__(kNW * 64, (N == 16 ? 4 : 2)) void k_lml_stream(cons
             out[1 + i] = sPost[2 + i];
             out[1 + D + i] = el[i];
         }
+        if (stamp) ka.part[4096 + 8 * blockIdx.x + 4] = (double)wall_clock64();
         if (ka.done_flag) {
             __threadfence_system();
             const unsigned old = atomicAdd(ka.counter, 1u);
@@ -467,6 +511,7 @@ int launch(hipStream_t st, const tgp_plan::Modal& md, const Geometry& g, long lo
     a.nhs = md.nhs;
     a.G = g.G;
     a.R = g.R;
+    a.C = g.C;
     a.y = y;
     a.part = b.part;
     a.head_in = b.head_in;
@@ -475,7 +520,18 @@ int launch(hipStream_t st, const tgp_plan::Modal& md, const Geometry& g, long lo
     a.seq = seq;
     a.nwg = g.nwg;
     a.done_flag = b.done_flag ? 1 : 0;
-    const size_t lds = (size_t)kNW * 64 * (N / 2) * 16 + (size_t)kNW * (2 + 2 * D) * sizeof(double);
+    {
+        static const int dbg = [] {
+            const char* v = std::getenv("TGP_LML_DBG");
+            return v ? std::atoi(v) : 0;
+        }();
+        a.dbg = dbg;
+    }
+    static const size_t lds_pad = [] {      // TGP_LML_LDS_PAD=<bytes>: development (does a launch that asks for more LDS start later?)
+        const char* v = std::getenv("TGP_LML_LDS_PAD");
+        return v ? (size_t)std::atol(v) : (size_t)0;
+    }();
+    const size_t lds = (size_t)kNW * 64 * (N / 2) * 16 + (size_t)kNW * (2 + 2 * D) * sizeof(double) + lds_pad;
     const bool aligned = (reinterpret_cast<uintptr_t>(y) & 15) == 0;
     // (the limit on dynamic LDS is a per-device attribute of the function)
     static bool attr_done_dev[64][2] = {{false, false}};
@@ -510,7 +566,8 @@ Geometry choose_geometry(const tgp_plan::Modal& md, long long T) {
     long long R = Tp / tile;               // a run holds at least one WHOLE tile (a partial last tile is its run's second or later), ...
     if (R < 1) R = 1;                      // ... unless the series is shorter than a tile: one run, one partial tile
     const long long rmax = (long long)(g.n == 16 ? kMaxWG : kMaxWG / 2) * kNW;      // four (n = 16) or two waves per SIMD: what LDS and registers hold
-    g.R = R < rmax ? R : rmax;
+    g.C = R <= rmax ? 1 : (R + rmax - 1) / rmax;      // whole tiles per run: equal shares (the last run: what is left of them, and a partial last tile)
+    g.R = (R + g.C - 1) / g.C;
     g.nwg = (int)((g.R + kNW - 1) / kNW);
     g.first_tile = Tp < tile ? Tp : tile;
     return g;

@@ -1089,6 +1089,7 @@ struct Engine {
     unsigned* lcounter = nullptr;      // device memory: the workgroups' arrival count (zero between launches)
     bool lml_flagged = false;          // the launched kernel raises flags[1] at its end
     void* pxch = nullptr;              // device memory: the exchange records of the streaming posterior kernel's runs (tgp_post.hpp)
+    long long stream_min_T = -1;       // TGP_OPT_STREAM_MIN_T
 };
 namespace {
 constexpr size_t kHH = tgp_plan::kHeadMax;
@@ -1100,6 +1101,15 @@ inline long long* hh_flag(Engine* e) { return reinterpret_cast<long long*>(e->hh
 }  // namespace
 
 Engine* create() { return new Engine(); }
+void set_stream_min_T(Engine* e, long long v) {
+    if (e) e->stream_min_T = v;
+}
+namespace {
+// The streaming kernels' crossovers against k_steady_one (scripts/r06_kernel_T.py, d = 3: fixed 18 / 24 us + 0.7 / 2.9 us per 1e6 steps against
+// 12 / 22 us + 1.9 / 3.8): below them the short-lived workgroups of k_steady_one finish first
+constexpr long long kLmlMinT = 5000000, kPostMinT = 3000000;
+inline bool stream_serves(const Engine* e, long long T, long long crossover) { return T >= (e->stream_min_T < 0 ? crossover : e->stream_min_T); }
+}  // namespace
 void destroy(Engine* e) {
     if (!e) return;
     delete e->tab;
@@ -1132,7 +1142,7 @@ static bool head_scans_enabled() {      // TGP_MODAL_HEAD_SCANS=0: the sequentia
 // buffer on a 16-byte boundary; segments, in-kernel heads and odd pointers stay on k_steady_one.
 static bool use_post_stream(const Engine* e, const Call& c) {
     if (c.mean == nullptr || !e->hosthead || c.seg_lo != 0 || (c.seg_hi >= 0 && c.seg_hi < c.T)) return false;
-    if (!tgp_post::applies(e->md, c.T)) return false;
+    if (!tgp_post::applies(e->md, c.T) || !stream_serves(e, c.T, kPostMinT)) return false;
     auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     return al(c.y) && al(c.mean) && al(c.var) && (!c.rnew_per_step || al(c.Rnew));
 }
@@ -1449,10 +1459,10 @@ bool plan(Engine* e, const tgp_plan::ModelHost& m, long long T, bool logpdf_only
     layout_tables(e);
     e->mh = m;
     e->hh_T = T;
-    if (logpdf_only && lml_stream_enabled()) {
+    if (logpdf_only && lml_stream_enabled() && stream_serves(e, T, kLmlMinT)) {
         // the streaming logpdf kernel: no tables (the head runs on the host from build_core's gains), no wait inside the kernel
         e->lg = tgp_lml::choose_geometry(e->md, T);
-        const size_t need = tgp_lml::part_doubles(e->md.d) + 64;
+        const size_t need = std::max<size_t>(tgp_lml::part_doubles(e->md.d) + 64, 4096 + 8 * 512 + 64);      // (+ the development stamps of TGP_LML_DBG)
         if (need > e->part_cap) {
             if (e->part) (void)tgp_alloc::host_free(e->part);
             e->part = nullptr;
@@ -1540,11 +1550,9 @@ void raise_flag(long long* f, long long v) {
 bool complete(Engine* e, long long T) {
     if (e->began && e->lml) {
         // the head's forward recursion, as soon as the kernel has handed its observations over (or the stream has drained)
-        const bool ok = await_host_flag(hh_flag(e), 2 * e->seq, e->stream);
-        if (!ok) {
-            e->info.why = tgp_plan::kEigFail;
-            return false;
-        }
+        // (false: the stream has drained without the flag -- a short series, whose head wave raises none: the kernel's end has delivered the data.
+        //  A launch that failed is the caller's stream synchronisation's to report; the head of garbage is then discarded with the rest)
+        (void)await_host_flag(hh_flag(e), 2 * e->seq, e->stream);
         tgp_plan::modal_head_forward_any(e->mh, e->md, *e->tab, hh_in(e), e->hr, hh_z0(e), &e->host_quad);
         return true;
     }
@@ -1719,6 +1727,19 @@ double finish(const Engine* e, long long T) {
         }
         fprintf(stderr, "[tgp post] %lld runs: starts within %.2f us; ends: first %.2f, mean %.2f, last %.2f us after the first start (run %lld); run 0 ends %.2f, run R/2 ends %.2f\n", n,
                 (s1 - s0) * 0.01, (e0 - s0) * 0.01, (esum / n - s0) * 0.01, (e1 - s0) * 0.01, elast, (q[1] - s0) * 0.01, (q[2 * (R / 2) + 1] - s0) * 0.01);
+    }
+    if (e->lml && std::getenv("TGP_LML_DBG") != nullptr) {
+        const double* q = e->part + 4096;
+        double s0 = 1e300, s1 = 0, l1 = 0, c1 = 0, b1 = 0, e1 = 0;
+        for (int g = 0; g < e->lg.nwg && g < 512; ++g) {
+            s0 = std::min(s0, q[8 * g]);
+            s1 = std::max(s1, q[8 * g]);
+        }
+        for (int g = 0; g < e->lg.nwg && g < 512; ++g) {
+            l1 = std::max(l1, q[8 * g + 1] - s0); c1 = std::max(c1, q[8 * g + 2] - s0); b1 = std::max(b1, q[8 * g + 3] - s0); e1 = std::max(e1, q[8 * g + 4] - s0);
+        }
+        fprintf(stderr, "[tgp lml] %d workgroups; wave 0 of each, us after the first start: starts within %.2f; first tile landed by %.2f; runs done by %.2f; barrier passed by %.2f; triples written by %.2f\n",
+                e->lg.nwg, (s1 - s0) * 0.01, l1 * 0.01, c1 * 0.01, b1 * 0.01, e1 * 0.01);
     }
     if (!e->lml && std::getenv("TGP_STEADY_DEBUG") != nullptr) {
         const double* q = e->part + e->nwg_local;

@@ -33,6 +33,8 @@ void destroy(Engine*);
 // Host half: builds the plan of a T-step call of the model (nothing is kept from earlier calls).  false: the path does not apply (last_plan().why).
 // logpdf_only: the call will be a logpdf over the whole series (no outputs, no segment) -- served by the streaming kernel of tgp_lml.hip.
 bool plan(Engine*, const tgp_plan::ModelHost&, long long T, bool logpdf_only = false);
+// TGP_OPT_STREAM_MIN_T: -1 the measured crossovers, 0 always, else the series length from which the streaming kernels serve
+void set_stream_min_T(Engine*, long long min_T);
 // the host's wait for a logpdf-only call's kernel: true once its last workgroup has said so through pinned memory (false: use the stream)
 bool await_done(Engine*);
 // Enqueues the kernel of the planned call on `stream` (no synchronisation); *kname names it for the profile.

@@ -81,6 +81,17 @@ __global__ __launch_bounds__(kNW * 64, 2) void k_post_stream(const PArgs<D> by_v
     typedef const __attribute__((address_space(4))) PArgs<D>* KaPtr;      // (the kernel-argument segment: scalar loads, tgp_lml.hip)
     KaPtr kap = (KaPtr)__builtin_amdgcn_kernarg_segment_ptr();
 #define ka (*kap)
+    {
+        // Touch every 64-byte line of the argument segment in ONE batch of scalar loads: the segment lives in host memory, a cold line is a PCIe round
+        // trip (~2 us), and the optimisation barriers below make the waves read the coefficients phase by phase -- five or six cold batches in a
+        // row were ~8 us of every wave's life, the whole launch at small T (k_steady_one reads its arguments in one batch by construction)
+        typedef const __attribute__((address_space(4))) unsigned* WordPtr;
+        WordPtr w = (WordPtr)kap;
+        unsigned warm = 0u;
+#pragma unroll
+        for (unsigned o = 0; o < sizeof(PArgs<D>); o += 64) warm ^= w[o / 4];
+        asm volatile("" ::"s"(warm));
+    }
     // two 8 KB slices per wave: the tile in work and the next one on its way (global -> LDS directly: no staging registers)
     __shared__ __attribute__((aligned(16))) v2d sSlice[kNW][2][64 * PPL];
     __shared__ double sAcc[kNW];
@@ -111,16 +122,36 @@ __global__ __launch_bounds__(kNW * 64, 2) void k_post_stream(const PArgs<D> by_v
     const long long run = (long long)blockIdx.x * kNW + wave;
     const bool active = run < ka.R;
     const long long T = ka.T;
-    // the head's inputs to the host, first thing (its forward recursion runs there; tgp_modal.hip k_steady_one)
-    if (blockIdx.x == 0 && wave == kNW - 1) {
+    // The head's inputs to the host, first thing (its forward recursion runs there; tgp_modal.hip k_steady_one): write-through stores now, the flag
+    // behind this wave's first tile -- the stores' acknowledgement from host memory takes ~7 us, and a __threadfence_system here stood that long in
+    // front of this wave's whole run (tgp_lml.hip)
+    bool head_flag_due = false;
+    if (blockIdx.x == 0 && wave == 0) {      // (run 0's wave: it waits for the host's answer anyway and holds one tile)
         for (int t = lane; t < ka.nhs; t += 64) {
-            ka.head_in[t] = ka.y[t];
-            if (ka.rnew_per_step) ka.head_in[ka.nhs + t] = ka.RnewT[t];
+            const double v = ka.y[t];
+            double* dst = ka.head_in + t;
+            asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(dst), "v"(v) : "memory");
+            if (ka.rnew_per_step) {
+                const double rv = ka.RnewT[t];
+                double* dr = ka.head_in + ka.nhs + t;
+                asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(dr), "v"(rv) : "memory");
+            }
         }
-        if (!ka.rnew_per_step && lane == 0) ka.head_in[ka.nhs] = ka.Rnew[0];
-        __threadfence_system();
-        if (lane == 0) __hip_atomic_store(ka.hflag, 2 * ka.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (!ka.rnew_per_step && lane == 0) {
+            const double rv = ka.Rnew[0];
+            double* dr = ka.head_in + ka.nhs;
+            asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(dr), "v"(rv) : "memory");
+        }
+        head_flag_due = true;
     }
+    auto raise_head_flag = [&]() {      // (every vector-memory operation of the wave has returned when this is called)
+        if (lane == 0) {
+            const long long fv = 2 * ka.seq;
+            long long* fp = ka.hflag;
+            asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(fp), "v"(fv) : "memory");
+        }
+        head_flag_due = false;
+    };
     double acc = 0.0, poison = 0.0;
     const long long dbg_t0 = (ka.dbg & 16) ? (long long)wall_clock64() : 0;
     if (active) {
@@ -401,7 +432,15 @@ __global__ __launch_bounds__(kNW * 64, 2) void k_post_stream(const PArgs<D> by_v
             return flush(sY, tile_t0, mm, ln);
         };
 
-        if (first) {      // the head's end state comes from the host (run 0 holds one tile: the wait is not the kernel's critical path)
+        int buf = 0, behind = 0;      // behind: vector-memory operations issued after the loads of the tile about to be worked on (16: the plain output stores)
+        fetch(sSlice[wave][0], t_lo, 0, n_own > 0 ? PPL : kh);
+        if (first) {
+            // run 0: its wave handed the head's observations to the host (write-through stores, above); once they are acknowledged -- the first tile's
+            // loads travel meanwhile -- the flag, then the wait for the host's answer: the head's end state
+            if (head_flag_due) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                raise_head_flag();
+            }
             if (!wait_flag(ka.hflag + 1, ka.seq)) poison = __builtin_nan("");
 #pragma unroll
             for (int i = 0; i < D; ++i) {
@@ -409,8 +448,6 @@ __global__ __launch_bounds__(kNW * 64, 2) void k_post_stream(const PArgs<D> by_v
                 asm volatile("" : "+v"(zin[i]));
             }
         }
-        int buf = 0, behind = 0;      // behind: vector-memory operations issued after the loads of the tile about to be worked on (16: the plain output stores)
-        fetch(sSlice[wave][0], t_lo, 0, n_own > 0 ? PPL : kh);
         for (long long p = 0; p < n_pass; ++p) {
             // (the coefficients are re-read through the scalar cache every tile: hoisted out of the loop they would not fit the SGPRs)
             asm volatile("" : "+s"(kap));
@@ -427,6 +464,10 @@ __global__ __launch_bounds__(kNW * 64, 2) void k_post_stream(const PArgs<D> by_v
             v2d* sY = sSlice[wave][buf];
             landed(behind);
             behind = 0;
+            if (head_flag_due) {      // (wave-uniform, once: this pass waited for everything -- nothing was issued behind its loads)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                raise_head_flag();
+            }
             if (p + 1 < n_pass) fetch(sSlice[wave][buf ^ 1], tile_t0 + TILE, 0, p + 1 >= n_own ? kh : PPL);      // the next pass's observations travel while this one is in work
             buf ^= 1;
             double yv[N], r[N];
@@ -565,6 +606,10 @@ __global__ __launch_bounds__(kNW * 64, 2) void k_post_stream(const PArgs<D> by_v
             ka.part[512 + 2 * run] = (double)dbg_t0;
             ka.part[512 + 2 * run + 1] = (double)wall_clock64();
         }
+    }
+    if (head_flag_due) {      // (a head wave without a run of its own: a short series)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        raise_head_flag();
     }
     if (lane == 0) sAcc[wave] = acc;
     __syncthreads();

@@ -29,9 +29,12 @@ def tgp():
     return t
 
 
-def device_model(tgp, model):
+def device_model(tgp, model, min_T=0):
     tr = tgp.GaussMarkovModel(tgp.Forward, model["A"], model["a"], model["Q"], tgp.Gaussian(model["x0m"], model["x0P"]))
-    return tgp.LGSSM(tr, tgp.ScalarOutputLGC(model["H"], np.atleast_1d(model["h"]), np.atleast_1d(model["R"])), T=model["T"])
+    dm = tgp.LGSSM(tr, tgp.ScalarOutputLGC(model["H"], np.atleast_1d(model["h"]), np.atleast_1d(model["R"])), T=model["T"])
+    # (by default the streaming kernels serve from their measured crossovers on -- 5e6 / 3e6 steps; here: every length)
+    dm.handle_options[tgp._lib.OPT_STREAM_MIN_T] = min_T
+    return dm
 
 
 def kernels_of(tgp, dm, fn):
@@ -108,6 +111,23 @@ def test_streaming_posterior(tgp, d):
                 # (series shorter than head + tail tables run the whole plan in front of the launch: k_steady_one with the head inside the kernel)
                 if T >= 5000:
                     assert names == {"k_post_stream"}, (d, T, names)
+
+
+def test_streaming_kernels_serve_from_their_crossovers_on(tgp):
+    """TGP_OPT_STREAM_MIN_T = -1 (the default): k_steady_one below 5e6 / 3e6 steps, the streaming kernels from there on; results agree across the switch"""
+    Rn = np.array([0.2])
+    for T, want_lml, want_post in ((1_000_000, False, False), (4_000_000, False, True), (6_000_000, True, True)):
+        model = oc.build_lgssm(KERNELS[3], ("regular", 0.0, 0.1, T), 0.1)
+        y = draw(model, T % 7)
+        dm = device_model(tgp, model, min_T=-1)
+        lp, names = kernels_of(tgp, dm, lambda: tgp.logpdf(dm, y))
+        assert next(iter(names)).startswith("k_lml_stream") == want_lml, (T, names)
+        (mean, var), names = kernels_of(tgp, dm, lambda: tgp.posterior_marginals(dm, y, Rn))
+        assert (names == {"k_post_stream"}) == want_post, (T, names)
+        ref = sk.logpdf(model, y)
+        m_ref, v_ref = sk.posterior_marginals(model, y, Rn)
+        assert abs(lp - ref) <= 1e-10 * abs(ref)
+        assert np.max(np.abs(mean - m_ref)) <= 1e-8 and np.max(np.abs(var - v_ref)) <= 1e-8
 
 
 def test_streaming_posterior_repeated_calls_and_odd_pointers(tgp):
