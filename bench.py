@@ -873,6 +873,13 @@ def main():
         for kk, vv in hd.profile().items():
             per_step_ms.setdefault(kk, []).append(vv["total_ms"] / max(1, vv["calls"]))
     hd.profile_reset()
+    # what the hipEvent bracket itself reads: an EMPTY kernel inside the same bracket on the same stream (tgp_profile_empty_launch). rocprofv3's kernel
+    # trace times the kernel alone, so its durations (profiles/*_kernel_stats.md) stand this much below the hipEvent ones above
+    for _ in range(30):
+        hd.check(hd.lib.tgp_profile_empty_launch(hd.h))
+    _pe = hd.profile().get("k_empty")
+    event_bracket_ms = (_pe["total_ms"] / max(1, _pe["calls"])) if _pe else None
+    hd.profile_reset()
     hd.set_option(tgp._lib.OPT_PROFILE, 0)
     fused = None
     if world == 1 and args.separate_calls:
@@ -975,6 +982,18 @@ def main():
                                "LTI (Fill) layout, general engine: streams only y in / (mean,var) out (plus the smoother scratch: `traffic`): the launch "
                                "is not HBM bound -- one wave per SIMD, it lasts as long as the dependent fp64 chain of its slowest wave (DESIGN 3.10)")
                               if lti else "per-step layout: HBM bound"))
+        def net_of_bracket(r, nbytes):
+            # (beside `frac`, never instead of it: `frac` stays the plain hipEvent figure)
+            if r is None or event_bracket_ms is None:
+                return
+            net = r["avg_kernel_ms"] - event_bracket_ms
+            r["event_bracket_ms"] = event_bracket_ms
+            r["frac_net_of_event_bracket"] = (nbytes / (net * 1e-3) / 1e9 / HBM_PEAK_GBS) if net > 0 else None
+            r["event_bracket_note"] = ("an EMPTY kernel inside the same hipEvent bracket reads event_bracket_ms; rocprofv3 --kernel-trace times the kernel alone "
+                                       "(profiles/r06_lti_kernel_stats.md), so its average sits about that far below avg_kernel_ms and corresponds to "
+                                       "frac_net_of_event_bracket")
+        if roof is not None:
+            net_of_bracket(roof, roof["algorithmic_bytes"])
         roof_lp = None
         lp_names = [k for k in prof if k.startswith("k_lml_stream") or (k.startswith("k_steady_one") and "logpdf" in k)]
         if lti and lp_names and roof is not None and lp_names[0] != roof["kernel"]:
@@ -987,6 +1006,7 @@ def main():
                            algorithmic_bytes_per_step=8, traffic=pmc_traffic(kn, d, args.layout) if (T == 10_000_000 and world == 1) else None,
                            note="the logpdf call's ONE kernel: reads y once (8 B/step), writes nothing of size T; 80 MB per launch -- a launch this short "
                                 "is bound by its fp64 instruction stream and its ramps as much as by HBM (DESIGN 3.19)")
+        net_of_bracket(roof_lp, 8 * Tseg)
         out = dict(
             metric="Kalman steps/sec (logpdf + posterior marginals), T=10^7 Matern32 d=3",
             value=value, unit="Kalman steps/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step,

@@ -166,6 +166,9 @@ int tgp_set_option(tgp_handle* h, int option, int64_t value);
 int tgp_set_stream(tgp_handle* h, void* hip_stream);
 /* the stream the handle's work is enqueued on (its own unless tgp_set_stream replaced it), as a hipStream_t */
 int tgp_get_stream(tgp_handle* h, void** hip_stream);
+/* hipStreamSynchronize on a stream of the CALLER's: the stream that produced a TGP_IN_DEVICE input must have passed it when the call is
+ * made (see "device inputs" above); the Python mirror calls this on torch's current stream in front of every call with device inputs */
+int tgp_stream_synchronize(void* hip_stream);
 const char* tgp_version(void);
 /* which build of the kernels the current model runs on: 1 out-of-line (safe), 2 fully inlined (d = 5, 6 after the check);
    dense path (d > 16): 16 + (1 if A is applied in sparse form) + (2 if H is) + (4 if the passes run as one persistent
@@ -479,6 +482,9 @@ int tgp_last_timing(const tgp_handle* h, double* kernel_ms, double* h2d_ms, doub
 int tgp_profile_reset(tgp_handle* h);
 int tgp_profile_count(tgp_handle* h);
 int tgp_profile_get(tgp_handle* h, int idx, char* name, int name_cap, double* total_ms, int64_t* calls);
+/* one EMPTY kernel inside the same hipEvent bracket (entry "k_empty"): what the bracket itself reads on this stack (about 6 us on ROCm 7.2 / MI355X --
+ * the events' own packets), i.e. how far a hipEvent duration stands above the duration rocprofv3 --kernel-trace reports for the same kernel */
+int tgp_profile_empty_launch(tgp_handle* h);
 
 #ifdef __cplusplus
 }

@@ -37,6 +37,7 @@ _SIGS = {
     "tgp_set_option": (ctypes.c_int, [_vp, ctypes.c_int, _i64]),
     "tgp_set_stream": (ctypes.c_int, [_vp, _vp]),
     "tgp_get_stream": (ctypes.c_int, [_vp, ctypes.POINTER(_vp)]),
+    "tgp_stream_synchronize": (ctypes.c_int, [_vp]),
     "tgp_version": (ctypes.c_char_p, []),
     "tgp_kernel_variant": (ctypes.c_int, [_vp]),
     "tgp_graph_replays": (_i64, [_vp]),
@@ -95,6 +96,7 @@ _SIGS = {
     "tgp_profile_reset": (ctypes.c_int, [_vp]),
     "tgp_profile_count": (ctypes.c_int, [_vp]),
     "tgp_profile_get": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_char_p, ctypes.c_int, _dp, ctypes.POINTER(_i64)]),
+    "tgp_profile_empty_launch": (ctypes.c_int, [_vp]),
 }
 EXPORTS = tuple(_SIGS)
 

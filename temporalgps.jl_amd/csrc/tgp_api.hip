@@ -1835,6 +1835,10 @@ int tgp_get_stream(tgp_handle* h, void** hip_stream) {
     return TGP_OK;
 }
 
+int tgp_stream_synchronize(void* hip_stream) {
+    return hipStreamSynchronize(static_cast<hipStream_t>(hip_stream)) == hipSuccess ? TGP_OK : TGP_EHIP;
+}
+
 int tgp_model_set(tgp_handle* h, int64_t T, int d, int p, int ordering, uint32_t flags, const double* A, const double* a,
                   const double* Q, const double* H, const double* hh, const double* R, const double* x0m, const double* x0P) {
     if (h) drop_graphs(h);
@@ -4466,6 +4470,22 @@ int tgp_last_timing(const tgp_handle* h, double* kernel_ms, double* h2d_ms, doub
     if (kernel_ms) *kernel_ms = h->kernel_ms;
     if (h2d_ms) *h2d_ms = h->h2d_ms;
     if (d2h_ms) *d2h_ms = h->d2h_ms;
+    return TGP_OK;
+}
+
+namespace {
+__global__ void k_empty() {}
+}  // namespace
+int tgp_profile_empty_launch(tgp_handle* h) {
+    if (!h) return TGP_EINVAL;
+    StreamGuard stream_guard_(h);
+    TRY(bind_device(h));
+    {
+        LaunchScope ls(h, "k_empty");
+        hipLaunchKernelGGL(k_empty, dim3(1), dim3(64), 0, h->stream);
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    resolve_profile(h);
     return TGP_OK;
 }
 

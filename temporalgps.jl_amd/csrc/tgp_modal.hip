@@ -1090,6 +1090,15 @@ struct Engine {
     bool lml_flagged = false;          // the launched kernel raises flags[1] at its end
     void* pxch = nullptr;              // device memory: the exchange records of the streaming posterior kernel's runs (tgp_post.hpp)
     long long stream_min_T = -1;       // TGP_OPT_STREAM_MIN_T
+    // the core of the last plan, kept while the model and the length stand (the reference's own sequence -- logpdf(model, y), then posterior(model, y) --
+    // plans the same model twice): key = the model's blocks as handed over
+    std::vector<double> memo_key;
+    long long memo_T = -1;
+    bool memo_ok = false;
+    unsigned long long memo_stamp = 0; // of the thread's plan workspace when the core was built (another engine's plan on this thread, another thread: no hit)
+    Modal memo_md{};
+    tgp_plan::Info memo_info{};
+    long long memo_Wt_n = -1;          // lWt holds quad_table(md, memo_Wt_n)
 };
 namespace {
 constexpr size_t kHH = tgp_plan::kHeadMax;
@@ -1399,6 +1408,7 @@ static void ship_stage(Engine* e, int stage, int why) {
 
 // the tables half of the plan, stage by stage, each shipped as soon as it exists.  Returns the Why of the first stage that declined
 static int build_and_ship_tables(Engine* e, long long T, int nstages = 3) {
+    e->memo_ok = false;      // (stage 0 rewrites the head's gains in place, in modal coordinates: the core in `tab` is no longer what build_core left)
     for (int stage = 0; stage < nstages; ++stage) {
         const int why = tgp_plan::build_tables_stage_any(e->md.d, stage, T, e->md, *e->tab, e->info);
         ship_stage(e, stage, why);
@@ -1423,6 +1433,40 @@ static bool lml_done_flag_enabled() {      // TGP_LML_DONE_FLAG=1: the kernel's 
     return on;
 }
 
+namespace {
+bool plan_memo_enabled() {      // TGP_PLAN_MEMO=0: every call plans from scratch (A/B runs)
+    static const bool on = [] {
+        const char* s = std::getenv("TGP_PLAN_MEMO");
+        return !(s && s[0] == '0');
+    }();
+    return on;
+}
+template <class F>
+void model_words(const tgp_plan::ModelHost& m, F&& f) {
+    const size_t d = (size_t)m.d;
+    f(m.A, d * d); f(m.a, d); f(m.Q, d * d); f(m.H, d); f(m.hh, 1); f(m.R, 1); f(m.x0m, d); f(m.x0P, d * d);
+}
+bool memo_hit(const Engine* e, const tgp_plan::ModelHost& m, long long T) {
+    if (!e->memo_ok || !plan_memo_enabled() || e->memo_T != T || e->memo_md.d != m.d) return false;
+    if (tgp_plan::work_stamp_any(m.d) != e->memo_stamp) return false;      // (the stages behind the core read the thread's workspace: it must still be this plan's)
+    const double* k = e->memo_key.data();
+    bool same = true;
+    model_words(m, [&](const double* p, size_t n) {
+        same = same && std::memcmp(k, p, n * sizeof(double)) == 0;
+        k += n;
+    });
+    return same;
+}
+void memo_store(Engine* e, const tgp_plan::ModelHost& m, long long T) {
+    e->memo_key.clear();
+    model_words(m, [&](const double* p, size_t n) { e->memo_key.insert(e->memo_key.end(), p, p + n); });
+    e->memo_T = T;
+    e->memo_md = e->md;
+    e->memo_info = e->info;
+    e->memo_stamp = tgp_plan::work_stamp_any(m.d);
+    e->memo_ok = true;
+}
+}  // namespace
 bool plan(Engine* e, const tgp_plan::ModelHost& m, long long T, bool logpdf_only) {
     e->began = false;
     e->lml = false;
@@ -1454,8 +1498,16 @@ bool plan(Engine* e, const tgp_plan::ModelHost& m, long long T, bool logpdf_only
         std::memset(e->hhead, 0, n * sizeof(double));
     }
     ++e->seq;
-    e->info = tgp_plan::build_core_any(m, T, e->md, *e->tab);
-    if (e->info.why != tgp_plan::kOk) return false;
+    if (memo_hit(e, m, T)) {
+        e->md = e->memo_md;
+        e->info = e->memo_info;
+    } else {
+        e->memo_ok = false;
+        e->memo_Wt_n = -1;
+        e->info = tgp_plan::build_core_any(m, T, e->md, *e->tab);
+        if (e->info.why != tgp_plan::kOk) return false;
+        memo_store(e, m, T);
+    }
     layout_tables(e);
     e->mh = m;
     e->hh_T = T;
@@ -1480,7 +1532,10 @@ bool plan(Engine* e, const tgp_plan::ModelHost& m, long long T, bool logpdf_only
                 return false;
             }
         }
-        tgp_lml::quad_table(e->md, e->lg.first_tile, e->lWt);
+        if (e->memo_Wt_n != e->lg.first_tile) {
+            tgp_lml::quad_table(e->md, e->lg.first_tile, e->lWt);
+            e->memo_Wt_n = e->memo_ok ? e->lg.first_tile : -1;
+        }
         e->deferred = false;
         e->hosthead = false;
         e->lml = true;

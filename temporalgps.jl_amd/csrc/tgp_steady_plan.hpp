@@ -16,6 +16,7 @@
 // Plain C++ (no HIP): compiled into libtgp_hip.so and exercised on the CPU tier through tgp_steady_plan_debug (tests/test_steady_plan.py).
 #pragma once
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -514,11 +515,16 @@ struct Work {
     double Gss[D][D], Lss[D][D], Psinf[D][D];
     double Vi[kMaxD * kMaxD];
     int n0, nhs;
+    unsigned long long stamp;      // of the build_core that filled this (unique in the process: whoever keeps a plan checks that the workspace is still its own)
 };
 template <int D>
 inline Work<D>& work() {
     static thread_local Work<D> w;
     return w;
+}
+inline unsigned long long next_work_stamp() {
+    static std::atomic<unsigned long long> c{0};
+    return ++c;
 }
 
 template <int D>
@@ -526,6 +532,7 @@ inline Info build_core(const ModelHost& m, long long T, Modal& md, HeadTables& t
     using namespace detail;
     Info info;
     Work<D>& wk = work<D>();
+    wk.stamp = next_work_stamp();
     double A[D][D], hv[D];      // (locals: the compiler keeps them in registers; copies go to `wk` for build_tables)
     double Q[D][D], P[D][D], Pold2[D][D];
     for (int i = 0; i < D; ++i) {
@@ -1910,6 +1917,10 @@ inline Info build_core_any(const ModelHost& m, long long T, Modal& md, HeadTable
     Info bad;
     bad.why = kEigFail;
     return bad;
+}
+inline unsigned long long work_stamp_any(int d) {      // the stamp of this thread's workspace for state dimension d (0: never filled)
+    TGP_PLAN_DISPATCH(d, work<D>().stamp)
+    return 0;
 }
 inline int build_tables_any(int d, long long T, Modal& md, HeadTables& tab, Info& info) {
     TGP_PLAN_DISPATCH(d, build_tables<D>(T, md, tab, info))

@@ -261,7 +261,14 @@ def _sync_torch(t, model=None):
     the device instead -- no host synchronisation -- was measured in round 5: the cross-stream dependency delays the kernel's start by
     ~10 us, three times what this synchronisation costs.)"""
     import torch
-    torch.cuda.current_stream(t.device).synchronize()
+    raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+    idx = t.device.index
+    if raw_stream is None or idx is None:
+        torch.cuda.current_stream(t.device).synchronize()
+        return
+    # (the raw hipStream_t, not a torch.cuda.Stream object: building one costs 1.7 us of a 40 us call -- scripts/py_overhead.py)
+    if _lib.load().tgp_stream_synchronize(raw_stream(idx)) != _lib.OK:
+        raise _lib.TGPError(_lib.EHIP, "hipStreamSynchronize on torch's current stream failed")
 
 
 def _handle_sde(self):
@@ -357,7 +364,7 @@ def _obs_impl(y, model, lazy_nan):
         return yy, (np.ascontiguousarray(mk.astype(np.uint8)) if mk.any() else None), False, False
     if _is_torch(y) and y.is_cuda:
         import torch
-        yy = y.to(torch.float64).contiguous()
+        yy = y if (y.dtype is torch.float64 and y.is_contiguous()) else y.to(torch.float64).contiguous()
         if mask is None:
             mm = None
         elif mask.dtype == torch.bool:
@@ -832,8 +839,9 @@ def posterior_marginals(model, y, R_new, _with_lml=False, out=None):
             raise ValueError("R_new must have length 1 or T")
         if model.p > 1 and tuple(Rn.shape[1:]) != (model.p,):
             raise ValueError(f"R_new must be (T|1, {model.p}) (diagonal of the new noise)")
-        mean, var = out if out is not None else (_out(model, _osh(model), dev), _out(model, _osh(model), dev))
-        if out is not None and (_lib.is_device(mean) != bool(dev) or tuple(mean.shape) != _osh(model) or tuple(var.shape) != _osh(model)):
+        osh = _osh(model)
+        mean, var = out if out is not None else (_out(model, osh, dev), _out(model, osh, dev))
+        if out is not None and (_lib.is_device(mean) != bool(dev) or tuple(mean.shape) != osh or tuple(var.shape) != osh):
             raise ValueError("out: buffers of another call shape / memory space")
         # (the log marginal likelihood is always asked for: it is a by-product, and a NaN in it reports a NaN observation)
         lml = ctypes.c_double()

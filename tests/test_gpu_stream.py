@@ -151,3 +151,25 @@ def test_streaming_posterior_repeated_calls_and_odd_pointers(tgp):
     (mean, var), names = kernels_of(tgp, dm, lambda: tgp.posterior_marginals(dm, yd, torch.from_numpy(Rn).cuda(), out=(buf_m[1:], buf_v[1:])))
     assert all(n.startswith("k_steady_one") for n in names), names
     assert np.max(np.abs(mean.cpu().numpy() - m_ref)) <= 1e-8 and np.max(np.abs(var.cpu().numpy() - v_ref)) <= 1e-8
+
+
+def test_plan_kept_between_calls_is_dropped_when_another_model_plans(tgp):
+    """the core of a handle's last plan is kept while model and length stand (logpdf, then posterior, of one model plan once); the stages behind the core
+    read a per-thread workspace, so a plan of ANOTHER model of the same state dimension in between must make the first handle plan again -- and a
+    changed noise variance on the same handle is a new model"""
+    T = 300_001
+    Rn = np.array([0.25])
+    models = [oc.build_lgssm(("matern52",), ("regular", 0.0, dt, T), s2) for dt, s2 in ((0.1, 0.1), (0.05, 0.3))]
+    ys = [draw(m, 11 + i) for i, m in enumerate(models)]
+    refs = [(sk.logpdf(m, y),) + tuple(sk.posterior_marginals(m, y, Rn)) for m, y in zip(models, ys)]
+    for min_T in (0, -1):      # the streaming kernels / k_steady_one with the head on the host
+        dms = [device_model(tgp, m, min_T=min_T) for m in models]
+        for order in ((0, 1, 0, 1), (0, 0, 1, 1), (1, 0, 0, 1)):
+            for i in order:
+                lp = tgp.logpdf(dms[i], ys[i])
+                assert abs(lp - refs[i][0]) <= 1e-10 * abs(refs[i][0]), (min_T, order, i)
+            for i in order:
+                mean, var = tgp.posterior_marginals(dms[i], ys[i], Rn)
+                assert np.max(np.abs(mean - refs[i][1])) <= 1e-8 and np.max(np.abs(var - refs[i][2])) <= 1e-8, (min_T, order, i)
+                lp = tgp.logpdf(dms[i], ys[i])
+                assert abs(lp - refs[i][0]) <= 1e-10 * abs(refs[i][0]), (min_T, order, i)
