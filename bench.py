@@ -81,6 +81,9 @@ def cpu_baseline(name, T_sample):
                        f"logpdf {t_lp / reps:.3f}s/pass ({reps * T_sample / t_lp:.3e} steps/s) + posterior marginals {t_pm / reps:.3f}s/pass")
 
 
+_START_AFFINITY = None
+
+
 def cpu_baseline_all_cores(name, T_sample):
     """the time-parallel chunked scan on EVERY host core (oracle/omp_scan.py: the product's chunk functions
     and monoids compiled for the host with OpenMP), so that the GPU speed-up is not quoted against one core only."""
@@ -754,6 +757,7 @@ def main():
                     "through torch.distributed) instead of driving the N GPUs from this process through the in-library multi-GPU handle")
     ap.add_argument("--devices", default=None, help="in-process multi-GPU path: comma-separated device ordinals, one per rank (repeat one to share a GPU)")
     ap.add_argument("--engine-factory", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--no-bind", action="store_true", help="leave the process on whatever CPUs it was started on (A/B: tgp_bind_host_thread)")
     args = ap.parse_args()
     # the headline is T / (t_logpdf + t_post), the two calls the reference's API has (lti_sde.jl:60-68, posterior_lti_sde.jl:27-36)
     args.separate_calls = not args.combined_call
@@ -788,6 +792,11 @@ def main():
     from temporalgps_jl_amd import parallel
 
     torch.cuda.set_device(local)
+    # one process per GPU, on the CPUs next to it (tgp_bind_host_thread: a host thread on the far socket of a two-socket box pays ~13 us per headline step
+    # for the call's hand-overs through pinned memory); the CPU baselines below run with the affinity the process was started with
+    global _START_AFFINITY
+    _START_AFFINITY = os.sched_getaffinity(0)
+    host_bound = (not args.no_bind) and tgp._lib.bind_host_thread(local)
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
@@ -1016,7 +1025,7 @@ def main():
                                  + ("(the reference's two calls: logpdf(fx, y), then marginals(posterior(fx, y)(x)) -- value = T / (t_logpdf + t_post), SURVEY.md 8d)"
                                     if args.separate_calls else "(one combined call: tgp_logpdf_and_posterior_marginals)"),
                         T=T, T_per_gpu=Tseg, d=d, calls=("separate" if args.separate_calls else "combined"),
-                        layout=args.layout,
+                        layout=args.layout, host_thread_bound_to_gpu_socket=bool(host_bound),
                         parallelism=f"time-shard x{world} ({args.scaling}: {'T per GPU fixed' if args.scaling == 'weak' else 'total T fixed'})",
                         ranks=world, backend=("rccl" if world > 1 else "none"), exchange=shard.transport,
                         hip_graph_replays=int(hd.lib.tgp_graph_replays(hd.h)),
@@ -1095,7 +1104,12 @@ def main():
             out["cpu_baseline"] = cpu_baseline(name, args.cpu_sample)
             if world == 1 and args.layout == "lti":
                 try:
-                    out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(name, args.cpu_sample * 4)
+                    bound_to = os.sched_getaffinity(0)
+                    os.sched_setaffinity(0, _START_AFFINITY)      # (every core the process was given, not only the GPU's socket)
+                    try:
+                        out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(name, args.cpu_sample * 4)
+                    finally:
+                        os.sched_setaffinity(0, bound_to)
                 except Exception as ex:      # noqa: BLE001 -- no g++ / OpenMP on the host: the one-core baseline stands alone
                     out["cpu_baseline_all_cores"] = dict(error=repr(ex))
         if "split" in out:

@@ -10,6 +10,14 @@ from temporalgps_jl_amd import _lib as L
 from temporalgps_jl_amd import lgssm as G
 from temporalgps_jl_amd import lti_sde as P
 
+import os
+_getcpu = ctypes.CDLL(None).sched_getcpu
+print("started on cpu", _getcpu(), "of", len(os.sched_getaffinity(0)))
+if os.environ.get("BIND") == "1":
+    print("bound:", L.bind_host_thread(0), "now on cpu", _getcpu(), "of", len(os.sched_getaffinity(0)))
+if os.environ.get("PIN"):
+    os.sched_setaffinity(0, {int(os.environ["PIN"])})
+    print("pinned to cpu", _getcpu())
 T = 10_000_000
 model = P.build_lgssm(P.to_kernel(("matern52",)), P.RegularSpacing(0.0, 0.1, T), 0.1)
 hd = model.handle()
@@ -59,4 +67,5 @@ t("python posterior_marginals(out=)", lambda: tgp.posterior_marginals(model, y, 
 rp, mp, vp = L.ptr(Rnew), L.ptr(mean), L.ptr(var)
 fl = L.IN_DEVICE | L.OUT_DEVICE | L.SHARED_R
 t("C posterior_marginals", lambda: hd.lib.tgp_posterior_marginals(hd.h, yp, None, rp, fl, mp, vp, None), 2000)
+print("ends on cpu", _getcpu())
 t("C fused", lambda: hd.lib.tgp_logpdf_and_posterior_marginals(hd.h, yp, None, rp, fl, ctypes.byref(out), mp, vp), 2000)

@@ -39,6 +39,7 @@ _SIGS = {
     "tgp_get_stream": (ctypes.c_int, [_vp, ctypes.POINTER(_vp)]),
     "tgp_stream_synchronize": (ctypes.c_int, [_vp]),
     "tgp_version": (ctypes.c_char_p, []),
+    "tgp_bind_host_thread": (ctypes.c_int, [ctypes.c_int]),
     "tgp_kernel_variant": (ctypes.c_int, [_vp]),
     "tgp_graph_replays": (_i64, [_vp]),
     "tgp_steady_steps": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),
@@ -145,6 +146,11 @@ def load():
             fn.argtypes = args
         _LIB = lib
     return _LIB
+
+
+def bind_host_thread(device=0):
+    """Bind the calling thread to the CPUs next to `device` (tgp_bind_host_thread); True if it was done."""
+    return load().tgp_bind_host_thread(int(device)) == OK
 
 
 def ptr(x):

@@ -25,11 +25,9 @@ struct LArgs {
     double* part;
     double* head_in;
     long long* flags;
-    unsigned* counter;
     long long seq;
     int nwg;
-    int dbg;            // development: 1 = wave 0 of every workgroup stamps its phases (100 MHz) into part[4096 + 8 wg ...]
-    int done_flag;      // 1: the last workgroup to finish says so in flags[1] (the host then needs no stream synchronisation to read `part`)
+    int dbg;            // development: 1 = wave 0 of every workgroup stamps its phases (100 MHz) into part[kStampOff + 8 wg ...]
 };
 
 template <int D>
@@ -102,7 +100,7 @@ __global__ __launch_bounds__(kNW * 64, (N == 16 ? 4 : 2)) void k_lml_stream(cons
     const long long run = (long long)blockIdx.x * kNW + wave;
     const bool active = run < ka.R;
     const bool stamp = ka.dbg && wave == 0 && lane == 0 && blockIdx.x < 512;
-    if (stamp) ka.part[4096 + 8 * blockIdx.x + 0] = (double)wall_clock64();
+    if (stamp) ka.part[kStampOff + 8 * blockIdx.x + 0] = (double)wall_clock64();
     // the head's observations to the host, first thing (its forward recursion runs there, beside the kernel)
     // The head's observations to the host (its forward recursion runs there, beside the kernel): write-through stores now, the flag at the END of this
     // wave's run -- the stores' acknowledgement from host memory takes ~7 us (measured: the workgroup's barrier stood that long behind this wave when
@@ -207,7 +205,7 @@ __global__ __launch_bounds__(kNW * 64, (N == 16 ? 4 : 2)) void k_lml_stream(cons
             if (staged) stage_to_lds();      // (waits for the loads)
             else load_tail(tile_t0);
             lds_sync();
-            if (stamp && first_tile) ka.part[4096 + 8 * blockIdx.x + 1] = (double)wall_clock64();
+            if (stamp && first_tile) ka.part[kStampOff + 8 * blockIdx.x + 1] = (double)wall_clock64();
             // the two waves of a SIMD take turns at the higher priority, tile by tile (tgp_post.hip: the arbiter prefers the older wave)
             if ((((int)((tile_t0 - t_lo) / TILE)) ^ (wave >> 2)) & 1) __builtin_amdgcn_s_setprio(1);
             else __builtin_amdgcn_s_setprio(0);
@@ -374,7 +372,7 @@ __global__ __launch_bounds__(kNW * 64, (N == 16 ? 4 : 2)) void k_lml_stream(cons
         Q = wave_sum(acc);
 #pragma unroll
         for (int i = 0; i < D; ++i) E[i] = zin[i];
-        if (stamp) ka.part[4096 + 8 * blockIdx.x + 2] = (double)wall_clock64();
+        if (stamp) ka.part[kStampOff + 8 * blockIdx.x + 2] = (double)wall_clock64();
     }
     if (head_flag_due && active) {      // (the stores were issued a whole run ago: nothing to wait for)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -392,7 +390,7 @@ __global__ __launch_bounds__(kNW * 64, (N == 16 ? 4 : 2)) void k_lml_stream(cons
         }
     }
     __syncthreads();
-    if (stamp) ka.part[4096 + 8 * blockIdx.x + 3] = (double)wall_clock64();
+    if (stamp) ka.part[kStampOff + 8 * blockIdx.x + 3] = (double)wall_clock64();
     if (threadIdx.x == 0) {
         // the runs of this workgroup close each other: run w starts from the end state of run w - 1; run 0 is the host's to close
         double tot = sPost[0], el[D];
@@ -414,23 +412,24 @@ __global__ __launch_bounds__(kNW * 64, (N == 16 ? 4 : 2)) void k_lml_stream(cons
 #pragma unroll
             for (int i = 0; i < D; ++i) el[i] = p[2 + D + i];
         }
-        double* out = ka.part + (size_t)blockIdx.x * (1 + 2 * D);
-        out[0] = tot;
+        // the workgroup's record: 1 + 2 D (value, check) pairs, each ONE 16-byte write-through store -- check = the value's bits ^ the call's key, so
+        // the host knows a pair of THIS call when it sees one and needs no stream synchronisation to read the records (tgp_lml.hpp await_records)
+        v2d* out = reinterpret_cast<v2d*>(ka.part) + (size_t)blockIdx.x * (1 + 2 * D);
+        const long long key = (long long)record_key(ka.seq);
+        auto put = [&](int k, double v) {
+            v2d rec;
+            rec.x = v;
+            rec.y = __longlong_as_double(__double_as_longlong(v) ^ key);
+            v2d* dst = out + k;
+            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(rec) : "memory");
+        };
+        put(0, tot);
 #pragma unroll
         for (int i = 0; i < D; ++i) {
-            out[1 + i] = sPost[2 + i];
-            out[1 + D + i] = el[i];
+            put(1 + i, sPost[2 + i]);
+            put(1 + D + i, el[i]);
         }
-        if (stamp) ka.part[4096 + 8 * blockIdx.x + 4] = (double)wall_clock64();
-        if (ka.done_flag) {
-            __threadfence_system();
-            const unsigned old = atomicAdd(ka.counter, 1u);
-            if (old == (unsigned)ka.nwg - 1u) {
-                *ka.counter = 0u;
-                __threadfence_system();
-                __hip_atomic_store(ka.flags + 1, 2 * ka.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-        }
+        if (stamp) ka.part[kStampOff + 8 * blockIdx.x + 4] = (double)wall_clock64();
     }
 }
 
@@ -516,10 +515,8 @@ int launch(hipStream_t st, const tgp_plan::Modal& md, const Geometry& g, long lo
     a.part = b.part;
     a.head_in = b.head_in;
     a.flags = b.flags;
-    a.counter = b.counter;
     a.seq = seq;
     a.nwg = g.nwg;
-    a.done_flag = b.done_flag ? 1 : 0;
     {
         static const int dbg = [] {
             const char* v = std::getenv("TGP_LML_DBG");
@@ -638,20 +635,35 @@ int enqueue(hipStream_t stream, const tgp_plan::Modal& md, const Geometry& g, lo
 double finish(const tgp_plan::Modal& md, const Geometry& g, const double* part, const double* z0, const double* Wt) {
     const int d = md.d, pw = 1 + 2 * d;
     double s = 0.0;
-    const double* st = z0;
+    double stv[tgp_plan::kMaxD];
+    for (int i = 0; i < d; ++i) stv[i] = z0[i];
     for (int w = 0; w < g.nwg; ++w) {
-        const double* p = part + (size_t)w * pw;
+        const double* p = part + (size_t)w * pw * 2;      // (value, check) pairs
         double lin = 0.0, quad = 0.0;
         for (int i = 0; i < d; ++i) {
-            lin += st[i] * p[1 + i];
+            lin += stv[i] * p[2 * (1 + i)];
             double v = 0.0;
-            for (int k = 0; k < d; ++k) v += Wt[i * d + k] * st[k];
-            quad += st[i] * v;
+            for (int k = 0; k < d; ++k) v += Wt[i * d + k] * stv[k];
+            quad += stv[i] * v;
         }
         s += p[0] - 2.0 * lin + quad;
-        st = p + 1 + d;
+        for (int i = 0; i < d; ++i) stv[i] = p[2 * (1 + d + i)];
     }
     return s;
+}
+
+bool records_there(const Geometry& g, int d, const double* part, long long seq, size_t* next) {
+    const size_t n = (size_t)g.nwg * (1 + 2 * d);
+    const unsigned long long key = record_key(seq);
+    const volatile unsigned long long* q = reinterpret_cast<const volatile unsigned long long*>(part);
+    size_t k = *next;
+    for (; k < n; ++k) {
+        const unsigned long long v = q[2 * k], c = q[2 * k + 1];
+        if ((v ^ c) != key) break;
+    }
+    *next = k;
+    if (k == n) __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    return k == n;
 }
 
 }  // namespace tgp_lml

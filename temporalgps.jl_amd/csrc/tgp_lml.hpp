@@ -31,15 +31,19 @@ struct Geometry {
 // R runs over the G tiles behind the head; every run starts with a whole tile (>= halo) unless the series is shorter than that (then ONE run)
 Geometry choose_geometry(const tgp_plan::Modal& md, long long T);
 
-// pinned host memory the launch writes: part [nwg][1 + 2 d] (Q, V, E per workgroup), head_in [nhs], flags [0]: head_in is there, [1]: all of part is there
+// pinned host memory the launch writes: part [nwg][1 + 2 d] (value, check) PAIRS (Q, V, E per workgroup; check = the value's bits ^ record_key(seq): a pair
+// of this call is known when seen), head_in [nhs], flags [0]: head_in is there
 struct Buffers {
     double* part = nullptr;
     double* head_in = nullptr;
     long long* flags = nullptr;
-    unsigned* counter = nullptr;      // device memory, zero between launches
-    bool done_flag = false;           // the kernel raises flags[1] when its last workgroup has written `part`
 };
-inline size_t part_doubles(int d) { return (size_t)kMaxWG * (1 + 2 * d); }
+constexpr size_t kStampOff = 2 * (size_t)kMaxWG * (1 + 2 * tgp_plan::kMaxD);      // development stamps (TGP_LML_DBG) behind the largest record table
+inline size_t part_doubles(int) { return kStampOff + 8 * (size_t)kMaxWG; }
+__host__ __device__ inline unsigned long long record_key(long long seq) { return (unsigned long long)seq * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull; }
+// Have all records of call `seq` arrived?  *next: the first pair not yet seen (0 at the first call; the scan resumes there).  With every record there
+// the kernel has read all of y and written all it writes: the host may go on without synchronising the stream (which stays ordered).
+bool records_there(const Geometry& g, int d, const double* part, long long seq, size_t* next);
 
 // Wt = sum_{t < n} w_t' w_t (d x d, row-major), n = Geometry::first_tile -- data-free, O(d^2 log n) on the host
 void quad_table(const tgp_plan::Modal& md, long long n, double* Wt);

@@ -1086,8 +1086,7 @@ struct Engine {
     bool lml = false;
     tgp_lml::Geometry lg{};
     double lWt[tgp_plan::kMaxD * tgp_plan::kMaxD];
-    unsigned* lcounter = nullptr;      // device memory: the workgroups' arrival count (zero between launches)
-    bool lml_flagged = false;          // the launched kernel raises flags[1] at its end
+    bool lml_records = false;          // the host may take the launched kernel's end from its records in pinned memory (tgp_lml.hpp records_there)
     void* pxch = nullptr;              // device memory: the exchange records of the streaming posterior kernel's runs (tgp_post.hpp)
     long long stream_min_T = -1;       // TGP_OPT_STREAM_MIN_T
     // the core of the last plan, kept while the model and the length stand (the reference's own sequence -- logpdf(model, y), then posterior(model, y) --
@@ -1126,7 +1125,6 @@ void destroy(Engine* e) {
     if (e->hhead) (void)tgp_alloc::host_free(e->hhead);
     if (e->dflat) (void)tgp_alloc::dev_free(e->dflat);
     if (e->part) (void)tgp_alloc::host_free(e->part);
-    if (e->lcounter) (void)tgp_alloc::dev_free(e->lcounter);
     if (e->pxch) (void)tgp_alloc::dev_free(e->pxch);
     delete e;
 }
@@ -1425,14 +1423,13 @@ static bool lml_stream_enabled() {      // TGP_LML_STREAM=0: logpdf on k_steady_
     return on;
 }
 
-static bool lml_done_flag_enabled() {      // TGP_LML_DONE_FLAG=1: the kernel's last workgroup reports the end through pinned memory (A/B runs; default off)
+static bool lml_records_enabled() {      // TGP_LML_RECORDS=0: the end of a logpdf-only launch by hipStreamSynchronize as before (A/B runs)
     static const bool on = [] {
-        const char* v = std::getenv("TGP_LML_DONE_FLAG");
-        return v && v[0] == '1';
+        const char* s = std::getenv("TGP_LML_RECORDS");
+        return !(s && s[0] == '0');
     }();
     return on;
 }
-
 namespace {
 bool plan_memo_enabled() {      // TGP_PLAN_MEMO=0: every call plans from scratch (A/B runs)
     static const bool on = [] {
@@ -1514,7 +1511,7 @@ bool plan(Engine* e, const tgp_plan::ModelHost& m, long long T, bool logpdf_only
     if (logpdf_only && lml_stream_enabled() && stream_serves(e, T, kLmlMinT)) {
         // the streaming logpdf kernel: no tables (the head runs on the host from build_core's gains), no wait inside the kernel
         e->lg = tgp_lml::choose_geometry(e->md, T);
-        const size_t need = std::max<size_t>(tgp_lml::part_doubles(e->md.d) + 64, 4096 + 8 * 512 + 64);      // (+ the development stamps of TGP_LML_DBG)
+        const size_t need = tgp_lml::part_doubles(e->md.d) + 64;      // (the records and the development stamps of TGP_LML_DBG)
         if (need > e->part_cap) {
             if (e->part) (void)tgp_alloc::host_free(e->part);
             e->part = nullptr;
@@ -1523,14 +1520,8 @@ bool plan(Engine* e, const tgp_plan::ModelHost& m, long long T, bool logpdf_only
                 e->info.why = tgp_plan::kEigFail;
                 return false;
             }
+            std::memset(e->part, 0, need * sizeof(double));
             e->part_cap = need;
-        }
-        if (!e->lcounter) {
-            if (tgp_alloc::dev_malloc(reinterpret_cast<void**>(&e->lcounter), 64) != hipSuccess || hipMemset(e->lcounter, 0, 64) != hipSuccess) {
-                e->lcounter = nullptr;
-                e->info.why = tgp_plan::kEigFail;
-                return false;
-            }
         }
         if (e->memo_Wt_n != e->lg.first_tile) {
             tgp_lml::quad_table(e->md, e->lg.first_tile, e->lWt);
@@ -1666,11 +1657,22 @@ bool complete(Engine* e, long long T) {
     return true;
 }
 
-// The kernel of a logpdf-only call produces nothing but the workgroups' triples in pinned memory; its last workgroup says so there as well
-// (flags[1]): the host needs no hipStreamSynchronize to read them (the stream itself stays ordered: whatever is enqueued next runs behind the kernel).
+// The kernel of a logpdf-only call produces nothing but the workgroups' records in pinned memory, each pair of them marked with the call's key: once
+// every record is there the kernel has read all of y and written all it writes, and the host goes on without hipStreamSynchronize (the kernel's own
+// end -- the release at the end of the dispatch, the queue's barrier packet, the completion signal -- is ~4 us the caller need not wait for; the
+// stream stays ordered: whatever is enqueued next runs behind the kernel).  false: the stream drained or failed without them -- synchronise.
 bool await_done(Engine* e) {
-    if (!e || !e->began || !e->lml || !e->lml_flagged) return false;
-    return await_host_flag(hh_flag(e) + 1, 2 * e->seq, e->stream);
+    if (!e || !e->began || !e->lml || !e->lml_records) return false;
+    size_t next = 0;
+    for (unsigned spin = 1;; ++spin) {
+        if (tgp_lml::records_there(e->lg, e->md.d, e->part, e->seq, &next)) return true;
+        if ((spin & 4095u) == 0) {
+            const hipError_t q = hipStreamQuery(e->stream);
+            (void)hipGetLastError();
+            if (q != hipErrorNotReady) return tgp_lml::records_there(e->lg, e->md.d, e->part, e->seq, &next);
+        }
+        __builtin_ia32_pause();
+    }
 }
 
 // A caller that leaves between enqueue() and complete() (an error return in between) must not leave the kernel waiting: raises the flags of
@@ -1702,9 +1704,7 @@ int enqueue(Engine* e, hipStream_t stream, const Call& c, const char** kname, st
         b.part = e->part;
         b.head_in = hh_in(e);
         b.flags = hh_flag(e);
-        b.counter = e->lcounter;
-        b.done_flag = lml_done_flag_enabled();
-        e->lml_flagged = b.done_flag;
+        e->lml_records = lml_records_enabled();
         e->post = false;
         e->stream = stream;
         e->owns_head = true;
@@ -1784,7 +1784,7 @@ double finish(const Engine* e, long long T) {
                 (s1 - s0) * 0.01, (e0 - s0) * 0.01, (esum / n - s0) * 0.01, (e1 - s0) * 0.01, elast, (q[1] - s0) * 0.01, (q[2 * (R / 2) + 1] - s0) * 0.01);
     }
     if (e->lml && std::getenv("TGP_LML_DBG") != nullptr) {
-        const double* q = e->part + 4096;
+        const double* q = e->part + tgp_lml::kStampOff;
         double s0 = 1e300, s1 = 0, l1 = 0, c1 = 0, b1 = 0, e1 = 0;
         for (int g = 0; g < e->lg.nwg && g < 512; ++g) {
             s0 = std::min(s0, q[8 * g]);

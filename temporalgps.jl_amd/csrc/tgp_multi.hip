@@ -161,6 +161,7 @@ void segment(int64_t T, int W, int r, int64_t& lo, int64_t& hi) {
 
 void worker(tgp_multi* m, int r) {
     (void)hipSetDevice(m->dev[r]);
+    (void)tgp_bind_host_thread(m->dev[r]);      // (a rank's host thread beside its GPU: the hand-overs through pinned memory are per call)
     uint64_t seen = 0;
     for (;;) {
         std::function<int(int)> fn;
