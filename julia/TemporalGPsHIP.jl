@@ -26,6 +26,10 @@ struct HIPStorage{T<:Real} <: StorageType{T}
 end
 HIPStorage(::Type{Float64}=Float64; device::Int=0) = HIPStorage{Float64}(device)
 
+# one process per GPU: the calling thread (Julia's main thread) onto the CPUs next to the device, once per process and before the first handle
+# (include/tgp_hip.h tgp_bind_host_thread; a thread on the far socket of a two-socket host pays ~13 us per logpdf + posterior pair)
+bind_host_thread(device::Integer=0) = ccall((:tgp_bind_host_thread, libtgp), Cint, (Cint,), device) == 0
+
 mutable struct Handle
     ptr::Ptr{Cvoid}
     function Handle(device::Integer)
