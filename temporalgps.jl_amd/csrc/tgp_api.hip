@@ -393,6 +393,8 @@ struct tgp_handle {
     bool fold_valid = false;
     // per-call staging
     DevBuf by, bmiss, bRnew, beps_t, beps_e, bo1, bo2, bo3;
+    DevBuf bflip_y, bflip_m, bflip_P;      // a Reverse-ordered LTI model served as the Forward model on the flipped series (reverse_by_flip)
+    std::vector<double> flip_host;
     // scans and scratch
     ScanCtx F, Rv, Fad;
     DevBuf btan, bx0ad, tile_tan;
@@ -1640,7 +1642,7 @@ int tgp_destroy(tgp_handle* h) {
     }
     drop_graphs(h);
     for (DevBuf* b : {&h->bA, &h->ba, &h->bQ, &h->bH, &h->bh, &h->bR, &h->bx0, &h->bx0r, &h->bx0fold, &h->by, &h->bmiss, &h->bRnew, &h->beps_t,
-                      &h->beps_e, &h->bo1, &h->bo2, &h->bo3, &h->F.slab, &h->Rv.slab, &h->fs, &h->partial, &h->result, &h->segtmp, &h->tile_t, &h->tile_e, &h->Fad.slab, &h->btan, &h->bx0ad, &h->tile_tan, &h->balt, &h->bF, &h->bPinf, &h->btimes, &h->bAQ1, &h->bsde, &h->ftab, &h->btau})
+                      &h->beps_e, &h->bo1, &h->bo2, &h->bo3, &h->bflip_y, &h->bflip_m, &h->bflip_P, &h->F.slab, &h->Rv.slab, &h->fs, &h->partial, &h->result, &h->segtmp, &h->tile_t, &h->tile_e, &h->Fad.slab, &h->btan, &h->bx0ad, &h->tile_tan, &h->balt, &h->bF, &h->bPinf, &h->btimes, &h->bAQ1, &h->bsde, &h->ftab, &h->btau})
         b->release();
     for (auto& e : h->ev)
         if (e) (void)hipEventDestroy(e);
@@ -2254,6 +2256,106 @@ static int smooth_lti_call(tgp_handle* h, const double* y, uint32_t flags, const
                            const SmoothRand* rnd = nullptr);
 static bool lti_but_offset(const tgp_handle* h);
 
+// ---- Reverse-ordered LTI priors (lgssm.jl:87-91, 111-115, 161-165): with every block shared and x0 stationary, the Reverse model on y IS the
+// Forward model on the flipped series (oracle identity: tests/test_oracle_identities.py) -- one flip pass in front of the one-launch kernels (and one behind them for
+// outputs of size T) instead of the general chunked scan.
+namespace {
+__global__ __launch_bounds__(256) void k_flip_rows(const double* __restrict__ in, double* __restrict__ out, long long T, int w) {
+    const long long n = T * w;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long t = i / w, c = i - t * w;
+        out[i] = in[(T - 1 - t) * w + c];
+    }
+}
+void launch_flip(tgp_handle* h, const double* in, double* out, long long T, int w) {
+    const long long n = T * w;
+    const unsigned nb = (unsigned)std::min<long long>((n + 255) / 256, 8192);
+    LaunchScope ls(h, "k_flip_rows");
+    hipLaunchKernelGGL(k_flip_rows, dim3(nb), dim3(256), 0, h->stream, in, out, T, w);
+}
+struct AsForward {      // the handle as its Forward twin for the length of a call
+    tgp_handle* h;
+    int o, mo;
+    explicit AsForward(tgp_handle* h_) : h(h_), o(h_->ordering), mo(h_->mv.ordering) {
+        h->ordering = 0;
+        h->mv.ordering = 0;
+    }
+    ~AsForward() {
+        h->ordering = o;
+        h->mv.ordering = mo;
+    }
+};
+// x0 = its own one-step prediction (A x0.m + a = x0.m, A x0.P A' + Q = x0.P to rounding): what to_sde's models have (x0 = the stationary distribution).
+// A Reverse-ordered model updates with y_T BEFORE its first prediction, the Forward one predicts first: the two agree on flipped series only then.
+bool x0_is_stationary(const tgp_handle* h) {
+    const int d = h->d;
+    const size_t dd = (size_t)d * d;
+    if (h->hostm.size() < 2 * dd + d || h->x0m.size() != (size_t)d || h->x0P.size() != dd) return false;
+    const double *A = h->hostm.data(), *a = A + dd, *Q = a + d;      // column-major blocks
+    const double *m = h->x0m.data(), *P = h->x0P.data();
+    double mmax = 0.0, pmax = 0.0;
+    for (int i = 0; i < d; ++i) mmax = std::max(mmax, std::fabs(m[i]));
+    for (size_t i = 0; i < dd; ++i) pmax = std::max(pmax, std::fabs(P[i]));
+    std::vector<double> AP(dd, 0.0);
+    for (int i = 0; i < d; ++i) {
+        double v = a[i];
+        for (int k = 0; k < d; ++k) v += A[i + (size_t)k * d] * m[k];
+        if (!(std::fabs(v - m[i]) <= 1e-13 * (1.0 + mmax))) return false;
+        for (int j = 0; j < d; ++j) {
+            double w = 0.0;
+            for (int k = 0; k < d; ++k) w += A[i + (size_t)k * d] * 0.5 * (P[k + (size_t)j * d] + P[j + (size_t)k * d]);
+            AP[i + (size_t)j * d] = w;
+        }
+    }
+    for (int i = 0; i < d; ++i)
+        for (int j = 0; j < d; ++j) {
+            double v = 0.5 * (Q[i + (size_t)j * d] + Q[j + (size_t)i * d]);
+            for (int k = 0; k < d; ++k) v += AP[i + (size_t)k * d] * A[j + (size_t)k * d];
+            if (!(std::fabs(v - 0.5 * (P[i + (size_t)j * d] + P[j + (size_t)i * d])) <= 1e-13 * pmax)) return false;
+        }
+    return true;
+}
+bool reverse_by_flip(const tgp_handle* h, const double* y, const uint8_t* missing, uint32_t flags) {
+    static const bool on = [] {      // TGP_REVERSE_FLIP=0: Reverse-ordered models on the general engine as before (A/B runs)
+        const char* s = std::getenv("TGP_REVERSE_FLIP");
+        return !(s && s[0] == '0');
+    }();
+    return on && h->ordering == 1 && h->opt_modal && h->opt_steady2 && !h->is_dense && !h->sde && h->lti && h->p == 1 && h->mv.sR == 0 && missing == nullptr &&
+           y != nullptr && !(flags & TGP_REUSE_REDUCE) && !chunk_engine_requested(h) && h->opt_chunk == 0 && !h->hostm.empty() && h->mv.T == h->T &&
+           x0_is_stationary(h);
+}
+// the flipped series where the input lives: *yf, *ff (flags for the forward call)
+int flip_series(tgp_handle* h, const double* y, uint32_t flags, const double** yf, uint32_t* ff) {
+    *ff = flags;
+    if (flags & TGP_IN_DEVICE) {
+        HIPCHK(h->bflip_y.ensure((size_t)h->T * sizeof(double)));
+        launch_flip(h, y, h->bflip_y.d(), h->T, 1);
+        *yf = h->bflip_y.d();
+    } else {
+        h->flip_host.resize((size_t)h->T);
+        std::reverse_copy(y, y + h->T, h->flip_host.begin());
+        *yf = h->flip_host.data();
+    }
+    return TGP_OK;
+}
+}  // namespace
+
+// logpdf of a Forward LTI model on the one-launch kernels
+static int logpdf_lti_one_launch(tgp_handle* h, const double* y, uint32_t flags, double* out, bool* served) {
+    *served = false;
+    if (!steady2_eligible(h, nullptr, flags)) return TGP_OK;
+    TRY(modal_call(h, y, flags, nullptr, nullptr, nullptr, out, served));
+    if (*served) return TGP_OK;
+    // no well-conditioned modal form (two summands with one length scale, ...): logpdf is the by-product of the filter's forward
+    // recursion, which needs none -- ONE kernel on the dense powers of the closed loop (d <= 6; k_filter_one without its outputs)
+    if (h->opt_modal && y != nullptr) {
+        TRY(smooth_lti_call(h, y, flags, nullptr, nullptr, nullptr, out, served));      // (k_smooth_one's forward half: one sweep, no outputs)
+        if (*served) return TGP_OK;
+        TRY(filter_lti_call(h, y, flags, nullptr, nullptr, out, served));
+    }
+    return TGP_OK;
+}
+
 int tgp_logpdf(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t flags, double* out) {
     StreamGuard stream_guard_(h);
     TRY(check_ready(h, /*general=*/false));
@@ -2261,18 +2363,21 @@ int tgp_logpdf(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t 
     h->steady2_last = false;
     h->modal_last = false;
     h->dense_last_n0 = -1;
-    if (steady2_eligible(h, missing, flags)) {
+    if (reverse_by_flip(h, y, missing, flags)) {
+        const double* yf = nullptr;
+        uint32_t ff = flags;
+        TRY(flip_series(h, y, flags, &yf, &ff));
         bool served = false;
-        TRY(modal_call(h, y, flags, nullptr, nullptr, nullptr, out, &served));
-        if (served) return TGP_OK;
-        // no well-conditioned modal form (two summands with one length scale, ...): logpdf is the by-product of the filter's forward
-        // recursion, which needs none -- ONE kernel on the dense powers of the closed loop (d <= 6; k_filter_one without its outputs)
-        if (h->opt_modal && missing == nullptr && y != nullptr) {
-            TRY(smooth_lti_call(h, y, flags, nullptr, nullptr, nullptr, out, &served));      // (k_smooth_one's forward half: one sweep, no outputs)
-            if (served) return TGP_OK;
-            TRY(filter_lti_call(h, y, flags, nullptr, nullptr, out, &served));
-            if (served) return TGP_OK;
+        {
+            AsForward as_forward(h);
+            TRY(logpdf_lti_one_launch(h, yf, ff, out, &served));
         }
+        if (served) return TGP_OK;
+    }
+    if (missing == nullptr) {
+        bool served = false;
+        TRY(logpdf_lti_one_launch(h, y, flags, out, &served));
+        if (served) return TGP_OK;
     }
     if (steady2_eligible(h, missing, flags)) {
         CallTimer tm(h, /*clear=*/false);      // (the engine's set-up kernel clears the result record itself: one launch less)
@@ -3039,6 +3144,33 @@ int tgp_filter(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t 
     h->dense_last_n0 = -1;
     h->modal_last = false;
     h->steady2_last = false;
+    if (reverse_by_flip(h, y, missing, flags) && m_out && P_out) {
+        // the Forward twin on the flipped series into device scratch, rows flipped back into the caller's arrays
+        const bool odev_r = (flags & TGP_OUT_DEVICE) != 0;
+        const size_t nm_r = (size_t)h->T * h->d * sizeof(double), nP_r = nm_r * h->d;
+        const double* yf = nullptr;
+        uint32_t ff = flags;
+        TRY(flip_series(h, y, flags, &yf, &ff));
+        HIPCHK(h->bflip_m.ensure(nm_r));
+        HIPCHK(h->bflip_P.ensure(nP_r));
+        bool served = false;
+        {
+            AsForward as_forward(h);
+            TRY(filter_lti_call(h, yf, ff | TGP_OUT_DEVICE, h->bflip_m.d(), h->bflip_P.d(), lml_out, &served));
+        }
+        if (served) {
+            double *dm = nullptr, *dP = nullptr;
+            TRY(stage_out(h, h->bo1, m_out, nm_r, odev_r, &dm));
+            TRY(stage_out(h, h->bo2, P_out, nP_r, odev_r, &dP));
+            launch_flip(h, h->bflip_m.d(), dm, h->T, h->d);
+            launch_flip(h, h->bflip_P.d(), dP, h->T, h->d * h->d);
+            TRY(copy_back(h, m_out, dm, nm_r, odev_r));
+            TRY(copy_back(h, P_out, dP, nP_r, odev_r));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            resolve_profile(h);
+            return TGP_OK;
+        }
+    }
     if (missing == nullptr && y != nullptr) {
         bool served = false;
         TRY(filter_lti_call(h, y, flags, m_out, P_out, lml_out, &served));

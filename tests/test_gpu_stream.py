@@ -173,3 +173,28 @@ def test_plan_kept_between_calls_is_dropped_when_another_model_plans(tgp):
                 assert np.max(np.abs(mean - refs[i][1])) <= 1e-8 and np.max(np.abs(var - refs[i][2])) <= 1e-8, (min_T, order, i)
                 lp = tgp.logpdf(dms[i], ys[i])
                 assert abs(lp - refs[i][0]) <= 1e-10 * abs(refs[i][0]), (min_T, order, i)
+
+
+@pytest.mark.parametrize("d", (3, 5))
+def test_reverse_ordered_lti_prior_runs_as_the_forward_twin_on_the_flipped_series(tgp, d):
+    """lgssm.jl:87-91, 161-165: a Reverse-ordered model with shared blocks is the Forward model on reverse(y) -- logpdf and _filter go through one flip
+    pass and the one-launch kernels (TGP_REVERSE_FLIP=0: the general engine as before); against the literal restatement with ordering = 'R'"""
+    import torch
+    from oracle import lgssm_ref as ref
+    for T in (900, 6000):
+        model = dict(oc.build_lgssm(KERNELS[d], ("regular", 0.0, 0.1, T), 0.1), ordering="R")
+        rng = np.random.default_rng(T + d)
+        y = ref.rand(model, rng.standard_normal((T, d)), rng.standard_normal(T), rng.standard_normal(d))
+        lp_ref = ref.logpdf(model, y)
+        fm_ref, fP_ref = ref.filter_(model, y)
+        tr = tgp.GaussMarkovModel(tgp.Reverse, model["A"], model["a"], model["Q"], tgp.Gaussian(model["x0m"], model["x0P"]))
+        dm = tgp.LGSSM(tr, tgp.ScalarOutputLGC(model["H"], np.atleast_1d(model["h"]), np.atleast_1d(model["R"])), T=T)
+        for yy in (y, torch.from_numpy(y).cuda()):
+            lp, names = kernels_of(tgp, dm, lambda: tgp.logpdf(dm, yy))
+            assert abs(lp - lp_ref) <= 1e-10 * abs(lp_ref), (d, T, lp, lp_ref)
+            assert any(n.startswith("k_steady_one") or n.startswith("k_lml_stream") for n in names), names
+            (fm, fP), names = kernels_of(tgp, dm, lambda: tgp._filter(dm, yy))
+            fm, fP = (fm.cpu().numpy(), fP.cpu().numpy()) if hasattr(fm, "cpu") else (fm, fP)
+            assert np.max(np.abs(fm - np.asarray(fm_ref))) <= 1e-8 and np.max(np.abs(fP - np.asarray(fP_ref))) <= 1e-8, (d, T)
+            if d <= 6:
+                assert "k_flip_rows" in names and any(n.startswith("k_filter_one") for n in names), names
