@@ -153,6 +153,8 @@ typedef struct tgp_handle tgp_handle;
 #define TGP_OPT_STREAM_MIN_T 18 /* series length from which the STREAMING kernels of the stationary-gain engine serve a call: persistent
                                    waves with ~7 us more fixed latency and 1.3 - 2.7 x the throughput of k_steady_one.  -1 (default): the measured
                                    crossovers (logpdf 5e6, posterior marginals 3e6 steps at d = 3); 0: always (the tests); a length: from there on */
+#define TGP_OPT_WIDE 19 /* 1 (default): logpdf of a Forward LTI model with 16 < d <= 63 and scalar observations on the stationary closed loop across the
+                           chip (tgp_wide.hip: k_wide_lml); 0: the dense engine's sequential passes (the A/B of the tests) */
 #define TGP_OPT_TIMING 6 /* 1: record the hipEvents behind tgp_last_timing (off by default: ~30 us of host time per call) */
 #define TGP_OPT_FUSE_SCAN 4 /* 1 (default): the level-0 scan reduce / apply of the forward scan run inside the chunk kernels;
                                0: stand-alone k_scan_reduce / k_scan_apply launches (bit-identical results, for A/B timing) */

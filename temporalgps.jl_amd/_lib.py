@@ -23,6 +23,7 @@ OK, EINVAL, ENOTPD, EHIP, EUNSUPPORTED = 0, 1, 2, 3, 4
 OPT_CHUNK, OPT_PROFILE, OPT_VARIANT, OPT_FUSE_SCAN, OPT_GROUP, OPT_TIMING, OPT_SPLIT_SMOOTHER, OPT_DENSE_STRUCTURE, OPT_GRAPH, OPT_DENSE_FUSED, OPT_SHARED_PARTS, OPT_STEADY, OPT_SDE_CLOSED_FORM = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13
 OPT_SWEEP, OPT_SWEEP_CHUNK, OPT_SWEEP_WARMUP, OPT_SWEEP_WARMUP_BACK = 14, 15, 16, 17
 OPT_STREAM_MIN_T = 18
+OPT_WIDE = 19
 
 _dp = ctypes.POINTER(ctypes.c_double)
 _u8p = ctypes.POINTER(ctypes.c_uint8)

@@ -24,6 +24,7 @@
 #include "tgp_steady.hpp"
 #include "tgp_modal.hpp"
 #include "tgp_sweep.hpp"
+#include "tgp_wide.hpp"
 #include "tgp_adjoint_host.hpp"
 #include "tgp_alloc.hpp"
 #include <map>
@@ -460,6 +461,10 @@ struct tgp_handle {
     DevBuf btau;                  // SDE: tau_k = t_k - t_(k-1), [T] (tau_0 unused: the first transition is explicit)
     int num_cu = 0;
     std::vector<double> hostm;   // host copy of the shared blocks of an LTI model: A | a | Q | H | hh | R (what the host plan reads)
+    std::vector<double> widem;   // the same for a wide LTI model (16 < d <= 63, scalar observations): what tgp_wide's plan reads
+    tgp_wide::Engine* wide = nullptr;
+    int wide_state = 0;          // 0 untried for the bound model, 1 served the last call, -1 does not apply
+    int opt_wide = 1;            // TGP_WIDE=0: such models on the dense engine's one-CU passes as before (A/B runs)
     std::vector<double> sweepm;  // the same for every model with shared A, a, Q, H and scalar observations (hh, R: the first step's where they are per step)
     void* steady2_scope = nullptr;
     bool table_pending = false;  // the kernel-variant choice (and its run-time check) of the general engine is deferred to its first use
@@ -1640,6 +1645,8 @@ int tgp_destroy(tgp_handle* h) {
         (void)hipEventDestroy(h->tab_dep);
         (void)hipStreamDestroy(h->side_stream);
     }
+    if (h->wide) tgp_wide::destroy(h->wide);
+    h->wide = nullptr;
     drop_graphs(h);
     for (DevBuf* b : {&h->bA, &h->ba, &h->bQ, &h->bH, &h->bh, &h->bR, &h->bx0, &h->bx0r, &h->bx0fold, &h->by, &h->bmiss, &h->bRnew, &h->beps_t,
                       &h->beps_e, &h->bo1, &h->bo2, &h->bo3, &h->bflip_y, &h->bflip_m, &h->bflip_P, &h->F.slab, &h->Rv.slab, &h->fs, &h->partial, &h->result, &h->segtmp, &h->tile_t, &h->tile_e, &h->Fad.slab, &h->btan, &h->bx0ad, &h->tile_tan, &h->balt, &h->bF, &h->bPinf, &h->btimes, &h->bAQ1, &h->bsde, &h->ftab, &h->btau})
@@ -1723,6 +1730,11 @@ int tgp_set_option(tgp_handle* h, int option, int64_t value) {
     if (option == TGP_OPT_SWEEP) {
         h->opt_sweep = value != 0;
         h->sweep_state = 0;
+        return TGP_OK;
+    }
+    if (option == TGP_OPT_WIDE) {
+        h->opt_wide = value != 0;
+        h->wide_state = 0;
         return TGP_OK;
     }
     if (option == TGP_OPT_STREAM_MIN_T) {
@@ -1960,6 +1972,23 @@ int tgp_model_set(tgp_handle* h, int64_t T, int d, int p, int ordering, uint32_t
         h->x0P.assign(x0P, x0P + (size_t)d * d);
         h->mv.small_out = (flags & TGP_SMALL_OUTPUT) != 0 || p > 1;
         h->lti = false;
+        h->widem.clear();
+        h->wide_state = 0;
+        {
+            const uint32_t all_shared = TGP_SHARED_A | TGP_SHARED_a | TGP_SHARED_Q | TGP_SHARED_H | TGP_SHARED_h | TGP_SHARED_R;
+            if ((flags & all_shared) == all_shared && p == 1 && ordering == 0 && tgp_wide::supports(d)) {
+                const size_t dd = (size_t)d * d;
+                h->widem.assign(2 * dd + 2 * (size_t)d + 2, 0.0);
+                double* q = h->widem.data();
+                const struct { const double* src; size_t n; } parts[6] = {{A, dd}, {a, (size_t)d}, {Q, dd}, {H, (size_t)d}, {hh, 1}, {R, 1}};
+                size_t off = 0;
+                for (const auto& pt : parts) {
+                    if (dev) HIPCHK(hipMemcpy(q + off, pt.src, pt.n * sizeof(double), hipMemcpyDeviceToHost));
+                    else std::memcpy(q + off, pt.src, pt.n * sizeof(double));
+                    off += pt.n;
+                }
+            }
+        }
         h->is_dense = true;
         h->have_model = true;
         return TGP_OK;
@@ -2340,6 +2369,58 @@ int flip_series(tgp_handle* h, const double* y, uint32_t flags, const double** y
 }
 }  // namespace
 
+// ---- wide LTI models (16 < d <= 63; tgp_wide.hip): logpdf across the chip on the stationary closed loop.  *served = false: the engine declined
+// (nothing the caller must undo) -- the dense engine's passes serve the call.
+static int wide_call(tgp_handle* h, const double* y, uint32_t flags, double* out, bool* served) {
+    *served = false;
+    static const bool env_on = [] {
+        const char* s = std::getenv("TGP_WIDE");
+        return !(s && s[0] == '0');
+    }();
+    if (!env_on || !h->opt_wide || h->wide_state < 0 || h->widem.empty() || y == nullptr || h->ordering != 0 || (flags & TGP_REUSE_REDUCE)) return TGP_OK;
+    if (!h->wide) h->wide = tgp_wide::create();
+    const int d = h->d;
+    const size_t dd = (size_t)d * d;
+    const double* q = h->widem.data();
+    tgp_wide::ModelHost mh;
+    mh.d = d;
+    mh.A = q; mh.a = q + dd; mh.Q = q + dd + d; mh.H = q + 2 * dd + d; mh.hh = q[2 * dd + 2 * d]; mh.R = q[2 * dd + 2 * d + 1];
+    mh.x0m = h->x0m.data();
+    mh.x0P = h->x0P.data();
+    if (!tgp_wide::plan(h->wide, mh, h->T)) {
+        h->wide_state = -1;
+        if (getenv("TGP_STEADY_DEBUG") != nullptr) {
+            const tgp_wide::Info& in = tgp_wide::last_plan(h->wide);
+            fprintf(stderr, "[tgp wide] does not apply: why %d, n0 %d halo %d\n", in.why, in.n0, in.halo);
+        }
+        return TGP_OK;
+    }
+    CallTimer tm(h, /*clear=*/false);
+    TRY(set_obs(h, y, nullptr, flags));
+    tm.inputs_done();
+    std::string err;
+    bool not_pd = false;
+    double lml = 0.0;
+    {
+        LaunchScope ls(h, tgp_wide::kernel_name(h->wide));
+        if (tgp_wide::logpdf(h->wide, h->stream, h->mv.y, h->T, &lml, &not_pd, &err) != 0) return h->fail(TGP_EHIP, err);
+    }
+    if (h->profile) HIPCHK(hipStreamSynchronize(h->stream));      // (the bracket's closing event)
+    resolve_profile(h);
+    if (getenv("TGP_STEADY_DEBUG") != nullptr) {
+        const tgp_wide::Info& in = tgp_wide::last_plan(h->wide);
+        fprintf(stderr, "[tgp wide] n0 %d halo %d chunks %lld x %lld steps, plan %.3f ms\n", in.n0, in.halo, in.chunks, in.chunk_len, in.plan_ms);
+    }
+    for (int i = 0; i < 8; ++i) h->host_result[i] = 0.0;
+    h->host_result[0] = lml;
+    h->host_result[6] = tgp_steady::kStatusRan;
+    h->host_result[7] = (double)tgp_wide::last_plan(h->wide).n0;
+    *out = lml;
+    h->wide_state = 1;
+    *served = true;
+    return TGP_OK;
+}
+
 // logpdf of a Forward LTI model on the one-launch kernels
 static int logpdf_lti_one_launch(tgp_handle* h, const double* y, uint32_t flags, double* out, bool* served) {
     *served = false;
@@ -2411,6 +2492,11 @@ int tgp_logpdf(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t 
             TRY(forward_apply(h, 0, fo));
             return TGP_OK;
         }, out);
+    }
+    if (h->is_dense && missing == nullptr) {
+        bool served = false;
+        TRY(wide_call(h, y, flags, out, &served));
+        if (served) return TGP_OK;
     }
     CallTimer tm(h);
     TRY(set_obs(h, y, missing, flags));

@@ -1,0 +1,53 @@
+// Stationary-gain engine for WIDE states (16 < d <= 63; round 6): the log marginal likelihood of a Forward LTI model with scalar observations, one
+// noise variance and no missing data (lgssm.jl:147-165 on the reference's `Fill` layout) across the whole chip -- what the one-launch kernels of
+// tgp_modal.hip do for d <= 8, without a modal form: products of kernels (lti_sde.jl:377-400: ApproxPeriodicKernel() * Matern32Kernel(), d = 28)
+// have defective closed loops, so the recursion runs on the DENSE closed-loop matrix.
+//
+//   host plan   the covariance half of the filter never sees y: iterate it to its fixed point (n0 steps, their gains K_t and innovation variances S_t
+//               kept for the head), Phi = (I - K h') A, the observer row g = A' h, and `halo` = the number of steps after which Phi^halo is below 2^-60
+//               (repeated squaring);
+//   head        the first nhs steps (time-varying gains) on the host, from the head's observations copied back;
+//   kernel      the steps behind the head are cut into chunks, one WAVE each: lane i owns component i of the filtered mean and row i of Phi in
+//               registers, the state goes round through a 512-byte LDS line (one ds_write, d/2 broadcast ds_read_b128 per step), lane d -- the
+//               observer -- carries the row -g and so computes the innovation r_t by the same multiply-adds.  A chunk starts `halo` steps early
+//               from a zero state (the closed loop forgets it to 2^-60) and sums r_t^2 over its own steps only.
+// Before this engine such models ran on ONE compute unit (tgp_dense_fused.hpp: a persistent kernel, sequential in time).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+namespace tgp_wide {
+
+constexpr int kMaxD = 63;          // (lane d is the observer)
+constexpr int kHeadMax = 8192;     // steps until the covariance recursion must have settled
+constexpr int kMaxChunks = 4096;
+
+struct Engine;
+
+struct ModelHost {      // shared blocks, column-major as handed to tgp_model_set
+    int d = 0;
+    const double *A = nullptr, *a = nullptr, *Q = nullptr, *H = nullptr;
+    double hh = 0.0, R = 0.0;
+    const double *x0m = nullptr, *x0P = nullptr;
+};
+
+enum Why { kOk = 0, kNotPD = 1, kNotSettled = 2, kSlowMixing = 3, kTooShort = 4, kAlloc = 5 };
+struct Info {
+    int why = kOk, n0 = -1, nhs = 0, halo = 0;
+    long long chunks = 0, chunk_len = 0;
+    double plan_ms = 0.0;      // 0 when the plan of the previous call was kept
+};
+
+Engine* create();
+void destroy(Engine* e);
+inline bool supports(int d) { return d > 16 && d <= kMaxD; }
+// The plan of model `m` for a series of T steps (kept between calls while the model's blocks and T stand).  false: the engine does not apply (Info::why).
+bool plan(Engine* e, const ModelHost& m, long long T);
+const Info& last_plan(const Engine* e);
+// logpdf of the planned model on y (device pointer, T doubles): the head on the host, ONE kernel behind it.  Synchronises `stream`.
+// 0, or a hipError_t; *not_pd: a head step met a non-positive innovation variance.
+int logpdf(Engine* e, hipStream_t stream, const double* y, long long T, double* lml_out, bool* not_pd, std::string* err);
+const char* kernel_name(const Engine* e);
+
+}  // namespace tgp_wide

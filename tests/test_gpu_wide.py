@@ -1,0 +1,93 @@
+"""GPU tier: the stationary-gain engine for WIDE states (16 < d <= 63; csrc/tgp_wide.hip, round 6) -- logpdf of Forward LTI models with scalar observations
+on the dense closed loop, one wave per chunk -- against the literal restatement of lgssm.jl:147-165 (oracle/lgssm_ref.py) at lengths its Python loops
+finish, and against the dense engine's sequential passes (TGP_OPT_WIDE = 0) beyond.  Products of kernels (lti_sde.jl:377-400) are what produces such states:
+ApproxPeriodicKernel() * Matern32Kernel() has d = 28.  Tolerance as everywhere: 1e-10 relative."""
+import numpy as np
+import pytest
+
+from oracle import components as oc
+from oracle import lgssm_ref as ref
+
+pytestmark = pytest.mark.gpu
+
+KERNELS = {
+    18: ("product", ("approx_periodic", 3, 1.0), ("matern52",)),
+    28: ("product", ("approx_periodic", 7, 1.0), ("matern32",)),
+    42: ("product", ("approx_periodic", 7, 1.0), ("matern52",)),
+}
+
+
+@pytest.fixture(scope="module")
+def tgp():
+    import temporalgps_jl_amd as t
+    t._lib.load()
+    return t
+
+
+def device_model(tgp, model, wide=1):
+    tr = tgp.GaussMarkovModel(tgp.Forward, model["A"], model["a"], model["Q"], tgp.Gaussian(model["x0m"], model["x0P"]))
+    dm = tgp.LGSSM(tr, tgp.ScalarOutputLGC(model["H"], np.atleast_1d(model["h"]), np.atleast_1d(model["R"])), T=model["T"])
+    dm.handle_options[tgp._lib.OPT_WIDE] = wide
+    return dm
+
+
+def kernels_of(tgp, dm, fn):
+    hd = dm.handle()
+    hd.set_option(tgp._lib.OPT_PROFILE, 1)
+    hd.profile_reset()
+    out = fn()
+    names = set(hd.profile())
+    hd.set_option(tgp._lib.OPT_PROFILE, 0)
+    return out, names
+
+
+def draw(model, seed):
+    T, d = model["T"], len(model["x0m"])
+    rng = np.random.default_rng(seed)
+    return ref.rand(model, rng.standard_normal((T, d)), rng.standard_normal(T), rng.standard_normal(d))
+
+
+@pytest.mark.parametrize("d", sorted(KERNELS))
+def test_wide_logpdf_against_the_restatement(tgp, d):
+    for T, dt, s2 in ((6000, 0.1, 0.1), (20_000, 0.05, 0.02)):
+        model = oc.build_lgssm(KERNELS[d], ("regular", 0.0, dt, T), s2)
+        assert len(model["x0m"]) == d
+        y = draw(model, d + T)
+        lp_ref = ref.logpdf(model, y)
+        dm = device_model(tgp, model)
+        lp, names = kernels_of(tgp, dm, lambda: tgp.logpdf(dm, y))
+        assert abs(lp - lp_ref) <= 1e-10 * abs(lp_ref), (d, T, lp, lp_ref)
+        assert names == {"k_wide_lml<32>" if d <= 31 else "k_wide_lml<64>"}, names
+        # a second call of the same model keeps the plan; another series, the same answer as the dense engine's sequential pass
+        y2 = draw(model, d + T + 1)
+        lp2 = tgp.logpdf(dm, y2)
+        dm0 = device_model(tgp, model, wide=0)
+        lp2_dense = tgp.logpdf(dm0, y2)
+        assert abs(lp2 - lp2_dense) <= 1e-10 * abs(lp2_dense), (d, T, lp2, lp2_dense)
+
+
+def test_wide_logpdf_long_series_device_input(tgp):
+    import torch
+    T = 400_000
+    model = oc.build_lgssm(KERNELS[28], ("regular", 0.0, 0.1, T), 0.1)
+    rng = np.random.default_rng(3)
+    # (a draw of the model's own scale without the restatement's Python loop: white noise of the prior's marginal variance is as good a series for parity)
+    y = rng.standard_normal(T) * np.sqrt(float(model["H"][0] @ model["x0P"] @ model["H"][0]) + 0.1)
+    yd = torch.from_numpy(y).cuda()
+    dm, dm0 = device_model(tgp, model), device_model(tgp, model, wide=0)
+    lp, names = kernels_of(tgp, dm, lambda: tgp.logpdf(dm, yd))
+    assert names == {"k_wide_lml<32>"}, names
+    lp0, names0 = kernels_of(tgp, dm0, lambda: tgp.logpdf(dm0, yd))
+    assert not any(n.startswith("k_wide") for n in names0), names0
+    assert abs(lp - lp0) <= 1e-10 * abs(lp0), (lp, lp0)
+
+
+def test_series_too_short_for_the_engine_goes_to_the_dense_passes(tgp):
+    T = 120      # (the covariance settles after 87 steps: 33 steps behind the head are fewer than one chunk)
+    model = oc.build_lgssm(KERNELS[28], ("regular", 0.0, 0.1, T), 0.1)
+    y = draw(model, 1)
+    dm = device_model(tgp, model)
+    lp, names = kernels_of(tgp, dm, lambda: tgp.logpdf(dm, y))
+    lp_ref = ref.logpdf(model, y)
+    assert abs(lp - lp_ref) <= 1e-10 * abs(lp_ref)
+    assert not any(n.startswith("k_wide") for n in names), names
