@@ -40,6 +40,16 @@ for d, spec in SPECS.items():
         prof = {k: v["total_ms"] for k, v in hd.profile().items()}
         hd.set_option(L.OPT_PROFILE, 0)
         res[wide] = (dt, first, lp, prof)
+        if wide:
+            Rn = torch.full((1,), 0.1, dtype=torch.float64, device="cuda:0")
+            out = (torch.empty_like(y), torch.empty_like(y))
+            tgp.posterior_marginals(model, y, Rn, out=out)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                tgp.posterior_marginals(model, y, Rn, out=out)
+            torch.cuda.synchronize()
+            print(f"d={d} T={T}: wide posterior marginals {(time.perf_counter() - t0) / 10 * 1e3:.3f} ms per call")
     (dw, fw, lw, pw), (dd_, fd, ld, pd) = res[1], res[0]
     print(f"d={d} T={T}: wide {dw * 1e3:.3f} ms per call (first call with the plan {fw * 1e3:.2f} ms; kernels {pw}), dense passes {dd_ * 1e3:.1f} ms "
           f"({dict(list(pd.items())[:3])}): x{dd_ / dw:.0f}; logpdf {lw:.6f} vs {ld:.6f} (rel {abs(lw - ld) / abs(ld):.1e})")

@@ -464,6 +464,7 @@ struct tgp_handle {
     std::vector<double> widem;   // the same for a wide LTI model (16 < d <= 63, scalar observations): what tgp_wide's plan reads
     tgp_wide::Engine* wide = nullptr;
     int wide_state = 0;          // 0 untried for the bound model, 1 served the last call, -1 does not apply
+    int wide_post_state = 0;     // ... its posterior half
     int opt_wide = 1;            // TGP_WIDE=0: such models on the dense engine's one-CU passes as before (A/B runs)
     std::vector<double> sweepm;  // the same for every model with shared A, a, Q, H and scalar observations (hh, R: the first step's where they are per step)
     void* steady2_scope = nullptr;
@@ -1735,6 +1736,7 @@ int tgp_set_option(tgp_handle* h, int option, int64_t value) {
     if (option == TGP_OPT_WIDE) {
         h->opt_wide = value != 0;
         h->wide_state = 0;
+        h->wide_post_state = 0;
         return TGP_OK;
     }
     if (option == TGP_OPT_STREAM_MIN_T) {
@@ -1974,6 +1976,7 @@ int tgp_model_set(tgp_handle* h, int64_t T, int d, int p, int ordering, uint32_t
         h->lti = false;
         h->widem.clear();
         h->wide_state = 0;
+        h->wide_post_state = 0;
         {
             const uint32_t all_shared = TGP_SHARED_A | TGP_SHARED_a | TGP_SHARED_Q | TGP_SHARED_H | TGP_SHARED_h | TGP_SHARED_R;
             if ((flags & all_shared) == all_shared && p == 1 && ordering == 0 && tgp_wide::supports(d)) {
@@ -2371,13 +2374,15 @@ int flip_series(tgp_handle* h, const double* y, uint32_t flags, const double** y
 
 // ---- wide LTI models (16 < d <= 63; tgp_wide.hip): logpdf across the chip on the stationary closed loop.  *served = false: the engine declined
 // (nothing the caller must undo) -- the dense engine's passes serve the call.
-static int wide_call(tgp_handle* h, const double* y, uint32_t flags, double* out, bool* served) {
+static int wide_call(tgp_handle* h, const double* y, uint32_t flags, const double* Rnew, double* mean_out, double* var_out, double* out, bool* served) {
     *served = false;
     static const bool env_on = [] {
         const char* s = std::getenv("TGP_WIDE");
         return !(s && s[0] == '0');
     }();
     if (!env_on || !h->opt_wide || h->wide_state < 0 || h->widem.empty() || y == nullptr || h->ordering != 0 || (flags & TGP_REUSE_REDUCE)) return TGP_OK;
+    const bool post = mean_out != nullptr;
+    if (post && h->wide_post_state < 0) return TGP_OK;
     if (!h->wide) h->wide = tgp_wide::create();
     const int d = h->d;
     const size_t dd = (size_t)d * d;
@@ -2387,35 +2392,60 @@ static int wide_call(tgp_handle* h, const double* y, uint32_t flags, double* out
     mh.A = q; mh.a = q + dd; mh.Q = q + dd + d; mh.H = q + 2 * dd + d; mh.hh = q[2 * dd + 2 * d]; mh.R = q[2 * dd + 2 * d + 1];
     mh.x0m = h->x0m.data();
     mh.x0P = h->x0P.data();
+    const bool dbg = getenv("TGP_STEADY_DEBUG") != nullptr;
     if (!tgp_wide::plan(h->wide, mh, h->T)) {
         h->wide_state = -1;
-        if (getenv("TGP_STEADY_DEBUG") != nullptr) {
+        if (dbg) {
             const tgp_wide::Info& in = tgp_wide::last_plan(h->wide);
             fprintf(stderr, "[tgp wide] does not apply: why %d, n0 %d halo %d\n", in.why, in.n0, in.halo);
         }
         return TGP_OK;
     }
+    if (post && !tgp_wide::plan_posterior(h->wide, h->T)) {
+        h->wide_post_state = -1;
+        if (dbg) {
+            const tgp_wide::Info& in = tgp_wide::last_plan(h->wide);
+            fprintf(stderr, "[tgp wide] posterior does not apply: why %d, n1 %d halo_back %d\n", in.why_post, in.n1, in.halo_back);
+        }
+        return TGP_OK;
+    }
+    const bool idev = (flags & TGP_IN_DEVICE) != 0, odev = (flags & TGP_OUT_DEVICE) != 0, rshared = (flags & TGP_SHARED_R) != 0;
+    const size_t nT = (size_t)h->T * sizeof(double);
     CallTimer tm(h, /*clear=*/false);
+    const void* pR = nullptr;
+    if (post) TRY(stage_in(h, h->bRnew, Rnew, rshared ? sizeof(double) : nT, idev, &pR));
     TRY(set_obs(h, y, nullptr, flags));
     tm.inputs_done();
+    double *dm = nullptr, *dv = nullptr;
+    TRY(stage_out(h, h->bo1, mean_out, nT, odev, &dm));
+    TRY(stage_out(h, h->bo2, var_out, nT, odev, &dv));
+    tgp_wide::Call c;
+    c.T = h->T;
+    c.y = h->mv.y;
+    c.Rnew = static_cast<const double*>(pR);
+    c.rnew_per_step = (post && !rshared) ? 1 : 0;
+    c.mean = dm;
+    c.var = dv;
     std::string err;
-    bool not_pd = false;
     double lml = 0.0;
     {
-        LaunchScope ls(h, tgp_wide::kernel_name(h->wide));
-        if (tgp_wide::logpdf(h->wide, h->stream, h->mv.y, h->T, &lml, &not_pd, &err) != 0) return h->fail(TGP_EHIP, err);
+        LaunchScope ls(h, post ? (d <= 31 ? "k_wide_lml<32> + k_wide_bwd<32>" : "k_wide_lml<64> + k_wide_bwd<64>") : tgp_wide::kernel_name(h->wide));
+        if (tgp_wide::run(h->wide, h->stream, c, &lml, &err) != 0) return h->fail(TGP_EHIP, err);
     }
-    if (h->profile) HIPCHK(hipStreamSynchronize(h->stream));      // (the bracket's closing event)
+    TRY(copy_back(h, mean_out, dm, nT, odev));
+    TRY(copy_back(h, var_out, dv, nT, odev));
+    if (h->profile || (post && !odev)) HIPCHK(hipStreamSynchronize(h->stream));      // (the bracket's closing event; host outputs)
     resolve_profile(h);
-    if (getenv("TGP_STEADY_DEBUG") != nullptr) {
+    if (dbg) {
         const tgp_wide::Info& in = tgp_wide::last_plan(h->wide);
-        fprintf(stderr, "[tgp wide] n0 %d halo %d chunks %lld x %lld steps, plan %.3f ms\n", in.n0, in.halo, in.chunks, in.chunk_len, in.plan_ms);
+        fprintf(stderr, "[tgp wide] n0 %d halo %d / %d n1 %d chunks %lld x %lld steps, plan %.3f + %.3f ms\n", in.n0, in.halo, in.halo_back, in.n1, in.chunks, in.chunk_len, in.plan_ms,
+                in.plan_post_ms);
     }
     for (int i = 0; i < 8; ++i) h->host_result[i] = 0.0;
     h->host_result[0] = lml;
     h->host_result[6] = tgp_steady::kStatusRan;
     h->host_result[7] = (double)tgp_wide::last_plan(h->wide).n0;
-    *out = lml;
+    if (out) *out = lml;
     h->wide_state = 1;
     *served = true;
     return TGP_OK;
@@ -2495,7 +2525,7 @@ int tgp_logpdf(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t 
     }
     if (h->is_dense && missing == nullptr) {
         bool served = false;
-        TRY(wide_call(h, y, flags, out, &served));
+        TRY(wide_call(h, y, flags, nullptr, nullptr, nullptr, out, &served));
         if (served) return TGP_OK;
     }
     CallTimer tm(h);
@@ -3519,6 +3549,11 @@ int tgp_posterior_marginals(tgp_handle* h, const double* y, const uint8_t* missi
             TRY(smoother_backward_impl(h, h->F.fin, Rnew, rshared ? 0 : 1, mean_out, var_out));
             return TGP_OK;
         }, lml_out);
+    }
+    if (h->is_dense && missing == nullptr && h->p == 1) {      // wide LTI models: the stationary closed loop across the chip (tgp_wide.hip)
+        bool served = false;
+        TRY(wide_call(h, y, flags, Rnew, mean_out, var_out, lml_out, &served));
+        if (served) return TGP_OK;
     }
     CallTimer tm(h);
     const void* pR = nullptr;

@@ -35,7 +35,7 @@ __device__ __forceinline__ double readlane_d(double x, int l) {      // l wave-u
 // early from zero, or at the head's end from the head's own end state where that is nearer.
 template <int DP>
 __global__ __launch_bounds__(64) void k_wide_lml(const double* __restrict__ tab, const double* __restrict__ y, double hh, long long T, long long t_head,
-                                                  long long chunk_len, long long halo, int obs_lane, ZArg z0, double* __restrict__ part) {
+                                                  long long chunk_len, long long halo, int obs_lane, ZArg z0, double* __restrict__ part, double* __restrict__ rout) {
     __shared__ __attribute__((aligned(16))) double zb[64];
     const int lane = threadIdx.x;
     const long long chunk = blockIdx.x;
@@ -56,6 +56,8 @@ __global__ __launch_bounds__(64) void k_wide_lml(const double* __restrict__ tab,
         const double yv = yn;
         yn = (tb + 64 + lane < s1) ? y[tb + 64 + lane] : 0.0;      // (the next block's observations: on their way while this block runs)
         const int nb = (int)((s1 - tb < 64) ? (s1 - tb) : 64);
+        const bool keep = rout != nullptr && tb + 64 > s0;          // (a posterior call: the innovations of the chunk's own steps go to memory)
+        double outr = 0.0;
         for (int l = 0; l < nb; ++l) {
             const double u = readlane_d(yv, l) - hh;
             double a0 = fma(kin, u, cin), a1 = 0.0, a2 = 0.0, a3 = 0.0;
@@ -77,10 +79,81 @@ __global__ __launch_bounds__(64) void k_wide_lml(const double* __restrict__ tab,
             zb[lane] = acc;
             lds_sync();
             if (tb + l >= s0) ssq = fma(acc, acc, ssq);      // (the observer's acc is the step's innovation)
+            if (keep) {
+                const double rr = readlane_d(acc, obs_lane);
+                outr = lane == l ? rr : outr;
+            }
         }
+        if (keep && lane < nb && tb + lane >= s0) rout[tb + lane] = outr;
     }
     const double s = readlane_d(ssq, obs_lane);
     if (lane == 0) part[chunk] = s;
+}
+
+// The backward half (Bryson-Frazier in the predicted form): lam_t = h r_t / S + Psi lam_(t+1), Psi = (I - h K') A';
+// mean_t = y_t - (R / S) r_t + gw . lam_(t+1), gw = R A K; var_t = (S - R) R / S - gw' Lam_(t+1) gw + Rnew_t, where the quadratic form is a constant
+// behind the last n1 steps (qtab: its partial sums at the series' end).  tab: [DP + 1][64] -- column j of the lanes' rows (lane i < d: row i of Psi;
+// lane d, the observer: gw), then the gains on r_t (h_i / S; observer: -R / S).  A chunk starts `halo` steps behind its end from lam = 0 (exact at T).
+template <int DP>
+__global__ __launch_bounds__(64) void k_wide_bwd(const double* __restrict__ tab, const double* __restrict__ y, const double* __restrict__ r,
+                                                  const double* __restrict__ Rnew, int rnew_per_step, const double* __restrict__ qtab, long long n1, double vbase,
+                                                  double qinf, long long T, long long t_head, long long chunk_len, long long halo, int obs_lane, int d,
+                                                  double* __restrict__ mean, double* __restrict__ var, double* __restrict__ lam_out) {
+    __shared__ __attribute__((aligned(16))) double zb[64];
+    const int lane = threadIdx.x;
+    const long long chunk = blockIdx.x;
+    const long long s0 = t_head + chunk * chunk_len;
+    long long s1 = s0 + chunk_len;
+    if (s1 > T) s1 = T;
+    long long w1 = s1 + halo;
+    if (w1 > T) w1 = T;
+    double phi[DP];
+#pragma unroll
+    for (int j = 0; j < DP; ++j) phi[j] = tab[(size_t)j * 64 + lane];
+    const double kin = tab[(size_t)DP * 64 + lane];
+    zb[lane] = 0.0;
+    lds_sync();
+    double rn = (w1 - 1 - lane >= s0) ? r[w1 - 1 - lane] : 0.0;
+    for (long long tb = w1 - 1; tb >= s0; tb -= 64) {      // the block holds the steps tb, tb - 1, ..., one per lane
+        const double rv = rn;
+        rn = (tb - 64 - lane >= s0) ? r[tb - 64 - lane] : 0.0;
+        const int nb = (int)((tb - s0 + 1 < 64) ? (tb - s0 + 1) : 64);
+        const bool own = tb - 63 < s1;      // (some step of the block is the chunk's own)
+        double outm = 0.0;
+        for (int l = 0; l < nb; ++l) {
+            const double rr = readlane_d(rv, l);
+            double a0 = kin * rr, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+            for (int j = 0; j < DP; j += 8) {
+                const v2d q0 = *reinterpret_cast<const v2d*>(&zb[j]), q1 = *reinterpret_cast<const v2d*>(&zb[j + 2]);
+                const v2d q2 = *reinterpret_cast<const v2d*>(&zb[j + 4]), q3 = *reinterpret_cast<const v2d*>(&zb[j + 6]);
+                a0 = fma(phi[j], q0.x, a0);
+                a1 = fma(phi[j + 1], q0.y, a1);
+                a2 = fma(phi[j + 2], q1.x, a2);
+                a3 = fma(phi[j + 3], q1.y, a3);
+                a0 = fma(phi[j + 4], q2.x, a0);
+                a1 = fma(phi[j + 5], q2.y, a1);
+                a2 = fma(phi[j + 6], q3.x, a2);
+                a3 = fma(phi[j + 7], q3.y, a3);
+            }
+            const double acc = (a0 + a1) + (a2 + a3);
+            lds_sync();
+            zb[lane] = acc;
+            lds_sync();
+            if (own) {
+                const double mm = readlane_d(acc, obs_lane);
+                outm = lane == l ? mm : outm;
+            }
+        }
+        const long long t = tb - lane;
+        if (own && lane < nb && t < s1) {
+            mean[t] = y[t] + outm;
+            const long long jt = T - 1 - t;
+            const double q = jt < n1 ? qtab[jt] : qinf;
+            var[t] = vbase - q + (rnew_per_step ? Rnew[t] : Rnew[0]);
+        }
+    }
+    if (chunk == 0 && lane < d) lam_out[lane] = zb[lane];      // lam at the head's end: the head's backward pass runs on the host
 }
 
 // ---- host: small dense linear algebra, row-major ---------------------------------------------------------------------------------------
@@ -114,21 +187,32 @@ struct Engine {
     long long key_T = -1;
     int d = 0, dp = 0;
     std::vector<double> A, avec, hvec;      // row-major A, a, h
-    double hh = 0.0, g0 = 0.0, Sss = 0.0, sum_logS_head = 0.0;
+    double hh = 0.0, R = 0.0, g0 = 0.0, Sss = 0.0, sum_logS_head = 0.0;
     std::vector<double> x0m;
     std::vector<double> Kt, St;            // the head's gains [n0][d] and innovation variances [n0]
-    std::vector<double> tab_host;          // the kernel's table (see k_wide_lml)
-    double* tab_dev = nullptr;
-    size_t tab_cap = 0;
-    bool tab_current = false;
-    double* pinned = nullptr;              // [kHeadMax] head observations | [kMaxChunks] the chunks' sums
+    std::vector<double> tab_host;          // the forward kernel's table (see k_wide_lml)
+    // the posterior half of the plan (built by the first posterior call of a model)
+    bool post_ready = false;
+    int post_why = kOk;
+    std::vector<double> tabb_host;         // the backward kernel's table (see k_wide_bwd)
+    std::vector<double> qtab;              // partial sums of the variance's quadratic form at the series' end [n1 + 1]
+    std::vector<double> headvar;           // (S_t - R) R / S_t - gw_t' Lam_(t+1) gw_t for the head's steps [n0]
+    double vbase = 0.0, qinf = 0.0;
+    double* dev = nullptr;                 // device: forward table | backward table | qtab
+    size_t dev_cap = 0;
+    bool dev_current = false, dev_post_current = false;
+    double* rbuf = nullptr;                // device: the innovations of the steps behind the head [T]
+    size_t rbuf_cap = 0;
+    double* pinned = nullptr;              // [kHeadMax] head y | [kHeadMax] head Rnew | [kHeadMax] head means | [kHeadMax] head vars | [64] lam | [kMaxChunks] sums
+    std::vector<double> head_r;
     const char* kname = "k_wide_lml<32>";
 };
 
 Engine* create() { return new Engine(); }
 void destroy(Engine* e) {
     if (!e) return;
-    if (e->tab_dev) (void)tgp_alloc::dev_free(e->tab_dev);
+    if (e->dev) (void)tgp_alloc::dev_free(e->dev);
+    if (e->rbuf) (void)tgp_alloc::dev_free(e->rbuf);
     if (e->pinned) (void)tgp_alloc::host_free(e->pinned);
     delete e;
 }
@@ -151,6 +235,36 @@ bool same_model(const Engine* e, const ModelHost& m, long long T) {
     });
     return same;
 }
+// the smallest tested k with |M^k|_inf <= 2^-60 (squarings, then the lower bits of the exponent); -1: not within 2^20 steps
+long long halo_of(int d, const std::vector<double>& M) {
+    const size_t dd = (size_t)d * d;
+    const double thr = std::ldexp(1.0, -60);
+    std::vector<std::vector<double>> pw;
+    pw.push_back(M);
+    int j = 0;
+    while (norm_inf(d, pw.back().data()) > thr) {
+        if (j >= 20) return -1;
+        std::vector<double> sq(dd);
+        matmul(d, pw.back().data(), pw.back().data(), sq.data());
+        pw.push_back(std::move(sq));
+        ++j;
+    }
+    long long halo = 1LL << j;
+    if (j >= 2) {
+        std::vector<double> cur = pw[j - 1], cand(dd);
+        long long ex = 1LL << (j - 1);
+        const int bmin = std::max(0, j - 5);
+        for (int b = j - 2; b >= bmin; --b) {
+            matmul(d, cur.data(), pw[b].data(), cand.data());
+            if (norm_inf(d, cand.data()) > thr) {
+                cur = cand;
+                ex += 1LL << b;
+            }
+        }
+        halo = ex + (1LL << bmin);
+    }
+    return halo;
+}
 }  // namespace
 
 bool plan(Engine* e, const ModelHost& m, long long T) {
@@ -166,7 +280,8 @@ bool plan(Engine* e, const ModelHost& m, long long T) {
     }
     const auto t_begin = std::chrono::steady_clock::now();
     e->have = false;
-    e->tab_current = false;
+    e->dev_current = false;
+    e->post_ready = false;
     e->info = Info{};
     const int d = m.d;
     const size_t dd = (size_t)d * d;
@@ -185,6 +300,7 @@ bool plan(Engine* e, const ModelHost& m, long long T) {
     e->hvec.assign(m.H, m.H + d);
     e->x0m.assign(m.x0m, m.x0m + d);
     e->hh = m.hh;
+    e->R = m.R;
     const double* A = e->A.data();
     const double* h = e->hvec.data();
     auto done = [&](int why) {
@@ -255,36 +371,9 @@ bool plan(Engine* e, const ModelHost& m, long long T) {
     e->g0 = g0;
     for (int i = 0; i < d; ++i)
         for (int j = 0; j < d; ++j) Phi[(size_t)i * d + j] = A[(size_t)i * d + j] - K[i] * g[j];
-    // ---- halo: the smallest tested k with |Phi^k|_inf <= 2^-60 (squarings, then the lower bits of the exponent)
-    {
-        const double thr = std::ldexp(1.0, -60);
-        std::vector<std::vector<double>> pw;
-        pw.push_back(Phi);
-        int j = 0;
-        while (norm_inf(d, pw.back().data()) > thr) {
-            if (j >= 20) return done(kSlowMixing);
-            std::vector<double> sq(dd);
-            matmul(d, pw.back().data(), pw.back().data(), sq.data());
-            pw.push_back(std::move(sq));
-            ++j;
-        }
-        long long halo = 1LL << j;
-        if (j >= 2) {
-            std::vector<double> cur = pw[j - 1], cand(dd);
-            long long ex = 1LL << (j - 1);
-            int b = j - 2;
-            const int bmin = std::max(0, j - 5);
-            for (; b >= bmin; --b) {
-                matmul(d, cur.data(), pw[b].data(), cand.data());
-                if (norm_inf(d, cand.data()) > thr) {
-                    cur = cand;
-                    ex += 1LL << b;
-                }
-            }
-            halo = ex + (1LL << bmin);
-        }
-        e->info.halo = (int)halo;
-    }
+    const long long halo = halo_of(d, Phi);
+    if (halo < 0) return done(kSlowMixing);
+    e->info.halo = (int)halo;
     const long long Tb = T - n0;      // steps behind the head
     if (Tb < 64) return done(kTooShort);
     // chunks: as many waves as the chip holds several times over, none shorter than 64 steps
@@ -293,7 +382,7 @@ bool plan(Engine* e, const ModelHost& m, long long T) {
     chunks = (Tb + len - 1) / len;
     e->info.chunks = chunks;
     e->info.chunk_len = len;
-    // ---- the kernel's table
+    // ---- the forward kernel's table
     const int DP = e->dp;
     e->tab_host.assign((size_t)(DP + 2) * 64, 0.0);
     for (int i = 0; i < d; ++i) {
@@ -307,47 +396,197 @@ bool plan(Engine* e, const ModelHost& m, long long T) {
     return done(kOk);
 }
 
-int logpdf(Engine* e, hipStream_t stream, const double* y, long long T, double* lml_out, bool* not_pd, std::string* err) {
-    *not_pd = false;
+namespace {
+// The posterior half of the plan, data-free as the rest: Psi = (I - h K') A' and gw = R A K of the stationary step, halo_back, the partial sums
+// q_j = sum_(k < j) (gw' Psi^k h)^2 / S of the variance's quadratic form at the series' end (n1 of them until they no longer change), Lam_inf = the
+// fixed point of Lam = h h' / S + Psi Lam Psi' by doubling, and from it the head's variances backwards through the head's own steps.
+int plan_post(Engine* e, long long T) {
+    const int d = e->d, DP = e->dp, n0 = e->info.n0;
+    const size_t dd = (size_t)d * d;
+    const double *A = e->A.data(), *h = e->hvec.data();
+    const double R = e->R, S = e->Sss;
+    const double* K = e->Kt.data() + (size_t)(n0 - 1) * d;
+    auto AK_of = [&](const double* Kv, std::vector<double>& out) {
+        for (int j = 0; j < d; ++j) {
+            double s = 0.0;
+            for (int k = 0; k < d; ++k) s += A[(size_t)j * d + k] * Kv[k];
+            out[j] = s;
+        }
+    };
+    auto psi_of = [&](const std::vector<double>& AK, std::vector<double>& Psi) {      // Psi[i][j] = A[j][i] - h_i (A K)_j
+        for (int i = 0; i < d; ++i)
+            for (int j = 0; j < d; ++j) Psi[(size_t)i * d + j] = A[(size_t)j * d + i] - h[i] * AK[j];
+    };
+    std::vector<double> AK(d), Psi(dd), gw(d);
+    AK_of(K, AK);
+    psi_of(AK, Psi);
+    for (int j = 0; j < d; ++j) gw[j] = R * AK[j];
+    const long long hb = halo_of(d, Psi);
+    if (hb < 0) return kSlowMixing;
+    e->info.halo_back = (int)hb;
+    // ---- the series' end: q_j
+    e->qtab.assign(1, 0.0);
+    {
+        std::vector<double> u(h, h + d), un(d);
+        double gw1 = 0.0;
+        for (int j = 0; j < d; ++j) gw1 += std::fabs(gw[j]);
+        double q = 0.0;
+        long long n1 = -1;
+        for (long long k = 0; k < kTailMax; ++k) {
+            double c = 0.0, umax = 0.0;
+            for (int j = 0; j < d; ++j) {
+                c += gw[j] * u[j];
+                umax = std::max(umax, std::fabs(u[j]));
+            }
+            q += c * c / S;
+            e->qtab.push_back(q);
+            const double bound = gw1 * umax;      // |gw' Psi^k' h| for every later k' is below this times |Psi^(k' - k)|
+            if (bound * bound / S <= 1e-20 * std::max(q, 1e-300) && k >= 2) {
+                n1 = k + 1;
+                break;
+            }
+            for (int i = 0; i < d; ++i) {
+                double s2 = 0.0;
+                for (int j = 0; j < d; ++j) s2 += Psi[(size_t)i * d + j] * u[j];
+                un[i] = s2;
+            }
+            u.swap(un);
+        }
+        if (n1 < 0) return kTailLong;
+        e->info.n1 = (int)n1;
+        e->qinf = q;
+        if ((long long)n0 + n1 + 1 > T) return kTooShort;
+    }
+    e->vbase = (S - R) * R / S;
+    // ---- Lam_inf by doubling: Lam <- Lam + M Lam M', M <- M^2
+    std::vector<double> Lam(dd), M(Psi), T1(dd), T2(dd);
+    for (int i = 0; i < d; ++i)
+        for (int j = 0; j < d; ++j) Lam[(size_t)i * d + j] = h[i] * h[j] / S;
+    for (int it = 0; it < 40; ++it) {
+        if (norm_inf(d, M.data()) <= 1e-12) break;
+        matmul(d, M.data(), Lam.data(), T1.data());      // T1 = M Lam
+        for (int i = 0; i < d; ++i)
+            for (int j = 0; j <= i; ++j) {               // Lam += T1 M'
+                double s2 = 0.0;
+                for (int k = 0; k < d; ++k) s2 += T1[(size_t)i * d + k] * M[(size_t)j * d + k];
+                T2[(size_t)i * d + j] = T2[(size_t)j * d + i] = s2;
+            }
+        for (size_t i = 0; i < dd; ++i) Lam[i] += T2[i];
+        matmul(d, M.data(), M.data(), T1.data());
+        M.swap(T1);
+    }
+    // ---- the head's variances, backwards through its own steps (row n0 - 1 first: Lam_(n0) = Lam_inf)
+    e->headvar.assign(n0, 0.0);
+    {
+        std::vector<double> AKt(d), gwt(d), Pt(dd);
+        for (int t = n0 - 1; t >= 0; --t) {
+            const double* Kv = e->Kt.data() + (size_t)t * d;
+            const double St = e->St[t];
+            AK_of(Kv, AKt);
+            for (int j = 0; j < d; ++j) gwt[j] = R * AKt[j];
+            double qf = 0.0;
+            for (int i = 0; i < d; ++i) {
+                double s2 = 0.0;
+                for (int j = 0; j < d; ++j) s2 += Lam[(size_t)i * d + j] * gwt[j];
+                qf += gwt[i] * s2;
+            }
+            e->headvar[t] = (St - R) * R / St - qf;
+            if (t == 0) break;
+            psi_of(AKt, Pt);
+            matmul(d, Pt.data(), Lam.data(), T1.data());
+            for (int i = 0; i < d; ++i)
+                for (int j = 0; j <= i; ++j) {
+                    double s2 = h[i] * h[j] / St;
+                    for (int k = 0; k < d; ++k) s2 += T1[(size_t)i * d + k] * Pt[(size_t)j * d + k];
+                    T2[(size_t)i * d + j] = T2[(size_t)j * d + i] = s2;
+                }
+            Lam.swap(T2);
+        }
+    }
+    // ---- the backward kernel's table
+    e->tabb_host.assign((size_t)(DP + 1) * 64, 0.0);
+    for (int i = 0; i < d; ++i) {
+        for (int j = 0; j < d; ++j) e->tabb_host[(size_t)j * 64 + i] = Psi[(size_t)i * d + j];
+        e->tabb_host[(size_t)DP * 64 + i] = h[i] / S;
+    }
+    for (int j = 0; j < d; ++j) e->tabb_host[(size_t)j * 64 + d] = gw[j];      // the observer: mean_t - y_t = gw . lam_(t+1) - (R / S) r_t
+    e->tabb_host[(size_t)DP * 64 + d] = -R / S;
+    return kOk;
+}
+}  // namespace
+
+bool plan_posterior(Engine* e, long long T) {
+    if (!e->have || e->info.why != kOk) return false;
+    if (!e->post_ready) {
+        const auto t_begin = std::chrono::steady_clock::now();
+        e->post_why = plan_post(e, T);
+        e->post_ready = true;
+        e->dev_current = false;
+        e->info.plan_post_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    } else {
+        e->info.plan_post_ms = 0.0;
+    }
+    e->info.why_post = e->post_why;
+    return e->post_why == kOk;
+}
+
+int run(Engine* e, hipStream_t stream, const Call& c, double* lml_out, std::string* err) {
     auto fail = [&](hipError_t rc, const char* what) {
         if (err) *err = std::string("tgp_wide: ") + what + ": " + hipGetErrorString(rc);
         return (int)rc;
     };
-    if (!e->have || e->info.why != kOk) return fail(hipErrorInvalidValue, "no plan");
+    const bool post = c.mean != nullptr;
+    if (!e->have || e->info.why != kOk || (post && (!e->post_ready || e->post_why != kOk || !c.var || !c.Rnew))) return fail(hipErrorInvalidValue, "no plan");
     const int d = e->d, DP = e->dp, n0 = e->info.n0;
+    const long long T = c.T;
     hipError_t rc;
     if (!e->pinned) {
-        rc = tgp_alloc::host_malloc(reinterpret_cast<void**>(&e->pinned), (size_t)(kHeadMax + kMaxChunks) * sizeof(double), hipHostMallocDefault);
+        rc = tgp_alloc::host_malloc(reinterpret_cast<void**>(&e->pinned), (size_t)(4 * kHeadMax + 64 + kMaxChunks) * sizeof(double), hipHostMallocDefault);
         if (rc != hipSuccess) return fail(rc, "pinned buffer");
     }
-    const size_t tab_bytes = e->tab_host.size() * sizeof(double);
-    if (tab_bytes > e->tab_cap) {
-        if (e->tab_dev) (void)tgp_alloc::dev_free(e->tab_dev);
-        e->tab_dev = nullptr;
-        e->tab_cap = 0;
-        rc = tgp_alloc::dev_malloc(reinterpret_cast<void**>(&e->tab_dev), tab_bytes);
-        if (rc != hipSuccess) return fail(rc, "table");
-        e->tab_cap = tab_bytes;
-        e->tab_current = false;
+    // device tables: forward | backward | qtab
+    const size_t nf = e->tab_host.size(), nb = post ? e->tabb_host.size() : 0, nq = post ? e->qtab.size() : 0;
+    const size_t need = (nf + (size_t)(DP + 1) * 64 + (size_t)kTailMax + 2) * sizeof(double);
+    if (need > e->dev_cap) {
+        if (e->dev) (void)tgp_alloc::dev_free(e->dev);
+        e->dev = nullptr;
+        e->dev_cap = 0;
+        rc = tgp_alloc::dev_malloc(reinterpret_cast<void**>(&e->dev), need);
+        if (rc != hipSuccess) return fail(rc, "tables");
+        e->dev_cap = need;
+        e->dev_current = false;
     }
-    if (!e->tab_current) {
-        rc = hipMemcpyAsync(e->tab_dev, e->tab_host.data(), tab_bytes, hipMemcpyHostToDevice, stream);
+    double *tab_f = e->dev, *tab_b = e->dev + nf, *qtab_d = tab_b + (size_t)(DP + 1) * 64;
+    if (!e->dev_current || (post && !e->dev_post_current)) {
+        rc = hipMemcpyAsync(tab_f, e->tab_host.data(), nf * sizeof(double), hipMemcpyHostToDevice, stream);
+        if (rc == hipSuccess && post) rc = hipMemcpyAsync(tab_b, e->tabb_host.data(), nb * sizeof(double), hipMemcpyHostToDevice, stream);
+        if (rc == hipSuccess && post) rc = hipMemcpyAsync(qtab_d, e->qtab.data(), nq * sizeof(double), hipMemcpyHostToDevice, stream);
         if (rc != hipSuccess) return fail(rc, "table upload");
-        e->tab_current = true;
+        e->dev_current = true;
+        e->dev_post_current = post;
     }
-    double* yh = e->pinned;
-    double* part = e->pinned + kHeadMax;
-    rc = hipMemcpyAsync(yh, y, (size_t)n0 * sizeof(double), hipMemcpyDeviceToHost, stream);
+    if (post && (size_t)T * sizeof(double) > e->rbuf_cap) {
+        if (e->rbuf) (void)tgp_alloc::dev_free(e->rbuf);
+        e->rbuf = nullptr;
+        e->rbuf_cap = 0;
+        rc = tgp_alloc::dev_malloc(reinterpret_cast<void**>(&e->rbuf), (size_t)T * sizeof(double));
+        if (rc != hipSuccess) return fail(rc, "innovation buffer");
+        e->rbuf_cap = (size_t)T * sizeof(double);
+    }
+    double *yh = e->pinned, *Rh = yh + kHeadMax, *mh = Rh + kHeadMax, *vh = mh + kHeadMax, *lam = vh + kHeadMax, *part = lam + 64;
+    rc = hipMemcpyAsync(yh, c.y, (size_t)n0 * sizeof(double), hipMemcpyDeviceToHost, stream);
+    if (rc == hipSuccess && post) rc = hipMemcpyAsync(Rh, c.Rnew, (size_t)(c.rnew_per_step ? n0 : 1) * sizeof(double), hipMemcpyDeviceToHost, stream);
     if (rc != hipSuccess) return fail(rc, "head observations");
     rc = hipStreamSynchronize(stream);
     if (rc != hipSuccess) return fail(rc, "head observations");
-    // ---- the head: lgssm.jl:147-165 with the plan's gains
+    // ---- the head forward: lgssm.jl:147-165 with the plan's gains
     ZArg z0;
     for (int i = 0; i < 64; ++i) z0.z[i] = 0.0;
     double quad = 0.0;
+    const double *A = e->A.data(), *h = e->hvec.data();
+    e->head_r.resize(n0);
     {
         std::vector<double> mcur(e->x0m), mp(d);
-        const double *A = e->A.data(), *h = e->hvec.data();
         for (int t = 0; t < n0; ++t) {
             double pred = e->hh;
             for (int i = 0; i < d; ++i) {
@@ -358,6 +597,7 @@ int logpdf(Engine* e, hipStream_t stream, const double* y, long long T, double* 
                 pred += h[i] * s;
             }
             const double r = yh[t] - pred;
+            e->head_r[t] = r;
             quad += r * r / e->St[t];
             const double* K = e->Kt.data() + (size_t)t * d;
             for (int i = 0; i < d; ++i) mcur[i] = mp[i] + K[i] * r;
@@ -365,21 +605,58 @@ int logpdf(Engine* e, hipStream_t stream, const double* y, long long T, double* 
         for (int i = 0; i < d; ++i) z0.z[i] = mcur[i];
     }
     const long long chunks = e->info.chunks;
+    double* rout = post ? e->rbuf : nullptr;
     if (DP == 32)
-        hipLaunchKernelGGL(k_wide_lml<32>, dim3((unsigned)chunks), dim3(64), 0, stream, e->tab_dev, y, e->hh, T, (long long)n0, e->info.chunk_len, (long long)e->info.halo, d, z0,
-                           part);
+        hipLaunchKernelGGL(k_wide_lml<32>, dim3((unsigned)chunks), dim3(64), 0, stream, tab_f, c.y, e->hh, T, (long long)n0, e->info.chunk_len, (long long)e->info.halo, d, z0, part,
+                           rout);
     else
-        hipLaunchKernelGGL(k_wide_lml<64>, dim3((unsigned)chunks), dim3(64), 0, stream, e->tab_dev, y, e->hh, T, (long long)n0, e->info.chunk_len, (long long)e->info.halo, d, z0,
-                           part);
+        hipLaunchKernelGGL(k_wide_lml<64>, dim3((unsigned)chunks), dim3(64), 0, stream, tab_f, c.y, e->hh, T, (long long)n0, e->info.chunk_len, (long long)e->info.halo, d, z0, part,
+                           rout);
     rc = hipGetLastError();
     if (rc != hipSuccess) return fail(rc, "launch");
+    if (post) {
+        if (DP == 32)
+            hipLaunchKernelGGL(k_wide_bwd<32>, dim3((unsigned)chunks), dim3(64), 0, stream, tab_b, c.y, e->rbuf, c.Rnew, c.rnew_per_step, qtab_d, (long long)e->info.n1, e->vbase,
+                               e->qinf, T, (long long)n0, e->info.chunk_len, (long long)e->info.halo_back, d, d, c.mean, c.var, lam);
+        else
+            hipLaunchKernelGGL(k_wide_bwd<64>, dim3((unsigned)chunks), dim3(64), 0, stream, tab_b, c.y, e->rbuf, c.Rnew, c.rnew_per_step, qtab_d, (long long)e->info.n1, e->vbase,
+                               e->qinf, T, (long long)n0, e->info.chunk_len, (long long)e->info.halo_back, d, d, c.mean, c.var, lam);
+        rc = hipGetLastError();
+        if (rc != hipSuccess) return fail(rc, "launch");
+    }
     rc = hipStreamSynchronize(stream);
     if (rc != hipSuccess) return fail(rc, "kernel");
+    if (post) {
+        // ---- the head backward: lam_t = h r_t / S_t + Psi_t lam_(t+1), Psi_t lam = A' lam - h (A K_t) . lam; mean_t = y_t - (R / S_t) r_t + R (A K_t) . lam_(t+1)
+        std::vector<double> lcur(lam, lam + d), AKt(d), ln(d);
+        for (int t = n0 - 1; t >= 0; --t) {
+            const double* Kv = e->Kt.data() + (size_t)t * d;
+            const double St = e->St[t], r = e->head_r[t];
+            double akl = 0.0;
+            for (int j = 0; j < d; ++j) {
+                double s = 0.0;
+                for (int k = 0; k < d; ++k) s += A[(size_t)j * d + k] * Kv[k];
+                AKt[j] = s;
+                akl += s * lcur[j];
+            }
+            mh[t] = yh[t] - (e->R / St) * r + e->R * akl;
+            vh[t] = e->headvar[t] + Rh[c.rnew_per_step ? t : 0];
+            for (int i = 0; i < d; ++i) {
+                double s = h[i] * (r / St - akl);
+                for (int k = 0; k < d; ++k) s += A[(size_t)k * d + i] * lcur[k];
+                ln[i] = s;
+            }
+            lcur.swap(ln);
+        }
+        rc = hipMemcpyAsync(c.mean, mh, (size_t)n0 * sizeof(double), hipMemcpyHostToDevice, stream);
+        if (rc == hipSuccess) rc = hipMemcpyAsync(c.var, vh, (size_t)n0 * sizeof(double), hipMemcpyHostToDevice, stream);
+        if (rc == hipSuccess) rc = hipStreamSynchronize(stream);
+        if (rc != hipSuccess) return fail(rc, "head outputs");
+    }
     double ssq = 0.0;
-    for (long long c = 0; c < chunks; ++c) ssq += part[c];
+    for (long long k = 0; k < chunks; ++k) ssq += part[k];
     const double kLog2Pi = 1.8378770664093454835606594728112;
     *lml_out = -0.5 * ((double)T * kLog2Pi + e->sum_logS_head + (double)(T - n0) * std::log(e->Sss) + quad + ssq / e->Sss);
-    if (!std::isfinite(*lml_out) && std::isfinite(ssq)) *not_pd = true;
     return 0;
 }
 

@@ -11,6 +11,10 @@
 //               registers, the state goes round through a 512-byte LDS line (one ds_write, d/2 broadcast ds_read_b128 per step), lane d -- the
 //               observer -- carries the row -g and so computes the innovation r_t by the same multiply-adds.  A chunk starts `halo` steps early
 //               from a zero state (the closed loop forgets it to 2^-60) and sums r_t^2 over its own steps only.
+//   posterior   marginals(replace_observation_noise_cov(posterior(model, y), Rnew)) (lgssm.jl:99-115, 193-238) in Bryson-Frazier form: the forward
+//               kernel keeps its innovations (8 B per step), a second kernel of the same shape runs lam_t = h r_t / S + Psi lam_(t+1) backwards
+//               (Psi = (I - h K') A'), its observer row gw = R A K gives mean_t = y_t - (R / S) r_t + gw . lam_(t+1); the variance is a constant
+//               between the head (host, from Lam_inf backwards through the head's steps) and the last n1 steps (a data-free table).
 // Before this engine such models ran on ONE compute unit (tgp_dense_fused.hpp: a persistent kernel, sequential in time).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -21,6 +25,7 @@ namespace tgp_wide {
 
 constexpr int kMaxD = 63;          // (lane d is the observer)
 constexpr int kHeadMax = 8192;     // steps until the covariance recursion must have settled
+constexpr int kTailMax = 8192;     // steps at the series' end whose smoothed variance is still in its transient
 constexpr int kMaxChunks = 4096;
 
 struct Engine;
@@ -32,11 +37,20 @@ struct ModelHost {      // shared blocks, column-major as handed to tgp_model_se
     const double *x0m = nullptr, *x0P = nullptr;
 };
 
-enum Why { kOk = 0, kNotPD = 1, kNotSettled = 2, kSlowMixing = 3, kTooShort = 4, kAlloc = 5 };
+enum Why { kOk = 0, kNotPD = 1, kNotSettled = 2, kSlowMixing = 3, kTooShort = 4, kAlloc = 5, kTailLong = 6 };
 struct Info {
     int why = kOk, n0 = -1, nhs = 0, halo = 0;
+    int why_post = kOk, n1 = -1, halo_back = 0;
     long long chunks = 0, chunk_len = 0;
-    double plan_ms = 0.0;      // 0 when the plan of the previous call was kept
+    double plan_ms = 0.0, plan_post_ms = 0.0;      // 0 when the plan of the previous call was kept
+};
+
+struct Call {      // device pointers; mean == nullptr: logpdf only
+    long long T = 0;
+    const double* y = nullptr;
+    const double* Rnew = nullptr;      // [T] or [1]
+    int rnew_per_step = 0;
+    double *mean = nullptr, *var = nullptr;
 };
 
 Engine* create();
@@ -44,10 +58,13 @@ void destroy(Engine* e);
 inline bool supports(int d) { return d > 16 && d <= kMaxD; }
 // The plan of model `m` for a series of T steps (kept between calls while the model's blocks and T stand).  false: the engine does not apply (Info::why).
 bool plan(Engine* e, const ModelHost& m, long long T);
+// ... and its posterior half (the backward recursion's matrix, the variances of the series' two ends), built once per planned model.  false: Info::why_post.
+bool plan_posterior(Engine* e, long long T);
 const Info& last_plan(const Engine* e);
-// logpdf of the planned model on y (device pointer, T doubles): the head on the host, ONE kernel behind it.  Synchronises `stream`.
-// 0, or a hipError_t; *not_pd: a head step met a non-positive innovation variance.
-int logpdf(Engine* e, hipStream_t stream, const double* y, long long T, double* lml_out, bool* not_pd, std::string* err);
+// logpdf (and, with Call::mean, the posterior marginals: lgssm.jl:99-115 on posterior(model, y) with the noise replaced by Rnew) of the planned model:
+// the head on the host, ONE kernel behind it (two for the posterior: forward keeping the innovations, backward in Bryson-Frazier form).
+// Synchronises `stream`.  0, or a hipError_t.
+int run(Engine* e, hipStream_t stream, const Call& c, double* lml_out, std::string* err);
 const char* kernel_name(const Engine* e);
 
 }  // namespace tgp_wide

@@ -91,3 +91,61 @@ def test_series_too_short_for_the_engine_goes_to_the_dense_passes(tgp):
     lp_ref = ref.logpdf(model, y)
     assert abs(lp - lp_ref) <= 1e-10 * abs(lp_ref)
     assert not any(n.startswith("k_wide") for n in names), names
+
+
+def dense_gp_posterior(model, y, Rn):
+    """The posterior marginals from the model's OWN covariance function, k(s - t) = h' A^|s - t| P_inf h (x0 stationary, no offsets: what to_sde builds), by a
+    dense Cholesky -- no state-space recursion involved, conditioned like K + R I (1e3), not like the predicted covariances."""
+    from scipy.linalg import cho_factor, cho_solve, toeplitz
+    T = model["T"]
+    A, H, P, R = model["A"][0], model["H"][0], model["x0P"], float(model["R"][0])
+    c, v = np.empty(T), P @ H
+    for k in range(T):
+        c[k] = H @ v
+        v = A @ v
+    K = toeplitz(c)
+    cf = cho_factor(K + R * np.eye(T), lower=True)
+    return K @ cho_solve(cf, y), np.diag(K) - np.einsum("ij,ji->i", K, cho_solve(cf, K)) + Rn
+
+
+@pytest.mark.parametrize("d", sorted(KERNELS))
+def test_wide_posterior_marginals(tgp, d):
+    """marginals(replace_observation_noise_cov(posterior(model, y), Rnew)) (lgssm.jl:99-115, 193-238): forward kernel keeping its innovations, backward
+    kernel in Bryson-Frazier form, the head and the last n1 steps' variances from the host's tables.  Two references: the dense GP on the model's own
+    covariance function at 1e-8 (independent of every recursion), and the literal RTS restatement at 1e-6 -- invert_dynamics solves with the predicted
+    covariance, whose condition at d = 28 costs the restatement itself 5e-8 of the mean against the dense GP (the Bryson-Frazier form has no solve)"""
+    rng = np.random.default_rng(d)
+    for T, dt, s2 in ((2500, 0.1, 0.1), (4000, 0.05, 0.02)):
+        model = oc.build_lgssm(KERNELS[d], ("regular", 0.0, dt, T), s2)
+        y = draw(model, 2 * d + T)
+        lp_ref = ref.logpdf(model, y)
+        post = ref.posterior(model, y)
+        for per_step in (False, True):
+            Rn = rng.random(T) * 0.3 + 0.01 if per_step else np.array([0.05])
+            Rfull = Rn if per_step else np.full(T, Rn[0])
+            m_rts, v_rts = ref.marginals(ref.replace_observation_noise_cov(post, Rfull))
+            m_rts, v_rts = np.asarray(m_rts).reshape(T), np.asarray(v_rts).reshape(T)
+            m_gp, v_gp = dense_gp_posterior(model, y, Rfull)
+            dm = device_model(tgp, model)
+            (lp, mean, var), names = kernels_of(tgp, dm, lambda: tgp.logpdf_and_posterior_marginals(dm, y, Rn))
+            assert abs(lp - lp_ref) <= 1e-10 * abs(lp_ref), (d, T, lp, lp_ref)
+            assert np.max(np.abs(mean - m_gp)) <= 1e-8 * max(1.0, np.abs(m_gp).max()), (d, T, per_step, np.max(np.abs(mean - m_gp)))
+            assert np.max(np.abs(var - v_gp)) <= 1e-8 * max(1.0, v_gp.max()), (d, T, per_step, np.max(np.abs(var - v_gp)))
+            assert np.max(np.abs(mean - m_rts)) <= 1e-6 * max(1.0, np.abs(m_rts).max()) and np.max(np.abs(var - v_rts)) <= 1e-6 * max(1.0, v_rts.max())
+            assert len(names) == 1 and next(iter(names)).startswith("k_wide_lml"), names
+
+
+def test_wide_posterior_long_series_device_arrays(tgp):
+    import torch
+    T = 300_000
+    model = oc.build_lgssm(KERNELS[28], ("regular", 0.0, 0.1, T), 0.1)
+    rng = np.random.default_rng(5)
+    y = rng.standard_normal(T) * np.sqrt(float(model["H"][0] @ model["x0P"] @ model["H"][0]) + 0.1)
+    yd, Rn = torch.from_numpy(y).cuda(), torch.full((1,), 0.2, dtype=torch.float64, device="cuda")
+    dm, dm0 = device_model(tgp, model), device_model(tgp, model, wide=0)
+    (mean, var), names = kernels_of(tgp, dm, lambda: tgp.posterior_marginals(dm, yd, Rn))
+    assert next(iter(names)).startswith("k_wide_lml"), names
+    # (the dense engine runs the reference's RTS chain with its solves against the predicted covariance: 1e-6, as in test_wide_posterior_marginals)
+    mean0, var0 = tgp.posterior_marginals(dm0, yd, Rn)
+    assert float((mean - mean0).abs().max()) <= 1e-6 * max(1.0, float(mean0.abs().max()))
+    assert float((var - var0).abs().max()) <= 1e-6 * max(1.0, float(var0.max()))
