@@ -616,6 +616,59 @@ def other_config_legs(args, torch, tgp, local):
         except Exception as ex:      # (an extra leg: never at the cost of the line)
             legs[f"cfg3_{name}"] = dict(error=repr(ex))
     try:
+        # wide states (16 < d <= 63; lti_sde.jl:377-400: ApproxPeriodicKernel() * Matern32Kernel(), d = 28): the stationary closed loop across the chip
+        # (tgp_wide.hip) against the dense engine's sequential passes on one compute unit (TGP_OPT_WIDE = 0; one call of each, a 1e5-step sample)
+        from temporalgps_jl_amd import lti_sde as _P
+        Tw, dw = 1_000_000, 28
+        spec = ("product", ("approx_periodic", 7, 1.0), ("matern32",))
+        mw = _P.build_lgssm(_P.to_kernel(spec), _P.RegularSpacing(0.0, 0.1, Tw), 0.1)
+        yw = torch.randn((Tw,), dtype=torch.float64, device=f"cuda:{local}")
+        Rw = torch.full((1,), 1e-18, dtype=torch.float64, device=f"cuda:{local}")
+        outw = (torch.empty_like(yw), torch.empty_like(yw))
+        for _ in range(2):
+            tgp.logpdf(mw, yw)
+            tgp.posterior_marginals(mw, yw, Rw, out=outw)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 10
+        for _ in range(n):
+            tgp.logpdf(mw, yw)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(n):
+            tgp.posterior_marginals(mw, yw, Rw, out=outw)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        hw = mw.handle()
+        hw.set_option(tgp._lib.OPT_PROFILE, 1)
+        hw.profile_reset()
+        tgp.logpdf(mw, yw)
+        kms = {k: v["total_ms"] / max(1, v["calls"]) for k, v in hw.profile().items()}
+        hw.set_option(tgp._lib.OPT_PROFILE, 0)
+        Ts = 100_000
+        m0 = _P.build_lgssm(_P.to_kernel(spec), _P.RegularSpacing(0.0, 0.1, Ts), 0.1)
+        m0.handle_options[tgp._lib.OPT_WIDE] = 0
+        tgp.logpdf(m0, yw[:Ts])
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        tgp.logpdf(m0, yw[:Ts])
+        torch.cuda.synchronize()
+        dense_us_per_step = (time.perf_counter() - t3) / Ts * 1e6
+        lp_ms, pm_ms = (t1 - t0) / n * 1e3, (t2 - t1) / n * 1e3
+        flops = 2.0 * dw * dw * Tw      # (the mean recursion's multiply-adds: the covariance half is the host plan's, data-free)
+        legs["wide_d28"] = dict(workload=f"ApproxPeriodicKernel() * Matern32Kernel() (d = {dw}), RegularSpacing(0,0.1,T={Tw}), sigma2_obs=0.1", T=Tw, d=dw,
+                                logpdf_ms=lp_ms, posterior_marginals_ms=pm_ms, ms_per_step=lp_ms + pm_ms, steps_per_s=Tw / ((lp_ms + pm_ms) * 1e-3),
+                                kernels_ms=kms, dense_engine_logpdf_us_per_step=dense_us_per_step,
+                                speedup_logpdf_vs_one_cu_pass=dense_us_per_step * Tw * 1e-3 / lp_ms,
+                                roofline=dict(bound="valu", kernel="k_wide_lml4", achieved=flops / (kms.get("k_wide_lml4", lp_ms) * 1e-3) / 1e12, peak=78.6, unit="TFLOP/s",
+                                              frac=flops / (kms.get("k_wide_lml4", lp_ms) * 1e-3) / 1e12 / 78.6,
+                                              note="algorithmic flops 2 d^2 per step over the logpdf kernel's hipEvent duration, against the fp64 vector peak; the kernel "
+                                                   "executes (1 + halo / chunk) x 32^2 / 28^2 of them (chunks of 245 steps behind 272 warm-up steps): four chunks per wave, "
+                                                   "the state's components broadcast inside v_fmac_f64_dpp (~12.7 cycles each, measured), DESIGN 4.4"))
+        del mw, m0, yw, outw
+    except Exception as ex:
+        legs["wide_d28"] = dict(error=repr(ex))
+    try:
         a5 = copy.copy(args)
         a5.T, a5.steps, a5.warmup, a5.no_cpu_baseline, a5.dense_products = 2000, 1, 1, True, False
         o5 = run_cfg5(a5, torch, tgp, 1, 0, local, emit=False)

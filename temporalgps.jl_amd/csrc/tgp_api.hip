@@ -2429,7 +2429,8 @@ static int wide_call(tgp_handle* h, const double* y, uint32_t flags, const doubl
     std::string err;
     double lml = 0.0;
     {
-        LaunchScope ls(h, post ? (d <= 31 ? "k_wide_lml<32> + k_wide_bwd<32>" : "k_wide_lml<64> + k_wide_bwd<64>") : tgp_wide::kernel_name(h->wide));
+        const std::string both = std::string(tgp_wide::kernel_name(h->wide)) + " + k_wide_bwd";      // (the posterior's two kernels under one bracket: the head's copy sits between)
+        LaunchScope ls(h, post ? both.c_str() : tgp_wide::kernel_name(h->wide));
         if (tgp_wide::run(h->wide, h->stream, c, &lml, &err) != 0) return h->fail(TGP_EHIP, err);
     }
     TRY(copy_back(h, mean_out, dm, nT, odev));

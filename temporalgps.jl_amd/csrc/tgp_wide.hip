@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <utility>
 #include <vector>
 
 #include "tgp_alloc.hpp"
@@ -156,6 +157,182 @@ __global__ __launch_bounds__(64) void k_wide_bwd(const double* __restrict__ tab,
     if (chunk == 0 && lane < d) lam_out[lane] = zb[lane];      // lam at the head's end: the head's backward pass runs on the host
 }
 
+// ---- d <= 31: FOUR chunks per wave, no LDS.  A row of sixteen lanes holds one chunk's state in two registers (lane p: components p and p + 16) and the
+// two matching rows of the matrix; component j reaches the row's lanes as the DPP operand of the multiply-add itself (v_fmac_f64_dpp row_newbcast:j), and
+// so does the step's observation out of the row's block of sixteen.  66 multiply-adds per step and wave for four chunks (the LDS form: 32 and 16 broadcast
+// reads for one).  The table is the LDS kernels' (DP = 32).
+// (measured: ~12.7 cycles per v_fmac_f64_dpp at one wave per SIMD, four accumulator chains or two alike -- 0.187 ms at d = 28, T = 1e6; two 32-bit
+//  DPP moves and two plain multiply-adds per component instead run at the full issue rate and come to 0.208 ms; the LDS form 0.36 ms)
+template <int J>
+__device__ __forceinline__ void fmac_bc(double& acc, double src, double mul) {      // acc += (lane J of the row's src) * mul
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mul), "n"(J));
+}
+struct Acc4 {
+    double v[4];
+    __device__ __forceinline__ double sum() const { return (v[0] + v[1]) + (v[2] + v[3]); }
+};
+template <int OFF, int... Js>
+__device__ __forceinline__ void dot16(Acc4& a, double z, const double (&phi)[32], std::integer_sequence<int, Js...>) {
+    (fmac_bc<Js>(a.v[Js % 4], z, phi[OFF + Js]), ...);
+}
+typedef std::make_integer_sequence<int, 16> Seq16;
+
+struct RowGeom {      // per lane, the same within a row
+    long long s0, s1, w;      // own steps [s0, s1); w: where the recursion starts (forward: w <= s0, upwards; backward: w >= s1, downwards from w - 1)
+    bool valid;
+};
+
+template <int L, bool KEEP>
+__device__ __forceinline__ void fwd_step4(double& yv, double& zlo, double& zhi, const double (&pA)[32], const double (&pB)[32], double kA, double kB, double cA, double cB,
+                                          long long t, const RowGeom& g, bool obsB, bool is_obs, double& ssq, double* __restrict__ rout) {
+    // (a DPP operand must not be read within two cycles of the VALU write of its register, nor within five of a write to EXEC: the recogniser that
+    //  spaces such pairs does not look into inline assembly)
+    asm volatile("s_nop 4" : "+v"(zlo), "+v"(zhi), "+v"(yv) : : "memory");
+    Acc4 a{{cA, 0.0, 0.0, 0.0}}, b{{cB, 0.0, 0.0, 0.0}};
+    fmac_bc<L>(a.v[3], yv, kA);
+    fmac_bc<L>(b.v[3], yv, kB);
+    dot16<0>(a, zlo, pA, Seq16{});
+    dot16<0>(b, zlo, pB, Seq16{});
+    dot16<16>(a, zhi, pA, Seq16{});
+    dot16<16>(b, zhi, pB, Seq16{});
+    const double nA = a.sum(), nB = b.sum();
+    const bool live = t < g.s1;
+    zlo = live ? nA : zlo;
+    zhi = live ? nB : zhi;
+    const bool own = live && t >= g.s0;
+    double rr = obsB ? nB : nA;
+    rr = own ? rr : 0.0;
+    ssq = fma(rr, rr, ssq);
+    if (KEEP) {
+        if (is_obs && own) rout[t] = rr;
+    }
+}
+template <bool KEEP, int... Ls>
+__device__ __forceinline__ void fwd_block4(double& yv, double& zlo, double& zhi, const double (&pA)[32], const double (&pB)[32], double kA, double kB, double cA, double cB,
+                                           long long t0, const RowGeom& g, bool obsB, bool is_obs, double& ssq, double* __restrict__ rout, std::integer_sequence<int, Ls...>) {
+    (fwd_step4<Ls, KEEP>(yv, zlo, zhi, pA, pB, kA, kB, cA, cB, t0 + Ls, g, obsB, is_obs, ssq, rout), ...);
+}
+
+template <bool KEEP>
+__global__ __launch_bounds__(64) void k_wide_lml4(const double* __restrict__ tab, const double* __restrict__ y, double hh, long long T, long long t_head, long long chunk_len,
+                                                   long long halo, long long chunks, int d, ZArg z0, double* __restrict__ part, double* __restrict__ rout) {
+    const int lane = threadIdx.x, p = lane & 15, row = lane >> 4;
+    const long long chunk = (long long)blockIdx.x * 4 + row;
+    RowGeom g;
+    g.valid = chunk < chunks;
+    g.s0 = t_head + chunk * chunk_len;
+    g.s1 = g.s0 + chunk_len;
+    if (g.s1 > T) g.s1 = T;
+    const bool from_head = g.s0 - halo <= t_head;
+    g.w = from_head ? t_head : g.s0 - halo;
+    if (!g.valid) g.s0 = g.s1 = g.w = T;
+    double pA[32], pB[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        pA[j] = tab[(size_t)j * 64 + p];
+        pB[j] = tab[(size_t)j * 64 + 16 + p];
+    }
+    const double kA = tab[(size_t)32 * 64 + p], kB = tab[(size_t)32 * 64 + 16 + p];
+    const double cA = tab[(size_t)33 * 64 + p] - kA * hh, cB = tab[(size_t)33 * 64 + 16 + p] - kB * hh;      // (u = y - hh folded into the constant)
+    double zlo = (g.valid && from_head) ? z0.z[p] : 0.0, zhi = (g.valid && from_head) ? z0.z[16 + p] : 0.0;
+    const bool obsB = d >= 16, is_obs = p == (d & 15);
+    // the longest row's number of steps (wave-uniform)
+    const long long len = g.s1 - g.w;
+    long long nmax = 0;
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+        const int lo = __builtin_amdgcn_readlane((int)(len & 0xffffffffll), 16 * r4), hi = __builtin_amdgcn_readlane((int)(len >> 32), 16 * r4);
+        const long long v = ((long long)hi << 32) | (unsigned)lo;
+        nmax = v > nmax ? v : nmax;
+    }
+    double ssq = 0.0;
+    double yn = (g.w + p < g.s1) ? y[g.w + p] : 0.0;
+    for (long long kb = 0; kb < nmax; kb += 16) {
+        double yv = yn;
+        yn = (g.w + kb + 16 + p < g.s1) ? y[g.w + kb + 16 + p] : 0.0;      // (the next block: on its way while this one runs)
+        fwd_block4<KEEP>(yv, zlo, zhi, pA, pB, kA, kB, cA, cB, g.w + kb, g, obsB, is_obs, ssq, rout, Seq16{});
+    }
+    if (is_obs && g.valid) part[chunk] = ssq;
+}
+
+template <int L>
+__device__ __forceinline__ void bwd_step4(double& rv, double& yv, double& zlo, double& zhi, const double (&pA)[32], const double (&pB)[32], double kA, double kB, double yA, double yB,
+                                          long long t, const RowGeom& g, bool obsB, bool is_obs, double* __restrict__ mean) {
+    asm volatile("s_nop 4" : "+v"(zlo), "+v"(zhi), "+v"(rv), "+v"(yv) : : "memory");
+    Acc4 a{{0.0, 0.0, 0.0, 0.0}}, b{{0.0, 0.0, 0.0, 0.0}};
+    fmac_bc<L>(a.v[3], rv, kA);
+    fmac_bc<L>(b.v[3], rv, kB);
+    fmac_bc<L>(a.v[2], yv, yA);      // (1 at the observer: its sum is the step's mean; its slot of the state multiplies a zero column)
+    fmac_bc<L>(b.v[2], yv, yB);
+    dot16<0>(a, zlo, pA, Seq16{});
+    dot16<0>(b, zlo, pB, Seq16{});
+    dot16<16>(a, zhi, pA, Seq16{});
+    dot16<16>(b, zhi, pB, Seq16{});
+    const double nA = a.sum(), nB = b.sum();
+    const bool live = t >= g.s0;
+    zlo = live ? nA : zlo;
+    zhi = live ? nB : zhi;
+    if (is_obs && live && t < g.s1) mean[t] = obsB ? nB : nA;
+}
+template <int... Ls>
+__device__ __forceinline__ void bwd_block4(double& rv, double& yv, double& zlo, double& zhi, const double (&pA)[32], const double (&pB)[32], double kA, double kB, double yA, double yB,
+                                           long long t0, const RowGeom& g, bool obsB, bool is_obs, double* __restrict__ mean, std::integer_sequence<int, Ls...>) {
+    (bwd_step4<Ls>(rv, yv, zlo, zhi, pA, pB, kA, kB, yA, yB, t0 - Ls, g, obsB, is_obs, mean), ...);
+}
+
+__global__ __launch_bounds__(64) void k_wide_bwd4(const double* __restrict__ tab, const double* __restrict__ y, const double* __restrict__ r, const double* __restrict__ Rnew,
+                                                   int rnew_per_step, const double* __restrict__ qtab, long long n1, double vbase, double qinf, long long T, long long t_head,
+                                                   long long chunk_len, long long halo, long long chunks, int d, double* __restrict__ mean, double* __restrict__ var,
+                                                   double* __restrict__ lam_out) {
+    const int lane = threadIdx.x, p = lane & 15, row = lane >> 4;
+    const long long chunk = (long long)blockIdx.x * 4 + row;
+    RowGeom g;
+    g.valid = chunk < chunks;
+    g.s0 = t_head + chunk * chunk_len;
+    g.s1 = g.s0 + chunk_len;
+    if (g.s1 > T) g.s1 = T;
+    g.w = g.s1 + halo;
+    if (g.w > T) g.w = T;
+    if (!g.valid) g.s0 = g.s1 = g.w = T;
+    double pA[32], pB[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        pA[j] = tab[(size_t)j * 64 + p];
+        pB[j] = tab[(size_t)j * 64 + 16 + p];
+    }
+    const double kA = tab[(size_t)32 * 64 + p], kB = tab[(size_t)32 * 64 + 16 + p];
+    const bool obsB = d >= 16, is_obs = p == (d & 15);
+    const double yA = (is_obs && !obsB) ? 1.0 : 0.0, yB = (is_obs && obsB) ? 1.0 : 0.0;
+    double zlo = 0.0, zhi = 0.0;
+    const long long len = g.w - g.s0;
+    long long nmax = 0;
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+        const int lo = __builtin_amdgcn_readlane((int)(len & 0xffffffffll), 16 * r4), hi = __builtin_amdgcn_readlane((int)(len >> 32), 16 * r4);
+        const long long v = ((long long)hi << 32) | (unsigned)lo;
+        nmax = v > nmax ? v : nmax;
+    }
+    const long long top = g.w - 1;      // the row's first step
+    double rn = (top - p >= g.s0) ? r[top - p] : 0.0;
+    for (long long kb = 0; kb < nmax; kb += 16) {      // the block holds the steps top - kb, top - kb - 1, ..., one per lane of the row
+        double rv = rn;
+        const long long tl = top - kb - p;
+        rn = (tl - 16 >= g.s0) ? r[tl - 16] : 0.0;
+        const bool mine = tl >= g.s0 && tl < g.s1;
+        double yv = mine ? y[tl] : 0.0;
+        bwd_block4(rv, yv, zlo, zhi, pA, pB, kA, kB, yA, yB, top - kb, g, obsB, is_obs, mean, Seq16{});
+        if (mine) {
+            const long long jt = T - 1 - tl;
+            const double q = jt < n1 ? qtab[jt] : qinf;
+            var[tl] = vbase - q + (rnew_per_step ? Rnew[tl] : Rnew[0]);
+        }
+    }
+    if (g.valid && chunk == 0) {      // lam at the head's end: the head's backward pass runs on the host
+        if (p < d) lam_out[p] = zlo;
+        if (16 + p < d) lam_out[16 + p] = zhi;
+    }
+}
+
 // ---- host: small dense linear algebra, row-major ---------------------------------------------------------------------------------------
 void matmul(int d, const double* X, const double* Y, double* Z) {      // Z = X Y
     for (int i = 0; i < d; ++i) {
@@ -208,6 +385,15 @@ struct Engine {
     const char* kname = "k_wide_lml<32>";
 };
 
+namespace {
+bool dpp_enabled() {      // TGP_WIDE_DPP=0: the LDS kernels for every d (A/B runs)
+    static const bool on = [] {
+        const char* sv = std::getenv("TGP_WIDE_DPP");
+        return !(sv && sv[0] == '0');
+    }();
+    return on;
+}
+}  // namespace
 Engine* create() { return new Engine(); }
 void destroy(Engine* e) {
     if (!e) return;
@@ -287,7 +473,7 @@ bool plan(Engine* e, const ModelHost& m, long long T) {
     const size_t dd = (size_t)d * d;
     e->d = d;
     e->dp = d <= 31 ? 32 : 64;
-    e->kname = e->dp == 32 ? "k_wide_lml<32>" : "k_wide_lml<64>";
+    e->kname = e->dp == 32 ? (dpp_enabled() ? "k_wide_lml4" : "k_wide_lml<32>") : "k_wide_lml<64>";
     e->A.assign(dd, 0.0);
     std::vector<double> Q(dd), P(dd), AP(dd), Pp(dd), Pf(dd), v(d);
     for (int i = 0; i < d; ++i)
@@ -606,7 +792,13 @@ int run(Engine* e, hipStream_t stream, const Call& c, double* lml_out, std::stri
     }
     const long long chunks = e->info.chunks;
     double* rout = post ? e->rbuf : nullptr;
-    if (DP == 32)
+    const bool four = DP == 32 && dpp_enabled();
+    const unsigned grid4 = (unsigned)((chunks + 3) / 4);
+    if (four && post)
+        hipLaunchKernelGGL(k_wide_lml4<true>, dim3(grid4), dim3(64), 0, stream, tab_f, c.y, e->hh, T, (long long)n0, e->info.chunk_len, (long long)e->info.halo, chunks, d, z0, part, rout);
+    else if (four)
+        hipLaunchKernelGGL(k_wide_lml4<false>, dim3(grid4), dim3(64), 0, stream, tab_f, c.y, e->hh, T, (long long)n0, e->info.chunk_len, (long long)e->info.halo, chunks, d, z0, part, rout);
+    else if (DP == 32)
         hipLaunchKernelGGL(k_wide_lml<32>, dim3((unsigned)chunks), dim3(64), 0, stream, tab_f, c.y, e->hh, T, (long long)n0, e->info.chunk_len, (long long)e->info.halo, d, z0, part,
                            rout);
     else
@@ -615,7 +807,10 @@ int run(Engine* e, hipStream_t stream, const Call& c, double* lml_out, std::stri
     rc = hipGetLastError();
     if (rc != hipSuccess) return fail(rc, "launch");
     if (post) {
-        if (DP == 32)
+        if (four)
+            hipLaunchKernelGGL(k_wide_bwd4, dim3(grid4), dim3(64), 0, stream, tab_b, c.y, e->rbuf, c.Rnew, c.rnew_per_step, qtab_d, (long long)e->info.n1, e->vbase, e->qinf, T,
+                               (long long)n0, e->info.chunk_len, (long long)e->info.halo_back, chunks, d, c.mean, c.var, lam);
+        else if (DP == 32)
             hipLaunchKernelGGL(k_wide_bwd<32>, dim3((unsigned)chunks), dim3(64), 0, stream, tab_b, c.y, e->rbuf, c.Rnew, c.rnew_per_step, qtab_d, (long long)e->info.n1, e->vbase,
                                e->qinf, T, (long long)n0, e->info.chunk_len, (long long)e->info.halo_back, d, d, c.mean, c.var, lam);
         else
