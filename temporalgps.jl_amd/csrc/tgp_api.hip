@@ -30,107 +30,7 @@
 #include <map>
 #include <unordered_map>
 
-// ---- tgp_alloc.hpp: the caching allocator ------------------------------------------------------------------------------------------------
-namespace tgp_alloc {
-namespace {
-constexpr size_t kCacheMax = size_t(4) << 20;      // blocks beyond 4 MiB are not parked
-constexpr size_t kParkedPerClass = 64;
-constexpr size_t kParkedBytesMax = size_t(128) << 20;      // per kind of memory (device / pinned host), over all devices: beyond it a freed block goes to the runtime
-struct Block {
-    size_t cls;         // size class (bytes actually allocated); 0: not cacheable
-    int device;
-    unsigned kind;      // 0 device, 1 + flags: pinned host with those flags
-};
-struct Key {
-    int device;
-    unsigned kind;
-    size_t cls;
-    bool operator<(const Key& o) const { return device != o.device ? device < o.device : (kind != o.kind ? kind < o.kind : cls < o.cls); }
-};
-std::mutex g_mu;
-std::unordered_map<void*, Block> g_live;
-std::map<Key, std::vector<void*>> g_parked;
-long long g_reused = 0, g_fresh = 0;
-size_t g_parked_bytes[2] = {0, 0};
-bool enabled() {
-    static const bool on = [] { const char* v = std::getenv("TGP_ALLOC_CACHE"); return !(v && v[0] == '0'); }();
-    return on;
-}
-size_t size_class(size_t bytes) {
-    if (!enabled() || bytes > kCacheMax) return 0;
-    size_t c = 256;
-    while (c < bytes) c <<= 1;
-    return c;
-}
-hipError_t get(void** p, size_t bytes, unsigned kind) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    const size_t cls = size_class(bytes);
-    if (cls) {
-        std::lock_guard<std::mutex> lk(g_mu);
-        auto it = g_parked.find(Key{dev, kind, cls});
-        if (it != g_parked.end() && !it->second.empty()) {
-            *p = it->second.back();
-            it->second.pop_back();
-            g_parked_bytes[kind != 0] -= cls;
-            g_live[*p] = Block{cls, dev, kind};
-            ++g_reused;
-            return hipSuccess;
-        }
-    }
-    const size_t n = cls ? cls : bytes;
-    const hipError_t e = kind == 0 ? hipMalloc(p, n) : hipHostMalloc(p, n, kind - 1);
-    if (e != hipSuccess) return e;
-    std::lock_guard<std::mutex> lk(g_mu);
-    g_live[*p] = Block{cls, dev, kind};
-    ++g_fresh;
-    return hipSuccess;
-}
-hipError_t put(void* p) {
-    if (!p) return hipSuccess;
-    Block b{0, 0, 0};
-    bool known = false;
-    {
-        std::lock_guard<std::mutex> lk(g_mu);
-        auto it = g_live.find(p);
-        if (it != g_live.end()) {
-            b = it->second;
-            known = true;
-            g_live.erase(it);
-            if (b.cls) {
-                auto& v = g_parked[Key{b.device, b.kind, b.cls}];
-                if (v.size() < kParkedPerClass && g_parked_bytes[b.kind != 0] + b.cls <= kParkedBytesMax) {
-                    v.push_back(p);
-                    g_parked_bytes[b.kind != 0] += b.cls;
-                    return hipSuccess;
-                }
-            }
-        }
-    }
-    (void)known;
-    return b.kind == 0 ? hipFree(p) : hipHostFree(p);
-}
-}  // namespace
-hipError_t dev_malloc(void** p, size_t bytes) { return get(p, bytes, 0); }
-hipError_t dev_free(void* p) { return put(p); }
-hipError_t host_malloc(void** p, size_t bytes, unsigned flags) { return get(p, bytes, 1 + flags); }
-hipError_t host_free(void* p) { return put(p); }
-void trim() {
-    std::map<Key, std::vector<void*>> parked;
-    {
-        std::lock_guard<std::mutex> lk(g_mu);
-        parked.swap(g_parked);
-        g_parked_bytes[0] = g_parked_bytes[1] = 0;
-    }
-    for (auto& kv : parked)
-        for (void* q : kv.second) (void)(kv.first.kind == 0 ? hipFree(q) : hipHostFree(q));
-}
-void stats(long long* reused, long long* fresh) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    if (reused) *reused = g_reused;
-    if (fresh) *fresh = g_fresh;
-}
-}  // namespace tgp_alloc
+#include "tgp_api_alloc.inc"      // the caching allocator (tgp_alloc.hpp)
 
 namespace tgp {
 const KernelTable *kernel_table_d1(), *kernel_table_d2(), *kernel_table_d3(), *kernel_table_d4(), *kernel_table_d5(),
@@ -1219,307 +1119,7 @@ int forward_apply(tgp_handle* h, int mode, const FilterOut& fo, const double* x0
 
 int* flag_ptr(tgp_handle* h) { return reinterpret_cast<int*>(h->result.d() + 4); }
 
-// ---- stationary-gain scan engine (tgp_steady.hip) ------------------------------------------------------------------------------------
-bool steady2_eligible(const tgp_handle* h, const uint8_t* missing, uint32_t flags) {
-    // (an explicit TGP_OPT_CHUNK asks for the chunked-scan engine: the chunk length means nothing here)
-    return h->opt_steady2 && h->steady2_state >= 0 && !h->is_dense && !h->sde && h->lti && h->p == 1 && h->mv.sR == 0 && h->ordering == 0 &&
-           missing == nullptr && !(flags & TGP_REUSE_REDUCE) && tgp_steady::supports(h->d) && h->mv.T == h->T && h->opt_chunk == 0;
-}
-void steady2_begin(void* ctx, const char* name) {
-    tgp_handle* h = static_cast<tgp_handle*>(ctx);
-    h->steady2_scope = new LaunchScope(h, name);
-}
-void steady2_end(void* ctx) {
-    tgp_handle* h = static_cast<tgp_handle*>(ctx);
-    delete static_cast<LaunchScope*>(h->steady2_scope);
-    h->steady2_scope = nullptr;
-}
-// Enqueues the call on the engine (y already staged in h->mv.y). mean_dev == nullptr: logpdf only.
-int steady2_enqueue(tgp_handle* h, const double* Rnew_dev, bool rnew_per_step, double* mean_dev, double* var_dev, bool grad = false,
-                    const tgp_steady::ShardDev* shard = nullptr, int phase = 0) {
-    if (!h->steady2) h->steady2 = tgp_steady::create();
-    tgp_steady::ModelDev md;
-    md.d = h->d;
-    md.A = h->mv.A; md.a = h->mv.a; md.Q = h->mv.Q; md.H = h->mv.H; md.hh = h->mv.h; md.R = h->mv.R;
-    md.x0 = h->bx0.d();
-    tgp_steady::CallDev cd;
-    cd.T = h->T;
-    cd.y = h->mv.y;
-    cd.Rnew = Rnew_dev;
-    cd.rnew_per_step = rnew_per_step ? 1 : 0;
-    cd.mean = mean_dev;
-    cd.var = var_dev;
-    cd.result = h->result.d();
-    cd.grad = grad;
-    tgp_steady::Hooks hk;
-    if (h->profile) {
-        hk.ctx = h;
-        hk.begin = steady2_begin;
-        hk.end = steady2_end;
-    }
-    std::string err;
-    if (shard) {
-        if (tgp_steady::enqueue_shard(h->steady2, h->stream, md, cd, *shard, phase, hk, &err) != 0) return h->fail(TGP_EHIP, err);
-        return TGP_OK;
-    }
-    if (tgp_steady::enqueue(h->steady2, h->stream, md, cd, hk, &err) != 0) return h->fail(TGP_EHIP, err);
-    return TGP_OK;
-}
-// After CallTimer::finish: did the engine serve the call? (host_result[6]; 2 = it found on the device that it does not apply)
-// ---- the one-launch form (tgp_modal.hip). Returns TGP_OK with *served = true when it ran the call (lml in *lml_out, outputs written);
-// *served = false: it does not apply to this model / series -- nothing was enqueued.
-// Behind a successful tgp_modal::enqueue with a deferred tables half the kernel waits for flags in pinned memory that only complete() raises:
-// an exit in between (today there is none; any future one) must raise them with the failure bit.
-struct ModalFlagGuard {
-    tgp_modal::Engine* e;
-    ~ModalFlagGuard() { tgp_modal::abandon(e); }
-};
-int modal_call(tgp_handle* h, const double* y, uint32_t flags, const double* Rnew, double* mean_out, double* var_out, double* lml_out, bool* served) {
-    *served = false;
-    h->modal_last = false;
-    h->dense_last_n0 = -1;
-    if (!h->opt_modal || h->modal_state < 0 || h->hostm.empty()) return TGP_OK;
-    if (!h->modal) h->modal = tgp_modal::create();
-    static const bool dbg = getenv("TGP_STEADY_DEBUG") != nullptr;
-    const auto tp0 = std::chrono::steady_clock::now();
-    const int d = h->d;
-    const size_t dd = (size_t)d * d;
-    const double* q = h->hostm.data();
-    tgp_plan::ModelHost mh;
-    mh.d = d;
-    mh.A = q; mh.a = q + dd; mh.Q = q + dd + d; mh.H = q + 2 * dd + d; mh.hh = q + 2 * dd + 2 * d; mh.R = h->has_R_over ? &h->R_over : q + 2 * dd + 2 * d + 1;
-    mh.x0m = h->x0m.data();
-    mh.x0P = h->x0P.data();
-    tgp_modal::set_stream_min_T(h->modal, h->opt_stream_min_T);
-    if (!tgp_modal::plan(h->modal, mh, h->T, /*logpdf_only=*/mean_out == nullptr && var_out == nullptr)) {
-        h->modal_state = -1;
-        if (getenv("TGP_STEADY_DEBUG") != nullptr) {
-            const tgp_plan::Info& in = tgp_modal::last_plan(h->modal);
-            fprintf(stderr, "[tgp modal] does not apply: why %d, n0 %d n1 %d halo %d cond %.3g / %.3g rho %.6f resid %.3g\n", in.why, in.n0, in.n1, in.halo, in.cond_f, in.cond_g, in.rho, in.resid);
-        }
-        return TGP_OK;
-    }
-    const auto tp1 = std::chrono::steady_clock::now();
-    const bool idev = (flags & TGP_IN_DEVICE) != 0, odev = (flags & TGP_OUT_DEVICE) != 0;
-    const bool rshared = (flags & TGP_SHARED_R) != 0;
-    const size_t nT = (size_t)h->T * sizeof(double);
-    CallTimer tm(h, /*clear=*/false);
-    const void* pR = nullptr;
-    if (mean_out) TRY(stage_in(h, h->bRnew, Rnew, rshared ? sizeof(double) : nT, idev, &pR));
-    TRY(set_obs(h, y, nullptr, flags));
-    tm.inputs_done();
-    double *dm = nullptr, *dv = nullptr;
-    TRY(stage_out(h, h->bo1, mean_out, nT, odev, &dm));
-    TRY(stage_out(h, h->bo2, var_out, nT, odev, &dv));
-    tgp_modal::Call c;
-    c.T = h->T;
-    c.y = h->mv.y;
-    c.Rnew = static_cast<const double*>(pR);
-    c.rnew_per_step = (mean_out && !rshared) ? 1 : 0;
-    c.mean = dm;
-    c.var = dv;
-    {
-        std::string err;
-        const char* kname = tgp_modal::kernel_name(h->modal, c);
-        LaunchScope ls(h, kname);
-        if (tgp_modal::enqueue(h->modal, h->stream, c, &kname, &err) != 0) return h->fail(TGP_EHIP, err);
-    }
-    const auto tp2 = std::chrono::steady_clock::now();
-    ModalFlagGuard flag_guard{h->modal};      // (whatever path leaves this function from here on: the kernel is never left waiting for its tables)
-    const bool tables_ok = tgp_modal::complete(h->modal, h->T);      // (the tables half of the plan, beside the kernel)
-    const auto tp3 = std::chrono::steady_clock::now();
-    tm.kernels_done();
-    TRY(copy_back(h, mean_out, dm, nT, odev));
-    TRY(copy_back(h, var_out, dv, nT, odev));
-    if (h->timing) (void)hipEventRecord(h->ev[3], h->stream);
-    // (a logpdf-only call on the streaming kernel with the end-of-kernel flag: nothing but the triples in pinned memory to wait for)
-    if (h->timing || h->profile || !tgp_modal::await_done(h->modal)) HIPCHK(hipStreamSynchronize(h->stream));
-    if (dbg) {
-        const auto tp4 = std::chrono::steady_clock::now();
-        auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
-        fprintf(stderr, "[tgp modal host] plan core %.1f us, staging + launch %.1f, tables + copies %.1f, wait %.1f\n", us(tp0, tp1), us(tp1, tp2), us(tp2, tp3), us(tp3, tp4));
-    }
-    if (h->timing) {
-        float t0 = 0.f, t1 = 0.f, t2 = 0.f;
-        (void)hipEventElapsedTime(&t0, h->ev[0], h->ev[1]);
-        (void)hipEventElapsedTime(&t1, h->ev[1], h->ev[2]);
-        (void)hipEventElapsedTime(&t2, h->ev[2], h->ev[3]);
-        h->h2d_ms = t0;
-        h->kernel_ms = t1;
-        h->d2h_ms = t2;
-    }
-    resolve_profile(h);
-    if (!tables_ok) {      // declined behind the launch (a head step not positive definite, a smoother transient beyond the table): the older engines serve the call
-        h->modal_state = -1;
-        return TGP_OK;
-    }
-    const double lml = tgp_modal::finish(h->modal, h->T);
-    for (int i = 0; i < 8; ++i) h->host_result[i] = 0.0;
-    h->host_result[0] = lml;
-    h->host_result[6] = tgp_steady::kStatusRan;
-    h->host_result[7] = (double)tgp_modal::last_plan(h->modal).n0;
-    if (lml_out) *lml_out = lml;
-    h->modal_state = 1;
-    h->modal_last = true;
-    h->steady2_last = false;
-    h->reduce_valid = false;
-    h->smoother_valid = false;
-    *served = true;
-    return TGP_OK;
-}
-
-// An explicit TGP_OPT_CHUNK or TGP_OPT_VARIANT asks for the chunked-scan engine's kernels (tests and A/B runs compare them with the one-launch
-// paths): every one-launch fast path steps aside, as steady2_eligible always did (round-4 advice).
-bool chunk_engine_requested(const tgp_handle* h) { return h->opt_chunk != 0 || h->variant_opt != 0; }
-
-// ---- the sweep engine (tgp_sweep.hip): time-varying gains -------------------------------------------------------------------
-// Forward models with scalar observations, d <= 4, whose transitions are one shared block (A, a, Q) or closed-form SDE transitions from the
-// time stamps, H shared; the noise variance and the emission offset may be per step, steps may be missing.  The stationary-gain engines
-// take what they can serve first (every block shared, one noise variance, nothing missing).
-bool sweep_eligible(const tgp_handle* h, uint32_t flags) {
-    if (!h->opt_sweep || h->sweep_state < 0 || h->is_dense || h->p != 1 || h->ordering != 0 || h->d > tgp_sweep::kMaxD) return false;
-    // (explicit requests for the chunked-scan engine: a chunk length, a kernel variant, TGP_OPT_STEADY = 0 / 1, hipGraph replay of its launch chain)
-    if ((flags & TGP_REUSE_REDUCE) || h->opt_chunk != 0 || h->variant_opt != 0 || !h->opt_steady2 || h->opt_graph != 0) return false;
-    if (h->T < tgp_sweep::kMinT || h->mv.T != h->T || h->mv.sH != 0 || h->sweepm.empty()) return false;
-    if (h->sde) return h->sde_closed && h->opt_sde_closed && !h->sde_coef_host.empty() && h->mv.sa == 0;
-    return h->mv.sA == 0 && h->mv.sa == 0 && h->mv.sQ == 0;
-}
-// Runs the call on the engine.  *served = false: it declined (nothing the caller must undo); the caller goes on to the general engine.
-int sweep_call(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t flags, const double* Rnew, double* mean_out, double* var_out,
-               double* lml_out, bool* served) {
-    *served = false;
-    h->sweep_last = false;
-    if (!h->sweep) h->sweep = tgp_sweep::create();
-    static const bool dbg = getenv("TGP_STEADY_DEBUG") != nullptr;
-    const int d = h->d;
-    const size_t dd = (size_t)d * d;
-    const double* q = h->sweepm.data();
-    tgp_sweep::ModelHost mh;
-    mh.d = d;
-    mh.sde = h->sde;
-    mh.A = h->sde ? h->sde_A1Q1_host.data() : q;
-    mh.a = q + dd;
-    mh.Q = h->sde ? h->sde_A1Q1_host.data() + dd : q + dd + d;
-    mh.H = q + 2 * dd + d;
-    mh.hh = q[2 * dd + 2 * d];
-    mh.R = h->sweep_Rrep;
-    mh.x0m = h->x0m.data();
-    mh.x0P = h->x0P.data();
-    mh.coef = h->sde ? h->sde_coef_host.data() : nullptr;
-    mh.tau_typ = h->sweep_tau;
-    const bool idev = (flags & TGP_IN_DEVICE) != 0, odev = (flags & TGP_OUT_DEVICE) != 0;
-    const bool rshared = (flags & TGP_SHARED_R) != 0;
-    const size_t nT = (size_t)h->T * sizeof(double);
-    int W = h->sweep_W, Wb = h->sweep_Wb;
-    for (int64_t& v : h->sweep_info) v = 0;
-    // inputs and outputs are staged ONCE, in front of the attempts (round-5 advice: a host-resident series was uploaded again by every retry)
-    {
-        std::string why;
-        tgp_sweep::force_geometry(h->sweep, h->sweep_fC, h->sweep_fW, h->sweep_fWb);
-        if (!tgp_sweep::plan(h->sweep, mh, h->T, W, Wb, h->num_cu, &why)) {
-            if (dbg) fprintf(stderr, "[tgp sweep] does not apply: %s\n", why.c_str());
-            h->sweep_state = -1;
-            return TGP_OK;
-        }
-    }
-    CallTimer tm(h, /*clear=*/false);
-    const void* pR = nullptr;
-    if (mean_out) TRY(stage_in(h, h->bRnew, Rnew, rshared ? sizeof(double) : nT, idev, &pR));
-    TRY(set_obs(h, y, missing, flags));
-    tm.inputs_done();
-    double *dm = nullptr, *dv = nullptr;
-    TRY(stage_out(h, h->bo1, mean_out, nT, odev, &dm));
-    TRY(stage_out(h, h->bo2, var_out, nT, odev, &dv));
-    for (int attempt = 0; attempt < 4; ++attempt) {
-        if (attempt > 0) {
-            std::string why;
-            tgp_sweep::force_geometry(h->sweep, h->sweep_fC, h->sweep_fW, h->sweep_fWb);
-            if (!tgp_sweep::plan(h->sweep, mh, h->T, W, Wb, h->num_cu, &why)) {
-                if (dbg) fprintf(stderr, "[tgp sweep] does not apply: %s\n", why.c_str());
-                h->sweep_state = -1;
-                return TGP_OK;
-            }
-        }
-        tgp_sweep::Call c;
-        c.T = h->T;
-        c.y = h->mv.y;
-        c.mask = h->mv.missing;
-        c.R = h->mv.sR != 0 ? h->mv.R : nullptr;
-        c.hh = h->mv.sh != 0 ? h->mv.h : nullptr;
-        c.tau = h->sde ? h->btau.d() : nullptr;
-        c.Rnew = static_cast<const double*>(pR);
-        c.rnew_per_step = (mean_out && !rshared) ? 1 : 0;
-        c.mean = dm;
-        c.var = dv;
-        {
-            std::string err;
-            const char* kname = tgp_sweep::kernel_name(d, h->sde, dm != nullptr);
-            LaunchScope ls(h, kname);
-            if (tgp_sweep::enqueue(h->sweep, h->stream, c, &kname, &err) != 0) return h->fail(TGP_EHIP, err);
-        }
-        tm.kernels_done();
-        if (h->timing) (void)hipEventRecord(h->ev[3], h->stream);
-        HIPCHK(hipStreamSynchronize(h->stream));
-        resolve_profile(h);
-        int status = 0, w = 0, wb = 0;
-        const double lml = tgp_sweep::finish(h->sweep, &status, &w, &wb, &h->sweep_dist[0], &h->sweep_dist[1]);
-        int C = 0;
-        int64_t nw = 0;
-        tgp_sweep::geometry(h->sweep, &C, nullptr, nullptr, &nw);
-        h->sweep_info[1] = C; h->sweep_info[2] = w; h->sweep_info[3] = wb; h->sweep_info[4] = nw; h->sweep_info[5] = attempt + 1; h->sweep_info[6] = status;
-        if (dbg) fprintf(stderr, "[tgp sweep] attempt %d: C %d W %d Wb %d waves %lld status %d dist %.3g / %.3g\n", attempt, C, w, wb, (long long)nw, status, h->sweep_dist[0], h->sweep_dist[1]);
-        if (status & 12) {      // not positive definite / non-finite values: the general engine reports it the way it always has
-            if (status & 4) h->sweep_state = -1;      // (a property of the model, not of this series: later calls do not pay for a launch that cannot serve them)
-            return TGP_OK;
-        }
-        if (status & 3) {       // a warm-up was too short: longer ones (a forced geometry is a test's: report, do not repair)
-            if (h->sweep_fW || h->sweep_fWb || h->sweep_fC) return TGP_OK;
-            if (status & 1) W = 2 * w;
-            if (status & 2) Wb = 2 * wb;
-            continue;
-        }
-        TRY(copy_back(h, mean_out, dm, nT, odev));
-        TRY(copy_back(h, var_out, dv, nT, odev));
-        if ((mean_out && !odev)) HIPCHK(hipStreamSynchronize(h->stream));
-        if (h->timing) {
-            float t0 = 0.f, t1 = 0.f, t2 = 0.f;
-            (void)hipEventElapsedTime(&t0, h->ev[0], h->ev[1]);
-            (void)hipEventElapsedTime(&t1, h->ev[1], h->ev[2]);
-            (void)hipEventElapsedTime(&t2, h->ev[2], h->ev[3]);
-            h->h2d_ms = t0;
-            h->kernel_ms = t1;
-            h->d2h_ms = t2;
-        }
-        for (int i = 0; i < 8; ++i) h->host_result[i] = 0.0;
-        h->host_result[0] = lml;
-        if (lml_out) *lml_out = lml;
-        h->sweep_W = w;
-        h->sweep_Wb = wb;
-        h->sweep_state = 1;
-        h->sweep_last = true;
-        h->sweep_info[0] = 1;
-        h->steady2_last = false;
-        h->modal_last = false;
-        h->reduce_valid = false;
-        h->smoother_valid = false;
-        *served = true;
-        return TGP_OK;
-    }
-    h->sweep_state = -1;      // four attempts, warm-ups still too short: a model that mixes too slowly for this engine
-    return TGP_OK;
-}
-
-bool steady2_served(tgp_handle* h) {
-    const bool ran = h->host_result[6] == tgp_steady::kStatusRan;
-    h->steady2_state = ran ? 1 : -1;
-    h->steady2_last = ran;
-    if (ran) {
-        h->reduce_valid = false;        // (the general path's pass-1 elements belong to an earlier call's observations)
-        h->smoother_valid = false;
-    }
-    return ran;
-}
-
+#include "tgp_api_engines.inc"      // how a call reaches the stationary-gain scan engine (tgp_steady.hip), the one-launch form (tgp_modal.hip) and the sweep engine (tgp_sweep.hip)
 }  // namespace
 
 // ------------------------------------------------------------------------------------------ run-time variant check
@@ -2280,194 +1880,7 @@ int tgp_model_set_x0(tgp_handle* h, const double* x0m, const double* x0P) {
     return upload_x0(h, h->bx0, x0m, x0P);
 }
 
-static int filter_lti_call(tgp_handle* h, const double* y, uint32_t flags, double* m_out, double* P_out, double* lml_out, bool* served);
-struct SmoothRand {      // a draw from the posterior instead of its marginals: eps_t [T][d], eps_e [T] (where TGP_IN_DEVICE says), eps_0 [d] (host)
-    const double *eps_t, *eps_e, *eps_0;
-};
-static int smooth_lti_call(tgp_handle* h, const double* y, uint32_t flags, const double* Rnew, double* mean_out, double* var_out, double* lml_out, bool* served,
-                           const SmoothRand* rnd = nullptr);
-static bool lti_but_offset(const tgp_handle* h);
-
-// ---- Reverse-ordered LTI priors (lgssm.jl:87-91, 111-115, 161-165): with every block shared and x0 stationary, the Reverse model on y IS the
-// Forward model on the flipped series (oracle identity: tests/test_oracle_identities.py) -- one flip pass in front of the one-launch kernels (and one behind them for
-// outputs of size T) instead of the general chunked scan.
-namespace {
-__global__ __launch_bounds__(256) void k_flip_rows(const double* __restrict__ in, double* __restrict__ out, long long T, int w) {
-    const long long n = T * w;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const long long t = i / w, c = i - t * w;
-        out[i] = in[(T - 1 - t) * w + c];
-    }
-}
-void launch_flip(tgp_handle* h, const double* in, double* out, long long T, int w) {
-    const long long n = T * w;
-    const unsigned nb = (unsigned)std::min<long long>((n + 255) / 256, 8192);
-    LaunchScope ls(h, "k_flip_rows");
-    hipLaunchKernelGGL(k_flip_rows, dim3(nb), dim3(256), 0, h->stream, in, out, T, w);
-}
-struct AsForward {      // the handle as its Forward twin for the length of a call
-    tgp_handle* h;
-    int o, mo;
-    explicit AsForward(tgp_handle* h_) : h(h_), o(h_->ordering), mo(h_->mv.ordering) {
-        h->ordering = 0;
-        h->mv.ordering = 0;
-    }
-    ~AsForward() {
-        h->ordering = o;
-        h->mv.ordering = mo;
-    }
-};
-// x0 = its own one-step prediction (A x0.m + a = x0.m, A x0.P A' + Q = x0.P to rounding): what to_sde's models have (x0 = the stationary distribution).
-// A Reverse-ordered model updates with y_T BEFORE its first prediction, the Forward one predicts first: the two agree on flipped series only then.
-bool x0_is_stationary(const tgp_handle* h) {
-    const int d = h->d;
-    const size_t dd = (size_t)d * d;
-    if (h->hostm.size() < 2 * dd + d || h->x0m.size() != (size_t)d || h->x0P.size() != dd) return false;
-    const double *A = h->hostm.data(), *a = A + dd, *Q = a + d;      // column-major blocks
-    const double *m = h->x0m.data(), *P = h->x0P.data();
-    double mmax = 0.0, pmax = 0.0;
-    for (int i = 0; i < d; ++i) mmax = std::max(mmax, std::fabs(m[i]));
-    for (size_t i = 0; i < dd; ++i) pmax = std::max(pmax, std::fabs(P[i]));
-    std::vector<double> AP(dd, 0.0);
-    for (int i = 0; i < d; ++i) {
-        double v = a[i];
-        for (int k = 0; k < d; ++k) v += A[i + (size_t)k * d] * m[k];
-        if (!(std::fabs(v - m[i]) <= 1e-13 * (1.0 + mmax))) return false;
-        for (int j = 0; j < d; ++j) {
-            double w = 0.0;
-            for (int k = 0; k < d; ++k) w += A[i + (size_t)k * d] * 0.5 * (P[k + (size_t)j * d] + P[j + (size_t)k * d]);
-            AP[i + (size_t)j * d] = w;
-        }
-    }
-    for (int i = 0; i < d; ++i)
-        for (int j = 0; j < d; ++j) {
-            double v = 0.5 * (Q[i + (size_t)j * d] + Q[j + (size_t)i * d]);
-            for (int k = 0; k < d; ++k) v += AP[i + (size_t)k * d] * A[j + (size_t)k * d];
-            if (!(std::fabs(v - 0.5 * (P[i + (size_t)j * d] + P[j + (size_t)i * d])) <= 1e-13 * pmax)) return false;
-        }
-    return true;
-}
-bool reverse_by_flip(const tgp_handle* h, const double* y, const uint8_t* missing, uint32_t flags) {
-    static const bool on = [] {      // TGP_REVERSE_FLIP=0: Reverse-ordered models on the general engine as before (A/B runs)
-        const char* s = std::getenv("TGP_REVERSE_FLIP");
-        return !(s && s[0] == '0');
-    }();
-    return on && h->ordering == 1 && h->opt_modal && h->opt_steady2 && !h->is_dense && !h->sde && h->lti && h->p == 1 && h->mv.sR == 0 && missing == nullptr &&
-           y != nullptr && !(flags & TGP_REUSE_REDUCE) && !chunk_engine_requested(h) && h->opt_chunk == 0 && !h->hostm.empty() && h->mv.T == h->T &&
-           x0_is_stationary(h);
-}
-// the flipped series where the input lives: *yf, *ff (flags for the forward call)
-int flip_series(tgp_handle* h, const double* y, uint32_t flags, const double** yf, uint32_t* ff) {
-    *ff = flags;
-    if (flags & TGP_IN_DEVICE) {
-        HIPCHK(h->bflip_y.ensure((size_t)h->T * sizeof(double)));
-        launch_flip(h, y, h->bflip_y.d(), h->T, 1);
-        *yf = h->bflip_y.d();
-    } else {
-        h->flip_host.resize((size_t)h->T);
-        std::reverse_copy(y, y + h->T, h->flip_host.begin());
-        *yf = h->flip_host.data();
-    }
-    return TGP_OK;
-}
-}  // namespace
-
-// ---- wide LTI models (16 < d <= 63; tgp_wide.hip): logpdf across the chip on the stationary closed loop.  *served = false: the engine declined
-// (nothing the caller must undo) -- the dense engine's passes serve the call.
-static int wide_call(tgp_handle* h, const double* y, uint32_t flags, const double* Rnew, double* mean_out, double* var_out, double* out, bool* served) {
-    *served = false;
-    static const bool env_on = [] {
-        const char* s = std::getenv("TGP_WIDE");
-        return !(s && s[0] == '0');
-    }();
-    if (!env_on || !h->opt_wide || h->wide_state < 0 || h->widem.empty() || y == nullptr || h->ordering != 0 || (flags & TGP_REUSE_REDUCE)) return TGP_OK;
-    const bool post = mean_out != nullptr;
-    if (post && h->wide_post_state < 0) return TGP_OK;
-    if (!h->wide) h->wide = tgp_wide::create();
-    const int d = h->d;
-    const size_t dd = (size_t)d * d;
-    const double* q = h->widem.data();
-    tgp_wide::ModelHost mh;
-    mh.d = d;
-    mh.A = q; mh.a = q + dd; mh.Q = q + dd + d; mh.H = q + 2 * dd + d; mh.hh = q[2 * dd + 2 * d]; mh.R = q[2 * dd + 2 * d + 1];
-    mh.x0m = h->x0m.data();
-    mh.x0P = h->x0P.data();
-    const bool dbg = getenv("TGP_STEADY_DEBUG") != nullptr;
-    if (!tgp_wide::plan(h->wide, mh, h->T)) {
-        h->wide_state = -1;
-        if (dbg) {
-            const tgp_wide::Info& in = tgp_wide::last_plan(h->wide);
-            fprintf(stderr, "[tgp wide] does not apply: why %d, n0 %d halo %d\n", in.why, in.n0, in.halo);
-        }
-        return TGP_OK;
-    }
-    if (post && !tgp_wide::plan_posterior(h->wide, h->T)) {
-        h->wide_post_state = -1;
-        if (dbg) {
-            const tgp_wide::Info& in = tgp_wide::last_plan(h->wide);
-            fprintf(stderr, "[tgp wide] posterior does not apply: why %d, n1 %d halo_back %d\n", in.why_post, in.n1, in.halo_back);
-        }
-        return TGP_OK;
-    }
-    const bool idev = (flags & TGP_IN_DEVICE) != 0, odev = (flags & TGP_OUT_DEVICE) != 0, rshared = (flags & TGP_SHARED_R) != 0;
-    const size_t nT = (size_t)h->T * sizeof(double);
-    CallTimer tm(h, /*clear=*/false);
-    const void* pR = nullptr;
-    if (post) TRY(stage_in(h, h->bRnew, Rnew, rshared ? sizeof(double) : nT, idev, &pR));
-    TRY(set_obs(h, y, nullptr, flags));
-    tm.inputs_done();
-    double *dm = nullptr, *dv = nullptr;
-    TRY(stage_out(h, h->bo1, mean_out, nT, odev, &dm));
-    TRY(stage_out(h, h->bo2, var_out, nT, odev, &dv));
-    tgp_wide::Call c;
-    c.T = h->T;
-    c.y = h->mv.y;
-    c.Rnew = static_cast<const double*>(pR);
-    c.rnew_per_step = (post && !rshared) ? 1 : 0;
-    c.mean = dm;
-    c.var = dv;
-    std::string err;
-    double lml = 0.0;
-    {
-        const std::string both = std::string(tgp_wide::kernel_name(h->wide)) + " + k_wide_bwd";      // (the posterior's two kernels under one bracket: the head's copy sits between)
-        LaunchScope ls(h, post ? both.c_str() : tgp_wide::kernel_name(h->wide));
-        if (tgp_wide::run(h->wide, h->stream, c, &lml, &err) != 0) return h->fail(TGP_EHIP, err);
-    }
-    TRY(copy_back(h, mean_out, dm, nT, odev));
-    TRY(copy_back(h, var_out, dv, nT, odev));
-    if (h->profile || (post && !odev)) HIPCHK(hipStreamSynchronize(h->stream));      // (the bracket's closing event; host outputs)
-    resolve_profile(h);
-    if (dbg) {
-        const tgp_wide::Info& in = tgp_wide::last_plan(h->wide);
-        fprintf(stderr, "[tgp wide] n0 %d halo %d / %d n1 %d chunks %lld x %lld steps, plan %.3f + %.3f ms\n", in.n0, in.halo, in.halo_back, in.n1, in.chunks, in.chunk_len, in.plan_ms,
-                in.plan_post_ms);
-    }
-    for (int i = 0; i < 8; ++i) h->host_result[i] = 0.0;
-    h->host_result[0] = lml;
-    h->host_result[6] = tgp_steady::kStatusRan;
-    h->host_result[7] = (double)tgp_wide::last_plan(h->wide).n0;
-    if (out) *out = lml;
-    h->wide_state = 1;
-    *served = true;
-    return TGP_OK;
-}
-
-// logpdf of a Forward LTI model on the one-launch kernels
-static int logpdf_lti_one_launch(tgp_handle* h, const double* y, uint32_t flags, double* out, bool* served) {
-    *served = false;
-    if (!steady2_eligible(h, nullptr, flags)) return TGP_OK;
-    TRY(modal_call(h, y, flags, nullptr, nullptr, nullptr, out, served));
-    if (*served) return TGP_OK;
-    // no well-conditioned modal form (two summands with one length scale, ...): logpdf is the by-product of the filter's forward
-    // recursion, which needs none -- ONE kernel on the dense powers of the closed loop (d <= 6; k_filter_one without its outputs)
-    if (h->opt_modal && y != nullptr) {
-        TRY(smooth_lti_call(h, y, flags, nullptr, nullptr, nullptr, out, served));      // (k_smooth_one's forward half: one sweep, no outputs)
-        if (*served) return TGP_OK;
-        TRY(filter_lti_call(h, y, flags, nullptr, nullptr, out, served));
-    }
-    return TGP_OK;
-}
-
+#include "tgp_api_lti_front.inc"      // Reverse-ordered LTI priors by flipping the series, wide LTI models (tgp_wide.hip), logpdf of an LTI model on the one-launch kernels
 int tgp_logpdf(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t flags, double* out) {
     StreamGuard stream_guard_(h);
     TRY(check_ready(h, /*general=*/false));
@@ -2575,686 +1988,8 @@ int tgp_logpdf_noise(tgp_handle* h, const double* y, uint32_t flags, double R, d
     return TGP_OK;
 }
 
-// ---- time segments on the one-launch path (one rank of several; tgp_multi.hip and the one-process-per-GPU driver) ----------------------
-// Both mean recursions forget a state within `halo` steps, so a rank needs nothing of its neighbours but their `halo` observations next to
-// the boundary: no exchange of filter elements, no carry between ranks.  The plan is a function of the model blocks and the series' length
-// only -- every rank computes the same one, and the same verdict for every segment.
-static bool modal_host_model(tgp_handle* h, tgp_plan::ModelHost& mh) {
-    if (!h->opt_modal || h->hostm.empty()) return false;
-    const int d = h->d;
-    const size_t dd = (size_t)d * d;
-    const double* q = h->hostm.data();
-    mh.d = d;
-    mh.A = q; mh.a = q + dd; mh.Q = q + dd + d; mh.H = q + 2 * dd + d; mh.hh = q + 2 * dd + 2 * d; mh.R = h->has_R_over ? &h->R_over : q + 2 * dd + 2 * d + 1;
-    mh.x0m = h->x0m.data();
-    mh.x0P = h->x0P.data();
-    return true;
-}
-
-int tgp_segment_plan(tgp_handle* h, int64_t T_total, int nseg, const int64_t* bounds, int32_t* applies, int32_t* halo) {
-    if (!h || !bounds || !applies || !halo || nseg < 1 || T_total <= 0) return TGP_EINVAL;
-    StreamGuard stream_guard_(h);
-    TRY(check_ready(h, /*general=*/false));
-    *applies = 0;
-    *halo = 0;
-    tgp_plan::ModelHost mh;
-    if (!modal_host_model(h, mh) || h->ordering != 0 || h->p != 1 || h->sde) return TGP_OK;
-    if (bounds[0] != 0 || bounds[nseg] != T_total) return h->fail(TGP_EINVAL, "tgp_segment_plan: the segments must tile [0, T)");
-    if (!h->modal) h->modal = tgp_modal::create();
-    if (!tgp_modal::plan(h->modal, mh, T_total)) return TGP_OK;
-    ModalFlagGuard flag_guard{h->modal};
-    (void)tgp_modal::complete(h->modal, T_total);      // (the verdict of the tables half is part of the answer: every rank must give the same one)
-    if (tgp_modal::last_plan(h->modal).why != 0) return TGP_OK;
-    const tgp_plan::Modal& md = tgp_modal::last_modal(h->modal);
-    bool ok = true;
-    for (int r = 0; r < nseg && ok; ++r) {
-        const int64_t lo = bounds[r], hi = bounds[r + 1];
-        ok = hi > lo && lo % 16 == 0 && (hi % 16 == 0 || hi == T_total) && hi - lo >= md.halo;
-        if (r > 0) ok = ok && lo >= (int64_t)md.nhs + md.halo;
-        if (r == 0) ok = ok && hi >= (int64_t)md.nhs + 16;
-        if (r == nseg - 1) ok = ok && hi - lo >= md.n1 + 16;
-    }
-    *applies = ok ? 1 : 0;
-    *halo = md.halo;
-    return TGP_OK;
-}
-
-int tgp_segment_logpdf_and_posterior_marginals(tgp_handle* h, int64_t T_total, int64_t seg_lo, int64_t seg_hi, const double* y_seg, const double* y_left,
-                                               const double* y_right, const double* Rnew, uint32_t flags, double* mean_out, double* var_out,
-                                               double* lml_share) {
-    if (!h || !lml_share) return TGP_EINVAL;
-    StreamGuard stream_guard_(h);
-    TRY(check_ready(h, /*general=*/false));
-    tgp_plan::ModelHost mh;
-    if (!modal_host_model(h, mh)) return h->fail(TGP_EUNSUPPORTED, "tgp_segment_*: not a model of the one-launch path (ask tgp_segment_plan first)");
-    if (h->T != seg_hi - seg_lo || seg_lo < 0 || seg_hi > T_total || !y_seg) return h->fail(TGP_EINVAL, "tgp_segment_*: the bound model has not the segment's length");
-    if ((mean_out != nullptr) != (var_out != nullptr) || (mean_out && !Rnew)) return h->fail(TGP_EINVAL, "tgp_segment_*: mean, var and Rnew go together");
-    if (!h->modal) h->modal = tgp_modal::create();
-    h->modal_last = false;
-    h->dense_last_n0 = -1;
-    h->steady2_last = false;
-    if (!tgp_modal::plan(h->modal, mh, T_total)) return h->fail(TGP_EUNSUPPORTED, "tgp_segment_*: the one-launch path does not apply to this model / series");
-    const tgp_plan::Modal& md = tgp_modal::last_modal(h->modal);
-    if ((seg_lo > 0 && !y_left) || (seg_hi < T_total && !y_right)) return h->fail(TGP_EINVAL, "tgp_segment_*: the neighbours' observations are missing");
-    {   // the per-segment conditions of tgp_segment_plan, again: a direct caller with other bounds gets an error, not wrong numbers (round-4 advice)
-        bool ok = seg_lo % 16 == 0 && (seg_hi % 16 == 0 || seg_hi == T_total) && seg_hi - seg_lo >= md.halo;
-        if (seg_lo > 0) ok = ok && seg_lo >= (int64_t)md.nhs + md.halo;
-        else ok = ok && seg_hi >= (int64_t)md.nhs + 16;
-        if (!ok) return h->fail(TGP_EUNSUPPORTED, "tgp_segment_*: bounds the one-launch path does not serve (multiples of 16, a segment holds the halo, the first one the head: tgp_segment_plan)");
-    }
-    const bool odev = (flags & TGP_OUT_DEVICE) != 0, rshared = (flags & TGP_SHARED_R) != 0;
-    const size_t nT = (size_t)h->T * sizeof(double);
-    CallTimer tm(h, /*clear=*/false);
-    const void* pR = nullptr;
-    if (mean_out) TRY(stage_in(h, h->bRnew, Rnew, rshared ? sizeof(double) : nT, (flags & TGP_IN_DEVICE) != 0, &pR));
-    h->mv.y = y_seg;
-    h->mv.missing = nullptr;
-    tm.inputs_done();
-    double *dm = nullptr, *dv = nullptr;
-    TRY(stage_out(h, h->bo1, mean_out, nT, odev, &dm));
-    TRY(stage_out(h, h->bo2, var_out, nT, odev, &dv));
-    tgp_modal::Call c;
-    c.T = T_total;
-    c.y = y_seg;
-    c.Rnew = static_cast<const double*>(pR);
-    c.rnew_per_step = (mean_out && !rshared) ? 1 : 0;
-    c.mean = dm;
-    c.var = dv;
-    c.seg_lo = seg_lo;
-    c.seg_hi = seg_hi;
-    c.yl = y_left;
-    c.yr = y_right;
-    {
-        std::string err;
-        const char* kname = tgp_modal::kernel_name(h->modal, dm != nullptr);
-        LaunchScope ls(h, kname);
-        if (tgp_modal::enqueue(h->modal, h->stream, c, &kname, &err) != 0) return h->fail(TGP_EHIP, err);
-    }
-    ModalFlagGuard flag_guard{h->modal};
-    const bool tables_ok = tgp_modal::complete(h->modal, T_total);
-    tm.kernels_done();
-    TRY(copy_back(h, mean_out, dm, nT, odev));
-    TRY(copy_back(h, var_out, dv, nT, odev));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    resolve_profile(h);
-    if (!tables_ok) return h->fail(TGP_EUNSUPPORTED, "tgp_segment_*: the plan's tables half declined (tgp_segment_plan would have said so)");
-    double ssq = 0.0, hq = 0.0;
-    tgp_modal::finish_parts(h->modal, &ssq, &hq);
-    double share = -0.5 * (hq + md.iS * ssq);
-    if (seg_lo == 0) share += -0.5 * ((double)T_total * 1.8378770664093454835606594728112 + md.LS + (double)(T_total - md.n0) * md.logS);
-    *lml_share = share;
-    h->modal_last = true;
-    h->reduce_valid = false;
-    h->smoother_valid = false;
-    return TGP_OK;
-}
-
-// Host-only (no GPU needed): the plan the one-launch path of the stationary-gain engine builds inside every call (tgp_steady_plan.hpp).
-int tgp_steady_plan(int d, const double* A, const double* a, const double* Q, const double* H, const double* hh, const double* R, const double* x0m,
-                    const double* x0P, int64_t T, int32_t* info_i, double* info_d, double* modal_out, double* tables_out) {
-    if (d < 1 || d > tgp_plan::kMaxD || !A || !a || !Q || !H || !hh || !R || !x0m || !x0P || T <= 0 || !info_i || !info_d) return TGP_EINVAL;
-    static thread_local tgp_plan::HeadTables tab;
-    tgp_plan::Modal md{};
-    tgp_plan::ModelHost mh;
-    mh.d = d;
-    mh.A = A; mh.a = a; mh.Q = Q; mh.H = H; mh.hh = hh; mh.R = R; mh.x0m = x0m; mh.x0P = x0P;
-    const tgp_plan::Info in = tgp_modal::plan_only(mh, T, md, tab);
-    info_i[0] = in.why; info_i[1] = in.n0; info_i[2] = in.n1; info_i[3] = in.why == 0 ? md.nhs : 0; info_i[4] = in.halo; info_i[5] = in.why == 0 ? md.npair : 0;
-    {
-        int nw = 8, sub = 8;
-        tgp_modal::choose_geometry(d, in.halo, &nw, &sub);
-        info_i[6] = nw;
-        info_i[7] = sub;
-    }
-    info_d[0] = in.cond_f; info_d[1] = in.cond_g; info_d[2] = in.rho; info_d[3] = in.resid;
-    if (in.why != 0) return TGP_OK;
-    if (modal_out) {
-        double* q = modal_out;
-        const double* arrs[17] = {md.fd, md.fo, md.fb, md.fa, md.fw, md.gd, md.go, md.gc, md.gw, md.fp8r, md.fp8i, md.gp8r, md.gp8i, md.fp512r, md.fp512i, md.gp512r, md.gp512i};
-        for (const double* ar : arrs)
-            for (int i = 0; i < tgp_plan::kMaxD; ++i) *q++ = ar[i];
-        for (int j = 0; j < tgp_plan::kSub; ++j)
-            for (int i = 0; i < tgp_plan::kMaxD; ++i) *q++ = md.WJ[j][i];
-        for (int j = 0; j < tgp_plan::kSub; ++j)
-            for (int i = 0; i < tgp_plan::kMaxD; ++i) *q++ = md.WG[j][i];
-        *q++ = md.hh; *q++ = md.rS; *q++ = md.iS; *q++ = md.logS; *q++ = md.LS; *q++ = md.vb;
-    }
-    if (tables_out) {
-        double* q = tables_out;
-        const int n = md.n0 + 1, dd = d * d;
-        for (int i = 0; i < tgp_plan::kMaxD; ++i) *q++ = tab.h[i];
-        for (int i = 0; i < tgp_plan::kMaxD; ++i) *q++ = tab.mu0[i];
-        for (int i = 0; i < tgp_plan::kMaxD * tgp_plan::kMaxD; ++i) *q++ = tab.Wm[i];
-        for (int i = 0; i < n * d; ++i) *q++ = tab.kA[i];
-        for (int i = 0; i < n; ++i) *q++ = tab.iS[i];
-        for (int i = 0; i < n; ++i) *q++ = tab.rS[i];
-        for (int i = 0; i < n * dd; ++i) *q++ = tab.G[i];
-        for (int i = 0; i < n * d; ++i) *q++ = tab.c[i];
-        for (int i = 0; i < n; ++i) *q++ = tab.vb[i];
-        for (int i = 0; i < md.n1; ++i) *q++ = tab.tvb[i];
-    }
-    return TGP_OK;
-}
-
-int tgp_adjoint_record_size(int d) { return (d >= 1 && d <= tgp_steady::kMaxD) ? tgp_adjoint::record_size(d) : 0; }
-
-int tgp_adjoint_finish(int d, const double* rec, const double* y_head, int64_t n_head, double* gA, double* ga, double* gQ, double* gH,
-                       double* ghh, double* gR, double* gx0m, double* gx0P) {
-    if (d < 1 || d > tgp_steady::kMaxD || !rec || !y_head) return TGP_EINVAL;
-    const tgp_adjoint::Out o{gA, ga, gQ, gH, ghh, gR, gx0m, gx0P};
-    return tgp_adjoint::finish(d, rec, y_head, n_head, o) == 0 ? TGP_OK : TGP_EINVAL;
-}
-
-// the pinned host buffer of the head-on-the-host paths (head observations in, head outputs and the workgroups' partial sums out)
-static int ensure_pinned(tgp_handle* h, size_t need) {
-    if (need <= h->flt_cap) return TGP_OK;
-    if (h->flt_host) (void)tgp_alloc::host_free(h->flt_host);
-    h->flt_host = nullptr;
-    h->flt_cap = 0;
-    if (tgp_alloc::host_malloc(reinterpret_cast<void**>(&h->flt_host), need * sizeof(double), hipHostMallocDefault) != hipSuccess) return h->fail(TGP_EHIP, "hipHostMalloc");
-    h->flt_cap = need;
-    return TGP_OK;
-}
-
-// The adjoint pass in ONE launch (d <= 6): plan and head on the host (tgp_plan::build_filter / filter_head: the covariance half, the head's
-// forward recursion from its few observations), forward and reverse recursions + the sums behind the head in k_adjoint_one, the head's
-// reverse part and the sweep through the covariance recursion in tgp_adjoint::finish as before.  *served = false: the five-launch form runs.
-static int adjoint_lti_call(tgp_handle* h, const double* y, uint32_t flags, double* lml_out, const tgp_adjoint::Out& o, bool* served) {
-    *served = false;
-    tgp_plan::ModelHost mh;
-    if (!h->opt_modal || chunk_engine_requested(h) || h->is_dense || !h->lti || h->p != 1 || h->ordering != 0 || h->sde || h->d > tgp_modal::kAdjointMaxD || !modal_host_model(h, mh)) return TGP_OK;
-    tgp_plan::FilterPlan fp;
-    tgp_modal::plan_filter(mh, h->T, fp);
-    if (fp.why != tgp_plan::kOk) return TGP_OK;
-    const long long nwg = tgp_modal::adjoint_workgroups(fp, h->T);
-    if (nwg < 1) return TGP_OK;
-    const int d = h->d, ns = tgp_modal::adjoint_sums(d);
-    const size_t dd = (size_t)d * d, nhs = (size_t)fp.nhs, nrec = tgp_adjoint::record_size(d);
-    const size_t need = nhs + (size_t)nwg * ns + d + nrec + 16;
-    TRY(ensure_pinned(h, need));
-    double *yh = h->flt_host, *part = yh + nhs, *psi = part + (size_t)nwg * ns, *rec = psi + d;
-    if (!h->sm_sync) {
-        if (tgp_alloc::host_malloc(reinterpret_cast<void**>(&h->sm_sync), 32 * sizeof(double), hipHostMallocDefault) != hipSuccess) return h->fail(TGP_EHIP, "hipHostMalloc");
-        std::memset(h->sm_sync, 0, 32 * sizeof(double));
-    }
-    CallTimer tm(h, /*clear=*/false);
-    TRY(set_obs(h, y, nullptr, flags));
-    tm.inputs_done();
-    // The head beside the kernel: the launch goes first, workgroup 0 hands the head's observations over through pinned memory,
-    // the host answers with the head's end state.  With synchronous launches: copy, synchronise, head, launch.
-    const bool overlap = tgp_modal::overlap_allowed();
-    double* mu_end = h->sm_sync;
-    long long* sflag = reinterpret_cast<long long*>(h->sm_sync + 16);
-    const long long seq = ++h->smooth_seq;
-    double quad_head = 0.0;
-    tgp_modal::HeadHandover hh;
-    if (overlap) {
-        hh.head_in = yh;
-        hh.head_in_flag = sflag;
-        hh.mu0 = mu_end;
-        hh.mu0_flag = sflag + 1;
-        hh.seq = seq;
-    } else {
-        HIPCHK(hipMemcpyAsync(yh, h->mv.y, nhs * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
-        tgp_modal::plan_filter_head(mh, fp, yh, nullptr, nullptr, mu_end, &quad_head);
-    }
-    {
-        LaunchScope ls(h, "k_adjoint_one");
-        const int rc = tgp_modal::adjoint_lti(h->stream, fp, overlap ? nullptr : mu_end, h->mv.y, h->T, part, psi, overlap ? &hh : nullptr);
-        if (rc != 0) return h->fail(TGP_EHIP, std::string("tgp_logpdf_adjoint: launch: ") + hipGetErrorString((hipError_t)rc));
-    }
-    bool handshake_ok = true;
-    if (overlap) {
-        handshake_ok = tgp_modal::await_host_flag(sflag, 2 * seq, h->stream);
-        if (handshake_ok) tgp_modal::plan_filter_head(mh, fp, yh, nullptr, nullptr, mu_end, &quad_head);
-        __atomic_store_n(sflag + 1, 2 * seq, __ATOMIC_RELEASE);      // (also when the hand-over failed: workgroup 0 never waits for what will not come)
-    }
-    tm.kernels_done();
-    if (h->timing) (void)hipEventRecord(h->ev[3], h->stream);
-    HIPCHK(hipStreamSynchronize(h->stream));
-    resolve_profile(h);
-    if (!handshake_ok) return h->fail(TGP_EHIP, "tgp_logpdf_adjoint: the host / device hand-over timed out");
-    // the record tgp_adjoint::finish reads: the sums (fixed order over the workgroups), psi at the head's end, n0 / T, the model blocks
-    for (size_t e = 0; e < nrec; ++e) rec[e] = 0.0;
-    for (long long g = 0; g < nwg; ++g)
-        for (int e = 0; e < ns; ++e) rec[e] += part[(size_t)g * ns + e];
-    for (int i = 0; i < d; ++i) rec[ns + i] = psi[i];
-    double* meta = rec + ns + 2 * d;
-    meta[0] = (double)fp.n0;
-    meta[1] = 0.0;
-    meta[2] = (double)h->T;
-    meta[3] = 1.0;
-    double* md = meta + 4;
-    std::memcpy(md, h->hostm.data(), (2 * dd + 2 * d + 2) * sizeof(double));
-    double* x0 = md + 2 * dd + 2 * d + 2;
-    for (int i = 0; i < d; ++i) x0[i] = h->x0m[i];
-    for (int c = 0; c < d; ++c)
-        for (int r = 0; r <= c; ++r) x0[d + c * (c + 1) / 2 + r] = h->x0P[r + (size_t)c * d];
-    if (tgp_adjoint::finish(d, rec, yh, (int64_t)nhs, o, (int64_t)nhs) != 0) return h->fail(TGP_EHIP, "tgp_logpdf_adjoint: inconsistent record");
-    const double ssq = rec[dd + 3 * d + 1];
-    const double lml = -0.5 * ((double)h->T * 1.8378770664093454835606594728112 + fp.LS + (double)(h->T - fp.n0) * fp.logS + quad_head + fp.iS * ssq);
-    for (int i = 0; i < 8; ++i) h->host_result[i] = 0.0;
-    h->host_result[0] = lml;
-    if (lml_out) *lml_out = lml;
-    h->reduce_valid = false;
-    h->smoother_valid = false;
-    h->modal_last = false;
-    h->steady2_last = false;
-    h->dense_last_n0 = fp.n0;
-    *served = true;
-    return TGP_OK;
-}
-
-int tgp_logpdf_adjoint(tgp_handle* h, const double* y, uint32_t flags, double* lml_out, double* gA, double* ga, double* gQ, double* gH,
-                       double* ghh, double* gR, double* gx0m, double* gx0P) {
-    StreamGuard stream_guard_(h);
-    TRY(check_ready(h, /*general=*/false));
-    h->dense_last_n0 = -1;
-    h->modal_last = false;
-    if (y != nullptr) {
-        bool served = false;
-        const tgp_adjoint::Out o1{gA, ga, gQ, gH, ghh, gR, gx0m, gx0P};
-        TRY(adjoint_lti_call(h, y, flags, lml_out, o1, &served));
-        if (served) return TGP_OK;
-    }
-    h->steady2_last = false;
-    const int keep_state = h->steady2_state;
-    h->steady2_state = 0;            // (an earlier "does not apply" verdict of a posterior call -- series shorter than head + tail -- does not bind this one)
-    const bool ok = steady2_eligible(h, nullptr, flags);
-    h->steady2_state = keep_state;
-    if (!ok)
-        return h->fail(TGP_EUNSUPPORTED, "tgp_logpdf_adjoint: Forward LTI models (every block shared), one noise variance, scalar observations, d <= 8 "
-                                         "(the stationary-gain engine); use tgp_logpdf_grad otherwise");
-    constexpr int64_t kHead = (int64_t)tgp_steady::kHeadMaxTiles * tgp_steady::kTile;
-    const size_t nrec = tgp_steady::grad_record_size(h->d);
-    const int64_t nyh = h->T < kHead ? h->T : kHead;
-    if (!h->adj_host && tgp_alloc::host_malloc(reinterpret_cast<void**>(&h->adj_host), (tgp_steady::grad_record_size(tgp_steady::kMaxD) + kHead) * sizeof(double), hipHostMallocDefault) != hipSuccess)
-        return h->fail(TGP_EHIP, "hipHostMalloc");
-    CallTimer tm(h, /*clear=*/false);
-    TRY(set_obs(h, y, nullptr, flags));
-    tm.inputs_done();
-    TRY(steady2_enqueue(h, nullptr, false, nullptr, nullptr, true));
-    tm.kernels_done();
-    HIPCHK(hipMemcpyAsync(h->adj_host, tgp_steady::grad_record(h->steady2), nrec * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(h->adj_host + nrec, h->mv.y, (size_t)nyh * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    TRY(tm.finish(lml_out));
-    if (h->host_result[6] != tgp_steady::kStatusRan)
-        return h->fail(TGP_EUNSUPPORTED, "tgp_logpdf_adjoint: the filter covariance of this model does not settle within the head (or the series is shorter "
-                                         "than the head); use tgp_logpdf_grad");
-    h->reduce_valid = false;
-    h->smoother_valid = false;
-    const tgp_adjoint::Out o{gA, ga, gQ, gH, ghh, gR, gx0m, gx0P};
-    if (tgp_adjoint::finish(h->d, h->adj_host, h->adj_host + nrec, nyh, o) != 0) return h->fail(TGP_EHIP, "tgp_logpdf_adjoint: inconsistent record");
-    return TGP_OK;
-}
-
-// _filter of an LTI model (Forward, scalar observations, one noise variance, no missing data, d <= 6): the head on the host from its few
-// observations, everything behind it in ONE kernel (tgp_modal::filter_lti).  *served = false: the caller runs the general engine.
-static int filter_lti_call(tgp_handle* h, const double* y, uint32_t flags, double* m_out, double* P_out, double* lml_out, bool* served) {
-    *served = false;
-    tgp_plan::ModelHost mh;
-    if (!h->opt_modal || chunk_engine_requested(h) || h->is_dense || !h->lti || h->p != 1 || h->ordering != 0 || h->sde || h->d > tgp_plan::kRandMaxD || !modal_host_model(h, mh)) return TGP_OK;
-    tgp_plan::FilterPlan fp;
-    tgp_modal::plan_filter(mh, h->T, fp);
-    if (fp.why != tgp_plan::kOk) return TGP_OK;
-    const int d = h->d;
-    const size_t dd = (size_t)d * d, nhs = (size_t)fp.nhs;
-    const long long nwg = tgp_modal::filter_workgroups(fp, h->T);
-    const size_t need = nhs * (1 + d + dd) + (size_t)nwg + 8;
-    TRY(ensure_pinned(h, need));
-    double *yh = h->flt_host, *mh_out = yh + nhs, *Ph_out = mh_out + nhs * d, *part = Ph_out + nhs * dd;
-    const bool odev = (flags & TGP_OUT_DEVICE) != 0;
-    const size_t nm = (size_t)h->T * d * sizeof(double), nP = nm * d;
-    CallTimer tm(h, /*clear=*/false);
-    TRY(set_obs(h, y, nullptr, flags));
-    tm.inputs_done();
-    HIPCHK(hipMemcpyAsync(yh, h->mv.y, nhs * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    double mu_end[tgp_plan::kRandMaxD], quad_head = 0.0;
-    tgp_modal::plan_filter_head(mh, fp, yh, m_out ? mh_out : nullptr, P_out ? Ph_out : nullptr, mu_end, &quad_head);
-    double *dm = nullptr, *dP = nullptr;
-    TRY(stage_out(h, h->bo1, m_out, nm, odev, &dm));
-    TRY(stage_out(h, h->bo2, P_out, nP, odev, &dP));
-    if (dm) HIPCHK(hipMemcpyAsync(dm, mh_out, nhs * d * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    if (dP) HIPCHK(hipMemcpyAsync(dP, Ph_out, nhs * dd * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    {
-        LaunchScope ls(h, "k_filter_one");
-        const int rc = tgp_modal::filter_lti(h->stream, fp, mu_end, h->mv.y, h->T, dm, dP, part);
-        if (rc != 0) return h->fail(TGP_EHIP, std::string("tgp_filter: launch: ") + hipGetErrorString((hipError_t)rc));
-    }
-    tm.kernels_done();
-    TRY(copy_back(h, m_out, dm, nm, odev));
-    TRY(copy_back(h, P_out, dP, nP, odev));
-    if (h->timing) (void)hipEventRecord(h->ev[3], h->stream);
-    HIPCHK(hipStreamSynchronize(h->stream));
-    resolve_profile(h);
-    double ssq = 0.0;
-    for (long long g = 0; g < nwg; ++g) ssq += part[g];
-    const double lml = -0.5 * ((double)h->T * 1.8378770664093454835606594728112 + fp.LS + (double)(h->T - fp.n0) * fp.logS + quad_head + fp.iS * ssq);
-    for (int i = 0; i < 8; ++i) h->host_result[i] = 0.0;
-    h->host_result[0] = lml;
-    if (lml_out) *lml_out = lml;
-    h->reduce_valid = false;
-    h->smoother_valid = false;
-    h->modal_last = false;
-    h->steady2_last = false;
-    h->dense_last_n0 = fp.n0;
-    *served = true;
-    return TGP_OK;
-}
-
-// logpdf + posterior marginals of an LTI model WITHOUT a modal form (Forward, scalar observations, one noise variance, no missing data,
-// d <= 8; a defective closed loop: two summands with one length scale, ...): the head on the host, everything behind it in ONE kernel on the
-// dense powers of the closed loop and of the settled reverse-time transition (tgp_modal::smooth_lti).  *served = false: the
-// five-launch engine runs the call.
-// Every block shared but the emission offset: a GP with a mean function on a regular grid (lti_sde.jl:118-131).  The gains never see the offset, so the
-// stationary structure holds; the dense-powers kernel subtracts it per step (SmoothCall::hh_t).
-static bool lti_but_offset(const tgp_handle* h) {
-    return !h->lti && !h->is_dense && !h->sde && h->p == 1 && h->ordering == 0 && h->mv.sA == 0 && h->mv.sa == 0 && h->mv.sQ == 0 && h->mv.sH == 0 && h->mv.sR == 0 &&
-           h->mv.sh != 0 && h->mv.T == h->T && !h->sweepm.empty() && h->opt_steady2 && h->opt_chunk == 0;
-}
-static int smooth_lti_call(tgp_handle* h, const double* y, uint32_t flags, const double* Rnew, double* mean_out, double* var_out, double* lml_out, bool* served,
-                           const SmoothRand* rnd) {
-    *served = false;
-    tgp_plan::ModelHost mh;
-    const bool offs = lti_but_offset(h);
-    if (offs && h->opt_modal && !rnd) {      // (the plans read the shared blocks the sweep engine's record holds: the same layout as hostm)
-        const int d = h->d;
-        const size_t dd = (size_t)d * d;
-        const double* q = h->sweepm.data();
-        mh.d = d;
-        mh.A = q; mh.a = q + dd; mh.Q = q + dd + d; mh.H = q + 2 * dd + d; mh.hh = q + 2 * dd + 2 * d; mh.R = q + 2 * dd + 2 * d + 1;
-        mh.x0m = h->x0m.data();
-        mh.x0P = h->x0P.data();
-    }
-    if (!h->opt_modal || h->smooth_state < 0 || chunk_engine_requested(h) || h->is_dense || !(h->lti || (offs && !rnd)) || h->p != 1 || h->ordering != 0 || h->sde ||
-        h->d > tgp_plan::kRandMaxD || (!offs && !modal_host_model(h, mh)) || (!rnd && (mean_out != nullptr) != (var_out != nullptr)) || (mean_out && !Rnew))
-        return TGP_OK;
-    if (rnd && (h->d > tgp_modal::kSmoothRandMaxD || !mean_out || var_out || !rnd->eps_t || !rnd->eps_e || !rnd->eps_0)) return TGP_OK;
-    const bool post = mean_out != nullptr;      // (false: logpdf only -- the forward half alone, no halo behind a span)
-    constexpr size_t HM = tgp_plan::kHeadMax;
-    const size_t nwg_max = (size_t)(h->T / 1024) + 2;
-    TRY(ensure_pinned(h, 14 * HM + nwg_max + tgp_plan::kTailMax + 8));
-    // hin: y | Rnew (| eta | eps [nhs][d <= 6] of a draw) of the head, its emission offsets at 10 nhs; hout: mean | var
-    double *hin = h->flt_host, *hout = hin + 12 * HM, *tvb = hout + 2 * HM, *part = tvb + tgp_plan::kTailMax;
-    if (!h->sm_sync) {
-        if (tgp_alloc::host_malloc(reinterpret_cast<void**>(&h->sm_sync), 32 * sizeof(double), hipHostMallocDefault) != hipSuccess) return h->fail(TGP_EHIP, "hipHostMalloc");
-        std::memset(h->sm_sync, 0, 32 * sizeof(double));
-    }
-    double *mu_end = h->sm_sync, *xi = h->sm_sync + 8;
-    long long* sflag = reinterpret_cast<long long*>(h->sm_sync + 16);      // [0] head inputs on the host, [1] mu_end, [2] xi, [3] head outputs
-    tgp_plan::SmoothPlan sp;
-    tgp_modal::plan_smooth(mh, h->T, sp, tvb, post);
-    if (sp.why != tgp_plan::kOk) {
-        if (post) h->smooth_state = -1;      // (a function of the model and T alone: the next call need not ask again)
-        return TGP_OK;
-    }
-    const tgp_plan::FilterPlan& fp = sp.fp;
-    const size_t nhs = (size_t)fp.nhs;
-    const long long nwg = tgp_modal::smooth_workgroups(sp, h->T, post);
-    if (nwg < 1 || (size_t)nwg > nwg_max) return TGP_OK;
-    const bool idev = (flags & TGP_IN_DEVICE) != 0, odev = (flags & TGP_OUT_DEVICE) != 0, rshared = (flags & TGP_SHARED_R) != 0;
-    const size_t nT = (size_t)h->T * sizeof(double);
-    // The head BESIDE the kernel (tgp_modal.hpp SmoothCall): the launch goes first; workgroup 0 hands the head's inputs to the host through
-    // pinned memory, the host answers with the head's end state, runs the head backwards once workgroup 0 has raised xi, and the last workgroup
-    // writes the head's outputs: one launch, one synchronisation, no copy on any stream in between.  With synchronous launches: the same
-    // steps one after the other, copies on the handle's stream.
-    const bool overlap = tgp_modal::overlap_allowed();
-    const long long seq = ++h->smooth_seq;
-    double rU[tgp_modal::kSmoothRandMaxD * tgp_modal::kSmoothRandMaxD], rv0[tgp_modal::kSmoothRandMaxD], rs0 = 0.0;
-    if (rnd && !tgp_modal::plan_smooth_rand_factors(sp, rnd->eps_0, rU, rv0, &rs0)) return TGP_OK;      // (a noise factor not positive definite: the evaluated route gives the verdict)
-    CallTimer tm(h, /*clear=*/false);
-    const void *pR = nullptr, *pet = nullptr, *pee = nullptr;
-    if (post) TRY(stage_in(h, h->bRnew, Rnew, rshared ? sizeof(double) : nT, idev, &pR));
-    if (rnd) {
-        TRY(stage_in(h, h->beps_t, rnd->eps_t, (size_t)h->T * h->d * sizeof(double), idev, &pet));
-        TRY(stage_in(h, h->beps_e, rnd->eps_e, nT, idev, &pee));
-    }
-    TRY(set_obs(h, y, nullptr, flags));
-    tm.inputs_done();
-    double *dm = nullptr, *dv = nullptr;
-    TRY(stage_out(h, h->bo1, mean_out, nT, odev, &dm));
-    TRY(stage_out(h, h->bo2, var_out, nT, odev, &dv));
-    double quad_head = 0.0;
-    const bool hand = idev || offs;      // the kernel hands the head's inputs over (a per-step offset lives on the device whatever the call's arrays are)
-    const double *yhead = hand ? hin : y, *rnhead = hand ? hin + nhs : Rnew;
-    const double* hhhead = offs ? hin + 10 * nhs : nullptr;
-    const double *eehead = rnd ? (hand ? hin + 2 * nhs : rnd->eps_e) : nullptr, *ethead = rnd ? (hand ? hin + 3 * nhs : rnd->eps_t) : nullptr;
-    tgp_modal::SmoothCall c;
-    c.T = h->T;
-    c.y = h->mv.y;
-    c.Rnew = static_cast<const double*>(pR);
-    c.rnew_per_step = rshared ? 0 : 1;
-    c.tvb = tvb;
-    c.mean = dm;
-    c.var = dv;
-    c.part = part;
-    c.xi_out = xi;
-    c.seq = seq;
-    c.hh_t = offs ? h->mv.h : nullptr;
-    if (rnd) {
-        c.eps_t = static_cast<const double*>(pet);
-        c.eps_e = static_cast<const double*>(pee);
-        c.U = rU;
-        c.v0 = rv0;
-        c.s0 = rs0;
-    }
-    if (overlap) {
-        if (hand) {
-            c.head_in = hin;
-            c.head_in_flag = sflag;
-        }
-        c.mu0 = mu_end;
-        c.mu0_flag = sflag + 1;
-        if (post) {
-            c.xi_flag = sflag + 2;
-            c.head_out = hout;
-            c.head_out_flag = sflag + 3;
-        }
-    } else {
-        if (hand) {
-            HIPCHK(hipMemcpyAsync(hin, h->mv.y, nhs * sizeof(double), hipMemcpyDeviceToHost, h->stream));      // (the staged copies: device whatever the call's arrays are)
-            if (post) HIPCHK(hipMemcpyAsync(hin + nhs, pR, (rshared ? 1 : nhs) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-            if (offs) HIPCHK(hipMemcpyAsync(hin + 10 * nhs, h->mv.h, nhs * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-            if (rnd) {
-                HIPCHK(hipMemcpyAsync(hin + 2 * nhs, rnd->eps_e, nhs * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-                HIPCHK(hipMemcpyAsync(hin + 3 * nhs, rnd->eps_t, nhs * h->d * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-            }
-            HIPCHK(hipStreamSynchronize(h->stream));
-        }
-        tgp_modal::plan_smooth_head_forward(mh, sp, yhead, mu_end, &quad_head, hhhead);
-    }
-    {
-        LaunchScope ls(h, rnd ? "k_smooth_one<rand>" : (post ? "k_smooth_one<posterior>" : "k_smooth_one<logpdf>"));
-        const int rc = tgp_modal::smooth_lti(h->stream, sp, overlap ? nullptr : mu_end, c);
-        if (rc != 0) return h->fail(TGP_EHIP, std::string("tgp_posterior_marginals: launch: ") + hipGetErrorString((hipError_t)rc));
-    }
-    struct FlagGuard {      // (whatever path leaves from here on: no workgroup is left waiting for the host)
-        long long* f;
-        long long v;
-        ~FlagGuard() {
-            if (!f) return;
-            for (int k : {1, 3})
-                if (__atomic_load_n(f + k, __ATOMIC_RELAXED) < v) __atomic_store_n(f + k, v, __ATOMIC_RELEASE);
-        }
-    } guard{overlap ? sflag : nullptr, 2 * seq};
-    auto await = [&](const long long* f) { return tgp_modal::await_host_flag(f, 2 * seq, h->stream); };
-    bool handshake_ok = true;
-    if (overlap) {
-        if (hand) handshake_ok = await(sflag);
-        if (handshake_ok) {
-            tgp_modal::plan_smooth_head_forward(mh, sp, yhead, mu_end, &quad_head, hhhead);
-            __atomic_store_n(sflag + 1, 2 * seq, __ATOMIC_RELEASE);
-        }
-    }
-    const bool tables_ok = !post || tgp_modal::plan_smooth_head_tables(mh, sp);      // (beside the kernel)
-    auto head_back = [&]() {
-        if (rnd) {
-            tgp_modal::plan_smooth_head_backward_rand(mh, sp, yhead, xi, eehead, ethead, rnhead, !rshared, hout);
-            return;
-        }
-        tgp_modal::plan_smooth_head_backward(mh, sp, yhead, xi, hout, hout + nhs);
-        for (size_t t = 0; t < nhs; ++t) hout[nhs + t] += rnhead[rshared ? 0 : t];
-    };
-    if (overlap && post && tables_ok && handshake_ok) {      // workgroup 0 is among the first to finish: its xi arrives long before the grid is through
-        handshake_ok = await(sflag + 2);
-        if (handshake_ok) {
-            head_back();
-            __atomic_store_n(sflag + 3, 2 * seq, __ATOMIC_RELEASE);
-        }
-    }
-    tm.kernels_done();
-    if (overlap) {
-        for (int k : {1, 3})      // (a hand-over that failed, head tables that declined: no workgroup waits for what will not come; the outputs are discarded)
-            if (__atomic_load_n(sflag + k, __ATOMIC_RELAXED) < 2 * seq) __atomic_store_n(sflag + k, 2 * seq, __ATOMIC_RELEASE);
-        TRY(copy_back(h, mean_out, dm, nT, odev));
-        TRY(copy_back(h, var_out, dv, nT, odev));
-    }
-    if (h->timing) (void)hipEventRecord(h->ev[3], h->stream);
-    HIPCHK(hipStreamSynchronize(h->stream));
-    resolve_profile(h);
-    if (!handshake_ok) return h->fail(TGP_EHIP, "the one-launch smoother's host / device hand-over timed out");
-    if (!tables_ok) {      // a head step's predicted covariance not positive definite: the older engines give the verdict
-        h->smooth_state = -1;
-        return TGP_OK;
-    }
-    if (!overlap) {
-        if (post) {
-            head_back();
-            HIPCHK(hipMemcpyAsync(dm, hout, nhs * sizeof(double), hipMemcpyHostToDevice, h->stream));
-            if (dv) HIPCHK(hipMemcpyAsync(dv, hout + nhs, nhs * sizeof(double), hipMemcpyHostToDevice, h->stream));
-        }
-        TRY(copy_back(h, mean_out, dm, nT, odev));
-        TRY(copy_back(h, var_out, dv, nT, odev));
-        HIPCHK(hipStreamSynchronize(h->stream));
-    }
-    double ssq = 0.0;
-    for (long long g = 0; g < nwg; ++g) ssq += part[g];
-    const double lml = -0.5 * ((double)h->T * 1.8378770664093454835606594728112 + fp.LS + (double)(h->T - fp.n0) * fp.logS + quad_head + fp.iS * ssq);
-    if (rnd && !(lml == lml)) return TGP_OK;      // (a NaN in the series -- NaN == missing in the mirrors' convention --: the evaluated route serves the draw)
-    if (getenv("TGP_STEADY_DEBUG") != nullptr)
-        fprintf(stderr, "[tgp smooth] T %lld post %d overlap %d idev %d odev %d nwg %lld nhs %d halo %d n1 %d seq %lld quad_head %.6g ssq %.6g lml %.10g\n", (long long)h->T,
-                (int)post, (int)overlap, (int)idev, (int)odev, nwg, fp.nhs, sp.halo, sp.n1, seq, quad_head, ssq, lml);
-    for (int i = 0; i < 8; ++i) h->host_result[i] = 0.0;
-    h->host_result[0] = lml;
-    if (lml_out) *lml_out = lml;
-    h->reduce_valid = false;
-    h->smoother_valid = false;
-    h->modal_last = false;
-    h->steady2_last = false;
-    h->dense_last_n0 = fp.n0;
-    *served = true;
-    return TGP_OK;
-}
-
-// rand of posterior(model, y) with replaced observation noise (lgssm.jl:65-91 on the reverse-time model of :193-221; posterior_lti_sde.jl:48-58)
-// WITHOUT evaluating that model: Forward LTI models with scalar observations, one noise variance, no missing data, d <= 6 -- k_smooth_one with a
-// noise input.  TGP_EUNSUPPORTED: the caller takes the evaluated route (tgp_posterior, then tgp_rand on the Reverse model).
-int tgp_posterior_rand(tgp_handle* h, const double* y, const double* Rnew, const double* eps_t, const double* eps_e, const double* eps_0, uint32_t flags,
-                       double* y_out) {
-    StreamGuard stream_guard_(h);
-    TRY(check_ready(h, /*general=*/false));
-    if (!y || !Rnew || !eps_t || !eps_e || !eps_0 || !y_out) return h->fail(TGP_EINVAL, "tgp_posterior_rand: null argument");
-    h->steady2_last = false;
-    h->modal_last = false;
-    h->dense_last_n0 = -1;
-    bool served = false;
-    const SmoothRand rnd{eps_t, eps_e, eps_0};
-    if (steady2_eligible(h, nullptr, flags)) TRY(smooth_lti_call(h, y, flags, Rnew, y_out, nullptr, nullptr, &served, &rnd));
-    if (!served) return h->fail(TGP_EUNSUPPORTED, "tgp_posterior_rand: Forward LTI models with scalar observations, one noise variance and d <= 6 (take tgp_posterior + tgp_rand)");
-    return TGP_OK;
-}
-
-// Two observations per step of ONE latent value with independent noise are one observation of it:
-//     N(y; f, R) N(y*; f, R*) = N(ybar; f, Rbar) N(y - y*; 0, R + R*),   Rbar = R R* / (R + R*),   ybar = (R* y + R y*) / (R + R*)
-// -- what turns logpdf(replace_observation_noise_cov(posterior(model, y), R*), y*) (posterior_lti_sde.jl:62-78 -> lgssm.jl:147-151 on the
-// reverse-time model of lgssm.jl:193-221) into two logpdf calls of the PRIOR: logpdf(model(Rbar), ybar) + pair - logpdf(model(R), y), DESIGN 3.18.
-// One pass over the two series: 16 bytes read and 8 written per step (+ 8 per per-step variance read or written, + the masks).
-namespace {
-struct PairArgs {
-    const double *y, *R, *ys, *Rs;
-    const uint8_t *m, *ms;
-    double *ybar, *Rbar, *part;
-    uint8_t* mbar;
-    long long n;
-    double R0, Rs0;
-};
-static __global__ __launch_bounds__(256) void k_pair_statistic(const PairArgs a) {
-    const long long stride = (long long)gridDim.x * 256;
-    const double tot0 = a.R0 + a.Rs0, lg0 = log(6.283185307179586 * tot0);
-    double acc = 0.0;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.n; i += stride) {
-        const double y = a.y[i], ys = a.ys[i];
-        const double R = a.R ? a.R[i] : a.R0, Rs = a.Rs ? a.Rs[i] : a.Rs0;
-        const bool my = a.m && a.m[i] != 0, mn = a.ms && a.ms[i] != 0;
-        double yb, Rb;
-        if (!my && !mn) {
-            const double tot = R + Rs, df = y - ys;
-            acc -= 0.5 * (((a.R || a.Rs) ? log(6.283185307179586 * tot) : lg0) + df * df / tot);
-            yb = (Rs * y + R * ys) / tot;       // (no division by a jitter-sized R*)
-            Rb = R * Rs / tot;
-        } else if (!my) {
-            yb = y, Rb = R;
-        } else if (!mn) {
-            yb = ys, Rb = Rs;
-        } else {
-            yb = 0.0, Rb = R;                   // missing on both sides: the joint step is missing
-        }
-        a.ybar[i] = yb;
-        if (a.Rbar) a.Rbar[i] = Rb;
-        if (a.mbar) a.mbar[i] = (my && mn) ? 1 : 0;
-    }
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
-    __shared__ double sw[4];
-    if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) a.part[blockIdx.x] = (sw[0] + sw[1]) + (sw[2] + sw[3]);
-}
-}  // namespace
-
-int tgp_pair_statistic(tgp_handle* h, int64_t n, const double* y, const uint8_t* missing, const double* R, int64_t nR, const double* y_new,
-                       const uint8_t* missing_new, const double* R_new, int64_t nR_new, double* ybar, double* Rbar, uint8_t* missing_bar,
-                       double* pair_out) {
-    if (!h) return TGP_EINVAL;
-    if (n < 0 || !y || !y_new || !R || !R_new || !ybar || !pair_out || (nR != 1 && nR != n) || (nR_new != 1 && nR_new != n))
-        return h->fail(TGP_EINVAL, "tgp_pair_statistic: null argument, or a variance count that is neither 1 nor n");
-    const bool per_step = nR == n && n > 1, per_step_new = nR_new == n && n > 1;
-    if (!Rbar && (per_step || per_step_new || missing || missing_new))
-        return h->fail(TGP_EINVAL, "tgp_pair_statistic: Rbar [n] is needed when a variance is per step or anything is missing");
-    if (!missing_bar && missing && missing_new) return h->fail(TGP_EINVAL, "tgp_pair_statistic: missing_bar [n] is needed with two masks");
-    *pair_out = 0.0;
-    if (n == 0) return TGP_OK;
-    TRY(bind_device(h));
-    PairArgs a{};
-    a.y = y, a.ys = y_new, a.m = missing, a.ms = missing_new, a.ybar = ybar, a.Rbar = Rbar, a.mbar = (missing && missing_new) ? missing_bar : nullptr, a.n = n;
-    a.R = per_step ? R : nullptr;
-    a.Rs = per_step_new ? R_new : nullptr;
-    a.R0 = a.Rs0 = 1.0;
-    // (a single variance is read on the host: a device value when n == 1 says both are per step -- one 8-byte copy each)
-    if (!per_step) {
-        hipPointerAttribute_t at{};
-        if (hipPointerGetAttributes(&at, R) == hipSuccess && at.type == hipMemoryTypeDevice) HIPCHK(hipMemcpy(&a.R0, R, sizeof(double), hipMemcpyDeviceToHost));
-        else { (void)hipGetLastError(); a.R0 = R[0]; }
-    }
-    if (!per_step_new) {
-        hipPointerAttribute_t at{};
-        if (hipPointerGetAttributes(&at, R_new) == hipSuccess && at.type == hipMemoryTypeDevice) HIPCHK(hipMemcpy(&a.Rs0, R_new, sizeof(double), hipMemcpyDeviceToHost));
-        else { (void)hipGetLastError(); a.Rs0 = R_new[0]; }
-    }
-    if (!(a.R0 + a.Rs0 > 0.0)) return h->fail(TGP_EINVAL, "tgp_pair_statistic: R + R_new must be positive");
-    const int nblk = (int)std::min<long long>(2048, (n + 1023) / 1024);
-    TRY(ensure_pinned(h, (size_t)nblk));
-    a.part = h->flt_host;
-    hipLaunchKernelGGL(k_pair_statistic, dim3(nblk), dim3(256), 0, h->stream, a);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(h->stream));
-    double sum = 0.0;
-    for (int b = 0; b < nblk; ++b) sum += h->flt_host[b];
-    *pair_out = sum;
-    return TGP_OK;
-}
-
+#include "tgp_api_segments.inc"      // time segments on the one-launch path, the plan and adjoint entry points without a handle
+#include "tgp_api_lti_calls.inc"      // the LTI one-launch calls behind the entry points: adjoint, filter, smoother / posterior draw, pair statistic
 int tgp_filter(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t flags, double* m_out, double* P_out, double* lml_out) {
     StreamGuard stream_guard_(h);
     TRY(check_ready(h, /*general=*/false));
@@ -3963,793 +2698,9 @@ int tgp_rand(tgp_handle* h, const double* eps_t, const double* eps_e, const doub
     return tm.finish();
 }
 
-int tgp_logpdf_grad(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t flags, int nparams, const double* dA,
-                    const double* da, const double* dQ, const double* dH, const double* dh, const double* dR, const double* dx0m,
-                    const double* dx0P, double* lml_out, double* grad_out) {
-    StreamGuard stream_guard_(h);
-    TRY(check_ready(h));
-    TRY(scan_only(h, "tgp_logpdf_grad"));
-    if (nparams < 1 || !grad_out) return h->fail(TGP_EINVAL, "nparams must be >= 1 and grad_out non-null");
-    if (!dA || !da || !dQ || !dH || !dh || !dR || !dx0m || !dx0P) return h->fail(TGP_EINVAL, "null tangent array");
-    if (!h->lti || h->mv.sR != 0 || h->p != 1 || h->ordering != 0)
-        return h->fail(TGP_EUNSUPPORTED, "tgp_logpdf_grad: Forward model with all blocks shared (Fill) and scalar observations only");
-    const int d = h->d, dd = d * d, per = 2 * dd + 2 * d + 2;   // A, a, Q, H, h, R tangents of one parameter
-    CallTimer tm(h);
-    TRY(set_obs(h, y, missing, flags));
-    // stage all tangent blocks once: [param][A | a | Q | H | h | R]
-    std::vector<double> host((size_t)nparams * per);
-    for (int k = 0; k < nparams; ++k) {
-        double* q = host.data() + (size_t)k * per;
-        std::memcpy(q, dA + (size_t)k * dd, dd * sizeof(double)); q += dd;
-        std::memcpy(q, da + (size_t)k * d, d * sizeof(double)); q += d;
-        std::memcpy(q, dQ + (size_t)k * dd, dd * sizeof(double)); q += dd;
-        std::memcpy(q, dH + (size_t)k * d, d * sizeof(double)); q += d;
-        *q++ = dh[k];
-        *q++ = dR[k];
-    }
-    HIPCHK(h->btan.ensure(host.size() * sizeof(double)));
-    HIPCHK(hipMemcpyAsync(h->btan.p, host.data(), host.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    const int ns = state_size(d);
-    std::vector<double> x0ad((size_t)nparams * 2 * ns), pv, pt;
-    for (int k = 0; k < nparams; ++k) {
-        pack_state(d, h->x0m.data(), h->x0P.data(), pv);
-        pack_state(d, dx0m + (size_t)k * d, dx0P + (size_t)k * dd, pt);
-        for (int i = 0; i < ns; ++i) {
-            x0ad[(size_t)k * 2 * ns + 2 * i] = pv[i];
-            x0ad[(size_t)k * 2 * ns + 2 * i + 1] = pt[i];
-        }
-    }
-    HIPCHK(h->bx0ad.ensure(x0ad.size() * sizeof(double)));
-    HIPCHK(hipMemcpyAsync(h->bx0ad.p, x0ad.data(), x0ad.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));   // host staging vectors go out of scope
-    tm.inputs_done();
-    choose_chunk(h);
-    h->reduce_valid = false;
-    h->smoother_valid = false;
-    TRY(scan_prepare(h, h->Fad, kFilterAD, h->n0));
-    const int64_t nblocks = (h->n0 + 255) / 256;
-    HIPCHK(h->partial.ensure((size_t)nblocks * 4 * sizeof(double)));
-    int rc = TGP_OK;
-    for (int k = 0; k < nparams && rc == TGP_OK; ++k) {
-        ModelView mv = h->mv;
-        const double* t = h->btan.d() + (size_t)k * per;
-        mv.dA = t; t += dd;
-        mv.da = t; t += d;
-        mv.dQ = t; t += dd;
-        mv.dH = t; t += d;
-        mv.dh = t; t += 1;
-        mv.dR = t;
-        {
-            LaunchScope ls(h, "k_reduce_filter<lti,grad>");
-            (void)h->kt->reduce_filter_ad(true, mv, h->L0, h->n0, h->Fad.E[0], h->stream);
-        }
-        scan_up(h, h->Fad);
-        scan_down(h, h->Fad, h->bx0ad.d() + (size_t)k * 2 * ns);
-        {
-            LaunchScope ls(h, "k_apply_filter<lti,grad>");
-            (void)h->kt->apply_filter_ad(true, mv, h->L0, h->n0, h->Fad.S[0], h->partial.d(), h->stream);
-        }
-        {
-            LaunchScope ls(h, "k_finalize<grad>");
-            hipLaunchKernelGGL(k_finalize_ad, dim3(1), dim3(256), 0, h->stream, h->partial.d(), nblocks, h->result.d());
-        }
-        if (k + 1 < nparams) {   // results of this parameter, then reuse the result block for the next one
-            HIPCHK(hipMemcpyAsync(h->host_result, h->result.p, 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-            HIPCHK(hipStreamSynchronize(h->stream));
-            grad_out[k] = h->host_result[3];
-            if (h->host_result[2] != 0.0) rc = h->fail(TGP_ENOTPD, "innovation variance not positive");
-        }
-    }
-    tm.kernels_done();
-    int rc2 = tm.finish(lml_out);
-    grad_out[nparams - 1] = h->host_result[3];
-    return rc != TGP_OK ? rc : rc2;
-}
-
-int tgp_logpdf_grad_sde(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t flags, int nparams, const double* dF,
-                        const double* dPinf, const double* dA1, const double* dQ1, const double* da, const double* dH, const double* dh,
-                        const double* dR, const double* dx0m, const double* dx0P, double rel_step, double* lml_out, double* grad_out) {
-    StreamGuard stream_guard_(h);
-    TRY(check_ready(h));
-    TRY(scan_only(h, "tgp_logpdf_grad_sde"));
-    if (nparams < 1 || !grad_out) return h->fail(TGP_EINVAL, "nparams must be >= 1 and grad_out non-null");
-    if (!dF || !dPinf || !da || !dH || !dh || !dR || !dx0m || !dx0P) return h->fail(TGP_EINVAL, "null tangent array");
-    if (!h->sde || h->p != 1 || h->ordering != 0 || h->mv.sH != 0 || h->mv.sh != 0)
-        return h->fail(TGP_EUNSUPPORTED, "tgp_logpdf_grad_sde: Forward model set with tgp_model_set_sde, shared H and h, scalar observations");
-    if (h->d > 4) return h->fail(TGP_EUNSUPPORTED, "tgp_logpdf_grad_sde: d <= 4 (the dual-number kernels of the general layout are built for d <= 4)");
-    if (h->have_AQ1 && (!dA1 || !dQ1)) return h->fail(TGP_EINVAL, "the model has an explicit first transition: dA1 / dQ1 are needed");
-    if (!(rel_step > 0.0)) rel_step = 1e-6;
-    const int d = h->d, dd = d * d, per = 4 * dd + 2 * d + 2;   // dF, dPinf, dA1, dQ1, da, dH, dh, dR of one parameter
-    CallTimer tm(h);
-    TRY(set_obs(h, y, missing, flags));
-    std::vector<double> host((size_t)nparams * per, 0.0), eps(nparams);
-    for (int k = 0; k < nparams; ++k) {
-        double* q = host.data() + (size_t)k * per;
-        std::memcpy(q, dF + (size_t)k * dd, dd * sizeof(double));
-        double nd = 0.0;
-        for (int i = 0; i < dd; ++i) nd += q[i] * q[i];
-        nd = std::sqrt(nd);
-        eps[k] = nd > 0.0 ? rel_step * std::max(1.0, h->normF) / nd : 1.0;    // F +- eps dF is a RELATIVE perturbation of size rel_step
-        q += dd;
-        std::memcpy(q, dPinf + (size_t)k * dd, dd * sizeof(double)); q += dd;
-        if (dA1) std::memcpy(q, dA1 + (size_t)k * dd, dd * sizeof(double));
-        q += dd;
-        if (dQ1) std::memcpy(q, dQ1 + (size_t)k * dd, dd * sizeof(double));
-        q += dd;
-        std::memcpy(q, da + (size_t)k * d, d * sizeof(double)); q += d;
-        std::memcpy(q, dH + (size_t)k * d, d * sizeof(double)); q += d;
-        *q++ = dh[k];
-        *q++ = dR[k];
-        if (h->mv.sR != 0 && dR[k] != 0.0) return h->fail(TGP_EUNSUPPORTED, "tgp_logpdf_grad_sde: a per-step noise variance has no tangent (dR must be 0)");
-    }
-    HIPCHK(h->btan.ensure(host.size() * sizeof(double)));
-    HIPCHK(hipMemcpyAsync(h->btan.p, host.data(), host.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    const int ns = state_size(d);
-    std::vector<double> x0ad((size_t)nparams * 2 * ns), pv, pt;
-    for (int k = 0; k < nparams; ++k) {
-        pack_state(d, h->x0m.data(), h->x0P.data(), pv);
-        pack_state(d, dx0m + (size_t)k * d, dx0P + (size_t)k * dd, pt);
-        for (int i = 0; i < ns; ++i) {
-            x0ad[(size_t)k * 2 * ns + 2 * i] = pv[i];
-            x0ad[(size_t)k * 2 * ns + 2 * i + 1] = pt[i];
-        }
-    }
-    HIPCHK(h->bx0ad.ensure(x0ad.size() * sizeof(double)));
-    HIPCHK(hipMemcpyAsync(h->bx0ad.p, x0ad.data(), x0ad.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    tm.inputs_done();
-    h->group_active = false;
-    choose_chunk(h);
-    TRY(ensure_tiled(h, /*full=*/true));        // the value tile (k_tile_sde) for this chunk size
-    h->reduce_valid = false;
-    h->smoother_valid = false;
-    const int Lt = h->L0;
-    const size_t nblk = (size_t)((h->n0 + 63) / 64) * 64;
-    HIPCHK(h->tile_tan.ensure((nblk * (size_t)Lt * (size_t)h->mv.nc_t + 1) * sizeof(double)));
-    TRY(scan_prepare(h, h->Fad, kFilterAD, h->n0));
-    const int64_t nblocks = (h->n0 + 255) / 256;
-    HIPCHK(h->partial.ensure((size_t)nblocks * 4 * sizeof(double)));
-    int rc = TGP_OK;
-    for (int k = 0; k < nparams && rc == TGP_OK; ++k) {
-        const double* t = h->btan.d() + (size_t)k * per;
-        {
-            LaunchScope ls(h, "k_tile_sde<grad>");
-            h->kt->tile_sde_tan(h->bF.d(), t, h->bPinf.d(), t + dd, h->times_dev, h->have_AQ1 ? t + 2 * dd : nullptr, h->T, Lt, h->n0, h->normF,
-                                eps[k], h->tile_tan.d(), h->stream);
-        }
-        ModelView mv = h->mv;
-        mv.tile_t_tan = h->tile_tan.d();
-        mv.dA = nullptr;                        // A, Q (and their tangents) come from the tiles
-        mv.dQ = nullptr;
-        mv.da = t + 4 * dd;
-        mv.dH = t + 4 * dd + d;
-        mv.dh = t + 4 * dd + 2 * d;
-        mv.dR = t + 4 * dd + 2 * d + 1;
-        bool okk;
-        {
-            LaunchScope ls(h, "k_reduce_filter<per-step,grad>");
-            okk = h->kt->reduce_filter_ad(false, mv, h->L0, h->n0, h->Fad.E[0], h->stream);
-        }
-        if (!okk) return h->fail(TGP_EUNSUPPORTED, "general-layout gradient kernels are not built for this d");
-        scan_up(h, h->Fad);
-        scan_down(h, h->Fad, h->bx0ad.d() + (size_t)k * 2 * ns);
-        {
-            LaunchScope ls(h, "k_apply_filter<per-step,grad>");
-            (void)h->kt->apply_filter_ad(false, mv, h->L0, h->n0, h->Fad.S[0], h->partial.d(), h->stream);
-        }
-        {
-            LaunchScope ls(h, "k_finalize<grad>");
-            hipLaunchKernelGGL(k_finalize_ad, dim3(1), dim3(256), 0, h->stream, h->partial.d(), nblocks, h->result.d());
-        }
-        if (k + 1 < nparams) {
-            HIPCHK(hipMemcpyAsync(h->host_result, h->result.p, 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-            HIPCHK(hipStreamSynchronize(h->stream));
-            grad_out[k] = h->host_result[3];
-            if (h->host_result[2] != 0.0) rc = h->fail(TGP_ENOTPD, "innovation variance not positive");
-        }
-    }
-    tm.kernels_done();
-    int rc2 = tm.finish(lml_out);
-    grad_out[nparams - 1] = h->host_result[3];
-    return rc != TGP_OK ? rc : rc2;
-}
-
-}  // extern "C"
-
-static unsigned variant_selftest(int device, int d, bool lti_layout) {
-    const int64_t T = 3000;
-    uint64_t st = 0x9E3779B97F4A7C15ull ^ (uint64_t)d;
-    auto rnd = [&]() {   // uniform in (-1, 1)
-        st = st * 6364136223846793005ull + 1442695040888963407ull;
-        return ((double)(st >> 11) / 9007199254740992.0) * 2.0 - 1.0;
-    };
-    const int dd = d * d;
-    std::vector<double> A(T * dd), a(T * d), Q(T * dd), H(T * d), hh(T), R(T), y(T), x0m(d), x0P(dd, 0.0), Rn(T), et(T * d), ee(T), e0(d);
-    for (int64_t t = 0; t < T; ++t) {
-        for (int j = 0; j < d; ++j)
-            for (int i = 0; i < d; ++i) A[t * dd + i + j * d] = (i == j ? 0.6 : 0.0) + 0.25 * rnd() / d;
-        std::vector<double> B(dd);
-        for (auto& v : B) v = 0.4 * rnd();
-        for (int j = 0; j < d; ++j)
-            for (int i = 0; i < d; ++i) {
-                double acc = (i == j) ? 0.3 : 0.0;
-                for (int k = 0; k < d; ++k) acc += B[i + k * d] * B[j + k * d];
-                Q[t * dd + i + j * d] = acc;
-            }
-        for (int i = 0; i < d; ++i) { a[t * d + i] = 0.3 * rnd(); H[t * d + i] = rnd(); et[t * d + i] = rnd(); }
-        hh[t] = 0.2 * rnd(); R[t] = 0.2 + 0.3 * (rnd() + 1.0); y[t] = 2.0 * rnd(); Rn[t] = 0.05 * (rnd() + 1.0); ee[t] = rnd();
-    }
-    for (int i = 0; i < d; ++i) { x0m[i] = rnd(); x0P[i + i * d] = 1.0 + 0.3 * rnd(); e0[i] = rnd(); }
-    std::vector<uint8_t> miss(T, 0);
-    for (int64_t t = 0; t < T; t += 17) miss[t] = 1;
-    // every operation on its own: (return code, outputs) per VariantOp
-    struct OpOut { int rc = TGP_OK; std::vector<double> v; };
-    auto run = [&](int variant, bool lti, OpOut* o) -> int {
-        tgp_handle* h = nullptr;
-        if (tgp_create(&h, device) != TGP_OK) return TGP_EHIP;
-        h->variant_opt = variant;
-        if (variant == 3) h->opt_group = 2;              // the check exercises the group kernels at every d they exist for
-        tgp_set_option(h, TGP_OPT_CHUNK, 4);
-        int rc = tgp_model_set(h, T, d, 1, 0, lti ? TGP_SHARED_ALL : 0u, A.data(), a.data(), Q.data(), H.data(), hh.data(), R.data(), x0m.data(),
-                               x0P.data());
-        if (rc != TGP_OK) { tgp_destroy(h); return rc; }
-        std::vector<double> b1(T * dd), b2(T * dd), b3(T * dd), xm(d), xP(dd);
-        auto push = [&](OpOut& q, const std::vector<double>& v, size_t n) { q.v.insert(q.v.end(), v.begin(), v.begin() + n); };
-        double lp = 0.0;
-        {   // M0: logpdf, with missing data; also at a chunk size with a ragged last IO group
-            OpOut& q = o[kOpM0];
-            q.rc = tgp_logpdf(h, y.data(), miss.data(), 0, &lp); q.v.push_back(lp);
-            tgp_set_option(h, TGP_OPT_CHUNK, 11);
-            if (q.rc == TGP_OK) { q.rc = tgp_logpdf(h, y.data(), nullptr, 0, &lp); q.v.push_back(lp); }
-            tgp_set_option(h, TGP_OPT_CHUNK, 4);
-        }
-        { OpOut& q = o[kOpM1]; q.rc = tgp_filter(h, y.data(), nullptr, 0, b1.data(), b2.data(), &lp); push(q, b1, T * d); push(q, b2, T * dd); q.v.push_back(lp); }
-        {
-            OpOut& q = o[kOpM3];
-            q.rc = tgp_posterior(h, y.data(), nullptr, 0, b1.data(), b2.data(), b3.data(), xm.data(), xP.data());
-            push(q, b1, T * dd); push(q, b2, T * d); push(q, b3, T * dd); push(q, xm, d); push(q, xP, dd);
-        }
-        {   // M2 + smoother: per-step R_new, shared R_new (k_smooth<.., RSTREAM = false>), ragged chunk size
-            OpOut& q = o[kOpM2];
-            q.rc = tgp_posterior_marginals(h, y.data(), miss.data(), Rn.data(), 0, b1.data(), b2.data(), &lp); push(q, b1, T); push(q, b2, T); q.v.push_back(lp);
-            if (q.rc == TGP_OK) { q.rc = tgp_posterior_marginals(h, y.data(), miss.data(), Rn.data(), TGP_SHARED_R, b1.data(), b2.data(), nullptr); push(q, b1, T); push(q, b2, T); }
-            tgp_set_option(h, TGP_OPT_CHUNK, 11);
-            if (q.rc == TGP_OK) { q.rc = tgp_posterior_marginals(h, y.data(), nullptr, Rn.data(), TGP_SHARED_R, b1.data(), b2.data(), nullptr); push(q, b1, T); push(q, b2, T); }
-            tgp_set_option(h, TGP_OPT_CHUNK, 4);
-        }
-        {
-            OpOut& q = o[kOpAffine];
-            q.rc = tgp_marginals(h, 0, b1.data(), b2.data()); push(q, b1, T); push(q, b2, T);
-            if (q.rc == TGP_OK) { q.rc = tgp_rand(h, et.data(), ee.data(), e0.data(), 0, b1.data()); push(q, b1, T); }
-        }
-        if (lti) {
-            OpOut& q = o[kOpGrad];
-            std::vector<double> dA(dd), da(d), dQ(dd), dH(d), dm(d), dP(dd, 0.0);
-            for (auto& v : dA) v = 0.1 * rnd();
-            for (auto& v : dQ) v = 0.0;
-            for (int i = 0; i < d; ++i) { da[i] = 0.1; dH[i] = 0.2; dm[i] = 0.1; dQ[i + i * d] = 0.05; dP[i + i * d] = 0.1; }
-            double dh = 0.1, dR = 1.0, lml = 0.0, g = 0.0;
-            q.rc = tgp_logpdf_grad(h, y.data(), nullptr, 0, 1, dA.data(), da.data(), dQ.data(), dH.data(), &dh, &dR, dm.data(), dP.data(), &lml, &g);
-            q.v.push_back(lml); q.v.push_back(g);
-        }
-        tgp_destroy(h);
-        // The verdict is applied to Reverse-ordered models, vector observations and the production chunk size as well, so
-        // those are checked too: the same series (i) Reverse-ordered at a chunk of 153 steps (what choose_chunk picks at
-        // T = 1e7), (ii) with p = 2 observations per time step (scalar micro-steps, whole time steps per chunk).
-        {
-            tgp_handle* h2 = nullptr;
-            if (tgp_create(&h2, device) != TGP_OK) return TGP_EHIP;
-            h2->variant_opt = variant;
-            if (variant == 3) h2->opt_group = 2;
-            tgp_set_option(h2, TGP_OPT_CHUNK, 153);
-            rc = tgp_model_set(h2, T, d, 1, 1, lti ? TGP_SHARED_ALL : 0u, A.data(), a.data(), Q.data(), H.data(), hh.data(), R.data(), x0m.data(), x0P.data());
-            if (rc == TGP_OK) {
-                OpOut& q0 = o[kOpM0];
-                if (q0.rc == TGP_OK) { q0.rc = tgp_logpdf(h2, y.data(), miss.data(), 0, &lp); q0.v.push_back(lp); }
-                OpOut& q1 = o[kOpM1];
-                if (q1.rc == TGP_OK) { q1.rc = tgp_filter(h2, y.data(), nullptr, 0, b1.data(), b2.data(), &lp); push(q1, b1, T * d); push(q1, b2, T * dd); }
-                OpOut& q4 = o[kOpAffine];
-                if (q4.rc == TGP_OK) { q4.rc = tgp_marginals(h2, 0, b1.data(), b2.data()); push(q4, b1, T); push(q4, b2, T); }
-                if (q4.rc == TGP_OK) { q4.rc = tgp_rand(h2, et.data(), ee.data(), e0.data(), 0, b1.data()); push(q4, b1, T); }
-            }
-            tgp_destroy(h2);
-            if (rc != TGP_OK) return rc;
-        }
-        // General layout: the verdict also covers the PARTLY shared models (run-time branches of the same kernels' loaders that the all-per-step
-        // model above never takes) -- per-step transitions with shared a, H, h and per-step or shared noise: what irregularly spaced GP inputs
-        // produce (tgp_model_set_sde tiles exactly these). Found by scripts/stress_sde.py: the inlined d = 8 build failed such a model
-        // (per-step noise) after passing the all-per-step check.
-        for (int flavour = 0; flavour < (lti ? 0 : 2); ++flavour) {
-            tgp_handle* h4 = nullptr;
-            if (tgp_create(&h4, device) != TGP_OK) return TGP_EHIP;
-            h4->variant_opt = variant;
-            if (variant == 3) h4->opt_group = 2;
-            tgp_set_option(h4, TGP_OPT_CHUNK, flavour == 0 ? 8 : 5);
-            const uint32_t fl = TGP_SHARED_a | TGP_SHARED_H | TGP_SHARED_h | (flavour == 1 ? TGP_SHARED_R : 0u);
-            rc = tgp_model_set(h4, T, d, 1, 0, fl, A.data(), a.data(), Q.data(), H.data(), hh.data(), R.data(), x0m.data(), x0P.data());
-            if (rc == TGP_OK) {
-                std::vector<double> c1(T * dd), c2(T * dd), c3(T * dd);
-                OpOut& q0 = o[kOpM0];
-                if (q0.rc == TGP_OK) { q0.rc = tgp_logpdf(h4, y.data(), flavour == 0 ? nullptr : miss.data(), 0, &lp); q0.v.push_back(lp); }
-                OpOut& q1 = o[kOpM1];
-                if (q1.rc == TGP_OK) { q1.rc = tgp_filter(h4, y.data(), nullptr, 0, c1.data(), c2.data(), &lp); push(q1, c1, T * d); push(q1, c2, T * dd); }
-                OpOut& q2 = o[kOpM2];
-                if (q2.rc == TGP_OK) {
-                    q2.rc = tgp_posterior_marginals(h4, y.data(), flavour == 0 ? miss.data() : nullptr, Rn.data(), TGP_SHARED_R, c1.data(), c2.data(), &lp);
-                    push(q2, c1, T); push(q2, c2, T); q2.v.push_back(lp);
-                }
-                OpOut& q3 = o[kOpM3];
-                if (q3.rc == TGP_OK) {
-                    q3.rc = tgp_posterior(h4, y.data(), nullptr, 0, c1.data(), c2.data(), c3.data(), xm.data(), xP.data());
-                    push(q3, c1, T * dd); push(q3, c2, T * d); push(q3, c3, T * dd);
-                }
-                OpOut& q4 = o[kOpAffine];
-                if (q4.rc == TGP_OK) { q4.rc = tgp_marginals(h4, 0, c1.data(), c2.data()); push(q4, c1, T); push(q4, c2, T); }
-                if (q4.rc == TGP_OK) { q4.rc = tgp_rand(h4, et.data(), ee.data(), e0.data(), 0, c1.data()); push(q4, c1, T); }
-            }
-            tgp_destroy(h4);
-            if (rc != TGP_OK) return rc;
-        }
-        // ... and a model with the STRUCTURE of a sum of Matern terms on (ir)regular inputs -- A_t = exp(F dt_t) per 2 x 2 block, Q_t = Pinf - A_t Pinf A_t',
-        // x0 = the stationary distribution, H picking one coordinate per block, small noise: strongly correlated states, filter elements whose
-        // combination pivots. The benign random model above does not reach those branches: the inlined d = 8 build reproduced it bit for bit and
-        // returned a log-likelihood wrong in the fourth digit for such a model at more than 256 chunks (scripts/stress_sde.py, seed 2).
-        {
-            std::vector<double> Am(T * dd, 0.0), Qm(T * dd, 0.0), Hm(d, 0.0), Pm(dd, 0.0), am(d, 0.0), Rm(T), hm(1, 0.1), xm0(d, 0.0);
-            uint64_t s2 = 0xD1B54A32D192ED03ull ^ (uint64_t)d;
-            auto rnd2 = [&]() { s2 = s2 * 6364136223846793005ull + 1442695040888963407ull; return (double)(s2 >> 11) / 9007199254740992.0; };
-            std::vector<double> lam(d), sig(d);
-            for (int b = 0; 2 * b < d; ++b) { lam[b] = 0.5 + 3.5 * rnd2(); sig[b] = 0.3 + rnd2(); }
-            for (int b = 0; 2 * b < d; ++b) {
-                const int i = 2 * b;
-                Hm[i] = 1.0;
-                Pm[i + i * d] = sig[b];
-                if (i + 1 < d) Pm[(i + 1) + (i + 1) * d] = lam[b] * lam[b] * sig[b];
-            }
-            for (int64_t t = 0; t < T; ++t) {
-                const double tau = lti ? 0.1 : 0.05 + 0.1 * rnd2();
-                double* At = Am.data() + t * dd;
-                double* Qt = Qm.data() + t * dd;
-                for (int b = 0; 2 * b < d; ++b) {
-                    const int i = 2 * b;
-                    const double l = lam[b], e = std::exp(-l * tau);
-                    if (i + 1 < d) {
-                        const double a00 = e * (1.0 + l * tau), a01 = e * tau, a10 = -e * l * l * tau, a11 = e * (1.0 - l * tau);
-                        At[i + i * d] = a00; At[i + (i + 1) * d] = a01; At[(i + 1) + i * d] = a10; At[(i + 1) + (i + 1) * d] = a11;
-                        const double p0 = Pm[i + i * d], p1 = Pm[(i + 1) + (i + 1) * d];
-                        Qt[i + i * d] = p0 - (a00 * a00 * p0 + a01 * a01 * p1);
-                        Qt[(i + 1) + (i + 1) * d] = p1 - (a10 * a10 * p0 + a11 * a11 * p1);
-                        Qt[i + (i + 1) * d] = Qt[(i + 1) + i * d] = -(a00 * a10 * p0 + a01 * a11 * p1);
-                    } else {
-                        At[i + i * d] = e;
-                        Qt[i + i * d] = Pm[i + i * d] * (1.0 - e * e);
-                    }
-                }
-                Rm[t] = 0.02 + 0.3 * rnd2();
-            }
-            for (int chunk : {4, 64}) {
-                tgp_handle* h5 = nullptr;
-                if (tgp_create(&h5, device) != TGP_OK) return TGP_EHIP;
-                h5->variant_opt = variant;
-                if (variant == 3) h5->opt_group = 2;
-                tgp_set_option(h5, TGP_OPT_CHUNK, chunk);
-                const uint32_t fl = lti ? (TGP_SHARED_A | TGP_SHARED_a | TGP_SHARED_Q | TGP_SHARED_H | TGP_SHARED_h) : (TGP_SHARED_a | TGP_SHARED_H | TGP_SHARED_h);
-                rc = tgp_model_set(h5, T, d, 1, 0, fl, Am.data(), am.data(), Qm.data(), Hm.data(), hm.data(), Rm.data(), xm0.data(), Pm.data());
-                if (rc == TGP_OK) {
-                    std::vector<double> c1(T * dd), c2(T * dd), c3(T * dd);
-                    OpOut& q0 = o[kOpM0];
-                    if (q0.rc == TGP_OK) { q0.rc = tgp_logpdf(h5, y.data(), chunk == 4 ? nullptr : miss.data(), 0, &lp); q0.v.push_back(lp); }
-                    OpOut& q1 = o[kOpM1];
-                    if (q1.rc == TGP_OK) { q1.rc = tgp_filter(h5, y.data(), nullptr, 0, c1.data(), c2.data(), &lp); push(q1, c1, T * d); push(q1, c2, T * dd); }
-                    OpOut& q2 = o[kOpM2];
-                    if (q2.rc == TGP_OK) {
-                        q2.rc = tgp_posterior_marginals(h5, y.data(), chunk == 4 ? miss.data() : nullptr, Rn.data(), TGP_SHARED_R, c1.data(), c2.data(), &lp);
-                        push(q2, c1, T); push(q2, c2, T); q2.v.push_back(lp);
-                    }
-                    OpOut& q3 = o[kOpM3];
-                    if (q3.rc == TGP_OK && chunk == 4) {
-                        q3.rc = tgp_posterior(h5, y.data(), nullptr, 0, c1.data(), c2.data(), c3.data(), xm.data(), xP.data());
-                        push(q3, c1, T * dd); push(q3, c2, T * d); push(q3, c3, T * dd);
-                    }
-                    OpOut& q4 = o[kOpAffine];
-                    if (q4.rc == TGP_OK && chunk == 4) { q4.rc = tgp_marginals(h5, 0, c1.data(), c2.data()); push(q4, c1, T); push(q4, c2, T); }
-                    if (q4.rc == TGP_OK && chunk == 4) { q4.rc = tgp_rand(h5, et.data(), ee.data(), e0.data(), 0, c1.data()); push(q4, c1, T); }
-                }
-                tgp_destroy(h5);
-                if (rc != TGP_OK) return rc;
-            }
-        }
-        {
-            const int64_t T2 = T / 2;                      // p = 2: the first 2 T2 scalars of y / R / hh / H rows are the observations
-            tgp_handle* h3 = nullptr;
-            if (tgp_create(&h3, device) != TGP_OK) return TGP_EHIP;
-            h3->variant_opt = variant;
-            if (variant == 3) h3->opt_group = 2;
-            tgp_set_option(h3, TGP_OPT_CHUNK, 154);
-            rc = tgp_model_set(h3, T2, d, 2, 0, lti ? TGP_SHARED_ALL : 0u, A.data(), a.data(), Q.data(), H.data(), hh.data(), R.data(), x0m.data(), x0P.data());
-            if (rc == TGP_OK) {
-                OpOut& q0 = o[kOpM0];
-                if (q0.rc == TGP_OK) { q0.rc = tgp_logpdf(h3, y.data(), miss.data(), 0, &lp); q0.v.push_back(lp); }
-                OpOut& q1 = o[kOpM1];
-                if (q1.rc == TGP_OK) { q1.rc = tgp_filter(h3, y.data(), nullptr, 0, b1.data(), b2.data(), &lp); push(q1, b1, T2 * d); push(q1, b2, T2 * dd); }
-                OpOut& q2 = o[kOpM2];
-                if (q2.rc == TGP_OK) {
-                    q2.rc = tgp_posterior_marginals(h3, y.data(), miss.data(), Rn.data(), 0, b1.data(), b2.data(), &lp);
-                    push(q2, b1, 2 * T2); push(q2, b2, 2 * T2); q2.v.push_back(lp);
-                }
-                OpOut& q3 = o[kOpM3];
-                if (q3.rc == TGP_OK) {
-                    q3.rc = tgp_posterior(h3, y.data(), nullptr, 0, b1.data(), b2.data(), b3.data(), xm.data(), xP.data());
-                    push(q3, b1, T2 * dd); push(q3, b2, T2 * d); push(q3, b3, T2 * dd);
-                }
-            }
-            tgp_destroy(h3);
-            if (rc != TGP_OK) return rc;
-        }
-        return TGP_OK;
-    };
-    OpOut ra[kOpCount], rb[kOpCount], rg[kOpCount];
-    const uint64_t keep = st;
-    const bool have_fast = fast_kernel_table(d) != nullptr;
-    st = keep; const int rca = run(1, lti_layout, ra);
-    st = keep; const int rcb = have_fast ? run(2, lti_layout, rb) : TGP_EUNSUPPORTED;
-    unsigned ok = 0u;
-    if (rca != TGP_OK) return ok;
-    // TGP_SELFTEST_DEBUG=1 (environment): print every comparison of the check (return codes, sizes, first and worst deviation)
-    static const bool dbg = [] { const char* e = std::getenv("TGP_SELFTEST_DEBUG"); return e != nullptr && e[0] == '1'; }();
-    auto same = [&](const OpOut& x, const OpOut& z, const char* what = "") {
-        bool good = x.rc == TGP_OK && z.rc == TGP_OK && x.v.size() == z.v.size();
-        size_t first = 0, nbad = 0;
-        double worst = 0.0;
-        if (good)
-            for (size_t i = 0; i < x.v.size(); ++i)
-                if (!(std::fabs(x.v[i] - z.v[i]) <= 1e-9 * (1.0 + std::fabs(x.v[i])))) {
-                    if (nbad++ == 0) first = i;
-                    const double dv = std::fabs(x.v[i] - z.v[i]);
-                    if (!(dv <= worst)) worst = dv;
-                    if (!dbg) break;
-                }
-        if (dbg)
-            std::fprintf(stderr, "[tgp selftest d=%d %s] %s: rc %d/%d sizes %zu/%zu deviating %zu first at %zu worst %.3e\n", d, lti_layout ? "lti" : "per-step",
-                         what, x.rc, z.rc, x.v.size(), z.v.size(), nbad, first, worst);
-        return good && nbad == 0;
-    };
-    if (kernel_table(d)->group_reduce_filter != nullptr) {   // group-per-chunk kernels against the out-of-line build
-        st = keep;
-        if (run(3, lti_layout, rg) == TGP_OK) {
-            // (general layout: the group-layout block scans then also serve the lane-per-chunk posterior passes -- operation M2 is
-            //  part of the verdict there)
-            if (same(ra[kOpM0], rg[kOpM0], "group logpdf") && (lti_layout || same(ra[kOpM2], rg[kOpM2], "group scans under the posterior passes"))) ok |= 1u << kOpGroup;
-            if (same(ra[kOpM1], rg[kOpM1], "group filter")) ok |= 1u << kOpGroupM1;             // filtering distributions
-            if (same(ra[kOpAffine], rg[kOpAffine], "group marginals / rand")) ok |= 1u << kOpGroupMarg;   // prior marginals and rand, both orderings
-            if (lti_layout) {
-                if (same(ra[kOpM2], rg[kOpM2])) ok |= 1u << kOpGroupAff;     // smoother with the group-layout affine scans
-                if (same(ra[kOpM3], rg[kOpM3])) ok |= 1u << kOpGroupM3;             // materialised posterior
-            }
-        }
-    }
-    if (rcb != TGP_OK) return ok;
-    for (int op = 0; op < kOpCount; ++op) {
-        if (op == kOpGrad && !lti_layout) continue;
-        bool pass = ra[op].rc == TGP_OK && rb[op].rc == TGP_OK && ra[op].v.size() == rb[op].v.size();
-        for (size_t i = 0; pass && i < ra[op].v.size(); ++i) {
-            const double tol = 1e-9 * (1.0 + std::fabs(ra[op].v[i]));
-            if (!(std::fabs(ra[op].v[i] - rb[op].v[i]) <= tol)) pass = false;
-        }
-        if (pass) ok |= 1u << op;
-        if (dbg) std::fprintf(stderr, "[tgp selftest d=%d %s] inlined build, operation %d: %s (rc %d/%d, %zu values)\n", d, lti_layout ? "lti" : "per-step", op,
-                              pass ? "same" : "DIFFERENT", ra[op].rc, rb[op].rc, ra[op].v.size());
-    }
-    if (dbg) std::fprintf(stderr, "[tgp selftest d=%d %s] verdict bits 0x%x\n", d, lti_layout ? "lti" : "per-step", ok);
-    return ok;
-}
-
-// ---- verdict cache on disk ------------------------------------------------------------------------------------------------
-// The known-answer check compares the fast / group kernels with the out-of-line build, and the out-of-line kernels of d >= 8 are
-// slow enough that the first model of such a d costs 5-17 s per process (d = 14: 17 s). Its verdict is a property of this binary
-// on this device, so it is kept in $TGP_CACHE_DIR (default ~/.cache/tgp_hip), keyed by the library file (path, size, mtime), the
-// HIP runtime version and the device name; TGP_NO_CACHE=1 disables both reading and writing. A fresh machine (every CI box) has no
-// cache and runs the check.
-static std::string verdict_cache_key(int device) {
-    Dl_info info{};
-    std::string lib = "?";
-    struct stat st{};
-    long long size = 0, mtime = 0;
-    if (dladdr(reinterpret_cast<const void*>(&verdict_cache_key), &info) != 0 && info.dli_fname != nullptr) {
-        lib = info.dli_fname;
-        if (stat(info.dli_fname, &st) == 0) { size = (long long)st.st_size; mtime = (long long)st.st_mtime; }
-    }
-    hipDeviceProp_t prop{};
-    int rt = 0;
-    (void)hipGetDeviceProperties(&prop, device);
-    (void)hipRuntimeGetVersion(&rt);
-    return lib + "|" + std::to_string(size) + "|" + std::to_string(mtime) + "|" + std::to_string(rt) + "|" + prop.name + "|" + prop.gcnArchName;
-}
-static std::string verdict_cache_path() {
-    const char* off = std::getenv("TGP_NO_CACHE");
-    if (off != nullptr && off[0] == '1') return "";
-    const char* dir = std::getenv("TGP_CACHE_DIR");
-    std::string base;
-    if (dir != nullptr && dir[0] != 0) base = dir;
-    else {
-        const char* home = std::getenv("HOME");
-        if (home == nullptr || home[0] == 0) return "";
-        base = std::string(home) + "/.cache/tgp_hip";
-    }
-    return base;
-}
-static bool verdict_cache_get(int device, int d, bool lti, unsigned& bits) {
-    const std::string dir = verdict_cache_path();
-    if (dir.empty()) return false;
-    FILE* f = std::fopen((dir + "/variant_verdicts.txt").c_str(), "r");
-    if (!f) return false;
-    const std::string key = verdict_cache_key(device);
-    char line[2048];
-    bool found = false;
-    while (std::fgets(line, sizeof line, f)) {
-        std::string l(line);
-        const size_t tab = l.rfind('\t');
-        if (tab == std::string::npos || l.compare(0, tab, key) != 0) continue;
-        int dd = 0, ll = 0;
-        unsigned b = 0;
-        if (std::sscanf(l.c_str() + tab + 1, "%d %d %u", &dd, &ll, &b) == 3 && dd == d && ll == (lti ? 1 : 0)) {
-            bits = b;
-            found = true;            // (keep reading: the last entry wins)
-        }
-    }
-    std::fclose(f);
-    return found;
-}
-static void verdict_cache_put(int device, int d, bool lti, unsigned bits) {
-    const std::string dir = verdict_cache_path();
-    if (dir.empty()) return;
-    (void)mkdir(dir.substr(0, dir.rfind('/')).c_str(), 0755);
-    (void)mkdir(dir.c_str(), 0755);
-    FILE* f = std::fopen((dir + "/variant_verdicts.txt").c_str(), "a");
-    if (!f) return;
-    std::fprintf(f, "%s\t%d %d %u\n", verdict_cache_key(device).c_str(), d, lti ? 1 : 0, bits);
-    std::fclose(f);
-}
-
-static void select_table(tgp_handle* h, int d, bool lti, int variant) {
-    const KernelTable* safe = kernel_table(d);
-    const KernelTable* fast = fast_kernel_table(d);
-    h->ktm = *safe;                 // always a private copy: entries are replaced one by one below
-    h->kt = &h->ktm;
-    h->use_group = false;
-    h->use_group_aff = false;
-    h->use_group_sm = false;
-    h->use_group_marg = false;
-    h->use_group_m1 = h->use_group_m3 = false;
-    h->variant_code = 1;
-    if (variant == 1) return;
-    if (variant == 3) {             // out-of-line build + the group-per-chunk logpdf kernels (used by the check itself)
-        h->use_group = safe->group_reduce_filter != nullptr;
-        h->use_group_aff = h->use_group && lti;
-        h->use_group_sm = h->use_group;                  // (per-step layout: pass 2 MODE 2 + pass 3 in the group layout too)
-        h->use_group_marg = h->use_group;
-        h->use_group_m1 = h->use_group;
-        h->use_group_m3 = h->use_group_aff;
-        return;
-    }
-    if (variant == 2) {
-        if (fast) { merge_tables(safe, fast, kAllOps, h->ktm); h->variant_code = 2; }
-        return;
-    }
-    if (!fast && safe->group_reduce_filter == nullptr) return;
-    unsigned g;
-    {
-        std::lock_guard<std::mutex> lock(g_variant_mutex);
-        unsigned& slot = g_variant[h->device % kMaxVariantDevices][d][lti ? 1 : 0];
-        if (!(slot & (1u << kOpDecided))) {
-            unsigned bits = 0u;
-            if (!verdict_cache_get(h->device, d, lti, bits)) {
-                bits = variant_selftest(h->device, d, lti);
-                if (bits != 0u) verdict_cache_put(h->device, d, lti, bits);      // (an all-zero verdict may be a failed check run: never kept)
-            }
-            slot = bits | (1u << kOpDecided);
-        }
-        g = slot;
-    }
-    unsigned ok = g & kAllOps;
-    if (!lti) ok &= ~(1u << kOpGrad);
-    const unsigned want = lti ? kAllOps : (kAllOps & ~(1u << kOpGrad));
-    if (fast && ok != 0u) {
-        merge_tables(safe, fast, ok, h->ktm);
-        h->variant_code = ok == want ? 2 : 3;
-    }
-    h->use_group = ((g >> kOpGroup) & 1u) != 0u && safe->group_reduce_filter != nullptr;
-    h->use_group_aff = lti && h->use_group && ((g >> kOpGroupAff) & 1u) != 0u;
-    // the same known-answer operation (posterior marginals) exercises both; per-step layout: M2 is part of the kOpGroup verdict
-    h->use_group_sm = lti ? h->use_group_aff : h->use_group;
-    h->use_group_marg = h->use_group && ((g >> kOpGroupMarg) & 1u) != 0u;
-    h->use_group_m1 = h->use_group && ((g >> kOpGroupM1) & 1u) != 0u;
-    h->use_group_m3 = h->use_group_sm && ((g >> kOpGroupM3) & 1u) != 0u;
-}
-
-extern "C" {
-
-int tgp_elem_size(int kind, int d) { return kind == 0 ? felem_size(d) : aelem_size(d); }
-
-int tgp_segment_reduce(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t flags, double* elem_out) {
-    StreamGuard stream_guard_(h);
-    TRY(check_ready(h));
-    TRY(scan_only(h, "tgp_segment_reduce"));
-    if (!elem_out) return h->fail(TGP_EINVAL, "elem_out is NULL");
-    CallTimer tm(h);
-    TRY(set_obs(h, y, missing, flags));
-    tm.inputs_done();
-    TRY(forward_reduce(h, flags));
-    TRY(scan_total_to_host(h, h->F, elem_out));
-    tm.kernels_done();
-    return tm.finish();
-}
-
-// ---- device-resident exchange (include/tgp_hip.h): every phase only ENQUEUES work on the handle's stream
-int tgp_shard_slot_size(int phase, int d) {
-    if (d < 1 || d > 16) return 0;
-    return phase == 0 ? felem_size(d) : aelem_size(d) + state_size(d);
-}
-
-int tgp_shard_reduce(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t flags, double* slot_dev) {
-    StreamGuard stream_guard_(h);
-    TRY(check_ready(h));
-    TRY(scan_only(h, "tgp_shard_reduce"));
-    if (!slot_dev) return h->fail(TGP_EINVAL, "slot_dev is NULL");
-    CallTimer tm(h);                                   // clears the result / flag words for the whole multi-phase call
-    h->fold_valid = false;
-    TRY(set_obs(h, y, missing, flags));
-    TRY(forward_reduce(h, flags));
-    const double* e = nullptr;
-    TRY(scan_total_dev(h, h->F, &e));
-    HIPCHK(hipMemcpyAsync(slot_dev, e, (size_t)h->F.NC * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-    return TGP_OK;
-}
-
-int tgp_shard_fold(tgp_handle* h, const double* gathered_dev, int world, int rank) {
-    StreamGuard stream_guard_(h);
-    TRY(check_ready(h));
-    TRY(scan_only(h, "tgp_shard_fold"));
-    if (!gathered_dev || world < 1 || rank < 0 || rank >= world) return h->fail(TGP_EINVAL, "bad gathered buffer / world / rank");
-    if (!h->reduce_valid) return h->fail(TGP_EINVAL, "tgp_shard_fold needs a preceding tgp_shard_reduce");
-    HIPCHK(h->bx0fold.ensure((size_t)state_size(h->d) * sizeof(double)));
-    {
-        LaunchScope ls(h, "k_fold<filter>");
-        h->kt->fold(kFilter, gathered_dev, felem_size(h->d), 0, rank, 1, h->bx0.d(), h->bx0fold.d(), h->stream);
-    }
-    h->fold_valid = true;
-    return TGP_OK;
-}
-
-int tgp_shard_logpdf(tgp_handle* h, double* stats_dev) {
-    StreamGuard stream_guard_(h);
-    TRY(check_ready(h));
-    TRY(scan_only(h, "tgp_shard_logpdf"));
-    if (!stats_dev) return h->fail(TGP_EINVAL, "stats_dev is NULL");
-    if (!h->fold_valid || !h->reduce_valid) return h->fail(TGP_EINVAL, "tgp_shard_logpdf needs tgp_shard_reduce + tgp_shard_fold first");
-    FilterOut fo{};
-    TRY(forward_apply(h, 0, fo, h->bx0fold.d()));
-    hipLaunchKernelGGL(k_pack_stats, dim3(1), dim3(64), 0, h->stream, h->result.d(), stats_dev);
-    HIPCHK(hipGetLastError());
-    return TGP_OK;
-}
-
-int tgp_shard_smoother_forward(tgp_handle* h, double* slot_dev) {
-    StreamGuard stream_guard_(h);
-    TRY(check_ready(h));
-    TRY(scan_only(h, "tgp_shard_smoother_forward"));
-    if (!slot_dev) return h->fail(TGP_EINVAL, "slot_dev is NULL");
-    if (h->ordering != 0) return h->fail(TGP_EUNSUPPORTED, "posterior of a Reverse-ordered model is not implemented on the device");
-    if (!h->fold_valid || !h->reduce_valid) return h->fail(TGP_EINVAL, "tgp_shard_smoother_forward needs tgp_shard_reduce + tgp_shard_fold first");
-    TRY(smoother_forward_impl(h, TGP_REUSE_REDUCE, h->bx0fold.d()));
-    const double* e = nullptr;
-    TRY(scan_total_dev(h, h->Rv, &e));
-    const size_t na = (size_t)aelem_size(h->d), ns = (size_t)state_size(h->d);
-    HIPCHK(hipMemcpyAsync(slot_dev, e, na * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(slot_dev + na, h->F.fin, ns * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-    return TGP_OK;
-}
-
-int tgp_shard_smoother_backward(tgp_handle* h, const double* gathered_dev, int world, int rank, const double* Rnew, uint32_t flags,
-                                double* mean_out, double* var_out, double* lml_out) {
-    StreamGuard stream_guard_(h);
-    TRY(check_ready(h));
-    TRY(scan_only(h, "tgp_shard_smoother_backward"));
-    if (!h->smoother_valid) return h->fail(TGP_EINVAL, "tgp_shard_smoother_backward needs a preceding tgp_shard_smoother_forward");
-    if (!gathered_dev || world < 1 || rank < 0 || rank >= world) return h->fail(TGP_EINVAL, "bad gathered buffer / world / rank");
-    if (!Rnew || !mean_out || !var_out) return h->fail(TGP_EINVAL, "null Rnew / output");
-    const bool idev = (flags & TGP_IN_DEVICE) != 0, odev = (flags & TGP_OUT_DEVICE) != 0;
-    const bool rshared = (flags & TGP_SHARED_R) != 0;
-    const size_t nT = (size_t)h->T * h->p * sizeof(double);
-    CallTimer tm(h, /*clear=*/false);
-    const void* pR = nullptr;
-    TRY(stage_in(h, h->bRnew, Rnew, rshared ? (size_t)h->p * sizeof(double) : nT, idev, &pR));
-    tm.inputs_done();
-    // x_{T_r | T}: the last rank's final filtered state pulled back through the smoother elements of ranks W-1 .. rank+1
-    const int64_t slot = aelem_size(h->d) + state_size(h->d);
-    HIPCHK(h->bx0r.ensure((size_t)state_size(h->d) * sizeof(double)));
-    {
-        LaunchScope ls(h, "k_fold<smoother>");
-        h->kt->fold(kAffineCov, gathered_dev, slot, world - 1, world - 1 - rank, -1,
-                    gathered_dev + (int64_t)(world - 1) * slot + aelem_size(h->d), h->bx0r.d(), h->stream);
-    }
-    double *dm = nullptr, *dv = nullptr;
-    TRY(stage_out(h, h->bo1, mean_out, nT, odev, &dm));
-    TRY(stage_out(h, h->bo2, var_out, nT, odev, &dv));
-    TRY(smoother_backward_impl(h, h->bx0r.d(), (const double*)pR, rshared ? 0 : 1, dm, dv));
-    tm.kernels_done();
-    TRY(copy_back(h, mean_out, dm, nT, odev));
-    TRY(copy_back(h, var_out, dv, nT, odev));
-    return tm.finish(lml_out);
-}
-
-// ---- time shards on the stationary-gain engine (tgp_steady.hpp: ShardDev) ----------------------------------------------------------------
-int tgp_shard_steady_slot_size(int d) { return tgp_steady::supports(d) ? (int)tgp_steady::shard_slot_size(d) : 0; }
-
-int tgp_shard_steady_begin(tgp_handle* h, const double* y, uint32_t flags, int first, int last, int posterior, double* slot_dev) {
-    StreamGuard stream_guard_(h);
-    TRY(check_ready(h, /*general=*/false));
-    h->shard2_open = false;
-    if (!slot_dev) return h->fail(TGP_EINVAL, "slot_dev is NULL");
-    if (!steady2_eligible(h, nullptr, flags) || h->T <= tgp_steady::kTile)
-        return h->fail(TGP_EUNSUPPORTED, "tgp_shard_steady_begin: not a model / segment of the stationary-gain engine (use the tgp_shard_* protocol of the general engine)");
-    CallTimer tm(h, /*clear=*/false);
-    TRY(set_obs(h, y, nullptr, flags));
-    tgp_steady::ShardDev sd;
-    sd.first = first ? 1 : 0;
-    sd.last = last ? 1 : 0;
-    sd.post = posterior ? 1 : 0;
-    sd.slot = slot_dev;
-    TRY(steady2_enqueue(h, nullptr, false, nullptr, nullptr, false, &sd, 0));
-    h->shard2_first = sd.first;
-    h->shard2_last = sd.last;
-    h->shard2_post = sd.post;
-    h->shard2_open = true;
-    return TGP_OK;
-}
-
-int tgp_shard_steady_finish(tgp_handle* h, const double* gathered_dev, int world, int rank, const double* Rnew, uint32_t flags, double* mean_out,
-                            double* var_out, double* lml_out, int* served) {
-    StreamGuard stream_guard_(h);
-    TRY(check_ready(h, /*general=*/false));
-    if (!h->shard2_open) return h->fail(TGP_EINVAL, "tgp_shard_steady_finish needs a preceding tgp_shard_steady_begin");
-    h->shard2_open = false;
-    if (!gathered_dev || world < 1 || world > 64 || rank < 0 || rank >= world || !served) return h->fail(TGP_EINVAL, "bad gathered buffer / world / rank / served");
-    const bool post = h->shard2_post != 0;
-    if (post && (!Rnew || !mean_out || !var_out)) return h->fail(TGP_EINVAL, "null Rnew / output");
-    const bool idev = (flags & TGP_IN_DEVICE) != 0, odev = (flags & TGP_OUT_DEVICE) != 0;
-    const bool rshared = (flags & TGP_SHARED_R) != 0;
-    const size_t nT = (size_t)h->T * sizeof(double);
-    CallTimer tm(h, /*clear=*/false);
-    tgp_steady::ShardDev sd;
-    sd.first = h->shard2_first;
-    sd.last = h->shard2_last;
-    sd.post = h->shard2_post;
-    sd.gathered = gathered_dev;
-    sd.world = world;
-    sd.rank = rank;
-    const void* pR = nullptr;
-    double *dm = nullptr, *dv = nullptr;
-    if (post) {
-        TRY(stage_in(h, h->bRnew, Rnew, rshared ? sizeof(double) : nT, idev, &pR));
-        TRY(stage_out(h, h->bo1, mean_out, nT, odev, &dm));
-        TRY(stage_out(h, h->bo2, var_out, nT, odev, &dv));
-    }
-    tm.inputs_done();
-    TRY(steady2_enqueue(h, (const double*)pR, !rshared, dm, dv, false, &sd, 1));
-    tm.kernels_done();
-    if (post) {
-        TRY(copy_back(h, mean_out, dm, nT, odev));
-        TRY(copy_back(h, var_out, dv, nT, odev));
-    }
-    TRY(tm.finish(lml_out));
-    *served = h->host_result[6] == tgp_steady::kStatusRan ? 1 : 0;
-    h->reduce_valid = false;
-    h->smoother_valid = false;
-    h->fold_valid = false;
-    return TGP_OK;
-}
-
+#include "tgp_api_grad.inc"      // tgp_logpdf_grad / tgp_logpdf_grad_sde: tangent scans and the dual-number kernels
+#include "tgp_api_cache.inc"      // the verdict cache on disk
+#include "tgp_api_shard.inc"      // time shards: the scan-element exchange of the general engine and of the stationary-gain engine
 int tgp_elem_apply(int kind, int d, const double* elem, const double* m, const double* P, double* m_out, double* P_out) {
     if (!elem || !m || !P || !m_out || !P_out) return TGP_EINVAL;
     const KernelTable* kt = kernel_table(d);
