@@ -141,7 +141,7 @@ def test_wide_posterior_marginals(tgp, d):
 
 def test_wide_posterior_long_series_device_arrays(tgp):
     import torch
-    T = 300_000
+    T = 60_000      # (the dense engine's RTS chain beside it takes 80 us per step)
     model = oc.build_lgssm(KERNELS[28], ("regular", 0.0, 0.1, T), 0.1)
     rng = np.random.default_rng(5)
     y = rng.standard_normal(T) * np.sqrt(float(model["H"][0] @ model["x0P"] @ model["H"][0]) + 0.1)
