@@ -361,7 +361,7 @@ struct tgp_handle {
     DevBuf btau;                  // SDE: tau_k = t_k - t_(k-1), [T] (tau_0 unused: the first transition is explicit)
     int num_cu = 0;
     std::vector<double> hostm;   // host copy of the shared blocks of an LTI model: A | a | Q | H | hh | R (what the host plan reads)
-    std::vector<double> widem;   // the same for a wide LTI model (16 < d <= 63, scalar observations): what tgp_wide's plan reads
+    std::vector<double> widem;   // the same for a wide LTI model (8 < d <= 63, scalar observations): what tgp_wide's plan reads
     tgp_wide::Engine* wide = nullptr;
     int wide_state = 0;          // 0 untried for the bound model, 1 served the last call, -1 does not apply
     int wide_post_state = 0;     // ... its posterior half
@@ -1685,6 +1685,25 @@ int tgp_model_set(tgp_handle* h, int64_t T, int d, int p, int ordering, uint32_t
         }
         if (one_launch_model) h->hostm = h->sweepm;
     }
+    // 9 <= d <= 16 with every block shared: what the wide-state engine's plan reads (tgp_wide.hip; beyond 16 the dense branch above keeps it)
+    h->widem.clear();
+    h->wide_state = 0;
+    h->wide_post_state = 0;
+    {
+        const uint32_t all_shared = TGP_SHARED_A | TGP_SHARED_a | TGP_SHARED_Q | TGP_SHARED_H | TGP_SHARED_h | TGP_SHARED_R;
+        if ((flags & all_shared) == all_shared && p == 1 && ordering == 0 && !h->binding_sde && tgp_wide::supports(d)) {
+            const size_t dd = (size_t)d * d;
+            h->widem.assign(2 * dd + 2 * (size_t)d + 2, 0.0);
+            double* q = h->widem.data();
+            const struct { const double* src; size_t n; } parts[6] = {{A, dd}, {a, (size_t)d}, {Q, dd}, {H, (size_t)d}, {hh, 1}, {R, 1}};
+            size_t off = 0;
+            for (const auto& pt : parts) {
+                if (dev) HIPCHK(hipMemcpy(q + off, pt.src, pt.n * sizeof(double), hipMemcpyDeviceToHost));
+                else std::memcpy(q + off, pt.src, pt.n * sizeof(double));
+                off += pt.n;
+            }
+        }
+    }
     h->have_model = true;
     return TGP_OK;
 }
@@ -1925,6 +1944,11 @@ int tgp_logpdf(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t 
         TRY(sweep_call(h, y, missing, flags, nullptr, nullptr, nullptr, out, &served));
         if (served) return TGP_OK;
     }
+    if (!h->widem.empty() && missing == nullptr && h->opt_chunk == 0 && h->variant_opt == 0 && h->opt_group != 2) {      // wide LTI models (8 < d <= 63): the stationary closed loop across the chip (tgp_wide.hip)
+        bool served = false;
+        TRY(wide_call(h, y, flags, nullptr, nullptr, nullptr, out, &served));
+        if (served) return TGP_OK;
+    }
     resolve_table(h);
     if (graph_eligible(h, flags, false)) {
         const uint64_t key[8] = {1, (uint64_t)(uintptr_t)y, (uint64_t)(uintptr_t)missing, flags, 0, 0, 0, 0};
@@ -1936,11 +1960,6 @@ int tgp_logpdf(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t 
             TRY(forward_apply(h, 0, fo));
             return TGP_OK;
         }, out);
-    }
-    if (h->is_dense && missing == nullptr) {
-        bool served = false;
-        TRY(wide_call(h, y, flags, nullptr, nullptr, nullptr, out, &served));
-        if (served) return TGP_OK;
     }
     CallTimer tm(h);
     TRY(set_obs(h, y, missing, flags));
@@ -2274,6 +2293,11 @@ int tgp_posterior_marginals(tgp_handle* h, const double* y, const uint8_t* missi
         TRY(sweep_call(h, y, missing, flags, Rnew, mean_out, var_out, lml_out, &served));
         if (served) return TGP_OK;
     }
+    if (!h->widem.empty() && missing == nullptr && h->p == 1 && h->opt_chunk == 0 && h->variant_opt == 0 && h->opt_group != 2) {      // wide LTI models: tgp_wide.hip
+        bool served = false;
+        TRY(wide_call(h, y, flags, Rnew, mean_out, var_out, lml_out, &served));
+        if (served) return TGP_OK;
+    }
     resolve_table(h);
     if (graph_eligible(h, flags, true)) {
         const uint64_t key[8] = {2, (uint64_t)(uintptr_t)y, (uint64_t)(uintptr_t)missing, flags, (uint64_t)(uintptr_t)Rnew, (uint64_t)(uintptr_t)mean_out,
@@ -2285,11 +2309,6 @@ int tgp_posterior_marginals(tgp_handle* h, const double* y, const uint8_t* missi
             TRY(smoother_backward_impl(h, h->F.fin, Rnew, rshared ? 0 : 1, mean_out, var_out));
             return TGP_OK;
         }, lml_out);
-    }
-    if (h->is_dense && missing == nullptr && h->p == 1) {      // wide LTI models: the stationary closed loop across the chip (tgp_wide.hip)
-        bool served = false;
-        TRY(wide_call(h, y, flags, Rnew, mean_out, var_out, lml_out, &served));
-        if (served) return TGP_OK;
     }
     CallTimer tm(h);
     const void* pR = nullptr;

@@ -182,7 +182,7 @@ struct RowGeom {      // per lane, the same within a row
     bool valid;
 };
 
-template <int L, bool KEEP>
+template <int L, bool KEEP, int NB>
 __device__ __forceinline__ void fwd_step4(double& yv, double& zlo, double& zhi, const double (&pA)[32], const double (&pB)[32], double kA, double kB, double cA, double cB,
                                           long long t, const RowGeom& g, bool obsB, bool is_obs, double& ssq, double* __restrict__ rout) {
     // (a DPP operand must not be read within two cycles of the VALU write of its register, nor within five of a write to EXEC: the recogniser that
@@ -190,12 +190,14 @@ __device__ __forceinline__ void fwd_step4(double& yv, double& zlo, double& zhi, 
     asm volatile("s_nop 4" : "+v"(zlo), "+v"(zhi), "+v"(yv) : : "memory");
     Acc4 a{{cA, 0.0, 0.0, 0.0}}, b{{cB, 0.0, 0.0, 0.0}};
     fmac_bc<L>(a.v[3], yv, kA);
-    fmac_bc<L>(b.v[3], yv, kB);
     dot16<0>(a, zlo, pA, Seq16{});
-    dot16<0>(b, zlo, pB, Seq16{});
-    dot16<16>(a, zhi, pA, Seq16{});
-    dot16<16>(b, zhi, pB, Seq16{});
-    const double nA = a.sum(), nB = b.sum();
+    if constexpr (NB == 2) {      // (d <= 15: one component per lane, sixteen columns)
+        fmac_bc<L>(b.v[3], yv, kB);
+        dot16<0>(b, zlo, pB, Seq16{});
+        dot16<16>(a, zhi, pA, Seq16{});
+        dot16<16>(b, zhi, pB, Seq16{});
+    }
+    const double nA = a.sum(), nB = NB == 2 ? b.sum() : 0.0;
     const bool live = t < g.s1;
     zlo = live ? nA : zlo;
     zhi = live ? nB : zhi;
@@ -207,13 +209,13 @@ __device__ __forceinline__ void fwd_step4(double& yv, double& zlo, double& zhi, 
         if (is_obs && own) rout[t] = rr;
     }
 }
-template <bool KEEP, int... Ls>
+template <bool KEEP, int NB, int... Ls>
 __device__ __forceinline__ void fwd_block4(double& yv, double& zlo, double& zhi, const double (&pA)[32], const double (&pB)[32], double kA, double kB, double cA, double cB,
                                            long long t0, const RowGeom& g, bool obsB, bool is_obs, double& ssq, double* __restrict__ rout, std::integer_sequence<int, Ls...>) {
-    (fwd_step4<Ls, KEEP>(yv, zlo, zhi, pA, pB, kA, kB, cA, cB, t0 + Ls, g, obsB, is_obs, ssq, rout), ...);
+    (fwd_step4<Ls, KEEP, NB>(yv, zlo, zhi, pA, pB, kA, kB, cA, cB, t0 + Ls, g, obsB, is_obs, ssq, rout), ...);
 }
 
-template <bool KEEP>
+template <bool KEEP, int NB>
 __global__ __launch_bounds__(64) void k_wide_lml4(const double* __restrict__ tab, const double* __restrict__ y, double hh, long long T, long long t_head, long long chunk_len,
                                                    long long halo, long long chunks, int d, ZArg z0, double* __restrict__ part, double* __restrict__ rout) {
     const int lane = threadIdx.x, p = lane & 15, row = lane >> 4;
@@ -229,8 +231,8 @@ __global__ __launch_bounds__(64) void k_wide_lml4(const double* __restrict__ tab
     double pA[32], pB[32];
 #pragma unroll
     for (int j = 0; j < 32; ++j) {
-        pA[j] = tab[(size_t)j * 64 + p];
-        pB[j] = tab[(size_t)j * 64 + 16 + p];
+        pA[j] = j < 16 * NB ? tab[(size_t)j * 64 + p] : 0.0;
+        pB[j] = NB == 2 ? tab[(size_t)j * 64 + 16 + p] : 0.0;
     }
     const double kA = tab[(size_t)32 * 64 + p], kB = tab[(size_t)32 * 64 + 16 + p];
     const double cA = tab[(size_t)33 * 64 + p] - kA * hh, cB = tab[(size_t)33 * 64 + 16 + p] - kB * hh;      // (u = y - hh folded into the constant)
@@ -250,36 +252,39 @@ __global__ __launch_bounds__(64) void k_wide_lml4(const double* __restrict__ tab
     for (long long kb = 0; kb < nmax; kb += 16) {
         double yv = yn;
         yn = (g.w + kb + 16 + p < g.s1) ? y[g.w + kb + 16 + p] : 0.0;      // (the next block: on its way while this one runs)
-        fwd_block4<KEEP>(yv, zlo, zhi, pA, pB, kA, kB, cA, cB, g.w + kb, g, obsB, is_obs, ssq, rout, Seq16{});
+        fwd_block4<KEEP, NB>(yv, zlo, zhi, pA, pB, kA, kB, cA, cB, g.w + kb, g, obsB, is_obs, ssq, rout, Seq16{});
     }
     if (is_obs && g.valid) part[chunk] = ssq;
 }
 
-template <int L>
+template <int L, int NB>
 __device__ __forceinline__ void bwd_step4(double& rv, double& yv, double& zlo, double& zhi, const double (&pA)[32], const double (&pB)[32], double kA, double kB, double yA, double yB,
                                           long long t, const RowGeom& g, bool obsB, bool is_obs, double* __restrict__ mean) {
     asm volatile("s_nop 4" : "+v"(zlo), "+v"(zhi), "+v"(rv), "+v"(yv) : : "memory");
     Acc4 a{{0.0, 0.0, 0.0, 0.0}}, b{{0.0, 0.0, 0.0, 0.0}};
     fmac_bc<L>(a.v[3], rv, kA);
-    fmac_bc<L>(b.v[3], rv, kB);
     fmac_bc<L>(a.v[2], yv, yA);      // (1 at the observer: its sum is the step's mean; its slot of the state multiplies a zero column)
-    fmac_bc<L>(b.v[2], yv, yB);
     dot16<0>(a, zlo, pA, Seq16{});
-    dot16<0>(b, zlo, pB, Seq16{});
-    dot16<16>(a, zhi, pA, Seq16{});
-    dot16<16>(b, zhi, pB, Seq16{});
-    const double nA = a.sum(), nB = b.sum();
+    if constexpr (NB == 2) {
+        fmac_bc<L>(b.v[3], rv, kB);
+        fmac_bc<L>(b.v[2], yv, yB);
+        dot16<0>(b, zlo, pB, Seq16{});
+        dot16<16>(a, zhi, pA, Seq16{});
+        dot16<16>(b, zhi, pB, Seq16{});
+    }
+    const double nA = a.sum(), nB = NB == 2 ? b.sum() : 0.0;
     const bool live = t >= g.s0;
     zlo = live ? nA : zlo;
     zhi = live ? nB : zhi;
     if (is_obs && live && t < g.s1) mean[t] = obsB ? nB : nA;
 }
-template <int... Ls>
+template <int NB, int... Ls>
 __device__ __forceinline__ void bwd_block4(double& rv, double& yv, double& zlo, double& zhi, const double (&pA)[32], const double (&pB)[32], double kA, double kB, double yA, double yB,
                                            long long t0, const RowGeom& g, bool obsB, bool is_obs, double* __restrict__ mean, std::integer_sequence<int, Ls...>) {
-    (bwd_step4<Ls>(rv, yv, zlo, zhi, pA, pB, kA, kB, yA, yB, t0 - Ls, g, obsB, is_obs, mean), ...);
+    (bwd_step4<Ls, NB>(rv, yv, zlo, zhi, pA, pB, kA, kB, yA, yB, t0 - Ls, g, obsB, is_obs, mean), ...);
 }
 
+template <int NB>
 __global__ __launch_bounds__(64) void k_wide_bwd4(const double* __restrict__ tab, const double* __restrict__ y, const double* __restrict__ r, const double* __restrict__ Rnew,
                                                    int rnew_per_step, const double* __restrict__ qtab, long long n1, double vbase, double qinf, long long T, long long t_head,
                                                    long long chunk_len, long long halo, long long chunks, int d, double* __restrict__ mean, double* __restrict__ var,
@@ -297,8 +302,8 @@ __global__ __launch_bounds__(64) void k_wide_bwd4(const double* __restrict__ tab
     double pA[32], pB[32];
 #pragma unroll
     for (int j = 0; j < 32; ++j) {
-        pA[j] = tab[(size_t)j * 64 + p];
-        pB[j] = tab[(size_t)j * 64 + 16 + p];
+        pA[j] = j < 16 * NB ? tab[(size_t)j * 64 + p] : 0.0;
+        pB[j] = NB == 2 ? tab[(size_t)j * 64 + 16 + p] : 0.0;
     }
     const double kA = tab[(size_t)32 * 64 + p], kB = tab[(size_t)32 * 64 + 16 + p];
     const bool obsB = d >= 16, is_obs = p == (d & 15);
@@ -320,7 +325,7 @@ __global__ __launch_bounds__(64) void k_wide_bwd4(const double* __restrict__ tab
         rn = (tl - 16 >= g.s0) ? r[tl - 16] : 0.0;
         const bool mine = tl >= g.s0 && tl < g.s1;
         double yv = mine ? y[tl] : 0.0;
-        bwd_block4(rv, yv, zlo, zhi, pA, pB, kA, kB, yA, yB, top - kb, g, obsB, is_obs, mean, Seq16{});
+        bwd_block4<NB>(rv, yv, zlo, zhi, pA, pB, kA, kB, yA, yB, top - kb, g, obsB, is_obs, mean, Seq16{});
         if (mine) {
             const long long jt = T - 1 - tl;
             const double q = jt < n1 ? qtab[jt] : qinf;
@@ -473,7 +478,7 @@ bool plan(Engine* e, const ModelHost& m, long long T) {
     const size_t dd = (size_t)d * d;
     e->d = d;
     e->dp = d <= 31 ? 32 : 64;
-    e->kname = e->dp == 32 ? (dpp_enabled() ? "k_wide_lml4" : "k_wide_lml<32>") : "k_wide_lml<64>";
+    e->kname = e->dp == 32 ? (dpp_enabled() ? (d <= 15 ? "k_wide_lml4<16>" : "k_wide_lml4") : "k_wide_lml<32>") : "k_wide_lml<64>";
     e->A.assign(dd, 0.0);
     std::vector<double> Q(dd), P(dd), AP(dd), Pp(dd), Pf(dd), v(d);
     for (int i = 0; i < d; ++i)
@@ -794,10 +799,14 @@ int run(Engine* e, hipStream_t stream, const Call& c, double* lml_out, std::stri
     double* rout = post ? e->rbuf : nullptr;
     const bool four = DP == 32 && dpp_enabled();
     const unsigned grid4 = (unsigned)((chunks + 3) / 4);
-    if (four && post)
-        hipLaunchKernelGGL(k_wide_lml4<true>, dim3(grid4), dim3(64), 0, stream, tab_f, c.y, e->hh, T, (long long)n0, e->info.chunk_len, (long long)e->info.halo, chunks, d, z0, part, rout);
-    else if (four)
-        hipLaunchKernelGGL(k_wide_lml4<false>, dim3(grid4), dim3(64), 0, stream, tab_f, c.y, e->hh, T, (long long)n0, e->info.chunk_len, (long long)e->info.halo, chunks, d, z0, part, rout);
+    const bool one = d <= 15;      // one component per lane
+#define TGP_WIDE_LML4(KEEP, NB) \
+    hipLaunchKernelGGL((k_wide_lml4<KEEP, NB>), dim3(grid4), dim3(64), 0, stream, tab_f, c.y, e->hh, T, (long long)n0, e->info.chunk_len, (long long)e->info.halo, chunks, d, z0, part, rout)
+    if (four && post && one) TGP_WIDE_LML4(true, 1);
+    else if (four && post) TGP_WIDE_LML4(true, 2);
+    else if (four && one) TGP_WIDE_LML4(false, 1);
+    else if (four) TGP_WIDE_LML4(false, 2);
+#undef TGP_WIDE_LML4
     else if (DP == 32)
         hipLaunchKernelGGL(k_wide_lml<32>, dim3((unsigned)chunks), dim3(64), 0, stream, tab_f, c.y, e->hh, T, (long long)n0, e->info.chunk_len, (long long)e->info.halo, d, z0, part,
                            rout);
@@ -807,8 +816,11 @@ int run(Engine* e, hipStream_t stream, const Call& c, double* lml_out, std::stri
     rc = hipGetLastError();
     if (rc != hipSuccess) return fail(rc, "launch");
     if (post) {
-        if (four)
-            hipLaunchKernelGGL(k_wide_bwd4, dim3(grid4), dim3(64), 0, stream, tab_b, c.y, e->rbuf, c.Rnew, c.rnew_per_step, qtab_d, (long long)e->info.n1, e->vbase, e->qinf, T,
+        if (four && one)
+            hipLaunchKernelGGL(k_wide_bwd4<1>, dim3(grid4), dim3(64), 0, stream, tab_b, c.y, e->rbuf, c.Rnew, c.rnew_per_step, qtab_d, (long long)e->info.n1, e->vbase, e->qinf, T,
+                               (long long)n0, e->info.chunk_len, (long long)e->info.halo_back, chunks, d, c.mean, c.var, lam);
+        else if (four)
+            hipLaunchKernelGGL(k_wide_bwd4<2>, dim3(grid4), dim3(64), 0, stream, tab_b, c.y, e->rbuf, c.Rnew, c.rnew_per_step, qtab_d, (long long)e->info.n1, e->vbase, e->qinf, T,
                                (long long)n0, e->info.chunk_len, (long long)e->info.halo_back, chunks, d, c.mean, c.var, lam);
         else if (DP == 32)
             hipLaunchKernelGGL(k_wide_bwd<32>, dim3((unsigned)chunks), dim3(64), 0, stream, tab_b, c.y, e->rbuf, c.Rnew, c.rnew_per_step, qtab_d, (long long)e->info.n1, e->vbase,

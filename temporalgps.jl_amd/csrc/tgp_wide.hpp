@@ -1,4 +1,4 @@
-// Stationary-gain engine for WIDE states (16 < d <= 63; round 6): the log marginal likelihood of a Forward LTI model with scalar observations, one
+// Stationary-gain engine for WIDE states (8 < d <= 63; round 6): the log marginal likelihood of a Forward LTI model with scalar observations, one
 // noise variance and no missing data (lgssm.jl:147-165 on the reference's `Fill` layout) across the whole chip -- what the one-launch kernels of
 // tgp_modal.hip do for d <= 8, without a modal form: products of kernels (lti_sde.jl:377-400: ApproxPeriodicKernel() * Matern32Kernel(), d = 28)
 // have defective closed loops, so the recursion runs on the DENSE closed-loop matrix.
@@ -55,7 +55,7 @@ struct Call {      // device pointers; mean == nullptr: logpdf only
 
 Engine* create();
 void destroy(Engine* e);
-inline bool supports(int d) { return d > 16 && d <= kMaxD; }
+inline bool supports(int d) { return d > 8 && d <= kMaxD; }      // (d <= 8: the modal engine's; 9 <= d <= 16 otherwise run the general chunked scan)
 // The plan of model `m` for a series of T steps (kept between calls while the model's blocks and T stand).  false: the engine does not apply (Info::why).
 bool plan(Engine* e, const ModelHost& m, long long T);
 // ... and its posterior half (the backward recursion's matrix, the variances of the series' two ends), built once per planned model.  false: Info::why_post.
