@@ -664,10 +664,42 @@ def other_config_legs(args, torch, tgp, local):
                                               frac=flops / (kms.get("k_wide_lml4", lp_ms) * 1e-3) / 1e12 / 78.6,
                                               note="algorithmic flops 2 d^2 per step over the logpdf kernel's hipEvent duration, against the fp64 vector peak; the kernel "
                                                    "executes (1 + halo / chunk) x 32^2 / 28^2 of them (chunks of 245 steps behind 272 warm-up steps): four chunks per wave, "
-                                                   "the state's components broadcast inside v_fmac_f64_dpp (~12.7 cycles each, measured), DESIGN 4.4"))
+                                                   "the state's components broadcast inside v_fmac_f64_dpp (8-9 cycles each, measured), DESIGN 4.4"))
         del mw, m0, yw, outw
     except Exception as ex:
         legs["wide_d28"] = dict(error=repr(ex))
+    try:
+        # ... and the same engine one component per lane (d <= 15): Matern52Kernel() * Matern52Kernel() (d = 9) at the headline's length
+        from temporalgps_jl_amd import lti_sde as _P
+        T9 = 10_000_000
+        m9 = _P.build_lgssm(_P.to_kernel(("product", ("matern52",), ("matern52",))), _P.RegularSpacing(0.0, 0.1, T9), 0.1)
+        y9 = torch.randn((T9,), dtype=torch.float64, device=f"cuda:{local}")
+        R9 = torch.full((1,), 1e-18, dtype=torch.float64, device=f"cuda:{local}")
+        out9 = (torch.empty_like(y9), torch.empty_like(y9))
+        for _ in range(2):
+            tgp.logpdf(m9, y9)
+            tgp.posterior_marginals(m9, y9, R9, out=out9)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 10
+        for _ in range(n):
+            tgp.logpdf(m9, y9)
+            tgp.posterior_marginals(m9, y9, R9, out=out9)
+        torch.cuda.synchronize()
+        dt9 = (time.perf_counter() - t0) / n
+        h9 = m9.handle()
+        h9.set_option(tgp._lib.OPT_PROFILE, 1)
+        h9.profile_reset()
+        tgp.logpdf(m9, y9)
+        tgp.posterior_marginals(m9, y9, R9, out=out9)
+        k9 = {k: v["total_ms"] / max(1, v["calls"]) for k, v in h9.profile().items()}
+        h9.set_option(tgp._lib.OPT_PROFILE, 0)
+        legs["wide_d9"] = dict(workload=f"Matern52Kernel() * Matern52Kernel() (d = 9), RegularSpacing(0,0.1,T={T9}), the reference's two calls", T=T9, d=9, ms_per_step=dt9 * 1e3,
+                               steps_per_s=T9 / dt9, kernels_ms=k9,
+                               note="rounds 2-5: the general chunked scan's group layout, 10.8 + 53.1 ms (scripts/r06_mid_d_time.py with TGP_WIDE=0)")
+        del m9, y9, out9
+    except Exception as ex:
+        legs["wide_d9"] = dict(error=repr(ex))
     try:
         a5 = copy.copy(args)
         a5.T, a5.steps, a5.warmup, a5.no_cpu_baseline, a5.dense_products = 2000, 1, 1, True, False

@@ -3,6 +3,7 @@
 #   collect_profiles.sh <tag> lti   [workload] [bench args...]   the headline command: bench.py on the stationary-gain engines
 #   collect_profiles.sh <tag> per_step [workload]               the general (per-step) layout: the monoid scan proper
 #   collect_profiles.sh <tag> sweep                              the predict-path legs (sweep engine): scripts/time_sweep.py
+#   collect_profiles.sh <tag> wide                               wide states (tgp_wide.hip): scripts/r06_wide_time.py
 #   collect_profiles.sh <tag> cfg5  [T]                          BASELINE config 5 (dense engine): bench.py --workload cfg5
 # Each class: 1. rocprofv3 --kernel-trace --stats of the command; 2. PMC passes, each in its OWN run with --kernel-trace only (never with
 # --sys-trace etc.: FETCH_SIZE and WRITE_SIZE do not fit one pass), then the SQ issue / stall counters (cfg5: the MFMA busy counter).
@@ -26,6 +27,10 @@ case $CLASS in
   sweep)
     OUT=$ROOT/gpurun_out/prof_${TAG}_sweep; mkdir -p $OUT
     FULL="python $ROOT/scripts/time_sweep.py 1e7 matern52 3"; SHORT="python $ROOT/scripts/time_sweep.py 1e7 matern52 1" ;;
+  wide)
+    OUT=$ROOT/gpurun_out/prof_${TAG}_wide; mkdir -p $OUT
+    FULL="python $ROOT/scripts/r06_wide_time.py 1e6 nodense"; SHORT="$FULL"
+    SQ="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY" ;;
   cfg5)
     T5=${1:-20000}
     OUT=$ROOT/gpurun_out/prof_${TAG}_cfg5; mkdir -p $OUT

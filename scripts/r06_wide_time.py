@@ -12,6 +12,7 @@ from temporalgps_jl_amd import lti_sde as P
 
 L.bind_host_thread(0)
 T = int(float(sys.argv[1])) if len(sys.argv) > 1 else 1_000_000
+NODENSE = len(sys.argv) > 2 and sys.argv[2] == "nodense"      # (profile runs: the wide engine's kernels only)
 SPECS = {
     18: ("product", ("approx_periodic", 3, 1.0), ("matern52",)),
     28: ("product", ("approx_periodic", 7, 1.0), ("matern32",)),
@@ -20,7 +21,7 @@ SPECS = {
 for d, spec in SPECS.items():
     res = {}
     y = torch.randn((T,), dtype=torch.float64, device="cuda:0")
-    for wide in (1, 0):
+    for wide in ((1,) if NODENSE else (1, 0)):
         model = P.build_lgssm(P.to_kernel(spec), P.RegularSpacing(0.0, 0.1, T), 0.1)
         model.handle_options[L.OPT_WIDE] = wide
         hd = model.handle()
@@ -50,6 +51,9 @@ for d, spec in SPECS.items():
                 tgp.posterior_marginals(model, y, Rn, out=out)
             torch.cuda.synchronize()
             print(f"d={d} T={T}: wide posterior marginals {(time.perf_counter() - t0) / 10 * 1e3:.3f} ms per call")
+    if NODENSE:
+        print(f"d={d} T={T}: wide {res[1][0] * 1e3:.3f} ms per call, kernels {res[1][3]}")
+        continue
     (dw, fw, lw, pw), (dd_, fd, ld, pd) = res[1], res[0]
     print(f"d={d} T={T}: wide {dw * 1e3:.3f} ms per call (first call with the plan {fw * 1e3:.2f} ms; kernels {pw}), dense passes {dd_ * 1e3:.1f} ms "
           f"({dict(list(pd.items())[:3])}): x{dd_ / dw:.0f}; logpdf {lw:.6f} vs {ld:.6f} (rel {abs(lw - ld) / abs(ld):.1e})")

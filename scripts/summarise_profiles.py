@@ -28,7 +28,7 @@ if cls in ("lti", "per_step"):
 suf = "" if (cls not in ("lti", "per_step") or wl == "matern52_d3") else "_" + wl
 src = os.path.join(root, "gpurun_out", f"prof_{tag}_{cls}{suf}")
 dst = src if from_box else os.path.join(root, "profiles")
-key = f"d={WL_D.get(wl, 3)}" if cls != "cfg5" else "d=768"
+key = "d=768" if cls == "cfg5" else "d=18,28,42" if cls == "wide" else f"d={WL_D.get(wl, 3)}"
 
 if not from_box:      # the box already summarised: copy what it wrote
     n = 0
@@ -93,6 +93,12 @@ def label(name):
         return "k_steady_setup"
     if re.match(r"tgp_steady::k_final<", n):
         return "k_steady_final"
+    m = re.match(r"tgp_wide::k_wide_(lml|bwd)4<(?:(true|false), )?(\d)>", n)
+    if m:      # four chunks per wave; <16>: one component per lane (d <= 15)
+        return f"k_wide_{m.group(1)}4" + ("<16>" if m.group(3) == "1" else "") + (",keeps r" if m.group(2) == "true" else "")
+    m = re.match(r"tgp_wide::k_wide_(lml|bwd)<(\d+)>", n)
+    if m:
+        return f"k_wide_{m.group(1)}<{m.group(2)}>"
     m = re.match(r"tgp_dense::(dk_\w+)", n)
     if m:
         return m.group(1)

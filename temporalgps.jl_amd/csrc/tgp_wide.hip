@@ -161,7 +161,7 @@ __global__ __launch_bounds__(64) void k_wide_bwd(const double* __restrict__ tab,
 // two matching rows of the matrix; component j reaches the row's lanes as the DPP operand of the multiply-add itself (v_fmac_f64_dpp row_newbcast:j), and
 // so does the step's observation out of the row's block of sixteen.  66 multiply-adds per step and wave for four chunks (the LDS form: 32 and 16 broadcast
 // reads for one).  The table is the LDS kernels' (DP = 32).
-// (measured: ~12.7 cycles per v_fmac_f64_dpp at one wave per SIMD, four accumulator chains or two alike -- 0.187 ms at d = 28, T = 1e6; two 32-bit
+// (measured: 8-9 cycles per v_fmac_f64_dpp at one wave per SIMD, four accumulator chains or two alike -- 0.187 ms at d = 28, T = 1e6; two 32-bit
 //  DPP moves and two plain multiply-adds per component instead run at the full issue rate and come to 0.208 ms; the LDS form 0.36 ms)
 template <int J>
 __device__ __forceinline__ void fmac_bc(double& acc, double src, double mul) {      // acc += (lane J of the row's src) * mul
@@ -174,6 +174,10 @@ struct Acc4 {
 template <int OFF, int... Js>
 __device__ __forceinline__ void dot16(Acc4& a, double z, const double (&phi)[32], std::integer_sequence<int, Js...>) {
     (fmac_bc<Js>(a.v[Js % 4], z, phi[OFF + Js]), ...);
+}
+template <int OFF, int... Js>      // both outputs of the lane against the same sixteen components, their chains interleaved (eight independent accumulators)
+__device__ __forceinline__ void dot16ab(Acc4& a, Acc4& b, double z, const double (&pA)[32], const double (&pB)[32], std::integer_sequence<int, Js...>) {
+    ((fmac_bc<Js>(a.v[Js % 4], z, pA[OFF + Js]), fmac_bc<Js>(b.v[Js % 4], z, pB[OFF + Js])), ...);
 }
 typedef std::make_integer_sequence<int, 16> Seq16;
 
@@ -190,12 +194,12 @@ __device__ __forceinline__ void fwd_step4(double& yv, double& zlo, double& zhi, 
     asm volatile("s_nop 4" : "+v"(zlo), "+v"(zhi), "+v"(yv) : : "memory");
     Acc4 a{{cA, 0.0, 0.0, 0.0}}, b{{cB, 0.0, 0.0, 0.0}};
     fmac_bc<L>(a.v[3], yv, kA);
-    dot16<0>(a, zlo, pA, Seq16{});
-    if constexpr (NB == 2) {      // (d <= 15: one component per lane, sixteen columns)
+    if constexpr (NB == 2) {
         fmac_bc<L>(b.v[3], yv, kB);
-        dot16<0>(b, zlo, pB, Seq16{});
-        dot16<16>(a, zhi, pA, Seq16{});
-        dot16<16>(b, zhi, pB, Seq16{});
+        dot16ab<0>(a, b, zlo, pA, pB, Seq16{});
+        dot16ab<16>(a, b, zhi, pA, pB, Seq16{});
+    } else {      // (d <= 15: one component per lane, sixteen columns)
+        dot16<0>(a, zlo, pA, Seq16{});
     }
     const double nA = a.sum(), nB = NB == 2 ? b.sum() : 0.0;
     const bool live = t < g.s1;
@@ -264,13 +268,13 @@ __device__ __forceinline__ void bwd_step4(double& rv, double& yv, double& zlo, d
     Acc4 a{{0.0, 0.0, 0.0, 0.0}}, b{{0.0, 0.0, 0.0, 0.0}};
     fmac_bc<L>(a.v[3], rv, kA);
     fmac_bc<L>(a.v[2], yv, yA);      // (1 at the observer: its sum is the step's mean; its slot of the state multiplies a zero column)
-    dot16<0>(a, zlo, pA, Seq16{});
     if constexpr (NB == 2) {
         fmac_bc<L>(b.v[3], rv, kB);
         fmac_bc<L>(b.v[2], yv, yB);
-        dot16<0>(b, zlo, pB, Seq16{});
-        dot16<16>(a, zhi, pA, Seq16{});
-        dot16<16>(b, zhi, pB, Seq16{});
+        dot16ab<0>(a, b, zlo, pA, pB, Seq16{});
+        dot16ab<16>(a, b, zhi, pA, pB, Seq16{});
+    } else {
+        dot16<0>(a, zlo, pA, Seq16{});
     }
     const double nA = a.sum(), nB = NB == 2 ? b.sum() : 0.0;
     const bool live = t >= g.s0;
