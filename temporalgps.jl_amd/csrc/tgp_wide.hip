@@ -572,7 +572,16 @@ bool plan(Engine* e, const ModelHost& m, long long T) {
     const long long Tb = T - n0;      // steps behind the head
     if (Tb < 64) return done(kTooShort);
     // chunks: as many waves as the chip holds several times over, none shorter than 64 steps
-    long long chunks = std::min<long long>(kMaxChunks, Tb / 64);
+    // chunks: one wave's worth of them per SIMD (4096) at least -- none shorter than 64 steps --, and more (up to 16384: the stalls of a wave's dependent
+    // DPP multiply-adds are another wave's issue slots) once a chunk is still four halos long: 12 % at T = 1e7 (scripts/r06_mid_d_time.py)
+    static const long long forced_chunks = [] {      // TGP_WIDE_CHUNKS=<n>: development
+        const char* sv = std::getenv("TGP_WIDE_CHUNKS");
+        const long long v = sv ? std::atoll(sv) : 0;
+        return v >= 1 && v <= 65536 ? v : 0ll;
+    }();
+    long long want = std::max<long long>(kMaxChunks, std::min<long long>(4 * (long long)kMaxChunks, Tb / (4 * std::max<long long>(halo, 16))));
+    if (forced_chunks) want = forced_chunks;
+    long long chunks = std::min<long long>(want, Tb / 64);
     long long len = (Tb + chunks - 1) / chunks;
     chunks = (Tb + len - 1) / len;
     e->info.chunks = chunks;
@@ -736,7 +745,7 @@ int run(Engine* e, hipStream_t stream, const Call& c, double* lml_out, std::stri
     const long long T = c.T;
     hipError_t rc;
     if (!e->pinned) {
-        rc = tgp_alloc::host_malloc(reinterpret_cast<void**>(&e->pinned), (size_t)(4 * kHeadMax + 64 + kMaxChunks) * sizeof(double), hipHostMallocDefault);
+        rc = tgp_alloc::host_malloc(reinterpret_cast<void**>(&e->pinned), (size_t)(4 * kHeadMax + 64 + 65536) * sizeof(double), hipHostMallocDefault);
         if (rc != hipSuccess) return fail(rc, "pinned buffer");
     }
     // device tables: forward | backward | qtab

@@ -26,7 +26,7 @@ namespace tgp_wide {
 constexpr int kMaxD = 63;          // (lane d is the observer)
 constexpr int kHeadMax = 8192;     // steps until the covariance recursion must have settled
 constexpr int kTailMax = 8192;     // steps at the series' end whose smoothed variance is still in its transient
-constexpr int kMaxChunks = 4096;
+constexpr int kMaxChunks = 4096;   // (four times as many where the series is long enough: tgp_wide.hip plan)
 
 struct Engine;
 
