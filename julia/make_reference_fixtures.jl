@@ -29,6 +29,11 @@ const CASES = [
     ("cfg4_sum52_12_T200000", Matern52Kernel() + Matern12Kernel(), "sum(matern52,matern12)", 0.0, 0.1, 200_000, 0.1, SArrayStorage(Float64)),
     ("scaled_stretched_T20000", 1.7 * stretched(Matern52Kernel(), 0.6), "scaled(1.7,stretched(0.6,matern52))", -3.0, 0.05, 20_000, 0.3,
      ArrayStorage(Float64)),
+    # wide states (round 6: csrc/tgp_wide.hip -- products of kernels, lti_sde.jl:377-400): d = 9 and d = 28
+    ("wide_prod52_52_T30000", Matern52Kernel() * stretched(Matern52Kernel(), 0.7), "product(matern52,stretched(0.7,matern52))", 0.0, 0.1, 30_000, 0.1,
+     ArrayStorage(Float64)),
+    ("wide_periodic_x_matern32_T30000", ApproxPeriodicKernel() * Matern32Kernel(), "product(approx_periodic(7,1.0),matern32)", 0.0, 0.1, 30_000, 0.1,
+     ArrayStorage(Float64)),
 ]
 
 function main()

@@ -37,8 +37,12 @@ def parse_spec(s):
     parts.append(cur)
     if head == "sum":
         return ("sum",) + tuple(parse_spec(p) for p in parts)
+    if head == "product":
+        return ("product",) + tuple(parse_spec(p) for p in parts)
     if head in ("scaled", "stretched"):
         return (head, float(parts[0]), parse_spec(parts[1]))
+    if head == "approx_periodic":      # approx_periodic(N, r): ApproxPeriodicKernel{N}(; r)
+        return (head, int(parts[0]), float(parts[1]))
     raise ValueError(s)
 
 
@@ -52,6 +56,7 @@ def cases():
 def test_spec_parser():
     assert parse_spec("sum(matern52,stretched(2.0,matern52))") == ("sum", ("matern52",), ("stretched", 2.0, ("matern52",)))
     assert parse_spec("scaled(1.7,stretched(0.6,matern52))") == ("scaled", 1.7, ("stretched", 0.6, ("matern52",)))
+    assert parse_spec("product(approx_periodic(7,1.0),matern32)") == ("product", ("approx_periodic", 7, 1.0), ("matern32",))
 
 
 @needs_file
