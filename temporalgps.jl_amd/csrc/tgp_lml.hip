@@ -2,6 +2,7 @@
 // uniform coefficients through the kernel-argument segment).
 #include "tgp_lml.hpp"
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 
@@ -20,7 +21,7 @@ struct LArgs {
     double wj[N][D];                               // fw' M^j (a row): step j of a lane sees the lane's start state through it
     double WN[D][D];                               // sum_{j < N} w_j' w_j: what a lane's start state adds to its sum of squares
     double Wt[D][D];                               // sum_t w_t' w_t over a run's first tile
-    long long T, nhs, G, R, C;      // G tiles behind the head, R runs of C tiles
+    long long T, nhs, G, W, Chi, Clo;      // G tiles behind the head, W of them whole; a workgroup's waves 0-3 run Chi tiles each, its waves 4-7 Clo
     const double* y;
     double* part;
     double* head_in;
@@ -97,8 +98,14 @@ __global__ __launch_bounds__(kNW * 64, (N == 16 ? 4 : 2)) void k_lml_stream(cons
     double* sPost = reinterpret_cast<double*>(lds_raw + (size_t)kNW * 64 * PPL * 16);      // [kNW][2 + 2 D]: Q, active, V, E per wave
     constexpr int PW = 2 + 2 * D;
 
-    const long long run = (long long)blockIdx.x * kNW + wave;
-    const bool active = run < ka.R;
+    // The run's tiles.  Waves w and w + 4 of a workgroup share a SIMD: the first four run Chi tiles each, the last four Clo (Chi - Clo <= 1), so that
+    // every SIMD of the chip holds Chi + Clo tiles -- with equal runs of three at T = 1e7 the launch was 204 workgroups on 256 CUs, six tiles on the busy
+    // SIMDs and none on a fifth of them; as (3, 2) it is 245 workgroups and five tiles everywhere.  (Dealt out without regard to the SIMDs, runs of
+    // two and three had the three-tile runs end 7 us behind the others.)
+    const long long g0 = (long long)blockIdx.x * 4 * (ka.Chi + ka.Clo) + (wave < 4 ? wave * ka.Chi : 4 * ka.Chi + (wave - 4) * ka.Clo);
+    const long long g1_own = g0 + (wave < 4 ? ka.Chi : ka.Clo);
+    // (a run holds at least one WHOLE tile -- what its first-tile closure sums over -- unless the series is shorter than a tile: one run, one partial tile)
+    const bool active = ka.W > 0 ? (g0 < ka.W && g1_own > g0) : (blockIdx.x == 0 && wave == 0);
     const bool stamp = ka.dbg && wave == 0 && lane == 0 && blockIdx.x < 512;
     if (stamp) ka.part[kStampOff + 8 * blockIdx.x + 0] = (double)wall_clock64();
     // the head's observations to the host, first thing (its forward recursion runs there, beside the kernel)
@@ -127,10 +134,8 @@ __global__ __launch_bounds__(kNW * 64, (N == 16 ? 4 : 2)) void k_lml_stream(cons
 #pragma unroll
     for (int i = 0; i < D; ++i) V[i] = E[i] = 0.0;
     if (active) {
-        // the run's tiles: the G tiles behind the head are dealt out evenly; only the series' last tile can be a partial one
-        // every run holds C tiles (the last one what is left): with 2.4 tiles per wave slot dealt out as 2 or 3, the three-tile runs ended 7 us
-        // behind the two-tile ones and the machine stood half empty meanwhile
-        const long long g0 = run * ka.C, g1 = run == ka.R - 1 ? ka.G : g0 + ka.C;      // (the last run takes what is left, a partial last tile included)
+        // (only the series' last tile can be a partial one: it belongs to the run that holds the last whole tile)
+        const long long g1 = g1_own >= ka.W ? ka.G : g1_own;
         const long long t_lo = ka.nhs + g0 * TILE;
         long long t_hi = ka.nhs + g1 * TILE;
         t_hi = t_hi < ka.T ? t_hi : ka.T;
@@ -509,8 +514,9 @@ int launch(hipStream_t st, const tgp_plan::Modal& md, const Geometry& g, long lo
     a.T = T;
     a.nhs = md.nhs;
     a.G = g.G;
-    a.R = g.R;
-    a.C = g.C;
+    a.W = g.W;
+    a.Chi = g.Chi;
+    a.Clo = g.Clo;
     a.y = y;
     a.part = b.part;
     a.head_in = b.head_in;
@@ -560,12 +566,22 @@ Geometry choose_geometry(const tgp_plan::Modal& md, long long T) {
     if (64 * g.n < md.halo) g.n = 32;      // (a tile must outlast the halo: 2048 >= kHaloMax)
     const long long Tp = T - md.nhs, tile = 64LL * g.n;
     g.G = (Tp + tile - 1) / tile;          // tiles behind the head; the last one may be partial
-    long long R = Tp / tile;               // a run holds at least one WHOLE tile (a partial last tile is its run's second or later), ...
-    if (R < 1) R = 1;                      // ... unless the series is shorter than a tile: one run, one partial tile
-    const long long rmax = (long long)(g.n == 16 ? kMaxWG : kMaxWG / 2) * kNW;      // four (n = 16) or two waves per SIMD: what LDS and registers hold
-    g.C = R <= rmax ? 1 : (R + rmax - 1) / rmax;      // whole tiles per run: equal shares (the last run: what is left of them, and a partial last tile)
-    g.R = (R + g.C - 1) / g.C;
-    g.nwg = (int)((g.R + kNW - 1) / kNW);
+    g.W = Tp / tile;                       // whole tiles: a run holds at least one (a partial last tile is its run's second or later)
+    // tiles per SIMD: the fewest (Chi + Clo) that the workgroups the chip holds at once cover -- four (n = 16) or two waves per SIMD: what LDS and registers
+    // hold -- and two at least (every wave of a workgroup a run: the head's hand-over rides on the last one) once there are tiles for that
+    const long long wgmax = g.n == 16 ? kMaxWG : kMaxWG / 2;
+    long long S = (g.W + 4 * wgmax - 1) / (4 * wgmax);
+    if (S < 2) S = 2;
+    g.Chi = (S + 1) / 2;
+    g.Clo = S / 2;
+    g.nwg = (int)std::max<long long>(1, (g.W + 4 * S - 1) / (4 * S));
+    g.R = 0;      // (runs that hold a tile: what the tests and the debug print report)
+    for (long long b = 0; b < g.nwg; ++b)
+        for (int w = 0; w < kNW; ++w) {
+            const long long g0 = b * 4 * S + (w < 4 ? w * g.Chi : 4 * g.Chi + (w - 4) * g.Clo);
+            g.R += (g.W > 0 ? g0 < g.W : (b == 0 && w == 0)) ? 1 : 0;
+        }
+    g.C = g.Chi;
     g.first_tile = Tp < tile ? Tp : tile;
     return g;
 }

@@ -23,7 +23,8 @@ constexpr int kMaxWG = 512;       // workgroups of a launch at most (n = 16: two
 
 struct Geometry {
     int n = 32;                    // steps per lane (16 or 32)
-    long long G = 0, R = 0, C = 1; // tiles of 64 n steps behind the head (the last one may be partial), runs (one wave each) of C tiles
+    long long G = 0, R = 0, C = 1; // tiles of 64 n steps behind the head (the last one may be partial), runs (one wave each) that hold a tile, C = Chi
+    long long W = 0, Chi = 1, Clo = 1;      // whole tiles; tiles per run of a workgroup's waves 0-3 / 4-7 (waves w and w + 4 share a SIMD)
     int nwg = 0;
     long long first_tile = 0;      // steps of a run's first tile (what Wt sums over)
 };
