@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Randomised check of the wide-state engine (csrc/tgp_wide.hip; 8 < d <= 63): random non-symmetric stable LTI models with offsets and a non-stationary
+x0 (tests/_util.py random_lgssm: the reference's own test models) and random products / sums of kernels, series lengths from a few chunks to 3e5,
+shared or per-step new noise, host or device arrays -- logpdf against the literal restatement (oracle/lgssm_ref.py; 1e-10), posterior marginals against
+the engines the model ran on before (TGP_OPT_WIDE = 0: the general chunked scan up to d = 16, the dense engine beyond; 1e-6: both carry the RTS chain's
+solves against the predicted covariance).  Reports which cases the plan declined.  usage: stress_wide.py [n_cases] [seed]"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import temporalgps_jl_amd as tgp  # noqa: E402
+from oracle import components as oc  # noqa: E402
+from oracle import lgssm_ref as ref  # noqa: E402
+from tests import _util as U  # noqa: E402
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+L = tgp._lib
+LENGTHS = [400, 1000, 2500, 6000, 20_000, 66_000, 300_001]
+BASE = [("matern12",), ("matern32",), ("matern52",), ("approx_periodic", 2, 1.0), ("approx_periodic", 3, 0.7), ("approx_periodic", 5, 1.3)]
+DIMS = [1, 2, 3, 4, 6, 10]
+
+
+def device_model(model, wide):
+    tr = tgp.GaussMarkovModel(tgp.Forward, model["A"], model["a"], model["Q"], tgp.Gaussian(model["x0m"], model["x0P"]))
+    dm = tgp.LGSSM(tr, tgp.ScalarOutputLGC(model["H"], np.atleast_1d(model["h"]), np.atleast_1d(model["R"])), T=model["T"])
+    dm.handle_options[L.OPT_WIDE] = wide
+    return dm
+
+
+bad = served = 0
+for case in range(n_cases):
+    T = int(LENGTHS[rng.integers(len(LENGTHS))])
+    if rng.random() < 0.4:
+        d = int(rng.integers(9, 41))
+        model = U.random_lgssm(rng, False, d, T)
+        what = f"random LTI d={d}"
+    else:
+        while True:
+            i, j = rng.integers(len(BASE), size=2)
+            if 8 < DIMS[i] * DIMS[j] <= 60 and not (BASE[i][0] == "approx_periodic" and BASE[j][0] == "approx_periodic"):
+                break
+        s1, s2 = float(np.exp(rng.normal(0, 0.5))), float(np.exp(rng.normal(0, 0.5)))
+        spec = ("product", ("stretched", s1, BASE[i]), ("stretched", s2, BASE[j]))
+        dt = float(np.exp(rng.uniform(np.log(0.02), np.log(0.5))))
+        model = oc.build_lgssm(spec, ("regular", 0.0, dt, T), float(np.exp(rng.uniform(np.log(1e-3), np.log(1.0)))))
+        d = len(model["x0m"])
+        what = f"{BASE[i]} x {BASE[j]} d={d} dt={dt:.3f}"
+        if rng.random() < 0.3:
+            model["a"] = np.broadcast_to(0.05 * rng.standard_normal(d), np.asarray(model["a"]).shape).copy()
+            model["h"] = np.broadcast_to(np.array(rng.standard_normal()), np.asarray(model["h"]).shape).copy()
+    scale = float(np.sqrt(abs(np.atleast_2d(model["H"])[0] @ model["x0P"] @ np.atleast_2d(model["H"])[0]) + float(np.atleast_1d(model["R"])[0])))
+    y = rng.standard_normal(T) * scale + float(np.atleast_1d(model["h"])[0])
+    Rn = np.exp(rng.normal(-2, 1, size=T)) if rng.random() < 0.3 else np.array([float(np.exp(rng.normal(-2, 1)))])
+    dev = rng.random() < 0.5
+    if dev:
+        import torch
+        yy, RR = torch.from_numpy(y).cuda(), torch.from_numpy(Rn).cuda()
+    else:
+        yy, RR = y, Rn
+    dm1, dm0 = device_model(model, 1), device_model(model, 0)
+    hd = dm1.handle()
+    hd.set_option(L.OPT_PROFILE, 1)
+    hd.profile_reset()
+    lp1, m1, v1 = tgp.logpdf_and_posterior_marginals(dm1, yy, RR)
+    names = list(hd.profile())
+    hd.set_option(L.OPT_PROFILE, 0)
+    lp0, m0, v0 = tgp.logpdf_and_posterior_marginals(dm0, yy, RR)
+    if dev:
+        m1, v1, m0, v0 = (t.cpu().numpy() for t in (m1, v1, m0, v0))
+    wide = any(n.startswith("k_wide") for n in names)
+    served += wide
+    lp_ref = ref.logpdf(model, y) if T <= 6000 else lp0
+    e_lp = abs(lp1 - lp_ref) / abs(lp_ref)
+    e_m = np.max(np.abs(m1 - m0)) / max(1.0, np.abs(m0).max())
+    e_v = np.max(np.abs(v1 - v0)) / max(1.0, v0.max())
+    ok = e_lp <= 1e-10 and e_m <= 1e-6 and e_v <= 1e-6
+    bad += not ok
+    print(f"[{case:3d}] {'ok ' if ok else 'BAD'} {what} T={T} Rn={'T' if Rn.shape[0] > 1 else '1'} {'device' if dev else 'host'}: "
+          f"{'wide engine' if wide else 'DECLINED -> ' + names[0] if names else '?'}  lp {e_lp:.1e} mean {e_m:.1e} var {e_v:.1e}", flush=True)
+print(f"{bad} failing cases of {n_cases} ({served} served by the wide engine)")
+sys.exit(1 if bad else 0)
