@@ -582,9 +582,8 @@ bool plan(Engine* e, const ModelHost& m, long long T) {
     long long want = std::max<long long>(kMaxChunks, std::min<long long>(4 * (long long)kMaxChunks, Tb / (4 * std::max<long long>(halo, 16))));
     if (forced_chunks) want = forced_chunks;
     long long chunks = std::min<long long>(want, Tb / 64);
-    // a slowly mixing closed loop: no chunk shorter than half its warm-up (else the warm-ups are most of the work) -- and a warm-up of a quarter of the
-    // series leaves the engine nothing over the sequential passes
-    if (halo > Tb / 4) return done(kSlowMixing);
+    // a slowly mixing closed loop: no chunk shorter than half its warm-up (else the warm-ups are most of the work; a chunk within `halo` of the head starts
+    // from the head's own end state whatever its length)
     chunks = std::max<long long>(1, std::min<long long>(chunks, Tb / std::max<long long>(64, halo / 2)));
     long long len = (Tb + chunks - 1) / chunks;
     chunks = (Tb + len - 1) / len;
