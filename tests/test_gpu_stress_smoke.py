@@ -25,7 +25,7 @@ SWEEPS = [            # (script, cases, seed)
     ("stress_space_time.py", 12, 19),
     ("stress_pseudo_point.py", 16, 20),
     ("stress_long.py", 5, 21),      # series of 1e6 - 6e6 steps: thousands of workgroups, the sequential head, rand in one launch
-    ("stress_wide.py", 8, 22),      # the wide-state engine (8 < d <= 63): random LTI models and products of kernels against the engines of before
+    ("stress_wide.py", 5, 22),      # the wide-state engine (8 < d <= 63): random LTI models and products of kernels against the engines of before
 ]
 
 

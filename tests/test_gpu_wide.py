@@ -69,9 +69,13 @@ def test_wide_logpdf_against_the_restatement(tgp, d):
         # a second call of the same model keeps the plan; another series, the same answer as the dense engine's sequential pass
         y2 = draw(model, d + T + 1)
         lp2 = tgp.logpdf(dm, y2)
-        dm0 = device_model(tgp, model, wide=0)
-        lp2_dense = tgp.logpdf(dm0, y2)
-        assert abs(lp2 - lp2_dense) <= 1e-10 * abs(lp2_dense), (d, T, lp2, lp2_dense)
+        if d > 16:      # (below: the general engine's code object of that d is 20 s to load; scripts/stress_wide.py compares with it)
+            dm0 = device_model(tgp, model, wide=0)
+            lp2_dense = tgp.logpdf(dm0, y2)
+            assert abs(lp2 - lp2_dense) <= 1e-10 * abs(lp2_dense), (d, T, lp2, lp2_dense)
+        else:
+            lp2_ref = ref.logpdf(model, y2)
+            assert abs(lp2 - lp2_ref) <= 1e-10 * abs(lp2_ref), (d, T, lp2, lp2_ref)
 
 
 def test_wide_logpdf_long_series_device_input(tgp):
