@@ -1603,7 +1603,8 @@ int tgp_model_set(tgp_handle* h, int64_t T, int d, int p, int ordering, uint32_t
         const uint32_t lb = TGP_SHARED_A | TGP_SHARED_a | TGP_SHARED_Q | TGP_SHARED_H | TGP_SHARED_h;
         const bool lti_model = (flags & lb) == lb && !h->binding_sde;     // (tgp_model_set_sde: transitions are per-step whatever the flags of its placeholder blocks say)
         // (what steady2_eligible will ask of the model: such a model's logpdf / posterior-marginals / adjoint calls never touch the table)
-        h->table_pending = h->variant_opt == 0 && h->opt_steady2 && lti_model && p == 1 && (flags & TGP_SHARED_R) && ordering == 0 && tgp_steady::supports(d);
+        h->table_pending = h->variant_opt == 0 && h->opt_steady2 && lti_model && p == 1 && (flags & TGP_SHARED_R) && ordering == 0 &&
+                           (tgp_steady::supports(d) || (tgp_wide::supports(d) && h->opt_wide));      // (... or the wide-state engine's, tgp_wide.hip)
         select_table(h, d, lti_model, h->table_pending ? 1 : h->variant_opt);
         kt = h->kt;
     }
