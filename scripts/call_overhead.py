@@ -12,6 +12,9 @@ import temporalgps_jl_amd as tgp
 from temporalgps_jl_amd import _lib as L
 from temporalgps_jl_amd import lti_sde as P
 
+import os
+if os.environ.get("BIND", "1") != "0":      # (as bench.py does: the process on the GPU's socket; BIND=0 for the A/B)
+    L.bind_host_thread(0)
 T = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10_000_000
 kname = sys.argv[2] if len(sys.argv) > 2 else "matern52"
 dev = "cuda:0"
