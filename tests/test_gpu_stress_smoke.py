@@ -17,7 +17,7 @@ SWEEPS = [            # (script, cases, seed)
     ("stress_modal.py", 40, 11),
     ("stress_steady.py", 24, 12),
     ("stress_general.py", 30, 13),
-    ("stress_general2.py", 20, 14),
+    ("stress_general2.py", 14, 14),
     ("stress_sde.py", 16, 15),
     ("stress_gp_api.py", 24, 16),
     ("stress_multi.py", 16, 17),
