@@ -2,8 +2,9 @@
 """Randomised check of the wide-state engine (csrc/tgp_wide.hip; 8 < d <= 63): random non-symmetric stable LTI models with offsets and a non-stationary
 x0 (tests/_util.py random_lgssm: the reference's own test models) and random products / sums of kernels, series lengths from a few chunks to 3e5,
 shared or per-step new noise, host or device arrays -- logpdf against the literal restatement (oracle/lgssm_ref.py; 1e-10), posterior marginals against
-the engines the model ran on before (TGP_OPT_WIDE = 0: the general chunked scan up to d = 16, the dense engine beyond; 1e-6: both carry the RTS chain's
-solves against the predicted covariance).  Reports which cases the plan declined.  usage: stress_wide.py [n_cases] [seed]"""
+the dense GP on the model's own covariance function where that can be built (1e-8), else against the engines the model ran on before (TGP_OPT_WIDE = 0:
+the general chunked scan up to d = 16, the dense engine beyond; 1e-8 for the well-conditioned random models, 1e-5 for products of kernels, whose RTS
+chain carries solves against predicted covariances of condition 1e10).  Reports which cases the plan declined.  usage: stress_wide.py [n_cases] [seed]"""
 import os
 import sys
 
@@ -74,9 +75,32 @@ for case in range(n_cases):
     served += wide
     lp_ref = ref.logpdf(model, y) if T <= 6000 else lp0
     e_lp = abs(lp1 - lp_ref) / abs(lp_ref)
-    e_m = np.max(np.abs(m1 - m0)) / max(1.0, np.abs(m0).max())
-    e_v = np.max(np.abs(v1 - v0)) / max(1.0, v0.max())
-    ok = e_lp <= 1e-10 and e_m <= 1e-6 and e_v <= 1e-6
+    # The posterior's reference.  Random LTI models are well conditioned: the engine of before at 1e-8 (they agree to 1e-12).  Products of kernels are not:
+    # the RTS chain of the engines of before (and of the literal restatement) solves against predicted covariances of condition 1e10 and stands 1e-7 .. 4e-6
+    # from the truth at d = 30 -- so, where it can be built (T <= 6000, no offsets: x0 stationary), the reference is the dense GP on the model's OWN covariance
+    # function k(s - t) = h' A^|s - t| P_inf h at 1e-8, and the engines of before at 1e-5 elsewhere.
+    gp = what[0] == "(" and T <= 6000 and not np.any(np.asarray(model["a"])) and not np.any(np.asarray(model["h"]))
+    if gp:
+        from scipy.linalg import cho_factor, cho_solve, toeplitz
+        A_, H_, P_, R_ = model["A"][0], model["H"][0], model["x0P"], float(model["R"][0])
+        c, vv = np.empty(T), P_ @ H_
+        for k in range(T):
+            c[k] = H_ @ vv
+            vv = A_ @ vv
+        K = toeplitz(c)
+        cf = cho_factor(K + R_ * np.eye(T), lower=True)
+        m_ref = K @ cho_solve(cf, y)
+        v_ref = np.diag(K) - np.einsum("ij,ji->i", K, cho_solve(cf, K)) + (Rn if Rn.shape[0] > 1 else Rn[0])
+        tol = 1e-8
+    else:
+        m_ref, v_ref = m0, v0
+        tol = 1e-8 if what.startswith("random") else 1e-5
+    e_m = np.max(np.abs(m1 - m_ref)) / max(1.0, np.abs(m_ref).max())
+    e_v = np.max(np.abs(v1 - v_ref)) / max(1.0, v_ref.max())
+    if not wide and what[0] == "(":      # (declined: the engine of before itself, whose RTS chain is what stands 1e-7 .. 4e-6 from the dense GP)
+        tol = 1e-5
+    ok = e_lp <= 1e-10 and e_m <= tol and e_v <= tol
+    what += " [vs dense GP]" if gp else ""
     bad += not ok
     print(f"[{case:3d}] {'ok ' if ok else 'BAD'} {what} T={T} Rn={'T' if Rn.shape[0] > 1 else '1'} {'device' if dev else 'host'}: "
           f"{'wide engine' if wide else 'DECLINED -> ' + names[0] if names else '?'}  lp {e_lp:.1e} mean {e_m:.1e} var {e_v:.1e}", flush=True)
