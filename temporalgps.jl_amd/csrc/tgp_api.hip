@@ -2514,10 +2514,12 @@ __global__ __launch_bounds__(256) void k_fill_marginals(double* __restrict__ mea
 
 static int lti_marginals(tgp_handle* h, double* dm, double* dv, bool* served) {
     *served = false;
-    if (!h->opt_modal || chunk_engine_requested(h) || h->hostm.empty() || h->p != 1 || h->sde) return TGP_OK;
+    // (the shared blocks on the host: `hostm` up to d = 8, `widem` -- the same layout -- for the wide LTI models of 8 < d <= 63, tgp_wide.hip)
+    const std::vector<double>& blocks = !h->hostm.empty() ? h->hostm : h->widem;
+    if (!h->opt_modal || chunk_engine_requested(h) || blocks.empty() || h->p != 1 || h->sde || (h->hostm.empty() && !h->opt_wide)) return TGP_OK;
     const int d = h->d;
     const size_t dd = (size_t)d * d;
-    const double* q = h->hostm.data();
+    const double* q = blocks.data();
     const double *A = q, *a = q + dd, *Q = q + dd + d, *H = q + 2 * dd + d, hh = q[2 * dd + 2 * d], R = q[2 * dd + 2 * d + 1];
     constexpr int kMax = 4096;
     std::vector<double> m(h->x0m), P(dd), Pn(dd), t1(dd), mn(d), tab_m, tab_v;
@@ -2605,7 +2607,7 @@ int tgp_marginals(tgp_handle* h, uint32_t flags, double* mean_out, double* var_o
     if (!mean_out || !var_out) return h->fail(TGP_EINVAL, "null output");
     const bool odev = (flags & TGP_OUT_DEVICE) != 0;
     const size_t nT = (size_t)h->T * h->p * sizeof(double);   // one value per (time step, observation)
-    if (!h->is_dense) {
+    if (!h->is_dense || !h->widem.empty()) {      // (LTI models: the recursion on the host until it settles, one fill kernel)
         double *dm0 = nullptr, *dv0 = nullptr;
         TRY(stage_out(h, h->bo1, mean_out, nT, odev, &dm0));
         TRY(stage_out(h, h->bo2, var_out, nT, odev, &dv0));
@@ -2618,7 +2620,7 @@ int tgp_marginals(tgp_handle* h, uint32_t flags, double* mean_out, double* var_o
             resolve_profile(h);
             return TGP_OK;
         }
-        resolve_table(h);
+        if (!h->is_dense) resolve_table(h);
     }
     CallTimer tm(h);
     tm.inputs_done();

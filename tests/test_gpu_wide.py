@@ -161,3 +161,22 @@ def test_wide_posterior_long_series_device_arrays(tgp):
     mean0, var0 = tgp.posterior_marginals(dm0, yd, Rn)
     assert float((mean - mean0).abs().max()) <= 1e-6 * max(1.0, float(mean0.abs().max()))
     assert float((var - var0).abs().max()) <= 1e-6 * max(1.0, float(var0.max()))
+
+
+@pytest.mark.parametrize("d", (12, 28))
+def test_wide_prior_marginals_settle_on_the_host(tgp, d):
+    """marginals(model) of an LTI prior (lgssm.jl:99-109): the (m, P) recursion on the host until it no longer moves, one fill kernel -- for wide states too
+    (before: the general engine's affine scan up to d = 16, the dense engine's sequential pass beyond)"""
+    rng = np.random.default_rng(d)
+    T = 3000
+    model = oc.build_lgssm(KERNELS[d], ("regular", 0.0, 0.1, T), 0.1)
+    # (a prior that does not start in its stationary state: the recursion has a transient to follow)
+    U = np.linalg.qr(rng.standard_normal((d, d)))[0]
+    model["x0m"] = rng.standard_normal(d)
+    model["x0P"] = (U * (rng.random(d) + 0.5)) @ U.T
+    m_ref, v_ref = ref.marginals(model)
+    m_ref, v_ref = np.asarray(m_ref).reshape(T), np.asarray(v_ref).reshape(T)
+    dm = device_model(tgp, model)
+    (mean, var), names = kernels_of(tgp, dm, lambda: tgp.marginals(dm))
+    assert np.max(np.abs(mean - m_ref)) <= 1e-10 * max(1.0, np.abs(m_ref).max()) and np.max(np.abs(var - v_ref)) <= 1e-10 * max(1.0, v_ref.max())
+    assert names == {"k_fill_marginals<lti>"}, names
