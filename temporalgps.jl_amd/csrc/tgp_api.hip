@@ -365,6 +365,7 @@ struct tgp_handle {
     tgp_wide::Engine* wide = nullptr;
     int wide_state = 0;          // 0 untried for the bound model, 1 served the last call, -1 does not apply
     int wide_post_state = 0;     // ... its posterior half
+    const double* wide_ht = nullptr;      // device: the emission offset per step of such a model (a mean function at the inputs), else null
     int opt_wide = 1;            // TGP_WIDE=0: such models on the dense engine's one-CU passes as before (A/B runs)
     std::vector<double> sweepm;  // the same for every model with shared A, a, Q, H and scalar observations (hh, R: the first step's where they are per step)
     void* steady2_scope = nullptr;
@@ -1578,18 +1579,24 @@ int tgp_model_set(tgp_handle* h, int64_t T, int d, int p, int ordering, uint32_t
         h->wide_state = 0;
         h->wide_post_state = 0;
         {
-            const uint32_t all_shared = TGP_SHARED_A | TGP_SHARED_a | TGP_SHARED_Q | TGP_SHARED_H | TGP_SHARED_h | TGP_SHARED_R;
-            if ((flags & all_shared) == all_shared && p == 1 && ordering == 0 && tgp_wide::supports(d)) {
+            // (every block shared; the emission offset may be per step -- a mean function at the inputs: the gains do not see it)
+            const uint32_t need_shared = TGP_SHARED_A | TGP_SHARED_a | TGP_SHARED_Q | TGP_SHARED_H | TGP_SHARED_R;
+            h->wide_ht = nullptr;
+            if ((flags & need_shared) == need_shared && p == 1 && ordering == 0 && tgp_wide::supports(d)) {
                 const size_t dd = (size_t)d * d;
+                const bool h_per_step = !(flags & TGP_SHARED_h);
                 h->widem.assign(2 * dd + 2 * (size_t)d + 2, 0.0);
                 double* q = h->widem.data();
                 const struct { const double* src; size_t n; } parts[6] = {{A, dd}, {a, (size_t)d}, {Q, dd}, {H, (size_t)d}, {hh, 1}, {R, 1}};
                 size_t off = 0;
-                for (const auto& pt : parts) {
+                for (int k = 0; k < 6; ++k) {
+                    const auto& pt = parts[k];
+                    if (k == 4 && h_per_step) { off += 1; continue; }      // (hh stays 0: the kernels subtract h_t)
                     if (dev) HIPCHK(hipMemcpy(q + off, pt.src, pt.n * sizeof(double), hipMemcpyDeviceToHost));
                     else std::memcpy(q + off, pt.src, pt.n * sizeof(double));
                     off += pt.n;
                 }
+                if (h_per_step) h->wide_ht = static_cast<const double*>(ph);
             }
         }
         h->is_dense = true;
@@ -1691,18 +1698,23 @@ int tgp_model_set(tgp_handle* h, int64_t T, int d, int p, int ordering, uint32_t
     h->wide_state = 0;
     h->wide_post_state = 0;
     {
-        const uint32_t all_shared = TGP_SHARED_A | TGP_SHARED_a | TGP_SHARED_Q | TGP_SHARED_H | TGP_SHARED_h | TGP_SHARED_R;
-        if ((flags & all_shared) == all_shared && p == 1 && ordering == 0 && !h->binding_sde && tgp_wide::supports(d)) {
+        const uint32_t need_shared = TGP_SHARED_A | TGP_SHARED_a | TGP_SHARED_Q | TGP_SHARED_H | TGP_SHARED_R;
+        h->wide_ht = nullptr;
+        if ((flags & need_shared) == need_shared && p == 1 && ordering == 0 && !h->binding_sde && tgp_wide::supports(d)) {
             const size_t dd = (size_t)d * d;
+            const bool h_per_step = !(flags & TGP_SHARED_h);      // (a mean function at the inputs: see the dense branch)
             h->widem.assign(2 * dd + 2 * (size_t)d + 2, 0.0);
             double* q = h->widem.data();
             const struct { const double* src; size_t n; } parts[6] = {{A, dd}, {a, (size_t)d}, {Q, dd}, {H, (size_t)d}, {hh, 1}, {R, 1}};
             size_t off = 0;
-            for (const auto& pt : parts) {
+            for (int k = 0; k < 6; ++k) {
+                const auto& pt = parts[k];
+                if (k == 4 && h_per_step) { off += 1; continue; }
                 if (dev) HIPCHK(hipMemcpy(q + off, pt.src, pt.n * sizeof(double), hipMemcpyDeviceToHost));
                 else std::memcpy(q + off, pt.src, pt.n * sizeof(double));
                 off += pt.n;
             }
+            if (h_per_step) h->wide_ht = h->mv.h;
         }
     }
     h->have_model = true;
@@ -2516,7 +2528,7 @@ static int lti_marginals(tgp_handle* h, double* dm, double* dv, bool* served) {
     *served = false;
     // (the shared blocks on the host: `hostm` up to d = 8, `widem` -- the same layout -- for the wide LTI models of 8 < d <= 63, tgp_wide.hip)
     const std::vector<double>& blocks = !h->hostm.empty() ? h->hostm : h->widem;
-    if (!h->opt_modal || chunk_engine_requested(h) || blocks.empty() || h->p != 1 || h->sde || (h->hostm.empty() && !h->opt_wide)) return TGP_OK;
+    if (!h->opt_modal || chunk_engine_requested(h) || blocks.empty() || h->p != 1 || h->sde || (h->hostm.empty() && (!h->opt_wide || h->wide_ht != nullptr))) return TGP_OK;
     const int d = h->d;
     const size_t dd = (size_t)d * d;
     const double* q = blocks.data();

@@ -36,13 +36,16 @@ __device__ __forceinline__ double readlane_d(double x, int l) {      // l wave-u
 // early from zero, or at the head's end from the head's own end state where that is nearer.
 template <int DP>
 __global__ __launch_bounds__(64) void k_wide_lml(const double* __restrict__ tab, const double* __restrict__ y, double hh, long long T, long long t_head,
-                                                  long long chunk_len, long long halo, int obs_lane, ZArg z0, double* __restrict__ part, double* __restrict__ rout) {
+                                                  long long chunk_len, long long halo, int obs_lane, ZArg z0, double* __restrict__ part, double* __restrict__ rout,
+                                                  const double* __restrict__ ht) {
     __shared__ __attribute__((aligned(16))) double zb[64];
     const int lane = threadIdx.x;
     const long long chunk = blockIdx.x;
     const long long s0 = t_head + chunk * chunk_len;
     long long s1 = s0 + chunk_len;
     if (s1 > T) s1 = T;
+    // (ht: an emission offset PER STEP -- a mean function at the inputs -- instead of the shared hh: the gains do not see it)
+    auto obs = [&](long long t) { return y[t] - (ht != nullptr ? ht[t] : 0.0); };
     const bool from_head = s0 - halo <= t_head;
     const long long w0 = from_head ? t_head : s0 - halo;
     double phi[DP];
@@ -52,10 +55,10 @@ __global__ __launch_bounds__(64) void k_wide_lml(const double* __restrict__ tab,
     zb[lane] = from_head ? z0.z[lane] : 0.0;
     lds_sync();
     double ssq = 0.0;
-    double yn = (w0 + lane < s1) ? y[w0 + lane] : 0.0;
+    double yn = (w0 + lane < s1) ? obs(w0 + lane) : 0.0;
     for (long long tb = w0; tb < s1; tb += 64) {
         const double yv = yn;
-        yn = (tb + 64 + lane < s1) ? y[tb + 64 + lane] : 0.0;      // (the next block's observations: on their way while this block runs)
+        yn = (tb + 64 + lane < s1) ? obs(tb + 64 + lane) : 0.0;      // (the next block's observations: on their way while this block runs)
         const int nb = (int)((s1 - tb < 64) ? (s1 - tb) : 64);
         const bool keep = rout != nullptr && tb + 64 > s0;          // (a posterior call: the innovations of the chunk's own steps go to memory)
         double outr = 0.0;
@@ -221,7 +224,9 @@ __device__ __forceinline__ void fwd_block4(double& yv, double& zlo, double& zhi,
 
 template <bool KEEP, int NB>
 __global__ __launch_bounds__(64) void k_wide_lml4(const double* __restrict__ tab, const double* __restrict__ y, double hh, long long T, long long t_head, long long chunk_len,
-                                                   long long halo, long long chunks, int d, ZArg z0, double* __restrict__ part, double* __restrict__ rout) {
+                                                   long long halo, long long chunks, int d, ZArg z0, double* __restrict__ part, double* __restrict__ rout,
+                                                   const double* __restrict__ ht) {
+    auto obs = [&](long long t) { return y[t] - (ht != nullptr ? ht[t] : 0.0); };      // (see k_wide_lml)
     const int lane = threadIdx.x, p = lane & 15, row = lane >> 4;
     const long long chunk = (long long)blockIdx.x * 4 + row;
     RowGeom g;
@@ -252,10 +257,10 @@ __global__ __launch_bounds__(64) void k_wide_lml4(const double* __restrict__ tab
         nmax = v > nmax ? v : nmax;
     }
     double ssq = 0.0;
-    double yn = (g.w + p < g.s1) ? y[g.w + p] : 0.0;
+    double yn = (g.w + p < g.s1) ? obs(g.w + p) : 0.0;
     for (long long kb = 0; kb < nmax; kb += 16) {
         double yv = yn;
-        yn = (g.w + kb + 16 + p < g.s1) ? y[g.w + kb + 16 + p] : 0.0;      // (the next block: on its way while this one runs)
+        yn = (g.w + kb + 16 + p < g.s1) ? obs(g.w + kb + 16 + p) : 0.0;      // (the next block: on its way while this one runs)
         fwd_block4<KEEP, NB>(yv, zlo, zhi, pA, pB, kA, kB, cA, cB, g.w + kb, g, obsB, is_obs, ssq, rout, Seq16{});
     }
     if (is_obs && g.valid) part[chunk] = ssq;
@@ -748,7 +753,7 @@ int run(Engine* e, hipStream_t stream, const Call& c, double* lml_out, std::stri
     const long long T = c.T;
     hipError_t rc;
     if (!e->pinned) {
-        rc = tgp_alloc::host_malloc(reinterpret_cast<void**>(&e->pinned), (size_t)(4 * kHeadMax + 64 + 65536) * sizeof(double), hipHostMallocDefault);
+        rc = tgp_alloc::host_malloc(reinterpret_cast<void**>(&e->pinned), (size_t)(5 * kHeadMax + 64 + 65536) * sizeof(double), hipHostMallocDefault);
         if (rc != hipSuccess) return fail(rc, "pinned buffer");
     }
     // device tables: forward | backward | qtab
@@ -780,9 +785,10 @@ int run(Engine* e, hipStream_t stream, const Call& c, double* lml_out, std::stri
         if (rc != hipSuccess) return fail(rc, "innovation buffer");
         e->rbuf_cap = (size_t)T * sizeof(double);
     }
-    double *yh = e->pinned, *Rh = yh + kHeadMax, *mh = Rh + kHeadMax, *vh = mh + kHeadMax, *lam = vh + kHeadMax, *part = lam + 64;
+    double *yh = e->pinned, *Rh = yh + kHeadMax, *mh = Rh + kHeadMax, *vh = mh + kHeadMax, *hth = vh + kHeadMax, *lam = hth + kHeadMax, *part = lam + 64;
     rc = hipMemcpyAsync(yh, c.y, (size_t)n0 * sizeof(double), hipMemcpyDeviceToHost, stream);
     if (rc == hipSuccess && post) rc = hipMemcpyAsync(Rh, c.Rnew, (size_t)(c.rnew_per_step ? n0 : 1) * sizeof(double), hipMemcpyDeviceToHost, stream);
+    if (rc == hipSuccess && c.h_t) rc = hipMemcpyAsync(hth, c.h_t, (size_t)n0 * sizeof(double), hipMemcpyDeviceToHost, stream);
     if (rc != hipSuccess) return fail(rc, "head observations");
     rc = hipStreamSynchronize(stream);
     if (rc != hipSuccess) return fail(rc, "head observations");
@@ -795,7 +801,7 @@ int run(Engine* e, hipStream_t stream, const Call& c, double* lml_out, std::stri
     {
         std::vector<double> mcur(e->x0m), mp(d);
         for (int t = 0; t < n0; ++t) {
-            double pred = e->hh;
+            double pred = c.h_t ? hth[t] : e->hh;
             for (int i = 0; i < d; ++i) {
                 double s = e->avec[i];
                 const double* ai = A + (size_t)i * d;
@@ -817,7 +823,7 @@ int run(Engine* e, hipStream_t stream, const Call& c, double* lml_out, std::stri
     const unsigned grid4 = (unsigned)((chunks + 3) / 4);
     const bool one = d <= 15;      // one component per lane
 #define TGP_WIDE_LML4(KEEP, NB) \
-    hipLaunchKernelGGL((k_wide_lml4<KEEP, NB>), dim3(grid4), dim3(64), 0, stream, tab_f, c.y, e->hh, T, (long long)n0, e->info.chunk_len, (long long)e->info.halo, chunks, d, z0, part, rout)
+    hipLaunchKernelGGL((k_wide_lml4<KEEP, NB>), dim3(grid4), dim3(64), 0, stream, tab_f, c.y, e->hh, T, (long long)n0, e->info.chunk_len, (long long)e->info.halo, chunks, d, z0, part, rout, c.h_t)
     if (four && post && one) TGP_WIDE_LML4(true, 1);
     else if (four && post) TGP_WIDE_LML4(true, 2);
     else if (four && one) TGP_WIDE_LML4(false, 1);
@@ -825,10 +831,10 @@ int run(Engine* e, hipStream_t stream, const Call& c, double* lml_out, std::stri
 #undef TGP_WIDE_LML4
     else if (DP == 32)
         hipLaunchKernelGGL(k_wide_lml<32>, dim3((unsigned)chunks), dim3(64), 0, stream, tab_f, c.y, e->hh, T, (long long)n0, e->info.chunk_len, (long long)e->info.halo, d, z0, part,
-                           rout);
+                           rout, c.h_t);
     else
         hipLaunchKernelGGL(k_wide_lml<64>, dim3((unsigned)chunks), dim3(64), 0, stream, tab_f, c.y, e->hh, T, (long long)n0, e->info.chunk_len, (long long)e->info.halo, d, z0, part,
-                           rout);
+                           rout, c.h_t);
     rc = hipGetLastError();
     if (rc != hipSuccess) return fail(rc, "launch");
     if (post) {

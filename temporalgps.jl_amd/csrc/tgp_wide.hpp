@@ -51,6 +51,7 @@ struct Call {      // device pointers; mean == nullptr: logpdf only
     const double* Rnew = nullptr;      // [T] or [1]
     int rnew_per_step = 0;
     double *mean = nullptr, *var = nullptr;
+    const double* h_t = nullptr;       // [T]: an emission offset per step (a mean function at the inputs) in place of ModelHost::hh, which is then 0
 };
 
 Engine* create();

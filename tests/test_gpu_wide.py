@@ -180,3 +180,31 @@ def test_wide_prior_marginals_settle_on_the_host(tgp, d):
     (mean, var), names = kernels_of(tgp, dm, lambda: tgp.marginals(dm))
     assert np.max(np.abs(mean - m_ref)) <= 1e-10 * max(1.0, np.abs(m_ref).max()) and np.max(np.abs(var - v_ref)) <= 1e-10 * max(1.0, v_ref.max())
     assert names == {"k_fill_marginals<lti>"}, names
+
+
+@pytest.mark.parametrize("d", (12, 28, 42))
+def test_wide_model_with_a_mean_function_at_the_inputs(tgp, d):
+    """an emission offset PER STEP (a GP with a mean function on a regular grid: everything else shared): the gains do not see it -- the kernels subtract
+    h_t where they load y_t.  logpdf against the restatement, posterior marginals against the dense GP on y - h (mean + h), prior marginals on the
+    engine of before (the host recursion does not serve a per-step offset)"""
+    rng = np.random.default_rng(100 + d)
+    T = 2500
+    model = oc.build_lgssm(KERNELS[d], ("regular", 0.0, 0.1, T), 0.1)
+    ht = 0.8 * np.sin(0.013 * np.arange(T)) + 0.0004 * np.arange(T) - 0.5
+    y = draw(model, d) + ht
+    model_h = dict(model, h=ht)
+    lp_ref = ref.logpdf(model_h, y)
+    for per_step in (False, True):
+        Rn = rng.random(T) * 0.3 + 0.01 if per_step else np.array([0.05])
+        m_gp, v_gp = dense_gp_posterior(model, y - ht, Rn if per_step else np.full(T, Rn[0]))
+        dm = device_model(tgp, model_h)
+        (lp, mean, var), names = kernels_of(tgp, dm, lambda: tgp.logpdf_and_posterior_marginals(dm, y, Rn))
+        assert abs(lp - lp_ref) <= 1e-10 * abs(lp_ref), (d, lp, lp_ref)
+        assert np.max(np.abs(mean - (m_gp + ht))) <= 1e-8 * max(1.0, np.abs(m_gp).max()) and np.max(np.abs(var - v_gp)) <= 1e-8 * max(1.0, v_gp.max())
+        assert len(names) == 1 and next(iter(names)).startswith("k_wide_lml"), names
+    lp, names = kernels_of(tgp, dm, lambda: tgp.logpdf(dm, y))
+    assert abs(lp - lp_ref) <= 1e-10 * abs(lp_ref) and next(iter(names)).startswith("k_wide_lml"), names
+    m_ref, v_ref = ref.marginals(model_h)
+    (mean, var), names = kernels_of(tgp, dm, lambda: tgp.marginals(dm))
+    assert np.max(np.abs(mean - np.asarray(m_ref).reshape(T))) <= 1e-9 and np.max(np.abs(var - np.asarray(v_ref).reshape(T))) <= 1e-9
+    assert "k_fill_marginals<lti>" not in names, names
