@@ -208,3 +208,39 @@ def test_wide_model_with_a_mean_function_at_the_inputs(tgp, d):
     (mean, var), names = kernels_of(tgp, dm, lambda: tgp.marginals(dm))
     assert np.max(np.abs(mean - np.asarray(m_ref).reshape(T))) <= 1e-9 and np.max(np.abs(var - np.asarray(v_ref).reshape(T))) <= 1e-9
     assert "k_fill_marginals<lti>" not in names, names
+
+
+def test_gp_level_api_on_a_product_kernel(tgp, monkeypatch):
+    """The reference's own call chain (lti_sde.jl:33-68, posterior_lti_sde.jl:18-37) on ApproxPeriodicKernel() * Matern32Kernel(): logpdf(fx, y) and
+    marginals(posterior(fx, y)(x)) bind ONE model whose calls run on the wide engine; values against the dense GP on the kernel itself."""
+    from oracle import dense_gp as dg
+    from temporalgps_jl_amd import lti_sde as P
+    rng = np.random.default_rng(2)
+    T = 1800
+    spec = KERNELS[28]
+    x = P.RegularSpacing(0.0, 0.1, T)
+    f = P.to_sde(P.GP(P.ApproxPeriodicKernel() * P.Matern32Kernel()), P.HIPStorage())
+    fx = f(x, 0.1)
+    built, real = [], P.build_lgssm
+    monkeypatch.setattr(P, "build_lgssm", lambda *a, **k: built.append(real(*a, **k)) or built[-1])
+    y = np.asarray(P.rand(rng, fx))
+    lp = P.logpdf(fx, y)
+    m, sd = P.marginals(P.posterior(fx, y)(x, 1e-9))
+    models = [b for b in built if b.T == T]
+    assert models and all(b.dim == 28 for b in models)
+    hd = models[-1].handle()
+    hd.set_option(tgp._lib.OPT_PROFILE, 1)
+    hd.profile_reset()
+    m2, sd2 = P.marginals(P.posterior(fx, y)(x, 1e-9))
+    names = set()
+    for b in built:
+        if b.T == T and b._handle is not None:
+            names |= set(b.handle().profile())
+    assert any(n.startswith("k_wide_lml") for n in names), names
+    xs = x.collect()
+    lp_d = dg.logpdf(spec, xs, 0.1, y)
+    md, vd = dg.posterior_marginals(spec, xs, 0.1, y, xs, 1e-9)
+    # (ApproxPeriodicKernel{7} approximates the periodic kernel the dense GP is built on to ~1e-7: test/gp/lti_sde.jl:113-116, tests/test_gpu_parity.py)
+    assert abs(lp - lp_d) <= 1e-5 * abs(lp_d), (lp, lp_d)
+    assert np.max(np.abs(np.asarray(m) - md)) <= 1e-4 and np.max(np.abs(np.asarray(sd) ** 2 - vd)) <= 1e-4
+    np.testing.assert_array_equal(np.asarray(m), np.asarray(m2))
