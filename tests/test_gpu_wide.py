@@ -221,22 +221,24 @@ def test_gp_level_api_on_a_product_kernel(tgp, monkeypatch):
     x = P.RegularSpacing(0.0, 0.1, T)
     f = P.to_sde(P.GP(P.ApproxPeriodicKernel() * P.Matern32Kernel()), P.HIPStorage())
     fx = f(x, 0.1)
-    built, real = [], P.build_lgssm
-    monkeypatch.setattr(P, "build_lgssm", lambda *a, **k: built.append(real(*a, **k)) or built[-1])
     y = np.asarray(P.rand(rng, fx))
+    built, real = [], P.build_lgssm
+
+    def profiled(*a, **k):      # (every model the API binds from here on records its kernels)
+        mdl = real(*a, **k)
+        mdl.handle_options[tgp._lib.OPT_PROFILE] = 1
+        built.append(mdl)
+        return mdl
+    monkeypatch.setattr(P, "build_lgssm", profiled)
     lp = P.logpdf(fx, y)
     m, sd = P.marginals(P.posterior(fx, y)(x, 1e-9))
-    models = [b for b in built if b.T == T]
-    assert models and all(b.dim == 28 for b in models)
-    hd = models[-1].handle()
-    hd.set_option(tgp._lib.OPT_PROFILE, 1)
-    hd.profile_reset()
     m2, sd2 = P.marginals(P.posterior(fx, y)(x, 1e-9))
+    assert built and all(b.dim == 28 and b.T == T for b in built)
     names = set()
     for b in built:
-        if b.T == T and b._handle is not None:
+        if b._handle is not None:
             names |= set(b.handle().profile())
-    assert any(n.startswith("k_wide_lml") for n in names), names
+    assert names and all(n.startswith("k_wide_lml") for n in names), names
     xs = x.collect()
     lp_d = dg.logpdf(spec, xs, 0.1, y)
     md, vd = dg.posterior_marginals(spec, xs, 0.1, y, xs, 1e-9)
