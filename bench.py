@@ -820,8 +820,10 @@ def run_engine_factory(args, world, rank):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    # (defaults: 200 timed steps behind 50 untimed ones -- 22 ms of headline work; the first tens of milliseconds after an idle spell run at lower clocks:
+    #  20 steps behind 3 read 0.109 - 0.111 ms per step where 400 behind 400 read 0.106 on the same box)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--T", type=int, default=None, help="series length (default: 1e7 on one GPU, 1e8 for the N > 1 strong-scaling series, 1e5 for cfg5)")
     ap.add_argument("--workload", default=None, choices=list(WORKLOADS) + ["cfg5"])
     ap.add_argument("--layout", default="lti", choices=["lti", "per_step"])
