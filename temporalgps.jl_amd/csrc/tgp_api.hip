@@ -2681,8 +2681,38 @@ int tgp_rand(tgp_handle* h, const double* eps_t, const double* eps_e, const doub
     }
     // LTI, Forward, scalar observations, d <= 6: ONE kernel over the draws on the dense powers of the transition (tgp_modal::rand_lti)
     const bool rand_one = !chunk_engine_requested(h) && !h->is_dense && h->opt_modal && h->lti && h->p == 1 && h->ordering == 0 && !h->sde && d <= tgp_plan::kRandMaxD && !h->hostm.empty();
-    if (!rand_one) resolve_table(h);      // (the general engine's kernel choice -- seconds on a machine without a cached verdict -- is not part of the call's time)
+    // ... wide LTI models (8 < d <= 63, tgp_wide.hip): ONE kernel on the open loop, chunks warmed up on the same draws
+    const bool rand_wide = !rand_one && !chunk_engine_requested(h) && h->opt_group != 2 && h->opt_modal && h->opt_wide && !h->widem.empty() && h->wide_ht == nullptr &&
+                           h->p == 1 && h->ordering == 0;
+    if (!rand_one && !rand_wide) resolve_table(h);      // (the general engine's kernel choice -- seconds on a machine without a cached verdict -- is not part of the call's time)
     CallTimer tm(h);
+    if (rand_wide) {
+        if (!h->wide) h->wide = tgp_wide::create();
+        const size_t dd = (size_t)d * d;
+        const double* q = h->widem.data();
+        tgp_wide::ModelHost mh;
+        mh.d = d;
+        mh.A = q; mh.a = q + dd; mh.Q = q + dd + d; mh.H = q + 2 * dd + d; mh.hh = q[2 * dd + 2 * d]; mh.R = q[2 * dd + 2 * d + 1];
+        mh.x0m = h->x0m.data();
+        mh.x0P = h->x0P.data();
+        const void *pet = nullptr, *pee = nullptr;
+        TRY(stage_in(h, h->beps_t, eps_t, (size_t)h->T * d * sizeof(double), idev, &pet));
+        TRY(stage_in(h, h->beps_e, eps_e, nT, idev, &pee));
+        tm.inputs_done();
+        double* dy = nullptr;
+        TRY(stage_out(h, h->bo1, y_out, nT, odev, &dy));
+        bool declined = true;
+        std::string err;
+        {
+            LaunchScope ls(h, "k_wide_rand");
+            if (tgp_wide::rand(h->wide, h->stream, mh, h->T, x0.data(), (const double*)pet, (const double*)pee, dy, &declined, &err) != 0) return h->fail(TGP_EHIP, err);
+        }
+        if (!declined) {
+            tm.kernels_done();
+            TRY(copy_back(h, y_out, dy, nT, odev));
+            return tm.finish();
+        }
+    }
     if (rand_one) {
         tgp_plan::ModelHost mh;
         tgp_plan::RandPlan rp;

@@ -347,6 +347,80 @@ __global__ __launch_bounds__(64) void k_wide_bwd4(const double* __restrict__ tab
     }
 }
 
+// ---- rand (lgssm.jl:65-91 with the draws supplied): x_t = A x_(t-1) + a + U' eps_t (U = chol(Q + 1e-9 I), lgc.jl:84-87), y_t = h . x_t + hh + sqrt(R) e_t
+// (lgc.jl:241-243).  The same shape as k_wide_lml -- a lane per component, the state round an LDS line -- with a second line for the step's draws; the
+// open loop A forgets a state as the closed loop does, so a chunk warms up `halo` steps early from zero ON THE SAME DRAWS.  tab: [2 DP + 1][64] -- columns
+// of the lanes' rows of A (observer, lane d: g = A' h), of U' (observer: U h), then the constants (a_i; observer: h . a + hh).
+template <int DP>
+__global__ __launch_bounds__(64) void k_wide_rand(const double* __restrict__ tab, const double* __restrict__ eps_t, const double* __restrict__ eps_e, double sqrtR,
+                                                   long long T, long long chunk_len, long long halo, int obs_lane, int d, ZArg x0, double* __restrict__ y_out) {
+    __shared__ __attribute__((aligned(16))) double zb[64];
+    __shared__ __attribute__((aligned(16))) double eb[4][64];
+    const int lane = threadIdx.x;
+    const long long chunk = blockIdx.x;
+    const long long s0 = chunk * chunk_len;
+    long long s1 = s0 + chunk_len;
+    if (s1 > T) s1 = T;
+    const bool from_start = s0 - halo <= 0;
+    const long long w0 = from_start ? 0 : s0 - halo;
+    double pa[DP], pu[DP];
+#pragma unroll
+    for (int j = 0; j < DP; ++j) {
+        pa[j] = tab[(size_t)j * 64 + lane];
+        pu[j] = tab[(size_t)(DP + j) * 64 + lane];
+    }
+    const double cin = tab[(size_t)(2 * DP) * 64 + lane];
+    zb[lane] = from_start ? x0.z[lane] : 0.0;
+    lds_sync();
+    auto draw = [&](long long t) { return (lane < d && t < s1) ? eps_t[t * d + lane] : 0.0; };
+    // the draws of four steps ahead are on their way while a step runs
+    double e0 = draw(w0), e1 = draw(w0 + 1), e2 = draw(w0 + 2), e3 = draw(w0 + 3);
+    double outy = 0.0;
+    for (long long t4 = w0; t4 < s1; t4 += 4) {
+        eb[0][lane] = e0;
+        eb[1][lane] = e1;
+        eb[2][lane] = e2;
+        eb[3][lane] = e3;
+        e0 = draw(t4 + 4);
+        e1 = draw(t4 + 5);
+        e2 = draw(t4 + 6);
+        e3 = draw(t4 + 7);
+        lds_sync();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const long long t = t4 + k;
+            if (t < s1) {      // (wave-uniform)
+                double a0 = cin, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+                for (int j = 0; j < DP; j += 4) {
+                    const v2d q0 = *reinterpret_cast<const v2d*>(&zb[j]), q1 = *reinterpret_cast<const v2d*>(&zb[j + 2]);
+                    const v2d r0 = *reinterpret_cast<const v2d*>(&eb[k][j]), r1 = *reinterpret_cast<const v2d*>(&eb[k][j + 2]);
+                    a0 = fma(pa[j], q0.x, a0);
+                    a1 = fma(pa[j + 1], q0.y, a1);
+                    a2 = fma(pa[j + 2], q1.x, a2);
+                    a3 = fma(pa[j + 3], q1.y, a3);
+                    a0 = fma(pu[j], r0.x, a0);
+                    a1 = fma(pu[j + 1], r0.y, a1);
+                    a2 = fma(pu[j + 2], r1.x, a2);
+                    a3 = fma(pu[j + 3], r1.y, a3);
+                }
+                const double acc = (a0 + a1) + (a2 + a3);
+                lds_sync();
+                zb[lane] = acc;
+                lds_sync();
+                if (t >= s0) {
+                    const double yy = readlane_d(acc, obs_lane);
+                    outy = lane == (int)((t - s0) & 63) ? yy : outy;
+                    if (((t - s0) & 63) == 63 || t == s1 - 1) {      // (a block of up to 64 emissions: one coalesced store)
+                        const long long tb = t - ((t - s0) & 63), tl = tb + lane;
+                        if (tl <= t) y_out[tl] = outy + sqrtR * eps_e[tl];
+                    }
+                }
+            }
+        }
+    }
+}
+
 // ---- host: small dense linear algebra, row-major ---------------------------------------------------------------------------------------
 void matmul(int d, const double* X, const double* Y, double* Z) {      // Z = X Y
     for (int i = 0; i < d; ++i) {
@@ -397,6 +471,8 @@ struct Engine {
     double* pinned = nullptr;              // [kHeadMax] head y | [kHeadMax] head Rnew | [kHeadMax] head means | [kHeadMax] head vars | [64] lam | [kMaxChunks] sums
     std::vector<double> head_r;
     const char* kname = "k_wide_lml<32>";
+    double* rand_dev = nullptr;           // device: k_wide_rand's table
+    size_t rand_cap = 0;
 };
 
 namespace {
@@ -413,6 +489,7 @@ void destroy(Engine* e) {
     if (!e) return;
     if (e->dev) (void)tgp_alloc::dev_free(e->dev);
     if (e->rbuf) (void)tgp_alloc::dev_free(e->rbuf);
+    if (e->rand_dev) (void)tgp_alloc::dev_free(e->rand_dev);
     if (e->pinned) (void)tgp_alloc::host_free(e->pinned);
     delete e;
 }
@@ -886,6 +963,84 @@ int run(Engine* e, hipStream_t stream, const Call& c, double* lml_out, std::stri
     for (long long k = 0; k < chunks; ++k) ssq += part[k];
     const double kLog2Pi = 1.8378770664093454835606594728112;
     *lml_out = -0.5 * ((double)T * kLog2Pi + e->sum_logS_head + (double)(T - n0) * std::log(e->Sss) + quad + ssq / e->Sss);
+    return 0;
+}
+
+int rand(Engine* e, hipStream_t stream, const ModelHost& m, long long T, const double* x0_host, const double* eps_t, const double* eps_e, double* y_out, bool* declined,
+         std::string* err) {
+    *declined = true;
+    auto fail = [&](hipError_t rc, const char* what) {
+        if (err) *err = std::string("tgp_wide: ") + what + ": " + hipGetErrorString(rc);
+        return (int)rc;
+    };
+    static const bool cpu_ok = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma");
+    const int d = m.d;
+    if (!cpu_ok || !supports(d) || T < 256) return 0;
+    const size_t dd = (size_t)d * d;
+    const int DP = d <= 31 ? 32 : 64;
+    // row-major A; U = chol(Q + 1e-9 I) (upper, row-major); the open loop's halo
+    std::vector<double> A(dd), U(dd, 0.0);
+    for (int i = 0; i < d; ++i)
+        for (int k = 0; k < d; ++k) A[(size_t)i * d + k] = m.A[i + (size_t)k * d];
+    for (int j = 0; j < d; ++j)
+        for (int i = 0; i <= j; ++i) {
+            double acc = 0.5 * (m.Q[i + (size_t)j * d] + m.Q[j + (size_t)i * d]) + (i == j ? 1e-9 : 0.0);
+            for (int k = 0; k < i; ++k) acc -= U[(size_t)k * d + i] * U[(size_t)k * d + j];
+            if (i == j) {
+                if (!(acc > 0.0)) return 0;      // (not positive definite: the engines of before report it)
+                U[(size_t)j * d + j] = std::sqrt(acc);
+            } else {
+                U[(size_t)i * d + j] = acc / U[(size_t)i * d + i];
+            }
+        }
+    const long long halo = halo_of(d, A);
+    if (halo < 0 || halo > T / 4) return 0;      // (an open loop that does not forget -- ApproxPeriodicKernel() alone: |lambda| = 1 -- or hardly)
+    long long chunks = std::min<long long>(kMaxChunks, std::max<long long>(1, T / std::max<long long>(64, halo / 2)));
+    const long long len = (T + chunks - 1) / chunks;
+    chunks = (T + len - 1) / len;
+    std::vector<double> tab((size_t)(2 * DP + 1) * 64, 0.0);
+    double ha = m.hh;
+    for (int i = 0; i < d; ++i) ha += m.H[i] * m.a[i];
+    for (int i = 0; i < d; ++i) {
+        for (int j = 0; j < d; ++j) {
+            tab[(size_t)j * 64 + i] = A[(size_t)i * d + j];
+            tab[(size_t)(DP + j) * 64 + i] = U[(size_t)j * d + i];      // U'[i][j]
+        }
+        tab[(size_t)(2 * DP) * 64 + i] = m.a[i];
+    }
+    for (int j = 0; j < d; ++j) {
+        double gj = 0.0, uh = 0.0;
+        for (int i = 0; i < d; ++i) {
+            gj += m.H[i] * A[(size_t)i * d + j];
+            uh += U[(size_t)j * d + i] * m.H[i];
+        }
+        tab[(size_t)j * 64 + d] = gj;
+        tab[(size_t)(DP + j) * 64 + d] = uh;
+    }
+    tab[(size_t)(2 * DP) * 64 + d] = ha;
+    hipError_t rc;
+    const size_t need = tab.size() * sizeof(double);
+    if (need > e->rand_cap) {
+        if (e->rand_dev) (void)tgp_alloc::dev_free(e->rand_dev);
+        e->rand_dev = nullptr;
+        e->rand_cap = 0;
+        rc = tgp_alloc::dev_malloc(reinterpret_cast<void**>(&e->rand_dev), need);
+        if (rc != hipSuccess) return fail(rc, "rand table");
+        e->rand_cap = need;
+    }
+    rc = hipMemcpyAsync(e->rand_dev, tab.data(), need, hipMemcpyHostToDevice, stream);
+    if (rc == hipSuccess) rc = hipStreamSynchronize(stream);      // (tab is a temporary)
+    if (rc != hipSuccess) return fail(rc, "rand table upload");
+    ZArg x0;
+    for (int i = 0; i < 64; ++i) x0.z[i] = i < d ? x0_host[i] : 0.0;
+    const double sqrtR = std::sqrt(m.R);
+    if (DP == 32)
+        hipLaunchKernelGGL(k_wide_rand<32>, dim3((unsigned)chunks), dim3(64), 0, stream, e->rand_dev, eps_t, eps_e, sqrtR, T, len, halo, d, d, x0, y_out);
+    else
+        hipLaunchKernelGGL(k_wide_rand<64>, dim3((unsigned)chunks), dim3(64), 0, stream, e->rand_dev, eps_t, eps_e, sqrtR, T, len, halo, d, d, x0, y_out);
+    rc = hipGetLastError();
+    if (rc != hipSuccess) return fail(rc, "launch");
+    *declined = false;
     return 0;
 }
 

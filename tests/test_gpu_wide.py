@@ -246,3 +246,26 @@ def test_gp_level_api_on_a_product_kernel(tgp, monkeypatch):
     assert abs(lp - lp_d) <= 1e-5 * abs(lp_d), (lp, lp_d)
     assert np.max(np.abs(np.asarray(m) - md)) <= 1e-4 and np.max(np.abs(np.asarray(sd) ** 2 - vd)) <= 1e-4
     np.testing.assert_array_equal(np.asarray(m), np.asarray(m2))
+
+
+@pytest.mark.parametrize("d", (12, 28, 42))
+def test_wide_rand_with_the_draws_supplied(tgp, d):
+    """rand(model) (lgssm.jl:65-91) of a wide LTI prior in ONE kernel on the open loop (k_wide_rand: chunks warmed up on the same draws) against the literal
+    restatement on the same draws; a long series against the engine of before"""
+    import torch
+    rng = np.random.default_rng(7 * d)
+    T = 3000
+    model = oc.build_lgssm(KERNELS[d], ("regular", 0.0, 0.1, T), 0.1)
+    eps = (rng.standard_normal((T, d)), rng.standard_normal(T), rng.standard_normal(d))
+    y_ref = ref.rand(model, *eps)
+    dm = device_model(tgp, model)
+    y, names = kernels_of(tgp, dm, lambda: tgp.rand(eps, dm))
+    assert np.max(np.abs(y - y_ref)) <= 1e-9 * max(1.0, np.abs(y_ref).max()), (d, np.max(np.abs(y - y_ref)))
+    assert names == {"k_wide_rand"}, names
+    if d == 28:
+        T2 = 200_000
+        model2 = oc.build_lgssm(KERNELS[d], ("regular", 0.0, 0.1, T2), 0.1)
+        eps2 = (torch.randn((T2, d), dtype=torch.float64, device="cuda"), torch.randn((T2,), dtype=torch.float64, device="cuda"), rng.standard_normal(d))
+        y1 = tgp.rand(eps2, device_model(tgp, model2))
+        y0 = tgp.rand(eps2, device_model(tgp, model2, wide=0))
+        assert float((y1 - y0).abs().max()) <= 1e-9 * max(1.0, float(y0.abs().max()))
