@@ -1,4 +1,4 @@
-// Stationary-gain engine for wide states (16 < d <= 63) -- see tgp_wide.hpp.  gfx950 only (wave64).
+// Stationary-gain engine for wide states (8 < d <= 63) -- see tgp_wide.hpp.  gfx950 only (wave64).
 #include "tgp_wide.hpp"
 
 #include <algorithm>
