@@ -79,7 +79,7 @@ def test_group_path_is_selected_for_d8(tgp):
     assert abs(lp - lp_ref) <= 1e-10 * abs(lp_ref)
 
 
-@pytest.mark.parametrize("d", [5, 7, 8, 9, 13, 14] if ALL_D else [5, 7, 8, 9, 11])
+@pytest.mark.parametrize("d", [5, 7, 8, 9, 13, 14] if ALL_D else [5, 7, 8, 9, 16])
 def test_group_scans_under_the_smoother(tgp, d):
     """posterior marginals with the group-layout block scans (filter elements forward, affine elements in reverse) under the
     lane-per-chunk passes, forced on for every d (TGP_OPT_GROUP = 2), against the oracle; several scan levels"""
@@ -146,7 +146,7 @@ def test_group_smoother_equals_oracle(tgp, d, per_step_R):
         np.testing.assert_allclose(gv1, pC1, rtol=1e-8, atol=1e-9)
 
 
-@pytest.mark.parametrize("d,p", [(5, 2), (8, 3), (12, 5), (15, 4)] if ALL_D else [(5, 2), (8, 3), (11, 5), (16, 4)])
+@pytest.mark.parametrize("d,p", [(5, 2), (8, 3), (12, 5), (15, 4)] if ALL_D else [(5, 2), (8, 3), (9, 5), (16, 4)])
 def test_group_vector_observations(tgp, d, p):
     """p > 1 (SmallOutputLGC with diagonal noise, shared emission block) through the group kernels: p scalar micro-steps per
     time step, predict only at the first; logpdf (with per-element missing data) and posterior marginals against the oracle's
@@ -183,7 +183,7 @@ def test_group_vector_observations(tgp, d, p):
         np.testing.assert_allclose(gv, np.diagonal(pC, axis1=-2, axis2=-1), rtol=1e-8, atol=1e-9)
 
 
-@pytest.mark.parametrize("d,p", [(5, 1), (8, 1), (12, 1), (8, 3), (15, 4)] if ALL_D else [(5, 1), (8, 1), (11, 1), (8, 3), (16, 4)])
+@pytest.mark.parametrize("d,p", [(5, 1), (8, 1), (12, 1), (8, 3), (15, 4)] if ALL_D else [(5, 1), (8, 1), (9, 1), (8, 3), (16, 4)])
 @pytest.mark.parametrize("per_step_R", [False, True])
 def test_group_prior_marginals(tgp, d, p, per_step_R):
     """marginals(model) of a Forward LTI model (lgssm.jl:99-109) through the group kernels, scalar and vector observations"""
@@ -218,7 +218,7 @@ def test_group_prior_marginals(tgp, d, p, per_step_R):
         np.testing.assert_allclose(gv, want_v, rtol=1e-10, atol=1e-11)
 
 
-@pytest.mark.parametrize("d,p,pn", [(5, 1, 3), (8, 1, 7), (12, 3, 5), (15, 4, 20)] if ALL_D else [(5, 1, 3), (8, 1, 7), (11, 3, 5), (16, 4, 20)])
+@pytest.mark.parametrize("d,p,pn", [(5, 1, 3), (8, 1, 7), (12, 3, 5), (15, 4, 20)] if ALL_D else [(5, 1, 3), (8, 1, 7), (9, 3, 5), (16, 4, 20)])
 def test_posterior_marginals_through_other_emissions(tgp, d, p, pn):
     """tgp_posterior_marginals_at: the smoothed state through an alternative emission block, against the oracle's posterior model
     with its emissions swapped (what pseudo_point.jl:198-235 does)"""
@@ -260,7 +260,7 @@ def test_posterior_marginals_at_unsupported_for_small_d(tgp):
         tgp.posterior_marginals_at(dm, rng.standard_normal(100), np.ones((2, 3)), np.zeros(2), np.ones((1, 2)))
 
 
-@pytest.mark.parametrize("d", [5, 8, 9, 13] if ALL_D else [5, 8, 9, 11])
+@pytest.mark.parametrize("d", [5, 8, 9, 13] if ALL_D else [5, 8, 9, 16])
 @pytest.mark.parametrize("ordering", ["F", "R"])
 def test_group_filter_and_materialised_posterior(tgp, d, ordering):
     """_filter (MODE 1) and posterior (MODE 3: the per-step reversed transitions) through the group kernels"""
