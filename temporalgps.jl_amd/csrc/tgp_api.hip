@@ -2060,6 +2060,11 @@ int tgp_filter(tgp_handle* h, const double* y, const uint8_t* missing, uint32_t 
         TRY(filter_lti_call(h, y, flags, m_out, P_out, lml_out, &served));
         if (served) return TGP_OK;
     }
+    if (!h->widem.empty() && missing == nullptr && h->p == 1 && h->opt_chunk == 0 && h->variant_opt == 0 && h->opt_group != 2) {      // wide LTI models: tgp_wide.hip
+        bool served = false;
+        TRY(wide_filter_call(h, y, flags, m_out, P_out, lml_out, &served));
+        if (served) return TGP_OK;
+    }
     resolve_table(h);
     const bool odev = (flags & TGP_OUT_DEVICE) != 0;
     const size_t nm = (size_t)h->T * h->d * sizeof(double), nP = nm * h->d;

@@ -37,7 +37,7 @@ __device__ __forceinline__ double readlane_d(double x, int l) {      // l wave-u
 template <int DP>
 __global__ __launch_bounds__(64) void k_wide_lml(const double* __restrict__ tab, const double* __restrict__ y, double hh, long long T, long long t_head,
                                                   long long chunk_len, long long halo, int obs_lane, ZArg z0, double* __restrict__ part, double* __restrict__ rout,
-                                                  const double* __restrict__ ht) {
+                                                  const double* __restrict__ ht, double* __restrict__ mout, int d) {
     __shared__ __attribute__((aligned(16))) double zb[64];
     const int lane = threadIdx.x;
     const long long chunk = blockIdx.x;
@@ -83,6 +83,7 @@ __global__ __launch_bounds__(64) void k_wide_lml(const double* __restrict__ tab,
             zb[lane] = acc;
             lds_sync();
             if (tb + l >= s0) ssq = fma(acc, acc, ssq);      // (the observer's acc is the step's innovation)
+            if (mout != nullptr && tb + l >= s0 && lane < d) mout[(tb + l) * d + lane] = acc;      // (_filter: the filtered mean of the chunk's own steps)
             if (keep) {
                 const double rr = readlane_d(acc, obs_lane);
                 outr = lane == l ? rr : outr;
@@ -191,7 +192,7 @@ struct RowGeom {      // per lane, the same within a row
 
 template <int L, bool KEEP, int NB>
 __device__ __forceinline__ void fwd_step4(double& yv, double& zlo, double& zhi, const double (&pA)[32], const double (&pB)[32], double kA, double kB, double cA, double cB,
-                                          long long t, const RowGeom& g, bool obsB, bool is_obs, double& ssq, double* __restrict__ rout) {
+                                          long long t, const RowGeom& g, bool obsB, bool is_obs, double& ssq, double* __restrict__ rout, double* __restrict__ mout, int d, int p) {
     // (a DPP operand must not be read within two cycles of the VALU write of its register, nor within five of a write to EXEC: the recogniser that
     //  spaces such pairs does not look into inline assembly)
     asm volatile("s_nop 4" : "+v"(zlo), "+v"(zhi), "+v"(yv) : : "memory");
@@ -215,17 +216,22 @@ __device__ __forceinline__ void fwd_step4(double& yv, double& zlo, double& zhi, 
     if (KEEP) {
         if (is_obs && own) rout[t] = rr;
     }
+    if (mout != nullptr) {      // (_filter: the filtered mean of the chunk's own steps -- wave-uniform test)
+        if (own && p < d) mout[t * d + p] = nA;
+        if (NB == 2 && own && 16 + p < d) mout[t * d + 16 + p] = nB;
+    }
 }
 template <bool KEEP, int NB, int... Ls>
 __device__ __forceinline__ void fwd_block4(double& yv, double& zlo, double& zhi, const double (&pA)[32], const double (&pB)[32], double kA, double kB, double cA, double cB,
-                                           long long t0, const RowGeom& g, bool obsB, bool is_obs, double& ssq, double* __restrict__ rout, std::integer_sequence<int, Ls...>) {
-    (fwd_step4<Ls, KEEP, NB>(yv, zlo, zhi, pA, pB, kA, kB, cA, cB, t0 + Ls, g, obsB, is_obs, ssq, rout), ...);
+                                           long long t0, const RowGeom& g, bool obsB, bool is_obs, double& ssq, double* __restrict__ rout, double* __restrict__ mout, int d, int p,
+                                           std::integer_sequence<int, Ls...>) {
+    (fwd_step4<Ls, KEEP, NB>(yv, zlo, zhi, pA, pB, kA, kB, cA, cB, t0 + Ls, g, obsB, is_obs, ssq, rout, mout, d, p), ...);
 }
 
 template <bool KEEP, int NB>
 __global__ __launch_bounds__(64) void k_wide_lml4(const double* __restrict__ tab, const double* __restrict__ y, double hh, long long T, long long t_head, long long chunk_len,
                                                    long long halo, long long chunks, int d, ZArg z0, double* __restrict__ part, double* __restrict__ rout,
-                                                   const double* __restrict__ ht) {
+                                                   const double* __restrict__ ht, double* __restrict__ mout) {
     auto obs = [&](long long t) { return y[t] - (ht != nullptr ? ht[t] : 0.0); };      // (see k_wide_lml)
     const int lane = threadIdx.x, p = lane & 15, row = lane >> 4;
     const long long chunk = (long long)blockIdx.x * 4 + row;
@@ -261,7 +267,7 @@ __global__ __launch_bounds__(64) void k_wide_lml4(const double* __restrict__ tab
     for (long long kb = 0; kb < nmax; kb += 16) {
         double yv = yn;
         yn = (g.w + kb + 16 + p < g.s1) ? obs(g.w + kb + 16 + p) : 0.0;      // (the next block: on its way while this one runs)
-        fwd_block4<KEEP, NB>(yv, zlo, zhi, pA, pB, kA, kB, cA, cB, g.w + kb, g, obsB, is_obs, ssq, rout, Seq16{});
+        fwd_block4<KEEP, NB>(yv, zlo, zhi, pA, pB, kA, kB, cA, cB, g.w + kb, g, obsB, is_obs, ssq, rout, mout, d, p, Seq16{});
     }
     if (is_obs && g.valid) part[chunk] = ssq;
 }
@@ -421,6 +427,14 @@ __global__ __launch_bounds__(64) void k_wide_rand(const double* __restrict__ tab
     }
 }
 
+// _filter's covariances behind the head: the settled one (block n0 - 1, which the head's copy has just put there) into every later block
+__global__ __launch_bounds__(256) void k_wide_fill_cov(double* __restrict__ P, long long n0, long long T, int dd) {
+    const double* __restrict__ src = P + (n0 - 1) * dd;
+    const long long n = (T - n0) * dd;
+    double* __restrict__ dst = P + n0 * dd;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) dst[i] = src[i % dd];
+}
+
 // ---- host: small dense linear algebra, row-major ---------------------------------------------------------------------------------------
 void matmul(int d, const double* X, const double* Y, double* Z) {      // Z = X Y
     for (int i = 0; i < d; ++i) {
@@ -469,8 +483,9 @@ struct Engine {
     double* rbuf = nullptr;                // device: the innovations of the steps behind the head [T]
     size_t rbuf_cap = 0;
     double* pinned = nullptr;              // [kHeadMax] head y | [kHeadMax] head Rnew | [kHeadMax] head means | [kHeadMax] head vars | [64] lam | [kMaxChunks] sums
-    std::vector<double> head_r;
+    std::vector<double> head_r, head_m;
     const char* kname = "k_wide_lml<32>";
+    std::vector<double> Pf_head;          // the head's filtered covariances [n0][d d] (row-major = column-major: symmetric), for _filter; empty: too large
     double* rand_dev = nullptr;           // device: k_wide_rand's table
     size_t rand_cap = 0;
 };
@@ -495,6 +510,7 @@ void destroy(Engine* e) {
 }
 const Info& last_plan(const Engine* e) { return e->info; }
 const char* kernel_name(const Engine* e) { return e->kname; }
+bool filter_ready(const Engine* e) { return e->have && e->info.why == kOk && e->Pf_head.size() == (size_t)e->info.n0 * e->d * e->d; }
 
 namespace {
 template <class F>
@@ -593,6 +609,8 @@ bool plan(Engine* e, const ModelHost& m, long long T) {
     // ---- the covariance half of lgssm.jl:99-165 to its fixed point: P <- A P A' + Q; S = h' P h + R; K = P h / S; P <- P - K S K'
     e->Kt.clear();
     e->St.clear();
+    e->Pf_head.clear();
+    bool keep_pf = true;
     e->sum_logS_head = 0.0;
     int n0 = -1;
     double prev_chg = 1e300;
@@ -626,6 +644,14 @@ bool plan(Engine* e, const ModelHost& m, long long T) {
         for (int i = 0; i < d; ++i) e->Kt.push_back(v[i] * iS);
         e->St.push_back(S);
         e->sum_logS_head += std::log(S);
+        if (keep_pf) {
+            if (e->Pf_head.size() + dd > ((size_t)64 << 20) / sizeof(double)) {      // (64 MB of head covariances at most: beyond, _filter is the dense engine's)
+                keep_pf = false;
+                e->Pf_head.clear();
+            } else {
+                e->Pf_head.insert(e->Pf_head.end(), Pf.begin(), Pf.end());
+            }
+        }
         P.swap(Pf);
         // settled: the step changes nothing beyond rounding -- a few ulps of the largest entry, or no longer shrinking at the rounding floor
         if (chg <= 4.0 * 2.220446049250313e-16 * scale || (t >= 16 && chg >= prev_chg && chg <= 1e-13 * scale)) {
@@ -875,6 +901,7 @@ int run(Engine* e, hipStream_t stream, const Call& c, double* lml_out, std::stri
     double quad = 0.0;
     const double *A = e->A.data(), *h = e->hvec.data();
     e->head_r.resize(n0);
+    e->head_m.clear();
     {
         std::vector<double> mcur(e->x0m), mp(d);
         for (int t = 0; t < n0; ++t) {
@@ -891,8 +918,18 @@ int run(Engine* e, hipStream_t stream, const Call& c, double* lml_out, std::stri
             quad += r * r / e->St[t];
             const double* K = e->Kt.data() + (size_t)t * d;
             for (int i = 0; i < d; ++i) mcur[i] = mp[i] + K[i] * r;
+            if (c.fm) e->head_m.insert(e->head_m.end(), mcur.begin(), mcur.end());
         }
         for (int i = 0; i < d; ++i) z0.z[i] = mcur[i];
+    }
+    if (c.fm) {      // _filter: the head's means and covariances, the settled covariance behind them
+        if (!c.fP || e->Pf_head.size() != (size_t)n0 * d * d) return fail(hipErrorInvalidValue, "filter outputs");
+        rc = hipMemcpyAsync(c.fm, e->head_m.data(), (size_t)n0 * d * sizeof(double), hipMemcpyHostToDevice, stream);
+        if (rc == hipSuccess) rc = hipMemcpyAsync(c.fP, e->Pf_head.data(), e->Pf_head.size() * sizeof(double), hipMemcpyHostToDevice, stream);
+        if (rc != hipSuccess) return fail(rc, "head filter outputs");
+        const long long nfill = (T - n0) * (long long)d * d;
+        const unsigned blocks = (unsigned)std::min<long long>((nfill + 255) / 256, 16384);
+        if (nfill > 0) hipLaunchKernelGGL(k_wide_fill_cov, dim3(blocks), dim3(256), 0, stream, c.fP, (long long)n0, T, d * d);
     }
     const long long chunks = e->info.chunks;
     double* rout = post ? e->rbuf : nullptr;
@@ -900,7 +937,7 @@ int run(Engine* e, hipStream_t stream, const Call& c, double* lml_out, std::stri
     const unsigned grid4 = (unsigned)((chunks + 3) / 4);
     const bool one = d <= 15;      // one component per lane
 #define TGP_WIDE_LML4(KEEP, NB) \
-    hipLaunchKernelGGL((k_wide_lml4<KEEP, NB>), dim3(grid4), dim3(64), 0, stream, tab_f, c.y, e->hh, T, (long long)n0, e->info.chunk_len, (long long)e->info.halo, chunks, d, z0, part, rout, c.h_t)
+    hipLaunchKernelGGL((k_wide_lml4<KEEP, NB>), dim3(grid4), dim3(64), 0, stream, tab_f, c.y, e->hh, T, (long long)n0, e->info.chunk_len, (long long)e->info.halo, chunks, d, z0, part, rout, c.h_t, c.fm)
     if (four && post && one) TGP_WIDE_LML4(true, 1);
     else if (four && post) TGP_WIDE_LML4(true, 2);
     else if (four && one) TGP_WIDE_LML4(false, 1);
@@ -908,10 +945,10 @@ int run(Engine* e, hipStream_t stream, const Call& c, double* lml_out, std::stri
 #undef TGP_WIDE_LML4
     else if (DP == 32)
         hipLaunchKernelGGL(k_wide_lml<32>, dim3((unsigned)chunks), dim3(64), 0, stream, tab_f, c.y, e->hh, T, (long long)n0, e->info.chunk_len, (long long)e->info.halo, d, z0, part,
-                           rout, c.h_t);
+                           rout, c.h_t, c.fm, d);
     else
         hipLaunchKernelGGL(k_wide_lml<64>, dim3((unsigned)chunks), dim3(64), 0, stream, tab_f, c.y, e->hh, T, (long long)n0, e->info.chunk_len, (long long)e->info.halo, d, z0, part,
-                           rout, c.h_t);
+                           rout, c.h_t, c.fm, d);
     rc = hipGetLastError();
     if (rc != hipSuccess) return fail(rc, "launch");
     if (post) {

@@ -269,3 +269,20 @@ def test_wide_rand_with_the_draws_supplied(tgp, d):
         y1 = tgp.rand(eps2, device_model(tgp, model2))
         y0 = tgp.rand(eps2, device_model(tgp, model2, wide=0))
         assert float((y1 - y0).abs().max()) <= 1e-9 * max(1.0, float(y0.abs().max()))
+
+
+@pytest.mark.parametrize("d", (9, 15, 28, 42))
+def test_wide_filter(tgp, d):
+    """_filter (lgssm.jl:171-187): filtered means from the forward kernel, the head's covariances from the host plan, the settled covariance behind them"""
+    import torch
+    T = 2500
+    model = oc.build_lgssm(KERNELS[d], ("regular", 0.0, 0.1, T), 0.1)
+    y = draw(model, 11 * d)
+    fm_ref, fP_ref = ref.filter_(model, y)
+    dm = device_model(tgp, model)
+    for yy in (y, torch.from_numpy(y).cuda()):
+        (fm, fP), names = kernels_of(tgp, dm, lambda: tgp._filter(dm, yy))
+        fm, fP = (fm.cpu().numpy(), fP.cpu().numpy()) if hasattr(fm, "cpu") else (fm, fP)
+        assert np.max(np.abs(fm - fm_ref)) <= 1e-8 * max(1.0, np.abs(fm_ref).max()), (d, np.max(np.abs(fm - fm_ref)))
+        assert np.max(np.abs(fP - fP_ref)) <= 1e-8 * max(1.0, np.abs(fP_ref).max()), (d, np.max(np.abs(fP - fP_ref)))
+        assert len(names) == 1 and next(iter(names)).startswith("k_wide_lml"), names
