@@ -96,6 +96,9 @@ def label(name):
     m = re.match(r"tgp_wide::k_wide_(lml|bwd)4<(?:(true|false), )?(\d)>", n)
     if m:      # four chunks per wave; <16>: one component per lane (d <= 15)
         return f"k_wide_{m.group(1)}4" + ("<16>" if m.group(3) == "1" else "") + (",keeps r" if m.group(2) == "true" else "")
+    m = re.match(r"tgp_wide::k_wide_(lml|bwd)43(?:<(true|false)>)?", n)
+    if m:      # three components per lane (32 <= d <= 47)
+        return f"k_wide_{m.group(1)}4<48>" + (",keeps r" if m.group(2) == "true" else "")
     m = re.match(r"tgp_wide::k_wide_(lml|bwd)<(\d+)>", n)
     if m:
         return f"k_wide_{m.group(1)}<{m.group(2)}>"

@@ -427,6 +427,172 @@ __global__ __launch_bounds__(64) void k_wide_rand(const double* __restrict__ tab
     }
 }
 
+// ---- 32 <= d <= 47: the same four chunks per wave with THREE components per lane (p, p + 16, p + 32) and three rows of the matrix of 48 columns each --
+// 144 doubles of rows, a fifth of them in accumulation registers (v_accvgpr reads ahead of their multiply-adds); 146 multiply-adds per step and wave
+// against the LDS form's 64 and 32 broadcast reads for ONE chunk.  The table is the LDS kernels' (DP = 64).
+template <int OFF, int W, int... Js>
+__device__ __forceinline__ void dot16w(double (&a)[4], double z, const double (&phi)[W], std::integer_sequence<int, Js...>) {
+    (fmac_bc<Js>(a[Js % 4], z, phi[OFF + Js]), ...);
+}
+template <int L, bool KEEP>
+__device__ __forceinline__ void fwd_step43(double& yv, double (&z)[3], const double (&P)[3][48], const double (&kin)[3], const double (&cin)[3], long long t, const RowGeom& g,
+                                           int obs_o, bool is_obs, double& ssq, double* __restrict__ rout, double* __restrict__ mout, int d, int p) {
+    asm volatile("s_nop 4" : "+v"(z[0]), "+v"(z[1]), "+v"(z[2]), "+v"(yv) : : "memory");      // (DPP hazards: see fwd_step4)
+    double n[3];
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+        double a[4] = {cin[o], 0.0, 0.0, 0.0};
+        fmac_bc<L>(a[3], yv, kin[o]);
+        dot16w<0, 48>(a, z[0], P[o], Seq16{});
+        dot16w<16, 48>(a, z[1], P[o], Seq16{});
+        dot16w<32, 48>(a, z[2], P[o], Seq16{});
+        n[o] = (a[0] + a[1]) + (a[2] + a[3]);
+    }
+    const bool live = t < g.s1;
+#pragma unroll
+    for (int o = 0; o < 3; ++o) z[o] = live ? n[o] : z[o];
+    const bool own = live && t >= g.s0;
+    double rr = obs_o == 0 ? n[0] : (obs_o == 1 ? n[1] : n[2]);
+    rr = own ? rr : 0.0;
+    ssq = fma(rr, rr, ssq);
+    if (KEEP) {
+        if (is_obs && own) rout[t] = rr;
+    }
+    if (mout != nullptr) {
+#pragma unroll
+        for (int o = 0; o < 3; ++o)
+            if (own && 16 * o + p < d) mout[t * d + 16 * o + p] = n[o];
+    }
+}
+template <bool KEEP, int... Ls>
+__device__ __forceinline__ void fwd_block43(double& yv, double (&z)[3], const double (&P)[3][48], const double (&kin)[3], const double (&cin)[3], long long t0, const RowGeom& g,
+                                            int obs_o, bool is_obs, double& ssq, double* __restrict__ rout, double* __restrict__ mout, int d, int p, std::integer_sequence<int, Ls...>) {
+    (fwd_step43<Ls, KEEP>(yv, z, P, kin, cin, t0 + Ls, g, obs_o, is_obs, ssq, rout, mout, d, p), ...);
+}
+template <bool KEEP>
+__global__ __launch_bounds__(64) void k_wide_lml43(const double* __restrict__ tab, const double* __restrict__ y, double hh, long long T, long long t_head, long long chunk_len,
+                                                    long long halo, long long chunks, int d, ZArg z0, double* __restrict__ part, double* __restrict__ rout,
+                                                    const double* __restrict__ ht, double* __restrict__ mout) {
+    auto obs = [&](long long t) { return y[t] - (ht != nullptr ? ht[t] : 0.0); };
+    const int lane = threadIdx.x, p = lane & 15, row = lane >> 4;
+    const long long chunk = (long long)blockIdx.x * 4 + row;
+    RowGeom g;
+    g.valid = chunk < chunks;
+    g.s0 = t_head + chunk * chunk_len;
+    g.s1 = g.s0 + chunk_len;
+    if (g.s1 > T) g.s1 = T;
+    const bool from_head = g.s0 - halo <= t_head;
+    g.w = from_head ? t_head : g.s0 - halo;
+    if (!g.valid) g.s0 = g.s1 = g.w = T;
+    double P[3][48], kin[3], cin[3], z[3];
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+#pragma unroll
+        for (int j = 0; j < 48; ++j) P[o][j] = tab[(size_t)j * 64 + 16 * o + p];
+        kin[o] = tab[(size_t)64 * 64 + 16 * o + p];
+        cin[o] = tab[(size_t)65 * 64 + 16 * o + p] - kin[o] * hh;
+        z[o] = (g.valid && from_head) ? z0.z[16 * o + p] : 0.0;
+    }
+    const int obs_o = d >> 4;
+    const bool is_obs = p == (d & 15);
+    const long long len = g.s1 - g.w;
+    long long nmax = 0;
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+        const int lo = __builtin_amdgcn_readlane((int)(len & 0xffffffffll), 16 * r4), hi = __builtin_amdgcn_readlane((int)(len >> 32), 16 * r4);
+        const long long v = ((long long)hi << 32) | (unsigned)lo;
+        nmax = v > nmax ? v : nmax;
+    }
+    double ssq = 0.0;
+    double yn = (g.w + p < g.s1) ? obs(g.w + p) : 0.0;
+    for (long long kb = 0; kb < nmax; kb += 16) {
+        double yv = yn;
+        yn = (g.w + kb + 16 + p < g.s1) ? obs(g.w + kb + 16 + p) : 0.0;
+        fwd_block43<KEEP>(yv, z, P, kin, cin, g.w + kb, g, obs_o, is_obs, ssq, rout, mout, d, p, Seq16{});
+    }
+    if (is_obs && g.valid) part[chunk] = ssq;
+}
+
+template <int L>
+__device__ __forceinline__ void bwd_step43(double& rv, double& yv, double (&z)[3], const double (&P)[3][48], const double (&kin)[3], const double (&yin)[3], long long t,
+                                           const RowGeom& g, int obs_o, bool is_obs, double* __restrict__ mean) {
+    asm volatile("s_nop 4" : "+v"(z[0]), "+v"(z[1]), "+v"(z[2]), "+v"(rv), "+v"(yv) : : "memory");
+    double n[3];
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+        double a[4] = {0.0, 0.0, 0.0, 0.0};
+        fmac_bc<L>(a[3], rv, kin[o]);
+        fmac_bc<L>(a[2], yv, yin[o]);      // (1 at the observer)
+        dot16w<0, 48>(a, z[0], P[o], Seq16{});
+        dot16w<16, 48>(a, z[1], P[o], Seq16{});
+        dot16w<32, 48>(a, z[2], P[o], Seq16{});
+        n[o] = (a[0] + a[1]) + (a[2] + a[3]);
+    }
+    const bool live = t >= g.s0;
+#pragma unroll
+    for (int o = 0; o < 3; ++o) z[o] = live ? n[o] : z[o];
+    if (is_obs && live && t < g.s1) mean[t] = obs_o == 0 ? n[0] : (obs_o == 1 ? n[1] : n[2]);
+}
+template <int... Ls>
+__device__ __forceinline__ void bwd_block43(double& rv, double& yv, double (&z)[3], const double (&P)[3][48], const double (&kin)[3], const double (&yin)[3], long long t0,
+                                            const RowGeom& g, int obs_o, bool is_obs, double* __restrict__ mean, std::integer_sequence<int, Ls...>) {
+    (bwd_step43<Ls>(rv, yv, z, P, kin, yin, t0 - Ls, g, obs_o, is_obs, mean), ...);
+}
+__global__ __launch_bounds__(64) void k_wide_bwd43(const double* __restrict__ tab, const double* __restrict__ y, const double* __restrict__ r, const double* __restrict__ Rnew,
+                                                    int rnew_per_step, const double* __restrict__ qtab, long long n1, double vbase, double qinf, long long T, long long t_head,
+                                                    long long chunk_len, long long halo, long long chunks, int d, double* __restrict__ mean, double* __restrict__ var,
+                                                    double* __restrict__ lam_out) {
+    const int lane = threadIdx.x, p = lane & 15, row = lane >> 4;
+    const long long chunk = (long long)blockIdx.x * 4 + row;
+    RowGeom g;
+    g.valid = chunk < chunks;
+    g.s0 = t_head + chunk * chunk_len;
+    g.s1 = g.s0 + chunk_len;
+    if (g.s1 > T) g.s1 = T;
+    g.w = g.s1 + halo;
+    if (g.w > T) g.w = T;
+    if (!g.valid) g.s0 = g.s1 = g.w = T;
+    const int obs_o = d >> 4;
+    const bool is_obs = p == (d & 15);
+    double P[3][48], kin[3], yin[3], z[3];
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+#pragma unroll
+        for (int j = 0; j < 48; ++j) P[o][j] = tab[(size_t)j * 64 + 16 * o + p];
+        kin[o] = tab[(size_t)64 * 64 + 16 * o + p];
+        yin[o] = (is_obs && o == obs_o) ? 1.0 : 0.0;
+        z[o] = 0.0;
+    }
+    const long long len = g.w - g.s0;
+    long long nmax = 0;
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+        const int lo = __builtin_amdgcn_readlane((int)(len & 0xffffffffll), 16 * r4), hi = __builtin_amdgcn_readlane((int)(len >> 32), 16 * r4);
+        const long long v = ((long long)hi << 32) | (unsigned)lo;
+        nmax = v > nmax ? v : nmax;
+    }
+    const long long top = g.w - 1;
+    double rn = (top - p >= g.s0) ? r[top - p] : 0.0;
+    for (long long kb = 0; kb < nmax; kb += 16) {
+        double rv = rn;
+        const long long tl = top - kb - p;
+        rn = (tl - 16 >= g.s0) ? r[tl - 16] : 0.0;
+        const bool mine = tl >= g.s0 && tl < g.s1;
+        double yv = mine ? y[tl] : 0.0;
+        bwd_block43(rv, yv, z, P, kin, yin, top - kb, g, obs_o, is_obs, mean, Seq16{});
+        if (mine) {
+            const long long jt = T - 1 - tl;
+            const double q = jt < n1 ? qtab[jt] : qinf;
+            var[tl] = vbase - q + (rnew_per_step ? Rnew[tl] : Rnew[0]);
+        }
+    }
+    if (g.valid && chunk == 0) {
+#pragma unroll
+        for (int o = 0; o < 3; ++o)
+            if (16 * o + p < d) lam_out[16 * o + p] = z[o];
+    }
+}
+
 // _filter's covariances behind the head: the settled one (block n0 - 1, which the head's copy has just put there) into every later block
 __global__ __launch_bounds__(256) void k_wide_fill_cov(double* __restrict__ P, long long n0, long long T, int dd) {
     const double* __restrict__ src = P + (n0 - 1) * dd;
@@ -580,7 +746,7 @@ bool plan(Engine* e, const ModelHost& m, long long T) {
     const size_t dd = (size_t)d * d;
     e->d = d;
     e->dp = d <= 31 ? 32 : 64;
-    e->kname = e->dp == 32 ? (dpp_enabled() ? (d <= 15 ? "k_wide_lml4<16>" : "k_wide_lml4") : "k_wide_lml<32>") : "k_wide_lml<64>";
+    e->kname = e->dp == 32 ? (dpp_enabled() ? (d <= 15 ? "k_wide_lml4<16>" : "k_wide_lml4") : "k_wide_lml<32>") : (d <= 47 && dpp_enabled() ? "k_wide_lml4<48>" : "k_wide_lml<64>");
     e->A.assign(dd, 0.0);
     std::vector<double> Q(dd), P(dd), AP(dd), Pp(dd), Pf(dd), v(d);
     for (int i = 0; i < d; ++i)
@@ -935,10 +1101,17 @@ int run(Engine* e, hipStream_t stream, const Call& c, double* lml_out, std::stri
     double* rout = post ? e->rbuf : nullptr;
     const bool four = DP == 32 && dpp_enabled();
     const unsigned grid4 = (unsigned)((chunks + 3) / 4);
+    const bool three = DP == 64 && d <= 47 && dpp_enabled();      // three components per lane
     const bool one = d <= 15;      // one component per lane
 #define TGP_WIDE_LML4(KEEP, NB) \
     hipLaunchKernelGGL((k_wide_lml4<KEEP, NB>), dim3(grid4), dim3(64), 0, stream, tab_f, c.y, e->hh, T, (long long)n0, e->info.chunk_len, (long long)e->info.halo, chunks, d, z0, part, rout, c.h_t, c.fm)
-    if (four && post && one) TGP_WIDE_LML4(true, 1);
+    if (three && post)
+        hipLaunchKernelGGL(k_wide_lml43<true>, dim3(grid4), dim3(64), 0, stream, tab_f, c.y, e->hh, T, (long long)n0, e->info.chunk_len, (long long)e->info.halo, chunks, d, z0, part, rout,
+                           c.h_t, c.fm);
+    else if (three)
+        hipLaunchKernelGGL(k_wide_lml43<false>, dim3(grid4), dim3(64), 0, stream, tab_f, c.y, e->hh, T, (long long)n0, e->info.chunk_len, (long long)e->info.halo, chunks, d, z0, part, rout,
+                           c.h_t, c.fm);
+    else if (four && post && one) TGP_WIDE_LML4(true, 1);
     else if (four && post) TGP_WIDE_LML4(true, 2);
     else if (four && one) TGP_WIDE_LML4(false, 1);
     else if (four) TGP_WIDE_LML4(false, 2);
@@ -952,7 +1125,10 @@ int run(Engine* e, hipStream_t stream, const Call& c, double* lml_out, std::stri
     rc = hipGetLastError();
     if (rc != hipSuccess) return fail(rc, "launch");
     if (post) {
-        if (four && one)
+        if (three)
+            hipLaunchKernelGGL(k_wide_bwd43, dim3(grid4), dim3(64), 0, stream, tab_b, c.y, e->rbuf, c.Rnew, c.rnew_per_step, qtab_d, (long long)e->info.n1, e->vbase, e->qinf, T,
+                               (long long)n0, e->info.chunk_len, (long long)e->info.halo_back, chunks, d, c.mean, c.var, lam);
+        else if (four && one)
             hipLaunchKernelGGL(k_wide_bwd4<1>, dim3(grid4), dim3(64), 0, stream, tab_b, c.y, e->rbuf, c.Rnew, c.rnew_per_step, qtab_d, (long long)e->info.n1, e->vbase, e->qinf, T,
                                (long long)n0, e->info.chunk_len, (long long)e->info.halo_back, chunks, d, c.mean, c.var, lam);
         else if (four)
