@@ -109,7 +109,7 @@ for case in range(n_cases):
     e_m = np.max(np.abs(m1 - m_ref)) / max(1.0, np.abs(m_ref).max())
     e_v = np.max(np.abs(v1 - v_ref)) / max(1.0, v_ref.max())
     if not wide and what[0] == "(":      # (declined: the engine of before itself, whose RTS chain is what stands 1e-7 .. 4e-6 from the dense GP)
-        tol = 1e-5
+        tol = 1e-4
     ok = e_lp <= 1e-10 and e_m <= tol and e_v <= tol and e_r <= 1e-9
     what += " [vs dense GP]" if gp else ""
     bad += not ok

@@ -779,7 +779,7 @@ bool plan(Engine* e, const ModelHost& m, long long T) {
     bool keep_pf = true;
     e->sum_logS_head = 0.0;
     int n0 = -1;
-    double prev_chg = 1e300;
+    double prev_chg = 1e300, rate = 0.0, prev_S = 0.0;
     for (int t = 0; t < kHeadMax; ++t) {
         matmul(d, A, P.data(), AP.data());
         double scale = 0.0;
@@ -819,12 +819,21 @@ bool plan(Engine* e, const ModelHost& m, long long T) {
             }
         }
         P.swap(Pf);
-        // settled: the step changes nothing beyond rounding -- a few ulps of the largest entry, or no longer shrinking at the rounding floor
-        if (chg <= 4.0 * 2.220446049250313e-16 * scale || (t >= 16 && chg >= prev_chg && chg <= 1e-13 * scale)) {
+        // the contraction rate, while the changes are still well above rounding: "no longer moves" bounds the DISTANCE to the fixed point by
+        // (last change) / (1 - rate) only -- a recursion that creeps (fine spacings: rate -> 1) is not settled when its steps fall to the rounding floor
+        if (chg > 1e-11 * scale && prev_chg > 1e-11 * scale && chg < prev_chg) rate = chg / prev_chg;
+        // settled: the step changes nothing at all, or nothing beyond rounding -- a few ulps of the largest entry, or no longer shrinking at the rounding
+        // floor -- with the fixed point within 1e-12 of it by that bound
+        // (... and the innovation variance -- what the log-likelihood sees -- within 1e-13 of ITS fixed point: S can be orders of magnitude below the
+        //  covariance's largest entry)
+        const bool still = chg <= 4.0 * 2.220446049250313e-16 * scale || (t >= 16 && chg >= prev_chg && chg <= 1e-13 * scale);
+        const double dS = std::fabs(S - prev_S);
+        if (chg == 0.0 || (still && chg <= (1.0 - rate) * 1e-12 * scale && dS <= (1.0 - rate) * 1e-13 * S)) {
             n0 = t + 1;
             break;
         }
         prev_chg = chg;
+        prev_S = S;
     }
     if (n0 < 0) return done(kNotSettled);
     e->info.n0 = n0;
