@@ -276,6 +276,13 @@ int tgp_logpdf_adjoint(tgp_handle* h, const double* y, uint32_t flags, double* l
 int tgp_steady_plan(int d, const double* A, const double* a, const double* Q, const double* H, const double* hh, const double* R,
                     const double* x0m, const double* x0P, int64_t T, int32_t* info_i, double* info_d, double* modal_out,
                     double* tables_out);
+
+/* The host plan of the wide-state engine (8 < d <= 63: csrc/tgp_wide.hip) as a pure host function -- no handle, no GPU: the covariance half of
+ * lgssm.jl:99-165 to its fixed point.  info [8]: why (0 = applies), n0 (head steps), halo, why_post (-1: not asked), n1 (steps at the series' end whose
+ * smoothed variance is in its transient), halo_back, chunks, chunk length.  Kss [d], Sss: the stationary gain and innovation variance;
+ * var_parts [2] (want_posterior): the stationary smoothed emission variance is var_parts[0] - var_parts[1] (+ the new noise). */
+int tgp_wide_plan(int d, const double* A, const double* a, const double* Q, const double* H, const double* hh, const double* R, const double* x0m,
+                  const double* x0P, int64_t T, int want_posterior, int64_t* info, double* Kss, double* Sss, double* var_parts);
 /* ---- time segments of ONE series on the one-launch path (TGP_OPT_STEADY = 3): what a rank of a multi-GPU run calls (tgp_multi_* and the
  * one-process-per-GPU driver use them).  Both mean recursions of the stationary region forget a state within `halo` steps, so a segment needs
  * nothing of its neighbours but their `halo` observations next to the boundary: ONE all-gather of 2 halo observations per rank before the

@@ -54,6 +54,7 @@ _SIGS = {
     "tgp_logpdf_adjoint": (ctypes.c_int, [_vp, _vp, _u32, _dp] + [_vp] * 8),
     "tgp_adjoint_record_size": (ctypes.c_int, [ctypes.c_int]),
     "tgp_steady_plan": (ctypes.c_int, [ctypes.c_int] + [_vp] * 8 + [_i64, _vp, _vp, _vp, _vp]),
+    "tgp_wide_plan": (ctypes.c_int, [ctypes.c_int] + [_vp] * 8 + [_i64, ctypes.c_int, _vp, _vp, _vp, _vp]),
     "tgp_segment_plan": (ctypes.c_int, [_vp, _i64, ctypes.c_int, _vp, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
     "tgp_segment_logpdf_and_posterior_marginals": (ctypes.c_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _dp]),
     "tgp_adjoint_finish": (ctypes.c_int, [ctypes.c_int, _vp, _vp, _i64] + [_vp] * 8),

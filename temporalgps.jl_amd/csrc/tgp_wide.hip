@@ -676,6 +676,14 @@ void destroy(Engine* e) {
 }
 const Info& last_plan(const Engine* e) { return e->info; }
 const char* kernel_name(const Engine* e) { return e->kname; }
+void stationary(const Engine* e, double* K, double* S, double* vbase, double* qinf) {
+    const int d = e->d, n0 = e->info.n0;
+    if (K && n0 > 0)
+        for (int i = 0; i < d; ++i) K[i] = e->Kt[(size_t)(n0 - 1) * d + i];
+    if (S) *S = e->Sss;
+    if (vbase) *vbase = e->vbase;
+    if (qinf) *qinf = e->qinf;
+}
 bool filter_ready(const Engine* e) { return e->have && e->info.why == kOk && e->Pf_head.size() == (size_t)e->info.n0 * e->d * e->d; }
 
 namespace {

@@ -68,7 +68,9 @@ const Info& last_plan(const Engine* e);
 // Synchronises `stream`.  0, or a hipError_t.
 int run(Engine* e, hipStream_t stream, const Call& c, double* lml_out, std::string* err);
 const char* kernel_name(const Engine* e);
-bool filter_ready(const Engine* e);      // the plan kept the head's filtered covariances (64 MB at most)
+bool filter_ready(const Engine* e);
+// the planned model's stationary gain K [d], innovation variance S, and (behind plan_posterior) the smoothed emission variance's two parts: vbase - qinf
+void stationary(const Engine* e, double* K, double* S, double* vbase, double* qinf);      // the plan kept the head's filtered covariances (64 MB at most)
 // rand(model) with the draws supplied (lgssm.jl:65-91): x0_host the drawn initial state (host, d), eps_t [T][d], eps_e [T], y_out [T] device pointers.
 // Enqueues ONE kernel (k_wide_rand) on `stream` -- no synchronisation behind it.  *declined: the open loop does not forget (nothing was enqueued).
 int rand(Engine* e, hipStream_t stream, const ModelHost& m, long long T, const double* x0_host, const double* eps_t, const double* eps_e, double* y_out, bool* declined,
