@@ -39,3 +39,21 @@ def test_kernels_at_full_register_budget_are_pinned_by_a_check():
     assert not loose, f"kernels at 512 registers with spills outside the families pinned by a known-answer check: {loose}"
     # the kernel whose miscompile was root-caused in round 2 must stay out of the library
     assert not any("k_compose_smoother<8" in k["name"] for k in ks)
+
+
+@pytest.mark.skipif(not os.path.exists(LIB) or not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf") or shutil.which("c++filt") is None,
+                    reason="needs the built library and the LLVM binutils")
+def test_streaming_and_wide_kernels_use_no_scratch():
+    """round 6's kernels are written to their register budgets -- a spill in k_post_stream / k_lml_stream is a counted vector load inside the pipelined
+    sweep, one in the wide kernels' unrolled steps a scratch round trip per multiply-add: a compiler or source change that tips one over
+    shows here, not in a bench two rounds later.  (d = 3 is the headline; the wide kernels at every instantiation.)"""
+    spec = importlib.util.spec_from_file_location("list_kernel_resources", os.path.join(ROOT, "scripts", "list_kernel_resources.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    ks = [k for blob in mod.code_objects(LIB) for k in mod.kernels(blob)]
+    watched = [k for k in ks if re.search(r"tgp_post::k_post_stream<[123]>|tgp_lml::k_lml_stream<3, 32|tgp_wide::k_wide_", k["name"])]
+    assert len(watched) >= 12, [k["name"] for k in watched]
+    # (k_post_stream<3>: ONE 8-byte value -- stored once in the prologue, reloaded once behind the run's last tile -- is the budget's remainder)
+    allowed = lambda k: 16 if "k_post_stream<3>" in k["name"] else 0      # noqa: E731
+    bad = [(k["name"], k["scratch"], k["vspill"]) for k in watched if k["scratch"] > allowed(k)]
+    assert not bad, bad
